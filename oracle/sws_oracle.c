@@ -1,0 +1,1702 @@
+/*
+ * sws_oracle.c -- TEST INFRASTRUCTURE ONLY (see sws_oracle.h).
+ *
+ * Scalar CPU restatement of the librempeg libswscale legacy path
+ * (sws_getContext / sws_setColorspaceDetails / sws_scale) for the pixel
+ * formats on the hot path.  Written from the reference's arithmetic, not
+ * copied: whole-frame intermediates replace the reference's line ring buffer
+ * (libswscale/slice.c), one generic routine per stage replaces the macro
+ * families.  Each routine cites the reference lines whose results it must
+ * reproduce bit for bit.
+ */
+#include "sws_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ */
+/* small helpers (libavutil/common.h, libavutil/macros.h)              */
+/* ------------------------------------------------------------------ */
+#define ORMIN(a, b) ((a) < (b) ? (a) : (b))
+#define ORMAX(a, b) ((a) > (b) ? (a) : (b))
+#define ORABS(a) ((a) >= 0 ? (a) : -(a))
+#define CEIL_RSHIFT(a, b) (-((-(a)) >> (b)))
+
+static int64_t rounded_div(int64_t a, int64_t b) /* ROUNDED_DIV, libavutil/common.h:58 */
+{
+    return (a >= 0 ? a + (b >> 1) : a - (b >> 1)) / b;
+}
+static int ilog2(unsigned v) /* av_log2: floor(log2(v|1)) */
+{
+    int n = 0;
+    v |= 1;
+    while (v >>= 1) n++;
+    return n;
+}
+static int clip_u8(int a) { return a < 0 ? 0 : a > 255 ? 255 : a; }
+static int clip_uintp2(int a, int p)
+{
+    if (a & ~((1 << p) - 1)) return (~a) >> 31 & ((1 << p) - 1);
+    return a;
+}
+static int clip_u16(int a) { return a < 0 ? 0 : a > 65535 ? 65535 : a; }
+static int clip_i16(int a) { return a < -32768 ? -32768 : a > 32767 ? 32767 : a; }
+
+/* ------------------------------------------------------------------ */
+/* pixel format descriptors (libavutil/pixdesc.c rows, subset)         */
+/* ------------------------------------------------------------------ */
+#define PF_BE     (1 << 0)
+#define PF_PLANAR (1 << 4)
+#define PF_RGB    (1 << 5)
+#define PF_ALPHA  (1 << 7)
+#define PF_FLOAT  (1 << 9)
+
+typedef struct { int plane, step, offset, shift, depth; } Comp;
+typedef struct {
+    int fmt; const char *name; int nb; int lw, lh; Comp c[4]; unsigned flags;
+} Desc;
+
+static const Desc descs[] = {
+    { ORF_YUV420P, "yuv420p", 3, 1, 1, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8}}, PF_PLANAR },
+    { ORF_YUVJ420P,"yuvj420p",3, 1, 1, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8}}, PF_PLANAR },
+    { ORF_YUV422P, "yuv422p", 3, 1, 0, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8}}, PF_PLANAR },
+    { ORF_YUV444P, "yuv444p", 3, 0, 0, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8}}, PF_PLANAR },
+    { ORF_NV12,    "nv12",    3, 1, 1, {{0,1,0,0,8},{1,2,0,0,8},{1,2,1,0,8}}, PF_PLANAR },
+    { ORF_NV21,    "nv21",    3, 1, 1, {{0,1,0,0,8},{1,2,1,0,8},{1,2,0,0,8}}, PF_PLANAR },
+    { ORF_YUV420P10LE, "yuv420p10le", 3, 1, 1, {{0,2,0,0,10},{1,2,0,0,10},{2,2,0,0,10}}, PF_PLANAR },
+    { ORF_YUV444P10LE, "yuv444p10le", 3, 0, 0, {{0,2,0,0,10},{1,2,0,0,10},{2,2,0,0,10}}, PF_PLANAR },
+    { ORF_YUV420P16LE, "yuv420p16le", 3, 1, 1, {{0,2,0,0,16},{1,2,0,0,16},{2,2,0,0,16}}, PF_PLANAR },
+    { ORF_YUV444P16LE, "yuv444p16le", 3, 0, 0, {{0,2,0,0,16},{1,2,0,0,16},{2,2,0,0,16}}, PF_PLANAR },
+    { ORF_P010LE,  "p010le",  3, 1, 1, {{0,2,0,6,10},{1,4,0,6,10},{1,4,2,6,10}}, PF_PLANAR },
+    { ORF_RGB24,   "rgb24",   3, 0, 0, {{0,3,0,0,8},{0,3,1,0,8},{0,3,2,0,8}}, PF_RGB },
+    { ORF_BGR24,   "bgr24",   3, 0, 0, {{0,3,2,0,8},{0,3,1,0,8},{0,3,0,0,8}}, PF_RGB },
+    { ORF_ARGB,    "argb",    4, 0, 0, {{0,4,1,0,8},{0,4,2,0,8},{0,4,3,0,8},{0,4,0,0,8}}, PF_RGB | PF_ALPHA },
+    { ORF_RGBA,    "rgba",    4, 0, 0, {{0,4,0,0,8},{0,4,1,0,8},{0,4,2,0,8},{0,4,3,0,8}}, PF_RGB | PF_ALPHA },
+    { ORF_ABGR,    "abgr",    4, 0, 0, {{0,4,3,0,8},{0,4,2,0,8},{0,4,1,0,8},{0,4,0,0,8}}, PF_RGB | PF_ALPHA },
+    { ORF_BGRA,    "bgra",    4, 0, 0, {{0,4,2,0,8},{0,4,1,0,8},{0,4,0,0,8},{0,4,3,0,8}}, PF_RGB | PF_ALPHA },
+    { ORF_0RGB,    "0rgb",    3, 0, 0, {{0,4,1,0,8},{0,4,2,0,8},{0,4,3,0,8}}, PF_RGB },
+    { ORF_RGB0,    "rgb0",    3, 0, 0, {{0,4,0,0,8},{0,4,1,0,8},{0,4,2,0,8}}, PF_RGB },
+    { ORF_0BGR,    "0bgr",    3, 0, 0, {{0,4,3,0,8},{0,4,2,0,8},{0,4,1,0,8}}, PF_RGB },
+    { ORF_BGR0,    "bgr0",    3, 0, 0, {{0,4,2,0,8},{0,4,1,0,8},{0,4,0,0,8}}, PF_RGB },
+    { ORF_GBRP,    "gbrp",    3, 0, 0, {{2,1,0,0,8},{0,1,0,0,8},{1,1,0,0,8}}, PF_PLANAR | PF_RGB },
+    { ORF_GBRPF32LE, "gbrpf32le", 3, 0, 0, {{2,4,0,0,32},{0,4,0,0,32},{1,4,0,0,32}}, PF_PLANAR | PF_RGB | PF_FLOAT },
+};
+
+static const Desc *desc_get(int fmt)
+{
+    for (size_t i = 0; i < sizeof(descs) / sizeof(descs[0]); i++)
+        if (descs[i].fmt == fmt) return &descs[i];
+    return NULL;
+}
+/* libswscale/swscale_internal.h:746-988 */
+static int is16BPS(int f) { return desc_get(f)->c[0].depth == 16; }
+static int isNBPS(int f) { int d = desc_get(f)->c[0].depth; return d >= 9 && d <= 14; }
+static int isYUV(int f) { const Desc *d = desc_get(f); return !(d->flags & PF_RGB) && d->nb >= 2; }
+static int isPlanarYUV(int f) { return (desc_get(f)->flags & PF_PLANAR) && isYUV(f); }
+static int isSemiPlanarYUV(int f) { const Desc *d = desc_get(f); return isPlanarYUV(f) && d->c[1].plane == d->c[2].plane; }
+static int isAnyRGB(int f) { return !!(desc_get(f)->flags & PF_RGB); }
+static int isGray(int f) { return desc_get(f)->nb <= 2; }
+static int isFloat(int f) { return !!(desc_get(f)->flags & PF_FLOAT); }
+static int isALPHA(int f) { return !!(desc_get(f)->flags & PF_ALPHA); }
+static int isPlanarRGB(int f) { return (desc_get(f)->flags & (PF_PLANAR | PF_RGB)) == (PF_PLANAR | PF_RGB); }
+static int isPacked(int f) { const Desc *d = desc_get(f); return d->nb >= 2 && !(d->flags & PF_PLANAR); }
+static int isSwappedChroma(int f)
+{
+    const Desc *d = desc_get(f);
+    if (!isYUV(f) || d->nb < 3) return 0;
+    if (!isPlanarYUV(f) || isSemiPlanarYUV(f)) return d->c[1].offset > d->c[2].offset;
+    return d->c[1].plane > d->c[2].plane;
+}
+static int isDataInHighBits(int f)
+{
+    const Desc *d = desc_get(f);
+    for (int i = 0; i < d->nb; i++) {
+        if (!d->c[i].shift) return 0;
+        if ((d->c[i].shift + d->c[i].depth) & 7) return 0;
+    }
+    return 1;
+}
+static int bits_per_pixel(const Desc *d) /* av_get_bits_per_pixel, libavutil/pixdesc.c */
+{
+    int bits = 0, log2_pixels = d->lw + d->lh;
+    for (int c = 0; c < d->nb; c++) {
+        int s = c == 1 || c == 2 ? 0 : log2_pixels;
+        bits += d->c[c].depth << s;
+    }
+    return bits >> log2_pixels;
+}
+
+/* ------------------------------------------------------------------ */
+/* context                                                            */
+/* ------------------------------------------------------------------ */
+enum { RY, GY, BY, RU, GU, BU, RV, GV, BV };
+
+#define HEADROOM 512   /* YUVRGB_TABLE_HEADROOM / _LUMA_HEADROOM, swscale_internal.h */
+#define TABLE_PLANE 2048
+
+enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
+       UNSC_NV122PLANAR, UNSC_PLANARCOPY };
+
+struct OrSws {
+    OrSwsOpts o;
+    int src0Alpha, dst0Alpha;
+    int brightness, contrast, saturation;
+    int srcColorspaceTable[4], dstColorspaceTable[4];
+    int dstFormatBpp, srcFormatBpp;
+    int chrSrcHSub, chrSrcVSub, chrDstHSub, chrDstVSub;
+    int chrSrcW, chrSrcH, chrDstW, chrDstH;
+    int srcBpc, dstBpc;
+    int lumXInc, lumYInc, chrXInc, chrYInc;
+    int unscaled_kind;
+    int16_t *hLumFilter, *hChrFilter, *vLumFilter, *vChrFilter;
+    int32_t *hLumFilterPos, *hChrFilterPos, *vLumFilterPos, *vChrFilterPos;
+    int hLumFilterSize, hChrFilterSize, vLumFilterSize, vChrFilterSize;
+    int32_t rgb2yuv[9];
+    int yuv2rgb_y_offset, yuv2rgb_y_coeff, yuv2rgb_v2r, yuv2rgb_v2g, yuv2rgb_u2g, yuv2rgb_u2b;
+    /* LUTs (yuv2rgb.c:717-973): yuvTable + offsets (in elements) into it */
+    uint8_t *yuvTable; int lut_elem; /* 1 or 4 bytes */
+    int table_rV[256 + 2 * HEADROOM], table_gU[256 + 2 * HEADROOM], table_bU[256 + 2 * HEADROOM];
+    int table_gV[256 + 2 * HEADROOM];
+    int has_lut;
+    int range_active; uint32_t lumCoeff, chrCoeff; int64_t lumOffset, chrOffset;
+    int needAlpha;
+    OrSws *cascade[2]; uint8_t *casc_tmp[4]; int casc_stride[4];
+    int initialized;
+};
+
+static const int32_t yuv2rgb_coeffs[11][4] = { /* yuv2rgb.c:47-59 */
+    { 104597, 132201, 25675, 53279 }, { 117489, 138438, 13975, 34925 },
+    { 104597, 132201, 25675, 53279 }, { 104597, 132201, 25675, 53279 },
+    { 104448, 132798, 24759, 53109 }, { 104597, 132201, 25675, 53279 },
+    { 104597, 132201, 25675, 53279 }, { 117579, 136230, 16907, 35559 },
+    { 0 }, { 110013, 140363, 12277, 42626 }, { 110013, 140363, 12277, 42626 },
+};
+const int *or_sws_get_coefficients(int cs)
+{
+    if (cs > 10 || cs < 0 || cs == 8) cs = 5;
+    return yuv2rgb_coeffs[cs];
+}
+
+static const uint8_t dither_8x8_128[9][8] = { /* swscale.c:42-52 */
+    {  36, 68,  60, 92,  34, 66,  58, 90 }, { 100,  4, 124, 28,  98,  2, 122, 26 },
+    {  52, 84,  44, 76,  50, 82,  42, 74 }, { 116, 20, 108, 12, 114, 18, 106, 10 },
+    {  32, 64,  56, 88,  38, 70,  62, 94 }, {  96,  0, 120, 24, 102,  6, 126, 30 },
+    {  48, 80,  40, 72,  54, 86,  46, 78 }, { 112, 16, 104,  8, 118, 22, 110, 14 },
+    {  36, 68,  60, 92,  34, 66,  58, 90 },
+};
+static const uint8_t pb_64[8] = { 64, 64, 64, 64, 64, 64, 64, 64 };
+
+/* ------------------------------------------------------------------ */
+/* initFilter  (libswscale/utils.c:197-612)                            */
+/* ------------------------------------------------------------------ */
+#define RET_CASCADE -12345
+
+static double spline_coeff(double a, double b, double c, double d, double dist) /* utils.c:152-166 */
+{
+    if (dist <= 1.0) return ((d * dist + c) * dist + b) * dist + a;
+    return spline_coeff(0.0, b + 2.0 * c + 3.0 * d, c + 3.0 * d, -b - 3.0 * c - 6.0 * d, dist - 1.0);
+}
+
+static int init_filter(int16_t **outFilter, int32_t **filterPos, int *outFilterSize,
+                       int xInc, int srcW, int dstW, int filterAlign, int one,
+                       int scaler, int flags, const double param[2], int srcPos, int dstPos)
+{
+    int filterSize, filter2Size, minFilterSize, i, j, ret = -1;
+    int64_t *filter = NULL, *filter2 = NULL;
+    const int64_t fone = 1LL << (54 - ORMIN(ilog2(srcW / dstW), 8));
+
+    *filterPos = malloc((dstW + 3) * sizeof(int32_t));
+
+    if (ORABS(xInc - 0x10000) < 10 && srcPos == dstPos) { /* :219 unscaled */
+        filterSize = 1;
+        filter = calloc(dstW, sizeof(*filter));
+        for (i = 0; i < dstW; i++) { filter[i] = fone; (*filterPos)[i] = i; }
+    } else if (scaler == OR_SWS_POINT) { /* :229 */
+        int64_t xDstInSrc;
+        filterSize = 1;
+        filter = malloc(dstW * sizeof(*filter));
+        xDstInSrc = ((dstPos * (int64_t)xInc) >> 8) - ((srcPos * 0x8000LL) >> 7);
+        for (i = 0; i < dstW; i++) {
+            int xx = (int)((xDstInSrc - ((int64_t)(filterSize - 1) << 15) + (1 << 15)) >> 16);
+            (*filterPos)[i] = xx; filter[i] = fone; xDstInSrc += xInc;
+        }
+    } else if ((xInc <= (1 << 16) && scaler == OR_SWS_AREA) || scaler == OR_SWS_FAST_BILINEAR) { /* :244 */
+        int64_t xDstInSrc;
+        filterSize = 2;
+        filter = malloc(dstW * filterSize * sizeof(*filter));
+        xDstInSrc = ((dstPos * (int64_t)xInc) >> 8) - ((srcPos * 0x8000LL) >> 7);
+        for (i = 0; i < dstW; i++) {
+            int xx = (int)((xDstInSrc - ((int64_t)(filterSize - 1) << 15) + (1 << 15)) >> 16);
+            (*filterPos)[i] = xx;
+            for (j = 0; j < filterSize; j++) {
+                int64_t coeff = fone - ORABS((int64_t)xx * (1 << 16) - xDstInSrc) * (fone >> 16);
+                if (coeff < 0) coeff = 0;
+                filter[i * filterSize + j] = coeff;
+                xx++;
+            }
+            xDstInSrc += xInc;
+        }
+    } else { /* :268 general */
+        int64_t xDstInSrc;
+        int sizeFactor = -1;
+        switch (scaler) {
+        case OR_SWS_AREA: sizeFactor = 1; break;
+        case OR_SWS_BICUBIC: sizeFactor = 4; break;
+        case OR_SWS_BILINEAR: sizeFactor = 2; break;
+        case OR_SWS_GAUSS: sizeFactor = 8; break;
+        case OR_SWS_SINC: sizeFactor = 20; break;
+        case OR_SWS_SPLINE: sizeFactor = 20; break;
+        case OR_SWS_X: sizeFactor = 8; break;
+        case OR_SWS_LANCZOS:
+            sizeFactor = param[0] != OR_SWS_PARAM_DEFAULT ? (int)ceil(2 * param[0]) : 6; break;
+        }
+        if (sizeFactor <= 0 || sizeFactor > 50) goto fail;
+
+        if (xInc <= 1 << 16) filterSize = 1 + sizeFactor;
+        else filterSize = 1 + (sizeFactor * srcW + dstW - 1) / dstW;
+        filterSize = ORMIN(filterSize, srcW - 2);
+        filterSize = ORMAX(filterSize, 1);
+
+        filter = malloc((size_t)dstW * filterSize * sizeof(*filter));
+        xDstInSrc = ((dstPos * (int64_t)xInc) >> 7) - ((srcPos * 0x10000LL) >> 7);
+        for (i = 0; i < dstW; i++) {
+            int xx = (int)((xDstInSrc - (filterSize - 2) * (1LL << 16)) / (1 << 17));
+            (*filterPos)[i] = xx;
+            for (j = 0; j < filterSize; j++) {
+                int64_t d = ORABS(((int64_t)xx * (1 << 17)) - xDstInSrc) << 13;
+                double floatd;
+                int64_t coeff;
+
+                if (xInc > 1 << 16) d = d * dstW / srcW;
+                floatd = d * (1.0 / (1 << 30));
+
+                if (scaler == OR_SWS_BICUBIC) { /* :312 */
+                    int64_t B = (int64_t)((param[0] != OR_SWS_PARAM_DEFAULT ? param[0] : 0) * (1 << 24));
+                    int64_t C = (int64_t)((param[1] != OR_SWS_PARAM_DEFAULT ? param[1] : 0.6) * (1 << 24));
+                    if (d >= 1LL << 31) {
+                        coeff = 0;
+                    } else {
+                        int64_t dd = (d * d) >> 30;
+                        int64_t ddd = (dd * d) >> 30;
+                        if (d < 1LL << 30)
+                            coeff = (12 * (1 << 24) - 9 * B - 6 * C) * ddd +
+                                    (-18 * (1 << 24) + 12 * B + 6 * C) * dd +
+                                    (6 * (1 << 24) - 2 * B) * (1 << 30);
+                        else
+                            coeff = (-B - 6 * C) * ddd + (6 * B + 30 * C) * dd +
+                                    (-12 * B - 48 * C) * d + (8 * B + 24 * C) * (1 << 30);
+                    }
+                    coeff /= (1LL << 54) / fone;
+                } else if (scaler == OR_SWS_X) {
+                    double A = param[0] != OR_SWS_PARAM_DEFAULT ? param[0] : 1.0;
+                    double c = floatd < 1.0 ? cos(floatd * M_PI) : -1.0;
+                    if (c < 0.0) c = -pow(-c, A); else c = pow(c, A);
+                    coeff = (int64_t)((c * 0.5 + 0.5) * fone);
+                } else if (scaler == OR_SWS_AREA) {
+                    int64_t d2 = d - (1 << 29);
+                    if (d2 * xInc < -(1LL << (29 + 16))) coeff = 1LL << (30 + 16);
+                    else if (d2 * xInc < (1LL << (29 + 16))) coeff = -d2 * xInc + (1LL << (29 + 16));
+                    else coeff = 0;
+                    coeff *= fone >> (30 + 16);
+                } else if (scaler == OR_SWS_GAUSS) {
+                    double p = param[0] != OR_SWS_PARAM_DEFAULT ? param[0] : 3.0;
+                    coeff = (int64_t)(exp2(-p * floatd * floatd) * fone);
+                } else if (scaler == OR_SWS_SINC) {
+                    coeff = (int64_t)((d ? sin(floatd * M_PI) / (floatd * M_PI) : 1.0) * fone);
+                } else if (scaler == OR_SWS_LANCZOS) { /* :360 */
+                    double p = param[0] != OR_SWS_PARAM_DEFAULT ? param[0] : 3.0;
+                    coeff = (int64_t)((d ? sin(floatd * M_PI) * sin(floatd * M_PI / p) /
+                                           (floatd * floatd * M_PI * M_PI / p) : 1.0) * fone);
+                    if (floatd > p) coeff = 0;
+                } else if (scaler == OR_SWS_BILINEAR) { /* :366 */
+                    coeff = (1 << 30) - d;
+                    if (coeff < 0) coeff = 0;
+                    coeff *= fone >> 30;
+                } else if (scaler == OR_SWS_SPLINE) {
+                    double p = -2.196152422706632;
+                    coeff = (int64_t)(spline_coeff(1.0, 0.0, p, -p - 1.0, floatd) * fone);
+                } else {
+                    goto fail;
+                }
+                filter[i * filterSize + j] = coeff;
+                xx++;
+            }
+            xDstInSrc += 2LL * xInc;
+        }
+    }
+
+    /* no src/dst SwsVector: filter2 == filter (:385-415) */
+    filter2Size = filterSize;
+    filter2 = calloc((size_t)dstW * filter2Size, sizeof(*filter2));
+    memcpy(filter2, filter, (size_t)dstW * filter2Size * sizeof(*filter2));
+    free(filter); filter = NULL;
+
+    /* reduce, step 1 (:417-457) */
+    minFilterSize = 0;
+    for (i = dstW - 1; i >= 0; i--) {
+        int min = filter2Size;
+        int64_t cutOff = 0;
+        for (j = 0; j < filter2Size; j++) {
+            int k;
+            cutOff += ORABS(filter2[i * filter2Size]);
+            if (cutOff > 0.002 * fone) break;
+            if (i < dstW - 1 && (*filterPos)[i] >= (*filterPos)[i + 1]) break;
+            for (k = 1; k < filter2Size; k++)
+                filter2[i * filter2Size + k - 1] = filter2[i * filter2Size + k];
+            filter2[i * filter2Size + k - 1] = 0;
+            (*filterPos)[i]++;
+        }
+        cutOff = 0;
+        for (j = filter2Size - 1; j > 0; j--) {
+            cutOff += ORABS(filter2[i * filter2Size + j]);
+            if (cutOff > 0.002 * fone) break;
+            min--;
+        }
+        if (min > minFilterSize) minFilterSize = min;
+    }
+
+    filterSize = (minFilterSize + (filterAlign - 1)) & (~(filterAlign - 1));
+    filter = malloc((size_t)dstW * filterSize * sizeof(*filter));
+    if (filterSize >= 256 * 16 / ((flags & OR_SWS_ACCURATE_RND) ? 16 : 16)) { /* :492; APCK_SIZE == 16 in the
+                                                                                * C-only (ARCH_X86_64 0) build, swscale_internal.h:64-73 */
+        ret = RET_CASCADE;
+        goto fail;
+    }
+    *outFilterSize = filterSize;
+
+    for (i = 0; i < dstW; i++) /* reduce, step 2 (:503-515) */
+        for (j = 0; j < filterSize; j++) {
+            filter[i * filterSize + j] = j >= filter2Size ? 0 : filter2[i * filter2Size + j];
+            if ((flags & OR_SWS_BITEXACT) && j >= minFilterSize)
+                filter[i * filterSize + j] = 0;
+        }
+
+    for (i = 0; i < dstW; i++) { /* fix borders (:519-560) */
+        if ((*filterPos)[i] < 0) {
+            for (j = 1; j < filterSize; j++) {
+                int left = ORMAX(j + (*filterPos)[i], 0);
+                filter[i * filterSize + left] += filter[i * filterSize + j];
+                filter[i * filterSize + j] = 0;
+            }
+            (*filterPos)[i] = 0;
+        }
+        if ((*filterPos)[i] + filterSize > srcW) {
+            int shift = (*filterPos)[i] + ORMIN(filterSize - srcW, 0);
+            int64_t acc = 0;
+            for (j = filterSize - 1; j >= 0; j--)
+                if ((*filterPos)[i] + j >= srcW) {
+                    acc += filter[i * filterSize + j];
+                    filter[i * filterSize + j] = 0;
+                }
+            for (j = filterSize - 1; j >= 0; j--) {
+                if (j < shift) filter[i * filterSize + j] = 0;
+                else filter[i * filterSize + j] = filter[i * filterSize + j - shift];
+            }
+            (*filterPos)[i] -= shift;
+            filter[i * filterSize + srcW - 1 - (*filterPos)[i]] += acc;
+        }
+    }
+
+    *outFilter = calloc((size_t)(dstW + 3) * filterSize, sizeof(int16_t));
+    for (i = 0; i < dstW; i++) { /* normalise (:568-588) */
+        int64_t error = 0, sum = 0;
+        for (j = 0; j < filterSize; j++) sum += filter[i * filterSize + j];
+        sum = (sum + one / 2) / one;
+        if (!sum) sum = 1;
+        for (j = 0; j < filterSize; j++) {
+            int64_t v = filter[i * filterSize + j] + error;
+            int intV = (int)rounded_div(v, sum);
+            (*outFilter)[i * filterSize + j] = (int16_t)intV;
+            error = v - intV * sum;
+        }
+    }
+    (*filterPos)[dstW + 0] = (*filterPos)[dstW + 1] = (*filterPos)[dstW + 2] = (*filterPos)[dstW - 1];
+    for (i = 0; i < filterSize; i++) {
+        int k = (dstW - 1) * filterSize + i;
+        (*outFilter)[k + 1 * filterSize] = (*outFilter)[k + 2 * filterSize] =
+        (*outFilter)[k + 3 * filterSize] = (*outFilter)[k];
+    }
+    ret = 0;
+fail:
+    free(filter); free(filter2);
+    return ret;
+}
+
+/* ------------------------------------------------------------------ */
+/* colour tables                                                       */
+/* ------------------------------------------------------------------ */
+static int round_to_int16(int64_t f) /* yuv2rgb.c:705-715; returns value as int16 */
+{
+    int r = (int)((f + (1 << 15)) >> 16);
+    if (r < -0x7FFF) return (int16_t)0x8000;
+    if (r > 0x7FFF) return 0x7FFF;
+    return r;
+}
+
+static void fill_table(int *table, int64_t inc, int yoffs) /* yuv2rgb.c:680-692 (offsets, in elements) */
+{
+    int base = yoffs - (int)(inc >> 9);
+    for (int i = 0; i < 256 + 2 * HEADROOM; i++) {
+        int64_t cb = clip_u8(i - HEADROOM) * inc;
+        table[i] = base + (int)(cb >> 16);
+    }
+}
+static void fill_gv_table(int *table, int64_t inc) /* yuv2rgb.c:694-703 */
+{
+    int off = -(int)(inc >> 9);
+    for (int i = 0; i < 256 + 2 * HEADROOM; i++) {
+        int64_t cb = clip_u8(i - HEADROOM) * inc;
+        table[i] = off + (int)(cb >> 16);
+    }
+}
+
+/* ff_yuv2rgb_c_init_tables, yuv2rgb.c:717-973 (24 and 32 bpp cases) */
+static int yuv2rgb_init_tables(OrSws *c, const int inv_table[4], int fullRange,
+                               int brightness, int contrast, int saturation)
+{
+    const int df = c->o.dst_format;
+    /* AV_PIX_FMT_RGB32 = BGRA, RGB32_1 = ABGR, BGR32 = RGBA, BGR32_1 = ARGB on little endian */
+    const int isRgb = df == ORF_BGRA || df == ORF_ABGR || df == ORF_BGR24;
+    const int bpp = c->dstFormatBpp;
+    const int yoffs = (fullRange ? 384 : 326) + HEADROOM;
+    int64_t crv = inv_table[0], cbu = inv_table[1], cgu = -inv_table[2], cgv = -inv_table[3];
+    int64_t cy = 1 << 16, oy = 0, yb;
+    int i;
+
+    if (!fullRange) {
+        cy = (cy * 255) / 219;
+        oy = 16 << 16;
+    } else {
+        crv = (crv * 224) / 255; cbu = (cbu * 224) / 255;
+        cgu = (cgu * 224) / 255; cgv = (cgv * 224) / 255;
+    }
+    cy  = (cy * contrast) >> 16;
+    crv = (crv * contrast * saturation) >> 32;
+    cbu = (cbu * contrast * saturation) >> 32;
+    cgu = (cgu * contrast * saturation) >> 32;
+    cgv = (cgv * contrast * saturation) >> 32;
+    oy -= 256LL * brightness;
+
+    c->yuv2rgb_y_coeff  = (int16_t)round_to_int16(cy * (1 << 13));
+    c->yuv2rgb_y_offset = (int16_t)round_to_int16(oy * (1 << 9));
+    c->yuv2rgb_v2r = (int16_t)round_to_int16(crv * (1 << 13));
+    c->yuv2rgb_v2g = (int16_t)round_to_int16(cgv * (1 << 13));
+    c->yuv2rgb_u2g = (int16_t)round_to_int16(cgu * (1 << 13));
+    c->yuv2rgb_u2b = (int16_t)round_to_int16(cbu * (1 << 13));
+
+    crv = ((crv * (1 << 16)) + 0x8000) / ORMAX(cy, 1);
+    cbu = ((cbu * (1 << 16)) + 0x8000) / ORMAX(cy, 1);
+    cgu = ((cgu * (1 << 16)) + 0x8000) / ORMAX(cy, 1);
+    cgv = ((cgv * (1 << 16)) + 0x8000) / ORMAX(cy, 1);
+
+    free(c->yuvTable); c->yuvTable = NULL; c->has_lut = 0;
+    yb = -(384 << 16) - HEADROOM * cy - oy;
+    switch (bpp) {
+    case 24:
+    case 48:
+        c->yuvTable = malloc(TABLE_PLANE);
+        c->lut_elem = 1;
+        for (i = 0; i < TABLE_PLANE; i++) {
+            c->yuvTable[i] = (uint8_t)clip_u8((int)((yb + 0x8000) >> 16));
+            yb += cy;
+        }
+        fill_table(c->table_rV, crv, yoffs);
+        fill_table(c->table_gU, cgu, yoffs);
+        fill_table(c->table_bU, cbu, yoffs);
+        fill_gv_table(c->table_gV, cgv);
+        c->has_lut = 1;
+        break;
+    case 32:
+    case 64: {
+        int base = (df == ORF_ABGR || df == ORF_ARGB) ? 8 : 0;
+        int rbase = base + (isRgb ? 16 : 0), gbase = base + 8, bbase = base + (isRgb ? 0 : 16);
+        int needAlpha = isALPHA(c->o.src_format);
+        int abase = (base + 24) & 31;
+        uint32_t *t = malloc(TABLE_PLANE * 3 * 4);
+        c->yuvTable = (uint8_t *)t;
+        c->lut_elem = 4;
+        for (i = 0; i < TABLE_PLANE; i++) {
+            unsigned yval = clip_u8((int)((yb + 0x8000) >> 16));
+            t[i] = (yval << rbase) + (needAlpha ? 0 : (255u << abase));
+            t[i + TABLE_PLANE] = yval << gbase;
+            t[i + 2 * TABLE_PLANE] = yval << bbase;
+            yb += cy;
+        }
+        fill_table(c->table_rV, crv, yoffs);
+        fill_table(c->table_gU, cgu, yoffs + TABLE_PLANE);
+        fill_table(c->table_bU, cbu, yoffs + 2 * TABLE_PLANE);
+        fill_gv_table(c->table_gV, cgv);
+        c->has_lut = 1;
+        break;
+    }
+    default:
+        return -1; /* other bpp: not restated (reference returns EINVAL for planar >24) */
+    }
+    return 0;
+}
+
+/* fill_rgb2yuv_table, utils.c:614-706 */
+static void fill_rgb2yuv_table(OrSws *c, const int table[4])
+{
+    int64_t W, V, Z, Cy, Cu, Cv;
+    int64_t vr = table[0], ub = table[1], ug = -table[2], vg = -table[3];
+    const int64_t ONE = 65536;
+    int64_t cy = ONE;
+
+    cy = cy * 255 / 219; /* dstRange forced 0, utils.c:663 */
+    W = rounded_div(ONE * ONE * ug, ub);
+    V = rounded_div(ONE * ONE * vg, vr);
+    Z = ONE * ONE - W - V;
+    Cy = rounded_div(cy * Z, ONE);
+    Cu = rounded_div(ub * Z, ONE);
+    Cv = rounded_div(vr * Z, ONE);
+
+    c->rgb2yuv[RY] = (int32_t)-rounded_div((1 << 15) * V, Cy);
+    c->rgb2yuv[GY] = (int32_t) rounded_div((1 << 15) * ONE * ONE, Cy);
+    c->rgb2yuv[BY] = (int32_t)-rounded_div((1 << 15) * W, Cy);
+    c->rgb2yuv[RU] = (int32_t) rounded_div((1 << 15) * V, Cu);
+    c->rgb2yuv[GU] = (int32_t)-rounded_div((1 << 15) * ONE * ONE, Cu);
+    c->rgb2yuv[BU] = (int32_t) rounded_div((1 << 15) * (Z + W), Cu);
+    c->rgb2yuv[RV] = (int32_t) rounded_div((1 << 15) * (V + Z), Cv);
+    c->rgb2yuv[GV] = (int32_t)-rounded_div((1 << 15) * ONE * ONE, Cv);
+    c->rgb2yuv[BV] = (int32_t) rounded_div((1 << 15) * W, Cv);
+
+    if (!memcmp(table, yuv2rgb_coeffs[5], sizeof(int) * 4)) { /* :693-703 */
+        c->rgb2yuv[BY] =  ((int)(0.114 * 219 / 255 * (1 << 15) + 0.5));
+        c->rgb2yuv[BV] = (-(int)(0.081 * 224 / 255 * (1 << 15) + 0.5));
+        c->rgb2yuv[BU] =  ((int)(0.500 * 224 / 255 * (1 << 15) + 0.5));
+        c->rgb2yuv[GY] =  ((int)(0.587 * 219 / 255 * (1 << 15) + 0.5));
+        c->rgb2yuv[GV] = (-(int)(0.419 * 224 / 255 * (1 << 15) + 0.5));
+        c->rgb2yuv[GU] = (-(int)(0.331 * 224 / 255 * (1 << 15) + 0.5));
+        c->rgb2yuv[RY] =  ((int)(0.299 * 219 / 255 * (1 << 15) + 0.5));
+        c->rgb2yuv[RV] =  ((int)(0.500 * 224 / 255 * (1 << 15) + 0.5));
+        c->rgb2yuv[RU] = (-(int)(0.169 * 224 / 255 * (1 << 15) + 0.5));
+    }
+}
+
+/* swscale.c:577-660 */
+static void solve_range_convert(uint16_t src_min, uint16_t src_max, uint16_t dst_min, uint16_t dst_max,
+                                int src_shift, int mult_shift, uint32_t *coeff, int64_t *offset)
+{
+    uint16_t src_range = src_max - src_min, dst_range = dst_max - dst_min;
+    int total_shift = mult_shift + src_shift;
+    *coeff = (uint32_t)CEIL_RSHIFT((int64_t)(((uint64_t)dst_range << total_shift) / src_range), src_shift);
+    *offset = ((int64_t)dst_max << total_shift) - ((int64_t)src_max << src_shift) * *coeff +
+              (1U << (mult_shift - 1));
+}
+static void init_range_convert(OrSws *c)
+{
+    c->range_active = 0;
+    if (c->o.src_range != c->o.dst_range && !isAnyRGB(c->o.dst_format) && c->dstBpc < 32) {
+        const int bit_depth = c->dstBpc ? ORMIN(c->dstBpc, 16) : 8;
+        const int src_bits = bit_depth <= 14 ? 15 : 19;
+        const int src_shift = src_bits - bit_depth;
+        const int mult_shift = bit_depth <= 14 ? 14 : 18;
+        const uint16_t mpeg_min = 16U << (bit_depth - 8);
+        const uint16_t mpeg_max_lum = 235U << (bit_depth - 8);
+        const uint16_t mpeg_max_chr = 240U << (bit_depth - 8);
+        const uint16_t jpeg_max = (1U << bit_depth) - 1;
+        if (c->o.src_range) {
+            solve_range_convert(0, jpeg_max, mpeg_min, mpeg_max_lum, src_shift, mult_shift, &c->lumCoeff, &c->lumOffset);
+            solve_range_convert(0, jpeg_max, mpeg_min, mpeg_max_chr, src_shift, mult_shift, &c->chrCoeff, &c->chrOffset);
+        } else {
+            solve_range_convert(mpeg_min, mpeg_max_lum, 0, jpeg_max, src_shift, mult_shift, &c->lumCoeff, &c->lumOffset);
+            solve_range_convert(mpeg_min, mpeg_max_chr, 0, jpeg_max, src_shift, mult_shift, &c->chrCoeff, &c->chrOffset);
+        }
+        c->range_active = 1;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* init                                                                */
+/* ------------------------------------------------------------------ */
+static int handle_0alpha(int *format) /* utils.c:811-820 */
+{
+    switch (*format) {
+    case ORF_0BGR: *format = ORF_ABGR; return 1;
+    case ORF_BGR0: *format = ORF_BGRA; return 4;
+    case ORF_0RGB: *format = ORF_ARGB; return 1;
+    case ORF_RGB0: *format = ORF_RGBA; return 4;
+    default: return 0;
+    }
+}
+static void handle_formats(OrSws *c)
+{
+    c->src0Alpha |= handle_0alpha(&c->o.src_format);
+    c->dst0Alpha |= handle_0alpha(&c->o.dst_format);
+}
+static int get_local_pos(int chr_subsample, int pos) /* utils.c:168-175 */
+{
+    if (pos == -1 || pos <= -513) pos = (128 << chr_subsample) - 128;
+    pos += 128;
+    return pos >> chr_subsample;
+}
+
+static int or_init(OrSws *c);
+
+void or_sws_default_opts(OrSwsOpts *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->flags = OR_SWS_BICUBIC; /* options.c:35 */
+    o->scaler_params[0] = o->scaler_params[1] = OR_SWS_PARAM_DEFAULT;
+    o->dither = 1; /* AUTO */
+    o->src_v_chr_pos = o->src_h_chr_pos = o->dst_v_chr_pos = o->dst_h_chr_pos = -513;
+    o->src_format = o->dst_format = ORF_NONE;
+}
+
+static OrSws *alloc_set_opts(int srcW, int srcH, int srcFmt, int dstW, int dstH, int dstFmt,
+                             int flags, const double *param) /* utils.c:75-95 */
+{
+    OrSws *c = calloc(1, sizeof(*c));
+    or_sws_default_opts(&c->o);
+    c->o.flags = flags;
+    c->o.src_w = srcW; c->o.src_h = srcH; c->o.dst_w = dstW; c->o.dst_h = dstH;
+    c->o.src_format = srcFmt; c->o.dst_format = dstFmt;
+    if (param) { c->o.scaler_params[0] = param[0]; c->o.scaler_params[1] = param[1]; }
+    return c;
+}
+
+static int handle_jpeg(int *format) /* utils.c:773 */
+{
+    if (*format == ORF_YUVJ420P) { *format = ORF_YUV420P; return 1; }
+    if (*format == ORF_GRAY8) return 1;
+    return 0;
+}
+
+static int init_context(OrSws *c) /* sws_init_context, utils.c:1884 */
+{
+    c->o.src_range |= handle_jpeg(&c->o.src_format);
+    c->o.dst_range |= handle_jpeg(&c->o.dst_format);
+    return or_init(c);
+}
+
+OrSws *or_sws_create(const OrSwsOpts *o)
+{
+    OrSws *c = calloc(1, sizeof(*c));
+    c->o = *o;
+    if (!desc_get(o->src_format) || !desc_get(o->dst_format) || init_context(c) < 0) {
+        or_sws_free(c);
+        return NULL;
+    }
+    return c;
+}
+
+OrSws *or_sws_get_context(int srcW, int srcH, int srcFmt, int dstW, int dstH, int dstFmt,
+                          int flags, const double *param)
+{
+    OrSws *c;
+    if (!desc_get(srcFmt) || !desc_get(dstFmt)) return NULL;
+    c = alloc_set_opts(srcW, srcH, srcFmt, dstW, dstH, dstFmt, flags, param);
+    if (init_context(c) < 0) { or_sws_free(c); return NULL; }
+    return c;
+}
+
+void or_sws_free(OrSws *c)
+{
+    if (!c) return;
+    free(c->hLumFilter); free(c->hChrFilter); free(c->vLumFilter); free(c->vChrFilter);
+    free(c->hLumFilterPos); free(c->hChrFilterPos); free(c->vLumFilterPos); free(c->vChrFilterPos);
+    free(c->yuvTable);
+    or_sws_free(c->cascade[0]); or_sws_free(c->cascade[1]);
+    free(c->casc_tmp[0]);
+    free(c);
+}
+
+static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.c:2392-2706 (subset) */
+{
+    const int s = c->o.src_format, d = c->o.dst_format, flags = c->o.flags;
+    c->unscaled_kind = UNSC_NONE;
+    if (s == ORF_YUV420P && (d == ORF_NV12 || d == ORF_NV21)) c->unscaled_kind = UNSC_PLANAR2NV12;
+    if (d == ORF_YUV420P && (s == ORF_NV12 || s == ORF_NV21)) c->unscaled_kind = UNSC_NV122PLANAR;
+    if ((s == ORF_YUV420P || s == ORF_YUV422P) && isAnyRGB(d) && !(flags & OR_SWS_ACCURATE_RND) &&
+        (c->o.dither == 2 || c->o.dither == 1) && !(c->o.dst_h & 1)) { /* :2425-2431 */
+        /* ff_yuv2rgb_get_func_ptr, yuv2rgb.c:561-678: 24/32 bpp C converters */
+        if (d == ORF_RGB24 || d == ORF_BGR24 || d == ORF_RGBA || d == ORF_BGRA || d == ORF_ARGB || d == ORF_ABGR)
+            c->unscaled_kind = UNSC_YUV2RGB;
+        else
+            c->unscaled_kind = UNSC_NONE; /* gbrp etc. not restated: main path would NOT be taken by the reference */
+    }
+    if ((s == ORF_YUV420P10LE || s == ORF_YUV420P16LE) && d == ORF_P010LE) c->unscaled_kind = UNSC_P01X;
+    if (s == ORF_YUV420P && d == ORF_P010LE) c->unscaled_kind = UNSC_8_P01X;
+    /* simple copy (:2647-2668) */
+    if (s == d ||
+        (isFloat(s) == isFloat(d) &&
+         (isPlanarYUV(s) && isPlanarYUV(d) && c->chrDstHSub == c->chrSrcHSub && c->chrDstVSub == c->chrSrcVSub &&
+          isSemiPlanarYUV(s) == isSemiPlanarYUV(d) && isSwappedChroma(s) == isSwappedChroma(d)))) {
+        if (!isPacked(s)) c->unscaled_kind = UNSC_PLANARCOPY;
+        else c->unscaled_kind = UNSC_NONE; /* packedCopyWrapper / rgbToRgb: not restated */
+    }
+}
+
+static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
+{
+    int srcW = c->o.src_w, srcH = c->o.src_h, dstW = c->o.dst_w, dstH = c->o.dst_h;
+    int flags, unscaled, i, srcFormat, dstFormat, ret;
+    const Desc *ds, *dd;
+    int64_t lumXInc, lumYInc, chrXInc, chrYInc;
+    int lum_scaler, chr_scaler;
+
+    flags = c->o.flags;
+    unscaled = srcW == dstW && srcH == dstH;
+
+    if (!c->contrast && !c->saturation && !c->dstFormatBpp)
+        or_sws_set_colorspace(c, yuv2rgb_coeffs[5], c->o.src_range, yuv2rgb_coeffs[5],
+                              c->o.dst_range, 0, 1 << 16, 1 << 16);
+    handle_formats(c);
+    srcFormat = c->o.src_format; dstFormat = c->o.dst_format;
+    ds = desc_get(srcFormat); dd = desc_get(dstFormat);
+    if (!ds || !dd) return -1;
+
+    i = flags & (OR_SWS_POINT | OR_SWS_AREA | OR_SWS_BILINEAR | OR_SWS_FAST_BILINEAR | OR_SWS_BICUBIC |
+                 OR_SWS_X | OR_SWS_GAUSS | OR_SWS_LANCZOS | OR_SWS_SINC | OR_SWS_SPLINE | OR_SWS_BICUBLIN);
+    if (!i) { i = OR_SWS_BICUBIC; flags |= i; c->o.flags = flags; }
+    else if (i & (i - 1)) return -1;
+    if (i == OR_SWS_FAST_BILINEAR) {
+        if (srcW < 8 || dstW <= 8) { i = OR_SWS_BILINEAR; flags ^= OR_SWS_FAST_BILINEAR | i; c->o.flags = flags; }
+        else return -1; /* fast bilinear hscale not restated */
+    }
+    lum_scaler = i == OR_SWS_BICUBLIN ? OR_SWS_BICUBIC : i;
+    chr_scaler = i == OR_SWS_BICUBLIN ? OR_SWS_BILINEAR : i;
+
+    if (srcW < 1 || srcH < 1 || dstW < 1 || dstH < 1) return -1;
+
+    lumXInc = (((int64_t)srcW << 16) + (dstW >> 1)) / dstW;
+    lumYInc = (((int64_t)srcH << 16) + (dstH >> 1)) / dstH;
+    c->dstFormatBpp = bits_per_pixel(dd);
+    c->srcFormatBpp = bits_per_pixel(ds);
+
+    c->chrSrcHSub = ds->lw; c->chrSrcVSub = ds->lh;
+    c->chrDstHSub = dd->lw; c->chrDstVSub = dd->lh;
+
+    if (isAnyRGB(dstFormat) && !(flags & OR_SWS_FULL_CHR_H_INT)) { /* :1270-1286 */
+        if (dstW & 1) { flags |= OR_SWS_FULL_CHR_H_INT; c->o.flags = flags; }
+        if (c->chrSrcHSub == 0 && c->chrSrcVSub == 0 && c->o.dither != 2 && !(c->o.flags & OR_SWS_FAST_BILINEAR)) {
+            flags |= OR_SWS_FULL_CHR_H_INT; c->o.flags = flags;
+        }
+    }
+    if (isPlanarRGB(dstFormat) && !(flags & OR_SWS_FULL_CHR_H_INT)) { flags |= OR_SWS_FULL_CHR_H_INT; c->o.flags = flags; }
+    if (isAnyRGB(dstFormat) && !(flags & OR_SWS_FULL_CHR_H_INT)) c->chrDstHSub = 1; /* :1359 */
+
+    if (flags & 0x30000) return -1; /* vChrDrop not restated */
+
+    if (isAnyRGB(srcFormat) && !(srcW & 1) && !(flags & OR_SWS_FULL_CHR_H_INP) &&
+        srcFormat != ORF_GBRPF32LE &&
+        ((dstW >> c->chrDstHSub) <= (srcW >> 1) || (flags & OR_SWS_FAST_BILINEAR))) /* :1369-1390 */
+        c->chrSrcHSub = 1;
+
+    c->chrSrcW = CEIL_RSHIFT(srcW, c->chrSrcHSub);
+    c->chrSrcH = CEIL_RSHIFT(srcH, c->chrSrcVSub);
+    c->chrDstW = CEIL_RSHIFT(dstW, c->chrDstHSub);
+    c->chrDstH = CEIL_RSHIFT(dstH, c->chrDstVSub);
+
+    c->srcBpc = ds->c[0].depth; if (c->srcBpc < 8) c->srcBpc = 8;
+    c->dstBpc = dd->c[0].depth; if (c->dstBpc < 8) c->dstBpc = 8;
+    if (isAnyRGB(srcFormat)) c->srcBpc = 16;
+
+    chrXInc = (((int64_t)c->chrSrcW << 16) + (c->chrDstW >> 1)) / c->chrDstW;
+    chrYInc = (((int64_t)c->chrSrcH << 16) + (c->chrDstH >> 1)) / c->chrDstH;
+    if (chrXInc < 10 || chrXInc > 0x7fffffff || chrYInc < 10 || chrYInc > 0x7fffffff ||
+        lumXInc < 10 || lumXInc > 0x7fffffff || lumYInc < 10 || lumYInc > 0x7fffffff)
+        return -1;
+    c->lumXInc = (int)lumXInc; c->lumYInc = (int)lumYInc; c->chrXInc = (int)chrXInc; c->chrYInc = (int)chrYInc;
+
+    /* alpha: src alpha dropped -> reference cascades through alpha blend only if alpha_blend != NONE (default NONE) */
+    c->needAlpha = isALPHA(srcFormat) && isALPHA(dstFormat);
+    if (c->needAlpha) return -1; /* alpha plane scaling not restated */
+
+    if (unscaled && (c->o.src_range == c->o.dst_range || isAnyRGB(dstFormat) || isFloat(srcFormat) || isFloat(dstFormat))) {
+        get_unscaled(c);
+        if (c->unscaled_kind) { c->initialized = 1; return 0; }
+    }
+
+    /* filters (:1675-1735), filterAlign == 1 in the C-only build */
+    ret = init_filter(&c->hLumFilter, &c->hLumFilterPos, &c->hLumFilterSize, c->lumXInc, srcW, dstW, 1, 1 << 14,
+                      lum_scaler, flags, c->o.scaler_params, get_local_pos(0, 0), get_local_pos(0, 0));
+    if (ret < 0) return -1;
+    ret = init_filter(&c->hChrFilter, &c->hChrFilterPos, &c->hChrFilterSize, c->chrXInc, c->chrSrcW, c->chrDstW, 1, 1 << 14,
+                      chr_scaler, flags, c->o.scaler_params,
+                      get_local_pos(c->chrSrcHSub, c->o.src_h_chr_pos), get_local_pos(c->chrDstHSub, c->o.dst_h_chr_pos));
+    if (ret < 0) return -1;
+    ret = init_filter(&c->vLumFilter, &c->vLumFilterPos, &c->vLumFilterSize, c->lumYInc, srcH, dstH, 1, 1 << 12,
+                      lum_scaler, flags, c->o.scaler_params, get_local_pos(0, 0), get_local_pos(0, 0));
+    if (ret < 0) return -1; /* RET_CASCADE: extreme-ratio cascade not restated */
+    ret = init_filter(&c->vChrFilter, &c->vChrFilterPos, &c->vChrFilterSize, c->chrYInc, c->chrSrcH, c->chrDstH, 1, 1 << 12,
+                      chr_scaler, flags, c->o.scaler_params,
+                      get_local_pos(c->chrSrcVSub, c->o.src_v_chr_pos), get_local_pos(c->chrDstVSub, c->o.dst_v_chr_pos));
+    if (ret < 0) return -1;
+
+    init_range_convert(c); /* ff_sws_init_scale -> sws_init_swscale, swscale.c:662-695 */
+    c->initialized = 1;
+    return 0;
+}
+
+static int range_override_needed(int f) { return !isYUV(f) && !isGray(f); }
+
+int or_sws_set_colorspace(OrSws *c, const int inv_table[4], int srcRange, const int table[4],
+                          int dstRange, int brightness, int contrast, int saturation) /* utils.c:849-1005 */
+{
+    int need_reinit = 0;
+    const Desc *dd, *ds;
+
+    handle_formats(c);
+    dd = desc_get(c->o.dst_format); ds = desc_get(c->o.src_format);
+    if (range_override_needed(c->o.dst_format)) dstRange = 0;
+    if (range_override_needed(c->o.src_format)) srcRange = 0;
+
+    if (c->o.src_range != srcRange || c->o.dst_range != dstRange || c->brightness != brightness ||
+        c->contrast != contrast || c->saturation != saturation ||
+        memcmp(c->srcColorspaceTable, inv_table, sizeof(int) * 4) ||
+        memcmp(c->dstColorspaceTable, table, sizeof(int) * 4))
+        need_reinit = 1;
+
+    memmove(c->srcColorspaceTable, inv_table, sizeof(int) * 4);
+    memmove(c->dstColorspaceTable, table, sizeof(int) * 4);
+    c->brightness = brightness; c->contrast = contrast; c->saturation = saturation;
+    c->o.src_range = srcRange; c->o.dst_range = dstRange;
+
+    if (need_reinit) init_range_convert(c);
+
+    c->dstFormatBpp = bits_per_pixel(dd);
+    c->srcFormatBpp = bits_per_pixel(ds);
+
+    if (c->cascade[0]) /* cascaded_mainindex == 0 here */
+        return or_sws_set_colorspace(c->cascade[0], inv_table, srcRange, table, dstRange, brightness, contrast, saturation);
+    if (!need_reinit) return 0;
+
+    if ((isYUV(c->o.dst_format) || isGray(c->o.dst_format)) && (isYUV(c->o.src_format) || isGray(c->o.src_format))) {
+        if (!c->cascade[0] && memcmp(c->dstColorspaceTable, c->srcColorspaceTable, sizeof(int) * 4) &&
+            c->o.src_w && c->o.src_h && c->o.dst_w && c->o.dst_h) { /* :915-984 */
+            int tmp_format, tmp_w, tmp_h, srcW = c->o.src_w, srcH = c->o.src_h, dstW = c->o.dst_w, dstH = c->o.dst_h;
+            if (isNBPS(c->o.dst_format) || is16BPS(c->o.dst_format)) return -1; /* BGR48 intermediate not restated */
+            tmp_format = ORF_BGR24;
+            if (srcW * srcH > dstW * dstH) { tmp_w = dstW; tmp_h = dstH; } else { tmp_w = srcW; tmp_h = srcH; }
+            c->casc_stride[0] = (tmp_w * 3 + 63) & ~63;
+            c->casc_tmp[0] = malloc((size_t)c->casc_stride[0] * tmp_h + 64);
+
+            c->cascade[0] = alloc_set_opts(srcW, srcH, c->o.src_format, tmp_w, tmp_h, tmp_format, c->o.flags, c->o.scaler_params);
+            if (init_context(c->cascade[0]) < 0) return -1;
+            or_sws_set_colorspace(c->cascade[0], inv_table, srcRange, table, dstRange, brightness, contrast, saturation);
+
+            c->cascade[1] = alloc_set_opts(tmp_w, tmp_h, tmp_format, dstW, dstH, c->o.dst_format, c->o.flags, c->o.scaler_params);
+            c->cascade[1]->o.src_range = srcRange;
+            c->cascade[1]->o.dst_range = dstRange;
+            if (init_context(c->cascade[1]) < 0) return -1;
+            or_sws_set_colorspace(c->cascade[1], inv_table, srcRange, table, dstRange, 0, 1 << 16, 1 << 16);
+            return 0;
+        }
+        if (c->cascade[0] && memcmp(c->dstColorspaceTable, c->srcColorspaceTable, sizeof(int) * 4)) return -1;
+        return 0;
+    }
+    if (!isYUV(c->o.dst_format) && !isGray(c->o.dst_format))
+        yuv2rgb_init_tables(c, inv_table, srcRange, brightness, contrast, saturation);
+    fill_rgb2yuv_table(c, table);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* unscaled converters                                                 */
+/* ------------------------------------------------------------------ */
+static inline uint32_t lut_at(const OrSws *c, int idx)
+{
+    if (c->lut_elem == 1) return c->yuvTable[idx];
+    return ((const uint32_t *)c->yuvTable)[idx];
+}
+
+/* YUV420FUNC/YUV422FUNC + PUTRGB24/PUTBGR24/PUTRGB, yuv2rgb.c:68-559.
+ * The 8/4/2-pixel block structure of the macros reduces to: pixel pair i on
+ * rows (2k, 2k+1) uses chroma sample i of chroma row k (420) / row y (422);
+ * widths that are not a multiple of 2 leave the last column untouched. */
+static int unscaled_yuv2rgb(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                            int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    const int is422 = c->o.src_format == ORF_YUV422P;
+    const int d = c->o.dst_format;
+    const int npairs = ((c->o.dst_w >> 3) << 2) + ((c->o.dst_w & 4) ? 2 : 0) + ((c->o.dst_w & 2) ? 1 : 0);
+    for (int y = 0; y < srcSliceH; y += 2) {
+        for (int l = 0; l < 2; l++) {
+            int yy = y + l;
+            const uint8_t *py = src[0] + yy * srcStride[0];
+            const uint8_t *pu = src[1] + (is422 ? yy : (y >> 1)) * srcStride[1];
+            const uint8_t *pv = src[2] + (is422 ? yy : (y >> 1)) * srcStride[2];
+            uint8_t *out = dst[0] + (yy + srcSliceY) * dstStride[0];
+            for (int i = 0; i < npairs; i++) {
+                int U = pu[i], V = pv[i];
+                int r = c->table_rV[V + HEADROOM];
+                int g = c->table_gU[U + HEADROOM] + c->table_gV[V + HEADROOM];
+                int b = c->table_bU[U + HEADROOM];
+                for (int k = 0; k < 2; k++) {
+                    int Y = py[2 * i + k];
+                    if (d == ORF_RGB24 || d == ORF_BGR24) {
+                        uint8_t R = (uint8_t)lut_at(c, r + Y), G = (uint8_t)lut_at(c, g + Y), B = (uint8_t)lut_at(c, b + Y);
+                        uint8_t *p = out + 6 * i + 3 * k;
+                        if (d == ORF_RGB24) { p[0] = R; p[1] = G; p[2] = B; }
+                        else { p[0] = B; p[1] = G; p[2] = R; }
+                    } else {
+                        uint32_t v = lut_at(c, r + Y) + lut_at(c, g + Y) + lut_at(c, b + Y);
+                        memcpy(out + 8 * i + 4 * k, &v, 4);
+                    }
+                }
+            }
+        }
+    }
+    return srcSliceH;
+}
+
+/* planarToP01xWrapper, swscale_unscaled.c:273-322 */
+static int unscaled_p01x(OrSws *c, const uint8_t *const src8[], const int srcStride[], int srcSliceY,
+                         int srcSliceH, uint8_t *const dst8[], const int dstStride[])
+{
+    const Desc *sf = desc_get(c->o.src_format), *df = desc_get(c->o.dst_format);
+    int shift[3];
+    for (int k = 0; k < 3; k++)
+        shift[k] = df->c[k].depth + df->c[k].shift - sf->c[k].depth - sf->c[k].shift;
+    for (int y = 0; y < srcSliceH; y++) {
+        const uint16_t *s0 = (const uint16_t *)(src8[0] + y * srcStride[0]);
+        uint16_t *dY = (uint16_t *)(dst8[0] + (srcSliceY + y) * dstStride[0]);
+        for (int x = 0; x < c->o.src_w; x++) dY[x] = (uint16_t)(s0[x] << shift[0]);
+        if (!(y & 1)) {
+            const uint16_t *s1 = (const uint16_t *)(src8[1] + (y >> 1) * srcStride[1]);
+            const uint16_t *s2 = (const uint16_t *)(src8[2] + (y >> 1) * srcStride[2]);
+            uint16_t *dUV = (uint16_t *)(dst8[1] + ((srcSliceY + y) >> 1) * dstStride[1]);
+            for (int x = 0; x < c->o.src_w / 2; x++) {
+                dUV[2 * x] = (uint16_t)(s1[x] << shift[1]);
+                dUV[2 * x + 1] = (uint16_t)(s2[x] << shift[2]);
+            }
+        }
+    }
+    return srcSliceH;
+}
+
+/* planar8ToP01xleWrapper, swscale_unscaled.c:333-372 */
+static int unscaled_8_p01x(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                           int srcSliceH, uint8_t *const dst8[], const int dstStride[])
+{
+    for (int y = 0; y < srcSliceH; y++) {
+        const uint8_t *s0 = src[0] + y * srcStride[0];
+        uint16_t *dY = (uint16_t *)(dst8[0] + (srcSliceY + y) * dstStride[0]);
+        for (int x = 0; x < c->o.src_w; x++) dY[x] = (uint16_t)(s0[x] << 8);
+        if (!(y & 1)) {
+            const uint8_t *s1 = src[1] + (y >> 1) * srcStride[1], *s2 = src[2] + (y >> 1) * srcStride[2];
+            uint16_t *dUV = (uint16_t *)(dst8[1] + ((srcSliceY + y) >> 1) * dstStride[1]);
+            for (int x = 0; x < c->o.src_w / 2; x++) {
+                dUV[2 * x] = (uint16_t)(s1[x] << 8);
+                dUV[2 * x + 1] = (uint16_t)(s2[x] << 8);
+            }
+        }
+    }
+    return srcSliceH;
+}
+
+static void copy_plane(const uint8_t *src, int srcStride, int y0, int h, int w, uint8_t *dst, int dstStride)
+{
+    dst += dstStride * y0;
+    for (int i = 0; i < h; i++) { memcpy(dst, src, w); src += srcStride; dst += dstStride; }
+}
+
+/* planarToNv12Wrapper / nv12ToPlanarWrapper, swscale_unscaled.c:147-186 */
+static int unscaled_planar2nv12(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                                int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    uint8_t *d = dst[1] + dstStride[1] * srcSliceY / 2;
+    int a = c->o.dst_format == ORF_NV12 ? 1 : 2, b = 3 - a;
+    copy_plane(src[0], srcStride[0], srcSliceY, srcSliceH, c->o.src_w, dst[0], dstStride[0]);
+    for (int y = 0; y < (srcSliceH + 1) / 2; y++) {
+        const uint8_t *s1 = src[a] + y * srcStride[a], *s2 = src[b] + y * srcStride[b];
+        for (int x = 0; x < c->chrSrcW; x++) { d[2 * x] = s1[x]; d[2 * x + 1] = s2[x]; }
+        d += dstStride[1];
+    }
+    return srcSliceH;
+}
+static int unscaled_nv122planar(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                                int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    int a = c->o.src_format == ORF_NV12 ? 1 : 2, b = 3 - a;
+    copy_plane(src[0], srcStride[0], srcSliceY, srcSliceH, c->o.src_w, dst[0], dstStride[0]);
+    for (int y = 0; y < (srcSliceH + 1) / 2; y++) {
+        const uint8_t *s = src[1] + y * srcStride[1];
+        uint8_t *d1 = dst[a] + dstStride[a] * (srcSliceY / 2 + y), *d2 = dst[b] + dstStride[b] * (srcSliceY / 2 + y);
+        for (int x = 0; x < c->chrSrcW; x++) { d1[x] = s[2 * x]; d2[x] = s[2 * x + 1]; }
+    }
+    return srcSliceH;
+}
+
+static const uint8_t dithers[8][8][8] = { /* swscale_unscaled.c:39-112 */
+{ {0,1,0,1,0,1,0,1},{1,0,1,0,1,0,1,0},{0,1,0,1,0,1,0,1},{1,0,1,0,1,0,1,0},{0,1,0,1,0,1,0,1},{1,0,1,0,1,0,1,0},{0,1,0,1,0,1,0,1},{1,0,1,0,1,0,1,0} },
+{ {1,2,1,2,1,2,1,2},{3,0,3,0,3,0,3,0},{1,2,1,2,1,2,1,2},{3,0,3,0,3,0,3,0},{1,2,1,2,1,2,1,2},{3,0,3,0,3,0,3,0},{1,2,1,2,1,2,1,2},{3,0,3,0,3,0,3,0} },
+{ {2,4,3,5,2,4,3,5},{6,0,7,1,6,0,7,1},{3,5,2,4,3,5,2,4},{7,1,6,0,7,1,6,0},{2,4,3,5,2,4,3,5},{6,0,7,1,6,0,7,1},{3,5,2,4,3,5,2,4},{7,1,6,0,7,1,6,0} },
+{ {4,8,7,11,4,8,7,11},{12,0,15,3,12,0,15,3},{6,10,5,9,6,10,5,9},{14,2,13,1,14,2,13,1},{4,8,7,11,4,8,7,11},{12,0,15,3,12,0,15,3},{6,10,5,9,6,10,5,9},{14,2,13,1,14,2,13,1} },
+{ {9,17,15,23,8,16,14,22},{25,1,31,7,24,0,30,6},{13,21,11,19,12,20,10,18},{29,5,27,3,28,4,26,2},{8,16,14,22,9,17,15,23},{24,0,30,6,25,1,31,7},{12,20,10,18,13,21,11,19},{28,4,26,2,29,5,27,3} },
+{ {18,34,30,46,17,33,29,45},{50,2,62,14,49,1,61,13},{26,42,22,38,25,41,21,37},{58,10,54,6,57,9,53,5},{16,32,28,44,19,35,31,47},{48,0,60,12,51,3,63,15},{24,40,20,36,27,43,23,39},{56,8,52,4,59,11,55,7} },
+{ {18,34,30,46,17,33,29,45},{50,2,62,14,49,1,61,13},{26,42,22,38,25,41,21,37},{58,10,54,6,57,9,53,5},{16,32,28,44,19,35,31,47},{48,0,60,12,51,3,63,15},{24,40,20,36,27,43,23,39},{56,8,52,4,59,11,55,7} },
+{ {36,68,60,92,34,66,58,90},{100,4,124,28,98,2,122,26},{52,84,44,76,50,82,42,74},{116,20,108,12,114,18,106,10},{32,64,56,88,38,70,62,94},{96,0,120,24,102,6,126,30},{48,80,40,72,54,86,46,78},{112,16,104,8,118,22,110,14} },
+};
+
+/* planarCopyWrapper, swscale_unscaled.c:2220-2384 (little-endian formats only) */
+static int unscaled_planarcopy(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                               int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    const Desc *ds = desc_get(c->o.src_format), *dd = desc_get(c->o.dst_format);
+    const int sf = c->o.src_format, df = c->o.dst_format;
+    int nplanes = isSemiPlanarYUV(df) ? 2 : 3;
+    for (int plane = 0; plane < nplanes; plane++) {
+        int length = plane == 0 ? c->o.src_w : CEIL_RSHIFT(c->o.src_w, c->chrDstHSub);
+        int y = plane == 0 ? srcSliceY : CEIL_RSHIFT(srcSliceY, c->chrDstVSub);
+        int height = plane == 0 ? srcSliceH : CEIL_RSHIFT(srcSliceH, c->chrDstVSub);
+        const uint8_t *srcPtr = src[plane];
+        uint8_t *dstPtr = dst[plane] + dstStride[plane] * y;
+        int shiftonly = plane == 1 || plane == 2 || (!c->o.src_range && plane == 0);
+        int i, j;
+        if (plane == 1 && isSemiPlanarYUV(df)) length *= 2;
+        if (isNBPS(sf) || isNBPS(df) || (is16BPS(sf) != is16BPS(df))) {
+            const int src_depth = ds->c[plane].depth, dst_depth = dd->c[plane].depth;
+            const int src_shift = ds->c[plane].shift, dst_shift = dd->c[plane].shift;
+            const uint16_t *srcPtr2 = (const uint16_t *)srcPtr;
+            uint16_t *dstPtr2 = (uint16_t *)dstPtr;
+            if (dst_depth == 8 || src_depth > dst_depth) { /* DITHER_COPY :2159-2218 */
+                unsigned shift = src_depth - dst_depth, tmp, bias = 1u << (shift - 1);
+                int to8 = dst_depth == 8;
+                int sstride = srcStride[plane] / 2, dstride = to8 ? dstStride[plane] : dstStride[plane] / 2;
+                uint8_t *d8 = dstPtr; uint16_t *d16 = dstPtr2;
+                /* the macro's vector body (j < length-7) applies src_shift/dst_shift, its scalar
+                 * tail does not; restated exactly */
+                for (i = 0; i < height; i++) {
+                    const uint8_t *dither = dithers[shift - 1][i & 7];
+                    for (j = 0; j < length; j++) {
+                        int body = j < ((length - 7 > 0) ? ((length - 7 + 7) / 8) * 8 : 0);
+                        unsigned v;
+                        if (c->o.dither == 0) {
+                            if (body) { tmp = ((srcPtr2[j] >> src_shift) + bias) >> shift; v = (tmp - (tmp >> dst_depth)) << dst_shift; }
+                            else { tmp = (srcPtr2[j] + bias) >> shift; v = tmp - ((tmp >> dst_depth) << dst_shift); }
+                        } else if (shiftonly) {
+                            if (body) { tmp = ((srcPtr2[j] >> src_shift) + dither[j & 7]) >> shift; v = (tmp - (tmp >> dst_depth)) << dst_shift; }
+                            else { tmp = (srcPtr2[j] + dither[j & 7]) >> shift; v = tmp - ((tmp >> dst_depth) << dst_shift); }
+                        } else {
+                            if (body) { tmp = srcPtr2[j] >> src_shift; v = ((tmp - (tmp >> dst_depth) + dither[j & 7]) >> shift) << dst_shift; }
+                            else { tmp = srcPtr2[j]; v = (tmp - (tmp >> dst_depth) + dither[j & 7]) >> shift; }
+                        }
+                        if (to8) d8[j] = (uint8_t)v; else d16[j] = (uint16_t)v;
+                    }
+                    if (to8) d8 += dstride; else d16 += dstride;
+                    srcPtr2 += sstride;
+                }
+            } else if (src_depth == 8) { /* :2266-2284 */
+                for (i = 0; i < height; i++) {
+                    for (j = 0; j < length; j++)
+                        dstPtr2[j] = shiftonly ? (uint16_t)((srcPtr[j] << (dst_depth - 8)) << dst_shift)
+                                               : (uint16_t)(((srcPtr[j] << (dst_depth - 8)) | (srcPtr[j] >> (2 * 8 - dst_depth))) << dst_shift);
+                    dstPtr2 += dstStride[plane] / 2; srcPtr += srcStride[plane];
+                }
+            } else { /* src_depth <= dst_depth :2285-2331 */
+                unsigned shift = dst_depth - src_depth;
+                for (i = 0; i < height; i++) {
+                    for (j = 0; j < length; j++) {
+                        unsigned v = srcPtr2[j] >> src_shift;
+                        dstPtr2[j] = shiftonly ? (uint16_t)((v << shift) << dst_shift)
+                                               : (uint16_t)(((v << shift) | (v >> (2 * src_depth - dst_depth))) << dst_shift);
+                    }
+                    dstPtr2 += dstStride[plane] / 2; srcPtr2 += srcStride[plane] / 2;
+                }
+            }
+        } else {
+            if (is16BPS(sf) && is16BPS(df)) length *= 2;
+            else if (isFloat(sf) && isFloat(df)) length *= 4;
+            for (i = 0; i < height; i++) { memcpy(dstPtr, srcPtr, length); srcPtr += srcStride[plane]; dstPtr += dstStride[plane]; }
+        }
+    }
+    return srcSliceH;
+}
+
+/* ------------------------------------------------------------------ */
+/* main path: readers                                                  */
+/* ------------------------------------------------------------------ */
+static int f2u16(float x) /* lrintf(av_clipf(65535.0f * x, 0, 65535)), input.c:1300 */
+{
+    float v = 65535.0f * x;
+    v = v < 0.0f ? 0.0f : v; /* av_clipf_c: FFMIN(FFMAX(a, amin), amax) */
+    v = v > 65535.0f ? 65535.0f : v;
+    return (int)lrintf(v);
+}
+
+/* Produce the 8/16-bit "formatConv" luma line for source row y (NULL if the plane is read directly).
+ * returns pointer to the line to feed to hscale. */
+static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], const int stride[], int y, uint8_t *tmp)
+{
+    const int f = c->o.src_format, w = c->o.src_w;
+    const int32_t *t = c->rgb2yuv;
+    int i;
+    switch (f) {
+    case ORF_P010LE: { /* p010LEToY_c input.c:970-1001 */
+        const uint16_t *s = (const uint16_t *)(src[0] + y * stride[0]); uint16_t *d = (uint16_t *)tmp;
+        for (i = 0; i < w; i++) d[i] = s[i] >> 6;
+        return tmp; }
+    case ORF_RGB24: case ORF_BGR24: { /* rgb24ToY_c / bgr24ToY_c input.c:1068-1124 */
+        const uint8_t *s = src[0] + y * stride[0]; int16_t *d = (int16_t *)tmp;
+        int ro = f == ORF_RGB24 ? 0 : 2, bo = 2 - ro;
+        for (i = 0; i < w; i++) {
+            int r = s[3 * i + ro], g = s[3 * i + 1], b = s[3 * i + bo];
+            d[i] = (int16_t)((t[RY] * r + t[GY] * g + t[BY] * b + (32 << (15 - 1)) + (1 << (15 - 7))) >> (15 - 6));
+        }
+        return tmp; }
+    case ORF_RGBA: case ORF_BGRA: case ORF_ARGB: case ORF_ABGR: { /* rgb16_32ToY_c_template input.c:264-293 */
+        const uint8_t *s = src[0] + y * stride[0]; int16_t *d = (int16_t *)tmp;
+        /* byte positions of r,g,b inside the pixel */
+        const Desc *ds = desc_get(f);
+        int ro = ds->c[0].offset, go = ds->c[1].offset, bo = ds->c[2].offset;
+        const int S = 15 + 8;
+        const int ry = t[RY] << 8, gy = t[GY] << 0, by = t[BY] << 8;
+        const unsigned rnd = (32u << (S - 1)) + (1u << (S - 7));
+        for (i = 0; i < w; i++) {
+            /* the template extracts g as (px & 0xFF00) (i.e. g<<8) and r,b as 0..255 with coeffs <<8 */
+            int r = s[4 * i + ro], g = s[4 * i + go] << 8, b = s[4 * i + bo];
+            d[i] = (int16_t)((int)(ry * r + gy * g + by * b + rnd) >> (S - 6));
+        }
+        return tmp; }
+    case ORF_GBRP: { /* planar_rgb_to_y input.c:1174-1186 */
+        const uint8_t *G = src[0] + y * stride[0], *B = src[1] + y * stride[1], *R = src[2] + y * stride[2];
+        uint16_t *d = (uint16_t *)tmp;
+        for (i = 0; i < w; i++)
+            d[i] = (uint16_t)((int)((unsigned)t[RY] * R[i] + (unsigned)t[GY] * G[i] + (unsigned)t[BY] * B[i] + (0x801 << (15 - 7))) >> (15 - 6));
+        return tmp; }
+    case ORF_GBRPF32LE: { /* planar_rgbf32_to_y input.c:1319-1334 */
+        const float *G = (const float *)(src[0] + y * stride[0]), *B = (const float *)(src[1] + y * stride[1]),
+                    *R = (const float *)(src[2] + y * stride[2]);
+        uint16_t *d = (uint16_t *)tmp;
+        for (i = 0; i < w; i++) {
+            int g = f2u16(G[i]), b = f2u16(B[i]), r = f2u16(R[i]);
+            d[i] = (uint16_t)((int)((unsigned)t[RY] * r + (unsigned)t[GY] * g + (unsigned)t[BY] * b + (0x2001u << (15 - 1))) >> 15);
+        }
+        return tmp; }
+    default:
+        return src[0] + y * stride[0];
+    }
+}
+
+/* chroma line for chroma source row y -> (u,v) lines of chrSrcW samples */
+static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int stride[], int y,
+                          uint8_t *tu, uint8_t *tv, const uint8_t **pu, const uint8_t **pv)
+{
+    const int f = c->o.src_format, w = c->chrSrcW;
+    const int32_t *t = c->rgb2yuv;
+    int i;
+    *pu = tu; *pv = tv;
+    switch (f) {
+    case ORF_NV12: case ORF_NV21: { /* nv12ToUV_c / nv21ToUV_c input.c:926-948 */
+        const uint8_t *s = src[1] + y * stride[1];
+        uint8_t *a = f == ORF_NV12 ? tu : tv, *b = f == ORF_NV12 ? tv : tu;
+        for (i = 0; i < w; i++) { a[i] = s[2 * i]; b[i] = s[2 * i + 1]; }
+        return; }
+    case ORF_P010LE: { /* p010LEToUV_c input.c:950-968 */
+        const uint16_t *s = (const uint16_t *)(src[1] + y * stride[1]);
+        uint16_t *a = (uint16_t *)tu, *b = (uint16_t *)tv;
+        for (i = 0; i < w; i++) { a[i] = s[2 * i] >> 6; b[i] = s[2 * i + 1] >> 6; }
+        return; }
+    case ORF_RGB24: case ORF_BGR24: { /* rgb24ToUV(_half)_c, bgr24ToUV(_half)_c input.c:1082-1172 */
+        /* chroma row y reads source row y << chrSrcVSub (hscale.c:212) */
+        const uint8_t *s = src[0] + (y << c->chrSrcVSub) * stride[0];
+        int16_t *du = (int16_t *)tu, *dv = (int16_t *)tv;
+        int ro = f == ORF_RGB24 ? 0 : 2, bo = 2 - ro;
+        if (c->chrSrcHSub) {
+            for (i = 0; i < w; i++) {
+                int r = s[6 * i + ro] + s[6 * i + 3 + ro], g = s[6 * i + 1] + s[6 * i + 4], b = s[6 * i + bo] + s[6 * i + 3 + bo];
+                du[i] = (int16_t)((t[RU] * r + t[GU] * g + t[BU] * b + (256 << 15) + (1 << (15 - 6))) >> (15 - 5));
+                dv[i] = (int16_t)((t[RV] * r + t[GV] * g + t[BV] * b + (256 << 15) + (1 << (15 - 6))) >> (15 - 5));
+            }
+        } else {
+            for (i = 0; i < w; i++) {
+                int r = s[3 * i + ro], g = s[3 * i + 1], b = s[3 * i + bo];
+                du[i] = (int16_t)((t[RU] * r + t[GU] * g + t[BU] * b + (256 << (15 - 1)) + (1 << (15 - 7))) >> (15 - 6));
+                dv[i] = (int16_t)((t[RV] * r + t[GV] * g + t[BV] * b + (256 << (15 - 1)) + (1 << (15 - 7))) >> (15 - 6));
+            }
+        }
+        return; }
+    case ORF_RGBA: case ORF_BGRA: case ORF_ARGB: case ORF_ABGR: { /* rgb16_32ToUV(_half)_c_template input.c:295-372 */
+        const uint8_t *s = src[0] + (y << c->chrSrcVSub) * stride[0];
+        int16_t *du = (int16_t *)tu, *dv = (int16_t *)tv;
+        const Desc *ds = desc_get(f);
+        int ro = ds->c[0].offset, go = ds->c[1].offset, bo = ds->c[2].offset;
+        const int S = 15 + 8;
+        const int ru = t[RU] * (1 << 8), gu = t[GU], bu = t[BU] * (1 << 8);
+        const int rv = t[RV] * (1 << 8), gv = t[GV], bv = t[BV] * (1 << 8);
+        if (c->chrSrcHSub) {
+            const unsigned rnd = (256U << S) + (1 << (S - 6));
+            for (i = 0; i < w; i++) {
+                /* sums of two pixels; g keeps its <<8 position (maskg|maskg<<1 applied to the sum) */
+                int r = s[8 * i + ro] + s[8 * i + 4 + ro];
+                int g = (s[8 * i + go] + s[8 * i + 4 + go]) << 8;
+                int b = s[8 * i + bo] + s[8 * i + 4 + bo];
+                du[i] = (int16_t)((int)(ru * r + gu * g + bu * b + rnd) >> (S - 6 + 1));
+                dv[i] = (int16_t)((int)(rv * r + gv * g + bv * b + rnd) >> (S - 6 + 1));
+            }
+        } else {
+            const unsigned rnd = (256u << (S - 1)) + (1 << (S - 7));
+            for (i = 0; i < w; i++) {
+                int r = s[4 * i + ro], g = s[4 * i + go] << 8, b = s[4 * i + bo];
+                du[i] = (int16_t)((int)(ru * r + gu * g + bu * b + rnd) >> (S - 6));
+                dv[i] = (int16_t)((int)(rv * r + gv * g + bv * b + rnd) >> (S - 6));
+            }
+        }
+        return; }
+    case ORF_GBRP: {
+        const uint8_t *G = src[0] + y * stride[0], *B = src[1] + y * stride[1], *R = src[2] + y * stride[2];
+        uint16_t *du = (uint16_t *)tu, *dv = (uint16_t *)tv;
+        if (c->chrSrcHSub) { /* gbr24pToUV_half_c input.c:412-432 */
+            for (i = 0; i < w; i++) {
+                unsigned g = G[2 * i] + G[2 * i + 1], b = B[2 * i] + B[2 * i + 1], r = R[2 * i] + R[2 * i + 1];
+                du[i] = (uint16_t)((int)(t[RU] * r + t[GU] * g + t[BU] * b + (0x4001 << (15 - 6))) >> (15 - 6 + 1));
+                dv[i] = (uint16_t)((int)(t[RV] * r + t[GV] * g + t[BV] * b + (0x4001 << (15 - 6))) >> (15 - 6 + 1));
+            }
+        } else { /* planar_rgb_to_uv input.c:1196-1211 */
+            for (i = 0; i < w; i++) {
+                int g = G[i], b = B[i], r = R[i];
+                du[i] = (uint16_t)((int)((unsigned)t[RU] * r + (unsigned)t[GU] * g + (unsigned)t[BU] * b + (0x4001 << (15 - 7))) >> (15 - 6));
+                dv[i] = (uint16_t)((int)((unsigned)t[RV] * r + (unsigned)t[GV] * g + (unsigned)t[BV] * b + (0x4001 << (15 - 7))) >> (15 - 6));
+            }
+        }
+        return; }
+    case ORF_GBRPF32LE: { /* planar_rgbf32_to_uv input.c:1300-1317 */
+        const float *G = (const float *)(src[0] + y * stride[0]), *B = (const float *)(src[1] + y * stride[1]),
+                    *R = (const float *)(src[2] + y * stride[2]);
+        uint16_t *du = (uint16_t *)tu, *dv = (uint16_t *)tv;
+        for (i = 0; i < w; i++) {
+            int g = f2u16(G[i]), b = f2u16(B[i]), r = f2u16(R[i]);
+            du[i] = (uint16_t)((int)((unsigned)t[RU] * r + (unsigned)t[GU] * g + (unsigned)t[BU] * b + (0x10001u << (15 - 1))) >> 15);
+            dv[i] = (uint16_t)((int)((unsigned)t[RV] * r + (unsigned)t[GV] * g + (unsigned)t[BV] * b + (0x10001u << (15 - 1))) >> 15);
+        }
+        return; }
+    default: { /* planar YUV: direct */
+        const Desc *ds = desc_get(f);
+        *pu = src[ds->c[1].plane] + y * stride[ds->c[1].plane];
+        *pv = src[ds->c[2].plane] + y * stride[ds->c[2].plane];
+        return; }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* main path: horizontal stage (swscale.c:69-159)                      */
+/* ------------------------------------------------------------------ */
+static void hscale_line(const OrSws *c, int32_t *dst, int dstW, const uint8_t *src,
+                        const int16_t *filter, const int32_t *filterPos, int fs)
+{
+    const Desc *ds = desc_get(c->o.src_format);
+    const int depth = ds->c[0].depth;
+    const int rgbish = isAnyRGB(c->o.src_format);
+    int i, j;
+    if (c->srcBpc == 8) {
+        for (i = 0; i < dstW; i++) {
+            int val = 0, sp = filterPos[i];
+            for (j = 0; j < fs; j++) val += ((int)src[sp + j]) * filter[fs * i + j];
+            if (c->dstBpc <= 14) dst[i] = (int16_t)ORMIN(val >> 7, (1 << 15) - 1);   /* hScale8To15_c */
+            else dst[i] = ORMIN(val >> 3, (1 << 19) - 1);                             /* hScale8To19_c */
+        }
+    } else {
+        const uint16_t *s = (const uint16_t *)src;
+        int sh;
+        if (c->dstBpc > 14) { /* hScale16To19_c :69-97 */
+            sh = depth - 1 - 4;
+            if (rgbish && depth < 16) sh = 9;
+            else if (ds->flags & PF_FLOAT) sh = 16 - 1 - 4;
+        } else { /* hScale16To15_c :99-125 */
+            sh = depth - 1;
+            if (sh < 15) sh = rgbish ? 13 : depth - 1;
+            else if (ds->flags & PF_FLOAT) sh = 16 - 1;
+        }
+        for (i = 0; i < dstW; i++) {
+            int val = 0, sp = filterPos[i];
+            for (j = 0; j < fs; j++) val += s[sp + j] * filter[fs * i + j];
+            if (c->dstBpc > 14) dst[i] = ORMIN(val >> sh, (1 << 19) - 1);
+            else dst[i] = (int16_t)ORMIN(val >> sh, (1 << 15) - 1);
+        }
+    }
+}
+
+/* range conversion on the intermediate (swscale.c:163-255) */
+static void range_line(const OrSws *c, int32_t *d, int w, int chroma)
+{
+    int i;
+    if (c->dstBpc <= 14) {
+        uint16_t coeff = (uint16_t)(chroma ? c->chrCoeff : c->lumCoeff);
+        int32_t offset = (int32_t)(chroma ? c->chrOffset : c->lumOffset);
+        for (i = 0; i < w; i++) {
+            int v = (d[i] * coeff + offset) >> 14;
+            if (!c->o.src_range) v = ORMIN(v, (1 << 15) - 1); /* ToJpeg */
+            d[i] = (int16_t)v;
+        }
+    } else {
+        uint32_t coeff = chroma ? c->chrCoeff : c->lumCoeff;
+        int64_t offset = chroma ? c->chrOffset : c->lumOffset;
+        for (i = 0; i < w; i++) {
+            int v = (int)(((int64_t)d[i] * coeff + offset) >> 18);
+            if (!c->o.src_range) v = ORMIN(v, (1 << 19) - 1);
+            d[i] = v;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* main path: vertical stage + writers (vscale.c, output.c)            */
+/* ------------------------------------------------------------------ */
+typedef struct { const int32_t *rows[64]; } RowSet; /* only used for small fs; general path indexes planes */
+
+/* planar writers: one output line of width w from fs rows. rows(j) = plane + (first+j clipped)*w */
+static void write_planar_line(const OrSws *c, uint8_t *dest, int w, const int32_t *plane, int planeW, int planeH,
+                              int first, const int16_t *filter, int fs, const uint8_t *dither, int offset,
+                              int is_luma_of_p01x)
+{
+    const Desc *dd = desc_get(c->o.dst_format);
+    const int bits = dd->c[0].depth;
+    int i, j;
+#define ROW(j) (plane + (size_t)ORMIN(first + (j), planeH - 1) * planeW)
+    (void)is_luma_of_p01x;
+    if (isSemiPlanarYUV(c->o.dst_format) && isDataInHighBits(c->o.dst_format)) { /* yuv2p01xl1_c / lX_c output.c:538-569 */
+        uint16_t *d = (uint16_t *)dest;
+        int oshift = 16 - bits;
+        if (fs == 1) {
+            int shift = 15 - bits; const int32_t *s = ROW(0);
+            for (i = 0; i < w; i++) d[i] = (uint16_t)(clip_uintp2((s[i] + (1 << (shift - 1))) >> shift, bits) << oshift);
+        } else {
+            int shift = 11 + 16 - bits;
+            for (i = 0; i < w; i++) {
+                int val = 1 << (shift - 1);
+                for (j = 0; j < fs; j++) val += ROW(j)[i] * filter[j];
+                d[i] = (uint16_t)(clip_uintp2(val >> shift, bits) << oshift);
+            }
+        }
+    } else if (bits == 16) { /* yuv2plane1_16 / planeX_16 output.c:149-187 */
+        uint16_t *d = (uint16_t *)dest;
+        if (fs == 1) {
+            const int32_t *s = ROW(0);
+            for (i = 0; i < w; i++) d[i] = (uint16_t)clip_u16((s[i] + (1 << 2)) >> 3);
+        } else {
+            for (i = 0; i < w; i++) {
+                int val = (1 << 14) - 0x40000000;
+                for (j = 0; j < fs; j++) val += (int)(ROW(j)[i] * (unsigned)filter[j]);
+                d[i] = (uint16_t)(0x8000 + clip_i16(val >> 15));
+            }
+        }
+    } else if (bits >= 9 && bits <= 14) { /* yuv2plane1_10 / planeX_10 output.c:327-357 */
+        uint16_t *d = (uint16_t *)dest;
+        if (fs == 1) {
+            int shift = 15 - bits; const int32_t *s = ROW(0);
+            for (i = 0; i < w; i++) d[i] = (uint16_t)clip_uintp2((s[i] + (1 << (shift - 1))) >> shift, bits);
+        } else {
+            int shift = 11 + 16 - bits;
+            for (i = 0; i < w; i++) {
+                int val = 1 << (shift - 1);
+                for (j = 0; j < fs; j++) val += ROW(j)[i] * filter[j];
+                d[i] = (uint16_t)clip_uintp2(val >> shift, bits);
+            }
+        }
+    } else { /* 8 bit: yuv2plane1_8_c / yuv2planeX_8_c output.c:468-493 */
+        if (fs == 1) {
+            const int32_t *s = ROW(0);
+            for (i = 0; i < w; i++) dest[i] = (uint8_t)clip_u8((s[i] + dither[(i + offset) & 7]) >> 7);
+        } else {
+            for (i = 0; i < w; i++) {
+                int val = dither[(i + offset) & 7] << 12;
+                for (j = 0; j < fs; j++) val += (int)(unsigned)(ROW(j)[i] * filter[j]);
+                dest[i] = (uint8_t)clip_u8(val >> 19);
+            }
+        }
+    }
+#undef ROW
+}
+
+/* interleaved chroma writers: yuv2nv12cX_c, yuv2p01xcX_c (output.c:495-528, 571-589) */
+static void write_nv_chroma_line(const OrSws *c, uint8_t *dest, int w, const int32_t *up, const int32_t *vp,
+                                 int planeW, int planeH, int first, const int16_t *filter, int fs, const uint8_t *dither)
+{
+    const Desc *dd = desc_get(c->o.dst_format);
+    const int bits = dd->c[0].depth;
+    int i, j;
+#define ROWU(j) (up + (size_t)ORMIN(first + (j), planeH - 1) * planeW)
+#define ROWV(j) (vp + (size_t)ORMIN(first + (j), planeH - 1) * planeW)
+    if (isDataInHighBits(c->o.dst_format)) {
+        uint16_t *d = (uint16_t *)dest;
+        int shift = 11 + 16 - bits, oshift = 16 - bits;
+        for (i = 0; i < w; i++) {
+            int u = 1 << (shift - 1), v = 1 << (shift - 1);
+            for (j = 0; j < fs; j++) {
+                u += (int)(ROWU(j)[i] * (unsigned)filter[j]);
+                v += (int)(ROWV(j)[i] * (unsigned)filter[j]);
+            }
+            d[2 * i] = (uint16_t)(clip_uintp2(u >> shift, bits) << oshift);
+            d[2 * i + 1] = (uint16_t)(clip_uintp2(v >> shift, bits) << oshift);
+        }
+    } else {
+        int swap = isSwappedChroma(c->o.dst_format);
+        for (i = 0; i < w; i++) {
+            int u = dither[i & 7] << 12, v = dither[(i + 3) & 7] << 12;
+            for (j = 0; j < fs; j++) {
+                u += (int)(ROWU(j)[i] * (unsigned)filter[j]);
+                v += (int)(ROWV(j)[i] * (unsigned)filter[j]);
+            }
+            dest[2 * i + swap] = (uint8_t)clip_u8(u >> 19);
+            dest[2 * i + 1 - swap] = (uint8_t)clip_u8(v >> 19);
+        }
+    }
+#undef ROWU
+#undef ROWV
+}
+
+/* LUT rgb pixel-pair write (yuv2rgb_write, output.c:1662-1785; 24/32 bpp) */
+static void rgb_write2(const OrSws *c, uint8_t *dest, int i, int Y1, int Y2, int U, int V)
+{
+    const int d = c->o.dst_format;
+    int r = c->table_rV[V + HEADROOM];
+    int g = c->table_gU[U + HEADROOM] + c->table_gV[V + HEADROOM];
+    int b = c->table_bU[U + HEADROOM];
+    if (c->lut_elem == 4) {
+        uint32_t v1 = lut_at(c, r + Y1) + lut_at(c, g + Y1) + lut_at(c, b + Y1);
+        uint32_t v2 = lut_at(c, r + Y2) + lut_at(c, g + Y2) + lut_at(c, b + Y2);
+        memcpy(dest + 8 * i, &v1, 4); memcpy(dest + 8 * i + 4, &v2, 4);
+    } else {
+        uint8_t *p = dest + 6 * i;
+        int rb = d == ORF_RGB24 ? r : b, br = d == ORF_RGB24 ? b : r;
+        p[0] = (uint8_t)lut_at(c, rb + Y1); p[1] = (uint8_t)lut_at(c, g + Y1); p[2] = (uint8_t)lut_at(c, br + Y1);
+        p[3] = (uint8_t)lut_at(c, rb + Y2); p[4] = (uint8_t)lut_at(c, g + Y2); p[5] = (uint8_t)lut_at(c, br + Y2);
+    }
+}
+
+/* full-chroma pixel write (yuv2rgb_write_full, output.c:2005-2070; 8-bit per channel targets) */
+static void rgb_write_full(const OrSws *c, uint8_t *dest, int Y, int U, int V)
+{
+    const int d = c->o.dst_format;
+    int R, G, B;
+    Y -= c->yuv2rgb_y_offset;
+    Y = (int)((unsigned)Y * (unsigned)c->yuv2rgb_y_coeff);
+    Y = (int)((unsigned)Y + (1U << 21));
+    R = (int)((unsigned)Y + (unsigned)V * (unsigned)c->yuv2rgb_v2r);
+    G = (int)((unsigned)Y + (unsigned)V * (unsigned)c->yuv2rgb_v2g + (unsigned)U * (unsigned)c->yuv2rgb_u2g);
+    B = (int)((unsigned)Y + (unsigned)U * (unsigned)c->yuv2rgb_u2b);
+    if ((R | G | B) & 0xC0000000) {
+        R = clip_uintp2(R, 30); G = clip_uintp2(G, 30); B = clip_uintp2(B, 30);
+    }
+    R >>= 22; G >>= 22; B >>= 22;
+    switch (d) {
+    case ORF_ARGB: dest[0] = 255; dest[1] = (uint8_t)R; dest[2] = (uint8_t)G; dest[3] = (uint8_t)B; break;
+    case ORF_RGB24: dest[0] = (uint8_t)R; dest[1] = (uint8_t)G; dest[2] = (uint8_t)B; break;
+    case ORF_RGBA: dest[0] = (uint8_t)R; dest[1] = (uint8_t)G; dest[2] = (uint8_t)B; dest[3] = 255; break;
+    case ORF_ABGR: dest[0] = 255; dest[1] = (uint8_t)B; dest[2] = (uint8_t)G; dest[3] = (uint8_t)R; break;
+    case ORF_BGR24: dest[0] = (uint8_t)B; dest[1] = (uint8_t)G; dest[2] = (uint8_t)R; break;
+    case ORF_BGRA: dest[0] = (uint8_t)B; dest[1] = (uint8_t)G; dest[2] = (uint8_t)R; dest[3] = 255; break;
+    }
+}
+
+typedef struct {
+    int32_t *lum, *chrU, *chrV; /* h-scaled planes: [srcH][dstW], [chrSrcH][chrDstW] */
+} Planes;
+
+/* packed_vscale (vscale.c:109-171) + yuv2rgb_{X,2,1}_c_template (output.c:1788-1939)
+ * + yuv2rgb_full_{X,2,1}_c_template (output.c:2163-2312) */
+static void write_packed_rgb_line(const OrSws *c, const Planes *P, uint8_t *dest, int y)
+{
+    const int dstW = c->o.dst_w, lw = dstW, cw = c->chrDstW;
+    const int srcH = c->o.src_h, chrSrcH = c->chrSrcH;
+    const int chrY = y >> c->chrDstVSub;
+    const int lfs = c->vLumFilterSize, cfs = c->vChrFilterSize;
+    const int16_t *lf = c->vLumFilter + y * lfs, *cf = c->vChrFilter + chrY * cfs;
+    const int firstLum = ORMAX(1 - lfs, c->vLumFilterPos[y]);
+    const int firstChr = ORMAX(1 - cfs, c->vChrFilterPos[chrY]);
+    const int full = !!(c->o.flags & OR_SWS_FULL_CHR_H_INT);
+    const int step = c->lut_elem == 4 || c->dstFormatBpp == 32 ? 4 : 3;
+    int i, j;
+#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+#define CU(j) (P->chrU + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+#define CV(j) (P->chrV + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+    int mode; /* 1: packed1 (uvalpha in ua), 2: packed2, 0: X */
+    int ua = 0, ya = 0;
+    if (lfs == 1 && cfs == 1) { mode = 1; ua = 0; }
+    else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 1; ua = (uint16_t)cf[1]; }
+    else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
+             (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 2; ya = (uint16_t)lf[1]; ua = (uint16_t)cf[1]; }
+    else mode = 0;
+
+    if (!full) {
+        for (i = 0; i < ((dstW + 1) >> 1); i++) {
+            int Y1, Y2, U, V;
+            if (mode == 0) {
+                Y1 = Y2 = U = V = 1 << 18;
+                for (j = 0; j < lfs; j++) { Y1 += (int)(L(j)[2 * i] * (unsigned)lf[j]); Y2 += (int)(L(j)[2 * i + 1] * (unsigned)lf[j]); }
+                for (j = 0; j < cfs; j++) { U += (int)(CU(j)[i] * (unsigned)cf[j]); V += (int)(CV(j)[i] * (unsigned)cf[j]); }
+                Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
+            } else if (mode == 2) {
+                int ya1 = 4096 - ya, ua1 = 4096 - ua;
+                Y1 = (L(0)[2 * i] * ya1 + L(1)[2 * i] * ya) >> 19;
+                Y2 = (L(0)[2 * i + 1] * ya1 + L(1)[2 * i + 1] * ya) >> 19;
+                U = (CU(0)[i] * ua1 + CU(1)[i] * ua) >> 19;
+                V = (CV(0)[i] * ua1 + CV(1)[i] * ua) >> 19;
+            } else {
+                Y1 = (L(0)[2 * i] + 64) >> 7;
+                Y2 = (L(0)[2 * i + 1] + 64) >> 7;
+                if (ua == 0) { U = (CU(0)[i] + 64) >> 7; V = (CV(0)[i] + 64) >> 7; }
+                else {
+                    int ua1 = 4096 - ua;
+                    U = (CU(0)[i] * ua1 + CU(1)[i] * ua + (128 << 11)) >> 19;
+                    V = (CV(0)[i] * ua1 + CV(1)[i] * ua + (128 << 11)) >> 19;
+                }
+            }
+            rgb_write2(c, dest, i, Y1, Y2, U, V);
+        }
+    } else {
+        for (i = 0; i < dstW; i++) {
+            int Y, U, V;
+            if (mode == 0) { /* :2163-2212 */
+                Y = 1 << 9; U = (1 << 9) - (128 << 19); V = (1 << 9) - (128 << 19);
+                for (j = 0; j < lfs; j++) Y += (int)(L(j)[i] * (unsigned)lf[j]);
+                for (j = 0; j < cfs; j++) { U += (int)(CU(j)[i] * (unsigned)cf[j]); V += (int)(CV(j)[i] * (unsigned)cf[j]); }
+                Y >>= 10; U >>= 10; V >>= 10;
+            } else if (mode == 2) { /* :2214-2260 */
+                int ya1 = 4096 - ya, ua1 = 4096 - ua;
+                Y = (L(0)[i] * ya1 + L(1)[i] * ya) >> 10;
+                U = (CU(0)[i] * ua1 + CU(1)[i] * ua - (128 << 19)) >> 10;
+                V = (CV(0)[i] * ua1 + CV(1)[i] * ua - (128 << 19)) >> 10;
+            } else { /* :2262-2312 */
+                Y = L(0)[i] * 4;
+                if (ua == 0) { U = (CU(0)[i] - (128 << 7)) * 4; V = (CV(0)[i] - (128 << 7)) * 4; }
+                else {
+                    int ua1 = 4096 - ua;
+                    U = (CU(0)[i] * ua1 + CU(1)[i] * ua - (128 << 19)) >> 10;
+                    V = (CV(0)[i] * ua1 + CV(1)[i] * ua - (128 << 19)) >> 10;
+                }
+            }
+            rgb_write_full(c, dest + step * i, Y, U, V);
+        }
+    }
+#undef L
+#undef CU
+#undef CV
+}
+
+/* ff_swscale (swscale.c:263-567) for a whole frame */
+static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[],
+                     uint8_t *const dst[], const int dstStride[])
+{
+    const int srcW = c->o.src_w, srcH = c->o.src_h, dstW = c->o.dst_w, dstH = c->o.dst_h;
+    const int df = c->o.dst_format, sf = c->o.src_format;
+    const int should_dither = isNBPS(sf) || is16BPS(sf);
+    Planes P;
+    uint8_t *t0 = malloc((size_t)srcW * 4 + 128), *t1 = malloc((size_t)srcW * 4 + 128);
+    int y;
+
+    P.lum = malloc((size_t)srcH * dstW * sizeof(int32_t));
+    P.chrU = malloc((size_t)c->chrSrcH * c->chrDstW * sizeof(int32_t));
+    P.chrV = malloc((size_t)c->chrSrcH * c->chrDstW * sizeof(int32_t));
+
+    for (y = 0; y < srcH; y++) { /* lum_convert + lum_h_scale, hscale.c:39-131 */
+        const uint8_t *line = read_lum_line(c, src, srcStride, y, t0);
+        int32_t *d = P.lum + (size_t)y * dstW;
+        hscale_line(c, d, dstW, line, c->hLumFilter, c->hLumFilterPos, c->hLumFilterSize);
+        if (c->range_active) range_line(c, d, dstW, 0);
+    }
+    for (y = 0; y < c->chrSrcH; y++) { /* chr_convert + chr_h_scale, hscale.c:168-245 */
+        const uint8_t *pu, *pv;
+        int32_t *du = P.chrU + (size_t)y * c->chrDstW, *dv = P.chrV + (size_t)y * c->chrDstW;
+        read_chr_line(c, src, srcStride, y, t0, t1, &pu, &pv);
+        hscale_line(c, du, c->chrDstW, pu, c->hChrFilter, c->hChrFilterPos, c->hChrFilterSize);
+        hscale_line(c, dv, c->chrDstW, pv, c->hChrFilter, c->hChrFilterPos, c->hChrFilterSize);
+        if (c->range_active) { range_line(c, du, c->chrDstW, 1); range_line(c, dv, c->chrDstW, 1); }
+    }
+
+    for (y = 0; y < dstH; y++) {
+        const int chrDstY = y >> c->chrDstVSub;
+        const uint8_t *lumDither = should_dither ? dither_8x8_128[y & 7] : pb_64;       /* swscale.c:385-387, :519-522 */
+        const uint8_t *chrDither = should_dither ? dither_8x8_128[chrDstY & 7] : pb_64;
+        if (isPlanarYUV(df)) {
+            const Desc *dd = desc_get(df);
+            int firstLum = ORMAX(1 - c->vLumFilterSize, c->vLumFilterPos[y]);
+            write_planar_line(c, dst[0] + (size_t)y * dstStride[0], dstW, P.lum, dstW, srcH, firstLum,
+                              c->vLumFilter + y * c->vLumFilterSize, c->vLumFilterSize, lumDither, 0, 1);
+            if (!(y & ((1 << c->chrDstVSub) - 1))) { /* chr_planar_vscale vscale.c:74-107 */
+                int firstChr = ORMAX(1 - c->vChrFilterSize, c->vChrFilterPos[chrDstY]);
+                const int16_t *cf = c->vChrFilter + chrDstY * c->vChrFilterSize;
+                if (isSemiPlanarYUV(df)) {
+                    write_nv_chroma_line(c, dst[1] + (size_t)chrDstY * dstStride[1], c->chrDstW, P.chrU, P.chrV,
+                                         c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither);
+                } else {
+                    write_planar_line(c, dst[dd->c[1].plane] + (size_t)chrDstY * dstStride[dd->c[1].plane], c->chrDstW, P.chrU,
+                                      c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither, 0, 0);
+                    write_planar_line(c, dst[dd->c[2].plane] + (size_t)chrDstY * dstStride[dd->c[2].plane], c->chrDstW, P.chrV,
+                                      c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither, 3, 0);
+                }
+            }
+        } else if (isAnyRGB(df) && !isPlanarRGB(df)) {
+            write_packed_rgb_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
+        } else {
+            free(P.lum); free(P.chrU); free(P.chrV); free(t0); free(t1);
+            return -1; /* planar RGB writers (yuv2gbrp*_full_X_c): not restated yet */
+        }
+    }
+    free(P.lum); free(P.chrU); free(P.chrV); free(t0); free(t1);
+    return dstH;
+}
+
+int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], int srcSliceY, int srcSliceH,
+                 uint8_t *const dst[4], const int dstStride[4])
+{
+    if (!c || !src || !dst || !srcStride || !dstStride) return -22;
+    if (srcSliceY != 0 || srcSliceH != c->o.src_h) return -22; /* oracle: whole frames only */
+    if (c->cascade[0]) { /* scale_cascaded, swscale.c:992-1018 */
+        uint8_t *tmp[4] = { c->casc_tmp[0], NULL, NULL, NULL };
+        int ret = or_sws_scale(c->cascade[0], src, srcStride, 0, srcSliceH, tmp, c->casc_stride);
+        if (ret < 0) return ret;
+        return or_sws_scale(c->cascade[1], (const uint8_t *const *)tmp, c->casc_stride, 0, c->cascade[0]->o.dst_h, dst, dstStride);
+    }
+    if (c->src0Alpha && !c->dst0Alpha && isALPHA(c->o.dst_format)) return -22; /* rgb0 scratch copy: needAlpha rejected at init */
+    switch (c->unscaled_kind) {
+    case UNSC_YUV2RGB: return unscaled_yuv2rgb(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_P01X: return unscaled_p01x(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_8_P01X: return unscaled_8_p01x(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_PLANAR2NV12: return unscaled_planar2nv12(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_NV122PLANAR: return unscaled_nv122planar(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_PLANARCOPY: return unscaled_planarcopy(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    }
+    return main_path(c, src, srcStride, dst, dstStride);
+}
+
+/* ------------------------------------------------------------------ */
+/* introspection                                                       */
+/* ------------------------------------------------------------------ */
+int or_sws_get_filter(const OrSws *c, int which, const int16_t **filter, const int32_t **pos, int *count)
+{
+    switch (which) {
+    case 0: *filter = c->hLumFilter; *pos = c->hLumFilterPos; *count = c->o.dst_w; return c->hLumFilterSize;
+    case 1: *filter = c->hChrFilter; *pos = c->hChrFilterPos; *count = c->chrDstW; return c->hChrFilterSize;
+    case 2: *filter = c->vLumFilter; *pos = c->vLumFilterPos; *count = c->o.dst_h; return c->vLumFilterSize;
+    case 3: *filter = c->vChrFilter; *pos = c->vChrFilterPos; *count = c->chrDstH; return c->vChrFilterSize;
+    }
+    return 0;
+}
+int or_sws_path(const OrSws *c) { return c->cascade[0] ? 2 : c->unscaled_kind ? 1 : 0; }
+const char *or_sws_path_name(const OrSws *c)
+{
+    static const char *n[] = { "main", "yuv2rgb_c", "planarToP01x", "planar8ToP01xle", "planarToNv12", "nv12ToPlanar", "planarCopy" };
+    return c->cascade[0] ? "cascade" : n[c->unscaled_kind];
+}
+const int32_t *or_sws_rgb2yuv_table(const OrSws *c) { return c->rgb2yuv; }
+void or_sws_yuv2rgb_coeffs(const OrSws *c, int out[6])
+{
+    out[0] = c->yuv2rgb_y_offset; out[1] = c->yuv2rgb_y_coeff; out[2] = c->yuv2rgb_v2r;
+    out[3] = c->yuv2rgb_v2g; out[4] = c->yuv2rgb_u2g; out[5] = c->yuv2rgb_u2b;
+}
+void or_sws_range_consts(const OrSws *c, uint32_t coeff[2], int64_t offset[2], int *active)
+{
+    coeff[0] = c->lumCoeff; coeff[1] = c->chrCoeff; offset[0] = c->lumOffset; offset[1] = c->chrOffset;
+    *active = c->range_active;
+}
+uint32_t or_sws_lut_rgb(const OrSws *c, int Y, int U, int V, int comp)
+{
+    int idx;
+    if (!c->has_lut) return 0;
+    if (comp == 0) idx = c->table_rV[V + HEADROOM];
+    else if (comp == 1) idx = c->table_gU[U + HEADROOM] + c->table_gV[V + HEADROOM];
+    else idx = c->table_bU[U + HEADROOM];
+    return lut_at(c, idx + Y);
+}
+int or_sws_chroma_dims(const OrSws *c, int out[8])
+{
+    out[0] = c->chrSrcW; out[1] = c->chrSrcH; out[2] = c->chrDstW; out[3] = c->chrDstH;
+    out[4] = c->chrSrcHSub; out[5] = c->chrSrcVSub; out[6] = c->chrDstHSub; out[7] = c->chrDstVSub;
+    return 0;
+}

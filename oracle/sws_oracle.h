@@ -1,0 +1,100 @@
+/*
+ * sws_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, scalar) of the librempeg libswscale legacy
+ * scaler / colour-conversion path, used ONLY as the parity checker by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The product
+ * (librempeg_amd/csrc) never links, loads or calls anything in this directory.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * the reference tree).  Pinning status: see oracle/README.md.
+ */
+#ifndef SWS_ORACLE_H
+#define SWS_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* AVPixelFormat numeric values, libavutil/pixfmt.h (enum order) */
+enum {
+    ORF_NONE = -1,
+    ORF_YUV420P = 0, ORF_RGB24 = 2, ORF_BGR24 = 3, ORF_YUV422P = 4, ORF_YUV444P = 5,
+    ORF_GRAY8 = 8, ORF_YUVJ420P = 12, ORF_NV12 = 23, ORF_NV21 = 24,
+    ORF_ARGB = 25, ORF_RGBA = 26, ORF_ABGR = 27, ORF_BGRA = 28,
+    ORF_YUV420P16LE = 45, ORF_YUV444P16LE = 49, ORF_YUV420P10LE = 62,
+    ORF_YUV444P10LE = 68, ORF_GBRP = 71,
+    ORF_0RGB = 118, ORF_RGB0 = 119, ORF_0BGR = 120, ORF_BGR0 = 121,
+    ORF_P010LE = 158, ORF_GBRPF32LE = 175,
+};
+
+/* libswscale/swscale.h:131-208 */
+#define OR_SWS_FAST_BILINEAR (1 << 0)
+#define OR_SWS_BILINEAR      (1 << 1)
+#define OR_SWS_BICUBIC       (1 << 2)
+#define OR_SWS_X             (1 << 3)
+#define OR_SWS_POINT         (1 << 4)
+#define OR_SWS_AREA          (1 << 5)
+#define OR_SWS_BICUBLIN      (1 << 6)
+#define OR_SWS_GAUSS         (1 << 7)
+#define OR_SWS_SINC          (1 << 8)
+#define OR_SWS_LANCZOS       (1 << 9)
+#define OR_SWS_SPLINE        (1 << 10)
+#define OR_SWS_PRINT_INFO    (1 << 12)
+#define OR_SWS_FULL_CHR_H_INT (1 << 13)
+#define OR_SWS_FULL_CHR_H_INP (1 << 14)
+#define OR_SWS_ACCURATE_RND  (1 << 18)
+#define OR_SWS_BITEXACT      (1 << 19)
+#define OR_SWS_PARAM_DEFAULT 123456
+
+typedef struct OrSws OrSws;
+
+/* options block mirroring the public SwsContext fields (swscale.h:227-315) */
+typedef struct OrSwsOpts {
+    int src_w, src_h, src_format;
+    int dst_w, dst_h, dst_format;
+    unsigned flags;
+    double scaler_params[2];
+    int dither;            /* SwsDither: 0 none, 1 auto, 2 bayer, 3 ed ... */
+    int src_range, dst_range;
+    int src_v_chr_pos, src_h_chr_pos, dst_v_chr_pos, dst_h_chr_pos; /* -513 = default */
+} OrSwsOpts;
+
+void   or_sws_default_opts(OrSwsOpts *o);
+/* = sws_getContext(): legacy init, ranges 0, chroma pos -513 (utils.c:1919) */
+OrSws *or_sws_get_context(int srcW, int srcH, int srcFmt, int dstW, int dstH,
+                          int dstFmt, int flags, const double *param);
+/* = sws_alloc_context + set fields + sws_init_context */
+OrSws *or_sws_create(const OrSwsOpts *o);
+/* = sws_setColorspaceDetails (utils.c:849) */
+int    or_sws_set_colorspace(OrSws *c, const int inv_table[4], int srcRange,
+                             const int table[4], int dstRange,
+                             int brightness, int contrast, int saturation);
+const int *or_sws_get_coefficients(int colorspace); /* yuv2rgb.c:61 */
+/* whole-frame sws_scale (srcSliceY must be 0 and srcSliceH == src_h).
+ * returns number of output rows, <0 on error. */
+int    or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4],
+                    int srcSliceY, int srcSliceH,
+                    uint8_t *const dst[4], const int dstStride[4]);
+void   or_sws_free(OrSws *c);
+
+/* ---- introspection for table tests ---- */
+/* which: 0 hLum, 1 hChr, 2 vLum, 3 vChr.  returns filterSize (0 if none) */
+int    or_sws_get_filter(const OrSws *c, int which, const int16_t **filter,
+                         const int32_t **pos, int *count);
+/* path: 0 = main (scaled) path, 1 = unscaled special converter, 2 = cascade */
+int    or_sws_path(const OrSws *c);
+const char *or_sws_path_name(const OrSws *c);
+const int32_t *or_sws_rgb2yuv_table(const OrSws *c);           /* 9 ints RY..BV */
+void   or_sws_yuv2rgb_coeffs(const OrSws *c, int out[6]);      /* y_offset,y_coeff,v2r,v2g,u2g,u2b */
+void   or_sws_range_consts(const OrSws *c, uint32_t coeff[2], int64_t offset[2], int *active);
+/* LUT access as the reference uses it: value at table_X[idx] + Y (bytes for 24bpp, dword for 32bpp) */
+uint32_t or_sws_lut_rgb(const OrSws *c, int Y, int U, int V, int comp /*0 r,1 g,2 b*/);
+int    or_sws_chroma_dims(const OrSws *c, int out[8]); /* chrSrcW,chrSrcH,chrDstW,chrDstH,hsubS,vsubS,hsubD,vsubD */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

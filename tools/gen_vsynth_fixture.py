@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/vsynth1_f0_352x288.yuv420p.bin.
+
+Runs the reference's OWN test-video generator (tests/videogen.c, compiled from its own
+sources by oracle/ref_build.mk into oracle/_ref/videogen) and keeps frame 0 of the
+352x288 yuv420p stream -- the input of fate-sws-yuv-range / fate-sws-yuv-colorspace
+(tests/fate/libswscale.mak) and of fate-filter-pixfmts-* (tests/fate-run.sh pixfmts()).
+Build container only (needs /root/reference)."""
+import os, subprocess, sys, tempfile, zlib
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "-f", "ref_build.mk"])
+with tempfile.TemporaryDirectory() as d:
+    out = os.path.join(d, "vsynth1.yuv")
+    subprocess.check_call([os.path.join(root, "oracle", "_ref", "videogen"), out])
+    data = open(out, "rb").read()
+fsz = 352 * 288 * 3 // 2
+assert len(data) % fsz == 0
+dst = os.path.join(root, "tests", "golden", "vsynth1_f0_352x288.yuv420p.bin.z")
+open(dst, "wb").write(zlib.compress(data[:fsz], 9))
+print("wrote", dst, len(data[:fsz]), "bytes raw")
