@@ -1,0 +1,252 @@
+/*
+ * swscale_hip.h -- C-ABI of libswscale_hip.so, the MI355X-native drop-in for the
+ * librempeg libswscale scaler / colour-conversion hot path.
+ *
+ * Every entry point below replaces the reference symbol of the same name; the
+ * reference declaration it mirrors is cited as (libswscale/swscale.h:LINE) or
+ * (libavutil/...:LINE), paths relative to the reference tree.  Signatures,
+ * argument meaning, return values and error codes follow the reference, so a
+ * caller compiled against the reference's <libswscale/swscale.h> can link
+ * against this library unchanged.  Plain pointers and sizes only -- no torch,
+ * no C++ types.
+ *
+ * Pixel buffers passed to sws_scale() may be HOST pointers (staged to HBM and
+ * back, synchronous, like the reference) or DEVICE (HBM) pointers obtained
+ * from sws_hip_malloc()/hipMalloc()/torch (zero-copy, stream-ordered).
+ */
+#ifndef SWSCALE_HIP_H
+#define SWSCALE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- libavutil/pixfmt.h enum AVPixelFormat (numeric values are ABI) ---- */
+#ifndef AVUTIL_PIXFMT_H
+enum AVPixelFormat {
+    AV_PIX_FMT_NONE = -1,
+    AV_PIX_FMT_YUV420P = 0,
+    AV_PIX_FMT_RGB24 = 2,
+    AV_PIX_FMT_BGR24 = 3,
+    AV_PIX_FMT_YUV422P = 4,
+    AV_PIX_FMT_YUV444P = 5,
+    AV_PIX_FMT_GRAY8 = 8,
+    AV_PIX_FMT_YUVJ420P = 12,
+    AV_PIX_FMT_NV12 = 23,
+    AV_PIX_FMT_NV21 = 24,
+    AV_PIX_FMT_ARGB = 25,
+    AV_PIX_FMT_RGBA = 26,
+    AV_PIX_FMT_ABGR = 27,
+    AV_PIX_FMT_BGRA = 28,
+    AV_PIX_FMT_YUV420P16LE = 45,
+    AV_PIX_FMT_YUV444P16LE = 49,
+    AV_PIX_FMT_YUV420P10LE = 62,
+    AV_PIX_FMT_YUV444P10LE = 68,
+    AV_PIX_FMT_GBRP = 71,
+    AV_PIX_FMT_0RGB = 118,
+    AV_PIX_FMT_RGB0 = 119,
+    AV_PIX_FMT_0BGR = 120,
+    AV_PIX_FMT_BGR0 = 121,
+    AV_PIX_FMT_P010LE = 158,
+    AV_PIX_FMT_GBRPF32LE = 175,
+    /* NEW: hardware surface format of the HIP hwcontext slot; appended after the
+     * reference's last format (AV_PIX_FMT_NB == 268, libavutil/pixfmt.h) */
+    AV_PIX_FMT_HIP = 268,
+};
+#endif
+
+/* ---- libavutil/hwcontext.h:27-44 enum AVHWDeviceType: the new slot is appended
+ *      after AV_HWDEVICE_TYPE_OHCODEC ---- */
+#define AV_HWDEVICE_TYPE_HIP 15
+
+/* ---- libavutil/error.h ---- */
+#define SWS_AVERROR(e) (-(e))
+
+/* ---- flags (libswscale/swscale.h:131-208) ---- */
+#define SWS_FAST_BILINEAR (1 << 0)
+#define SWS_BILINEAR      (1 << 1)
+#define SWS_BICUBIC       (1 << 2)
+#define SWS_X             (1 << 3)
+#define SWS_POINT         (1 << 4)
+#define SWS_AREA          (1 << 5)
+#define SWS_BICUBLIN      (1 << 6)
+#define SWS_GAUSS         (1 << 7)
+#define SWS_SINC          (1 << 8)
+#define SWS_LANCZOS       (1 << 9)
+#define SWS_SPLINE        (1 << 10)
+#define SWS_STRICT        (1 << 11)
+#define SWS_PRINT_INFO    (1 << 12)
+#define SWS_FULL_CHR_H_INT (1 << 13)
+#define SWS_FULL_CHR_H_INP (1 << 14)
+#define SWS_DIRECT_BGR    (1 << 15)
+#define SWS_ACCURATE_RND  (1 << 18)
+#define SWS_BITEXACT      (1 << 19)
+#define SWS_UNSTABLE      (1 << 20)
+#define SWS_ERROR_DIFFUSION (1 << 23)
+
+#define SWS_SRC_V_CHR_DROP_MASK  0x30000   /* swscale.h:453 */
+#define SWS_SRC_V_CHR_DROP_SHIFT 16
+#define SWS_PARAM_DEFAULT 123456           /* swscale.h:456 */
+#define SWS_MAX_REDUCE_CUTOFF 0.002        /* swscale.h:447 */
+
+#define SWS_CS_ITU709    1                 /* swscale.h:458-465 */
+#define SWS_CS_FCC       4
+#define SWS_CS_ITU601    5
+#define SWS_CS_ITU624    5
+#define SWS_CS_SMPTE170M 5
+#define SWS_CS_SMPTE240M 7
+#define SWS_CS_DEFAULT   5
+#define SWS_CS_BT2020    9
+
+typedef enum SwsDither {                    /* swscale.h:77-86 */
+    SWS_DITHER_NONE = 0, SWS_DITHER_AUTO, SWS_DITHER_BAYER, SWS_DITHER_ED,
+    SWS_DITHER_A_DITHER, SWS_DITHER_X_DITHER, SWS_DITHER_NB,
+    SWS_DITHER_MAX_ENUM = 0x7FFFFFFF,
+} SwsDither;
+
+typedef enum SwsAlphaBlend {                /* swscale.h:88-94 */
+    SWS_ALPHA_BLEND_NONE = 0, SWS_ALPHA_BLEND_UNIFORM, SWS_ALPHA_BLEND_CHECKERBOARD,
+    SWS_ALPHA_BLEND_NB, SWS_ALPHA_BLEND_MAX_ENUM = 0x7FFFFFFF,
+} SwsAlphaBlend;
+
+typedef enum SwsScaler {                    /* swscale.h:96-108 */
+    SWS_SCALE_AUTO = 0, SWS_SCALE_BILINEAR, SWS_SCALE_BICUBIC, SWS_SCALE_POINT, SWS_SCALE_AREA,
+    SWS_SCALE_GAUSSIAN, SWS_SCALE_SINC, SWS_SCALE_LANCZOS, SWS_SCALE_SPLINE, SWS_SCALE_NB,
+    SWS_SCALE_MAX_ENUM = 0x7FFFFFFF,
+} SwsScaler;
+
+typedef enum SwsBackend {                   /* swscale.h:110-128 + NEW HIP bit */
+    SWS_BACKEND_LEGACY = (1 << 0),
+    SWS_BACKEND_HIP    = (1 << 8),          /* NEW: this library */
+    SWS_BACKEND_MAX_ENUM = 0x7FFFFFFF,
+} SwsBackend;
+
+/* Main external API structure (libswscale/swscale.h:227-315): identical field
+ * order and types, so code that pokes the public fields keeps working. */
+typedef struct SwsContext {
+    const void *av_class;
+    void *opaque;
+    unsigned flags;
+#define SWS_NUM_SCALER_PARAMS 2
+    double scaler_params[SWS_NUM_SCALER_PARAMS];
+    int threads;
+    SwsDither dither;
+    SwsAlphaBlend alpha_blend;
+    int gamma_flag;
+    int src_w, src_h;
+    int dst_w, dst_h;
+    int src_format;
+    int dst_format;
+    int src_range;
+    int dst_range;
+    int src_v_chr_pos;
+    int src_h_chr_pos;
+    int dst_v_chr_pos;
+    int dst_h_chr_pos;
+    int intent;
+    SwsScaler scaler;
+    SwsScaler scaler_sub;
+    SwsBackend backends;
+} SwsContext;
+
+typedef struct SwsVector { double *coeff; int length; } SwsVector;           /* swscale.h:478-481 */
+typedef struct SwsFilter { SwsVector *lumH, *lumV, *chrH, *chrV; } SwsFilter; /* swscale.h:484-489 */
+
+/* ---- version (swscale.h:50-63, version.h) ---- */
+unsigned    swscale_version(void);
+const char *swscale_configuration(void);
+const char *swscale_license(void);
+
+/* ---- context management ---- */
+SwsContext *sws_alloc_context(void);                                   /* swscale.h:320 */
+void        sws_free_context(SwsContext **ctx);                        /* swscale.h:326 */
+int         sws_init_context(SwsContext *c, SwsFilter *srcFilter, SwsFilter *dstFilter); /* swscale.h:522 */
+void        sws_freeContext(SwsContext *c);                            /* swscale.h:528 */
+SwsContext *sws_getContext(int srcW, int srcH, enum AVPixelFormat srcFormat,
+                           int dstW, int dstH, enum AVPixelFormat dstFormat,
+                           int flags, SwsFilter *srcFilter, SwsFilter *dstFilter,
+                           const double *param);                       /* swscale.h:551 */
+SwsContext *sws_getCachedContext(SwsContext *context, int srcW, int srcH, enum AVPixelFormat srcFormat,
+                                 int dstW, int dstH, enum AVPixelFormat dstFormat, int flags,
+                                 SwsFilter *srcFilter, SwsFilter *dstFilter, const double *param); /* swscale.h:737 */
+
+int sws_isSupportedInput(enum AVPixelFormat pix_fmt);                  /* swscale.h:495 */
+int sws_isSupportedOutput(enum AVPixelFormat pix_fmt);                 /* swscale.h:501 */
+int sws_isSupportedEndiannessConversion(enum AVPixelFormat pix_fmt);   /* swscale.h:508 */
+
+/* ---- colourspace ---- */
+const int *sws_getCoefficients(int colorspace);                        /* swscale.h:474 */
+int sws_setColorspaceDetails(SwsContext *c, const int inv_table[4], int srcRange,
+                             const int table[4], int dstRange,
+                             int brightness, int contrast, int saturation); /* swscale.h:684 */
+int sws_getColorspaceDetails(SwsContext *c, int **inv_table, int *srcRange, int **table,
+                             int *dstRange, int *brightness, int *contrast, int *saturation); /* swscale.h:692 */
+
+/* ---- the hot path ---- */
+/* swscale.h:583.  Returns the number of output rows written (>= 0) or a negative
+ * AVERROR: EINVAL for NULL arguments / bad slice geometry / bad plane pointers
+ * (libswscale/swscale.c:1041-1070), ENOSYS-style AVERROR(ENOTSUP) for slice-wise
+ * calls on the scaled path (round-1 limitation), AVERROR_EXTERNAL for
+ * HIP failures. */
+int sws_scale(SwsContext *c, const uint8_t *const srcSlice[], const int srcStride[],
+              int srcSliceY, int srcSliceH, uint8_t *const dst[], const int dstStride[]);
+
+/* Prefix of libavutil/frame.h:472-559 struct AVFrame (data, linesize,
+ * extended_data, width, height, nb_samples, format): a real AVFrame* may be
+ * passed wherever SwsFrameView* is expected. */
+typedef struct SwsFrameView {
+    uint8_t *data[8];
+    int linesize[8];
+    uint8_t **extended_data;
+    int width, height;
+    int nb_samples;
+    int format;
+} SwsFrameView;
+
+/* swscale.h:439 (legacy-initialised contexts only: frame props must match the context) */
+int sws_scale_frame(SwsContext *c, SwsFrameView *dst, const SwsFrameView *src);
+
+/* NEW: nb_frames independent sws_scale_frame() calls with identical
+ * results, executed as ONE batched launch per kernel on this context's GPU/stream.
+ * Frames must be HBM-resident for the zero-copy path; host frames are staged.
+ * Returns nb_frames on success or a negative AVERROR. */
+int sws_scale_frames(SwsContext *c, SwsFrameView *const dst[], const SwsFrameView *const src[], int nb_frames);
+
+/* ---- HIP device plumbing (the AV_HWDEVICE_TYPE_HIP slot; shape of
+ *      libavutil/hwcontext_internal.h:29-99 HWContextType, model
+ *      libavutil/hwcontext_cuda.c:132-197, :523-655) ---- */
+int   sws_hip_device_count(void);
+int   sws_hip_set_device(SwsContext *c, int device);       /* device_create/derive */
+int   sws_hip_set_stream(SwsContext *c, void *hip_stream); /* use caller's hipStream_t (NULL = context-owned) */
+void *sws_hip_get_stream(SwsContext *c);
+int   sws_hip_sync(SwsContext *c);
+/* frames_get_buffer: one linear HBM allocation per frame, planes at 256-byte aligned
+ * offsets, linesize aligned to 256 bytes (hwcontext_cuda.c:132-197 analogue). */
+int   sws_hip_frame_alloc(SwsFrameView *f, int format, int width, int height, int device);
+void  sws_hip_frame_free(SwsFrameView *f);
+/* transfer_data_to / transfer_data_from: per-plane 2-D async copies on the stream */
+int   sws_hip_frame_upload(SwsContext *c, SwsFrameView *dev, const SwsFrameView *host);
+int   sws_hip_frame_download(SwsContext *c, SwsFrameView *host, const SwsFrameView *dev);
+int   sws_hip_image_layout(int format, int width, int height, int align, int linesize[4], size_t offset[4], size_t *total);
+
+/* ---- table blob: what rank 0 broadcasts to the other GPUs (RCCL) once per context.
+ *      export on the rank that ran the host-side init, import on the others. ---- */
+size_t sws_hip_tables_size(const SwsContext *c);
+int    sws_hip_tables_export(const SwsContext *c, void *buf, size_t size);
+int    sws_hip_tables_import(SwsContext *c, const void *buf, size_t size);
+
+/* ---- introspection used by tests and the bench ---- */
+const char *sws_hip_path_name(const SwsContext *c);   /* e.g. "unscaled:yuv2rgb", "fused:rgb_lut", "generic:hv" */
+const char *sws_hip_kernel_name(const SwsContext *c); /* dominant kernel symbol for rocprof matching */
+int    sws_hip_get_filter(const SwsContext *c, int which, const int16_t **filter, const int32_t **pos, int *count);
+int    sws_hip_get_tables(const SwsContext *c, int32_t rgb2yuv[9], int yuv2rgb[6], uint32_t range_coeff[2], int64_t range_offset[2]);
+double sws_hip_last_kernel_ms(SwsContext *c);         /* HIP-event time of the last timed launch (see below) */
+int    sws_hip_set_timing(SwsContext *c, int enable); /* record hipEvents around each launch on the context's stream */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWSCALE_HIP_H */

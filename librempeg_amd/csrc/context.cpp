@@ -1,0 +1,539 @@
+// Context construction: the host-side (cold) half of the drop-in.  Restates the decisions of
+// libswscale/utils.c (sws_alloc_context :1032, sws_init_context :1884, ff_sws_init_single_context
+// :1137-1835, sws_setColorspaceDetails :849-1005, sws_getContext :1919, sws_freeContext :2250) and
+// of ff_get_unscaled_swscale (libswscale/swscale_unscaled.c:2392-2706) for the formats on the hot
+// path, and turns them into an execution plan for the HIP kernels.
+#include <cerrno>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "swsint.hpp"
+
+namespace swship {
+
+static const uint32_t kMagic = 0x53574850; // 'SWHP'
+
+void log_msg(const SwsInternal *c, int level, const char *fmt, ...)
+{
+    // level: 0 error, 1 warning, 2 info (only with SWS_PRINT_INFO), 3 debug (env SWS_HIP_DEBUG)
+    static const int debug = std::getenv("SWS_HIP_DEBUG") ? std::atoi(std::getenv("SWS_HIP_DEBUG")) : 0;
+    if (level == 2 && !(c && (c->opts.flags & SWS_PRINT_INFO)) && !debug) return;
+    if (level >= 3 && !debug) return;
+    std::va_list ap;
+    va_start(ap, fmt);
+    std::fprintf(stderr, "[swscaler-hip @ %p] ", (const void *)c);
+    std::vfprintf(stderr, fmt, ap);
+    va_end(ap);
+}
+
+static int ceil_rshift(int a, int b) { return -((-a) >> b); }
+
+static int zero_alpha_alias(int *format) // handle_0alpha, utils.c:811-820
+{
+    switch (*format) {
+    case AV_PIX_FMT_0BGR: *format = AV_PIX_FMT_ABGR; return 1;
+    case AV_PIX_FMT_BGR0: *format = AV_PIX_FMT_BGRA; return 4;
+    case AV_PIX_FMT_0RGB: *format = AV_PIX_FMT_ARGB; return 1;
+    case AV_PIX_FMT_RGB0: *format = AV_PIX_FMT_RGBA; return 4;
+    }
+    return 0;
+}
+
+static void canonicalise_formats(SwsInternal *c) // handle_formats, utils.c:833-842 (no XYZ)
+{
+    c->src0Alpha |= zero_alpha_alias(&c->opts.src_format);
+    c->dst0Alpha |= zero_alpha_alias(&c->opts.dst_format);
+}
+
+static int jpeg_alias(int *format) // handle_jpeg, utils.c:773-809
+{
+    if (*format == AV_PIX_FMT_YUVJ420P) { *format = AV_PIX_FMT_YUV420P; return 1; }
+    if (*format == AV_PIX_FMT_GRAY8) return 1;
+    return 0;
+}
+
+static int local_pos(int chr_subsample, int pos) // get_local_pos, utils.c:168-175
+{
+    if (pos == -1 || pos <= -513) pos = (128 << chr_subsample) - 128;
+    pos += 128;
+    return pos >> chr_subsample;
+}
+
+static int scaler_from_enum(SwsScaler s, int fallback) // scaler_flag, utils.c:1121-1135
+{
+    switch (s) {
+    case SWS_SCALE_BILINEAR: return SWS_BILINEAR;
+    case SWS_SCALE_BICUBIC:  return SWS_BICUBIC;
+    case SWS_SCALE_POINT:    return SWS_POINT;
+    case SWS_SCALE_AREA:     return SWS_AREA;
+    case SWS_SCALE_GAUSSIAN: return SWS_GAUSS;
+    case SWS_SCALE_SINC:     return SWS_SINC;
+    case SWS_SCALE_LANCZOS:  return SWS_LANCZOS;
+    case SWS_SCALE_SPLINE:   return SWS_SPLINE;
+    default: return fallback;
+    }
+}
+
+static bool fmt_supported_in(int f)
+{
+    switch (f) {
+    case AV_PIX_FMT_YUV420P: case AV_PIX_FMT_YUVJ420P: case AV_PIX_FMT_YUV422P: case AV_PIX_FMT_YUV444P:
+    case AV_PIX_FMT_NV12: case AV_PIX_FMT_NV21:
+    case AV_PIX_FMT_YUV420P10LE: case AV_PIX_FMT_YUV444P10LE: case AV_PIX_FMT_YUV420P16LE: case AV_PIX_FMT_YUV444P16LE:
+    case AV_PIX_FMT_P010LE:
+    case AV_PIX_FMT_RGB24: case AV_PIX_FMT_BGR24:
+    case AV_PIX_FMT_RGBA: case AV_PIX_FMT_BGRA: case AV_PIX_FMT_ARGB: case AV_PIX_FMT_ABGR:
+    case AV_PIX_FMT_RGB0: case AV_PIX_FMT_BGR0: case AV_PIX_FMT_0RGB: case AV_PIX_FMT_0BGR:
+    case AV_PIX_FMT_GBRP: case AV_PIX_FMT_GBRPF32LE:
+        return true;
+    }
+    return false;
+}
+static bool fmt_supported_out(int f)
+{
+    switch (f) {
+    case AV_PIX_FMT_YUV420P: case AV_PIX_FMT_YUVJ420P: case AV_PIX_FMT_YUV422P: case AV_PIX_FMT_YUV444P:
+    case AV_PIX_FMT_NV12: case AV_PIX_FMT_NV21:
+    case AV_PIX_FMT_YUV420P10LE: case AV_PIX_FMT_YUV444P10LE: case AV_PIX_FMT_YUV420P16LE: case AV_PIX_FMT_YUV444P16LE:
+    case AV_PIX_FMT_P010LE:
+    case AV_PIX_FMT_RGB24: case AV_PIX_FMT_BGR24:
+    case AV_PIX_FMT_RGBA: case AV_PIX_FMT_BGRA: case AV_PIX_FMT_ARGB: case AV_PIX_FMT_ABGR:
+    case AV_PIX_FMT_RGB0: case AV_PIX_FMT_BGR0: case AV_PIX_FMT_0RGB: case AV_PIX_FMT_0BGR:
+        return true;
+    }
+    return false;
+}
+
+// ff_get_unscaled_swscale (swscale_unscaled.c:2392-2706): "last match wins"
+void choose_unscaled(SwsInternal *c)
+{
+    const int s = c->opts.src_format, d = c->opts.dst_format;
+    const unsigned flags = c->opts.flags;
+    PlanKind k = PLAN_NONE;
+    bool unsupported = false;
+    if (s == AV_PIX_FMT_YUV420P && (d == AV_PIX_FMT_NV12 || d == AV_PIX_FMT_NV21)) k = PLAN_UNSC_PLANAR2NV12; // :2405
+    if (d == AV_PIX_FMT_YUV420P && (s == AV_PIX_FMT_NV12 || s == AV_PIX_FMT_NV21)) k = PLAN_UNSC_NV122PLANAR; // :2415
+    if ((s == AV_PIX_FMT_YUV420P || s == AV_PIX_FMT_YUV422P) && isAnyRGB(d) && !(flags & SWS_ACCURATE_RND) &&
+        (c->opts.dither == SWS_DITHER_BAYER || c->opts.dither == SWS_DITHER_AUTO) && !(c->opts.dst_h & 1)) { // :2425-2431
+        k = PLAN_UNSC_YUV2RGB;
+        c->dst_slice_align = 2;
+    }
+    if ((s == AV_PIX_FMT_YUV420P10LE || s == AV_PIX_FMT_YUV420P16LE) && d == AV_PIX_FMT_P010LE) k = PLAN_UNSC_P01X;   // :2432-2439
+    if (s == AV_PIX_FMT_YUV420P && d == AV_PIX_FMT_P010LE) k = PLAN_UNSC_8_P01X;                                      // :2440-2444
+    if (isAnyRGB(s) && isAnyRGB(d) && !isPlanarRGB(s) && !isPlanarRGB(d) && s != d) unsupported = true; // rgbToRgbWrapper (:2461)
+    if (s == AV_PIX_FMT_GBRP && isAnyRGB(d) && !isPlanarRGB(d)) unsupported = true;                     // planarRgbToRgbWrapper (:2482)
+    if (s == d ||
+        (isFloatFmt(s) == isFloatFmt(d) && isPlanarYUV(s) && isPlanarYUV(d) &&
+         c->chrDstHSubSample == c->chrSrcHSubSample && c->chrDstVSubSample == c->chrSrcVSubSample &&
+         isSemiPlanarYUV(s) == isSemiPlanarYUV(d) && isSwappedChroma(s) == isSwappedChroma(d))) { // :2647-2668
+        if (isPackedFmt(s)) unsupported = true; // packedCopyWrapper
+        else { k = PLAN_UNSC_PLANARCOPY; unsupported = false;
+               if (c->opts.dither != SWS_DITHER_NONE) c->dst_slice_align = 8 << c->chrDstVSubSample; }
+    }
+    c->plan = unsupported ? PLAN_NONE : k;
+    if (unsupported) c->plan = (PlanKind)-1;
+}
+
+// ff_sws_init_single_context, utils.c:1137-1835
+int init_single_context(SwsInternal *c)
+{
+    SwsContext *o = &c->opts;
+    const int srcW = o->src_w, srcH = o->src_h, dstW = o->dst_w, dstH = o->dst_h;
+    unsigned flags = o->flags;
+    const bool unscaled = srcW == dstW && srcH == dstH;
+
+    if (!c->contrast && !c->saturation && !c->dstFormatBpp)   // :1164-1167
+        sws_setColorspaceDetails(o, yuv2rgb_coeffs(SWS_CS_DEFAULT), o->src_range,
+                                 yuv2rgb_coeffs(SWS_CS_DEFAULT), o->dst_range, 0, 1 << 16, 1 << 16);
+    canonicalise_formats(c);
+    const int srcFormat = o->src_format, dstFormat = o->dst_format;
+    const PixDesc *ds = pix_desc(srcFormat), *dd = pix_desc(dstFormat);
+    if (!ds || !fmt_supported_in(srcFormat)) {
+        log_msg(c, 0, "pixel format %d is not supported as input pixel format\n", srcFormat);
+        return SWS_AVERROR(EINVAL);
+    }
+    if (!dd || !fmt_supported_out(dstFormat)) {
+        log_msg(c, 0, "pixel format %d is not supported as output pixel format\n", dstFormat);
+        return SWS_AVERROR(EINVAL);
+    }
+
+    int alg = flags & (SWS_POINT | SWS_AREA | SWS_BILINEAR | SWS_FAST_BILINEAR | SWS_BICUBIC | SWS_X | SWS_GAUSS |
+                       SWS_LANCZOS | SWS_SINC | SWS_SPLINE | SWS_BICUBLIN);
+    if (!alg) { alg = SWS_BICUBIC; flags |= alg; o->flags = flags; }           // :1210-1219
+    else if (alg & (alg - 1)) {
+        log_msg(c, 0, "Exactly one scaler algorithm must be chosen, got %X\n", alg);
+        return SWS_AVERROR(EINVAL);
+    }
+    if (alg == SWS_FAST_BILINEAR) {                                             // :1226-1232
+        if (srcW < 8 || dstW <= 8) { alg = SWS_BILINEAR; flags ^= SWS_FAST_BILINEAR | alg; o->flags = flags; }
+        else if (!unscaled) {
+            log_msg(c, 0, "SWS_FAST_BILINEAR horizontal scaler is not implemented on the HIP path\n");
+            return SWS_AVERROR(ENOTSUP);
+        }
+    }
+    const SwsScaler sub = o->scaler_sub ? o->scaler_sub : o->scaler;
+    const int lum_scaler = scaler_from_enum(o->scaler, alg == SWS_BICUBLIN ? SWS_BICUBIC : alg);
+    const int chr_scaler = scaler_from_enum(sub, alg == SWS_BICUBLIN ? SWS_BILINEAR : alg);
+
+    if (srcW < 1 || srcH < 1 || dstW < 1 || dstH < 1) {
+        log_msg(c, 0, "%dx%d -> %dx%d is invalid scaling dimension\n", srcW, srcH, dstW, dstH);
+        return SWS_AVERROR(EINVAL);
+    }
+
+    const int64_t lumXInc = (((int64_t)srcW << 16) + (dstW >> 1)) / dstW;     // :1250-1251
+    const int64_t lumYInc = (((int64_t)srcH << 16) + (dstH >> 1)) / dstH;
+    c->dstFormatBpp = pix_bits_per_pixel(dd);
+    c->srcFormatBpp = pix_bits_per_pixel(ds);
+    c->chrSrcHSubSample = ds->log2_chroma_w; c->chrSrcVSubSample = ds->log2_chroma_h;
+    c->chrDstHSubSample = dd->log2_chroma_w; c->chrDstVSubSample = dd->log2_chroma_h;
+    c->dst_slice_align = 1 << c->chrDstVSubSample;
+
+    if (isAnyRGB(dstFormat) && !(flags & SWS_FULL_CHR_H_INT)) {                 // :1270-1286
+        if (dstW & 1) { flags |= SWS_FULL_CHR_H_INT; o->flags = flags; }
+        if (c->chrSrcHSubSample == 0 && c->chrSrcVSubSample == 0 && o->dither != SWS_DITHER_BAYER &&
+            !(o->flags & SWS_FAST_BILINEAR)) { flags |= SWS_FULL_CHR_H_INT; o->flags = flags; }
+    }
+    if (o->dither == SWS_DITHER_AUTO && (flags & SWS_ERROR_DIFFUSION)) o->dither = SWS_DITHER_ED; // :1288-1291
+    if (isPlanarRGB(dstFormat) && !(flags & SWS_FULL_CHR_H_INT)) { flags |= SWS_FULL_CHR_H_INT; o->flags = flags; }
+    if (isAnyRGB(dstFormat) && !(flags & SWS_FULL_CHR_H_INT)) c->chrDstHSubSample = 1;         // :1359-1360
+
+    if (flags & SWS_SRC_V_CHR_DROP_MASK) {
+        log_msg(c, 0, "SWS_SRC_V_CHR_DROP is not implemented on the HIP path\n");
+        return SWS_AVERROR(ENOTSUP);
+    }
+    // RGB sources: chroma is taken from horizontally averaged pixel pairs unless full chroma input
+    // is requested (:1369-1390; planar float/high-depth RGB are exempt)
+    if (isAnyRGB(srcFormat) && !(srcW & 1) && !(flags & SWS_FULL_CHR_H_INP) && srcFormat != AV_PIX_FMT_GBRPF32LE &&
+        ((dstW >> c->chrDstHSubSample) <= (srcW >> 1) || (flags & SWS_FAST_BILINEAR)))
+        c->chrSrcHSubSample = 1;
+
+    c->chrSrcW = ceil_rshift(srcW, c->chrSrcHSubSample);                        // :1393-1396
+    c->chrSrcH = ceil_rshift(srcH, c->chrSrcVSubSample);
+    c->chrDstW = ceil_rshift(dstW, c->chrDstHSubSample);
+    c->chrDstH = ceil_rshift(dstH, c->chrDstVSubSample);
+
+    c->srcBpc = std::max(ds->comp[0].depth, 8);                                 // :1401-1410
+    c->dstBpc = std::max(dd->comp[0].depth, 8);
+    if (isAnyRGB(srcFormat)) c->srcBpc = 16;
+
+    const int64_t chrXInc = (((int64_t)c->chrSrcW << 16) + (c->chrDstW >> 1)) / c->chrDstW; // :1428-1429
+    const int64_t chrYInc = (((int64_t)c->chrSrcH << 16) + (c->chrDstH >> 1)) / c->chrDstH;
+    if (chrXInc < 10 || chrXInc > INT32_MAX || chrYInc < 10 || chrYInc > INT32_MAX ||
+        lumXInc < 10 || lumXInc > INT32_MAX || lumYInc < 10 || lumYInc > INT32_MAX)
+        return -0x45574150; // AVERROR_PATCHWELCOME (:1449-1453)
+    c->lumXInc = (int)lumXInc; c->lumYInc = (int)lumYInc; c->chrXInc = (int)chrXInc; c->chrYInc = (int)chrYInc;
+
+    if (o->gamma_flag && !unscaled) {
+        log_msg(c, 0, "gamma-correct scaling cascade is not implemented on the HIP path\n");
+        return SWS_AVERROR(ENOTSUP);
+    }
+    c->needAlpha = isALPHA(srcFormat) && isALPHA(dstFormat);                    // :1746
+    if (c->needAlpha) {
+        log_msg(c, 0, "alpha-plane scaling (%s -> %s) is not implemented on the HIP path\n", ds->name, dd->name);
+        return SWS_AVERROR(ENOTSUP);
+    }
+
+    c->plan = PLAN_NONE;
+    if (unscaled && (o->src_range == o->dst_range || isAnyRGB(dstFormat) || isFloatFmt(srcFormat) || isFloatFmt(dstFormat))) { // :1623-1637
+        choose_unscaled(c);
+        if ((int)c->plan == -1) {
+            log_msg(c, 0, "unscaled %s -> %s special converter is not implemented on the HIP path\n", ds->name, dd->name);
+            c->plan = PLAN_NONE;
+            return SWS_AVERROR(ENOTSUP);
+        }
+        if (c->plan != PLAN_NONE) {
+            log_msg(c, 2, "using unscaled %s -> %s special converter\n", ds->name, dd->name);
+            return 0;
+        }
+    }
+
+    // filters; filterAlign is 1 in the reference's C path (:1675-1735)
+    const int hp = local_pos(0, 0);
+    int ret = build_filter_bank(c->hLum, c->lumXInc, srcW, dstW, 1, 1 << 14, lum_scaler, flags, o->scaler_params, hp, hp);
+    if (ret == FILTER_OK)
+        ret = build_filter_bank(c->hChr, c->chrXInc, c->chrSrcW, c->chrDstW, 1, 1 << 14, chr_scaler, flags, o->scaler_params,
+                                local_pos(c->chrSrcHSubSample, o->src_h_chr_pos), local_pos(c->chrDstHSubSample, o->dst_h_chr_pos));
+    if (ret == FILTER_OK)
+        ret = build_filter_bank(c->vLum, c->lumYInc, srcH, dstH, 1, 1 << 12, lum_scaler, flags, o->scaler_params, hp, hp);
+    if (ret == FILTER_OK)
+        ret = build_filter_bank(c->vChr, c->chrYInc, c->chrSrcH, c->chrDstH, 1, 1 << 12, chr_scaler, flags, o->scaler_params,
+                                local_pos(c->chrSrcVSubSample, o->src_v_chr_pos), local_pos(c->chrDstVSubSample, o->dst_v_chr_pos));
+    if (ret == FILTER_USE_CASCADE) {
+        log_msg(c, 0, "extreme scaling ratio needs the two-step cascade (utils.c:1803-1833): not implemented on the HIP path\n");
+        return SWS_AVERROR(ENOTSUP);
+    }
+    if (ret != FILTER_OK) return SWS_AVERROR(EINVAL);
+
+    build_range_conv(c->range, o->src_range, o->dst_range, dstFormat, c->dstBpc); // sws_init_swscale, swscale.c:662-695
+    c->plan = PLAN_MAIN;
+    {
+        const char *name = "?";
+        switch (alg) { case SWS_BICUBIC: name = "bicubic"; break; case SWS_BILINEAR: name = "bilinear"; break;
+                       case SWS_LANCZOS: name = "Lanczos"; break; case SWS_POINT: name = "nearest neighbor / point"; break;
+                       case SWS_AREA: name = "area averaging"; break; case SWS_GAUSS: name = "Gaussian"; break;
+                       case SWS_SINC: name = "sinc"; break; case SWS_SPLINE: name = "bicubic spline"; break;
+                       case SWS_BICUBLIN: name = "luma bicubic / chroma bilinear"; break; case SWS_X: name = "experimental"; break; }
+        log_msg(c, 2, "%s scaler, from %s to %s using HIP (gfx950)\n", name, ds->name, dd->name);
+        log_msg(c, 3, "lum srcW=%d srcH=%d dstW=%d dstH=%d xInc=%d yInc=%d fs h=%d v=%d\n", srcW, srcH, dstW, dstH,
+                c->lumXInc, c->lumYInc, c->hLum.size, c->vLum.size);
+        log_msg(c, 3, "chr srcW=%d srcH=%d dstW=%d dstH=%d xInc=%d yInc=%d fs h=%d v=%d\n", c->chrSrcW, c->chrSrcH,
+                c->chrDstW, c->chrDstH, c->chrXInc, c->chrYInc, c->hChr.size, c->vChr.size);
+    }
+    return 0;
+}
+
+static SwsInternal *new_context()
+{
+    SwsInternal *c = new (std::nothrow) SwsInternal();
+    if (!c) return nullptr;
+    std::memset(&c->opts, 0, sizeof(c->opts));
+    c->magic = kMagic;
+    // defaults of the AVOption table, libswscale/options.c:34-122
+    c->opts.flags = SWS_BICUBIC;
+    c->opts.scaler_params[0] = c->opts.scaler_params[1] = SWS_PARAM_DEFAULT;
+    c->opts.threads = 1;
+    c->opts.dither = SWS_DITHER_AUTO;
+    c->opts.src_format = c->opts.dst_format = AV_PIX_FMT_NONE;
+    c->opts.src_v_chr_pos = c->opts.src_h_chr_pos = c->opts.dst_v_chr_pos = c->opts.dst_h_chr_pos = -513;
+    return c;
+}
+
+static void destroy(SwsInternal *c)
+{
+    if (!c) return;
+    destroy(c->cascade[0]);
+    destroy(c->cascade[1]);
+    dev_release(c);
+    c->magic = 0;
+    delete c;
+}
+
+static SwsInternal *alloc_set_opts(int srcW, int srcH, int srcFormat, int dstW, int dstH, int dstFormat,
+                                   unsigned flags, const double *param) // utils.c:75-95
+{
+    SwsInternal *c = new_context();
+    if (!c) return nullptr;
+    c->opts.flags = flags;
+    c->opts.src_w = srcW; c->opts.src_h = srcH; c->opts.dst_w = dstW; c->opts.dst_h = dstH;
+    c->opts.src_format = srcFormat; c->opts.dst_format = dstFormat;
+    if (param) { c->opts.scaler_params[0] = param[0]; c->opts.scaler_params[1] = param[1]; }
+    return c;
+}
+
+static int init_context_impl(SwsInternal *c, SwsFilter *srcFilter, SwsFilter *dstFilter)
+{
+    auto has_taps = [](const SwsFilter *f) {
+        return f && ((f->lumH && f->lumH->length > 1) || (f->lumV && f->lumV->length > 1) ||
+                     (f->chrH && f->chrH->length > 1) || (f->chrV && f->chrV->length > 1));
+    };
+    if (has_taps(srcFilter) || has_taps(dstFilter)) {
+        log_msg(c, 0, "SwsFilter pre/post convolution vectors are not implemented on the HIP path\n");
+        return SWS_AVERROR(ENOTSUP);
+    }
+    c->legacy_init = true;                                   // utils.c:1892
+    c->opts.src_range |= jpeg_alias(&c->opts.src_format);    // :1903-1904
+    c->opts.dst_range |= jpeg_alias(&c->opts.dst_format);
+    int ret = init_single_context(c);
+    if (ret < 0) return ret;
+    c->tables_dirty = true;
+    return 0;
+}
+
+} // namespace swship
+
+using namespace swship;
+
+extern "C" {
+
+unsigned swscale_version(void) { return (10u << 16) | (2u << 8) | 100u; } // libswscale/version.h:31-36
+const char *swscale_configuration(void) { return "hip gfx950 (librempeg_amd)"; }
+const char *swscale_license(void) { return "LGPL version 2.1 or later"; }
+
+SwsContext *sws_alloc_context(void)
+{
+    SwsInternal *c = new_context();
+    return c ? &c->opts : nullptr;
+}
+
+void sws_freeContext(SwsContext *sws)
+{
+    if (!sws) return;
+    SwsInternal *c = internal(sws);
+    if (c->magic != kMagic) return;
+    destroy(c);
+}
+
+void sws_free_context(SwsContext **pctx)
+{
+    if (!pctx || !*pctx) return;
+    sws_freeContext(*pctx);
+    *pctx = nullptr;
+}
+
+int sws_init_context(SwsContext *sws, SwsFilter *srcFilter, SwsFilter *dstFilter)
+{
+    if (!sws) return SWS_AVERROR(EINVAL);
+    return init_context_impl(internal(sws), srcFilter, dstFilter);
+}
+
+SwsContext *sws_getContext(int srcW, int srcH, enum AVPixelFormat srcFormat, int dstW, int dstH,
+                           enum AVPixelFormat dstFormat, int flags, SwsFilter *srcFilter,
+                           SwsFilter *dstFilter, const double *param)
+{
+    SwsInternal *c = alloc_set_opts(srcW, srcH, srcFormat, dstW, dstH, dstFormat, (unsigned)flags, param);
+    if (!c) return nullptr;
+    if (init_context_impl(c, srcFilter, dstFilter) < 0) { // utils.c:1935-1938: NULL on any failure
+        destroy(c);
+        return nullptr;
+    }
+    return &c->opts;
+}
+
+SwsContext *sws_getCachedContext(SwsContext *prev, int srcW, int srcH, enum AVPixelFormat srcFormat, int dstW,
+                                 int dstH, enum AVPixelFormat dstFormat, int flags, SwsFilter *srcFilter,
+                                 SwsFilter *dstFilter, const double *param) // utils.c:2331-2381
+{
+    static const double default_param[2] = { SWS_PARAM_DEFAULT, SWS_PARAM_DEFAULT };
+    if (!param) param = default_param;
+    if (prev) {
+        SwsInternal *p = internal(prev);
+        // note: formats may have been canonicalised at init (bgr0 -> bgra); compare like the reference does,
+        // on the stored fields, after applying the same aliasing to the request
+        int sf = srcFormat, df = dstFormat;
+        jpeg_alias(&sf); jpeg_alias(&df); zero_alpha_alias(&sf); zero_alpha_alias(&df);
+        if (prev->src_w != srcW || prev->src_h != srcH || prev->src_format != sf || prev->dst_w != dstW ||
+            prev->dst_h != dstH || prev->dst_format != df || prev->flags != (unsigned)flags ||
+            prev->scaler_params[0] != param[0] || prev->scaler_params[1] != param[1]) {
+            destroy(p);
+            prev = nullptr;
+        }
+    }
+    if (!prev) return sws_getContext(srcW, srcH, srcFormat, dstW, dstH, dstFormat, flags, srcFilter, dstFilter, param);
+    return prev;
+}
+
+int sws_isSupportedInput(enum AVPixelFormat f) { return fmt_supported_in(f) ? 1 : 0; }
+int sws_isSupportedOutput(enum AVPixelFormat f) { return fmt_supported_out(f) ? 1 : 0; }
+int sws_isSupportedEndiannessConversion(enum AVPixelFormat) { return 0; }
+
+const int *sws_getCoefficients(int colorspace) { return yuv2rgb_coeffs(colorspace); }
+
+int sws_setColorspaceDetails(SwsContext *sws, const int inv_table[4], int srcRange, const int table[4],
+                             int dstRange, int brightness, int contrast, int saturation) // utils.c:849-1005
+{
+    if (!sws || !inv_table || !table) return -1;
+    SwsInternal *c = internal(sws);
+    canonicalise_formats(c);
+    const PixDesc *dd = pix_desc(sws->dst_format), *ds = pix_desc(sws->src_format);
+    if (!dd || !ds) return -1;
+    auto override_needed = [](int f) { return !isYUV(f) && !isGray(f); }; // range_override_needed :844
+    if (override_needed(sws->dst_format)) dstRange = 0;
+    if (override_needed(sws->src_format)) srcRange = 0;
+
+    const bool need_reinit = sws->src_range != srcRange || sws->dst_range != dstRange || c->brightness != brightness ||
+                             c->contrast != contrast || c->saturation != saturation ||
+                             std::memcmp(c->srcColorspaceTable, inv_table, sizeof(int) * 4) ||
+                             std::memcmp(c->dstColorspaceTable, table, sizeof(int) * 4);
+    int inv_copy[4], tab_copy[4];
+    std::memcpy(inv_copy, inv_table, sizeof(inv_copy));
+    std::memcpy(tab_copy, table, sizeof(tab_copy));
+    std::memcpy(c->srcColorspaceTable, inv_copy, sizeof(inv_copy));
+    std::memcpy(c->dstColorspaceTable, tab_copy, sizeof(tab_copy));
+    c->brightness = brightness; c->contrast = contrast; c->saturation = saturation;
+    sws->src_range = srcRange; sws->dst_range = dstRange;
+
+    if (need_reinit) build_range_conv(c->range, srcRange, dstRange, sws->dst_format, c->dstBpc);
+    c->dstFormatBpp = pix_bits_per_pixel(dd);
+    c->srcFormatBpp = pix_bits_per_pixel(ds);
+    c->tables_dirty = true;
+
+    if (c->cascade[0])
+        return sws_setColorspaceDetails(&c->cascade[0]->opts, inv_copy, srcRange, tab_copy, dstRange, brightness, contrast, saturation);
+    if (!need_reinit) return 0;
+
+    if ((isYUV(sws->dst_format) || isGray(sws->dst_format)) && (isYUV(sws->src_format) || isGray(sws->src_format))) {
+        if (!c->cascade[0] && std::memcmp(c->dstColorspaceTable, c->srcColorspaceTable, sizeof(int) * 4) &&
+            sws->src_w && sws->src_h && sws->dst_w && sws->dst_h) {               // :915-984
+            if (isNBPS(sws->dst_format) || is16BPS(sws->dst_format)) {
+                log_msg(c, 0, "YUV matrix change through a BGR48 intermediate is not implemented on the HIP path\n");
+                return -1;
+            }
+            log_msg(c, 2, "YUV color matrix differs for YUV->YUV, using intermediate RGB to convert\n");
+            const int tmp_format = AV_PIX_FMT_BGR24;
+            int tw, th;
+            if (sws->src_w * sws->src_h > sws->dst_w * sws->dst_h) { tw = sws->dst_w; th = sws->dst_h; }
+            else { tw = sws->src_w; th = sws->src_h; }
+            c->cascade_fmt = tmp_format; c->cascade_w = tw; c->cascade_h = th;
+
+            c->cascade[0] = alloc_set_opts(sws->src_w, sws->src_h, sws->src_format, tw, th, tmp_format, sws->flags, sws->scaler_params);
+            if (!c->cascade[0]) return -1;
+            c->cascade[0]->opts.alpha_blend = sws->alpha_blend;
+            if (init_context_impl(c->cascade[0], nullptr, nullptr) < 0) return -1;
+            sws_setColorspaceDetails(&c->cascade[0]->opts, inv_copy, srcRange, tab_copy, dstRange, brightness, contrast, saturation);
+
+            c->cascade[1] = alloc_set_opts(tw, th, tmp_format, sws->dst_w, sws->dst_h, sws->dst_format, sws->flags, sws->scaler_params);
+            if (!c->cascade[1]) return -1;
+            c->cascade[1]->opts.src_range = srcRange;
+            c->cascade[1]->opts.dst_range = dstRange;
+            if (init_context_impl(c->cascade[1], nullptr, nullptr) < 0) return -1;
+            sws_setColorspaceDetails(&c->cascade[1]->opts, inv_copy, srcRange, tab_copy, dstRange, 0, 1 << 16, 1 << 16);
+            c->plan = PLAN_CASCADE;
+            return 0;
+        }
+        if (c->cascade[0] && std::memcmp(c->dstColorspaceTable, c->srcColorspaceTable, sizeof(int) * 4)) return -1;
+        return 0;
+    }
+    if (!isYUV(sws->dst_format) && !isGray(sws->dst_format))
+        build_yuv2rgb(c->lut, inv_copy, srcRange, brightness, contrast, saturation);
+    build_rgb2yuv(c->rgb2yuv, tab_copy);
+    return 0;
+}
+
+int sws_getColorspaceDetails(SwsContext *sws, int **inv_table, int *srcRange, int **table, int *dstRange,
+                             int *brightness, int *contrast, int *saturation) // utils.c:1007-1026
+{
+    if (!sws) return -1;
+    SwsInternal *c = internal(sws);
+    if (inv_table) *inv_table = c->srcColorspaceTable;
+    if (table) *table = c->dstColorspaceTable;
+    if (srcRange) *srcRange = sws->src_range;  // the reference reports range_override_needed(fmt) ? 1 : src_range
+    if (dstRange) *dstRange = sws->dst_range;
+    if (pix_desc(sws->src_format) && !isYUV(sws->src_format) && !isGray(sws->src_format) && srcRange) *srcRange = 1;
+    if (pix_desc(sws->dst_format) && !isYUV(sws->dst_format) && !isGray(sws->dst_format) && dstRange) *dstRange = 1;
+    if (brightness) *brightness = c->brightness;
+    if (contrast) *contrast = c->contrast;
+    if (saturation) *saturation = c->saturation;
+    return 0;
+}
+
+const char *sws_hip_path_name(const SwsContext *sws) { return sws ? internal(sws)->path_name.c_str() : ""; }
+const char *sws_hip_kernel_name(const SwsContext *sws) { return sws ? internal(sws)->kernel_name.c_str() : ""; }
+
+int sws_hip_get_filter(const SwsContext *sws, int which, const int16_t **filter, const int32_t **pos, int *count)
+{
+    if (!sws) return 0;
+    const SwsInternal *c = internal(sws);
+    const FilterBank *b = which == 0 ? &c->hLum : which == 1 ? &c->hChr : which == 2 ? &c->vLum : &c->vChr;
+    if (!b->size) return 0;
+    if (filter) *filter = b->taps.data();
+    if (pos) *pos = b->pos.data();
+    if (count) *count = b->count;
+    return b->size;
+}
+
+int sws_hip_get_tables(const SwsContext *sws, int32_t rgb2yuv[9], int yuv2rgb[6], uint32_t range_coeff[2], int64_t range_offset[2])
+{
+    if (!sws) return -1;
+    const SwsInternal *c = internal(sws);
+    if (rgb2yuv) std::memcpy(rgb2yuv, c->rgb2yuv, sizeof(c->rgb2yuv));
+    if (yuv2rgb) { yuv2rgb[0] = c->lut.y_offset; yuv2rgb[1] = c->lut.y_coeff; yuv2rgb[2] = c->lut.v2r;
+                   yuv2rgb[3] = c->lut.v2g; yuv2rgb[4] = c->lut.u2g; yuv2rgb[5] = c->lut.u2b; }
+    if (range_coeff) { range_coeff[0] = c->range.lumCoeff; range_coeff[1] = c->range.chrCoeff; }
+    if (range_offset) { range_offset[0] = c->range.lumOffset; range_offset[1] = c->range.chrOffset; }
+    return c->range.active ? 1 : 0;
+}
+
+} // extern "C"

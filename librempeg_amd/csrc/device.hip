@@ -1,0 +1,888 @@
+// HIP side of libswscale_hip: device state, table upload, kernel selection and launch, the
+// sws_scale()/sws_scale_frame()/sws_scale_frames() entry points and the hwcontext-shaped helpers.
+// gfx950 only; no CPU fallback: if HIP is unavailable every call fails with AVERROR_EXTERNAL.
+#include <hip/hip_runtime.h>
+
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "kernels_fast.hpp"
+#include "swsint.hpp"
+
+#define AVERROR_EXTERNAL_ (-0x20545845) /* FFERRTAG('E','X','T',' '), libavutil/error.h */
+
+namespace swship {
+
+struct DeviceState {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    void *d_tables = nullptr; size_t tables_bytes = 0;
+    SwsDevParams params;
+    bool unity_h = false;
+    void *scratch = nullptr; size_t scratch_bytes = 0;
+    void *stage_src = nullptr; size_t stage_src_bytes = 0;
+    void *stage_dst = nullptr; size_t stage_dst_bytes = 0;
+    SwsFramePtrs *d_frames = nullptr, *h_frames = nullptr; int frames_cap = 0;
+    void *casc_img = nullptr; size_t casc_bytes = 0; int casc_stride = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timing = false; bool timed = false;
+};
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    log_msg(c, 0, "HIP error %s at %s:%d: %s\n", hipGetErrorName(e_), __FILE__, __LINE__, #expr); \
+    (void)hipGetLastError(); return AVERROR_EXTERNAL_; } } while (0)
+
+static int ensure_dev(SwsInternal *c)
+{
+    if (c->dev) return 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        log_msg(c, 0, "no HIP device available: libswscale_hip has no CPU fallback\n");
+        return AVERROR_EXTERNAL_;
+    }
+    DeviceState *d = new DeviceState();
+    std::memset(&d->params, 0, sizeof(d->params));
+    if (hipGetDevice(&d->device) != hipSuccess) d->device = 0;
+    c->dev = d;
+    return 0;
+}
+
+void dev_release(SwsInternal *c)
+{
+    DeviceState *d = c->dev;
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    if (d->stream && d->own_stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
+    else if (d->stream) (void)hipStreamSynchronize(d->stream);
+    if (d->d_tables) (void)hipFree(d->d_tables);
+    if (d->scratch) (void)hipFree(d->scratch);
+    if (d->stage_src) (void)hipFree(d->stage_src);
+    if (d->stage_dst) (void)hipFree(d->stage_dst);
+    if (d->d_frames) (void)hipFree(d->d_frames);
+    if (d->h_frames) (void)hipHostFree(d->h_frames);
+    if (d->casc_img) (void)hipFree(d->casc_img);
+    if (d->ev0) (void)hipEventDestroy(d->ev0);
+    if (d->ev1) (void)hipEventDestroy(d->ev1);
+    delete d;
+    c->dev = nullptr;
+}
+
+static bool bank_is_identity(const FilterBank &b, int one)
+{
+    if (b.size != 1) return false;
+    for (int i = 0; i < b.count; i++)
+        if (b.pos[i] != i || b.taps[i] != one) return false;
+    return true;
+}
+
+static int src_kind_of(int f)
+{
+    switch (f) {
+    case AV_PIX_FMT_YUV420P: case AV_PIX_FMT_YUV422P: case AV_PIX_FMT_YUV444P: return SRCK_PLANAR8;
+    case AV_PIX_FMT_YUV420P10LE: case AV_PIX_FMT_YUV444P10LE: case AV_PIX_FMT_YUV420P16LE: case AV_PIX_FMT_YUV444P16LE: return SRCK_PLANAR16;
+    case AV_PIX_FMT_NV12: case AV_PIX_FMT_NV21: return SRCK_NV12;
+    case AV_PIX_FMT_P010LE: return SRCK_P010;
+    case AV_PIX_FMT_RGB24: case AV_PIX_FMT_BGR24: return SRCK_RGB24;
+    case AV_PIX_FMT_RGBA: case AV_PIX_FMT_BGRA: case AV_PIX_FMT_ARGB: case AV_PIX_FMT_ABGR: return SRCK_RGB32;
+    case AV_PIX_FMT_GBRP: return SRCK_GBRP;
+    case AV_PIX_FMT_GBRPF32LE: return SRCK_GBRPF32;
+    }
+    return -1;
+}
+static int dst_kind_of(int f)
+{
+    switch (f) {
+    case AV_PIX_FMT_YUV420P: case AV_PIX_FMT_YUV422P: case AV_PIX_FMT_YUV444P: return DSTK_PLANAR8;
+    case AV_PIX_FMT_YUV420P10LE: case AV_PIX_FMT_YUV444P10LE: return DSTK_PLANARN;
+    case AV_PIX_FMT_YUV420P16LE: case AV_PIX_FMT_YUV444P16LE: return DSTK_PLANAR16;
+    case AV_PIX_FMT_NV12: case AV_PIX_FMT_NV21: return DSTK_NV12;
+    case AV_PIX_FMT_P010LE: return DSTK_P010;
+    case AV_PIX_FMT_RGB24: case AV_PIX_FMT_BGR24: return DSTK_RGB24;
+    case AV_PIX_FMT_RGBA: case AV_PIX_FMT_BGRA: case AV_PIX_FMT_ARGB: case AV_PIX_FMT_ABGR: return DSTK_RGB32;
+    }
+    return -1;
+}
+
+// upload filter banks (one blob) and fill SwsDevParams
+int dev_prepare(SwsInternal *c)
+{
+    int ret = ensure_dev(c);
+    if (ret < 0) return ret;
+    DeviceState *d = c->dev;
+    if (!c->tables_dirty) return 0;
+    HIPCHK(hipSetDevice(d->device));
+    if (!d->stream) { HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)); d->own_stream = true; }
+
+    SwsDevParams &p = d->params;
+    std::memset(&p, 0, sizeof(p));
+    const SwsContext &o = c->opts;
+    const PixDesc *ds = pix_desc(o.src_format), *dd = pix_desc(o.dst_format);
+    p.srcW = o.src_w; p.srcH = o.src_h; p.dstW = o.dst_w; p.dstH = o.dst_h;
+    p.chrSrcW = c->chrSrcW; p.chrSrcH = c->chrSrcH; p.chrDstW = c->chrDstW; p.chrDstH = c->chrDstH;
+    p.chrSrcHSub = c->chrSrcHSubSample; p.chrSrcVSub = c->chrSrcVSubSample;
+    p.chrDstHSub = c->chrDstHSubSample; p.chrDstVSub = c->chrDstVSubSample;
+    p.srcKind = src_kind_of(o.src_format); p.dstKind = dst_kind_of(o.dst_format);
+    p.srcBpc = c->srcBpc; p.dstBpc = c->dstBpc;
+    p.src_depth = ds->comp[0].depth;
+    p.wide = c->dstBpc > 14;
+    p.hclip = p.wide ? (1 << 19) - 1 : (1 << 15) - 1;
+    if (c->srcBpc == 8) p.hshift = p.wide ? 3 : 7;                       // hScale8To15_c / hScale8To19_c
+    else if (p.wide) {                                                    // hScale16To19_c, swscale.c:69-97
+        p.hshift = ds->comp[0].depth - 1 - 4;
+        if (isAnyRGB(o.src_format) && ds->comp[0].depth < 16) p.hshift = 9;
+        else if (ds->flags & PIXFLAG_FLOAT) p.hshift = 16 - 1 - 4;
+    } else {                                                              // hScale16To15_c, swscale.c:99-125
+        p.hshift = ds->comp[0].depth - 1;
+        if (p.hshift < 15) p.hshift = isAnyRGB(o.src_format) ? 13 : ds->comp[0].depth - 1;
+        else if (ds->flags & PIXFLAG_FLOAT) p.hshift = 16 - 1;
+    }
+    p.dst_bits = dd->comp[0].depth; p.dst_shift = dd->comp[0].shift;
+    p.uv_swap_src = isSwappedChroma(o.src_format); p.uv_swap_dst = isSwappedChroma(o.dst_format);
+    p.u_plane_src = ds->comp[1].plane; p.v_plane_src = ds->comp[2].plane;
+    p.u_plane_dst = dd->comp[1].plane; p.v_plane_dst = dd->comp[2].plane;
+    p.should_dither = isNBPS(o.src_format) || is16BPS(o.src_format);     // swscale.c:292-293
+    p.full_chr = (o.flags & SWS_FULL_CHR_H_INT) ? 1 : 0;
+    if (isAnyRGB(o.src_format) && !isPlanarRGB(o.src_format)) {
+        p.src_pix_step = ds->comp[0].step;
+        p.src_r_pos = ds->comp[0].offset; p.src_g_pos = ds->comp[1].offset; p.src_b_pos = ds->comp[2].offset;
+    }
+    p.chr_half = isAnyRGB(o.src_format) && c->chrSrcHSubSample;
+    std::memcpy(p.rgb2yuv, c->rgb2yuv, sizeof(p.rgb2yuv));
+    p.src_range = o.src_range;
+
+    if (isAnyRGB(o.dst_format) && c->lut.valid) {
+        const Yuv2RgbLut &l = c->lut;
+        SwsLutParams &L = p.lut;
+        auto fits = [](int64_t v) { return v >= INT32_MIN && v <= INT32_MAX; };
+        if (!fits(l.yb0 + 0x8000 + 2048 * l.cy) || !fits(l.yb0 + 0x8000) || !fits(255 * l.crv) || !fits(255 * l.cbu) ||
+            !fits(255 * l.cgu) || !fits(255 * l.cgv)) {
+            log_msg(c, 0, "brightness/contrast/saturation out of the range the HIP LUT closed form supports\n");
+            return SWS_AVERROR(ENOTSUP);
+        }
+        L.cy = (int32_t)l.cy; L.yb0r = (int32_t)(l.yb0 + 0x8000);
+        L.crv = (int32_t)l.crv; L.cbu = (int32_t)l.cbu; L.cgu = (int32_t)l.cgu; L.cgv = (int32_t)l.cgv;
+        L.base_r = l.yoffs - (int32_t)(l.crv >> 9);
+        L.base_b = l.yoffs - (int32_t)(l.cbu >> 9);
+        L.base_g = l.yoffs - (int32_t)(l.cgu >> 9) - (int32_t)(l.cgv >> 9);
+        const int df = o.dst_format;
+        // yuv2rgb.c:941-961: AV_PIX_FMT_RGB32 == BGRA, RGB32_1 == ABGR, BGR32 == RGBA, BGR32_1 == ARGB (little endian)
+        const bool isRgb = df == AV_PIX_FMT_BGRA || df == AV_PIX_FMT_ABGR || df == AV_PIX_FMT_BGR24;
+        const int base = (df == AV_PIX_FMT_ABGR || df == AV_PIX_FMT_ARGB) ? 8 : 0;
+        L.rshift = base + (isRgb ? 16 : 0); L.gshift = base + 8; L.bshift = base + (isRgb ? 0 : 16);
+        L.alpha_or = isALPHA(o.src_format) ? 0u : (255u << ((base + 24) & 31));
+        L.rgb_order = df == AV_PIX_FMT_BGR24 ? 1 : 0;
+        L.y_offset = l.y_offset; L.y_coeff = l.y_coeff; L.v2r = l.v2r; L.v2g = l.v2g; L.u2g = l.u2g; L.u2b = l.u2b;
+        L.pix_step = dd->comp[0].step;
+        L.r_pos = dd->comp[0].offset; L.g_pos = dd->comp[1].offset; L.b_pos = dd->comp[2].offset;
+        L.a_pos = dd->nb_components > 3 ? dd->comp[3].offset : 0;
+    }
+    p.range_active = c->range.active; p.range_to_jpeg = !o.src_range;
+    p.lumCoeff = c->range.lumCoeff; p.chrCoeff = c->range.chrCoeff;
+    p.lumOffset = c->range.lumOffset; p.chrOffset = c->range.chrOffset;
+    if (c->plan == PLAN_UNSC_P01X) {                                      // swscale_unscaled.c:285-293
+        p.shiftY = dd->comp[0].depth + dd->comp[0].shift - ds->comp[0].depth - ds->comp[0].shift;
+        p.shiftU = dd->comp[1].depth + dd->comp[1].shift - ds->comp[1].depth - ds->comp[1].shift;
+        p.shiftV = dd->comp[2].depth + dd->comp[2].shift - ds->comp[2].depth - ds->comp[2].shift;
+    }
+    p.copy_depth_src = ds->comp[0].depth; p.copy_depth_dst = dd->comp[0].depth;
+    p.copy_shift_src = ds->comp[0].shift; p.copy_shift_dst = dd->comp[0].shift;
+    p.copy_shiftonly_luma = !o.src_range;
+    p.dither_mode = o.dither;
+
+    // ---- filter tables -> one device blob ----
+    d->unity_h = false;
+    if (c->plan == PLAN_MAIN) {
+        const FilterBank *banks[4] = { &c->hLum, &c->hChr, &c->vLum, &c->vChr };
+        size_t off = 0, offs_t[4], offs_p[4];
+        auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        for (int i = 0; i < 4; i++) {
+            offs_t[i] = off; off = align(off + banks[i]->taps.size() * sizeof(int16_t));
+            offs_p[i] = off; off = align(off + banks[i]->pos.size() * sizeof(int32_t));
+        }
+        if (off > d->tables_bytes) {
+            if (d->d_tables) HIPCHK(hipFree(d->d_tables));
+            d->d_tables = nullptr;
+            HIPCHK(hipMalloc(&d->d_tables, off));
+            d->tables_bytes = off;
+        }
+        std::vector<uint8_t> host(off, 0);
+        for (int i = 0; i < 4; i++) {
+            std::memcpy(host.data() + offs_t[i], banks[i]->taps.data(), banks[i]->taps.size() * sizeof(int16_t));
+            std::memcpy(host.data() + offs_p[i], banks[i]->pos.data(), banks[i]->pos.size() * sizeof(int32_t));
+        }
+        HIPCHK(hipMemcpyAsync(d->d_tables, host.data(), off, hipMemcpyHostToDevice, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream)); // host vector goes out of scope
+        uint8_t *b = (uint8_t *)d->d_tables;
+        p.hLumF = (const int16_t *)(b + offs_t[0]); p.hLumPos = (const int32_t *)(b + offs_p[0]); p.hLumFs = c->hLum.size;
+        p.hChrF = (const int16_t *)(b + offs_t[1]); p.hChrPos = (const int32_t *)(b + offs_p[1]); p.hChrFs = c->hChr.size;
+        p.vLumF = (const int16_t *)(b + offs_t[2]); p.vLumPos = (const int32_t *)(b + offs_p[2]); p.vLumFs = c->vLum.size;
+        p.vChrF = (const int16_t *)(b + offs_t[3]); p.vChrPos = (const int32_t *)(b + offs_p[3]); p.vChrFs = c->vChr.size;
+        d->unity_h = bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14);
+    }
+
+    // ---- name the path (for SWS_PRINT_INFO, tests and rocprof matching) ----
+    switch (c->plan) {
+    case PLAN_UNSC_YUV2RGB: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb_unscaled"; break;
+    case PLAN_UNSC_P01X: c->path_name = "unscaled:planarToP01x"; c->kernel_name = "sws_k_p01x_unscaled"; break;
+    case PLAN_UNSC_8_P01X: c->path_name = "unscaled:planar8ToP01xle"; c->kernel_name = "sws_k_p01x_unscaled"; break;
+    case PLAN_UNSC_PLANAR2NV12: c->path_name = "unscaled:planarToNv12"; c->kernel_name = "sws_k_planar_misc"; break;
+    case PLAN_UNSC_NV122PLANAR: c->path_name = "unscaled:nv12ToPlanar"; c->kernel_name = "sws_k_planar_misc"; break;
+    case PLAN_UNSC_PLANARCOPY: c->path_name = "unscaled:planarCopy"; c->kernel_name = "sws_k_planar_misc"; break;
+    case PLAN_CASCADE: c->path_name = "cascade"; c->kernel_name = ""; break;
+    case PLAN_MAIN: {
+        const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
+        if (d->unity_h && rgb_lut && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
+            c->path_name = "main:fused_rgb_unity"; c->kernel_name = "sws_k_rgb_fused_unity";
+        } else if (d->unity_h) {
+            c->path_name = "main:fused_generic_unity";
+            c->kernel_name = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) ? "sws_k_vscale_rgb" : "sws_k_vscale_planar";
+        } else {
+            c->path_name = "main:two_pass";
+            c->kernel_name = "sws_k_hscale";
+        }
+        break;
+    }
+    default: c->path_name = "none"; c->kernel_name = ""; break;
+    }
+    log_msg(c, 2, "HIP path: %s (dominant kernel %s)\n", c->path_name.c_str(), c->kernel_name.c_str());
+    c->tables_dirty = false;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// frame layout helpers (hwcontext: frames_get_buffer analogue of libavutil/hwcontext_cuda.c:132-197)
+// ------------------------------------------------------------------------------------------
+static int plane_geometry(int format, int w, int h, int plane, int *row_bytes, int *rows)
+{
+    const PixDesc *d = pix_desc(format);
+    if (!d) return -1;
+    const int np = pix_nb_planes(d);
+    if (plane >= np) { *row_bytes = 0; *rows = 0; return 0; }
+    // bytes per row = max over components in this plane of (step * samples); libavutil/imgutils.c av_image_get_linesize
+    int step = 0; bool chroma = false;
+    for (int c = 0; c < d->nb_components; c++)
+        if (d->comp[c].plane == plane) { step = d->comp[c].step; chroma = (c == 1 || c == 2); }
+    const bool sub = chroma && !(d->flags & PIXFLAG_RGB);
+    const int sw = sub ? -((-w) >> d->log2_chroma_w) : w, sh = sub ? -((-h) >> d->log2_chroma_h) : h;
+    *row_bytes = sw * step;
+    *rows = sh;
+    return 0;
+}
+
+static int rows_of_slice(int format, int plane, int sliceY, int sliceH, int *y0, int *rows)
+{
+    const PixDesc *d = pix_desc(format);
+    bool chroma = false;
+    for (int c = 0; c < d->nb_components; c++) if (d->comp[c].plane == plane) chroma = (c == 1 || c == 2);
+    const bool sub = chroma && !(d->flags & PIXFLAG_RGB);
+    if (sub) { *y0 = sliceY >> d->log2_chroma_h; *rows = -((-sliceH) >> d->log2_chroma_h); }
+    else { *y0 = sliceY; *rows = sliceH; }
+    return 0;
+}
+
+static bool is_device_ptr(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeArray;
+}
+
+static int grow(SwsInternal *c, void **buf, size_t *cap, size_t need)
+{
+    if (need <= *cap) return 0;
+    if (*buf) HIPCHK(hipFree(*buf));
+    *buf = nullptr; *cap = 0;
+    HIPCHK(hipMalloc(buf, need));
+    *cap = need;
+    return 0;
+}
+
+static bool frames_vec_ok(const SwsFramePtrs *fr, int n)
+{
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 4; k++) {
+            if (fr[i].src[k] && (((uintptr_t)fr[i].src[k] | (uintptr_t)(uint32_t)fr[i].srcStride[k]) & 15)) return false;
+            if (fr[i].dst[k] && (((uintptr_t)fr[i].dst[k] | (uintptr_t)(uint32_t)fr[i].dstStride[k]) & 15)) return false;
+        }
+    return true;
+}
+
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// launch the kernels of one (non-cascaded) context over `n` device-resident frames
+static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
+{
+    DeviceState *d = c->dev;
+    const SwsDevParams &p = d->params;
+    hipStream_t st = d->stream;
+    SwsFrameSet fs;
+    std::memset(&fs, 0, sizeof(fs));
+    fs.count = n;
+    if (n == 1) { fs.table = nullptr; fs.one = frames[0]; }
+    else {
+        if (n > d->frames_cap) {
+            if (d->d_frames) HIPCHK(hipFree(d->d_frames));
+            if (d->h_frames) HIPCHK(hipHostFree(d->h_frames));
+            d->d_frames = nullptr; d->h_frames = nullptr; d->frames_cap = 0;
+            HIPCHK(hipMalloc((void **)&d->d_frames, sizeof(SwsFramePtrs) * n));
+            HIPCHK(hipHostMalloc((void **)&d->h_frames, sizeof(SwsFramePtrs) * n, hipHostMallocDefault));
+            d->frames_cap = n;
+        } else {
+            HIPCHK(hipStreamSynchronize(st)); // previous batch may still be reading the pinned table
+        }
+        std::memcpy(d->h_frames, frames, sizeof(SwsFramePtrs) * n);
+        HIPCHK(hipMemcpyAsync(d->d_frames, d->h_frames, sizeof(SwsFramePtrs) * n, hipMemcpyHostToDevice, st));
+        fs.table = d->d_frames;
+    }
+    const bool vec = frames_vec_ok(frames, n);
+    const dim3 blk(256);
+    if (d->timing) { HIPCHK(hipEventRecord(d->ev0, st)); }
+
+    switch (c->plan) {
+    case PLAN_UNSC_YUV2RGB: {
+        const int dstW = p.dstW;
+        const int npairs = ((dstW >> 3) << 2) + ((dstW & 4) ? 2 : 0) + ((dstW & 2) ? 1 : 0); // yuv2rgb.c:198-236
+        const int is422 = c->opts.src_format == AV_PIX_FMT_YUV422P;
+        const int nrowpairs = (sliceH + 1) >> 1; // "for (y = 0; y < srcSliceH; y += 2)"
+        const int bpr = (npairs + 3) >> 2;
+        if (!bpr || !nrowpairs) break;
+        const dim3 grid(cdiv((int64_t)bpr * nrowpairs, 256), 1, n);
+        const bool bpp4 = p.dstKind == DSTK_RGB32;
+        if (bpp4 && vec) hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled<4, true>), grid, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
+        else if (bpp4) hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled<4, false>), grid, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
+        else if (vec) hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled<3, true>), grid, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
+        else hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled<3, false>), grid, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
+        break;
+    }
+    case PLAN_UNSC_P01X:
+    case PLAN_UNSC_8_P01X: {
+        const int rows = sliceH + ((sliceH + 1) >> 1);
+        const dim3 grid(cdiv(cdiv(p.srcW, 8), 256), rows, n);
+        const bool s8 = c->plan == PLAN_UNSC_8_P01X;
+        if (s8 && vec) hipLaunchKernelGGL((swsk::sws_k_p01x_unscaled<true, true>), grid, blk, 0, st, fs, p, sliceY, sliceH);
+        else if (s8) hipLaunchKernelGGL((swsk::sws_k_p01x_unscaled<true, false>), grid, blk, 0, st, fs, p, sliceY, sliceH);
+        else if (vec) hipLaunchKernelGGL((swsk::sws_k_p01x_unscaled<false, true>), grid, blk, 0, st, fs, p, sliceY, sliceH);
+        else hipLaunchKernelGGL((swsk::sws_k_p01x_unscaled<false, false>), grid, blk, 0, st, fs, p, sliceY, sliceH);
+        break;
+    }
+    case PLAN_UNSC_PLANAR2NV12:
+    case PLAN_UNSC_NV122PLANAR:
+    case PLAN_UNSC_PLANARCOPY: {
+        swsk::MiscPlan plan;
+        std::memset(&plan, 0, sizeof(plan));
+        int maxw = 0, rows = 0;
+        if (c->plan != PLAN_UNSC_PLANARCOPY) {
+            plan.mode = c->plan == PLAN_UNSC_PLANAR2NV12 ? 0 : 1;
+            plan.nplanes = 2;
+            plan.pl[0] = { 0, 0, p.srcW, sliceH, sliceY, 1, 0, 0 };
+            plan.pl[1] = { 1, 1, c->chrSrcW, (sliceH + 1) / 2, sliceY / 2, 1, 0, 1 };
+        } else {
+            plan.mode = 2;
+            const PixDesc *ds = pix_desc(c->opts.src_format), *dd = pix_desc(c->opts.dst_format);
+            // equal layouts are row memcpy in the reference, except 9..14-bit formats which always take the
+            // depth-conversion branch (swscale_unscaled.c:2246-2248) and re-replicate the top bits
+            const bool same = ds->comp[0].depth == dd->comp[0].depth && ds->comp[0].shift == dd->comp[0].shift &&
+                              !isNBPS(c->opts.src_format) && !isNBPS(c->opts.dst_format);
+            plan.bytecopy = same;
+            const int np = pix_nb_planes(dd);
+            plan.nplanes = np;
+            for (int pl = 0; pl < np; pl++) {
+                int len = pl == 0 ? p.srcW : -((-p.srcW) >> c->chrDstHSubSample);
+                const int y0 = pl == 0 ? sliceY : -((-sliceY) >> c->chrDstVSubSample);
+                const int h = pl == 0 ? sliceH : -((-sliceH) >> c->chrDstVSubSample);
+                if (pl == 1 && isSemiPlanarYUV(c->opts.dst_format)) len *= 2;
+                if (same) len *= (ds->comp[0].depth + 7) / 8;  // byte copy: width counts bytes
+                const int shiftonly = pl == 1 || pl == 2 || (!c->opts.src_range && pl == 0);
+                plan.pl[pl] = { pl, pl, len, h, y0, 1, shiftonly, pl != 0 };
+            }
+        }
+        for (int i = 0; i < plan.nplanes; i++) { maxw = std::max(maxw, plan.pl[i].width); rows += plan.pl[i].rows; }
+        if (!maxw || !rows) break;
+        const dim3 grid(cdiv(maxw, 256), rows, n);
+        hipLaunchKernelGGL(swsk::sws_k_planar_misc, grid, blk, 0, st, fs, p, plan);
+        break;
+    }
+    case PLAN_MAIN: {
+        const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32;
+        const bool rgb_lut = rgb && !p.full_chr;
+        if (d->unity_h && rgb_lut && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
+            const int npairs = (p.dstW + 1) >> 1, bpr = (npairs + 3) >> 2;
+            const dim3 grid(cdiv((int64_t)bpr * p.dstH, 256), 1, n);
+            const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;
+#define LAUNCH_FUSED(B, N, V) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity<B, N, V>), grid, blk, 0, st, fs, p)
+            if (b4) { if (nv) { if (vec) LAUNCH_FUSED(4, true, true); else LAUNCH_FUSED(4, true, false); }
+                      else    { if (vec) LAUNCH_FUSED(4, false, true); else LAUNCH_FUSED(4, false, false); } }
+            else    { if (nv) { if (vec) LAUNCH_FUSED(3, true, true); else LAUNCH_FUSED(3, true, false); }
+                      else    { if (vec) LAUNCH_FUSED(3, false, true); else LAUNCH_FUSED(3, false, false); } }
+#undef LAUNCH_FUSED
+            break;
+        }
+        // generic: optional pass 1 into scratch, then writers
+        const int64_t lumElems = (int64_t)p.srcH * p.dstW, chrElems = (int64_t)p.chrSrcH * p.chrDstW;
+        const int64_t frame_elems = lumElems + 2 * chrElems;
+        const size_t esz = p.wide ? 4 : 2;
+        const bool direct = d->unity_h;
+        int chunk = n;
+        if (!direct) {
+            const size_t budget = (size_t)2 << 30; // scratch budget per launch group
+            chunk = (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(budget / (frame_elems * esz))));
+            int r = grow(c, &d->scratch, &d->scratch_bytes, (size_t)frame_elems * esz * chunk);
+            if (r < 0) return r;
+        }
+        for (int f0 = 0; f0 < n; f0 += chunk) {
+            const int m = std::min(chunk, n - f0);
+            SwsFrameSet sub = fs;
+            sub.count = m;
+            if (n == 1) sub.one = frames[0]; else sub.table = d->d_frames + f0;
+            if (!direct) {
+                const int maxW = std::max(p.dstW, p.chrDstW), maxH = std::max(p.srcH, p.chrSrcH);
+                const dim3 g1(cdiv(maxW, 256), maxH, 3 * m);
+                if (p.wide) hipLaunchKernelGGL((swsk::sws_k_hscale<int32_t>), g1, blk, 0, st, sub, p, (int32_t *)d->scratch, frame_elems);
+                else hipLaunchKernelGGL((swsk::sws_k_hscale<int16_t>), g1, blk, 0, st, sub, p, (int16_t *)d->scratch, frame_elems);
+            }
+#define LAUNCH_W(K, G, ...) do { \
+    if (direct) hipLaunchKernelGGL((swsk::K<true, int16_t>), G, blk, 0, st, sub, p, (const int16_t *)nullptr, frame_elems, ##__VA_ARGS__); \
+    else if (p.wide) hipLaunchKernelGGL((swsk::K<false, int32_t>), G, blk, 0, st, sub, p, (const int32_t *)d->scratch, frame_elems, ##__VA_ARGS__); \
+    else hipLaunchKernelGGL((swsk::K<false, int16_t>), G, blk, 0, st, sub, p, (const int16_t *)d->scratch, frame_elems, ##__VA_ARGS__); } while (0)
+            if (rgb) {
+                const int units = p.full_chr ? p.dstW : (p.dstW + 1) >> 1;
+                const dim3 g(cdiv(units, 256), p.dstH, m);
+                LAUNCH_W(sws_k_vscale_rgb, g);
+            } else if (p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010) {
+                const dim3 gl(cdiv(p.dstW, 256), p.dstH, m);
+                LAUNCH_W(sws_k_vscale_planar, gl, 1);
+                const dim3 gc(cdiv(p.chrDstW, 256), p.chrDstH, m);
+                LAUNCH_W(sws_k_vscale_nvchroma, gc);
+            } else {
+                const dim3 g(cdiv(std::max(p.dstW, p.chrDstW), 256), std::max(p.dstH, p.chrDstH), 3 * m);
+                LAUNCH_W(sws_k_vscale_planar, g, 3);
+            }
+#undef LAUNCH_W
+        }
+        break;
+    }
+    default:
+        log_msg(c, 0, "internal error: no execution plan\n");
+        return SWS_AVERROR(EINVAL);
+    }
+    HIPCHK(hipGetLastError());
+    if (d->timing) { HIPCHK(hipEventRecord(d->ev1, st)); d->timed = true; }
+    return 0;
+}
+
+// build device-side frame descriptors for host or device user pointers; stages host memory
+struct Staging {
+    bool src_host = false, dst_host = false;
+};
+
+static int image_layout(int format, int w, int h, int align, int linesize[4], size_t offset[4], size_t *total)
+{
+    const PixDesc *d = pix_desc(format);
+    if (!d) return SWS_AVERROR(EINVAL);
+    size_t off = 0;
+    for (int pl = 0; pl < 4; pl++) {
+        int rb = 0, rows = 0;
+        plane_geometry(format, w, h, pl, &rb, &rows);
+        linesize[pl] = rb ? (rb + align - 1) / align * align : 0;
+        offset[pl] = off;
+        off += (size_t)linesize[pl] * rows;
+        off = (off + 255) & ~(size_t)255;
+    }
+    *total = off;
+    return 0;
+}
+
+static int run_single(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4], int sliceY, int sliceH,
+                      uint8_t *const dst[4], const int dstStride[4]);
+
+int dev_run(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4], int srcSliceY, int srcSliceH,
+            uint8_t *const dst[4], const int dstStride[4], int nb_frames,
+            const SwsFrameView *const *srcFrames, SwsFrameView *const *dstFrames)
+{
+    int ret = dev_prepare(c);
+    if (ret < 0) return ret;
+    DeviceState *d = c->dev;
+    HIPCHK(hipSetDevice(d->device));
+    if (nb_frames <= 0) return run_single(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
+
+    // batched: all frames device resident -> one launch set; otherwise frame by frame (host staging)
+    const int nps = pix_nb_planes(pix_desc(c->opts.src_format)), npd = pix_nb_planes(pix_desc(c->opts.dst_format));
+    bool all_dev = c->plan != PLAN_CASCADE;
+    for (int i = 0; i < nb_frames && all_dev; i++)
+        all_dev = is_device_ptr(srcFrames[i]->data[0]) && is_device_ptr(dstFrames[i]->data[0]);
+    if (!all_dev) {
+        for (int i = 0; i < nb_frames; i++) {
+            ret = run_single(c, srcFrames[i]->data, srcFrames[i]->linesize, 0, c->opts.src_h, dstFrames[i]->data, dstFrames[i]->linesize);
+            if (ret < 0) return ret;
+        }
+        return nb_frames;
+    }
+    std::vector<SwsFramePtrs> fr(nb_frames);
+    for (int i = 0; i < nb_frames; i++) {
+        std::memset(&fr[i], 0, sizeof(SwsFramePtrs));
+        for (int k = 0; k < nps; k++) { fr[i].src[k] = srcFrames[i]->data[k]; fr[i].srcStride[k] = srcFrames[i]->linesize[k]; }
+        for (int k = 0; k < npd; k++) { fr[i].dst[k] = dstFrames[i]->data[k]; fr[i].dstStride[k] = dstFrames[i]->linesize[k]; }
+    }
+    ret = launch_plan(c, fr.data(), nb_frames, 0, c->opts.src_h);
+    return ret < 0 ? ret : nb_frames;
+}
+
+static int run_single(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4], int sliceY, int sliceH,
+                      uint8_t *const dst[4], const int dstStride[4])
+{
+    DeviceState *d = c->dev;
+    const SwsContext &o = c->opts;
+
+    if (c->plan == PLAN_CASCADE) { // scale_cascaded, swscale.c:992-1018 (whole frames)
+        SwsInternal *c0 = c->cascade[0], *c1 = c->cascade[1];
+        for (SwsInternal *cc : { c0, c1 }) {
+            int r = dev_prepare(cc);
+            if (r < 0) return r;
+            // children share the parent's device and stream
+            if (cc->dev->stream != d->stream) {
+                if (cc->dev->own_stream && cc->dev->stream) { (void)hipStreamDestroy(cc->dev->stream); }
+                cc->dev->stream = d->stream; cc->dev->own_stream = false; cc->dev->device = d->device;
+            }
+        }
+        int ls[4]; size_t offs[4], total;
+        image_layout(c->cascade_fmt, c->cascade_w, c->cascade_h, 256, ls, offs, &total);
+        int r = grow(c, &d->casc_img, &d->casc_bytes, total);
+        if (r < 0) return r;
+        uint8_t *tmp[4] = { (uint8_t *)d->casc_img, nullptr, nullptr, nullptr };
+        int tls[4] = { ls[0], 0, 0, 0 };
+        r = run_single(c0, src, srcStride, sliceY, sliceH, tmp, tls);
+        if (r < 0) return r;
+        return run_single(c1, tmp, tls, 0, c0->opts.dst_h, dst, dstStride);
+    }
+
+    const int nps = pix_nb_planes(pix_desc(o.src_format)), npd = pix_nb_planes(pix_desc(o.dst_format));
+    const bool src_dev = is_device_ptr(src[0]), dst_dev = is_device_ptr(dst[0]);
+    const bool unscaled = c->plan != PLAN_MAIN;
+    // destination rows produced by this call
+    const int outY = unscaled ? sliceY : 0, outH = unscaled ? sliceH : o.dst_h;
+
+    SwsFramePtrs fr;
+    std::memset(&fr, 0, sizeof(fr));
+    hipStream_t st = d->stream;
+
+    if (src_dev) {
+        for (int k = 0; k < nps; k++) {
+            int y0, rows; rows_of_slice(o.src_format, k, sliceY, sliceH, &y0, &rows);
+            // unscaled converters take slice-relative source pointers (swscale.c:1163-1188): rebase to absolute rows
+            fr.src[k] = src[k] - (int64_t)(unscaled ? y0 : 0) * srcStride[k];
+            fr.srcStride[k] = srcStride[k];
+        }
+    } else {
+        int ls[4]; size_t offs[4], total;
+        image_layout(o.src_format, o.src_w, o.src_h, 256, ls, offs, &total);
+        int r = grow(c, &d->stage_src, &d->stage_src_bytes, total);
+        if (r < 0) return r;
+        for (int k = 0; k < nps; k++) {
+            int rb, prow; plane_geometry(o.src_format, o.src_w, o.src_h, k, &rb, &prow);
+            int y0, rows; rows_of_slice(o.src_format, k, sliceY, sliceH, &y0, &rows);
+            if (!unscaled) { y0 = 0; rows = prow; }
+            rows = std::min(rows, prow - y0);
+            uint8_t *dbase = (uint8_t *)d->stage_src + offs[k];
+            const uint8_t *s = src[k]; // slice-relative for unscaled, whole plane otherwise
+            if (srcStride[k] >= 0) {
+                HIPCHK(hipMemcpy2DAsync(dbase + (size_t)y0 * ls[k], ls[k], s, srcStride[k], rb, rows, hipMemcpyHostToDevice, st));
+            } else { // bottom-up image: copy row by row in reverse so the staged plane is top-down
+                for (int y = 0; y < rows; y++)
+                    HIPCHK(hipMemcpyAsync(dbase + (size_t)(y0 + y) * ls[k], s + (int64_t)y * srcStride[k], rb, hipMemcpyHostToDevice, st));
+            }
+            fr.src[k] = dbase; fr.srcStride[k] = ls[k];
+        }
+    }
+    int dls[4]; size_t doffs[4], dtotal = 0;
+    if (dst_dev) {
+        for (int k = 0; k < npd; k++) { fr.dst[k] = dst[k]; fr.dstStride[k] = dstStride[k]; }
+    } else {
+        image_layout(o.dst_format, o.dst_w, o.dst_h, 256, dls, doffs, &dtotal);
+        int r = grow(c, &d->stage_dst, &d->stage_dst_bytes, dtotal);
+        if (r < 0) return r;
+        for (int k = 0; k < npd; k++) { fr.dst[k] = (uint8_t *)d->stage_dst + doffs[k]; fr.dstStride[k] = dls[k]; }
+        // converters that leave pixels untouched (odd widths in yuv2rgb.c) must preserve the caller's data
+        if (c->plan == PLAN_UNSC_YUV2RGB && (o.dst_w & 1)) {
+            for (int k = 0; k < npd; k++) {
+                int rb, prow; plane_geometry(o.dst_format, o.dst_w, o.dst_h, k, &rb, &prow);
+                int y0, rows; rows_of_slice(o.dst_format, k, outY, outH, &y0, &rows);
+                if (dstStride[k] >= 0)
+                    HIPCHK(hipMemcpy2DAsync(fr.dst[k] + (size_t)y0 * dls[k], dls[k], dst[k] + (int64_t)y0 * dstStride[k], dstStride[k], rb, rows, hipMemcpyHostToDevice, st));
+            }
+        }
+    }
+
+    int ret = launch_plan(c, &fr, 1, sliceY, sliceH);
+    if (ret < 0) return ret;
+
+    if (!dst_dev) {
+        for (int k = 0; k < npd; k++) {
+            int rb, prow; plane_geometry(o.dst_format, o.dst_w, o.dst_h, k, &rb, &prow);
+            int y0, rows; rows_of_slice(o.dst_format, k, outY, outH, &y0, &rows);
+            rows = std::min(rows, prow - y0);
+            const uint8_t *sbase = (const uint8_t *)d->stage_dst + doffs[k] + (size_t)y0 * dls[k];
+            if (dstStride[k] >= 0) {
+                HIPCHK(hipMemcpy2DAsync(dst[k] + (int64_t)y0 * dstStride[k], dstStride[k], sbase, dls[k], rb, rows, hipMemcpyDeviceToHost, st));
+            } else {
+                for (int y = 0; y < rows; y++)
+                    HIPCHK(hipMemcpyAsync(dst[k] + (int64_t)(y0 + y) * dstStride[k], sbase + (size_t)y * dls[k], rb, hipMemcpyDeviceToHost, st));
+            }
+        }
+    }
+    if (!dst_dev || !src_dev) HIPCHK(hipStreamSynchronize(st)); // host buffers: synchronous like the reference
+    return unscaled ? sliceH : o.dst_h;
+}
+
+} // namespace swship
+
+using namespace swship;
+
+// ------------------------------------------------------------------------------------------
+// public entry points
+// ------------------------------------------------------------------------------------------
+static int check_image_pointers(const uint8_t *const data[4], int fmt, const int linesizes[4]) // swscale.c:729-743
+{
+    const PixDesc *d = pix_desc(fmt);
+    for (int i = 0; i < d->nb_components; i++) {
+        const int plane = d->comp[i].plane;
+        if (!data[plane] || !linesizes[plane]) return 0;
+    }
+    return 1;
+}
+
+extern "C" {
+
+int sws_scale(SwsContext *sws, const uint8_t *const srcSlice[], const int srcStride[], int srcSliceY,
+              int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    if (!sws) return SWS_AVERROR(EINVAL);
+    SwsInternal *c = internal(sws);
+    if (!c->legacy_init) {                      // swscale.c:1633-1634
+        log_msg(c, 0, "sws_scale() called on a context that was not initialised with sws_init_context()\n");
+        return SWS_AVERROR(EINVAL);
+    }
+    // scale_internal(), swscale.c:1022-1070
+    if (!srcStride || !dstStride || !dst || !srcSlice) {
+        log_msg(c, 0, "One of the input parameters to sws_scale() is NULL, please check the calling code\n");
+        return SWS_AVERROR(EINVAL);
+    }
+    const int mh_src = 1 << c->chrSrcVSubSample;
+    if ((srcSliceY & (mh_src - 1)) || ((srcSliceH & (mh_src - 1)) && srcSliceY + srcSliceH != sws->src_h) ||
+        srcSliceY + srcSliceH > sws->src_h || srcSliceY < 0 || srcSliceH < 0) {
+        log_msg(c, 0, "Slice parameters %d, %d are invalid\n", srcSliceY, srcSliceH);
+        return SWS_AVERROR(EINVAL);
+    }
+    if (!check_image_pointers(srcSlice, sws->src_format, srcStride)) {
+        log_msg(c, 0, "bad src image pointers\n");
+        return SWS_AVERROR(EINVAL);
+    }
+    if (!check_image_pointers((const uint8_t *const *)dst, sws->dst_format, dstStride)) {
+        log_msg(c, 0, "bad dst image pointers\n");
+        return SWS_AVERROR(EINVAL);
+    }
+    if (srcSliceH == 0) return 0;               // :1072-1074
+    const bool whole = srcSliceY == 0 && srcSliceH == sws->src_h;
+    if (!whole && (c->plan == PLAN_MAIN || c->plan == PLAN_CASCADE)) {
+        log_msg(c, 0, "slice-wise sws_scale() on the scaled path is not implemented on the HIP path; pass whole frames\n");
+        return SWS_AVERROR(ENOTSUP);
+    }
+    const uint8_t *s4[4] = { srcSlice[0], nullptr, nullptr, nullptr };
+    uint8_t *d4[4] = { dst[0], nullptr, nullptr, nullptr };
+    int ss4[4] = { srcStride[0], 0, 0, 0 }, ds4[4] = { dstStride[0], 0, 0, 0 };
+    const int nps = pix_nb_planes(pix_desc(sws->src_format)), npd = pix_nb_planes(pix_desc(sws->dst_format));
+    for (int k = 1; k < nps; k++) { s4[k] = srcSlice[k]; ss4[k] = srcStride[k]; }
+    for (int k = 1; k < npd; k++) { d4[k] = dst[k]; ds4[k] = dstStride[k]; }
+    return dev_run(c, s4, ss4, srcSliceY, srcSliceH, d4, ds4, 0, nullptr, nullptr);
+}
+
+static int frame_matches(const SwsInternal *c, const SwsFrameView *f, bool is_src)
+{
+    int fmt = f->format;
+    // the context stores canonicalised formats (yuvj420p -> yuv420p, bgr0 -> bgra)
+    if (fmt == AV_PIX_FMT_YUVJ420P) fmt = AV_PIX_FMT_YUV420P;
+    if (fmt == AV_PIX_FMT_BGR0) fmt = AV_PIX_FMT_BGRA;
+    if (fmt == AV_PIX_FMT_RGB0) fmt = AV_PIX_FMT_RGBA;
+    if (fmt == AV_PIX_FMT_0BGR) fmt = AV_PIX_FMT_ABGR;
+    if (fmt == AV_PIX_FMT_0RGB) fmt = AV_PIX_FMT_ARGB;
+    const SwsContext &o = c->opts;
+    return is_src ? (fmt == o.src_format && f->width == o.src_w && f->height == o.src_h)
+                  : (fmt == o.dst_format && f->width == o.dst_w && f->height == o.dst_h);
+}
+
+int sws_scale_frame(SwsContext *sws, SwsFrameView *dstf, const SwsFrameView *srcf)
+{
+    if (!sws || !dstf || !srcf) return SWS_AVERROR(EINVAL);
+    SwsInternal *c = internal(sws);
+    if (!c->legacy_init) {
+        log_msg(c, 0, "sws_scale_frame(): dynamic (uninitialised) contexts are not implemented; call sws_init_context() first\n");
+        return SWS_AVERROR(ENOTSUP);
+    }
+    if (!frame_matches(c, srcf, true) || !frame_matches(c, dstf, false)) return SWS_AVERROR(EINVAL);
+    const SwsFrameView *s1[1] = { srcf };
+    SwsFrameView *d1[1] = { dstf };
+    int r = dev_run(c, nullptr, nullptr, 0, sws->src_h, nullptr, nullptr, 1, s1, d1);
+    return r < 0 ? r : sws->dst_h;
+}
+
+int sws_scale_frames(SwsContext *sws, SwsFrameView *const dst[], const SwsFrameView *const src[], int nb_frames)
+{
+    if (!sws || !dst || !src || nb_frames < 0) return SWS_AVERROR(EINVAL);
+    if (!nb_frames) return 0;
+    SwsInternal *c = internal(sws);
+    if (!c->legacy_init) return SWS_AVERROR(EINVAL);
+    for (int i = 0; i < nb_frames; i++) {
+        if (!src[i] || !dst[i]) return SWS_AVERROR(EINVAL);
+        if (!frame_matches(c, src[i], true) || !frame_matches(c, dst[i], false)) return SWS_AVERROR(EINVAL);
+        if (!check_image_pointers(src[i]->data, sws->src_format, src[i]->linesize) ||
+            !check_image_pointers(dst[i]->data, sws->dst_format, dst[i]->linesize)) return SWS_AVERROR(EINVAL);
+    }
+    return dev_run(c, nullptr, nullptr, 0, sws->src_h, nullptr, nullptr, nb_frames, src, dst);
+}
+
+// ---- HIP device plumbing ----
+int sws_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int sws_hip_set_device(SwsContext *sws, int device)
+{
+    if (!sws) return SWS_AVERROR(EINVAL);
+    SwsInternal *c = internal(sws);
+    if (c->dev && c->dev->device != device) dev_release(c);
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
+    int r = ensure_dev(c);
+    if (r < 0) return r;
+    c->dev->device = device;
+    c->tables_dirty = true;
+    return 0;
+}
+
+int sws_hip_set_stream(SwsContext *sws, void *stream)
+{
+    if (!sws) return SWS_AVERROR(EINVAL);
+    SwsInternal *c = internal(sws);
+    int r = ensure_dev(c);
+    if (r < 0) return r;
+    DeviceState *d = c->dev;
+    if (d->stream && d->own_stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
+    d->stream = (hipStream_t)stream;
+    d->own_stream = false;
+    if (!stream) { // back to a context-owned stream
+        if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) return AVERROR_EXTERNAL_;
+        d->own_stream = true;
+    }
+    return 0;
+}
+
+void *sws_hip_get_stream(SwsContext *sws)
+{
+    if (!sws) return nullptr;
+    SwsInternal *c = internal(sws);
+    if (dev_prepare(c) < 0) return nullptr;
+    return (void *)c->dev->stream;
+}
+
+int sws_hip_sync(SwsContext *sws)
+{
+    if (!sws) return SWS_AVERROR(EINVAL);
+    SwsInternal *c = internal(sws);
+    if (!c->dev || !c->dev->stream) return 0;
+    return hipStreamSynchronize(c->dev->stream) == hipSuccess ? 0 : AVERROR_EXTERNAL_;
+}
+
+int sws_hip_set_timing(SwsContext *sws, int enable)
+{
+    if (!sws) return SWS_AVERROR(EINVAL);
+    SwsInternal *c = internal(sws);
+    int r = ensure_dev(c);
+    if (r < 0) return r;
+    DeviceState *d = c->dev;
+    if (enable && !d->ev0) {
+        if (hipEventCreate(&d->ev0) != hipSuccess || hipEventCreate(&d->ev1) != hipSuccess) return AVERROR_EXTERNAL_;
+    }
+    d->timing = enable != 0;
+    d->timed = false;
+    return 0;
+}
+
+double sws_hip_last_kernel_ms(SwsContext *sws)
+{
+    if (!sws) return -1.0;
+    SwsInternal *c = internal(sws);
+    if (!c->dev || !c->dev->timed) return -1.0;
+    float ms = 0.f;
+    if (hipEventSynchronize(c->dev->ev1) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, c->dev->ev0, c->dev->ev1) != hipSuccess) return -1.0;
+    return ms;
+}
+
+int sws_hip_image_layout(int format, int width, int height, int align, int linesize[4], size_t offset[4], size_t *total)
+{
+    if (align <= 0) align = 256;
+    return image_layout(format, width, height, align, linesize, offset, total);
+}
+
+int sws_hip_frame_alloc(SwsFrameView *f, int format, int width, int height, int device)
+{
+    if (!f) return SWS_AVERROR(EINVAL);
+    std::memset(f, 0, sizeof(*f));
+    int ls[4]; size_t offs[4], total;
+    int r = image_layout(format, width, height, 256, ls, offs, &total);
+    if (r < 0) return r;
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
+    void *base = nullptr;
+    if (hipMalloc(&base, total ? total : 256) != hipSuccess) { (void)hipGetLastError(); return SWS_AVERROR(ENOMEM); }
+    const int np = pix_nb_planes(pix_desc(format));
+    for (int k = 0; k < np; k++) { f->data[k] = (uint8_t *)base + offs[k]; f->linesize[k] = ls[k]; }
+    f->extended_data = f->data;
+    f->width = width; f->height = height; f->format = format;
+    return 0;
+}
+
+void sws_hip_frame_free(SwsFrameView *f)
+{
+    if (!f || !f->data[0]) return;
+    (void)hipFree(f->data[0]);
+    std::memset(f, 0, sizeof(*f));
+}
+
+static int frame_copy(SwsContext *sws, SwsFrameView *dstf, const SwsFrameView *srcf, hipMemcpyKind kind)
+{
+    if (!dstf || !srcf || dstf->format != srcf->format || dstf->width != srcf->width || dstf->height != srcf->height)
+        return SWS_AVERROR(EINVAL);
+    hipStream_t st = nullptr;
+    SwsInternal *c = sws ? internal(sws) : nullptr;
+    if (c) { int r = ensure_dev(c); if (r < 0) return r;
+             if (!c->dev->stream) { if (hipStreamCreateWithFlags(&c->dev->stream, hipStreamNonBlocking) != hipSuccess) return AVERROR_EXTERNAL_; c->dev->own_stream = true; }
+             st = c->dev->stream; }
+    const int np = pix_nb_planes(pix_desc(srcf->format));
+    for (int k = 0; k < np; k++) {
+        int rb, rows; plane_geometry(srcf->format, srcf->width, srcf->height, k, &rb, &rows);
+        if (hipMemcpy2DAsync(dstf->data[k], dstf->linesize[k], srcf->data[k], srcf->linesize[k], rb, rows, kind, st) != hipSuccess) {
+            (void)hipGetLastError(); return AVERROR_EXTERNAL_;
+        }
+    }
+    // sync only when the destination is a software frame (hwcontext_cuda.c:642-646)
+    if (kind == hipMemcpyDeviceToHost) { if (hipStreamSynchronize(st) != hipSuccess) return AVERROR_EXTERNAL_; }
+    return 0;
+}
+
+int sws_hip_frame_upload(SwsContext *sws, SwsFrameView *dev, const SwsFrameView *host)
+{
+    int r = frame_copy(sws, dev, host, hipMemcpyHostToDevice);
+    if (r == 0 && sws) (void)sws_hip_sync(sws); // pageable host memory: make the source reusable on return
+    return r;
+}
+int sws_hip_frame_download(SwsContext *sws, SwsFrameView *host, const SwsFrameView *dev)
+{
+    return frame_copy(sws, host, dev, hipMemcpyDeviceToHost);
+}
+
+} // extern "C"

@@ -1,0 +1,89 @@
+// Parameter blocks shared by host code and HIP kernels (plain C structs, passed by value).
+#pragma once
+#include <stdint.h>
+
+// how a component line is fetched from the source image ("input reader", libswscale/input.c)
+enum SrcKind {
+    SRCK_PLANAR8 = 0,   // u8 planes read directly (yuv420p/422p/444p)
+    SRCK_PLANAR16,      // u16 LE planes read directly (yuv4xxpNNle)
+    SRCK_NV12,          // Y direct, UV interleaved bytes (nv12ToUV_c input.c:926-948); swap for nv21
+    SRCK_P010,          // u16 >> 6, UV interleaved (input.c:950-1008)
+    SRCK_RGB24,         // packed 3 bytes; rgb24ToY/UV(_half) input.c:1068-1172
+    SRCK_RGB32,         // packed 4 bytes; rgb16_32To*_c_template input.c:264-372
+    SRCK_GBRP,          // planar 8-bit RGB; planar_rgb_to_y/uv input.c:1174-1211, gbr24pToUV_half_c :414
+    SRCK_GBRPF32,       // planar float RGB; planar_rgbf32_to_y/uv input.c:1287-1334
+};
+
+// how an output line is produced ("output writer", libswscale/output.c)
+enum DstKind {
+    DSTK_PLANAR8 = 0,   // yuv2plane1_8_c / yuv2planeX_8_c output.c:468-493
+    DSTK_PLANARN,       // 9..14 bit LE, yuv2planeX_10_c_template output.c:327-357
+    DSTK_PLANAR16,      // yuv2planeX_16_c_template output.c:149-187
+    DSTK_NV12,          // luma DSTK_PLANAR8 + yuv2nv12cX_c output.c:495-528
+    DSTK_P010,          // yuv2p01xl1_c/lX_c/cX_c output.c:538-589
+    DSTK_RGB24,         // yuv2rgb_write 24 bpp (rgb24 / bgr24 by rgb_order)
+    DSTK_RGB32,         // yuv2rgb_write 32 bpp (rgba/bgra/argb/abgr by shifts)
+};
+
+struct SwsFramePtrs {       // one frame: plane base pointers (device addresses) and byte strides
+    const uint8_t *src[4];
+    uint8_t *dst[4];
+    int32_t srcStride[4];
+    int32_t dstStride[4];
+};
+
+struct SwsFrameSet {        // batch of frames for one launch
+    const SwsFramePtrs *table;  // device array, or NULL -> use `one`
+    SwsFramePtrs one;
+    int32_t count;
+};
+
+struct SwsLutParams {       // closed form of the yuv2rgb LUTs (yuv2rgb.c:680-703, :901-961)
+    int32_t cy;             // y ramp increment
+    int32_t yb0r;           // yb0 + 0x8000
+    int32_t crv, cbu, cgu, cgv; // chroma increments (scaled by cy)
+    int32_t base_r, base_b, base_g; // yoffs - (inc>>9) [g: yoffs - (cgu>>9) - (cgv>>9)]
+    int32_t rshift, gshift, bshift; // 32 bpp channel positions
+    uint32_t alpha_or;      // 255 << abase (32 bpp, no source alpha) or 0
+    int32_t rgb_order;      // 24 bpp: 0 = R first (rgb24), 1 = B first (bgr24)
+    // 13-bit coefficients for the full-chroma writers (output.c:2005-2020)
+    int32_t y_offset, y_coeff, v2r, v2g, u2g, u2b;
+    // byte positions inside the pixel for the full-chroma writers
+    int32_t r_pos, g_pos, b_pos, a_pos, pix_step;
+};
+
+struct SwsDevParams {
+    int32_t srcW, srcH, dstW, dstH;
+    int32_t chrSrcW, chrSrcH, chrDstW, chrDstH;
+    int32_t chrSrcHSub, chrSrcVSub, chrDstHSub, chrDstVSub;
+    int32_t srcKind, dstKind;
+    int32_t srcBpc, dstBpc;
+    int32_t src_depth;        // bits per source component
+    int32_t hshift;           // hscale output shift (swscale.c:69-159)
+    int32_t hclip;            // (1<<15)-1 or (1<<19)-1
+    int32_t wide;             // 1 -> 19-bit int32 intermediates, 0 -> 15-bit int16
+    int32_t dst_bits, dst_shift; // writer depth / left shift (p010: 10, 6)
+    int32_t uv_swap_src, uv_swap_dst; // nv21-style chroma order
+    int32_t u_plane_src, v_plane_src, u_plane_dst, v_plane_dst;
+    int32_t should_dither;    // source is >8 bit (swscale.c:292-293)
+    int32_t full_chr;         // SWS_FULL_CHR_H_INT writers
+    int32_t src_pix_step;     // packed RGB: 3 or 4
+    int32_t src_r_pos, src_g_pos, src_b_pos; // byte offsets of R,G,B in a packed source pixel
+    int32_t chr_half;         // RGB source: chroma from averaged pixel pairs (chrSrcHSubSample)
+    // filters (device pointers)
+    const int16_t *hLumF, *hChrF, *vLumF, *vChrF;
+    const int32_t *hLumPos, *hChrPos, *vLumPos, *vChrPos;
+    int32_t hLumFs, hChrFs, vLumFs, vChrFs;
+    // colour
+    int32_t rgb2yuv[9];
+    SwsLutParams lut;
+    // range conversion (swscale.c:163-255)
+    int32_t range_active, range_to_jpeg;
+    uint32_t lumCoeff, chrCoeff;
+    int64_t lumOffset, chrOffset;
+    // unscaled helpers
+    int32_t shiftY, shiftU, shiftV;   // planarToP01x net shifts
+    int32_t copy_depth_src, copy_depth_dst, copy_shift_src, copy_shift_dst, copy_shiftonly_luma;
+    int32_t dither_mode;              // SwsDither for planarCopy depth reduction
+    int32_t src_range;
+};

@@ -1,0 +1,62 @@
+// Device-side helpers shared by all HIP kernels of libswscale_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "devparams.h"
+
+namespace swsk {
+
+__device__ __forceinline__ int clip_u8(int a) { return min(max(a, 0), 255); }
+__device__ __forceinline__ int clip_u16(int a) { return min(max(a, 0), 65535); }
+__device__ __forceinline__ int clip_i16(int a) { return min(max(a, -32768), 32767); }
+__device__ __forceinline__ int clip_uintp2(int a, int p) { return min(max(a, 0), (1 << p) - 1); }
+
+__device__ __forceinline__ const SwsFramePtrs &frame_of(const SwsFrameSet &fs, int idx)
+{
+    return fs.table ? fs.table[idx] : fs.one;
+}
+
+// ---- closed form of the yuv2rgb LUTs (yuv2rgb.c:680-703, :901-961; colorspace.cpp) ----
+struct ChromaIdx { int r, g, b; };
+__device__ __forceinline__ ChromaIdx lut_chroma(const SwsLutParams &L, int U, int V)
+{
+    const int cu = clip_u8(U), cv = clip_u8(V);
+    ChromaIdx k;
+    k.r = L.base_r + ((cv * L.crv) >> 16);
+    k.g = L.base_g + ((cu * L.cgu) >> 16) + ((cv * L.cgv) >> 16);
+    k.b = L.base_b + ((cu * L.cbu) >> 16);
+    return k;
+}
+__device__ __forceinline__ int lut_luma(const SwsLutParams &L, int k) // y_table[k]
+{
+    return clip_u8((L.yb0r + k * L.cy) >> 16);
+}
+__device__ __forceinline__ uint32_t lut_rgb32(const SwsLutParams &L, const ChromaIdx &k, int Y)
+{
+    return ((uint32_t)lut_luma(L, k.r + Y) << L.rshift) | ((uint32_t)lut_luma(L, k.g + Y) << L.gshift) |
+           ((uint32_t)lut_luma(L, k.b + Y) << L.bshift) | L.alpha_or;
+}
+
+// ordered-dither rows (swscale.c:42-52 ff_dither_8x8_128, :54 sws_pb_64)
+__device__ __constant__ const uint8_t k_dither_8x8_128[8][8] = {
+    {  36, 68,  60, 92,  34, 66,  58, 90 }, { 100,  4, 124, 28,  98,  2, 122, 26 },
+    {  52, 84,  44, 76,  50, 82,  42, 74 }, { 116, 20, 108, 12, 114, 18, 106, 10 },
+    {  32, 64,  56, 88,  38, 70,  62, 94 }, {  96,  0, 120, 24, 102,  6, 126, 30 },
+    {  48, 80,  40, 72,  54, 86,  46, 78 }, { 112, 16, 104,  8, 118, 22, 110, 14 },
+};
+__device__ __forceinline__ int dither8(bool should_dither, int row, int col)
+{
+    return should_dither ? k_dither_8x8_128[row & 7][col & 7] : 64;
+}
+
+// lrintf(av_clipf(65535.0f * x, 0, 65535)) (input.c:1300): round-to-nearest-even like the host default mode
+__device__ __forceinline__ int f32_to_u16(float x)
+{
+    float v = 65535.0f * x;
+    v = fmaxf(v, 0.0f);       // av_clipf_c = FFMIN(FFMAX(a, amin), amax); NaN inputs are unspecified in the reference
+    v = fminf(v, 65535.0f);
+    return __float2int_rn(v);
+}
+
+} // namespace swsk

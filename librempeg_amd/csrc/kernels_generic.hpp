@@ -1,0 +1,413 @@
+// Generic (any supported format / any tap count) kernels: input readers, horizontal stage,
+// vertical stage + output writers.  One thread per output element; used directly for uncommon
+// shapes and as the structural template of the specialised kernels in kernels_fast.hpp.
+//
+// Arithmetic contract: every shift, rounding constant and clip sits at the
+// same point as in the reference's C functions cited next to each routine.
+#pragma once
+#include "kernels_common.hpp"
+
+namespace swsk {
+
+// ------------------------------------------------------------------------------------------
+// input readers (libswscale/input.c): value of the "formatConv" line for component comp
+// (0 = Y, 1 = U, 2 = V) at source row `row` (luma or chroma row), column x.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFramePtrs &f, int comp, int row, int x)
+{
+    switch (p.srcKind) {
+    case SRCK_PLANAR8: {
+        const int pl = comp == 0 ? 0 : comp == 1 ? p.u_plane_src : p.v_plane_src;
+        return f.src[pl][(int64_t)row * f.srcStride[pl] + x];
+    }
+    case SRCK_PLANAR16: {
+        const int pl = comp == 0 ? 0 : comp == 1 ? p.u_plane_src : p.v_plane_src;
+        return *(const uint16_t *)(f.src[pl] + (int64_t)row * f.srcStride[pl] + 2 * x);
+    }
+    case SRCK_NV12: // nv12ToUV_c / nv21ToUV_c, input.c:926-948
+        if (comp == 0) return f.src[0][(int64_t)row * f.srcStride[0] + x];
+        return f.src[1][(int64_t)row * f.srcStride[1] + 2 * x + ((comp == 1) ^ p.uv_swap_src ? 0 : 1)];
+    case SRCK_P010: // p010LEToY_c / p010LEToUV_c, input.c:950-1008
+        if (comp == 0) return *(const uint16_t *)(f.src[0] + (int64_t)row * f.srcStride[0] + 2 * x) >> 6;
+        return *(const uint16_t *)(f.src[1] + (int64_t)row * f.srcStride[1] + 4 * x + (comp == 1 ? 0 : 2)) >> 6;
+    case SRCK_RGB24: { // rgb24ToY_c, rgb24ToUV_c, rgb24ToUV_half_c (and bgr24*), input.c:1068-1172
+        const int srow = comp == 0 ? row : (row << p.chrSrcVSub);
+        const uint8_t *s = f.src[0] + (int64_t)srow * f.srcStride[0];
+        const int32_t *t = p.rgb2yuv;
+        if (comp == 0) {
+            const int r = s[3 * x + p.src_r_pos], g = s[3 * x + 1], b = s[3 * x + p.src_b_pos];
+            return (int16_t)((t[0] * r + t[1] * g + t[2] * b + (32 << 14) + (1 << 8)) >> 9);
+        }
+        const int o = comp == 1 ? 3 : 6;
+        if (p.chr_half) {
+            const int r = s[6 * x + p.src_r_pos] + s[6 * x + 3 + p.src_r_pos], g = s[6 * x + 1] + s[6 * x + 4];
+            const int b = s[6 * x + p.src_b_pos] + s[6 * x + 3 + p.src_b_pos];
+            return (int16_t)((t[o] * r + t[o + 1] * g + t[o + 2] * b + (256 << 15) + (1 << 9)) >> 10);
+        }
+        const int r = s[3 * x + p.src_r_pos], g = s[3 * x + 1], b = s[3 * x + p.src_b_pos];
+        return (int16_t)((t[o] * r + t[o + 1] * g + t[o + 2] * b + (256 << 14) + (1 << 8)) >> 9);
+    }
+    case SRCK_RGB32: { // rgb16_32ToY/UV/UV_half_c_template with the 32-bit parameter rows, input.c:264-393
+        const int srow = comp == 0 ? row : (row << p.chrSrcVSub);
+        const uint8_t *s = f.src[0] + (int64_t)srow * f.srcStride[0];
+        const int32_t *t = p.rgb2yuv;
+        const int S = 15 + 8;
+        if (comp == 0) {
+            const int r = s[4 * x + p.src_r_pos], g = s[4 * x + p.src_g_pos] << 8, b = s[4 * x + p.src_b_pos];
+            const unsigned rnd = (32u << (S - 1)) + (1u << (S - 7));
+            return (int16_t)((int)((t[0] << 8) * r + t[1] * g + (t[2] << 8) * b + rnd) >> (S - 6));
+        }
+        const int o = comp == 1 ? 3 : 6;
+        const int cr = t[o] * (1 << 8), cg = t[o + 1], cb = t[o + 2] * (1 << 8);
+        if (p.chr_half) {
+            const int r = s[8 * x + p.src_r_pos] + s[8 * x + 4 + p.src_r_pos];
+            const int g = (s[8 * x + p.src_g_pos] + s[8 * x + 4 + p.src_g_pos]) << 8;
+            const int b = s[8 * x + p.src_b_pos] + s[8 * x + 4 + p.src_b_pos];
+            const unsigned rnd = (256U << S) + (1 << (S - 6));
+            return (int16_t)((int)(cr * r + cg * g + cb * b + rnd) >> (S - 6 + 1));
+        }
+        const int r = s[4 * x + p.src_r_pos], g = s[4 * x + p.src_g_pos] << 8, b = s[4 * x + p.src_b_pos];
+        const unsigned rnd = (256u << (S - 1)) + (1 << (S - 7));
+        return (int16_t)((int)(cr * r + cg * g + cb * b + rnd) >> (S - 6));
+    }
+    case SRCK_GBRP: { // planar_rgb_to_y / planar_rgb_to_uv input.c:1174-1211; gbr24pToUV_half_c :414-432
+        const uint8_t *G = f.src[0] + (int64_t)row * f.srcStride[0], *B = f.src[1] + (int64_t)row * f.srcStride[1],
+                      *R = f.src[2] + (int64_t)row * f.srcStride[2];
+        const int32_t *t = p.rgb2yuv;
+        if (comp == 0)
+            return (uint16_t)((int)((unsigned)t[0] * R[x] + (unsigned)t[1] * G[x] + (unsigned)t[2] * B[x] + (0x801 << 8)) >> 9);
+        const int o = comp == 1 ? 3 : 6;
+        if (p.chr_half) {
+            const unsigned g = G[2 * x] + G[2 * x + 1], b = B[2 * x] + B[2 * x + 1], r = R[2 * x] + R[2 * x + 1];
+            return (uint16_t)((t[o] * r + t[o + 1] * g + t[o + 2] * b + (0x4001u << 9)) >> 10);
+        }
+        return (uint16_t)((int)((unsigned)t[o] * R[x] + (unsigned)t[o + 1] * G[x] + (unsigned)t[o + 2] * B[x] + (0x4001 << 8)) >> 9);
+    }
+    case SRCK_GBRPF32: { // planar_rgbf32_to_y / _to_uv, input.c:1300-1334
+        const int g = f32_to_u16(*(const float *)(f.src[0] + (int64_t)row * f.srcStride[0] + 4 * x));
+        const int b = f32_to_u16(*(const float *)(f.src[1] + (int64_t)row * f.srcStride[1] + 4 * x));
+        const int r = f32_to_u16(*(const float *)(f.src[2] + (int64_t)row * f.srcStride[2] + 4 * x));
+        const int32_t *t = p.rgb2yuv;
+        if (comp == 0)
+            return (uint16_t)((int)((unsigned)t[0] * r + (unsigned)t[1] * g + (unsigned)t[2] * b + (0x2001u << 14)) >> 15);
+        const int o = comp == 1 ? 3 : 6;
+        return (uint16_t)((int)((unsigned)t[o] * r + (unsigned)t[o + 1] * g + (unsigned)t[o + 2] * b + (0x10001u << 14)) >> 15);
+    }
+    }
+    return 0;
+}
+
+// range conversion of one intermediate sample (lum/chrRange{To,From}Jpeg(16)_c, swscale.c:163-255)
+__device__ __forceinline__ int range_sample(const SwsDevParams &p, int v, int chroma)
+{
+    if (!p.range_active) return v;
+    if (!p.wide) {
+        const uint16_t coeff = (uint16_t)(chroma ? p.chrCoeff : p.lumCoeff);
+        const int32_t offset = (int32_t)(chroma ? p.chrOffset : p.lumOffset);
+        int r = (v * coeff + offset) >> 14;
+        if (p.range_to_jpeg) r = min(r, (1 << 15) - 1);
+        return (int16_t)r;
+    }
+    const uint32_t coeff = chroma ? p.chrCoeff : p.lumCoeff;
+    const int64_t offset = chroma ? p.chrOffset : p.lumOffset;
+    int r = (int)(((int64_t)v * coeff + offset) >> 18);
+    if (p.range_to_jpeg) r = min(r, (1 << 19) - 1);
+    return r;
+}
+
+// horizontal stage for one output sample (hScale8To15_c / 8To19 / 16To15 / 16To19, swscale.c:69-159)
+__device__ __forceinline__ int hscale_sample(const SwsDevParams &p, const SwsFramePtrs &f, int comp, int row, int x)
+{
+    const int16_t *filter = comp == 0 ? p.hLumF : p.hChrF;
+    const int32_t *pos = comp == 0 ? p.hLumPos : p.hChrPos;
+    const int fs = comp == 0 ? p.hLumFs : p.hChrFs;
+    const int sp = pos[x];
+    int val = 0;
+    for (int j = 0; j < fs; j++) val += read_sample(p, f, comp, row, sp + j) * filter[fs * x + j];
+    int r = min(val >> p.hshift, p.hclip);
+    if (!p.wide) r = (int16_t)r;
+    return range_sample(p, r, comp != 0);
+}
+
+// ---- samplers: where the vertical stage gets h-scaled samples from ----
+template <typename T> struct ScratchSampler { // pass-1 output in HBM
+    const T *lum, *u, *v; int lumW, chrW;
+    __device__ __forceinline__ int get(int comp, int row, int x) const
+    {
+        return comp == 0 ? lum[(int64_t)row * lumW + x] : comp == 1 ? u[(int64_t)row * chrW + x] : v[(int64_t)row * chrW + x];
+    }
+};
+struct DirectSampler { // horizontal filters are 1-tap identity: compute the sample on the fly
+    const SwsDevParams *p; const SwsFramePtrs *f;
+    __device__ __forceinline__ int get(int comp, int row, int x) const
+    {
+        int r = min((read_sample(*p, *f, comp, row, x) * 16384) >> p->hshift, p->hclip);
+        if (!p->wide) r = (int16_t)r;
+        return range_sample(*p, r, comp != 0);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// pass 1: reader + hscale + range -> scratch planes
+// grid: x over output columns, y over source rows, z = frame * 3 + comp
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) sws_k_hscale(SwsFrameSet fs, SwsDevParams p, T *scratch, int64_t frame_elems)
+{
+    const int comp = blockIdx.z % 3, fi = blockIdx.z / 3;
+    const int W = comp == 0 ? p.dstW : p.chrDstW, H = comp == 0 ? p.srcH : p.chrSrcH;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    if (x >= W || row >= H) return;
+    const SwsFramePtrs &f = frame_of(fs, fi);
+    T *base = scratch + fi * frame_elems;
+    const int64_t lumElems = (int64_t)p.srcH * p.dstW, chrElems = (int64_t)p.chrSrcH * p.chrDstW;
+    T *plane = comp == 0 ? base : comp == 1 ? base + lumElems : base + lumElems + chrElems;
+    plane[(int64_t)row * W + x] = (T)hscale_sample(p, f, comp, row, x);
+}
+
+// ------------------------------------------------------------------------------------------
+// vertical stage + planar writers (lum_planar_vscale / chr_planar_vscale vscale.c:41-107,
+// writers output.c:149-187, :327-357, :468-493, :538-569)
+// comp 0 -> luma plane, 1/2 -> separate chroma planes (planar YUV only)
+// ------------------------------------------------------------------------------------------
+template <typename S>
+__device__ __forceinline__ void planar_write_one(const SwsDevParams &p, const S &smp, const SwsFramePtrs &f, int comp, int x, int y)
+{
+    const int16_t *vf; int fs, first, srcRows, plane;
+    if (comp == 0) { fs = p.vLumFs; vf = p.vLumF + y * fs; first = max(1 - fs, p.vLumPos[y]); srcRows = p.srcH; plane = 0; }
+    else { fs = p.vChrFs; vf = p.vChrF + y * fs; first = max(1 - fs, p.vChrPos[y]); srcRows = p.chrSrcH;
+           plane = comp == 1 ? p.u_plane_dst : p.v_plane_dst; }
+    uint8_t *drow = f.dst[plane] + (int64_t)y * f.dstStride[plane];
+    const int bits = p.dst_bits;
+    if (p.dstKind == DSTK_P010) { // luma of P010: yuv2p01xl1_c / yuv2p01xlX_c
+        uint16_t *d = (uint16_t *)drow;
+        if (fs == 1) {
+            const int shift = 15 - bits;
+            d[x] = (uint16_t)(clip_uintp2((smp.get(comp, min(first, srcRows - 1), x) + (1 << (shift - 1))) >> shift, bits) << p.dst_shift);
+        } else {
+            const int shift = 11 + 16 - bits;
+            int val = 1 << (shift - 1);
+            for (int j = 0; j < fs; j++) val += smp.get(comp, min(first + j, srcRows - 1), x) * vf[j];
+            d[x] = (uint16_t)(clip_uintp2(val >> shift, bits) << p.dst_shift);
+        }
+    } else if (p.dstKind == DSTK_PLANAR16) {
+        uint16_t *d = (uint16_t *)drow;
+        if (fs == 1) {
+            d[x] = (uint16_t)clip_u16((smp.get(comp, min(first, srcRows - 1), x) + 4) >> 3);
+        } else {
+            int val = (1 << 14) - 0x40000000;
+            for (int j = 0; j < fs; j++) val += (int)((unsigned)smp.get(comp, min(first + j, srcRows - 1), x) * (unsigned)(int)vf[j]);
+            d[x] = (uint16_t)(0x8000 + clip_i16(val >> 15));
+        }
+    } else if (p.dstKind == DSTK_PLANARN) {
+        uint16_t *d = (uint16_t *)drow;
+        if (fs == 1) {
+            const int shift = 15 - bits;
+            d[x] = (uint16_t)clip_uintp2((smp.get(comp, min(first, srcRows - 1), x) + (1 << (shift - 1))) >> shift, bits);
+        } else {
+            const int shift = 11 + 16 - bits;
+            int val = 1 << (shift - 1);
+            for (int j = 0; j < fs; j++) val += smp.get(comp, min(first + j, srcRows - 1), x) * vf[j];
+            d[x] = (uint16_t)clip_uintp2(val >> shift, bits);
+        }
+    } else { // 8 bit (also the luma plane of NV12)
+        const int off = comp == 2 ? 3 : 0; // V plane uses dither offset 3 (vscale.c:99-102)
+        const int dv = dither8(p.should_dither, y, x + off);
+        if (fs == 1) {
+            drow[x] = (uint8_t)clip_u8((smp.get(comp, min(first, srcRows - 1), x) + dv) >> 7);
+        } else {
+            int val = dv << 12;
+            for (int j = 0; j < fs; j++) val += (int)(unsigned)(smp.get(comp, min(first + j, srcRows - 1), x) * vf[j]);
+            drow[x] = (uint8_t)clip_u8(val >> 19);
+        }
+    }
+}
+
+// interleaved chroma writers: yuv2nv12cX_c (output.c:495-528), yuv2p01xcX_c (:571-589)
+template <typename S>
+__device__ __forceinline__ void nv_chroma_write_one(const SwsDevParams &p, const S &smp, const SwsFramePtrs &f, int x, int cy)
+{
+    const int fs = p.vChrFs;
+    const int16_t *vf = p.vChrF + cy * fs;
+    const int first = max(1 - fs, p.vChrPos[cy]);
+    uint8_t *drow = f.dst[1] + (int64_t)cy * f.dstStride[1];
+    if (p.dstKind == DSTK_P010) {
+        const int bits = p.dst_bits, shift = 11 + 16 - bits;
+        int u = 1 << (shift - 1), v = 1 << (shift - 1);
+        for (int j = 0; j < fs; j++) {
+            const int r = min(first + j, p.chrSrcH - 1);
+            u += (int)((unsigned)smp.get(1, r, x) * (unsigned)(int)vf[j]);
+            v += (int)((unsigned)smp.get(2, r, x) * (unsigned)(int)vf[j]);
+        }
+        uint16_t *d = (uint16_t *)drow;
+        d[2 * x] = (uint16_t)(clip_uintp2(u >> shift, bits) << p.dst_shift);
+        d[2 * x + 1] = (uint16_t)(clip_uintp2(v >> shift, bits) << p.dst_shift);
+    } else {
+        int u = dither8(p.should_dither, cy, x) << 12, v = dither8(p.should_dither, cy, x + 3) << 12;
+        for (int j = 0; j < fs; j++) {
+            const int r = min(first + j, p.chrSrcH - 1);
+            u += (int)((unsigned)smp.get(1, r, x) * (unsigned)(int)vf[j]);
+            v += (int)((unsigned)smp.get(2, r, x) * (unsigned)(int)vf[j]);
+        }
+        drow[2 * x + p.uv_swap_dst] = (uint8_t)clip_u8(u >> 19);
+        drow[2 * x + 1 - p.uv_swap_dst] = (uint8_t)clip_u8(v >> 19);
+    }
+}
+
+// packed RGB: packed_vscale (vscale.c:109-171) choosing yuv2rgb_{1,2,X}_c_template (output.c:1788-1939)
+// or yuv2rgb_full_{1,2,X}_c_template (output.c:2163-2312); unit = pixel pair (LUT) or pixel (full chroma)
+template <typename S>
+__device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &smp, const SwsFramePtrs &f, int i, int y)
+{
+    const int cy = y >> p.chrDstVSub;
+    const int lfs = p.vLumFs, cfs = p.vChrFs;
+    const int16_t *lf = p.vLumF + y * lfs, *cf = p.vChrF + cy * cfs;
+    const int firstL = max(1 - lfs, p.vLumPos[y]), firstC = max(1 - cfs, p.vChrPos[cy]);
+    const int lH = p.srcH - 1, cH = p.chrSrcH - 1;
+    uint8_t *drow = f.dst[0] + (int64_t)y * f.dstStride[0];
+    const SwsLutParams &L = p.lut;
+    int mode = 0, ua = 0, ya = 0; // 1: packed1, 2: packed2, 0: X
+    if (lfs == 1 && cfs == 1) { mode = 1; }
+    else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 1; ua = (uint16_t)cf[1]; }
+    else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
+             (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 2; ya = (uint16_t)lf[1]; ua = (uint16_t)cf[1]; }
+#define LUM(j, xx) smp.get(0, min(firstL + (j), lH), (xx))
+#define CHU(j, xx) smp.get(1, min(firstC + (j), cH), (xx))
+#define CHV(j, xx) smp.get(2, min(firstC + (j), cH), (xx))
+    if (!p.full_chr) {
+        int Y1, Y2, U, V;
+        if (mode == 0) {
+            Y1 = Y2 = U = V = 1 << 18;
+            for (int j = 0; j < lfs; j++) {
+                Y1 += (int)((unsigned)LUM(j, 2 * i) * (unsigned)(int)lf[j]);
+                Y2 += (int)((unsigned)LUM(j, 2 * i + 1) * (unsigned)(int)lf[j]);
+            }
+            for (int j = 0; j < cfs; j++) {
+                U += (int)((unsigned)CHU(j, i) * (unsigned)(int)cf[j]);
+                V += (int)((unsigned)CHV(j, i) * (unsigned)(int)cf[j]);
+            }
+            Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
+        } else if (mode == 2) {
+            const int ya1 = 4096 - ya, ua1 = 4096 - ua;
+            Y1 = (LUM(0, 2 * i) * ya1 + LUM(1, 2 * i) * ya) >> 19;
+            Y2 = (LUM(0, 2 * i + 1) * ya1 + LUM(1, 2 * i + 1) * ya) >> 19;
+            U = (CHU(0, i) * ua1 + CHU(1, i) * ua) >> 19;
+            V = (CHV(0, i) * ua1 + CHV(1, i) * ua) >> 19;
+        } else {
+            Y1 = (LUM(0, 2 * i) + 64) >> 7;
+            Y2 = (LUM(0, 2 * i + 1) + 64) >> 7;
+            if (ua == 0) { U = (CHU(0, i) + 64) >> 7; V = (CHV(0, i) + 64) >> 7; }
+            else {
+                const int ua1 = 4096 - ua;
+                U = (CHU(0, i) * ua1 + CHU(1, i) * ua + (128 << 11)) >> 19;
+                V = (CHV(0, i) * ua1 + CHV(1, i) * ua + (128 << 11)) >> 19;
+            }
+        }
+        const ChromaIdx k = lut_chroma(L, U, V);
+        if (p.dstKind == DSTK_RGB32) {
+            uint32_t *d = (uint32_t *)drow;
+            d[2 * i] = lut_rgb32(L, k, Y1);
+            d[2 * i + 1] = lut_rgb32(L, k, Y2);
+        } else {
+            uint8_t *d = drow + 6 * i;
+            const int k0 = L.rgb_order ? k.b : k.r, k2 = L.rgb_order ? k.r : k.b;
+            d[0] = (uint8_t)lut_luma(L, k0 + Y1); d[1] = (uint8_t)lut_luma(L, k.g + Y1); d[2] = (uint8_t)lut_luma(L, k2 + Y1);
+            d[3] = (uint8_t)lut_luma(L, k0 + Y2); d[4] = (uint8_t)lut_luma(L, k.g + Y2); d[5] = (uint8_t)lut_luma(L, k2 + Y2);
+        }
+    } else {
+        int Y, U, V;
+        if (mode == 0) {
+            Y = 1 << 9; U = (1 << 9) - (128 << 19); V = (1 << 9) - (128 << 19);
+            for (int j = 0; j < lfs; j++) Y += (int)((unsigned)LUM(j, i) * (unsigned)(int)lf[j]);
+            for (int j = 0; j < cfs; j++) {
+                U += (int)((unsigned)CHU(j, i) * (unsigned)(int)cf[j]);
+                V += (int)((unsigned)CHV(j, i) * (unsigned)(int)cf[j]);
+            }
+            Y >>= 10; U >>= 10; V >>= 10;
+        } else if (mode == 2) {
+            const int ya1 = 4096 - ya, ua1 = 4096 - ua;
+            Y = (LUM(0, i) * ya1 + LUM(1, i) * ya) >> 10;
+            U = (CHU(0, i) * ua1 + CHU(1, i) * ua - (128 << 19)) >> 10;
+            V = (CHV(0, i) * ua1 + CHV(1, i) * ua - (128 << 19)) >> 10;
+        } else {
+            Y = LUM(0, i) * 4;
+            if (ua == 0) { U = (CHU(0, i) - (128 << 7)) * 4; V = (CHV(0, i) - (128 << 7)) * 4; }
+            else {
+                const int ua1 = 4096 - ua;
+                U = (CHU(0, i) * ua1 + CHU(1, i) * ua - (128 << 19)) >> 10;
+                V = (CHV(0, i) * ua1 + CHV(1, i) * ua - (128 << 19)) >> 10;
+            }
+        }
+        // yuv2rgb_write_full, output.c:2005-2070 (8-bit-per-channel targets, no dithering)
+        Y -= L.y_offset;
+        Y = (int)((unsigned)Y * (unsigned)L.y_coeff);
+        Y = (int)((unsigned)Y + (1u << 21));
+        int R = (int)((unsigned)Y + (unsigned)V * (unsigned)L.v2r);
+        int G = (int)((unsigned)Y + (unsigned)V * (unsigned)L.v2g + (unsigned)U * (unsigned)L.u2g);
+        int B = (int)((unsigned)Y + (unsigned)U * (unsigned)L.u2b);
+        if ((R | G | B) & 0xC0000000) { R = clip_uintp2(R, 30); G = clip_uintp2(G, 30); B = clip_uintp2(B, 30); }
+        uint8_t *d = drow + L.pix_step * i;
+        d[L.r_pos] = (uint8_t)(R >> 22); d[L.g_pos] = (uint8_t)(G >> 22); d[L.b_pos] = (uint8_t)(B >> 22);
+        if (L.pix_step == 4) d[L.a_pos] = 255;
+    }
+#undef LUM
+#undef CHU
+#undef CHV
+}
+
+// ---- pass-2 / fused kernels over the generic per-element routines ----
+// DIRECT = true : horizontal filters are identity, samples are computed on the fly (single pass)
+// DIRECT = false: samples come from the pass-1 scratch planes
+template <bool DIRECT, typename T>
+struct SamplerFor {
+    static __device__ __forceinline__ auto make(const SwsDevParams &p, const SwsFramePtrs &f, const T *scratch, int64_t frame_elems, int fi)
+    {
+        if constexpr (DIRECT) {
+            return DirectSampler{&p, &f};
+        } else {
+            const T *base = scratch + fi * frame_elems;
+            const int64_t lumElems = (int64_t)p.srcH * p.dstW, chrElems = (int64_t)p.chrSrcH * p.chrDstW;
+            return ScratchSampler<T>{base, base + lumElems, base + lumElems + chrElems, p.dstW, p.chrDstW};
+        }
+    }
+};
+
+// planar: grid x over columns, y over output rows of that plane, z = frame * ncomp + comp
+template <bool DIRECT, typename T>
+__global__ void __launch_bounds__(256) sws_k_vscale_planar(SwsFrameSet fs, SwsDevParams p, const T *scratch, int64_t frame_elems, int ncomp)
+{
+    const int comp = blockIdx.z % ncomp, fi = blockIdx.z / ncomp;
+    const int W = comp == 0 ? p.dstW : p.chrDstW, H = comp == 0 ? p.dstH : p.chrDstH;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    const SwsFramePtrs &f = frame_of(fs, fi);
+    const auto smp = SamplerFor<DIRECT, T>::make(p, f, scratch, frame_elems, fi);
+    planar_write_one(p, smp, f, comp, x, y);
+}
+
+// semi-planar chroma: grid x over chroma columns, y over chroma rows, z = frame
+template <bool DIRECT, typename T>
+__global__ void __launch_bounds__(256) sws_k_vscale_nvchroma(SwsFrameSet fs, SwsDevParams p, const T *scratch, int64_t frame_elems)
+{
+    const int fi = blockIdx.z;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, cy = blockIdx.y;
+    if (x >= p.chrDstW || cy >= p.chrDstH) return;
+    const SwsFramePtrs &f = frame_of(fs, fi);
+    const auto smp = SamplerFor<DIRECT, T>::make(p, f, scratch, frame_elems, fi);
+    nv_chroma_write_one(p, smp, f, x, cy);
+}
+
+// packed RGB: grid x over units (pixel pairs, or pixels with full chroma), y over rows, z = frame
+template <bool DIRECT, typename T>
+__global__ void __launch_bounds__(256) sws_k_vscale_rgb(SwsFrameSet fs, SwsDevParams p, const T *scratch, int64_t frame_elems)
+{
+    const int fi = blockIdx.z;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int units = p.full_chr ? p.dstW : (p.dstW + 1) >> 1;
+    if (i >= units || y >= p.dstH) return;
+    const SwsFramePtrs &f = frame_of(fs, fi);
+    const auto smp = SamplerFor<DIRECT, T>::make(p, f, scratch, frame_elems, fi);
+    rgb_write_unit(p, smp, f, i, y);
+}
+
+} // namespace swsk

@@ -1,0 +1,88 @@
+// Pixel-format descriptor rows and predicates for the formats on the hot path.
+// Rows follow libavutil/pixdesc.c (:204 yuv420p, :261 rgb24, :567 nv12, :1440 yuv420p10le,
+// :1656 yuv444p16le, :2352 p010le, :2529 gbrpf32le ...); predicates follow
+// libswscale/swscale_internal.h:746-988.
+#include "swsint.hpp"
+
+namespace swship {
+
+static const PixDesc g_descs[] = {
+    { AV_PIX_FMT_YUV420P,  "yuv420p",  3, 1, 1, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8},{0,0,0,0,0}}, PIXFLAG_PLANAR },
+    { AV_PIX_FMT_YUVJ420P, "yuvj420p", 3, 1, 1, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8},{0,0,0,0,0}}, PIXFLAG_PLANAR },
+    { AV_PIX_FMT_YUV422P,  "yuv422p",  3, 1, 0, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8},{0,0,0,0,0}}, PIXFLAG_PLANAR },
+    { AV_PIX_FMT_YUV444P,  "yuv444p",  3, 0, 0, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8},{0,0,0,0,0}}, PIXFLAG_PLANAR },
+    { AV_PIX_FMT_NV12,     "nv12",     3, 1, 1, {{0,1,0,0,8},{1,2,0,0,8},{1,2,1,0,8},{0,0,0,0,0}}, PIXFLAG_PLANAR },
+    { AV_PIX_FMT_NV21,     "nv21",     3, 1, 1, {{0,1,0,0,8},{1,2,1,0,8},{1,2,0,0,8},{0,0,0,0,0}}, PIXFLAG_PLANAR },
+    { AV_PIX_FMT_YUV420P10LE, "yuv420p10le", 3, 1, 1, {{0,2,0,0,10},{1,2,0,0,10},{2,2,0,0,10},{0,0,0,0,0}}, PIXFLAG_PLANAR },
+    { AV_PIX_FMT_YUV444P10LE, "yuv444p10le", 3, 0, 0, {{0,2,0,0,10},{1,2,0,0,10},{2,2,0,0,10},{0,0,0,0,0}}, PIXFLAG_PLANAR },
+    { AV_PIX_FMT_YUV420P16LE, "yuv420p16le", 3, 1, 1, {{0,2,0,0,16},{1,2,0,0,16},{2,2,0,0,16},{0,0,0,0,0}}, PIXFLAG_PLANAR },
+    { AV_PIX_FMT_YUV444P16LE, "yuv444p16le", 3, 0, 0, {{0,2,0,0,16},{1,2,0,0,16},{2,2,0,0,16},{0,0,0,0,0}}, PIXFLAG_PLANAR },
+    { AV_PIX_FMT_P010LE,   "p010le",   3, 1, 1, {{0,2,0,6,10},{1,4,0,6,10},{1,4,2,6,10},{0,0,0,0,0}}, PIXFLAG_PLANAR },
+    { AV_PIX_FMT_RGB24,    "rgb24",    3, 0, 0, {{0,3,0,0,8},{0,3,1,0,8},{0,3,2,0,8},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_BGR24,    "bgr24",    3, 0, 0, {{0,3,2,0,8},{0,3,1,0,8},{0,3,0,0,8},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_ARGB,     "argb",     4, 0, 0, {{0,4,1,0,8},{0,4,2,0,8},{0,4,3,0,8},{0,4,0,0,8}}, PIXFLAG_RGB | PIXFLAG_ALPHA },
+    { AV_PIX_FMT_RGBA,     "rgba",     4, 0, 0, {{0,4,0,0,8},{0,4,1,0,8},{0,4,2,0,8},{0,4,3,0,8}}, PIXFLAG_RGB | PIXFLAG_ALPHA },
+    { AV_PIX_FMT_ABGR,     "abgr",     4, 0, 0, {{0,4,3,0,8},{0,4,2,0,8},{0,4,1,0,8},{0,4,0,0,8}}, PIXFLAG_RGB | PIXFLAG_ALPHA },
+    { AV_PIX_FMT_BGRA,     "bgra",     4, 0, 0, {{0,4,2,0,8},{0,4,1,0,8},{0,4,0,0,8},{0,4,3,0,8}}, PIXFLAG_RGB | PIXFLAG_ALPHA },
+    { AV_PIX_FMT_0RGB,     "0rgb",     3, 0, 0, {{0,4,1,0,8},{0,4,2,0,8},{0,4,3,0,8},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_RGB0,     "rgb0",     3, 0, 0, {{0,4,0,0,8},{0,4,1,0,8},{0,4,2,0,8},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_0BGR,     "0bgr",     3, 0, 0, {{0,4,3,0,8},{0,4,2,0,8},{0,4,1,0,8},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_BGR0,     "bgr0",     3, 0, 0, {{0,4,2,0,8},{0,4,1,0,8},{0,4,0,0,8},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_GBRP,     "gbrp",     3, 0, 0, {{2,1,0,0,8},{0,1,0,0,8},{1,1,0,0,8},{0,0,0,0,0}}, PIXFLAG_PLANAR | PIXFLAG_RGB },
+    { AV_PIX_FMT_GBRPF32LE,"gbrpf32le",3, 0, 0, {{2,4,0,0,32},{0,4,0,0,32},{1,4,0,0,32},{0,0,0,0,0}}, PIXFLAG_PLANAR | PIXFLAG_RGB | PIXFLAG_FLOAT },
+};
+
+const PixDesc *pix_desc(int fmt)
+{
+    for (const PixDesc &d : g_descs)
+        if (d.fmt == fmt) return &d;
+    return nullptr;
+}
+
+int pix_bits_per_pixel(const PixDesc *d) // av_get_bits_per_pixel
+{
+    int bits = 0;
+    const int log2_pixels = d->log2_chroma_w + d->log2_chroma_h;
+    for (int c = 0; c < d->nb_components; c++)
+        bits += d->comp[c].depth << ((c == 1 || c == 2) ? 0 : log2_pixels);
+    return bits >> log2_pixels;
+}
+
+int pix_nb_planes(const PixDesc *d)
+{
+    int n = 0;
+    for (int c = 0; c < d->nb_components; c++)
+        if (d->comp[c].plane + 1 > n) n = d->comp[c].plane + 1;
+    return n;
+}
+
+bool is16BPS(int f) { return pix_desc(f)->comp[0].depth == 16; }
+bool isNBPS(int f) { const int d = pix_desc(f)->comp[0].depth; return d >= 9 && d <= 14; }
+bool isYUV(int f) { const PixDesc *d = pix_desc(f); return !(d->flags & PIXFLAG_RGB) && d->nb_components >= 2; }
+bool isPlanarYUV(int f) { return (pix_desc(f)->flags & PIXFLAG_PLANAR) && isYUV(f); }
+bool isSemiPlanarYUV(int f) { const PixDesc *d = pix_desc(f); return isPlanarYUV(f) && d->comp[1].plane == d->comp[2].plane; }
+bool isAnyRGB(int f) { return (pix_desc(f)->flags & PIXFLAG_RGB) != 0; }
+bool isGray(int f) { return pix_desc(f)->nb_components <= 2; }
+bool isFloatFmt(int f) { return (pix_desc(f)->flags & PIXFLAG_FLOAT) != 0; }
+bool isALPHA(int f) { return (pix_desc(f)->flags & PIXFLAG_ALPHA) != 0; }
+bool isPlanarRGB(int f) { return (pix_desc(f)->flags & (PIXFLAG_PLANAR | PIXFLAG_RGB)) == (PIXFLAG_PLANAR | PIXFLAG_RGB); }
+bool isPackedFmt(int f) { const PixDesc *d = pix_desc(f); return d->nb_components >= 2 && !(d->flags & PIXFLAG_PLANAR); }
+bool isPlanarFmt(int f) { const PixDesc *d = pix_desc(f); return d->nb_components >= 2 && (d->flags & PIXFLAG_PLANAR); }
+bool isSwappedChroma(int f)
+{
+    const PixDesc *d = pix_desc(f);
+    if (!isYUV(f) || d->nb_components < 3) return false;
+    if (!isPlanarYUV(f) || isSemiPlanarYUV(f)) return d->comp[1].offset > d->comp[2].offset;
+    return d->comp[1].plane > d->comp[2].plane;
+}
+bool isDataInHighBits(int f)
+{
+    const PixDesc *d = pix_desc(f);
+    for (int i = 0; i < d->nb_components; i++) {
+        if (!d->comp[i].shift) return false;
+        if ((d->comp[i].shift + d->comp[i].depth) & 7) return false;
+    }
+    return true;
+}
+
+} // namespace swship

@@ -1,0 +1,113 @@
+// Internal declarations of libswscale_hip (host side).  Product code: never includes or
+// links anything from oracle/.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <string>
+#include <vector>
+
+#include "../../include/swscale_hip.h"
+#include "devparams.h"
+
+namespace swship {
+
+// ---- pixel format descriptors (subset of libavutil/pixdesc.c) ----
+struct CompDesc { int plane, step, offset, shift, depth; };
+struct PixDesc {
+    int fmt; const char *name; int nb_components; int log2_chroma_w, log2_chroma_h;
+    CompDesc comp[4]; unsigned flags;
+};
+enum : unsigned { PIXFLAG_BE = 1u << 0, PIXFLAG_PLANAR = 1u << 4, PIXFLAG_RGB = 1u << 5,
+                  PIXFLAG_ALPHA = 1u << 7, PIXFLAG_FLOAT = 1u << 9 };
+const PixDesc *pix_desc(int fmt);
+int  pix_bits_per_pixel(const PixDesc *d);
+int  pix_nb_planes(const PixDesc *d);
+// predicates, libswscale/swscale_internal.h:746-988
+bool is16BPS(int f); bool isNBPS(int f); bool isYUV(int f); bool isPlanarYUV(int f);
+bool isSemiPlanarYUV(int f); bool isAnyRGB(int f); bool isGray(int f); bool isFloatFmt(int f);
+bool isALPHA(int f); bool isPlanarRGB(int f); bool isPackedFmt(int f); bool isPlanarFmt(int f);
+bool isSwappedChroma(int f); bool isDataInHighBits(int f);
+
+// ---- polyphase filter bank (libswscale/utils.c:197-612) ----
+struct FilterBank {
+    std::vector<int16_t> taps;   // count * size (+3 replicated rows like the reference)
+    std::vector<int32_t> pos;    // count (+3)
+    int size = 0, count = 0;
+};
+enum { FILTER_OK = 0, FILTER_ERR = -1, FILTER_USE_CASCADE = -12345 };
+int build_filter_bank(FilterBank &out, int xInc, int srcW, int dstW, int filterAlign, int one,
+                      int scaler, int flags, const double param[2], int srcPos, int dstPos);
+
+// ---- colour tables ----
+struct Yuv2RgbLut {          // closed form of ff_yuv2rgb_c_init_tables (yuv2rgb.c:717-973)
+    bool valid = false;
+    int64_t cy = 0, yb0 = 0;  // y_table[k] = clip8((yb0 + k*cy + 0x8000) >> 16)
+    int64_t crv = 0, cbu = 0, cgu = 0, cgv = 0; // already divided by cy
+    int yoffs = 0;
+    int y_offset = 0, y_coeff = 0, v2r = 0, v2g = 0, u2g = 0, u2b = 0; // 13-bit coeffs for full-chroma writers
+};
+void build_yuv2rgb(Yuv2RgbLut &l, const int inv_table[4], int fullRange, int brightness, int contrast, int saturation);
+void build_rgb2yuv(int32_t out[9], const int table[4]);   // utils.c:614-706
+struct RangeConv { bool active = false; uint32_t lumCoeff = 0, chrCoeff = 0; int64_t lumOffset = 0, chrOffset = 0; };
+void build_range_conv(RangeConv &r, int src_range, int dst_range, int dstFormat, int dstBpc); // swscale.c:577-660
+const int *yuv2rgb_coeffs(int colorspace);                 // yuv2rgb.c:47-66
+
+// ---- execution plan chosen at init (which kernels run) ----
+enum PlanKind {
+    PLAN_NONE = 0,
+    PLAN_UNSC_YUV2RGB,     // yuv2rgb_c_* (yuv2rgb.c:68-559)
+    PLAN_UNSC_P01X,        // planarToP01xWrapper
+    PLAN_UNSC_8_P01X,      // planar8ToP01xleWrapper
+    PLAN_UNSC_PLANAR2NV12, // planarToNv12Wrapper
+    PLAN_UNSC_NV122PLANAR, // nv12ToPlanarWrapper
+    PLAN_UNSC_PLANARCOPY,  // planarCopyWrapper
+    PLAN_MAIN,             // ff_swscale chain
+    PLAN_CASCADE,          // two contexts through an intermediate image
+};
+
+struct DeviceState;  // HIP side (device.cpp)
+
+struct SwsInternal {
+    SwsContext opts;          // MUST be first: the public struct (swscale_internal.h:337-340 idiom)
+    uint32_t magic;
+    bool legacy_init = false;
+    int src0Alpha = 0, dst0Alpha = 0;
+    int brightness = 0, contrast = 0, saturation = 0;
+    int srcColorspaceTable[4] = {0}, dstColorspaceTable[4] = {0};
+    int dstFormatBpp = 0, srcFormatBpp = 0;
+    int chrSrcHSubSample = 0, chrSrcVSubSample = 0, chrDstHSubSample = 0, chrDstVSubSample = 0;
+    int chrSrcW = 0, chrSrcH = 0, chrDstW = 0, chrDstH = 0;
+    int srcBpc = 0, dstBpc = 0;
+    int lumXInc = 0, lumYInc = 0, chrXInc = 0, chrYInc = 0;
+    int dst_slice_align = 1;
+    int needAlpha = 0;
+    PlanKind plan = PLAN_NONE;
+    FilterBank hLum, hChr, vLum, vChr;
+    int32_t rgb2yuv[9] = {0};
+    Yuv2RgbLut lut;
+    RangeConv range;
+    SwsInternal *cascade[2] = {nullptr, nullptr};
+    int cascade_fmt = -1, cascade_w = 0, cascade_h = 0;
+    std::string path_name, kernel_name;
+    DeviceState *dev = nullptr;
+    bool tables_dirty = true;  // device copies need refresh
+};
+
+inline SwsInternal *internal(SwsContext *c) { return reinterpret_cast<SwsInternal *>(c); }
+inline const SwsInternal *internal(const SwsContext *c) { return reinterpret_cast<const SwsInternal *>(c); }
+
+int  init_single_context(SwsInternal *c);   // utils.c:1137-1835
+void choose_unscaled(SwsInternal *c);       // swscale_unscaled.c:2392-2706
+void log_msg(const SwsInternal *c, int level, const char *fmt, ...);
+
+// ---- device side (device.cpp / kernels.hip) ----
+int  dev_prepare(SwsInternal *c);                         // upload tables, build DevParams
+void dev_release(SwsInternal *c);
+int  dev_run(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4], int srcSliceY, int srcSliceH,
+             uint8_t *const dst[4], const int dstStride[4], int nb_frames,
+             const SwsFrameView *const *srcFrames, SwsFrameView *const *dstFrames);
+size_t tables_blob_size(const SwsInternal *c);
+int  tables_blob_export(const SwsInternal *c, void *buf, size_t size);
+int  tables_blob_import(SwsInternal *c, const void *buf, size_t size);
+
+} // namespace swship

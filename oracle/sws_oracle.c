@@ -1068,10 +1068,10 @@ static int unscaled_planarcopy(OrSws *c, const uint8_t *const src[], const int s
                         unsigned v;
                         if (c->o.dither == 0) {
                             if (body) { tmp = ((srcPtr2[j] >> src_shift) + bias) >> shift; v = (tmp - (tmp >> dst_depth)) << dst_shift; }
-                            else { tmp = (srcPtr2[j] + bias) >> shift; v = tmp - ((tmp >> dst_depth) << dst_shift); }
+                            else { tmp = (srcPtr2[j] + bias) >> shift; v = (tmp - (tmp >> dst_depth)) << dst_shift; /* '-' binds tighter than '<<' */ }
                         } else if (shiftonly) {
                             if (body) { tmp = ((srcPtr2[j] >> src_shift) + dither[j & 7]) >> shift; v = (tmp - (tmp >> dst_depth)) << dst_shift; }
-                            else { tmp = (srcPtr2[j] + dither[j & 7]) >> shift; v = tmp - ((tmp >> dst_depth) << dst_shift); }
+                            else { tmp = (srcPtr2[j] + dither[j & 7]) >> shift; v = (tmp - (tmp >> dst_depth)) << dst_shift; /* '-' binds tighter than '<<' */ }
                         } else {
                             if (body) { tmp = srcPtr2[j] >> src_shift; v = ((tmp - (tmp >> dst_depth) + dither[j & 7]) >> shift) << dst_shift; }
                             else { tmp = srcPtr2[j]; v = (tmp - (tmp >> dst_depth) + dither[j & 7]) >> shift; }
