@@ -8,6 +8,11 @@
 namespace swsk {
 
 __device__ __forceinline__ int clip_u8(int a) { return min(max(a, 0), 255); }
+// clip_u8(x >> sh), written as clamp-then-shift.  hipcc 7.2 pattern-matches sat_u8(x >> sh) pairs into the new
+// gfx950 instruction v_ashr_pk_u8_i32 and then ORs further bytes into the upper half of its result, but the
+// instruction leaves stale data in bits 31:16 -> corrupted 3rd/4th bytes (caught by the parity tests against
+// the oracle).  Clamping first is arithmetically identical and does not match that pattern.
+__device__ __forceinline__ int clip_u8_shr(int x, int sh) { return min(max(x, 0), (256 << sh) - 1) >> sh; }
 __device__ __forceinline__ int clip_u16(int a) { return min(max(a, 0), 65535); }
 __device__ __forceinline__ int clip_i16(int a) { return min(max(a, -32768), 32767); }
 __device__ __forceinline__ int clip_uintp2(int a, int p) { return min(max(a, 0), (1 << p) - 1); }
@@ -30,7 +35,7 @@ __device__ __forceinline__ ChromaIdx lut_chroma(const SwsLutParams &L, int U, in
 }
 __device__ __forceinline__ int lut_luma(const SwsLutParams &L, int k) // y_table[k]
 {
-    return clip_u8((L.yb0r + k * L.cy) >> 16);
+    return clip_u8_shr(L.yb0r + k * L.cy, 16);
 }
 __device__ __forceinline__ uint32_t lut_rgb32(const SwsLutParams &L, const ChromaIdx &k, int Y)
 {

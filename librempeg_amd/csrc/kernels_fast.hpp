@@ -32,7 +32,9 @@ __device__ __forceinline__ void emit8(const SwsLutParams &L, uint8_t *d, const i
             for (int k = 0; k < 8; k++) { d[4 * k] = px[k]; d[4 * k + 1] = px[k] >> 8; d[4 * k + 2] = px[k] >> 16; d[4 * k + 3] = px[k] >> 24; }
         }
     } else {
-        uint8_t b[24];
+        // 24 channel values kept as ints and packed with shifts (a byte array here made hipcc 7.2 emit a
+        // wrong SDWA byte merge for some third bytes: caught by the parity tests)
+        int v[24];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const ChromaIdx c = lut_chroma(L, U[k], V[k]);
@@ -40,21 +42,21 @@ __device__ __forceinline__ void emit8(const SwsLutParams &L, uint8_t *d, const i
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int y = Y[2 * k + h];
-                b[6 * k + 3 * h + 0] = (uint8_t)lut_luma(L, k0 + y);
-                b[6 * k + 3 * h + 1] = (uint8_t)lut_luma(L, c.g + y);
-                b[6 * k + 3 * h + 2] = (uint8_t)lut_luma(L, k2 + y);
+                v[6 * k + 3 * h + 0] = lut_luma(L, k0 + y);
+                v[6 * k + 3 * h + 1] = lut_luma(L, c.g + y);
+                v[6 * k + 3 * h + 2] = lut_luma(L, k2 + y);
             }
         }
         if constexpr (VEC) {
             uint32_t w[6];
 #pragma unroll
             for (int k = 0; k < 6; k++)
-                w[k] = (uint32_t)b[4 * k] | ((uint32_t)b[4 * k + 1] << 8) | ((uint32_t)b[4 * k + 2] << 16) | ((uint32_t)b[4 * k + 3] << 24);
+                w[k] = (uint32_t)v[4 * k] | ((uint32_t)v[4 * k + 1] << 8) | ((uint32_t)v[4 * k + 2] << 16) | ((uint32_t)v[4 * k + 3] << 24);
             uint2 *o = (uint2 *)d;
             o[0] = make_uint2(w[0], w[1]); o[1] = make_uint2(w[2], w[3]); o[2] = make_uint2(w[4], w[5]);
         } else {
 #pragma unroll
-            for (int k = 0; k < 24; k++) d[k] = b[k];
+            for (int k = 0; k < 24; k++) d[k] = (uint8_t)v[k];
         }
     }
 }

@@ -36,16 +36,16 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         const int32_t *t = p.rgb2yuv;
         if (comp == 0) {
             const int r = s[3 * x + p.src_r_pos], g = s[3 * x + 1], b = s[3 * x + p.src_b_pos];
-            return (int16_t)((t[0] * r + t[1] * g + t[2] * b + (32 << 14) + (1 << 8)) >> 9);
+            return (uint16_t)((t[0] * r + t[1] * g + t[2] * b + (32 << 14) + (1 << 8)) >> 9); // stored int16, read back as u16 by hscale
         }
         const int o = comp == 1 ? 3 : 6;
         if (p.chr_half) {
             const int r = s[6 * x + p.src_r_pos] + s[6 * x + 3 + p.src_r_pos], g = s[6 * x + 1] + s[6 * x + 4];
             const int b = s[6 * x + p.src_b_pos] + s[6 * x + 3 + p.src_b_pos];
-            return (int16_t)((t[o] * r + t[o + 1] * g + t[o + 2] * b + (256 << 15) + (1 << 9)) >> 10);
+            return (uint16_t)((t[o] * r + t[o + 1] * g + t[o + 2] * b + (256 << 15) + (1 << 9)) >> 10);
         }
         const int r = s[3 * x + p.src_r_pos], g = s[3 * x + 1], b = s[3 * x + p.src_b_pos];
-        return (int16_t)((t[o] * r + t[o + 1] * g + t[o + 2] * b + (256 << 14) + (1 << 8)) >> 9);
+        return (uint16_t)((t[o] * r + t[o + 1] * g + t[o + 2] * b + (256 << 14) + (1 << 8)) >> 9);
     }
     case SRCK_RGB32: { // rgb16_32ToY/UV/UV_half_c_template with the 32-bit parameter rows, input.c:264-393
         const int srow = comp == 0 ? row : (row << p.chrSrcVSub);
@@ -55,7 +55,7 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         if (comp == 0) {
             const int r = s[4 * x + p.src_r_pos], g = s[4 * x + p.src_g_pos] << 8, b = s[4 * x + p.src_b_pos];
             const unsigned rnd = (32u << (S - 1)) + (1u << (S - 7));
-            return (int16_t)((int)((t[0] << 8) * r + t[1] * g + (t[2] << 8) * b + rnd) >> (S - 6));
+            return (uint16_t)((unsigned)((t[0] << 8) * r + t[1] * g + (t[2] << 8) * b + rnd) >> (S - 6));
         }
         const int o = comp == 1 ? 3 : 6;
         const int cr = t[o] * (1 << 8), cg = t[o + 1], cb = t[o + 2] * (1 << 8);
@@ -64,11 +64,11 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
             const int g = (s[8 * x + p.src_g_pos] + s[8 * x + 4 + p.src_g_pos]) << 8;
             const int b = s[8 * x + p.src_b_pos] + s[8 * x + 4 + p.src_b_pos];
             const unsigned rnd = (256U << S) + (1 << (S - 6));
-            return (int16_t)((int)(cr * r + cg * g + cb * b + rnd) >> (S - 6 + 1));
+            return (uint16_t)((unsigned)(cr * r + cg * g + cb * b + rnd) >> (S - 6 + 1)); // unsigned expr, logical shift
         }
         const int r = s[4 * x + p.src_r_pos], g = s[4 * x + p.src_g_pos] << 8, b = s[4 * x + p.src_b_pos];
         const unsigned rnd = (256u << (S - 1)) + (1 << (S - 7));
-        return (int16_t)((int)(cr * r + cg * g + cb * b + rnd) >> (S - 6));
+        return (uint16_t)((unsigned)(cr * r + cg * g + cb * b + rnd) >> (S - 6));
     }
     case SRCK_GBRP: { // planar_rgb_to_y / planar_rgb_to_uv input.c:1174-1211; gbr24pToUV_half_c :414-432
         const uint8_t *G = f.src[0] + (int64_t)row * f.srcStride[0], *B = f.src[1] + (int64_t)row * f.srcStride[1],
@@ -214,11 +214,11 @@ __device__ __forceinline__ void planar_write_one(const SwsDevParams &p, const S 
         const int off = comp == 2 ? 3 : 0; // V plane uses dither offset 3 (vscale.c:99-102)
         const int dv = dither8(p.should_dither, y, x + off);
         if (fs == 1) {
-            drow[x] = (uint8_t)clip_u8((smp.get(comp, min(first, srcRows - 1), x) + dv) >> 7);
+            drow[x] = (uint8_t)clip_u8_shr(smp.get(comp, min(first, srcRows - 1), x) + dv, 7);
         } else {
             int val = dv << 12;
             for (int j = 0; j < fs; j++) val += (int)(unsigned)(smp.get(comp, min(first + j, srcRows - 1), x) * vf[j]);
-            drow[x] = (uint8_t)clip_u8(val >> 19);
+            drow[x] = (uint8_t)clip_u8_shr(val, 19);
         }
     }
 }
@@ -249,8 +249,8 @@ __device__ __forceinline__ void nv_chroma_write_one(const SwsDevParams &p, const
             u += (int)((unsigned)smp.get(1, r, x) * (unsigned)(int)vf[j]);
             v += (int)((unsigned)smp.get(2, r, x) * (unsigned)(int)vf[j]);
         }
-        drow[2 * x + p.uv_swap_dst] = (uint8_t)clip_u8(u >> 19);
-        drow[2 * x + 1 - p.uv_swap_dst] = (uint8_t)clip_u8(v >> 19);
+        drow[2 * x + p.uv_swap_dst] = (uint8_t)clip_u8_shr(u, 19);
+        drow[2 * x + 1 - p.uv_swap_dst] = (uint8_t)clip_u8_shr(v, 19);
     }
 }
 

@@ -52,6 +52,12 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch bundles its own ROCm runtime (libamdhip64.so.7 / libhsa-runtime64); load it FIRST so that
+    # libswscale_hip.so binds to the same HIP/HSA instance -- two HSA runtimes in one process lose the GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build it with librempeg_amd.build_library() "
@@ -212,6 +218,7 @@ class DeviceFrame:
         for i, a in enumerate(host.planes):
             rb = self.row_bytes[i]
             self.plane_tensor(i)[:, :rb].copy_(torch.from_numpy(np.ascontiguousarray(a[:, :rb])))
+        torch.cuda.synchronize()  # the context runs on its own stream: make the upload visible to it
         return self
 
     def download(self, host=None):

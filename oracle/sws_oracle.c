@@ -1150,7 +1150,7 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
         for (i = 0; i < w; i++) {
             /* the template extracts g as (px & 0xFF00) (i.e. g<<8) and r,b as 0..255 with coeffs <<8 */
             int r = s[4 * i + ro], g = s[4 * i + go] << 8, b = s[4 * i + bo];
-            d[i] = (int16_t)((int)(ry * r + gy * g + by * b + rnd) >> (S - 6));
+            d[i] = (int16_t)((unsigned)(ry * r + gy * g + by * b + rnd) >> (S - 6)); /* unsigned expression, logical shift */
         }
         return tmp; }
     case ORF_GBRP: { /* planar_rgb_to_y input.c:1174-1186 */
@@ -1226,15 +1226,16 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
                 int r = s[8 * i + ro] + s[8 * i + 4 + ro];
                 int g = (s[8 * i + go] + s[8 * i + 4 + go]) << 8;
                 int b = s[8 * i + bo] + s[8 * i + 4 + bo];
-                du[i] = (int16_t)((int)(ru * r + gu * g + bu * b + rnd) >> (S - 6 + 1));
-                dv[i] = (int16_t)((int)(rv * r + gv * g + bv * b + rnd) >> (S - 6 + 1));
+                /* rnd is unsigned (256U << S == 2^31): the whole expression is unsigned, the shift is logical */
+                du[i] = (int16_t)((unsigned)(ru * r + gu * g + bu * b + rnd) >> (S - 6 + 1));
+                dv[i] = (int16_t)((unsigned)(rv * r + gv * g + bv * b + rnd) >> (S - 6 + 1));
             }
         } else {
             const unsigned rnd = (256u << (S - 1)) + (1 << (S - 7));
             for (i = 0; i < w; i++) {
                 int r = s[4 * i + ro], g = s[4 * i + go] << 8, b = s[4 * i + bo];
-                du[i] = (int16_t)((int)(ru * r + gu * g + bu * b + rnd) >> (S - 6));
-                dv[i] = (int16_t)((int)(rv * r + gv * g + bv * b + rnd) >> (S - 6));
+                du[i] = (int16_t)((unsigned)(ru * r + gu * g + bu * b + rnd) >> (S - 6));
+                dv[i] = (int16_t)((unsigned)(rv * r + gv * g + bv * b + rnd) >> (S - 6));
             }
         }
         return; }

@@ -36,6 +36,8 @@ def run_case(sw, sh, sfmt, dw, dh, dfmt, flags, seed=1, colorspace=None, device_
         ds = DeviceFrame(sfmt, sw, sh).upload(hs)
         dd = DeviceFrame(dfmt, dw, dh)
         dd.buf.fill_(prefill)
+        import torch
+        torch.cuda.synchronize()  # torch filled/uploaded on its own stream; the context has its own
         ret = p.scale(ds, dd)
         p.sync()
         out = dd.download(hd)
