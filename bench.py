@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""bench.py -- sws_scale throughput of libswscale_hip on MI355X.
+
+A "step" is ONE sws_scale_frames() call = one pass of the hot path over one batch of synthetic
+HBM-resident frames (one kernel launch on the dominant path).  Default workload = BASELINE.json
+configs[1]: 3840x2160 yuv420p -> rgb24, SWS_BICUBIC|SWS_BITEXACT.  With those flags and equal sizes
+the reference selects the unscaled LUT converter yuv2rgb_c_24_rgb and so does this
+library ("c2a").  The polyphase variant of the same conversion (flags + SWS_ACCURATE_RND, "c2b":
+1-tap luma, 4-tap bicubic vertical chroma, yuv2rgb24_X) is measured too and reported in the same
+JSON line under "variants".  Both have the same algorithmic bytes (37 324 800 B / frame).
+
+Contract: python bench.py --gpus N --steps K --warmup W ; for N>1 launched by torch.distributed.run,
+one rank per GPU (RCCL).  Frames are sharded across ranks (weak scaling, no data-path collective);
+the only collective is the one-off broadcast of the context's table blob from rank 0.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from librempeg_amd import (SwsContext, DeviceFrame, HostFrame, plane_layout,  # noqa: E402
+                           SWS_BICUBIC, SWS_BILINEAR, SWS_LANCZOS, SWS_BITEXACT, SWS_ACCURATE_RND, SWS_CS_BT2020)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (srcW, srcH, srcFmt, dstW, dstH, dstFmt, flags, colorspace, default batch, description)
+    "c2a": (3840, 2160, "yuv420p", 3840, 2160, "rgb24", SWS_BICUBIC | SWS_BITEXACT, None, 32,
+            "C2a 3840x2160 yuv420p->rgb24 SWS_BICUBIC|SWS_BITEXACT (reference path: unscaled yuv2rgb_c_24_rgb)"),
+    "c2b": (3840, 2160, "yuv420p", 3840, 2160, "rgb24", SWS_BICUBIC | SWS_BITEXACT | SWS_ACCURATE_RND, None, 32,
+            "C2b 3840x2160 yuv420p->rgb24 SWS_BICUBIC|SWS_BITEXACT|SWS_ACCURATE_RND (polyphase chain, 4-tap vertical chroma)"),
+    "c1": (1280, 720, "yuv420p", 640, 360, "yuv420p", SWS_BILINEAR | SWS_BITEXACT, None, 64,
+           "C1 1280x720->640x360 yuv420p SWS_BILINEAR|SWS_BITEXACT"),
+    "c3a": (7680, 4320, "yuv420p10le", 7680, 4320, "p010le", SWS_LANCZOS | SWS_BITEXACT, None, 8,
+            "C3a 7680x4320 yuv420p10le->p010le same size (reference path: planarToP01xWrapper)"),
+    "c3b": (7680, 4320, "yuv420p10le", 3840, 2160, "p010le", SWS_LANCZOS | SWS_BITEXACT, None, 8,
+            "C3b 7680x4320->3840x2160 yuv420p10le->p010le SWS_LANCZOS (12-tap h and v)"),
+    "c4": (1920, 1080, "nv12", 1920, 1080, "bgr0", SWS_BICUBIC | SWS_BITEXACT, None, 64,
+           "C4 1920x1080 nv12->bgr0 SWS_BICUBIC|SWS_BITEXACT (main path, 4-tap vertical chroma)"),
+    "c5": (3840, 2160, "gbrpf32le", 3840, 2160, "yuv444p16le", SWS_BICUBIC | SWS_BITEXACT,
+           (SWS_CS_BT2020, 1, SWS_CS_BT2020, 1), 8,
+           "C5 3840x2160 gbrpf32le->yuv444p16le BT.2020 full range"),
+}
+
+
+def algorithmic_bytes(sw, sh, sfmt, dw, dh, dfmt):
+    """visible bytes of all planes in + out (no padding, tables or halo re-reads)."""
+    return sum(rb * r for rb, r in plane_layout(sfmt, sw, sh)) + sum(rb * r for rb, r in plane_layout(dfmt, dw, dh))
+
+
+def fill_device_frame(fr, seed):
+    """synthetic content: uniform random bytes (10-bit / float formats get format-valid samples)."""
+    g = torch.Generator(device=fr.buf.device)
+    g.manual_seed(seed)
+    f = fr.fmt
+    for i in range(fr.nplanes):
+        t = fr.plane_tensor(i)
+        rows, ls = t.shape
+        if f in ("yuv420p10le", "yuv444p10le"):
+            v = torch.randint(0, 1024, (rows, ls // 2), generator=g, device=t.device, dtype=torch.int16)
+            t.copy_(v.view(torch.uint8).view(rows, ls))
+        elif f == "p010le":
+            v = (torch.randint(0, 1024, (rows, ls // 2), generator=g, device=t.device, dtype=torch.int32) << 6).to(torch.int16)
+            t.copy_(v.view(torch.uint8).view(rows, ls))
+        elif f == "gbrpf32le":
+            v = torch.rand((rows, ls // 4), generator=g, device=t.device, dtype=torch.float32) * 1.5 - 0.25
+            t.copy_(v.view(torch.uint8).view(rows, ls))
+        else:
+            t.copy_(torch.randint(0, 256, (rows, ls), generator=g, device=t.device, dtype=torch.uint8))
+
+
+def make_context(name, rank, world, device_index):
+    sw, sh, sf, dw, dh, df, flags, cs, _, _ = WORKLOADS[name]
+    if world == 1 or rank == 0:
+        ctx = SwsContext(sw, sh, sf, dw, dh, df, flags, device=device_index)
+        if cs:
+            assert ctx.set_colorspace(*cs) >= 0
+    else:
+        ctx = SwsContext(sw, sh, sf, dw, dh, df, flags, device=device_index, empty=True)
+    if world > 1:
+        # one-off broadcast of the table blob (filters, LUT constants, plan) from rank 0 over RCCL/xGMI
+        import torch.distributed as dist
+        blob = ctx.export_tables() if rank == 0 else b""
+        n = torch.tensor([len(blob)], dtype=torch.int64, device=f"cuda:{device_index}")
+        dist.broadcast(n, 0)
+        buf = torch.empty(int(n.item()), dtype=torch.uint8, device=f"cuda:{device_index}")
+        if rank == 0:
+            buf.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        dist.broadcast(buf, 0)
+        if rank != 0:
+            ctx.import_tables(bytes(buf.cpu().numpy().tobytes()))
+    return ctx
+
+
+def run_workload(name, batch, steps, warmup, rank, world, device_index, barrier):
+    sw, sh, sf, dw, dh, df, flags, cs, dbatch, desc = WORKLOADS[name]
+    batch = batch or dbatch
+    dev = f"cuda:{device_index}"
+    ctx = make_context(name, rank, world, device_index)
+    stream = torch.cuda.Stream(device_index)  # a real (non-null) HIP stream shared by torch events and the library
+    ctx.set_stream(stream.cuda_stream)
+    srcs = [DeviceFrame(sf, sw, sh, dev) for _ in range(batch)]
+    dsts = [DeviceFrame(df, dw, dh, dev) for _ in range(batch)]
+    for i, s in enumerate(srcs):
+        fill_device_frame(s, 1000 * (rank + 1) + i)
+    torch.cuda.synchronize(device_index)
+    b = ctx.make_batch(srcs, dsts)
+    path = ctx.path()
+    for _ in range(warmup):
+        r = ctx.run_batch(b)
+        assert r == batch, f"sws_scale_frames returned {r}"
+    torch.cuda.synchronize(device_index)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    barrier()
+    torch.cuda.synchronize(device_index)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record(stream)
+        ctx.run_batch(b)
+        ev[k][1].record(stream)
+    torch.cuda.synchronize(device_index)
+    barrier()
+    t1 = time.perf_counter()
+    kernel_ms = [a.elapsed_time(c) for a, c in ev]
+    res = dict(name=name, desc=desc, batch=batch, wall_s=t1 - t0, kernel_ms_avg=float(np.mean(kernel_ms)),
+               kernel_ms_min=float(np.min(kernel_ms)), path=path, kernel=ctx.kernel_name(),
+               out_pixels_per_step=batch * dw * dh, alg_bytes_per_step=batch * algorithmic_bytes(sw, sh, sf, dw, dh, df))
+    del srcs, dsts
+    ctx.close()
+    torch.cuda.empty_cache()
+    return res
+
+
+def cpu_baseline(name, seconds=10.0):
+    """The oracle ("port" of the reference C path) timed on this host: 1 thread and all cores, frame-parallel with
+    one context per thread (sws_scale itself never multi-threads)."""
+    import oracle_lib as OL
+    sw, sh, sf, dw, dh, df, flags, cs, _, desc = WORKLOADS[name]
+    OL.lib()
+
+    def worker(out, idx, deadline):
+        o = OL.Oracle(sw, sh, sf, dw, dh, df, flags)
+        if cs:
+            o.set_colorspace(*cs)
+        src = OL.fill_random(OL.Frame(sf, sw, sh), 77 + idx)
+        dst = OL.Frame(df, dw, dh)
+        o.scale(src, dst)  # warm-up
+        n = 0
+        t0 = time.perf_counter()
+        while True:
+            o.scale(src, dst)
+            n += 1
+            if time.perf_counter() >= deadline and n >= 3:
+                break
+        out[idx] = (n, time.perf_counter() - t0)
+
+    def run(nthreads):
+        out = [None] * nthreads
+        deadline = time.perf_counter() + seconds
+        th = [threading.Thread(target=worker, args=(out, i, deadline)) for i in range(nthreads)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        wall = time.perf_counter() - t0
+        frames = sum(n for n, _ in out)
+        # per-thread rates summed (each thread times its own loop; setup/fill excluded)
+        rate = sum(n / dt for n, dt in out)
+        return frames, wall, rate * dw * dh / 1e6
+
+    cores = os.cpu_count() or 1
+    f1, w1, mp1 = run(1)
+    fN, wN, mpN = run(cores) if cores > 1 else (f1, w1, mp1)
+    return {"value": round(mpN, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "value_1core": round(mp1, 2),
+            "sample": f"{desc}; oracle/ (scalar C restatement of the reference C path, gcc -O3 -fno-tree-vectorize like "
+                      f"the reference's own flags), ~{seconds:.0f}s per leg: {f1} frames on 1 thread, {fN} frames on {cores} "
+                      f"threads (one context per thread)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2a", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (0 = workload default)")
+    ap.add_argument("--variants", default="auto", help="comma list of extra workloads to time (auto: c2b when workload is c2a)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs the MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+        def barrier():
+            dist.barrier()
+    else:
+        def barrier():
+            pass
+
+    main_res = run_workload(args.workload, args.batch, args.steps, args.warmup, rank, world, local_rank, barrier)
+    variants = [] if args.variants in ("", "none") else (["c2b"] if args.variants == "auto" and args.workload == "c2a"
+                                                          else [] if args.variants == "auto" else args.variants.split(","))
+    var_res = [run_workload(v, 0, args.steps, args.warmup, rank, world, local_rank, barrier) for v in variants]
+
+    def reduce_max(x):
+        if world == 1:
+            return x
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def summarize(r):
+        wall = reduce_max(r["wall_s"])
+        kms = reduce_max(r["kernel_ms_avg"])
+        mpix = world * args.steps * r["out_pixels_per_step"] / wall / 1e6
+        achieved = r["alg_bytes_per_step"] / (kms * 1e-3) / 1e9
+        return wall, kms, mpix, achieved
+
+    wall, kms, mpix, achieved = summarize(main_res)
+    out = None
+    if rank == 0:
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                traffic = pmc.get(main_res["name"], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpixels/sec sws_scale 4K yuv420p->rgb24 bicubic" if main_res["name"].startswith("c2")
+                      else f"Mpixels/sec sws_scale {main_res['name']}",
+            "value": round(mpix, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8" if "10" not in main_res["name"] else "u16", "data": "synthetic",
+            "config": {"workload": main_res["desc"], "frames_per_step_per_gpu": main_res["batch"],
+                       "path": main_res["path"], "sharding": f"frames x{world} (one rank per GPU, no data-path collective)",
+                       "frames_resident": "HBM"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": main_res["kernel"], "kernel_ms_avg": round(kms, 4),
+                         "algorithmic_bytes_per_launch": main_res["alg_bytes_per_step"]},
+        }
+        if main_res["name"] == "c5":
+            out["dtype"] = "f32->int32"
+        if var_res:
+            out["variants"] = {}
+    for r in var_res:
+        w2, k2, m2, a2 = summarize(r)
+        if rank == 0:
+            out["variants"][r["name"]] = {"workload": r["desc"], "value": round(m2, 1), "unit": "Mpixels/s",
+                                          "ms_per_step": round(w2 / args.steps * 1e3, 4), "path": r["path"], "kernel": r["kernel"],
+                                          "roofline": {"bound": "hbm", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                       "frac": round(a2 / HBM_PEAK_GBS, 4), "kernel_ms_avg": round(k2, 4)}}
+    if rank == 0:
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(main_res["name"], args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

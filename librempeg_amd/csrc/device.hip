@@ -26,7 +26,7 @@ struct DeviceState {
     void *scratch = nullptr; size_t scratch_bytes = 0;
     void *stage_src = nullptr; size_t stage_src_bytes = 0;
     void *stage_dst = nullptr; size_t stage_dst_bytes = 0;
-    SwsFramePtrs *d_frames = nullptr, *h_frames = nullptr; int frames_cap = 0;
+    SwsFramePtrs *d_frames = nullptr, *h_frames = nullptr; int frames_cap = 0, frames_valid = 0;
     void *casc_img = nullptr; size_t casc_bytes = 0; int casc_stride = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timing = false; bool timed = false;
 };
@@ -324,18 +324,22 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
     fs.count = n;
     if (n == 1) { fs.table = nullptr; fs.one = frames[0]; }
     else {
-        if (n > d->frames_cap) {
-            if (d->d_frames) HIPCHK(hipFree(d->d_frames));
-            if (d->h_frames) HIPCHK(hipHostFree(d->h_frames));
-            d->d_frames = nullptr; d->h_frames = nullptr; d->frames_cap = 0;
-            HIPCHK(hipMalloc((void **)&d->d_frames, sizeof(SwsFramePtrs) * n));
-            HIPCHK(hipHostMalloc((void **)&d->h_frames, sizeof(SwsFramePtrs) * n, hipHostMallocDefault));
-            d->frames_cap = n;
-        } else {
-            HIPCHK(hipStreamSynchronize(st)); // previous batch may still be reading the pinned table
+        const bool same_table = d->frames_cap >= n && d->frames_valid == n && !std::memcmp(d->h_frames, frames, sizeof(SwsFramePtrs) * n);
+        if (!same_table) {
+            if (n > d->frames_cap) {
+                if (d->d_frames) HIPCHK(hipFree(d->d_frames));
+                if (d->h_frames) HIPCHK(hipHostFree(d->h_frames));
+                d->d_frames = nullptr; d->h_frames = nullptr; d->frames_cap = 0;
+                HIPCHK(hipMalloc((void **)&d->d_frames, sizeof(SwsFramePtrs) * n));
+                HIPCHK(hipHostMalloc((void **)&d->h_frames, sizeof(SwsFramePtrs) * n, hipHostMallocDefault));
+                d->frames_cap = n;
+            } else {
+                HIPCHK(hipStreamSynchronize(st)); // a previous batch may still be reading the pinned table
+            }
+            std::memcpy(d->h_frames, frames, sizeof(SwsFramePtrs) * n);
+            HIPCHK(hipMemcpyAsync(d->d_frames, d->h_frames, sizeof(SwsFramePtrs) * n, hipMemcpyHostToDevice, st));
+            d->frames_valid = n;
         }
-        std::memcpy(d->h_frames, frames, sizeof(SwsFramePtrs) * n);
-        HIPCHK(hipMemcpyAsync(d->d_frames, d->h_frames, sizeof(SwsFramePtrs) * n, hipMemcpyHostToDevice, st));
         fs.table = d->d_frames;
     }
     const bool vec = frames_vec_ok(frames, n);
