@@ -9,7 +9,7 @@
 #include <cstring>
 #include <vector>
 
-#include "kernels_fast.hpp"
+#include "kernels_wave.hpp"
 #include "swsint.hpp"
 
 #define AVERROR_EXTERNAL_ (-0x20545845) /* FFERRTAG('E','X','T',' '), libavutil/error.h */
@@ -23,6 +23,7 @@ struct DeviceState {
     void *d_tables = nullptr; size_t tables_bytes = 0;
     SwsDevParams params;
     bool unity_h = false;
+    bool all_x_mode = false;   // every output row uses the general yuv2rgb_X writer (vscale.c:135-169)
     void *scratch = nullptr; size_t scratch_bytes = 0;
     void *stage_src = nullptr; size_t stage_src_bytes = 0;
     void *stage_dst = nullptr; size_t stage_dst_bytes = 0;
@@ -158,8 +159,9 @@ int dev_prepare(SwsInternal *c)
         const Yuv2RgbLut &l = c->lut;
         SwsLutParams &L = p.lut;
         auto fits = [](int64_t v) { return v >= INT32_MIN && v <= INT32_MAX; };
-        if (!fits(l.yb0 + 0x8000 + 2048 * l.cy) || !fits(l.yb0 + 0x8000) || !fits(255 * l.crv) || !fits(255 * l.cbu) ||
-            !fits(255 * l.cgu) || !fits(255 * l.cgv)) {
+        auto fits24 = [](int64_t v) { return v > -(1 << 23) && v < (1 << 23); };
+        if (!fits(l.yb0 + 0x8000 + 2048 * l.cy) || !fits(l.yb0 + 0x8000 - 2048 * l.cy) || !fits(255 * l.crv) || !fits(255 * l.cbu) ||
+            !fits(255 * l.cgu) || !fits(255 * l.cgv) || !fits24(l.cy) || !fits24(l.crv) || !fits24(l.cbu) || !fits24(l.cgu) || !fits24(l.cgv)) {
             log_msg(c, 0, "brightness/contrast/saturation out of the range the HIP LUT closed form supports\n");
             return SWS_AVERROR(ENOTSUP);
         }
@@ -222,11 +224,23 @@ int dev_prepare(SwsInternal *c)
         p.vLumF = (const int16_t *)(b + offs_t[2]); p.vLumPos = (const int32_t *)(b + offs_p[2]); p.vLumFs = c->vLum.size;
         p.vChrF = (const int16_t *)(b + offs_t[3]); p.vChrPos = (const int32_t *)(b + offs_p[3]); p.vChrFs = c->vChr.size;
         d->unity_h = bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14);
+        {   // packed_vscale picks yuv2packed1 / yuv2packed2 per row from (lfs, cfs, taps): vscale.c:135-157
+            const int lfs = c->vLum.size, cfs = c->vChr.size;
+            bool all_x = !(lfs == 1 && cfs == 1);
+            for (int y = 0; y < o.dst_h && all_x; y++) {
+                const int cy = y >> c->chrDstVSubSample;
+                const int16_t *lf = &c->vLum.taps[(size_t)y * lfs], *cf = &c->vChr.taps[(size_t)cy * cfs];
+                if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) all_x = false;
+                if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
+                    (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) all_x = false;
+            }
+            d->all_x_mode = all_x;
+        }
     }
 
     // ---- name the path (for SWS_PRINT_INFO, tests and rocprof matching) ----
     switch (c->plan) {
-    case PLAN_UNSC_YUV2RGB: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb_unscaled"; break;
+    case PLAN_UNSC_YUV2RGB: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb_unscaled_wave"; break;
     case PLAN_UNSC_P01X: c->path_name = "unscaled:planarToP01x"; c->kernel_name = "sws_k_p01x_unscaled"; break;
     case PLAN_UNSC_8_P01X: c->path_name = "unscaled:planar8ToP01xle"; c->kernel_name = "sws_k_p01x_unscaled"; break;
     case PLAN_UNSC_PLANAR2NV12: c->path_name = "unscaled:planarToNv12"; c->kernel_name = "sws_k_planar_misc"; break;
@@ -236,7 +250,7 @@ int dev_prepare(SwsInternal *c)
     case PLAN_MAIN: {
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
         if (d->unity_h && rgb_lut && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
-            c->path_name = "main:fused_rgb_unity"; c->kernel_name = "sws_k_rgb_fused_unity";
+            c->path_name = "main:fused_rgb_unity"; c->kernel_name = "sws_k_rgb_fused_unity_wave";
         } else if (d->unity_h) {
             c->path_name = "main:fused_generic_unity";
             c->kernel_name = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) ? "sws_k_vscale_rgb" : "sws_k_vscale_planar";
@@ -343,6 +357,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         fs.table = d->d_frames;
     }
     const bool vec = frames_vec_ok(frames, n);
+    static const bool no_wave = std::getenv("SWS_HIP_NO_WAVE") != nullptr; // A/B switch: older per-thread kernels
     const dim3 blk(256);
     if (d->timing) { HIPCHK(hipEventRecord(d->ev0, st)); }
 
@@ -354,8 +369,15 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         const int nrowpairs = (sliceH + 1) >> 1; // "for (y = 0; y < srcSliceH; y += 2)"
         const int bpr = (npairs + 3) >> 2;
         if (!bpr || !nrowpairs) break;
-        const dim3 grid(cdiv((int64_t)bpr * nrowpairs, 256), 1, n);
         const bool bpp4 = p.dstKind == DSTK_RGB32;
+        if (vec && !no_wave) { // wave-tiled kernel: 1024 pixels x 2 rows per wave, LDS-transposed 16-byte stores
+            const int segs = (2 * npairs + 1023) >> 10;
+            const dim3 gridw(cdiv((int64_t)segs * nrowpairs, 4), 1, n);
+            if (bpp4) hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled_wave<4>), gridw, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
+            else hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled_wave<3>), gridw, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
+            break;
+        }
+        const dim3 grid(cdiv((int64_t)bpr * nrowpairs, 256), 1, n);
         if (bpp4 && vec) hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled<4, true>), grid, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
         else if (bpp4) hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled<4, false>), grid, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
         else if (vec) hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled<3, true>), grid, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
@@ -414,9 +436,19 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32;
         const bool rgb_lut = rgb && !p.full_chr;
         if (d->unity_h && rgb_lut && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
+            const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;
+            if (vec && !no_wave && d->all_x_mode) { // wave-tiled kernel: 1024 pixels x 2 rows per wave
+                constexpr int ROWS = 2;
+                const int segs = (p.dstW + 1023) >> 10, rgroups = (p.dstH + ROWS - 1) / ROWS;
+                const dim3 gridw(cdiv((int64_t)segs * rgroups, 4), 1, n);
+#define LAUNCH_WAVE(B, N) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave<B, N, ROWS>), gridw, blk, 0, st, fs, p)
+                if (b4) { if (nv) LAUNCH_WAVE(4, true); else LAUNCH_WAVE(4, false); }
+                else    { if (nv) LAUNCH_WAVE(3, true); else LAUNCH_WAVE(3, false); }
+#undef LAUNCH_WAVE
+                break;
+            }
             const int npairs = (p.dstW + 1) >> 1, bpr = (npairs + 3) >> 2;
             const dim3 grid(cdiv((int64_t)bpr * p.dstH, 256), 1, n);
-            const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;
 #define LAUNCH_FUSED(B, N, V) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity<B, N, V>), grid, blk, 0, st, fs, p)
             if (b4) { if (nv) { if (vec) LAUNCH_FUSED(4, true, true); else LAUNCH_FUSED(4, true, false); }
                       else    { if (vec) LAUNCH_FUSED(4, false, true); else LAUNCH_FUSED(4, false, false); } }

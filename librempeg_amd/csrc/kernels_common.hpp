@@ -13,6 +13,8 @@ __device__ __forceinline__ int clip_u8(int a) { return min(max(a, 0), 255); }
 // instruction leaves stale data in bits 31:16 -> corrupted 3rd/4th bytes (caught by the parity tests against
 // the oracle).  Clamping first is arithmetically identical and does not match that pattern.
 __device__ __forceinline__ int clip_u8_shr(int x, int sh) { return min(max(x, 0), (256 << sh) - 1) >> sh; }
+// a*b + c with |a|,|b| < 2^23: v_mad_i32_i24 (full rate; v_mul_lo_u32 is quarter rate)
+__device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
 __device__ __forceinline__ int clip_u16(int a) { return min(max(a, 0), 65535); }
 __device__ __forceinline__ int clip_i16(int a) { return min(max(a, -32768), 32767); }
 __device__ __forceinline__ int clip_uintp2(int a, int p) { return min(max(a, 0), (1 << p) - 1); }
@@ -22,20 +24,45 @@ __device__ __forceinline__ const SwsFramePtrs &frame_of(const SwsFrameSet &fs, i
     return fs.table ? fs.table[idx] : fs.one;
 }
 
+// Frame descriptor in scalar registers: the frame index is wave-uniform (blockIdx.z), so every plane pointer
+// and stride is read once and pinned to SGPRs; later address arithmetic is scalar-base + vector-offset.
+struct FrameRegs {
+    const uint8_t *src[4]; uint8_t *dst[4]; int srcStride[4]; int dstStride[4];
+};
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ FrameRegs load_frame(const SwsFrameSet &fs, int idx)
+{
+    const SwsFramePtrs &f = frame_of(fs, idx);
+    FrameRegs r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        r.src[k] = (const uint8_t *)uniform_u64((uint64_t)f.src[k]);
+        r.dst[k] = (uint8_t *)uniform_u64((uint64_t)f.dst[k]);
+        r.srcStride[k] = __builtin_amdgcn_readfirstlane(f.srcStride[k]);
+        r.dstStride[k] = __builtin_amdgcn_readfirstlane(f.dstStride[k]);
+    }
+    return r;
+}
+
 // ---- closed form of the yuv2rgb LUTs (yuv2rgb.c:680-703, :901-961; colorspace.cpp) ----
 struct ChromaIdx { int r, g, b; };
 __device__ __forceinline__ ChromaIdx lut_chroma(const SwsLutParams &L, int U, int V)
 {
     const int cu = clip_u8(U), cv = clip_u8(V);
     ChromaIdx k;
-    k.r = L.base_r + ((cv * L.crv) >> 16);
-    k.g = L.base_g + ((cu * L.cgu) >> 16) + ((cv * L.cgv) >> 16);
-    k.b = L.base_b + ((cu * L.cbu) >> 16);
+    // operands are < 2^23 in magnitude (checked on the host): full-rate 24-bit multiplies
+    k.r = L.base_r + (__mul24(cv, L.crv) >> 16);
+    k.g = L.base_g + (__mul24(cu, L.cgu) >> 16) + (__mul24(cv, L.cgv) >> 16);
+    k.b = L.base_b + (__mul24(cu, L.cbu) >> 16);
     return k;
 }
 __device__ __forceinline__ int lut_luma(const SwsLutParams &L, int k) // y_table[k]
 {
-    return clip_u8_shr(L.yb0r + k * L.cy, 16);
+    return clip_u8_shr(L.yb0r + __mul24(k, L.cy), 16);
 }
 __device__ __forceinline__ uint32_t lut_rgb32(const SwsLutParams &L, const ChromaIdx &k, int Y)
 {

@@ -1,0 +1,253 @@
+// Wave-tiled kernels for the packed-RGB writers (the north-star shapes C2a / C2b / C4).
+//
+// One wavefront = one output-row tile of 64 lanes x 16 pixels = 1024 pixels.  Each lane converts 16
+// horizontally adjacent pixels (one 16-byte luma load per row, 8-byte chroma loads); the wave then
+// transposes its 3 KiB (rgb24) / 4 KiB (rgb32) of output through LDS so that every global store
+// instruction writes one contiguous, 16-byte-per-lane, 1 KiB run of the destination row.
+// Plane pointers / strides live in SGPRs (FrameRegs), loads and stores use the global address space,
+// the output is written non-temporally.  Arithmetic is the generic kernels' arithmetic.
+#pragma once
+#include "kernels_fast.hpp"
+
+namespace swsk {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#define SWS_GLOBAL __attribute__((address_space(1)))
+
+__device__ __forceinline__ u32x4 gload16(const uint8_t *p) { return *(const SWS_GLOBAL u32x4 *)p; }
+__device__ __forceinline__ u32x2 gload8(const uint8_t *p) { return *(const SWS_GLOBAL u32x2 *)p; }
+__device__ __forceinline__ void gstore16_nt(uint8_t *p, u32x4 v) { __builtin_nontemporal_store(v, (SWS_GLOBAL u32x4 *)p); }
+
+// row tails: n (< 16 / < 8) valid bytes, the rest reads as 0.  Out of line: rare, keeps the hot loop small.
+__device__ __noinline__ u32x4 gload16_partial(const uint8_t *s, int n)
+{
+    uint32_t w[4] = { 0, 0, 0, 0 };
+    for (int k = 0; k < n; k++) w[k >> 2] |= (uint32_t)s[k] << (8 * (k & 3));
+    u32x4 v = { w[0], w[1], w[2], w[3] };
+    return v;
+}
+__device__ __noinline__ void gstore_partial(uint8_t *d, u32x4 v, int n)
+{
+    uint32_t w[4] = { v[0], v[1], v[2], v[3] };
+    for (int b = 0; b < n; b++) d[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+}
+__device__ __forceinline__ u32x4 load16_or_tail(const uint8_t *s, int nvalid)
+{
+    return nvalid >= 16 ? gload16(s) : gload16_partial(s, max(nvalid, 0));
+}
+__device__ __forceinline__ u32x2 load8_or_tail(const uint8_t *s, int nvalid)
+{
+    if (nvalid >= 8) return gload8(s);
+    const u32x4 t = gload16_partial(s, max(nvalid, 0));
+    u32x2 r = { t[0], t[1] };
+    return r;
+}
+
+__device__ __forceinline__ void unpack16(u32x4 v, int (&o)[16])
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[4 * q + k] = (v[q] >> (8 * k)) & 0xFF;
+}
+__device__ __forceinline__ void unpack8(u32x2 v, int (&o)[8])
+{
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[4 * q + k] = (v[q] >> (8 * k)) & 0xFF;
+}
+
+// LUT stage for 16 pixels (8 chroma pairs) -> NDW = 4*BPP packed dwords in w[]
+template <int BPP>
+__device__ __forceinline__ void lut16(const SwsLutParams &L, const int (&Y)[16], const int (&U)[8], const int (&V)[8], uint32_t (&w)[4 * BPP])
+{
+    if constexpr (BPP == 4) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const ChromaIdx c = lut_chroma(L, U[k], V[k]);
+            w[2 * k] = lut_rgb32(L, c, Y[2 * k]);
+            w[2 * k + 1] = lut_rgb32(L, c, Y[2 * k + 1]);
+        }
+    } else {
+        int v[48];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const ChromaIdx c = lut_chroma(L, U[k], V[k]);
+            const int k0 = L.rgb_order ? c.b : c.r, k2 = L.rgb_order ? c.r : c.b;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int y = Y[2 * k + h];
+                v[6 * k + 3 * h + 0] = lut_luma(L, k0 + y);
+                v[6 * k + 3 * h + 1] = lut_luma(L, c.g + y);
+                v[6 * k + 3 * h + 2] = lut_luma(L, k2 + y);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++)
+            w[k] = (uint32_t)v[4 * k] | ((uint32_t)v[4 * k + 1] << 8) | ((uint32_t)v[4 * k + 2] << 16) | ((uint32_t)v[4 * k + 3] << 24);
+    }
+}
+
+// Transpose the wave's packed pixels through its private LDS region and store them as contiguous 16-byte chunks.
+// seg: global address of the first byte of this wave's 1024-pixel segment (16-byte aligned), seg_bytes: valid bytes.
+// LDS layout: lane l owns dwords [l*LS, l*LS + NDW); LS = 20 for 32 bpp (bank-conflict padding), 12 for 24 bpp.
+template <int BPP>
+__device__ __forceinline__ void wave_store16(uint8_t *seg, int seg_bytes, const uint32_t (&w)[4 * BPP], uint32_t *lds, int lane)
+{
+    constexpr int NDW = 4 * BPP, LS = BPP == 4 ? 20 : 12, NCH = NDW / 4;
+    u32x4 *lw = (u32x4 *)(lds + lane * LS);
+#pragma unroll
+    for (int k = 0; k < NCH; k++) { u32x4 t = { w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] }; lw[k] = t; }
+    // same-wave LDS hand-off: DS instructions of one wave execute in order; only stop compiler reordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+        const int c = j * 64 + lane;              // 16-byte chunk index inside the segment
+        const int off = 16 * c;
+        const u32x4 v = *(const u32x4 *)(lds + (c / NCH) * LS + (c % NCH) * 4);
+        if (off + 16 <= seg_bytes) gstore16_nt(seg + off, v);
+        else if (off < seg_bytes) gstore_partial(seg + off, v, seg_bytes - off);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();              // the next row reuses the LDS region
+}
+
+// ------------------------------------------------------------------------------------------
+// C2a: unscaled yuv420p / yuv422p -> packed RGB (yuv2rgb.c:68-559).  Wave = 1024 pixels x 2 rows.
+// grid.x over (row pair, 1024-pixel segment) in units of waves, 4 waves per block; grid.z = frame.
+// Requires 16-byte aligned planes/strides (else the host picks sws_k_yuv2rgb_unscaled).
+// ------------------------------------------------------------------------------------------
+template <int BPP>
+__global__ void __launch_bounds__(256) sws_k_yuv2rgb_unscaled_wave(SwsFrameSet fs, SwsDevParams p, int is422, int npairs,
+                                                                   int y0, int nrowpairs)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4 * 64 * (BPP == 4 ? 20 : 12)];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    uint32_t *lds = lds_all + wib * 64 * (BPP == 4 ? 20 : 12);
+    const int npix = 2 * npairs;                               // pixels the reference's block structure covers
+    const int segs = (npix + 1023) >> 10;                      // waves per row
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wib;
+    if (wid >= (int64_t)segs * nrowpairs) return;              // whole wave exits together
+    const int rp = (int)(wid / segs), seg = (int)(wid % segs);
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const SwsLutParams &L = p.lut;
+    const int yrow = y0 + 2 * rp, crow = is422 ? yrow : (yrow >> 1);
+    const int x = seg * 1024 + lane * 16;                      // first pixel of this lane
+    const int seg_bytes = min(1024, npix - seg * 1024) * BPP;
+    const int nvalid = npix - x;                               // pixels of this lane inside the row (may be <= 0)
+    int Y[16], U[8], V[8];
+    uint32_t w[4 * BPP];
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        if (l == 0 || is422) {
+            const int cr = crow + (is422 ? l : 0);
+            unpack8(load8_or_tail(f.src[1] + (int64_t)cr * f.srcStride[1] + (x >> 1), nvalid >> 1), U);
+            unpack8(load8_or_tail(f.src[2] + (int64_t)cr * f.srcStride[2] + (x >> 1), nvalid >> 1), V);
+        }
+        unpack16(load16_or_tail(f.src[0] + (int64_t)(yrow + l) * f.srcStride[0] + x, nvalid), Y);
+        lut16<BPP>(L, Y, U, V, w);
+        uint8_t *segp = f.dst[0] + (int64_t)(yrow + l) * f.dstStride[0] + (int64_t)seg * 1024 * BPP;
+        wave_store16<BPP>(segp, seg_bytes, w, lds, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// C2b / C4: polyphase chain with identity horizontal filters, 8-bit planar or nv12 source, packed RGB
+// LUT writer, general vertical filters in "X" mode (yuv2rgb_X_c_template, output.c:1788-1840).
+// Wave = 1024 pixels x ROWS output rows.  Chroma source rows are loaded ONCE per lane and accumulated
+// into the ROWS outputs that use them (integer adds are associative, so the order is irrelevant to the
+// result); luma rows are per output row.  The host launches this kernel only when every output row is
+// in X mode (no row selects the _1/_2 writers of vscale.c:135-157).
+// ------------------------------------------------------------------------------------------
+template <int BPP, bool NV, int ROWS>
+__global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_wave(SwsFrameSet fs, SwsDevParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4 * 64 * (BPP == 4 ? 20 : 12)];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    uint32_t *lds = lds_all + wib * 64 * (BPP == 4 ? 20 : 12);
+    const int npix = p.dstW;                                   // even (odd widths force the full-chroma writers)
+    const int segs = (npix + 1023) >> 10;
+    const int rgroups = (p.dstH + ROWS - 1) / ROWS;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wib;
+    if (wid >= (int64_t)segs * rgroups) return;
+    const int rg = (int)(wid / segs), seg = (int)(wid % segs);
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const SwsLutParams &L = p.lut;
+    const int x = seg * 1024 + lane * 16;
+    const int seg_bytes = min(1024, npix - seg * 1024) * BPP;
+    const int nvalid = npix - x;
+    const int lfs = p.vLumFs, cfs = p.vChrFs;
+    const int lH = p.srcH - 1, cH = p.chrSrcH - 1;
+    const int yb = rg * ROWS;
+    const int nrows = min(ROWS, p.dstH - yb);
+
+    int U[ROWS][8], V[ROWS][8];
+    int firstC[ROWS], cyr[ROWS];
+    int cmin = 0x7fffffff, cmax = -1;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const int y = min(yb + r, p.dstH - 1);
+        cyr[r] = y >> p.chrDstVSub;
+        firstC[r] = max(1 - cfs, p.vChrPos[cyr[r]]);
+        cmin = min(cmin, firstC[r]); cmax = max(cmax, firstC[r] + cfs - 1);
+#pragma unroll
+        for (int k = 0; k < 8; k++) U[r][k] = V[r][k] = 1 << 18;
+    }
+    // chroma rows [cmin, cmax]: load once, accumulate into every output row whose window contains them
+    for (int cr = cmin; cr <= cmax; cr++) {
+        const int srow = min(max(cr, 0), cH);
+        int u[8], v[8];
+        if constexpr (NV) {
+            int t[16];
+            unpack16(load16_or_tail(f.src[1] + (int64_t)srow * f.srcStride[1] + x, nvalid), t);
+#pragma unroll
+            for (int k = 0; k < 8; k++) { u[k] = t[2 * k + p.uv_swap_src]; v[k] = t[2 * k + 1 - p.uv_swap_src]; }
+        } else {
+            // planes 1/2 selected with ?: (a runtime index into the register-resident FrameRegs would go to scratch)
+            const bool u1 = p.u_plane_src == 1;
+            const uint8_t *ub = u1 ? f.src[1] : f.src[2], *vb = u1 ? f.src[2] : f.src[1];
+            const int us = u1 ? f.srcStride[1] : f.srcStride[2], vs = u1 ? f.srcStride[2] : f.srcStride[1];
+            unpack8(load8_or_tail(ub + (int64_t)srow * us + (x >> 1), nvalid >> 1), u);
+            unpack8(load8_or_tail(vb + (int64_t)srow * vs + (x >> 1), nvalid >> 1), v);
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const int j = cr - firstC[r];
+            if (j >= 0 && j < cfs) {                              // wave-uniform
+                const int wgt = p.vChrF[cyr[r] * cfs + j];
+#pragma unroll
+                for (int k = 0; k < 8; k++) { U[r][k] = mad24(u[k] << 7, wgt, U[r][k]); V[r][k] = mad24(v[k] << 7, wgt, V[r][k]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        if (r >= nrows) break;
+        const int y = yb + r;
+        const int16_t *lf = p.vLumF + y * lfs;
+        const int firstL = max(1 - lfs, p.vLumPos[y]);
+        int Y[16], Uo[8], Vo[8], t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) Y[k] = 1 << 18;
+        for (int j = 0; j < lfs; j++) {
+            unpack16(load16_or_tail(f.src[0] + (int64_t)min(firstL + j, lH) * f.srcStride[0] + x, nvalid), t);
+            const int wgt = lf[j];
+#pragma unroll
+            for (int k = 0; k < 16; k++) Y[k] = mad24(t[k] << 7, wgt, Y[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) Y[k] >>= 19;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { Uo[k] = U[r][k] >> 19; Vo[k] = V[r][k] >> 19; }
+        uint32_t w[4 * BPP];
+        lut16<BPP>(L, Y, Uo, Vo, w);
+        uint8_t *segp = f.dst[0] + (int64_t)y * f.dstStride[0] + (int64_t)seg * 1024 * BPP;
+        wave_store16<BPP>(segp, seg_bytes, w, lds, lane);
+    }
+}
+
+} // namespace swsk
