@@ -177,6 +177,12 @@ int dev_prepare(SwsInternal *c)
         L.rshift = base + (isRgb ? 16 : 0); L.gshift = base + 8; L.bshift = base + (isRgb ? 0 : 16);
         L.alpha_or = isALPHA(o.src_format) ? 0u : (255u << ((base + 24) & 31));
         L.rgb_order = df == AV_PIX_FMT_BGR24 ? 1 : 0;
+        {   // 32 bpp wave kernels pack bytes as {c0, g, c2, 255} with c0 = R (or B when swap_rb32) and then permute:
+            // rgba: R,G,B,A  bgra: B,G,R,A (swap)  argb: A,R,G,B  abgr: A,B,G,R (swap).  v_perm_b32(px, px, sel):
+            // result byte i = source byte sel[i] (0..3 select from the second operand = px).
+            L.swap_rb32 = (df == AV_PIX_FMT_BGRA || df == AV_PIX_FMT_ABGR) ? 1 : 0;
+            L.perm32 = (df == AV_PIX_FMT_ARGB || df == AV_PIX_FMT_ABGR) ? 0x02010003u : 0x03020100u;
+        }
         L.y_offset = l.y_offset; L.y_coeff = l.y_coeff; L.v2r = l.v2r; L.v2g = l.v2g; L.u2g = l.u2g; L.u2b = l.u2b;
         L.pix_step = dd->comp[0].step;
         L.r_pos = dd->comp[0].offset; L.g_pos = dd->comp[1].offset; L.b_pos = dd->comp[2].offset;
@@ -373,8 +379,11 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         if (vec && !no_wave) { // wave-tiled kernel: 1024 pixels x 2 rows per wave, LDS-transposed 16-byte stores
             const int segs = (2 * npairs + 1023) >> 10;
             const dim3 gridw(cdiv((int64_t)segs * nrowpairs, 4), 1, n);
-            if (bpp4) hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled_wave<4>), gridw, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
-            else hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled_wave<3>), gridw, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
+            const bool swap = bpp4 ? p.lut.swap_rb32 != 0 : p.lut.rgb_order != 0;
+#define LAUNCH_K1(B, S) hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled_wave<B, S>), gridw, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs)
+            if (bpp4) { if (swap) LAUNCH_K1(4, true); else LAUNCH_K1(4, false); }
+            else      { if (swap) LAUNCH_K1(3, true); else LAUNCH_K1(3, false); }
+#undef LAUNCH_K1
             break;
         }
         const dim3 grid(cdiv((int64_t)bpr * nrowpairs, 256), 1, n);
@@ -441,9 +450,12 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
                 constexpr int ROWS = 2;
                 const int segs = (p.dstW + 1023) >> 10, rgroups = (p.dstH + ROWS - 1) / ROWS;
                 const dim3 gridw(cdiv((int64_t)segs * rgroups, 4), 1, n);
-#define LAUNCH_WAVE(B, N) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave<B, N, ROWS>), gridw, blk, 0, st, fs, p)
-                if (b4) { if (nv) LAUNCH_WAVE(4, true); else LAUNCH_WAVE(4, false); }
-                else    { if (nv) LAUNCH_WAVE(3, true); else LAUNCH_WAVE(3, false); }
+                const bool swap = b4 ? p.lut.swap_rb32 != 0 : p.lut.rgb_order != 0;
+#define LAUNCH_WAVE(B, S, N) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave<B, S, N, ROWS>), gridw, blk, 0, st, fs, p)
+                if (b4) { if (nv) { if (swap) LAUNCH_WAVE(4, true, true); else LAUNCH_WAVE(4, false, true); }
+                          else    { if (swap) LAUNCH_WAVE(4, true, false); else LAUNCH_WAVE(4, false, false); } }
+                else    { if (nv) { if (swap) LAUNCH_WAVE(3, true, true); else LAUNCH_WAVE(3, false, true); }
+                          else    { if (swap) LAUNCH_WAVE(3, true, false); else LAUNCH_WAVE(3, false, false); } }
 #undef LAUNCH_WAVE
                 break;
             }

@@ -46,6 +46,8 @@ struct SwsLutParams {       // closed form of the yuv2rgb LUTs (yuv2rgb.c:680-70
     int32_t rshift, gshift, bshift; // 32 bpp channel positions
     uint32_t alpha_or;      // 255 << abase (32 bpp, no source alpha) or 0
     int32_t rgb_order;      // 24 bpp: 0 = R first (rgb24), 1 = B first (bgr24)
+    uint32_t perm32;        // 32 bpp: v_perm_b32 selector moving canonical bytes {first,g,third,alpha} to the format's order
+    int32_t swap_rb32;      // 32 bpp: canonical 'first' channel is B (bgra / abgr)
     // 13-bit coefficients for the full-chroma writers (output.c:2005-2020)
     int32_t y_offset, y_coeff, v2r, v2g, u2g, u2b;
     // byte positions inside the pixel for the full-chroma writers

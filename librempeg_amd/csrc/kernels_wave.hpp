@@ -59,44 +59,79 @@ __device__ __forceinline__ void unpack8(u32x2 v, int (&o)[8])
         for (int k = 0; k < 4; k++) o[4 * q + k] = (v[q] >> (8 * k)) & 0xFF;
 }
 
-// LUT stage for 16 pixels (8 chroma pairs) -> NDW = 4*BPP packed dwords in w[]
+// Four values t0..t3 -> one dword of bytes clip_u8(t >> 16).  v_ashr_pk_u8_i32 (new on gfx950) shifts two int32, saturates
+// them to u8 and writes ONE HALF of the destination (low half, or high half with op_sel[3]); the other half is preserved
+// (semantics verified on hardware with tools/isa_probe.hip).  Two of them clamp, shift and pack 4 channel values.
+__device__ __forceinline__ uint32_t pack4_u8_shr16(int t0, int t1, int t2, int t3)
+{
+    uint32_t d;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 16\n\tv_ashr_pk_u8_i32 %0, %3, %4, 16 op_sel:[0,0,0,1]"
+        : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3));
+    return d;
+}
+
+// chroma part of the LUT for the 8 pixel pairs of a lane
+struct Chroma8 { int r[8], g[8], b[8]; };
+template <bool SWAP_RB>
+__device__ __forceinline__ void chroma8(const SwsLutParams &L, const int (&U)[8], const int (&V)[8], Chroma8 &c)
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const ChromaIdx q = lut_chroma(L, U[k], V[k]);
+        c.r[k] = SWAP_RB ? q.b : q.r; c.g[k] = q.g; c.b[k] = SWAP_RB ? q.r : q.b;  // "r" = first byte of the pixel
+    }
+}
+
+// LUT stage for 16 pixels (8 chroma pairs) -> NDW = 4*BPP packed dwords in w[].
+// channel value = clip_u8((yb0r + (idx + Y) * cy) >> 16)   (lut_luma); the clamp/shift/pack is pack4_u8_shr16.
 template <int BPP>
-__device__ __forceinline__ void lut16(const SwsLutParams &L, const int (&Y)[16], const int (&U)[8], const int (&V)[8], uint32_t (&w)[4 * BPP])
+__device__ __forceinline__ void lut16(const SwsLutParams &L, const int (&Y)[16], const Chroma8 &c, uint32_t (&w)[4 * BPP])
 {
     if constexpr (BPP == 4) {
+        const int ta = 255 << 16;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const ChromaIdx c = lut_chroma(L, U[k], V[k]);
-            w[2 * k] = lut_rgb32(L, c, Y[2 * k]);
-            w[2 * k + 1] = lut_rgb32(L, c, Y[2 * k + 1]);
-        }
-    } else {
-        int v[48];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const ChromaIdx c = lut_chroma(L, U[k], V[k]);
-            const int k0 = L.rgb_order ? c.b : c.r, k2 = L.rgb_order ? c.r : c.b;
+        for (int k = 0; k < 8; k++)
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int y = Y[2 * k + h];
-                v[6 * k + 3 * h + 0] = lut_luma(L, k0 + y);
-                v[6 * k + 3 * h + 1] = lut_luma(L, c.g + y);
-                v[6 * k + 3 * h + 2] = lut_luma(L, k2 + y);
+                // canonical byte order first,g,third,alpha; L.perm32 moves the bytes to the format's positions
+                const uint32_t px = pack4_u8_shr16(mad24(c.r[k] + y, L.cy, L.yb0r), mad24(c.g[k] + y, L.cy, L.yb0r),
+                                                   mad24(c.b[k] + y, L.cy, L.yb0r), ta);
+                w[2 * k + h] = __builtin_amdgcn_perm(px, px, L.perm32);
             }
-        }
+    } else {
+        int t[48];
 #pragma unroll
-        for (int k = 0; k < 12; k++)
-            w[k] = (uint32_t)v[4 * k] | ((uint32_t)v[4 * k + 1] << 8) | ((uint32_t)v[4 * k + 2] << 16) | ((uint32_t)v[4 * k + 3] << 24);
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int y = Y[2 * k + h];
+                t[6 * k + 3 * h + 0] = mad24(c.r[k] + y, L.cy, L.yb0r);
+                t[6 * k + 3 * h + 1] = mad24(c.g[k] + y, L.cy, L.yb0r);
+                t[6 * k + 3 * h + 2] = mad24(c.b[k] + y, L.cy, L.yb0r);
+            }
+#pragma unroll
+        for (int k = 0; k < 12; k++) w[k] = pack4_u8_shr16(t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
     }
 }
 
 // Transpose the wave's packed pixels through its private LDS region and store them as contiguous 16-byte chunks.
 // seg: global address of the first byte of this wave's 1024-pixel segment (16-byte aligned), seg_bytes: valid bytes.
 // LDS layout: lane l owns dwords [l*LS, l*LS + NDW); LS = 20 for 32 bpp (bank-conflict padding), 12 for 24 bpp.
-template <int BPP>
+template <int BPP, bool XPOSE = true, bool NT = true>
 __device__ __forceinline__ void wave_store16(uint8_t *seg, int seg_bytes, const uint32_t (&w)[4 * BPP], uint32_t *lds, int lane)
 {
     constexpr int NDW = 4 * BPP, LS = BPP == 4 ? 20 : 12, NCH = NDW / 4;
+    if constexpr (!XPOSE) { // experiment: each lane stores its own 16-pixel run (lane stride 48/64 bytes)
+#pragma unroll
+        for (int k = 0; k < NCH; k++) {
+            const int off = lane * NDW * 4 + 16 * k;
+            u32x4 t = { w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
+            if (off + 16 <= seg_bytes) { if constexpr (NT) gstore16_nt(seg + off, t); else *(SWS_GLOBAL u32x4 *)(seg + off) = t; }
+            else if (off < seg_bytes) gstore_partial(seg + off, t, seg_bytes - off);
+        }
+        return;
+    }
     u32x4 *lw = (u32x4 *)(lds + lane * LS);
 #pragma unroll
     for (int k = 0; k < NCH; k++) { u32x4 t = { w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] }; lw[k] = t; }
@@ -109,7 +144,7 @@ __device__ __forceinline__ void wave_store16(uint8_t *seg, int seg_bytes, const 
         const int c = j * 64 + lane;              // 16-byte chunk index inside the segment
         const int off = 16 * c;
         const u32x4 v = *(const u32x4 *)(lds + (c / NCH) * LS + (c % NCH) * 4);
-        if (off + 16 <= seg_bytes) gstore16_nt(seg + off, v);
+        if (off + 16 <= seg_bytes) { if constexpr (NT) gstore16_nt(seg + off, v); else *(SWS_GLOBAL u32x4 *)(seg + off) = v; }
         else if (off < seg_bytes) gstore_partial(seg + off, v, seg_bytes - off);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -121,7 +156,7 @@ __device__ __forceinline__ void wave_store16(uint8_t *seg, int seg_bytes, const 
 // grid.x over (row pair, 1024-pixel segment) in units of waves, 4 waves per block; grid.z = frame.
 // Requires 16-byte aligned planes/strides (else the host picks sws_k_yuv2rgb_unscaled).
 // ------------------------------------------------------------------------------------------
-template <int BPP>
+template <int BPP, bool SWAP_RB, bool XPOSE = true, bool NT = true, int EXP = 0>
 __global__ void __launch_bounds__(256) sws_k_yuv2rgb_unscaled_wave(SwsFrameSet fs, SwsDevParams p, int is422, int npairs,
                                                                    int y0, int nrowpairs)
 {
@@ -141,17 +176,22 @@ __global__ void __launch_bounds__(256) sws_k_yuv2rgb_unscaled_wave(SwsFrameSet f
     const int nvalid = npix - x;                               // pixels of this lane inside the row (may be <= 0)
     int Y[16], U[8], V[8];
     uint32_t w[4 * BPP];
+    Chroma8 c;
 #pragma unroll
     for (int l = 0; l < 2; l++) {
-        if (l == 0 || is422) {
+        if (l == 0 || is422) {   // 4:2:0: both rows of the pair share the chroma row and its LUT indices
             const int cr = crow + (is422 ? l : 0);
             unpack8(load8_or_tail(f.src[1] + (int64_t)cr * f.srcStride[1] + (x >> 1), nvalid >> 1), U);
             unpack8(load8_or_tail(f.src[2] + (int64_t)cr * f.srcStride[2] + (x >> 1), nvalid >> 1), V);
+            chroma8<SWAP_RB>(L, U, V, c);
         }
         unpack16(load16_or_tail(f.src[0] + (int64_t)(yrow + l) * f.srcStride[0] + x, nvalid), Y);
-        lut16<BPP>(L, Y, U, V, w);
+        if constexpr (EXP == 1) { // experiment: memory-only floor (no LUT arithmetic)
+#pragma unroll
+            for (int k = 0; k < 4 * BPP; k++) w[k] = (uint32_t)(Y[k & 15] + U[k & 7] * 256 + V[(k + 3) & 7] * 65536);
+        } else lut16<BPP>(L, Y, c, w);
         uint8_t *segp = f.dst[0] + (int64_t)(yrow + l) * f.dstStride[0] + (int64_t)seg * 1024 * BPP;
-        wave_store16<BPP>(segp, seg_bytes, w, lds, lane);
+        wave_store16<BPP, XPOSE, NT>(segp, seg_bytes, w, lds, lane);
     }
 }
 
@@ -163,7 +203,7 @@ __global__ void __launch_bounds__(256) sws_k_yuv2rgb_unscaled_wave(SwsFrameSet f
 // result); luma rows are per output row.  The host launches this kernel only when every output row is
 // in X mode (no row selects the _1/_2 writers of vscale.c:135-157).
 // ------------------------------------------------------------------------------------------
-template <int BPP, bool NV, int ROWS>
+template <int BPP, bool SWAP_RB, bool NV, int ROWS>
 __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_wave(SwsFrameSet fs, SwsDevParams p)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[4 * 64 * (BPP == 4 ? 20 : 12)];
@@ -244,7 +284,9 @@ __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_wave(SwsFrameSet fs
 #pragma unroll
         for (int k = 0; k < 8; k++) { Uo[k] = U[r][k] >> 19; Vo[k] = V[r][k] >> 19; }
         uint32_t w[4 * BPP];
-        lut16<BPP>(L, Y, Uo, Vo, w);
+        Chroma8 c;
+        chroma8<SWAP_RB>(L, Uo, Vo, c);
+        lut16<BPP>(L, Y, c, w);
         uint8_t *segp = f.dst[0] + (int64_t)y * f.dstStride[0] + (int64_t)seg * 1024 * BPP;
         wave_store16<BPP>(segp, seg_bytes, w, lds, lane);
     }
