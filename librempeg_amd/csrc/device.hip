@@ -24,6 +24,7 @@ struct DeviceState {
     SwsDevParams params;
     bool unity_h = false;
     bool all_x_mode = false;   // every output row uses the general yuv2rgb_X writer (vscale.c:135-169)
+    int chr_window2 = 0;       // max chroma source rows spanned by a pair of output rows (wave kernel register budget)
     void *scratch = nullptr; size_t scratch_bytes = 0;
     void *stage_src = nullptr; size_t stage_src_bytes = 0;
     void *stage_dst = nullptr; size_t stage_dst_bytes = 0;
@@ -241,6 +242,13 @@ int dev_prepare(SwsInternal *c)
                     (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) all_x = false;
             }
             d->all_x_mode = all_x;
+            int win = 0;
+            for (int y = 0; y < o.dst_h; y += 2) {
+                const int c0 = y >> c->chrDstVSubSample, c1 = std::min(y + 1, o.dst_h - 1) >> c->chrDstVSubSample;
+                const int lo = std::min(c->vChr.pos[c0], c->vChr.pos[c1]), hi = std::max(c->vChr.pos[c0], c->vChr.pos[c1]) + cfs - 1;
+                win = std::max(win, hi - lo + 1);
+            }
+            d->chr_window2 = win;
         }
     }
 
@@ -446,12 +454,12 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         const bool rgb_lut = rgb && !p.full_chr;
         if (d->unity_h && rgb_lut && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;
-            if (vec && !no_wave && d->all_x_mode) { // wave-tiled kernel: 1024 pixels x 2 rows per wave
+            if (vec && !no_wave && d->all_x_mode && d->chr_window2 <= 8 && p.vChrFs <= 64) { // wave-tiled kernel: 1024 pixels x 2 rows per wave
                 constexpr int ROWS = 2;
                 const int segs = (p.dstW + 1023) >> 10, rgroups = (p.dstH + ROWS - 1) / ROWS;
-                const dim3 gridw(cdiv((int64_t)segs * rgroups, 4), 1, n);
+                const dim3 gridw((cdiv((int64_t)segs * rgroups, 4) + 7) & ~7u, 1, n); // multiple of 8: XCD-aware order
                 const bool swap = b4 ? p.lut.swap_rb32 != 0 : p.lut.rgb_order != 0;
-#define LAUNCH_WAVE(B, S, N) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave<B, S, N, ROWS>), gridw, blk, 0, st, fs, p)
+#define LAUNCH_WAVE(B, S, N) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave<B, S, N, ROWS, 8>), gridw, blk, 0, st, fs, p)
                 if (b4) { if (nv) { if (swap) LAUNCH_WAVE(4, true, true); else LAUNCH_WAVE(4, false, true); }
                           else    { if (swap) LAUNCH_WAVE(4, true, false); else LAUNCH_WAVE(4, false, false); } }
                 else    { if (nv) { if (swap) LAUNCH_WAVE(3, true, true); else LAUNCH_WAVE(3, false, true); }

@@ -161,7 +161,9 @@ __global__ void __launch_bounds__(256) sws_k_yuv2rgb_unscaled_wave(SwsFrameSet f
                                                                    int y0, int nrowpairs)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[4 * 64 * (BPP == 4 ? 20 : 12)];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in the block: scalar, so that rows,
+                                                                        // segments, taps and branches below are wave-uniform (SGPR)
     uint32_t *lds = lds_all + wib * 64 * (BPP == 4 ? 20 : 12);
     const int npix = 2 * npairs;                               // pixels the reference's block structure covers
     const int segs = (npix + 1023) >> 10;                      // waves per row
@@ -200,19 +202,26 @@ __global__ void __launch_bounds__(256) sws_k_yuv2rgb_unscaled_wave(SwsFrameSet f
 // LUT writer, general vertical filters in "X" mode (yuv2rgb_X_c_template, output.c:1788-1840).
 // Wave = 1024 pixels x ROWS output rows.  Chroma source rows are loaded ONCE per lane and accumulated
 // into the ROWS outputs that use them (integer adds are associative, so the order is irrelevant to the
-// result); luma rows are per output row.  The host launches this kernel only when every output row is
+// result); luma rows are per output row.  Vertical taps sit one-per-lane in a VGPR and are broadcast with
+// v_readlane (no memory access inside the accumulation loop).  The host launches this kernel only when every output row is
 // in X mode (no row selects the _1/_2 writers of vscale.c:135-157).
 // ------------------------------------------------------------------------------------------
-template <int BPP, bool SWAP_RB, bool NV, int ROWS>
+template <int BPP, bool SWAP_RB, bool NV, int ROWS, int NCR>
 __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_wave(SwsFrameSet fs, SwsDevParams p)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[4 * 64 * (BPP == 4 ? 20 : 12)];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *lds = lds_all + wib * 64 * (BPP == 4 ? 20 : 12);
     const int npix = p.dstW;                                   // even (odd widths force the full-chroma writers)
     const int segs = (npix + 1023) >> 10;
     const int rgroups = (p.dstH + ROWS - 1) / ROWS;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + wib;
+    // XCD-aware block order: the dispatcher places block b on XCD b % 8 (speed-only assumption, gridDim.x is a
+    // multiple of 8).  Give every XCD a contiguous band of row groups so that the chroma source rows shared by
+    // vertically adjacent row groups are re-read from that XCD's own L2 instead of from the fabric.
+    const int per_xcd = gridDim.x >> 3;
+    const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t wid = (int64_t)lb * 4 + wib;
     if (wid >= (int64_t)segs * rgroups) return;
     const int rg = (int)(wid / segs), seg = (int)(wid % segs);
     const FrameRegs f = load_frame(fs, blockIdx.z);
@@ -225,42 +234,65 @@ __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_wave(SwsFrameSet fs
     const int yb = rg * ROWS;
     const int nrows = min(ROWS, p.dstH - yb);
 
-    int U[ROWS][8], V[ROWS][8];
-    int firstC[ROWS], cyr[ROWS];
+    // per output row: chroma window start (scalar) and its taps, one tap per lane (read back with v_readlane)
+    int firstC[ROWS], wv[ROWS];
     int cmin = 0x7fffffff, cmax = -1;
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         const int y = min(yb + r, p.dstH - 1);
-        cyr[r] = y >> p.chrDstVSub;
-        firstC[r] = max(1 - cfs, p.vChrPos[cyr[r]]);
+        const int cy = y >> p.chrDstVSub;
+        firstC[r] = max(1 - cfs, p.vChrPos[cy]);
+        wv[r] = lane < cfs ? (int)p.vChrF[cy * cfs + lane] : 0;
         cmin = min(cmin, firstC[r]); cmax = max(cmax, firstC[r] + cfs - 1);
+    }
+    // issue the loads of every chroma source row of the group first (host guarantees cmax - cmin < NCR) ...
+    const bool u1 = p.u_plane_src == 1;   // planes selected with ?: (runtime-indexed FrameRegs would go to scratch)
+    const uint8_t *ub = u1 ? f.src[1] : f.src[2], *vb = u1 ? f.src[2] : f.src[1];
+    const int us = u1 ? f.srcStride[1] : f.srcStride[2], vs = u1 ? f.srcStride[2] : f.srcStride[1];
+    u32x4 craw[NCR];
+#pragma unroll
+    for (int i = 0; i < NCR; i++) {
+        const int cr = cmin + i;
+        if (cr <= cmax) {
+            const int srow = min(max(cr, 0), cH);
+            if constexpr (NV) craw[i] = load16_or_tail(f.src[1] + (int64_t)srow * f.srcStride[1] + x, nvalid);
+            else {
+                const u32x2 a = load8_or_tail(ub + (int64_t)srow * us + (x >> 1), nvalid >> 1);
+                const u32x2 b = load8_or_tail(vb + (int64_t)srow * vs + (x >> 1), nvalid >> 1);
+                u32x4 t = { a[0], a[1], b[0], b[1] };
+                craw[i] = t;
+            }
+        }
+    }
+    // ... then accumulate each of them into every output row whose window contains it
+    int U[ROWS][8], V[ROWS][8];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
 #pragma unroll
         for (int k = 0; k < 8; k++) U[r][k] = V[r][k] = 1 << 18;
-    }
-    // chroma rows [cmin, cmax]: load once, accumulate into every output row whose window contains them
-    for (int cr = cmin; cr <= cmax; cr++) {
-        const int srow = min(max(cr, 0), cH);
-        int u[8], v[8];
-        if constexpr (NV) {
-            int t[16];
-            unpack16(load16_or_tail(f.src[1] + (int64_t)srow * f.srcStride[1] + x, nvalid), t);
 #pragma unroll
-            for (int k = 0; k < 8; k++) { u[k] = t[2 * k + p.uv_swap_src]; v[k] = t[2 * k + 1 - p.uv_swap_src]; }
-        } else {
-            // planes 1/2 selected with ?: (a runtime index into the register-resident FrameRegs would go to scratch)
-            const bool u1 = p.u_plane_src == 1;
-            const uint8_t *ub = u1 ? f.src[1] : f.src[2], *vb = u1 ? f.src[2] : f.src[1];
-            const int us = u1 ? f.srcStride[1] : f.srcStride[2], vs = u1 ? f.srcStride[2] : f.srcStride[1];
-            unpack8(load8_or_tail(ub + (int64_t)srow * us + (x >> 1), nvalid >> 1), u);
-            unpack8(load8_or_tail(vb + (int64_t)srow * vs + (x >> 1), nvalid >> 1), v);
-        }
+    for (int i = 0; i < NCR; i++) {
+        const int cr = cmin + i;
+        if (cr <= cmax) {
+            int u[8], v[8];
+            if constexpr (NV) {
+                int t[16];
+                unpack16(craw[i], t);
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            const int j = cr - firstC[r];
-            if (j >= 0 && j < cfs) {                              // wave-uniform
-                const int wgt = p.vChrF[cyr[r] * cfs + j];
+                for (int k = 0; k < 8; k++) { u[k] = t[2 * k + p.uv_swap_src]; v[k] = t[2 * k + 1 - p.uv_swap_src]; }
+            } else {
+                u32x2 a = { craw[i][0], craw[i][1] }, b = { craw[i][2], craw[i][3] };
+                unpack8(a, u); unpack8(b, v);
+            }
 #pragma unroll
-                for (int k = 0; k < 8; k++) { U[r][k] = mad24(u[k] << 7, wgt, U[r][k]); V[r][k] = mad24(v[k] << 7, wgt, V[r][k]); }
+            for (int r = 0; r < ROWS; r++) {
+                const int j = cr - firstC[r];
+                if (j >= 0 && j < cfs) {                              // wave-uniform
+                    // (u << 7) * w == u * (w << 7); |w << 7| < 2^23 so the product stays a full-rate 24-bit multiply
+                    const int wgt = __builtin_amdgcn_readlane(wv[r], j) << 7;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { U[r][k] = mad24(u[k], wgt, U[r][k]); V[r][k] = mad24(v[k], wgt, V[r][k]); }
+                }
             }
         }
     }
@@ -271,16 +303,21 @@ __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_wave(SwsFrameSet fs
         const int16_t *lf = p.vLumF + y * lfs;
         const int firstL = max(1 - lfs, p.vLumPos[y]);
         int Y[16], Uo[8], Vo[8], t[16];
+        if (lfs == 1 && lf[0] == 4096) {
+            // ((1 << 18) + (y << 7) * 4096) >> 19 == y: identity vertical luma filter (same-height conversions)
+            unpack16(load16_or_tail(f.src[0] + (int64_t)min(firstL, lH) * f.srcStride[0] + x, nvalid), Y);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 16; k++) Y[k] = 1 << 18;
-        for (int j = 0; j < lfs; j++) {
-            unpack16(load16_or_tail(f.src[0] + (int64_t)min(firstL + j, lH) * f.srcStride[0] + x, nvalid), t);
-            const int wgt = lf[j];
+            for (int k = 0; k < 16; k++) Y[k] = 1 << 18;
+            for (int j = 0; j < lfs; j++) {
+                unpack16(load16_or_tail(f.src[0] + (int64_t)min(firstL + j, lH) * f.srcStride[0] + x, nvalid), t);
+                const int wgt = (int)lf[j] << 7;
 #pragma unroll
-            for (int k = 0; k < 16; k++) Y[k] = mad24(t[k] << 7, wgt, Y[k]);
+                for (int k = 0; k < 16; k++) Y[k] = mad24(t[k], wgt, Y[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) Y[k] >>= 19;
         }
-#pragma unroll
-        for (int k = 0; k < 16; k++) Y[k] >>= 19;
 #pragma unroll
         for (int k = 0; k < 8; k++) { Uo[k] = U[r][k] >> 19; Vo[k] = V[r][k] >> 19; }
         uint32_t w[4 * BPP];
