@@ -9,6 +9,7 @@
 #include <cstring>
 #include <vector>
 
+#include "kernels_tile.hpp"
 #include "kernels_wave.hpp"
 #include "swsint.hpp"
 
@@ -22,9 +23,10 @@ struct DeviceState {
     bool own_stream = false;
     void *d_tables = nullptr; size_t tables_bytes = 0;
     SwsDevParams params;
-    bool unity_h = false;
+    bool unity_h = false, unity_v = false;
     bool all_x_mode = false;   // every output row uses the general yuv2rgb_X writer (vscale.c:135-169)
     int chr_window2 = 0;       // max chroma source rows spanned by a pair of output rows (wave kernel register budget)
+    bool tile_ok = false; SwsTileGeom tileL, tileC; void *d_tilegeom = nullptr; size_t tilegeom_bytes = 0;
     void *scratch = nullptr; size_t scratch_bytes = 0;
     void *stage_src = nullptr; size_t stage_src_bytes = 0;
     void *stage_dst = nullptr; size_t stage_dst_bytes = 0;
@@ -67,6 +69,7 @@ void dev_release(SwsInternal *c)
     if (d->d_frames) (void)hipFree(d->d_frames);
     if (d->h_frames) (void)hipHostFree(d->h_frames);
     if (d->casc_img) (void)hipFree(d->casc_img);
+    if (d->d_tilegeom) (void)hipFree(d->d_tilegeom);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
     delete d;
@@ -231,6 +234,63 @@ int dev_prepare(SwsInternal *c)
         p.vLumF = (const int16_t *)(b + offs_t[2]); p.vLumPos = (const int32_t *)(b + offs_p[2]); p.vLumFs = c->vLum.size;
         p.vChrF = (const int16_t *)(b + offs_t[3]); p.vChrPos = (const int32_t *)(b + offs_p[3]); p.vChrFs = c->vChr.size;
         d->unity_h = bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14);
+        d->unity_v = bank_is_identity(c->vLum, 1 << 12) && bank_is_identity(c->vChr, 1 << 12);
+        // ---- fused h+v tile kernel geometry (planar / semi-planar YUV outputs, non-identity horizontal filters) ----
+        d->tile_ok = false;
+        if (!d->unity_h && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16 ||
+                            p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010) && !std::getenv("SWS_HIP_NO_TILE")) {
+            const size_t hsz = p.wide ? 4 : 2;
+            auto plan = [&](const FilterBank &hb, const FilterBank &vb, int W, int H, int sW, int sH, int ncomp,
+                            SwsTileGeom &g, std::vector<int32_t> &arr) -> bool {
+                const int TW = 128;
+                for (int TH : { 32, 16, 8, 4, 2, 1 }) {
+                    const int tX = (W + TW - 1) / TW, tY = (H + TH - 1) / TH;
+                    std::vector<int32_t> rs(tY), rc(tY), cs(tX), cc(tX);
+                    int nrmax = 0, ncmax = 0;
+                    for (int t = 0; t < tY; t++) {
+                        int lo = INT32_MAX, hi = -1;
+                        for (int y = t * TH; y < std::min(H, (t + 1) * TH); y++) {
+                            lo = std::min(lo, vb.pos[y]); hi = std::max(hi, std::min(vb.pos[y] + vb.size - 1, sH - 1));
+                        }
+                        rs[t] = lo; rc[t] = hi - lo + 1; nrmax = std::max(nrmax, rc[t]);
+                    }
+                    for (int t = 0; t < tX; t++) {
+                        int lo = INT32_MAX, hi = -1;
+                        for (int x = t * TW; x < std::min(W, (t + 1) * TW); x++) {
+                            lo = std::min(lo, hb.pos[x]); hi = std::max(hi, hb.pos[x] + hb.size - 1);
+                        }
+                        cs[t] = lo; cc[t] = hi - lo + 1; ncmax = std::max(ncmax, cc[t]);
+                    }
+                    const size_t lds = (((size_t)nrmax * ncmax * 2 + 15) & ~(size_t)15) + (size_t)ncomp * nrmax * TW * hsz;
+                    if (lds > 64 * 1024) continue;
+                    g.TW = TW; g.TH = TH; g.tilesX = tX; g.tilesY = tY; g.NRmax = nrmax; g.NCmax = ncmax; g.lds_bytes = (int32_t)lds;
+                    arr.clear();
+                    arr.insert(arr.end(), rs.begin(), rs.end()); arr.insert(arr.end(), rc.begin(), rc.end());
+                    arr.insert(arr.end(), cs.begin(), cs.end()); arr.insert(arr.end(), cc.begin(), cc.end());
+                    return true;
+                }
+                return false;
+            };
+            std::vector<int32_t> aL, aC;
+            if (plan(c->hLum, c->vLum, p.dstW, p.dstH, p.srcW, p.srcH, 1, d->tileL, aL) &&
+                plan(c->hChr, c->vChr, p.chrDstW, p.chrDstH, p.chrSrcW, p.chrSrcH, 2, d->tileC, aC)) {
+                const size_t bytes = (aL.size() + aC.size()) * sizeof(int32_t);
+                if (bytes > d->tilegeom_bytes) {
+                    if (d->d_tilegeom) HIPCHK(hipFree(d->d_tilegeom));
+                    d->d_tilegeom = nullptr;
+                    HIPCHK(hipMalloc(&d->d_tilegeom, bytes));
+                    d->tilegeom_bytes = bytes;
+                }
+                std::vector<int32_t> all(aL); all.insert(all.end(), aC.begin(), aC.end());
+                HIPCHK(hipMemcpy(d->d_tilegeom, all.data(), bytes, hipMemcpyHostToDevice));
+                const int32_t *bL = (const int32_t *)d->d_tilegeom, *bC = bL + aL.size();
+                auto bind = [](SwsTileGeom &g, const int32_t *b) {
+                    g.rowStart = b; g.rowCount = b + g.tilesY; g.colStart = b + 2 * g.tilesY; g.colCount = b + 2 * g.tilesY + g.tilesX;
+                };
+                bind(d->tileL, bL); bind(d->tileC, bC);
+                d->tile_ok = true;
+            }
+        }
         {   // packed_vscale picks yuv2packed1 / yuv2packed2 per row from (lfs, cfs, taps): vscale.c:135-157
             const int lfs = c->vLum.size, cfs = c->vChr.size;
             bool all_x = !(lfs == 1 && cfs == 1);
@@ -265,9 +325,14 @@ int dev_prepare(SwsInternal *c)
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
         if (d->unity_h && rgb_lut && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             c->path_name = "main:fused_rgb_unity"; c->kernel_name = "sws_k_rgb_fused_unity_wave";
+        } else if (d->unity_h && d->unity_v && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 &&
+                   (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16)) {
+            c->path_name = "main:fused_f32rgb_yuv444"; c->kernel_name = "sws_k_f32rgb_to_yuv444_unity";
         } else if (d->unity_h) {
             c->path_name = "main:fused_generic_unity";
             c->kernel_name = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) ? "sws_k_vscale_rgb" : "sws_k_vscale_planar";
+        } else if (d->tile_ok) {
+            c->path_name = "main:fused_tile"; c->kernel_name = "sws_k_tile_planar";
         } else {
             c->path_name = "main:two_pass";
             c->kernel_name = "sws_k_hscale";
@@ -475,6 +540,23 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
             else    { if (nv) { if (vec) LAUNCH_FUSED(3, true, true); else LAUNCH_FUSED(3, true, false); }
                       else    { if (vec) LAUNCH_FUSED(3, false, true); else LAUNCH_FUSED(3, false, false); } }
 #undef LAUNCH_FUSED
+            break;
+        }
+        if (vec && d->unity_h && d->unity_v && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 &&
+            (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16)) {
+            const dim3 g(cdiv((int64_t)((p.srcW + 3) >> 2) * p.srcH, 256), 1, n);
+            hipLaunchKernelGGL(swsk::sws_k_f32rgb_to_yuv444_unity, g, blk, 0, st, fs, p);
+            break;
+        }
+        if (d->tile_ok) { // fused h+v LDS-tile kernel: one launch for luma, one for chroma
+            const dim3 gl(d->tileL.tilesX, d->tileL.tilesY, n), gc(d->tileC.tilesX, d->tileC.tilesY, n);
+            if (p.wide) {
+                hipLaunchKernelGGL((swsk::sws_k_tile_planar<int32_t, false>), gl, blk, d->tileL.lds_bytes, st, fs, p, d->tileL);
+                hipLaunchKernelGGL((swsk::sws_k_tile_planar<int32_t, true>), gc, blk, d->tileC.lds_bytes, st, fs, p, d->tileC);
+            } else {
+                hipLaunchKernelGGL((swsk::sws_k_tile_planar<int16_t, false>), gl, blk, d->tileL.lds_bytes, st, fs, p, d->tileL);
+                hipLaunchKernelGGL((swsk::sws_k_tile_planar<int16_t, true>), gc, blk, d->tileC.lds_bytes, st, fs, p, d->tileC);
+            }
             break;
         }
         // generic: optional pass 1 into scratch, then writers

@@ -54,6 +54,13 @@ struct SwsLutParams {       // closed form of the yuv2rgb LUTs (yuv2rgb.c:680-70
     int32_t r_pos, g_pos, b_pos, a_pos, pix_step;
 };
 
+struct SwsTileGeom {        // fused h+v tile kernel: per component group, from the filter banks (host)
+    int32_t TW, TH, tilesX, tilesY, NRmax, NCmax;
+    const int32_t *rowStart, *rowCount;   // [tilesY] first source row / number of source rows a tile row needs
+    const int32_t *colStart, *colCount;   // [tilesX] first source column / number of source columns
+    int32_t lds_bytes;
+};
+
 struct SwsDevParams {
     int32_t srcW, srcH, dstW, dstH;
     int32_t chrSrcW, chrSrcH, chrDstW, chrDstH;

@@ -330,3 +330,80 @@ __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_wave(SwsFrameSet fs
 }
 
 } // namespace swsk
+
+namespace swsk {
+
+// ------------------------------------------------------------------------------------------
+// C5: planar float RGB -> planar 4:4:4 YUV with identity filters in both directions
+// (planar_rgbf32_to_y/uv input.c:1300-1334 -> hScale16To15/19_c with 1 tap -> lum/chrRange*Jpeg(16)_c ->
+//  yuv2plane1_{8,10,16}_c).  Every pixel is independent: lane = 4 pixels (3 x 16-byte float loads, 3 stores),
+// all three output planes come from ONE pass over the input (the generic path re-reads and re-quantises the
+// three float planes once per output plane).  grid.x over 4-pixel groups of a frame, grid.z = frame.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) sws_k_f32rgb_to_yuv444_unity(SwsFrameSet fs, SwsDevParams p)
+{
+    const int groups = (p.srcW + 3) >> 2;
+    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= (int64_t)groups * p.srcH) return;
+    const int y = (int)(item / groups), x = 4 * (int)(item % groups);
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int n = min(4, p.srcW - x);
+    float g[4], b[4], r[4];
+    const uint8_t *pg = f.src[0] + (int64_t)y * f.srcStride[0] + 4 * x, *pb = f.src[1] + (int64_t)y * f.srcStride[1] + 4 * x,
+                  *pr = f.src[2] + (int64_t)y * f.srcStride[2] + 4 * x;
+    if (n == 4) {
+        const f32x4 vg = *(const SWS_GLOBAL f32x4 *)pg, vb = *(const SWS_GLOBAL f32x4 *)pb, vr = *(const SWS_GLOBAL f32x4 *)pr;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { g[k] = vg[k]; b[k] = vb[k]; r[k] = vr[k]; }
+    } else {
+        for (int k = 0; k < 4; k++) {
+            const bool in = k < n;
+            g[k] = in ? ((const float *)pg)[k] : 0.f; b[k] = in ? ((const float *)pb)[k] : 0.f; r[k] = in ? ((const float *)pr)[k] : 0.f;
+        }
+    }
+    const int32_t *t = p.rgb2yuv;
+    int out[3][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int gi = f32_to_u16(g[k]), bi = f32_to_u16(b[k]), ri = f32_to_u16(r[k]);
+        // 16-bit samples x 15-bit coefficients: 24-bit multiplies, 32-bit wrap-around sums like the C code
+        int c[3];
+        c[0] = (int)((unsigned)(mad24(t[0], ri, mad24(t[1], gi, __mul24(t[2], bi))) + (int)(0x2001u << 14))) >> 15;
+        c[1] = (int)((unsigned)(mad24(t[3], ri, mad24(t[4], gi, __mul24(t[5], bi))) + (int)(0x10001u << 14))) >> 15;
+        c[2] = (int)((unsigned)(mad24(t[6], ri, mad24(t[7], gi, __mul24(t[8], bi))) + (int)(0x10001u << 14))) >> 15;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            int v = min((int)(((uint16_t)c[q] * 16384u) >> p.hshift), p.hclip);   // 1-tap hscale of the u16 line
+            if (!p.wide) v = (int16_t)v;
+            out[q][k] = range_sample(p, v, q != 0);
+        }
+    }
+    // vertical 1-tap writers (yuv2plane1_*): planes Y, U, V
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int pl = q == 0 ? 0 : q == 1 ? 1 : 2;  // yuv444p*: U = plane 1, V = plane 2
+        uint8_t *d = f.dst[pl] + (int64_t)y * f.dstStride[pl];
+        if (p.dstKind == DSTK_PLANAR16) {
+            uint16_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) o[k] = (uint16_t)clip_u16((out[q][k] + 4) >> 3);
+            if (n == 4) { u16x4 v = { o[0], o[1], o[2], o[3] }; *(SWS_GLOBAL u16x4 *)(d + 2 * x) = v; }
+            else for (int k = 0; k < n; k++) ((uint16_t *)d)[x + k] = o[k];
+        } else if (p.dstKind == DSTK_PLANARN) {
+            const int shift = 15 - p.dst_bits;
+            uint16_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) o[k] = (uint16_t)clip_uintp2((out[q][k] + (1 << (shift - 1))) >> shift, p.dst_bits);
+            if (n == 4) { u16x4 v = { o[0], o[1], o[2], o[3] }; *(SWS_GLOBAL u16x4 *)(d + 2 * x) = v; }
+            else for (int k = 0; k < n; k++) ((uint16_t *)d)[x + k] = o[k];
+        } else {
+            const int off = q == 2 ? 3 : 0;
+            for (int k = 0; k < n; k++) d[x + k] = (uint8_t)clip_u8_shr(out[q][k] + dither8(p.should_dither, y, x + k + off), 7);
+        }
+    }
+}
+
+} // namespace swsk
