@@ -27,6 +27,7 @@ struct DeviceState {
     bool all_x_mode = false;   // every output row uses the general yuv2rgb_X writer (vscale.c:135-169)
     int chr_window2 = 0;       // max chroma source rows spanned by a pair of output rows (wave kernel register budget)
     bool tile_ok = false; SwsTileGeom tileL, tileC; void *d_tilegeom = nullptr; size_t tilegeom_bytes = 0;
+    bool dot2_ok = false; SwsTileGeom dotL, dotC; void *d_dot2 = nullptr; size_t dot2_bytes = 0;
     void *scratch = nullptr; size_t scratch_bytes = 0;
     void *stage_src = nullptr; size_t stage_src_bytes = 0;
     void *stage_dst = nullptr; size_t stage_dst_bytes = 0;
@@ -70,6 +71,7 @@ void dev_release(SwsInternal *c)
     if (d->h_frames) (void)hipHostFree(d->h_frames);
     if (d->casc_img) (void)hipFree(d->casc_img);
     if (d->d_tilegeom) (void)hipFree(d->d_tilegeom);
+    if (d->d_dot2) (void)hipFree(d->d_dot2);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
     delete d;
@@ -235,6 +237,76 @@ int dev_prepare(SwsInternal *c)
         p.vChrF = (const int16_t *)(b + offs_t[3]); p.vChrPos = (const int32_t *)(b + offs_p[3]); p.vChrFs = c->vChr.size;
         d->unity_h = bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14);
         d->unity_v = bank_is_identity(c->vLum, 1 << 12) && bank_is_identity(c->vChr, 1 << 12);
+        // ---- dot2 tile kernel (sws_k_tile_dot2): planar 8-bit / <= 15-bit sources, 15-bit intermediates, vfs >= 2 ----
+        d->dot2_ok = false;
+        {
+            const bool src_ok = p.srcKind == SRCK_PLANAR8 || (p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15);
+            const bool dst_ok = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010;
+            auto fs2 = [](int fs) { return (fs + 2) & ~1; };
+            if (!d->unity_h && src_ok && dst_ok && !p.wide && c->vLum.size >= 2 && c->vChr.size >= 2 &&
+                fs2(c->hLum.size) <= 16 && fs2(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && fs2(c->vChr.size) <= 16 &&
+                !std::getenv("SWS_HIP_NO_DOT2")) {
+                const int SPC = p.srcKind == SRCK_PLANAR16 ? 8 : 16;
+                std::vector<uint8_t> blob;
+                auto put = [&](const void *ptr, size_t n) { size_t o = (blob.size() + 15) & ~(size_t)15; blob.resize(o + n); std::memcpy(blob.data() + o, ptr, n); return o; };
+                auto padded = [&](const FilterBank &b) {
+                    const int f2 = fs2(b.size);
+                    std::vector<int16_t> t((size_t)b.count * f2, 0);
+                    for (int i = 0; i < b.count; i++)
+                        for (int j = 0; j < b.size; j++) t[(size_t)i * f2 + (b.pos[i] & 1) + j] = b.taps[(size_t)i * b.size + j];
+                    return t;
+                };
+                struct Off { size_t rs, rc, cs, cc, ht, vt; };
+                auto plan2 = [&](const FilterBank &hb, const FilterBank &vb, int W, int H, int ncomp, SwsTileGeom &g, Off &o) -> bool {
+                    const int TW = 128, hf2 = fs2(hb.size), vf2 = fs2(vb.size);
+                    for (int TH : { 32, 16, 8, 4, 2 }) {
+                        const int tX = (W + TW - 1) / TW, tY = (H + TH - 1) / TH;
+                        std::vector<int32_t> rs(tY), rc(tY), cs(tX), cc(tX);
+                        int nrmax = 0, ncmax = 0;
+                        for (int t = 0; t < tY; t++) {
+                            int lo = INT32_MAX, hi = -1;
+                            for (int y = t * TH; y < std::min(H, (t + 1) * TH); y++) { lo = std::min(lo, vb.pos[y] & ~1); hi = std::max(hi, (vb.pos[y] & ~1) + vf2); }
+                            rs[t] = lo; rc[t] = (hi - lo + 1) & ~1; nrmax = std::max(nrmax, rc[t]);
+                        }
+                        for (int t = 0; t < tX; t++) {
+                            int lo = INT32_MAX, hi = -1;
+                            for (int x = t * TW; x < std::min(W, (t + 1) * TW); x++) { lo = std::min(lo, hb.pos[x] & ~1); hi = std::max(hi, (hb.pos[x] & ~1) + hf2); }
+                            lo = lo / SPC * SPC;
+                            cs[t] = lo; cc[t] = (hi - lo + SPC - 1) / SPC * SPC; ncmax = std::max(ncmax, cc[t]);
+                        }
+                        const size_t lds = (size_t)nrmax * ncmax * 2 + (size_t)ncomp * (nrmax / 2) * TW * 4;
+                        if (lds > 40 * 1024 && TH > 2) continue;
+                        if (lds > 64 * 1024) return false;
+                        g.TW = TW; g.TH = TH; g.tilesX = tX; g.tilesY = tY; g.NRmax = nrmax; g.NCmax = ncmax; g.lds_bytes = (int32_t)lds;
+                        g.hfs2 = hf2; g.vfs2 = vf2;
+                        o.rs = put(rs.data(), rs.size() * 4); o.rc = put(rc.data(), rc.size() * 4);
+                        o.cs = put(cs.data(), cs.size() * 4); o.cc = put(cc.data(), cc.size() * 4);
+                        const std::vector<int16_t> ht = padded(hb), vt = padded(vb);
+                        o.ht = put(ht.data(), ht.size() * 2); o.vt = put(vt.data(), vt.size() * 2);
+                        return true;
+                    }
+                    return false;
+                };
+                Off oL, oC;
+                if (plan2(c->hLum, c->vLum, p.dstW, p.dstH, 1, d->dotL, oL) && plan2(c->hChr, c->vChr, p.chrDstW, p.chrDstH, 2, d->dotC, oC)) {
+                    if (blob.size() > d->dot2_bytes) {
+                        if (d->d_dot2) HIPCHK(hipFree(d->d_dot2));
+                        d->d_dot2 = nullptr;
+                        HIPCHK(hipMalloc(&d->d_dot2, blob.size()));
+                        d->dot2_bytes = blob.size();
+                    }
+                    HIPCHK(hipMemcpy(d->d_dot2, blob.data(), blob.size(), hipMemcpyHostToDevice));
+                    auto bind = [&](SwsTileGeom &g, const Off &o) {
+                        const uint8_t *b = (const uint8_t *)d->d_dot2;
+                        g.rowStart = (const int32_t *)(b + o.rs); g.rowCount = (const int32_t *)(b + o.rc);
+                        g.colStart = (const int32_t *)(b + o.cs); g.colCount = (const int32_t *)(b + o.cc);
+                        g.hT2 = (const int16_t *)(b + o.ht); g.vT2 = (const int16_t *)(b + o.vt);
+                    };
+                    bind(d->dotL, oL); bind(d->dotC, oC);
+                    d->dot2_ok = true;
+                }
+            }
+        }
         // ---- fused h+v tile kernel geometry (planar / semi-planar YUV outputs, non-identity horizontal filters) ----
         d->tile_ok = false;
         if (!d->unity_h && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16 ||
@@ -331,6 +403,8 @@ int dev_prepare(SwsInternal *c)
         } else if (d->unity_h) {
             c->path_name = "main:fused_generic_unity";
             c->kernel_name = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) ? "sws_k_vscale_rgb" : "sws_k_vscale_planar";
+        } else if (d->dot2_ok) {
+            c->path_name = "main:fused_tile_dot2"; c->kernel_name = "sws_k_tile_dot2";
         } else if (d->tile_ok) {
             c->path_name = "main:fused_tile"; c->kernel_name = "sws_k_tile_planar";
         } else {
@@ -546,6 +620,17 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
             (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16)) {
             const dim3 g(cdiv((int64_t)((p.srcW + 3) >> 2) * p.srcH, 256), 1, n);
             hipLaunchKernelGGL(swsk::sws_k_f32rgb_to_yuv444_unity, g, blk, 0, st, fs, p);
+            break;
+        }
+        if (d->dot2_ok && vec) { // dot2 LDS-tile kernel: one launch for luma, one for chroma
+            const dim3 gl(d->dotL.tilesX, d->dotL.tilesY, n), gc(d->dotC.tilesX, d->dotC.tilesY, n);
+            if (p.srcKind == SRCK_PLANAR16) {
+                hipLaunchKernelGGL((swsk::sws_k_tile_dot2<true, false>), gl, blk, d->dotL.lds_bytes, st, fs, p, d->dotL);
+                hipLaunchKernelGGL((swsk::sws_k_tile_dot2<true, true>), gc, blk, d->dotC.lds_bytes, st, fs, p, d->dotC);
+            } else {
+                hipLaunchKernelGGL((swsk::sws_k_tile_dot2<false, false>), gl, blk, d->dotL.lds_bytes, st, fs, p, d->dotL);
+                hipLaunchKernelGGL((swsk::sws_k_tile_dot2<false, true>), gc, blk, d->dotC.lds_bytes, st, fs, p, d->dotC);
+            }
             break;
         }
         if (d->tile_ok) { // fused h+v LDS-tile kernel: one launch for luma, one for chroma

@@ -59,6 +59,8 @@ struct SwsTileGeom {        // fused h+v tile kernel: per component group, from 
     const int32_t *rowStart, *rowCount;   // [tilesY] first source row / number of source rows a tile row needs
     const int32_t *colStart, *colCount;   // [tilesX] first source column / number of source columns
     int32_t lds_bytes;
+    // dot2 variant: tap rows padded to start on an even sample/row and to an even length (host)
+    const int16_t *hT2, *vT2; int32_t hfs2, vfs2;
 };
 
 struct SwsDevParams {

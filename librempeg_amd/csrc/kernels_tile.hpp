@@ -9,6 +9,7 @@
 // from the filter banks (SwsTileGeom); arithmetic is the generic kernels' (same device functions).
 #pragma once
 #include "kernels_generic.hpp"
+#include "kernels_wave.hpp"
 
 namespace swsk {
 
@@ -72,6 +73,182 @@ __global__ void __launch_bounds__(256) sws_k_tile_planar(SwsFrameSet fs, SwsDevP
         if (!CHROMA) planar_write_one(p, smp, f, 0, x0 + xl, y0 + yl);
         else if (nvdst) nv_chroma_write_one(p, smp, f, x0 + xl, y0 + yl);
         else { planar_write_one(p, smp, f, 1, x0 + xl, y0 + yl); planar_write_one(p, smp, f, 2, x0 + xl, y0 + yl); }
+    }
+}
+
+} // namespace swsk
+
+namespace swsk {
+
+// ------------------------------------------------------------------------------------------
+// Optimised fused h+v tile kernel: planar 8-bit or <= 15-bit LE sources, 15-bit (int16) intermediates,
+// vertical filter size >= 2.  Same three phases as sws_k_tile_planar, but
+//   * the source window is staged with 16-byte loads (no per-sample reader),
+//   * both filter stages run on v_dot2c_i32_i16: two taps per instruction on dword-packed sample pairs.
+//     The host pads every tap row so that it starts on an even sample / even row (a leading zero tap when the
+//     filter position is odd; SwsTileGeom.hT2/vT2), window origins are even, so pairs are always aligned;
+//   * the h-scaled tile is stored as row PAIRS ({row 2k, row 2k+1} per dword) so the vertical stage reads one
+//     dword per tap pair; a lane produces 4 adjacent outputs from ds_read_b128 and stores them in one go.
+// Taps that fall outside the window multiply by zero (integer arithmetic: 0 * garbage == 0).
+// ------------------------------------------------------------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+}
+
+template <bool SRC16, bool CHROMA>
+__global__ void __launch_bounds__(256) sws_k_tile_dot2(SwsFrameSet fs, SwsDevParams p, SwsTileGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tx = blockIdx.x, ty = blockIdx.y, tid = threadIdx.x;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int W = CHROMA ? p.chrDstW : p.dstW, H = CHROMA ? p.chrDstH : p.dstH;
+    const int x0 = tx * g.TW, y0 = ty * g.TH;
+    const int tw = min(g.TW, W - x0), th = min(g.TH, H - y0);
+    const int rs = g.rowStart[ty], nrp = g.rowCount[ty];     // even start row, even row count
+    const int cs = g.colStart[tx], ncp = g.colCount[tx];     // window start aligned to a 16-byte source chunk
+    const int32_t *hpos = CHROMA ? p.hChrPos : p.hLumPos;
+    constexpr int NCOMP = CHROMA ? 2 : 1;
+    constexpr int SPC = SRC16 ? 8 : 16;                      // samples per 16-byte source chunk
+    uint32_t *S = (uint32_t *)smem;                          // [NRmax][NCmax/2] dwords = sample pairs
+    const int srow_dw = g.NCmax >> 1;
+    uint32_t *Hp = (uint32_t *)(smem + (size_t)g.NRmax * g.NCmax * 2);   // NCOMP x [NRmax/2][TW] row-pair dwords
+    const int hplane = (g.NRmax >> 1) * g.TW;
+    const int sH = CHROMA ? p.chrSrcH : p.srcH;
+
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++) {
+        const bool second = CHROMA && ci == 1;
+        const bool u1 = p.u_plane_src == 1;
+        const uint8_t *sb = !CHROMA ? f.src[0] : ((ci == 0) == u1 ? f.src[1] : f.src[2]);
+        const int sst = !CHROMA ? f.srcStride[0] : ((ci == 0) == u1 ? f.srcStride[1] : f.srcStride[2]);
+        if (second) __syncthreads();                          // phase 2 of the previous component still reads S
+        // ---- phase 1: 16-byte chunks of the source window -> LDS as u16 pairs ----
+        const int chunks = ncp / SPC;
+        for (int i = tid; i < nrp * chunks; i += 256) {
+            const int r = i / chunks, ch = i - r * chunks;
+            const int srow = min(rs + r, sH - 1);
+            const int64_t boff = (int64_t)(cs + ch * SPC) * (SRC16 ? 2 : 1);
+            const uint8_t *src = sb + (int64_t)srow * sst + boff;
+            u32x4 v;
+            if (boff + 16 <= (int64_t)(sst < 0 ? -sst : sst)) v = gload16(src);
+            else v = gload16_partial(src, (int)max((int64_t)0, (int64_t)(sst < 0 ? -sst : sst) - boff));
+            uint32_t *dst = S + r * srow_dw + ch * (SPC / 2);
+            if constexpr (SRC16) { *(u32x4 *)dst = v; }
+            else {
+                u32x4 lo, hi;                                  // bytes -> u16 pairs
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    lo[2 * q] = (v[q] & 0xFF) | ((v[q] & 0xFF00) << 8); lo[2 * q + 1] = ((v[q] >> 16) & 0xFF) | ((v[q] >> 8) & 0xFF0000);
+                    hi[2 * q] = (v[q + 2] & 0xFF) | ((v[q + 2] & 0xFF00) << 8); hi[2 * q + 1] = ((v[q + 2] >> 16) & 0xFF) | ((v[q + 2] >> 8) & 0xFF0000);
+                }
+                *(u32x4 *)dst = lo; *(u32x4 *)(dst + 4) = hi;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: horizontal stage on sample pairs; thread = output column, marching down the window ----
+        {
+            const int xl = tid & (g.TW - 1), half = tid / g.TW;    // TW == 128: two row phases
+            if (xl < tw) {
+                const int x = x0 + xl;
+                const int spd = ((hpos[x] & ~1) - cs) >> 1;          // dword index of the first (even-aligned) pair
+                const uint32_t *tp = (const uint32_t *)(g.hT2 + (int64_t)x * g.hfs2);
+                uint32_t t[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) t[k] = 2 * k < g.hfs2 ? tp[k] : 0u;
+                uint32_t *Hc = Hp + ci * hplane;
+                for (int r = half; r < nrp; r += 256 / g.TW) {
+                    const uint32_t *sr = S + r * srow_dw + spd;
+                    int val = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) if (2 * k < g.hfs2) val = dot2(sr[k], t[k], val);
+                    int v = min(val >> p.hshift, p.hclip);
+                    v = range_sample(p, (int16_t)v, CHROMA);
+                    ((uint16_t *)Hc)[((r >> 1) * g.TW + xl) * 2 + (r & 1)] = (uint16_t)v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: vertical stage on row pairs + writer; lane = 4 adjacent outputs of one row ----
+    const int16_t *vT2 = g.vT2;
+    const int32_t *vpos = CHROMA ? p.vChrPos : p.vLumPos;
+    const int q4 = (tw + 3) >> 2;
+    const int bits = p.dst_bits;
+    for (int i = tid; i < q4 * th; i += 256) {
+        const int yl = i / q4, xl = 4 * (i - yl * q4);
+        const int y = y0 + yl, x = x0 + xl;
+        const int n = min(4, tw - xl);
+        const int rpd = ((vpos[y] & ~1) - rs) >> 1;              // first row pair
+        const uint32_t *vt = (const uint32_t *)(vT2 + (int64_t)y * g.vfs2);
+        int acc[NCOMP][4];
+#pragma unroll
+        for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[ci][k] = 0;
+        for (int k = 0; 2 * k < g.vfs2; k++) {
+            const uint32_t w = vt[k];
+#pragma unroll
+            for (int ci = 0; ci < NCOMP; ci++) {
+                const u32x4 hv = *(const u32x4 *)(Hp + ci * hplane + (rpd + k) * g.TW + xl);
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[ci][e] = dot2(hv[e], w, acc[ci][e]);
+            }
+        }
+        // writers, "X" forms (filter size >= 2): output.c:468-483 (8 bit), :344-357 (9..14 bit), :554-569 / :571-589 (P01x),
+        // :495-528 (nv12 chroma)
+        if (!CHROMA || (p.dstKind != DSTK_NV12 && p.dstKind != DSTK_P010)) {
+#pragma unroll
+            for (int ci = 0; ci < NCOMP; ci++) {
+                const int pl = !CHROMA ? 0 : ci == 0 ? p.u_plane_dst : p.v_plane_dst;
+                uint8_t *drow = (pl == 0 ? f.dst[0] : pl == 1 ? f.dst[1] : f.dst[2]) +
+                                (int64_t)y * (pl == 0 ? f.dstStride[0] : pl == 1 ? f.dstStride[1] : f.dstStride[2]);
+                if (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_NV12) {
+                    const int off = (CHROMA && ci == 1) ? 3 : 0;
+                    uint32_t o = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        o |= (uint32_t)clip_u8_shr((dither8(p.should_dither, y, x + e + off) << 12) + acc[ci][e], 19) << (8 * e);
+                    if (n == 4 && !((uintptr_t)(drow + x) & 3)) *(uint32_t *)(drow + x) = o;
+                    else for (int e = 0; e < n; e++) drow[x + e] = (uint8_t)(o >> (8 * e));
+                } else { // DSTK_PLANARN, or the luma plane of P010
+                    const int shift = 11 + 16 - bits, osh = p.dstKind == DSTK_P010 ? p.dst_shift : 0;
+                    uint16_t o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) o[e] = (uint16_t)(clip_uintp2(((1 << (shift - 1)) + acc[ci][e]) >> shift, bits) << osh);
+                    uint16_t *d16 = (uint16_t *)drow + x;
+                    if (n == 4 && !((uintptr_t)d16 & 7)) { u32x2 v = { (uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16) }; *(u32x2 *)d16 = v; }
+                    else for (int e = 0; e < n; e++) d16[e] = o[e];
+                }
+            }
+        } else if constexpr (CHROMA) {
+            uint8_t *drow = f.dst[1] + (int64_t)y * f.dstStride[1];
+            if (p.dstKind == DSTK_NV12) {
+                uint8_t o[8];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int u = clip_u8_shr((dither8(p.should_dither, y, x + e) << 12) + acc[0][e], 19);
+                    const int v = clip_u8_shr((dither8(p.should_dither, y, x + e + 3) << 12) + acc[1][e], 19);
+                    o[2 * e + p.uv_swap_dst] = (uint8_t)u; o[2 * e + 1 - p.uv_swap_dst] = (uint8_t)v;
+                }
+                for (int e = 0; e < 2 * n; e++) drow[2 * x + e] = o[e];
+            } else { // P010 chroma
+                const int shift = 11 + 16 - bits;
+                uint16_t *d16 = (uint16_t *)drow + 2 * x;
+                uint16_t o[8];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    o[2 * e] = (uint16_t)(clip_uintp2(((1 << (shift - 1)) + acc[0][e]) >> shift, bits) << p.dst_shift);
+                    o[2 * e + 1] = (uint16_t)(clip_uintp2(((1 << (shift - 1)) + acc[1][e]) >> shift, bits) << p.dst_shift);
+                }
+                if (n == 4 && !((uintptr_t)d16 & 15)) {
+                    u32x4 v = { (uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16),
+                                (uint32_t)o[4] | ((uint32_t)o[5] << 16), (uint32_t)o[6] | ((uint32_t)o[7] << 16) };
+                    *(u32x4 *)d16 = v;
+                } else for (int e = 0; e < 2 * n; e++) d16[e] = o[e];
+            }
+        }
     }
 }
 
