@@ -9,8 +9,7 @@
 #include <cstring>
 #include <vector>
 
-#include "kernels_tile.hpp"
-#include "kernels_wave.hpp"
+#include "kernels_march.hpp"
 #include "swsint.hpp"
 
 #define AVERROR_EXTERNAL_ (-0x20545845) /* FFERRTAG('E','X','T',' '), libavutil/error.h */
@@ -28,6 +27,7 @@ struct DeviceState {
     int chr_window2 = 0;       // max chroma source rows spanned by a pair of output rows (wave kernel register budget)
     bool tile_ok = false; SwsTileGeom tileL, tileC; void *d_tilegeom = nullptr; size_t tilegeom_bytes = 0;
     bool dot2_ok = false; SwsTileGeom dotL, dotC; void *d_dot2 = nullptr; size_t dot2_bytes = 0;
+    bool march_ok = false; SwsMarchGeom marL, marC; void *d_march = nullptr; size_t march_bytes = 0;
     void *scratch = nullptr; size_t scratch_bytes = 0;
     void *stage_src = nullptr; size_t stage_src_bytes = 0;
     void *stage_dst = nullptr; size_t stage_dst_bytes = 0;
@@ -72,6 +72,7 @@ void dev_release(SwsInternal *c)
     if (d->casc_img) (void)hipFree(d->casc_img);
     if (d->d_tilegeom) (void)hipFree(d->d_tilegeom);
     if (d->d_dot2) (void)hipFree(d->d_dot2);
+    if (d->d_march) (void)hipFree(d->d_march);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
     delete d;
@@ -237,6 +238,64 @@ int dev_prepare(SwsInternal *c)
         p.vChrF = (const int16_t *)(b + offs_t[3]); p.vChrPos = (const int32_t *)(b + offs_p[3]); p.vChrFs = c->vChr.size;
         d->unity_h = bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14);
         d->unity_v = bank_is_identity(c->vLum, 1 << 12) && bank_is_identity(c->vChr, 1 << 12);
+        // ---- wave-marching fused kernel (sws_k_march_dot2): same coverage as the dot2 tile kernel, preferred ----
+        d->march_ok = false;
+        {
+            const bool src_ok = p.srcKind == SRCK_PLANAR8 || (p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15);
+            const bool dst_ok = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010;
+            auto fs4 = [](int fs) { return (fs + 3 + 3) & ~3; };
+            auto fs2 = [](int fs) { return (fs + 2) & ~1; };
+            auto monotone = [](const FilterBank &b) { for (int i = 1; i < b.count; i++) if (b.pos[i] < b.pos[i - 1]) return false; return true; };
+            if (!d->unity_h && src_ok && dst_ok && !p.wide && c->vLum.size >= 2 && c->vChr.size >= 2 &&
+                fs4(c->hLum.size) <= 16 && fs4(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && fs2(c->vChr.size) <= 16 &&
+                monotone(c->vLum) && monotone(c->vChr) && std::getenv("SWS_HIP_MARCH")) { // opt-in: the tile kernel is faster today
+                const int SPC = p.srcKind == SRCK_PLANAR16 ? 8 : 16;
+                std::vector<uint8_t> blob;
+                auto put = [&](const void *ptr, size_t n) { size_t o = (blob.size() + 15) & ~(size_t)15; blob.resize(o + n); std::memcpy(blob.data() + o, ptr, n); return o; };
+                auto padded = [&](const FilterBank &b, int f, int mask) {
+                    std::vector<int16_t> t((size_t)b.count * f, 0);
+                    for (int i = 0; i < b.count; i++)
+                        for (int j = 0; j < b.size; j++) t[(size_t)i * f + (b.pos[i] & mask) + j] = b.taps[(size_t)i * b.size + j];
+                    return t;
+                };
+                struct Off { size_t cs, cc, ht, vt; };
+                auto planm = [&](const FilterBank &hb, const FilterBank &vb, int W, int isChroma, SwsMarchGeom &g, Off &o) -> bool {
+                    const int hf4 = fs4(hb.size), vf2 = fs2(vb.size);
+                    const int strips = (W + 127) / 128;
+                    std::vector<int32_t> cs(strips), cc(strips);
+                    int ncmax = 0;
+                    for (int t = 0; t < strips; t++) {
+                        int lo = INT32_MAX, hi = -1;
+                        for (int x = t * 128; x < std::min(W, (t + 1) * 128); x++) { lo = std::min(lo, hb.pos[x] & ~3); hi = std::max(hi, (hb.pos[x] & ~3) + hf4); }
+                        lo = lo / SPC * SPC;
+                        cs[t] = lo; cc[t] = (hi - lo + SPC - 1) / SPC * SPC; ncmax = std::max(ncmax, cc[t]);
+                    }
+                    if (ncmax / SPC > 128) return false;
+                    g.chroma = isChroma; g.strips = strips; g.bands = 0; g.BAND = 0; g.NCmax = ncmax; g.hfs4 = hf4; g.vfs2 = vf2;
+                    o.cs = put(cs.data(), cs.size() * 4); o.cc = put(cc.data(), cc.size() * 4);
+                    const std::vector<int16_t> ht = padded(hb, hf4, 3), vt = padded(vb, vf2, 1);
+                    o.ht = put(ht.data(), ht.size() * 2); o.vt = put(vt.data(), vt.size() * 2);
+                    return true;
+                };
+                Off oL, oC;
+                if (planm(c->hLum, c->vLum, p.dstW, 0, d->marL, oL) && planm(c->hChr, c->vChr, p.chrDstW, 1, d->marC, oC)) {
+                    if (blob.size() > d->march_bytes) {
+                        if (d->d_march) HIPCHK(hipFree(d->d_march));
+                        d->d_march = nullptr;
+                        HIPCHK(hipMalloc(&d->d_march, blob.size()));
+                        d->march_bytes = blob.size();
+                    }
+                    HIPCHK(hipMemcpy(d->d_march, blob.data(), blob.size(), hipMemcpyHostToDevice));
+                    auto bind = [&](SwsMarchGeom &g, const Off &o) {
+                        const uint8_t *b = (const uint8_t *)d->d_march;
+                        g.colStart = (const int32_t *)(b + o.cs); g.colCount = (const int32_t *)(b + o.cc);
+                        g.hT4 = (const int16_t *)(b + o.ht); g.vT2 = (const int16_t *)(b + o.vt);
+                    };
+                    bind(d->marL, oL); bind(d->marC, oC);
+                    d->march_ok = true;
+                }
+            }
+        }
         // ---- dot2 tile kernel (sws_k_tile_dot2): planar 8-bit / <= 15-bit sources, 15-bit intermediates, vfs >= 2 ----
         d->dot2_ok = false;
         {
@@ -275,7 +334,8 @@ int dev_prepare(SwsInternal *c)
                             cs[t] = lo; cc[t] = (hi - lo + SPC - 1) / SPC * SPC; ncmax = std::max(ncmax, cc[t]);
                         }
                         const size_t lds = (size_t)nrmax * ncmax * 2 + (size_t)ncomp * (nrmax / 2) * TW * 4;
-                        if (lds > 40 * 1024 && TH > 2) continue;
+                        static const int lds_budget = std::getenv("SWS_HIP_TILE_LDS_KB") ? std::atoi(std::getenv("SWS_HIP_TILE_LDS_KB")) : 40;
+                        if (lds > (size_t)lds_budget * 1024 && TH > 2) continue;
                         if (lds > 64 * 1024) return false;
                         g.TW = TW; g.TH = TH; g.tilesX = tX; g.tilesY = tY; g.NRmax = nrmax; g.NCmax = ncmax; g.lds_bytes = (int32_t)lds;
                         g.hfs2 = hf2; g.vfs2 = vf2;
@@ -403,6 +463,8 @@ int dev_prepare(SwsInternal *c)
         } else if (d->unity_h) {
             c->path_name = "main:fused_generic_unity";
             c->kernel_name = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) ? "sws_k_vscale_rgb" : "sws_k_vscale_planar";
+        } else if (d->march_ok) {
+            c->path_name = "main:fused_march"; c->kernel_name = "sws_k_march_dot2";
         } else if (d->dot2_ok) {
             c->path_name = "main:fused_tile_dot2"; c->kernel_name = "sws_k_tile_dot2";
         } else if (d->tile_ok) {
@@ -620,6 +682,27 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
             (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16)) {
             const dim3 g(cdiv((int64_t)((p.srcW + 3) >> 2) * p.srcH, 256), 1, n);
             hipLaunchKernelGGL(swsk::sws_k_f32rgb_to_yuv444_unity, g, blk, 0, st, fs, p);
+            break;
+        }
+        if (d->march_ok && vec) { // wave-marching fused kernel: one launch for luma, one for chroma
+            const bool semi = p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010;
+            auto launch = [&](SwsMarchGeom g, int H, int ncomp, int ydim) {
+                const int64_t per_band_row = (int64_t)g.strips * n * ydim;
+                static const int target = std::getenv("SWS_HIP_MARCH_WAVES") ? std::atoi(std::getenv("SWS_HIP_MARCH_WAVES")) : 8192;
+                int band = (int)std::min<int64_t>(128, std::max<int64_t>(8, (int64_t)H * per_band_row / target));
+                band &= ~7;
+                g.BAND = band; g.bands = (H + band - 1) / band;
+                const int wave_dw = ncomp * (4 * (g.NCmax >> 1)) + ncomp * swsk::MARCH_RING * 128;
+                const size_t lds = (size_t)4 * wave_dw * 4;
+                const dim3 grid(cdiv((int64_t)g.strips * g.bands, 4), ydim, n);
+                const bool s16 = p.srcKind == SRCK_PLANAR16;
+                if (ncomp == 1) { if (s16) hipLaunchKernelGGL((swsk::sws_k_march_dot2<true, 1>), grid, blk, lds, st, fs, p, g);
+                                  else     hipLaunchKernelGGL((swsk::sws_k_march_dot2<false, 1>), grid, blk, lds, st, fs, p, g); }
+                else            { if (s16) hipLaunchKernelGGL((swsk::sws_k_march_dot2<true, 2>), grid, blk, lds, st, fs, p, g);
+                                  else     hipLaunchKernelGGL((swsk::sws_k_march_dot2<false, 2>), grid, blk, lds, st, fs, p, g); }
+            };
+            launch(d->marL, p.dstH, 1, 1);
+            if (semi) launch(d->marC, p.chrDstH, 2, 1); else launch(d->marC, p.chrDstH, 1, 2);
             break;
         }
         if (d->dot2_ok && vec) { // dot2 LDS-tile kernel: one launch for luma, one for chroma

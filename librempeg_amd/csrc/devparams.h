@@ -63,6 +63,16 @@ struct SwsTileGeom {        // fused h+v tile kernel: per component group, from 
     const int16_t *hT2, *vT2; int32_t hfs2, vfs2;
 };
 
+struct SwsMarchGeom {       // wave-marching fused kernel (kernels_march.hpp), per component group
+    int32_t chroma;           // 0 = luma group, 1 = chroma group
+    int32_t strips, bands, BAND;
+    int32_t NCmax;            // max source-window width (samples, multiple of the 16-byte chunk) over strips
+    const int32_t *colStart, *colCount;   // [strips] window origin (chunk aligned) / width per strip
+    const int16_t *hT4; int32_t hfs4;     // horizontal taps padded to start on a multiple-of-4 sample, length multiple of 4
+    const int16_t *vT2; int32_t vfs2;     // vertical taps padded to start on an even row, even length
+    int32_t lds_bytes;
+};
+
 struct SwsDevParams {
     int32_t srcW, srcH, dstW, dstH;
     int32_t chrSrcW, chrSrcH, chrDstW, chrDstH;

@@ -97,6 +97,41 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
 }
 
+// horizontal stage for one output column over `npairs` row pairs (rows 2q, 2q+1), NP tap pairs per output
+template <int NP, bool CHROMA>
+__device__ __forceinline__ void hscale_pairs(const SwsDevParams &p, const uint32_t *S, int srow_dw, const uint32_t *tp,
+                                             uint32_t *Hcol, int tw_dw, int q0, int npairs, int qstep)
+{
+    uint32_t t[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) t[k] = tp[k];
+    for (int q = q0; q < npairs; q += qstep) {
+        const uint32_t *s0 = S + (2 * q) * srow_dw, *s1 = s0 + srow_dw;
+        int a = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < NP; k++) { a = dot2(s0[k], t[k], a); b = dot2(s1[k], t[k], b); }
+        int va = min(a >> p.hshift, p.hclip), vb = min(b >> p.hshift, p.hclip);
+        va = range_sample(p, (int16_t)va, CHROMA); vb = range_sample(p, (int16_t)vb, CHROMA);
+        Hcol[q * tw_dw] = (uint32_t)(uint16_t)va | ((uint32_t)(uint16_t)vb << 16);
+    }
+}
+
+// vertical stage for 4 adjacent columns, NP tap pairs
+template <int NP, int NCOMP>
+__device__ __forceinline__ void vscale_pairs4(const uint32_t *Hp, int hplane, int tw_dw, const uint32_t *vt, int (&acc)[NCOMP][4])
+{
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const uint32_t w = vt[k];
+#pragma unroll
+        for (int ci = 0; ci < NCOMP; ci++) {
+            const u32x4 hv = *(const u32x4 *)(Hp + ci * hplane + k * tw_dw);
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[ci][e] = dot2(hv[e], w, acc[ci][e]);
+        }
+    }
+}
+
 template <bool SRC16, bool CHROMA>
 __global__ void __launch_bounds__(256) sws_k_tile_dot2(SwsFrameSet fs, SwsDevParams p, SwsTileGeom g)
 {
@@ -147,25 +182,19 @@ __global__ void __launch_bounds__(256) sws_k_tile_dot2(SwsFrameSet fs, SwsDevPar
             }
         }
         __syncthreads();
-        // ---- phase 2: horizontal stage on sample pairs; thread = output column, marching down the window ----
+        // ---- phase 2: horizontal stage on sample pairs; thread = output column, marching down the window in ROW PAIRS
+        //      (one dword store per pair: {even row, odd row}) ----
         {
-            const int xl = tid & (g.TW - 1), half = tid / g.TW;    // TW == 128: two row phases
+            const int xl = tid & (g.TW - 1), half = tid / g.TW;    // TW == 128: two interleaved pair phases
             if (xl < tw) {
                 const int x = x0 + xl;
                 const int spd = ((hpos[x] & ~1) - cs) >> 1;          // dword index of the first (even-aligned) pair
                 const uint32_t *tp = (const uint32_t *)(g.hT2 + (int64_t)x * g.hfs2);
-                uint32_t t[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) t[k] = 2 * k < g.hfs2 ? tp[k] : 0u;
                 uint32_t *Hc = Hp + ci * hplane;
-                for (int r = half; r < nrp; r += 256 / g.TW) {
-                    const uint32_t *sr = S + r * srow_dw + spd;
-                    int val = 0;
-#pragma unroll
-                    for (int k = 0; k < 8; k++) if (2 * k < g.hfs2) val = dot2(sr[k], t[k], val);
-                    int v = min(val >> p.hshift, p.hclip);
-                    v = range_sample(p, (int16_t)v, CHROMA);
-                    ((uint16_t *)Hc)[((r >> 1) * g.TW + xl) * 2 + (r & 1)] = (uint16_t)v;
+                switch (g.hfs2 >> 1) {
+#define SWS_HCASE(NP) case NP: hscale_pairs<NP, CHROMA>(p, S + spd, srow_dw, tp, Hc + xl, g.TW, half, nrp >> 1, 256 / g.TW); break;
+                SWS_HCASE(1) SWS_HCASE(2) SWS_HCASE(3) SWS_HCASE(4) SWS_HCASE(5) SWS_HCASE(6) SWS_HCASE(7) SWS_HCASE(8)
+#undef SWS_HCASE
                 }
             }
         }
@@ -187,14 +216,10 @@ __global__ void __launch_bounds__(256) sws_k_tile_dot2(SwsFrameSet fs, SwsDevPar
         for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
             for (int k = 0; k < 4; k++) acc[ci][k] = 0;
-        for (int k = 0; 2 * k < g.vfs2; k++) {
-            const uint32_t w = vt[k];
-#pragma unroll
-            for (int ci = 0; ci < NCOMP; ci++) {
-                const u32x4 hv = *(const u32x4 *)(Hp + ci * hplane + (rpd + k) * g.TW + xl);
-#pragma unroll
-                for (int e = 0; e < 4; e++) acc[ci][e] = dot2(hv[e], w, acc[ci][e]);
-            }
+        switch (g.vfs2 >> 1) {
+#define SWS_VCASE(NP) case NP: vscale_pairs4<NP, NCOMP>(Hp + rpd * g.TW + xl, hplane, g.TW, vt, acc); break;
+        SWS_VCASE(1) SWS_VCASE(2) SWS_VCASE(3) SWS_VCASE(4) SWS_VCASE(5) SWS_VCASE(6) SWS_VCASE(7) SWS_VCASE(8)
+#undef SWS_VCASE
         }
         // writers, "X" forms (filter size >= 2): output.c:468-483 (8 bit), :344-357 (9..14 bit), :554-569 / :571-589 (P01x),
         // :495-528 (nv12 chroma)
