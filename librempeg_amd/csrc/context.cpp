@@ -123,13 +123,19 @@ void choose_unscaled(SwsInternal *c)
     }
     if ((s == AV_PIX_FMT_YUV420P10LE || s == AV_PIX_FMT_YUV420P16LE) && d == AV_PIX_FMT_P010LE) k = PLAN_UNSC_P01X;   // :2432-2439
     if (s == AV_PIX_FMT_YUV420P && d == AV_PIX_FMT_P010LE) k = PLAN_UNSC_8_P01X;                                      // :2440-2444
-    if (isAnyRGB(s) && isAnyRGB(d) && !isPlanarRGB(s) && !isPlanarRGB(d) && s != d) unsupported = true; // rgbToRgbWrapper (:2461)
+    // rgbToRgbWrapper (:2459-2463) whenever findRgbConvFn (:1843-1998) has a converter.  All formats here are 8-bit
+    // 24/32 bpp (needsDither == 0).  ":1991-1994 Maintain symmetry between endianness": with BITEXACT a 24 bpp source
+    // is not shuffled into RGB32/BGR32 (bgra/rgba bytes on a little-endian host) and goes through the scaler chain.
+    if (isAnyRGB(s) && isAnyRGB(d) && !isPlanarRGB(s) && !isPlanarRGB(d) && s != d) {
+        const bool s32 = pix_desc(s)->comp[0].step == 4;
+        if (!(!s32 && (d == AV_PIX_FMT_BGRA || d == AV_PIX_FMT_RGBA) && (flags & SWS_BITEXACT))) k = PLAN_UNSC_RGB2RGB;
+    }
     if (s == AV_PIX_FMT_GBRP && isAnyRGB(d) && !isPlanarRGB(d)) unsupported = true;                     // planarRgbToRgbWrapper (:2482)
     if (s == d ||
         (isFloatFmt(s) == isFloatFmt(d) && isPlanarYUV(s) && isPlanarYUV(d) &&
          c->chrDstHSubSample == c->chrSrcHSubSample && c->chrDstVSubSample == c->chrSrcVSubSample &&
          isSemiPlanarYUV(s) == isSemiPlanarYUV(d) && isSwappedChroma(s) == isSwappedChroma(d))) { // :2647-2668
-        if (isPackedFmt(s)) unsupported = true; // packedCopyWrapper
+        if (isPackedFmt(s)) k = PLAN_UNSC_PACKEDCOPY; // packedCopyWrapper (:2138-2157)
         else { k = PLAN_UNSC_PLANARCOPY; unsupported = false;
                if (c->opts.dither != SWS_DITHER_NONE) c->dst_slice_align = 8 << c->chrDstVSubSample; }
     }
@@ -231,10 +237,6 @@ int init_single_context(SwsInternal *c)
         return SWS_AVERROR(ENOTSUP);
     }
     c->needAlpha = isALPHA(srcFormat) && isALPHA(dstFormat);                    // :1746
-    if (c->needAlpha) {
-        log_msg(c, 0, "alpha-plane scaling (%s -> %s) is not implemented on the HIP path\n", ds->name, dd->name);
-        return SWS_AVERROR(ENOTSUP);
-    }
 
     c->plan = PLAN_NONE;
     if (unscaled && (o->src_range == o->dst_range || isAnyRGB(dstFormat) || isFloatFmt(srcFormat) || isFloatFmt(dstFormat))) { // :1623-1637
@@ -244,10 +246,16 @@ int init_single_context(SwsInternal *c)
             c->plan = PLAN_NONE;
             return SWS_AVERROR(ENOTSUP);
         }
+        if (c->plan != PLAN_NONE && c->needAlpha && c->plan != PLAN_UNSC_RGB2RGB && c->plan != PLAN_UNSC_PACKEDCOPY)
+            c->plan = PLAN_NONE;
         if (c->plan != PLAN_NONE) {
             log_msg(c, 2, "using unscaled %s -> %s special converter\n", ds->name, dd->name);
             return 0;
         }
+    }
+    if (c->needAlpha) {
+        log_msg(c, 0, "alpha-plane scaling (%s -> %s) is not implemented on the HIP path\n", ds->name, dd->name);
+        return SWS_AVERROR(ENOTSUP);
     }
 
     // filters; filterAlign is 1 in the reference's C path (:1675-1735)

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "kernels_march.hpp"
+#include "kernels_shuffle.hpp"
 #include "swsint.hpp"
 
 #define AVERROR_EXTERNAL_ (-0x20545845) /* FFERRTAG('E','X','T',' '), libavutil/error.h */
@@ -452,6 +453,8 @@ int dev_prepare(SwsInternal *c)
     case PLAN_UNSC_PLANAR2NV12: c->path_name = "unscaled:planarToNv12"; c->kernel_name = "sws_k_planar_misc"; break;
     case PLAN_UNSC_NV122PLANAR: c->path_name = "unscaled:nv12ToPlanar"; c->kernel_name = "sws_k_planar_misc"; break;
     case PLAN_UNSC_PLANARCOPY: c->path_name = "unscaled:planarCopy"; c->kernel_name = "sws_k_planar_misc"; break;
+    case PLAN_UNSC_RGB2RGB: c->path_name = "unscaled:rgbToRgb"; c->kernel_name = "sws_k_rgb_shuffle"; break;
+    case PLAN_UNSC_PACKEDCOPY: c->path_name = "unscaled:packedCopy"; c->kernel_name = "sws_k_packed_copy"; break;
     case PLAN_CASCADE: c->path_name = "cascade"; c->kernel_name = ""; break;
     case PLAN_MAIN: {
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
@@ -648,6 +651,45 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         if (!maxw || !rows) break;
         const dim3 grid(cdiv(maxw, 256), rows, n);
         hipLaunchKernelGGL(swsk::sws_k_planar_misc, grid, blk, 0, st, fs, p, plan);
+        break;
+    }
+    case PLAN_UNSC_RGB2RGB: {
+        const PixDesc *ds = pix_desc(c->opts.src_format), *dd = pix_desc(c->opts.dst_format);
+        swsk::ShufflePlan sp;
+        std::memset(&sp, 0, sizeof(sp));
+        sp.src_step = ds->comp[0].step; sp.dst_step = dd->comp[0].step;
+        for (int k = 0; k < 4; k++) {
+            sp.spos[k] = k < ds->nb_components ? ds->comp[k].offset : -1;
+            sp.dpos[k] = k < dd->nb_components ? dd->comp[k].offset : -1;
+        }
+        // swscale.c:1106-1124: an rgb0-style source feeding a real alpha channel is made opaque first
+        sp.opaque = c->src0Alpha && !c->dst0Alpha && isALPHA(c->opts.dst_format);
+        const bool s3 = sp.src_step == 3, d3 = sp.dst_step == 3;
+        static const int off3[4] = { 0, 3, 2, 1 };   // where pixel i of a 12-byte group starts inside its dword pair
+        for (int i = 0; i < 4; i++) {
+            uint32_t sel = 0;
+            const int base = s3 ? off3[i] : 0;
+            for (int j = 0; j < 4; j++) {
+                uint32_t b = 0x0c;                    // unused byte -> 0
+                for (int k = 0; k < 4; k++)
+                    if (sp.dpos[k] == j) b = (k == 3 && (sp.spos[3] < 0 || sp.opaque)) ? 0x0du : (uint32_t)(base + sp.spos[k]);
+                sel |= b << (8 * j);
+            }
+            sp.sel[i] = sel;
+        }
+        const dim3 grid(cdiv(cdiv(p.srcW, 4), 256), sliceH, n);
+        if (s3 && d3) hipLaunchKernelGGL((swsk::sws_k_rgb_shuffle<true, true>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
+        else if (s3) hipLaunchKernelGGL((swsk::sws_k_rgb_shuffle<true, false>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
+        else if (d3) hipLaunchKernelGGL((swsk::sws_k_rgb_shuffle<false, true>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
+        else hipLaunchKernelGGL((swsk::sws_k_rgb_shuffle<false, false>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
+        break;
+    }
+    case PLAN_UNSC_PACKEDCOPY: {
+        const PixDesc *ds = pix_desc(c->opts.src_format);
+        const int row_bytes = p.srcW * ds->comp[0].step;
+        const bool opaque = c->src0Alpha && !c->dst0Alpha && isALPHA(c->opts.dst_format);
+        const dim3 grid(cdiv(cdiv(row_bytes, 16), 256), sliceH, n);
+        hipLaunchKernelGGL(swsk::sws_k_packed_copy, grid, blk, 0, st, fs, row_bytes, sliceY, opaque ? ds->comp[3].offset : -1);
         break;
     }
     case PLAN_MAIN: {

@@ -61,6 +61,8 @@ enum PlanKind {
     PLAN_UNSC_PLANAR2NV12, // planarToNv12Wrapper
     PLAN_UNSC_NV122PLANAR, // nv12ToPlanarWrapper
     PLAN_UNSC_PLANARCOPY,  // planarCopyWrapper
+    PLAN_UNSC_RGB2RGB,     // rgbToRgbWrapper (8-bit 24/32 bpp byte shuffles)
+    PLAN_UNSC_PACKEDCOPY,  // packedCopyWrapper
     PLAN_MAIN,             // ff_swscale chain
     PLAN_CASCADE,          // two contexts through an intermediate image
 };

@@ -229,15 +229,45 @@ class DeviceFrame:
         return host
 
 
-class SwsContext:
-    """sws_getContext(...) wrapper.  scale() takes HostFrame or DeviceFrame objects."""
+class SwsContextFields(C.Structure):
+    """public part of SwsContext (include/swscale_hip.h; reference swscale.h:227-315), for the
+    sws_alloc_context() + set fields + sws_init_context() construction the reference documents."""
+    _fields_ = [("av_class", C.c_void_p), ("opaque", C.c_void_p), ("flags", C.c_uint), ("scaler_params", C.c_double * 2),
+                ("threads", C.c_int), ("dither", C.c_int), ("alpha_blend", C.c_int), ("gamma_flag", C.c_int),
+                ("src_w", C.c_int), ("src_h", C.c_int), ("dst_w", C.c_int), ("dst_h", C.c_int),
+                ("src_format", C.c_int), ("dst_format", C.c_int), ("src_range", C.c_int), ("dst_range", C.c_int),
+                ("src_v_chr_pos", C.c_int), ("src_h_chr_pos", C.c_int), ("dst_v_chr_pos", C.c_int), ("dst_h_chr_pos", C.c_int),
+                ("intent", C.c_int), ("scaler", C.c_int), ("scaler_sub", C.c_int), ("backends", C.c_int)]
 
-    def __init__(self, sw, sh, sfmt, dw, dh, dfmt, flags, param=None, device=None, empty=False):
+
+class SwsContext:
+    """sws_getContext(...) wrapper.  scale() takes HostFrame or DeviceFrame objects.
+    Keyword options (dither=, src_range=, dst_range=, src_h_chr_pos=, ...) select the sws_alloc_context() + public
+    fields + sws_init_context() construction instead."""
+
+    def __init__(self, sw, sh, sfmt, dw, dh, dfmt, flags, param=None, device=None, empty=False, **opts):
         L = load_library()
         self.L = L
         self.sw, self.sh, self.sfmt, self.dw, self.dh, self.dfmt = sw, sh, sfmt, dw, dh, dfmt
         if empty:
             self.c = L.sws_alloc_context()
+        elif opts:
+            self.c = L.sws_alloc_context()
+            if not self.c:
+                raise RuntimeError("sws_alloc_context failed")
+            f = self.fields()
+            f.src_w, f.src_h, f.src_format = sw, sh, PIX_FMT[sfmt]
+            f.dst_w, f.dst_h, f.dst_format = dw, dh, PIX_FMT[dfmt]
+            f.flags = flags
+            if param:
+                f.scaler_params[0], f.scaler_params[1] = param
+            for k, v in opts.items():
+                setattr(f, k, v)
+            r = L.sws_init_context(self.c, None, None)
+            if r < 0:
+                L.sws_freeContext(self.c)
+                self.c = None
+                raise RuntimeError(f"sws_init_context({sfmt} -> {dfmt}, {opts}) = {r}")
         else:
             p = (C.c_double * 2)(*param) if param else None
             self.c = L.sws_getContext(sw, sh, PIX_FMT[sfmt], dw, dh, PIX_FMT[dfmt], flags, None, None, p)
@@ -247,6 +277,9 @@ class SwsContext:
             r = L.sws_hip_set_device(self.c, int(device))
             if r < 0:
                 raise RuntimeError(f"sws_hip_set_device({device}) = {r}")
+
+    def fields(self):
+        return C.cast(self.c, C.POINTER(SwsContextFields)).contents
 
     def set_colorspace(self, inv_cs, src_range, cs, dst_range, brightness=0, contrast=1 << 16, saturation=1 << 16):
         L = self.L

@@ -12,6 +12,7 @@
 #include "sws_oracle.h"
 
 #include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -137,7 +138,7 @@ enum { RY, GY, BY, RU, GU, BU, RV, GV, BV };
 #define TABLE_PLANE 2048
 
 enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
-       UNSC_NV122PLANAR, UNSC_PLANARCOPY };
+       UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_PACKEDCOPY };
 
 struct OrSws {
     OrSwsOpts o;
@@ -720,13 +721,21 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
     }
     if ((s == ORF_YUV420P10LE || s == ORF_YUV420P16LE) && d == ORF_P010LE) c->unscaled_kind = UNSC_P01X;
     if (s == ORF_YUV420P && d == ORF_P010LE) c->unscaled_kind = UNSC_8_P01X;
+    /* rgbToRgbWrapper (:2459-2463) when findRgbConvFn (:1843-1998) has a converter; 8-bit 24/32 bpp formats on a
+     * little-endian host.  needsDither is 0 for >= 24 bpp destinations.  ":1991-1994 Maintain symmetry between
+     * endianness": with BITEXACT a 24 bpp source is not shuffled into RGB32/BGR32 (= bgra/rgba bytes on LE). */
+    if (isAnyRGB(s) && isAnyRGB(d) && isPacked(s) && isPacked(d) && s != d) {
+        const int s32 = desc_get(s)->c[0].step == 4;
+        if (!(!s32 && (d == ORF_BGRA || d == ORF_RGBA) && (flags & OR_SWS_BITEXACT)))
+            c->unscaled_kind = UNSC_RGB2RGB;
+    }
     /* simple copy (:2647-2668) */
     if (s == d ||
         (isFloat(s) == isFloat(d) &&
          (isPlanarYUV(s) && isPlanarYUV(d) && c->chrDstHSub == c->chrSrcHSub && c->chrDstVSub == c->chrSrcVSub &&
           isSemiPlanarYUV(s) == isSemiPlanarYUV(d) && isSwappedChroma(s) == isSwappedChroma(d)))) {
         if (!isPacked(s)) c->unscaled_kind = UNSC_PLANARCOPY;
-        else c->unscaled_kind = UNSC_NONE; /* packedCopyWrapper / rgbToRgb: not restated */
+        else c->unscaled_kind = UNSC_PACKEDCOPY; /* packedCopyWrapper (:2138-2157) */
     }
 }
 
@@ -804,12 +813,13 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
 
     /* alpha: src alpha dropped -> reference cascades through alpha blend only if alpha_blend != NONE (default NONE) */
     c->needAlpha = isALPHA(srcFormat) && isALPHA(dstFormat);
-    if (c->needAlpha) return -1; /* alpha plane scaling not restated */
 
     if (unscaled && (c->o.src_range == c->o.dst_range || isAnyRGB(dstFormat) || isFloat(srcFormat) || isFloat(dstFormat))) {
         get_unscaled(c);
-        if (c->unscaled_kind) { c->initialized = 1; return 0; }
+        if (c->unscaled_kind == UNSC_RGB2RGB || c->unscaled_kind == UNSC_PACKEDCOPY) { c->initialized = 1; return 0; }
+        if (c->unscaled_kind && !c->needAlpha) { c->initialized = 1; return 0; }
     }
+    if (c->needAlpha) return -1; /* alpha plane scaling not restated */
 
     /* filters (:1675-1735), filterAlign == 1 in the C-only build */
     ret = init_filter(&c->hLumFilter, &c->hLumFilterPos, &c->hLumFilterSize, c->lumXInc, srcW, dstW, 1, 1 << 14,
@@ -1018,6 +1028,47 @@ static int unscaled_nv122planar(OrSws *c, const uint8_t *const src[], const int 
         const uint8_t *s = src[1] + y * srcStride[1];
         uint8_t *d1 = dst[a] + dstStride[a] * (srcSliceY / 2 + y), *d2 = dst[b] + dstStride[b] * (srcSliceY / 2 + y);
         for (int x = 0; x < c->chrSrcW; x++) { d1[x] = s[2 * x]; d2[x] = s[2 * x + 1]; }
+    }
+    return srcSliceH;
+}
+
+/* rgbToRgbWrapper (swscale_unscaled.c:2001-2060) with the little-endian C converters of rgb2rgb.c / rgb2rgb_template.c
+ * (shuffle_bytes_*, rgb24to32, rgb32to24, rgb24tobgr24, rgb24tobgr32, rgb32tobgr24): every one of them moves the R, G
+ * and B bytes of the source pixel to the R, G and B positions of the destination pixel, copies A when both have one
+ * and writes 255 when only the destination has one.  The ALT32_CORR offset tricks for argb/abgr (:2021-2032) give
+ * the same visible bytes (the row-start 255 plus each pixel's trailing 255 land on the A positions); the one byte
+ * they spill past the end of a row is outside the picture and not restated. */
+static int unscaled_rgb2rgb(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                            int srcSliceH, uint8_t *const dst[], const int dstStride[], int force_opaque)
+{
+    const Desc *ds = desc_get(c->o.src_format), *dd = desc_get(c->o.dst_format);
+    const int sa = isALPHA(c->o.src_format) && !force_opaque, da = isALPHA(c->o.dst_format);
+    (void)srcSliceY;
+    for (int y = 0; y < srcSliceH; y++) {
+        const uint8_t *s = src[0] + (ptrdiff_t)y * srcStride[0];
+        uint8_t *d = dst[0] + (ptrdiff_t)y * dstStride[0];
+        for (int x = 0; x < c->o.src_w; x++, s += ds->c[0].step, d += dd->c[0].step) {
+            for (int k = 0; k < 3; k++) d[dd->c[k].offset] = s[ds->c[k].offset];
+            if (da) d[dd->c[3].offset] = sa ? s[ds->c[3].offset] : 255;
+        }
+    }
+    return srcSliceH;
+}
+
+/* packedCopyWrapper (swscale_unscaled.c:2138-2157); only the visible bytes of each row are restated.
+ * rgb0-style sources going to a real-alpha destination were made opaque by the caller (swscale.c:1106-1124). */
+static int unscaled_packedcopy(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                               int srcSliceH, uint8_t *const dst[], const int dstStride[], int force_opaque)
+{
+    const Desc *ds = desc_get(c->o.src_format);
+    const int step = ds->c[0].step;
+    (void)srcSliceY;
+    for (int y = 0; y < srcSliceH; y++) {
+        const uint8_t *s = src[0] + (ptrdiff_t)y * srcStride[0];
+        uint8_t *d = dst[0] + (ptrdiff_t)y * dstStride[0];
+        memcpy(d, s, (size_t)c->o.src_w * step);
+        if (force_opaque)
+            for (int x = 0; x < c->o.src_w; x++) d[x * step + ds->c[3].offset] = 255;
     }
     return srcSliceH;
 }
@@ -1644,7 +1695,12 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
         if (ret < 0) return ret;
         return or_sws_scale(c->cascade[1], (const uint8_t *const *)tmp, c->casc_stride, 0, c->cascade[0]->o.dst_h, dst, dstStride);
     }
-    if (c->src0Alpha && !c->dst0Alpha && isALPHA(c->o.dst_format)) return -22; /* rgb0 scratch copy: needAlpha rejected at init */
+    {   /* swscale.c:1106-1124: an rgb0-style source feeding a real alpha channel is made opaque first */
+        const int opaque = c->src0Alpha && !c->dst0Alpha && isALPHA(c->o.dst_format);
+        if (c->unscaled_kind == UNSC_RGB2RGB) return unscaled_rgb2rgb(c, src, srcStride, 0, srcSliceH, dst, dstStride, opaque);
+        if (c->unscaled_kind == UNSC_PACKEDCOPY) return unscaled_packedcopy(c, src, srcStride, 0, srcSliceH, dst, dstStride, opaque);
+        if (opaque) return -22; /* other paths: needAlpha contexts are rejected at init */
+    }
     switch (c->unscaled_kind) {
     case UNSC_YUV2RGB: return unscaled_yuv2rgb(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_P01X: return unscaled_p01x(c, src, srcStride, 0, srcSliceH, dst, dstStride);
@@ -1672,7 +1728,8 @@ int or_sws_get_filter(const OrSws *c, int which, const int16_t **filter, const i
 int or_sws_path(const OrSws *c) { return c->cascade[0] ? 2 : c->unscaled_kind ? 1 : 0; }
 const char *or_sws_path_name(const OrSws *c)
 {
-    static const char *n[] = { "main", "yuv2rgb_c", "planarToP01x", "planar8ToP01xle", "planarToNv12", "nv12ToPlanar", "planarCopy" };
+    static const char *n[] = { "main", "yuv2rgb_c", "planarToP01x", "planar8ToP01xle", "planarToNv12", "nv12ToPlanar", "planarCopy",
+                               "rgbToRgb", "packedCopy" };
     return c->cascade[0] ? "cascade" : n[c->unscaled_kind];
 }
 const int32_t *or_sws_rgb2yuv_table(const OrSws *c) { return c->rgb2yuv; }

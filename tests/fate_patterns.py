@@ -1,0 +1,90 @@
+"""Input pictures of the reference's fate-pixfmt tests, restated as data generators (test infrastructure).
+
+* vsynth1 frame 0: committed fixture produced by the reference's tests/videogen.c (tools/gen_vsynth_fixture.py);
+* yuvtestsrc / rgbtestsrc at 352x288: three horizontal bands, each a left-to-right ramp c = (1<<depth)*x/w in one
+  component (libavfilter/vsrc_testsrc.c:1111-1131 rgbtest_fill_picture, :1290-1312 yuvtest_fill_picture).
+"""
+import hashlib
+import json
+import os
+import zlib
+
+import numpy as np
+
+import oracle_lib as OL
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+W, H = 352, 288
+SWS_FLAGS = OL.SWS_BICUBIC | OL.SWS_ACCURATE_RND | OL.SWS_BITEXACT   # tests/fate-run.sh:258 + the filter's default scaler
+FMT_OF = {"gray": "gray8", "rgb32": "bgra"}                           # lavu pixfmt aliases on little endian
+BASE_FMT = {"yuv444p": "yuv444p", "rgb24": "rgb24", "yuv444p10": "yuv444p10le", "yuv444p16": "yuv444p16le"}
+GOLDEN = json.load(open(os.path.join(HERE, "golden", "fate_pixfmt_md5.json")))
+
+
+def vsynth_frame():
+    raw = zlib.decompress(open(os.path.join(HERE, "golden", "vsynth1_f0_352x288.yuv420p.bin.z"), "rb").read())
+    f = OL.Frame("yuv420p", W, H)
+    o = 0
+    for a, rb in zip(f.planes, f.row_bytes):
+        n = rb * a.shape[0]
+        a[:, :rb] = np.frombuffer(raw[o:o + n], np.uint8).reshape(a.shape[0], rb)
+        o += n
+    return f
+
+
+def band_of(y):
+    return 0 if 3 * y < H else (1 if 3 * y < 2 * H else 2)
+
+
+def yuvtestsrc(depth):
+    fmt = "yuv444p" if depth == 8 else f"yuv444p{depth}le"
+    f = OL.Frame(fmt, W, H)
+    ramp = ((1 << depth) * np.arange(W) // W)
+    dt = np.uint8 if depth == 8 else np.dtype("<u2")
+    planes = [np.full((H, W), 1 << (depth - 1), dt) for _ in range(3)]
+    for y in range(H):
+        planes[band_of(y)][y, :] = ramp
+    for a, p in zip(f.planes, planes):
+        a[:, :p.shape[1] * p.itemsize] = p.view(np.uint8).reshape(H, -1)
+    return f
+
+
+def rgbtestsrc():
+    f = OL.Frame("rgb24", W, H)
+    img = np.zeros((H, W, 3), np.uint8)
+    ramp = (256 * np.arange(W) // W).astype(np.uint8)
+    for y in range(H):
+        img[y, :, band_of(y)] = ramp
+    f.planes[0][:, :3 * W] = img.reshape(H, 3 * W)
+    return f
+
+
+def base_picture(base):
+    if base == "rgb24":
+        return rgbtestsrc()
+    return yuvtestsrc({"yuv444p": 8, "yuv444p10": 10, "yuv444p16": 16}[base])
+
+
+def cases():
+    """[(golden key, base or None, middle format)]"""
+    out = []
+    for key in sorted(GOLDEN):
+        base, _, name = key.rpartition("-")
+        out.append((key, base or None, FMT_OF.get(name, name)))
+    return out
+
+
+def fate_pixfmt_md5(key, base, fmt, convert):
+    """run one fate-pixfmt pipeline; convert(src_frame, src_fmt, dst_fmt, dither_none) -> dst frame (host)."""
+    if base is None:      # pixfmt_conversion: vsynth1 -> fmt -> yuv444p, one frame
+        mid = vsynth_frame() if fmt == "yuv420p" else convert(vsynth_frame(), "yuv420p", fmt, False)
+        out = mid if fmt == "yuv444p" else convert(mid, fmt, "yuv444p", False)
+        reps = 1
+    else:                 # pixfmt_conversion_ext: testsrc(base) -> fmt (sws_dither=none) -> base, 25 frames at -t 1
+        bf = BASE_FMT[base]
+        src = base_picture(base)
+        out = src if fmt == bf else convert(convert(src, bf, fmt, True), fmt, bf, False)
+        reps = 25
+    data = out.visible() * reps
+    assert len(data) == GOLDEN[key]["bytes"]
+    return hashlib.md5(data).hexdigest()

@@ -97,8 +97,6 @@ def test_format_matrix_scaled(sfmt, dfmt):
 @pytest.mark.parametrize("dfmt", FORMAT_MATRIX_DST)
 def test_format_matrix_same_size(sfmt, dfmt):
     """same-size conversions: unscaled special converters or the identity-horizontal fused path."""
-    if OL.FMT[sfmt] in (26, 28, 25, 27) and OL.FMT[dfmt] in (26, 28, 25, 27):
-        pytest.skip("alpha -> alpha / packed copy not implemented")
     try:
         o = OL.Oracle(96, 64, sfmt, 96, 64, dfmt, SWS_BICUBIC | BX)
     except RuntimeError:
@@ -118,6 +116,26 @@ def test_scalers_and_geometries(flags, geom):
     sw, sh, dw, dh = geom
     run_case(sw, sh, "yuv420p", dw, dh, "yuv420p", flags | BX, seed=7)
     run_case(sw, sh, "yuv420p", dw & ~1, dh, "bgra", flags | BX, seed=8)
+
+
+PACKED_RGB = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "bgr0", "0rgb", "0bgr"]
+
+
+@pytest.mark.parametrize("sfmt", PACKED_RGB)
+@pytest.mark.parametrize("dfmt", PACKED_RGB)
+@pytest.mark.parametrize("bitexact", [0, BX], ids=["plain", "bitexact"])
+def test_rgb_to_rgb_shuffles_and_packed_copies(sfmt, dfmt, bitexact):
+    """rgbToRgbWrapper / packedCopyWrapper (swscale_unscaled.c:1843-2157): byte shuffles incl. rgb0-style sources made
+    opaque; 24 bpp -> bgra/rgba with BITEXACT goes through the scaler chain instead (:1991-1994)."""
+    for (w, h) in ((64, 8), (37, 5), (3, 2)):
+        path, opath = run_case(w, h, sfmt, w, h, dfmt, SWS_BICUBIC | bitexact, seed=w)
+        canon = lambda f: {"rgb0": "rgba", "bgr0": "bgra", "0rgb": "argb", "0bgr": "abgr"}.get(f, f)
+        if canon(sfmt) == canon(dfmt):
+            assert (path, opath) == ("unscaled:packedCopy", "packedCopy")
+        elif bitexact and sfmt in ("rgb24", "bgr24") and canon(dfmt) in ("bgra", "rgba"):
+            assert opath == "main" and path.startswith("main")
+        else:
+            assert (path, opath) == ("unscaled:rgbToRgb", "rgbToRgb")
 
 
 @pytest.mark.parametrize("w,h", [(2, 2), (6, 2), (14, 6), (18, 4), (30, 2), (258, 6), (1022, 4), (8, 8), (16, 2)])

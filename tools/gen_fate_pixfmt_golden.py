@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Collect the reference's fate-pixfmt known answers (tests/ref/pixfmt/*, data files of the reference's own test
+suite) for the pixel formats in SURVEY.md §8's scope into tests/golden/fate_pixfmt_md5.json.
+
+Each entry is the MD5 + byte count of a raw video file the reference's FATE run produces
+(tests/fate-run.sh:575-597 pixfmt_conversion / pixfmt_conversion_ext, tests/fate/pixfmt.mak):
+  "<fmt>"          vsynth1 frame 0 (yuv420p 352x288) -> <fmt> -> yuv444p, 1 frame
+  "<base>-<fmt>"   {yuv,rgb}testsrc 352x288 in <base> -> <fmt> (sws_dither=none) -> <base>, 25 identical frames
+all with sws flags bicubic+accurate_rnd+bitexact.  Run in the build container (needs /root/reference)."""
+import json
+import os
+import sys
+
+REF = "/root/reference/tests/ref/pixfmt"
+SCOPE = ["bgr24", "nv12", "rgb24", "rgb32", "yuv420p", "yuv422p", "yuv444p", "yuvj420p", "yuv420p16le",
+         "yuv444p16le", "yuv420p10le", "yuv444p10le", "p010le"]
+BASES = ["", "yuv444p-", "rgb24-", "yuv444p10-", "yuv444p16-"]
+
+out = {}
+for b in BASES:
+    for f in SCOPE:
+        p = os.path.join(REF, b + f)
+        if os.path.exists(p):
+            tok = open(p).read().split()
+            out[b + f] = {"md5": tok[0], "bytes": int(tok[2])}
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "fate_pixfmt_md5.json")
+json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
+print(len(out), "entries ->", dst, file=sys.stderr)
