@@ -123,6 +123,8 @@ void choose_unscaled(SwsInternal *c)
     }
     if ((s == AV_PIX_FMT_YUV420P10LE || s == AV_PIX_FMT_YUV420P16LE) && d == AV_PIX_FMT_P010LE) k = PLAN_UNSC_P01X;   // :2432-2439
     if (s == AV_PIX_FMT_YUV420P && d == AV_PIX_FMT_P010LE) k = PLAN_UNSC_8_P01X;                                      // :2440-2444
+    if (s == AV_PIX_FMT_BGR24 && d == AV_PIX_FMT_YUV420P && !(flags & SWS_ACCURATE_RND) && !(c->opts.dst_w & 1))
+        k = PLAN_UNSC_BGR24_YV12;                                                                        // :2452-2456
     // rgbToRgbWrapper (:2459-2463) whenever findRgbConvFn (:1843-1998) has a converter.  All formats here are 8-bit
     // 24/32 bpp (needsDither == 0).  ":1991-1994 Maintain symmetry between endianness": with BITEXACT a 24 bpp source
     // is not shuffled into RGB32/BGR32 (bgra/rgba bytes on a little-endian host) and goes through the scaler chain.

@@ -455,6 +455,7 @@ int dev_prepare(SwsInternal *c)
     case PLAN_UNSC_PLANARCOPY: c->path_name = "unscaled:planarCopy"; c->kernel_name = "sws_k_planar_misc"; break;
     case PLAN_UNSC_RGB2RGB: c->path_name = "unscaled:rgbToRgb"; c->kernel_name = "sws_k_rgb_shuffle"; break;
     case PLAN_UNSC_PACKEDCOPY: c->path_name = "unscaled:packedCopy"; c->kernel_name = "sws_k_packed_copy"; break;
+    case PLAN_UNSC_BGR24_YV12: c->path_name = "unscaled:bgr24ToYv12"; c->kernel_name = "sws_k_bgr24_to_yv12"; break;
     case PLAN_CASCADE: c->path_name = "cascade"; c->kernel_name = ""; break;
     case PLAN_MAIN: {
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
@@ -682,6 +683,11 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         else if (s3) hipLaunchKernelGGL((swsk::sws_k_rgb_shuffle<true, false>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
         else if (d3) hipLaunchKernelGGL((swsk::sws_k_rgb_shuffle<false, true>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
         else hipLaunchKernelGGL((swsk::sws_k_rgb_shuffle<false, false>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
+        break;
+    }
+    case PLAN_UNSC_BGR24_YV12: {
+        const dim3 grid(cdiv(cdiv(p.srcW >> 1, 4), 256), (sliceH + 1) / 2, n);
+        if (p.srcW >> 1) hipLaunchKernelGGL(swsk::sws_k_bgr24_to_yv12, grid, blk, 0, st, fs, p, sliceY, sliceH);
         break;
     }
     case PLAN_UNSC_PACKEDCOPY: {

@@ -93,4 +93,62 @@ __global__ void __launch_bounds__(256) sws_k_packed_copy(SwsFrameSet fs, int row
     }
 }
 
+// bgr24ToYv12Wrapper (swscale_unscaled.c:2062-2078) -> ff_rgb24toyv12_c (rgb2rgb_template.c:580-641).
+// One thread = 4 chroma samples = 8 pixels x 2 rows: 2 x 24 bytes in, 2 x 8 luma + 4 U + 4 V bytes out.
+// All arithmetic is unsigned and the results are stored modulo 256 exactly like the reference's uint8_t stores.
+__device__ __forceinline__ uint32_t rgb24toyv12_dot(int32_t cr, int32_t cg, int32_t cb, uint32_t r, uint32_t g, uint32_t b, uint32_t bias)
+{
+    return ((((uint32_t)cr * r + (uint32_t)cg * g + (uint32_t)cb * b) >> 15) + bias) & 0xffu;
+}
+
+__global__ void __launch_bounds__(256) sws_k_bgr24_to_yv12(SwsFrameSet fs, SwsDevParams p, int sliceY, int sliceH)
+{
+    const int cw = p.srcW >> 1;
+    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c0 >= cw) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int y = blockIdx.y * 2, y2 = (y + 1 == sliceH) ? y : y + 1;
+    const uint8_t *s1 = f.src[0] + (int64_t)y * f.srcStride[0] + c0 * 6;
+    const uint8_t *s2 = f.src[0] + (int64_t)y2 * f.srcStride[0] + c0 * 6;
+    uint8_t *d1 = f.dst[0] + (int64_t)(sliceY + y) * f.dstStride[0] + c0 * 2;
+    uint8_t *d2 = f.dst[0] + (int64_t)(sliceY + y2) * f.dstStride[0] + c0 * 2;
+    uint8_t *du = f.dst[1] + (int64_t)((sliceY >> 1) + (y >> 1)) * f.dstStride[1] + c0;
+    uint8_t *dv = f.dst[2] + (int64_t)((sliceY >> 1) + (y >> 1)) * f.dstStride[2] + c0;
+    const int n = min(4, cw - c0);
+    const int32_t ry = p.rgb2yuv[0], gy = p.rgb2yuv[1], by = p.rgb2yuv[2], ru = p.rgb2yuv[3], gu = p.rgb2yuv[4], bu = p.rgb2yuv[5],
+                  rv = p.rgb2yuv[6], gv = p.rgb2yuv[7], bv = p.rgb2yuv[8];
+    uint8_t row1[24], row2[24];
+    const bool fast = n == 4 && ((((uintptr_t)s1) | ((uintptr_t)s2)) & 3) == 0;
+    if (fast) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            reinterpret_cast<uint32_t *>(row1)[k] = reinterpret_cast<const uint32_t *>(s1)[k];
+            reinterpret_cast<uint32_t *>(row2)[k] = reinterpret_cast<const uint32_t *>(s2)[k];
+        }
+    } else {
+        for (int k = 0; k < 6 * n; k++) { row1[k] = s1[k]; row2[k] = s2[k]; }
+    }
+    uint8_t Y1[8], Y2[8], U[4], V[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t b[4], g[4], r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint8_t *px = (k < 2 ? row1 : row2) + 6 * i + 3 * (k & 1);
+            b[k] = px[0]; g[k] = px[1]; r[k] = px[2];
+        }
+        Y1[2 * i] = rgb24toyv12_dot(ry, gy, by, r[0], g[0], b[0], 16); Y1[2 * i + 1] = rgb24toyv12_dot(ry, gy, by, r[1], g[1], b[1], 16);
+        Y2[2 * i] = rgb24toyv12_dot(ry, gy, by, r[2], g[2], b[2], 16); Y2[2 * i + 1] = rgb24toyv12_dot(ry, gy, by, r[3], g[3], b[3], 16);
+        const uint32_t bx = (b[0] + b[1] + b[2] + b[3]) >> 2, gx = (g[0] + g[1] + g[2] + g[3]) >> 2, rx = (r[0] + r[1] + r[2] + r[3]) >> 2;
+        U[i] = rgb24toyv12_dot(ru, gu, bu, rx, gx, bx, 128);
+        V[i] = rgb24toyv12_dot(rv, gv, bv, rx, gx, bx, 128);
+    }
+    for (int i = 0; i < n; i++) {
+        d1[2 * i] = Y1[2 * i]; d1[2 * i + 1] = Y1[2 * i + 1];
+        if (y2 != y) { d2[2 * i] = Y2[2 * i]; d2[2 * i + 1] = Y2[2 * i + 1]; }
+        else { d1[2 * i] = Y2[2 * i]; d1[2 * i + 1] = Y2[2 * i + 1]; }   // odd last row: ydst2 == ydst1, the later stores win
+        du[i] = U[i]; dv[i] = V[i];
+    }
+}
+
 } // namespace swsk

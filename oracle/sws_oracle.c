@@ -138,7 +138,7 @@ enum { RY, GY, BY, RU, GU, BU, RV, GV, BV };
 #define TABLE_PLANE 2048
 
 enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
-       UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_PACKEDCOPY };
+       UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_PACKEDCOPY, UNSC_BGR24_YV12 };
 
 struct OrSws {
     OrSwsOpts o;
@@ -721,6 +721,9 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
     }
     if ((s == ORF_YUV420P10LE || s == ORF_YUV420P16LE) && d == ORF_P010LE) c->unscaled_kind = UNSC_P01X;
     if (s == ORF_YUV420P && d == ORF_P010LE) c->unscaled_kind = UNSC_8_P01X;
+    /* bgr24toYV12 (:2452-2456) */
+    if (s == ORF_BGR24 && d == ORF_YUV420P && !(flags & OR_SWS_ACCURATE_RND) && !(c->o.dst_w & 1))
+        c->unscaled_kind = UNSC_BGR24_YV12;
     /* rgbToRgbWrapper (:2459-2463) when findRgbConvFn (:1843-1998) has a converter; 8-bit 24/32 bpp formats on a
      * little-endian host.  needsDither is 0 for >= 24 bpp destinations.  ":1991-1994 Maintain symmetry between
      * endianness": with BITEXACT a 24 bpp source is not shuffled into RGB32/BGR32 (= bgra/rgba bytes on LE). */
@@ -1050,6 +1053,37 @@ static int unscaled_rgb2rgb(OrSws *c, const uint8_t *const src[], const int srcS
         for (int x = 0; x < c->o.src_w; x++, s += ds->c[0].step, d += dd->c[0].step) {
             for (int k = 0; k < 3; k++) d[dd->c[k].offset] = s[ds->c[k].offset];
             if (da) d[dd->c[3].offset] = sa ? s[ds->c[3].offset] : 255;
+        }
+    }
+    return srcSliceH;
+}
+
+/* bgr24ToYv12Wrapper (swscale_unscaled.c:2062-2078) -> ff_rgb24toyv12_c (rgb2rgb_template.c:580-641): truncating
+ * Y per pixel, U/V from the truncated 2x2 mean of each channel; everything unsigned, stored modulo 256. */
+static int unscaled_bgr24_yv12(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                               int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    const int32_t *t = c->rgb2yuv;
+    const int cw = c->o.src_w >> 1;
+    (void)srcSliceY;
+    for (int y = 0; y < srcSliceH; y += 2) {
+        const int y2 = y + 1 == srcSliceH ? y : y + 1;
+        const uint8_t *s1 = src[0] + (ptrdiff_t)y * srcStride[0], *s2 = src[0] + (ptrdiff_t)y2 * srcStride[0];
+        uint8_t *d1 = dst[0] + (ptrdiff_t)y * dstStride[0], *d2 = dst[0] + (ptrdiff_t)y2 * dstStride[0];
+        uint8_t *du = dst[1] + (ptrdiff_t)(y >> 1) * dstStride[1], *dv = dst[2] + (ptrdiff_t)(y >> 1) * dstStride[2];
+        for (int i = 0; i < cw; i++) {
+            unsigned b[4], g[4], r[4], Y[4], bx, gx, rx;
+            for (int k = 0; k < 4; k++) {
+                const uint8_t *p = (k < 2 ? s1 : s2) + 6 * i + 3 * (k & 1);
+                b[k] = p[0]; g[k] = p[1]; r[k] = p[2];
+                Y[k] = (((unsigned)t[RY] * r[k] + (unsigned)t[GY] * g[k] + (unsigned)t[BY] * b[k]) >> 15) + 16;
+            }
+            bx = (b[0] + b[1] + b[2] + b[3]) >> 2; gx = (g[0] + g[1] + g[2] + g[3]) >> 2; rx = (r[0] + r[1] + r[2] + r[3]) >> 2;
+            /* order of the stores as in the reference: for an odd last row d2 == d1 and the second pair wins */
+            d1[2 * i] = (uint8_t)Y[0]; d1[2 * i + 1] = (uint8_t)Y[1];
+            d2[2 * i] = (uint8_t)Y[2]; d2[2 * i + 1] = (uint8_t)Y[3];
+            du[i] = (uint8_t)((((unsigned)t[RU] * rx + (unsigned)t[GU] * gx + (unsigned)t[BU] * bx) >> 15) + 128);
+            dv[i] = (uint8_t)((((unsigned)t[RV] * rx + (unsigned)t[GV] * gx + (unsigned)t[BV] * bx) >> 15) + 128);
         }
     }
     return srcSliceH;
@@ -1708,6 +1742,7 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
     case UNSC_PLANAR2NV12: return unscaled_planar2nv12(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_NV122PLANAR: return unscaled_nv122planar(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_PLANARCOPY: return unscaled_planarcopy(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_BGR24_YV12: return unscaled_bgr24_yv12(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     }
     return main_path(c, src, srcStride, dst, dstStride);
 }
@@ -1729,7 +1764,7 @@ int or_sws_path(const OrSws *c) { return c->cascade[0] ? 2 : c->unscaled_kind ? 
 const char *or_sws_path_name(const OrSws *c)
 {
     static const char *n[] = { "main", "yuv2rgb_c", "planarToP01x", "planar8ToP01xle", "planarToNv12", "nv12ToPlanar", "planarCopy",
-                               "rgbToRgb", "packedCopy" };
+                               "rgbToRgb", "packedCopy", "bgr24ToYv12" };
     return c->cascade[0] ? "cascade" : n[c->unscaled_kind];
 }
 const int32_t *or_sws_rgb2yuv_table(const OrSws *c) { return c->rgb2yuv; }

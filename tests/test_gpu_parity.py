@@ -118,6 +118,18 @@ def test_scalers_and_geometries(flags, geom):
     run_case(sw, sh, "yuv420p", dw & ~1, dh, "bgra", flags | BX, seed=8)
 
 
+@pytest.mark.parametrize("w,h", [(96, 64), (2, 2), (10, 5), (38, 7), (258, 3), (64, 1)])
+def test_bgr24_to_yuv420p_special_converter(w, h):
+    """bgr24ToYv12Wrapper -> ff_rgb24toyv12_c (rgb2rgb_template.c:580-641): taken without ACCURATE_RND for even widths."""
+    for fl in (SWS_BICUBIC, SWS_BICUBIC | BX):
+        path, opath = run_case(w, h, "bgr24", w, h, "yuv420p", fl, seed=w + h)
+        assert (path, opath) == ("unscaled:bgr24ToYv12", "bgr24ToYv12")
+    path, opath = run_case(w, h, "bgr24", w, h, "yuv420p", SWS_BICUBIC | BX | AR, seed=w)
+    assert opath == "main"
+    path, opath = run_case(w + 1, h, "bgr24", w + 1, h, "yuv420p", SWS_BICUBIC | BX, seed=w)
+    assert opath == "main"
+
+
 PACKED_RGB = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "bgr0", "0rgb", "0bgr"]
 
 
