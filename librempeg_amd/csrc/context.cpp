@@ -132,7 +132,7 @@ void choose_unscaled(SwsInternal *c)
         const bool s32 = pix_desc(s)->comp[0].step == 4;
         if (!(!s32 && (d == AV_PIX_FMT_BGRA || d == AV_PIX_FMT_RGBA) && (flags & SWS_BITEXACT))) k = PLAN_UNSC_RGB2RGB;
     }
-    if (s == AV_PIX_FMT_GBRP && isAnyRGB(d) && !isPlanarRGB(d)) unsupported = true;                     // planarRgbToRgbWrapper (:2482)
+    if (s == AV_PIX_FMT_GBRP && isAnyRGB(d) && !isPlanarRGB(d)) k = PLAN_UNSC_GBRP_PACKED;             // planarRgbToRgbWrapper (:2480-2481)
     if (s == d ||
         (isFloatFmt(s) == isFloatFmt(d) && isPlanarYUV(s) && isPlanarYUV(d) &&
          c->chrDstHSubSample == c->chrSrcHSubSample && c->chrDstVSubSample == c->chrSrcVSubSample &&

@@ -456,6 +456,7 @@ int dev_prepare(SwsInternal *c)
     case PLAN_UNSC_RGB2RGB: c->path_name = "unscaled:rgbToRgb"; c->kernel_name = "sws_k_rgb_shuffle"; break;
     case PLAN_UNSC_PACKEDCOPY: c->path_name = "unscaled:packedCopy"; c->kernel_name = "sws_k_packed_copy"; break;
     case PLAN_UNSC_BGR24_YV12: c->path_name = "unscaled:bgr24ToYv12"; c->kernel_name = "sws_k_bgr24_to_yv12"; break;
+    case PLAN_UNSC_GBRP_PACKED: c->path_name = "unscaled:planarRgbToRgb"; c->kernel_name = "sws_k_gbrp_to_packed"; break;
     case PLAN_CASCADE: c->path_name = "cascade"; c->kernel_name = ""; break;
     case PLAN_MAIN: {
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
@@ -683,6 +684,16 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         else if (s3) hipLaunchKernelGGL((swsk::sws_k_rgb_shuffle<true, false>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
         else if (d3) hipLaunchKernelGGL((swsk::sws_k_rgb_shuffle<false, true>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
         else hipLaunchKernelGGL((swsk::sws_k_rgb_shuffle<false, false>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
+        break;
+    }
+    case PLAN_UNSC_GBRP_PACKED: {
+        const PixDesc *dd = pix_desc(c->opts.dst_format);
+        swsk::ShufflePlan sp;
+        std::memset(&sp, 0, sizeof(sp));
+        for (int k = 0; k < 4; k++) sp.dpos[k] = k < dd->nb_components ? dd->comp[k].offset : -1;
+        const dim3 grid(cdiv(cdiv(p.srcW, 4), 256), sliceH, n);
+        if (dd->comp[0].step == 3) hipLaunchKernelGGL((swsk::sws_k_gbrp_to_packed<true>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
+        else hipLaunchKernelGGL((swsk::sws_k_gbrp_to_packed<false>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
         break;
     }
     case PLAN_UNSC_BGR24_YV12: {

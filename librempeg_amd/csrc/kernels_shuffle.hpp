@@ -93,6 +93,28 @@ __global__ void __launch_bounds__(256) sws_k_packed_copy(SwsFrameSet fs, int row
     }
 }
 
+// planarRgbToRgbWrapper (swscale_unscaled.c:1322-1378, gbr24ptopacked24/32 :1188-1233): gbrp -> packed 24/32 bpp,
+// A = 255.  pl[k] = source plane of destination colour k (R,G,B); dpos[] = byte positions in the destination pixel.
+template <bool D3>
+__global__ void __launch_bounds__(256) sws_k_gbrp_to_packed(SwsFrameSet fs, ShufflePlan sp, int w, int sliceY)
+{
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x0 >= w) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int y = blockIdx.y;
+    const uint8_t *pr = f.src[2] + (int64_t)y * f.srcStride[2] + x0;   // gbrp: plane 0 = G, 1 = B, 2 = R
+    const uint8_t *pg = f.src[0] + (int64_t)y * f.srcStride[0] + x0;
+    const uint8_t *pb = f.src[1] + (int64_t)y * f.srcStride[1] + x0;
+    constexpr int DS = D3 ? 3 : 4;
+    uint8_t *d = f.dst[0] + (int64_t)(sliceY + y) * f.dstStride[0] + x0 * DS;
+    const int n = min(4, w - x0);
+    for (int i = 0; i < n; i++) {
+        uint8_t *q = d + i * DS;
+        q[sp.dpos[0]] = pr[i]; q[sp.dpos[1]] = pg[i]; q[sp.dpos[2]] = pb[i];
+        if (!D3) q[sp.dpos[3]] = 255;
+    }
+}
+
 // bgr24ToYv12Wrapper (swscale_unscaled.c:2062-2078) -> ff_rgb24toyv12_c (rgb2rgb_template.c:580-641).
 // One thread = 4 chroma samples = 8 pixels x 2 rows: 2 x 24 bytes in, 2 x 8 luma + 4 U + 4 V bytes out.
 // All arithmetic is unsigned and the results are stored modulo 256 exactly like the reference's uint8_t stores.

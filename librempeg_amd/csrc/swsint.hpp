@@ -64,6 +64,7 @@ enum PlanKind {
     PLAN_UNSC_RGB2RGB,     // rgbToRgbWrapper (8-bit 24/32 bpp byte shuffles)
     PLAN_UNSC_PACKEDCOPY,  // packedCopyWrapper
     PLAN_UNSC_BGR24_YV12,  // bgr24ToYv12Wrapper -> ff_rgb24toyv12_c
+    PLAN_UNSC_GBRP_PACKED, // planarRgbToRgbWrapper (gbrp -> 24/32 bpp packed)
     PLAN_MAIN,             // ff_swscale chain
     PLAN_CASCADE,          // two contexts through an intermediate image
 };

@@ -138,7 +138,7 @@ enum { RY, GY, BY, RU, GU, BU, RV, GV, BV };
 #define TABLE_PLANE 2048
 
 enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
-       UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_PACKEDCOPY, UNSC_BGR24_YV12 };
+       UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED };
 
 struct OrSws {
     OrSwsOpts o;
@@ -732,6 +732,8 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         if (!(!s32 && (d == ORF_BGRA || d == ORF_RGBA) && (flags & OR_SWS_BITEXACT)))
             c->unscaled_kind = UNSC_RGB2RGB;
     }
+    /* planarRgbToRgbWrapper (:2480-2481): gbrp -> byte RGB */
+    if (s == ORF_GBRP && isAnyRGB(d) && isPacked(d) && desc_get(d)->c[0].depth == 8) c->unscaled_kind = UNSC_GBRP2PACKED;
     /* simple copy (:2647-2668) */
     if (s == d ||
         (isFloat(s) == isFloat(d) &&
@@ -1084,6 +1086,23 @@ static int unscaled_bgr24_yv12(OrSws *c, const uint8_t *const src[], const int s
             d2[2 * i] = (uint8_t)Y[2]; d2[2 * i + 1] = (uint8_t)Y[3];
             du[i] = (uint8_t)((((unsigned)t[RU] * rx + (unsigned)t[GU] * gx + (unsigned)t[BU] * bx) >> 15) + 128);
             dv[i] = (uint8_t)((((unsigned)t[RV] * rx + (unsigned)t[GV] * gx + (unsigned)t[BV] * bx) >> 15) + 128);
+        }
+    }
+    return srcSliceH;
+}
+
+/* planarRgbToRgbWrapper (swscale_unscaled.c:1322-1378) with gbr24ptopacked24/32 (:1188-1233): interleave, A = 255 */
+static int unscaled_gbrp2packed(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                                int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    const Desc *ds = desc_get(c->o.src_format), *dd = desc_get(c->o.dst_format);
+    (void)srcSliceY;
+    for (int y = 0; y < srcSliceH; y++) {
+        uint8_t *d = dst[0] + (ptrdiff_t)y * dstStride[0];
+        for (int x = 0; x < c->o.src_w; x++, d += dd->c[0].step) {
+            for (int k = 0; k < 3; k++)
+                d[dd->c[k].offset] = src[ds->c[k].plane][(ptrdiff_t)y * srcStride[ds->c[k].plane] + x];
+            if (dd->c[0].step == 4) d[isALPHA(c->o.dst_format) ? dd->c[3].offset : 0] = 0xff;
         }
     }
     return srcSliceH;
@@ -1743,6 +1762,7 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
     case UNSC_NV122PLANAR: return unscaled_nv122planar(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_PLANARCOPY: return unscaled_planarcopy(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_BGR24_YV12: return unscaled_bgr24_yv12(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_GBRP2PACKED: return unscaled_gbrp2packed(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     }
     return main_path(c, src, srcStride, dst, dstStride);
 }
@@ -1764,7 +1784,7 @@ int or_sws_path(const OrSws *c) { return c->cascade[0] ? 2 : c->unscaled_kind ? 
 const char *or_sws_path_name(const OrSws *c)
 {
     static const char *n[] = { "main", "yuv2rgb_c", "planarToP01x", "planar8ToP01xle", "planarToNv12", "nv12ToPlanar", "planarCopy",
-                               "rgbToRgb", "packedCopy", "bgr24ToYv12" };
+                               "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb" };
     return c->cascade[0] ? "cascade" : n[c->unscaled_kind];
 }
 const int32_t *or_sws_rgb2yuv_table(const OrSws *c) { return c->rgb2yuv; }
