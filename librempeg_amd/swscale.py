@@ -21,11 +21,46 @@ SWS_ACCURATE_RND, SWS_BITEXACT = 1 << 18, 1 << 19
 SWS_CS_ITU709, SWS_CS_ITU601, SWS_CS_DEFAULT, SWS_CS_BT2020 = 1, 5, 5, 9
 
 # enum AVPixelFormat values (libavutil/pixfmt.h)
-PIX_FMT = dict(yuv420p=0, rgb24=2, bgr24=3, yuv422p=4, yuv444p=5, gray8=8, yuvj420p=12, nv12=23, nv21=24,
-               argb=25, rgba=26, abgr=27, bgra=28, yuv420p16le=45, yuv444p16le=49, yuv420p10le=62,
-               yuv444p10le=68, gbrp=71, rgb0=119, bgr0=121, p010le=158, gbrpf32le=175)
-PIX_FMT["0rgb"] = 118
-PIX_FMT["0bgr"] = 120
+# name: (AVPixelFormat value, layout, log2 chroma w, log2 chroma h, bytes per sample)
+# layout: "planar" (3 planes), "semi" (Y + interleaved UV), "packed" (bytes per sample = bytes per pixel),
+#         "rgbp" (3 full-size planes), "gray" (1 plane)
+_FORMATS = {
+    "yuv420p": (0, "planar", 1, 1, 1), "yuvj420p": (12, "planar", 1, 1, 1), "yuv422p": (4, "planar", 1, 0, 1),
+    "yuvj422p": (13, "planar", 1, 0, 1), "yuv444p": (5, "planar", 0, 0, 1), "yuvj444p": (14, "planar", 0, 0, 1),
+    "yuv410p": (6, "planar", 2, 2, 1), "yuv411p": (7, "planar", 2, 0, 1), "yuv440p": (31, "planar", 0, 1, 1),
+    "yuvj440p": (32, "planar", 0, 1, 1),
+    "yuv420p9le": (60, "planar", 1, 1, 2), "yuv422p9le": (70, "planar", 1, 0, 2), "yuv444p9le": (66, "planar", 0, 0, 2),
+    "yuv420p10le": (62, "planar", 1, 1, 2), "yuv422p10le": (64, "planar", 1, 0, 2), "yuv444p10le": (68, "planar", 0, 0, 2),
+    "yuv440p10le": (151, "planar", 0, 1, 2),
+    "yuv420p12le": (123, "planar", 1, 1, 2), "yuv422p12le": (127, "planar", 1, 0, 2), "yuv444p12le": (131, "planar", 0, 0, 2),
+    "yuv440p12le": (153, "planar", 0, 1, 2),
+    "yuv420p14le": (125, "planar", 1, 1, 2), "yuv422p14le": (129, "planar", 1, 0, 2), "yuv444p14le": (133, "planar", 0, 0, 2),
+    "yuv420p16le": (45, "planar", 1, 1, 2), "yuv422p16le": (47, "planar", 1, 0, 2), "yuv444p16le": (49, "planar", 0, 0, 2),
+    "nv12": (23, "semi", 1, 1, 1), "nv21": (24, "semi", 1, 1, 1), "nv16": (101, "semi", 1, 0, 1),
+    "nv24": (188, "semi", 0, 0, 1), "nv42": (189, "semi", 0, 0, 1),
+    "p010le": (158, "semi", 1, 1, 2), "p012le": (209, "semi", 1, 1, 2), "p016le": (169, "semi", 1, 1, 2),
+    "p210le": (198, "semi", 1, 0, 2), "p212le": (222, "semi", 1, 0, 2), "p216le": (202, "semi", 1, 0, 2),
+    "p410le": (200, "semi", 0, 0, 2), "p412le": (224, "semi", 0, 0, 2), "p416le": (204, "semi", 0, 0, 2),
+    "rgb24": (2, "packed", 0, 0, 3), "bgr24": (3, "packed", 0, 0, 3),
+    "argb": (25, "packed", 0, 0, 4), "rgba": (26, "packed", 0, 0, 4), "abgr": (27, "packed", 0, 0, 4), "bgra": (28, "packed", 0, 0, 4),
+    "0rgb": (118, "packed", 0, 0, 4), "rgb0": (119, "packed", 0, 0, 4), "0bgr": (120, "packed", 0, 0, 4), "bgr0": (121, "packed", 0, 0, 4),
+    "gbrp": (71, "rgbp", 0, 0, 1), "gbrpf32le": (175, "rgbp", 0, 0, 4),
+    "gray8": (8, "gray", 0, 0, 1),
+}
+
+
+def plane_layout(fmt, w, h):
+    """[(visible_bytes_per_row, rows)] per plane."""
+    _, kind, lw, lh, bps = _FORMATS[fmt]
+    cw, ch = -(-w >> lw), -(-h >> lh)
+    if kind == "planar":
+        return [(bps * w, h), (bps * cw, ch), (bps * cw, ch)]
+    if kind == "semi":
+        return [(bps * w, h), (2 * bps * cw, ch)]
+    if kind == "rgbp":
+        return [(bps * w, h)] * 3
+    return [(bps * w, h)]   # packed, gray
+PIX_FMT = {k: v[0] for k, v in _FORMATS.items()}
 _FMT_NAME = {v: k for k, v in PIX_FMT.items()}
 
 
@@ -116,34 +151,6 @@ def image_layout(fmt, w, h, align=256):
     if r < 0:
         raise ValueError(fmt)
     return list(ls), list(off), tot.value
-
-
-def plane_layout(fmt, w, h):
-    """[(visible_bytes_per_row, rows)] per plane."""
-    cw, ch = -(-w // 2), -(-h // 2)
-    if fmt in ("yuv420p", "yuvj420p"):
-        return [(w, h), (cw, ch), (cw, ch)]
-    if fmt == "yuv422p":
-        return [(w, h), (cw, h), (cw, h)]
-    if fmt in ("yuv444p", "gbrp"):
-        return [(w, h)] * 3
-    if fmt in ("nv12", "nv21"):
-        return [(w, h), (2 * cw, ch)]
-    if fmt in ("yuv420p10le", "yuv420p16le"):
-        return [(2 * w, h), (2 * cw, ch), (2 * cw, ch)]
-    if fmt in ("yuv444p10le", "yuv444p16le"):
-        return [(2 * w, h)] * 3
-    if fmt == "p010le":
-        return [(2 * w, h), (4 * cw, ch)]
-    if fmt in ("rgb24", "bgr24"):
-        return [(3 * w, h)]
-    if fmt in ("rgba", "bgra", "argb", "abgr", "rgb0", "bgr0", "0rgb", "0bgr"):
-        return [(4 * w, h)]
-    if fmt == "gbrpf32le":
-        return [(4 * w, h)] * 3
-    if fmt == "gray8":
-        return [(w, h)]
-    raise KeyError(fmt)
 
 
 class HostFrame:

@@ -71,6 +71,22 @@ static const Desc descs[] = {
     { ORF_YUV420P16LE, "yuv420p16le", 3, 1, 1, {{0,2,0,0,16},{1,2,0,0,16},{2,2,0,0,16}}, PF_PLANAR },
     { ORF_YUV444P16LE, "yuv444p16le", 3, 0, 0, {{0,2,0,0,16},{1,2,0,0,16},{2,2,0,0,16}}, PF_PLANAR },
     { ORF_P010LE,  "p010le",  3, 1, 1, {{0,2,0,6,10},{1,4,0,6,10},{1,4,2,6,10}}, PF_PLANAR },
+#define PL8(F, N, LW, LH)      { F, N, 3, LW, LH, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8}}, PF_PLANAR }
+#define PLN(F, N, LW, LH, D)   { F, N, 3, LW, LH, {{0,2,0,0,D},{1,2,0,0,D},{2,2,0,0,D}}, PF_PLANAR }
+#define SP8(F, N, LW, LH, UO)  { F, N, 3, LW, LH, {{0,1,0,0,8},{1,2,UO,0,8},{1,2,1-(UO),0,8}}, PF_PLANAR }
+#define SPN(F, N, LW, LH, D)   { F, N, 3, LW, LH, {{0,2,0,16-(D),D},{1,4,0,16-(D),D},{1,4,2,16-(D),D}}, PF_PLANAR }
+    PL8(ORF_YUV410P, "yuv410p", 2, 2), PL8(ORF_YUV411P, "yuv411p", 2, 0), PL8(ORF_YUV440P, "yuv440p", 0, 1),
+    PL8(ORF_YUVJ422P, "yuvj422p", 1, 0), PL8(ORF_YUVJ444P, "yuvj444p", 0, 0), PL8(ORF_YUVJ440P, "yuvj440p", 0, 1),
+    PLN(ORF_YUV420P9LE, "yuv420p9le", 1, 1, 9), PLN(ORF_YUV422P9LE, "yuv422p9le", 1, 0, 9), PLN(ORF_YUV444P9LE, "yuv444p9le", 0, 0, 9),
+    PLN(ORF_YUV422P10LE, "yuv422p10le", 1, 0, 10), PLN(ORF_YUV440P10LE, "yuv440p10le", 0, 1, 10),
+    PLN(ORF_YUV420P12LE, "yuv420p12le", 1, 1, 12), PLN(ORF_YUV422P12LE, "yuv422p12le", 1, 0, 12),
+    PLN(ORF_YUV444P12LE, "yuv444p12le", 0, 0, 12), PLN(ORF_YUV440P12LE, "yuv440p12le", 0, 1, 12),
+    PLN(ORF_YUV420P14LE, "yuv420p14le", 1, 1, 14), PLN(ORF_YUV422P14LE, "yuv422p14le", 1, 0, 14), PLN(ORF_YUV444P14LE, "yuv444p14le", 0, 0, 14),
+    PLN(ORF_YUV422P16LE, "yuv422p16le", 1, 0, 16),
+    SP8(ORF_NV16, "nv16", 1, 0, 0), SP8(ORF_NV24, "nv24", 0, 0, 0), SP8(ORF_NV42, "nv42", 0, 0, 1),
+    SPN(ORF_P210LE, "p210le", 1, 0, 10), SPN(ORF_P410LE, "p410le", 0, 0, 10),
+    SPN(ORF_P012LE, "p012le", 1, 1, 12), SPN(ORF_P212LE, "p212le", 1, 0, 12), SPN(ORF_P412LE, "p412le", 0, 0, 12),
+    SPN(ORF_P016LE, "p016le", 1, 1, 16), SPN(ORF_P216LE, "p216le", 1, 0, 16), SPN(ORF_P416LE, "p416le", 0, 0, 16),
     { ORF_RGB24,   "rgb24",   3, 0, 0, {{0,3,0,0,8},{0,3,1,0,8},{0,3,2,0,8}}, PF_RGB },
     { ORF_BGR24,   "bgr24",   3, 0, 0, {{0,3,2,0,8},{0,3,1,0,8},{0,3,0,0,8}}, PF_RGB },
     { ORF_ARGB,    "argb",    4, 0, 0, {{0,4,1,0,8},{0,4,2,0,8},{0,4,3,0,8},{0,4,0,0,8}}, PF_RGB | PF_ALPHA },
@@ -138,7 +154,8 @@ enum { RY, GY, BY, RU, GU, BU, RV, GV, BV };
 #define TABLE_PLANE 2048
 
 enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
-       UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED };
+       UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED,
+       UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12 };
 
 struct OrSws {
     OrSwsOpts o;
@@ -662,6 +679,9 @@ static OrSws *alloc_set_opts(int srcW, int srcH, int srcFmt, int dstW, int dstH,
 static int handle_jpeg(int *format) /* utils.c:773 */
 {
     if (*format == ORF_YUVJ420P) { *format = ORF_YUV420P; return 1; }
+    if (*format == ORF_YUVJ422P) { *format = ORF_YUV422P; return 1; }
+    if (*format == ORF_YUVJ444P) { *format = ORF_YUV444P; return 1; }
+    if (*format == ORF_YUVJ440P) { *format = ORF_YUV440P; return 1; }
     if (*format == ORF_GRAY8) return 1;
     return 0;
 }
@@ -719,8 +739,13 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         else
             c->unscaled_kind = UNSC_NONE; /* gbrp etc. not restated: main path would NOT be taken by the reference */
     }
-    if ((s == ORF_YUV420P10LE || s == ORF_YUV420P16LE) && d == ORF_P010LE) c->unscaled_kind = UNSC_P01X;
-    if (s == ORF_YUV420P && d == ORF_P010LE) c->unscaled_kind = UNSC_8_P01X;
+    if (s == ORF_YUV444P && (d == ORF_NV24 || d == ORF_NV42)) c->unscaled_kind = UNSC_PLANAR2NV24;   /* :2410-2413 */
+    if (d == ORF_YUV444P && (s == ORF_NV24 || s == ORF_NV42)) c->unscaled_kind = UNSC_NV242PLANAR;   /* :2420-2423 */
+    if ((s == ORF_YUV420P10LE || s == ORF_YUV420P12LE || s == ORF_YUV420P14LE || s == ORF_YUV420P16LE) &&
+        (d == ORF_P010LE || d == ORF_P016LE)) c->unscaled_kind = UNSC_P01X;                           /* :2432-2439 */
+    if (s == ORF_YUV420P && (d == ORF_P010LE || d == ORF_P016LE)) c->unscaled_kind = UNSC_8_P01X;     /* :2440-2444 */
+    if (s == ORF_YUV410P && !(c->o.dst_h & 3) && d == ORF_YUV420P && !(flags & OR_SWS_BITEXACT))
+        c->unscaled_kind = UNSC_YVU9_YV12;                                                            /* :2446-2451 */
     /* bgr24toYV12 (:2452-2456) */
     if (s == ORF_BGR24 && d == ORF_YUV420P && !(flags & OR_SWS_ACCURATE_RND) && !(c->o.dst_w & 1))
         c->unscaled_kind = UNSC_BGR24_YV12;
@@ -742,6 +767,7 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         if (!isPacked(s)) c->unscaled_kind = UNSC_PLANARCOPY;
         else c->unscaled_kind = UNSC_PACKEDCOPY; /* packedCopyWrapper (:2138-2157) */
     }
+    if (d == ORF_YUV420P && (s == ORF_NV24 || s == ORF_NV42)) c->unscaled_kind = UNSC_NV242YUV420;    /* :2703-2705 */
 }
 
 static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
@@ -1037,6 +1063,83 @@ static int unscaled_nv122planar(OrSws *c, const uint8_t *const src[], const int 
     return srcSliceH;
 }
 
+/* planarToNv24Wrapper / nv24ToPlanarWrapper / nv24ToYuv420Wrapper, swscale_unscaled.c:188-271 */
+static int unscaled_planar2nv24(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                                int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    int a = c->o.dst_format == ORF_NV24 ? 1 : 2, b = 3 - a;
+    copy_plane(src[0], srcStride[0], srcSliceY, srcSliceH, c->o.src_w, dst[0], dstStride[0]);
+    for (int y = 0; y < srcSliceH; y++) {
+        const uint8_t *s1 = src[a] + y * srcStride[a], *s2 = src[b] + y * srcStride[b];
+        uint8_t *d = dst[1] + dstStride[1] * (srcSliceY + y);
+        for (int x = 0; x < c->chrSrcW; x++) { d[2 * x] = s1[x]; d[2 * x + 1] = s2[x]; }
+    }
+    return srcSliceH;
+}
+static int unscaled_nv242planar(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                                int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    int a = c->o.src_format == ORF_NV24 ? 1 : 2, b = 3 - a;
+    copy_plane(src[0], srcStride[0], srcSliceY, srcSliceH, c->o.src_w, dst[0], dstStride[0]);
+    for (int y = 0; y < srcSliceH; y++) {
+        const uint8_t *s = src[1] + y * srcStride[1];
+        uint8_t *d1 = dst[a] + dstStride[a] * (srcSliceY + y), *d2 = dst[b] + dstStride[b] * (srcSliceY + y);
+        for (int x = 0; x < c->chrSrcW; x++) { d1[x] = s[2 * x]; d2[x] = s[2 * x + 1]; }
+    }
+    return srcSliceH;
+}
+static int unscaled_nv242yuv420(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                                int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    int a = c->o.src_format == ORF_NV24 ? 1 : 2, b = 3 - a;
+    const int w = c->o.src_w / 2;
+    copy_plane(src[0], srcStride[0], srcSliceY, srcSliceH, c->o.src_w, dst[0], dstStride[0]);
+    for (int y = 0; y < srcSliceH; y += 2) { /* nv24_to_yuv420p_chroma :229-251: truncating 2x2 mean */
+        const uint8_t *s1 = src[1] + y * srcStride[1], *s2 = y + 1 == srcSliceH ? s1 : s1 + srcStride[1];
+        uint8_t *d1 = dst[a] + dstStride[a] * (srcSliceY / 2 + y / 2), *d2 = dst[b] + dstStride[b] * (srcSliceY / 2 + y / 2);
+        for (int x = 0; x < w; x++) {
+            d1[x] = (uint8_t)((s1[4 * x + 0] + s1[4 * x + 2] + s2[4 * x + 0] + s2[4 * x + 2]) >> 2);
+            d2[x] = (uint8_t)((s1[4 * x + 1] + s1[4 * x + 3] + s2[4 * x + 1] + s2[4 * x + 3]) >> 2);
+        }
+    }
+    return srcSliceH;
+}
+
+/* yvu9ToYv12Wrapper (swscale_unscaled.c:2079-2093) -> planar2x_c (rgb2rgb_template.c:531-574): 2x chroma up-sampling
+ * with (3,1)/4 weights, diagonal neighbours on the interior lines.  Written per output sample. */
+static void planar2x(const uint8_t *src, uint8_t *dst, int W, int H, int srcStride, int dstStride)
+{
+    for (int Y = 0; Y < 2 * H; Y++) {
+        uint8_t *d = dst + (ptrdiff_t)Y * dstStride;
+        if (Y == 0 || Y == 2 * H - 1) { /* first / last line: horizontal only */
+            const uint8_t *s = src + (ptrdiff_t)(Y ? H - 1 : 0) * srcStride;
+            d[0] = s[0];
+            for (int x = 0; x < W - 1; x++) { d[2 * x + 1] = (uint8_t)((3 * s[x] + s[x + 1]) >> 2); d[2 * x + 2] = (uint8_t)((s[x] + 3 * s[x + 1]) >> 2); }
+            d[2 * W - 1] = s[W - 1];
+        } else {
+            const int y = (Y + 1) >> 1;                        /* lines 2y-1 and 2y come from source rows y-1 (A) and y (B) */
+            const uint8_t *A = src + (ptrdiff_t)(y - 1) * srcStride, *B = A + srcStride;
+            if (Y & 1) {                                         /* line 2y-1: 3*A + B */
+                d[0] = (uint8_t)((3 * A[0] + B[0]) >> 2);
+                for (int x = 0; x < W - 1; x++) { d[2 * x + 1] = (uint8_t)((3 * A[x] + B[x + 1]) >> 2); d[2 * x + 2] = (uint8_t)((3 * A[x + 1] + B[x]) >> 2); }
+                d[2 * W - 1] = (uint8_t)((3 * A[W - 1] + B[W - 1]) >> 2);
+            } else {                                             /* line 2y: A + 3*B */
+                d[0] = (uint8_t)((A[0] + 3 * B[0]) >> 2);
+                for (int x = 0; x < W - 1; x++) { d[2 * x + 2] = (uint8_t)((A[x] + 3 * B[x + 1]) >> 2); d[2 * x + 1] = (uint8_t)((A[x + 1] + 3 * B[x]) >> 2); }
+                d[2 * W - 1] = (uint8_t)((A[W - 1] + 3 * B[W - 1]) >> 2);
+            }
+        }
+    }
+}
+static int unscaled_yvu9_yv12(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                              int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    copy_plane(src[0], srcStride[0], srcSliceY, srcSliceH, c->o.src_w, dst[0], dstStride[0]);
+    planar2x(src[1], dst[1] + dstStride[1] * (srcSliceY >> 1), c->chrSrcW, srcSliceH >> 2, srcStride[1], dstStride[1]);
+    planar2x(src[2], dst[2] + dstStride[2] * (srcSliceY >> 1), c->chrSrcW, srcSliceH >> 2, srcStride[2], dstStride[2]);
+    return srcSliceH;
+}
+
 /* rgbToRgbWrapper (swscale_unscaled.c:2001-2060) with the little-endian C converters of rgb2rgb.c / rgb2rgb_template.c
  * (shuffle_bytes_*, rgb24to32, rgb32to24, rgb24tobgr24, rgb24tobgr32, rgb32tobgr24): every one of them moves the R, G
  * and B bytes of the source pixel to the R, G and B positions of the destination pixel, copies A when both have one
@@ -1230,11 +1333,14 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
     const int f = c->o.src_format, w = c->o.src_w;
     const int32_t *t = c->rgb2yuv;
     int i;
-    switch (f) {
-    case ORF_P010LE: { /* p010LEToY_c input.c:970-1001 */
+    if (isSemiPlanarYUV(f) && desc_get(f)->c[0].depth > 8) { /* p010/p012 LEToY_c input.c:979-1007; p016 reads the plane directly */
+        const int sh = desc_get(f)->c[0].shift;
         const uint16_t *s = (const uint16_t *)(src[0] + y * stride[0]); uint16_t *d = (uint16_t *)tmp;
-        for (i = 0; i < w; i++) d[i] = s[i] >> 6;
-        return tmp; }
+        if (!sh) return src[0] + y * stride[0];
+        for (i = 0; i < w; i++) d[i] = s[i] >> sh;
+        return tmp;
+    }
+    switch (f) {
     case ORF_RGB24: case ORF_BGR24: { /* rgb24ToY_c / bgr24ToY_c input.c:1068-1124 */
         const uint8_t *s = src[0] + y * stride[0]; int16_t *d = (int16_t *)tmp;
         int ro = f == ORF_RGB24 ? 0 : 2, bo = 2 - ro;
@@ -1285,17 +1391,21 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
     const int32_t *t = c->rgb2yuv;
     int i;
     *pu = tu; *pv = tv;
-    switch (f) {
-    case ORF_NV12: case ORF_NV21: { /* nv12ToUV_c / nv21ToUV_c input.c:926-948 */
+    if (isSemiPlanarYUV(f) && desc_get(f)->c[0].depth == 8) { /* nv12ToUV_c / nv21ToUV_c input.c:926-948 (nv12/16/24, nv21/42) */
         const uint8_t *s = src[1] + y * stride[1];
-        uint8_t *a = f == ORF_NV12 ? tu : tv, *b = f == ORF_NV12 ? tv : tu;
+        const int swapped = isSwappedChroma(f);
+        uint8_t *a = swapped ? tv : tu, *b = swapped ? tu : tv;
         for (i = 0; i < w; i++) { a[i] = s[2 * i]; b[i] = s[2 * i + 1]; }
-        return; }
-    case ORF_P010LE: { /* p010LEToUV_c input.c:950-968 */
+        return;
+    }
+    if (isSemiPlanarYUV(f)) { /* p010/p012/p016 LEToUV_c input.c:950-1008 (and the 4:2:2 / 4:4:4 siblings) */
+        const int sh = desc_get(f)->c[1].shift;
         const uint16_t *s = (const uint16_t *)(src[1] + y * stride[1]);
         uint16_t *a = (uint16_t *)tu, *b = (uint16_t *)tv;
-        for (i = 0; i < w; i++) { a[i] = s[2 * i] >> 6; b[i] = s[2 * i + 1] >> 6; }
-        return; }
+        for (i = 0; i < w; i++) { a[i] = s[2 * i] >> sh; b[i] = s[2 * i + 1] >> sh; }
+        return;
+    }
+    switch (f) {
     case ORF_RGB24: case ORF_BGR24: { /* rgb24ToUV(_half)_c, bgr24ToUV(_half)_c input.c:1082-1172 */
         /* chroma row y reads source row y << chrSrcVSub (hscale.c:212) */
         const uint8_t *s = src[0] + (y << c->chrSrcVSub) * stride[0];
@@ -1517,7 +1627,18 @@ static void write_nv_chroma_line(const OrSws *c, uint8_t *dest, int w, const int
     int i, j;
 #define ROWU(j) (up + (size_t)ORMIN(first + (j), planeH - 1) * planeW)
 #define ROWV(j) (vp + (size_t)ORMIN(first + (j), planeH - 1) * planeW)
-    if (isDataInHighBits(c->o.dst_format)) {
+    if (bits == 16) { /* yuv2nv12cX_16_c_template output.c:189-217 */
+        uint16_t *d = (uint16_t *)dest;
+        for (i = 0; i < w; i++) {
+            int u = (1 << 14) - 0x40000000, v = (1 << 14) - 0x40000000;
+            for (j = 0; j < fs; j++) {
+                u += (int)(ROWU(j)[i] * (unsigned)filter[j]);
+                v += (int)(ROWV(j)[i] * (unsigned)filter[j]);
+            }
+            d[2 * i] = (uint16_t)(0x8000 + clip_i16(u >> 15));
+            d[2 * i + 1] = (uint16_t)(0x8000 + clip_i16(v >> 15));
+        }
+    } else if (isDataInHighBits(c->o.dst_format)) {
         uint16_t *d = (uint16_t *)dest;
         int shift = 11 + 16 - bits, oshift = 16 - bits;
         for (i = 0; i < w; i++) {
@@ -1763,6 +1884,10 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
     case UNSC_PLANARCOPY: return unscaled_planarcopy(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_BGR24_YV12: return unscaled_bgr24_yv12(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_GBRP2PACKED: return unscaled_gbrp2packed(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_PLANAR2NV24: return unscaled_planar2nv24(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_NV242PLANAR: return unscaled_nv242planar(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_NV242YUV420: return unscaled_nv242yuv420(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_YVU9_YV12: return unscaled_yvu9_yv12(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     }
     return main_path(c, src, srcStride, dst, dstStride);
 }
@@ -1784,7 +1909,8 @@ int or_sws_path(const OrSws *c) { return c->cascade[0] ? 2 : c->unscaled_kind ? 
 const char *or_sws_path_name(const OrSws *c)
 {
     static const char *n[] = { "main", "yuv2rgb_c", "planarToP01x", "planar8ToP01xle", "planarToNv12", "nv12ToPlanar", "planarCopy",
-                               "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb" };
+                               "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb",
+                               "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12" };
     return c->cascade[0] ? "cascade" : n[c->unscaled_kind];
 }
 const int32_t *or_sws_rgb2yuv_table(const OrSws *c) { return c->rgb2yuv; }

@@ -28,6 +28,13 @@ enum {
     ORF_YUV444P10LE = 68, ORF_GBRP = 71,
     ORF_0RGB = 118, ORF_RGB0 = 119, ORF_0BGR = 120, ORF_BGR0 = 121,
     ORF_P010LE = 158, ORF_GBRPF32LE = 175,
+    /* wider planar / semi-planar YUV family (same readers, writers and wrappers, other depth or subsampling) */
+    ORF_YUV410P = 6, ORF_YUV411P = 7, ORF_YUVJ422P = 13, ORF_YUVJ444P = 14, ORF_YUV440P = 31, ORF_YUVJ440P = 32,
+    ORF_YUV422P16LE = 47, ORF_YUV420P9LE = 60, ORF_YUV422P10LE = 64, ORF_YUV444P9LE = 66, ORF_YUV422P9LE = 70,
+    ORF_NV16 = 101, ORF_YUV420P12LE = 123, ORF_YUV420P14LE = 125, ORF_YUV422P12LE = 127, ORF_YUV422P14LE = 129,
+    ORF_YUV444P12LE = 131, ORF_YUV444P14LE = 133, ORF_YUV440P10LE = 151, ORF_YUV440P12LE = 153,
+    ORF_P016LE = 169, ORF_NV24 = 188, ORF_NV42 = 189, ORF_P210LE = 198, ORF_P410LE = 200, ORF_P216LE = 202,
+    ORF_P416LE = 204, ORF_P012LE = 209, ORF_P212LE = 222, ORF_P412LE = 224,
 };
 
 /* libswscale/swscale.h:131-208 */

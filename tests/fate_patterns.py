@@ -17,7 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 W, H = 352, 288
 SWS_FLAGS = OL.SWS_BICUBIC | OL.SWS_ACCURATE_RND | OL.SWS_BITEXACT   # tests/fate-run.sh:258 + the filter's default scaler
 FMT_OF = {"gray": "gray8", "rgb32": "bgra"}                           # lavu pixfmt aliases on little endian
-BASE_FMT = {"yuv444p": "yuv444p", "rgb24": "rgb24", "yuv444p10": "yuv444p10le", "yuv444p16": "yuv444p16le"}
+BASE_FMT = {"yuv444p": "yuv444p", "rgb24": "rgb24", "yuv444p10": "yuv444p10le", "yuv444p12": "yuv444p12le",
+            "yuv444p16": "yuv444p16le", "nv24": "nv24", "p410": "p410le", "p412": "p412le", "p416": "p416le"}
 GOLDEN = json.load(open(os.path.join(HERE, "golden", "fate_pixfmt_md5.json")))
 
 
@@ -36,14 +37,25 @@ def band_of(y):
     return 0 if 3 * y < H else (1 if 3 * y < 2 * H else 2)
 
 
-def yuvtestsrc(depth):
-    fmt = "yuv444p" if depth == 8 else f"yuv444p{depth}le"
+def yuvtestsrc(depth, semi=False):
+    """yuvtest_fill_picture + yuvtest_put_pixel (vsrc_testsrc.c:1201-1312); semi-planar formats (nv24, p41x) keep the
+    value in the high bits: v << (16 - depth)."""
+    if semi:
+        fmt = "nv24" if depth == 8 else f"p4{depth}le"
+    else:
+        fmt = "yuv444p" if depth == 8 else f"yuv444p{depth}le"
     f = OL.Frame(fmt, W, H)
     ramp = ((1 << depth) * np.arange(W) // W)
     dt = np.uint8 if depth == 8 else np.dtype("<u2")
     planes = [np.full((H, W), 1 << (depth - 1), dt) for _ in range(3)]
     for y in range(H):
         planes[band_of(y)][y, :] = ramp
+    if semi:
+        if depth > 8:
+            planes = [(p.astype(np.uint32) << (16 - depth)).astype(dt) for p in planes]
+        uv = np.empty((H, 2 * W), dt)
+        uv[:, 0::2], uv[:, 1::2] = planes[1], planes[2]
+        planes = [planes[0], uv]
     for a, p in zip(f.planes, planes):
         a[:, :p.shape[1] * p.itemsize] = p.view(np.uint8).reshape(H, -1)
     return f
@@ -62,7 +74,9 @@ def rgbtestsrc():
 def base_picture(base):
     if base == "rgb24":
         return rgbtestsrc()
-    return yuvtestsrc({"yuv444p": 8, "yuv444p10": 10, "yuv444p16": 16}[base])
+    if base in ("nv24", "p410", "p412", "p416"):
+        return yuvtestsrc({"nv24": 8, "p410": 10, "p412": 12, "p416": 16}[base], semi=True)
+    return yuvtestsrc({"yuv444p": 8, "yuv444p10": 10, "yuv444p12": 12, "yuv444p16": 16}[base])
 
 
 def cases():
