@@ -52,6 +52,15 @@ enum AVPixelFormat {
     AV_PIX_FMT_BGR0 = 121,
     AV_PIX_FMT_P010LE = 158,
     AV_PIX_FMT_GBRPF32LE = 175,
+    /* the wider planar / semi-planar YUV family the same readers, writers and wrappers cover */
+    AV_PIX_FMT_YUV410P = 6, AV_PIX_FMT_YUV411P = 7, AV_PIX_FMT_YUVJ422P = 13, AV_PIX_FMT_YUVJ444P = 14,
+    AV_PIX_FMT_YUV440P = 31, AV_PIX_FMT_YUVJ440P = 32, AV_PIX_FMT_YUV422P16LE = 47, AV_PIX_FMT_YUV420P9LE = 60,
+    AV_PIX_FMT_YUV422P10LE = 64, AV_PIX_FMT_YUV444P9LE = 66, AV_PIX_FMT_YUV422P9LE = 70, AV_PIX_FMT_NV16 = 101,
+    AV_PIX_FMT_YUV420P12LE = 123, AV_PIX_FMT_YUV420P14LE = 125, AV_PIX_FMT_YUV422P12LE = 127,
+    AV_PIX_FMT_YUV422P14LE = 129, AV_PIX_FMT_YUV444P12LE = 131, AV_PIX_FMT_YUV444P14LE = 133,
+    AV_PIX_FMT_YUV440P10LE = 151, AV_PIX_FMT_YUV440P12LE = 153, AV_PIX_FMT_P016LE = 169, AV_PIX_FMT_NV24 = 188,
+    AV_PIX_FMT_NV42 = 189, AV_PIX_FMT_P210LE = 198, AV_PIX_FMT_P410LE = 200, AV_PIX_FMT_P216LE = 202,
+    AV_PIX_FMT_P416LE = 204, AV_PIX_FMT_P012LE = 209, AV_PIX_FMT_P212LE = 222, AV_PIX_FMT_P412LE = 224,
     /* NEW: hardware surface format of the HIP hwcontext slot; appended after the
      * reference's last format (AV_PIX_FMT_NB == 268, libavutil/pixfmt.h) */
     AV_PIX_FMT_HIP = 268,

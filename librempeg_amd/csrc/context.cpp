@@ -51,6 +51,9 @@ static void canonicalise_formats(SwsInternal *c) // handle_formats, utils.c:833-
 static int jpeg_alias(int *format) // handle_jpeg, utils.c:773-809
 {
     if (*format == AV_PIX_FMT_YUVJ420P) { *format = AV_PIX_FMT_YUV420P; return 1; }
+    if (*format == AV_PIX_FMT_YUVJ422P) { *format = AV_PIX_FMT_YUV422P; return 1; }
+    if (*format == AV_PIX_FMT_YUVJ444P) { *format = AV_PIX_FMT_YUV444P; return 1; }
+    if (*format == AV_PIX_FMT_YUVJ440P) { *format = AV_PIX_FMT_YUV440P; return 1; }
     if (*format == AV_PIX_FMT_GRAY8) return 1;
     return 0;
 }
@@ -77,34 +80,14 @@ static int scaler_from_enum(SwsScaler s, int fallback) // scaler_flag, utils.c:1
     }
 }
 
+// every descriptor row of pixdesc.cpp has a reader; every row except the planar-RGB ones has a writer
 static bool fmt_supported_in(int f)
 {
-    switch (f) {
-    case AV_PIX_FMT_YUV420P: case AV_PIX_FMT_YUVJ420P: case AV_PIX_FMT_YUV422P: case AV_PIX_FMT_YUV444P:
-    case AV_PIX_FMT_NV12: case AV_PIX_FMT_NV21:
-    case AV_PIX_FMT_YUV420P10LE: case AV_PIX_FMT_YUV444P10LE: case AV_PIX_FMT_YUV420P16LE: case AV_PIX_FMT_YUV444P16LE:
-    case AV_PIX_FMT_P010LE:
-    case AV_PIX_FMT_RGB24: case AV_PIX_FMT_BGR24:
-    case AV_PIX_FMT_RGBA: case AV_PIX_FMT_BGRA: case AV_PIX_FMT_ARGB: case AV_PIX_FMT_ABGR:
-    case AV_PIX_FMT_RGB0: case AV_PIX_FMT_BGR0: case AV_PIX_FMT_0RGB: case AV_PIX_FMT_0BGR:
-    case AV_PIX_FMT_GBRP: case AV_PIX_FMT_GBRPF32LE:
-        return true;
-    }
-    return false;
+    return f != AV_PIX_FMT_GRAY8 && pix_desc(f) != nullptr;
 }
 static bool fmt_supported_out(int f)
 {
-    switch (f) {
-    case AV_PIX_FMT_YUV420P: case AV_PIX_FMT_YUVJ420P: case AV_PIX_FMT_YUV422P: case AV_PIX_FMT_YUV444P:
-    case AV_PIX_FMT_NV12: case AV_PIX_FMT_NV21:
-    case AV_PIX_FMT_YUV420P10LE: case AV_PIX_FMT_YUV444P10LE: case AV_PIX_FMT_YUV420P16LE: case AV_PIX_FMT_YUV444P16LE:
-    case AV_PIX_FMT_P010LE:
-    case AV_PIX_FMT_RGB24: case AV_PIX_FMT_BGR24:
-    case AV_PIX_FMT_RGBA: case AV_PIX_FMT_BGRA: case AV_PIX_FMT_ARGB: case AV_PIX_FMT_ABGR:
-    case AV_PIX_FMT_RGB0: case AV_PIX_FMT_BGR0: case AV_PIX_FMT_0RGB: case AV_PIX_FMT_0BGR:
-        return true;
-    }
-    return false;
+    return f != AV_PIX_FMT_GRAY8 && pix_desc(f) != nullptr && !isPlanarRGB(f);
 }
 
 // ff_get_unscaled_swscale (swscale_unscaled.c:2392-2706): "last match wins"
@@ -115,14 +98,21 @@ void choose_unscaled(SwsInternal *c)
     PlanKind k = PLAN_NONE;
     bool unsupported = false;
     if (s == AV_PIX_FMT_YUV420P && (d == AV_PIX_FMT_NV12 || d == AV_PIX_FMT_NV21)) k = PLAN_UNSC_PLANAR2NV12; // :2405
+    if (s == AV_PIX_FMT_YUV444P && (d == AV_PIX_FMT_NV24 || d == AV_PIX_FMT_NV42)) k = PLAN_UNSC_PLANAR2NV24; // :2410
     if (d == AV_PIX_FMT_YUV420P && (s == AV_PIX_FMT_NV12 || s == AV_PIX_FMT_NV21)) k = PLAN_UNSC_NV122PLANAR; // :2415
+    if (d == AV_PIX_FMT_YUV444P && (s == AV_PIX_FMT_NV24 || s == AV_PIX_FMT_NV42)) k = PLAN_UNSC_NV242PLANAR; // :2420
     if ((s == AV_PIX_FMT_YUV420P || s == AV_PIX_FMT_YUV422P) && isAnyRGB(d) && !(flags & SWS_ACCURATE_RND) &&
         (c->opts.dither == SWS_DITHER_BAYER || c->opts.dither == SWS_DITHER_AUTO) && !(c->opts.dst_h & 1)) { // :2425-2431
         k = PLAN_UNSC_YUV2RGB;
         c->dst_slice_align = 2;
     }
-    if ((s == AV_PIX_FMT_YUV420P10LE || s == AV_PIX_FMT_YUV420P16LE) && d == AV_PIX_FMT_P010LE) k = PLAN_UNSC_P01X;   // :2432-2439
-    if (s == AV_PIX_FMT_YUV420P && d == AV_PIX_FMT_P010LE) k = PLAN_UNSC_8_P01X;                                      // :2440-2444
+    if ((s == AV_PIX_FMT_YUV420P10LE || s == AV_PIX_FMT_YUV420P12LE || s == AV_PIX_FMT_YUV420P14LE || s == AV_PIX_FMT_YUV420P16LE) &&
+        (d == AV_PIX_FMT_P010LE || d == AV_PIX_FMT_P016LE)) k = PLAN_UNSC_P01X;                                       // :2432-2439
+    if (s == AV_PIX_FMT_YUV420P && (d == AV_PIX_FMT_P010LE || d == AV_PIX_FMT_P016LE)) k = PLAN_UNSC_8_P01X;           // :2440-2444
+    if (s == AV_PIX_FMT_YUV410P && !(c->opts.dst_h & 3) && d == AV_PIX_FMT_YUV420P && !(flags & SWS_BITEXACT)) {       // :2446-2451
+        k = PLAN_UNSC_YVU9_YV12;
+        c->dst_slice_align = 4;
+    }
     if (s == AV_PIX_FMT_BGR24 && d == AV_PIX_FMT_YUV420P && !(flags & SWS_ACCURATE_RND) && !(c->opts.dst_w & 1))
         k = PLAN_UNSC_BGR24_YV12;                                                                        // :2452-2456
     // rgbToRgbWrapper (:2459-2463) whenever findRgbConvFn (:1843-1998) has a converter.  All formats here are 8-bit
@@ -141,6 +131,7 @@ void choose_unscaled(SwsInternal *c)
         else { k = PLAN_UNSC_PLANARCOPY; unsupported = false;
                if (c->opts.dither != SWS_DITHER_NONE) c->dst_slice_align = 8 << c->chrDstVSubSample; }
     }
+    if (d == AV_PIX_FMT_YUV420P && (s == AV_PIX_FMT_NV24 || s == AV_PIX_FMT_NV42)) k = PLAN_UNSC_NV242YUV420;         // :2703-2705
     c->plan = unsupported ? PLAN_NONE : k;
     if (unsupported) c->plan = (PlanKind)-1;
 }

@@ -90,29 +90,22 @@ static bool bank_is_identity(const FilterBank &b, int one)
 
 static int src_kind_of(int f)
 {
-    switch (f) {
-    case AV_PIX_FMT_YUV420P: case AV_PIX_FMT_YUV422P: case AV_PIX_FMT_YUV444P: return SRCK_PLANAR8;
-    case AV_PIX_FMT_YUV420P10LE: case AV_PIX_FMT_YUV444P10LE: case AV_PIX_FMT_YUV420P16LE: case AV_PIX_FMT_YUV444P16LE: return SRCK_PLANAR16;
-    case AV_PIX_FMT_NV12: case AV_PIX_FMT_NV21: return SRCK_NV12;
-    case AV_PIX_FMT_P010LE: return SRCK_P010;
-    case AV_PIX_FMT_RGB24: case AV_PIX_FMT_BGR24: return SRCK_RGB24;
-    case AV_PIX_FMT_RGBA: case AV_PIX_FMT_BGRA: case AV_PIX_FMT_ARGB: case AV_PIX_FMT_ABGR: return SRCK_RGB32;
-    case AV_PIX_FMT_GBRP: return SRCK_GBRP;
-    case AV_PIX_FMT_GBRPF32LE: return SRCK_GBRPF32;
-    }
+    const PixDesc *d = pix_desc(f);
+    if (!d) return -1;
+    if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? SRCK_GBRPF32 : SRCK_GBRP;
+    if (isAnyRGB(f)) return d->comp[0].step == 3 ? SRCK_RGB24 : SRCK_RGB32;
+    if (isSemiPlanarYUV(f)) return d->comp[0].depth == 8 ? SRCK_NV12 : SRCK_P010;
+    if (isPlanarYUV(f)) return d->comp[0].depth == 8 ? SRCK_PLANAR8 : SRCK_PLANAR16;
     return -1;
 }
 static int dst_kind_of(int f)
 {
-    switch (f) {
-    case AV_PIX_FMT_YUV420P: case AV_PIX_FMT_YUV422P: case AV_PIX_FMT_YUV444P: return DSTK_PLANAR8;
-    case AV_PIX_FMT_YUV420P10LE: case AV_PIX_FMT_YUV444P10LE: return DSTK_PLANARN;
-    case AV_PIX_FMT_YUV420P16LE: case AV_PIX_FMT_YUV444P16LE: return DSTK_PLANAR16;
-    case AV_PIX_FMT_NV12: case AV_PIX_FMT_NV21: return DSTK_NV12;
-    case AV_PIX_FMT_P010LE: return DSTK_P010;
-    case AV_PIX_FMT_RGB24: case AV_PIX_FMT_BGR24: return DSTK_RGB24;
-    case AV_PIX_FMT_RGBA: case AV_PIX_FMT_BGRA: case AV_PIX_FMT_ARGB: case AV_PIX_FMT_ABGR: return DSTK_RGB32;
-    }
+    const PixDesc *d = pix_desc(f);
+    if (!d || isPlanarRGB(f)) return -1;
+    if (isAnyRGB(f)) return d->comp[0].step == 3 ? DSTK_RGB24 : DSTK_RGB32;
+    const int depth = d->comp[0].depth;
+    if (isSemiPlanarYUV(f)) return depth == 8 ? DSTK_NV12 : depth == 16 ? DSTK_P016 : DSTK_P010;
+    if (isPlanarYUV(f)) return depth == 8 ? DSTK_PLANAR8 : depth == 16 ? DSTK_PLANAR16 : DSTK_PLANARN;
     return -1;
 }
 
@@ -137,6 +130,7 @@ int dev_prepare(SwsInternal *c)
     p.srcKind = src_kind_of(o.src_format); p.dstKind = dst_kind_of(o.dst_format);
     p.srcBpc = c->srcBpc; p.dstBpc = c->dstBpc;
     p.src_depth = ds->comp[0].depth;
+    p.src_shift = ds->comp[0].shift;
     p.wide = c->dstBpc > 14;
     p.hclip = p.wide ? (1 << 19) - 1 : (1 << 15) - 1;
     if (c->srcBpc == 8) p.hshift = p.wide ? 3 : 7;                       // hScale8To15_c / hScale8To19_c
@@ -199,7 +193,7 @@ int dev_prepare(SwsInternal *c)
     p.range_active = c->range.active; p.range_to_jpeg = !o.src_range;
     p.lumCoeff = c->range.lumCoeff; p.chrCoeff = c->range.chrCoeff;
     p.lumOffset = c->range.lumOffset; p.chrOffset = c->range.chrOffset;
-    if (c->plan == PLAN_UNSC_P01X) {                                      // swscale_unscaled.c:285-293
+    if (c->plan == PLAN_UNSC_P01X || c->plan == PLAN_UNSC_8_P01X) {       // swscale_unscaled.c:285-293
         p.shiftY = dd->comp[0].depth + dd->comp[0].shift - ds->comp[0].depth - ds->comp[0].shift;
         p.shiftU = dd->comp[1].depth + dd->comp[1].shift - ds->comp[1].depth - ds->comp[1].shift;
         p.shiftV = dd->comp[2].depth + dd->comp[2].shift - ds->comp[2].depth - ds->comp[2].shift;
@@ -457,6 +451,10 @@ int dev_prepare(SwsInternal *c)
     case PLAN_UNSC_PACKEDCOPY: c->path_name = "unscaled:packedCopy"; c->kernel_name = "sws_k_packed_copy"; break;
     case PLAN_UNSC_BGR24_YV12: c->path_name = "unscaled:bgr24ToYv12"; c->kernel_name = "sws_k_bgr24_to_yv12"; break;
     case PLAN_UNSC_GBRP_PACKED: c->path_name = "unscaled:planarRgbToRgb"; c->kernel_name = "sws_k_gbrp_to_packed"; break;
+    case PLAN_UNSC_PLANAR2NV24: c->path_name = "unscaled:planarToNv24"; c->kernel_name = "sws_k_planar_misc"; break;
+    case PLAN_UNSC_NV242PLANAR: c->path_name = "unscaled:nv24ToPlanar"; c->kernel_name = "sws_k_planar_misc"; break;
+    case PLAN_UNSC_NV242YUV420: c->path_name = "unscaled:nv24ToYuv420"; c->kernel_name = "sws_k_planar_misc"; break;
+    case PLAN_UNSC_YVU9_YV12: c->path_name = "unscaled:yvu9ToYv12"; c->kernel_name = "sws_k_planar_misc"; break;
     case PLAN_CASCADE: c->path_name = "cascade"; c->kernel_name = ""; break;
     case PLAN_MAIN: {
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
@@ -620,11 +618,36 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
     }
     case PLAN_UNSC_PLANAR2NV12:
     case PLAN_UNSC_NV122PLANAR:
+    case PLAN_UNSC_PLANAR2NV24:
+    case PLAN_UNSC_NV242PLANAR:
+    case PLAN_UNSC_NV242YUV420:
+    case PLAN_UNSC_YVU9_YV12:
     case PLAN_UNSC_PLANARCOPY: {
         swsk::MiscPlan plan;
         std::memset(&plan, 0, sizeof(plan));
         int maxw = 0, rows = 0;
-        if (c->plan != PLAN_UNSC_PLANARCOPY) {
+        if (c->plan == PLAN_UNSC_PLANAR2NV24 || c->plan == PLAN_UNSC_NV242PLANAR) {       // 4:4:4: chroma rows == luma rows
+            plan.mode = c->plan == PLAN_UNSC_PLANAR2NV24 ? 0 : 1;
+            plan.nplanes = 2;
+            plan.pl[0] = { 0, 0, p.srcW, sliceH, sliceY, 1, 0, 0 };
+            plan.pl[1] = { 1, 1, c->chrSrcW, sliceH, sliceY, 1, 0, 1 };
+        } else if (c->plan == PLAN_UNSC_NV242YUV420) {                                     // nv24_to_yuv420p_chroma (:229-251)
+            plan.mode = 3;
+            plan.nplanes = 2;
+            plan.aux = sliceH;                                                             // odd last row repeats itself
+            plan.pl[0] = { 0, 0, p.srcW, sliceH, sliceY, 1, 0, 0 };
+            plan.pl[1] = { 1, 1, p.srcW / 2, (sliceH + 1) / 2, sliceY / 2, 1, 0, 1 };
+        } else if (c->plan == PLAN_UNSC_YVU9_YV12) {                                       // planar2x_c per slice (:2079-2093)
+            plan.mode = 4;
+            plan.nplanes = 3;
+            plan.aux = sliceH >> 2;                                                        // source chroma rows of the slice
+            plan.aux2 = c->chrSrcW;
+            // planar2x writes 2*chrSrcW columns, one more than chrDstW when srcW % 4 is 1 or 2; only the visible ones are produced
+            const int cwv = std::min(2 * c->chrSrcW, c->chrDstW);
+            plan.pl[1] = { 1, 1, cwv, 2 * (sliceH >> 2), sliceY >> 1, 1, 0, 1 };
+            plan.pl[0] = { 0, 0, p.srcW, sliceH, sliceY, 1, 0, 0 };
+            plan.pl[2] = { 2, 2, cwv, 2 * (sliceH >> 2), sliceY >> 1, 1, 0, 1 };
+        } else if (c->plan != PLAN_UNSC_PLANARCOPY) {
             plan.mode = c->plan == PLAN_UNSC_PLANAR2NV12 ? 0 : 1;
             plan.nplanes = 2;
             plan.pl[0] = { 0, 0, p.srcW, sliceH, sliceY, 1, 0, 0 };
@@ -744,7 +767,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
             break;
         }
         if (d->march_ok && vec) { // wave-marching fused kernel: one launch for luma, one for chroma
-            const bool semi = p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010;
+            const bool semi = p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010 || p.dstKind == DSTK_P016;
             auto launch = [&](SwsMarchGeom g, int H, int ncomp, int ydim) {
                 const int64_t per_band_row = (int64_t)g.strips * n * ydim;
                 static const int target = std::getenv("SWS_HIP_MARCH_WAVES") ? std::atoi(std::getenv("SWS_HIP_MARCH_WAVES")) : 8192;
@@ -817,7 +840,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
                 const int units = p.full_chr ? p.dstW : (p.dstW + 1) >> 1;
                 const dim3 g(cdiv(units, 256), p.dstH, m);
                 LAUNCH_W(sws_k_vscale_rgb, g);
-            } else if (p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010) {
+            } else if (p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010 || p.dstKind == DSTK_P016) {
                 const dim3 gl(cdiv(p.dstW, 256), p.dstH, m);
                 LAUNCH_W(sws_k_vscale_planar, gl, 1);
                 const dim3 gc(cdiv(p.chrDstW, 256), p.chrDstH, m);

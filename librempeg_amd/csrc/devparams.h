@@ -23,6 +23,7 @@ enum DstKind {
     DSTK_P010,          // yuv2p01xl1_c/lX_c/cX_c output.c:538-589
     DSTK_RGB24,         // yuv2rgb_write 24 bpp (rgb24 / bgr24 by rgb_order)
     DSTK_RGB32,         // yuv2rgb_write 32 bpp (rgba/bgra/argb/abgr by shifts)
+    DSTK_P016,          // 16-bit semi-planar: luma yuv2planeX_16_c, chroma yuv2nv12cX_16_c_template output.c:189-217
 };
 
 struct SwsFramePtrs {       // one frame: plane base pointers (device addresses) and byte strides
@@ -80,6 +81,7 @@ struct SwsDevParams {
     int32_t srcKind, dstKind;
     int32_t srcBpc, dstBpc;
     int32_t src_depth;        // bits per source component
+    int32_t src_shift;        // right shift of p010/p012-style sources (input.c:950-1008)
     int32_t hshift;           // hscale output shift (swscale.c:69-159)
     int32_t hclip;            // (1<<15)-1 or (1<<19)-1
     int32_t wide;             // 1 -> 19-bit int32 intermediates, 0 -> 15-bit int16

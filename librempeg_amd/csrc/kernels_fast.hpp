@@ -328,7 +328,7 @@ __device__ __constant__ const uint8_t k_copy_dithers[8][8][8] = { // swscale_uns
 };
 
 struct MiscPlane { int srcPlane, dstPlane, width /*elements*/, rows, y0, elem /*bytes per element*/, shiftonly, chroma; };
-struct MiscPlan { int mode; int nplanes; int bytecopy; MiscPlane pl[3]; };
+struct MiscPlan { int mode; int nplanes; int bytecopy; int aux, aux2; MiscPlane pl[3]; };
 
 __global__ void __launch_bounds__(256) sws_k_planar_misc(SwsFrameSet fs, SwsDevParams p, MiscPlan plan)
 {
@@ -352,6 +352,38 @@ __global__ void __launch_bounds__(256) sws_k_planar_misc(SwsFrameSet fs, SwsDevP
         const uint8_t *s = f.src[1] + (int64_t)ys * f.srcStride[1] + 2 * x;
         f.dst[a][(int64_t)yd * f.dstStride[a] + x] = s[0];
         f.dst[b][(int64_t)yd * f.dstStride[b] + x] = s[1];
+    } else if (plan.mode == 3) {      // nv24ToYuv420Wrapper: luma copy + truncating 2x2 chroma mean (swscale_unscaled.c:229-271)
+        if (pi == 0) { f.dst[0][(int64_t)yd * f.dstStride[0] + x] = f.src[0][(int64_t)ys * f.srcStride[0] + x]; return; }
+        const int a = p.uv_swap_src ? 2 : 1, b = 3 - a;
+        // chroma source rows are luma rows: r counts chroma rows of the slice, the slice starts at luma row 2*P.y0
+        const int sr = 2 * r, sr2 = (sr + 1 == plan.aux) ? sr : sr + 1;
+        const uint8_t *s1 = f.src[1] + (int64_t)(2 * P.y0 + sr) * f.srcStride[1] + 4 * x;
+        const uint8_t *s2 = f.src[1] + (int64_t)(2 * P.y0 + sr2) * f.srcStride[1] + 4 * x;
+        f.dst[a][(int64_t)yd * f.dstStride[a] + x] = (uint8_t)((s1[0] + s1[2] + s2[0] + s2[2]) >> 2);
+        f.dst[b][(int64_t)yd * f.dstStride[b] + x] = (uint8_t)((s1[1] + s1[3] + s2[1] + s2[3]) >> 2);
+    } else if (plan.mode == 4) {      // yvu9ToYv12Wrapper: luma copy + planar2x_c chroma (rgb2rgb_template.c:531-574), per slice
+        if (pi == 0) { f.dst[0][(int64_t)yd * f.dstStride[0] + x] = f.src[0][(int64_t)ys * f.srcStride[0] + x]; return; }
+        const int W = plan.aux2, H = plan.aux;                 // source chroma size of this slice
+        const int s0row = P.y0 >> 1;                           // first source chroma row of the slice (absolute)
+        const uint8_t *src = f.src[P.srcPlane] + (int64_t)s0row * f.srcStride[P.srcPlane];
+        const int st = f.srcStride[P.srcPlane];
+        const int Y = r, X = x;
+        int v;
+        // column taps: output X=0 and X=2W-1 take one source column; odd X = 2k+1 mixes k (near) and k+1, even X = 2k+2 mixes k+1 (near) and k
+        const int k = (X - 1) >> 1;
+        const bool edgeL = X == 0, edgeR = X == 2 * W - 1;
+        const int cn = edgeL ? 0 : edgeR ? W - 1 : (X & 1) ? k : k + 1;     // "near" column (weight 3 horizontally on border lines)
+        const int cf = edgeL ? 0 : edgeR ? W - 1 : (X & 1) ? k + 1 : k;     // "far" column
+        if (Y == 0 || Y == 2 * H - 1) {                        // first / last line: horizontal taps only
+            const uint8_t *s = src + (int64_t)(Y ? H - 1 : 0) * st;
+            v = (edgeL || edgeR) ? s[cn] : (3 * s[cn] + s[cf]) >> 2;
+        } else {                                               // lines 2y-1 (3A+B) and 2y (A+3B): A = row y-1, B = row y, diagonal taps
+            const int y = (Y + 1) >> 1;
+            const uint8_t *A = src + (int64_t)(y - 1) * st, *B = A + st;
+            if (Y & 1) v = (3 * A[cn] + B[cf]) >> 2;           // dst[2x+1] = 3A[x]+B[x+1]; dst[2x+2] = 3A[x+1]+B[x]
+            else       v = (A[cf] + 3 * B[cn]) >> 2;           // dst[2x+2] = A[x]+3B[x+1]; dst[2x+1] = A[x+1]+3B[x]
+        }
+        f.dst[P.dstPlane][(int64_t)yd * f.dstStride[P.dstPlane] + x] = (uint8_t)v;
     } else {                          // planarCopyWrapper
         const uint8_t *srow = f.src[P.srcPlane] + (int64_t)ys * f.srcStride[P.srcPlane];
         uint8_t *drow = f.dst[P.dstPlane] + (int64_t)yd * f.dstStride[P.dstPlane];

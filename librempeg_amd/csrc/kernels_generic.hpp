@@ -28,8 +28,8 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         if (comp == 0) return f.src[0][(int64_t)row * f.srcStride[0] + x];
         return f.src[1][(int64_t)row * f.srcStride[1] + 2 * x + ((comp == 1) ^ p.uv_swap_src ? 0 : 1)];
     case SRCK_P010: // p010LEToY_c / p010LEToUV_c, input.c:950-1008
-        if (comp == 0) return *(const uint16_t *)(f.src[0] + (int64_t)row * f.srcStride[0] + 2 * x) >> 6;
-        return *(const uint16_t *)(f.src[1] + (int64_t)row * f.srcStride[1] + 4 * x + (comp == 1 ? 0 : 2)) >> 6;
+        if (comp == 0) return *(const uint16_t *)(f.src[0] + (int64_t)row * f.srcStride[0] + 2 * x) >> p.src_shift;
+        return *(const uint16_t *)(f.src[1] + (int64_t)row * f.srcStride[1] + 4 * x + (comp == 1 ? 0 : 2)) >> p.src_shift;
     case SRCK_RGB24: { // rgb24ToY_c, rgb24ToUV_c, rgb24ToUV_half_c (and bgr24*), input.c:1068-1172
         const int srow = comp == 0 ? row : (row << p.chrSrcVSub);
         const uint8_t *s = f.src[0] + (int64_t)srow * f.srcStride[0];
@@ -190,7 +190,7 @@ __device__ __forceinline__ void planar_write_one(const SwsDevParams &p, const S 
             for (int j = 0; j < fs; j++) val += smp.get(comp, min(first + j, srcRows - 1), x) * vf[j];
             d[x] = (uint16_t)(clip_uintp2(val >> shift, bits) << p.dst_shift);
         }
-    } else if (p.dstKind == DSTK_PLANAR16) {
+    } else if (p.dstKind == DSTK_PLANAR16 || p.dstKind == DSTK_P016) {
         uint16_t *d = (uint16_t *)drow;
         if (fs == 1) {
             d[x] = (uint16_t)clip_u16((smp.get(comp, min(first, srcRows - 1), x) + 4) >> 3);
@@ -231,7 +231,17 @@ __device__ __forceinline__ void nv_chroma_write_one(const SwsDevParams &p, const
     const int16_t *vf = p.vChrF + cy * fs;
     const int first = max(1 - fs, p.vChrPos[cy]);
     uint8_t *drow = f.dst[1] + (int64_t)cy * f.dstStride[1];
-    if (p.dstKind == DSTK_P010) {
+    if (p.dstKind == DSTK_P016) {   // yuv2nv12cX_16_c_template, output.c:189-217
+        int u = (1 << 14) - 0x40000000, v = (1 << 14) - 0x40000000;
+        for (int j = 0; j < fs; j++) {
+            const int r = min(first + j, p.chrSrcH - 1);
+            u += (int)((unsigned)smp.get(1, r, x) * (unsigned)(int)vf[j]);
+            v += (int)((unsigned)smp.get(2, r, x) * (unsigned)(int)vf[j]);
+        }
+        uint16_t *d = (uint16_t *)drow;
+        d[2 * x] = (uint16_t)(0x8000 + clip_i16(u >> 15));
+        d[2 * x + 1] = (uint16_t)(0x8000 + clip_i16(v >> 15));
+    } else if (p.dstKind == DSTK_P010) {
         const int bits = p.dst_bits, shift = 11 + 16 - bits;
         int u = 1 << (shift - 1), v = 1 << (shift - 1);
         for (int j = 0; j < fs; j++) {

@@ -18,6 +18,23 @@ static const PixDesc g_descs[] = {
     { AV_PIX_FMT_YUV420P16LE, "yuv420p16le", 3, 1, 1, {{0,2,0,0,16},{1,2,0,0,16},{2,2,0,0,16},{0,0,0,0,0}}, PIXFLAG_PLANAR },
     { AV_PIX_FMT_YUV444P16LE, "yuv444p16le", 3, 0, 0, {{0,2,0,0,16},{1,2,0,0,16},{2,2,0,0,16},{0,0,0,0,0}}, PIXFLAG_PLANAR },
     { AV_PIX_FMT_P010LE,   "p010le",   3, 1, 1, {{0,2,0,6,10},{1,4,0,6,10},{1,4,2,6,10},{0,0,0,0,0}}, PIXFLAG_PLANAR },
+#define PL8(F, N, LW, LH)     { F, N, 3, LW, LH, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8},{0,0,0,0,0}}, PIXFLAG_PLANAR }
+#define PLN(F, N, LW, LH, D)  { F, N, 3, LW, LH, {{0,2,0,0,D},{1,2,0,0,D},{2,2,0,0,D},{0,0,0,0,0}}, PIXFLAG_PLANAR }
+#define SP8(F, N, LW, LH, UO) { F, N, 3, LW, LH, {{0,1,0,0,8},{1,2,UO,0,8},{1,2,1-(UO),0,8},{0,0,0,0,0}}, PIXFLAG_PLANAR }
+#define SPN(F, N, LW, LH, D)  { F, N, 3, LW, LH, {{0,2,0,16-(D),D},{1,4,0,16-(D),D},{1,4,2,16-(D),D},{0,0,0,0,0}}, PIXFLAG_PLANAR }
+    PL8(AV_PIX_FMT_YUV410P, "yuv410p", 2, 2), PL8(AV_PIX_FMT_YUV411P, "yuv411p", 2, 0), PL8(AV_PIX_FMT_YUV440P, "yuv440p", 0, 1),
+    PL8(AV_PIX_FMT_YUVJ422P, "yuvj422p", 1, 0), PL8(AV_PIX_FMT_YUVJ444P, "yuvj444p", 0, 0), PL8(AV_PIX_FMT_YUVJ440P, "yuvj440p", 0, 1),
+    PLN(AV_PIX_FMT_YUV420P9LE, "yuv420p9le", 1, 1, 9), PLN(AV_PIX_FMT_YUV422P9LE, "yuv422p9le", 1, 0, 9),
+    PLN(AV_PIX_FMT_YUV444P9LE, "yuv444p9le", 0, 0, 9),
+    PLN(AV_PIX_FMT_YUV422P10LE, "yuv422p10le", 1, 0, 10), PLN(AV_PIX_FMT_YUV440P10LE, "yuv440p10le", 0, 1, 10),
+    PLN(AV_PIX_FMT_YUV420P12LE, "yuv420p12le", 1, 1, 12), PLN(AV_PIX_FMT_YUV422P12LE, "yuv422p12le", 1, 0, 12),
+    PLN(AV_PIX_FMT_YUV444P12LE, "yuv444p12le", 0, 0, 12), PLN(AV_PIX_FMT_YUV440P12LE, "yuv440p12le", 0, 1, 12),
+    PLN(AV_PIX_FMT_YUV420P14LE, "yuv420p14le", 1, 1, 14), PLN(AV_PIX_FMT_YUV422P14LE, "yuv422p14le", 1, 0, 14),
+    PLN(AV_PIX_FMT_YUV444P14LE, "yuv444p14le", 0, 0, 14), PLN(AV_PIX_FMT_YUV422P16LE, "yuv422p16le", 1, 0, 16),
+    SP8(AV_PIX_FMT_NV16, "nv16", 1, 0, 0), SP8(AV_PIX_FMT_NV24, "nv24", 0, 0, 0), SP8(AV_PIX_FMT_NV42, "nv42", 0, 0, 1),
+    SPN(AV_PIX_FMT_P210LE, "p210le", 1, 0, 10), SPN(AV_PIX_FMT_P410LE, "p410le", 0, 0, 10),
+    SPN(AV_PIX_FMT_P012LE, "p012le", 1, 1, 12), SPN(AV_PIX_FMT_P212LE, "p212le", 1, 0, 12), SPN(AV_PIX_FMT_P412LE, "p412le", 0, 0, 12),
+    SPN(AV_PIX_FMT_P016LE, "p016le", 1, 1, 16), SPN(AV_PIX_FMT_P216LE, "p216le", 1, 0, 16), SPN(AV_PIX_FMT_P416LE, "p416le", 0, 0, 16),
     { AV_PIX_FMT_RGB24,    "rgb24",    3, 0, 0, {{0,3,0,0,8},{0,3,1,0,8},{0,3,2,0,8},{0,0,0,0,0}}, PIXFLAG_RGB },
     { AV_PIX_FMT_BGR24,    "bgr24",    3, 0, 0, {{0,3,2,0,8},{0,3,1,0,8},{0,3,0,0,8},{0,0,0,0,0}}, PIXFLAG_RGB },
     { AV_PIX_FMT_ARGB,     "argb",     4, 0, 0, {{0,4,1,0,8},{0,4,2,0,8},{0,4,3,0,8},{0,4,0,0,8}}, PIXFLAG_RGB | PIXFLAG_ALPHA },

@@ -65,6 +65,10 @@ enum PlanKind {
     PLAN_UNSC_PACKEDCOPY,  // packedCopyWrapper
     PLAN_UNSC_BGR24_YV12,  // bgr24ToYv12Wrapper -> ff_rgb24toyv12_c
     PLAN_UNSC_GBRP_PACKED, // planarRgbToRgbWrapper (gbrp -> 24/32 bpp packed)
+    PLAN_UNSC_PLANAR2NV24, // planarToNv24Wrapper
+    PLAN_UNSC_NV242PLANAR, // nv24ToPlanarWrapper
+    PLAN_UNSC_NV242YUV420, // nv24ToYuv420Wrapper
+    PLAN_UNSC_YVU9_YV12,   // yvu9ToYv12Wrapper -> planar2x_c
     PLAN_MAIN,             // ff_swscale chain
     PLAN_CASCADE,          // two contexts through an intermediate image
 };

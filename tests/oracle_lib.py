@@ -1,6 +1,7 @@
 """ctypes binding of the CPU oracle (oracle/libsws_oracle.so) -- test infrastructure only."""
 import ctypes as C
 import os
+import re
 import subprocess
 import numpy as np
 
@@ -107,11 +108,14 @@ def fill_random(frame, seed):
     f = frame.fmt
     for pi, (a, rb) in enumerate(zip(frame.planes, frame.row_bytes)):
         rows = a.shape[0]
-        if f in ("yuv420p10le", "yuv444p10le"):
-            v = rng.integers(0, 1024, size=(rows, rb // 2), dtype=np.uint16)
+        m = re.match(r"yuv4\d\dp(9|10|12|14)le$", f)
+        mp = re.match(r"p[024](10|12)le$", f)
+        if m:      # N-bit samples in the low bits of 16-bit words
+            v = rng.integers(0, 1 << int(m.group(1)), size=(rows, rb // 2), dtype=np.uint16)
             a[:, :rb] = v.view(np.uint8).reshape(rows, rb)
-        elif f == "p010le":
-            v = (rng.integers(0, 1024, size=(rows, rb // 2), dtype=np.uint16) << 6).astype(np.uint16)
+        elif mp:   # N-bit samples in the high bits (p010 / p012 families)
+            d = int(mp.group(1))
+            v = (rng.integers(0, 1 << d, size=(rows, rb // 2), dtype=np.uint16) << (16 - d)).astype(np.uint16)
             a[:, :rb] = v.view(np.uint8).reshape(rows, rb)
         elif f == "gbrpf32le":
             v = rng.random(size=(rows, rb // 4), dtype=np.float32)

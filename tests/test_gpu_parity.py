@@ -78,10 +78,14 @@ def test_c5_float_rgb_to_yuv444p16_bt2020_full():
              colorspace=(SWS_CS_BT2020, 1, SWS_CS_BT2020, 1))
 
 
-FORMAT_MATRIX_SRC = ["yuv420p", "yuv422p", "yuv444p", "nv12", "nv21", "yuv420p10le", "yuv444p16le", "p010le",
-                     "rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "gbrp", "gbrpf32le"]
-FORMAT_MATRIX_DST = ["yuv420p", "yuv444p", "nv12", "nv21", "yuv420p10le", "yuv444p16le", "p010le",
-                     "rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"]
+YUV_FAMILY = ["yuv420p", "yuv422p", "yuv444p", "yuv410p", "yuv411p", "yuv440p", "yuvj420p", "yuvj422p", "yuvj444p", "yuvj440p",
+              "nv12", "nv21", "nv16", "nv24", "nv42",
+              "yuv420p9le", "yuv422p9le", "yuv444p9le", "yuv420p10le", "yuv422p10le", "yuv444p10le", "yuv440p10le",
+              "yuv420p12le", "yuv422p12le", "yuv444p12le", "yuv440p12le", "yuv420p14le", "yuv422p14le", "yuv444p14le",
+              "yuv420p16le", "yuv422p16le", "yuv444p16le",
+              "p010le", "p210le", "p410le", "p012le", "p212le", "p412le", "p016le", "p216le", "p416le"]
+FORMAT_MATRIX_SRC = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "gbrp", "gbrpf32le"]
+FORMAT_MATRIX_DST = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"]
 
 
 @pytest.mark.parametrize("sfmt", FORMAT_MATRIX_SRC)
@@ -106,6 +110,18 @@ def test_format_matrix_same_size(sfmt, dfmt):
     except RuntimeError:
         pytest.skip("HIP path reports this unscaled converter as not implemented (sws_getContext -> NULL)")
     run_case(96, 64, sfmt, 96, 64, dfmt, SWS_BICUBIC | BX, seed=5)
+
+
+@pytest.mark.parametrize("w,h", [(96, 64), (8, 4), (6, 8), (13, 12), (130, 20)])
+def test_yvu9_to_yv12_and_nv24_wrappers(w, h):
+    """yvu9ToYv12Wrapper/planar2x_c (non-bitexact, dstH % 4 == 0), planarToNv24 / nv24ToPlanar / nv24ToYuv420 wrappers."""
+    path, opath = run_case(w, h, "yuv410p", w, h, "yuv420p", SWS_BICUBIC, seed=w)
+    assert (path, opath) == ("unscaled:yvu9ToYv12", "yvu9ToYv12")
+    for nv in ("nv24", "nv42"):
+        assert run_case(w, h, "yuv444p", w, h, nv, SWS_BICUBIC | BX, seed=w) == ("unscaled:planarToNv24", "planarToNv24")
+        assert run_case(w, h, nv, w, h, "yuv444p", SWS_BICUBIC | BX, seed=w) == ("unscaled:nv24ToPlanar", "nv24ToPlanar")
+        assert run_case(w, h, nv, w, h, "yuv420p", SWS_BICUBIC | BX, seed=w) == ("unscaled:nv24ToYuv420", "nv24ToYuv420")
+    assert run_case(w, h + 1, "nv24", w, h + 1, "yuv420p", SWS_BICUBIC | BX, seed=w)[1] == "nv24ToYuv420"
 
 
 @pytest.mark.parametrize("flags", [SWS_POINT, SWS_AREA, SWS_BILINEAR, SWS_BICUBIC, SWS_GAUSS, SWS_LANCZOS, SWS_SPLINE],
