@@ -45,6 +45,8 @@ _FORMATS = {
     "argb": (25, "packed", 0, 0, 4), "rgba": (26, "packed", 0, 0, 4), "abgr": (27, "packed", 0, 0, 4), "bgra": (28, "packed", 0, 0, 4),
     "0rgb": (118, "packed", 0, 0, 4), "rgb0": (119, "packed", 0, 0, 4), "0bgr": (120, "packed", 0, 0, 4), "bgr0": (121, "packed", 0, 0, 4),
     "gbrp": (71, "rgbp", 0, 0, 1), "gbrpf32le": (175, "rgbp", 0, 0, 4),
+    "gbrp9le": (73, "rgbp", 0, 0, 2), "gbrp10le": (75, "rgbp", 0, 0, 2), "gbrp12le": (135, "rgbp", 0, 0, 2),
+    "gbrp14le": (137, "rgbp", 0, 0, 2), "gbrp16le": (77, "rgbp", 0, 0, 2),
     "gray8": (8, "gray", 0, 0, 1),
 }
 

@@ -98,6 +98,9 @@ static const Desc descs[] = {
     { ORF_0BGR,    "0bgr",    3, 0, 0, {{0,4,3,0,8},{0,4,2,0,8},{0,4,1,0,8}}, PF_RGB },
     { ORF_BGR0,    "bgr0",    3, 0, 0, {{0,4,2,0,8},{0,4,1,0,8},{0,4,0,0,8}}, PF_RGB },
     { ORF_GBRP,    "gbrp",    3, 0, 0, {{2,1,0,0,8},{0,1,0,0,8},{1,1,0,0,8}}, PF_PLANAR | PF_RGB },
+#define GBRN(F, N, D) { F, N, 3, 0, 0, {{2,2,0,0,D},{0,2,0,0,D},{1,2,0,0,D}}, PF_PLANAR | PF_RGB }
+    GBRN(ORF_GBRP9LE, "gbrp9le", 9), GBRN(ORF_GBRP10LE, "gbrp10le", 10), GBRN(ORF_GBRP12LE, "gbrp12le", 12),
+    GBRN(ORF_GBRP14LE, "gbrp14le", 14), GBRN(ORF_GBRP16LE, "gbrp16le", 16),
     { ORF_GBRPF32LE, "gbrpf32le", 3, 0, 0, {{2,4,0,0,32},{0,4,0,0,32},{1,4,0,0,32}}, PF_PLANAR | PF_RGB | PF_FLOAT },
 };
 
@@ -155,7 +158,7 @@ enum { RY, GY, BY, RU, GU, BU, RV, GV, BV };
 
 enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
        UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED,
-       UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12 };
+       UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP };
 
 struct OrSws {
     OrSwsOpts o;
@@ -734,10 +737,9 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
     if ((s == ORF_YUV420P || s == ORF_YUV422P) && isAnyRGB(d) && !(flags & OR_SWS_ACCURATE_RND) &&
         (c->o.dither == 2 || c->o.dither == 1) && !(c->o.dst_h & 1)) { /* :2425-2431 */
         /* ff_yuv2rgb_get_func_ptr, yuv2rgb.c:561-678: 24/32 bpp C converters */
-        if (d == ORF_RGB24 || d == ORF_BGR24 || d == ORF_RGBA || d == ORF_BGRA || d == ORF_ARGB || d == ORF_ABGR)
+        /* yuv2rgb_c_24_rgb/_bgr, yuv2rgb_c_32, yuv420p_gbrp_c / yuv422p_gbrp_c; NULL (-> scaler chain) for gbrp9..16/f32 */
+        if (d == ORF_RGB24 || d == ORF_BGR24 || d == ORF_RGBA || d == ORF_BGRA || d == ORF_ARGB || d == ORF_ABGR || d == ORF_GBRP)
             c->unscaled_kind = UNSC_YUV2RGB;
-        else
-            c->unscaled_kind = UNSC_NONE; /* gbrp etc. not restated: main path would NOT be taken by the reference */
     }
     if (s == ORF_YUV444P && (d == ORF_NV24 || d == ORF_NV42)) c->unscaled_kind = UNSC_PLANAR2NV24;   /* :2410-2413 */
     if (d == ORF_YUV444P && (s == ORF_NV24 || s == ORF_NV42)) c->unscaled_kind = UNSC_NV242PLANAR;   /* :2420-2423 */
@@ -757,6 +759,8 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         if (!(!s32 && (d == ORF_BGRA || d == ORF_RGBA) && (flags & OR_SWS_BITEXACT)))
             c->unscaled_kind = UNSC_RGB2RGB;
     }
+    /* rgbToPlanarRgbWrapper (:2542-2544): 8-bit packed RGB -> gbrp */
+    if (isAnyRGB(s) && isPacked(s) && desc_get(s)->c[0].depth == 8 && d == ORF_GBRP) c->unscaled_kind = UNSC_PACKED2GBRP;
     /* planarRgbToRgbWrapper (:2480-2481): gbrp -> byte RGB */
     if (s == ORF_GBRP && isAnyRGB(d) && isPacked(d) && desc_get(d)->c[0].depth == 8) c->unscaled_kind = UNSC_GBRP2PACKED;
     /* simple copy (:2647-2668) */
@@ -822,7 +826,7 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
     if (flags & 0x30000) return -1; /* vChrDrop not restated */
 
     if (isAnyRGB(srcFormat) && !(srcW & 1) && !(flags & OR_SWS_FULL_CHR_H_INP) &&
-        srcFormat != ORF_GBRPF32LE &&
+        !(isPlanarRGB(srcFormat) && ds->c[0].depth > 8) && /* gbrp9..16, gbrpf32: no _half readers (:1369-1388) */
         ((dstW >> c->chrDstHSub) <= (srcW >> 1) || (flags & OR_SWS_FAST_BILINEAR))) /* :1369-1390 */
         c->chrSrcHSub = 1;
 
@@ -969,7 +973,11 @@ static int unscaled_yuv2rgb(OrSws *c, const uint8_t *const src[], const int srcS
                 int b = c->table_bU[U + HEADROOM];
                 for (int k = 0; k < 2; k++) {
                     int Y = py[2 * i + k];
-                    if (d == ORF_RGB24 || d == ORF_BGR24) {
+                    if (d == ORF_GBRP) { /* PUTGBRP yuv2rgb.c:127-135 */
+                        dst[0][(ptrdiff_t)(yy + srcSliceY) * dstStride[0] + 2 * i + k] = (uint8_t)lut_at(c, g + Y);
+                        dst[1][(ptrdiff_t)(yy + srcSliceY) * dstStride[1] + 2 * i + k] = (uint8_t)lut_at(c, b + Y);
+                        dst[2][(ptrdiff_t)(yy + srcSliceY) * dstStride[2] + 2 * i + k] = (uint8_t)lut_at(c, r + Y);
+                    } else if (d == ORF_RGB24 || d == ORF_BGR24) {
                         uint8_t R = (uint8_t)lut_at(c, r + Y), G = (uint8_t)lut_at(c, g + Y), B = (uint8_t)lut_at(c, b + Y);
                         uint8_t *p = out + 6 * i + 3 * k;
                         if (d == ORF_RGB24) { p[0] = R; p[1] = G; p[2] = B; }
@@ -1211,6 +1219,21 @@ static int unscaled_gbrp2packed(OrSws *c, const uint8_t *const src[], const int 
     return srcSliceH;
 }
 
+/* rgbToPlanarRgbWrapper (swscale_unscaled.c:1436-1490) with packedtogbr24p (:1404-1434): de-interleave, alpha dropped */
+static int unscaled_packed2gbrp(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                                int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    const Desc *ds = desc_get(c->o.src_format), *dd = desc_get(c->o.dst_format);
+    (void)srcSliceY;
+    for (int y = 0; y < srcSliceH; y++) {
+        const uint8_t *s = src[0] + (ptrdiff_t)y * srcStride[0];
+        for (int x = 0; x < c->o.src_w; x++, s += ds->c[0].step)
+            for (int k = 0; k < 3; k++)
+                dst[dd->c[k].plane][(ptrdiff_t)y * dstStride[dd->c[k].plane] + x] = s[ds->c[k].offset];
+    }
+    return srcSliceH;
+}
+
 /* packedCopyWrapper (swscale_unscaled.c:2138-2157); only the visible bytes of each row are restated.
  * rgb0-style sources going to a real-alpha destination were made opaque by the caller (swscale.c:1106-1124). */
 static int unscaled_packedcopy(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
@@ -1369,6 +1392,15 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
         for (i = 0; i < w; i++)
             d[i] = (uint16_t)((int)((unsigned)t[RY] * R[i] + (unsigned)t[GY] * G[i] + (unsigned)t[BY] * B[i] + (0x801 << (15 - 7))) >> (15 - 6));
         return tmp; }
+    case ORF_GBRP9LE: case ORF_GBRP10LE: case ORF_GBRP12LE: case ORF_GBRP14LE: case ORF_GBRP16LE: { /* planar_rgb16_s16_to_y input.c:1216-1232 */
+        const uint16_t *G = (const uint16_t *)(src[0] + y * stride[0]), *B = (const uint16_t *)(src[1] + y * stride[1]),
+                       *R = (const uint16_t *)(src[2] + y * stride[2]);
+        const int bpc = desc_get(f)->c[0].depth, shift = bpc < 16 ? bpc : 14;
+        uint16_t *d = (uint16_t *)tmp;
+        for (i = 0; i < w; i++)
+            d[i] = (uint16_t)((int)((unsigned)t[RY] * R[i] + (unsigned)t[GY] * G[i] + (unsigned)t[BY] * B[i] +
+                                    (16u << (15 + bpc - 8)) + (1u << (15 + shift - 15))) >> (15 + shift - 14));
+        return tmp; }
     case ORF_GBRPF32LE: { /* planar_rgbf32_to_y input.c:1319-1334 */
         const float *G = (const float *)(src[0] + y * stride[0]), *B = (const float *)(src[1] + y * stride[1]),
                     *R = (const float *)(src[2] + y * stride[2]);
@@ -1468,6 +1500,18 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
                 du[i] = (uint16_t)((int)((unsigned)t[RU] * r + (unsigned)t[GU] * g + (unsigned)t[BU] * b + (0x4001 << (15 - 7))) >> (15 - 6));
                 dv[i] = (uint16_t)((int)((unsigned)t[RV] * r + (unsigned)t[GV] * g + (unsigned)t[BV] * b + (0x4001 << (15 - 7))) >> (15 - 6));
             }
+        }
+        return; }
+    case ORF_GBRP9LE: case ORF_GBRP10LE: case ORF_GBRP12LE: case ORF_GBRP14LE: case ORF_GBRP16LE: { /* planar_rgb16_s16_to_uv input.c:1248-1270 */
+        const uint16_t *G = (const uint16_t *)(src[0] + y * stride[0]), *B = (const uint16_t *)(src[1] + y * stride[1]),
+                       *R = (const uint16_t *)(src[2] + y * stride[2]);
+        const int bpc = desc_get(f)->c[0].depth, shift = bpc < 16 ? bpc : 14;
+        uint16_t *du = (uint16_t *)tu, *dv = (uint16_t *)tv;
+        for (i = 0; i < w; i++) {
+            du[i] = (uint16_t)((int)((unsigned)t[RU] * R[i] + (unsigned)t[GU] * G[i] + (unsigned)t[BU] * B[i] +
+                                     (128u << (15 + bpc - 8)) + (1u << (15 + shift - 15))) >> (15 + shift - 14));
+            dv[i] = (uint16_t)((int)((unsigned)t[RV] * R[i] + (unsigned)t[GV] * G[i] + (unsigned)t[BV] * B[i] +
+                                     (128u << (15 + bpc - 8)) + (1u << (15 + shift - 15))) >> (15 + shift - 14));
         }
         return; }
     case ORF_GBRPF32LE: { /* planar_rgbf32_to_uv input.c:1300-1317 */
@@ -1795,6 +1839,73 @@ static void write_packed_rgb_line(const OrSws *c, const Planes *P, uint8_t *dest
 #undef CV
 }
 
+/* any_vscale (vscale.c:173-212) + yuv2gbrp_full_X_c / yuv2gbrp16_full_X_c / yuv2gbrpf32_full_X_c (output.c:2342-2580):
+ * planar RGB destinations always use the X form.  dst planes are G, B, R. */
+static void write_planar_rgb_line(const OrSws *c, const Planes *P, uint8_t *const dst[], const int dstStride[], int y)
+{
+    const int dstW = c->o.dst_w, lw = dstW, cw = c->chrDstW;
+    const int srcH = c->o.src_h, chrSrcH = c->chrSrcH;
+    const int chrY = y >> c->chrDstVSub;
+    const int lfs = c->vLumFilterSize, cfs = c->vChrFilterSize;
+    const int16_t *lf = c->vLumFilter + y * lfs, *cf = c->vChrFilter + chrY * cfs;
+    const int firstLum = ORMAX(1 - lfs, c->vLumFilterPos[y]);
+    const int firstChr = ORMAX(1 - cfs, c->vChrFilterPos[chrY]);
+    const Desc *dd = desc_get(c->o.dst_format);
+    const int depth = dd->c[0].depth, isf = !!(dd->flags & PF_FLOAT);
+    uint8_t *dg = dst[0] + (size_t)y * dstStride[0], *db = dst[1] + (size_t)y * dstStride[1], *dr = dst[2] + (size_t)y * dstStride[2];
+    int i, j;
+#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+#define CU(j) (P->chrU + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+#define CV(j) (P->chrV + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+    for (i = 0; i < dstW; i++) {
+        int Y, U, V, R, G, B;
+        if (depth <= 14) { /* yuv2gbrp_full_X_c :2342-2421, 15-bit intermediates */
+            const int SH = 22 + 8 - depth;
+            Y = 1 << 9; U = (1 << 9) - (128 << 19); V = (1 << 9) - (128 << 19);
+            for (j = 0; j < lfs; j++) Y += (int)(L(j)[i] * (unsigned)lf[j]);
+            for (j = 0; j < cfs; j++) { U += (int)(CU(j)[i] * (unsigned)cf[j]); V += (int)(CV(j)[i] * (unsigned)cf[j]); }
+            Y >>= 10; U >>= 10; V >>= 10;
+            Y -= c->yuv2rgb_y_offset;
+            Y = (int)((unsigned)Y * (unsigned)c->yuv2rgb_y_coeff);
+            Y = (int)((unsigned)Y + (1u << (SH - 1)));
+            R = (int)((unsigned)Y + (unsigned)V * (unsigned)c->yuv2rgb_v2r);
+            G = (int)((unsigned)Y + (unsigned)V * (unsigned)c->yuv2rgb_v2g + (unsigned)U * (unsigned)c->yuv2rgb_u2g);
+            B = (int)((unsigned)Y + (unsigned)U * (unsigned)c->yuv2rgb_u2b);
+            if ((R | G | B) & 0xC0000000) { R = clip_uintp2(R, 30); G = clip_uintp2(G, 30); B = clip_uintp2(B, 30); }
+            if (SH != 22) {
+                ((uint16_t *)dg)[i] = (uint16_t)(G >> SH); ((uint16_t *)db)[i] = (uint16_t)(B >> SH); ((uint16_t *)dr)[i] = (uint16_t)(R >> SH);
+            } else {
+                dg[i] = (uint8_t)(G >> 22); db[i] = (uint8_t)(B >> 22); dr[i] = (uint8_t)(R >> 22);
+            }
+        } else { /* yuv2gbrp16_full_X_c :2467-2530 / yuv2gbrpf32_full_X_c :2533-2605, 19-bit intermediates */
+            Y = -0x40000000; U = -(128 << 23); V = -(128 << 23);
+            for (j = 0; j < lfs; j++) Y += (int)(L(j)[i] * (unsigned)lf[j]);
+            for (j = 0; j < cfs; j++) { U += (int)(CU(j)[i] * (unsigned)cf[j]); V += (int)(CV(j)[i] * (unsigned)cf[j]); }
+            Y >>= 14; Y += 0x10000; U >>= 14; V >>= 14;
+            Y -= c->yuv2rgb_y_offset;
+            Y = (int)((unsigned)Y * (unsigned)c->yuv2rgb_y_coeff);
+            Y = (int)((unsigned)Y + (unsigned)((1 << 13) - (1 << 29)));
+            R = (int)((unsigned)V * (unsigned)c->yuv2rgb_v2r);
+            G = (int)((unsigned)V * (unsigned)c->yuv2rgb_v2g + (unsigned)U * (unsigned)c->yuv2rgb_u2g);
+            B = (int)((unsigned)U * (unsigned)c->yuv2rgb_u2b);
+            if (!isf) { /* 64-bit sums */
+                ((uint16_t *)dr)[i] = (uint16_t)clip_uintp2((int)(((int64_t)Y + R) >> 14) + (1 << 15), 16);
+                ((uint16_t *)dg)[i] = (uint16_t)clip_uintp2((int)(((int64_t)Y + G) >> 14) + (1 << 15), 16);
+                ((uint16_t *)db)[i] = (uint16_t)clip_uintp2((int)(((int64_t)Y + B) >> 14) + (1 << 15), 16);
+            } else {   /* 32-bit sums (the float writer adds in int), then float_mult * (float)v */
+                static const float float_mult = 1.0f / 65535.0f;
+                R = clip_uintp2(((int)((unsigned)Y + (unsigned)R) >> 14) + (1 << 15), 16);
+                G = clip_uintp2(((int)((unsigned)Y + (unsigned)G) >> 14) + (1 << 15), 16);
+                B = clip_uintp2(((int)((unsigned)Y + (unsigned)B) >> 14) + (1 << 15), 16);
+                ((float *)dg)[i] = float_mult * (float)G; ((float *)db)[i] = float_mult * (float)B; ((float *)dr)[i] = float_mult * (float)R;
+            }
+        }
+    }
+#undef L
+#undef CU
+#undef CV
+}
+
 /* ff_swscale (swscale.c:263-567) for a whole frame */
 static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[],
                      uint8_t *const dst[], const int dstStride[])
@@ -1850,8 +1961,7 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
         } else if (isAnyRGB(df) && !isPlanarRGB(df)) {
             write_packed_rgb_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
         } else {
-            free(P.lum); free(P.chrU); free(P.chrV); free(t0); free(t1);
-            return -1; /* planar RGB writers (yuv2gbrp*_full_X_c): not restated yet */
+            write_planar_rgb_line(c, &P, dst, dstStride, y);
         }
     }
     free(P.lum); free(P.chrU); free(P.chrV); free(t0); free(t1);
@@ -1888,6 +1998,7 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
     case UNSC_NV242PLANAR: return unscaled_nv242planar(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_NV242YUV420: return unscaled_nv242yuv420(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_YVU9_YV12: return unscaled_yvu9_yv12(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_PACKED2GBRP: return unscaled_packed2gbrp(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     }
     return main_path(c, src, srcStride, dst, dstStride);
 }
@@ -1910,7 +2021,7 @@ const char *or_sws_path_name(const OrSws *c)
 {
     static const char *n[] = { "main", "yuv2rgb_c", "planarToP01x", "planar8ToP01xle", "planarToNv12", "nv12ToPlanar", "planarCopy",
                                "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb",
-                               "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12" };
+                               "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb" };
     return c->cascade[0] ? "cascade" : n[c->unscaled_kind];
 }
 const int32_t *or_sws_rgb2yuv_table(const OrSws *c) { return c->rgb2yuv; }

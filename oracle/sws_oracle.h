@@ -35,6 +35,8 @@ enum {
     ORF_YUV444P12LE = 131, ORF_YUV444P14LE = 133, ORF_YUV440P10LE = 151, ORF_YUV440P12LE = 153,
     ORF_P016LE = 169, ORF_NV24 = 188, ORF_NV42 = 189, ORF_P210LE = 198, ORF_P410LE = 200, ORF_P216LE = 202,
     ORF_P416LE = 204, ORF_P012LE = 209, ORF_P212LE = 222, ORF_P412LE = 224,
+    /* planar RGB 9..16 bit (readers input.c:1213-1283, writers output.c:2342-2530) */
+    ORF_GBRP9LE = 73, ORF_GBRP10LE = 75, ORF_GBRP16LE = 77, ORF_GBRP12LE = 135, ORF_GBRP14LE = 137,
 };
 
 /* libswscale/swscale.h:131-208 */

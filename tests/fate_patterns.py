@@ -18,7 +18,8 @@ W, H = 352, 288
 SWS_FLAGS = OL.SWS_BICUBIC | OL.SWS_ACCURATE_RND | OL.SWS_BITEXACT   # tests/fate-run.sh:258 + the filter's default scaler
 FMT_OF = {"gray": "gray8", "rgb32": "bgra"}                           # lavu pixfmt aliases on little endian
 BASE_FMT = {"yuv444p": "yuv444p", "rgb24": "rgb24", "yuv444p10": "yuv444p10le", "yuv444p12": "yuv444p12le",
-            "yuv444p16": "yuv444p16le", "nv24": "nv24", "p410": "p410le", "p412": "p412le", "p416": "p416le"}
+            "yuv444p16": "yuv444p16le", "nv24": "nv24", "p410": "p410le", "p412": "p412le", "p416": "p416le",
+            "gbrp": "gbrp", "gbrp10": "gbrp10le", "gbrp12": "gbrp12le", "gbrp16": "gbrp16le"}
 GOLDEN = json.load(open(os.path.join(HERE, "golden", "fate_pixfmt_md5.json")))
 
 
@@ -61,7 +62,19 @@ def yuvtestsrc(depth, semi=False):
     return f
 
 
-def rgbtestsrc():
+def rgbtestsrc(planar_depth=0):
+    """rgbtest_fill_picture (vsrc_testsrc.c:1111-1131): c = (1 << max(depth, 8)) * x / w in the band's channel."""
+    if planar_depth:
+        fmt = "gbrp" if planar_depth == 8 else f"gbrp{planar_depth}le"
+        f = OL.Frame(fmt, W, H)
+        dt = np.uint8 if planar_depth == 8 else np.dtype("<u2")
+        ramp = ((1 << planar_depth) * np.arange(W) // W).astype(dt)
+        rgb = [np.zeros((H, W), dt) for _ in range(3)]
+        for y in range(H):
+            rgb[band_of(y)][y, :] = ramp
+        for a, p in zip(f.planes, (rgb[1], rgb[2], rgb[0])):     # planes are G, B, R
+            a[:, :p.shape[1] * p.itemsize] = p.view(np.uint8).reshape(H, -1)
+        return f
     f = OL.Frame("rgb24", W, H)
     img = np.zeros((H, W, 3), np.uint8)
     ramp = (256 * np.arange(W) // W).astype(np.uint8)
@@ -74,6 +87,8 @@ def rgbtestsrc():
 def base_picture(base):
     if base == "rgb24":
         return rgbtestsrc()
+    if base.startswith("gbrp"):
+        return rgbtestsrc({"gbrp": 8, "gbrp10": 10, "gbrp12": 12, "gbrp16": 16}[base])
     if base in ("nv24", "p410", "p412", "p416"):
         return yuvtestsrc({"nv24": 8, "p410": 10, "p412": 12, "p416": 16}[base], semi=True)
     return yuvtestsrc({"yuv444p": 8, "yuv444p10": 10, "yuv444p12": 12, "yuv444p16": 16}[base])

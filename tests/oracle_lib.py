@@ -33,6 +33,8 @@ _FORMATS = {
     "argb": (25, "packed", 0, 0, 4), "rgba": (26, "packed", 0, 0, 4), "abgr": (27, "packed", 0, 0, 4), "bgra": (28, "packed", 0, 0, 4),
     "0rgb": (118, "packed", 0, 0, 4), "rgb0": (119, "packed", 0, 0, 4), "0bgr": (120, "packed", 0, 0, 4), "bgr0": (121, "packed", 0, 0, 4),
     "gbrp": (71, "rgbp", 0, 0, 1), "gbrpf32le": (175, "rgbp", 0, 0, 4),
+    "gbrp9le": (73, "rgbp", 0, 0, 2), "gbrp10le": (75, "rgbp", 0, 0, 2), "gbrp12le": (135, "rgbp", 0, 0, 2),
+    "gbrp14le": (137, "rgbp", 0, 0, 2), "gbrp16le": (77, "rgbp", 0, 0, 2),
     "gray8": (8, "gray", 0, 0, 1),
 }
 
@@ -108,7 +110,7 @@ def fill_random(frame, seed):
     f = frame.fmt
     for pi, (a, rb) in enumerate(zip(frame.planes, frame.row_bytes)):
         rows = a.shape[0]
-        m = re.match(r"yuv4\d\dp(9|10|12|14)le$", f)
+        m = re.match(r"(?:yuv4\d\dp|gbrp)(9|10|12|14)le$", f)
         mp = re.match(r"p[024](10|12)le$", f)
         if m:      # N-bit samples in the low bits of 16-bit words
             v = rng.integers(0, 1 << int(m.group(1)), size=(rows, rb // 2), dtype=np.uint16)
