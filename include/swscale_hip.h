@@ -61,6 +61,9 @@ enum AVPixelFormat {
     AV_PIX_FMT_YUV440P10LE = 151, AV_PIX_FMT_YUV440P12LE = 153, AV_PIX_FMT_P016LE = 169, AV_PIX_FMT_NV24 = 188,
     AV_PIX_FMT_NV42 = 189, AV_PIX_FMT_P210LE = 198, AV_PIX_FMT_P410LE = 200, AV_PIX_FMT_P216LE = 202,
     AV_PIX_FMT_P416LE = 204, AV_PIX_FMT_P012LE = 209, AV_PIX_FMT_P212LE = 222, AV_PIX_FMT_P412LE = 224,
+    /* planar RGB 9..16 bit */
+    AV_PIX_FMT_GBRP9LE = 73, AV_PIX_FMT_GBRP10LE = 75, AV_PIX_FMT_GBRP16LE = 77, AV_PIX_FMT_GBRP12LE = 135,
+    AV_PIX_FMT_GBRP14LE = 137,
     /* NEW: hardware surface format of the HIP hwcontext slot; appended after the
      * reference's last format (AV_PIX_FMT_NB == 268, libavutil/pixfmt.h) */
     AV_PIX_FMT_HIP = 268,

@@ -80,14 +80,14 @@ static int scaler_from_enum(SwsScaler s, int fallback) // scaler_flag, utils.c:1
     }
 }
 
-// every descriptor row of pixdesc.cpp has a reader; every row except the planar-RGB ones has a writer
+// every descriptor row of pixdesc.cpp has a reader and a writer
 static bool fmt_supported_in(int f)
 {
     return f != AV_PIX_FMT_GRAY8 && pix_desc(f) != nullptr;
 }
 static bool fmt_supported_out(int f)
 {
-    return f != AV_PIX_FMT_GRAY8 && pix_desc(f) != nullptr && !isPlanarRGB(f);
+    return f != AV_PIX_FMT_GRAY8 && pix_desc(f) != nullptr;
 }
 
 // ff_get_unscaled_swscale (swscale_unscaled.c:2392-2706): "last match wins"
@@ -103,7 +103,10 @@ void choose_unscaled(SwsInternal *c)
     if (d == AV_PIX_FMT_YUV444P && (s == AV_PIX_FMT_NV24 || s == AV_PIX_FMT_NV42)) k = PLAN_UNSC_NV242PLANAR; // :2420
     if ((s == AV_PIX_FMT_YUV420P || s == AV_PIX_FMT_YUV422P) && isAnyRGB(d) && !(flags & SWS_ACCURATE_RND) &&
         (c->opts.dither == SWS_DITHER_BAYER || c->opts.dither == SWS_DITHER_AUTO) && !(c->opts.dst_h & 1)) { // :2425-2431
-        k = PLAN_UNSC_YUV2RGB;
+        // ff_yuv2rgb_get_func_ptr (yuv2rgb.c:561-678) has C converters for the 24/32 bpp packed formats and gbrp;
+        // it returns NULL for gbrp9..16 / gbrpf32 and the scaler chain is used
+        if (!isPlanarRGB(d)) k = PLAN_UNSC_YUV2RGB;
+        else if (d == AV_PIX_FMT_GBRP) k = PLAN_UNSC_YUV2GBRP;
         c->dst_slice_align = 2;
     }
     if ((s == AV_PIX_FMT_YUV420P10LE || s == AV_PIX_FMT_YUV420P12LE || s == AV_PIX_FMT_YUV420P14LE || s == AV_PIX_FMT_YUV420P16LE) &&
@@ -122,6 +125,7 @@ void choose_unscaled(SwsInternal *c)
         const bool s32 = pix_desc(s)->comp[0].step == 4;
         if (!(!s32 && (d == AV_PIX_FMT_BGRA || d == AV_PIX_FMT_RGBA) && (flags & SWS_BITEXACT))) k = PLAN_UNSC_RGB2RGB;
     }
+    if (isAnyRGB(s) && !isPlanarRGB(s) && d == AV_PIX_FMT_GBRP) k = PLAN_UNSC_PACKED_GBRP;             // rgbToPlanarRgbWrapper (:2542-2544)
     if (s == AV_PIX_FMT_GBRP && isAnyRGB(d) && !isPlanarRGB(d)) k = PLAN_UNSC_GBRP_PACKED;             // planarRgbToRgbWrapper (:2480-2481)
     if (s == d ||
         (isFloatFmt(s) == isFloatFmt(d) && isPlanarYUV(s) && isPlanarYUV(d) &&
@@ -205,7 +209,7 @@ int init_single_context(SwsInternal *c)
     }
     // RGB sources: chroma is taken from horizontally averaged pixel pairs unless full chroma input
     // is requested (:1369-1390; planar float/high-depth RGB are exempt)
-    if (isAnyRGB(srcFormat) && !(srcW & 1) && !(flags & SWS_FULL_CHR_H_INP) && srcFormat != AV_PIX_FMT_GBRPF32LE &&
+    if (isAnyRGB(srcFormat) && !(srcW & 1) && !(flags & SWS_FULL_CHR_H_INP) && !(isPlanarRGB(srcFormat) && ds->comp[0].depth > 8) &&
         ((dstW >> c->chrDstHSubSample) <= (srcW >> 1) || (flags & SWS_FAST_BILINEAR)))
         c->chrSrcHSubSample = 1;
 

@@ -92,7 +92,7 @@ static int src_kind_of(int f)
 {
     const PixDesc *d = pix_desc(f);
     if (!d) return -1;
-    if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? SRCK_GBRPF32 : SRCK_GBRP;
+    if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? SRCK_GBRPF32 : d->comp[0].depth > 8 ? SRCK_GBRP16 : SRCK_GBRP;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? SRCK_RGB24 : SRCK_RGB32;
     if (isSemiPlanarYUV(f)) return d->comp[0].depth == 8 ? SRCK_NV12 : SRCK_P010;
     if (isPlanarYUV(f)) return d->comp[0].depth == 8 ? SRCK_PLANAR8 : SRCK_PLANAR16;
@@ -101,7 +101,8 @@ static int src_kind_of(int f)
 static int dst_kind_of(int f)
 {
     const PixDesc *d = pix_desc(f);
-    if (!d || isPlanarRGB(f)) return -1;
+    if (!d) return -1;
+    if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? DSTK_GBRPF32 : d->comp[0].depth == 16 ? DSTK_GBRP16 : DSTK_GBRP;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? DSTK_RGB24 : DSTK_RGB32;
     const int depth = d->comp[0].depth;
     if (isSemiPlanarYUV(f)) return depth == 8 ? DSTK_NV12 : depth == 16 ? DSTK_P016 : DSTK_P010;
@@ -455,6 +456,8 @@ int dev_prepare(SwsInternal *c)
     case PLAN_UNSC_NV242PLANAR: c->path_name = "unscaled:nv24ToPlanar"; c->kernel_name = "sws_k_planar_misc"; break;
     case PLAN_UNSC_NV242YUV420: c->path_name = "unscaled:nv24ToYuv420"; c->kernel_name = "sws_k_planar_misc"; break;
     case PLAN_UNSC_YVU9_YV12: c->path_name = "unscaled:yvu9ToYv12"; c->kernel_name = "sws_k_planar_misc"; break;
+    case PLAN_UNSC_YUV2GBRP: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2gbrp_unscaled"; break;
+    case PLAN_UNSC_PACKED_GBRP: c->path_name = "unscaled:rgbToPlanarRgb"; c->kernel_name = "sws_k_packed_to_gbrp"; break;
     case PLAN_CASCADE: c->path_name = "cascade"; c->kernel_name = ""; break;
     case PLAN_MAIN: {
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
@@ -709,6 +712,25 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         else hipLaunchKernelGGL((swsk::sws_k_rgb_shuffle<false, false>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
         break;
     }
+    case PLAN_UNSC_YUV2GBRP: {
+        const int dstW = p.dstW;
+        const int npairs = ((dstW >> 3) << 2) + ((dstW & 4) ? 2 : 0) + ((dstW & 2) ? 1 : 0); // yuv2rgb.c:198-236
+        const int nrowpairs = (sliceH + 1) >> 1;
+        if (!npairs || !nrowpairs) break;
+        const dim3 grid(cdiv(npairs, 256), nrowpairs, n);
+        hipLaunchKernelGGL(swsk::sws_k_yuv2gbrp_unscaled, grid, blk, 0, st, fs, p, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 0, npairs, sliceY);
+        break;
+    }
+    case PLAN_UNSC_PACKED_GBRP: {
+        const PixDesc *ds = pix_desc(c->opts.src_format);
+        swsk::ShufflePlan sp;
+        std::memset(&sp, 0, sizeof(sp));
+        sp.src_step = ds->comp[0].step;
+        for (int k = 0; k < 4; k++) sp.spos[k] = k < ds->nb_components ? ds->comp[k].offset : -1;
+        const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
+        hipLaunchKernelGGL(swsk::sws_k_packed_to_gbrp, grid, blk, 0, st, fs, sp, p.srcW, sliceY);
+        break;
+    }
     case PLAN_UNSC_GBRP_PACKED: {
         const PixDesc *dd = pix_desc(c->opts.dst_format);
         swsk::ShufflePlan sp;
@@ -733,8 +755,9 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         break;
     }
     case PLAN_MAIN: {
-        const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32;
-        const bool rgb_lut = rgb && !p.full_chr;
+        const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 ||
+                         p.dstKind == DSTK_GBRPF32;
+        const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
         if (d->unity_h && rgb_lut && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;
             if (vec && !no_wave && d->all_x_mode && d->chr_window2 <= 8 && p.vChrFs <= 64) { // wave-tiled kernel: 1024 pixels x 2 rows per wave

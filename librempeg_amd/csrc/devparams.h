@@ -12,6 +12,7 @@ enum SrcKind {
     SRCK_RGB32,         // packed 4 bytes; rgb16_32To*_c_template input.c:264-372
     SRCK_GBRP,          // planar 8-bit RGB; planar_rgb_to_y/uv input.c:1174-1211, gbr24pToUV_half_c :414
     SRCK_GBRPF32,       // planar float RGB; planar_rgbf32_to_y/uv input.c:1287-1334
+    SRCK_GBRP16,        // planar 9..16-bit RGB; planar_rgb16_s16_to_y/uv input.c:1216-1270
 };
 
 // how an output line is produced ("output writer", libswscale/output.c)
@@ -23,6 +24,9 @@ enum DstKind {
     DSTK_P010,          // yuv2p01xl1_c/lX_c/cX_c output.c:538-589
     DSTK_RGB24,         // yuv2rgb_write 24 bpp (rgb24 / bgr24 by rgb_order)
     DSTK_RGB32,         // yuv2rgb_write 32 bpp (rgba/bgra/argb/abgr by shifts)
+    DSTK_GBRP,          // planar RGB 8..14 bit: yuv2gbrp_full_X_c output.c:2342-2421
+    DSTK_GBRP16,        // planar RGB 16 bit: yuv2gbrp16_full_X_c output.c:2467-2530
+    DSTK_GBRPF32,       // planar RGB float: yuv2gbrpf32_full_X_c output.c:2533-2605
     DSTK_P016,          // 16-bit semi-planar: luma yuv2planeX_16_c, chroma yuv2nv12cX_16_c_template output.c:189-217
 };
 

@@ -83,6 +83,16 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         }
         return (uint16_t)((int)((unsigned)t[o] * R[x] + (unsigned)t[o + 1] * G[x] + (unsigned)t[o + 2] * B[x] + (0x4001 << 8)) >> 9);
     }
+    case SRCK_GBRP16: { // planar_rgb16_s16_to_y / _to_uv, input.c:1216-1270
+        const int g = *(const uint16_t *)(f.src[0] + (int64_t)row * f.srcStride[0] + 2 * x);
+        const int b = *(const uint16_t *)(f.src[1] + (int64_t)row * f.srcStride[1] + 2 * x);
+        const int r = *(const uint16_t *)(f.src[2] + (int64_t)row * f.srcStride[2] + 2 * x);
+        const int32_t *t = p.rgb2yuv;
+        const int bpc = p.src_depth, shift = bpc < 16 ? bpc : 14;
+        const int o = comp == 0 ? 0 : comp == 1 ? 3 : 6;
+        const unsigned bias = ((comp == 0 ? 16u : 128u) << (15 + bpc - 8)) + (1u << shift);
+        return (uint16_t)((int)((unsigned)t[o] * r + (unsigned)t[o + 1] * g + (unsigned)t[o + 2] * b + bias) >> (shift + 1));
+    }
     case SRCK_GBRPF32: { // planar_rgbf32_to_y / _to_uv, input.c:1300-1334
         const int g = f32_to_u16(*(const float *)(f.src[0] + (int64_t)row * f.srcStride[0] + 4 * x));
         const int b = f32_to_u16(*(const float *)(f.src[1] + (int64_t)row * f.srcStride[1] + 4 * x));
@@ -276,14 +286,68 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
     const int lH = p.srcH - 1, cH = p.chrSrcH - 1;
     uint8_t *drow = f.dst[0] + (int64_t)y * f.dstStride[0];
     const SwsLutParams &L = p.lut;
+#define LUM(j, xx) smp.get(0, min(firstL + (j), lH), (xx))
+#define CHU(j, xx) smp.get(1, min(firstC + (j), cH), (xx))
+#define CHV(j, xx) smp.get(2, min(firstC + (j), cH), (xx))
+    if (p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 || p.dstKind == DSTK_GBRPF32) {
+        // any_vscale (vscale.c:173-212): planar RGB always takes the X form; planes are G, B, R
+        uint8_t *dg = drow, *db = f.dst[1] + (int64_t)y * f.dstStride[1], *dr = f.dst[2] + (int64_t)y * f.dstStride[2];
+        int Y, U, V, R, G, B;
+        if (p.dstKind == DSTK_GBRP) {          // yuv2gbrp_full_X_c, output.c:2342-2421 (15-bit intermediates)
+            const int SH = 22 + 8 - p.dst_bits;
+            Y = 1 << 9; U = (1 << 9) - (128 << 19); V = (1 << 9) - (128 << 19);
+            for (int j = 0; j < lfs; j++) Y += (int)((unsigned)LUM(j, i) * (unsigned)(int)lf[j]);
+            for (int j = 0; j < cfs; j++) {
+                U += (int)((unsigned)CHU(j, i) * (unsigned)(int)cf[j]);
+                V += (int)((unsigned)CHV(j, i) * (unsigned)(int)cf[j]);
+            }
+            Y >>= 10; U >>= 10; V >>= 10;
+            Y -= L.y_offset;
+            Y = (int)((unsigned)Y * (unsigned)L.y_coeff);
+            Y = (int)((unsigned)Y + (1u << (SH - 1)));
+            R = (int)((unsigned)Y + (unsigned)V * (unsigned)L.v2r);
+            G = (int)((unsigned)Y + (unsigned)V * (unsigned)L.v2g + (unsigned)U * (unsigned)L.u2g);
+            B = (int)((unsigned)Y + (unsigned)U * (unsigned)L.u2b);
+            if ((R | G | B) & 0xC0000000) { R = clip_uintp2(R, 30); G = clip_uintp2(G, 30); B = clip_uintp2(B, 30); }
+            if (SH != 22) {
+                ((uint16_t *)dg)[i] = (uint16_t)(G >> SH); ((uint16_t *)db)[i] = (uint16_t)(B >> SH); ((uint16_t *)dr)[i] = (uint16_t)(R >> SH);
+            } else {
+                dg[i] = (uint8_t)(G >> 22); db[i] = (uint8_t)(B >> 22); dr[i] = (uint8_t)(R >> 22);
+            }
+        } else {                                // yuv2gbrp16_full_X_c :2467-2530 / yuv2gbrpf32_full_X_c :2533-2605 (19-bit)
+            Y = -0x40000000; U = -(128 << 23); V = -(128 << 23);
+            for (int j = 0; j < lfs; j++) Y += (int)((unsigned)LUM(j, i) * (unsigned)(int)lf[j]);
+            for (int j = 0; j < cfs; j++) {
+                U += (int)((unsigned)CHU(j, i) * (unsigned)(int)cf[j]);
+                V += (int)((unsigned)CHV(j, i) * (unsigned)(int)cf[j]);
+            }
+            Y >>= 14; Y += 0x10000; U >>= 14; V >>= 14;
+            Y -= L.y_offset;
+            Y = (int)((unsigned)Y * (unsigned)L.y_coeff);
+            Y = (int)((unsigned)Y + (unsigned)((1 << 13) - (1 << 29)));
+            R = (int)((unsigned)V * (unsigned)L.v2r);
+            G = (int)((unsigned)V * (unsigned)L.v2g + (unsigned)U * (unsigned)L.u2g);
+            B = (int)((unsigned)U * (unsigned)L.u2b);
+            if (p.dstKind == DSTK_GBRP16) {     // 64-bit sums
+                ((uint16_t *)dr)[i] = (uint16_t)clip_uintp2((int)(((int64_t)Y + R) >> 14) + (1 << 15), 16);
+                ((uint16_t *)dg)[i] = (uint16_t)clip_uintp2((int)(((int64_t)Y + G) >> 14) + (1 << 15), 16);
+                ((uint16_t *)db)[i] = (uint16_t)clip_uintp2((int)(((int64_t)Y + B) >> 14) + (1 << 15), 16);
+            } else {                            // the float writer adds in 32 bits, then float_mult * (float)v
+                const float float_mult = 1.0f / 65535.0f;
+                R = clip_uintp2(((int)((unsigned)Y + (unsigned)R) >> 14) + (1 << 15), 16);
+                G = clip_uintp2(((int)((unsigned)Y + (unsigned)G) >> 14) + (1 << 15), 16);
+                B = clip_uintp2(((int)((unsigned)Y + (unsigned)B) >> 14) + (1 << 15), 16);
+                ((float *)dg)[i] = __fmul_rn(float_mult, (float)G); ((float *)db)[i] = __fmul_rn(float_mult, (float)B);
+                ((float *)dr)[i] = __fmul_rn(float_mult, (float)R);
+            }
+        }
+        return;
+    }
     int mode = 0, ua = 0, ya = 0; // 1: packed1, 2: packed2, 0: X
     if (lfs == 1 && cfs == 1) { mode = 1; }
     else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 1; ua = (uint16_t)cf[1]; }
     else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
              (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 2; ya = (uint16_t)lf[1]; ua = (uint16_t)cf[1]; }
-#define LUM(j, xx) smp.get(0, min(firstL + (j), lH), (xx))
-#define CHU(j, xx) smp.get(1, min(firstC + (j), cH), (xx))
-#define CHV(j, xx) smp.get(2, min(firstC + (j), cH), (xx))
     if (!p.full_chr) {
         int Y1, Y2, U, V;
         if (mode == 0) {

@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) sws_k_rgb_shuffle(SwsFrameSet fs, Shuffle
     if (x0 >= w) return;
     const FrameRegs f = load_frame(fs, blockIdx.z);
     const int y = blockIdx.y;
-    const uint8_t *srow = f.src[0] + (int64_t)y * f.srcStride[0];
+    const uint8_t *srow = f.src[0] + (int64_t)(sliceY + y) * f.srcStride[0];   // the host rebases slice pointers to absolute rows
     uint8_t *drow = f.dst[0] + (int64_t)(sliceY + y) * f.dstStride[0];
     constexpr int SS = S3 ? 3 : 4, DS = D3 ? 3 : 4;
     const uint8_t *s = srow + x0 * SS;
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) sws_k_packed_copy(SwsFrameSet fs, int row
     if (b0 >= row_bytes) return;
     const FrameRegs f = load_frame(fs, blockIdx.z);
     const int y = blockIdx.y;
-    const uint8_t *srow = f.src[0] + (int64_t)y * f.srcStride[0];
+    const uint8_t *srow = f.src[0] + (int64_t)(sliceY + y) * f.srcStride[0];
     uint8_t *drow = f.dst[0] + (int64_t)(sliceY + y) * f.dstStride[0];
     const bool aligned = ((((uintptr_t)srow) | ((uintptr_t)drow)) & 15) == 0;
     if (aligned && b0 + 16 <= row_bytes) {
@@ -102,9 +102,9 @@ __global__ void __launch_bounds__(256) sws_k_gbrp_to_packed(SwsFrameSet fs, Shuf
     if (x0 >= w) return;
     const FrameRegs f = load_frame(fs, blockIdx.z);
     const int y = blockIdx.y;
-    const uint8_t *pr = f.src[2] + (int64_t)y * f.srcStride[2] + x0;   // gbrp: plane 0 = G, 1 = B, 2 = R
-    const uint8_t *pg = f.src[0] + (int64_t)y * f.srcStride[0] + x0;
-    const uint8_t *pb = f.src[1] + (int64_t)y * f.srcStride[1] + x0;
+    const uint8_t *pr = f.src[2] + (int64_t)(sliceY + y) * f.srcStride[2] + x0;   // gbrp: plane 0 = G, 1 = B, 2 = R
+    const uint8_t *pg = f.src[0] + (int64_t)(sliceY + y) * f.srcStride[0] + x0;
+    const uint8_t *pb = f.src[1] + (int64_t)(sliceY + y) * f.srcStride[1] + x0;
     constexpr int DS = D3 ? 3 : 4;
     uint8_t *d = f.dst[0] + (int64_t)(sliceY + y) * f.dstStride[0] + x0 * DS;
     const int n = min(4, w - x0);
@@ -112,6 +112,45 @@ __global__ void __launch_bounds__(256) sws_k_gbrp_to_packed(SwsFrameSet fs, Shuf
         uint8_t *q = d + i * DS;
         q[sp.dpos[0]] = pr[i]; q[sp.dpos[1]] = pg[i]; q[sp.dpos[2]] = pb[i];
         if (!D3) q[sp.dpos[3]] = 255;
+    }
+}
+
+// rgbToPlanarRgbWrapper (swscale_unscaled.c:1436-1490, packedtogbr24p :1404-1434): packed 24/32 bpp -> gbrp, alpha dropped
+__global__ void __launch_bounds__(256) sws_k_packed_to_gbrp(SwsFrameSet fs, ShufflePlan sp, int w, int sliceY)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= w) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int y = blockIdx.y;
+    const uint8_t *s = f.src[0] + (int64_t)(sliceY + y) * f.srcStride[0] + x * sp.src_step;
+    f.dst[2][(int64_t)(sliceY + y) * f.dstStride[2] + x] = s[sp.spos[0]];   // R
+    f.dst[0][(int64_t)(sliceY + y) * f.dstStride[0] + x] = s[sp.spos[1]];   // G
+    f.dst[1][(int64_t)(sliceY + y) * f.dstStride[1] + x] = s[sp.spos[2]];   // B
+}
+
+// yuv420p_gbrp_c / yuv422p_gbrp_c (yuv2rgb.c:127-135 PUTGBRP, :532, :553): the 24 bpp LUT values written to the
+// G, B and R planes.  One thread = one chroma sample = 2 pixels x 2 rows.
+__global__ void __launch_bounds__(256) sws_k_yuv2gbrp_unscaled(SwsFrameSet fs, SwsDevParams p, int is422, int npairs, int sliceY)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const SwsLutParams &L = p.lut;
+    const int yrow = 2 * blockIdx.y;                       // slice-relative luma row of the pair
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const int yy = yrow + l;
+        const int cr = is422 ? sliceY + yy : ((sliceY + yrow) >> 1);   // absolute rows: the host rebases slice pointers
+        const int U = f.src[1][(int64_t)cr * f.srcStride[1] + i], V = f.src[2][(int64_t)cr * f.srcStride[2] + i];
+        const ChromaIdx k = lut_chroma(L, U, V);
+        const uint8_t *py = f.src[0] + (int64_t)(sliceY + yy) * f.srcStride[0] + 2 * i;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int Y = py[h];
+            f.dst[0][(int64_t)(sliceY + yy) * f.dstStride[0] + 2 * i + h] = (uint8_t)lut_luma(L, k.g + Y);
+            f.dst[1][(int64_t)(sliceY + yy) * f.dstStride[1] + 2 * i + h] = (uint8_t)lut_luma(L, k.b + Y);
+            f.dst[2][(int64_t)(sliceY + yy) * f.dstStride[2] + 2 * i + h] = (uint8_t)lut_luma(L, k.r + Y);
+        }
     }
 }
 
@@ -130,8 +169,8 @@ __global__ void __launch_bounds__(256) sws_k_bgr24_to_yv12(SwsFrameSet fs, SwsDe
     if (c0 >= cw) return;
     const FrameRegs f = load_frame(fs, blockIdx.z);
     const int y = blockIdx.y * 2, y2 = (y + 1 == sliceH) ? y : y + 1;
-    const uint8_t *s1 = f.src[0] + (int64_t)y * f.srcStride[0] + c0 * 6;
-    const uint8_t *s2 = f.src[0] + (int64_t)y2 * f.srcStride[0] + c0 * 6;
+    const uint8_t *s1 = f.src[0] + (int64_t)(sliceY + y) * f.srcStride[0] + c0 * 6;   // absolute rows (host rebases slice pointers)
+    const uint8_t *s2 = f.src[0] + (int64_t)(sliceY + y2) * f.srcStride[0] + c0 * 6;
     uint8_t *d1 = f.dst[0] + (int64_t)(sliceY + y) * f.dstStride[0] + c0 * 2;
     uint8_t *d2 = f.dst[0] + (int64_t)(sliceY + y2) * f.dstStride[0] + c0 * 2;
     uint8_t *du = f.dst[1] + (int64_t)((sliceY >> 1) + (y >> 1)) * f.dstStride[1] + c0;

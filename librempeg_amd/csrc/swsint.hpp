@@ -69,6 +69,8 @@ enum PlanKind {
     PLAN_UNSC_NV242PLANAR, // nv24ToPlanarWrapper
     PLAN_UNSC_NV242YUV420, // nv24ToYuv420Wrapper
     PLAN_UNSC_YVU9_YV12,   // yvu9ToYv12Wrapper -> planar2x_c
+    PLAN_UNSC_YUV2GBRP,    // yuv420p_gbrp_c / yuv422p_gbrp_c (yuv2rgb.c:532,553)
+    PLAN_UNSC_PACKED_GBRP, // rgbToPlanarRgbWrapper (8-bit packed RGB -> gbrp)
     PLAN_MAIN,             // ff_swscale chain
     PLAN_CASCADE,          // two contexts through an intermediate image
 };

@@ -84,8 +84,9 @@ YUV_FAMILY = ["yuv420p", "yuv422p", "yuv444p", "yuv410p", "yuv411p", "yuv440p", 
               "yuv420p12le", "yuv422p12le", "yuv444p12le", "yuv440p12le", "yuv420p14le", "yuv422p14le", "yuv444p14le",
               "yuv420p16le", "yuv422p16le", "yuv444p16le",
               "p010le", "p210le", "p410le", "p012le", "p212le", "p412le", "p016le", "p216le", "p416le"]
-FORMAT_MATRIX_SRC = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "gbrp", "gbrpf32le"]
-FORMAT_MATRIX_DST = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"]
+PLANAR_RGB = ["gbrp", "gbrp9le", "gbrp10le", "gbrp12le", "gbrp14le", "gbrp16le", "gbrpf32le"]
+FORMAT_MATRIX_SRC = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB
+FORMAT_MATRIX_DST = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB
 
 
 @pytest.mark.parametrize("sfmt", FORMAT_MATRIX_SRC)
@@ -144,6 +145,61 @@ def test_bgr24_to_yuv420p_special_converter(w, h):
     assert opath == "main"
     path, opath = run_case(w + 1, h, "bgr24", w + 1, h, "yuv420p", SWS_BICUBIC | BX, seed=w)
     assert opath == "main"
+
+
+def _slice_ptrs(frame, fmt, y0):
+    """plane pointers of a DeviceFrame advanced to luma row y0 (what a caller feeding slices passes as srcSlice[])."""
+    import ctypes as C
+    _, kind, _, lh, _ = OL._FORMATS[fmt]
+    p, s = frame.ptrs()
+    q = (C.c_void_p * 4)()
+    for i in range(frame.nplanes):
+        rows = y0 if (i == 0 or kind in ("rgbp", "packed", "gray")) else (y0 >> lh)
+        q[i] = p[i] + rows * s[i]
+    return q, s
+
+
+SLICED_UNSCALED = [
+    ("yuv420p", "rgb24", BX), ("yuv422p", "bgra", BX), ("yuv420p", "gbrp", BX), ("yuv420p", "nv12", BX), ("nv21", "yuv420p", BX),
+    ("yuv444p", "nv24", BX), ("nv42", "yuv444p", BX), ("nv24", "yuv420p", BX), ("yuv420p10le", "p010le", BX), ("yuv420p", "p016le", BX),
+    ("yuv420p12le", "p016le", BX), ("yuv444p10le", "yuv444p", BX), ("yuv420p", "yuv420p16le", BX), ("yuv422p16le", "yuv422p10le", BX),
+    ("p010le", "p016le", BX), ("nv12", "nv12", BX), ("rgb24", "bgr24", BX), ("rgba", "argb", BX), ("rgb24", "abgr", 0), ("bgr0", "rgba", BX),
+    ("rgba", "rgba", BX), ("rgb0", "rgba", BX), ("bgr24", "yuv420p", BX), ("gbrp", "rgb24", BX), ("gbrp", "bgra", BX), ("rgb24", "gbrp", BX),
+    ("argb", "gbrp", BX), ("gbrp", "gbrp", BX), ("gbrp10le", "gbrp10le", BX),
+]
+
+
+@pytest.mark.parametrize("sfmt,dfmt,fl", SLICED_UNSCALED, ids=[f"{a}-{b}" for a, b, _ in SLICED_UNSCALED])
+def test_unscaled_converters_accept_slices(sfmt, dfmt, fl):
+    """sws_scale() with srcSliceY/srcSliceH on the unscaled special converters: three slices (cut at multiples of 16 rows)
+    must give the whole-frame oracle result, top-down and in shuffled order."""
+    w, h = 70, 80
+    flags = SWS_BICUBIC | fl
+    o = OL.Oracle(w, h, sfmt, w, h, dfmt, flags)
+    assert o.path() != "main"
+    src = OL.fill_random(OL.Frame(sfmt, w, h), 21)
+    ref = OL.Frame(dfmt, w, h)
+    assert o.scale(src, ref) == h
+    p = SwsContext(w, h, sfmt, w, h, dfmt, flags)
+    assert p.path().startswith("unscaled:")
+    hs = HostFrame(sfmt, w, h)
+    for a, b in zip(hs.planes, src.planes):
+        a[:] = b
+    import torch
+    for order in ([(0, 32), (32, 16), (48, 32)], [(48, 32), (0, 32), (32, 16)]):
+        ds = DeviceFrame(sfmt, w, h).upload(hs)
+        dd = DeviceFrame(dfmt, w, h)
+        dd.buf.fill_(0x5A)
+        torch.cuda.synchronize()
+        dp, dstr = dd.ptrs()
+        for (y0, sh) in order:
+            sp, ss = _slice_ptrs(ds, sfmt, y0)
+            assert p.L.sws_scale(p.c, sp, ss, y0, sh, dp, dstr) == sh
+        p.sync()
+        out = dd.download()
+        for i, (a, b) in enumerate(zip(out.planes, ref.planes)):
+            rb = out.row_bytes[i]
+            assert np.array_equal(a[:, :rb], b[:, :rb]), (sfmt, dfmt, order, i)
 
 
 PACKED_RGB = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "bgr0", "0rgb", "0bgr"]
