@@ -313,8 +313,9 @@ int dev_prepare(SwsInternal *c)
                 };
                 struct Off { size_t rs, rc, cs, cc, ht, vt; };
                 auto plan2 = [&](const FilterBank &hb, const FilterBank &vb, int W, int H, int ncomp, SwsTileGeom &g, Off &o) -> bool {
-                    const int TW = 128, hf2 = fs2(hb.size), vf2 = fs2(vb.size);
-                    for (int TH : { 32, 16, 8, 4, 2 }) {
+                    static const int TWenv = std::getenv("SWS_HIP_TILE_TW") ? std::atoi(std::getenv("SWS_HIP_TILE_TW")) : 128;
+                    const int TW = TWenv, hf2 = fs2(hb.size), vf2 = fs2(vb.size);
+                    for (int TH : { 64, 32, 16, 8, 4, 2 }) {
                         const int tX = (W + TW - 1) / TW, tY = (H + TH - 1) / TH;
                         std::vector<int32_t> rs(tY), rc(tY), cs(tX), cc(tX);
                         int nrmax = 0, ncmax = 0;

@@ -160,25 +160,54 @@ __global__ void __launch_bounds__(256) sws_k_tile_dot2(SwsFrameSet fs, SwsDevPar
         const int sst = !CHROMA ? f.srcStride[0] : ((ci == 0) == u1 ? f.srcStride[1] : f.srcStride[2]);
         if (second) __syncthreads();                          // phase 2 of the previous component still reads S
         // ---- phase 1: 16-byte chunks of the source window -> LDS as u16 pairs ----
-        const int chunks = ncp / SPC;
-        for (int i = tid; i < nrp * chunks; i += 256) {
-            const int r = i / chunks, ch = i - r * chunks;
-            const int srow = min(rs + r, sH - 1);
-            const int64_t boff = (int64_t)(cs + ch * SPC) * (SRC16 ? 2 : 1);
-            const uint8_t *src = sb + (int64_t)srow * sst + boff;
-            u32x4 v;
-            if (boff + 16 <= (int64_t)(sst < 0 ? -sst : sst)) v = gload16(src);
-            else v = gload16_partial(src, (int)max((int64_t)0, (int64_t)(sst < 0 ? -sst : sst) - boff));
-            uint32_t *dst = S + r * srow_dw + ch * (SPC / 2);
-            if constexpr (SRC16) { *(u32x4 *)dst = v; }
-            else {
-                u32x4 lo, hi;                                  // bytes -> u16 pairs
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    lo[2 * q] = (v[q] & 0xFF) | ((v[q] & 0xFF00) << 8); lo[2 * q + 1] = ((v[q] >> 16) & 0xFF) | ((v[q] >> 8) & 0xFF0000);
-                    hi[2 * q] = (v[q + 2] & 0xFF) | ((v[q + 2] & 0xFF00) << 8); hi[2 * q + 1] = ((v[q + 2] >> 16) & 0xFF) | ((v[q + 2] >> 8) & 0xFF0000);
+        // The kernel is instruction-issue bound (about 1000 wave instructions per tile, < 20 % of them dot2), so the row
+        // is wave-uniform (scalar address math), a lane owns a chunk column, and 4 rows are in flight per wave.
+        {
+            const int chunks = ncp / SPC;
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+            const int64_t asst = sst < 0 ? -(int64_t)sst : (int64_t)sst;
+            const int64_t csb = (int64_t)cs * (SRC16 ? 2 : 1);
+            auto put = [&](int r, int ch, u32x4 v) {
+                uint32_t *dst = S + r * srow_dw + ch * (SPC / 2);
+                if constexpr (SRC16) { *(u32x4 *)dst = v; }
+                else {
+                    u32x4 lo, hi;                                  // bytes -> u16 pairs: v_perm_b32 with a zero byte source
+                    lo[0] = __builtin_amdgcn_perm(0, v[0], 0x0c010c00u); lo[1] = __builtin_amdgcn_perm(0, v[0], 0x0c030c02u);
+                    lo[2] = __builtin_amdgcn_perm(0, v[1], 0x0c010c00u); lo[3] = __builtin_amdgcn_perm(0, v[1], 0x0c030c02u);
+                    hi[0] = __builtin_amdgcn_perm(0, v[2], 0x0c010c00u); hi[1] = __builtin_amdgcn_perm(0, v[2], 0x0c030c02u);
+                    hi[2] = __builtin_amdgcn_perm(0, v[3], 0x0c010c00u); hi[3] = __builtin_amdgcn_perm(0, v[3], 0x0c030c02u);
+                    *(u32x4 *)dst = lo; *(u32x4 *)(dst + 4) = hi;
                 }
-                *(u32x4 *)dst = lo; *(u32x4 *)(dst + 4) = hi;
+            };
+            if (chunks >= 32) {   // wide windows: lane = chunk column, wave-uniform rows (scalar address math), 4 rows in flight
+                for (int ch = lane; ch < chunks; ch += 64) {
+                    const int64_t boff = csb + (int64_t)ch * 16;
+                    const bool full = boff + 16 <= asst;
+                    const int nvalid = (int)max((int64_t)0, asst - boff);
+                    for (int r0 = wave; r0 < nrp; r0 += 16) {          // rows r0, r0+4, r0+8, r0+12 of this wave
+                        u32x4 v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int r = r0 + 4 * k;
+                            if (r < nrp) {
+                                const uint8_t *src = sb + (int64_t)min(rs + r, sH - 1) * sst + boff;
+                                v[k] = full ? gload16(src) : gload16_partial(src, nvalid);
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int r = r0 + 4 * k;
+                            if (r < nrp) put(r, ch, v[k]);
+                        }
+                    }
+                }
+            } else {              // narrow windows (few chunks per row): flat index over (row, chunk) keeps all lanes busy
+                for (int i = tid; i < nrp * chunks; i += 256) {
+                    const int r = i / chunks, ch = i - r * chunks;
+                    const int64_t boff = csb + (int64_t)ch * 16;
+                    const uint8_t *src = sb + (int64_t)min(rs + r, sH - 1) * sst + boff;
+                    put(r, ch, boff + 16 <= asst ? gload16(src) : gload16_partial(src, (int)max((int64_t)0, asst - boff)));
+                }
             }
         }
         __syncthreads();
@@ -205,8 +234,9 @@ __global__ void __launch_bounds__(256) sws_k_tile_dot2(SwsFrameSet fs, SwsDevPar
     const int32_t *vpos = CHROMA ? p.vChrPos : p.vLumPos;
     const int q4 = (tw + 3) >> 2;
     const int bits = p.dst_bits;
+    const int q4s = 31 - __builtin_clz((unsigned)(g.TW >> 2));      // log2(TW / 4): full-width tiles index with shifts
     for (int i = tid; i < q4 * th; i += 256) {
-        const int yl = i / q4, xl = 4 * (i - yl * q4);
+        const int yl = tw == g.TW ? i >> q4s : i / q4, xl = 4 * (i - yl * q4);
         const int y = y0 + yl, x = x0 + xl;
         const int n = min(4, tw - xl);
         const int rpd = ((vpos[y] & ~1) - rs) >> 1;              // first row pair

@@ -1,0 +1,4 @@
+for w in c3b c1; do
+    echo -n "$w: "
+    python bench.py --workload $w --variants none --no-cpu --steps 20 --warmup 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['roofline']['kernel_ms_avg'], d['ms_per_step'])"
+done
