@@ -58,6 +58,13 @@ static int jpeg_alias(int *format) // handle_jpeg, utils.c:773-809
     return 0;
 }
 
+int canonical_pix_fmt(int fmt)
+{
+    jpeg_alias(&fmt);
+    zero_alpha_alias(&fmt);
+    return fmt;
+}
+
 static int local_pos(int chr_subsample, int pos) // get_local_pos, utils.c:168-175
 {
     if (pos == -1 || pos <= -513) pos = (128 << chr_subsample) - 128;
@@ -345,6 +352,26 @@ static int init_context_impl(SwsInternal *c, SwsFilter *srcFilter, SwsFilter *ds
     if (ret < 0) return ret;
     c->tables_dirty = true;
     return 0;
+}
+
+// sws_scale_frame() on a context that was only sws_alloc_context()ed: (re)configure from the frames
+int init_from_frames(SwsInternal *c, int sw, int sh, int sfmt, int dw, int dh, int dfmt)
+{
+    SwsContext &o = c->opts;
+    if (c->dynamic_init && o.src_w == sw && o.src_h == sh && o.dst_w == dw && o.dst_h == dh &&
+        o.src_format == canonical_pix_fmt(sfmt) && o.dst_format == canonical_pix_fmt(dfmt)) return 0;
+    // new geometry: drop everything derived from the old one
+    destroy(c->cascade[0]); destroy(c->cascade[1]);
+    c->cascade[0] = c->cascade[1] = nullptr;
+    dev_release(c);
+    c->src0Alpha = c->dst0Alpha = 0;
+    c->dstFormatBpp = c->srcFormatBpp = 0;
+    c->contrast = c->saturation = c->brightness = 0;
+    o.src_w = sw; o.src_h = sh; o.src_format = sfmt; o.dst_w = dw; o.dst_h = dh; o.dst_format = dfmt;
+    int ret = init_context_impl(c, nullptr, nullptr);
+    c->legacy_init = false;       // sws_scale() keeps refusing a context that was not sws_init_context()ed (swscale.c:1633)
+    c->dynamic_init = ret >= 0;
+    return ret;
 }
 
 } // namespace swship

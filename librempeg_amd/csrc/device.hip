@@ -34,6 +34,7 @@ struct DeviceState {
     void *stage_dst = nullptr; size_t stage_dst_bytes = 0;
     SwsFramePtrs *d_frames = nullptr, *h_frames = nullptr; int frames_cap = 0, frames_valid = 0;
     void *casc_img = nullptr; size_t casc_bytes = 0; int casc_stride = 0;
+    void *slice_img = nullptr; size_t slice_bytes = 0;   // source image assembled from sws_scale() slices (scaled path)
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timing = false; bool timed = false;
 };
 
@@ -71,6 +72,7 @@ void dev_release(SwsInternal *c)
     if (d->d_frames) (void)hipFree(d->d_frames);
     if (d->h_frames) (void)hipHostFree(d->h_frames);
     if (d->casc_img) (void)hipFree(d->casc_img);
+    if (d->slice_img) (void)hipFree(d->slice_img);
     if (d->d_tilegeom) (void)hipFree(d->d_tilegeom);
     if (d->d_dot2) (void)hipFree(d->d_dot2);
     if (d->d_march) (void)hipFree(d->d_march);
@@ -1066,6 +1068,84 @@ static int check_image_pointers(const uint8_t *const data[4], int fmt, const int
     return 1;
 }
 
+// Slices on the scaled path (scale_internal swscale.c:1076-1104, ff_swscale :372-381, :404-470, :566).
+// The reference pulls destination rows as soon as the ring buffer holds the source rows they need and returns how many
+// it produced.  Here the slices are assembled into a context-owned device copy of the source picture, the return
+// value of every call is the count the reference's cursor logic gives, and the picture is converted in one go when
+// the last slice arrives (rows become valid then).  Bottom-up sequences are the reference's flipped image
+// (negative strides on both sides), so the result is flip(scale(flip(src))) exactly as there.
+static int scale_slice(SwsInternal *c, const uint8_t *const src[], const int srcStride[], int srcSliceY, int srcSliceH,
+                       uint8_t *const dst[], const int dstStride[])
+{
+    const SwsContext &o = c->opts;
+    if (c->sliceDir == 0 && srcSliceY != 0 && srcSliceY + srcSliceH != o.src_h) {
+        log_msg(c, 0, "Slices start in the middle!\n");                       // swscale.c:1096-1099
+        return SWS_AVERROR(EINVAL);
+    }
+    if (c->sliceDir == 0) c->sliceDir = srcSliceY == 0 ? 1 : -1;
+    const int yint = c->sliceDir == 1 ? srcSliceY : o.src_h - srcSliceY - srcSliceH;   // srcSliceY_internal (:1158)
+    int ret = dev_prepare(c);
+    if (ret < 0) return ret;
+    DeviceState *d = c->dev;
+    HIPCHK(hipSetDevice(d->device));
+    hipStream_t st = d->stream;
+    int ls[4]; size_t offs[4], total;
+    image_layout(o.src_format, o.src_w, o.src_h, 256, ls, offs, &total);
+    if (total > d->slice_bytes) {
+        if (d->slice_img) HIPCHK(hipFree(d->slice_img));
+        d->slice_img = nullptr; d->slice_bytes = 0;
+        HIPCHK(hipMalloc(&d->slice_img, total));
+        d->slice_bytes = total;
+    }
+    const int nps = pix_nb_planes(pix_desc(o.src_format));
+    const bool src_dev = is_device_ptr(src[0]);
+    for (int k = 0; k < nps; k++) {
+        int rb, prow; plane_geometry(o.src_format, o.src_w, o.src_h, k, &rb, &prow);
+        int y0, rows; rows_of_slice(o.src_format, k, srcSliceY, srcSliceH, &y0, &rows);
+        uint8_t *dp = (uint8_t *)d->slice_img + offs[k] + (size_t)y0 * ls[k];
+        const hipMemcpyKind kind = src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        if (srcStride[k] >= rb) HIPCHK(hipMemcpy2DAsync(dp, ls[k], src[k], srcStride[k], rb, rows, kind, st));
+        else for (int y = 0; y < rows; y++) HIPCHK(hipMemcpyAsync(dp + (size_t)y * ls[k], src[k] + (int64_t)y * srcStride[k], rb, kind, st));
+    }
+    if (!src_dev) HIPCHK(hipStreamSynchronize(st));                            // the caller may reuse its slice buffer
+    // ---- the reference's cursor: how many destination rows this slice completes ----
+    if (yint == 0) c->slice_dstY = 0;
+    const int last = c->slice_dstY;
+    int dstY = last;
+    const int cvs = c->chrDstVSubSample;
+    for (; dstY < o.dst_h; dstY++) {
+        const int chrDstY = dstY >> cvs;
+        const int firstLum2 = std::max(1 - c->vLum.size, c->vLum.pos[std::min(dstY | ((1 << cvs) - 1), o.dst_h - 1)]);
+        const int firstChr = std::max(1 - c->vChr.size, c->vChr.pos[chrDstY]);
+        const int lastLum2 = std::min(o.src_h, firstLum2 + c->vLum.size) - 1;
+        const int lastChr = std::min(c->chrSrcH, firstChr + c->vChr.size) - 1;
+        const bool enough = lastLum2 < yint + srcSliceH && lastChr < -((-(yint + srcSliceH)) >> c->chrSrcVSubSample);
+        if (!enough) break;
+    }
+    c->slice_dstY = dstY;
+    if (yint + srcSliceH == o.src_h) {                                         // sequence complete (:1189-1190): convert
+        const bool flip = c->sliceDir == -1;
+        c->sliceDir = 0;
+        const uint8_t *s4[4] = { nullptr, nullptr, nullptr, nullptr };
+        uint8_t *d4[4] = { nullptr, nullptr, nullptr, nullptr };
+        int ss4[4] = { 0, 0, 0, 0 }, ds4[4] = { 0, 0, 0, 0 };
+        const int npd = pix_nb_planes(pix_desc(o.dst_format));
+        for (int k = 0; k < nps; k++) {
+            int rb, prow; plane_geometry(o.src_format, o.src_w, o.src_h, k, &rb, &prow);
+            s4[k] = (const uint8_t *)d->slice_img + offs[k] + (flip ? (size_t)(prow - 1) * ls[k] : 0);
+            ss4[k] = flip ? -ls[k] : ls[k];
+        }
+        for (int k = 0; k < npd; k++) {
+            int rb, prow; plane_geometry(o.dst_format, o.dst_w, o.dst_h, k, &rb, &prow);
+            d4[k] = dst[k] + (flip ? (int64_t)(prow - 1) * dstStride[k] : 0);
+            ds4[k] = flip ? -dstStride[k] : dstStride[k];
+        }
+        ret = run_single(c, s4, ss4, 0, o.src_h, d4, ds4);
+        if (ret < 0) return ret;
+    }
+    return dstY - last;
+}
+
 extern "C" {
 
 int sws_scale(SwsContext *sws, const uint8_t *const srcSlice[], const int srcStride[], int srcSliceY,
@@ -1098,10 +1178,11 @@ int sws_scale(SwsContext *sws, const uint8_t *const srcSlice[], const int srcStr
     }
     if (srcSliceH == 0) return 0;               // :1072-1074
     const bool whole = srcSliceY == 0 && srcSliceH == sws->src_h;
-    if (!whole && (c->plan == PLAN_MAIN || c->plan == PLAN_CASCADE)) {
-        log_msg(c, 0, "slice-wise sws_scale() on the scaled path is not implemented on the HIP path; pass whole frames\n");
+    if (!whole && c->plan == PLAN_CASCADE) {
+        log_msg(c, 0, "slice-wise sws_scale() through a cascade is not implemented on the HIP path; pass whole frames\n");
         return SWS_AVERROR(ENOTSUP);
     }
+    if (c->plan == PLAN_MAIN && (!whole || c->sliceDir != 0)) return scale_slice(c, srcSlice, srcStride, srcSliceY, srcSliceH, dst, dstStride);
     const uint8_t *s4[4] = { srcSlice[0], nullptr, nullptr, nullptr };
     uint8_t *d4[4] = { dst[0], nullptr, nullptr, nullptr };
     int ss4[4] = { srcStride[0], 0, 0, 0 }, ds4[4] = { dstStride[0], 0, 0, 0 };
@@ -1113,13 +1194,7 @@ int sws_scale(SwsContext *sws, const uint8_t *const srcSlice[], const int srcStr
 
 static int frame_matches(const SwsInternal *c, const SwsFrameView *f, bool is_src)
 {
-    int fmt = f->format;
-    // the context stores canonicalised formats (yuvj420p -> yuv420p, bgr0 -> bgra)
-    if (fmt == AV_PIX_FMT_YUVJ420P) fmt = AV_PIX_FMT_YUV420P;
-    if (fmt == AV_PIX_FMT_BGR0) fmt = AV_PIX_FMT_BGRA;
-    if (fmt == AV_PIX_FMT_RGB0) fmt = AV_PIX_FMT_RGBA;
-    if (fmt == AV_PIX_FMT_0BGR) fmt = AV_PIX_FMT_ABGR;
-    if (fmt == AV_PIX_FMT_0RGB) fmt = AV_PIX_FMT_ARGB;
+    const int fmt = canonical_pix_fmt(f->format); // the context stores canonicalised formats (yuvj420p -> yuv420p, bgr0 -> bgra)
     const SwsContext &o = c->opts;
     return is_src ? (fmt == o.src_format && f->width == o.src_w && f->height == o.src_h)
                   : (fmt == o.dst_format && f->width == o.dst_w && f->height == o.dst_h);
@@ -1130,8 +1205,10 @@ int sws_scale_frame(SwsContext *sws, SwsFrameView *dstf, const SwsFrameView *src
     if (!sws || !dstf || !srcf) return SWS_AVERROR(EINVAL);
     SwsInternal *c = internal(sws);
     if (!c->legacy_init) {
-        log_msg(c, 0, "sws_scale_frame(): dynamic (uninitialised) contexts are not implemented; call sws_init_context() first\n");
-        return SWS_AVERROR(ENOTSUP);
+        // dynamic mode (swscale.c:1405-1480): the context is (re)configured from the frames; flags, scaler parameters,
+        // dither and the range fields of the context apply as set by the caller
+        int r = init_from_frames(c, srcf->width, srcf->height, srcf->format, dstf->width, dstf->height, dstf->format);
+        if (r < 0) return r;
     }
     if (!frame_matches(c, srcf, true) || !frame_matches(c, dstf, false)) return SWS_AVERROR(EINVAL);
     const SwsFrameView *s1[1] = { srcf };
@@ -1145,7 +1222,11 @@ int sws_scale_frames(SwsContext *sws, SwsFrameView *const dst[], const SwsFrameV
     if (!sws || !dst || !src || nb_frames < 0) return SWS_AVERROR(EINVAL);
     if (!nb_frames) return 0;
     SwsInternal *c = internal(sws);
-    if (!c->legacy_init) return SWS_AVERROR(EINVAL);
+    if (!c->legacy_init) {
+        if (!src[0] || !dst[0]) return SWS_AVERROR(EINVAL);
+        int r = init_from_frames(c, src[0]->width, src[0]->height, src[0]->format, dst[0]->width, dst[0]->height, dst[0]->format);
+        if (r < 0) return r;
+    }
     for (int i = 0; i < nb_frames; i++) {
         if (!src[i] || !dst[i]) return SWS_AVERROR(EINVAL);
         if (!frame_matches(c, src[i], true) || !frame_matches(c, dst[i], false)) return SWS_AVERROR(EINVAL);

@@ -75,12 +75,18 @@ enum PlanKind {
     PLAN_CASCADE,          // two contexts through an intermediate image
 };
 
+int init_from_frames(struct SwsInternal *c, int sw, int sh, int sfmt, int dw, int dh, int dfmt);
+int canonical_pix_fmt(int fmt); // handle_jpeg + handle_0alpha aliases (utils.c:773-842)
+
 struct DeviceState;  // HIP side (device.cpp)
 
 struct SwsInternal {
     SwsContext opts;          // MUST be first: the public struct (swscale_internal.h:337-340 idiom)
     uint32_t magic;
     bool legacy_init = false;
+    bool dynamic_init = false;    // configured from the frames of sws_scale_frame() (swscale.c:1405-1480)
+    int sliceDir = 0;             // 0 = no slice sequence in progress, 1 = top-down, -1 = bottom-up (swscale.c:1096-1104)
+    int slice_dstY = 0;           // ff_swscale's dstY cursor (swscale.c:372-381, :566)
     int src0Alpha = 0, dst0Alpha = 0;
     int brightness = 0, contrast = 0, saturation = 0;
     int srcColorspaceTable[4] = {0}, dstColorspaceTable[4] = {0};

@@ -301,6 +301,11 @@ class SwsContext:
         dp, ds = dst.ptrs()
         return self.L.sws_scale(self.c, sp, ss, slice_y, self.sh if slice_h is None else slice_h, dp, ds)
 
+    def scale_frame(self, src, dst):
+        """sws_scale_frame(); on an sws_alloc_context()ed context (empty=True) the library configures itself from the frames."""
+        sv, dv = src.view(), dst.view()
+        return self.L.sws_scale_frame(self.c, C.byref(dv), C.byref(sv))
+
     def scale_frames(self, srcs, dsts):
         n = len(srcs)
         sv = [s.view() for s in srcs]

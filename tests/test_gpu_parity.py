@@ -202,6 +202,103 @@ def test_unscaled_converters_accept_slices(sfmt, dfmt, fl):
             assert np.array_equal(a[:, :rb], b[:, :rb]), (sfmt, dfmt, order, i)
 
 
+SLICED_SCALED = [
+    (96, 80, "yuv420p", 48, 40, "yuv420p", SWS_BILINEAR | BX), (96, 80, "yuv420p", 130, 100, "rgb24", SWS_BICUBIC | BX),
+    (96, 80, "yuv420p10le", 64, 48, "p010le", SWS_LANCZOS | BX), (96, 80, "nv12", 96, 80, "bgra", SWS_BICUBIC | BX | AR),
+    (96, 80, "rgb24", 64, 120, "yuv444p", SWS_BICUBIC | BX), (96, 80, "yuv410p", 96, 80, "yuv420p", SWS_BICUBIC | BX),
+]
+
+
+def _flip_frame(fr):
+    out = OL.Frame(fr.fmt, fr.w, fr.h)
+    for a, b in zip(out.planes, fr.planes):
+        a[:] = b[::-1]
+    return out
+
+
+@pytest.mark.parametrize("case", SLICED_SCALED, ids=[f"{c[2]}-{c[5]}-{c[3]}x{c[4]}" for c in SLICED_SCALED])
+@pytest.mark.parametrize("bottom_up", [False, True], ids=["topdown", "bottomup"])
+def test_scaled_path_accepts_slices(case, bottom_up):
+    """sws_scale() slice sequences on the scaled path (swscale.c:1076-1104): the assembled picture equals the whole-frame
+    result (for bottom-up sequences: the reference's flipped picture), and the per-call return values add up to dstH."""
+    sw, sh, sfmt, dw, dh, dfmt, flags = case
+    o = OL.Oracle(sw, sh, sfmt, dw, dh, dfmt, flags)
+    assert o.path() == "main"
+    src = OL.fill_random(OL.Frame(sfmt, sw, sh), 31)
+    ref = OL.Frame(dfmt, dw, dh)
+    if bottom_up:       # flip(scale(flip(src)))
+        tmp = OL.Frame(dfmt, dw, dh)
+        assert o.scale(_flip_frame(src), tmp) == dh
+        ref = _flip_frame(tmp)
+    else:
+        assert o.scale(src, ref) == dh
+    p = SwsContext(sw, sh, sfmt, dw, dh, dfmt, flags)
+    hs = HostFrame(sfmt, sw, sh)
+    for a, b in zip(hs.planes, src.planes):
+        a[:] = b
+    import torch
+    cuts = [(0, 32), (32, 16), (48, 32)]
+    if bottom_up:
+        cuts = cuts[::-1]
+    for device_src in (True, False):
+        ds = DeviceFrame(sfmt, sw, sh).upload(hs)
+        dd = DeviceFrame(dfmt, dw, dh)
+        dd.buf.fill_(0x5A)
+        torch.cuda.synchronize()
+        dp, dstr = dd.ptrs()
+        rets = []
+        for (y0, n) in cuts:
+            if device_src:
+                sp, ss = _slice_ptrs(ds, sfmt, y0)
+            else:
+                import ctypes as C
+                _, kind, _, lh, _ = OL._FORMATS[sfmt]
+                sp, ss = (C.c_void_p * 4)(), (C.c_int * 4)()
+                for i, a in enumerate(hs.planes):
+                    rows = y0 if (i == 0 or kind in ("rgbp", "packed", "gray")) else (y0 >> lh)
+                    sp[i] = a.ctypes.data + rows * a.strides[0]
+                    ss[i] = a.strides[0]
+            rets.append(p.L.sws_scale(p.c, sp, ss, y0, n, dp, dstr))
+        p.sync()
+        assert all(r >= 0 for r in rets) and sum(rets) == dh, rets
+        if not bottom_up and dh <= sh:
+            assert rets[0] < dh and rets[0] > 0          # rows are released as their source rows arrive
+        out = dd.download()
+        for i, (a, b) in enumerate(zip(out.planes, ref.planes)):
+            rb = out.row_bytes[i]
+            assert np.array_equal(a[:, :rb], b[:, :rb]), (case, bottom_up, device_src, i)
+    # a slice that starts in the middle without a sequence in progress is refused like the reference does
+    sp, ss = _slice_ptrs(ds, sfmt, 16)
+    assert p.L.sws_scale(p.c, sp, ss, 16, 16, dp, dstr) == -22
+
+
+def test_sws_scale_frame_configures_itself_from_the_frames():
+    """dynamic mode of sws_scale_frame()/sws_scale_frames() (swscale.c:1405-1480): sws_alloc_context() + flags, no init call;
+    a change of geometry re-configures the context; sws_scale() keeps refusing such a context (:1633)."""
+    import torch
+    p = SwsContext(0, 0, "yuv420p", 0, 0, "yuv420p", 0, empty=True)
+    p.fields().flags = SWS_BICUBIC | BX
+    for (sw, sh, sfmt, dw, dh, dfmt) in [(96, 64, "yuv420p", 64, 40, "rgb24"), (128, 72, "nv12", 128, 72, "bgra"), (96, 64, "yuv420p", 64, 40, "rgb24")]:
+        src = OL.fill_random(OL.Frame(sfmt, sw, sh), 41)
+        ref = OL.Frame(dfmt, dw, dh)
+        assert OL.Oracle(sw, sh, sfmt, dw, dh, dfmt, SWS_BICUBIC | BX).scale(src, ref) == dh
+        hs = HostFrame(sfmt, sw, sh)
+        for a, b in zip(hs.planes, src.planes):
+            a[:] = b
+        ds = DeviceFrame(sfmt, sw, sh).upload(hs)
+        dd = DeviceFrame(dfmt, dw, dh)
+        torch.cuda.synchronize()
+        assert p.scale_frame(ds, dd) == dh
+        p.sync()
+        out = dd.download()
+        for i, (a, b) in enumerate(zip(out.planes, ref.planes)):
+            assert np.array_equal(a[:, :out.row_bytes[i]], b[:, :out.row_bytes[i]])
+        assert p.scale_frames([ds, ds], [dd, dd]) == 2
+        sp, ss = ds.ptrs()
+        dp, dstr = dd.ptrs()
+        assert p.L.sws_scale(p.c, sp, ss, 0, sh, dp, dstr) == -22
+
+
 PACKED_RGB = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "bgr0", "0rgb", "0bgr"]
 
 
