@@ -179,10 +179,6 @@ int init_single_context(SwsInternal *c)
     }
     if (alg == SWS_FAST_BILINEAR) {                                             // :1226-1232
         if (srcW < 8 || dstW <= 8) { alg = SWS_BILINEAR; flags ^= SWS_FAST_BILINEAR | alg; o->flags = flags; }
-        else if (!unscaled) {
-            log_msg(c, 0, "SWS_FAST_BILINEAR horizontal scaler is not implemented on the HIP path\n");
-            return SWS_AVERROR(ENOTSUP);
-        }
     }
     const SwsScaler sub = o->scaler_sub ? o->scaler_sub : o->scaler;
     const int lum_scaler = scaler_from_enum(o->scaler, alg == SWS_BICUBLIN ? SWS_BICUBIC : alg);

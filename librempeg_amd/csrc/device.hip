@@ -201,6 +201,8 @@ int dev_prepare(SwsInternal *c)
         p.shiftU = dd->comp[1].depth + dd->comp[1].shift - ds->comp[1].depth - ds->comp[1].shift;
         p.shiftV = dd->comp[2].depth + dd->comp[2].shift - ds->comp[2].depth - ds->comp[2].shift;
     }
+    p.fast_bilinear = (o.flags & SWS_FAST_BILINEAR) && c->srcBpc == 8 && c->dstBpc <= 14;   // swscale.c:676-681
+    p.lumXInc = c->lumXInc; p.chrXInc = c->chrXInc;
     p.copy_depth_src = ds->comp[0].depth; p.copy_depth_dst = dd->comp[0].depth;
     p.copy_shift_src = ds->comp[0].shift; p.copy_shift_dst = dd->comp[0].shift;
     p.copy_shiftonly_luma = !o.src_range;
@@ -234,7 +236,8 @@ int dev_prepare(SwsInternal *c)
         p.hChrF = (const int16_t *)(b + offs_t[1]); p.hChrPos = (const int32_t *)(b + offs_p[1]); p.hChrFs = c->hChr.size;
         p.vLumF = (const int16_t *)(b + offs_t[2]); p.vLumPos = (const int32_t *)(b + offs_p[2]); p.vLumFs = c->vLum.size;
         p.vChrF = (const int16_t *)(b + offs_t[3]); p.vChrPos = (const int32_t *)(b + offs_p[3]); p.vChrFs = c->vChr.size;
-        d->unity_h = bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14);
+        // the fast-bilinear chroma function weighs with (xalpha ^ 127): not the identity even at equal widths
+        d->unity_h = bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14) && !p.fast_bilinear;
         d->unity_v = bank_is_identity(c->vLum, 1 << 12) && bank_is_identity(c->vChr, 1 << 12);
         // ---- wave-marching fused kernel (sws_k_march_dot2): same coverage as the dot2 tile kernel, preferred ----
         d->march_ok = false;
@@ -244,7 +247,7 @@ int dev_prepare(SwsInternal *c)
             auto fs4 = [](int fs) { return (fs + 3 + 3) & ~3; };
             auto fs2 = [](int fs) { return (fs + 2) & ~1; };
             auto monotone = [](const FilterBank &b) { for (int i = 1; i < b.count; i++) if (b.pos[i] < b.pos[i - 1]) return false; return true; };
-            if (!d->unity_h && src_ok && dst_ok && !p.wide && c->vLum.size >= 2 && c->vChr.size >= 2 &&
+            if (!d->unity_h && !p.fast_bilinear && src_ok && dst_ok && !p.wide && c->vLum.size >= 2 && c->vChr.size >= 2 &&
                 fs4(c->hLum.size) <= 16 && fs4(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && fs2(c->vChr.size) <= 16 &&
                 monotone(c->vLum) && monotone(c->vChr) && std::getenv("SWS_HIP_MARCH")) { // opt-in: the tile kernel is faster today
                 const int SPC = p.srcKind == SRCK_PLANAR16 ? 8 : 16;
@@ -300,7 +303,7 @@ int dev_prepare(SwsInternal *c)
             const bool src_ok = p.srcKind == SRCK_PLANAR8 || (p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15);
             const bool dst_ok = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010;
             auto fs2 = [](int fs) { return (fs + 2) & ~1; };
-            if (!d->unity_h && src_ok && dst_ok && !p.wide && c->vLum.size >= 2 && c->vChr.size >= 2 &&
+            if (!d->unity_h && !p.fast_bilinear && src_ok && dst_ok && !p.wide && c->vLum.size >= 2 && c->vChr.size >= 2 &&
                 fs2(c->hLum.size) <= 16 && fs2(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && fs2(c->vChr.size) <= 16 &&
                 !std::getenv("SWS_HIP_NO_DOT2")) {
                 const int SPC = p.srcKind == SRCK_PLANAR16 ? 8 : 16;
@@ -368,7 +371,7 @@ int dev_prepare(SwsInternal *c)
         }
         // ---- fused h+v tile kernel geometry (planar / semi-planar YUV outputs, non-identity horizontal filters) ----
         d->tile_ok = false;
-        if (!d->unity_h && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16 ||
+        if (!d->unity_h && !p.fast_bilinear && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16 ||
                             p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010) && !std::getenv("SWS_HIP_NO_TILE")) {
             const size_t hsz = p.wide ? 4 : 2;
             auto plan = [&](const FilterBank &hb, const FilterBank &vb, int W, int H, int sW, int sH, int ncomp,

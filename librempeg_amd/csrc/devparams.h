@@ -113,4 +113,7 @@ struct SwsDevParams {
     int32_t copy_depth_src, copy_depth_dst, copy_shift_src, copy_shift_dst, copy_shiftonly_luma;
     int32_t dither_mode;              // SwsDither for planarCopy depth reduction
     int32_t src_range;
+    // SWS_FAST_BILINEAR with 8-bit sources and <= 14-bit intermediates: ff_hyscale_fast_c / ff_hcscale_fast_c
+    // (hscale_fast_bilinear.c:23-55) replace the polyphase horizontal stage
+    int32_t fast_bilinear, lumXInc, chrXInc;
 };

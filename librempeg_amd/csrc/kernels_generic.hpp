@@ -128,6 +128,18 @@ __device__ __forceinline__ int range_sample(const SwsDevParams &p, int v, int ch
 // horizontal stage for one output sample (hScale8To15_c / 8To19 / 16To15 / 16To19, swscale.c:69-159)
 __device__ __forceinline__ int hscale_sample(const SwsDevParams &p, const SwsFramePtrs &f, int comp, int row, int x)
 {
+    if (p.fast_bilinear) {   // ff_hyscale_fast_c / ff_hcscale_fast_c, hscale_fast_bilinear.c:23-55
+        const int sW = comp == 0 ? p.srcW : p.chrSrcW;
+        const uint32_t xpos = (uint32_t)x * (uint32_t)(comp == 0 ? p.lumXInc : p.chrXInc);
+        const int xx = (int)(xpos >> 16), xalpha = (int)((xpos & 0xFFFF) >> 9);
+        int r;
+        if (xx >= sW - 1) r = read_sample(p, f, comp, row, sW - 1) * 128;        // the tail loop of the reference
+        else {
+            const int a = read_sample(p, f, comp, row, xx), b = read_sample(p, f, comp, row, xx + 1);
+            r = comp == 0 ? (a << 7) + (b - a) * xalpha : a * (xalpha ^ 127) + b * xalpha;
+        }
+        return range_sample(p, (int16_t)r, comp != 0);
+    }
     const int16_t *filter = comp == 0 ? p.hLumF : p.hChrF;
     const int32_t *pos = comp == 0 ? p.hLumPos : p.hChrPos;
     const int fs = comp == 0 ? p.hLumFs : p.hChrFs;

@@ -799,7 +799,6 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
     else if (i & (i - 1)) return -1;
     if (i == OR_SWS_FAST_BILINEAR) {
         if (srcW < 8 || dstW <= 8) { i = OR_SWS_BILINEAR; flags ^= OR_SWS_FAST_BILINEAR | i; c->o.flags = flags; }
-        else return -1; /* fast bilinear hscale not restated */
     }
     lum_scaler = i == OR_SWS_BICUBLIN ? OR_SWS_BICUBIC : i;
     chr_scaler = i == OR_SWS_BICUBLIN ? OR_SWS_BILINEAR : i;
@@ -1542,6 +1541,22 @@ static void hscale_line(const OrSws *c, int32_t *dst, int dstW, const uint8_t *s
     const int depth = ds->c[0].depth;
     const int rgbish = isAnyRGB(c->o.src_format);
     int i, j;
+    if (c->srcBpc == 8 && c->dstBpc <= 14 && (c->o.flags & OR_SWS_FAST_BILINEAR)) {
+        /* ff_hyscale_fast_c / ff_hcscale_fast_c (hscale_fast_bilinear.c:23-55), selected in sws_init_swscale (swscale.c:676-681) */
+        const int chroma = filter == c->hChrFilter && filterPos == c->hChrFilterPos;
+        const int srcW = chroma ? c->chrSrcW : c->o.src_w;
+        const unsigned xInc = (unsigned)(chroma ? c->chrXInc : c->lumXInc);
+        unsigned xpos = 0;
+        for (i = 0; i < dstW; i++) {
+            const unsigned xx = xpos >> 16, xalpha = (xpos & 0xFFFF) >> 9;
+            if ((int)xx < srcW - 1)   /* the tail loop below overwrites every other position */
+                dst[i] = chroma ? (int16_t)(src[xx] * (xalpha ^ 127) + src[xx + 1] * xalpha)
+                                : (int16_t)((src[xx] << 7) + (src[xx + 1] - src[xx]) * xalpha);
+            xpos += xInc;
+        }
+        for (i = dstW - 1; i >= 0 && ((i * (int64_t)xInc) >> 16) >= srcW - 1; i--) dst[i] = src[srcW - 1] * 128;
+        return;
+    }
     if (c->srcBpc == 8) {
         for (i = 0; i < dstW; i++) {
             int val = 0, sp = filterPos[i];

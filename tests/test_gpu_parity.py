@@ -202,6 +202,19 @@ def test_unscaled_converters_accept_slices(sfmt, dfmt, fl):
             assert np.array_equal(a[:, :rb], b[:, :rb]), (sfmt, dfmt, order, i)
 
 
+@pytest.mark.parametrize("geom", [(97, 61, 160, 90), (160, 90, 53, 31), (64, 48, 64, 96), (64, 48, 128, 48), (352, 288, 200, 100), (40, 8, 72, 8)],
+                         ids=["up", "down", "vonly", "honly", "cif", "wide"])
+def test_fast_bilinear(geom):
+    """SWS_FAST_BILINEAR: ff_hyscale_fast_c / ff_hcscale_fast_c (hscale_fast_bilinear.c:23-55) for 8-bit sources with
+    <= 14-bit intermediates, the 2-tap `fast bilinear` initFilter branch (utils.c:244-267) everywhere else."""
+    sw, sh, dw, dh = geom
+    FB = OL.SWS_FAST_BILINEAR
+    for sfmt, dfmt in (("yuv420p", "yuv420p"), ("yuv422p", "nv12"), ("nv12", "rgb24"), ("yuv420p", "bgra"), ("yuv444p", "yuv420p10le"),
+                       ("yuv420p", "yuv444p16le"), ("yuv420p10le", "yuv420p"), ("rgb24", "yuv420p"), ("yuv410p", "gbrp")):
+        run_case(sw, sh, sfmt, dw & ~1, dh, dfmt, FB | BX, seed=sw)
+        run_case(sw, sh, sfmt, dw & ~1, dh, dfmt, FB, seed=sw + 1)
+
+
 SLICED_SCALED = [
     (96, 80, "yuv420p", 48, 40, "yuv420p", SWS_BILINEAR | BX), (96, 80, "yuv420p", 130, 100, "rgb24", SWS_BICUBIC | BX),
     (96, 80, "yuv420p10le", 64, 48, "p010le", SWS_LANCZOS | BX), (96, 80, "nv12", 96, 80, "bgra", SWS_BICUBIC | BX | AR),
