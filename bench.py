@@ -90,15 +90,24 @@ def make_context(name, rank, world, device_index):
     if world > 1:
         # one-off broadcast of the table blob (filters, LUT constants, plan) from rank 0 over RCCL/xGMI
         import torch.distributed as dist
-        blob = ctx.export_tables() if rank == 0 else b""
-        n = torch.tensor([len(blob)], dtype=torch.int64, device=f"cuda:{device_index}")
-        dist.broadcast(n, 0)
-        buf = torch.empty(int(n.item()), dtype=torch.uint8, device=f"cuda:{device_index}")
-        if rank == 0:
-            buf.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
-        dist.broadcast(buf, 0)
-        if rank != 0:
-            ctx.import_tables(bytes(buf.cpu().numpy().tobytes()))
+        try:
+            blob = ctx.export_tables() if rank == 0 else b""
+            tdev = "cpu" if dist.get_backend() == "gloo" else f"cuda:{device_index}"
+            n = torch.tensor([len(blob)], dtype=torch.int64, device=tdev)
+            dist.broadcast(n, 0)
+            buf = torch.empty(int(n.item()), dtype=torch.uint8, device=tdev)
+            if rank == 0:
+                buf.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+            dist.broadcast(buf, 0)
+            if rank != 0:
+                ctx.import_tables(bytes(buf.cpu().numpy().tobytes()))
+        except Exception as e:  # the tables are a pure function of the options: every rank can also build them itself
+            print(f"[bench rank {rank}] table broadcast failed ({e!r}); building the tables locally", file=sys.stderr, flush=True)
+            if rank != 0:
+                ctx.close()
+                ctx = SwsContext(sw, sh, sf, dw, dh, df, flags, device=device_index)
+                if cs:
+                    assert ctx.set_colorspace(*cs) >= 0
     return ctx
 
 
@@ -206,11 +215,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X (no CPU fallback in the product path)")
+    # test hooks (single-GPU boxes): BENCH_DEVICE pins every rank to one device, BENCH_DIST_BACKEND=gloo avoids RCCL's
+    # one-rank-per-GPU rule.  The driver's runs use neither: one rank per GPU over RCCL.
+    if "BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["BENCH_DEVICE"])
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
 
         def barrier():
             dist.barrier()
@@ -227,7 +244,7 @@ def main():
         if world == 1:
             return x
         import torch.distributed as dist
-        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -254,7 +271,8 @@ def main():
                       else f"Mpixels/sec sws_scale {main_res['name']}",
             "value": round(mpix, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8" if "10" not in main_res["name"] else "u16", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"c3a": "u16", "c3b": "u16 (int32 accumulate)", "c5": "f32->int32"}.get(main_res["name"], "u8"),
+            "data": "synthetic",
             "config": {"workload": main_res["desc"], "frames_per_step_per_gpu": main_res["batch"],
                        "path": main_res["path"], "sharding": f"frames x{world} (one rank per GPU, no data-path collective)",
                        "frames_resident": "HBM"},
