@@ -34,6 +34,25 @@ def vsynth_frame():
     return f
 
 
+def vsynth_yuv444_pictures(n=2):
+    """fate-filter-scalechroma reads tests/data/vsynth1.yuv (the yuv420p videogen stream) as 352x288 *yuv444p* pictures
+    (tests/fate/filter-video.mak:533-535): picture k is bytes [k*304128, (k+1)*304128) = videogen frames 2k and 2k+1."""
+    import lzma
+    raw = zlib.decompress(open(os.path.join(HERE, "golden", "vsynth1_f0_352x288.yuv420p.bin.z"), "rb").read()) + \
+        lzma.decompress(open(os.path.join(HERE, "golden", "vsynth1_f1-3_352x288.yuv420p.bin.xz"), "rb").read())
+    out = []
+    for k in range(n):
+        fr = OL.Frame("yuv444p", W, H)
+        d = np.frombuffer(raw[k * W * H * 3:(k + 1) * W * H * 3], np.uint8).reshape(3, H, W)
+        for i in range(3):
+            fr.planes[i][:, :W] = d[i]
+        out.append(fr)
+    return out
+
+
+SCALECHROMA_CRC = [0x77bb80f8, 0x3a21f6e8]   # tests/ref/fate/filter-scalechroma, frames 0 and 1
+
+
 def band_of(y):
     return 0 if 3 * y < H else (1 if 3 * y < 2 * H else 2)
 

@@ -26,3 +26,20 @@ def hip_convert(src, sfmt, dfmt, dither_none):
 @pytest.mark.parametrize("key,base,fmt", FP.cases(), ids=[c[0] for c in FP.cases()])
 def test_fate_pixfmt_md5_hip(key, base, fmt):
     assert FP.fate_pixfmt_md5(key, base, fmt, hip_convert) == FP.GOLDEN[key]["md5"]
+
+
+def test_fate_filter_scalechroma_crc_hip():
+    """tests/ref/fate/filter-scalechroma through the HIP library (see tests/test_oracle_fate_pixfmt.py)."""
+    import zlib
+    import oracle_lib as OL
+    for fr, want in zip(FP.vsynth_yuv444_pictures(), FP.SCALECHROMA_CRC):
+        ctx = SwsContext(FP.W, FP.H, "yuv444p", FP.W, FP.H, "yuv420p", OL.SWS_BICUBIC | OL.SWS_BITEXACT, dst_h_chr_pos=0, dst_v_chr_pos=256)
+        hs = HostFrame("yuv444p", FP.W, FP.H)
+        for a, b in zip(hs.planes, fr.planes):
+            a[:] = b
+        ds = DeviceFrame("yuv444p", FP.W, FP.H).upload(hs)
+        dd = DeviceFrame("yuv420p", FP.W, FP.H)
+        torch.cuda.synchronize()
+        assert ctx.scale(ds, dd) == FP.H
+        ctx.sync()
+        assert zlib.adler32(dd.download().visible(), 0) & 0xFFFFFFFF == want

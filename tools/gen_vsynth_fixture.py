@@ -18,3 +18,9 @@ assert len(data) % fsz == 0
 dst = os.path.join(root, "tests", "golden", "vsynth1_f0_352x288.yuv420p.bin.z")
 open(dst, "wb").write(zlib.compress(data[:fsz], 9))
 print("wrote", dst, len(data[:fsz]), "bytes raw")
+# frames 1..3: together with frame 0 they are the first two 352x288 yuv444p pictures that fate-filter-scalechroma reads
+# out of the same byte stream (tests/fate/filter-video.mak:533-535)
+import lzma
+dst2 = os.path.join(root, "tests", "golden", "vsynth1_f1-3_352x288.yuv420p.bin.xz")
+open(dst2, "wb").write(lzma.compress(data[fsz:4 * fsz], preset=9 | lzma.PRESET_EXTREME))
+print("wrote", dst2, os.path.getsize(dst2), "bytes")
