@@ -61,6 +61,9 @@ enum AVPixelFormat {
     AV_PIX_FMT_YUV440P10LE = 151, AV_PIX_FMT_YUV440P12LE = 153, AV_PIX_FMT_P016LE = 169, AV_PIX_FMT_NV24 = 188,
     AV_PIX_FMT_NV42 = 189, AV_PIX_FMT_P210LE = 198, AV_PIX_FMT_P410LE = 200, AV_PIX_FMT_P216LE = 202,
     AV_PIX_FMT_P416LE = 204, AV_PIX_FMT_P012LE = 209, AV_PIX_FMT_P212LE = 222, AV_PIX_FMT_P412LE = 224,
+    /* gray (always full range, utils.c:791-805) */
+    AV_PIX_FMT_GRAY16LE = 30, AV_PIX_FMT_GRAY12LE = 166, AV_PIX_FMT_GRAY10LE = 168, AV_PIX_FMT_GRAY9LE = 173,
+    AV_PIX_FMT_GRAY14LE = 181,
     /* planar RGB 9..16 bit */
     AV_PIX_FMT_GBRP9LE = 73, AV_PIX_FMT_GBRP10LE = 75, AV_PIX_FMT_GBRP16LE = 77, AV_PIX_FMT_GBRP12LE = 135,
     AV_PIX_FMT_GBRP14LE = 137,

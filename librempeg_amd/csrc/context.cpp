@@ -54,7 +54,7 @@ static int jpeg_alias(int *format) // handle_jpeg, utils.c:773-809
     if (*format == AV_PIX_FMT_YUVJ422P) { *format = AV_PIX_FMT_YUV422P; return 1; }
     if (*format == AV_PIX_FMT_YUVJ444P) { *format = AV_PIX_FMT_YUV444P; return 1; }
     if (*format == AV_PIX_FMT_YUVJ440P) { *format = AV_PIX_FMT_YUV440P; return 1; }
-    if (*format == AV_PIX_FMT_GRAY8) return 1;
+    if (pix_desc(*format) && isGray(*format)) return 1;   // gray8 .. gray16: always full range (:791-805)
     return 0;
 }
 
@@ -90,11 +90,11 @@ static int scaler_from_enum(SwsScaler s, int fallback) // scaler_flag, utils.c:1
 // every descriptor row of pixdesc.cpp has a reader and a writer
 static bool fmt_supported_in(int f)
 {
-    return f != AV_PIX_FMT_GRAY8 && pix_desc(f) != nullptr;
+    return pix_desc(f) != nullptr;
 }
 static bool fmt_supported_out(int f)
 {
-    return f != AV_PIX_FMT_GRAY8 && pix_desc(f) != nullptr;
+    return pix_desc(f) != nullptr;
 }
 
 // ff_get_unscaled_swscale (swscale_unscaled.c:2392-2706): "last match wins"
@@ -135,6 +135,7 @@ void choose_unscaled(SwsInternal *c)
     if (isAnyRGB(s) && !isPlanarRGB(s) && d == AV_PIX_FMT_GBRP) k = PLAN_UNSC_PACKED_GBRP;             // rgbToPlanarRgbWrapper (:2542-2544)
     if (s == AV_PIX_FMT_GBRP && isAnyRGB(d) && !isPlanarRGB(d)) k = PLAN_UNSC_GBRP_PACKED;             // planarRgbToRgbWrapper (:2480-2481)
     if (s == d ||
+        (isFloatFmt(s) == isFloatFmt(d) && ((isPlanarYUV(s) && isGray(d)) || (isPlanarYUV(d) && isGray(s)) || (isGray(d) && isGray(s)))) ||
         (isFloatFmt(s) == isFloatFmt(d) && isPlanarYUV(s) && isPlanarYUV(d) &&
          c->chrDstHSubSample == c->chrSrcHSubSample && c->chrDstVSubSample == c->chrSrcVSubSample &&
          isSemiPlanarYUV(s) == isSemiPlanarYUV(d) && isSwappedChroma(s) == isSwappedChroma(d))) { // :2647-2668

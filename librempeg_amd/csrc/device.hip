@@ -97,7 +97,7 @@ static int src_kind_of(int f)
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? SRCK_GBRPF32 : d->comp[0].depth > 8 ? SRCK_GBRP16 : SRCK_GBRP;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? SRCK_RGB24 : SRCK_RGB32;
     if (isSemiPlanarYUV(f)) return d->comp[0].depth == 8 ? SRCK_NV12 : SRCK_P010;
-    if (isPlanarYUV(f)) return d->comp[0].depth == 8 ? SRCK_PLANAR8 : SRCK_PLANAR16;
+    if (isPlanarYUV(f) || isGray(f)) return d->comp[0].depth == 8 ? SRCK_PLANAR8 : SRCK_PLANAR16;
     return -1;
 }
 static int dst_kind_of(int f)
@@ -108,7 +108,7 @@ static int dst_kind_of(int f)
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? DSTK_RGB24 : DSTK_RGB32;
     const int depth = d->comp[0].depth;
     if (isSemiPlanarYUV(f)) return depth == 8 ? DSTK_NV12 : depth == 16 ? DSTK_P016 : DSTK_P010;
-    if (isPlanarYUV(f)) return depth == 8 ? DSTK_PLANAR8 : depth == 16 ? DSTK_PLANAR16 : DSTK_PLANARN;
+    if (isPlanarYUV(f) || isGray(f)) return depth == 8 ? DSTK_PLANAR8 : depth == 16 ? DSTK_PLANAR16 : DSTK_PLANARN;
     return -1;
 }
 
@@ -150,6 +150,7 @@ int dev_prepare(SwsInternal *c)
     p.uv_swap_src = isSwappedChroma(o.src_format); p.uv_swap_dst = isSwappedChroma(o.dst_format);
     p.u_plane_src = ds->comp[1].plane; p.v_plane_src = ds->comp[2].plane;
     p.u_plane_dst = dd->comp[1].plane; p.v_plane_dst = dd->comp[2].plane;
+    const bool gray_any = isGray(o.src_format) || isGray(o.dst_format);
     p.should_dither = isNBPS(o.src_format) || is16BPS(o.src_format);     // swscale.c:292-293
     p.full_chr = (o.flags & SWS_FULL_CHR_H_INT) ? 1 : 0;
     if (isAnyRGB(o.src_format) && !isPlanarRGB(o.src_format)) {
@@ -201,6 +202,7 @@ int dev_prepare(SwsInternal *c)
         p.shiftU = dd->comp[1].depth + dd->comp[1].shift - ds->comp[1].depth - ds->comp[1].shift;
         p.shiftV = dd->comp[2].depth + dd->comp[2].shift - ds->comp[2].depth - ds->comp[2].shift;
     }
+    p.no_chroma = isGray(o.src_format) || isGray(o.dst_format);                              // swscale.c:692-694
     p.fast_bilinear = (o.flags & SWS_FAST_BILINEAR) && c->srcBpc == 8 && c->dstBpc <= 14;   // swscale.c:676-681
     p.lumXInc = c->lumXInc; p.chrXInc = c->chrXInc;
     p.copy_depth_src = ds->comp[0].depth; p.copy_depth_dst = dd->comp[0].depth;
@@ -247,7 +249,7 @@ int dev_prepare(SwsInternal *c)
             auto fs4 = [](int fs) { return (fs + 3 + 3) & ~3; };
             auto fs2 = [](int fs) { return (fs + 2) & ~1; };
             auto monotone = [](const FilterBank &b) { for (int i = 1; i < b.count; i++) if (b.pos[i] < b.pos[i - 1]) return false; return true; };
-            if (!d->unity_h && !p.fast_bilinear && src_ok && dst_ok && !p.wide && c->vLum.size >= 2 && c->vChr.size >= 2 &&
+            if (!d->unity_h && !p.fast_bilinear && !gray_any && src_ok && dst_ok && !p.wide && c->vLum.size >= 2 && c->vChr.size >= 2 &&
                 fs4(c->hLum.size) <= 16 && fs4(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && fs2(c->vChr.size) <= 16 &&
                 monotone(c->vLum) && monotone(c->vChr) && std::getenv("SWS_HIP_MARCH")) { // opt-in: the tile kernel is faster today
                 const int SPC = p.srcKind == SRCK_PLANAR16 ? 8 : 16;
@@ -303,7 +305,7 @@ int dev_prepare(SwsInternal *c)
             const bool src_ok = p.srcKind == SRCK_PLANAR8 || (p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15);
             const bool dst_ok = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010;
             auto fs2 = [](int fs) { return (fs + 2) & ~1; };
-            if (!d->unity_h && !p.fast_bilinear && src_ok && dst_ok && !p.wide && c->vLum.size >= 2 && c->vChr.size >= 2 &&
+            if (!d->unity_h && !p.fast_bilinear && !gray_any && src_ok && dst_ok && !p.wide && c->vLum.size >= 2 && c->vChr.size >= 2 &&
                 fs2(c->hLum.size) <= 16 && fs2(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && fs2(c->vChr.size) <= 16 &&
                 !std::getenv("SWS_HIP_NO_DOT2")) {
                 const int SPC = p.srcKind == SRCK_PLANAR16 ? 8 : 16;
@@ -371,7 +373,7 @@ int dev_prepare(SwsInternal *c)
         }
         // ---- fused h+v tile kernel geometry (planar / semi-planar YUV outputs, non-identity horizontal filters) ----
         d->tile_ok = false;
-        if (!d->unity_h && !p.fast_bilinear && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16 ||
+        if (!d->unity_h && !p.fast_bilinear && !gray_any && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16 ||
                             p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010) && !std::getenv("SWS_HIP_NO_TILE")) {
             const size_t hsz = p.wide ? 4 : 2;
             auto plan = [&](const FilterBank &hb, const FilterBank &vb, int W, int H, int sW, int sH, int ncomp,
@@ -467,9 +469,9 @@ int dev_prepare(SwsInternal *c)
     case PLAN_CASCADE: c->path_name = "cascade"; c->kernel_name = ""; break;
     case PLAN_MAIN: {
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
-        if (d->unity_h && rgb_lut && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
+        if (d->unity_h && rgb_lut && !p.no_chroma && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             c->path_name = "main:fused_rgb_unity"; c->kernel_name = "sws_k_rgb_fused_unity_wave";
-        } else if (d->unity_h && d->unity_v && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 &&
+        } else if (d->unity_h && d->unity_v && !p.no_chroma && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 &&
                    (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16)) {
             c->path_name = "main:fused_f32rgb_yuv444"; c->kernel_name = "sws_k_f32rgb_to_yuv444_unity";
         } else if (d->unity_h) {
@@ -678,7 +680,9 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
                 if (pl == 1 && isSemiPlanarYUV(c->opts.dst_format)) len *= 2;
                 if (same) len *= (ds->comp[0].depth + 7) / 8;  // byte copy: width counts bytes
                 const int shiftonly = pl == 1 || pl == 2 || (!c->opts.src_range && pl == 0);
-                plan.pl[pl] = { pl, pl, len, h, y0, 1, shiftonly, pl != 0 };
+                const bool missing = pl > 0 && isGray(c->opts.src_format);   // fillPlane / fillPlane16 (:2239-2247); width in samples
+                if (missing && same) len /= (ds->comp[0].depth + 7) / 8;
+                plan.pl[pl] = { missing ? -1 : pl, pl, len, h, y0, 1, shiftonly, pl != 0 };
             }
         }
         for (int i = 0; i < plan.nplanes; i++) { maxw = std::max(maxw, plan.pl[i].width); rows += plan.pl[i].rows; }
@@ -764,7 +768,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 ||
                          p.dstKind == DSTK_GBRPF32;
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
-        if (d->unity_h && rgb_lut && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
+        if (d->unity_h && rgb_lut && !p.no_chroma && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;
             if (vec && !no_wave && d->all_x_mode && d->chr_window2 <= 8 && p.vChrFs <= 64) { // wave-tiled kernel: 1024 pixels x 2 rows per wave
                 constexpr int ROWS = 2;
@@ -789,7 +793,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
 #undef LAUNCH_FUSED
             break;
         }
-        if (vec && d->unity_h && d->unity_v && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 &&
+        if (vec && d->unity_h && d->unity_v && !p.no_chroma && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 &&
             (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16)) {
             const dim3 g(cdiv((int64_t)((p.srcW + 3) >> 2) * p.srcH, 256), 1, n);
             hipLaunchKernelGGL(swsk::sws_k_f32rgb_to_yuv444_unity, g, blk, 0, st, fs, p);
@@ -875,8 +879,9 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
                 const dim3 gc(cdiv(p.chrDstW, 256), p.chrDstH, m);
                 LAUNCH_W(sws_k_vscale_nvchroma, gc);
             } else {
-                const dim3 g(cdiv(std::max(p.dstW, p.chrDstW), 256), std::max(p.dstH, p.chrDstH), 3 * m);
-                LAUNCH_W(sws_k_vscale_planar, g, 3);
+                const int ncomp = isGray(c->opts.dst_format) ? 1 : 3;          // vscale.c:219-233: gray destinations have luma only
+                const dim3 g(cdiv(std::max(p.dstW, p.chrDstW), 256), std::max(p.dstH, p.chrDstH), ncomp * m);
+                LAUNCH_W(sws_k_vscale_planar, g, ncomp);
             }
 #undef LAUNCH_W
         }

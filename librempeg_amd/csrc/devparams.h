@@ -116,4 +116,7 @@ struct SwsDevParams {
     // SWS_FAST_BILINEAR with 8-bit sources and <= 14-bit intermediates: ff_hyscale_fast_c / ff_hcscale_fast_c
     // (hscale_fast_bilinear.c:23-55) replace the polyphase horizontal stage
     int32_t fast_bilinear, lumXInc, chrXInc;
+    // gray on either side: chroma is never h-scaled (needs_hcscale == 0, swscale.c:692-694); the vertical stage sees the
+    // ring buffer's initial value (fill_ones, slice.c:190-208): 1 << 14 (15-bit lines) or 1 << 18 (19-bit lines)
+    int32_t no_chroma;
 };

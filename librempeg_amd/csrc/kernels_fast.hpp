@@ -384,6 +384,10 @@ __global__ void __launch_bounds__(256) sws_k_planar_misc(SwsFrameSet fs, SwsDevP
             else       v = (A[cf] + 3 * B[cn]) >> 2;           // dst[2x+2] = A[x]+3B[x+1]; dst[2x+1] = A[x+1]+3B[x]
         }
         f.dst[P.dstPlane][(int64_t)yd * f.dstStride[P.dstPlane] + x] = (uint8_t)v;
+    } else if (P.srcPlane < 0) {      // planarCopyWrapper, plane missing in a gray source: fillPlane / fillPlane16 (:2239-2247)
+        uint8_t *drow = f.dst[P.dstPlane] + (int64_t)yd * f.dstStride[P.dstPlane];
+        if (p.copy_depth_dst > 8) ((uint16_t *)drow)[x] = (uint16_t)(1 << (p.copy_depth_dst - 1));
+        else drow[x] = 128;
     } else {                          // planarCopyWrapper
         const uint8_t *srow = f.src[P.srcPlane] + (int64_t)ys * f.srcStride[P.srcPlane];
         uint8_t *drow = f.dst[P.dstPlane] + (int64_t)yd * f.dstStride[P.dstPlane];

@@ -128,6 +128,7 @@ __device__ __forceinline__ int range_sample(const SwsDevParams &p, int v, int ch
 // horizontal stage for one output sample (hScale8To15_c / 8To19 / 16To15 / 16To19, swscale.c:69-159)
 __device__ __forceinline__ int hscale_sample(const SwsDevParams &p, const SwsFramePtrs &f, int comp, int row, int x)
 {
+    if (p.no_chroma && comp != 0) return p.wide ? 1 << 18 : 1 << 14;   // ff_init_desc_no_chr: fill_ones() value, never range converted
     if (p.fast_bilinear) {   // ff_hyscale_fast_c / ff_hcscale_fast_c, hscale_fast_bilinear.c:23-55
         const int sW = comp == 0 ? p.srcW : p.chrSrcW;
         const uint32_t xpos = (uint32_t)x * (uint32_t)(comp == 0 ? p.lumXInc : p.chrXInc);
@@ -163,6 +164,7 @@ struct DirectSampler { // horizontal filters are 1-tap identity: compute the sam
     const SwsDevParams *p; const SwsFramePtrs *f;
     __device__ __forceinline__ int get(int comp, int row, int x) const
     {
+        if (p->no_chroma && comp != 0) return p->wide ? 1 << 18 : 1 << 14;
         int r = min((read_sample(*p, *f, comp, row, x) * 16384) >> p->hshift, p->hclip);
         if (!p->wide) r = (int16_t)r;
         return range_sample(*p, r, comp != 0);

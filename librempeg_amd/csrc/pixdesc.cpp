@@ -46,6 +46,10 @@ static const PixDesc g_descs[] = {
     { AV_PIX_FMT_0BGR,     "0bgr",     3, 0, 0, {{0,4,3,0,8},{0,4,2,0,8},{0,4,1,0,8},{0,0,0,0,0}}, PIXFLAG_RGB },
     { AV_PIX_FMT_BGR0,     "bgr0",     3, 0, 0, {{0,4,2,0,8},{0,4,1,0,8},{0,4,0,0,8},{0,0,0,0,0}}, PIXFLAG_RGB },
     { AV_PIX_FMT_GBRP,     "gbrp",     3, 0, 0, {{2,1,0,0,8},{0,1,0,0,8},{1,1,0,0,8},{0,0,0,0,0}}, PIXFLAG_PLANAR | PIXFLAG_RGB },
+    { AV_PIX_FMT_GRAY8, "gray", 1, 0, 0, {{0,1,0,0,8},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, 0 },
+#define GRAYN(F, N, D) { F, N, 1, 0, 0, {{0,2,0,0,D},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, 0 }
+    GRAYN(AV_PIX_FMT_GRAY9LE, "gray9le", 9), GRAYN(AV_PIX_FMT_GRAY10LE, "gray10le", 10), GRAYN(AV_PIX_FMT_GRAY12LE, "gray12le", 12),
+    GRAYN(AV_PIX_FMT_GRAY14LE, "gray14le", 14), GRAYN(AV_PIX_FMT_GRAY16LE, "gray16le", 16),
 #define GBRN(F, N, D) { F, N, 3, 0, 0, {{2,2,0,0,D},{0,2,0,0,D},{1,2,0,0,D},{0,0,0,0,0}}, PIXFLAG_PLANAR | PIXFLAG_RGB }
     GBRN(AV_PIX_FMT_GBRP9LE, "gbrp9le", 9), GBRN(AV_PIX_FMT_GBRP10LE, "gbrp10le", 10), GBRN(AV_PIX_FMT_GBRP12LE, "gbrp12le", 12),
     GBRN(AV_PIX_FMT_GBRP14LE, "gbrp14le", 14), GBRN(AV_PIX_FMT_GBRP16LE, "gbrp16le", 16),

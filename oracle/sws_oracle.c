@@ -98,6 +98,10 @@ static const Desc descs[] = {
     { ORF_0BGR,    "0bgr",    3, 0, 0, {{0,4,3,0,8},{0,4,2,0,8},{0,4,1,0,8}}, PF_RGB },
     { ORF_BGR0,    "bgr0",    3, 0, 0, {{0,4,2,0,8},{0,4,1,0,8},{0,4,0,0,8}}, PF_RGB },
     { ORF_GBRP,    "gbrp",    3, 0, 0, {{2,1,0,0,8},{0,1,0,0,8},{1,1,0,0,8}}, PF_PLANAR | PF_RGB },
+    { ORF_GRAY8, "gray", 1, 0, 0, {{0,1,0,0,8}}, 0 },
+#define GRAYN(F, N, D) { F, N, 1, 0, 0, {{0,2,0,0,D}}, 0 }
+    GRAYN(ORF_GRAY9LE, "gray9le", 9), GRAYN(ORF_GRAY10LE, "gray10le", 10), GRAYN(ORF_GRAY12LE, "gray12le", 12),
+    GRAYN(ORF_GRAY14LE, "gray14le", 14), GRAYN(ORF_GRAY16LE, "gray16le", 16),
 #define GBRN(F, N, D) { F, N, 3, 0, 0, {{2,2,0,0,D},{0,2,0,0,D},{1,2,0,0,D}}, PF_PLANAR | PF_RGB }
     GBRN(ORF_GBRP9LE, "gbrp9le", 9), GBRN(ORF_GBRP10LE, "gbrp10le", 10), GBRN(ORF_GBRP12LE, "gbrp12le", 12),
     GBRN(ORF_GBRP14LE, "gbrp14le", 14), GBRN(ORF_GBRP16LE, "gbrp16le", 16),
@@ -685,7 +689,7 @@ static int handle_jpeg(int *format) /* utils.c:773 */
     if (*format == ORF_YUVJ422P) { *format = ORF_YUV422P; return 1; }
     if (*format == ORF_YUVJ444P) { *format = ORF_YUV444P; return 1; }
     if (*format == ORF_YUVJ440P) { *format = ORF_YUV440P; return 1; }
-    if (*format == ORF_GRAY8) return 1;
+    if (isGray(*format)) return 1;   /* gray8 .. gray16: always full range (utils.c:791-805) */
     return 0;
 }
 
@@ -765,6 +769,8 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
     if (s == ORF_GBRP && isAnyRGB(d) && isPacked(d) && desc_get(d)->c[0].depth == 8) c->unscaled_kind = UNSC_GBRP2PACKED;
     /* simple copy (:2647-2668) */
     if (s == d ||
+        (isFloat(s) == isFloat(d) &&
+         ((isPlanarYUV(s) && isGray(d)) || (isPlanarYUV(d) && isGray(s)) || (isGray(d) && isGray(s)))) ||
         (isFloat(s) == isFloat(d) &&
          (isPlanarYUV(s) && isPlanarYUV(d) && c->chrDstHSub == c->chrSrcHSub && c->chrDstVSub == c->chrSrcVSub &&
           isSemiPlanarYUV(s) == isSemiPlanarYUV(d) && isSwappedChroma(s) == isSwappedChroma(d)))) {
@@ -1268,8 +1274,18 @@ static int unscaled_planarcopy(OrSws *c, const uint8_t *const src[], const int s
 {
     const Desc *ds = desc_get(c->o.src_format), *dd = desc_get(c->o.dst_format);
     const int sf = c->o.src_format, df = c->o.dst_format;
-    int nplanes = isSemiPlanarYUV(df) ? 2 : 3;
+    int nplanes = isGray(df) ? 1 : isSemiPlanarYUV(df) ? 2 : 3;
     for (int plane = 0; plane < nplanes; plane++) {
+        if (plane > 0 && isGray(sf)) { /* gray source: chroma planes are filled with mid-grey (fillPlane / fillPlane16 :2239-2247) */
+            int flen = CEIL_RSHIFT(c->o.src_w, c->chrDstHSub) * (isSemiPlanarYUV(df) ? 2 : 1);
+            int fy = CEIL_RSHIFT(srcSliceY, c->chrDstVSub), fh = CEIL_RSHIFT(srcSliceH, c->chrDstVSub);
+            for (int i = 0; i < fh; i++) {
+                uint8_t *row = dst[plane] + (ptrdiff_t)(fy + i) * dstStride[plane];
+                if (is16BPS(df) || isNBPS(df)) { uint16_t *r16 = (uint16_t *)row; for (int j = 0; j < flen; j++) r16[j] = (uint16_t)(1 << (dd->c[plane].depth - 1)); }
+                else memset(row, 128, flen);
+            }
+            continue;
+        }
         int length = plane == 0 ? c->o.src_w : CEIL_RSHIFT(c->o.src_w, c->chrDstHSub);
         int y = plane == 0 ? srcSliceY : CEIL_RSHIFT(srcSliceY, c->chrDstVSub);
         int height = plane == 0 ? srcSliceH : CEIL_RSHIFT(srcSliceH, c->chrDstVSub);
@@ -1942,7 +1958,12 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
         hscale_line(c, d, dstW, line, c->hLumFilter, c->hLumFilterPos, c->hLumFilterSize);
         if (c->range_active) range_line(c, d, dstW, 0);
     }
-    for (y = 0; y < c->chrSrcH; y++) { /* chr_convert + chr_h_scale, hscale.c:168-245 */
+    const int needs_hcscale = !(isGray(sf) || isGray(df));   /* swscale.c:692-694 */
+    if (!needs_hcscale) { /* ff_init_desc_no_chr: the chroma lines keep fill_ones()' value (slice.c:190-208, :358-361) */
+        const int32_t neutral = c->dstBpc >= 16 ? 1 << 18 : 1 << 14;
+        for (size_t k = 0; k < (size_t)c->chrSrcH * c->chrDstW; k++) P.chrU[k] = P.chrV[k] = neutral;
+    }
+    for (y = 0; needs_hcscale && y < c->chrSrcH; y++) { /* chr_convert + chr_h_scale, hscale.c:168-245 */
         const uint8_t *pu, *pv;
         int32_t *du = P.chrU + (size_t)y * c->chrDstW, *dv = P.chrV + (size_t)y * c->chrDstW;
         read_chr_line(c, src, srcStride, y, t0, t1, &pu, &pv);
@@ -1955,7 +1976,11 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
         const int chrDstY = y >> c->chrDstVSub;
         const uint8_t *lumDither = should_dither ? dither_8x8_128[y & 7] : pb_64;       /* swscale.c:385-387, :519-522 */
         const uint8_t *chrDither = should_dither ? dither_8x8_128[chrDstY & 7] : pb_64;
-        if (isPlanarYUV(df)) {
+        if (isGray(df)) { /* vscale.c:219-233: luma only */
+            int firstLum = ORMAX(1 - c->vLumFilterSize, c->vLumFilterPos[y]);
+            write_planar_line(c, dst[0] + (size_t)y * dstStride[0], dstW, P.lum, dstW, srcH, firstLum,
+                              c->vLumFilter + y * c->vLumFilterSize, c->vLumFilterSize, lumDither, 0, 1);
+        } else if (isPlanarYUV(df)) {
             const Desc *dd = desc_get(df);
             int firstLum = ORMAX(1 - c->vLumFilterSize, c->vLumFilterPos[y]);
             write_planar_line(c, dst[0] + (size_t)y * dstStride[0], dstW, P.lum, dstW, srcH, firstLum,

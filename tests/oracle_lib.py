@@ -35,7 +35,8 @@ _FORMATS = {
     "gbrp": (71, "rgbp", 0, 0, 1), "gbrpf32le": (175, "rgbp", 0, 0, 4),
     "gbrp9le": (73, "rgbp", 0, 0, 2), "gbrp10le": (75, "rgbp", 0, 0, 2), "gbrp12le": (135, "rgbp", 0, 0, 2),
     "gbrp14le": (137, "rgbp", 0, 0, 2), "gbrp16le": (77, "rgbp", 0, 0, 2),
-    "gray8": (8, "gray", 0, 0, 1),
+    "gray8": (8, "gray", 0, 0, 1), "gray9le": (173, "gray", 0, 0, 2), "gray10le": (168, "gray", 0, 0, 2),
+    "gray12le": (166, "gray", 0, 0, 2), "gray14le": (181, "gray", 0, 0, 2), "gray16le": (30, "gray", 0, 0, 2),
 }
 
 
@@ -110,7 +111,7 @@ def fill_random(frame, seed):
     f = frame.fmt
     for pi, (a, rb) in enumerate(zip(frame.planes, frame.row_bytes)):
         rows = a.shape[0]
-        m = re.match(r"(?:yuv4\d\dp|gbrp)(9|10|12|14)le$", f)
+        m = re.match(r"(?:yuv4\d\dp|gbrp|gray)(9|10|12|14)le$", f)
         mp = re.match(r"p[024](10|12)le$", f)
         if m:      # N-bit samples in the low bits of 16-bit words
             v = rng.integers(0, 1 << int(m.group(1)), size=(rows, rb // 2), dtype=np.uint16)

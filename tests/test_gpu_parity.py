@@ -85,8 +85,9 @@ YUV_FAMILY = ["yuv420p", "yuv422p", "yuv444p", "yuv410p", "yuv411p", "yuv440p", 
               "yuv420p16le", "yuv422p16le", "yuv444p16le",
               "p010le", "p210le", "p410le", "p012le", "p212le", "p412le", "p016le", "p216le", "p416le"]
 PLANAR_RGB = ["gbrp", "gbrp9le", "gbrp10le", "gbrp12le", "gbrp14le", "gbrp16le", "gbrpf32le"]
-FORMAT_MATRIX_SRC = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB
-FORMAT_MATRIX_DST = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB
+GRAYS = ["gray8", "gray9le", "gray10le", "gray12le", "gray14le", "gray16le"]
+FORMAT_MATRIX_SRC = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS
+FORMAT_MATRIX_DST = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS
 
 
 @pytest.mark.parametrize("sfmt", FORMAT_MATRIX_SRC)
@@ -166,6 +167,7 @@ SLICED_UNSCALED = [
     ("p010le", "p016le", BX), ("nv12", "nv12", BX), ("rgb24", "bgr24", BX), ("rgba", "argb", BX), ("rgb24", "abgr", 0), ("bgr0", "rgba", BX),
     ("rgba", "rgba", BX), ("rgb0", "rgba", BX), ("bgr24", "yuv420p", BX), ("gbrp", "rgb24", BX), ("gbrp", "bgra", BX), ("rgb24", "gbrp", BX),
     ("argb", "gbrp", BX), ("gbrp", "gbrp", BX), ("gbrp10le", "gbrp10le", BX),
+    ("yuvj420p", "gray8", BX), ("gray8", "yuvj444p", BX), ("gray8", "gray16le", BX), ("gray12le", "gray8", BX), ("gray10le", "yuvj420p", BX),
 ]
 
 
