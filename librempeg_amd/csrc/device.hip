@@ -343,6 +343,7 @@ int dev_prepare(SwsInternal *c)
                         if (lds > 64 * 1024) return false;
                         g.TW = TW; g.TH = TH; g.tilesX = tX; g.tilesY = tY; g.NRmax = nrmax; g.NCmax = ncmax; g.lds_bytes = (int32_t)lds;
                         g.hfs2 = hf2; g.vfs2 = vf2;
+                        g.debug = std::getenv("SWS_HIP_TILE_DEBUG") ? std::atoi(std::getenv("SWS_HIP_TILE_DEBUG")) : 0;
                         o.rs = put(rs.data(), rs.size() * 4); o.rc = put(rc.data(), rc.size() * 4);
                         o.cs = put(cs.data(), cs.size() * 4); o.cc = put(cc.data(), cc.size() * 4);
                         const std::vector<int16_t> ht = padded(hb), vt = padded(vb);
@@ -822,13 +823,15 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         }
         if (d->dot2_ok && vec) { // dot2 LDS-tile kernel: one launch for luma, one for chroma
             const dim3 gl(d->dotL.tilesX, d->dotL.tilesY, n), gc(d->dotC.tilesX, d->dotC.tilesY, n);
-            if (p.srcKind == SRCK_PLANAR16) {
-                hipLaunchKernelGGL((swsk::sws_k_tile_dot2<true, false>), gl, blk, d->dotL.lds_bytes, st, fs, p, d->dotL);
-                hipLaunchKernelGGL((swsk::sws_k_tile_dot2<true, true>), gc, blk, d->dotC.lds_bytes, st, fs, p, d->dotC);
-            } else {
-                hipLaunchKernelGGL((swsk::sws_k_tile_dot2<false, false>), gl, blk, d->dotL.lds_bytes, st, fs, p, d->dotL);
-                hipLaunchKernelGGL((swsk::sws_k_tile_dot2<false, true>), gc, blk, d->dotC.lds_bytes, st, fs, p, d->dotC);
-            }
+            static const int NT = std::getenv("SWS_HIP_TILE_THREADS") ? std::atoi(std::getenv("SWS_HIP_TILE_THREADS")) : 256;
+            const bool s16 = p.srcKind == SRCK_PLANAR16;
+#define LAUNCH_T(N) do { const dim3 b(N); \
+    if (s16) { hipLaunchKernelGGL((swsk::sws_k_tile_dot2<true, false, N>), gl, b, d->dotL.lds_bytes, st, fs, p, d->dotL); \
+               hipLaunchKernelGGL((swsk::sws_k_tile_dot2<true, true, N>), gc, b, d->dotC.lds_bytes, st, fs, p, d->dotC); } \
+    else     { hipLaunchKernelGGL((swsk::sws_k_tile_dot2<false, false, N>), gl, b, d->dotL.lds_bytes, st, fs, p, d->dotL); \
+               hipLaunchKernelGGL((swsk::sws_k_tile_dot2<false, true, N>), gc, b, d->dotC.lds_bytes, st, fs, p, d->dotC); } } while (0)
+            if (NT == 512) LAUNCH_T(512); else if (NT == 1024) LAUNCH_T(1024); else LAUNCH_T(256);
+#undef LAUNCH_T
             break;
         }
         if (d->tile_ok) { // fused h+v LDS-tile kernel: one launch for luma, one for chroma

@@ -66,6 +66,7 @@ struct SwsTileGeom {        // fused h+v tile kernel: per component group, from 
     int32_t lds_bytes;
     // dot2 variant: tap rows padded to start on an even sample/row and to an even length (host)
     const int16_t *hT2, *vT2; int32_t hfs2, vfs2;
+    int32_t debug;            // profiling experiments only (SWS_HIP_TILE_DEBUG): 1 = skip phase 2, 2 = skip phase 3, 4 = skip phase 1
 };
 
 struct SwsMarchGeom {       // wave-marching fused kernel (kernels_march.hpp), per component group

@@ -97,7 +97,31 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
 }
 
-// horizontal stage for one output column over `npairs` row pairs (rows 2q, 2q+1), NP tap pairs per output
+// horizontal stage for one output column over `npairs` row pairs (rows 2q, 2q+1), NP tap pairs per output.
+// The kernel is instruction-issue bound, so the epilogue is as short as it gets: with the 15-bit clip (hclip == 32767)
+// min(v >> sh, 32767) followed by the int16 store IS v_cvt_pk_i16_i32's signed saturation (the negative side cannot
+// overflow: samples are unsigned and the taps' negative lobes are a fraction of their sum), which also packs the row
+// pair into the dword the vertical stage reads.  Range conversion (rare) takes the general per-sample path.
+typedef short s16x2v __attribute__((ext_vector_type(2)));
+template <int NP, bool CHROMA, bool RANGE>
+__device__ __forceinline__ void hscale_pairs_impl(const SwsDevParams &p, const uint32_t *S, int srow_dw, const uint32_t (&t)[NP],
+                                                  uint32_t *Hcol, int tw_dw, int q0, int npairs, int qstep)
+{
+    const int sh = p.hshift;
+    for (int q = q0; q < npairs; q += qstep) {
+        const uint32_t *s0 = S + (2 * q) * srow_dw, *s1 = s0 + srow_dw;
+        int a = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < NP; k++) { a = dot2(s0[k], t[k], a); b = dot2(s1[k], t[k], b); }
+        if constexpr (RANGE) {
+            int va = min(a >> sh, p.hclip), vb = min(b >> sh, p.hclip);
+            va = range_sample(p, (int16_t)va, CHROMA); vb = range_sample(p, (int16_t)vb, CHROMA);
+            Hcol[q * tw_dw] = (uint32_t)(uint16_t)va | ((uint32_t)(uint16_t)vb << 16);
+        } else {
+            Hcol[q * tw_dw] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(a >> sh, b >> sh));
+        }
+    }
+}
 template <int NP, bool CHROMA>
 __device__ __forceinline__ void hscale_pairs(const SwsDevParams &p, const uint32_t *S, int srow_dw, const uint32_t *tp,
                                              uint32_t *Hcol, int tw_dw, int q0, int npairs, int qstep)
@@ -105,15 +129,8 @@ __device__ __forceinline__ void hscale_pairs(const SwsDevParams &p, const uint32
     uint32_t t[NP];
 #pragma unroll
     for (int k = 0; k < NP; k++) t[k] = tp[k];
-    for (int q = q0; q < npairs; q += qstep) {
-        const uint32_t *s0 = S + (2 * q) * srow_dw, *s1 = s0 + srow_dw;
-        int a = 0, b = 0;
-#pragma unroll
-        for (int k = 0; k < NP; k++) { a = dot2(s0[k], t[k], a); b = dot2(s1[k], t[k], b); }
-        int va = min(a >> p.hshift, p.hclip), vb = min(b >> p.hshift, p.hclip);
-        va = range_sample(p, (int16_t)va, CHROMA); vb = range_sample(p, (int16_t)vb, CHROMA);
-        Hcol[q * tw_dw] = (uint32_t)(uint16_t)va | ((uint32_t)(uint16_t)vb << 16);
-    }
+    if (p.range_active || p.hclip != 32767) hscale_pairs_impl<NP, CHROMA, true>(p, S, srow_dw, t, Hcol, tw_dw, q0, npairs, qstep);
+    else hscale_pairs_impl<NP, CHROMA, false>(p, S, srow_dw, t, Hcol, tw_dw, q0, npairs, qstep);
 }
 
 // vertical stage for 4 adjacent columns, NP tap pairs
@@ -132,8 +149,8 @@ __device__ __forceinline__ void vscale_pairs4(const uint32_t *Hp, int hplane, in
     }
 }
 
-template <bool SRC16, bool CHROMA>
-__global__ void __launch_bounds__(256) sws_k_tile_dot2(SwsFrameSet fs, SwsDevParams p, SwsTileGeom g)
+template <bool SRC16, bool CHROMA, int NT>
+__global__ void __launch_bounds__(NT) sws_k_tile_dot2(SwsFrameSet fs, SwsDevParams p, SwsTileGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tx = blockIdx.x, ty = blockIdx.y, tid = threadIdx.x;
@@ -179,16 +196,17 @@ __global__ void __launch_bounds__(256) sws_k_tile_dot2(SwsFrameSet fs, SwsDevPar
                     *(u32x4 *)dst = lo; *(u32x4 *)(dst + 4) = hi;
                 }
             };
+            if (g.debug & 4) {} else
             if (chunks >= 32) {   // wide windows: lane = chunk column, wave-uniform rows (scalar address math), 4 rows in flight
                 for (int ch = lane; ch < chunks; ch += 64) {
                     const int64_t boff = csb + (int64_t)ch * 16;
                     const bool full = boff + 16 <= asst;
                     const int nvalid = (int)max((int64_t)0, asst - boff);
-                    for (int r0 = wave; r0 < nrp; r0 += 16) {          // rows r0, r0+4, r0+8, r0+12 of this wave
+                    for (int r0 = wave; r0 < nrp; r0 += 4 * (NT / 64)) {   // 4 rows of this wave in flight
                         u32x4 v[4];
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const int r = r0 + 4 * k;
+                            const int r = r0 + (NT / 64) * k;
                             if (r < nrp) {
                                 const uint8_t *src = sb + (int64_t)min(rs + r, sH - 1) * sst + boff;
                                 v[k] = full ? gload16(src) : gload16_partial(src, nvalid);
@@ -196,13 +214,13 @@ __global__ void __launch_bounds__(256) sws_k_tile_dot2(SwsFrameSet fs, SwsDevPar
                         }
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const int r = r0 + 4 * k;
+                            const int r = r0 + (NT / 64) * k;
                             if (r < nrp) put(r, ch, v[k]);
                         }
                     }
                 }
             } else {              // narrow windows (few chunks per row): flat index over (row, chunk) keeps all lanes busy
-                for (int i = tid; i < nrp * chunks; i += 256) {
+                for (int i = tid; i < nrp * chunks; i += NT) {
                     const int r = i / chunks, ch = i - r * chunks;
                     const int64_t boff = csb + (int64_t)ch * 16;
                     const uint8_t *src = sb + (int64_t)min(rs + r, sH - 1) * sst + boff;
@@ -215,13 +233,13 @@ __global__ void __launch_bounds__(256) sws_k_tile_dot2(SwsFrameSet fs, SwsDevPar
         //      (one dword store per pair: {even row, odd row}) ----
         {
             const int xl = tid & (g.TW - 1), half = tid / g.TW;    // TW == 128: two interleaved pair phases
-            if (xl < tw) {
+            if (xl < tw && !(g.debug & 1)) {
                 const int x = x0 + xl;
                 const int spd = ((hpos[x] & ~1) - cs) >> 1;          // dword index of the first (even-aligned) pair
                 const uint32_t *tp = (const uint32_t *)(g.hT2 + (int64_t)x * g.hfs2);
                 uint32_t *Hc = Hp + ci * hplane;
                 switch (g.hfs2 >> 1) {
-#define SWS_HCASE(NP) case NP: hscale_pairs<NP, CHROMA>(p, S + spd, srow_dw, tp, Hc + xl, g.TW, half, nrp >> 1, 256 / g.TW); break;
+#define SWS_HCASE(NP) case NP: hscale_pairs<NP, CHROMA>(p, S + spd, srow_dw, tp, Hc + xl, g.TW, half, nrp >> 1, NT / g.TW); break;
                 SWS_HCASE(1) SWS_HCASE(2) SWS_HCASE(3) SWS_HCASE(4) SWS_HCASE(5) SWS_HCASE(6) SWS_HCASE(7) SWS_HCASE(8)
 #undef SWS_HCASE
                 }
@@ -235,7 +253,7 @@ __global__ void __launch_bounds__(256) sws_k_tile_dot2(SwsFrameSet fs, SwsDevPar
     const int q4 = (tw + 3) >> 2;
     const int bits = p.dst_bits;
     const int q4s = 31 - __builtin_clz((unsigned)(g.TW >> 2));      // log2(TW / 4): full-width tiles index with shifts
-    for (int i = tid; i < q4 * th; i += 256) {
+    for (int i = tid; i < ((g.debug & 2) ? 0 : q4 * th); i += NT) {
         const int yl = tw == g.TW ? i >> q4s : i / q4, xl = 4 * (i - yl * q4);
         const int y = y0 + yl, x = x0 + xl;
         const int n = min(4, tw - xl);
