@@ -104,11 +104,11 @@ void choose_unscaled(SwsInternal *c)
     const unsigned flags = c->opts.flags;
     PlanKind k = PLAN_NONE;
     bool unsupported = false;
-    if (s == AV_PIX_FMT_YUV420P && (d == AV_PIX_FMT_NV12 || d == AV_PIX_FMT_NV21)) k = PLAN_UNSC_PLANAR2NV12; // :2405
+    if ((s == AV_PIX_FMT_YUV420P || s == AV_PIX_FMT_YUVA420P) && (d == AV_PIX_FMT_NV12 || d == AV_PIX_FMT_NV21)) k = PLAN_UNSC_PLANAR2NV12; // :2405
     if (s == AV_PIX_FMT_YUV444P && (d == AV_PIX_FMT_NV24 || d == AV_PIX_FMT_NV42)) k = PLAN_UNSC_PLANAR2NV24; // :2410
     if (d == AV_PIX_FMT_YUV420P && (s == AV_PIX_FMT_NV12 || s == AV_PIX_FMT_NV21)) k = PLAN_UNSC_NV122PLANAR; // :2415
     if (d == AV_PIX_FMT_YUV444P && (s == AV_PIX_FMT_NV24 || s == AV_PIX_FMT_NV42)) k = PLAN_UNSC_NV242PLANAR; // :2420
-    if ((s == AV_PIX_FMT_YUV420P || s == AV_PIX_FMT_YUV422P) && isAnyRGB(d) && !(flags & SWS_ACCURATE_RND) &&
+    if ((s == AV_PIX_FMT_YUV420P || s == AV_PIX_FMT_YUV422P || s == AV_PIX_FMT_YUVA420P) && isAnyRGB(d) && !(flags & SWS_ACCURATE_RND) &&
         (c->opts.dither == SWS_DITHER_BAYER || c->opts.dither == SWS_DITHER_AUTO) && !(c->opts.dst_h & 1)) { // :2425-2431
         // ff_yuv2rgb_get_func_ptr (yuv2rgb.c:561-678) has C converters for the 24/32 bpp packed formats and gbrp;
         // it returns NULL for gbrp9..16 / gbrpf32 and the scaler chain is used
@@ -118,7 +118,7 @@ void choose_unscaled(SwsInternal *c)
     }
     if ((s == AV_PIX_FMT_YUV420P10LE || s == AV_PIX_FMT_YUV420P12LE || s == AV_PIX_FMT_YUV420P14LE || s == AV_PIX_FMT_YUV420P16LE) &&
         (d == AV_PIX_FMT_P010LE || d == AV_PIX_FMT_P016LE)) k = PLAN_UNSC_P01X;                                       // :2432-2439
-    if (s == AV_PIX_FMT_YUV420P && (d == AV_PIX_FMT_P010LE || d == AV_PIX_FMT_P016LE)) k = PLAN_UNSC_8_P01X;           // :2440-2444
+    if ((s == AV_PIX_FMT_YUV420P || s == AV_PIX_FMT_YUVA420P) && (d == AV_PIX_FMT_P010LE || d == AV_PIX_FMT_P016LE)) k = PLAN_UNSC_8_P01X; // :2440-2444
     if (s == AV_PIX_FMT_YUV410P && !(c->opts.dst_h & 3) && d == AV_PIX_FMT_YUV420P && !(flags & SWS_BITEXACT)) {       // :2446-2451
         k = PLAN_UNSC_YVU9_YV12;
         c->dst_slice_align = 4;
@@ -134,13 +134,16 @@ void choose_unscaled(SwsInternal *c)
     }
     if (isAnyRGB(s) && !isPlanarRGB(s) && d == AV_PIX_FMT_GBRP) k = PLAN_UNSC_PACKED_GBRP;             // rgbToPlanarRgbWrapper (:2542-2544)
     if (s == AV_PIX_FMT_GBRP && isAnyRGB(d) && !isPlanarRGB(d)) k = PLAN_UNSC_GBRP_PACKED;             // planarRgbToRgbWrapper (:2480-2481)
-    if (s == d ||
+    // bgr24ToYv12 / yvu9ToYv12 also take a yuva420p destination in the reference (alpha filled with 255): not built
+    if (d == AV_PIX_FMT_YUVA420P && ((s == AV_PIX_FMT_BGR24 && !(flags & SWS_ACCURATE_RND) && !(c->opts.dst_w & 1)) ||
+                                     (s == AV_PIX_FMT_YUV410P && !(c->opts.dst_h & 3) && !(flags & SWS_BITEXACT)))) unsupported = true;
+    if (s == d || (s == AV_PIX_FMT_YUVA420P && d == AV_PIX_FMT_YUV420P) || (s == AV_PIX_FMT_YUV420P && d == AV_PIX_FMT_YUVA420P) ||
         (isFloatFmt(s) == isFloatFmt(d) && ((isPlanarYUV(s) && isGray(d)) || (isPlanarYUV(d) && isGray(s)) || (isGray(d) && isGray(s)))) ||
         (isFloatFmt(s) == isFloatFmt(d) && isPlanarYUV(s) && isPlanarYUV(d) &&
          c->chrDstHSubSample == c->chrSrcHSubSample && c->chrDstVSubSample == c->chrSrcVSubSample &&
          isSemiPlanarYUV(s) == isSemiPlanarYUV(d) && isSwappedChroma(s) == isSwappedChroma(d))) { // :2647-2668
         if (isPackedFmt(s)) k = PLAN_UNSC_PACKEDCOPY; // packedCopyWrapper (:2138-2157)
-        else { k = PLAN_UNSC_PLANARCOPY; unsupported = false;
+        else { k = PLAN_UNSC_PLANARCOPY;
                if (c->opts.dither != SWS_DITHER_NONE) c->dst_slice_align = 8 << c->chrDstVSubSample; }
     }
     if (d == AV_PIX_FMT_YUV420P && (s == AV_PIX_FMT_NV24 || s == AV_PIX_FMT_NV42)) k = PLAN_UNSC_NV242YUV420;         // :2703-2705
@@ -247,15 +250,13 @@ int init_single_context(SwsInternal *c)
             c->plan = PLAN_NONE;
             return SWS_AVERROR(ENOTSUP);
         }
-        if (c->plan != PLAN_NONE && c->needAlpha && c->plan != PLAN_UNSC_RGB2RGB && c->plan != PLAN_UNSC_PACKEDCOPY)
-            c->plan = PLAN_NONE;
         if (c->plan != PLAN_NONE) {
             log_msg(c, 2, "using unscaled %s -> %s special converter\n", ds->name, dd->name);
             return 0;
         }
     }
-    if (c->needAlpha) {
-        log_msg(c, 0, "alpha-plane scaling (%s -> %s) is not implemented on the HIP path\n", ds->name, dd->name);
+    if (c->needAlpha && isPlanarRGB(dstFormat)) {
+        log_msg(c, 0, "alpha-plane output to planar RGB (%s -> %s) is not implemented on the HIP path\n", ds->name, dd->name);
         return SWS_AVERROR(ENOTSUP);
     }
 

@@ -150,7 +150,7 @@ int dev_prepare(SwsInternal *c)
     p.uv_swap_src = isSwappedChroma(o.src_format); p.uv_swap_dst = isSwappedChroma(o.dst_format);
     p.u_plane_src = ds->comp[1].plane; p.v_plane_src = ds->comp[2].plane;
     p.u_plane_dst = dd->comp[1].plane; p.v_plane_dst = dd->comp[2].plane;
-    const bool gray_any = isGray(o.src_format) || isGray(o.dst_format);
+    const bool gray_any = isGray(o.src_format) || isGray(o.dst_format) || c->needAlpha;   // paths the fused kernels do not cover
     p.should_dither = isNBPS(o.src_format) || is16BPS(o.src_format);     // swscale.c:292-293
     p.full_chr = (o.flags & SWS_FULL_CHR_H_INT) ? 1 : 0;
     if (isAnyRGB(o.src_format) && !isPlanarRGB(o.src_format)) {
@@ -182,6 +182,7 @@ int dev_prepare(SwsInternal *c)
         const int base = (df == AV_PIX_FMT_ABGR || df == AV_PIX_FMT_ARGB) ? 8 : 0;
         L.rshift = base + (isRgb ? 16 : 0); L.gshift = base + 8; L.bshift = base + (isRgb ? 0 : 16);
         L.alpha_or = isALPHA(o.src_format) ? 0u : (255u << ((base + 24) & 31));
+        L.a_shift = (base + 24) & 31;
         L.rgb_order = df == AV_PIX_FMT_BGR24 ? 1 : 0;
         {   // 32 bpp wave kernels pack bytes as {c0, g, c2, 255} with c0 = R (or B when swap_rb32) and then permute:
             // rgba: R,G,B,A  bgra: B,G,R,A (swap)  argb: A,R,G,B  abgr: A,B,G,R (swap).  v_perm_b32(px, px, sel):
@@ -202,6 +203,10 @@ int dev_prepare(SwsInternal *c)
         p.shiftU = dd->comp[1].depth + dd->comp[1].shift - ds->comp[1].depth - ds->comp[1].shift;
         p.shiftV = dd->comp[2].depth + dd->comp[2].shift - ds->comp[2].depth - ds->comp[2].shift;
     }
+    p.need_alpha = c->needAlpha;                                                             // utils.c:1746
+    p.src_a_pos = (isALPHA(o.src_format) && !isPlanarFmt(o.src_format)) ? ds->comp[3].offset : 0;
+    p.src_alpha_opaque = c->src0Alpha && !c->dst0Alpha && isALPHA(o.dst_format);
+    p.dst_alpha_fill = isALPHA(o.dst_format) && isPlanarFmt(o.dst_format) && !c->needAlpha;
     p.no_chroma = isGray(o.src_format) || isGray(o.dst_format);                              // swscale.c:692-694
     p.fast_bilinear = (o.flags & SWS_FAST_BILINEAR) && c->srcBpc == 8 && c->dstBpc <= 14;   // swscale.c:676-681
     p.lumXInc = c->lumXInc; p.chrXInc = c->chrXInc;
@@ -470,7 +475,7 @@ int dev_prepare(SwsInternal *c)
     case PLAN_CASCADE: c->path_name = "cascade"; c->kernel_name = ""; break;
     case PLAN_MAIN: {
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
-        if (d->unity_h && rgb_lut && !p.no_chroma && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
+        if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             c->path_name = "main:fused_rgb_unity"; c->kernel_name = "sws_k_rgb_fused_unity_wave";
         } else if (d->unity_h && d->unity_v && !p.no_chroma && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 &&
                    (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16)) {
@@ -600,6 +605,11 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         const int bpr = (npairs + 3) >> 2;
         if (!bpr || !nrowpairs) break;
         const bool bpp4 = p.dstKind == DSTK_RGB32;
+        auto merge_alpha = [&]() {   // yuva2rgba_c / yuva2argb_c (yuv2rgb.c:524-528): source alpha into the A byte
+            if (!bpp4 || !isALPHA(c->opts.src_format)) return;
+            const dim3 ga(cdiv(2 * npairs, 256), 2 * nrowpairs, n);
+            hipLaunchKernelGGL(swsk::sws_k_alpha_merge, ga, blk, 0, st, fs, 2 * npairs, sliceY, pix_desc(c->opts.dst_format)->comp[3].offset);
+        };
         if (vec && !no_wave) { // wave-tiled kernel: 1024 pixels x 2 rows per wave, LDS-transposed 16-byte stores
             const int segs = (2 * npairs + 1023) >> 10;
             const dim3 gridw(cdiv((int64_t)segs * nrowpairs, 4), 1, n);
@@ -608,6 +618,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
             if (bpp4) { if (swap) LAUNCH_K1(4, true); else LAUNCH_K1(4, false); }
             else      { if (swap) LAUNCH_K1(3, true); else LAUNCH_K1(3, false); }
 #undef LAUNCH_K1
+            merge_alpha();
             break;
         }
         const dim3 grid(cdiv((int64_t)bpr * nrowpairs, 256), 1, n);
@@ -615,6 +626,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         else if (bpp4) hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled<4, false>), grid, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
         else if (vec) hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled<3, true>), grid, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
         else hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled<3, false>), grid, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
+        merge_alpha();
         break;
     }
     case PLAN_UNSC_P01X:
@@ -683,6 +695,10 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
                 const int shiftonly = pl == 1 || pl == 2 || (!c->opts.src_range && pl == 0);
                 const bool missing = pl > 0 && isGray(c->opts.src_format);   // fillPlane / fillPlane16 (:2239-2247); width in samples
                 if (missing && same) len /= (ds->comp[0].depth + 7) / 8;
+                if (pl == 3) {   // alpha plane (:2226-2247): full size, copied when the source has one, 255 otherwise
+                    plan.pl[pl] = { isALPHA(c->opts.src_format) ? 3 : -2, 3, p.srcW, sliceH, sliceY, 1, 0, 0 };
+                    continue;
+                }
                 plan.pl[pl] = { missing ? -1 : pl, pl, len, h, y0, 1, shiftonly, pl != 0 };
             }
         }
@@ -766,10 +782,14 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         break;
     }
     case PLAN_MAIN: {
+        if (p.dst_alpha_fill) {   // swscale.c:536-552
+            const dim3 gf(cdiv(p.dstW, 256), p.dstH, n);
+            hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.dstW, 0);
+        }
         const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 ||
                          p.dstKind == DSTK_GBRPF32;
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
-        if (d->unity_h && rgb_lut && !p.no_chroma && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
+        if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;
             if (vec && !no_wave && d->all_x_mode && d->chr_window2 <= 8 && p.vChrFs <= 64) { // wave-tiled kernel: 1024 pixels x 2 rows per wave
                 constexpr int ROWS = 2;
@@ -847,7 +867,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         }
         // generic: optional pass 1 into scratch, then writers
         const int64_t lumElems = (int64_t)p.srcH * p.dstW, chrElems = (int64_t)p.chrSrcH * p.chrDstW;
-        const int64_t frame_elems = lumElems + 2 * chrElems;
+        const int64_t frame_elems = lumElems + 2 * chrElems + (p.need_alpha ? lumElems : 0);
         const size_t esz = p.wide ? 4 : 2;
         const bool direct = d->unity_h;
         int chunk = n;
@@ -864,7 +884,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
             if (n == 1) sub.one = frames[0]; else sub.table = d->d_frames + f0;
             if (!direct) {
                 const int maxW = std::max(p.dstW, p.chrDstW), maxH = std::max(p.srcH, p.chrSrcH);
-                const dim3 g1(cdiv(maxW, 256), maxH, 3 * m);
+                const dim3 g1(cdiv(maxW, 256), maxH, (p.need_alpha ? 4 : 3) * m);
                 if (p.wide) hipLaunchKernelGGL((swsk::sws_k_hscale<int32_t>), g1, blk, 0, st, sub, p, (int32_t *)d->scratch, frame_elems);
                 else hipLaunchKernelGGL((swsk::sws_k_hscale<int16_t>), g1, blk, 0, st, sub, p, (int16_t *)d->scratch, frame_elems);
             }
@@ -882,7 +902,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
                 const dim3 gc(cdiv(p.chrDstW, 256), p.chrDstH, m);
                 LAUNCH_W(sws_k_vscale_nvchroma, gc);
             } else {
-                const int ncomp = isGray(c->opts.dst_format) ? 1 : 3;          // vscale.c:219-233: gray destinations have luma only
+                const int ncomp = isGray(c->opts.dst_format) ? 1 : (p.need_alpha ? 4 : 3); // vscale.c:219-233 (gray: luma only), :59-71 (alpha)
                 const dim3 g(cdiv(std::max(p.dstW, p.chrDstW), 256), std::max(p.dstH, p.chrDstH), ncomp * m);
                 LAUNCH_W(sws_k_vscale_planar, g, ncomp);
             }

@@ -50,6 +50,7 @@ struct SwsLutParams {       // closed form of the yuv2rgb LUTs (yuv2rgb.c:680-70
     int32_t base_r, base_b, base_g; // yoffs - (inc>>9) [g: yoffs - (cgu>>9) - (cgv>>9)]
     int32_t rshift, gshift, bshift; // 32 bpp channel positions
     uint32_t alpha_or;      // 255 << abase (32 bpp, no source alpha) or 0
+    int32_t a_shift;        // 32 bpp: bit position of the alpha byte (abase)
     int32_t rgb_order;      // 24 bpp: 0 = R first (rgb24), 1 = B first (bgr24)
     uint32_t perm32;        // 32 bpp: v_perm_b32 selector moving canonical bytes {first,g,third,alpha} to the format's order
     int32_t swap_rb32;      // 32 bpp: canonical 'first' channel is B (bgra / abgr)
@@ -120,4 +121,8 @@ struct SwsDevParams {
     // gray on either side: chroma is never h-scaled (needs_hcscale == 0, swscale.c:692-694); the vertical stage sees the
     // ring buffer's initial value (fill_ones, slice.c:190-208): 1 << 14 (15-bit lines) or 1 << 18 (19-bit lines)
     int32_t no_chroma;
+    // alpha: both formats carry one (needAlpha, utils.c:1746): plane 3 / the A byte is h-scaled with the LUMA filter and
+    // written by the planar or packed writers; dst_alpha_fill: the destination has an alpha plane the source cannot feed
+    int32_t need_alpha, src_a_pos, dst_alpha_fill;
+    int32_t src_alpha_opaque;   // rgb0-style source feeding a real alpha channel: its X byte counts as 255 (swscale.c:1106-1124)
 };

@@ -328,7 +328,7 @@ __device__ __constant__ const uint8_t k_copy_dithers[8][8][8] = { // swscale_uns
 };
 
 struct MiscPlane { int srcPlane, dstPlane, width /*elements*/, rows, y0, elem /*bytes per element*/, shiftonly, chroma; };
-struct MiscPlan { int mode; int nplanes; int bytecopy; int aux, aux2; MiscPlane pl[3]; };
+struct MiscPlan { int mode; int nplanes; int bytecopy; int aux, aux2; MiscPlane pl[4]; };
 
 __global__ void __launch_bounds__(256) sws_k_planar_misc(SwsFrameSet fs, SwsDevParams p, MiscPlan plan)
 {
@@ -386,7 +386,8 @@ __global__ void __launch_bounds__(256) sws_k_planar_misc(SwsFrameSet fs, SwsDevP
         f.dst[P.dstPlane][(int64_t)yd * f.dstStride[P.dstPlane] + x] = (uint8_t)v;
     } else if (P.srcPlane < 0) {      // planarCopyWrapper, plane missing in a gray source: fillPlane / fillPlane16 (:2239-2247)
         uint8_t *drow = f.dst[P.dstPlane] + (int64_t)yd * f.dstStride[P.dstPlane];
-        if (p.copy_depth_dst > 8) ((uint16_t *)drow)[x] = (uint16_t)(1 << (p.copy_depth_dst - 1));
+        if (P.srcPlane == -2) drow[x] = 255;                     // alpha plane of a destination the source cannot feed
+        else if (p.copy_depth_dst > 8) ((uint16_t *)drow)[x] = (uint16_t)(1 << (p.copy_depth_dst - 1));
         else drow[x] = 128;
     } else {                          // planarCopyWrapper
         const uint8_t *srow = f.src[P.srcPlane] + (int64_t)ys * f.srcStride[P.srcPlane];

@@ -15,6 +15,13 @@ namespace swsk {
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFramePtrs &f, int comp, int row, int x)
 {
+    if (comp == 3) {   // alpha line: plane 3 of yuva (8 bit), or rgbaToA_c / abgrToA_c (input.c:454-472) for 32 bpp RGB
+        if (p.srcKind == SRCK_RGB32) {
+            const int a = p.src_alpha_opaque ? 255 : f.src[0][(int64_t)row * f.srcStride[0] + 4 * x + p.src_a_pos];
+            return a << 6 | a >> 2;
+        }
+        return f.src[3][(int64_t)row * f.srcStride[3] + x];
+    }
     switch (p.srcKind) {
     case SRCK_PLANAR8: {
         const int pl = comp == 0 ? 0 : comp == 1 ? p.u_plane_src : p.v_plane_src;
@@ -129,35 +136,37 @@ __device__ __forceinline__ int range_sample(const SwsDevParams &p, int v, int ch
 __device__ __forceinline__ int hscale_sample(const SwsDevParams &p, const SwsFramePtrs &f, int comp, int row, int x)
 {
     if (p.no_chroma && comp != 0) return p.wide ? 1 << 18 : 1 << 14;   // ff_init_desc_no_chr: fill_ones() value, never range converted
+    const bool lumlike = comp == 0 || comp == 3;   // the alpha plane goes through the luma functions (hscale.c:39-131)
     if (p.fast_bilinear) {   // ff_hyscale_fast_c / ff_hcscale_fast_c, hscale_fast_bilinear.c:23-55
-        const int sW = comp == 0 ? p.srcW : p.chrSrcW;
-        const uint32_t xpos = (uint32_t)x * (uint32_t)(comp == 0 ? p.lumXInc : p.chrXInc);
+        const int sW = lumlike ? p.srcW : p.chrSrcW;
+        const uint32_t xpos = (uint32_t)x * (uint32_t)(lumlike ? p.lumXInc : p.chrXInc);
         const int xx = (int)(xpos >> 16), xalpha = (int)((xpos & 0xFFFF) >> 9);
         int r;
         if (xx >= sW - 1) r = read_sample(p, f, comp, row, sW - 1) * 128;        // the tail loop of the reference
         else {
             const int a = read_sample(p, f, comp, row, xx), b = read_sample(p, f, comp, row, xx + 1);
-            r = comp == 0 ? (a << 7) + (b - a) * xalpha : a * (xalpha ^ 127) + b * xalpha;
+            r = lumlike ? (a << 7) + (b - a) * xalpha : a * (xalpha ^ 127) + b * xalpha;
         }
-        return range_sample(p, (int16_t)r, comp != 0);
+        return comp == 3 ? (int16_t)r : range_sample(p, (int16_t)r, comp != 0);
     }
-    const int16_t *filter = comp == 0 ? p.hLumF : p.hChrF;
-    const int32_t *pos = comp == 0 ? p.hLumPos : p.hChrPos;
-    const int fs = comp == 0 ? p.hLumFs : p.hChrFs;
+    const int16_t *filter = lumlike ? p.hLumF : p.hChrF;
+    const int32_t *pos = lumlike ? p.hLumPos : p.hChrPos;
+    const int fs = lumlike ? p.hLumFs : p.hChrFs;
     const int sp = pos[x];
     int val = 0;
     for (int j = 0; j < fs; j++) val += read_sample(p, f, comp, row, sp + j) * filter[fs * x + j];
     int r = min(val >> p.hshift, p.hclip);
     if (!p.wide) r = (int16_t)r;
-    return range_sample(p, r, comp != 0);
+    return comp == 3 ? r : range_sample(p, r, comp != 0);
 }
 
 // ---- samplers: where the vertical stage gets h-scaled samples from ----
 template <typename T> struct ScratchSampler { // pass-1 output in HBM
-    const T *lum, *u, *v; int lumW, chrW;
+    const T *lum, *u, *v; int lumW, chrW; const T *a;
     __device__ __forceinline__ int get(int comp, int row, int x) const
     {
-        return comp == 0 ? lum[(int64_t)row * lumW + x] : comp == 1 ? u[(int64_t)row * chrW + x] : v[(int64_t)row * chrW + x];
+        return comp == 0 ? lum[(int64_t)row * lumW + x] : comp == 1 ? u[(int64_t)row * chrW + x] :
+               comp == 2 ? v[(int64_t)row * chrW + x] : a[(int64_t)row * lumW + x];
     }
 };
 struct DirectSampler { // horizontal filters are 1-tap identity: compute the sample on the fly
@@ -167,7 +176,7 @@ struct DirectSampler { // horizontal filters are 1-tap identity: compute the sam
         if (p->no_chroma && comp != 0) return p->wide ? 1 << 18 : 1 << 14;
         int r = min((read_sample(*p, *f, comp, row, x) * 16384) >> p->hshift, p->hclip);
         if (!p->wide) r = (int16_t)r;
-        return range_sample(*p, r, comp != 0);
+        return comp == 3 ? r : range_sample(*p, r, comp != 0);
     }
 };
 
@@ -178,14 +187,15 @@ struct DirectSampler { // horizontal filters are 1-tap identity: compute the sam
 template <typename T>
 __global__ void __launch_bounds__(256) sws_k_hscale(SwsFrameSet fs, SwsDevParams p, T *scratch, int64_t frame_elems)
 {
-    const int comp = blockIdx.z % 3, fi = blockIdx.z / 3;
-    const int W = comp == 0 ? p.dstW : p.chrDstW, H = comp == 0 ? p.srcH : p.chrSrcH;
+    const int ncomp = p.need_alpha ? 4 : 3;
+    const int comp = blockIdx.z % ncomp, fi = blockIdx.z / ncomp;
+    const int W = (comp == 0 || comp == 3) ? p.dstW : p.chrDstW, H = (comp == 0 || comp == 3) ? p.srcH : p.chrSrcH;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
     if (x >= W || row >= H) return;
     const SwsFramePtrs &f = frame_of(fs, fi);
     T *base = scratch + fi * frame_elems;
     const int64_t lumElems = (int64_t)p.srcH * p.dstW, chrElems = (int64_t)p.chrSrcH * p.chrDstW;
-    T *plane = comp == 0 ? base : comp == 1 ? base + lumElems : base + lumElems + chrElems;
+    T *plane = comp == 0 ? base : comp == 1 ? base + lumElems : comp == 2 ? base + lumElems + chrElems : base + lumElems + 2 * chrElems;
     plane[(int64_t)row * W + x] = (T)hscale_sample(p, f, comp, row, x);
 }
 
@@ -198,7 +208,7 @@ template <typename S>
 __device__ __forceinline__ void planar_write_one(const SwsDevParams &p, const S &smp, const SwsFramePtrs &f, int comp, int x, int y)
 {
     const int16_t *vf; int fs, first, srcRows, plane;
-    if (comp == 0) { fs = p.vLumFs; vf = p.vLumF + y * fs; first = max(1 - fs, p.vLumPos[y]); srcRows = p.srcH; plane = 0; }
+    if (comp == 0 || comp == 3) { fs = p.vLumFs; vf = p.vLumF + y * fs; first = max(1 - fs, p.vLumPos[y]); srcRows = p.srcH; plane = comp; }  // alpha: vscale.c:59-71
     else { fs = p.vChrFs; vf = p.vChrF + y * fs; first = max(1 - fs, p.vChrPos[y]); srcRows = p.chrSrcH;
            plane = comp == 1 ? p.u_plane_dst : p.v_plane_dst; }
     uint8_t *drow = f.dst[plane] + (int64_t)y * f.dstStride[plane];
@@ -303,6 +313,7 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
 #define LUM(j, xx) smp.get(0, min(firstL + (j), lH), (xx))
 #define CHU(j, xx) smp.get(1, min(firstC + (j), cH), (xx))
 #define CHV(j, xx) smp.get(2, min(firstC + (j), cH), (xx))
+#define ALP(j, xx) smp.get(3, min(firstL + (j), lH), (xx))
     if (p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 || p.dstKind == DSTK_GBRPF32) {
         // any_vscale (vscale.c:173-212): planar RGB always takes the X form; planes are G, B, R
         uint8_t *dg = drow, *db = f.dst[1] + (int64_t)y * f.dstStride[1], *dr = f.dst[2] + (int64_t)y * f.dstStride[2];
@@ -394,8 +405,32 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
         const ChromaIdx k = lut_chroma(L, U, V);
         if (p.dstKind == DSTK_RGB32) {
             uint32_t *d = (uint32_t *)drow;
-            d[2 * i] = lut_rgb32(L, k, Y1);
-            d[2 * i + 1] = lut_rgb32(L, k, Y2);
+            uint32_t a1 = 0, a2 = 0;
+            if (p.need_alpha) {   // output.c:1818-1830 (X), :1870-1875 (2), :1904-1908 / :1929-1933 (1); yuv2rgb_write :1680-1687
+                int A1, A2;
+                if (mode == 0) {
+                    A1 = A2 = 1 << 18;
+                    for (int j = 0; j < lfs; j++) {
+                        A1 += (int)((unsigned)ALP(j, 2 * i) * (unsigned)(int)lf[j]);
+                        A2 += (int)((unsigned)ALP(j, 2 * i + 1) * (unsigned)(int)lf[j]);
+                    }
+                    A1 >>= 19; A2 >>= 19;
+                    if ((A1 | A2) & 0x100) { A1 = clip_u8(A1); A2 = clip_u8(A2); }
+                } else if (mode == 2) {
+                    A1 = clip_u8((ALP(0, 2 * i) * (4096 - ya) + ALP(1, 2 * i) * ya) >> 19);
+                    A2 = clip_u8((ALP(0, 2 * i + 1) * (4096 - ya) + ALP(1, 2 * i + 1) * ya) >> 19);
+                } else if (ua == 0) {
+                    A1 = clip_u8((ALP(0, 2 * i) * 255 + 16384) >> 15);
+                    A2 = clip_u8((ALP(0, 2 * i + 1) * 255 + 16384) >> 15);
+                } else {
+                    A1 = clip_u8((ALP(0, 2 * i) + 64) >> 7);
+                    A2 = clip_u8((ALP(0, 2 * i + 1) + 64) >> 7);
+                }
+                const int ash = L.a_shift;
+                a1 = (uint32_t)A1 << ash; a2 = (uint32_t)A2 << ash;
+            }
+            d[2 * i] = lut_rgb32(L, k, Y1) + a1;
+            d[2 * i + 1] = lut_rgb32(L, k, Y2) + a2;
         } else {
             uint8_t *d = drow + 6 * i;
             const int k0 = L.rgb_order ? k.b : k.r, k2 = L.rgb_order ? k.r : k.b;
@@ -436,11 +471,44 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
         if ((R | G | B) & 0xC0000000) { R = clip_uintp2(R, 30); G = clip_uintp2(G, 30); B = clip_uintp2(B, 30); }
         uint8_t *d = drow + L.pix_step * i;
         d[L.r_pos] = (uint8_t)(R >> 22); d[L.g_pos] = (uint8_t)(G >> 22); d[L.b_pos] = (uint8_t)(B >> 22);
-        if (L.pix_step == 4) d[L.a_pos] = 255;
+        if (L.pix_step == 4) {
+            int A = 255;
+            if (p.need_alpha) {   // output.c:2193-2201 (X), :2241-2245 (2), :2278-2283 / :2298-2303 (1)
+                if (mode == 0) {
+                    A = 1 << 18;
+                    for (int j = 0; j < lfs; j++) A += (int)((unsigned)ALP(j, i) * (unsigned)(int)lf[j]);
+                    A >>= 19;
+                } else if (mode == 2) A = (ALP(0, i) * (4096 - ya) + ALP(1, i) * ya + (1 << 18)) >> 19;
+                else A = (ALP(0, i) + 64) >> 7;
+                if (A & 0x100) A = clip_u8(A);
+            }
+            d[L.a_pos] = (uint8_t)A;
+        }
     }
 #undef LUM
 #undef CHU
 #undef CHV
+#undef ALP
+}
+
+// destination alpha plane the source cannot feed: fillPlane(dst[3], ..., 255) (swscale.c:536-552)
+__global__ void __launch_bounds__(256) sws_k_fill_alpha_plane(SwsFrameSet fs, int w, int y0)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= w) return;
+    const SwsFramePtrs &f = frame_of(fs, blockIdx.z);
+    f.dst[3][(int64_t)(y0 + blockIdx.y) * f.dstStride[3] + x] = 255;
+}
+
+// yuva2rgba_c / yuva2argb_c (PUTRGBA, yuv2rgb.c:101-105): the 32 bpp LUT converter's pixels (written with A = 0 because
+// the table was built for a source with alpha) get the source alpha byte.  npix = pixels per row the converter covered.
+__global__ void __launch_bounds__(256) sws_k_alpha_merge(SwsFrameSet fs, int npix, int y0, int a_pos)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= npix) return;
+    const SwsFramePtrs &f = frame_of(fs, blockIdx.z);
+    const int y = y0 + blockIdx.y;   // absolute row (the host rebases slice pointers)
+    f.dst[0][(int64_t)y * f.dstStride[0] + 4 * x + a_pos] = f.src[3][(int64_t)y * f.srcStride[3] + x];
 }
 
 // ---- pass-2 / fused kernels over the generic per-element routines ----
@@ -455,7 +523,7 @@ struct SamplerFor {
         } else {
             const T *base = scratch + fi * frame_elems;
             const int64_t lumElems = (int64_t)p.srcH * p.dstW, chrElems = (int64_t)p.chrSrcH * p.chrDstW;
-            return ScratchSampler<T>{base, base + lumElems, base + lumElems + chrElems, p.dstW, p.chrDstW};
+            return ScratchSampler<T>{base, base + lumElems, base + lumElems + chrElems, p.dstW, p.chrDstW, base + lumElems + 2 * chrElems};
         }
     }
 };
@@ -465,7 +533,7 @@ template <bool DIRECT, typename T>
 __global__ void __launch_bounds__(256) sws_k_vscale_planar(SwsFrameSet fs, SwsDevParams p, const T *scratch, int64_t frame_elems, int ncomp)
 {
     const int comp = blockIdx.z % ncomp, fi = blockIdx.z / ncomp;
-    const int W = comp == 0 ? p.dstW : p.chrDstW, H = comp == 0 ? p.dstH : p.chrDstH;
+    const int W = (comp == 0 || comp == 3) ? p.dstW : p.chrDstW, H = (comp == 0 || comp == 3) ? p.dstH : p.chrDstH;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W || y >= H) return;
     const SwsFramePtrs &f = frame_of(fs, fi);

@@ -22,6 +22,8 @@ static const PixDesc g_descs[] = {
 #define PLN(F, N, LW, LH, D)  { F, N, 3, LW, LH, {{0,2,0,0,D},{1,2,0,0,D},{2,2,0,0,D},{0,0,0,0,0}}, PIXFLAG_PLANAR }
 #define SP8(F, N, LW, LH, UO) { F, N, 3, LW, LH, {{0,1,0,0,8},{1,2,UO,0,8},{1,2,1-(UO),0,8},{0,0,0,0,0}}, PIXFLAG_PLANAR }
 #define SPN(F, N, LW, LH, D)  { F, N, 3, LW, LH, {{0,2,0,16-(D),D},{1,4,0,16-(D),D},{1,4,2,16-(D),D},{0,0,0,0,0}}, PIXFLAG_PLANAR }
+#define PLA(F, N, LW, LH)     { F, N, 4, LW, LH, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8},{3,1,0,0,8}}, PIXFLAG_PLANAR | PIXFLAG_ALPHA }
+    PLA(AV_PIX_FMT_YUVA420P, "yuva420p", 1, 1), PLA(AV_PIX_FMT_YUVA422P, "yuva422p", 1, 0), PLA(AV_PIX_FMT_YUVA444P, "yuva444p", 0, 0),
     PL8(AV_PIX_FMT_YUV410P, "yuv410p", 2, 2), PL8(AV_PIX_FMT_YUV411P, "yuv411p", 2, 0), PL8(AV_PIX_FMT_YUV440P, "yuv440p", 0, 1),
     PL8(AV_PIX_FMT_YUVJ422P, "yuvj422p", 1, 0), PL8(AV_PIX_FMT_YUVJ444P, "yuvj444p", 0, 0), PL8(AV_PIX_FMT_YUVJ440P, "yuvj440p", 0, 1),
     PLN(AV_PIX_FMT_YUV420P9LE, "yuv420p9le", 1, 1, 9), PLN(AV_PIX_FMT_YUV422P9LE, "yuv422p9le", 1, 0, 9),

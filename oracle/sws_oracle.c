@@ -75,6 +75,8 @@ static const Desc descs[] = {
 #define PLN(F, N, LW, LH, D)   { F, N, 3, LW, LH, {{0,2,0,0,D},{1,2,0,0,D},{2,2,0,0,D}}, PF_PLANAR }
 #define SP8(F, N, LW, LH, UO)  { F, N, 3, LW, LH, {{0,1,0,0,8},{1,2,UO,0,8},{1,2,1-(UO),0,8}}, PF_PLANAR }
 #define SPN(F, N, LW, LH, D)   { F, N, 3, LW, LH, {{0,2,0,16-(D),D},{1,4,0,16-(D),D},{1,4,2,16-(D),D}}, PF_PLANAR }
+#define PLA(F, N, LW, LH)      { F, N, 4, LW, LH, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8},{3,1,0,0,8}}, PF_PLANAR | PF_ALPHA }
+    PLA(ORF_YUVA420P, "yuva420p", 1, 1), PLA(ORF_YUVA422P, "yuva422p", 1, 0), PLA(ORF_YUVA444P, "yuva444p", 0, 0),
     PL8(ORF_YUV410P, "yuv410p", 2, 2), PL8(ORF_YUV411P, "yuv411p", 2, 0), PL8(ORF_YUV440P, "yuv440p", 0, 1),
     PL8(ORF_YUVJ422P, "yuvj422p", 1, 0), PL8(ORF_YUVJ444P, "yuvj444p", 0, 0), PL8(ORF_YUVJ440P, "yuvj440p", 0, 1),
     PLN(ORF_YUV420P9LE, "yuv420p9le", 1, 1, 9), PLN(ORF_YUV422P9LE, "yuv422p9le", 1, 0, 9), PLN(ORF_YUV444P9LE, "yuv444p9le", 0, 0, 9),
@@ -736,9 +738,9 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
 {
     const int s = c->o.src_format, d = c->o.dst_format, flags = c->o.flags;
     c->unscaled_kind = UNSC_NONE;
-    if (s == ORF_YUV420P && (d == ORF_NV12 || d == ORF_NV21)) c->unscaled_kind = UNSC_PLANAR2NV12;
+    if ((s == ORF_YUV420P || s == ORF_YUVA420P) && (d == ORF_NV12 || d == ORF_NV21)) c->unscaled_kind = UNSC_PLANAR2NV12;
     if (d == ORF_YUV420P && (s == ORF_NV12 || s == ORF_NV21)) c->unscaled_kind = UNSC_NV122PLANAR;
-    if ((s == ORF_YUV420P || s == ORF_YUV422P) && isAnyRGB(d) && !(flags & OR_SWS_ACCURATE_RND) &&
+    if ((s == ORF_YUV420P || s == ORF_YUV422P || s == ORF_YUVA420P) && isAnyRGB(d) && !(flags & OR_SWS_ACCURATE_RND) &&
         (c->o.dither == 2 || c->o.dither == 1) && !(c->o.dst_h & 1)) { /* :2425-2431 */
         /* ff_yuv2rgb_get_func_ptr, yuv2rgb.c:561-678: 24/32 bpp C converters */
         /* yuv2rgb_c_24_rgb/_bgr, yuv2rgb_c_32, yuv420p_gbrp_c / yuv422p_gbrp_c; NULL (-> scaler chain) for gbrp9..16/f32 */
@@ -749,7 +751,7 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
     if (d == ORF_YUV444P && (s == ORF_NV24 || s == ORF_NV42)) c->unscaled_kind = UNSC_NV242PLANAR;   /* :2420-2423 */
     if ((s == ORF_YUV420P10LE || s == ORF_YUV420P12LE || s == ORF_YUV420P14LE || s == ORF_YUV420P16LE) &&
         (d == ORF_P010LE || d == ORF_P016LE)) c->unscaled_kind = UNSC_P01X;                           /* :2432-2439 */
-    if (s == ORF_YUV420P && (d == ORF_P010LE || d == ORF_P016LE)) c->unscaled_kind = UNSC_8_P01X;     /* :2440-2444 */
+    if ((s == ORF_YUV420P || s == ORF_YUVA420P) && (d == ORF_P010LE || d == ORF_P016LE)) c->unscaled_kind = UNSC_8_P01X; /* :2440-2444 */
     if (s == ORF_YUV410P && !(c->o.dst_h & 3) && d == ORF_YUV420P && !(flags & OR_SWS_BITEXACT))
         c->unscaled_kind = UNSC_YVU9_YV12;                                                            /* :2446-2451 */
     /* bgr24toYV12 (:2452-2456) */
@@ -768,7 +770,7 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
     /* planarRgbToRgbWrapper (:2480-2481): gbrp -> byte RGB */
     if (s == ORF_GBRP && isAnyRGB(d) && isPacked(d) && desc_get(d)->c[0].depth == 8) c->unscaled_kind = UNSC_GBRP2PACKED;
     /* simple copy (:2647-2668) */
-    if (s == d ||
+    if (s == d || (s == ORF_YUVA420P && d == ORF_YUV420P) || (s == ORF_YUV420P && d == ORF_YUVA420P) ||
         (isFloat(s) == isFloat(d) &&
          ((isPlanarYUV(s) && isGray(d)) || (isPlanarYUV(d) && isGray(s)) || (isGray(d) && isGray(s)))) ||
         (isFloat(s) == isFloat(d) &&
@@ -856,10 +858,13 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
 
     if (unscaled && (c->o.src_range == c->o.dst_range || isAnyRGB(dstFormat) || isFloat(srcFormat) || isFloat(dstFormat))) {
         get_unscaled(c);
-        if (c->unscaled_kind == UNSC_RGB2RGB || c->unscaled_kind == UNSC_PACKEDCOPY) { c->initialized = 1; return 0; }
-        if (c->unscaled_kind && !c->needAlpha) { c->initialized = 1; return 0; }
+        /* bgr24ToYv12 / yvu9ToYv12 also take a yuva420p destination in the reference (alpha filled with 255): not restated */
+        if (dstFormat == ORF_YUVA420P &&
+            ((srcFormat == ORF_BGR24 && !(flags & OR_SWS_ACCURATE_RND) && !(dstW & 1)) ||
+             (srcFormat == ORF_YUV410P && !(dstH & 3) && !(flags & OR_SWS_BITEXACT)))) return -1;
+        if (c->unscaled_kind) { c->initialized = 1; return 0; }
     }
-    if (c->needAlpha) return -1; /* alpha plane scaling not restated */
+    if (c->needAlpha && isPlanarRGB(dstFormat)) return -1; /* gbrap writers not restated */
 
     /* filters (:1675-1735), filterAlign == 1 in the C-only build */
     ret = init_filter(&c->hLumFilter, &c->hLumFilterPos, &c->hLumFilterSize, c->lumXInc, srcW, dstW, 1, 1 << 14,
@@ -989,6 +994,10 @@ static int unscaled_yuv2rgb(OrSws *c, const uint8_t *const src[], const int srcS
                         else { p[0] = B; p[1] = G; p[2] = R; }
                     } else {
                         uint32_t v = lut_at(c, r + Y) + lut_at(c, g + Y) + lut_at(c, b + Y);
+                        if (isALPHA(c->o.src_format)) { /* yuva2rgba_c / yuva2argb_c: PUTRGBA yuv2rgb.c:101-105, :524-528 */
+                            const int abase = (d == ORF_ARGB || d == ORF_ABGR) ? 0 : 24;
+                            v += (uint32_t)src[3][(ptrdiff_t)yy * srcStride[3] + 2 * i + k] << abase;
+                        }
                         memcpy(out + 8 * i + 4 * k, &v, 4);
                     }
                 }
@@ -1275,6 +1284,13 @@ static int unscaled_planarcopy(OrSws *c, const uint8_t *const src[], const int s
     const Desc *ds = desc_get(c->o.src_format), *dd = desc_get(c->o.dst_format);
     const int sf = c->o.src_format, df = c->o.dst_format;
     int nplanes = isGray(df) ? 1 : isSemiPlanarYUV(df) ? 2 : 3;
+    if (isALPHA(df) && isPlanarYUV(df)) { /* plane 3 (:2226-2247): copied when the source has one, 255 otherwise */
+        for (int i = 0; i < srcSliceH; i++) {
+            uint8_t *row = dst[3] + (ptrdiff_t)(srcSliceY + i) * dstStride[3];
+            if (isALPHA(sf)) memcpy(row, src[3] + (ptrdiff_t)i * srcStride[3], c->o.src_w);
+            else memset(row, 255, c->o.src_w);
+        }
+    }
     for (int plane = 0; plane < nplanes; plane++) {
         if (plane > 0 && isGray(sf)) { /* gray source: chroma planes are filled with mid-grey (fillPlane / fillPlane16 :2239-2247) */
             int flen = CEIL_RSHIFT(c->o.src_w, c->chrDstHSub) * (isSemiPlanarYUV(df) ? 2 : 1);
@@ -1742,7 +1758,7 @@ static void write_nv_chroma_line(const OrSws *c, uint8_t *dest, int w, const int
 }
 
 /* LUT rgb pixel-pair write (yuv2rgb_write, output.c:1662-1785; 24/32 bpp) */
-static void rgb_write2(const OrSws *c, uint8_t *dest, int i, int Y1, int Y2, int U, int V)
+static void rgb_write2(const OrSws *c, uint8_t *dest, int i, int Y1, int Y2, int U, int V, int hasAlpha, unsigned A1, unsigned A2)
 {
     const int d = c->o.dst_format;
     int r = c->table_rV[V + HEADROOM];
@@ -1751,6 +1767,10 @@ static void rgb_write2(const OrSws *c, uint8_t *dest, int i, int Y1, int Y2, int
     if (c->lut_elem == 4) {
         uint32_t v1 = lut_at(c, r + Y1) + lut_at(c, g + Y1) + lut_at(c, b + Y1);
         uint32_t v2 = lut_at(c, r + Y2) + lut_at(c, g + Y2) + lut_at(c, b + Y2);
+        if (hasAlpha) { /* yuv2rgb_write output.c:1680-1687 */
+            const int sh = (d == ORF_ABGR || d == ORF_ARGB) ? 0 : 24;
+            v1 += A1 << sh; v2 += A2 << sh;
+        }
         memcpy(dest + 8 * i, &v1, 4); memcpy(dest + 8 * i + 4, &v2, 4);
     } else {
         uint8_t *p = dest + 6 * i;
@@ -1761,7 +1781,7 @@ static void rgb_write2(const OrSws *c, uint8_t *dest, int i, int Y1, int Y2, int
 }
 
 /* full-chroma pixel write (yuv2rgb_write_full, output.c:2005-2070; 8-bit per channel targets) */
-static void rgb_write_full(const OrSws *c, uint8_t *dest, int Y, int U, int V)
+static void rgb_write_full(const OrSws *c, uint8_t *dest, int Y, int U, int V, int hasAlpha, int A)
 {
     const int d = c->o.dst_format;
     int R, G, B;
@@ -1776,17 +1796,18 @@ static void rgb_write_full(const OrSws *c, uint8_t *dest, int Y, int U, int V)
     }
     R >>= 22; G >>= 22; B >>= 22;
     switch (d) {
-    case ORF_ARGB: dest[0] = 255; dest[1] = (uint8_t)R; dest[2] = (uint8_t)G; dest[3] = (uint8_t)B; break;
+    case ORF_ARGB: dest[0] = hasAlpha ? (uint8_t)A : 255; dest[1] = (uint8_t)R; dest[2] = (uint8_t)G; dest[3] = (uint8_t)B; break;
     case ORF_RGB24: dest[0] = (uint8_t)R; dest[1] = (uint8_t)G; dest[2] = (uint8_t)B; break;
-    case ORF_RGBA: dest[0] = (uint8_t)R; dest[1] = (uint8_t)G; dest[2] = (uint8_t)B; dest[3] = 255; break;
-    case ORF_ABGR: dest[0] = 255; dest[1] = (uint8_t)B; dest[2] = (uint8_t)G; dest[3] = (uint8_t)R; break;
+    case ORF_RGBA: dest[0] = (uint8_t)R; dest[1] = (uint8_t)G; dest[2] = (uint8_t)B; dest[3] = hasAlpha ? (uint8_t)A : 255; break;
+    case ORF_ABGR: dest[0] = hasAlpha ? (uint8_t)A : 255; dest[1] = (uint8_t)B; dest[2] = (uint8_t)G; dest[3] = (uint8_t)R; break;
     case ORF_BGR24: dest[0] = (uint8_t)B; dest[1] = (uint8_t)G; dest[2] = (uint8_t)R; break;
-    case ORF_BGRA: dest[0] = (uint8_t)B; dest[1] = (uint8_t)G; dest[2] = (uint8_t)R; dest[3] = 255; break;
+    case ORF_BGRA: dest[0] = (uint8_t)B; dest[1] = (uint8_t)G; dest[2] = (uint8_t)R; dest[3] = hasAlpha ? (uint8_t)A : 255; break;
     }
 }
 
 typedef struct {
     int32_t *lum, *chrU, *chrV; /* h-scaled planes: [srcH][dstW], [chrSrcH][chrDstW] */
+    int32_t *alp;               /* h-scaled alpha plane [srcH][dstW] when needAlpha (hscale.c:137, vscale.c:59-71) */
 } Planes;
 
 /* packed_vscale (vscale.c:109-171) + yuv2rgb_{X,2,1}_c_template (output.c:1788-1939)
@@ -1806,6 +1827,8 @@ static void write_packed_rgb_line(const OrSws *c, const Planes *P, uint8_t *dest
 #define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
 #define CU(j) (P->chrU + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
 #define CV(j) (P->chrV + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+#define AL(j) (P->alp + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+    const int hasAlpha = c->needAlpha;
     int mode; /* 1: packed1 (uvalpha in ua), 2: packed2, 0: X */
     int ua = 0, ya = 0;
     if (lfs == 1 && cfs == 1) { mode = 1; ua = 0; }
@@ -1838,7 +1861,27 @@ static void write_packed_rgb_line(const OrSws *c, const Planes *P, uint8_t *dest
                     V = (CV(0)[i] * ua1 + CV(1)[i] * ua + (128 << 11)) >> 19;
                 }
             }
-            rgb_write2(c, dest, i, Y1, Y2, U, V);
+            {   /* alpha of the pixel pair: output.c:1818-1830 (X), :1870-1875 (2), :1904-1908 / :1929-1933 (1) */
+                int A1 = 0, A2 = 0;
+                if (hasAlpha) {
+                    if (mode == 0) {
+                        A1 = A2 = 1 << 18;
+                        for (j = 0; j < lfs; j++) { A1 += (int)(AL(j)[2 * i] * (unsigned)lf[j]); A2 += (int)(AL(j)[2 * i + 1] * (unsigned)lf[j]); }
+                        A1 >>= 19; A2 >>= 19;
+                        if ((A1 | A2) & 0x100) { A1 = clip_u8(A1); A2 = clip_u8(A2); }
+                    } else if (mode == 2) {
+                        A1 = clip_u8((AL(0)[2 * i] * (4096 - ya) + AL(1)[2 * i] * ya) >> 19);
+                        A2 = clip_u8((AL(0)[2 * i + 1] * (4096 - ya) + AL(1)[2 * i + 1] * ya) >> 19);
+                    } else if (ua == 0) {
+                        A1 = clip_u8((AL(0)[2 * i] * 255 + 16384) >> 15);
+                        A2 = clip_u8((AL(0)[2 * i + 1] * 255 + 16384) >> 15);
+                    } else {
+                        A1 = clip_u8((AL(0)[2 * i] + 64) >> 7);
+                        A2 = clip_u8((AL(0)[2 * i + 1] + 64) >> 7);
+                    }
+                }
+                rgb_write2(c, dest, i, Y1, Y2, U, V, hasAlpha, (unsigned)A1, (unsigned)A2);
+            }
         }
     } else {
         for (i = 0; i < dstW; i++) {
@@ -1862,12 +1905,25 @@ static void write_packed_rgb_line(const OrSws *c, const Planes *P, uint8_t *dest
                     V = (CV(0)[i] * ua1 + CV(1)[i] * ua - (128 << 19)) >> 10;
                 }
             }
-            rgb_write_full(c, dest + step * i, Y, U, V);
+            {   /* output.c:2193-2201 (X), :2241-2245 (2), :2278-2283 / :2298-2303 (1) */
+                int A = 0;
+                if (hasAlpha) {
+                    if (mode == 0) {
+                        A = 1 << 18;
+                        for (j = 0; j < lfs; j++) A += (int)(AL(j)[i] * (unsigned)lf[j]);
+                        A >>= 19;
+                    } else if (mode == 2) A = (AL(0)[i] * (4096 - ya) + AL(1)[i] * ya + (1 << 18)) >> 19;
+                    else A = (AL(0)[i] + 64) >> 7;
+                    if (A & 0x100) A = clip_u8(A);
+                }
+                rgb_write_full(c, dest + step * i, Y, U, V, hasAlpha, A);
+            }
         }
     }
 #undef L
 #undef CU
 #undef CV
+#undef AL
 }
 
 /* any_vscale (vscale.c:173-212) + yuv2gbrp_full_X_c / yuv2gbrp16_full_X_c / yuv2gbrpf32_full_X_c (output.c:2342-2580):
@@ -1958,6 +2014,22 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
         hscale_line(c, d, dstW, line, c->hLumFilter, c->hLumFilterPos, c->hLumFilterSize);
         if (c->range_active) range_line(c, d, dstW, 0);
     }
+    P.alp = NULL;
+    if (c->needAlpha) { /* lum_convert/lum_h_scale also process plane 3 (hscale.c:39-131, desc->alpha) with the LUMA filter; no range conversion */
+        P.alp = malloc((size_t)srcH * dstW * sizeof(int32_t));
+        for (y = 0; y < srcH; y++) {
+            const uint8_t *line;
+            if (isAnyRGB(sf)) { /* rgbaToA_c / abgrToA_c input.c:454-472 */
+                const Desc *dsd = desc_get(sf);
+                const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0] + dsd->c[3].offset;
+                int16_t *d16 = (int16_t *)t0;
+                const int opaque = c->src0Alpha && !c->dst0Alpha; /* rgb0-style source: swscale.c:1106-1124 sets the X byte to 255 first */
+                for (int i = 0; i < srcW; i++) { const int a = opaque ? 255 : sp[4 * i]; d16[i] = (int16_t)(a << 6 | a >> 2); }
+                line = t0;
+            } else line = src[3] + (ptrdiff_t)y * srcStride[3];
+            hscale_line(c, P.alp + (size_t)y * dstW, dstW, line, c->hLumFilter, c->hLumFilterPos, c->hLumFilterSize);
+        }
+    }
     const int needs_hcscale = !(isGray(sf) || isGray(df));   /* swscale.c:692-694 */
     if (!needs_hcscale) { /* ff_init_desc_no_chr: the chroma lines keep fill_ones()' value (slice.c:190-208, :358-361) */
         const int32_t neutral = c->dstBpc >= 16 ? 1 << 18 : 1 << 14;
@@ -1985,6 +2057,12 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
             int firstLum = ORMAX(1 - c->vLumFilterSize, c->vLumFilterPos[y]);
             write_planar_line(c, dst[0] + (size_t)y * dstStride[0], dstW, P.lum, dstW, srcH, firstLum,
                               c->vLumFilter + y * c->vLumFilterSize, c->vLumFilterSize, lumDither, 0, 1);
+            if (isALPHA(df)) {
+                if (c->needAlpha) /* lum_planar_vscale vscale.c:59-71: same writer, luma filter, luma dither */
+                    write_planar_line(c, dst[3] + (size_t)y * dstStride[3], dstW, P.alp, dstW, srcH, firstLum,
+                                      c->vLumFilter + y * c->vLumFilterSize, c->vLumFilterSize, lumDither, 0, 1);
+                else memset(dst[3] + (size_t)y * dstStride[3], 255, dstW); /* fillPlane swscale.c:536-552 (8-bit alpha only here) */
+            }
             if (!(y & ((1 << c->chrDstVSub) - 1))) { /* chr_planar_vscale vscale.c:74-107 */
                 int firstChr = ORMAX(1 - c->vChrFilterSize, c->vChrFilterPos[chrDstY]);
                 const int16_t *cf = c->vChrFilter + chrDstY * c->vChrFilterSize;
@@ -2004,7 +2082,7 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
             write_planar_rgb_line(c, &P, dst, dstStride, y);
         }
     }
-    free(P.lum); free(P.chrU); free(P.chrV); free(t0); free(t1);
+    free(P.lum); free(P.chrU); free(P.chrV); free(P.alp); free(t0); free(t1);
     return dstH;
 }
 
@@ -2023,7 +2101,7 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
         const int opaque = c->src0Alpha && !c->dst0Alpha && isALPHA(c->o.dst_format);
         if (c->unscaled_kind == UNSC_RGB2RGB) return unscaled_rgb2rgb(c, src, srcStride, 0, srcSliceH, dst, dstStride, opaque);
         if (c->unscaled_kind == UNSC_PACKEDCOPY) return unscaled_packedcopy(c, src, srcStride, 0, srcSliceH, dst, dstStride, opaque);
-        if (opaque) return -22; /* other paths: needAlpha contexts are rejected at init */
+        if (opaque && c->unscaled_kind) return -22; /* no other special converter takes an rgb0-style source to an alpha destination */
     }
     switch (c->unscaled_kind) {
     case UNSC_YUV2RGB: return unscaled_yuv2rgb(c, src, srcStride, 0, srcSliceH, dst, dstStride);

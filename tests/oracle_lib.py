@@ -15,6 +15,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 _FORMATS = {
     "yuv420p": (0, "planar", 1, 1, 1), "yuvj420p": (12, "planar", 1, 1, 1), "yuv422p": (4, "planar", 1, 0, 1),
     "yuvj422p": (13, "planar", 1, 0, 1), "yuv444p": (5, "planar", 0, 0, 1), "yuvj444p": (14, "planar", 0, 0, 1),
+    "yuva420p": (33, "planara", 1, 1, 1), "yuva422p": (78, "planara", 1, 0, 1), "yuva444p": (79, "planara", 0, 0, 1),
     "yuv410p": (6, "planar", 2, 2, 1), "yuv411p": (7, "planar", 2, 0, 1), "yuv440p": (31, "planar", 0, 1, 1),
     "yuvj440p": (32, "planar", 0, 1, 1),
     "yuv420p9le": (60, "planar", 1, 1, 2), "yuv422p9le": (70, "planar", 1, 0, 2), "yuv444p9le": (66, "planar", 0, 0, 2),
@@ -46,6 +47,8 @@ def plane_layout(fmt, w, h):
     cw, ch = -(-w >> lw), -(-h >> lh)
     if kind == "planar":
         return [(bps * w, h), (bps * cw, ch), (bps * cw, ch)]
+    if kind == "planara":
+        return [(bps * w, h), (bps * cw, ch), (bps * cw, ch), (bps * w, h)]
     if kind == "semi":
         return [(bps * w, h), (2 * bps * cw, ch)]
     if kind == "rgbp":

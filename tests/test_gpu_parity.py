@@ -78,7 +78,7 @@ def test_c5_float_rgb_to_yuv444p16_bt2020_full():
              colorspace=(SWS_CS_BT2020, 1, SWS_CS_BT2020, 1))
 
 
-YUV_FAMILY = ["yuv420p", "yuv422p", "yuv444p", "yuv410p", "yuv411p", "yuv440p", "yuvj420p", "yuvj422p", "yuvj444p", "yuvj440p",
+YUV_FAMILY = ["yuva420p", "yuva422p", "yuva444p", "yuv420p", "yuv422p", "yuv444p", "yuv410p", "yuv411p", "yuv440p", "yuvj420p", "yuvj422p", "yuvj444p", "yuvj440p",
               "nv12", "nv21", "nv16", "nv24", "nv42",
               "yuv420p9le", "yuv422p9le", "yuv444p9le", "yuv420p10le", "yuv422p10le", "yuv444p10le", "yuv440p10le",
               "yuv420p12le", "yuv422p12le", "yuv444p12le", "yuv440p12le", "yuv420p14le", "yuv422p14le", "yuv444p14le",
@@ -94,8 +94,6 @@ FORMAT_MATRIX_DST = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abg
 @pytest.mark.parametrize("dfmt", FORMAT_MATRIX_DST)
 def test_format_matrix_scaled(sfmt, dfmt):
     """every supported src x dst pair through the scaled (two-pass) path, bicubic down-scale."""
-    if OL.FMT[sfmt] in (26, 28, 25, 27) and OL.FMT[dfmt] in (26, 28, 25, 27):
-        pytest.skip("alpha -> alpha needs the alpha plane path (not implemented, init fails like documented)")
     run_case(98, 66, sfmt, 64, 40, dfmt, SWS_BICUBIC | BX | AR, seed=3)
 
 
@@ -155,7 +153,7 @@ def _slice_ptrs(frame, fmt, y0):
     p, s = frame.ptrs()
     q = (C.c_void_p * 4)()
     for i in range(frame.nplanes):
-        rows = y0 if (i == 0 or kind in ("rgbp", "packed", "gray")) else (y0 >> lh)
+        rows = y0 if (i == 0 or i == 3 or kind in ("rgbp", "packed", "gray")) else (y0 >> lh)   # plane 3 = alpha: full height
         q[i] = p[i] + rows * s[i]
     return q, s
 
@@ -167,6 +165,8 @@ SLICED_UNSCALED = [
     ("p010le", "p016le", BX), ("nv12", "nv12", BX), ("rgb24", "bgr24", BX), ("rgba", "argb", BX), ("rgb24", "abgr", 0), ("bgr0", "rgba", BX),
     ("rgba", "rgba", BX), ("rgb0", "rgba", BX), ("bgr24", "yuv420p", BX), ("gbrp", "rgb24", BX), ("gbrp", "bgra", BX), ("rgb24", "gbrp", BX),
     ("argb", "gbrp", BX), ("gbrp", "gbrp", BX), ("gbrp10le", "gbrp10le", BX),
+    ("yuva420p", "rgba", BX), ("yuva420p", "abgr", BX), ("yuva420p", "yuv420p", BX), ("yuv420p", "yuva420p", BX), ("yuva444p", "yuva444p", BX),
+    ("yuva420p", "nv12", BX), ("yuva420p", "p010le", BX),
     ("yuvj420p", "gray8", BX), ("gray8", "yuvj444p", BX), ("gray8", "gray16le", BX), ("gray12le", "gray8", BX), ("gray10le", "yuvj420p", BX),
 ]
 
@@ -215,6 +215,27 @@ def test_fast_bilinear(geom):
                        ("yuv420p", "yuv444p16le"), ("yuv420p10le", "yuv420p"), ("rgb24", "yuv420p"), ("yuv410p", "gbrp")):
         run_case(sw, sh, sfmt, dw & ~1, dh, dfmt, FB | BX, seed=sw)
         run_case(sw, sh, sfmt, dw & ~1, dh, dfmt, FB, seed=sw + 1)
+
+
+ALPHA_FMTS = ["rgba", "bgra", "argb", "abgr", "yuva420p", "yuva422p", "yuva444p"]
+
+
+@pytest.mark.parametrize("sfmt", ALPHA_FMTS + ["rgb0", "0bgr", "yuv420p", "rgb24"])
+@pytest.mark.parametrize("dfmt", ALPHA_FMTS + ["bgr0"])
+def test_alpha_plane_scaling(sfmt, dfmt):
+    """needAlpha (utils.c:1746): the A byte / plane 3 goes through the luma filters (hscale.c:39-131, vscale.c:59-71) and the
+    alpha arithmetic of the packed writers (output.c:1818-1830, :2193-2201, and the _1/_2 forms); destinations with an alpha
+    the source cannot feed get 255."""
+    for (sw, sh, dw, dh, fl) in ((64, 48, 40, 30, SWS_BICUBIC | BX), (64, 48, 97, 75, SWS_BILINEAR | BX), (64, 48, 64, 96, SWS_BILINEAR),
+                                 (64, 48, 64, 48, SWS_BICUBIC | BX | AR), (66, 48, 35, 48, OL.SWS_POINT | BX), (64, 48, 128, 48, OL.SWS_FAST_BILINEAR | BX)):
+        try:
+            OL.Oracle(sw, sh, sfmt, dw, dh, dfmt, fl)
+        except RuntimeError:
+            continue
+        run_case(sw, sh, sfmt, dw, dh, dfmt, fl, seed=sw + dw)
+    for dfmt2 in ("rgba", "argb", "bgra", "abgr"):   # yuva2rgba_c / yuva2argb_c special converters
+        if sfmt == "yuva420p":
+            assert run_case(64, 48, sfmt, 64, 48, dfmt2, SWS_BICUBIC | BX, seed=9) == ("unscaled:yuv2rgb", "yuv2rgb_c")
 
 
 SLICED_SCALED = [
@@ -270,7 +291,7 @@ def test_scaled_path_accepts_slices(case, bottom_up):
                 _, kind, _, lh, _ = OL._FORMATS[sfmt]
                 sp, ss = (C.c_void_p * 4)(), (C.c_int * 4)()
                 for i, a in enumerate(hs.planes):
-                    rows = y0 if (i == 0 or kind in ("rgbp", "packed", "gray")) else (y0 >> lh)
+                    rows = y0 if (i == 0 or i == 3 or kind in ("rgbp", "packed", "gray")) else (y0 >> lh)
                     sp[i] = a.ctypes.data + rows * a.strides[0]
                     ss[i] = a.strides[0]
             rets.append(p.L.sws_scale(p.c, sp, ss, y0, n, dp, dstr))
