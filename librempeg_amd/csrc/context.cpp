@@ -136,7 +136,8 @@ void choose_unscaled(SwsInternal *c)
     if (s == AV_PIX_FMT_GBRP && isAnyRGB(d) && !isPlanarRGB(d)) k = PLAN_UNSC_GBRP_PACKED;             // planarRgbToRgbWrapper (:2480-2481)
     // bgr24ToYv12 / yvu9ToYv12 also take a yuva420p destination in the reference (alpha filled with 255): not built
     if (d == AV_PIX_FMT_YUVA420P && ((s == AV_PIX_FMT_BGR24 && !(flags & SWS_ACCURATE_RND) && !(c->opts.dst_w & 1)) ||
-                                     (s == AV_PIX_FMT_YUV410P && !(c->opts.dst_h & 3) && !(flags & SWS_BITEXACT)))) unsupported = true;
+                                     (s == AV_PIX_FMT_YUV410P && !(c->opts.dst_h & 3) && !(flags & SWS_BITEXACT)) ||
+                                     s == AV_PIX_FMT_YUYV422 || s == AV_PIX_FMT_UYVY422)) unsupported = true;
     if (s == d || (s == AV_PIX_FMT_YUVA420P && d == AV_PIX_FMT_YUV420P) || (s == AV_PIX_FMT_YUV420P && d == AV_PIX_FMT_YUVA420P) ||
         (isFloatFmt(s) == isFloatFmt(d) && ((isPlanarYUV(s) && isGray(d)) || (isPlanarYUV(d) && isGray(s)) || (isGray(d) && isGray(s)))) ||
         (isFloatFmt(s) == isFloatFmt(d) && isPlanarYUV(s) && isPlanarYUV(d) &&
@@ -146,6 +147,11 @@ void choose_unscaled(SwsInternal *c)
         else { k = PLAN_UNSC_PLANARCOPY;
                if (c->opts.dither != SWS_DITHER_NONE) c->dst_slice_align = 8 << c->chrDstVSubSample; }
     }
+    if (s == AV_PIX_FMT_YUV422P && (d == AV_PIX_FMT_YUYV422 || d == AV_PIX_FMT_UYVY422)) k = PLAN_UNSC_PLANAR2P422;   // :2667-2672
+    if ((flags & (SWS_FAST_BILINEAR | SWS_POINT)) && (s == AV_PIX_FMT_YUV420P || s == AV_PIX_FMT_YUVA420P) &&
+        (d == AV_PIX_FMT_YUYV422 || d == AV_PIX_FMT_UYVY422)) k = PLAN_UNSC_PLANAR2P422;                               // :2684-2692
+    if ((s == AV_PIX_FMT_YUYV422 || s == AV_PIX_FMT_UYVY422) && (d == AV_PIX_FMT_YUV420P || d == AV_PIX_FMT_YUV422P))
+        k = PLAN_UNSC_P4222PLANAR;                                                                                     // :2693-2702
     if (d == AV_PIX_FMT_YUV420P && (s == AV_PIX_FMT_NV24 || s == AV_PIX_FMT_NV42)) k = PLAN_UNSC_NV242YUV420;         // :2703-2705
     c->plan = unsupported ? PLAN_NONE : k;
     if (unsupported) c->plan = (PlanKind)-1;

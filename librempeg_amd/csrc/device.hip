@@ -96,6 +96,7 @@ static int src_kind_of(int f)
     if (!d) return -1;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? SRCK_GBRPF32 : d->comp[0].depth > 8 ? SRCK_GBRP16 : SRCK_GBRP;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? SRCK_RGB24 : SRCK_RGB32;
+    if (isYUV(f) && isPackedFmt(f)) return SRCK_PACKED422;
     if (isSemiPlanarYUV(f)) return d->comp[0].depth == 8 ? SRCK_NV12 : SRCK_P010;
     if (isPlanarYUV(f) || isGray(f)) return d->comp[0].depth == 8 ? SRCK_PLANAR8 : SRCK_PLANAR16;
     return -1;
@@ -106,6 +107,7 @@ static int dst_kind_of(int f)
     if (!d) return -1;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? DSTK_GBRPF32 : d->comp[0].depth == 16 ? DSTK_GBRP16 : DSTK_GBRP;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? DSTK_RGB24 : DSTK_RGB32;
+    if (isYUV(f) && isPackedFmt(f)) return DSTK_PACKED422;
     const int depth = d->comp[0].depth;
     if (isSemiPlanarYUV(f)) return depth == 8 ? DSTK_NV12 : depth == 16 ? DSTK_P016 : DSTK_P010;
     if (isPlanarYUV(f) || isGray(f)) return depth == 8 ? DSTK_PLANAR8 : depth == 16 ? DSTK_PLANAR16 : DSTK_PLANARN;
@@ -152,7 +154,7 @@ int dev_prepare(SwsInternal *c)
     p.u_plane_dst = dd->comp[1].plane; p.v_plane_dst = dd->comp[2].plane;
     const bool gray_any = isGray(o.src_format) || isGray(o.dst_format) || c->needAlpha;   // paths the fused kernels do not cover
     p.should_dither = isNBPS(o.src_format) || is16BPS(o.src_format);     // swscale.c:292-293
-    p.full_chr = (o.flags & SWS_FULL_CHR_H_INT) ? 1 : 0;
+    p.full_chr = ((o.flags & SWS_FULL_CHR_H_INT) && isAnyRGB(o.dst_format)) ? 1 : 0;
     if (isAnyRGB(o.src_format) && !isPlanarRGB(o.src_format)) {
         p.src_pix_step = ds->comp[0].step;
         p.src_r_pos = ds->comp[0].offset; p.src_g_pos = ds->comp[1].offset; p.src_b_pos = ds->comp[2].offset;
@@ -203,6 +205,8 @@ int dev_prepare(SwsInternal *c)
         p.shiftU = dd->comp[1].depth + dd->comp[1].shift - ds->comp[1].depth - ds->comp[1].shift;
         p.shiftV = dd->comp[2].depth + dd->comp[2].shift - ds->comp[2].depth - ds->comp[2].shift;
     }
+    p.s422_y = ds->comp[0].offset; p.s422_u = ds->comp[1].offset; p.s422_v = ds->comp[2].offset;
+    p.d422_y = dd->comp[0].offset; p.d422_u = dd->comp[1].offset; p.d422_v = dd->comp[2].offset;
     p.need_alpha = c->needAlpha;                                                             // utils.c:1746
     p.src_a_pos = (isALPHA(o.src_format) && !isPlanarFmt(o.src_format)) ? ds->comp[3].offset : 0;
     p.src_alpha_opaque = c->src0Alpha && !c->dst0Alpha && isALPHA(o.dst_format);
@@ -472,6 +476,8 @@ int dev_prepare(SwsInternal *c)
     case PLAN_UNSC_YVU9_YV12: c->path_name = "unscaled:yvu9ToYv12"; c->kernel_name = "sws_k_planar_misc"; break;
     case PLAN_UNSC_YUV2GBRP: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2gbrp_unscaled"; break;
     case PLAN_UNSC_PACKED_GBRP: c->path_name = "unscaled:rgbToPlanarRgb"; c->kernel_name = "sws_k_packed_to_gbrp"; break;
+    case PLAN_UNSC_PLANAR2P422: c->path_name = "unscaled:planarToYuy2"; c->kernel_name = "sws_k_planar_to_p422"; break;
+    case PLAN_UNSC_P4222PLANAR: c->path_name = "unscaled:yuyvToPlanar"; c->kernel_name = "sws_k_p422_to_planar"; break;
     case PLAN_CASCADE: c->path_name = "cascade"; c->kernel_name = ""; break;
     case PLAN_MAIN: {
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
@@ -748,6 +754,18 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         hipLaunchKernelGGL(swsk::sws_k_yuv2gbrp_unscaled, grid, blk, 0, st, fs, p, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 0, npairs, sliceY);
         break;
     }
+    case PLAN_UNSC_PLANAR2P422: {
+        const int npairs = p.srcW >> 1;
+        if (!npairs || !sliceH) break;
+        const dim3 grid(cdiv(npairs, 256), sliceH, n);
+        hipLaunchKernelGGL(swsk::sws_k_planar_to_p422, grid, blk, 0, st, fs, p, npairs, sliceY, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 2);
+        break;
+    }
+    case PLAN_UNSC_P4222PLANAR: {
+        const dim3 grid(cdiv((p.srcW + 1) >> 1, 256), sliceH, n);
+        hipLaunchKernelGGL(swsk::sws_k_p422_to_planar, grid, blk, 0, st, fs, p, p.srcW, sliceY, c->opts.dst_format == AV_PIX_FMT_YUV420P ? 1 : 0);
+        break;
+    }
     case PLAN_UNSC_PACKED_GBRP: {
         const PixDesc *ds = pix_desc(c->opts.src_format);
         swsk::ShufflePlan sp;
@@ -787,7 +805,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
             hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.dstW, 0);
         }
         const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 ||
-                         p.dstKind == DSTK_GBRPF32;
+                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
         if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;

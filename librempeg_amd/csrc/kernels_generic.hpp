@@ -90,6 +90,10 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         }
         return (uint16_t)((int)((unsigned)t[o] * R[x] + (unsigned)t[o + 1] * G[x] + (unsigned)t[o + 2] * B[x] + (0x4001 << 8)) >> 9);
     }
+    case SRCK_PACKED422: { // yuy2ToY_c / yuy2ToUV_c / yvy2ToUV_c (input.c:550-578), uyvyToY_c / uyvyToUV_c (:890-907)
+        const uint8_t *s = f.src[0] + (int64_t)row * f.srcStride[0];
+        return comp == 0 ? s[2 * x + p.s422_y] : s[4 * x + (comp == 1 ? p.s422_u : p.s422_v)];
+    }
     case SRCK_GBRP16: { // planar_rgb16_s16_to_y / _to_uv, input.c:1216-1270
         const int g = *(const uint16_t *)(f.src[0] + (int64_t)row * f.srcStride[0] + 2 * x);
         const int b = *(const uint16_t *)(f.src[1] + (int64_t)row * f.srcStride[1] + 2 * x);
@@ -373,6 +377,34 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
     else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 1; ua = (uint16_t)cf[1]; }
     else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
              (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 2; ya = (uint16_t)lf[1]; ua = (uint16_t)cf[1]; }
+    if (p.dstKind == DSTK_PACKED422) {   // yuv2422_{X,2,1}_c_template, output.c:883-1000
+        int Y1, Y2, U, V;
+        if (mode == 0) {
+            Y1 = Y2 = U = V = 1 << 18;
+            for (int j = 0; j < lfs; j++) {
+                Y1 += (int)((unsigned)LUM(j, 2 * i) * (unsigned)(int)lf[j]);
+                Y2 += (int)((unsigned)LUM(j, 2 * i + 1) * (unsigned)(int)lf[j]);
+            }
+            for (int j = 0; j < cfs; j++) {
+                U += (int)((unsigned)CHU(j, i) * (unsigned)(int)cf[j]);
+                V += (int)((unsigned)CHV(j, i) * (unsigned)(int)cf[j]);
+            }
+            Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
+        } else if (mode == 2) {
+            Y1 = (LUM(0, 2 * i) * (4096 - ya) + LUM(1, 2 * i) * ya) >> 19;
+            Y2 = (LUM(0, 2 * i + 1) * (4096 - ya) + LUM(1, 2 * i + 1) * ya) >> 19;
+            U = (CHU(0, i) * (4096 - ua) + CHU(1, i) * ua) >> 19;
+            V = (CHV(0, i) * (4096 - ua) + CHV(1, i) * ua) >> 19;
+        } else {
+            Y1 = (LUM(0, 2 * i) + 64) >> 7; Y2 = (LUM(0, 2 * i + 1) + 64) >> 7;
+            if (ua < 2048) { U = (CHU(0, i) + 64) >> 7; V = (CHV(0, i) + 64) >> 7; }
+            else { U = (CHU(0, i) + CHU(1, i) + 128) >> 8; V = (CHV(0, i) + CHV(1, i) + 128) >> 8; }
+        }
+        if ((Y1 | Y2 | U | V) & 0x100) { Y1 = clip_u8(Y1); Y2 = clip_u8(Y2); U = clip_u8(U); V = clip_u8(V); }
+        uint8_t *d = drow + 4 * i;
+        d[p.d422_y] = (uint8_t)Y1; d[p.d422_y + 2] = (uint8_t)Y2; d[p.d422_u] = (uint8_t)U; d[p.d422_v] = (uint8_t)V;
+        return;
+    }
     if (!p.full_chr) {
         int Y1, Y2, U, V;
         if (mode == 0) {

@@ -154,6 +154,47 @@ __global__ void __launch_bounds__(256) sws_k_yuv2gbrp_unscaled(SwsFrameSet fs, S
     }
 }
 
+// yuv422pToYuy2/UyvyWrapper, planarToYuy2/UyvyWrapper (swscale_unscaled.c:376-422) -> yuvPlanartoyuy2_c / yuvPlanartouyvy_c
+// (rgb2rgb_template.c:379-470): thread = pixel pair; vlpc = luma rows per chroma row (1 or 2), counted from the slice start.
+__global__ void __launch_bounds__(256) sws_k_planar_to_p422(SwsFrameSet fs, SwsDevParams p, int npairs, int sliceY, int vlpc)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int y = blockIdx.y;                                   // slice-relative row
+    const int cr = (vlpc == 2 ? (sliceY >> 1) : sliceY) + y / vlpc;   // absolute chroma row (host rebases slice pointers)
+    const uint8_t *ys = f.src[0] + (int64_t)(sliceY + y) * f.srcStride[0] + 2 * i;
+    uint8_t *d = f.dst[0] + (int64_t)(sliceY + y) * f.dstStride[0] + 4 * i;
+    d[p.d422_y] = ys[0]; d[p.d422_y + 2] = ys[1];
+    d[p.d422_u] = f.src[1][(int64_t)cr * f.srcStride[1] + i];
+    d[p.d422_v] = f.src[2][(int64_t)cr * f.srcStride[2] + i];
+}
+
+// yuyv/uyvy ToYuv420/422Wrapper (swscale_unscaled.c:424-484) -> yuyvtoyuv420_c .. uyvytoyuv422_c (rgb2rgb_template.c:751-825).
+// grid.y = luma rows of the slice; thread = pixel pair: two luma samples, and the chroma sample of the row (4:2:2) or the
+// truncating mean of rows (y-1, y) on odd slice rows (4:2:0).
+__global__ void __launch_bounds__(256) sws_k_p422_to_planar(SwsFrameSet fs, SwsDevParams p, int w, int sliceY, int to420)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int cw = (w + 1) >> 1;
+    if (i >= cw) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int y = blockIdx.y;
+    const uint8_t *s = f.src[0] + (int64_t)(sliceY + y) * f.srcStride[0] + 4 * i;
+    uint8_t *yd = f.dst[0] + (int64_t)(sliceY + y) * f.dstStride[0] + 2 * i;
+    yd[0] = s[p.s422_y];
+    if (2 * i + 1 < w) yd[1] = s[p.s422_y + 2];
+    if (!to420) {
+        f.dst[1][(int64_t)(sliceY + y) * f.dstStride[1] + i] = s[p.s422_u];
+        f.dst[2][(int64_t)(sliceY + y) * f.dstStride[2] + i] = s[p.s422_v];
+    } else if (y & 1) {
+        const uint8_t *s0 = s - f.srcStride[0];
+        const int cr = (sliceY >> 1) + (y >> 1);
+        f.dst[1][(int64_t)cr * f.dstStride[1] + i] = (uint8_t)((s0[p.s422_u] + s[p.s422_u]) >> 1);
+        f.dst[2][(int64_t)cr * f.dstStride[2] + i] = (uint8_t)((s0[p.s422_v] + s[p.s422_v]) >> 1);
+    }
+}
+
 // bgr24ToYv12Wrapper (swscale_unscaled.c:2062-2078) -> ff_rgb24toyv12_c (rgb2rgb_template.c:580-641).
 // One thread = 4 chroma samples = 8 pixels x 2 rows: 2 x 24 bytes in, 2 x 8 luma + 4 U + 4 V bytes out.
 // All arithmetic is unsigned and the results are stored modulo 256 exactly like the reference's uint8_t stores.

@@ -22,6 +22,9 @@ static const PixDesc g_descs[] = {
 #define PLN(F, N, LW, LH, D)  { F, N, 3, LW, LH, {{0,2,0,0,D},{1,2,0,0,D},{2,2,0,0,D},{0,0,0,0,0}}, PIXFLAG_PLANAR }
 #define SP8(F, N, LW, LH, UO) { F, N, 3, LW, LH, {{0,1,0,0,8},{1,2,UO,0,8},{1,2,1-(UO),0,8},{0,0,0,0,0}}, PIXFLAG_PLANAR }
 #define SPN(F, N, LW, LH, D)  { F, N, 3, LW, LH, {{0,2,0,16-(D),D},{1,4,0,16-(D),D},{1,4,2,16-(D),D},{0,0,0,0,0}}, PIXFLAG_PLANAR }
+    { AV_PIX_FMT_YUYV422, "yuyv422", 3, 1, 0, {{0,2,0,0,8},{0,4,1,0,8},{0,4,3,0,8},{0,0,0,0,0}}, 0 },
+    { AV_PIX_FMT_UYVY422, "uyvy422", 3, 1, 0, {{0,2,1,0,8},{0,4,0,0,8},{0,4,2,0,8},{0,0,0,0,0}}, 0 },
+    { AV_PIX_FMT_YVYU422, "yvyu422", 3, 1, 0, {{0,2,0,0,8},{0,4,3,0,8},{0,4,1,0,8},{0,0,0,0,0}}, 0 },
 #define PLA(F, N, LW, LH)     { F, N, 4, LW, LH, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8},{3,1,0,0,8}}, PIXFLAG_PLANAR | PIXFLAG_ALPHA }
     PLA(AV_PIX_FMT_YUVA420P, "yuva420p", 1, 1), PLA(AV_PIX_FMT_YUVA422P, "yuva422p", 1, 0), PLA(AV_PIX_FMT_YUVA444P, "yuva444p", 0, 0),
     PL8(AV_PIX_FMT_YUV410P, "yuv410p", 2, 2), PL8(AV_PIX_FMT_YUV411P, "yuv411p", 2, 0), PL8(AV_PIX_FMT_YUV440P, "yuv440p", 0, 1),

@@ -71,6 +71,8 @@ enum PlanKind {
     PLAN_UNSC_YVU9_YV12,   // yvu9ToYv12Wrapper -> planar2x_c
     PLAN_UNSC_YUV2GBRP,    // yuv420p_gbrp_c / yuv422p_gbrp_c (yuv2rgb.c:532,553)
     PLAN_UNSC_PACKED_GBRP, // rgbToPlanarRgbWrapper (8-bit packed RGB -> gbrp)
+    PLAN_UNSC_PLANAR2P422, // yuv422pToYuy2/UyvyWrapper, planarToYuy2/UyvyWrapper
+    PLAN_UNSC_P4222PLANAR, // yuyv/uyvy ToYuv420/422Wrapper
     PLAN_MAIN,             // ff_swscale chain
     PLAN_CASCADE,          // two contexts through an intermediate image
 };

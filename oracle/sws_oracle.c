@@ -75,6 +75,9 @@ static const Desc descs[] = {
 #define PLN(F, N, LW, LH, D)   { F, N, 3, LW, LH, {{0,2,0,0,D},{1,2,0,0,D},{2,2,0,0,D}}, PF_PLANAR }
 #define SP8(F, N, LW, LH, UO)  { F, N, 3, LW, LH, {{0,1,0,0,8},{1,2,UO,0,8},{1,2,1-(UO),0,8}}, PF_PLANAR }
 #define SPN(F, N, LW, LH, D)   { F, N, 3, LW, LH, {{0,2,0,16-(D),D},{1,4,0,16-(D),D},{1,4,2,16-(D),D}}, PF_PLANAR }
+    { ORF_YUYV422, "yuyv422", 3, 1, 0, {{0,2,0,0,8},{0,4,1,0,8},{0,4,3,0,8}}, 0 },
+    { ORF_UYVY422, "uyvy422", 3, 1, 0, {{0,2,1,0,8},{0,4,0,0,8},{0,4,2,0,8}}, 0 },
+    { ORF_YVYU422, "yvyu422", 3, 1, 0, {{0,2,0,0,8},{0,4,3,0,8},{0,4,1,0,8}}, 0 },
 #define PLA(F, N, LW, LH)      { F, N, 4, LW, LH, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8},{3,1,0,0,8}}, PF_PLANAR | PF_ALPHA }
     PLA(ORF_YUVA420P, "yuva420p", 1, 1), PLA(ORF_YUVA422P, "yuva422p", 1, 0), PLA(ORF_YUVA444P, "yuva444p", 0, 0),
     PL8(ORF_YUV410P, "yuv410p", 2, 2), PL8(ORF_YUV411P, "yuv411p", 2, 0), PL8(ORF_YUV440P, "yuv440p", 0, 1),
@@ -164,7 +167,8 @@ enum { RY, GY, BY, RU, GU, BU, RV, GV, BV };
 
 enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
        UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED,
-       UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP };
+       UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP,
+       UNSC_PLANAR2P422, UNSC_P4222PLANAR };
 
 struct OrSws {
     OrSwsOpts o;
@@ -779,6 +783,10 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         if (!isPacked(s)) c->unscaled_kind = UNSC_PLANARCOPY;
         else c->unscaled_kind = UNSC_PACKEDCOPY; /* packedCopyWrapper (:2138-2157) */
     }
+    if (s == ORF_YUV422P && (d == ORF_YUYV422 || d == ORF_UYVY422)) c->unscaled_kind = UNSC_PLANAR2P422;          /* :2667-2672 */
+    if ((flags & (OR_SWS_FAST_BILINEAR | OR_SWS_POINT)) && (s == ORF_YUV420P || s == ORF_YUVA420P) &&
+        (d == ORF_YUYV422 || d == ORF_UYVY422)) c->unscaled_kind = UNSC_PLANAR2P422;                               /* :2684-2692 */
+    if ((s == ORF_YUYV422 || s == ORF_UYVY422) && (d == ORF_YUV420P || d == ORF_YUV422P)) c->unscaled_kind = UNSC_P4222PLANAR; /* :2693-2702 */
     if (d == ORF_YUV420P && (s == ORF_NV24 || s == ORF_NV42)) c->unscaled_kind = UNSC_NV242YUV420;    /* :2703-2705 */
 }
 
@@ -861,7 +869,8 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
         /* bgr24ToYv12 / yvu9ToYv12 also take a yuva420p destination in the reference (alpha filled with 255): not restated */
         if (dstFormat == ORF_YUVA420P &&
             ((srcFormat == ORF_BGR24 && !(flags & OR_SWS_ACCURATE_RND) && !(dstW & 1)) ||
-             (srcFormat == ORF_YUV410P && !(dstH & 3) && !(flags & OR_SWS_BITEXACT)))) return -1;
+             (srcFormat == ORF_YUV410P && !(dstH & 3) && !(flags & OR_SWS_BITEXACT)) ||
+             srcFormat == ORF_YUYV422 || srcFormat == ORF_UYVY422)) return -1;
         if (c->unscaled_kind) { c->initialized = 1; return 0; }
     }
     if (c->needAlpha && isPlanarRGB(dstFormat)) return -1; /* gbrap writers not restated */
@@ -1233,6 +1242,53 @@ static int unscaled_gbrp2packed(OrSws *c, const uint8_t *const src[], const int 
     return srcSliceH;
 }
 
+/* yuv422pToYuy2Wrapper / yuv422pToUyvyWrapper / planarToYuy2Wrapper / planarToUyvyWrapper (swscale_unscaled.c:376-422)
+ * -> yuvPlanartoyuy2_c / yuvPlanartouyvy_c (rgb2rgb_template.c:379-470): width >> 1 pixel pairs per row, the chroma row
+ * advances every vertLumPerChroma (1 or 2) luma rows counted from the slice start. */
+static int unscaled_planar2p422(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                                int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    const int vlpc = c->o.src_format == ORF_YUV422P ? 1 : 2;
+    const Desc *dd = desc_get(c->o.dst_format);
+    (void)srcSliceY;
+    for (int y = 0; y < srcSliceH; y++) {
+        const uint8_t *ys = src[0] + (ptrdiff_t)y * srcStride[0];
+        const uint8_t *us = src[1] + (ptrdiff_t)(y / vlpc) * srcStride[1], *vs = src[2] + (ptrdiff_t)(y / vlpc) * srcStride[2];
+        uint8_t *d = dst[0] + (ptrdiff_t)y * dstStride[0];
+        for (int i = 0; i < (c->o.src_w >> 1); i++) {
+            d[4 * i + dd->c[0].offset] = ys[2 * i]; d[4 * i + dd->c[0].offset + 2] = ys[2 * i + 1];
+            d[4 * i + dd->c[1].offset] = us[i]; d[4 * i + dd->c[2].offset] = vs[i];
+        }
+    }
+    return srcSliceH;
+}
+
+/* yuyvToYuv420/422Wrapper, uyvyToYuv420/422Wrapper (swscale_unscaled.c:424-484) -> yuyvtoyuv420_c .. uyvytoyuv422_c
+ * (rgb2rgb_template.c:751-825): luma extracted, 4:2:2 chroma extracted, 4:2:0 chroma = truncating mean of the two rows of
+ * each row pair counted from the slice start (an odd last row produces no chroma row). */
+static int unscaled_p4222planar(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                                int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    const Desc *ds = desc_get(c->o.src_format);
+    const int w = c->o.src_w, cw = CEIL_RSHIFT(w, 1), to420 = c->o.dst_format == ORF_YUV420P;
+    const int yo = ds->c[0].offset, uo = ds->c[1].offset, vo = ds->c[2].offset;
+    (void)srcSliceY;
+    for (int y = 0; y < srcSliceH; y++) {
+        const uint8_t *s = src[0] + (ptrdiff_t)y * srcStride[0];
+        uint8_t *yd = dst[0] + (ptrdiff_t)y * dstStride[0];
+        for (int i = 0; i < w; i++) yd[i] = s[2 * i + yo];
+        if (!to420) {
+            uint8_t *ud = dst[1] + (ptrdiff_t)y * dstStride[1], *vd = dst[2] + (ptrdiff_t)y * dstStride[2];
+            for (int i = 0; i < cw; i++) { ud[i] = s[4 * i + uo]; vd[i] = s[4 * i + vo]; }
+        } else if (y & 1) {
+            const uint8_t *s0 = s - srcStride[0];
+            uint8_t *ud = dst[1] + (ptrdiff_t)(y >> 1) * dstStride[1], *vd = dst[2] + (ptrdiff_t)(y >> 1) * dstStride[2];
+            for (int i = 0; i < cw; i++) { ud[i] = (uint8_t)((s0[4 * i + uo] + s[4 * i + uo]) >> 1); vd[i] = (uint8_t)((s0[4 * i + vo] + s[4 * i + vo]) >> 1); }
+        }
+    }
+    return srcSliceH;
+}
+
 /* rgbToPlanarRgbWrapper (swscale_unscaled.c:1436-1490) with packedtogbr24p (:1404-1434): de-interleave, alpha dropped */
 static int unscaled_packed2gbrp(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
                                 int srcSliceH, uint8_t *const dst[], const int dstStride[])
@@ -1394,6 +1450,11 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
         for (i = 0; i < w; i++) d[i] = s[i] >> sh;
         return tmp;
     }
+    if (f == ORF_YUYV422 || f == ORF_UYVY422 || f == ORF_YVYU422) { /* yuy2ToY_c input.c:550-556, uyvyToY_c :890-896 */
+        const uint8_t *s = src[0] + y * stride[0] + desc_get(f)->c[0].offset;
+        for (i = 0; i < w; i++) tmp[i] = s[2 * i];
+        return tmp;
+    }
     switch (f) {
     case ORF_RGB24: case ORF_BGR24: { /* rgb24ToY_c / bgr24ToY_c input.c:1068-1124 */
         const uint8_t *s = src[0] + y * stride[0]; int16_t *d = (int16_t *)tmp;
@@ -1454,6 +1515,12 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
     const int32_t *t = c->rgb2yuv;
     int i;
     *pu = tu; *pv = tv;
+    if (f == ORF_YUYV422 || f == ORF_UYVY422 || f == ORF_YVYU422) { /* yuy2ToUV_c / yvy2ToUV_c input.c:558-578, uyvyToUV_c :898-907 */
+        const Desc *ds = desc_get(f);
+        const uint8_t *s = src[0] + (ptrdiff_t)(y << c->chrSrcVSub) * stride[0];
+        for (i = 0; i < w; i++) { tu[i] = s[4 * i + ds->c[1].offset]; tv[i] = s[4 * i + ds->c[2].offset]; }
+        return;
+    }
     if (isSemiPlanarYUV(f) && desc_get(f)->c[0].depth == 8) { /* nv12ToUV_c / nv21ToUV_c input.c:926-948 (nv12/16/24, nv21/42) */
         const uint8_t *s = src[1] + y * stride[1];
         const int swapped = isSwappedChroma(f);
@@ -1926,6 +1993,52 @@ static void write_packed_rgb_line(const OrSws *c, const Planes *P, uint8_t *dest
 #undef AL
 }
 
+/* packed_vscale (vscale.c:109-171) + yuv2422_{X,2,1}_c_template (output.c:883-1000) for yuyv422 / yvyu422 / uyvy422 */
+static void write_packed422_line(const OrSws *c, const Planes *P, uint8_t *dest, int y)
+{
+    const int dstW = c->o.dst_w, lw = dstW, cw = c->chrDstW;
+    const int srcH = c->o.src_h, chrSrcH = c->chrSrcH;
+    const int chrY = y >> c->chrDstVSub;
+    const int lfs = c->vLumFilterSize, cfs = c->vChrFilterSize;
+    const int16_t *lf = c->vLumFilter + y * lfs, *cf = c->vChrFilter + chrY * cfs;
+    const int firstLum = ORMAX(1 - lfs, c->vLumFilterPos[y]);
+    const int firstChr = ORMAX(1 - cfs, c->vChrFilterPos[chrY]);
+    const Desc *dd = desc_get(c->o.dst_format);
+    int i, j, mode, ua = 0, ya = 0;
+#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+#define CU(j) (P->chrU + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+#define CV(j) (P->chrV + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+    if (lfs == 1 && cfs == 1) mode = 1;
+    else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 1; ua = (uint16_t)cf[1]; }
+    else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
+             (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 2; ya = (uint16_t)lf[1]; ua = (uint16_t)cf[1]; }
+    else mode = 0;
+    for (i = 0; i < ((dstW + 1) >> 1); i++) {
+        int Y1, Y2, U, V;
+        if (mode == 0) {
+            Y1 = Y2 = U = V = 1 << 18;
+            for (j = 0; j < lfs; j++) { Y1 += (int)(L(j)[2 * i] * (unsigned)lf[j]); Y2 += (int)(L(j)[2 * i + 1] * (unsigned)lf[j]); }
+            for (j = 0; j < cfs; j++) { U += (int)(CU(j)[i] * (unsigned)cf[j]); V += (int)(CV(j)[i] * (unsigned)cf[j]); }
+            Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
+        } else if (mode == 2) {
+            Y1 = (L(0)[2 * i] * (4096 - ya) + L(1)[2 * i] * ya) >> 19;
+            Y2 = (L(0)[2 * i + 1] * (4096 - ya) + L(1)[2 * i + 1] * ya) >> 19;
+            U = (CU(0)[i] * (4096 - ua) + CU(1)[i] * ua) >> 19;
+            V = (CV(0)[i] * (4096 - ua) + CV(1)[i] * ua) >> 19;
+        } else {
+            Y1 = (L(0)[2 * i] + 64) >> 7; Y2 = (L(0)[2 * i + 1] + 64) >> 7;
+            if (ua < 2048) { U = (CU(0)[i] + 64) >> 7; V = (CV(0)[i] + 64) >> 7; }
+            else { U = (CU(0)[i] + CU(1)[i] + 128) >> 8; V = (CV(0)[i] + CV(1)[i] + 128) >> 8; }
+        }
+        if ((Y1 | Y2 | U | V) & 0x100) { Y1 = clip_u8(Y1); Y2 = clip_u8(Y2); U = clip_u8(U); V = clip_u8(V); }
+        dest[4 * i + dd->c[0].offset] = (uint8_t)Y1; dest[4 * i + dd->c[0].offset + 2] = (uint8_t)Y2;   /* output_pixels :864-881 */
+        dest[4 * i + dd->c[1].offset] = (uint8_t)U; dest[4 * i + dd->c[2].offset] = (uint8_t)V;
+    }
+#undef L
+#undef CU
+#undef CV
+}
+
 /* any_vscale (vscale.c:173-212) + yuv2gbrp_full_X_c / yuv2gbrp16_full_X_c / yuv2gbrpf32_full_X_c (output.c:2342-2580):
  * planar RGB destinations always use the X form.  dst planes are G, B, R. */
 static void write_planar_rgb_line(const OrSws *c, const Planes *P, uint8_t *const dst[], const int dstStride[], int y)
@@ -2076,6 +2189,8 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
                                       c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither, 3, 0);
                 }
             }
+        } else if (df == ORF_YUYV422 || df == ORF_UYVY422 || df == ORF_YVYU422) {
+            write_packed422_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
         } else if (isAnyRGB(df) && !isPlanarRGB(df)) {
             write_packed_rgb_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
         } else {
@@ -2117,6 +2232,8 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
     case UNSC_NV242YUV420: return unscaled_nv242yuv420(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_YVU9_YV12: return unscaled_yvu9_yv12(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_PACKED2GBRP: return unscaled_packed2gbrp(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_PLANAR2P422: return unscaled_planar2p422(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_P4222PLANAR: return unscaled_p4222planar(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     }
     return main_path(c, src, srcStride, dst, dstStride);
 }
@@ -2139,7 +2256,8 @@ const char *or_sws_path_name(const OrSws *c)
 {
     static const char *n[] = { "main", "yuv2rgb_c", "planarToP01x", "planar8ToP01xle", "planarToNv12", "nv12ToPlanar", "planarCopy",
                                "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb",
-                               "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb" };
+                               "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb",
+                               "planarToYuy2", "yuyvToPlanar" };
     return c->cascade[0] ? "cascade" : n[c->unscaled_kind];
 }
 const int32_t *or_sws_rgb2yuv_table(const OrSws *c) { return c->rgb2yuv; }

@@ -30,6 +30,7 @@ _FORMATS = {
     "p010le": (158, "semi", 1, 1, 2), "p012le": (209, "semi", 1, 1, 2), "p016le": (169, "semi", 1, 1, 2),
     "p210le": (198, "semi", 1, 0, 2), "p212le": (222, "semi", 1, 0, 2), "p216le": (202, "semi", 1, 0, 2),
     "p410le": (200, "semi", 0, 0, 2), "p412le": (224, "semi", 0, 0, 2), "p416le": (204, "semi", 0, 0, 2),
+    "yuyv422": (1, "packed422", 1, 0, 1), "uyvy422": (15, "packed422", 1, 0, 1), "yvyu422": (108, "packed422", 1, 0, 1),
     "rgb24": (2, "packed", 0, 0, 3), "bgr24": (3, "packed", 0, 0, 3),
     "argb": (25, "packed", 0, 0, 4), "rgba": (26, "packed", 0, 0, 4), "abgr": (27, "packed", 0, 0, 4), "bgra": (28, "packed", 0, 0, 4),
     "0rgb": (118, "packed", 0, 0, 4), "rgb0": (119, "packed", 0, 0, 4), "0bgr": (120, "packed", 0, 0, 4), "bgr0": (121, "packed", 0, 0, 4),
@@ -51,6 +52,8 @@ def plane_layout(fmt, w, h):
         return [(bps * w, h), (bps * cw, ch), (bps * cw, ch), (bps * w, h)]
     if kind == "semi":
         return [(bps * w, h), (2 * bps * cw, ch)]
+    if kind == "packed422":      # Y0 U Y1 V groups: 4 bytes per pixel pair (libavutil/imgutils.c av_image_get_linesize)
+        return [(4 * cw, h)]
     if kind == "rgbp":
         return [(bps * w, h)] * 3
     return [(bps * w, h)]   # packed, gray

@@ -78,7 +78,7 @@ def test_c5_float_rgb_to_yuv444p16_bt2020_full():
              colorspace=(SWS_CS_BT2020, 1, SWS_CS_BT2020, 1))
 
 
-YUV_FAMILY = ["yuva420p", "yuva422p", "yuva444p", "yuv420p", "yuv422p", "yuv444p", "yuv410p", "yuv411p", "yuv440p", "yuvj420p", "yuvj422p", "yuvj444p", "yuvj440p",
+YUV_FAMILY = ["yuyv422", "uyvy422", "yvyu422", "yuva420p", "yuva422p", "yuva444p", "yuv420p", "yuv422p", "yuv444p", "yuv410p", "yuv411p", "yuv440p", "yuvj420p", "yuvj422p", "yuvj444p", "yuvj440p",
               "nv12", "nv21", "nv16", "nv24", "nv42",
               "yuv420p9le", "yuv422p9le", "yuv444p9le", "yuv420p10le", "yuv422p10le", "yuv444p10le", "yuv440p10le",
               "yuv420p12le", "yuv422p12le", "yuv444p12le", "yuv440p12le", "yuv420p14le", "yuv422p14le", "yuv444p14le",
@@ -167,6 +167,8 @@ SLICED_UNSCALED = [
     ("argb", "gbrp", BX), ("gbrp", "gbrp", BX), ("gbrp10le", "gbrp10le", BX),
     ("yuva420p", "rgba", BX), ("yuva420p", "abgr", BX), ("yuva420p", "yuv420p", BX), ("yuv420p", "yuva420p", BX), ("yuva444p", "yuva444p", BX),
     ("yuva420p", "nv12", BX), ("yuva420p", "p010le", BX),
+    ("yuv422p", "yuyv422", BX), ("yuv422p", "uyvy422", BX), ("yuv420p", "yuyv422", OL.SWS_POINT), ("yuv420p", "uyvy422", OL.SWS_POINT | BX),
+    ("yuyv422", "yuv420p", BX), ("uyvy422", "yuv420p", BX), ("yuyv422", "yuv422p", BX), ("uyvy422", "yuv422p", BX), ("yvyu422", "yvyu422", BX),
     ("yuvj420p", "gray8", BX), ("gray8", "yuvj444p", BX), ("gray8", "gray16le", BX), ("gray12le", "gray8", BX), ("gray10le", "yuvj420p", BX),
 ]
 
@@ -176,7 +178,7 @@ def test_unscaled_converters_accept_slices(sfmt, dfmt, fl):
     """sws_scale() with srcSliceY/srcSliceH on the unscaled special converters: three slices (cut at multiples of 16 rows)
     must give the whole-frame oracle result, top-down and in shuffled order."""
     w, h = 70, 80
-    flags = SWS_BICUBIC | fl
+    flags = fl if fl & (OL.SWS_POINT | OL.SWS_FAST_BILINEAR) else SWS_BICUBIC | fl
     o = OL.Oracle(w, h, sfmt, w, h, dfmt, flags)
     assert o.path() != "main"
     src = OL.fill_random(OL.Frame(sfmt, w, h), 21)
