@@ -640,6 +640,17 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         const int rows = sliceH + ((sliceH + 1) >> 1);
         const dim3 grid(cdiv(cdiv(p.srcW, 8), 256), rows, n);
         const bool s8 = c->plan == PLAN_UNSC_8_P01X;
+        static const int p01x_ch = std::getenv("SWS_HIP_P01X_CH") ? std::atoi(std::getenv("SWS_HIP_P01X_CH")) : 1;
+        if (!s8 && vec && p01x_ch > 0) {   // streaming form: CH x 16 bytes per lane, wave-contiguous
+            const int row_chunks = cdiv(2 * p.srcW, 16);
+            if (p01x_ch == 4) { const dim3 g4(cdiv(row_chunks, 4 * 256), rows, n);
+                                hipLaunchKernelGGL((swsk::sws_k_p01x_stream<4>), g4, blk, 0, st, fs, p, sliceY, sliceH); }
+            else if (p01x_ch == 1) { const dim3 g1(cdiv(row_chunks, 256), rows, n);
+                                hipLaunchKernelGGL((swsk::sws_k_p01x_stream<1>), g1, blk, 0, st, fs, p, sliceY, sliceH); }
+            else { const dim3 g2(cdiv(row_chunks, 2 * 256), rows, n);
+                   hipLaunchKernelGGL((swsk::sws_k_p01x_stream<2>), g2, blk, 0, st, fs, p, sliceY, sliceH); }
+            break;
+        }
         if (s8 && vec) hipLaunchKernelGGL((swsk::sws_k_p01x_unscaled<true, true>), grid, blk, 0, st, fs, p, sliceY, sliceH);
         else if (s8) hipLaunchKernelGGL((swsk::sws_k_p01x_unscaled<true, false>), grid, blk, 0, st, fs, p, sliceY, sliceH);
         else if (vec) hipLaunchKernelGGL((swsk::sws_k_p01x_unscaled<false, true>), grid, blk, 0, st, fs, p, sliceY, sliceH);
@@ -834,7 +845,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         }
         if (vec && d->unity_h && d->unity_v && !p.no_chroma && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 &&
             (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16)) {
-            const dim3 g(cdiv((int64_t)((p.srcW + 3) >> 2) * p.srcH, 256), 1, n);
+            const dim3 g(cdiv((int64_t)((p.srcW + 7) >> 3) * p.srcH, 256), 1, n);
             hipLaunchKernelGGL(swsk::sws_k_f32rgb_to_yuv444_unity, g, blk, 0, st, fs, p);
             break;
         }
