@@ -461,7 +461,7 @@ int dev_prepare(SwsInternal *c)
     // ---- name the path (for SWS_PRINT_INFO, tests and rocprof matching) ----
     switch (c->plan) {
     case PLAN_UNSC_YUV2RGB: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb_unscaled_wave"; break;
-    case PLAN_UNSC_P01X: c->path_name = "unscaled:planarToP01x"; c->kernel_name = "sws_k_p01x_unscaled"; break;
+    case PLAN_UNSC_P01X: c->path_name = "unscaled:planarToP01x"; c->kernel_name = "sws_k_p01x_stream"; break;
     case PLAN_UNSC_8_P01X: c->path_name = "unscaled:planar8ToP01xle"; c->kernel_name = "sws_k_p01x_unscaled"; break;
     case PLAN_UNSC_PLANAR2NV12: c->path_name = "unscaled:planarToNv12"; c->kernel_name = "sws_k_planar_misc"; break;
     case PLAN_UNSC_NV122PLANAR: c->path_name = "unscaled:nv12ToPlanar"; c->kernel_name = "sws_k_planar_misc"; break;
