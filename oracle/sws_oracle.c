@@ -75,6 +75,10 @@ static const Desc descs[] = {
 #define PLN(F, N, LW, LH, D)   { F, N, 3, LW, LH, {{0,2,0,0,D},{1,2,0,0,D},{2,2,0,0,D}}, PF_PLANAR }
 #define SP8(F, N, LW, LH, UO)  { F, N, 3, LW, LH, {{0,1,0,0,8},{1,2,UO,0,8},{1,2,1-(UO),0,8}}, PF_PLANAR }
 #define SPN(F, N, LW, LH, D)   { F, N, 3, LW, LH, {{0,2,0,16-(D),D},{1,4,0,16-(D),D},{1,4,2,16-(D),D}}, PF_PLANAR }
+    { ORF_RGB48LE,  "rgb48le",  3, 0, 0, {{0,6,0,0,16},{0,6,2,0,16},{0,6,4,0,16}}, PF_RGB },
+    { ORF_BGR48LE,  "bgr48le",  3, 0, 0, {{0,6,4,0,16},{0,6,2,0,16},{0,6,0,0,16}}, PF_RGB },
+    { ORF_RGBA64LE, "rgba64le", 4, 0, 0, {{0,8,0,0,16},{0,8,2,0,16},{0,8,4,0,16},{0,8,6,0,16}}, PF_RGB | PF_ALPHA },
+    { ORF_BGRA64LE, "bgra64le", 4, 0, 0, {{0,8,4,0,16},{0,8,2,0,16},{0,8,0,0,16},{0,8,6,0,16}}, PF_RGB | PF_ALPHA },
     { ORF_YUYV422, "yuyv422", 3, 1, 0, {{0,2,0,0,8},{0,4,1,0,8},{0,4,3,0,8}}, 0 },
     { ORF_UYVY422, "uyvy422", 3, 1, 0, {{0,2,1,0,8},{0,4,0,0,8},{0,4,2,0,8}}, 0 },
     { ORF_YVYU422, "yvyu422", 3, 1, 0, {{0,2,0,0,8},{0,4,3,0,8},{0,4,1,0,8}}, 0 },
@@ -168,7 +172,8 @@ enum { RY, GY, BY, RU, GU, BU, RV, GV, BV };
 enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
        UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED,
        UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP,
-       UNSC_PLANAR2P422, UNSC_P4222PLANAR };
+       UNSC_PLANAR2P422, UNSC_P4222PLANAR,
+       UNSC_RGB16SHUFFLE, UNSC_PACKED16_TO_GBRP16, UNSC_GBRP16_TO_PACKED16 };
 
 struct OrSws {
     OrSwsOpts o;
@@ -748,8 +753,10 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         (c->o.dither == 2 || c->o.dither == 1) && !(c->o.dst_h & 1)) { /* :2425-2431 */
         /* ff_yuv2rgb_get_func_ptr, yuv2rgb.c:561-678: 24/32 bpp C converters */
         /* yuv2rgb_c_24_rgb/_bgr, yuv2rgb_c_32, yuv420p_gbrp_c / yuv422p_gbrp_c; NULL (-> scaler chain) for gbrp9..16/f32 */
-        if (d == ORF_RGB24 || d == ORF_BGR24 || d == ORF_RGBA || d == ORF_BGRA || d == ORF_ARGB || d == ORF_ABGR || d == ORF_GBRP)
+        if (d == ORF_RGB24 || d == ORF_BGR24 || d == ORF_RGBA || d == ORF_BGRA || d == ORF_ARGB || d == ORF_ABGR || d == ORF_GBRP ||
+            d == ORF_RGB48LE || d == ORF_BGR48LE)   /* yuv2rgb_c_48 / yuv2rgb_c_bgr48 (yuv2rgb.c:107-125, :505-508) */
             c->unscaled_kind = UNSC_YUV2RGB;
+        else if (d == ORF_RGBA64LE || d == ORF_BGRA64LE) c->unscaled_kind = UNSC_NONE; /* no C converter: ff_yuv2rgb_get_func_ptr returns NULL */
     }
     if (s == ORF_YUV444P && (d == ORF_NV24 || d == ORF_NV42)) c->unscaled_kind = UNSC_PLANAR2NV24;   /* :2410-2413 */
     if (d == ORF_YUV444P && (s == ORF_NV24 || s == ORF_NV42)) c->unscaled_kind = UNSC_NV242PLANAR;   /* :2420-2423 */
@@ -764,10 +771,20 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
     /* rgbToRgbWrapper (:2459-2463) when findRgbConvFn (:1843-1998) has a converter; 8-bit 24/32 bpp formats on a
      * little-endian host.  needsDither is 0 for >= 24 bpp destinations.  ":1991-1994 Maintain symmetry between
      * endianness": with BITEXACT a 24 bpp source is not shuffled into RGB32/BGR32 (= bgra/rgba bytes on LE). */
-    if (isAnyRGB(s) && isAnyRGB(d) && isPacked(s) && isPacked(d) && s != d) {
+    if (isAnyRGB(s) && isAnyRGB(d) && isPacked(s) && isPacked(d) && s != d &&
+        desc_get(s)->c[0].depth == 8 && desc_get(d)->c[0].depth == 8) {
         const int s32 = desc_get(s)->c[0].step == 4;
         if (!(!s32 && (d == ORF_BGRA || d == ORF_RGBA) && (flags & OR_SWS_BITEXACT)))
             c->unscaled_kind = UNSC_RGB2RGB;
+    }
+    {   /* 16-bit packed RGB: findRgbConvFn rows for rgb48 <-> bgr48, rgb48 -> rgba64, rgba64 -> rgb48 (:1869-1911);
+         * Rgb16ToPlanarRgb16Wrapper (:2488-2507) and planarRgb16ToRgb16Wrapper (:2514-2533) */
+        const int s48 = s == ORF_RGB48LE || s == ORF_BGR48LE, s64 = s == ORF_RGBA64LE || s == ORF_BGRA64LE;
+        const int d48 = d == ORF_RGB48LE || d == ORF_BGR48LE, d64 = d == ORF_RGBA64LE || d == ORF_BGRA64LE;
+        const int sp16 = isPlanarRGB(s) && !isFloat(s) && desc_get(s)->c[0].depth > 8, dp16 = isPlanarRGB(d) && !isFloat(d) && desc_get(d)->c[0].depth > 8;
+        if (s != d && ((s48 && d48) || (s48 && d64) || (s64 && d48))) c->unscaled_kind = UNSC_RGB16SHUFFLE;
+        if ((s48 || s64) && dp16) c->unscaled_kind = UNSC_PACKED16_TO_GBRP16;
+        if (sp16 && (d48 || d64)) c->unscaled_kind = UNSC_GBRP16_TO_PACKED16;
     }
     /* rgbToPlanarRgbWrapper (:2542-2544): 8-bit packed RGB -> gbrp */
     if (isAnyRGB(s) && isPacked(s) && desc_get(s)->c[0].depth == 8 && d == ORF_GBRP) c->unscaled_kind = UNSC_PACKED2GBRP;
@@ -992,7 +1009,12 @@ static int unscaled_yuv2rgb(OrSws *c, const uint8_t *const src[], const int srcS
                 int b = c->table_bU[U + HEADROOM];
                 for (int k = 0; k < 2; k++) {
                     int Y = py[2 * i + k];
-                    if (d == ORF_GBRP) { /* PUTGBRP yuv2rgb.c:127-135 */
+                    if (d == ORF_RGB48LE || d == ORF_BGR48LE) { /* PUTRGB48 / PUTBGR48 yuv2rgb.c:107-125: each 8-bit LUT value fills both bytes */
+                        uint8_t R = (uint8_t)lut_at(c, r + Y), G = (uint8_t)lut_at(c, g + Y), B = (uint8_t)lut_at(c, b + Y);
+                        uint8_t *p = out + 12 * i + 6 * k;
+                        uint8_t first = d == ORF_RGB48LE ? R : B, third = d == ORF_RGB48LE ? B : R;
+                        p[0] = p[1] = first; p[2] = p[3] = G; p[4] = p[5] = third;
+                    } else if (d == ORF_GBRP) { /* PUTGBRP yuv2rgb.c:127-135 */
                         dst[0][(ptrdiff_t)(yy + srcSliceY) * dstStride[0] + 2 * i + k] = (uint8_t)lut_at(c, g + Y);
                         dst[1][(ptrdiff_t)(yy + srcSliceY) * dstStride[1] + 2 * i + k] = (uint8_t)lut_at(c, b + Y);
                         dst[2][(ptrdiff_t)(yy + srcSliceY) * dstStride[2] + 2 * i + k] = (uint8_t)lut_at(c, r + Y);
@@ -1289,6 +1311,57 @@ static int unscaled_p4222planar(OrSws *c, const uint8_t *const src[], const int 
     return srcSliceH;
 }
 
+/* rgb48tobgr48 / rgb48to64 / rgb48tobgr64 / rgb64to48 / rgb64tobgr48 (rgb2rgb.c:322-413): 16-bit channel moves, A = 0xFFFF */
+static int unscaled_rgb16shuffle(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                                 int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    const Desc *ds = desc_get(c->o.src_format), *dd = desc_get(c->o.dst_format);
+    (void)srcSliceY;
+    for (int y = 0; y < srcSliceH; y++) {
+        const uint16_t *s = (const uint16_t *)(src[0] + (ptrdiff_t)y * srcStride[0]);
+        uint16_t *d = (uint16_t *)(dst[0] + (ptrdiff_t)y * dstStride[0]);
+        for (int x = 0; x < c->o.src_w; x++, s += ds->c[0].step / 2, d += dd->c[0].step / 2) {
+            for (int k = 0; k < 3; k++) d[dd->c[k].offset / 2] = s[ds->c[k].offset / 2];
+            if (dd->nb == 4) d[3] = 0xFFFF;
+        }
+    }
+    return srcSliceH;
+}
+/* Rgb16ToPlanarRgb16Wrapper + packed16togbra16 (swscale_unscaled.c:685-889, :891-962): sample >> (16 - depth) */
+static int unscaled_packed16_gbrp16(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                                    int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    const Desc *ds = desc_get(c->o.src_format), *dd = desc_get(c->o.dst_format);
+    const int shift = 16 - dd->c[0].depth;
+    (void)srcSliceY;
+    for (int y = 0; y < srcSliceH; y++) {
+        const uint16_t *s = (const uint16_t *)(src[0] + (ptrdiff_t)y * srcStride[0]);
+        for (int x = 0; x < c->o.src_w; x++, s += ds->c[0].step / 2)
+            for (int k = 0; k < 3; k++)
+                ((uint16_t *)(dst[dd->c[k].plane] + (ptrdiff_t)y * dstStride[dd->c[k].plane]))[x] = (uint16_t)(s[ds->c[k].offset / 2] >> shift);
+    }
+    return srcSliceH;
+}
+/* planarRgb16ToRgb16Wrapper + gbr16ptopacked16 (swscale_unscaled.c:964-1120, :1122-1186): c << (16-bpp) | c >> ((bpp-8)*2) */
+static int unscaled_gbrp16_packed16(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                                    int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    const Desc *ds = desc_get(c->o.src_format), *dd = desc_get(c->o.dst_format);
+    const int bpp = ds->c[0].depth, hi = 16 - bpp, lo = (bpp - 8) * 2;
+    (void)srcSliceY;
+    for (int y = 0; y < srcSliceH; y++) {
+        uint16_t *d = (uint16_t *)(dst[0] + (ptrdiff_t)y * dstStride[0]);
+        for (int x = 0; x < c->o.src_w; x++, d += dd->c[0].step / 2) {
+            for (int k = 0; k < 3; k++) {
+                const uint16_t v = ((const uint16_t *)(src[ds->c[k].plane] + (ptrdiff_t)y * srcStride[ds->c[k].plane]))[x];
+                d[dd->c[k].offset / 2] = (uint16_t)(v << hi | v >> lo);
+            }
+            if (dd->nb == 4) d[3] = 0xffff;
+        }
+    }
+    return srcSliceH;
+}
+
 /* rgbToPlanarRgbWrapper (swscale_unscaled.c:1436-1490) with packedtogbr24p (:1404-1434): de-interleave, alpha dropped */
 static int unscaled_packed2gbrp(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
                                 int srcSliceH, uint8_t *const dst[], const int dstStride[])
@@ -1455,6 +1528,15 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
         for (i = 0; i < w; i++) tmp[i] = s[2 * i];
         return tmp;
     }
+    if (f == ORF_RGB48LE || f == ORF_BGR48LE || f == ORF_RGBA64LE || f == ORF_BGRA64LE) { /* rgb48ToY_c_template / rgb64ToY_c_template input.c:45-57, :136-150 */
+        const Desc *ds = desc_get(f);
+        const int st = ds->c[0].step / 2, ro = ds->c[0].offset / 2, go = ds->c[1].offset / 2, bo = ds->c[2].offset / 2;
+        const uint16_t *s = (const uint16_t *)(src[0] + y * stride[0]);
+        uint16_t *d = (uint16_t *)tmp;
+        for (i = 0; i < w; i++)
+            d[i] = (uint16_t)(((unsigned)t[RY] * s[st * i + ro] + (unsigned)t[GY] * s[st * i + go] + (unsigned)t[BY] * s[st * i + bo] + (0x2001u << 14)) >> 15);
+        return tmp;
+    }
     switch (f) {
     case ORF_RGB24: case ORF_BGR24: { /* rgb24ToY_c / bgr24ToY_c input.c:1068-1124 */
         const uint8_t *s = src[0] + y * stride[0]; int16_t *d = (int16_t *)tmp;
@@ -1515,6 +1597,23 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
     const int32_t *t = c->rgb2yuv;
     int i;
     *pu = tu; *pv = tv;
+    if (f == ORF_RGB48LE || f == ORF_BGR48LE || f == ORF_RGBA64LE || f == ORF_BGRA64LE) { /* rgb48/64ToUV(_half)_c_template input.c:58-96, :151-203 */
+        const Desc *ds = desc_get(f);
+        const int st = ds->c[0].step / 2, ro = ds->c[0].offset / 2, go = ds->c[1].offset / 2, bo = ds->c[2].offset / 2;
+        const uint16_t *s = (const uint16_t *)(src[0] + (ptrdiff_t)(y << c->chrSrcVSub) * stride[0]);
+        uint16_t *du = (uint16_t *)tu, *dv = (uint16_t *)tv;
+        for (i = 0; i < w; i++) {
+            unsigned r, g, b;
+            if (c->chrSrcHSub) {
+                r = (s[2 * st * i + ro] + s[2 * st * i + st + ro] + 1u) >> 1;
+                g = (s[2 * st * i + go] + s[2 * st * i + st + go] + 1u) >> 1;
+                b = (s[2 * st * i + bo] + s[2 * st * i + st + bo] + 1u) >> 1;
+            } else { r = s[st * i + ro]; g = s[st * i + go]; b = s[st * i + bo]; }
+            du[i] = (uint16_t)(((unsigned)t[RU] * r + (unsigned)t[GU] * g + (unsigned)t[BU] * b + (0x10001u << 14)) >> 15);
+            dv[i] = (uint16_t)(((unsigned)t[RV] * r + (unsigned)t[GV] * g + (unsigned)t[BV] * b + (0x10001u << 14)) >> 15);
+        }
+        return;
+    }
     if (f == ORF_YUYV422 || f == ORF_UYVY422 || f == ORF_YVYU422) { /* yuy2ToUV_c / yvy2ToUV_c input.c:558-578, uyvyToUV_c :898-907 */
         const Desc *ds = desc_get(f);
         const uint8_t *s = src[0] + (ptrdiff_t)(y << c->chrSrcVSub) * stride[0];
@@ -1993,6 +2092,87 @@ static void write_packed_rgb_line(const OrSws *c, const Planes *P, uint8_t *dest
 #undef AL
 }
 
+/* packed_vscale (vscale.c:109-171) + yuv2rgba64_{X,2,1}_c_template and yuv2rgba64_full_{X,2,1}_c_template (output.c:1115-1560)
+ * for rgb48le / bgr48le / rgba64le / bgra64le: 19-bit intermediates, 32-bit wrap-around arithmetic with the reference's
+ * exact signedness of every shift (one of the full_1 shifts is logical, see the SUINT lines at :1538-1539). */
+static void write_packed_rgb16_line(const OrSws *c, const Planes *P, uint8_t *dest8, int y)
+{
+    const int dstW = c->o.dst_w, lw = dstW, cw = c->chrDstW;
+    const int srcH = c->o.src_h, chrSrcH = c->chrSrcH;
+    const int chrY = y >> c->chrDstVSub;
+    const int lfs = c->vLumFilterSize, cfs = c->vChrFilterSize;
+    const int16_t *lf = c->vLumFilter + y * lfs, *cf = c->vChrFilter + chrY * cfs;
+    const int firstLum = ORMAX(1 - lfs, c->vLumFilterPos[y]);
+    const int firstChr = ORMAX(1 - cfs, c->vChrFilterPos[chrY]);
+    const int full = !!(c->o.flags & OR_SWS_FULL_CHR_H_INT);
+    const Desc *dd = desc_get(c->o.dst_format);
+    const int st = dd->c[0].step / 2, ro = dd->c[0].offset / 2, go = dd->c[1].offset / 2, bo = dd->c[2].offset / 2;
+    const int hasAlpha = c->needAlpha;
+    uint16_t *dest = (uint16_t *)dest8;
+    int j, mode;
+    unsigned ua = 0, ya = 0;
+#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+#define CU(j) (P->chrU + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+#define CV(j) (P->chrV + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+#define AL(j) (P->alp + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+    if (lfs == 1 && cfs == 1) mode = 1;
+    else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 1; ua = (uint16_t)cf[1]; }
+    else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
+             (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 2; ya = (uint16_t)lf[1]; ua = (uint16_t)cf[1]; }
+    else mode = 0;
+    const int npx = full ? dstW : 2 * ((dstW + 1) >> 1);      /* the pair writers also emit the pixel after an odd width */
+    for (int x = 0; x < npx; x++) {
+        const int ci = full ? x : x >> 1;                       /* chroma sample of this pixel */
+        unsigned Y, U, V;
+        int A = 0xffff << 14;
+        if (mode == 0) {
+            Y = (unsigned)-0x40000000; U = (unsigned)-(128 << 23); V = (unsigned)-(128 << 23);
+            for (j = 0; j < lfs; j++) Y += L(j)[x] * (unsigned)lf[j];
+            for (j = 0; j < cfs; j++) { U += CU(j)[ci] * (unsigned)cf[j]; V += CV(j)[ci] * (unsigned)cf[j]; }
+            if (hasAlpha) {
+                A = -0x40000000;
+                for (j = 0; j < lfs; j++) A = (int)((unsigned)A + AL(j)[x] * (unsigned)lf[j]);
+                A >>= 1; A += 0x20002000;
+            }
+            Y = (unsigned)((int)Y >> 14); Y += 0x10000;
+            U = (unsigned)((int)U >> 14); V = (unsigned)((int)V >> 14);
+        } else if (mode == 2) {
+            const unsigned ya1 = 4096 - ya, ua1 = 4096 - ua;
+            Y = (unsigned)((int)(L(0)[x] * ya1 + L(1)[x] * ya) >> 14);
+            U = (unsigned)((int)(CU(0)[ci] * ua1 + CU(1)[ci] * ua - (128 << 23)) >> 14);
+            V = (unsigned)((int)(CV(0)[ci] * ua1 + CV(1)[ci] * ua - (128 << 23)) >> 14);
+            if (hasAlpha) { A = (int)(AL(0)[x] * ya1 + AL(1)[x] * ya) >> 1; A += 1 << 13; }
+        } else {
+            Y = (unsigned)(L(0)[x] >> 2);
+            if (ua == 0) { U = (unsigned)((CU(0)[ci] - (128 << 11)) >> 2); V = (unsigned)((CV(0)[ci] - (128 << 11)) >> 2); }
+            else {
+                const unsigned ua1 = 4096 - ua;
+                const unsigned tu = CU(0)[ci] * ua1 + CU(1)[ci] * ua - (128 << 23), tv = CV(0)[ci] * ua1 + CV(1)[ci] * ua - (128 << 23);
+                if (full) { U = tu >> 14; V = tv >> 14; }           /* :1538-1539: SUINT expression, LOGICAL shift */
+                else { U = (unsigned)((int)tu >> 14); V = (unsigned)((int)tv >> 14); }   /* :1318-1319: (int) cast, arithmetic */
+            }
+            if (hasAlpha) { A = (int)((unsigned)AL(0)[x] * (1u << 11)); A += 1 << 13; }
+        }
+        Y -= (unsigned)c->yuv2rgb_y_offset;
+        Y *= (unsigned)c->yuv2rgb_y_coeff;
+        Y += (unsigned)((1 << 13) - (1 << 29));
+        {
+            const unsigned R = V * (unsigned)c->yuv2rgb_v2r, G = V * (unsigned)c->yuv2rgb_v2g + U * (unsigned)c->yuv2rgb_u2g,
+                           B = U * (unsigned)c->yuv2rgb_u2b;
+            uint16_t *d = dest + st * x;
+            if (x >= dstW) continue;      /* the extra pixel of an odd width lands in the row padding: not restated */
+            d[ro] = (uint16_t)clip_uintp2(((int)(R + Y) >> 14) + (1 << 15), 16);
+            d[go] = (uint16_t)clip_uintp2(((int)(G + Y) >> 14) + (1 << 15), 16);
+            d[bo] = (uint16_t)clip_uintp2(((int)(B + Y) >> 14) + (1 << 15), 16);
+            if (st == 4) d[3] = (uint16_t)(clip_uintp2(A, 30) >> 14);
+        }
+    }
+#undef L
+#undef CU
+#undef CV
+#undef AL
+}
+
 /* packed_vscale (vscale.c:109-171) + yuv2422_{X,2,1}_c_template (output.c:883-1000) for yuyv422 / yvyu422 / uyvy422 */
 static void write_packed422_line(const OrSws *c, const Planes *P, uint8_t *dest, int y)
 {
@@ -2132,7 +2312,12 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
         P.alp = malloc((size_t)srcH * dstW * sizeof(int32_t));
         for (y = 0; y < srcH; y++) {
             const uint8_t *line;
-            if (isAnyRGB(sf)) { /* rgbaToA_c / abgrToA_c input.c:454-472 */
+            if (sf == ORF_RGBA64LE || sf == ORF_BGRA64LE) { /* rgba64leToA_c: the 16-bit A sample as is */
+                const uint16_t *sp = (const uint16_t *)(src[0] + (ptrdiff_t)y * srcStride[0]) + 3;
+                uint16_t *d16 = (uint16_t *)t0;
+                for (int i = 0; i < srcW; i++) d16[i] = sp[4 * i];
+                line = t0;
+            } else if (isAnyRGB(sf)) { /* rgbaToA_c / abgrToA_c input.c:454-472 */
                 const Desc *dsd = desc_get(sf);
                 const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0] + dsd->c[3].offset;
                 int16_t *d16 = (int16_t *)t0;
@@ -2191,6 +2376,8 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
             }
         } else if (df == ORF_YUYV422 || df == ORF_UYVY422 || df == ORF_YVYU422) {
             write_packed422_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
+        } else if (df == ORF_RGB48LE || df == ORF_BGR48LE || df == ORF_RGBA64LE || df == ORF_BGRA64LE) {
+            write_packed_rgb16_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
         } else if (isAnyRGB(df) && !isPlanarRGB(df)) {
             write_packed_rgb_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
         } else {
@@ -2234,6 +2421,9 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
     case UNSC_PACKED2GBRP: return unscaled_packed2gbrp(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_PLANAR2P422: return unscaled_planar2p422(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_P4222PLANAR: return unscaled_p4222planar(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_RGB16SHUFFLE: return unscaled_rgb16shuffle(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_PACKED16_TO_GBRP16: return unscaled_packed16_gbrp16(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_GBRP16_TO_PACKED16: return unscaled_gbrp16_packed16(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     }
     return main_path(c, src, srcStride, dst, dstStride);
 }
@@ -2257,7 +2447,8 @@ const char *or_sws_path_name(const OrSws *c)
     static const char *n[] = { "main", "yuv2rgb_c", "planarToP01x", "planar8ToP01xle", "planarToNv12", "nv12ToPlanar", "planarCopy",
                                "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb",
                                "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb",
-                               "planarToYuy2", "yuyvToPlanar" };
+                               "planarToYuy2", "yuyvToPlanar",
+                               "rgb16Shuffle", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16" };
     return c->cascade[0] ? "cascade" : n[c->unscaled_kind];
 }
 const int32_t *or_sws_rgb2yuv_table(const OrSws *c) { return c->rgb2yuv; }

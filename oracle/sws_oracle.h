@@ -36,6 +36,7 @@ enum {
     ORF_P016LE = 169, ORF_NV24 = 188, ORF_NV42 = 189, ORF_P210LE = 198, ORF_P410LE = 200, ORF_P216LE = 202,
     ORF_P416LE = 204, ORF_P012LE = 209, ORF_P212LE = 222, ORF_P412LE = 224,
     /* planar RGB 9..16 bit (readers input.c:1213-1283, writers output.c:2342-2530) */
+    ORF_RGB48LE = 35, ORF_BGR48LE = 58, ORF_RGBA64LE = 105, ORF_BGRA64LE = 107,
     ORF_YUYV422 = 1, ORF_UYVY422 = 15, ORF_YVYU422 = 108,
     ORF_YUVA420P = 33, ORF_YUVA422P = 78, ORF_YUVA444P = 79,
     ORF_GRAY16LE = 30, ORF_GRAY12LE = 166, ORF_GRAY10LE = 168, ORF_GRAY9LE = 173, ORF_GRAY14LE = 181,

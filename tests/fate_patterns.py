@@ -16,10 +16,10 @@ import oracle_lib as OL
 HERE = os.path.dirname(os.path.abspath(__file__))
 W, H = 352, 288
 SWS_FLAGS = OL.SWS_BICUBIC | OL.SWS_ACCURATE_RND | OL.SWS_BITEXACT   # tests/fate-run.sh:258 + the filter's default scaler
-FMT_OF = {"gray": "gray8", "rgb32": "bgra"}                           # lavu pixfmt aliases on little endian
+FMT_OF = {"gray": "gray8", "rgb32": "bgra", "rgb48": "rgb48le"}                           # lavu pixfmt aliases on little endian
 BASE_FMT = {"yuv444p": "yuv444p", "rgb24": "rgb24", "yuv444p10": "yuv444p10le", "yuv444p12": "yuv444p12le",
             "yuv444p16": "yuv444p16le", "nv24": "nv24", "p410": "p410le", "p412": "p412le", "p416": "p416le",
-            "gbrp": "gbrp", "gbrp10": "gbrp10le", "gbrp12": "gbrp12le", "gbrp16": "gbrp16le"}
+            "gbrp": "gbrp", "gbrp10": "gbrp10le", "gbrp12": "gbrp12le", "gbrp16": "gbrp16le", "rgb48": "rgb48le"}
 GOLDEN = json.load(open(os.path.join(HERE, "golden", "fate_pixfmt_md5.json")))
 
 
@@ -106,6 +106,15 @@ def rgbtestsrc(planar_depth=0):
 def base_picture(base):
     if base == "rgb24":
         return rgbtestsrc()
+    if base == "rgb48":   # rgbtest_put_pixel RGB48 (vsrc_testsrc.c:1020-1027): 16-bit ramp c = 65536 * x / w per band;
+        # the three words are stored as v16 >> 32, >> 16, >> 0 with r in the LOW word: the r band lands in the third slot
+        f = OL.Frame("rgb48le", W, H)
+        img = np.zeros((H, W, 3), np.dtype("<u2"))
+        ramp = (65536 * np.arange(W) // W).astype(np.uint16)
+        for y in range(H):
+            img[y, :, 2 - band_of(y)] = ramp
+        f.planes[0][:, :6 * W] = img.view(np.uint8).reshape(H, 6 * W)
+        return f
     if base.startswith("gbrp"):
         return rgbtestsrc({"gbrp": 8, "gbrp10": 10, "gbrp12": 12, "gbrp16": 16}[base])
     if base in ("nv24", "p410", "p412", "p416"):

@@ -31,6 +31,7 @@ _FORMATS = {
     "p210le": (198, "semi", 1, 0, 2), "p212le": (222, "semi", 1, 0, 2), "p216le": (202, "semi", 1, 0, 2),
     "p410le": (200, "semi", 0, 0, 2), "p412le": (224, "semi", 0, 0, 2), "p416le": (204, "semi", 0, 0, 2),
     "yuyv422": (1, "packed422", 1, 0, 1), "uyvy422": (15, "packed422", 1, 0, 1), "yvyu422": (108, "packed422", 1, 0, 1),
+    "rgb48le": (35, "packed", 0, 0, 6), "bgr48le": (58, "packed", 0, 0, 6), "rgba64le": (105, "packed", 0, 0, 8), "bgra64le": (107, "packed", 0, 0, 8),
     "rgb24": (2, "packed", 0, 0, 3), "bgr24": (3, "packed", 0, 0, 3),
     "argb": (25, "packed", 0, 0, 4), "rgba": (26, "packed", 0, 0, 4), "abgr": (27, "packed", 0, 0, 4), "bgra": (28, "packed", 0, 0, 4),
     "0rgb": (118, "packed", 0, 0, 4), "rgb0": (119, "packed", 0, 0, 4), "0bgr": (120, "packed", 0, 0, 4), "bgr0": (121, "packed", 0, 0, 4),

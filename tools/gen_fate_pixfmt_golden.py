@@ -17,9 +17,9 @@ SCOPE = ["bgr24", "nv12", "rgb24", "rgb32", "yuv420p", "yuv422p", "yuv444p", "yu
          "nv16", "nv24", "yuv410p", "yuv411p", "yuv440p", "yuvj422p", "yuvj440p", "yuvj444p",
          "yuv422p10le", "yuv440p10le", "yuv420p12le", "yuv422p12le", "yuv440p12le", "yuv444p12le", "yuv422p16le",
          "p210le", "p410le", "p012le", "p212le", "p412le", "p016le", "p216le", "p416le",
-         "gbrp10le", "gbrp12le", "gbrp16le", "gray", "gray10le", "gray12le", "gray16le", "yuyv422", "yvyu422", "uyvy422"]
+         "gbrp10le", "gbrp12le", "gbrp16le", "gray", "gray10le", "gray12le", "gray16le", "yuyv422", "yvyu422", "uyvy422", "rgb48"]
 BASES = ["", "yuv444p-", "rgb24-", "yuv444p10-", "yuv444p12-", "yuv444p16-", "nv24-", "p410-", "p412-", "p416-",
-         "gbrp-", "gbrp10-", "gbrp12-", "gbrp16-"]
+         "gbrp-", "gbrp10-", "gbrp12-", "gbrp16-", "rgb48-"]
 
 out = {}
 for b in BASES:
