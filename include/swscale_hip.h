@@ -61,6 +61,8 @@ enum AVPixelFormat {
     AV_PIX_FMT_YUV440P10LE = 151, AV_PIX_FMT_YUV440P12LE = 153, AV_PIX_FMT_P016LE = 169, AV_PIX_FMT_NV24 = 188,
     AV_PIX_FMT_NV42 = 189, AV_PIX_FMT_P210LE = 198, AV_PIX_FMT_P410LE = 200, AV_PIX_FMT_P216LE = 202,
     AV_PIX_FMT_P416LE = 204, AV_PIX_FMT_P012LE = 209, AV_PIX_FMT_P212LE = 222, AV_PIX_FMT_P412LE = 224,
+    /* packed 16-bit RGB */
+    AV_PIX_FMT_RGB48LE = 35, AV_PIX_FMT_BGR48LE = 58, AV_PIX_FMT_RGBA64LE = 105, AV_PIX_FMT_BGRA64LE = 107,
     /* packed 4:2:2 */
     AV_PIX_FMT_YUYV422 = 1, AV_PIX_FMT_UYVY422 = 15, AV_PIX_FMT_YVYU422 = 108,
     /* planar YUV with an alpha plane */

@@ -112,7 +112,8 @@ void choose_unscaled(SwsInternal *c)
         (c->opts.dither == SWS_DITHER_BAYER || c->opts.dither == SWS_DITHER_AUTO) && !(c->opts.dst_h & 1)) { // :2425-2431
         // ff_yuv2rgb_get_func_ptr (yuv2rgb.c:561-678) has C converters for the 24/32 bpp packed formats and gbrp;
         // it returns NULL for gbrp9..16 / gbrpf32 and the scaler chain is used
-        if (!isPlanarRGB(d)) k = PLAN_UNSC_YUV2RGB;
+        if (!isPlanarRGB(d) && pix_desc(d)->comp[0].depth == 8) k = PLAN_UNSC_YUV2RGB;
+        else if (d == AV_PIX_FMT_RGB48LE || d == AV_PIX_FMT_BGR48LE) k = PLAN_UNSC_YUV2RGB48;
         else if (d == AV_PIX_FMT_GBRP) k = PLAN_UNSC_YUV2GBRP;
         c->dst_slice_align = 2;
     }
@@ -128,12 +129,22 @@ void choose_unscaled(SwsInternal *c)
     // rgbToRgbWrapper (:2459-2463) whenever findRgbConvFn (:1843-1998) has a converter.  All formats here are 8-bit
     // 24/32 bpp (needsDither == 0).  ":1991-1994 Maintain symmetry between endianness": with BITEXACT a 24 bpp source
     // is not shuffled into RGB32/BGR32 (bgra/rgba bytes on a little-endian host) and goes through the scaler chain.
-    if (isAnyRGB(s) && isAnyRGB(d) && !isPlanarRGB(s) && !isPlanarRGB(d) && s != d) {
+    if (isAnyRGB(s) && isAnyRGB(d) && !isPlanarRGB(s) && !isPlanarRGB(d) && s != d &&
+        pix_desc(s)->comp[0].depth == 8 && pix_desc(d)->comp[0].depth == 8) {
         const bool s32 = pix_desc(s)->comp[0].step == 4;
         if (!(!s32 && (d == AV_PIX_FMT_BGRA || d == AV_PIX_FMT_RGBA) && (flags & SWS_BITEXACT))) k = PLAN_UNSC_RGB2RGB;
     }
-    if (isAnyRGB(s) && !isPlanarRGB(s) && d == AV_PIX_FMT_GBRP) k = PLAN_UNSC_PACKED_GBRP;             // rgbToPlanarRgbWrapper (:2542-2544)
-    if (s == AV_PIX_FMT_GBRP && isAnyRGB(d) && !isPlanarRGB(d)) k = PLAN_UNSC_GBRP_PACKED;             // planarRgbToRgbWrapper (:2480-2481)
+    {   // 16-bit packed RGB: findRgbConvFn rows (:1869-1911), Rgb16ToPlanarRgb16Wrapper (:2488-2507), planarRgb16ToRgb16Wrapper (:2514-2533)
+        const bool s48 = s == AV_PIX_FMT_RGB48LE || s == AV_PIX_FMT_BGR48LE, s64 = s == AV_PIX_FMT_RGBA64LE || s == AV_PIX_FMT_BGRA64LE;
+        const bool d48 = d == AV_PIX_FMT_RGB48LE || d == AV_PIX_FMT_BGR48LE, d64 = d == AV_PIX_FMT_RGBA64LE || d == AV_PIX_FMT_BGRA64LE;
+        const bool sp16 = isPlanarRGB(s) && !isFloatFmt(s) && pix_desc(s)->comp[0].depth > 8;
+        const bool dp16 = isPlanarRGB(d) && !isFloatFmt(d) && pix_desc(d)->comp[0].depth > 8;
+        if (s != d && ((s48 && d48) || (s48 && d64) || (s64 && d48))) k = PLAN_UNSC_RGB16SHUFFLE;
+        if ((s48 || s64) && dp16) k = PLAN_UNSC_PACKED16_GBRP16;
+        if (sp16 && (d48 || d64)) k = PLAN_UNSC_GBRP16_PACKED16;
+    }
+    if (isAnyRGB(s) && !isPlanarRGB(s) && pix_desc(s)->comp[0].depth == 8 && d == AV_PIX_FMT_GBRP) k = PLAN_UNSC_PACKED_GBRP;             // rgbToPlanarRgbWrapper (:2542-2544)
+    if (s == AV_PIX_FMT_GBRP && isAnyRGB(d) && !isPlanarRGB(d) && pix_desc(d)->comp[0].depth == 8) k = PLAN_UNSC_GBRP_PACKED;             // planarRgbToRgbWrapper (:2480-2481)
     // bgr24ToYv12 / yvu9ToYv12 also take a yuva420p destination in the reference (alpha filled with 255): not built
     if (d == AV_PIX_FMT_YUVA420P && ((s == AV_PIX_FMT_BGR24 && !(flags & SWS_ACCURATE_RND) && !(c->opts.dst_w & 1)) ||
                                      (s == AV_PIX_FMT_YUV410P && !(c->opts.dst_h & 3) && !(flags & SWS_BITEXACT)) ||

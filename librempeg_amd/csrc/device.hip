@@ -95,6 +95,7 @@ static int src_kind_of(int f)
     const PixDesc *d = pix_desc(f);
     if (!d) return -1;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? SRCK_GBRPF32 : d->comp[0].depth > 8 ? SRCK_GBRP16 : SRCK_GBRP;
+    if (isAnyRGB(f) && d->comp[0].depth == 16) return SRCK_RGB48;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? SRCK_RGB24 : SRCK_RGB32;
     if (isYUV(f) && isPackedFmt(f)) return SRCK_PACKED422;
     if (isSemiPlanarYUV(f)) return d->comp[0].depth == 8 ? SRCK_NV12 : SRCK_P010;
@@ -106,6 +107,7 @@ static int dst_kind_of(int f)
     const PixDesc *d = pix_desc(f);
     if (!d) return -1;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? DSTK_GBRPF32 : d->comp[0].depth == 16 ? DSTK_GBRP16 : DSTK_GBRP;
+    if (isAnyRGB(f) && d->comp[0].depth == 16) return DSTK_RGB48;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? DSTK_RGB24 : DSTK_RGB32;
     if (isYUV(f) && isPackedFmt(f)) return DSTK_PACKED422;
     const int depth = d->comp[0].depth;
@@ -205,6 +207,8 @@ int dev_prepare(SwsInternal *c)
         p.shiftU = dd->comp[1].depth + dd->comp[1].shift - ds->comp[1].depth - ds->comp[1].shift;
         p.shiftV = dd->comp[2].depth + dd->comp[2].shift - ds->comp[2].depth - ds->comp[2].shift;
     }
+    p.s16_step = ds->comp[0].step / 2; p.s16_r = ds->comp[0].offset / 2; p.s16_g = ds->comp[1].offset / 2; p.s16_b = ds->comp[2].offset / 2;
+    p.d16_step = dd->comp[0].step / 2; p.d16_r = dd->comp[0].offset / 2; p.d16_g = dd->comp[1].offset / 2; p.d16_b = dd->comp[2].offset / 2;
     p.s422_y = ds->comp[0].offset; p.s422_u = ds->comp[1].offset; p.s422_v = ds->comp[2].offset;
     p.d422_y = dd->comp[0].offset; p.d422_u = dd->comp[1].offset; p.d422_v = dd->comp[2].offset;
     p.need_alpha = c->needAlpha;                                                             // utils.c:1746
@@ -476,6 +480,10 @@ int dev_prepare(SwsInternal *c)
     case PLAN_UNSC_YVU9_YV12: c->path_name = "unscaled:yvu9ToYv12"; c->kernel_name = "sws_k_planar_misc"; break;
     case PLAN_UNSC_YUV2GBRP: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2gbrp_unscaled"; break;
     case PLAN_UNSC_PACKED_GBRP: c->path_name = "unscaled:rgbToPlanarRgb"; c->kernel_name = "sws_k_packed_to_gbrp"; break;
+    case PLAN_UNSC_RGB16SHUFFLE: c->path_name = "unscaled:rgb16Shuffle"; c->kernel_name = "sws_k_rgb16_convert"; break;
+    case PLAN_UNSC_PACKED16_GBRP16: c->path_name = "unscaled:Rgb16ToPlanarRgb16"; c->kernel_name = "sws_k_rgb16_convert"; break;
+    case PLAN_UNSC_GBRP16_PACKED16: c->path_name = "unscaled:planarRgb16ToRgb16"; c->kernel_name = "sws_k_rgb16_convert"; break;
+    case PLAN_UNSC_YUV2RGB48: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb48_unscaled"; break;
     case PLAN_UNSC_PLANAR2P422: c->path_name = "unscaled:planarToYuy2"; c->kernel_name = "sws_k_planar_to_p422"; break;
     case PLAN_UNSC_P4222PLANAR: c->path_name = "unscaled:yuyvToPlanar"; c->kernel_name = "sws_k_p422_to_planar"; break;
     case PLAN_CASCADE: c->path_name = "cascade"; c->kernel_name = ""; break;
@@ -765,6 +773,32 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
         hipLaunchKernelGGL(swsk::sws_k_yuv2gbrp_unscaled, grid, blk, 0, st, fs, p, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 0, npairs, sliceY);
         break;
     }
+    case PLAN_UNSC_RGB16SHUFFLE:
+    case PLAN_UNSC_PACKED16_GBRP16:
+    case PLAN_UNSC_GBRP16_PACKED16: {
+        const PixDesc *ds = pix_desc(c->opts.src_format), *dd = pix_desc(c->opts.dst_format);
+        swsk::Rgb16Plan rp;
+        std::memset(&rp, 0, sizeof(rp));
+        rp.mode = c->plan == PLAN_UNSC_RGB16SHUFFLE ? 0 : c->plan == PLAN_UNSC_PACKED16_GBRP16 ? 1 : 2;
+        rp.sstep = ds->comp[0].step / 2; rp.dstep = dd->comp[0].step / 2;
+        for (int k = 0; k < 3; k++) {
+            rp.spos[k] = rp.mode == 2 ? ds->comp[k].plane : ds->comp[k].offset / 2;
+            rp.dpos[k] = rp.mode == 1 ? dd->comp[k].plane : dd->comp[k].offset / 2;
+        }
+        rp.depth = rp.mode == 1 ? dd->comp[0].depth : ds->comp[0].depth;
+        const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
+        hipLaunchKernelGGL(swsk::sws_k_rgb16_convert, grid, blk, 0, st, fs, rp, p.srcW, sliceY);
+        break;
+    }
+    case PLAN_UNSC_YUV2RGB48: {
+        const int dstW = p.dstW;
+        const int npairs = ((dstW >> 3) << 2) + ((dstW & 4) ? 2 : 0) + ((dstW & 2) ? 1 : 0); // yuv2rgb.c:198-236
+        const int nrowpairs = (sliceH + 1) >> 1;
+        if (!npairs || !nrowpairs) break;
+        const dim3 grid(cdiv(npairs, 256), nrowpairs, n);
+        hipLaunchKernelGGL(swsk::sws_k_yuv2rgb48_unscaled, grid, blk, 0, st, fs, p, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 0, npairs, sliceY);
+        break;
+    }
     case PLAN_UNSC_PLANAR2P422: {
         const int npairs = p.srcW >> 1;
         if (!npairs || !sliceH) break;
@@ -816,7 +850,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
             hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.dstW, 0);
         }
         const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 ||
-                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
+                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_RGB48;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
         if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;
@@ -1080,7 +1114,7 @@ static int run_single(SwsInternal *c, const uint8_t *const src[4], const int src
         if (r < 0) return r;
         for (int k = 0; k < npd; k++) { fr.dst[k] = (uint8_t *)d->stage_dst + doffs[k]; fr.dstStride[k] = dls[k]; }
         // converters that leave pixels untouched (odd widths in yuv2rgb.c) must preserve the caller's data
-        if (c->plan == PLAN_UNSC_YUV2RGB && (o.dst_w & 1)) {
+        if ((c->plan == PLAN_UNSC_YUV2RGB || c->plan == PLAN_UNSC_YUV2GBRP || c->plan == PLAN_UNSC_YUV2RGB48) && (o.dst_w & 1)) {
             for (int k = 0; k < npd; k++) {
                 int rb, prow; plane_geometry(o.dst_format, o.dst_w, o.dst_h, k, &rb, &prow);
                 int y0, rows; rows_of_slice(o.dst_format, k, outY, outH, &y0, &rows);

@@ -12,6 +12,7 @@ enum SrcKind {
     SRCK_RGB32,         // packed 4 bytes; rgb16_32To*_c_template input.c:264-372
     SRCK_GBRP,          // planar 8-bit RGB; planar_rgb_to_y/uv input.c:1174-1211, gbr24pToUV_half_c :414
     SRCK_GBRPF32,       // planar float RGB; planar_rgbf32_to_y/uv input.c:1287-1334
+    SRCK_RGB48,         // rgb48le / bgr48le / rgba64le / bgra64le; rgb48/64ToY/UV(_half)_c_template input.c:45-203
     SRCK_PACKED422,     // yuyv422 / uyvy422 / yvyu422: yuy2ToY/UV, yvy2ToUV, uyvyToY/UV input.c:550-578, :890-907
     SRCK_GBRP16,        // planar 9..16-bit RGB; planar_rgb16_s16_to_y/uv input.c:1216-1270
 };
@@ -28,6 +29,7 @@ enum DstKind {
     DSTK_GBRP,          // planar RGB 8..14 bit: yuv2gbrp_full_X_c output.c:2342-2421
     DSTK_GBRP16,        // planar RGB 16 bit: yuv2gbrp16_full_X_c output.c:2467-2530
     DSTK_GBRPF32,       // planar RGB float: yuv2gbrpf32_full_X_c output.c:2533-2605
+    DSTK_RGB48,         // rgb48le / bgr48le / rgba64le / bgra64le: yuv2rgba64_{X,2,1}_c_template + _full_ variants output.c:1115-1560
     DSTK_PACKED422,     // yuyv422 / yvyu422 / uyvy422: yuv2422_{1,2,X}_c_template output.c:883-1000
     DSTK_P016,          // 16-bit semi-planar: luma yuv2planeX_16_c, chroma yuv2nv12cX_16_c_template output.c:189-217
 };
@@ -126,6 +128,7 @@ struct SwsDevParams {
     // alpha: both formats carry one (needAlpha, utils.c:1746): plane 3 / the A byte is h-scaled with the LUMA filter and
     // written by the planar or packed writers; dst_alpha_fill: the destination has an alpha plane the source cannot feed
     int32_t need_alpha, src_a_pos, dst_alpha_fill;
+    int32_t s16_step, s16_r, s16_g, s16_b, d16_step, d16_r, d16_g, d16_b;   // 16-bit packed RGB: words per pixel and word offsets of R, G, B
     int32_t s422_y, s422_u, s422_v, d422_y, d422_u, d422_v;   // packed 4:2:2: byte offsets of Y0, U, V inside a 4-byte pixel pair
     int32_t src_alpha_opaque;   // rgb0-style source feeding a real alpha channel: its X byte counts as 255 (swscale.c:1106-1124)
 };

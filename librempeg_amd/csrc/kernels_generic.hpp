@@ -15,6 +15,8 @@ namespace swsk {
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFramePtrs &f, int comp, int row, int x)
 {
+    if (comp == 3 && p.srcKind == SRCK_RGB48)   // rgba64leToA_c: the 16-bit A word as is
+        return ((const uint16_t *)(f.src[0] + (int64_t)row * f.srcStride[0]))[4 * x + 3];
     if (comp == 3) {   // alpha line: plane 3 of yuva (8 bit), or rgbaToA_c / abgrToA_c (input.c:454-472) for 32 bpp RGB
         if (p.srcKind == SRCK_RGB32) {
             const int a = p.src_alpha_opaque ? 255 : f.src[0][(int64_t)row * f.srcStride[0] + 4 * x + p.src_a_pos];
@@ -89,6 +91,19 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
             return (uint16_t)((t[o] * r + t[o + 1] * g + t[o + 2] * b + (0x4001u << 9)) >> 10);
         }
         return (uint16_t)((int)((unsigned)t[o] * R[x] + (unsigned)t[o + 1] * G[x] + (unsigned)t[o + 2] * B[x] + (0x4001 << 8)) >> 9);
+    }
+    case SRCK_RGB48: { // rgb48ToY/UV(_half)_c_template, rgb64ToY/UV(_half)_c_template (input.c:45-203)
+        const int srow = comp == 0 ? row : (row << p.chrSrcVSub);
+        const uint16_t *s = (const uint16_t *)(f.src[0] + (int64_t)srow * f.srcStride[0]);
+        const int32_t *t = p.rgb2yuv;
+        const int st = p.s16_step;
+        unsigned r, g, b;
+        if (comp != 0 && p.chr_half) {
+            const uint16_t *q = s + 2 * st * x;
+            r = (q[p.s16_r] + q[st + p.s16_r] + 1u) >> 1; g = (q[p.s16_g] + q[st + p.s16_g] + 1u) >> 1; b = (q[p.s16_b] + q[st + p.s16_b] + 1u) >> 1;
+        } else { const uint16_t *q = s + st * x; r = q[p.s16_r]; g = q[p.s16_g]; b = q[p.s16_b]; }
+        const int o = comp == 0 ? 0 : comp == 1 ? 3 : 6;
+        return (uint16_t)(((unsigned)t[o] * r + (unsigned)t[o + 1] * g + (unsigned)t[o + 2] * b + ((comp == 0 ? 0x2001u : 0x10001u) << 14)) >> 15);
     }
     case SRCK_PACKED422: { // yuy2ToY_c / yuy2ToUV_c / yvy2ToUV_c (input.c:550-578), uyvyToY_c / uyvyToUV_c (:890-907)
         const uint8_t *s = f.src[0] + (int64_t)row * f.srcStride[0];
@@ -377,6 +392,56 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
     else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 1; ua = (uint16_t)cf[1]; }
     else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
              (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 2; ya = (uint16_t)lf[1]; ua = (uint16_t)cf[1]; }
+    if (p.dstKind == DSTK_RGB48) {
+        // yuv2rgba64_{X,2,1}_c_template and yuv2rgba64_full_{X,2,1}_c_template (output.c:1115-1560): 19-bit lines, 32-bit
+        // wrap-around arithmetic with the reference's signedness of every shift (the full_1 blend shifts LOGICALLY, :1538-1539)
+        const int npx = p.full_chr ? 1 : 2;
+        uint16_t *drow16 = (uint16_t *)drow;
+        for (int h = 0; h < npx; h++) {
+            const int x = p.full_chr ? i : 2 * i + h;
+            if (x >= p.dstW) break;
+            unsigned Y, U, V;
+            int A = 0xffff << 14;
+            if (mode == 0) {
+                Y = (unsigned)-0x40000000; U = (unsigned)-(128 << 23); V = (unsigned)-(128 << 23);
+                for (int j = 0; j < lfs; j++) Y += (unsigned)LUM(j, x) * (unsigned)(int)lf[j];
+                for (int j = 0; j < cfs; j++) { U += (unsigned)CHU(j, i) * (unsigned)(int)cf[j]; V += (unsigned)CHV(j, i) * (unsigned)(int)cf[j]; }
+                if (p.need_alpha) {
+                    unsigned a = (unsigned)-0x40000000;
+                    for (int j = 0; j < lfs; j++) a += (unsigned)ALP(j, x) * (unsigned)(int)lf[j];
+                    A = ((int)a >> 1) + 0x20002000;
+                }
+                Y = (unsigned)((int)Y >> 14) + 0x10000u;
+                U = (unsigned)((int)U >> 14); V = (unsigned)((int)V >> 14);
+            } else if (mode == 2) {
+                const unsigned ya1 = 4096 - ya, ua1 = 4096 - ua;
+                Y = (unsigned)((int)((unsigned)LUM(0, x) * ya1 + (unsigned)LUM(1, x) * (unsigned)ya) >> 14);
+                U = (unsigned)((int)((unsigned)CHU(0, i) * ua1 + (unsigned)CHU(1, i) * (unsigned)ua - (128u << 23)) >> 14);
+                V = (unsigned)((int)((unsigned)CHV(0, i) * ua1 + (unsigned)CHV(1, i) * (unsigned)ua - (128u << 23)) >> 14);
+                if (p.need_alpha) A = ((int)((unsigned)ALP(0, x) * ya1 + (unsigned)ALP(1, x) * (unsigned)ya) >> 1) + (1 << 13);
+            } else {
+                Y = (unsigned)(LUM(0, x) >> 2);
+                if (ua == 0) { U = (unsigned)((CHU(0, i) - (128 << 11)) >> 2); V = (unsigned)((CHV(0, i) - (128 << 11)) >> 2); }
+                else {
+                    const unsigned ua1 = 4096 - ua;
+                    const unsigned tu = (unsigned)CHU(0, i) * ua1 + (unsigned)CHU(1, i) * (unsigned)ua - (128u << 23);
+                    const unsigned tv = (unsigned)CHV(0, i) * ua1 + (unsigned)CHV(1, i) * (unsigned)ua - (128u << 23);
+                    if (p.full_chr) { U = tu >> 14; V = tv >> 14; } else { U = (unsigned)((int)tu >> 14); V = (unsigned)((int)tv >> 14); }
+                }
+                if (p.need_alpha) A = (int)((unsigned)ALP(0, x) * (1u << 11)) + (1 << 13);
+            }
+            Y -= (unsigned)L.y_offset;
+            Y *= (unsigned)L.y_coeff;
+            Y += (unsigned)((1 << 13) - (1 << 29));
+            const unsigned R = V * (unsigned)L.v2r, G = V * (unsigned)L.v2g + U * (unsigned)L.u2g, B = U * (unsigned)L.u2b;
+            uint16_t *d = drow16 + p.d16_step * x;
+            d[p.d16_r] = (uint16_t)clip_uintp2(((int)(R + Y) >> 14) + (1 << 15), 16);
+            d[p.d16_g] = (uint16_t)clip_uintp2(((int)(G + Y) >> 14) + (1 << 15), 16);
+            d[p.d16_b] = (uint16_t)clip_uintp2(((int)(B + Y) >> 14) + (1 << 15), 16);
+            if (p.d16_step == 4) d[3] = (uint16_t)(clip_uintp2(A, 30) >> 14);
+        }
+        return;
+    }
     if (p.dstKind == DSTK_PACKED422) {   // yuv2422_{X,2,1}_c_template, output.c:883-1000
         int Y1, Y2, U, V;
         if (mode == 0) {

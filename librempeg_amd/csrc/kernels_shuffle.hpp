@@ -195,6 +195,75 @@ __global__ void __launch_bounds__(256) sws_k_p422_to_planar(SwsFrameSet fs, SwsD
     }
 }
 
+// 16-bit packed RGB converters; thread = pixel.
+//   mode 0: rgb48tobgr48 / rgb48to64 / rgb48tobgr64 / rgb64to48 / rgb64tobgr48 (rgb2rgb.c:322-413): word moves, A = 0xFFFF
+//   mode 1: Rgb16ToPlanarRgb16Wrapper / packed16togbra16 (swscale_unscaled.c:685-962): plane[x] = word >> (16 - depth)
+//   mode 2: planarRgb16ToRgb16Wrapper / gbr16ptopacked16 (:964-1186): word = c << (16 - bpp) | c >> ((bpp - 8) * 2), A = 0xFFFF
+struct Rgb16Plan { int mode, sstep, dstep, spos[3], dpos[3], depth; };   // positions in 16-bit words (packed) or plane index (planar)
+__global__ void __launch_bounds__(256) sws_k_rgb16_convert(SwsFrameSet fs, Rgb16Plan rp, int w, int sliceY)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= w) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int y = sliceY + blockIdx.y;                          // absolute row (the host rebases slice pointers)
+    uint16_t v[3];
+    if (rp.mode == 2) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int pl = rp.spos[k];
+            const uint8_t *sp = pl == 0 ? f.src[0] : pl == 1 ? f.src[1] : f.src[2];
+            const int ss = pl == 0 ? f.srcStride[0] : pl == 1 ? f.srcStride[1] : f.srcStride[2];
+            const uint16_t c = ((const uint16_t *)(sp + (int64_t)y * ss))[x];
+            v[k] = (uint16_t)(c << (16 - rp.depth) | c >> ((rp.depth - 8) * 2));
+        }
+    } else {
+        const uint16_t *s = (const uint16_t *)(f.src[0] + (int64_t)y * f.srcStride[0]) + rp.sstep * x;
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[k] = s[rp.spos[k]];
+    }
+    if (rp.mode == 1) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int pl = rp.dpos[k];
+            uint8_t *dp = pl == 0 ? f.dst[0] : pl == 1 ? f.dst[1] : f.dst[2];
+            const int dst = pl == 0 ? f.dstStride[0] : pl == 1 ? f.dstStride[1] : f.dstStride[2];
+            ((uint16_t *)(dp + (int64_t)y * dst))[x] = (uint16_t)(v[k] >> (16 - rp.depth));
+        }
+    } else {
+        uint16_t *d = (uint16_t *)(f.dst[0] + (int64_t)y * f.dstStride[0]) + rp.dstep * x;
+#pragma unroll
+        for (int k = 0; k < 3; k++) d[rp.dpos[k]] = v[k];
+        if (rp.dstep == 4) d[3] = 0xFFFF;
+    }
+}
+
+// yuv2rgb_c_48 / yuv2rgb_c_bgr48 (PUTRGB48 / PUTBGR48, yuv2rgb.c:107-125): the 8-bit LUT value fills both bytes of the
+// 16-bit component.  One thread = one chroma sample = 2 pixels x 2 rows.
+__global__ void __launch_bounds__(256) sws_k_yuv2rgb48_unscaled(SwsFrameSet fs, SwsDevParams p, int is422, int npairs, int sliceY)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const SwsLutParams &L = p.lut;
+    const int yrow = 2 * blockIdx.y;
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const int yy = yrow + l;
+        const int cr = is422 ? sliceY + yy : ((sliceY + yrow) >> 1);
+        const int U = f.src[1][(int64_t)cr * f.srcStride[1] + i], V = f.src[2][(int64_t)cr * f.srcStride[2] + i];
+        const ChromaIdx k = lut_chroma(L, U, V);
+        const uint8_t *py = f.src[0] + (int64_t)(sliceY + yy) * f.srcStride[0] + 2 * i;
+        uint16_t *d = (uint16_t *)(f.dst[0] + (int64_t)(sliceY + yy) * f.dstStride[0]) + 6 * i;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int Y = py[h];
+            d[3 * h + p.d16_r] = (uint16_t)(lut_luma(L, k.r + Y) * 257);
+            d[3 * h + p.d16_g] = (uint16_t)(lut_luma(L, k.g + Y) * 257);
+            d[3 * h + p.d16_b] = (uint16_t)(lut_luma(L, k.b + Y) * 257);
+        }
+    }
+}
+
 // bgr24ToYv12Wrapper (swscale_unscaled.c:2062-2078) -> ff_rgb24toyv12_c (rgb2rgb_template.c:580-641).
 // One thread = 4 chroma samples = 8 pixels x 2 rows: 2 x 24 bytes in, 2 x 8 luma + 4 U + 4 V bytes out.
 // All arithmetic is unsigned and the results are stored modulo 256 exactly like the reference's uint8_t stores.

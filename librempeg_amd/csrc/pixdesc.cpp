@@ -22,6 +22,10 @@ static const PixDesc g_descs[] = {
 #define PLN(F, N, LW, LH, D)  { F, N, 3, LW, LH, {{0,2,0,0,D},{1,2,0,0,D},{2,2,0,0,D},{0,0,0,0,0}}, PIXFLAG_PLANAR }
 #define SP8(F, N, LW, LH, UO) { F, N, 3, LW, LH, {{0,1,0,0,8},{1,2,UO,0,8},{1,2,1-(UO),0,8},{0,0,0,0,0}}, PIXFLAG_PLANAR }
 #define SPN(F, N, LW, LH, D)  { F, N, 3, LW, LH, {{0,2,0,16-(D),D},{1,4,0,16-(D),D},{1,4,2,16-(D),D},{0,0,0,0,0}}, PIXFLAG_PLANAR }
+    { AV_PIX_FMT_RGB48LE,  "rgb48le",  3, 0, 0, {{0,6,0,0,16},{0,6,2,0,16},{0,6,4,0,16},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_BGR48LE,  "bgr48le",  3, 0, 0, {{0,6,4,0,16},{0,6,2,0,16},{0,6,0,0,16},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_RGBA64LE, "rgba64le", 4, 0, 0, {{0,8,0,0,16},{0,8,2,0,16},{0,8,4,0,16},{0,8,6,0,16}}, PIXFLAG_RGB | PIXFLAG_ALPHA },
+    { AV_PIX_FMT_BGRA64LE, "bgra64le", 4, 0, 0, {{0,8,4,0,16},{0,8,2,0,16},{0,8,0,0,16},{0,8,6,0,16}}, PIXFLAG_RGB | PIXFLAG_ALPHA },
     { AV_PIX_FMT_YUYV422, "yuyv422", 3, 1, 0, {{0,2,0,0,8},{0,4,1,0,8},{0,4,3,0,8},{0,0,0,0,0}}, 0 },
     { AV_PIX_FMT_UYVY422, "uyvy422", 3, 1, 0, {{0,2,1,0,8},{0,4,0,0,8},{0,4,2,0,8},{0,0,0,0,0}}, 0 },
     { AV_PIX_FMT_YVYU422, "yvyu422", 3, 1, 0, {{0,2,0,0,8},{0,4,3,0,8},{0,4,1,0,8},{0,0,0,0,0}}, 0 },

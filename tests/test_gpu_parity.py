@@ -86,8 +86,9 @@ YUV_FAMILY = ["yuyv422", "uyvy422", "yvyu422", "yuva420p", "yuva422p", "yuva444p
               "p010le", "p210le", "p410le", "p012le", "p212le", "p412le", "p016le", "p216le", "p416le"]
 PLANAR_RGB = ["gbrp", "gbrp9le", "gbrp10le", "gbrp12le", "gbrp14le", "gbrp16le", "gbrpf32le"]
 GRAYS = ["gray8", "gray9le", "gray10le", "gray12le", "gray14le", "gray16le"]
-FORMAT_MATRIX_SRC = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS
-FORMAT_MATRIX_DST = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS
+RGB16 = ["rgb48le", "bgr48le", "rgba64le", "bgra64le"]
+FORMAT_MATRIX_SRC = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+FORMAT_MATRIX_DST = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
 
 
 @pytest.mark.parametrize("sfmt", FORMAT_MATRIX_SRC)
@@ -167,6 +168,9 @@ SLICED_UNSCALED = [
     ("argb", "gbrp", BX), ("gbrp", "gbrp", BX), ("gbrp10le", "gbrp10le", BX),
     ("yuva420p", "rgba", BX), ("yuva420p", "abgr", BX), ("yuva420p", "yuv420p", BX), ("yuv420p", "yuva420p", BX), ("yuva444p", "yuva444p", BX),
     ("yuva420p", "nv12", BX), ("yuva420p", "p010le", BX),
+    ("rgb48le", "bgr48le", BX), ("rgb48le", "rgba64le", BX), ("bgr48le", "rgba64le", BX), ("rgba64le", "bgr48le", BX), ("bgra64le", "bgr48le", BX),
+    ("rgb48le", "gbrp10le", BX), ("bgra64le", "gbrp16le", BX), ("gbrp12le", "rgba64le", BX), ("gbrp9le", "bgr48le", BX),
+    ("yuv420p", "rgb48le", BX), ("yuv422p", "bgr48le", BX), ("rgb48le", "rgb48le", BX),
     ("yuv422p", "yuyv422", BX), ("yuv422p", "uyvy422", BX), ("yuv420p", "yuyv422", OL.SWS_POINT), ("yuv420p", "uyvy422", OL.SWS_POINT | BX),
     ("yuyv422", "yuv420p", BX), ("uyvy422", "yuv420p", BX), ("yuyv422", "yuv422p", BX), ("uyvy422", "yuv422p", BX), ("yvyu422", "yvyu422", BX),
     ("yuvj420p", "gray8", BX), ("gray8", "yuvj444p", BX), ("gray8", "gray16le", BX), ("gray12le", "gray8", BX), ("gray10le", "yuvj420p", BX),
@@ -219,7 +223,7 @@ def test_fast_bilinear(geom):
         run_case(sw, sh, sfmt, dw & ~1, dh, dfmt, FB, seed=sw + 1)
 
 
-ALPHA_FMTS = ["rgba", "bgra", "argb", "abgr", "yuva420p", "yuva422p", "yuva444p"]
+ALPHA_FMTS = ["rgba", "bgra", "argb", "abgr", "yuva420p", "yuva422p", "yuva444p", "rgba64le", "bgra64le"]
 
 
 @pytest.mark.parametrize("sfmt", ALPHA_FMTS + ["rgb0", "0bgr", "yuv420p", "rgb24"])
