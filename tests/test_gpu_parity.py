@@ -336,6 +336,7 @@ def test_sws_scale_frame_configures_itself_from_the_frames():
         for i, (a, b) in enumerate(zip(out.planes, ref.planes)):
             assert np.array_equal(a[:, :out.row_bytes[i]], b[:, :out.row_bytes[i]])
         assert p.scale_frames([ds, ds], [dd, dd]) == 2
+        p.sync()   # device frames are processed asynchronously on the context's stream: finish before they are freed
         sp, ss = ds.ptrs()
         dp, dstr = dd.ptrs()
         assert p.L.sws_scale(p.c, sp, ss, 0, sh, dp, dstr) == -22
