@@ -236,6 +236,32 @@ int sws_scale_frame(SwsContext *c, SwsFrameView *dst, const SwsFrameView *src);
  * Returns nb_frames on success or a negative AVERROR. */
 int sws_scale_frames(SwsContext *c, SwsFrameView *const dst[], const SwsFrameView *const src[], int nb_frames);
 
+/* ---- the rest of the reference's exported API (swscale.h) ---- */
+const void *sws_get_class(void);                                            /* swscale.h:71 (const AVClass *) */
+int sws_test_format(enum AVPixelFormat format, int output);                 /* :342 */
+int sws_test_hw_format(enum AVPixelFormat format);                          /* :352 */
+int sws_test_colorspace(int colorspace, int output);                        /* :363 (enum AVColorSpace) */
+int sws_test_primaries(int primaries, int output);                          /* :374 (enum AVColorPrimaries) */
+int sws_test_transfer(int trc, int output);                                 /* :385 (enum AVColorTransferCharacteristic) */
+int sws_test_frame(const SwsFrameView *frame, int output);                  /* :392 */
+int sws_frame_setup(SwsContext *ctx, const SwsFrameView *dst, const SwsFrameView *src); /* :405 */
+int sws_is_noop(const SwsFrameView *dst, const SwsFrameView *src);          /* :415 */
+int sws_frame_start(SwsContext *c, SwsFrameView *dst, const SwsFrameView *src);  /* :613 */
+void sws_frame_end(SwsContext *c);                                          /* :623 */
+int sws_send_slice(SwsContext *c, unsigned int slice_start, unsigned int slice_height);    /* :637 */
+int sws_receive_slice(SwsContext *c, unsigned int slice_start, unsigned int slice_height); /* :657 */
+unsigned int sws_receive_slice_alignment(const SwsContext *c);              /* :669 */
+SwsVector *sws_allocVec(int length);                                        /* :699 */
+SwsVector *sws_getGaussianVec(double variance, double quality);             /* :705 */
+void sws_scaleVec(SwsVector *a, double scalar);                             /* :710 */
+void sws_normalizeVec(SwsVector *a, double height);                         /* :715 */
+void sws_freeVec(SwsVector *a);                                             /* :717 */
+SwsFilter *sws_getDefaultFilter(float lumaGBlur, float chromaGBlur, float lumaSharpen, float chromaSharpen,
+                                float chromaHShift, float chromaVShift, int verbose); /* :719 */
+void sws_freeFilter(SwsFilter *filter);                                     /* :723 */
+void sws_convertPalette8ToPacked32(const uint8_t *src, uint8_t *dst, int num_pixels, const uint8_t *palette); /* :753 */
+void sws_convertPalette8ToPacked24(const uint8_t *src, uint8_t *dst, int num_pixels, const uint8_t *palette); /* :765 */
+
 /* ---- HIP device plumbing (the AV_HWDEVICE_TYPE_HIP slot; shape of
  *      libavutil/hwcontext_internal.h:29-99 HWContextType, model
  *      libavutil/hwcontext_cuda.c:132-197, :523-655) ---- */

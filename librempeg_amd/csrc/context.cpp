@@ -260,7 +260,10 @@ int init_single_context(SwsInternal *c)
     c->needAlpha = isALPHA(srcFormat) && isALPHA(dstFormat);                    // :1746
 
     c->plan = PLAN_NONE;
-    if (unscaled && (o->src_range == o->dst_range || isAnyRGB(dstFormat) || isFloatFmt(srcFormat) || isFloatFmt(dstFormat))) { // :1623-1637
+    const bool usesHFilter = c->srcVec[0].size() > 1 || c->srcVec[2].size() > 1 || c->dstVecLen[0] > 1 || c->dstVecLen[2] > 1;   // :1256-1263
+    const bool usesVFilter = c->srcVec[1].size() > 1 || c->srcVec[3].size() > 1 || c->dstVecLen[1] > 1 || c->dstVecLen[3] > 1;
+    if (unscaled && !usesHFilter && !usesVFilter &&
+        (o->src_range == o->dst_range || isAnyRGB(dstFormat) || isFloatFmt(srcFormat) || isFloatFmt(dstFormat))) { // :1623-1637
         choose_unscaled(c);
         if ((int)c->plan == -1) {
             log_msg(c, 0, "unscaled %s -> %s special converter is not implemented on the HIP path\n", ds->name, dd->name);
@@ -279,15 +282,17 @@ int init_single_context(SwsInternal *c)
 
     // filters; filterAlign is 1 in the reference's C path (:1675-1735)
     const int hp = local_pos(0, 0);
-    int ret = build_filter_bank(c->hLum, c->lumXInc, srcW, dstW, 1, 1 << 14, lum_scaler, flags, o->scaler_params, hp, hp);
+    auto fvec = [&](int k) { FilterVec v; v.coeff = c->srcVec[k].empty() ? nullptr : c->srcVec[k].data(); v.length = (int)c->srcVec[k].size();
+                             v.dst_length = c->dstVecLen[k]; return v; };
+    int ret = build_filter_bank(c->hLum, c->lumXInc, srcW, dstW, 1, 1 << 14, lum_scaler, flags, o->scaler_params, hp, hp, fvec(0));
     if (ret == FILTER_OK)
         ret = build_filter_bank(c->hChr, c->chrXInc, c->chrSrcW, c->chrDstW, 1, 1 << 14, chr_scaler, flags, o->scaler_params,
-                                local_pos(c->chrSrcHSubSample, o->src_h_chr_pos), local_pos(c->chrDstHSubSample, o->dst_h_chr_pos));
+                                local_pos(c->chrSrcHSubSample, o->src_h_chr_pos), local_pos(c->chrDstHSubSample, o->dst_h_chr_pos), fvec(2));
     if (ret == FILTER_OK)
-        ret = build_filter_bank(c->vLum, c->lumYInc, srcH, dstH, 1, 1 << 12, lum_scaler, flags, o->scaler_params, hp, hp);
+        ret = build_filter_bank(c->vLum, c->lumYInc, srcH, dstH, 1, 1 << 12, lum_scaler, flags, o->scaler_params, hp, hp, fvec(1));
     if (ret == FILTER_OK)
         ret = build_filter_bank(c->vChr, c->chrYInc, c->chrSrcH, c->chrDstH, 1, 1 << 12, chr_scaler, flags, o->scaler_params,
-                                local_pos(c->chrSrcVSubSample, o->src_v_chr_pos), local_pos(c->chrDstVSubSample, o->dst_v_chr_pos));
+                                local_pos(c->chrSrcVSubSample, o->src_v_chr_pos), local_pos(c->chrDstVSubSample, o->dst_v_chr_pos), fvec(3));
     if (ret == FILTER_USE_CASCADE) {
         log_msg(c, 0, "extreme scaling ratio needs the two-step cascade (utils.c:1803-1833): not implemented on the HIP path\n");
         return SWS_AVERROR(ENOTSUP);
@@ -352,13 +357,17 @@ static SwsInternal *alloc_set_opts(int srcW, int srcH, int srcFormat, int dstW, 
 
 static int init_context_impl(SwsInternal *c, SwsFilter *srcFilter, SwsFilter *dstFilter)
 {
-    auto has_taps = [](const SwsFilter *f) {
-        return f && ((f->lumH && f->lumH->length > 1) || (f->lumV && f->lumV->length > 1) ||
-                     (f->chrH && f->chrH->length > 1) || (f->chrV && f->chrV->length > 1));
-    };
-    if (has_taps(srcFilter) || has_taps(dstFilter)) {
-        log_msg(c, 0, "SwsFilter pre/post convolution vectors are not implemented on the HIP path\n");
-        return SWS_AVERROR(ENOTSUP);
+    // SwsFilter arguments are read at init only (utils.c:1884-1890): keep copies of the vectors
+    {
+        const SwsVector *sv[4] = { srcFilter ? srcFilter->lumH : nullptr, srcFilter ? srcFilter->lumV : nullptr,
+                                   srcFilter ? srcFilter->chrH : nullptr, srcFilter ? srcFilter->chrV : nullptr };
+        const SwsVector *dv[4] = { dstFilter ? dstFilter->lumH : nullptr, dstFilter ? dstFilter->lumV : nullptr,
+                                   dstFilter ? dstFilter->chrH : nullptr, dstFilter ? dstFilter->chrV : nullptr };
+        for (int k = 0; k < 4; k++) {
+            c->srcVec[k].clear();
+            if (sv[k] && sv[k]->coeff && sv[k]->length > 0) c->srcVec[k].assign(sv[k]->coeff, sv[k]->coeff + sv[k]->length);
+            c->dstVecLen[k] = dv[k] ? dv[k]->length : 0;
+        }
     }
     c->legacy_init = true;                                   // utils.c:1892
     c->opts.src_range |= jpeg_alias(&c->opts.src_format);    // :1903-1904

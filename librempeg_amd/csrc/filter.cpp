@@ -100,7 +100,7 @@ int support_factor(int scaler, const double *param) // utils.c:183-195, :278-279
 } // namespace
 
 int build_filter_bank(FilterBank &out, int xInc, int srcW, int dstW, int filterAlign, int one,
-                      int scaler, int flags, const double param[2], int srcPos, int dstPos)
+                      int scaler, int flags, const double param[2], int srcPos, int dstPos, const FilterVec &vec)
 {
     const int64_t fone = 1LL << (54 - std::min(floor_log2((unsigned)(srcW / dstW)), 8));
     std::vector<int64_t> raw;  // dstW x rawSize, 54-ish bit fixed point
@@ -146,6 +146,30 @@ int build_filter_bank(FilterBank &out, int xInc, int srcW, int dstW, int filterA
                 raw[(size_t)i * rawSize + j] = weight(d);
             }
         }
+    }
+
+    // ---- stage 1b: SwsFilter vectors (:385-415).  The source vector is convolved into every row (double products
+    // accumulated into the int64 taps, as the C expression does); the destination vector only widens the rows
+    // ("FIXME dstFilter" in the reference); positions are re-centred. ----
+    if ((vec.coeff && vec.length > 0) || vec.dst_length > 0) {
+        int size2 = rawSize;
+        if (vec.coeff) size2 += vec.length - 1;
+        if (vec.dst_length) size2 += vec.dst_length - 1;
+        std::vector<int64_t> raw2((size_t)dstW * size2, 0);
+        for (int i = 0; i < dstW; i++) {
+            if (vec.coeff) {
+                for (int k = 0; k < vec.length; k++)
+                    for (int j = 0; j < rawSize; j++) {
+                        int64_t &t = raw2[(size_t)i * size2 + k + j];
+                        t = (int64_t)((double)t + vec.coeff[k] * (double)raw[(size_t)i * rawSize + j]);
+                    }
+            } else {
+                for (int j = 0; j < rawSize; j++) raw2[(size_t)i * size2 + j] = raw[(size_t)i * rawSize + j];
+            }
+            pos[i] += (rawSize - 1) / 2 - (size2 - 1) / 2;
+        }
+        raw.swap(raw2);
+        rawSize = size2;
     }
 
     // ---- stage 2: trim near-zero taps (:417-457).  Leading taps are shifted out while the row

@@ -35,8 +35,9 @@ struct FilterBank {
     int size = 0, count = 0;
 };
 enum { FILTER_OK = 0, FILTER_ERR = -1, FILTER_USE_CASCADE = -12345 };
+struct FilterVec { const double *coeff = nullptr; int length = 0; int dst_length = 0; };   // SwsFilter vectors of one axis/plane class
 int build_filter_bank(FilterBank &out, int xInc, int srcW, int dstW, int filterAlign, int one,
-                      int scaler, int flags, const double param[2], int srcPos, int dstPos);
+                      int scaler, int flags, const double param[2], int srcPos, int dstPos, const FilterVec &vec = FilterVec());
 
 // ---- colour tables ----
 struct Yuv2RgbLut {          // closed form of ff_yuv2rgb_c_init_tables (yuv2rgb.c:717-973)
@@ -90,6 +91,9 @@ struct SwsInternal {
     SwsContext opts;          // MUST be first: the public struct (swscale_internal.h:337-340 idiom)
     uint32_t magic;
     bool legacy_init = false;
+    std::vector<double> srcVec[4];   // copies of the SwsFilter vectors given to sws_init_context: lumH, lumV, chrH, chrV
+    int dstVecLen[4] = {0, 0, 0, 0};
+    const SwsFrameView *frame_src = nullptr; SwsFrameView *frame_dst = nullptr; int frame_rows_in = 0;   // sws_frame_start .. sws_frame_end
     bool dynamic_init = false;    // configured from the frames of sws_scale_frame() (swscale.c:1405-1480)
     int sliceDir = 0;             // 0 = no slice sequence in progress, 1 = top-down, -1 = bottom-up (swscale.c:1096-1104)
     int slice_dstY = 0;           // ff_swscale's dstY cursor (swscale.c:372-381, :566)

@@ -93,6 +93,26 @@ class SwsFrameView(C.Structure):
                 ("width", C.c_int), ("height", C.c_int), ("nb_samples", C.c_int), ("format", C.c_int)]
 
 
+class SwsVector(C.Structure):
+    """swscale.h:478-481"""
+    _fields_ = [("coeff", C.POINTER(C.c_double)), ("length", C.c_int)]
+
+
+class SwsFilter(C.Structure):
+    """swscale.h:484-489"""
+    _fields_ = [("lumH", C.POINTER(SwsVector)), ("lumV", C.POINTER(SwsVector)),
+                ("chrH", C.POINTER(SwsVector)), ("chrV", C.POINTER(SwsVector))]
+
+
+def vec_to_list(v):
+    return [v.contents.coeff[i] for i in range(v.contents.length)]
+
+
+def filter_to_dict(f):
+    """SwsFilter* -> {"lumH": [...], ...} (the shape tests/oracle_lib.Oracle(src_filter=) takes)"""
+    return {n: vec_to_list(getattr(f.contents, n)) for n in ("lumH", "lumV", "chrH", "chrV")}
+
+
 def load_library():
     global _LIB
     if _LIB is not None:
@@ -147,6 +167,39 @@ def load_library():
     L.sws_hip_last_kernel_ms.argtypes = [vp]
     L.sws_hip_set_timing.argtypes = [vp, ci]
     L.swscale_version.restype = C.c_uint
+    cd, cf, cu = C.c_double, C.c_float, C.c_uint
+    L.sws_allocVec.restype = C.POINTER(SwsVector)
+    L.sws_allocVec.argtypes = [ci]
+    L.sws_getGaussianVec.restype = C.POINTER(SwsVector)
+    L.sws_getGaussianVec.argtypes = [cd, cd]
+    L.sws_scaleVec.argtypes = [C.POINTER(SwsVector), cd]
+    L.sws_scaleVec.restype = None
+    L.sws_normalizeVec.argtypes = [C.POINTER(SwsVector), cd]
+    L.sws_normalizeVec.restype = None
+    L.sws_freeVec.argtypes = [C.POINTER(SwsVector)]
+    L.sws_freeVec.restype = None
+    L.sws_getDefaultFilter.restype = C.POINTER(SwsFilter)
+    L.sws_getDefaultFilter.argtypes = [cf, cf, cf, cf, cf, cf, ci]
+    L.sws_freeFilter.argtypes = [C.POINTER(SwsFilter)]
+    L.sws_freeFilter.restype = None
+    L.sws_convertPalette8ToPacked32.argtypes = [vp, vp, ci, vp]
+    L.sws_convertPalette8ToPacked32.restype = None
+    L.sws_convertPalette8ToPacked24.argtypes = [vp, vp, ci, vp]
+    L.sws_convertPalette8ToPacked24.restype = None
+    L.sws_get_class.restype = vp
+    for n in ("sws_test_format", "sws_test_colorspace", "sws_test_primaries", "sws_test_transfer"):
+        getattr(L, n).argtypes = [ci, ci]
+    L.sws_test_hw_format.argtypes = [ci]
+    L.sws_test_frame.argtypes = [C.POINTER(SwsFrameView), ci]
+    L.sws_is_noop.argtypes = [C.POINTER(SwsFrameView), C.POINTER(SwsFrameView)]
+    L.sws_frame_setup.argtypes = [vp, C.POINTER(SwsFrameView), C.POINTER(SwsFrameView)]
+    L.sws_frame_start.argtypes = [vp, C.POINTER(SwsFrameView), C.POINTER(SwsFrameView)]
+    L.sws_frame_end.argtypes = [vp]
+    L.sws_frame_end.restype = None
+    L.sws_send_slice.argtypes = [vp, cu, cu]
+    L.sws_receive_slice.argtypes = [vp, cu, cu]
+    L.sws_receive_slice_alignment.argtypes = [vp]
+    L.sws_receive_slice_alignment.restype = cu
     _LIB = L
     return L
 
@@ -269,6 +322,7 @@ class SwsContext:
         if empty:
             self.c = L.sws_alloc_context()
         elif opts:
+            opts = dict(opts)
             self.c = L.sws_alloc_context()
             if not self.c:
                 raise RuntimeError("sws_alloc_context failed")
@@ -278,9 +332,11 @@ class SwsContext:
             f.flags = flags
             if param:
                 f.scaler_params[0], f.scaler_params[1] = param
+            src_filter = opts.pop("src_filter", None)     # POINTER(SwsFilter) from sws_getDefaultFilter(), or None
+            dst_filter = opts.pop("dst_filter", None)
             for k, v in opts.items():
                 setattr(f, k, v)
-            r = L.sws_init_context(self.c, None, None)
+            r = L.sws_init_context(self.c, src_filter, dst_filter)
             if r < 0:
                 L.sws_freeContext(self.c)
                 self.c = None

@@ -237,7 +237,8 @@ static double spline_coeff(double a, double b, double c, double d, double dist) 
 
 static int init_filter(int16_t **outFilter, int32_t **filterPos, int *outFilterSize,
                        int xInc, int srcW, int dstW, int filterAlign, int one,
-                       int scaler, int flags, const double param[2], int srcPos, int dstPos)
+                       int scaler, int flags, const double param[2], int srcPos, int dstPos,
+                       const double *srcVec, int srcVecLen, int dstVecLen)
 {
     int filterSize, filter2Size, minFilterSize, i, j, ret = -1;
     int64_t *filter = NULL, *filter2 = NULL;
@@ -363,10 +364,22 @@ static int init_filter(int16_t **outFilter, int32_t **filterPos, int *outFilterS
         }
     }
 
-    /* no src/dst SwsVector: filter2 == filter (:385-415) */
+    /* apply src & dst SwsVector to filter -> filter2 (:385-415): the source vector is convolved in (double products
+     * accumulated into the int64 taps), the destination vector only widens the row ("FIXME dstFilter") */
     filter2Size = filterSize;
+    if (srcVec) filter2Size += srcVecLen - 1;
+    if (dstVecLen) filter2Size += dstVecLen - 1;
     filter2 = calloc((size_t)dstW * filter2Size, sizeof(*filter2));
-    memcpy(filter2, filter, (size_t)dstW * filter2Size * sizeof(*filter2));
+    for (i = 0; i < dstW; i++) {
+        if (srcVec) {
+            for (int k = 0; k < srcVecLen; k++)
+                for (j = 0; j < filterSize; j++)
+                    filter2[(size_t)i * filter2Size + k + j] += srcVec[k] * filter[(size_t)i * filterSize + j];
+        } else {
+            for (j = 0; j < filterSize; j++) filter2[(size_t)i * filter2Size + j] = filter[(size_t)i * filterSize + j];
+        }
+        (*filterPos)[i] += (filterSize - 1) / 2 - (filter2Size - 1) / 2;
+    }
     free(filter); filter = NULL;
 
     /* reduce, step 1 (:417-457) */
@@ -881,7 +894,12 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
     /* alpha: src alpha dropped -> reference cascades through alpha blend only if alpha_blend != NONE (default NONE) */
     c->needAlpha = isALPHA(srcFormat) && isALPHA(dstFormat);
 
-    if (unscaled && (c->o.src_range == c->o.dst_range || isAnyRGB(dstFormat) || isFloat(srcFormat) || isFloat(dstFormat))) {
+    const int usesHFilter = (c->o.src_vec[0] && c->o.src_vec_len[0] > 1) || (c->o.src_vec[2] && c->o.src_vec_len[2] > 1) ||
+                            c->o.dst_vec_len[0] > 1 || c->o.dst_vec_len[2] > 1;   /* utils.c:1256-1263 */
+    const int usesVFilter = (c->o.src_vec[1] && c->o.src_vec_len[1] > 1) || (c->o.src_vec[3] && c->o.src_vec_len[3] > 1) ||
+                            c->o.dst_vec_len[1] > 1 || c->o.dst_vec_len[3] > 1;
+    if (unscaled && !usesHFilter && !usesVFilter &&
+        (c->o.src_range == c->o.dst_range || isAnyRGB(dstFormat) || isFloat(srcFormat) || isFloat(dstFormat))) {
         get_unscaled(c);
         /* bgr24ToYv12 / yvu9ToYv12 also take a yuva420p destination in the reference (alpha filled with 255): not restated */
         if (dstFormat == ORF_YUVA420P &&
@@ -894,18 +912,22 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
 
     /* filters (:1675-1735), filterAlign == 1 in the C-only build */
     ret = init_filter(&c->hLumFilter, &c->hLumFilterPos, &c->hLumFilterSize, c->lumXInc, srcW, dstW, 1, 1 << 14,
-                      lum_scaler, flags, c->o.scaler_params, get_local_pos(0, 0), get_local_pos(0, 0));
+                      lum_scaler, flags, c->o.scaler_params, get_local_pos(0, 0), get_local_pos(0, 0),
+                      c->o.src_vec[0], c->o.src_vec_len[0], c->o.dst_vec_len[0]);
     if (ret < 0) return -1;
     ret = init_filter(&c->hChrFilter, &c->hChrFilterPos, &c->hChrFilterSize, c->chrXInc, c->chrSrcW, c->chrDstW, 1, 1 << 14,
                       chr_scaler, flags, c->o.scaler_params,
-                      get_local_pos(c->chrSrcHSub, c->o.src_h_chr_pos), get_local_pos(c->chrDstHSub, c->o.dst_h_chr_pos));
+                      get_local_pos(c->chrSrcHSub, c->o.src_h_chr_pos), get_local_pos(c->chrDstHSub, c->o.dst_h_chr_pos),
+                      c->o.src_vec[2], c->o.src_vec_len[2], c->o.dst_vec_len[2]);
     if (ret < 0) return -1;
     ret = init_filter(&c->vLumFilter, &c->vLumFilterPos, &c->vLumFilterSize, c->lumYInc, srcH, dstH, 1, 1 << 12,
-                      lum_scaler, flags, c->o.scaler_params, get_local_pos(0, 0), get_local_pos(0, 0));
+                      lum_scaler, flags, c->o.scaler_params, get_local_pos(0, 0), get_local_pos(0, 0),
+                      c->o.src_vec[1], c->o.src_vec_len[1], c->o.dst_vec_len[1]);
     if (ret < 0) return -1; /* RET_CASCADE: extreme-ratio cascade not restated */
     ret = init_filter(&c->vChrFilter, &c->vChrFilterPos, &c->vChrFilterSize, c->chrYInc, c->chrSrcH, c->chrDstH, 1, 1 << 12,
                       chr_scaler, flags, c->o.scaler_params,
-                      get_local_pos(c->chrSrcVSub, c->o.src_v_chr_pos), get_local_pos(c->chrDstVSub, c->o.dst_v_chr_pos));
+                      get_local_pos(c->chrSrcVSub, c->o.src_v_chr_pos), get_local_pos(c->chrDstVSub, c->o.dst_v_chr_pos),
+                      c->o.src_vec[3], c->o.src_vec_len[3], c->o.dst_vec_len[3]);
     if (ret < 0) return -1;
 
     init_range_convert(c); /* ff_sws_init_scale -> sws_init_swscale, swscale.c:662-695 */

@@ -73,6 +73,11 @@ typedef struct OrSwsOpts {
     int dither;            /* SwsDither: 0 none, 1 auto, 2 bayer, 3 ed ... */
     int src_range, dst_range;
     int src_v_chr_pos, src_h_chr_pos, dst_v_chr_pos, dst_h_chr_pos; /* -513 = default */
+    /* SwsFilter arguments of sws_init_context (order lumH, lumV, chrH, chrV): source vectors are convolved into the
+     * taps, destination vectors only widen the rows (utils.c:385-415); NULL / 0 = none */
+    const double *src_vec[4];
+    int src_vec_len[4];
+    int dst_vec_len[4];
 } OrSwsOpts;
 
 void   or_sws_default_opts(OrSwsOpts *o);

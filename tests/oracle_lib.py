@@ -144,7 +144,8 @@ class OrSwsOpts(C.Structure):
                 ("flags", C.c_uint), ("scaler_params", C.c_double * 2), ("dither", C.c_int),
                 ("src_range", C.c_int), ("dst_range", C.c_int),
                 ("src_v_chr_pos", C.c_int), ("src_h_chr_pos", C.c_int),
-                ("dst_v_chr_pos", C.c_int), ("dst_h_chr_pos", C.c_int)]
+                ("dst_v_chr_pos", C.c_int), ("dst_h_chr_pos", C.c_int),
+                ("src_vec", C.POINTER(C.c_double) * 4), ("src_vec_len", C.c_int * 4), ("dst_vec_len", C.c_int * 4)]
 
 
 _lib = None
@@ -203,8 +204,20 @@ class Oracle:
             o.flags = flags
             if param:
                 o.scaler_params[0], o.scaler_params[1] = param
+            self._vecs = []
             for k, v in opts.items():
-                setattr(o, k, v)
+                if k == "src_filter":      # {"lumH": [...], "lumV": [...], "chrH": [...], "chrV": [...]}
+                    for idx, name in enumerate(("lumH", "lumV", "chrH", "chrV")):
+                        if v.get(name) is not None:
+                            arr = (C.c_double * len(v[name]))(*v[name])
+                            self._vecs.append(arr)
+                            o.src_vec[idx] = C.cast(arr, C.POINTER(C.c_double))
+                            o.src_vec_len[idx] = len(v[name])
+                elif k == "dst_filter_len":
+                    for idx, name in enumerate(("lumH", "lumV", "chrH", "chrV")):
+                        o.dst_vec_len[idx] = int(v.get(name, 0))
+                else:
+                    setattr(o, k, v)
             self.c = L.or_sws_create(C.byref(o))
         else:
             p = (C.c_double * 2)(*param) if param else None
