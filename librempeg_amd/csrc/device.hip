@@ -27,6 +27,7 @@ struct DeviceState {
     bool all_x_mode = false;   // every output row uses the general yuv2rgb_X writer (vscale.c:135-169)
     int chr_window2 = 0;       // max chroma source rows spanned by a pair of output rows (wave kernel register budget)
     bool tile_ok = false; SwsTileGeom tileL, tileC; void *d_tilegeom = nullptr; size_t tilegeom_bytes = 0;
+    bool rgb_march_ok = false; void *d_rgbplan = nullptr; size_t rgbplan_bytes = 0; int rgb_groups = 0;   // sws_k_rgb_fused_unity_march
     bool dot2_ok = false; SwsTileGeom dotL, dotC; void *d_dot2 = nullptr; size_t dot2_bytes = 0;
     bool march_ok = false; SwsMarchGeom marL, marC; void *d_march = nullptr; size_t march_bytes = 0;
     void *scratch = nullptr; size_t scratch_bytes = 0;
@@ -74,6 +75,7 @@ void dev_release(SwsInternal *c)
     if (d->casc_img) (void)hipFree(d->casc_img);
     if (d->slice_img) (void)hipFree(d->slice_img);
     if (d->d_tilegeom) (void)hipFree(d->d_tilegeom);
+    if (d->d_rgbplan) (void)hipFree(d->d_rgbplan);
     if (d->d_dot2) (void)hipFree(d->d_dot2);
     if (d->d_march) (void)hipFree(d->d_march);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
@@ -459,6 +461,52 @@ int dev_prepare(SwsInternal *c)
                 win = std::max(win, hi - lo + 1);
             }
             d->chr_window2 = win;
+            // plan of the marching packed-RGB kernel: identity vertical luma filter, chroma window of a row pair <= 8 rows,
+            // ring advance of at most 1 row per step
+            d->rgb_march_ok = false;
+            bool lum_unity = lfs == 1;
+            for (int y = 0; y < o.dst_h && lum_unity; y++) lum_unity = c->vLum.taps[y] == 4096;
+            if (all_x && lum_unity && win <= 8 && cfs <= 8) {
+                const int groups = (o.dst_h + 1) / 2;
+                std::vector<SwsRgbGroupPlan> plan((size_t)groups);
+                bool ok = true;
+                int prev = INT32_MIN;
+                for (int g = 0; g < groups && ok; g++) {
+                    SwsRgbGroupPlan &e = plan[(size_t)g];
+                    std::memset(&e, 0, sizeof(e));
+                    int first[2], yy[2];
+                    for (int r = 0; r < 2; r++) {
+                        yy[r] = std::min(2 * g + r, o.dst_h - 1);
+                        first[r] = std::max(1 - cfs, c->vChr.pos[yy[r] >> c->chrDstVSubSample]);
+                    }
+                    e.cbase = std::min(first[0], first[1]);
+                    if (prev != INT32_MIN && (e.cbase < prev || e.cbase - prev > 1)) ok = false;
+                    prev = e.cbase;
+                    e.ylum0 = std::min(std::max(c->vLum.pos[yy[0]], 0), o.src_h - 1);
+                    e.ylum1 = std::min(std::max(c->vLum.pos[yy[1]], 0), o.src_h - 1);
+                    for (int r = 0; r < 2; r++) {
+                        const int16_t *cf = &c->vChr.taps[(size_t)(yy[r] >> c->chrDstVSubSample) * cfs];
+                        if (first[r] + cfs - 1 - e.cbase >= 8) ok = false;
+                        for (int ip = 0; ip < 4; ip++) {
+                            const int j0 = e.cbase + 2 * ip - first[r], j1 = j0 + 1;
+                            const uint32_t lo = (j0 >= 0 && j0 < cfs) ? (uint16_t)cf[j0] : 0u, hi = (j1 >= 0 && j1 < cfs) ? (uint16_t)cf[j1] : 0u;
+                            e.wp[r][ip] = lo | (hi << 16);
+                        }
+                    }
+                }
+                if (ok) {
+                    const size_t bytes = plan.size() * sizeof(SwsRgbGroupPlan);
+                    if (bytes > d->rgbplan_bytes) {
+                        if (d->d_rgbplan) HIPCHK(hipFree(d->d_rgbplan));
+                        d->d_rgbplan = nullptr;
+                        HIPCHK(hipMalloc(&d->d_rgbplan, bytes));
+                        d->rgbplan_bytes = bytes;
+                    }
+                    HIPCHK(hipMemcpy(d->d_rgbplan, plan.data(), bytes, hipMemcpyHostToDevice));
+                    d->rgb_groups = groups;
+                    d->rgb_march_ok = true;
+                }
+            }
         }
     }
 
@@ -490,7 +538,8 @@ int dev_prepare(SwsInternal *c)
     case PLAN_MAIN: {
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
         if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
-            c->path_name = "main:fused_rgb_unity"; c->kernel_name = "sws_k_rgb_fused_unity_wave";
+            c->path_name = "main:fused_rgb_unity";
+            c->kernel_name = d->rgb_march_ok ? "sws_k_rgb_fused_unity_march" : (d->all_x_mode && d->chr_window2 <= 8 ? "sws_k_rgb_fused_unity_wave2" : "sws_k_rgb_fused_unity");
         } else if (d->unity_h && d->unity_v && !p.no_chroma && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 &&
                    (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16)) {
             c->path_name = "main:fused_f32rgb_yuv444"; c->kernel_name = "sws_k_f32rgb_to_yuv444_unity";
@@ -570,6 +619,17 @@ static bool frames_vec_ok(const SwsFramePtrs *fr, int n)
         for (int k = 0; k < 4; k++) {
             if (fr[i].src[k] && (((uintptr_t)fr[i].src[k] | (uintptr_t)(uint32_t)fr[i].srcStride[k]) & 15)) return false;
             if (fr[i].dst[k] && (((uintptr_t)fr[i].dst[k] | (uintptr_t)(uint32_t)fr[i].dstStride[k]) & 15)) return false;
+        }
+    return true;
+}
+
+// buffer-descriptor kernels address a plane as base + 32-bit offset: strides must be positive and planes below 2 GiB
+static bool frames_desc_ok(const SwsFramePtrs *fr, int n, int srcH, int dstH)
+{
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 4; k++) {
+            if (fr[i].src[k] && (fr[i].srcStride[k] <= 0 || (int64_t)fr[i].srcStride[k] * srcH >= (int64_t)1 << 31)) return false;
+            if (fr[i].dst[k] && (fr[i].dstStride[k] <= 0 || (int64_t)fr[i].dstStride[k] * dstH >= (int64_t)1 << 31)) return false;
         }
     return true;
 }
@@ -859,7 +919,42 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
                 const int segs = (p.dstW + 1023) >> 10, rgroups = (p.dstH + ROWS - 1) / ROWS;
                 const dim3 gridw((cdiv((int64_t)segs * rgroups, 4) + 7) & ~7u, 1, n); // multiple of 8: XCD-aware order
                 const bool swap = b4 ? p.lut.swap_rb32 != 0 : p.lut.rgb_order != 0;
-#define LAUNCH_WAVE(B, S, N) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave<B, S, N, ROWS, 8>), gridw, blk, 0, st, fs, p)
+                static const bool v1 = std::getenv("SWS_HIP_FUSED_V1") != nullptr;   // previous generations, kept for A/B measurements
+                static const bool v2 = std::getenv("SWS_HIP_FUSED_V2") != nullptr;
+                const bool afirst = b4 && p.lut.perm32 == 0x02010003u;
+                const bool ncr6 = d->chr_window2 <= 6;      // rows of chroma a pair of output rows spans: 3 or 4 row pairs
+                if (d->rgb_march_ok && !v1 && !v2 && frames_desc_ok(frames, n, p.srcH, p.dstH)) {
+                    // one resident round: 4 waves per SIMD on 1024 SIMDs; bands of at least 8 row pairs
+                    static const int target = std::getenv("SWS_HIP_RGB_MARCH_WAVES") ? std::atoi(std::getenv("SWS_HIP_RGB_MARCH_WAVES")) : 12288;
+                    const int groups = d->rgb_groups;
+                    int bands = std::max(1, std::min(target / std::max(1, segs * n), (groups + 7) / 8));
+                    int band_groups = (groups + bands - 1) / bands;
+                    bands = (groups + band_groups - 1) / band_groups;
+                    const dim3 gm(cdiv((int64_t)segs * bands, 4), 1, n);
+                    const SwsRgbGroupPlan *plan = (const SwsRgbGroupPlan *)d->d_rgbplan;
+                    static const int mexp = std::getenv("SWS_HIP_RGB_MARCH_EXP") ? std::atoi(std::getenv("SWS_HIP_RGB_MARCH_EXP")) : 0;
+                    if (mexp && !b4 && !nv && !swap && ncr6) {     // profiling experiments on the C2b instantiation only (results are wrong)
+                        if (mexp == 1) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_march<3, false, false, false, 6, 1>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups);
+                        if (mexp == 2) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_march<3, false, false, false, 6, 2>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups);
+                        if (mexp == 3) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_march<3, false, false, false, 6, 3>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups);
+                        break;
+                    }
+#define LAUNCH_MARCH(B, S, N, A) do { if (ncr6) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_march<B, S, N, A, 6>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups); \
+                                      else hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_march<B, S, N, A, 8>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups); } while (0)
+                    if (b4) { if (afirst) { if (nv) { if (swap) LAUNCH_MARCH(4, true, true, true); else LAUNCH_MARCH(4, false, true, true); }
+                                            else    { if (swap) LAUNCH_MARCH(4, true, false, true); else LAUNCH_MARCH(4, false, false, true); } }
+                              else        { if (nv) { if (swap) LAUNCH_MARCH(4, true, true, false); else LAUNCH_MARCH(4, false, true, false); }
+                                            else    { if (swap) LAUNCH_MARCH(4, true, false, false); else LAUNCH_MARCH(4, false, false, false); } } }
+                    else    { if (nv) { if (swap) LAUNCH_MARCH(3, true, true, false); else LAUNCH_MARCH(3, false, true, false); }
+                              else    { if (swap) LAUNCH_MARCH(3, true, false, false); else LAUNCH_MARCH(3, false, false, false); } }
+#undef LAUNCH_MARCH
+                    break;
+                }
+#define LAUNCH_WAVE(B, S, N) do { if (v1) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave<B, S, N, ROWS, 8>), gridw, blk, 0, st, fs, p); \
+                                  else if (B == 4 && afirst) { if (ncr6) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave2<B, S, N, B == 4, ROWS, 6>), gridw, blk, 0, st, fs, p); \
+                                                              else hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave2<B, S, N, B == 4, ROWS, 8>), gridw, blk, 0, st, fs, p); } \
+                                  else { if (ncr6) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave2<B, S, N, false, ROWS, 6>), gridw, blk, 0, st, fs, p); \
+                                         else hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave2<B, S, N, false, ROWS, 8>), gridw, blk, 0, st, fs, p); } } while (0)
                 if (b4) { if (nv) { if (swap) LAUNCH_WAVE(4, true, true); else LAUNCH_WAVE(4, false, true); }
                           else    { if (swap) LAUNCH_WAVE(4, true, false); else LAUNCH_WAVE(4, false, false); } }
                 else    { if (nv) { if (swap) LAUNCH_WAVE(3, true, true); else LAUNCH_WAVE(3, false, true); }

@@ -84,6 +84,14 @@ struct SwsMarchGeom {       // wave-marching fused kernel (kernels_march.hpp), p
     int32_t lds_bytes;
 };
 
+struct SwsRgbGroupPlan {    // marching packed-RGB kernel: everything one pair of output rows needs, as scalars (64 bytes)
+    int32_t cbase;            // first chroma source row of the register ring for this group (may be negative: loads clamp)
+    int32_t ylum0, ylum1;     // luma source rows of the two output rows (identity vertical luma filter)
+    int32_t pad0;
+    uint32_t wp[2][4];        // per output row: vertical chroma taps of ring rows (2i, 2i+1) packed (lo & 0xffff) | hi << 16
+    int32_t pad1[4];
+};
+
 struct SwsDevParams {
     int32_t srcW, srcH, dstW, dstH;
     int32_t chrSrcW, chrSrcH, chrDstW, chrDstH;

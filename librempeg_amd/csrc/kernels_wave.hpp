@@ -329,6 +329,414 @@ __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_wave(SwsFrameSet fs
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Second generation of the kernel above (same decomposition, same results, about half the vector instructions):
+//  * vertical filters run on v_dot2_i32_i16: two vertically adjacent source rows are byte-interleaved into (lo | hi << 16)
+//    pairs with one v_perm_b32 per sample and multiplied by a scalar tap pair.  The sums are formed on the raw bytes:
+//    ((1 << 18) + sum((u << 7) * w)) >> 19 == (2048 + sum(u * w)) >> 12 exactly (both sides floor the same multiple of 128).
+//  * the accumulated chroma is shifted, clamped to u8 and packed by v_ashr_pk_u8_i32 (the index tables of yuv2rgb.c have
+//    head-room entries equal to the clamped ones, so clamping is what the table does);
+//  * per pixel pair the chroma side of the LUT is folded into three addends A_c = (base_c + idx_c(u, v)) * cy + yb0r, so that a
+//    pixel costs one multiply-add per channel: t_c = Y * cy + A_c, out_c = clip_u8(t_c >> 16);
+//  * 32 bpp: the alpha byte position is a template parameter (operand order of the pack) instead of a v_perm per pixel;
+//  * segments that lie completely inside the row take a store path without per-lane bounds checks.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack4_u8_shr12(int t0, int t1, int t2, int t3)
+{
+    uint32_t d;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 12\n\tv_ashr_pk_u8_i32 %0, %3, %4, 12 op_sel:[0,0,0,1]"
+        : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3));
+    return d;
+}
+__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
+{
+    typedef short s16x2w __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2w, a), __builtin_bit_cast(s16x2w, b), c, false);
+}
+// 16 bytes of row A and row B -> 16 dwords (A_k | B_k << 16)
+__device__ __forceinline__ void interleave_rows(const u32x4 &A, const u32x4 &B, uint32_t (&P)[16])
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        P[4 * q + 0] = __builtin_amdgcn_perm(B[q], A[q], 0x0c040c00u);
+        P[4 * q + 1] = __builtin_amdgcn_perm(B[q], A[q], 0x0c050c01u);
+        P[4 * q + 2] = __builtin_amdgcn_perm(B[q], A[q], 0x0c060c02u);
+        P[4 * q + 3] = __builtin_amdgcn_perm(B[q], A[q], 0x0c070c03u);
+    }
+}
+
+template <int BPP, bool FULL, bool NT = true>
+__device__ __forceinline__ void wave_store16_v2(uint8_t *seg, int seg_bytes, const uint32_t (&w)[4 * BPP], uint32_t *lds, int lane)
+{
+    constexpr int NDW = 4 * BPP, LS = BPP == 4 ? 20 : 12, NCH = NDW / 4;
+    u32x4 *lw = (u32x4 *)(lds + lane * LS);
+#pragma unroll
+    for (int k = 0; k < NCH; k++) { u32x4 t = { w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] }; lw[k] = t; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+        const int c = j * 64 + lane;
+        const int off = 16 * c;
+        const u32x4 v = *(const u32x4 *)(lds + (c / NCH) * LS + (c % NCH) * 4);
+        if constexpr (FULL) gstore16_nt(seg + off, v);
+        else {
+            if (off + 16 <= seg_bytes) gstore16_nt(seg + off, v);
+            else if (off < seg_bytes) gstore_partial(seg + off, v, seg_bytes - off);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// uvp[m >> 1] holds the clamped bytes {U_m, V_m, U_m+1, V_m+1}; Y[16] raw luma values -> packed pixels
+template <int BPP, bool SWAP_RB, bool AFIRST>
+__device__ __forceinline__ void lut16_v2(const SwsLutParams &L, const int (&Y)[16], const uint32_t (&uvp)[4], uint32_t (&w)[4 * BPP])
+{
+    int A0[8], A1[8], A2[8];   // addends of the first, green and third channel per pixel pair
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const uint32_t d = uvp[m >> 1];
+        const int cu = (int)((d >> (16 * (m & 1))) & 0xFF), cv = (int)((d >> (16 * (m & 1) + 8)) & 0xFF);
+        const int ir = L.base_r + (__mul24(cv, L.crv) >> 16);
+        const int ig = L.base_g + (__mul24(cu, L.cgu) >> 16) + (__mul24(cv, L.cgv) >> 16);
+        const int ib = L.base_b + (__mul24(cu, L.cbu) >> 16);
+        const int ar = mad24(ir, L.cy, L.yb0r), ab = mad24(ib, L.cy, L.yb0r);
+        A0[m] = SWAP_RB ? ab : ar; A1[m] = mad24(ig, L.cy, L.yb0r); A2[m] = SWAP_RB ? ar : ab;
+    }
+    if constexpr (BPP == 4) {
+        const int ta = 255 << 16;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int m = k >> 1, y = Y[k];
+            const int t0 = mad24(y, L.cy, A0[m]), t1 = mad24(y, L.cy, A1[m]), t2 = mad24(y, L.cy, A2[m]);
+            w[k] = AFIRST ? pack4_u8_shr16(ta, t0, t1, t2) : pack4_u8_shr16(t0, t1, t2, ta);
+        }
+    } else {
+        int t[48];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int m = k >> 1, y = Y[k];
+            t[3 * k + 0] = mad24(y, L.cy, A0[m]); t[3 * k + 1] = mad24(y, L.cy, A1[m]); t[3 * k + 2] = mad24(y, L.cy, A2[m]);
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) w[k] = pack4_u8_shr16(t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
+    }
+}
+
+template <int BPP, bool SWAP_RB, bool NV, bool AFIRST, int ROWS, int NCR, bool FULL>
+__device__ __forceinline__ void rgb_fused_unity_v2_body(const FrameRegs &f, const SwsDevParams &p, int rg, int seg, uint32_t *lds, int lane)
+{
+    const SwsLutParams &L = p.lut;
+    const int npix = p.dstW;
+    const int x = seg * 1024 + lane * 16;
+    const int seg_bytes = min(1024, npix - seg * 1024) * BPP;
+    const int nvalid = FULL ? 16 : npix - x;
+    const int lfs = p.vLumFs, cfs = p.vChrFs;
+    const int lH = p.srcH - 1, cH = p.chrSrcH - 1;
+    const int yb = rg * ROWS;
+    const int nrows = min(ROWS, p.dstH - yb);
+
+    // per output row: chroma window start (scalar); taps one per lane, lane l holds tap l - NCR (v_readlane broadcasts them)
+    int firstC[ROWS], wv[ROWS];
+    int cmin = 0x7fffffff, cmax = -1;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const int y = min(yb + r, p.dstH - 1);
+        const int cy = y >> p.chrDstVSub;
+        firstC[r] = max(1 - cfs, p.vChrPos[cy]);
+        const int tl = lane - NCR;
+        wv[r] = (tl >= 0 && tl < cfs) ? (int)p.vChrF[cy * cfs + tl] : 0;
+        cmin = min(cmin, firstC[r]); cmax = max(cmax, firstC[r] + cfs - 1);
+    }
+    const bool u1 = p.u_plane_src == 1;
+    const uint8_t *ub = u1 ? f.src[1] : f.src[2], *vb = u1 ? f.src[2] : f.src[1];
+    const int us = u1 ? f.srcStride[1] : f.srcStride[2], vs = u1 ? f.srcStride[2] : f.srcStride[1];
+    u32x4 craw[NCR];
+#pragma unroll
+    for (int i = 0; i < NCR; i++) {
+        const int cr = cmin + i;
+        // straight-line code on purpose (wave-uniform branches around the accumulation made the compiler copy the 32 accumulators
+        // per path): rows beyond the window are re-reads of its last row and meet zero taps; the host picks the smallest NCR
+        const int srow = min(max(min(cr, cmax), 0), cH);
+        if constexpr (NV) craw[i] = load16_or_tail(f.src[1] + (int64_t)srow * f.srcStride[1] + x, nvalid);
+        else {
+            const u32x2 a = load8_or_tail(ub + (int64_t)srow * us + (x >> 1), nvalid >> 1);
+            const u32x2 b = load8_or_tail(vb + (int64_t)srow * vs + (x >> 1), nvalid >> 1);
+            u32x4 t = { a[0], a[1], b[0], b[1] };
+            craw[i] = t;
+        }
+    }
+    // luma rows of the identity case are independent of the chroma work: issue them now
+    const bool lum_unity = lfs == 1 && p.vLumF[yb * lfs] == 4096 && p.vLumF[min(yb + ROWS - 1, p.dstH - 1) * lfs] == 4096;
+    u32x4 yraw[ROWS];
+    if (lum_unity) {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const int y = min(yb + r, p.dstH - 1);
+            yraw[r] = load16_or_tail(f.src[0] + (int64_t)min(max(p.vLumPos[y], 0), lH) * f.srcStride[0] + x, nvalid);
+        }
+    }
+    int acc[ROWS][16];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[r][k] = 2048;
+#pragma unroll
+    for (int ip = 0; ip < NCR / 2; ip++) {
+        const int cr = cmin + 2 * ip;
+        uint32_t P[16];
+        interleave_rows(craw[2 * ip], craw[2 * ip + 1], P);
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const int j0 = cr - firstC[r] + NCR;                                   // in [1, 2 * NCR)
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane(wv[r], j0) & 0xFFFFu;
+            const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane(wv[r], j0 + 1);
+            const uint32_t wp = w0 | (w1 << 16);
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc[r][k] = sdot2(P[k], wp, acc[r][k]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        if (r >= nrows) break;
+        const int y = yb + r;
+        int Y[16];
+        if (lum_unity) unpack16(yraw[r], Y);
+        else {
+            const int16_t *lf = p.vLumF + y * lfs;
+            const int firstL = max(1 - lfs, p.vLumPos[y]);
+#pragma unroll
+            for (int k = 0; k < 16; k++) Y[k] = 2048;
+            for (int j = 0; j < lfs; j += 2) {
+                const int r0 = min(max(firstL + j, 0), lH), r1 = min(max(firstL + j + 1, 0), lH);
+                const u32x4 a = load16_or_tail(f.src[0] + (int64_t)r0 * f.srcStride[0] + x, nvalid);
+                const u32x4 b = load16_or_tail(f.src[0] + (int64_t)r1 * f.srcStride[0] + x, nvalid);
+                const uint32_t wp = ((uint32_t)(int)lf[j] & 0xFFFFu) | (j + 1 < lfs ? (uint32_t)(int)lf[j + 1] << 16 : 0u);
+                uint32_t P[16];
+                interleave_rows(a, b, P);
+#pragma unroll
+                for (int k = 0; k < 16; k++) Y[k] = sdot2(P[k], wp, Y[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) Y[k] >>= 12;
+        }
+        // chroma: shift, clamp, pack {U_m, V_m, U_m+1, V_m+1}
+        uint32_t uvp[4];
+        if constexpr (NV) {
+            if (p.uv_swap_src) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) uvp[q] = pack4_u8_shr12(acc[r][4 * q + 1], acc[r][4 * q], acc[r][4 * q + 3], acc[r][4 * q + 2]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) uvp[q] = pack4_u8_shr12(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) uvp[q] = pack4_u8_shr12(acc[r][2 * q], acc[r][8 + 2 * q], acc[r][2 * q + 1], acc[r][8 + 2 * q + 1]);
+        }
+        uint32_t w[4 * BPP];
+        lut16_v2<BPP, SWAP_RB, AFIRST>(L, Y, uvp, w);
+        uint8_t *segp = f.dst[0] + (int64_t)y * f.dstStride[0] + (int64_t)seg * 1024 * BPP;
+        wave_store16_v2<BPP, FULL>(segp, seg_bytes, w, lds, lane);
+    }
+}
+
+template <int BPP, bool SWAP_RB, bool NV, bool AFIRST, int ROWS, int NCR>
+__global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_wave2(SwsFrameSet fs, SwsDevParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4 * 64 * (BPP == 4 ? 20 : 12)];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *lds = lds_all + wib * 64 * (BPP == 4 ? 20 : 12);
+    const int segs = (p.dstW + 1023) >> 10;
+    const int rgroups = (p.dstH + ROWS - 1) / ROWS;
+    const int per_xcd = gridDim.x >> 3;                          // XCD-aware block order, see sws_k_rgb_fused_unity_wave
+    const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t wid = (int64_t)lb * 4 + wib;
+    if (wid >= (int64_t)segs * rgroups) return;
+    const int rg = (int)(wid / segs), seg = (int)(wid % segs);
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    if (seg * 1024 + 1024 <= p.dstW) rgb_fused_unity_v2_body<BPP, SWAP_RB, NV, AFIRST, ROWS, NCR, true>(f, p, rg, seg, lds, lane);
+    else rgb_fused_unity_v2_body<BPP, SWAP_RB, NV, AFIRST, ROWS, NCR, false>(f, p, rg, seg, lds, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Marching form of the kernel above for the identity-vertical-luma case (C2b, C4: same-size conversions whose chroma is
+// up-sampled vertically).  A wave owns a 1024-pixel column strip and walks down a band of output-row pairs:
+//  * the chroma source rows live in a ring of NCR register rows; a step loads only the rows that enter the window (one per
+//    step at 2x chroma up-sampling) instead of the whole window (3x fewer load instructions);
+//  * the loads of step g+1 (new chroma rows, two luma rows) and the plan entry of step g+2 are issued before step g is
+//    computed, so memory latency overlaps the arithmetic instead of adding to it (the one-shot kernel spent over half of a
+//    wave's life waiting: VALU 50 % busy at 40 % of the HBM roofline);
+//  * everything a step needs from the filter banks is a 64-byte host-built plan entry fetched with scalar loads.
+// ------------------------------------------------------------------------------------------
+//  * memory goes through buffer descriptors: the per-lane offset is a constant VGPR, the row offset an SGPR (no 64-bit vector
+//    address arithmetic), reads past the end of a row stay inside the plane's descriptor (out-of-range dwords read 0 and feed
+//    pixels that are never stored), stores past the end of a row are dropped by the per-row destination descriptor.
+typedef __amdgpu_buffer_rsrc_t sws_rsrc_t;
+__device__ __forceinline__ sws_rsrc_t make_rsrc(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 bload16(sws_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ u32x2 bload8(sws_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+
+template <int BPP, bool SWAP_RB, bool NV, bool AFIRST, int NCR, int EXP = 0>
+__global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_march(SwsFrameSet fs, SwsDevParams p, const SwsRgbGroupPlan *__restrict__ plan,
+                                                                   int ngroups, int bands, int band_groups)
+{
+    constexpr int LS = BPP == 4 ? 20 : 12, NDW = 4 * BPP, NCH = NDW / 4;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4 * 2 * 64 * LS];   // per wave: one region per output row of a step
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *lds = lds_all + wib * 2 * 64 * LS;
+    const int segs = (p.dstW + 1023) >> 10;
+    const int wid = blockIdx.x * 4 + wib;                        // the 4 waves of a block: adjacent segments of one band
+    if (wid >= segs * bands) return;
+    const int band = wid / segs, seg = wid % segs;
+    const int g0 = band * band_groups, g1 = min(ngroups, g0 + band_groups);
+    if (g0 >= g1) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const SwsLutParams &L = p.lut;
+    const int x = seg * 1024 + lane * 16;
+    const int seg_bytes = min(1024, p.dstW - seg * 1024) * BPP;
+    const int cH = p.chrSrcH - 1;
+    const bool u1 = p.u_plane_src == 1;
+    // descriptors: whole planes for the sources (strides are positive and planes < 2 GiB: checked on the host)
+    const sws_rsrc_t ry = make_rsrc(f.src[0], (uint32_t)f.srcStride[0] * (uint32_t)(p.srcH - 1) + (uint32_t)p.srcW);
+    const int cbytes = NV ? 2 * p.chrSrcW : p.chrSrcW;
+    const sws_rsrc_t ru = make_rsrc(NV ? f.src[1] : (u1 ? f.src[1] : f.src[2]),
+                                    (uint32_t)(NV ? f.srcStride[1] : (u1 ? f.srcStride[1] : f.srcStride[2])) * (uint32_t)cH + (uint32_t)cbytes);
+    const sws_rsrc_t rv = make_rsrc(NV ? f.src[1] : (u1 ? f.src[2] : f.src[1]),
+                                    (uint32_t)(NV ? f.srcStride[1] : (u1 ? f.srcStride[2] : f.srcStride[1])) * (uint32_t)cH + (uint32_t)cbytes);
+    const int us = NV ? f.srcStride[1] : (u1 ? f.srcStride[1] : f.srcStride[2]), vs = NV ? f.srcStride[1] : (u1 ? f.srcStride[2] : f.srcStride[1]);
+    const int ys = f.srcStride[0];
+    const int cvoff = NV ? x : (x >> 1);
+    auto load_crow = [&](int cr) -> u32x4 {
+        const int srow = min(max(cr, 0), cH);
+        if constexpr (NV) return bload16(ru, cvoff, srow * us);
+        else {
+            const u32x2 a = bload8(ru, cvoff, srow * us), b = bload8(rv, cvoff, srow * vs);
+            u32x4 t = { a[0], a[1], b[0], b[1] };
+            return t;
+        }
+    };
+    auto load_yrow = [&](int row) -> u32x4 { return bload16(ry, x, row * ys); };
+
+    SwsRgbGroupPlan e = plan[g0], en = plan[min(g0 + 1, g1 - 1)];
+    u32x4 craw[NCR];
+#pragma unroll
+    for (int i = 0; i < NCR; i++) craw[i] = load_crow(e.cbase + i);
+    u32x4 yr0 = load_yrow(e.ylum0), yr1 = load_yrow(e.ylum1);
+    // finish the initial fill here: otherwise the waits for it inside the loop (counted from the newest request) also drain the
+    // previous step's stores in every later iteration
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+
+    for (int g = g0; g < g1; g++) {
+        const SwsRgbGroupPlan en2 = plan[min(g + 2, g1 - 1)];
+        const int delta = en.cbase - e.cbase;                     // 0 or 1 (checked on the host)
+        // prefetch of the next step (the last step of a band re-reads its own rows: harmless)
+        const u32x4 n0 = load_crow(en.cbase + NCR - 1);
+        const u32x4 ny0 = load_yrow(en.ylum0), ny1 = load_yrow(en.ylum1);
+        int acc[2][16];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc[r][k] = 2048;
+#pragma unroll
+        for (int ip = 0; ip < NCR / 2; ip++) {
+            if constexpr (EXP == 2) {       // experiment: no vertical filter
+#pragma unroll
+                for (int k = 0; k < 16; k++) { acc[0][k] += craw[2 * ip][k & 3]; acc[1][k] += craw[2 * ip + 1][k & 3]; }
+                continue;
+            }
+            uint32_t P[16];
+            interleave_rows(craw[2 * ip], craw[2 * ip + 1], P);
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[r][k] = sdot2(P[k], e.wp[r][ip], acc[r][k]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int y = 2 * g + r;
+            if (y >= p.dstH) break;
+            int Y[16];
+            unpack16(r ? yr1 : yr0, Y);
+            uint32_t uvp[4];
+            if constexpr (NV) {
+                if (p.uv_swap_src) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) uvp[q] = pack4_u8_shr12(acc[r][4 * q + 1], acc[r][4 * q], acc[r][4 * q + 3], acc[r][4 * q + 2]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) uvp[q] = pack4_u8_shr12(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) uvp[q] = pack4_u8_shr12(acc[r][2 * q], acc[r][8 + 2 * q], acc[r][2 * q + 1], acc[r][8 + 2 * q + 1]);
+            }
+            uint32_t w[NDW];
+            if constexpr (EXP == 1) {       // experiment: memory-only floor (no LUT stage)
+#pragma unroll
+                for (int k = 0; k < NDW; k++) w[k] = (uint32_t)Y[k & 15] + uvp[k & 3];
+            } else lut16_v2<BPP, SWAP_RB, AFIRST>(L, Y, uvp, w);
+            // park the packed pixels in the wave's LDS region of this row (lane-major); they are stored after the ring advanced
+            u32x4 *lw = (u32x4 *)(lds + r * 64 * LS + lane * LS);
+#pragma unroll
+            for (int k = 0; k < NCH; k++) { u32x4 t = { w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] }; lw[k] = t; }
+        }
+        // advance the ring BEFORE this step's stores are issued: vmcnt counts loads and stores together and the compiler has to
+        // assume they retire out of order, so a wait for the prefetched rows behind freshly issued stores would drain the stores
+        if (delta == 1) {
+#pragma unroll
+            for (int i = 0; i + 1 < NCR; i++) craw[i] = craw[i + 1];
+            craw[NCR - 1] = n0;
+        }
+        yr0 = ny0; yr1 = ny1;
+        // pin the hand-over here: without it the register copies (and with them the wait for the prefetch) sink below the stores
+        asm volatile("" : "+v"(yr0), "+v"(yr1), "+v"(craw[NCR - 1]) :: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // transposed read-back: every store instruction writes one contiguous KiB; the row's descriptor drops what lies beyond it
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int y = 2 * g + r;
+            if (y >= p.dstH) break;
+            uint8_t *segp = f.dst[0] + (int64_t)y * f.dstStride[0] + (int64_t)seg * 1024 * BPP;
+            const sws_rsrc_t rd = make_rsrc(segp, EXP == 3 ? (p.dstW == 12345 ? 16u : 0u) : (uint32_t)seg_bytes);   // a dword that straddles the end is dropped as a whole
+            const uint32_t *lr = lds + r * 64 * LS;
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+                const int c = j * 64 + lane;
+                const u32x4 v = *(const u32x4 *)(lr + (c / NCH) * LS + (c % NCH) * 4);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rd, 16 * c, 0, 2 /* nt */);
+            }
+            if constexpr (BPP == 3) {
+                if (seg_bytes & 2) {      // 24 bpp rows end on a multiple of 6 bytes: a last half dword
+                    const int b = seg_bytes - 2;
+                    // (a buffer store, not a flat one: flat stores complete out of order and would turn every wait into vmcnt(0))
+                    if (lane == 0) __builtin_amdgcn_raw_buffer_store_b16(*(const uint16_t *)((const uint8_t *)lr + (b / (NDW * 4)) * LS * 4 + b % (NDW * 4)), rd, b, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();              // the next step reuses the LDS region
+        e = en; en = en2;
+    }
+}
+
 } // namespace swsk
 
 namespace swsk {
