@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "kernels_march.hpp"
+#include "kernels_strip.hpp"
 #include "kernels_shuffle.hpp"
 #include "swsint.hpp"
 
@@ -29,6 +30,7 @@ struct DeviceState {
     bool tile_ok = false; SwsTileGeom tileL, tileC; void *d_tilegeom = nullptr; size_t tilegeom_bytes = 0;
     bool rgb_march_ok = false; void *d_rgbplan = nullptr; size_t rgbplan_bytes = 0; int rgb_groups = 0;   // sws_k_rgb_fused_unity_march
     bool dot2_ok = false; SwsTileGeom dotL, dotC; void *d_dot2 = nullptr; size_t dot2_bytes = 0;
+    bool strip_ok = false; SwsStripGeom stripL, stripC;    // sws_k_strip_march (tables live in d_dot2)
     bool march_ok = false; SwsMarchGeom marL, marC; void *d_march = nullptr; size_t march_bytes = 0;
     void *scratch = nullptr; size_t scratch_bytes = 0;
     void *stage_src = nullptr; size_t stage_src_bytes = 0;
@@ -367,6 +369,48 @@ int dev_prepare(SwsInternal *c)
                     }
                     return false;
                 };
+                // marching strip kernel: strips of 64 * cols output columns; window of a strip <= 128 chunks of 16 bytes
+                struct SOff { size_t cs, cc, rows; };
+                auto plan3 = [&](const FilterBank &hb, const FilterBank &vb, int W, int cols, int ncomp, SwsStripGeom &g, SOff &o) -> bool {
+                    const int TW = 64 * cols, hf2 = fs2(hb.size), vf2 = fs2(vb.size);
+                    const int strips = (W + TW - 1) / TW;
+                    std::vector<int32_t> cs(strips), cc(strips);
+                    int ncmax = 0, nph = 1, npv = 1;
+                    for (int t = 0; t < strips; t++) {
+                        int lo = INT32_MAX, hi = -1;
+                        for (int x = t * TW; x < std::min(W, (t + 1) * TW); x++) { lo = std::min(lo, hb.pos[x] & ~1); hi = std::max(hi, (hb.pos[x] & ~1) + hf2); }
+                        if (lo < 0) return false;
+                        lo = lo / SPC * SPC;
+                        cs[t] = lo; cc[t] = (hi - lo + SPC - 1) / SPC * SPC; ncmax = std::max(ncmax, cc[t]);
+                    }
+                    if (ncmax / SPC > (ncomp == 2 ? 64 : 128)) return false;   // one (chroma) or two (luma) 16-byte chunks per lane and row
+                    for (int x = 0; x < hb.count; x++) nph = std::max(nph, ((hb.pos[x] & 1) + hb.size + 1) / 2);
+                    for (int y = 0; y < vb.count; y++) { if (vb.pos[y] < 0) return false; npv = std::max(npv, ((vb.pos[y] & 1) + vb.size + 1) / 2); }
+                    for (int y = 1; y < vb.count; y++) if (vb.pos[y] < vb.pos[y - 1]) return false;   // the ring only moves forward
+                    g.TW = TW; g.strips = strips; g.NCmax = ncmax; g.nph = nph; g.npv = npv; g.hfs2 = hf2; g.vfs2 = vf2;
+                    g.lds_bytes = 4 * ncomp * 2 * ((ncmax + SPC) / 2) * 4;
+                    o.cs = put(cs.data(), cs.size() * 4); o.cc = put(cc.data(), cc.size() * 4);
+                    std::vector<SwsStripRow> rows((size_t)vb.count);
+                    for (int y = 0; y < vb.count; y++) {
+                        SwsStripRow &e = rows[(size_t)y];
+                        std::memset(&e, 0, sizeof(e));
+                        e.pf = (vb.pos[y] & ~1) >> 1;
+                        for (int j = 0; j < vb.size; j++) {
+                            const int k = (vb.pos[y] & 1) + j;
+                            e.vt[k >> 1] |= (uint32_t)(uint16_t)vb.taps[(size_t)y * vb.size + j] << (16 * (k & 1));
+                        }
+                    }
+                    o.rows = put(rows.data(), rows.size() * sizeof(SwsStripRow));
+                    return true;
+                };
+                SOff sL, sC;
+                static const int strip_cols_l = std::getenv("SWS_HIP_STRIP_COLS_L") ? std::atoi(std::getenv("SWS_HIP_STRIP_COLS_L")) : 4;
+                static const int strip_cols_c = std::getenv("SWS_HIP_STRIP_COLS_C") ? std::atoi(std::getenv("SWS_HIP_STRIP_COLS_C")) : 2;
+                // (narrow pictures leave most of a 256-column strip idle and pay the per-band ring fill: the tile kernel keeps them)
+                const int strip_min_w = std::getenv("SWS_HIP_STRIP_MIN_W") ? std::atoi(std::getenv("SWS_HIP_STRIP_MIN_W")) : 1024;
+                const bool strip_plan = !p.range_active && !std::getenv("SWS_HIP_NO_STRIP") && p.dstW >= strip_min_w &&
+                                        plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sL) && plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sC);
+                d->strip_ok = false;
                 Off oL, oC;
                 if (plan2(c->hLum, c->vLum, p.dstW, p.dstH, 1, d->dotL, oL) && plan2(c->hChr, c->vChr, p.chrDstW, p.chrDstH, 2, d->dotC, oC)) {
                     if (blob.size() > d->dot2_bytes) {
@@ -384,6 +428,14 @@ int dev_prepare(SwsInternal *c)
                     };
                     bind(d->dotL, oL); bind(d->dotC, oC);
                     d->dot2_ok = true;
+                    if (strip_plan) {
+                        const uint8_t *b = (const uint8_t *)d->d_dot2;
+                        d->stripL.colStart = (const int32_t *)(b + sL.cs); d->stripL.colCount = (const int32_t *)(b + sL.cc);
+                        d->stripC.colStart = (const int32_t *)(b + sC.cs); d->stripC.colCount = (const int32_t *)(b + sC.cc);
+                        d->stripL.hT2 = d->dotL.hT2; d->stripL.vT2 = d->dotL.vT2; d->stripC.hT2 = d->dotC.hT2; d->stripC.vT2 = d->dotC.vT2;
+                        d->stripL.rows = (const SwsStripRow *)(b + sL.rows); d->stripC.rows = (const SwsStripRow *)(b + sC.rows);
+                        d->strip_ok = true;
+                    }
                 }
             }
         }
@@ -548,6 +600,8 @@ int dev_prepare(SwsInternal *c)
             c->kernel_name = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) ? "sws_k_vscale_rgb" : "sws_k_vscale_planar";
         } else if (d->march_ok) {
             c->path_name = "main:fused_march"; c->kernel_name = "sws_k_march_dot2";
+        } else if (d->strip_ok) {
+            c->path_name = "main:strip_march"; c->kernel_name = "sws_k_strip_march";
         } else if (d->dot2_ok) {
             c->path_name = "main:fused_tile_dot2"; c->kernel_name = "sws_k_tile_dot2";
         } else if (d->tile_ok) {
@@ -982,7 +1036,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
             const bool semi = p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010 || p.dstKind == DSTK_P016;
             auto launch = [&](SwsMarchGeom g, int H, int ncomp, int ydim) {
                 const int64_t per_band_row = (int64_t)g.strips * n * ydim;
-                static const int target = std::getenv("SWS_HIP_MARCH_WAVES") ? std::atoi(std::getenv("SWS_HIP_MARCH_WAVES")) : 8192;
+                static const int target = std::getenv("SWS_HIP_MARCH_WAVES") ? std::atoi(std::getenv("SWS_HIP_MARCH_WAVES")) : 4096;
                 int band = (int)std::min<int64_t>(128, std::max<int64_t>(8, (int64_t)H * per_band_row / target));
                 band &= ~7;
                 g.BAND = band; g.bands = (H + band - 1) / band;
@@ -997,6 +1051,27 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
             };
             launch(d->marL, p.dstH, 1, 1);
             if (semi) launch(d->marC, p.chrDstH, 2, 1); else launch(d->marC, p.chrDstH, 1, 2);
+            break;
+        }
+        if (d->strip_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) { // marching strip kernel: one launch for luma, one for chroma
+            static const int target = std::getenv("SWS_HIP_STRIP_WAVES") ? std::atoi(std::getenv("SWS_HIP_STRIP_WAVES")) : 4096;
+            const bool s16 = p.srcKind == SRCK_PLANAR16;
+            auto launch = [&](SwsStripGeom g, int H, bool chroma) {
+                int bands = std::max(1, std::min(target / std::max(1, g.strips * n), (H + 15) / 16));
+                g.debug = std::getenv("SWS_HIP_STRIP_DEBUG") ? std::atoi(std::getenv("SWS_HIP_STRIP_DEBUG")) : 0;
+                g.band_rows = (H + bands - 1) / bands;
+                g.bands = (H + g.band_rows - 1) / g.band_rows;
+                const dim3 grid(cdiv((int64_t)g.strips * g.bands, 4), 1, n);
+#define SWS_STRIP(S, C, K) hipLaunchKernelGGL((swsk::sws_k_strip_march<S, C, K>), grid, blk, g.lds_bytes, st, fs, p, g)
+                const int cols = g.TW / 64;
+                if (chroma) { if (s16) { if (cols == 1) SWS_STRIP(true, true, 1); else SWS_STRIP(true, true, 2); }
+                              else     { if (cols == 1) SWS_STRIP(false, true, 1); else SWS_STRIP(false, true, 2); } }
+                else        { if (s16) { if (cols == 2) SWS_STRIP(true, false, 2); else SWS_STRIP(true, false, 4); }
+                              else     { if (cols == 2) SWS_STRIP(false, false, 2); else SWS_STRIP(false, false, 4); } }
+#undef SWS_STRIP
+            };
+            launch(d->stripL, p.dstH, false);
+            launch(d->stripC, p.chrDstH, true);
             break;
         }
         if (d->dot2_ok && vec) { // dot2 LDS-tile kernel: one launch for luma, one for chroma

@@ -84,6 +84,25 @@ struct SwsMarchGeom {       // wave-marching fused kernel (kernels_march.hpp), p
     int32_t lds_bytes;
 };
 
+struct SwsStripRow {         // marching strip kernel: the scalars of one output row (64 bytes, fetched with one scalar load)
+    int32_t pf;               // first source-row PAIR of the row's vertical window ((vpos & ~1) >> 1)
+    int32_t pad0[3];
+    uint32_t vt[8];           // vertical taps as pairs aligned to even source rows, zero beyond the filter
+    int32_t pad1[4];
+};
+
+struct SwsStripGeom {        // marching strip kernel (kernels_strip.hpp), per plane class
+    int32_t TW, strips, NCmax;            // output columns per strip (64 per lane column), strips per row, max window width (samples)
+    int32_t nph, npv;                     // tap pairs that can be non-zero (<= hfs2 / 2, vfs2 / 2)
+    int32_t hfs2, vfs2;                   // padded tap-row lengths of hT2 / vT2
+    const int32_t *colStart, *colCount;   // [strips] source-window origin (chunk aligned) / width (samples)
+    const int16_t *hT2, *vT2;
+    const SwsStripRow *rows;              // [plane height]
+    int32_t bands, band_rows;             // filled per launch
+    int32_t lds_bytes;                    // per block of 4 waves
+    int32_t debug;                        // profiling experiments only (SWS_HIP_STRIP_DEBUG): 1 no h-stage, 2 no v-stage, 4 no stores, 8 no loads
+};
+
 struct SwsRgbGroupPlan {    // marching packed-RGB kernel: everything one pair of output rows needs, as scalars (64 bytes)
     int32_t cbase;            // first chroma source row of the register ring for this group (may be negative: loads clamp)
     int32_t ylum0, ylum1;     // luma source rows of the two output rows (identity vertical luma filter)

@@ -1,0 +1,312 @@
+// Marching strip kernel for the general h+v polyphase chain on planar sources (the C1 / C3b shapes):
+// readers + hScale8To15_c / hScale16To15_c (swscale.c:99-142) + yuv2planeX_8_c / yuv2planeX_10_c / yuv2nv12cX_c /
+// yuv2p01x*X_c (output.c:327-357, :468-528, :538-589).  Same arithmetic as sws_k_tile_dot2, different schedule:
+//
+//  * a wave owns a strip of 64 * COLS output columns (lane l: columns l, l + 64, ...; neighbouring lanes read neighbouring
+//    LDS dwords, so the horizontal stage is bank-conflict free at 2:1) and walks down a band of output rows;
+//  * per step it h-scales ONE PAIR of source rows (rows 2q, 2q+1 -> one dword {even row, odd row} per column, which is the
+//    operand layout of v_dot2_i32_i16 for the vertical stage) and keeps the last pairs in a REGISTER ring: the vertical
+//    stage is lane-local, h-scaled samples never touch LDS or HBM, and no source row is h-scaled twice inside a band
+//    (the tile kernel re-did its vertical halo: (2 * 32 + 12) / 64 rows per output row at 2:1 Lanczos);
+//  * the only LDS traffic is the wave-private staging of the two source rows (written once, read by every tap);
+//  * horizontal taps live in registers for the whole band, vertical taps and row positions arrive through scalar loads
+//    one row ahead, the next pair of source rows is prefetched into registers while the current one is computed;
+//  * no block-level barrier anywhere: the 4 waves of a block are independent;
+//  * all memory goes through buffer descriptors (constant per-lane offsets, scalar row offsets, out-of-range lanes dropped
+//    by the hardware); vmcnt counts loads and stores together and the compiler must assume they retire out of order, so a
+//    row's stores are issued AFTER the wait for the prefetched rows and BEFORE the next prefetch is issued.
+#pragma once
+#include "kernels_wave.hpp"
+
+namespace swsk {
+
+struct StripLds { uint32_t *S; int row_dw; };
+
+// first tap pair of a chain: VOP3P form with an inline 0 addend (the compiler would emit v_mov 0 + v_dot2c)
+__device__ __forceinline__ int sdot2_first(uint32_t a, uint32_t b)
+{
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// horizontal stage of one row pair for COLS columns of NCOMP components -> one packed dword per (component, column)
+template <int NP, int NCOMP, int COLS>
+__device__ __forceinline__ void strip_hstage(const StripLds &L, const int (&spd)[COLS], const uint32_t (&ht)[COLS][NP], int sh,
+                                             uint32_t (&out)[NCOMP][COLS])
+{
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+        for (int c = 0; c < COLS; c++) {
+            const uint32_t *s0 = L.S + (ci * 2) * L.row_dw + spd[c], *s1 = s0 + L.row_dw;
+            int a = sdot2_first(s0[0], ht[c][0]), b = sdot2_first(s1[0], ht[c][0]);
+#pragma unroll
+            for (int k = 1; k < NP; k++) { a = sdot2(s0[k], ht[c][k], a); b = sdot2(s1[k], ht[c][k], b); }
+            // min(v >> sh, 32767) + int16 store == v_cvt_pk_i16_i32's saturation (see hscale_pairs_impl in kernels_tile.hpp)
+            out[ci][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(a >> sh, b >> sh));
+        }
+}
+
+template <bool SRC16, bool CHROMA, int COLS, int NPH>
+__device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParams &p, const SwsStripGeom &g, int strip, int y0, int y1,
+                                           uint8_t *smem, int wib, int lane)
+{
+    constexpr int NCOMP = CHROMA ? 2 : 1;
+    constexpr int SPC = SRC16 ? 8 : 16;                       // samples per 16-byte source chunk
+    const int W = CHROMA ? p.chrDstW : p.dstW, H = CHROMA ? p.chrDstH : p.dstH;
+    const int sH = CHROMA ? p.chrSrcH : p.srcH;
+    const int xs = strip * g.TW;
+    const int cs = g.colStart[strip], chunks = g.colCount[strip] / SPC;
+    const int32_t *hpos = CHROMA ? p.hChrPos : p.hLumPos;
+    const int npv = g.npv, sh = p.hshift;
+    StripLds L;
+    L.row_dw = (g.NCmax + SPC) >> 1;                          // one spare chunk per row: the dump slot of idle lanes
+    L.S = (uint32_t *)smem + wib * (NCOMP * 2 * L.row_dw);
+
+    // ---- per-lane column state: window offsets and horizontal taps (registers for the whole band) ----
+    int spd[COLS];
+    uint32_t ht[COLS][NPH];
+#pragma unroll
+    for (int c = 0; c < COLS; c++) {
+        const int x = min(xs + 64 * c + lane, W - 1);
+        spd[c] = ((hpos[x] & ~1) - cs) >> 1;
+        const uint32_t *tp = (const uint32_t *)(g.hT2 + (int64_t)x * g.hfs2);
+#pragma unroll
+        for (int k = 0; k < NPH; k++) ht[c][k] = tp[k];
+    }
+    // ---- source descriptors (whole rows including their padding) ----
+    const bool u1 = p.u_plane_src == 1;
+    sws_rsrc_t rs[NCOMP];
+    int sst[NCOMP];
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++) {
+        const bool first = !CHROMA || ((ci == 0) == u1);
+        const uint8_t *sb = !CHROMA ? f.src[0] : (first ? f.src[1] : f.src[2]);
+        sst[ci] = !CHROMA ? f.srcStride[0] : (first ? f.srcStride[1] : f.srcStride[2]);
+        rs[ci] = make_rsrc(sb, (uint32_t)sst[ci] * (uint32_t)sH);
+    }
+    // Two 16-byte chunks per lane and source row, unconditionally (straight-line code): a lane whose chunk lies beyond the strip's
+    // window gets an out-of-range offset (the descriptor answers 0 without touching memory) and dumps into the spare LDS chunk.
+    const int sbase = cs * (SRC16 ? 2 : 1) + lane * 16;
+    // (chroma strips are 128 columns wide and take one chunk per lane: windows of up to 64 chunks, checked on the host)
+    constexpr bool TWO = !CHROMA;
+    const int voff0 = lane < chunks ? sbase : 0x7fffffff, voff1 = 64 + lane < chunks ? sbase + 1024 : 0x7fffffff;
+    const int slot0 = min(lane, chunks) * (SPC / 2), slot1 = min(64 + lane, chunks) * (SPC / 2);
+
+    u32x4 pre[NCOMP * 4];                                      // [component][row of the pair][chunk]
+    auto prefetch = [&](int q) {                               // source rows 2q, 2q+1 (clamped) -> registers
+        const int r0 = min(max(2 * q, 0), sH - 1), r1 = min(max(2 * q + 1, 0), sH - 1);
+#pragma unroll
+        for (int ci = 0; ci < NCOMP; ci++) {
+            pre[4 * ci + 0] = bload16(rs[ci], voff0, r0 * sst[ci]);
+            if constexpr (TWO) pre[4 * ci + 1] = bload16(rs[ci], voff1, r0 * sst[ci]);
+            pre[4 * ci + 2] = bload16(rs[ci], voff0, r1 * sst[ci]);
+            if constexpr (TWO) pre[4 * ci + 3] = bload16(rs[ci], voff1, r1 * sst[ci]);
+        }
+    };
+    auto put = [&](uint32_t *dst, const u32x4 &v) {
+        if constexpr (SRC16) *(u32x4 *)dst = v;
+        else {
+            u32x4 lo, hi;                                      // bytes -> u16 pairs
+            lo[0] = __builtin_amdgcn_perm(0, v[0], 0x0c010c00u); lo[1] = __builtin_amdgcn_perm(0, v[0], 0x0c030c02u);
+            lo[2] = __builtin_amdgcn_perm(0, v[1], 0x0c010c00u); lo[3] = __builtin_amdgcn_perm(0, v[1], 0x0c030c02u);
+            hi[0] = __builtin_amdgcn_perm(0, v[2], 0x0c010c00u); hi[1] = __builtin_amdgcn_perm(0, v[2], 0x0c030c02u);
+            hi[2] = __builtin_amdgcn_perm(0, v[3], 0x0c010c00u); hi[3] = __builtin_amdgcn_perm(0, v[3], 0x0c030c02u);
+            *(u32x4 *)dst = lo; *(u32x4 *)(dst + 4) = hi;
+        }
+    };
+    auto stage = [&]() {                                       // registers -> the wave's LDS rows (u16 sample pairs)
+#pragma unroll
+        for (int ci = 0; ci < NCOMP; ci++) {
+            uint32_t *row0 = L.S + (ci * 2) * L.row_dw, *row1 = row0 + L.row_dw;
+            put(row0 + slot0, pre[4 * ci + 0]); put(row1 + slot0, pre[4 * ci + 2]);
+            if constexpr (TWO) { put(row0 + slot1, pre[4 * ci + 1]); put(row1 + slot1, pre[4 * ci + 3]); }
+        }
+    };
+
+    // ---- destination descriptors and per-lane offsets (columns beyond the plane get an out-of-range offset) ----
+    const bool semi = CHROMA && (p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010);
+    const bool d8 = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_NV12;
+    const int kind = semi ? (d8 ? 2 : 3) : (d8 ? 0 : 1);       // store form: b8 / b16 per component, or b16 / b32 of an interleaved pair
+    const int dbytes = (d8 ? 1 : 2) * (semi ? 2 : 1);          // bytes per stored element
+    sws_rsrc_t rd[NCOMP];
+    int dstr[NCOMP];
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++) {
+        const int pl = !CHROMA ? 0 : semi ? 1 : (ci == 0 ? p.u_plane_dst : p.v_plane_dst);
+        uint8_t *db = pl == 0 ? f.dst[0] : pl == 1 ? f.dst[1] : f.dst[2];
+        dstr[ci] = pl == 0 ? f.dstStride[0] : pl == 1 ? f.dstStride[1] : f.dstStride[2];
+        rd[ci] = make_rsrc(db, (uint32_t)dstr[ci] * (uint32_t)(H - 1) + (uint32_t)W * (uint32_t)dbytes);
+    }
+    int doff[COLS];
+#pragma unroll
+    for (int c = 0; c < COLS; c++) {
+        const int x = xs + 64 * c + lane;
+        doff[c] = x < W ? x * dbytes : 0x7fffffff;
+    }
+
+    uint32_t ring[NCOMP][COLS][8];
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+        for (int c = 0; c < COLS; c++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) ring[ci][c][k] = 0;
+
+    // pending output row (its stores are issued after the next wait for prefetched rows, see the header)
+    uint32_t pend[NCOMP][COLS];
+    int pend_y = -1;
+    auto flush = [&]() {
+        if (pend_y >= 0 && !(g.debug & 4)) {
+            switch (kind) {
+            case 0:
+#pragma unroll
+                for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                    for (int c = 0; c < COLS; c++) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)pend[ci][c], rd[ci], doff[c], pend_y * dstr[ci], 0);
+                break;
+            case 1:
+#pragma unroll
+                for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                    for (int c = 0; c < COLS; c++) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)pend[ci][c], rd[ci], doff[c], pend_y * dstr[ci], 0);
+                break;
+            case 2:
+#pragma unroll
+                for (int c = 0; c < COLS; c++)
+                    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(pend[0][c] | (pend[NCOMP - 1][c] << 8)), rd[0], doff[c], pend_y * dstr[0], 0);
+                break;
+            default:
+#pragma unroll
+                for (int c = 0; c < COLS; c++)
+                    __builtin_amdgcn_raw_buffer_store_b32(pend[0][c] | (pend[NCOMP - 1][c] << 16), rd[0], doff[c], pend_y * dstr[0], 0);
+                break;
+            }
+            pend_y = -1;
+        }
+    };
+
+    // ---- march ----
+    const SwsStripRow *rows = g.rows;
+    SwsStripRow e = rows[y0];                                  // scalar loads: first ring pair and vertical tap pairs of the row
+    int qnext = e.pf;                                          // next source-row pair to h-scale == the pair staged in LDS
+    prefetch(qnext);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): keep the fill out of the loop's wait arithmetic
+    stage();
+    prefetch(qnext + 1);
+    const int bits = p.dst_bits;
+    for (int y = y0; y < y1; y++) {
+        const SwsStripRow en = rows[min(y + 1, H - 1)];        // next row's scalars, one row ahead
+        const int pfy = e.pf;
+        if (qnext < pfy) {                                     // rows nobody needs (steep down-scaling with short filters): skip
+            qnext = pfy;
+            prefetch(qnext);
+            stage();
+            prefetch(qnext + 1);
+        }
+        while (qnext <= pfy + npv - 1) {
+            uint32_t np[NCOMP][COLS];
+            if (g.debug & 1) {
+#pragma unroll
+                for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                    for (int c = 0; c < COLS; c++) np[ci][c] = L.S[(ci * 2) * L.row_dw + spd[c]];
+            } else
+            strip_hstage<NPH, NCOMP, COLS>(L, spd, ht, sh, np);
+#pragma unroll
+            for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++) {
+#pragma unroll
+                    for (int k = 0; k < 7; k++) ring[ci][c][k] = ring[ci][c][k + 1];
+                    ring[ci][c][7] = np[ci][c];
+                }
+            qnext++;
+            // LDS rows are consumed: wait for the prefetched pair, stage it, release the pending row, prefetch the next pair
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            stage();
+            flush();
+            prefetch(qnext + 1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        flush();                                               // (a row that needed no new pair still has to release the previous one)
+        // ---- vertical stage: the npv newest ring entries are pairs pfy .. pfy + npv - 1 ----
+        int acc[NCOMP][COLS];
+        if (g.debug & 2) {
+#pragma unroll
+            for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++) acc[ci][c] = (int)ring[ci][c][7];
+        } else
+        switch (npv) {
+#define SWS_SV(N) case N: \
+            _Pragma("unroll") for (int ci = 0; ci < NCOMP; ci++) _Pragma("unroll") for (int c = 0; c < COLS; c++) { \
+                acc[ci][c] = sdot2_first(ring[ci][c][8 - N], e.vt[0]); \
+                _Pragma("unroll") for (int k = 1; k < N; k++) acc[ci][c] = sdot2(ring[ci][c][8 - N + k], e.vt[k], acc[ci][c]); } \
+            break;
+        SWS_SV(1) SWS_SV(2) SWS_SV(3) SWS_SV(4) SWS_SV(5) SWS_SV(6) SWS_SV(7)
+#undef SWS_SV
+        default:
+#pragma unroll
+            for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++) {
+                    acc[ci][c] = sdot2_first(ring[ci][c][0], e.vt[0]);
+#pragma unroll
+                    for (int k = 1; k < 8; k++) acc[ci][c] = sdot2(ring[ci][c][k], e.vt[k], acc[ci][c]);
+                }
+            break;
+        }
+        // ---- writers ("X" forms) ----
+        if (d8) {
+#pragma unroll
+            for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++) {
+                    const int x = xs + 64 * c + lane;
+                    const int off = (CHROMA && ci == 1) ? 3 : 0;
+                    pend[ci][c] = (uint32_t)clip_u8_shr((dither8(p.should_dither, y, x + off) << 12) + acc[ci][c], 19);
+                }
+        } else {
+            const int shift = 11 + 16 - bits, osh = p.dstKind == DSTK_P010 ? p.dst_shift : 0;
+#pragma unroll
+            for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++)
+                    pend[ci][c] = (uint32_t)(clip_uintp2(((1 << (shift - 1)) + acc[ci][c]) >> shift, bits) << osh);
+        }
+        if (semi && p.uv_swap_dst) {
+#pragma unroll
+            for (int c = 0; c < COLS; c++) { const uint32_t t = pend[0][c]; pend[0][c] = pend[NCOMP - 1][c]; pend[NCOMP - 1][c] = t; }
+        }
+        pend_y = y;
+        e = en;
+    }
+    flush();
+}
+
+template <bool SRC16, bool CHROMA, int COLS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) sws_k_strip_march(SwsFrameSet fs, SwsDevParams p, SwsStripGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wid = blockIdx.x * 4 + wib;
+    if (wid >= g.strips * g.bands) return;
+    const int strip = wid % g.strips, band = wid / g.strips;
+    const int H = CHROMA ? p.chrDstH : p.dstH;
+    const int y0 = band * g.band_rows, y1 = min(H, y0 + g.band_rows);
+    if (y0 >= y1) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    switch (g.nph) {        // the whole march is instantiated per horizontal tap-pair count: the loop body is branch-free
+#define SWS_SB(N) case N: strip_body<SRC16, CHROMA, COLS, N>(f, p, g, strip, y0, y1, smem, wib, lane); break;
+    SWS_SB(1) SWS_SB(2) SWS_SB(3) SWS_SB(4) SWS_SB(5) SWS_SB(6) SWS_SB(7) SWS_SB(8)
+#undef SWS_SB
+    }
+}
+
+} // namespace swsk

@@ -580,7 +580,9 @@ __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_wave2(SwsFrameSet f
 typedef __amdgpu_buffer_rsrc_t sws_rsrc_t;
 __device__ __forceinline__ sws_rsrc_t make_rsrc(const void *base, uint32_t bytes)
 {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+    // descriptor inputs go through readfirstlane so that their uniformity is provable (else every buffer op gets a waterfall loop)
+    void *b = (void *)uniform_u64((uint64_t)base);
+    return __builtin_amdgcn_make_buffer_rsrc(b, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
 __device__ __forceinline__ u32x4 bload16(sws_rsrc_t r, int voff, int soff)
 {
@@ -613,12 +615,12 @@ __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_march(SwsFrameSet f
     const int cH = p.chrSrcH - 1;
     const bool u1 = p.u_plane_src == 1;
     // descriptors: whole planes for the sources (strides are positive and planes < 2 GiB: checked on the host)
-    const sws_rsrc_t ry = make_rsrc(f.src[0], (uint32_t)f.srcStride[0] * (uint32_t)(p.srcH - 1) + (uint32_t)p.srcW);
-    const int cbytes = NV ? 2 * p.chrSrcW : p.chrSrcW;
+    // (whole rows including their padding: a dword that is only partially inside the visible row must not be cut off)
+    const sws_rsrc_t ry = make_rsrc(f.src[0], (uint32_t)f.srcStride[0] * (uint32_t)p.srcH);
     const sws_rsrc_t ru = make_rsrc(NV ? f.src[1] : (u1 ? f.src[1] : f.src[2]),
-                                    (uint32_t)(NV ? f.srcStride[1] : (u1 ? f.srcStride[1] : f.srcStride[2])) * (uint32_t)cH + (uint32_t)cbytes);
+                                    (uint32_t)(NV ? f.srcStride[1] : (u1 ? f.srcStride[1] : f.srcStride[2])) * (uint32_t)p.chrSrcH);
     const sws_rsrc_t rv = make_rsrc(NV ? f.src[1] : (u1 ? f.src[2] : f.src[1]),
-                                    (uint32_t)(NV ? f.srcStride[1] : (u1 ? f.srcStride[2] : f.srcStride[1])) * (uint32_t)cH + (uint32_t)cbytes);
+                                    (uint32_t)(NV ? f.srcStride[1] : (u1 ? f.srcStride[2] : f.srcStride[1])) * (uint32_t)p.chrSrcH);
     const int us = NV ? f.srcStride[1] : (u1 ? f.srcStride[1] : f.srcStride[2]), vs = NV ? f.srcStride[1] : (u1 ? f.srcStride[2] : f.srcStride[1]);
     const int ys = f.srcStride[0];
     const int cvoff = NV ? x : (x >> 1);
