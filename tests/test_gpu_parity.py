@@ -389,3 +389,66 @@ def test_yuv_range_and_matrix_conversion():
     assert path == "cascade" and opath == "cascade"
     run_case(96, 64, "yuv420p", 96, 64, "rgb24", SWS_BICUBIC | BX | AR, colorspace=(SWS_CS_ITU709, 1, SWS_CS_ITU709, 0))
     run_case(96, 64, "yuv420p", 96, 64, "bgra", SWS_BICUBIC | BX, colorspace=(SWS_CS_BT2020, 0, SWS_CS_BT2020, 0))
+
+
+NEG_STRIDE_CASES = [
+    (96, 64, "yuv420p", 96, 64, "rgb24", SWS_BICUBIC | BX),                 # unscaled yuv2rgb
+    (96, 64, "yuv420p", 96, 64, "bgra", SWS_BICUBIC | BX | AR),             # fused packed-RGB path
+    (96, 64, "yuv420p", 64, 40, "yuv420p", SWS_BILINEAR | BX),              # general h+v
+    (96, 64, "yuv420p10le", 96, 64, "p010le", SWS_LANCZOS | BX),            # planarToP01x
+    (96, 64, "rgb24", 96, 64, "yuv420p", SWS_BICUBIC | BX),                 # bgr24ToYv12-style / main path
+    (96, 64, "gbrpf32le", 96, 64, "yuv444p16le", SWS_BICUBIC | BX),
+    (96, 64, "nv12", 128, 72, "rgba", SWS_BICUBIC | BX),
+]
+
+
+@pytest.mark.parametrize("case", NEG_STRIDE_CASES, ids=[f"{c[2]}-{c[5]}-{c[3]}x{c[4]}" for c in NEG_STRIDE_CASES])
+@pytest.mark.parametrize("which", ["src", "dst", "both"])
+@pytest.mark.parametrize("device_frames", [True, False], ids=["hbm", "host"])
+def test_negative_strides(case, which, device_frames):
+    """bottom-up pictures: data pointers at the last row, negative linesizes (swscale.h:583 allows any stride sign).
+    A bottom-up source is the flipped picture; a bottom-up destination receives the flipped result."""
+    import ctypes as C
+    import torch
+    sw, sh, sfmt, dw, dh, dfmt, flags = case
+    o = OL.Oracle(sw, sh, sfmt, dw, dh, dfmt, flags)
+    p = SwsContext(sw, sh, sfmt, dw, dh, dfmt, flags)
+    src = OL.fill_random(OL.Frame(sfmt, sw, sh), 19)
+    neg_src, neg_dst = which in ("src", "both"), which in ("dst", "both")
+    ref = OL.Frame(dfmt, dw, dh)
+    assert o.scale(_flip_frame(src) if neg_src else src, ref) == dh
+    if neg_dst:
+        ref = _flip_frame(ref)
+    hs = HostFrame(sfmt, sw, sh)
+    for a, b in zip(hs.planes, src.planes):
+        a[:] = b
+    hd = HostFrame(dfmt, dw, dh)
+    for a in hd.planes:
+        a[:] = 0x77
+    if device_frames:
+        fs_ = DeviceFrame(sfmt, sw, sh).upload(hs)
+        fd_ = DeviceFrame(dfmt, dw, dh)
+        fd_.buf.fill_(0x77)
+        torch.cuda.synchronize()
+    else:
+        fs_, fd_ = hs, hd
+
+    def ptrs(fr, neg, host):
+        pp, ss = fr.ptrs()
+        out_p, out_s = (C.c_void_p * 4)(), (C.c_int * 4)()
+        for i in range(4):
+            if not pp[i]:
+                continue
+            rows = (fr.planes[i].shape[0] if host else fr.plane_tensor(i).shape[0])
+            out_p[i] = pp[i] + (rows - 1) * ss[i] if neg else pp[i]
+            out_s[i] = -ss[i] if neg else ss[i]
+        return out_p, out_s
+
+    sp, ss = ptrs(fs_, neg_src, not device_frames)
+    dp, ds = ptrs(fd_, neg_dst, not device_frames)
+    assert p.L.sws_scale(p.c, sp, ss, 0, sh, dp, ds) == dh
+    p.sync()
+    out = fd_.download() if device_frames else hd
+    for i, (a, b) in enumerate(zip(out.planes, ref.planes)):
+        rb = out.row_bytes[i]
+        assert np.array_equal(a[:, :rb], b[:, :rb]), (case, which, device_frames, i, p.path())
