@@ -75,6 +75,17 @@ enum AVPixelFormat {
     AV_PIX_FMT_GBRP14LE = 137,
     /* NEW: hardware surface format of the HIP hwcontext slot; appended after the
      * reference's last format (AV_PIX_FMT_NB == 268, libavutil/pixfmt.h) */
+    /* big-endian twins of the 16-bit / float formats above (converted through the little-endian twin + a byte-swap pass) */
+    AV_PIX_FMT_YUV420P9BE = 59, AV_PIX_FMT_YUV420P10BE = 61, AV_PIX_FMT_YUV420P12BE = 122, AV_PIX_FMT_YUV420P14BE = 124,
+    AV_PIX_FMT_YUV420P16BE = 46, AV_PIX_FMT_YUV422P9BE = 69, AV_PIX_FMT_YUV422P10BE = 63, AV_PIX_FMT_YUV422P12BE = 126,
+    AV_PIX_FMT_YUV422P14BE = 128, AV_PIX_FMT_YUV422P16BE = 48, AV_PIX_FMT_YUV444P9BE = 65, AV_PIX_FMT_YUV444P10BE = 67,
+    AV_PIX_FMT_YUV444P12BE = 130, AV_PIX_FMT_YUV444P14BE = 132, AV_PIX_FMT_YUV444P16BE = 50, AV_PIX_FMT_YUV440P10BE = 152,
+    AV_PIX_FMT_YUV440P12BE = 154, AV_PIX_FMT_GRAY9BE = 172, AV_PIX_FMT_GRAY10BE = 167, AV_PIX_FMT_GRAY12BE = 165,
+    AV_PIX_FMT_GRAY14BE = 180, AV_PIX_FMT_GRAY16BE = 29, AV_PIX_FMT_GBRP9BE = 72, AV_PIX_FMT_GBRP10BE = 74,
+    AV_PIX_FMT_GBRP12BE = 134, AV_PIX_FMT_GBRP14BE = 136, AV_PIX_FMT_GBRP16BE = 76, AV_PIX_FMT_GBRPF32BE = 174,
+    AV_PIX_FMT_P010BE = 159, AV_PIX_FMT_P012BE = 210, AV_PIX_FMT_P016BE = 170, AV_PIX_FMT_P210BE = 197, AV_PIX_FMT_P212BE = 221,
+    AV_PIX_FMT_P216BE = 201, AV_PIX_FMT_P410BE = 199, AV_PIX_FMT_P412BE = 223, AV_PIX_FMT_P416BE = 203, AV_PIX_FMT_RGB48BE = 34,
+    AV_PIX_FMT_BGR48BE = 57, AV_PIX_FMT_RGBA64BE = 104, AV_PIX_FMT_BGRA64BE = 106,
     AV_PIX_FMT_HIP = 268,
 };
 #endif

@@ -31,7 +31,7 @@ void write_ctx(Writer &w, const SwsInternal *c)
                        c->chrSrcHSubSample, c->chrSrcVSubSample, c->chrDstHSubSample, c->chrDstVSubSample,
                        c->chrSrcW, c->chrSrcH, c->chrDstW, c->chrDstH, c->srcBpc, c->dstBpc,
                        c->lumXInc, c->lumYInc, c->chrXInc, c->chrYInc, c->dst_slice_align, c->needAlpha, (int32_t)c->plan,
-                       c->cascade_fmt, c->cascade_w, c->cascade_h, c->legacy_init ? 1 : 0 };
+                       c->cascade_fmt, c->cascade_w, c->cascade_h, c->legacy_init ? 1 : 0, c->srcBE ? 1 : 0, c->dstBE ? 1 : 0 };
     w.put(ints, sizeof(ints));
     w.put(c->srcColorspaceTable, sizeof(c->srcColorspaceTable));
     w.put(c->dstColorspaceTable, sizeof(c->dstColorspaceTable));
@@ -54,7 +54,7 @@ bool read_ctx(Reader &r, SwsInternal *c)
     const void *cls = c->opts.av_class; void *opaque = c->opts.opaque;
     r.pod(c->opts);
     c->opts.av_class = cls; c->opts.opaque = opaque;   // process-local pointers are not transported
-    int32_t ints[28];
+    int32_t ints[30];
     r.get(ints, sizeof(ints));
     int k = 0;
     c->src0Alpha = ints[k++]; c->dst0Alpha = ints[k++]; c->brightness = ints[k++]; c->contrast = ints[k++]; c->saturation = ints[k++];
@@ -64,6 +64,7 @@ bool read_ctx(Reader &r, SwsInternal *c)
     c->lumXInc = ints[k++]; c->lumYInc = ints[k++]; c->chrXInc = ints[k++]; c->chrYInc = ints[k++]; c->dst_slice_align = ints[k++];
     c->needAlpha = ints[k++]; c->plan = (PlanKind)ints[k++]; c->cascade_fmt = ints[k++]; c->cascade_w = ints[k++]; c->cascade_h = ints[k++];
     c->legacy_init = ints[k++] != 0;
+    c->srcBE = ints[k++] != 0; c->dstBE = ints[k++] != 0;
     r.get(c->srcColorspaceTable, sizeof(c->srcColorspaceTable));
     r.get(c->dstColorspaceTable, sizeof(c->dstColorspaceTable));
     for (FilterBank *b : { &c->hLum, &c->hChr, &c->vLum, &c->vChr }) {

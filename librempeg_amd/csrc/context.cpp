@@ -42,8 +42,18 @@ static int zero_alpha_alias(int *format) // handle_0alpha, utils.c:811-820
     return 0;
 }
 
+static bool be_alias(int *format)
+{
+    const int t = pix_be_twin(*format);
+    if (t < 0) return false;
+    *format = t;
+    return true;
+}
+
 static void canonicalise_formats(SwsInternal *c) // handle_formats, utils.c:833-842 (no XYZ)
 {
+    c->srcBE |= be_alias(&c->opts.src_format);
+    c->dstBE |= be_alias(&c->opts.dst_format);
     c->src0Alpha |= zero_alpha_alias(&c->opts.src_format);
     c->dst0Alpha |= zero_alpha_alias(&c->opts.dst_format);
 }
@@ -60,6 +70,7 @@ static int jpeg_alias(int *format) // handle_jpeg, utils.c:773-809
 
 int canonical_pix_fmt(int fmt)
 {
+    be_alias(&fmt);
     jpeg_alias(&fmt);
     zero_alpha_alias(&fmt);
     return fmt;
@@ -90,11 +101,11 @@ static int scaler_from_enum(SwsScaler s, int fallback) // scaler_flag, utils.c:1
 // every descriptor row of pixdesc.cpp has a reader and a writer
 static bool fmt_supported_in(int f)
 {
-    return pix_desc(f) != nullptr;
+    return pix_desc(f) != nullptr || pix_be_twin(f) >= 0;
 }
 static bool fmt_supported_out(int f)
 {
-    return pix_desc(f) != nullptr;
+    return pix_desc(f) != nullptr || pix_be_twin(f) >= 0;
 }
 
 // ff_get_unscaled_swscale (swscale_unscaled.c:2392-2706): "last match wins"
@@ -118,8 +129,8 @@ void choose_unscaled(SwsInternal *c)
         c->dst_slice_align = 2;
     }
     if ((s == AV_PIX_FMT_YUV420P10LE || s == AV_PIX_FMT_YUV420P12LE || s == AV_PIX_FMT_YUV420P14LE || s == AV_PIX_FMT_YUV420P16LE) &&
-        (d == AV_PIX_FMT_P010LE || d == AV_PIX_FMT_P016LE)) k = PLAN_UNSC_P01X;                                       // :2432-2439
-    if ((s == AV_PIX_FMT_YUV420P || s == AV_PIX_FMT_YUVA420P) && (d == AV_PIX_FMT_P010LE || d == AV_PIX_FMT_P016LE)) k = PLAN_UNSC_8_P01X; // :2440-2444
+        (d == AV_PIX_FMT_P010LE || d == AV_PIX_FMT_P016LE) && !c->srcBE && !c->dstBE) k = PLAN_UNSC_P01X;           // :2432-2439 (native-endian names only)
+    if ((s == AV_PIX_FMT_YUV420P || s == AV_PIX_FMT_YUVA420P) && (d == AV_PIX_FMT_P010LE || d == AV_PIX_FMT_P016LE) && !c->dstBE) k = PLAN_UNSC_8_P01X; // :2440-2444
     if (s == AV_PIX_FMT_YUV410P && !(c->opts.dst_h & 3) && d == AV_PIX_FMT_YUV420P && !(flags & SWS_BITEXACT)) {       // :2446-2451
         k = PLAN_UNSC_YVU9_YV12;
         c->dst_slice_align = 4;
@@ -383,12 +394,14 @@ int init_from_frames(SwsInternal *c, int sw, int sh, int sfmt, int dw, int dh, i
 {
     SwsContext &o = c->opts;
     if (c->dynamic_init && o.src_w == sw && o.src_h == sh && o.dst_w == dw && o.dst_h == dh &&
-        o.src_format == canonical_pix_fmt(sfmt) && o.dst_format == canonical_pix_fmt(dfmt)) return 0;
+        o.src_format == canonical_pix_fmt(sfmt) && o.dst_format == canonical_pix_fmt(dfmt) &&
+        c->srcBE == (pix_be_twin(sfmt) >= 0) && c->dstBE == (pix_be_twin(dfmt) >= 0)) return 0;
     // new geometry: drop everything derived from the old one
     destroy(c->cascade[0]); destroy(c->cascade[1]);
     c->cascade[0] = c->cascade[1] = nullptr;
     dev_release(c);
     c->src0Alpha = c->dst0Alpha = 0;
+    c->srcBE = c->dstBE = false;
     c->dstFormatBpp = c->srcFormatBpp = 0;
     c->contrast = c->saturation = c->brightness = 0;
     o.src_w = sw; o.src_h = sh; o.src_format = sfmt; o.dst_w = dw; o.dst_h = dh; o.dst_format = dfmt;
@@ -459,8 +472,9 @@ SwsContext *sws_getCachedContext(SwsContext *prev, int srcW, int srcH, enum AVPi
         // note: formats may have been canonicalised at init (bgr0 -> bgra); compare like the reference does,
         // on the stored fields, after applying the same aliasing to the request
         int sf = srcFormat, df = dstFormat;
+        const bool sbe = be_alias(&sf), dbe = be_alias(&df);
         jpeg_alias(&sf); jpeg_alias(&df); zero_alpha_alias(&sf); zero_alpha_alias(&df);
-        if (prev->src_w != srcW || prev->src_h != srcH || prev->src_format != sf || prev->dst_w != dstW ||
+        if (p->srcBE != sbe || p->dstBE != dbe || prev->src_w != srcW || prev->src_h != srcH || prev->src_format != sf || prev->dst_w != dstW ||
             prev->dst_h != dstH || prev->dst_format != df || prev->flags != (unsigned)flags ||
             prev->scaler_params[0] != param[0] || prev->scaler_params[1] != param[1]) {
             destroy(p);

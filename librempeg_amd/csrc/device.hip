@@ -29,6 +29,7 @@ struct DeviceState {
     int chr_window2 = 0;       // max chroma source rows spanned by a pair of output rows (wave kernel register budget)
     bool tile_ok = false; SwsTileGeom tileL, tileC; void *d_tilegeom = nullptr; size_t tilegeom_bytes = 0;
     bool rgb_march_ok = false; void *d_rgbplan = nullptr; size_t rgbplan_bytes = 0; int rgb_groups = 0;   // sws_k_rgb_fused_unity_march
+    void *d_be = nullptr; size_t be_bytes = 0;   // little-endian copies of big-endian source pictures
     bool dot2_ok = false; SwsTileGeom dotL, dotC; void *d_dot2 = nullptr; size_t dot2_bytes = 0;
     bool strip_ok = false; SwsStripGeom stripL, stripC;    // sws_k_strip_march (tables live in d_dot2)
     bool march_ok = false; SwsMarchGeom marL, marC; void *d_march = nullptr; size_t march_bytes = 0;
@@ -78,6 +79,7 @@ void dev_release(SwsInternal *c)
     if (d->slice_img) (void)hipFree(d->slice_img);
     if (d->d_tilegeom) (void)hipFree(d->d_tilegeom);
     if (d->d_rgbplan) (void)hipFree(d->d_rgbplan);
+    if (d->d_be) (void)hipFree(d->d_be);
     if (d->d_dot2) (void)hipFree(d->d_dot2);
     if (d->d_march) (void)hipFree(d->d_march);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
@@ -691,7 +693,7 @@ static bool frames_desc_ok(const SwsFramePtrs *fr, int n, int srcH, int dstH)
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
 // launch the kernels of one (non-cascaded) context over `n` device-resident frames
-static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
+static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
 {
     DeviceState *d = c->dev;
     const SwsDevParams &p = d->params;
@@ -1152,6 +1154,96 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
     return 0;
 }
 
+static int image_layout(int format, int w, int h, int align, int linesize[4], size_t offset[4], size_t *total);
+// ---- big-endian pictures: byte-swap passes around the little-endian conversion (context.cpp: be_alias) ----
+namespace swsk {
+__global__ void __launch_bounds__(256) sws_k_bswap(const uint8_t *src, int64_t sstride, uint8_t *dst, int64_t dstride, int rows, int row_bytes, int unit)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (y >= rows || (i + 1) * unit > row_bytes) return;
+    const uint8_t *s = src + y * sstride + (int64_t)i * unit;
+    uint8_t *d = dst + y * dstride + (int64_t)i * unit;
+    if (unit == 2) { const uint16_t v = *(const uint16_t *)s; *(uint16_t *)d = (uint16_t)((v >> 8) | (v << 8)); }
+    else { const uint32_t v = *(const uint32_t *)s; *(uint32_t *)d = __builtin_bswap32(v); }
+}
+} // namespace swsk
+
+// rows and visible bytes per row of plane k of a picture
+static void plane_extent(const PixDesc *d, int w, int h, int k, int *rows, int *row_bytes, int *vsub)
+{
+    int maxb = 0; bool chroma = false, used = false;
+    for (int i = 0; i < d->nb_components; i++) {
+        if (d->comp[i].plane != k) continue;
+        used = true;
+        if ((i == 1 || i == 2) && !(d->flags & PIXFLAG_RGB)) chroma = true;
+    }
+    *rows = 0; *row_bytes = 0; *vsub = 0;
+    if (!used) return;
+    const int pw = chroma ? -((-w) >> d->log2_chroma_w) : w;
+    for (int i = 0; i < d->nb_components; i++)
+        if (d->comp[i].plane == k) maxb = std::max(maxb, d->comp[i].step * pw);
+    *vsub = chroma ? d->log2_chroma_h : 0;
+    *rows = chroma ? -((-h) >> d->log2_chroma_h) : h;
+    *row_bytes = maxb;
+}
+
+static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
+{
+    if (!c->srcBE && !c->dstBE) return launch_plan_le(c, frames, n, sliceY, sliceH);
+    DeviceState *d = c->dev;
+    hipStream_t st = d->stream;
+    const SwsContext &o = c->opts;
+    std::vector<SwsFramePtrs> fr(frames, frames + n);
+    const dim3 blk(256);
+    if (c->srcBE) {
+        const PixDesc *ds = pix_desc(o.src_format);
+        const int unit = (ds->flags & PIXFLAG_FLOAT) ? 4 : 2;
+        int ls[4]; size_t offs[4], total = 0;
+        int r = image_layout(o.src_format, o.src_w, o.src_h, 256, ls, offs, &total);
+        if (r < 0) return r;
+        if ((size_t)n * total > d->be_bytes) {
+            HIPCHK(hipStreamSynchronize(st));
+            if (d->d_be) HIPCHK(hipFree(d->d_be));
+            d->d_be = nullptr;
+            HIPCHK(hipMalloc(&d->d_be, (size_t)n * total));
+            d->be_bytes = (size_t)n * total;
+        }
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 4; k++) {
+                int rows, rb, vs;
+                plane_extent(ds, o.src_w, o.src_h, k, &rows, &rb, &vs);
+                if (!rows || !frames[i].src[k]) continue;
+                const int y0 = sliceY >> vs, y1 = std::min(rows, -((-(sliceY + sliceH)) >> vs));
+                uint8_t *scr = (uint8_t *)d->d_be + (size_t)i * total + offs[k];
+                if (y1 > y0) {
+                    const dim3 grid((rb / unit + 255) / 256, y1 - y0);
+                    hipLaunchKernelGGL(swsk::sws_k_bswap, grid, blk, 0, st, frames[i].src[k] + (int64_t)y0 * frames[i].srcStride[k],
+                                       (int64_t)frames[i].srcStride[k], scr + (int64_t)y0 * ls[k], (int64_t)ls[k], y1 - y0, rb, unit);
+                }
+                fr[i].src[k] = scr; fr[i].srcStride[k] = ls[k];
+            }
+    }
+    int ret = launch_plan_le(c, fr.data(), n, sliceY, sliceH);
+    if (ret >= 0 && c->dstBE) {
+        const PixDesc *dd = pix_desc(o.dst_format);
+        const int unit = (dd->flags & PIXFLAG_FLOAT) ? 4 : 2;
+        const bool whole = c->plan == PLAN_MAIN || c->plan == PLAN_CASCADE || (sliceY == 0 && sliceH == o.src_h);
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 4; k++) {
+                int rows, rb, vs;
+                plane_extent(dd, o.dst_w, o.dst_h, k, &rows, &rb, &vs);
+                if (!rows || !frames[i].dst[k]) continue;
+                const int y0 = whole ? 0 : sliceY >> vs, y1 = whole ? rows : std::min(rows, -((-(sliceY + sliceH)) >> vs));
+                if (y1 <= y0) continue;
+                uint8_t *p0 = frames[i].dst[k] + (int64_t)y0 * frames[i].dstStride[k];
+                const dim3 grid((rb / unit + 255) / 256, y1 - y0);
+                hipLaunchKernelGGL(swsk::sws_k_bswap, grid, blk, 0, st, p0, (int64_t)frames[i].dstStride[k], p0, (int64_t)frames[i].dstStride[k], y1 - y0, rb, unit);
+            }
+    }
+    return ret;
+}
+
+
 // build device-side frame descriptors for host or device user pointers; stages host memory
 struct Staging {
     bool src_host = false, dst_host = false;
@@ -1460,6 +1552,7 @@ static int frame_matches(const SwsInternal *c, const SwsFrameView *f, bool is_sr
 {
     const int fmt = canonical_pix_fmt(f->format); // the context stores canonicalised formats (yuvj420p -> yuv420p, bgr0 -> bgra)
     const SwsContext &o = c->opts;
+    if ((is_src ? c->srcBE : c->dstBE) != (pix_be_twin(f->format) >= 0)) return 0;
     return is_src ? (fmt == o.src_format && f->width == o.src_w && f->height == o.src_h)
                   : (fmt == o.dst_format && f->width == o.dst_w && f->height == o.dst_h);
 }

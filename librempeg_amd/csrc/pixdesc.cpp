@@ -69,6 +69,10 @@ const PixDesc *pix_desc(int fmt)
 {
     for (const PixDesc &d : g_descs)
         if (d.fmt == fmt) return &d;
+    const int twin = pix_be_twin(fmt);   // a big-endian format has the layout of its little-endian twin
+    if (twin >= 0)
+        for (const PixDesc &d : g_descs)
+            if (d.fmt == twin) return &d;
     return nullptr;
 }
 
@@ -116,6 +120,57 @@ bool isDataInHighBits(int f)
         if ((d->comp[i].shift + d->comp[i].depth) & 7) return false;
     }
     return true;
+}
+
+// big-endian formats are converted through their little-endian twin (the reference's BE readers / writers are the LE ones behind
+// AV_RB16 / AV_WB16: input.c:608-629, the output_pixel macros of output.c); returns the twin or -1
+int pix_be_twin(int fmt)
+{
+    static const int pairs[][2] = {
+    { AV_PIX_FMT_YUV420P9BE, AV_PIX_FMT_YUV420P9LE },
+    { AV_PIX_FMT_YUV420P10BE, AV_PIX_FMT_YUV420P10LE },
+    { AV_PIX_FMT_YUV420P12BE, AV_PIX_FMT_YUV420P12LE },
+    { AV_PIX_FMT_YUV420P14BE, AV_PIX_FMT_YUV420P14LE },
+    { AV_PIX_FMT_YUV420P16BE, AV_PIX_FMT_YUV420P16LE },
+    { AV_PIX_FMT_YUV422P9BE, AV_PIX_FMT_YUV422P9LE },
+    { AV_PIX_FMT_YUV422P10BE, AV_PIX_FMT_YUV422P10LE },
+    { AV_PIX_FMT_YUV422P12BE, AV_PIX_FMT_YUV422P12LE },
+    { AV_PIX_FMT_YUV422P14BE, AV_PIX_FMT_YUV422P14LE },
+    { AV_PIX_FMT_YUV422P16BE, AV_PIX_FMT_YUV422P16LE },
+    { AV_PIX_FMT_YUV444P9BE, AV_PIX_FMT_YUV444P9LE },
+    { AV_PIX_FMT_YUV444P10BE, AV_PIX_FMT_YUV444P10LE },
+    { AV_PIX_FMT_YUV444P12BE, AV_PIX_FMT_YUV444P12LE },
+    { AV_PIX_FMT_YUV444P14BE, AV_PIX_FMT_YUV444P14LE },
+    { AV_PIX_FMT_YUV444P16BE, AV_PIX_FMT_YUV444P16LE },
+    { AV_PIX_FMT_YUV440P10BE, AV_PIX_FMT_YUV440P10LE },
+    { AV_PIX_FMT_YUV440P12BE, AV_PIX_FMT_YUV440P12LE },
+    { AV_PIX_FMT_GRAY9BE, AV_PIX_FMT_GRAY9LE },
+    { AV_PIX_FMT_GRAY10BE, AV_PIX_FMT_GRAY10LE },
+    { AV_PIX_FMT_GRAY12BE, AV_PIX_FMT_GRAY12LE },
+    { AV_PIX_FMT_GRAY14BE, AV_PIX_FMT_GRAY14LE },
+    { AV_PIX_FMT_GRAY16BE, AV_PIX_FMT_GRAY16LE },
+    { AV_PIX_FMT_GBRP9BE, AV_PIX_FMT_GBRP9LE },
+    { AV_PIX_FMT_GBRP10BE, AV_PIX_FMT_GBRP10LE },
+    { AV_PIX_FMT_GBRP12BE, AV_PIX_FMT_GBRP12LE },
+    { AV_PIX_FMT_GBRP14BE, AV_PIX_FMT_GBRP14LE },
+    { AV_PIX_FMT_GBRP16BE, AV_PIX_FMT_GBRP16LE },
+    { AV_PIX_FMT_GBRPF32BE, AV_PIX_FMT_GBRPF32LE },
+    { AV_PIX_FMT_P010BE, AV_PIX_FMT_P010LE },
+    { AV_PIX_FMT_P012BE, AV_PIX_FMT_P012LE },
+    { AV_PIX_FMT_P016BE, AV_PIX_FMT_P016LE },
+    { AV_PIX_FMT_P210BE, AV_PIX_FMT_P210LE },
+    { AV_PIX_FMT_P212BE, AV_PIX_FMT_P212LE },
+    { AV_PIX_FMT_P216BE, AV_PIX_FMT_P216LE },
+    { AV_PIX_FMT_P410BE, AV_PIX_FMT_P410LE },
+    { AV_PIX_FMT_P412BE, AV_PIX_FMT_P412LE },
+    { AV_PIX_FMT_P416BE, AV_PIX_FMT_P416LE },
+    { AV_PIX_FMT_RGB48BE, AV_PIX_FMT_RGB48LE },
+    { AV_PIX_FMT_BGR48BE, AV_PIX_FMT_BGR48LE },
+    { AV_PIX_FMT_RGBA64BE, AV_PIX_FMT_RGBA64LE },
+    { AV_PIX_FMT_BGRA64BE, AV_PIX_FMT_BGRA64LE }
+    };
+    for (const auto &pr : pairs) if (pr[0] == fmt) return pr[1];
+    return -1;
 }
 
 } // namespace swship

@@ -20,6 +20,7 @@ struct PixDesc {
 enum : unsigned { PIXFLAG_BE = 1u << 0, PIXFLAG_PLANAR = 1u << 4, PIXFLAG_RGB = 1u << 5,
                   PIXFLAG_ALPHA = 1u << 7, PIXFLAG_FLOAT = 1u << 9 };
 const PixDesc *pix_desc(int fmt);
+int pix_be_twin(int fmt);   // little-endian twin of a big-endian format, or -1
 int  pix_bits_per_pixel(const PixDesc *d);
 int  pix_nb_planes(const PixDesc *d);
 // predicates, libswscale/swscale_internal.h:746-988
@@ -94,6 +95,7 @@ struct SwsInternal {
     std::vector<double> srcVec[4];   // copies of the SwsFilter vectors given to sws_init_context: lumH, lumV, chrH, chrV
     int dstVecLen[4] = {0, 0, 0, 0};
     const SwsFrameView *frame_src = nullptr; SwsFrameView *frame_dst = nullptr; int frame_rows_in = 0;   // sws_frame_start .. sws_frame_end
+    bool srcBE = false, dstBE = false;   // the caller's formats were big-endian: opts.src_format / dst_format hold the LE twins
     bool dynamic_init = false;    // configured from the frames of sws_scale_frame() (swscale.c:1405-1480)
     int sliceDir = 0;             // 0 = no slice sequence in progress, 1 = top-down, -1 = bottom-up (swscale.c:1096-1104)
     int slice_dstY = 0;           // ff_swscale's dstY cursor (swscale.c:372-381, :566)

@@ -123,6 +123,60 @@ static const Desc *desc_get(int fmt)
         if (descs[i].fmt == fmt) return &descs[i];
     return NULL;
 }
+
+/* big-endian formats: {BE, LE} values of libavutil/pixfmt.h.  The oracle converts through the little-endian twin: a BE source is
+ * byte-swapped into a scratch copy first, a BE destination is byte-swapped in place afterwards (the reference's BE readers and
+ * writers are the LE ones behind AV_RB16 / AV_WB16: input.c:608-629, output.c output_pixel macros); converter selection follows
+ * the reference's rules, which only name a byte order for planarToP01xWrapper / planar8ToP01xleWrapper (native-endian only). */
+static const int be_pairs[][2] = {
+    { 59, 60 } /* yuv420p9 */,
+    { 61, 62 } /* yuv420p10 */,
+    { 122, 123 } /* yuv420p12 */,
+    { 124, 125 } /* yuv420p14 */,
+    { 46, 45 } /* yuv420p16 */,
+    { 69, 70 } /* yuv422p9 */,
+    { 63, 64 } /* yuv422p10 */,
+    { 126, 127 } /* yuv422p12 */,
+    { 128, 129 } /* yuv422p14 */,
+    { 48, 47 } /* yuv422p16 */,
+    { 65, 66 } /* yuv444p9 */,
+    { 67, 68 } /* yuv444p10 */,
+    { 130, 131 } /* yuv444p12 */,
+    { 132, 133 } /* yuv444p14 */,
+    { 50, 49 } /* yuv444p16 */,
+    { 152, 151 } /* yuv440p10 */,
+    { 154, 153 } /* yuv440p12 */,
+    { 172, 173 } /* gray9 */,
+    { 167, 168 } /* gray10 */,
+    { 165, 166 } /* gray12 */,
+    { 180, 181 } /* gray14 */,
+    { 29, 30 } /* gray16 */,
+    { 72, 73 } /* gbrp9 */,
+    { 74, 75 } /* gbrp10 */,
+    { 134, 135 } /* gbrp12 */,
+    { 136, 137 } /* gbrp14 */,
+    { 76, 77 } /* gbrp16 */,
+    { 174, 175 } /* gbrpf32 */,
+    { 159, 158 } /* p010 */,
+    { 210, 209 } /* p012 */,
+    { 170, 169 } /* p016 */,
+    { 197, 198 } /* p210 */,
+    { 221, 222 } /* p212 */,
+    { 201, 202 } /* p216 */,
+    { 199, 200 } /* p410 */,
+    { 223, 224 } /* p412 */,
+    { 203, 204 } /* p416 */,
+    { 34, 35 } /* rgb48 */,
+    { 57, 58 } /* bgr48 */,
+    { 104, 105 } /* rgba64 */,
+    { 106, 107 } /* bgra64 */
+};
+static int be_twin(int *fmt)
+{
+    for (size_t i = 0; i < sizeof(be_pairs) / sizeof(be_pairs[0]); i++)
+        if (be_pairs[i][0] == *fmt) { *fmt = be_pairs[i][1]; return 1; }
+    return 0;
+}
 /* libswscale/swscale_internal.h:746-988 */
 static int is16BPS(int f) { return desc_get(f)->c[0].depth == 16; }
 static int isNBPS(int f) { int d = desc_get(f)->c[0].depth; return d >= 9 && d <= 14; }
@@ -178,6 +232,7 @@ enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
 struct OrSws {
     OrSwsOpts o;
     int src0Alpha, dst0Alpha;
+    int src_be, dst_be;   /* the caller's formats were big-endian: o.src_format / o.dst_format hold the LE twins */
     int brightness, contrast, saturation;
     int srcColorspaceTable[4], dstColorspaceTable[4];
     int dstFormatBpp, srcFormatBpp;
@@ -728,7 +783,9 @@ OrSws *or_sws_create(const OrSwsOpts *o)
 {
     OrSws *c = calloc(1, sizeof(*c));
     c->o = *o;
-    if (!desc_get(o->src_format) || !desc_get(o->dst_format) || init_context(c) < 0) {
+    c->src_be = be_twin(&c->o.src_format);
+    c->dst_be = be_twin(&c->o.dst_format);
+    if (!desc_get(c->o.src_format) || !desc_get(c->o.dst_format) || init_context(c) < 0) {
         or_sws_free(c);
         return NULL;
     }
@@ -739,8 +796,10 @@ OrSws *or_sws_get_context(int srcW, int srcH, int srcFmt, int dstW, int dstH, in
                           int flags, const double *param)
 {
     OrSws *c;
+    const int sbe = be_twin(&srcFmt), dbe = be_twin(&dstFmt);
     if (!desc_get(srcFmt) || !desc_get(dstFmt)) return NULL;
     c = alloc_set_opts(srcW, srcH, srcFmt, dstW, dstH, dstFmt, flags, param);
+    c->src_be = sbe; c->dst_be = dbe;
     if (init_context(c) < 0) { or_sws_free(c); return NULL; }
     return c;
 }
@@ -774,8 +833,8 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
     if (s == ORF_YUV444P && (d == ORF_NV24 || d == ORF_NV42)) c->unscaled_kind = UNSC_PLANAR2NV24;   /* :2410-2413 */
     if (d == ORF_YUV444P && (s == ORF_NV24 || s == ORF_NV42)) c->unscaled_kind = UNSC_NV242PLANAR;   /* :2420-2423 */
     if ((s == ORF_YUV420P10LE || s == ORF_YUV420P12LE || s == ORF_YUV420P14LE || s == ORF_YUV420P16LE) &&
-        (d == ORF_P010LE || d == ORF_P016LE)) c->unscaled_kind = UNSC_P01X;                           /* :2432-2439 */
-    if ((s == ORF_YUV420P || s == ORF_YUVA420P) && (d == ORF_P010LE || d == ORF_P016LE)) c->unscaled_kind = UNSC_8_P01X; /* :2440-2444 */
+        (d == ORF_P010LE || d == ORF_P016LE) && !c->src_be && !c->dst_be) c->unscaled_kind = UNSC_P01X;                           /* :2432-2439 */
+    if ((s == ORF_YUV420P || s == ORF_YUVA420P) && (d == ORF_P010LE || d == ORF_P016LE) && !c->dst_be) c->unscaled_kind = UNSC_8_P01X; /* :2440-2444 */
     if (s == ORF_YUV410P && !(c->o.dst_h & 3) && d == ORF_YUV420P && !(flags & OR_SWS_BITEXACT))
         c->unscaled_kind = UNSC_YVU9_YV12;                                                            /* :2446-2451 */
     /* bgr24toYV12 (:2452-2456) */
@@ -2410,11 +2469,82 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
     return dstH;
 }
 
+static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4], int srcSliceY, int srcSliceH,
+                    uint8_t *const dst[4], const int dstStride[4]);
+
+/* rows and visible bytes per row of plane k */
+static void plane_geom(const Desc *d, int w, int h, int k, int *rows, int *row_bytes)
+{
+    int maxb = 0, chroma = 0, used = 0;
+    for (int i = 0; i < d->nb; i++) {
+        if (d->c[i].plane != k) continue;
+        used = 1;
+        if ((i == 1 || i == 2) && !(d->flags & PF_RGB)) chroma = 1;
+    }
+    if (!used) { *rows = 0; *row_bytes = 0; return; }
+    {
+        const int pw = chroma ? -((-w) >> d->lw) : w;
+        for (int i = 0; i < d->nb; i++)
+            if (d->c[i].plane == k) { const int b = d->c[i].step * pw; if (b > maxb) maxb = b; }
+        if (!(d->flags & PF_PLANAR) && d->nb >= 3 && !(d->flags & PF_RGB)) maxb = d->c[0].step * w;   /* packed 4:2:2 */
+    }
+    *rows = chroma ? -((-h) >> d->lh) : h;
+    *row_bytes = maxb;
+}
+static void bswap_rows(uint8_t *dst, int dstStride, const uint8_t *src, int srcStride, int rows, int row_bytes, int unit)
+{
+    for (int y = 0; y < rows; y++) {
+        const uint8_t *s = src + (ptrdiff_t)y * srcStride;
+        uint8_t *d = dst + (ptrdiff_t)y * dstStride;
+        for (int x = 0; x + unit <= row_bytes; x += unit) {
+            uint8_t t[4];
+            for (int b = 0; b < unit; b++) t[b] = s[x + unit - 1 - b];
+            for (int b = 0; b < unit; b++) d[x + b] = t[b];
+        }
+    }
+}
+
 int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], int srcSliceY, int srcSliceH,
                  uint8_t *const dst[4], const int dstStride[4])
 {
     if (!c || !src || !dst || !srcStride || !dstStride) return -22;
     if (srcSliceY != 0 || srcSliceH != c->o.src_h) return -22; /* oracle: whole frames only */
+    if (c->src_be || c->dst_be) {
+        const Desc *ds = desc_get(c->o.src_format), *dd = desc_get(c->o.dst_format);
+        const uint8_t *sp[4] = { src[0], src[1], src[2], src[3] };
+        int ss[4] = { srcStride[0], srcStride[1], srcStride[2], srcStride[3] };
+        uint8_t *tmp[4] = { NULL, NULL, NULL, NULL };
+        int ret;
+        if (c->src_be) {
+            const int unit = (ds->flags & PF_FLOAT) ? 4 : 2;
+            for (int k = 0; k < 4; k++) {
+                int rows, rb;
+                plane_geom(ds, c->o.src_w, c->o.src_h, k, &rows, &rb);
+                if (!rows || !src[k]) continue;
+                tmp[k] = malloc((size_t)rows * rb + 16);
+                bswap_rows(tmp[k], rb, src[k], srcStride[k], rows, rb, unit);
+                sp[k] = tmp[k]; ss[k] = rb;
+            }
+        }
+        ret = scale_le(c, sp, ss, srcSliceY, srcSliceH, dst, dstStride);
+        for (int k = 0; k < 4; k++) free(tmp[k]);
+        if (ret >= 0 && c->dst_be) {
+            const int unit = (dd->flags & PF_FLOAT) ? 4 : 2;
+            for (int k = 0; k < 4; k++) {
+                int rows, rb;
+                plane_geom(dd, c->o.dst_w, c->o.dst_h, k, &rows, &rb);
+                if (!rows || !dst[k]) continue;
+                bswap_rows(dst[k], dstStride[k], dst[k], dstStride[k], rows, rb, unit);
+            }
+        }
+        return ret;
+    }
+    return scale_le(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
+}
+
+static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4], int srcSliceY, int srcSliceH,
+                    uint8_t *const dst[4], const int dstStride[4])
+{
     if (c->cascade[0]) { /* scale_cascaded, swscale.c:992-1018 */
         uint8_t *tmp[4] = { c->casc_tmp[0], NULL, NULL, NULL };
         int ret = or_sws_scale(c->cascade[0], src, srcStride, 0, srcSliceH, tmp, c->casc_stride);

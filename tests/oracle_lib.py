@@ -42,6 +42,12 @@ _FORMATS = {
     "gray12le": (166, "gray", 0, 0, 2), "gray14le": (181, "gray", 0, 0, 2), "gray16le": (30, "gray", 0, 0, 2),
 }
 
+# big-endian twins: same layout as the little-endian format, AVPixelFormat value from libavutil/pixfmt.h
+_BE_VALUES = {"yuv420p9be": 59, "yuv420p10be": 61, "yuv420p12be": 122, "yuv420p14be": 124, "yuv420p16be": 46, "yuv422p9be": 69, "yuv422p10be": 63, "yuv422p12be": 126, "yuv422p14be": 128, "yuv422p16be": 48, "yuv444p9be": 65, "yuv444p10be": 67, "yuv444p12be": 130, "yuv444p14be": 132, "yuv444p16be": 50, "yuv440p10be": 152, "yuv440p12be": 154, "gray9be": 172, "gray10be": 167, "gray12be": 165, "gray14be": 180, "gray16be": 29, "gbrp9be": 72, "gbrp10be": 74, "gbrp12be": 134, "gbrp14be": 136, "gbrp16be": 76, "gbrpf32be": 174, "p010be": 159, "p012be": 210, "p016be": 170, "p210be": 197, "p212be": 221, "p216be": 201, "p410be": 199, "p412be": 223, "p416be": 203, "rgb48be": 34, "bgr48be": 57, "rgba64be": 104, "bgra64be": 106}
+for _n, _v in list(_BE_VALUES.items()):
+    _le = _FORMATS[_n[:-2] + "le"]
+    _FORMATS[_n] = (_v,) + _le[1:]
+
 
 def plane_layout(fmt, w, h):
     """[(visible_bytes_per_row, rows)] per plane."""
@@ -118,21 +124,22 @@ def fill_random(frame, seed):
     f = frame.fmt
     for pi, (a, rb) in enumerate(zip(frame.planes, frame.row_bytes)):
         rows = a.shape[0]
-        m = re.match(r"(?:yuv4\d\dp|gbrp|gray)(9|10|12|14)le$", f)
-        mp = re.match(r"p[024](10|12)le$", f)
+        m = re.match(r"(?:yuv4\d\dp|gbrp|gray)(9|10|12|14)[lb]e$", f)
+        mp = re.match(r"p[024](10|12)[lb]e$", f)
+        be = f.endswith("be")
         if m:      # N-bit samples in the low bits of 16-bit words
             v = rng.integers(0, 1 << int(m.group(1)), size=(rows, rb // 2), dtype=np.uint16)
-            a[:, :rb] = v.view(np.uint8).reshape(rows, rb)
+            a[:, :rb] = (v.byteswap() if be else v).view(np.uint8).reshape(rows, rb)
         elif mp:   # N-bit samples in the high bits (p010 / p012 families)
             d = int(mp.group(1))
             v = (rng.integers(0, 1 << d, size=(rows, rb // 2), dtype=np.uint16) << (16 - d)).astype(np.uint16)
-            a[:, :rb] = v.view(np.uint8).reshape(rows, rb)
-        elif f == "gbrpf32le":
+            a[:, :rb] = (v.byteswap() if be else v).view(np.uint8).reshape(rows, rb)
+        elif f in ("gbrpf32le", "gbrpf32be"):
             v = rng.random(size=(rows, rb // 4), dtype=np.float32)
             flat = v.reshape(-1)
             flat[::257] = -0.25
             flat[128::257] = 1.25
-            a[:, :rb] = v.view(np.uint8).reshape(rows, rb)
+            a[:, :rb] = (v.byteswap() if be else v).view(np.uint8).reshape(rows, rb)
         else:
             a[:, :rb] = rng.integers(0, 256, size=(rows, rb), dtype=np.uint8)
     return frame

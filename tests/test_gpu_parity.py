@@ -87,8 +87,10 @@ YUV_FAMILY = ["yuyv422", "uyvy422", "yvyu422", "yuva420p", "yuva422p", "yuva444p
 PLANAR_RGB = ["gbrp", "gbrp9le", "gbrp10le", "gbrp12le", "gbrp14le", "gbrp16le", "gbrpf32le"]
 GRAYS = ["gray8", "gray9le", "gray10le", "gray12le", "gray14le", "gray16le"]
 RGB16 = ["rgb48le", "bgr48le", "rgba64le", "bgra64le"]
-FORMAT_MATRIX_SRC = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
-FORMAT_MATRIX_DST = YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+BIG_ENDIAN = ["yuv420p10be", "yuv422p12be", "yuv444p16be", "yuv440p10be", "p010be", "p416be", "gbrp12be", "gbrp16be", "gray10be", "gray16be",
+              "rgb48be", "bgr48be", "rgba64be", "bgra64be", "gbrpf32be"]
+FORMAT_MATRIX_SRC = BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+FORMAT_MATRIX_DST = BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
 
 
 @pytest.mark.parametrize("sfmt", FORMAT_MATRIX_SRC)
@@ -160,6 +162,9 @@ def _slice_ptrs(frame, fmt, y0):
 
 
 SLICED_UNSCALED = [
+    ("yuv420p10be", "yuv420p10le", 0), ("yuv420p12le", "yuv420p12be", 0), ("yuv420p10be", "yuv420p", 0), ("yuv444p", "yuv444p16be", 0),
+    ("rgb48be", "bgr48le", 0), ("rgba64le", "rgb48be", 0), ("gbrp10be", "rgb48le", 0), ("rgb48le", "gbrp12be", 0), ("gray16be", "gray16le", 0),
+    ("p010be", "p010le", 0),
     ("yuv420p", "rgb24", BX), ("yuv422p", "bgra", BX), ("yuv420p", "gbrp", BX), ("yuv420p", "nv12", BX), ("nv21", "yuv420p", BX),
     ("yuv444p", "nv24", BX), ("nv42", "yuv444p", BX), ("nv24", "yuv420p", BX), ("yuv420p10le", "p010le", BX), ("yuv420p", "p016le", BX),
     ("yuv420p12le", "p016le", BX), ("yuv444p10le", "yuv444p", BX), ("yuv420p", "yuv420p16le", BX), ("yuv422p16le", "yuv422p10le", BX),

@@ -17,7 +17,11 @@ SCOPE = ["bgr24", "nv12", "rgb24", "rgb32", "yuv420p", "yuv422p", "yuv444p", "yu
          "nv16", "nv24", "yuv410p", "yuv411p", "yuv440p", "yuvj422p", "yuvj440p", "yuvj444p",
          "yuv422p10le", "yuv440p10le", "yuv420p12le", "yuv422p12le", "yuv440p12le", "yuv444p12le", "yuv422p16le",
          "p210le", "p410le", "p012le", "p212le", "p412le", "p016le", "p216le", "p416le",
-         "gbrp10le", "gbrp12le", "gbrp16le", "gray", "gray10le", "gray12le", "gray16le", "yuyv422", "yvyu422", "uyvy422", "rgb48"]
+         "gbrp10le", "gbrp12le", "gbrp16le", "gray", "gray10le", "gray12le", "gray16le", "yuyv422", "yvyu422", "uyvy422", "rgb48",
+         # big-endian twins
+         "yuv420p10be", "yuv420p12be", "yuv420p16be", "yuv422p10be", "yuv422p12be", "yuv422p16be", "yuv440p10be", "yuv440p12be",
+         "yuv444p10be", "yuv444p12be", "yuv444p16be", "gbrp10be", "gbrp12be", "gbrp16be", "gray10be", "gray12be", "gray16be",
+         "p010be", "p012be", "p016be", "p210be", "p212be", "p216be", "p410be", "p412be", "p416be"]
 BASES = ["", "yuv444p-", "rgb24-", "yuv444p10-", "yuv444p12-", "yuv444p16-", "nv24-", "p410-", "p412-", "p416-",
          "gbrp-", "gbrp10-", "gbrp12-", "gbrp16-", "rgb48-"]
 
