@@ -75,6 +75,9 @@ enum AVPixelFormat {
     AV_PIX_FMT_GBRP14LE = 137,
     /* NEW: hardware surface format of the HIP hwcontext slot; appended after the
      * reference's last format (AV_PIX_FMT_NB == 268, libavutil/pixfmt.h) */
+    /* 16 bits per pixel packed RGB (ordered-dither writers, output.c:1714-1748) */
+    AV_PIX_FMT_RGB565BE = 36, AV_PIX_FMT_RGB565LE = 37, AV_PIX_FMT_RGB555BE = 38, AV_PIX_FMT_RGB555LE = 39, AV_PIX_FMT_BGR565BE = 40, AV_PIX_FMT_BGR565LE = 41,
+    AV_PIX_FMT_BGR555BE = 42, AV_PIX_FMT_BGR555LE = 43, AV_PIX_FMT_RGB444LE = 52, AV_PIX_FMT_RGB444BE = 53, AV_PIX_FMT_BGR444LE = 54, AV_PIX_FMT_BGR444BE = 55,
     /* big-endian twins of the 16-bit / float formats above (converted through the little-endian twin + a byte-swap pass) */
     AV_PIX_FMT_YUV420P9BE = 59, AV_PIX_FMT_YUV420P10BE = 61, AV_PIX_FMT_YUV420P12BE = 122, AV_PIX_FMT_YUV420P14BE = 124,
     AV_PIX_FMT_YUV420P16BE = 46, AV_PIX_FMT_YUV422P9BE = 69, AV_PIX_FMT_YUV422P10BE = 63, AV_PIX_FMT_YUV422P12BE = 126,

@@ -108,6 +108,12 @@ static bool fmt_supported_out(int f)
     return pix_desc(f) != nullptr || pix_be_twin(f) >= 0;
 }
 
+static bool isRGB16fmt(int f)
+{
+    return f == AV_PIX_FMT_RGB565LE || f == AV_PIX_FMT_RGB555LE || f == AV_PIX_FMT_RGB444LE || f == AV_PIX_FMT_BGR565LE || f == AV_PIX_FMT_BGR555LE ||
+           f == AV_PIX_FMT_BGR444LE;
+}
+
 // ff_get_unscaled_swscale (swscale_unscaled.c:2392-2706): "last match wins"
 void choose_unscaled(SwsInternal *c)
 {
@@ -125,6 +131,7 @@ void choose_unscaled(SwsInternal *c)
         // it returns NULL for gbrp9..16 / gbrpf32 and the scaler chain is used
         if (!isPlanarRGB(d) && pix_desc(d)->comp[0].depth == 8) k = PLAN_UNSC_YUV2RGB;
         else if (d == AV_PIX_FMT_RGB48LE || d == AV_PIX_FMT_BGR48LE) k = PLAN_UNSC_YUV2RGB48;
+        else if (isRGB16fmt(d)) k = PLAN_UNSC_YUV2RGB16;   // yuv2rgb_c_16/15/12_ordered_dither, yuv422p_bgr16/15/12 (yuv2rgb.c:612-640)
         else if (d == AV_PIX_FMT_GBRP) k = PLAN_UNSC_YUV2GBRP;
         c->dst_slice_align = 2;
     }
@@ -144,6 +151,24 @@ void choose_unscaled(SwsInternal *c)
         pix_desc(s)->comp[0].depth == 8 && pix_desc(d)->comp[0].depth == 8) {
         const bool s32 = pix_desc(s)->comp[0].step == 4;
         if (!(!s32 && (d == AV_PIX_FMT_BGRA || d == AV_PIX_FMT_RGBA) && (flags & SWS_BITEXACT))) k = PLAN_UNSC_RGB2RGB;
+    }
+    if (isAnyRGB(s) && isAnyRGB(d) && !isPlanarRGB(s) && !isPlanarRGB(d) && (isRGB16fmt(s) || isRGB16fmt(d))) {
+        // findRgbConvFn's two switch tables (:1941-1979) on (srcFormatBpp, dstFormatBpp), for formats of the same / of opposite channel
+        // order "in int"; rgbToRgbWrapper only without dither need or with FAST_BILINEAR / POINT (:2400-2403, :2459-2463)
+        const int sid = pix_bits_per_pixel(pix_desc(s)), did = pix_bits_per_pixel(pix_desc(d));
+        auto rgbint = [](int f) { return f == AV_PIX_FMT_RGB24 || f == AV_PIX_FMT_BGRA || f == AV_PIX_FMT_ABGR || f == AV_PIX_FMT_RGB565LE ||
+                                         f == AV_PIX_FMT_RGB555LE || f == AV_PIX_FMT_RGB444LE; };
+        const bool needsDither = did < 24 && did < sid;
+        bool have;
+        if (rgbint(s) == rgbint(d))
+            have = (did == 15 && (sid == 12 || sid == 16 || sid == 24 || sid == 32)) || (did == 16 && (sid == 15 || sid == 24 || sid == 32)) ||
+                   (did == 24 && (sid == 15 || sid == 16)) || (did == 32 && (sid == 15 || sid == 16));
+        else
+            have = (did == 12 && sid == 12) || (did == 15 && (sid == 15 || sid == 16 || sid == 24 || sid == 32)) ||
+                   (did == 16 && (sid == 15 || sid == 16 || sid == 24 || sid == 32)) || (did == 24 && (sid == 15 || sid == 16)) ||
+                   (did == 32 && (sid == 15 || sid == 16));
+        if ((d == AV_PIX_FMT_BGRA || d == AV_PIX_FMT_RGBA) && (flags & SWS_BITEXACT)) have = false;   // :1991-1994
+        if (have && (!needsDither || (flags & (SWS_FAST_BILINEAR | SWS_POINT)))) k = PLAN_UNSC_RGBLOW;
     }
     {   // 16-bit packed RGB: findRgbConvFn rows (:1869-1911), Rgb16ToPlanarRgb16Wrapper (:2488-2507), planarRgb16ToRgb16Wrapper (:2514-2533)
         const bool s48 = s == AV_PIX_FMT_RGB48LE || s == AV_PIX_FMT_BGR48LE, s64 = s == AV_PIX_FMT_RGBA64LE || s == AV_PIX_FMT_BGRA64LE;
@@ -236,6 +261,9 @@ int init_single_context(SwsInternal *c)
     }
     if (o->dither == SWS_DITHER_AUTO && (flags & SWS_ERROR_DIFFUSION)) o->dither = SWS_DITHER_ED; // :1288-1291
     if (isPlanarRGB(dstFormat) && !(flags & SWS_FULL_CHR_H_INT)) { flags |= SWS_FULL_CHR_H_INT; o->flags = flags; }
+    if ((flags & SWS_FULL_CHR_H_INT) && isRGB16fmt(dstFormat)) {   // "full chroma interpolation ... not yet implemented" (:1325-1358)
+        flags &= ~SWS_FULL_CHR_H_INT; o->flags = flags;
+    }
     if (isAnyRGB(dstFormat) && !(flags & SWS_FULL_CHR_H_INT)) c->chrDstHSubSample = 1;         // :1359-1360
 
     if (flags & SWS_SRC_V_CHR_DROP_MASK) {

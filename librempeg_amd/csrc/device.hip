@@ -102,6 +102,7 @@ static int src_kind_of(int f)
     if (!d) return -1;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? SRCK_GBRPF32 : d->comp[0].depth > 8 ? SRCK_GBRP16 : SRCK_GBRP;
     if (isAnyRGB(f) && d->comp[0].depth == 16) return SRCK_RGB48;
+    if (isAnyRGB(f) && d->comp[0].step == 2) return SRCK_RGB16;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? SRCK_RGB24 : SRCK_RGB32;
     if (isYUV(f) && isPackedFmt(f)) return SRCK_PACKED422;
     if (isSemiPlanarYUV(f)) return d->comp[0].depth == 8 ? SRCK_NV12 : SRCK_P010;
@@ -114,6 +115,7 @@ static int dst_kind_of(int f)
     if (!d) return -1;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? DSTK_GBRPF32 : d->comp[0].depth == 16 ? DSTK_GBRP16 : DSTK_GBRP;
     if (isAnyRGB(f) && d->comp[0].depth == 16) return DSTK_RGB48;
+    if (isAnyRGB(f) && d->comp[0].step == 2) return DSTK_RGB16;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? DSTK_RGB24 : DSTK_RGB32;
     if (isYUV(f) && isPackedFmt(f)) return DSTK_PACKED422;
     const int depth = d->comp[0].depth;
@@ -167,6 +169,17 @@ int dev_prepare(SwsInternal *c)
         p.src_pix_step = ds->comp[0].step;
         p.src_r_pos = ds->comp[0].offset; p.src_g_pos = ds->comp[1].offset; p.src_b_pos = ds->comp[2].offset;
     }
+    if (p.srcKind == SRCK_RGB16) {   // RGB16_32FUNCS rows of input.c:396-401
+        switch (o.src_format) {
+        case AV_PIX_FMT_BGR565LE: p.s16_maskr = 0x001F; p.s16_maskg = 0x07E0; p.s16_maskb = 0xF800; p.s16_rsh = 11; p.s16_gsh = 5; p.s16_bsh = 0; p.s16_S = 15 + 8; break;
+        case AV_PIX_FMT_BGR555LE: p.s16_maskr = 0x001F; p.s16_maskg = 0x03E0; p.s16_maskb = 0x7C00; p.s16_rsh = 10; p.s16_gsh = 5; p.s16_bsh = 0; p.s16_S = 15 + 7; break;
+        case AV_PIX_FMT_BGR444LE: p.s16_maskr = 0x000F; p.s16_maskg = 0x00F0; p.s16_maskb = 0x0F00; p.s16_rsh = 8; p.s16_gsh = 4; p.s16_bsh = 0; p.s16_S = 15 + 4; break;
+        case AV_PIX_FMT_RGB565LE: p.s16_maskr = 0xF800; p.s16_maskg = 0x07E0; p.s16_maskb = 0x001F; p.s16_rsh = 0; p.s16_gsh = 5; p.s16_bsh = 11; p.s16_S = 15 + 8; break;
+        case AV_PIX_FMT_RGB555LE: p.s16_maskr = 0x7C00; p.s16_maskg = 0x03E0; p.s16_maskb = 0x001F; p.s16_rsh = 0; p.s16_gsh = 5; p.s16_bsh = 10; p.s16_S = 15 + 7; break;
+        default:                  p.s16_maskr = 0x0F00; p.s16_maskg = 0x00F0; p.s16_maskb = 0x000F; p.s16_rsh = 0; p.s16_gsh = 4; p.s16_bsh = 8; p.s16_S = 15 + 4; break;
+        }
+        p.s16_is565 = o.src_format == AV_PIX_FMT_RGB565LE || o.src_format == AV_PIX_FMT_BGR565LE;
+    }
     p.chr_half = isAnyRGB(o.src_format) && c->chrSrcHSubSample;
     std::memcpy(p.rgb2yuv, c->rgb2yuv, sizeof(p.rgb2yuv));
     p.src_range = o.src_range;
@@ -194,6 +207,14 @@ int dev_prepare(SwsInternal *c)
         L.alpha_or = isALPHA(o.src_format) ? 0u : (255u << ((base + 24) & 31));
         L.a_shift = (base + 24) & 31;
         L.rgb_order = df == AV_PIX_FMT_BGR24 ? 1 : 0;
+        if (p.dstKind == DSTK_RGB16) {   // yuv2rgb.c:853-897 (isRgb: the RGB565 / RGB555 / RGB444 orders, R in the high bits)
+            const int bpp = pix_bits_per_pixel(dd);
+            const bool rgb16 = df == AV_PIX_FMT_RGB565LE || df == AV_PIX_FMT_RGB555LE || df == AV_PIX_FMT_RGB444LE;
+            L.bpp16 = bpp;
+            L.r16 = bpp == 12 ? (rgb16 ? 8 : 0) : (rgb16 ? bpp - 5 : 0);
+            L.g16 = bpp == 12 ? 4 : 5;
+            L.b16 = bpp == 12 ? (rgb16 ? 0 : 8) : (rgb16 ? 0 : bpp - 5);
+        }
         {   // 32 bpp wave kernels pack bytes as {c0, g, c2, 255} with c0 = R (or B when swap_rb32) and then permute:
             // rgba: R,G,B,A  bgra: B,G,R,A (swap)  argb: A,R,G,B  abgr: A,B,G,R (swap).  v_perm_b32(px, px, sel):
             // result byte i = source byte sel[i] (0..3 select from the second operand = px).
@@ -586,6 +607,8 @@ int dev_prepare(SwsInternal *c)
     case PLAN_UNSC_PACKED16_GBRP16: c->path_name = "unscaled:Rgb16ToPlanarRgb16"; c->kernel_name = "sws_k_rgb16_convert"; break;
     case PLAN_UNSC_GBRP16_PACKED16: c->path_name = "unscaled:planarRgb16ToRgb16"; c->kernel_name = "sws_k_rgb16_convert"; break;
     case PLAN_UNSC_YUV2RGB48: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb48_unscaled"; break;
+    case PLAN_UNSC_YUV2RGB16: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb16_unscaled"; break;
+    case PLAN_UNSC_RGBLOW: c->path_name = "unscaled:rgbToRgb"; c->kernel_name = "sws_k_rgb_low_convert"; break;
     case PLAN_UNSC_PLANAR2P422: c->path_name = "unscaled:planarToYuy2"; c->kernel_name = "sws_k_planar_to_p422"; break;
     case PLAN_UNSC_P4222PLANAR: c->path_name = "unscaled:yuyvToPlanar"; c->kernel_name = "sws_k_p422_to_planar"; break;
     case PLAN_CASCADE: c->path_name = "cascade"; c->kernel_name = ""; break;
@@ -915,6 +938,29 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
         hipLaunchKernelGGL(swsk::sws_k_yuv2rgb48_unscaled, grid, blk, 0, st, fs, p, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 0, npairs, sliceY);
         break;
     }
+    case PLAN_UNSC_YUV2RGB16: {
+        const int dstW = p.dstW;
+        const int npairs = ((dstW >> 3) << 2) + ((dstW & 4) ? 2 : 0) + ((dstW & 2) ? 1 : 0); // yuv2rgb.c:198-236
+        const int nrowpairs = (sliceH + 1) >> 1;
+        if (!npairs || !nrowpairs) break;
+        const dim3 grid(cdiv(npairs, 256), nrowpairs, n);
+        hipLaunchKernelGGL(swsk::sws_k_yuv2rgb16_unscaled, grid, blk, 0, st, fs, p, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 0, npairs, sliceY);
+        break;
+    }
+    case PLAN_UNSC_RGBLOW: {
+        const int sf = c->opts.src_format, df = c->opts.dst_format;
+        auto rgbint = [](int f) { return f == AV_PIX_FMT_RGB24 || f == AV_PIX_FMT_BGRA || f == AV_PIX_FMT_ABGR || f == AV_PIX_FMT_RGB565LE ||
+                                         f == AV_PIX_FMT_RGB555LE || f == AV_PIX_FMT_RGB444LE; };
+        swsk::RgbLowPlan rp;
+        rp.sid = pix_bits_per_pixel(pix_desc(sf)); rp.did = pix_bits_per_pixel(pix_desc(df));
+        rp.same = rgbint(sf) == rgbint(df) ? 1 : 0;
+        rp.s_alt = (sf == AV_PIX_FMT_ABGR || sf == AV_PIX_FMT_ARGB) ? 1 : 0;
+        rp.d_alt = (df == AV_PIX_FMT_ABGR || df == AV_PIX_FMT_ARGB) ? 1 : 0;
+        if (!p.srcW || !sliceH) break;
+        const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
+        hipLaunchKernelGGL(swsk::sws_k_rgb_low_convert, grid, blk, 0, st, fs, rp, p.srcW, sliceY);
+        break;
+    }
     case PLAN_UNSC_PLANAR2P422: {
         const int npairs = p.srcW >> 1;
         if (!npairs || !sliceH) break;
@@ -966,7 +1012,7 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
             hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.dstW, 0);
         }
         const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 ||
-                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_RGB48;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
+                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_RGB48 || p.dstKind == DSTK_RGB16;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
         if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;
@@ -1376,7 +1422,7 @@ static int run_single(SwsInternal *c, const uint8_t *const src[4], const int src
         if (r < 0) return r;
         for (int k = 0; k < npd; k++) { fr.dst[k] = (uint8_t *)d->stage_dst + doffs[k]; fr.dstStride[k] = dls[k]; }
         // converters that leave pixels untouched (odd widths in yuv2rgb.c) must preserve the caller's data
-        if ((c->plan == PLAN_UNSC_YUV2RGB || c->plan == PLAN_UNSC_YUV2GBRP || c->plan == PLAN_UNSC_YUV2RGB48) && (o.dst_w & 1)) {
+        if ((c->plan == PLAN_UNSC_YUV2RGB || c->plan == PLAN_UNSC_YUV2GBRP || c->plan == PLAN_UNSC_YUV2RGB48 || c->plan == PLAN_UNSC_YUV2RGB16) && (o.dst_w & 1)) {
             for (int k = 0; k < npd; k++) {
                 int rb, prow; plane_geometry(o.dst_format, o.dst_w, o.dst_h, k, &rb, &prow);
                 int y0, rows; rows_of_slice(o.dst_format, k, outY, outH, &y0, &rows);

@@ -70,6 +70,29 @@ __device__ __forceinline__ uint32_t lut_rgb32(const SwsLutParams &L, const Chrom
            ((uint32_t)lut_luma(L, k.b + Y) << L.bshift) | L.alpha_or;
 }
 
+// 12/15/16 bpp pixel from the three luma-table indices (yuv2rgb.c:853-897: y_table16 planes, summed by yuv2rgb_write)
+__device__ __forceinline__ uint32_t lut_rgb16(const SwsLutParams &L, int ir, int ig, int ib)
+{
+    const int r = lut_luma(L, ir), g = lut_luma(L, ig), b = lut_luma(L, ib);
+    if (L.bpp16 == 12) return (uint32_t)(((r >> 4) << L.r16) | ((g >> 4) << L.g16) | ((b >> 4) << L.b16));
+    return (uint32_t)(((r >> 3) << L.r16) | ((g >> (18 - L.bpp16)) << L.g16) | ((b >> 3) << L.b16));
+}
+// ordered dither of the 12/15/16 bpp writers (output.c:40-58 ff_dither_2x2_4 / 2x2_8 / 4x4_16), row r, column c
+__device__ __forceinline__ int dither_2x2_4(int r, int c) { return (r & 1) ? ((c & 1) ? 0 : 2) : ((c & 1) ? 3 : 1); }
+__device__ __forceinline__ int dither_2x2_8(int r, int c) { return (r & 1) ? ((c & 1) ? 4 : 0) : ((c & 1) ? 2 : 6); }
+__device__ __forceinline__ int dither_4x4_16(int r, int c)
+{
+    const uint32_t rows[4] = { 0x070b0408u, 0x0d010e02u, 0x0509060au, 0x0f030c00u };   // { 8,4,11,7 }, { 2,14,1,13 }, { 10,6,9,5 }, { 0,12,3,15 }
+    return (int)((rows[r & 3] >> (8 * (c & 3))) & 0xff);
+}
+// yuv2rgb_write (output.c:1721-1745): dither of channel ch (0 r, 1 g, 2 b) for the pixel of parity e in destination row y
+__device__ __forceinline__ int dither_rgb16_main(int bpp, int y, int e, int ch)
+{
+    if (bpp == 16) return ch == 0 ? dither_2x2_8(y, e) : ch == 1 ? dither_2x2_4(y, e) : dither_2x2_8(y ^ 1, e);
+    if (bpp == 15) return ch == 0 ? dither_2x2_8(y, e) : ch == 1 ? dither_2x2_8(y, e ^ 1) : dither_2x2_8(y ^ 1, e);
+    return ch == 0 ? dither_4x4_16(y, e) : ch == 1 ? dither_4x4_16(y, e ^ 1) : dither_4x4_16(y ^ 3, e);
+}
+
 // ordered-dither rows (swscale.c:42-52 ff_dither_8x8_128, :54 sws_pb_64)
 __device__ __constant__ const uint8_t k_dither_8x8_128[8][8] = {
     {  36, 68,  60, 92,  34, 66,  58, 90 }, { 100,  4, 124, 28,  98,  2, 122, 26 },

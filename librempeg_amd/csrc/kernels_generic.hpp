@@ -79,6 +79,26 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         const unsigned rnd = (256u << (S - 1)) + (1 << (S - 7));
         return (uint16_t)((unsigned)(cr * r + cg * g + cb * b + rnd) >> (S - 6));
     }
+    case SRCK_RGB16: { // rgb16_32ToY/UV/UV_half_c_template with the 16 bpp rows (input.c:264-372, :396-401): masks on the unshifted pixel
+        const int srow = comp == 0 ? row : (row << p.chrSrcVSub);
+        const uint16_t *s = (const uint16_t *)(f.src[0] + (int64_t)srow * f.srcStride[0]);
+        const int32_t *t = p.rgb2yuv;
+        const int S = p.s16_S, o = comp == 0 ? 0 : comp == 1 ? 3 : 6;
+        const int cr = t[o] * (1 << p.s16_rsh), cg = t[o + 1] * (1 << p.s16_gsh), cb = t[o + 2] * (1 << p.s16_bsh);
+        if (comp != 0 && p.chr_half) {
+            const unsigned maskgx = ~(unsigned)(p.s16_maskr | p.s16_maskb);
+            const unsigned px0 = s[2 * x], px1 = s[2 * x + 1];
+            int g = (int)((px0 & maskgx) + (px1 & maskgx));
+            const int rb = (int)(px0 + px1) - g;
+            const int b = rb & (p.s16_maskb | (p.s16_maskb << 1)), r = rb & (p.s16_maskr | (p.s16_maskr << 1));
+            if (!p.s16_is565) g &= p.s16_maskg | (p.s16_maskg << 1);
+            const unsigned rnd = (256U << S) + (1u << (S - 6));
+            return (uint16_t)((unsigned)(cr * r + cg * g + cb * b + rnd) >> (S - 6 + 1));
+        }
+        const int px = s[x], b = px & p.s16_maskb, g = px & p.s16_maskg, r = px & p.s16_maskr;
+        const unsigned rnd = ((comp == 0 ? 32u : 256u) << (S - 1)) + (1u << (S - 7));
+        return (uint16_t)((unsigned)(cr * r + cg * g + cb * b + rnd) >> (S - 6));
+    }
     case SRCK_GBRP: { // planar_rgb_to_y / planar_rgb_to_uv input.c:1174-1211; gbr24pToUV_half_c :414-432
         const uint8_t *G = f.src[0] + (int64_t)row * f.srcStride[0], *B = f.src[1] + (int64_t)row * f.srcStride[1],
                       *R = f.src[2] + (int64_t)row * f.srcStride[2];
@@ -528,6 +548,13 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
             }
             d[2 * i] = lut_rgb32(L, k, Y1) + a1;
             d[2 * i + 1] = lut_rgb32(L, k, Y2) + a2;
+        } else if (p.dstKind == DSTK_RGB16) {   // yuv2rgb_write, 12/15/16 bpp: ordered dither on the luma index (output.c:1714-1748)
+            uint16_t *d = (uint16_t *)drow;
+            const int bpp = L.bpp16;
+            d[2 * i] = (uint16_t)lut_rgb16(L, k.r + Y1 + dither_rgb16_main(bpp, y, 0, 0), k.g + Y1 + dither_rgb16_main(bpp, y, 0, 1),
+                                           k.b + Y1 + dither_rgb16_main(bpp, y, 0, 2));
+            d[2 * i + 1] = (uint16_t)lut_rgb16(L, k.r + Y2 + dither_rgb16_main(bpp, y, 1, 0), k.g + Y2 + dither_rgb16_main(bpp, y, 1, 1),
+                                               k.b + Y2 + dither_rgb16_main(bpp, y, 1, 2));
         } else {
             uint8_t *d = drow + 6 * i;
             const int k0 = L.rgb_order ? k.b : k.r, k2 = L.rgb_order ? k.r : k.b;

@@ -264,6 +264,88 @@ __global__ void __launch_bounds__(256) sws_k_yuv2rgb48_unscaled(SwsFrameSet fs, 
     }
 }
 
+// yuv2rgb_c_16/15/12_ordered_dither and yuv422p_bgr16/15/12 (YUV420FUNC_DITHER / YUV422FUNC_DITHER + PUTRGB16/15/12,
+// yuv2rgb.c:283-330, :371-411).  One thread = one chroma sample = 2 pixels x 2 rows.  The dither row is selected by the loop's
+// slice-relative even row (always table row 0 / 1 for the 2x2 tables, row (y & 3) (+1 for the second line) of the 4x4 table).
+__global__ void __launch_bounds__(256) sws_k_yuv2rgb16_unscaled(SwsFrameSet fs, SwsDevParams p, int is422, int npairs, int sliceY)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const SwsLutParams &L = p.lut;
+    const int yrow = 2 * blockIdx.y, bpp = L.bpp16, o = 2 * (i & 3);
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const int yy = yrow + l;
+        const int cr = is422 ? sliceY + yy : ((sliceY + yrow) >> 1);
+        const int U = f.src[1][(int64_t)cr * f.srcStride[1] + i], V = f.src[2][(int64_t)cr * f.srcStride[2] + i];
+        const ChromaIdx k = lut_chroma(L, U, V);
+        const uint8_t *py = f.src[0] + (int64_t)(sliceY + yy) * f.srcStride[0] + 2 * i;
+        uint16_t *d = (uint16_t *)(f.dst[0] + (int64_t)(sliceY + yy) * f.dstStride[0]) + 2 * i;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int Y = py[e];
+            int dr, dg, db;
+            if (bpp == 16) { dr = dither_2x2_8(l, o + e); dg = dither_2x2_4(l, o + e); db = dither_2x2_8(1 + l, o + e); }
+            else if (bpp == 15) { dr = dither_2x2_8(l, o + e); dg = dither_2x2_8(l, o + (e ^ 1)); db = dither_2x2_8(1 + l, o + e); }
+            else { dr = dg = db = dither_4x4_16((yrow & 3) + l, o + e); }
+            d[e] = (uint16_t)lut_rgb16(L, k.r + Y + dr, k.g + Y + dg, k.b + Y + db);
+        }
+    }
+}
+
+// rgbToRgbWrapper with the 12/15/16 bpp converters of rgb2rgb.c:179-320 and rgb2rgb_template.c:85-316: bit-field shuffles in "int"
+// order (a 16-bit pixel has a high, a middle and a low field; a 24/32 bpp pixel three bytes in memory order, after the alpha byte
+// for the _1 layouts).  same = both formats have the same channel order "in int" (findRgbConvFn's first switch), else the second.
+struct RgbLowPlan { int32_t sid, did, same, s_alt, d_alt; };
+__global__ void __launch_bounds__(256) sws_k_rgb_low_convert(SwsFrameSet fs, RgbLowPlan rp, int w, int sliceY)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= w) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int y = sliceY + blockIdx.y;
+    const uint8_t *sp = f.src[0] + (int64_t)y * f.srcStride[0] + (rp.s_alt ? 1 : 0);
+    uint8_t *dp = f.dst[0] + (int64_t)y * f.dstStride[0];
+    const int sid = rp.sid, did = rp.did;
+    const bool same = rp.same != 0;
+    unsigned px = 0, b0 = 0, b1 = 0, b2 = 0;
+    if (sid <= 16) px = ((const uint16_t *)sp)[x];
+    else { const uint8_t *q = sp + (sid == 24 ? 3 : 4) * x; b0 = q[0]; b1 = q[1]; b2 = q[2]; }
+    if (did <= 16) {
+        unsigned out;
+        if (sid == 12 && did == 15) {                                   // rgb12to15
+            unsigned r = px & 0xF00, g = px & 0x0F0, b = px & 0x00F;
+            r = (r << 3) | ((r & 0x800) >> 1); g = (g << 2) | ((g & 0x080) >> 2); b = (b << 1) | (b >> 3);
+            out = r | g | b;
+        } else if (sid == 12) out = (px << 8 | (px & 0xF0) | px >> 8) & 0xFFF;                                              // rgb12tobgr12
+        else if (sid == 15 && did == 16) out = same ? (px & 0x7FFF) + (px & 0x7FE0) : ((px & 0x7C00) >> 10) | ((px & 0x3E0) << 1) | (px << 11);   // rgb15to16 / rgb15tobgr16
+        else if (sid == 16 && did == 15) out = same ? ((px >> 1) & 0x7FE0) | (px & 0x001F) : (px >> 11) | ((px & 0x7C0) >> 1) | ((px & 0x1F) << 10); // rgb16to15 / rgb16tobgr15
+        else if (sid == 16 && did == 16) out = (px >> 11) | (px & 0x7E0) | (px << 11);                                      // rgb16tobgr16
+        else if (sid == 15 && did == 15) { const unsigned br = px & 0x7C1F; out = (br >> 10) | (px & 0x3E0) | (br << 10); }  // rgb15tobgr15
+        else if (sid == 24) {                                           // rgb24to16/15 (first byte -> high field), rgb24tobgr16/15 (first byte -> low field)
+            const unsigned hi = same ? b0 : b2, lo = same ? b2 : b0;
+            out = did == 16 ? (lo >> 3) | ((b1 & 0xFC) << 3) | ((hi & 0xF8) << 8) : (lo >> 3) | ((b1 & 0xF8) << 2) | ((hi & 0xF8) << 7);
+        } else {                                                        // rgb32to16/15 (byte 0 -> low field), rgb32tobgr16/15 (byte 0 -> high field)
+            const unsigned lo = same ? b0 : b2, hi = same ? b2 : b0;
+            out = did == 16 ? (lo >> 3) + ((b1 & 0xFC) << 3) + ((hi & 0xF8) << 8) : (lo >> 3) + ((b1 & 0xF8) << 2) + ((hi & 0xF8) << 7);
+        }
+        ((uint16_t *)dp)[x] = (uint16_t)out;
+    } else {
+        unsigned hi8, mid8, lo8;
+        if (sid == 16) { hi8 = ((px & 0xF800) >> 8) | ((px & 0xF800) >> 13); mid8 = ((px & 0x07E0) >> 3) | ((px & 0x07E0) >> 9); lo8 = ((px & 0x001F) << 3) | ((px & 0x001F) >> 2); }
+        else           { hi8 = ((px & 0x7C00) >> 7) | ((px & 0x7C00) >> 12); mid8 = ((px & 0x03E0) >> 2) | ((px & 0x03E0) >> 7); lo8 = ((px & 0x001F) << 3) | ((px & 0x001F) >> 2); }
+        if (did == 24) {                                                // rgb16to24 / rgb15to24: high field first; ...tobgr24: low field first
+            uint8_t *q = dp + 3 * x;
+            q[0] = (uint8_t)(same ? hi8 : lo8); q[1] = (uint8_t)mid8; q[2] = (uint8_t)(same ? lo8 : hi8);
+        } else {                                                        // rgb16to32 / rgb15to32: low field first; ...tobgr32: high field first; opaque alpha
+            uint8_t *q = dp + 4 * x;
+            const unsigned o0 = same ? lo8 : hi8, o2 = same ? hi8 : lo8;
+            if (rp.d_alt) { q[0] = 255; q[1] = (uint8_t)o0; q[2] = (uint8_t)mid8; q[3] = (uint8_t)o2; }
+            else          { q[0] = (uint8_t)o0; q[1] = (uint8_t)mid8; q[2] = (uint8_t)o2; q[3] = 255; }
+        }
+    }
+}
+
 // bgr24ToYv12Wrapper (swscale_unscaled.c:2062-2078) -> ff_rgb24toyv12_c (rgb2rgb_template.c:580-641).
 // One thread = 4 chroma samples = 8 pixels x 2 rows: 2 x 24 bytes in, 2 x 8 luma + 4 U + 4 V bytes out.
 // All arithmetic is unsigned and the results are stored modulo 256 exactly like the reference's uint8_t stores.

@@ -63,6 +63,13 @@ static const PixDesc g_descs[] = {
     GBRN(AV_PIX_FMT_GBRP9LE, "gbrp9le", 9), GBRN(AV_PIX_FMT_GBRP10LE, "gbrp10le", 10), GBRN(AV_PIX_FMT_GBRP12LE, "gbrp12le", 12),
     GBRN(AV_PIX_FMT_GBRP14LE, "gbrp14le", 14), GBRN(AV_PIX_FMT_GBRP16LE, "gbrp16le", 16),
     { AV_PIX_FMT_GBRPF32LE,"gbrpf32le",3, 0, 0, {{2,4,0,0,32},{0,4,0,0,32},{1,4,0,0,32},{0,0,0,0,0}}, PIXFLAG_PLANAR | PIXFLAG_RGB | PIXFLAG_FLOAT },
+    // 16 bits per pixel packed RGB (libavutil/pixdesc.c:1229-1420)
+    { AV_PIX_FMT_RGB565LE, "rgb565le", 3, 0, 0, {{0,2,1,3,5},{0,2,0,5,6},{0,2,0,0,5},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_RGB555LE, "rgb555le", 3, 0, 0, {{0,2,1,2,5},{0,2,0,5,5},{0,2,0,0,5},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_RGB444LE, "rgb444le", 3, 0, 0, {{0,2,1,0,4},{0,2,0,4,4},{0,2,0,0,4},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_BGR565LE, "bgr565le", 3, 0, 0, {{0,2,0,0,5},{0,2,0,5,6},{0,2,1,3,5},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_BGR555LE, "bgr555le", 3, 0, 0, {{0,2,0,0,5},{0,2,0,5,5},{0,2,1,2,5},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_BGR444LE, "bgr444le", 3, 0, 0, {{0,2,0,0,4},{0,2,0,4,4},{0,2,1,0,4},{0,0,0,0,0}}, PIXFLAG_RGB },
 };
 
 const PixDesc *pix_desc(int fmt)
@@ -127,6 +134,8 @@ bool isDataInHighBits(int f)
 int pix_be_twin(int fmt)
 {
     static const int pairs[][2] = {
+    { AV_PIX_FMT_RGB565BE, AV_PIX_FMT_RGB565LE }, { AV_PIX_FMT_RGB555BE, AV_PIX_FMT_RGB555LE }, { AV_PIX_FMT_RGB444BE, AV_PIX_FMT_RGB444LE },
+    { AV_PIX_FMT_BGR565BE, AV_PIX_FMT_BGR565LE }, { AV_PIX_FMT_BGR555BE, AV_PIX_FMT_BGR555LE }, { AV_PIX_FMT_BGR444BE, AV_PIX_FMT_BGR444LE },
     { AV_PIX_FMT_YUV420P9BE, AV_PIX_FMT_YUV420P9LE },
     { AV_PIX_FMT_YUV420P10BE, AV_PIX_FMT_YUV420P10LE },
     { AV_PIX_FMT_YUV420P12BE, AV_PIX_FMT_YUV420P12LE },

@@ -115,7 +115,15 @@ static const Desc descs[] = {
     GBRN(ORF_GBRP9LE, "gbrp9le", 9), GBRN(ORF_GBRP10LE, "gbrp10le", 10), GBRN(ORF_GBRP12LE, "gbrp12le", 12),
     GBRN(ORF_GBRP14LE, "gbrp14le", 14), GBRN(ORF_GBRP16LE, "gbrp16le", 16),
     { ORF_GBRPF32LE, "gbrpf32le", 3, 0, 0, {{2,4,0,0,32},{0,4,0,0,32},{1,4,0,0,32}}, PF_PLANAR | PF_RGB | PF_FLOAT },
+    /* 16 bits per pixel packed RGB (libavutil/pixdesc.c:1229-1420) */
+    { ORF_RGB565LE, "rgb565le", 3, 0, 0, {{0,2,1,3,5},{0,2,0,5,6},{0,2,0,0,5}}, PF_RGB },
+    { ORF_RGB555LE, "rgb555le", 3, 0, 0, {{0,2,1,2,5},{0,2,0,5,5},{0,2,0,0,5}}, PF_RGB },
+    { ORF_RGB444LE, "rgb444le", 3, 0, 0, {{0,2,1,0,4},{0,2,0,4,4},{0,2,0,0,4}}, PF_RGB },
+    { ORF_BGR565LE, "bgr565le", 3, 0, 0, {{0,2,0,0,5},{0,2,0,5,6},{0,2,1,3,5}}, PF_RGB },
+    { ORF_BGR555LE, "bgr555le", 3, 0, 0, {{0,2,0,0,5},{0,2,0,5,5},{0,2,1,2,5}}, PF_RGB },
+    { ORF_BGR444LE, "bgr444le", 3, 0, 0, {{0,2,0,0,4},{0,2,0,4,4},{0,2,1,0,4}}, PF_RGB },
 };
+static int isRGB16(int f) { return f == ORF_RGB565LE || f == ORF_RGB555LE || f == ORF_RGB444LE || f == ORF_BGR565LE || f == ORF_BGR555LE || f == ORF_BGR444LE; }
 
 static const Desc *desc_get(int fmt)
 {
@@ -129,6 +137,8 @@ static const Desc *desc_get(int fmt)
  * writers are the LE ones behind AV_RB16 / AV_WB16: input.c:608-629, output.c output_pixel macros); converter selection follows
  * the reference's rules, which only name a byte order for planarToP01xWrapper / planar8ToP01xleWrapper (native-endian only). */
 static const int be_pairs[][2] = {
+    { ORF_RGB565BE, ORF_RGB565LE }, { ORF_RGB555BE, ORF_RGB555LE }, { ORF_RGB444BE, ORF_RGB444LE },
+    { ORF_BGR565BE, ORF_BGR565LE }, { ORF_BGR555BE, ORF_BGR555LE }, { ORF_BGR444BE, ORF_BGR444LE },
     { 59, 60 } /* yuv420p9 */,
     { 61, 62 } /* yuv420p10 */,
     { 122, 123 } /* yuv420p12 */,
@@ -224,7 +234,7 @@ enum { RY, GY, BY, RU, GU, BU, RV, GV, BV };
 #define TABLE_PLANE 2048
 
 enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
-       UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED,
+       UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_RGBLOW, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED,
        UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP,
        UNSC_PLANAR2P422, UNSC_P4222PLANAR,
        UNSC_RGB16SHUFFLE, UNSC_PACKED16_TO_GBRP16, UNSC_GBRP16_TO_PACKED16 };
@@ -562,7 +572,7 @@ static int yuv2rgb_init_tables(OrSws *c, const int inv_table[4], int fullRange,
 {
     const int df = c->o.dst_format;
     /* AV_PIX_FMT_RGB32 = BGRA, RGB32_1 = ABGR, BGR32 = RGBA, BGR32_1 = ARGB on little endian */
-    const int isRgb = df == ORF_BGRA || df == ORF_ABGR || df == ORF_BGR24;
+    const int isRgb = df == ORF_BGRA || df == ORF_ABGR || df == ORF_BGR24 || df == ORF_RGB565LE || df == ORF_RGB555LE || df == ORF_RGB444LE;
     const int bpp = c->dstFormatBpp;
     const int yoffs = (fullRange ? 384 : 326) + HEADROOM;
     int64_t crv = inv_table[0], cbu = inv_table[1], cgu = -inv_table[2], cgv = -inv_table[3];
@@ -626,6 +636,29 @@ static int yuv2rgb_init_tables(OrSws *c, const int inv_table[4], int fullRange,
             t[i] = (yval << rbase) + (needAlpha ? 0 : (255u << abase));
             t[i + TABLE_PLANE] = yval << gbase;
             t[i + 2 * TABLE_PLANE] = yval << bbase;
+            yb += cy;
+        }
+        fill_table(c->table_rV, crv, yoffs);
+        fill_table(c->table_gU, cgu, yoffs + TABLE_PLANE);
+        fill_table(c->table_bU, cbu, yoffs + 2 * TABLE_PLANE);
+        fill_gv_table(c->table_gV, cgv);
+        c->has_lut = 1;
+        break;
+    }
+    case 12: case 15: case 16: { /* yuv2rgb.c:853-897; the byte swap of the non-native-endian tables is the oracle's BE pass */
+        const int rbase = bpp == 12 ? (isRgb ? 8 : 0) : (isRgb ? bpp - 5 : 0);
+        const int gbase = bpp == 12 ? 4 : 5;
+        const int bbase = bpp == 12 ? (isRgb ? 0 : 8) : (isRgb ? 0 : bpp - 5);
+        uint16_t *t = malloc(TABLE_PLANE * 3 * 2);
+        c->yuvTable = (uint8_t *)t;
+        c->lut_elem = 2;
+        for (i = 0; i < TABLE_PLANE; i++) {
+            const unsigned yval = (uint8_t)clip_u8((int)((yb + 0x8000) >> 16));
+            if (bpp == 12) {
+                t[i] = (uint16_t)((yval >> 4) << rbase); t[i + TABLE_PLANE] = (uint16_t)((yval >> 4) << gbase); t[i + 2 * TABLE_PLANE] = (uint16_t)((yval >> 4) << bbase);
+            } else {
+                t[i] = (uint16_t)((yval >> 3) << rbase); t[i + TABLE_PLANE] = (uint16_t)((yval >> (18 - bpp)) << gbase); t[i + 2 * TABLE_PLANE] = (uint16_t)((yval >> 3) << bbase);
+            }
             yb += cy;
         }
         fill_table(c->table_rV, crv, yoffs);
@@ -826,7 +859,8 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         /* ff_yuv2rgb_get_func_ptr, yuv2rgb.c:561-678: 24/32 bpp C converters */
         /* yuv2rgb_c_24_rgb/_bgr, yuv2rgb_c_32, yuv420p_gbrp_c / yuv422p_gbrp_c; NULL (-> scaler chain) for gbrp9..16/f32 */
         if (d == ORF_RGB24 || d == ORF_BGR24 || d == ORF_RGBA || d == ORF_BGRA || d == ORF_ARGB || d == ORF_ABGR || d == ORF_GBRP ||
-            d == ORF_RGB48LE || d == ORF_BGR48LE)   /* yuv2rgb_c_48 / yuv2rgb_c_bgr48 (yuv2rgb.c:107-125, :505-508) */
+            d == ORF_RGB48LE || d == ORF_BGR48LE ||   /* yuv2rgb_c_48 / yuv2rgb_c_bgr48 (yuv2rgb.c:107-125, :505-508) */
+            isRGB16(d))                                /* yuv2rgb_c_16/15/12_ordered_dither, yuv422p_bgr16/15/12 (:533-535, :554-556, :612-640) */
             c->unscaled_kind = UNSC_YUV2RGB;
         else if (d == ORF_RGBA64LE || d == ORF_BGRA64LE) c->unscaled_kind = UNSC_NONE; /* no C converter: ff_yuv2rgb_get_func_ptr returns NULL */
     }
@@ -848,6 +882,24 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         const int s32 = desc_get(s)->c[0].step == 4;
         if (!(!s32 && (d == ORF_BGRA || d == ORF_RGBA) && (flags & OR_SWS_BITEXACT)))
             c->unscaled_kind = UNSC_RGB2RGB;
+    }
+    if (isAnyRGB(s) && isAnyRGB(d) && isPacked(s) && isPacked(d) && (isRGB16(s) || isRGB16(d))) {
+        /* findRgbConvFn's two switch tables (:1941-1979) on (srcFormatBpp, dstFormatBpp) for formats of the same / of opposite
+         * "in int" channel order; rgbToRgbWrapper only without dither need, or with FAST_BILINEAR / POINT (:2459-2463) */
+        const int sid = c->srcFormatBpp, did = c->dstFormatBpp;
+        const int s_rgbint = s == ORF_RGB24 || s == ORF_BGRA || s == ORF_ABGR || s == ORF_RGB565LE || s == ORF_RGB555LE || s == ORF_RGB444LE;
+        const int d_rgbint = d == ORF_RGB24 || d == ORF_BGRA || d == ORF_ABGR || d == ORF_RGB565LE || d == ORF_RGB555LE || d == ORF_RGB444LE;
+        const int needsDither = did < 24 && did < sid;   /* (:2400-2403), both sides are RGB here */
+        int have;
+        if (s_rgbint == d_rgbint)
+            have = (did == 15 && (sid == 12 || sid == 16 || sid == 24 || sid == 32)) || (did == 16 && (sid == 15 || sid == 24 || sid == 32)) ||
+                   (did == 24 && (sid == 15 || sid == 16)) || (did == 32 && (sid == 15 || sid == 16));
+        else
+            have = (did == 12 && sid == 12) || (did == 15 && (sid == 15 || sid == 16 || sid == 24 || sid == 32)) ||
+                   (did == 16 && (sid == 15 || sid == 16 || sid == 24 || sid == 32)) || (did == 24 && (sid == 15 || sid == 16)) ||
+                   (did == 32 && (sid == 15 || sid == 16));
+        if ((d == ORF_BGRA || d == ORF_RGBA) && (flags & OR_SWS_BITEXACT)) have = 0;   /* :1991-1994 */
+        if (have && (!needsDither || (flags & (OR_SWS_FAST_BILINEAR | OR_SWS_POINT)))) c->unscaled_kind = UNSC_RGBLOW;
     }
     {   /* 16-bit packed RGB: findRgbConvFn rows for rgb48 <-> bgr48, rgb48 -> rgba64, rgba64 -> rgb48 (:1869-1911);
          * Rgb16ToPlanarRgb16Wrapper (:2488-2507) and planarRgb16ToRgb16Wrapper (:2514-2533) */
@@ -925,6 +977,9 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
         }
     }
     if (isPlanarRGB(dstFormat) && !(flags & OR_SWS_FULL_CHR_H_INT)) { flags |= OR_SWS_FULL_CHR_H_INT; c->o.flags = flags; }
+    if ((flags & OR_SWS_FULL_CHR_H_INT) && isRGB16(dstFormat)) { /* "full chroma interpolation ... not yet implemented" (:1325-1358) */
+        flags &= ~OR_SWS_FULL_CHR_H_INT; c->o.flags = flags;
+    }
     if (isAnyRGB(dstFormat) && !(flags & OR_SWS_FULL_CHR_H_INT)) c->chrDstHSub = 1; /* :1359 */
 
     if (flags & 0x30000) return -1; /* vChrDrop not restated */
@@ -1063,8 +1118,15 @@ int or_sws_set_colorspace(OrSws *c, const int inv_table[4], int srcRange, const 
 static inline uint32_t lut_at(const OrSws *c, int idx)
 {
     if (c->lut_elem == 1) return c->yuvTable[idx];
+    if (c->lut_elem == 2) return ((const uint16_t *)c->yuvTable)[idx];
     return ((const uint32_t *)c->yuvTable)[idx];
 }
+
+/* ordered-dither rows of output.c:40-58 (ff_dither_2x2_4, ff_dither_2x2_8, ff_dither_4x4_16) */
+static const uint8_t dither_2x2_4[3][8] = { { 1, 3, 1, 3, 1, 3, 1, 3 }, { 2, 0, 2, 0, 2, 0, 2, 0 }, { 1, 3, 1, 3, 1, 3, 1, 3 } };
+static const uint8_t dither_2x2_8[3][8] = { { 6, 2, 6, 2, 6, 2, 6, 2 }, { 0, 4, 0, 4, 0, 4, 0, 4 }, { 6, 2, 6, 2, 6, 2, 6, 2 } };
+static const uint8_t dither_4x4_16[5][8] = { { 8, 4, 11, 7, 8, 4, 11, 7 }, { 2, 14, 1, 13, 2, 14, 1, 13 }, { 10, 6, 9, 5, 10, 6, 9, 5 },
+                                             { 0, 12, 3, 15, 0, 12, 3, 15 }, { 8, 4, 11, 7, 8, 4, 11, 7 } };
 
 /* YUV420FUNC/YUV422FUNC + PUTRGB24/PUTBGR24/PUTRGB, yuv2rgb.c:68-559.
  * The 8/4/2-pixel block structure of the macros reduces to: pixel pair i on
@@ -1090,7 +1152,17 @@ static int unscaled_yuv2rgb(OrSws *c, const uint8_t *const src[], const int srcS
                 int b = c->table_bU[U + HEADROOM];
                 for (int k = 0; k < 2; k++) {
                     int Y = py[2 * i + k];
-                    if (d == ORF_RGB48LE || d == ORF_BGR48LE) { /* PUTRGB48 / PUTBGR48 yuv2rgb.c:107-125: each 8-bit LUT value fills both bytes */
+                    if (isRGB16(d)) { /* YUV420FUNC_DITHER / YUV422FUNC_DITHER + PUTRGB16/15/12 (yuv2rgb.c:283-330, :371-411): the dither row is
+                                        * chosen by the loop's slice-relative even y, the second line of a pair reads the following table row */
+                        const int e = k, o = 2 * (i & 3);
+                        int dr, dg, db;
+                        uint16_t v;
+                        if (d == ORF_RGB565LE || d == ORF_BGR565LE) { dr = dither_2x2_8[l][o + e]; dg = dither_2x2_4[l][o + e]; db = dither_2x2_8[1 + l][o + e]; }
+                        else if (d == ORF_RGB555LE || d == ORF_BGR555LE) { dr = dither_2x2_8[l][o + e]; dg = dither_2x2_8[l][o + (e ^ 1)]; db = dither_2x2_8[1 + l][o + e]; }
+                        else { dr = dg = db = dither_4x4_16[(y & 3) + l][o + e]; }
+                        v = (uint16_t)(lut_at(c, r + Y + dr) + lut_at(c, g + Y + dg) + lut_at(c, b + Y + db));
+                        memcpy(out + 4 * i + 2 * k, &v, 2);
+                    } else if (d == ORF_RGB48LE || d == ORF_BGR48LE) { /* PUTRGB48 / PUTBGR48 yuv2rgb.c:107-125: each 8-bit LUT value fills both bytes */
                         uint8_t R = (uint8_t)lut_at(c, r + Y), G = (uint8_t)lut_at(c, g + Y), B = (uint8_t)lut_at(c, b + Y);
                         uint8_t *p = out + 12 * i + 6 * k;
                         uint8_t first = d == ORF_RGB48LE ? R : B, third = d == ORF_RGB48LE ? B : R;
@@ -1292,6 +1364,69 @@ static int unscaled_rgb2rgb(OrSws *c, const uint8_t *const src[], const int srcS
         for (int x = 0; x < c->o.src_w; x++, s += ds->c[0].step, d += dd->c[0].step) {
             for (int k = 0; k < 3; k++) d[dd->c[k].offset] = s[ds->c[k].offset];
             if (da) d[dd->c[3].offset] = sa ? s[ds->c[3].offset] : 255;
+        }
+    }
+    return srcSliceH;
+}
+
+
+/* rgbToRgbWrapper (swscale_unscaled.c:2000-2060) with the 12/15/16 bpp converters of rgb2rgb.c:179-320 and
+ * rgb2rgb_template.c:85-316.  They are bit-field shuffles in "int" order: a 16-bit pixel has a high, a middle and a low field,
+ * a 24/32 bpp pixel three bytes in memory order (32_1 formats: after the alpha byte, ALT32_CORR). */
+static int unscaled_rgblow(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                           int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    const int s = c->o.src_format, d = c->o.dst_format, sid = c->srcFormatBpp, did = c->dstFormatBpp;
+    const int s_rgbint = s == ORF_RGB24 || s == ORF_BGRA || s == ORF_ABGR || s == ORF_RGB565LE || s == ORF_RGB555LE || s == ORF_RGB444LE;
+    const int d_rgbint = d == ORF_RGB24 || d == ORF_BGRA || d == ORF_ABGR || d == ORF_RGB565LE || d == ORF_RGB555LE || d == ORF_RGB444LE;
+    const int same = s_rgbint == d_rgbint;
+    const int s_alt = s == ORF_ABGR || s == ORF_ARGB, d_alt = d == ORF_ABGR || d == ORF_ARGB;   /* RGB32_1 / BGR32_1 */
+    (void)srcSliceY;
+    for (int y = 0; y < srcSliceH; y++) {
+        const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0] + (s_alt ? 1 : 0);
+        uint8_t *dp = dst[0] + (ptrdiff_t)y * dstStride[0];
+        for (int x = 0; x < c->o.src_w; x++) {
+            unsigned px = 0, b0 = 0, b1 = 0, b2 = 0;       /* 16-bit source pixel, or the three bytes of a 24/32 bpp one */
+            unsigned out16 = 0, o0 = 0, o1 = 0, o2 = 0;
+            if (sid <= 16) { uint16_t t; memcpy(&t, sp + 2 * x, 2); px = t; }
+            else { const uint8_t *q = sp + (sid == 24 ? 3 : 4) * x; b0 = q[0]; b1 = q[1]; b2 = q[2]; }
+            if (did <= 16) {
+                if (sid == 12 && did == 15) {                 /* rgb12to15 */
+                    unsigned r = px & 0xF00, g = px & 0x0F0, b = px & 0x00F;
+                    r = (r << 3) | ((r & 0x800) >> 1); g = (g << 2) | ((g & 0x080) >> 2); b = (b << 1) | (b >> 3);
+                    out16 = (r | g | b) & 0xFFFF;
+                } else if (sid == 12 && did == 12) out16 = (px << 8 | (px & 0xF0) | px >> 8) & 0xFFF;                          /* rgb12tobgr12 */
+                else if (sid == 15 && did == 16) out16 = same ? ((px & 0x7FFF) + (px & 0x7FE0)) & 0xFFFF                     /* rgb15to16 */
+                                                              : (((px & 0x7C00) >> 10) | ((px & 0x3E0) << 1) | (px << 11)) & 0xFFFF; /* rgb15tobgr16 */
+                else if (sid == 16 && did == 15) out16 = same ? (((px >> 1) & 0x7FE0) | (px & 0x001F))                      /* rgb16to15 */
+                                                              : ((px >> 11) | ((px & 0x7C0) >> 1) | ((px & 0x1F) << 10)) & 0xFFFF; /* rgb16tobgr15 */
+                else if (sid == 16 && did == 16) out16 = ((px >> 11) | (px & 0x7E0) | (px << 11)) & 0xFFFF;                   /* rgb16tobgr16 */
+                else if (sid == 15 && did == 15) { const unsigned br = px & 0x7C1F; out16 = ((br >> 10) | (px & 0x3E0) | (br << 10)) & 0xFFFF; } /* rgb15tobgr15 */
+                else if (sid == 24) {
+                    /* rgb24to16/15: first byte -> high field; rgb24tobgr16/15: first byte -> low field (rgb2rgb_template.c:185-241) */
+                    const unsigned hi = same ? b0 : b2, lo = same ? b2 : b0;
+                    out16 = did == 16 ? ((lo >> 3) | ((b1 & 0xFC) << 3) | ((hi & 0xF8) << 8)) : ((lo >> 3) | ((b1 & 0xF8) << 2) | ((hi & 0xF8) << 7));
+                } else {
+                    /* rgb32to16/15: byte 0 -> low field; rgb32tobgr16/15: byte 0 -> high field (:123-183) */
+                    const unsigned lo = same ? b0 : b2, hi = same ? b2 : b0;
+                    out16 = did == 16 ? ((lo >> 3) + ((b1 & 0xFC) << 3) + ((hi & 0xF8) << 8)) : ((lo >> 3) + ((b1 & 0xF8) << 2) + ((hi & 0xF8) << 7));
+                }
+                { const uint16_t t = (uint16_t)out16; memcpy(dp + 2 * x, &t, 2); }
+            } else {
+                /* 15/16 -> 24/32: fields widened by bit replication */
+                unsigned hi8, mid8, lo8;
+                if (sid == 16) { hi8 = ((px & 0xF800) >> 8) | ((px & 0xF800) >> 13); mid8 = ((px & 0x07E0) >> 3) | ((px & 0x07E0) >> 9); lo8 = ((px & 0x001F) << 3) | ((px & 0x001F) >> 2); }
+                else           { hi8 = ((px & 0x7C00) >> 7) | ((px & 0x7C00) >> 12); mid8 = ((px & 0x03E0) >> 2) | ((px & 0x03E0) >> 7); lo8 = ((px & 0x001F) << 3) | ((px & 0x001F) >> 2); }
+                if (did == 24) {           /* rgb16to24 / rgb15to24: high field first; rgb16tobgr24 / rgb15tobgr24: low field first */
+                    o0 = same ? hi8 : lo8; o1 = mid8; o2 = same ? lo8 : hi8;
+                    dp[3 * x] = (uint8_t)o0; dp[3 * x + 1] = (uint8_t)o1; dp[3 * x + 2] = (uint8_t)o2;
+                } else {                   /* rgb16to32 / rgb15to32: low field first; ...tobgr32: high field first; 255 last (first for the _1 layouts) */
+                    uint8_t *q = dp + 4 * x;
+                    o0 = same ? lo8 : hi8; o1 = mid8; o2 = same ? hi8 : lo8;
+                    if (d_alt) { q[0] = 255; q[1] = (uint8_t)o0; q[2] = (uint8_t)o1; q[3] = (uint8_t)o2; }
+                    else       { q[0] = (uint8_t)o0; q[1] = (uint8_t)o1; q[2] = (uint8_t)o2; q[3] = 255; }
+                }
+            }
         }
     }
     return srcSliceH;
@@ -1592,6 +1727,19 @@ static int f2u16(float x) /* lrintf(av_clipf(65535.0f * x, 0, 65535)), input.c:1
 
 /* Produce the 8/16-bit "formatConv" luma line for source row y (NULL if the plane is read directly).
  * returns pointer to the line to feed to hscale. */
+/* RGB16_32FUNCS rows for the 16 bits-per-pixel formats (input.c:396-401): masks on the unshifted pixel, coefficient shifts, S */
+static void rgb16_params(int f, int *maskr, int *maskg, int *maskb, int *rsh, int *gsh, int *bsh, int *S)
+{
+    switch (f) {
+    case ORF_BGR565LE: *maskr = 0x001F; *maskg = 0x07E0; *maskb = 0xF800; *rsh = 11; *gsh = 5; *bsh = 0; *S = 15 + 8; break;
+    case ORF_BGR555LE: *maskr = 0x001F; *maskg = 0x03E0; *maskb = 0x7C00; *rsh = 10; *gsh = 5; *bsh = 0; *S = 15 + 7; break;
+    case ORF_BGR444LE: *maskr = 0x000F; *maskg = 0x00F0; *maskb = 0x0F00; *rsh = 8; *gsh = 4; *bsh = 0; *S = 15 + 4; break;
+    case ORF_RGB565LE: *maskr = 0xF800; *maskg = 0x07E0; *maskb = 0x001F; *rsh = 0; *gsh = 5; *bsh = 11; *S = 15 + 8; break;
+    case ORF_RGB555LE: *maskr = 0x7C00; *maskg = 0x03E0; *maskb = 0x001F; *rsh = 0; *gsh = 5; *bsh = 10; *S = 15 + 7; break;
+    default:           *maskr = 0x0F00; *maskg = 0x00F0; *maskb = 0x000F; *rsh = 0; *gsh = 4; *bsh = 8; *S = 15 + 4; break;   /* rgb444le */
+    }
+}
+
 static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], const int stride[], int y, uint8_t *tmp)
 {
     const int f = c->o.src_format, w = c->o.src_w;
@@ -1616,6 +1764,20 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
         uint16_t *d = (uint16_t *)tmp;
         for (i = 0; i < w; i++)
             d[i] = (uint16_t)(((unsigned)t[RY] * s[st * i + ro] + (unsigned)t[GY] * s[st * i + go] + (unsigned)t[BY] * s[st * i + bo] + (0x2001u << 14)) >> 15);
+        return tmp;
+    }
+    if (isRGB16(f)) { /* rgb16_32ToY_c_template input.c:264-293 with the 12/15/16 bpp rows of :396-401 */
+        const uint16_t *s = (const uint16_t *)(src[0] + y * stride[0]); int16_t *d = (int16_t *)tmp;
+        int maskr, maskg, maskb, rsh, gsh, bsh, S;
+        rgb16_params(f, &maskr, &maskg, &maskb, &rsh, &gsh, &bsh, &S);
+        {
+            const int ry = t[RY] << rsh, gy = t[GY] << gsh, by = t[BY] << bsh;
+            const unsigned rnd = (32u << (S - 1)) + (1u << (S - 7));
+            for (i = 0; i < w; i++) {
+                const int px = s[i], b = px & maskb, g = px & maskg, r = px & maskr;
+                d[i] = (int16_t)((unsigned)(ry * r + gy * g + by * b + rnd) >> (S - 6));
+            }
+        }
         return tmp;
     }
     switch (f) {
@@ -1678,6 +1840,39 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
     const int32_t *t = c->rgb2yuv;
     int i;
     *pu = tu; *pv = tv;
+    if (isRGB16(f)) { /* rgb16_32ToUV_c_template / rgb16_32ToUV_half_c_template input.c:295-372 */
+        const uint16_t *s = (const uint16_t *)(src[0] + (ptrdiff_t)(y << c->chrSrcVSub) * stride[0]);
+        int16_t *du = (int16_t *)tu, *dv = (int16_t *)tv;
+        int maskr, maskg, maskb, rsh, gsh, bsh, S;
+        rgb16_params(f, &maskr, &maskg, &maskb, &rsh, &gsh, &bsh, &S);
+        {
+            const int ru = t[RU] * (1 << rsh), gu = t[GU] * (1 << gsh), bu = t[BU] * (1 << bsh);
+            const int rv = t[RV] * (1 << rsh), gv = t[GV] * (1 << gsh), bv = t[BV] * (1 << bsh);
+            if (c->chrSrcHSub) {
+                const unsigned maskgx = ~(unsigned)(maskr | maskb);
+                const unsigned rnd = (256U << S) + (1u << (S - 6));
+                const int is565 = f == ORF_RGB565LE || f == ORF_BGR565LE;
+                const int mr = maskr | (maskr << 1), mb = maskb | (maskb << 1), mg = maskg | (maskg << 1);
+                for (i = 0; i < w; i++) {
+                    const unsigned px0 = s[2 * i], px1 = s[2 * i + 1];
+                    int g = (int)((px0 & maskgx) + (px1 & maskgx));
+                    const int rb = (int)(px0 + px1) - g;
+                    const int b = rb & mb, r = rb & mr;
+                    if (!is565) g = g & mg;            /* shp == 0: only the 565 formats keep the unmasked green sum (:344-351) */
+                    du[i] = (int16_t)((unsigned)(ru * r + gu * g + bu * b + rnd) >> (S - 6 + 1));
+                    dv[i] = (int16_t)((unsigned)(rv * r + gv * g + bv * b + rnd) >> (S - 6 + 1));
+                }
+            } else {
+                const unsigned rnd = (256u << (S - 1)) + (1u << (S - 7));
+                for (i = 0; i < w; i++) {
+                    const int px = s[i], b = px & maskb, g = px & maskg, r = px & maskr;
+                    du[i] = (int16_t)((unsigned)(ru * r + gu * g + bu * b + rnd) >> (S - 6));
+                    dv[i] = (int16_t)((unsigned)(rv * r + gv * g + bv * b + rnd) >> (S - 6));
+                }
+            }
+        }
+        return;
+    }
     if (f == ORF_RGB48LE || f == ORF_BGR48LE || f == ORF_RGBA64LE || f == ORF_BGRA64LE) { /* rgb48/64ToUV(_half)_c_template input.c:58-96, :151-203 */
         const Desc *ds = desc_get(f);
         const int st = ds->c[0].step / 2, ro = ds->c[0].offset / 2, go = ds->c[1].offset / 2, bo = ds->c[2].offset / 2;
@@ -2005,13 +2200,29 @@ static void write_nv_chroma_line(const OrSws *c, uint8_t *dest, int w, const int
 }
 
 /* LUT rgb pixel-pair write (yuv2rgb_write, output.c:1662-1785; 24/32 bpp) */
-static void rgb_write2(const OrSws *c, uint8_t *dest, int i, int Y1, int Y2, int U, int V, int hasAlpha, unsigned A1, unsigned A2)
+static void rgb_write2(const OrSws *c, uint8_t *dest, int i, int y, int Y1, int Y2, int U, int V, int hasAlpha, unsigned A1, unsigned A2)
 {
     const int d = c->o.dst_format;
     int r = c->table_rV[V + HEADROOM];
     int g = c->table_gU[U + HEADROOM] + c->table_gV[V + HEADROOM];
     int b = c->table_bU[U + HEADROOM];
-    if (c->lut_elem == 4) {
+    if (c->lut_elem == 2) { /* yuv2rgb_write output.c:1714-1748: ordered dither added to the luma index */
+        int dr1, dg1, db1, dr2, dg2, db2;
+        uint16_t v1, v2;
+        if (d == ORF_RGB565LE || d == ORF_BGR565LE) {
+            dr1 = dither_2x2_8[y & 1][0]; dg1 = dither_2x2_4[y & 1][0]; db1 = dither_2x2_8[(y & 1) ^ 1][0];
+            dr2 = dither_2x2_8[y & 1][1]; dg2 = dither_2x2_4[y & 1][1]; db2 = dither_2x2_8[(y & 1) ^ 1][1];
+        } else if (d == ORF_RGB555LE || d == ORF_BGR555LE) {
+            dr1 = dither_2x2_8[y & 1][0]; dg1 = dither_2x2_8[y & 1][1]; db1 = dither_2x2_8[(y & 1) ^ 1][0];
+            dr2 = dither_2x2_8[y & 1][1]; dg2 = dither_2x2_8[y & 1][0]; db2 = dither_2x2_8[(y & 1) ^ 1][1];
+        } else {
+            dr1 = dither_4x4_16[y & 3][0]; dg1 = dither_4x4_16[y & 3][1]; db1 = dither_4x4_16[(y & 3) ^ 3][0];
+            dr2 = dither_4x4_16[y & 3][1]; dg2 = dither_4x4_16[y & 3][0]; db2 = dither_4x4_16[(y & 3) ^ 3][1];
+        }
+        v1 = (uint16_t)(lut_at(c, r + Y1 + dr1) + lut_at(c, g + Y1 + dg1) + lut_at(c, b + Y1 + db1));
+        v2 = (uint16_t)(lut_at(c, r + Y2 + dr2) + lut_at(c, g + Y2 + dg2) + lut_at(c, b + Y2 + db2));
+        memcpy(dest + 4 * i, &v1, 2); memcpy(dest + 4 * i + 2, &v2, 2);
+    } else if (c->lut_elem == 4) {
         uint32_t v1 = lut_at(c, r + Y1) + lut_at(c, g + Y1) + lut_at(c, b + Y1);
         uint32_t v2 = lut_at(c, r + Y2) + lut_at(c, g + Y2) + lut_at(c, b + Y2);
         if (hasAlpha) { /* yuv2rgb_write output.c:1680-1687 */
@@ -2127,7 +2338,7 @@ static void write_packed_rgb_line(const OrSws *c, const Planes *P, uint8_t *dest
                         A2 = clip_u8((AL(0)[2 * i + 1] + 64) >> 7);
                     }
                 }
-                rgb_write2(c, dest, i, Y1, Y2, U, V, hasAlpha, (unsigned)A1, (unsigned)A2);
+                rgb_write2(c, dest, i, y, Y1, Y2, U, V, hasAlpha, (unsigned)A1, (unsigned)A2);
             }
         }
     } else {
@@ -2554,6 +2765,7 @@ static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4
     {   /* swscale.c:1106-1124: an rgb0-style source feeding a real alpha channel is made opaque first */
         const int opaque = c->src0Alpha && !c->dst0Alpha && isALPHA(c->o.dst_format);
         if (c->unscaled_kind == UNSC_RGB2RGB) return unscaled_rgb2rgb(c, src, srcStride, 0, srcSliceH, dst, dstStride, opaque);
+        if (c->unscaled_kind == UNSC_RGBLOW) return unscaled_rgblow(c, src, srcStride, 0, srcSliceH, dst, dstStride);
         if (c->unscaled_kind == UNSC_PACKEDCOPY) return unscaled_packedcopy(c, src, srcStride, 0, srcSliceH, dst, dstStride, opaque);
         if (opaque && c->unscaled_kind) return -22; /* no other special converter takes an rgb0-style source to an alpha destination */
     }
@@ -2597,7 +2809,7 @@ int or_sws_path(const OrSws *c) { return c->cascade[0] ? 2 : c->unscaled_kind ? 
 const char *or_sws_path_name(const OrSws *c)
 {
     static const char *n[] = { "main", "yuv2rgb_c", "planarToP01x", "planar8ToP01xle", "planarToNv12", "nv12ToPlanar", "planarCopy",
-                               "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb",
+                               "rgbToRgb", "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb",
                                "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb",
                                "planarToYuy2", "yuyvToPlanar",
                                "rgb16Shuffle", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16" };

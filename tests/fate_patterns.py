@@ -16,7 +16,7 @@ import oracle_lib as OL
 HERE = os.path.dirname(os.path.abspath(__file__))
 W, H = 352, 288
 SWS_FLAGS = OL.SWS_BICUBIC | OL.SWS_ACCURATE_RND | OL.SWS_BITEXACT   # tests/fate-run.sh:258 + the filter's default scaler
-FMT_OF = {"gray": "gray8", "rgb32": "bgra", "rgb48": "rgb48le"}                           # lavu pixfmt aliases on little endian
+FMT_OF = {"gray": "gray8", "rgb32": "bgra", "rgb48": "rgb48le", "rgb565": "rgb565le", "rgb555": "rgb555le"}                           # lavu pixfmt aliases on little endian
 BASE_FMT = {"yuv444p": "yuv444p", "rgb24": "rgb24", "yuv444p10": "yuv444p10le", "yuv444p12": "yuv444p12le",
             "yuv444p16": "yuv444p16le", "nv24": "nv24", "p410": "p410le", "p412": "p412le", "p416": "p416le",
             "gbrp": "gbrp", "gbrp10": "gbrp10le", "gbrp12": "gbrp12le", "gbrp16": "gbrp16le", "rgb48": "rgb48le"}

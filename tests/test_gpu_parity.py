@@ -89,8 +89,9 @@ GRAYS = ["gray8", "gray9le", "gray10le", "gray12le", "gray14le", "gray16le"]
 RGB16 = ["rgb48le", "bgr48le", "rgba64le", "bgra64le"]
 BIG_ENDIAN = ["yuv420p10be", "yuv422p12be", "yuv444p16be", "yuv440p10be", "p010be", "p416be", "gbrp12be", "gbrp16be", "gray10be", "gray16be",
               "rgb48be", "bgr48be", "rgba64be", "bgra64be", "gbrpf32be"]
-FORMAT_MATRIX_SRC = BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
-FORMAT_MATRIX_DST = BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+RGB_LOW = ["rgb565le", "bgr565le", "rgb555le", "bgr555le", "rgb444le", "bgr444le", "rgb565be", "bgr555be"]
+FORMAT_MATRIX_SRC = RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+FORMAT_MATRIX_DST = RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
 
 
 @pytest.mark.parametrize("sfmt", FORMAT_MATRIX_SRC)
@@ -162,6 +163,12 @@ def _slice_ptrs(frame, fmt, y0):
 
 
 SLICED_UNSCALED = [
+    ("yuv420p", "rgb565le", BX), ("yuv422p", "bgr565le", 0), ("yuv420p", "rgb555le", BX), ("yuv422p", "bgr555le", BX), ("yuv420p", "rgb444le", BX),
+    ("yuv422p", "bgr444le", 0), ("yuv420p", "rgb565be", BX),
+    ("rgb565le", "rgb24", BX), ("rgb565le", "bgr24", 0), ("bgr565le", "bgra", 0), ("rgb555le", "argb", BX), ("bgr555le", "rgb24", BX), ("rgb555le", "abgr", 0),
+    ("rgb24", "rgb565le", OL.SWS_POINT | BX), ("bgr24", "rgb555le", OL.SWS_POINT), ("bgra", "bgr565le", OL.SWS_POINT), ("argb", "rgb555le", OL.SWS_FAST_BILINEAR),
+    ("rgb555le", "rgb565le", BX), ("rgb565le", "rgb555le", OL.SWS_POINT), ("rgb565le", "bgr565le", BX), ("rgb555le", "bgr555le", 0), ("rgb555le", "bgr565le", 0),
+    ("rgb565le", "bgr555le", OL.SWS_POINT), ("rgb444le", "bgr444le", BX), ("rgb444le", "rgb555le", BX), ("rgb565be", "rgb24", BX), ("rgb565le", "rgb565le", BX),
     ("yuv420p10be", "yuv420p10le", 0), ("yuv420p12le", "yuv420p12be", 0), ("yuv420p10be", "yuv420p", 0), ("yuv444p", "yuv444p16be", 0),
     ("rgb48be", "bgr48le", 0), ("rgba64le", "rgb48be", 0), ("gbrp10be", "rgb48le", 0), ("rgb48le", "gbrp12be", 0), ("gray16be", "gray16le", 0),
     ("p010be", "p010le", 0),
@@ -365,6 +372,14 @@ def test_rgb_to_rgb_shuffles_and_packed_copies(sfmt, dfmt, bitexact):
             assert opath == "main" and path.startswith("main")
         else:
             assert (path, opath) == ("unscaled:rgbToRgb", "rgbToRgb")
+
+
+@pytest.mark.parametrize("w,h", [(2, 2), (6, 2), (14, 6), (18, 4), (30, 4), (258, 6), (8, 8)])
+@pytest.mark.parametrize("dfmt", ["rgb565le", "bgr555le", "rgb444le"])
+def test_unscaled_yuv2rgb16_ragged_widths(w, h, dfmt):
+    for sfmt in ("yuv420p", "yuv422p"):
+        path, opath = run_case(w, h, sfmt, w, h, dfmt, SWS_BICUBIC | BX, seed=w)
+        assert path == "unscaled:yuv2rgb" and opath == "yuv2rgb_c"
 
 
 @pytest.mark.parametrize("w,h", [(2, 2), (6, 2), (14, 6), (18, 4), (30, 2), (258, 6), (1022, 4), (8, 8), (16, 2)])
