@@ -284,7 +284,7 @@ int dev_prepare(SwsInternal *c)
         // ---- wave-marching fused kernel (sws_k_march_dot2): same coverage as the dot2 tile kernel, preferred ----
         d->march_ok = false;
         {
-            const bool src_ok = p.srcKind == SRCK_PLANAR8 || (p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15);
+            const bool src_ok = p.srcKind == SRCK_PLANAR8 || (p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15 && p.src_shift == 0);
             const bool dst_ok = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010;
             auto fs4 = [](int fs) { return (fs + 3 + 3) & ~3; };
             auto fs2 = [](int fs) { return (fs + 2) & ~1; };
@@ -342,7 +342,7 @@ int dev_prepare(SwsInternal *c)
         // ---- dot2 tile kernel (sws_k_tile_dot2): planar 8-bit / <= 15-bit sources, 15-bit intermediates, vfs >= 2 ----
         d->dot2_ok = false;
         {
-            const bool src_ok = p.srcKind == SRCK_PLANAR8 || (p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15);
+            const bool src_ok = p.srcKind == SRCK_PLANAR8 || (p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15 && p.src_shift == 0);
             const bool dst_ok = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010;
             auto fs2 = [](int fs) { return (fs + 2) & ~1; };
             if (!d->unity_h && !p.fast_bilinear && !gray_any && src_ok && dst_ok && !p.wide && c->vLum.size >= 2 && c->vChr.size >= 2 &&
@@ -617,7 +617,7 @@ int dev_prepare(SwsInternal *c)
         if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             c->path_name = "main:fused_rgb_unity";
             c->kernel_name = d->rgb_march_ok ? "sws_k_rgb_fused_unity_march" : (d->all_x_mode && d->chr_window2 <= 8 ? "sws_k_rgb_fused_unity_wave2" : "sws_k_rgb_fused_unity");
-        } else if (d->unity_h && d->unity_v && !p.no_chroma && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 &&
+        } else if (d->unity_h && d->unity_v && !p.no_chroma && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 && p.dst_shift == 0 &&
                    (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16)) {
             c->path_name = "main:fused_f32rgb_yuv444"; c->kernel_name = "sws_k_f32rgb_to_yuv444_unity";
         } else if (d->unity_h) {
@@ -1074,7 +1074,7 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
 #undef LAUNCH_FUSED
             break;
         }
-        if (vec && d->unity_h && d->unity_v && !p.no_chroma && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 &&
+        if (vec && d->unity_h && d->unity_v && !p.no_chroma && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 && p.dst_shift == 0 &&
             (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16)) {
             const dim3 g(cdiv((int64_t)((p.srcW + 7) >> 3) * p.srcH, 256), 1, n);
             hipLaunchKernelGGL(swsk::sws_k_f32rgb_to_yuv444_unity, g, blk, 0, st, fs, p);

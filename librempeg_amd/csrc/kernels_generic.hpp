@@ -31,7 +31,7 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
     }
     case SRCK_PLANAR16: {
         const int pl = comp == 0 ? 0 : comp == 1 ? p.u_plane_src : p.v_plane_src;
-        return *(const uint16_t *)(f.src[pl] + (int64_t)row * f.srcStride[pl] + 2 * x);
+        return *(const uint16_t *)(f.src[pl] + (int64_t)row * f.srcStride[pl] + 2 * x) >> p.src_shift;   // shf16_NNLEToY/UV_c for the msb formats
     }
     case SRCK_NV12: // nv12ToUV_c / nv21ToUV_c, input.c:926-948
         if (comp == 0) return f.src[0][(int64_t)row * f.srcStride[0] + x];
@@ -276,12 +276,12 @@ __device__ __forceinline__ void planar_write_one(const SwsDevParams &p, const S 
         uint16_t *d = (uint16_t *)drow;
         if (fs == 1) {
             const int shift = 15 - bits;
-            d[x] = (uint16_t)clip_uintp2((smp.get(comp, min(first, srcRows - 1), x) + (1 << (shift - 1))) >> shift, bits);
+            d[x] = (uint16_t)(clip_uintp2((smp.get(comp, min(first, srcRows - 1), x) + (1 << (shift - 1))) >> shift, bits) << p.dst_shift);
         } else {
             const int shift = 11 + 16 - bits;
             int val = 1 << (shift - 1);
             for (int j = 0; j < fs; j++) val += smp.get(comp, min(first + j, srcRows - 1), x) * vf[j];
-            d[x] = (uint16_t)clip_uintp2(val >> shift, bits);
+            d[x] = (uint16_t)(clip_uintp2(val >> shift, bits) << p.dst_shift);
         }
     } else { // 8 bit (also the luma plane of NV12)
         const int off = comp == 2 ? 3 : 0; // V plane uses dither offset 3 (vscale.c:99-102)

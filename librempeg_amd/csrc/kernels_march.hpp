@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256) sws_k_march_dot2(SwsFrameSet fs, SwsDevPa
                 if (vb) *(uint16_t *)(drow + xa) = (uint16_t)(o0 | (o1 << 8));
                 else if (va) drow[xa] = (uint8_t)o0;
             } else {
-                const int shift = 11 + 16 - bits, osh = p.dstKind == DSTK_P010 ? p.dst_shift : 0;
+                const int shift = 11 + 16 - bits, osh = p.dst_shift;   // p010-style and msb planar formats keep the samples in the high bits
                 const uint32_t o0 = (uint32_t)clip_uintp2(((1 << (shift - 1)) + acc[0][0]) >> shift, bits) << osh;
                 const uint32_t o1 = (uint32_t)clip_uintp2(((1 << (shift - 1)) + acc[0][1]) >> shift, bits) << osh;
                 uint16_t *d16 = (uint16_t *)drow + xa;

@@ -272,7 +272,7 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
                     pend[ci][c] = (uint32_t)clip_u8_shr((dither8(p.should_dither, y, x + off) << 12) + acc[ci][c], 19);
                 }
         } else {
-            const int shift = 11 + 16 - bits, osh = p.dstKind == DSTK_P010 ? p.dst_shift : 0;
+            const int shift = 11 + 16 - bits, osh = p.dst_shift;   // p010-style and msb planar formats keep the samples in the high bits
 #pragma unroll
             for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll

@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(NT) sws_k_tile_dot2(SwsFrameSet fs, SwsDevPara
                     if (n == 4 && !((uintptr_t)(drow + x) & 3)) *(uint32_t *)(drow + x) = o;
                     else for (int e = 0; e < n; e++) drow[x + e] = (uint8_t)(o >> (8 * e));
                 } else { // DSTK_PLANARN, or the luma plane of P010
-                    const int shift = 11 + 16 - bits, osh = p.dstKind == DSTK_P010 ? p.dst_shift : 0;
+                    const int shift = 11 + 16 - bits, osh = p.dst_shift;   // p010-style and msb planar formats keep the samples in the high bits
                     uint16_t o[4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) o[e] = (uint16_t)(clip_uintp2(((1 << (shift - 1)) + acc[ci][e]) >> shift, bits) << osh);

@@ -63,6 +63,9 @@ static const PixDesc g_descs[] = {
     GBRN(AV_PIX_FMT_GBRP9LE, "gbrp9le", 9), GBRN(AV_PIX_FMT_GBRP10LE, "gbrp10le", 10), GBRN(AV_PIX_FMT_GBRP12LE, "gbrp12le", 12),
     GBRN(AV_PIX_FMT_GBRP14LE, "gbrp14le", 14), GBRN(AV_PIX_FMT_GBRP16LE, "gbrp16le", 16),
     { AV_PIX_FMT_GBRPF32LE,"gbrpf32le",3, 0, 0, {{2,4,0,0,32},{0,4,0,0,32},{1,4,0,0,32},{0,0,0,0,0}}, PIXFLAG_PLANAR | PIXFLAG_RGB | PIXFLAG_FLOAT },
+    // planar 4:4:4 with the samples in the high bits of each 16-bit word
+    { AV_PIX_FMT_YUV444P10MSBLE, "yuv444p10msble", 3, 0, 0, {{0,2,0,6,10},{1,2,0,6,10},{2,2,0,6,10},{0,0,0,0,0}}, PIXFLAG_PLANAR },
+    { AV_PIX_FMT_YUV444P12MSBLE, "yuv444p12msble", 3, 0, 0, {{0,2,0,4,12},{1,2,0,4,12},{2,2,0,4,12},{0,0,0,0,0}}, PIXFLAG_PLANAR },
     // 16 bits per pixel packed RGB (libavutil/pixdesc.c:1229-1420)
     { AV_PIX_FMT_RGB565LE, "rgb565le", 3, 0, 0, {{0,2,1,3,5},{0,2,0,5,6},{0,2,0,0,5},{0,0,0,0,0}}, PIXFLAG_RGB },
     { AV_PIX_FMT_RGB555LE, "rgb555le", 3, 0, 0, {{0,2,1,2,5},{0,2,0,5,5},{0,2,0,0,5},{0,0,0,0,0}}, PIXFLAG_RGB },
@@ -134,6 +137,7 @@ bool isDataInHighBits(int f)
 int pix_be_twin(int fmt)
 {
     static const int pairs[][2] = {
+    { AV_PIX_FMT_YUV444P10MSBBE, AV_PIX_FMT_YUV444P10MSBLE }, { AV_PIX_FMT_YUV444P12MSBBE, AV_PIX_FMT_YUV444P12MSBLE },
     { AV_PIX_FMT_RGB565BE, AV_PIX_FMT_RGB565LE }, { AV_PIX_FMT_RGB555BE, AV_PIX_FMT_RGB555LE }, { AV_PIX_FMT_RGB444BE, AV_PIX_FMT_RGB444LE },
     { AV_PIX_FMT_BGR565BE, AV_PIX_FMT_BGR565LE }, { AV_PIX_FMT_BGR555BE, AV_PIX_FMT_BGR555LE }, { AV_PIX_FMT_BGR444BE, AV_PIX_FMT_BGR444LE },
     { AV_PIX_FMT_YUV420P9BE, AV_PIX_FMT_YUV420P9LE },

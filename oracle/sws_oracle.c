@@ -115,6 +115,9 @@ static const Desc descs[] = {
     GBRN(ORF_GBRP9LE, "gbrp9le", 9), GBRN(ORF_GBRP10LE, "gbrp10le", 10), GBRN(ORF_GBRP12LE, "gbrp12le", 12),
     GBRN(ORF_GBRP14LE, "gbrp14le", 14), GBRN(ORF_GBRP16LE, "gbrp16le", 16),
     { ORF_GBRPF32LE, "gbrpf32le", 3, 0, 0, {{2,4,0,0,32},{0,4,0,0,32},{1,4,0,0,32}}, PF_PLANAR | PF_RGB | PF_FLOAT },
+    /* planar 4:4:4 with the samples in the high bits (pixdesc.c yuv444p10msb / yuv444p12msb) */
+    { ORF_YUV444P10MSBLE, "yuv444p10msble", 3, 0, 0, {{0,2,0,6,10},{1,2,0,6,10},{2,2,0,6,10}}, PF_PLANAR },
+    { ORF_YUV444P12MSBLE, "yuv444p12msble", 3, 0, 0, {{0,2,0,4,12},{1,2,0,4,12},{2,2,0,4,12}}, PF_PLANAR },
     /* 16 bits per pixel packed RGB (libavutil/pixdesc.c:1229-1420) */
     { ORF_RGB565LE, "rgb565le", 3, 0, 0, {{0,2,1,3,5},{0,2,0,5,6},{0,2,0,0,5}}, PF_RGB },
     { ORF_RGB555LE, "rgb555le", 3, 0, 0, {{0,2,1,2,5},{0,2,0,5,5},{0,2,0,0,5}}, PF_RGB },
@@ -137,6 +140,7 @@ static const Desc *desc_get(int fmt)
  * writers are the LE ones behind AV_RB16 / AV_WB16: input.c:608-629, output.c output_pixel macros); converter selection follows
  * the reference's rules, which only name a byte order for planarToP01xWrapper / planar8ToP01xleWrapper (native-endian only). */
 static const int be_pairs[][2] = {
+    { ORF_YUV444P10MSBBE, ORF_YUV444P10MSBLE }, { ORF_YUV444P12MSBBE, ORF_YUV444P12MSBLE },
     { ORF_RGB565BE, ORF_RGB565LE }, { ORF_RGB555BE, ORF_RGB555LE }, { ORF_RGB444BE, ORF_RGB444LE },
     { ORF_BGR565BE, ORF_BGR565LE }, { ORF_BGR555BE, ORF_BGR555LE }, { ORF_BGR444BE, ORF_BGR444LE },
     { 59, 60 } /* yuv420p9 */,
@@ -1828,6 +1832,12 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
         }
         return tmp; }
     default:
+        if ((desc_get(f)->flags & PF_PLANAR) && desc_get(f)->c[0].shift && desc_get(f)->c[0].depth > 8) { /* shf16_10LEToY_c / shf16_12LEToY_c (yuv444pNNmsb) */
+            const int sh = desc_get(f)->c[0].shift;
+            const uint16_t *s = (const uint16_t *)(src[0] + y * stride[0]); uint16_t *d = (uint16_t *)tmp;
+            for (i = 0; i < w; i++) d[i] = s[i] >> sh;
+            return tmp;
+        }
         return src[0] + y * stride[0];
     }
 }
@@ -1999,6 +2009,13 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
         return; }
     default: { /* planar YUV: direct */
         const Desc *ds = desc_get(f);
+        if (ds->c[1].shift && ds->c[1].depth > 8) { /* shf16_10LEToUV_c / shf16_12LEToUV_c */
+            const uint16_t *su = (const uint16_t *)(src[ds->c[1].plane] + y * stride[ds->c[1].plane]);
+            const uint16_t *sv = (const uint16_t *)(src[ds->c[2].plane] + y * stride[ds->c[2].plane]);
+            uint16_t *a = (uint16_t *)tu, *b = (uint16_t *)tv;
+            for (i = 0; i < w; i++) { a[i] = su[i] >> ds->c[1].shift; b[i] = sv[i] >> ds->c[2].shift; }
+            return;
+        }
         *pu = src[ds->c[1].plane] + y * stride[ds->c[1].plane];
         *pv = src[ds->c[2].plane] + y * stride[ds->c[2].plane];
         return; }
@@ -2097,7 +2114,7 @@ static void write_planar_line(const OrSws *c, uint8_t *dest, int w, const int32_
     int i, j;
 #define ROW(j) (plane + (size_t)ORMIN(first + (j), planeH - 1) * planeW)
     (void)is_luma_of_p01x;
-    if (isSemiPlanarYUV(c->o.dst_format) && isDataInHighBits(c->o.dst_format)) { /* yuv2p01xl1_c / lX_c output.c:538-569 */
+    if (isDataInHighBits(c->o.dst_format) && bits < 16) { /* yuv2p01xl1_c / lX_c output.c:538-569; yuv2msbplane1/X_10_c_template :396-426 (same arithmetic) */
         uint16_t *d = (uint16_t *)dest;
         int oshift = 16 - bits;
         if (fs == 1) {

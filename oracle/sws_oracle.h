@@ -44,6 +44,7 @@ enum {
     ORF_YUV420P9BE = 59, ORF_YUV420P10BE = 61, ORF_YUV420P12BE = 122, ORF_YUV420P14BE = 124, ORF_YUV420P16BE = 46, ORF_YUV422P9BE = 69, ORF_YUV422P10BE = 63, ORF_YUV422P12BE = 126, ORF_YUV422P14BE = 128, ORF_YUV422P16BE = 48, ORF_YUV444P9BE = 65, ORF_YUV444P10BE = 67, ORF_YUV444P12BE = 130, ORF_YUV444P14BE = 132, ORF_YUV444P16BE = 50, ORF_YUV440P10BE = 152, ORF_YUV440P12BE = 154, ORF_GRAY9BE = 172, ORF_GRAY10BE = 167, ORF_GRAY12BE = 165, ORF_GRAY14BE = 180, ORF_GRAY16BE = 29, ORF_GBRP9BE = 72, ORF_GBRP10BE = 74, ORF_GBRP12BE = 134, ORF_GBRP14BE = 136, ORF_GBRP16BE = 76, ORF_GBRPF32BE = 174, ORF_P010BE = 159, ORF_P012BE = 210, ORF_P016BE = 170, ORF_P210BE = 197, ORF_P212BE = 221, ORF_P216BE = 201, ORF_P410BE = 199, ORF_P412BE = 223, ORF_P416BE = 203, ORF_RGB48BE = 34, ORF_BGR48BE = 57, ORF_RGBA64BE = 104, ORF_BGRA64BE = 106,
     ORF_RGB565BE = 36, ORF_RGB565LE = 37, ORF_RGB555BE = 38, ORF_RGB555LE = 39, ORF_BGR565BE = 40, ORF_BGR565LE = 41,
     ORF_BGR555BE = 42, ORF_BGR555LE = 43, ORF_RGB444LE = 52, ORF_RGB444BE = 53, ORF_BGR444LE = 54, ORF_BGR444BE = 55,
+    ORF_YUV444P10MSBBE = 258, ORF_YUV444P10MSBLE = 259, ORF_YUV444P12MSBBE = 260, ORF_YUV444P12MSBLE = 261,
     ORF_GBRP9LE = 73, ORF_GBRP10LE = 75, ORF_GBRP16LE = 77, ORF_GBRP12LE = 135, ORF_GBRP14LE = 137,
 };
 
