@@ -75,6 +75,7 @@ enum AVPixelFormat {
     AV_PIX_FMT_GBRP14LE = 137,
     /* NEW: hardware surface format of the HIP hwcontext slot; appended after the
      * reference's last format (AV_PIX_FMT_NB == 268, libavutil/pixfmt.h) */
+    AV_PIX_FMT_VUYA = 205, AV_PIX_FMT_VUYX = 208, AV_PIX_FMT_AYUV = 228, AV_PIX_FMT_UYVA = 229, AV_PIX_FMT_VYU444 = 230,
     AV_PIX_FMT_YUV444P10MSBBE = 258, AV_PIX_FMT_YUV444P10MSBLE = 259, AV_PIX_FMT_YUV444P12MSBBE = 260, AV_PIX_FMT_YUV444P12MSBLE = 261,
     /* 16 bits per pixel packed RGB (ordered-dither writers, output.c:1714-1748) */
     AV_PIX_FMT_RGB565BE = 36, AV_PIX_FMT_RGB565LE = 37, AV_PIX_FMT_RGB555BE = 38, AV_PIX_FMT_RGB555LE = 39, AV_PIX_FMT_BGR565BE = 40, AV_PIX_FMT_BGR565LE = 41,

@@ -152,6 +152,10 @@ void choose_unscaled(SwsInternal *c)
         const bool s32 = pix_desc(s)->comp[0].step == 4;
         if (!(!s32 && (d == AV_PIX_FMT_BGRA || d == AV_PIX_FMT_RGBA) && (flags & SWS_BITEXACT))) k = PLAN_UNSC_RGB2RGB;
     }
+    // AYUV / VUYA / UYVA -> AYUV / VUYA / VUYX / UYVA byte shuffles through rgbToRgbWrapper (:1938-1949, :2459-2461)
+    if (s != d && ((s == AV_PIX_FMT_AYUV && (d == AV_PIX_FMT_VUYA || d == AV_PIX_FMT_VUYX || d == AV_PIX_FMT_UYVA)) ||
+                   (s == AV_PIX_FMT_VUYA && (d == AV_PIX_FMT_AYUV || d == AV_PIX_FMT_UYVA)) ||
+                   (s == AV_PIX_FMT_UYVA && (d == AV_PIX_FMT_AYUV || d == AV_PIX_FMT_VUYA || d == AV_PIX_FMT_VUYX)))) k = PLAN_UNSC_RGB2RGB;
     if (isAnyRGB(s) && isAnyRGB(d) && !isPlanarRGB(s) && !isPlanarRGB(d) && (isRGB16fmt(s) || isRGB16fmt(d))) {
         // findRgbConvFn's two switch tables (:1941-1979) on (srcFormatBpp, dstFormatBpp), for formats of the same / of opposite channel
         // order "in int"; rgbToRgbWrapper only without dither need or with FAST_BILINEAR / POINT (:2400-2403, :2459-2463)

@@ -104,7 +104,7 @@ static int src_kind_of(int f)
     if (isAnyRGB(f) && d->comp[0].depth == 16) return SRCK_RGB48;
     if (isAnyRGB(f) && d->comp[0].step == 2) return SRCK_RGB16;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? SRCK_RGB24 : SRCK_RGB32;
-    if (isYUV(f) && isPackedFmt(f)) return SRCK_PACKED422;
+    if (isYUV(f) && isPackedFmt(f)) return d->log2_chroma_w ? SRCK_PACKED422 : SRCK_PACKED444;
     if (isSemiPlanarYUV(f)) return d->comp[0].depth == 8 ? SRCK_NV12 : SRCK_P010;
     if (isPlanarYUV(f) || isGray(f)) return d->comp[0].depth == 8 ? SRCK_PLANAR8 : SRCK_PLANAR16;
     return -1;
@@ -117,7 +117,7 @@ static int dst_kind_of(int f)
     if (isAnyRGB(f) && d->comp[0].depth == 16) return DSTK_RGB48;
     if (isAnyRGB(f) && d->comp[0].step == 2) return DSTK_RGB16;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? DSTK_RGB24 : DSTK_RGB32;
-    if (isYUV(f) && isPackedFmt(f)) return DSTK_PACKED422;
+    if (isYUV(f) && isPackedFmt(f)) return d->log2_chroma_w ? DSTK_PACKED422 : DSTK_PACKED444;
     const int depth = d->comp[0].depth;
     if (isSemiPlanarYUV(f)) return depth == 8 ? DSTK_NV12 : depth == 16 ? DSTK_P016 : DSTK_P010;
     if (isPlanarYUV(f) || isGray(f)) return depth == 8 ? DSTK_PLANAR8 : depth == 16 ? DSTK_PLANAR16 : DSTK_PLANARN;
@@ -165,6 +165,13 @@ int dev_prepare(SwsInternal *c)
     const bool gray_any = isGray(o.src_format) || isGray(o.dst_format) || c->needAlpha;   // paths the fused kernels do not cover
     p.should_dither = isNBPS(o.src_format) || is16BPS(o.src_format);     // swscale.c:292-293
     p.full_chr = ((o.flags & SWS_FULL_CHR_H_INT) && isAnyRGB(o.dst_format)) ? 1 : 0;
+    if (p.dstKind == DSTK_PACKED444) {   // one work unit per pixel, like the full-chroma RGB writers
+        p.full_chr = 1;
+        p.d444_step = dd->comp[0].step; p.d444_y = dd->comp[0].offset; p.d444_u = dd->comp[1].offset; p.d444_v = dd->comp[2].offset; p.d444_a = dd->comp[3].offset;
+    }
+    if (p.srcKind == SRCK_PACKED444) {
+        p.s444_step = ds->comp[0].step; p.s444_y = ds->comp[0].offset; p.s444_u = ds->comp[1].offset; p.s444_v = ds->comp[2].offset; p.s444_a = ds->comp[3].offset;
+    }
     if (isAnyRGB(o.src_format) && !isPlanarRGB(o.src_format)) {
         p.src_pix_step = ds->comp[0].step;
         p.src_r_pos = ds->comp[0].offset; p.src_g_pos = ds->comp[1].offset; p.src_b_pos = ds->comp[2].offset;
@@ -1012,7 +1019,7 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
             hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.dstW, 0);
         }
         const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 ||
-                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_RGB48 || p.dstKind == DSTK_RGB16;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
+                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_RGB48 || p.dstKind == DSTK_RGB16;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
         if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;

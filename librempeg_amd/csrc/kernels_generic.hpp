@@ -17,6 +17,8 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
 {
     if (comp == 3 && p.srcKind == SRCK_RGB48)   // rgba64leToA_c: the 16-bit A word as is
         return ((const uint16_t *)(f.src[0] + (int64_t)row * f.srcStride[0]))[4 * x + 3];
+    if (comp == 3 && p.srcKind == SRCK_PACKED444)   // read_vuya_A_c / read_ayuv_A_c
+        return f.src[0][(int64_t)row * f.srcStride[0] + 4 * x + p.s444_a];
     if (comp == 3) {   // alpha line: plane 3 of yuva (8 bit), or rgbaToA_c / abgrToA_c (input.c:454-472) for 32 bpp RGB
         if (p.srcKind == SRCK_RGB32) {
             const int a = p.src_alpha_opaque ? 255 : f.src[0][(int64_t)row * f.srcStride[0] + 4 * x + p.src_a_pos];
@@ -124,6 +126,10 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         } else { const uint16_t *q = s + st * x; r = q[p.s16_r]; g = q[p.s16_g]; b = q[p.s16_b]; }
         const int o = comp == 0 ? 0 : comp == 1 ? 3 : 6;
         return (uint16_t)(((unsigned)t[o] * r + (unsigned)t[o + 1] * g + (unsigned)t[o + 2] * b + ((comp == 0 ? 0x2001u : 0x10001u) << 14)) >> 15);
+    }
+    case SRCK_PACKED444: {
+        const uint8_t *s = f.src[0] + (int64_t)row * f.srcStride[0] + p.s444_step * x;
+        return s[comp == 0 ? p.s444_y : comp == 1 ? p.s444_u : p.s444_v];
     }
     case SRCK_PACKED422: { // yuy2ToY_c / yuy2ToUV_c / yvy2ToUV_c (input.c:550-578), uyvyToY_c / uyvyToUV_c (:890-907)
         const uint8_t *s = f.src[0] + (int64_t)row * f.srcStride[0];
@@ -460,6 +466,38 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
             d[p.d16_b] = (uint16_t)clip_uintp2(((int)(B + Y) >> 14) + (1 << 15), 16);
             if (p.d16_step == 4) d[3] = (uint16_t)(clip_uintp2(A, 30) >> 14);
         }
+        return;
+    }
+    if (p.dstKind == DSTK_PACKED444) {   // yuv2ayuv_{X,2,1}_c_template (output.c:2903-3060), yuv2vyu444_{X,2,1}_c (:3171-3290); unit = pixel
+        int Y, U, V, A = 255;
+        if (mode == 0) {
+            Y = U = V = 1 << 18;
+            for (int j = 0; j < lfs; j++) Y += (int)((unsigned)LUM(j, i) * (unsigned)(int)lf[j]);
+            for (int j = 0; j < cfs; j++) { U += (int)((unsigned)CHU(j, i) * (unsigned)(int)cf[j]); V += (int)((unsigned)CHV(j, i) * (unsigned)(int)cf[j]); }
+            Y >>= 19; U >>= 19; V >>= 19;
+            if (p.need_alpha) {
+                A = 1 << 18;
+                for (int j = 0; j < lfs; j++) A += (int)((unsigned)ALP(j, i) * (unsigned)(int)lf[j]);
+                A >>= 19;
+                if (A & 0x100) A = clip_u8(A);
+            }
+        } else if (mode == 2) {
+            Y = (LUM(0, i) * (4096 - ya) + LUM(1, i) * ya) >> 19;
+            U = (CHU(0, i) * (4096 - ua) + CHU(1, i) * ua) >> 19;
+            V = (CHV(0, i) * (4096 - ua) + CHV(1, i) * ua) >> 19;
+            if (p.need_alpha) A = clip_u8((ALP(0, i) * (4096 - ya) + ALP(1, i) * ya) >> 19);
+        } else {
+            Y = (LUM(0, i) + 64) >> 7;
+            if (ua < 2048) { U = (CHU(0, i) + 64) >> 7; V = (CHV(0, i) + 64) >> 7; }
+            else { U = (CHU(0, i) + CHU(1, i) + 128) >> 8; V = (CHV(0, i) + CHV(1, i) + 128) >> 8; }
+            if (p.need_alpha) { A = (ALP(0, i) + 64) >> 7; if (A & 0x100) A = clip_u8(A); }
+        }
+        if (Y & 0x100) Y = clip_u8(Y);
+        if (U & 0x100) U = clip_u8(U);
+        if (V & 0x100) V = clip_u8(V);
+        uint8_t *d = drow + p.d444_step * i;
+        d[p.d444_y] = (uint8_t)Y; d[p.d444_u] = (uint8_t)U; d[p.d444_v] = (uint8_t)V;
+        if (p.d444_step == 4) d[p.d444_a] = (uint8_t)A;
         return;
     }
     if (p.dstKind == DSTK_PACKED422) {   // yuv2422_{X,2,1}_c_template, output.c:883-1000

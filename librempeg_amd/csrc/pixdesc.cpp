@@ -63,6 +63,12 @@ static const PixDesc g_descs[] = {
     GBRN(AV_PIX_FMT_GBRP9LE, "gbrp9le", 9), GBRN(AV_PIX_FMT_GBRP10LE, "gbrp10le", 10), GBRN(AV_PIX_FMT_GBRP12LE, "gbrp12le", 12),
     GBRN(AV_PIX_FMT_GBRP14LE, "gbrp14le", 14), GBRN(AV_PIX_FMT_GBRP16LE, "gbrp16le", 16),
     { AV_PIX_FMT_GBRPF32LE,"gbrpf32le",3, 0, 0, {{2,4,0,0,32},{0,4,0,0,32},{1,4,0,0,32},{0,0,0,0,0}}, PIXFLAG_PLANAR | PIXFLAG_RGB | PIXFLAG_FLOAT },
+    // packed 4:4:4, 8 bit (libavutil/pixdesc.c:2290-2324, :2895-2917)
+    { AV_PIX_FMT_VYU444, "vyu444", 3, 0, 0, {{0,3,1,0,8},{0,3,2,0,8},{0,3,0,0,8},{0,0,0,0,0}}, 0 },
+    { AV_PIX_FMT_UYVA, "uyva", 4, 0, 0, {{0,4,1,0,8},{0,4,0,0,8},{0,4,2,0,8},{0,4,3,0,8}}, PIXFLAG_ALPHA },
+    { AV_PIX_FMT_AYUV, "ayuv", 4, 0, 0, {{0,4,1,0,8},{0,4,2,0,8},{0,4,3,0,8},{0,4,0,0,8}}, PIXFLAG_ALPHA },
+    { AV_PIX_FMT_VUYA, "vuya", 4, 0, 0, {{0,4,2,0,8},{0,4,1,0,8},{0,4,0,0,8},{0,4,3,0,8}}, PIXFLAG_ALPHA },
+    { AV_PIX_FMT_VUYX, "vuyx", 4, 0, 0, {{0,4,2,0,8},{0,4,1,0,8},{0,4,0,0,8},{0,4,3,0,8}}, 0 },
     // planar 4:4:4 with the samples in the high bits of each 16-bit word
     { AV_PIX_FMT_YUV444P10MSBLE, "yuv444p10msble", 3, 0, 0, {{0,2,0,6,10},{1,2,0,6,10},{2,2,0,6,10},{0,0,0,0,0}}, PIXFLAG_PLANAR },
     { AV_PIX_FMT_YUV444P12MSBLE, "yuv444p12msble", 3, 0, 0, {{0,2,0,4,12},{1,2,0,4,12},{2,2,0,4,12},{0,0,0,0,0}}, PIXFLAG_PLANAR },

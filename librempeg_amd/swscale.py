@@ -47,6 +47,7 @@ _FORMATS = {
     "rgb565le": (37, "packed", 0, 0, 2), "rgb555le": (39, "packed", 0, 0, 2), "rgb444le": (52, "packed", 0, 0, 2),
     "bgr565le": (41, "packed", 0, 0, 2), "bgr555le": (43, "packed", 0, 0, 2), "bgr444le": (54, "packed", 0, 0, 2),
     "yuv444p10msble": (259, "planar", 0, 0, 2), "yuv444p12msble": (261, "planar", 0, 0, 2),
+    "vyu444": (230, "packed", 0, 0, 3), "uyva": (229, "packed", 0, 0, 4), "ayuv": (228, "packed", 0, 0, 4), "vuya": (205, "packed", 0, 0, 4), "vuyx": (208, "packed", 0, 0, 4),
     "rgb24": (2, "packed", 0, 0, 3), "bgr24": (3, "packed", 0, 0, 3),
     "argb": (25, "packed", 0, 0, 4), "rgba": (26, "packed", 0, 0, 4), "abgr": (27, "packed", 0, 0, 4), "bgra": (28, "packed", 0, 0, 4),
     "0rgb": (118, "packed", 0, 0, 4), "rgb0": (119, "packed", 0, 0, 4), "0bgr": (120, "packed", 0, 0, 4), "bgr0": (121, "packed", 0, 0, 4),

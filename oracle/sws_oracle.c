@@ -115,6 +115,12 @@ static const Desc descs[] = {
     GBRN(ORF_GBRP9LE, "gbrp9le", 9), GBRN(ORF_GBRP10LE, "gbrp10le", 10), GBRN(ORF_GBRP12LE, "gbrp12le", 12),
     GBRN(ORF_GBRP14LE, "gbrp14le", 14), GBRN(ORF_GBRP16LE, "gbrp16le", 16),
     { ORF_GBRPF32LE, "gbrpf32le", 3, 0, 0, {{2,4,0,0,32},{0,4,0,0,32},{1,4,0,0,32}}, PF_PLANAR | PF_RGB | PF_FLOAT },
+    /* packed 4:4:4, 8 bit (pixdesc.c:2290-2324, :2895-2917) */
+    { ORF_VYU444, "vyu444", 3, 0, 0, {{0,3,1,0,8},{0,3,2,0,8},{0,3,0,0,8}}, 0 },
+    { ORF_UYVA, "uyva", 4, 0, 0, {{0,4,1,0,8},{0,4,0,0,8},{0,4,2,0,8},{0,4,3,0,8}}, PF_ALPHA },
+    { ORF_AYUV, "ayuv", 4, 0, 0, {{0,4,1,0,8},{0,4,2,0,8},{0,4,3,0,8},{0,4,0,0,8}}, PF_ALPHA },
+    { ORF_VUYA, "vuya", 4, 0, 0, {{0,4,2,0,8},{0,4,1,0,8},{0,4,0,0,8},{0,4,3,0,8}}, PF_ALPHA },
+    { ORF_VUYX, "vuyx", 4, 0, 0, {{0,4,2,0,8},{0,4,1,0,8},{0,4,0,0,8},{0,4,3,0,8}}, 0 },
     /* planar 4:4:4 with the samples in the high bits (pixdesc.c yuv444p10msb / yuv444p12msb) */
     { ORF_YUV444P10MSBLE, "yuv444p10msble", 3, 0, 0, {{0,2,0,6,10},{1,2,0,6,10},{2,2,0,6,10}}, PF_PLANAR },
     { ORF_YUV444P12MSBLE, "yuv444p12msble", 3, 0, 0, {{0,2,0,4,12},{1,2,0,4,12},{2,2,0,4,12}}, PF_PLANAR },
@@ -126,6 +132,7 @@ static const Desc descs[] = {
     { ORF_BGR555LE, "bgr555le", 3, 0, 0, {{0,2,0,0,5},{0,2,0,5,5},{0,2,1,2,5}}, PF_RGB },
     { ORF_BGR444LE, "bgr444le", 3, 0, 0, {{0,2,0,0,4},{0,2,0,4,4},{0,2,1,0,4}}, PF_RGB },
 };
+static int isPacked444(int f) { return f == ORF_VYU444 || f == ORF_UYVA || f == ORF_AYUV || f == ORF_VUYA || f == ORF_VUYX; }
 static int isRGB16(int f) { return f == ORF_RGB565LE || f == ORF_RGB555LE || f == ORF_RGB444LE || f == ORF_BGR565LE || f == ORF_BGR555LE || f == ORF_BGR444LE; }
 
 static const Desc *desc_get(int fmt)
@@ -887,6 +894,10 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         if (!(!s32 && (d == ORF_BGRA || d == ORF_RGBA) && (flags & OR_SWS_BITEXACT)))
             c->unscaled_kind = UNSC_RGB2RGB;
     }
+    /* AYUV / VUYA / UYVA -> AYUV / VUYA / VUYX / UYVA byte shuffles (:1938-1949, :2459-2461); vuyx is never a source, uyva never a destination but of ayuv / vuya */
+    if (s != d && ((s == ORF_AYUV && (d == ORF_VUYA || d == ORF_VUYX || d == ORF_UYVA)) || (s == ORF_VUYA && (d == ORF_AYUV || d == ORF_UYVA)) ||
+                   (s == ORF_UYVA && (d == ORF_AYUV || d == ORF_VUYA || d == ORF_VUYX))))
+        c->unscaled_kind = UNSC_RGB2RGB;
     if (isAnyRGB(s) && isAnyRGB(d) && isPacked(s) && isPacked(d) && (isRGB16(s) || isRGB16(d))) {
         /* findRgbConvFn's two switch tables (:1941-1979) on (srcFormatBpp, dstFormatBpp) for formats of the same / of opposite
          * "in int" channel order; rgbToRgbWrapper only without dither need, or with FAST_BILINEAR / POINT (:2459-2463) */
@@ -1368,6 +1379,7 @@ static int unscaled_rgb2rgb(OrSws *c, const uint8_t *const src[], const int srcS
         for (int x = 0; x < c->o.src_w; x++, s += ds->c[0].step, d += dd->c[0].step) {
             for (int k = 0; k < 3; k++) d[dd->c[k].offset] = s[ds->c[k].offset];
             if (da) d[dd->c[3].offset] = sa ? s[ds->c[3].offset] : 255;
+            else if (dd->nb == 4 && ds->nb == 4) d[dd->c[3].offset] = s[ds->c[3].offset];   /* vuyx: the X byte is the shuffled source alpha */
         }
     }
     return srcSliceH;
@@ -1756,6 +1768,12 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
         for (i = 0; i < w; i++) d[i] = s[i] >> sh;
         return tmp;
     }
+    if (isPacked444(f)) { /* read_vuyx_Y_c / read_ayuv_Y_c / vyuToY_c input.c:741-799: the byte at the descriptor's Y offset */
+        const Desc *ds = desc_get(f);
+        const uint8_t *s = src[0] + y * stride[0] + ds->c[0].offset;
+        for (i = 0; i < w; i++) tmp[i] = s[ds->c[0].step * i];
+        return tmp;
+    }
     if (f == ORF_YUYV422 || f == ORF_UYVY422 || f == ORF_YVYU422) { /* yuy2ToY_c input.c:550-556, uyvyToY_c :890-896 */
         const uint8_t *s = src[0] + y * stride[0] + desc_get(f)->c[0].offset;
         for (i = 0; i < w; i++) tmp[i] = s[2 * i];
@@ -1898,6 +1916,12 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
             du[i] = (uint16_t)(((unsigned)t[RU] * r + (unsigned)t[GU] * g + (unsigned)t[BU] * b + (0x10001u << 14)) >> 15);
             dv[i] = (uint16_t)(((unsigned)t[RV] * r + (unsigned)t[GV] * g + (unsigned)t[BV] * b + (0x10001u << 14)) >> 15);
         }
+        return;
+    }
+    if (isPacked444(f)) { /* read_vuyx_UV_c / read_ayuv_UV_c / read_uyva_UV_c / vyuToUV_c input.c:731-809 */
+        const Desc *ds = desc_get(f);
+        const uint8_t *s = src[0] + y * stride[0];
+        for (i = 0; i < w; i++) { tu[i] = s[ds->c[0].step * i + ds->c[1].offset]; tv[i] = s[ds->c[0].step * i + ds->c[2].offset]; }
         return;
     }
     if (f == ORF_YUYV422 || f == ORF_UYVY422 || f == ORF_YVYU422) { /* yuy2ToUV_c / yvy2ToUV_c input.c:558-578, uyvyToUV_c :898-907 */
@@ -2528,6 +2552,65 @@ static void write_packed422_line(const OrSws *c, const Planes *P, uint8_t *dest,
 #undef CV
 }
 
+
+/* packed_vscale + yuv2ayuv_{1,2,X}_c_template (output.c:2903-3060: ayuv / vuya / vuyx / uyva) and yuv2vyu444_{1,2,X}_c (:3171-3290) */
+static void write_packed444_line(const OrSws *c, const Planes *P, uint8_t *dest, int y)
+{
+    const int dstW = c->o.dst_w, lw = dstW, cw = c->chrDstW;
+    const int srcH = c->o.src_h, chrSrcH = c->chrSrcH;
+    const int chrY = y >> c->chrDstVSub;
+    const int lfs = c->vLumFilterSize, cfs = c->vChrFilterSize;
+    const int16_t *lf = c->vLumFilter + y * lfs, *cf = c->vChrFilter + chrY * cfs;
+    const int firstLum = ORMAX(1 - lfs, c->vLumFilterPos[y]);
+    const int firstChr = ORMAX(1 - cfs, c->vChrFilterPos[chrY]);
+    const Desc *dd = desc_get(c->o.dst_format);
+    const int step = dd->c[0].step, hasAlpha = c->needAlpha;
+    int i, j, mode, ua = 0, ya = 0;
+#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+#define CU(j) (P->chrU + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+#define CV(j) (P->chrV + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+#define AL(j) (P->alp + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+    if (lfs == 1 && cfs == 1) mode = 1;
+    else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 1; ua = (uint16_t)cf[1]; }
+    else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
+             (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 2; ya = (uint16_t)lf[1]; ua = (uint16_t)cf[1]; }
+    else mode = 0;
+    for (i = 0; i < dstW; i++) {
+        int Y, U, V, A = 255;
+        if (mode == 0) {
+            Y = U = V = 1 << 18;
+            for (j = 0; j < lfs; j++) Y += (int)(L(j)[i] * (unsigned)lf[j]);
+            for (j = 0; j < cfs; j++) { U += (int)(CU(j)[i] * (unsigned)cf[j]); V += (int)(CV(j)[i] * (unsigned)cf[j]); }
+            Y >>= 19; U >>= 19; V >>= 19;
+            if (hasAlpha) {
+                A = 1 << 18;
+                for (j = 0; j < lfs; j++) A += (int)(AL(j)[i] * (unsigned)lf[j]);
+                A >>= 19;
+                if (A & 0x100) A = clip_u8(A);
+            }
+        } else if (mode == 2) {
+            Y = (L(0)[i] * (4096 - ya) + L(1)[i] * ya) >> 19;
+            U = (CU(0)[i] * (4096 - ua) + CU(1)[i] * ua) >> 19;
+            V = (CV(0)[i] * (4096 - ua) + CV(1)[i] * ua) >> 19;
+            if (hasAlpha) A = clip_u8((AL(0)[i] * (4096 - ya) + AL(1)[i] * ya) >> 19);
+        } else {
+            Y = (L(0)[i] + 64) >> 7;
+            if (ua < 2048) { U = (CU(0)[i] + 64) >> 7; V = (CV(0)[i] + 64) >> 7; }
+            else { U = (CU(0)[i] + CU(1)[i] + 128) >> 8; V = (CV(0)[i] + CV(1)[i] + 128) >> 8; }
+            if (hasAlpha) { A = (AL(0)[i] + 64) >> 7; if (A & 0x100) A = clip_u8(A); }
+        }
+        if (Y & 0x100) Y = clip_u8(Y);
+        if (U & 0x100) U = clip_u8(U);
+        if (V & 0x100) V = clip_u8(V);
+        dest[step * i + dd->c[0].offset] = (uint8_t)Y; dest[step * i + dd->c[1].offset] = (uint8_t)U; dest[step * i + dd->c[2].offset] = (uint8_t)V;
+        if (step == 4) dest[4 * i + dd->c[3].offset] = (uint8_t)A;
+    }
+#undef L
+#undef CU
+#undef CV
+#undef AL
+}
+
 /* any_vscale (vscale.c:173-212) + yuv2gbrp_full_X_c / yuv2gbrp16_full_X_c / yuv2gbrpf32_full_X_c (output.c:2342-2580):
  * planar RGB destinations always use the X form.  dst planes are G, B, R. */
 static void write_planar_rgb_line(const OrSws *c, const Planes *P, uint8_t *const dst[], const int dstStride[], int y)
@@ -2626,6 +2709,11 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
                 uint16_t *d16 = (uint16_t *)t0;
                 for (int i = 0; i < srcW; i++) d16[i] = sp[4 * i];
                 line = t0;
+            } else if (isPacked444(sf)) { /* read_vuya_A_c / read_ayuv_A_c input.c:749-781 */
+                const Desc *dsd = desc_get(sf);
+                const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0] + dsd->c[3].offset;
+                for (int i = 0; i < srcW; i++) t0[i] = sp[4 * i];
+                line = t0;
             } else if (isAnyRGB(sf)) { /* rgbaToA_c / abgrToA_c input.c:454-472 */
                 const Desc *dsd = desc_get(sf);
                 const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0] + dsd->c[3].offset;
@@ -2683,6 +2771,8 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
                                       c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither, 3, 0);
                 }
             }
+        } else if (isPacked444(df)) {
+            write_packed444_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
         } else if (df == ORF_YUYV422 || df == ORF_UYVY422 || df == ORF_YVYU422) {
             write_packed422_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
         } else if (df == ORF_RGB48LE || df == ORF_BGR48LE || df == ORF_RGBA64LE || df == ORF_BGRA64LE) {

@@ -45,6 +45,7 @@ enum {
     ORF_RGB565BE = 36, ORF_RGB565LE = 37, ORF_RGB555BE = 38, ORF_RGB555LE = 39, ORF_BGR565BE = 40, ORF_BGR565LE = 41,
     ORF_BGR555BE = 42, ORF_BGR555LE = 43, ORF_RGB444LE = 52, ORF_RGB444BE = 53, ORF_BGR444LE = 54, ORF_BGR444BE = 55,
     ORF_YUV444P10MSBBE = 258, ORF_YUV444P10MSBLE = 259, ORF_YUV444P12MSBBE = 260, ORF_YUV444P12MSBLE = 261,
+    ORF_VUYA = 205, ORF_VUYX = 208, ORF_AYUV = 228, ORF_UYVA = 229, ORF_VYU444 = 230,
     ORF_GBRP9LE = 73, ORF_GBRP10LE = 75, ORF_GBRP16LE = 77, ORF_GBRP12LE = 135, ORF_GBRP14LE = 137,
 };
 

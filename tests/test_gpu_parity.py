@@ -89,10 +89,11 @@ GRAYS = ["gray8", "gray9le", "gray10le", "gray12le", "gray14le", "gray16le"]
 RGB16 = ["rgb48le", "bgr48le", "rgba64le", "bgra64le"]
 BIG_ENDIAN = ["yuv420p10be", "yuv422p12be", "yuv444p16be", "yuv440p10be", "p010be", "p416be", "gbrp12be", "gbrp16be", "gray10be", "gray16be",
               "rgb48be", "bgr48be", "rgba64be", "bgra64be", "gbrpf32be"]
+PACKED444 = ["vyu444", "uyva", "ayuv", "vuya", "vuyx"]
 MSB = ["yuv444p10msble", "yuv444p12msble", "yuv444p10msbbe"]
 RGB_LOW = ["rgb565le", "bgr565le", "rgb555le", "bgr555le", "rgb444le", "bgr444le", "rgb565be", "bgr555be"]
-FORMAT_MATRIX_SRC = MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
-FORMAT_MATRIX_DST = MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+FORMAT_MATRIX_SRC = PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+FORMAT_MATRIX_DST = PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
 
 
 @pytest.mark.parametrize("sfmt", FORMAT_MATRIX_SRC)
@@ -164,6 +165,8 @@ def _slice_ptrs(frame, fmt, y0):
 
 
 SLICED_UNSCALED = [
+    ("ayuv", "vuya", BX), ("ayuv", "vuyx", 0), ("ayuv", "uyva", BX), ("vuya", "ayuv", BX), ("vuya", "uyva", 0), ("uyva", "ayuv", BX), ("uyva", "vuya", BX),
+    ("uyva", "vuyx", BX), ("vuyx", "vuyx", BX), ("vyu444", "vyu444", 0),
     ("yuv444p10msble", "yuv444p10le", 0), ("yuv444p10le", "yuv444p12msble", 0), ("yuv444p12msble", "yuv444p", BX), ("yuv444p", "yuv444p10msble", BX),
     ("yuv444p10msble", "yuv444p10msbbe", 0),
     ("yuv420p", "rgb565le", BX), ("yuv422p", "bgr565le", 0), ("yuv420p", "rgb555le", BX), ("yuv422p", "bgr555le", BX), ("yuv420p", "rgb444le", BX),
@@ -238,7 +241,7 @@ def test_fast_bilinear(geom):
         run_case(sw, sh, sfmt, dw & ~1, dh, dfmt, FB, seed=sw + 1)
 
 
-ALPHA_FMTS = ["rgba", "bgra", "argb", "abgr", "yuva420p", "yuva422p", "yuva444p", "rgba64le", "bgra64le"]
+ALPHA_FMTS = ["rgba", "bgra", "argb", "abgr", "yuva420p", "yuva422p", "yuva444p", "rgba64le", "bgra64le", "ayuv", "vuya", "uyva"]
 
 
 @pytest.mark.parametrize("sfmt", ALPHA_FMTS + ["rgb0", "0bgr", "yuv420p", "rgb24"])
