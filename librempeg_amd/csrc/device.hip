@@ -104,6 +104,7 @@ static int src_kind_of(int f)
     if (isAnyRGB(f) && d->comp[0].depth == 16) return SRCK_RGB48;
     if (isAnyRGB(f) && d->comp[0].step == 2) return SRCK_RGB16;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? SRCK_RGB24 : SRCK_RGB32;
+    if (isYUV(f) && isPackedFmt(f) && d->comp[0].depth > 8) return SRCK_PACKEDHI;
     if (isYUV(f) && isPackedFmt(f)) return d->log2_chroma_w ? SRCK_PACKED422 : SRCK_PACKED444;
     if (isSemiPlanarYUV(f)) return d->comp[0].depth == 8 ? SRCK_NV12 : SRCK_P010;
     if (isPlanarYUV(f) || isGray(f)) return d->comp[0].depth == 8 ? SRCK_PLANAR8 : SRCK_PLANAR16;
@@ -117,6 +118,7 @@ static int dst_kind_of(int f)
     if (isAnyRGB(f) && d->comp[0].depth == 16) return DSTK_RGB48;
     if (isAnyRGB(f) && d->comp[0].step == 2) return DSTK_RGB16;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? DSTK_RGB24 : DSTK_RGB32;
+    if (isYUV(f) && isPackedFmt(f) && d->comp[0].depth > 8) return DSTK_PACKEDHI;
     if (isYUV(f) && isPackedFmt(f)) return d->log2_chroma_w ? DSTK_PACKED422 : DSTK_PACKED444;
     const int depth = d->comp[0].depth;
     if (isSemiPlanarYUV(f)) return depth == 8 ? DSTK_NV12 : depth == 16 ? DSTK_P016 : DSTK_P010;
@@ -165,6 +167,26 @@ int dev_prepare(SwsInternal *c)
     const bool gray_any = isGray(o.src_format) || isGray(o.dst_format) || c->needAlpha;   // paths the fused kernels do not cover
     p.should_dither = isNBPS(o.src_format) || is16BPS(o.src_format);     // swscale.c:292-293
     p.full_chr = ((o.flags & SWS_FULL_CHR_H_INT) && isAnyRGB(o.dst_format)) ? 1 : 0;
+    if (p.srcKind == SRCK_PACKEDHI)
+        for (int k = 0; k < ds->nb_components; k++) {
+            p.shi_step[k] = ds->comp[k].step; p.shi_off[k] = ds->comp[k].offset; p.shi_shift[k] = ds->comp[k].shift;
+            p.shi_mask[k] = (1 << ds->comp[k].depth) - 1;
+        }
+    if (p.dstKind == DSTK_PACKEDHI) {
+        const int df = o.dst_format;
+        p.dhi_sub = dd->log2_chroma_w; p.dhi_bits = dd->comp[0].depth;
+        p.dhi_unit_bytes = p.dhi_sub ? 8 : dd->comp[0].step;
+        p.full_chr = p.dhi_sub ? 0 : 1;       // work unit: pixel pair (4:2:2) or pixel
+        for (int k = 0; k < 3; k++) p.dhi_bitpos[k] = 8 * dd->comp[k].offset + dd->comp[k].shift;
+        p.dhi_bitpos[3] = p.dhi_bitpos[0] + 32;                                  // second luma sample of a 4:2:2 unit
+        p.dhi_alpha = df == AV_PIX_FMT_AYUV64LE; p.dhi_bitpos[4] = 0;
+        uint64_t fill = 0;
+        if (df == AV_PIX_FMT_XV30LE) fill = 3ull << 30;                          // yuv2v30_X_c_template: A = 3
+        else if (df == AV_PIX_FMT_V30XLE) fill = 3ull;
+        else if (df == AV_PIX_FMT_XV36LE) fill = 0xFFF0ull << 48;                // av_clip_uintp2(65535, 12) << 4
+        else if (df == AV_PIX_FMT_XV48LE) fill = 0xFFFFull << 48;
+        p.dhi_fill_lo = (uint32_t)fill; p.dhi_fill_hi = (uint32_t)(fill >> 32);
+    }
     if (p.dstKind == DSTK_PACKED444) {   // one work unit per pixel, like the full-chroma RGB writers
         p.full_chr = 1;
         p.d444_step = dd->comp[0].step; p.d444_y = dd->comp[0].offset; p.d444_u = dd->comp[1].offset; p.d444_v = dd->comp[2].offset; p.d444_a = dd->comp[3].offset;
@@ -1019,7 +1041,7 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
             hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.dstW, 0);
         }
         const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 ||
-                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_RGB48 || p.dstKind == DSTK_RGB16;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
+                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI || p.dstKind == DSTK_RGB48 || p.dstKind == DSTK_RGB16;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
         if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;

@@ -15,6 +15,7 @@ enum SrcKind {
     SRCK_RGB48,         // rgb48le / bgr48le / rgba64le / bgra64le; rgb48/64ToY/UV(_half)_c_template input.c:45-203
     SRCK_PACKED422,     // yuyv422 / uyvy422 / yvyu422: yuy2ToY/UV, yvy2ToUV, uyvyToY/UV input.c:550-578, :890-907
     SRCK_GBRP16,        // planar 9..16-bit RGB; planar_rgb16_s16_to_y/uv input.c:1216-1270
+    SRCK_PACKEDHI,      // y210 / y212 / y216, xv30 / v30x, xv36, xv48, ayuv64: (16-bit word at the descriptor offset) >> shift, masked (input.c:580-606, :663-729, :811-866)
     SRCK_PACKED444,     // ayuv / vuya / vuyx / uyva / vyu444: read_*_Y/UV/A_c, vyuToY/UV_c input.c:731-809 (bytes at the descriptor offsets)
     SRCK_RGB16,         // rgb565 / rgb555 / rgb444 and the bgr orders: rgb16_32To*_c_template with the 16 bpp rows of input.c:396-401
 };
@@ -34,6 +35,7 @@ enum DstKind {
     DSTK_RGB48,         // rgb48le / bgr48le / rgba64le / bgra64le: yuv2rgba64_{X,2,1}_c_template + _full_ variants output.c:1115-1560
     DSTK_PACKED422,     // yuyv422 / yvyu422 / uyvy422: yuv2422_{1,2,X}_c_template output.c:883-1000
     DSTK_P016,          // 16-bit semi-planar: luma yuv2planeX_16_c, chroma yuv2nv12cX_16_c_template output.c:189-217
+    DSTK_PACKEDHI,      // yuv2y2xxle_X_c, yuv2y216le_X_c, yuv2xv30le / v30xle_X_c, yuv2xv36le_X_c, yuv2ayuv64le / xv48le_X_c (output.c:2712-2866, :3088-3169)
     DSTK_PACKED444,     // ayuv / vuya / vuyx / uyva: yuv2ayuv_{1,2,X}_c_template output.c:2903-3060; vyu444: yuv2vyu444_{1,2,X}_c :3171-3290
     DSTK_RGB16,         // rgb565 / rgb555 / rgb444 (+ bgr): yuv2rgb_write 16/15/12 bpp with ordered dither output.c:1714-1748
 };
@@ -161,6 +163,9 @@ struct SwsDevParams {
     // written by the planar or packed writers; dst_alpha_fill: the destination has an alpha plane the source cannot feed
     int32_t need_alpha, src_a_pos, dst_alpha_fill;
     int32_t s16_step, s16_r, s16_g, s16_b, d16_step, d16_r, d16_g, d16_b;   // 16-bit packed RGB: words per pixel and word offsets of R, G, B
+    int32_t shi_step[4], shi_off[4], shi_shift[4], shi_mask[4];   // SRCK_PACKEDHI: per component (Y, U, V, A) byte step / offset, right shift, mask
+    int32_t dhi_unit_bytes, dhi_bits, dhi_sub, dhi_alpha, dhi_bitpos[5];   // DSTK_PACKEDHI: bytes per unit (pixel, or pixel pair when dhi_sub), sample depth, bit position of Y, U, V, Y2, A inside the unit
+    uint32_t dhi_fill_lo, dhi_fill_hi;   // constant bits of a unit (the X fields)
     int32_t s444_step, s444_y, s444_u, s444_v, s444_a, d444_step, d444_y, d444_u, d444_v, d444_a;   // packed 4:4:4: pixel step and byte offsets
     int32_t s422_y, s422_u, s422_v, d422_y, d422_u, d422_v;   // packed 4:2:2: byte offsets of Y0, U, V inside a 4-byte pixel pair
     int32_t s16_maskr, s16_maskg, s16_maskb, s16_rsh, s16_gsh, s16_bsh, s16_S, s16_is565;   // SRCK_RGB16 reader rows (input.c:396-401)

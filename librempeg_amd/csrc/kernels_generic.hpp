@@ -17,6 +17,10 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
 {
     if (comp == 3 && p.srcKind == SRCK_RGB48)   // rgba64leToA_c: the 16-bit A word as is
         return ((const uint16_t *)(f.src[0] + (int64_t)row * f.srcStride[0]))[4 * x + 3];
+    if (p.srcKind == SRCK_PACKEDHI) {   // the descriptor's field of component comp
+        const uint8_t *s = f.src[0] + (int64_t)row * f.srcStride[0] + p.shi_step[comp] * x + p.shi_off[comp];
+        return (*(const uint16_t *)s >> p.shi_shift[comp]) & p.shi_mask[comp];
+    }
     if (comp == 3 && p.srcKind == SRCK_PACKED444)   // read_vuya_A_c / read_ayuv_A_c
         return f.src[0][(int64_t)row * f.srcStride[0] + 4 * x + p.s444_a];
     if (comp == 3) {   // alpha line: plane 3 of yuva (8 bit), or rgbaToA_c / abgrToA_c (input.c:454-472) for 32 bpp RGB
@@ -466,6 +470,41 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
             d[p.d16_b] = (uint16_t)clip_uintp2(((int)(B + Y) >> 14) + (1 << 15), 16);
             if (p.d16_step == 4) d[3] = (uint16_t)(clip_uintp2(A, 30) >> 14);
         }
+        return;
+    }
+    if (p.dstKind == DSTK_PACKEDHI) {   // X writers only (no packed1 / packed2 functions exist for these formats)
+        const int bits = p.dhi_bits, n = p.dhi_sub ? 4 : 3;
+        uint64_t px = (uint64_t)p.dhi_fill_lo | ((uint64_t)p.dhi_fill_hi << 32);
+        for (int k = 0; k < n; k++) {
+            const bool chroma = k == 1 || k == 2;
+            const int fs = chroma ? cfs : lfs;
+            const int16_t *fl = chroma ? cf : lf;
+            const int x = chroma ? i : (p.dhi_sub ? 2 * i + (k == 3) : i);
+            int v;
+            if (bits == 16) {
+                int acc = (1 << 14) - 0x40000000;
+                for (int j = 0; j < fs; j++) acc += (int)((unsigned)(k == 1 ? CHU(j, x) : k == 2 ? CHV(j, x) : LUM(j, x)) * (unsigned)(int)fl[j]);
+                v = 0x8000 + min(max(acc >> 15, -32768), 32767);
+            } else {
+                const int shift = 11 + 16 - bits;
+                int acc = 1 << (shift - 1);
+                for (int j = 0; j < fs; j++) acc += (int)((unsigned)(k == 1 ? CHU(j, x) : k == 2 ? CHV(j, x) : LUM(j, x)) * (unsigned)(int)fl[j]);
+                v = clip_uintp2(acc >> shift, bits);
+            }
+            px |= (uint64_t)(uint32_t)v << p.dhi_bitpos[k];
+        }
+        if (p.dhi_alpha) {
+            int v = 65535;
+            if (p.need_alpha) {
+                int acc = (1 << 14) - 0x40000000;
+                for (int j = 0; j < lfs; j++) acc += (int)((unsigned)ALP(j, i) * (unsigned)(int)lf[j]);
+                v = 0x8000 + min(max(acc >> 15, -32768), 32767);
+            }
+            px |= (uint64_t)(uint32_t)v << p.dhi_bitpos[4];
+        }
+        uint8_t *d = drow + (int64_t)p.dhi_unit_bytes * i;
+        if (p.dhi_unit_bytes == 4) *(uint32_t *)d = (uint32_t)px;
+        else { ((uint32_t *)d)[0] = (uint32_t)px; ((uint32_t *)d)[1] = (uint32_t)(px >> 32); }
         return;
     }
     if (p.dstKind == DSTK_PACKED444) {   // yuv2ayuv_{X,2,1}_c_template (output.c:2903-3060), yuv2vyu444_{X,2,1}_c (:3171-3290); unit = pixel

@@ -63,6 +63,15 @@ static const PixDesc g_descs[] = {
     GBRN(AV_PIX_FMT_GBRP9LE, "gbrp9le", 9), GBRN(AV_PIX_FMT_GBRP10LE, "gbrp10le", 10), GBRN(AV_PIX_FMT_GBRP12LE, "gbrp12le", 12),
     GBRN(AV_PIX_FMT_GBRP14LE, "gbrp14le", 14), GBRN(AV_PIX_FMT_GBRP16LE, "gbrp16le", 16),
     { AV_PIX_FMT_GBRPF32LE,"gbrpf32le",3, 0, 0, {{2,4,0,0,32},{0,4,0,0,32},{1,4,0,0,32},{0,0,0,0,0}}, PIXFLAG_PLANAR | PIXFLAG_RGB | PIXFLAG_FLOAT },
+    // packed YUV with 10..16-bit samples (pixdesc.c:239-262, :2327-2350, :2973-3090, :3248-3270); X fields are not components
+    { AV_PIX_FMT_Y210LE, "y210le", 3, 1, 0, {{0,4,0,6,10},{0,8,2,6,10},{0,8,6,6,10},{0,0,0,0,0}}, 0 },
+    { AV_PIX_FMT_Y212LE, "y212le", 3, 1, 0, {{0,4,0,4,12},{0,8,2,4,12},{0,8,6,4,12},{0,0,0,0,0}}, 0 },
+    { AV_PIX_FMT_Y216LE, "y216le", 3, 1, 0, {{0,4,0,0,16},{0,8,2,0,16},{0,8,6,0,16},{0,0,0,0,0}}, 0 },
+    { AV_PIX_FMT_XV30LE, "xv30le", 3, 0, 0, {{0,4,1,2,10},{0,4,0,0,10},{0,4,2,4,10},{0,0,0,0,0}}, 0 },
+    { AV_PIX_FMT_V30XLE, "v30xle", 3, 0, 0, {{0,4,1,4,10},{0,4,0,2,10},{0,4,2,6,10},{0,0,0,0,0}}, 0 },
+    { AV_PIX_FMT_XV36LE, "xv36le", 3, 0, 0, {{0,8,2,4,12},{0,8,0,4,12},{0,8,4,4,12},{0,0,0,0,0}}, 0 },
+    { AV_PIX_FMT_XV48LE, "xv48le", 3, 0, 0, {{0,8,2,0,16},{0,8,0,0,16},{0,8,4,0,16},{0,0,0,0,0}}, 0 },
+    { AV_PIX_FMT_AYUV64LE, "ayuv64le", 4, 0, 0, {{0,8,2,0,16},{0,8,4,0,16},{0,8,6,0,16},{0,8,0,0,16}}, PIXFLAG_ALPHA },
     // packed 4:4:4, 8 bit (libavutil/pixdesc.c:2290-2324, :2895-2917)
     { AV_PIX_FMT_VYU444, "vyu444", 3, 0, 0, {{0,3,1,0,8},{0,3,2,0,8},{0,3,0,0,8},{0,0,0,0,0}}, 0 },
     { AV_PIX_FMT_UYVA, "uyva", 4, 0, 0, {{0,4,1,0,8},{0,4,0,0,8},{0,4,2,0,8},{0,4,3,0,8}}, PIXFLAG_ALPHA },
@@ -143,6 +152,7 @@ bool isDataInHighBits(int f)
 int pix_be_twin(int fmt)
 {
     static const int pairs[][2] = {
+    { AV_PIX_FMT_XV36BE, AV_PIX_FMT_XV36LE }, { AV_PIX_FMT_XV48BE, AV_PIX_FMT_XV48LE }, { AV_PIX_FMT_AYUV64BE, AV_PIX_FMT_AYUV64LE },
     { AV_PIX_FMT_YUV444P10MSBBE, AV_PIX_FMT_YUV444P10MSBLE }, { AV_PIX_FMT_YUV444P12MSBBE, AV_PIX_FMT_YUV444P12MSBLE },
     { AV_PIX_FMT_RGB565BE, AV_PIX_FMT_RGB565LE }, { AV_PIX_FMT_RGB555BE, AV_PIX_FMT_RGB555LE }, { AV_PIX_FMT_RGB444BE, AV_PIX_FMT_RGB444LE },
     { AV_PIX_FMT_BGR565BE, AV_PIX_FMT_BGR565LE }, { AV_PIX_FMT_BGR555BE, AV_PIX_FMT_BGR555LE }, { AV_PIX_FMT_BGR444BE, AV_PIX_FMT_BGR444LE },

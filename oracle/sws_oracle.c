@@ -115,6 +115,15 @@ static const Desc descs[] = {
     GBRN(ORF_GBRP9LE, "gbrp9le", 9), GBRN(ORF_GBRP10LE, "gbrp10le", 10), GBRN(ORF_GBRP12LE, "gbrp12le", 12),
     GBRN(ORF_GBRP14LE, "gbrp14le", 14), GBRN(ORF_GBRP16LE, "gbrp16le", 16),
     { ORF_GBRPF32LE, "gbrpf32le", 3, 0, 0, {{2,4,0,0,32},{0,4,0,0,32},{1,4,0,0,32}}, PF_PLANAR | PF_RGB | PF_FLOAT },
+    /* packed YUV with 10..16-bit samples (pixdesc.c:239-262, :2327-2350, :2973-3090, :3248-3270); the X fields are not components */
+    { ORF_Y210LE, "y210le", 3, 1, 0, {{0,4,0,6,10},{0,8,2,6,10},{0,8,6,6,10}}, 0 },
+    { ORF_Y212LE, "y212le", 3, 1, 0, {{0,4,0,4,12},{0,8,2,4,12},{0,8,6,4,12}}, 0 },
+    { ORF_Y216LE, "y216le", 3, 1, 0, {{0,4,0,0,16},{0,8,2,0,16},{0,8,6,0,16}}, 0 },
+    { ORF_XV30LE, "xv30le", 3, 0, 0, {{0,4,1,2,10},{0,4,0,0,10},{0,4,2,4,10}}, 0 },
+    { ORF_V30XLE, "v30xle", 3, 0, 0, {{0,4,1,4,10},{0,4,0,2,10},{0,4,2,6,10}}, 0 },
+    { ORF_XV36LE, "xv36le", 3, 0, 0, {{0,8,2,4,12},{0,8,0,4,12},{0,8,4,4,12}}, 0 },
+    { ORF_XV48LE, "xv48le", 3, 0, 0, {{0,8,2,0,16},{0,8,0,0,16},{0,8,4,0,16}}, 0 },
+    { ORF_AYUV64LE, "ayuv64le", 4, 0, 0, {{0,8,2,0,16},{0,8,4,0,16},{0,8,6,0,16},{0,8,0,0,16}}, PF_ALPHA },
     /* packed 4:4:4, 8 bit (pixdesc.c:2290-2324, :2895-2917) */
     { ORF_VYU444, "vyu444", 3, 0, 0, {{0,3,1,0,8},{0,3,2,0,8},{0,3,0,0,8}}, 0 },
     { ORF_UYVA, "uyva", 4, 0, 0, {{0,4,1,0,8},{0,4,0,0,8},{0,4,2,0,8},{0,4,3,0,8}}, PF_ALPHA },
@@ -132,6 +141,7 @@ static const Desc descs[] = {
     { ORF_BGR555LE, "bgr555le", 3, 0, 0, {{0,2,0,0,5},{0,2,0,5,5},{0,2,1,2,5}}, PF_RGB },
     { ORF_BGR444LE, "bgr444le", 3, 0, 0, {{0,2,0,0,4},{0,2,0,4,4},{0,2,1,0,4}}, PF_RGB },
 };
+static int isPackedHi(int f) { return f == ORF_Y210LE || f == ORF_Y212LE || f == ORF_Y216LE || f == ORF_XV30LE || f == ORF_V30XLE || f == ORF_XV36LE || f == ORF_XV48LE || f == ORF_AYUV64LE; }
 static int isPacked444(int f) { return f == ORF_VYU444 || f == ORF_UYVA || f == ORF_AYUV || f == ORF_VUYA || f == ORF_VUYX; }
 static int isRGB16(int f) { return f == ORF_RGB565LE || f == ORF_RGB555LE || f == ORF_RGB444LE || f == ORF_BGR565LE || f == ORF_BGR555LE || f == ORF_BGR444LE; }
 
@@ -147,6 +157,7 @@ static const Desc *desc_get(int fmt)
  * writers are the LE ones behind AV_RB16 / AV_WB16: input.c:608-629, output.c output_pixel macros); converter selection follows
  * the reference's rules, which only name a byte order for planarToP01xWrapper / planar8ToP01xleWrapper (native-endian only). */
 static const int be_pairs[][2] = {
+    { ORF_XV36BE, ORF_XV36LE }, { ORF_XV48BE, ORF_XV48LE }, { ORF_AYUV64BE, ORF_AYUV64LE },
     { ORF_YUV444P10MSBBE, ORF_YUV444P10MSBLE }, { ORF_YUV444P12MSBBE, ORF_YUV444P12MSBLE },
     { ORF_RGB565BE, ORF_RGB565LE }, { ORF_RGB555BE, ORF_RGB555LE }, { ORF_RGB444BE, ORF_RGB444LE },
     { ORF_BGR565BE, ORF_BGR565LE }, { ORF_BGR555BE, ORF_BGR555LE }, { ORF_BGR444BE, ORF_BGR444LE },
@@ -1768,6 +1779,14 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
         for (i = 0; i < w; i++) d[i] = s[i] >> sh;
         return tmp;
     }
+    if (isPackedHi(f)) { /* y210/y212/y216 le_Y_c (input.c:580-606), read_ayuv64le_Y_c (:663), read_xv30le/v30xle/xv36le_Y_c (:811-857): the
+                          * descriptor's field, (16-bit word at offset) >> shift, masked to the depth */
+        const Desc *ds = desc_get(f);
+        const uint8_t *s = src[0] + y * stride[0] + ds->c[0].offset;
+        uint16_t *d = (uint16_t *)tmp;
+        for (i = 0; i < w; i++) { uint16_t v; memcpy(&v, s + ds->c[0].step * i, 2); d[i] = (uint16_t)((v >> ds->c[0].shift) & ((1u << ds->c[0].depth) - 1)); }
+        return tmp;
+    }
     if (isPacked444(f)) { /* read_vuyx_Y_c / read_ayuv_Y_c / vyuToY_c input.c:741-799: the byte at the descriptor's Y offset */
         const Desc *ds = desc_get(f);
         const uint8_t *s = src[0] + y * stride[0] + ds->c[0].offset;
@@ -1915,6 +1934,17 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
             } else { r = s[st * i + ro]; g = s[st * i + go]; b = s[st * i + bo]; }
             du[i] = (uint16_t)(((unsigned)t[RU] * r + (unsigned)t[GU] * g + (unsigned)t[BU] * b + (0x10001u << 14)) >> 15);
             dv[i] = (uint16_t)(((unsigned)t[RV] * r + (unsigned)t[GV] * g + (unsigned)t[BV] * b + (0x10001u << 14)) >> 15);
+        }
+        return;
+    }
+    if (isPackedHi(f)) { /* y2xxle_UV_c, read_ayuv64le/xv48le_UV_c, read_xv30le/v30xle/xv36le_UV_c */
+        const Desc *ds = desc_get(f);
+        const uint8_t *s = src[0] + y * stride[0];
+        uint16_t *a = (uint16_t *)tu, *b = (uint16_t *)tv;
+        for (i = 0; i < w; i++) {
+            uint16_t u, v;
+            memcpy(&u, s + ds->c[1].step * i + ds->c[1].offset, 2); memcpy(&v, s + ds->c[2].step * i + ds->c[2].offset, 2);
+            a[i] = (uint16_t)((u >> ds->c[1].shift) & ((1u << ds->c[1].depth) - 1)); b[i] = (uint16_t)((v >> ds->c[2].shift) & ((1u << ds->c[2].depth) - 1));
         }
         return;
     }
@@ -2553,6 +2583,77 @@ static void write_packed422_line(const OrSws *c, const Planes *P, uint8_t *dest,
 }
 
 
+
+/* packed_vscale, X writers only: yuv2y210le/y212le_X_c (output.c:3088-3127), yuv2y216le_X_c (:3129-3169), yuv2xv30le/v30xle_X_c (:2784-2837),
+ * yuv2xv36le_X_c (:2839-2866), yuv2ayuv64le / yuv2xv48le_X_c (:2712-2776).  15-bit lines for <= 14-bit targets, 19-bit lines for 16-bit ones. */
+static void write_packedhi_line(const OrSws *c, const Planes *P, uint8_t *dest, int y)
+{
+    const int df = c->o.dst_format;
+    const int dstW = c->o.dst_w, lw = dstW, cw = c->chrDstW;
+    const int srcH = c->o.src_h, chrSrcH = c->chrSrcH;
+    const int chrY = y >> c->chrDstVSub;
+    const int lfs = c->vLumFilterSize, cfs = c->vChrFilterSize;
+    const int16_t *lf = c->vLumFilter + y * lfs, *cf = c->vChrFilter + chrY * cfs;
+    const int firstLum = ORMAX(1 - lfs, c->vLumFilterPos[y]);
+    const int firstChr = ORMAX(1 - cfs, c->vChrFilterPos[chrY]);
+    const Desc *dd = desc_get(df);
+    const int bits = dd->c[0].depth, sub = dd->lw;          /* sub: 4:2:2 (y21x) */
+    const int units = sub ? (dstW + 1) >> 1 : dstW;
+    int i, j;
+#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+#define CU(j) (P->chrU + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+#define CV(j) (P->chrV + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+#define AL(j) (P->alp + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+    for (i = 0; i < units; i++) {
+        int v[5];        /* Y (Y1), U, V, Y2, A as final sample values */
+        int n = sub ? 4 : 3, k;
+        for (k = 0; k < n; k++) {
+            const int chroma = k == 1 || k == 2;
+            const int fs = chroma ? cfs : lfs;
+            const int16_t *f = chroma ? cf : lf;
+            const int x = chroma ? i : (sub ? 2 * i + (k == 3) : i);
+            int acc;
+            if (bits == 16) { /* 0x40000000 bias trick of yuv2planeX_16_c_template */
+                acc = (1 << 14) - 0x40000000;
+                for (j = 0; j < fs; j++) acc += (int)((chroma ? (k == 1 ? CU(j) : CV(j)) : L(j))[x] * (unsigned)f[j]);
+                v[k] = 0x8000 + clip_i16(acc >> 15);
+            } else {
+                const int shift = 11 + 16 - bits;
+                acc = 1 << (shift - 1);
+                for (j = 0; j < fs; j++) acc += (int)((chroma ? (k == 1 ? CU(j) : CV(j)) : L(j))[x] * (unsigned)f[j]);
+                v[k] = clip_uintp2(acc >> shift, bits);
+            }
+        }
+        if (df == ORF_AYUV64LE) {
+            if (c->needAlpha) {
+                int acc = (1 << 14) - 0x40000000;
+                for (j = 0; j < lfs; j++) acc += (int)(AL(j)[i] * (unsigned)lf[j]);
+                v[4] = 0x8000 + clip_i16(acc >> 15);
+            } else v[4] = 65535;
+        }
+        if (df == ORF_XV30LE || df == ORF_V30XLE) { /* one little-endian dword */
+            const int sh = df == ORF_XV30LE ? 0 : 2;
+            const uint32_t px = (uint32_t)v[1] << (sh + 0) | (uint32_t)v[0] << (sh + 10) | (uint32_t)v[2] << (sh + 20) | 3u << (sh ? 0 : 30);
+            memcpy(dest + 4 * i, &px, 4);
+        } else {
+            const int step = sub ? 8 : dd->c[0].step;      /* bytes per unit */
+            uint16_t w[4] = { 0, 0, 0, 0 };
+            w[dd->c[0].offset / 2] = (uint16_t)(v[0] << dd->c[0].shift);
+            w[dd->c[1].offset / 2] = (uint16_t)(v[1] << dd->c[1].shift);
+            w[dd->c[2].offset / 2] = (uint16_t)(v[2] << dd->c[2].shift);
+            if (sub) w[dd->c[0].offset / 2 + 2] = (uint16_t)(v[3] << dd->c[0].shift);
+            else if (df == ORF_AYUV64LE) w[0] = (uint16_t)v[4];
+            else if (df == ORF_XV36LE) w[3] = 0xFFF0;      /* av_clip_uintp2(65535, 12) << 4 */
+            else w[3] = 65535;                              /* xv48 */
+            memcpy(dest + (size_t)step * i, w, 8);
+        }
+    }
+#undef L
+#undef CU
+#undef CV
+#undef AL
+}
+
 /* packed_vscale + yuv2ayuv_{1,2,X}_c_template (output.c:2903-3060: ayuv / vuya / vuyx / uyva) and yuv2vyu444_{1,2,X}_c (:3171-3290) */
 static void write_packed444_line(const OrSws *c, const Planes *P, uint8_t *dest, int y)
 {
@@ -2709,6 +2810,11 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
                 uint16_t *d16 = (uint16_t *)t0;
                 for (int i = 0; i < srcW; i++) d16[i] = sp[4 * i];
                 line = t0;
+            } else if (sf == ORF_AYUV64LE) { /* read_ayuv64le_A_c input.c:715-721 */
+                const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0];
+                uint16_t *d16 = (uint16_t *)t0;
+                for (int i = 0; i < srcW; i++) memcpy(&d16[i], sp + 8 * i, 2);
+                line = t0;
             } else if (isPacked444(sf)) { /* read_vuya_A_c / read_ayuv_A_c input.c:749-781 */
                 const Desc *dsd = desc_get(sf);
                 const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0] + dsd->c[3].offset;
@@ -2771,6 +2877,8 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
                                       c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither, 3, 0);
                 }
             }
+        } else if (isPackedHi(df)) {
+            write_packedhi_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
         } else if (isPacked444(df)) {
             write_packed444_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
         } else if (df == ORF_YUYV422 || df == ORF_UYVY422 || df == ORF_YVYU422) {

@@ -46,6 +46,8 @@ enum {
     ORF_BGR555BE = 42, ORF_BGR555LE = 43, ORF_RGB444LE = 52, ORF_RGB444BE = 53, ORF_BGR444LE = 54, ORF_BGR444BE = 55,
     ORF_YUV444P10MSBBE = 258, ORF_YUV444P10MSBLE = 259, ORF_YUV444P12MSBBE = 260, ORF_YUV444P12MSBLE = 261,
     ORF_VUYA = 205, ORF_VUYX = 208, ORF_AYUV = 228, ORF_UYVA = 229, ORF_VYU444 = 230,
+    ORF_AYUV64LE = 155, ORF_AYUV64BE = 156, ORF_Y210LE = 192, ORF_Y212LE = 212, ORF_Y216LE = 240, ORF_XV30LE = 214, ORF_V30XLE = 232,
+    ORF_XV36BE = 215, ORF_XV36LE = 216, ORF_XV48BE = 241, ORF_XV48LE = 242,
     ORF_GBRP9LE = 73, ORF_GBRP10LE = 75, ORF_GBRP16LE = 77, ORF_GBRP12LE = 135, ORF_GBRP14LE = 137,
 };
 

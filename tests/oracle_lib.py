@@ -36,6 +36,8 @@ _FORMATS = {
     "bgr565le": (41, "packed", 0, 0, 2), "bgr555le": (43, "packed", 0, 0, 2), "bgr444le": (54, "packed", 0, 0, 2),
     "yuv444p10msble": (259, "planar", 0, 0, 2), "yuv444p12msble": (261, "planar", 0, 0, 2),
     "vyu444": (230, "packed", 0, 0, 3), "uyva": (229, "packed", 0, 0, 4), "ayuv": (228, "packed", 0, 0, 4), "vuya": (205, "packed", 0, 0, 4), "vuyx": (208, "packed", 0, 0, 4),
+    "y210le": (192, "packed422", 1, 0, 2), "y212le": (212, "packed422", 1, 0, 2), "y216le": (240, "packed422", 1, 0, 2),
+    "xv30le": (214, "packed", 0, 0, 4), "v30xle": (232, "packed", 0, 0, 4), "xv36le": (216, "packed", 0, 0, 8), "xv48le": (242, "packed", 0, 0, 8), "ayuv64le": (155, "packed", 0, 0, 8),
     "rgb24": (2, "packed", 0, 0, 3), "bgr24": (3, "packed", 0, 0, 3),
     "argb": (25, "packed", 0, 0, 4), "rgba": (26, "packed", 0, 0, 4), "abgr": (27, "packed", 0, 0, 4), "bgra": (28, "packed", 0, 0, 4),
     "0rgb": (118, "packed", 0, 0, 4), "rgb0": (119, "packed", 0, 0, 4), "0bgr": (120, "packed", 0, 0, 4), "bgr0": (121, "packed", 0, 0, 4),
@@ -47,7 +49,7 @@ _FORMATS = {
 }
 
 # big-endian twins: same layout as the little-endian format, AVPixelFormat value from libavutil/pixfmt.h
-_BE_VALUES = {"yuv444p10msbbe": 258, "yuv444p12msbbe": 260, "rgb565be": 36, "rgb555be": 38, "rgb444be": 53, "bgr565be": 40, "bgr555be": 42, "bgr444be": 55, "yuv420p9be": 59, "yuv420p10be": 61, "yuv420p12be": 122, "yuv420p14be": 124, "yuv420p16be": 46, "yuv422p9be": 69, "yuv422p10be": 63, "yuv422p12be": 126, "yuv422p14be": 128, "yuv422p16be": 48, "yuv444p9be": 65, "yuv444p10be": 67, "yuv444p12be": 130, "yuv444p14be": 132, "yuv444p16be": 50, "yuv440p10be": 152, "yuv440p12be": 154, "gray9be": 172, "gray10be": 167, "gray12be": 165, "gray14be": 180, "gray16be": 29, "gbrp9be": 72, "gbrp10be": 74, "gbrp12be": 134, "gbrp14be": 136, "gbrp16be": 76, "gbrpf32be": 174, "p010be": 159, "p012be": 210, "p016be": 170, "p210be": 197, "p212be": 221, "p216be": 201, "p410be": 199, "p412be": 223, "p416be": 203, "rgb48be": 34, "bgr48be": 57, "rgba64be": 104, "bgra64be": 106}
+_BE_VALUES = {"xv36be": 215, "xv48be": 241, "ayuv64be": 156, "yuv444p10msbbe": 258, "yuv444p12msbbe": 260, "rgb565be": 36, "rgb555be": 38, "rgb444be": 53, "bgr565be": 40, "bgr555be": 42, "bgr444be": 55, "yuv420p9be": 59, "yuv420p10be": 61, "yuv420p12be": 122, "yuv420p14be": 124, "yuv420p16be": 46, "yuv422p9be": 69, "yuv422p10be": 63, "yuv422p12be": 126, "yuv422p14be": 128, "yuv422p16be": 48, "yuv444p9be": 65, "yuv444p10be": 67, "yuv444p12be": 130, "yuv444p14be": 132, "yuv444p16be": 50, "yuv440p10be": 152, "yuv440p12be": 154, "gray9be": 172, "gray10be": 167, "gray12be": 165, "gray14be": 180, "gray16be": 29, "gbrp9be": 72, "gbrp10be": 74, "gbrp12be": 134, "gbrp14be": 136, "gbrp16be": 76, "gbrpf32be": 174, "p010be": 159, "p012be": 210, "p016be": 170, "p210be": 197, "p212be": 221, "p216be": 201, "p410be": 199, "p412be": 223, "p416be": 203, "rgb48be": 34, "bgr48be": 57, "rgba64be": 104, "bgra64be": 106}
 for _n, _v in list(_BE_VALUES.items()):
     _le = _FORMATS[_n[:-2] + "le"]
     _FORMATS[_n] = (_v,) + _le[1:]
@@ -64,7 +66,7 @@ def plane_layout(fmt, w, h):
     if kind == "semi":
         return [(bps * w, h), (2 * bps * cw, ch)]
     if kind == "packed422":      # Y0 U Y1 V groups: 4 bytes per pixel pair (libavutil/imgutils.c av_image_get_linesize)
-        return [(4 * cw, h)]
+        return [(4 * bps * cw, h)]
     if kind == "rgbp":
         return [(bps * w, h)] * 3
     return [(bps * w, h)]   # packed, gray

@@ -89,11 +89,12 @@ GRAYS = ["gray8", "gray9le", "gray10le", "gray12le", "gray14le", "gray16le"]
 RGB16 = ["rgb48le", "bgr48le", "rgba64le", "bgra64le"]
 BIG_ENDIAN = ["yuv420p10be", "yuv422p12be", "yuv444p16be", "yuv440p10be", "p010be", "p416be", "gbrp12be", "gbrp16be", "gray10be", "gray16be",
               "rgb48be", "bgr48be", "rgba64be", "bgra64be", "gbrpf32be"]
+PACKED_HI = ["y210le", "y212le", "y216le", "xv30le", "v30xle", "xv36le", "xv48le", "ayuv64le", "xv36be", "ayuv64be"]
 PACKED444 = ["vyu444", "uyva", "ayuv", "vuya", "vuyx"]
 MSB = ["yuv444p10msble", "yuv444p12msble", "yuv444p10msbbe"]
 RGB_LOW = ["rgb565le", "bgr565le", "rgb555le", "bgr555le", "rgb444le", "bgr444le", "rgb565be", "bgr555be"]
-FORMAT_MATRIX_SRC = PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
-FORMAT_MATRIX_DST = PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+FORMAT_MATRIX_SRC = PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+FORMAT_MATRIX_DST = PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
 
 
 @pytest.mark.parametrize("sfmt", FORMAT_MATRIX_SRC)
@@ -165,6 +166,7 @@ def _slice_ptrs(frame, fmt, y0):
 
 
 SLICED_UNSCALED = [
+    ("y210le", "y210le", BX), ("xv30le", "xv30le", 0), ("xv36le", "xv36be", BX), ("xv48be", "xv48le", 0), ("ayuv64le", "ayuv64le", BX),
     ("ayuv", "vuya", BX), ("ayuv", "vuyx", 0), ("ayuv", "uyva", BX), ("vuya", "ayuv", BX), ("vuya", "uyva", 0), ("uyva", "ayuv", BX), ("uyva", "vuya", BX),
     ("uyva", "vuyx", BX), ("vuyx", "vuyx", BX), ("vyu444", "vyu444", 0),
     ("yuv444p10msble", "yuv444p10le", 0), ("yuv444p10le", "yuv444p12msble", 0), ("yuv444p12msble", "yuv444p", BX), ("yuv444p", "yuv444p10msble", BX),
@@ -241,7 +243,7 @@ def test_fast_bilinear(geom):
         run_case(sw, sh, sfmt, dw & ~1, dh, dfmt, FB, seed=sw + 1)
 
 
-ALPHA_FMTS = ["rgba", "bgra", "argb", "abgr", "yuva420p", "yuva422p", "yuva444p", "rgba64le", "bgra64le", "ayuv", "vuya", "uyva"]
+ALPHA_FMTS = ["rgba", "bgra", "argb", "abgr", "yuva420p", "yuva422p", "yuva444p", "rgba64le", "bgra64le", "ayuv", "vuya", "uyva", "ayuv64le"]
 
 
 @pytest.mark.parametrize("sfmt", ALPHA_FMTS + ["rgb0", "0bgr", "yuv420p", "rgb24"])
