@@ -1029,7 +1029,9 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
     }
     case PLAN_UNSC_PACKEDCOPY: {
         const PixDesc *ds = pix_desc(c->opts.src_format);
-        const int row_bytes = p.srcW * ds->comp[0].step;
+        // the reference copies as many multiples of src_w bytes as fit into both strides (:2138-2157), i.e. the whole visible row:
+        // for the packed 4:2:2 layouts that is a whole number of pixel pairs
+        const int row_bytes = ds->log2_chroma_w ? ((p.srcW + 1) >> 1) * 2 * ds->comp[0].step : p.srcW * ds->comp[0].step;
         const bool opaque = c->src0Alpha && !c->dst0Alpha && isALPHA(c->opts.dst_format);
         const dim3 grid(cdiv(cdiv(row_bytes, 16), 256), sliceH, n);
         hipLaunchKernelGGL(swsk::sws_k_packed_copy, grid, blk, 0, st, fs, row_bytes, sliceY, opaque ? ds->comp[3].offset : -1);
@@ -1451,7 +1453,8 @@ static int run_single(SwsInternal *c, const uint8_t *const src[4], const int src
         if (r < 0) return r;
         for (int k = 0; k < npd; k++) { fr.dst[k] = (uint8_t *)d->stage_dst + doffs[k]; fr.dstStride[k] = dls[k]; }
         // converters that leave pixels untouched (odd widths in yuv2rgb.c) must preserve the caller's data
-        if ((c->plan == PLAN_UNSC_YUV2RGB || c->plan == PLAN_UNSC_YUV2GBRP || c->plan == PLAN_UNSC_YUV2RGB48 || c->plan == PLAN_UNSC_YUV2RGB16) && (o.dst_w & 1)) {
+        if ((c->plan == PLAN_UNSC_YUV2RGB || c->plan == PLAN_UNSC_YUV2GBRP || c->plan == PLAN_UNSC_YUV2RGB48 || c->plan == PLAN_UNSC_YUV2RGB16 ||
+             c->plan == PLAN_UNSC_PLANAR2P422) && (o.dst_w & 1)) {
             for (int k = 0; k < npd; k++) {
                 int rb, prow; plane_geometry(o.dst_format, o.dst_w, o.dst_h, k, &rb, &prow);
                 int y0, rows; rows_of_slice(o.dst_format, k, outY, outH, &y0, &rows);

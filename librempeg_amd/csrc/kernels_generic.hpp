@@ -359,7 +359,9 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
     const int lH = p.srcH - 1, cH = p.chrSrcH - 1;
     uint8_t *drow = f.dst[0] + (int64_t)y * f.dstStride[0];
     const SwsLutParams &L = p.lut;
-#define LUM(j, xx) smp.get(0, min(firstL + (j), lH), (xx))
+// a luma column beyond the line (second pixel of the last pair of an odd-width 4:2:2 picture) holds the line buffers' initial value
+// (fill_ones, slice.c:190-208): 1 << 14, or 1 << 18 for the 19-bit lines
+#define LUM(j, xx) ((xx) < p.dstW ? smp.get(0, min(firstL + (j), lH), (xx)) : (p.wide ? 1 << 18 : 1 << 14))
 #define CHU(j, xx) smp.get(1, min(firstC + (j), cH), (xx))
 #define CHV(j, xx) smp.get(2, min(firstC + (j), cH), (xx))
 #define ALP(j, xx) smp.get(3, min(firstL + (j), lH), (xx))
@@ -630,8 +632,10 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
             const int bpp = L.bpp16;
             d[2 * i] = (uint16_t)lut_rgb16(L, k.r + Y1 + dither_rgb16_main(bpp, y, 0, 0), k.g + Y1 + dither_rgb16_main(bpp, y, 0, 1),
                                            k.b + Y1 + dither_rgb16_main(bpp, y, 0, 2));
-            d[2 * i + 1] = (uint16_t)lut_rgb16(L, k.r + Y2 + dither_rgb16_main(bpp, y, 1, 0), k.g + Y2 + dither_rgb16_main(bpp, y, 1, 1),
-                                               k.b + Y2 + dither_rgb16_main(bpp, y, 1, 2));
+            // (odd widths reach this pair writer: the second pixel of the last pair lies beyond the picture and is not stored)
+            if (2 * i + 1 < p.dstW)
+                d[2 * i + 1] = (uint16_t)lut_rgb16(L, k.r + Y2 + dither_rgb16_main(bpp, y, 1, 0), k.g + Y2 + dither_rgb16_main(bpp, y, 1, 1),
+                                                   k.b + Y2 + dither_rgb16_main(bpp, y, 1, 2));
         } else {
             uint8_t *d = drow + 6 * i;
             const int k0 = L.rgb_order ? k.b : k.r, k2 = L.rgb_order ? k.r : k.b;

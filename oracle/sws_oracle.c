@@ -1627,11 +1627,14 @@ static int unscaled_packedcopy(OrSws *c, const uint8_t *const src[], const int s
 {
     const Desc *ds = desc_get(c->o.src_format);
     const int step = ds->c[0].step;
+    /* the reference copies as many multiples of src_w bytes as fit into both strides (:2138-2157), i.e. the whole visible row:
+     * for the packed 4:2:2 layouts that is a whole number of pixel pairs */
+    const size_t row_bytes = ds->lw ? (size_t)((c->o.src_w + 1) >> 1) * 2 * step : (size_t)c->o.src_w * step;
     (void)srcSliceY;
     for (int y = 0; y < srcSliceH; y++) {
         const uint8_t *s = src[0] + (ptrdiff_t)y * srcStride[0];
         uint8_t *d = dst[0] + (ptrdiff_t)y * dstStride[0];
-        memcpy(d, s, (size_t)c->o.src_w * step);
+        memcpy(d, s, row_bytes);
         if (force_opaque)
             for (int x = 0; x < c->o.src_w; x++) d[x * step + ds->c[3].offset] = 255;
     }
@@ -2271,7 +2274,7 @@ static void write_nv_chroma_line(const OrSws *c, uint8_t *dest, int w, const int
 }
 
 /* LUT rgb pixel-pair write (yuv2rgb_write, output.c:1662-1785; 24/32 bpp) */
-static void rgb_write2(const OrSws *c, uint8_t *dest, int i, int y, int Y1, int Y2, int U, int V, int hasAlpha, unsigned A1, unsigned A2)
+static void rgb_write2(const OrSws *c, uint8_t *dest, int i, int y, int Y1, int Y2, int U, int V, int hasAlpha, unsigned A1, unsigned A2, int second)
 {
     const int d = c->o.dst_format;
     int r = c->table_rV[V + HEADROOM];
@@ -2292,7 +2295,7 @@ static void rgb_write2(const OrSws *c, uint8_t *dest, int i, int y, int Y1, int 
         }
         v1 = (uint16_t)(lut_at(c, r + Y1 + dr1) + lut_at(c, g + Y1 + dg1) + lut_at(c, b + Y1 + db1));
         v2 = (uint16_t)(lut_at(c, r + Y2 + dr2) + lut_at(c, g + Y2 + dg2) + lut_at(c, b + Y2 + db2));
-        memcpy(dest + 4 * i, &v1, 2); memcpy(dest + 4 * i + 2, &v2, 2);
+        memcpy(dest + 4 * i, &v1, 2); if (second) memcpy(dest + 4 * i + 2, &v2, 2);
     } else if (c->lut_elem == 4) {
         uint32_t v1 = lut_at(c, r + Y1) + lut_at(c, g + Y1) + lut_at(c, b + Y1);
         uint32_t v2 = lut_at(c, r + Y2) + lut_at(c, g + Y2) + lut_at(c, b + Y2);
@@ -2300,12 +2303,12 @@ static void rgb_write2(const OrSws *c, uint8_t *dest, int i, int y, int Y1, int 
             const int sh = (d == ORF_ABGR || d == ORF_ARGB) ? 0 : 24;
             v1 += A1 << sh; v2 += A2 << sh;
         }
-        memcpy(dest + 8 * i, &v1, 4); memcpy(dest + 8 * i + 4, &v2, 4);
+        memcpy(dest + 8 * i, &v1, 4); if (second) memcpy(dest + 8 * i + 4, &v2, 4);
     } else {
         uint8_t *p = dest + 6 * i;
         int rb = d == ORF_RGB24 ? r : b, br = d == ORF_RGB24 ? b : r;
         p[0] = (uint8_t)lut_at(c, rb + Y1); p[1] = (uint8_t)lut_at(c, g + Y1); p[2] = (uint8_t)lut_at(c, br + Y1);
-        p[3] = (uint8_t)lut_at(c, rb + Y2); p[4] = (uint8_t)lut_at(c, g + Y2); p[5] = (uint8_t)lut_at(c, br + Y2);
+        if (second) { p[3] = (uint8_t)lut_at(c, rb + Y2); p[4] = (uint8_t)lut_at(c, g + Y2); p[5] = (uint8_t)lut_at(c, br + Y2); }
     }
 }
 
@@ -2367,22 +2370,26 @@ static void write_packed_rgb_line(const OrSws *c, const Planes *P, uint8_t *dest
     else mode = 0;
 
     if (!full) {
+        /* odd widths reach the pair writers only for the 16 bpp formats (no full-chroma writer): the second pixel of the last pair lies
+         * beyond the picture; the reference computes it from the line buffers' fill value and stores it into the row padding, the oracle
+         * computes it the same way and does not store it */
+#define LB(j) (2 * i + 1 < dstW ? L(j)[2 * i + 1] : (1 << 14))
         for (i = 0; i < ((dstW + 1) >> 1); i++) {
             int Y1, Y2, U, V;
             if (mode == 0) {
                 Y1 = Y2 = U = V = 1 << 18;
-                for (j = 0; j < lfs; j++) { Y1 += (int)(L(j)[2 * i] * (unsigned)lf[j]); Y2 += (int)(L(j)[2 * i + 1] * (unsigned)lf[j]); }
+                for (j = 0; j < lfs; j++) { Y1 += (int)(L(j)[2 * i] * (unsigned)lf[j]); Y2 += (int)(LB(j) * (unsigned)lf[j]); }
                 for (j = 0; j < cfs; j++) { U += (int)(CU(j)[i] * (unsigned)cf[j]); V += (int)(CV(j)[i] * (unsigned)cf[j]); }
                 Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
             } else if (mode == 2) {
                 int ya1 = 4096 - ya, ua1 = 4096 - ua;
                 Y1 = (L(0)[2 * i] * ya1 + L(1)[2 * i] * ya) >> 19;
-                Y2 = (L(0)[2 * i + 1] * ya1 + L(1)[2 * i + 1] * ya) >> 19;
+                Y2 = (LB(0) * ya1 + LB(1) * ya) >> 19;
                 U = (CU(0)[i] * ua1 + CU(1)[i] * ua) >> 19;
                 V = (CV(0)[i] * ua1 + CV(1)[i] * ua) >> 19;
             } else {
                 Y1 = (L(0)[2 * i] + 64) >> 7;
-                Y2 = (L(0)[2 * i + 1] + 64) >> 7;
+                Y2 = (LB(0) + 64) >> 7;
                 if (ua == 0) { U = (CU(0)[i] + 64) >> 7; V = (CV(0)[i] + 64) >> 7; }
                 else {
                     int ua1 = 4096 - ua;
@@ -2409,7 +2416,7 @@ static void write_packed_rgb_line(const OrSws *c, const Planes *P, uint8_t *dest
                         A2 = clip_u8((AL(0)[2 * i + 1] + 64) >> 7);
                     }
                 }
-                rgb_write2(c, dest, i, y, Y1, Y2, U, V, hasAlpha, (unsigned)A1, (unsigned)A2);
+                rgb_write2(c, dest, i, y, Y1, Y2, U, V, hasAlpha, (unsigned)A1, (unsigned)A2, 2 * i + 1 < dstW);
             }
         }
     } else {
@@ -2551,6 +2558,9 @@ static void write_packed422_line(const OrSws *c, const Planes *P, uint8_t *dest,
 #define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
 #define CU(j) (P->chrU + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
 #define CV(j) (P->chrV + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+    /* the second pixel of the last pair of an odd-width picture: the line buffers are pre-filled with 1 << 14 (fill_ones, slice.c:190-208)
+     * and the horizontal scaler writes dstW entries only */
+#define L2(j) (2 * i + 1 < dstW ? L(j)[2 * i + 1] : (1 << 14))
     if (lfs == 1 && cfs == 1) mode = 1;
     else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 1; ua = (uint16_t)cf[1]; }
     else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
@@ -2560,16 +2570,16 @@ static void write_packed422_line(const OrSws *c, const Planes *P, uint8_t *dest,
         int Y1, Y2, U, V;
         if (mode == 0) {
             Y1 = Y2 = U = V = 1 << 18;
-            for (j = 0; j < lfs; j++) { Y1 += (int)(L(j)[2 * i] * (unsigned)lf[j]); Y2 += (int)(L(j)[2 * i + 1] * (unsigned)lf[j]); }
+            for (j = 0; j < lfs; j++) { Y1 += (int)(L(j)[2 * i] * (unsigned)lf[j]); Y2 += (int)(L2(j) * (unsigned)lf[j]); }
             for (j = 0; j < cfs; j++) { U += (int)(CU(j)[i] * (unsigned)cf[j]); V += (int)(CV(j)[i] * (unsigned)cf[j]); }
             Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
         } else if (mode == 2) {
             Y1 = (L(0)[2 * i] * (4096 - ya) + L(1)[2 * i] * ya) >> 19;
-            Y2 = (L(0)[2 * i + 1] * (4096 - ya) + L(1)[2 * i + 1] * ya) >> 19;
+            Y2 = (L2(0) * (4096 - ya) + L2(1) * ya) >> 19;
             U = (CU(0)[i] * (4096 - ua) + CU(1)[i] * ua) >> 19;
             V = (CV(0)[i] * (4096 - ua) + CV(1)[i] * ua) >> 19;
         } else {
-            Y1 = (L(0)[2 * i] + 64) >> 7; Y2 = (L(0)[2 * i + 1] + 64) >> 7;
+            Y1 = (L(0)[2 * i] + 64) >> 7; Y2 = (L2(0) + 64) >> 7;
             if (ua < 2048) { U = (CU(0)[i] + 64) >> 7; V = (CV(0)[i] + 64) >> 7; }
             else { U = (CU(0)[i] + CU(1)[i] + 128) >> 8; V = (CV(0)[i] + CV(1)[i] + 128) >> 8; }
         }
@@ -2613,14 +2623,16 @@ static void write_packedhi_line(const OrSws *c, const Planes *P, uint8_t *dest, 
             const int16_t *f = chroma ? cf : lf;
             const int x = chroma ? i : (sub ? 2 * i + (k == 3) : i);
             int acc;
+            /* a luma column beyond the line (second pixel of the last pair, odd widths) holds fill_ones()' value: 1 << 14 / 1 << 18 */
+#define SMP(j) (chroma ? (k == 1 ? CU(j) : CV(j))[x] : (x < dstW ? L(j)[x] : (bits == 16 ? 1 << 18 : 1 << 14)))
             if (bits == 16) { /* 0x40000000 bias trick of yuv2planeX_16_c_template */
                 acc = (1 << 14) - 0x40000000;
-                for (j = 0; j < fs; j++) acc += (int)((chroma ? (k == 1 ? CU(j) : CV(j)) : L(j))[x] * (unsigned)f[j]);
+                for (j = 0; j < fs; j++) acc += (int)(SMP(j) * (unsigned)f[j]);
                 v[k] = 0x8000 + clip_i16(acc >> 15);
             } else {
                 const int shift = 11 + 16 - bits;
                 acc = 1 << (shift - 1);
-                for (j = 0; j < fs; j++) acc += (int)((chroma ? (k == 1 ? CU(j) : CV(j)) : L(j))[x] * (unsigned)f[j]);
+                for (j = 0; j < fs; j++) acc += (int)(SMP(j) * (unsigned)f[j]);
                 v[k] = clip_uintp2(acc >> shift, bits);
             }
         }
