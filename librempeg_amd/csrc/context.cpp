@@ -138,11 +138,11 @@ void choose_unscaled(SwsInternal *c)
     if ((s == AV_PIX_FMT_YUV420P10LE || s == AV_PIX_FMT_YUV420P12LE || s == AV_PIX_FMT_YUV420P14LE || s == AV_PIX_FMT_YUV420P16LE) &&
         (d == AV_PIX_FMT_P010LE || d == AV_PIX_FMT_P016LE) && !c->srcBE && !c->dstBE) k = PLAN_UNSC_P01X;           // :2432-2439 (native-endian names only)
     if ((s == AV_PIX_FMT_YUV420P || s == AV_PIX_FMT_YUVA420P) && (d == AV_PIX_FMT_P010LE || d == AV_PIX_FMT_P016LE) && !c->dstBE) k = PLAN_UNSC_8_P01X; // :2440-2444
-    if (s == AV_PIX_FMT_YUV410P && !(c->opts.dst_h & 3) && d == AV_PIX_FMT_YUV420P && !(flags & SWS_BITEXACT)) {       // :2446-2451
+    if (s == AV_PIX_FMT_YUV410P && !(c->opts.dst_h & 3) && (d == AV_PIX_FMT_YUV420P || d == AV_PIX_FMT_YUVA420P) && !(flags & SWS_BITEXACT)) {       // :2446-2451
         k = PLAN_UNSC_YVU9_YV12;
         c->dst_slice_align = 4;
     }
-    if (s == AV_PIX_FMT_BGR24 && d == AV_PIX_FMT_YUV420P && !(flags & SWS_ACCURATE_RND) && !(c->opts.dst_w & 1))
+    if (s == AV_PIX_FMT_BGR24 && (d == AV_PIX_FMT_YUV420P || d == AV_PIX_FMT_YUVA420P) && !(flags & SWS_ACCURATE_RND) && !(c->opts.dst_w & 1))
         k = PLAN_UNSC_BGR24_YV12;                                                                        // :2452-2456
     // rgbToRgbWrapper (:2459-2463) whenever findRgbConvFn (:1843-1998) has a converter.  All formats here are 8-bit
     // 24/32 bpp (needsDither == 0).  ":1991-1994 Maintain symmetry between endianness": with BITEXACT a 24 bpp source
@@ -185,10 +185,6 @@ void choose_unscaled(SwsInternal *c)
     }
     if (isAnyRGB(s) && !isPlanarRGB(s) && pix_desc(s)->comp[0].depth == 8 && d == AV_PIX_FMT_GBRP) k = PLAN_UNSC_PACKED_GBRP;             // rgbToPlanarRgbWrapper (:2542-2544)
     if (s == AV_PIX_FMT_GBRP && isAnyRGB(d) && !isPlanarRGB(d) && pix_desc(d)->comp[0].depth == 8) k = PLAN_UNSC_GBRP_PACKED;             // planarRgbToRgbWrapper (:2480-2481)
-    // bgr24ToYv12 / yvu9ToYv12 also take a yuva420p destination in the reference (alpha filled with 255): not built
-    if (d == AV_PIX_FMT_YUVA420P && ((s == AV_PIX_FMT_BGR24 && !(flags & SWS_ACCURATE_RND) && !(c->opts.dst_w & 1)) ||
-                                     (s == AV_PIX_FMT_YUV410P && !(c->opts.dst_h & 3) && !(flags & SWS_BITEXACT)) ||
-                                     s == AV_PIX_FMT_YUYV422 || s == AV_PIX_FMT_UYVY422)) unsupported = true;
     if (s == d || (s == AV_PIX_FMT_YUVA420P && d == AV_PIX_FMT_YUV420P) || (s == AV_PIX_FMT_YUV420P && d == AV_PIX_FMT_YUVA420P) ||
         (isFloatFmt(s) == isFloatFmt(d) && ((isPlanarYUV(s) && isGray(d)) || (isPlanarYUV(d) && isGray(s)) || (isGray(d) && isGray(s)))) ||
         (isFloatFmt(s) == isFloatFmt(d) && isPlanarYUV(s) && isPlanarYUV(d) &&
@@ -201,7 +197,7 @@ void choose_unscaled(SwsInternal *c)
     if (s == AV_PIX_FMT_YUV422P && (d == AV_PIX_FMT_YUYV422 || d == AV_PIX_FMT_UYVY422)) k = PLAN_UNSC_PLANAR2P422;   // :2667-2672
     if ((flags & (SWS_FAST_BILINEAR | SWS_POINT)) && (s == AV_PIX_FMT_YUV420P || s == AV_PIX_FMT_YUVA420P) &&
         (d == AV_PIX_FMT_YUYV422 || d == AV_PIX_FMT_UYVY422)) k = PLAN_UNSC_PLANAR2P422;                               // :2684-2692
-    if ((s == AV_PIX_FMT_YUYV422 || s == AV_PIX_FMT_UYVY422) && (d == AV_PIX_FMT_YUV420P || d == AV_PIX_FMT_YUV422P))
+    if ((s == AV_PIX_FMT_YUYV422 || s == AV_PIX_FMT_UYVY422) && (d == AV_PIX_FMT_YUV420P || d == AV_PIX_FMT_YUVA420P || d == AV_PIX_FMT_YUV422P))
         k = PLAN_UNSC_P4222PLANAR;                                                                                     // :2693-2702
     if (d == AV_PIX_FMT_YUV420P && (s == AV_PIX_FMT_NV24 || s == AV_PIX_FMT_NV42)) k = PLAN_UNSC_NV242YUV420;         // :2703-2705
     c->plan = unsupported ? PLAN_NONE : k;
@@ -559,12 +555,16 @@ int sws_setColorspaceDetails(SwsContext *sws, const int inv_table[4], int srcRan
     if ((isYUV(sws->dst_format) || isGray(sws->dst_format)) && (isYUV(sws->src_format) || isGray(sws->src_format))) {
         if (!c->cascade[0] && std::memcmp(c->dstColorspaceTable, c->srcColorspaceTable, sizeof(int) * 4) &&
             sws->src_w && sws->src_h && sws->dst_w && sws->dst_h) {               // :915-984
-            if (isNBPS(sws->dst_format) || is16BPS(sws->dst_format)) {
-                log_msg(c, 0, "YUV matrix change through a BGR48 intermediate is not implemented on the HIP path\n");
-                return -1;
-            }
             log_msg(c, 2, "YUV color matrix differs for YUV->YUV, using intermediate RGB to convert\n");
-            const int tmp_format = AV_PIX_FMT_BGR24;
+            const bool both_alpha = isALPHA(sws->src_format) && isALPHA(sws->dst_format);
+            const int tmp_format = (isNBPS(sws->dst_format) || is16BPS(sws->dst_format))
+                                       ? (both_alpha ? AV_PIX_FMT_BGRA64LE : AV_PIX_FMT_BGR48LE)   // :927-933 (native endian)
+                                       : (both_alpha ? AV_PIX_FMT_BGRA : AV_PIX_FMT_BGR24);        // :934-940
+            auto fail = [&]() {   // a child could not be built: drop both so that a later sws_scale() cannot run half a cascade
+                destroy(c->cascade[0]); destroy(c->cascade[1]);
+                c->cascade[0] = c->cascade[1] = nullptr;
+                return -1;
+            };
             int tw, th;
             if (sws->src_w * sws->src_h > sws->dst_w * sws->dst_h) { tw = sws->dst_w; th = sws->dst_h; }
             else { tw = sws->src_w; th = sws->src_h; }
@@ -573,14 +573,16 @@ int sws_setColorspaceDetails(SwsContext *sws, const int inv_table[4], int srcRan
             c->cascade[0] = alloc_set_opts(sws->src_w, sws->src_h, sws->src_format, tw, th, tmp_format, sws->flags, sws->scaler_params);
             if (!c->cascade[0]) return -1;
             c->cascade[0]->opts.alpha_blend = sws->alpha_blend;
-            if (init_context_impl(c->cascade[0], nullptr, nullptr) < 0) return -1;
+            c->cascade[0]->srcBE = c->srcBE;     // the stored formats are the little-endian twins: the byte order travels with the flags
+            if (init_context_impl(c->cascade[0], nullptr, nullptr) < 0) return fail();
             sws_setColorspaceDetails(&c->cascade[0]->opts, inv_copy, srcRange, tab_copy, dstRange, brightness, contrast, saturation);
 
             c->cascade[1] = alloc_set_opts(tw, th, tmp_format, sws->dst_w, sws->dst_h, sws->dst_format, sws->flags, sws->scaler_params);
-            if (!c->cascade[1]) return -1;
+            if (!c->cascade[1]) return fail();
             c->cascade[1]->opts.src_range = srcRange;
             c->cascade[1]->opts.dst_range = dstRange;
-            if (init_context_impl(c->cascade[1], nullptr, nullptr) < 0) return -1;
+            c->cascade[1]->dstBE = c->dstBE;
+            if (init_context_impl(c->cascade[1], nullptr, nullptr) < 0) return fail();
             sws_setColorspaceDetails(&c->cascade[1]->opts, inv_copy, srcRange, tab_copy, dstRange, 0, 1 << 16, 1 << 16);
             c->plan = PLAN_CASCADE;
             return 0;

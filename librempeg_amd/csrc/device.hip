@@ -778,6 +778,13 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
     const dim3 blk(256);
     if (d->timing) { HIPCHK(hipEventRecord(d->ev0, st)); }
 
+    // bgr24ToYv12Wrapper (:2062-2077), yvu9ToYv12Wrapper (:2079-2093), yuyv/uyvyToYuv420Wrapper (:423-470) with a yuva420p
+    // destination: fillPlane(dst[3], ..., src_w, srcSliceH, srcSliceY, 255)
+    if (c->opts.dst_format == AV_PIX_FMT_YUVA420P && sliceH > 0 &&
+        (c->plan == PLAN_UNSC_BGR24_YV12 || c->plan == PLAN_UNSC_YVU9_YV12 || c->plan == PLAN_UNSC_P4222PLANAR)) {
+        const dim3 gf(cdiv(p.srcW, 256), sliceH, n);
+        hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.srcW, sliceY);
+    }
     switch (c->plan) {
     case PLAN_UNSC_YUV2RGB: {
         const int dstW = p.dstW;
@@ -999,7 +1006,7 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
     }
     case PLAN_UNSC_P4222PLANAR: {
         const dim3 grid(cdiv((p.srcW + 1) >> 1, 256), sliceH, n);
-        hipLaunchKernelGGL(swsk::sws_k_p422_to_planar, grid, blk, 0, st, fs, p, p.srcW, sliceY, c->opts.dst_format == AV_PIX_FMT_YUV420P ? 1 : 0);
+        hipLaunchKernelGGL(swsk::sws_k_p422_to_planar, grid, blk, 0, st, fs, p, p.srcW, sliceY, c->opts.dst_format != AV_PIX_FMT_YUV422P ? 1 : 0);
         break;
     }
     case PLAN_UNSC_PACKED_GBRP: {
@@ -1397,8 +1404,12 @@ static int run_single(SwsInternal *c, const uint8_t *const src[4], const int src
         }
         int ls[4]; size_t offs[4], total;
         image_layout(c->cascade_fmt, c->cascade_w, c->cascade_h, 256, ls, offs, &total);
+        const size_t had = d->casc_bytes;
         int r = grow(c, &d->casc_img, &d->casc_bytes, total);
         if (r < 0) return r;
+        // av_image_alloc() leaves the intermediate picture uninitialised and the pair-wise yuv2rgb converters never write the last
+        // pixel of an odd width: start from zeros (as the oracle does) so that the result does not depend on stale memory
+        if (d->casc_bytes != had) { HIPCHK(hipMemsetAsync(d->casc_img, 0, d->casc_bytes, d->stream)); }
         uint8_t *tmp[4] = { (uint8_t *)d->casc_img, nullptr, nullptr, nullptr };
         int tls[4] = { ls[0], 0, 0, 0 };
         r = run_single(c0, src, srcStride, sliceY, sliceH, tmp, tls);
@@ -1452,14 +1463,19 @@ static int run_single(SwsInternal *c, const uint8_t *const src[4], const int src
         int r = grow(c, &d->stage_dst, &d->stage_dst_bytes, dtotal);
         if (r < 0) return r;
         for (int k = 0; k < npd; k++) { fr.dst[k] = (uint8_t *)d->stage_dst + doffs[k]; fr.dstStride[k] = dls[k]; }
-        // converters that leave pixels untouched (odd widths in yuv2rgb.c) must preserve the caller's data
-        if ((c->plan == PLAN_UNSC_YUV2RGB || c->plan == PLAN_UNSC_YUV2GBRP || c->plan == PLAN_UNSC_YUV2RGB48 || c->plan == PLAN_UNSC_YUV2RGB16 ||
-             c->plan == PLAN_UNSC_PLANAR2P422) && (o.dst_w & 1)) {
+        // the special converters leave the last pixel (pair) of an odd width untouched (yuv2rgb.c pair loops, planarToP01x's
+        // "src_w / 2" chroma loop, nv24_to_yuv420p_chroma, planarToYuy2 ...): the staging picture starts from the caller's data
+        if (unscaled && ((o.dst_w & 1) || (o.dst_h & 1))) {   // (odd heights: yuyvtoyuv420 writes chroma on odd rows only)
             for (int k = 0; k < npd; k++) {
                 int rb, prow; plane_geometry(o.dst_format, o.dst_w, o.dst_h, k, &rb, &prow);
                 int y0, rows; rows_of_slice(o.dst_format, k, outY, outH, &y0, &rows);
-                if (dstStride[k] >= 0)
+                rows = std::min(rows, prow - y0);
+                if (dstStride[k] >= 0) {
                     HIPCHK(hipMemcpy2DAsync(fr.dst[k] + (size_t)y0 * dls[k], dls[k], dst[k] + (int64_t)y0 * dstStride[k], dstStride[k], rb, rows, hipMemcpyHostToDevice, st));
+                } else {
+                    for (int y = 0; y < rows; y++)
+                        HIPCHK(hipMemcpyAsync(fr.dst[k] + (size_t)(y0 + y) * dls[k], dst[k] + (int64_t)(y0 + y) * dstStride[k], rb, hipMemcpyHostToDevice, st));
+                }
             }
         }
     }

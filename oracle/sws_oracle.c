@@ -891,10 +891,10 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
     if ((s == ORF_YUV420P10LE || s == ORF_YUV420P12LE || s == ORF_YUV420P14LE || s == ORF_YUV420P16LE) &&
         (d == ORF_P010LE || d == ORF_P016LE) && !c->src_be && !c->dst_be) c->unscaled_kind = UNSC_P01X;                           /* :2432-2439 */
     if ((s == ORF_YUV420P || s == ORF_YUVA420P) && (d == ORF_P010LE || d == ORF_P016LE) && !c->dst_be) c->unscaled_kind = UNSC_8_P01X; /* :2440-2444 */
-    if (s == ORF_YUV410P && !(c->o.dst_h & 3) && d == ORF_YUV420P && !(flags & OR_SWS_BITEXACT))
+    if (s == ORF_YUV410P && !(c->o.dst_h & 3) && (d == ORF_YUV420P || d == ORF_YUVA420P) && !(flags & OR_SWS_BITEXACT))
         c->unscaled_kind = UNSC_YVU9_YV12;                                                            /* :2446-2451 */
     /* bgr24toYV12 (:2452-2456) */
-    if (s == ORF_BGR24 && d == ORF_YUV420P && !(flags & OR_SWS_ACCURATE_RND) && !(c->o.dst_w & 1))
+    if (s == ORF_BGR24 && (d == ORF_YUV420P || d == ORF_YUVA420P) && !(flags & OR_SWS_ACCURATE_RND) && !(c->o.dst_w & 1))
         c->unscaled_kind = UNSC_BGR24_YV12;
     /* rgbToRgbWrapper (:2459-2463) when findRgbConvFn (:1843-1998) has a converter; 8-bit 24/32 bpp formats on a
      * little-endian host.  needsDither is 0 for >= 24 bpp destinations.  ":1991-1994 Maintain symmetry between
@@ -953,7 +953,7 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
     if (s == ORF_YUV422P && (d == ORF_YUYV422 || d == ORF_UYVY422)) c->unscaled_kind = UNSC_PLANAR2P422;          /* :2667-2672 */
     if ((flags & (OR_SWS_FAST_BILINEAR | OR_SWS_POINT)) && (s == ORF_YUV420P || s == ORF_YUVA420P) &&
         (d == ORF_YUYV422 || d == ORF_UYVY422)) c->unscaled_kind = UNSC_PLANAR2P422;                               /* :2684-2692 */
-    if ((s == ORF_YUYV422 || s == ORF_UYVY422) && (d == ORF_YUV420P || d == ORF_YUV422P)) c->unscaled_kind = UNSC_P4222PLANAR; /* :2693-2702 */
+    if ((s == ORF_YUYV422 || s == ORF_UYVY422) && (d == ORF_YUV420P || d == ORF_YUVA420P || d == ORF_YUV422P)) c->unscaled_kind = UNSC_P4222PLANAR; /* :2693-2702 */
     if (d == ORF_YUV420P && (s == ORF_NV24 || s == ORF_NV42)) c->unscaled_kind = UNSC_NV242YUV420;    /* :2703-2705 */
 }
 
@@ -1041,11 +1041,6 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
     if (unscaled && !usesHFilter && !usesVFilter &&
         (c->o.src_range == c->o.dst_range || isAnyRGB(dstFormat) || isFloat(srcFormat) || isFloat(dstFormat))) {
         get_unscaled(c);
-        /* bgr24ToYv12 / yvu9ToYv12 also take a yuva420p destination in the reference (alpha filled with 255): not restated */
-        if (dstFormat == ORF_YUVA420P &&
-            ((srcFormat == ORF_BGR24 && !(flags & OR_SWS_ACCURATE_RND) && !(dstW & 1)) ||
-             (srcFormat == ORF_YUV410P && !(dstH & 3) && !(flags & OR_SWS_BITEXACT)) ||
-             srcFormat == ORF_YUYV422 || srcFormat == ORF_UYVY422)) return -1;
         if (c->unscaled_kind) { c->initialized = 1; return 0; }
     }
     if (c->needAlpha && isPlanarRGB(dstFormat)) return -1; /* gbrap writers not restated */
@@ -1112,20 +1107,28 @@ int or_sws_set_colorspace(OrSws *c, const int inv_table[4], int srcRange, const 
         if (!c->cascade[0] && memcmp(c->dstColorspaceTable, c->srcColorspaceTable, sizeof(int) * 4) &&
             c->o.src_w && c->o.src_h && c->o.dst_w && c->o.dst_h) { /* :915-984 */
             int tmp_format, tmp_w, tmp_h, srcW = c->o.src_w, srcH = c->o.src_h, dstW = c->o.dst_w, dstH = c->o.dst_h;
-            if (isNBPS(c->o.dst_format) || is16BPS(c->o.dst_format)) return -1; /* BGR48 intermediate not restated */
-            tmp_format = ORF_BGR24;
+            const int both_alpha = isALPHA(c->o.src_format) && isALPHA(c->o.dst_format);
+            if (isNBPS(c->o.dst_format) || is16BPS(c->o.dst_format)) tmp_format = both_alpha ? ORF_BGRA64LE : ORF_BGR48LE; /* :927-933 */
+            else tmp_format = both_alpha ? ORF_BGRA : ORF_BGR24;                                                       /* :934-940 */
             if (srcW * srcH > dstW * dstH) { tmp_w = dstW; tmp_h = dstH; } else { tmp_w = srcW; tmp_h = srcH; }
-            c->casc_stride[0] = (tmp_w * 3 + 63) & ~63;
-            c->casc_tmp[0] = malloc((size_t)c->casc_stride[0] * tmp_h + 64);
+            c->casc_stride[0] = (tmp_w * desc_get(tmp_format)->c[0].step + 63) & ~63;   /* av_image_alloc(..., 64) */
+            c->casc_tmp[0] = calloc((size_t)c->casc_stride[0] * tmp_h + 64, 1);   /* av_image_alloc leaves it uninitialised; the pair-wise yuv2rgb
+                                                                                   * converters never write the last pixel of an odd width: zero here and in the product */
 
             c->cascade[0] = alloc_set_opts(srcW, srcH, c->o.src_format, tmp_w, tmp_h, tmp_format, c->o.flags, c->o.scaler_params);
-            if (init_context(c->cascade[0]) < 0) return -1;
+            if (init_context(c->cascade[0]) < 0) goto casc_fail;
             or_sws_set_colorspace(c->cascade[0], inv_table, srcRange, table, dstRange, brightness, contrast, saturation);
 
             c->cascade[1] = alloc_set_opts(tmp_w, tmp_h, tmp_format, dstW, dstH, c->o.dst_format, c->o.flags, c->o.scaler_params);
             c->cascade[1]->o.src_range = srcRange;
             c->cascade[1]->o.dst_range = dstRange;
-            if (init_context(c->cascade[1]) < 0) return -1;
+            if (init_context(c->cascade[1]) < 0) {
+            casc_fail:  /* the reference returns the error with the half-built children in place; the oracle drops them so that a
+                         * later or_sws_scale() takes the plain path instead of a broken cascade */
+                or_sws_free(c->cascade[0]); or_sws_free(c->cascade[1]); free(c->casc_tmp[0]);
+                c->cascade[0] = c->cascade[1] = NULL; c->casc_tmp[0] = NULL;
+                return -1;
+            }
             or_sws_set_colorspace(c->cascade[1], inv_table, srcRange, table, dstRange, 0, 1 << 16, 1 << 16);
             return 0;
         }
@@ -1535,7 +1538,7 @@ static int unscaled_p4222planar(OrSws *c, const uint8_t *const src[], const int 
                                 int srcSliceH, uint8_t *const dst[], const int dstStride[])
 {
     const Desc *ds = desc_get(c->o.src_format);
-    const int w = c->o.src_w, cw = CEIL_RSHIFT(w, 1), to420 = c->o.dst_format == ORF_YUV420P;
+    const int w = c->o.src_w, cw = CEIL_RSHIFT(w, 1), to420 = c->o.dst_format != ORF_YUV422P;
     const int yo = ds->c[0].offset, uo = ds->c[1].offset, vo = ds->c[2].offset;
     (void)srcSliceY;
     for (int y = 0; y < srcSliceH; y++) {
@@ -2996,6 +2999,11 @@ static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4
         if (c->unscaled_kind == UNSC_PACKEDCOPY) return unscaled_packedcopy(c, src, srcStride, 0, srcSliceH, dst, dstStride, opaque);
         if (opaque && c->unscaled_kind) return -22; /* no other special converter takes an rgb0-style source to an alpha destination */
     }
+    /* bgr24ToYv12Wrapper (:2062-2077), yvu9ToYv12Wrapper (:2079-2093), yuyv/uyvyToYuv420Wrapper (:423-470) with a yuva420p
+     * destination: fillPlane(dst[3], ..., 255) after the converter */
+    if (c->o.dst_format == ORF_YUVA420P && dst[3] &&
+        (c->unscaled_kind == UNSC_BGR24_YV12 || c->unscaled_kind == UNSC_YVU9_YV12 || c->unscaled_kind == UNSC_P4222PLANAR))
+        for (int y = 0; y < srcSliceH; y++) memset(dst[3] + (ptrdiff_t)y * dstStride[3], 255, c->o.src_w);
     switch (c->unscaled_kind) {
     case UNSC_YUV2RGB: return unscaled_yuv2rgb(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_P01X: return unscaled_p01x(c, src, srcStride, 0, srcSliceH, dst, dstStride);

@@ -42,3 +42,38 @@ def test_random_conversions(case):
         pytest.skip("the oracle refuses this context (the product must refuse it too, see test_refusals_agree)")
     del o
     run_case(sw, sh, sf, dw, dh, df, flags, seed=k + 1, device_frames=bool(k & 1))
+
+
+def _opt_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for k in range(n):
+        sf, df = rng.choice(FORMAT_MATRIX_SRC), rng.choice(FORMAT_MATRIX_DST)
+        if rng.random() < 0.4:
+            sw = dw = rng.randint(2, 160); sh = dh = rng.randint(2, 100)
+        else:
+            sw, dw, sh, dh = rng.randint(2, 200), rng.randint(2, 200), rng.randint(2, 120), rng.randint(2, 120)
+        flags = rng.choice(SCALERS) | rng.choice(EXTRA)
+        opts = {"dither": rng.choice([0, 1, 2]), "src_range": rng.choice([0, 1]), "dst_range": rng.choice([0, 1]), "threads": 1}
+        if rng.random() < 0.5:
+            opts.update(src_h_chr_pos=rng.choice([-513, 0, 128, 256]), src_v_chr_pos=rng.choice([-513, 0, 128, 256]),
+                        dst_h_chr_pos=rng.choice([-513, 0, 128, 256]), dst_v_chr_pos=rng.choice([-513, 0, 128, 256]))
+        cs = None
+        if rng.random() < 0.5:
+            cs = (rng.choice([1, 5, 9]), rng.choice([0, 1]), rng.choice([1, 5, 9]), rng.choice([0, 1]),
+                  rng.choice([0, 0, 1 << 12]), rng.choice([1 << 16, 1 << 16, 3 << 15]), rng.choice([1 << 16, 1 << 16, 1 << 15]))
+        out.append((sw, sh, sf, dw, dh, df, flags, k, opts, cs))
+    return out
+
+
+@pytest.mark.parametrize("case", _opt_cases(3000, 777), ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
+def test_random_conversions_with_options(case):
+    """the same with the sws_alloc_context() + public fields + sws_init_context() construction: dither mode, ranges, chroma positions,
+    and sws_setColorspaceDetails() with brightness / contrast / saturation."""
+    sw, sh, sf, dw, dh, df, flags, k, opts, cs = case
+    try:
+        o = OL.Oracle(sw, sh, sf, dw, dh, df, flags, **opts)
+    except Exception:
+        pytest.skip("the oracle refuses this context")
+    del o
+    run_case(sw, sh, sf, dw, dh, df, flags, seed=k + 7, colorspace=cs, device_frames=bool(k & 1), opts=opts)
