@@ -180,8 +180,12 @@ void choose_unscaled(SwsInternal *c)
         const bool sp16 = isPlanarRGB(s) && !isFloatFmt(s) && pix_desc(s)->comp[0].depth > 8;
         const bool dp16 = isPlanarRGB(d) && !isFloatFmt(d) && pix_desc(d)->comp[0].depth > 8;
         if (s != d && ((s48 && d48) || (s48 && d64) || (s64 && d48))) k = PLAN_UNSC_RGB16SHUFFLE;
+        const bool s30 = s == AV_PIX_FMT_X2RGB10LE || s == AV_PIX_FMT_X2BGR10LE, d30 = d == AV_PIX_FMT_X2RGB10LE || d == AV_PIX_FMT_X2BGR10LE;
+        if (s30 && (d48 || d64)) k = PLAN_UNSC_RGB30_TO_16;                       // findRgbConvFn :1912-1937 through rgbToRgbWrapper (:2459-2463)
         if ((s48 || s64) && dp16) k = PLAN_UNSC_PACKED16_GBRP16;
+        if (s30 && isPlanarRGB(d) && !isFloatFmt(d) && pix_desc(d)->comp[0].depth >= 10) k = PLAN_UNSC_RGB30_TO_GBRP;   // :2509-2512
         if (sp16 && (d48 || d64)) k = PLAN_UNSC_GBRP16_PACKED16;
+        if (d30 && isPlanarRGB(s) && !isFloatFmt(s) && pix_desc(s)->comp[0].depth >= 10) k = PLAN_UNSC_GBRP_TO_RGB30;   // :2535-2538
     }
     if (isAnyRGB(s) && !isPlanarRGB(s) && pix_desc(s)->comp[0].depth == 8 && d == AV_PIX_FMT_GBRP) k = PLAN_UNSC_PACKED_GBRP;             // rgbToPlanarRgbWrapper (:2542-2544)
     if (s == AV_PIX_FMT_GBRP && isAnyRGB(d) && !isPlanarRGB(d) && pix_desc(d)->comp[0].depth == 8) k = PLAN_UNSC_GBRP_PACKED;             // planarRgbToRgbWrapper (:2480-2481)

@@ -102,6 +102,7 @@ static int src_kind_of(int f)
     if (!d) return -1;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? SRCK_GBRPF32 : d->comp[0].depth > 8 ? SRCK_GBRP16 : SRCK_GBRP;
     if (isAnyRGB(f) && d->comp[0].depth == 16) return SRCK_RGB48;
+    if (isAnyRGB(f) && d->comp[0].depth == 10 && d->comp[0].step == 4) return SRCK_RGB30;
     if (isAnyRGB(f) && d->comp[0].step == 2) return SRCK_RGB16;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? SRCK_RGB24 : SRCK_RGB32;
     if (isYUV(f) && isPackedFmt(f) && d->comp[0].depth > 8) return SRCK_PACKEDHI;
@@ -116,6 +117,7 @@ static int dst_kind_of(int f)
     if (!d) return -1;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? DSTK_GBRPF32 : d->comp[0].depth == 16 ? DSTK_GBRP16 : DSTK_GBRP;
     if (isAnyRGB(f) && d->comp[0].depth == 16) return DSTK_RGB48;
+    if (isAnyRGB(f) && d->comp[0].depth == 10 && d->comp[0].step == 4) return DSTK_RGB30;
     if (isAnyRGB(f) && d->comp[0].step == 2) return DSTK_RGB16;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? DSTK_RGB24 : DSTK_RGB32;
     if (isYUV(f) && isPackedFmt(f) && d->comp[0].depth > 8) return DSTK_PACKEDHI;
@@ -198,6 +200,7 @@ int dev_prepare(SwsInternal *c)
         p.src_pix_step = ds->comp[0].step;
         p.src_r_pos = ds->comp[0].offset; p.src_g_pos = ds->comp[1].offset; p.src_b_pos = ds->comp[2].offset;
     }
+    if (p.srcKind == SRCK_RGB30) p.s16_is565 = o.src_format == AV_PIX_FMT_X2RGB10LE;   // (reused as the field-order flag of the 30 bpp reader)
     if (p.srcKind == SRCK_RGB16) {   // RGB16_32FUNCS rows of input.c:396-401
         switch (o.src_format) {
         case AV_PIX_FMT_BGR565LE: p.s16_maskr = 0x001F; p.s16_maskg = 0x07E0; p.s16_maskb = 0xF800; p.s16_rsh = 11; p.s16_gsh = 5; p.s16_bsh = 0; p.s16_S = 15 + 8; break;
@@ -236,6 +239,12 @@ int dev_prepare(SwsInternal *c)
         L.alpha_or = isALPHA(o.src_format) ? 0u : (255u << ((base + 24) & 31));
         L.a_shift = (base + 24) & 31;
         L.rgb_order = df == AV_PIX_FMT_BGR24 ? 1 : 0;
+        if (p.dstKind == DSTK_RGB30) {   // yuv2rgb.c:915-941: "255u << 30" keeps the two X bits set unless the source has alpha
+            const bool x2rgb = df == AV_PIX_FMT_X2RGB10LE;
+            L.bpp30 = 1;
+            L.rshift = x2rgb ? 20 : 0; L.gshift = 10; L.bshift = x2rgb ? 0 : 20;
+            L.alpha_or = isALPHA(o.src_format) ? 0u : 0xC0000000u;
+        }
         if (p.dstKind == DSTK_RGB16) {   // yuv2rgb.c:853-897 (isRgb: the RGB565 / RGB555 / RGB444 orders, R in the high bits)
             const int bpp = pix_bits_per_pixel(dd);
             const bool rgb16 = df == AV_PIX_FMT_RGB565LE || df == AV_PIX_FMT_RGB555LE || df == AV_PIX_FMT_RGB444LE;
@@ -635,6 +644,9 @@ int dev_prepare(SwsInternal *c)
     case PLAN_UNSC_RGB16SHUFFLE: c->path_name = "unscaled:rgb16Shuffle"; c->kernel_name = "sws_k_rgb16_convert"; break;
     case PLAN_UNSC_PACKED16_GBRP16: c->path_name = "unscaled:Rgb16ToPlanarRgb16"; c->kernel_name = "sws_k_rgb16_convert"; break;
     case PLAN_UNSC_GBRP16_PACKED16: c->path_name = "unscaled:planarRgb16ToRgb16"; c->kernel_name = "sws_k_rgb16_convert"; break;
+    case PLAN_UNSC_RGB30_TO_16: c->path_name = "unscaled:rgbToRgb"; c->kernel_name = "sws_k_rgb30_convert"; break;
+    case PLAN_UNSC_RGB30_TO_GBRP: c->path_name = "unscaled:Rgb16ToPlanarRgb16"; c->kernel_name = "sws_k_rgb30_convert"; break;
+    case PLAN_UNSC_GBRP_TO_RGB30: c->path_name = "unscaled:planarRgb16ToRgb16"; c->kernel_name = "sws_k_rgb30_convert"; break;
     case PLAN_UNSC_YUV2RGB48: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb48_unscaled"; break;
     case PLAN_UNSC_YUV2RGB16: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb16_unscaled"; break;
     case PLAN_UNSC_RGBLOW: c->path_name = "unscaled:rgbToRgb"; c->kernel_name = "sws_k_rgb_low_convert"; break;
@@ -965,6 +977,22 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
         hipLaunchKernelGGL(swsk::sws_k_rgb16_convert, grid, blk, 0, st, fs, rp, p.srcW, sliceY);
         break;
     }
+    case PLAN_UNSC_RGB30_TO_16:
+    case PLAN_UNSC_RGB30_TO_GBRP:
+    case PLAN_UNSC_GBRP_TO_RGB30: {
+        const PixDesc *ds = pix_desc(c->opts.src_format), *dd = pix_desc(c->opts.dst_format);
+        swsk::Rgb30Plan rp;
+        std::memset(&rp, 0, sizeof(rp));
+        rp.mode = c->plan == PLAN_UNSC_RGB30_TO_16 ? 0 : c->plan == PLAN_UNSC_RGB30_TO_GBRP ? 1 : 2;
+        rp.x2rgb = (rp.mode == 2 ? c->opts.dst_format : c->opts.src_format) == AV_PIX_FMT_X2RGB10LE;
+        rp.dstep = dd->comp[0].step / 2;
+        for (int k = 0; k < 3; k++) rp.pos[k] = rp.mode == 0 ? dd->comp[k].offset / 2 : rp.mode == 1 ? dd->comp[k].plane : ds->comp[k].plane;
+        if (rp.mode == 1) { rp.hi = dd->comp[0].depth - 10; rp.lo = 10 - rp.hi; rp.shift = dd->comp[0].shift; }
+        if (rp.mode == 2) rp.shift = ds->comp[0].depth + ds->comp[0].shift - 10;
+        const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
+        hipLaunchKernelGGL(swsk::sws_k_rgb30_convert, grid, blk, 0, st, fs, rp, p.srcW, sliceY);
+        break;
+    }
     case PLAN_UNSC_YUV2RGB48: {
         const int dstW = p.dstW;
         const int npairs = ((dstW >> 3) << 2) + ((dstW & 4) ? 2 : 0) + ((dstW & 2) ? 1 : 0); // yuv2rgb.c:198-236
@@ -1050,7 +1078,7 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
             hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.dstW, 0);
         }
         const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 ||
-                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI || p.dstKind == DSTK_RGB48 || p.dstKind == DSTK_RGB16;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
+                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI || p.dstKind == DSTK_RGB48 || p.dstKind == DSTK_RGB16 || p.dstKind == DSTK_RGB30;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
         if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;

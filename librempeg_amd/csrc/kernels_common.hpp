@@ -70,6 +70,17 @@ __device__ __forceinline__ uint32_t lut_rgb32(const SwsLutParams &L, const Chrom
            ((uint32_t)lut_luma(L, k.b + Y) << L.bshift) | L.alpha_or;
 }
 
+// 30 bpp pixel (yuv2rgb.c:915-941 y_table32 planes with 10-bit ramps, summed by yuv2rgb_write output.c:1748-1754)
+__device__ __forceinline__ uint32_t lut_luma10(const SwsLutParams &L, int k)
+{
+    const int v = (L.yb0r + __mul24(k, L.cy)) >> 14;
+    return (uint32_t)(v < 0 ? 0 : v > 1023 ? 1023 : v);
+}
+__device__ __forceinline__ uint32_t lut_rgb30(const SwsLutParams &L, const ChromaIdx &k, int Y)
+{
+    return (lut_luma10(L, k.r + Y) << L.rshift) + (lut_luma10(L, k.g + Y) << L.gshift) + (lut_luma10(L, k.b + Y) << L.bshift) + L.alpha_or;
+}
+
 // 12/15/16 bpp pixel from the three luma-table indices (yuv2rgb.c:853-897: y_table16 planes, summed by yuv2rgb_write)
 __device__ __forceinline__ uint32_t lut_rgb16(const SwsLutParams &L, int ir, int ig, int ib)
 {

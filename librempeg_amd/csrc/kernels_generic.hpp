@@ -85,6 +85,28 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         const unsigned rnd = (256u << (S - 1)) + (1 << (S - 7));
         return (uint16_t)((unsigned)(cr * r + cg * g + cb * b + rnd) >> (S - 6));
     }
+    case SRCK_RGB30: { // rgb16_32ToY/UV/UV_half_c_template with the rgb30le / bgr30le rows (input.c:264-372, :411-412); s16_is565 = x2rgb10le
+        const int srow = comp == 0 ? row : (row << p.chrSrcVSub);
+        const uint32_t *s = (const uint32_t *)(f.src[0] + (int64_t)srow * f.srcStride[0]);
+        const int32_t *t = p.rgb2yuv;
+        const int S = 15 + 6, o = comp == 0 ? 0 : comp == 1 ? 3 : 6;
+        const int x2rgb = p.s16_is565, shr = x2rgb ? 16 : 0, shb = x2rgb ? 0 : 16;
+        const int maskr = x2rgb ? 0x3FF00000 : 0x3FF, maskg = 0xFFC00, maskb = x2rgb ? 0x3FF : 0x3FF00000;
+        const int cr = t[o] * (x2rgb ? 1 : 16), cg = t[o + 1], cb = t[o + 2] * (x2rgb ? 16 : 1);
+        if (comp != 0 && p.chr_half) {
+            const unsigned maskgx = ~(unsigned)(maskr | maskb);
+            const unsigned px0 = s[2 * x], px1 = s[2 * x + 1];
+            int g = (int)((px0 & maskgx) + (px1 & maskgx));
+            const int rb = (int)(px0 + px1 - (unsigned)g);
+            const int b = (rb & (maskb | (maskb << 1))) >> shb, r = (rb & (maskr | (maskr << 1))) >> shr;
+            g = (g & (maskg | (maskg << 1))) >> 6;
+            const unsigned rnd = (256U << S) + (1u << (S - 6));
+            return (uint16_t)((unsigned)(cr * r + cg * g + cb * b + rnd) >> (S - 6 + 1));
+        }
+        const int px = (int)s[x], b = (px & maskb) >> shb, g = (px & maskg) >> 6, r = (px & maskr) >> shr;
+        const unsigned rnd = ((comp == 0 ? 32u : 256u) << (S - 1)) + (1u << (S - 7));
+        return (uint16_t)((unsigned)(cr * r + cg * g + cb * b + rnd) >> (S - 6));
+    }
     case SRCK_RGB16: { // rgb16_32ToY/UV/UV_half_c_template with the 16 bpp rows (input.c:264-372, :396-401): masks on the unshifted pixel
         const int srow = comp == 0 ? row : (row << p.chrSrcVSub);
         const uint16_t *s = (const uint16_t *)(f.src[0] + (int64_t)srow * f.srcStride[0]);
@@ -627,6 +649,10 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
             }
             d[2 * i] = lut_rgb32(L, k, Y1) + a1;
             d[2 * i + 1] = lut_rgb32(L, k, Y2) + a2;
+        } else if (p.dstKind == DSTK_RGB30) {   // yuv2rgb_write, x2rgb10 / x2bgr10 (output.c:1748-1754)
+            uint32_t *d = (uint32_t *)drow;
+            d[2 * i] = lut_rgb30(L, k, Y1);
+            if (2 * i + 1 < p.dstW) d[2 * i + 1] = lut_rgb30(L, k, Y2);
         } else if (p.dstKind == DSTK_RGB16) {   // yuv2rgb_write, 12/15/16 bpp: ordered dither on the luma index (output.c:1714-1748)
             uint16_t *d = (uint16_t *)drow;
             const int bpp = L.bpp16;
@@ -674,6 +700,11 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
         int G = (int)((unsigned)Y + (unsigned)V * (unsigned)L.v2g + (unsigned)U * (unsigned)L.u2g);
         int B = (int)((unsigned)Y + (unsigned)U * (unsigned)L.u2b);
         if ((R | G | B) & 0xC0000000) { R = clip_uintp2(R, 30); G = clip_uintp2(G, 30); B = clip_uintp2(B, 30); }
+        if (p.dstKind == DSTK_RGB30) {   // output.c:2052-2063
+            const uint32_t r = (uint32_t)(R >> 20), g = (uint32_t)(G >> 20), b = (uint32_t)(B >> 20);
+            ((uint32_t *)drow)[i] = (3u << 30) + (r << L.rshift) + (g << 10) + (b << L.bshift);
+            return;
+        }
         uint8_t *d = drow + L.pix_step * i;
         d[L.r_pos] = (uint8_t)(R >> 22); d[L.g_pos] = (uint8_t)(G >> 22); d[L.b_pos] = (uint8_t)(B >> 22);
         if (L.pix_step == 4) {

@@ -237,6 +237,50 @@ __global__ void __launch_bounds__(256) sws_k_rgb16_convert(SwsFrameSet fs, Rgb16
     }
 }
 
+// x2rgb10le / x2bgr10le special converters: mode 0 = x2rgb10to48 / to64 / tobgr48 / tobgr64 (rgb2rgb.c:415-471), mode 1 =
+// packed30togbra10 (swscale_unscaled.c:819-889), mode 2 = gbr16ptopacked30 (:1076-1103).  pos[] = R, G, B word offsets (mode 0)
+// or plane indices (modes 1, 2); hi / lo = bit replication shifts, shift = the planar format's sample shift
+struct Rgb30Plan { int mode, x2rgb, dstep, pos[3], hi, lo, shift; };
+__global__ void __launch_bounds__(256) sws_k_rgb30_convert(SwsFrameSet fs, Rgb30Plan rp, int w, int sliceY)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= w) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int y = sliceY + blockIdx.y;
+    if (rp.mode == 2) {
+        uint32_t v[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int pl = rp.pos[k];
+            const uint8_t *sp = pl == 0 ? f.src[0] : pl == 1 ? f.src[1] : f.src[2];
+            const int ss = pl == 0 ? f.srcStride[0] : pl == 1 ? f.srcStride[1] : f.srcStride[2];
+            v[k] = (uint32_t)((const uint16_t *)(sp + (int64_t)y * ss))[x] >> rp.shift;
+        }
+        ((uint32_t *)(f.dst[0] + (int64_t)y * f.dstStride[0]))[x] =
+            rp.x2rgb ? (3u << 30) + (v[0] << 20) + (v[1] << 10) + v[2] : (3u << 30) + (v[2] << 20) + (v[1] << 10) + v[0];
+        return;
+    }
+    const uint32_t px = ((const uint32_t *)(f.src[0] + (int64_t)y * f.srcStride[0]))[x];
+    uint32_t v[3];
+    v[1] = (px >> 10) & 0x3FF;
+    v[0] = rp.x2rgb ? (px >> 20) & 0x3FF : px & 0x3FF;
+    v[2] = rp.x2rgb ? px & 0x3FF : (px >> 20) & 0x3FF;
+    if (rp.mode == 0) {
+        uint16_t *d = (uint16_t *)(f.dst[0] + (int64_t)y * f.dstStride[0]) + rp.dstep * x;
+#pragma unroll
+        for (int k = 0; k < 3; k++) d[rp.pos[k]] = (uint16_t)(v[k] << 6 | v[k] >> 4);
+        if (rp.dstep == 4) d[3] = 0xFFFF;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int pl = rp.pos[k];
+            uint8_t *dp = pl == 0 ? f.dst[0] : pl == 1 ? f.dst[1] : f.dst[2];
+            const int dst = pl == 0 ? f.dstStride[0] : pl == 1 ? f.dstStride[1] : f.dstStride[2];
+            ((uint16_t *)(dp + (int64_t)y * dst))[x] = (uint16_t)((v[k] << rp.hi | v[k] >> rp.lo) << rp.shift);
+        }
+    }
+}
+
 // yuv2rgb_c_48 / yuv2rgb_c_bgr48 (PUTRGB48 / PUTBGR48, yuv2rgb.c:107-125): the 8-bit LUT value fills both bytes of the
 // 16-bit component.  One thread = one chroma sample = 2 pixels x 2 rows.
 __global__ void __launch_bounds__(256) sws_k_yuv2rgb48_unscaled(SwsFrameSet fs, SwsDevParams p, int is422, int npairs, int sliceY)

@@ -82,6 +82,8 @@ static const PixDesc g_descs[] = {
     { AV_PIX_FMT_YUV444P10MSBLE, "yuv444p10msble", 3, 0, 0, {{0,2,0,6,10},{1,2,0,6,10},{2,2,0,6,10},{0,0,0,0,0}}, PIXFLAG_PLANAR },
     { AV_PIX_FMT_YUV444P12MSBLE, "yuv444p12msble", 3, 0, 0, {{0,2,0,4,12},{1,2,0,4,12},{2,2,0,4,12},{0,0,0,0,0}}, PIXFLAG_PLANAR },
     // 16 bits per pixel packed RGB (libavutil/pixdesc.c:1229-1420)
+    { AV_PIX_FMT_X2RGB10LE, "x2rgb10le", 3, 0, 0, {{0,4,2,4,10},{0,4,1,2,10},{0,4,0,0,10},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_X2BGR10LE, "x2bgr10le", 3, 0, 0, {{0,4,0,0,10},{0,4,1,2,10},{0,4,2,4,10},{0,0,0,0,0}}, PIXFLAG_RGB },
     { AV_PIX_FMT_RGB565LE, "rgb565le", 3, 0, 0, {{0,2,1,3,5},{0,2,0,5,6},{0,2,0,0,5},{0,0,0,0,0}}, PIXFLAG_RGB },
     { AV_PIX_FMT_RGB555LE, "rgb555le", 3, 0, 0, {{0,2,1,2,5},{0,2,0,5,5},{0,2,0,0,5},{0,0,0,0,0}}, PIXFLAG_RGB },
     { AV_PIX_FMT_RGB444LE, "rgb444le", 3, 0, 0, {{0,2,1,0,4},{0,2,0,4,4},{0,2,0,0,4},{0,0,0,0,0}}, PIXFLAG_RGB },

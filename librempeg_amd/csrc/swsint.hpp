@@ -78,6 +78,9 @@ enum PlanKind {
     PLAN_UNSC_RGB16SHUFFLE,   // rgb48tobgr48 / rgb48to64 / rgb48tobgr64 / rgb64to48 / rgb64tobgr48 (rgb2rgb.c:322-413)
     PLAN_UNSC_PACKED16_GBRP16,// Rgb16ToPlanarRgb16Wrapper
     PLAN_UNSC_GBRP16_PACKED16,// planarRgb16ToRgb16Wrapper
+    PLAN_UNSC_RGB30_TO_16,    // x2rgb10to48 / x2rgb10to64 / x2rgb10tobgr48 / x2rgb10tobgr64 (rgb2rgb.c:415-471)
+    PLAN_UNSC_RGB30_TO_GBRP,  // Rgb16ToPlanarRgb16Wrapper + packed30togbra10
+    PLAN_UNSC_GBRP_TO_RGB30,  // planarRgb16ToRgb16Wrapper + gbr16ptopacked30
     PLAN_UNSC_YUV2RGB48, PLAN_UNSC_YUV2RGB16, PLAN_UNSC_RGBLOW,      // yuv2rgb_c_48 / yuv2rgb_c_bgr48 (yuv2rgb.c:107-125, :505-508)
     PLAN_MAIN,             // ff_swscale chain
     PLAN_CASCADE,          // two contexts through an intermediate image

@@ -49,7 +49,7 @@ _FORMATS = {
     "yuv444p10msble": (259, "planar", 0, 0, 2), "yuv444p12msble": (261, "planar", 0, 0, 2),
     "vyu444": (230, "packed", 0, 0, 3), "uyva": (229, "packed", 0, 0, 4), "ayuv": (228, "packed", 0, 0, 4), "vuya": (205, "packed", 0, 0, 4), "vuyx": (208, "packed", 0, 0, 4),
     "y210le": (192, "packed422", 1, 0, 2), "y212le": (212, "packed422", 1, 0, 2), "y216le": (240, "packed422", 1, 0, 2),
-    "xv30le": (214, "packed", 0, 0, 4), "v30xle": (232, "packed", 0, 0, 4), "xv36le": (216, "packed", 0, 0, 8), "xv48le": (242, "packed", 0, 0, 8), "ayuv64le": (155, "packed", 0, 0, 8),
+    "x2rgb10le": (193, "packed", 0, 0, 4), "x2bgr10le": (195, "packed", 0, 0, 4), "xv30le": (214, "packed", 0, 0, 4), "v30xle": (232, "packed", 0, 0, 4), "xv36le": (216, "packed", 0, 0, 8), "xv48le": (242, "packed", 0, 0, 8), "ayuv64le": (155, "packed", 0, 0, 8),
     "rgb24": (2, "packed", 0, 0, 3), "bgr24": (3, "packed", 0, 0, 3),
     "argb": (25, "packed", 0, 0, 4), "rgba": (26, "packed", 0, 0, 4), "abgr": (27, "packed", 0, 0, 4), "bgra": (28, "packed", 0, 0, 4),
     "0rgb": (118, "packed", 0, 0, 4), "rgb0": (119, "packed", 0, 0, 4), "0bgr": (120, "packed", 0, 0, 4), "bgr0": (121, "packed", 0, 0, 4),

@@ -121,6 +121,8 @@ static const Desc descs[] = {
     { ORF_Y216LE, "y216le", 3, 1, 0, {{0,4,0,0,16},{0,8,2,0,16},{0,8,6,0,16}}, 0 },
     { ORF_XV30LE, "xv30le", 3, 0, 0, {{0,4,1,2,10},{0,4,0,0,10},{0,4,2,4,10}}, 0 },
     { ORF_V30XLE, "v30xle", 3, 0, 0, {{0,4,1,4,10},{0,4,0,2,10},{0,4,2,6,10}}, 0 },
+    { ORF_X2RGB10LE, "x2rgb10le", 3, 0, 0, {{0,4,2,4,10},{0,4,1,2,10},{0,4,0,0,10}}, PF_RGB },
+    { ORF_X2BGR10LE, "x2bgr10le", 3, 0, 0, {{0,4,0,0,10},{0,4,1,2,10},{0,4,2,4,10}}, PF_RGB },
     { ORF_XV36LE, "xv36le", 3, 0, 0, {{0,8,2,4,12},{0,8,0,4,12},{0,8,4,4,12}}, 0 },
     { ORF_XV48LE, "xv48le", 3, 0, 0, {{0,8,2,0,16},{0,8,0,0,16},{0,8,4,0,16}}, 0 },
     { ORF_AYUV64LE, "ayuv64le", 4, 0, 0, {{0,8,2,0,16},{0,8,4,0,16},{0,8,6,0,16},{0,8,0,0,16}}, PF_ALPHA },
@@ -143,6 +145,7 @@ static const Desc descs[] = {
 };
 static int isPackedHi(int f) { return f == ORF_Y210LE || f == ORF_Y212LE || f == ORF_Y216LE || f == ORF_XV30LE || f == ORF_V30XLE || f == ORF_XV36LE || f == ORF_XV48LE || f == ORF_AYUV64LE; }
 static int isPacked444(int f) { return f == ORF_VYU444 || f == ORF_UYVA || f == ORF_AYUV || f == ORF_VUYA || f == ORF_VUYX; }
+static int isRGB30(int f) { return f == ORF_X2RGB10LE || f == ORF_X2BGR10LE; }
 static int isRGB16(int f) { return f == ORF_RGB565LE || f == ORF_RGB555LE || f == ORF_RGB444LE || f == ORF_BGR565LE || f == ORF_BGR555LE || f == ORF_BGR444LE; }
 
 static const Desc *desc_get(int fmt)
@@ -257,7 +260,7 @@ enum { RY, GY, BY, RU, GU, BU, RV, GV, BV };
 
 enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
        UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_RGBLOW, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED,
-       UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP,
+       UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP, UNSC_RGB30_TO_16, UNSC_RGB30_TO_GBRP, UNSC_GBRP_TO_RGB30,
        UNSC_PLANAR2P422, UNSC_P4222PLANAR,
        UNSC_RGB16SHUFFLE, UNSC_PACKED16_TO_GBRP16, UNSC_GBRP16_TO_PACKED16 };
 
@@ -594,7 +597,7 @@ static int yuv2rgb_init_tables(OrSws *c, const int inv_table[4], int fullRange,
 {
     const int df = c->o.dst_format;
     /* AV_PIX_FMT_RGB32 = BGRA, RGB32_1 = ABGR, BGR32 = RGBA, BGR32_1 = ARGB on little endian */
-    const int isRgb = df == ORF_BGRA || df == ORF_ABGR || df == ORF_BGR24 || df == ORF_RGB565LE || df == ORF_RGB555LE || df == ORF_RGB444LE;
+    const int isRgb = df == ORF_BGRA || df == ORF_ABGR || df == ORF_BGR24 || df == ORF_RGB565LE || df == ORF_RGB555LE || df == ORF_RGB444LE || df == ORF_X2RGB10LE;
     const int bpp = c->dstFormatBpp;
     const int yoffs = (fullRange ? 384 : 326) + HEADROOM;
     int64_t crv = inv_table[0], cbu = inv_table[1], cgu = -inv_table[2], cgv = -inv_table[3];
@@ -656,6 +659,27 @@ static int yuv2rgb_init_tables(OrSws *c, const int inv_table[4], int fullRange,
         for (i = 0; i < TABLE_PLANE; i++) {
             unsigned yval = clip_u8((int)((yb + 0x8000) >> 16));
             t[i] = (yval << rbase) + (needAlpha ? 0 : (255u << abase));
+            t[i + TABLE_PLANE] = yval << gbase;
+            t[i + 2 * TABLE_PLANE] = yval << bbase;
+            yb += cy;
+        }
+        fill_table(c->table_rV, crv, yoffs);
+        fill_table(c->table_gU, cgu, yoffs + TABLE_PLANE);
+        fill_table(c->table_bU, cbu, yoffs + 2 * TABLE_PLANE);
+        fill_gv_table(c->table_gV, cgv);
+        c->has_lut = 1;
+        break;
+    }
+    case 30: { /* yuv2rgb.c:915-941: three planes of 10-bit ramps at bit 20 / 10 / 0; "255u << 30" keeps the two X bits set
+                * unless the source has alpha */
+        const int rbase = isRgb ? 20 : 0, gbase = 10, bbase = isRgb ? 0 : 20;
+        const int needAlpha = isALPHA(c->o.src_format);
+        uint32_t *t = malloc(TABLE_PLANE * 3 * 4);
+        c->yuvTable = (uint8_t *)t;
+        c->lut_elem = 4;
+        for (i = 0; i < TABLE_PLANE; i++) {
+            const unsigned yval = (unsigned)clip_uintp2((int)((yb + 0x8000) >> 14), 10);
+            t[i] = (yval << rbase) + (needAlpha ? 0 : (255u << 30));
             t[i + TABLE_PLANE] = yval << gbase;
             t[i + 2 * TABLE_PLANE] = yval << bbase;
             yb += cy;
@@ -933,8 +957,11 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         const int d48 = d == ORF_RGB48LE || d == ORF_BGR48LE, d64 = d == ORF_RGBA64LE || d == ORF_BGRA64LE;
         const int sp16 = isPlanarRGB(s) && !isFloat(s) && desc_get(s)->c[0].depth > 8, dp16 = isPlanarRGB(d) && !isFloat(d) && desc_get(d)->c[0].depth > 8;
         if (s != d && ((s48 && d48) || (s48 && d64) || (s64 && d48))) c->unscaled_kind = UNSC_RGB16SHUFFLE;
+        if (isRGB30(s) && (d48 || d64)) c->unscaled_kind = UNSC_RGB30_TO_16;   /* x2rgb10to48 / x2rgb10tobgr48 / ..64 (:1912-1937, :2459-2463) */
         if ((s48 || s64) && dp16) c->unscaled_kind = UNSC_PACKED16_TO_GBRP16;
+        if (isRGB30(s) && isPlanarRGB(d) && !isFloat(d) && desc_get(d)->c[0].depth >= 10) c->unscaled_kind = UNSC_RGB30_TO_GBRP;   /* :2509-2512 */
         if (sp16 && (d48 || d64)) c->unscaled_kind = UNSC_GBRP16_TO_PACKED16;
+        if (isRGB30(d) && isPlanarRGB(s) && !isFloat(s) && desc_get(s)->c[0].depth >= 10) c->unscaled_kind = UNSC_GBRP_TO_RGB30;   /* :2535-2538 */
     }
     /* rgbToPlanarRgbWrapper (:2542-2544): 8-bit packed RGB -> gbrp */
     if (isAnyRGB(s) && isPacked(s) && desc_get(s)->c[0].depth == 8 && d == ORF_GBRP) c->unscaled_kind = UNSC_PACKED2GBRP;
@@ -1608,6 +1635,69 @@ static int unscaled_gbrp16_packed16(OrSws *c, const uint8_t *const src[], const 
     return srcSliceH;
 }
 
+/* the 10-bit fields of an x2rgb10le / x2bgr10le pixel in R, G, B order */
+static void rgb30_fields(int f, uint32_t p, unsigned v[3])
+{
+    v[1] = (p >> 10) & 0x3FF;
+    if (f == ORF_X2RGB10LE) { v[0] = (p >> 20) & 0x3FF; v[2] = p & 0x3FF; } else { v[0] = p & 0x3FF; v[2] = (p >> 20) & 0x3FF; }
+}
+/* x2rgb10to48 / x2rgb10to64 / x2rgb10tobgr48 / x2rgb10tobgr64 (rgb2rgb.c:415-471): component << 6 | component >> 4, A = 0xffff */
+static int unscaled_rgb30_to_16(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                                int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    const Desc *dd = desc_get(c->o.dst_format);
+    (void)srcSliceY;
+    for (int y = 0; y < srcSliceH; y++) {
+        const uint8_t *s = src[0] + (ptrdiff_t)y * srcStride[0];
+        uint16_t *d = (uint16_t *)(dst[0] + (ptrdiff_t)y * dstStride[0]);
+        for (int x = 0; x < c->o.src_w; x++, d += dd->c[0].step / 2) {
+            uint32_t p; unsigned v[3];
+            memcpy(&p, s + 4 * x, 4);
+            rgb30_fields(c->o.src_format, p, v);
+            for (int k = 0; k < 3; k++) d[dd->c[k].offset / 2] = (uint16_t)(v[k] << 6 | v[k] >> 4);
+            if (dd->nb == 4) d[3] = 0xffff;
+        }
+    }
+    return srcSliceH;
+}
+/* Rgb16ToPlanarRgb16Wrapper + packed30togbra10 (swscale_unscaled.c:819-889, :933-953): (c << (bpc-10) | c >> (20-bpc)) << shift */
+static int unscaled_rgb30_to_gbrp(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                                  int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    const Desc *dd = desc_get(c->o.dst_format);
+    const int bpc = dd->c[0].depth, shift = dd->c[0].shift, hi = bpc - 10, lo = 10 - hi;
+    (void)srcSliceY;
+    for (int y = 0; y < srcSliceH; y++) {
+        const uint8_t *s = src[0] + (ptrdiff_t)y * srcStride[0];
+        for (int x = 0; x < c->o.src_w; x++) {
+            uint32_t p; unsigned v[3];
+            memcpy(&p, s + 4 * x, 4);
+            rgb30_fields(c->o.src_format, p, v);
+            for (int k = 0; k < 3; k++)
+                ((uint16_t *)(dst[dd->c[k].plane] + (ptrdiff_t)y * dstStride[dd->c[k].plane]))[x] = (uint16_t)((v[k] << hi | v[k] >> lo) << shift);
+        }
+    }
+    return srcSliceH;
+}
+/* planarRgb16ToRgb16Wrapper + gbr16ptopacked30 (swscale_unscaled.c:1076-1103, :1169-1178): sample >> (depth + shift - 10), fields added */
+static int unscaled_gbrp_to_rgb30(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                                  int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    const Desc *ds = desc_get(c->o.src_format);
+    const int shift = ds->c[0].depth + ds->c[0].shift - 10, x2rgb = c->o.dst_format == ORF_X2RGB10LE;
+    (void)srcSliceY;
+    for (int y = 0; y < srcSliceH; y++) {
+        uint8_t *d = dst[0] + (ptrdiff_t)y * dstStride[0];
+        for (int x = 0; x < c->o.src_w; x++) {
+            unsigned v[3]; uint32_t p;
+            for (int k = 0; k < 3; k++) v[k] = (unsigned)((const uint16_t *)(src[ds->c[k].plane] + (ptrdiff_t)y * srcStride[ds->c[k].plane]))[x] >> shift;
+            p = x2rgb ? (3U << 30) + (v[0] << 20) + (v[1] << 10) + v[2] : (3U << 30) + (v[2] << 20) + (v[1] << 10) + v[0];
+            memcpy(d + 4 * x, &p, 4);
+        }
+    }
+    return srcSliceH;
+}
+
 /* rgbToPlanarRgbWrapper (swscale_unscaled.c:1436-1490) with packedtogbr24p (:1404-1434): de-interleave, alpha dropped */
 static int unscaled_packed2gbrp(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
                                 int srcSliceH, uint8_t *const dst[], const int dstStride[])
@@ -1813,6 +1903,20 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
             d[i] = (uint16_t)(((unsigned)t[RY] * s[st * i + ro] + (unsigned)t[GY] * s[st * i + go] + (unsigned)t[BY] * s[st * i + bo] + (0x2001u << 14)) >> 15);
         return tmp;
     }
+    if (isRGB30(f)) { /* rgb16_32ToY_c_template input.c:264-293 with the rgb30le / bgr30le rows of :411-412 */
+        const uint8_t *s = src[0] + y * stride[0]; int16_t *d = (int16_t *)tmp;
+        const int x2rgb = f == ORF_X2RGB10LE, shr = x2rgb ? 16 : 0, shg = 6, shb = x2rgb ? 0 : 16, S = 15 + 6;
+        const int maskr = x2rgb ? 0x3FF00000 : 0x3FF, maskg = 0xFFC00, maskb = x2rgb ? 0x3FF : 0x3FF00000;
+        const int ry = t[RY] << (x2rgb ? 0 : 4), gy = t[GY], by = t[BY] << (x2rgb ? 4 : 0);
+        const unsigned rnd = (32u << (S - 1)) + (1u << (S - 7));
+        for (i = 0; i < w; i++) {
+            uint32_t pv; int px, r, g, b;
+            memcpy(&pv, s + 4 * i, 4);
+            px = (int)pv; b = (px & maskb) >> shb; g = (px & maskg) >> shg; r = (px & maskr) >> shr;
+            d[i] = (int16_t)((unsigned)(ry * r + gy * g + by * b + rnd) >> (S - 6));
+        }
+        return tmp;
+    }
     if (isRGB16(f)) { /* rgb16_32ToY_c_template input.c:264-293 with the 12/15/16 bpp rows of :396-401 */
         const uint16_t *s = (const uint16_t *)(src[0] + y * stride[0]); int16_t *d = (int16_t *)tmp;
         int maskr, maskg, maskb, rsh, gsh, bsh, S;
@@ -1893,6 +1997,38 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
     const int32_t *t = c->rgb2yuv;
     int i;
     *pu = tu; *pv = tv;
+    if (isRGB30(f)) { /* rgb16_32ToUV_c_template / rgb16_32ToUV_half_c_template input.c:295-372 with the rows of :411-412 */
+        const uint8_t *s = src[0] + (ptrdiff_t)(y << c->chrSrcVSub) * stride[0];
+        int16_t *du = (int16_t *)tu, *dv = (int16_t *)tv;
+        const int x2rgb = f == ORF_X2RGB10LE, shr = x2rgb ? 16 : 0, shg = 6, shb = x2rgb ? 0 : 16, S = 15 + 6;
+        int maskr = x2rgb ? 0x3FF00000 : 0x3FF, maskg = 0xFFC00, maskb = x2rgb ? 0x3FF : 0x3FF00000;
+        const int rsh = x2rgb ? 0 : 4, bsh = x2rgb ? 4 : 0;
+        const int ru = t[RU] * (1 << rsh), gu = t[GU], bu = t[BU] * (1 << bsh), rv = t[RV] * (1 << rsh), gv = t[GV], bv = t[BV] * (1 << bsh);
+        if (c->chrSrcHSub) {
+            const unsigned maskgx = ~(unsigned)(maskr | maskb);
+            const unsigned rnd = (256U << S) + (1u << (S - 6));
+            maskr |= maskr << 1; maskb |= maskb << 1; maskg |= maskg << 1;
+            for (i = 0; i < w; i++) {
+                uint32_t px0, px1; int b, r, g, rb;
+                memcpy(&px0, s + 8 * i, 4); memcpy(&px1, s + 8 * i + 4, 4);
+                g = (int)((px0 & maskgx) + (px1 & maskgx));
+                rb = (int)(px0 + px1 - (unsigned)g);
+                b = (rb & maskb) >> shb; g = (g & maskg) >> shg; r = (rb & maskr) >> shr;
+                du[i] = (int16_t)((unsigned)(ru * r + gu * g + bu * b + rnd) >> (S - 6 + 1));
+                dv[i] = (int16_t)((unsigned)(rv * r + gv * g + bv * b + rnd) >> (S - 6 + 1));
+            }
+        } else {
+            const unsigned rnd = (256u << (S - 1)) + (1u << (S - 7));
+            for (i = 0; i < w; i++) {
+                uint32_t pv; int px, r, g, b;
+                memcpy(&pv, s + 4 * i, 4);
+                px = (int)pv; b = (px & maskb) >> shb; g = (px & maskg) >> shg; r = (px & maskr) >> shr;
+                du[i] = (int16_t)((unsigned)(ru * r + gu * g + bu * b + rnd) >> (S - 6));
+                dv[i] = (int16_t)((unsigned)(rv * r + gv * g + bv * b + rnd) >> (S - 6));
+            }
+        }
+        return;
+    }
     if (isRGB16(f)) { /* rgb16_32ToUV_c_template / rgb16_32ToUV_half_c_template input.c:295-372 */
         const uint16_t *s = (const uint16_t *)(src[0] + (ptrdiff_t)(y << c->chrSrcVSub) * stride[0]);
         int16_t *du = (int16_t *)tu, *dv = (int16_t *)tv;
@@ -2328,6 +2464,14 @@ static void rgb_write_full(const OrSws *c, uint8_t *dest, int Y, int U, int V, i
     B = (int)((unsigned)Y + (unsigned)U * (unsigned)c->yuv2rgb_u2b);
     if ((R | G | B) & 0xC0000000) {
         R = clip_uintp2(R, 30); G = clip_uintp2(G, 30); B = clip_uintp2(B, 30);
+    }
+    if (d == ORF_X2RGB10LE || d == ORF_X2BGR10LE) {   /* output.c:2052-2063 */
+        uint32_t v;
+        R >>= 20; G >>= 20; B >>= 20;
+        v = d == ORF_X2RGB10LE ? (3U << 30) + ((unsigned)R << 20) + ((unsigned)G << 10) + (unsigned)B
+                               : (3U << 30) + ((unsigned)B << 20) + ((unsigned)G << 10) + (unsigned)R;
+        memcpy(dest, &v, 4);
+        return;
     }
     R >>= 22; G >>= 22; B >>= 22;
     switch (d) {
@@ -3018,6 +3162,9 @@ static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4
     case UNSC_NV242YUV420: return unscaled_nv242yuv420(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_YVU9_YV12: return unscaled_yvu9_yv12(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_PACKED2GBRP: return unscaled_packed2gbrp(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_RGB30_TO_16: return unscaled_rgb30_to_16(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_RGB30_TO_GBRP: return unscaled_rgb30_to_gbrp(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_GBRP_TO_RGB30: return unscaled_gbrp_to_rgb30(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_PLANAR2P422: return unscaled_planar2p422(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_P4222PLANAR: return unscaled_p4222planar(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_RGB16SHUFFLE: return unscaled_rgb16shuffle(c, src, srcStride, 0, srcSliceH, dst, dstStride);
@@ -3045,7 +3192,7 @@ const char *or_sws_path_name(const OrSws *c)
 {
     static const char *n[] = { "main", "yuv2rgb_c", "planarToP01x", "planar8ToP01xle", "planarToNv12", "nv12ToPlanar", "planarCopy",
                                "rgbToRgb", "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb",
-                               "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb",
+                               "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb", "rgbToRgb", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16",
                                "planarToYuy2", "yuyvToPlanar",
                                "rgb16Shuffle", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16" };
     return c->cascade[0] ? "cascade" : n[c->unscaled_kind];

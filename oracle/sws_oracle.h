@@ -48,6 +48,7 @@ enum {
     ORF_VUYA = 205, ORF_VUYX = 208, ORF_AYUV = 228, ORF_UYVA = 229, ORF_VYU444 = 230,
     ORF_AYUV64LE = 155, ORF_AYUV64BE = 156, ORF_Y210LE = 192, ORF_Y212LE = 212, ORF_Y216LE = 240, ORF_XV30LE = 214, ORF_V30XLE = 232,
     ORF_XV36BE = 215, ORF_XV36LE = 216, ORF_XV48BE = 241, ORF_XV48LE = 242,
+    ORF_X2RGB10LE = 193, ORF_X2BGR10LE = 195,
     ORF_GBRP9LE = 73, ORF_GBRP10LE = 75, ORF_GBRP16LE = 77, ORF_GBRP12LE = 135, ORF_GBRP14LE = 137,
 };
 

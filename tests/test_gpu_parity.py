@@ -95,9 +95,10 @@ BIG_ENDIAN = ["yuv420p10be", "yuv422p12be", "yuv444p16be", "yuv440p10be", "p010b
 PACKED_HI = ["y210le", "y212le", "y216le", "xv30le", "v30xle", "xv36le", "xv48le", "ayuv64le", "xv36be", "ayuv64be"]
 PACKED444 = ["vyu444", "uyva", "ayuv", "vuya", "vuyx"]
 MSB = ["yuv444p10msble", "yuv444p12msble", "yuv444p10msbbe"]
+RGB30 = ["x2rgb10le", "x2bgr10le"]
 RGB_LOW = ["rgb565le", "bgr565le", "rgb555le", "bgr555le", "rgb444le", "bgr444le", "rgb565be", "bgr555be"]
-FORMAT_MATRIX_SRC = PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
-FORMAT_MATRIX_DST = PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+FORMAT_MATRIX_SRC = RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+FORMAT_MATRIX_DST = RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
 
 
 @pytest.mark.parametrize("sfmt", FORMAT_MATRIX_SRC)
@@ -169,6 +170,8 @@ def _slice_ptrs(frame, fmt, y0):
 
 
 SLICED_UNSCALED = [
+    ("x2rgb10le", "rgb48le", BX), ("x2bgr10le", "rgba64le", 0), ("x2rgb10le", "bgr48be", 0), ("x2bgr10le", "rgb48le", BX), ("x2rgb10le", "gbrp10le", BX),
+    ("x2bgr10le", "gbrp16le", 0), ("x2rgb10le", "gbrp12be", 0), ("gbrp12le", "x2rgb10le", BX), ("gbrp10be", "x2bgr10le", 0), ("gbrp16le", "x2bgr10le", BX), ("x2rgb10le", "x2rgb10le", BX),
     ("y210le", "y210le", BX), ("xv30le", "xv30le", 0), ("xv36le", "xv36be", BX), ("xv48be", "xv48le", 0), ("ayuv64le", "ayuv64le", BX),
     ("ayuv", "vuya", BX), ("ayuv", "vuyx", 0), ("ayuv", "uyva", BX), ("vuya", "ayuv", BX), ("vuya", "uyva", 0), ("uyva", "ayuv", BX), ("uyva", "vuya", BX),
     ("uyva", "vuyx", BX), ("vuyx", "vuyx", BX), ("vyu444", "vyu444", 0),
