@@ -77,6 +77,8 @@ enum AVPixelFormat {
      * reference's last format (AV_PIX_FMT_NB == 268, libavutil/pixfmt.h) */
     AV_PIX_FMT_AYUV64LE = 155, AV_PIX_FMT_AYUV64BE = 156, AV_PIX_FMT_Y210LE = 192, AV_PIX_FMT_Y212LE = 212, AV_PIX_FMT_Y216LE = 240,
     AV_PIX_FMT_X2RGB10LE = 193, AV_PIX_FMT_X2BGR10LE = 195,
+    AV_PIX_FMT_YUVJ411P = 138, AV_PIX_FMT_NV20LE = 102, AV_PIX_FMT_NV20BE = 103,
+    AV_PIX_FMT_GBRP10MSBBE = 262, AV_PIX_FMT_GBRP10MSBLE = 263, AV_PIX_FMT_GBRP12MSBBE = 264, AV_PIX_FMT_GBRP12MSBLE = 265,
     AV_PIX_FMT_XV30LE = 214, AV_PIX_FMT_V30XLE = 232, AV_PIX_FMT_XV36BE = 215, AV_PIX_FMT_XV36LE = 216, AV_PIX_FMT_XV48BE = 241, AV_PIX_FMT_XV48LE = 242,
     AV_PIX_FMT_VUYA = 205, AV_PIX_FMT_VUYX = 208, AV_PIX_FMT_AYUV = 228, AV_PIX_FMT_UYVA = 229, AV_PIX_FMT_VYU444 = 230,
     AV_PIX_FMT_YUV444P10MSBBE = 258, AV_PIX_FMT_YUV444P10MSBLE = 259, AV_PIX_FMT_YUV444P12MSBBE = 260, AV_PIX_FMT_YUV444P12MSBLE = 261,

@@ -64,6 +64,7 @@ static int jpeg_alias(int *format) // handle_jpeg, utils.c:773-809
     if (*format == AV_PIX_FMT_YUVJ422P) { *format = AV_PIX_FMT_YUV422P; return 1; }
     if (*format == AV_PIX_FMT_YUVJ444P) { *format = AV_PIX_FMT_YUV444P; return 1; }
     if (*format == AV_PIX_FMT_YUVJ440P) { *format = AV_PIX_FMT_YUV440P; return 1; }
+    if (*format == AV_PIX_FMT_YUVJ411P) { *format = AV_PIX_FMT_YUV411P; return 1; }
     if (pix_desc(*format) && isGray(*format)) return 1;   // gray8 .. gray16: always full range (:791-805)
     return 0;
 }

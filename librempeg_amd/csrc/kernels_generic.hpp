@@ -162,9 +162,10 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         return comp == 0 ? s[2 * x + p.s422_y] : s[4 * x + (comp == 1 ? p.s422_u : p.s422_v)];
     }
     case SRCK_GBRP16: { // planar_rgb16_s16_to_y / _to_uv, input.c:1216-1270
-        const int g = *(const uint16_t *)(f.src[0] + (int64_t)row * f.srcStride[0] + 2 * x);
-        const int b = *(const uint16_t *)(f.src[1] + (int64_t)row * f.srcStride[1] + 2 * x);
-        const int r = *(const uint16_t *)(f.src[2] + (int64_t)row * f.srcStride[2] + 2 * x);
+        // (gbrp10msb / gbrp12msb: planar_rgb16_s10 / s12 shift the samples down first, input.c:1462-1474)
+        const int g = *(const uint16_t *)(f.src[0] + (int64_t)row * f.srcStride[0] + 2 * x) >> p.src_shift;
+        const int b = *(const uint16_t *)(f.src[1] + (int64_t)row * f.srcStride[1] + 2 * x) >> p.src_shift;
+        const int r = *(const uint16_t *)(f.src[2] + (int64_t)row * f.srcStride[2] + 2 * x) >> p.src_shift;
         const int32_t *t = p.rgb2yuv;
         const int bpc = p.src_depth, shift = bpc < 16 ? bpc : 14;
         const int o = comp == 0 ? 0 : comp == 1 ? 3 : 6;
@@ -408,7 +409,9 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
             B = (int)((unsigned)Y + (unsigned)U * (unsigned)L.u2b);
             if ((R | G | B) & 0xC0000000) { R = clip_uintp2(R, 30); G = clip_uintp2(G, 30); B = clip_uintp2(B, 30); }
             if (SH != 22) {
-                ((uint16_t *)dg)[i] = (uint16_t)(G >> SH); ((uint16_t *)db)[i] = (uint16_t)(B >> SH); ((uint16_t *)dr)[i] = (uint16_t)(R >> SH);
+                // (yuv2gbrpmsb_full_X_c output.c:2424-2462: the same samples << (16 - depth))
+                ((uint16_t *)dg)[i] = (uint16_t)((G >> SH) << p.dst_shift); ((uint16_t *)db)[i] = (uint16_t)((B >> SH) << p.dst_shift);
+                ((uint16_t *)dr)[i] = (uint16_t)((R >> SH) << p.dst_shift);
             } else {
                 dg[i] = (uint8_t)(G >> 22); db[i] = (uint8_t)(B >> 22); dr[i] = (uint8_t)(R >> 22);
             }

@@ -121,6 +121,10 @@ static const Desc descs[] = {
     { ORF_Y216LE, "y216le", 3, 1, 0, {{0,4,0,0,16},{0,8,2,0,16},{0,8,6,0,16}}, 0 },
     { ORF_XV30LE, "xv30le", 3, 0, 0, {{0,4,1,2,10},{0,4,0,0,10},{0,4,2,4,10}}, 0 },
     { ORF_V30XLE, "v30xle", 3, 0, 0, {{0,4,1,4,10},{0,4,0,2,10},{0,4,2,6,10}}, 0 },
+    PL8(ORF_YUVJ411P, "yuvj411p", 2, 0),
+    { ORF_NV20LE, "nv20le", 3, 1, 0, {{0,2,0,0,10},{1,4,0,0,10},{1,4,2,0,10}}, PF_PLANAR },
+    { ORF_GBRP10MSBLE, "gbrp10msble", 3, 0, 0, {{2,2,0,6,10},{0,2,0,6,10},{1,2,0,6,10}}, PF_PLANAR | PF_RGB },
+    { ORF_GBRP12MSBLE, "gbrp12msble", 3, 0, 0, {{2,2,0,4,12},{0,2,0,4,12},{1,2,0,4,12}}, PF_PLANAR | PF_RGB },
     { ORF_X2RGB10LE, "x2rgb10le", 3, 0, 0, {{0,4,2,4,10},{0,4,1,2,10},{0,4,0,0,10}}, PF_RGB },
     { ORF_X2BGR10LE, "x2bgr10le", 3, 0, 0, {{0,4,0,0,10},{0,4,1,2,10},{0,4,2,4,10}}, PF_RGB },
     { ORF_XV36LE, "xv36le", 3, 0, 0, {{0,8,2,4,12},{0,8,0,4,12},{0,8,4,4,12}}, 0 },
@@ -161,6 +165,7 @@ static const Desc *desc_get(int fmt)
  * the reference's rules, which only name a byte order for planarToP01xWrapper / planar8ToP01xleWrapper (native-endian only). */
 static const int be_pairs[][2] = {
     { ORF_XV36BE, ORF_XV36LE }, { ORF_XV48BE, ORF_XV48LE }, { ORF_AYUV64BE, ORF_AYUV64LE },
+    { ORF_NV20BE, ORF_NV20LE }, { ORF_GBRP10MSBBE, ORF_GBRP10MSBLE }, { ORF_GBRP12MSBBE, ORF_GBRP12MSBLE },
     { ORF_YUV444P10MSBBE, ORF_YUV444P10MSBLE }, { ORF_YUV444P12MSBBE, ORF_YUV444P12MSBLE },
     { ORF_RGB565BE, ORF_RGB565LE }, { ORF_RGB555BE, ORF_RGB555LE }, { ORF_RGB444BE, ORF_RGB444LE },
     { ORF_BGR565BE, ORF_BGR565LE }, { ORF_BGR555BE, ORF_BGR555LE }, { ORF_BGR444BE, ORF_BGR444LE },
@@ -847,6 +852,7 @@ static int handle_jpeg(int *format) /* utils.c:773 */
     if (*format == ORF_YUVJ422P) { *format = ORF_YUV422P; return 1; }
     if (*format == ORF_YUVJ444P) { *format = ORF_YUV444P; return 1; }
     if (*format == ORF_YUVJ440P) { *format = ORF_YUV440P; return 1; }
+    if (*format == ORF_YUVJ411P) { *format = ORF_YUV411P; return 1; }
     if (isGray(*format)) return 1;   /* gray8 .. gray16: always full range (utils.c:791-805) */
     return 0;
 }
@@ -1960,13 +1966,14 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
         for (i = 0; i < w; i++)
             d[i] = (uint16_t)((int)((unsigned)t[RY] * R[i] + (unsigned)t[GY] * G[i] + (unsigned)t[BY] * B[i] + (0x801 << (15 - 7))) >> (15 - 6));
         return tmp; }
+    case ORF_GBRP10MSBLE: case ORF_GBRP12MSBLE:   /* planar_rgb16_s10 / s12_to_y: samples >> (16 - bits) (input.c:1216-1232, :1462-1474) */
     case ORF_GBRP9LE: case ORF_GBRP10LE: case ORF_GBRP12LE: case ORF_GBRP14LE: case ORF_GBRP16LE: { /* planar_rgb16_s16_to_y input.c:1216-1232 */
         const uint16_t *G = (const uint16_t *)(src[0] + y * stride[0]), *B = (const uint16_t *)(src[1] + y * stride[1]),
                        *R = (const uint16_t *)(src[2] + y * stride[2]);
-        const int bpc = desc_get(f)->c[0].depth, shift = bpc < 16 ? bpc : 14;
+        const int bpc = desc_get(f)->c[0].depth, shift = bpc < 16 ? bpc : 14, ms = desc_get(f)->c[0].shift;
         uint16_t *d = (uint16_t *)tmp;
         for (i = 0; i < w; i++)
-            d[i] = (uint16_t)((int)((unsigned)t[RY] * R[i] + (unsigned)t[GY] * G[i] + (unsigned)t[BY] * B[i] +
+            d[i] = (uint16_t)((int)((unsigned)t[RY] * (R[i] >> ms) + (unsigned)t[GY] * (G[i] >> ms) + (unsigned)t[BY] * (B[i] >> ms) +
                                     (16u << (15 + bpc - 8)) + (1u << (15 + shift - 15))) >> (15 + shift - 14));
         return tmp; }
     case ORF_GBRPF32LE: { /* planar_rgbf32_to_y input.c:1319-1334 */
@@ -2181,15 +2188,16 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
             }
         }
         return; }
+    case ORF_GBRP10MSBLE: case ORF_GBRP12MSBLE:
     case ORF_GBRP9LE: case ORF_GBRP10LE: case ORF_GBRP12LE: case ORF_GBRP14LE: case ORF_GBRP16LE: { /* planar_rgb16_s16_to_uv input.c:1248-1270 */
         const uint16_t *G = (const uint16_t *)(src[0] + y * stride[0]), *B = (const uint16_t *)(src[1] + y * stride[1]),
                        *R = (const uint16_t *)(src[2] + y * stride[2]);
-        const int bpc = desc_get(f)->c[0].depth, shift = bpc < 16 ? bpc : 14;
+        const int bpc = desc_get(f)->c[0].depth, shift = bpc < 16 ? bpc : 14, ms = desc_get(f)->c[0].shift;
         uint16_t *du = (uint16_t *)tu, *dv = (uint16_t *)tv;
         for (i = 0; i < w; i++) {
-            du[i] = (uint16_t)((int)((unsigned)t[RU] * R[i] + (unsigned)t[GU] * G[i] + (unsigned)t[BU] * B[i] +
+            du[i] = (uint16_t)((int)((unsigned)t[RU] * (R[i] >> ms) + (unsigned)t[GU] * (G[i] >> ms) + (unsigned)t[BU] * (B[i] >> ms) +
                                      (128u << (15 + bpc - 8)) + (1u << (15 + shift - 15))) >> (15 + shift - 14));
-            dv[i] = (uint16_t)((int)((unsigned)t[RV] * R[i] + (unsigned)t[GV] * G[i] + (unsigned)t[BV] * B[i] +
+            dv[i] = (uint16_t)((int)((unsigned)t[RV] * (R[i] >> ms) + (unsigned)t[GV] * (G[i] >> ms) + (unsigned)t[BV] * (B[i] >> ms) +
                                      (128u << (15 + bpc - 8)) + (1u << (15 + shift - 15))) >> (15 + shift - 14));
         }
         return; }
@@ -2384,9 +2392,9 @@ static void write_nv_chroma_line(const OrSws *c, uint8_t *dest, int w, const int
             d[2 * i] = (uint16_t)(0x8000 + clip_i16(u >> 15));
             d[2 * i + 1] = (uint16_t)(0x8000 + clip_i16(v >> 15));
         }
-    } else if (isDataInHighBits(c->o.dst_format)) {
+    } else if (isDataInHighBits(c->o.dst_format) || bits > 8) {   /* yuv2p010cX / yuv2p012cX / yuv2nv20cX (output.c:571-593, :650-652) */
         uint16_t *d = (uint16_t *)dest;
-        int shift = 11 + 16 - bits, oshift = 16 - bits;
+        int shift = 11 + 16 - bits, oshift = desc_get(c->o.dst_format)->c[0].shift;
         for (i = 0; i < w; i++) {
             int u = 1 << (shift - 1), v = 1 << (shift - 1);
             for (j = 0; j < fs; j++) {
@@ -2904,8 +2912,9 @@ static void write_planar_rgb_line(const OrSws *c, const Planes *P, uint8_t *cons
             G = (int)((unsigned)Y + (unsigned)V * (unsigned)c->yuv2rgb_v2g + (unsigned)U * (unsigned)c->yuv2rgb_u2g);
             B = (int)((unsigned)Y + (unsigned)U * (unsigned)c->yuv2rgb_u2b);
             if ((R | G | B) & 0xC0000000) { R = clip_uintp2(R, 30); G = clip_uintp2(G, 30); B = clip_uintp2(B, 30); }
-            if (SH != 22) {
-                ((uint16_t *)dg)[i] = (uint16_t)(G >> SH); ((uint16_t *)db)[i] = (uint16_t)(B >> SH); ((uint16_t *)dr)[i] = (uint16_t)(R >> SH);
+            if (SH != 22) {   /* (yuv2gbrpmsb_full_X_c output.c:2424-2462: the same samples << (16 - depth)) */
+                const int ms = desc_get(c->o.dst_format)->c[0].shift;
+                ((uint16_t *)dg)[i] = (uint16_t)((G >> SH) << ms); ((uint16_t *)db)[i] = (uint16_t)((B >> SH) << ms); ((uint16_t *)dr)[i] = (uint16_t)((R >> SH) << ms);
             } else {
                 dg[i] = (uint8_t)(G >> 22); db[i] = (uint8_t)(B >> 22); dr[i] = (uint8_t)(R >> 22);
             }

@@ -96,9 +96,10 @@ PACKED_HI = ["y210le", "y212le", "y216le", "xv30le", "v30xle", "xv36le", "xv48le
 PACKED444 = ["vyu444", "uyva", "ayuv", "vuya", "vuyx"]
 MSB = ["yuv444p10msble", "yuv444p12msble", "yuv444p10msbbe"]
 RGB30 = ["x2rgb10le", "x2bgr10le"]
+MISC7 = ["yuvj411p", "nv20le", "nv20be", "gbrp10msble", "gbrp12msble", "gbrp10msbbe", "gbrp12msbbe"]
 RGB_LOW = ["rgb565le", "bgr565le", "rgb555le", "bgr555le", "rgb444le", "bgr444le", "rgb565be", "bgr555be"]
-FORMAT_MATRIX_SRC = RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
-FORMAT_MATRIX_DST = RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+FORMAT_MATRIX_SRC = MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+FORMAT_MATRIX_DST = MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
 
 
 @pytest.mark.parametrize("sfmt", FORMAT_MATRIX_SRC)
@@ -170,6 +171,8 @@ def _slice_ptrs(frame, fmt, y0):
 
 
 SLICED_UNSCALED = [
+    ("nv20le", "nv20le", BX), ("nv20be", "nv20le", 0), ("gbrp10msble", "gbrp10msble", BX), ("gbrp12msbbe", "gbrp12msble", 0), ("x2rgb10le", "gbrp10msble", 0),
+    ("gbrp12msble", "x2bgr10le", BX), ("yuvj411p", "yuvj411p", BX),
     ("x2rgb10le", "rgb48le", BX), ("x2bgr10le", "rgba64le", 0), ("x2rgb10le", "bgr48be", 0), ("x2bgr10le", "rgb48le", BX), ("x2rgb10le", "gbrp10le", BX),
     ("x2bgr10le", "gbrp16le", 0), ("x2rgb10le", "gbrp12be", 0), ("gbrp12le", "x2rgb10le", BX), ("gbrp10be", "x2bgr10le", 0), ("gbrp16le", "x2bgr10le", BX), ("x2rgb10le", "x2rgb10le", BX),
     ("y210le", "y210le", BX), ("xv30le", "xv30le", 0), ("xv36le", "xv36be", BX), ("xv48be", "xv48le", 0), ("ayuv64le", "ayuv64le", BX),
