@@ -192,7 +192,7 @@ int sws_frame_setup(SwsContext *sws, const SwsFrameView *dst, const SwsFrameView
     if (!c->legacy_init) return init_from_frames(c, src->width, src->height, src->format, dst->width, dst->height, dst->format);
     return (canonical_pix_fmt(src->format) == sws->src_format && src->width == sws->src_w && src->height == sws->src_h &&
             canonical_pix_fmt(dst->format) == sws->dst_format && dst->width == sws->dst_w && dst->height == sws->dst_h &&
-            c->srcBE == (pix_be_twin(src->format) >= 0) && c->dstBE == (pix_be_twin(dst->format) >= 0)) ? 0 : SWS_AVERROR(EINVAL);
+            src_tags_match(c, src->format) && dst_tags_match(c, dst->format)) ? 0 : SWS_AVERROR(EINVAL);
 }
 
 int sws_frame_start(SwsContext *sws, SwsFrameView *dst, const SwsFrameView *src)

@@ -31,7 +31,7 @@ void write_ctx(Writer &w, const SwsInternal *c)
                        c->chrSrcHSubSample, c->chrSrcVSubSample, c->chrDstHSubSample, c->chrDstVSubSample,
                        c->chrSrcW, c->chrSrcH, c->chrDstW, c->chrDstH, c->srcBpc, c->dstBpc,
                        c->lumXInc, c->lumYInc, c->chrXInc, c->chrYInc, c->dst_slice_align, c->needAlpha, (int32_t)c->plan,
-                       c->cascade_fmt, c->cascade_w, c->cascade_h, c->legacy_init ? 1 : 0, c->srcBE ? 1 : 0, c->dstBE ? 1 : 0 };
+                       c->cascade_fmt, c->cascade_w, c->cascade_h, c->legacy_init ? 1 : 0, (c->srcBE ? 1 : 0) | (c->srcXYZ ? 2 : 0), (c->dstBE ? 1 : 0) | (c->dstXYZ ? 2 : 0) };
     w.put(ints, sizeof(ints));
     w.put(c->srcColorspaceTable, sizeof(c->srcColorspaceTable));
     w.put(c->dstColorspaceTable, sizeof(c->dstColorspaceTable));
@@ -64,7 +64,7 @@ bool read_ctx(Reader &r, SwsInternal *c)
     c->lumXInc = ints[k++]; c->lumYInc = ints[k++]; c->chrXInc = ints[k++]; c->chrYInc = ints[k++]; c->dst_slice_align = ints[k++];
     c->needAlpha = ints[k++]; c->plan = (PlanKind)ints[k++]; c->cascade_fmt = ints[k++]; c->cascade_w = ints[k++]; c->cascade_h = ints[k++];
     c->legacy_init = ints[k++] != 0;
-    c->srcBE = ints[k++] != 0; c->dstBE = ints[k++] != 0;
+    c->srcBE = (ints[k] & 1) != 0; c->srcXYZ = (ints[k++] & 2) != 0; c->dstBE = (ints[k] & 1) != 0; c->dstXYZ = (ints[k++] & 2) != 0;
     r.get(c->srcColorspaceTable, sizeof(c->srcColorspaceTable));
     r.get(c->dstColorspaceTable, sizeof(c->dstColorspaceTable));
     for (FilterBank *b : { &c->hLum, &c->hChr, &c->vLum, &c->vChr }) {

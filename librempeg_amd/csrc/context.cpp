@@ -50,12 +50,21 @@ static bool be_alias(int *format)
     return true;
 }
 
-static void canonicalise_formats(SwsInternal *c) // handle_formats, utils.c:833-842 (no XYZ)
+static bool xyz_alias(int *format) // handle_xyz, utils.c:822-829 (after be_alias: xyz12be is xyz12le + the BE flag)
+{
+    if (*format != AV_PIX_FMT_XYZ12LE) return false;
+    *format = AV_PIX_FMT_RGB48LE;
+    return true;
+}
+
+static void canonicalise_formats(SwsInternal *c) // handle_formats, utils.c:833-842
 {
     c->srcBE |= be_alias(&c->opts.src_format);
     c->dstBE |= be_alias(&c->opts.dst_format);
     c->src0Alpha |= zero_alpha_alias(&c->opts.src_format);
     c->dst0Alpha |= zero_alpha_alias(&c->opts.dst_format);
+    c->srcXYZ |= xyz_alias(&c->opts.src_format);
+    c->dstXYZ |= xyz_alias(&c->opts.dst_format);
 }
 
 static int jpeg_alias(int *format) // handle_jpeg, utils.c:773-809
@@ -74,6 +83,7 @@ int canonical_pix_fmt(int fmt)
     be_alias(&fmt);
     jpeg_alias(&fmt);
     zero_alpha_alias(&fmt);
+    xyz_alias(&fmt);
     return fmt;
 }
 
@@ -428,13 +438,14 @@ int init_from_frames(SwsInternal *c, int sw, int sh, int sfmt, int dw, int dh, i
     SwsContext &o = c->opts;
     if (c->dynamic_init && o.src_w == sw && o.src_h == sh && o.dst_w == dw && o.dst_h == dh &&
         o.src_format == canonical_pix_fmt(sfmt) && o.dst_format == canonical_pix_fmt(dfmt) &&
-        c->srcBE == (pix_be_twin(sfmt) >= 0) && c->dstBE == (pix_be_twin(dfmt) >= 0)) return 0;
+        src_tags_match(c, sfmt) && dst_tags_match(c, dfmt)) return 0;
     // new geometry: drop everything derived from the old one
     destroy(c->cascade[0]); destroy(c->cascade[1]);
     c->cascade[0] = c->cascade[1] = nullptr;
     dev_release(c);
     c->src0Alpha = c->dst0Alpha = 0;
     c->srcBE = c->dstBE = false;
+    c->srcXYZ = c->dstXYZ = false;
     c->dstFormatBpp = c->srcFormatBpp = 0;
     c->contrast = c->saturation = c->brightness = 0;
     o.src_w = sw; o.src_h = sh; o.src_format = sfmt; o.dst_w = dw; o.dst_h = dh; o.dst_format = dfmt;
@@ -507,7 +518,8 @@ SwsContext *sws_getCachedContext(SwsContext *prev, int srcW, int srcH, enum AVPi
         int sf = srcFormat, df = dstFormat;
         const bool sbe = be_alias(&sf), dbe = be_alias(&df);
         jpeg_alias(&sf); jpeg_alias(&df); zero_alpha_alias(&sf); zero_alpha_alias(&df);
-        if (p->srcBE != sbe || p->dstBE != dbe || prev->src_w != srcW || prev->src_h != srcH || prev->src_format != sf || prev->dst_w != dstW ||
+        const bool sxyz = xyz_alias(&sf), dxyz = xyz_alias(&df);
+        if (p->srcXYZ != sxyz || p->dstXYZ != dxyz || p->srcBE != sbe || p->dstBE != dbe || prev->src_w != srcW || prev->src_h != srcH || prev->src_format != sf || prev->dst_w != dstW ||
             prev->dst_h != dstH || prev->dst_format != df || prev->flags != (unsigned)flags ||
             prev->scaler_params[0] != param[0] || prev->scaler_params[1] != param[1]) {
             destroy(p);

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
+#include <mutex>
 #include <vector>
 
 #include "kernels_march.hpp"
@@ -30,6 +32,7 @@ struct DeviceState {
     bool tile_ok = false; SwsTileGeom tileL, tileC; void *d_tilegeom = nullptr; size_t tilegeom_bytes = 0;
     bool rgb_march_ok = false; void *d_rgbplan = nullptr; size_t rgbplan_bytes = 0; int rgb_groups = 0;   // sws_k_rgb_fused_unity_march
     void *d_be = nullptr; size_t be_bytes = 0;   // little-endian copies of big-endian source pictures
+    void *d_xyz = nullptr; size_t xyz_bytes = 0; void *d_xyz_tab = nullptr;   // rgb48 copies of xyz12 source pictures; the four gamma LUTs
     bool dot2_ok = false; SwsTileGeom dotL, dotC; void *d_dot2 = nullptr; size_t dot2_bytes = 0;
     bool strip_ok = false; SwsStripGeom stripL, stripC;    // sws_k_strip_march (tables live in d_dot2)
     bool march_ok = false; SwsMarchGeom marL, marC; void *d_march = nullptr; size_t march_bytes = 0;
@@ -80,6 +83,8 @@ void dev_release(SwsInternal *c)
     if (d->d_tilegeom) (void)hipFree(d->d_tilegeom);
     if (d->d_rgbplan) (void)hipFree(d->d_rgbplan);
     if (d->d_be) (void)hipFree(d->d_be);
+    if (d->d_xyz) (void)hipFree(d->d_xyz);
+    if (d->d_xyz_tab) (void)hipFree(d->d_xyz_tab);
     if (d->d_dot2) (void)hipFree(d->d_dot2);
     if (d->d_march) (void)hipFree(d->d_march);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
@@ -1299,9 +1304,74 @@ static void plane_extent(const PixDesc *d, int w, int h, int k, int *rows, int *
     *row_bytes = maxb;
 }
 
+// sws_scale's XYZ stages (swscale.c:1126-1139, :1194-1210): an xyz12 source slice is converted into an rgb48 scratch picture first
+// (xyz12Torgb48_c :745-802), the written rows of an xyz12 destination are converted in place afterwards (rgb48Toxyz12_c :804-861);
+// both are skipped for xyz12 -> xyz12 at equal sizes.  Gamma LUTs as init_xyz_tables (utils.c:709-733) builds them, from libm pow().
+static int launch_plan_xyz(SwsInternal *c, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
+{
+    const SwsContext &o = c->opts;
+    if ((!c->srcXYZ && !c->dstXYZ) || (c->srcXYZ && c->dstXYZ && o.src_w == o.dst_w && o.src_h == o.dst_h))
+        return launch_plan_le(c, frames, n, sliceY, sliceH);
+    DeviceState *d = c->dev;
+    hipStream_t st = d->stream;
+    if (!d->d_xyz_tab) {
+        static std::vector<uint16_t> tab;   // xyzgamma[4096], rgbgammainv[4096], rgbgamma[65536], xyzgammainv[65536]
+        static std::once_flag once;
+        std::call_once(once, [] {
+            tab.resize(2 * 4096 + 2 * 65536);
+            for (int i = 0; i < 4096; i++) {
+                tab[i] = (uint16_t)lrint(pow(i / 4095.0, 2.6) * 65535.0);
+                tab[4096 + i] = (uint16_t)lrint(pow(i / 4095.0, 2.2) * 65535.0);
+            }
+            for (int i = 0; i < 65536; i++) {
+                tab[8192 + i] = (uint16_t)lrint(pow(i / 65535.0, 1.0 / 2.2) * 4095.0);
+                tab[8192 + 65536 + i] = (uint16_t)lrint(pow(i / 65535.0, 1.0 / 2.6) * 4095.0);
+            }
+        });
+        HIPCHK(hipMalloc(&d->d_xyz_tab, tab.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpyAsync(d->d_xyz_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));   // (static storage: stays valid)
+    }
+    const uint16_t *T = (const uint16_t *)d->d_xyz_tab;
+    std::vector<SwsFramePtrs> fr(frames, frames + n);
+    const dim3 blk(256);
+    if (c->srcXYZ && sliceH > 0) {
+        const int ls = (o.src_w * 6 + 255) & ~255;
+        const size_t total = (size_t)ls * o.src_h;
+        if ((size_t)n * total > d->xyz_bytes) {
+            HIPCHK(hipStreamSynchronize(st));
+            if (d->d_xyz) HIPCHK(hipFree(d->d_xyz));
+            d->d_xyz = nullptr;
+            HIPCHK(hipMalloc(&d->d_xyz, (size_t)n * total));
+            d->xyz_bytes = (size_t)n * total;
+        }
+        for (int i = 0; i < n; i++) {
+            uint8_t *scr = (uint8_t *)d->d_xyz + (size_t)i * total;
+            const int y1 = std::min(o.src_h, sliceY + sliceH);
+            if (y1 > sliceY) {
+                const dim3 grid(cdiv(o.src_w, 256), y1 - sliceY);
+                hipLaunchKernelGGL(::swsk::sws_k_xyz12, grid, blk, 0, st, frames[i].src[0] + (int64_t)sliceY * frames[i].srcStride[0], (int64_t)frames[i].srcStride[0],
+                                   scr + (int64_t)sliceY * ls, (int64_t)ls, o.src_w, T, T + 8192, 1);
+            }
+            fr[i].src[0] = scr; fr[i].srcStride[0] = ls;
+        }
+    }
+    int ret = launch_plan_le(c, fr.data(), n, sliceY, sliceH);
+    if (ret >= 0 && c->dstXYZ) {
+        const bool whole = c->plan == PLAN_MAIN || c->plan == PLAN_CASCADE || (sliceY == 0 && sliceH == o.src_h);
+        const int y0 = whole ? 0 : sliceY, y1 = whole ? o.dst_h : std::min(o.dst_h, sliceY + sliceH);
+        for (int i = 0; i < n && y1 > y0; i++) {
+            uint8_t *p0 = frames[i].dst[0] + (int64_t)y0 * frames[i].dstStride[0];
+            const dim3 grid(cdiv(o.dst_w, 256), y1 - y0);
+            hipLaunchKernelGGL(::swsk::sws_k_xyz12, grid, blk, 0, st, p0, (int64_t)frames[i].dstStride[0], p0, (int64_t)frames[i].dstStride[0], o.dst_w,
+                               T + 4096, T + 8192 + 65536, 0);
+        }
+    }
+    return ret;
+}
+
 static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
 {
-    if (!c->srcBE && !c->dstBE) return launch_plan_le(c, frames, n, sliceY, sliceH);
+    if (!c->srcBE && !c->dstBE) return launch_plan_xyz(c, frames, n, sliceY, sliceH);
     DeviceState *d = c->dev;
     hipStream_t st = d->stream;
     const SwsContext &o = c->opts;
@@ -1335,7 +1405,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
                 fr[i].src[k] = scr; fr[i].srcStride[k] = ls[k];
             }
     }
-    int ret = launch_plan_le(c, fr.data(), n, sliceY, sliceH);
+    int ret = launch_plan_xyz(c, fr.data(), n, sliceY, sliceH);
     if (ret >= 0 && c->dstBE) {
         const PixDesc *dd = pix_desc(o.dst_format);
         const int unit = (dd->flags & PIXFLAG_FLOAT) ? 4 : 2;
@@ -1674,7 +1744,7 @@ static int frame_matches(const SwsInternal *c, const SwsFrameView *f, bool is_sr
 {
     const int fmt = canonical_pix_fmt(f->format); // the context stores canonicalised formats (yuvj420p -> yuv420p, bgr0 -> bgra)
     const SwsContext &o = c->opts;
-    if ((is_src ? c->srcBE : c->dstBE) != (pix_be_twin(f->format) >= 0)) return 0;
+    if (!(is_src ? src_tags_match(c, f->format) : dst_tags_match(c, f->format))) return 0;
     return is_src ? (fmt == o.src_format && f->width == o.src_w && f->height == o.src_h)
                   : (fmt == o.dst_format && f->width == o.dst_w && f->height == o.dst_h);
 }

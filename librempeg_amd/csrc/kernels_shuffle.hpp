@@ -237,6 +237,26 @@ __global__ void __launch_bounds__(256) sws_k_rgb16_convert(SwsFrameSet fs, Rgb16
     }
 }
 
+// xyz12Torgb48_c (swscale.c:745-802) when to_rgb, rgb48Toxyz12_c (:804-861) otherwise: gamma LUT in, Q12 matrix, clip, gamma LUT out,
+// 12-bit result in the high bits; little-endian words, in place allowed.  One thread = one pixel.
+__global__ void __launch_bounds__(256) sws_k_xyz12(const uint8_t *src, int64_t sstride, uint8_t *dst, int64_t dstride, int w,
+                                                   const uint16_t *gin, const uint16_t *gout, int to_rgb)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= w) return;
+    const uint16_t *s = (const uint16_t *)(src + (int64_t)blockIdx.y * sstride) + 3 * x;
+    uint16_t *d = (uint16_t *)(dst + (int64_t)blockIdx.y * dstride) + 3 * x;
+    const int a = gin[s[0] >> 4], b = gin[s[1] >> 4], e = gin[s[2] >> 4];
+    int o0, o1, o2;
+    if (to_rgb) {
+        o0 = (13270 * a - 6295 * b - 2041 * e) >> 12; o1 = (-3969 * a + 7682 * b + 170 * e) >> 12; o2 = (228 * a - 835 * b + 4329 * e) >> 12;
+    } else {
+        o0 = (1689 * a + 1464 * b + 739 * e) >> 12; o1 = (871 * a + 2929 * b + 296 * e) >> 12; o2 = (79 * a + 488 * b + 3891 * e) >> 12;
+    }
+    o0 = min(max(o0, 0), 65535); o1 = min(max(o1, 0), 65535); o2 = min(max(o2, 0), 65535);
+    d[0] = (uint16_t)(gout[o0] << 4); d[1] = (uint16_t)(gout[o1] << 4); d[2] = (uint16_t)(gout[o2] << 4);
+}
+
 // x2rgb10le / x2bgr10le special converters: mode 0 = x2rgb10to48 / to64 / tobgr48 / tobgr64 (rgb2rgb.c:415-471), mode 1 =
 // packed30togbra10 (swscale_unscaled.c:819-889), mode 2 = gbr16ptopacked30 (:1076-1103).  pos[] = R, G, B word offsets (mode 0)
 // or plane indices (modes 1, 2); hi / lo = bit replication shifts, shift = the planar format's sample shift

@@ -20,7 +20,8 @@ struct PixDesc {
 enum : unsigned { PIXFLAG_BE = 1u << 0, PIXFLAG_PLANAR = 1u << 4, PIXFLAG_RGB = 1u << 5,
                   PIXFLAG_ALPHA = 1u << 7, PIXFLAG_FLOAT = 1u << 9 };
 const PixDesc *pix_desc(int fmt);
-int pix_be_twin(int fmt);   // little-endian twin of a big-endian format, or -1
+int pix_be_twin(int fmt);
+inline bool pix_is_xyz(int fmt) { return fmt == AV_PIX_FMT_XYZ12LE || fmt == AV_PIX_FMT_XYZ12BE; }   // little-endian twin of a big-endian format, or -1
 int  pix_bits_per_pixel(const PixDesc *d);
 int  pix_nb_planes(const PixDesc *d);
 // predicates, libswscale/swscale_internal.h:746-988
@@ -98,6 +99,7 @@ struct SwsInternal {
     std::vector<double> srcVec[4];   // copies of the SwsFilter vectors given to sws_init_context: lumH, lumV, chrH, chrV
     int dstVecLen[4] = {0, 0, 0, 0};
     const SwsFrameView *frame_src = nullptr; SwsFrameView *frame_dst = nullptr; int frame_rows_in = 0;   // sws_frame_start .. sws_frame_end
+    bool srcXYZ = false, dstXYZ = false; // handle_xyz (utils.c:822-842): the caller's formats were xyz12, opts.*_format hold rgb48le
     bool srcBE = false, dstBE = false;   // the caller's formats were big-endian: opts.src_format / dst_format hold the LE twins
     bool dynamic_init = false;    // configured from the frames of sws_scale_frame() (swscale.c:1405-1480)
     int sliceDir = 0;             // 0 = no slice sequence in progress, 1 = top-down, -1 = bottom-up (swscale.c:1096-1104)
@@ -140,5 +142,9 @@ int  dev_run(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4]
 size_t tables_blob_size(const SwsInternal *c);
 int  tables_blob_export(const SwsInternal *c, void *buf, size_t size);
 int  tables_blob_import(SwsInternal *c, const void *buf, size_t size);
+
+// the byte order and XYZ-ness of the caller's formats live in flags next to the canonicalised opts.*_format
+inline bool src_tags_match(const SwsInternal *c, int fmt) { return c->srcBE == (pix_be_twin(fmt) >= 0) && c->srcXYZ == pix_is_xyz(fmt); }
+inline bool dst_tags_match(const SwsInternal *c, int fmt) { return c->dstBE == (pix_be_twin(fmt) >= 0) && c->dstXYZ == pix_is_xyz(fmt); }
 
 } // namespace swship

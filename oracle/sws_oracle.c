@@ -37,12 +37,13 @@ static int ilog2(unsigned v) /* av_log2: floor(log2(v|1)) */
     return n;
 }
 static int clip_u8(int a) { return a < 0 ? 0 : a > 255 ? 255 : a; }
+static int clip_u16(int a) { return a < 0 ? 0 : a > 65535 ? 65535 : a; }
 static int clip_uintp2(int a, int p)
 {
     if (a & ~((1 << p) - 1)) return (~a) >> 31 & ((1 << p) - 1);
     return a;
 }
-static int clip_u16(int a) { return a < 0 ? 0 : a > 65535 ? 65535 : a; }
+
 static int clip_i16(int a) { return a < -32768 ? -32768 : a > 32767 ? 32767 : a; }
 
 /* ------------------------------------------------------------------ */
@@ -125,6 +126,7 @@ static const Desc descs[] = {
     { ORF_NV20LE, "nv20le", 3, 1, 0, {{0,2,0,0,10},{1,4,0,0,10},{1,4,2,0,10}}, PF_PLANAR },
     { ORF_GBRP10MSBLE, "gbrp10msble", 3, 0, 0, {{2,2,0,6,10},{0,2,0,6,10},{1,2,0,6,10}}, PF_PLANAR | PF_RGB },
     { ORF_GBRP12MSBLE, "gbrp12msble", 3, 0, 0, {{2,2,0,4,12},{0,2,0,4,12},{1,2,0,4,12}}, PF_PLANAR | PF_RGB },
+    { ORF_XYZ12LE, "xyz12le", 3, 0, 0, {{0,6,0,4,12},{0,6,2,4,12},{0,6,4,4,12}}, 0 },   /* only ever seen before handle_xyz() */
     { ORF_X2RGB10LE, "x2rgb10le", 3, 0, 0, {{0,4,2,4,10},{0,4,1,2,10},{0,4,0,0,10}}, PF_RGB },
     { ORF_X2BGR10LE, "x2bgr10le", 3, 0, 0, {{0,4,0,0,10},{0,4,1,2,10},{0,4,2,4,10}}, PF_RGB },
     { ORF_XV36LE, "xv36le", 3, 0, 0, {{0,8,2,4,12},{0,8,0,4,12},{0,8,4,4,12}}, 0 },
@@ -165,7 +167,7 @@ static const Desc *desc_get(int fmt)
  * the reference's rules, which only name a byte order for planarToP01xWrapper / planar8ToP01xleWrapper (native-endian only). */
 static const int be_pairs[][2] = {
     { ORF_XV36BE, ORF_XV36LE }, { ORF_XV48BE, ORF_XV48LE }, { ORF_AYUV64BE, ORF_AYUV64LE },
-    { ORF_NV20BE, ORF_NV20LE }, { ORF_GBRP10MSBBE, ORF_GBRP10MSBLE }, { ORF_GBRP12MSBBE, ORF_GBRP12MSBLE },
+    { ORF_XYZ12BE, ORF_XYZ12LE }, { ORF_NV20BE, ORF_NV20LE }, { ORF_GBRP10MSBBE, ORF_GBRP10MSBLE }, { ORF_GBRP12MSBBE, ORF_GBRP12MSBLE },
     { ORF_YUV444P10MSBBE, ORF_YUV444P10MSBLE }, { ORF_YUV444P12MSBBE, ORF_YUV444P12MSBLE },
     { ORF_RGB565BE, ORF_RGB565LE }, { ORF_RGB555BE, ORF_RGB555LE }, { ORF_RGB444BE, ORF_RGB444LE },
     { ORF_BGR565BE, ORF_BGR565LE }, { ORF_BGR555BE, ORF_BGR555LE }, { ORF_BGR444BE, ORF_BGR444LE },
@@ -272,6 +274,7 @@ enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
 struct OrSws {
     OrSwsOpts o;
     int src0Alpha, dst0Alpha;
+    int src_xyz, dst_xyz; /* handle_xyz (utils.c:822-842): the formats were xyz12, o.src_format / o.dst_format hold rgb48le */
     int src_be, dst_be;   /* the caller's formats were big-endian: o.src_format / o.dst_format hold the LE twins */
     int brightness, contrast, saturation;
     int srcColorspaceTable[4], dstColorspaceTable[4];
@@ -814,6 +817,8 @@ static void handle_formats(OrSws *c)
 {
     c->src0Alpha |= handle_0alpha(&c->o.src_format);
     c->dst0Alpha |= handle_0alpha(&c->o.dst_format);
+    if (c->o.src_format == ORF_XYZ12LE) { c->o.src_format = ORF_RGB48LE; c->src_xyz = 1; }   /* handle_xyz utils.c:822-829 */
+    if (c->o.dst_format == ORF_XYZ12LE) { c->o.dst_format = ORF_RGB48LE; c->dst_xyz = 1; }
 }
 static int get_local_pos(int chr_subsample, int pos) /* utils.c:168-175 */
 {
@@ -3066,6 +3071,67 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
 static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4], int srcSliceY, int srcSliceH,
                     uint8_t *const dst[4], const int dstStride[4]);
 
+/* init_xyz_tables / ff_sws_fill_xyztables (utils.c:709-770): gamma LUTs from libm pow(), Q12 matrices */
+static uint16_t xyzgamma_tab[4096], rgbgammainv_tab[4096], rgbgamma_tab[65536], xyzgammainv_tab[65536];
+static void init_xyz_tables(void)
+{
+    static int done;
+    if (done) return;
+    for (int i = 0; i < 4096; i++) {
+        xyzgamma_tab[i]    = (uint16_t)lrint(pow(i / 4095.0, 2.6) * 65535.0);
+        rgbgammainv_tab[i] = (uint16_t)lrint(pow(i / 4095.0, 2.2) * 65535.0);
+    }
+    for (int i = 0; i < 65536; i++) {
+        rgbgamma_tab[i]    = (uint16_t)lrint(pow(i / 65535.0, 1.0 / 2.2) * 4095.0);
+        xyzgammainv_tab[i] = (uint16_t)lrint(pow(i / 65535.0, 1.0 / 2.6) * 4095.0);
+    }
+    done = 1;
+}
+
+/* xyz12Torgb48_c (swscale.c:745-802) when to_rgb, rgb48Toxyz12_c (:804-861) otherwise; little-endian words */
+static void xyz_convert(uint8_t *dst, int dstStride, const uint8_t *src, int srcStride, int w, int h, int to_rgb)
+{
+    static const int16_t xyz2rgb[3][3] = { { 13270, -6295, -2041 }, { -3969, 7682, 170 }, { 228, -835, 4329 } };
+    static const int16_t rgb2xyz[3][3] = { { 1689, 1464, 739 }, { 871, 2929, 296 }, { 79, 488, 3891 } };
+    const int16_t (*m)[3] = to_rgb ? xyz2rgb : rgb2xyz;
+    const uint16_t *gin = to_rgb ? xyzgamma_tab : rgbgammainv_tab, *gout = to_rgb ? rgbgamma_tab : xyzgammainv_tab;
+    init_xyz_tables();
+    for (int yp = 0; yp < h; yp++) {
+        const uint16_t *s = (const uint16_t *)(src + (ptrdiff_t)yp * srcStride);
+        uint16_t *d = (uint16_t *)(dst + (ptrdiff_t)yp * dstStride);
+        for (int xp = 0; xp < 3 * w; xp += 3) {
+            const int a = gin[s[xp] >> 4], b = gin[s[xp + 1] >> 4], e = gin[s[xp + 2] >> 4];
+            const int o0 = clip_u16((m[0][0] * a + m[0][1] * b + m[0][2] * e) >> 12);
+            const int o1 = clip_u16((m[1][0] * a + m[1][1] * b + m[1][2] * e) >> 12);
+            const int o2 = clip_u16((m[2][0] * a + m[2][1] * b + m[2][2] * e) >> 12);
+            d[xp] = (uint16_t)(gout[o0] << 4); d[xp + 1] = (uint16_t)(gout[o1] << 4); d[xp + 2] = (uint16_t)(gout[o2] << 4);
+        }
+    }
+}
+/* sws_scale's XYZ stages (swscale.c:1126-1139, :1194-1210): the source slice is converted into a scratch picture first, the
+ * written destination rows in place afterwards; both are skipped for an xyz12 -> xyz12 conversion at equal sizes */
+static int scale_xyz(OrSws *c, const uint8_t *const src[4], const int srcStride[4], int srcSliceY, int srcSliceH,
+                     uint8_t *const dst[4], const int dstStride[4])
+{
+    const int same = c->src_xyz && c->dst_xyz && c->o.src_w == c->o.dst_w && c->o.src_h == c->o.dst_h;
+    const uint8_t *sp[4] = { src[0], src[1], src[2], src[3] };
+    uint8_t *scratch = NULL;
+    int ret;
+    if (c->src_xyz && !same) {
+        const int st = srcStride[0] < 0 ? -srcStride[0] : srcStride[0];
+        uint8_t *base;
+        scratch = malloc((size_t)st * srcSliceH + 32);
+        base = srcStride[0] < 0 ? scratch + (ptrdiff_t)st * (srcSliceH - 1) : scratch;
+        xyz_convert(base, srcStride[0], src[0], srcStride[0], c->o.src_w, srcSliceH, 1);
+        sp[0] = base;
+    }
+    ret = scale_le(c, sp, srcStride, srcSliceY, srcSliceH, dst, dstStride);
+    free(scratch);
+    if (ret >= 0 && c->dst_xyz && !same)
+        xyz_convert(dst[0], dstStride[0], dst[0], dstStride[0], c->o.dst_w, c->o.dst_h, 0);   /* (whole frames only here) */
+    return ret;
+}
+
 /* rows and visible bytes per row of plane k */
 static void plane_geom(const Desc *d, int w, int h, int k, int *rows, int *row_bytes)
 {
@@ -3120,7 +3186,7 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
                 sp[k] = tmp[k]; ss[k] = rb;
             }
         }
-        ret = scale_le(c, sp, ss, srcSliceY, srcSliceH, dst, dstStride);
+        ret = scale_xyz(c, sp, ss, srcSliceY, srcSliceH, dst, dstStride);
         for (int k = 0; k < 4; k++) free(tmp[k]);
         if (ret >= 0 && c->dst_be) {
             const int unit = (dd->flags & PF_FLOAT) ? 4 : 2;
@@ -3133,7 +3199,7 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
         }
         return ret;
     }
-    return scale_le(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
+    return scale_xyz(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
 }
 
 static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4], int srcSliceY, int srcSliceH,

@@ -96,7 +96,7 @@ PACKED_HI = ["y210le", "y212le", "y216le", "xv30le", "v30xle", "xv36le", "xv48le
 PACKED444 = ["vyu444", "uyva", "ayuv", "vuya", "vuyx"]
 MSB = ["yuv444p10msble", "yuv444p12msble", "yuv444p10msbbe"]
 RGB30 = ["x2rgb10le", "x2bgr10le"]
-MISC7 = ["yuvj411p", "nv20le", "nv20be", "gbrp10msble", "gbrp12msble", "gbrp10msbbe", "gbrp12msbbe"]
+MISC7 = ["xyz12le", "xyz12be", "yuvj411p", "nv20le", "nv20be", "gbrp10msble", "gbrp12msble", "gbrp10msbbe", "gbrp12msbbe"]
 RGB_LOW = ["rgb565le", "bgr565le", "rgb555le", "bgr555le", "rgb444le", "bgr444le", "rgb565be", "bgr555be"]
 FORMAT_MATRIX_SRC = MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
 FORMAT_MATRIX_DST = MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
@@ -171,6 +171,7 @@ def _slice_ptrs(frame, fmt, y0):
 
 
 SLICED_UNSCALED = [
+    ("xyz12le", "xyz12le", BX), ("xyz12le", "rgb48le", 0), ("rgb48le", "xyz12be", BX), ("xyz12be", "bgr48le", 0), ("xyz12le", "xyz12be", 0),
     ("nv20le", "nv20le", BX), ("nv20be", "nv20le", 0), ("gbrp10msble", "gbrp10msble", BX), ("gbrp12msbbe", "gbrp12msble", 0), ("x2rgb10le", "gbrp10msble", 0),
     ("gbrp12msble", "x2bgr10le", BX), ("yuvj411p", "yuvj411p", BX),
     ("x2rgb10le", "rgb48le", BX), ("x2bgr10le", "rgba64le", 0), ("x2rgb10le", "bgr48be", 0), ("x2bgr10le", "rgb48le", BX), ("x2rgb10le", "gbrp10le", BX),
