@@ -144,6 +144,7 @@ void choose_unscaled(SwsInternal *c)
         else if (d == AV_PIX_FMT_RGB48LE || d == AV_PIX_FMT_BGR48LE) k = PLAN_UNSC_YUV2RGB48;
         else if (isRGB16fmt(d)) k = PLAN_UNSC_YUV2RGB16;   // yuv2rgb_c_16/15/12_ordered_dither, yuv422p_bgr16/15/12 (yuv2rgb.c:612-640)
         else if (d == AV_PIX_FMT_GBRP) k = PLAN_UNSC_YUV2GBRP;
+        else if (d == AV_PIX_FMT_MONOBLACK) k = PLAN_UNSC_YUV2MONO;   // yuv2rgb_c_1_ordered_dither (yuv2rgb.c:457-517, :624, :671)
         c->dst_slice_align = 2;
     }
     if ((s == AV_PIX_FMT_YUV420P10LE || s == AV_PIX_FMT_YUV420P12LE || s == AV_PIX_FMT_YUV420P14LE || s == AV_PIX_FMT_YUV420P16LE) &&
@@ -276,7 +277,12 @@ int init_single_context(SwsInternal *c)
     }
     if (o->dither == SWS_DITHER_AUTO && (flags & SWS_ERROR_DIFFUSION)) o->dither = SWS_DITHER_ED; // :1288-1291
     if (isPlanarRGB(dstFormat) && !(flags & SWS_FULL_CHR_H_INT)) { flags |= SWS_FULL_CHR_H_INT; o->flags = flags; }
-    if ((flags & SWS_FULL_CHR_H_INT) && isRGB16fmt(dstFormat)) {   // "full chroma interpolation ... not yet implemented" (:1325-1358)
+    const bool dstMono = dstFormat == AV_PIX_FMT_MONOWHITE || dstFormat == AV_PIX_FMT_MONOBLACK;
+    if (dstMono && o->dither == SWS_DITHER_ED) {
+        log_msg(c, 0, "error diffusion dither for 1 bpp destinations is not implemented on the HIP path\n");
+        return SWS_AVERROR(ENOTSUP);
+    }
+    if ((flags & SWS_FULL_CHR_H_INT) && (isRGB16fmt(dstFormat) || dstMono)) {   // "full chroma interpolation ... not yet implemented" (:1325-1358)
         flags &= ~SWS_FULL_CHR_H_INT; o->flags = flags;
     }
     if (isAnyRGB(dstFormat) && !(flags & SWS_FULL_CHR_H_INT)) c->chrDstHSubSample = 1;         // :1359-1360

@@ -107,6 +107,7 @@ static int src_kind_of(int f)
     if (!d) return -1;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? SRCK_GBRPF32 : d->comp[0].depth > 8 ? SRCK_GBRP16 : SRCK_GBRP;
     if (isAnyRGB(f) && d->comp[0].depth == 16) return SRCK_RGB48;
+    if (f == AV_PIX_FMT_MONOWHITE || f == AV_PIX_FMT_MONOBLACK) return SRCK_MONO;
     if (isAnyRGB(f) && d->comp[0].depth == 10 && d->comp[0].step == 4) return SRCK_RGB30;
     if (isAnyRGB(f) && d->comp[0].step == 2) return SRCK_RGB16;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? SRCK_RGB24 : SRCK_RGB32;
@@ -122,6 +123,7 @@ static int dst_kind_of(int f)
     if (!d) return -1;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? DSTK_GBRPF32 : d->comp[0].depth == 16 ? DSTK_GBRP16 : DSTK_GBRP;
     if (isAnyRGB(f) && d->comp[0].depth == 16) return DSTK_RGB48;
+    if (f == AV_PIX_FMT_MONOWHITE || f == AV_PIX_FMT_MONOBLACK) return DSTK_MONO;
     if (isAnyRGB(f) && d->comp[0].depth == 10 && d->comp[0].step == 4) return DSTK_RGB30;
     if (isAnyRGB(f) && d->comp[0].step == 2) return DSTK_RGB16;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? DSTK_RGB24 : DSTK_RGB32;
@@ -171,7 +173,7 @@ int dev_prepare(SwsInternal *c)
     p.uv_swap_src = isSwappedChroma(o.src_format); p.uv_swap_dst = isSwappedChroma(o.dst_format);
     p.u_plane_src = ds->comp[1].plane; p.v_plane_src = ds->comp[2].plane;
     p.u_plane_dst = dd->comp[1].plane; p.v_plane_dst = dd->comp[2].plane;
-    const bool gray_any = isGray(o.src_format) || isGray(o.dst_format) || c->needAlpha;   // paths the fused kernels do not cover
+    const bool gray_any = isGray(o.src_format) || isGray(o.dst_format) || c->needAlpha || p.srcKind == SRCK_MONO;   // paths the fused kernels do not cover
     p.should_dither = isNBPS(o.src_format) || is16BPS(o.src_format);     // swscale.c:292-293
     p.full_chr = ((o.flags & SWS_FULL_CHR_H_INT) && isAnyRGB(o.dst_format)) ? 1 : 0;
     if (p.srcKind == SRCK_PACKEDHI)
@@ -205,6 +207,8 @@ int dev_prepare(SwsInternal *c)
         p.src_pix_step = ds->comp[0].step;
         p.src_r_pos = ds->comp[0].offset; p.src_g_pos = ds->comp[1].offset; p.src_b_pos = ds->comp[2].offset;
     }
+    if (p.srcKind == SRCK_MONO) p.s16_is565 = o.src_format == AV_PIX_FMT_MONOWHITE;   // (reused: bits are stored inverted)
+    p.dst_mono_white = o.dst_format == AV_PIX_FMT_MONOWHITE;
     if (p.srcKind == SRCK_RGB30) p.s16_is565 = o.src_format == AV_PIX_FMT_X2RGB10LE;   // (reused as the field-order flag of the 30 bpp reader)
     if (p.srcKind == SRCK_RGB16) {   // RGB16_32FUNCS rows of input.c:396-401
         switch (o.src_format) {
@@ -285,7 +289,7 @@ int dev_prepare(SwsInternal *c)
     p.src_a_pos = (isALPHA(o.src_format) && !isPlanarFmt(o.src_format)) ? ds->comp[3].offset : 0;
     p.src_alpha_opaque = c->src0Alpha && !c->dst0Alpha && isALPHA(o.dst_format);
     p.dst_alpha_fill = isALPHA(o.dst_format) && isPlanarFmt(o.dst_format) && !c->needAlpha;
-    p.no_chroma = isGray(o.src_format) || isGray(o.dst_format);                              // swscale.c:692-694
+    p.no_chroma = isGray(o.src_format) || isGray(o.dst_format) || p.srcKind == SRCK_MONO;                              // swscale.c:692-694
     p.fast_bilinear = (o.flags & SWS_FAST_BILINEAR) && c->srcBpc == 8 && c->dstBpc <= 14;   // swscale.c:676-681
     p.lumXInc = c->lumXInc; p.chrXInc = c->chrXInc;
     p.copy_depth_src = ds->comp[0].depth; p.copy_depth_dst = dd->comp[0].depth;
@@ -649,6 +653,7 @@ int dev_prepare(SwsInternal *c)
     case PLAN_UNSC_RGB16SHUFFLE: c->path_name = "unscaled:rgb16Shuffle"; c->kernel_name = "sws_k_rgb16_convert"; break;
     case PLAN_UNSC_PACKED16_GBRP16: c->path_name = "unscaled:Rgb16ToPlanarRgb16"; c->kernel_name = "sws_k_rgb16_convert"; break;
     case PLAN_UNSC_GBRP16_PACKED16: c->path_name = "unscaled:planarRgb16ToRgb16"; c->kernel_name = "sws_k_rgb16_convert"; break;
+    case PLAN_UNSC_YUV2MONO: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2mono_unscaled"; break;
     case PLAN_UNSC_RGB30_TO_16: c->path_name = "unscaled:rgbToRgb"; c->kernel_name = "sws_k_rgb30_convert"; break;
     case PLAN_UNSC_RGB30_TO_GBRP: c->path_name = "unscaled:Rgb16ToPlanarRgb16"; c->kernel_name = "sws_k_rgb30_convert"; break;
     case PLAN_UNSC_GBRP_TO_RGB30: c->path_name = "unscaled:planarRgb16ToRgb16"; c->kernel_name = "sws_k_rgb30_convert"; break;
@@ -705,7 +710,7 @@ static int plane_geometry(int format, int w, int h, int plane, int *row_bytes, i
         if (d->comp[c].plane == plane) { step = d->comp[c].step; chroma = (c == 1 || c == 2); }
     const bool sub = chroma && !(d->flags & PIXFLAG_RGB);
     const int sw = sub ? -((-w) >> d->log2_chroma_w) : w, sh = sub ? -((-h) >> d->log2_chroma_h) : h;
-    *row_bytes = sw * step;
+    *row_bytes = (format == AV_PIX_FMT_MONOWHITE || format == AV_PIX_FMT_MONOBLACK) ? (w + 7) >> 3 : sw * step;
     *rows = sh;
     return 0;
 }
@@ -982,6 +987,16 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
         hipLaunchKernelGGL(swsk::sws_k_rgb16_convert, grid, blk, 0, st, fs, rp, p.srcW, sliceY);
         break;
     }
+    case PLAN_UNSC_YUV2MONO: {
+        const int nbytes = (p.dstW + 7) >> 3, nrowpairs = (sliceH + 1) >> 1;
+        if (!nrowpairs) break;
+        // g = table_gU[128] + table_gV[128] (yuv2rgb.c:460): the closed form's green index for U = V = 128
+        const SwsLutParams &L = p.lut;
+        const int gidx = L.base_g + (int)(((int64_t)128 * L.cgu) >> 16) + (int)(((int64_t)128 * L.cgv) >> 16);
+        const dim3 grid(cdiv(nbytes, 256), nrowpairs, n);
+        hipLaunchKernelGGL(swsk::sws_k_yuv2mono_unscaled, grid, blk, 0, st, fs, p, gidx, sliceY);
+        break;
+    }
     case PLAN_UNSC_RGB30_TO_16:
     case PLAN_UNSC_RGB30_TO_GBRP:
     case PLAN_UNSC_GBRP_TO_RGB30: {
@@ -1071,7 +1086,8 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
         const PixDesc *ds = pix_desc(c->opts.src_format);
         // the reference copies as many multiples of src_w bytes as fit into both strides (:2138-2157), i.e. the whole visible row:
         // for the packed 4:2:2 layouts that is a whole number of pixel pairs
-        const int row_bytes = ds->log2_chroma_w ? ((p.srcW + 1) >> 1) * 2 * ds->comp[0].step : p.srcW * ds->comp[0].step;
+        const int row_bytes = p.srcKind == SRCK_MONO ? (p.srcW + 7) >> 3 :
+                              ds->log2_chroma_w ? ((p.srcW + 1) >> 1) * 2 * ds->comp[0].step : p.srcW * ds->comp[0].step;
         const bool opaque = c->src0Alpha && !c->dst0Alpha && isALPHA(c->opts.dst_format);
         const dim3 grid(cdiv(cdiv(row_bytes, 16), 256), sliceH, n);
         hipLaunchKernelGGL(swsk::sws_k_packed_copy, grid, blk, 0, st, fs, row_bytes, sliceY, opaque ? ds->comp[3].offset : -1);
@@ -1083,7 +1099,7 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
             hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.dstW, 0);
         }
         const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 ||
-                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI || p.dstKind == DSTK_RGB48 || p.dstKind == DSTK_RGB16 || p.dstKind == DSTK_RGB30;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
+                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI || p.dstKind == DSTK_RGB48 || p.dstKind == DSTK_RGB16 || p.dstKind == DSTK_RGB30 || p.dstKind == DSTK_MONO;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
         if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;
@@ -1245,7 +1261,7 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
     else if (p.wide) hipLaunchKernelGGL((swsk::K<false, int32_t>), G, blk, 0, st, sub, p, (const int32_t *)d->scratch, frame_elems, ##__VA_ARGS__); \
     else hipLaunchKernelGGL((swsk::K<false, int16_t>), G, blk, 0, st, sub, p, (const int16_t *)d->scratch, frame_elems, ##__VA_ARGS__); } while (0)
             if (rgb) {
-                const int units = p.full_chr ? p.dstW : (p.dstW + 1) >> 1;
+                const int units = p.dstKind == DSTK_MONO ? (p.dstW + 7) >> 3 : p.full_chr ? p.dstW : (p.dstW + 1) >> 1;
                 const dim3 g(cdiv(units, 256), p.dstH, m);
                 LAUNCH_W(sws_k_vscale_rgb, g);
             } else if (p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010 || p.dstKind == DSTK_P016) {

@@ -85,6 +85,10 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         const unsigned rnd = (256u << (S - 1)) + (1 << (S - 7));
         return (uint16_t)((unsigned)(cr * r + cg * g + cb * b + rnd) >> (S - 6));
     }
+    case SRCK_MONO: { // monowhite2Y_c / monoblack2Y_c (input.c:514-548); s16_is565 = monowhite.  Chroma is never read (swscale.c:692-694)
+        const int v = f.src[0][(int64_t)row * f.srcStride[0] + (x >> 3)];
+        return ((((p.s16_is565 ? ~v : v) >> (7 - (x & 7))) & 1) * 16383);
+    }
     case SRCK_RGB30: { // rgb16_32ToY/UV/UV_half_c_template with the rgb30le / bgr30le rows (input.c:264-372, :411-412); s16_is565 = x2rgb10le
         const int srow = comp == 0 ? row : (row << p.chrSrcVSub);
         const uint32_t *s = (const uint32_t *)(f.src[0] + (int64_t)srow * f.srcStride[0]);
@@ -449,6 +453,33 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
     else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 1; ua = (uint16_t)cf[1]; }
     else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
              (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 2; ya = (uint16_t)lf[1]; ua = (uint16_t)cf[1]; }
+    if (p.dstKind == DSTK_MONO) {   // yuv2mono_{X,2,1}_c_template (output.c:654-860), ordered dither (ff_dither_8x8_220 :84-95); unit i = byte i
+        const uint32_t drow_lo[8] = { 0x679e3e75u, 0xba15c722u, 0x4c835990u, 0xce29a500u, 0x6097376eu, 0xb30ec11cu, 0x457c538au, 0xd530ac07u };
+        const uint32_t drow_hi[8] = { 0x649b3a71u, 0xb611c41fu, 0x487f568du, 0xd934af0au, 0x6ba24178u, 0xbd18cb26u, 0x4f865d94u, 0xd22da803u };
+        const uint32_t dlo = drow_lo[y & 7], dhi = drow_hi[y & 7];
+        // the X form shifts every pixel through one running accumulator: a trailing partial byte holds the LAST 8 bits seen, counted
+        // over the even-rounded width; the 2 / 1 forms build whole bytes, entries past dstW being the line buffers' fill value
+        const int n = (p.dstW + 1) & ~1;
+        const bool tail = mode == 0 && 8 * i + 8 > n;
+        const int x0 = tail ? n - 8 : 8 * i;
+        unsigned acc = 0;
+        for (int k = 0; k < 8; k++) {
+            const int x = x0 + k;
+            int Y;
+            if (x < 0) { acc <<= 1; continue; }
+            if (mode == 0) {
+                Y = 1 << 18;
+                for (int j = 0; j < lfs; j++) Y += (int)((unsigned)LUM(j, x) * (unsigned)(int)lf[j]);
+                Y >>= 19;
+                if (Y & 0x100) Y = clip_u8(Y);   // (the pair test "(Y1 | Y2) & 0x100" clips both: clipping an in-range value is the identity)
+            } else if (mode == 2) Y = (LUM(0, x) * (4096 - ya) + LUM(1, x) * ya) >> 19;
+            else Y = (LUM(0, x) + 64) >> 7;
+            const int dth = (int)(((x & 4) ? dhi : dlo) >> (8 * (x & 3))) & 0xff;
+            acc = (acc << 1) | (unsigned)(Y + dth >= 234);
+        }
+        drow[i] = (uint8_t)(p.dst_mono_white ? ~acc : acc);
+        return;
+    }
     if (p.dstKind == DSTK_RGB48) {
         // yuv2rgba64_{X,2,1}_c_template and yuv2rgba64_full_{X,2,1}_c_template (output.c:1115-1560): 19-bit lines, 32-bit
         // wrap-around arithmetic with the reference's signedness of every shift (the full_1 blend shifts LOGICALLY, :1538-1539)
@@ -798,7 +829,7 @@ __global__ void __launch_bounds__(256) sws_k_vscale_rgb(SwsFrameSet fs, SwsDevPa
 {
     const int fi = blockIdx.z;
     const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    const int units = p.full_chr ? p.dstW : (p.dstW + 1) >> 1;
+    const int units = p.dstKind == DSTK_MONO ? (p.dstW + 7) >> 3 : p.full_chr ? p.dstW : (p.dstW + 1) >> 1;
     if (i >= units || y >= p.dstH) return;
     const SwsFramePtrs &f = frame_of(fs, fi);
     const auto smp = SamplerFor<DIRECT, T>::make(p, f, scratch, frame_elems, fi);

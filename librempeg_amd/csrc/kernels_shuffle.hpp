@@ -237,6 +237,39 @@ __global__ void __launch_bounds__(256) sws_k_rgb16_convert(SwsFrameSet fs, Rgb16
     }
 }
 
+// yuv2rgb_c_1_ordered_dither (yuv2rgb.c:457-517): chroma ignored (g = the table index of U = V = 128); the 1-bit table is
+// (y_table[k] >> 7) with the ramp starting at element 110 (yuv2rgb.c:806-816).  One thread = one output byte of a row pair.  The tail
+// (dst_w & 7) counts PIXEL PAIRS across both rows in the macro's order and shifts the rest.
+__global__ void __launch_bounds__(256) sws_k_yuv2mono_unscaled(SwsFrameSet fs, SwsDevParams p, int gidx, int sliceY)
+{
+    const int bx = blockIdx.x * 256 + threadIdx.x;
+    const int nfull = p.dstW >> 3;
+    if (bx > nfull || (bx == nfull && !(p.dstW & 7))) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int y = 2 * blockIdx.y, yd = y + sliceY;                    // slice-relative pair, absolute rows (the host rebases slice pointers)
+    const uint8_t *py0 = f.src[0] + (int64_t)yd * f.srcStride[0] + 8 * bx, *py1 = py0 + f.srcStride[0];
+    uint8_t *o0 = f.dst[0] + (int64_t)yd * f.dstStride[0] + bx, *o1 = o0 + f.dstStride[0];
+    const uint32_t drow_lo[9] = { 0x679e3e75u, 0xba15c722u, 0x4c835990u, 0xce29a500u, 0x6097376eu, 0xb30ec11cu, 0x457c538au, 0xd530ac07u, 0x679e3e75u };
+    const uint32_t drow_hi[9] = { 0x649b3a71u, 0xb611c41fu, 0x487f568du, 0xd934af0au, 0x6ba24178u, 0xbd18cb26u, 0x4f865d94u, 0xd22da803u, 0x649b3a71u };
+    auto dth = [&](int l, int k) { const uint32_t w = (k & 4) ? drow_hi[(yd & 7) + l] : drow_lo[(yd & 7) + l]; return (int)(w >> (8 * (k & 3))) & 0xff; };
+    auto bit = [&](int Y, int d) { const int idx = gidx + Y + d - 110; return idx < 0 ? 0u : (unsigned)(lut_luma(p.lut, idx) >> 7); };
+    unsigned a0 = 0, a1 = 0;
+    if (bx < nfull) {
+        for (int k = 0; k < 8; k++) { a0 = a0 + a0 + bit(py0[k], dth(0, k)); a1 = a1 + a1 + bit(py1[k], dth(1, k)); }
+    } else {
+        int left = p.dstW & 7;
+        const int order[8] = { 0x00, 0x10, 0x11, 0x01, 0x02, 0x12, 0x13, 0x03 };   // (row << 4) | pair
+        for (int s = 0; s < 8; s++) {
+            const int l = order[s] >> 4, i = order[s] & 15;
+            unsigned &a = l ? a1 : a0;
+            const uint8_t *py = l ? py1 : py0;
+            if (left) { a = a + a + bit(py[2 * i], dth(l, 2 * i)); a = a + a + bit(py[2 * i + 1], dth(l, 2 * i + 1)); left--; }
+            else a <<= 2;
+        }
+    }
+    *o0 = (uint8_t)a0; *o1 = (uint8_t)a1;
+}
+
 // xyz12Torgb48_c (swscale.c:745-802) when to_rgb, rgb48Toxyz12_c (:804-861) otherwise: gamma LUT in, Q12 matrix, clip, gamma LUT out,
 // 12-bit result in the high bits; little-endian words, in place allowed.  One thread = one pixel.
 __global__ void __launch_bounds__(256) sws_k_xyz12(const uint8_t *src, int64_t sstride, uint8_t *dst, int64_t dstride, int w,

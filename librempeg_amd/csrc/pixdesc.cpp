@@ -86,6 +86,8 @@ static const PixDesc g_descs[] = {
     { AV_PIX_FMT_NV20LE, "nv20le", 3, 1, 0, {{0,2,0,0,10},{1,4,0,0,10},{1,4,2,0,10},{0,0,0,0,0}}, PIXFLAG_PLANAR },
     { AV_PIX_FMT_GBRP10MSBLE, "gbrp10msble", 3, 0, 0, {{2,2,0,6,10},{0,2,0,6,10},{1,2,0,6,10},{0,0,0,0,0}}, PIXFLAG_PLANAR | PIXFLAG_RGB },
     { AV_PIX_FMT_GBRP12MSBLE, "gbrp12msble", 3, 0, 0, {{2,2,0,4,12},{0,2,0,4,12},{1,2,0,4,12},{0,0,0,0,0}}, PIXFLAG_PLANAR | PIXFLAG_RGB },
+    { AV_PIX_FMT_MONOWHITE, "monow", 1, 0, 0, {{0,1,0,0,1},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_RGB },   // 1 bit per pixel, MSB first; isAnyRGB() counts them in
+    { AV_PIX_FMT_MONOBLACK, "monob", 1, 0, 0, {{0,1,0,7,1},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_RGB },
     { AV_PIX_FMT_XYZ12LE, "xyz12le", 3, 0, 0, {{0,6,0,4,12},{0,6,2,4,12},{0,6,4,4,12},{0,0,0,0,0}}, 0 },   // only ever seen before the handle_xyz() aliasing
     { AV_PIX_FMT_X2RGB10LE, "x2rgb10le", 3, 0, 0, {{0,4,2,4,10},{0,4,1,2,10},{0,4,0,0,10},{0,0,0,0,0}}, PIXFLAG_RGB },
     { AV_PIX_FMT_X2BGR10LE, "x2bgr10le", 3, 0, 0, {{0,4,0,0,10},{0,4,1,2,10},{0,4,2,4,10},{0,0,0,0,0}}, PIXFLAG_RGB },
@@ -131,11 +133,12 @@ bool isYUV(int f) { const PixDesc *d = pix_desc(f); return !(d->flags & PIXFLAG_
 bool isPlanarYUV(int f) { return (pix_desc(f)->flags & PIXFLAG_PLANAR) && isYUV(f); }
 bool isSemiPlanarYUV(int f) { const PixDesc *d = pix_desc(f); return isPlanarYUV(f) && d->comp[1].plane == d->comp[2].plane; }
 bool isAnyRGB(int f) { return (pix_desc(f)->flags & PIXFLAG_RGB) != 0; }
-bool isGray(int f) { return pix_desc(f)->nb_components <= 2; }
+static bool isMonoFmt(int f) { return f == AV_PIX_FMT_MONOWHITE || f == AV_PIX_FMT_MONOBLACK; }
+bool isGray(int f) { return pix_desc(f)->nb_components <= 2 && !isMonoFmt(f); }   // swscale_internal.h:805-815
 bool isFloatFmt(int f) { return (pix_desc(f)->flags & PIXFLAG_FLOAT) != 0; }
 bool isALPHA(int f) { return (pix_desc(f)->flags & PIXFLAG_ALPHA) != 0; }
 bool isPlanarRGB(int f) { return (pix_desc(f)->flags & (PIXFLAG_PLANAR | PIXFLAG_RGB)) == (PIXFLAG_PLANAR | PIXFLAG_RGB); }
-bool isPackedFmt(int f) { const PixDesc *d = pix_desc(f); return d->nb_components >= 2 && !(d->flags & PIXFLAG_PLANAR); }
+bool isPackedFmt(int f) { const PixDesc *d = pix_desc(f); return (d->nb_components >= 2 && !(d->flags & PIXFLAG_PLANAR)) || isMonoFmt(f); }   // swscale_internal.h:906-914
 bool isPlanarFmt(int f) { const PixDesc *d = pix_desc(f); return d->nb_components >= 2 && (d->flags & PIXFLAG_PLANAR); }
 bool isSwappedChroma(int f)
 {

@@ -126,6 +126,8 @@ static const Desc descs[] = {
     { ORF_NV20LE, "nv20le", 3, 1, 0, {{0,2,0,0,10},{1,4,0,0,10},{1,4,2,0,10}}, PF_PLANAR },
     { ORF_GBRP10MSBLE, "gbrp10msble", 3, 0, 0, {{2,2,0,6,10},{0,2,0,6,10},{1,2,0,6,10}}, PF_PLANAR | PF_RGB },
     { ORF_GBRP12MSBLE, "gbrp12msble", 3, 0, 0, {{2,2,0,4,12},{0,2,0,4,12},{1,2,0,4,12}}, PF_PLANAR | PF_RGB },
+    { ORF_MONOWHITE, "monow", 1, 0, 0, {{0,1,0,0,1}}, PF_RGB },   /* 1 bit per pixel, MSB first; isAnyRGB() counts them in (swscale_internal.h:876-882) */
+    { ORF_MONOBLACK, "monob", 1, 0, 0, {{0,1,0,7,1}}, PF_RGB },
     { ORF_XYZ12LE, "xyz12le", 3, 0, 0, {{0,6,0,4,12},{0,6,2,4,12},{0,6,4,4,12}}, 0 },   /* only ever seen before handle_xyz() */
     { ORF_X2RGB10LE, "x2rgb10le", 3, 0, 0, {{0,4,2,4,10},{0,4,1,2,10},{0,4,0,0,10}}, PF_RGB },
     { ORF_X2BGR10LE, "x2bgr10le", 3, 0, 0, {{0,4,0,0,10},{0,4,1,2,10},{0,4,2,4,10}}, PF_RGB },
@@ -226,11 +228,12 @@ static int isYUV(int f) { const Desc *d = desc_get(f); return !(d->flags & PF_RG
 static int isPlanarYUV(int f) { return (desc_get(f)->flags & PF_PLANAR) && isYUV(f); }
 static int isSemiPlanarYUV(int f) { const Desc *d = desc_get(f); return isPlanarYUV(f) && d->c[1].plane == d->c[2].plane; }
 static int isAnyRGB(int f) { return !!(desc_get(f)->flags & PF_RGB); }
-static int isGray(int f) { return desc_get(f)->nb <= 2; }
+static int isMono(int f) { return f == ORF_MONOWHITE || f == ORF_MONOBLACK; }
+static int isGray(int f) { return desc_get(f)->nb <= 2 && !isMono(f); }   /* swscale_internal.h:805-815 */
 static int isFloat(int f) { return !!(desc_get(f)->flags & PF_FLOAT); }
 static int isALPHA(int f) { return !!(desc_get(f)->flags & PF_ALPHA); }
 static int isPlanarRGB(int f) { return (desc_get(f)->flags & (PF_PLANAR | PF_RGB)) == (PF_PLANAR | PF_RGB); }
-static int isPacked(int f) { const Desc *d = desc_get(f); return d->nb >= 2 && !(d->flags & PF_PLANAR); }
+static int isPacked(int f) { const Desc *d = desc_get(f); return (d->nb >= 2 && !(d->flags & PF_PLANAR)) || isMono(f); }   /* swscale_internal.h:906-914 */
 static int isSwappedChroma(int f)
 {
     const Desc *d = desc_get(f);
@@ -267,7 +270,7 @@ enum { RY, GY, BY, RU, GU, BU, RV, GV, BV };
 
 enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
        UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_RGBLOW, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED,
-       UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP, UNSC_RGB30_TO_16, UNSC_RGB30_TO_GBRP, UNSC_GBRP_TO_RGB30,
+       UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP, UNSC_RGB30_TO_16, UNSC_RGB30_TO_GBRP, UNSC_GBRP_TO_RGB30, UNSC_YUV2MONO,
        UNSC_PLANAR2P422, UNSC_P4222PLANAR,
        UNSC_RGB16SHUFFLE, UNSC_PACKED16_TO_GBRP16, UNSC_GBRP16_TO_PACKED16 };
 
@@ -678,6 +681,18 @@ static int yuv2rgb_init_tables(OrSws *c, const int inv_table[4], int fullRange,
         c->has_lut = 1;
         break;
     }
+    case 1: { /* yuv2rgb.c:806-816: one plane of 0 / 1, the ramp starts at element 110 (the first 110 are never reached: zero here) */
+        c->yuvTable = calloc(TABLE_PLANE, 1);
+        c->lut_elem = 1;
+        for (i = 0; i < TABLE_PLANE - 110; i++) {
+            c->yuvTable[i + 110] = (uint8_t)(clip_u8((int)((yb + 0x8000) >> 16)) >> 7);
+            yb += cy;
+        }
+        fill_table(c->table_gU, cgu, yoffs);
+        fill_gv_table(c->table_gV, cgv);
+        c->has_lut = 1;
+        break;
+    }
     case 30: { /* yuv2rgb.c:915-941: three planes of 10-bit ramps at bit 20 / 10 / 0; "255u << 30" keeps the two X bits set
                 * unless the source has alpha */
         const int rbase = isRgb ? 20 : 0, gbase = 10, bbase = isRgb ? 0 : 20;
@@ -919,6 +934,7 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
             d == ORF_RGB48LE || d == ORF_BGR48LE ||   /* yuv2rgb_c_48 / yuv2rgb_c_bgr48 (yuv2rgb.c:107-125, :505-508) */
             isRGB16(d))                                /* yuv2rgb_c_16/15/12_ordered_dither, yuv422p_bgr16/15/12 (:533-535, :554-556, :612-640) */
             c->unscaled_kind = UNSC_YUV2RGB;
+        else if (d == ORF_MONOBLACK) c->unscaled_kind = UNSC_YUV2MONO;   /* yuv2rgb_c_1_ordered_dither (yuv2rgb.c:457-517, :624, :671) */
         else if (d == ORF_RGBA64LE || d == ORF_BGRA64LE) c->unscaled_kind = UNSC_NONE; /* no C converter: ff_yuv2rgb_get_func_ptr returns NULL */
     }
     if (s == ORF_YUV444P && (d == ORF_NV24 || d == ORF_NV42)) c->unscaled_kind = UNSC_PLANAR2NV24;   /* :2410-2413 */
@@ -1041,7 +1057,8 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
         }
     }
     if (isPlanarRGB(dstFormat) && !(flags & OR_SWS_FULL_CHR_H_INT)) { flags |= OR_SWS_FULL_CHR_H_INT; c->o.flags = flags; }
-    if ((flags & OR_SWS_FULL_CHR_H_INT) && isRGB16(dstFormat)) { /* "full chroma interpolation ... not yet implemented" (:1325-1358) */
+    if (isMono(dstFormat) && c->o.dither == 3) return -1;   /* SWS_DITHER_ED for 1 bpp (yuv2mono_*_c_template's error diffusion): not restated */
+    if ((flags & OR_SWS_FULL_CHR_H_INT) && (isRGB16(dstFormat) || isMono(dstFormat))) { /* "full chroma interpolation ... not yet implemented" (:1325-1358) */
         flags &= ~OR_SWS_FULL_CHR_H_INT; c->o.flags = flags;
     }
     if (isAnyRGB(dstFormat) && !(flags & OR_SWS_FULL_CHR_H_INT)) c->chrDstHSub = 1; /* :1359 */
@@ -1253,6 +1270,48 @@ static int unscaled_yuv2rgb(OrSws *c, const uint8_t *const src[], const int srcS
                     }
                 }
             }
+        }
+    }
+    return srcSliceH;
+}
+
+static const uint8_t dither_8x8_220_u[9][8] = {   /* ff_dither_8x8_220 (output.c:84-95), nine rows: the second row of a pair reads row + 1 */
+    { 117,  62, 158, 103, 113,  58, 155, 100 }, {  34, 199,  21, 186,  31, 196,  17, 182 }, { 144,  89, 131,  76, 141,  86, 127,  72 },
+    {   0, 165,  41, 206,  10, 175,  52, 217 }, { 110,  55, 151,  96, 120,  65, 162, 107 }, {  28, 193,  14, 179,  38, 203,  24, 189 },
+    { 138,  83, 124,  69, 148,  93, 134,  79 }, {   7, 172,  48, 213,   3, 168,  45, 210 }, { 117,  62, 158, 103, 113,  58, 155, 100 },
+};
+/* yuv2rgb_c_1_ordered_dither (yuv2rgb.c:457-517): chroma is ignored (g is the table pointer of U = V = 128); each 8-pixel group of a row
+ * pair becomes one byte per row, the second row with the following dither row.  The tail (dst_w & 7) counts PIXEL PAIRS across both
+ * rows in the macro's order - row 1 pair 0, row 2 pair 0, row 2 pair 1, row 1 pair 1, row 1 pair 2, ... - and shifts the rest */
+static int unscaled_yuv2mono(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                             int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    const int g = c->table_gU[128 + HEADROOM] + c->table_gV[128 + HEADROOM];
+    static const int order[8][2] = { { 0, 0 }, { 1, 0 }, { 1, 1 }, { 0, 1 }, { 0, 2 }, { 1, 2 }, { 1, 3 }, { 0, 3 } };   /* { row, pair } */
+    for (int y = 0; y < srcSliceH; y += 2) {
+        const int yd = y + srcSliceY;
+        const uint8_t *py[2] = { src[0] + (ptrdiff_t)y * srcStride[0], src[0] + (ptrdiff_t)(y + 1) * srcStride[0] };
+        uint8_t *out[2] = { dst[0] + (ptrdiff_t)yd * dstStride[0], dst[0] + (ptrdiff_t)(yd + 1) * dstStride[0] };
+        const uint8_t *d128 = dither_8x8_220_u[yd & 7];
+        int x;
+        for (x = 0; x + 8 <= c->o.dst_w; x += 8)
+            for (int l = 0; l < 2; l++) {
+                unsigned acc = 0;
+                for (int k = 0; k < 8; k++) acc = acc + acc + lut_at(c, g + py[l][x + k] + d128[k + 8 * l]);
+                out[l][x >> 3] = (uint8_t)acc;
+            }
+        if (c->o.dst_w & 7) {
+            int pixels_left = c->o.dst_w & 7;
+            unsigned acc[2] = { 0, 0 };
+            for (int s = 0; s < 8; s++) {
+                const int l = order[s][0], i = order[s][1];
+                if (pixels_left) {
+                    acc[l] = acc[l] + acc[l] + lut_at(c, g + py[l][x + 2 * i] + d128[2 * i + 8 * l]);
+                    acc[l] = acc[l] + acc[l] + lut_at(c, g + py[l][x + 2 * i + 1] + d128[2 * i + 1 + 8 * l]);
+                    pixels_left--;
+                } else acc[l] <<= 2;
+            }
+            out[0][x >> 3] = (uint8_t)acc[0]; out[1][x >> 3] = (uint8_t)acc[1];
         }
     }
     return srcSliceH;
@@ -1733,7 +1792,8 @@ static int unscaled_packedcopy(OrSws *c, const uint8_t *const src[], const int s
     const int step = ds->c[0].step;
     /* the reference copies as many multiples of src_w bytes as fit into both strides (:2138-2157), i.e. the whole visible row:
      * for the packed 4:2:2 layouts that is a whole number of pixel pairs */
-    const size_t row_bytes = ds->lw ? (size_t)((c->o.src_w + 1) >> 1) * 2 * step : (size_t)c->o.src_w * step;
+    const size_t row_bytes = isMono(c->o.src_format) ? (size_t)((c->o.src_w + 7) >> 3) :
+                             ds->lw ? (size_t)((c->o.src_w + 1) >> 1) * 2 * step : (size_t)c->o.src_w * step;
     (void)srcSliceY;
     for (int y = 0; y < srcSliceH; y++) {
         const uint8_t *s = src[0] + (ptrdiff_t)y * srcStride[0];
@@ -1912,6 +1972,14 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
         uint16_t *d = (uint16_t *)tmp;
         for (i = 0; i < w; i++)
             d[i] = (uint16_t)(((unsigned)t[RY] * s[st * i + ro] + (unsigned)t[GY] * s[st * i + go] + (unsigned)t[BY] * s[st * i + bo] + (0x2001u << 14)) >> 15);
+        return tmp;
+    }
+    if (isMono(f)) { /* monowhite2Y_c / monoblack2Y_c input.c:514-548: MSB-first bits -> 0 or 16383 */
+        const uint8_t *s = src[0] + y * stride[0]; int16_t *d = (int16_t *)tmp;
+        for (i = 0; i < w; i++) {
+            const int v = f == ORF_MONOWHITE ? ~s[i >> 3] : s[i >> 3];
+            d[i] = (int16_t)(((v >> (7 - (i & 7))) & 1) * 16383);
+        }
         return tmp;
     }
     if (isRGB30(f)) { /* rgb16_32ToY_c_template input.c:264-293 with the rgb30le / bgr30le rows of :411-412 */
@@ -2704,6 +2772,58 @@ static void write_packed_rgb16_line(const OrSws *c, const Planes *P, uint8_t *de
 }
 
 /* packed_vscale (vscale.c:109-171) + yuv2422_{X,2,1}_c_template (output.c:883-1000) for yuyv422 / yvyu422 / uyvy422 */
+/* ff_dither_8x8_220 (output.c:84-95, the `#if 1` variant), nine rows */
+static const uint8_t dither_8x8_220[9][8] = {
+    { 117,  62, 158, 103, 113,  58, 155, 100 }, {  34, 199,  21, 186,  31, 196,  17, 182 }, { 144,  89, 131,  76, 141,  86, 127,  72 },
+    {   0, 165,  41, 206,  10, 175,  52, 217 }, { 110,  55, 151,  96, 120,  65, 162, 107 }, {  28, 193,  14, 179,  38, 203,  24, 189 },
+    { 138,  83, 124,  69, 148,  93, 134,  79 }, {   7, 172,  48, 213,   3, 168,  45, 210 }, { 117,  62, 158, 103, 113,  58, 155, 100 },
+};
+/* packed_vscale + yuv2mono_{X,2,1}_c_template (output.c:654-860), ordered dither only.  The X form shifts bits through one running
+ * accumulator (a trailing partial byte holds the last 8 bits seen); the 2 and 1 forms build whole bytes from 8 luma entries, the ones
+ * past dstW being the line buffers' fill_ones() value (slice.c:190-208) */
+static void write_mono_line(const OrSws *c, const Planes *P, uint8_t *dest, int y)
+{
+    const int dstW = c->o.dst_w, lw = dstW, srcH = c->o.src_h;
+    const int chrY = y >> c->chrDstVSub;
+    const int lfs = c->vLumFilterSize, cfs = c->vChrFilterSize;
+    const int16_t *lf = c->vLumFilter + y * lfs, *cf = c->vChrFilter + chrY * cfs;
+    const int firstLum = ORMAX(1 - lfs, c->vLumFilterPos[y]);
+    const uint8_t *d128 = dither_8x8_220[y & 7];
+    const int white = c->o.dst_format == ORF_MONOWHITE;
+    int i, j, mode, ya = 0;
+#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+#define LBM(j, x) ((x) < dstW ? L(j)[x] : (1 << 14))
+    if (lfs == 1 && cfs == 1) mode = 1;
+    else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) mode = 1;
+    else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
+             (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 2; ya = (uint16_t)lf[1]; }
+    else mode = 0;
+    if (mode == 0) {
+        unsigned acc = 0;
+        for (i = 0; i < dstW; i += 2) {
+            int Y1 = 1 << 18, Y2 = 1 << 18;
+            for (j = 0; j < lfs; j++) { Y1 += (int)(L(j)[i] * (unsigned)lf[j]); Y2 += (int)(LBM(j, i + 1) * (unsigned)lf[j]); }
+            Y1 >>= 19; Y2 >>= 19;
+            if ((Y1 | Y2) & 0x100) { Y1 = clip_u8(Y1); Y2 = clip_u8(Y2); }
+            acc = (acc << 1) | (Y1 + d128[i & 7] >= 234);
+            acc = (acc << 1) | (Y2 + d128[(i + 1) & 7] >= 234);
+            if ((i & 7) == 6) *dest++ = (uint8_t)(white ? ~acc : acc);
+        }
+        if (i & 6) *dest = (uint8_t)(white ? ~acc : acc);
+    } else {
+        for (i = 0; i < dstW; i += 8) {
+            unsigned acc = 0;
+            for (int k = 0; k < 8; k++) {
+                const int Y = mode == 2 ? (LBM(0, i + k) * (4096 - ya) + LBM(1, i + k) * ya) >> 19 : (LBM(0, i + k) + 64) >> 7;
+                acc = (acc << 1) | (Y + d128[k] >= 234);
+            }
+            *dest++ = (uint8_t)(white ? ~acc : acc);
+        }
+    }
+#undef L
+#undef LBM
+}
+
 static void write_packed422_line(const OrSws *c, const Planes *P, uint8_t *dest, int y)
 {
     const int dstW = c->o.dst_w, lw = dstW, cw = c->chrDstW;
@@ -3004,7 +3124,7 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
             hscale_line(c, P.alp + (size_t)y * dstW, dstW, line, c->hLumFilter, c->hLumFilterPos, c->hLumFilterSize);
         }
     }
-    const int needs_hcscale = !(isGray(sf) || isGray(df));   /* swscale.c:692-694 */
+    const int needs_hcscale = !(isGray(sf) || isGray(df) || isMono(sf));   /* swscale.c:692-694 */
     if (!needs_hcscale) { /* ff_init_desc_no_chr: the chroma lines keep fill_ones()' value (slice.c:190-208, :358-361) */
         const int32_t neutral = c->dstBpc >= 16 ? 1 << 18 : 1 << 14;
         for (size_t k = 0; k < (size_t)c->chrSrcH * c->chrDstW; k++) P.chrU[k] = P.chrV[k] = neutral;
@@ -3050,6 +3170,8 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
                                       c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither, 3, 0);
                 }
             }
+        } else if (isMono(df)) {
+            write_mono_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
         } else if (isPackedHi(df)) {
             write_packedhi_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
         } else if (isPacked444(df)) {
@@ -3148,6 +3270,7 @@ static void plane_geom(const Desc *d, int w, int h, int k, int *rows, int *row_b
             if (d->c[i].plane == k) { const int b = d->c[i].step * pw; if (b > maxb) maxb = b; }
         if (!(d->flags & PF_PLANAR) && d->nb >= 3 && !(d->flags & PF_RGB)) maxb = d->c[0].step * w;   /* packed 4:2:2 */
     }
+    if (isMono(d->fmt)) maxb = (w + 7) >> 3;
     *rows = chroma ? -((-h) >> d->lh) : h;
     *row_bytes = maxb;
 }
@@ -3237,6 +3360,7 @@ static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4
     case UNSC_NV242YUV420: return unscaled_nv242yuv420(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_YVU9_YV12: return unscaled_yvu9_yv12(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_PACKED2GBRP: return unscaled_packed2gbrp(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_YUV2MONO: return unscaled_yuv2mono(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_RGB30_TO_16: return unscaled_rgb30_to_16(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_RGB30_TO_GBRP: return unscaled_rgb30_to_gbrp(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_GBRP_TO_RGB30: return unscaled_gbrp_to_rgb30(c, src, srcStride, 0, srcSliceH, dst, dstStride);
@@ -3267,7 +3391,7 @@ const char *or_sws_path_name(const OrSws *c)
 {
     static const char *n[] = { "main", "yuv2rgb_c", "planarToP01x", "planar8ToP01xle", "planarToNv12", "nv12ToPlanar", "planarCopy",
                                "rgbToRgb", "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb",
-                               "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb", "rgbToRgb", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16",
+                               "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb", "rgbToRgb", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "yuv2rgb_c",
                                "planarToYuy2", "yuyvToPlanar",
                                "rgb16Shuffle", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16" };
     return c->cascade[0] ? "cascade" : n[c->unscaled_kind];

@@ -49,7 +49,7 @@ enum {
     ORF_AYUV64LE = 155, ORF_AYUV64BE = 156, ORF_Y210LE = 192, ORF_Y212LE = 212, ORF_Y216LE = 240, ORF_XV30LE = 214, ORF_V30XLE = 232,
     ORF_XV36BE = 215, ORF_XV36LE = 216, ORF_XV48BE = 241, ORF_XV48LE = 242,
     ORF_X2RGB10LE = 193, ORF_X2BGR10LE = 195,
-    ORF_XYZ12LE = 99, ORF_XYZ12BE = 100,
+    ORF_MONOWHITE = 9, ORF_MONOBLACK = 10, ORF_XYZ12LE = 99, ORF_XYZ12BE = 100,
     ORF_YUVJ411P = 138, ORF_NV20LE = 102, ORF_NV20BE = 103, ORF_GBRP10MSBBE = 262, ORF_GBRP10MSBLE = 263, ORF_GBRP12MSBBE = 264, ORF_GBRP12MSBLE = 265,
     ORF_GBRP9LE = 73, ORF_GBRP10LE = 75, ORF_GBRP16LE = 77, ORF_GBRP12LE = 135, ORF_GBRP14LE = 137,
 };

@@ -18,7 +18,7 @@ SCOPE = ["bgr24", "nv12", "rgb24", "rgb32", "yuv420p", "yuv422p", "yuv444p", "yu
          "yuv422p10le", "yuv440p10le", "yuv420p12le", "yuv422p12le", "yuv440p12le", "yuv444p12le", "yuv422p16le",
          "p210le", "p410le", "p012le", "p212le", "p412le", "p016le", "p216le", "p416le",
          "gbrp10le", "gbrp12le", "gbrp16le", "gray", "gray10le", "gray12le", "gray16le", "yuyv422", "yvyu422", "uyvy422", "rgb48",
-         "rgb565", "rgb555", "vuyx", "vyu444", "y210le", "y212le", "y216le", "xv30le", "v30xle", "xv36le", "xv36be", "xv48le", "xv48be", "yuv444p10msble", "yuv444p10msbbe", "yuv444p12msble", "yuv444p12msbbe", "x2rgb10le", "x2bgr10le", "xyz12le",
+         "rgb565", "rgb555", "vuyx", "vyu444", "y210le", "y212le", "y216le", "xv30le", "v30xle", "xv36le", "xv36be", "xv48le", "xv48be", "yuv444p10msble", "yuv444p10msbbe", "yuv444p12msble", "yuv444p12msbbe", "x2rgb10le", "x2bgr10le", "xyz12le", "monob", "monow",
          # big-endian twins
          "yuv420p10be", "yuv420p12be", "yuv420p16be", "yuv422p10be", "yuv422p12be", "yuv422p16be", "yuv440p10be", "yuv440p12be",
          "yuv444p10be", "yuv444p12be", "yuv444p16be", "gbrp10be", "gbrp12be", "gbrp16be", "gray10be", "gray12be", "gray16be",
