@@ -66,6 +66,7 @@ enum AVPixelFormat {
     /* packed 4:2:2 */
     AV_PIX_FMT_YUYV422 = 1, AV_PIX_FMT_UYVY422 = 15, AV_PIX_FMT_YVYU422 = 108,
     /* planar YUV with an alpha plane */
+    AV_PIX_FMT_YUVA420P9LE = 81, AV_PIX_FMT_YUVA420P9BE = 80, AV_PIX_FMT_YUVA420P10LE = 87, AV_PIX_FMT_YUVA420P10BE = 86, AV_PIX_FMT_YUVA420P16LE = 93, AV_PIX_FMT_YUVA420P16BE = 92, AV_PIX_FMT_YUVA422P9LE = 83, AV_PIX_FMT_YUVA422P9BE = 82, AV_PIX_FMT_YUVA422P10LE = 89, AV_PIX_FMT_YUVA422P10BE = 88, AV_PIX_FMT_YUVA422P12LE = 185, AV_PIX_FMT_YUVA422P12BE = 184, AV_PIX_FMT_YUVA422P16LE = 95, AV_PIX_FMT_YUVA422P16BE = 94, AV_PIX_FMT_YUVA444P9LE = 85, AV_PIX_FMT_YUVA444P9BE = 84, AV_PIX_FMT_YUVA444P10LE = 91, AV_PIX_FMT_YUVA444P10BE = 90, AV_PIX_FMT_YUVA444P12LE = 187, AV_PIX_FMT_YUVA444P12BE = 186, AV_PIX_FMT_YUVA444P16LE = 97, AV_PIX_FMT_YUVA444P16BE = 96,
     AV_PIX_FMT_YUVA420P = 33, AV_PIX_FMT_YUVA422P = 78, AV_PIX_FMT_YUVA444P = 79,
     /* gray (always full range, utils.c:791-805) */
     AV_PIX_FMT_GRAY16LE = 30, AV_PIX_FMT_GRAY12LE = 166, AV_PIX_FMT_GRAY10LE = 168, AV_PIX_FMT_GRAY9LE = 173,

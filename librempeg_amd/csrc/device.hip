@@ -805,7 +805,7 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
     if (c->opts.dst_format == AV_PIX_FMT_YUVA420P && sliceH > 0 &&
         (c->plan == PLAN_UNSC_BGR24_YV12 || c->plan == PLAN_UNSC_YVU9_YV12 || c->plan == PLAN_UNSC_P4222PLANAR)) {
         const dim3 gf(cdiv(p.srcW, 256), sliceH, n);
-        hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.srcW, sliceY);
+        hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.srcW, sliceY, 0);
     }
     switch (c->plan) {
     case PLAN_UNSC_YUV2RGB: {
@@ -917,8 +917,9 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
                 const int shiftonly = pl == 1 || pl == 2 || (!c->opts.src_range && pl == 0);
                 const bool missing = pl > 0 && isGray(c->opts.src_format);   // fillPlane / fillPlane16 (:2239-2247); width in samples
                 if (missing && same) len /= (ds->comp[0].depth + 7) / 8;
-                if (pl == 3) {   // alpha plane (:2226-2247): full size, copied when the source has one, 255 otherwise
-                    plan.pl[pl] = { isALPHA(c->opts.src_format) ? 3 : -2, 3, p.srcW, sliceH, sliceY, 1, 0, 0 };
+                if (pl == 3) {   // alpha plane (:2226-2247): full size, converted like luma with shiftonly = 0 when the source has one, all ones otherwise
+                    const int bytes = same ? (ds->comp[0].depth + 7) / 8 : 1;
+                    plan.pl[pl] = { isALPHA(c->opts.src_format) ? 3 : -2, 3, isALPHA(c->opts.src_format) ? p.srcW * bytes : p.srcW, sliceH, sliceY, 1, 0, 0 };
                     continue;
                 }
                 plan.pl[pl] = { missing ? -1 : pl, pl, len, h, y0, 1, shiftonly, pl != 0 };
@@ -1096,7 +1097,7 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
     case PLAN_MAIN: {
         if (p.dst_alpha_fill) {   // swscale.c:536-552
             const dim3 gf(cdiv(p.dstW, 256), p.dstH, n);
-            hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.dstW, 0);
+            hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.dstW, 0, p.dst_bits > 8 ? p.dst_bits : 0);
         }
         const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 ||
                          p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI || p.dstKind == DSTK_RGB48 || p.dstKind == DSTK_RGB16 || p.dstKind == DSTK_RGB30 || p.dstKind == DSTK_MONO;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)

@@ -386,7 +386,9 @@ __global__ void __launch_bounds__(256) sws_k_planar_misc(SwsFrameSet fs, SwsDevP
         f.dst[P.dstPlane][(int64_t)yd * f.dstStride[P.dstPlane] + x] = (uint8_t)v;
     } else if (P.srcPlane < 0) {      // planarCopyWrapper, plane missing in a gray source: fillPlane / fillPlane16 (:2239-2247)
         uint8_t *drow = f.dst[P.dstPlane] + (int64_t)yd * f.dstStride[P.dstPlane];
-        if (P.srcPlane == -2) drow[x] = 255;                     // alpha plane of a destination the source cannot feed
+        if (P.srcPlane == -2) {                                   // alpha plane of a destination the source cannot feed: 255 / all ones
+            if (p.copy_depth_dst > 8) ((uint16_t *)drow)[x] = (uint16_t)(0xFFFF >> (16 - p.copy_depth_dst)); else drow[x] = 255;
+        }
         else if (p.copy_depth_dst > 8) ((uint16_t *)drow)[x] = (uint16_t)(1 << (p.copy_depth_dst - 1));
         else drow[x] = 128;
     } else {                          // planarCopyWrapper

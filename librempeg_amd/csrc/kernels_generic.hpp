@@ -28,6 +28,7 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
             const int a = p.src_alpha_opaque ? 255 : f.src[0][(int64_t)row * f.srcStride[0] + 4 * x + p.src_a_pos];
             return a << 6 | a >> 2;
         }
+        if (p.srcKind == SRCK_PLANAR16) return *(const uint16_t *)(f.src[3] + (int64_t)row * f.srcStride[3] + 2 * x) >> p.src_shift;   // yuva4xxp9..16: the plane as is
         return f.src[3][(int64_t)row * f.srcStride[3] + x];
     }
     switch (p.srcKind) {
@@ -762,12 +763,15 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
 }
 
 // destination alpha plane the source cannot feed: fillPlane(dst[3], ..., 255) (swscale.c:536-552)
-__global__ void __launch_bounds__(256) sws_k_fill_alpha_plane(SwsFrameSet fs, int w, int y0)
+// bits: 0 = fillPlane(…, 255); 9..16 = fillPlane16(…, alpha = 1, bits) = 0xFFFF >> (16 - bits) in 16-bit samples
+__global__ void __launch_bounds__(256) sws_k_fill_alpha_plane(SwsFrameSet fs, int w, int y0, int bits)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= w) return;
     const SwsFramePtrs &f = frame_of(fs, blockIdx.z);
-    f.dst[3][(int64_t)(y0 + blockIdx.y) * f.dstStride[3] + x] = 255;
+    uint8_t *row = f.dst[3] + (int64_t)(y0 + blockIdx.y) * f.dstStride[3];
+    if (bits) ((uint16_t *)row)[x] = (uint16_t)(0xFFFF >> (16 - bits));
+    else row[x] = 255;
 }
 
 // yuva2rgba_c / yuva2argb_c (PUTRGBA, yuv2rgb.c:101-105): the 32 bpp LUT converter's pixels (written with A = 0 because

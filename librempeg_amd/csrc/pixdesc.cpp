@@ -30,6 +30,18 @@ static const PixDesc g_descs[] = {
     { AV_PIX_FMT_UYVY422, "uyvy422", 3, 1, 0, {{0,2,1,0,8},{0,4,0,0,8},{0,4,2,0,8},{0,0,0,0,0}}, 0 },
     { AV_PIX_FMT_YVYU422, "yvyu422", 3, 1, 0, {{0,2,0,0,8},{0,4,3,0,8},{0,4,1,0,8},{0,0,0,0,0}}, 0 },
 #define PLA(F, N, LW, LH)     { F, N, 4, LW, LH, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8},{3,1,0,0,8}}, PIXFLAG_PLANAR | PIXFLAG_ALPHA }
+#define PLAN_(F, N, LW, LH, D) { F, N, 4, LW, LH, {{0,2,0,0,D},{1,2,0,0,D},{2,2,0,0,D},{3,2,0,0,D}}, PIXFLAG_PLANAR | PIXFLAG_ALPHA }
+    PLAN_(AV_PIX_FMT_YUVA420P9LE, "yuva420p9le", 1, 1, 9),
+    PLAN_(AV_PIX_FMT_YUVA420P10LE, "yuva420p10le", 1, 1, 10),
+    PLAN_(AV_PIX_FMT_YUVA420P16LE, "yuva420p16le", 1, 1, 16),
+    PLAN_(AV_PIX_FMT_YUVA422P9LE, "yuva422p9le", 1, 0, 9),
+    PLAN_(AV_PIX_FMT_YUVA422P10LE, "yuva422p10le", 1, 0, 10),
+    PLAN_(AV_PIX_FMT_YUVA422P12LE, "yuva422p12le", 1, 0, 12),
+    PLAN_(AV_PIX_FMT_YUVA422P16LE, "yuva422p16le", 1, 0, 16),
+    PLAN_(AV_PIX_FMT_YUVA444P9LE, "yuva444p9le", 0, 0, 9),
+    PLAN_(AV_PIX_FMT_YUVA444P10LE, "yuva444p10le", 0, 0, 10),
+    PLAN_(AV_PIX_FMT_YUVA444P12LE, "yuva444p12le", 0, 0, 12),
+    PLAN_(AV_PIX_FMT_YUVA444P16LE, "yuva444p16le", 0, 0, 16),
     PLA(AV_PIX_FMT_YUVA420P, "yuva420p", 1, 1), PLA(AV_PIX_FMT_YUVA422P, "yuva422p", 1, 0), PLA(AV_PIX_FMT_YUVA444P, "yuva444p", 0, 0),
     PL8(AV_PIX_FMT_YUV410P, "yuv410p", 2, 2), PL8(AV_PIX_FMT_YUV411P, "yuv411p", 2, 0), PL8(AV_PIX_FMT_YUV440P, "yuv440p", 0, 1),
     PL8(AV_PIX_FMT_YUVJ422P, "yuvj422p", 1, 0), PL8(AV_PIX_FMT_YUVJ444P, "yuvj444p", 0, 0), PL8(AV_PIX_FMT_YUVJ440P, "yuvj440p", 0, 1),
@@ -163,6 +175,7 @@ int pix_be_twin(int fmt)
 {
     static const int pairs[][2] = {
     { AV_PIX_FMT_XV36BE, AV_PIX_FMT_XV36LE }, { AV_PIX_FMT_XV48BE, AV_PIX_FMT_XV48LE }, { AV_PIX_FMT_AYUV64BE, AV_PIX_FMT_AYUV64LE },
+    { AV_PIX_FMT_YUVA420P9BE, AV_PIX_FMT_YUVA420P9LE }, { AV_PIX_FMT_YUVA420P10BE, AV_PIX_FMT_YUVA420P10LE }, { AV_PIX_FMT_YUVA420P16BE, AV_PIX_FMT_YUVA420P16LE }, { AV_PIX_FMT_YUVA422P9BE, AV_PIX_FMT_YUVA422P9LE }, { AV_PIX_FMT_YUVA422P10BE, AV_PIX_FMT_YUVA422P10LE }, { AV_PIX_FMT_YUVA422P12BE, AV_PIX_FMT_YUVA422P12LE }, { AV_PIX_FMT_YUVA422P16BE, AV_PIX_FMT_YUVA422P16LE }, { AV_PIX_FMT_YUVA444P9BE, AV_PIX_FMT_YUVA444P9LE }, { AV_PIX_FMT_YUVA444P10BE, AV_PIX_FMT_YUVA444P10LE }, { AV_PIX_FMT_YUVA444P12BE, AV_PIX_FMT_YUVA444P12LE }, { AV_PIX_FMT_YUVA444P16BE, AV_PIX_FMT_YUVA444P16LE },
     { AV_PIX_FMT_XYZ12BE, AV_PIX_FMT_XYZ12LE }, { AV_PIX_FMT_NV20BE, AV_PIX_FMT_NV20LE }, { AV_PIX_FMT_GBRP10MSBBE, AV_PIX_FMT_GBRP10MSBLE }, { AV_PIX_FMT_GBRP12MSBBE, AV_PIX_FMT_GBRP12MSBLE },
     { AV_PIX_FMT_YUV444P10MSBBE, AV_PIX_FMT_YUV444P10MSBLE }, { AV_PIX_FMT_YUV444P12MSBBE, AV_PIX_FMT_YUV444P12MSBLE },
     { AV_PIX_FMT_RGB565BE, AV_PIX_FMT_RGB565LE }, { AV_PIX_FMT_RGB555BE, AV_PIX_FMT_RGB555LE }, { AV_PIX_FMT_RGB444BE, AV_PIX_FMT_RGB444LE },

@@ -84,6 +84,18 @@ static const Desc descs[] = {
     { ORF_UYVY422, "uyvy422", 3, 1, 0, {{0,2,1,0,8},{0,4,0,0,8},{0,4,2,0,8}}, 0 },
     { ORF_YVYU422, "yvyu422", 3, 1, 0, {{0,2,0,0,8},{0,4,3,0,8},{0,4,1,0,8}}, 0 },
 #define PLA(F, N, LW, LH)      { F, N, 4, LW, LH, {{0,1,0,0,8},{1,1,0,0,8},{2,1,0,0,8},{3,1,0,0,8}}, PF_PLANAR | PF_ALPHA }
+#define PLAN_(F, N, LW, LH, D) { F, N, 4, LW, LH, {{0,2,0,0,D},{1,2,0,0,D},{2,2,0,0,D},{3,2,0,0,D}}, PF_PLANAR | PF_ALPHA }
+    PLAN_(ORF_YUVA420P9LE, "yuva420p9le", 1, 1, 9),
+    PLAN_(ORF_YUVA420P10LE, "yuva420p10le", 1, 1, 10),
+    PLAN_(ORF_YUVA420P16LE, "yuva420p16le", 1, 1, 16),
+    PLAN_(ORF_YUVA422P9LE, "yuva422p9le", 1, 0, 9),
+    PLAN_(ORF_YUVA422P10LE, "yuva422p10le", 1, 0, 10),
+    PLAN_(ORF_YUVA422P12LE, "yuva422p12le", 1, 0, 12),
+    PLAN_(ORF_YUVA422P16LE, "yuva422p16le", 1, 0, 16),
+    PLAN_(ORF_YUVA444P9LE, "yuva444p9le", 0, 0, 9),
+    PLAN_(ORF_YUVA444P10LE, "yuva444p10le", 0, 0, 10),
+    PLAN_(ORF_YUVA444P12LE, "yuva444p12le", 0, 0, 12),
+    PLAN_(ORF_YUVA444P16LE, "yuva444p16le", 0, 0, 16),
     PLA(ORF_YUVA420P, "yuva420p", 1, 1), PLA(ORF_YUVA422P, "yuva422p", 1, 0), PLA(ORF_YUVA444P, "yuva444p", 0, 0),
     PL8(ORF_YUV410P, "yuv410p", 2, 2), PL8(ORF_YUV411P, "yuv411p", 2, 0), PL8(ORF_YUV440P, "yuv440p", 0, 1),
     PL8(ORF_YUVJ422P, "yuvj422p", 1, 0), PL8(ORF_YUVJ444P, "yuvj444p", 0, 0), PL8(ORF_YUVJ440P, "yuvj440p", 0, 1),
@@ -169,6 +181,7 @@ static const Desc *desc_get(int fmt)
  * the reference's rules, which only name a byte order for planarToP01xWrapper / planar8ToP01xleWrapper (native-endian only). */
 static const int be_pairs[][2] = {
     { ORF_XV36BE, ORF_XV36LE }, { ORF_XV48BE, ORF_XV48LE }, { ORF_AYUV64BE, ORF_AYUV64LE },
+    { ORF_YUVA420P9BE, ORF_YUVA420P9LE }, { ORF_YUVA420P10BE, ORF_YUVA420P10LE }, { ORF_YUVA420P16BE, ORF_YUVA420P16LE }, { ORF_YUVA422P9BE, ORF_YUVA422P9LE }, { ORF_YUVA422P10BE, ORF_YUVA422P10LE }, { ORF_YUVA422P12BE, ORF_YUVA422P12LE }, { ORF_YUVA422P16BE, ORF_YUVA422P16LE }, { ORF_YUVA444P9BE, ORF_YUVA444P9LE }, { ORF_YUVA444P10BE, ORF_YUVA444P10LE }, { ORF_YUVA444P12BE, ORF_YUVA444P12LE }, { ORF_YUVA444P16BE, ORF_YUVA444P16LE },
     { ORF_XYZ12BE, ORF_XYZ12LE }, { ORF_NV20BE, ORF_NV20LE }, { ORF_GBRP10MSBBE, ORF_GBRP10MSBLE }, { ORF_GBRP12MSBBE, ORF_GBRP12MSBLE },
     { ORF_YUV444P10MSBBE, ORF_YUV444P10MSBLE }, { ORF_YUV444P12MSBBE, ORF_YUV444P12MSBLE },
     { ORF_RGB565BE, ORF_RGB565LE }, { ORF_RGB555BE, ORF_RGB555LE }, { ORF_RGB444BE, ORF_RGB444LE },
@@ -1823,15 +1836,18 @@ static int unscaled_planarcopy(OrSws *c, const uint8_t *const src[], const int s
     const Desc *ds = desc_get(c->o.src_format), *dd = desc_get(c->o.dst_format);
     const int sf = c->o.src_format, df = c->o.dst_format;
     int nplanes = isGray(df) ? 1 : isSemiPlanarYUV(df) ? 2 : 3;
-    if (isALPHA(df) && isPlanarYUV(df)) { /* plane 3 (:2226-2247): copied when the source has one, 255 otherwise */
-        for (int i = 0; i < srcSliceH; i++) {
-            uint8_t *row = dst[3] + (ptrdiff_t)(srcSliceY + i) * dstStride[3];
-            if (isALPHA(sf)) memcpy(row, src[3] + (ptrdiff_t)i * srcStride[3], c->o.src_w);
-            else memset(row, 255, c->o.src_w);
+    const int with_alpha = isALPHA(df) && isPlanarYUV(df);
+    for (int plane = 0; plane < 4; plane++) {
+        if (plane >= nplanes && !(plane == 3 && with_alpha)) continue;
+        if (plane == 3 && !isALPHA(sf)) { /* plane 3 the source cannot feed (:2239-2247): fillPlane 255 / fillPlane16 all ones */
+            for (int i = 0; i < srcSliceH; i++) {
+                uint8_t *row = dst[3] + (ptrdiff_t)(srcSliceY + i) * dstStride[3];
+                if (is16BPS(df) || isNBPS(df)) { uint16_t *r16 = (uint16_t *)row; for (int j = 0; j < c->o.src_w; j++) r16[j] = (uint16_t)(0xFFFF >> (16 - dd->c[3].depth)); }
+                else memset(row, 255, c->o.src_w);
+            }
+            continue;
         }
-    }
-    for (int plane = 0; plane < nplanes; plane++) {
-        if (plane > 0 && isGray(sf)) { /* gray source: chroma planes are filled with mid-grey (fillPlane / fillPlane16 :2239-2247) */
+        if (plane > 0 && plane < 3 && isGray(sf)) { /* gray source: chroma planes are filled with mid-grey (fillPlane / fillPlane16 :2239-2247) */
             int flen = CEIL_RSHIFT(c->o.src_w, c->chrDstHSub) * (isSemiPlanarYUV(df) ? 2 : 1);
             int fy = CEIL_RSHIFT(srcSliceY, c->chrDstVSub), fh = CEIL_RSHIFT(srcSliceH, c->chrDstVSub);
             for (int i = 0; i < fh; i++) {
@@ -1841,9 +1857,9 @@ static int unscaled_planarcopy(OrSws *c, const uint8_t *const src[], const int s
             }
             continue;
         }
-        int length = plane == 0 ? c->o.src_w : CEIL_RSHIFT(c->o.src_w, c->chrDstHSub);
-        int y = plane == 0 ? srcSliceY : CEIL_RSHIFT(srcSliceY, c->chrDstVSub);
-        int height = plane == 0 ? srcSliceH : CEIL_RSHIFT(srcSliceH, c->chrDstVSub);
+        int length = (plane == 0 || plane == 3) ? c->o.src_w : CEIL_RSHIFT(c->o.src_w, c->chrDstHSub);
+        int y = (plane == 0 || plane == 3) ? srcSliceY : CEIL_RSHIFT(srcSliceY, c->chrDstVSub);
+        int height = (plane == 0 || plane == 3) ? srcSliceH : CEIL_RSHIFT(srcSliceH, c->chrDstVSub);
         const uint8_t *srcPtr = src[plane];
         uint8_t *dstPtr = dst[plane] + dstStride[plane] * y;
         int shiftonly = plane == 1 || plane == 2 || (!c->o.src_range && plane == 0);
@@ -3155,7 +3171,10 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
                 if (c->needAlpha) /* lum_planar_vscale vscale.c:59-71: same writer, luma filter, luma dither */
                     write_planar_line(c, dst[3] + (size_t)y * dstStride[3], dstW, P.alp, dstW, srcH, firstLum,
                                       c->vLumFilter + y * c->vLumFilterSize, c->vLumFilterSize, lumDither, 0, 1);
-                else memset(dst[3] + (size_t)y * dstStride[3], 255, dstW); /* fillPlane swscale.c:536-552 (8-bit alpha only here) */
+                else if (dd->c[0].depth > 8) { /* fillPlane16 (swscale.c:536-552, swscale_internal.h fillPlane16): 0xFFFF >> (16 - bits) */
+                    uint16_t *a16 = (uint16_t *)(dst[3] + (size_t)y * dstStride[3]);
+                    for (int i = 0; i < dstW; i++) a16[i] = (uint16_t)(0xFFFF >> (16 - dd->c[3].depth));
+                } else memset(dst[3] + (size_t)y * dstStride[3], 255, dstW); /* fillPlane swscale.c:536-552 */
             }
             if (!(y & ((1 << c->chrDstVSub) - 1))) { /* chr_planar_vscale vscale.c:74-107 */
                 int firstChr = ORMAX(1 - c->vChrFilterSize, c->vChrFilterPos[chrDstY]);

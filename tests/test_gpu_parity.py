@@ -100,10 +100,12 @@ PACKED_HI = ["y210le", "y212le", "y216le", "xv30le", "v30xle", "xv36le", "xv48le
 PACKED444 = ["vyu444", "uyva", "ayuv", "vuya", "vuyx"]
 MSB = ["yuv444p10msble", "yuv444p12msble", "yuv444p10msbbe"]
 RGB30 = ["x2rgb10le", "x2bgr10le"]
+YUVA_N = ["yuva420p9le", "yuva420p10le", "yuva420p16le", "yuva422p9le", "yuva422p10le", "yuva422p12le", "yuva422p16le", "yuva444p9le", "yuva444p10le",
+          "yuva444p12le", "yuva444p16le", "yuva420p10be", "yuva422p12be", "yuva444p16be", "yuva444p9be"]
 MISC7 = ["monob", "monow", "xyz12le", "xyz12be", "yuvj411p", "nv20le", "nv20be", "gbrp10msble", "gbrp12msble", "gbrp10msbbe", "gbrp12msbbe"]
 RGB_LOW = ["rgb565le", "bgr565le", "rgb555le", "bgr555le", "rgb444le", "bgr444le", "rgb565be", "bgr555be"]
-FORMAT_MATRIX_SRC = MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
-FORMAT_MATRIX_DST = MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+FORMAT_MATRIX_SRC = YUVA_N + MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+FORMAT_MATRIX_DST = YUVA_N + MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
 
 
 @pytest.mark.parametrize("sfmt", FORMAT_MATRIX_SRC)
@@ -175,6 +177,8 @@ def _slice_ptrs(frame, fmt, y0):
 
 
 SLICED_UNSCALED = [
+    ("yuva420p10le", "yuva420p10le", BX), ("yuva444p16le", "yuva444p", 0), ("yuva420p", "yuva420p12le" if False else "yuva420p16le", BX), ("yuv422p", "yuva422p10le", 0),
+    ("yuva444p12le", "yuv444p9le", BX), ("yuva420p9le", "yuva420p10be", 0), ("yuva422p16be", "yuva422p12le", BX), ("yuv444p10le", "yuva444p10le", 0),
     ("monob", "monob", BX), ("monow", "monow", 0), ("yuv420p", "monob", BX), ("yuv422p", "monob", 0),
     ("xyz12le", "xyz12le", BX), ("xyz12le", "rgb48le", 0), ("rgb48le", "xyz12be", BX), ("xyz12be", "bgr48le", 0), ("xyz12le", "xyz12be", 0),
     ("nv20le", "nv20le", BX), ("nv20be", "nv20le", 0), ("gbrp10msble", "gbrp10msble", BX), ("gbrp12msbbe", "gbrp12msble", 0), ("x2rgb10le", "gbrp10msble", 0),
