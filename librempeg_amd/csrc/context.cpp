@@ -210,6 +210,9 @@ void choose_unscaled(SwsInternal *c)
         else { k = PLAN_UNSC_PLANARCOPY;
                if (c->opts.dither != SWS_DITHER_NONE) c->dst_slice_align = 8 << c->chrDstVSubSample; }
     }
+    // uint_y_to_float_y_wrapper / float_y_to_uint_y_wrapper (:2639-2647; the rules name the native-endian format)
+    if (s == AV_PIX_FMT_GRAY8 && d == AV_PIX_FMT_GRAYF32LE && !c->dstBE) k = PLAN_UNSC_U8_TO_F32;
+    if (s == AV_PIX_FMT_GRAYF32LE && d == AV_PIX_FMT_GRAY8 && !c->srcBE) k = PLAN_UNSC_F32_TO_U8;
     if (s == AV_PIX_FMT_YUV422P && (d == AV_PIX_FMT_YUYV422 || d == AV_PIX_FMT_UYVY422)) k = PLAN_UNSC_PLANAR2P422;   // :2667-2672
     if ((flags & (SWS_FAST_BILINEAR | SWS_POINT)) && (s == AV_PIX_FMT_YUV420P || s == AV_PIX_FMT_YUVA420P) &&
         (d == AV_PIX_FMT_YUYV422 || d == AV_PIX_FMT_UYVY422)) k = PLAN_UNSC_PLANAR2P422;                               // :2684-2692
@@ -305,6 +308,7 @@ int init_single_context(SwsInternal *c)
     c->srcBpc = std::max(ds->comp[0].depth, 8);                                 // :1401-1410
     c->dstBpc = std::max(dd->comp[0].depth, 8);
     if (isAnyRGB(srcFormat)) c->srcBpc = 16;
+    if (isFloatFmt(srcFormat) && !isAnyRGB(srcFormat)) c->srcBpc = 16;   // "float will be converted to uint16_t" (utils.c:1558-1563)
 
     const int64_t chrXInc = (((int64_t)c->chrSrcW << 16) + (c->chrDstW >> 1)) / c->chrDstW; // :1428-1429
     const int64_t chrYInc = (((int64_t)c->chrSrcH << 16) + (c->chrDstH >> 1)) / c->chrDstH;

@@ -107,6 +107,7 @@ static int src_kind_of(int f)
     if (!d) return -1;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? SRCK_GBRPF32 : d->comp[0].depth > 8 ? SRCK_GBRP16 : SRCK_GBRP;
     if (isAnyRGB(f) && d->comp[0].depth == 16) return SRCK_RGB48;
+    if (f == AV_PIX_FMT_GRAYF32LE) return SRCK_GRAYF32;
     if (f == AV_PIX_FMT_MONOWHITE || f == AV_PIX_FMT_MONOBLACK) return SRCK_MONO;
     if (isAnyRGB(f) && d->comp[0].depth == 10 && d->comp[0].step == 4) return SRCK_RGB30;
     if (isAnyRGB(f) && d->comp[0].step == 2) return SRCK_RGB16;
@@ -123,6 +124,7 @@ static int dst_kind_of(int f)
     if (!d) return -1;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? DSTK_GBRPF32 : d->comp[0].depth == 16 ? DSTK_GBRP16 : DSTK_GBRP;
     if (isAnyRGB(f) && d->comp[0].depth == 16) return DSTK_RGB48;
+    if (f == AV_PIX_FMT_GRAYF32LE) return DSTK_PLANARF32;
     if (f == AV_PIX_FMT_MONOWHITE || f == AV_PIX_FMT_MONOBLACK) return DSTK_MONO;
     if (isAnyRGB(f) && d->comp[0].depth == 10 && d->comp[0].step == 4) return DSTK_RGB30;
     if (isAnyRGB(f) && d->comp[0].step == 2) return DSTK_RGB16;
@@ -653,6 +655,8 @@ int dev_prepare(SwsInternal *c)
     case PLAN_UNSC_RGB16SHUFFLE: c->path_name = "unscaled:rgb16Shuffle"; c->kernel_name = "sws_k_rgb16_convert"; break;
     case PLAN_UNSC_PACKED16_GBRP16: c->path_name = "unscaled:Rgb16ToPlanarRgb16"; c->kernel_name = "sws_k_rgb16_convert"; break;
     case PLAN_UNSC_GBRP16_PACKED16: c->path_name = "unscaled:planarRgb16ToRgb16"; c->kernel_name = "sws_k_rgb16_convert"; break;
+    case PLAN_UNSC_U8_TO_F32: c->path_name = "unscaled:uint_y_to_float_y"; c->kernel_name = "sws_k_gray_f32"; break;
+    case PLAN_UNSC_F32_TO_U8: c->path_name = "unscaled:float_y_to_uint_y"; c->kernel_name = "sws_k_gray_f32"; break;
     case PLAN_UNSC_YUV2MONO: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2mono_unscaled"; break;
     case PLAN_UNSC_RGB30_TO_16: c->path_name = "unscaled:rgbToRgb"; c->kernel_name = "sws_k_rgb30_convert"; break;
     case PLAN_UNSC_RGB30_TO_GBRP: c->path_name = "unscaled:Rgb16ToPlanarRgb16"; c->kernel_name = "sws_k_rgb30_convert"; break;
@@ -986,6 +990,12 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
         rp.depth = rp.mode == 1 ? dd->comp[0].depth : ds->comp[0].depth;
         const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
         hipLaunchKernelGGL(swsk::sws_k_rgb16_convert, grid, blk, 0, st, fs, rp, p.srcW, sliceY);
+        break;
+    }
+    case PLAN_UNSC_U8_TO_F32:
+    case PLAN_UNSC_F32_TO_U8: {
+        const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
+        hipLaunchKernelGGL(swsk::sws_k_gray_f32, grid, blk, 0, st, fs, p.srcW, sliceY, c->plan == PLAN_UNSC_U8_TO_F32 ? 1 : 0);
         break;
     }
     case PLAN_UNSC_YUV2MONO: {

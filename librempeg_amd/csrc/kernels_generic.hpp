@@ -86,6 +86,8 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         const unsigned rnd = (256u << (S - 1)) + (1 << (S - 7));
         return (uint16_t)((unsigned)(cr * r + cg * g + cb * b + rnd) >> (S - 6));
     }
+    case SRCK_GRAYF32:   // grayf32ToY16_c input.c:1399-1409
+        return f32_to_u16(*(const float *)(f.src[0] + (int64_t)row * f.srcStride[0] + 4 * x));
     case SRCK_MONO: { // monowhite2Y_c / monoblack2Y_c (input.c:514-548); s16_is565 = monowhite.  Chroma is never read (swscale.c:692-694)
         const int v = f.src[0][(int64_t)row * f.srcStride[0] + (x >> 3)];
         return ((((p.s16_is565 ? ~v : v) >> (7 - (x & 7))) & 1) * 16383);
@@ -300,6 +302,16 @@ __device__ __forceinline__ void planar_write_one(const SwsDevParams &p, const S 
             int val = 1 << (shift - 1);
             for (int j = 0; j < fs; j++) val += smp.get(comp, min(first + j, srcRows - 1), x) * vf[j];
             d[x] = (uint16_t)(clip_uintp2(val >> shift, bits) << p.dst_shift);
+        }
+    } else if (p.dstKind == DSTK_PLANARF32) {   // yuv2plane1_float / yuv2planeX_float_c_template (output.c:219-260): the 16-bit value times 1 / 65535
+        float *d = (float *)drow;
+        const float float_mult = 1.0f / 65535.0f;
+        if (fs == 1) {
+            d[x] = float_mult * (float)clip_u16((smp.get(comp, min(first, srcRows - 1), x) + 4) >> 3);
+        } else {
+            int val = (1 << 14) - 0x40000000;
+            for (int j = 0; j < fs; j++) val += (int)((unsigned)smp.get(comp, min(first + j, srcRows - 1), x) * (unsigned)(int)vf[j]);
+            d[x] = float_mult * (float)(0x8000 + clip_i16(val >> 15));
         }
     } else if (p.dstKind == DSTK_PLANAR16 || p.dstKind == DSTK_P016) {
         uint16_t *d = (uint16_t *)drow;

@@ -237,6 +237,21 @@ __global__ void __launch_bounds__(256) sws_k_rgb16_convert(SwsFrameSet fs, Rgb16
     }
 }
 
+// uint_y_to_float_y_wrapper (swscale_unscaled.c:2095-2113; uint2float_lut[i] = (float)i * (1 / 255), utils.c:1552-1556) when to_float,
+// float_y_to_uint_y_wrapper (:2115-2135) otherwise
+__global__ void __launch_bounds__(256) sws_k_gray_f32(SwsFrameSet fs, int w, int sliceY, int to_float)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= w) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int y = sliceY + blockIdx.y;
+    if (to_float) ((float *)(f.dst[0] + (int64_t)y * f.dstStride[0]))[x] = (float)f.src[0][(int64_t)y * f.srcStride[0] + x] * (1.0f / 255.0f);
+    else {
+        const int v = (int)lrintf(255.0f * ((const float *)(f.src[0] + (int64_t)y * f.srcStride[0]))[x]);
+        f.dst[0][(int64_t)y * f.dstStride[0] + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+}
+
 // yuv2rgb_c_1_ordered_dither (yuv2rgb.c:457-517): chroma ignored (g = the table index of U = V = 128); the 1-bit table is
 // (y_table[k] >> 7) with the ramp starting at element 110 (yuv2rgb.c:806-816).  One thread = one output byte of a row pair.  The tail
 // (dst_w & 7) counts PIXEL PAIRS across both rows in the macro's order and shifts the rest.

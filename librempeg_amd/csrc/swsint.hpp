@@ -79,6 +79,8 @@ enum PlanKind {
     PLAN_UNSC_RGB16SHUFFLE,   // rgb48tobgr48 / rgb48to64 / rgb48tobgr64 / rgb64to48 / rgb64tobgr48 (rgb2rgb.c:322-413)
     PLAN_UNSC_PACKED16_GBRP16,// Rgb16ToPlanarRgb16Wrapper
     PLAN_UNSC_GBRP16_PACKED16,// planarRgb16ToRgb16Wrapper
+    PLAN_UNSC_U8_TO_F32,      // uint_y_to_float_y_wrapper (swscale_unscaled.c:2095-2113)
+    PLAN_UNSC_F32_TO_U8,      // float_y_to_uint_y_wrapper (:2115-2135)
     PLAN_UNSC_YUV2MONO,       // yuv2rgb_c_1_ordered_dither (yuv2rgb.c:457-517)
     PLAN_UNSC_RGB30_TO_16,    // x2rgb10to48 / x2rgb10to64 / x2rgb10tobgr48 / x2rgb10tobgr64 (rgb2rgb.c:415-471)
     PLAN_UNSC_RGB30_TO_GBRP,  // Rgb16ToPlanarRgb16Wrapper + packed30togbra10

@@ -138,6 +138,7 @@ static const Desc descs[] = {
     { ORF_NV20LE, "nv20le", 3, 1, 0, {{0,2,0,0,10},{1,4,0,0,10},{1,4,2,0,10}}, PF_PLANAR },
     { ORF_GBRP10MSBLE, "gbrp10msble", 3, 0, 0, {{2,2,0,6,10},{0,2,0,6,10},{1,2,0,6,10}}, PF_PLANAR | PF_RGB },
     { ORF_GBRP12MSBLE, "gbrp12msble", 3, 0, 0, {{2,2,0,4,12},{0,2,0,4,12},{1,2,0,4,12}}, PF_PLANAR | PF_RGB },
+    { ORF_GRAYF32LE, "grayf32le", 1, 0, 0, {{0,4,0,0,32}}, PF_FLOAT },
     { ORF_MONOWHITE, "monow", 1, 0, 0, {{0,1,0,0,1}}, PF_RGB },   /* 1 bit per pixel, MSB first; isAnyRGB() counts them in (swscale_internal.h:876-882) */
     { ORF_MONOBLACK, "monob", 1, 0, 0, {{0,1,0,7,1}}, PF_RGB },
     { ORF_XYZ12LE, "xyz12le", 3, 0, 0, {{0,6,0,4,12},{0,6,2,4,12},{0,6,4,4,12}}, 0 },   /* only ever seen before handle_xyz() */
@@ -182,7 +183,7 @@ static const Desc *desc_get(int fmt)
 static const int be_pairs[][2] = {
     { ORF_XV36BE, ORF_XV36LE }, { ORF_XV48BE, ORF_XV48LE }, { ORF_AYUV64BE, ORF_AYUV64LE },
     { ORF_YUVA420P9BE, ORF_YUVA420P9LE }, { ORF_YUVA420P10BE, ORF_YUVA420P10LE }, { ORF_YUVA420P16BE, ORF_YUVA420P16LE }, { ORF_YUVA422P9BE, ORF_YUVA422P9LE }, { ORF_YUVA422P10BE, ORF_YUVA422P10LE }, { ORF_YUVA422P12BE, ORF_YUVA422P12LE }, { ORF_YUVA422P16BE, ORF_YUVA422P16LE }, { ORF_YUVA444P9BE, ORF_YUVA444P9LE }, { ORF_YUVA444P10BE, ORF_YUVA444P10LE }, { ORF_YUVA444P12BE, ORF_YUVA444P12LE }, { ORF_YUVA444P16BE, ORF_YUVA444P16LE },
-    { ORF_XYZ12BE, ORF_XYZ12LE }, { ORF_NV20BE, ORF_NV20LE }, { ORF_GBRP10MSBBE, ORF_GBRP10MSBLE }, { ORF_GBRP12MSBBE, ORF_GBRP12MSBLE },
+    { ORF_GRAYF32BE, ORF_GRAYF32LE }, { ORF_XYZ12BE, ORF_XYZ12LE }, { ORF_NV20BE, ORF_NV20LE }, { ORF_GBRP10MSBBE, ORF_GBRP10MSBLE }, { ORF_GBRP12MSBBE, ORF_GBRP12MSBLE },
     { ORF_YUV444P10MSBBE, ORF_YUV444P10MSBLE }, { ORF_YUV444P12MSBBE, ORF_YUV444P12MSBLE },
     { ORF_RGB565BE, ORF_RGB565LE }, { ORF_RGB555BE, ORF_RGB555LE }, { ORF_RGB444BE, ORF_RGB444LE },
     { ORF_BGR565BE, ORF_BGR565LE }, { ORF_BGR555BE, ORF_BGR555LE }, { ORF_BGR444BE, ORF_BGR444LE },
@@ -283,7 +284,7 @@ enum { RY, GY, BY, RU, GU, BU, RV, GV, BV };
 
 enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
        UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_RGBLOW, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED,
-       UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP, UNSC_RGB30_TO_16, UNSC_RGB30_TO_GBRP, UNSC_GBRP_TO_RGB30, UNSC_YUV2MONO,
+       UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP, UNSC_RGB30_TO_16, UNSC_RGB30_TO_GBRP, UNSC_GBRP_TO_RGB30, UNSC_YUV2MONO, UNSC_U8_TO_F32, UNSC_F32_TO_U8,
        UNSC_PLANAR2P422, UNSC_P4222PLANAR,
        UNSC_RGB16SHUFFLE, UNSC_PACKED16_TO_GBRP16, UNSC_GBRP16_TO_PACKED16 };
 
@@ -1017,6 +1018,9 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         if (!isPacked(s)) c->unscaled_kind = UNSC_PLANARCOPY;
         else c->unscaled_kind = UNSC_PACKEDCOPY; /* packedCopyWrapper (:2138-2157) */
     }
+    /* uint_y_to_float_y_wrapper / float_y_to_uint_y_wrapper (:2639-2647); rules name the native-endian format */
+    if (s == ORF_GRAY8 && d == ORF_GRAYF32LE && !c->dst_be) c->unscaled_kind = UNSC_U8_TO_F32;
+    if (s == ORF_GRAYF32LE && d == ORF_GRAY8 && !c->src_be) c->unscaled_kind = UNSC_F32_TO_U8;
     if (s == ORF_YUV422P && (d == ORF_YUYV422 || d == ORF_UYVY422)) c->unscaled_kind = UNSC_PLANAR2P422;          /* :2667-2672 */
     if ((flags & (OR_SWS_FAST_BILINEAR | OR_SWS_POINT)) && (s == ORF_YUV420P || s == ORF_YUVA420P) &&
         (d == ORF_YUYV422 || d == ORF_UYVY422)) c->unscaled_kind = UNSC_PLANAR2P422;                               /* :2684-2692 */
@@ -1091,6 +1095,7 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
     c->srcBpc = ds->c[0].depth; if (c->srcBpc < 8) c->srcBpc = 8;
     c->dstBpc = dd->c[0].depth; if (c->dstBpc < 8) c->dstBpc = 8;
     if (isAnyRGB(srcFormat)) c->srcBpc = 16;
+    if (isFloat(srcFormat) && !isAnyRGB(srcFormat)) c->srcBpc = 16;   /* "float will be converted to uint16_t" (utils.c:1558-1563; the unscaled exceptions never reach the scaler) */
 
     chrXInc = (((int64_t)c->chrSrcW << 16) + (c->chrDstW >> 1)) / c->chrDstW;
     chrYInc = (((int64_t)c->chrSrcH << 16) + (c->chrDstH >> 1)) / c->chrDstH;
@@ -2065,6 +2070,11 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
             d[i] = (uint16_t)((int)((unsigned)t[RY] * (R[i] >> ms) + (unsigned)t[GY] * (G[i] >> ms) + (unsigned)t[BY] * (B[i] >> ms) +
                                     (16u << (15 + bpc - 8)) + (1u << (15 + shift - 15))) >> (15 + shift - 14));
         return tmp; }
+    case ORF_GRAYF32LE: { /* grayf32ToY16_c input.c:1399-1409 */
+        const float *s = (const float *)(src[0] + y * stride[0]);
+        uint16_t *d = (uint16_t *)tmp;
+        for (i = 0; i < w; i++) d[i] = (uint16_t)f2u16(s[i]);
+        return tmp; }
     case ORF_GBRPF32LE: { /* planar_rgbf32_to_y input.c:1319-1334 */
         const float *G = (const float *)(src[0] + y * stride[0]), *B = (const float *)(src[1] + y * stride[1]),
                     *R = (const float *)(src[2] + y * stride[2]);
@@ -2419,6 +2429,19 @@ static void write_planar_line(const OrSws *c, uint8_t *dest, int w, const int32_
                 int val = 1 << (shift - 1);
                 for (j = 0; j < fs; j++) val += ROW(j)[i] * filter[j];
                 d[i] = (uint16_t)(clip_uintp2(val >> shift, bits) << oshift);
+            }
+        }
+    } else if (bits == 32) { /* yuv2plane1_float / yuv2planeX_float_c_template (output.c:219-260): the 16-bit value times 1 / 65535 */
+        static const float float_mult = 1.0f / 65535.0f;
+        float *d = (float *)dest;
+        if (fs == 1) {
+            const int32_t *s = ROW(0);
+            for (i = 0; i < w; i++) d[i] = float_mult * (float)clip_u16((s[i] + (1 << 2)) >> 3);
+        } else {
+            for (i = 0; i < w; i++) {
+                int val = (1 << 14) - 0x40000000;
+                for (j = 0; j < fs; j++) val += (int)(ROW(j)[i] * (unsigned)filter[j]);
+                d[i] = float_mult * (float)(0x8000 + clip_i16(val >> 15));
             }
         }
     } else if (bits == 16) { /* yuv2plane1_16 / planeX_16 output.c:149-187 */
@@ -3379,6 +3402,18 @@ static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4
     case UNSC_NV242YUV420: return unscaled_nv242yuv420(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_YVU9_YV12: return unscaled_yvu9_yv12(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_PACKED2GBRP: return unscaled_packed2gbrp(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_U8_TO_F32: /* uint_y_to_float_y_wrapper (:2095-2113): uint2float_lut[i] = (float)i * (1 / 255) (utils.c:1552-1556) */
+        for (int y = 0; y < srcSliceH; y++) {
+            const uint8_t *s = src[0] + (ptrdiff_t)y * srcStride[0]; float *d = (float *)(dst[0] + (ptrdiff_t)y * dstStride[0]);
+            for (int x = 0; x < c->o.src_w; x++) d[x] = (float)s[x] * (1.0f / 255.0f);
+        }
+        return srcSliceH;
+    case UNSC_F32_TO_U8: /* float_y_to_uint_y_wrapper (:2115-2135) */
+        for (int y = 0; y < srcSliceH; y++) {
+            const float *s = (const float *)(src[0] + (ptrdiff_t)y * srcStride[0]); uint8_t *d = dst[0] + (ptrdiff_t)y * dstStride[0];
+            for (int x = 0; x < c->o.src_w; x++) d[x] = (uint8_t)clip_u8((int)lrintf(255.0f * s[x]));
+        }
+        return srcSliceH;
     case UNSC_YUV2MONO: return unscaled_yuv2mono(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_RGB30_TO_16: return unscaled_rgb30_to_16(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_RGB30_TO_GBRP: return unscaled_rgb30_to_gbrp(c, src, srcStride, 0, srcSliceH, dst, dstStride);
@@ -3410,7 +3445,7 @@ const char *or_sws_path_name(const OrSws *c)
 {
     static const char *n[] = { "main", "yuv2rgb_c", "planarToP01x", "planar8ToP01xle", "planarToNv12", "nv12ToPlanar", "planarCopy",
                                "rgbToRgb", "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb",
-                               "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb", "rgbToRgb", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "yuv2rgb_c",
+                               "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb", "rgbToRgb", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "yuv2rgb_c", "uint_y_to_float_y", "float_y_to_uint_y",
                                "planarToYuy2", "yuyvToPlanar",
                                "rgb16Shuffle", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16" };
     return c->cascade[0] ? "cascade" : n[c->unscaled_kind];
