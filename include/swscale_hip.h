@@ -78,6 +78,7 @@ enum AVPixelFormat {
      * reference's last format (AV_PIX_FMT_NB == 268, libavutil/pixfmt.h) */
     AV_PIX_FMT_AYUV64LE = 155, AV_PIX_FMT_AYUV64BE = 156, AV_PIX_FMT_Y210LE = 192, AV_PIX_FMT_Y212LE = 212, AV_PIX_FMT_Y216LE = 240,
     AV_PIX_FMT_X2RGB10LE = 193, AV_PIX_FMT_X2BGR10LE = 195,
+    AV_PIX_FMT_YA8 = 56, AV_PIX_FMT_YA16BE = 109, AV_PIX_FMT_YA16LE = 110,
     AV_PIX_FMT_GRAYF32BE = 182, AV_PIX_FMT_GRAYF32LE = 183,
     AV_PIX_FMT_MONOWHITE = 9, AV_PIX_FMT_MONOBLACK = 10, AV_PIX_FMT_XYZ12LE = 99, AV_PIX_FMT_XYZ12BE = 100,
     AV_PIX_FMT_YUVJ411P = 138, AV_PIX_FMT_NV20LE = 102, AV_PIX_FMT_NV20BE = 103,

@@ -202,7 +202,8 @@ void choose_unscaled(SwsInternal *c)
     if (isAnyRGB(s) && !isPlanarRGB(s) && pix_desc(s)->comp[0].depth == 8 && d == AV_PIX_FMT_GBRP) k = PLAN_UNSC_PACKED_GBRP;             // rgbToPlanarRgbWrapper (:2542-2544)
     if (s == AV_PIX_FMT_GBRP && isAnyRGB(d) && !isPlanarRGB(d) && pix_desc(d)->comp[0].depth == 8) k = PLAN_UNSC_GBRP_PACKED;             // planarRgbToRgbWrapper (:2480-2481)
     if (s == d || (s == AV_PIX_FMT_YUVA420P && d == AV_PIX_FMT_YUV420P) || (s == AV_PIX_FMT_YUV420P && d == AV_PIX_FMT_YUVA420P) ||
-        (isFloatFmt(s) == isFloatFmt(d) && ((isPlanarYUV(s) && isGray(d)) || (isPlanarYUV(d) && isGray(s)) || (isGray(d) && isGray(s)))) ||
+        (isFloatFmt(s) == isFloatFmt(d) && ((isPlanarYUV(s) && isGray(d) && !isALPHA(d)) || (isPlanarYUV(d) && isGray(s) && !isALPHA(s)) ||
+                                           (isGray(d) && !isALPHA(d) && isGray(s) && !isALPHA(s)))) ||   // isPlanarGray(x) = isGray(x) && !isALPHA(x) (:2673)
         (isFloatFmt(s) == isFloatFmt(d) && isPlanarYUV(s) && isPlanarYUV(d) &&
          c->chrDstHSubSample == c->chrSrcHSubSample && c->chrDstVSubSample == c->chrSrcVSubSample &&
          isSemiPlanarYUV(s) == isSemiPlanarYUV(d) && isSwappedChroma(s) == isSwappedChroma(d))) { // :2647-2668

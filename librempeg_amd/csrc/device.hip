@@ -107,6 +107,7 @@ static int src_kind_of(int f)
     if (!d) return -1;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? SRCK_GBRPF32 : d->comp[0].depth > 8 ? SRCK_GBRP16 : SRCK_GBRP;
     if (isAnyRGB(f) && d->comp[0].depth == 16) return SRCK_RGB48;
+    if (f == AV_PIX_FMT_YA8 || f == AV_PIX_FMT_YA16LE) return SRCK_YA;
     if (f == AV_PIX_FMT_GRAYF32LE) return SRCK_GRAYF32;
     if (f == AV_PIX_FMT_MONOWHITE || f == AV_PIX_FMT_MONOBLACK) return SRCK_MONO;
     if (isAnyRGB(f) && d->comp[0].depth == 10 && d->comp[0].step == 4) return SRCK_RGB30;
@@ -124,6 +125,7 @@ static int dst_kind_of(int f)
     if (!d) return -1;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? DSTK_GBRPF32 : d->comp[0].depth == 16 ? DSTK_GBRP16 : DSTK_GBRP;
     if (isAnyRGB(f) && d->comp[0].depth == 16) return DSTK_RGB48;
+    if (f == AV_PIX_FMT_YA8 || f == AV_PIX_FMT_YA16LE) return DSTK_YA;
     if (f == AV_PIX_FMT_GRAYF32LE) return DSTK_PLANARF32;
     if (f == AV_PIX_FMT_MONOWHITE || f == AV_PIX_FMT_MONOBLACK) return DSTK_MONO;
     if (isAnyRGB(f) && d->comp[0].depth == 10 && d->comp[0].step == 4) return DSTK_RGB30;
@@ -1110,7 +1112,7 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
             hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.dstW, 0, p.dst_bits > 8 ? p.dst_bits : 0);
         }
         const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 ||
-                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI || p.dstKind == DSTK_RGB48 || p.dstKind == DSTK_RGB16 || p.dstKind == DSTK_RGB30 || p.dstKind == DSTK_MONO;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
+                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI || p.dstKind == DSTK_RGB48 || p.dstKind == DSTK_RGB16 || p.dstKind == DSTK_RGB30 || p.dstKind == DSTK_MONO || p.dstKind == DSTK_YA;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
         if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;
@@ -1272,7 +1274,7 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
     else if (p.wide) hipLaunchKernelGGL((swsk::K<false, int32_t>), G, blk, 0, st, sub, p, (const int32_t *)d->scratch, frame_elems, ##__VA_ARGS__); \
     else hipLaunchKernelGGL((swsk::K<false, int16_t>), G, blk, 0, st, sub, p, (const int16_t *)d->scratch, frame_elems, ##__VA_ARGS__); } while (0)
             if (rgb) {
-                const int units = p.dstKind == DSTK_MONO ? (p.dstW + 7) >> 3 : p.full_chr ? p.dstW : (p.dstW + 1) >> 1;
+                const int units = p.dstKind == DSTK_MONO ? (p.dstW + 7) >> 3 : (p.full_chr || p.dstKind == DSTK_YA) ? p.dstW : (p.dstW + 1) >> 1;
                 const dim3 g(cdiv(units, 256), p.dstH, m);
                 LAUNCH_W(sws_k_vscale_rgb, g);
             } else if (p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010 || p.dstKind == DSTK_P016) {

@@ -17,6 +17,7 @@ enum SrcKind {
     SRCK_GBRP16,        // planar 9..16-bit RGB; planar_rgb16_s16_to_y/uv input.c:1216-1270
     SRCK_PACKEDHI,      // y210 / y212 / y216, xv30 / v30x, xv36, xv48, ayuv64: (16-bit word at the descriptor offset) >> shift, masked (input.c:580-606, :663-729, :811-866)
     SRCK_PACKED444,     // ayuv / vuya / vuyx / uyva / vyu444: read_*_Y/UV/A_c, vyuToY/UV_c input.c:731-809 (bytes at the descriptor offsets)
+    SRCK_YA,            // ya8 / ya16le: gray and alpha samples interleaved (input.c:631-645, :2400-2403, :2773-2775)
     SRCK_GRAYF32,       // grayf32: grayf32ToY16_c input.c:1399-1409
     SRCK_MONO,          // monowhite / monoblack: monowhite2Y_c / monoblack2Y_c input.c:514-548
     SRCK_RGB30,         // x2rgb10le / x2bgr10le: rgb16_32To*_c_template with the rgb30le / bgr30le rows of input.c:411-412
@@ -40,6 +41,7 @@ enum DstKind {
     DSTK_P016,          // 16-bit semi-planar: luma yuv2planeX_16_c, chroma yuv2nv12cX_16_c_template output.c:189-217
     DSTK_PACKEDHI,      // yuv2y2xxle_X_c, yuv2y216le_X_c, yuv2xv30le / v30xle_X_c, yuv2xv36le_X_c, yuv2ayuv64le / xv48le_X_c (output.c:2712-2866, :3088-3169)
     DSTK_PACKED444,     // ayuv / vuya / vuyx / uyva: yuv2ayuv_{1,2,X}_c_template output.c:2903-3060; vyu444: yuv2vyu444_{1,2,X}_c :3171-3290
+    DSTK_YA,            // ya8 / ya16le: yuv2ya8_{1,2,X}_c output.c:2613-2705, yuv2ya16_{X,2,1}_c_template :1016-1113
     DSTK_PLANARF32,     // grayf32: yuv2plane1_float / yuv2planeX_float_c_template output.c:219-260
     DSTK_MONO,          // monowhite / monoblack: yuv2mono_{X,2,1}_c_template output.c:654-860 (ordered dither)
     DSTK_RGB30,         // x2rgb10le / x2bgr10le: yuv2rgb_write 30 bpp (output.c:1748-1754), yuv2rgb_write_full (:2052-2063)

@@ -21,6 +21,11 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         const uint8_t *s = f.src[0] + (int64_t)row * f.srcStride[0] + p.shi_step[comp] * x + p.shi_off[comp];
         return (*(const uint16_t *)s >> p.shi_shift[comp]) & p.shi_mask[comp];
     }
+    if (p.srcKind == SRCK_YA) {   // ya8: yuy2ToY_c / uyvyToY_c on the two bytes; ya16le: read_ya16le_gray_c / _alpha_c (comp 0 = gray, 3 = alpha)
+        const uint8_t *s = f.src[0] + (int64_t)row * f.srcStride[0];
+        if (p.src_depth == 8) return s[2 * x + (comp == 3 ? 1 : 0)];
+        return ((const uint16_t *)s)[2 * x + (comp == 3 ? 1 : 0)];
+    }
     if (comp == 3 && p.srcKind == SRCK_PACKED444)   // read_vuya_A_c / read_ayuv_A_c
         return f.src[0][(int64_t)row * f.srcStride[0] + 4 * x + p.s444_a];
     if (comp == 3) {   // alpha line: plane 3 of yuva (8 bit), or rgbaToA_c / abgrToA_c (input.c:454-472) for 32 bpp RGB
@@ -214,7 +219,7 @@ __device__ __forceinline__ int range_sample(const SwsDevParams &p, int v, int ch
 // horizontal stage for one output sample (hScale8To15_c / 8To19 / 16To15 / 16To19, swscale.c:69-159)
 __device__ __forceinline__ int hscale_sample(const SwsDevParams &p, const SwsFramePtrs &f, int comp, int row, int x)
 {
-    if (p.no_chroma && comp != 0) return p.wide ? 1 << 18 : 1 << 14;   // ff_init_desc_no_chr: fill_ones() value, never range converted
+    if (p.no_chroma && comp != 0 && comp != 3) return p.wide ? 1 << 18 : 1 << 14;   // ff_init_desc_no_chr: fill_ones() value, never range converted
     const bool lumlike = comp == 0 || comp == 3;   // the alpha plane goes through the luma functions (hscale.c:39-131)
     if (p.fast_bilinear) {   // ff_hyscale_fast_c / ff_hcscale_fast_c, hscale_fast_bilinear.c:23-55
         const int sW = lumlike ? p.srcW : p.chrSrcW;
@@ -252,7 +257,7 @@ struct DirectSampler { // horizontal filters are 1-tap identity: compute the sam
     const SwsDevParams *p; const SwsFramePtrs *f;
     __device__ __forceinline__ int get(int comp, int row, int x) const
     {
-        if (p->no_chroma && comp != 0) return p->wide ? 1 << 18 : 1 << 14;
+        if (p->no_chroma && comp != 0 && comp != 3) return p->wide ? 1 << 18 : 1 << 14;
         int r = min((read_sample(*p, *f, comp, row, x) * 16384) >> p->hshift, p->hclip);
         if (!p->wide) r = (int16_t)r;
         return comp == 3 ? r : range_sample(*p, r, comp != 0);
@@ -466,6 +471,45 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
     else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 1; ua = (uint16_t)cf[1]; }
     else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
              (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 2; ya = (uint16_t)lf[1]; ua = (uint16_t)cf[1]; }
+    if (p.dstKind == DSTK_YA) {   // yuv2ya8_{1,2,X}_c (output.c:2613-2705), yuv2ya16_{X,2,1}_c_template (:1016-1113); unit i = pixel i
+        int Y, A = 0;
+        if (!p.wide) {
+            if (mode == 1) {
+                Y = clip_u8((LUM(0, i) + 64) >> 7);
+                if (p.need_alpha) { A = (ALP(0, i) + 64) >> 7; if (A & 0x100) A = clip_u8(A); }
+            } else if (mode == 2) {
+                Y = clip_u8((LUM(0, i) * (4096 - ya) + LUM(1, i) * ya) >> 19);
+                if (p.need_alpha) A = clip_u8((ALP(0, i) * (4096 - ya) + ALP(1, i) * ya) >> 19);
+            } else {
+                Y = 1 << 18; A = 1 << 18;
+                for (int j = 0; j < lfs; j++) Y += (int)((unsigned)LUM(j, i) * (unsigned)(int)lf[j]);
+                Y >>= 19; if (Y & 0x100) Y = clip_u8(Y);
+                if (p.need_alpha) { for (int j = 0; j < lfs; j++) A += (int)((unsigned)ALP(j, i) * (unsigned)(int)lf[j]); A >>= 19; if (A & 0x100) A = clip_u8(A); }
+            }
+            drow[2 * i] = (uint8_t)Y; drow[2 * i + 1] = p.need_alpha ? (uint8_t)A : 255;
+        } else {
+            if (mode == 1) {
+                Y = clip_u16(LUM(0, i) >> 3);
+                if (p.need_alpha) { A = ALP(0, i) >> 3; if (A & 0x100) A = clip_u16(A); }   // (sic: the 8-bit test, output.c:1106-1107)
+                else A = 65535;
+            } else if (mode == 2) {
+                const unsigned ya1 = 4096 - ya;
+                Y = clip_u16((int)((unsigned)LUM(0, i) * ya1 + (unsigned)LUM(1, i) * (unsigned)ya) >> 15);
+                A = p.need_alpha ? clip_u16((int)((unsigned)ALP(0, i) * ya1 + (unsigned)ALP(1, i) * (unsigned)ya) >> 15) : 65535;
+            } else {
+                Y = -0x40000000; A = 0xffff;
+                for (int j = 0; j < lfs; j++) Y += (int)((unsigned)LUM(j, i) * (unsigned)(int)lf[j]);
+                Y >>= 15; Y += (1 << 3) + 0x8000; Y = clip_u16(Y);
+                if (p.need_alpha) {
+                    A = -0x40000000 + (1 << 14);
+                    for (int j = 0; j < lfs; j++) A += (int)((unsigned)ALP(j, i) * (unsigned)(int)lf[j]);
+                    A >>= 15; A += 0x8000; A = clip_u16(A);
+                }
+            }
+            ((uint16_t *)drow)[2 * i] = (uint16_t)Y; ((uint16_t *)drow)[2 * i + 1] = (uint16_t)A;
+        }
+        return;
+    }
     if (p.dstKind == DSTK_MONO) {   // yuv2mono_{X,2,1}_c_template (output.c:654-860), ordered dither (ff_dither_8x8_220 :84-95); unit i = byte i
         const uint32_t drow_lo[8] = { 0x679e3e75u, 0xba15c722u, 0x4c835990u, 0xce29a500u, 0x6097376eu, 0xb30ec11cu, 0x457c538au, 0xd530ac07u };
         const uint32_t drow_hi[8] = { 0x649b3a71u, 0xb611c41fu, 0x487f568du, 0xd934af0au, 0x6ba24178u, 0xbd18cb26u, 0x4f865d94u, 0xd22da803u };
@@ -845,7 +889,7 @@ __global__ void __launch_bounds__(256) sws_k_vscale_rgb(SwsFrameSet fs, SwsDevPa
 {
     const int fi = blockIdx.z;
     const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    const int units = p.dstKind == DSTK_MONO ? (p.dstW + 7) >> 3 : p.full_chr ? p.dstW : (p.dstW + 1) >> 1;
+    const int units = p.dstKind == DSTK_MONO ? (p.dstW + 7) >> 3 : (p.full_chr || p.dstKind == DSTK_YA) ? p.dstW : (p.dstW + 1) >> 1;
     if (i >= units || y >= p.dstH) return;
     const SwsFramePtrs &f = frame_of(fs, fi);
     const auto smp = SamplerFor<DIRECT, T>::make(p, f, scratch, frame_elems, fi);

@@ -98,6 +98,8 @@ static const PixDesc g_descs[] = {
     { AV_PIX_FMT_NV20LE, "nv20le", 3, 1, 0, {{0,2,0,0,10},{1,4,0,0,10},{1,4,2,0,10},{0,0,0,0,0}}, PIXFLAG_PLANAR },
     { AV_PIX_FMT_GBRP10MSBLE, "gbrp10msble", 3, 0, 0, {{2,2,0,6,10},{0,2,0,6,10},{1,2,0,6,10},{0,0,0,0,0}}, PIXFLAG_PLANAR | PIXFLAG_RGB },
     { AV_PIX_FMT_GBRP12MSBLE, "gbrp12msble", 3, 0, 0, {{2,2,0,4,12},{0,2,0,4,12},{1,2,0,4,12},{0,0,0,0,0}}, PIXFLAG_PLANAR | PIXFLAG_RGB },
+    { AV_PIX_FMT_YA8, "ya8", 2, 0, 0, {{0,2,0,0,8},{0,2,1,0,8},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_ALPHA },
+    { AV_PIX_FMT_YA16LE, "ya16le", 2, 0, 0, {{0,4,0,0,16},{0,4,2,0,16},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_ALPHA },
     { AV_PIX_FMT_GRAYF32LE, "grayf32le", 1, 0, 0, {{0,4,0,0,32},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_FLOAT },
     { AV_PIX_FMT_MONOWHITE, "monow", 1, 0, 0, {{0,1,0,0,1},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_RGB },   // 1 bit per pixel, MSB first; isAnyRGB() counts them in
     { AV_PIX_FMT_MONOBLACK, "monob", 1, 0, 0, {{0,1,0,7,1},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_RGB },
@@ -177,7 +179,7 @@ int pix_be_twin(int fmt)
     static const int pairs[][2] = {
     { AV_PIX_FMT_XV36BE, AV_PIX_FMT_XV36LE }, { AV_PIX_FMT_XV48BE, AV_PIX_FMT_XV48LE }, { AV_PIX_FMT_AYUV64BE, AV_PIX_FMT_AYUV64LE },
     { AV_PIX_FMT_YUVA420P9BE, AV_PIX_FMT_YUVA420P9LE }, { AV_PIX_FMT_YUVA420P10BE, AV_PIX_FMT_YUVA420P10LE }, { AV_PIX_FMT_YUVA420P16BE, AV_PIX_FMT_YUVA420P16LE }, { AV_PIX_FMT_YUVA422P9BE, AV_PIX_FMT_YUVA422P9LE }, { AV_PIX_FMT_YUVA422P10BE, AV_PIX_FMT_YUVA422P10LE }, { AV_PIX_FMT_YUVA422P12BE, AV_PIX_FMT_YUVA422P12LE }, { AV_PIX_FMT_YUVA422P16BE, AV_PIX_FMT_YUVA422P16LE }, { AV_PIX_FMT_YUVA444P9BE, AV_PIX_FMT_YUVA444P9LE }, { AV_PIX_FMT_YUVA444P10BE, AV_PIX_FMT_YUVA444P10LE }, { AV_PIX_FMT_YUVA444P12BE, AV_PIX_FMT_YUVA444P12LE }, { AV_PIX_FMT_YUVA444P16BE, AV_PIX_FMT_YUVA444P16LE },
-    { AV_PIX_FMT_GRAYF32BE, AV_PIX_FMT_GRAYF32LE }, { AV_PIX_FMT_XYZ12BE, AV_PIX_FMT_XYZ12LE }, { AV_PIX_FMT_NV20BE, AV_PIX_FMT_NV20LE }, { AV_PIX_FMT_GBRP10MSBBE, AV_PIX_FMT_GBRP10MSBLE }, { AV_PIX_FMT_GBRP12MSBBE, AV_PIX_FMT_GBRP12MSBLE },
+    { AV_PIX_FMT_YA16BE, AV_PIX_FMT_YA16LE }, { AV_PIX_FMT_GRAYF32BE, AV_PIX_FMT_GRAYF32LE }, { AV_PIX_FMT_XYZ12BE, AV_PIX_FMT_XYZ12LE }, { AV_PIX_FMT_NV20BE, AV_PIX_FMT_NV20LE }, { AV_PIX_FMT_GBRP10MSBBE, AV_PIX_FMT_GBRP10MSBLE }, { AV_PIX_FMT_GBRP12MSBBE, AV_PIX_FMT_GBRP12MSBLE },
     { AV_PIX_FMT_YUV444P10MSBBE, AV_PIX_FMT_YUV444P10MSBLE }, { AV_PIX_FMT_YUV444P12MSBBE, AV_PIX_FMT_YUV444P12MSBLE },
     { AV_PIX_FMT_RGB565BE, AV_PIX_FMT_RGB565LE }, { AV_PIX_FMT_RGB555BE, AV_PIX_FMT_RGB555LE }, { AV_PIX_FMT_RGB444BE, AV_PIX_FMT_RGB444LE },
     { AV_PIX_FMT_BGR565BE, AV_PIX_FMT_BGR565LE }, { AV_PIX_FMT_BGR555BE, AV_PIX_FMT_BGR555LE }, { AV_PIX_FMT_BGR444BE, AV_PIX_FMT_BGR444LE },

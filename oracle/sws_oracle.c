@@ -138,6 +138,8 @@ static const Desc descs[] = {
     { ORF_NV20LE, "nv20le", 3, 1, 0, {{0,2,0,0,10},{1,4,0,0,10},{1,4,2,0,10}}, PF_PLANAR },
     { ORF_GBRP10MSBLE, "gbrp10msble", 3, 0, 0, {{2,2,0,6,10},{0,2,0,6,10},{1,2,0,6,10}}, PF_PLANAR | PF_RGB },
     { ORF_GBRP12MSBLE, "gbrp12msble", 3, 0, 0, {{2,2,0,4,12},{0,2,0,4,12},{1,2,0,4,12}}, PF_PLANAR | PF_RGB },
+    { ORF_YA8, "ya8", 2, 0, 0, {{0,2,0,0,8},{0,2,1,0,8}}, PF_ALPHA },
+    { ORF_YA16LE, "ya16le", 2, 0, 0, {{0,4,0,0,16},{0,4,2,0,16}}, PF_ALPHA },
     { ORF_GRAYF32LE, "grayf32le", 1, 0, 0, {{0,4,0,0,32}}, PF_FLOAT },
     { ORF_MONOWHITE, "monow", 1, 0, 0, {{0,1,0,0,1}}, PF_RGB },   /* 1 bit per pixel, MSB first; isAnyRGB() counts them in (swscale_internal.h:876-882) */
     { ORF_MONOBLACK, "monob", 1, 0, 0, {{0,1,0,7,1}}, PF_RGB },
@@ -183,7 +185,7 @@ static const Desc *desc_get(int fmt)
 static const int be_pairs[][2] = {
     { ORF_XV36BE, ORF_XV36LE }, { ORF_XV48BE, ORF_XV48LE }, { ORF_AYUV64BE, ORF_AYUV64LE },
     { ORF_YUVA420P9BE, ORF_YUVA420P9LE }, { ORF_YUVA420P10BE, ORF_YUVA420P10LE }, { ORF_YUVA420P16BE, ORF_YUVA420P16LE }, { ORF_YUVA422P9BE, ORF_YUVA422P9LE }, { ORF_YUVA422P10BE, ORF_YUVA422P10LE }, { ORF_YUVA422P12BE, ORF_YUVA422P12LE }, { ORF_YUVA422P16BE, ORF_YUVA422P16LE }, { ORF_YUVA444P9BE, ORF_YUVA444P9LE }, { ORF_YUVA444P10BE, ORF_YUVA444P10LE }, { ORF_YUVA444P12BE, ORF_YUVA444P12LE }, { ORF_YUVA444P16BE, ORF_YUVA444P16LE },
-    { ORF_GRAYF32BE, ORF_GRAYF32LE }, { ORF_XYZ12BE, ORF_XYZ12LE }, { ORF_NV20BE, ORF_NV20LE }, { ORF_GBRP10MSBBE, ORF_GBRP10MSBLE }, { ORF_GBRP12MSBBE, ORF_GBRP12MSBLE },
+    { ORF_YA16BE, ORF_YA16LE }, { ORF_GRAYF32BE, ORF_GRAYF32LE }, { ORF_XYZ12BE, ORF_XYZ12LE }, { ORF_NV20BE, ORF_NV20LE }, { ORF_GBRP10MSBBE, ORF_GBRP10MSBLE }, { ORF_GBRP12MSBBE, ORF_GBRP12MSBLE },
     { ORF_YUV444P10MSBBE, ORF_YUV444P10MSBLE }, { ORF_YUV444P12MSBBE, ORF_YUV444P12MSBLE },
     { ORF_RGB565BE, ORF_RGB565LE }, { ORF_RGB555BE, ORF_RGB555LE }, { ORF_RGB444BE, ORF_RGB444LE },
     { ORF_BGR565BE, ORF_BGR565LE }, { ORF_BGR555BE, ORF_BGR555LE }, { ORF_BGR444BE, ORF_BGR444LE },
@@ -242,6 +244,7 @@ static int isYUV(int f) { const Desc *d = desc_get(f); return !(d->flags & PF_RG
 static int isPlanarYUV(int f) { return (desc_get(f)->flags & PF_PLANAR) && isYUV(f); }
 static int isSemiPlanarYUV(int f) { const Desc *d = desc_get(f); return isPlanarYUV(f) && d->c[1].plane == d->c[2].plane; }
 static int isAnyRGB(int f) { return !!(desc_get(f)->flags & PF_RGB); }
+static int isYA(int f) { return f == ORF_YA8 || f == ORF_YA16LE; }
 static int isMono(int f) { return f == ORF_MONOWHITE || f == ORF_MONOBLACK; }
 static int isGray(int f) { return desc_get(f)->nb <= 2 && !isMono(f); }   /* swscale_internal.h:805-815 */
 static int isFloat(int f) { return !!(desc_get(f)->flags & PF_FLOAT); }
@@ -1011,7 +1014,8 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
     /* simple copy (:2647-2668) */
     if (s == d || (s == ORF_YUVA420P && d == ORF_YUV420P) || (s == ORF_YUV420P && d == ORF_YUVA420P) ||
         (isFloat(s) == isFloat(d) &&
-         ((isPlanarYUV(s) && isGray(d)) || (isPlanarYUV(d) && isGray(s)) || (isGray(d) && isGray(s)))) ||
+         ((isPlanarYUV(s) && isGray(d) && !isALPHA(d)) || (isPlanarYUV(d) && isGray(s) && !isALPHA(s)) ||
+          (isGray(d) && !isALPHA(d) && isGray(s) && !isALPHA(s)))) ||   /* isPlanarGray(x) = isGray(x) && !isALPHA(x) (:2673) */
         (isFloat(s) == isFloat(d) &&
          (isPlanarYUV(s) && isPlanarYUV(d) && c->chrDstHSub == c->chrSrcHSub && c->chrDstVSub == c->chrSrcVSub &&
           isSemiPlanarYUV(s) == isSemiPlanarYUV(d) && isSwappedChroma(s) == isSwappedChroma(d)))) {
@@ -2070,6 +2074,13 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
             d[i] = (uint16_t)((int)((unsigned)t[RY] * (R[i] >> ms) + (unsigned)t[GY] * (G[i] >> ms) + (unsigned)t[BY] * (B[i] >> ms) +
                                     (16u << (15 + bpc - 8)) + (1u << (15 + shift - 15))) >> (15 + shift - 14));
         return tmp; }
+    case ORF_YA8: /* yuy2ToY_c on the gray byte (input.c:2400-2403) */
+        for (i = 0; i < w; i++) tmp[i] = src[0][(ptrdiff_t)y * stride[0] + 2 * i];
+        return tmp;
+    case ORF_YA16LE: { /* read_ya16le_gray_c input.c:631-637 */
+        uint16_t *d = (uint16_t *)tmp;
+        for (i = 0; i < w; i++) memcpy(&d[i], src[0] + (ptrdiff_t)y * stride[0] + 4 * i, 2);
+        return tmp; }
     case ORF_GRAYF32LE: { /* grayf32ToY16_c input.c:1399-1409 */
         const float *s = (const float *)(src[0] + y * stride[0]);
         uint16_t *d = (uint16_t *)tmp;
@@ -2811,6 +2822,67 @@ static void write_packed_rgb16_line(const OrSws *c, const Planes *P, uint8_t *de
 }
 
 /* packed_vscale (vscale.c:109-171) + yuv2422_{X,2,1}_c_template (output.c:883-1000) for yuyv422 / yvyu422 / uyvy422 */
+/* packed_vscale + yuv2ya8_{1,2,X}_c (output.c:2613-2705), yuv2ya16_{X,2,1}_c_template (:1016-1113): gray + alpha pairs */
+static void write_ya_line(const OrSws *c, const Planes *P, uint8_t *dest, int y)
+{
+    const int dstW = c->o.dst_w, lw = dstW, srcH = c->o.src_h;
+    const int chrY = y >> c->chrDstVSub;
+    const int lfs = c->vLumFilterSize, cfs = c->vChrFilterSize;
+    const int16_t *lf = c->vLumFilter + y * lfs, *cf = c->vChrFilter + chrY * cfs;
+    const int firstLum = ORMAX(1 - lfs, c->vLumFilterPos[y]);
+    const int hasAlpha = c->needAlpha, wide = c->o.dst_format == ORF_YA16LE;
+    int i, j, mode, ya = 0;
+#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+#define AL(j) (P->alp + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+    if (lfs == 1 && cfs == 1) mode = 1;
+    else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) mode = 1;
+    else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
+             (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 2; ya = (uint16_t)lf[1]; }
+    else mode = 0;
+    for (i = 0; i < dstW; i++) {
+        int Y, A = 0;
+        if (!wide) {
+            if (mode == 1) {
+                Y = clip_u8((L(0)[i] + 64) >> 7);
+                if (hasAlpha) { A = (AL(0)[i] + 64) >> 7; if (A & 0x100) A = clip_u8(A); }
+            } else if (mode == 2) {
+                Y = clip_u8((L(0)[i] * (4096 - ya) + L(1)[i] * ya) >> 19);
+                if (hasAlpha) A = clip_u8((AL(0)[i] * (4096 - ya) + AL(1)[i] * ya) >> 19);
+            } else {
+                Y = 1 << 18; A = 1 << 18;
+                for (j = 0; j < lfs; j++) Y += (int)(L(j)[i] * (unsigned)lf[j]);
+                Y >>= 19; if (Y & 0x100) Y = clip_u8(Y);
+                if (hasAlpha) { for (j = 0; j < lfs; j++) A += (int)(AL(j)[i] * (unsigned)lf[j]); A >>= 19; if (A & 0x100) A = clip_u8(A); }
+            }
+            dest[2 * i] = (uint8_t)Y; dest[2 * i + 1] = hasAlpha ? (uint8_t)A : 255;
+        } else {
+            uint16_t v[2];
+            if (mode == 1) {
+                Y = clip_u16(L(0)[i] >> 3);
+                if (hasAlpha) { A = AL(0)[i] >> 3; if (A & 0x100) A = clip_u16(A); }   /* (sic: the 8-bit test, :1106-1107) */
+                else A = 65535;
+            } else if (mode == 2) {
+                const unsigned ya1 = 4096 - ya;
+                Y = clip_u16((int)((unsigned)L(0)[i] * ya1 + (unsigned)L(1)[i] * (unsigned)ya) >> 15);
+                A = hasAlpha ? clip_u16((int)((unsigned)AL(0)[i] * ya1 + (unsigned)AL(1)[i] * (unsigned)ya) >> 15) : 65535;
+            } else {
+                Y = -0x40000000; A = 0xffff;
+                for (j = 0; j < lfs; j++) Y += (int)(L(j)[i] * (unsigned)lf[j]);
+                Y >>= 15; Y += (1 << 3) + 0x8000; Y = clip_u16(Y);
+                if (hasAlpha) {
+                    A = -0x40000000 + (1 << 14);
+                    for (j = 0; j < lfs; j++) A += (int)(AL(j)[i] * (unsigned)lf[j]);
+                    A >>= 15; A += 0x8000; A = clip_u16(A);
+                }
+            }
+            v[0] = (uint16_t)Y; v[1] = (uint16_t)A;
+            memcpy(dest + 4 * i, v, 4);
+        }
+    }
+#undef L
+#undef AL
+}
+
 /* ff_dither_8x8_220 (output.c:84-95, the `#if 1` variant), nine rows */
 static const uint8_t dither_8x8_220[9][8] = {
     { 117,  62, 158, 103, 113,  58, 155, 100 }, {  34, 199,  21, 186,  31, 196,  17, 182 }, { 144,  89, 131,  76, 141,  86, 127,  72 },
@@ -3137,7 +3209,14 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
         P.alp = malloc((size_t)srcH * dstW * sizeof(int32_t));
         for (y = 0; y < srcH; y++) {
             const uint8_t *line;
-            if (sf == ORF_RGBA64LE || sf == ORF_BGRA64LE) { /* rgba64leToA_c: the 16-bit A sample as is */
+            if (sf == ORF_YA8) { /* uyvyToY_c on the alpha byte (input.c:2773-2775) */
+                for (int i = 0; i < srcW; i++) t0[i] = src[0][(ptrdiff_t)y * srcStride[0] + 2 * i + 1];
+                line = t0;
+            } else if (sf == ORF_YA16LE) { /* read_ya16le_alpha_c input.c:639-645 */
+                uint16_t *d16 = (uint16_t *)t0;
+                for (int i = 0; i < srcW; i++) memcpy(&d16[i], src[0] + (ptrdiff_t)y * srcStride[0] + 4 * i + 2, 2);
+                line = t0;
+            } else if (sf == ORF_RGBA64LE || sf == ORF_BGRA64LE) { /* rgba64leToA_c: the 16-bit A sample as is */
                 const uint16_t *sp = (const uint16_t *)(src[0] + (ptrdiff_t)y * srcStride[0]) + 3;
                 uint16_t *d16 = (uint16_t *)t0;
                 for (int i = 0; i < srcW; i++) d16[i] = sp[4 * i];
@@ -3181,7 +3260,7 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
         const int chrDstY = y >> c->chrDstVSub;
         const uint8_t *lumDither = should_dither ? dither_8x8_128[y & 7] : pb_64;       /* swscale.c:385-387, :519-522 */
         const uint8_t *chrDither = should_dither ? dither_8x8_128[chrDstY & 7] : pb_64;
-        if (isGray(df)) { /* vscale.c:219-233: luma only */
+        if (isGray(df) && !isYA(df)) { /* vscale.c:219-233: luma only */
             int firstLum = ORMAX(1 - c->vLumFilterSize, c->vLumFilterPos[y]);
             write_planar_line(c, dst[0] + (size_t)y * dstStride[0], dstW, P.lum, dstW, srcH, firstLum,
                               c->vLumFilter + y * c->vLumFilterSize, c->vLumFilterSize, lumDither, 0, 1);
@@ -3212,6 +3291,8 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
                                       c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither, 3, 0);
                 }
             }
+        } else if (isYA(df)) {
+            write_ya_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
         } else if (isMono(df)) {
             write_mono_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
         } else if (isPackedHi(df)) {

@@ -50,6 +50,7 @@ enum {
     ORF_XV36BE = 215, ORF_XV36LE = 216, ORF_XV48BE = 241, ORF_XV48LE = 242,
     ORF_X2RGB10LE = 193, ORF_X2BGR10LE = 195,
     ORF_YUVA420P9LE = 81, ORF_YUVA420P9BE = 80, ORF_YUVA420P10LE = 87, ORF_YUVA420P10BE = 86, ORF_YUVA420P16LE = 93, ORF_YUVA420P16BE = 92, ORF_YUVA422P9LE = 83, ORF_YUVA422P9BE = 82, ORF_YUVA422P10LE = 89, ORF_YUVA422P10BE = 88, ORF_YUVA422P12LE = 185, ORF_YUVA422P12BE = 184, ORF_YUVA422P16LE = 95, ORF_YUVA422P16BE = 94, ORF_YUVA444P9LE = 85, ORF_YUVA444P9BE = 84, ORF_YUVA444P10LE = 91, ORF_YUVA444P10BE = 90, ORF_YUVA444P12LE = 187, ORF_YUVA444P12BE = 186, ORF_YUVA444P16LE = 97, ORF_YUVA444P16BE = 96,
+    ORF_YA8 = 56, ORF_YA16BE = 109, ORF_YA16LE = 110,
     ORF_GRAYF32BE = 182, ORF_GRAYF32LE = 183,
     ORF_MONOWHITE = 9, ORF_MONOBLACK = 10, ORF_XYZ12LE = 99, ORF_XYZ12BE = 100,
     ORF_YUVJ411P = 138, ORF_NV20LE = 102, ORF_NV20BE = 103, ORF_GBRP10MSBBE = 262, ORF_GBRP10MSBLE = 263, ORF_GBRP12MSBBE = 264, ORF_GBRP12MSBLE = 265,

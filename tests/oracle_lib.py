@@ -18,7 +18,7 @@ _FORMATS = {
     "yuva420p": (33, "planara", 1, 1, 1), "yuva422p": (78, "planara", 1, 0, 1), "yuva444p": (79, "planara", 0, 0, 1),
     "yuv410p": (6, "planar", 2, 2, 1), "yuv411p": (7, "planar", 2, 0, 1), "yuv440p": (31, "planar", 0, 1, 1),
     "yuva420p9le": (81, "planara", 1, 1, 2), "yuva420p10le": (87, "planara", 1, 1, 2), "yuva420p16le": (93, "planara", 1, 1, 2), "yuva422p9le": (83, "planara", 1, 0, 2), "yuva422p10le": (89, "planara", 1, 0, 2), "yuva422p12le": (185, "planara", 1, 0, 2), "yuva422p16le": (95, "planara", 1, 0, 2), "yuva444p9le": (85, "planara", 0, 0, 2), "yuva444p10le": (91, "planara", 0, 0, 2), "yuva444p12le": (187, "planara", 0, 0, 2), "yuva444p16le": (97, "planara", 0, 0, 2),
-    "grayf32le": (183, "gray", 0, 0, 4),
+    "grayf32le": (183, "gray", 0, 0, 4), "ya8": (56, "packed", 0, 0, 2), "ya16le": (110, "packed", 0, 0, 4),
     "yuvj440p": (32, "planar", 0, 1, 1), "monow": (9, "mono", 0, 0, 1), "monob": (10, "mono", 0, 0, 1), "xyz12le": (99, "packed", 0, 0, 6), "yuvj411p": (138, "planar", 2, 0, 1), "nv20le": (102, "semi", 1, 0, 2),
     "gbrp10msble": (263, "rgbp", 0, 0, 2), "gbrp12msble": (265, "rgbp", 0, 0, 2),
     "yuv420p9le": (60, "planar", 1, 1, 2), "yuv422p9le": (70, "planar", 1, 0, 2), "yuv444p9le": (66, "planar", 0, 0, 2),
@@ -52,7 +52,7 @@ _FORMATS = {
 }
 
 # big-endian twins: same layout as the little-endian format, AVPixelFormat value from libavutil/pixfmt.h
-_BE_VALUES = {"grayf32be": 182, "yuva420p9be": 80, "yuva420p10be": 86, "yuva420p16be": 92, "yuva422p9be": 82, "yuva422p10be": 88, "yuva422p12be": 184, "yuva422p16be": 94, "yuva444p9be": 84, "yuva444p10be": 90, "yuva444p12be": 186, "yuva444p16be": 96, "xyz12be": 100, "nv20be": 103, "gbrp10msbbe": 262, "gbrp12msbbe": 264, "xv36be": 215, "xv48be": 241, "ayuv64be": 156, "yuv444p10msbbe": 258, "yuv444p12msbbe": 260, "rgb565be": 36, "rgb555be": 38, "rgb444be": 53, "bgr565be": 40, "bgr555be": 42, "bgr444be": 55, "yuv420p9be": 59, "yuv420p10be": 61, "yuv420p12be": 122, "yuv420p14be": 124, "yuv420p16be": 46, "yuv422p9be": 69, "yuv422p10be": 63, "yuv422p12be": 126, "yuv422p14be": 128, "yuv422p16be": 48, "yuv444p9be": 65, "yuv444p10be": 67, "yuv444p12be": 130, "yuv444p14be": 132, "yuv444p16be": 50, "yuv440p10be": 152, "yuv440p12be": 154, "gray9be": 172, "gray10be": 167, "gray12be": 165, "gray14be": 180, "gray16be": 29, "gbrp9be": 72, "gbrp10be": 74, "gbrp12be": 134, "gbrp14be": 136, "gbrp16be": 76, "gbrpf32be": 174, "p010be": 159, "p012be": 210, "p016be": 170, "p210be": 197, "p212be": 221, "p216be": 201, "p410be": 199, "p412be": 223, "p416be": 203, "rgb48be": 34, "bgr48be": 57, "rgba64be": 104, "bgra64be": 106}
+_BE_VALUES = {"ya16be": 109, "grayf32be": 182, "yuva420p9be": 80, "yuva420p10be": 86, "yuva420p16be": 92, "yuva422p9be": 82, "yuva422p10be": 88, "yuva422p12be": 184, "yuva422p16be": 94, "yuva444p9be": 84, "yuva444p10be": 90, "yuva444p12be": 186, "yuva444p16be": 96, "xyz12be": 100, "nv20be": 103, "gbrp10msbbe": 262, "gbrp12msbbe": 264, "xv36be": 215, "xv48be": 241, "ayuv64be": 156, "yuv444p10msbbe": 258, "yuv444p12msbbe": 260, "rgb565be": 36, "rgb555be": 38, "rgb444be": 53, "bgr565be": 40, "bgr555be": 42, "bgr444be": 55, "yuv420p9be": 59, "yuv420p10be": 61, "yuv420p12be": 122, "yuv420p14be": 124, "yuv420p16be": 46, "yuv422p9be": 69, "yuv422p10be": 63, "yuv422p12be": 126, "yuv422p14be": 128, "yuv422p16be": 48, "yuv444p9be": 65, "yuv444p10be": 67, "yuv444p12be": 130, "yuv444p14be": 132, "yuv444p16be": 50, "yuv440p10be": 152, "yuv440p12be": 154, "gray9be": 172, "gray10be": 167, "gray12be": 165, "gray14be": 180, "gray16be": 29, "gbrp9be": 72, "gbrp10be": 74, "gbrp12be": 134, "gbrp14be": 136, "gbrp16be": 76, "gbrpf32be": 174, "p010be": 159, "p012be": 210, "p016be": 170, "p210be": 197, "p212be": 221, "p216be": 201, "p410be": 199, "p412be": 223, "p416be": 203, "rgb48be": 34, "bgr48be": 57, "rgba64be": 104, "bgra64be": 106}
 for _n, _v in list(_BE_VALUES.items()):
     _le = _FORMATS[_n[:-2] + "le"]
     _FORMATS[_n] = (_v,) + _le[1:]

@@ -102,7 +102,7 @@ MSB = ["yuv444p10msble", "yuv444p12msble", "yuv444p10msbbe"]
 RGB30 = ["x2rgb10le", "x2bgr10le"]
 YUVA_N = ["yuva420p9le", "yuva420p10le", "yuva420p16le", "yuva422p9le", "yuva422p10le", "yuva422p12le", "yuva422p16le", "yuva444p9le", "yuva444p10le",
           "yuva444p12le", "yuva444p16le", "yuva420p10be", "yuva422p12be", "yuva444p16be", "yuva444p9be"]
-MISC7 = ["grayf32le", "grayf32be", "monob", "monow", "xyz12le", "xyz12be", "yuvj411p", "nv20le", "nv20be", "gbrp10msble", "gbrp12msble", "gbrp10msbbe", "gbrp12msbbe"]
+MISC7 = ["ya8", "ya16le", "ya16be", "grayf32le", "grayf32be", "monob", "monow", "xyz12le", "xyz12be", "yuvj411p", "nv20le", "nv20be", "gbrp10msble", "gbrp12msble", "gbrp10msbbe", "gbrp12msbbe"]
 RGB_LOW = ["rgb565le", "bgr565le", "rgb555le", "bgr555le", "rgb444le", "bgr444le", "rgb565be", "bgr555be"]
 FORMAT_MATRIX_SRC = YUVA_N + MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
 FORMAT_MATRIX_DST = YUVA_N + MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
@@ -177,6 +177,7 @@ def _slice_ptrs(frame, fmt, y0):
 
 
 SLICED_UNSCALED = [
+    ("ya8", "ya8", BX), ("ya16le", "ya16le", 0), ("ya16be", "ya16le", BX),
     ("gray8", "grayf32le", BX), ("grayf32le", "gray8", 0), ("grayf32le", "grayf32le", BX), ("grayf32be", "grayf32le", 0),
     ("yuva420p10le", "yuva420p10le", BX), ("yuva444p16le", "yuva444p", 0), ("yuva420p", "yuva420p12le" if False else "yuva420p16le", BX), ("yuv422p", "yuva422p10le", 0),
     ("yuva444p12le", "yuv444p9le", BX), ("yuva420p9le", "yuva420p10be", 0), ("yuva422p16be", "yuva422p12le", BX), ("yuv444p10le", "yuva444p10le", 0),
