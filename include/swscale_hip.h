@@ -23,6 +23,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden and the reference's version script (libswscale/libswscale.v:
+ * only sws_* and swscale_* are exported); everything declared in this header is public */
+#pragma GCC visibility push(default)
 
 /* ---- libavutil/pixfmt.h enum AVPixelFormat (numeric values are ABI) ---- */
 #ifndef AVUTIL_PIXFMT_H
@@ -234,9 +237,10 @@ int sws_getColorspaceDetails(SwsContext *c, int **inv_table, int *srcRange, int 
 /* ---- the hot path ---- */
 /* swscale.h:583.  Returns the number of output rows written (>= 0) or a negative
  * AVERROR: EINVAL for NULL arguments / bad slice geometry / bad plane pointers
- * (libswscale/swscale.c:1041-1070), ENOSYS-style AVERROR(ENOTSUP) for slice-wise
- * calls on the scaled path (round-1 limitation), AVERROR_EXTERNAL for
- * HIP failures. */
+ * (libswscale/swscale.c:1041-1070), AVERROR_EXTERNAL for HIP failures.  Slices are
+ * accepted in order, top-down or bottom-up, on every path (scaled path: the slices
+ * are assembled on the device and each call returns the row count the reference's
+ * cursor gives, swscale.c:372-381, :566). */
 int sws_scale(SwsContext *c, const uint8_t *const srcSlice[], const int srcStride[],
               int srcSliceY, int srcSliceH, uint8_t *const dst[], const int dstStride[]);
 
@@ -255,11 +259,18 @@ typedef struct SwsFrameView {
 /* swscale.h:439 (legacy-initialised contexts only: frame props must match the context) */
 int sws_scale_frame(SwsContext *c, SwsFrameView *dst, const SwsFrameView *src);
 
-/* NEW (SURVEY.md 8b): nb_frames independent sws_scale_frame() calls with identical
- * results, executed as ONE batched launch per kernel on this context's GPU/stream.
- * Frames must be HBM-resident for the zero-copy path; host frames are staged.
+/* NEW (SURVEY.md 8b, 8e): nb_frames independent sws_scale_frame() calls with identical
+ * results, sharded over the GPUs of the node inside the library: a frame that lives
+ * in HBM is converted on the GPU that holds it (ONE batched launch set per GPU, on
+ * that GPU's stream, launches issued on every GPU before anything is waited for);
+ * frames in host memory are dealt round-robin over the GPUs and staged by one host
+ * thread per GPU.  Each GPU gets its own copy of the context's tables at first use.
+ * Asynchronous for HBM-resident frames: sws_hip_sync() waits for all GPUs.
  * Returns nb_frames on success or a negative AVERROR. */
 int sws_scale_frames(SwsContext *c, SwsFrameView *const dst[], const SwsFrameView *const src[], int nb_frames);
+/* the partition rule of sws_scale_frames() as a pure function: src_device[i] / dst_device[i] = GPU that holds the
+ * frame's source / destination (-1 = host memory); out_device[i] = GPU that converts frame i */
+int sws_hip_plan_shards(int nb_frames, const int *src_device, const int *dst_device, int nb_devices, int home, int *out_device);
 
 /* ---- the rest of the reference's exported API (swscale.h) ---- */
 const void *sws_get_class(void);                                            /* swscale.h:71 (const AVClass *) */
@@ -291,7 +302,8 @@ void sws_convertPalette8ToPacked24(const uint8_t *src, uint8_t *dst, int num_pix
  *      libavutil/hwcontext_internal.h:29-99 HWContextType, model
  *      libavutil/hwcontext_cuda.c:132-197, :523-655) ---- */
 int   sws_hip_device_count(void);
-int   sws_hip_set_device(SwsContext *c, int device);       /* device_create/derive */
+int   sws_hip_set_device(SwsContext *c, int device);       /* device_create/derive: the context's home GPU */
+int   sws_hip_get_device(SwsContext *c);
 int   sws_hip_set_stream(SwsContext *c, void *hip_stream); /* use caller's hipStream_t (NULL = context-owned) */
 void *sws_hip_get_stream(SwsContext *c);
 int   sws_hip_sync(SwsContext *c);
@@ -317,6 +329,10 @@ int    sws_hip_get_filter(const SwsContext *c, int which, const int16_t **filter
 int    sws_hip_get_tables(const SwsContext *c, int32_t rgb2yuv[9], int yuv2rgb[6], uint32_t range_coeff[2], int64_t range_offset[2]);
 double sws_hip_last_kernel_ms(SwsContext *c);         /* HIP-event time of the last timed launch (see below) */
 int    sws_hip_set_timing(SwsContext *c, int enable); /* record hipEvents around each launch on the context's stream */
+/* launch heuristics ("strip_min_w", "rgb_march_waves", "max_devices", "no_strip", ...): every setting gives the same bytes */
+int    sws_hip_set_option(SwsContext *c, const char *name, int value);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

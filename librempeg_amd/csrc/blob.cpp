@@ -22,10 +22,13 @@ struct Reader {
     template <typename T> void vec(std::vector<T> &v) { uint64_t n = 0; pod(n); if (!ok || n > (1u << 28)) { ok = false; return; } v.resize(n); if (n) get(v.data(), n * sizeof(T)); }
 };
 const uint32_t kBlobMagic = 0x53574254; // 'SWBT'
+const uint32_t kBlobVersion = 2;        // layout version of the records below; exporter and importer must be the same build family
 
 void write_ctx(Writer &w, const SwsInternal *c)
 {
     w.pod(kBlobMagic);
+    const uint32_t hdr[4] = { kBlobVersion, (uint32_t)sizeof(SwsContext), (uint32_t)sizeof(Yuv2RgbLut), (uint32_t)sizeof(RangeConv) };
+    w.put(hdr, sizeof(hdr));
     w.pod(c->opts);
     int32_t ints[] = { c->src0Alpha, c->dst0Alpha, c->brightness, c->contrast, c->saturation, c->dstFormatBpp, c->srcFormatBpp,
                        c->chrSrcHSubSample, c->chrSrcVSubSample, c->chrDstHSubSample, c->chrDstVSubSample,
@@ -51,6 +54,9 @@ bool read_ctx(Reader &r, SwsInternal *c)
 {
     uint32_t magic = 0; r.pod(magic);
     if (!r.ok || magic != kBlobMagic) return false;
+    uint32_t hdr[4] = { 0, 0, 0, 0 };
+    r.get(hdr, sizeof(hdr));
+    if (!r.ok || hdr[0] != kBlobVersion || hdr[1] != sizeof(SwsContext) || hdr[2] != sizeof(Yuv2RgbLut) || hdr[3] != sizeof(RangeConv)) return false;
     const void *cls = c->opts.av_class; void *opaque = c->opts.opaque;
     r.pod(c->opts);
     c->opts.av_class = cls; c->opts.opaque = opaque;   // process-local pointers are not transported
@@ -77,6 +83,29 @@ bool read_ctx(Reader &r, SwsInternal *c)
     uint8_t has[2] = { 0, 0 };
     r.get(has, 2);
     if (!r.ok) return false;
+    // a truncated or foreign blob must not turn into out-of-bounds reads in the kernels or in scale_slice(): check every invariant
+    // the launch planner relies on
+    if ((int)c->plan < PLAN_NONE || (int)c->plan > PLAN_CASCADE) return false;
+    if (!pix_desc(c->opts.src_format) || !pix_desc(c->opts.dst_format)) return false;
+    if (c->opts.src_w < 1 || c->opts.src_h < 1 || c->opts.dst_w < 1 || c->opts.dst_h < 1) return false;
+    if (c->plan == PLAN_MAIN) {
+        struct { const FilterBank *b; int count, src; bool horizontal; } want[4] = {
+            { &c->hLum, c->opts.dst_w, c->opts.src_w, true }, { &c->hChr, c->chrDstW, c->chrSrcW, true },
+            { &c->vLum, c->opts.dst_h, c->opts.src_h, false }, { &c->vChr, c->chrDstH, c->chrSrcH, false } };
+        if (c->chrSrcW < 1 || c->chrSrcH < 1 || c->chrDstW < 1 || c->chrDstH < 1) return false;
+        for (const auto &e : want) {
+            const FilterBank &b = *e.b;
+            if (b.size < 1 || b.size > 4096 || b.count != e.count) return false;
+            if (b.taps.size() < (size_t)b.size * (size_t)b.count || b.pos.size() < (size_t)b.count) return false;
+            for (int i = 0; i < b.count; i++) {
+                const int pos = b.pos[(size_t)i];
+                // horizontal windows are read unclamped: inside the line (initFilter folds border taps, utils.c:519-560); vertical
+                // windows are clamped row by row (max(1 - size, pos), min(row, last)): they only have to touch the picture
+                if (e.horizontal ? (pos < 0 || pos + b.size > e.src) : (pos < 1 - b.size || pos > e.src - 1)) return false;
+            }
+        }
+    }
+    if (c->plan == PLAN_CASCADE && (!has[0] || !has[1] || !pix_desc(c->cascade_fmt) || c->cascade_w < 1 || c->cascade_h < 1)) return false;
     for (int i = 0; i < 2; i++) {
         if (c->cascade[i]) { sws_freeContext(&c->cascade[i]->opts); c->cascade[i] = nullptr; }
         if (has[i]) {
@@ -86,7 +115,7 @@ bool read_ctx(Reader &r, SwsInternal *c)
             if (!read_ctx(r, c->cascade[i])) return false;
         }
     }
-    c->tables_dirty = true;
+    mark_tables_dirty(c);
     return r.ok;
 }
 } // namespace

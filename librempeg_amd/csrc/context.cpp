@@ -323,6 +323,10 @@ int init_single_context(SwsInternal *c)
         return SWS_AVERROR(ENOTSUP);
     }
     c->needAlpha = isALPHA(srcFormat) && isALPHA(dstFormat);                    // :1746
+    if (o->alpha_blend != SWS_ALPHA_BLEND_NONE && isALPHA(srcFormat) && !isALPHA(dstFormat)) {   // utils.c:1565-1615, alphablend.c
+        log_msg(c, 0, "alpha blending (alpha_blend=%d, %s -> %s) is not implemented on the HIP path\n", (int)o->alpha_blend, ds->name, dd->name);
+        return SWS_AVERROR(ENOTSUP);
+    }
 
     c->plan = PLAN_NONE;
     const bool usesHFilter = c->srcVec[0].size() > 1 || c->srcVec[2].size() > 1 || c->dstVecLen[0] > 1 || c->dstVecLen[2] > 1;   // :1256-1263
@@ -439,7 +443,7 @@ static int init_context_impl(SwsInternal *c, SwsFilter *srcFilter, SwsFilter *ds
     c->opts.dst_range |= jpeg_alias(&c->opts.dst_format);
     int ret = init_single_context(c);
     if (ret < 0) return ret;
-    c->tables_dirty = true;
+    mark_tables_dirty(c);
     return 0;
 }
 
@@ -450,6 +454,13 @@ int init_from_frames(SwsInternal *c, int sw, int sh, int sfmt, int dw, int dh, i
     if (c->dynamic_init && o.src_w == sw && o.src_h == sh && o.dst_w == dw && o.dst_h == dh &&
         o.src_format == canonical_pix_fmt(sfmt) && o.dst_format == canonical_pix_fmt(dfmt) &&
         src_tags_match(c, sfmt) && dst_tags_match(c, dfmt)) return 0;
+    // The yuvj / gray aliasing of the previous configuration ORed 1 into the range fields (utils.c:1903-1904): unless the caller has
+    // changed them since, this configuration starts from the values the caller set, not from the aliased ones
+    if (c->dynamic_init) {
+        if (o.src_range == c->eff_src_range) o.src_range = c->user_src_range;
+        if (o.dst_range == c->eff_dst_range) o.dst_range = c->user_dst_range;
+    }
+    c->user_src_range = o.src_range; c->user_dst_range = o.dst_range;
     // new geometry: drop everything derived from the old one
     destroy(c->cascade[0]); destroy(c->cascade[1]);
     c->cascade[0] = c->cascade[1] = nullptr;
@@ -463,6 +474,7 @@ int init_from_frames(SwsInternal *c, int sw, int sh, int sfmt, int dw, int dh, i
     int ret = init_context_impl(c, nullptr, nullptr);
     c->legacy_init = false;       // sws_scale() keeps refusing a context that was not sws_init_context()ed (swscale.c:1633)
     c->dynamic_init = ret >= 0;
+    c->eff_src_range = o.src_range; c->eff_dst_range = o.dst_range;
     return ret;
 }
 
@@ -574,7 +586,7 @@ int sws_setColorspaceDetails(SwsContext *sws, const int inv_table[4], int srcRan
     if (need_reinit) build_range_conv(c->range, srcRange, dstRange, sws->dst_format, c->dstBpc);
     c->dstFormatBpp = pix_bits_per_pixel(dd);
     c->srcFormatBpp = pix_bits_per_pixel(ds);
-    c->tables_dirty = true;
+    mark_tables_dirty(c);
 
     if (c->cascade[0])
         return sws_setColorspaceDetails(&c->cascade[0]->opts, inv_copy, srcRange, tab_copy, dstRange, brightness, contrast, saturation);

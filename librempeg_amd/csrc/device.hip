@@ -1,53 +1,21 @@
-// HIP side of libswscale_hip: device state, table upload, kernel selection and launch, the
-// sws_scale()/sws_scale_frame()/sws_scale_frames() entry points and the hwcontext-shaped helpers.
+// HIP side of libswscale_hip: device state, table upload, launch planning, the sws_scale() / sws_scale_frame() /
+// sws_scale_frames() entry points and the hwcontext-shaped helpers.  The kernels live in the k_*.hip translation units.
 // gfx950 only; no CPU fallback: if HIP is unavailable every call fails with AVERROR_EXTERNAL.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <mutex>
+#include <thread>
 #include <vector>
 
-#include "kernels_march.hpp"
-#include "kernels_strip.hpp"
-#include "kernels_shuffle.hpp"
-#include "swsint.hpp"
-
-#define AVERROR_EXTERNAL_ (-0x20545845) /* FFERRTAG('E','X','T',' '), libavutil/error.h */
+#include "devstate.hpp"
 
 namespace swship {
-
-struct DeviceState {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    void *d_tables = nullptr; size_t tables_bytes = 0;
-    SwsDevParams params;
-    bool unity_h = false, unity_v = false;
-    bool all_x_mode = false;   // every output row uses the general yuv2rgb_X writer (vscale.c:135-169)
-    int chr_window2 = 0;       // max chroma source rows spanned by a pair of output rows (wave kernel register budget)
-    bool tile_ok = false; SwsTileGeom tileL, tileC; void *d_tilegeom = nullptr; size_t tilegeom_bytes = 0;
-    bool rgb_march_ok = false; void *d_rgbplan = nullptr; size_t rgbplan_bytes = 0; int rgb_groups = 0;   // sws_k_rgb_fused_unity_march
-    void *d_be = nullptr; size_t be_bytes = 0;   // little-endian copies of big-endian source pictures
-    void *d_xyz = nullptr; size_t xyz_bytes = 0; void *d_xyz_tab = nullptr;   // rgb48 copies of xyz12 source pictures; the four gamma LUTs
-    bool dot2_ok = false; SwsTileGeom dotL, dotC; void *d_dot2 = nullptr; size_t dot2_bytes = 0;
-    bool strip_ok = false; SwsStripGeom stripL, stripC;    // sws_k_strip_march (tables live in d_dot2)
-    bool march_ok = false; SwsMarchGeom marL, marC; void *d_march = nullptr; size_t march_bytes = 0;
-    void *scratch = nullptr; size_t scratch_bytes = 0;
-    void *stage_src = nullptr; size_t stage_src_bytes = 0;
-    void *stage_dst = nullptr; size_t stage_dst_bytes = 0;
-    SwsFramePtrs *d_frames = nullptr, *h_frames = nullptr; int frames_cap = 0, frames_valid = 0;
-    void *casc_img = nullptr; size_t casc_bytes = 0; int casc_stride = 0;
-    void *slice_img = nullptr; size_t slice_bytes = 0;   // source image assembled from sws_scale() slices (scaled path)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timing = false; bool timed = false;
-};
-
-#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
-    log_msg(c, 0, "HIP error %s at %s:%d: %s\n", hipGetErrorName(e_), __FILE__, __LINE__, #expr); \
-    (void)hipGetLastError(); return AVERROR_EXTERNAL_; } } while (0)
 
 static int ensure_dev(SwsInternal *c)
 {
@@ -65,32 +33,46 @@ static int ensure_dev(SwsInternal *c)
     return 0;
 }
 
-void dev_release(SwsInternal *c)
+// the context's state on HIP device `device`: the home state, or a peer state created on first use (sws_scale_frames() sharding)
+static DeviceState *dev_state_for(SwsInternal *c, int device)
 {
-    DeviceState *d = c->dev;
+    if (ensure_dev(c) < 0) return nullptr;
+    if (c->dev->device == device) return c->dev;
+    if (device < 0) return nullptr;
+    if ((size_t)device >= c->peers.size()) c->peers.resize((size_t)device + 1, nullptr);
+    if (!c->peers[(size_t)device]) {
+        DeviceState *d = new DeviceState();
+        std::memset(&d->params, 0, sizeof(d->params));
+        d->device = device;
+        d->timing = false;
+        c->peers[(size_t)device] = d;
+    }
+    return c->peers[(size_t)device];
+}
+
+static void dev_state_free(DeviceState *d)
+{
     if (!d) return;
     (void)hipSetDevice(d->device);
     if (d->stream && d->own_stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
     else if (d->stream) (void)hipStreamSynchronize(d->stream);
-    if (d->d_tables) (void)hipFree(d->d_tables);
-    if (d->scratch) (void)hipFree(d->scratch);
-    if (d->stage_src) (void)hipFree(d->stage_src);
-    if (d->stage_dst) (void)hipFree(d->stage_dst);
-    if (d->d_frames) (void)hipFree(d->d_frames);
+    for (void *p : { d->d_tables, d->scratch, d->stage_src, d->stage_dst, (void *)d->d_frames, d->casc_img, d->slice_img, d->d_tilegeom,
+                     d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2 })
+        if (p) (void)hipFree(p);
     if (d->h_frames) (void)hipHostFree(d->h_frames);
-    if (d->casc_img) (void)hipFree(d->casc_img);
-    if (d->slice_img) (void)hipFree(d->slice_img);
-    if (d->d_tilegeom) (void)hipFree(d->d_tilegeom);
-    if (d->d_rgbplan) (void)hipFree(d->d_rgbplan);
-    if (d->d_be) (void)hipFree(d->d_be);
-    if (d->d_xyz) (void)hipFree(d->d_xyz);
-    if (d->d_xyz_tab) (void)hipFree(d->d_xyz_tab);
-    if (d->d_dot2) (void)hipFree(d->d_dot2);
-    if (d->d_march) (void)hipFree(d->d_march);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
     delete d;
+}
+
+void dev_release(SwsInternal *c)
+{
+    if (!c->dev && c->peers.empty()) return;
+    DeviceGuard guard;
+    dev_state_free(c->dev);
     c->dev = nullptr;
+    for (DeviceState *d : c->peers) dev_state_free(d);
+    c->peers.clear();
 }
 
 static bool bank_is_identity(const FilterBank &b, int one)
@@ -140,14 +122,13 @@ static int dst_kind_of(int f)
 }
 
 // upload filter banks (one blob) and fill SwsDevParams
-int dev_prepare(SwsInternal *c)
+static int dev_prepare_on(SwsInternal *c, DeviceState *d)
 {
-    int ret = ensure_dev(c);
-    if (ret < 0) return ret;
-    DeviceState *d = c->dev;
-    if (!c->tables_dirty) return 0;
+    if (d->epoch == c->tables_epoch && d->stream) return 0;
     HIPCHK(hipSetDevice(d->device));
     if (!d->stream) { HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)); d->own_stream = true; }
+    // a rebuild rewrites plan tables that launches still in flight on the (non-blocking) stream may be reading
+    else HIPCHK(hipStreamSynchronize(d->stream));
 
     SwsDevParams &p = d->params;
     std::memset(&p, 0, sizeof(p));
@@ -332,64 +313,6 @@ int dev_prepare(SwsInternal *c)
         // the fast-bilinear chroma function weighs with (xalpha ^ 127): not the identity even at equal widths
         d->unity_h = bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14) && !p.fast_bilinear;
         d->unity_v = bank_is_identity(c->vLum, 1 << 12) && bank_is_identity(c->vChr, 1 << 12);
-        // ---- wave-marching fused kernel (sws_k_march_dot2): same coverage as the dot2 tile kernel, preferred ----
-        d->march_ok = false;
-        {
-            const bool src_ok = p.srcKind == SRCK_PLANAR8 || (p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15 && p.src_shift == 0);
-            const bool dst_ok = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010;
-            auto fs4 = [](int fs) { return (fs + 3 + 3) & ~3; };
-            auto fs2 = [](int fs) { return (fs + 2) & ~1; };
-            auto monotone = [](const FilterBank &b) { for (int i = 1; i < b.count; i++) if (b.pos[i] < b.pos[i - 1]) return false; return true; };
-            if (!d->unity_h && !p.fast_bilinear && !gray_any && src_ok && dst_ok && !p.wide && c->vLum.size >= 2 && c->vChr.size >= 2 &&
-                fs4(c->hLum.size) <= 16 && fs4(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && fs2(c->vChr.size) <= 16 &&
-                monotone(c->vLum) && monotone(c->vChr) && std::getenv("SWS_HIP_MARCH")) { // opt-in: the tile kernel is faster today
-                const int SPC = p.srcKind == SRCK_PLANAR16 ? 8 : 16;
-                std::vector<uint8_t> blob;
-                auto put = [&](const void *ptr, size_t n) { size_t o = (blob.size() + 15) & ~(size_t)15; blob.resize(o + n); std::memcpy(blob.data() + o, ptr, n); return o; };
-                auto padded = [&](const FilterBank &b, int f, int mask) {
-                    std::vector<int16_t> t((size_t)b.count * f, 0);
-                    for (int i = 0; i < b.count; i++)
-                        for (int j = 0; j < b.size; j++) t[(size_t)i * f + (b.pos[i] & mask) + j] = b.taps[(size_t)i * b.size + j];
-                    return t;
-                };
-                struct Off { size_t cs, cc, ht, vt; };
-                auto planm = [&](const FilterBank &hb, const FilterBank &vb, int W, int isChroma, SwsMarchGeom &g, Off &o) -> bool {
-                    const int hf4 = fs4(hb.size), vf2 = fs2(vb.size);
-                    const int strips = (W + 127) / 128;
-                    std::vector<int32_t> cs(strips), cc(strips);
-                    int ncmax = 0;
-                    for (int t = 0; t < strips; t++) {
-                        int lo = INT32_MAX, hi = -1;
-                        for (int x = t * 128; x < std::min(W, (t + 1) * 128); x++) { lo = std::min(lo, hb.pos[x] & ~3); hi = std::max(hi, (hb.pos[x] & ~3) + hf4); }
-                        lo = lo / SPC * SPC;
-                        cs[t] = lo; cc[t] = (hi - lo + SPC - 1) / SPC * SPC; ncmax = std::max(ncmax, cc[t]);
-                    }
-                    if (ncmax / SPC > 128) return false;
-                    g.chroma = isChroma; g.strips = strips; g.bands = 0; g.BAND = 0; g.NCmax = ncmax; g.hfs4 = hf4; g.vfs2 = vf2;
-                    o.cs = put(cs.data(), cs.size() * 4); o.cc = put(cc.data(), cc.size() * 4);
-                    const std::vector<int16_t> ht = padded(hb, hf4, 3), vt = padded(vb, vf2, 1);
-                    o.ht = put(ht.data(), ht.size() * 2); o.vt = put(vt.data(), vt.size() * 2);
-                    return true;
-                };
-                Off oL, oC;
-                if (planm(c->hLum, c->vLum, p.dstW, 0, d->marL, oL) && planm(c->hChr, c->vChr, p.chrDstW, 1, d->marC, oC)) {
-                    if (blob.size() > d->march_bytes) {
-                        if (d->d_march) HIPCHK(hipFree(d->d_march));
-                        d->d_march = nullptr;
-                        HIPCHK(hipMalloc(&d->d_march, blob.size()));
-                        d->march_bytes = blob.size();
-                    }
-                    HIPCHK(hipMemcpy(d->d_march, blob.data(), blob.size(), hipMemcpyHostToDevice));
-                    auto bind = [&](SwsMarchGeom &g, const Off &o) {
-                        const uint8_t *b = (const uint8_t *)d->d_march;
-                        g.colStart = (const int32_t *)(b + o.cs); g.colCount = (const int32_t *)(b + o.cc);
-                        g.hT4 = (const int16_t *)(b + o.ht); g.vT2 = (const int16_t *)(b + o.vt);
-                    };
-                    bind(d->marL, oL); bind(d->marC, oC);
-                    d->march_ok = true;
-                }
-            }
-        }
         // ---- dot2 tile kernel (sws_k_tile_dot2): planar 8-bit / <= 15-bit sources, 15-bit intermediates, vfs >= 2 ----
         d->dot2_ok = false;
         {
@@ -398,7 +321,7 @@ int dev_prepare(SwsInternal *c)
             auto fs2 = [](int fs) { return (fs + 2) & ~1; };
             if (!d->unity_h && !p.fast_bilinear && !gray_any && src_ok && dst_ok && !p.wide && c->vLum.size >= 2 && c->vChr.size >= 2 &&
                 fs2(c->hLum.size) <= 16 && fs2(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && fs2(c->vChr.size) <= 16 &&
-                !std::getenv("SWS_HIP_NO_DOT2")) {
+                !c->tune.no_dot2) {
                 const int SPC = p.srcKind == SRCK_PLANAR16 ? 8 : 16;
                 std::vector<uint8_t> blob;
                 auto put = [&](const void *ptr, size_t n) { size_t o = (blob.size() + 15) & ~(size_t)15; blob.resize(o + n); std::memcpy(blob.data() + o, ptr, n); return o; };
@@ -411,8 +334,7 @@ int dev_prepare(SwsInternal *c)
                 };
                 struct Off { size_t rs, rc, cs, cc, ht, vt; };
                 auto plan2 = [&](const FilterBank &hb, const FilterBank &vb, int W, int H, int ncomp, SwsTileGeom &g, Off &o) -> bool {
-                    static const int TWenv = std::getenv("SWS_HIP_TILE_TW") ? std::atoi(std::getenv("SWS_HIP_TILE_TW")) : 128;
-                    const int TW = TWenv, hf2 = fs2(hb.size), vf2 = fs2(vb.size);
+                    const int TW = 128, hf2 = fs2(hb.size), vf2 = fs2(vb.size);
                     for (int TH : { 64, 32, 16, 8, 4, 2 }) {
                         const int tX = (W + TW - 1) / TW, tY = (H + TH - 1) / TH;
                         std::vector<int32_t> rs(tY), rc(tY), cs(tX), cc(tX);
@@ -429,12 +351,12 @@ int dev_prepare(SwsInternal *c)
                             cs[t] = lo; cc[t] = (hi - lo + SPC - 1) / SPC * SPC; ncmax = std::max(ncmax, cc[t]);
                         }
                         const size_t lds = (size_t)nrmax * ncmax * 2 + (size_t)ncomp * (nrmax / 2) * TW * 4;
-                        static const int lds_budget = std::getenv("SWS_HIP_TILE_LDS_KB") ? std::atoi(std::getenv("SWS_HIP_TILE_LDS_KB")) : 40;
+                        const int lds_budget = c->tune.tile_lds_kb;
                         if (lds > (size_t)lds_budget * 1024 && TH > 2) continue;
                         if (lds > 64 * 1024) return false;
                         g.TW = TW; g.TH = TH; g.tilesX = tX; g.tilesY = tY; g.NRmax = nrmax; g.NCmax = ncmax; g.lds_bytes = (int32_t)lds;
                         g.hfs2 = hf2; g.vfs2 = vf2;
-                        g.debug = std::getenv("SWS_HIP_TILE_DEBUG") ? std::atoi(std::getenv("SWS_HIP_TILE_DEBUG")) : 0;
+                        g.debug = c->tune.debug;
                         o.rs = put(rs.data(), rs.size() * 4); o.rc = put(rc.data(), rc.size() * 4);
                         o.cs = put(cs.data(), cs.size() * 4); o.cc = put(cc.data(), cc.size() * 4);
                         const std::vector<int16_t> ht = padded(hb), vt = padded(vb);
@@ -478,11 +400,11 @@ int dev_prepare(SwsInternal *c)
                     return true;
                 };
                 SOff sL, sC;
-                static const int strip_cols_l = std::getenv("SWS_HIP_STRIP_COLS_L") ? std::atoi(std::getenv("SWS_HIP_STRIP_COLS_L")) : 4;
-                static const int strip_cols_c = std::getenv("SWS_HIP_STRIP_COLS_C") ? std::atoi(std::getenv("SWS_HIP_STRIP_COLS_C")) : 2;
+                const int strip_cols_l = c->tune.strip_cols_l == 2 ? 2 : 4;
+                const int strip_cols_c = c->tune.strip_cols_c == 1 ? 1 : 2;
                 // (narrow pictures leave most of a 256-column strip idle and pay the per-band ring fill: the tile kernel keeps them)
-                const int strip_min_w = std::getenv("SWS_HIP_STRIP_MIN_W") ? std::atoi(std::getenv("SWS_HIP_STRIP_MIN_W")) : 1024;
-                const bool strip_plan = !p.range_active && !std::getenv("SWS_HIP_NO_STRIP") && p.dstW >= strip_min_w &&
+                const int strip_min_w = c->tune.strip_min_w;
+                const bool strip_plan = !p.range_active && !c->tune.no_strip && p.dstW >= strip_min_w &&
                                         plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sL) && plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sC);
                 d->strip_ok = false;
                 Off oL, oC;
@@ -516,7 +438,7 @@ int dev_prepare(SwsInternal *c)
         // ---- fused h+v tile kernel geometry (planar / semi-planar YUV outputs, non-identity horizontal filters) ----
         d->tile_ok = false;
         if (!d->unity_h && !p.fast_bilinear && !gray_any && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16 ||
-                            p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010) && !std::getenv("SWS_HIP_NO_TILE")) {
+                            p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010) && !c->tune.no_tile) {
             const size_t hsz = p.wide ? 4 : 2;
             auto plan = [&](const FilterBank &hb, const FilterBank &vb, int W, int H, int sW, int sH, int ncomp,
                             SwsTileGeom &g, std::vector<int32_t> &arr) -> bool {
@@ -680,8 +602,6 @@ int dev_prepare(SwsInternal *c)
         } else if (d->unity_h) {
             c->path_name = "main:fused_generic_unity";
             c->kernel_name = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) ? "sws_k_vscale_rgb" : "sws_k_vscale_planar";
-        } else if (d->march_ok) {
-            c->path_name = "main:fused_march"; c->kernel_name = "sws_k_march_dot2";
         } else if (d->strip_ok) {
             c->path_name = "main:strip_march"; c->kernel_name = "sws_k_strip_march";
         } else if (d->dot2_ok) {
@@ -697,8 +617,16 @@ int dev_prepare(SwsInternal *c)
     default: c->path_name = "none"; c->kernel_name = ""; break;
     }
     log_msg(c, 2, "HIP path: %s (dominant kernel %s)\n", c->path_name.c_str(), c->kernel_name.c_str());
-    c->tables_dirty = false;
+    d->epoch = c->tables_epoch;
     return 0;
+}
+
+int dev_prepare(SwsInternal *c)
+{
+    int ret = ensure_dev(c);
+    if (ret < 0) return ret;
+    DeviceGuard guard;
+    return dev_prepare_on(c, c->dev);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -732,14 +660,17 @@ static int rows_of_slice(int format, int plane, int sliceY, int sliceH, int *y0,
     return 0;
 }
 
-static bool is_device_ptr(const void *p)
+// HIP device that owns a pointer, -1 for host memory
+static int ptr_device(const void *p)
 {
     hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeArray;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeArray) return a.device;
+    return -1;
 }
+static bool is_device_ptr(const void *p) { return ptr_device(p) >= 0; }
 
-static int grow(SwsInternal *c, void **buf, size_t *cap, size_t need)
+int grow(SwsInternal *c, void **buf, size_t *cap, size_t need)
 {
     if (need <= *cap) return 0;
     if (*buf) HIPCHK(hipFree(*buf));
@@ -759,27 +690,14 @@ static bool frames_vec_ok(const SwsFramePtrs *fr, int n)
     return true;
 }
 
-// buffer-descriptor kernels address a plane as base + 32-bit offset: strides must be positive and planes below 2 GiB
-static bool frames_desc_ok(const SwsFramePtrs *fr, int n, int srcH, int dstH)
-{
-    for (int i = 0; i < n; i++)
-        for (int k = 0; k < 4; k++) {
-            if (fr[i].src[k] && (fr[i].srcStride[k] <= 0 || (int64_t)fr[i].srcStride[k] * srcH >= (int64_t)1 << 31)) return false;
-            if (fr[i].dst[k] && (fr[i].dstStride[k] <= 0 || (int64_t)fr[i].dstStride[k] * dstH >= (int64_t)1 << 31)) return false;
-        }
-    return true;
-}
-
-static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
-
 // launch the kernels of one (non-cascaded) context over `n` device-resident frames
-static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
+static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
 {
-    DeviceState *d = c->dev;
     const SwsDevParams &p = d->params;
     hipStream_t st = d->stream;
-    SwsFrameSet fs;
-    std::memset(&fs, 0, sizeof(fs));
+    LaunchCtx L;
+    std::memset(&L.fs, 0, sizeof(L.fs));
+    SwsFrameSet &fs = L.fs;
     fs.count = n;
     if (n == 1) { fs.table = nullptr; fs.one = frames[0]; }
     else {
@@ -802,517 +720,46 @@ static int launch_plan_le(SwsInternal *c, const SwsFramePtrs *frames, int n, int
         fs.table = d->d_frames;
     }
     const bool vec = frames_vec_ok(frames, n);
-    static const bool no_wave = std::getenv("SWS_HIP_NO_WAVE") != nullptr; // A/B switch: older per-thread kernels
-    const dim3 blk(256);
+    L.c = c; L.d = d; L.p = &p; L.st = st; L.frames = frames; L.n = n; L.sliceY = sliceY; L.sliceH = sliceH; L.vec = vec;
     if (d->timing) { HIPCHK(hipEventRecord(d->ev0, st)); }
 
     // bgr24ToYv12Wrapper (:2062-2077), yvu9ToYv12Wrapper (:2079-2093), yuyv/uyvyToYuv420Wrapper (:423-470) with a yuva420p
     // destination: fillPlane(dst[3], ..., src_w, srcSliceH, srcSliceY, 255)
     if (c->opts.dst_format == AV_PIX_FMT_YUVA420P && sliceH > 0 &&
-        (c->plan == PLAN_UNSC_BGR24_YV12 || c->plan == PLAN_UNSC_YVU9_YV12 || c->plan == PLAN_UNSC_P4222PLANAR)) {
-        const dim3 gf(cdiv(p.srcW, 256), sliceH, n);
-        hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.srcW, sliceY, 0);
-    }
+        (c->plan == PLAN_UNSC_BGR24_YV12 || c->plan == PLAN_UNSC_YVU9_YV12 || c->plan == PLAN_UNSC_P4222PLANAR))
+        launch_fill_alpha(L, p.srcW, sliceY, sliceH, 0);
+    int ret = 0;
     switch (c->plan) {
-    case PLAN_UNSC_YUV2RGB: {
-        const int dstW = p.dstW;
-        const int npairs = ((dstW >> 3) << 2) + ((dstW & 4) ? 2 : 0) + ((dstW & 2) ? 1 : 0); // yuv2rgb.c:198-236
-        const int is422 = c->opts.src_format == AV_PIX_FMT_YUV422P;
-        const int nrowpairs = (sliceH + 1) >> 1; // "for (y = 0; y < srcSliceH; y += 2)"
-        const int bpr = (npairs + 3) >> 2;
-        if (!bpr || !nrowpairs) break;
-        const bool bpp4 = p.dstKind == DSTK_RGB32;
-        auto merge_alpha = [&]() {   // yuva2rgba_c / yuva2argb_c (yuv2rgb.c:524-528): source alpha into the A byte
-            if (!bpp4 || !isALPHA(c->opts.src_format)) return;
-            const dim3 ga(cdiv(2 * npairs, 256), 2 * nrowpairs, n);
-            hipLaunchKernelGGL(swsk::sws_k_alpha_merge, ga, blk, 0, st, fs, 2 * npairs, sliceY, pix_desc(c->opts.dst_format)->comp[3].offset);
-        };
-        if (vec && !no_wave) { // wave-tiled kernel: 1024 pixels x 2 rows per wave, LDS-transposed 16-byte stores
-            const int segs = (2 * npairs + 1023) >> 10;
-            const dim3 gridw(cdiv((int64_t)segs * nrowpairs, 4), 1, n);
-            const bool swap = bpp4 ? p.lut.swap_rb32 != 0 : p.lut.rgb_order != 0;
-#define LAUNCH_K1(B, S) hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled_wave<B, S>), gridw, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs)
-            if (bpp4) { if (swap) LAUNCH_K1(4, true); else LAUNCH_K1(4, false); }
-            else      { if (swap) LAUNCH_K1(3, true); else LAUNCH_K1(3, false); }
-#undef LAUNCH_K1
-            merge_alpha();
-            break;
-        }
-        const dim3 grid(cdiv((int64_t)bpr * nrowpairs, 256), 1, n);
-        if (bpp4 && vec) hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled<4, true>), grid, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
-        else if (bpp4) hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled<4, false>), grid, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
-        else if (vec) hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled<3, true>), grid, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
-        else hipLaunchKernelGGL((swsk::sws_k_yuv2rgb_unscaled<3, false>), grid, blk, 0, st, fs, p, is422, npairs, sliceY, nrowpairs);
-        merge_alpha();
-        break;
-    }
+    case PLAN_UNSC_YUV2RGB: ret = launch_yuv2rgb(L); break;
     case PLAN_UNSC_P01X:
-    case PLAN_UNSC_8_P01X: {
-        const int rows = sliceH + ((sliceH + 1) >> 1);
-        const dim3 grid(cdiv(cdiv(p.srcW, 8), 256), rows, n);
-        const bool s8 = c->plan == PLAN_UNSC_8_P01X;
-        static const int p01x_ch = std::getenv("SWS_HIP_P01X_CH") ? std::atoi(std::getenv("SWS_HIP_P01X_CH")) : 1;
-        if (!s8 && vec && p01x_ch > 0) {   // streaming form: CH x 16 bytes per lane, wave-contiguous
-            const int row_chunks = cdiv(2 * p.srcW, 16);
-            if (p01x_ch == 4) { const dim3 g4(cdiv(row_chunks, 4 * 256), rows, n);
-                                hipLaunchKernelGGL((swsk::sws_k_p01x_stream<4>), g4, blk, 0, st, fs, p, sliceY, sliceH); }
-            else if (p01x_ch == 1) { const dim3 g1(cdiv(row_chunks, 256), rows, n);
-                                hipLaunchKernelGGL((swsk::sws_k_p01x_stream<1>), g1, blk, 0, st, fs, p, sliceY, sliceH); }
-            else { const dim3 g2(cdiv(row_chunks, 2 * 256), rows, n);
-                   hipLaunchKernelGGL((swsk::sws_k_p01x_stream<2>), g2, blk, 0, st, fs, p, sliceY, sliceH); }
-            break;
-        }
-        if (s8 && vec) hipLaunchKernelGGL((swsk::sws_k_p01x_unscaled<true, true>), grid, blk, 0, st, fs, p, sliceY, sliceH);
-        else if (s8) hipLaunchKernelGGL((swsk::sws_k_p01x_unscaled<true, false>), grid, blk, 0, st, fs, p, sliceY, sliceH);
-        else if (vec) hipLaunchKernelGGL((swsk::sws_k_p01x_unscaled<false, true>), grid, blk, 0, st, fs, p, sliceY, sliceH);
-        else hipLaunchKernelGGL((swsk::sws_k_p01x_unscaled<false, false>), grid, blk, 0, st, fs, p, sliceY, sliceH);
-        break;
-    }
-    case PLAN_UNSC_PLANAR2NV12:
-    case PLAN_UNSC_NV122PLANAR:
-    case PLAN_UNSC_PLANAR2NV24:
-    case PLAN_UNSC_NV242PLANAR:
-    case PLAN_UNSC_NV242YUV420:
-    case PLAN_UNSC_YVU9_YV12:
-    case PLAN_UNSC_PLANARCOPY: {
-        swsk::MiscPlan plan;
-        std::memset(&plan, 0, sizeof(plan));
-        int maxw = 0, rows = 0;
-        if (c->plan == PLAN_UNSC_PLANAR2NV24 || c->plan == PLAN_UNSC_NV242PLANAR) {       // 4:4:4: chroma rows == luma rows
-            plan.mode = c->plan == PLAN_UNSC_PLANAR2NV24 ? 0 : 1;
-            plan.nplanes = 2;
-            plan.pl[0] = { 0, 0, p.srcW, sliceH, sliceY, 1, 0, 0 };
-            plan.pl[1] = { 1, 1, c->chrSrcW, sliceH, sliceY, 1, 0, 1 };
-        } else if (c->plan == PLAN_UNSC_NV242YUV420) {                                     // nv24_to_yuv420p_chroma (:229-251)
-            plan.mode = 3;
-            plan.nplanes = 2;
-            plan.aux = sliceH;                                                             // odd last row repeats itself
-            plan.pl[0] = { 0, 0, p.srcW, sliceH, sliceY, 1, 0, 0 };
-            plan.pl[1] = { 1, 1, p.srcW / 2, (sliceH + 1) / 2, sliceY / 2, 1, 0, 1 };
-        } else if (c->plan == PLAN_UNSC_YVU9_YV12) {                                       // planar2x_c per slice (:2079-2093)
-            plan.mode = 4;
-            plan.nplanes = 3;
-            plan.aux = sliceH >> 2;                                                        // source chroma rows of the slice
-            plan.aux2 = c->chrSrcW;
-            // planar2x writes 2*chrSrcW columns, one more than chrDstW when srcW % 4 is 1 or 2; only the visible ones are produced
-            const int cwv = std::min(2 * c->chrSrcW, c->chrDstW);
-            plan.pl[1] = { 1, 1, cwv, 2 * (sliceH >> 2), sliceY >> 1, 1, 0, 1 };
-            plan.pl[0] = { 0, 0, p.srcW, sliceH, sliceY, 1, 0, 0 };
-            plan.pl[2] = { 2, 2, cwv, 2 * (sliceH >> 2), sliceY >> 1, 1, 0, 1 };
-        } else if (c->plan != PLAN_UNSC_PLANARCOPY) {
-            plan.mode = c->plan == PLAN_UNSC_PLANAR2NV12 ? 0 : 1;
-            plan.nplanes = 2;
-            plan.pl[0] = { 0, 0, p.srcW, sliceH, sliceY, 1, 0, 0 };
-            plan.pl[1] = { 1, 1, c->chrSrcW, (sliceH + 1) / 2, sliceY / 2, 1, 0, 1 };
-        } else {
-            plan.mode = 2;
-            const PixDesc *ds = pix_desc(c->opts.src_format), *dd = pix_desc(c->opts.dst_format);
-            // equal layouts are row memcpy in the reference, except 9..14-bit formats which always take the
-            // depth-conversion branch (swscale_unscaled.c:2246-2248) and re-replicate the top bits
-            const bool same = ds->comp[0].depth == dd->comp[0].depth && ds->comp[0].shift == dd->comp[0].shift &&
-                              !isNBPS(c->opts.src_format) && !isNBPS(c->opts.dst_format);
-            plan.bytecopy = same;
-            const int np = pix_nb_planes(dd);
-            plan.nplanes = np;
-            for (int pl = 0; pl < np; pl++) {
-                int len = pl == 0 ? p.srcW : -((-p.srcW) >> c->chrDstHSubSample);
-                const int y0 = pl == 0 ? sliceY : -((-sliceY) >> c->chrDstVSubSample);
-                const int h = pl == 0 ? sliceH : -((-sliceH) >> c->chrDstVSubSample);
-                if (pl == 1 && isSemiPlanarYUV(c->opts.dst_format)) len *= 2;
-                if (same) len *= (ds->comp[0].depth + 7) / 8;  // byte copy: width counts bytes
-                const int shiftonly = pl == 1 || pl == 2 || (!c->opts.src_range && pl == 0);
-                const bool missing = pl > 0 && isGray(c->opts.src_format);   // fillPlane / fillPlane16 (:2239-2247); width in samples
-                if (missing && same) len /= (ds->comp[0].depth + 7) / 8;
-                if (pl == 3) {   // alpha plane (:2226-2247): full size, converted like luma with shiftonly = 0 when the source has one, all ones otherwise
-                    const int bytes = same ? (ds->comp[0].depth + 7) / 8 : 1;
-                    plan.pl[pl] = { isALPHA(c->opts.src_format) ? 3 : -2, 3, isALPHA(c->opts.src_format) ? p.srcW * bytes : p.srcW, sliceH, sliceY, 1, 0, 0 };
-                    continue;
-                }
-                plan.pl[pl] = { missing ? -1 : pl, pl, len, h, y0, 1, shiftonly, pl != 0 };
-            }
-        }
-        for (int i = 0; i < plan.nplanes; i++) { maxw = std::max(maxw, plan.pl[i].width); rows += plan.pl[i].rows; }
-        if (!maxw || !rows) break;
-        const dim3 grid(cdiv(maxw, 256), rows, n);
-        hipLaunchKernelGGL(swsk::sws_k_planar_misc, grid, blk, 0, st, fs, p, plan);
-        break;
-    }
-    case PLAN_UNSC_RGB2RGB: {
-        const PixDesc *ds = pix_desc(c->opts.src_format), *dd = pix_desc(c->opts.dst_format);
-        swsk::ShufflePlan sp;
-        std::memset(&sp, 0, sizeof(sp));
-        sp.src_step = ds->comp[0].step; sp.dst_step = dd->comp[0].step;
-        for (int k = 0; k < 4; k++) {
-            sp.spos[k] = k < ds->nb_components ? ds->comp[k].offset : -1;
-            sp.dpos[k] = k < dd->nb_components ? dd->comp[k].offset : -1;
-        }
-        // swscale.c:1106-1124: an rgb0-style source feeding a real alpha channel is made opaque first
-        sp.opaque = c->src0Alpha && !c->dst0Alpha && isALPHA(c->opts.dst_format);
-        const bool s3 = sp.src_step == 3, d3 = sp.dst_step == 3;
-        static const int off3[4] = { 0, 3, 2, 1 };   // where pixel i of a 12-byte group starts inside its dword pair
-        for (int i = 0; i < 4; i++) {
-            uint32_t sel = 0;
-            const int base = s3 ? off3[i] : 0;
-            for (int j = 0; j < 4; j++) {
-                uint32_t b = 0x0c;                    // unused byte -> 0
-                for (int k = 0; k < 4; k++)
-                    if (sp.dpos[k] == j) b = (k == 3 && (sp.spos[3] < 0 || sp.opaque)) ? 0x0du : (uint32_t)(base + sp.spos[k]);
-                sel |= b << (8 * j);
-            }
-            sp.sel[i] = sel;
-        }
-        const dim3 grid(cdiv(cdiv(p.srcW, 4), 256), sliceH, n);
-        if (s3 && d3) hipLaunchKernelGGL((swsk::sws_k_rgb_shuffle<true, true>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
-        else if (s3) hipLaunchKernelGGL((swsk::sws_k_rgb_shuffle<true, false>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
-        else if (d3) hipLaunchKernelGGL((swsk::sws_k_rgb_shuffle<false, true>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
-        else hipLaunchKernelGGL((swsk::sws_k_rgb_shuffle<false, false>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
-        break;
-    }
-    case PLAN_UNSC_YUV2GBRP: {
-        const int dstW = p.dstW;
-        const int npairs = ((dstW >> 3) << 2) + ((dstW & 4) ? 2 : 0) + ((dstW & 2) ? 1 : 0); // yuv2rgb.c:198-236
-        const int nrowpairs = (sliceH + 1) >> 1;
-        if (!npairs || !nrowpairs) break;
-        const dim3 grid(cdiv(npairs, 256), nrowpairs, n);
-        hipLaunchKernelGGL(swsk::sws_k_yuv2gbrp_unscaled, grid, blk, 0, st, fs, p, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 0, npairs, sliceY);
-        break;
-    }
-    case PLAN_UNSC_RGB16SHUFFLE:
-    case PLAN_UNSC_PACKED16_GBRP16:
-    case PLAN_UNSC_GBRP16_PACKED16: {
-        const PixDesc *ds = pix_desc(c->opts.src_format), *dd = pix_desc(c->opts.dst_format);
-        swsk::Rgb16Plan rp;
-        std::memset(&rp, 0, sizeof(rp));
-        rp.mode = c->plan == PLAN_UNSC_RGB16SHUFFLE ? 0 : c->plan == PLAN_UNSC_PACKED16_GBRP16 ? 1 : 2;
-        rp.sstep = ds->comp[0].step / 2; rp.dstep = dd->comp[0].step / 2;
-        for (int k = 0; k < 3; k++) {
-            rp.spos[k] = rp.mode == 2 ? ds->comp[k].plane : ds->comp[k].offset / 2;
-            rp.dpos[k] = rp.mode == 1 ? dd->comp[k].plane : dd->comp[k].offset / 2;
-        }
-        rp.depth = rp.mode == 1 ? dd->comp[0].depth : ds->comp[0].depth;
-        const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
-        hipLaunchKernelGGL(swsk::sws_k_rgb16_convert, grid, blk, 0, st, fs, rp, p.srcW, sliceY);
-        break;
-    }
-    case PLAN_UNSC_U8_TO_F32:
-    case PLAN_UNSC_F32_TO_U8: {
-        const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
-        hipLaunchKernelGGL(swsk::sws_k_gray_f32, grid, blk, 0, st, fs, p.srcW, sliceY, c->plan == PLAN_UNSC_U8_TO_F32 ? 1 : 0);
-        break;
-    }
-    case PLAN_UNSC_YUV2MONO: {
-        const int nbytes = (p.dstW + 7) >> 3, nrowpairs = (sliceH + 1) >> 1;
-        if (!nrowpairs) break;
-        // g = table_gU[128] + table_gV[128] (yuv2rgb.c:460): the closed form's green index for U = V = 128
-        const SwsLutParams &L = p.lut;
-        const int gidx = L.base_g + (int)(((int64_t)128 * L.cgu) >> 16) + (int)(((int64_t)128 * L.cgv) >> 16);
-        const dim3 grid(cdiv(nbytes, 256), nrowpairs, n);
-        hipLaunchKernelGGL(swsk::sws_k_yuv2mono_unscaled, grid, blk, 0, st, fs, p, gidx, sliceY);
-        break;
-    }
-    case PLAN_UNSC_RGB30_TO_16:
-    case PLAN_UNSC_RGB30_TO_GBRP:
-    case PLAN_UNSC_GBRP_TO_RGB30: {
-        const PixDesc *ds = pix_desc(c->opts.src_format), *dd = pix_desc(c->opts.dst_format);
-        swsk::Rgb30Plan rp;
-        std::memset(&rp, 0, sizeof(rp));
-        rp.mode = c->plan == PLAN_UNSC_RGB30_TO_16 ? 0 : c->plan == PLAN_UNSC_RGB30_TO_GBRP ? 1 : 2;
-        rp.x2rgb = (rp.mode == 2 ? c->opts.dst_format : c->opts.src_format) == AV_PIX_FMT_X2RGB10LE;
-        rp.dstep = dd->comp[0].step / 2;
-        for (int k = 0; k < 3; k++) rp.pos[k] = rp.mode == 0 ? dd->comp[k].offset / 2 : rp.mode == 1 ? dd->comp[k].plane : ds->comp[k].plane;
-        if (rp.mode == 1) { rp.hi = dd->comp[0].depth - 10; rp.lo = 10 - rp.hi; rp.shift = dd->comp[0].shift; }
-        if (rp.mode == 2) rp.shift = ds->comp[0].depth + ds->comp[0].shift - 10;
-        const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
-        hipLaunchKernelGGL(swsk::sws_k_rgb30_convert, grid, blk, 0, st, fs, rp, p.srcW, sliceY);
-        break;
-    }
-    case PLAN_UNSC_YUV2RGB48: {
-        const int dstW = p.dstW;
-        const int npairs = ((dstW >> 3) << 2) + ((dstW & 4) ? 2 : 0) + ((dstW & 2) ? 1 : 0); // yuv2rgb.c:198-236
-        const int nrowpairs = (sliceH + 1) >> 1;
-        if (!npairs || !nrowpairs) break;
-        const dim3 grid(cdiv(npairs, 256), nrowpairs, n);
-        hipLaunchKernelGGL(swsk::sws_k_yuv2rgb48_unscaled, grid, blk, 0, st, fs, p, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 0, npairs, sliceY);
-        break;
-    }
-    case PLAN_UNSC_YUV2RGB16: {
-        const int dstW = p.dstW;
-        const int npairs = ((dstW >> 3) << 2) + ((dstW & 4) ? 2 : 0) + ((dstW & 2) ? 1 : 0); // yuv2rgb.c:198-236
-        const int nrowpairs = (sliceH + 1) >> 1;
-        if (!npairs || !nrowpairs) break;
-        const dim3 grid(cdiv(npairs, 256), nrowpairs, n);
-        hipLaunchKernelGGL(swsk::sws_k_yuv2rgb16_unscaled, grid, blk, 0, st, fs, p, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 0, npairs, sliceY);
-        break;
-    }
-    case PLAN_UNSC_RGBLOW: {
-        const int sf = c->opts.src_format, df = c->opts.dst_format;
-        auto rgbint = [](int f) { return f == AV_PIX_FMT_RGB24 || f == AV_PIX_FMT_BGRA || f == AV_PIX_FMT_ABGR || f == AV_PIX_FMT_RGB565LE ||
-                                         f == AV_PIX_FMT_RGB555LE || f == AV_PIX_FMT_RGB444LE; };
-        swsk::RgbLowPlan rp;
-        rp.sid = pix_bits_per_pixel(pix_desc(sf)); rp.did = pix_bits_per_pixel(pix_desc(df));
-        rp.same = rgbint(sf) == rgbint(df) ? 1 : 0;
-        rp.s_alt = (sf == AV_PIX_FMT_ABGR || sf == AV_PIX_FMT_ARGB) ? 1 : 0;
-        rp.d_alt = (df == AV_PIX_FMT_ABGR || df == AV_PIX_FMT_ARGB) ? 1 : 0;
-        if (!p.srcW || !sliceH) break;
-        const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
-        hipLaunchKernelGGL(swsk::sws_k_rgb_low_convert, grid, blk, 0, st, fs, rp, p.srcW, sliceY);
-        break;
-    }
-    case PLAN_UNSC_PLANAR2P422: {
-        const int npairs = p.srcW >> 1;
-        if (!npairs || !sliceH) break;
-        const dim3 grid(cdiv(npairs, 256), sliceH, n);
-        hipLaunchKernelGGL(swsk::sws_k_planar_to_p422, grid, blk, 0, st, fs, p, npairs, sliceY, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 2);
-        break;
-    }
-    case PLAN_UNSC_P4222PLANAR: {
-        const dim3 grid(cdiv((p.srcW + 1) >> 1, 256), sliceH, n);
-        hipLaunchKernelGGL(swsk::sws_k_p422_to_planar, grid, blk, 0, st, fs, p, p.srcW, sliceY, c->opts.dst_format != AV_PIX_FMT_YUV422P ? 1 : 0);
-        break;
-    }
-    case PLAN_UNSC_PACKED_GBRP: {
-        const PixDesc *ds = pix_desc(c->opts.src_format);
-        swsk::ShufflePlan sp;
-        std::memset(&sp, 0, sizeof(sp));
-        sp.src_step = ds->comp[0].step;
-        for (int k = 0; k < 4; k++) sp.spos[k] = k < ds->nb_components ? ds->comp[k].offset : -1;
-        const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
-        hipLaunchKernelGGL(swsk::sws_k_packed_to_gbrp, grid, blk, 0, st, fs, sp, p.srcW, sliceY);
-        break;
-    }
-    case PLAN_UNSC_GBRP_PACKED: {
-        const PixDesc *dd = pix_desc(c->opts.dst_format);
-        swsk::ShufflePlan sp;
-        std::memset(&sp, 0, sizeof(sp));
-        for (int k = 0; k < 4; k++) sp.dpos[k] = k < dd->nb_components ? dd->comp[k].offset : -1;
-        const dim3 grid(cdiv(cdiv(p.srcW, 4), 256), sliceH, n);
-        if (dd->comp[0].step == 3) hipLaunchKernelGGL((swsk::sws_k_gbrp_to_packed<true>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
-        else hipLaunchKernelGGL((swsk::sws_k_gbrp_to_packed<false>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
-        break;
-    }
-    case PLAN_UNSC_BGR24_YV12: {
-        const dim3 grid(cdiv(cdiv(p.srcW >> 1, 4), 256), (sliceH + 1) / 2, n);
-        if (p.srcW >> 1) hipLaunchKernelGGL(swsk::sws_k_bgr24_to_yv12, grid, blk, 0, st, fs, p, sliceY, sliceH);
-        break;
-    }
-    case PLAN_UNSC_PACKEDCOPY: {
-        const PixDesc *ds = pix_desc(c->opts.src_format);
-        // the reference copies as many multiples of src_w bytes as fit into both strides (:2138-2157), i.e. the whole visible row:
-        // for the packed 4:2:2 layouts that is a whole number of pixel pairs
-        const int row_bytes = p.srcKind == SRCK_MONO ? (p.srcW + 7) >> 3 :
-                              ds->log2_chroma_w ? ((p.srcW + 1) >> 1) * 2 * ds->comp[0].step : p.srcW * ds->comp[0].step;
-        const bool opaque = c->src0Alpha && !c->dst0Alpha && isALPHA(c->opts.dst_format);
-        const dim3 grid(cdiv(cdiv(row_bytes, 16), 256), sliceH, n);
-        hipLaunchKernelGGL(swsk::sws_k_packed_copy, grid, blk, 0, st, fs, row_bytes, sliceY, opaque ? ds->comp[3].offset : -1);
-        break;
-    }
+    case PLAN_UNSC_8_P01X: ret = launch_p01x(L); break;
     case PLAN_MAIN: {
-        if (p.dst_alpha_fill) {   // swscale.c:536-552
-            const dim3 gf(cdiv(p.dstW, 256), p.dstH, n);
-            hipLaunchKernelGGL(swsk::sws_k_fill_alpha_plane, gf, blk, 0, st, fs, p.dstW, 0, p.dst_bits > 8 ? p.dst_bits : 0);
-        }
-        const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 ||
-                         p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI || p.dstKind == DSTK_RGB48 || p.dstKind == DSTK_RGB16 || p.dstKind == DSTK_RGB30 || p.dstKind == DSTK_MONO || p.dstKind == DSTK_YA;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
+        if (p.dst_alpha_fill) launch_fill_alpha(L, p.dstW, 0, p.dstH, p.dst_bits > 8 ? p.dst_bits : 0);   // swscale.c:536-552
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
-        if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
-            const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;
-            if (vec && !no_wave && d->all_x_mode && d->chr_window2 <= 8 && p.vChrFs <= 64) { // wave-tiled kernel: 1024 pixels x 2 rows per wave
-                constexpr int ROWS = 2;
-                const int segs = (p.dstW + 1023) >> 10, rgroups = (p.dstH + ROWS - 1) / ROWS;
-                const dim3 gridw((cdiv((int64_t)segs * rgroups, 4) + 7) & ~7u, 1, n); // multiple of 8: XCD-aware order
-                const bool swap = b4 ? p.lut.swap_rb32 != 0 : p.lut.rgb_order != 0;
-                static const bool v1 = std::getenv("SWS_HIP_FUSED_V1") != nullptr;   // previous generations, kept for A/B measurements
-                static const bool v2 = std::getenv("SWS_HIP_FUSED_V2") != nullptr;
-                const bool afirst = b4 && p.lut.perm32 == 0x02010003u;
-                const bool ncr6 = d->chr_window2 <= 6;      // rows of chroma a pair of output rows spans: 3 or 4 row pairs
-                if (d->rgb_march_ok && !v1 && !v2 && frames_desc_ok(frames, n, p.srcH, p.dstH)) {
-                    // one resident round: 4 waves per SIMD on 1024 SIMDs; bands of at least 8 row pairs
-                    static const int target = std::getenv("SWS_HIP_RGB_MARCH_WAVES") ? std::atoi(std::getenv("SWS_HIP_RGB_MARCH_WAVES")) : 12288;
-                    const int groups = d->rgb_groups;
-                    int bands = std::max(1, std::min(target / std::max(1, segs * n), (groups + 7) / 8));
-                    int band_groups = (groups + bands - 1) / bands;
-                    bands = (groups + band_groups - 1) / band_groups;
-                    const dim3 gm(cdiv((int64_t)segs * bands, 4), 1, n);
-                    const SwsRgbGroupPlan *plan = (const SwsRgbGroupPlan *)d->d_rgbplan;
-                    static const int mexp = std::getenv("SWS_HIP_RGB_MARCH_EXP") ? std::atoi(std::getenv("SWS_HIP_RGB_MARCH_EXP")) : 0;
-                    if (mexp && !b4 && !nv && !swap && ncr6) {     // profiling experiments on the C2b instantiation only (results are wrong)
-                        if (mexp == 1) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_march<3, false, false, false, 6, 1>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups);
-                        if (mexp == 2) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_march<3, false, false, false, 6, 2>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups);
-                        if (mexp == 3) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_march<3, false, false, false, 6, 3>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups);
-                        break;
-                    }
-#define LAUNCH_MARCH(B, S, N, A) do { if (ncr6) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_march<B, S, N, A, 6>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups); \
-                                      else hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_march<B, S, N, A, 8>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups); } while (0)
-                    if (b4) { if (afirst) { if (nv) { if (swap) LAUNCH_MARCH(4, true, true, true); else LAUNCH_MARCH(4, false, true, true); }
-                                            else    { if (swap) LAUNCH_MARCH(4, true, false, true); else LAUNCH_MARCH(4, false, false, true); } }
-                              else        { if (nv) { if (swap) LAUNCH_MARCH(4, true, true, false); else LAUNCH_MARCH(4, false, true, false); }
-                                            else    { if (swap) LAUNCH_MARCH(4, true, false, false); else LAUNCH_MARCH(4, false, false, false); } } }
-                    else    { if (nv) { if (swap) LAUNCH_MARCH(3, true, true, false); else LAUNCH_MARCH(3, false, true, false); }
-                              else    { if (swap) LAUNCH_MARCH(3, true, false, false); else LAUNCH_MARCH(3, false, false, false); } }
-#undef LAUNCH_MARCH
-                    break;
-                }
-#define LAUNCH_WAVE(B, S, N) do { if (v1) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave<B, S, N, ROWS, 8>), gridw, blk, 0, st, fs, p); \
-                                  else if (B == 4 && afirst) { if (ncr6) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave2<B, S, N, B == 4, ROWS, 6>), gridw, blk, 0, st, fs, p); \
-                                                              else hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave2<B, S, N, B == 4, ROWS, 8>), gridw, blk, 0, st, fs, p); } \
-                                  else { if (ncr6) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave2<B, S, N, false, ROWS, 6>), gridw, blk, 0, st, fs, p); \
-                                         else hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_wave2<B, S, N, false, ROWS, 8>), gridw, blk, 0, st, fs, p); } } while (0)
-                if (b4) { if (nv) { if (swap) LAUNCH_WAVE(4, true, true); else LAUNCH_WAVE(4, false, true); }
-                          else    { if (swap) LAUNCH_WAVE(4, true, false); else LAUNCH_WAVE(4, false, false); } }
-                else    { if (nv) { if (swap) LAUNCH_WAVE(3, true, true); else LAUNCH_WAVE(3, false, true); }
-                          else    { if (swap) LAUNCH_WAVE(3, true, false); else LAUNCH_WAVE(3, false, false); } }
-#undef LAUNCH_WAVE
-                break;
-            }
-            const int npairs = (p.dstW + 1) >> 1, bpr = (npairs + 3) >> 2;
-            const dim3 grid(cdiv((int64_t)bpr * p.dstH, 256), 1, n);
-#define LAUNCH_FUSED(B, N, V) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity<B, N, V>), grid, blk, 0, st, fs, p)
-            if (b4) { if (nv) { if (vec) LAUNCH_FUSED(4, true, true); else LAUNCH_FUSED(4, true, false); }
-                      else    { if (vec) LAUNCH_FUSED(4, false, true); else LAUNCH_FUSED(4, false, false); } }
-            else    { if (nv) { if (vec) LAUNCH_FUSED(3, true, true); else LAUNCH_FUSED(3, true, false); }
-                      else    { if (vec) LAUNCH_FUSED(3, false, true); else LAUNCH_FUSED(3, false, false); } }
-#undef LAUNCH_FUSED
-            break;
-        }
-        if (vec && d->unity_h && d->unity_v && !p.no_chroma && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 && p.dst_shift == 0 &&
-            (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16)) {
-            const dim3 g(cdiv((int64_t)((p.srcW + 7) >> 3) * p.srcH, 256), 1, n);
-            hipLaunchKernelGGL(swsk::sws_k_f32rgb_to_yuv444_unity, g, blk, 0, st, fs, p);
-            break;
-        }
-        if (d->march_ok && vec) { // wave-marching fused kernel: one launch for luma, one for chroma
-            const bool semi = p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010 || p.dstKind == DSTK_P016;
-            auto launch = [&](SwsMarchGeom g, int H, int ncomp, int ydim) {
-                const int64_t per_band_row = (int64_t)g.strips * n * ydim;
-                static const int target = std::getenv("SWS_HIP_MARCH_WAVES") ? std::atoi(std::getenv("SWS_HIP_MARCH_WAVES")) : 4096;
-                int band = (int)std::min<int64_t>(128, std::max<int64_t>(8, (int64_t)H * per_band_row / target));
-                band &= ~7;
-                g.BAND = band; g.bands = (H + band - 1) / band;
-                const int wave_dw = ncomp * (4 * (g.NCmax >> 1)) + ncomp * swsk::MARCH_RING * 128;
-                const size_t lds = (size_t)4 * wave_dw * 4;
-                const dim3 grid(cdiv((int64_t)g.strips * g.bands, 4), ydim, n);
-                const bool s16 = p.srcKind == SRCK_PLANAR16;
-                if (ncomp == 1) { if (s16) hipLaunchKernelGGL((swsk::sws_k_march_dot2<true, 1>), grid, blk, lds, st, fs, p, g);
-                                  else     hipLaunchKernelGGL((swsk::sws_k_march_dot2<false, 1>), grid, blk, lds, st, fs, p, g); }
-                else            { if (s16) hipLaunchKernelGGL((swsk::sws_k_march_dot2<true, 2>), grid, blk, lds, st, fs, p, g);
-                                  else     hipLaunchKernelGGL((swsk::sws_k_march_dot2<false, 2>), grid, blk, lds, st, fs, p, g); }
-            };
-            launch(d->marL, p.dstH, 1, 1);
-            if (semi) launch(d->marC, p.chrDstH, 2, 1); else launch(d->marC, p.chrDstH, 1, 2);
-            break;
-        }
-        if (d->strip_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) { // marching strip kernel: one launch for luma, one for chroma
-            static const int target = std::getenv("SWS_HIP_STRIP_WAVES") ? std::atoi(std::getenv("SWS_HIP_STRIP_WAVES")) : 4096;
-            const bool s16 = p.srcKind == SRCK_PLANAR16;
-            auto launch = [&](SwsStripGeom g, int H, bool chroma) {
-                int bands = std::max(1, std::min(target / std::max(1, g.strips * n), (H + 15) / 16));
-                g.debug = std::getenv("SWS_HIP_STRIP_DEBUG") ? std::atoi(std::getenv("SWS_HIP_STRIP_DEBUG")) : 0;
-                g.band_rows = (H + bands - 1) / bands;
-                g.bands = (H + g.band_rows - 1) / g.band_rows;
-                const dim3 grid(cdiv((int64_t)g.strips * g.bands, 4), 1, n);
-#define SWS_STRIP(S, C, K) hipLaunchKernelGGL((swsk::sws_k_strip_march<S, C, K>), grid, blk, g.lds_bytes, st, fs, p, g)
-                const int cols = g.TW / 64;
-                if (chroma) { if (s16) { if (cols == 1) SWS_STRIP(true, true, 1); else SWS_STRIP(true, true, 2); }
-                              else     { if (cols == 1) SWS_STRIP(false, true, 1); else SWS_STRIP(false, true, 2); } }
-                else        { if (s16) { if (cols == 2) SWS_STRIP(true, false, 2); else SWS_STRIP(true, false, 4); }
-                              else     { if (cols == 2) SWS_STRIP(false, false, 2); else SWS_STRIP(false, false, 4); } }
-#undef SWS_STRIP
-            };
-            launch(d->stripL, p.dstH, false);
-            launch(d->stripC, p.chrDstH, true);
-            break;
-        }
-        if (d->dot2_ok && vec) { // dot2 LDS-tile kernel: one launch for luma, one for chroma
-            const dim3 gl(d->dotL.tilesX, d->dotL.tilesY, n), gc(d->dotC.tilesX, d->dotC.tilesY, n);
-            static const int NT = std::getenv("SWS_HIP_TILE_THREADS") ? std::atoi(std::getenv("SWS_HIP_TILE_THREADS")) : 256;
-            const bool s16 = p.srcKind == SRCK_PLANAR16;
-#define LAUNCH_T(N) do { const dim3 b(N); \
-    if (s16) { hipLaunchKernelGGL((swsk::sws_k_tile_dot2<true, false, N>), gl, b, d->dotL.lds_bytes, st, fs, p, d->dotL); \
-               hipLaunchKernelGGL((swsk::sws_k_tile_dot2<true, true, N>), gc, b, d->dotC.lds_bytes, st, fs, p, d->dotC); } \
-    else     { hipLaunchKernelGGL((swsk::sws_k_tile_dot2<false, false, N>), gl, b, d->dotL.lds_bytes, st, fs, p, d->dotL); \
-               hipLaunchKernelGGL((swsk::sws_k_tile_dot2<false, true, N>), gc, b, d->dotC.lds_bytes, st, fs, p, d->dotC); } } while (0)
-            if (NT == 512) LAUNCH_T(512); else if (NT == 1024) LAUNCH_T(1024); else LAUNCH_T(256);
-#undef LAUNCH_T
-            break;
-        }
-        if (d->tile_ok) { // fused h+v LDS-tile kernel: one launch for luma, one for chroma
-            const dim3 gl(d->tileL.tilesX, d->tileL.tilesY, n), gc(d->tileC.tilesX, d->tileC.tilesY, n);
-            if (p.wide) {
-                hipLaunchKernelGGL((swsk::sws_k_tile_planar<int32_t, false>), gl, blk, d->tileL.lds_bytes, st, fs, p, d->tileL);
-                hipLaunchKernelGGL((swsk::sws_k_tile_planar<int32_t, true>), gc, blk, d->tileC.lds_bytes, st, fs, p, d->tileC);
-            } else {
-                hipLaunchKernelGGL((swsk::sws_k_tile_planar<int16_t, false>), gl, blk, d->tileL.lds_bytes, st, fs, p, d->tileL);
-                hipLaunchKernelGGL((swsk::sws_k_tile_planar<int16_t, true>), gc, blk, d->tileC.lds_bytes, st, fs, p, d->tileC);
-            }
-            break;
-        }
-        // generic: optional pass 1 into scratch, then writers
-        const int64_t lumElems = (int64_t)p.srcH * p.dstW, chrElems = (int64_t)p.chrSrcH * p.chrDstW;
-        const int64_t frame_elems = lumElems + 2 * chrElems + (p.need_alpha ? lumElems : 0);
-        const size_t esz = p.wide ? 4 : 2;
-        const bool direct = d->unity_h;
-        int chunk = n;
-        if (!direct) {
-            const size_t budget = (size_t)2 << 30; // scratch budget per launch group
-            chunk = (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(budget / (frame_elems * esz))));
-            int r = grow(c, &d->scratch, &d->scratch_bytes, (size_t)frame_elems * esz * chunk);
-            if (r < 0) return r;
-        }
-        for (int f0 = 0; f0 < n; f0 += chunk) {
-            const int m = std::min(chunk, n - f0);
-            SwsFrameSet sub = fs;
-            sub.count = m;
-            if (n == 1) sub.one = frames[0]; else sub.table = d->d_frames + f0;
-            if (!direct) {
-                const int maxW = std::max(p.dstW, p.chrDstW), maxH = std::max(p.srcH, p.chrSrcH);
-                const dim3 g1(cdiv(maxW, 256), maxH, (p.need_alpha ? 4 : 3) * m);
-                if (p.wide) hipLaunchKernelGGL((swsk::sws_k_hscale<int32_t>), g1, blk, 0, st, sub, p, (int32_t *)d->scratch, frame_elems);
-                else hipLaunchKernelGGL((swsk::sws_k_hscale<int16_t>), g1, blk, 0, st, sub, p, (int16_t *)d->scratch, frame_elems);
-            }
-#define LAUNCH_W(K, G, ...) do { \
-    if (direct) hipLaunchKernelGGL((swsk::K<true, int16_t>), G, blk, 0, st, sub, p, (const int16_t *)nullptr, frame_elems, ##__VA_ARGS__); \
-    else if (p.wide) hipLaunchKernelGGL((swsk::K<false, int32_t>), G, blk, 0, st, sub, p, (const int32_t *)d->scratch, frame_elems, ##__VA_ARGS__); \
-    else hipLaunchKernelGGL((swsk::K<false, int16_t>), G, blk, 0, st, sub, p, (const int16_t *)d->scratch, frame_elems, ##__VA_ARGS__); } while (0)
-            if (rgb) {
-                const int units = p.dstKind == DSTK_MONO ? (p.dstW + 7) >> 3 : (p.full_chr || p.dstKind == DSTK_YA) ? p.dstW : (p.dstW + 1) >> 1;
-                const dim3 g(cdiv(units, 256), p.dstH, m);
-                LAUNCH_W(sws_k_vscale_rgb, g);
-            } else if (p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010 || p.dstKind == DSTK_P016) {
-                const dim3 gl(cdiv(p.dstW, 256), p.dstH, m);
-                LAUNCH_W(sws_k_vscale_planar, gl, 1);
-                const dim3 gc(cdiv(p.chrDstW, 256), p.chrDstH, m);
-                LAUNCH_W(sws_k_vscale_nvchroma, gc);
-            } else {
-                const int ncomp = isGray(c->opts.dst_format) ? 1 : (p.need_alpha ? 4 : 3); // vscale.c:219-233 (gray: luma only), :59-71 (alpha)
-                const dim3 g(cdiv(std::max(p.dstW, p.chrDstW), 256), std::max(p.dstH, p.chrDstH), ncomp * m);
-                LAUNCH_W(sws_k_vscale_planar, g, ncomp);
-            }
-#undef LAUNCH_W
-        }
+        if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12))
+            ret = launch_rgb_unity(L);
+        else if (vec && d->unity_h && d->unity_v && !p.no_chroma && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 && p.dst_shift == 0 &&
+                 (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16))
+            ret = launch_f32rgb(L);
+        else if (d->strip_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_strip(L);   // marching strip kernel
+        else if (d->dot2_ok && vec) ret = launch_tile_dot2(L);                                              // dot2 LDS-tile kernel
+        else if (d->tile_ok) ret = launch_tile(L);                                                          // fused h+v LDS-tile kernel
+        else ret = launch_generic(L);                                                                       // optional pass 1 into scratch, then writers
         break;
     }
-    default:
+    case PLAN_NONE:
+    case PLAN_CASCADE:
         log_msg(c, 0, "internal error: no execution plan\n");
         return SWS_AVERROR(EINVAL);
+    default: ret = launch_misc(L); break;
     }
+    if (ret < 0) return ret;
     HIPCHK(hipGetLastError());
     if (d->timing) { HIPCHK(hipEventRecord(d->ev1, st)); d->timed = true; }
     return 0;
 }
 
 static int image_layout(int format, int w, int h, int align, int linesize[4], size_t offset[4], size_t *total);
-// ---- big-endian pictures: byte-swap passes around the little-endian conversion (context.cpp: be_alias) ----
-namespace swsk {
-__global__ void __launch_bounds__(256) sws_k_bswap(const uint8_t *src, int64_t sstride, uint8_t *dst, int64_t dstride, int rows, int row_bytes, int unit)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (y >= rows || (i + 1) * unit > row_bytes) return;
-    const uint8_t *s = src + y * sstride + (int64_t)i * unit;
-    uint8_t *d = dst + y * dstride + (int64_t)i * unit;
-    if (unit == 2) { const uint16_t v = *(const uint16_t *)s; *(uint16_t *)d = (uint16_t)((v >> 8) | (v << 8)); }
-    else { const uint32_t v = *(const uint32_t *)s; *(uint32_t *)d = __builtin_bswap32(v); }
-}
-} // namespace swsk
 
 // rows and visible bytes per row of plane k of a picture
 static void plane_extent(const PixDesc *d, int w, int h, int k, int *rows, int *row_bytes, int *vsub)
@@ -1336,12 +783,11 @@ static void plane_extent(const PixDesc *d, int w, int h, int k, int *rows, int *
 // sws_scale's XYZ stages (swscale.c:1126-1139, :1194-1210): an xyz12 source slice is converted into an rgb48 scratch picture first
 // (xyz12Torgb48_c :745-802), the written rows of an xyz12 destination are converted in place afterwards (rgb48Toxyz12_c :804-861);
 // both are skipped for xyz12 -> xyz12 at equal sizes.  Gamma LUTs as init_xyz_tables (utils.c:709-733) builds them, from libm pow().
-static int launch_plan_xyz(SwsInternal *c, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
+static int launch_plan_xyz(SwsInternal *c, DeviceState *d, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
 {
     const SwsContext &o = c->opts;
     if ((!c->srcXYZ && !c->dstXYZ) || (c->srcXYZ && c->dstXYZ && o.src_w == o.dst_w && o.src_h == o.dst_h))
-        return launch_plan_le(c, frames, n, sliceY, sliceH);
-    DeviceState *d = c->dev;
+        return launch_plan_le(c, d, frames, n, sliceY, sliceH);
     hipStream_t st = d->stream;
     if (!d->d_xyz_tab) {
         static std::vector<uint16_t> tab;   // xyzgamma[4096], rgbgammainv[4096], rgbgamma[65536], xyzgammainv[65536]
@@ -1376,32 +822,27 @@ static int launch_plan_xyz(SwsInternal *c, const SwsFramePtrs *frames, int n, in
         for (int i = 0; i < n; i++) {
             uint8_t *scr = (uint8_t *)d->d_xyz + (size_t)i * total;
             const int y1 = std::min(o.src_h, sliceY + sliceH);
-            if (y1 > sliceY) {
-                const dim3 grid(cdiv(o.src_w, 256), y1 - sliceY);
-                hipLaunchKernelGGL(::swsk::sws_k_xyz12, grid, blk, 0, st, frames[i].src[0] + (int64_t)sliceY * frames[i].srcStride[0], (int64_t)frames[i].srcStride[0],
-                                   scr + (int64_t)sliceY * ls, (int64_t)ls, o.src_w, T, T + 8192, 1);
-            }
+            if (y1 > sliceY)
+                launch_xyz12(st, frames[i].src[0] + (int64_t)sliceY * frames[i].srcStride[0], (int64_t)frames[i].srcStride[0],
+                             scr + (int64_t)sliceY * ls, (int64_t)ls, o.src_w, y1 - sliceY, T, T + 8192, 1);
             fr[i].src[0] = scr; fr[i].srcStride[0] = ls;
         }
     }
-    int ret = launch_plan_le(c, fr.data(), n, sliceY, sliceH);
+    int ret = launch_plan_le(c, d, fr.data(), n, sliceY, sliceH);
     if (ret >= 0 && c->dstXYZ) {
         const bool whole = c->plan == PLAN_MAIN || c->plan == PLAN_CASCADE || (sliceY == 0 && sliceH == o.src_h);
         const int y0 = whole ? 0 : sliceY, y1 = whole ? o.dst_h : std::min(o.dst_h, sliceY + sliceH);
         for (int i = 0; i < n && y1 > y0; i++) {
             uint8_t *p0 = frames[i].dst[0] + (int64_t)y0 * frames[i].dstStride[0];
-            const dim3 grid(cdiv(o.dst_w, 256), y1 - y0);
-            hipLaunchKernelGGL(::swsk::sws_k_xyz12, grid, blk, 0, st, p0, (int64_t)frames[i].dstStride[0], p0, (int64_t)frames[i].dstStride[0], o.dst_w,
-                               T + 4096, T + 8192 + 65536, 0);
+            launch_xyz12(st, p0, (int64_t)frames[i].dstStride[0], p0, (int64_t)frames[i].dstStride[0], o.dst_w, y1 - y0, T + 4096, T + 8192 + 65536, 0);
         }
     }
     return ret;
 }
 
-static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
+static int launch_plan(SwsInternal *c, DeviceState *d, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
 {
-    if (!c->srcBE && !c->dstBE) return launch_plan_xyz(c, frames, n, sliceY, sliceH);
-    DeviceState *d = c->dev;
+    if (!c->srcBE && !c->dstBE) return launch_plan_xyz(c, d, frames, n, sliceY, sliceH);
     hipStream_t st = d->stream;
     const SwsContext &o = c->opts;
     std::vector<SwsFramePtrs> fr(frames, frames + n);
@@ -1426,15 +867,13 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
                 if (!rows || !frames[i].src[k]) continue;
                 const int y0 = sliceY >> vs, y1 = std::min(rows, -((-(sliceY + sliceH)) >> vs));
                 uint8_t *scr = (uint8_t *)d->d_be + (size_t)i * total + offs[k];
-                if (y1 > y0) {
-                    const dim3 grid((rb / unit + 255) / 256, y1 - y0);
-                    hipLaunchKernelGGL(swsk::sws_k_bswap, grid, blk, 0, st, frames[i].src[k] + (int64_t)y0 * frames[i].srcStride[k],
-                                       (int64_t)frames[i].srcStride[k], scr + (int64_t)y0 * ls[k], (int64_t)ls[k], y1 - y0, rb, unit);
-                }
+                if (y1 > y0)
+                    launch_bswap(st, frames[i].src[k] + (int64_t)y0 * frames[i].srcStride[k], (int64_t)frames[i].srcStride[k],
+                                 scr + (int64_t)y0 * ls[k], (int64_t)ls[k], y1 - y0, rb, unit);
                 fr[i].src[k] = scr; fr[i].srcStride[k] = ls[k];
             }
     }
-    int ret = launch_plan_xyz(c, fr.data(), n, sliceY, sliceH);
+    int ret = launch_plan_xyz(c, d, fr.data(), n, sliceY, sliceH);
     if (ret >= 0 && c->dstBE) {
         const PixDesc *dd = pix_desc(o.dst_format);
         const int unit = (dd->flags & PIXFLAG_FLOAT) ? 4 : 2;
@@ -1447,8 +886,7 @@ static int launch_plan(SwsInternal *c, const SwsFramePtrs *frames, int n, int sl
                 const int y0 = whole ? 0 : sliceY >> vs, y1 = whole ? rows : std::min(rows, -((-(sliceY + sliceH)) >> vs));
                 if (y1 <= y0) continue;
                 uint8_t *p0 = frames[i].dst[k] + (int64_t)y0 * frames[i].dstStride[k];
-                const dim3 grid((rb / unit + 255) / 256, y1 - y0);
-                hipLaunchKernelGGL(swsk::sws_k_bswap, grid, blk, 0, st, p0, (int64_t)frames[i].dstStride[k], p0, (int64_t)frames[i].dstStride[k], y1 - y0, rb, unit);
+                launch_bswap(st, p0, (int64_t)frames[i].dstStride[k], p0, (int64_t)frames[i].dstStride[k], y1 - y0, rb, unit);
             }
     }
     return ret;
@@ -1477,57 +915,130 @@ static int image_layout(int format, int w, int h, int align, int linesize[4], si
     return 0;
 }
 
-static int run_single(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4], int sliceY, int sliceH,
+static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4], const int srcStride[4], int sliceY, int sliceH,
                       uint8_t *const dst[4], const int dstStride[4]);
+
+} // namespace swship
+
+// The partition rule of sws_scale_frames(), as a pure function so that it can be tested without GPUs:
+// a frame that lives in HBM is converted on the GPU that holds it (the two sides of a frame must not live on different GPUs: -1);
+// frames in host memory are dealt round-robin over the first `nb_devices` GPUs starting at the context's home GPU.
+extern "C" int sws_hip_plan_shards(int nb_frames, const int *src_device, const int *dst_device, int nb_devices, int home, int *out_device)
+{
+    if (nb_frames < 0 || nb_devices <= 0 || !out_device) return SWS_AVERROR(EINVAL);
+    if (home < 0 || home >= nb_devices) home = 0;
+    int rr = 0;
+    for (int i = 0; i < nb_frames; i++) {
+        const int sd = src_device ? src_device[i] : -1, dd = dst_device ? dst_device[i] : -1;
+        if (sd >= 0 && dd >= 0 && sd != dd) return SWS_AVERROR(EINVAL);
+        if (sd >= 0 || dd >= 0) out_device[i] = sd >= 0 ? sd : dd;
+        else out_device[i] = (home + rr++) % nb_devices;
+    }
+    return 0;
+}
+
+namespace swship {
 
 int dev_run(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4], int srcSliceY, int srcSliceH,
             uint8_t *const dst[4], const int dstStride[4], int nb_frames,
             const SwsFrameView *const *srcFrames, SwsFrameView *const *dstFrames)
 {
-    int ret = dev_prepare(c);
+    int ret = ensure_dev(c);
     if (ret < 0) return ret;
-    DeviceState *d = c->dev;
-    HIPCHK(hipSetDevice(d->device));
-    if (nb_frames <= 0) return run_single(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
+    DeviceGuard guard;
+    if (nb_frames <= 0) {   // sws_scale(): the home GPU, or the GPU the caller's device buffers live on
+        DeviceState *d = c->dev;
+        const int sd = ptr_device(src[0]), dd = ptr_device(dst[0]);
+        if (sd >= 0 && dd >= 0 && sd != dd) { log_msg(c, 0, "source and destination live on different GPUs\n"); return SWS_AVERROR(EINVAL); }
+        const int dev = sd >= 0 ? sd : dd;
+        if (dev >= 0 && dev != d->device) d = dev_state_for(c, dev);
+        if (!d) return AVERROR_EXTERNAL_;
+        ret = dev_prepare_on(c, d);
+        if (ret < 0) return ret;
+        HIPCHK(hipSetDevice(d->device));
+        return run_single(c, d, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
+    }
 
-    // batched: all frames device resident -> one launch set; otherwise frame by frame (host staging)
+    // ---- sws_scale_frames(): shard the independent frames over the visible GPUs ----
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
+    if (c->tune.max_devices > 0) ndev = std::max(std::min(ndev, c->tune.max_devices), c->dev->device + 1);
+    std::vector<int> sdev(nb_frames), ddev(nb_frames), owner(nb_frames);
+    for (int i = 0; i < nb_frames; i++) { sdev[i] = ptr_device(srcFrames[i]->data[0]); ddev[i] = ptr_device(dstFrames[i]->data[0]); }
+    ret = sws_hip_plan_shards(nb_frames, sdev.data(), ddev.data(), ndev, c->dev->device, owner.data());
+    if (ret < 0) { log_msg(c, 0, "sws_scale_frames(): a frame's source and destination live on different GPUs\n"); return ret; }
+
     const int nps = pix_nb_planes(pix_desc(c->opts.src_format)), npd = pix_nb_planes(pix_desc(c->opts.dst_format));
-    bool all_dev = c->plan != PLAN_CASCADE;
-    for (int i = 0; i < nb_frames && all_dev; i++)
-        all_dev = is_device_ptr(srcFrames[i]->data[0]) && is_device_ptr(dstFrames[i]->data[0]);
-    if (!all_dev) {
-        for (int i = 0; i < nb_frames; i++) {
-            ret = run_single(c, srcFrames[i]->data, srcFrames[i]->linesize, 0, c->opts.src_h, dstFrames[i]->data, dstFrames[i]->linesize);
-            if (ret < 0) return ret;
-        }
-        return nb_frames;
-    }
-    std::vector<SwsFramePtrs> fr(nb_frames);
+    // per GPU: the HBM-resident frames go out as ONE launch set on that GPU's stream; launches are issued on every GPU before
+    // anything is waited for.  Frames with a host side are staged frame by frame, one host thread per GPU.
+    std::vector<std::vector<int>> resident(ndev), staged(ndev);
     for (int i = 0; i < nb_frames; i++) {
-        std::memset(&fr[i], 0, sizeof(SwsFramePtrs));
-        for (int k = 0; k < nps; k++) { fr[i].src[k] = srcFrames[i]->data[k]; fr[i].srcStride[k] = srcFrames[i]->linesize[k]; }
-        for (int k = 0; k < npd; k++) { fr[i].dst[k] = dstFrames[i]->data[k]; fr[i].dstStride[k] = dstFrames[i]->linesize[k]; }
+        if (owner[i] >= ndev) { log_msg(c, 0, "sws_scale_frames(): frame %d lives on GPU %d, beyond the %d GPUs in use\n", i, owner[i], ndev); return SWS_AVERROR(EINVAL); }
+        const bool res = sdev[i] >= 0 && ddev[i] >= 0 && c->plan != PLAN_CASCADE;
+        (res ? resident : staged)[(size_t)owner[i]].push_back(i);
     }
-    ret = launch_plan(c, fr.data(), nb_frames, 0, c->opts.src_h);
-    return ret < 0 ? ret : nb_frames;
+    std::vector<DeviceState *> st(ndev, nullptr);
+    for (int g = 0; g < ndev; g++) {
+        if (resident[g].empty() && staged[g].empty()) continue;
+        st[g] = dev_state_for(c, g);
+        if (!st[g]) return AVERROR_EXTERNAL_;
+        ret = dev_prepare_on(c, st[g]);     // first use on a GPU: its own copy of the tables (one H2D copy of the blob per GPU)
+        if (ret < 0) return ret;
+    }
+    for (int g = 0; g < ndev; g++) {
+        if (resident[g].empty()) continue;
+        HIPCHK(hipSetDevice(g));
+        std::vector<SwsFramePtrs> fr(resident[g].size());
+        for (size_t j = 0; j < fr.size(); j++) {
+            const int i = resident[g][j];
+            std::memset(&fr[j], 0, sizeof(SwsFramePtrs));
+            for (int k = 0; k < nps; k++) { fr[j].src[k] = srcFrames[i]->data[k]; fr[j].srcStride[k] = srcFrames[i]->linesize[k]; }
+            for (int k = 0; k < npd; k++) { fr[j].dst[k] = dstFrames[i]->data[k]; fr[j].dstStride[k] = dstFrames[i]->linesize[k]; }
+        }
+        ret = launch_plan(c, st[g], fr.data(), (int)fr.size(), 0, c->opts.src_h);
+        if (ret < 0) return ret;
+    }
+    int nthreads = 0;
+    for (int g = 0; g < ndev; g++) nthreads += !staged[g].empty();
+    auto run_staged = [&](int g) -> int {
+        if (hipSetDevice(g) != hipSuccess) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
+        for (int i : staged[g]) {
+            int r = run_single(c, st[g], srcFrames[i]->data, srcFrames[i]->linesize, 0, c->opts.src_h, dstFrames[i]->data, dstFrames[i]->linesize);
+            if (r < 0) return r;
+        }
+        return 0;
+    };
+    if (nthreads <= 1) {
+        for (int g = 0; g < ndev; g++) if (!staged[g].empty()) { ret = run_staged(g); if (ret < 0) return ret; }
+    } else {
+        std::vector<std::thread> th;
+        std::vector<int> rc(ndev, 0);
+        for (int g = 0; g < ndev; g++) if (!staged[g].empty()) th.emplace_back([&, g] { rc[g] = run_staged(g); });
+        for (auto &t : th) t.join();
+        for (int g = 0; g < ndev; g++) if (rc[g] < 0) return rc[g];
+    }
+    return nb_frames;
 }
 
-static int run_single(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4], int sliceY, int sliceH,
+static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4], const int srcStride[4], int sliceY, int sliceH,
                       uint8_t *const dst[4], const int dstStride[4])
 {
-    DeviceState *d = c->dev;
     const SwsContext &o = c->opts;
 
     if (c->plan == PLAN_CASCADE) { // scale_cascaded, swscale.c:992-1018 (whole frames)
         SwsInternal *c0 = c->cascade[0], *c1 = c->cascade[1];
-        for (SwsInternal *cc : { c0, c1 }) {
-            int r = dev_prepare(cc);
-            if (r < 0) return r;
-            // children share the parent's device and stream
-            if (cc->dev->stream != d->stream) {
-                if (cc->dev->own_stream && cc->dev->stream) { (void)hipStreamDestroy(cc->dev->stream); }
-                cc->dev->stream = d->stream; cc->dev->own_stream = false; cc->dev->device = d->device;
+        DeviceState *cd[2] = { nullptr, nullptr };
+        for (int k = 0; k < 2; k++) {
+            SwsInternal *cc = k ? c1 : c0;
+            // children run on the parent's GPU and stream
+            cd[k] = dev_state_for(cc, d->device);
+            if (!cd[k]) return AVERROR_EXTERNAL_;
+            if (cd[k]->stream != d->stream) {
+                if (cd[k]->own_stream && cd[k]->stream) { (void)hipStreamSynchronize(cd[k]->stream); (void)hipStreamDestroy(cd[k]->stream); }
+                cd[k]->stream = d->stream; cd[k]->own_stream = false;
             }
+            int r = dev_prepare_on(cc, cd[k]);
+            if (r < 0) return r;
         }
         int ls[4]; size_t offs[4], total;
         image_layout(c->cascade_fmt, c->cascade_w, c->cascade_h, 256, ls, offs, &total);
@@ -1539,9 +1050,9 @@ static int run_single(SwsInternal *c, const uint8_t *const src[4], const int src
         if (d->casc_bytes != had) { HIPCHK(hipMemsetAsync(d->casc_img, 0, d->casc_bytes, d->stream)); }
         uint8_t *tmp[4] = { (uint8_t *)d->casc_img, nullptr, nullptr, nullptr };
         int tls[4] = { ls[0], 0, 0, 0 };
-        r = run_single(c0, src, srcStride, sliceY, sliceH, tmp, tls);
+        r = run_single(c0, cd[0], src, srcStride, sliceY, sliceH, tmp, tls);
         if (r < 0) return r;
-        return run_single(c1, tmp, tls, 0, c0->opts.dst_h, dst, dstStride);
+        return run_single(c1, cd[1], tmp, tls, 0, c0->opts.dst_h, dst, dstStride);
     }
 
     const int nps = pix_nb_planes(pix_desc(o.src_format)), npd = pix_nb_planes(pix_desc(o.dst_format));
@@ -1607,7 +1118,7 @@ static int run_single(SwsInternal *c, const uint8_t *const src[4], const int src
         }
     }
 
-    int ret = launch_plan(c, &fr, 1, sliceY, sliceH);
+    int ret = launch_plan(c, d, &fr, 1, sliceY, sliceH);
     if (ret < 0) return ret;
 
     if (!dst_dev) {
@@ -1663,6 +1174,7 @@ static int scale_slice(SwsInternal *c, const uint8_t *const src[], const int src
     const int yint = c->sliceDir == 1 ? srcSliceY : o.src_h - srcSliceY - srcSliceH;   // srcSliceY_internal (:1158)
     int ret = dev_prepare(c);
     if (ret < 0) return ret;
+    DeviceGuard guard;
     DeviceState *d = c->dev;
     HIPCHK(hipSetDevice(d->device));
     hipStream_t st = d->stream;
@@ -1717,7 +1229,7 @@ static int scale_slice(SwsInternal *c, const uint8_t *const src[], const int src
             d4[k] = dst[k] + (flip ? (int64_t)(prow - 1) * dstStride[k] : 0);
             ds4[k] = flip ? -dstStride[k] : dstStride[k];
         }
-        ret = run_single(c, s4, ss4, 0, o.src_h, d4, ds4);
+        ret = run_single(c, d, s4, ss4, 0, o.src_h, d4, ds4);
         if (ret < 0) return ret;
     }
     return dstY - last;
@@ -1826,13 +1338,25 @@ int sws_hip_set_device(SwsContext *sws, int device)
 {
     if (!sws) return SWS_AVERROR(EINVAL);
     SwsInternal *c = internal(sws);
-    if (c->dev && c->dev->device != device) dev_release(c);
-    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
+    if (c->dev && c->dev->device == device) return 0;
+    // a new home GPU: everything the context (and the children of a cascade) holds on any GPU is released and rebuilt on first use
+    dev_release(c);
+    for (SwsInternal *cc : { c->cascade[0], c->cascade[1] }) if (cc) dev_release(cc);
     int r = ensure_dev(c);
     if (r < 0) return r;
     c->dev->device = device;
-    c->tables_dirty = true;
+    mark_tables_dirty(c);
     return 0;
+}
+
+int sws_hip_get_device(SwsContext *sws)
+{
+    if (!sws) return SWS_AVERROR(EINVAL);
+    SwsInternal *c = internal(sws);
+    int r = ensure_dev(c);
+    return r < 0 ? r : c->dev->device;
 }
 
 int sws_hip_set_stream(SwsContext *sws, void *stream)
@@ -1841,12 +1365,15 @@ int sws_hip_set_stream(SwsContext *sws, void *stream)
     SwsInternal *c = internal(sws);
     int r = ensure_dev(c);
     if (r < 0) return r;
+    DeviceGuard guard;
     DeviceState *d = c->dev;
-    if (d->stream && d->own_stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
+    if (hipSetDevice(d->device) != hipSuccess) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
+    if (d->stream) (void)hipStreamSynchronize(d->stream);
+    if (d->stream && d->own_stream) (void)hipStreamDestroy(d->stream);
     d->stream = (hipStream_t)stream;
     d->own_stream = false;
     if (!stream) { // back to a context-owned stream
-        if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) return AVERROR_EXTERNAL_;
+        if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
         d->own_stream = true;
     }
     return 0;
@@ -1860,12 +1387,15 @@ void *sws_hip_get_stream(SwsContext *sws)
     return (void *)c->dev->stream;
 }
 
-int sws_hip_sync(SwsContext *sws)
+int sws_hip_sync(SwsContext *sws)   // waits for the context's work on every GPU it has used
 {
     if (!sws) return SWS_AVERROR(EINVAL);
     SwsInternal *c = internal(sws);
-    if (!c->dev || !c->dev->stream) return 0;
-    return hipStreamSynchronize(c->dev->stream) == hipSuccess ? 0 : AVERROR_EXTERNAL_;
+    int ret = 0;
+    if (c->dev && c->dev->stream && hipStreamSynchronize(c->dev->stream) != hipSuccess) { (void)hipGetLastError(); ret = AVERROR_EXTERNAL_; }
+    for (DeviceState *d : c->peers)
+        if (d && d->stream && hipStreamSynchronize(d->stream) != hipSuccess) { (void)hipGetLastError(); ret = AVERROR_EXTERNAL_; }
+    return ret;
 }
 
 int sws_hip_set_timing(SwsContext *sws, int enable)
@@ -1874,7 +1404,9 @@ int sws_hip_set_timing(SwsContext *sws, int enable)
     SwsInternal *c = internal(sws);
     int r = ensure_dev(c);
     if (r < 0) return r;
+    DeviceGuard guard;
     DeviceState *d = c->dev;
+    if (hipSetDevice(d->device) != hipSuccess) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
     if (enable && !d->ev0) {
         if (hipEventCreate(&d->ev0) != hipSuccess || hipEventCreate(&d->ev1) != hipSuccess) return AVERROR_EXTERNAL_;
     }
@@ -1894,6 +1426,28 @@ double sws_hip_last_kernel_ms(SwsContext *sws)
     return ms;
 }
 
+// launch heuristics (swsint.hpp: Tuning); returns 0, or AVERROR(EINVAL) for an unknown name
+int sws_hip_set_option(SwsContext *sws, const char *name, int value)
+{
+    if (!sws || !name) return SWS_AVERROR(EINVAL);
+    SwsInternal *c = internal(sws);
+    struct { const char *n; int *v; } tab[] = {
+        { "strip_min_w", &c->tune.strip_min_w }, { "strip_cols_l", &c->tune.strip_cols_l }, { "strip_cols_c", &c->tune.strip_cols_c },
+        { "strip_waves", &c->tune.strip_waves }, { "rgb_march_waves", &c->tune.rgb_march_waves }, { "tile_lds_kb", &c->tune.tile_lds_kb },
+        { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
+        { "no_strip", &c->tune.no_strip }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
+        { "debug", &c->tune.debug },
+    };
+    for (auto &e : tab)
+        if (!std::strcmp(e.n, name)) {
+            *e.v = value;
+            mark_tables_dirty(c);
+            for (SwsInternal *cc : { c->cascade[0], c->cascade[1] }) if (cc) { cc->tune = c->tune; mark_tables_dirty(cc); }
+            return 0;
+        }
+    return SWS_AVERROR(EINVAL);
+}
+
 int sws_hip_image_layout(int format, int width, int height, int align, int linesize[4], size_t offset[4], size_t *total)
 {
     if (align <= 0) align = 256;
@@ -1907,6 +1461,7 @@ int sws_hip_frame_alloc(SwsFrameView *f, int format, int width, int height, int 
     int ls[4]; size_t offs[4], total;
     int r = image_layout(format, width, height, 256, ls, offs, &total);
     if (r < 0) return r;
+    DeviceGuard guard;      // the caller's current device is left as it was
     if (device >= 0 && hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
     void *base = nullptr;
     if (hipMalloc(&base, total ? total : 256) != hipSuccess) { (void)hipGetLastError(); return SWS_AVERROR(ENOMEM); }
@@ -1930,9 +1485,15 @@ static int frame_copy(SwsContext *sws, SwsFrameView *dstf, const SwsFrameView *s
         return SWS_AVERROR(EINVAL);
     hipStream_t st = nullptr;
     SwsInternal *c = sws ? internal(sws) : nullptr;
-    if (c) { int r = ensure_dev(c); if (r < 0) return r;
-             if (!c->dev->stream) { if (hipStreamCreateWithFlags(&c->dev->stream, hipStreamNonBlocking) != hipSuccess) return AVERROR_EXTERNAL_; c->dev->own_stream = true; }
-             st = c->dev->stream; }
+    DeviceGuard guard;
+    const int fdev = ptr_device(kind == hipMemcpyHostToDevice ? (const void *)dstf->data[0] : (const void *)srcf->data[0]);
+    if (fdev >= 0 && hipSetDevice(fdev) != hipSuccess) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
+    if (c) {   // the copy is ordered on the context's stream of the GPU that holds the frame
+        DeviceState *d = fdev >= 0 ? dev_state_for(c, fdev) : (ensure_dev(c) < 0 ? nullptr : c->dev);
+        if (!d) return AVERROR_EXTERNAL_;
+        if (!d->stream) { if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) return AVERROR_EXTERNAL_; d->own_stream = true; }
+        st = d->stream;
+    }
     const int np = pix_nb_planes(pix_desc(srcf->format));
     for (int k = 0; k < np; k++) {
         int rb, rows; plane_geometry(srcf->format, srcf->width, srcf->height, k, &rb, &rows);

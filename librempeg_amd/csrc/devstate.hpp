@@ -1,0 +1,100 @@
+// Host-side device state of a context and the interface between the launch planner (device.hip) and the translation units
+// that hold the kernels (k_*.hip).  One DeviceState per (context, GPU): tables, plans, scratch and the stream live on that GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "swsint.hpp"
+
+#define AVERROR_EXTERNAL_ (-0x20545845) /* FFERRTAG('E','X','T',' '), libavutil/error.h */
+
+namespace swship {
+
+struct DeviceState {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint64_t epoch = 0;        // SwsInternal::tables_epoch this state was built for (0 = never)
+    void *d_tables = nullptr; size_t tables_bytes = 0;
+    SwsDevParams params;
+    bool unity_h = false, unity_v = false;
+    bool all_x_mode = false;   // every output row uses the general yuv2rgb_X writer (vscale.c:135-169)
+    int chr_window2 = 0;       // max chroma source rows spanned by a pair of output rows (wave kernel register budget)
+    bool tile_ok = false; SwsTileGeom tileL, tileC; void *d_tilegeom = nullptr; size_t tilegeom_bytes = 0;
+    bool rgb_march_ok = false; void *d_rgbplan = nullptr; size_t rgbplan_bytes = 0; int rgb_groups = 0;   // sws_k_rgb_fused_unity_march
+    void *d_be = nullptr; size_t be_bytes = 0;   // little-endian copies of big-endian source pictures
+    void *d_xyz = nullptr; size_t xyz_bytes = 0; void *d_xyz_tab = nullptr;   // rgb48 copies of xyz12 source pictures; the four gamma LUTs
+    bool dot2_ok = false; SwsTileGeom dotL, dotC; void *d_dot2 = nullptr; size_t dot2_bytes = 0;
+    bool strip_ok = false; SwsStripGeom stripL, stripC;    // sws_k_strip_march (tables live in d_dot2)
+    void *scratch = nullptr; size_t scratch_bytes = 0;
+    void *stage_src = nullptr; size_t stage_src_bytes = 0;
+    void *stage_dst = nullptr; size_t stage_dst_bytes = 0;
+    SwsFramePtrs *d_frames = nullptr, *h_frames = nullptr; int frames_cap = 0, frames_valid = 0;
+    void *casc_img = nullptr; size_t casc_bytes = 0; int casc_stride = 0;
+    void *slice_img = nullptr; size_t slice_bytes = 0;   // source image assembled from sws_scale() slices (scaled path)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timing = false; bool timed = false;
+};
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    log_msg(c, 0, "HIP error %s at %s:%d: %s\n", hipGetErrorName(e_), __FILE__, __LINE__, #expr); \
+    (void)hipGetLastError(); return AVERROR_EXTERNAL_; } } while (0)
+
+// saves the caller's current device and restores it on scope exit: library entry points never retarget the caller's HIP calls
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) { (void)hipGetLastError(); saved = -1; } }
+    ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+};
+
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// everything a kernel-holding translation unit needs to launch its part of a plan over `n` device-resident frames
+struct LaunchCtx {
+    SwsInternal *c;
+    DeviceState *d;
+    const SwsDevParams *p;
+    hipStream_t st;
+    SwsFrameSet fs;                 // frame table (device) or the single frame
+    const SwsFramePtrs *frames;     // host copy of the descriptors
+    int n, sliceY, sliceH;
+    bool vec;                       // all planes and strides 16-byte aligned
+};
+
+// buffer-descriptor kernels address a plane as base + 32-bit offset: strides must be positive and planes below 2 GiB
+static inline bool frames_desc_ok(const SwsFramePtrs *fr, int n, int srcH, int dstH)
+{
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 4; k++) {
+            if (fr[i].src[k] && (fr[i].srcStride[k] <= 0 || (int64_t)fr[i].srcStride[k] * srcH >= (int64_t)1 << 31)) return false;
+            if (fr[i].dst[k] && (fr[i].dstStride[k] <= 0 || (int64_t)fr[i].dstStride[k] * dstH >= (int64_t)1 << 31)) return false;
+        }
+    return true;
+}
+
+// ---- k_misc.hip: element-per-thread unscaled converters and helper passes ----
+int  launch_misc(const LaunchCtx &L);                                   // every PLAN_UNSC_* plan not named below
+void launch_fill_alpha(const LaunchCtx &L, int w, int y0, int rows, int bits);
+void launch_alpha_merge(const LaunchCtx &L, int npix, int y0, int rows, int a_pos);
+void launch_bswap(hipStream_t st, const uint8_t *src, int64_t sstride, uint8_t *dst, int64_t dstride, int rows, int row_bytes, int unit);
+void launch_xyz12(hipStream_t st, const uint8_t *src, int64_t sstride, uint8_t *dst, int64_t dstride, int w, int rows,
+                  const uint16_t *gamma_in, const uint16_t *gamma_out, int to_rgb);
+// ---- k_yuv2rgb.hip: PLAN_UNSC_YUV2RGB (C2a) ----
+int  launch_yuv2rgb(const LaunchCtx &L);
+// ---- k_rgb_unity.hip: PLAN_MAIN, identity horizontal filters, 8-bit planar / nv12 -> 24/32 bpp LUT writers (C2b, C4) ----
+int  launch_rgb_unity(const LaunchCtx &L);
+// ---- k_stream.hip: planarToP01x (C3a), planar float RGB -> yuv444 (C5) ----
+int  launch_p01x(const LaunchCtx &L);
+int  launch_f32rgb(const LaunchCtx &L);
+// ---- k_strip.hip / k_tile.hip: fused h+v polyphase kernels for planar / semi-planar outputs (C3b, C1) ----
+int  launch_strip(const LaunchCtx &L);
+int  launch_tile_dot2(const LaunchCtx &L);
+int  launch_tile(const LaunchCtx &L);
+// ---- k_generic.hip: two-pass / direct element-per-thread path ----
+int  launch_generic(const LaunchCtx &L);
+
+// device.hip
+int grow(SwsInternal *c, void **buf, size_t *cap, size_t need);
+
+} // namespace swship

@@ -1,0 +1,63 @@
+// Translation unit of the generic element-per-thread path: every reader (input.c), hScale*_c, every writer (output.c) in their
+// _1 / _2 / _X forms.  Two passes through an HBM scratch, or one pass when both horizontal banks are the identity.
+#include "devstate.hpp"
+#include "kernels_generic.hpp"
+
+namespace swship {
+
+int launch_generic(const LaunchCtx &L)
+{
+    SwsInternal *c = L.c; DeviceState *d = L.d; const SwsDevParams &p = *L.p; hipStream_t st = L.st; const SwsFrameSet &fs = L.fs;
+    const SwsFramePtrs *frames = L.frames; const int n = L.n, sliceY = L.sliceY, sliceH = L.sliceH; const bool vec = L.vec;
+    const dim3 blk(256);
+    (void)c; (void)d; (void)frames; (void)vec; (void)sliceY; (void)sliceH;
+    const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 ||
+                     p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI ||
+                     p.dstKind == DSTK_RGB48 || p.dstKind == DSTK_RGB16 || p.dstKind == DSTK_RGB30 || p.dstKind == DSTK_MONO ||
+                     p.dstKind == DSTK_YA;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
+        const int64_t lumElems = (int64_t)p.srcH * p.dstW, chrElems = (int64_t)p.chrSrcH * p.chrDstW;
+        const int64_t frame_elems = lumElems + 2 * chrElems + (p.need_alpha ? lumElems : 0);
+        const size_t esz = p.wide ? 4 : 2;
+        const bool direct = d->unity_h;
+        int chunk = n;
+        if (!direct) {
+            const size_t budget = (size_t)2 << 30; // scratch budget per launch group
+            chunk = (int)std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(budget / (frame_elems * esz))));
+            int r = grow(c, &d->scratch, &d->scratch_bytes, (size_t)frame_elems * esz * chunk);
+            if (r < 0) return r;
+        }
+        for (int f0 = 0; f0 < n; f0 += chunk) {
+            const int m = std::min(chunk, n - f0);
+            SwsFrameSet sub = fs;
+            sub.count = m;
+            if (n == 1) sub.one = frames[0]; else sub.table = d->d_frames + f0;
+            if (!direct) {
+                const int maxW = std::max(p.dstW, p.chrDstW), maxH = std::max(p.srcH, p.chrSrcH);
+                const dim3 g1(cdiv(maxW, 256), maxH, (p.need_alpha ? 4 : 3) * m);
+                if (p.wide) hipLaunchKernelGGL((swsk::sws_k_hscale<int32_t>), g1, blk, 0, st, sub, p, (int32_t *)d->scratch, frame_elems);
+                else hipLaunchKernelGGL((swsk::sws_k_hscale<int16_t>), g1, blk, 0, st, sub, p, (int16_t *)d->scratch, frame_elems);
+            }
+#define LAUNCH_W(K, G, ...) do { \
+    if (direct) hipLaunchKernelGGL((swsk::K<true, int16_t>), G, blk, 0, st, sub, p, (const int16_t *)nullptr, frame_elems, ##__VA_ARGS__); \
+    else if (p.wide) hipLaunchKernelGGL((swsk::K<false, int32_t>), G, blk, 0, st, sub, p, (const int32_t *)d->scratch, frame_elems, ##__VA_ARGS__); \
+    else hipLaunchKernelGGL((swsk::K<false, int16_t>), G, blk, 0, st, sub, p, (const int16_t *)d->scratch, frame_elems, ##__VA_ARGS__); } while (0)
+            if (rgb) {
+                const int units = p.dstKind == DSTK_MONO ? (p.dstW + 7) >> 3 : (p.full_chr || p.dstKind == DSTK_YA) ? p.dstW : (p.dstW + 1) >> 1;
+                const dim3 g(cdiv(units, 256), p.dstH, m);
+                LAUNCH_W(sws_k_vscale_rgb, g);
+            } else if (p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010 || p.dstKind == DSTK_P016) {
+                const dim3 gl(cdiv(p.dstW, 256), p.dstH, m);
+                LAUNCH_W(sws_k_vscale_planar, gl, 1);
+                const dim3 gc(cdiv(p.chrDstW, 256), p.chrDstH, m);
+                LAUNCH_W(sws_k_vscale_nvchroma, gc);
+            } else {
+                const int ncomp = isGray(c->opts.dst_format) ? 1 : (p.need_alpha ? 4 : 3); // vscale.c:219-233 (gray: luma only), :59-71 (alpha)
+                const dim3 g(cdiv(std::max(p.dstW, p.chrDstW), 256), std::max(p.dstH, p.chrDstH), ncomp * m);
+                LAUNCH_W(sws_k_vscale_planar, g, ncomp);
+            }
+#undef LAUNCH_W
+        }
+    return 0;
+}
+
+} // namespace swship

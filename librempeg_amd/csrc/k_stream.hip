@@ -1,0 +1,47 @@
+// Translation unit of the streaming converters: planarToP01xWrapper / planar8ToP01xleWrapper (C3a) and the fused planar float
+// RGB -> 4:4:4 YUV chain (C5).
+#include "devstate.hpp"
+#include "kernels_fast.hpp"
+#include "kernels_stream.hpp"
+
+namespace swship {
+
+int launch_p01x(const LaunchCtx &L)
+{
+    SwsInternal *c = L.c; DeviceState *d = L.d; const SwsDevParams &p = *L.p; hipStream_t st = L.st; const SwsFrameSet &fs = L.fs;
+    const SwsFramePtrs *frames = L.frames; const int n = L.n, sliceY = L.sliceY, sliceH = L.sliceH; const bool vec = L.vec;
+    const dim3 blk(256);
+    (void)c; (void)d; (void)frames; (void)vec; (void)sliceY; (void)sliceH;
+        const int rows = sliceH + ((sliceH + 1) >> 1);
+        const dim3 grid(cdiv(cdiv(p.srcW, 8), 256), rows, n);
+        const bool s8 = c->plan == PLAN_UNSC_8_P01X;
+        const int p01x_ch = c->tune.p01x_ch;
+        if (!s8 && vec && p01x_ch > 0) {   // streaming form: CH x 16 bytes per lane, wave-contiguous
+            const int row_chunks = cdiv(2 * p.srcW, 16);
+            if (p01x_ch == 4) { const dim3 g4(cdiv(row_chunks, 4 * 256), rows, n);
+                                hipLaunchKernelGGL((swsk::sws_k_p01x_stream<4>), g4, blk, 0, st, fs, p, sliceY, sliceH); }
+            else if (p01x_ch == 1) { const dim3 g1(cdiv(row_chunks, 256), rows, n);
+                                hipLaunchKernelGGL((swsk::sws_k_p01x_stream<1>), g1, blk, 0, st, fs, p, sliceY, sliceH); }
+            else { const dim3 g2(cdiv(row_chunks, 2 * 256), rows, n);
+                   hipLaunchKernelGGL((swsk::sws_k_p01x_stream<2>), g2, blk, 0, st, fs, p, sliceY, sliceH); }
+            return 0;
+        }
+        if (s8 && vec) hipLaunchKernelGGL((swsk::sws_k_p01x_unscaled<true, true>), grid, blk, 0, st, fs, p, sliceY, sliceH);
+        else if (s8) hipLaunchKernelGGL((swsk::sws_k_p01x_unscaled<true, false>), grid, blk, 0, st, fs, p, sliceY, sliceH);
+        else if (vec) hipLaunchKernelGGL((swsk::sws_k_p01x_unscaled<false, true>), grid, blk, 0, st, fs, p, sliceY, sliceH);
+        else hipLaunchKernelGGL((swsk::sws_k_p01x_unscaled<false, false>), grid, blk, 0, st, fs, p, sliceY, sliceH);
+    return 0;
+}
+
+int launch_f32rgb(const LaunchCtx &L)
+{
+    SwsInternal *c = L.c; DeviceState *d = L.d; const SwsDevParams &p = *L.p; hipStream_t st = L.st; const SwsFrameSet &fs = L.fs;
+    const SwsFramePtrs *frames = L.frames; const int n = L.n, sliceY = L.sliceY, sliceH = L.sliceH; const bool vec = L.vec;
+    const dim3 blk(256);
+    (void)c; (void)d; (void)frames; (void)vec; (void)sliceY; (void)sliceH;
+            const dim3 g(cdiv((int64_t)((p.srcW + 7) >> 3) * p.srcH, 256), 1, n);
+            hipLaunchKernelGGL(swsk::sws_k_f32rgb_to_yuv444_unity, g, blk, 0, st, fs, p);
+    return 0;
+}
+
+} // namespace swship

@@ -1,0 +1,36 @@
+// Translation unit of the marching strip kernel (C3b and every wide h+v polyphase conversion to planar / semi-planar YUV).
+#include <algorithm>
+
+#include "devstate.hpp"
+#include "kernels_strip.hpp"
+
+namespace swship {
+
+int launch_strip(const LaunchCtx &L)
+{
+    SwsInternal *c = L.c; DeviceState *d = L.d; const SwsDevParams &p = *L.p; hipStream_t st = L.st; const SwsFrameSet &fs = L.fs;
+    const SwsFramePtrs *frames = L.frames; const int n = L.n, sliceY = L.sliceY, sliceH = L.sliceH; const bool vec = L.vec;
+    const dim3 blk(256);
+    (void)c; (void)d; (void)frames; (void)vec; (void)sliceY; (void)sliceH;
+            const int target = c->tune.strip_waves;
+            const bool s16 = p.srcKind == SRCK_PLANAR16;
+            auto launch = [&](SwsStripGeom g, int H, bool chroma) {
+                int bands = std::max(1, std::min(target / std::max(1, g.strips * n), (H + 15) / 16));
+                g.debug = c->tune.debug;
+                g.band_rows = (H + bands - 1) / bands;
+                g.bands = (H + g.band_rows - 1) / g.band_rows;
+                const dim3 grid(cdiv((int64_t)g.strips * g.bands, 4), 1, n);
+#define SWS_STRIP(S, C, K) hipLaunchKernelGGL((swsk::sws_k_strip_march<S, C, K>), grid, blk, g.lds_bytes, st, fs, p, g)
+                const int cols = g.TW / 64;
+                if (chroma) { if (s16) { if (cols == 1) SWS_STRIP(true, true, 1); else SWS_STRIP(true, true, 2); }
+                              else     { if (cols == 1) SWS_STRIP(false, true, 1); else SWS_STRIP(false, true, 2); } }
+                else        { if (s16) { if (cols == 2) SWS_STRIP(true, false, 2); else SWS_STRIP(true, false, 4); }
+                              else     { if (cols == 2) SWS_STRIP(false, false, 2); else SWS_STRIP(false, false, 4); } }
+#undef SWS_STRIP
+            };
+            launch(d->stripL, p.dstH, false);
+            launch(d->stripC, p.chrDstH, true);
+    return 0;
+}
+
+} // namespace swship

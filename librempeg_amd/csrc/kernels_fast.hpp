@@ -310,121 +310,4 @@ __global__ void __launch_bounds__(256) sws_k_p01x_unscaled(SwsFrameSet fs, SwsDe
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// remaining unscaled planar converters, one element per thread:
-//   mode 0 planarToNv12Wrapper / 1 nv12ToPlanarWrapper (swscale_unscaled.c:147-186)
-//   mode 2 planarCopyWrapper (:2220-2384; little-endian, incl. depth change with ordered dither)
-// grid.x over bytes/elements of a row, grid.y over rows of all planes stacked, grid.z = frame
-// ------------------------------------------------------------------------------------------
-__device__ __constant__ const uint8_t k_copy_dithers[8][8][8] = { // swscale_unscaled.c:39-112
-{ {0,1,0,1,0,1,0,1},{1,0,1,0,1,0,1,0},{0,1,0,1,0,1,0,1},{1,0,1,0,1,0,1,0},{0,1,0,1,0,1,0,1},{1,0,1,0,1,0,1,0},{0,1,0,1,0,1,0,1},{1,0,1,0,1,0,1,0} },
-{ {1,2,1,2,1,2,1,2},{3,0,3,0,3,0,3,0},{1,2,1,2,1,2,1,2},{3,0,3,0,3,0,3,0},{1,2,1,2,1,2,1,2},{3,0,3,0,3,0,3,0},{1,2,1,2,1,2,1,2},{3,0,3,0,3,0,3,0} },
-{ {2,4,3,5,2,4,3,5},{6,0,7,1,6,0,7,1},{3,5,2,4,3,5,2,4},{7,1,6,0,7,1,6,0},{2,4,3,5,2,4,3,5},{6,0,7,1,6,0,7,1},{3,5,2,4,3,5,2,4},{7,1,6,0,7,1,6,0} },
-{ {4,8,7,11,4,8,7,11},{12,0,15,3,12,0,15,3},{6,10,5,9,6,10,5,9},{14,2,13,1,14,2,13,1},{4,8,7,11,4,8,7,11},{12,0,15,3,12,0,15,3},{6,10,5,9,6,10,5,9},{14,2,13,1,14,2,13,1} },
-{ {9,17,15,23,8,16,14,22},{25,1,31,7,24,0,30,6},{13,21,11,19,12,20,10,18},{29,5,27,3,28,4,26,2},{8,16,14,22,9,17,15,23},{24,0,30,6,25,1,31,7},{12,20,10,18,13,21,11,19},{28,4,26,2,29,5,27,3} },
-{ {18,34,30,46,17,33,29,45},{50,2,62,14,49,1,61,13},{26,42,22,38,25,41,21,37},{58,10,54,6,57,9,53,5},{16,32,28,44,19,35,31,47},{48,0,60,12,51,3,63,15},{24,40,20,36,27,43,23,39},{56,8,52,4,59,11,55,7} },
-{ {18,34,30,46,17,33,29,45},{50,2,62,14,49,1,61,13},{26,42,22,38,25,41,21,37},{58,10,54,6,57,9,53,5},{16,32,28,44,19,35,31,47},{48,0,60,12,51,3,63,15},{24,40,20,36,27,43,23,39},{56,8,52,4,59,11,55,7} },
-{ {36,68,60,92,34,66,58,90},{100,4,124,28,98,2,122,26},{52,84,44,76,50,82,42,74},{116,20,108,12,114,18,106,10},{32,64,56,88,38,70,62,94},{96,0,120,24,102,6,126,30},{48,80,40,72,54,86,46,78},{112,16,104,8,118,22,110,14} },
-};
-
-struct MiscPlane { int srcPlane, dstPlane, width /*elements*/, rows, y0, elem /*bytes per element*/, shiftonly, chroma; };
-struct MiscPlan { int mode; int nplanes; int bytecopy; int aux, aux2; MiscPlane pl[4]; };
-
-__global__ void __launch_bounds__(256) sws_k_planar_misc(SwsFrameSet fs, SwsDevParams p, MiscPlan plan)
-{
-    const SwsFramePtrs &f = frame_of(fs, blockIdx.z);
-    int r = blockIdx.y, pi = 0;
-    while (pi < plan.nplanes && r >= plan.pl[pi].rows) { r -= plan.pl[pi].rows; pi++; }
-    if (pi >= plan.nplanes) return;
-    const MiscPlane &P = plan.pl[pi];
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= P.width) return;
-    const int ys = P.y0 + r, yd = P.y0 + r;  // absolute plane rows (the host rebases slice pointers)
-    if (plan.mode == 0) {             // planar -> nv12/nv21
-        if (pi == 0) { f.dst[0][(int64_t)yd * f.dstStride[0] + x] = f.src[0][(int64_t)ys * f.srcStride[0] + x]; return; }
-        const int a = p.uv_swap_dst ? 2 : 1, b = 3 - a;
-        uint8_t *d = f.dst[1] + (int64_t)yd * f.dstStride[1] + 2 * x;
-        d[0] = f.src[a][(int64_t)ys * f.srcStride[a] + x];
-        d[1] = f.src[b][(int64_t)ys * f.srcStride[b] + x];
-    } else if (plan.mode == 1) {      // nv12/nv21 -> planar
-        if (pi == 0) { f.dst[0][(int64_t)yd * f.dstStride[0] + x] = f.src[0][(int64_t)ys * f.srcStride[0] + x]; return; }
-        const int a = p.uv_swap_src ? 2 : 1, b = 3 - a;
-        const uint8_t *s = f.src[1] + (int64_t)ys * f.srcStride[1] + 2 * x;
-        f.dst[a][(int64_t)yd * f.dstStride[a] + x] = s[0];
-        f.dst[b][(int64_t)yd * f.dstStride[b] + x] = s[1];
-    } else if (plan.mode == 3) {      // nv24ToYuv420Wrapper: luma copy + truncating 2x2 chroma mean (swscale_unscaled.c:229-271)
-        if (pi == 0) { f.dst[0][(int64_t)yd * f.dstStride[0] + x] = f.src[0][(int64_t)ys * f.srcStride[0] + x]; return; }
-        const int a = p.uv_swap_src ? 2 : 1, b = 3 - a;
-        // chroma source rows are luma rows: r counts chroma rows of the slice, the slice starts at luma row 2*P.y0
-        const int sr = 2 * r, sr2 = (sr + 1 == plan.aux) ? sr : sr + 1;
-        const uint8_t *s1 = f.src[1] + (int64_t)(2 * P.y0 + sr) * f.srcStride[1] + 4 * x;
-        const uint8_t *s2 = f.src[1] + (int64_t)(2 * P.y0 + sr2) * f.srcStride[1] + 4 * x;
-        f.dst[a][(int64_t)yd * f.dstStride[a] + x] = (uint8_t)((s1[0] + s1[2] + s2[0] + s2[2]) >> 2);
-        f.dst[b][(int64_t)yd * f.dstStride[b] + x] = (uint8_t)((s1[1] + s1[3] + s2[1] + s2[3]) >> 2);
-    } else if (plan.mode == 4) {      // yvu9ToYv12Wrapper: luma copy + planar2x_c chroma (rgb2rgb_template.c:531-574), per slice
-        if (pi == 0) { f.dst[0][(int64_t)yd * f.dstStride[0] + x] = f.src[0][(int64_t)ys * f.srcStride[0] + x]; return; }
-        const int W = plan.aux2, H = plan.aux;                 // source chroma size of this slice
-        const int s0row = P.y0 >> 1;                           // first source chroma row of the slice (absolute)
-        const uint8_t *src = f.src[P.srcPlane] + (int64_t)s0row * f.srcStride[P.srcPlane];
-        const int st = f.srcStride[P.srcPlane];
-        const int Y = r, X = x;
-        int v;
-        // column taps: output X=0 and X=2W-1 take one source column; odd X = 2k+1 mixes k (near) and k+1, even X = 2k+2 mixes k+1 (near) and k
-        const int k = (X - 1) >> 1;
-        const bool edgeL = X == 0, edgeR = X == 2 * W - 1;
-        const int cn = edgeL ? 0 : edgeR ? W - 1 : (X & 1) ? k : k + 1;     // "near" column (weight 3 horizontally on border lines)
-        const int cf = edgeL ? 0 : edgeR ? W - 1 : (X & 1) ? k + 1 : k;     // "far" column
-        if (Y == 0 || Y == 2 * H - 1) {                        // first / last line: horizontal taps only
-            const uint8_t *s = src + (int64_t)(Y ? H - 1 : 0) * st;
-            v = (edgeL || edgeR) ? s[cn] : (3 * s[cn] + s[cf]) >> 2;
-        } else {                                               // lines 2y-1 (3A+B) and 2y (A+3B): A = row y-1, B = row y, diagonal taps
-            const int y = (Y + 1) >> 1;
-            const uint8_t *A = src + (int64_t)(y - 1) * st, *B = A + st;
-            if (Y & 1) v = (3 * A[cn] + B[cf]) >> 2;           // dst[2x+1] = 3A[x]+B[x+1]; dst[2x+2] = 3A[x+1]+B[x]
-            else       v = (A[cf] + 3 * B[cn]) >> 2;           // dst[2x+2] = A[x]+3B[x+1]; dst[2x+1] = A[x+1]+3B[x]
-        }
-        f.dst[P.dstPlane][(int64_t)yd * f.dstStride[P.dstPlane] + x] = (uint8_t)v;
-    } else if (P.srcPlane < 0) {      // planarCopyWrapper, plane missing in a gray source: fillPlane / fillPlane16 (:2239-2247)
-        uint8_t *drow = f.dst[P.dstPlane] + (int64_t)yd * f.dstStride[P.dstPlane];
-        if (P.srcPlane == -2) {                                   // alpha plane of a destination the source cannot feed: 255 / all ones
-            if (p.copy_depth_dst > 8) ((uint16_t *)drow)[x] = (uint16_t)(0xFFFF >> (16 - p.copy_depth_dst)); else drow[x] = 255;
-        }
-        else if (p.copy_depth_dst > 8) ((uint16_t *)drow)[x] = (uint16_t)(1 << (p.copy_depth_dst - 1));
-        else drow[x] = 128;
-    } else {                          // planarCopyWrapper
-        const uint8_t *srow = f.src[P.srcPlane] + (int64_t)ys * f.srcStride[P.srcPlane];
-        uint8_t *drow = f.dst[P.dstPlane] + (int64_t)yd * f.dstStride[P.dstPlane];
-        const int sd = p.copy_depth_src, dd = p.copy_depth_dst, ss = p.copy_shift_src, dsh = p.copy_shift_dst;
-        if (plan.bytecopy) {           // same layout: byte copy (P.width counts bytes)
-            drow[x] = srow[x];
-        } else if (dd == 8 || sd > dd) { // DITHER_COPY (:2159-2218); the macro's scalar tail skips src_shift / dst_shift
-            const unsigned shift = sd - dd, bias = 1u << (shift - 1);
-            const int body_end = P.width - 7 > 0 ? ((P.width - 7 + 7) / 8) * 8 : 0;
-            const bool body = x < body_end;
-            const unsigned sv = ((const uint16_t *)srow)[x];
-            const unsigned dth = k_copy_dithers[shift - 1][r & 7][x & 7];
-            unsigned tmp, v;
-            if (p.dither_mode == 0) {
-                if (body) { tmp = ((sv >> ss) + bias) >> shift; v = (tmp - (tmp >> dd)) << dsh; }
-                else { tmp = (sv + bias) >> shift; v = (tmp - (tmp >> dd)) << dsh; }
-            } else if (P.shiftonly) {
-                if (body) { tmp = ((sv >> ss) + dth) >> shift; v = (tmp - (tmp >> dd)) << dsh; }
-                else { tmp = (sv + dth) >> shift; v = (tmp - (tmp >> dd)) << dsh; }
-            } else {
-                if (body) { tmp = sv >> ss; v = ((tmp - (tmp >> dd) + dth) >> shift) << dsh; }
-                else { tmp = sv; v = (tmp - (tmp >> dd) + dth) >> shift; }
-            }
-            if (dd == 8) drow[x] = (uint8_t)v; else ((uint16_t *)drow)[x] = (uint16_t)v;
-        } else if (sd == 8) {           // 8 -> N (:2266-2284)
-            const unsigned s8 = srow[x];
-            ((uint16_t *)drow)[x] = P.shiftonly ? (uint16_t)((s8 << (dd - 8)) << dsh)
-                                                : (uint16_t)(((s8 << (dd - 8)) | (s8 >> (2 * 8 - dd))) << dsh);
-        } else {                        // N -> M up (:2285-2331)
-            const unsigned shift = dd - sd, v = ((const uint16_t *)srow)[x] >> ss;
-            ((uint16_t *)drow)[x] = P.shiftonly ? (uint16_t)((v << shift) << dsh)
-                                                : (uint16_t)(((v << shift) | (v >> (2 * sd - dd))) << dsh);
-        }
-    }
-}
-
 } // namespace swsk

@@ -818,29 +818,6 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
 #undef ALP
 }
 
-// destination alpha plane the source cannot feed: fillPlane(dst[3], ..., 255) (swscale.c:536-552)
-// bits: 0 = fillPlane(…, 255); 9..16 = fillPlane16(…, alpha = 1, bits) = 0xFFFF >> (16 - bits) in 16-bit samples
-__global__ void __launch_bounds__(256) sws_k_fill_alpha_plane(SwsFrameSet fs, int w, int y0, int bits)
-{
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= w) return;
-    const SwsFramePtrs &f = frame_of(fs, blockIdx.z);
-    uint8_t *row = f.dst[3] + (int64_t)(y0 + blockIdx.y) * f.dstStride[3];
-    if (bits) ((uint16_t *)row)[x] = (uint16_t)(0xFFFF >> (16 - bits));
-    else row[x] = 255;
-}
-
-// yuva2rgba_c / yuva2argb_c (PUTRGBA, yuv2rgb.c:101-105): the 32 bpp LUT converter's pixels (written with A = 0 because
-// the table was built for a source with alpha) get the source alpha byte.  npix = pixels per row the converter covered.
-__global__ void __launch_bounds__(256) sws_k_alpha_merge(SwsFrameSet fs, int npix, int y0, int a_pos)
-{
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= npix) return;
-    const SwsFramePtrs &f = frame_of(fs, blockIdx.z);
-    const int y = y0 + blockIdx.y;   // absolute row (the host rebases slice pointers)
-    f.dst[0][(int64_t)y * f.dstStride[0] + 4 * x + a_pos] = f.src[3][(int64_t)y * f.srcStride[3] + x];
-}
-
 // ---- pass-2 / fused kernels over the generic per-element routines ----
 // DIRECT = true : horizontal filters are identity, samples are computed on the fly (single pass)
 // DIRECT = false: samples come from the pass-1 scratch planes

@@ -1,0 +1,148 @@
+// Streaming kernels: every pixel is independent, every wave instruction moves contiguous KiBs (C3a, C5).
+#pragma once
+#include "kernels_generic.hpp"
+#include "wave_util.hpp"
+
+namespace swsk {
+
+// ------------------------------------------------------------------------------------------
+// C5: planar float RGB -> planar 4:4:4 YUV with identity filters in both directions
+// (planar_rgbf32_to_y/uv input.c:1300-1334 -> hScale16To15/19_c with 1 tap -> lum/chrRange*Jpeg(16)_c ->
+//  yuv2plane1_{8,10,16}_c).  Every pixel is independent: lane = 4 pixels (3 x 16-byte float loads, 3 stores),
+// all three output planes come from ONE pass over the input (the generic path re-reads and re-quantises the
+// three float planes once per output plane).  grid.x over 4-pixel groups of a frame, grid.z = frame.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) sws_k_f32rgb_to_yuv444_unity(SwsFrameSet fs, SwsDevParams p)
+{
+    constexpr int PX = 8;                                       // pixels per lane: 2 x 16-byte loads per plane, one 16-byte store per plane
+    const int groups = (p.srcW + PX - 1) / PX;
+    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= (int64_t)groups * p.srcH) return;
+    const int y = (int)(item / groups), x = PX * (int)(item % groups);
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int n = min(PX, p.srcW - x);
+    float g[PX], b[PX], r[PX];
+    const uint8_t *pg = f.src[0] + (int64_t)y * f.srcStride[0] + 4 * x, *pb = f.src[1] + (int64_t)y * f.srcStride[1] + 4 * x,
+                  *pr = f.src[2] + (int64_t)y * f.srcStride[2] + 4 * x;
+    if (n == PX) {
+#pragma unroll
+        for (int h = 0; h < PX / 4; h++) {
+            const f32x4 vg = *(const SWS_GLOBAL f32x4 *)(pg + 16 * h), vb = *(const SWS_GLOBAL f32x4 *)(pb + 16 * h), vr = *(const SWS_GLOBAL f32x4 *)(pr + 16 * h);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { g[4 * h + k] = vg[k]; b[4 * h + k] = vb[k]; r[4 * h + k] = vr[k]; }
+        }
+    } else {
+        for (int k = 0; k < PX; k++) {
+            const bool in = k < n;
+            g[k] = in ? ((const float *)pg)[k] : 0.f; b[k] = in ? ((const float *)pb)[k] : 0.f; r[k] = in ? ((const float *)pr)[k] : 0.f;
+        }
+    }
+    const int32_t *t = p.rgb2yuv;
+    int out[3][PX];
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+        const int gi = f32_to_u16(g[k]), bi = f32_to_u16(b[k]), ri = f32_to_u16(r[k]);
+        // 16-bit samples x 15-bit coefficients: 24-bit multiplies, 32-bit wrap-around sums like the C code
+        int c[3];
+        c[0] = (int)((unsigned)(mad24(t[0], ri, mad24(t[1], gi, __mul24(t[2], bi))) + (int)(0x2001u << 14))) >> 15;
+        c[1] = (int)((unsigned)(mad24(t[3], ri, mad24(t[4], gi, __mul24(t[5], bi))) + (int)(0x10001u << 14))) >> 15;
+        c[2] = (int)((unsigned)(mad24(t[6], ri, mad24(t[7], gi, __mul24(t[8], bi))) + (int)(0x10001u << 14))) >> 15;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            int v = min((int)(((uint16_t)c[q] * 16384u) >> p.hshift), p.hclip);   // 1-tap hscale of the u16 line
+            if (!p.wide) v = (int16_t)v;
+            out[q][k] = range_sample(p, v, q != 0);
+        }
+    }
+    // vertical 1-tap writers (yuv2plane1_*): planes Y, U, V
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int pl = q == 0 ? 0 : q == 1 ? 1 : 2;  // yuv444p*: U = plane 1, V = plane 2
+        uint8_t *d = f.dst[pl] + (int64_t)y * f.dstStride[pl];
+        if (p.dstKind == DSTK_PLANAR16 || p.dstKind == DSTK_PLANARN) {
+            uint32_t o[PX];
+            if (p.dstKind == DSTK_PLANAR16) {
+#pragma unroll
+                for (int k = 0; k < PX; k++) o[k] = (uint32_t)clip_u16((out[q][k] + 4) >> 3);
+            } else {
+                const int shift = 15 - p.dst_bits;
+#pragma unroll
+                for (int k = 0; k < PX; k++) o[k] = (uint32_t)clip_uintp2((out[q][k] + (1 << (shift - 1))) >> shift, p.dst_bits);
+            }
+            if (n == PX) {
+                u32x4 v = { o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16) };
+                gstore16_nt(d + 2 * x, v);
+            } else for (int k = 0; k < n; k++) ((uint16_t *)d)[x + k] = (uint16_t)o[k];
+        } else {
+            const int off = q == 2 ? 3 : 0;
+            for (int k = 0; k < n; k++) d[x + k] = (uint8_t)clip_u8_shr(out[q][k] + dither8(p.should_dither, y, x + k + off), 7);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// C3a: planarToP01xWrapper (swscale_unscaled.c:273-322) for aligned 16-bit sources, streaming form.
+// grid.y = luma rows then chroma rows; a lane moves CH x 16 bytes spaced one wave apart, so every load/store
+// instruction of a wave covers 1 KiB of contiguous memory; plane pointers live in SGPRs; stores are non-temporal.
+// Luma: out = in << shiftY.  Chroma: 4 U + 4 V samples -> 4 interleaved pairs (16 bytes).
+// ------------------------------------------------------------------------------------------
+template <int CH>
+__global__ void __launch_bounds__(256) sws_k_p01x_stream(SwsFrameSet fs, SwsDevParams p, int y0, int nrows)
+{
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = blockIdx.y;
+    const int chr_rows = (nrows + 1) >> 1;
+    auto sh2 = [](uint32_t w, int sh) { return (uint32_t)(uint16_t)((w & 0xFFFF) << sh) | ((uint32_t)(uint16_t)((w >> 16) << sh) << 16); };
+    if (r < nrows) {
+        const int y = y0 + r;
+        const uint8_t *srow = f.src[0] + (int64_t)y * f.srcStride[0];
+        uint8_t *drow = f.dst[0] + (int64_t)y * f.dstStride[0];
+        const int row_bytes = 2 * p.srcW, sh = p.shiftY;
+        u32x4 v[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int off = ((wave * CH + k) * 64 + lane) * 16;
+            if (off + 16 <= row_bytes) v[k] = gload16(srow + off);
+            else if (off < row_bytes) v[k] = gload16_partial(srow + off, row_bytes - off);
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int off = ((wave * CH + k) * 64 + lane) * 16;
+            if (off >= row_bytes) continue;
+            const u32x4 o = { sh2(v[k][0], sh), sh2(v[k][1], sh), sh2(v[k][2], sh), sh2(v[k][3], sh) };
+            if (off + 16 <= row_bytes) gstore16_nt(drow + off, o); else gstore_partial(drow + off, o, row_bytes - off);
+        }
+    } else if (r < nrows + chr_rows) {
+        const int cr = (y0 >> 1) + (r - nrows);
+        const int cw = p.srcW / 2;                             // the reference converts srcW/2 chroma samples (:311)
+        const uint8_t *su = f.src[1] + (int64_t)cr * f.srcStride[1], *sv = f.src[2] + (int64_t)cr * f.srcStride[2];
+        uint8_t *drow = f.dst[1] + (int64_t)cr * f.dstStride[1];
+        const int in_bytes = 2 * cw, shu = p.shiftU, shv = p.shiftV;
+        u32x2 u[CH], w[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int off = ((wave * CH + k) * 64 + lane) * 8;   // bytes into the U / V row: 4 samples
+            if (off + 8 <= in_bytes) { u[k] = gload8(su + off); w[k] = gload8(sv + off); }
+            else if (off < in_bytes) {
+                const u32x4 tu = gload16_partial(su + off, in_bytes - off), tv = gload16_partial(sv + off, in_bytes - off);
+                u[k][0] = tu[0]; u[k][1] = tu[1]; w[k][0] = tv[0]; w[k][1] = tv[1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int off = ((wave * CH + k) * 64 + lane) * 8;
+            if (off >= in_bytes) continue;
+            auto il = [&](uint32_t a, uint32_t b) { return (uint32_t)(uint16_t)(a << shu) | ((uint32_t)(uint16_t)(b << shv) << 16); };
+            const u32x4 o = { il(u[k][0] & 0xFFFF, w[k][0] & 0xFFFF), il(u[k][0] >> 16, w[k][0] >> 16),
+                              il(u[k][1] & 0xFFFF, w[k][1] & 0xFFFF), il(u[k][1] >> 16, w[k][1] >> 16) };
+            if (off + 8 <= in_bytes) gstore16_nt(drow + 2 * off, o); else gstore_partial(drow + 2 * off, o, 2 * (in_bytes - off));
+        }
+    }
+}
+
+} // namespace swsk

@@ -16,9 +16,16 @@
 //    by the hardware); vmcnt counts loads and stores together and the compiler must assume they retire out of order, so a
 //    row's stores are issued AFTER the wait for the prefetched rows and BEFORE the next prefetch is issued.
 #pragma once
-#include "kernels_wave.hpp"
+#include "wave_util.hpp"
 
 namespace swsk {
+
+// g.debug switches stages off for profiling (results are WRONG): only in -DSWS_HIP_PROFILING builds
+#ifdef SWS_HIP_PROFILING
+#define SWS_DBG(g, bit) ((g).debug & (bit))
+#else
+#define SWS_DBG(g, bit) false
+#endif
 
 struct StripLds { uint32_t *S; int row_dw; };
 
@@ -158,7 +165,7 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
     uint32_t pend[NCOMP][COLS];
     int pend_y = -1;
     auto flush = [&]() {
-        if (pend_y >= 0 && !(g.debug & 4)) {
+        if (pend_y >= 0 && !SWS_DBG(g, 4)) {
             switch (kind) {
             case 0:
 #pragma unroll
@@ -207,7 +214,7 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
         }
         while (qnext <= pfy + npv - 1) {
             uint32_t np[NCOMP][COLS];
-            if (g.debug & 1) {
+            if (SWS_DBG(g, 1)) {
 #pragma unroll
                 for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
@@ -236,7 +243,7 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
         flush();                                               // (a row that needed no new pair still has to release the previous one)
         // ---- vertical stage: the npv newest ring entries are pairs pfy .. pfy + npv - 1 ----
         int acc[NCOMP][COLS];
-        if (g.debug & 2) {
+        if (SWS_DBG(g, 2)) {
 #pragma unroll
             for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll

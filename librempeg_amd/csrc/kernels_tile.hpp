@@ -9,9 +9,17 @@
 // from the filter banks (SwsTileGeom); arithmetic is the generic kernels' (same device functions).
 #pragma once
 #include "kernels_generic.hpp"
-#include "kernels_wave.hpp"
+#include "wave_util.hpp"
 
 namespace swsk {
+
+#ifndef SWS_DBG
+#ifdef SWS_HIP_PROFILING
+#define SWS_DBG(g, bit) ((g).debug & (bit))
+#else
+#define SWS_DBG(g, bit) false
+#endif
+#endif
 
 template <typename HT> struct LdsSampler {
     const HT *h[3]; int r0, x0, tw;
@@ -196,7 +204,7 @@ __global__ void __launch_bounds__(NT) sws_k_tile_dot2(SwsFrameSet fs, SwsDevPara
                     *(u32x4 *)dst = lo; *(u32x4 *)(dst + 4) = hi;
                 }
             };
-            if (g.debug & 4) {} else
+            if (SWS_DBG(g, 4)) {} else
             if (chunks >= 32) {   // wide windows: lane = chunk column, wave-uniform rows (scalar address math), 4 rows in flight
                 for (int ch = lane; ch < chunks; ch += 64) {
                     const int64_t boff = csb + (int64_t)ch * 16;
@@ -233,7 +241,7 @@ __global__ void __launch_bounds__(NT) sws_k_tile_dot2(SwsFrameSet fs, SwsDevPara
         //      (one dword store per pair: {even row, odd row}) ----
         {
             const int xl = tid & (g.TW - 1), half = tid / g.TW;    // TW == 128: two interleaved pair phases
-            if (xl < tw && !(g.debug & 1)) {
+            if (xl < tw && !SWS_DBG(g, 1)) {
                 const int x = x0 + xl;
                 const int spd = ((hpos[x] & ~1) - cs) >> 1;          // dword index of the first (even-aligned) pair
                 const uint32_t *tp = (const uint32_t *)(g.hT2 + (int64_t)x * g.hfs2);
@@ -253,7 +261,7 @@ __global__ void __launch_bounds__(NT) sws_k_tile_dot2(SwsFrameSet fs, SwsDevPara
     const int q4 = (tw + 3) >> 2;
     const int bits = p.dst_bits;
     const int q4s = 31 - __builtin_clz((unsigned)(g.TW >> 2));      // log2(TW / 4): full-width tiles index with shifts
-    for (int i = tid; i < ((g.debug & 2) ? 0 : q4 * th); i += NT) {
+    for (int i = tid; i < (SWS_DBG(g, 2) ? 0 : q4 * th); i += NT) {
         const int yl = tw == g.TW ? i >> q4s : i / q4, xl = 4 * (i - yl * q4);
         const int y = y0 + yl, x = x0 + xl;
         const int n = min(4, tw - xl);

@@ -7,68 +7,16 @@
 // Plane pointers / strides live in SGPRs (FrameRegs), loads and stores use the global address space,
 // the output is written non-temporally.  Arithmetic is the generic kernels' arithmetic.
 #pragma once
-#include "kernels_fast.hpp"
+#include "wave_util.hpp"
 
 namespace swsk {
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-#define SWS_GLOBAL __attribute__((address_space(1)))
-
-__device__ __forceinline__ u32x4 gload16(const uint8_t *p) { return *(const SWS_GLOBAL u32x4 *)p; }
-__device__ __forceinline__ u32x2 gload8(const uint8_t *p) { return *(const SWS_GLOBAL u32x2 *)p; }
-__device__ __forceinline__ void gstore16_nt(uint8_t *p, u32x4 v) { __builtin_nontemporal_store(v, (SWS_GLOBAL u32x4 *)p); }
-
-// row tails: n (< 16 / < 8) valid bytes, the rest reads as 0.  Out of line: rare, keeps the hot loop small.
-__device__ __noinline__ u32x4 gload16_partial(const uint8_t *s, int n)
-{
-    uint32_t w[4] = { 0, 0, 0, 0 };
-    for (int k = 0; k < n; k++) w[k >> 2] |= (uint32_t)s[k] << (8 * (k & 3));
-    u32x4 v = { w[0], w[1], w[2], w[3] };
-    return v;
-}
-__device__ __noinline__ void gstore_partial(uint8_t *d, u32x4 v, int n)
-{
-    uint32_t w[4] = { v[0], v[1], v[2], v[3] };
-    for (int b = 0; b < n; b++) d[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
-}
-__device__ __forceinline__ u32x4 load16_or_tail(const uint8_t *s, int nvalid)
-{
-    return nvalid >= 16 ? gload16(s) : gload16_partial(s, max(nvalid, 0));
-}
-__device__ __forceinline__ u32x2 load8_or_tail(const uint8_t *s, int nvalid)
-{
-    if (nvalid >= 8) return gload8(s);
-    const u32x4 t = gload16_partial(s, max(nvalid, 0));
-    u32x2 r = { t[0], t[1] };
-    return r;
-}
-
-__device__ __forceinline__ void unpack16(u32x4 v, int (&o)[16])
-{
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) o[4 * q + k] = (v[q] >> (8 * k)) & 0xFF;
-}
-__device__ __forceinline__ void unpack8(u32x2 v, int (&o)[8])
-{
-#pragma unroll
-    for (int q = 0; q < 2; q++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) o[4 * q + k] = (v[q] >> (8 * k)) & 0xFF;
-}
-
-// Four values t0..t3 -> one dword of bytes clip_u8(t >> 16).  v_ashr_pk_u8_i32 (new on gfx950) shifts two int32, saturates
-// them to u8 and writes ONE HALF of the destination (low half, or high half with op_sel[3]); the other half is preserved
-// (semantics verified on hardware with tools/isa_probe.hip).  Two of them clamp, shift and pack 4 channel values.
-__device__ __forceinline__ uint32_t pack4_u8_shr16(int t0, int t1, int t2, int t3)
-{
-    uint32_t d;
-    asm("v_ashr_pk_u8_i32 %0, %1, %2, 16\n\tv_ashr_pk_u8_i32 %0, %3, %4, 16 op_sel:[0,0,0,1]"
-        : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3));
-    return d;
-}
+// EXP template arguments select profiling experiments (results are WRONG): they exist only in -DSWS_HIP_PROFILING builds
+#ifdef SWS_HIP_PROFILING
+#define SWS_EXP(n) (EXP == (n))
+#else
+#define SWS_EXP(n) false
+#endif
 
 // chroma part of the LUT for the 8 pixel pairs of a lane
 struct Chroma8 { int r[8], g[8], b[8]; };
@@ -188,7 +136,7 @@ __global__ void __launch_bounds__(256) sws_k_yuv2rgb_unscaled_wave(SwsFrameSet f
             chroma8<SWAP_RB>(L, U, V, c);
         }
         unpack16(load16_or_tail(f.src[0] + (int64_t)(yrow + l) * f.srcStride[0] + x, nvalid), Y);
-        if constexpr (EXP == 1) { // experiment: memory-only floor (no LUT arithmetic)
+        if constexpr (SWS_EXP(1)) { // experiment: memory-only floor (no LUT arithmetic)
 #pragma unroll
             for (int k = 0; k < 4 * BPP; k++) w[k] = (uint32_t)(Y[k & 15] + U[k & 7] * 256 + V[(k + 3) & 7] * 65536);
         } else lut16<BPP>(L, Y, c, w);
@@ -196,139 +144,6 @@ __global__ void __launch_bounds__(256) sws_k_yuv2rgb_unscaled_wave(SwsFrameSet f
         wave_store16<BPP, XPOSE, NT>(segp, seg_bytes, w, lds, lane);
     }
 }
-
-// ------------------------------------------------------------------------------------------
-// C2b / C4: polyphase chain with identity horizontal filters, 8-bit planar or nv12 source, packed RGB
-// LUT writer, general vertical filters in "X" mode (yuv2rgb_X_c_template, output.c:1788-1840).
-// Wave = 1024 pixels x ROWS output rows.  Chroma source rows are loaded ONCE per lane and accumulated
-// into the ROWS outputs that use them (integer adds are associative, so the order is irrelevant to the
-// result); luma rows are per output row.  Vertical taps sit one-per-lane in a VGPR and are broadcast with
-// v_readlane (no memory access inside the accumulation loop).  The host launches this kernel only when every output row is
-// in X mode (no row selects the _1/_2 writers of vscale.c:135-157).
-// ------------------------------------------------------------------------------------------
-template <int BPP, bool SWAP_RB, bool NV, int ROWS, int NCR>
-__global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_wave(SwsFrameSet fs, SwsDevParams p)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4 * 64 * (BPP == 4 ? 20 : 12)];
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t *lds = lds_all + wib * 64 * (BPP == 4 ? 20 : 12);
-    const int npix = p.dstW;                                   // even (odd widths force the full-chroma writers)
-    const int segs = (npix + 1023) >> 10;
-    const int rgroups = (p.dstH + ROWS - 1) / ROWS;
-    // XCD-aware block order: the dispatcher places block b on XCD b % 8 (speed-only assumption, gridDim.x is a
-    // multiple of 8).  Give every XCD a contiguous band of row groups so that the chroma source rows shared by
-    // vertically adjacent row groups are re-read from that XCD's own L2 instead of from the fabric.
-    const int per_xcd = gridDim.x >> 3;
-    const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int64_t wid = (int64_t)lb * 4 + wib;
-    if (wid >= (int64_t)segs * rgroups) return;
-    const int rg = (int)(wid / segs), seg = (int)(wid % segs);
-    const FrameRegs f = load_frame(fs, blockIdx.z);
-    const SwsLutParams &L = p.lut;
-    const int x = seg * 1024 + lane * 16;
-    const int seg_bytes = min(1024, npix - seg * 1024) * BPP;
-    const int nvalid = npix - x;
-    const int lfs = p.vLumFs, cfs = p.vChrFs;
-    const int lH = p.srcH - 1, cH = p.chrSrcH - 1;
-    const int yb = rg * ROWS;
-    const int nrows = min(ROWS, p.dstH - yb);
-
-    // per output row: chroma window start (scalar) and its taps, one tap per lane (read back with v_readlane)
-    int firstC[ROWS], wv[ROWS];
-    int cmin = 0x7fffffff, cmax = -1;
-#pragma unroll
-    for (int r = 0; r < ROWS; r++) {
-        const int y = min(yb + r, p.dstH - 1);
-        const int cy = y >> p.chrDstVSub;
-        firstC[r] = max(1 - cfs, p.vChrPos[cy]);
-        wv[r] = lane < cfs ? (int)p.vChrF[cy * cfs + lane] : 0;
-        cmin = min(cmin, firstC[r]); cmax = max(cmax, firstC[r] + cfs - 1);
-    }
-    // issue the loads of every chroma source row of the group first (host guarantees cmax - cmin < NCR) ...
-    const bool u1 = p.u_plane_src == 1;   // planes selected with ?: (runtime-indexed FrameRegs would go to scratch)
-    const uint8_t *ub = u1 ? f.src[1] : f.src[2], *vb = u1 ? f.src[2] : f.src[1];
-    const int us = u1 ? f.srcStride[1] : f.srcStride[2], vs = u1 ? f.srcStride[2] : f.srcStride[1];
-    u32x4 craw[NCR];
-#pragma unroll
-    for (int i = 0; i < NCR; i++) {
-        const int cr = cmin + i;
-        if (cr <= cmax) {
-            const int srow = min(max(cr, 0), cH);
-            if constexpr (NV) craw[i] = load16_or_tail(f.src[1] + (int64_t)srow * f.srcStride[1] + x, nvalid);
-            else {
-                const u32x2 a = load8_or_tail(ub + (int64_t)srow * us + (x >> 1), nvalid >> 1);
-                const u32x2 b = load8_or_tail(vb + (int64_t)srow * vs + (x >> 1), nvalid >> 1);
-                u32x4 t = { a[0], a[1], b[0], b[1] };
-                craw[i] = t;
-            }
-        }
-    }
-    // ... then accumulate each of them into every output row whose window contains it
-    int U[ROWS][8], V[ROWS][8];
-#pragma unroll
-    for (int r = 0; r < ROWS; r++)
-#pragma unroll
-        for (int k = 0; k < 8; k++) U[r][k] = V[r][k] = 1 << 18;
-#pragma unroll
-    for (int i = 0; i < NCR; i++) {
-        const int cr = cmin + i;
-        if (cr <= cmax) {
-            int u[8], v[8];
-            if constexpr (NV) {
-                int t[16];
-                unpack16(craw[i], t);
-#pragma unroll
-                for (int k = 0; k < 8; k++) { u[k] = t[2 * k + p.uv_swap_src]; v[k] = t[2 * k + 1 - p.uv_swap_src]; }
-            } else {
-                u32x2 a = { craw[i][0], craw[i][1] }, b = { craw[i][2], craw[i][3] };
-                unpack8(a, u); unpack8(b, v);
-            }
-#pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                const int j = cr - firstC[r];
-                if (j >= 0 && j < cfs) {                              // wave-uniform
-                    // (u << 7) * w == u * (w << 7); |w << 7| < 2^23 so the product stays a full-rate 24-bit multiply
-                    const int wgt = __builtin_amdgcn_readlane(wv[r], j) << 7;
-#pragma unroll
-                    for (int k = 0; k < 8; k++) { U[r][k] = mad24(u[k], wgt, U[r][k]); V[r][k] = mad24(v[k], wgt, V[r][k]); }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < ROWS; r++) {
-        if (r >= nrows) break;
-        const int y = yb + r;
-        const int16_t *lf = p.vLumF + y * lfs;
-        const int firstL = max(1 - lfs, p.vLumPos[y]);
-        int Y[16], Uo[8], Vo[8], t[16];
-        if (lfs == 1 && lf[0] == 4096) {
-            // ((1 << 18) + (y << 7) * 4096) >> 19 == y: identity vertical luma filter (same-height conversions)
-            unpack16(load16_or_tail(f.src[0] + (int64_t)min(firstL, lH) * f.srcStride[0] + x, nvalid), Y);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) Y[k] = 1 << 18;
-            for (int j = 0; j < lfs; j++) {
-                unpack16(load16_or_tail(f.src[0] + (int64_t)min(firstL + j, lH) * f.srcStride[0] + x, nvalid), t);
-                const int wgt = (int)lf[j] << 7;
-#pragma unroll
-                for (int k = 0; k < 16; k++) Y[k] = mad24(t[k], wgt, Y[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < 16; k++) Y[k] >>= 19;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) { Uo[k] = U[r][k] >> 19; Vo[k] = V[r][k] >> 19; }
-        uint32_t w[4 * BPP];
-        Chroma8 c;
-        chroma8<SWAP_RB>(L, Uo, Vo, c);
-        lut16<BPP>(L, Y, c, w);
-        uint8_t *segp = f.dst[0] + (int64_t)y * f.dstStride[0] + (int64_t)seg * 1024 * BPP;
-        wave_store16<BPP>(segp, seg_bytes, w, lds, lane);
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------
 // Second generation of the kernel above (same decomposition, same results, about half the vector instructions):
@@ -342,30 +157,6 @@ __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_wave(SwsFrameSet fs
 //  * 32 bpp: the alpha byte position is a template parameter (operand order of the pack) instead of a v_perm per pixel;
 //  * segments that lie completely inside the row take a store path without per-lane bounds checks.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t pack4_u8_shr12(int t0, int t1, int t2, int t3)
-{
-    uint32_t d;
-    asm("v_ashr_pk_u8_i32 %0, %1, %2, 12\n\tv_ashr_pk_u8_i32 %0, %3, %4, 12 op_sel:[0,0,0,1]"
-        : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3));
-    return d;
-}
-__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
-{
-    typedef short s16x2w __attribute__((ext_vector_type(2)));
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2w, a), __builtin_bit_cast(s16x2w, b), c, false);
-}
-// 16 bytes of row A and row B -> 16 dwords (A_k | B_k << 16)
-__device__ __forceinline__ void interleave_rows(const u32x4 &A, const u32x4 &B, uint32_t (&P)[16])
-{
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        P[4 * q + 0] = __builtin_amdgcn_perm(B[q], A[q], 0x0c040c00u);
-        P[4 * q + 1] = __builtin_amdgcn_perm(B[q], A[q], 0x0c050c01u);
-        P[4 * q + 2] = __builtin_amdgcn_perm(B[q], A[q], 0x0c060c02u);
-        P[4 * q + 3] = __builtin_amdgcn_perm(B[q], A[q], 0x0c070c03u);
-    }
-}
-
 template <int BPP, bool FULL, bool NT = true>
 __device__ __forceinline__ void wave_store16_v2(uint8_t *seg, int seg_bytes, const uint32_t (&w)[4 * BPP], uint32_t *lds, int lane)
 {
@@ -574,25 +365,6 @@ __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_wave2(SwsFrameSet f
 //    wave's life waiting: VALU 50 % busy at 40 % of the HBM roofline);
 //  * everything a step needs from the filter banks is a 64-byte host-built plan entry fetched with scalar loads.
 // ------------------------------------------------------------------------------------------
-//  * memory goes through buffer descriptors: the per-lane offset is a constant VGPR, the row offset an SGPR (no 64-bit vector
-//    address arithmetic), reads past the end of a row stay inside the plane's descriptor (out-of-range dwords read 0 and feed
-//    pixels that are never stored), stores past the end of a row are dropped by the per-row destination descriptor.
-typedef __amdgpu_buffer_rsrc_t sws_rsrc_t;
-__device__ __forceinline__ sws_rsrc_t make_rsrc(const void *base, uint32_t bytes)
-{
-    // descriptor inputs go through readfirstlane so that their uniformity is provable (else every buffer op gets a waterfall loop)
-    void *b = (void *)uniform_u64((uint64_t)base);
-    return __builtin_amdgcn_make_buffer_rsrc(b, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
-}
-__device__ __forceinline__ u32x4 bload16(sws_rsrc_t r, int voff, int soff)
-{
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ u32x2 bload8(sws_rsrc_t r, int voff, int soff)
-{
-    return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
-}
-
 template <int BPP, bool SWAP_RB, bool NV, bool AFIRST, int NCR, int EXP = 0>
 __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_march(SwsFrameSet fs, SwsDevParams p, const SwsRgbGroupPlan *__restrict__ plan,
                                                                    int ngroups, int bands, int band_groups)
@@ -657,7 +429,7 @@ __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_march(SwsFrameSet f
             for (int k = 0; k < 16; k++) acc[r][k] = 2048;
 #pragma unroll
         for (int ip = 0; ip < NCR / 2; ip++) {
-            if constexpr (EXP == 2) {       // experiment: no vertical filter
+            if constexpr (SWS_EXP(2)) {       // experiment: no vertical filter
 #pragma unroll
                 for (int k = 0; k < 16; k++) { acc[0][k] += craw[2 * ip][k & 3]; acc[1][k] += craw[2 * ip + 1][k & 3]; }
                 continue;
@@ -689,7 +461,7 @@ __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_march(SwsFrameSet f
                 for (int q = 0; q < 4; q++) uvp[q] = pack4_u8_shr12(acc[r][2 * q], acc[r][8 + 2 * q], acc[r][2 * q + 1], acc[r][8 + 2 * q + 1]);
             }
             uint32_t w[NDW];
-            if constexpr (EXP == 1) {       // experiment: memory-only floor (no LUT stage)
+            if constexpr (SWS_EXP(1)) {       // experiment: memory-only floor (no LUT stage)
 #pragma unroll
                 for (int k = 0; k < NDW; k++) w[k] = (uint32_t)Y[k & 15] + uvp[k & 3];
             } else lut16_v2<BPP, SWAP_RB, AFIRST>(L, Y, uvp, w);
@@ -717,7 +489,7 @@ __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_march(SwsFrameSet f
             const int y = 2 * g + r;
             if (y >= p.dstH) break;
             uint8_t *segp = f.dst[0] + (int64_t)y * f.dstStride[0] + (int64_t)seg * 1024 * BPP;
-            const sws_rsrc_t rd = make_rsrc(segp, EXP == 3 ? (p.dstW == 12345 ? 16u : 0u) : (uint32_t)seg_bytes);   // a dword that straddles the end is dropped as a whole
+            const sws_rsrc_t rd = make_rsrc(segp, SWS_EXP(3) ? (p.dstW == 12345 ? 16u : 0u) : (uint32_t)seg_bytes);   // a dword that straddles the end is dropped as a whole
             const uint32_t *lr = lds + r * 64 * LS;
 #pragma unroll
             for (int j = 0; j < NCH; j++) {
@@ -736,150 +508,6 @@ __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_march(SwsFrameSet f
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();              // the next step reuses the LDS region
         e = en; en = en2;
-    }
-}
-
-} // namespace swsk
-
-namespace swsk {
-
-// ------------------------------------------------------------------------------------------
-// C5: planar float RGB -> planar 4:4:4 YUV with identity filters in both directions
-// (planar_rgbf32_to_y/uv input.c:1300-1334 -> hScale16To15/19_c with 1 tap -> lum/chrRange*Jpeg(16)_c ->
-//  yuv2plane1_{8,10,16}_c).  Every pixel is independent: lane = 4 pixels (3 x 16-byte float loads, 3 stores),
-// all three output planes come from ONE pass over the input (the generic path re-reads and re-quantises the
-// three float planes once per output plane).  grid.x over 4-pixel groups of a frame, grid.z = frame.
-// ------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
-
-__global__ void __launch_bounds__(256) sws_k_f32rgb_to_yuv444_unity(SwsFrameSet fs, SwsDevParams p)
-{
-    constexpr int PX = 8;                                       // pixels per lane: 2 x 16-byte loads per plane, one 16-byte store per plane
-    const int groups = (p.srcW + PX - 1) / PX;
-    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= (int64_t)groups * p.srcH) return;
-    const int y = (int)(item / groups), x = PX * (int)(item % groups);
-    const FrameRegs f = load_frame(fs, blockIdx.z);
-    const int n = min(PX, p.srcW - x);
-    float g[PX], b[PX], r[PX];
-    const uint8_t *pg = f.src[0] + (int64_t)y * f.srcStride[0] + 4 * x, *pb = f.src[1] + (int64_t)y * f.srcStride[1] + 4 * x,
-                  *pr = f.src[2] + (int64_t)y * f.srcStride[2] + 4 * x;
-    if (n == PX) {
-#pragma unroll
-        for (int h = 0; h < PX / 4; h++) {
-            const f32x4 vg = *(const SWS_GLOBAL f32x4 *)(pg + 16 * h), vb = *(const SWS_GLOBAL f32x4 *)(pb + 16 * h), vr = *(const SWS_GLOBAL f32x4 *)(pr + 16 * h);
-#pragma unroll
-            for (int k = 0; k < 4; k++) { g[4 * h + k] = vg[k]; b[4 * h + k] = vb[k]; r[4 * h + k] = vr[k]; }
-        }
-    } else {
-        for (int k = 0; k < PX; k++) {
-            const bool in = k < n;
-            g[k] = in ? ((const float *)pg)[k] : 0.f; b[k] = in ? ((const float *)pb)[k] : 0.f; r[k] = in ? ((const float *)pr)[k] : 0.f;
-        }
-    }
-    const int32_t *t = p.rgb2yuv;
-    int out[3][PX];
-#pragma unroll
-    for (int k = 0; k < PX; k++) {
-        const int gi = f32_to_u16(g[k]), bi = f32_to_u16(b[k]), ri = f32_to_u16(r[k]);
-        // 16-bit samples x 15-bit coefficients: 24-bit multiplies, 32-bit wrap-around sums like the C code
-        int c[3];
-        c[0] = (int)((unsigned)(mad24(t[0], ri, mad24(t[1], gi, __mul24(t[2], bi))) + (int)(0x2001u << 14))) >> 15;
-        c[1] = (int)((unsigned)(mad24(t[3], ri, mad24(t[4], gi, __mul24(t[5], bi))) + (int)(0x10001u << 14))) >> 15;
-        c[2] = (int)((unsigned)(mad24(t[6], ri, mad24(t[7], gi, __mul24(t[8], bi))) + (int)(0x10001u << 14))) >> 15;
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            int v = min((int)(((uint16_t)c[q] * 16384u) >> p.hshift), p.hclip);   // 1-tap hscale of the u16 line
-            if (!p.wide) v = (int16_t)v;
-            out[q][k] = range_sample(p, v, q != 0);
-        }
-    }
-    // vertical 1-tap writers (yuv2plane1_*): planes Y, U, V
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-        const int pl = q == 0 ? 0 : q == 1 ? 1 : 2;  // yuv444p*: U = plane 1, V = plane 2
-        uint8_t *d = f.dst[pl] + (int64_t)y * f.dstStride[pl];
-        if (p.dstKind == DSTK_PLANAR16 || p.dstKind == DSTK_PLANARN) {
-            uint32_t o[PX];
-            if (p.dstKind == DSTK_PLANAR16) {
-#pragma unroll
-                for (int k = 0; k < PX; k++) o[k] = (uint32_t)clip_u16((out[q][k] + 4) >> 3);
-            } else {
-                const int shift = 15 - p.dst_bits;
-#pragma unroll
-                for (int k = 0; k < PX; k++) o[k] = (uint32_t)clip_uintp2((out[q][k] + (1 << (shift - 1))) >> shift, p.dst_bits);
-            }
-            if (n == PX) {
-                u32x4 v = { o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16) };
-                gstore16_nt(d + 2 * x, v);
-            } else for (int k = 0; k < n; k++) ((uint16_t *)d)[x + k] = (uint16_t)o[k];
-        } else {
-            const int off = q == 2 ? 3 : 0;
-            for (int k = 0; k < n; k++) d[x + k] = (uint8_t)clip_u8_shr(out[q][k] + dither8(p.should_dither, y, x + k + off), 7);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// C3a: planarToP01xWrapper (swscale_unscaled.c:273-322) for aligned 16-bit sources, streaming form.
-// grid.y = luma rows then chroma rows; a lane moves CH x 16 bytes spaced one wave apart, so every load/store
-// instruction of a wave covers 1 KiB of contiguous memory; plane pointers live in SGPRs; stores are non-temporal.
-// Luma: out = in << shiftY.  Chroma: 4 U + 4 V samples -> 4 interleaved pairs (16 bytes).
-// ------------------------------------------------------------------------------------------
-template <int CH>
-__global__ void __launch_bounds__(256) sws_k_p01x_stream(SwsFrameSet fs, SwsDevParams p, int y0, int nrows)
-{
-    const FrameRegs f = load_frame(fs, blockIdx.z);
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = blockIdx.y;
-    const int chr_rows = (nrows + 1) >> 1;
-    auto sh2 = [](uint32_t w, int sh) { return (uint32_t)(uint16_t)((w & 0xFFFF) << sh) | ((uint32_t)(uint16_t)((w >> 16) << sh) << 16); };
-    if (r < nrows) {
-        const int y = y0 + r;
-        const uint8_t *srow = f.src[0] + (int64_t)y * f.srcStride[0];
-        uint8_t *drow = f.dst[0] + (int64_t)y * f.dstStride[0];
-        const int row_bytes = 2 * p.srcW, sh = p.shiftY;
-        u32x4 v[CH];
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int off = ((wave * CH + k) * 64 + lane) * 16;
-            if (off + 16 <= row_bytes) v[k] = gload16(srow + off);
-            else if (off < row_bytes) v[k] = gload16_partial(srow + off, row_bytes - off);
-        }
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int off = ((wave * CH + k) * 64 + lane) * 16;
-            if (off >= row_bytes) continue;
-            const u32x4 o = { sh2(v[k][0], sh), sh2(v[k][1], sh), sh2(v[k][2], sh), sh2(v[k][3], sh) };
-            if (off + 16 <= row_bytes) gstore16_nt(drow + off, o); else gstore_partial(drow + off, o, row_bytes - off);
-        }
-    } else if (r < nrows + chr_rows) {
-        const int cr = (y0 >> 1) + (r - nrows);
-        const int cw = p.srcW / 2;                             // the reference converts srcW/2 chroma samples (:311)
-        const uint8_t *su = f.src[1] + (int64_t)cr * f.srcStride[1], *sv = f.src[2] + (int64_t)cr * f.srcStride[2];
-        uint8_t *drow = f.dst[1] + (int64_t)cr * f.dstStride[1];
-        const int in_bytes = 2 * cw, shu = p.shiftU, shv = p.shiftV;
-        u32x2 u[CH], w[CH];
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int off = ((wave * CH + k) * 64 + lane) * 8;   // bytes into the U / V row: 4 samples
-            if (off + 8 <= in_bytes) { u[k] = gload8(su + off); w[k] = gload8(sv + off); }
-            else if (off < in_bytes) {
-                const u32x4 tu = gload16_partial(su + off, in_bytes - off), tv = gload16_partial(sv + off, in_bytes - off);
-                u[k][0] = tu[0]; u[k][1] = tu[1]; w[k][0] = tv[0]; w[k][1] = tv[1];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int off = ((wave * CH + k) * 64 + lane) * 8;
-            if (off >= in_bytes) continue;
-            auto il = [&](uint32_t a, uint32_t b) { return (uint32_t)(uint16_t)(a << shu) | ((uint32_t)(uint16_t)(b << shv) << 16); };
-            const u32x4 o = { il(u[k][0] & 0xFFFF, w[k][0] & 0xFFFF), il(u[k][0] >> 16, w[k][0] >> 16),
-                              il(u[k][1] & 0xFFFF, w[k][1] & 0xFFFF), il(u[k][1] >> 16, w[k][1] >> 16) };
-            if (off + 8 <= in_bytes) gstore16_nt(drow + 2 * off, o); else gstore_partial(drow + 2 * off, o, 2 * (in_bytes - off));
-        }
     }
 }
 

@@ -93,7 +93,21 @@ enum PlanKind {
 int init_from_frames(struct SwsInternal *c, int sw, int sh, int sfmt, int dw, int dh, int dfmt);
 int canonical_pix_fmt(int fmt); // handle_jpeg + handle_0alpha aliases (utils.c:773-842)
 
-struct DeviceState;  // HIP side (device.cpp)
+struct DeviceState;  // HIP side (devstate.hpp)
+
+// Launch heuristics of a context.  sws_hip_set_option() changes them (A/B measurements, tests that force a kernel onto shapes
+// the planner would give to another one); every combination produces the same bytes.  `debug` is read only by
+// -DSWS_HIP_PROFILING builds (stage switches whose results are wrong).
+struct Tuning {
+    int strip_min_w = 1024;        // narrower pictures stay on the LDS-tile kernel
+    int strip_cols_l = 4, strip_cols_c = 2, strip_waves = 4096;
+    int rgb_march_waves = 12288;   // resident waves the packed-RGB march kernel is banded for
+    int tile_lds_kb = 40, tile_threads = 256;
+    int p01x_ch = 1;
+    int no_wave = 0, no_march = 0, no_strip = 0, no_dot2 = 0, no_tile = 0;
+    int max_devices = 0;           // sws_scale_frames(): GPUs to shard over (0 = all visible)
+    int debug = 0;
+};
 
 struct SwsInternal {
     SwsContext opts;          // MUST be first: the public struct (swscale_internal.h:337-340 idiom)
@@ -105,6 +119,7 @@ struct SwsInternal {
     bool srcXYZ = false, dstXYZ = false; // handle_xyz (utils.c:822-842): the caller's formats were xyz12, opts.*_format hold rgb48le
     bool srcBE = false, dstBE = false;   // the caller's formats were big-endian: opts.src_format / dst_format hold the LE twins
     bool dynamic_init = false;    // configured from the frames of sws_scale_frame() (swscale.c:1405-1480)
+    int user_src_range = 0, user_dst_range = 0, eff_src_range = 0, eff_dst_range = 0;   // dynamic mode: ranges as the caller set them / after the yuvj-gray aliasing
     int sliceDir = 0;             // 0 = no slice sequence in progress, 1 = top-down, -1 = bottom-up (swscale.c:1096-1104)
     int slice_dstY = 0;           // ff_swscale's dstY cursor (swscale.c:372-381, :566)
     int src0Alpha = 0, dst0Alpha = 0;
@@ -125,9 +140,12 @@ struct SwsInternal {
     SwsInternal *cascade[2] = {nullptr, nullptr};
     int cascade_fmt = -1, cascade_w = 0, cascade_h = 0;
     std::string path_name, kernel_name;
-    DeviceState *dev = nullptr;
-    bool tables_dirty = true;  // device copies need refresh
+    DeviceState *dev = nullptr;             // state on the context's home GPU
+    std::vector<DeviceState *> peers;       // states on the other GPUs sws_scale_frames() shards over (index = HIP device id, may hold nullptr)
+    uint64_t tables_epoch = 1;              // bumped whenever the host tables change: device copies with another epoch are rebuilt
+    Tuning tune;
 };
+inline void mark_tables_dirty(SwsInternal *c) { c->tables_epoch++; }
 
 inline SwsInternal *internal(SwsContext *c) { return reinterpret_cast<SwsInternal *>(c); }
 inline const SwsInternal *internal(const SwsContext *c) { return reinterpret_cast<const SwsInternal *>(c); }
@@ -137,8 +155,8 @@ void choose_unscaled(SwsInternal *c);       // swscale_unscaled.c:2392-2706
 void log_msg(const SwsInternal *c, int level, const char *fmt, ...);
 
 // ---- device side (device.cpp / kernels.hip) ----
-int  dev_prepare(SwsInternal *c);                         // upload tables, build DevParams
-void dev_release(SwsInternal *c);
+int  dev_prepare(SwsInternal *c);                         // upload tables, build DevParams (home GPU)
+void dev_release(SwsInternal *c);                         // frees the device state on every GPU
 int  dev_run(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4], int srcSliceY, int srcSliceH,
              uint8_t *const dst[4], const int dstStride[4], int nb_frames,
              const SwsFrameView *const *srcFrames, SwsFrameView *const *dstFrames);

@@ -100,7 +100,7 @@ def build_library(force=False):
     src = os.path.join(_HERE, "csrc")
     if force:
         subprocess.check_call(["make", "-s", "-C", src, "clean"])
-    subprocess.check_call(["make", "-s", "-C", src])
+    subprocess.check_call(["make", "-s", "-j", str(max(2, os.cpu_count() or 2)), "-C", src])   # one object per translation unit
     return library_path()
 
 
@@ -183,6 +183,9 @@ def load_library():
     L.sws_hip_last_kernel_ms.restype = C.c_double
     L.sws_hip_last_kernel_ms.argtypes = [vp]
     L.sws_hip_set_timing.argtypes = [vp, ci]
+    L.sws_hip_set_option.argtypes = [vp, C.c_char_p, ci]
+    L.sws_hip_get_device.argtypes = [vp]
+    L.sws_hip_plan_shards.argtypes = [ci, C.POINTER(ci), C.POINTER(ci), ci, ci, C.POINTER(ci)]
     L.swscale_version.restype = C.c_uint
     cd, cf, cu = C.c_double, C.c_float, C.c_uint
     L.sws_allocVec.restype = C.POINTER(SwsVector)
@@ -380,7 +383,7 @@ class SwsContext:
     def scale(self, src, dst, slice_y=0, slice_h=None):
         sp, ss = src.ptrs()
         dp, ds = dst.ptrs()
-        return self.L.sws_scale(self.c, sp, ss, slice_y, self.sh if slice_h is None else slice_h, dp, ds)
+        return self.L.sws_scale(self.c, sp, ss, slice_y, self.fields().src_h if slice_h is None else slice_h, dp, ds)
 
     def scale_frame(self, src, dst):
         """sws_scale_frame(); on an sws_alloc_context()ed context (empty=True) the library configures itself from the frames."""
@@ -412,6 +415,13 @@ class SwsContext:
 
     def sync(self):
         return self.L.sws_hip_sync(self.c)
+
+    def set_option(self, name, value):
+        """launch heuristics of the context (sws_hip_set_option): e.g. strip_min_w, max_devices, no_strip"""
+        r = self.L.sws_hip_set_option(self.c, name.encode(), int(value))
+        if r < 0:
+            raise ValueError(name)
+        return r
 
     def set_timing(self, on=True):
         return self.L.sws_hip_set_timing(self.c, 1 if on else 0)
@@ -456,7 +466,15 @@ class SwsContext:
         r = self.L.sws_hip_tables_import(self.c, buf, len(blob))
         if r < 0:
             raise RuntimeError("tables import failed")
+        self._refresh_geometry()
         return r
+
+    def _refresh_geometry(self):
+        """the wrapper's copy of the geometry follows the C struct (a context that was configured by import_tables())"""
+        f = self.fields()
+        self.sw, self.sh, self.dw, self.dh = f.src_w, f.src_h, f.dst_w, f.dst_h
+        names = {v: k for k, v in PIX_FMT.items()}
+        self.sfmt, self.dfmt = names.get(f.src_format, self.sfmt), names.get(f.dst_format, self.dfmt)
 
     def close(self):
         if getattr(self, "c", None):

@@ -1,13 +1,9 @@
 """-m gpu tests at BASELINE.json's full sizes.
 
-The scalar oracle is too slow to produce full 4K/8K frames for every case in a test run, so full-size parity is
-checked through size-independent properties the domain offers:
-  * locality: a pixel of the output depends only on a bounded source window, so a CROP of the full-size problem that
-    contains the window must reproduce the same bytes -> the oracle runs on crops (top-left, bottom-right, middle) and
-    the HIP full-size output must equal it there bit for bit (unscaled / identity-horizontal paths are exactly local);
-  * batch consistency: sws_scale_frames() over N frames == N sws_scale() calls (checksum of checksums);
-  * idempotence of the context: running the same frame twice gives identical bytes;
-  * linearity-free invariants: constant input -> constant output equal to the oracle's small-size answer.
+Every BASELINE configuration is converted once at its full size and compared with the oracle over the WHOLE frame (the scalar C
+oracle needs 8 ms .. 1 s per frame); the real C4 batch (512 frames through one sws_scale_frames() call) is
+checked frame by frame; widths that straddle the 1024-pixel wave strips are covered at small heights for every wave / march /
+strip / stream kernel.  Size-independent properties on top: batch == N single calls, idempotence, constant image.
 """
 import hashlib
 
@@ -18,6 +14,7 @@ import torch
 import oracle_lib as OL
 from librempeg_amd import (SwsContext, HostFrame, DeviceFrame, plane_layout, SWS_BICUBIC, SWS_BILINEAR, SWS_LANCZOS,
                            SWS_BITEXACT, SWS_ACCURATE_RND, SWS_CS_BT2020)
+from test_gpu_parity import run_case
 
 pytestmark = pytest.mark.gpu
 BX, AR = SWS_BITEXACT, SWS_ACCURATE_RND
@@ -31,112 +28,128 @@ def random_device_frame(fmt, w, h, seed):
     return DeviceFrame(fmt, w, h).upload(hf), hf
 
 
-def crop(frame, fmt, x0, y0, w, h):
-    """crop a HostFrame (x0,y0,w,h even) into an oracle Frame."""
-    out = OL.Frame(fmt, w, h)
-    full = plane_layout(fmt, frame.w, frame.h)
-    part = plane_layout(fmt, w, h)
-    for i, (a, b) in enumerate(zip(out.planes, frame.planes)):
-        bpp_x = full[i][0] / frame.w          # bytes per luma pixel horizontally in this plane
-        sub_y = frame.h // full[i][1]
-        xb, yb = int(x0 * bpp_x), y0 // sub_y
-        a[:, :part[i][0]] = b[yb:yb + part[i][1], xb:xb + part[i][0]]
-    return out
-
-
 def digest(frame):
     return hashlib.sha256(frame.visible()).hexdigest()
 
 
-@pytest.mark.parametrize("sfmt,dfmt,w,h,flags,cs", [
-    ("yuv420p", "rgb24", 3840, 2160, SWS_BICUBIC | BX, None),                        # C2a
-    ("yuv420p10le", "p010le", 7680, 4320, SWS_LANCZOS | BX, None),                    # C3a
-    ("gbrpf32le", "yuv444p16le", 3840, 2160, SWS_BICUBIC | BX, (SWS_CS_BT2020, 1, SWS_CS_BT2020, 1)),  # C5
-], ids=["c2a", "c3a", "c5"])
-def test_fullsize_pointwise_paths_equal_oracle_on_crops(sfmt, dfmt, w, h, flags, cs):
-    """these paths are pointwise (per pixel / per 2x2 block): any even-aligned crop is an exact sub-problem."""
-    ctx = SwsContext(w, h, sfmt, w, h, dfmt, flags)
+def oracle_frame(sfmt, dfmt, sw, sh, dw, dh, flags, hsrc, cs=None):
+    """the oracle's whole output frame for the host copy `hsrc` of the source"""
+    o = OL.Oracle(sw, sh, sfmt, dw, dh, dfmt, flags)
+    if cs:
+        assert o.set_colorspace(*cs) == 0
+    osrc = OL.Frame(sfmt, sw, sh)
+    for a, b, (rb, _) in zip(osrc.planes, hsrc.planes, plane_layout(sfmt, sw, sh)):
+        a[:, :rb] = b[:, :rb]
+    ref = OL.Frame(dfmt, dw, dh)
+    assert o.scale(osrc, ref) == dh
+    return ref
+
+
+def assert_frames_equal(out, ref, dfmt, w, h, what):
+    for pi, (a, b, (rb, _)) in enumerate(zip(out.planes, ref.planes, plane_layout(dfmt, w, h))):
+        if not np.array_equal(a[:, :rb], b[:, :rb]):
+            bad = np.argwhere(a[:, :rb] != b[:, :rb])
+            raise AssertionError(f"{what}: plane {pi}: {len(bad)} bytes differ, first at row {bad[0][0]} byte {bad[0][1]}")
+
+
+FULL = {
+    "c2a": ("yuv420p", "rgb24", 3840, 2160, 3840, 2160, SWS_BICUBIC | BX, None, "unscaled:yuv2rgb"),
+    "c2b": ("yuv420p", "rgb24", 3840, 2160, 3840, 2160, SWS_BICUBIC | BX | AR, None, "main:fused_rgb_unity"),
+    "c3a": ("yuv420p10le", "p010le", 7680, 4320, 7680, 4320, SWS_LANCZOS | BX, None, "unscaled:planarToP01x"),
+    "c3b": ("yuv420p10le", "p010le", 7680, 4320, 3840, 2160, SWS_LANCZOS | BX, None, "main:strip_march"),
+    "c4": ("nv12", "bgr0", 1920, 1080, 1920, 1080, SWS_BICUBIC | BX, None, "main:fused_rgb_unity"),
+    "c5": ("gbrpf32le", "yuv444p16le", 3840, 2160, 3840, 2160, SWS_BICUBIC | BX, (SWS_CS_BT2020, 1, SWS_CS_BT2020, 1), "main:fused_f32rgb_yuv444"),
+    "c1": ("yuv420p", "yuv420p", 1280, 720, 640, 360, SWS_BILINEAR | BX, None, None),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_fullsize_whole_frame_equals_oracle(name):
+    """every BASELINE configuration at its full size, every byte of the output against the oracle"""
+    sfmt, dfmt, sw, sh, dw, dh, flags, cs, path = FULL[name]
+    ctx = SwsContext(sw, sh, sfmt, dw, dh, dfmt, flags)
     if cs:
         assert ctx.set_colorspace(*cs) == 0
-    src, hsrc = random_device_frame(sfmt, w, h, 11)
-    dst = DeviceFrame(dfmt, w, h)
-    torch.cuda.synchronize()
-    assert ctx.scale(src, dst) == h
-    ctx.sync()
-    out = dst.download()
-    cw, ch = 256, 64
-    for (x0, y0) in [(0, 0), (w - cw, h - ch), ((w // 2) & ~15, (h // 2) & ~15)]:
-        o = OL.Oracle(cw, ch, sfmt, cw, ch, dfmt, flags)
-        if cs:
-            o.set_colorspace(*cs)
-        ref = OL.Frame(dfmt, cw, ch)
-        assert o.scale(crop(hsrc, sfmt, x0, y0, cw, ch), ref) == ch
-        got = crop(out, dfmt, x0, y0, cw, ch)
-        for a, b, (rb, _) in zip(got.planes, ref.planes, plane_layout(dfmt, cw, ch)):
-            assert np.array_equal(a[:, :rb], b[:, :rb]), (sfmt, dfmt, x0, y0)
-
-
-@pytest.mark.parametrize("sfmt,dfmt,w,h,flags", [
-    ("yuv420p", "rgb24", 3840, 2160, SWS_BICUBIC | BX | AR),     # C2b: 4-tap vertical chroma
-    ("nv12", "bgr0", 1920, 1080, SWS_BICUBIC | BX),               # C4
-], ids=["c2b", "c4"])
-def test_fullsize_vertical_filter_paths_equal_oracle_on_row_bands(sfmt, dfmt, w, h, flags):
-    """identity horizontal filters: columns are independent, rows depend on a +-2 chroma row window.  A full-height
-    column strip is an exact sub-problem (the vertical filter tables depend only on the height)."""
-    ctx = SwsContext(w, h, sfmt, w, h, dfmt, flags)
-    src, hsrc = random_device_frame(sfmt, w, h, 12)
-    dst = DeviceFrame(dfmt, w, h)
-    torch.cuda.synchronize()
-    assert ctx.scale(src, dst) == h
-    ctx.sync()
-    out = dst.download()
-    cw = 64
-    for x0 in (0, w - cw, (w // 2) & ~15):
-        o = OL.Oracle(cw, h, sfmt, cw, h, dfmt, flags)
-        ref = OL.Frame(dfmt, cw, h)
-        assert o.scale(crop(hsrc, sfmt, x0, 0, cw, h), ref) == h
-        got = crop(out, dfmt, x0, 0, cw, h)
-        rb = plane_layout(dfmt, cw, h)[0][0]
-        assert np.array_equal(got.planes[0][:, :rb], ref.planes[0][:, :rb]), (sfmt, dfmt, x0)
-
-
-def test_fullsize_c3b_lanczos_downscale_matches_oracle():
-    """C3b 7680x4320 -> 3840x2160 yuv420p10le -> p010le, 12-tap Lanczos both ways: the scalar oracle needs ~1 s for it,
-    so this one is compared in full."""
-    sw, sh, dw, dh = 7680, 4320, 3840, 2160
-    flags = SWS_LANCZOS | BX
-    ctx = SwsContext(sw, sh, "yuv420p10le", dw, dh, "p010le", flags)
-    src, hsrc = random_device_frame("yuv420p10le", sw, sh, 13)
-    dst = DeviceFrame("p010le", dw, dh)
+    src, hsrc = random_device_frame(sfmt, sw, sh, 11)
+    dst = DeviceFrame(dfmt, dw, dh)
     torch.cuda.synchronize()
     assert ctx.scale(src, dst) == dh
     ctx.sync()
-    out = dst.download()
-    o = OL.Oracle(sw, sh, "yuv420p10le", dw, dh, "p010le", flags)
-    osrc = OL.Frame("yuv420p10le", sw, sh)
-    for a, b in zip(osrc.planes, hsrc.planes):
-        a[:, :] = b[:, :a.shape[1]] if a.shape[1] <= b.shape[1] else np.pad(b, ((0, 0), (0, a.shape[1] - b.shape[1])))
-    ref = OL.Frame("p010le", dw, dh)
-    assert o.scale(osrc, ref) == dh
-    for a, b, (rb, _) in zip(out.planes, ref.planes, plane_layout("p010le", dw, dh)):
-        assert np.array_equal(a[:, :rb], b[:, :rb])
+    if path:
+        assert ctx.path() == path
+    assert_frames_equal(dst.download(), oracle_frame(sfmt, dfmt, sw, sh, dw, dh, flags, hsrc, cs), dfmt, dw, dh, name)
 
 
-def test_c1_full_size_matches_oracle():
-    ctx = SwsContext(1280, 720, "yuv420p", 640, 360, "yuv420p", SWS_BILINEAR | BX)
-    src, hsrc = random_device_frame("yuv420p", 1280, 720, 14)
-    dst = DeviceFrame("yuv420p", 640, 360)
+# widths around the 1024-pixel strips of the wave / march kernels (one wave = 1024 pixels; 4 waves per block = adjacent segments),
+# and around the 256- / 128-column strips of the planar strip kernel
+EVEN_W = [1022, 1024, 1026, 2046, 2050, 3074, 4098]
+ANY_W = [1023, 1025, 2047, 2050, 3074]
+
+
+@pytest.mark.parametrize("w", EVEN_W)
+@pytest.mark.parametrize("case", [("yuv420p", "rgb24", SWS_BICUBIC | BX, "unscaled:yuv2rgb"), ("yuv422p", "bgra", SWS_BICUBIC | BX, "unscaled:yuv2rgb"),
+                                  ("yuv420p", "rgb24", SWS_BICUBIC | BX | AR, "main:fused_rgb_unity"), ("yuv420p", "argb", SWS_BICUBIC | BX | AR, "main:fused_rgb_unity"),
+                                  ("nv12", "bgr0", SWS_BICUBIC | BX, "main:fused_rgb_unity"), ("nv21", "bgr24", SWS_BICUBIC | BX, "main:fused_rgb_unity"),
+                                  ("yuv422p", "rgba", SWS_BICUBIC | BX | AR, "main:fused_rgb_unity")],
+                         ids=lambda c: f"{c[0]}-{c[1]}-{c[2]:x}")
+def test_wave_strip_boundaries_packed_rgb(case, w):
+    sfmt, dfmt, flags, path = case
+    for h in (34, 6):
+        got, _ = run_case(w, h, sfmt, w, h, dfmt, flags, seed=w + h)
+        assert got == path
+
+
+@pytest.mark.parametrize("w", ANY_W)
+def test_wave_strip_boundaries_streaming_kernels(w):
+    assert run_case(w, 18, "yuv420p10le", w, 18, "p010le", SWS_LANCZOS | BX, seed=w)[0] == "unscaled:planarToP01x"
+    assert run_case(w, 18, "yuv420p16le", w, 18, "p016le", SWS_LANCZOS | BX, seed=w)[0] == "unscaled:planarToP01x"
+    assert run_case(w, 10, "gbrpf32le", w, 10, "yuv444p16le", SWS_BICUBIC | BX, seed=w, colorspace=(SWS_CS_BT2020, 1, SWS_CS_BT2020, 1))[0] == "main:fused_f32rgb_yuv444"
+    assert run_case(w, 10, "gbrpf32le", w, 10, "yuv444p10le", SWS_BICUBIC | BX, seed=w)[0] == "main:fused_f32rgb_yuv444"
+
+
+@pytest.mark.parametrize("dw", ANY_W)
+@pytest.mark.parametrize("case", [("yuv420p10le", "p010le", 2, SWS_LANCZOS), ("yuv420p", "yuv420p", 2, SWS_BILINEAR), ("yuv420p", "nv12", 1.5, SWS_BICUBIC),
+                                  ("yuv444p12le", "yuv422p10le", 0.75, SWS_BICUBIC)], ids=lambda c: f"{c[0]}-{c[1]}-x{c[2]}")
+def test_strip_kernel_boundaries(case, dw):
+    """the planar strip kernel (256-column luma / 128-column chroma strips, 4 waves per block) at widths around its strips"""
+    sfmt, dfmt, ratio, scaler = case
+    sw = int(dw * ratio)
+    got, _ = run_case(sw, 40, sfmt, dw, 22, dfmt, scaler | BX, seed=dw)
+    assert got == "main:strip_march"
+
+
+def test_c4_batch_of_512_frames_through_one_call():
+    """BASELINE config 4 as written: 512 1080p nv12 frames -> bgr0 through ONE sws_scale_frames() call.  Frames 0..7 are random and
+    compared with the oracle over the whole frame; frames 8..511 are distinct variations of them made on the GPU (luma xor a
+    per-frame byte) and compared with what a single sws_scale() call gives for the same frame."""
+    sfmt, dfmt, w, h, flags = "nv12", "bgr0", 1920, 1080, SWS_BICUBIC | BX
+    n, nbase = 512, 8
+    ctx = SwsContext(w, h, sfmt, w, h, dfmt, flags)
+    base = [random_device_frame(sfmt, w, h, 500 + i) for i in range(nbase)]
+    srcs = [b[0] for b in base]
+    for i in range(nbase, n):
+        f = DeviceFrame(sfmt, w, h)
+        for k in range(f.nplanes):
+            f.plane_tensor(k).copy_(srcs[i % nbase].plane_tensor(k))
+        f.plane_tensor(0).bitwise_xor_(i // nbase)
+        srcs.append(f)
+    dsts = [DeviceFrame(dfmt, w, h) for _ in range(n)]
     torch.cuda.synchronize()
-    assert ctx.scale(src, dst) == 360
+    assert ctx.scale_frames(srcs, dsts) == n
     ctx.sync()
-    out = dst.download()
-    o = OL.Oracle(1280, 720, "yuv420p", 640, 360, "yuv420p", SWS_BILINEAR | BX)
-    osrc = OL.Frame("yuv420p", 1280, 720)
-    for a, b in zip(osrc.planes, hsrc.planes):
-        a[:, :] = b[:, :a.shape[1]]
-    ref = OL.Frame("yuv420p", 640, 360)
-    o.scale(osrc, ref)
-    assert out.visible() == ref.visible()
+    for i in range(nbase):
+        assert_frames_equal(dsts[i].download(), oracle_frame(sfmt, dfmt, w, h, w, h, flags, base[i][1]), dfmt, w, h, f"frame {i}")
+    single = DeviceFrame(dfmt, w, h)
+    rb = plane_layout(dfmt, w, h)[0][0]
+    seen, sampled = set(), 0
+    for i in range(nbase, n):
+        assert ctx.scale(srcs[i], single) == h
+        ctx.sync()
+        assert torch.equal(dsts[i].plane_tensor(0)[:, :rb], single.plane_tensor(0)[:, :rb]), f"frame {i}"
+        if i % 37 == 0:
+            sampled += 1
+            seen.add(digest(dsts[i].download()))
+    assert len(seen) == sampled   # distinct inputs -> distinct outputs
 
 
 @pytest.mark.parametrize("name", ["c2a", "c2b", "c4"])

@@ -18,9 +18,11 @@ BX = SWS_BITEXACT
 AR = SWS_ACCURATE_RND
 
 
-def run_case(sw, sh, sfmt, dw, dh, dfmt, flags, seed=1, colorspace=None, device_frames=True, prefill=0xA5, opts=None):
+def run_case(sw, sh, sfmt, dw, dh, dfmt, flags, seed=1, colorspace=None, device_frames=True, prefill=0xA5, opts=None, tune=None):
     o = OL.Oracle(sw, sh, sfmt, dw, dh, dfmt, flags, **(opts or {}))
     p = SwsContext(sw, sh, sfmt, dw, dh, dfmt, flags, **(opts or {}))
+    for k, v in (tune or {}).items():   # launch heuristics (sws_hip_set_option): force a kernel onto shapes the planner gives to another one
+        p.set_option(k, v)
     if colorspace:
         rc = o.set_colorspace(*colorspace)
         assert rc == p.set_colorspace(*colorspace)

@@ -1,8 +1,6 @@
 """-m gpu parity for the marching strip kernel (kernels_strip.hpp) at oracle-friendly sizes.  The library keeps narrow
-pictures on the tile kernel (SWS_HIP_STRIP_MIN_W, default 1024 output columns); these tests lower the threshold so that the
+pictures on the tile kernel (option "strip_min_w", default 1024 output columns); these tests lower the threshold so that the
 strip kernel itself is compared with the oracle: scalers, ratios, ragged widths, every planar / semi-planar writer."""
-import os
-
 import pytest
 
 from librempeg_amd import (SWS_BICUBIC, SWS_BILINEAR, SWS_LANCZOS, SWS_BITEXACT, SWS_ACCURATE_RND, SWS_POINT, SWS_AREA,
@@ -13,15 +11,7 @@ pytestmark = pytest.mark.gpu
 BX = SWS_BITEXACT
 
 
-@pytest.fixture(autouse=True)
-def _strip_everywhere():
-    old = os.environ.get("SWS_HIP_STRIP_MIN_W")
-    os.environ["SWS_HIP_STRIP_MIN_W"] = "0"
-    yield
-    if old is None:
-        del os.environ["SWS_HIP_STRIP_MIN_W"]
-    else:
-        os.environ["SWS_HIP_STRIP_MIN_W"] = old
+STRIP = {"strip_min_w": 0}
 
 
 SRC = ["yuv420p", "yuv422p", "yuv444p", "yuv410p", "yuv420p10le", "yuv422p12le", "yuv444p9le", "yuv420p14le"]
@@ -31,7 +21,7 @@ DST = ["yuv420p", "yuv444p", "yuv411p", "yuv420p10le", "yuv444p12le", "nv12", "n
 @pytest.mark.parametrize("sfmt", SRC)
 @pytest.mark.parametrize("dfmt", DST)
 def test_strip_formats(sfmt, dfmt):
-    path, _ = run_case(322, 130, sfmt, 200, 74, dfmt, SWS_BICUBIC | BX, seed=5)
+    path, _ = run_case(322, 130, sfmt, 200, 74, dfmt, SWS_BICUBIC | BX, seed=5, tune=STRIP)
     if not (dfmt == "yuv411p" and "444" in sfmt):      # 4:4:4 -> 4:1:1 chroma needs more than 16 horizontal taps: tile kernel
         assert path == "main:strip_march"
 
@@ -44,14 +34,12 @@ def test_strip_formats(sfmt, dfmt):
 def test_strip_scalers_and_geometries(flags, geom):
     sw, sh, dw, dh = geom
     for sfmt, dfmt in (("yuv420p", "yuv420p"), ("yuv420p10le", "p010le")):
-        path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, flags | BX, seed=11)
+        path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, flags | BX, seed=11, tune=STRIP)
         assert path in ("main:strip_march", "main:fused_tile_dot2", "main:fused_tile", "main:two_pass", "main:fused_generic_unity"), path
 
 
 def test_strip_is_used_for_wide_pictures_by_default():
-    del os.environ["SWS_HIP_STRIP_MIN_W"]
     path, _ = run_case(2048, 24, "yuv420p10le", 1024, 12, "p010le", SWS_LANCZOS | BX, seed=2)
     assert path == "main:strip_march"
     path, _ = run_case(640, 48, "yuv420p", 320, 24, "yuv420p", SWS_BILINEAR | BX, seed=2)
     assert path != "main:strip_march"
-    os.environ["SWS_HIP_STRIP_MIN_W"] = "0"
