@@ -79,7 +79,17 @@ def fill_device_frame(fr, seed):
             t.copy_(torch.randint(0, 256, (rows, ls), generator=g, device=t.device, dtype=torch.uint8))
 
 
+TUNE = {}   # --opt name=value: launch heuristics passed to sws_hip_set_option() (A/B measurements; results never change)
+
+
 def make_context(name, rank, world, device_index):
+    ctx = _make_context(name, rank, world, device_index)
+    for k, v in TUNE.items():
+        ctx.set_option(k, v)
+    return ctx
+
+
+def _make_context(name, rank, world, device_index):
     sw, sh, sf, dw, dh, df, flags, cs, _, _ = WORKLOADS[name]
     if world == 1 or rank == 0:
         ctx = SwsContext(sw, sh, sf, dw, dh, df, flags, device=device_index)
@@ -208,7 +218,11 @@ def main():
     ap.add_argument("--variants", default="auto", help="comma list of extra workloads to time (auto: c2b when workload is c2a)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--opt", action="append", default=[], help="name=value launch heuristic (sws_hip_set_option), repeatable")
     args = ap.parse_args()
+    for o in args.opt:
+        k, v = o.split("=")
+        TUNE[k] = int(v)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

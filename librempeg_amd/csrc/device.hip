@@ -518,7 +518,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 const int groups = (o.dst_h + 1) / 2;
                 std::vector<SwsRgbGroupPlan> plan((size_t)groups);
                 bool ok = true;
-                int prev = INT32_MIN;
+                int prev = INT32_MIN, maxspan = 0;
                 for (int g = 0; g < groups && ok; g++) {
                     SwsRgbGroupPlan &e = plan[(size_t)g];
                     std::memset(&e, 0, sizeof(e));
@@ -535,6 +535,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     for (int r = 0; r < 2; r++) {
                         const int16_t *cf = &c->vChr.taps[(size_t)(yy[r] >> c->chrDstVSubSample) * cfs];
                         if (first[r] + cfs - 1 - e.cbase >= 8) ok = false;
+                        maxspan = std::max(maxspan, first[r] + cfs - 1 - e.cbase);
                         for (int ip = 0; ip < 4; ip++) {
                             const int j0 = e.cbase + 2 * ip - first[r], j1 = j0 + 1;
                             const uint32_t lo = (j0 >= 0 && j0 < cfs) ? (uint16_t)cf[j0] : 0u, hi = (j1 >= 0 && j1 < cfs) ? (uint16_t)cf[j1] : 0u;
@@ -542,6 +543,12 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         }
                     }
                 }
+                // ring rows of the kernel instantiation: 5 (2x chroma up-sampling with 4 taps, the common case), 6 or 8.  With 5 rows the
+                // sixth slot of the three v_dot2 pairs is free: it carries the rounding constant (sample 1 x tap 2048)
+                d->rgb_ncr = maxspan <= 4 ? 5 : maxspan <= 5 ? 6 : 8;
+                if (ok && d->rgb_ncr == 5)
+                    for (auto &e : plan)
+                        for (int r = 0; r < 2; r++) e.wp[r][2] = (e.wp[r][2] & 0xFFFFu) | (2048u << 16);
                 if (ok) {
                     const size_t bytes = plan.size() * sizeof(SwsRgbGroupPlan);
                     if (bytes > d->rgbplan_bytes) {
@@ -595,7 +602,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
         if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             c->path_name = "main:fused_rgb_unity";
-            c->kernel_name = d->rgb_march_ok ? "sws_k_rgb_fused_unity_march" : (d->all_x_mode && d->chr_window2 <= 8 ? "sws_k_rgb_fused_unity_wave2" : "sws_k_rgb_fused_unity");
+            c->kernel_name = d->rgb_march_ok ? "sws_k_rgb_march" : (d->all_x_mode && d->chr_window2 <= 8 ? "sws_k_rgb_fused_unity_wave2" : "sws_k_rgb_fused_unity");
         } else if (d->unity_h && d->unity_v && !p.no_chroma && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 && p.dst_shift == 0 &&
                    (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16)) {
             c->path_name = "main:fused_f32rgb_yuv444"; c->kernel_name = "sws_k_f32rgb_to_yuv444_unity";

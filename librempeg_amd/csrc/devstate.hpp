@@ -23,7 +23,7 @@ struct DeviceState {
     bool all_x_mode = false;   // every output row uses the general yuv2rgb_X writer (vscale.c:135-169)
     int chr_window2 = 0;       // max chroma source rows spanned by a pair of output rows (wave kernel register budget)
     bool tile_ok = false; SwsTileGeom tileL, tileC; void *d_tilegeom = nullptr; size_t tilegeom_bytes = 0;
-    bool rgb_march_ok = false; void *d_rgbplan = nullptr; size_t rgbplan_bytes = 0; int rgb_groups = 0;   // sws_k_rgb_fused_unity_march
+    bool rgb_march_ok = false; void *d_rgbplan = nullptr; size_t rgbplan_bytes = 0; int rgb_groups = 0, rgb_ncr = 6;   // sws_k_rgb_march
     void *d_be = nullptr; size_t be_bytes = 0;   // little-endian copies of big-endian source pictures
     void *d_xyz = nullptr; size_t xyz_bytes = 0; void *d_xyz_tab = nullptr;   // rgb48 copies of xyz12 source pictures; the four gamma LUTs
     bool dot2_ok = false; SwsTileGeom dotL, dotC; void *d_dot2 = nullptr; size_t dot2_bytes = 0;

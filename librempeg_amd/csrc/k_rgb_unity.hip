@@ -30,8 +30,12 @@ int launch_rgb_unity(const LaunchCtx &L)
 } // namespace swship
 #else
 
+#if RGBU_KIND == 0
+#include "kernels_rgbmarch.hpp"
+#else
 #include "kernels_fast.hpp"
 #include "kernels_wave.hpp"
+#endif
 
 #define RGBU_CAT2(a, b, c) a##b##nv##c
 #define RGBU_CAT(a, b, c) RGBU_CAT2(a, b, c)
@@ -50,7 +54,7 @@ int RGBU_CAT(launch_rgbu_march_b, RGBU_BPP, RGBU_NV)(const LaunchCtx &L)
     const int segs = (p.dstW + 1023) >> 10;
     const bool swap = B == 4 ? p.lut.swap_rb32 != 0 : p.lut.rgb_order != 0;
     const bool afirst = B == 4 && p.lut.perm32 == 0x02010003u;
-    const bool ncr6 = d->chr_window2 <= 6;      // rows of chroma a pair of output rows spans: 3 or 4 row pairs
+    const int ncr = d->rgb_ncr;                 // ring rows: 5 (+ the rounding constant in the sixth slot), 6 or 8
     // one resident round: 4 waves per SIMD on 1024 SIMDs; bands of at least 8 row pairs
     const int target = c->tune.rgb_march_waves;
     const int groups = d->rgb_groups;
@@ -62,16 +66,19 @@ int RGBU_CAT(launch_rgbu_march_b, RGBU_BPP, RGBU_NV)(const LaunchCtx &L)
 #ifdef SWS_HIP_PROFILING
     if constexpr (B == 3 && !N) {
         const int mexp = c->tune.debug;
-        if (mexp && !swap && ncr6) {     // profiling experiments on the C2b instantiation only (results are wrong)
-            if (mexp == 1) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_march<3, false, false, false, 6, 1>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups);
-            if (mexp == 2) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_march<3, false, false, false, 6, 2>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups);
-            if (mexp == 3) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_march<3, false, false, false, 6, 3>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups);
+        if (mexp && !swap && ncr == 5) {     // profiling experiments on the C2b instantiation only (results are wrong)
+            if (mexp == 1) hipLaunchKernelGGL((swsk::sws_k_rgb_march<3, false, false, false, 5, 1>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups);
+            if (mexp == 2) hipLaunchKernelGGL((swsk::sws_k_rgb_march<3, false, false, false, 5, 2>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups);
+            if (mexp == 3) hipLaunchKernelGGL((swsk::sws_k_rgb_march<3, false, false, false, 5, 3>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups);
+            if (mexp == 4) hipLaunchKernelGGL((swsk::sws_k_rgb_march<3, false, false, false, 5, 4>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups);
+            if (mexp == 5) hipLaunchKernelGGL((swsk::sws_k_rgb_march<3, false, false, false, 5, 5>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups);
             return 0;
         }
     }
 #endif
-#define LAUNCH_MARCH(S, A) do { if (ncr6) hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_march<B, S, N, A, 6>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups); \
-                                else hipLaunchKernelGGL((swsk::sws_k_rgb_fused_unity_march<B, S, N, A, 8>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups); } while (0)
+#define LAUNCH_MARCH(S, A) do { if (ncr == 5) hipLaunchKernelGGL((swsk::sws_k_rgb_march<B, S, N, A, 5>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups); \
+                                else if (ncr == 6) hipLaunchKernelGGL((swsk::sws_k_rgb_march<B, S, N, A, 6>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups); \
+                                else hipLaunchKernelGGL((swsk::sws_k_rgb_march<B, S, N, A, 8>), gm, blk, 0, st, fs, p, plan, groups, bands, band_groups); } while (0)
     if constexpr (B == 4) {
         if (afirst) { if (swap) LAUNCH_MARCH(true, true); else LAUNCH_MARCH(false, true); }
         else        { if (swap) LAUNCH_MARCH(true, false); else LAUNCH_MARCH(false, false); }

@@ -29,14 +29,6 @@ namespace swsk {
 
 struct StripLds { uint32_t *S; int row_dw; };
 
-// first tap pair of a chain: VOP3P form with an inline 0 addend (the compiler would emit v_mov 0 + v_dot2c)
-__device__ __forceinline__ int sdot2_first(uint32_t a, uint32_t b)
-{
-    int d;
-    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-
 // horizontal stage of one row pair for COLS columns of NCOMP components -> one packed dword per (component, column)
 template <int NP, int NCOMP, int COLS>
 __device__ __forceinline__ void strip_hstage(const StripLds &L, const int (&spd)[COLS], const uint32_t (&ht)[COLS][NP], int sh,

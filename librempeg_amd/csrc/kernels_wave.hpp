@@ -355,160 +355,4 @@ __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_wave2(SwsFrameSet f
 }
 
 
-// ------------------------------------------------------------------------------------------
-// Marching form of the kernel above for the identity-vertical-luma case (C2b, C4: same-size conversions whose chroma is
-// up-sampled vertically).  A wave owns a 1024-pixel column strip and walks down a band of output-row pairs:
-//  * the chroma source rows live in a ring of NCR register rows; a step loads only the rows that enter the window (one per
-//    step at 2x chroma up-sampling) instead of the whole window (3x fewer load instructions);
-//  * the loads of step g+1 (new chroma rows, two luma rows) and the plan entry of step g+2 are issued before step g is
-//    computed, so memory latency overlaps the arithmetic instead of adding to it (the one-shot kernel spent over half of a
-//    wave's life waiting: VALU 50 % busy at 40 % of the HBM roofline);
-//  * everything a step needs from the filter banks is a 64-byte host-built plan entry fetched with scalar loads.
-// ------------------------------------------------------------------------------------------
-template <int BPP, bool SWAP_RB, bool NV, bool AFIRST, int NCR, int EXP = 0>
-__global__ void __launch_bounds__(256) sws_k_rgb_fused_unity_march(SwsFrameSet fs, SwsDevParams p, const SwsRgbGroupPlan *__restrict__ plan,
-                                                                   int ngroups, int bands, int band_groups)
-{
-    constexpr int LS = BPP == 4 ? 20 : 12, NDW = 4 * BPP, NCH = NDW / 4;
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4 * 2 * 64 * LS];   // per wave: one region per output row of a step
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t *lds = lds_all + wib * 2 * 64 * LS;
-    const int segs = (p.dstW + 1023) >> 10;
-    const int wid = blockIdx.x * 4 + wib;                        // the 4 waves of a block: adjacent segments of one band
-    if (wid >= segs * bands) return;
-    const int band = wid / segs, seg = wid % segs;
-    const int g0 = band * band_groups, g1 = min(ngroups, g0 + band_groups);
-    if (g0 >= g1) return;
-    const FrameRegs f = load_frame(fs, blockIdx.z);
-    const SwsLutParams &L = p.lut;
-    const int x = seg * 1024 + lane * 16;
-    const int seg_bytes = min(1024, p.dstW - seg * 1024) * BPP;
-    const int cH = p.chrSrcH - 1;
-    const bool u1 = p.u_plane_src == 1;
-    // descriptors: whole planes for the sources (strides are positive and planes < 2 GiB: checked on the host)
-    // (whole rows including their padding: a dword that is only partially inside the visible row must not be cut off)
-    const sws_rsrc_t ry = make_rsrc(f.src[0], (uint32_t)f.srcStride[0] * (uint32_t)p.srcH);
-    const sws_rsrc_t ru = make_rsrc(NV ? f.src[1] : (u1 ? f.src[1] : f.src[2]),
-                                    (uint32_t)(NV ? f.srcStride[1] : (u1 ? f.srcStride[1] : f.srcStride[2])) * (uint32_t)p.chrSrcH);
-    const sws_rsrc_t rv = make_rsrc(NV ? f.src[1] : (u1 ? f.src[2] : f.src[1]),
-                                    (uint32_t)(NV ? f.srcStride[1] : (u1 ? f.srcStride[2] : f.srcStride[1])) * (uint32_t)p.chrSrcH);
-    const int us = NV ? f.srcStride[1] : (u1 ? f.srcStride[1] : f.srcStride[2]), vs = NV ? f.srcStride[1] : (u1 ? f.srcStride[2] : f.srcStride[1]);
-    const int ys = f.srcStride[0];
-    const int cvoff = NV ? x : (x >> 1);
-    auto load_crow = [&](int cr) -> u32x4 {
-        const int srow = min(max(cr, 0), cH);
-        if constexpr (NV) return bload16(ru, cvoff, srow * us);
-        else {
-            const u32x2 a = bload8(ru, cvoff, srow * us), b = bload8(rv, cvoff, srow * vs);
-            u32x4 t = { a[0], a[1], b[0], b[1] };
-            return t;
-        }
-    };
-    auto load_yrow = [&](int row) -> u32x4 { return bload16(ry, x, row * ys); };
-
-    SwsRgbGroupPlan e = plan[g0], en = plan[min(g0 + 1, g1 - 1)];
-    u32x4 craw[NCR];
-#pragma unroll
-    for (int i = 0; i < NCR; i++) craw[i] = load_crow(e.cbase + i);
-    u32x4 yr0 = load_yrow(e.ylum0), yr1 = load_yrow(e.ylum1);
-    // finish the initial fill here: otherwise the waits for it inside the loop (counted from the newest request) also drain the
-    // previous step's stores in every later iteration
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-
-    for (int g = g0; g < g1; g++) {
-        const SwsRgbGroupPlan en2 = plan[min(g + 2, g1 - 1)];
-        const int delta = en.cbase - e.cbase;                     // 0 or 1 (checked on the host)
-        // prefetch of the next step (the last step of a band re-reads its own rows: harmless)
-        const u32x4 n0 = load_crow(en.cbase + NCR - 1);
-        const u32x4 ny0 = load_yrow(en.ylum0), ny1 = load_yrow(en.ylum1);
-        int acc[2][16];
-#pragma unroll
-        for (int r = 0; r < 2; r++)
-#pragma unroll
-            for (int k = 0; k < 16; k++) acc[r][k] = 2048;
-#pragma unroll
-        for (int ip = 0; ip < NCR / 2; ip++) {
-            if constexpr (SWS_EXP(2)) {       // experiment: no vertical filter
-#pragma unroll
-                for (int k = 0; k < 16; k++) { acc[0][k] += craw[2 * ip][k & 3]; acc[1][k] += craw[2 * ip + 1][k & 3]; }
-                continue;
-            }
-            uint32_t P[16];
-            interleave_rows(craw[2 * ip], craw[2 * ip + 1], P);
-#pragma unroll
-            for (int r = 0; r < 2; r++)
-#pragma unroll
-                for (int k = 0; k < 16; k++) acc[r][k] = sdot2(P[k], e.wp[r][ip], acc[r][k]);
-        }
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int y = 2 * g + r;
-            if (y >= p.dstH) break;
-            int Y[16];
-            unpack16(r ? yr1 : yr0, Y);
-            uint32_t uvp[4];
-            if constexpr (NV) {
-                if (p.uv_swap_src) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) uvp[q] = pack4_u8_shr12(acc[r][4 * q + 1], acc[r][4 * q], acc[r][4 * q + 3], acc[r][4 * q + 2]);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) uvp[q] = pack4_u8_shr12(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; q++) uvp[q] = pack4_u8_shr12(acc[r][2 * q], acc[r][8 + 2 * q], acc[r][2 * q + 1], acc[r][8 + 2 * q + 1]);
-            }
-            uint32_t w[NDW];
-            if constexpr (SWS_EXP(1)) {       // experiment: memory-only floor (no LUT stage)
-#pragma unroll
-                for (int k = 0; k < NDW; k++) w[k] = (uint32_t)Y[k & 15] + uvp[k & 3];
-            } else lut16_v2<BPP, SWAP_RB, AFIRST>(L, Y, uvp, w);
-            // park the packed pixels in the wave's LDS region of this row (lane-major); they are stored after the ring advanced
-            u32x4 *lw = (u32x4 *)(lds + r * 64 * LS + lane * LS);
-#pragma unroll
-            for (int k = 0; k < NCH; k++) { u32x4 t = { w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] }; lw[k] = t; }
-        }
-        // advance the ring BEFORE this step's stores are issued: vmcnt counts loads and stores together and the compiler has to
-        // assume they retire out of order, so a wait for the prefetched rows behind freshly issued stores would drain the stores
-        if (delta == 1) {
-#pragma unroll
-            for (int i = 0; i + 1 < NCR; i++) craw[i] = craw[i + 1];
-            craw[NCR - 1] = n0;
-        }
-        yr0 = ny0; yr1 = ny1;
-        // pin the hand-over here: without it the register copies (and with them the wait for the prefetch) sink below the stores
-        asm volatile("" : "+v"(yr0), "+v"(yr1), "+v"(craw[NCR - 1]) :: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // transposed read-back: every store instruction writes one contiguous KiB; the row's descriptor drops what lies beyond it
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int y = 2 * g + r;
-            if (y >= p.dstH) break;
-            uint8_t *segp = f.dst[0] + (int64_t)y * f.dstStride[0] + (int64_t)seg * 1024 * BPP;
-            const sws_rsrc_t rd = make_rsrc(segp, SWS_EXP(3) ? (p.dstW == 12345 ? 16u : 0u) : (uint32_t)seg_bytes);   // a dword that straddles the end is dropped as a whole
-            const uint32_t *lr = lds + r * 64 * LS;
-#pragma unroll
-            for (int j = 0; j < NCH; j++) {
-                const int c = j * 64 + lane;
-                const u32x4 v = *(const u32x4 *)(lr + (c / NCH) * LS + (c % NCH) * 4);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rd, 16 * c, 0, 2 /* nt */);
-            }
-            if constexpr (BPP == 3) {
-                if (seg_bytes & 2) {      // 24 bpp rows end on a multiple of 6 bytes: a last half dword
-                    const int b = seg_bytes - 2;
-                    // (a buffer store, not a flat one: flat stores complete out of order and would turn every wait into vmcnt(0))
-                    if (lane == 0) __builtin_amdgcn_raw_buffer_store_b16(*(const uint16_t *)((const uint8_t *)lr + (b / (NDW * 4)) * LS * 4 + b % (NDW * 4)), rd, b, 0, 0);
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();              // the next step reuses the LDS region
-        e = en; en = en2;
-    }
-}
-
 } // namespace swsk

@@ -76,6 +76,19 @@ __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
     typedef short s16x2w __attribute__((ext_vector_type(2)));
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2w, a), __builtin_bit_cast(s16x2w, b), c, false);
 }
+// first tap pair of a chain: VOP3P form with an inline 0 addend (the compiler would emit v_mov 0 + v_dot2c)
+__device__ __forceinline__ int sdot2_first(uint32_t a, uint32_t b)
+{
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ int sdot2_first_s(uint32_t a, uint32_t b_uniform)   // tap pair in an SGPR
+{
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "s"(b_uniform));
+    return d;
+}
 // 16 bytes of row A and row B -> 16 dwords (A_k | B_k << 16)
 __device__ __forceinline__ void interleave_rows(const u32x4 &A, const u32x4 &B, uint32_t (&P)[16])
 {

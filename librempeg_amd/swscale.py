@@ -92,7 +92,8 @@ _FMT_NAME = {v: k for k, v in PIX_FMT.items()}
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "libswscale_hip.so")
+    # SWS_HIP_LIBRARY: load another build of the same library (the -DSWS_HIP_PROFILING build of tools/build_profiling.sh)
+    return os.environ.get("SWS_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libswscale_hip.so")
 
 
 def build_library(force=False):

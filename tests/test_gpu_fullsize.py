@@ -114,7 +114,7 @@ def test_strip_kernel_boundaries(case, dw):
     """the planar strip kernel (256-column luma / 128-column chroma strips, 4 waves per block) at widths around its strips"""
     sfmt, dfmt, ratio, scaler = case
     sw = int(dw * ratio)
-    got, _ = run_case(sw, 40, sfmt, dw, 22, dfmt, scaler | BX, seed=dw)
+    got, _ = run_case(sw, 40, sfmt, dw, 22, dfmt, scaler | BX, seed=dw, tune={"strip_min_w": 0})
     assert got == "main:strip_march"
 
 

@@ -8,7 +8,7 @@ cd /tmp
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_${W}_$i -o res -- python $ROOT/bench.py --workload $W --variants none --no-cpu --steps 5 --warmup 1 > $OUT/pmc_${W}_$i.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_${W}_$i -o res -- python $ROOT/bench.py --workload $W --variants none --no-cpu --steps 5 --warmup 1 $BENCH_ARGS > $OUT/pmc_${W}_$i.log 2>&1
 done
 cd $ROOT
 python - "$OUT" "$W" <<'PY'
