@@ -385,6 +385,12 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     for (int y = 1; y < vb.count; y++) if (vb.pos[y] < vb.pos[y - 1]) return false;   // the ring only moves forward
                     g.TW = TW; g.strips = strips; g.NCmax = ncmax; g.nph = nph; g.npv = npv; g.hfs2 = hf2; g.vfs2 = vf2;
                     g.lds_bytes = 4 * ncomp * 2 * ((ncmax + SPC) / 2) * 4;
+                    // LDS-DMA form: a ring of 4 row pairs per wave, rows of ncmax 16-bit samples; every pair between the first and the last
+                    // one a band needs is requested, so the windows of consecutive rows must touch (no skipped pair)
+                    g.lds_dma_bytes = 4 * 4 * ncomp * 2 * (ncmax / 2) * 4;
+                    g.dma_ok = SPC == 8 && g.lds_dma_bytes <= 40 * 1024;
+                    for (int y = 1; y < vb.count && g.dma_ok; y++)
+                        if (((vb.pos[y] & ~1) >> 1) > ((vb.pos[y - 1] & ~1) >> 1) + npv) g.dma_ok = 0;
                     o.cs = put(cs.data(), cs.size() * 4); o.cc = put(cc.data(), cc.size() * 4);
                     std::vector<SwsStripRow> rows((size_t)vb.count);
                     for (int y = 0; y < vb.count; y++) {
@@ -610,7 +616,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             c->path_name = "main:fused_generic_unity";
             c->kernel_name = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) ? "sws_k_vscale_rgb" : "sws_k_vscale_planar";
         } else if (d->strip_ok) {
-            c->path_name = "main:strip_march"; c->kernel_name = "sws_k_strip_march";
+            c->path_name = "main:strip_march";
+            c->kernel_name = (p.srcKind == SRCK_PLANAR16 && d->stripL.dma_ok && !c->tune.no_strip_dma) ? "sws_k_strip_dma" : "sws_k_strip_march";
         } else if (d->dot2_ok) {
             c->path_name = "main:fused_tile_dot2"; c->kernel_name = "sws_k_tile_dot2";
         } else if (d->tile_ok) {
@@ -1442,7 +1449,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "strip_min_w", &c->tune.strip_min_w }, { "strip_cols_l", &c->tune.strip_cols_l }, { "strip_cols_c", &c->tune.strip_cols_c },
         { "strip_waves", &c->tune.strip_waves }, { "rgb_march_waves", &c->tune.rgb_march_waves }, { "tile_lds_kb", &c->tune.tile_lds_kb },
         { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
-        { "no_strip", &c->tune.no_strip }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
+        { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
         { "debug", &c->tune.debug },
     };
     for (auto &e : tab)

@@ -116,7 +116,8 @@ struct SwsStripGeom {        // marching strip kernel (kernels_strip.hpp), per p
     const SwsStripRow *rows;              // [plane height]
     int32_t bands, band_rows;             // filled per launch
     int32_t lds_bytes;                    // per block of 4 waves
-    int32_t debug;                        // profiling experiments only (SWS_HIP_STRIP_DEBUG): 1 no h-stage, 2 no v-stage, 4 no stores, 8 no loads
+    int32_t dma_ok, lds_dma_bytes;        // LDS-DMA form (16-bit sources): no source row pair is skipped inside a band; its LDS per block
+    int32_t debug;                        // profiling builds only: 1 no h-stage, 2 no v-stage, 4 no stores
 };
 
 struct SwsRgbGroupPlan {    // marching packed-RGB kernel: everything one pair of output rows needs, as scalars (64 bytes)

@@ -21,12 +21,19 @@ int launch_strip(const LaunchCtx &L)
                 g.bands = (H + g.band_rows - 1) / g.band_rows;
                 const dim3 grid(cdiv((int64_t)g.strips * g.bands, 4), 1, n);
 #define SWS_STRIP(S, C, K) hipLaunchKernelGGL((swsk::sws_k_strip_march<S, C, K>), grid, blk, g.lds_bytes, st, fs, p, g)
+#define SWS_STRIP_DMA(C, K) hipLaunchKernelGGL((swsk::sws_k_strip_dma<C, K>), grid, blk, g.lds_dma_bytes, st, fs, p, g)
                 const int cols = g.TW / 64;
+                if (s16 && g.dma_ok && !c->tune.no_strip_dma) {   // 16-bit sources: LDS-DMA ring, 3 row pairs in flight per wave
+                    if (chroma) { if (cols == 1) SWS_STRIP_DMA(true, 1); else SWS_STRIP_DMA(true, 2); }
+                    else        { if (cols == 2) SWS_STRIP_DMA(false, 2); else SWS_STRIP_DMA(false, 4); }
+                    return;
+                }
                 if (chroma) { if (s16) { if (cols == 1) SWS_STRIP(true, true, 1); else SWS_STRIP(true, true, 2); }
                               else     { if (cols == 1) SWS_STRIP(false, true, 1); else SWS_STRIP(false, true, 2); } }
                 else        { if (s16) { if (cols == 2) SWS_STRIP(true, false, 2); else SWS_STRIP(true, false, 4); }
                               else     { if (cols == 2) SWS_STRIP(false, false, 2); else SWS_STRIP(false, false, 4); } }
 #undef SWS_STRIP
+#undef SWS_STRIP_DMA
             };
             launch(d->stripL, p.dstH, false);
             launch(d->stripC, p.chrDstH, true);

@@ -206,7 +206,10 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
         }
         while (qnext <= pfy + npv - 1) {
             uint32_t np[NCOMP][COLS];
-            if (SWS_DBG(g, 1)) {
+            // The horizontal stage sits in a basic block of its own: straight-line code lets hipcc interleave it with the ring and the
+            // vertical stage until the live set overshoots the 128 VGPRs of 4 waves per SIMD and the loop spills (4x slower, measured).
+            // g.hfs2 is never negative; the compiler cannot know that.  (-DSWS_HIP_PROFILING builds switch the stage off with debug bit 1.)
+            if (g.hfs2 < 0 || SWS_DBG(g, 1)) {
 #pragma unroll
                 for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
@@ -244,7 +247,7 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
         switch (npv) {
 #define SWS_SV(N) case N: \
             _Pragma("unroll") for (int ci = 0; ci < NCOMP; ci++) _Pragma("unroll") for (int c = 0; c < COLS; c++) { \
-                acc[ci][c] = sdot2_first(ring[ci][c][8 - N], e.vt[0]); \
+                acc[ci][c] = sdot2_first_s(ring[ci][c][8 - N], e.vt[0]); \
                 _Pragma("unroll") for (int k = 1; k < N; k++) acc[ci][c] = sdot2(ring[ci][c][8 - N + k], e.vt[k], acc[ci][c]); } \
             break;
         SWS_SV(1) SWS_SV(2) SWS_SV(3) SWS_SV(4) SWS_SV(5) SWS_SV(6) SWS_SV(7)
@@ -254,7 +257,7 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
             for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
                 for (int c = 0; c < COLS; c++) {
-                    acc[ci][c] = sdot2_first(ring[ci][c][0], e.vt[0]);
+                    acc[ci][c] = sdot2_first_s(ring[ci][c][0], e.vt[0]);
 #pragma unroll
                     for (int k = 1; k < 8; k++) acc[ci][c] = sdot2(ring[ci][c][k], e.vt[k], acc[ci][c]);
                 }
@@ -303,6 +306,286 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     const FrameRegs f = load_frame(fs, blockIdx.z);
     switch (g.nph) {        // the whole march is instantiated per horizontal tap-pair count: the loop body is branch-free
 #define SWS_SB(N) case N: strip_body<SRC16, CHROMA, COLS, N>(f, p, g, strip, y0, y1, smem, wib, lane); break;
+    SWS_SB(1) SWS_SB(2) SWS_SB(3) SWS_SB(4) SWS_SB(5) SWS_SB(6) SWS_SB(7) SWS_SB(8)
+#undef SWS_SB
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA form of the march for 16-bit sources (C3b).  Same arithmetic, same lane / column mapping, same register ring; the
+// source rows take another way into LDS:
+//  * `buffer_load_dwordx4 ... lds` writes a row's 16-byte chunks straight into the wave's LDS ring (destination = M0 + lane * 16,
+//    lanes outside the strip's window are switched off in EXEC): no staging registers, no ds_write pass, no v_perm;
+//  * the ring holds D row pairs: up to D - 1 pairs (>= 6 KB of luma) are in flight per wave while one is being h-scaled -- the
+//    register-staged form has one pair (2 KB) in flight, which is what bounds it;
+//  * the requests are asm statements the compiler does not count, so every wait is written by hand: before pair q is read,
+//    `s_waitcnt vmcnt((D - 1) * P)` (P = DMA instructions per pair).  Loads return in order among themselves: if pair q were
+//    still outstanding so would the (D - 1) * P requests behind it, hence at most (D - 1) * P outstanding operations implies pair
+//    q has landed -- whatever the stores of earlier rows (same counter, unordered against loads) are doing;
+//  * a slot is re-requested only after `lgkmcnt(0)`: every ds_read of the h-stage that consumed it has returned;
+//  * the wave drains its requests (vmcnt(0)) before it ends: a late DMA write must not hit LDS that belongs to another wave by then.
+// The host selects it when no source row pair inside a band is skipped (pf(y + 1) <= pf(y) + npv: always true for the polyphase
+// scalers at ratios up to the filter length).
+// ------------------------------------------------------------------------------------------
+typedef int i32x4s __attribute__((ext_vector_type(4)));
+constexpr int STRIP_DMA_DEPTH = 4;
+
+__device__ __forceinline__ void strip_dma16(uint32_t lds_dst, int voff, const i32x4s &rsrc, int soff, uint32_t mask_lo, uint32_t mask_hi)
+{
+    // (s_nop 4: the descriptor / offset SGPRs may come straight from v_readfirstlane; M0 is written in the statement that reads it)
+    uint64_t keep;
+    asm volatile("s_nop 4\n\t"
+                 "s_mov_b64 %0, exec\n\t"
+                 "s_mov_b32 exec_lo, %5\n\t"
+                 "s_mov_b32 exec_hi, %6\n\t"
+                 "s_mov_b32 m0, %1\n\t"
+                 "s_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff), "s"(mask_lo), "s"(mask_hi) : "memory");
+}
+
+template <bool CHROMA, int COLS, int NPH>
+__device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevParams &p, const SwsStripGeom &g, int strip, int y0, int y1,
+                                               uint8_t *smem, int wib, int lane)
+{
+    constexpr int NCOMP = CHROMA ? 2 : 1, SPC = 8, D = STRIP_DMA_DEPTH;
+    constexpr int PARTS = CHROMA ? 1 : 2;                     // 1 KiB pieces per staged row (chroma windows are <= 64 chunks: host)
+    const int W = CHROMA ? p.chrDstW : p.dstW, H = CHROMA ? p.chrDstH : p.dstH;
+    const int sH = CHROMA ? p.chrSrcH : p.srcH;
+    const int xs = strip * g.TW;
+    const int cs = g.colStart[strip], chunks = g.colCount[strip] / SPC;
+    const int32_t *hpos = CHROMA ? p.hChrPos : p.hLumPos;
+    const int npv = g.npv, sh = p.hshift;
+    const int row_dw = g.NCmax >> 1;                          // dwords of a staged row (NCmax is a multiple of the 8-sample chunk)
+    const int pair_dw = NCOMP * 2 * row_dw;
+    uint32_t *ringS = (uint32_t *)smem + wib * (D * pair_dw);
+    const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)ringS);
+
+    // ---- per-lane column state: window offsets and horizontal taps (registers for the whole band) ----
+    int spd[COLS];
+    uint32_t ht[COLS][NPH];
+#pragma unroll
+    for (int c = 0; c < COLS; c++) {
+        const int x = min(xs + 64 * c + lane, W - 1);
+        spd[c] = ((hpos[x] & ~1) - cs) >> 1;
+        const uint32_t *tp = (const uint32_t *)(g.hT2 + (int64_t)x * g.hfs2);
+#pragma unroll
+        for (int k = 0; k < NPH; k++) ht[c][k] = tp[k];
+    }
+    // ---- source descriptors (whole rows including their padding), as plain dwords for the asm statements ----
+    const bool u1 = p.u_plane_src == 1;
+    i32x4s rs[NCOMP];
+    int sst[NCOMP];
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++) {
+        const bool first = !CHROMA || ((ci == 0) == u1);
+        const uint8_t *sb = !CHROMA ? f.src[0] : (first ? f.src[1] : f.src[2]);
+        sst[ci] = !CHROMA ? f.srcStride[0] : (first ? f.srcStride[1] : f.srcStride[2]);
+        const uint64_t a = uniform_u64((uint64_t)sb);
+        rs[ci][0] = (int)(uint32_t)a; rs[ci][1] = (int)(uint32_t)(a >> 32);
+        rs[ci][2] = __builtin_amdgcn_readfirstlane((int)((uint32_t)sst[ci] * (uint32_t)sH)); rs[ci][3] = 0x00020000;
+    }
+    const int voff = cs * 2 + lane * 16;
+    const int nparts = (PARTS == 2 && chunks > 64) ? 2 : 1;   // wave-uniform: the second piece is not issued when the window fits one
+    const int n0 = min(chunks, 64), n1 = max(chunks - 64, 0);
+    auto lanes_lo = [](int n) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(n >= 32 ? 0xffffffffu : ((1u << n) - 1u))); };
+    auto lanes_hi = [](int n) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(n >= 64 ? 0xffffffffu : (n > 32 ? ((1u << (n - 32)) - 1u) : 0u))); };
+    const uint32_t m0lo = lanes_lo(n0), m0hi = lanes_hi(n0), m1lo = lanes_lo(n1), m1hi = lanes_hi(n1);   // EXEC masks of the two pieces
+    auto dma = [&](int q) {                                    // request source rows 2q, 2q + 1 (clamped) into ring slot q % D
+        const int r0 = min(max(2 * q, 0), sH - 1), r1 = min(max(2 * q + 1, 0), sH - 1);
+        const uint32_t slot = lds_base + (uint32_t)((q & (D - 1)) * pair_dw) * 4u;
+#pragma unroll
+        for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const uint32_t dst = slot + (uint32_t)((ci * 2 + r) * row_dw) * 4u;
+                const int soff = (r ? r1 : r0) * sst[ci];
+                strip_dma16(dst, voff, rs[ci], soff, m0lo, m0hi);
+                if (PARTS == 2 && nparts == 2) strip_dma16(dst + 1024u, voff + 1024, rs[ci], soff, m1lo, m1hi);
+            }
+    };
+    auto wait_pair = [&]() {                                   // at most (D - 1) * P operations outstanding
+        if (NCOMP * 2 * nparts == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    };
+    static_assert(D == 4, "the wait immediates above are (D - 1) * P for D = 4");
+
+    // ---- destination descriptors and per-lane offsets (columns beyond the plane get an out-of-range offset) ----
+    const bool semi = CHROMA && (p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010);
+    const bool d8 = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_NV12;
+    const int kind = semi ? (d8 ? 2 : 3) : (d8 ? 0 : 1);
+    const int dbytes = (d8 ? 1 : 2) * (semi ? 2 : 1);
+    sws_rsrc_t rd[NCOMP];
+    int dstr[NCOMP];
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++) {
+        const int pl = !CHROMA ? 0 : semi ? 1 : (ci == 0 ? p.u_plane_dst : p.v_plane_dst);
+        uint8_t *db = pl == 0 ? f.dst[0] : pl == 1 ? f.dst[1] : f.dst[2];
+        dstr[ci] = pl == 0 ? f.dstStride[0] : pl == 1 ? f.dstStride[1] : f.dstStride[2];
+        rd[ci] = make_rsrc(db, (uint32_t)dstr[ci] * (uint32_t)(H - 1) + (uint32_t)W * (uint32_t)dbytes);
+    }
+    int doff[COLS];
+#pragma unroll
+    for (int c = 0; c < COLS; c++) {
+        const int x = xs + 64 * c + lane;
+        doff[c] = x < W ? x * dbytes : 0x7fffffff;
+    }
+
+    uint32_t ring[NCOMP][COLS][8];
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+        for (int c = 0; c < COLS; c++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) ring[ci][c][k] = 0;
+
+    uint32_t pend[NCOMP][COLS];
+    int pend_y = -1;
+    auto flush = [&]() {
+        if (pend_y >= 0 && !SWS_DBG(g, 4)) {
+            switch (kind) {
+            case 0:
+#pragma unroll
+                for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                    for (int c = 0; c < COLS; c++) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)pend[ci][c], rd[ci], doff[c], pend_y * dstr[ci], 0);
+                break;
+            case 1:
+#pragma unroll
+                for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                    for (int c = 0; c < COLS; c++) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)pend[ci][c], rd[ci], doff[c], pend_y * dstr[ci], 0);
+                break;
+            case 2:
+#pragma unroll
+                for (int c = 0; c < COLS; c++)
+                    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(pend[0][c] | (pend[NCOMP - 1][c] << 8)), rd[0], doff[c], pend_y * dstr[0], 0);
+                break;
+            default:
+#pragma unroll
+                for (int c = 0; c < COLS; c++)
+                    __builtin_amdgcn_raw_buffer_store_b32(pend[0][c] | (pend[NCOMP - 1][c] << 16), rd[0], doff[c], pend_y * dstr[0], 0);
+                break;
+            }
+            pend_y = -1;
+        }
+    };
+
+    // ---- march ----
+    const SwsStripRow *rows = g.rows;
+    SwsStripRow e = rows[y0];
+    int qnext = e.pf;                                          // next source-row pair to h-scale
+    int qdma = qnext;                                          // next pair to request
+#pragma unroll
+    for (int i = 0; i < D; i++) dma(qdma++);
+    const int bits = p.dst_bits;
+    for (int y = y0; y < y1; y++) {
+        const SwsStripRow en = rows[min(y + 1, H - 1)];
+        const int pfy = e.pf;
+        while (qnext <= pfy + npv - 1) {
+            wait_pair();
+            StripLds L;
+            L.row_dw = row_dw;
+            L.S = ringS + (qnext & (D - 1)) * pair_dw;
+            uint32_t np[NCOMP][COLS];
+            // The horizontal stage sits in a basic block of its own: straight-line code lets hipcc interleave it with the ring and the
+            // vertical stage until the live set overshoots the 128 VGPRs of 4 waves per SIMD and the loop spills (4x slower, measured).
+            // g.hfs2 is never negative; the compiler cannot know that.  (-DSWS_HIP_PROFILING builds switch the stage off with debug bit 1.)
+            if (g.hfs2 < 0 || SWS_DBG(g, 1)) {
+#pragma unroll
+                for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                    for (int c = 0; c < COLS; c++) np[ci][c] = L.S[(ci * 2) * L.row_dw + spd[c]];
+            } else
+            strip_hstage<NPH, NCOMP, COLS>(L, spd, ht, sh, np);
+#pragma unroll
+            for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++) {
+#pragma unroll
+                    for (int k = 0; k < 7; k++) ring[ci][c][k] = ring[ci][c][k + 1];
+                    ring[ci][c][7] = np[ci][c];
+                }
+            qnext++;
+            // the slot's ds_reads have returned (their results are in np): pin that, release the pending row, re-request the slot
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            flush();
+            dma(qdma++);
+        }
+        flush();
+        // ---- vertical stage: the npv newest ring entries are pairs pfy .. pfy + npv - 1 ----
+        int acc[NCOMP][COLS];
+        if (SWS_DBG(g, 2)) {
+#pragma unroll
+            for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++) acc[ci][c] = (int)ring[ci][c][7];
+        } else
+        switch (npv) {
+#define SWS_SV(N) case N: \
+            _Pragma("unroll") for (int ci = 0; ci < NCOMP; ci++) _Pragma("unroll") for (int c = 0; c < COLS; c++) { \
+                acc[ci][c] = sdot2_first_s(ring[ci][c][8 - N], e.vt[0]); \
+                _Pragma("unroll") for (int k = 1; k < N; k++) acc[ci][c] = sdot2(ring[ci][c][8 - N + k], e.vt[k], acc[ci][c]); } \
+            break;
+        SWS_SV(1) SWS_SV(2) SWS_SV(3) SWS_SV(4) SWS_SV(5) SWS_SV(6) SWS_SV(7)
+#undef SWS_SV
+        default:
+#pragma unroll
+            for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++) {
+                    acc[ci][c] = sdot2_first_s(ring[ci][c][0], e.vt[0]);
+#pragma unroll
+                    for (int k = 1; k < 8; k++) acc[ci][c] = sdot2(ring[ci][c][k], e.vt[k], acc[ci][c]);
+                }
+            break;
+        }
+        // ---- writers ("X" forms) ----
+        if (d8) {
+#pragma unroll
+            for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++) {
+                    const int x = xs + 64 * c + lane;
+                    const int off = (CHROMA && ci == 1) ? 3 : 0;
+                    pend[ci][c] = (uint32_t)clip_u8_shr((dither8(p.should_dither, y, x + off) << 12) + acc[ci][c], 19);
+                }
+        } else {
+            const int shift = 11 + 16 - bits, osh = p.dst_shift;
+#pragma unroll
+            for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++)
+                    pend[ci][c] = (uint32_t)(clip_uintp2(((1 << (shift - 1)) + acc[ci][c]) >> shift, bits) << osh);
+        }
+        if (semi && p.uv_swap_dst) {
+#pragma unroll
+            for (int c = 0; c < COLS; c++) { const uint32_t t = pend[0][c]; pend[0][c] = pend[NCOMP - 1][c]; pend[NCOMP - 1][c] = t; }
+        }
+        pend_y = y;
+        e = en;
+    }
+    flush();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA write may land after the wave has given up its LDS
+}
+
+template <bool CHROMA, int COLS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) sws_k_strip_dma(SwsFrameSet fs, SwsDevParams p, SwsStripGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wid = blockIdx.x * 4 + wib;
+    if (wid >= g.strips * g.bands) return;
+    const int strip = wid % g.strips, band = wid / g.strips;
+    const int H = CHROMA ? p.chrDstH : p.dstH;
+    const int y0 = band * g.band_rows, y1 = min(H, y0 + g.band_rows);
+    if (y0 >= y1) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    switch (g.nph) {
+#define SWS_SB(N) case N: strip_body_dma<CHROMA, COLS, N>(f, p, g, strip, y0, y1, smem, wib, lane); break;
     SWS_SB(1) SWS_SB(2) SWS_SB(3) SWS_SB(4) SWS_SB(5) SWS_SB(6) SWS_SB(7) SWS_SB(8)
 #undef SWS_SB
     }
