@@ -13,6 +13,11 @@ Contract: python bench.py --gpus N --steps K --warmup W ; for N>1 launched by to
 one rank per GPU (RCCL).  Frames are sharded across ranks (weak scaling, no data-path collective);
 the only collective is the one-off broadcast of the context's table blob from rank 0.
 Rank 0 prints ONE JSON line.
+
+`python bench.py --gpus N --inproc` (no launcher) measures the OTHER multi-GPU form: ONE process, ONE context, ONE
+sws_scale_frames() call per step over frames that live on N GPUs -- the library shards them itself (a frame is converted on the
+GPU that holds it; device.hip: dev_run), each GPU gets its own copy of the tables at first use, launches go out on every GPU's
+stream before anything is waited for.
 """
 import argparse
 import json
@@ -50,6 +55,17 @@ WORKLOADS = {
     "c5": (3840, 2160, "gbrpf32le", 3840, 2160, "yuv444p16le", SWS_BICUBIC | SWS_BITEXACT,
            (SWS_CS_BT2020, 1, SWS_CS_BT2020, 1), 8,
            "C5 3840x2160 gbrpf32le->yuv444p16le BT.2020 full range"),
+}
+
+
+# what pins each workload's arithmetic to the reference (oracle/README.md)
+PARITY_PIN = {
+    "c2a": "LUT tables pinned by the reference's pixfmt MD5s (yuv2rgb24_X); the unscaled converter's 8/4/2-pixel block structure "
+           "(yuv2rgb_c_24_rgb) by the oracle twin only: no reference golden exists without accurate_rnd",
+    "c2b": "fate-pixfmt-rgb24 MD5 (tests/ref/pixfmt/rgb24: bicubic+accurate_rnd+bitexact) through oracle and HIP path",
+    "c3a": "fate-pixfmt p010le / yuv420p10le MD5s", "c3b": "SURVEY Appendix D filter banks + fate-pixfmt p010le MD5s",
+    "c4": "fate-pixfmt nv12 / bgr0 MD5s", "c5": "fate-sws-floatimg-cmp (tests/ref/fate/sws-floatimg-cmp) + SURVEY Appendix D rgb2yuv BT.2020",
+    "c1": "fate-sws-yuv-range / filter-scalechroma framecrcs (hScale8To15_c, yuv2planeX_8_c)",
 }
 
 
@@ -121,6 +137,44 @@ def _make_context(name, rank, world, device_index):
     return ctx
 
 
+def run_workload_inproc(name, batch, steps, warmup, ngpus):
+    """one process, one context, frames on `ngpus` GPUs, one sws_scale_frames() call per step (in-library sharding)"""
+    sw, sh, sf, dw, dh, df, flags, cs, dbatch, desc = WORKLOADS[name]
+    batch = batch or dbatch
+    ctx = make_context(name, 0, 1, 0)
+    srcs, dsts = [], []
+    for g in range(ngpus):
+        for i in range(batch):
+            s, d = DeviceFrame(sf, sw, sh, f"cuda:{g}"), DeviceFrame(df, dw, dh, f"cuda:{g}")
+            fill_device_frame(s, 1000 * (g + 1) + i)
+            srcs.append(s); dsts.append(d)
+    for g in range(ngpus):
+        torch.cuda.synchronize(g)
+    b = ctx.make_batch(srcs, dsts)
+    path = ctx.path()
+    for _ in range(warmup):
+        r = ctx.run_batch(b)
+        assert r == batch * ngpus, f"sws_scale_frames returned {r}"
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.run_batch(b)
+    ctx.sync()                       # waits for the context's streams on every GPU
+    t1 = time.perf_counter()
+    ctx.set_timing(True)             # kernel time of the home GPU's launch set (HIP events on its stream)
+    kms = []
+    for _ in range(min(steps, 10)):
+        ctx.run_batch(b); ctx.sync()
+        kms.append(ctx.last_kernel_ms())
+    res = dict(name=name, desc=desc, batch=batch, wall_s=t1 - t0, kernel_ms_avg=float(np.mean(kms)), kernel_ms_min=float(np.min(kms)),
+               path=path, kernel=ctx.kernel_name(), out_pixels_per_step=batch * ngpus * dw * dh,
+               alg_bytes_per_step=batch * algorithmic_bytes(sw, sh, sf, dw, dh, df))
+    del srcs, dsts
+    ctx.close()
+    torch.cuda.empty_cache()
+    return res
+
+
 def run_workload(name, batch, steps, warmup, rank, world, device_index, barrier):
     sw, sh, sf, dw, dh, df, flags, cs, dbatch, desc = WORKLOADS[name]
     batch = batch or dbatch
@@ -168,6 +222,10 @@ def cpu_baseline(name, seconds=10.0):
     OL.lib()
 
     def worker(out, idx, deadline):
+        try:    # one thread per host core, pinned: the frame-parallel form the reference would be run in (one context per core)
+            os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[idx % len(os.sched_getaffinity(0))]})
+        except Exception:
+            pass
         o = OL.Oracle(sw, sh, sf, dw, dh, df, flags)
         if cs:
             o.set_colorspace(*cs)
@@ -219,6 +277,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--opt", action="append", default=[], help="name=value launch heuristic (sws_hip_set_option), repeatable")
+    ap.add_argument("--inproc", action="store_true", help="N GPUs from ONE process: in-library sharding of sws_scale_frames() (no launcher)")
     args = ap.parse_args()
     for o in args.opt:
         k, v = o.split("=")
@@ -249,6 +308,23 @@ def main():
         def barrier():
             pass
 
+    if args.inproc:
+        assert world == 1, "--inproc is the single-process form: run it without torch.distributed.run"
+        ngpus = min(args.gpus, torch.cuda.device_count())
+        r = run_workload_inproc(args.workload, args.batch, args.steps, args.warmup, ngpus)
+        mpix = args.steps * r["out_pixels_per_step"] / r["wall_s"] / 1e6
+        ach = r["alg_bytes_per_step"] / (r["kernel_ms_avg"] * 1e-3) / 1e9
+        print(json.dumps({"metric": "Mpixels/sec sws_scale 4K yuv420p->rgb24 bicubic" if r["name"].startswith("c2") else f"Mpixels/sec sws_scale {r['name']}",
+                          "value": round(mpix, 1), "unit": "Mpixels/s", "n_gpus": ngpus, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(r["wall_s"] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "u8", "data": "synthetic",
+                          "config": {"workload": r["desc"], "frames_per_step_per_gpu": r["batch"], "path": r["path"],
+                                     "sharding": f"in-library: one process, one sws_scale_frames() call over frames on {ngpus} GPU(s)", "frames_resident": "HBM"},
+                          "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                       "traffic": None, "kernel": r["kernel"], "kernel_ms_avg": round(r["kernel_ms_avg"], 4),
+                                       "algorithmic_bytes_per_launch": r["alg_bytes_per_step"], "note": "per-GPU launch set on the home GPU"},
+                          "cpu_baseline": None}), flush=True)
+        return
     main_res = run_workload(args.workload, args.batch, args.steps, args.warmup, rank, world, local_rank, barrier)
     variants = [] if args.variants in ("", "none") else (["c2b"] if args.variants == "auto" and args.workload == "c2a"
                                                           else [] if args.variants == "auto" else args.variants.split(","))
@@ -272,12 +348,15 @@ def main():
     wall, kms, mpix, achieved = summarize(main_res)
     out = None
     if rank == 0:
-        traffic = None
+        # HBM bytes per launch from the PMC counters: NOT measured by this run (counters need their own rocprofv3 --pmc passes);
+        # read from the committed summary of the latest such passes over the same command and labelled with its source
+        traffic, traffic_source = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
                 traffic = pmc.get(main_res["name"], {}).get("hbm_bytes_per_launch")
+                traffic_source = "profiles/pmc_latest.json (" + str(pmc.get("_source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.sh")) + ")"
             except Exception:
                 traffic = None
         out = {
@@ -288,10 +367,11 @@ def main():
             "vs_baseline": None, "dtype": {"c3a": "u16", "c3b": "u16 (int32 accumulate)", "c5": "f32->int32"}.get(main_res["name"], "u8"),
             "data": "synthetic",
             "config": {"workload": main_res["desc"], "frames_per_step_per_gpu": main_res["batch"],
+                       "parity_pin": PARITY_PIN.get(main_res["name"], "reference goldens"),
                        "path": main_res["path"], "sharding": f"frames x{world} (one rank per GPU, no data-path collective)",
                        "frames_resident": "HBM"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": main_res["kernel"], "kernel_ms_avg": round(kms, 4),
                          "algorithmic_bytes_per_launch": main_res["alg_bytes_per_step"]},
         }

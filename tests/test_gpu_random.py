@@ -39,7 +39,7 @@ def test_random_conversions(case):
     try:
         o = OL.Oracle(sw, sh, sf, dw, dh, df, flags)
     except Exception:
-        pytest.skip("the oracle refuses this context (the product must refuse it too, see test_refusals_agree)")
+        pytest.skip("the oracle refuses this context (the product refuses it too: tests/test_refusals_agree.py)")
     del o
     run_case(sw, sh, sf, dw, dh, df, flags, seed=k + 1, device_frames=bool(k & 1))
 
