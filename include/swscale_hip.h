@@ -77,8 +77,6 @@ enum AVPixelFormat {
     /* planar RGB 9..16 bit */
     AV_PIX_FMT_GBRP9LE = 73, AV_PIX_FMT_GBRP10LE = 75, AV_PIX_FMT_GBRP16LE = 77, AV_PIX_FMT_GBRP12LE = 135,
     AV_PIX_FMT_GBRP14LE = 137,
-    /* NEW: hardware surface format of the HIP hwcontext slot; appended after the
-     * reference's last format (AV_PIX_FMT_NB == 268, libavutil/pixfmt.h) */
     AV_PIX_FMT_AYUV64LE = 155, AV_PIX_FMT_AYUV64BE = 156, AV_PIX_FMT_Y210LE = 192, AV_PIX_FMT_Y212LE = 212, AV_PIX_FMT_Y216LE = 240,
     AV_PIX_FMT_X2RGB10LE = 193, AV_PIX_FMT_X2BGR10LE = 195,
     AV_PIX_FMT_YA8 = 56, AV_PIX_FMT_YA16BE = 109, AV_PIX_FMT_YA16LE = 110,
@@ -103,6 +101,8 @@ enum AVPixelFormat {
     AV_PIX_FMT_P010BE = 159, AV_PIX_FMT_P012BE = 210, AV_PIX_FMT_P016BE = 170, AV_PIX_FMT_P210BE = 197, AV_PIX_FMT_P212BE = 221,
     AV_PIX_FMT_P216BE = 201, AV_PIX_FMT_P410BE = 199, AV_PIX_FMT_P412BE = 223, AV_PIX_FMT_P416BE = 203, AV_PIX_FMT_RGB48BE = 34,
     AV_PIX_FMT_BGR48BE = 57, AV_PIX_FMT_RGBA64BE = 104, AV_PIX_FMT_BGRA64BE = 106,
+    /* NEW: hardware surface format of the HIP hwcontext slot; takes the value of the
+     * reference's AV_PIX_FMT_NB (268, libavutil/pixfmt.h:508), i.e. it is appended as the last format */
     AV_PIX_FMT_HIP = 268,
 };
 #endif
@@ -244,9 +244,19 @@ int sws_getColorspaceDetails(SwsContext *c, int **inv_table, int *srcRange, int 
 int sws_scale(SwsContext *c, const uint8_t *const srcSlice[], const int srcStride[],
               int srcSliceY, int srcSliceH, uint8_t *const dst[], const int dstStride[]);
 
-/* Prefix of libavutil/frame.h:472-559 struct AVFrame (data, linesize,
- * extended_data, width, height, nb_samples, format): a real AVFrame* may be
- * passed wherever SwsFrameView* is expected. */
+/* libavutil/buffer.h:82-95 struct AVBufferRef, libavutil/rational.h:58-61, libavutil/channel_layout.h (AVChannelLayout):
+ * the member types struct AVFrame is made of. */
+typedef struct SwsBufferRef { void *buffer; uint8_t *data; size_t size; } SwsBufferRef;
+typedef struct SwsRational { int num, den; } SwsRational;
+typedef struct SwsChannelLayout { int order; int nb_channels; union { uint64_t mask; void *map; } u; void *opaque; } SwsChannelLayout;
+/* libavutil/frame.h:236-251 struct AVFrameSideData */
+typedef struct SwsFrameSideData { int type; uint8_t *data; size_t size; void *metadata; SwsBufferRef *buf; } SwsFrameSideData;
+
+/* Field-for-field mirror of libavutil/frame.h:472-828 struct AVFrame (same order, same types,
+ * sizeof == sizeof(AVFrame)): a real AVFrame* may be passed wherever SwsFrameView* is expected.
+ * The library reads data, linesize, width, height, format, flags (AV_FRAME_FLAG_INTERLACED),
+ * color_range, color_primaries, color_trc, colorspace, chroma_location, side_data (compared only)
+ * and hw_frames_ctx; it writes nothing but the pixels data[] points at. */
 typedef struct SwsFrameView {
     uint8_t *data[8];
     int linesize[8];
@@ -254,7 +264,50 @@ typedef struct SwsFrameView {
     int width, height;
     int nb_samples;
     int format;
+    int pict_type;
+    SwsRational sample_aspect_ratio;
+    int64_t pts;
+    int64_t pkt_dts;
+    SwsRational time_base;
+    int quality;
+    void *opaque;
+    int repeat_pict;
+    int sample_rate;
+    SwsBufferRef *buf[8];
+    SwsBufferRef **extended_buf;
+    int nb_extended_buf;
+    SwsFrameSideData **side_data;
+    int nb_side_data;
+    int flags;
+    int color_range;          /* enum AVColorRange */
+    int color_primaries;      /* enum AVColorPrimaries */
+    int color_trc;            /* enum AVColorTransferCharacteristic */
+    int colorspace;           /* enum AVColorSpace */
+    int chroma_location;      /* enum AVChromaLocation */
+    int64_t best_effort_timestamp;
+    void *metadata;
+    int decode_error_flags;
+    SwsBufferRef *hw_frames_ctx;   /* -> struct AVHWFramesContext (include/hwcontext_hip.h) when format == AV_PIX_FMT_HIP */
+    SwsBufferRef *opaque_ref;
+    size_t crop_top, crop_bottom, crop_left, crop_right;
+    void *private_ref;
+    SwsChannelLayout ch_layout;
+    int64_t duration;
+    int alpha_mode;
 } SwsFrameView;
+
+#define SWS_FRAME_FLAG_INTERLACED (1 << 3)   /* AV_FRAME_FLAG_INTERLACED, frame.h:695 */
+/* libavutil/pixfmt.h enum AVColorRange / AVChromaLocation values the frame fields carry */
+#define SWS_COL_RANGE_UNSPECIFIED 0
+#define SWS_COL_RANGE_MPEG 1
+#define SWS_COL_RANGE_JPEG 2
+#define SWS_CHROMA_LOC_UNSPECIFIED 0
+#define SWS_CHROMA_LOC_LEFT 1
+#define SWS_CHROMA_LOC_CENTER 2
+#define SWS_CHROMA_LOC_TOPLEFT 3
+#define SWS_CHROMA_LOC_TOP 4
+#define SWS_CHROMA_LOC_BOTTOMLEFT 5
+#define SWS_CHROMA_LOC_BOTTOM 6
 
 /* swscale.h:439 (legacy-initialised contexts only: frame props must match the context) */
 int sws_scale_frame(SwsContext *c, SwsFrameView *dst, const SwsFrameView *src);

@@ -172,86 +172,4 @@ int sws_test_transfer(int trc, int output)     // enum AVColorTransferCharacteri
                    case 16: case 17: case 18: case 256: return 1; }
     return 0;
 }
-int sws_test_frame(const SwsFrameView *frame, int output)
-{
-    return frame && frame->width > 0 && frame->height > 0 && sws_test_format((enum AVPixelFormat)frame->format, output);
-}
-int sws_is_noop(const SwsFrameView *dst, const SwsFrameView *src)
-{
-    // only the AVFrame prefix (data, linesize, extended_data, width, height, nb_samples, format) is visible to this library:
-    // colour metadata is taken from the context, so equal geometry and format is the test
-    return dst && src && dst->format == src->format && dst->width == src->width && dst->height == src->height;
-}
-
-// ---- frame / slice API (swscale.c:1271-1404) on top of sws_scale() ----
-int sws_frame_setup(SwsContext *sws, const SwsFrameView *dst, const SwsFrameView *src)
-{
-    if (!sws || !dst || !src) return SWS_AVERROR(EINVAL);
-    if (!sws_test_frame(src, 0) || !sws_test_frame(dst, 1)) return SWS_AVERROR(ENOTSUP);
-    SwsInternal *c = internal(sws);
-    if (!c->legacy_init) return init_from_frames(c, src->width, src->height, src->format, dst->width, dst->height, dst->format);
-    return (canonical_pix_fmt(src->format) == sws->src_format && src->width == sws->src_w && src->height == sws->src_h &&
-            canonical_pix_fmt(dst->format) == sws->dst_format && dst->width == sws->dst_w && dst->height == sws->dst_h &&
-            src_tags_match(c, src->format) && dst_tags_match(c, dst->format)) ? 0 : SWS_AVERROR(EINVAL);
-}
-
-int sws_frame_start(SwsContext *sws, SwsFrameView *dst, const SwsFrameView *src)
-{
-    int r = sws_frame_setup(sws, dst, src);
-    if (r < 0) return r;
-    if (!dst->data[0]) return SWS_AVERROR(ENOMEM);   // this library cannot allocate AVFrame buffers (no libavutil): bring your own
-    SwsInternal *c = internal(sws);
-    c->frame_src = src; c->frame_dst = dst; c->frame_rows_in = 0;
-    return 0;
-}
-
-void sws_frame_end(SwsContext *sws)
-{
-    if (!sws) return;
-    SwsInternal *c = internal(sws);
-    c->frame_src = nullptr; c->frame_dst = nullptr; c->frame_rows_in = 0;
-}
-
-int sws_send_slice(SwsContext *sws, unsigned int slice_start, unsigned int slice_height)
-{
-    if (!sws) return SWS_AVERROR(EINVAL);
-    SwsInternal *c = internal(sws);
-    if (!c->frame_src || !c->frame_dst) return SWS_AVERROR(EINVAL);
-    const SwsFrameView *s = c->frame_src;
-    const PixDesc *d = pix_desc(canonical_pix_fmt(s->format));
-    const uint8_t *ptr[4] = { nullptr, nullptr, nullptr, nullptr };
-    int ls[4] = { 0, 0, 0, 0 };
-    for (int k = 0; k < 4 && s->data[k]; k++) {
-        bool chroma = false;
-        for (int q = 0; q < d->nb_components; q++) if (d->comp[q].plane == k) chroma = (q == 1 || q == 2);
-        const int sub = (chroma && !(d->flags & PIXFLAG_RGB)) ? d->log2_chroma_h : 0;
-        ptr[k] = (const uint8_t *)s->data[k] + (int64_t)(slice_start >> sub) * s->linesize[k];
-        ls[k] = s->linesize[k];
-    }
-    const bool legacy = c->legacy_init;
-    c->legacy_init = true;                                    // the frame API may drive a dynamically configured context
-    int r = sws_scale(sws, ptr, ls, (int)slice_start, (int)slice_height, (uint8_t *const *)c->frame_dst->data, c->frame_dst->linesize);
-    c->legacy_init = legacy;
-    if (r >= 0) c->frame_rows_in += (int)slice_height;
-    return r;
-}
-
-unsigned int sws_receive_slice_alignment(const SwsContext *sws)
-{
-    if (!sws) return 1;
-    const SwsInternal *c = (const SwsInternal *)sws;
-    return c->dst_slice_align > 0 ? (unsigned)c->dst_slice_align : 1u;
-}
-
-int sws_receive_slice(SwsContext *sws, unsigned int slice_start, unsigned int slice_height)
-{
-    if (!sws) return SWS_AVERROR(EINVAL);
-    SwsInternal *c = internal(sws);
-    if (!c->frame_src || !c->frame_dst) return SWS_AVERROR(EINVAL);
-    const unsigned align = sws_receive_slice_alignment(sws);
-    if (slice_start % align || (slice_height % align && slice_start + slice_height != (unsigned)sws->dst_h)) return SWS_AVERROR(EINVAL);
-    // rows are final once every source row has been sent (the scaled path converts when the last slice arrives)
-    return c->frame_rows_in >= sws->src_h ? 0 : SWS_AVERROR(EAGAIN);
-}
-
 } // extern "C"

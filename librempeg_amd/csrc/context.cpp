@@ -407,6 +407,7 @@ static void destroy(SwsInternal *c)
     if (!c) return;
     destroy(c->cascade[0]);
     destroy(c->cascade[1]);
+    frames_release(c);
     dev_release(c);
     c->magic = 0;
     delete c;
@@ -445,37 +446,6 @@ static int init_context_impl(SwsInternal *c, SwsFilter *srcFilter, SwsFilter *ds
     if (ret < 0) return ret;
     mark_tables_dirty(c);
     return 0;
-}
-
-// sws_scale_frame() on a context that was only sws_alloc_context()ed: (re)configure from the frames
-int init_from_frames(SwsInternal *c, int sw, int sh, int sfmt, int dw, int dh, int dfmt)
-{
-    SwsContext &o = c->opts;
-    if (c->dynamic_init && o.src_w == sw && o.src_h == sh && o.dst_w == dw && o.dst_h == dh &&
-        o.src_format == canonical_pix_fmt(sfmt) && o.dst_format == canonical_pix_fmt(dfmt) &&
-        src_tags_match(c, sfmt) && dst_tags_match(c, dfmt)) return 0;
-    // The yuvj / gray aliasing of the previous configuration ORed 1 into the range fields (utils.c:1903-1904): unless the caller has
-    // changed them since, this configuration starts from the values the caller set, not from the aliased ones
-    if (c->dynamic_init) {
-        if (o.src_range == c->eff_src_range) o.src_range = c->user_src_range;
-        if (o.dst_range == c->eff_dst_range) o.dst_range = c->user_dst_range;
-    }
-    c->user_src_range = o.src_range; c->user_dst_range = o.dst_range;
-    // new geometry: drop everything derived from the old one
-    destroy(c->cascade[0]); destroy(c->cascade[1]);
-    c->cascade[0] = c->cascade[1] = nullptr;
-    dev_release(c);
-    c->src0Alpha = c->dst0Alpha = 0;
-    c->srcBE = c->dstBE = false;
-    c->srcXYZ = c->dstXYZ = false;
-    c->dstFormatBpp = c->srcFormatBpp = 0;
-    c->contrast = c->saturation = c->brightness = 0;
-    o.src_w = sw; o.src_h = sh; o.src_format = sfmt; o.dst_w = dw; o.dst_h = dh; o.dst_format = dfmt;
-    int ret = init_context_impl(c, nullptr, nullptr);
-    c->legacy_init = false;       // sws_scale() keeps refusing a context that was not sws_init_context()ed (swscale.c:1633)
-    c->dynamic_init = ret >= 0;
-    c->eff_src_range = o.src_range; c->eff_dst_range = o.dst_range;
-    return ret;
 }
 
 } // namespace swship
@@ -653,13 +623,25 @@ int sws_getColorspaceDetails(SwsContext *sws, int **inv_table, int *srcRange, in
     return 0;
 }
 
-const char *sws_hip_path_name(const SwsContext *sws) { return sws ? internal(sws)->path_name.c_str() : ""; }
-const char *sws_hip_kernel_name(const SwsContext *sws) { return sws ? internal(sws)->kernel_name.c_str() : ""; }
+// a dynamic context answers for the conversion sws_frame_setup() built for the (top field of the) last frames
+static const SwsInternal *introspected(const SwsContext *sws)
+{
+    const SwsInternal *c = internal(sws);
+    return (!c->legacy_init && c->graph[0].valid && c->graph[0].legacy) ? internal(c->graph[0].legacy) : c;
+}
+const char *sws_hip_path_name(const SwsContext *sws)
+{
+    if (!sws) return "";
+    const SwsInternal *c = internal(sws);
+    if (!c->legacy_init && c->graph[0].valid && c->graph[0].noop) return "noop:copy";
+    return introspected(sws)->path_name.c_str();
+}
+const char *sws_hip_kernel_name(const SwsContext *sws) { return sws ? introspected(sws)->kernel_name.c_str() : ""; }
 
 int sws_hip_get_filter(const SwsContext *sws, int which, const int16_t **filter, const int32_t **pos, int *count)
 {
     if (!sws) return 0;
-    const SwsInternal *c = internal(sws);
+    const SwsInternal *c = introspected(sws);
     const FilterBank *b = which == 0 ? &c->hLum : which == 1 ? &c->hChr : which == 2 ? &c->vLum : &c->vChr;
     if (!b->size) return 0;
     if (filter) *filter = b->taps.data();
@@ -671,7 +653,7 @@ int sws_hip_get_filter(const SwsContext *sws, int which, const int16_t **filter,
 int sws_hip_get_tables(const SwsContext *sws, int32_t rgb2yuv[9], int yuv2rgb[6], uint32_t range_coeff[2], int64_t range_offset[2])
 {
     if (!sws) return -1;
-    const SwsInternal *c = internal(sws);
+    const SwsInternal *c = introspected(sws);
     if (rgb2yuv) std::memcpy(rgb2yuv, c->rgb2yuv, sizeof(c->rgb2yuv));
     if (yuv2rgb) { yuv2rgb[0] = c->lut.y_offset; yuv2rgb[1] = c->lut.y_coeff; yuv2rgb[2] = c->lut.v2r;
                    yuv2rgb[3] = c->lut.v2g; yuv2rgb[4] = c->lut.u2g; yuv2rgb[5] = c->lut.u2b; }

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "devstate.hpp"
+#include "../../include/hwcontext_hip.h"
 
 namespace swship {
 
@@ -1153,6 +1154,59 @@ static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4
     return unscaled ? sliceH : o.dst_h;
 }
 
+// A dynamic context's per-field child runs where the parent would: same home GPU, same launch heuristics, and on the stream of
+// the frames' AVHIPDeviceContext if they have one, else on the stream the caller gave the parent, else on its own.
+int dev_inherit(SwsInternal *child, SwsInternal *parent, bool have_stream, void *stream)
+{
+    int r = ensure_dev(parent);
+    if (r < 0) return r;
+    if ((r = ensure_dev(child)) < 0) return r;
+    if (child->dev->device != parent->dev->device && (r = sws_hip_set_device(&child->opts, parent->dev->device)) < 0) return r;
+    if (std::memcmp(&child->tune, &parent->tune, sizeof(Tuning))) {
+        child->tune = parent->tune;
+        mark_tables_dirty(child);
+        for (SwsInternal *cc : { child->cascade[0], child->cascade[1] }) if (cc) { cc->tune = parent->tune; mark_tables_dirty(cc); }
+    }
+    if (child->dev->timing != parent->dev->timing && (r = sws_hip_set_timing(&child->opts, parent->dev->timing)) < 0) return r;
+    void *want = have_stream ? stream : (parent->dev->stream && !parent->dev->own_stream ? (void *)parent->dev->stream : nullptr);
+    if (want) return dev_use_stream(child, want);
+    if (child->dev->stream && !child->dev->own_stream) return sws_hip_set_stream(&child->opts, nullptr);
+    return 0;
+}
+
+int dev_use_stream(SwsInternal *c, void *stream)
+{
+    int r = ensure_dev(c);
+    if (r < 0) return r;
+    if ((void *)c->dev->stream == stream && !c->dev->own_stream) return 0;
+    return sws_hip_set_stream(&c->opts, stream);
+}
+
+// a conversion that changes nothing (ff_fmt_equal): the reference's threaded plane copy (graph.c:817-830)
+int dev_copy_frame(SwsInternal *c, SwsFrameView *dstf, const SwsFrameView *srcf, bool have_stream, void *stream)
+{
+    int r = ensure_dev(c);
+    if (r < 0) return r;
+    DeviceGuard guard;
+    const int sd = ptr_device(srcf->data[0]), dd = ptr_device(dstf->data[0]);
+    const int dev = sd >= 0 ? sd : dd >= 0 ? dd : c->dev->device;
+    HIPCHK(hipSetDevice(dev));
+    hipStream_t st = (hipStream_t)stream;
+    if (!have_stream) {
+        DeviceState *d = dev_state_for(c, dev);
+        if (!d) return AVERROR_EXTERNAL_;
+        if (!d->stream) { HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)); d->own_stream = true; }
+        st = d->stream;
+    }
+    const int np = pix_nb_planes(pix_desc(srcf->format));
+    for (int k = 0; k < np; k++) {
+        int rb, rows; plane_geometry(srcf->format, srcf->width, srcf->height, k, &rb, &rows);
+        HIPCHK(hipMemcpy2DAsync(dstf->data[k], (size_t)dstf->linesize[k], srcf->data[k], (size_t)srcf->linesize[k], (size_t)rb, (size_t)rows, hipMemcpyDefault, st));
+    }
+    if (dd < 0) HIPCHK(hipStreamSynchronize(st));   // a host destination is complete on return
+    return 0;
+}
+
 } // namespace swship
 
 using namespace swship;
@@ -1160,14 +1214,14 @@ using namespace swship;
 // ------------------------------------------------------------------------------------------
 // public entry points
 // ------------------------------------------------------------------------------------------
-static int check_image_pointers(const uint8_t *const data[4], int fmt, const int linesizes[4]) // swscale.c:729-743
+bool swship::check_image_pointers(const uint8_t *const data[4], int fmt, const int linesizes[4]) // swscale.c:729-743
 {
     const PixDesc *d = pix_desc(fmt);
     for (int i = 0; i < d->nb_components; i++) {
         const int plane = d->comp[i].plane;
-        if (!data[plane] || !linesizes[plane]) return 0;
+        if (!data[plane] || !linesizes[plane]) return false;
     }
-    return 1;
+    return true;
 }
 
 // Slices on the scaled path (scale_internal swscale.c:1076-1104, ff_swscale :372-381, :404-470, :566).
@@ -1295,49 +1349,61 @@ int sws_scale(SwsContext *sws, const uint8_t *const srcSlice[], const int srcStr
     return dev_run(c, s4, ss4, srcSliceY, srcSliceH, d4, ds4, 0, nullptr, nullptr);
 }
 
-static int frame_matches(const SwsInternal *c, const SwsFrameView *f, bool is_src)
+// ---- device-level helpers (include/hwcontext_hip.h): what integration/hwcontext_hip.c needs from the HIP runtime ----
+int sws_hip_mem_alloc(int device, size_t size, void **ptr)
 {
-    const int fmt = canonical_pix_fmt(f->format); // the context stores canonicalised formats (yuvj420p -> yuv420p, bgr0 -> bgra)
-    const SwsContext &o = c->opts;
-    if (!(is_src ? src_tags_match(c, f->format) : dst_tags_match(c, f->format))) return 0;
-    return is_src ? (fmt == o.src_format && f->width == o.src_w && f->height == o.src_h)
-                  : (fmt == o.dst_format && f->width == o.dst_w && f->height == o.dst_h);
+    if (!ptr || device < 0) return SWS_AVERROR(EINVAL);
+    *ptr = nullptr;
+    DeviceGuard guard;
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
+    if (hipMalloc(ptr, size ? size : 256) != hipSuccess) { (void)hipGetLastError(); *ptr = nullptr; return SWS_AVERROR(ENOMEM); }
+    return 0;
 }
-
-int sws_scale_frame(SwsContext *sws, SwsFrameView *dstf, const SwsFrameView *srcf)
+void sws_hip_mem_free(int device, void *ptr)
 {
-    if (!sws || !dstf || !srcf) return SWS_AVERROR(EINVAL);
-    SwsInternal *c = internal(sws);
-    if (!c->legacy_init) {
-        // dynamic mode (swscale.c:1405-1480): the context is (re)configured from the frames; flags, scaler parameters,
-        // dither and the range fields of the context apply as set by the caller
-        int r = init_from_frames(c, srcf->width, srcf->height, srcf->format, dstf->width, dstf->height, dstf->format);
-        if (r < 0) return r;
-    }
-    if (!frame_matches(c, srcf, true) || !frame_matches(c, dstf, false)) return SWS_AVERROR(EINVAL);
-    const SwsFrameView *s1[1] = { srcf };
-    SwsFrameView *d1[1] = { dstf };
-    int r = dev_run(c, nullptr, nullptr, 0, sws->src_h, nullptr, nullptr, 1, s1, d1);
-    return r < 0 ? r : sws->dst_h;
+    if (!ptr) return;
+    DeviceGuard guard;
+    if (device >= 0) (void)hipSetDevice(device);
+    (void)hipFree(ptr);
 }
-
-int sws_scale_frames(SwsContext *sws, SwsFrameView *const dst[], const SwsFrameView *const src[], int nb_frames)
+int sws_hip_stream_create(int device, void **stream)
 {
-    if (!sws || !dst || !src || nb_frames < 0) return SWS_AVERROR(EINVAL);
-    if (!nb_frames) return 0;
-    SwsInternal *c = internal(sws);
-    if (!c->legacy_init) {
-        if (!src[0] || !dst[0]) return SWS_AVERROR(EINVAL);
-        int r = init_from_frames(c, src[0]->width, src[0]->height, src[0]->format, dst[0]->width, dst[0]->height, dst[0]->format);
-        if (r < 0) return r;
-    }
-    for (int i = 0; i < nb_frames; i++) {
-        if (!src[i] || !dst[i]) return SWS_AVERROR(EINVAL);
-        if (!frame_matches(c, src[i], true) || !frame_matches(c, dst[i], false)) return SWS_AVERROR(EINVAL);
-        if (!check_image_pointers(src[i]->data, sws->src_format, src[i]->linesize) ||
-            !check_image_pointers(dst[i]->data, sws->dst_format, dst[i]->linesize)) return SWS_AVERROR(EINVAL);
-    }
-    return dev_run(c, nullptr, nullptr, 0, sws->src_h, nullptr, nullptr, nb_frames, src, dst);
+    if (!stream || device < 0) return SWS_AVERROR(EINVAL);
+    DeviceGuard guard;
+    hipStream_t st = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
+    *stream = (void *)st;
+    return 0;
+}
+void sws_hip_stream_destroy(int device, void *stream)
+{
+    if (!stream) return;
+    DeviceGuard guard;
+    if (device >= 0) (void)hipSetDevice(device);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipStreamDestroy((hipStream_t)stream);
+}
+int sws_hip_stream_sync(int device, void *stream)
+{
+    DeviceGuard guard;
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
+    return 0;
+}
+int sws_hip_copy_plane(int device, void *stream, void *dst, int dst_linesize, const void *src, int src_linesize, int bytewidth, int height)
+{
+    if (!dst || !src || bytewidth < 0 || height < 0) return SWS_AVERROR(EINVAL);
+    if (!bytewidth || !height) return 0;
+    DeviceGuard guard;
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
+    if (hipMemcpy2DAsync(dst, (size_t)dst_linesize, src, (size_t)src_linesize, (size_t)bytewidth, (size_t)height, hipMemcpyDefault,
+                         (hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); return AVERROR_EXTERNAL_; }
+    return 0;
+}
+int sws_hip_pointer_device(const void *ptr) { return ptr_device(ptr); }
+int sws_hip_frames_format_supported(int sw_format)
+{
+    return pix_desc(sw_format) && sws_isSupportedInput((enum AVPixelFormat)sw_format) && sws_isSupportedOutput((enum AVPixelFormat)sw_format);
 }
 
 // ---- HIP device plumbing ----
@@ -1358,6 +1424,7 @@ int sws_hip_set_device(SwsContext *sws, int device)
     // a new home GPU: everything the context (and the children of a cascade) holds on any GPU is released and rebuilt on first use
     dev_release(c);
     for (SwsInternal *cc : { c->cascade[0], c->cascade[1] }) if (cc) dev_release(cc);
+    frames_release(c);      // the per-field conversions of a dynamic context are rebuilt on the new GPU
     int r = ensure_dev(c);
     if (r < 0) return r;
     c->dev->device = device;
@@ -1409,6 +1476,7 @@ int sws_hip_sync(SwsContext *sws)   // waits for the context's work on every GPU
     if (c->dev && c->dev->stream && hipStreamSynchronize(c->dev->stream) != hipSuccess) { (void)hipGetLastError(); ret = AVERROR_EXTERNAL_; }
     for (DeviceState *d : c->peers)
         if (d && d->stream && hipStreamSynchronize(d->stream) != hipSuccess) { (void)hipGetLastError(); ret = AVERROR_EXTERNAL_; }
+    for (const FrameGraph &g : c->graph) if (g.legacy) { int r = sws_hip_sync(g.legacy); if (r < 0) ret = r; }
     return ret;
 }
 
@@ -1433,6 +1501,7 @@ double sws_hip_last_kernel_ms(SwsContext *sws)
 {
     if (!sws) return -1.0;
     SwsInternal *c = internal(sws);
+    if (!c->legacy_init && c->graph[0].legacy) return sws_hip_last_kernel_ms(c->graph[0].legacy);   // dynamic context: its top-field conversion
     if (!c->dev || !c->dev->timed) return -1.0;
     float ms = 0.f;
     if (hipEventSynchronize(c->dev->ev1) != hipSuccess) return -1.0;
@@ -1483,6 +1552,8 @@ int sws_hip_frame_alloc(SwsFrameView *f, int format, int width, int height, int 
     for (int k = 0; k < np; k++) { f->data[k] = (uint8_t *)base + offs[k]; f->linesize[k] = ls[k]; }
     f->extended_data = f->data;
     f->width = width; f->height = height; f->format = format;
+    f->color_primaries = f->color_trc = f->colorspace = 2;   // *_UNSPECIFIED: get_frame_defaults(), libavutil/frame.c
+    f->sample_aspect_ratio.den = 1;
     return 0;
 }
 

@@ -90,7 +90,6 @@ enum PlanKind {
     PLAN_CASCADE,          // two contexts through an intermediate image
 };
 
-int init_from_frames(struct SwsInternal *c, int sw, int sh, int sfmt, int dw, int dh, int dfmt);
 int canonical_pix_fmt(int fmt); // handle_jpeg + handle_0alpha aliases (utils.c:773-842)
 
 struct DeviceState;  // HIP side (devstate.hpp)
@@ -109,6 +108,23 @@ struct Tuning {
     int debug = 0;
 };
 
+// What sws_scale_frame() on a dynamic context knows about one field of a frame (libswscale/format.h:79-110 SwsFormat)
+struct SwsFmt {
+    int width, height, format, hw_format;
+    int range, csp, loc, prim, trc;      // enum AVColorRange / AVColorSpace / AVChromaLocation / AVColorPrimaries / AVColorTransferCharacteristic
+    int interlaced, field;
+    uint64_t side_hash;                  // fingerprint of the mastering-display / HDR10+ side data (compared, never interpreted)
+    int hip_device; void *hip_stream;    // AV_PIX_FMT_HIP frames: AVHIPDeviceContext of their device
+    const void *device_ref;              // AVHWDeviceContext the frames context belongs to
+};
+// One field's conversion of a dynamic context (libswscale/graph.h SwsGraph, reduced to what the legacy back-end needs)
+struct FrameGraph {
+    bool valid = false, noop = false, incomplete = false;
+    SwsFmt src{}, dst{};
+    SwsContext opts_copy{};
+    SwsContext *legacy = nullptr;        // sws_init_context()ed child that does the work
+};
+
 struct SwsInternal {
     SwsContext opts;          // MUST be first: the public struct (swscale_internal.h:337-340 idiom)
     uint32_t magic;
@@ -118,8 +134,7 @@ struct SwsInternal {
     const SwsFrameView *frame_src = nullptr; SwsFrameView *frame_dst = nullptr; int frame_rows_in = 0;   // sws_frame_start .. sws_frame_end
     bool srcXYZ = false, dstXYZ = false; // handle_xyz (utils.c:822-842): the caller's formats were xyz12, opts.*_format hold rgb48le
     bool srcBE = false, dstBE = false;   // the caller's formats were big-endian: opts.src_format / dst_format hold the LE twins
-    bool dynamic_init = false;    // configured from the frames of sws_scale_frame() (swscale.c:1405-1480)
-    int user_src_range = 0, user_dst_range = 0, eff_src_range = 0, eff_dst_range = 0;   // dynamic mode: ranges as the caller set them / after the yuvj-gray aliasing
+    FrameGraph graph[2];          // dynamic mode (sws_alloc_context() only): top / bottom field conversions built by sws_frame_setup()
     int sliceDir = 0;             // 0 = no slice sequence in progress, 1 = top-down, -1 = bottom-up (swscale.c:1096-1104)
     int slice_dstY = 0;           // ff_swscale's dstY cursor (swscale.c:372-381, :566)
     int src0Alpha = 0, dst0Alpha = 0;
@@ -160,6 +175,11 @@ void dev_release(SwsInternal *c);                         // frees the device st
 int  dev_run(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4], int srcSliceY, int srcSliceH,
              uint8_t *const dst[4], const int dstStride[4], int nb_frames,
              const SwsFrameView *const *srcFrames, SwsFrameView *const *dstFrames);
+int  dev_inherit(SwsInternal *child, SwsInternal *parent, bool have_stream, void *stream);  // a dynamic context's child runs on its GPU / stream / tuning
+int  dev_use_stream(SwsInternal *c, void *stream);        // run on the stream of the frames' AVHIPDeviceContext
+int  dev_copy_frame(SwsInternal *c, SwsFrameView *dst, const SwsFrameView *src, bool have_stream, void *stream);   // no-op conversion: plane copies
+void frames_release(SwsInternal *c);                      // frees the per-field conversions of a dynamic context
+bool check_image_pointers(const uint8_t *const data[4], int fmt, const int linesizes[4]);
 size_t tables_blob_size(const SwsInternal *c);
 int  tables_blob_export(const SwsInternal *c, void *buf, size_t size);
 int  tables_blob_import(SwsInternal *c, const void *buf, size_t size);

@@ -105,10 +105,72 @@ def build_library(force=False):
     return library_path()
 
 
+class SwsBufferRef(C.Structure):
+    """libavutil/buffer.h:82-95 AVBufferRef"""
+    _fields_ = [("buffer", C.c_void_p), ("data", C.c_void_p), ("size", C.c_size_t)]
+
+
+class SwsRational(C.Structure):
+    _fields_ = [("num", C.c_int), ("den", C.c_int)]
+
+
+class SwsFrameSideData(C.Structure):
+    """libavutil/frame.h:236-251 AVFrameSideData"""
+    _fields_ = [("type", C.c_int), ("data", C.c_void_p), ("size", C.c_size_t), ("metadata", C.c_void_p), ("buf", C.c_void_p)]
+
+
+class SwsChannelLayout(C.Structure):
+    _fields_ = [("order", C.c_int), ("nb_channels", C.c_int), ("mask", C.c_uint64), ("opaque", C.c_void_p)]
+
+
 class SwsFrameView(C.Structure):
-    """Prefix of AVFrame (libavutil/frame.h:472-559), see include/swscale_hip.h."""
+    """Field-for-field mirror of AVFrame (libavutil/frame.h:472-828), see include/swscale_hip.h."""
     _fields_ = [("data", C.c_void_p * 8), ("linesize", C.c_int * 8), ("extended_data", C.c_void_p),
-                ("width", C.c_int), ("height", C.c_int), ("nb_samples", C.c_int), ("format", C.c_int)]
+                ("width", C.c_int), ("height", C.c_int), ("nb_samples", C.c_int), ("format", C.c_int),
+                ("pict_type", C.c_int), ("sample_aspect_ratio", SwsRational), ("pts", C.c_int64), ("pkt_dts", C.c_int64),
+                ("time_base", SwsRational), ("quality", C.c_int), ("opaque", C.c_void_p), ("repeat_pict", C.c_int),
+                ("sample_rate", C.c_int), ("buf", C.c_void_p * 8), ("extended_buf", C.c_void_p), ("nb_extended_buf", C.c_int),
+                ("side_data", C.POINTER(C.POINTER(SwsFrameSideData))), ("nb_side_data", C.c_int), ("flags", C.c_int),
+                ("color_range", C.c_int), ("color_primaries", C.c_int), ("color_trc", C.c_int), ("colorspace", C.c_int),
+                ("chroma_location", C.c_int), ("best_effort_timestamp", C.c_int64), ("metadata", C.c_void_p),
+                ("decode_error_flags", C.c_int), ("hw_frames_ctx", C.POINTER(SwsBufferRef)), ("opaque_ref", C.c_void_p),
+                ("crop_top", C.c_size_t), ("crop_bottom", C.c_size_t), ("crop_left", C.c_size_t), ("crop_right", C.c_size_t),
+                ("private_ref", C.c_void_p), ("ch_layout", SwsChannelLayout), ("duration", C.c_int64), ("alpha_mode", C.c_int)]
+
+
+class AVHIPDeviceContext(C.Structure):
+    """include/hwcontext_hip.h"""
+    _fields_ = [("device", C.c_int), ("stream", C.c_void_p)]
+
+
+class SwsHWDeviceContext(C.Structure):
+    """libavutil/hwcontext.h:63-106 AVHWDeviceContext"""
+    _fields_ = [("av_class", C.c_void_p), ("type", C.c_int), ("hwctx", C.c_void_p), ("free", C.c_void_p), ("user_opaque", C.c_void_p)]
+
+
+class SwsHWFramesContext(C.Structure):
+    """libavutil/hwcontext.h:118-221 AVHWFramesContext"""
+    _fields_ = [("av_class", C.c_void_p), ("device_ref", C.c_void_p), ("device_ctx", C.POINTER(SwsHWDeviceContext)), ("hwctx", C.c_void_p),
+                ("free", C.c_void_p), ("user_opaque", C.c_void_p), ("pool", C.c_void_p), ("initial_pool_size", C.c_int),
+                ("format", C.c_int), ("sw_format", C.c_int), ("width", C.c_int), ("height", C.c_int)]
+
+
+AV_PIX_FMT_HIP = 268
+AV_HWDEVICE_TYPE_HIP = 15
+AV_FRAME_FLAG_INTERLACED = 1 << 3
+COL_RANGE = {"unspecified": 0, "mpeg": 1, "tv": 1, "jpeg": 2, "pc": 2}
+CHROMA_LOC = {"unspecified": 0, "left": 1, "center": 2, "topleft": 3, "top": 4, "bottomleft": 5, "bottom": 6}
+COL_SPC = {"rgb": 0, "bt709": 1, "unspecified": 2, "fcc": 4, "bt470bg": 5, "smpte170m": 6, "smpte240m": 7, "bt2020nc": 9}
+
+
+def apply_props(v, props):
+    """frame properties (AVFrame fields by name: color_range=, colorspace=, chroma_location=, color_primaries=, color_trc=, flags=)"""
+    v.color_primaries = v.color_trc = v.colorspace = 2      # *_UNSPECIFIED, as av_frame_alloc() leaves them (frame.c get_frame_defaults)
+    for k, val in (props or {}).items():
+        if isinstance(val, str):
+            val = {"color_range": COL_RANGE, "chroma_location": CHROMA_LOC, "colorspace": COL_SPC}[k][val]
+        setattr(v, k, val)
+    return v
 
 
 class SwsVector(C.Structure):
@@ -166,6 +228,17 @@ def load_library():
     L.sws_hip_get_stream.restype = vp
     L.sws_hip_get_stream.argtypes = [vp]
     L.sws_hip_sync.argtypes = [vp]
+    # device-level helpers of include/hwcontext_hip.h
+    L.sws_hip_mem_alloc.argtypes = [ci, C.c_size_t, C.POINTER(vp)]
+    L.sws_hip_mem_free.argtypes = [ci, vp]
+    L.sws_hip_mem_free.restype = None
+    L.sws_hip_stream_create.argtypes = [ci, C.POINTER(vp)]
+    L.sws_hip_stream_destroy.argtypes = [ci, vp]
+    L.sws_hip_stream_destroy.restype = None
+    L.sws_hip_stream_sync.argtypes = [ci, vp]
+    L.sws_hip_copy_plane.argtypes = [ci, vp, vp, ci, vp, ci, ci, ci]
+    L.sws_hip_pointer_device.argtypes = [vp]
+    L.sws_hip_frames_format_supported.argtypes = [ci]
     L.sws_hip_frame_alloc.argtypes = [C.POINTER(SwsFrameView), ci, ci, ci, ci]
     L.sws_hip_frame_free.argtypes = [C.POINTER(SwsFrameView)]
     L.sws_hip_frame_upload.argtypes = [vp, C.POINTER(SwsFrameView), C.POINTER(SwsFrameView)]
@@ -262,7 +335,7 @@ class HostFrame:
             v.data[i] = a.ctypes.data
             v.linesize[i] = a.strides[0]
         v.width, v.height, v.format = self.w, self.h, PIX_FMT[self.fmt]
-        return v
+        return apply_props(v, getattr(self, "props", None))
 
     def visible(self):
         return b"".join(a[:, :rb].tobytes() for a, rb in zip(self.planes, self.row_bytes))
@@ -297,7 +370,7 @@ class DeviceFrame:
             v.data[i] = self.base + self.offset[i]
             v.linesize[i] = self.linesize[i]
         v.width, v.height, v.format = self.w, self.h, PIX_FMT[self.fmt]
-        return v
+        return apply_props(v, getattr(self, "props", None))
 
     def plane_tensor(self, i):
         """2-D (rows, linesize) uint8 view of plane i."""

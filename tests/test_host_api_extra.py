@@ -84,7 +84,10 @@ def test_capability_queries(hiplib):
     assert [L.sws_test_colorspace(i, 0) for i in range(12)] == [1, 1, 1, 0, 1, 1, 1, 1, 0, 1, 0, 0]   # format.c:625-640
     assert [L.sws_test_primaries(i, 0) for i in (0, 1, 2, 3, 4, 12, 22, 23)] == [0, 1, 1, 0, 1, 1, 1, 0]
     assert [L.sws_test_transfer(i, 0) for i in (0, 1, 2, 3, 8, 9, 10, 11, 16, 18, 19)] == [0, 1, 1, 0, 1, 0, 0, 1, 1, 1, 0]
-    a = S.SwsFrameView(); b = S.SwsFrameView()
+    a = S.apply_props(S.SwsFrameView(), {}); b = S.apply_props(S.SwsFrameView(), {})   # av_frame_alloc() defaults: *_UNSPECIFIED
+    z = S.SwsFrameView()
+    z.width, z.height, z.format = 64, 32, P["yuv420p"]
+    assert not L.sws_test_frame(C.byref(z), 0)          # all-zero colour fields: AVCOL_PRI_RESERVED0 is refused (format.c:648-653)
     a.width, a.height, a.format = 64, 32, P["yuv420p"]
     b.width, b.height, b.format = 64, 32, P["yuv420p"]
     assert L.sws_test_frame(C.byref(a), 0) and L.sws_is_noop(C.byref(a), C.byref(b))
