@@ -15,6 +15,9 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#ifdef SWS_HIP_PREFIXED
+#include "swscale_hip_prefix.h"
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -76,6 +79,8 @@ int   sws_hip_pointer_device(const void *ptr);
 /* plane layout of one linear allocation: linesize[] aligned to `align`, planes at `align`ed offsets
  * (av_image_fill_linesizes / av_image_fill_plane_sizes / av_image_fill_pointers, hwcontext_cuda.c:160-185) */
 int   sws_hip_image_layout(int format, int width, int height, int align, int linesize[4], size_t offset[4], size_t *total);
+/* visible bytes per row and rows of plane `plane` of a width x height picture (the 2-D extent a transfer copies) */
+int   sws_hip_plane_geometry(int format, int width, int height, int plane, int *bytewidth, int *rows);
 /* the sw_formats frames_init accepts == the formats libswscale_hip converts (cuda's supported_formats[], hwcontext_cuda.c:44-80) */
 int   sws_hip_frames_format_supported(int sw_format);
 

@@ -19,6 +19,9 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#ifdef SWS_HIP_PREFIXED      /* libswship.so: the same entry points as swship_* (swscale_hip_prefix.h) */
+#include "swscale_hip_prefix.h"
+#endif
 
 #ifdef __cplusplus
 extern "C" {

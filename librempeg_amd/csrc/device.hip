@@ -1401,6 +1401,12 @@ int sws_hip_copy_plane(int device, void *stream, void *dst, int dst_linesize, co
     return 0;
 }
 int sws_hip_pointer_device(const void *ptr) { return ptr_device(ptr); }
+int sws_hip_plane_geometry(int format, int width, int height, int plane, int *bytewidth, int *rows)
+{
+    const PixDesc *d = pix_desc(format);
+    if (!d || width <= 0 || height <= 0 || plane < 0 || plane >= pix_nb_planes(d) || !bytewidth || !rows) return SWS_AVERROR(EINVAL);
+    return plane_geometry(format, width, height, plane, bytewidth, rows);
+}
 int sws_hip_frames_format_supported(int sw_format)
 {
     return pix_desc(sw_format) && sws_isSupportedInput((enum AVPixelFormat)sw_format) && sws_isSupportedOutput((enum AVPixelFormat)sw_format);

@@ -101,7 +101,8 @@ def build_library(force=False):
     src = os.path.join(_HERE, "csrc")
     if force:
         subprocess.check_call(["make", "-s", "-C", src, "clean"])
-    subprocess.check_call(["make", "-s", "-j", str(max(2, os.cpu_count() or 2)), "-C", src])   # one object per translation unit
+    # one object per translation unit; "prefixed" = libswship.so, the same code exported as swship_* (include/swscale_hip_prefix.h)
+    subprocess.check_call(["make", "-s", "-j", str(max(2, os.cpu_count() or 2)), "-C", src, "all", "prefixed"])
     return library_path()
 
 

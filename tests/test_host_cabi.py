@@ -128,3 +128,26 @@ def test_table_blob_roundtrip(hiplib):
     d = LA.SwsContext(0, 0, "yuv420p", 0, 0, "yuv420p", 0, empty=True)
     d.import_tables(c.export_tables())
     assert d.export_tables() == c.export_tables()
+
+
+def test_prefixed_twin_exports_the_same_api_as_swship(hiplib):
+    """libswship.so (make prefixed): every export of libswscale_hip.so under the swship_ prefix and nothing else, so that a process can
+    hold it next to the real libswscale; include/swscale_hip_prefix.h is the rename list."""
+    import subprocess
+    libdir = os.path.join(ROOT, "librempeg_amd", "lib")
+    def exports(name):
+        out = subprocess.check_output(["nm", "-D", os.path.join(libdir, name)], text=True)
+        return sorted(l.split()[2].split("@")[0] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T")
+    plain, pref = exports("libswscale_hip.so"), exports("libswship.so")
+    assert all(s.startswith(("sws_", "swscale_")) for s in plain) and all(s.startswith("swship_") for s in pref)
+    ren = lambda s: "swship_" + s[4:] if s.startswith("sws_") else "swship_" + s
+    assert sorted(ren(s) for s in plain) == pref
+    hdr = open(os.path.join(ROOT, "include", "swscale_hip_prefix.h")).read()
+    assert sorted(re.findall(r"^#define (\w+) swship_\w+$", hdr, flags=re.M)) == plain
+    both = C.CDLL(os.path.join(libdir, "libswship.so"))
+    assert both.swship_swscale_version() == hiplib.swscale_version()
+    both.swship_alloc_context.restype = C.c_void_p
+    c = both.swship_alloc_context()
+    assert c
+    both.swship_freeContext.argtypes = [C.c_void_p]
+    both.swship_freeContext(c)
