@@ -55,6 +55,11 @@ WORKLOADS = {
     "c5": (3840, 2160, "gbrpf32le", 3840, 2160, "yuv444p16le", SWS_BICUBIC | SWS_BITEXACT,
            (SWS_CS_BT2020, 1, SWS_CS_BT2020, 1), 8,
            "C5 3840x2160 gbrpf32le->yuv444p16le BT.2020 full range"),
+    # not BASELINE.json configs: the most common real use of sws_scale, kept as bench variants
+    "d1": (3840, 2160, "yuv420p", 1920, 1080, "rgb24", SWS_BICUBIC | SWS_BITEXACT, None, 32,
+           "D1 3840x2160->1920x1080 yuv420p->rgb24 SWS_BICUBIC|SWS_BITEXACT (downscale to packed RGB)"),
+    "d2": (3840, 2160, "yuv420p", 1920, 1080, "bgra", SWS_BICUBIC | SWS_BITEXACT, None, 32,
+           "D2 3840x2160->1920x1080 yuv420p->bgra SWS_BICUBIC|SWS_BITEXACT (downscale to packed RGB)"),
 }
 
 

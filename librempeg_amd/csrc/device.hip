@@ -320,7 +320,13 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             const bool src_ok = p.srcKind == SRCK_PLANAR8 || (p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15 && p.src_shift == 0);
             const bool dst_ok = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010;
             auto fs2 = [](int fs) { return (fs + 2) & ~1; };
-            if (!d->unity_h && !p.fast_bilinear && !gray_any && src_ok && dst_ok && !p.wide && c->vLum.size >= 2 && c->vChr.size >= 2 &&
+            // packed 24 / 32 bpp RGB through the LUT writers (not the full-chroma ones): the strip kernel with the RGB epilogue
+            const bool rgb_ok = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr && p.srcKind == SRCK_PLANAR8 && c->srcBpc == 8 &&
+                                !p.no_chroma && !p.need_alpha && !(p.dstW & 1) && !p.range_active && !c->tune.no_strip;
+            d->striprgb_ok = false;
+            // (planar writers: a one-tap vertical filter takes the reference's yuv2plane1 form, not the "X" arithmetic of these kernels;
+            //  the packed writers are in "X" mode unless both vertical filters are short, which all_x_mode checks row by row)
+            if (!d->unity_h && !p.fast_bilinear && !gray_any && src_ok && ((dst_ok && c->vLum.size >= 2 && c->vChr.size >= 2) || rgb_ok) && !p.wide &&
                 fs2(c->hLum.size) <= 16 && fs2(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && fs2(c->vChr.size) <= 16 &&
                 !c->tune.no_dot2) {
                 const int SPC = p.srcKind == SRCK_PLANAR16 ? 8 : 16;
@@ -411,10 +417,35 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 const int strip_cols_c = c->tune.strip_cols_c == 1 ? 1 : 2;
                 // (narrow pictures leave most of a 256-column strip idle and pay the per-band ring fill: the tile kernel keeps them)
                 const int strip_min_w = c->tune.strip_min_w;
-                const bool strip_plan = !p.range_active && !c->tune.no_strip && p.dstW >= strip_min_w &&
+                const bool strip_plan = dst_ok && !p.range_active && !c->tune.no_strip && p.dstW >= strip_min_w &&
                                         plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sL) && plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sC);
                 d->strip_ok = false;
                 Off oL, oC;
+                if (rgb_ok) {
+                    // RGB epilogue: 256 luma columns + the 128 chroma columns under them per wave, one 16-byte chunk per lane and row for
+                    // both (windows of up to 1024 source samples), rings of 5 / 3 row pairs (8 / 5 in the long form)
+                    SOff rL, rC;
+                    SwsStripGeom &gl = d->stripRL, &gc = d->stripRC;
+                    if (plan3(c->hLum, c->vLum, p.dstW, 4, 1, gl, rL) && plan3(c->hChr, c->vChr, p.chrDstW, 2, 2, gc, rC) && gl.strips == gc.strips &&
+                        gl.NCmax / 16 <= 64 && gc.NCmax / 16 <= 64 && std::max(gl.nph, gc.nph) <= 8 && gl.npv <= 8 && gc.npv <= 5 && p.chrDstH == p.dstH) {
+                        const std::vector<int16_t> htl = padded(c->hLum), htc = padded(c->hChr);
+                        const size_t ohl = put(htl.data(), htl.size() * 2), ohc = put(htc.data(), htc.size() * 2);
+                        if (blob.size() > d->dot2_bytes) {
+                            if (d->d_dot2) HIPCHK(hipFree(d->d_dot2));
+                            d->d_dot2 = nullptr;
+                            HIPCHK(hipMalloc(&d->d_dot2, blob.size()));
+                            d->dot2_bytes = blob.size();
+                        }
+                        HIPCHK(hipMemcpy(d->d_dot2, blob.data(), blob.size(), hipMemcpyHostToDevice));
+                        const uint8_t *b = (const uint8_t *)d->d_dot2;
+                        gl.colStart = (const int32_t *)(b + rL.cs); gl.colCount = (const int32_t *)(b + rL.cc); gl.rows = (const SwsStripRow *)(b + rL.rows);
+                        gc.colStart = (const int32_t *)(b + rC.cs); gc.colCount = (const int32_t *)(b + rC.cc); gc.rows = (const SwsStripRow *)(b + rC.rows);
+                        gl.hT2 = (const int16_t *)(b + ohl); gc.hT2 = (const int16_t *)(b + ohc); gl.vT2 = gc.vT2 = nullptr;
+                        gl.nph = gc.nph = std::max(gl.nph, gc.nph);      // one instantiation: the shorter tap rows are zero-extended in the kernel
+                        d->striprgb_long = gl.npv > 5 || gc.npv > 3;
+                        d->striprgb_ok = true;                           // (and every row in the "X" writer mode: checked below)
+                    }
+                } else
                 if (plan2(c->hLum, c->vLum, p.dstW, p.dstH, 1, d->dotL, oL) && plan2(c->hChr, c->vChr, p.chrDstW, p.chrDstH, 2, d->dotC, oC)) {
                     if (blob.size() > d->dot2_bytes) {
                         if (d->d_dot2) HIPCHK(hipFree(d->d_dot2));
@@ -509,6 +540,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) all_x = false;
             }
             d->all_x_mode = all_x;
+            d->striprgb_ok = d->striprgb_ok && all_x;
             int win = 0;
             for (int y = 0; y < o.dst_h; y += 2) {
                 const int c0 = y >> c->chrDstVSubSample, c1 = std::min(y + 1, o.dst_h - 1) >> c->chrDstVSubSample;
@@ -616,6 +648,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         } else if (d->unity_h) {
             c->path_name = "main:fused_generic_unity";
             c->kernel_name = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) ? "sws_k_vscale_rgb" : "sws_k_vscale_planar";
+        } else if (d->striprgb_ok) {
+            c->path_name = "main:strip_rgb"; c->kernel_name = "sws_k_strip_rgb";
         } else if (d->strip_ok) {
             c->path_name = "main:strip_march";
             c->kernel_name = (p.srcKind == SRCK_PLANAR16 && d->stripL.dma_ok && !c->tune.no_strip_dma) ? "sws_k_strip_dma" : "sws_k_strip_march";
@@ -756,6 +790,7 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         else if (vec && d->unity_h && d->unity_v && !p.no_chroma && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 && p.dst_shift == 0 &&
                  (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16))
             ret = launch_f32rgb(L);
+        else if (d->striprgb_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_striprgb(L);   // marching strip kernel, RGB epilogue
         else if (d->strip_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_strip(L);   // marching strip kernel
         else if (d->dot2_ok && vec) ret = launch_tile_dot2(L);                                              // dot2 LDS-tile kernel
         else if (d->tile_ok) ret = launch_tile(L);                                                          // fused h+v LDS-tile kernel

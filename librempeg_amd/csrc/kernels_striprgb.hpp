@@ -1,0 +1,292 @@
+// Marching strip kernel with the packed-RGB epilogue: the general h+v polyphase chain from planar 8-bit YUV to 24 / 32 bpp RGB
+// (the "downscale 4K to 1080p and hand it to the display / encoder as RGB" shape): hScale8To15_c for luma and chroma
+// (swscale.c:128-142) + packed_vscale + yuv2rgb24_X_c / yuv2rgbx32_X_c (vscale.c:109-171, output.c:1788-1840; the LUTs of
+// yuv2rgb.c:901-961 in closed form).
+//
+// Schedule (kernels_strip.hpp describes the planar form this extends):
+//  * a wave owns a strip of 256 output columns -- 256 luma columns and the 128 chroma columns under them -- and walks down a band
+//    of output rows.  Luma and chroma are two instances of the same machine (StripPlane): wave-private LDS staging of ONE PAIR of
+//    source rows, horizontal taps in registers, a register ring of h-scaled row pairs, v_dot2_i32_i16 for both stages.  Nothing
+//    h-scaled ever leaves the wave: the reference's 15-bit intermediate planes (2 x 4 bytes per output pixel written and read
+//    back by the two-pass form) do not exist;
+//  * lane l owns luma columns l, l + 64, l + 128, l + 192 and chroma columns l, l + 64 of the strip (bank-conflict-free LDS reads in
+//    the horizontal stage).  The pixel pair (2j, 2j + 1) needs chroma column j: the vertical stage's luma results cross lanes once
+//    per row through 512 bytes of wave-private LDS (4 ds_write_b16, 2 ds_read_b32), after which lane l holds the pairs l and
+//    l + 64 and writes their 6 or 8 bytes each;
+//  * the chroma side of the LUT is two 256-entry tables in LDS built per workgroup (kernels_rgbmarch.hpp), a pixel costs one
+//    multiply-add per channel plus the clamping pack;
+//  * per output row the scalars (first ring pair, vertical tap pairs) of both planes arrive through one 64-byte scalar load each,
+//    one row ahead; the next source row pair of each plane is prefetched into registers while the current one is computed;
+//  * buffer descriptors everywhere (out-of-range lanes are dropped by the hardware), stores issued after the wait for the
+//    prefetched rows and before the next prefetch (vmcnt counts loads and stores together).
+#pragma once
+#include "kernels_strip.hpp"
+#include "kernels_rgbmarch.hpp"
+
+namespace swsk {
+
+template <int NCOMP, int COLS, int NPH, int RD>
+struct StripPlane {
+    StripLds L;
+    int spd[COLS];
+    uint32_t ht[COLS][NPH];
+    sws_rsrc_t rs[NCOMP];
+    int sst[NCOMP], sH, voff, slot, qnext;
+    u32x4 pre[NCOMP * 2];                 // [component][row of the pair]
+    uint32_t ring[NCOMP][COLS][RD];
+};
+
+template <int NCOMP, int COLS, int NPH, int RD>
+__device__ __forceinline__ void sp_prefetch(StripPlane<NCOMP, COLS, NPH, RD> &P, int q)
+{
+    const int r0 = min(max(2 * q, 0), P.sH - 1), r1 = min(max(2 * q + 1, 0), P.sH - 1);
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++) {
+        P.pre[2 * ci + 0] = bload16(P.rs[ci], P.voff, r0 * P.sst[ci]);
+        P.pre[2 * ci + 1] = bload16(P.rs[ci], P.voff, r1 * P.sst[ci]);
+    }
+}
+
+__device__ __forceinline__ void sp_put8(uint32_t *dst, const u32x4 &v)   // 16 bytes -> 8 dwords of u16 sample pairs
+{
+    u32x4 lo, hi;
+    lo[0] = __builtin_amdgcn_perm(0, v[0], 0x0c010c00u); lo[1] = __builtin_amdgcn_perm(0, v[0], 0x0c030c02u);
+    lo[2] = __builtin_amdgcn_perm(0, v[1], 0x0c010c00u); lo[3] = __builtin_amdgcn_perm(0, v[1], 0x0c030c02u);
+    hi[0] = __builtin_amdgcn_perm(0, v[2], 0x0c010c00u); hi[1] = __builtin_amdgcn_perm(0, v[2], 0x0c030c02u);
+    hi[2] = __builtin_amdgcn_perm(0, v[3], 0x0c010c00u); hi[3] = __builtin_amdgcn_perm(0, v[3], 0x0c030c02u);
+    *(u32x4 *)dst = lo; *(u32x4 *)(dst + 4) = hi;
+}
+
+template <int NCOMP, int COLS, int NPH, int RD>
+__device__ __forceinline__ void sp_stage(StripPlane<NCOMP, COLS, NPH, RD> &P)
+{
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++) {
+        uint32_t *row0 = P.L.S + (ci * 2) * P.L.row_dw, *row1 = row0 + P.L.row_dw;
+        sp_put8(row0 + P.slot, P.pre[2 * ci + 0]); sp_put8(row1 + P.slot, P.pre[2 * ci + 1]);
+    }
+}
+
+// per-lane column state of one plane class: window offsets, horizontal taps, source descriptors
+template <int NCOMP, int COLS, int NPH, int RD>
+__device__ __forceinline__ void sp_init(StripPlane<NCOMP, COLS, NPH, RD> &P, const SwsStripGeom &g, int strip, int W, int sH, const int32_t *hpos,
+                                        const uint8_t *const (&sb)[NCOMP], const int (&sst)[NCOMP], uint32_t *lds, int lane)
+{
+    const int xs = strip * g.TW, cs = g.colStart[strip], chunks = g.colCount[strip] / 16;
+    P.L.row_dw = (g.NCmax + 16) >> 1;      // one spare chunk per row: the dump slot of idle lanes
+    P.L.S = lds;
+    P.sH = sH;
+    const int nd = g.hfs2 >> 1;            // dwords per tap row (rows are padded to hfs2 taps: beyond that the next column's taps begin)
+#pragma unroll
+    for (int c = 0; c < COLS; c++) {
+        const int x = min(xs + 64 * c + lane, W - 1);
+        P.spd[c] = ((hpos[x] & ~1) - cs) >> 1;
+        const uint32_t *tp = (const uint32_t *)(g.hT2 + (int64_t)x * g.hfs2);
+#pragma unroll
+        for (int k = 0; k < NPH; k++) P.ht[c][k] = k < nd ? tp[k] : 0u;
+    }
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++) { P.sst[ci] = sst[ci]; P.rs[ci] = make_rsrc(sb[ci], (uint32_t)sst[ci] * (uint32_t)sH); }
+    // one 16-byte chunk per lane and source row, unconditionally: a lane beyond the strip's window gets an out-of-range offset (the
+    // descriptor answers 0 without touching memory) and dumps into the spare chunk
+    P.voff = lane < chunks ? cs + lane * 16 : 0x7fffffff;
+    P.slot = min(lane, chunks) * 8;
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+        for (int c = 0; c < COLS; c++)
+#pragma unroll
+            for (int k = 0; k < RD; k++) P.ring[ci][c][k] = 0;
+}
+
+// h-scale the staged row pair into the ring, then stage the prefetched pair and request the one after it.  `flush` releases the
+// pending output row between the wait for the prefetched pair and the next request (see the header of kernels_strip.hpp).
+template <int NCOMP, int COLS, int NPH, int RD, typename F>
+__device__ __forceinline__ void sp_step(StripPlane<NCOMP, COLS, NPH, RD> &P, int sh, int opaque_neg, F &&flush)
+{
+    uint32_t np[NCOMP][COLS];
+    // (a basic block of its own: see strip_body in kernels_strip.hpp -- straight-line code makes hipcc spill inside the loop)
+    if (opaque_neg < 0) {
+#pragma unroll
+        for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+            for (int c = 0; c < COLS; c++) np[ci][c] = P.L.S[(ci * 2) * P.L.row_dw + P.spd[c]];
+    } else
+    strip_hstage<NPH, NCOMP, COLS>(P.L, P.spd, P.ht, sh, np);
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+        for (int c = 0; c < COLS; c++) {
+#pragma unroll
+            for (int k = 0; k < RD - 1; k++) P.ring[ci][c][k] = P.ring[ci][c][k + 1];
+            P.ring[ci][c][RD - 1] = np[ci][c];
+        }
+    P.qnext++;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    sp_stage(P);
+    flush();
+    sp_prefetch(P, P.qnext + 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NCOMP, int COLS, int NPH, int RD>
+__device__ __forceinline__ void sp_restart(StripPlane<NCOMP, COLS, NPH, RD> &P, int q)   // (re)fill: pair q staged, pair q + 1 requested
+{
+    P.qnext = q;
+    sp_prefetch(P, q);
+    sp_stage(P);
+    sp_prefetch(P, q + 1);
+}
+
+// vertical stage over the newest npv ring entries (npv <= RD): sums of sample * tap, no rounding constant
+template <int NCOMP, int COLS, int NPH, int RD>
+__device__ __forceinline__ void sp_vstage(const StripPlane<NCOMP, COLS, NPH, RD> &P, const SwsStripRow &e, int npv, int (&acc)[NCOMP][COLS])
+{
+#pragma unroll
+    for (int n = 1; n <= RD; n++)
+        if (n == npv) {
+#pragma unroll
+            for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++) {
+                    acc[ci][c] = sdot2_first_s(P.ring[ci][c][RD - n], e.vt[0]);
+#pragma unroll
+                    for (int k = 1; k < n; k++) acc[ci][c] = sdot2(P.ring[ci][c][RD - n + k], e.vt[k], acc[ci][c]);
+                }
+        }
+}
+
+// one pixel pair through the LUT: Y1, Y2, U, V as the reference's ">> 19" results -> BPP == 3: w[0] = bytes 0..3, w[1] = bytes 4..5;
+// BPP == 4: w[0], w[1] = the two pixels
+template <int BPP>
+__device__ __forceinline__ void lut_pair(const SwsLutParams &L, const LutTabs &T, bool swap_rb, int Y1, int Y2, int U, int V, uint32_t (&w)[2])
+{
+    const uint32_t ou = (uint32_t)clip_u8(U) << 3, ov = (uint32_t)clip_u8(V) << 3;
+    const u32x2 ev = *(const u32x2 *)(T.v + ov), eu = *(const u32x2 *)(T.u + ou);
+    const int A0 = (int)(swap_rb ? eu[0] : ev[0]), A1 = (int)(ev[1] + eu[1]), A2 = (int)(swap_rb ? ev[0] : eu[0]);
+    const int a0 = mad24(Y1, L.cy, A0), a1 = mad24(Y1, L.cy, A1), a2 = mad24(Y1, L.cy, A2);
+    const int b0 = mad24(Y2, L.cy, A0), b1 = mad24(Y2, L.cy, A1), b2 = mad24(Y2, L.cy, A2);
+    if constexpr (BPP == 4) {
+        const int ta = 255 << 16;
+        // canonical bytes {first, g, third, alpha}; L.perm32 moves them to the format's order (alpha-first formats)
+        w[0] = __builtin_amdgcn_perm(0, pack4_u8_shr16(a0, a1, a2, ta), L.perm32);
+        w[1] = __builtin_amdgcn_perm(0, pack4_u8_shr16(b0, b1, b2, ta), L.perm32);
+    } else {
+        w[0] = pack4_u8_shr16(a0, a1, a2, b0);
+        w[1] = pack4_u8_shr16(b1, b2, 0, 0);
+    }
+}
+
+template <int BPP, int NPH, int RL, int RC>
+__device__ __forceinline__ void strip_rgb_body(const FrameRegs &f, const SwsDevParams &p, const SwsStripGeom &gl, const SwsStripGeom &gc,
+                                               int strip, int y0, int y1, uint32_t *lds, const LutTabs &T, int lane)
+{
+    const int W = p.dstW, H = p.dstH;
+    StripPlane<1, 4, NPH, RL> PL;
+    StripPlane<2, 2, NPH, RC> PC;
+    const int ldw = (gl.NCmax + 16) >> 1, cdw = (gc.NCmax + 16) >> 1;
+    uint32_t *ldsL = lds, *ldsC = lds + 2 * ldw, *ldsX = ldsC + 4 * cdw;       // luma rows, chroma rows, 256 x int16 exchange row
+    {
+        const uint8_t *const sb[1] = { f.src[0] };
+        const int st[1] = { f.srcStride[0] };
+        sp_init(PL, gl, strip, W, p.srcH, p.hLumPos, sb, st, ldsL, lane);
+    }
+    {
+        const bool u1 = p.u_plane_src == 1;
+        const uint8_t *const sb[2] = { u1 ? f.src[1] : f.src[2], u1 ? f.src[2] : f.src[1] };
+        const int st[2] = { u1 ? f.srcStride[1] : f.srcStride[2], u1 ? f.srcStride[2] : f.srcStride[1] };
+        sp_init(PC, gc, strip, p.chrDstW, p.chrSrcH, p.hChrPos, sb, st, ldsC, lane);
+    }
+    // destination: whole picture, pair j of the strip at byte (256 * strip + 2 * j) * BPP of a row
+    const sws_rsrc_t rd = make_rsrc(f.dst[0], (uint32_t)f.dstStride[0] * (uint32_t)(H - 1) + (uint32_t)W * (uint32_t)BPP);
+    const int dstr = f.dstStride[0];
+    int doff[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int x = strip * 256 + 2 * (64 * c + lane);
+        doff[c] = x < W ? x * BPP : 0x7fffffff;
+    }
+    uint32_t pend[2][2];
+    int pend_y = -1;
+    auto flush = [&]() {
+        if (pend_y >= 0) {
+            const int ro = pend_y * dstr;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                if constexpr (BPP == 4) {
+                    u32x2 v = { pend[c][0], pend[c][1] };
+                    __builtin_amdgcn_raw_buffer_store_b64(v, rd, doff[c], ro, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(pend[c][0], rd, doff[c], ro, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)pend[c][1], rd, doff[c] + 4, ro, 0);
+                }
+            }
+            pend_y = -1;
+        }
+    };
+
+    const SwsStripRow *rowsL = gl.rows, *rowsC = gc.rows;
+    const int npvL = gl.npv, npvC = gc.npv, sh = p.hshift;
+    const bool swap_rb = BPP == 4 ? p.lut.swap_rb32 != 0 : p.lut.rgb_order != 0;
+    SwsStripRow el = rowsL[y0], ec = rowsC[y0];
+    sp_restart(PL, el.pf);
+    sp_restart(PC, ec.pf);
+    for (int y = y0; y < y1; y++) {
+        const int yn = min(y + 1, H - 1);
+        const SwsStripRow eln = rowsL[yn], ecn = rowsC[yn];     // next row's scalars, one row ahead
+        if (PL.qnext < el.pf) sp_restart(PL, el.pf);            // pairs nobody needs (steep down-scaling with short filters)
+        if (PC.qnext < ec.pf) sp_restart(PC, ec.pf);
+        while (PL.qnext <= el.pf + npvL - 1) sp_step(PL, sh, gl.hfs2, flush);
+        while (PC.qnext <= ec.pf + npvC - 1) sp_step(PC, sh, gc.hfs2, flush);
+        flush();                                                // (a row that needed no new pair still has to release the previous one)
+        int aL[1][4], aC[2][2];
+        sp_vstage(PL, el, npvL, aL);
+        sp_vstage(PC, ec, npvC, aC);
+        // luma across lanes: column 64 c + l (lane l) -> pairs (2j, 2j + 1) for j = l, l + 64
+        int16_t *X = (int16_t *)ldsX;
+#pragma unroll
+        for (int c = 0; c < 4; c++) X[64 * c + lane] = (int16_t)((aL[0][c] + (1 << 18)) >> 19);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint32_t yy = ((const uint32_t *)ldsX)[64 * c + lane];
+            const int Y1 = (int)(int16_t)(yy & 0xFFFFu), Y2 = (int)yy >> 16;
+            const int U = (aC[0][c] + (1 << 18)) >> 19, V = (aC[1][c] + (1 << 18)) >> 19;
+            lut_pair<BPP>(p.lut, T, swap_rb, Y1, Y2, U, V, pend[c]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the exchange row is rewritten by the next output row
+        __builtin_amdgcn_wave_barrier();
+        pend_y = y;
+        el = eln; ec = ecn;
+    }
+    flush();
+}
+
+// RLONG: ring depths for long vertical filters (8 luma / 5 chroma pairs); otherwise 5 / 3 (bicubic down to 2:1, bilinear down to 4:1)
+template <int BPP, bool RLONG, int NPH>      // one kernel per horizontal tap-pair count: each gets the register allocation it needs
+__global__ void __launch_bounds__(256) sws_k_strip_rgb(SwsFrameSet fs, SwsDevParams p, SwsStripGeom gl, SwsStripGeom gc, int wave_lds_dw)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ __attribute__((aligned(16))) u32x2 lds_tab[2][256];
+    build_lut_tabs(p.lut, lds_tab[0], lds_tab[1], (int)threadIdx.x);
+    __syncthreads();
+    const LutTabs T = { (const uint8_t *)lds_tab[0], (const uint8_t *)lds_tab[1] };
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wid = blockIdx.x * 4 + wib;
+    if (wid >= gl.strips * gl.bands) return;
+    const int strip = wid % gl.strips, band = wid / gl.strips;
+    const int y0 = band * gl.band_rows, y1 = min(p.dstH, y0 + gl.band_rows);
+    if (y0 >= y1) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    uint32_t *lds = (uint32_t *)smem + wib * wave_lds_dw;
+    constexpr int RL = RLONG ? 8 : 5, RC = RLONG ? 5 : 3;
+    strip_rgb_body<BPP, NPH, RL, RC>(f, p, gl, gc, strip, y0, y1, lds, T, lane);
+}
+
+} // namespace swsk

@@ -60,6 +60,10 @@ FULL = {
     "c4": ("nv12", "bgr0", 1920, 1080, 1920, 1080, SWS_BICUBIC | BX, None, "main:fused_rgb_unity"),
     "c5": ("gbrpf32le", "yuv444p16le", 3840, 2160, 3840, 2160, SWS_BICUBIC | BX, (SWS_CS_BT2020, 1, SWS_CS_BT2020, 1), "main:fused_f32rgb_yuv444"),
     "c1": ("yuv420p", "yuv420p", 1280, 720, 640, 360, SWS_BILINEAR | BX, None, None),
+    # not BASELINE configurations: the downscale-to-packed-RGB shapes of bench.py's d1 / d2 variants
+    "d1": ("yuv420p", "rgb24", 3840, 2160, 1920, 1080, SWS_BICUBIC | BX, None, "main:strip_rgb"),
+    "d2": ("yuv420p", "bgra", 3840, 2160, 1920, 1080, SWS_BICUBIC | BX, None, "main:strip_rgb"),
+    "d3": ("yuv422p", "argb", 1920, 1080, 2560, 1440, SWS_LANCZOS | BX | AR, None, "main:strip_rgb"),
 }
 
 
@@ -116,6 +120,19 @@ def test_strip_kernel_boundaries(case, dw):
     sw = int(dw * ratio)
     got, _ = run_case(sw, 40, sfmt, dw, 22, dfmt, scaler | BX, seed=dw, tune={"strip_min_w": 0})
     assert got == "main:strip_march"
+
+
+@pytest.mark.parametrize("dw", [254, 256, 258, 510, 512, 514, 1022, 1026, 1918, 2050])
+@pytest.mark.parametrize("case", [("yuv420p", "rgb24", 2, SWS_BICUBIC), ("yuv420p", "bgra", 1.5, SWS_BILINEAR), ("yuv422p", "abgr", 0.75, SWS_LANCZOS),
+                                  ("yuv444p", "bgr24", 3, SWS_BICUBIC), ("yuv420p", "rgb0", 2, SWS_LANCZOS | AR)], ids=lambda c: f"{c[0]}-{c[1]}-x{c[2]}")
+def test_strip_rgb_kernel_boundaries(case, dw):
+    """the strip kernel with the packed-RGB epilogue (256 luma + 128 chroma columns per wave) at widths around its strips, short and
+    long ring forms, bands of different heights"""
+    sfmt, dfmt, ratio, scaler = case
+    sw = int(dw * ratio) & ~1
+    for sh, dh in ((40, 22), (37, 91)):
+        got, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, scaler | BX, seed=dw + dh)
+        assert got == "main:strip_rgb"
 
 
 def test_c4_batch_of_512_frames_through_one_call():
