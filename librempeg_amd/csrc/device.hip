@@ -423,11 +423,14 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 Off oL, oC;
                 if (rgb_ok) {
                     // RGB epilogue: 256 luma columns + the 128 chroma columns under them per wave, one 16-byte chunk per lane and row for
-                    // both (windows of up to 1024 source samples), rings of 5 / 3 row pairs (8 / 5 in the long form)
+                    // both (windows of up to 1024 source samples), rings of 5 / 3 row pairs (8 / 8 in the long form)
                     SOff rL, rC;
                     SwsStripGeom &gl = d->stripRL, &gc = d->stripRC;
-                    if (plan3(c->hLum, c->vLum, p.dstW, 4, 1, gl, rL) && plan3(c->hChr, c->vChr, p.chrDstW, 2, 2, gc, rC) && gl.strips == gc.strips &&
-                        gl.NCmax / 16 <= 64 && gc.NCmax / 16 <= 64 && std::max(gl.nph, gc.nph) <= 8 && gl.npv <= 8 && gc.npv <= 5 && p.chrDstH == p.dstH) {
+                    const bool pl = plan3(c->hLum, c->vLum, p.dstW, 4, 1, gl, rL), pc = pl && plan3(c->hChr, c->vChr, p.chrDstW, 2, 2, gc, rC);
+                    log_msg(c, 3, "strip_rgb plan: luma %d chroma %d strips %d/%d window %d/%d nph %d/%d npv %d/%d chrDstH %d dstH %d\n", pl, pc, gl.strips, gc.strips,
+                            gl.NCmax, gc.NCmax, gl.nph, gc.nph, gl.npv, gc.npv, p.chrDstH, p.dstH);
+                    if (pl && pc && gl.strips == gc.strips &&
+                        gl.NCmax / 16 <= 64 && gc.NCmax / 16 <= 64 && std::max(gl.nph, gc.nph) <= 8 && gl.npv <= 8 && gc.npv <= 8 && p.chrDstH == p.dstH) {
                         const std::vector<int16_t> htl = padded(c->hLum), htc = padded(c->hChr);
                         const size_t ohl = put(htl.data(), htl.size() * 2), ohc = put(htc.data(), htc.size() * 2);
                         if (blob.size() > d->dot2_bytes) {

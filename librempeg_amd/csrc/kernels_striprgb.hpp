@@ -267,7 +267,7 @@ __device__ __forceinline__ void strip_rgb_body(const FrameRegs &f, const SwsDevP
     flush();
 }
 
-// RLONG: ring depths for long vertical filters (8 luma / 5 chroma pairs); otherwise 5 / 3 (bicubic down to 2:1, bilinear down to 4:1)
+// RLONG: ring depths for long vertical filters (8 luma / 8 chroma pairs); otherwise 5 / 3 (bicubic down to 2:1, bilinear down to 4:1)
 template <int BPP, bool RLONG, int NPH>      // one kernel per horizontal tap-pair count: each gets the register allocation it needs
 __global__ void __launch_bounds__(256) sws_k_strip_rgb(SwsFrameSet fs, SwsDevParams p, SwsStripGeom gl, SwsStripGeom gc, int wave_lds_dw)
 {
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) sws_k_strip_rgb(SwsFrameSet fs, SwsDevPar
     if (y0 >= y1) return;
     const FrameRegs f = load_frame(fs, blockIdx.z);
     uint32_t *lds = (uint32_t *)smem + wib * wave_lds_dw;
-    constexpr int RL = RLONG ? 8 : 5, RC = RLONG ? 5 : 3;
+    constexpr int RL = RLONG ? 8 : 5, RC = RLONG ? 8 : 3;
     strip_rgb_body<BPP, NPH, RL, RC>(f, p, gl, gc, strip, y0, y1, lds, T, lane);
 }
 

@@ -124,13 +124,13 @@ def test_strip_kernel_boundaries(case, dw):
 
 @pytest.mark.parametrize("dw", [254, 256, 258, 510, 512, 514, 1022, 1026, 1918, 2050])
 @pytest.mark.parametrize("case", [("yuv420p", "rgb24", 2, SWS_BICUBIC), ("yuv420p", "bgra", 1.5, SWS_BILINEAR), ("yuv422p", "abgr", 0.75, SWS_LANCZOS),
-                                  ("yuv444p", "bgr24", 3, SWS_BICUBIC), ("yuv420p", "rgb0", 2, SWS_LANCZOS | AR)], ids=lambda c: f"{c[0]}-{c[1]}-x{c[2]}")
+                                  ("yuv440p", "bgr24", 1.5, SWS_BICUBIC), ("yuv420p", "rgb0", 2, SWS_LANCZOS | AR)], ids=lambda c: f"{c[0]}-{c[1]}-x{c[2]}")
 def test_strip_rgb_kernel_boundaries(case, dw):
     """the strip kernel with the packed-RGB epilogue (256 luma + 128 chroma columns per wave) at widths around its strips, short and
     long ring forms, bands of different heights"""
     sfmt, dfmt, ratio, scaler = case
     sw = int(dw * ratio) & ~1
-    for sh, dh in ((40, 22), (37, 91)):
+    for sh, dh in ((40, 22), (91, 37)):     # (vertical up-scaling with two taps would select the reference's yuv2packed2 rows: not this kernel)
         got, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, scaler | BX, seed=dw + dh)
         assert got == "main:strip_rgb"
 
