@@ -374,7 +374,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 };
                 // marching strip kernel: strips of 64 * cols output columns; window of a strip <= 128 chunks of 16 bytes
                 struct SOff { size_t cs, cc, rows; };
-                auto plan3 = [&](const FilterBank &hb, const FilterBank &vb, int W, int cols, int ncomp, SwsStripGeom &g, SOff &o) -> bool {
+                // ring_of(npv) != 0: the kernel multiplies a whole ring of that depth per output sample (sws_k_strip_rgb): the row's tap pairs
+                // are laid out against the newest npv slots, the older slots get zero taps
+                auto plan3 = [&](const FilterBank &hb, const FilterBank &vb, int W, int cols, int ncomp, SwsStripGeom &g, SOff &o, int (*ring_of)(int) = nullptr) -> bool {
                     const int TW = 64 * cols, hf2 = fs2(hb.size), vf2 = fs2(vb.size);
                     const int strips = (W + TW - 1) / TW;
                     std::vector<int32_t> cs(strips), cc(strips);
@@ -404,8 +406,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         SwsStripRow &e = rows[(size_t)y];
                         std::memset(&e, 0, sizeof(e));
                         e.pf = (vb.pos[y] & ~1) >> 1;
+                        const int lead = ring_of ? 2 * (ring_of(npv) - npv) : 0;
+                        if (lead < 0) return false;
                         for (int j = 0; j < vb.size; j++) {
-                            const int k = (vb.pos[y] & 1) + j;
+                            const int k = (vb.pos[y] & 1) + j + lead;
                             e.vt[k >> 1] |= (uint32_t)(uint16_t)vb.taps[(size_t)y * vb.size + j] << (16 * (k & 1));
                         }
                     }
@@ -426,7 +430,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     // both (windows of up to 1024 source samples), rings of 5 / 3 row pairs (8 / 8 in the long form)
                     SOff rL, rC;
                     SwsStripGeom &gl = d->stripRL, &gc = d->stripRC;
-                    const bool pl = plan3(c->hLum, c->vLum, p.dstW, 4, 1, gl, rL), pc = pl && plan3(c->hChr, c->vChr, p.chrDstW, 2, 2, gc, rC);
+                    auto ringL = [](int npv) { return npv <= 5 ? 5 : npv <= 8 ? 8 : -1; };
+                    auto ringC = [](int npv) { return npv <= 1 ? 1 : npv <= 3 ? 3 : npv <= 8 ? 8 : -1; };
+                    const int rcl = c->tune.strip_rgb_cols == 2 ? 2 : 4;
+                    const bool pl = plan3(c->hLum, c->vLum, p.dstW, rcl, 1, gl, rL, ringL), pc = pl && plan3(c->hChr, c->vChr, p.chrDstW, rcl / 2, 2, gc, rC, ringC);
                     log_msg(c, 3, "strip_rgb plan: luma %d chroma %d strips %d/%d window %d/%d nph %d/%d npv %d/%d chrDstH %d dstH %d\n", pl, pc, gl.strips, gc.strips,
                             gl.NCmax, gc.NCmax, gl.nph, gc.nph, gl.npv, gc.npv, p.chrDstH, p.dstH);
                     if (pl && pc && gl.strips == gc.strips &&
@@ -445,7 +452,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         gc.colStart = (const int32_t *)(b + rC.cs); gc.colCount = (const int32_t *)(b + rC.cc); gc.rows = (const SwsStripRow *)(b + rC.rows);
                         gl.hT2 = (const int16_t *)(b + ohl); gc.hT2 = (const int16_t *)(b + ohc); gl.vT2 = gc.vT2 = nullptr;
                         gl.nph = gc.nph = std::max(gl.nph, gc.nph);      // one instantiation: the shorter tap rows are zero-extended in the kernel
-                        d->striprgb_long = gl.npv > 5 || gc.npv > 3;
+                        d->striprgb_long = gl.npv > 5;
                         d->striprgb_ok = true;                           // (and every row in the "X" writer mode: checked below)
                     }
                 } else
@@ -1560,7 +1567,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
     SwsInternal *c = internal(sws);
     struct { const char *n; int *v; } tab[] = {
         { "strip_min_w", &c->tune.strip_min_w }, { "strip_cols_l", &c->tune.strip_cols_l }, { "strip_cols_c", &c->tune.strip_cols_c },
-        { "strip_waves", &c->tune.strip_waves }, { "rgb_march_waves", &c->tune.rgb_march_waves }, { "tile_lds_kb", &c->tune.tile_lds_kb },
+        { "strip_waves", &c->tune.strip_waves }, { "strip_rgb_cols", &c->tune.strip_rgb_cols }, { "rgb_march_waves", &c->tune.rgb_march_waves }, { "tile_lds_kb", &c->tune.tile_lds_kb },
         { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
         { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
         { "debug", &c->tune.debug },

@@ -1,13 +1,14 @@
 // Translation unit of the marching strip kernel with the packed-RGB epilogue (scaled planar 8-bit YUV -> rgb24 / bgr24 / rgba / bgra /
-// argb / abgr and their 0-alpha twins).  Compiled once per (bytes per pixel, ring form) part (-DSRGB_BPP=3|4 -DSRGB_LONG=0|1) so that
-// the eight horizontal tap counts of each part build in parallel with the other parts; without the macros it compiles the dispatcher.
+// argb / abgr and their 0-alpha twins).  Compiled once per (bytes per pixel, luma ring depth) part (-DSRGB_BPP=3|4 -DSRGB_RL=5|8) so that
+// the chroma ring depths and horizontal tap counts of each part build in parallel with the other parts; without the macros it compiles the
+// dispatcher.
 #include <algorithm>
 
 #include "devstate.hpp"
 
 namespace swship {
-int launch_striprgb_b3l0(const LaunchCtx &L); int launch_striprgb_b3l1(const LaunchCtx &L);
-int launch_striprgb_b4l0(const LaunchCtx &L); int launch_striprgb_b4l1(const LaunchCtx &L);
+int launch_striprgb_b3l5(const LaunchCtx &L); int launch_striprgb_b3l8(const LaunchCtx &L);
+int launch_striprgb_b4l5(const LaunchCtx &L); int launch_striprgb_b4l8(const LaunchCtx &L);
 }
 
 #ifndef SRGB_BPP
@@ -15,8 +16,8 @@ namespace swship {
 
 int launch_striprgb(const LaunchCtx &L)
 {
-    const bool b4 = L.p->dstKind == DSTK_RGB32, lng = L.d->striprgb_long;
-    return b4 ? (lng ? launch_striprgb_b4l1(L) : launch_striprgb_b4l0(L)) : (lng ? launch_striprgb_b3l1(L) : launch_striprgb_b3l0(L));
+    const bool b4 = L.p->dstKind == DSTK_RGB32, lng = L.d->stripRL.npv > 5;
+    return b4 ? (lng ? launch_striprgb_b4l8(L) : launch_striprgb_b4l5(L)) : (lng ? launch_striprgb_b3l8(L) : launch_striprgb_b3l5(L));
 }
 
 } // namespace swship
@@ -28,7 +29,7 @@ int launch_striprgb(const LaunchCtx &L)
 
 namespace swship {
 
-int SRGB_CAT(launch_striprgb_b, SRGB_BPP, SRGB_LONG)(const LaunchCtx &L)
+int SRGB_CAT(launch_striprgb_b, SRGB_BPP, SRGB_RL)(const LaunchCtx &L)
 {
     SwsInternal *c = L.c; DeviceState *d = L.d; const SwsDevParams &p = *L.p; hipStream_t st = L.st; const SwsFrameSet &fs = L.fs;
     const int n = L.n;
@@ -39,14 +40,18 @@ int SRGB_CAT(launch_striprgb_b, SRGB_BPP, SRGB_LONG)(const LaunchCtx &L)
     gl.band_rows = (H + bands - 1) / bands;
     gl.bands = (H + gl.band_rows - 1) / gl.band_rows;
     gl.debug = gc.debug = c->tune.debug;
-    const int wave_dw = 2 * ((gl.NCmax + 16) >> 1) + 4 * ((gc.NCmax + 16) >> 1) + 128;   // luma rows, chroma rows, exchange row
+    const int cl = gl.TW / 64;
+    const int wave_dw = 2 * ((gl.NCmax + 16) >> 1) + 4 * ((gc.NCmax + 16) >> 1) + 32 * cl;   // luma rows, chroma rows, exchange row
     const dim3 grid(cdiv((int64_t)gl.strips * gl.bands, 4), 1, n), blk(256);
-    switch (gl.nph) {
-#define SWS_SR(N) case N: hipLaunchKernelGGL((swsk::sws_k_strip_rgb<SRGB_BPP, SRGB_LONG != 0, N>), grid, blk, (size_t)4 * wave_dw * 4, st, fs, p, gl, gc, wave_dw); break;
-    SWS_SR(1) SWS_SR(2) SWS_SR(3) SWS_SR(4) SWS_SR(5) SWS_SR(6) SWS_SR(7) SWS_SR(8)
+    const int rc = gc.npv <= 1 ? 1 : gc.npv <= 3 ? 3 : 8;     // chroma ring depth of the instantiation (device.hip laid the taps out for it)
+#define SWS_SR(RC, N) do { if (cl == 4) hipLaunchKernelGGL((swsk::sws_k_strip_rgb<SRGB_BPP, SRGB_RL, RC, N, 4>), grid, blk, (size_t)4 * wave_dw * 4, st, fs, p, gl, gc, wave_dw); \
+                           else hipLaunchKernelGGL((swsk::sws_k_strip_rgb<SRGB_BPP, SRGB_RL, RC, N, 2>), grid, blk, (size_t)4 * wave_dw * 4, st, fs, p, gl, gc, wave_dw); } while (0)
+#define SWS_SRN(RC) switch (gl.nph) { case 1: SWS_SR(RC, 1); break; case 2: SWS_SR(RC, 2); break; case 3: SWS_SR(RC, 3); break; case 4: SWS_SR(RC, 4); break; \
+                                      case 5: SWS_SR(RC, 5); break; case 6: SWS_SR(RC, 6); break; case 7: SWS_SR(RC, 7); break; case 8: SWS_SR(RC, 8); break; \
+                                      default: return SWS_AVERROR(EINVAL); }
+    if (rc == 1) SWS_SRN(1) else if (rc == 3) SWS_SRN(3) else SWS_SRN(8)
+#undef SWS_SRN
 #undef SWS_SR
-    default: return SWS_AVERROR(EINVAL);
-    }
     return 0;
 }
 

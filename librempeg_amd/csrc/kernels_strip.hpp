@@ -29,6 +29,22 @@ namespace swsk {
 
 struct StripLds { uint32_t *S; int row_dw; };
 
+// One plan entry through the scalar data cache (s_load_dwordx*, lgkmcnt).  Written as loads from the constant address space because
+// hipcc turns a plain `rows[y]` inside the march loop into global_load + v_readfirstlane: the kernel stores to global memory, so the
+// loop's loads are not provably unclobbered and lose their scalar form.  A vector load there is poison for the schedule: vmcnt is one
+// in-order counter, so the `s_waitcnt vmcnt(n)` that guards the entry also waits for every source row requested before it -- the
+// prefetch distance collapses to nothing once per output row (measured: C3b 0.289 -> see DESIGN.md 6).
+__device__ __forceinline__ SwsStripRow load_strip_row(const SwsStripRow *rows, int idx)
+{
+    typedef const uint32_t __attribute__((address_space(4))) *cptr;
+    cptr q = (cptr)(uintptr_t)(rows + idx);
+    SwsStripRow e;
+    e.pf = (int)q[0];
+#pragma unroll
+    for (int k = 0; k < 8; k++) e.vt[k] = q[4 + k];
+    return e;
+}
+
 // horizontal stage of one row pair for COLS columns of NCOMP components -> one packed dword per (component, column)
 template <int NP, int NCOMP, int COLS>
 __device__ __forceinline__ void strip_hstage(const StripLds &L, const int (&spd)[COLS], const uint32_t (&ht)[COLS][NP], int sh,
@@ -188,7 +204,7 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
 
     // ---- march ----
     const SwsStripRow *rows = g.rows;
-    SwsStripRow e = rows[y0];                                  // scalar loads: first ring pair and vertical tap pairs of the row
+    SwsStripRow e = load_strip_row(rows, y0);                  // scalar loads: first ring pair and vertical tap pairs of the row
     int qnext = e.pf;                                          // next source-row pair to h-scale == the pair staged in LDS
     prefetch(qnext);
     __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): keep the fill out of the loop's wait arithmetic
@@ -196,7 +212,7 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
     prefetch(qnext + 1);
     const int bits = p.dst_bits;
     for (int y = y0; y < y1; y++) {
-        const SwsStripRow en = rows[min(y + 1, H - 1)];        // next row's scalars, one row ahead
+        const SwsStripRow en = load_strip_row(rows, min(y + 1, H - 1));   // next row's scalars, one row ahead
         const int pfy = e.pf;
         if (qnext < pfy) {                                     // rows nobody needs (steep down-scaling with short filters): skip
             qnext = pfy;
@@ -474,14 +490,14 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
 
     // ---- march ----
     const SwsStripRow *rows = g.rows;
-    SwsStripRow e = rows[y0];
+    SwsStripRow e = load_strip_row(rows, y0);
     int qnext = e.pf;                                          // next source-row pair to h-scale
     int qdma = qnext;                                          // next pair to request
 #pragma unroll
     for (int i = 0; i < D; i++) dma(qdma++);
     const int bits = p.dst_bits;
     for (int y = y0; y < y1; y++) {
-        const SwsStripRow en = rows[min(y + 1, H - 1)];
+        const SwsStripRow en = load_strip_row(rows, min(y + 1, H - 1));
         const int pfy = e.pf;
         while (qnext <= pfy + npv - 1) {
             wait_pair();

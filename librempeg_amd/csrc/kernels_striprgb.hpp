@@ -141,21 +141,18 @@ __device__ __forceinline__ void sp_restart(StripPlane<NCOMP, COLS, NPH, RD> &P, 
     sp_prefetch(P, q + 1);
 }
 
-// vertical stage over the newest npv ring entries (npv <= RD): sums of sample * tap, no rounding constant
+// vertical stage over the whole ring: the host lays the row's tap pairs out against the ring slots (slots older than the row's
+// window carry zero taps), so there is nothing to decide here.  Sums of sample * tap, no rounding constant.
 template <int NCOMP, int COLS, int NPH, int RD>
-__device__ __forceinline__ void sp_vstage(const StripPlane<NCOMP, COLS, NPH, RD> &P, const SwsStripRow &e, int npv, int (&acc)[NCOMP][COLS])
+__device__ __forceinline__ void sp_vstage(const StripPlane<NCOMP, COLS, NPH, RD> &P, const SwsStripRow &e, int (&acc)[NCOMP][COLS])
 {
 #pragma unroll
-    for (int n = 1; n <= RD; n++)
-        if (n == npv) {
+    for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
-            for (int ci = 0; ci < NCOMP; ci++)
+        for (int c = 0; c < COLS; c++) {
+            acc[ci][c] = sdot2_first_s(P.ring[ci][c][0], e.vt[0]);
 #pragma unroll
-                for (int c = 0; c < COLS; c++) {
-                    acc[ci][c] = sdot2_first_s(P.ring[ci][c][RD - n], e.vt[0]);
-#pragma unroll
-                    for (int k = 1; k < n; k++) acc[ci][c] = sdot2(P.ring[ci][c][RD - n + k], e.vt[k], acc[ci][c]);
-                }
+            for (int k = 1; k < RD; k++) acc[ci][c] = sdot2(P.ring[ci][c][k], e.vt[k], acc[ci][c]);
         }
 }
 
@@ -180,13 +177,14 @@ __device__ __forceinline__ void lut_pair(const SwsLutParams &L, const LutTabs &T
     }
 }
 
-template <int BPP, int NPH, int RL, int RC>
+template <int BPP, int NPH, int RL, int RC, int CL>
 __device__ __forceinline__ void strip_rgb_body(const FrameRegs &f, const SwsDevParams &p, const SwsStripGeom &gl, const SwsStripGeom &gc,
                                                int strip, int y0, int y1, uint32_t *lds, const LutTabs &T, int lane)
 {
     const int W = p.dstW, H = p.dstH;
-    StripPlane<1, 4, NPH, RL> PL;
-    StripPlane<2, 2, NPH, RC> PC;
+    constexpr int CC = CL / 2;             // lane l: luma columns l + 64 c (c < CL), chroma columns and pixel pairs l + 64 c (c < CC)
+    StripPlane<1, CL, NPH, RL> PL;
+    StripPlane<2, CC, NPH, RC> PC;
     const int ldw = (gl.NCmax + 16) >> 1, cdw = (gc.NCmax + 16) >> 1;
     uint32_t *ldsL = lds, *ldsC = lds + 2 * ldw, *ldsX = ldsC + 4 * cdw;       // luma rows, chroma rows, 256 x int16 exchange row
     {
@@ -203,19 +201,19 @@ __device__ __forceinline__ void strip_rgb_body(const FrameRegs &f, const SwsDevP
     // destination: whole picture, pair j of the strip at byte (256 * strip + 2 * j) * BPP of a row
     const sws_rsrc_t rd = make_rsrc(f.dst[0], (uint32_t)f.dstStride[0] * (uint32_t)(H - 1) + (uint32_t)W * (uint32_t)BPP);
     const int dstr = f.dstStride[0];
-    int doff[2];
+    int doff[CC];
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const int x = strip * 256 + 2 * (64 * c + lane);
+    for (int c = 0; c < CC; c++) {
+        const int x = strip * (64 * CL) + 2 * (64 * c + lane);
         doff[c] = x < W ? x * BPP : 0x7fffffff;
     }
-    uint32_t pend[2][2];
+    uint32_t pend[CC][2];
     int pend_y = -1;
     auto flush = [&]() {
         if (pend_y >= 0) {
             const int ro = pend_y * dstr;
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
+            for (int c = 0; c < CC; c++) {
                 if constexpr (BPP == 4) {
                     u32x2 v = { pend[c][0], pend[c][1] };
                     __builtin_amdgcn_raw_buffer_store_b64(v, rd, doff[c], ro, 0);
@@ -231,29 +229,29 @@ __device__ __forceinline__ void strip_rgb_body(const FrameRegs &f, const SwsDevP
     const SwsStripRow *rowsL = gl.rows, *rowsC = gc.rows;
     const int npvL = gl.npv, npvC = gc.npv, sh = p.hshift;
     const bool swap_rb = BPP == 4 ? p.lut.swap_rb32 != 0 : p.lut.rgb_order != 0;
-    SwsStripRow el = rowsL[y0], ec = rowsC[y0];
+    SwsStripRow el = load_strip_row(rowsL, y0), ec = load_strip_row(rowsC, y0);
     sp_restart(PL, el.pf);
     sp_restart(PC, ec.pf);
     for (int y = y0; y < y1; y++) {
         const int yn = min(y + 1, H - 1);
-        const SwsStripRow eln = rowsL[yn], ecn = rowsC[yn];     // next row's scalars, one row ahead
+        const SwsStripRow eln = load_strip_row(rowsL, yn), ecn = load_strip_row(rowsC, yn);     // next row's scalars, one row ahead
         if (PL.qnext < el.pf) sp_restart(PL, el.pf);            // pairs nobody needs (steep down-scaling with short filters)
         if (PC.qnext < ec.pf) sp_restart(PC, ec.pf);
         while (PL.qnext <= el.pf + npvL - 1) sp_step(PL, sh, gl.hfs2, flush);
         while (PC.qnext <= ec.pf + npvC - 1) sp_step(PC, sh, gc.hfs2, flush);
         flush();                                                // (a row that needed no new pair still has to release the previous one)
-        int aL[1][4], aC[2][2];
-        sp_vstage(PL, el, npvL, aL);
-        sp_vstage(PC, ec, npvC, aC);
+        int aL[1][CL], aC[2][CC];
+        sp_vstage(PL, el, aL);
+        sp_vstage(PC, ec, aC);
         // luma across lanes: column 64 c + l (lane l) -> pairs (2j, 2j + 1) for j = l, l + 64
         int16_t *X = (int16_t *)ldsX;
 #pragma unroll
-        for (int c = 0; c < 4; c++) X[64 * c + lane] = (int16_t)((aL[0][c] + (1 << 18)) >> 19);
+        for (int c = 0; c < CL; c++) X[64 * c + lane] = (int16_t)((aL[0][c] + (1 << 18)) >> 19);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
+        for (int c = 0; c < CC; c++) {
             const uint32_t yy = ((const uint32_t *)ldsX)[64 * c + lane];
             const int Y1 = (int)(int16_t)(yy & 0xFFFFu), Y2 = (int)yy >> 16;
             const int U = (aC[0][c] + (1 << 18)) >> 19, V = (aC[1][c] + (1 << 18)) >> 19;
@@ -267,9 +265,12 @@ __device__ __forceinline__ void strip_rgb_body(const FrameRegs &f, const SwsDevP
     flush();
 }
 
-// RLONG: ring depths for long vertical filters (8 luma / 8 chroma pairs); otherwise 5 / 3 (bicubic down to 2:1, bilinear down to 4:1)
-template <int BPP, bool RLONG, int NPH>      // one kernel per horizontal tap-pair count: each gets the register allocation it needs
-__global__ void __launch_bounds__(256) sws_k_strip_rgb(SwsFrameSet fs, SwsDevParams p, SwsStripGeom gl, SwsStripGeom gc, int wave_lds_dw)
+// RL / RC: ring depths (row pairs) of the luma / chroma plane = the vertical tap pairs the kernel multiplies per output sample
+#ifndef SWS_SRGB_ATTR
+#define SWS_SRGB_ATTR
+#endif
+template <int BPP, int RL, int RC, int NPH, int CL>      // one kernel per ring form and horizontal tap-pair count: each gets the register allocation it needs
+__global__ void __launch_bounds__(256) SWS_SRGB_ATTR sws_k_strip_rgb(SwsFrameSet fs, SwsDevParams p, SwsStripGeom gl, SwsStripGeom gc, int wave_lds_dw)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ __attribute__((aligned(16))) u32x2 lds_tab[2][256];
@@ -285,8 +286,7 @@ __global__ void __launch_bounds__(256) sws_k_strip_rgb(SwsFrameSet fs, SwsDevPar
     if (y0 >= y1) return;
     const FrameRegs f = load_frame(fs, blockIdx.z);
     uint32_t *lds = (uint32_t *)smem + wib * wave_lds_dw;
-    constexpr int RL = RLONG ? 8 : 5, RC = RLONG ? 8 : 3;
-    strip_rgb_body<BPP, NPH, RL, RC>(f, p, gl, gc, strip, y0, y1, lds, T, lane);
+    strip_rgb_body<BPP, NPH, RL, RC, CL>(f, p, gl, gc, strip, y0, y1, lds, T, lane);
 }
 
 } // namespace swsk
