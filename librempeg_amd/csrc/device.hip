@@ -729,14 +729,31 @@ static int ptr_device(const void *p)
 }
 static bool is_device_ptr(const void *p) { return ptr_device(p) >= 0; }
 
+// SWS_HIP_DEBUG & 16: every working buffer the library allocates (scratch planes, staging copies, byte-swapped / XYZ copies, slice
+// assembly) starts out filled with 0xCD instead of whatever the allocator hands back.  A kernel that reads working memory nobody
+// wrote in the same call then fails its parity test every time instead of once in 310 000 runs (the audit behind the
+// one unreproduced failure of round 1).
+static bool poison_enabled()
+{
+    static const bool on = std::getenv("SWS_HIP_DEBUG") && (std::atoi(std::getenv("SWS_HIP_DEBUG")) & 16);
+    return on;
+}
+static int poison(SwsInternal *c, void *buf, size_t bytes)
+{
+    if (!poison_enabled() || !buf || !bytes) return 0;
+    HIPCHK(hipMemset(buf, 0xCD, bytes));
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
 int grow(SwsInternal *c, void **buf, size_t *cap, size_t need)
 {
     if (need <= *cap) return 0;
-    if (*buf) HIPCHK(hipFree(*buf));
+    if (*buf) HIPCHK(hipFree(*buf));   // (hipFree waits for the device: nothing in flight can still be using the old block)
     *buf = nullptr; *cap = 0;
     HIPCHK(hipMalloc(buf, need));
     *cap = need;
-    return 0;
+    return poison(c, *buf, need);
 }
 
 static bool frames_vec_ok(const SwsFramePtrs *fr, int n)
@@ -877,6 +894,7 @@ static int launch_plan_xyz(SwsInternal *c, DeviceState *d, const SwsFramePtrs *f
             if (d->d_xyz) HIPCHK(hipFree(d->d_xyz));
             d->d_xyz = nullptr;
             HIPCHK(hipMalloc(&d->d_xyz, (size_t)n * total));
+            { int pr = poison(c, d->d_xyz, (size_t)n * total); if (pr < 0) return pr; }
             d->xyz_bytes = (size_t)n * total;
         }
         for (int i = 0; i < n; i++) {
@@ -918,6 +936,7 @@ static int launch_plan(SwsInternal *c, DeviceState *d, const SwsFramePtrs *frame
             if (d->d_be) HIPCHK(hipFree(d->d_be));
             d->d_be = nullptr;
             HIPCHK(hipMalloc(&d->d_be, (size_t)n * total));
+            { int pr = poison(c, d->d_be, (size_t)n * total); if (pr < 0) return pr; }
             d->be_bytes = (size_t)n * total;
         }
         for (int i = 0; i < n; i++)
@@ -1297,6 +1316,7 @@ static int scale_slice(SwsInternal *c, const uint8_t *const src[], const int src
         if (d->slice_img) HIPCHK(hipFree(d->slice_img));
         d->slice_img = nullptr; d->slice_bytes = 0;
         HIPCHK(hipMalloc(&d->slice_img, total));
+        { int pr = poison(c, d->slice_img, total); if (pr < 0) return pr; }
         d->slice_bytes = total;
     }
     const int nps = pix_nb_planes(pix_desc(o.src_format));

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic per launch of each workload's dominant kernel: separate --pmc passes for FETCH_SIZE and WRITE_SIZE
 # (MI355X_MICROARCH.md: FETCH_SIZE is doubled on gfx950, both are KiB).  usage: tools/pmc_traffic.sh <tag> "<workloads>"
-TAG=$1; WLS=${2:-"c2a c2b c4 c3a c3b c5 c1"}
+TAG=$1; WLS=${2:-"c2a c2b c4 c3a c3b c5 c1 d1 d2"}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$PWD
