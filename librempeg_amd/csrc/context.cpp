@@ -291,10 +291,9 @@ int init_single_context(SwsInternal *c)
     }
     if (isAnyRGB(dstFormat) && !(flags & SWS_FULL_CHR_H_INT)) c->chrDstHSubSample = 1;         // :1359-1360
 
-    if (flags & SWS_SRC_V_CHR_DROP_MASK) {
-        log_msg(c, 0, "SWS_SRC_V_CHR_DROP is not implemented on the HIP path\n");
-        return SWS_AVERROR(ENOTSUP);
-    }
+    // "drop some chroma lines if the user wants it" (:1362-1365): the scaler sees a chroma plane of every 2^vChrDrop-th row
+    // (device.hip multiplies the chroma strides, like ff_swscale does at swscale.c:333-334)
+    c->chrSrcVSubSample += (flags & SWS_SRC_V_CHR_DROP_MASK) >> SWS_SRC_V_CHR_DROP_SHIFT;
     // RGB sources: chroma is taken from horizontally averaged pixel pairs unless full chroma input
     // is requested (:1369-1390; planar float/high-depth RGB are exempt)
     if (isAnyRGB(srcFormat) && !(srcW & 1) && !(flags & SWS_FULL_CHR_H_INP) && !(isPlanarRGB(srcFormat) && ds->comp[0].depth > 8) &&

@@ -771,6 +771,16 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
 {
     const SwsDevParams &p = d->params;
     hipStream_t st = d->stream;
+    // SWS_SRC_V_CHR_DROP (swscale.c:333-334): "srcStride2[1] *= 1 << c->vChrDrop; srcStride2[2] *= 1 << c->vChrDrop" -- the scaler (not the
+    // special converters) reads every 2^vChrDrop-th row of the chroma planes; packed sources reach the same rows through
+    // `row << chrSrcVSub` in their readers
+    std::vector<SwsFramePtrs> dropped;
+    const int drop = (c->opts.flags & SWS_SRC_V_CHR_DROP_MASK) >> SWS_SRC_V_CHR_DROP_SHIFT;
+    if (drop && c->plan == PLAN_MAIN) {
+        dropped.assign(frames, frames + n);
+        for (auto &f : dropped) { f.srcStride[1] *= 1 << drop; f.srcStride[2] *= 1 << drop; }
+        frames = dropped.data();
+    }
     LaunchCtx L;
     std::memset(&L.fs, 0, sizeof(L.fs));
     SwsFrameSet &fs = L.fs;

@@ -17,8 +17,15 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
 {
     if (comp == 3 && p.srcKind == SRCK_RGB48)   // rgba64leToA_c: the 16-bit A word as is
         return ((const uint16_t *)(f.src[0] + (int64_t)row * f.srcStride[0]))[4 * x + 3];
+    // single-plane sources: chroma row r of the scaler is picture row r << chrSrcVSub (non-zero only with SWS_SRC_V_CHR_DROP: ff_swscale
+    // multiplies the chroma strides, which for a packed source are the strides of plane 0, swscale.c:318-334)
+    const int prow = (comp == 1 || comp == 2) ? (row << p.chrSrcVSub) : row;
+    // planar RGB sources: every line needs all three planes.  The reference's slices index planes 1 and 2 by chroma row and planes 0 and 3
+    // by luma row whatever the line is for (slice.c ff_init_slice_from_src, hscale.c:lum_convert / chr_convert): a luma line y reads B and R
+    // at chroma row y >> chrSrcVSub, a chroma line reads G at luma row y << chrSrcVSub (both the same row unless SWS_SRC_V_CHR_DROP is set)
+    const int grow = prow, brow = (comp == 1 || comp == 2) ? row : (row >> p.chrSrcVSub);
     if (p.srcKind == SRCK_PACKEDHI) {   // the descriptor's field of component comp
-        const uint8_t *s = f.src[0] + (int64_t)row * f.srcStride[0] + p.shi_step[comp] * x + p.shi_off[comp];
+        const uint8_t *s = f.src[0] + (int64_t)prow * f.srcStride[0] + p.shi_step[comp] * x + p.shi_off[comp];
         return (*(const uint16_t *)s >> p.shi_shift[comp]) & p.shi_mask[comp];
     }
     if (p.srcKind == SRCK_YA) {   // ya8: yuy2ToY_c / uyvyToY_c on the two bytes; ya16le: read_ya16le_gray_c / _alpha_c (comp 0 = gray, 3 = alpha)
@@ -140,8 +147,8 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         return (uint16_t)((unsigned)(cr * r + cg * g + cb * b + rnd) >> (S - 6));
     }
     case SRCK_GBRP: { // planar_rgb_to_y / planar_rgb_to_uv input.c:1174-1211; gbr24pToUV_half_c :414-432
-        const uint8_t *G = f.src[0] + (int64_t)row * f.srcStride[0], *B = f.src[1] + (int64_t)row * f.srcStride[1],
-                      *R = f.src[2] + (int64_t)row * f.srcStride[2];
+        const uint8_t *G = f.src[0] + (int64_t)grow * f.srcStride[0], *B = f.src[1] + (int64_t)brow * f.srcStride[1],
+                      *R = f.src[2] + (int64_t)brow * f.srcStride[2];
         const int32_t *t = p.rgb2yuv;
         if (comp == 0)
             return (uint16_t)((int)((unsigned)t[0] * R[x] + (unsigned)t[1] * G[x] + (unsigned)t[2] * B[x] + (0x801 << 8)) >> 9);
@@ -166,18 +173,18 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         return (uint16_t)(((unsigned)t[o] * r + (unsigned)t[o + 1] * g + (unsigned)t[o + 2] * b + ((comp == 0 ? 0x2001u : 0x10001u) << 14)) >> 15);
     }
     case SRCK_PACKED444: {
-        const uint8_t *s = f.src[0] + (int64_t)row * f.srcStride[0] + p.s444_step * x;
+        const uint8_t *s = f.src[0] + (int64_t)prow * f.srcStride[0] + p.s444_step * x;
         return s[comp == 0 ? p.s444_y : comp == 1 ? p.s444_u : p.s444_v];
     }
     case SRCK_PACKED422: { // yuy2ToY_c / yuy2ToUV_c / yvy2ToUV_c (input.c:550-578), uyvyToY_c / uyvyToUV_c (:890-907)
-        const uint8_t *s = f.src[0] + (int64_t)row * f.srcStride[0];
+        const uint8_t *s = f.src[0] + (int64_t)prow * f.srcStride[0];
         return comp == 0 ? s[2 * x + p.s422_y] : s[4 * x + (comp == 1 ? p.s422_u : p.s422_v)];
     }
     case SRCK_GBRP16: { // planar_rgb16_s16_to_y / _to_uv, input.c:1216-1270
         // (gbrp10msb / gbrp12msb: planar_rgb16_s10 / s12 shift the samples down first, input.c:1462-1474)
-        const int g = *(const uint16_t *)(f.src[0] + (int64_t)row * f.srcStride[0] + 2 * x) >> p.src_shift;
-        const int b = *(const uint16_t *)(f.src[1] + (int64_t)row * f.srcStride[1] + 2 * x) >> p.src_shift;
-        const int r = *(const uint16_t *)(f.src[2] + (int64_t)row * f.srcStride[2] + 2 * x) >> p.src_shift;
+        const int g = *(const uint16_t *)(f.src[0] + (int64_t)grow * f.srcStride[0] + 2 * x) >> p.src_shift;
+        const int b = *(const uint16_t *)(f.src[1] + (int64_t)brow * f.srcStride[1] + 2 * x) >> p.src_shift;
+        const int r = *(const uint16_t *)(f.src[2] + (int64_t)brow * f.srcStride[2] + 2 * x) >> p.src_shift;
         const int32_t *t = p.rgb2yuv;
         const int bpc = p.src_depth, shift = bpc < 16 ? bpc : 14;
         const int o = comp == 0 ? 0 : comp == 1 ? 3 : 6;
@@ -185,9 +192,9 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         return (uint16_t)((int)((unsigned)t[o] * r + (unsigned)t[o + 1] * g + (unsigned)t[o + 2] * b + bias) >> (shift + 1));
     }
     case SRCK_GBRPF32: { // planar_rgbf32_to_y / _to_uv, input.c:1300-1334
-        const int g = f32_to_u16(*(const float *)(f.src[0] + (int64_t)row * f.srcStride[0] + 4 * x));
-        const int b = f32_to_u16(*(const float *)(f.src[1] + (int64_t)row * f.srcStride[1] + 4 * x));
-        const int r = f32_to_u16(*(const float *)(f.src[2] + (int64_t)row * f.srcStride[2] + 4 * x));
+        const int g = f32_to_u16(*(const float *)(f.src[0] + (int64_t)grow * f.srcStride[0] + 4 * x));
+        const int b = f32_to_u16(*(const float *)(f.src[1] + (int64_t)brow * f.srcStride[1] + 4 * x));
+        const int r = f32_to_u16(*(const float *)(f.src[2] + (int64_t)brow * f.srcStride[2] + 4 * x));
         const int32_t *t = p.rgb2yuv;
         if (comp == 0)
             return (uint16_t)((int)((unsigned)t[0] * r + (unsigned)t[1] * g + (unsigned)t[2] * b + (0x2001u << 14)) >> 15);

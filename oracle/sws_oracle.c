@@ -1084,7 +1084,7 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
     }
     if (isAnyRGB(dstFormat) && !(flags & OR_SWS_FULL_CHR_H_INT)) c->chrDstHSub = 1; /* :1359 */
 
-    if (flags & 0x30000) return -1; /* vChrDrop not restated */
+    c->chrSrcVSub += (flags & 0x30000) >> 16; /* vChrDrop: "drop some chroma lines if the user wants it" (utils.c:1362-1365) */
 
     if (isAnyRGB(srcFormat) && !(srcW & 1) && !(flags & OR_SWS_FULL_CHR_H_INP) &&
         !(isPlanarRGB(srcFormat) && ds->c[0].depth > 8) && /* gbrp9..16, gbrpf32: no _half readers (:1369-1388) */
@@ -1963,6 +1963,9 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
 {
     const int f = c->o.src_format, w = c->o.src_w;
     const int32_t *t = c->rgb2yuv;
+    /* planar RGB: planes 1 and 2 of a slice are indexed by chroma row, also when a luma line is made (slice.c ff_init_slice_from_src,
+     * hscale.c lum_convert): the same row unless SWS_SRC_V_CHR_DROP gave the RGB source a vertical chroma sub-sampling */
+    const ptrdiff_t yc = y >> c->chrSrcVSub;
     int i;
     if (isSemiPlanarYUV(f) && desc_get(f)->c[0].depth > 8) { /* p010/p012 LEToY_c input.c:979-1007; p016 reads the plane directly */
         const int sh = desc_get(f)->c[0].shift;
@@ -2059,15 +2062,15 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
         }
         return tmp; }
     case ORF_GBRP: { /* planar_rgb_to_y input.c:1174-1186 */
-        const uint8_t *G = src[0] + y * stride[0], *B = src[1] + y * stride[1], *R = src[2] + y * stride[2];
+        const uint8_t *G = src[0] + y * stride[0], *B = src[1] + yc * stride[1], *R = src[2] + yc * stride[2];
         uint16_t *d = (uint16_t *)tmp;
         for (i = 0; i < w; i++)
             d[i] = (uint16_t)((int)((unsigned)t[RY] * R[i] + (unsigned)t[GY] * G[i] + (unsigned)t[BY] * B[i] + (0x801 << (15 - 7))) >> (15 - 6));
         return tmp; }
     case ORF_GBRP10MSBLE: case ORF_GBRP12MSBLE:   /* planar_rgb16_s10 / s12_to_y: samples >> (16 - bits) (input.c:1216-1232, :1462-1474) */
     case ORF_GBRP9LE: case ORF_GBRP10LE: case ORF_GBRP12LE: case ORF_GBRP14LE: case ORF_GBRP16LE: { /* planar_rgb16_s16_to_y input.c:1216-1232 */
-        const uint16_t *G = (const uint16_t *)(src[0] + y * stride[0]), *B = (const uint16_t *)(src[1] + y * stride[1]),
-                       *R = (const uint16_t *)(src[2] + y * stride[2]);
+        const uint16_t *G = (const uint16_t *)(src[0] + y * stride[0]), *B = (const uint16_t *)(src[1] + yc * stride[1]),
+                       *R = (const uint16_t *)(src[2] + yc * stride[2]);
         const int bpc = desc_get(f)->c[0].depth, shift = bpc < 16 ? bpc : 14, ms = desc_get(f)->c[0].shift;
         uint16_t *d = (uint16_t *)tmp;
         for (i = 0; i < w; i++)
@@ -2087,8 +2090,8 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
         for (i = 0; i < w; i++) d[i] = (uint16_t)f2u16(s[i]);
         return tmp; }
     case ORF_GBRPF32LE: { /* planar_rgbf32_to_y input.c:1319-1334 */
-        const float *G = (const float *)(src[0] + y * stride[0]), *B = (const float *)(src[1] + y * stride[1]),
-                    *R = (const float *)(src[2] + y * stride[2]);
+        const float *G = (const float *)(src[0] + y * stride[0]), *B = (const float *)(src[1] + yc * stride[1]),
+                    *R = (const float *)(src[2] + yc * stride[2]);
         uint16_t *d = (uint16_t *)tmp;
         for (i = 0; i < w; i++) {
             int g = f2u16(G[i]), b = f2u16(B[i]), r = f2u16(R[i]);
@@ -2112,6 +2115,7 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
 {
     const int f = c->o.src_format, w = c->chrSrcW;
     const int32_t *t = c->rgb2yuv;
+    const ptrdiff_t yl = (ptrdiff_t)y << c->chrSrcVSub;   /* planar RGB: plane 0 is indexed by luma row (hscale.c chr_convert) */
     int i;
     *pu = tu; *pv = tv;
     if (isRGB30(f)) { /* rgb16_32ToUV_c_template / rgb16_32ToUV_half_c_template input.c:295-372 with the rows of :411-412 */
@@ -2198,7 +2202,7 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
     }
     if (isPackedHi(f)) { /* y2xxle_UV_c, read_ayuv64le/xv48le_UV_c, read_xv30le/v30xle/xv36le_UV_c */
         const Desc *ds = desc_get(f);
-        const uint8_t *s = src[0] + y * stride[0];
+        const uint8_t *s = src[0] + (ptrdiff_t)(y << c->chrSrcVSub) * stride[0];   /* (non-zero only with SWS_SRC_V_CHR_DROP) */
         uint16_t *a = (uint16_t *)tu, *b = (uint16_t *)tv;
         for (i = 0; i < w; i++) {
             uint16_t u, v;
@@ -2209,7 +2213,7 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
     }
     if (isPacked444(f)) { /* read_vuyx_UV_c / read_ayuv_UV_c / read_uyva_UV_c / vyuToUV_c input.c:731-809 */
         const Desc *ds = desc_get(f);
-        const uint8_t *s = src[0] + y * stride[0];
+        const uint8_t *s = src[0] + (ptrdiff_t)(y << c->chrSrcVSub) * stride[0];
         for (i = 0; i < w; i++) { tu[i] = s[ds->c[0].step * i + ds->c[1].offset]; tv[i] = s[ds->c[0].step * i + ds->c[2].offset]; }
         return;
     }
@@ -2282,7 +2286,7 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
         }
         return; }
     case ORF_GBRP: {
-        const uint8_t *G = src[0] + y * stride[0], *B = src[1] + y * stride[1], *R = src[2] + y * stride[2];
+        const uint8_t *G = src[0] + yl * stride[0], *B = src[1] + y * stride[1], *R = src[2] + y * stride[2];
         uint16_t *du = (uint16_t *)tu, *dv = (uint16_t *)tv;
         if (c->chrSrcHSub) { /* gbr24pToUV_half_c input.c:412-432 */
             for (i = 0; i < w; i++) {
@@ -2300,7 +2304,7 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
         return; }
     case ORF_GBRP10MSBLE: case ORF_GBRP12MSBLE:
     case ORF_GBRP9LE: case ORF_GBRP10LE: case ORF_GBRP12LE: case ORF_GBRP14LE: case ORF_GBRP16LE: { /* planar_rgb16_s16_to_uv input.c:1248-1270 */
-        const uint16_t *G = (const uint16_t *)(src[0] + y * stride[0]), *B = (const uint16_t *)(src[1] + y * stride[1]),
+        const uint16_t *G = (const uint16_t *)(src[0] + yl * stride[0]), *B = (const uint16_t *)(src[1] + y * stride[1]),
                        *R = (const uint16_t *)(src[2] + y * stride[2]);
         const int bpc = desc_get(f)->c[0].depth, shift = bpc < 16 ? bpc : 14, ms = desc_get(f)->c[0].shift;
         uint16_t *du = (uint16_t *)tu, *dv = (uint16_t *)tv;
@@ -2312,7 +2316,7 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
         }
         return; }
     case ORF_GBRPF32LE: { /* planar_rgbf32_to_uv input.c:1300-1317 */
-        const float *G = (const float *)(src[0] + y * stride[0]), *B = (const float *)(src[1] + y * stride[1]),
+        const float *G = (const float *)(src[0] + yl * stride[0]), *B = (const float *)(src[1] + y * stride[1]),
                     *R = (const float *)(src[2] + y * stride[2]);
         uint16_t *du = (uint16_t *)tu, *dv = (uint16_t *)tv;
         for (i = 0; i < w; i++) {
@@ -3505,7 +3509,12 @@ static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4
     case UNSC_PACKED16_TO_GBRP16: return unscaled_packed16_gbrp16(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_GBRP16_TO_PACKED16: return unscaled_gbrp16_packed16(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     }
-    return main_path(c, src, srcStride, dst, dstStride);
+    {   /* ff_swscale (swscale.c:333-334): "srcStride2[1] *= 1 << c->vChrDrop; srcStride2[2] *= 1 << c->vChrDrop;" -- the chroma planes are read
+         * every 2^vChrDrop-th row (packed sources reach the same rows through `y << chrSrcVSub` in their readers) */
+        const int drop = (c->o.flags & 0x30000) >> 16;
+        int ss[4] = { srcStride[0], srcStride[1] << drop, srcStride[2] << drop, srcStride[3] };
+        return main_path(c, src, ss, dst, dstStride);
+    }
 }
 
 /* ------------------------------------------------------------------ */
