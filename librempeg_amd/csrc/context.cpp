@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <new>
 
@@ -225,6 +226,10 @@ void choose_unscaled(SwsInternal *c)
 }
 
 // ff_sws_init_single_context, utils.c:1137-1835
+static void destroy(SwsInternal *c);
+static SwsInternal *alloc_set_opts(int srcW, int srcH, int srcFormat, int dstW, int dstH, int dstFormat, unsigned flags, const double *param);
+static int init_context_impl(SwsInternal *c, SwsFilter *srcFilter, SwsFilter *dstFilter);
+
 int init_single_context(SwsInternal *c)
 {
     SwsContext *o = &c->opts;
@@ -362,8 +367,40 @@ int init_single_context(SwsInternal *c)
         ret = build_filter_bank(c->vChr, c->chrYInc, c->chrSrcH, c->chrDstH, 1, 1 << 12, chr_scaler, flags, o->scaler_params,
                                 local_pos(c->chrSrcVSubSample, o->src_v_chr_pos), local_pos(c->chrDstVSubSample, o->dst_v_chr_pos), fvec(3));
     if (ret == FILTER_USE_CASCADE) {
-        log_msg(c, 0, "extreme scaling ratio needs the two-step cascade (utils.c:1803-1833): not implemented on the HIP path\n");
-        return SWS_AVERROR(ENOTSUP);
+        // A filter of 256 taps or more (down-scaling by 64 with bicubic, 43 with Lanczos, ...): two steps through a yuv420p / yuva420p
+        // picture of the geometric-mean size (utils.c:1803-1833).  The children are plain sws_getContext() contexts: flags and scaler
+        // parameters travel, ranges / dither / chroma positions are the defaults, the source filter goes to the first step and the
+        // destination filter to the second.
+        const int tmpW = (int)std::sqrt((double)(srcW * (int64_t)dstW)), tmpH = (int)std::sqrt((double)(srcH * (int64_t)dstH));
+        const int tmpFormat = isALPHA(srcFormat) ? AV_PIX_FMT_YUVA420P : AV_PIX_FMT_YUV420P;
+        if (srcW * (int64_t)srcH <= 4LL * dstW * dstH) return SWS_AVERROR(EINVAL);
+        if (c->srcXYZ || c->dstXYZ) {   // (the reference runs such a cascade without its XYZ passes, swscale.c:1084-1090 before :1106: not reproduced)
+            log_msg(c, 0, "extreme scaling ratio with an XYZ picture is not implemented on the HIP path\n");
+            return SWS_AVERROR(ENOTSUP);
+        }
+        log_msg(c, 2, "extreme scaling ratio: cascading through %dx%d %s\n", tmpW, tmpH, pix_desc(tmpFormat)->name);
+        auto fail = [&](int err) { destroy(c->cascade[0]); destroy(c->cascade[1]); c->cascade[0] = c->cascade[1] = nullptr; return err; };
+        c->cascade_fmt = tmpFormat; c->cascade_w = tmpW; c->cascade_h = tmpH;
+        SwsFilter sf, df;
+        SwsVector sv[4], dv[4];
+        for (int k = 0; k < 4; k++) {
+            sv[k].coeff = c->srcVec[k].empty() ? nullptr : c->srcVec[k].data(); sv[k].length = (int)c->srcVec[k].size();
+            dv[k].coeff = nullptr; dv[k].length = c->dstVecLen[k];
+        }
+        sf.lumH = sv[0].length ? &sv[0] : nullptr; sf.lumV = sv[1].length ? &sv[1] : nullptr; sf.chrH = sv[2].length ? &sv[2] : nullptr; sf.chrV = sv[3].length ? &sv[3] : nullptr;
+        df.lumH = dv[0].length ? &dv[0] : nullptr; df.lumV = dv[1].length ? &dv[1] : nullptr; df.chrH = dv[2].length ? &dv[2] : nullptr; df.chrV = dv[3].length ? &dv[3] : nullptr;
+        c->cascade[0] = alloc_set_opts(srcW, srcH, srcFormat, tmpW, tmpH, tmpFormat, flags, o->scaler_params);
+        if (!c->cascade[0]) return SWS_AVERROR(ENOMEM);
+        c->cascade[0]->srcBE = c->srcBE;     // the stored formats are the little-endian twins: the byte order travels with the flags
+        c->cascade[0]->tune = c->tune;
+        if (init_context_impl(c->cascade[0], &sf, nullptr) < 0) return fail(SWS_AVERROR(ENOMEM));
+        c->cascade[1] = alloc_set_opts(tmpW, tmpH, tmpFormat, dstW, dstH, dstFormat, flags, o->scaler_params);
+        if (!c->cascade[1]) return fail(SWS_AVERROR(ENOMEM));
+        c->cascade[1]->dstBE = c->dstBE;
+        c->cascade[1]->tune = c->tune;
+        if (init_context_impl(c->cascade[1], nullptr, &df) < 0) return fail(SWS_AVERROR(ENOMEM));
+        c->plan = PLAN_CASCADE;
+        return 0;
     }
     if (ret != FILTER_OK) return SWS_AVERROR(EINVAL);
 
@@ -633,6 +670,7 @@ const char *sws_hip_path_name(const SwsContext *sws)
     if (!sws) return "";
     const SwsInternal *c = internal(sws);
     if (!c->legacy_init && c->graph[0].valid && c->graph[0].noop) return "noop:copy";
+    if (introspected(sws)->plan == PLAN_CASCADE) return "cascade";   // (known from the host-side init alone)
     return introspected(sws)->path_name.c_str();
 }
 const char *sws_hip_kernel_name(const SwsContext *sws) { return sws ? introspected(sws)->kernel_name.c_str() : ""; }

@@ -1137,8 +1137,9 @@ static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4
         // av_image_alloc() leaves the intermediate picture uninitialised and the pair-wise yuv2rgb converters never write the last
         // pixel of an odd width: start from zeros (as the oracle does) so that the result does not depend on stale memory
         if (d->casc_bytes != had) { HIPCHK(hipMemsetAsync(d->casc_img, 0, d->casc_bytes, d->stream)); }
-        uint8_t *tmp[4] = { (uint8_t *)d->casc_img, nullptr, nullptr, nullptr };
-        int tls[4] = { ls[0], 0, 0, 0 };
+        uint8_t *tmp[4] = { nullptr, nullptr, nullptr, nullptr };   // bgr24 / bgra / bgr48 / bgra64 (matrix cascade) or yuv420p / yuva420p (extreme ratios)
+        int tls[4] = { 0, 0, 0, 0 };
+        for (int k = 0; k < pix_nb_planes(pix_desc(c->cascade_fmt)); k++) { tmp[k] = (uint8_t *)d->casc_img + offs[k]; tls[k] = ls[k]; }
         r = run_single(c0, cd[0], src, srcStride, sliceY, sliceH, tmp, tls);
         if (r < 0) return r;
         return run_single(c1, cd[1], tmp, tls, 0, c0->opts.dst_h, dst, dstStride);

@@ -933,7 +933,7 @@ void or_sws_free(OrSws *c)
     free(c->hLumFilterPos); free(c->hChrFilterPos); free(c->vLumFilterPos); free(c->vChrFilterPos);
     free(c->yuvTable);
     or_sws_free(c->cascade[0]); or_sws_free(c->cascade[1]);
-    free(c->casc_tmp[0]);
+    free(c->casc_tmp[0]); free(c->casc_tmp[1]); free(c->casc_tmp[2]); free(c->casc_tmp[3]);
     free(c);
 }
 
@@ -1123,23 +1123,54 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
     if (c->needAlpha && isPlanarRGB(dstFormat)) return -1; /* gbrap writers not restated */
 
     /* filters (:1675-1735), filterAlign == 1 in the C-only build */
-    ret = init_filter(&c->hLumFilter, &c->hLumFilterPos, &c->hLumFilterSize, c->lumXInc, srcW, dstW, 1, 1 << 14,
-                      lum_scaler, flags, c->o.scaler_params, get_local_pos(0, 0), get_local_pos(0, 0),
-                      c->o.src_vec[0], c->o.src_vec_len[0], c->o.dst_vec_len[0]);
-    if (ret < 0) return -1;
-    ret = init_filter(&c->hChrFilter, &c->hChrFilterPos, &c->hChrFilterSize, c->chrXInc, c->chrSrcW, c->chrDstW, 1, 1 << 14,
-                      chr_scaler, flags, c->o.scaler_params,
-                      get_local_pos(c->chrSrcHSub, c->o.src_h_chr_pos), get_local_pos(c->chrDstHSub, c->o.dst_h_chr_pos),
-                      c->o.src_vec[2], c->o.src_vec_len[2], c->o.dst_vec_len[2]);
-    if (ret < 0) return -1;
-    ret = init_filter(&c->vLumFilter, &c->vLumFilterPos, &c->vLumFilterSize, c->lumYInc, srcH, dstH, 1, 1 << 12,
-                      lum_scaler, flags, c->o.scaler_params, get_local_pos(0, 0), get_local_pos(0, 0),
-                      c->o.src_vec[1], c->o.src_vec_len[1], c->o.dst_vec_len[1]);
-    if (ret < 0) return -1; /* RET_CASCADE: extreme-ratio cascade not restated */
-    ret = init_filter(&c->vChrFilter, &c->vChrFilterPos, &c->vChrFilterSize, c->chrYInc, c->chrSrcH, c->chrDstH, 1, 1 << 12,
-                      chr_scaler, flags, c->o.scaler_params,
-                      get_local_pos(c->chrSrcVSub, c->o.src_v_chr_pos), get_local_pos(c->chrDstVSub, c->o.dst_v_chr_pos),
-                      c->o.src_vec[3], c->o.src_vec_len[3], c->o.dst_vec_len[3]);
+    {
+        int r[4];
+        r[0] = init_filter(&c->hLumFilter, &c->hLumFilterPos, &c->hLumFilterSize, c->lumXInc, srcW, dstW, 1, 1 << 14,
+                           lum_scaler, flags, c->o.scaler_params, get_local_pos(0, 0), get_local_pos(0, 0),
+                           c->o.src_vec[0], c->o.src_vec_len[0], c->o.dst_vec_len[0]);
+        r[1] = r[0] < 0 ? r[0] : init_filter(&c->hChrFilter, &c->hChrFilterPos, &c->hChrFilterSize, c->chrXInc, c->chrSrcW, c->chrDstW, 1, 1 << 14,
+                           chr_scaler, flags, c->o.scaler_params,
+                           get_local_pos(c->chrSrcHSub, c->o.src_h_chr_pos), get_local_pos(c->chrDstHSub, c->o.dst_h_chr_pos),
+                           c->o.src_vec[2], c->o.src_vec_len[2], c->o.dst_vec_len[2]);
+        /* vertical: a cascade request of the luma filter is remembered while the chroma filter is still built (:1719-1735) */
+        r[2] = r[1] < 0 ? r[1] : init_filter(&c->vLumFilter, &c->vLumFilterPos, &c->vLumFilterSize, c->lumYInc, srcH, dstH, 1, 1 << 12,
+                           lum_scaler, flags, c->o.scaler_params, get_local_pos(0, 0), get_local_pos(0, 0),
+                           c->o.src_vec[1], c->o.src_vec_len[1], c->o.dst_vec_len[1]);
+        r[3] = (r[2] < 0 && r[2] != RET_CASCADE) ? r[2] : init_filter(&c->vChrFilter, &c->vChrFilterPos, &c->vChrFilterSize, c->chrYInc, c->chrSrcH, c->chrDstH, 1, 1 << 12,
+                           chr_scaler, flags, c->o.scaler_params,
+                           get_local_pos(c->chrSrcVSub, c->o.src_v_chr_pos), get_local_pos(c->chrDstVSub, c->o.dst_v_chr_pos),
+                           c->o.src_vec[3], c->o.src_vec_len[3], c->o.dst_vec_len[3]);
+        ret = r[3] < 0 ? r[3] : r[2];
+    }
+    if (ret == RET_CASCADE) {
+        /* utils.c:1803-1833: two steps through a yuv420p / yuva420p picture of the geometric-mean size.  The children are plain
+         * sws_getContext() contexts (flags and scaler parameters only); srcFilter goes to the first, dstFilter to the second. */
+        const int tmpW = (int)sqrt((double)(srcW * (int64_t)dstW)), tmpH = (int)sqrt((double)(srcH * (int64_t)dstH));
+        const int tmpFormat = isALPHA(srcFormat) ? ORF_YUVA420P : ORF_YUV420P;
+        const int aw = (tmpW + 7) & ~7;                      /* av_image_alloc(..., 64): linesizes of the width rounded up to 8, aligned to 64 */
+        const int np = tmpFormat == ORF_YUVA420P ? 4 : 3;
+        int k;
+        if (srcW * (int64_t)srcH <= 4LL * dstW * dstH) return -1;
+        if (c->src_xyz || c->dst_xyz) return -1;   /* (the reference skips its XYZ passes here: not restated) */
+        for (k = 0; k < np; k++) {
+            const int chroma = k == 1 || k == 2;
+            const int rows = chroma ? (tmpH + 1) >> 1 : tmpH;
+            c->casc_stride[k] = ((chroma ? (aw + 1) >> 1 : aw) + 63) & ~63;
+            c->casc_tmp[k] = calloc((size_t)c->casc_stride[k] * rows + 64, 1);
+        }
+        c->cascade[0] = alloc_set_opts(srcW, srcH, c->o.src_format, tmpW, tmpH, tmpFormat, c->o.flags, c->o.scaler_params);
+        for (k = 0; k < 4; k++) { c->cascade[0]->o.src_vec[k] = c->o.src_vec[k]; c->cascade[0]->o.src_vec_len[k] = c->o.src_vec_len[k]; }
+        c->cascade[1] = alloc_set_opts(tmpW, tmpH, tmpFormat, dstW, dstH, c->o.dst_format, c->o.flags, c->o.scaler_params);
+        for (k = 0; k < 4; k++) c->cascade[1]->o.dst_vec_len[k] = c->o.dst_vec_len[k];
+        if (init_context(c->cascade[0]) < 0 || init_context(c->cascade[1]) < 0) {
+            or_sws_free(c->cascade[0]); or_sws_free(c->cascade[1]);
+            for (k = 0; k < 4; k++) { free(c->casc_tmp[k]); c->casc_tmp[k] = NULL; }
+            c->cascade[0] = c->cascade[1] = NULL;
+            return -1;
+        }
+        c->initialized = 1;
+        return 0;
+    }
     if (ret < 0) return -1;
 
     init_range_convert(c); /* ff_sws_init_scale -> sws_init_swscale, swscale.c:662-695 */
@@ -3456,7 +3487,7 @@ static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4
                     uint8_t *const dst[4], const int dstStride[4])
 {
     if (c->cascade[0]) { /* scale_cascaded, swscale.c:992-1018 */
-        uint8_t *tmp[4] = { c->casc_tmp[0], NULL, NULL, NULL };
+        uint8_t *tmp[4] = { c->casc_tmp[0], c->casc_tmp[1], c->casc_tmp[2], c->casc_tmp[3] };
         int ret = or_sws_scale(c->cascade[0], src, srcStride, 0, srcSliceH, tmp, c->casc_stride);
         if (ret < 0) return ret;
         return or_sws_scale(c->cascade[1], (const uint8_t *const *)tmp, c->casc_stride, 0, c->cascade[0]->o.dst_h, dst, dstStride);
