@@ -322,9 +322,36 @@ int init_single_context(SwsInternal *c)
         return -0x45574150; // AVERROR_PATCHWELCOME (:1449-1453)
     c->lumXInc = (int)lumXInc; c->lumYInc = (int)lumYInc; c->chrXInc = (int)chrXInc; c->chrYInc = (int)chrYInc;
 
-    if (o->gamma_flag && !unscaled) {
-        log_msg(c, 0, "gamma-correct scaling cascade is not implemented on the HIP path\n");
-        return SWS_AVERROR(ENOTSUP);
+    if (!unscaled && o->gamma_flag && (srcFormat != AV_PIX_FMT_RGBA64LE || dstFormat != AV_PIX_FMT_RGBA64LE || c->srcBE || c->dstBE)) {
+        // Gamma-correct scaling (utils.c:1461-1522): source -> RGBA64LE at the source size, RGBA64LE scaled between a pow(x, 1/2.2) and a
+        // pow(x, 2.2) table pass over its R, G, B words (gamma.c:31-58), RGBA64LE -> destination at the destination size.  The children are
+        // plain sws_getContext() contexts (flags and scaler parameters only); both filters go to the scaling step.
+        if (c->srcXYZ || c->dstXYZ) {   // (the reference runs this cascade without its XYZ passes, swscale.c:1076 before :1106: not reproduced)
+            log_msg(c, 0, "gamma-correct scaling of an XYZ picture is not implemented on the HIP path\n");
+            return SWS_AVERROR(ENOTSUP);
+        }
+        auto fail = [&](int err) { for (auto &cc : c->cascade) { destroy(cc); cc = nullptr; } c->cascade_gamma = false; return err; };
+        SwsFilter sf, df;
+        SwsVector sv[4], dv[4];
+        for (int k = 0; k < 4; k++) {
+            sv[k].coeff = c->srcVec[k].empty() ? nullptr : c->srcVec[k].data(); sv[k].length = (int)c->srcVec[k].size();
+            dv[k].coeff = nullptr; dv[k].length = c->dstVecLen[k];
+        }
+        sf.lumH = sv[0].length ? &sv[0] : nullptr; sf.lumV = sv[1].length ? &sv[1] : nullptr; sf.chrH = sv[2].length ? &sv[2] : nullptr; sf.chrV = sv[3].length ? &sv[3] : nullptr;
+        df.lumH = dv[0].length ? &dv[0] : nullptr; df.lumV = dv[1].length ? &dv[1] : nullptr; df.chrH = dv[2].length ? &dv[2] : nullptr; df.chrV = dv[3].length ? &dv[3] : nullptr;
+        c->cascade_gamma = true;
+        c->cascade_fmt = AV_PIX_FMT_RGBA64LE; c->cascade_w = srcW; c->cascade_h = srcH;
+        c->cascade[0] = alloc_set_opts(srcW, srcH, srcFormat, srcW, srcH, AV_PIX_FMT_RGBA64LE, flags, o->scaler_params);
+        c->cascade[1] = alloc_set_opts(srcW, srcH, AV_PIX_FMT_RGBA64LE, dstW, dstH, AV_PIX_FMT_RGBA64LE, flags, o->scaler_params);
+        if (dstFormat != AV_PIX_FMT_RGBA64LE || c->dstBE) c->cascade[2] = alloc_set_opts(dstW, dstH, AV_PIX_FMT_RGBA64LE, dstW, dstH, dstFormat, flags, o->scaler_params);
+        if (!c->cascade[0] || !c->cascade[1]) return fail(SWS_AVERROR(ENOMEM));
+        c->cascade[0]->srcBE = c->srcBE;
+        if (c->cascade[2]) c->cascade[2]->dstBE = c->dstBE;
+        for (SwsInternal *cc : c->cascade) if (cc) cc->tune = c->tune;
+        if (init_context_impl(c->cascade[0], nullptr, nullptr) < 0 || init_context_impl(c->cascade[1], &sf, &df) < 0 ||
+            (c->cascade[2] && init_context_impl(c->cascade[2], nullptr, nullptr) < 0)) return fail(SWS_AVERROR(ENOMEM));
+        c->plan = PLAN_CASCADE;
+        return 0;
     }
     c->needAlpha = isALPHA(srcFormat) && isALPHA(dstFormat);                    // :1746
     if (o->alpha_blend != SWS_ALPHA_BLEND_NONE && isALPHA(srcFormat) && !isALPHA(dstFormat)) {   // utils.c:1565-1615, alphablend.c
@@ -441,8 +468,7 @@ static SwsInternal *new_context()
 static void destroy(SwsInternal *c)
 {
     if (!c) return;
-    destroy(c->cascade[0]);
-    destroy(c->cascade[1]);
+    for (SwsInternal *cc : c->cascade) destroy(cc);
     frames_release(c);
     dev_release(c);
     c->magic = 0;

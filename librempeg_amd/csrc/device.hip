@@ -58,7 +58,7 @@ static void dev_state_free(DeviceState *d)
     if (d->stream && d->own_stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
     else if (d->stream) (void)hipStreamSynchronize(d->stream);
     for (void *p : { d->d_tables, d->scratch, d->stage_src, d->stage_dst, (void *)d->d_frames, d->casc_img, d->slice_img, d->d_tilegeom,
-                     d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2 })
+                     d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2, d->casc_img2, d->d_gamma_tab })
         if (p) (void)hipFree(p);
     if (d->h_frames) (void)hipHostFree(d->h_frames);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
@@ -1114,11 +1114,12 @@ static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4
 {
     const SwsContext &o = c->opts;
 
-    if (c->plan == PLAN_CASCADE) { // scale_cascaded, swscale.c:992-1018 (whole frames)
-        SwsInternal *c0 = c->cascade[0], *c1 = c->cascade[1];
-        DeviceState *cd[2] = { nullptr, nullptr };
-        for (int k = 0; k < 2; k++) {
-            SwsInternal *cc = k ? c1 : c0;
+    if (c->plan == PLAN_CASCADE) { // scale_cascaded, swscale.c:992-1018; scale_gamma, :959-990 (whole frames)
+        SwsInternal *c0 = c->cascade[0], *c1 = c->cascade[1], *c2 = c->cascade[2];
+        DeviceState *cd[3] = { nullptr, nullptr, nullptr };
+        for (int k = 0; k < 3; k++) {
+            SwsInternal *cc = c->cascade[k];
+            if (!cc) continue;
             // children run on the parent's GPU and stream
             cd[k] = dev_state_for(cc, d->device);
             if (!cd[k]) return AVERROR_EXTERNAL_;
@@ -1142,7 +1143,55 @@ static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4
         for (int k = 0; k < pix_nb_planes(pix_desc(c->cascade_fmt)); k++) { tmp[k] = (uint8_t *)d->casc_img + offs[k]; tls[k] = ls[k]; }
         r = run_single(c0, cd[0], src, srcStride, sliceY, sliceH, tmp, tls);
         if (r < 0) return r;
-        return run_single(c1, cd[1], tmp, tls, 0, c0->opts.dst_h, dst, dstStride);
+        if (!c->cascade_gamma) return run_single(c1, cd[1], tmp, tls, 0, c0->opts.dst_h, dst, dstStride);
+        // gamma cascade: table pass over the RGBA64 source of the scaling step (in place, like gamma_convert on the cascade's own
+        // intermediate), scale, table pass over its output, then the conversion to the destination format
+        if (!d->d_gamma_tab) {   // alloc_gamma_tbl (utils.c:1046-1058): tbl[i] = pow(i / 65535.0, e) * 65535.0 stored to uint16_t; [0] = 2.2, [1] = 1 / 2.2
+            static std::vector<uint16_t> tab;
+            static std::once_flag once;
+            std::call_once(once, [] {
+                tab.resize(2 * 65536);
+                for (int i = 0; i < 65536; i++) {
+                    tab[(size_t)i] = (uint16_t)(std::pow(i / 65535.0, 2.2) * 65535.0);
+                    tab[(size_t)65536 + i] = (uint16_t)(std::pow(i / 65535.0, 1.f / 2.2) * 65535.0);
+                }
+            });
+            HIPCHK(hipMalloc(&d->d_gamma_tab, tab.size() * sizeof(uint16_t)));
+            HIPCHK(hipMemcpyAsync(d->d_gamma_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice, d->stream));   // (static storage: stays valid)
+        }
+        const uint16_t *gt = (const uint16_t *)d->d_gamma_tab;
+        launch_gamma_rgba64(d->stream, tmp[0], tls[0], o.src_w, o.src_h, gt + 65536);
+        uint8_t *out1[4] = { dst[0], dst[1], dst[2], dst[3] };
+        int os1[4] = { dstStride[0], dstStride[1], dstStride[2], dstStride[3] };
+        bool out1_dev = true;
+        if (c2) {
+            int ls2[4]; size_t offs2[4], total2;
+            image_layout(AV_PIX_FMT_RGBA64LE, o.dst_w, o.dst_h, 256, ls2, offs2, &total2);
+            r = grow(c, &d->casc_img2, &d->casc_bytes2, total2);
+            if (r < 0) return r;
+            out1[0] = (uint8_t *)d->casc_img2; out1[1] = out1[2] = out1[3] = nullptr; os1[0] = ls2[0]; os1[1] = os1[2] = os1[3] = 0;
+        } else out1_dev = is_device_ptr(dst[0]);
+        if (!out1_dev) {
+            // the scaling step writes straight into a host picture: its output has to pass the table before it leaves the device, so the
+            // step runs into a device picture first
+            int ls2[4]; size_t offs2[4], total2;
+            image_layout(AV_PIX_FMT_RGBA64LE, o.dst_w, o.dst_h, 256, ls2, offs2, &total2);
+            r = grow(c, &d->casc_img2, &d->casc_bytes2, total2);
+            if (r < 0) return r;
+            uint8_t *t1[4] = { (uint8_t *)d->casc_img2, nullptr, nullptr, nullptr };
+            int s1[4] = { ls2[0], 0, 0, 0 };
+            r = run_single(c1, cd[1], tmp, tls, 0, o.src_h, t1, s1);
+            if (r < 0) return r;
+            launch_gamma_rgba64(d->stream, t1[0], s1[0], o.dst_w, o.dst_h, gt);
+            HIPCHK(hipMemcpy2DAsync(dst[0], (size_t)dstStride[0], t1[0], (size_t)s1[0], (size_t)o.dst_w * 8, (size_t)o.dst_h, hipMemcpyDeviceToHost, d->stream));
+            HIPCHK(hipStreamSynchronize(d->stream));
+            return r;
+        }
+        r = run_single(c1, cd[1], tmp, tls, 0, o.src_h, out1, os1);
+        if (r < 0) return r;
+        launch_gamma_rgba64(d->stream, out1[0], os1[0], o.dst_w, o.dst_h, gt);
+        if (c2) r = run_single(c2, cd[2], out1, os1, 0, o.dst_h, dst, dstStride);
+        return r;
     }
 
     const int nps = pix_nb_planes(pix_desc(o.src_format)), npd = pix_nb_planes(pix_desc(o.dst_format));
@@ -1240,7 +1289,7 @@ int dev_inherit(SwsInternal *child, SwsInternal *parent, bool have_stream, void 
     if (std::memcmp(&child->tune, &parent->tune, sizeof(Tuning))) {
         child->tune = parent->tune;
         mark_tables_dirty(child);
-        for (SwsInternal *cc : { child->cascade[0], child->cascade[1] }) if (cc) { cc->tune = parent->tune; mark_tables_dirty(cc); }
+        for (SwsInternal *cc : child->cascade) if (cc) { cc->tune = parent->tune; mark_tables_dirty(cc); }
     }
     if (child->dev->timing != parent->dev->timing && (r = sws_hip_set_timing(&child->opts, parent->dev->timing)) < 0) return r;
     void *want = have_stream ? stream : (parent->dev->stream && !parent->dev->own_stream ? (void *)parent->dev->stream : nullptr);
@@ -1505,7 +1554,7 @@ int sws_hip_set_device(SwsContext *sws, int device)
     if (c->dev && c->dev->device == device) return 0;
     // a new home GPU: everything the context (and the children of a cascade) holds on any GPU is released and rebuilt on first use
     dev_release(c);
-    for (SwsInternal *cc : { c->cascade[0], c->cascade[1] }) if (cc) dev_release(cc);
+    for (SwsInternal *cc : c->cascade) if (cc) dev_release(cc);
     frames_release(c);      // the per-field conversions of a dynamic context are rebuilt on the new GPU
     int r = ensure_dev(c);
     if (r < 0) return r;
@@ -1607,7 +1656,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         if (!std::strcmp(e.n, name)) {
             *e.v = value;
             mark_tables_dirty(c);
-            for (SwsInternal *cc : { c->cascade[0], c->cascade[1] }) if (cc) { cc->tune = c->tune; mark_tables_dirty(cc); }
+            for (SwsInternal *cc : c->cascade) if (cc) { cc->tune = c->tune; mark_tables_dirty(cc); }
             return 0;
         }
     return SWS_AVERROR(EINVAL);

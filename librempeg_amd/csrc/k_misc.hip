@@ -278,6 +278,13 @@ void launch_bswap(hipStream_t st, const uint8_t *src, int64_t sstride, uint8_t *
     hipLaunchKernelGGL(swsk::sws_k_bswap, grid, dim3(256), 0, st, src, sstride, dst, dstride, rows, row_bytes, unit);
 }
 
+void launch_gamma_rgba64(hipStream_t st, uint8_t *img, int64_t stride, int w, int rows, const uint16_t *table)
+{
+    if (w <= 0 || rows <= 0) return;
+    const dim3 grid(cdiv(w, 256), rows);
+    hipLaunchKernelGGL(swsk::sws_k_gamma_rgba64, grid, dim3(256), 0, st, img, stride, w, rows, table);
+}
+
 void launch_xyz12(hipStream_t st, const uint8_t *src, int64_t sstride, uint8_t *dst, int64_t dstride, int w, int rows,
                   const uint16_t *gamma_in, const uint16_t *gamma_out, int to_rgb)
 {

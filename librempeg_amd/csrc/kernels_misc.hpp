@@ -157,4 +157,13 @@ __global__ void __launch_bounds__(256) sws_k_bswap(const uint8_t *src, int64_t s
     else { const uint32_t v = *(const uint32_t *)s; *(uint32_t *)d = __builtin_bswap32(v); }
 }
 
+// gamma_convert (gamma.c:31-58): table look-up on the R, G, B words of an RGBA64LE picture, in place; the alpha word stays
+__global__ void __launch_bounds__(256) sws_k_gamma_rgba64(uint8_t *img, int64_t stride, int w, int rows, const uint16_t *__restrict__ table)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= rows) return;
+    uint16_t *px = (uint16_t *)(img + y * stride) + 4 * x;
+    px[0] = table[px[0]]; px[1] = table[px[1]]; px[2] = table[px[2]];
+}
+
 } // namespace swsk

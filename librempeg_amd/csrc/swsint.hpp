@@ -153,7 +153,8 @@ struct SwsInternal {
     int32_t rgb2yuv[9] = {0};
     Yuv2RgbLut lut;
     RangeConv range;
-    SwsInternal *cascade[2] = {nullptr, nullptr};
+    SwsInternal *cascade[3] = {nullptr, nullptr, nullptr};   // [2]: third step of the gamma cascade (RGBA64LE -> destination format)
+    bool cascade_gamma = false;   // gamma-correct scaling (utils.c:1461-1522): cascade[1] scales RGBA64 between two in-place table passes
     int cascade_fmt = -1, cascade_w = 0, cascade_h = 0;
     std::string path_name, kernel_name;
     DeviceState *dev = nullptr;             // state on the context's home GPU

@@ -316,7 +316,10 @@ struct OrSws {
     int has_lut;
     int range_active; uint32_t lumCoeff, chrCoeff; int64_t lumOffset, chrOffset;
     int needAlpha;
-    OrSws *cascade[2]; uint8_t *casc_tmp[4]; int casc_stride[4];
+    OrSws *cascade[3]; uint8_t *casc_tmp[4]; int casc_stride[4];
+    /* gamma cascade (utils.c:1461-1522): cascade[1] scales RGBA64 -> RGBA64 between two in-place table passes, cascade[2] converts to the
+     * destination format from a second intermediate */
+    int casc_gamma; uint8_t *casc_tmp2; int casc_stride2; uint16_t *gamma_tab, *inv_gamma_tab;
     int initialized;
 };
 
@@ -932,7 +935,8 @@ void or_sws_free(OrSws *c)
     free(c->hLumFilter); free(c->hChrFilter); free(c->vLumFilter); free(c->vChrFilter);
     free(c->hLumFilterPos); free(c->hChrFilterPos); free(c->vLumFilterPos); free(c->vChrFilterPos);
     free(c->yuvTable);
-    or_sws_free(c->cascade[0]); or_sws_free(c->cascade[1]);
+    or_sws_free(c->cascade[0]); or_sws_free(c->cascade[1]); or_sws_free(c->cascade[2]);
+    free(c->casc_tmp2); free(c->gamma_tab); free(c->inv_gamma_tab);
     free(c->casc_tmp[0]); free(c->casc_tmp[1]); free(c->casc_tmp[2]); free(c->casc_tmp[3]);
     free(c);
 }
@@ -1107,6 +1111,41 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
         lumXInc < 10 || lumXInc > 0x7fffffff || lumYInc < 10 || lumYInc > 0x7fffffff)
         return -1;
     c->lumXInc = (int)lumXInc; c->lumYInc = (int)lumYInc; c->chrXInc = (int)chrXInc; c->chrYInc = (int)chrYInc;
+
+    if (!unscaled && c->o.gamma_flag && (c->o.src_format != ORF_RGBA64LE || c->o.dst_format != ORF_RGBA64LE || c->src_be || c->dst_be)) {
+        /* utils.c:1461-1522: source -> RGBA64LE (same size), RGBA64LE scaled between pow(x, 1/2.2) and pow(x, 2.2) table passes, RGBA64LE ->
+         * destination (same size).  Children are plain sws_getContext() contexts; the filters go to the scaling step. */
+        int k;
+        if (c->src_xyz || c->dst_xyz) return -1;   /* (the reference runs this cascade without its XYZ passes: not restated) */
+        c->casc_gamma = 1;
+        c->casc_stride[0] = (((srcW + 7) & ~7) * 8 + 63) & ~63;
+        c->casc_tmp[0] = calloc((size_t)c->casc_stride[0] * srcH + 64, 1);
+        c->cascade[0] = alloc_set_opts(srcW, srcH, c->o.src_format, srcW, srcH, ORF_RGBA64LE, c->o.flags, c->o.scaler_params);
+        c->cascade[1] = alloc_set_opts(srcW, srcH, ORF_RGBA64LE, dstW, dstH, ORF_RGBA64LE, c->o.flags, c->o.scaler_params);
+        for (k = 0; k < 4; k++) {
+            c->cascade[1]->o.src_vec[k] = c->o.src_vec[k]; c->cascade[1]->o.src_vec_len[k] = c->o.src_vec_len[k];
+            c->cascade[1]->o.dst_vec_len[k] = c->o.dst_vec_len[k];
+        }
+        if (c->o.dst_format != ORF_RGBA64LE || c->dst_be) {
+            c->casc_stride2 = (((dstW + 7) & ~7) * 8 + 63) & ~63;
+            c->casc_tmp2 = calloc((size_t)c->casc_stride2 * dstH + 64, 1);
+            c->cascade[2] = alloc_set_opts(dstW, dstH, ORF_RGBA64LE, dstW, dstH, c->o.dst_format, c->o.flags, c->o.scaler_params);
+        }
+        if (init_context(c->cascade[0]) < 0 || init_context(c->cascade[1]) < 0 || (c->cascade[2] && init_context(c->cascade[2]) < 0)) {
+            or_sws_free(c->cascade[0]); or_sws_free(c->cascade[1]); or_sws_free(c->cascade[2]);
+            free(c->casc_tmp[0]); free(c->casc_tmp2);
+            c->cascade[0] = c->cascade[1] = c->cascade[2] = NULL; c->casc_tmp[0] = c->casc_tmp2 = NULL; c->casc_gamma = 0;
+            return -1;
+        }
+        /* alloc_gamma_tbl (utils.c:1046-1058): tbl[i] = pow(i / 65535.0, e) * 65535.0, converted to uint16_t by the assignment */
+        c->gamma_tab = malloc(65536 * sizeof(uint16_t)); c->inv_gamma_tab = malloc(65536 * sizeof(uint16_t));
+        for (k = 0; k < 65536; k++) {
+            c->gamma_tab[k] = (uint16_t)(pow(k / 65535.0, 2.2) * 65535.0);
+            c->inv_gamma_tab[k] = (uint16_t)(pow(k / 65535.0, 1.f / 2.2) * 65535.0);
+        }
+        c->initialized = 1;
+        return 0;
+    }
 
     /* alpha: src alpha dropped -> reference cascades through alpha blend only if alpha_blend != NONE (default NONE) */
     c->needAlpha = isALPHA(srcFormat) && isALPHA(dstFormat);
@@ -3486,6 +3525,26 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
 static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4], int srcSliceY, int srcSliceH,
                     uint8_t *const dst[4], const int dstStride[4])
 {
+    if (c->casc_gamma) { /* scale_gamma, swscale.c:959-990; gamma_convert (gamma.c:31-58) in place on the RGB words of the RGBA64 pictures */
+        uint8_t *t0[4] = { c->casc_tmp[0], NULL, NULL, NULL }, *t1[4] = { c->casc_tmp2, NULL, NULL, NULL };
+        int s0[4] = { c->casc_stride[0], 0, 0, 0 }, s1[4] = { c->casc_stride2, 0, 0, 0 };
+        uint8_t *const *out1 = c->cascade[2] ? t1 : dst;
+        const int *os1 = c->cascade[2] ? s1 : dstStride;
+        int ret = or_sws_scale(c->cascade[0], src, srcStride, 0, srcSliceH, t0, s0), y, x, k;
+        if (ret < 0) return ret;
+        for (y = 0; y < c->o.src_h; y++) {
+            uint16_t *row = (uint16_t *)(t0[0] + (ptrdiff_t)y * s0[0]);
+            for (x = 0; x < c->o.src_w; x++) for (k = 0; k < 3; k++) row[4 * x + k] = c->inv_gamma_tab[row[4 * x + k]];
+        }
+        ret = or_sws_scale(c->cascade[1], (const uint8_t *const *)t0, s0, 0, c->o.src_h, out1, os1);
+        if (ret < 0) return ret;
+        for (y = 0; y < c->o.dst_h; y++) {
+            uint16_t *row = (uint16_t *)(out1[0] + (ptrdiff_t)y * os1[0]);
+            for (x = 0; x < c->o.dst_w; x++) for (k = 0; k < 3; k++) row[4 * x + k] = c->gamma_tab[row[4 * x + k]];
+        }
+        if (c->cascade[2]) ret = or_sws_scale(c->cascade[2], (const uint8_t *const *)t1, s1, 0, c->o.dst_h, dst, dstStride);
+        return ret;
+    }
     if (c->cascade[0]) { /* scale_cascaded, swscale.c:992-1018 */
         uint8_t *tmp[4] = { c->casc_tmp[0], c->casc_tmp[1], c->casc_tmp[2], c->casc_tmp[3] };
         int ret = or_sws_scale(c->cascade[0], src, srcStride, 0, srcSliceH, tmp, c->casc_stride);

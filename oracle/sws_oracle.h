@@ -92,6 +92,7 @@ typedef struct OrSwsOpts {
     const double *src_vec[4];
     int src_vec_len[4];
     int dst_vec_len[4];
+    int gamma_flag;        /* SwsContext.gamma_flag: gamma-correct scaling through RGBA64 (utils.c:1461-1522) */
 } OrSwsOpts;
 
 void   or_sws_default_opts(OrSwsOpts *o);
