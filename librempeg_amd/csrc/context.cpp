@@ -230,6 +230,22 @@ static void destroy(SwsInternal *c);
 static SwsInternal *alloc_set_opts(int srcW, int srcH, int srcFormat, int dstW, int dstH, int dstFormat, unsigned flags, const double *param);
 static int init_context_impl(SwsInternal *c, SwsFilter *srcFilter, SwsFilter *dstFilter);
 
+static int alphaless_fmt(int fmt)   // utils.c:1060-1118 (the stored formats are the little-endian twins; gbrap* is not built)
+{
+    switch (fmt) {
+    case AV_PIX_FMT_ARGB: case AV_PIX_FMT_RGBA: return AV_PIX_FMT_RGB24;
+    case AV_PIX_FMT_ABGR: case AV_PIX_FMT_BGRA: return AV_PIX_FMT_BGR24;
+    case AV_PIX_FMT_YA8: return AV_PIX_FMT_GRAY8;
+    case AV_PIX_FMT_YUVA420P: return AV_PIX_FMT_YUV420P; case AV_PIX_FMT_YUVA422P: return AV_PIX_FMT_YUV422P; case AV_PIX_FMT_YUVA444P: return AV_PIX_FMT_YUV444P;
+    case AV_PIX_FMT_RGBA64LE: return AV_PIX_FMT_RGB48LE; case AV_PIX_FMT_BGRA64LE: return AV_PIX_FMT_BGR48LE;
+    case AV_PIX_FMT_YA16LE: return AV_PIX_FMT_GRAY16LE;
+    case AV_PIX_FMT_YUVA420P9LE: return AV_PIX_FMT_YUV420P9LE; case AV_PIX_FMT_YUVA422P9LE: return AV_PIX_FMT_YUV422P9LE; case AV_PIX_FMT_YUVA444P9LE: return AV_PIX_FMT_YUV444P9LE;
+    case AV_PIX_FMT_YUVA420P10LE: return AV_PIX_FMT_YUV420P10LE; case AV_PIX_FMT_YUVA422P10LE: return AV_PIX_FMT_YUV422P10LE; case AV_PIX_FMT_YUVA444P10LE: return AV_PIX_FMT_YUV444P10LE;
+    case AV_PIX_FMT_YUVA420P16LE: return AV_PIX_FMT_YUV420P16LE; case AV_PIX_FMT_YUVA422P16LE: return AV_PIX_FMT_YUV422P16LE; case AV_PIX_FMT_YUVA444P16LE: return AV_PIX_FMT_YUV444P16LE;
+    }
+    return AV_PIX_FMT_NONE;
+}
+
 int init_single_context(SwsInternal *c)
 {
     SwsContext *o = &c->opts;
@@ -354,14 +370,48 @@ int init_single_context(SwsInternal *c)
         return 0;
     }
     c->needAlpha = isALPHA(srcFormat) && isALPHA(dstFormat);                    // :1746
-    if (o->alpha_blend != SWS_ALPHA_BLEND_NONE && isALPHA(srcFormat) && !isALPHA(dstFormat)) {   // utils.c:1565-1615, alphablend.c
-        log_msg(c, 0, "alpha blending (alpha_blend=%d, %s -> %s) is not implemented on the HIP path\n", (int)o->alpha_blend, ds->name, dd->name);
-        return SWS_AVERROR(ENOTSUP);
-    }
 
     c->plan = PLAN_NONE;
     const bool usesHFilter = c->srcVec[0].size() > 1 || c->srcVec[2].size() > 1 || c->dstVecLen[0] > 1 || c->dstVecLen[2] > 1;   // :1256-1263
     const bool usesVFilter = c->srcVec[1].size() > 1 || c->srcVec[3].size() > 1 || c->dstVecLen[1] > 1 || c->dstVecLen[3] > 1;
+    if (o->alpha_blend != SWS_ALPHA_BLEND_NONE && isALPHA(srcFormat) && !isALPHA(dstFormat)) {   // utils.c:1565-1616, alphablend.c
+        const int tmpFormat = alphaless_fmt(srcFormat);
+        if (tmpFormat != AV_PIX_FMT_NONE &&
+            (!unscaled || dstFormat != tmpFormat || c->dstBE || usesHFilter || usesVFilter || o->src_range != o->dst_range)) {
+            // blend away at the source size into the alpha-less twin of the source format, then convert / scale that
+            auto fail = [&](int err) { destroy(c->cascade[0]); destroy(c->cascade[1]); c->cascade[0] = c->cascade[1] = nullptr; c->cascade_mainindex = 0; return err; };
+            SwsFilter sf, df;
+            SwsVector sv[4], dv[4];
+            for (int k = 0; k < 4; k++) {
+                sv[k].coeff = c->srcVec[k].empty() ? nullptr : c->srcVec[k].data(); sv[k].length = (int)c->srcVec[k].size();
+                dv[k].coeff = nullptr; dv[k].length = c->dstVecLen[k];
+            }
+            sf.lumH = sv[0].length ? &sv[0] : nullptr; sf.lumV = sv[1].length ? &sv[1] : nullptr; sf.chrH = sv[2].length ? &sv[2] : nullptr; sf.chrV = sv[3].length ? &sv[3] : nullptr;
+            df.lumH = dv[0].length ? &dv[0] : nullptr; df.lumV = dv[1].length ? &dv[1] : nullptr; df.chrH = dv[2].length ? &dv[2] : nullptr; df.chrV = dv[3].length ? &dv[3] : nullptr;
+            c->cascade_mainindex = 1;
+            c->cascade_fmt = tmpFormat; c->cascade_w = srcW; c->cascade_h = srcH;
+            c->cascade[0] = alloc_set_opts(srcW, srcH, srcFormat, srcW, srcH, tmpFormat, flags, o->scaler_params);
+            c->cascade[1] = alloc_set_opts(srcW, srcH, tmpFormat, dstW, dstH, dstFormat, flags, o->scaler_params);
+            if (!c->cascade[0] || !c->cascade[1]) return fail(SWS_AVERROR(EINVAL));
+            c->cascade[0]->opts.alpha_blend = o->alpha_blend;
+            c->cascade[0]->srcBE = c->srcBE;
+            c->cascade[1]->opts.src_range = o->src_range; c->cascade[1]->opts.dst_range = o->dst_range;
+            c->cascade[1]->dstBE = c->dstBE;
+            c->cascade[0]->tune = c->cascade[1]->tune = c->tune;
+            int r = init_context_impl(c->cascade[0], nullptr, nullptr);
+            if (r < 0) return fail(r);
+            if ((r = init_context_impl(c->cascade[1], &sf, &df)) < 0) return fail(r);
+            c->plan = PLAN_CASCADE;
+            return 0;
+        }
+    }
+    // "alpha blend special case, note this has been split via cascaded contexts if its scaled" (:1603-1616)
+    if (unscaled && !usesHFilter && !usesVFilter && o->alpha_blend != SWS_ALPHA_BLEND_NONE && isALPHA(srcFormat) &&
+        (o->src_range == o->dst_range || isAnyRGB(dstFormat)) && alphaless_fmt(srcFormat) == dstFormat && !c->dstBE) {
+        c->plan = PLAN_UNSC_ALPHABLEND;
+        log_msg(c, 2, "using alpha blendaway %s -> %s special converter\n", ds->name, dd->name);
+        return 0;
+    }
     if (unscaled && !usesHFilter && !usesVFilter &&
         (o->src_range == o->dst_range || isAnyRGB(dstFormat) || isFloatFmt(srcFormat) || isFloatFmt(dstFormat))) { // :1623-1637
         choose_unscaled(c);
@@ -620,8 +670,8 @@ int sws_setColorspaceDetails(SwsContext *sws, const int inv_table[4], int srcRan
     c->srcFormatBpp = pix_bits_per_pixel(ds);
     mark_tables_dirty(c);
 
-    if (c->cascade[0])
-        return sws_setColorspaceDetails(&c->cascade[0]->opts, inv_copy, srcRange, tab_copy, dstRange, brightness, contrast, saturation);
+    if (c->cascade[c->cascade_mainindex])
+        return sws_setColorspaceDetails(&c->cascade[c->cascade_mainindex]->opts, inv_copy, srcRange, tab_copy, dstRange, brightness, contrast, saturation);
     if (!need_reinit) return 0;
 
     if ((isYUV(sws->dst_format) || isGray(sws->dst_format)) && (isYUV(sws->src_format) || isGray(sws->src_format))) {

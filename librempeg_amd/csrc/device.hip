@@ -646,6 +646,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     case PLAN_UNSC_RGBLOW: c->path_name = "unscaled:rgbToRgb"; c->kernel_name = "sws_k_rgb_low_convert"; break;
     case PLAN_UNSC_PLANAR2P422: c->path_name = "unscaled:planarToYuy2"; c->kernel_name = "sws_k_planar_to_p422"; break;
     case PLAN_UNSC_P4222PLANAR: c->path_name = "unscaled:yuyvToPlanar"; c->kernel_name = "sws_k_p422_to_planar"; break;
+    case PLAN_UNSC_ALPHABLEND: c->path_name = "unscaled:alphablendaway"; c->kernel_name = "sws_k_alphablend"; break;
     case PLAN_CASCADE: c->path_name = "cascade"; c->kernel_name = ""; break;
     case PLAN_MAIN: {
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;

@@ -210,6 +210,36 @@ int launch_misc(const LaunchCtx &L)
         hipLaunchKernelGGL(swsk::sws_k_planar_to_p422, grid, blk, 0, st, fs, p, npairs, sliceY, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 2);
         break;
     }
+    case PLAN_UNSC_ALPHABLEND: {   // ff_sws_alphablendaway: one launch per plane (planar) or one for the packed picture
+        const PixDesc *ds = pix_desc(c->opts.src_format);
+        swsk::AlphaBlendPlan ap;
+        std::memset(&ap, 0, sizeof(ap));
+        ap.planar = (ds->flags & PIXFLAG_PLANAR) ? 1 : 0;
+        ap.plane_count = isGray(c->opts.src_format) ? 1 : 3;
+        ap.depth = ds->comp[0].depth;
+        ap.alpha_pos = ds->comp[ap.plane_count].offset;
+        ap.lum_w = p.srcW; ap.lum_h = p.srcH; ap.lw = ds->log2_chroma_w; ap.lh = ds->log2_chroma_h;
+        for (int pl = 0; pl < ap.plane_count; pl++) {
+            int a = 0, b = 0;
+            if (c->opts.alpha_blend == SWS_ALPHA_BLEND_CHECKERBOARD) { a = (1 << (ap.depth - 1)) / 2; b = 3 * (1 << (ap.depth - 1)) / 2; }
+            const bool mid = pl && !(ds->flags & PIXFLAG_RGB);
+            ap.target[0][pl] = mid ? 1 << (ap.depth - 1) : a;
+            ap.target[1][pl] = mid ? 1 << (ap.depth - 1) : b;
+        }
+        if (!sliceH) break;
+        if (ap.planar) {
+            for (int pl = 0; pl < ap.plane_count; pl++) {
+                const int xs = pl ? ap.lw : 0, ys = pl ? ap.lh : 0;
+                const int w = pl ? -((-p.srcW) >> xs) : p.srcW, rows = -((-sliceH) >> ys);
+                const dim3 grid(cdiv(w, 256), rows, n);
+                hipLaunchKernelGGL(swsk::sws_k_alphablend, grid, blk, 0, st, fs, ap, pl, w, sliceY >> ys);
+            }
+        } else {
+            const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
+            hipLaunchKernelGGL(swsk::sws_k_alphablend, grid, blk, 0, st, fs, ap, 0, p.srcW, sliceY);
+        }
+        break;
+    }
     case PLAN_UNSC_P4222PLANAR: {
         const dim3 grid(cdiv((p.srcW + 1) >> 1, 256), sliceH, n);
         hipLaunchKernelGGL(swsk::sws_k_p422_to_planar, grid, blk, 0, st, fs, p, p.srcW, sliceY, c->opts.dst_format != AV_PIX_FMT_YUV422P ? 1 : 0);

@@ -195,6 +195,67 @@ __global__ void __launch_bounds__(256) sws_k_p422_to_planar(SwsFrameSet fs, SwsD
     }
 }
 
+// ff_sws_alphablendaway (alphablend.c:23-175): the source's alpha channel blends the picture over a uniform (black) or 32-pixel
+// checkerboard background into the alpha-less twin of the source format.  Thread = one sample of plane `plane` (planar: chroma planes take the
+// mean of the 2 or 2x2 alpha samples over them) or one pixel (packed).  Rows are absolute picture rows.
+struct AlphaBlendPlan { int planar, plane_count, depth, alpha_pos, lum_w, lum_h, lw, lh, target[2][3]; };
+__global__ void __launch_bounds__(256) sws_k_alphablend(SwsFrameSet fs, AlphaBlendPlan ap, int plane, int w, int y0)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= w) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int y = y0 + blockIdx.y;
+    const int depth = ap.depth;
+    const bool wide = depth >= 9;
+    const unsigned off = 1u << (depth - 1), shift = depth, maxv = (1u << shift) - 1;
+    if (ap.planar) {
+        const int xs = plane ? ap.lw : 0, ys = plane ? ap.lh : 0, pc = ap.plane_count;
+        const bool subsample_row = ys && (y << ys) + 1 < ap.lum_h;
+        const uint8_t *sp = f.src[plane] + (int64_t)f.srcStride[plane] * y;
+        uint8_t *dp = f.dst[plane] + (int64_t)f.dstStride[plane] * y;
+        const uint8_t *ap0 = f.src[pc] + (int64_t)f.srcStride[pc] * (y << ys), *ap1 = ap0 + f.srcStride[pc];
+        const unsigned t = (unsigned)ap.target[((x ^ y) >> 5) & 1][plane];
+        unsigned alpha;
+        if (xs || subsample_row) {
+            const int xn = min(2 * x + 1, ap.lum_w - 1);
+            if (wide) {
+                const uint16_t *a = (const uint16_t *)ap0, *a2 = (const uint16_t *)ap1;
+                alpha = subsample_row ? (unsigned)(a[2 * x] + a[xn] + 2 + a2[2 * x] + a2[xn]) >> 2 : (unsigned)(a[2 * x] + a[xn]) >> 1;
+            } else
+                alpha = subsample_row ? (unsigned)(ap0[2 * x] + ap0[xn] + 2 + ap1[2 * x] + ap1[xn]) >> 2 : (unsigned)(ap0[2 * x] + ap0[xn]) >> 1;
+        } else alpha = wide ? ((const uint16_t *)ap0)[x] : ap0[x];
+        if (wide) {
+            unsigned u = ((const uint16_t *)sp)[x] * alpha + t * (maxv - alpha) + off;
+            u = (u + (u >> shift)) >> shift;
+            ((uint16_t *)dp)[x] = (uint16_t)min(u, maxv);
+        } else {
+            const unsigned u = sp[x] * alpha + t * (255u - alpha) + 128u;
+            dp[x] = (uint8_t)((257u * u) >> 16);
+        }
+    } else {
+        const int pc = ap.plane_count, xi = (pc + 1) * x;
+        const uint8_t *row = f.src[0] + (int64_t)f.srcStride[0] * y;
+        uint8_t *drow = f.dst[0] + (int64_t)f.dstStride[0] * y;
+        if (wide) {
+            const uint16_t *s = (const uint16_t *)(row + 2 * !ap.alpha_pos), *a = (const uint16_t *)(row + ap.alpha_pos);
+            uint16_t *d = (uint16_t *)drow;
+            const unsigned alpha = a[xi];
+            for (int pl = 0; pl < pc; pl++) {
+                unsigned u = s[xi + pl] * alpha + (unsigned)ap.target[((x ^ y) >> 5) & 1][pl] * (maxv - alpha) + off;
+                u = (u + (u >> shift)) >> shift;
+                d[pc * x + pl] = (uint16_t)min(u, maxv);
+            }
+        } else {
+            const uint8_t *s = row + !ap.alpha_pos, *a = row + ap.alpha_pos;
+            const unsigned alpha = a[xi];
+            for (int pl = 0; pl < pc; pl++) {
+                const unsigned u = s[xi + pl] * alpha + (unsigned)ap.target[((x ^ y) >> 5) & 1][pl] * (255u - alpha) + 128u;
+                drow[pc * x + pl] = (uint8_t)((257u * u) >> 16);
+            }
+        }
+    }
+}
+
 // 16-bit packed RGB converters; thread = pixel.
 //   mode 0: rgb48tobgr48 / rgb48to64 / rgb48tobgr64 / rgb64to48 / rgb64tobgr48 (rgb2rgb.c:322-413): word moves, A = 0xFFFF
 //   mode 1: Rgb16ToPlanarRgb16Wrapper / packed16togbra16 (swscale_unscaled.c:685-962): plane[x] = word >> (16 - depth)

@@ -76,6 +76,7 @@ enum PlanKind {
     PLAN_UNSC_PACKED_GBRP, // rgbToPlanarRgbWrapper (8-bit packed RGB -> gbrp)
     PLAN_UNSC_PLANAR2P422, // yuv422pToYuy2/UyvyWrapper, planarToYuy2/UyvyWrapper
     PLAN_UNSC_P4222PLANAR, // yuyv/uyvy ToYuv420/422Wrapper
+    PLAN_UNSC_ALPHABLEND,  // ff_sws_alphablendaway (alphablend.c)
     PLAN_UNSC_RGB16SHUFFLE,   // rgb48tobgr48 / rgb48to64 / rgb48tobgr64 / rgb64to48 / rgb64tobgr48 (rgb2rgb.c:322-413)
     PLAN_UNSC_PACKED16_GBRP16,// Rgb16ToPlanarRgb16Wrapper
     PLAN_UNSC_GBRP16_PACKED16,// planarRgb16ToRgb16Wrapper
@@ -154,6 +155,7 @@ struct SwsInternal {
     Yuv2RgbLut lut;
     RangeConv range;
     SwsInternal *cascade[3] = {nullptr, nullptr, nullptr};   // [2]: third step of the gamma cascade (RGBA64LE -> destination format)
+    int cascade_mainindex = 0;    // the child sws_setColorspaceDetails() is forwarded to (utils.c:909-910): 1 for the alpha-blend cascade
     bool cascade_gamma = false;   // gamma-correct scaling (utils.c:1461-1522): cascade[1] scales RGBA64 between two in-place table passes
     int cascade_fmt = -1, cascade_w = 0, cascade_h = 0;
     std::string path_name, kernel_name;

@@ -289,7 +289,7 @@ enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
        UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_RGBLOW, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED,
        UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP, UNSC_RGB30_TO_16, UNSC_RGB30_TO_GBRP, UNSC_GBRP_TO_RGB30, UNSC_YUV2MONO, UNSC_U8_TO_F32, UNSC_F32_TO_U8,
        UNSC_PLANAR2P422, UNSC_P4222PLANAR,
-       UNSC_RGB16SHUFFLE, UNSC_PACKED16_TO_GBRP16, UNSC_GBRP16_TO_PACKED16 };
+       UNSC_RGB16SHUFFLE, UNSC_PACKED16_TO_GBRP16, UNSC_GBRP16_TO_PACKED16, UNSC_ALPHABLEND };
 
 struct OrSws {
     OrSwsOpts o;
@@ -319,6 +319,7 @@ struct OrSws {
     OrSws *cascade[3]; uint8_t *casc_tmp[4]; int casc_stride[4];
     /* gamma cascade (utils.c:1461-1522): cascade[1] scales RGBA64 -> RGBA64 between two in-place table passes, cascade[2] converts to the
      * destination format from a second intermediate */
+    int casc_mainindex;   /* the child sws_setColorspaceDetails() is forwarded to (utils.c:909-910): 1 for the alpha-blend cascade */
     int casc_gamma; uint8_t *casc_tmp2; int casc_stride2; uint16_t *gamma_tab, *inv_gamma_tab;
     int initialized;
 };
@@ -941,6 +942,114 @@ void or_sws_free(OrSws *c)
     free(c);
 }
 
+static int alphaless_fmt(int f) /* utils.c:1060-1118 (the big-endian rows are the same formats here: byte order is handled outside) */
+{
+    switch (f) {
+    case ORF_ARGB: case ORF_RGBA: return ORF_RGB24;
+    case ORF_ABGR: case ORF_BGRA: return ORF_BGR24;
+    case ORF_YA8: return ORF_GRAY8;
+    case ORF_YUVA420P: return ORF_YUV420P; case ORF_YUVA422P: return ORF_YUV422P; case ORF_YUVA444P: return ORF_YUV444P;
+    case ORF_RGBA64LE: return ORF_RGB48LE; case ORF_BGRA64LE: return ORF_BGR48LE;
+    case ORF_YA16LE: return ORF_GRAY16LE;
+    case ORF_YUVA420P9LE: return ORF_YUV420P9LE; case ORF_YUVA422P9LE: return ORF_YUV422P9LE; case ORF_YUVA444P9LE: return ORF_YUV444P9LE;
+    case ORF_YUVA420P10LE: return ORF_YUV420P10LE; case ORF_YUVA422P10LE: return ORF_YUV422P10LE; case ORF_YUVA444P10LE: return ORF_YUV444P10LE;
+    case ORF_YUVA420P16LE: return ORF_YUV420P16LE; case ORF_YUVA422P16LE: return ORF_YUV422P16LE; case ORF_YUVA444P16LE: return ORF_YUV444P16LE;
+    }
+    return ORF_NONE;
+}
+
+/* ff_sws_alphablendaway, alphablend.c:23-175 (little-endian words) */
+static int unscaled_alphablend(const OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY, int srcSliceH,
+                               uint8_t *const dst[], const int dstStride[])
+{
+    const Desc *desc = desc_get(c->o.src_format);
+    const int lum_w = c->o.src_w, lum_h = c->o.src_h;
+    const int plane_count = isGray(c->o.src_format) ? 1 : 3;
+    const int depth = desc->c[0].depth, sixteen_bits = depth >= 9;
+    const unsigned off = 1u << (depth - 1), shift = depth, max = (1u << shift) - 1;
+    int target_table[2][3], plane, x, ysrc;
+    for (plane = 0; plane < plane_count; plane++) {
+        int a = 0, b = 0;
+        if (c->o.alpha_blend == 2) { a = (1 << (depth - 1)) / 2; b = 3 * (1 << (depth - 1)) / 2; }
+        target_table[0][plane] = plane && !(desc->flags & PF_RGB) ? 1 << (depth - 1) : a;
+        target_table[1][plane] = plane && !(desc->flags & PF_RGB) ? 1 << (depth - 1) : b;
+    }
+    if (desc->flags & PF_PLANAR) {
+        for (plane = 0; plane < plane_count; plane++) {
+            const int w = plane ? c->chrSrcW : c->o.src_w;
+            const int x_subsample = plane ? desc->lw : 0, y_subsample = plane ? desc->lh : 0;
+            for (ysrc = 0; ysrc < CEIL_RSHIFT(srcSliceH, y_subsample); ysrc++) {
+                const int y = ysrc + (srcSliceY >> y_subsample);
+                const int subsample_row = y_subsample && (y << y_subsample) + 1 < lum_h;
+                const uint8_t *sp = src[plane] + (ptrdiff_t)srcStride[plane] * ysrc;
+                uint8_t *dp = dst[plane] + (ptrdiff_t)dstStride[plane] * y;
+                if (x_subsample || subsample_row) {
+                    const uint8_t *ap = src[plane_count] + (((ptrdiff_t)srcStride[plane_count] * ysrc) << y_subsample);
+                    for (x = 0; x < w; x++) {
+                        const int xnext = 2 * x + 1 < lum_w - 1 ? 2 * x + 1 : lum_w - 1;
+                        int alpha;
+                        if (sixteen_bits) {
+                            const uint16_t *a = (const uint16_t *)ap, *a2 = (const uint16_t *)(ap + srcStride[plane_count]);
+                            unsigned u;
+                            alpha = subsample_row ? (a[2 * x] + a[xnext] + 2 + a2[2 * x] + a2[xnext]) >> 2 : (a[2 * x] + a[xnext]) >> 1;
+                            u = ((const uint16_t *)sp)[x] * (unsigned)alpha + target_table[((x ^ y) >> 5) & 1][plane] * (max - alpha) + off;
+                            u = (u + (u >> shift)) >> shift;
+                            ((uint16_t *)dp)[x] = (uint16_t)(u > max ? max : u);
+                        } else {
+                            const uint8_t *a = ap, *a2 = ap + srcStride[plane_count];
+                            unsigned u;
+                            alpha = subsample_row ? (a[2 * x] + a[xnext] + 2 + a2[2 * x] + a2[xnext]) >> 2 : (a[2 * x] + a[xnext]) >> 1;
+                            u = sp[x] * alpha + target_table[((x ^ y) >> 5) & 1][plane] * (255 - alpha) + 128;
+                            dp[x] = (uint8_t)((257 * u) >> 16);
+                        }
+                    }
+                } else {
+                    const uint8_t *ap = src[plane_count] + (ptrdiff_t)srcStride[plane_count] * ysrc;
+                    for (x = 0; x < w; x++) {
+                        if (sixteen_bits) {
+                            const unsigned a = ((const uint16_t *)ap)[x];
+                            unsigned u = ((const uint16_t *)sp)[x] * a + target_table[((x ^ y) >> 5) & 1][plane] * (max - a) + off;
+                            u = (u + (u >> shift)) >> shift;
+                            ((uint16_t *)dp)[x] = (uint16_t)(u > max ? max : u);
+                        } else {
+                            const unsigned u = sp[x] * ap[x] + target_table[((x ^ y) >> 5) & 1][plane] * (255 - ap[x]) + 128;
+                            dp[x] = (uint8_t)((257 * u) >> 16);
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        const int alpha_pos = desc->c[plane_count].offset, w = c->o.src_w;
+        for (ysrc = 0; ysrc < srcSliceH; ysrc++) {
+            const int y = ysrc + srcSliceY;
+            if (sixteen_bits) {
+                const uint16_t *s = (const uint16_t *)(src[0] + (ptrdiff_t)srcStride[0] * ysrc + 2 * !alpha_pos);
+                const uint16_t *a = (const uint16_t *)(src[0] + (ptrdiff_t)srcStride[0] * ysrc + alpha_pos);
+                uint16_t *d = (uint16_t *)(dst[0] + (ptrdiff_t)dstStride[0] * y);
+                for (x = 0; x < w; x++)
+                    for (plane = 0; plane < plane_count; plane++) {
+                        const int x_index = (plane_count + 1) * x;
+                        unsigned u = s[x_index + plane] * (unsigned)a[x_index] + target_table[((x ^ y) >> 5) & 1][plane] * (max - a[x_index]) + off;
+                        u = (u + (u >> shift)) >> shift;
+                        d[plane_count * x + plane] = (uint16_t)(u > max ? max : u);
+                    }
+            } else {
+                const uint8_t *s = src[0] + (ptrdiff_t)srcStride[0] * ysrc + !alpha_pos;
+                const uint8_t *a = src[0] + (ptrdiff_t)srcStride[0] * ysrc + alpha_pos;
+                uint8_t *d = dst[0] + (ptrdiff_t)dstStride[0] * y;
+                for (x = 0; x < w; x++)
+                    for (plane = 0; plane < plane_count; plane++) {
+                        const int x_index = (plane_count + 1) * x;
+                        const unsigned u = s[x_index + plane] * a[x_index] + target_table[((x ^ y) >> 5) & 1][plane] * (255 - a[x_index]) + 128;
+                        d[plane_count * x + plane] = (uint8_t)((257 * u) >> 16);
+                    }
+            }
+        }
+    }
+    return srcSliceH;
+}
+
 static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.c:2392-2706 (subset) */
 {
     const int s = c->o.src_format, d = c->o.dst_format, flags = c->o.flags;
@@ -1154,6 +1263,47 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
                             c->o.dst_vec_len[0] > 1 || c->o.dst_vec_len[2] > 1;   /* utils.c:1256-1263 */
     const int usesVFilter = (c->o.src_vec[1] && c->o.src_vec_len[1] > 1) || (c->o.src_vec[3] && c->o.src_vec_len[3] > 1) ||
                             c->o.dst_vec_len[1] > 1 || c->o.dst_vec_len[3] > 1;
+    if (isALPHA(srcFormat) && !isALPHA(dstFormat)) {   /* utils.c:1565-1601 */
+        const int tmpFormat = alphaless_fmt(srcFormat);
+        if (tmpFormat != ORF_NONE && c->o.alpha_blend != 0) {
+            if (!unscaled || dstFormat != tmpFormat || c->dst_be || usesHFilter || usesVFilter || c->o.src_range != c->o.dst_range) {
+                /* blend at the source size into the alpha-less twin of the source format, then convert / scale that */
+                const Desc *td = desc_get(tmpFormat);
+                const int np = (td->flags & PF_PLANAR) ? td->nb : 1, aw = (srcW + 7) & ~7;
+                int k;
+                c->casc_mainindex = 1;
+                for (k = 0; k < np; k++) {
+                    const int chroma = np > 1 && (k == 1 || k == 2) && !(td->flags & PF_RGB);
+                    const int pw = chroma ? CEIL_RSHIFT(aw, td->lw) : aw, ph = chroma ? CEIL_RSHIFT(srcH, td->lh) : srcH;
+                    c->casc_stride[k] = (pw * (np > 1 ? (td->c[0].depth > 8 ? 2 : 1) : td->c[0].step) + 63) & ~63;
+                    c->casc_tmp[k] = calloc((size_t)c->casc_stride[k] * ph + 64, 1);
+                }
+                c->cascade[0] = alloc_set_opts(srcW, srcH, srcFormat, srcW, srcH, tmpFormat, flags, c->o.scaler_params);
+                c->cascade[0]->o.alpha_blend = c->o.alpha_blend;
+                c->cascade[1] = alloc_set_opts(srcW, srcH, tmpFormat, dstW, dstH, dstFormat, flags, c->o.scaler_params);
+                c->cascade[1]->o.src_range = c->o.src_range; c->cascade[1]->o.dst_range = c->o.dst_range;
+                for (k = 0; k < 4; k++) {
+                    c->cascade[1]->o.src_vec[k] = c->o.src_vec[k]; c->cascade[1]->o.src_vec_len[k] = c->o.src_vec_len[k];
+                    c->cascade[1]->o.dst_vec_len[k] = c->o.dst_vec_len[k];
+                }
+                if (init_context(c->cascade[0]) < 0 || init_context(c->cascade[1]) < 0) {
+                    or_sws_free(c->cascade[0]); or_sws_free(c->cascade[1]);
+                    for (k = 0; k < 4; k++) { free(c->casc_tmp[k]); c->casc_tmp[k] = NULL; }
+                    c->cascade[0] = c->cascade[1] = NULL; c->casc_mainindex = 0;
+                    return -1;
+                }
+                c->initialized = 1;
+                return 0;
+            }
+        }
+    }
+    /* "alpha blend special case, note this has been split via cascaded contexts if its scaled" (utils.c:1603-1616) */
+    if (unscaled && !usesHFilter && !usesVFilter && c->o.alpha_blend != 0 && isALPHA(srcFormat) &&
+        (c->o.src_range == c->o.dst_range || isAnyRGB(dstFormat)) && alphaless_fmt(srcFormat) == dstFormat && !c->dst_be) {
+        c->unscaled_kind = UNSC_ALPHABLEND;
+        c->initialized = 1;
+        return 0;
+    }
     if (unscaled && !usesHFilter && !usesVFilter &&
         (c->o.src_range == c->o.dst_range || isAnyRGB(dstFormat) || isFloat(srcFormat) || isFloat(dstFormat))) {
         get_unscaled(c);
@@ -1246,8 +1396,8 @@ int or_sws_set_colorspace(OrSws *c, const int inv_table[4], int srcRange, const 
     c->dstFormatBpp = bits_per_pixel(dd);
     c->srcFormatBpp = bits_per_pixel(ds);
 
-    if (c->cascade[0]) /* cascaded_mainindex == 0 here */
-        return or_sws_set_colorspace(c->cascade[0], inv_table, srcRange, table, dstRange, brightness, contrast, saturation);
+    if (c->cascade[c->casc_mainindex])
+        return or_sws_set_colorspace(c->cascade[c->casc_mainindex], inv_table, srcRange, table, dstRange, brightness, contrast, saturation);
     if (!need_reinit) return 0;
 
     if ((isYUV(c->o.dst_format) || isGray(c->o.dst_format)) && (isYUV(c->o.src_format) || isGray(c->o.src_format))) {
@@ -3598,6 +3748,7 @@ static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4
     case UNSC_RGB16SHUFFLE: return unscaled_rgb16shuffle(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_PACKED16_TO_GBRP16: return unscaled_packed16_gbrp16(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_GBRP16_TO_PACKED16: return unscaled_gbrp16_packed16(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_ALPHABLEND: return unscaled_alphablend(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     }
     {   /* ff_swscale (swscale.c:333-334): "srcStride2[1] *= 1 << c->vChrDrop; srcStride2[2] *= 1 << c->vChrDrop;" -- the chroma planes are read
          * every 2^vChrDrop-th row (packed sources reach the same rows through `y << chrSrcVSub` in their readers) */
@@ -3627,7 +3778,7 @@ const char *or_sws_path_name(const OrSws *c)
                                "rgbToRgb", "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb",
                                "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb", "rgbToRgb", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "yuv2rgb_c", "uint_y_to_float_y", "float_y_to_uint_y",
                                "planarToYuy2", "yuyvToPlanar",
-                               "rgb16Shuffle", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16" };
+                               "rgb16Shuffle", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "alphablendaway" };
     return c->cascade[0] ? "cascade" : n[c->unscaled_kind];
 }
 const int32_t *or_sws_rgb2yuv_table(const OrSws *c) { return c->rgb2yuv; }

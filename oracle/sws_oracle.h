@@ -93,6 +93,7 @@ typedef struct OrSwsOpts {
     int src_vec_len[4];
     int dst_vec_len[4];
     int gamma_flag;        /* SwsContext.gamma_flag: gamma-correct scaling through RGBA64 (utils.c:1461-1522) */
+    int alpha_blend;       /* SwsAlphaBlend: 0 none, 1 uniform, 2 checkerboard (utils.c:1565-1615, alphablend.c) */
 } OrSwsOpts;
 
 void   or_sws_default_opts(OrSwsOpts *o);

@@ -164,7 +164,7 @@ class OrSwsOpts(C.Structure):
                 ("src_range", C.c_int), ("dst_range", C.c_int),
                 ("src_v_chr_pos", C.c_int), ("src_h_chr_pos", C.c_int),
                 ("dst_v_chr_pos", C.c_int), ("dst_h_chr_pos", C.c_int),
-                ("src_vec", C.POINTER(C.c_double) * 4), ("src_vec_len", C.c_int * 4), ("dst_vec_len", C.c_int * 4), ("gamma_flag", C.c_int)]
+                ("src_vec", C.POINTER(C.c_double) * 4), ("src_vec_len", C.c_int * 4), ("dst_vec_len", C.c_int * 4), ("gamma_flag", C.c_int), ("alpha_blend", C.c_int)]
 
 
 _lib = None
