@@ -104,6 +104,9 @@ enum AVPixelFormat {
     AV_PIX_FMT_P010BE = 159, AV_PIX_FMT_P012BE = 210, AV_PIX_FMT_P016BE = 170, AV_PIX_FMT_P210BE = 197, AV_PIX_FMT_P212BE = 221,
     AV_PIX_FMT_P216BE = 201, AV_PIX_FMT_P410BE = 199, AV_PIX_FMT_P412BE = 223, AV_PIX_FMT_P416BE = 203, AV_PIX_FMT_RGB48BE = 34,
     AV_PIX_FMT_BGR48BE = 57, AV_PIX_FMT_RGBA64BE = 104, AV_PIX_FMT_BGRA64BE = 106,
+    /* planar RGB with an alpha plane */
+    AV_PIX_FMT_GBRAP = 111, AV_PIX_FMT_GBRAP16BE = 112, AV_PIX_FMT_GBRAP16LE = 113, AV_PIX_FMT_GBRAP12BE = 160, AV_PIX_FMT_GBRAP12LE = 161,
+    AV_PIX_FMT_GBRAP10BE = 162, AV_PIX_FMT_GBRAP10LE = 163, AV_PIX_FMT_GBRAPF32BE = 176, AV_PIX_FMT_GBRAPF32LE = 177, AV_PIX_FMT_GBRAP14BE = 225, AV_PIX_FMT_GBRAP14LE = 226,
     /* NEW: hardware surface format of the HIP hwcontext slot; takes the value of the
      * reference's AV_PIX_FMT_NB (268, libavutil/pixfmt.h:508), i.e. it is appended as the last format */
     AV_PIX_FMT_HIP = 268,

@@ -202,6 +202,17 @@ void choose_unscaled(SwsInternal *c)
     }
     if (isAnyRGB(s) && !isPlanarRGB(s) && pix_desc(s)->comp[0].depth == 8 && d == AV_PIX_FMT_GBRP) k = PLAN_UNSC_PACKED_GBRP;             // rgbToPlanarRgbWrapper (:2542-2544)
     if (s == AV_PIX_FMT_GBRP && isAnyRGB(d) && !isPlanarRGB(d) && pix_desc(d)->comp[0].depth == 8) k = PLAN_UNSC_GBRP_PACKED;             // planarRgbToRgbWrapper (:2480-2481)
+    // planarRgbToplanarRgbWrapper (:2469-2479): gbrp <-> gbrap at the same depth (the rules name the native-endian formats)
+    if (!c->srcBE && !c->dstBE && isPlanarRGB(s) && isPlanarRGB(d) && !isFloatFmt(s) && !isFloatFmt(d) && isALPHA(s) != isALPHA(d) &&
+        pix_desc(s)->comp[0].depth == pix_desc(d)->comp[0].depth && pix_desc(s)->comp[0].depth != 9 && !pix_desc(s)->comp[0].shift && !pix_desc(d)->comp[0].shift)
+        k = PLAN_UNSC_PLANARRGB_PLANARRGB;
+    // the alpha-carrying rows of the packed <-> planar RGB wrappers are not built: planarRgbaToRgbWrapper (:2483-2484), rgbToPlanarRgbaWrapper
+    // (:2546-2548), Rgb16ToPlanarRgb16Wrapper / planarRgb16ToRgb16Wrapper with a gbrap side (:2486-2538)
+    if ((s == AV_PIX_FMT_GBRAP && isAnyRGB(d) && !isPlanarRGB(d) && pix_desc(d)->comp[0].depth == 8 && !isRGB16fmt(d)) ||
+        (d == AV_PIX_FMT_GBRAP && isAnyRGB(s) && !isPlanarRGB(s) && pix_desc(s)->comp[0].depth == 8) ||
+        ((k == PLAN_UNSC_PACKED16_GBRP16 || k == PLAN_UNSC_RGB30_TO_GBRP) && isALPHA(d)) ||
+        ((k == PLAN_UNSC_GBRP16_PACKED16 || k == PLAN_UNSC_GBRP_TO_RGB30) && isALPHA(s)))
+        unsupported = true;
     if (s == d || (s == AV_PIX_FMT_YUVA420P && d == AV_PIX_FMT_YUV420P) || (s == AV_PIX_FMT_YUV420P && d == AV_PIX_FMT_YUVA420P) ||
         (isFloatFmt(s) == isFloatFmt(d) && ((isPlanarYUV(s) && isGray(d) && !isALPHA(d)) || (isPlanarYUV(d) && isGray(s) && !isALPHA(s)) ||
                                            (isGray(d) && !isALPHA(d) && isGray(s) && !isALPHA(s)))) ||   // isPlanarGray(x) = isGray(x) && !isALPHA(x) (:2673)
@@ -424,10 +435,6 @@ int init_single_context(SwsInternal *c)
             log_msg(c, 2, "using unscaled %s -> %s special converter\n", ds->name, dd->name);
             return 0;
         }
-    }
-    if (c->needAlpha && isPlanarRGB(dstFormat)) {
-        log_msg(c, 0, "alpha-plane output to planar RGB (%s -> %s) is not implemented on the HIP path\n", ds->name, dd->name);
-        return SWS_AVERROR(ENOTSUP);
     }
 
     // filters; filterAlign is 1 in the reference's C path (:1675-1735)

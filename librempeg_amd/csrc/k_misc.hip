@@ -210,6 +210,16 @@ int launch_misc(const LaunchCtx &L)
         hipLaunchKernelGGL(swsk::sws_k_planar_to_p422, grid, blk, 0, st, fs, p, npairs, sliceY, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 2);
         break;
     }
+    case PLAN_UNSC_PLANARRGB_PLANARRGB: {   // three plane copies (ff_copyPlane with its byte / pixel mix-up), the alpha plane filled if there is one
+        if (!sliceH) break;
+        const int bps = p.dst_bits > 8 ? 2 : 1, row_bytes = p.srcW * bps;
+        for (int pl = 0; pl < 3; pl++) {
+            const dim3 grid(cdiv(row_bytes, 256), sliceH, n);
+            hipLaunchKernelGGL(swsk::sws_k_planarrgb_copy, grid, blk, 0, st, fs, pl, p.srcW, row_bytes, sliceY, sliceH);
+        }
+        if (isALPHA(c->opts.dst_format)) launch_fill_alpha(L, p.srcW, sliceY, sliceH, p.dst_bits > 8 ? p.dst_bits : 0);
+        break;
+    }
     case PLAN_UNSC_ALPHABLEND: {   // ff_sws_alphablendaway: one launch per plane (planar) or one for the packed picture
         const PixDesc *ds = pix_desc(c->opts.src_format);
         swsk::AlphaBlendPlan ap;

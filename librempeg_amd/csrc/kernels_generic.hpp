@@ -40,6 +40,12 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
             const int a = p.src_alpha_opaque ? 255 : f.src[0][(int64_t)row * f.srcStride[0] + 4 * x + p.src_a_pos];
             return a << 6 | a >> 2;
         }
+        if (p.srcKind == SRCK_GBRP) return f.src[3][(int64_t)row * f.srcStride[3] + x] << 6;                                   // planar_rgb_to_a input.c:1188-1194
+        if (p.srcKind == SRCK_GBRP16) {                                                                                            // planar_rgb16_s16_to_a :1235-1247
+            const int bpc = p.src_depth;
+            return (uint16_t)(*(const uint16_t *)(f.src[3] + (int64_t)row * f.srcStride[3] + 2 * x) << (14 - (bpc < 16 ? bpc : 14)));
+        }
+        if (p.srcKind == SRCK_GBRPF32) return f32_to_u16(*(const float *)(f.src[3] + (int64_t)row * f.srcStride[3] + 4 * x));    // planar_rgbf32_to_a :1289-1298
         if (p.srcKind == SRCK_PLANAR16) return *(const uint16_t *)(f.src[3] + (int64_t)row * f.srcStride[3] + 2 * x) >> p.src_shift;   // yuva4xxp9..16: the plane as is
         return f.src[3][(int64_t)row * f.srcStride[3] + x];
     }
@@ -469,6 +475,23 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
                 B = clip_uintp2(((int)((unsigned)Y + (unsigned)B) >> 14) + (1 << 15), 16);
                 ((float *)dg)[i] = __fmul_rn(float_mult, (float)G); ((float *)db)[i] = __fmul_rn(float_mult, (float)B);
                 ((float *)dr)[i] = __fmul_rn(float_mult, (float)R);
+            }
+        }
+        if (p.need_alpha) {   // hasAlpha: the A plane through the luma filter (gbrap*); an alpha plane without source alpha is filled by launch_fill_alpha
+            uint8_t *da = f.dst[3] + (int64_t)y * f.dstStride[3];
+            int A;
+            if (p.dstKind == DSTK_GBRP) {
+                const int SH = 22 + 8 - p.dst_bits;
+                A = 1 << 18;
+                for (int j = 0; j < lfs; j++) A += (int)((unsigned)ALP(j, i) * (unsigned)(int)lf[j]);
+                if (A & 0xF8000000) A = clip_uintp2(A, 27);
+                if (SH != 22) ((uint16_t *)da)[i] = (uint16_t)(A >> (SH - 3)); else da[i] = (uint8_t)(A >> 19);
+            } else {
+                A = -0x40000000;
+                for (int j = 0; j < lfs; j++) A += (int)((unsigned)ALP(j, i) * (unsigned)(int)lf[j]);
+                A >>= 1; A += 0x20002000;
+                if (p.dstKind == DSTK_GBRP16) ((uint16_t *)da)[i] = (uint16_t)(clip_uintp2(A, 30) >> 14);
+                else ((float *)da)[i] = __fmul_rn(1.0f / 65535.0f, (float)(clip_uintp2(A, 30) >> 14));
             }
         }
         return;

@@ -131,7 +131,8 @@ __global__ void __launch_bounds__(256) sws_k_fill_alpha_plane(SwsFrameSet fs, in
     if (x >= w) return;
     const SwsFramePtrs &f = frame_of(fs, blockIdx.z);
     uint8_t *row = f.dst[3] + (int64_t)(y0 + blockIdx.y) * f.dstStride[3];
-    if (bits) ((uint16_t *)row)[x] = (uint16_t)(0xFFFF >> (16 - bits));
+    if (bits == 32) ((uint32_t *)row)[x] = 0x3f800000u;   // fillPlane32, float: 1.0f (swscale_internal.h:1082-1100)
+    else if (bits) ((uint16_t *)row)[x] = (uint16_t)(0xFFFF >> (16 - bits));
     else row[x] = 255;
 }
 
@@ -155,6 +156,18 @@ __global__ void __launch_bounds__(256) sws_k_bswap(const uint8_t *src, int64_t s
     uint8_t *d = dst + y * dstride + (int64_t)i * unit;
     if (unit == 2) { const uint16_t v = *(const uint16_t *)s; *(uint16_t *)d = (uint16_t)((v >> 8) | (v << 8)); }
     else { const uint32_t v = *(const uint32_t *)s; *(uint32_t *)d = __builtin_bswap32(v); }
+}
+
+// planarRgbToplanarRgbWrapper (swscale_unscaled.c:1380-1402) with ff_copyPlane (:126-145) as it is: the width is handed over in pixels and
+// used as a byte count, so a 16-bit row is copied in full only when the two strides are equal (one memcpy over the slice: whole rows
+// but for the last one).  Thread = byte of a row of plane `plane`.
+__global__ void __launch_bounds__(256) sws_k_planarrgb_copy(SwsFrameSet fs, int plane, int w, int row_bytes, int y0, int rows)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    const SwsFramePtrs &f = frame_of(fs, blockIdx.z);
+    const bool whole = f.srcStride[plane] == f.dstStride[plane] && f.srcStride[plane] > 0 && r < rows - 1;
+    if (x >= (whole ? row_bytes : w)) return;
+    f.dst[plane][(int64_t)(y0 + r) * f.dstStride[plane] + x] = f.src[plane][(int64_t)(y0 + r) * f.srcStride[plane] + x];
 }
 
 // gamma_convert (gamma.c:31-58): table look-up on the R, G, B words of an RGBA64LE picture, in place; the alpha word stays

@@ -75,6 +75,12 @@ static const PixDesc g_descs[] = {
     GBRN(AV_PIX_FMT_GBRP9LE, "gbrp9le", 9), GBRN(AV_PIX_FMT_GBRP10LE, "gbrp10le", 10), GBRN(AV_PIX_FMT_GBRP12LE, "gbrp12le", 12),
     GBRN(AV_PIX_FMT_GBRP14LE, "gbrp14le", 14), GBRN(AV_PIX_FMT_GBRP16LE, "gbrp16le", 16),
     { AV_PIX_FMT_GBRPF32LE,"gbrpf32le",3, 0, 0, {{2,4,0,0,32},{0,4,0,0,32},{1,4,0,0,32},{0,0,0,0,0}}, PIXFLAG_PLANAR | PIXFLAG_RGB | PIXFLAG_FLOAT },
+    // planar RGB + alpha plane (pixdesc.c: gbrap, gbrap10/12/14/16, gbrapf32)
+    { AV_PIX_FMT_GBRAP, "gbrap", 4, 0, 0, {{2,1,0,0,8},{0,1,0,0,8},{1,1,0,0,8},{3,1,0,0,8}}, PIXFLAG_PLANAR | PIXFLAG_RGB | PIXFLAG_ALPHA },
+#define GBRAN(F, N, D) { F, N, 4, 0, 0, {{2,2,0,0,D},{0,2,0,0,D},{1,2,0,0,D},{3,2,0,0,D}}, PIXFLAG_PLANAR | PIXFLAG_RGB | PIXFLAG_ALPHA }
+    GBRAN(AV_PIX_FMT_GBRAP10LE, "gbrap10le", 10), GBRAN(AV_PIX_FMT_GBRAP12LE, "gbrap12le", 12), GBRAN(AV_PIX_FMT_GBRAP14LE, "gbrap14le", 14),
+    GBRAN(AV_PIX_FMT_GBRAP16LE, "gbrap16le", 16),
+    { AV_PIX_FMT_GBRAPF32LE, "gbrapf32le", 4, 0, 0, {{2,4,0,0,32},{0,4,0,0,32},{1,4,0,0,32},{3,4,0,0,32}}, PIXFLAG_PLANAR | PIXFLAG_RGB | PIXFLAG_FLOAT | PIXFLAG_ALPHA },
     // packed YUV with 10..16-bit samples (pixdesc.c:239-262, :2327-2350, :2973-3090, :3248-3270); X fields are not components
     { AV_PIX_FMT_Y210LE, "y210le", 3, 1, 0, {{0,4,0,6,10},{0,8,2,6,10},{0,8,6,6,10},{0,0,0,0,0}}, 0 },
     { AV_PIX_FMT_Y212LE, "y212le", 3, 1, 0, {{0,4,0,4,12},{0,8,2,4,12},{0,8,6,4,12},{0,0,0,0,0}}, 0 },
@@ -211,6 +217,8 @@ int pix_be_twin(int fmt)
     { AV_PIX_FMT_GBRP14BE, AV_PIX_FMT_GBRP14LE },
     { AV_PIX_FMT_GBRP16BE, AV_PIX_FMT_GBRP16LE },
     { AV_PIX_FMT_GBRPF32BE, AV_PIX_FMT_GBRPF32LE },
+    { AV_PIX_FMT_GBRAP10BE, AV_PIX_FMT_GBRAP10LE }, { AV_PIX_FMT_GBRAP12BE, AV_PIX_FMT_GBRAP12LE }, { AV_PIX_FMT_GBRAP14BE, AV_PIX_FMT_GBRAP14LE },
+    { AV_PIX_FMT_GBRAP16BE, AV_PIX_FMT_GBRAP16LE }, { AV_PIX_FMT_GBRAPF32BE, AV_PIX_FMT_GBRAPF32LE },
     { AV_PIX_FMT_P010BE, AV_PIX_FMT_P010LE },
     { AV_PIX_FMT_P012BE, AV_PIX_FMT_P012LE },
     { AV_PIX_FMT_P016BE, AV_PIX_FMT_P016LE },

@@ -77,6 +77,7 @@ enum PlanKind {
     PLAN_UNSC_PLANAR2P422, // yuv422pToYuy2/UyvyWrapper, planarToYuy2/UyvyWrapper
     PLAN_UNSC_P4222PLANAR, // yuyv/uyvy ToYuv420/422Wrapper
     PLAN_UNSC_ALPHABLEND,  // ff_sws_alphablendaway (alphablend.c)
+    PLAN_UNSC_PLANARRGB_PLANARRGB,   // planarRgbToplanarRgbWrapper: gbrp <-> gbrap
     PLAN_UNSC_RGB16SHUFFLE,   // rgb48tobgr48 / rgb48to64 / rgb48tobgr64 / rgb64to48 / rgb64tobgr48 (rgb2rgb.c:322-413)
     PLAN_UNSC_PACKED16_GBRP16,// Rgb16ToPlanarRgb16Wrapper
     PLAN_UNSC_GBRP16_PACKED16,// planarRgb16ToRgb16Wrapper

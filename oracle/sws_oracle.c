@@ -128,6 +128,11 @@ static const Desc descs[] = {
     GBRN(ORF_GBRP9LE, "gbrp9le", 9), GBRN(ORF_GBRP10LE, "gbrp10le", 10), GBRN(ORF_GBRP12LE, "gbrp12le", 12),
     GBRN(ORF_GBRP14LE, "gbrp14le", 14), GBRN(ORF_GBRP16LE, "gbrp16le", 16),
     { ORF_GBRPF32LE, "gbrpf32le", 3, 0, 0, {{2,4,0,0,32},{0,4,0,0,32},{1,4,0,0,32}}, PF_PLANAR | PF_RGB | PF_FLOAT },
+    /* planar RGB + alpha plane (pixdesc.c: gbrap, gbrap10/12/14/16, gbrapf32) */
+    { ORF_GBRAP, "gbrap", 4, 0, 0, {{2,1,0,0,8},{0,1,0,0,8},{1,1,0,0,8},{3,1,0,0,8}}, PF_PLANAR | PF_RGB | PF_ALPHA },
+#define GBRAN(F, N, D) { F, N, 4, 0, 0, {{2,2,0,0,D},{0,2,0,0,D},{1,2,0,0,D},{3,2,0,0,D}}, PF_PLANAR | PF_RGB | PF_ALPHA }
+    GBRAN(ORF_GBRAP10LE, "gbrap10le", 10), GBRAN(ORF_GBRAP12LE, "gbrap12le", 12), GBRAN(ORF_GBRAP14LE, "gbrap14le", 14), GBRAN(ORF_GBRAP16LE, "gbrap16le", 16),
+    { ORF_GBRAPF32LE, "gbrapf32le", 4, 0, 0, {{2,4,0,0,32},{0,4,0,0,32},{1,4,0,0,32},{3,4,0,0,32}}, PF_PLANAR | PF_RGB | PF_FLOAT | PF_ALPHA },
     /* packed YUV with 10..16-bit samples (pixdesc.c:239-262, :2327-2350, :2973-3090, :3248-3270); the X fields are not components */
     { ORF_Y210LE, "y210le", 3, 1, 0, {{0,4,0,6,10},{0,8,2,6,10},{0,8,6,6,10}}, 0 },
     { ORF_Y212LE, "y212le", 3, 1, 0, {{0,4,0,4,12},{0,8,2,4,12},{0,8,6,4,12}}, 0 },
@@ -183,6 +188,7 @@ static const Desc *desc_get(int fmt)
  * writers are the LE ones behind AV_RB16 / AV_WB16: input.c:608-629, output.c output_pixel macros); converter selection follows
  * the reference's rules, which only name a byte order for planarToP01xWrapper / planar8ToP01xleWrapper (native-endian only). */
 static const int be_pairs[][2] = {
+    { ORF_GBRAP10BE, ORF_GBRAP10LE }, { ORF_GBRAP12BE, ORF_GBRAP12LE }, { ORF_GBRAP14BE, ORF_GBRAP14LE }, { ORF_GBRAP16BE, ORF_GBRAP16LE }, { ORF_GBRAPF32BE, ORF_GBRAPF32LE },
     { ORF_XV36BE, ORF_XV36LE }, { ORF_XV48BE, ORF_XV48LE }, { ORF_AYUV64BE, ORF_AYUV64LE },
     { ORF_YUVA420P9BE, ORF_YUVA420P9LE }, { ORF_YUVA420P10BE, ORF_YUVA420P10LE }, { ORF_YUVA420P16BE, ORF_YUVA420P16LE }, { ORF_YUVA422P9BE, ORF_YUVA422P9LE }, { ORF_YUVA422P10BE, ORF_YUVA422P10LE }, { ORF_YUVA422P12BE, ORF_YUVA422P12LE }, { ORF_YUVA422P16BE, ORF_YUVA422P16LE }, { ORF_YUVA444P9BE, ORF_YUVA444P9LE }, { ORF_YUVA444P10BE, ORF_YUVA444P10LE }, { ORF_YUVA444P12BE, ORF_YUVA444P12LE }, { ORF_YUVA444P16BE, ORF_YUVA444P16LE },
     { ORF_YA16BE, ORF_YA16LE }, { ORF_GRAYF32BE, ORF_GRAYF32LE }, { ORF_XYZ12BE, ORF_XYZ12LE }, { ORF_NV20BE, ORF_NV20LE }, { ORF_GBRP10MSBBE, ORF_GBRP10MSBLE }, { ORF_GBRP12MSBBE, ORF_GBRP12MSBLE },
@@ -289,7 +295,8 @@ enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
        UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_RGBLOW, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED,
        UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP, UNSC_RGB30_TO_16, UNSC_RGB30_TO_GBRP, UNSC_GBRP_TO_RGB30, UNSC_YUV2MONO, UNSC_U8_TO_F32, UNSC_F32_TO_U8,
        UNSC_PLANAR2P422, UNSC_P4222PLANAR,
-       UNSC_RGB16SHUFFLE, UNSC_PACKED16_TO_GBRP16, UNSC_GBRP16_TO_PACKED16, UNSC_ALPHABLEND };
+       UNSC_RGB16SHUFFLE, UNSC_PACKED16_TO_GBRP16, UNSC_GBRP16_TO_PACKED16, UNSC_ALPHABLEND, UNSC_PLANARRGB_PLANARRGB,
+       UNSC_REFUSE = -1 /* a special converter of the reference that is not restated */ };
 
 struct OrSws {
     OrSwsOpts o;
@@ -1050,6 +1057,28 @@ static int unscaled_alphablend(const OrSws *c, const uint8_t *const src[], const
     return srcSliceH;
 }
 
+/* planarRgbToplanarRgbWrapper (swscale_unscaled.c:1380-1402) with ff_copyPlane (:126-145) as it is: `width` is passed in pixels
+ * and used as a byte count, so a 16-bit row is copied in full only when the two strides are equal (one memcpy over the whole slice) */
+static int unscaled_planarrgb_planarrgb(const OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY, int srcSliceH,
+                                        uint8_t *const dst[], const int dstStride[])
+{
+    const Desc *dd = desc_get(c->o.dst_format);
+    const int w = c->o.src_w;
+    if (!srcSliceH) return 0;
+    for (int k = 0; k < 3; k++) {
+        uint8_t *d = dst[k] + (ptrdiff_t)dstStride[k] * srcSliceY;
+        if (dstStride[k] == srcStride[k] && srcStride[k] > 0) memcpy(d, src[k], (size_t)(srcSliceH - 1) * dstStride[k] + w);
+        else for (int i = 0; i < srcSliceH; i++) memcpy(d + (ptrdiff_t)i * dstStride[k], src[k] + (ptrdiff_t)i * srcStride[k], w);
+    }
+    if (dst[3] && isALPHA(c->o.dst_format))
+        for (int i = 0; i < srcSliceH; i++) {
+            uint8_t *row = dst[3] + (ptrdiff_t)(srcSliceY + i) * dstStride[3];
+            if (dd->c[0].depth > 8) { uint16_t *r16 = (uint16_t *)row; for (int j = 0; j < w; j++) r16[j] = (uint16_t)(0xFFFF >> (16 - dd->c[3].depth)); }
+            else memset(row, 255, w);
+        }
+    return srcSliceH;
+}
+
 static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.c:2392-2706 (subset) */
 {
     const int s = c->o.src_format, d = c->o.dst_format, flags = c->o.flags;
@@ -1124,6 +1153,17 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
     if (isAnyRGB(s) && isPacked(s) && desc_get(s)->c[0].depth == 8 && d == ORF_GBRP) c->unscaled_kind = UNSC_PACKED2GBRP;
     /* planarRgbToRgbWrapper (:2480-2481): gbrp -> byte RGB */
     if (s == ORF_GBRP && isAnyRGB(d) && isPacked(d) && desc_get(d)->c[0].depth == 8) c->unscaled_kind = UNSC_GBRP2PACKED;
+    /* planarRgbToplanarRgbWrapper (:2469-2479): gbrp <-> gbrap at the same depth (native byte order only) */
+    if (!c->src_be && !c->dst_be && isPlanarRGB(s) && isPlanarRGB(d) && !isFloat(s) && !isFloat(d) && isALPHA(s) != isALPHA(d) &&
+        desc_get(s)->c[0].depth == desc_get(d)->c[0].depth && desc_get(s)->c[0].depth != 9 && !desc_get(s)->c[0].shift && !desc_get(d)->c[0].shift)
+        c->unscaled_kind = UNSC_PLANARRGB_PLANARRGB;
+    /* the alpha-carrying rows of the packed <-> planar RGB wrappers are not restated: planarRgbaToRgbWrapper (:2483-2484),
+     * rgbToPlanarRgbaWrapper (:2546-2548), Rgb16ToPlanarRgb16Wrapper / planarRgb16ToRgb16Wrapper with a gbrap side (:2486-2538) */
+    if ((s == ORF_GBRAP && isAnyRGB(d) && isPacked(d) && desc_get(d)->c[0].depth == 8 && !isRGB16(d)) ||
+        (d == ORF_GBRAP && isAnyRGB(s) && isPacked(s) && desc_get(s)->c[0].depth == 8) ||
+        ((c->unscaled_kind == UNSC_PACKED16_TO_GBRP16 || c->unscaled_kind == UNSC_RGB30_TO_GBRP) && isALPHA(d)) ||
+        ((c->unscaled_kind == UNSC_GBRP16_TO_PACKED16 || c->unscaled_kind == UNSC_GBRP_TO_RGB30) && isALPHA(s)))
+        c->unscaled_kind = UNSC_REFUSE;
     /* simple copy (:2647-2668) */
     if (s == d || (s == ORF_YUVA420P && d == ORF_YUV420P) || (s == ORF_YUV420P && d == ORF_YUVA420P) ||
         (isFloat(s) == isFloat(d) &&
@@ -1307,9 +1347,9 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
     if (unscaled && !usesHFilter && !usesVFilter &&
         (c->o.src_range == c->o.dst_range || isAnyRGB(dstFormat) || isFloat(srcFormat) || isFloat(dstFormat))) {
         get_unscaled(c);
+        if (c->unscaled_kind == UNSC_REFUSE) return -1;
         if (c->unscaled_kind) { c->initialized = 1; return 0; }
     }
-    if (c->needAlpha && isPlanarRGB(dstFormat)) return -1; /* gbrap writers not restated */
 
     /* filters (:1675-1735), filterAlign == 1 in the C-only build */
     {
@@ -2065,7 +2105,7 @@ static int unscaled_planarcopy(OrSws *c, const uint8_t *const src[], const int s
     const Desc *ds = desc_get(c->o.src_format), *dd = desc_get(c->o.dst_format);
     const int sf = c->o.src_format, df = c->o.dst_format;
     int nplanes = isGray(df) ? 1 : isSemiPlanarYUV(df) ? 2 : 3;
-    const int with_alpha = isALPHA(df) && isPlanarYUV(df);
+    const int with_alpha = isALPHA(df) && (isPlanarYUV(df) || isPlanarRGB(df));
     for (int plane = 0; plane < 4; plane++) {
         if (plane >= nplanes && !(plane == 3 && with_alpha)) continue;
         if (plane == 3 && !isALPHA(sf)) { /* plane 3 the source cannot feed (:2239-2247): fillPlane 255 / fillPlane16 all ones */
@@ -2281,6 +2321,7 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
             d[i] = (int16_t)((unsigned)(ry * r + gy * g + by * b + rnd) >> (S - 6)); /* unsigned expression, logical shift */
         }
         return tmp; }
+    case ORF_GBRAP:
     case ORF_GBRP: { /* planar_rgb_to_y input.c:1174-1186 */
         const uint8_t *G = src[0] + y * stride[0], *B = src[1] + yc * stride[1], *R = src[2] + yc * stride[2];
         uint16_t *d = (uint16_t *)tmp;
@@ -2288,6 +2329,7 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
             d[i] = (uint16_t)((int)((unsigned)t[RY] * R[i] + (unsigned)t[GY] * G[i] + (unsigned)t[BY] * B[i] + (0x801 << (15 - 7))) >> (15 - 6));
         return tmp; }
     case ORF_GBRP10MSBLE: case ORF_GBRP12MSBLE:   /* planar_rgb16_s10 / s12_to_y: samples >> (16 - bits) (input.c:1216-1232, :1462-1474) */
+    case ORF_GBRAP10LE: case ORF_GBRAP12LE: case ORF_GBRAP14LE: case ORF_GBRAP16LE:
     case ORF_GBRP9LE: case ORF_GBRP10LE: case ORF_GBRP12LE: case ORF_GBRP14LE: case ORF_GBRP16LE: { /* planar_rgb16_s16_to_y input.c:1216-1232 */
         const uint16_t *G = (const uint16_t *)(src[0] + y * stride[0]), *B = (const uint16_t *)(src[1] + yc * stride[1]),
                        *R = (const uint16_t *)(src[2] + yc * stride[2]);
@@ -2309,6 +2351,7 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
         uint16_t *d = (uint16_t *)tmp;
         for (i = 0; i < w; i++) d[i] = (uint16_t)f2u16(s[i]);
         return tmp; }
+    case ORF_GBRAPF32LE:
     case ORF_GBRPF32LE: { /* planar_rgbf32_to_y input.c:1319-1334 */
         const float *G = (const float *)(src[0] + y * stride[0]), *B = (const float *)(src[1] + yc * stride[1]),
                     *R = (const float *)(src[2] + yc * stride[2]);
@@ -2505,6 +2548,7 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
             }
         }
         return; }
+    case ORF_GBRAP:
     case ORF_GBRP: {
         const uint8_t *G = src[0] + yl * stride[0], *B = src[1] + y * stride[1], *R = src[2] + y * stride[2];
         uint16_t *du = (uint16_t *)tu, *dv = (uint16_t *)tv;
@@ -2523,6 +2567,7 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
         }
         return; }
     case ORF_GBRP10MSBLE: case ORF_GBRP12MSBLE:
+    case ORF_GBRAP10LE: case ORF_GBRAP12LE: case ORF_GBRAP14LE: case ORF_GBRAP16LE:
     case ORF_GBRP9LE: case ORF_GBRP10LE: case ORF_GBRP12LE: case ORF_GBRP14LE: case ORF_GBRP16LE: { /* planar_rgb16_s16_to_uv input.c:1248-1270 */
         const uint16_t *G = (const uint16_t *)(src[0] + yl * stride[0]), *B = (const uint16_t *)(src[1] + y * stride[1]),
                        *R = (const uint16_t *)(src[2] + y * stride[2]);
@@ -2535,6 +2580,7 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
                                      (128u << (15 + bpc - 8)) + (1u << (15 + shift - 15))) >> (15 + shift - 14));
         }
         return; }
+    case ORF_GBRAPF32LE:
     case ORF_GBRPF32LE: { /* planar_rgbf32_to_uv input.c:1300-1317 */
         const float *G = (const float *)(src[0] + yl * stride[0]), *B = (const float *)(src[1] + y * stride[1]),
                     *R = (const float *)(src[2] + y * stride[2]);
@@ -3402,6 +3448,31 @@ static void write_planar_rgb_line(const OrSws *c, const Planes *P, uint8_t *cons
             }
         }
     }
+    if (isALPHA(c->o.dst_format)) {   /* the A plane: from the alpha lines through the luma filter (hasAlpha), or filled (swscale.c:536-552) */
+        uint8_t *da = dst[3] + (size_t)y * dstStride[3];
+        const int abits = dd->c[3].depth;
+        for (i = 0; i < dstW; i++) {
+            if (P->alp) {
+                int A;
+                const int32_t *al;
+                if (depth <= 14) {
+                    const int SH = 22 + 8 - depth;
+                    A = 1 << 18;
+                    for (j = 0; j < lfs; j++) { al = P->alp + (size_t)ORMIN(firstLum + j, srcH - 1) * lw; A += (int)(al[i] * (unsigned)lf[j]); }
+                    if (A & 0xF8000000) A = clip_uintp2(A, 27);
+                    if (SH != 22) ((uint16_t *)da)[i] = (uint16_t)(A >> (SH - 3)); else da[i] = (uint8_t)(A >> 19);
+                } else {
+                    A = -0x40000000;
+                    for (j = 0; j < lfs; j++) { al = P->alp + (size_t)ORMIN(firstLum + j, srcH - 1) * lw; A += (int)(al[i] * (unsigned)lf[j]); }
+                    A >>= 1; A += 0x20002000;
+                    if (isf) ((float *)da)[i] = (1.0f / 65535.0f) * (float)(clip_uintp2(A, 30) >> 14);
+                    else ((uint16_t *)da)[i] = (uint16_t)(clip_uintp2(A, 30) >> 14);
+                }
+            } else if (isf) { const uint32_t one = 0x3f800000; memcpy(da + 4 * i, &one, 4); }          /* fillPlane32 */
+            else if (depth > 8) ((uint16_t *)da)[i] = (uint16_t)(0xFFFF >> (16 - abits));               /* fillPlane16 */
+            else da[i] = 255;                                                                           /* fillPlane */
+        }
+    }
 #undef L
 #undef CU
 #undef CV
@@ -3454,6 +3525,14 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
                 const Desc *dsd = desc_get(sf);
                 const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0] + dsd->c[3].offset;
                 for (int i = 0; i < srcW; i++) t0[i] = sp[4 * i];
+                line = t0;
+            } else if (isPlanarRGB(sf)) { /* planar_rgb_to_a (input.c:1188-1194), planar_rgb16_s16_to_a (:1235-1247), planar_rgbf32_to_a (:1289-1298) */
+                const Desc *dsd = desc_get(sf);
+                uint16_t *d16 = (uint16_t *)t0;
+                const uint8_t *sp = src[3] + (ptrdiff_t)y * srcStride[3];
+                if (dsd->flags & PF_FLOAT) for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)f2u16(((const float *)sp)[i]);
+                else if (dsd->c[0].depth == 8) for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)(sp[i] << 6);
+                else { const int bpc = dsd->c[0].depth, sh = 14 - (bpc < 16 ? bpc : 14); for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)(((const uint16_t *)sp)[i] << sh); }
                 line = t0;
             } else if (isAnyRGB(sf)) { /* rgbaToA_c / abgrToA_c input.c:454-472 */
                 const Desc *dsd = desc_get(sf);
@@ -3749,6 +3828,7 @@ static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4
     case UNSC_PACKED16_TO_GBRP16: return unscaled_packed16_gbrp16(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_GBRP16_TO_PACKED16: return unscaled_gbrp16_packed16(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_ALPHABLEND: return unscaled_alphablend(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_PLANARRGB_PLANARRGB: return unscaled_planarrgb_planarrgb(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     }
     {   /* ff_swscale (swscale.c:333-334): "srcStride2[1] *= 1 << c->vChrDrop; srcStride2[2] *= 1 << c->vChrDrop;" -- the chroma planes are read
          * every 2^vChrDrop-th row (packed sources reach the same rows through `y << chrSrcVSub` in their readers) */
@@ -3778,7 +3858,7 @@ const char *or_sws_path_name(const OrSws *c)
                                "rgbToRgb", "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb",
                                "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb", "rgbToRgb", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "yuv2rgb_c", "uint_y_to_float_y", "float_y_to_uint_y",
                                "planarToYuy2", "yuyvToPlanar",
-                               "rgb16Shuffle", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "alphablendaway" };
+                               "rgb16Shuffle", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "alphablendaway", "planarRgbToplanarRgb" };
     return c->cascade[0] ? "cascade" : n[c->unscaled_kind];
 }
 const int32_t *or_sws_rgb2yuv_table(const OrSws *c) { return c->rgb2yuv; }

@@ -55,6 +55,9 @@ enum {
     ORF_MONOWHITE = 9, ORF_MONOBLACK = 10, ORF_XYZ12LE = 99, ORF_XYZ12BE = 100,
     ORF_YUVJ411P = 138, ORF_NV20LE = 102, ORF_NV20BE = 103, ORF_GBRP10MSBBE = 262, ORF_GBRP10MSBLE = 263, ORF_GBRP12MSBBE = 264, ORF_GBRP12MSBLE = 265,
     ORF_GBRP9LE = 73, ORF_GBRP10LE = 75, ORF_GBRP16LE = 77, ORF_GBRP12LE = 135, ORF_GBRP14LE = 137,
+    /* planar RGB with an alpha plane */
+    ORF_GBRAP = 111, ORF_GBRAP16BE = 112, ORF_GBRAP16LE = 113, ORF_GBRAP12BE = 160, ORF_GBRAP12LE = 161, ORF_GBRAP10BE = 162, ORF_GBRAP10LE = 163,
+    ORF_GBRAPF32BE = 176, ORF_GBRAPF32LE = 177, ORF_GBRAP14BE = 225, ORF_GBRAP14LE = 226,
 };
 
 /* libswscale/swscale.h:131-208 */

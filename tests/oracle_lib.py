@@ -45,6 +45,8 @@ _FORMATS = {
     "argb": (25, "packed", 0, 0, 4), "rgba": (26, "packed", 0, 0, 4), "abgr": (27, "packed", 0, 0, 4), "bgra": (28, "packed", 0, 0, 4),
     "0rgb": (118, "packed", 0, 0, 4), "rgb0": (119, "packed", 0, 0, 4), "0bgr": (120, "packed", 0, 0, 4), "bgr0": (121, "packed", 0, 0, 4),
     "gbrp": (71, "rgbp", 0, 0, 1), "gbrpf32le": (175, "rgbp", 0, 0, 4),
+    "gbrap": (111, "rgbap", 0, 0, 1), "gbrap10le": (163, "rgbap", 0, 0, 2), "gbrap12le": (161, "rgbap", 0, 0, 2), "gbrap14le": (226, "rgbap", 0, 0, 2),
+    "gbrap16le": (113, "rgbap", 0, 0, 2), "gbrapf32le": (177, "rgbap", 0, 0, 4),
     "gbrp9le": (73, "rgbp", 0, 0, 2), "gbrp10le": (75, "rgbp", 0, 0, 2), "gbrp12le": (135, "rgbp", 0, 0, 2),
     "gbrp14le": (137, "rgbp", 0, 0, 2), "gbrp16le": (77, "rgbp", 0, 0, 2),
     "gray8": (8, "gray", 0, 0, 1), "gray9le": (173, "gray", 0, 0, 2), "gray10le": (168, "gray", 0, 0, 2),
@@ -52,7 +54,7 @@ _FORMATS = {
 }
 
 # big-endian twins: same layout as the little-endian format, AVPixelFormat value from libavutil/pixfmt.h
-_BE_VALUES = {"ya16be": 109, "grayf32be": 182, "yuva420p9be": 80, "yuva420p10be": 86, "yuva420p16be": 92, "yuva422p9be": 82, "yuva422p10be": 88, "yuva422p12be": 184, "yuva422p16be": 94, "yuva444p9be": 84, "yuva444p10be": 90, "yuva444p12be": 186, "yuva444p16be": 96, "xyz12be": 100, "nv20be": 103, "gbrp10msbbe": 262, "gbrp12msbbe": 264, "xv36be": 215, "xv48be": 241, "ayuv64be": 156, "yuv444p10msbbe": 258, "yuv444p12msbbe": 260, "rgb565be": 36, "rgb555be": 38, "rgb444be": 53, "bgr565be": 40, "bgr555be": 42, "bgr444be": 55, "yuv420p9be": 59, "yuv420p10be": 61, "yuv420p12be": 122, "yuv420p14be": 124, "yuv420p16be": 46, "yuv422p9be": 69, "yuv422p10be": 63, "yuv422p12be": 126, "yuv422p14be": 128, "yuv422p16be": 48, "yuv444p9be": 65, "yuv444p10be": 67, "yuv444p12be": 130, "yuv444p14be": 132, "yuv444p16be": 50, "yuv440p10be": 152, "yuv440p12be": 154, "gray9be": 172, "gray10be": 167, "gray12be": 165, "gray14be": 180, "gray16be": 29, "gbrp9be": 72, "gbrp10be": 74, "gbrp12be": 134, "gbrp14be": 136, "gbrp16be": 76, "gbrpf32be": 174, "p010be": 159, "p012be": 210, "p016be": 170, "p210be": 197, "p212be": 221, "p216be": 201, "p410be": 199, "p412be": 223, "p416be": 203, "rgb48be": 34, "bgr48be": 57, "rgba64be": 104, "bgra64be": 106}
+_BE_VALUES = {"gbrap10be": 162, "gbrap12be": 160, "gbrap14be": 225, "gbrap16be": 112, "gbrapf32be": 176, "ya16be": 109, "grayf32be": 182, "yuva420p9be": 80, "yuva420p10be": 86, "yuva420p16be": 92, "yuva422p9be": 82, "yuva422p10be": 88, "yuva422p12be": 184, "yuva422p16be": 94, "yuva444p9be": 84, "yuva444p10be": 90, "yuva444p12be": 186, "yuva444p16be": 96, "xyz12be": 100, "nv20be": 103, "gbrp10msbbe": 262, "gbrp12msbbe": 264, "xv36be": 215, "xv48be": 241, "ayuv64be": 156, "yuv444p10msbbe": 258, "yuv444p12msbbe": 260, "rgb565be": 36, "rgb555be": 38, "rgb444be": 53, "bgr565be": 40, "bgr555be": 42, "bgr444be": 55, "yuv420p9be": 59, "yuv420p10be": 61, "yuv420p12be": 122, "yuv420p14be": 124, "yuv420p16be": 46, "yuv422p9be": 69, "yuv422p10be": 63, "yuv422p12be": 126, "yuv422p14be": 128, "yuv422p16be": 48, "yuv444p9be": 65, "yuv444p10be": 67, "yuv444p12be": 130, "yuv444p14be": 132, "yuv444p16be": 50, "yuv440p10be": 152, "yuv440p12be": 154, "gray9be": 172, "gray10be": 167, "gray12be": 165, "gray14be": 180, "gray16be": 29, "gbrp9be": 72, "gbrp10be": 74, "gbrp12be": 134, "gbrp14be": 136, "gbrp16be": 76, "gbrpf32be": 174, "p010be": 159, "p012be": 210, "p016be": 170, "p210be": 197, "p212be": 221, "p216be": 201, "p410be": 199, "p412be": 223, "p416be": 203, "rgb48be": 34, "bgr48be": 57, "rgba64be": 104, "bgra64be": 106}
 for _n, _v in list(_BE_VALUES.items()):
     _le = _FORMATS[_n[:-2] + "le"]
     _FORMATS[_n] = (_v,) + _le[1:]
@@ -74,6 +76,8 @@ def plane_layout(fmt, w, h):
         return [((w + 7) >> 3, h)]
     if kind == "rgbp":
         return [(bps * w, h)] * 3
+    if kind == "rgbap":
+        return [(bps * w, h)] * 4
     return [(bps * w, h)]   # packed, gray
 FMT = {k: v[0] for k, v in _FORMATS.items()}
 
@@ -135,7 +139,7 @@ def fill_random(frame, seed):
     f = frame.fmt
     for pi, (a, rb) in enumerate(zip(frame.planes, frame.row_bytes)):
         rows = a.shape[0]
-        m = re.match(r"(?:yuva?4\d\dp|gbrp|gray)(9|10|12|14)[lb]e$", f)
+        m = re.match(r"(?:yuva?4\d\dp|gbra?p|gray)(9|10|12|14)[lb]e$", f)
         depth = 10 if f in ("nv20le", "nv20be") else int(m.group(1)) if m else 0
         mp = re.match(r"(?:p[024]|yuv444p|gbrp)(10|12)(?:msb)?[lb]e$", f) if ("msb" in f or f[0] == "p") else None
         be = f.endswith("be")
@@ -146,7 +150,7 @@ def fill_random(frame, seed):
             d = int(mp.group(1))
             v = (rng.integers(0, 1 << d, size=(rows, rb // 2), dtype=np.uint16) << (16 - d)).astype(np.uint16)
             a[:, :rb] = (v.byteswap() if be else v).view(np.uint8).reshape(rows, rb)
-        elif f in ("gbrpf32le", "gbrpf32be", "grayf32le", "grayf32be"):
+        elif f in ("gbrpf32le", "gbrpf32be", "grayf32le", "grayf32be", "gbrapf32le", "gbrapf32be"):
             v = rng.random(size=(rows, rb // 4), dtype=np.float32)
             flat = v.reshape(-1)
             flat[::257] = -0.25
