@@ -84,6 +84,8 @@ enum AVPixelFormat {
     AV_PIX_FMT_X2RGB10LE = 193, AV_PIX_FMT_X2BGR10LE = 195,
     AV_PIX_FMT_YA8 = 56, AV_PIX_FMT_YA16BE = 109, AV_PIX_FMT_YA16LE = 110,
     AV_PIX_FMT_GRAYF32BE = 182, AV_PIX_FMT_GRAYF32LE = 183,
+    /* 8 / 4 bits per pixel RGB: destinations only (sources need the palette path, swscale_internal.h:936-953 usePal) */
+    AV_PIX_FMT_BGR8 = 17, AV_PIX_FMT_BGR4 = 18, AV_PIX_FMT_BGR4_BYTE = 19, AV_PIX_FMT_RGB8 = 20, AV_PIX_FMT_RGB4 = 21, AV_PIX_FMT_RGB4_BYTE = 22,
     AV_PIX_FMT_MONOWHITE = 9, AV_PIX_FMT_MONOBLACK = 10, AV_PIX_FMT_XYZ12LE = 99, AV_PIX_FMT_XYZ12BE = 100,
     AV_PIX_FMT_YUVJ411P = 138, AV_PIX_FMT_NV20LE = 102, AV_PIX_FMT_NV20BE = 103,
     AV_PIX_FMT_GBRP10MSBBE = 262, AV_PIX_FMT_GBRP10MSBLE = 263, AV_PIX_FMT_GBRP12MSBBE = 264, AV_PIX_FMT_GBRP12MSBLE = 265,

@@ -120,11 +120,12 @@ bool read_ctx(Reader &r, SwsInternal *c)
 }
 } // namespace
 
-// (a gamma cascade is three contexts and two tables: every rank builds it itself, it is not shipped)
-size_t tables_blob_size(const SwsInternal *c) { if (c->cascade_gamma) return 0; Writer w{nullptr, 0, 0, true}; write_ctx(w, c); return w.off; }
+// (a gamma cascade is three contexts and two tables, an error-diffusion context carries a running error line: every rank builds those
+// itself, they are not shipped)
+size_t tables_blob_size(const SwsInternal *c) { if (c->cascade_gamma || c->cascade_ed) return 0; Writer w{nullptr, 0, 0, true}; write_ctx(w, c); return w.off; }
 int tables_blob_export(const SwsInternal *c, void *buf, size_t size)
 {
-    if (c->cascade_gamma) return -95;   // AVERROR(ENOTSUP)
+    if (c->cascade_gamma || c->cascade_ed) return -95;   // AVERROR(ENOTSUP)
     Writer w{(uint8_t *)buf, size, 0, false};
     write_ctx(w, c);
     return w.off <= size ? 0 : -22;

@@ -110,15 +110,21 @@ static int scaler_from_enum(SwsScaler s, int fallback) // scaler_flag, utils.c:1
     }
 }
 
-// every descriptor row of pixdesc.cpp has a reader and a writer
+// every descriptor row of pixdesc.cpp has a reader and a writer, except the 8 / 4 bpp RGB formats: the reference reads those through
+// a palette (usePal, swscale_internal.h:936-953; palToY_c / palToUV_c), which is not built
 static bool fmt_supported_in(int f)
 {
+    if (f == AV_PIX_FMT_RGB8 || f == AV_PIX_FMT_BGR8 || f == AV_PIX_FMT_RGB4_BYTE || f == AV_PIX_FMT_BGR4_BYTE || f == AV_PIX_FMT_RGB4 || f == AV_PIX_FMT_BGR4)
+        return false;
     return pix_desc(f) != nullptr || pix_be_twin(f) >= 0;
 }
 static bool fmt_supported_out(int f)
 {
     return pix_desc(f) != nullptr || pix_be_twin(f) >= 0;
 }
+
+static bool isRGB8class(int f) { return f == AV_PIX_FMT_RGB8 || f == AV_PIX_FMT_BGR8 || f == AV_PIX_FMT_RGB4_BYTE || f == AV_PIX_FMT_BGR4_BYTE; }   // one byte per pixel
+static bool isRGB4bits(int f) { return f == AV_PIX_FMT_RGB4 || f == AV_PIX_FMT_BGR4; }                                                               // two pixels per byte
 
 static bool isRGB16fmt(int f)
 {
@@ -144,6 +150,7 @@ void choose_unscaled(SwsInternal *c)
         if (!isPlanarRGB(d) && pix_desc(d)->comp[0].depth == 8) k = PLAN_UNSC_YUV2RGB;
         else if (d == AV_PIX_FMT_RGB48LE || d == AV_PIX_FMT_BGR48LE) k = PLAN_UNSC_YUV2RGB48;
         else if (isRGB16fmt(d)) k = PLAN_UNSC_YUV2RGB16;   // yuv2rgb_c_16/15/12_ordered_dither, yuv422p_bgr16/15/12 (yuv2rgb.c:612-640)
+        else if (isRGB8class(d) || isRGB4bits(d)) k = PLAN_UNSC_YUV2RGB8;   // yuv2rgb_c_8/4/4b_ordered_dither, yuv422p_bgr8/4/4_byte (:536-538, :557-559, :615-623)
         else if (d == AV_PIX_FMT_GBRP) k = PLAN_UNSC_YUV2GBRP;
         else if (d == AV_PIX_FMT_MONOBLACK) k = PLAN_UNSC_YUV2MONO;   // yuv2rgb_c_1_ordered_dither (yuv2rgb.c:457-517, :624, :671)
         c->dst_slice_align = 2;
@@ -238,6 +245,7 @@ void choose_unscaled(SwsInternal *c)
 
 // ff_sws_init_single_context, utils.c:1137-1835
 static void destroy(SwsInternal *c);
+static SwsInternal *new_context();
 static SwsInternal *alloc_set_opts(int srcW, int srcH, int srcFormat, int dstW, int dstH, int dstFormat, unsigned flags, const double *param);
 static int init_context_impl(SwsInternal *c, SwsFilter *srcFilter, SwsFilter *dstFilter);
 
@@ -312,13 +320,19 @@ int init_single_context(SwsInternal *c)
             !(o->flags & SWS_FAST_BILINEAR)) { flags |= SWS_FULL_CHR_H_INT; o->flags = flags; }
     }
     if (o->dither == SWS_DITHER_AUTO && (flags & SWS_ERROR_DIFFUSION)) o->dither = SWS_DITHER_ED; // :1288-1291
+    if (isRGB8class(dstFormat)) {   // :1293-1316: ordered dither only with chroma pairs, every other dither only with full chroma
+        if (o->dither == SWS_DITHER_AUTO) o->dither = (flags & SWS_FULL_CHR_H_INT) ? SWS_DITHER_ED : SWS_DITHER_BAYER;
+        if (!(flags & SWS_FULL_CHR_H_INT) && (o->dither == SWS_DITHER_ED || o->dither == SWS_DITHER_A_DITHER || o->dither == SWS_DITHER_X_DITHER ||
+                                              o->dither == SWS_DITHER_NONE)) { flags |= SWS_FULL_CHR_H_INT; o->flags = flags; }
+        if ((flags & SWS_FULL_CHR_H_INT) && o->dither == SWS_DITHER_BAYER) o->dither = SWS_DITHER_ED;
+    }
     if (isPlanarRGB(dstFormat) && !(flags & SWS_FULL_CHR_H_INT)) { flags |= SWS_FULL_CHR_H_INT; o->flags = flags; }
     const bool dstMono = dstFormat == AV_PIX_FMT_MONOWHITE || dstFormat == AV_PIX_FMT_MONOBLACK;
     if (dstMono && o->dither == SWS_DITHER_ED) {
         log_msg(c, 0, "error diffusion dither for 1 bpp destinations is not implemented on the HIP path\n");
         return SWS_AVERROR(ENOTSUP);
     }
-    if ((flags & SWS_FULL_CHR_H_INT) && (isRGB16fmt(dstFormat) || dstMono)) {   // "full chroma interpolation ... not yet implemented" (:1325-1358)
+    if ((flags & SWS_FULL_CHR_H_INT) && (isRGB16fmt(dstFormat) || dstMono || isRGB4bits(dstFormat))) {   // "full chroma interpolation ... not yet implemented" (:1325-1358)
         flags &= ~SWS_FULL_CHR_H_INT; o->flags = flags;
     }
     if (isAnyRGB(dstFormat) && !(flags & SWS_FULL_CHR_H_INT)) c->chrDstHSubSample = 1;         // :1359-1360
@@ -423,7 +437,7 @@ int init_single_context(SwsInternal *c)
         log_msg(c, 2, "using alpha blendaway %s -> %s special converter\n", ds->name, dd->name);
         return 0;
     }
-    if (unscaled && !usesHFilter && !usesVFilter &&
+    if (unscaled && !usesHFilter && !usesVFilter && !c->force_scaler &&
         (o->src_range == o->dst_range || isAnyRGB(dstFormat) || isFloatFmt(srcFormat) || isFloatFmt(dstFormat))) { // :1623-1637
         choose_unscaled(c);
         if ((int)c->plan == -1) {
@@ -487,6 +501,35 @@ int init_single_context(SwsInternal *c)
         return 0;
     }
     if (ret != FILTER_OK) return SWS_AVERROR(EINVAL);
+
+    if (isRGB8class(dstFormat) && o->dither == SWS_DITHER_ED) {
+        // Error diffusion (yuv2rgb_write_full, output.c:2084-2108): every pixel depends on its left neighbour and on the row above, and the
+        // error line (c->dither_error, utils.c:1744-1747) lives as long as the context.  The sums that enter the diffusion are R >> 22,
+        // G >> 22, B >> 22, which is the rgb24 full-chroma writer's output: an inner context produces that picture with this context's
+        // geometry, filters and colour tables (the scaler chain always: the reference has no special converter for these destinations),
+        // and a wavefront pass diffuses it into the destination (device.hip, sws_k_ed_rgb8).
+        SwsInternal *in = new_context();
+        if (!in) return SWS_AVERROR(ENOMEM);
+        in->opts = *o;
+        in->opts.dst_format = AV_PIX_FMT_RGB24;
+        in->opts.flags = flags | SWS_FULL_CHR_H_INT;
+        in->srcBE = c->srcBE; in->src0Alpha = c->src0Alpha; in->srcXYZ = c->srcXYZ;   // (the stored source format is the canonical twin)
+        in->force_scaler = true;
+        in->tune = c->tune;
+        in->legacy_init = true;
+        for (int k = 0; k < 4; k++) { in->srcVec[k] = c->srcVec[k]; in->dstVecLen[k] = c->dstVecLen[k]; }
+        sws_setColorspaceDetails(&in->opts, c->srcColorspaceTable, o->src_range, c->dstColorspaceTable, o->dst_range,
+                                 c->brightness, c->contrast, c->saturation);
+        const int r = init_single_context(in);
+        if (r < 0 || in->plan != PLAN_MAIN) { destroy(in); return r < 0 ? r : SWS_AVERROR(EINVAL); }
+        mark_tables_dirty(in);
+        c->cascade[0] = in;
+        c->cascade_ed = true;
+        c->cascade_fmt = AV_PIX_FMT_RGB24; c->cascade_w = dstW; c->cascade_h = dstH;
+        c->plan = PLAN_CASCADE;
+        log_msg(c, 2, "error-diffusion dither: %s through an rgb24 picture and a diffusion pass\n", dd->name);
+        return 0;
+    }
 
     build_range_conv(c->range, o->src_range, o->dst_range, dstFormat, c->dstBpc); // sws_init_swscale, swscale.c:662-695
     c->plan = PLAN_MAIN;

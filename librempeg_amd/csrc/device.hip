@@ -58,7 +58,7 @@ static void dev_state_free(DeviceState *d)
     if (d->stream && d->own_stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
     else if (d->stream) (void)hipStreamSynchronize(d->stream);
     for (void *p : { d->d_tables, d->scratch, d->stage_src, d->stage_dst, (void *)d->d_frames, d->casc_img, d->slice_img, d->d_tilegeom,
-                     d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2, d->casc_img2, d->d_gamma_tab })
+                     d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2, d->casc_img2, d->d_gamma_tab, d->d_ed_err })
         if (p) (void)hipFree(p);
     if (d->h_frames) (void)hipHostFree(d->h_frames);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
@@ -113,6 +113,8 @@ static int dst_kind_of(int f)
     if (f == AV_PIX_FMT_MONOWHITE || f == AV_PIX_FMT_MONOBLACK) return DSTK_MONO;
     if (isAnyRGB(f) && d->comp[0].depth == 10 && d->comp[0].step == 4) return DSTK_RGB30;
     if (isAnyRGB(f) && d->comp[0].step == 2) return DSTK_RGB16;
+    if (f == AV_PIX_FMT_RGB4 || f == AV_PIX_FMT_BGR4) return DSTK_RGB4;
+    if (isAnyRGB(f) && d->comp[0].step == 1) return DSTK_RGB8;
     if (isAnyRGB(f)) return d->comp[0].step == 3 ? DSTK_RGB24 : DSTK_RGB32;
     if (isYUV(f) && isPackedFmt(f) && d->comp[0].depth > 8) return DSTK_PACKEDHI;
     if (isYUV(f) && isPackedFmt(f)) return d->log2_chroma_w ? DSTK_PACKED422 : DSTK_PACKED444;
@@ -247,6 +249,13 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             L.r16 = bpp == 12 ? (rgb16 ? 8 : 0) : (rgb16 ? bpp - 5 : 0);
             L.g16 = bpp == 12 ? 4 : 5;
             L.b16 = bpp == 12 ? (rgb16 ? 0 : 8) : (rgb16 ? 0 : bpp - 5);
+        }
+        if (p.dstKind == DSTK_RGB8 || p.dstKind == DSTK_RGB4) {   // yuv2rgb.c:817-856 (isRgb: rgb8 / rgb4 / rgb4_byte, R in the high bits)
+            const bool rgbo = df == AV_PIX_FMT_RGB8 || df == AV_PIX_FMT_RGB4 || df == AV_PIX_FMT_RGB4_BYTE;
+            L.bpp8 = pix_bits_per_pixel(dd);
+            if (L.bpp8 == 8) { L.r8 = rgbo ? 5 : 0; L.g8 = rgbo ? 2 : 3; L.b8 = rgbo ? 0 : 6; }
+            else { L.r8 = rgbo ? 3 : 0; L.g8 = 1; L.b8 = rgbo ? 0 : 3; }
+            L.dither8 = o.dither;
         }
         {   // 32 bpp wave kernels pack bytes as {c0, g, c2, 255} with c0 = R (or B when swap_rb32) and then permute:
             // rgba: R,G,B,A  bgra: B,G,R,A (swap)  argb: A,R,G,B  abgr: A,B,G,R (swap).  v_perm_b32(px, px, sel):
@@ -643,6 +652,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     case PLAN_UNSC_GBRP_TO_RGB30: c->path_name = "unscaled:planarRgb16ToRgb16"; c->kernel_name = "sws_k_rgb30_convert"; break;
     case PLAN_UNSC_YUV2RGB48: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb48_unscaled"; break;
     case PLAN_UNSC_YUV2RGB16: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb16_unscaled"; break;
+    case PLAN_UNSC_YUV2RGB8: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb8_unscaled"; break;
     case PLAN_UNSC_RGBLOW: c->path_name = "unscaled:rgbToRgb"; c->kernel_name = "sws_k_rgb_low_convert"; break;
     case PLAN_UNSC_PLANAR2P422: c->path_name = "unscaled:planarToYuy2"; c->kernel_name = "sws_k_planar_to_p422"; break;
     case PLAN_UNSC_P4222PLANAR: c->path_name = "unscaled:yuyvToPlanar"; c->kernel_name = "sws_k_p422_to_planar"; break;
@@ -705,7 +715,8 @@ static int plane_geometry(int format, int w, int h, int plane, int *row_bytes, i
         if (d->comp[c].plane == plane) { step = d->comp[c].step; chroma = (c == 1 || c == 2); }
     const bool sub = chroma && !(d->flags & PIXFLAG_RGB);
     const int sw = sub ? -((-w) >> d->log2_chroma_w) : w, sh = sub ? -((-h) >> d->log2_chroma_h) : h;
-    *row_bytes = (format == AV_PIX_FMT_MONOWHITE || format == AV_PIX_FMT_MONOBLACK) ? (w + 7) >> 3 : sw * step;
+    *row_bytes = (format == AV_PIX_FMT_MONOWHITE || format == AV_PIX_FMT_MONOBLACK) ? (w + 7) >> 3 :
+                 (format == AV_PIX_FMT_RGB4 || format == AV_PIX_FMT_BGR4) ? (4 * w + 7) >> 3 : sw * step;   // bit streams: av_image_get_linesize, imgutils.c
     *rows = sh;
     return 0;
 }
@@ -1057,6 +1068,8 @@ int dev_run(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4],
     std::vector<int> sdev(nb_frames), ddev(nb_frames), owner(nb_frames);
     for (int i = 0; i < nb_frames; i++) { sdev[i] = ptr_device(srcFrames[i]->data[0]); ddev[i] = ptr_device(dstFrames[i]->data[0]); }
     ret = sws_hip_plan_shards(nb_frames, sdev.data(), ddev.data(), ndev, c->dev->device, owner.data());
+    // an error-diffusion context carries its error line from frame to frame, per GPU: host frames all go to the home GPU, in order
+    if (ret >= 0 && c->cascade_ed) for (int i = 0; i < nb_frames; i++) if (sdev[i] < 0 && ddev[i] < 0) owner[i] = c->dev->device;
     if (ret < 0) { log_msg(c, 0, "sws_scale_frames(): a frame's source and destination live on different GPUs\n"); return ret; }
 
     const int nps = pix_nb_planes(pix_desc(c->opts.src_format)), npd = pix_nb_planes(pix_desc(c->opts.dst_format));
@@ -1145,6 +1158,28 @@ static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4
         for (int k = 0; k < pix_nb_planes(pix_desc(c->cascade_fmt)); k++) { tmp[k] = (uint8_t *)d->casc_img + offs[k]; tls[k] = ls[k]; }
         r = run_single(c0, cd[0], src, srcStride, sliceY, sliceH, tmp, tls);
         if (r < 0) return r;
+        if (c->cascade_ed) {   // error diffusion of the rgb24 picture into the 8 / 4 bpp destination (context.cpp; sws_k_ed_rgb8)
+            const int df = o.dst_format, W = o.dst_w, H = o.dst_h;
+            const bool rgbo = df == AV_PIX_FMT_RGB8 || df == AV_PIX_FMT_RGB4_BYTE, b8pp = df == AV_PIX_FMT_RGB8 || df == AV_PIX_FMT_BGR8;
+            const int r8 = b8pp ? (rgbo ? 5 : 0) : (rgbo ? 3 : 0), g8 = b8pp ? (rgbo ? 2 : 3) : 1, b8 = b8pp ? (rgbo ? 0 : 6) : (rgbo ? 0 : 3);
+            if (!d->d_ed_err) {   // FF_ALLOCZ_TYPED_ARRAY(c->dither_error[i], dst_w + 3), utils.c:1744-1747
+                HIPCHK(hipMalloc(&d->d_ed_err, sizeof(int) * 3 * (size_t)(W + 3)));
+                HIPCHK(hipMemsetAsync(d->d_ed_err, 0, sizeof(int) * 3 * (size_t)(W + 3), d->stream));
+            }
+            if (is_device_ptr(dst[0])) {
+                launch_ed_rgb8(d->stream, tmp[0], tls[0], dst[0], dstStride[0], W, H, (int *)d->d_ed_err, b8pp ? 8 : 4, r8, g8, b8);
+                HIPCHK(hipGetLastError());
+                return r;
+            }
+            const int ls2 = (W + 255) & ~255;
+            r = grow(c, &d->casc_img2, &d->casc_bytes2, (size_t)ls2 * H);
+            if (r < 0) return r;
+            launch_ed_rgb8(d->stream, tmp[0], tls[0], (uint8_t *)d->casc_img2, ls2, W, H, (int *)d->d_ed_err, b8pp ? 8 : 4, r8, g8, b8);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpy2DAsync(dst[0], (size_t)dstStride[0], d->casc_img2, (size_t)ls2, (size_t)W, (size_t)H, hipMemcpyDeviceToHost, d->stream));
+            HIPCHK(hipStreamSynchronize(d->stream));
+            return c0->opts.dst_h;
+        }
         if (!c->cascade_gamma) return run_single(c1, cd[1], tmp, tls, 0, c0->opts.dst_h, dst, dstStride);
         // gamma cascade: table pass over the RGBA64 source of the scaling step (in place, like gamma_convert on the cascade's own
         // intermediate), scale, table pass over its output, then the conversion to the destination format

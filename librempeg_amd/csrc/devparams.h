@@ -45,6 +45,8 @@ enum DstKind {
     DSTK_PLANARF32,     // grayf32: yuv2plane1_float / yuv2planeX_float_c_template output.c:219-260
     DSTK_MONO,          // monowhite / monoblack: yuv2mono_{X,2,1}_c_template output.c:654-860 (ordered dither)
     DSTK_RGB30,         // x2rgb10le / x2bgr10le: yuv2rgb_write 30 bpp (output.c:1748-1754), yuv2rgb_write_full (:2052-2063)
+    DSTK_RGB8,          // rgb8 / bgr8 / rgb4_byte / bgr4_byte (one byte per pixel): yuv2rgb_write "8/4 bits" output.c:1755-1784, yuv2rgb_write_full :2064-2158
+    DSTK_RGB4,          // rgb4 / bgr4 (two pixels per byte): yuv2rgb_write output.c:1778-1780
     DSTK_RGB16,         // rgb565 / rgb555 / rgb444 (+ bgr): yuv2rgb_write 16/15/12 bpp with ordered dither output.c:1714-1748
 };
 
@@ -73,6 +75,8 @@ struct SwsLutParams {       // closed form of the yuv2rgb LUTs (yuv2rgb.c:680-70
     uint32_t perm32;        // 32 bpp: v_perm_b32 selector moving canonical bytes {first,g,third,alpha} to the format's order
     int32_t swap_rb32;      // 32 bpp: canonical 'first' channel is B (bgra / abgr)
     int32_t bpp30;          // 30 bpp tables (yuv2rgb.c:915-941): 10-bit ramps, rshift / gshift / bshift = 20 / 10 / 0 (or swapped), alpha_or = the X bits
+    int32_t bpp8, r8, g8, b8;       // 8 / 4 bpp byte tables (yuv2rgb.c:817-856): 8 or 4 (0 = not such a format) and the bit position of each field
+    int32_t dither8;                // full-chroma 8 / 4 bpp writers: SwsDither (NONE, A_DITHER or X_DITHER; error diffusion runs as its own pass)
     int32_t bpp16, r16, g16, b16;   // 12/15/16 bpp tables (yuv2rgb.c:853-897): bits per pixel (0 = not such a format) and the bit position of each field
     // 13-bit coefficients for the full-chroma writers (output.c:2005-2020)
     int32_t y_offset, y_coeff, v2r, v2g, u2g, u2b;

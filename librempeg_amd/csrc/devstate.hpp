@@ -34,6 +34,7 @@ struct DeviceState {
     void *stage_dst = nullptr; size_t stage_dst_bytes = 0;
     SwsFramePtrs *d_frames = nullptr, *h_frames = nullptr; int frames_cap = 0, frames_valid = 0;
     void *casc_img = nullptr; size_t casc_bytes = 0; int casc_stride = 0;
+    void *d_ed_err = nullptr;   // error-diffusion line of an 8 / 4 bpp destination: 3 x (dst_w + 3) ints, zeroed once, carried between frames
     void *casc_img2 = nullptr; size_t casc_bytes2 = 0; void *d_gamma_tab = nullptr;   // gamma cascade: second RGBA64 intermediate, the two 65536-entry tables
     void *slice_img = nullptr; size_t slice_bytes = 0;   // source image assembled from sws_scale() slices (scaled path)
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timing = false; bool timed = false;
@@ -81,6 +82,8 @@ void launch_fill_alpha(const LaunchCtx &L, int w, int y0, int rows, int bits);
 void launch_alpha_merge(const LaunchCtx &L, int npix, int y0, int rows, int a_pos);
 void launch_bswap(hipStream_t st, const uint8_t *src, int64_t sstride, uint8_t *dst, int64_t dstride, int rows, int row_bytes, int unit);
 void launch_gamma_rgba64(hipStream_t st, uint8_t *img, int64_t stride, int w, int rows, const uint16_t *table);
+void launch_ed_rgb8(hipStream_t st, const uint8_t *rgb, int64_t rgbStride, uint8_t *dst, int64_t dstStride, int w, int h, int *errline,
+                    int bpp8, int r8, int g8, int b8);
 void launch_xyz12(hipStream_t st, const uint8_t *src, int64_t sstride, uint8_t *dst, int64_t dstride, int w, int rows,
                   const uint16_t *gamma_in, const uint16_t *gamma_out, int to_rgb);
 // ---- k_yuv2rgb.hip: PLAN_UNSC_YUV2RGB (C2a) ----

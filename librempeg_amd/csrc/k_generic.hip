@@ -14,6 +14,7 @@ int launch_generic(const LaunchCtx &L)
     const bool rgb = p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP || p.dstKind == DSTK_GBRP16 ||
                      p.dstKind == DSTK_GBRPF32 || p.dstKind == DSTK_PACKED422 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI ||
                      p.dstKind == DSTK_RGB48 || p.dstKind == DSTK_RGB16 || p.dstKind == DSTK_RGB30 || p.dstKind == DSTK_MONO ||
+                     p.dstKind == DSTK_RGB8 || p.dstKind == DSTK_RGB4 ||
                      p.dstKind == DSTK_YA;   // all written by sws_k_vscale_rgb (packed_vscale / any_vscale)
         const int64_t lumElems = (int64_t)p.srcH * p.dstW, chrElems = (int64_t)p.chrSrcH * p.chrDstW;
         const int64_t frame_elems = lumElems + 2 * chrElems + (p.need_alpha ? lumElems : 0);

@@ -189,6 +189,15 @@ int launch_misc(const LaunchCtx &L)
         hipLaunchKernelGGL(swsk::sws_k_yuv2rgb16_unscaled, grid, blk, 0, st, fs, p, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 0, npairs, sliceY);
         break;
     }
+    case PLAN_UNSC_YUV2RGB8: {
+        const int dstW = p.dstW;
+        const int npairs = ((dstW >> 3) << 2) + ((dstW & 4) ? 2 : 0) + ((dstW & 2) ? 1 : 0); // yuv2rgb.c:198-236
+        const int nrowpairs = (sliceH + 1) >> 1;
+        if (!npairs || !nrowpairs) break;
+        const dim3 grid(cdiv(npairs, 256), nrowpairs, n);
+        hipLaunchKernelGGL(swsk::sws_k_yuv2rgb8_unscaled, grid, blk, 0, st, fs, p, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 0, npairs, sliceY);
+        break;
+    }
     case PLAN_UNSC_RGBLOW: {
         const int sf = c->opts.src_format, df = c->opts.dst_format;
         auto rgbint = [](int f) { return f == AV_PIX_FMT_RGB24 || f == AV_PIX_FMT_BGRA || f == AV_PIX_FMT_ABGR || f == AV_PIX_FMT_RGB565LE ||
@@ -323,6 +332,11 @@ void launch_gamma_rgba64(hipStream_t st, uint8_t *img, int64_t stride, int w, in
     if (w <= 0 || rows <= 0) return;
     const dim3 grid(cdiv(w, 256), rows);
     hipLaunchKernelGGL(swsk::sws_k_gamma_rgba64, grid, dim3(256), 0, st, img, stride, w, rows, table);
+}
+void launch_ed_rgb8(hipStream_t st, const uint8_t *rgb, int64_t rgbStride, uint8_t *dst, int64_t dstStride, int w, int h, int *errline,
+                    int bpp8, int r8, int g8, int b8)
+{
+    hipLaunchKernelGGL(swsk::sws_k_ed_rgb8, dim3(1), dim3(1024), 0, st, rgb, rgbStride, dst, dstStride, w, h, errline, bpp8, r8, g8, b8);
 }
 
 void launch_xyz12(hipStream_t st, const uint8_t *src, int64_t sstride, uint8_t *dst, int64_t dstride, int w, int rows,

@@ -104,6 +104,69 @@ __device__ __forceinline__ int dither_rgb16_main(int bpp, int y, int e, int ch)
     return ch == 0 ? dither_4x4_16(y, e) : ch == 1 ? dither_4x4_16(y, e ^ 1) : dither_4x4_16(y ^ 3, e);
 }
 
+// ---- 8 / 4 bpp destinations (rgb8, bgr8, rgb4, bgr4, rgb4_byte, bgr4_byte) ----
+// ff_dither_8x8_32 / ff_dither_8x8_73 / ff_dither_8x8_220 (output.c:60-95); the reference's ninth row repeats the first
+__device__ __constant__ const uint8_t k_dither_8x8_32[8][8] = {
+    { 17, 9, 23, 15, 16, 8, 22, 14 }, { 5, 29, 3, 27, 4, 28, 2, 26 }, { 21, 13, 19, 11, 20, 12, 18, 10 }, { 0, 24, 6, 30, 1, 25, 7, 31 },
+    { 16, 8, 22, 14, 17, 9, 23, 15 }, { 4, 28, 2, 26, 5, 29, 3, 27 }, { 20, 12, 18, 10, 21, 13, 19, 11 }, { 1, 25, 7, 31, 0, 24, 6, 30 },
+};
+__device__ __constant__ const uint8_t k_dither_8x8_73[8][8] = {
+    { 0, 55, 14, 68, 3, 58, 17, 72 }, { 37, 18, 50, 32, 40, 22, 54, 35 }, { 9, 64, 5, 59, 13, 67, 8, 63 }, { 46, 27, 41, 23, 49, 31, 44, 26 },
+    { 2, 57, 16, 71, 1, 56, 15, 70 }, { 39, 21, 52, 34, 38, 19, 51, 33 }, { 11, 66, 7, 62, 10, 65, 6, 60 }, { 48, 30, 43, 25, 47, 29, 42, 24 },
+};
+__device__ __constant__ const uint8_t k_dither_8x8_220[8][8] = {
+    { 117, 62, 158, 103, 113, 58, 155, 100 }, { 34, 199, 21, 186, 31, 196, 17, 182 }, { 144, 89, 131, 76, 141, 86, 127, 72 },
+    { 0, 165, 41, 206, 10, 175, 52, 217 }, { 110, 55, 151, 96, 120, 65, 162, 107 }, { 28, 193, 14, 179, 38, 203, 24, 189 },
+    { 138, 83, 124, 69, 148, 93, 134, 79 }, { 7, 172, 48, 213, 3, 168, 45, 210 },
+};
+// one field of the byte tables of yuv2rgb.c:817-856.  A plane holds a ramp of n elements that starts `off` elements in, so that
+// index + dither is a centred threshold; what lies around the ramp is unwritten in the reference (never reached) and reads 0 here,
+// like the oracle.  kind 0: yval >> 7, 1: (yval + 43) / 85, 2: (yval + 18) / 36
+__device__ __forceinline__ int lut8_field(const SwsLutParams &L, int k, int off, int n, int kind)
+{
+    const int j = k - off;
+    if ((unsigned)j >= (unsigned)n) return 0;
+    const int yval = lut_luma(L, j);
+    return kind == 0 ? yval >> 7 : kind == 1 ? (yval + 43) / 85 : (yval + 18) / 36;
+}
+// pixel of destination row y, column x from the chroma indices and the luma value (yuv2rgb_write output.c:1755-1784: the dither of
+// the column is added to the table index)
+__device__ __forceinline__ uint32_t lut_rgb8(const SwsLutParams &L, const ChromaIdx &k, int Y, int y, int x)
+{
+    const int TPS = 2048;   // table_plane_size = 1024 + 2 * YUVRGB_TABLE_LUMA_HEADROOM
+    if (L.bpp8 == 8) {
+        const int d32 = k_dither_8x8_32[y & 7][x & 7], d73 = k_dither_8x8_73[y & 7][x & 7];
+        return (uint32_t)((lut8_field(L, k.r + Y + d32, 16, TPS - 38, 2) << L.r8) + (lut8_field(L, k.g + Y + d32, 16, TPS - 38, 2) << L.g8) +
+                          (lut8_field(L, k.b + Y + d73, 37, TPS - 38, 1) << L.b8));
+    }
+    const int d220 = k_dither_8x8_220[y & 7][x & 7], d73 = k_dither_8x8_73[y & 7][x & 7];
+    return (uint32_t)((lut8_field(L, k.r + Y + d220, 110, TPS - 110, 0) << L.r8) + (lut8_field(L, k.g + Y + d73, 37, TPS - 110, 1) << L.g8) +
+                      (lut8_field(L, k.b + Y + d220, 110, TPS - 110, 0) << L.b8));
+}
+// yuv2rgb_write_full's 8 / 4 bpp arm without error diffusion (output.c:2064-2158): R, G, B are the clipped 30-bit sums
+__device__ __forceinline__ uint32_t full_rgb8(const SwsLutParams &L, int R, int G, int B, int i, int y)
+{
+    const bool rgb8 = L.bpp8 == 8;
+    int r, g, b;
+    if (L.dither8 == 0) {   // SWS_DITHER_NONE
+        if (rgb8) { r = clip_uintp2(R >> 27, 3); g = clip_uintp2(G >> 27, 3); b = clip_uintp2(B >> 28, 2); }
+        else { r = clip_uintp2(R >> 29, 1); g = clip_uintp2(G >> 28, 2); b = clip_uintp2(B >> 29, 1); }
+    } else {
+        int dr, dg, db;
+        if (L.dither8 == 4) {   // A_DITHER(u, v) = ((u + v * 236) * 119) & 0xff
+            dr = ((i + y * 236) * 119) & 0xff; dg = ((i + 17 + y * 236) * 119) & 0xff; db = ((i + 34 + y * 236) * 119) & 0xff;
+        } else {                // X_DITHER(u, v) = (((u ^ (v * 237)) * 181) & 0x1ff) / 2
+            dr = (((i ^ (y * 237)) * 181) & 0x1ff) / 2; dg = ((((i + 17) ^ (y * 237)) * 181) & 0x1ff) / 2; db = ((((i + 34) ^ (y * 237)) * 181) & 0x1ff) / 2;
+        }
+        if (rgb8) {
+            r = clip_uintp2(((R >> 19) + dr - 96) >> 8, 3); g = clip_uintp2(((G >> 19) + dg - 96) >> 8, 3); b = clip_uintp2(((B >> 20) + db - 96) >> 8, 2);
+        } else {
+            r = clip_uintp2(((R >> 21) + dr - 256) >> 8, 1); g = clip_uintp2(((G >> 19) + dg - 256) >> 8, 2); b = clip_uintp2(((B >> 21) + db - 256) >> 8, 1);
+        }
+    }
+    return (uint32_t)((r << L.r8) + (g << L.g8) + (b << L.b8));
+}
+
 // ordered-dither rows (swscale.c:42-52 ff_dither_8x8_128, :54 sws_pb_64)
 __device__ __constant__ const uint8_t k_dither_8x8_128[8][8] = {
     {  36, 68,  60, 92,  34, 66,  58, 90 }, { 100,  4, 124, 28,  98,  2, 122, 26 },

@@ -774,6 +774,12 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
             uint32_t *d = (uint32_t *)drow;
             d[2 * i] = lut_rgb30(L, k, Y1);
             if (2 * i + 1 < p.dstW) d[2 * i + 1] = lut_rgb30(L, k, Y2);
+        } else if (p.dstKind == DSTK_RGB8) {    // yuv2rgb_write, "8/4 bits" (output.c:1755-1784): 8x8 ordered dither on the table index
+            drow[2 * i] = (uint8_t)lut_rgb8(L, k, Y1, y, 2 * i);
+            if (2 * i + 1 < p.dstW) drow[2 * i + 1] = (uint8_t)lut_rgb8(L, k, Y2, y, 2 * i + 1);
+        } else if (p.dstKind == DSTK_RGB4) {    // two pixels per byte, the first in the low nibble (output.c:1778-1780); the byte of the last pair of an
+                                                // odd width is stored whole, its high nibble from the line buffers' fill value like the reference
+            drow[i] = (uint8_t)(lut_rgb8(L, k, Y1, y, 2 * i) + (lut_rgb8(L, k, Y2, y, 2 * i + 1) << 4));
         } else if (p.dstKind == DSTK_RGB16) {   // yuv2rgb_write, 12/15/16 bpp: ordered dither on the luma index (output.c:1714-1748)
             uint16_t *d = (uint16_t *)drow;
             const int bpp = L.bpp16;
@@ -824,6 +830,10 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
         if (p.dstKind == DSTK_RGB30) {   // output.c:2052-2063
             const uint32_t r = (uint32_t)(R >> 20), g = (uint32_t)(G >> 20), b = (uint32_t)(B >> 20);
             ((uint32_t *)drow)[i] = (3u << 30) + (r << L.rshift) + (g << 10) + (b << L.bshift);
+            return;
+        }
+        if (p.dstKind == DSTK_RGB8) {    // output.c:2064-2158 (dither none / a_dither / x_dither; error diffusion is a pass of its own)
+            drow[i] = (uint8_t)full_rgb8(L, R, G, B, i, y);
             return;
         }
         uint8_t *d = drow + L.pix_step * i;

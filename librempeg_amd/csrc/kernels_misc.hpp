@@ -179,4 +179,61 @@ __global__ void __launch_bounds__(256) sws_k_gamma_rgba64(uint8_t *img, int64_t 
     px[0] = table[px[0]]; px[1] = table[px[1]]; px[2] = table[px[2]];
 }
 
+// Error diffusion of yuv2rgb_write_full (output.c:2084-2108) for rgb8 / bgr8 / rgb4_byte / bgr4_byte, over the rgb24 picture the
+// inner context wrote (R >> 22, G >> 22, B >> 22).  Pixel (y, i) needs the error of (y, i - 1) and those of (y - 1, i - 1 .. i + 1):
+// a wavefront.  One workgroup; thread r owns row y0 + r of the current group of up to 1024 rows and runs two pixels behind thread
+// r - 1, so that step t handles pixel t - 2r of every row.  Rows hand their errors down through a 4-slot LDS ring per row; the row
+// above the group and the row that outlives the picture live in `errline` (3 x (W + 3) ints, the reference's c->dither_error:
+// element k holds the error of pixel k - 1, elements 0, W + 1 and W + 2 stay 0).  The line is kept between frames like the
+// reference's, which never resets it.
+__global__ void __launch_bounds__(1024) sws_k_ed_rgb8(const uint8_t *__restrict__ rgb, int64_t rgbStride, uint8_t *__restrict__ dst, int64_t dstStride,
+                                                      int W, int H, int *__restrict__ errline, int bpp8, int r8, int g8, int b8)
+{
+    __shared__ int ring[3][1024][4];
+    const int r = threadIdx.x;
+    const bool rgb8 = bpp8 == 8;
+    const int shr = rgb8 ? 5 : 7, shg = rgb8 ? 5 : 6, shb = rgb8 ? 6 : 7;
+    const int maxr = rgb8 ? 7 : 1, maxg = rgb8 ? 7 : 3, maxb = rgb8 ? 3 : 1;
+    const int qr = rgb8 ? 36 : 255, qg = rgb8 ? 36 : 85, qb = rgb8 ? 85 : 255;
+    int *el[3] = { errline, errline + (W + 3), errline + 2 * (W + 3) };
+    for (int y0 = 0; y0 < H; y0 += 1024) {
+        const int NR = min(1024, H - y0);
+        const int y = y0 + r;
+        const bool live = r < NR, last = r == NR - 1;
+        const uint8_t *srow = rgb + (int64_t)y * rgbStride;
+        uint8_t *drow = dst + (int64_t)y * dstStride;
+        int err[3] = { 0, 0, 0 };
+        const int steps = W + 2 * (NR - 1);
+        for (int t = 0; t < steps; t++) {
+            const int i = t - 2 * r;
+            if (live && i >= 0 && i < W) {
+                int v[3] = { srow[3 * i], srow[3 * i + 1], srow[3 * i + 2] };
+                int out[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    int em, e0, ep;
+                    if (r == 0) { em = el[c][i]; e0 = el[c][i + 1]; ep = el[c][i + 2]; }
+                    else {
+                        em = i > 0 ? ring[c][r - 1][(i - 1) & 3] : 0;
+                        e0 = ring[c][r - 1][i & 3];
+                        ep = i + 1 < W ? ring[c][r - 1][(i + 1) & 3] : 0;
+                    }
+                    const int V = v[c] + ((7 * err[c] + em + 5 * e0 + 3 * ep) >> 4);
+                    if (last) el[c][i] = err[c];                       // c->dither_error[c][i] = err[c]: the error of pixel i - 1
+                    const int sh = c == 0 ? shr : c == 1 ? shg : shb, mx = c == 0 ? maxr : c == 1 ? maxg : maxb, q = c == 0 ? qr : c == 1 ? qg : qb;
+                    const int lv = min(max(V >> sh, 0), mx);
+                    err[c] = V - lv * q;
+                    out[c] = lv;
+                    ring[c][r][i & 3] = err[c];
+                    if (last && i == W - 1) el[c][W] = err[c];         // the row's closing store (output.c:2204-2206)
+                }
+                drow[i] = (uint8_t)((out[0] << r8) + (out[1] << g8) + (out[2] << b8));
+            }
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 } // namespace swsk

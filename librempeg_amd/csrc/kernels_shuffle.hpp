@@ -467,6 +467,30 @@ __global__ void __launch_bounds__(256) sws_k_yuv2rgb16_unscaled(SwsFrameSet fs, 
     }
 }
 
+// yuv2rgb_c_8 / 4 / 4b_ordered_dither and yuv422p_bgr8 / bgr4 / bgr4_byte (YUV420FUNC_DITHER / YUV422FUNC_DITHER + PUTRGB8 / PUTRGB4D /
+// PUTRGB4DB, yuv2rgb.c:283-369, :413-455).  One thread = one chroma sample = 2 pixels x 2 rows.  LOADDITHER8 / 4D / 4DB select the rows
+// of the 8x8 tables by the ABSOLUTE even row (yd & 7), the second line of the pair reads the following row; the column is the pixel's.
+__global__ void __launch_bounds__(256) sws_k_yuv2rgb8_unscaled(SwsFrameSet fs, SwsDevParams p, int is422, int npairs, int sliceY)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const SwsLutParams &L = p.lut;
+    const int yrow = 2 * blockIdx.y;
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const int yy = sliceY + yrow + l;
+        const int cr = is422 ? yy : ((sliceY + yrow) >> 1);
+        const int U = f.src[1][(int64_t)cr * f.srcStride[1] + i], V = f.src[2][(int64_t)cr * f.srcStride[2] + i];
+        const ChromaIdx k = lut_chroma(L, U, V);
+        const uint8_t *py = f.src[0] + (int64_t)yy * f.srcStride[0] + 2 * i;
+        uint8_t *drow = f.dst[0] + (int64_t)yy * f.dstStride[0];
+        const uint32_t v0 = lut_rgb8(L, k, py[0], yy, 2 * i), v1 = lut_rgb8(L, k, py[1], yy, 2 * i + 1);
+        if (p.dstKind == DSTK_RGB4) drow[i] = (uint8_t)(v0 | (v1 << 4));
+        else { drow[2 * i] = (uint8_t)v0; drow[2 * i + 1] = (uint8_t)v1; }
+    }
+}
+
 // rgbToRgbWrapper with the 12/15/16 bpp converters of rgb2rgb.c:179-320 and rgb2rgb_template.c:85-316: bit-field shuffles in "int"
 // order (a 16-bit pixel has a high, a middle and a low field; a 24/32 bpp pixel three bytes in memory order, after the alpha byte
 // for the _1 layouts).  same = both formats have the same channel order "in int" (findRgbConvFn's first switch), else the second.

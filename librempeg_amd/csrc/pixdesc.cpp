@@ -109,6 +109,13 @@ static const PixDesc g_descs[] = {
     { AV_PIX_FMT_GRAYF32LE, "grayf32le", 1, 0, 0, {{0,4,0,0,32},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_FLOAT },
     { AV_PIX_FMT_MONOWHITE, "monow", 1, 0, 0, {{0,1,0,0,1},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_RGB },   // 1 bit per pixel, MSB first; isAnyRGB() counts them in
     { AV_PIX_FMT_MONOBLACK, "monob", 1, 0, 0, {{0,1,0,7,1},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_RGB },
+    // 8 / 4 bpp RGB (libavutil/pixdesc.c:495-566), destinations only; rgb4 / bgr4 are bit streams (step and offset count bits)
+    { AV_PIX_FMT_BGR8, "bgr8", 3, 0, 0, {{0,1,0,0,3},{0,1,0,3,3},{0,1,0,6,2},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_BGR4, "bgr4", 3, 0, 0, {{0,4,3,0,1},{0,4,1,0,2},{0,4,0,0,1},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_BGR4_BYTE, "bgr4_byte", 3, 0, 0, {{0,1,0,0,1},{0,1,0,1,2},{0,1,0,3,1},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_RGB8, "rgb8", 3, 0, 0, {{0,1,0,5,3},{0,1,0,2,3},{0,1,0,0,2},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_RGB4, "rgb4", 3, 0, 0, {{0,4,0,0,1},{0,4,1,0,2},{0,4,3,0,1},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_RGB4_BYTE, "rgb4_byte", 3, 0, 0, {{0,1,0,3,1},{0,1,0,1,2},{0,1,0,0,1},{0,0,0,0,0}}, PIXFLAG_RGB },
     { AV_PIX_FMT_XYZ12LE, "xyz12le", 3, 0, 0, {{0,6,0,4,12},{0,6,2,4,12},{0,6,4,4,12},{0,0,0,0,0}}, 0 },   // only ever seen before the handle_xyz() aliasing
     { AV_PIX_FMT_X2RGB10LE, "x2rgb10le", 3, 0, 0, {{0,4,2,4,10},{0,4,1,2,10},{0,4,0,0,10},{0,0,0,0,0}}, PIXFLAG_RGB },
     { AV_PIX_FMT_X2BGR10LE, "x2bgr10le", 3, 0, 0, {{0,4,0,0,10},{0,4,1,2,10},{0,4,2,4,10},{0,0,0,0,0}}, PIXFLAG_RGB },

@@ -87,7 +87,7 @@ enum PlanKind {
     PLAN_UNSC_RGB30_TO_16,    // x2rgb10to48 / x2rgb10to64 / x2rgb10tobgr48 / x2rgb10tobgr64 (rgb2rgb.c:415-471)
     PLAN_UNSC_RGB30_TO_GBRP,  // Rgb16ToPlanarRgb16Wrapper + packed30togbra10
     PLAN_UNSC_GBRP_TO_RGB30,  // planarRgb16ToRgb16Wrapper + gbr16ptopacked30
-    PLAN_UNSC_YUV2RGB48, PLAN_UNSC_YUV2RGB16, PLAN_UNSC_RGBLOW,      // yuv2rgb_c_48 / yuv2rgb_c_bgr48 (yuv2rgb.c:107-125, :505-508)
+    PLAN_UNSC_YUV2RGB48, PLAN_UNSC_YUV2RGB16, PLAN_UNSC_YUV2RGB8, PLAN_UNSC_RGBLOW,      // yuv2rgb_c_48 / yuv2rgb_c_bgr48 (yuv2rgb.c:107-125, :505-508)
     PLAN_MAIN,             // ff_swscale chain
     PLAN_CASCADE,          // two contexts through an intermediate image
 };
@@ -158,6 +158,8 @@ struct SwsInternal {
     SwsInternal *cascade[3] = {nullptr, nullptr, nullptr};   // [2]: third step of the gamma cascade (RGBA64LE -> destination format)
     int cascade_mainindex = 0;    // the child sws_setColorspaceDetails() is forwarded to (utils.c:909-910): 1 for the alpha-blend cascade
     bool cascade_gamma = false;   // gamma-correct scaling (utils.c:1461-1522): cascade[1] scales RGBA64 between two in-place table passes
+    bool cascade_ed = false;      // 8 / 4 bpp destination with error diffusion: cascade[0] writes rgb24 at the destination size, a diffusion pass follows
+    bool force_scaler = false;    // (inner context of the above) never take an unscaled special converter
     int cascade_fmt = -1, cascade_w = 0, cascade_h = 0;
     std::string path_name, kernel_name;
     DeviceState *dev = nullptr;             // state on the context's home GPU

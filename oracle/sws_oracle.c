@@ -148,6 +148,14 @@ static const Desc descs[] = {
     { ORF_GRAYF32LE, "grayf32le", 1, 0, 0, {{0,4,0,0,32}}, PF_FLOAT },
     { ORF_MONOWHITE, "monow", 1, 0, 0, {{0,1,0,0,1}}, PF_RGB },   /* 1 bit per pixel, MSB first; isAnyRGB() counts them in (swscale_internal.h:876-882) */
     { ORF_MONOBLACK, "monob", 1, 0, 0, {{0,1,0,7,1}}, PF_RGB },
+    /* 8 / 4 bpp RGB (pixdesc.c:495-566); rgb4 / bgr4 are bit streams of two pixels per byte, first pixel in the low nibble as the
+     * writers store them (output.c:1778-1780) */
+    { ORF_BGR8, "bgr8", 3, 0, 0, {{0,1,0,0,3},{0,1,0,3,3},{0,1,0,6,2}}, PF_RGB },
+    { ORF_BGR4, "bgr4", 3, 0, 0, {{0,4,3,0,1},{0,4,1,0,2},{0,4,0,0,1}}, PF_RGB },
+    { ORF_BGR4_BYTE, "bgr4_byte", 3, 0, 0, {{0,1,0,0,1},{0,1,0,1,2},{0,1,0,3,1}}, PF_RGB },
+    { ORF_RGB8, "rgb8", 3, 0, 0, {{0,1,0,5,3},{0,1,0,2,3},{0,1,0,0,2}}, PF_RGB },
+    { ORF_RGB4, "rgb4", 3, 0, 0, {{0,4,0,0,1},{0,4,1,0,2},{0,4,3,0,1}}, PF_RGB },
+    { ORF_RGB4_BYTE, "rgb4_byte", 3, 0, 0, {{0,1,0,3,1},{0,1,0,1,2},{0,1,0,0,1}}, PF_RGB },
     { ORF_XYZ12LE, "xyz12le", 3, 0, 0, {{0,6,0,4,12},{0,6,2,4,12},{0,6,4,4,12}}, 0 },   /* only ever seen before handle_xyz() */
     { ORF_X2RGB10LE, "x2rgb10le", 3, 0, 0, {{0,4,2,4,10},{0,4,1,2,10},{0,4,0,0,10}}, PF_RGB },
     { ORF_X2BGR10LE, "x2bgr10le", 3, 0, 0, {{0,4,0,0,10},{0,4,1,2,10},{0,4,2,4,10}}, PF_RGB },
@@ -174,6 +182,8 @@ static const Desc descs[] = {
 static int isPackedHi(int f) { return f == ORF_Y210LE || f == ORF_Y212LE || f == ORF_Y216LE || f == ORF_XV30LE || f == ORF_V30XLE || f == ORF_XV36LE || f == ORF_XV48LE || f == ORF_AYUV64LE; }
 static int isPacked444(int f) { return f == ORF_VYU444 || f == ORF_UYVA || f == ORF_AYUV || f == ORF_VUYA || f == ORF_VUYX; }
 static int isRGB30(int f) { return f == ORF_X2RGB10LE || f == ORF_X2BGR10LE; }
+static int isRGB8class(int f) { return f == ORF_RGB8 || f == ORF_BGR8 || f == ORF_RGB4_BYTE || f == ORF_BGR4_BYTE; }   /* one byte per pixel */
+static int isRGB4bits(int f) { return f == ORF_RGB4 || f == ORF_BGR4; }                                                   /* two pixels per byte */
 static int isRGB16(int f) { return f == ORF_RGB565LE || f == ORF_RGB555LE || f == ORF_RGB444LE || f == ORF_BGR565LE || f == ORF_BGR555LE || f == ORF_BGR444LE; }
 
 static const Desc *desc_get(int fmt)
@@ -327,6 +337,7 @@ struct OrSws {
     /* gamma cascade (utils.c:1461-1522): cascade[1] scales RGBA64 -> RGBA64 between two in-place table passes, cascade[2] converts to the
      * destination format from a second intermediate */
     int casc_mainindex;   /* the child sws_setColorspaceDetails() is forwarded to (utils.c:909-910): 1 for the alpha-blend cascade */
+    int *dither_error[3];   /* utils.c:1744-1747: dst_w + 3 zeroed ints per channel; never reset between frames or slices */
     int casc_gamma; uint8_t *casc_tmp2; int casc_stride2; uint16_t *gamma_tab, *inv_gamma_tab;
     int initialized;
 };
@@ -636,7 +647,8 @@ static int yuv2rgb_init_tables(OrSws *c, const int inv_table[4], int fullRange,
 {
     const int df = c->o.dst_format;
     /* AV_PIX_FMT_RGB32 = BGRA, RGB32_1 = ABGR, BGR32 = RGBA, BGR32_1 = ARGB on little endian */
-    const int isRgb = df == ORF_BGRA || df == ORF_ABGR || df == ORF_BGR24 || df == ORF_RGB565LE || df == ORF_RGB555LE || df == ORF_RGB444LE || df == ORF_X2RGB10LE;
+    const int isRgb = df == ORF_BGRA || df == ORF_ABGR || df == ORF_BGR24 || df == ORF_RGB565LE || df == ORF_RGB555LE || df == ORF_RGB444LE || df == ORF_X2RGB10LE ||
+                      df == ORF_RGB8 || df == ORF_RGB4 || df == ORF_RGB4_BYTE;
     const int bpp = c->dstFormatBpp;
     const int yoffs = (fullRange ? 384 : 326) + HEADROOM;
     int64_t crv = inv_table[0], cbu = inv_table[1], cgu = -inv_table[2], cgv = -inv_table[3];
@@ -717,6 +729,44 @@ static int yuv2rgb_init_tables(OrSws *c, const int inv_table[4], int fullRange,
             yb += cy;
         }
         fill_table(c->table_gU, cgu, yoffs);
+        fill_gv_table(c->table_gV, cgv);
+        c->has_lut = 1;
+        break;
+    }
+    case 4: { /* yuv2rgb.c:817-836 (rgb4 / bgr4 / rgb4_byte / bgr4_byte): three byte planes whose ramps start at element 110 / 37 / 110, so
+               * that index + dither (0..220 / 0..72) is a centred threshold.  The elements before a ramp and the 73 after the green one are
+               * left unwritten by the reference (av_malloc) and never reached by sane coefficients: zero here */
+        const int rbase = isRgb ? 3 : 0, gbase = 1, bbase = isRgb ? 0 : 3;
+        c->yuvTable = calloc(TABLE_PLANE * 3, 1);
+        c->lut_elem = 1;
+        for (i = 0; i < TABLE_PLANE - 110; i++) {
+            const int yval = clip_u8((int)((yb + 0x8000) >> 16));
+            c->yuvTable[i + 110] = (uint8_t)((yval >> 7) << rbase);
+            c->yuvTable[i + 37 + TABLE_PLANE] = (uint8_t)(((yval + 43) / 85) << gbase);
+            c->yuvTable[i + 110 + 2 * TABLE_PLANE] = (uint8_t)((yval >> 7) << bbase);
+            yb += cy;
+        }
+        fill_table(c->table_rV, crv, yoffs);
+        fill_table(c->table_gU, cgu, yoffs + TABLE_PLANE);
+        fill_table(c->table_bU, cbu, yoffs + 2 * TABLE_PLANE);
+        fill_gv_table(c->table_gV, cgv);
+        c->has_lut = 1;
+        break;
+    }
+    case 8: { /* yuv2rgb.c:837-856 (rgb8 / bgr8): ramps start at element 16 / 16 / 37 (dither 0..31 / 0..31 / 0..72); unwritten elements zero */
+        const int rbase = isRgb ? 5 : 0, gbase = isRgb ? 2 : 3, bbase = isRgb ? 0 : 6;
+        c->yuvTable = calloc(TABLE_PLANE * 3, 1);
+        c->lut_elem = 1;
+        for (i = 0; i < TABLE_PLANE - 38; i++) {
+            const int yval = clip_u8((int)((yb + 0x8000) >> 16));
+            c->yuvTable[i + 16] = (uint8_t)(((yval + 18) / 36) << rbase);
+            c->yuvTable[i + 16 + TABLE_PLANE] = (uint8_t)(((yval + 18) / 36) << gbase);
+            c->yuvTable[i + 37 + 2 * TABLE_PLANE] = (uint8_t)(((yval + 43) / 85) << bbase);
+            yb += cy;
+        }
+        fill_table(c->table_rV, crv, yoffs);
+        fill_table(c->table_gU, cgu, yoffs + TABLE_PLANE);
+        fill_table(c->table_bU, cbu, yoffs + 2 * TABLE_PLANE);
         fill_gv_table(c->table_gV, cgv);
         c->has_lut = 1;
         break;
@@ -943,6 +993,7 @@ void or_sws_free(OrSws *c)
     free(c->hLumFilter); free(c->hChrFilter); free(c->vLumFilter); free(c->vChrFilter);
     free(c->hLumFilterPos); free(c->hChrFilterPos); free(c->vLumFilterPos); free(c->vChrFilterPos);
     free(c->yuvTable);
+    free(c->dither_error[0]); free(c->dither_error[1]); free(c->dither_error[2]);
     or_sws_free(c->cascade[0]); or_sws_free(c->cascade[1]); or_sws_free(c->cascade[2]);
     free(c->casc_tmp2); free(c->gamma_tab); free(c->inv_gamma_tab);
     free(c->casc_tmp[0]); free(c->casc_tmp[1]); free(c->casc_tmp[2]); free(c->casc_tmp[3]);
@@ -1091,7 +1142,8 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         /* yuv2rgb_c_24_rgb/_bgr, yuv2rgb_c_32, yuv420p_gbrp_c / yuv422p_gbrp_c; NULL (-> scaler chain) for gbrp9..16/f32 */
         if (d == ORF_RGB24 || d == ORF_BGR24 || d == ORF_RGBA || d == ORF_BGRA || d == ORF_ARGB || d == ORF_ABGR || d == ORF_GBRP ||
             d == ORF_RGB48LE || d == ORF_BGR48LE ||   /* yuv2rgb_c_48 / yuv2rgb_c_bgr48 (yuv2rgb.c:107-125, :505-508) */
-            isRGB16(d))                                /* yuv2rgb_c_16/15/12_ordered_dither, yuv422p_bgr16/15/12 (:533-535, :554-556, :612-640) */
+            isRGB16(d) ||                              /* yuv2rgb_c_16/15/12_ordered_dither, yuv422p_bgr16/15/12 (:533-535, :554-556, :612-640) */
+            isRGB8class(d) || isRGB4bits(d))           /* yuv2rgb_c_8/4/4b_ordered_dither, yuv422p_bgr8/4/4_byte (:536-538, :557-559, :615-623) */
             c->unscaled_kind = UNSC_YUV2RGB;
         else if (d == ORF_MONOBLACK) c->unscaled_kind = UNSC_YUV2MONO;   /* yuv2rgb_c_1_ordered_dither (yuv2rgb.c:457-517, :624, :671) */
         else if (d == ORF_RGBA64LE || d == ORF_BGRA64LE) c->unscaled_kind = UNSC_NONE; /* no C converter: ff_yuv2rgb_get_func_ptr returns NULL */
@@ -1203,6 +1255,7 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
     srcFormat = c->o.src_format; dstFormat = c->o.dst_format;
     ds = desc_get(srcFormat); dd = desc_get(dstFormat);
     if (!ds || !dd) return -1;
+    if (isRGB8class(srcFormat) || isRGB4bits(srcFormat)) return -1;   /* palette-expanded inputs (usePal, swscale_internal.h:936-953): not restated */
 
     i = flags & (OR_SWS_POINT | OR_SWS_AREA | OR_SWS_BILINEAR | OR_SWS_FAST_BILINEAR | OR_SWS_BICUBIC |
                  OR_SWS_X | OR_SWS_GAUSS | OR_SWS_LANCZOS | OR_SWS_SINC | OR_SWS_SPLINE | OR_SWS_BICUBLIN);
@@ -1230,9 +1283,17 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
             flags |= OR_SWS_FULL_CHR_H_INT; c->o.flags = flags;
         }
     }
+    if (c->o.dither == 1 && (flags & OR_SWS_ERROR_DIFFUSION)) c->o.dither = 3;   /* :1288-1291 */
+    if (isRGB8class(dstFormat)) {   /* :1293-1316: ordered dither only with chroma pairs, everything else only with full chroma */
+        if (c->o.dither == 1) c->o.dither = (flags & OR_SWS_FULL_CHR_H_INT) ? 3 : 2;
+        if (!(flags & OR_SWS_FULL_CHR_H_INT) && (c->o.dither == 3 || c->o.dither == 4 || c->o.dither == 5 || c->o.dither == 0)) {
+            flags |= OR_SWS_FULL_CHR_H_INT; c->o.flags = flags;
+        }
+        if ((flags & OR_SWS_FULL_CHR_H_INT) && c->o.dither == 2) c->o.dither = 3;
+    }
     if (isPlanarRGB(dstFormat) && !(flags & OR_SWS_FULL_CHR_H_INT)) { flags |= OR_SWS_FULL_CHR_H_INT; c->o.flags = flags; }
     if (isMono(dstFormat) && c->o.dither == 3) return -1;   /* SWS_DITHER_ED for 1 bpp (yuv2mono_*_c_template's error diffusion): not restated */
-    if ((flags & OR_SWS_FULL_CHR_H_INT) && (isRGB16(dstFormat) || isMono(dstFormat))) { /* "full chroma interpolation ... not yet implemented" (:1325-1358) */
+    if ((flags & OR_SWS_FULL_CHR_H_INT) && (isRGB16(dstFormat) || isMono(dstFormat) || isRGB4bits(dstFormat))) { /* "full chroma interpolation ... not yet implemented" (:1325-1358) */
         flags &= ~OR_SWS_FULL_CHR_H_INT; c->o.flags = flags;
     }
     if (isAnyRGB(dstFormat) && !(flags & OR_SWS_FULL_CHR_H_INT)) c->chrDstHSub = 1; /* :1359 */
@@ -1298,6 +1359,8 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
 
     /* alpha: src alpha dropped -> reference cascades through alpha blend only if alpha_blend != NONE (default NONE) */
     c->needAlpha = isALPHA(srcFormat) && isALPHA(dstFormat);
+    if (isRGB8class(dstFormat))   /* utils.c:1744-1747 (allocated for every context there; only these writers use them) */
+        for (i = 0; i < 3; i++) if (!c->dither_error[i]) c->dither_error[i] = calloc((size_t)dstW + 3, sizeof(int));
 
     const int usesHFilter = (c->o.src_vec[0] && c->o.src_vec_len[0] > 1) || (c->o.src_vec[2] && c->o.src_vec_len[2] > 1) ||
                             c->o.dst_vec_len[0] > 1 || c->o.dst_vec_len[2] > 1;   /* utils.c:1256-1263 */
@@ -1488,6 +1551,32 @@ static inline uint32_t lut_at(const OrSws *c, int idx)
     return ((const uint32_t *)c->yuvTable)[idx];
 }
 
+/* ff_dither_8x8_32 / ff_dither_8x8_73 (output.c:60-82), nine rows like the reference's tables (row 8 = row 0) */
+static const uint8_t dither_8x8_32[9][8] = {
+    { 17, 9, 23, 15, 16, 8, 22, 14 }, { 5, 29, 3, 27, 4, 28, 2, 26 }, { 21, 13, 19, 11, 20, 12, 18, 10 }, { 0, 24, 6, 30, 1, 25, 7, 31 },
+    { 16, 8, 22, 14, 17, 9, 23, 15 }, { 4, 28, 2, 26, 5, 29, 3, 27 }, { 20, 12, 18, 10, 21, 13, 19, 11 }, { 1, 25, 7, 31, 0, 24, 6, 30 },
+    { 17, 9, 23, 15, 16, 8, 22, 14 },
+};
+static const uint8_t dither_8x8_73[9][8] = {
+    { 0, 55, 14, 68, 3, 58, 17, 72 }, { 37, 18, 50, 32, 40, 22, 54, 35 }, { 9, 64, 5, 59, 13, 67, 8, 63 }, { 46, 27, 41, 23, 49, 31, 44, 26 },
+    { 2, 57, 16, 71, 1, 56, 15, 70 }, { 39, 21, 52, 34, 38, 19, 51, 33 }, { 11, 66, 7, 62, 10, 65, 6, 60 }, { 48, 30, 43, 25, 47, 29, 42, 24 },
+    { 0, 55, 14, 68, 3, 58, 17, 72 },
+};
+static const uint8_t dither_8x8_220_w[9][8] = {   /* ff_dither_8x8_220 (output.c:84-95, the `#if 1` variant) */
+    { 117, 62, 158, 103, 113, 58, 155, 100 }, { 34, 199, 21, 186, 31, 196, 17, 182 }, { 144, 89, 131, 76, 141, 86, 127, 72 },
+    { 0, 165, 41, 206, 10, 175, 52, 217 }, { 110, 55, 151, 96, 120, 65, 162, 107 }, { 28, 193, 14, 179, 38, 203, 24, 189 },
+    { 138, 83, 124, 69, 148, 93, 134, 79 }, { 7, 172, 48, 213, 3, 168, 45, 210 }, { 117, 62, 158, 103, 113, 58, 155, 100 },
+};
+
+/* the three ordered-dither offsets of pixel column x in row y for the 8 / 4 bpp tables (yuv2rgb_write output.c:1762-1776; the same
+ * rows LOADDITHER8 / LOADDITHER4D / LOADDITHER4DB pick in yuv2rgb.c:415-455) */
+static void dither_rgb8_rows(int fmt, int row, int col, int *dr, int *dg, int *db)   /* row 0..8, col 0..7 */
+{
+    if (fmt == ORF_RGB8 || fmt == ORF_BGR8) { *dr = *dg = dither_8x8_32[row][col]; *db = dither_8x8_73[row][col]; }
+    else { *dr = *db = dither_8x8_220_w[row][col]; *dg = dither_8x8_73[row][col]; }
+}
+static void dither_rgb8(int fmt, int y, int x, int *dr, int *dg, int *db) { dither_rgb8_rows(fmt, y & 7, x & 7, dr, dg, db); }
+
 /* ordered-dither rows of output.c:40-58 (ff_dither_2x2_4, ff_dither_2x2_8, ff_dither_4x4_16) */
 static const uint8_t dither_2x2_4[3][8] = { { 1, 3, 1, 3, 1, 3, 1, 3 }, { 2, 0, 2, 0, 2, 0, 2, 0 }, { 1, 3, 1, 3, 1, 3, 1, 3 } };
 static const uint8_t dither_2x2_8[3][8] = { { 6, 2, 6, 2, 6, 2, 6, 2 }, { 0, 4, 0, 4, 0, 4, 0, 4 }, { 6, 2, 6, 2, 6, 2, 6, 2 } };
@@ -1528,6 +1617,14 @@ static int unscaled_yuv2rgb(OrSws *c, const uint8_t *const src[], const int srcS
                         else { dr = dg = db = dither_4x4_16[(y & 3) + l][o + e]; }
                         v = (uint16_t)(lut_at(c, r + Y + dr) + lut_at(c, g + Y + dg) + lut_at(c, b + Y + db));
                         memcpy(out + 4 * i + 2 * k, &v, 2);
+                    } else if (isRGB8class(d) || isRGB4bits(d)) { /* PUTRGB8 / PUTRGB4D / PUTRGB4DB with LOADDITHER8 / 4D / 4DB (yuv2rgb.c:413-455): rows
+                                                                   * of the 8x8 tables by the ABSOLUTE even row, the second line reads the following row */
+                        int dr, dg, db;
+                        uint8_t v;
+                        dither_rgb8_rows(d, ((y + srcSliceY) & 7) + l, 2 * (i & 3) + k, &dr, &dg, &db);
+                        v = (uint8_t)(lut_at(c, r + Y + dr) + lut_at(c, g + Y + dg) + lut_at(c, b + Y + db));
+                        if (isRGB4bits(d)) { if (!k) out[i] = v; else out[i] = (uint8_t)(out[i] | (v << 4)); }
+                        else out[2 * i + k] = v;
                     } else if (d == ORF_RGB48LE || d == ORF_BGR48LE) { /* PUTRGB48 / PUTBGR48 yuv2rgb.c:107-125: each 8-bit LUT value fills both bytes */
                         uint8_t R = (uint8_t)lut_at(c, r + Y), G = (uint8_t)lut_at(c, g + Y), B = (uint8_t)lut_at(c, b + Y);
                         uint8_t *p = out + 12 * i + 6 * k;
@@ -2836,6 +2933,15 @@ static void rgb_write2(const OrSws *c, uint8_t *dest, int i, int y, int Y1, int 
         v1 = (uint16_t)(lut_at(c, r + Y1 + dr1) + lut_at(c, g + Y1 + dg1) + lut_at(c, b + Y1 + db1));
         v2 = (uint16_t)(lut_at(c, r + Y2 + dr2) + lut_at(c, g + Y2 + dg2) + lut_at(c, b + Y2 + db2));
         memcpy(dest + 4 * i, &v1, 2); if (second) memcpy(dest + 4 * i + 2, &v2, 2);
+    } else if (c->dstFormatBpp == 8 || c->dstFormatBpp == 4) { /* "8/4 bits", output.c:1755-1784: byte sums of the three planes */
+        int dr1, dg1, db1, dr2, dg2, db2;
+        uint8_t v1, v2;
+        dither_rgb8(d, y, 2 * i, &dr1, &dg1, &db1);
+        dither_rgb8(d, y, 2 * i + 1, &dr2, &dg2, &db2);
+        v1 = (uint8_t)(lut_at(c, r + Y1 + dr1) + lut_at(c, g + Y1 + dg1) + lut_at(c, b + Y1 + db1));
+        v2 = (uint8_t)(lut_at(c, r + Y2 + dr2) + lut_at(c, g + Y2 + dg2) + lut_at(c, b + Y2 + db2));
+        if (isRGB4bits(d)) dest[i] = (uint8_t)(v1 + (v2 << 4));   /* the pair's byte is stored whole, also for the last pair of an odd width */
+        else { dest[2 * i] = v1; if (second) dest[2 * i + 1] = v2; }
     } else if (c->lut_elem == 4) {
         uint32_t v1 = lut_at(c, r + Y1) + lut_at(c, g + Y1) + lut_at(c, b + Y1);
         uint32_t v2 = lut_at(c, r + Y2) + lut_at(c, g + Y2) + lut_at(c, b + Y2);
@@ -2853,7 +2959,7 @@ static void rgb_write2(const OrSws *c, uint8_t *dest, int i, int y, int Y1, int 
 }
 
 /* full-chroma pixel write (yuv2rgb_write_full, output.c:2005-2070; 8-bit per channel targets) */
-static void rgb_write_full(const OrSws *c, uint8_t *dest, int Y, int U, int V, int hasAlpha, int A)
+static void rgb_write_full(OrSws *c, uint8_t *dest, int i, int y, int Y, int U, int V, int hasAlpha, int A, int err[4])
 {
     const int d = c->o.dst_format;
     int R, G, B;
@@ -2874,6 +2980,53 @@ static void rgb_write_full(const OrSws *c, uint8_t *dest, int Y, int U, int V, i
         memcpy(dest, &v, 4);
         return;
     }
+    if (isRGB8class(d)) {   /* output.c:2064-2158 */
+        const int isrgb8 = d == ORF_BGR8 || d == ORF_RGB8;
+        int r, g, b;
+#define A_DITHER(u, v) (((((u) + ((v) * 236)) * 119) & 0xff))
+#define X_DITHER(u, v) (((((u) ^ ((v) * 237)) * 181) & 0x1ff) / 2)
+        switch (c->o.dither) {
+        case 0: /* SWS_DITHER_NONE */
+            if (isrgb8) { r = clip_uintp2(R >> 27, 3); g = clip_uintp2(G >> 27, 3); b = clip_uintp2(B >> 28, 2); }
+            else { r = clip_uintp2(R >> 29, 1); g = clip_uintp2(G >> 28, 2); b = clip_uintp2(B >> 29, 1); }
+            break;
+        default: /* SWS_DITHER_AUTO / SWS_DITHER_ED: error diffusion along the row with the previous row's errors (c->dither_error) */
+            R >>= 22; G >>= 22; B >>= 22;
+            R += (7 * err[0] + 1 * c->dither_error[0][i] + 5 * c->dither_error[0][i + 1] + 3 * c->dither_error[0][i + 2]) >> 4;
+            G += (7 * err[1] + 1 * c->dither_error[1][i] + 5 * c->dither_error[1][i + 1] + 3 * c->dither_error[1][i + 2]) >> 4;
+            B += (7 * err[2] + 1 * c->dither_error[2][i] + 5 * c->dither_error[2][i + 1] + 3 * c->dither_error[2][i + 2]) >> 4;
+            c->dither_error[0][i] = err[0]; c->dither_error[1][i] = err[1]; c->dither_error[2][i] = err[2];
+            r = R >> (isrgb8 ? 5 : 7); g = G >> (isrgb8 ? 5 : 6); b = B >> (isrgb8 ? 6 : 7);
+            r = ORMAX(0, ORMIN(r, isrgb8 ? 7 : 1)); g = ORMAX(0, ORMIN(g, isrgb8 ? 7 : 3)); b = ORMAX(0, ORMIN(b, isrgb8 ? 3 : 1));
+            err[0] = R - r * (isrgb8 ? 36 : 255); err[1] = G - g * (isrgb8 ? 36 : 85); err[2] = B - b * (isrgb8 ? 85 : 255);
+            break;
+        case 4: /* SWS_DITHER_A_DITHER */
+            if (isrgb8) {
+                r = ((R >> 19) + A_DITHER(i, y) - 96) >> 8; g = ((G >> 19) + A_DITHER(i + 17, y) - 96) >> 8; b = ((B >> 20) + A_DITHER(i + 17 * 2, y) - 96) >> 8;
+                r = clip_uintp2(r, 3); g = clip_uintp2(g, 3); b = clip_uintp2(b, 2);
+            } else {
+                r = ((R >> 21) + A_DITHER(i, y) - 256) >> 8; g = ((G >> 19) + A_DITHER(i + 17, y) - 256) >> 8; b = ((B >> 21) + A_DITHER(i + 17 * 2, y) - 256) >> 8;
+                r = clip_uintp2(r, 1); g = clip_uintp2(g, 2); b = clip_uintp2(b, 1);
+            }
+            break;
+        case 5: /* SWS_DITHER_X_DITHER */
+            if (isrgb8) {
+                r = ((R >> 19) + X_DITHER(i, y) - 96) >> 8; g = ((G >> 19) + X_DITHER(i + 17, y) - 96) >> 8; b = ((B >> 20) + X_DITHER(i + 17 * 2, y) - 96) >> 8;
+                r = clip_uintp2(r, 3); g = clip_uintp2(g, 3); b = clip_uintp2(b, 2);
+            } else {
+                r = ((R >> 21) + X_DITHER(i, y) - 256) >> 8; g = ((G >> 19) + X_DITHER(i + 17, y) - 256) >> 8; b = ((B >> 21) + X_DITHER(i + 17 * 2, y) - 256) >> 8;
+                r = clip_uintp2(r, 1); g = clip_uintp2(g, 2); b = clip_uintp2(b, 1);
+            }
+            break;
+        }
+#undef A_DITHER
+#undef X_DITHER
+        if (d == ORF_BGR4_BYTE) dest[0] = (uint8_t)(r + 2 * g + 8 * b);
+        else if (d == ORF_RGB4_BYTE) dest[0] = (uint8_t)(b + 2 * g + 8 * r);
+        else if (d == ORF_BGR8) dest[0] = (uint8_t)(r + 8 * g + 64 * b);
+        else dest[0] = (uint8_t)(b + 4 * g + 32 * r);
+        return;
+    }
     R >>= 22; G >>= 22; B >>= 22;
     switch (d) {
     case ORF_ARGB: dest[0] = hasAlpha ? (uint8_t)A : 255; dest[1] = (uint8_t)R; dest[2] = (uint8_t)G; dest[3] = (uint8_t)B; break;
@@ -2892,7 +3045,7 @@ typedef struct {
 
 /* packed_vscale (vscale.c:109-171) + yuv2rgb_{X,2,1}_c_template (output.c:1788-1939)
  * + yuv2rgb_full_{X,2,1}_c_template (output.c:2163-2312) */
-static void write_packed_rgb_line(const OrSws *c, const Planes *P, uint8_t *dest, int y)
+static void write_packed_rgb_line(OrSws *c, const Planes *P, uint8_t *dest, int y)
 {
     const int dstW = c->o.dst_w, lw = dstW, cw = c->chrDstW;
     const int srcH = c->o.src_h, chrSrcH = c->chrSrcH;
@@ -2902,7 +3055,8 @@ static void write_packed_rgb_line(const OrSws *c, const Planes *P, uint8_t *dest
     const int firstLum = ORMAX(1 - lfs, c->vLumFilterPos[y]);
     const int firstChr = ORMAX(1 - cfs, c->vChrFilterPos[chrY]);
     const int full = !!(c->o.flags & OR_SWS_FULL_CHR_H_INT);
-    const int step = c->lut_elem == 4 || c->dstFormatBpp == 32 ? 4 : 3;
+    const int step = isRGB8class(c->o.dst_format) ? 1 : c->lut_elem == 4 || c->dstFormatBpp == 32 ? 4 : 3;
+    int err[4] = { 0, 0, 0, 0 };   /* the running error of the row (yuv2rgb_full_{X,2,1}_c_template: "int err[4] = {0}") */
     int i, j;
 #define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
 #define CU(j) (P->chrU + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
@@ -3000,8 +3154,11 @@ static void write_packed_rgb_line(const OrSws *c, const Planes *P, uint8_t *dest
                     else A = (AL(0)[i] + 64) >> 7;
                     if (A & 0x100) A = clip_u8(A);
                 }
-                rgb_write_full(c, dest + step * i, Y, U, V, hasAlpha, A);
+                rgb_write_full(c, dest + step * i, i, y, Y, U, V, hasAlpha, A, err);
             }
+        }
+        if (c->dither_error[0]) {   /* output.c:2204-2206 / :2249-2251 / :2306-2308: the last pixel's error closes the line */
+            c->dither_error[0][i] = err[0]; c->dither_error[1][i] = err[1]; c->dither_error[2][i] = err[2];
         }
     }
 #undef L

@@ -52,6 +52,8 @@ enum {
     ORF_YUVA420P9LE = 81, ORF_YUVA420P9BE = 80, ORF_YUVA420P10LE = 87, ORF_YUVA420P10BE = 86, ORF_YUVA420P16LE = 93, ORF_YUVA420P16BE = 92, ORF_YUVA422P9LE = 83, ORF_YUVA422P9BE = 82, ORF_YUVA422P10LE = 89, ORF_YUVA422P10BE = 88, ORF_YUVA422P12LE = 185, ORF_YUVA422P12BE = 184, ORF_YUVA422P16LE = 95, ORF_YUVA422P16BE = 94, ORF_YUVA444P9LE = 85, ORF_YUVA444P9BE = 84, ORF_YUVA444P10LE = 91, ORF_YUVA444P10BE = 90, ORF_YUVA444P12LE = 187, ORF_YUVA444P12BE = 186, ORF_YUVA444P16LE = 97, ORF_YUVA444P16BE = 96,
     ORF_YA8 = 56, ORF_YA16BE = 109, ORF_YA16LE = 110,
     ORF_GRAYF32BE = 182, ORF_GRAYF32LE = 183,
+    /* 8 / 4 bits per pixel RGB (destinations only) */
+    ORF_BGR8 = 17, ORF_BGR4 = 18, ORF_BGR4_BYTE = 19, ORF_RGB8 = 20, ORF_RGB4 = 21, ORF_RGB4_BYTE = 22,
     ORF_MONOWHITE = 9, ORF_MONOBLACK = 10, ORF_XYZ12LE = 99, ORF_XYZ12BE = 100,
     ORF_YUVJ411P = 138, ORF_NV20LE = 102, ORF_NV20BE = 103, ORF_GBRP10MSBBE = 262, ORF_GBRP10MSBLE = 263, ORF_GBRP12MSBBE = 264, ORF_GBRP12MSBLE = 265,
     ORF_GBRP9LE = 73, ORF_GBRP10LE = 75, ORF_GBRP16LE = 77, ORF_GBRP12LE = 135, ORF_GBRP14LE = 137,
@@ -77,6 +79,7 @@ enum {
 #define OR_SWS_FULL_CHR_H_INP (1 << 14)
 #define OR_SWS_ACCURATE_RND  (1 << 18)
 #define OR_SWS_BITEXACT      (1 << 19)
+#define OR_SWS_ERROR_DIFFUSION (1 << 23)
 #define OR_SWS_PARAM_DEFAULT 123456
 
 typedef struct OrSws OrSws;

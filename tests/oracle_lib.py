@@ -19,7 +19,9 @@ _FORMATS = {
     "yuv410p": (6, "planar", 2, 2, 1), "yuv411p": (7, "planar", 2, 0, 1), "yuv440p": (31, "planar", 0, 1, 1),
     "yuva420p9le": (81, "planara", 1, 1, 2), "yuva420p10le": (87, "planara", 1, 1, 2), "yuva420p16le": (93, "planara", 1, 1, 2), "yuva422p9le": (83, "planara", 1, 0, 2), "yuva422p10le": (89, "planara", 1, 0, 2), "yuva422p12le": (185, "planara", 1, 0, 2), "yuva422p16le": (95, "planara", 1, 0, 2), "yuva444p9le": (85, "planara", 0, 0, 2), "yuva444p10le": (91, "planara", 0, 0, 2), "yuva444p12le": (187, "planara", 0, 0, 2), "yuva444p16le": (97, "planara", 0, 0, 2),
     "grayf32le": (183, "gray", 0, 0, 4), "ya8": (56, "packed", 0, 0, 2), "ya16le": (110, "packed", 0, 0, 4),
-    "yuvj440p": (32, "planar", 0, 1, 1), "monow": (9, "mono", 0, 0, 1), "monob": (10, "mono", 0, 0, 1), "xyz12le": (99, "packed", 0, 0, 6), "yuvj411p": (138, "planar", 2, 0, 1), "nv20le": (102, "semi", 1, 0, 2),
+    "yuvj440p": (32, "planar", 0, 1, 1), "monow": (9, "mono", 0, 0, 1), "monob": (10, "mono", 0, 0, 1),
+    "bgr8": (17, "packed", 0, 0, 1), "bgr4": (18, "nibble", 0, 0, 1), "bgr4_byte": (19, "packed", 0, 0, 1), "rgb8": (20, "packed", 0, 0, 1), "rgb4": (21, "nibble", 0, 0, 1), "rgb4_byte": (22, "packed", 0, 0, 1),
+    "xyz12le": (99, "packed", 0, 0, 6), "yuvj411p": (138, "planar", 2, 0, 1), "nv20le": (102, "semi", 1, 0, 2),
     "gbrp10msble": (263, "rgbp", 0, 0, 2), "gbrp12msble": (265, "rgbp", 0, 0, 2),
     "yuv420p9le": (60, "planar", 1, 1, 2), "yuv422p9le": (70, "planar", 1, 0, 2), "yuv444p9le": (66, "planar", 0, 0, 2),
     "yuv420p10le": (62, "planar", 1, 1, 2), "yuv422p10le": (64, "planar", 1, 0, 2), "yuv444p10le": (68, "planar", 0, 0, 2),
@@ -74,6 +76,8 @@ def plane_layout(fmt, w, h):
         return [(4 * bps * cw, h)]
     if kind == "mono":           # 1 bit per pixel, MSB first
         return [((w + 7) >> 3, h)]
+    if kind == "nibble":         # rgb4 / bgr4: 4 bits per pixel, two pixels per byte
+        return [((4 * w + 7) >> 3, h)]
     if kind == "rgbp":
         return [(bps * w, h)] * 3
     if kind == "rgbap":

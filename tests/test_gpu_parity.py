@@ -107,7 +107,8 @@ YUVA_N = ["yuva420p9le", "yuva420p10le", "yuva420p16le", "yuva422p9le", "yuva422
 MISC7 = ["ya8", "ya16le", "ya16be", "grayf32le", "grayf32be", "monob", "monow", "xyz12le", "xyz12be", "yuvj411p", "nv20le", "nv20be", "gbrp10msble", "gbrp12msble", "gbrp10msbbe", "gbrp12msbbe"]
 RGB_LOW = ["rgb565le", "bgr565le", "rgb555le", "bgr555le", "rgb444le", "bgr444le", "rgb565be", "bgr555be"]
 FORMAT_MATRIX_SRC = YUVA_N + MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
-FORMAT_MATRIX_DST = YUVA_N + MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+RGB8_4 = ["rgb8", "bgr8", "rgb4", "bgr4", "rgb4_byte", "bgr4_byte"]   # destinations only (sources need the palette path)
+FORMAT_MATRIX_DST = YUVA_N + MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16 + RGB8_4
 
 
 @pytest.mark.parametrize("sfmt", FORMAT_MATRIX_SRC)
