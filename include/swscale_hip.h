@@ -84,6 +84,11 @@ enum AVPixelFormat {
     AV_PIX_FMT_X2RGB10LE = 193, AV_PIX_FMT_X2BGR10LE = 195,
     AV_PIX_FMT_YA8 = 56, AV_PIX_FMT_YA16BE = 109, AV_PIX_FMT_YA16LE = 110,
     AV_PIX_FMT_GRAYF32BE = 182, AV_PIX_FMT_GRAYF32LE = 183,
+    /* inputs only (like the reference's format table): float / half-float pictures and the packed 4:1:1 layout */
+    AV_PIX_FMT_UYYVYY411 = 16, AV_PIX_FMT_RGBAF16BE = 206, AV_PIX_FMT_RGBAF16LE = 207, AV_PIX_FMT_RGBF32BE = 217, AV_PIX_FMT_RGBF32LE = 218,
+    AV_PIX_FMT_RGBF16BE = 233, AV_PIX_FMT_RGBF16LE = 234, AV_PIX_FMT_GBRPF16BE = 243, AV_PIX_FMT_GBRPF16LE = 244, AV_PIX_FMT_GBRAPF16BE = 245,
+    AV_PIX_FMT_GBRAPF16LE = 246, AV_PIX_FMT_GRAYF16BE = 247, AV_PIX_FMT_GRAYF16LE = 248, AV_PIX_FMT_YAF32BE = 252, AV_PIX_FMT_YAF32LE = 253,
+    AV_PIX_FMT_YAF16BE = 254, AV_PIX_FMT_YAF16LE = 255,
     /* 8 / 4 bits per pixel RGB: destinations only (sources need the palette path, swscale_internal.h:936-953 usePal) */
     AV_PIX_FMT_BGR8 = 17, AV_PIX_FMT_BGR4 = 18, AV_PIX_FMT_BGR4_BYTE = 19, AV_PIX_FMT_RGB8 = 20, AV_PIX_FMT_RGB4 = 21, AV_PIX_FMT_RGB4_BYTE = 22,
     AV_PIX_FMT_MONOWHITE = 9, AV_PIX_FMT_MONOBLACK = 10, AV_PIX_FMT_XYZ12LE = 99, AV_PIX_FMT_XYZ12BE = 100,

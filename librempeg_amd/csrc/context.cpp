@@ -75,7 +75,9 @@ static int jpeg_alias(int *format) // handle_jpeg, utils.c:773-809
     if (*format == AV_PIX_FMT_YUVJ444P) { *format = AV_PIX_FMT_YUV444P; return 1; }
     if (*format == AV_PIX_FMT_YUVJ440P) { *format = AV_PIX_FMT_YUV440P; return 1; }
     if (*format == AV_PIX_FMT_YUVJ411P) { *format = AV_PIX_FMT_YUV411P; return 1; }
-    if (pix_desc(*format) && isGray(*format)) return 1;   // gray8 .. gray16: always full range (:791-805)
+    // gray8, ya8, gray9 .. gray16, ya16 (LE and BE): always full range (:791-805).  The float gray formats are NOT in that list: a grayf32 /
+    // grayf16 / yaf32 / yaf16 picture keeps the range it was given (0 by default, i.e. "limited")
+    if (pix_desc(*format) && isGray(*format) && !isFloatFmt(*format)) return 1;
     return 0;
 }
 
@@ -118,8 +120,13 @@ static bool fmt_supported_in(int f)
         return false;
     return pix_desc(f) != nullptr || pix_be_twin(f) >= 0;
 }
-static bool fmt_supported_out(int f)
+static bool fmt_supported_out(int f)   // (the reference's table, format.c legacy_format_entries, lists the float / half-float family and uyyvyy411 as inputs only)
 {
+    const int t = pix_be_twin(f) >= 0 ? pix_be_twin(f) : f;
+    switch (t) {
+    case AV_PIX_FMT_UYYVYY411: case AV_PIX_FMT_RGBF32LE: case AV_PIX_FMT_RGBF16LE: case AV_PIX_FMT_RGBAF16LE: case AV_PIX_FMT_GRAYF16LE:
+    case AV_PIX_FMT_YAF32LE: case AV_PIX_FMT_YAF16LE: case AV_PIX_FMT_GBRPF16LE: case AV_PIX_FMT_GBRAPF16LE: return false;
+    }
     return pix_desc(f) != nullptr || pix_be_twin(f) >= 0;
 }
 
@@ -221,9 +228,9 @@ void choose_unscaled(SwsInternal *c)
         ((k == PLAN_UNSC_GBRP16_PACKED16 || k == PLAN_UNSC_GBRP_TO_RGB30) && isALPHA(s)))
         unsupported = true;
     if (s == d || (s == AV_PIX_FMT_YUVA420P && d == AV_PIX_FMT_YUV420P) || (s == AV_PIX_FMT_YUV420P && d == AV_PIX_FMT_YUVA420P) ||
-        (isFloatFmt(s) == isFloatFmt(d) && ((isPlanarYUV(s) && isGray(d) && !isALPHA(d)) || (isPlanarYUV(d) && isGray(s) && !isALPHA(s)) ||
+        (isFloatFmt(s) == isFloatFmt(d) && isFloat16Fmt(s) == isFloat16Fmt(d) && ((isPlanarYUV(s) && isGray(d) && !isALPHA(d)) || (isPlanarYUV(d) && isGray(s) && !isALPHA(s)) ||
                                            (isGray(d) && !isALPHA(d) && isGray(s) && !isALPHA(s)))) ||   // isPlanarGray(x) = isGray(x) && !isALPHA(x) (:2673)
-        (isFloatFmt(s) == isFloatFmt(d) && isPlanarYUV(s) && isPlanarYUV(d) &&
+        (isFloatFmt(s) == isFloatFmt(d) && isFloat16Fmt(s) == isFloat16Fmt(d) && isPlanarYUV(s) && isPlanarYUV(d) &&
          c->chrDstHSubSample == c->chrSrcHSubSample && c->chrDstVSubSample == c->chrSrcVSubSample &&
          isSemiPlanarYUV(s) == isSemiPlanarYUV(d) && isSwappedChroma(s) == isSwappedChroma(d))) { // :2647-2668
         if (isPackedFmt(s)) k = PLAN_UNSC_PACKEDCOPY; // packedCopyWrapper (:2138-2157)

@@ -88,6 +88,8 @@ static int src_kind_of(int f)
 {
     const PixDesc *d = pix_desc(f);
     if (!d) return -1;
+    if (f == AV_PIX_FMT_UYYVYY411) return SRCK_PACKED411;
+    if ((d->flags & PIXFLAG_FLOAT) && f != AV_PIX_FMT_GRAYF32LE && f != AV_PIX_FMT_GBRPF32LE && f != AV_PIX_FMT_GBRAPF32LE) return SRCK_FLOATX;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? SRCK_GBRPF32 : d->comp[0].depth > 8 ? SRCK_GBRP16 : SRCK_GBRP;
     if (isAnyRGB(f) && d->comp[0].depth == 16) return SRCK_RGB48;
     if (f == AV_PIX_FMT_YA8 || f == AV_PIX_FMT_YA16LE) return SRCK_YA;
@@ -194,6 +196,12 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     if (isAnyRGB(o.src_format) && !isPlanarRGB(o.src_format)) {
         p.src_pix_step = ds->comp[0].step;
         p.src_r_pos = ds->comp[0].offset; p.src_g_pos = ds->comp[1].offset; p.src_b_pos = ds->comp[2].offset;
+    }
+    if (p.srcKind == SRCK_FLOATX) {
+        p.sf_half = ds->comp[0].depth == 16;
+        p.sf_layout = isPlanarRGB(o.src_format) ? 2 : isAnyRGB(o.src_format) ? 0 : 1;
+        p.sf_step = ds->comp[0].step;
+        p.sf_a_off = isALPHA(o.src_format) ? ds->comp[ds->nb_components - 1].offset : 0;
     }
     if (p.srcKind == SRCK_MONO) p.s16_is565 = o.src_format == AV_PIX_FMT_MONOWHITE;   // (reused: bits are stored inverted)
     p.dst_mono_white = o.dst_format == AV_PIX_FMT_MONOWHITE;
@@ -716,7 +724,8 @@ static int plane_geometry(int format, int w, int h, int plane, int *row_bytes, i
     const bool sub = chroma && !(d->flags & PIXFLAG_RGB);
     const int sw = sub ? -((-w) >> d->log2_chroma_w) : w, sh = sub ? -((-h) >> d->log2_chroma_h) : h;
     *row_bytes = (format == AV_PIX_FMT_MONOWHITE || format == AV_PIX_FMT_MONOBLACK) ? (w + 7) >> 3 :
-                 (format == AV_PIX_FMT_RGB4 || format == AV_PIX_FMT_BGR4) ? (4 * w + 7) >> 3 : sw * step;   // bit streams: av_image_get_linesize, imgutils.c
+                 (format == AV_PIX_FMT_RGB4 || format == AV_PIX_FMT_BGR4) ? (4 * w + 7) >> 3 :
+                 format == AV_PIX_FMT_UYYVYY411 ? 6 * ((w + 3) >> 2) : sw * step;   // bit streams: av_image_get_linesize, imgutils.c
     *rows = sh;
     return 0;
 }
@@ -950,7 +959,7 @@ static int launch_plan(SwsInternal *c, DeviceState *d, const SwsFramePtrs *frame
     const dim3 blk(256);
     if (c->srcBE) {
         const PixDesc *ds = pix_desc(o.src_format);
-        const int unit = (ds->flags & PIXFLAG_FLOAT) ? 4 : 2;
+        const int unit = ds->comp[0].depth == 32 ? 4 : 2;
         int ls[4]; size_t offs[4], total = 0;
         int r = image_layout(o.src_format, o.src_w, o.src_h, 256, ls, offs, &total);
         if (r < 0) return r;
@@ -978,7 +987,7 @@ static int launch_plan(SwsInternal *c, DeviceState *d, const SwsFramePtrs *frame
     int ret = launch_plan_xyz(c, d, fr.data(), n, sliceY, sliceH);
     if (ret >= 0 && c->dstBE) {
         const PixDesc *dd = pix_desc(o.dst_format);
-        const int unit = (dd->flags & PIXFLAG_FLOAT) ? 4 : 2;
+        const int unit = dd->comp[0].depth == 32 ? 4 : 2;
         const bool whole = c->plan == PLAN_MAIN || c->plan == PLAN_CASCADE || (sliceY == 0 && sliceH == o.src_h);
         for (int i = 0; i < n; i++)
             for (int k = 0; k < 4; k++) {

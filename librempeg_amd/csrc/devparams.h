@@ -21,6 +21,8 @@ enum SrcKind {
     SRCK_GRAYF32,       // grayf32: grayf32ToY16_c input.c:1399-1409
     SRCK_MONO,          // monowhite / monoblack: monowhite2Y_c / monoblack2Y_c input.c:514-548
     SRCK_RGB30,         // x2rgb10le / x2bgr10le: rgb16_32To*_c_template with the rgb30le / bgr30le rows of input.c:411-412
+    SRCK_FLOATX,        // rgbf32 / rgbf16 / rgbaf16 (input.c:1336-1397, :1629-1740), grayf16 / yaf32 / yaf16 (:1411-1431, :1601-1627), gbrpf16 / gbrapf16 (:1561-1599)
+    SRCK_PACKED411,     // uyyvyy411: uyyvyyToY_c / uyyvyyToUV_c input.c:909-925
     SRCK_RGB16,         // rgb565 / rgb555 / rgb444 and the bgr orders: rgb16_32To*_c_template with the 16 bpp rows of input.c:396-401
 };
 
@@ -181,6 +183,7 @@ struct SwsDevParams {
     int32_t shi_step[4], shi_off[4], shi_shift[4], shi_mask[4];   // SRCK_PACKEDHI: per component (Y, U, V, A) byte step / offset, right shift, mask
     int32_t dhi_unit_bytes, dhi_bits, dhi_sub, dhi_alpha, dhi_bitpos[5];   // DSTK_PACKEDHI: bytes per unit (pixel, or pixel pair when dhi_sub), sample depth, bit position of Y, U, V, Y2, A inside the unit
     uint32_t dhi_fill_lo, dhi_fill_hi;   // constant bits of a unit (the X fields)
+    int32_t sf_half, sf_layout, sf_step, sf_a_off;   // SRCK_FLOATX: half-float elements; 0 packed RGB(A), 1 gray (+ alpha), 2 planar G B R (A); bytes per pixel; byte offset of the alpha element
     int32_t s444_step, s444_y, s444_u, s444_v, s444_a, d444_step, d444_y, d444_u, d444_v, d444_a;   // packed 4:4:4: pixel step and byte offsets
     int32_t s422_y, s422_u, s422_v, d422_y, d422_u, d422_v;   // packed 4:2:2: byte offsets of Y0, U, V inside a 4-byte pixel pair
     int32_t s16_maskr, s16_maskg, s16_maskb, s16_rsh, s16_gsh, s16_bsh, s16_S, s16_is565;   // SRCK_RGB16 reader rows (input.c:396-401)

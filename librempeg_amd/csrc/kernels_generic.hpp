@@ -28,6 +28,37 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         const uint8_t *s = f.src[0] + (int64_t)prow * f.srcStride[0] + p.shi_step[comp] * x + p.shi_off[comp];
         return (*(const uint16_t *)s >> p.shi_shift[comp]) & p.shi_mask[comp];
     }
+    if (p.srcKind == SRCK_FLOATX) {
+        // float / half-float sources: every element becomes lrintf(av_clipf(65535.0f * x, 0.0f, 65535.0f)) first, then the 16-bit RGB
+        // arithmetic of the rgb48 readers.  rgbf32_to_y_c / _uv_c / _uv_half_c (input.c:1336-1397), rgbf16To*_endian / rgbaf16To*_endian
+        // (:1629-1740), grayf16ToY16_c / read_yaf16_* / read_yaf32_* (:1411-1431, :1601-1627), planar_rgbf16_to_y / _uv / _a (:1561-1599).
+        // half2float (libavutil/half2float.h) is the exact widening, like the hardware conversion.
+        auto ld = [&](const uint8_t *q) { return p.sf_half ? f32_to_u16((float)*(const _Float16 *)q) : f32_to_u16(*(const float *)q); };
+        const int esz = p.sf_half ? 2 : 4;
+        if (p.sf_layout == 1)   // gray, gray + alpha: comp 0 = gray, 3 = alpha
+            return ld(f.src[0] + (int64_t)row * f.srcStride[0] + p.sf_step * x + (comp == 3 ? p.sf_a_off : 0));
+        int r, g, b;
+        if (p.sf_layout == 2) {
+            if (comp == 3) return ld(f.src[3] + (int64_t)row * f.srcStride[3] + esz * x);
+            g = ld(f.src[0] + (int64_t)grow * f.srcStride[0] + esz * x);
+            b = ld(f.src[1] + (int64_t)brow * f.srcStride[1] + esz * x);
+            r = ld(f.src[2] + (int64_t)brow * f.srcStride[2] + esz * x);
+        } else {
+            if (comp == 3) return ld(f.src[0] + (int64_t)row * f.srcStride[0] + p.sf_step * x + p.sf_a_off);
+            const uint8_t *s = f.src[0] + (int64_t)prow * f.srcStride[0];
+            if (comp != 0 && p.chr_half) {   // the half forms average the two converted pixels with a plain >> 1 (no rounding term)
+                const uint8_t *q = s + 2 * p.sf_step * x;
+                r = (ld(q) + ld(q + p.sf_step)) >> 1; g = (ld(q + esz) + ld(q + p.sf_step + esz)) >> 1; b = (ld(q + 2 * esz) + ld(q + p.sf_step + 2 * esz)) >> 1;
+            } else { const uint8_t *q = s + p.sf_step * x; r = ld(q); g = ld(q + esz); b = ld(q + 2 * esz); }
+        }
+        const int32_t *t = p.rgb2yuv;
+        const int o = comp == 0 ? 0 : comp == 1 ? 3 : 6;
+        return (uint16_t)((int)((unsigned)t[o] * r + (unsigned)t[o + 1] * g + (unsigned)t[o + 2] * b + ((comp == 0 ? 0x2001u : 0x10001u) << 14)) >> 15);
+    }
+    if (p.srcKind == SRCK_PACKED411) {   // uyyvyyToY_c / uyyvyyToUV_c (input.c:909-925): U Y Y V Y Y groups
+        const uint8_t *s = f.src[0] + (int64_t)prow * f.srcStride[0];
+        return comp == 0 ? s[3 * (x >> 1) + 1 + (x & 1)] : s[6 * x + (comp == 1 ? 0 : 3)];
+    }
     if (p.srcKind == SRCK_YA) {   // ya8: yuy2ToY_c / uyvyToY_c on the two bytes; ya16le: read_ya16le_gray_c / _alpha_c (comp 0 = gray, 3 = alpha)
         const uint8_t *s = f.src[0] + (int64_t)row * f.srcStride[0];
         if (p.src_depth == 8) return s[2 * x + (comp == 3 ? 1 : 0)];

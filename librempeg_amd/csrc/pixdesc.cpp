@@ -109,6 +109,16 @@ static const PixDesc g_descs[] = {
     { AV_PIX_FMT_GRAYF32LE, "grayf32le", 1, 0, 0, {{0,4,0,0,32},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_FLOAT },
     { AV_PIX_FMT_MONOWHITE, "monow", 1, 0, 0, {{0,1,0,0,1},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_RGB },   // 1 bit per pixel, MSB first; isAnyRGB() counts them in
     { AV_PIX_FMT_MONOBLACK, "monob", 1, 0, 0, {{0,1,0,7,1},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_RGB },
+    // float and half-float sources (libavutil/pixdesc.c:2583-2717, :2932-2971, :3108-3119) and the packed 4:1:1 source (:484-494): inputs only
+    { AV_PIX_FMT_RGBF32LE, "rgbf32le", 3, 0, 0, {{0,12,0,0,32},{0,12,4,0,32},{0,12,8,0,32},{0,0,0,0,0}}, PIXFLAG_RGB | PIXFLAG_FLOAT },
+    { AV_PIX_FMT_RGBF16LE, "rgbf16le", 3, 0, 0, {{0,6,0,0,16},{0,6,2,0,16},{0,6,4,0,16},{0,0,0,0,0}}, PIXFLAG_RGB | PIXFLAG_FLOAT },
+    { AV_PIX_FMT_RGBAF16LE, "rgbaf16le", 4, 0, 0, {{0,8,0,0,16},{0,8,2,0,16},{0,8,4,0,16},{0,8,6,0,16}}, PIXFLAG_RGB | PIXFLAG_FLOAT | PIXFLAG_ALPHA },
+    { AV_PIX_FMT_GRAYF16LE, "grayf16le", 1, 0, 0, {{0,2,0,0,16},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_FLOAT },
+    { AV_PIX_FMT_YAF32LE, "yaf32le", 2, 0, 0, {{0,8,0,0,32},{0,8,4,0,32},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_FLOAT | PIXFLAG_ALPHA },
+    { AV_PIX_FMT_YAF16LE, "yaf16le", 2, 0, 0, {{0,4,0,0,16},{0,4,2,0,16},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_FLOAT | PIXFLAG_ALPHA },
+    { AV_PIX_FMT_GBRPF16LE, "gbrpf16le", 3, 0, 0, {{2,2,0,0,16},{0,2,0,0,16},{1,2,0,0,16},{0,0,0,0,0}}, PIXFLAG_PLANAR | PIXFLAG_RGB | PIXFLAG_FLOAT },
+    { AV_PIX_FMT_GBRAPF16LE, "gbrapf16le", 4, 0, 0, {{2,2,0,0,16},{0,2,0,0,16},{1,2,0,0,16},{3,2,0,0,16}}, PIXFLAG_PLANAR | PIXFLAG_RGB | PIXFLAG_FLOAT | PIXFLAG_ALPHA },
+    { AV_PIX_FMT_UYYVYY411, "uyyvyy411", 3, 2, 0, {{0,4,1,0,8},{0,6,0,0,8},{0,6,3,0,8},{0,0,0,0,0}}, 0 },
     // 8 / 4 bpp RGB (libavutil/pixdesc.c:495-566), destinations only; rgb4 / bgr4 are bit streams (step and offset count bits)
     { AV_PIX_FMT_BGR8, "bgr8", 3, 0, 0, {{0,1,0,0,3},{0,1,0,3,3},{0,1,0,6,2},{0,0,0,0,0}}, PIXFLAG_RGB },
     { AV_PIX_FMT_BGR4, "bgr4", 3, 0, 0, {{0,4,3,0,1},{0,4,1,0,2},{0,4,0,0,1},{0,0,0,0,0}}, PIXFLAG_RGB },
@@ -164,6 +174,7 @@ bool isAnyRGB(int f) { return (pix_desc(f)->flags & PIXFLAG_RGB) != 0; }
 static bool isMonoFmt(int f) { return f == AV_PIX_FMT_MONOWHITE || f == AV_PIX_FMT_MONOBLACK; }
 bool isGray(int f) { return pix_desc(f)->nb_components <= 2 && !isMonoFmt(f); }   // swscale_internal.h:805-815
 bool isFloatFmt(int f) { return (pix_desc(f)->flags & PIXFLAG_FLOAT) != 0; }
+bool isFloat16Fmt(int f) { const PixDesc *d = pix_desc(f); return (d->flags & PIXFLAG_FLOAT) && d->comp[0].depth == 16; }   // swscale_internal.h:890-895
 bool isALPHA(int f) { return (pix_desc(f)->flags & PIXFLAG_ALPHA) != 0; }
 bool isPlanarRGB(int f) { return (pix_desc(f)->flags & (PIXFLAG_PLANAR | PIXFLAG_RGB)) == (PIXFLAG_PLANAR | PIXFLAG_RGB); }
 bool isPackedFmt(int f) { const PixDesc *d = pix_desc(f); return (d->nb_components >= 2 && !(d->flags & PIXFLAG_PLANAR)) || isMonoFmt(f); }   // swscale_internal.h:906-914
@@ -192,6 +203,8 @@ int pix_be_twin(int fmt)
     static const int pairs[][2] = {
     { AV_PIX_FMT_XV36BE, AV_PIX_FMT_XV36LE }, { AV_PIX_FMT_XV48BE, AV_PIX_FMT_XV48LE }, { AV_PIX_FMT_AYUV64BE, AV_PIX_FMT_AYUV64LE },
     { AV_PIX_FMT_YUVA420P9BE, AV_PIX_FMT_YUVA420P9LE }, { AV_PIX_FMT_YUVA420P10BE, AV_PIX_FMT_YUVA420P10LE }, { AV_PIX_FMT_YUVA420P16BE, AV_PIX_FMT_YUVA420P16LE }, { AV_PIX_FMT_YUVA422P9BE, AV_PIX_FMT_YUVA422P9LE }, { AV_PIX_FMT_YUVA422P10BE, AV_PIX_FMT_YUVA422P10LE }, { AV_PIX_FMT_YUVA422P12BE, AV_PIX_FMT_YUVA422P12LE }, { AV_PIX_FMT_YUVA422P16BE, AV_PIX_FMT_YUVA422P16LE }, { AV_PIX_FMT_YUVA444P9BE, AV_PIX_FMT_YUVA444P9LE }, { AV_PIX_FMT_YUVA444P10BE, AV_PIX_FMT_YUVA444P10LE }, { AV_PIX_FMT_YUVA444P12BE, AV_PIX_FMT_YUVA444P12LE }, { AV_PIX_FMT_YUVA444P16BE, AV_PIX_FMT_YUVA444P16LE },
+    { AV_PIX_FMT_RGBF32BE, AV_PIX_FMT_RGBF32LE }, { AV_PIX_FMT_RGBF16BE, AV_PIX_FMT_RGBF16LE }, { AV_PIX_FMT_RGBAF16BE, AV_PIX_FMT_RGBAF16LE }, { AV_PIX_FMT_GRAYF16BE, AV_PIX_FMT_GRAYF16LE },
+    { AV_PIX_FMT_YAF32BE, AV_PIX_FMT_YAF32LE }, { AV_PIX_FMT_YAF16BE, AV_PIX_FMT_YAF16LE }, { AV_PIX_FMT_GBRPF16BE, AV_PIX_FMT_GBRPF16LE }, { AV_PIX_FMT_GBRAPF16BE, AV_PIX_FMT_GBRAPF16LE },
     { AV_PIX_FMT_YA16BE, AV_PIX_FMT_YA16LE }, { AV_PIX_FMT_GRAYF32BE, AV_PIX_FMT_GRAYF32LE }, { AV_PIX_FMT_XYZ12BE, AV_PIX_FMT_XYZ12LE }, { AV_PIX_FMT_NV20BE, AV_PIX_FMT_NV20LE }, { AV_PIX_FMT_GBRP10MSBBE, AV_PIX_FMT_GBRP10MSBLE }, { AV_PIX_FMT_GBRP12MSBBE, AV_PIX_FMT_GBRP12MSBLE },
     { AV_PIX_FMT_YUV444P10MSBBE, AV_PIX_FMT_YUV444P10MSBLE }, { AV_PIX_FMT_YUV444P12MSBBE, AV_PIX_FMT_YUV444P12MSBLE },
     { AV_PIX_FMT_RGB565BE, AV_PIX_FMT_RGB565LE }, { AV_PIX_FMT_RGB555BE, AV_PIX_FMT_RGB555LE }, { AV_PIX_FMT_RGB444BE, AV_PIX_FMT_RGB444LE },

@@ -26,7 +26,7 @@ int  pix_bits_per_pixel(const PixDesc *d);
 int  pix_nb_planes(const PixDesc *d);
 // predicates, libswscale/swscale_internal.h:746-988
 bool is16BPS(int f); bool isNBPS(int f); bool isYUV(int f); bool isPlanarYUV(int f);
-bool isSemiPlanarYUV(int f); bool isAnyRGB(int f); bool isGray(int f); bool isFloatFmt(int f);
+bool isSemiPlanarYUV(int f); bool isAnyRGB(int f); bool isGray(int f); bool isFloatFmt(int f); bool isFloat16Fmt(int f);
 bool isALPHA(int f); bool isPlanarRGB(int f); bool isPackedFmt(int f); bool isPlanarFmt(int f);
 bool isSwappedChroma(int f); bool isDataInHighBits(int f);
 

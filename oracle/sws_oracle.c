@@ -148,6 +148,16 @@ static const Desc descs[] = {
     { ORF_GRAYF32LE, "grayf32le", 1, 0, 0, {{0,4,0,0,32}}, PF_FLOAT },
     { ORF_MONOWHITE, "monow", 1, 0, 0, {{0,1,0,0,1}}, PF_RGB },   /* 1 bit per pixel, MSB first; isAnyRGB() counts them in (swscale_internal.h:876-882) */
     { ORF_MONOBLACK, "monob", 1, 0, 0, {{0,1,0,7,1}}, PF_RGB },
+    /* float and half-float sources (pixdesc.c:2583-2717, :2932-2971, :3108-3119), the packed 4:1:1 source (:484-494): inputs only */
+    { ORF_RGBF32LE, "rgbf32le", 3, 0, 0, {{0,12,0,0,32},{0,12,4,0,32},{0,12,8,0,32}}, PF_RGB | PF_FLOAT },
+    { ORF_RGBF16LE, "rgbf16le", 3, 0, 0, {{0,6,0,0,16},{0,6,2,0,16},{0,6,4,0,16}}, PF_RGB | PF_FLOAT },
+    { ORF_RGBAF16LE, "rgbaf16le", 4, 0, 0, {{0,8,0,0,16},{0,8,2,0,16},{0,8,4,0,16},{0,8,6,0,16}}, PF_RGB | PF_FLOAT | PF_ALPHA },
+    { ORF_GRAYF16LE, "grayf16le", 1, 0, 0, {{0,2,0,0,16}}, PF_FLOAT },
+    { ORF_YAF32LE, "yaf32le", 2, 0, 0, {{0,8,0,0,32},{0,8,4,0,32}}, PF_FLOAT | PF_ALPHA },
+    { ORF_YAF16LE, "yaf16le", 2, 0, 0, {{0,4,0,0,16},{0,4,2,0,16}}, PF_FLOAT | PF_ALPHA },
+    { ORF_GBRPF16LE, "gbrpf16le", 3, 0, 0, {{2,2,0,0,16},{0,2,0,0,16},{1,2,0,0,16}}, PF_PLANAR | PF_RGB | PF_FLOAT },
+    { ORF_GBRAPF16LE, "gbrapf16le", 4, 0, 0, {{2,2,0,0,16},{0,2,0,0,16},{1,2,0,0,16},{3,2,0,0,16}}, PF_PLANAR | PF_RGB | PF_FLOAT | PF_ALPHA },
+    { ORF_UYYVYY411, "uyyvyy411", 3, 2, 0, {{0,4,1,0,8},{0,6,0,0,8},{0,6,3,0,8}}, 0 },
     /* 8 / 4 bpp RGB (pixdesc.c:495-566); rgb4 / bgr4 are bit streams of two pixels per byte, first pixel in the low nibble as the
      * writers store them (output.c:1778-1780) */
     { ORF_BGR8, "bgr8", 3, 0, 0, {{0,1,0,0,3},{0,1,0,3,3},{0,1,0,6,2}}, PF_RGB },
@@ -201,6 +211,8 @@ static const int be_pairs[][2] = {
     { ORF_GBRAP10BE, ORF_GBRAP10LE }, { ORF_GBRAP12BE, ORF_GBRAP12LE }, { ORF_GBRAP14BE, ORF_GBRAP14LE }, { ORF_GBRAP16BE, ORF_GBRAP16LE }, { ORF_GBRAPF32BE, ORF_GBRAPF32LE },
     { ORF_XV36BE, ORF_XV36LE }, { ORF_XV48BE, ORF_XV48LE }, { ORF_AYUV64BE, ORF_AYUV64LE },
     { ORF_YUVA420P9BE, ORF_YUVA420P9LE }, { ORF_YUVA420P10BE, ORF_YUVA420P10LE }, { ORF_YUVA420P16BE, ORF_YUVA420P16LE }, { ORF_YUVA422P9BE, ORF_YUVA422P9LE }, { ORF_YUVA422P10BE, ORF_YUVA422P10LE }, { ORF_YUVA422P12BE, ORF_YUVA422P12LE }, { ORF_YUVA422P16BE, ORF_YUVA422P16LE }, { ORF_YUVA444P9BE, ORF_YUVA444P9LE }, { ORF_YUVA444P10BE, ORF_YUVA444P10LE }, { ORF_YUVA444P12BE, ORF_YUVA444P12LE }, { ORF_YUVA444P16BE, ORF_YUVA444P16LE },
+    { ORF_RGBF32BE, ORF_RGBF32LE }, { ORF_RGBF16BE, ORF_RGBF16LE }, { ORF_RGBAF16BE, ORF_RGBAF16LE }, { ORF_GRAYF16BE, ORF_GRAYF16LE }, { ORF_YAF32BE, ORF_YAF32LE },
+    { ORF_YAF16BE, ORF_YAF16LE }, { ORF_GBRPF16BE, ORF_GBRPF16LE }, { ORF_GBRAPF16BE, ORF_GBRAPF16LE },
     { ORF_YA16BE, ORF_YA16LE }, { ORF_GRAYF32BE, ORF_GRAYF32LE }, { ORF_XYZ12BE, ORF_XYZ12LE }, { ORF_NV20BE, ORF_NV20LE }, { ORF_GBRP10MSBBE, ORF_GBRP10MSBLE }, { ORF_GBRP12MSBBE, ORF_GBRP12MSBLE },
     { ORF_YUV444P10MSBBE, ORF_YUV444P10MSBLE }, { ORF_YUV444P12MSBBE, ORF_YUV444P12MSBLE },
     { ORF_RGB565BE, ORF_RGB565LE }, { ORF_RGB555BE, ORF_RGB555LE }, { ORF_RGB444BE, ORF_RGB444LE },
@@ -264,6 +276,9 @@ static int isYA(int f) { return f == ORF_YA8 || f == ORF_YA16LE; }
 static int isMono(int f) { return f == ORF_MONOWHITE || f == ORF_MONOBLACK; }
 static int isGray(int f) { return desc_get(f)->nb <= 2 && !isMono(f); }   /* swscale_internal.h:805-815 */
 static int isFloat(int f) { return !!(desc_get(f)->flags & PF_FLOAT); }
+static int isFloat16(int f) { return isFloat(f) && desc_get(f)->c[0].depth == 16; }   /* swscale_internal.h:890-895 */
+/* the formats the reference's table (format.c legacy_format_entries) lists as inputs only */
+static int isInputOnly(int f) { return f == ORF_UYYVYY411 || f == ORF_RGBF32LE || f == ORF_RGBF16LE || f == ORF_RGBAF16LE || f == ORF_GRAYF16LE || f == ORF_YAF32LE || f == ORF_YAF16LE || f == ORF_GBRPF16LE || f == ORF_GBRAPF16LE; }
 static int isALPHA(int f) { return !!(desc_get(f)->flags & PF_ALPHA); }
 static int isPlanarRGB(int f) { return (desc_get(f)->flags & (PF_PLANAR | PF_RGB)) == (PF_PLANAR | PF_RGB); }
 static int isPacked(int f) { const Desc *d = desc_get(f); return (d->nb >= 2 && !(d->flags & PF_PLANAR)) || isMono(f); }   /* swscale_internal.h:906-914 */
@@ -951,7 +966,9 @@ static int handle_jpeg(int *format) /* utils.c:773 */
     if (*format == ORF_YUVJ444P) { *format = ORF_YUV444P; return 1; }
     if (*format == ORF_YUVJ440P) { *format = ORF_YUV440P; return 1; }
     if (*format == ORF_YUVJ411P) { *format = ORF_YUV411P; return 1; }
-    if (isGray(*format)) return 1;   /* gray8 .. gray16: always full range (utils.c:791-805) */
+    /* gray8, ya8, gray9 .. gray16, ya16 (LE and BE): always full range (utils.c:791-805).  The float gray formats are NOT in the list: a
+     * grayf32 / grayf16 / yaf32 / yaf16 picture keeps the range it was given (0 by default, i.e. "limited") */
+    if (isGray(*format) && !isFloat(*format)) return 1;
     return 0;
 }
 
@@ -1218,10 +1235,10 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         c->unscaled_kind = UNSC_REFUSE;
     /* simple copy (:2647-2668) */
     if (s == d || (s == ORF_YUVA420P && d == ORF_YUV420P) || (s == ORF_YUV420P && d == ORF_YUVA420P) ||
-        (isFloat(s) == isFloat(d) &&
+        (isFloat(s) == isFloat(d) && isFloat16(s) == isFloat16(d) &&
          ((isPlanarYUV(s) && isGray(d) && !isALPHA(d)) || (isPlanarYUV(d) && isGray(s) && !isALPHA(s)) ||
           (isGray(d) && !isALPHA(d) && isGray(s) && !isALPHA(s)))) ||   /* isPlanarGray(x) = isGray(x) && !isALPHA(x) (:2673) */
-        (isFloat(s) == isFloat(d) &&
+        (isFloat(s) == isFloat(d) && isFloat16(s) == isFloat16(d) &&
          (isPlanarYUV(s) && isPlanarYUV(d) && c->chrDstHSub == c->chrSrcHSub && c->chrDstVSub == c->chrSrcVSub &&
           isSemiPlanarYUV(s) == isSemiPlanarYUV(d) && isSwappedChroma(s) == isSwappedChroma(d)))) {
         if (!isPacked(s)) c->unscaled_kind = UNSC_PLANARCOPY;
@@ -1255,7 +1272,8 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
     srcFormat = c->o.src_format; dstFormat = c->o.dst_format;
     ds = desc_get(srcFormat); dd = desc_get(dstFormat);
     if (!ds || !dd) return -1;
-    if (isRGB8class(srcFormat) || isRGB4bits(srcFormat)) return -1;   /* palette-expanded inputs (usePal, swscale_internal.h:936-953): not restated */
+    if (isRGB8class(srcFormat) || isRGB4bits(srcFormat)) return -1;
+    if (isInputOnly(dstFormat)) return -1;   /* "... is not supported as output pixel format" (utils.c:1198-1208) */   /* palette-expanded inputs (usePal, swscale_internal.h:936-953): not restated */
 
     i = flags & (OR_SWS_POINT | OR_SWS_AREA | OR_SWS_BILINEAR | OR_SWS_FAST_BILINEAR | OR_SWS_BICUBIC |
                  OR_SWS_X | OR_SWS_GAUSS | OR_SWS_LANCZOS | OR_SWS_SINC | OR_SWS_SPLINE | OR_SWS_BICUBLIN);
@@ -2296,10 +2314,37 @@ static int unscaled_planarcopy(OrSws *c, const uint8_t *const src[], const int s
 static int f2u16(float x) /* lrintf(av_clipf(65535.0f * x, 0, 65535)), input.c:1300 */
 {
     float v = 65535.0f * x;
-    v = v < 0.0f ? 0.0f : v; /* av_clipf_c: FFMIN(FFMAX(a, amin), amax) */
+    v = v > 0.0f ? v : 0.0f; /* av_clipf_c: FFMIN(FFMAX(a, amin), amax) with FFMAX(a, b) = a > b ? a : b: a NaN becomes amin, like maxss does */
     v = v > 65535.0f ? 65535.0f : v;
     return (int)lrintf(v);
 }
+
+/* half2float (libavutil/half2float.h:43-60, half2float.c:22-66): the exact binary16 -> binary32 widening, NaNs quieted */
+static float half_to_float(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000) << 16, e = (h >> 10) & 31, m = h & 0x3ff;
+    uint32_t bits;
+    float f;
+    if (e == 0) {
+        if (!m) bits = sign;
+        else { /* subnormal: normalise */
+            uint32_t mm = m << 13; int ee = 0;
+            while (!(mm & 0x00800000)) { ee--; mm <<= 1; }
+            bits = sign | ((uint32_t)(ee + 113) << 23) | (mm & 0x007fffff);
+        }
+    } else if (e == 31) bits = sign | 0x7f800000u | (m ? (m << 13) | 0x400000u : 0);
+    else bits = sign | ((e + 112) << 23) | (m << 13);
+    memcpy(&f, &bits, 4);
+    return f;
+}
+/* one float / half-float element as the readers see it: lrintf(av_clipf(65535.0f * x, 0.0f, 65535.0f)) (input.c:1289-1431, :1558-1740) */
+static int rdf16(const uint8_t *p, int half)
+{
+    if (half) { uint16_t h; memcpy(&h, p, 2); return f2u16(half_to_float(h)); }
+    else { float v; memcpy(&v, p, 4); return f2u16(v); }
+}
+static int isPackedFloatRGB(int f) { return f == ORF_RGBF32LE || f == ORF_RGBF16LE || f == ORF_RGBAF16LE; }
+static int isFloatGrayX(int f) { return f == ORF_GRAYF16LE || f == ORF_YAF32LE || f == ORF_YAF16LE; }   /* (grayf32 has its own case) */
 
 /* Produce the 8/16-bit "formatConv" luma line for source row y (NULL if the plane is read directly).
  * returns pointer to the line to feed to hscale. */
@@ -2395,6 +2440,39 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
         }
         return tmp;
     }
+    if (f == ORF_UYYVYY411) { /* uyyvyyToY_c input.c:909-914 */
+        const uint8_t *s = src[0] + y * stride[0];
+        for (i = 0; i < w; i++) tmp[i] = s[3 * (i >> 1) + 1 + (i & 1)];
+        return tmp;
+    }
+    if (isPackedFloatRGB(f)) { /* rgbf32_to_y_c (input.c:1380-1397), rgbf16ToY_endian (:1726-1740), rgbaf16ToY_endian (:1666-1678) */
+        const Desc *ds = desc_get(f);
+        const int half = ds->c[0].depth == 16, esz = half ? 2 : 4, st = ds->c[0].step;
+        const uint8_t *s = src[0] + y * stride[0];
+        uint16_t *d = (uint16_t *)tmp;
+        for (i = 0; i < w; i++) {
+            const int r = rdf16(s + st * i, half), g = rdf16(s + st * i + esz, half), b = rdf16(s + st * i + 2 * esz, half);
+            d[i] = (uint16_t)((int)((unsigned)t[RY] * r + (unsigned)t[GY] * g + (unsigned)t[BY] * b + (0x2001u << (15 - 1))) >> 15);
+        }
+        return tmp;
+    }
+    if (isFloatGrayX(f)) { /* grayf16ToY16_c (input.c:1601-1609), read_yaf32_gray_c (:1411-1420), read_yaf16_gray_c (:1611-1618) */
+        const Desc *ds = desc_get(f);
+        const int half = ds->c[0].depth == 16, st = ds->c[0].step;
+        const uint8_t *s = src[0] + y * stride[0];
+        uint16_t *d = (uint16_t *)tmp;
+        for (i = 0; i < w; i++) d[i] = (uint16_t)rdf16(s + st * i, half);
+        return tmp;
+    }
+    if (f == ORF_GBRPF16LE || f == ORF_GBRAPF16LE) { /* planar_rgbf16_to_y input.c:1586-1599 */
+        const uint8_t *G = src[0] + y * stride[0], *B = src[1] + yc * stride[1], *R = src[2] + yc * stride[2];
+        uint16_t *d = (uint16_t *)tmp;
+        for (i = 0; i < w; i++) {
+            const int g = rdf16(G + 2 * i, 1), b = rdf16(B + 2 * i, 1), r = rdf16(R + 2 * i, 1);
+            d[i] = (uint16_t)((int)((unsigned)t[RY] * r + (unsigned)t[GY] * g + (unsigned)t[BY] * b + (0x2001u << (15 - 1))) >> 15);
+        }
+        return tmp;
+    }
     switch (f) {
     case ORF_RGB24: case ORF_BGR24: { /* rgb24ToY_c / bgr24ToY_c input.c:1068-1124 */
         const uint8_t *s = src[0] + y * stride[0]; int16_t *d = (int16_t *)tmp;
@@ -2478,6 +2556,39 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
     const ptrdiff_t yl = (ptrdiff_t)y << c->chrSrcVSub;   /* planar RGB: plane 0 is indexed by luma row (hscale.c chr_convert) */
     int i;
     *pu = tu; *pv = tv;
+    if (f == ORF_UYYVYY411) { /* uyyvyyToUV_c input.c:916-925 */
+        const uint8_t *s = src[0] + (ptrdiff_t)(y << c->chrSrcVSub) * stride[0];
+        for (i = 0; i < w; i++) { tu[i] = s[6 * i]; tv[i] = s[6 * i + 3]; }
+        return;
+    }
+    if (isPackedFloatRGB(f)) { /* rgbf32_to_uv_c / _uv_half_c (input.c:1336-1378), rgbf16ToUV(_half)_endian (:1689-1724), rgbaf16ToUV(_half)_endian (:1629-1664):
+                                * the half forms average the two converted pixels with a plain >> 1 */
+        const Desc *ds = desc_get(f);
+        const int half = ds->c[0].depth == 16, esz = half ? 2 : 4, st = ds->c[0].step;
+        const uint8_t *s = src[0] + (ptrdiff_t)(y << c->chrSrcVSub) * stride[0];
+        uint16_t *du = (uint16_t *)tu, *dv = (uint16_t *)tv;
+        for (i = 0; i < w; i++) {
+            int r, g, b;
+            if (c->chrSrcHSub) {
+                r = (rdf16(s + 2 * st * i, half) + rdf16(s + 2 * st * i + st, half)) >> 1;
+                g = (rdf16(s + 2 * st * i + esz, half) + rdf16(s + 2 * st * i + st + esz, half)) >> 1;
+                b = (rdf16(s + 2 * st * i + 2 * esz, half) + rdf16(s + 2 * st * i + st + 2 * esz, half)) >> 1;
+            } else { r = rdf16(s + st * i, half); g = rdf16(s + st * i + esz, half); b = rdf16(s + st * i + 2 * esz, half); }
+            du[i] = (uint16_t)((int)((unsigned)t[RU] * r + (unsigned)t[GU] * g + (unsigned)t[BU] * b + (0x10001u << (15 - 1))) >> 15);
+            dv[i] = (uint16_t)((int)((unsigned)t[RV] * r + (unsigned)t[GV] * g + (unsigned)t[BV] * b + (0x10001u << (15 - 1))) >> 15);
+        }
+        return;
+    }
+    if (f == ORF_GBRPF16LE || f == ORF_GBRAPF16LE) { /* planar_rgbf16_to_uv input.c:1570-1584 */
+        const uint8_t *G = src[0] + yl * stride[0], *B = src[1] + (ptrdiff_t)y * stride[1], *R = src[2] + (ptrdiff_t)y * stride[2];
+        uint16_t *du = (uint16_t *)tu, *dv = (uint16_t *)tv;
+        for (i = 0; i < w; i++) {
+            const int g = rdf16(G + 2 * i, 1), b = rdf16(B + 2 * i, 1), r = rdf16(R + 2 * i, 1);
+            du[i] = (uint16_t)((int)((unsigned)t[RU] * r + (unsigned)t[GU] * g + (unsigned)t[BU] * b + (0x10001u << (15 - 1))) >> 15);
+            dv[i] = (uint16_t)((int)((unsigned)t[RV] * r + (unsigned)t[GV] * g + (unsigned)t[BV] * b + (0x10001u << (15 - 1))) >> 15);
+        }
+        return;
+    }
     if (isRGB30(f)) { /* rgb16_32ToUV_c_template / rgb16_32ToUV_half_c_template input.c:295-372 with the rows of :411-412 */
         const uint8_t *s = src[0] + (ptrdiff_t)(y << c->chrSrcVSub) * stride[0];
         int16_t *du = (int16_t *)tu, *dv = (int16_t *)tv;
@@ -3668,6 +3779,14 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
                 uint16_t *d16 = (uint16_t *)t0;
                 for (int i = 0; i < srcW; i++) memcpy(&d16[i], src[0] + (ptrdiff_t)y * srcStride[0] + 4 * i + 2, 2);
                 line = t0;
+            } else if (sf == ORF_YAF32LE || sf == ORF_YAF16LE || sf == ORF_RGBAF16LE) { /* read_yaf32_alpha_c (input.c:1422-1431), read_yaf16_alpha_c (:1620-1627),
+                                                                                         * rgbaf16ToA_endian (:1680-1687): the last element of the pixel */
+                const Desc *dsd = desc_get(sf);
+                const int half = dsd->c[0].depth == 16, ai = dsd->nb - 1;
+                const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0] + dsd->c[ai].offset;
+                uint16_t *d16 = (uint16_t *)t0;
+                for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)rdf16(sp + dsd->c[ai].step * i, half);
+                line = t0;
             } else if (sf == ORF_RGBA64LE || sf == ORF_BGRA64LE) { /* rgba64leToA_c: the 16-bit A sample as is */
                 const uint16_t *sp = (const uint16_t *)(src[0] + (ptrdiff_t)y * srcStride[0]) + 3;
                 uint16_t *d16 = (uint16_t *)t0;
@@ -3687,7 +3806,8 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
                 const Desc *dsd = desc_get(sf);
                 uint16_t *d16 = (uint16_t *)t0;
                 const uint8_t *sp = src[3] + (ptrdiff_t)y * srcStride[3];
-                if (dsd->flags & PF_FLOAT) for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)f2u16(((const float *)sp)[i]);
+                if ((dsd->flags & PF_FLOAT) && dsd->c[0].depth == 16) for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)rdf16(sp + 2 * i, 1);   /* planar_rgbf16_to_a :1561-1568 */
+                else if (dsd->flags & PF_FLOAT) for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)f2u16(((const float *)sp)[i]);
                 else if (dsd->c[0].depth == 8) for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)(sp[i] << 6);
                 else { const int bpc = dsd->c[0].depth, sh = 14 - (bpc < 16 ? bpc : 14); for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)(((const uint16_t *)sp)[i] << sh); }
                 line = t0;
@@ -3854,6 +3974,7 @@ static void plane_geom(const Desc *d, int w, int h, int k, int *rows, int *row_b
         if (!(d->flags & PF_PLANAR) && d->nb >= 3 && !(d->flags & PF_RGB)) maxb = d->c[0].step * w;   /* packed 4:2:2 */
     }
     if (isMono(d->fmt)) maxb = (w + 7) >> 3;
+    if (d->fmt == ORF_UYYVYY411) maxb = 6 * ((w + 3) >> 2);   /* av_image_get_linesize: the widest step (6) over the chroma-shifted width */
     *rows = chroma ? -((-h) >> d->lh) : h;
     *row_bytes = maxb;
 }
@@ -3882,7 +4003,7 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
         uint8_t *tmp[4] = { NULL, NULL, NULL, NULL };
         int ret;
         if (c->src_be) {
-            const int unit = (ds->flags & PF_FLOAT) ? 4 : 2;
+            const int unit = ds->c[0].depth == 32 ? 4 : 2;
             for (int k = 0; k < 4; k++) {
                 int rows, rb;
                 plane_geom(ds, c->o.src_w, c->o.src_h, k, &rows, &rb);
@@ -3895,7 +4016,7 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
         ret = scale_xyz(c, sp, ss, srcSliceY, srcSliceH, dst, dstStride);
         for (int k = 0; k < 4; k++) free(tmp[k]);
         if (ret >= 0 && c->dst_be) {
-            const int unit = (dd->flags & PF_FLOAT) ? 4 : 2;
+            const int unit = dd->c[0].depth == 32 ? 4 : 2;
             for (int k = 0; k < 4; k++) {
                 int rows, rb;
                 plane_geom(dd, c->o.dst_w, c->o.dst_h, k, &rows, &rb);

@@ -20,6 +20,12 @@ _FORMATS = {
     "yuva420p9le": (81, "planara", 1, 1, 2), "yuva420p10le": (87, "planara", 1, 1, 2), "yuva420p16le": (93, "planara", 1, 1, 2), "yuva422p9le": (83, "planara", 1, 0, 2), "yuva422p10le": (89, "planara", 1, 0, 2), "yuva422p12le": (185, "planara", 1, 0, 2), "yuva422p16le": (95, "planara", 1, 0, 2), "yuva444p9le": (85, "planara", 0, 0, 2), "yuva444p10le": (91, "planara", 0, 0, 2), "yuva444p12le": (187, "planara", 0, 0, 2), "yuva444p16le": (97, "planara", 0, 0, 2),
     "grayf32le": (183, "gray", 0, 0, 4), "ya8": (56, "packed", 0, 0, 2), "ya16le": (110, "packed", 0, 0, 4),
     "yuvj440p": (32, "planar", 0, 1, 1), "monow": (9, "mono", 0, 0, 1), "monob": (10, "mono", 0, 0, 1),
+    # inputs only: float / half-float pictures and the packed 4:1:1 layout
+    "rgbf32le": (218, "packed", 0, 0, 12), "rgbf32be": (217, "packed", 0, 0, 12), "rgbf16le": (234, "packed", 0, 0, 6), "rgbf16be": (233, "packed", 0, 0, 6),
+    "rgbaf16le": (207, "packed", 0, 0, 8), "rgbaf16be": (206, "packed", 0, 0, 8), "grayf16le": (248, "gray", 0, 0, 2), "grayf16be": (247, "gray", 0, 0, 2),
+    "yaf32le": (253, "packed", 0, 0, 8), "yaf32be": (252, "packed", 0, 0, 8), "yaf16le": (255, "packed", 0, 0, 4), "yaf16be": (254, "packed", 0, 0, 4),
+    "gbrpf16le": (244, "rgbp", 0, 0, 2), "gbrpf16be": (243, "rgbp", 0, 0, 2), "gbrapf16le": (246, "rgbap", 0, 0, 2), "gbrapf16be": (245, "rgbap", 0, 0, 2),
+    "uyyvyy411": (16, "packed411", 2, 0, 1),
     "bgr8": (17, "packed", 0, 0, 1), "bgr4": (18, "nibble", 0, 0, 1), "bgr4_byte": (19, "packed", 0, 0, 1), "rgb8": (20, "packed", 0, 0, 1), "rgb4": (21, "nibble", 0, 0, 1), "rgb4_byte": (22, "packed", 0, 0, 1),
     "xyz12le": (99, "packed", 0, 0, 6), "yuvj411p": (138, "planar", 2, 0, 1), "nv20le": (102, "semi", 1, 0, 2),
     "gbrp10msble": (263, "rgbp", 0, 0, 2), "gbrp12msble": (265, "rgbp", 0, 0, 2),
@@ -76,6 +82,8 @@ def plane_layout(fmt, w, h):
         return [(4 * bps * cw, h)]
     if kind == "mono":           # 1 bit per pixel, MSB first
         return [((w + 7) >> 3, h)]
+    if kind == "packed411":      # U Y Y V Y Y groups: 6 bytes per 4 pixels (av_image_get_linesize: step 6 over the chroma-shifted width)
+        return [(6 * cw, h)]
     if kind == "nibble":         # rgb4 / bgr4: 4 bits per pixel, two pixels per byte
         return [((4 * w + 7) >> 3, h)]
     if kind == "rgbp":
@@ -154,11 +162,20 @@ def fill_random(frame, seed):
             d = int(mp.group(1))
             v = (rng.integers(0, 1 << d, size=(rows, rb // 2), dtype=np.uint16) << (16 - d)).astype(np.uint16)
             a[:, :rb] = (v.byteswap() if be else v).view(np.uint8).reshape(rows, rb)
-        elif f in ("gbrpf32le", "gbrpf32be", "grayf32le", "grayf32be", "gbrapf32le", "gbrapf32be"):
+        elif f[:-2] in ("rgbf16", "rgbaf16", "grayf16", "yaf16", "gbrpf16", "gbrapf16"):
+            v = rng.random(size=(rows, rb // 2), dtype=np.float32).astype(np.float16)
+            flat = v.reshape(-1)
+            flat[::257] = -0.25
+            flat[128::257] = 1.25
+            bits = flat.view(np.uint16)
+            bits[64::131] = rng.integers(0, 65536, size=len(bits[64::131]), dtype=np.uint16)   # any bit pattern: subnormals, infinities, NaNs
+            a[:, :rb] = (v.byteswap() if be else v).view(np.uint8).reshape(rows, rb)
+        elif f in ("gbrpf32le", "gbrpf32be", "grayf32le", "grayf32be", "gbrapf32le", "gbrapf32be", "rgbf32le", "rgbf32be", "yaf32le", "yaf32be"):
             v = rng.random(size=(rows, rb // 4), dtype=np.float32)
             flat = v.reshape(-1)
             flat[::257] = -0.25
             flat[128::257] = 1.25
+            flat[64::1031] = np.nan; flat[65::1031] = np.inf; flat[66::1031] = -np.inf; flat[67::1031] = 1e-42   # av_clipf's NaN rule, a denormal
             a[:, :rb] = (v.byteswap() if be else v).view(np.uint8).reshape(rows, rb)
         else:
             a[:, :rb] = rng.integers(0, 256, size=(rows, rb), dtype=np.uint8)

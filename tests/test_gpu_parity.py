@@ -106,7 +106,9 @@ YUVA_N = ["yuva420p9le", "yuva420p10le", "yuva420p16le", "yuva422p9le", "yuva422
           "yuva444p12le", "yuva444p16le", "yuva420p10be", "yuva422p12be", "yuva444p16be", "yuva444p9be"]
 MISC7 = ["ya8", "ya16le", "ya16be", "grayf32le", "grayf32be", "monob", "monow", "xyz12le", "xyz12be", "yuvj411p", "nv20le", "nv20be", "gbrp10msble", "gbrp12msble", "gbrp10msbbe", "gbrp12msbbe"]
 RGB_LOW = ["rgb565le", "bgr565le", "rgb555le", "bgr555le", "rgb444le", "bgr444le", "rgb565be", "bgr555be"]
-FORMAT_MATRIX_SRC = YUVA_N + MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16
+FLOAT_IN = ["rgbf32le", "rgbf32be", "rgbf16le", "rgbf16be", "rgbaf16le", "rgbaf16be", "grayf16le", "grayf16be", "yaf32le", "yaf32be", "yaf16le", "yaf16be",
+            "gbrpf16le", "gbrpf16be", "gbrapf16le", "gbrapf16be", "uyyvyy411"]   # sources only, like the reference's format table
+FORMAT_MATRIX_SRC = YUVA_N + MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16 + FLOAT_IN
 RGB8_4 = ["rgb8", "bgr8", "rgb4", "bgr4", "rgb4_byte", "bgr4_byte"]   # destinations only (sources need the palette path)
 FORMAT_MATRIX_DST = YUVA_N + MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16 + RGB8_4
 
