@@ -84,6 +84,7 @@ enum AVPixelFormat {
     AV_PIX_FMT_X2RGB10LE = 193, AV_PIX_FMT_X2BGR10LE = 195,
     AV_PIX_FMT_YA8 = 56, AV_PIX_FMT_YA16BE = 109, AV_PIX_FMT_YA16LE = 110,
     AV_PIX_FMT_GRAYF32BE = 182, AV_PIX_FMT_GRAYF32LE = 183,
+    AV_PIX_FMT_PAL8 = 11,   /* input only: data[1] holds 256 native-endian 0xAARRGGBB words */
     /* inputs only (like the reference's format table): float / half-float pictures and the packed 4:1:1 layout */
     AV_PIX_FMT_UYYVYY411 = 16, AV_PIX_FMT_RGBAF16BE = 206, AV_PIX_FMT_RGBAF16LE = 207, AV_PIX_FMT_RGBF32BE = 217, AV_PIX_FMT_RGBF32LE = 218,
     AV_PIX_FMT_RGBF16BE = 233, AV_PIX_FMT_RGBF16LE = 234, AV_PIX_FMT_GBRPF16BE = 243, AV_PIX_FMT_GBRPF16LE = 244, AV_PIX_FMT_GBRAPF16BE = 245,

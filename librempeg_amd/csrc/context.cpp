@@ -112,19 +112,17 @@ static int scaler_from_enum(SwsScaler s, int fallback) // scaler_flag, utils.c:1
     }
 }
 
-// every descriptor row of pixdesc.cpp has a reader and a writer, except the 8 / 4 bpp RGB formats: the reference reads those through
-// a palette (usePal, swscale_internal.h:936-953; palToY_c / palToUV_c), which is not built
+// every descriptor row of pixdesc.cpp has a reader, except the two bit-stream formats (outputs only in the reference's table too)
 static bool fmt_supported_in(int f)
 {
-    if (f == AV_PIX_FMT_RGB8 || f == AV_PIX_FMT_BGR8 || f == AV_PIX_FMT_RGB4_BYTE || f == AV_PIX_FMT_BGR4_BYTE || f == AV_PIX_FMT_RGB4 || f == AV_PIX_FMT_BGR4)
-        return false;
+    if (f == AV_PIX_FMT_RGB4 || f == AV_PIX_FMT_BGR4) return false;
     return pix_desc(f) != nullptr || pix_be_twin(f) >= 0;
 }
 static bool fmt_supported_out(int f)   // (the reference's table, format.c legacy_format_entries, lists the float / half-float family and uyyvyy411 as inputs only)
 {
     const int t = pix_be_twin(f) >= 0 ? pix_be_twin(f) : f;
     switch (t) {
-    case AV_PIX_FMT_UYYVYY411: case AV_PIX_FMT_RGBF32LE: case AV_PIX_FMT_RGBF16LE: case AV_PIX_FMT_RGBAF16LE: case AV_PIX_FMT_GRAYF16LE:
+    case AV_PIX_FMT_PAL8: case AV_PIX_FMT_UYYVYY411: case AV_PIX_FMT_RGBF32LE: case AV_PIX_FMT_RGBF16LE: case AV_PIX_FMT_RGBAF16LE: case AV_PIX_FMT_GRAYF16LE:
     case AV_PIX_FMT_YAF32LE: case AV_PIX_FMT_YAF16LE: case AV_PIX_FMT_GBRPF16LE: case AV_PIX_FMT_GBRAPF16LE: return false;
     }
     return pix_desc(f) != nullptr || pix_be_twin(f) >= 0;
@@ -227,6 +225,11 @@ void choose_unscaled(SwsInternal *c)
         ((k == PLAN_UNSC_PACKED16_GBRP16 || k == PLAN_UNSC_RGB30_TO_GBRP) && isALPHA(d)) ||
         ((k == PLAN_UNSC_GBRP16_PACKED16 || k == PLAN_UNSC_GBRP_TO_RGB30) && isALPHA(s)))
         unsupported = true;
+    // palToRgbWrapper / palToGbrpWrapper (:2619-2630) for the palette-expanded sources.  (usePal() also names gray8, whose grey palette makes
+    // these wrappers a plain replication: the scaler chain gives the same bytes, tests/test_oracle_properties_extra.py)
+    if ((s == AV_PIX_FMT_PAL8 || isRGB8class(s)) && (d == AV_PIX_FMT_GBRP || d == AV_PIX_FMT_GBRAP || d == AV_PIX_FMT_RGB24 || d == AV_PIX_FMT_BGR24 ||
+                                                   d == AV_PIX_FMT_RGBA || d == AV_PIX_FMT_BGRA || d == AV_PIX_FMT_ARGB || d == AV_PIX_FMT_ABGR))
+        k = PLAN_UNSC_PAL2RGB;
     if (s == d || (s == AV_PIX_FMT_YUVA420P && d == AV_PIX_FMT_YUV420P) || (s == AV_PIX_FMT_YUV420P && d == AV_PIX_FMT_YUVA420P) ||
         (isFloatFmt(s) == isFloatFmt(d) && isFloat16Fmt(s) == isFloat16Fmt(d) && ((isPlanarYUV(s) && isGray(d) && !isALPHA(d)) || (isPlanarYUV(d) && isGray(s) && !isALPHA(s)) ||
                                            (isGray(d) && !isALPHA(d) && isGray(s) && !isALPHA(s)))) ||   // isPlanarGray(x) = isGray(x) && !isALPHA(x) (:2673)
@@ -349,7 +352,7 @@ int init_single_context(SwsInternal *c)
     c->chrSrcVSubSample += (flags & SWS_SRC_V_CHR_DROP_MASK) >> SWS_SRC_V_CHR_DROP_SHIFT;
     // RGB sources: chroma is taken from horizontally averaged pixel pairs unless full chroma input
     // is requested (:1369-1390; planar float/high-depth RGB are exempt)
-    if (isAnyRGB(srcFormat) && !(srcW & 1) && !(flags & SWS_FULL_CHR_H_INP) && !(isPlanarRGB(srcFormat) && ds->comp[0].depth > 8) &&
+    if (isAnyRGB(srcFormat) && !(srcW & 1) && !(flags & SWS_FULL_CHR_H_INP) && !(isPlanarRGB(srcFormat) && ds->comp[0].depth > 8) && !isRGB8class(srcFormat) &&
         ((dstW >> c->chrDstHSubSample) <= (srcW >> 1) || (flags & SWS_FAST_BILINEAR)))
         c->chrSrcHSubSample = 1;
 
@@ -360,7 +363,7 @@ int init_single_context(SwsInternal *c)
 
     c->srcBpc = std::max(ds->comp[0].depth, 8);                                 // :1401-1410
     c->dstBpc = std::max(dd->comp[0].depth, 8);
-    if (isAnyRGB(srcFormat)) c->srcBpc = 16;
+    if (isAnyRGB(srcFormat) || srcFormat == AV_PIX_FMT_PAL8) c->srcBpc = 16;
     if (isFloatFmt(srcFormat) && !isAnyRGB(srcFormat)) c->srcBpc = 16;   // "float will be converted to uint16_t" (utils.c:1558-1563)
 
     const int64_t chrXInc = (((int64_t)c->chrSrcW << 16) + (c->chrDstW >> 1)) / c->chrDstW; // :1428-1429

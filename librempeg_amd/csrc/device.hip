@@ -58,7 +58,7 @@ static void dev_state_free(DeviceState *d)
     if (d->stream && d->own_stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
     else if (d->stream) (void)hipStreamSynchronize(d->stream);
     for (void *p : { d->d_tables, d->scratch, d->stage_src, d->stage_dst, (void *)d->d_frames, d->casc_img, d->slice_img, d->d_tilegeom,
-                     d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2, d->casc_img2, d->d_gamma_tab, d->d_ed_err })
+                     d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2, d->casc_img2, d->d_gamma_tab, d->d_ed_err, d->d_pal })
         if (p) (void)hipFree(p);
     if (d->h_frames) (void)hipHostFree(d->h_frames);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
@@ -88,6 +88,7 @@ static int src_kind_of(int f)
 {
     const PixDesc *d = pix_desc(f);
     if (!d) return -1;
+    if (f == AV_PIX_FMT_PAL8 || f == AV_PIX_FMT_RGB8 || f == AV_PIX_FMT_BGR8 || f == AV_PIX_FMT_RGB4_BYTE || f == AV_PIX_FMT_BGR4_BYTE) return SRCK_PAL;
     if (f == AV_PIX_FMT_UYYVYY411) return SRCK_PACKED411;
     if ((d->flags & PIXFLAG_FLOAT) && f != AV_PIX_FMT_GRAYF32LE && f != AV_PIX_FMT_GBRPF32LE && f != AV_PIX_FMT_GBRAPF32LE) return SRCK_FLOATX;
     if (isPlanarRGB(f)) return (d->flags & PIXFLAG_FLOAT) ? SRCK_GBRPF32 : d->comp[0].depth > 8 ? SRCK_GBRP16 : SRCK_GBRP;
@@ -152,11 +153,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     if (c->srcBpc == 8) p.hshift = p.wide ? 3 : 7;                       // hScale8To15_c / hScale8To19_c
     else if (p.wide) {                                                    // hScale16To19_c, swscale.c:69-97
         p.hshift = ds->comp[0].depth - 1 - 4;
-        if (isAnyRGB(o.src_format) && ds->comp[0].depth < 16) p.hshift = 9;
+        if ((isAnyRGB(o.src_format) || o.src_format == AV_PIX_FMT_PAL8) && ds->comp[0].depth < 16) p.hshift = 9;
         else if (ds->flags & PIXFLAG_FLOAT) p.hshift = 16 - 1 - 4;
     } else {                                                              // hScale16To15_c, swscale.c:99-125
         p.hshift = ds->comp[0].depth - 1;
-        if (p.hshift < 15) p.hshift = isAnyRGB(o.src_format) ? 13 : ds->comp[0].depth - 1;
+        if (p.hshift < 15) p.hshift = (isAnyRGB(o.src_format) || o.src_format == AV_PIX_FMT_PAL8) ? 13 : ds->comp[0].depth - 1;
         else if (ds->flags & PIXFLAG_FLOAT) p.hshift = 16 - 1;
     }
     p.dst_bits = dd->comp[0].depth; p.dst_shift = dd->comp[0].shift;
@@ -661,6 +662,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     case PLAN_UNSC_YUV2RGB48: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb48_unscaled"; break;
     case PLAN_UNSC_YUV2RGB16: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb16_unscaled"; break;
     case PLAN_UNSC_YUV2RGB8: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb8_unscaled"; break;
+    case PLAN_UNSC_PAL2RGB: c->path_name = "unscaled:palToRgb"; c->kernel_name = "sws_k_pal2rgb"; break;
     case PLAN_UNSC_RGBLOW: c->path_name = "unscaled:rgbToRgb"; c->kernel_name = "sws_k_rgb_low_convert"; break;
     case PLAN_UNSC_PLANAR2P422: c->path_name = "unscaled:planarToYuy2"; c->kernel_name = "sws_k_planar_to_p422"; break;
     case PLAN_UNSC_P4222PLANAR: c->path_name = "unscaled:yuyvToPlanar"; c->kernel_name = "sws_k_p422_to_planar"; break;
@@ -717,6 +719,7 @@ static int plane_geometry(int format, int w, int h, int plane, int *row_bytes, i
     if (!d) return -1;
     const int np = pix_nb_planes(d);
     if (plane >= np) { *row_bytes = 0; *rows = 0; return 0; }
+    if ((d->flags & PIXFLAG_PAL) && plane == 1) { *row_bytes = 1024; *rows = 1; return 0; }   // the palette: 256 words, one "row"
     // bytes per row = max over components in this plane of (step * samples); libavutil/imgutils.c av_image_get_linesize
     int step = 0; bool chroma = false;
     for (int c = 0; c < d->nb_components; c++)
@@ -734,6 +737,7 @@ static int rows_of_slice(int format, int plane, int sliceY, int sliceH, int *y0,
 {
     const PixDesc *d = pix_desc(format);
     bool chroma = false;
+    if ((d->flags & PIXFLAG_PAL) && plane == 1) { *y0 = 0; *rows = 1; return 0; }   // every slice comes with the whole palette
     for (int c = 0; c < d->nb_components; c++) if (d->comp[c].plane == plane) chroma = (c == 1 || c == 2);
     const bool sub = chroma && !(d->flags & PIXFLAG_RGB);
     if (sub) { *y0 = sliceY >> d->log2_chroma_h; *rows = -((-sliceH) >> d->log2_chroma_h); }
@@ -803,6 +807,22 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         for (auto &f : dropped) { f.srcStride[1] *= 1 << drop; f.srcStride[2] *= 1 << drop; }
         frames = dropped.data();
     }
+    // Palette-expanded sources (usePal, swscale_internal.h:937-950): scale_internal runs ff_update_palette before every conversion
+    // (swscale.c:1088-1089).  Here every frame of the batch gets its own pair of 256-word tables in HBM - pal_yuv, then pal_rgb in the
+    // destination's byte order - filled by sws_k_update_palette ahead of the converter on the same stream; the kernels find them through
+    // src[1] of the frame, the caller's palette (pal8 only) moves to src[2].
+    std::vector<SwsFramePtrs> palfr;
+    if (p.srcKind == SRCK_PAL) {
+        int r = grow(c, &d->d_pal, &d->d_pal_bytes, (size_t)n * 512 * sizeof(uint32_t));
+        if (r < 0) return r;
+        palfr.assign(frames, frames + n);
+        for (int i = 0; i < n; i++) {
+            palfr[i].src[2] = c->opts.src_format == AV_PIX_FMT_PAL8 ? palfr[i].src[1] : nullptr;
+            palfr[i].src[1] = (const uint8_t *)((uint32_t *)d->d_pal + (size_t)i * 512);
+            if (c->opts.src_format == AV_PIX_FMT_PAL8 && !palfr[i].src[2]) { log_msg(c, 0, "pal8 picture without a palette in data[1]\n"); return SWS_AVERROR(EINVAL); }
+        }
+        frames = palfr.data();
+    }
     LaunchCtx L;
     std::memset(&L.fs, 0, sizeof(L.fs));
     SwsFrameSet &fs = L.fs;
@@ -836,6 +856,7 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
     if (c->opts.dst_format == AV_PIX_FMT_YUVA420P && sliceH > 0 &&
         (c->plan == PLAN_UNSC_BGR24_YV12 || c->plan == PLAN_UNSC_YVU9_YV12 || c->plan == PLAN_UNSC_P4222PLANAR))
         launch_fill_alpha(L, p.srcW, sliceY, sliceH, 0);
+    if (p.srcKind == SRCK_PAL) launch_update_palette(L);
     int ret = 0;
     switch (c->plan) {
     case PLAN_UNSC_YUV2RGB: ret = launch_yuv2rgb(L); break;
@@ -1174,6 +1195,8 @@ static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4
             if (!d->d_ed_err) {   // FF_ALLOCZ_TYPED_ARRAY(c->dither_error[i], dst_w + 3), utils.c:1744-1747
                 HIPCHK(hipMalloc(&d->d_ed_err, sizeof(int) * 3 * (size_t)(W + 3)));
                 HIPCHK(hipMemsetAsync(d->d_ed_err, 0, sizeof(int) * 3 * (size_t)(W + 3), d->stream));
+            } else if (o.flags & SWS_BITEXACT) {   // scale_internal (swscale.c:1084-1086): a bit-exact context starts every frame from a clean line
+                HIPCHK(hipMemsetAsync(d->d_ed_err, 0, sizeof(int) * 3 * (size_t)(W + 3), d->stream));
             }
             if (is_device_ptr(dst[0])) {
                 launch_ed_rgb8(d->stream, tmp[0], tls[0], dst[0], dstStride[0], W, H, (int *)d->d_ed_err, b8pp ? 8 : 4, r8, g8, b8);
@@ -1269,7 +1292,9 @@ static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4
             rows = std::min(rows, prow - y0);
             uint8_t *dbase = (uint8_t *)d->stage_src + offs[k];
             const uint8_t *s = src[k]; // slice-relative for unscaled, whole plane otherwise
-            if (srcStride[k] >= 0) {
+            if (rows == 1) {   // (also the palette of a pal8 picture, whose linesize means nothing)
+                HIPCHK(hipMemcpyAsync(dbase + (size_t)y0 * ls[k], s, rb, hipMemcpyHostToDevice, st));
+            } else if (srcStride[k] >= 0) {
                 HIPCHK(hipMemcpy2DAsync(dbase + (size_t)y0 * ls[k], ls[k], s, srcStride[k], rb, rows, hipMemcpyHostToDevice, st));
             } else { // bottom-up image: copy row by row in reverse so the staged plane is top-down
                 for (int y = 0; y < rows; y++)

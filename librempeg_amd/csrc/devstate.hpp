@@ -34,6 +34,7 @@ struct DeviceState {
     void *stage_dst = nullptr; size_t stage_dst_bytes = 0;
     SwsFramePtrs *d_frames = nullptr, *h_frames = nullptr; int frames_cap = 0, frames_valid = 0;
     void *casc_img = nullptr; size_t casc_bytes = 0; int casc_stride = 0;
+    void *d_pal = nullptr; size_t d_pal_bytes = 0;   // palette-expanded sources: per frame pal_yuv[256] + pal_rgb[256]
     void *d_ed_err = nullptr;   // error-diffusion line of an 8 / 4 bpp destination: 3 x (dst_w + 3) ints, zeroed once, carried between frames
     void *casc_img2 = nullptr; size_t casc_bytes2 = 0; void *d_gamma_tab = nullptr;   // gamma cascade: second RGBA64 intermediate, the two 65536-entry tables
     void *slice_img = nullptr; size_t slice_bytes = 0;   // source image assembled from sws_scale() slices (scaled path)
@@ -79,6 +80,7 @@ static inline bool frames_desc_ok(const SwsFramePtrs *fr, int n, int srcH, int d
 // ---- k_misc.hip: element-per-thread unscaled converters and helper passes ----
 int  launch_misc(const LaunchCtx &L);                                   // every PLAN_UNSC_* plan not named below
 void launch_fill_alpha(const LaunchCtx &L, int w, int y0, int rows, int bits);
+void launch_update_palette(const LaunchCtx &L);
 void launch_alpha_merge(const LaunchCtx &L, int npix, int y0, int rows, int a_pos);
 void launch_bswap(hipStream_t st, const uint8_t *src, int64_t sstride, uint8_t *dst, int64_t dstride, int rows, int row_bytes, int unit);
 void launch_gamma_rgba64(hipStream_t st, uint8_t *img, int64_t stride, int w, int rows, const uint16_t *table);

@@ -189,6 +189,15 @@ int launch_misc(const LaunchCtx &L)
         hipLaunchKernelGGL(swsk::sws_k_yuv2rgb16_unscaled, grid, blk, 0, st, fs, p, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 0, npairs, sliceY);
         break;
     }
+    case PLAN_UNSC_PAL2RGB: {
+        const int df = c->opts.dst_format;
+        const bool planar = df == AV_PIX_FMT_GBRP || df == AV_PIX_FMT_GBRAP;
+        const int nbytes = planar ? (df == AV_PIX_FMT_GBRAP ? 4 : 3) : pix_desc(df)->comp[0].step;
+        if (sliceH <= 0) break;
+        const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
+        hipLaunchKernelGGL(swsk::sws_k_pal2rgb, grid, blk, 0, st, fs, p.srcW, sliceY, nbytes, planar ? 1 : 0);
+        break;
+    }
     case PLAN_UNSC_YUV2RGB8: {
         const int dstW = p.dstW;
         const int npairs = ((dstW >> 3) << 2) + ((dstW & 4) ? 2 : 0) + ((dstW & 2) ? 1 : 0); // yuv2rgb.c:198-236
@@ -332,6 +341,10 @@ void launch_gamma_rgba64(hipStream_t st, uint8_t *img, int64_t stride, int w, in
     if (w <= 0 || rows <= 0) return;
     const dim3 grid(cdiv(w, 256), rows);
     hipLaunchKernelGGL(swsk::sws_k_gamma_rgba64, grid, dim3(256), 0, st, img, stride, w, rows, table);
+}
+void launch_update_palette(const LaunchCtx &L)
+{
+    hipLaunchKernelGGL(swsk::sws_k_update_palette, dim3(L.n), dim3(256), 0, L.st, L.fs, *L.p, L.c->opts.src_format, L.c->opts.dst_format);
 }
 void launch_ed_rgb8(hipStream_t st, const uint8_t *rgb, int64_t rgbStride, uint8_t *dst, int64_t dstStride, int w, int h, int *errline,
                     int bpp8, int r8, int g8, int b8)

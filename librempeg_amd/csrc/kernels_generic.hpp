@@ -55,6 +55,11 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         const int o = comp == 0 ? 0 : comp == 1 ? 3 : 6;
         return (uint16_t)((int)((unsigned)t[o] * r + (unsigned)t[o + 1] * g + (unsigned)t[o + 2] * b + ((comp == 0 ? 0x2001u : 0x10001u) << 14)) >> 15);
     }
+    if (p.srcKind == SRCK_PAL) {   // palToY_c / palToUV_c / palToA_c (input.c:474-512) on the frame's pal_yuv table (sws_k_update_palette)
+        const uint32_t e = ((const uint32_t *)f.src[1])[f.src[0][(int64_t)prow * f.srcStride[0] + x]];
+        if (comp == 3) return (int)((e >> 24) << 6 | e >> 26);
+        return (int)((e >> (8 * comp)) & 0xFF) << 6;
+    }
     if (p.srcKind == SRCK_PACKED411) {   // uyyvyyToY_c / uyyvyyToUV_c (input.c:909-925): U Y Y V Y Y groups
         const uint8_t *s = f.src[0] + (int64_t)prow * f.srcStride[0];
         return comp == 0 ? s[3 * (x >> 1) + 1 + (x & 1)] : s[6 * x + (comp == 1 ? 0 : 3)];

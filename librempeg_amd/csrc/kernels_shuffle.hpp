@@ -467,6 +467,58 @@ __global__ void __launch_bounds__(256) sws_k_yuv2rgb16_unscaled(SwsFrameSet fs, 
     }
 }
 
+// ff_update_palette (swscale.c:873-951): one workgroup per frame, one thread per palette entry.  pal8 reads the caller's 0xAARRGGBB
+// words (src[2]), the 8 / 4 bpp RGB formats expand their bit fields (an index beyond a 4-bit format's 16 values spills a channel
+// into its neighbours, like the reference's plain sums).  Writes pal_yuv[256] then pal_rgb[256] (the word whose bytes are the
+// destination's, little-endian rows of :916-949) at src[1].
+__global__ void __launch_bounds__(256) sws_k_update_palette(SwsFrameSet fs, SwsDevParams p, int srcFormat, int dstFormat)
+{
+    const int i = threadIdx.x;
+    const FrameRegs f = load_frame(fs, blockIdx.x);
+    uint32_t *tab = (uint32_t *)f.src[1];
+    int r, g, b, a = 0xff;
+    if (srcFormat == AV_PIX_FMT_PAL8) { const uint32_t e = ((const uint32_t *)f.src[2])[i]; a = (e >> 24) & 0xFF; r = (e >> 16) & 0xFF; g = (e >> 8) & 0xFF; b = e & 0xFF; }
+    else if (srcFormat == AV_PIX_FMT_RGB8) { r = (i >> 5) * 36; g = ((i >> 2) & 7) * 36; b = (i & 3) * 85; }
+    else if (srcFormat == AV_PIX_FMT_BGR8) { b = (i >> 6) * 85; g = ((i >> 3) & 7) * 36; r = (i & 7) * 36; }
+    else if (srcFormat == AV_PIX_FMT_RGB4_BYTE) { r = (i >> 3) * 255; g = ((i >> 1) & 3) * 85; b = (i & 1) * 255; }
+    else { b = (i >> 3) * 255; g = ((i >> 1) & 3) * 85; r = (i & 1) * 255; }
+    const int32_t *t = p.rgb2yuv;
+    // (clip_u8_shr, not clip_u8(x >> 15): packing three of those into one word is the pattern hipcc 7.2 turns into v_ashr_pk_u8_i32 with
+    // stale upper bits, see kernels_common.hpp)
+    const int y = clip_u8_shr(t[0] * r + t[1] * g + t[2] * b + (33 << 14), 15);
+    const int u = clip_u8_shr(t[3] * r + t[4] * g + t[5] * b + (257 << 14), 15);
+    const int v = clip_u8_shr(t[6] * r + t[7] * g + t[8] * b + (257 << 14), 15);
+    tab[i] = (uint32_t)y + ((uint32_t)u << 8) + ((uint32_t)v << 16) + ((uint32_t)a << 24);
+    uint32_t w;
+    switch (dstFormat) {
+    case AV_PIX_FMT_RGBA: case AV_PIX_FMT_RGB24: w = (uint32_t)(r + (g << 8) + (b << 16)) + ((uint32_t)a << 24); break;   // BGR32, RGB24
+    case AV_PIX_FMT_ARGB: w = (uint32_t)(a + (r << 8) + (g << 16)) + ((uint32_t)b << 24); break;                          // BGR32_1
+    case AV_PIX_FMT_ABGR: w = (uint32_t)(a + (b << 8) + (g << 16)) + ((uint32_t)r << 24); break;                          // RGB32_1
+    case AV_PIX_FMT_GBRP: case AV_PIX_FMT_GBRAP: w = (uint32_t)(g + (b << 8) + (r << 16)) + ((uint32_t)a << 24); break;
+    default: w = (uint32_t)(b + (g << 8) + (r << 16)) + ((uint32_t)a << 24); break;                                       // RGB32, BGR24, ...
+    }
+    tab[256 + i] = w;
+}
+
+// palToRgbWrapper with sws_convertPalette8ToPacked32 / 24 (swscale_unscaled.c:600-644, :2707-2730) and palToGbrpWrapper with pal8ToPlanar8
+// (:531-545, :646-683): the bytes of the pal_rgb word are the destination's bytes.  nbytes = 3 / 4 (packed) or the number of planes.
+__global__ void __launch_bounds__(256) sws_k_pal2rgb(SwsFrameSet fs, int w, int sliceY, int nbytes, int planar)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= w) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int y = sliceY + blockIdx.y;
+    const uint32_t e = ((const uint32_t *)f.src[1])[256 + f.src[0][(int64_t)y * f.srcStride[0] + x]];
+    if (planar) {
+        for (int k = 0; k < nbytes; k++) f.dst[k][(int64_t)y * f.dstStride[k] + x] = (uint8_t)(e >> (8 * k));
+    } else if (nbytes == 4) {
+        ((uint32_t *)(f.dst[0] + (int64_t)y * f.dstStride[0]))[x] = e;
+    } else {
+        uint8_t *d = f.dst[0] + (int64_t)y * f.dstStride[0] + 3 * x;
+        d[0] = (uint8_t)e; d[1] = (uint8_t)(e >> 8); d[2] = (uint8_t)(e >> 16);
+    }
+}
+
 // yuv2rgb_c_8 / 4 / 4b_ordered_dither and yuv422p_bgr8 / bgr4 / bgr4_byte (YUV420FUNC_DITHER / YUV422FUNC_DITHER + PUTRGB8 / PUTRGB4D /
 // PUTRGB4DB, yuv2rgb.c:283-369, :413-455).  One thread = one chroma sample = 2 pixels x 2 rows.  LOADDITHER8 / 4D / 4DB select the rows
 // of the 8x8 tables by the ABSOLUTE even row (yd & 7), the second line of the pair reads the following row; the column is the pixel's.

@@ -109,6 +109,7 @@ static const PixDesc g_descs[] = {
     { AV_PIX_FMT_GRAYF32LE, "grayf32le", 1, 0, 0, {{0,4,0,0,32},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_FLOAT },
     { AV_PIX_FMT_MONOWHITE, "monow", 1, 0, 0, {{0,1,0,0,1},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_RGB },   // 1 bit per pixel, MSB first; isAnyRGB() counts them in
     { AV_PIX_FMT_MONOBLACK, "monob", 1, 0, 0, {{0,1,0,7,1},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_RGB },
+    { AV_PIX_FMT_PAL8, "pal8", 1, 0, 0, {{0,1,0,0,8},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_PAL | PIXFLAG_ALPHA },   // one index plane + the palette in data[1]; input only
     // float and half-float sources (libavutil/pixdesc.c:2583-2717, :2932-2971, :3108-3119) and the packed 4:1:1 source (:484-494): inputs only
     { AV_PIX_FMT_RGBF32LE, "rgbf32le", 3, 0, 0, {{0,12,0,0,32},{0,12,4,0,32},{0,12,8,0,32},{0,0,0,0,0}}, PIXFLAG_RGB | PIXFLAG_FLOAT },
     { AV_PIX_FMT_RGBF16LE, "rgbf16le", 3, 0, 0, {{0,6,0,0,16},{0,6,2,0,16},{0,6,4,0,16},{0,0,0,0,0}}, PIXFLAG_RGB | PIXFLAG_FLOAT },
@@ -162,6 +163,7 @@ int pix_nb_planes(const PixDesc *d)
     int n = 0;
     for (int c = 0; c < d->nb_components; c++)
         if (d->comp[c].plane + 1 > n) n = d->comp[c].plane + 1;
+    if (d->flags & PIXFLAG_PAL) n = 2;   // data[1]: the palette
     return n;
 }
 
@@ -172,12 +174,12 @@ bool isPlanarYUV(int f) { return (pix_desc(f)->flags & PIXFLAG_PLANAR) && isYUV(
 bool isSemiPlanarYUV(int f) { const PixDesc *d = pix_desc(f); return isPlanarYUV(f) && d->comp[1].plane == d->comp[2].plane; }
 bool isAnyRGB(int f) { return (pix_desc(f)->flags & PIXFLAG_RGB) != 0; }
 static bool isMonoFmt(int f) { return f == AV_PIX_FMT_MONOWHITE || f == AV_PIX_FMT_MONOBLACK; }
-bool isGray(int f) { return pix_desc(f)->nb_components <= 2 && !isMonoFmt(f); }   // swscale_internal.h:805-815
+bool isGray(int f) { return pix_desc(f)->nb_components <= 2 && !isMonoFmt(f) && !(pix_desc(f)->flags & PIXFLAG_PAL); }   // swscale_internal.h:805-815
 bool isFloatFmt(int f) { return (pix_desc(f)->flags & PIXFLAG_FLOAT) != 0; }
 bool isFloat16Fmt(int f) { const PixDesc *d = pix_desc(f); return (d->flags & PIXFLAG_FLOAT) && d->comp[0].depth == 16; }   // swscale_internal.h:890-895
 bool isALPHA(int f) { return (pix_desc(f)->flags & PIXFLAG_ALPHA) != 0; }
 bool isPlanarRGB(int f) { return (pix_desc(f)->flags & (PIXFLAG_PLANAR | PIXFLAG_RGB)) == (PIXFLAG_PLANAR | PIXFLAG_RGB); }
-bool isPackedFmt(int f) { const PixDesc *d = pix_desc(f); return (d->nb_components >= 2 && !(d->flags & PIXFLAG_PLANAR)) || isMonoFmt(f); }   // swscale_internal.h:906-914
+bool isPackedFmt(int f) { const PixDesc *d = pix_desc(f); return (d->nb_components >= 2 && !(d->flags & PIXFLAG_PLANAR)) || isMonoFmt(f) || f == AV_PIX_FMT_PAL8; }   // swscale_internal.h:906-914
 bool isPlanarFmt(int f) { const PixDesc *d = pix_desc(f); return d->nb_components >= 2 && (d->flags & PIXFLAG_PLANAR); }
 bool isSwappedChroma(int f)
 {

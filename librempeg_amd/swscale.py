@@ -37,7 +37,7 @@ _FORMATS = {
     "rgbaf16le": (207, "packed", 0, 0, 8), "rgbaf16be": (206, "packed", 0, 0, 8), "grayf16le": (248, "gray", 0, 0, 2), "grayf16be": (247, "gray", 0, 0, 2),
     "yaf32le": (253, "packed", 0, 0, 8), "yaf32be": (252, "packed", 0, 0, 8), "yaf16le": (255, "packed", 0, 0, 4), "yaf16be": (254, "packed", 0, 0, 4),
     "gbrpf16le": (244, "rgbp", 0, 0, 2), "gbrpf16be": (243, "rgbp", 0, 0, 2), "gbrapf16le": (246, "rgbap", 0, 0, 2), "gbrapf16be": (245, "rgbap", 0, 0, 2),
-    "uyyvyy411": (16, "packed411", 2, 0, 1),
+    "uyyvyy411": (16, "packed411", 2, 0, 1), "pal8": (11, "pal", 0, 0, 1),
     "bgr8": (17, "packed", 0, 0, 1), "bgr4": (18, "nibble", 0, 0, 1), "bgr4_byte": (19, "packed", 0, 0, 1), "rgb8": (20, "packed", 0, 0, 1), "rgb4": (21, "nibble", 0, 0, 1), "rgb4_byte": (22, "packed", 0, 0, 1),
     "xyz12le": (99, "packed", 0, 0, 6), "yuvj411p": (138, "planar", 2, 0, 1), "nv20le": (102, "semi", 1, 0, 2),
     "gbrp10msble": (263, "rgbp", 0, 0, 2), "gbrp12msble": (265, "rgbp", 0, 0, 2),
@@ -96,6 +96,8 @@ def plane_layout(fmt, w, h):
         return [((w + 7) >> 3, h)]
     if kind == "packed411":      # U Y Y V Y Y groups: 6 bytes per 4 pixels (av_image_get_linesize: step 6 over the chroma-shifted width)
         return [(6 * cw, h)]
+    if kind == "pal":            # index plane + 256 native-endian 0xAARRGGBB words in data[1]
+        return [(w, h), (1024, 1)]
     if kind == "nibble":         # rgb4 / bgr4: 4 bits per pixel, two pixels per byte
         return [((4 * w + 7) >> 3, h)]
     if kind == "rgbp":

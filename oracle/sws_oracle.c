@@ -54,6 +54,7 @@ static int clip_i16(int a) { return a < -32768 ? -32768 : a > 32767 ? 32767 : a;
 #define PF_RGB    (1 << 5)
 #define PF_ALPHA  (1 << 7)
 #define PF_FLOAT  (1 << 9)
+#define PF_PAL    (1 << 1)
 
 typedef struct { int plane, step, offset, shift, depth; } Comp;
 typedef struct {
@@ -148,6 +149,7 @@ static const Desc descs[] = {
     { ORF_GRAYF32LE, "grayf32le", 1, 0, 0, {{0,4,0,0,32}}, PF_FLOAT },
     { ORF_MONOWHITE, "monow", 1, 0, 0, {{0,1,0,0,1}}, PF_RGB },   /* 1 bit per pixel, MSB first; isAnyRGB() counts them in (swscale_internal.h:876-882) */
     { ORF_MONOBLACK, "monob", 1, 0, 0, {{0,1,0,7,1}}, PF_RGB },
+    { ORF_PAL8, "pal8", 1, 0, 0, {{0,1,0,0,8}}, PF_PAL | PF_ALPHA },   /* pixdesc.c: one index plane + the palette in data[1] */
     /* float and half-float sources (pixdesc.c:2583-2717, :2932-2971, :3108-3119), the packed 4:1:1 source (:484-494): inputs only */
     { ORF_RGBF32LE, "rgbf32le", 3, 0, 0, {{0,12,0,0,32},{0,12,4,0,32},{0,12,8,0,32}}, PF_RGB | PF_FLOAT },
     { ORF_RGBF16LE, "rgbf16le", 3, 0, 0, {{0,6,0,0,16},{0,6,2,0,16},{0,6,4,0,16}}, PF_RGB | PF_FLOAT },
@@ -274,14 +276,17 @@ static int isSemiPlanarYUV(int f) { const Desc *d = desc_get(f); return isPlanar
 static int isAnyRGB(int f) { return !!(desc_get(f)->flags & PF_RGB); }
 static int isYA(int f) { return f == ORF_YA8 || f == ORF_YA16LE; }
 static int isMono(int f) { return f == ORF_MONOWHITE || f == ORF_MONOBLACK; }
-static int isGray(int f) { return desc_get(f)->nb <= 2 && !isMono(f); }   /* swscale_internal.h:805-815 */
+static int isGray(int f) { return desc_get(f)->nb <= 2 && !isMono(f) && !(desc_get(f)->flags & PF_PAL); }   /* swscale_internal.h:805-815 */
 static int isFloat(int f) { return !!(desc_get(f)->flags & PF_FLOAT); }
 static int isFloat16(int f) { return isFloat(f) && desc_get(f)->c[0].depth == 16; }   /* swscale_internal.h:890-895 */
 /* the formats the reference's table (format.c legacy_format_entries) lists as inputs only */
-static int isInputOnly(int f) { return f == ORF_UYYVYY411 || f == ORF_RGBF32LE || f == ORF_RGBF16LE || f == ORF_RGBAF16LE || f == ORF_GRAYF16LE || f == ORF_YAF32LE || f == ORF_YAF16LE || f == ORF_GBRPF16LE || f == ORF_GBRAPF16LE; }
+/* usePal (swscale_internal.h:937-950) without gray8, whose grey palette only feeds palToRgbWrapper / palToGbrpWrapper: the scaler chain gives
+ * the same bytes for it (tests/test_oracle_properties_extra.py) */
+static int isPalSrc(int f) { return f == ORF_PAL8 || f == ORF_RGB8 || f == ORF_BGR8 || f == ORF_RGB4_BYTE || f == ORF_BGR4_BYTE; }
+static int isInputOnly(int f) { return f == ORF_PAL8 || f == ORF_UYYVYY411 || f == ORF_RGBF32LE || f == ORF_RGBF16LE || f == ORF_RGBAF16LE || f == ORF_GRAYF16LE || f == ORF_YAF32LE || f == ORF_YAF16LE || f == ORF_GBRPF16LE || f == ORF_GBRAPF16LE; }
 static int isALPHA(int f) { return !!(desc_get(f)->flags & PF_ALPHA); }
 static int isPlanarRGB(int f) { return (desc_get(f)->flags & (PF_PLANAR | PF_RGB)) == (PF_PLANAR | PF_RGB); }
-static int isPacked(int f) { const Desc *d = desc_get(f); return (d->nb >= 2 && !(d->flags & PF_PLANAR)) || isMono(f); }   /* swscale_internal.h:906-914 */
+static int isPacked(int f) { const Desc *d = desc_get(f); return (d->nb >= 2 && !(d->flags & PF_PLANAR)) || isMono(f) || f == ORF_PAL8; }   /* swscale_internal.h:906-914 */
 static int isSwappedChroma(int f)
 {
     const Desc *d = desc_get(f);
@@ -320,7 +325,7 @@ enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
        UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_RGBLOW, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED,
        UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP, UNSC_RGB30_TO_16, UNSC_RGB30_TO_GBRP, UNSC_GBRP_TO_RGB30, UNSC_YUV2MONO, UNSC_U8_TO_F32, UNSC_F32_TO_U8,
        UNSC_PLANAR2P422, UNSC_P4222PLANAR,
-       UNSC_RGB16SHUFFLE, UNSC_PACKED16_TO_GBRP16, UNSC_GBRP16_TO_PACKED16, UNSC_ALPHABLEND, UNSC_PLANARRGB_PLANARRGB,
+       UNSC_RGB16SHUFFLE, UNSC_PACKED16_TO_GBRP16, UNSC_GBRP16_TO_PACKED16, UNSC_ALPHABLEND, UNSC_PLANARRGB_PLANARRGB, UNSC_PAL2RGB,
        UNSC_REFUSE = -1 /* a special converter of the reference that is not restated */ };
 
 struct OrSws {
@@ -352,6 +357,7 @@ struct OrSws {
     /* gamma cascade (utils.c:1461-1522): cascade[1] scales RGBA64 -> RGBA64 between two in-place table passes, cascade[2] converts to the
      * destination format from a second intermediate */
     int casc_mainindex;   /* the child sws_setColorspaceDetails() is forwarded to (utils.c:909-910): 1 for the alpha-blend cascade */
+    uint32_t pal_yuv[256], pal_rgb[256];   /* ff_update_palette (swscale.c:873-951) */
     int *dither_error[3];   /* utils.c:1744-1747: dst_w + 3 zeroed ints per channel; never reset between frames or slices */
     int casc_gamma; uint8_t *casc_tmp2; int casc_stride2; uint16_t *gamma_tab, *inv_gamma_tab;
     int initialized;
@@ -1233,6 +1239,9 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         ((c->unscaled_kind == UNSC_PACKED16_TO_GBRP16 || c->unscaled_kind == UNSC_RGB30_TO_GBRP) && isALPHA(d)) ||
         ((c->unscaled_kind == UNSC_GBRP16_TO_PACKED16 || c->unscaled_kind == UNSC_GBRP_TO_RGB30) && isALPHA(s)))
         c->unscaled_kind = UNSC_REFUSE;
+    /* palToRgbWrapper / palToGbrpWrapper (:2619-2630) for the palette-expanded sources (gray8 is left to the scaler chain, see isPalSrc) */
+    if (isPalSrc(s) && (d == ORF_GBRP || d == ORF_GBRAP || d == ORF_RGB24 || d == ORF_BGR24 || d == ORF_RGBA || d == ORF_BGRA || d == ORF_ARGB || d == ORF_ABGR))
+        c->unscaled_kind = UNSC_PAL2RGB;
     /* simple copy (:2647-2668) */
     if (s == d || (s == ORF_YUVA420P && d == ORF_YUV420P) || (s == ORF_YUV420P && d == ORF_YUVA420P) ||
         (isFloat(s) == isFloat(d) && isFloat16(s) == isFloat16(d) &&
@@ -1272,7 +1281,7 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
     srcFormat = c->o.src_format; dstFormat = c->o.dst_format;
     ds = desc_get(srcFormat); dd = desc_get(dstFormat);
     if (!ds || !dd) return -1;
-    if (isRGB8class(srcFormat) || isRGB4bits(srcFormat)) return -1;
+    if (isRGB4bits(srcFormat)) return -1;   /* rgb4 / bgr4: outputs only (format.c legacy_format_entries) */
     if (isInputOnly(dstFormat)) return -1;   /* "... is not supported as output pixel format" (utils.c:1198-1208) */   /* palette-expanded inputs (usePal, swscale_internal.h:936-953): not restated */
 
     i = flags & (OR_SWS_POINT | OR_SWS_AREA | OR_SWS_BILINEAR | OR_SWS_FAST_BILINEAR | OR_SWS_BICUBIC |
@@ -1318,7 +1327,7 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
 
     c->chrSrcVSub += (flags & 0x30000) >> 16; /* vChrDrop: "drop some chroma lines if the user wants it" (utils.c:1362-1365) */
 
-    if (isAnyRGB(srcFormat) && !(srcW & 1) && !(flags & OR_SWS_FULL_CHR_H_INP) &&
+    if (isAnyRGB(srcFormat) && !(srcW & 1) && !(flags & OR_SWS_FULL_CHR_H_INP) && !isRGB8class(srcFormat) &&
         !(isPlanarRGB(srcFormat) && ds->c[0].depth > 8) && /* gbrp9..16, gbrpf32: no _half readers (:1369-1388) */
         ((dstW >> c->chrDstHSub) <= (srcW >> 1) || (flags & OR_SWS_FAST_BILINEAR))) /* :1369-1390 */
         c->chrSrcHSub = 1;
@@ -1330,7 +1339,7 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
 
     c->srcBpc = ds->c[0].depth; if (c->srcBpc < 8) c->srcBpc = 8;
     c->dstBpc = dd->c[0].depth; if (c->dstBpc < 8) c->dstBpc = 8;
-    if (isAnyRGB(srcFormat)) c->srcBpc = 16;
+    if (isAnyRGB(srcFormat) || srcFormat == ORF_PAL8) c->srcBpc = 16;
     if (isFloat(srcFormat) && !isAnyRGB(srcFormat)) c->srcBpc = 16;   /* "float will be converted to uint16_t" (utils.c:1558-1563; the unscaled exceptions never reach the scaler) */
 
     chrXInc = (((int64_t)c->chrSrcW << 16) + (c->chrDstW >> 1)) / c->chrDstW;
@@ -2346,6 +2355,57 @@ static int rdf16(const uint8_t *p, int half)
 static int isPackedFloatRGB(int f) { return f == ORF_RGBF32LE || f == ORF_RGBF16LE || f == ORF_RGBAF16LE; }
 static int isFloatGrayX(int f) { return f == ORF_GRAYF16LE || f == ORF_YAF32LE || f == ORF_YAF16LE; }   /* (grayf32 has its own case) */
 
+/* ff_update_palette (swscale.c:873-951), run by scale_internal before every conversion of a usePal() source (:1088-1089): pal8 reads
+ * data[1] (256 native-endian 0xAARRGGBB words), the 8 / 4 bpp RGB formats expand their bit fields */
+static void update_palette(OrSws *c, const uint8_t *pal)
+{
+    const int32_t *t = c->rgb2yuv;
+    const int f = c->o.src_format;
+    for (int i = 0; i < 256; i++) {
+        int r, g, b, y, u, v, a = 0xff;
+        if (f == ORF_PAL8) { uint32_t p; memcpy(&p, pal + 4 * i, 4); a = (p >> 24) & 0xFF; r = (p >> 16) & 0xFF; g = (p >> 8) & 0xFF; b = p & 0xFF; }
+        else if (f == ORF_RGB8) { r = (i >> 5) * 36; g = ((i >> 2) & 7) * 36; b = (i & 3) * 85; }
+        else if (f == ORF_BGR8) { b = (i >> 6) * 85; g = ((i >> 3) & 7) * 36; r = (i & 7) * 36; }
+        else if (f == ORF_RGB4_BYTE) { r = (i >> 3) * 255; g = ((i >> 1) & 3) * 85; b = (i & 1) * 255; }
+        else { b = (i >> 3) * 255; g = ((i >> 1) & 3) * 85; r = (i & 1) * 255; }   /* bgr4_byte */
+        y = clip_u8((t[RY] * r + t[GY] * g + t[BY] * b + (33 << (15 - 1))) >> 15);
+        u = clip_u8((t[RU] * r + t[GU] * g + t[BU] * b + (257 << (15 - 1))) >> 15);
+        v = clip_u8((t[RV] * r + t[GV] * g + t[BV] * b + (257 << (15 - 1))) >> 15);
+        c->pal_yuv[i] = (uint32_t)y + ((uint32_t)u << 8) + ((uint32_t)v << 16) + ((uint32_t)a << 24);
+        /* the word whose memory bytes are the destination's (little-endian rows of swscale.c:916-949); plain sums, so an index beyond a
+         * 4-bit format's 16 values spills a channel into its neighbours exactly like there */
+        switch (c->o.dst_format) {
+        case ORF_RGBA: case ORF_RGB24: c->pal_rgb[i] = (uint32_t)(r + (g << 8) + (b << 16)) + ((uint32_t)a << 24); break;   /* BGR32, RGB24 */
+        case ORF_ARGB: c->pal_rgb[i] = (uint32_t)(a + (r << 8) + (g << 16)) + ((uint32_t)b << 24); break;                  /* BGR32_1 */
+        case ORF_ABGR: c->pal_rgb[i] = (uint32_t)(a + (b << 8) + (g << 16)) + ((uint32_t)r << 24); break;                  /* RGB32_1 */
+        case ORF_GBRP: case ORF_GBRAP: c->pal_rgb[i] = (uint32_t)(g + (b << 8) + (r << 16)) + ((uint32_t)a << 24); break;
+        default: c->pal_rgb[i] = (uint32_t)(b + (g << 8) + (r << 16)) + ((uint32_t)a << 24); break;                        /* RGB32, BGR24, everything else */
+        }
+    }
+}
+
+/* palToRgbWrapper with sws_convertPalette8ToPacked32 / 24 (swscale_unscaled.c:600-644, :2707-2730) and palToGbrpWrapper with pal8ToPlanar8
+ * (:531-545, :646-683): the bytes of the pal_rgb word are the destination's bytes */
+static int unscaled_pal2rgb(const OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY, int srcSliceH,
+                            uint8_t *const dst[], const int dstStride[])
+{
+    const int d = c->o.dst_format, w = c->o.src_w;
+    const Desc *dd = desc_get(d);
+    for (int y = 0; y < srcSliceH; y++) {
+        const uint8_t *s = src[0] + (ptrdiff_t)y * srcStride[0];
+        for (int x = 0; x < w; x++) {
+            const uint32_t p = c->pal_rgb[s[x]];
+            if (d == ORF_GBRP || d == ORF_GBRAP) {
+                for (int k = 0; k < (d == ORF_GBRAP && dst[3] ? 4 : 3); k++) dst[k][(ptrdiff_t)(y + srcSliceY) * dstStride[k] + x] = (uint8_t)(p >> (8 * k));
+            } else {
+                uint8_t *o = dst[0] + (ptrdiff_t)(y + srcSliceY) * dstStride[0] + dd->c[0].step * x;
+                for (int k = 0; k < dd->c[0].step; k++) o[k] = (uint8_t)(p >> (8 * k));
+            }
+        }
+    }
+    return srcSliceH;
+}
+
 /* Produce the 8/16-bit "formatConv" luma line for source row y (NULL if the plane is read directly).
  * returns pointer to the line to feed to hscale. */
 /* RGB16_32FUNCS rows for the 16 bits-per-pixel formats (input.c:396-401): masks on the unshifted pixel, coefficient shifts, S */
@@ -2438,6 +2498,11 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
                 d[i] = (int16_t)((unsigned)(ry * r + gy * g + by * b + rnd) >> (S - 6));
             }
         }
+        return tmp;
+    }
+    if (isPalSrc(f)) { /* palToY_c input.c:486-496 */
+        const uint8_t *s = src[0] + y * stride[0]; int16_t *d = (int16_t *)tmp;
+        for (i = 0; i < w; i++) d[i] = (int16_t)((c->pal_yuv[s[i]] & 0xFF) << 6);
         return tmp;
     }
     if (f == ORF_UYYVYY411) { /* uyyvyyToY_c input.c:909-914 */
@@ -2556,6 +2621,12 @@ static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int 
     const ptrdiff_t yl = (ptrdiff_t)y << c->chrSrcVSub;   /* planar RGB: plane 0 is indexed by luma row (hscale.c chr_convert) */
     int i;
     *pu = tu; *pv = tv;
+    if (isPalSrc(f)) { /* palToUV_c input.c:498-512 */
+        const uint8_t *s = src[0] + (ptrdiff_t)(y << c->chrSrcVSub) * stride[0];
+        uint16_t *du = (uint16_t *)tu; int16_t *dv = (int16_t *)tv;
+        for (i = 0; i < w; i++) { const uint32_t p = c->pal_yuv[s[i]]; du[i] = (uint16_t)((uint8_t)(p >> 8) << 6); dv[i] = (int16_t)((uint8_t)(p >> 16) << 6); }
+        return;
+    }
     if (f == ORF_UYYVYY411) { /* uyyvyyToUV_c input.c:916-925 */
         const uint8_t *s = src[0] + (ptrdiff_t)(y << c->chrSrcVSub) * stride[0];
         for (i = 0; i < w; i++) { tu[i] = s[6 * i]; tv[i] = s[6 * i + 3]; }
@@ -2822,7 +2893,7 @@ static void hscale_line(const OrSws *c, int32_t *dst, int dstW, const uint8_t *s
 {
     const Desc *ds = desc_get(c->o.src_format);
     const int depth = ds->c[0].depth;
-    const int rgbish = isAnyRGB(c->o.src_format);
+    const int rgbish = isAnyRGB(c->o.src_format) || c->o.src_format == ORF_PAL8;
     int i, j;
     if (c->srcBpc == 8 && c->dstBpc <= 14 && (c->o.flags & OR_SWS_FAST_BILINEAR)) {
         /* ff_hyscale_fast_c / ff_hcscale_fast_c (hscale_fast_bilinear.c:23-55), selected in sws_init_swscale (swscale.c:676-681) */
@@ -3757,6 +3828,10 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
     uint8_t *t0 = malloc((size_t)srcW * 4 + 128), *t1 = malloc((size_t)srcW * 4 + 128);
     int y;
 
+    /* scale_internal (swscale.c:1084-1086): a bit-exact context starts every frame from a clean error line; any other one carries it on */
+    if ((c->o.flags & OR_SWS_BITEXACT) && c->o.dither == 3 && c->dither_error[0])
+        for (y = 0; y < 3; y++) memset(c->dither_error[y], 0, sizeof(int) * ((size_t)dstW + 2));
+
     P.lum = malloc((size_t)srcH * dstW * sizeof(int32_t));
     P.chrU = malloc((size_t)c->chrSrcH * c->chrDstW * sizeof(int32_t));
     P.chrV = malloc((size_t)c->chrSrcH * c->chrDstW * sizeof(int32_t));
@@ -3778,6 +3853,10 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
             } else if (sf == ORF_YA16LE) { /* read_ya16le_alpha_c input.c:639-645 */
                 uint16_t *d16 = (uint16_t *)t0;
                 for (int i = 0; i < srcW; i++) memcpy(&d16[i], src[0] + (ptrdiff_t)y * srcStride[0] + 4 * i + 2, 2);
+                line = t0;
+            } else if (sf == ORF_PAL8) { /* palToA_c input.c:474-484 */
+                int16_t *d16 = (int16_t *)t0;
+                for (int i = 0; i < srcW; i++) { const uint32_t p = c->pal_yuv[src[0][(ptrdiff_t)y * srcStride[0] + i]]; d16[i] = (int16_t)((p >> 24) << 6 | p >> 26); }
                 line = t0;
             } else if (sf == ORF_YAF32LE || sf == ORF_YAF16LE || sf == ORF_RGBAF16LE) { /* read_yaf32_alpha_c (input.c:1422-1431), read_yaf16_alpha_c (:1620-1627),
                                                                                          * rgbaf16ToA_endian (:1680-1687): the last element of the pixel */
@@ -4070,7 +4149,9 @@ static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4
     if (c->o.dst_format == ORF_YUVA420P && dst[3] &&
         (c->unscaled_kind == UNSC_BGR24_YV12 || c->unscaled_kind == UNSC_YVU9_YV12 || c->unscaled_kind == UNSC_P4222PLANAR))
         for (int y = 0; y < srcSliceH; y++) memset(dst[3] + (ptrdiff_t)y * dstStride[3], 255, c->o.src_w);
+    if (isPalSrc(c->o.src_format)) update_palette(c, src[1]);   /* scale_internal, swscale.c:1088-1089 */
     switch (c->unscaled_kind) {
+    case UNSC_PAL2RGB: return unscaled_pal2rgb(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_YUV2RGB: return unscaled_yuv2rgb(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_P01X: return unscaled_p01x(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_8_P01X: return unscaled_8_p01x(c, src, srcStride, 0, srcSliceH, dst, dstStride);
@@ -4136,7 +4217,7 @@ const char *or_sws_path_name(const OrSws *c)
                                "rgbToRgb", "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb",
                                "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb", "rgbToRgb", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "yuv2rgb_c", "uint_y_to_float_y", "float_y_to_uint_y",
                                "planarToYuy2", "yuyvToPlanar",
-                               "rgb16Shuffle", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "alphablendaway", "planarRgbToplanarRgb" };
+                               "rgb16Shuffle", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "alphablendaway", "planarRgbToplanarRgb", "palToRgb" };
     return c->cascade[0] ? "cascade" : n[c->unscaled_kind];
 }
 const int32_t *or_sws_rgb2yuv_table(const OrSws *c) { return c->rgb2yuv; }

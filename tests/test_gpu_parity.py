@@ -108,8 +108,9 @@ MISC7 = ["ya8", "ya16le", "ya16be", "grayf32le", "grayf32be", "monob", "monow", 
 RGB_LOW = ["rgb565le", "bgr565le", "rgb555le", "bgr555le", "rgb444le", "bgr444le", "rgb565be", "bgr555be"]
 FLOAT_IN = ["rgbf32le", "rgbf32be", "rgbf16le", "rgbf16be", "rgbaf16le", "rgbaf16be", "grayf16le", "grayf16be", "yaf32le", "yaf32be", "yaf16le", "yaf16be",
             "gbrpf16le", "gbrpf16be", "gbrapf16le", "gbrapf16be", "uyyvyy411"]   # sources only, like the reference's format table
-FORMAT_MATRIX_SRC = YUVA_N + MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16 + FLOAT_IN
+PAL_IN = ["pal8", "rgb8", "bgr8", "rgb4_byte", "bgr4_byte"]   # sources read through a palette (usePal)
 RGB8_4 = ["rgb8", "bgr8", "rgb4", "bgr4", "rgb4_byte", "bgr4_byte"]   # destinations only (sources need the palette path)
+FORMAT_MATRIX_SRC = YUVA_N + MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16 + FLOAT_IN + PAL_IN
 FORMAT_MATRIX_DST = YUVA_N + MISC7 + RGB30 + PACKED_HI + PACKED444 + MSB + RGB_LOW + BIG_ENDIAN + YUV_FAMILY + ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr"] + PLANAR_RGB + GRAYS + RGB16 + RGB8_4
 
 

@@ -93,11 +93,13 @@ def test_error_diffusion(fmt):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("device_frames", [True, False], ids=["hbm", "host"])
-def test_error_line_outlives_the_frame(device_frames):
-    """c->dither_error is zeroed at init and never again (utils.c:1744-1747): the second frame starts from the first frame's last row."""
+@pytest.mark.parametrize("bitexact", [False, True], ids=["carried", "bitexact"])
+def test_error_line_outlives_the_frame(device_frames, bitexact):
+    """c->dither_error is zeroed at init (utils.c:1744-1747); after that only a bit-exact context clears it, at the start of every frame
+    (swscale.c:1084-1086).  Any other context starts the second frame from the first frame's last row."""
     import torch
     sw, sh, dw, dh = 96, 64, 51, 37
-    flags = SWS_BICUBIC | BX
+    flags = SWS_BICUBIC | (BX if bitexact else 0)
     o = OL.Oracle(sw, sh, "yuv420p", dw, dh, "rgb8", flags)
     p = SwsContext(sw, sh, "yuv420p", dw, dh, "rgb8", flags)
     fresh = None
@@ -120,8 +122,8 @@ def test_error_line_outlives_the_frame(device_frames):
         assert np.array_equal(hd.planes[0][:, :dw], ref.planes[0][:, :dw]), k
         if k == 0:
             fresh = ref.planes[0][:, :dw].copy()
-        else:
-            assert not np.array_equal(ref.planes[0][:, :dw], fresh)   # ... so the same picture does not convert to the same bytes
+        else:   # ... so without SWS_BITEXACT the same picture does not convert to the same bytes
+            assert np.array_equal(ref.planes[0][:, :dw], fresh) == bitexact
     p.close()
 
 
@@ -129,7 +131,7 @@ def test_error_line_outlives_the_frame(device_frames):
 def test_error_diffusion_through_the_batch_entry():
     """sws_scale_frames() on an error-diffusion context: the frames are converted in order on one GPU, like a loop of sws_scale()."""
     sw, sh, dw, dh, n = 64, 48, 41, 30, 4
-    flags = SWS_BICUBIC | BX
+    flags = SWS_BICUBIC
     o = OL.Oracle(sw, sh, "yuv444p", dw, dh, "bgr4_byte", flags)
     p = SwsContext(sw, sh, "yuv444p", dw, dh, "bgr4_byte", flags)
     refs, srcs, dsts = [], [], []
@@ -150,10 +152,10 @@ def test_error_diffusion_through_the_batch_entry():
 
 
 def test_dither_rules_and_refusals(hiplib):
-    # sources of these formats need the palette path: refused by both sides, and the query functions say so
     L = hiplib
     for f in BYTE + NIB:
-        assert L.sws_isSupportedOutput(LA.PIX_FMT[f]) == 1 and L.sws_isSupportedInput(LA.PIX_FMT[f]) == 0
+        assert L.sws_isSupportedOutput(LA.PIX_FMT[f]) == 1
+    for f in NIB:   # the bit-stream formats are outputs only (format.c legacy_format_entries); the byte formats are read through a palette (test_gpu_pal.py)
         for make in (OL.Oracle, SwsContext):
             with pytest.raises(RuntimeError):
                 make(64, 48, f, 64, 48, "yuv420p", SWS_BICUBIC | BX)
