@@ -84,6 +84,10 @@ enum AVPixelFormat {
     AV_PIX_FMT_X2RGB10LE = 193, AV_PIX_FMT_X2BGR10LE = 195,
     AV_PIX_FMT_YA8 = 56, AV_PIX_FMT_YA16BE = 109, AV_PIX_FMT_YA16LE = 110,
     AV_PIX_FMT_GRAYF32BE = 182, AV_PIX_FMT_GRAYF32LE = 183,
+    /* bayer mosaics: inputs only, through their own unscaled converters or a cascade over rgb24 / rgb48 */
+    AV_PIX_FMT_BAYER_BGGR8 = 139, AV_PIX_FMT_BAYER_RGGB8 = 140, AV_PIX_FMT_BAYER_GBRG8 = 141, AV_PIX_FMT_BAYER_GRBG8 = 142,
+    AV_PIX_FMT_BAYER_BGGR16LE = 143, AV_PIX_FMT_BAYER_BGGR16BE = 144, AV_PIX_FMT_BAYER_RGGB16LE = 145, AV_PIX_FMT_BAYER_RGGB16BE = 146,
+    AV_PIX_FMT_BAYER_GBRG16LE = 147, AV_PIX_FMT_BAYER_GBRG16BE = 148, AV_PIX_FMT_BAYER_GRBG16LE = 149, AV_PIX_FMT_BAYER_GRBG16BE = 150,
     AV_PIX_FMT_PAL8 = 11,   /* input only: data[1] holds 256 native-endian 0xAARRGGBB words */
     /* inputs only (like the reference's format table): float / half-float pictures and the packed 4:1:1 layout */
     AV_PIX_FMT_UYYVYY411 = 16, AV_PIX_FMT_RGBAF16BE = 206, AV_PIX_FMT_RGBAF16LE = 207, AV_PIX_FMT_RGBF32BE = 217, AV_PIX_FMT_RGBF32LE = 218,

@@ -121,6 +121,7 @@ static bool fmt_supported_in(int f)
 static bool fmt_supported_out(int f)   // (the reference's table, format.c legacy_format_entries, lists the float / half-float family and uyyvyy411 as inputs only)
 {
     const int t = pix_be_twin(f) >= 0 ? pix_be_twin(f) : f;
+    if (pix_desc(t) && isBayerFmt(t)) return false;
     switch (t) {
     case AV_PIX_FMT_PAL8: case AV_PIX_FMT_UYYVYY411: case AV_PIX_FMT_RGBF32LE: case AV_PIX_FMT_RGBF16LE: case AV_PIX_FMT_RGBAF16LE: case AV_PIX_FMT_GRAYF16LE:
     case AV_PIX_FMT_YAF32LE: case AV_PIX_FMT_YAF16LE: case AV_PIX_FMT_GBRPF16LE: case AV_PIX_FMT_GBRAPF16LE: return false;
@@ -225,6 +226,8 @@ void choose_unscaled(SwsInternal *c)
         ((k == PLAN_UNSC_PACKED16_GBRP16 || k == PLAN_UNSC_RGB30_TO_GBRP) && isALPHA(d)) ||
         ((k == PLAN_UNSC_GBRP16_PACKED16 || k == PLAN_UNSC_GBRP_TO_RGB30) && isALPHA(s)))
         unsupported = true;
+    // bayer_to_rgb24_wrapper / bayer_to_rgb48_wrapper / bayer_to_yv12_wrapper (:2543-2555; AV_PIX_FMT_RGB48 is the native-endian name)
+    if (isBayerFmt(s) && (d == AV_PIX_FMT_RGB24 || (d == AV_PIX_FMT_RGB48LE && !c->dstBE) || d == AV_PIX_FMT_YUV420P)) { k = PLAN_UNSC_BAYER; c->dst_slice_align = 2; }
     // palToRgbWrapper / palToGbrpWrapper (:2619-2630) for the palette-expanded sources.  (usePal() also names gray8, whose grey palette makes
     // these wrappers a plain replication: the scaler chain gives the same bytes, tests/test_oracle_properties_extra.py)
     if ((s == AV_PIX_FMT_PAL8 || isRGB8class(s)) && (d == AV_PIX_FMT_GBRP || d == AV_PIX_FMT_GBRAP || d == AV_PIX_FMT_RGB24 || d == AV_PIX_FMT_BGR24 ||
@@ -404,6 +407,32 @@ int init_single_context(SwsInternal *c)
         c->plan = PLAN_CASCADE;
         return 0;
     }
+    if (isBayerFmt(srcFormat)) {   // utils.c:1524-1550: anything but the three direct conversions goes through rgb24 / rgb48 at the source size
+        if (srcH < 2) { log_msg(c, 0, "a bayer picture needs two rows\n"); return SWS_AVERROR(EINVAL); }   // (the wrappers: av_assert0(srcSliceH > 1))
+        if (!unscaled || c->dstBE || (dstFormat != AV_PIX_FMT_RGB24 && dstFormat != AV_PIX_FMT_YUV420P && dstFormat != AV_PIX_FMT_RGB48LE)) {
+            const int tmpFormat = ds->comp[1].depth == 8 ? AV_PIX_FMT_RGB48LE : AV_PIX_FMT_RGB24;   // isBayer16BPS
+            auto fail = [&](int err) { destroy(c->cascade[0]); destroy(c->cascade[1]); c->cascade[0] = c->cascade[1] = nullptr; return err; };
+            SwsFilter sf, df;
+            SwsVector sv[4], dv[4];
+            for (int k = 0; k < 4; k++) {
+                sv[k].coeff = c->srcVec[k].empty() ? nullptr : c->srcVec[k].data(); sv[k].length = (int)c->srcVec[k].size();
+                dv[k].coeff = nullptr; dv[k].length = c->dstVecLen[k];
+            }
+            sf.lumH = sv[0].length ? &sv[0] : nullptr; sf.lumV = sv[1].length ? &sv[1] : nullptr; sf.chrH = sv[2].length ? &sv[2] : nullptr; sf.chrV = sv[3].length ? &sv[3] : nullptr;
+            df.lumH = dv[0].length ? &dv[0] : nullptr; df.lumV = dv[1].length ? &dv[1] : nullptr; df.chrH = dv[2].length ? &dv[2] : nullptr; df.chrV = dv[3].length ? &dv[3] : nullptr;
+            c->cascade_fmt = tmpFormat; c->cascade_w = srcW; c->cascade_h = srcH;
+            c->cascade[0] = alloc_set_opts(srcW, srcH, srcFormat, srcW, srcH, tmpFormat, flags, o->scaler_params);
+            c->cascade[1] = alloc_set_opts(srcW, srcH, tmpFormat, dstW, dstH, dstFormat, flags, o->scaler_params);
+            if (!c->cascade[0] || !c->cascade[1]) return fail(SWS_AVERROR(ENOMEM));
+            c->cascade[0]->srcBE = c->srcBE;     // the stored formats are the little-endian twins: the byte order travels with the flags
+            c->cascade[1]->dstBE = c->dstBE;
+            c->cascade[0]->tune = c->cascade[1]->tune = c->tune;
+            if (init_context_impl(c->cascade[0], &sf, nullptr) < 0 || init_context_impl(c->cascade[1], nullptr, &df) < 0) return fail(SWS_AVERROR(ENOMEM));
+            c->plan = PLAN_CASCADE;
+            log_msg(c, 2, "bayer source: cascading through %s\n", pix_desc(tmpFormat)->name);
+            return 0;
+        }
+    }
     c->needAlpha = isALPHA(srcFormat) && isALPHA(dstFormat);                    // :1746
 
     c->plan = PLAN_NONE;
@@ -448,7 +477,7 @@ int init_single_context(SwsInternal *c)
         return 0;
     }
     if (unscaled && !usesHFilter && !usesVFilter && !c->force_scaler &&
-        (o->src_range == o->dst_range || isAnyRGB(dstFormat) || isFloatFmt(srcFormat) || isFloatFmt(dstFormat))) { // :1623-1637
+        (o->src_range == o->dst_range || isAnyRGB(dstFormat) || isFloatFmt(srcFormat) || isFloatFmt(dstFormat) || isBayerFmt(srcFormat))) { // :1623-1637
         choose_unscaled(c);
         if ((int)c->plan == -1) {
             log_msg(c, 0, "unscaled %s -> %s special converter is not implemented on the HIP path\n", ds->name, dd->name);
@@ -461,6 +490,10 @@ int init_single_context(SwsInternal *c)
         }
     }
 
+    if (isBayerFmt(srcFormat)) {   // (a source filter on one of the three direct conversions: the reference has no reader to fall back on)
+        log_msg(c, 0, "bayer sources have no scaler input reader\n");
+        return SWS_AVERROR(EINVAL);
+    }
     // filters; filterAlign is 1 in the reference's C path (:1675-1735)
     const int hp = local_pos(0, 0);
     auto fvec = [&](int k) { FilterVec v; v.coeff = c->srcVec[k].empty() ? nullptr : c->srcVec[k].data(); v.length = (int)c->srcVec[k].size();

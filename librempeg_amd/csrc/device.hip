@@ -88,6 +88,7 @@ static int src_kind_of(int f)
 {
     const PixDesc *d = pix_desc(f);
     if (!d) return -1;
+    if (d->flags & PIXFLAG_BAYER) return SRCK_BAYER;
     if (f == AV_PIX_FMT_PAL8 || f == AV_PIX_FMT_RGB8 || f == AV_PIX_FMT_BGR8 || f == AV_PIX_FMT_RGB4_BYTE || f == AV_PIX_FMT_BGR4_BYTE) return SRCK_PAL;
     if (f == AV_PIX_FMT_UYYVYY411) return SRCK_PACKED411;
     if ((d->flags & PIXFLAG_FLOAT) && f != AV_PIX_FMT_GRAYF32LE && f != AV_PIX_FMT_GBRPF32LE && f != AV_PIX_FMT_GBRAPF32LE) return SRCK_FLOATX;
@@ -663,6 +664,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     case PLAN_UNSC_YUV2RGB16: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb16_unscaled"; break;
     case PLAN_UNSC_YUV2RGB8: c->path_name = "unscaled:yuv2rgb"; c->kernel_name = "sws_k_yuv2rgb8_unscaled"; break;
     case PLAN_UNSC_PAL2RGB: c->path_name = "unscaled:palToRgb"; c->kernel_name = "sws_k_pal2rgb"; break;
+    case PLAN_UNSC_BAYER: c->path_name = "unscaled:bayer"; c->kernel_name = "sws_k_bayer"; break;
     case PLAN_UNSC_RGBLOW: c->path_name = "unscaled:rgbToRgb"; c->kernel_name = "sws_k_rgb_low_convert"; break;
     case PLAN_UNSC_PLANAR2P422: c->path_name = "unscaled:planarToYuy2"; c->kernel_name = "sws_k_planar_to_p422"; break;
     case PLAN_UNSC_P4222PLANAR: c->path_name = "unscaled:yuyvToPlanar"; c->kernel_name = "sws_k_p422_to_planar"; break;

@@ -23,6 +23,7 @@ enum SrcKind {
     SRCK_RGB30,         // x2rgb10le / x2bgr10le: rgb16_32To*_c_template with the rgb30le / bgr30le rows of input.c:411-412
     SRCK_FLOATX,        // rgbf32 / rgbf16 / rgbaf16 (input.c:1336-1397, :1629-1740), grayf16 / yaf32 / yaf16 (:1411-1431, :1601-1627), gbrpf16 / gbrapf16 (:1561-1599)
     SRCK_PAL,           // pal8 and rgb8 / bgr8 / rgb4_byte / bgr4_byte through the palette of ff_update_palette (swscale.c:873-951): palToY_c / palToUV_c / palToA_c input.c:474-512
+    SRCK_BAYER,         // bayer mosaics: no scaler reader, only sws_k_bayer (bayer_template.c)
     SRCK_PACKED411,     // uyyvyy411: uyyvyyToY_c / uyyvyyToUV_c input.c:909-925
     SRCK_RGB16,         // rgb565 / rgb555 / rgb444 and the bgr orders: rgb16_32To*_c_template with the 16 bpp rows of input.c:396-401
 };

@@ -189,6 +189,17 @@ int launch_misc(const LaunchCtx &L)
         hipLaunchKernelGGL(swsk::sws_k_yuv2rgb16_unscaled, grid, blk, 0, st, fs, p, c->opts.src_format == AV_PIX_FMT_YUV422P ? 1 : 0, npairs, sliceY);
         break;
     }
+    case PLAN_UNSC_BAYER: {
+        const int sf = c->opts.src_format, df = c->opts.dst_format;
+        const int quad = sf == AV_PIX_FMT_BAYER_BGGR8 || sf == AV_PIX_FMT_BAYER_BGGR16LE || sf == AV_PIX_FMT_BAYER_RGGB8 || sf == AV_PIX_FMT_BAYER_RGGB16LE;
+        const int rpos = (sf == AV_PIX_FMT_BAYER_BGGR8 || sf == AV_PIX_FMT_BAYER_BGGR16LE || sf == AV_PIX_FMT_BAYER_GBRG8 || sf == AV_PIX_FMT_BAYER_GBRG16LE) ? 0 : 2;
+        const int sz = pix_desc(sf)->comp[0].step, mode = df == AV_PIX_FMT_YUV420P ? 2 : df == AV_PIX_FMT_RGB48LE ? 1 : 0;
+        const int sh = (sz == 2 && mode != 1) ? 8 : 0;
+        if (sliceH < 2) { log_msg(c, 0, "a bayer slice needs two rows\n"); return SWS_AVERROR(EINVAL); }
+        const dim3 grid(cdiv((p.srcW + 1) / 2, 256), (sliceH + 1) / 2, n);
+        hipLaunchKernelGGL(swsk::sws_k_bayer, grid, blk, 0, st, fs, p, p.srcW, sliceY, sliceH, quad, rpos, sz, sh, mode);
+        break;
+    }
     case PLAN_UNSC_PAL2RGB: {
         const int df = c->opts.dst_format;
         const bool planar = df == AV_PIX_FMT_GBRP || df == AV_PIX_FMT_GBRAP;

@@ -467,6 +467,91 @@ __global__ void __launch_bounds__(256) sws_k_yuv2rgb16_unscaled(SwsFrameSet fs, 
     }
 }
 
+// bayer_to_rgb24_wrapper / bayer_to_rgb48_wrapper / bayer_to_yv12_wrapper (swscale_unscaled.c:1652-1806) over bayer_template.c.  One thread =
+// one 2x2 block.  Block rows: the first one and the last one are "copied" (nearest samples of the block itself), the others "interpolated"
+// from the 4x4 neighbourhood except for their first and last block; an odd height ends with a copy that runs upwards from the last row
+// (negative strides in the reference) and owns the row above it too, which the block row before it therefore leaves alone.  The template's
+// R() / B() names are byte positions (rpos = 0 for bggr / gbrg, 2 for rggb / grbg).  sh = BAYER_SHIFT (8 for 16-bit samples into the 8-bit
+// destinations).  mode: 0 rgb24, 1 rgb48, 2 yuv420p (rgb24toyv12_2x2: ff_rgb24toyv12_c reads byte 0 as B and the wrapper swaps the chroma
+// pointers).  A column beyond the picture (odd widths) is read from the row's padding like the reference does, where the stride holds it.
+__global__ void __launch_bounds__(256) sws_k_bayer(SwsFrameSet fs, SwsDevParams p, int W, int sliceY, int H, int quad, int rpos, int sz, int sh, int mode)
+{
+    const int bx = blockIdx.x * 256 + threadIdx.x, x0 = 2 * bx, r = blockIdx.y;
+    if (x0 >= W) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const bool flipped = (H & 1) && 2 * r == H - 1;
+    const int row0 = 2 * r, dir = flipped ? -1 : 1;
+    const bool interp = !flipped && row0 >= 2 && row0 < H - 2 && x0 >= 2 && x0 < W - 2;
+    const bool skip_second = !flipped && (H & 1) && row0 + 1 == H - 2;   // that row belongs to the upward copy
+    const int64_t ss = f.srcStride[0];
+    const int avail = (int)(ss < 0 ? -ss : ss);
+    const uint8_t *base = f.src[0] + (int64_t)(sliceY + row0) * ss;
+    auto T = [&](int y, int x) -> unsigned {
+        const int col = x0 + x;
+        if ((col + 1) * sz > avail) return 0u;
+        const uint8_t *q = base + (int64_t)(dir * y) * ss + (int64_t)sz * col;
+        return sz == 1 ? (unsigned)q[0] : (unsigned)*(const uint16_t *)q;
+    };
+    unsigned v[2][2][3];
+    if (quad) {
+        if (!interp) {
+            v[0][0][0] = v[0][1][0] = v[1][1][0] = v[1][0][0] = T(1, 1) >> sh;
+            v[0][1][1] = T(0, 1) >> sh; v[0][0][1] = v[1][1][1] = (T(0, 1) + T(1, 0)) >> (1 + sh); v[1][0][1] = T(1, 0) >> sh;
+            v[1][1][2] = v[0][0][2] = v[0][1][2] = v[1][0][2] = T(0, 0) >> sh;
+        } else {
+            v[0][0][0] = (T(-1, -1) + T(-1, 1) + T(1, -1) + T(1, 1)) >> (2 + sh); v[0][0][1] = (T(-1, 0) + T(0, -1) + T(0, 1) + T(1, 0)) >> (2 + sh); v[0][0][2] = T(0, 0) >> sh;
+            v[0][1][0] = (T(-1, 1) + T(1, 1)) >> (1 + sh); v[0][1][1] = T(0, 1) >> sh; v[0][1][2] = (T(0, 0) + T(0, 2)) >> (1 + sh);
+            v[1][0][0] = (T(1, -1) + T(1, 1)) >> (1 + sh); v[1][0][1] = T(1, 0) >> sh; v[1][0][2] = (T(0, 0) + T(2, 0)) >> (1 + sh);
+            v[1][1][0] = T(1, 1) >> sh; v[1][1][1] = (T(0, 1) + T(1, 0) + T(1, 2) + T(2, 1)) >> (2 + sh); v[1][1][2] = (T(0, 0) + T(0, 2) + T(2, 0) + T(2, 2)) >> (2 + sh);
+        }
+    } else {
+        if (!interp) {
+            v[0][0][0] = v[0][1][0] = v[1][1][0] = v[1][0][0] = T(1, 0) >> sh;
+            v[0][0][1] = T(0, 0) >> sh; v[1][1][1] = T(1, 1) >> sh; v[0][1][1] = v[1][0][1] = (T(0, 0) + T(1, 1)) >> (1 + sh);
+            v[1][1][2] = v[0][0][2] = v[0][1][2] = v[1][0][2] = T(0, 1) >> sh;
+        } else {
+            v[0][0][0] = (T(-1, 0) + T(1, 0)) >> (1 + sh); v[0][0][1] = T(0, 0) >> sh; v[0][0][2] = (T(0, -1) + T(0, 1)) >> (1 + sh);
+            v[0][1][0] = (T(-1, 0) + T(-1, 2) + T(1, 0) + T(1, 2)) >> (2 + sh); v[0][1][1] = (T(-1, 1) + T(0, 0) + T(0, 2) + T(1, 1)) >> (2 + sh); v[0][1][2] = T(0, 1) >> sh;
+            v[1][0][0] = T(1, 0) >> sh; v[1][0][1] = (T(0, 0) + T(1, -1) + T(1, 1) + T(2, 0)) >> (2 + sh); v[1][0][2] = (T(0, -1) + T(0, 1) + T(2, -1) + T(2, 1)) >> (2 + sh);
+            v[1][1][0] = (T(1, 0) + T(1, 2)) >> (1 + sh); v[1][1][1] = T(1, 1) >> sh; v[1][1][2] = (T(0, 1) + T(2, 1)) >> (1 + sh);
+        }
+    }
+    if (mode == 2) {
+        const int32_t *t = p.rgb2yuv;
+        unsigned sb = 0, sg = 0, sr = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned *px = v[k >> 1][k & 1];
+            const unsigned byte0 = (rpos == 0 ? px[0] : px[2]) & 0xff, byte1 = px[1] & 0xff, byte2 = (rpos == 0 ? px[2] : px[0]) & 0xff;   // block bytes in memory order
+            sb += byte0; sg += byte1; sr += byte2;                                                                                      // ff_rgb24toyv12_c: b = byte 0, r = byte 2
+            if (x0 + (k & 1) < W && !((k >> 1) && skip_second))
+                f.dst[0][(int64_t)(sliceY + row0 + dir * (k >> 1)) * f.dstStride[0] + x0 + (k & 1)] =
+                    (uint8_t)((((unsigned)t[0] * byte2 + (unsigned)t[1] * byte1 + (unsigned)t[2] * byte0) >> 15) + 16);
+        }
+        const unsigned bxm = sb >> 2, gxm = sg >> 2, rxm = sr >> 2;
+        const int64_t crow = (sliceY + row0) >> 1;
+        f.dst[2][crow * f.dstStride[2] + bx] = (uint8_t)((((unsigned)t[3] * rxm + (unsigned)t[4] * gxm + (unsigned)t[5] * bxm) >> 15) + 128);
+        f.dst[1][crow * f.dstStride[1] + bx] = (uint8_t)((((unsigned)t[6] * rxm + (unsigned)t[7] * gxm + (unsigned)t[8] * bxm) >> 15) + 128);
+        return;
+    }
+#pragma unroll
+    for (int py = 0; py < 2; py++) {
+        if (py && skip_second) continue;
+        uint8_t *o = f.dst[0] + (int64_t)(sliceY + row0 + dir * py) * f.dstStride[0];
+#pragma unroll
+        for (int px = 0; px < 2; px++) {
+            if (x0 + px >= W) continue;
+            if (mode == 1) {
+                uint16_t *o16 = (uint16_t *)o + 3 * (x0 + px);
+                o16[rpos] = (uint16_t)v[py][px][0]; o16[1] = (uint16_t)v[py][px][1]; o16[2 - rpos] = (uint16_t)v[py][px][2];
+            } else {
+                uint8_t *o8 = o + 3 * (x0 + px);
+                o8[rpos] = (uint8_t)v[py][px][0]; o8[1] = (uint8_t)v[py][px][1]; o8[2 - rpos] = (uint8_t)v[py][px][2];
+            }
+        }
+    }
+}
+
 // ff_update_palette (swscale.c:873-951): one workgroup per frame, one thread per palette entry.  pal8 reads the caller's 0xAARRGGBB
 // words (src[2]), the 8 / 4 bpp RGB formats expand their bit fields (an index beyond a 4-bit format's 16 values spills a channel
 // into its neighbours, like the reference's plain sums).  Writes pal_yuv[256] then pal_rgb[256] (the word whose bytes are the

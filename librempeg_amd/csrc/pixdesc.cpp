@@ -109,6 +109,12 @@ static const PixDesc g_descs[] = {
     { AV_PIX_FMT_GRAYF32LE, "grayf32le", 1, 0, 0, {{0,4,0,0,32},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_FLOAT },
     { AV_PIX_FMT_MONOWHITE, "monow", 1, 0, 0, {{0,1,0,0,1},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_RGB },   // 1 bit per pixel, MSB first; isAnyRGB() counts them in
     { AV_PIX_FMT_MONOBLACK, "monob", 1, 0, 0, {{0,1,0,7,1},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_RGB },
+    // bayer mosaics (libavutil/pixdesc.c:2149-2250): one plane of 8- or 16-bit samples; inputs only
+#define BAYER8(F, N)  { F, N, 3, 0, 0, {{0,1,0,0,2},{0,1,0,0,4},{0,1,0,0,2},{0,0,0,0,0}}, PIXFLAG_RGB | PIXFLAG_BAYER }
+#define BAYER16(F, N) { F, N, 3, 0, 0, {{0,2,0,0,4},{0,2,0,0,8},{0,2,0,0,4},{0,0,0,0,0}}, PIXFLAG_RGB | PIXFLAG_BAYER }
+    BAYER8(AV_PIX_FMT_BAYER_BGGR8, "bayer_bggr8"), BAYER8(AV_PIX_FMT_BAYER_RGGB8, "bayer_rggb8"), BAYER8(AV_PIX_FMT_BAYER_GBRG8, "bayer_gbrg8"), BAYER8(AV_PIX_FMT_BAYER_GRBG8, "bayer_grbg8"),
+    BAYER16(AV_PIX_FMT_BAYER_BGGR16LE, "bayer_bggr16le"), BAYER16(AV_PIX_FMT_BAYER_RGGB16LE, "bayer_rggb16le"), BAYER16(AV_PIX_FMT_BAYER_GBRG16LE, "bayer_gbrg16le"),
+    BAYER16(AV_PIX_FMT_BAYER_GRBG16LE, "bayer_grbg16le"),
     { AV_PIX_FMT_PAL8, "pal8", 1, 0, 0, {{0,1,0,0,8},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}}, PIXFLAG_PAL | PIXFLAG_ALPHA },   // one index plane + the palette in data[1]; input only
     // float and half-float sources (libavutil/pixdesc.c:2583-2717, :2932-2971, :3108-3119) and the packed 4:1:1 source (:484-494): inputs only
     { AV_PIX_FMT_RGBF32LE, "rgbf32le", 3, 0, 0, {{0,12,0,0,32},{0,12,4,0,32},{0,12,8,0,32},{0,0,0,0,0}}, PIXFLAG_RGB | PIXFLAG_FLOAT },
@@ -176,6 +182,7 @@ bool isAnyRGB(int f) { return (pix_desc(f)->flags & PIXFLAG_RGB) != 0; }
 static bool isMonoFmt(int f) { return f == AV_PIX_FMT_MONOWHITE || f == AV_PIX_FMT_MONOBLACK; }
 bool isGray(int f) { return pix_desc(f)->nb_components <= 2 && !isMonoFmt(f) && !(pix_desc(f)->flags & PIXFLAG_PAL); }   // swscale_internal.h:805-815
 bool isFloatFmt(int f) { return (pix_desc(f)->flags & PIXFLAG_FLOAT) != 0; }
+bool isBayerFmt(int f) { return (pix_desc(f)->flags & PIXFLAG_BAYER) != 0; }
 bool isFloat16Fmt(int f) { const PixDesc *d = pix_desc(f); return (d->flags & PIXFLAG_FLOAT) && d->comp[0].depth == 16; }   // swscale_internal.h:890-895
 bool isALPHA(int f) { return (pix_desc(f)->flags & PIXFLAG_ALPHA) != 0; }
 bool isPlanarRGB(int f) { return (pix_desc(f)->flags & (PIXFLAG_PLANAR | PIXFLAG_RGB)) == (PIXFLAG_PLANAR | PIXFLAG_RGB); }
@@ -205,6 +212,8 @@ int pix_be_twin(int fmt)
     static const int pairs[][2] = {
     { AV_PIX_FMT_XV36BE, AV_PIX_FMT_XV36LE }, { AV_PIX_FMT_XV48BE, AV_PIX_FMT_XV48LE }, { AV_PIX_FMT_AYUV64BE, AV_PIX_FMT_AYUV64LE },
     { AV_PIX_FMT_YUVA420P9BE, AV_PIX_FMT_YUVA420P9LE }, { AV_PIX_FMT_YUVA420P10BE, AV_PIX_FMT_YUVA420P10LE }, { AV_PIX_FMT_YUVA420P16BE, AV_PIX_FMT_YUVA420P16LE }, { AV_PIX_FMT_YUVA422P9BE, AV_PIX_FMT_YUVA422P9LE }, { AV_PIX_FMT_YUVA422P10BE, AV_PIX_FMT_YUVA422P10LE }, { AV_PIX_FMT_YUVA422P12BE, AV_PIX_FMT_YUVA422P12LE }, { AV_PIX_FMT_YUVA422P16BE, AV_PIX_FMT_YUVA422P16LE }, { AV_PIX_FMT_YUVA444P9BE, AV_PIX_FMT_YUVA444P9LE }, { AV_PIX_FMT_YUVA444P10BE, AV_PIX_FMT_YUVA444P10LE }, { AV_PIX_FMT_YUVA444P12BE, AV_PIX_FMT_YUVA444P12LE }, { AV_PIX_FMT_YUVA444P16BE, AV_PIX_FMT_YUVA444P16LE },
+    { AV_PIX_FMT_BAYER_BGGR16BE, AV_PIX_FMT_BAYER_BGGR16LE }, { AV_PIX_FMT_BAYER_RGGB16BE, AV_PIX_FMT_BAYER_RGGB16LE }, { AV_PIX_FMT_BAYER_GBRG16BE, AV_PIX_FMT_BAYER_GBRG16LE },
+    { AV_PIX_FMT_BAYER_GRBG16BE, AV_PIX_FMT_BAYER_GRBG16LE },
     { AV_PIX_FMT_RGBF32BE, AV_PIX_FMT_RGBF32LE }, { AV_PIX_FMT_RGBF16BE, AV_PIX_FMT_RGBF16LE }, { AV_PIX_FMT_RGBAF16BE, AV_PIX_FMT_RGBAF16LE }, { AV_PIX_FMT_GRAYF16BE, AV_PIX_FMT_GRAYF16LE },
     { AV_PIX_FMT_YAF32BE, AV_PIX_FMT_YAF32LE }, { AV_PIX_FMT_YAF16BE, AV_PIX_FMT_YAF16LE }, { AV_PIX_FMT_GBRPF16BE, AV_PIX_FMT_GBRPF16LE }, { AV_PIX_FMT_GBRAPF16BE, AV_PIX_FMT_GBRAPF16LE },
     { AV_PIX_FMT_YA16BE, AV_PIX_FMT_YA16LE }, { AV_PIX_FMT_GRAYF32BE, AV_PIX_FMT_GRAYF32LE }, { AV_PIX_FMT_XYZ12BE, AV_PIX_FMT_XYZ12LE }, { AV_PIX_FMT_NV20BE, AV_PIX_FMT_NV20LE }, { AV_PIX_FMT_GBRP10MSBBE, AV_PIX_FMT_GBRP10MSBLE }, { AV_PIX_FMT_GBRP12MSBBE, AV_PIX_FMT_GBRP12MSBLE },

@@ -18,7 +18,7 @@ struct PixDesc {
     CompDesc comp[4]; unsigned flags;
 };
 enum : unsigned { PIXFLAG_BE = 1u << 0, PIXFLAG_PLANAR = 1u << 4, PIXFLAG_RGB = 1u << 5,
-                  PIXFLAG_ALPHA = 1u << 7, PIXFLAG_FLOAT = 1u << 9, PIXFLAG_PAL = 1u << 1 };
+                  PIXFLAG_ALPHA = 1u << 7, PIXFLAG_FLOAT = 1u << 9, PIXFLAG_PAL = 1u << 1, PIXFLAG_BAYER = 1u << 8 };
 const PixDesc *pix_desc(int fmt);
 int pix_be_twin(int fmt);
 inline bool pix_is_xyz(int fmt) { return fmt == AV_PIX_FMT_XYZ12LE || fmt == AV_PIX_FMT_XYZ12BE; }   // little-endian twin of a big-endian format, or -1
@@ -26,7 +26,7 @@ int  pix_bits_per_pixel(const PixDesc *d);
 int  pix_nb_planes(const PixDesc *d);
 // predicates, libswscale/swscale_internal.h:746-988
 bool is16BPS(int f); bool isNBPS(int f); bool isYUV(int f); bool isPlanarYUV(int f);
-bool isSemiPlanarYUV(int f); bool isAnyRGB(int f); bool isGray(int f); bool isFloatFmt(int f); bool isFloat16Fmt(int f);
+bool isSemiPlanarYUV(int f); bool isAnyRGB(int f); bool isGray(int f); bool isFloatFmt(int f); bool isFloat16Fmt(int f); bool isBayerFmt(int f);
 bool isALPHA(int f); bool isPlanarRGB(int f); bool isPackedFmt(int f); bool isPlanarFmt(int f);
 bool isSwappedChroma(int f); bool isDataInHighBits(int f);
 
@@ -87,7 +87,7 @@ enum PlanKind {
     PLAN_UNSC_RGB30_TO_16,    // x2rgb10to48 / x2rgb10to64 / x2rgb10tobgr48 / x2rgb10tobgr64 (rgb2rgb.c:415-471)
     PLAN_UNSC_RGB30_TO_GBRP,  // Rgb16ToPlanarRgb16Wrapper + packed30togbra10
     PLAN_UNSC_GBRP_TO_RGB30,  // planarRgb16ToRgb16Wrapper + gbr16ptopacked30
-    PLAN_UNSC_YUV2RGB48, PLAN_UNSC_YUV2RGB16, PLAN_UNSC_YUV2RGB8, PLAN_UNSC_PAL2RGB, PLAN_UNSC_RGBLOW,      // yuv2rgb_c_48 / yuv2rgb_c_bgr48 (yuv2rgb.c:107-125, :505-508)
+    PLAN_UNSC_YUV2RGB48, PLAN_UNSC_YUV2RGB16, PLAN_UNSC_YUV2RGB8, PLAN_UNSC_PAL2RGB, PLAN_UNSC_BAYER, PLAN_UNSC_RGBLOW,      // yuv2rgb_c_48 / yuv2rgb_c_bgr48 (yuv2rgb.c:107-125, :505-508)
     PLAN_MAIN,             // ff_swscale chain
     PLAN_CASCADE,          // two contexts through an intermediate image
 };

@@ -55,6 +55,7 @@ static int clip_i16(int a) { return a < -32768 ? -32768 : a > 32767 ? 32767 : a;
 #define PF_ALPHA  (1 << 7)
 #define PF_FLOAT  (1 << 9)
 #define PF_PAL    (1 << 1)
+#define PF_BAYER  (1 << 8)
 
 typedef struct { int plane, step, offset, shift, depth; } Comp;
 typedef struct {
@@ -149,6 +150,11 @@ static const Desc descs[] = {
     { ORF_GRAYF32LE, "grayf32le", 1, 0, 0, {{0,4,0,0,32}}, PF_FLOAT },
     { ORF_MONOWHITE, "monow", 1, 0, 0, {{0,1,0,0,1}}, PF_RGB },   /* 1 bit per pixel, MSB first; isAnyRGB() counts them in (swscale_internal.h:876-882) */
     { ORF_MONOBLACK, "monob", 1, 0, 0, {{0,1,0,7,1}}, PF_RGB },
+    /* bayer mosaics (pixdesc.c: one plane, "RGB" components of depth 2 / 4 / 2 per sample for the 8-bit ones, 4 / 8 / 4 for the 16-bit ones) */
+#define BAYER8(F, N)  { F, N, 3, 0, 0, {{0,1,0,0,2},{0,1,0,0,4},{0,1,0,0,2}}, PF_RGB | PF_BAYER }
+#define BAYER16(F, N) { F, N, 3, 0, 0, {{0,2,0,0,4},{0,2,0,0,8},{0,2,0,0,4}}, PF_RGB | PF_BAYER }
+    BAYER8(ORF_BAYER_BGGR8, "bayer_bggr8"), BAYER8(ORF_BAYER_RGGB8, "bayer_rggb8"), BAYER8(ORF_BAYER_GBRG8, "bayer_gbrg8"), BAYER8(ORF_BAYER_GRBG8, "bayer_grbg8"),
+    BAYER16(ORF_BAYER_BGGR16LE, "bayer_bggr16le"), BAYER16(ORF_BAYER_RGGB16LE, "bayer_rggb16le"), BAYER16(ORF_BAYER_GBRG16LE, "bayer_gbrg16le"), BAYER16(ORF_BAYER_GRBG16LE, "bayer_grbg16le"),
     { ORF_PAL8, "pal8", 1, 0, 0, {{0,1,0,0,8}}, PF_PAL | PF_ALPHA },   /* pixdesc.c: one index plane + the palette in data[1] */
     /* float and half-float sources (pixdesc.c:2583-2717, :2932-2971, :3108-3119), the packed 4:1:1 source (:484-494): inputs only */
     { ORF_RGBF32LE, "rgbf32le", 3, 0, 0, {{0,12,0,0,32},{0,12,4,0,32},{0,12,8,0,32}}, PF_RGB | PF_FLOAT },
@@ -213,6 +219,7 @@ static const int be_pairs[][2] = {
     { ORF_GBRAP10BE, ORF_GBRAP10LE }, { ORF_GBRAP12BE, ORF_GBRAP12LE }, { ORF_GBRAP14BE, ORF_GBRAP14LE }, { ORF_GBRAP16BE, ORF_GBRAP16LE }, { ORF_GBRAPF32BE, ORF_GBRAPF32LE },
     { ORF_XV36BE, ORF_XV36LE }, { ORF_XV48BE, ORF_XV48LE }, { ORF_AYUV64BE, ORF_AYUV64LE },
     { ORF_YUVA420P9BE, ORF_YUVA420P9LE }, { ORF_YUVA420P10BE, ORF_YUVA420P10LE }, { ORF_YUVA420P16BE, ORF_YUVA420P16LE }, { ORF_YUVA422P9BE, ORF_YUVA422P9LE }, { ORF_YUVA422P10BE, ORF_YUVA422P10LE }, { ORF_YUVA422P12BE, ORF_YUVA422P12LE }, { ORF_YUVA422P16BE, ORF_YUVA422P16LE }, { ORF_YUVA444P9BE, ORF_YUVA444P9LE }, { ORF_YUVA444P10BE, ORF_YUVA444P10LE }, { ORF_YUVA444P12BE, ORF_YUVA444P12LE }, { ORF_YUVA444P16BE, ORF_YUVA444P16LE },
+    { ORF_BAYER_BGGR16BE, ORF_BAYER_BGGR16LE }, { ORF_BAYER_RGGB16BE, ORF_BAYER_RGGB16LE }, { ORF_BAYER_GBRG16BE, ORF_BAYER_GBRG16LE }, { ORF_BAYER_GRBG16BE, ORF_BAYER_GRBG16LE },
     { ORF_RGBF32BE, ORF_RGBF32LE }, { ORF_RGBF16BE, ORF_RGBF16LE }, { ORF_RGBAF16BE, ORF_RGBAF16LE }, { ORF_GRAYF16BE, ORF_GRAYF16LE }, { ORF_YAF32BE, ORF_YAF32LE },
     { ORF_YAF16BE, ORF_YAF16LE }, { ORF_GBRPF16BE, ORF_GBRPF16LE }, { ORF_GBRAPF16BE, ORF_GBRAPF16LE },
     { ORF_YA16BE, ORF_YA16LE }, { ORF_GRAYF32BE, ORF_GRAYF32LE }, { ORF_XYZ12BE, ORF_XYZ12LE }, { ORF_NV20BE, ORF_NV20LE }, { ORF_GBRP10MSBBE, ORF_GBRP10MSBLE }, { ORF_GBRP12MSBBE, ORF_GBRP12MSBLE },
@@ -283,7 +290,8 @@ static int isFloat16(int f) { return isFloat(f) && desc_get(f)->c[0].depth == 16
 /* usePal (swscale_internal.h:937-950) without gray8, whose grey palette only feeds palToRgbWrapper / palToGbrpWrapper: the scaler chain gives
  * the same bytes for it (tests/test_oracle_properties_extra.py) */
 static int isPalSrc(int f) { return f == ORF_PAL8 || f == ORF_RGB8 || f == ORF_BGR8 || f == ORF_RGB4_BYTE || f == ORF_BGR4_BYTE; }
-static int isInputOnly(int f) { return f == ORF_PAL8 || f == ORF_UYYVYY411 || f == ORF_RGBF32LE || f == ORF_RGBF16LE || f == ORF_RGBAF16LE || f == ORF_GRAYF16LE || f == ORF_YAF32LE || f == ORF_YAF16LE || f == ORF_GBRPF16LE || f == ORF_GBRAPF16LE; }
+static int isBayer(int f) { return !!(desc_get(f)->flags & PF_BAYER); }
+static int isInputOnly(int f) { return isBayer(f) || f == ORF_PAL8 || f == ORF_UYYVYY411 || f == ORF_RGBF32LE || f == ORF_RGBF16LE || f == ORF_RGBAF16LE || f == ORF_GRAYF16LE || f == ORF_YAF32LE || f == ORF_YAF16LE || f == ORF_GBRPF16LE || f == ORF_GBRAPF16LE; }
 static int isALPHA(int f) { return !!(desc_get(f)->flags & PF_ALPHA); }
 static int isPlanarRGB(int f) { return (desc_get(f)->flags & (PF_PLANAR | PF_RGB)) == (PF_PLANAR | PF_RGB); }
 static int isPacked(int f) { const Desc *d = desc_get(f); return (d->nb >= 2 && !(d->flags & PF_PLANAR)) || isMono(f) || f == ORF_PAL8; }   /* swscale_internal.h:906-914 */
@@ -325,7 +333,7 @@ enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
        UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_RGBLOW, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED,
        UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP, UNSC_RGB30_TO_16, UNSC_RGB30_TO_GBRP, UNSC_GBRP_TO_RGB30, UNSC_YUV2MONO, UNSC_U8_TO_F32, UNSC_F32_TO_U8,
        UNSC_PLANAR2P422, UNSC_P4222PLANAR,
-       UNSC_RGB16SHUFFLE, UNSC_PACKED16_TO_GBRP16, UNSC_GBRP16_TO_PACKED16, UNSC_ALPHABLEND, UNSC_PLANARRGB_PLANARRGB, UNSC_PAL2RGB,
+       UNSC_RGB16SHUFFLE, UNSC_PACKED16_TO_GBRP16, UNSC_GBRP16_TO_PACKED16, UNSC_ALPHABLEND, UNSC_PLANARRGB_PLANARRGB, UNSC_PAL2RGB, UNSC_BAYER,
        UNSC_REFUSE = -1 /* a special converter of the reference that is not restated */ };
 
 struct OrSws {
@@ -1239,6 +1247,7 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         ((c->unscaled_kind == UNSC_PACKED16_TO_GBRP16 || c->unscaled_kind == UNSC_RGB30_TO_GBRP) && isALPHA(d)) ||
         ((c->unscaled_kind == UNSC_GBRP16_TO_PACKED16 || c->unscaled_kind == UNSC_GBRP_TO_RGB30) && isALPHA(s)))
         c->unscaled_kind = UNSC_REFUSE;
+    if (isBayer(s) && (d == ORF_RGB24 || d == ORF_RGB48LE || d == ORF_YUV420P)) c->unscaled_kind = UNSC_BAYER;   /* bayer_to_rgb24 / rgb48 / yv12_wrapper (:2543-2555) */
     /* palToRgbWrapper / palToGbrpWrapper (:2619-2630) for the palette-expanded sources (gray8 is left to the scaler chain, see isPalSrc) */
     if (isPalSrc(s) && (d == ORF_GBRP || d == ORF_GBRAP || d == ORF_RGB24 || d == ORF_BGR24 || d == ORF_RGBA || d == ORF_BGRA || d == ORF_ARGB || d == ORF_ABGR))
         c->unscaled_kind = UNSC_PAL2RGB;
@@ -1384,6 +1393,28 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
         return 0;
     }
 
+    if (isBayer(srcFormat)) {   /* utils.c:1524-1550: anything but the three direct conversions goes through rgb24 / rgb48 at the source size */
+        if (srcH < 2) return -1;   /* (bayer_to_*_wrapper: av_assert0(srcSliceH > 1)) */
+        if (!unscaled || c->dst_be || (dstFormat != ORF_RGB24 && dstFormat != ORF_YUV420P && dstFormat != ORF_RGB48LE)) {
+            const int tmpFormat = ds->c[1].depth == 8 ? ORF_RGB48LE : ORF_RGB24;   /* isBayer16BPS */
+            int k;
+            c->casc_stride[0] = (srcW * desc_get(tmpFormat)->c[0].step + 63) & ~63;
+            c->casc_tmp[0] = calloc((size_t)c->casc_stride[0] * srcH + 64, 1);
+            c->cascade[0] = alloc_set_opts(srcW, srcH, srcFormat, srcW, srcH, tmpFormat, flags, c->o.scaler_params);
+            c->cascade[1] = alloc_set_opts(srcW, srcH, tmpFormat, dstW, dstH, dstFormat, flags, c->o.scaler_params);   /* (byte order is this context's business) */
+            for (k = 0; k < 4; k++) {   /* srcFilter to the first step, dstFilter to the second */
+                c->cascade[0]->o.src_vec[k] = c->o.src_vec[k]; c->cascade[0]->o.src_vec_len[k] = c->o.src_vec_len[k];
+                c->cascade[1]->o.dst_vec_len[k] = c->o.dst_vec_len[k];
+            }
+            if (init_context(c->cascade[0]) < 0 || init_context(c->cascade[1]) < 0) {
+                or_sws_free(c->cascade[0]); or_sws_free(c->cascade[1]); free(c->casc_tmp[0]);
+                c->cascade[0] = c->cascade[1] = NULL; c->casc_tmp[0] = NULL;
+                return -1;
+            }
+            c->initialized = 1;
+            return 0;
+        }
+    }
     /* alpha: src alpha dropped -> reference cascades through alpha blend only if alpha_blend != NONE (default NONE) */
     c->needAlpha = isALPHA(srcFormat) && isALPHA(dstFormat);
     if (isRGB8class(dstFormat))   /* utils.c:1744-1747 (allocated for every context there; only these writers use them) */
@@ -1435,11 +1466,12 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
         return 0;
     }
     if (unscaled && !usesHFilter && !usesVFilter &&
-        (c->o.src_range == c->o.dst_range || isAnyRGB(dstFormat) || isFloat(srcFormat) || isFloat(dstFormat))) {
+        (c->o.src_range == c->o.dst_range || isAnyRGB(dstFormat) || isFloat(srcFormat) || isFloat(dstFormat) || isBayer(srcFormat))) {
         get_unscaled(c);
         if (c->unscaled_kind == UNSC_REFUSE) return -1;
         if (c->unscaled_kind) { c->initialized = 1; return 0; }
     }
+    if (isBayer(srcFormat)) return -1;   /* (a source filter on one of the three direct conversions: there is no scaler reader to fall back on) */
 
     /* filters (:1675-1735), filterAlign == 1 in the C-only build */
     {
@@ -2400,6 +2432,107 @@ static int unscaled_pal2rgb(const OrSws *c, const uint8_t *const src[], const in
             } else {
                 uint8_t *o = dst[0] + (ptrdiff_t)(y + srcSliceY) * dstStride[0] + dd->c[0].step * x;
                 for (int k = 0; k < dd->c[0].step; k++) o[k] = (uint8_t)(p >> (8 * k));
+            }
+        }
+    }
+    return srcSliceH;
+}
+
+/* bayer_to_rgb24_wrapper / bayer_to_rgb48_wrapper / bayer_to_yv12_wrapper (swscale_unscaled.c:1652-1806) over bayer_template.c.
+ * A picture is a grid of 2x2 blocks.  The first and the last block row, and the first and last block of every other row, are "copied"
+ * (nearest samples of the block itself), the rest is "interpolated" from the 4x4 neighbourhood.  An odd height ends with a copy that runs
+ * upwards from the last row (negative strides) and so rewrites the row above it.  The R() / B() names of the template are byte positions:
+ * BAYER_R = 0 for bggr / gbrg and 2 for rggb / grbg, so that the bytes always come out as R, G, B.  16-bit samples are reduced by
+ * BAYER_SHIFT = 8 for the 8-bit destinations; the rgb48 destination takes the samples as they are (an 8-bit mosaic too).
+ * A column beyond the picture (odd widths) is read from the row's padding like the reference does, where the stride holds it. */
+typedef struct { const uint8_t *p; ptrdiff_t stride; int sz, w, avail; } BayerSrc;
+static unsigned bayer_s(const BayerSrc *b, int y, int x)   /* S(y, x) relative to the block, x counted from the row start */
+{
+    const uint8_t *q = b->p + y * b->stride + (ptrdiff_t)b->sz * x;
+    if ((x + 1) * b->sz > b->avail) return 0;
+    if (b->sz == 1) return q[0];
+    return (unsigned)q[0] | ((unsigned)q[1] << 8);
+}
+/* one block at column x0: v[py][px][0..2] = the template's R, G, B names */
+static void bayer_block(const BayerSrc *b, int x0, int quad, int interp, int sh, unsigned v[2][2][3])
+{
+#define T(y, x) bayer_s(b, (y), x0 + (x))
+    if (quad) {   /* BAYER_BGGR / BAYER_RGGB */
+        if (!interp) {
+            v[0][0][0] = v[0][1][0] = v[1][1][0] = v[1][0][0] = T(1, 1) >> sh;
+            v[0][1][1] = T(0, 1) >> sh; v[0][0][1] = v[1][1][1] = (T(0, 1) + T(1, 0)) >> (1 + sh); v[1][0][1] = T(1, 0) >> sh;
+            v[1][1][2] = v[0][0][2] = v[0][1][2] = v[1][0][2] = T(0, 0) >> sh;
+        } else {
+            v[0][0][0] = (T(-1, -1) + T(-1, 1) + T(1, -1) + T(1, 1)) >> (2 + sh); v[0][0][1] = (T(-1, 0) + T(0, -1) + T(0, 1) + T(1, 0)) >> (2 + sh); v[0][0][2] = T(0, 0) >> sh;
+            v[0][1][0] = (T(-1, 1) + T(1, 1)) >> (1 + sh); v[0][1][1] = T(0, 1) >> sh; v[0][1][2] = (T(0, 0) + T(0, 2)) >> (1 + sh);
+            v[1][0][0] = (T(1, -1) + T(1, 1)) >> (1 + sh); v[1][0][1] = T(1, 0) >> sh; v[1][0][2] = (T(0, 0) + T(2, 0)) >> (1 + sh);
+            v[1][1][0] = T(1, 1) >> sh; v[1][1][1] = (T(0, 1) + T(1, 0) + T(1, 2) + T(2, 1)) >> (2 + sh); v[1][1][2] = (T(0, 0) + T(0, 2) + T(2, 0) + T(2, 2)) >> (2 + sh);
+        }
+    } else {      /* BAYER_GBRG / BAYER_GRBG */
+        if (!interp) {
+            v[0][0][0] = v[0][1][0] = v[1][1][0] = v[1][0][0] = T(1, 0) >> sh;
+            v[0][0][1] = T(0, 0) >> sh; v[1][1][1] = T(1, 1) >> sh; v[0][1][1] = v[1][0][1] = (T(0, 0) + T(1, 1)) >> (1 + sh);
+            v[1][1][2] = v[0][0][2] = v[0][1][2] = v[1][0][2] = T(0, 1) >> sh;
+        } else {
+            v[0][0][0] = (T(-1, 0) + T(1, 0)) >> (1 + sh); v[0][0][1] = T(0, 0) >> sh; v[0][0][2] = (T(0, -1) + T(0, 1)) >> (1 + sh);
+            v[0][1][0] = (T(-1, 0) + T(-1, 2) + T(1, 0) + T(1, 2)) >> (2 + sh); v[0][1][1] = (T(-1, 1) + T(0, 0) + T(0, 2) + T(1, 1)) >> (2 + sh); v[0][1][2] = T(0, 1) >> sh;
+            v[1][0][0] = T(1, 0) >> sh; v[1][0][1] = (T(0, 0) + T(1, -1) + T(1, 1) + T(2, 0)) >> (2 + sh); v[1][0][2] = (T(0, -1) + T(0, 1) + T(2, -1) + T(2, 1)) >> (2 + sh);
+            v[1][1][0] = (T(1, 0) + T(1, 2)) >> (1 + sh); v[1][1][1] = T(1, 1) >> sh; v[1][1][2] = (T(0, 1) + T(2, 1)) >> (1 + sh);
+        }
+    }
+#undef T
+}
+static int unscaled_bayer(const OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY, int srcSliceH,
+                          uint8_t *const dst[], const int dstStride[])
+{
+    const int sf = c->o.src_format, df = c->o.dst_format, W = c->o.src_w, H = srcSliceH;
+    const int quad = sf == ORF_BAYER_BGGR8 || sf == ORF_BAYER_BGGR16LE || sf == ORF_BAYER_RGGB8 || sf == ORF_BAYER_RGGB16LE;
+    const int rpos = (sf == ORF_BAYER_BGGR8 || sf == ORF_BAYER_BGGR16LE || sf == ORF_BAYER_GBRG8 || sf == ORF_BAYER_GBRG16LE) ? 0 : 2;
+    const int sz = desc_get(sf)->c[0].step;
+    const int sh = (sz == 2 && df != ORF_RGB48LE) ? 8 : 0;
+    const int32_t *t = c->rgb2yuv;
+    const int avail = srcStride[0] < 0 ? -srcStride[0] : srcStride[0];
+    if (H < 2) return -22;
+    /* block rows in the reference's order: (row0, direction, interpolated) */
+    for (int pass = 0, i = 0; ; pass++) {
+        int row0, dir = 1, interp_row;
+        if (pass == 0) { row0 = 0; interp_row = 0; i = 2; }
+        else if (i < H - 2) { row0 = i; interp_row = 1; i += 2; }
+        else if (i + 1 == H) { row0 = i; dir = -1; interp_row = 0; i = H + 2; }
+        else if (i < H) { row0 = i; interp_row = 0; i = H + 2; }
+        else break;
+        {
+            BayerSrc b = { src[0] + (ptrdiff_t)row0 * srcStride[0], (ptrdiff_t)dir * srcStride[0], sz, W, avail };
+            for (int x0 = 0; x0 < W; x0 += 2) {
+                const int interp = interp_row && x0 >= 2 && x0 < W - 2;
+                unsigned v[2][2][3];
+                bayer_block(&b, x0, quad, interp, sh, v);
+                if (df == ORF_YUV420P) {   /* rgb24toyv12_2x2: ff_rgb24toyv12(block, dstY, dstV, dstU, ...) reads byte 0 as B and swaps the chroma pointers */
+                    unsigned bb[4], gg[4], rr[4], bx, gx, rx;
+                    for (int k = 0; k < 4; k++) {
+                        const unsigned *px = v[k >> 1][k & 1];
+                        unsigned byte[3];
+                        byte[rpos] = px[0] & 0xff; byte[1] = px[1] & 0xff; byte[2 - rpos] = px[2] & 0xff;
+                        bb[k] = byte[0]; gg[k] = byte[1]; rr[k] = byte[2];
+                        if (x0 + (k & 1) < W)
+                            dst[0][(ptrdiff_t)(srcSliceY + row0 + dir * (k >> 1)) * dstStride[0] + x0 + (k & 1)] =
+                                (uint8_t)((((unsigned)t[RY] * rr[k] + (unsigned)t[GY] * gg[k] + (unsigned)t[BY] * bb[k]) >> 15) + 16);
+                    }
+                    bx = (bb[0] + bb[1] + bb[2] + bb[3]) >> 2; gx = (gg[0] + gg[1] + gg[2] + gg[3]) >> 2; rx = (rr[0] + rr[1] + rr[2] + rr[3]) >> 2;
+                    dst[2][(ptrdiff_t)((srcSliceY + row0) >> 1) * dstStride[2] + (x0 >> 1)] = (uint8_t)((((unsigned)t[RU] * rx + (unsigned)t[GU] * gx + (unsigned)t[BU] * bx) >> 15) + 128);
+                    dst[1][(ptrdiff_t)((srcSliceY + row0) >> 1) * dstStride[1] + (x0 >> 1)] = (uint8_t)((((unsigned)t[RV] * rx + (unsigned)t[GV] * gx + (unsigned)t[BV] * bx) >> 15) + 128);
+                } else {
+                    for (int py = 0; py < 2; py++) for (int px = 0; px < 2 && x0 + px < W; px++) {
+                        uint8_t *o = dst[0] + (ptrdiff_t)(srcSliceY + row0 + dir * py) * dstStride[0];
+                        if (df == ORF_RGB48LE) {
+                            uint16_t *o16 = (uint16_t *)o + 3 * (x0 + px);
+                            o16[rpos] = (uint16_t)v[py][px][0]; o16[1] = (uint16_t)v[py][px][1]; o16[2 - rpos] = (uint16_t)v[py][px][2];
+                        } else {
+                            o += 3 * (x0 + px);
+                            o[rpos] = (uint8_t)v[py][px][0]; o[1] = (uint8_t)v[py][px][1]; o[2 - rpos] = (uint8_t)v[py][px][2];
+                        }
+                    }
+                }
             }
         }
     }
@@ -4152,6 +4285,7 @@ static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4
     if (isPalSrc(c->o.src_format)) update_palette(c, src[1]);   /* scale_internal, swscale.c:1088-1089 */
     switch (c->unscaled_kind) {
     case UNSC_PAL2RGB: return unscaled_pal2rgb(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_BAYER: return unscaled_bayer(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_YUV2RGB: return unscaled_yuv2rgb(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_P01X: return unscaled_p01x(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_8_P01X: return unscaled_8_p01x(c, src, srcStride, 0, srcSliceH, dst, dstStride);
@@ -4217,7 +4351,7 @@ const char *or_sws_path_name(const OrSws *c)
                                "rgbToRgb", "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb",
                                "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb", "rgbToRgb", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "yuv2rgb_c", "uint_y_to_float_y", "float_y_to_uint_y",
                                "planarToYuy2", "yuyvToPlanar",
-                               "rgb16Shuffle", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "alphablendaway", "planarRgbToplanarRgb", "palToRgb" };
+                               "rgb16Shuffle", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "alphablendaway", "planarRgbToplanarRgb", "palToRgb", "bayer" };
     return c->cascade[0] ? "cascade" : n[c->unscaled_kind];
 }
 const int32_t *or_sws_rgb2yuv_table(const OrSws *c) { return c->rgb2yuv; }

@@ -52,6 +52,9 @@ enum {
     ORF_YUVA420P9LE = 81, ORF_YUVA420P9BE = 80, ORF_YUVA420P10LE = 87, ORF_YUVA420P10BE = 86, ORF_YUVA420P16LE = 93, ORF_YUVA420P16BE = 92, ORF_YUVA422P9LE = 83, ORF_YUVA422P9BE = 82, ORF_YUVA422P10LE = 89, ORF_YUVA422P10BE = 88, ORF_YUVA422P12LE = 185, ORF_YUVA422P12BE = 184, ORF_YUVA422P16LE = 95, ORF_YUVA422P16BE = 94, ORF_YUVA444P9LE = 85, ORF_YUVA444P9BE = 84, ORF_YUVA444P10LE = 91, ORF_YUVA444P10BE = 90, ORF_YUVA444P12LE = 187, ORF_YUVA444P12BE = 186, ORF_YUVA444P16LE = 97, ORF_YUVA444P16BE = 96,
     ORF_YA8 = 56, ORF_YA16BE = 109, ORF_YA16LE = 110,
     ORF_GRAYF32BE = 182, ORF_GRAYF32LE = 183,
+    /* bayer mosaics: inputs only, through their own unscaled converters or a cascade over rgb24 / rgb48 */
+    ORF_BAYER_BGGR8 = 139, ORF_BAYER_RGGB8 = 140, ORF_BAYER_GBRG8 = 141, ORF_BAYER_GRBG8 = 142, ORF_BAYER_BGGR16LE = 143, ORF_BAYER_BGGR16BE = 144,
+    ORF_BAYER_RGGB16LE = 145, ORF_BAYER_RGGB16BE = 146, ORF_BAYER_GBRG16LE = 147, ORF_BAYER_GBRG16BE = 148, ORF_BAYER_GRBG16LE = 149, ORF_BAYER_GRBG16BE = 150,
     ORF_PAL8 = 11,   /* input only: data[1] holds 256 native-endian 0xAARRGGBB words */
     /* float / half-float sources and the packed 4:1:1 source (inputs only in the reference's format table) */
     ORF_UYYVYY411 = 16, ORF_RGBAF16BE = 206, ORF_RGBAF16LE = 207, ORF_RGBF32BE = 217, ORF_RGBF32LE = 218, ORF_RGBF16BE = 233, ORF_RGBF16LE = 234,

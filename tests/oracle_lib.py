@@ -26,6 +26,9 @@ _FORMATS = {
     "yaf32le": (253, "packed", 0, 0, 8), "yaf32be": (252, "packed", 0, 0, 8), "yaf16le": (255, "packed", 0, 0, 4), "yaf16be": (254, "packed", 0, 0, 4),
     "gbrpf16le": (244, "rgbp", 0, 0, 2), "gbrpf16be": (243, "rgbp", 0, 0, 2), "gbrapf16le": (246, "rgbap", 0, 0, 2), "gbrapf16be": (245, "rgbap", 0, 0, 2),
     "uyyvyy411": (16, "packed411", 2, 0, 1), "pal8": (11, "pal", 0, 0, 1),
+    "bayer_bggr8": (139, "gray", 0, 0, 1), "bayer_rggb8": (140, "gray", 0, 0, 1), "bayer_gbrg8": (141, "gray", 0, 0, 1), "bayer_grbg8": (142, "gray", 0, 0, 1),
+    "bayer_bggr16le": (143, "gray", 0, 0, 2), "bayer_bggr16be": (144, "gray", 0, 0, 2), "bayer_rggb16le": (145, "gray", 0, 0, 2), "bayer_rggb16be": (146, "gray", 0, 0, 2),
+    "bayer_gbrg16le": (147, "gray", 0, 0, 2), "bayer_gbrg16be": (148, "gray", 0, 0, 2), "bayer_grbg16le": (149, "gray", 0, 0, 2), "bayer_grbg16be": (150, "gray", 0, 0, 2),
     "bgr8": (17, "packed", 0, 0, 1), "bgr4": (18, "nibble", 0, 0, 1), "bgr4_byte": (19, "packed", 0, 0, 1), "rgb8": (20, "packed", 0, 0, 1), "rgb4": (21, "nibble", 0, 0, 1), "rgb4_byte": (22, "packed", 0, 0, 1),
     "xyz12le": (99, "packed", 0, 0, 6), "yuvj411p": (138, "planar", 2, 0, 1), "nv20le": (102, "semi", 1, 0, 2),
     "gbrp10msble": (263, "rgbp", 0, 0, 2), "gbrp12msble": (265, "rgbp", 0, 0, 2),

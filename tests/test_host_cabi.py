@@ -98,7 +98,8 @@ def test_unsupported_requests_fail_like_the_reference(hiplib):
     assert not L.sws_getContext(0, 10, 0, 10, 10, 0, 4, None, None, None)          # invalid dimension -> NULL
     assert not L.sws_getContext(16, 16, 0, 16, 16, 0, 4 | 2, None, None, None)     # two scaler flags -> NULL
     assert not L.sws_getContext(16, 16, 0, 16, 16, 11, 4, None, None, None)        # pal8 is an input only, like in the reference
-    assert not L.sws_getContext(16, 16, 139, 16, 16, 0, 4, None, None, None)       # bayer_bggr8: not on the HIP path
+    assert not L.sws_getContext(16, 16, 0, 16, 16, 139, 4, None, None, None)       # bayer_bggr8 too
+    assert not L.sws_getContext(16, 16, 16000, 16, 16, 0, 4, None, None, None)     # not a pixel format
     assert L.sws_isSupportedInput(LA.PIX_FMT["nv12"]) and L.sws_isSupportedOutput(LA.PIX_FMT["p010le"])
     assert L.sws_isSupportedOutput(LA.PIX_FMT["gbrpf32le"]) and L.sws_isSupportedInput(LA.PIX_FMT["gbrp12le"])
     assert L.sws_isSupportedOutput(LA.PIX_FMT["gray8"]) and L.sws_isSupportedInput(LA.PIX_FMT["gray12le"])
