@@ -153,3 +153,15 @@ def test_prefixed_twin_exports_the_same_api_as_swship(hiplib):
     assert c
     both.swship_freeContext.argtypes = [C.c_void_p]
     both.swship_freeContext(c)
+
+
+def test_format_queries_answer_like_the_reference_table(hiplib):
+    """sws_isSupportedInput() / sws_isSupportedOutput() for every AVPixelFormat value against libswscale/format.c legacy_format_entries
+    (tests/golden/legacy_format_entries.json, written by tools/gen_format_table.py): all 234 rows, and nothing outside the table."""
+    import json
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "legacy_format_entries.json")))
+    L = hiplib
+    want = {e["value"]: (e["in"], e["out"]) for e in tab["entries"]}
+    assert len(want) == 234
+    for v in range(-1, tab["nb"] + 8):
+        assert (L.sws_isSupportedInput(v), L.sws_isSupportedOutput(v)) == want.get(v, (0, 0)), v
