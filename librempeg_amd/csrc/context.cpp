@@ -208,9 +208,9 @@ void choose_unscaled(SwsInternal *c)
         if (s != d && ((s48 && d48) || (s48 && d64) || (s64 && d48))) k = PLAN_UNSC_RGB16SHUFFLE;
         const bool s30 = s == AV_PIX_FMT_X2RGB10LE || s == AV_PIX_FMT_X2BGR10LE, d30 = d == AV_PIX_FMT_X2RGB10LE || d == AV_PIX_FMT_X2BGR10LE;
         if (s30 && (d48 || d64)) k = PLAN_UNSC_RGB30_TO_16;                       // findRgbConvFn :1912-1937 through rgbToRgbWrapper (:2459-2463)
-        if ((s48 || s64) && dp16) k = PLAN_UNSC_PACKED16_GBRP16;
+        if ((s48 || s64) && dp16 && !pix_desc(d)->comp[0].shift) k = PLAN_UNSC_PACKED16_GBRP16;   // (the rule lists gbrp9..16 and gbrap10..16: not the msb formats)
         if (s30 && isPlanarRGB(d) && !isFloatFmt(d) && pix_desc(d)->comp[0].depth >= 10) k = PLAN_UNSC_RGB30_TO_GBRP;   // :2509-2512
-        if (sp16 && (d48 || d64)) k = PLAN_UNSC_GBRP16_PACKED16;
+        if (sp16 && !pix_desc(s)->comp[0].shift && (d48 || d64)) k = PLAN_UNSC_GBRP16_PACKED16;
         if (d30 && isPlanarRGB(s) && !isFloatFmt(s) && pix_desc(s)->comp[0].depth >= 10) k = PLAN_UNSC_GBRP_TO_RGB30;   // :2535-2538
     }
     if (isAnyRGB(s) && !isPlanarRGB(s) && pix_desc(s)->comp[0].depth == 8 && d == AV_PIX_FMT_GBRP) k = PLAN_UNSC_PACKED_GBRP;             // rgbToPlanarRgbWrapper (:2542-2544)
@@ -219,13 +219,12 @@ void choose_unscaled(SwsInternal *c)
     if (!c->srcBE && !c->dstBE && isPlanarRGB(s) && isPlanarRGB(d) && !isFloatFmt(s) && !isFloatFmt(d) && isALPHA(s) != isALPHA(d) &&
         pix_desc(s)->comp[0].depth == pix_desc(d)->comp[0].depth && pix_desc(s)->comp[0].depth != 9 && !pix_desc(s)->comp[0].shift && !pix_desc(d)->comp[0].shift)
         k = PLAN_UNSC_PLANARRGB_PLANARRGB;
-    // the alpha-carrying rows of the packed <-> planar RGB wrappers are not built: planarRgbaToRgbWrapper (:2483-2484), rgbToPlanarRgbaWrapper
-    // (:2546-2548), Rgb16ToPlanarRgb16Wrapper / planarRgb16ToRgb16Wrapper with a gbrap side (:2486-2538)
-    if ((s == AV_PIX_FMT_GBRAP && isAnyRGB(d) && !isPlanarRGB(d) && pix_desc(d)->comp[0].depth == 8 && !isRGB16fmt(d)) ||
-        (d == AV_PIX_FMT_GBRAP && isAnyRGB(s) && !isPlanarRGB(s) && pix_desc(s)->comp[0].depth == 8) ||
-        ((k == PLAN_UNSC_PACKED16_GBRP16 || k == PLAN_UNSC_RGB30_TO_GBRP) && isALPHA(d)) ||
-        ((k == PLAN_UNSC_GBRP16_PACKED16 || k == PLAN_UNSC_GBRP_TO_RGB30) && isALPHA(s)))
-        unsupported = true;
+    // planarRgbaToRgbWrapper (:2492-2493): gbrap -> byte RGB; rgbToPlanarRgbaWrapper (:2546-2548): 8-bit packed RGB -> gbrap
+    {
+        auto byteRGB = [](int f) { return f == AV_PIX_FMT_RGB24 || f == AV_PIX_FMT_BGR24 || f == AV_PIX_FMT_RGBA || f == AV_PIX_FMT_BGRA || f == AV_PIX_FMT_ARGB || f == AV_PIX_FMT_ABGR; };
+        if (s == AV_PIX_FMT_GBRAP && byteRGB(d)) k = PLAN_UNSC_GBRP_PACKED;
+        if (d == AV_PIX_FMT_GBRAP && byteRGB(s)) k = PLAN_UNSC_PACKED_GBRP;
+    }
     // bayer_to_rgb24_wrapper / bayer_to_rgb48_wrapper / bayer_to_yv12_wrapper (:2543-2555; AV_PIX_FMT_RGB48 is the native-endian name)
     if (isBayerFmt(s) && (d == AV_PIX_FMT_RGB24 || (d == AV_PIX_FMT_RGB48LE && !c->dstBE) || d == AV_PIX_FMT_YUV420P)) { k = PLAN_UNSC_BAYER; c->dst_slice_align = 2; }
     // palToRgbWrapper / palToGbrpWrapper (:2619-2630) for the palette-expanded sources.  (usePal() also names gray8, whose grey palette makes

@@ -135,6 +135,8 @@ int launch_misc(const LaunchCtx &L)
             rp.dpos[k] = rp.mode == 1 ? dd->comp[k].plane : dd->comp[k].offset / 2;
         }
         rp.depth = rp.mode == 1 ? dd->comp[0].depth : ds->comp[0].depth;
+        rp.src_alpha = isALPHA(c->opts.src_format) ? 1 : 0;
+        rp.dst_alpha = (rp.mode == 1 && isALPHA(c->opts.dst_format)) ? 1 : 0;
         const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
         hipLaunchKernelGGL(swsk::sws_k_rgb16_convert, grid, blk, 0, st, fs, rp, p.srcW, sliceY);
         break;
@@ -165,7 +167,8 @@ int launch_misc(const LaunchCtx &L)
         rp.x2rgb = (rp.mode == 2 ? c->opts.dst_format : c->opts.src_format) == AV_PIX_FMT_X2RGB10LE;
         rp.dstep = dd->comp[0].step / 2;
         for (int k = 0; k < 3; k++) rp.pos[k] = rp.mode == 0 ? dd->comp[k].offset / 2 : rp.mode == 1 ? dd->comp[k].plane : ds->comp[k].plane;
-        if (rp.mode == 1) { rp.hi = dd->comp[0].depth - 10; rp.lo = 10 - rp.hi; rp.shift = dd->comp[0].shift; }
+        if (rp.mode == 1) { rp.hi = dd->comp[0].depth - 10; rp.lo = 10 - rp.hi; rp.shift = dd->comp[0].shift;
+                            rp.dst_alpha = isALPHA(c->opts.dst_format) ? (int)((((1u << dd->comp[0].depth) - 1) << dd->comp[0].shift) & 0xFFFF) : 0; }
         if (rp.mode == 2) rp.shift = ds->comp[0].depth + ds->comp[0].shift - 10;
         const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
         hipLaunchKernelGGL(swsk::sws_k_rgb30_convert, grid, blk, 0, st, fs, rp, p.srcW, sliceY);
@@ -290,6 +293,11 @@ int launch_misc(const LaunchCtx &L)
         std::memset(&sp, 0, sizeof(sp));
         sp.src_step = ds->comp[0].step;
         for (int k = 0; k < 4; k++) sp.spos[k] = k < ds->nb_components ? ds->comp[k].offset : -1;
+        if (c->opts.dst_format == AV_PIX_FMT_GBRAP) {   // rgbToPlanarRgbaWrapper; an rgb0-style source was made opaque first (swscale.c:1106-1124)
+            const bool opaque = c->src0Alpha && !c->dst0Alpha;
+            sp.planar_alpha = (ds->comp[0].step == 4 && !opaque) ? 1 : 2;
+            if (ds->comp[0].step == 4) sp.spos[3] = (ds->comp[0].offset == 1 || ds->comp[2].offset == 1) ? 0 : 3;
+        }
         const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
         hipLaunchKernelGGL(swsk::sws_k_packed_to_gbrp, grid, blk, 0, st, fs, sp, p.srcW, sliceY);
         break;
@@ -299,6 +307,8 @@ int launch_misc(const LaunchCtx &L)
         swsk::ShufflePlan sp;
         std::memset(&sp, 0, sizeof(sp));
         for (int k = 0; k < 4; k++) sp.dpos[k] = k < dd->nb_components ? dd->comp[k].offset : -1;
+        if (dd->comp[0].step == 4) sp.dpos[3] = (dd->comp[0].offset == 1 || dd->comp[2].offset == 1) ? 0 : 3;
+        sp.planar_alpha = c->opts.src_format == AV_PIX_FMT_GBRAP ? 1 : 0;   // planarRgbaToRgbWrapper
         const dim3 grid(cdiv(cdiv(p.srcW, 4), 256), sliceH, n);
         if (dd->comp[0].step == 3) hipLaunchKernelGGL((swsk::sws_k_gbrp_to_packed<true>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);
         else hipLaunchKernelGGL((swsk::sws_k_gbrp_to_packed<false>), grid, blk, 0, st, fs, sp, p.srcW, sliceY);

@@ -12,6 +12,7 @@ struct ShufflePlan {
     int32_t src_step, dst_step;         // 3 or 4 bytes per pixel
     int32_t spos[4], dpos[4];           // byte offsets of R,G,B,A in a source / destination pixel (A: -1 = none)
     int32_t opaque;                     // write 255 to destination alpha even though the source has an alpha byte
+    int32_t planar_alpha;               // gbrap side: sws_k_gbrp_to_packed reads the alpha plane (1); sws_k_packed_to_gbrp writes one: 1 = from spos[3], 2 = 255
 };
 
 struct Tri { uint32_t a, b, c; };
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(256) sws_k_gbrp_to_packed(SwsFrameSet fs, Shuf
     for (int i = 0; i < n; i++) {
         uint8_t *q = d + i * DS;
         q[sp.dpos[0]] = pr[i]; q[sp.dpos[1]] = pg[i]; q[sp.dpos[2]] = pb[i];
-        if (!D3) q[sp.dpos[3]] = 255;
+        if (!D3) q[sp.dpos[3]] = sp.planar_alpha ? f.src[3][(int64_t)(sliceY + y) * f.srcStride[3] + x0 + i] : 255;   // gbraptopacked32 (:1235-1262) / gbr24ptopacked32
     }
 }
 
@@ -126,6 +127,8 @@ __global__ void __launch_bounds__(256) sws_k_packed_to_gbrp(SwsFrameSet fs, Shuf
     f.dst[2][(int64_t)(sliceY + y) * f.dstStride[2] + x] = s[sp.spos[0]];   // R
     f.dst[0][(int64_t)(sliceY + y) * f.dstStride[0] + x] = s[sp.spos[1]];   // G
     f.dst[1][(int64_t)(sliceY + y) * f.dstStride[1] + x] = s[sp.spos[2]];   // B
+    // rgbToPlanarRgbaWrapper (swscale_unscaled.c:1543-1590): packed32togbrap copies the fourth byte, packed24togbrap writes 255
+    if (sp.planar_alpha) f.dst[3][(int64_t)(sliceY + y) * f.dstStride[3] + x] = sp.planar_alpha == 1 ? s[sp.spos[3]] : 255;
 }
 
 // yuv420p_gbrp_c / yuv422p_gbrp_c (yuv2rgb.c:127-135 PUTGBRP, :532, :553): the 24 bpp LUT values written to the
@@ -260,7 +263,7 @@ __global__ void __launch_bounds__(256) sws_k_alphablend(SwsFrameSet fs, AlphaBle
 //   mode 0: rgb48tobgr48 / rgb48to64 / rgb48tobgr64 / rgb64to48 / rgb64tobgr48 (rgb2rgb.c:322-413): word moves, A = 0xFFFF
 //   mode 1: Rgb16ToPlanarRgb16Wrapper / packed16togbra16 (swscale_unscaled.c:685-962): plane[x] = word >> (16 - depth)
 //   mode 2: planarRgb16ToRgb16Wrapper / gbr16ptopacked16 (:964-1186): word = c << (16 - bpp) | c >> ((bpp - 8) * 2), A = 0xFFFF
-struct Rgb16Plan { int mode, sstep, dstep, spos[3], dpos[3], depth; };   // positions in 16-bit words (packed) or plane index (planar)
+struct Rgb16Plan { int mode, sstep, dstep, spos[3], dpos[3], depth, src_alpha, dst_alpha; };   // src_alpha / dst_alpha: the planar side has / gets an alpha plane, the packed side a fourth word   // positions in 16-bit words (packed) or plane index (planar)
 __global__ void __launch_bounds__(256) sws_k_rgb16_convert(SwsFrameSet fs, Rgb16Plan rp, int w, int sliceY)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -290,11 +293,20 @@ __global__ void __launch_bounds__(256) sws_k_rgb16_convert(SwsFrameSet fs, Rgb16
             const int dst = pl == 0 ? f.dstStride[0] : pl == 1 ? f.dstStride[1] : f.dstStride[2];
             ((uint16_t *)(dp + (int64_t)y * dst))[x] = (uint16_t)(v[k] >> (16 - rp.depth));
         }
+        if (rp.dst_alpha) {   // packed16togbra16: the source's alpha word, or 0xFFFF, >> shift
+            const unsigned a = rp.src_alpha ? ((const uint16_t *)(f.src[0] + (int64_t)y * f.srcStride[0]))[rp.sstep * x + 3] : 0xFFFFu;
+            ((uint16_t *)(f.dst[3] + (int64_t)y * f.dstStride[3]))[x] = (uint16_t)(a >> (16 - rp.depth));
+        }
     } else {
         uint16_t *d = (uint16_t *)(f.dst[0] + (int64_t)y * f.dstStride[0]) + rp.dstep * x;
 #pragma unroll
         for (int k = 0; k < 3; k++) d[rp.dpos[k]] = v[k];
-        if (rp.dstep == 4) d[3] = 0xFFFF;
+        if (rp.dstep == 4) {
+            if (rp.mode == 2 && rp.src_alpha) {   // gbr16ptopacked16: the alpha plane scaled like the colours
+                const uint16_t c = ((const uint16_t *)(f.src[3] + (int64_t)y * f.srcStride[3]))[x];
+                d[3] = (uint16_t)(c << (16 - rp.depth) | c >> ((rp.depth - 8) * 2));
+            } else d[3] = 0xFFFF;
+        }
     }
 }
 
@@ -369,7 +381,7 @@ __global__ void __launch_bounds__(256) sws_k_xyz12(const uint8_t *src, int64_t s
 // x2rgb10le / x2bgr10le special converters: mode 0 = x2rgb10to48 / to64 / tobgr48 / tobgr64 (rgb2rgb.c:415-471), mode 1 =
 // packed30togbra10 (swscale_unscaled.c:819-889), mode 2 = gbr16ptopacked30 (:1076-1103).  pos[] = R, G, B word offsets (mode 0)
 // or plane indices (modes 1, 2); hi / lo = bit replication shifts, shift = the planar format's sample shift
-struct Rgb30Plan { int mode, x2rgb, dstep, pos[3], hi, lo, shift; };
+struct Rgb30Plan { int mode, x2rgb, dstep, pos[3], hi, lo, shift, dst_alpha; };   // dst_alpha (mode 1): the alpha plane's value, 0 = no plane
 __global__ void __launch_bounds__(256) sws_k_rgb30_convert(SwsFrameSet fs, Rgb30Plan rp, int w, int sliceY)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -407,6 +419,7 @@ __global__ void __launch_bounds__(256) sws_k_rgb30_convert(SwsFrameSet fs, Rgb30
             const int dst = pl == 0 ? f.dstStride[0] : pl == 1 ? f.dstStride[1] : f.dstStride[2];
             ((uint16_t *)(dp + (int64_t)y * dst))[x] = (uint16_t)((v[k] << rp.hi | v[k] >> rp.lo) << rp.shift);
         }
+        if (rp.dst_alpha) ((uint16_t *)(f.dst[3] + (int64_t)y * f.dstStride[3]))[x] = (uint16_t)rp.dst_alpha;   // alpha_val = (1 << bpc) - 1, << shift
     }
 }
 

@@ -1227,9 +1227,9 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
         const int sp16 = isPlanarRGB(s) && !isFloat(s) && desc_get(s)->c[0].depth > 8, dp16 = isPlanarRGB(d) && !isFloat(d) && desc_get(d)->c[0].depth > 8;
         if (s != d && ((s48 && d48) || (s48 && d64) || (s64 && d48))) c->unscaled_kind = UNSC_RGB16SHUFFLE;
         if (isRGB30(s) && (d48 || d64)) c->unscaled_kind = UNSC_RGB30_TO_16;   /* x2rgb10to48 / x2rgb10tobgr48 / ..64 (:1912-1937, :2459-2463) */
-        if ((s48 || s64) && dp16) c->unscaled_kind = UNSC_PACKED16_TO_GBRP16;
+        if ((s48 || s64) && dp16 && !desc_get(d)->c[0].shift) c->unscaled_kind = UNSC_PACKED16_TO_GBRP16;   /* (the rule lists gbrp9..16 and gbrap10..16: not the msb formats) */
         if (isRGB30(s) && isPlanarRGB(d) && !isFloat(d) && desc_get(d)->c[0].depth >= 10) c->unscaled_kind = UNSC_RGB30_TO_GBRP;   /* :2509-2512 */
-        if (sp16 && (d48 || d64)) c->unscaled_kind = UNSC_GBRP16_TO_PACKED16;
+        if (sp16 && !desc_get(s)->c[0].shift && (d48 || d64)) c->unscaled_kind = UNSC_GBRP16_TO_PACKED16;
         if (isRGB30(d) && isPlanarRGB(s) && !isFloat(s) && desc_get(s)->c[0].depth >= 10) c->unscaled_kind = UNSC_GBRP_TO_RGB30;   /* :2535-2538 */
     }
     /* rgbToPlanarRgbWrapper (:2542-2544): 8-bit packed RGB -> gbrp */
@@ -1240,13 +1240,9 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
     if (!c->src_be && !c->dst_be && isPlanarRGB(s) && isPlanarRGB(d) && !isFloat(s) && !isFloat(d) && isALPHA(s) != isALPHA(d) &&
         desc_get(s)->c[0].depth == desc_get(d)->c[0].depth && desc_get(s)->c[0].depth != 9 && !desc_get(s)->c[0].shift && !desc_get(d)->c[0].shift)
         c->unscaled_kind = UNSC_PLANARRGB_PLANARRGB;
-    /* the alpha-carrying rows of the packed <-> planar RGB wrappers are not restated: planarRgbaToRgbWrapper (:2483-2484),
-     * rgbToPlanarRgbaWrapper (:2546-2548), Rgb16ToPlanarRgb16Wrapper / planarRgb16ToRgb16Wrapper with a gbrap side (:2486-2538) */
-    if ((s == ORF_GBRAP && isAnyRGB(d) && isPacked(d) && desc_get(d)->c[0].depth == 8 && !isRGB16(d)) ||
-        (d == ORF_GBRAP && isAnyRGB(s) && isPacked(s) && desc_get(s)->c[0].depth == 8) ||
-        ((c->unscaled_kind == UNSC_PACKED16_TO_GBRP16 || c->unscaled_kind == UNSC_RGB30_TO_GBRP) && isALPHA(d)) ||
-        ((c->unscaled_kind == UNSC_GBRP16_TO_PACKED16 || c->unscaled_kind == UNSC_GBRP_TO_RGB30) && isALPHA(s)))
-        c->unscaled_kind = UNSC_REFUSE;
+    /* planarRgbaToRgbWrapper (:2492-2493): gbrap -> byte RGB; rgbToPlanarRgbaWrapper (:2546-2548): 8-bit packed RGB -> gbrap */
+    if (s == ORF_GBRAP && (d == ORF_RGB24 || d == ORF_BGR24 || d == ORF_RGBA || d == ORF_BGRA || d == ORF_ARGB || d == ORF_ABGR)) c->unscaled_kind = UNSC_GBRP2PACKED;
+    if (d == ORF_GBRAP && (s == ORF_RGB24 || s == ORF_BGR24 || s == ORF_RGBA || s == ORF_BGRA || s == ORF_ARGB || s == ORF_ABGR)) c->unscaled_kind = UNSC_PACKED2GBRP;
     if (isBayer(s) && (d == ORF_RGB24 || d == ORF_RGB48LE || d == ORF_YUV420P)) c->unscaled_kind = UNSC_BAYER;   /* bayer_to_rgb24 / rgb48 / yv12_wrapper (:2543-2555) */
     /* palToRgbWrapper / palToGbrpWrapper (:2619-2630) for the palette-expanded sources (gray8 is left to the scaler chain, see isPalSrc) */
     if (isPalSrc(s) && (d == ORF_GBRP || d == ORF_GBRAP || d == ORF_RGB24 || d == ORF_BGR24 || d == ORF_RGBA || d == ORF_BGRA || d == ORF_ARGB || d == ORF_ABGR))
@@ -2039,7 +2035,8 @@ static int unscaled_gbrp2packed(OrSws *c, const uint8_t *const src[], const int 
         for (int x = 0; x < c->o.src_w; x++, d += dd->c[0].step) {
             for (int k = 0; k < 3; k++)
                 d[dd->c[k].offset] = src[ds->c[k].plane][(ptrdiff_t)y * srcStride[ds->c[k].plane] + x];
-            if (dd->c[0].step == 4) d[isALPHA(c->o.dst_format) ? dd->c[3].offset : 0] = 0xff;
+            if (dd->c[0].step == 4)   /* gbraptopacked32 (:1235-1262) takes the alpha plane, gbr24ptopacked32 (:1213-1233) writes 255 */
+                d[isALPHA(c->o.dst_format) ? dd->c[3].offset : 0] = c->o.src_format == ORF_GBRAP ? src[3][(ptrdiff_t)y * srcStride[3] + x] : 0xff;
         }
     }
     return srcSliceH;
@@ -2117,9 +2114,12 @@ static int unscaled_packed16_gbrp16(OrSws *c, const uint8_t *const src[], const 
     (void)srcSliceY;
     for (int y = 0; y < srcSliceH; y++) {
         const uint16_t *s = (const uint16_t *)(src[0] + (ptrdiff_t)y * srcStride[0]);
-        for (int x = 0; x < c->o.src_w; x++, s += ds->c[0].step / 2)
+        for (int x = 0; x < c->o.src_w; x++, s += ds->c[0].step / 2) {
             for (int k = 0; k < 3; k++)
                 ((uint16_t *)(dst[dd->c[k].plane] + (ptrdiff_t)y * dstStride[dd->c[k].plane]))[x] = (uint16_t)(s[ds->c[k].offset / 2] >> shift);
+            if (isALPHA(c->o.dst_format) && dst[3])   /* packed16togbra16 (:685-817): the source's alpha word, or 0xFFFF, >> shift */
+                ((uint16_t *)(dst[3] + (ptrdiff_t)y * dstStride[3]))[x] = (uint16_t)((isALPHA(c->o.src_format) ? s[3] : 0xFFFF) >> shift);
+        }
     }
     return srcSliceH;
 }
@@ -2137,7 +2137,10 @@ static int unscaled_gbrp16_packed16(OrSws *c, const uint8_t *const src[], const 
                 const uint16_t v = ((const uint16_t *)(src[ds->c[k].plane] + (ptrdiff_t)y * srcStride[ds->c[k].plane]))[x];
                 d[dd->c[k].offset / 2] = (uint16_t)(v << hi | v >> lo);
             }
-            if (dd->nb == 4) d[3] = 0xffff;
+            if (dd->nb == 4) {   /* gbr16ptopacked16 (:964-1081): the alpha plane scaled like the colours, or 0xffff */
+                if (isALPHA(c->o.src_format) && src[3]) { const uint16_t v = ((const uint16_t *)(src[3] + (ptrdiff_t)y * srcStride[3]))[x]; d[3] = (uint16_t)(v << hi | v >> lo); }
+                else d[3] = 0xffff;
+            }
         }
     }
     return srcSliceH;
@@ -2183,6 +2186,8 @@ static int unscaled_rgb30_to_gbrp(OrSws *c, const uint8_t *const src[], const in
             rgb30_fields(c->o.src_format, p, v);
             for (int k = 0; k < 3; k++)
                 ((uint16_t *)(dst[dd->c[k].plane] + (ptrdiff_t)y * dstStride[dd->c[k].plane]))[x] = (uint16_t)((v[k] << hi | v[k] >> lo) << shift);
+            if (isALPHA(c->o.dst_format) && dst[3])   /* packed30togbra10 (:819-889): alpha_val = (1 << bpc) - 1 */
+                ((uint16_t *)(dst[3] + (ptrdiff_t)y * dstStride[3]))[x] = (uint16_t)(((1u << bpc) - 1) << shift);
         }
     }
     return srcSliceH;
@@ -2208,15 +2213,21 @@ static int unscaled_gbrp_to_rgb30(OrSws *c, const uint8_t *const src[], const in
 
 /* rgbToPlanarRgbWrapper (swscale_unscaled.c:1436-1490) with packedtogbr24p (:1404-1434): de-interleave, alpha dropped */
 static int unscaled_packed2gbrp(OrSws *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
-                                int srcSliceH, uint8_t *const dst[], const int dstStride[])
+                                int srcSliceH, uint8_t *const dst[], const int dstStride[], int force_opaque)
 {
     const Desc *ds = desc_get(c->o.src_format), *dd = desc_get(c->o.dst_format);
+    /* rgbToPlanarRgbaWrapper: packed24togbrap writes 255 (:1480-1505), packed32togbrap copies the fourth byte (:1507-1541), which the
+     * caller made 255 for an rgb0-style source (swscale.c:1106-1124) */
+    const int want_a = c->o.dst_format == ORF_GBRAP && dst[3], have_a = ds->c[0].step == 4 && !force_opaque;
+    const int aoff = ds->c[0].step == 4 ? (ds->c[0].offset == 1 || ds->c[2].offset == 1 ? 0 : 3) : 0;
     (void)srcSliceY;
     for (int y = 0; y < srcSliceH; y++) {
         const uint8_t *s = src[0] + (ptrdiff_t)y * srcStride[0];
-        for (int x = 0; x < c->o.src_w; x++, s += ds->c[0].step)
+        for (int x = 0; x < c->o.src_w; x++, s += ds->c[0].step) {
             for (int k = 0; k < 3; k++)
                 dst[dd->c[k].plane][(ptrdiff_t)y * dstStride[dd->c[k].plane] + x] = s[ds->c[k].offset];
+            if (want_a) dst[3][(ptrdiff_t)y * dstStride[3] + x] = have_a ? s[aoff] : 0xff;
+        }
     }
     return srcSliceH;
 }
@@ -4275,6 +4286,7 @@ static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4
         if (c->unscaled_kind == UNSC_RGB2RGB) return unscaled_rgb2rgb(c, src, srcStride, 0, srcSliceH, dst, dstStride, opaque);
         if (c->unscaled_kind == UNSC_RGBLOW) return unscaled_rgblow(c, src, srcStride, 0, srcSliceH, dst, dstStride);
         if (c->unscaled_kind == UNSC_PACKEDCOPY) return unscaled_packedcopy(c, src, srcStride, 0, srcSliceH, dst, dstStride, opaque);
+        if (c->unscaled_kind == UNSC_PACKED2GBRP) return unscaled_packed2gbrp(c, src, srcStride, 0, srcSliceH, dst, dstStride, opaque);
         if (opaque && c->unscaled_kind) return -22; /* no other special converter takes an rgb0-style source to an alpha destination */
     }
     /* bgr24ToYv12Wrapper (:2062-2077), yvu9ToYv12Wrapper (:2079-2093), yuyv/uyvyToYuv420Wrapper (:423-470) with a yuva420p
@@ -4298,7 +4310,7 @@ static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4
     case UNSC_NV242PLANAR: return unscaled_nv242planar(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_NV242YUV420: return unscaled_nv242yuv420(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_YVU9_YV12: return unscaled_yvu9_yv12(c, src, srcStride, 0, srcSliceH, dst, dstStride);
-    case UNSC_PACKED2GBRP: return unscaled_packed2gbrp(c, src, srcStride, 0, srcSliceH, dst, dstStride);
+    case UNSC_PACKED2GBRP: return unscaled_packed2gbrp(c, src, srcStride, 0, srcSliceH, dst, dstStride, 0);
     case UNSC_U8_TO_F32: /* uint_y_to_float_y_wrapper (:2095-2113): uint2float_lut[i] = (float)i * (1 / 255) (utils.c:1552-1556) */
         for (int y = 0; y < srcSliceH; y++) {
             const uint8_t *s = src[0] + (ptrdiff_t)y * srcStride[0]; float *d = (float *)(dst[0] + (ptrdiff_t)y * dstStride[0]);

@@ -48,12 +48,29 @@ def test_planar_rgb_to_planar_rgb_wrapper(pair):
     run_case(70, 38, pair[0], 70, 38, pair[1], SWS_BICUBIC | BX, seed=8, device_frames=False)
 
 
-def test_wrappers_that_are_not_built_are_refused_by_both(hiplib):
-    for s, d in (("gbrap", "rgba"), ("rgba", "gbrap"), ("rgba64le", "gbrap10le"), ("gbrap16le", "rgb48le"), ("x2rgb10le", "gbrap12le")):
-        with pytest.raises(RuntimeError):
-            OL.Oracle(64, 32, s, 64, 32, d, SWS_BICUBIC | BX)
-        with pytest.raises(RuntimeError):
-            SwsContext(64, 32, s, 64, 32, d, SWS_BICUBIC | BX)
-        # ... scaled, the same pair goes through the scaler
-        OL.Oracle(64, 32, s, 48, 24, d, SWS_BICUBIC | BX)
-        SwsContext(64, 32, s, 48, 24, d, SWS_BICUBIC | BX).close()
+@pytest.mark.gpu
+@pytest.mark.parametrize("pair", [("gbrap", "rgba"), ("gbrap", "bgra"), ("gbrap", "argb"), ("gbrap", "abgr"), ("gbrap", "rgb24"), ("gbrap", "bgr24"), ("gbrap", "bgr0"),
+                                  ("rgba", "gbrap"), ("bgra", "gbrap"), ("argb", "gbrap"), ("abgr", "gbrap"), ("rgb24", "gbrap"), ("bgr24", "gbrap"), ("rgb0", "gbrap"), ("0bgr", "gbrap"),
+                                  ("rgba64le", "gbrap10le"), ("bgra64le", "gbrap16le"), ("rgb48le", "gbrap12le"), ("bgr48be", "gbrap14be"), ("rgba64be", "gbrap16le"), ("rgba64le", "gbrp12le"),
+                                  ("gbrap16le", "rgb48le"), ("gbrap10le", "rgba64le"), ("gbrap12be", "bgra64le"), ("gbrap14le", "bgra64be"), ("gbrp10le", "rgba64le"), ("gbrap16le", "bgr48be"),
+                                  ("x2rgb10le", "gbrap12le"), ("x2bgr10le", "gbrap10le"), ("x2rgb10le", "gbrap16be"), ("gbrap10le", "x2rgb10le"), ("gbrap16le", "x2bgr10le")],
+                         ids=lambda p: f"{p[0]}-{p[1]}")
+def test_alpha_rows_of_the_packed_planar_wrappers(pair):
+    """planarRgbaToRgbWrapper / gbraptopacked32 (swscale_unscaled.c:1235-1320), rgbToPlanarRgbaWrapper / packed24togbrap / packed32togbrap
+    (:1480-1590), packed16togbra16 and gbr16ptopacked16 with an alpha plane on either side (:685-817, :964-1081), packed30togbra10's
+    all-ones alpha (:819-889)."""
+    for w, h in ((70, 38), (1, 1), (129, 5)):
+        path, opath = run_case(w, h, pair[0], w, h, pair[1], SWS_BICUBIC | BX, seed=w)
+        assert path.startswith("unscaled:") and opath != "main", (path, opath)
+    run_case(70, 38, pair[0], 70, 38, pair[1], SWS_BICUBIC | BX, seed=9, device_frames=False)
+
+
+@pytest.mark.gpu
+def test_msb_planar_rgb_is_not_in_the_16_bit_wrapper_rules():
+    # Rgb16ToPlanarRgb16Wrapper / planarRgb16ToRgb16Wrapper name gbrp9..16 and gbrap10..16 (:2495-2533): gbrp10msb / gbrp12msb go through the scaler
+    for s, d in (("rgb48le", "gbrp10msble"), ("gbrp12msble", "rgba64le"), ("bgra64le", "gbrp12msbbe")):
+        assert run_case(70, 38, s, 70, 38, d, SWS_BICUBIC | BX, seed=3)[1] == "main"
+    # ... the 30 bpp rules take every planar RGB format of 10 bits and more (:2509-2512, :2535-2538)
+    assert OL.Oracle(70, 38, "x2rgb10le", 70, 38, "gbrp10msble", SWS_BICUBIC | BX).path() != "main"
+    run_case(70, 38, "x2rgb10le", 70, 38, "gbrp10msble", SWS_BICUBIC | BX, seed=4)
+    run_case(70, 38, "gbrp12msble", 70, 38, "x2bgr10le", SWS_BICUBIC | BX, seed=5)
