@@ -340,10 +340,6 @@ int init_single_context(SwsInternal *c)
     }
     if (isPlanarRGB(dstFormat) && !(flags & SWS_FULL_CHR_H_INT)) { flags |= SWS_FULL_CHR_H_INT; o->flags = flags; }
     const bool dstMono = dstFormat == AV_PIX_FMT_MONOWHITE || dstFormat == AV_PIX_FMT_MONOBLACK;
-    if (dstMono && o->dither == SWS_DITHER_ED) {
-        log_msg(c, 0, "error diffusion dither for 1 bpp destinations is not implemented on the HIP path\n");
-        return SWS_AVERROR(ENOTSUP);
-    }
     if ((flags & SWS_FULL_CHR_H_INT) && (isRGB16fmt(dstFormat) || dstMono || isRGB4bits(dstFormat))) {   // "full chroma interpolation ... not yet implemented" (:1325-1358)
         flags &= ~SWS_FULL_CHR_H_INT; o->flags = flags;
     }
@@ -544,6 +540,31 @@ int init_single_context(SwsInternal *c)
     }
     if (ret != FILTER_OK) return SWS_AVERROR(EINVAL);
 
+    if (dstMono && o->dither == SWS_DITHER_ED && !c->mono_y16) {
+        // yuv2mono_{X,2,1}_c_template with SWS_DITHER_ED (output.c:690-700, :734-753, :792-811): the same recurrence over one channel.  The inner
+        // context is this context with the mono writer switched to storing the vertically scaled luma values (16-bit words, the phantom pixel
+        // of an odd width included) instead of bits; sws_k_ed_mono diffuses and packs them.
+        SwsInternal *in = new_context();
+        if (!in) return SWS_AVERROR(ENOMEM);
+        in->opts = *o;
+        in->opts.flags = flags;
+        in->srcBE = c->srcBE; in->src0Alpha = c->src0Alpha; in->srcXYZ = c->srcXYZ;
+        in->force_scaler = true; in->mono_y16 = true;
+        in->tune = c->tune;
+        in->legacy_init = true;
+        for (int k = 0; k < 4; k++) { in->srcVec[k] = c->srcVec[k]; in->dstVecLen[k] = c->dstVecLen[k]; }
+        sws_setColorspaceDetails(&in->opts, c->srcColorspaceTable, o->src_range, c->dstColorspaceTable, o->dst_range,
+                                 c->brightness, c->contrast, c->saturation);
+        const int r = init_single_context(in);
+        if (r < 0 || in->plan != PLAN_MAIN) { destroy(in); return r < 0 ? r : SWS_AVERROR(EINVAL); }
+        mark_tables_dirty(in);
+        c->cascade[0] = in;
+        c->cascade_ed = true;
+        c->cascade_fmt = AV_PIX_FMT_GRAY16LE; c->cascade_w = ((dstW + 1) & ~1) + 2; c->cascade_h = dstH;   // luma words + the row's writer form
+        c->plan = PLAN_CASCADE;
+        log_msg(c, 2, "error-diffusion dither: %s through a luma picture and a diffusion pass\n", dd->name);
+        return 0;
+    }
     if (isRGB8class(dstFormat) && o->dither == SWS_DITHER_ED) {
         // Error diffusion (yuv2rgb_write_full, output.c:2084-2108): every pixel depends on its left neighbour and on the row above, and the
         // error line (c->dither_error, utils.c:1744-1747) lives as long as the context.  The sums that enter the diffusion are R >> 22,

@@ -207,6 +207,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     }
     if (p.srcKind == SRCK_MONO) p.s16_is565 = o.src_format == AV_PIX_FMT_MONOWHITE;   // (reused: bits are stored inverted)
     p.dst_mono_white = o.dst_format == AV_PIX_FMT_MONOWHITE;
+    p.mono_y16 = c->mono_y16 ? 1 : 0;
     if (p.srcKind == SRCK_RGB30) p.s16_is565 = o.src_format == AV_PIX_FMT_X2RGB10LE;   // (reused as the field-order flag of the 30 bpp reader)
     if (p.srcKind == SRCK_RGB16) {   // RGB16_32FUNCS rows of input.c:396-401
         switch (o.src_format) {
@@ -1190,6 +1191,31 @@ static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4
         for (int k = 0; k < pix_nb_planes(pix_desc(c->cascade_fmt)); k++) { tmp[k] = (uint8_t *)d->casc_img + offs[k]; tls[k] = ls[k]; }
         r = run_single(c0, cd[0], src, srcStride, sliceY, sliceH, tmp, tls);
         if (r < 0) return r;
+        if (c->cascade_ed && c0->mono_y16) {   // error diffusion of the luma words into a 1 bpp destination (context.cpp; sws_k_ed_mono)
+            const int n = (o.dst_w + 1) & ~1, H = o.dst_h, nbytes = (o.dst_w + 7) >> 3;
+            if (!d->d_ed_err) {
+                HIPCHK(hipMalloc(&d->d_ed_err, sizeof(int) * (size_t)(n + 4)));
+                HIPCHK(hipMemsetAsync(d->d_ed_err, 0, sizeof(int) * (size_t)(n + 4), d->stream));
+            } else if (o.flags & SWS_BITEXACT) {   // swscale.c:1084-1086
+                HIPCHK(hipMemsetAsync(d->d_ed_err, 0, sizeof(int) * (size_t)(n + 4), d->stream));
+            }
+            const int white = o.dst_format == AV_PIX_FMT_MONOWHITE;
+            if (is_device_ptr(dst[0])) {
+                launch_ed_mono(d->stream, tmp[0], tls[0], dst[0], dstStride[0], n, H, (int *)d->d_ed_err, white);
+                HIPCHK(hipGetLastError());
+                return r;
+            }
+            // a host destination: the 2 / 1 forms leave a trailing partial byte alone, so the staging picture starts from the caller's bytes
+            const int ls2 = (nbytes + 255) & ~255;
+            r = grow(c, &d->casc_img2, &d->casc_bytes2, (size_t)ls2 * H);
+            if (r < 0) return r;
+            HIPCHK(hipMemcpy2DAsync(d->casc_img2, (size_t)ls2, dst[0], (size_t)dstStride[0], (size_t)nbytes, (size_t)H, hipMemcpyHostToDevice, d->stream));
+            launch_ed_mono(d->stream, tmp[0], tls[0], (uint8_t *)d->casc_img2, ls2, n, H, (int *)d->d_ed_err, white);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpy2DAsync(dst[0], (size_t)dstStride[0], d->casc_img2, (size_t)ls2, (size_t)nbytes, (size_t)H, hipMemcpyDeviceToHost, d->stream));
+            HIPCHK(hipStreamSynchronize(d->stream));
+            return c0->opts.dst_h;
+        }
         if (c->cascade_ed) {   // error diffusion of the rgb24 picture into the 8 / 4 bpp destination (context.cpp; sws_k_ed_rgb8)
             const int df = o.dst_format, W = o.dst_w, H = o.dst_h;
             const bool rgbo = df == AV_PIX_FMT_RGB8 || df == AV_PIX_FMT_RGB4_BYTE, b8pp = df == AV_PIX_FMT_RGB8 || df == AV_PIX_FMT_BGR8;

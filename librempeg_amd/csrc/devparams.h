@@ -142,6 +142,7 @@ struct SwsDevParams {
     int32_t chrSrcHSub, chrSrcVSub, chrDstHSub, chrDstVSub;
     int32_t srcKind, dstKind;
     int32_t dst_mono_white;   // DSTK_MONO: bytes are stored inverted (monowhite)
+    int32_t mono_y16;         // DSTK_MONO: store the vertically scaled luma values as 16-bit words (input of sws_k_ed_mono) instead of bits
     int32_t srcBpc, dstBpc;
     int32_t src_depth;        // bits per source component
     int32_t src_shift;        // right shift of p010/p012-style sources (input.c:950-1008)

@@ -81,6 +81,7 @@ static inline bool frames_desc_ok(const SwsFramePtrs *fr, int n, int srcH, int d
 int  launch_misc(const LaunchCtx &L);                                   // every PLAN_UNSC_* plan not named below
 void launch_fill_alpha(const LaunchCtx &L, int w, int y0, int rows, int bits);
 void launch_update_palette(const LaunchCtx &L);
+void launch_ed_mono(hipStream_t st, const uint8_t *lum, int64_t lumStride, uint8_t *dst, int64_t dstStride, int n, int h, int *errline, int white);
 void launch_alpha_merge(const LaunchCtx &L, int npix, int y0, int rows, int a_pos);
 void launch_bswap(hipStream_t st, const uint8_t *src, int64_t sstride, uint8_t *dst, int64_t dstride, int rows, int row_bytes, int unit);
 void launch_gamma_rgba64(hipStream_t st, uint8_t *img, int64_t stride, int w, int rows, const uint16_t *table);

@@ -363,6 +363,10 @@ void launch_gamma_rgba64(hipStream_t st, uint8_t *img, int64_t stride, int w, in
     const dim3 grid(cdiv(w, 256), rows);
     hipLaunchKernelGGL(swsk::sws_k_gamma_rgba64, grid, dim3(256), 0, st, img, stride, w, rows, table);
 }
+void launch_ed_mono(hipStream_t st, const uint8_t *lum, int64_t lumStride, uint8_t *dst, int64_t dstStride, int n, int h, int *errline, int white)
+{
+    hipLaunchKernelGGL(swsk::sws_k_ed_mono, dim3(1), dim3(1024), 0, st, lum, lumStride, dst, dstStride, n, h, errline, white);
+}
 void launch_update_palette(const LaunchCtx &L)
 {
     hipLaunchKernelGGL(swsk::sws_k_update_palette, dim3(L.n), dim3(256), 0, L.st, L.fs, *L.p, L.c->opts.src_format, L.c->opts.dst_format);

@@ -583,13 +583,14 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
         // the X form shifts every pixel through one running accumulator: a trailing partial byte holds the LAST 8 bits seen, counted
         // over the even-rounded width; the 2 / 1 forms build whole bytes, entries past dstW being the line buffers' fill value
         const int n = (p.dstW + 1) & ~1;
-        const bool tail = mode == 0 && 8 * i + 8 > n;
+        const bool tail = mode == 0 && 8 * i + 8 > n && !p.mono_y16;
         const int x0 = tail ? n - 8 : 8 * i;
         unsigned acc = 0;
         for (int k = 0; k < 8; k++) {
             const int x = x0 + k;
             int Y;
             if (x < 0) { acc <<= 1; continue; }
+            if (p.mono_y16 && x >= n) break;
             if (mode == 0) {
                 Y = 1 << 18;
                 for (int j = 0; j < lfs; j++) Y += (int)((unsigned)LUM(j, x) * (unsigned)(int)lf[j]);
@@ -597,9 +598,11 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
                 if (Y & 0x100) Y = clip_u8(Y);   // (the pair test "(Y1 | Y2) & 0x100" clips both: clipping an in-range value is the identity)
             } else if (mode == 2) Y = (LUM(0, x) * (4096 - ya) + LUM(1, x) * ya) >> 19;
             else Y = (LUM(0, x) + 64) >> 7;
+            if (p.mono_y16) { ((int16_t *)drow)[x] = (int16_t)Y; continue; }   // error diffusion: sws_k_ed_mono takes it from here
             const int dth = (int)(((x & 4) ? dhi : dlo) >> (8 * (x & 3))) & 0xff;
             acc = (acc << 1) | (unsigned)(Y + dth >= 234);
         }
+        if (p.mono_y16) { if (i == 0) ((int16_t *)drow)[n] = (int16_t)mode; return; }   // (the diffusion pass stores a trailing partial byte for the X form only)
         drow[i] = (uint8_t)(p.dst_mono_white ? ~acc : acc);
         return;
     }

@@ -236,4 +236,52 @@ __global__ void __launch_bounds__(1024) sws_k_ed_rgb8(const uint8_t *__restrict_
     }
 }
 
+// Error diffusion of yuv2mono_{X,2,1}_c_template (output.c:690-700, :734-753, :792-811) over the luma words the inner context stored
+// (n = the even-rounded width: the reference's pair loop runs a phantom pixel through the recurrence for an odd width).  The same
+// wavefront as sws_k_ed_rgb8 with one channel: V = Y + ((7 * err + e(-1) + 5 * e(0) + 3 * e(+1) + 8 - 256) >> 4), bit = V >= 128,
+// err = V - 220 * bit.  Bits go MSB-first through one running accumulator per row; a byte is stored after every eighth pixel and -
+// by the X form only - the low eight bits of the accumulator once more at the end of a row that is not a multiple of 8.
+__global__ void __launch_bounds__(1024) sws_k_ed_mono(const uint8_t *__restrict__ lum, int64_t lumStride, uint8_t *__restrict__ dst, int64_t dstStride,
+                                                      int n, int H, int *__restrict__ errline, int white)
+{
+    __shared__ int ring[1024][4];
+    const int r = threadIdx.x;
+    for (int y0 = 0; y0 < H; y0 += 1024) {
+        const int NR = min(1024, H - y0);
+        const int y = y0 + r;
+        const bool live = r < NR, last = r == NR - 1;
+        const int16_t *srow = (const int16_t *)(lum + (int64_t)y * lumStride);
+        uint8_t *drow = dst + (int64_t)y * dstStride;
+        int err = 0;
+        unsigned acc = 0;
+        const int steps = n + 2 * (NR - 1);
+        for (int t = 0; t < steps; t++) {
+            const int i = t - 2 * r;
+            if (live && i >= 0 && i < n) {
+                int em, e0, ep;
+                if (r == 0) { em = errline[i]; e0 = errline[i + 1]; ep = errline[i + 2]; }
+                else {
+                    em = i > 0 ? ring[r - 1][(i - 1) & 3] : 0;
+                    e0 = ring[r - 1][i & 3];
+                    ep = i + 1 < n ? ring[r - 1][(i + 1) & 3] : 0;
+                }
+                const int V = srow[i] + ((7 * err + em + 5 * e0 + 3 * ep + 8 - 256) >> 4);
+                if (last) errline[i] = err;
+                const int bit = V >= 128;
+                acc = 2 * acc + (unsigned)bit;
+                err = V - 220 * bit;
+                ring[r][i & 3] = err;
+                if ((i & 7) == 7) drow[i >> 3] = (uint8_t)(white ? ~acc : acc);
+                if (i == n - 1) {
+                    if (last) errline[n] = err;
+                    if (srow[n] == 0 && (n & 6)) drow[n >> 3] = (uint8_t)(white ? ~acc : acc);   // word n of the row: the form (X = 0, 2, 1) the writer took for it
+                }
+            }
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 } // namespace swsk

@@ -159,6 +159,7 @@ struct SwsInternal {
     int cascade_mainindex = 0;    // the child sws_setColorspaceDetails() is forwarded to (utils.c:909-910): 1 for the alpha-blend cascade
     bool cascade_gamma = false;   // gamma-correct scaling (utils.c:1461-1522): cascade[1] scales RGBA64 between two in-place table passes
     bool cascade_ed = false;      // 8 / 4 bpp destination with error diffusion: cascade[0] writes rgb24 at the destination size, a diffusion pass follows
+    bool mono_y16 = false;        // (inner context of a 1 bpp error-diffusion context) the mono writer stores luma words instead of bits
     bool force_scaler = false;    // (inner context of the above) never take an unscaled special converter
     int cascade_fmt = -1, cascade_w = 0, cascade_h = 0;
     std::string path_name, kernel_name;

@@ -1324,7 +1324,6 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
         if ((flags & OR_SWS_FULL_CHR_H_INT) && c->o.dither == 2) c->o.dither = 3;
     }
     if (isPlanarRGB(dstFormat) && !(flags & OR_SWS_FULL_CHR_H_INT)) { flags |= OR_SWS_FULL_CHR_H_INT; c->o.flags = flags; }
-    if (isMono(dstFormat) && c->o.dither == 3) return -1;   /* SWS_DITHER_ED for 1 bpp (yuv2mono_*_c_template's error diffusion): not restated */
     if ((flags & OR_SWS_FULL_CHR_H_INT) && (isRGB16(dstFormat) || isMono(dstFormat) || isRGB4bits(dstFormat))) { /* "full chroma interpolation ... not yet implemented" (:1325-1358) */
         flags &= ~OR_SWS_FULL_CHR_H_INT; c->o.flags = flags;
     }
@@ -1413,7 +1412,7 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
     }
     /* alpha: src alpha dropped -> reference cascades through alpha blend only if alpha_blend != NONE (default NONE) */
     c->needAlpha = isALPHA(srcFormat) && isALPHA(dstFormat);
-    if (isRGB8class(dstFormat))   /* utils.c:1744-1747 (allocated for every context there; only these writers use them) */
+    if (isRGB8class(dstFormat) || isMono(dstFormat))   /* utils.c:1744-1747 (allocated for every context there; only these writers use them) */
         for (i = 0; i < 3; i++) if (!c->dither_error[i]) c->dither_error[i] = calloc((size_t)dstW + 3, sizeof(int));
 
     const int usesHFilter = (c->o.src_vec[0] && c->o.src_vec_len[0] > 1) || (c->o.src_vec[2] && c->o.src_vec_len[2] > 1) ||
@@ -3645,7 +3644,7 @@ static const uint8_t dither_8x8_220[9][8] = {
 /* packed_vscale + yuv2mono_{X,2,1}_c_template (output.c:654-860), ordered dither only.  The X form shifts bits through one running
  * accumulator (a trailing partial byte holds the last 8 bits seen); the 2 and 1 forms build whole bytes from 8 luma entries, the ones
  * past dstW being the line buffers' fill_ones() value (slice.c:190-208) */
-static void write_mono_line(const OrSws *c, const Planes *P, uint8_t *dest, int y)
+static void write_mono_line(OrSws *c, const Planes *P, uint8_t *dest, int y)
 {
     const int dstW = c->o.dst_w, lw = dstW, srcH = c->o.src_h;
     const int chrY = y >> c->chrDstVSub;
@@ -3662,7 +3661,34 @@ static void write_mono_line(const OrSws *c, const Planes *P, uint8_t *dest, int 
     else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
              (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 2; ya = (uint16_t)lf[1]; }
     else mode = 0;
-    if (mode == 0) {
+    if (c->o.dither == 3) {   /* SWS_DITHER_ED (output.c:690-700, :734-753, :792-811): Floyd-Steinberg over the pixel pairs with threshold 128 and step 220;
+                               * c->dither_error[0][k] holds the error of pixel k - 1 of the row above.  The 2 / 1 forms never store a trailing partial byte */
+        unsigned acc = 0;
+        int err = 0;
+        int *de = c->dither_error[0];
+        for (i = 0; i < dstW; i += 2) {
+            int Y1, Y2;
+            if (mode == 0) {
+                Y1 = Y2 = 1 << 18;
+                for (j = 0; j < lfs; j++) { Y1 += (int)(L(j)[i] * (unsigned)lf[j]); Y2 += (int)(LBM(j, i + 1) * (unsigned)lf[j]); }
+                Y1 >>= 19; Y2 >>= 19;
+                if ((Y1 | Y2) & 0x100) { Y1 = clip_u8(Y1); Y2 = clip_u8(Y2); }
+            } else if (mode == 2) {
+                Y1 = (LBM(0, i) * (4096 - ya) + LBM(1, i) * ya) >> 19; Y2 = (LBM(0, i + 1) * (4096 - ya) + LBM(1, i + 1) * ya) >> 19;
+            } else { Y1 = (LBM(0, i) + 64) >> 7; Y2 = (LBM(0, i + 1) + 64) >> 7; }
+            Y1 += (7 * err + 1 * de[i] + 5 * de[i + 1] + 3 * de[i + 2] + 8 - 256) >> 4;
+            de[i] = err;
+            acc = 2 * acc + (Y1 >= 128);
+            Y1 -= 220 * (int)(acc & 1);
+            err = Y2 + ((7 * Y1 + 1 * de[i + 1] + 5 * de[i + 2] + 3 * de[i + 3] + 8 - 256) >> 4);
+            de[i + 1] = Y1;
+            acc = 2 * acc + (err >= 128);
+            err -= 220 * (int)(acc & 1);
+            if ((i & 7) == 6) *dest++ = (uint8_t)(white ? ~acc : acc);
+        }
+        de[i] = err;
+        if (mode == 0 && (i & 6)) *dest = (uint8_t)(white ? ~acc : acc);
+    } else if (mode == 0) {
         unsigned acc = 0;
         for (i = 0; i < dstW; i += 2) {
             int Y1 = 1 << 18, Y2 = 1 << 18;
