@@ -34,6 +34,13 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
+// the frame descriptor by value (a reference that may point at the by-value argument would force that argument into scratch memory)
+__device__ __forceinline__ SwsFramePtrs frame_copy(const SwsFrameSet &fs, int idx)
+{
+    SwsFramePtrs f;
+    if (fs.table) f = fs.table[idx]; else f = fs.one;
+    return f;
+}
 __device__ __forceinline__ FrameRegs load_frame(const SwsFrameSet &fs, int idx)
 {
     const SwsFramePtrs &f = frame_of(fs, idx);
@@ -46,6 +53,35 @@ __device__ __forceinline__ FrameRegs load_frame(const SwsFrameSet &fs, int idx)
         r.dstStride[k] = __builtin_amdgcn_readfirstlane(f.dstStride[k]);
     }
     return r;
+}
+
+// Run-time selection among fields of the by-value argument structs.  A run-time index (p.arr[comp]), and also a plain select between two
+// fields ("c ? p.a : p.b", or a chain of them), is turned by LLVM into a load through a computed ADDRESS, which forces the whole struct
+// (SwsDevParams is about 800 bytes) into scratch memory for every lane: the generic kernels ran at 2.7 Gpix/s because of it.  Every value
+// that takes part in such a selection therefore goes through U(): readfirstlane of a wave-uniform value is free, and a select over
+// intrinsic results stays a select over values.
+__device__ __forceinline__ int U(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t U(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+template <typename T> __device__ __forceinline__ const T *U(const T *q) { return (const T *)uniform_u64((uint64_t)q); }
+template <typename T> __device__ __forceinline__ T *U(T *q) { return (T *)uniform_u64((uint64_t)q); }
+__device__ __forceinline__ int64_t U(int64_t v) { return (int64_t)uniform_u64((uint64_t)v); }
+template <typename T> __device__ __forceinline__ T pick4(const T (&a)[4], int i)
+{
+    const T a0 = U(a[0]), a1 = U(a[1]), a2 = U(a[2]), a3 = U(a[3]);
+    return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3;
+}
+template <typename T> __device__ __forceinline__ T pick5(const T (&a)[5], int i)
+{
+    const T a0 = U(a[0]), a1 = U(a[1]), a2 = U(a[2]), a3 = U(a[3]), a4 = U(a[4]);
+    return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : i == 3 ? a3 : a4;
+}
+struct Rgb2YuvRow { int32_t r, g, b; };   // one row of the rgb2yuv table: o = 0 (Y), 3 (U), 6 (V)
+__device__ __forceinline__ Rgb2YuvRow rgb2yuv_row(const int32_t (&t)[9], int o)
+{
+    const int t0 = U(t[0]), t1 = U(t[1]), t2 = U(t[2]), t3 = U(t[3]), t4 = U(t[4]), t5 = U(t[5]), t6 = U(t[6]), t7 = U(t[7]), t8 = U(t[8]);
+    Rgb2YuvRow w;
+    w.r = o == 0 ? t0 : o == 3 ? t3 : t6; w.g = o == 0 ? t1 : o == 3 ? t4 : t7; w.b = o == 0 ? t2 : o == 3 ? t5 : t8;
+    return w;
 }
 
 // ---- closed form of the yuv2rgb LUTs (yuv2rgb.c:680-703, :901-961; colorspace.cpp) ----

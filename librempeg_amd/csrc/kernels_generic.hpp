@@ -25,8 +25,8 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
     // at chroma row y >> chrSrcVSub, a chroma line reads G at luma row y << chrSrcVSub (both the same row unless SWS_SRC_V_CHR_DROP is set)
     const int grow = prow, brow = (comp == 1 || comp == 2) ? row : (row >> p.chrSrcVSub);
     if (p.srcKind == SRCK_PACKEDHI) {   // the descriptor's field of component comp
-        const uint8_t *s = f.src[0] + (int64_t)prow * f.srcStride[0] + p.shi_step[comp] * x + p.shi_off[comp];
-        return (*(const uint16_t *)s >> p.shi_shift[comp]) & p.shi_mask[comp];
+        const uint8_t *s = f.src[0] + (int64_t)prow * f.srcStride[0] + pick4(p.shi_step, comp) * x + pick4(p.shi_off, comp);
+        return (*(const uint16_t *)s >> pick4(p.shi_shift, comp)) & pick4(p.shi_mask, comp);
     }
     if (p.srcKind == SRCK_FLOATX) {
         // float / half-float sources: every element becomes lrintf(av_clipf(65535.0f * x, 0.0f, 65535.0f)) first, then the 16-bit RGB
@@ -53,7 +53,8 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         }
         const int32_t *t = p.rgb2yuv;
         const int o = comp == 0 ? 0 : comp == 1 ? 3 : 6;
-        return (uint16_t)((int)((unsigned)t[o] * r + (unsigned)t[o + 1] * g + (unsigned)t[o + 2] * b + ((comp == 0 ? 0x2001u : 0x10001u) << 14)) >> 15);
+        const Rgb2YuvRow tr = rgb2yuv_row(p.rgb2yuv, o);
+        return (uint16_t)((int)((unsigned)tr.r * r + (unsigned)tr.g * g + (unsigned)tr.b * b + ((comp == 0 ? 0x2001u : 0x10001u) << 14)) >> 15);
     }
     if (p.srcKind == SRCK_PAL) {   // palToY_c / palToUV_c / palToA_c (input.c:474-512) on the frame's pal_yuv table (sws_k_update_palette)
         const uint32_t e = ((const uint32_t *)f.src[1])[f.src[0][(int64_t)prow * f.srcStride[0] + x]];
@@ -87,12 +88,12 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
     }
     switch (p.srcKind) {
     case SRCK_PLANAR8: {
-        const int pl = comp == 0 ? 0 : comp == 1 ? p.u_plane_src : p.v_plane_src;
-        return f.src[pl][(int64_t)row * f.srcStride[pl] + x];
+        const int pl = comp == 0 ? 0 : comp == 1 ? U(p.u_plane_src) : U(p.v_plane_src);
+        return pick4(f.src, pl)[(int64_t)row * pick4(f.srcStride, pl) + x];
     }
     case SRCK_PLANAR16: {
-        const int pl = comp == 0 ? 0 : comp == 1 ? p.u_plane_src : p.v_plane_src;
-        return *(const uint16_t *)(f.src[pl] + (int64_t)row * f.srcStride[pl] + 2 * x) >> p.src_shift;   // shf16_NNLEToY/UV_c for the msb formats
+        const int pl = comp == 0 ? 0 : comp == 1 ? U(p.u_plane_src) : U(p.v_plane_src);
+        return *(const uint16_t *)(pick4(f.src, pl) + (int64_t)row * pick4(f.srcStride, pl) + 2 * x) >> p.src_shift;   // shf16_NNLEToY/UV_c for the msb formats
     }
     case SRCK_NV12: // nv12ToUV_c / nv21ToUV_c, input.c:926-948
         if (comp == 0) return f.src[0][(int64_t)row * f.srcStride[0] + x];
@@ -109,13 +110,14 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
             return (uint16_t)((t[0] * r + t[1] * g + t[2] * b + (32 << 14) + (1 << 8)) >> 9); // stored int16, read back as u16 by hscale
         }
         const int o = comp == 1 ? 3 : 6;
+        const Rgb2YuvRow tr = rgb2yuv_row(p.rgb2yuv, o);
         if (p.chr_half) {
             const int r = s[6 * x + p.src_r_pos] + s[6 * x + 3 + p.src_r_pos], g = s[6 * x + 1] + s[6 * x + 4];
             const int b = s[6 * x + p.src_b_pos] + s[6 * x + 3 + p.src_b_pos];
-            return (uint16_t)((t[o] * r + t[o + 1] * g + t[o + 2] * b + (256 << 15) + (1 << 9)) >> 10);
+            return (uint16_t)((tr.r * r + tr.g * g + tr.b * b + (256 << 15) + (1 << 9)) >> 10);
         }
         const int r = s[3 * x + p.src_r_pos], g = s[3 * x + 1], b = s[3 * x + p.src_b_pos];
-        return (uint16_t)((t[o] * r + t[o + 1] * g + t[o + 2] * b + (256 << 14) + (1 << 8)) >> 9);
+        return (uint16_t)((tr.r * r + tr.g * g + tr.b * b + (256 << 14) + (1 << 8)) >> 9);
     }
     case SRCK_RGB32: { // rgb16_32ToY/UV/UV_half_c_template with the 32-bit parameter rows, input.c:264-393
         const int srow = comp == 0 ? row : (row << p.chrSrcVSub);
@@ -128,7 +130,8 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
             return (uint16_t)((unsigned)((t[0] << 8) * r + t[1] * g + (t[2] << 8) * b + rnd) >> (S - 6));
         }
         const int o = comp == 1 ? 3 : 6;
-        const int cr = t[o] * (1 << 8), cg = t[o + 1], cb = t[o + 2] * (1 << 8);
+        const Rgb2YuvRow tr = rgb2yuv_row(p.rgb2yuv, o);
+        const int cr = tr.r * (1 << 8), cg = tr.g, cb = tr.b * (1 << 8);
         if (p.chr_half) {
             const int r = s[8 * x + p.src_r_pos] + s[8 * x + 4 + p.src_r_pos];
             const int g = (s[8 * x + p.src_g_pos] + s[8 * x + 4 + p.src_g_pos]) << 8;
@@ -151,9 +154,10 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         const uint32_t *s = (const uint32_t *)(f.src[0] + (int64_t)srow * f.srcStride[0]);
         const int32_t *t = p.rgb2yuv;
         const int S = 15 + 6, o = comp == 0 ? 0 : comp == 1 ? 3 : 6;
+        const Rgb2YuvRow tr = rgb2yuv_row(p.rgb2yuv, o);
         const int x2rgb = p.s16_is565, shr = x2rgb ? 16 : 0, shb = x2rgb ? 0 : 16;
         const int maskr = x2rgb ? 0x3FF00000 : 0x3FF, maskg = 0xFFC00, maskb = x2rgb ? 0x3FF : 0x3FF00000;
-        const int cr = t[o] * (x2rgb ? 1 : 16), cg = t[o + 1], cb = t[o + 2] * (x2rgb ? 16 : 1);
+        const int cr = tr.r * (x2rgb ? 1 : 16), cg = tr.g, cb = tr.b * (x2rgb ? 16 : 1);
         if (comp != 0 && p.chr_half) {
             const unsigned maskgx = ~(unsigned)(maskr | maskb);
             const unsigned px0 = s[2 * x], px1 = s[2 * x + 1];
@@ -173,7 +177,8 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         const uint16_t *s = (const uint16_t *)(f.src[0] + (int64_t)srow * f.srcStride[0]);
         const int32_t *t = p.rgb2yuv;
         const int S = p.s16_S, o = comp == 0 ? 0 : comp == 1 ? 3 : 6;
-        const int cr = t[o] * (1 << p.s16_rsh), cg = t[o + 1] * (1 << p.s16_gsh), cb = t[o + 2] * (1 << p.s16_bsh);
+        const Rgb2YuvRow tr = rgb2yuv_row(p.rgb2yuv, o);
+        const int cr = tr.r * (1 << p.s16_rsh), cg = tr.g * (1 << p.s16_gsh), cb = tr.b * (1 << p.s16_bsh);
         if (comp != 0 && p.chr_half) {
             const unsigned maskgx = ~(unsigned)(p.s16_maskr | p.s16_maskb);
             const unsigned px0 = s[2 * x], px1 = s[2 * x + 1];
@@ -195,11 +200,12 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         if (comp == 0)
             return (uint16_t)((int)((unsigned)t[0] * R[x] + (unsigned)t[1] * G[x] + (unsigned)t[2] * B[x] + (0x801 << 8)) >> 9);
         const int o = comp == 1 ? 3 : 6;
+        const Rgb2YuvRow tr = rgb2yuv_row(p.rgb2yuv, o);
         if (p.chr_half) {
             const unsigned g = G[2 * x] + G[2 * x + 1], b = B[2 * x] + B[2 * x + 1], r = R[2 * x] + R[2 * x + 1];
-            return (uint16_t)((t[o] * r + t[o + 1] * g + t[o + 2] * b + (0x4001u << 9)) >> 10);
+            return (uint16_t)((tr.r * r + tr.g * g + tr.b * b + (0x4001u << 9)) >> 10);
         }
-        return (uint16_t)((int)((unsigned)t[o] * R[x] + (unsigned)t[o + 1] * G[x] + (unsigned)t[o + 2] * B[x] + (0x4001 << 8)) >> 9);
+        return (uint16_t)((int)((unsigned)tr.r * R[x] + (unsigned)tr.g * G[x] + (unsigned)tr.b * B[x] + (0x4001 << 8)) >> 9);
     }
     case SRCK_RGB48: { // rgb48ToY/UV(_half)_c_template, rgb64ToY/UV(_half)_c_template (input.c:45-203)
         const int srow = comp == 0 ? row : (row << p.chrSrcVSub);
@@ -212,15 +218,16 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
             r = (q[p.s16_r] + q[st + p.s16_r] + 1u) >> 1; g = (q[p.s16_g] + q[st + p.s16_g] + 1u) >> 1; b = (q[p.s16_b] + q[st + p.s16_b] + 1u) >> 1;
         } else { const uint16_t *q = s + st * x; r = q[p.s16_r]; g = q[p.s16_g]; b = q[p.s16_b]; }
         const int o = comp == 0 ? 0 : comp == 1 ? 3 : 6;
-        return (uint16_t)(((unsigned)t[o] * r + (unsigned)t[o + 1] * g + (unsigned)t[o + 2] * b + ((comp == 0 ? 0x2001u : 0x10001u) << 14)) >> 15);
+        const Rgb2YuvRow tr = rgb2yuv_row(p.rgb2yuv, o);
+        return (uint16_t)(((unsigned)tr.r * r + (unsigned)tr.g * g + (unsigned)tr.b * b + ((comp == 0 ? 0x2001u : 0x10001u) << 14)) >> 15);
     }
     case SRCK_PACKED444: {
         const uint8_t *s = f.src[0] + (int64_t)prow * f.srcStride[0] + p.s444_step * x;
-        return s[comp == 0 ? p.s444_y : comp == 1 ? p.s444_u : p.s444_v];
+        return s[comp == 0 ? U(p.s444_y) : comp == 1 ? U(p.s444_u) : U(p.s444_v)];
     }
     case SRCK_PACKED422: { // yuy2ToY_c / yuy2ToUV_c / yvy2ToUV_c (input.c:550-578), uyvyToY_c / uyvyToUV_c (:890-907)
         const uint8_t *s = f.src[0] + (int64_t)prow * f.srcStride[0];
-        return comp == 0 ? s[2 * x + p.s422_y] : s[4 * x + (comp == 1 ? p.s422_u : p.s422_v)];
+        return comp == 0 ? s[2 * x + p.s422_y] : s[4 * x + (comp == 1 ? U(p.s422_u) : U(p.s422_v))];
     }
     case SRCK_GBRP16: { // planar_rgb16_s16_to_y / _to_uv, input.c:1216-1270
         // (gbrp10msb / gbrp12msb: planar_rgb16_s10 / s12 shift the samples down first, input.c:1462-1474)
@@ -230,8 +237,9 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         const int32_t *t = p.rgb2yuv;
         const int bpc = p.src_depth, shift = bpc < 16 ? bpc : 14;
         const int o = comp == 0 ? 0 : comp == 1 ? 3 : 6;
+        const Rgb2YuvRow tr = rgb2yuv_row(p.rgb2yuv, o);
         const unsigned bias = ((comp == 0 ? 16u : 128u) << (15 + bpc - 8)) + (1u << shift);
-        return (uint16_t)((int)((unsigned)t[o] * r + (unsigned)t[o + 1] * g + (unsigned)t[o + 2] * b + bias) >> (shift + 1));
+        return (uint16_t)((int)((unsigned)tr.r * r + (unsigned)tr.g * g + (unsigned)tr.b * b + bias) >> (shift + 1));
     }
     case SRCK_GBRPF32: { // planar_rgbf32_to_y / _to_uv, input.c:1300-1334
         const int g = f32_to_u16(*(const float *)(f.src[0] + (int64_t)grow * f.srcStride[0] + 4 * x));
@@ -241,7 +249,8 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         if (comp == 0)
             return (uint16_t)((int)((unsigned)t[0] * r + (unsigned)t[1] * g + (unsigned)t[2] * b + (0x2001u << 14)) >> 15);
         const int o = comp == 1 ? 3 : 6;
-        return (uint16_t)((int)((unsigned)t[o] * r + (unsigned)t[o + 1] * g + (unsigned)t[o + 2] * b + (0x10001u << 14)) >> 15);
+        const Rgb2YuvRow tr = rgb2yuv_row(p.rgb2yuv, o);
+        return (uint16_t)((int)((unsigned)tr.r * r + (unsigned)tr.g * g + (unsigned)tr.b * b + (0x10001u << 14)) >> 15);
     }
     }
     return 0;
@@ -252,14 +261,14 @@ __device__ __forceinline__ int range_sample(const SwsDevParams &p, int v, int ch
 {
     if (!p.range_active) return v;
     if (!p.wide) {
-        const uint16_t coeff = (uint16_t)(chroma ? p.chrCoeff : p.lumCoeff);
-        const int32_t offset = (int32_t)(chroma ? p.chrOffset : p.lumOffset);
+        const uint16_t coeff = (uint16_t)(chroma ? U(p.chrCoeff) : U(p.lumCoeff));
+        const int32_t offset = (int32_t)(chroma ? U(p.chrOffset) : U(p.lumOffset));
         int r = (v * coeff + offset) >> 14;
         if (p.range_to_jpeg) r = min(r, (1 << 15) - 1);
         return (int16_t)r;
     }
-    const uint32_t coeff = chroma ? p.chrCoeff : p.lumCoeff;
-    const int64_t offset = chroma ? p.chrOffset : p.lumOffset;
+    const uint32_t coeff = chroma ? U(p.chrCoeff) : U(p.lumCoeff);
+    const int64_t offset = chroma ? U(p.chrOffset) : U(p.lumOffset);
     int r = (int)(((int64_t)v * coeff + offset) >> 18);
     if (p.range_to_jpeg) r = min(r, (1 << 19) - 1);
     return r;
@@ -271,8 +280,8 @@ __device__ __forceinline__ int hscale_sample(const SwsDevParams &p, const SwsFra
     if (p.no_chroma && comp != 0 && comp != 3) return p.wide ? 1 << 18 : 1 << 14;   // ff_init_desc_no_chr: fill_ones() value, never range converted
     const bool lumlike = comp == 0 || comp == 3;   // the alpha plane goes through the luma functions (hscale.c:39-131)
     if (p.fast_bilinear) {   // ff_hyscale_fast_c / ff_hcscale_fast_c, hscale_fast_bilinear.c:23-55
-        const int sW = lumlike ? p.srcW : p.chrSrcW;
-        const uint32_t xpos = (uint32_t)x * (uint32_t)(lumlike ? p.lumXInc : p.chrXInc);
+        const int sW = lumlike ? U(p.srcW) : U(p.chrSrcW);
+        const uint32_t xpos = (uint32_t)x * (uint32_t)(lumlike ? U(p.lumXInc) : U(p.chrXInc));
         const int xx = (int)(xpos >> 16), xalpha = (int)((xpos & 0xFFFF) >> 9);
         int r;
         if (xx >= sW - 1) r = read_sample(p, f, comp, row, sW - 1) * 128;        // the tail loop of the reference
@@ -282,9 +291,9 @@ __device__ __forceinline__ int hscale_sample(const SwsDevParams &p, const SwsFra
         }
         return comp == 3 ? (int16_t)r : range_sample(p, (int16_t)r, comp != 0);
     }
-    const int16_t *filter = lumlike ? p.hLumF : p.hChrF;
-    const int32_t *pos = lumlike ? p.hLumPos : p.hChrPos;
-    const int fs = lumlike ? p.hLumFs : p.hChrFs;
+    const int16_t *filter = lumlike ? U(p.hLumF) : U(p.hChrF);
+    const int32_t *pos = lumlike ? U(p.hLumPos) : U(p.hChrPos);
+    const int fs = lumlike ? U(p.hLumFs) : U(p.hChrFs);
     const int sp = pos[x];
     int val = 0;
     for (int j = 0; j < fs; j++) val += read_sample(p, f, comp, row, sp + j) * filter[fs * x + j];
@@ -322,10 +331,10 @@ __global__ void __launch_bounds__(256) sws_k_hscale(SwsFrameSet fs, SwsDevParams
 {
     const int ncomp = p.need_alpha ? 4 : 3;
     const int comp = blockIdx.z % ncomp, fi = blockIdx.z / ncomp;
-    const int W = (comp == 0 || comp == 3) ? p.dstW : p.chrDstW, H = (comp == 0 || comp == 3) ? p.srcH : p.chrSrcH;
+    const int W = (comp == 0 || comp == 3) ? U(p.dstW) : U(p.chrDstW), H = (comp == 0 || comp == 3) ? U(p.srcH) : U(p.chrSrcH);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
     if (x >= W || row >= H) return;
-    const SwsFramePtrs &f = frame_of(fs, fi);
+    const SwsFramePtrs f = frame_copy(fs, fi);
     T *base = scratch + fi * frame_elems;
     const int64_t lumElems = (int64_t)p.srcH * p.dstW, chrElems = (int64_t)p.chrSrcH * p.chrDstW;
     T *plane = comp == 0 ? base : comp == 1 ? base + lumElems : comp == 2 ? base + lumElems + chrElems : base + lumElems + 2 * chrElems;
@@ -340,11 +349,13 @@ __global__ void __launch_bounds__(256) sws_k_hscale(SwsFrameSet fs, SwsDevParams
 template <typename S>
 __device__ __forceinline__ void planar_write_one(const SwsDevParams &p, const S &smp, const SwsFramePtrs &f, int comp, int x, int y)
 {
-    const int16_t *vf; int fs, first, srcRows, plane;
-    if (comp == 0 || comp == 3) { fs = p.vLumFs; vf = p.vLumF + y * fs; first = max(1 - fs, p.vLumPos[y]); srcRows = p.srcH; plane = comp; }  // alpha: vscale.c:59-71
-    else { fs = p.vChrFs; vf = p.vChrF + y * fs; first = max(1 - fs, p.vChrPos[y]); srcRows = p.chrSrcH;
-           plane = comp == 1 ? p.u_plane_dst : p.v_plane_dst; }
-    uint8_t *drow = f.dst[plane] + (int64_t)y * f.dstStride[plane];
+    const bool lumlike = comp == 0 || comp == 3;   // alpha: vscale.c:59-71
+    const int fs = lumlike ? U(p.vLumFs) : U(p.vChrFs);
+    const int16_t *vf = (lumlike ? U(p.vLumF) : U(p.vChrF)) + y * fs;
+    const int first = max(1 - fs, (lumlike ? U(p.vLumPos) : U(p.vChrPos))[y]);
+    const int srcRows = lumlike ? U(p.srcH) : U(p.chrSrcH);
+    const int plane = lumlike ? comp : comp == 1 ? U(p.u_plane_dst) : U(p.v_plane_dst);
+    uint8_t *drow = pick4(f.dst, plane) + (int64_t)y * pick4(f.dstStride, plane);
     const int bits = p.dst_bits;
     if (p.dstKind == DSTK_P010) { // luma of P010: yuv2p01xl1_c / yuv2p01xlX_c
         uint16_t *d = (uint16_t *)drow;
@@ -675,7 +686,7 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
                 for (int j = 0; j < fs; j++) acc += (int)((unsigned)(k == 1 ? CHU(j, x) : k == 2 ? CHV(j, x) : LUM(j, x)) * (unsigned)(int)fl[j]);
                 v = clip_uintp2(acc >> shift, bits);
             }
-            px |= (uint64_t)(uint32_t)v << p.dhi_bitpos[k];
+            px |= (uint64_t)(uint32_t)v << pick5(p.dhi_bitpos, k);
         }
         if (p.dhi_alpha) {
             int v = 65535;
@@ -919,10 +930,10 @@ template <bool DIRECT, typename T>
 __global__ void __launch_bounds__(256) sws_k_vscale_planar(SwsFrameSet fs, SwsDevParams p, const T *scratch, int64_t frame_elems, int ncomp)
 {
     const int comp = blockIdx.z % ncomp, fi = blockIdx.z / ncomp;
-    const int W = (comp == 0 || comp == 3) ? p.dstW : p.chrDstW, H = (comp == 0 || comp == 3) ? p.dstH : p.chrDstH;
+    const int W = (comp == 0 || comp == 3) ? U(p.dstW) : U(p.chrDstW), H = (comp == 0 || comp == 3) ? U(p.dstH) : U(p.chrDstH);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W || y >= H) return;
-    const SwsFramePtrs &f = frame_of(fs, fi);
+    const SwsFramePtrs f = frame_copy(fs, fi);
     const auto smp = SamplerFor<DIRECT, T>::make(p, f, scratch, frame_elems, fi);
     planar_write_one(p, smp, f, comp, x, y);
 }
@@ -934,7 +945,7 @@ __global__ void __launch_bounds__(256) sws_k_vscale_nvchroma(SwsFrameSet fs, Sws
     const int fi = blockIdx.z;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, cy = blockIdx.y;
     if (x >= p.chrDstW || cy >= p.chrDstH) return;
-    const SwsFramePtrs &f = frame_of(fs, fi);
+    const SwsFramePtrs f = frame_copy(fs, fi);
     const auto smp = SamplerFor<DIRECT, T>::make(p, f, scratch, frame_elems, fi);
     nv_chroma_write_one(p, smp, f, x, cy);
 }
@@ -947,7 +958,7 @@ __global__ void __launch_bounds__(256) sws_k_vscale_rgb(SwsFrameSet fs, SwsDevPa
     const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     const int units = p.dstKind == DSTK_MONO ? (p.dstW + 7) >> 3 : (p.full_chr || p.dstKind == DSTK_YA) ? p.dstW : (p.dstW + 1) >> 1;
     if (i >= units || y >= p.dstH) return;
-    const SwsFramePtrs &f = frame_of(fs, fi);
+    const SwsFramePtrs f = frame_copy(fs, fi);
     const auto smp = SamplerFor<DIRECT, T>::make(p, f, scratch, frame_elems, fi);
     rgb_write_unit(p, smp, f, i, y);
 }

@@ -202,18 +202,55 @@ __global__ void __launch_bounds__(1024) sws_k_ed_rgb8(const uint8_t *__restrict_
         const bool live = r < NR, last = r == NR - 1;
         const uint8_t *srow = rgb + (int64_t)y * rgbStride;
         uint8_t *drow = dst + (int64_t)y * dstStride;
+        const bool dw_ok = (((uintptr_t)drow) & 3) == 0;      // four output bytes go out as one dword where the row allows it
         int err[3] = { 0, 0, 0 };
         const int steps = W + 2 * (NR - 1);
+        // Nothing that comes from HBM is on the recurrence.  The input pixels (three dwords per four pixels) and, for the first row of the
+        // group, the error line above it (six ints per channel and four pixels) are fetched one four-pixel group ahead of their use; the
+        // per-step barrier waits for LDS only (s_waitcnt lgkmcnt(0); s_barrier), so those loads and the byte / error-line stores stay in
+        // flight across steps.  (A dword of the input is read only where it lies inside the row's linesize.)
+        uint32_t cur[3] = { 0, 0, 0 }, nxt[3] = { 0, 0, 0 };
+        int elc[3][6], eln[3][6];
+        auto fetch = [&](int g, uint32_t (&q)[3]) {   // pixels 4g .. 4g + 3
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const int64_t off = 12 * (int64_t)g + 4 * k; q[k] = (live && off + 4 <= rgbStride) ? *(const uint32_t *)(srow + off) : 0u; }
+        };
+        auto fetch_el = [&](int g, int (&q)[3][6]) {  // el[c][4g .. 4g + 5]: the errors of pixels 4g - 1 .. 4g + 4 of the line above
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int k = 0; k < 6; k++) { const int idx = 4 * g + k; q[c][k] = (r == 0 && idx < W + 3) ? el[c][idx] : 0; }
+        };
+        fetch(0, nxt);
+        fetch_el(0, eln);
+        uint32_t outw = 0;
         for (int t = 0; t < steps; t++) {
             const int i = t - 2 * r;
             if (live && i >= 0 && i < W) {
-                int v[3] = { srow[3 * i], srow[3 * i + 1], srow[3 * i + 2] };
+                if (!(i & 3)) {
+                    cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2]; fetch((i >> 2) + 1, nxt);
+                    if (r == 0) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++)
+#pragma unroll
+                            for (int k = 0; k < 6; k++) elc[c][k] = eln[c][k];
+                        fetch_el((i >> 2) + 1, eln);
+                    }
+                }
+                const int b0 = 3 * (i & 3);   // byte position of the pixel inside the 12-byte group
+                int v[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) { const int b = b0 + c; v[c] = (int)((cur[b >> 2] >> (8 * (b & 3))) & 0xff); }
                 int out[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     int em, e0, ep;
-                    if (r == 0) { em = el[c][i]; e0 = el[c][i + 1]; ep = el[c][i + 2]; }
-                    else {
+                    if (r == 0) {
+                        const int k = i & 3;
+                        em = k == 0 ? elc[c][0] : k == 1 ? elc[c][1] : k == 2 ? elc[c][2] : elc[c][3];
+                        e0 = k == 0 ? elc[c][1] : k == 1 ? elc[c][2] : k == 2 ? elc[c][3] : elc[c][4];
+                        ep = k == 0 ? elc[c][2] : k == 1 ? elc[c][3] : k == 2 ? elc[c][4] : elc[c][5];
+                    } else {
                         em = i > 0 ? ring[c][r - 1][(i - 1) & 3] : 0;
                         e0 = ring[c][r - 1][i & 3];
                         ep = i + 1 < W ? ring[c][r - 1][(i + 1) & 3] : 0;
@@ -227,9 +264,14 @@ __global__ void __launch_bounds__(1024) sws_k_ed_rgb8(const uint8_t *__restrict_
                     ring[c][r][i & 3] = err[c];
                     if (last && i == W - 1) el[c][W] = err[c];         // the row's closing store (output.c:2204-2206)
                 }
-                drow[i] = (uint8_t)((out[0] << r8) + (out[1] << g8) + (out[2] << b8));
+                const uint32_t px = (uint32_t)((out[0] << r8) + (out[1] << g8) + (out[2] << b8)) & 0xffu;
+                if (dw_ok) {
+                    outw = (i & 3) ? (outw | (px << (8 * (i & 3)))) : px;
+                    if ((i & 3) == 3) *(uint32_t *)(drow + (i & ~3)) = outw;
+                    else if (i == W - 1) { for (int k = 0; k <= (i & 3); k++) drow[(i & ~3) + k] = (uint8_t)(outw >> (8 * k)); }
+                } else drow[i] = (uint8_t)px;
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         __threadfence_block();
         __syncthreads();
@@ -255,17 +297,42 @@ __global__ void __launch_bounds__(1024) sws_k_ed_mono(const uint8_t *__restrict_
         int err = 0;
         unsigned acc = 0;
         const int steps = n + 2 * (NR - 1);
+        uint32_t cur[2] = { 0, 0 }, nxt[2] = { 0, 0 };   // four luma words per group, fetched one group ahead (see sws_k_ed_rgb8)
+        auto fetch = [&](int g, uint32_t (&q)[2]) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) { const int64_t off = 8 * (int64_t)g + 4 * k; q[k] = (live && off + 4 <= lumStride) ? *(const uint32_t *)((const uint8_t *)srow + off) : 0u; }
+        };
+        int elc[6], eln[6];                               // the error line above the group's first row, fetched the same way
+        auto fetch_el = [&](int g, int (&q)[6]) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) { const int idx = 4 * g + k; q[k] = (r == 0 && idx < n + 3) ? errline[idx] : 0; }
+        };
+        fetch(0, nxt);
+        fetch_el(0, eln);
         for (int t = 0; t < steps; t++) {
             const int i = t - 2 * r;
             if (live && i >= 0 && i < n) {
+                if (!(i & 3)) {
+                    cur[0] = nxt[0]; cur[1] = nxt[1]; fetch((i >> 2) + 1, nxt);
+                    if (r == 0) {
+#pragma unroll
+                        for (int k = 0; k < 6; k++) elc[k] = eln[k];
+                        fetch_el((i >> 2) + 1, eln);
+                    }
+                }
+                const int Yi = (int)(int16_t)(cur[(i & 3) >> 1] >> (16 * (i & 1)));
                 int em, e0, ep;
-                if (r == 0) { em = errline[i]; e0 = errline[i + 1]; ep = errline[i + 2]; }
-                else {
+                if (r == 0) {
+                    const int k = i & 3;
+                    em = k == 0 ? elc[0] : k == 1 ? elc[1] : k == 2 ? elc[2] : elc[3];
+                    e0 = k == 0 ? elc[1] : k == 1 ? elc[2] : k == 2 ? elc[3] : elc[4];
+                    ep = k == 0 ? elc[2] : k == 1 ? elc[3] : k == 2 ? elc[4] : elc[5];
+                } else {
                     em = i > 0 ? ring[r - 1][(i - 1) & 3] : 0;
                     e0 = ring[r - 1][i & 3];
                     ep = i + 1 < n ? ring[r - 1][(i + 1) & 3] : 0;
                 }
-                const int V = srow[i] + ((7 * err + em + 5 * e0 + 3 * ep + 8 - 256) >> 4);
+                const int V = Yi + ((7 * err + em + 5 * e0 + 3 * ep + 8 - 256) >> 4);
                 if (last) errline[i] = err;
                 const int bit = V >= 128;
                 acc = 2 * acc + (unsigned)bit;
@@ -277,7 +344,7 @@ __global__ void __launch_bounds__(1024) sws_k_ed_mono(const uint8_t *__restrict_
                     if (srow[n] == 0 && (n & 6)) drow[n >> 3] = (uint8_t)(white ? ~acc : acc);   // word n of the row: the form (X = 0, 2, 1) the writer took for it
                 }
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: the HBM traffic stays in flight (see sws_k_ed_rgb8)
         }
         __threadfence_block();
         __syncthreads();

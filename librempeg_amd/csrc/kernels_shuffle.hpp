@@ -214,9 +214,9 @@ __global__ void __launch_bounds__(256) sws_k_alphablend(SwsFrameSet fs, AlphaBle
     if (ap.planar) {
         const int xs = plane ? ap.lw : 0, ys = plane ? ap.lh : 0, pc = ap.plane_count;
         const bool subsample_row = ys && (y << ys) + 1 < ap.lum_h;
-        const uint8_t *sp = f.src[plane] + (int64_t)f.srcStride[plane] * y;
-        uint8_t *dp = f.dst[plane] + (int64_t)f.dstStride[plane] * y;
-        const uint8_t *ap0 = f.src[pc] + (int64_t)f.srcStride[pc] * (y << ys), *ap1 = ap0 + f.srcStride[pc];
+        const uint8_t *sp = pick4(f.src, plane) + (int64_t)pick4(f.srcStride, plane) * y;
+        uint8_t *dp = pick4(f.dst, plane) + (int64_t)pick4(f.dstStride, plane) * y;
+        const uint8_t *ap0 = pick4(f.src, pc) + (int64_t)pick4(f.srcStride, pc) * (y << ys), *ap1 = ap0 + pick4(f.srcStride, pc);
         const unsigned t = (unsigned)ap.target[((x ^ y) >> 5) & 1][plane];
         unsigned alpha;
         if (xs || subsample_row) {
@@ -607,8 +607,11 @@ __global__ void __launch_bounds__(256) sws_k_pal2rgb(SwsFrameSet fs, int w, int 
     const FrameRegs f = load_frame(fs, blockIdx.z);
     const int y = sliceY + blockIdx.y;
     const uint32_t e = ((const uint32_t *)f.src[1])[256 + f.src[0][(int64_t)y * f.srcStride[0] + x]];
-    if (planar) {
-        for (int k = 0; k < nbytes; k++) f.dst[k][(int64_t)y * f.dstStride[k] + x] = (uint8_t)(e >> (8 * k));
+    if (planar) {   // (static plane indices: a run-time index into the frame descriptor would put it into scratch memory)
+        f.dst[0][(int64_t)y * f.dstStride[0] + x] = (uint8_t)e;
+        f.dst[1][(int64_t)y * f.dstStride[1] + x] = (uint8_t)(e >> 8);
+        f.dst[2][(int64_t)y * f.dstStride[2] + x] = (uint8_t)(e >> 16);
+        if (nbytes == 4) f.dst[3][(int64_t)y * f.dstStride[3] + x] = (uint8_t)(e >> 24);
     } else if (nbytes == 4) {
         ((uint32_t *)(f.dst[0] + (int64_t)y * f.dstStride[0]))[x] = e;
     } else {
