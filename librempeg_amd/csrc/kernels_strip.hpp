@@ -97,8 +97,8 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++) {
         const bool first = !CHROMA || ((ci == 0) == u1);
-        const uint8_t *sb = !CHROMA ? f.src[0] : (first ? f.src[1] : f.src[2]);
-        sst[ci] = !CHROMA ? f.srcStride[0] : (first ? f.srcStride[1] : f.srcStride[2]);
+        const uint8_t *sb = !CHROMA ? f.src[0] : (first ? U(f.src[1]) : U(f.src[2]));   // (U(): keeps the frame descriptor out of scratch memory, kernels_common.hpp)
+        sst[ci] = !CHROMA ? f.srcStride[0] : (first ? U(f.srcStride[1]) : U(f.srcStride[2]));
         rs[ci] = make_rsrc(sb, (uint32_t)sst[ci] * (uint32_t)sH);
     }
     // Two 16-byte chunks per lane and source row, unconditionally (straight-line code): a lane whose chunk lies beyond the strip's
@@ -150,8 +150,8 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++) {
         const int pl = !CHROMA ? 0 : semi ? 1 : (ci == 0 ? p.u_plane_dst : p.v_plane_dst);
-        uint8_t *db = pl == 0 ? f.dst[0] : pl == 1 ? f.dst[1] : f.dst[2];
-        dstr[ci] = pl == 0 ? f.dstStride[0] : pl == 1 ? f.dstStride[1] : f.dstStride[2];
+        uint8_t *db = pl == 0 ? U(f.dst[0]) : pl == 1 ? U(f.dst[1]) : U(f.dst[2]);
+        dstr[ci] = pl == 0 ? U(f.dstStride[0]) : pl == 1 ? U(f.dstStride[1]) : U(f.dstStride[2]);
         rd[ci] = make_rsrc(db, (uint32_t)dstr[ci] * (uint32_t)(H - 1) + (uint32_t)W * (uint32_t)dbytes);
     }
     int doff[COLS];
@@ -396,8 +396,8 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++) {
         const bool first = !CHROMA || ((ci == 0) == u1);
-        const uint8_t *sb = !CHROMA ? f.src[0] : (first ? f.src[1] : f.src[2]);
-        sst[ci] = !CHROMA ? f.srcStride[0] : (first ? f.srcStride[1] : f.srcStride[2]);
+        const uint8_t *sb = !CHROMA ? f.src[0] : (first ? U(f.src[1]) : U(f.src[2]));   // (U(): keeps the frame descriptor out of scratch memory, kernels_common.hpp)
+        sst[ci] = !CHROMA ? f.srcStride[0] : (first ? U(f.srcStride[1]) : U(f.srcStride[2]));
         const uint64_t a = uniform_u64((uint64_t)sb);
         rs[ci][0] = (int)(uint32_t)a; rs[ci][1] = (int)(uint32_t)(a >> 32);
         rs[ci][2] = __builtin_amdgcn_readfirstlane((int)((uint32_t)sst[ci] * (uint32_t)sH)); rs[ci][3] = 0x00020000;
@@ -437,8 +437,8 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++) {
         const int pl = !CHROMA ? 0 : semi ? 1 : (ci == 0 ? p.u_plane_dst : p.v_plane_dst);
-        uint8_t *db = pl == 0 ? f.dst[0] : pl == 1 ? f.dst[1] : f.dst[2];
-        dstr[ci] = pl == 0 ? f.dstStride[0] : pl == 1 ? f.dstStride[1] : f.dstStride[2];
+        uint8_t *db = pl == 0 ? U(f.dst[0]) : pl == 1 ? U(f.dst[1]) : U(f.dst[2]);
+        dstr[ci] = pl == 0 ? U(f.dstStride[0]) : pl == 1 ? U(f.dstStride[1]) : U(f.dstStride[2]);
         rd[ci] = make_rsrc(db, (uint32_t)dstr[ci] * (uint32_t)(H - 1) + (uint32_t)W * (uint32_t)dbytes);
     }
     int doff[COLS];
