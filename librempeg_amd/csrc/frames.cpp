@@ -34,7 +34,7 @@ static uint64_t fnv1a(uint64_t h, const void *p, size_t n)
 // sanitize_fmt(), format.c:305-342
 static void sanitize_fmt(SwsFmt *fmt, const PixDesc *desc)
 {
-    if (desc->flags & PIXFLAG_RGB) {            // RGB-like family (this library has no palette / bayer formats)
+    if (desc->flags & (PIXFLAG_RGB | PIXFLAG_PAL | PIXFLAG_BAYER)) {   // RGB-like family
         fmt->csp = COL_SPC_RGB;
         fmt->range = SWS_COL_RANGE_JPEG;
     } else if (pix_is_xyz(fmt->format)) {

@@ -18,7 +18,7 @@ CSP = {"rgb": 0, "bt709": 1, "unspecified": 2, "fcc": 4, "bt470bg": 5, "smpte170
 
 
 def _is_rgb(fmt):
-    return fmt.startswith(("rgb", "bgr", "gbr", "argb", "abgr", "0rgb", "0bgr", "x2rgb", "x2bgr"))
+    return fmt.startswith(("rgb", "bgr", "gbr", "argb", "abgr", "0rgb", "0bgr", "x2rgb", "x2bgr", "pal8", "bayer_"))   # AV_PIX_FMT_FLAG_RGB | PAL | BAYER
 
 
 def _is_gray(fmt):
@@ -48,7 +48,7 @@ def sanitize(fmt, props):
         p["colorspace"] = 2
     elif _is_gray(fmt):
         p["colorspace"] = 2
-        p["color_range"] = 0 if "f32" in fmt else 2
+        p["color_range"] = 0 if ("f32" in fmt or "f16" in fmt) else 2
     if fmt.startswith("yuvj"):
         p["color_range"] = 2
     if _subsampling(fmt) == (0, 0):

@@ -56,6 +56,16 @@ CASES = [
     (128, 64, "yuv420p10le", dict(color_range="mpeg", colorspace="bt2020nc", chroma_location="topleft"), 64, 32, "p010le",
      dict(color_range="mpeg", colorspace="bt2020nc", chroma_location="topleft"), LA.SWS_LANCZOS | BX, False),
     (96, 64, "nv12", dict(color_range="mpeg", colorspace="bt709"), 96, 64, "bgra", {}, LA.SWS_BICUBIC | BX, False),
+    # the formats added late in round 2: palette and bayer sources are "RGB-like" (sanitize_fmt, format.c:305-311), the 8 bpp destination dithers
+    (96, 64, "pal8", {}, 64, 40, "yuv420p", dict(color_range="mpeg", colorspace="bt709"), LA.SWS_BICUBIC | BX, False),
+    (96, 64, "pal8", {}, 96, 64, "bgra", {}, LA.SWS_BICUBIC | BX, False),
+    (96, 64, "bayer_grbg16le", {}, 64, 40, "yuv444p", dict(color_range="jpeg", colorspace="bt470bg"), LA.SWS_BILINEAR | BX, False),
+    (96, 64, "bayer_bggr8", {}, 96, 64, "rgb24", {}, LA.SWS_BICUBIC | BX, False),
+    (96, 64, "yuv420p", dict(color_range="mpeg", colorspace="bt709", chroma_location="left"), 64, 40, "rgb8", {}, LA.SWS_BICUBIC | BX, False),
+    (96, 64, "yuv444p", dict(color_range="mpeg", colorspace="bt709"), 64, 40, "bgr4_byte", {}, LA.SWS_BICUBIC | BX, False),           # 4:4:4 source: error diffusion
+    (96, 64, "rgbaf16le", {}, 64, 40, "yuva420p", dict(color_range="mpeg", colorspace="bt709"), LA.SWS_BICUBIC | BX, False),
+    (96, 64, "grayf16le", dict(color_range="jpeg"), 64, 40, "gray8", {}, LA.SWS_BICUBIC | BX, False),
+    (96, 64, "uyyvyy411", dict(color_range="mpeg"), 64, 40, "yuv420p", dict(color_range="mpeg"), LA.SWS_BICUBIC | BX, False),
     # interlaced: two half-height conversions on every second row; odd heights give the top field the extra row
     (96, 63, "yuv420p", dict(chroma_location="left", color_range="mpeg"), 64, 47, "yuv420p", dict(chroma_location="left", color_range="mpeg"), LA.SWS_BICUBIC | BX, True),
     (96, 64, "yuv420p", dict(color_range="mpeg", colorspace="bt709"), 96, 64, "rgb24", {}, LA.SWS_BICUBIC | BX | LA.SWS_ACCURATE_RND, True),
