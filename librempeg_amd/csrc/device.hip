@@ -338,6 +338,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         d->dot2_ok = false;
         {
             const bool src_ok = p.srcKind == SRCK_PLANAR8 || (p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15 && p.src_shift == 0);
+            const bool nv_src = p.srcKind == SRCK_NV12 && c->srcBpc == 8;   // nv12 / nv21: the strip kernel de-interleaves plane 1 while staging (not the dot2 tile kernel)
             const bool dst_ok = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010;
             auto fs2 = [](int fs) { return (fs + 2) & ~1; };
             // packed 24 / 32 bpp RGB through the LUT writers (not the full-chroma ones): the strip kernel with the RGB epilogue
@@ -346,7 +347,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             d->striprgb_ok = false;
             // (planar writers: a one-tap vertical filter takes the reference's yuv2plane1 form, not the "X" arithmetic of these kernels;
             //  the packed writers are in "X" mode unless both vertical filters are short, which all_x_mode checks row by row)
-            if (!d->unity_h && !p.fast_bilinear && !gray_any && src_ok && ((dst_ok && c->vLum.size >= 2 && c->vChr.size >= 2) || rgb_ok) && !p.wide &&
+            if (!d->unity_h && !p.fast_bilinear && !gray_any && (src_ok || (nv_src && dst_ok)) && ((dst_ok && c->vLum.size >= 2 && c->vChr.size >= 2) || rgb_ok) && !p.wide &&
                 fs2(c->hLum.size) <= 16 && fs2(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && fs2(c->vChr.size) <= 16 &&
                 !c->tune.no_dot2) {
                 const int SPC = p.srcKind == SRCK_PLANAR16 ? 8 : 16;
@@ -491,7 +492,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         g.hT2 = (const int16_t *)(b + o.ht); g.vT2 = (const int16_t *)(b + o.vt);
                     };
                     bind(d->dotL, oL); bind(d->dotC, oC);
-                    d->dot2_ok = true;
+                    d->dot2_ok = src_ok;
                     if (strip_plan) {
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         d->stripL.colStart = (const int32_t *)(b + sL.cs); d->stripL.colCount = (const int32_t *)(b + sL.cc);

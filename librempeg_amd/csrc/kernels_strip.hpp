@@ -92,11 +92,13 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
     }
     // ---- source descriptors (whole rows including their padding) ----
     const bool u1 = p.u_plane_src == 1;
+    // nv12 / nv21 sources (8-bit): both chroma components come out of plane 1, de-interleaved on the way into LDS (nvXXtoUV_c, input.c:926-948)
+    const bool nvsrc = !SRC16 && CHROMA && p.srcKind == SRCK_NV12;
     sws_rsrc_t rs[NCOMP];
     int sst[NCOMP];
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++) {
-        const bool first = !CHROMA || ((ci == 0) == u1);
+        const bool first = !CHROMA || nvsrc || ((ci == 0) == u1);
         const uint8_t *sb = !CHROMA ? f.src[0] : (first ? U(f.src[1]) : U(f.src[2]));   // (U(): keeps the frame descriptor out of scratch memory, kernels_common.hpp)
         sst[ci] = !CHROMA ? f.srcStride[0] : (first ? U(f.srcStride[1]) : U(f.srcStride[2]));
         rs[ci] = make_rsrc(sb, (uint32_t)sst[ci] * (uint32_t)sH);
@@ -110,8 +112,26 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
     const int slot0 = min(lane, chunks) * (SPC / 2), slot1 = min(64 + lane, chunks) * (SPC / 2);
 
     u32x4 pre[NCOMP * 4];                                      // [component][row of the pair][chunk]
+    const int nvoff0 = lane < chunks ? cs * 2 + lane * 32 : 0x7fffffff, nvoff1 = lane < chunks ? cs * 2 + lane * 32 + 16 : 0x7fffffff;
     auto prefetch = [&](int q) {                               // source rows 2q, 2q+1 (clamped) -> registers
         const int r0 = min(max(2 * q, 0), sH - 1), r1 = min(max(2 * q + 1, 0), sH - 1);
+        if constexpr (CHROMA && !SRC16) {
+            if (nvsrc) {   // 16 interleaved pairs (32 bytes) per lane and row -> 16 samples of each component
+                const uint32_t se = p.uv_swap_src ? 0x07050301u : 0x06040200u, so = p.uv_swap_src ? 0x06040200u : 0x07050301u;
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int ro = (r ? r1 : r0) * sst[0];
+                    const u32x4 a = bload16(rs[0], nvoff0, ro), b = bload16(rs[0], nvoff1, ro);
+                    u32x4 u, v;
+                    u[0] = __builtin_amdgcn_perm(a[1], a[0], se); u[1] = __builtin_amdgcn_perm(a[3], a[2], se);
+                    u[2] = __builtin_amdgcn_perm(b[1], b[0], se); u[3] = __builtin_amdgcn_perm(b[3], b[2], se);
+                    v[0] = __builtin_amdgcn_perm(a[1], a[0], so); v[1] = __builtin_amdgcn_perm(a[3], a[2], so);
+                    v[2] = __builtin_amdgcn_perm(b[1], b[0], so); v[3] = __builtin_amdgcn_perm(b[3], b[2], so);
+                    pre[2 * r] = u; pre[4 + 2 * r] = v;
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int ci = 0; ci < NCOMP; ci++) {
             pre[4 * ci + 0] = bload16(rs[ci], voff0, r0 * sst[ci]);

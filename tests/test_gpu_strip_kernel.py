@@ -43,3 +43,17 @@ def test_strip_is_used_for_wide_pictures_by_default():
     assert path == "main:strip_march"
     path, _ = run_case(640, 48, "yuv420p", 320, 24, "yuv420p", SWS_BILINEAR | BX, seed=2)
     assert path != "main:strip_march"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src", ["nv12", "nv21"])
+@pytest.mark.parametrize("dst", ["yuv420p", "nv12", "nv21", "yuv420p10le", "p010le", "yuv422p", "yuv444p"])
+def test_semi_planar_sources_take_the_strip_kernel(src, dst):
+    """nv12 / nv21 sources: the strip kernel de-interleaves plane 1 while staging (nvXXtoUV_c, input.c:926-948)."""
+    for (sw, sh, dw, dh, fl) in ((1280, 96, 1024, 64, SWS_BICUBIC), (1300, 70, 1030, 46, SWS_BILINEAR), (1024, 64, 2050, 130, SWS_LANCZOS),
+                                 (1922, 50, 1280, 34, SWS_BICUBIC | SWS_ACCURATE_RND), (3840, 40, 1920, 20, SWS_AREA)):
+        path, _ = run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw)
+        # the same kernel a planar 4:2:0 source of this geometry gets (a one-tap vertical chroma filter, e.g., keeps the tile kernel)
+        assert path == run_case(sw, sh, "yuv420p", dw, dh, dst, fl | BX, seed=sw)[0], (path, sw, dw)
+        assert path == "main:strip_march" or sw == 3840, (path, sw, dw)
+    assert run_case(640, 96, src, 320, 64, dst, SWS_BICUBIC | BX, seed=3, tune=dict(strip_min_w=64))[0] == "main:strip_march"
