@@ -338,7 +338,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         d->dot2_ok = false;
         {
             const bool src_ok = p.srcKind == SRCK_PLANAR8 || (p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15 && p.src_shift == 0);
-            const bool nv_src = p.srcKind == SRCK_NV12 && c->srcBpc == 8;   // nv12 / nv21: the strip kernel de-interleaves plane 1 while staging (not the dot2 tile kernel)
+            // nv12 / nv21, p010 / p012 (and the 4:2:2 / 4:4:4 twins): the strip kernel de-interleaves plane 1 (and shifts the p01x samples down) while
+            // staging; the dot2 tile kernel does not
+            const bool nv_src = (p.srcKind == SRCK_NV12 && c->srcBpc == 8) || (p.srcKind == SRCK_P010 && p.src_depth <= 15);
             const bool dst_ok = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010;
             auto fs2 = [](int fs) { return (fs + 2) & ~1; };
             // packed 24 / 32 bpp RGB through the LUT writers (not the full-chroma ones): the strip kernel with the RGB epilogue
@@ -350,7 +352,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             if (!d->unity_h && !p.fast_bilinear && !gray_any && (src_ok || (nv_src && dst_ok)) && ((dst_ok && c->vLum.size >= 2 && c->vChr.size >= 2) || rgb_ok) && !p.wide &&
                 fs2(c->hLum.size) <= 16 && fs2(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && fs2(c->vChr.size) <= 16 &&
                 !c->tune.no_dot2) {
-                const int SPC = p.srcKind == SRCK_PLANAR16 ? 8 : 16;
+                const int SPC = (p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010) ? 8 : 16;
                 std::vector<uint8_t> blob;
                 auto put = [&](const void *ptr, size_t n) { size_t o = (blob.size() + 15) & ~(size_t)15; blob.resize(o + n); std::memcpy(blob.data() + o, ptr, n); return o; };
                 auto padded = [&](const FilterBank &b) {
@@ -418,7 +420,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     // LDS-DMA form: a ring of 4 row pairs per wave, rows of ncmax 16-bit samples; every pair between the first and the last
                     // one a band needs is requested, so the windows of consecutive rows must touch (no skipped pair)
                     g.lds_dma_bytes = 4 * 4 * ncomp * 2 * (ncmax / 2) * 4;
-                    g.dma_ok = SPC == 8 && g.lds_dma_bytes <= 40 * 1024;
+                    g.dma_ok = p.srcKind == SRCK_PLANAR16 && g.lds_dma_bytes <= 40 * 1024;   // (LDS-DMA copies rows as they are: planar 16-bit sources only)
                     for (int y = 1; y < vb.count && g.dma_ok; y++)
                         if (((vb.pos[y] & ~1) >> 1) > ((vb.pos[y - 1] & ~1) >> 1) + npv) g.dma_ok = 0;
                     o.cs = put(cs.data(), cs.size() * 4); o.cc = put(cc.data(), cc.size() * 4);
@@ -445,6 +447,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 const bool strip_plan = dst_ok && !p.range_active && !c->tune.no_strip && p.dstW >= strip_min_w &&
                                         plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sL) && plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sC);
                 d->strip_ok = false;
+                log_msg(c, 3, "strip plan: %d (windows %d/%d chunks of %d, taps %d/%d x %d/%d)\n", strip_plan, d->stripL.NCmax / SPC, d->stripC.NCmax / SPC, SPC,
+                        d->stripL.nph, d->stripC.nph, d->stripL.npv, d->stripC.npv);
                 Off oL, oC;
                 if (rgb_ok) {
                     // RGB epilogue: 256 luma columns + the 128 chroma columns under them per wave, one 16-byte chunk per lane and row for

@@ -13,7 +13,7 @@ int launch_strip(const LaunchCtx &L)
     const dim3 blk(256);
     (void)c; (void)d; (void)frames; (void)vec; (void)sliceY; (void)sliceH;
             const int target = c->tune.strip_waves;
-            const bool s16 = p.srcKind == SRCK_PLANAR16;
+            const bool s16 = p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010;
             auto launch = [&](SwsStripGeom g, int H, bool chroma) {
                 int bands = std::max(1, std::min(target / std::max(1, g.strips * n), (H + 15) / 16));
                 g.debug = c->tune.debug;

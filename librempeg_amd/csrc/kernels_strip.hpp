@@ -93,7 +93,10 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
     // ---- source descriptors (whole rows including their padding) ----
     const bool u1 = p.u_plane_src == 1;
     // nv12 / nv21 sources (8-bit): both chroma components come out of plane 1, de-interleaved on the way into LDS (nvXXtoUV_c, input.c:926-948)
-    const bool nvsrc = !SRC16 && CHROMA && p.srcKind == SRCK_NV12;
+    // p010 / p012 sources (16-bit words, samples in the high bits): the same for 16-bit pairs, and every sample >> src_shift (p010LEToY_c / p010LEToUV_c, :950-1008)
+    const bool nvsrc = CHROMA && (SRC16 ? p.srcKind == SRCK_P010 : p.srcKind == SRCK_NV12);
+    const int sshift = (SRC16 && p.srcKind == SRCK_P010) ? p.src_shift : 0;
+    const uint32_t smask = (0xFFFFu >> sshift) * 0x10001u;
     sws_rsrc_t rs[NCOMP];
     int sst[NCOMP];
 #pragma unroll
@@ -112,12 +115,14 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
     const int slot0 = min(lane, chunks) * (SPC / 2), slot1 = min(64 + lane, chunks) * (SPC / 2);
 
     u32x4 pre[NCOMP * 4];                                      // [component][row of the pair][chunk]
-    const int nvoff0 = lane < chunks ? cs * 2 + lane * 32 : 0x7fffffff, nvoff1 = lane < chunks ? cs * 2 + lane * 32 + 16 : 0x7fffffff;
+    const int nvbase = cs * (SRC16 ? 4 : 2) + lane * 32;      // a pair is 2 or 4 bytes; a lane takes 32 bytes = one chunk of each component
+    const int nvoff0 = lane < chunks ? nvbase : 0x7fffffff, nvoff1 = lane < chunks ? nvbase + 16 : 0x7fffffff;
     auto prefetch = [&](int q) {                               // source rows 2q, 2q+1 (clamped) -> registers
         const int r0 = min(max(2 * q, 0), sH - 1), r1 = min(max(2 * q + 1, 0), sH - 1);
-        if constexpr (CHROMA && !SRC16) {
-            if (nvsrc) {   // 16 interleaved pairs (32 bytes) per lane and row -> 16 samples of each component
-                const uint32_t se = p.uv_swap_src ? 0x07050301u : 0x06040200u, so = p.uv_swap_src ? 0x06040200u : 0x07050301u;
+        if constexpr (CHROMA) {
+            if (nvsrc) {   // 32 bytes of interleaved pairs per lane and row -> one 16-byte chunk of each component (16 bytes or 8 words)
+                const uint32_t s0 = SRC16 ? 0x05040100u : 0x06040200u, s1 = SRC16 ? 0x07060302u : 0x07050301u;
+                const uint32_t se = p.uv_swap_src ? s1 : s0, so = p.uv_swap_src ? s0 : s1;
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
                     const int ro = (r ? r1 : r0) * sst[0];
@@ -141,8 +146,10 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
         }
     };
     auto put = [&](uint32_t *dst, const u32x4 &v) {
-        if constexpr (SRC16) *(u32x4 *)dst = v;
-        else {
+        if constexpr (SRC16) {
+            if (sshift) { u32x4 w; w[0] = (v[0] >> sshift) & smask; w[1] = (v[1] >> sshift) & smask; w[2] = (v[2] >> sshift) & smask; w[3] = (v[3] >> sshift) & smask; *(u32x4 *)dst = w; }
+            else *(u32x4 *)dst = v;
+        } else {
             u32x4 lo, hi;                                      // bytes -> u16 pairs
             lo[0] = __builtin_amdgcn_perm(0, v[0], 0x0c010c00u); lo[1] = __builtin_amdgcn_perm(0, v[0], 0x0c030c02u);
             lo[2] = __builtin_amdgcn_perm(0, v[1], 0x0c010c00u); lo[3] = __builtin_amdgcn_perm(0, v[1], 0x0c030c02u);

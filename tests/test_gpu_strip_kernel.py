@@ -46,14 +46,20 @@ def test_strip_is_used_for_wide_pictures_by_default():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("src", ["nv12", "nv21"])
+@pytest.mark.parametrize("src", ["nv12", "nv21", "p010le", "p012le", "p010be", "nv16", "p210le", "nv24", "p410le"])
 @pytest.mark.parametrize("dst", ["yuv420p", "nv12", "nv21", "yuv420p10le", "p010le", "yuv422p", "yuv444p"])
 def test_semi_planar_sources_take_the_strip_kernel(src, dst):
-    """nv12 / nv21 sources: the strip kernel de-interleaves plane 1 while staging (nvXXtoUV_c, input.c:926-948)."""
+    """nv12 / nv21 / p010 / p012 sources and their 4:2:2 / 4:4:4 twins: the strip kernel de-interleaves plane 1 while staging (nvXXtoUV_c,
+    input.c:926-948) and shifts the p01x samples down (p010LEToY_c / p010LEToUV_c, :950-1008)."""
     for (sw, sh, dw, dh, fl) in ((1280, 96, 1024, 64, SWS_BICUBIC), (1300, 70, 1030, 46, SWS_BILINEAR), (1024, 64, 2050, 130, SWS_LANCZOS),
                                  (1922, 50, 1280, 34, SWS_BICUBIC | SWS_ACCURATE_RND), (3840, 40, 1920, 20, SWS_AREA)):
         path, _ = run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw)
         # the same kernel a planar 4:2:0 source of this geometry gets (a one-tap vertical chroma filter, e.g., keeps the tile kernel)
-        assert path == run_case(sw, sh, "yuv420p", dw, dh, dst, fl | BX, seed=sw)[0], (path, sw, dw)
-        assert path == "main:strip_march" or sw == 3840, (path, sw, dw)
-    assert run_case(640, 96, src, 320, 64, dst, SWS_BICUBIC | BX, seed=3, tune=dict(strip_min_w=64))[0] == "main:strip_march"
+        twin = {"nv12": "yuv420p", "nv21": "yuv420p", "p010le": "yuv420p10le", "p012le": "yuv420p12le", "p010be": "yuv420p10le", "nv16": "yuv422p",
+                "p210le": "yuv422p10le", "nv24": "yuv444p", "p410le": "yuv444p10le"}[src]
+        tpath = run_case(sw, sh, twin, dw, dh, dst, fl | BX, seed=sw)[0]
+        # (where the strip plan does not fit -- a 4:4:4 chroma window of more than 64 chunks -- the planar twin falls back to the dot2 tile
+        #  kernel, which does not de-interleave: the semi-planar source takes the plain tile kernel)
+        assert path == tpath or (tpath == "main:fused_tile_dot2" and path == "main:fused_tile"), (path, tpath, sw, dw)
+    if src not in ("nv24", "p410le") or dst == "yuv444p":     # 4:4:4 -> 4:2:0 / 4:2:2 bicubic chroma needs more than 16 horizontal taps
+        assert run_case(640, 96, src, 320, 64, dst, SWS_BICUBIC | BX, seed=3, tune=dict(strip_min_w=64))[0] == "main:strip_march"
