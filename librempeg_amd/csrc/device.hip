@@ -334,6 +334,17 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         // the fast-bilinear chroma function weighs with (xalpha ^ 127): not the identity even at equal widths
         d->unity_h = bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14) && !p.fast_bilinear;
         d->unity_v = bank_is_identity(c->vLum, 1 << 12) && bank_is_identity(c->vChr, 1 << 12);
+        // ---- packed 24 / 32 bpp RGB into 8-bit 4:2:0 / 4:2:2 YUV of the same size (sws_k_rgbsrc_unity): identity horizontal filters and luma
+        //      vertical filter, chroma of the "half" readers through a vertical filter of up to 16 taps whose positions only move forward ----
+        d->rgbsrc_ok = false;
+        if (d->unity_h && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32) && p.chr_half && !p.range_active && !p.need_alpha && !p.no_chroma &&
+            !p.wide && !p.dst_alpha_fill && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_NV12) && p.dst_bits == 8 && p.chrDstHSub == 1 && p.chrDstVSub <= 1 &&
+            p.chrSrcVSub == 0 && p.srcH == p.dstH && bank_is_identity(c->vLum, 1 << 12) && c->vChr.size <= 16 && p.chrDstW == ((p.dstW + 1) >> 1) &&
+            !c->tune.no_rgbsrc) {
+            bool fwd = true;
+            for (int y = 0; y < c->vChr.count && fwd; y++) fwd = c->vChr.pos[y] >= 0 && (y == 0 || c->vChr.pos[y] >= c->vChr.pos[y - 1]);
+            d->rgbsrc_ok = fwd;
+        }
         // ---- dot2 tile kernel (sws_k_tile_dot2): planar 8-bit / <= 15-bit sources, 15-bit intermediates, vfs >= 2 ----
         d->dot2_ok = false;
         {
@@ -685,6 +696,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         } else if (d->unity_h && d->unity_v && !p.no_chroma && !p.need_alpha && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 && p.dst_shift == 0 &&
                    (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16)) {
             c->path_name = "main:fused_f32rgb_yuv444"; c->kernel_name = "sws_k_f32rgb_to_yuv444_unity";
+        } else if (d->rgbsrc_ok) {
+            c->path_name = "main:rgbsrc_unity"; c->kernel_name = "sws_k_rgbsrc_unity";
         } else if (d->unity_h) {
             c->path_name = "main:fused_generic_unity";
             c->kernel_name = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) ? "sws_k_vscale_rgb" : "sws_k_vscale_planar";
@@ -878,6 +891,7 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         else if (vec && d->unity_h && d->unity_v && !p.no_chroma && !p.need_alpha && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 && p.dst_shift == 0 &&
                  (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16))
             ret = launch_f32rgb(L);
+        else if (d->rgbsrc_ok && vec) ret = launch_rgbsrc(L);                                             // packed RGB source, same size
         else if (d->striprgb_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_striprgb(L);   // marching strip kernel, RGB epilogue
         else if (d->strip_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_strip(L);   // marching strip kernel
         else if (d->dot2_ok && vec) ret = launch_tile_dot2(L);                                              // dot2 LDS-tile kernel
@@ -1754,7 +1768,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "strip_min_w", &c->tune.strip_min_w }, { "strip_cols_l", &c->tune.strip_cols_l }, { "strip_cols_c", &c->tune.strip_cols_c },
         { "strip_waves", &c->tune.strip_waves }, { "strip_rgb_cols", &c->tune.strip_rgb_cols }, { "rgb_march_waves", &c->tune.rgb_march_waves }, { "tile_lds_kb", &c->tune.tile_lds_kb },
         { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
-        { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
+        { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
         { "debug", &c->tune.debug },
     };
     for (auto &e : tab)

@@ -3,6 +3,7 @@
 #include "devstate.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_stream.hpp"
+#include "kernels_rgbsrc.hpp"
 
 namespace swship {
 
@@ -41,6 +42,26 @@ int launch_f32rgb(const LaunchCtx &L)
     (void)c; (void)d; (void)frames; (void)vec; (void)sliceY; (void)sliceH;
             const dim3 g(cdiv((int64_t)((p.srcW + 7) >> 3) * p.srcH, 256), 1, n);
             hipLaunchKernelGGL(swsk::sws_k_f32rgb_to_yuv444_unity, g, blk, 0, st, fs, p);
+    return 0;
+}
+
+// packed RGB -> planar / semi-planar 8-bit YUV of the same size: lanes of four luma columns, bands of rows sized for about 4096 waves
+int launch_rgbsrc(const LaunchCtx &L)
+{
+    const SwsDevParams &p = *L.p; hipStream_t st = L.st; const SwsFrameSet &fs = L.fs;
+    const int n = L.n;
+    const dim3 blk(256);
+    const int lanes = cdiv(p.dstW, 4), waves_row = cdiv(lanes, 64);
+    int bands = std::max(1, std::min((int)cdiv(4096, waves_row * n), (int)cdiv(p.dstH, 8)));
+    swsk::RgbSrcGeom g;
+    g.band_rows = (cdiv(p.dstH, bands) + 1) & ~1;
+    g.bands = cdiv(p.dstH, g.band_rows);
+    const dim3 grid(cdiv(lanes, 256), g.bands, n);
+    const bool nv = p.dstKind == DSTK_NV12;
+    if (p.srcKind == SRCK_RGB24) { if (nv) hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity<3, true>), grid, blk, 0, st, fs, p, g);
+                                   else    hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity<3, false>), grid, blk, 0, st, fs, p, g); }
+    else                         { if (nv) hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity<4, true>), grid, blk, 0, st, fs, p, g);
+                                   else    hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity<4, false>), grid, blk, 0, st, fs, p, g); }
     return 0;
 }
 

@@ -1,0 +1,151 @@
+// Packed 24 / 32 bpp RGB sources into 8-bit planar / semi-planar YUV of the same size (the capture -> encoder conversion):
+// rgb24ToY_c / rgb24ToUV_half_c (input.c:1068-1172), rgb16_32ToY / UV_half_c_template with the 32-bit rows (:264-393), the identity
+// hScale16To15_c (swscale.c:106-131, sh = 9 for RGB sources), yuv2plane1_8_c for luma (output.c:468-493) and yuv2planeX_8_c /
+// yuv2nv12cX_c for the vertically scaled chroma (:438-466, :495-528).
+//
+// Each lane owns four luma columns (= two chroma columns of the "half" chroma readers) and walks down a band of rows: one 12- or
+// 16-byte load per source row, four luma bytes stored as one dword.  The two {U, V} pairs of the row go into a 16-deep ring of
+// lane-private LDS slots - LDS as a register file that can be indexed by a run-time row number - from which the vertical chroma filter
+// of an output row is read once its last source row has passed.  No barriers: a lane only ever reads what it wrote.
+#pragma once
+#include "kernels_common.hpp"
+
+namespace swsk {
+
+struct RgbSrcGeom { int32_t band_rows, bands; };
+
+template <int BPP, bool NV>
+__global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDevParams p, RgbSrcGeom g)
+{
+    __shared__ uint2 ring[16][256];
+    const int tid = threadIdx.x, t = blockIdx.x * 256 + tid;
+    const int W = U(p.dstW), H = U(p.dstH), x0 = 4 * t;
+    if (x0 >= W) return;
+    const SwsFramePtrs f = frame_copy(fs, blockIdx.z);
+    const int vs = U(p.chrDstVSub), cW = U(p.chrDstW), cH = U(p.chrDstH), cSH = U(p.chrSrcH);
+    const int y0 = blockIdx.y * U(g.band_rows), y1 = min(H, y0 + U(g.band_rows));
+    int cy = y0 >> vs;
+    const int cy1 = min(cH, (y1 + (1 << vs) - 1) >> vs);
+    const int vfs = U(p.vChrFs);
+    const int32_t *vpos = U(p.vChrPos);
+    const int16_t *vF = U(p.vChrF);
+    const int hshift = U(p.hshift), hclip = U(p.hclip);
+    const bool sd = p.should_dither;
+    auto first_of = [&](int c) { return max(1 - vfs, vpos[c]); };
+    auto clampc = [&](int r) { return min(max(r, 0), cSH - 1); };
+    int clast = cy < cy1 ? clampc(first_of(cy) + vfs - 1) : -1;
+    const int cfirst = cy < cy1 ? clampc(first_of(cy)) : 0x7fffffff;
+    const int rlo = min(y0, cfirst), rhi = cy < cy1 ? max(y1 - 1, clampc(first_of(cy1 - 1) + vfs - 1)) : y1 - 1;
+
+    // per-byte coefficients: rgb24 has r / b at byte 0 / 2 or 2 / 0; the 32-bit rows have every component at any of the four bytes
+    const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);
+    const int rp = U(p.src_r_pos), gp = BPP == 3 ? 1 : U(p.src_g_pos), bp = U(p.src_b_pos);
+    auto coef = [&](const Rgb2YuvRow &w, int k) { const int v = k == rp ? w.r : k == gp ? w.g : k == bp ? w.b : 0; return BPP == 3 ? v : (int)((unsigned)v << 8); };
+    int cy_[4], cu_[4], cv_[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { cy_[k] = coef(ty, k); cu_[k] = coef(tu, k); cv_[k] = coef(tv, k); }
+
+    const bool full = x0 + 4 <= W;                     // (the last group of a ragged width goes byte by byte)
+    const int ncol = min(2, cW - 2 * t);               // chroma columns of this lane
+    const int uplane = U(p.u_plane_dst), vplane = U(p.v_plane_dst);
+    const uint8_t *s0 = f.src[0];
+    const int64_t sst = f.srcStride[0];
+    for (int r = rlo; r <= rhi; r++) {
+        // ---- the row's four pixels (and, for a ragged width, the partner of the last odd pixel: the half readers read it too) ----
+        uint32_t b[4][4] = {};
+        const uint8_t *row = s0 + (int64_t)r * sst + (int64_t)BPP * x0;
+        if (full) {
+            if (BPP == 3) {
+                const uint32_t d0 = ((const uint32_t *)row)[0], d1 = ((const uint32_t *)row)[1], d2 = ((const uint32_t *)row)[2];
+                const uint32_t d[3] = { d0, d1, d2 };
+#pragma unroll
+                for (int i = 0; i < 12; i++) b[i / 3][i % 3] = (d[i >> 2] >> (8 * (i & 3))) & 0xFF;
+            } else {
+                const uint4 q = *(const uint4 *)row;
+                const uint32_t d[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+                for (int i = 0; i < 16; i++) b[i >> 2][i & 3] = (d[i >> 2] >> (8 * (i & 3))) & 0xFF;
+            }
+        } else {
+            const int npx = min(4, ((W - x0) + 1) & ~1);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int j = 0; j < BPP; j++) b[k][j] = k < npx ? row[BPP * k + j] : 0;
+        }
+        // ---- luma: reader -> identity hscale -> yuv2plane1_8_c ----
+        if (r >= y0 && r < y1) {
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int yr;
+                if (BPP == 3) yr = (uint16_t)((cy_[0] * (int)b[k][0] + cy_[1] * (int)b[k][1] + cy_[2] * (int)b[k][2] + (32 << 14) + (1 << 8)) >> 9);
+                else yr = (uint16_t)(((unsigned)cy_[0] * b[k][0] + (unsigned)cy_[1] * b[k][1] + (unsigned)cy_[2] * b[k][2] + (unsigned)cy_[3] * b[k][3] +
+                                      ((32u << 22) + (1u << 16))) >> 17);
+                const int y15 = (int16_t)min((yr * 16384) >> hshift, hclip);
+                out |= (uint32_t)clip_u8_shr(y15 + dither8(sd, r, x0 + k), 7) << (8 * k);
+            }
+            uint8_t *drow = f.dst[0] + (int64_t)r * f.dstStride[0] + x0;
+            if (full) *(uint32_t *)drow = out;
+            else for (int k = 0; k < W - x0; k++) drow[k] = (uint8_t)(out >> (8 * k));
+        }
+        // ---- chroma: the half readers on the two pixel pairs -> identity hscale -> ring ----
+        if (r >= cfirst && r < cSH) {
+            uint32_t e[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                int ur, vr;
+                if (BPP == 3) {
+                    const int a0 = b[2 * k][0] + b[2 * k + 1][0], a1 = b[2 * k][1] + b[2 * k + 1][1], a2 = b[2 * k][2] + b[2 * k + 1][2];
+                    ur = (uint16_t)((cu_[0] * a0 + cu_[1] * a1 + cu_[2] * a2 + (256 << 15) + (1 << 9)) >> 10);
+                    vr = (uint16_t)((cv_[0] * a0 + cv_[1] * a1 + cv_[2] * a2 + (256 << 15) + (1 << 9)) >> 10);
+                } else {
+                    const unsigned a0 = b[2 * k][0] + b[2 * k + 1][0], a1 = b[2 * k][1] + b[2 * k + 1][1], a2 = b[2 * k][2] + b[2 * k + 1][2],
+                                   a3 = b[2 * k][3] + b[2 * k + 1][3];
+                    const unsigned rnd = (256u << 23) + (1u << 17);
+                    ur = (uint16_t)(((unsigned)cu_[0] * a0 + (unsigned)cu_[1] * a1 + (unsigned)cu_[2] * a2 + (unsigned)cu_[3] * a3 + rnd) >> 18);
+                    vr = (uint16_t)(((unsigned)cv_[0] * a0 + (unsigned)cv_[1] * a1 + (unsigned)cv_[2] * a2 + (unsigned)cv_[3] * a3 + rnd) >> 18);
+                }
+                const int u15 = (int16_t)min((ur * 16384) >> hshift, hclip), v15 = (int16_t)min((vr * 16384) >> hshift, hclip);
+                e[k] = (uint32_t)(uint16_t)u15 | (uint32_t)(uint16_t)v15 << 16;
+            }
+            ring[r & 15][tid] = make_uint2(e[0], e[1]);
+        }
+        // ---- every chroma output row whose last source row this was ----
+        while (cy < cy1 && clast <= r) {
+            const int first = first_of(cy);
+            int au[2], av[2];
+            const bool x_form = NV || vfs > 1;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int c = 2 * t + k;
+                au[k] = x_form ? dither8(sd, cy, c) << 12 : dither8(sd, cy, c);
+                av[k] = x_form ? dither8(sd, cy, c + 3) << 12 : dither8(sd, cy, c + 3);
+            }
+            for (int j = 0; j < vfs; j++) {
+                const uint2 q = ring[clampc(first + j) & 15][tid];
+                const int w = x_form ? (int)vF[cy * vfs + j] : 1;
+                au[0] += (int)(unsigned)((int)(int16_t)(q.x & 0xFFFF) * w); av[0] += (int)(unsigned)((int)(int16_t)(q.x >> 16) * w);
+                au[1] += (int)(unsigned)((int)(int16_t)(q.y & 0xFFFF) * w); av[1] += (int)(unsigned)((int)(int16_t)(q.y >> 16) * w);
+            }
+            const int sh = x_form ? 19 : 7;
+            const uint32_t u0 = clip_u8_shr(au[0], sh), u1 = clip_u8_shr(au[1], sh), v0 = clip_u8_shr(av[0], sh), v1 = clip_u8_shr(av[1], sh);
+            if (NV) {
+                uint8_t *d = f.dst[1] + (int64_t)cy * f.dstStride[1] + 4 * t;
+                const int sw = U(p.uv_swap_dst);
+                const uint32_t p0 = sw ? (v0 | u0 << 8) : (u0 | v0 << 8), p1 = sw ? (v1 | u1 << 8) : (u1 | v1 << 8);
+                if (ncol == 2) *(uint32_t *)d = p0 | p1 << 16;
+                else *(uint16_t *)d = (uint16_t)p0;
+            } else {
+                uint8_t *du = pick4(f.dst, uplane) + (int64_t)cy * pick4(f.dstStride, uplane) + 2 * t;
+                uint8_t *dv = pick4(f.dst, vplane) + (int64_t)cy * pick4(f.dstStride, vplane) + 2 * t;
+                if (ncol == 2) { *(uint16_t *)du = (uint16_t)(u0 | u1 << 8); *(uint16_t *)dv = (uint16_t)(v0 | v1 << 8); }
+                else { du[0] = (uint8_t)u0; dv[0] = (uint8_t)v0; }
+            }
+            cy++;
+            clast = cy < cy1 ? clampc(first_of(cy) + vfs - 1) : 0x7fffffff;
+        }
+    }
+}
+
+} // namespace swsk

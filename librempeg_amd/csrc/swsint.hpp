@@ -106,7 +106,7 @@ struct Tuning {
     int rgb_march_waves = 12288;   // resident waves the packed-RGB march kernel is banded for
     int tile_lds_kb = 40, tile_threads = 256;
     int p01x_ch = 1;
-    int no_wave = 0, no_march = 0, no_strip = 0, no_strip_dma = 0, no_dot2 = 0, no_tile = 0;
+    int no_wave = 0, no_march = 0, no_rgbsrc = 0, no_strip = 0, no_strip_dma = 0, no_dot2 = 0, no_tile = 0;
     int max_devices = 0;           // sws_scale_frames(): GPUs to shard over (0 = all visible)
     int debug = 0;
 };

@@ -1,0 +1,55 @@
+"""-m gpu parity for sws_k_rgbsrc_unity (kernels_rgbsrc.hpp): packed 24 / 32 bpp RGB into 8-bit 4:2:0 / 4:2:2 YUV of the same size.
+Readers rgb24ToY_c / rgb24ToUV_half_c (input.c:1068-1172) and the 32-bit rows of rgb16_32To*_c_template (:264-393); the chroma goes
+through whatever vertical filter the scaler flag gives the 2:1 chroma step."""
+import pytest
+
+from librempeg_amd import (SWS_BICUBIC, SWS_BILINEAR, SWS_LANCZOS, SWS_BITEXACT, SWS_ACCURATE_RND, SWS_POINT, SWS_AREA, SWS_GAUSS,
+                           SWS_SINC, SWS_SPLINE, SWS_FAST_BILINEAR, SWS_FULL_CHR_H_INP)
+from test_gpu_parity import run_case
+
+pytestmark = pytest.mark.gpu
+BX = SWS_BITEXACT
+PATH = "main:rgbsrc_unity"
+
+SRC = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "0bgr"]
+DST = ["yuv420p", "yuv422p", "nv12", "nv21", "nv16", "yuvj420p"]
+
+
+@pytest.mark.parametrize("src", SRC)
+@pytest.mark.parametrize("dst", DST)
+def test_formats(src, dst):
+    for (w, h) in ((256, 64), (322, 50), (129, 33), (67, 18), (1026, 21)):
+        path, _ = run_case(w, h, src, w, h, dst, SWS_BICUBIC | BX, seed=w)
+        # (a yuvj destination is a range conversion: the generic kernels keep it)
+        if not w & 1:     # (odd widths: the chroma filter bank is not the identity)
+            want = "main:fused_generic_unity" if dst == "yuvj420p" else PATH
+            if (src, dst) == ("bgr24", "yuv420p"):
+                want = "unscaled:bgr24ToYv12"     # the reference's special converter (bgr24ToYv12Wrapper, swscale_unscaled.c:2062-2077)
+            assert path == want, (path, w, h)
+
+
+@pytest.mark.parametrize("flags", [SWS_POINT, SWS_AREA, SWS_BILINEAR, SWS_BICUBIC, SWS_GAUSS, SWS_LANCZOS, SWS_SPLINE, SWS_SINC,
+                                   SWS_BICUBIC | SWS_ACCURATE_RND, SWS_FAST_BILINEAR],
+                         ids=["point", "area", "bilinear", "bicubic", "gauss", "lanczos", "spline", "sinc", "accurate", "fast_bilinear"])
+@pytest.mark.parametrize("geom", [(640, 96), (130, 200), (4, 2), (2, 2), (1, 1), (5, 3), (1922, 34)], ids=lambda g: f"{g[0]}x{g[1]}")
+def test_scalers_and_ragged_sizes(flags, geom):
+    w, h = geom
+    for src, dst in (("rgb24", "yuv420p"), ("bgra", "nv12"), ("argb", "yuv422p")):
+        path, _ = run_case(w, h, src, w, h, dst, flags | BX, seed=7)
+        if flags != SWS_FAST_BILINEAR and not (flags in (SWS_SINC, SWS_SPLINE) and dst != "yuv422p") and not w & 1:
+            assert path == PATH, path     # (fast bilinear has its own horizontal functions; the 2:1 chroma filters of sinc and spline have more than 16 taps)
+
+
+def test_other_shapes_keep_their_kernels():
+    assert run_case(640, 48, "rgb24", 640, 48, "yuv444p", SWS_BICUBIC | BX)[0] != PATH          # chroma is scaled up horizontally
+    assert run_case(640, 48, "rgb24", 640, 48, "yuv420p", SWS_BICUBIC | SWS_FULL_CHR_H_INP | BX)[0] != PATH
+    assert run_case(640, 48, "rgb24", 640, 40, "yuv420p", SWS_BICUBIC | BX)[0] != PATH
+    assert run_case(640, 48, "rgba", 640, 48, "yuva420p", SWS_BICUBIC | BX)[0] != PATH
+    assert run_case(640, 48, "rgb24", 640, 48, "yuv420p10le", SWS_BICUBIC | BX)[0] != PATH
+    assert run_case(640, 48, "rgb24", 640, 48, "yuv420p", SWS_BICUBIC | BX, tune=dict(no_rgbsrc=1))[0] == "main:fused_generic_unity"
+
+
+def test_full_size_frames():
+    for src, dst in (("rgb24", "yuv420p"), ("bgra", "nv12")):
+        assert run_case(1920, 1080, src, 1920, 1080, dst, SWS_BICUBIC | BX, seed=2)[0] == PATH
+    assert run_case(3840, 2160, "rgb24", 3840, 2160, "yuv420p", SWS_BILINEAR | BX, seed=3)[0] == PATH
