@@ -340,10 +340,31 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         if (d->unity_h && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32) && p.chr_half && !p.range_active && !p.need_alpha && !p.no_chroma &&
             !p.wide && !p.dst_alpha_fill && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_NV12) && p.dst_bits == 8 && p.chrDstHSub == 1 && p.chrDstVSub <= 1 &&
             p.chrSrcVSub == 0 && p.srcH == p.dstH && bank_is_identity(c->vLum, 1 << 12) && c->vChr.size <= 16 && p.chrDstW == ((p.dstW + 1) >> 1) &&
-            !c->tune.no_rgbsrc) {
+            !p.should_dither && !c->tune.no_rgbsrc) {
             bool fwd = true;
             for (int y = 0; y < c->vChr.count && fwd; y++) fwd = c->vChr.pos[y] >= 0 && (y == 0 || c->vChr.pos[y] >= c->vChr.pos[y - 1]);
-            d->rgbsrc_ok = fwd;
+            if (fwd) {
+                const bool x_form = p.dstKind == DSTK_NV12 || c->vChr.size > 1;   // yuv2nv12cX_c has no one-tap form
+                std::vector<SwsRgbSrcRow> rows((size_t)c->vChr.count);
+                for (int y = 0; y < c->vChr.count; y++) {
+                    SwsRgbSrcRow &e = rows[(size_t)y];
+                    std::memset(&e, 0, sizeof(e));
+                    e.first = std::max(1 - c->vChr.size, c->vChr.pos[y]);
+                    e.last = e.first + c->vChr.size - 1;
+                    for (int j = 0; j < c->vChr.size; j++)
+                        e.vt[j >> 1] |= (uint32_t)(uint16_t)(x_form ? c->vChr.taps[(size_t)y * c->vChr.size + j] : 1) << (16 * (j & 1));
+                }
+                const size_t bytes = rows.size() * sizeof(SwsRgbSrcRow);
+                if (bytes > d->dot2_bytes) {
+                    if (d->d_dot2) HIPCHK(hipFree(d->d_dot2));
+                    d->d_dot2 = nullptr;
+                    HIPCHK(hipMalloc(&d->d_dot2, bytes));
+                    d->dot2_bytes = bytes;
+                }
+                HIPCHK(hipMemcpy(d->d_dot2, rows.data(), bytes, hipMemcpyHostToDevice));
+                d->rgbsrc_rows = (const SwsRgbSrcRow *)d->d_dot2;
+                d->rgbsrc_ok = true;
+            }
         }
         // ---- dot2 tile kernel (sws_k_tile_dot2): planar 8-bit / <= 15-bit sources, 15-bit intermediates, vfs >= 2 ----
         d->dot2_ok = false;

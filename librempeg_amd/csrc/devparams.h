@@ -115,6 +115,13 @@ struct SwsStripRow {         // marching strip kernel: the scalars of one output
     int32_t pad1[4];
 };
 
+struct SwsRgbSrcRow {        // sws_k_rgbsrc_unity: the scalars of one chroma output row (64 bytes, through the scalar data cache)
+    int32_t first, last;      // chroma source rows of the vertical window: max(1 - vfs, vpos) and first + vfs - 1, both before clamping to the plane
+    int32_t pad0[2];
+    uint32_t vt[8];           // taps j, j + 1 as a pair of int16 (1 for the one-tap yuv2plane1 form), zero beyond the filter
+    int32_t pad1[4];
+};
+
 struct SwsStripGeom {        // marching strip kernel (kernels_strip.hpp), per plane class
     int32_t TW, strips, NCmax;            // output columns per strip (64 per lane column), strips per row, max window width (samples)
     int32_t nph, npv;                     // tap pairs that can be non-zero (<= hfs2 / 2, vfs2 / 2)

@@ -27,6 +27,7 @@ struct DeviceState {
     void *d_be = nullptr; size_t be_bytes = 0;   // little-endian copies of big-endian source pictures
     void *d_xyz = nullptr; size_t xyz_bytes = 0; void *d_xyz_tab = nullptr;   // rgb48 copies of xyz12 source pictures; the four gamma LUTs
     bool dot2_ok = false; SwsTileGeom dotL, dotC; void *d_dot2 = nullptr; size_t dot2_bytes = 0;
+    const SwsRgbSrcRow *rgbsrc_rows = nullptr;             // (in d_dot2)
     bool rgbsrc_ok = false;                                // sws_k_rgbsrc_unity (packed 24 / 32 bpp RGB -> 8-bit 4:2:x YUV of the same size)
     bool strip_ok = false; SwsStripGeom stripL, stripC;    // sws_k_strip_march (tables live in d_dot2)
     bool striprgb_ok = false; SwsStripGeom stripRL, stripRC; bool striprgb_long = false;   // sws_k_strip_rgb: scaled planar 8-bit YUV -> 24 / 32 bpp RGB

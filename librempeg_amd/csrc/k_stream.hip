@@ -56,6 +56,7 @@ int launch_rgbsrc(const LaunchCtx &L)
     swsk::RgbSrcGeom g;
     g.band_rows = (cdiv(p.dstH, bands) + 1) & ~1;
     g.bands = cdiv(p.dstH, g.band_rows);
+    g.rows = L.d->rgbsrc_rows;
     const dim3 grid(cdiv(lanes, 256), g.bands, n);
     const bool nv = p.dstKind == DSTK_NV12;
     if (p.srcKind == SRCK_RGB24) { if (nv) hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity<3, true>), grid, blk, 0, st, fs, p, g);

@@ -12,7 +12,20 @@
 
 namespace swsk {
 
-struct RgbSrcGeom { int32_t band_rows, bands; };
+struct RgbSrcGeom { int32_t band_rows, bands; const SwsRgbSrcRow *rows; };
+
+// One row entry through the scalar data cache (s_load_dwordx*): loads from the constant address space, because a plain load inside a loop
+// that also stores to global memory is not provably unclobbered and becomes a vector load with a full memory latency in the dependence chain.
+__device__ __forceinline__ SwsRgbSrcRow load_rgbsrc_row(const SwsRgbSrcRow *rows, int idx)
+{
+    typedef const uint32_t __attribute__((address_space(4))) *cptr;
+    cptr q = (cptr)(uintptr_t)(rows + idx);
+    SwsRgbSrcRow e;
+    e.first = (int)q[0]; e.last = (int)q[1];
+#pragma unroll
+    for (int k = 0; k < 8; k++) e.vt[k] = q[4 + k];
+    return e;
+}
 
 template <int BPP, bool NV>
 __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDevParams p, RgbSrcGeom g)
@@ -27,15 +40,13 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
     int cy = y0 >> vs;
     const int cy1 = min(cH, (y1 + (1 << vs) - 1) >> vs);
     const int vfs = U(p.vChrFs);
-    const int32_t *vpos = U(p.vChrPos);
-    const int16_t *vF = U(p.vChrF);
+    const SwsRgbSrcRow *rows = U(g.rows);
     const int hshift = U(p.hshift), hclip = U(p.hclip);
-    const bool sd = p.should_dither;
-    auto first_of = [&](int c) { return max(1 - vfs, vpos[c]); };
     auto clampc = [&](int r) { return min(max(r, 0), cSH - 1); };
-    int clast = cy < cy1 ? clampc(first_of(cy) + vfs - 1) : -1;
-    const int cfirst = cy < cy1 ? clampc(first_of(cy)) : 0x7fffffff;
-    const int rlo = min(y0, cfirst), rhi = cy < cy1 ? max(y1 - 1, clampc(first_of(cy1 - 1) + vfs - 1)) : y1 - 1;
+    SwsRgbSrcRow e = load_rgbsrc_row(rows, min(cy, cH - 1));
+    int clast = cy < cy1 ? clampc(e.last) : -1;
+    const int cfirst = cy < cy1 ? clampc(e.first) : 0x7fffffff;
+    const int rlo = min(y0, cfirst), rhi = cy < cy1 ? max(y1 - 1, clampc(load_rgbsrc_row(rows, cy1 - 1).last)) : y1 - 1;
 
     // per-byte coefficients: rgb24 has r / b at byte 0 / 2 or 2 / 0; the 32-bit rows have every component at any of the four bytes
     const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);
@@ -50,19 +61,25 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
     const int uplane = U(p.u_plane_dst), vplane = U(p.v_plane_dst);
     const uint8_t *s0 = f.src[0];
     const int64_t sst = f.srcStride[0];
+    // (the next row's load is issued before this row's arithmetic and stores: the compiler cannot move a load above a store that may alias)
+    uint32_t nx[4] = {};
+    auto fetch = [&](int r) {
+        const uint8_t *row = s0 + (int64_t)r * sst + (int64_t)BPP * x0;
+        if (BPP == 3) { nx[0] = ((const uint32_t *)row)[0]; nx[1] = ((const uint32_t *)row)[1]; nx[2] = ((const uint32_t *)row)[2]; }
+        else { const uint4 q = *(const uint4 *)row; nx[0] = q.x; nx[1] = q.y; nx[2] = q.z; nx[3] = q.w; }
+    };
+    if (full) fetch(rlo);
     for (int r = rlo; r <= rhi; r++) {
         // ---- the row's four pixels (and, for a ragged width, the partner of the last odd pixel: the half readers read it too) ----
         uint32_t b[4][4] = {};
         const uint8_t *row = s0 + (int64_t)r * sst + (int64_t)BPP * x0;
         if (full) {
+            const uint32_t d[4] = { nx[0], nx[1], nx[2], nx[3] };
+            if (r < rhi) fetch(r + 1);
             if (BPP == 3) {
-                const uint32_t d0 = ((const uint32_t *)row)[0], d1 = ((const uint32_t *)row)[1], d2 = ((const uint32_t *)row)[2];
-                const uint32_t d[3] = { d0, d1, d2 };
 #pragma unroll
                 for (int i = 0; i < 12; i++) b[i / 3][i % 3] = (d[i >> 2] >> (8 * (i & 3))) & 0xFF;
             } else {
-                const uint4 q = *(const uint4 *)row;
-                const uint32_t d[4] = { q.x, q.y, q.z, q.w };
 #pragma unroll
                 for (int i = 0; i < 16; i++) b[i >> 2][i & 3] = (d[i >> 2] >> (8 * (i & 3))) & 0xFF;
             }
@@ -83,7 +100,7 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
                 else yr = (uint16_t)(((unsigned)cy_[0] * b[k][0] + (unsigned)cy_[1] * b[k][1] + (unsigned)cy_[2] * b[k][2] + (unsigned)cy_[3] * b[k][3] +
                                       ((32u << 22) + (1u << 16))) >> 17);
                 const int y15 = (int16_t)min((yr * 16384) >> hshift, hclip);
-                out |= (uint32_t)clip_u8_shr(y15 + dither8(sd, r, x0 + k), 7) << (8 * k);
+                out |= (uint32_t)clip_u8_shr(y15 + 64, 7) << (8 * k);   // (8-bit sources: no dither pattern, swscale.c:292-293)
             }
             uint8_t *drow = f.dst[0] + (int64_t)r * f.dstStride[0] + x0;
             if (full) *(uint32_t *)drow = out;
@@ -113,21 +130,19 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
         }
         // ---- every chroma output row whose last source row this was ----
         while (cy < cy1 && clast <= r) {
-            const int first = first_of(cy);
-            int au[2], av[2];
             const bool x_form = NV || vfs > 1;
+            int au[2], av[2];
+            au[0] = au[1] = av[0] = av[1] = x_form ? 64 << 12 : 64;
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int c = 2 * t + k;
-                au[k] = x_form ? dither8(sd, cy, c) << 12 : dither8(sd, cy, c);
-                av[k] = x_form ? dither8(sd, cy, c + 3) << 12 : dither8(sd, cy, c + 3);
-            }
-            for (int j = 0; j < vfs; j++) {
-                const uint2 q = ring[clampc(first + j) & 15][tid];
-                const int w = x_form ? (int)vF[cy * vfs + j] : 1;
-                au[0] += (int)(unsigned)((int)(int16_t)(q.x & 0xFFFF) * w); av[0] += (int)(unsigned)((int)(int16_t)(q.x >> 16) * w);
-                au[1] += (int)(unsigned)((int)(int16_t)(q.y & 0xFFFF) * w); av[1] += (int)(unsigned)((int)(int16_t)(q.y >> 16) * w);
-            }
+            for (int jp = 0; jp < 8; jp++)
+                if (2 * jp < vfs) {   // (a tap past an odd filter length is zero: its slot may hold anything)
+                    const uint2 q0 = ring[clampc(e.first + 2 * jp) & 15][tid], q1 = ring[clampc(e.first + 2 * jp + 1) & 15][tid];
+                    const int w0 = (int16_t)(e.vt[jp] & 0xFFFF), w1 = (int16_t)(e.vt[jp] >> 16);
+                    au[0] += (int)(unsigned)((int)(int16_t)(q0.x & 0xFFFF) * w0) + (int)(unsigned)((int)(int16_t)(q1.x & 0xFFFF) * w1);
+                    av[0] += (int)(unsigned)((int)(int16_t)(q0.x >> 16) * w0) + (int)(unsigned)((int)(int16_t)(q1.x >> 16) * w1);
+                    au[1] += (int)(unsigned)((int)(int16_t)(q0.y & 0xFFFF) * w0) + (int)(unsigned)((int)(int16_t)(q1.y & 0xFFFF) * w1);
+                    av[1] += (int)(unsigned)((int)(int16_t)(q0.y >> 16) * w0) + (int)(unsigned)((int)(int16_t)(q1.y >> 16) * w1);
+                }
             const int sh = x_form ? 19 : 7;
             const uint32_t u0 = clip_u8_shr(au[0], sh), u1 = clip_u8_shr(au[1], sh), v0 = clip_u8_shr(av[0], sh), v1 = clip_u8_shr(av[1], sh);
             if (NV) {
@@ -143,7 +158,8 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
                 else { du[0] = (uint8_t)u0; dv[0] = (uint8_t)v0; }
             }
             cy++;
-            clast = cy < cy1 ? clampc(first_of(cy) + vfs - 1) : 0x7fffffff;
+            if (cy < cy1) { e = load_rgbsrc_row(rows, cy); clast = clampc(e.last); }
+            else clast = 0x7fffffff;
         }
     }
 }
