@@ -342,6 +342,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             p.chrSrcVSub == 0 && p.srcH == p.dstH && bank_is_identity(c->vLum, 1 << 12) && c->vChr.size <= 16 && p.chrDstW == ((p.dstW + 1) >> 1) &&
             !p.should_dither && !c->tune.no_rgbsrc) {
             bool fwd = true;
+            for (int k = 0; k < 9; k++) fwd = fwd && p.rgb2yuv[k] > -32768 && p.rgb2yuv[k] < 32768;   // (v_dot2_i32_i16 operands)
             for (int y = 0; y < c->vChr.count && fwd; y++) fwd = c->vChr.pos[y] >= 0 && (y == 0 || c->vChr.pos[y] >= c->vChr.pos[y - 1]);
             if (fwd) {
                 const bool x_form = p.dstKind == DSTK_NV12 || c->vChr.size > 1;   // yuv2nv12cX_c has no one-tap form

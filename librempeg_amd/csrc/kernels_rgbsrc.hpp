@@ -9,6 +9,7 @@
 // of an output row is read once its last source row has passed.  No barriers: a lane only ever reads what it wrote.
 #pragma once
 #include "kernels_common.hpp"
+#include "wave_util.hpp"
 
 namespace swsk {
 
@@ -34,7 +35,7 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
     const int tid = threadIdx.x, t = blockIdx.x * 256 + tid;
     const int W = U(p.dstW), H = U(p.dstH), x0 = 4 * t;
     if (x0 >= W) return;
-    const SwsFramePtrs f = frame_copy(fs, blockIdx.z);
+    const FrameRegs f = load_frame(fs, blockIdx.z);   // (wave-uniform: the row addressing stays on the scalar unit)
     const int vs = U(p.chrDstVSub), cW = U(p.chrDstW), cH = U(p.chrDstH), cSH = U(p.chrSrcH);
     const int y0 = blockIdx.y * U(g.band_rows), y1 = min(H, y0 + U(g.band_rows));
     int cy = y0 >> vs;
@@ -48,13 +49,14 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
     const int cfirst = cy < cy1 ? clampc(e.first) : 0x7fffffff;
     const int rlo = min(y0, cfirst), rhi = cy < cy1 ? max(y1 - 1, clampc(load_rgbsrc_row(rows, cy1 - 1).last)) : y1 - 1;
 
-    // per-byte coefficients: rgb24 has r / b at byte 0 / 2 or 2 / 0; the 32-bit rows have every component at any of the four bytes
+    // per-byte coefficients: rgb24 has r / b at byte 0 / 2 or 2 / 0; the 32-bit rows have every component at any of the four bytes.  Packed for
+    // v_dot2_i32_i16 against a pixel split into {byte 0, byte 2} and {byte 1, byte 3} halves (every coefficient fits int16: host check)
     const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);
     const int rp = U(p.src_r_pos), gp = BPP == 3 ? 1 : U(p.src_g_pos), bp = U(p.src_b_pos);
-    auto coef = [&](const Rgb2YuvRow &w, int k) { const int v = k == rp ? w.r : k == gp ? w.g : k == bp ? w.b : 0; return BPP == 3 ? v : (int)((unsigned)v << 8); };
-    int cy_[4], cu_[4], cv_[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { cy_[k] = coef(ty, k); cu_[k] = coef(tu, k); cv_[k] = coef(tv, k); }
+    auto coef = [&](const Rgb2YuvRow &w, int k) { return (uint32_t)(uint16_t)(k == rp ? w.r : k == gp ? w.g : k == bp ? w.b : 0); };
+    const uint32_t cyA = coef(ty, 0) | coef(ty, 2) << 16, cyB = coef(ty, 1) | coef(ty, 3) << 16;
+    const uint32_t cuA = coef(tu, 0) | coef(tu, 2) << 16, cuB = coef(tu, 1) | coef(tu, 3) << 16;
+    const uint32_t cvA = coef(tv, 0) | coef(tv, 2) << 16, cvB = coef(tv, 1) | coef(tv, 3) << 16;
 
     const bool full = x0 + 4 <= W;                     // (the last group of a ragged width goes byte by byte)
     const int ncol = min(2, cW - 2 * t);               // chroma columns of this lane
@@ -71,34 +73,40 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
     if (full) fetch(rlo);
     for (int r = rlo; r <= rhi; r++) {
         // ---- the row's four pixels (and, for a ragged width, the partner of the last odd pixel: the half readers read it too) ----
-        uint32_t b[4][4] = {};
+        uint32_t lo[4], hi[4];     // per pixel: {byte 0, byte 2} and {byte 1, byte 3 (0 for 24 bpp)} as 16-bit halves
         const uint8_t *row = s0 + (int64_t)r * sst + (int64_t)BPP * x0;
         if (full) {
             const uint32_t d[4] = { nx[0], nx[1], nx[2], nx[3] };
             if (r < rhi) fetch(r + 1);
             if (BPP == 3) {
-#pragma unroll
-                for (int i = 0; i < 12; i++) b[i / 3][i % 3] = (d[i >> 2] >> (8 * (i & 3))) & 0xFF;
+                lo[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c020c00u); hi[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c01u);
+                lo[1] = __builtin_amdgcn_perm(d[1], d[0], 0x0c050c03u); hi[1] = __builtin_amdgcn_perm(d[1], d[0], 0x0c0c0c04u);
+                lo[2] = __builtin_amdgcn_perm(d[2], d[1], 0x0c040c02u); hi[2] = __builtin_amdgcn_perm(d[2], d[1], 0x0c0c0c03u);
+                lo[3] = __builtin_amdgcn_perm(d[2], d[2], 0x0c030c01u); hi[3] = __builtin_amdgcn_perm(d[2], d[2], 0x0c0c0c02u);
             } else {
 #pragma unroll
-                for (int i = 0; i < 16; i++) b[i >> 2][i & 3] = (d[i >> 2] >> (8 * (i & 3))) & 0xFF;
+                for (int k = 0; k < 4; k++) { lo[k] = d[k] & 0x00FF00FFu; hi[k] = (d[k] >> 8) & 0x00FF00FFu; }
             }
         } else {
             const int npx = min(4, ((W - x0) + 1) & ~1);
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int j = 0; j < BPP; j++) b[k][j] = k < npx ? row[BPP * k + j] : 0;
+            for (int k = 0; k < 4; k++) {
+                lo[k] = hi[k] = 0;
+                if (k < npx) {
+                    lo[k] = row[BPP * k] | (uint32_t)row[BPP * k + 2] << 16;
+                    hi[k] = row[BPP * k + 1] | (BPP == 4 ? (uint32_t)row[BPP * k + 3] << 16 : 0u);
+                }
+            }
         }
         // ---- luma: reader -> identity hscale -> yuv2plane1_8_c ----
         if (r >= y0 && r < y1) {
             uint32_t out = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
+                const int S = sdot2(lo[k], cyA, sdot2_first_s(hi[k], cyB));
                 int yr;
-                if (BPP == 3) yr = (uint16_t)((cy_[0] * (int)b[k][0] + cy_[1] * (int)b[k][1] + cy_[2] * (int)b[k][2] + (32 << 14) + (1 << 8)) >> 9);
-                else yr = (uint16_t)(((unsigned)cy_[0] * b[k][0] + (unsigned)cy_[1] * b[k][1] + (unsigned)cy_[2] * b[k][2] + (unsigned)cy_[3] * b[k][3] +
-                                      ((32u << 22) + (1u << 16))) >> 17);
+                if (BPP == 3) yr = (uint16_t)((S + (32 << 14) + (1 << 8)) >> 9);
+                else yr = (uint16_t)((((unsigned)S << 8) + ((32u << 22) + (1u << 16))) >> 17);
                 const int y15 = (int16_t)min((yr * 16384) >> hshift, hclip);
                 out |= (uint32_t)clip_u8_shr(y15 + 64, 7) << (8 * k);   // (8-bit sources: no dither pattern, swscale.c:292-293)
             }
@@ -106,27 +114,26 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
             if (full) *(uint32_t *)drow = out;
             else for (int k = 0; k < W - x0; k++) drow[k] = (uint8_t)(out >> (8 * k));
         }
-        // ---- chroma: the half readers on the two pixel pairs -> identity hscale -> ring ----
+        // ---- chroma: the half readers on the two pixel pairs (byte sums stay inside their 16-bit halves) -> identity hscale -> ring ----
         if (r >= cfirst && r < cSH) {
-            uint32_t e[2];
+            uint32_t e2[2];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
+                const uint32_t al = lo[2 * k] + lo[2 * k + 1], ah = hi[2 * k] + hi[2 * k + 1];
+                const int Su = sdot2(al, cuA, sdot2_first_s(ah, cuB)), Sv = sdot2(al, cvA, sdot2_first_s(ah, cvB));
                 int ur, vr;
                 if (BPP == 3) {
-                    const int a0 = b[2 * k][0] + b[2 * k + 1][0], a1 = b[2 * k][1] + b[2 * k + 1][1], a2 = b[2 * k][2] + b[2 * k + 1][2];
-                    ur = (uint16_t)((cu_[0] * a0 + cu_[1] * a1 + cu_[2] * a2 + (256 << 15) + (1 << 9)) >> 10);
-                    vr = (uint16_t)((cv_[0] * a0 + cv_[1] * a1 + cv_[2] * a2 + (256 << 15) + (1 << 9)) >> 10);
+                    ur = (uint16_t)((Su + (256 << 15) + (1 << 9)) >> 10);
+                    vr = (uint16_t)((Sv + (256 << 15) + (1 << 9)) >> 10);
                 } else {
-                    const unsigned a0 = b[2 * k][0] + b[2 * k + 1][0], a1 = b[2 * k][1] + b[2 * k + 1][1], a2 = b[2 * k][2] + b[2 * k + 1][2],
-                                   a3 = b[2 * k][3] + b[2 * k + 1][3];
                     const unsigned rnd = (256u << 23) + (1u << 17);
-                    ur = (uint16_t)(((unsigned)cu_[0] * a0 + (unsigned)cu_[1] * a1 + (unsigned)cu_[2] * a2 + (unsigned)cu_[3] * a3 + rnd) >> 18);
-                    vr = (uint16_t)(((unsigned)cv_[0] * a0 + (unsigned)cv_[1] * a1 + (unsigned)cv_[2] * a2 + (unsigned)cv_[3] * a3 + rnd) >> 18);
+                    ur = (uint16_t)((((unsigned)Su << 8) + rnd) >> 18);
+                    vr = (uint16_t)((((unsigned)Sv << 8) + rnd) >> 18);
                 }
                 const int u15 = (int16_t)min((ur * 16384) >> hshift, hclip), v15 = (int16_t)min((vr * 16384) >> hshift, hclip);
-                e[k] = (uint32_t)(uint16_t)u15 | (uint32_t)(uint16_t)v15 << 16;
+                e2[k] = (uint32_t)(uint16_t)u15 | (uint32_t)(uint16_t)v15 << 16;
             }
-            ring[r & 15][tid] = make_uint2(e[0], e[1]);
+            ring[r & 15][tid] = make_uint2(e2[0], e2[1]);
         }
         // ---- every chroma output row whose last source row this was ----
         while (cy < cy1 && clast <= r) {
