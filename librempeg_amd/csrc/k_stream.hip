@@ -45,24 +45,26 @@ int launch_f32rgb(const LaunchCtx &L)
     return 0;
 }
 
-// packed RGB -> planar / semi-planar 8-bit YUV of the same size: lanes of four luma columns, bands of rows sized for about 4096 waves
+// packed RGB -> planar / semi-planar 8-bit YUV of the same size: lanes of four luma columns, bands of rows sized for about 8192 waves (eight per SIMD)
 int launch_rgbsrc(const LaunchCtx &L)
 {
     const SwsDevParams &p = *L.p; hipStream_t st = L.st; const SwsFrameSet &fs = L.fs;
     const int n = L.n;
     const dim3 blk(256);
     const int lanes = cdiv(p.dstW, 4), waves_row = cdiv(lanes, 64);
-    int bands = std::max(1, std::min((int)cdiv(4096, waves_row * n), (int)cdiv(p.dstH, 8)));
+    int bands = std::max(1, std::min((int)cdiv(8192, waves_row * n), (int)cdiv(p.dstH, 8)));
     swsk::RgbSrcGeom g;
     g.band_rows = (cdiv(p.dstH, bands) + 1) & ~1;
     g.bands = cdiv(p.dstH, g.band_rows);
     g.rows = L.d->rgbsrc_rows;
     const dim3 grid(cdiv(lanes, 256), g.bands, n);
     const bool nv = p.dstKind == DSTK_NV12;
-    if (p.srcKind == SRCK_RGB24) { if (nv) hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity<3, true>), grid, blk, 0, st, fs, p, g);
-                                   else    hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity<3, false>), grid, blk, 0, st, fs, p, g); }
-    else                         { if (nv) hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity<4, true>), grid, blk, 0, st, fs, p, g);
-                                   else    hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity<4, false>), grid, blk, 0, st, fs, p, g); }
+    const bool r8 = p.vChrFs <= 8;
+#define SWS_RGBSRC(B, N) do { if (r8) hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity<B, N, 8>), grid, blk, 0, st, fs, p, g); \
+                              else    hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity<B, N, 16>), grid, blk, 0, st, fs, p, g); } while (0)
+    if (p.srcKind == SRCK_RGB24) { if (nv) SWS_RGBSRC(3, true); else SWS_RGBSRC(3, false); }
+    else                         { if (nv) SWS_RGBSRC(4, true); else SWS_RGBSRC(4, false); }
+#undef SWS_RGBSRC
     return 0;
 }
 

@@ -4,7 +4,7 @@
 // yuv2nv12cX_c for the vertically scaled chroma (:438-466, :495-528).
 //
 // Each lane owns four luma columns (= two chroma columns of the "half" chroma readers) and walks down a band of rows: one 12- or
-// 16-byte load per source row, four luma bytes stored as one dword.  The two {U, V} pairs of the row go into a 16-deep ring of
+// 16-byte load per source row, four luma bytes stored as one dword.  The two {U, V} pairs of the row go into a 16-deep (8-deep for short filters) ring of
 // lane-private LDS slots - LDS as a register file that can be indexed by a run-time row number - from which the vertical chroma filter
 // of an output row is read once its last source row has passed.  No barriers: a lane only ever reads what it wrote.
 #pragma once
@@ -28,10 +28,10 @@ __device__ __forceinline__ SwsRgbSrcRow load_rgbsrc_row(const SwsRgbSrcRow *rows
     return e;
 }
 
-template <int BPP, bool NV>
+template <int BPP, bool NV, int RING>
 __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDevParams p, RgbSrcGeom g)
 {
-    __shared__ uint2 ring[16][256];
+    __shared__ uint2 ring[RING][256];     // RING = 8 when the vertical chroma filter has at most 8 taps: 16 KB, six waves per SIMD
     const int tid = threadIdx.x, t = blockIdx.x * 256 + tid;
     const int W = U(p.dstW), H = U(p.dstH), x0 = 4 * t;
     if (x0 >= W) return;
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
                 const int u15 = (int16_t)min((ur * 16384) >> hshift, hclip), v15 = (int16_t)min((vr * 16384) >> hshift, hclip);
                 e2[k] = (uint32_t)(uint16_t)u15 | (uint32_t)(uint16_t)v15 << 16;
             }
-            ring[r & 15][tid] = make_uint2(e2[0], e2[1]);
+            ring[r & (RING - 1)][tid] = make_uint2(e2[0], e2[1]);
         }
         // ---- every chroma output row whose last source row this was ----
         while (cy < cy1 && clast <= r) {
@@ -141,9 +141,9 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
             int au[2], av[2];
             au[0] = au[1] = av[0] = av[1] = x_form ? 64 << 12 : 64;
 #pragma unroll
-            for (int jp = 0; jp < 8; jp++)
+            for (int jp = 0; jp < RING / 2; jp++)
                 if (2 * jp < vfs) {   // (a tap past an odd filter length is zero: its slot may hold anything)
-                    const uint2 q0 = ring[clampc(e.first + 2 * jp) & 15][tid], q1 = ring[clampc(e.first + 2 * jp + 1) & 15][tid];
+                    const uint2 q0 = ring[clampc(e.first + 2 * jp) & (RING - 1)][tid], q1 = ring[clampc(e.first + 2 * jp + 1) & (RING - 1)][tid];
                     const int w0 = (int16_t)(e.vt[jp] & 0xFFFF), w1 = (int16_t)(e.vt[jp] >> 16);
                     au[0] += (int)(unsigned)((int)(int16_t)(q0.x & 0xFFFF) * w0) + (int)(unsigned)((int)(int16_t)(q1.x & 0xFFFF) * w1);
                     av[0] += (int)(unsigned)((int)(int16_t)(q0.x >> 16) * w0) + (int)(unsigned)((int)(int16_t)(q1.x >> 16) * w1);
