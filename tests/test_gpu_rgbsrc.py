@@ -21,7 +21,7 @@ def test_formats(src, dst):
     for (w, h) in ((256, 64), (322, 50), (129, 33), (67, 18), (1026, 21)):
         path, _ = run_case(w, h, src, w, h, dst, SWS_BICUBIC | BX, seed=w)
         # (a yuvj destination is a range conversion: the generic kernels keep it)
-        if not w & 1:     # (odd widths: the chroma filter bank is not the identity)
+        if not w & 1:     # (odd widths: the chroma readers are not the "half" forms, chroma is scaled horizontally)
             want = "main:fused_generic_unity" if dst == "yuvj420p" else PATH
             if (src, dst) == ("bgr24", "yuv420p"):
                 want = "unscaled:bgr24ToYv12"     # the reference's special converter (bgr24ToYv12Wrapper, swscale_unscaled.c:2062-2077)
