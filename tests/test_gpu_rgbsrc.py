@@ -53,3 +53,36 @@ def test_full_size_frames():
     for src, dst in (("rgb24", "yuv420p"), ("bgra", "nv12")):
         assert run_case(1920, 1080, src, 1920, 1080, dst, SWS_BICUBIC | BX, seed=2)[0] == PATH
     assert run_case(3840, 2160, "rgb24", 3840, 2160, "yuv420p", SWS_BILINEAR | BX, seed=3)[0] == PATH
+
+
+def test_batches_bands_and_host_frames():
+    """several frames per sws_scale_frames() call (grid z), a picture tall enough for many bands per frame (the chroma ring is primed from
+    rows above the band), and the host-pointer entry (sws_scale() on pageable memory)."""
+    import numpy as np
+    import torch
+    import oracle_lib as OL
+    from librempeg_amd import SwsContext, HostFrame, DeviceFrame
+    for src, dst, w, h, n, flags in (("rgb24", "yuv420p", 260, 700, 3, SWS_LANCZOS | BX), ("bgra", "nv12", 64, 1030, 5, SWS_BICUBIC | BX),
+                                     ("argb", "yuv422p", 516, 90, 4, SWS_BILINEAR | BX)):
+        o = OL.Oracle(w, h, src, w, h, dst, flags)
+        p = SwsContext(w, h, src, w, h, dst, flags)
+        refs, srcs, dsts = [], [], []
+        for k in range(n):
+            s = OL.fill_random(OL.Frame(src, w, h), 90 + k)
+            ref = OL.Frame(dst, w, h)
+            assert o.scale(s, ref) == h
+            refs.append(ref)
+            hs = HostFrame(src, w, h)
+            for a, b in zip(hs.planes, s.planes):
+                a[:] = b
+            srcs.append(DeviceFrame(src, w, h).upload(hs))
+            dsts.append(DeviceFrame(dst, w, h))
+        torch.cuda.synchronize()
+        assert p.scale_frames(srcs, dsts) == n and p.path() == PATH
+        p.sync()
+        for k in range(n):
+            out = dsts[k].download(HostFrame(dst, w, h))
+            for a, b, rb in zip(out.planes, refs[k].planes, out.row_bytes):
+                assert np.array_equal(a[:, :rb], b[:, :rb]), (src, dst, k)
+        p.close()
+    assert run_case(322, 240, "rgba", 322, 240, "nv21", SWS_BICUBIC | BX, seed=4, device_frames=False)[0] == PATH
