@@ -211,7 +211,7 @@ def run_workload(name, batch, steps, warmup, rank, world, device_index, barrier)
     t1 = time.perf_counter()
     kernel_ms = [a.elapsed_time(c) for a, c in ev]
     res = dict(name=name, desc=desc, batch=batch, wall_s=t1 - t0, kernel_ms_avg=float(np.mean(kernel_ms)),
-               kernel_ms_min=float(np.min(kernel_ms)), path=path, kernel=ctx.kernel_name(),
+               kernel_ms_min=float(np.min(kernel_ms)), kernel_ms_median=float(np.median(kernel_ms)), path=path, kernel=ctx.kernel_name(),
                out_pixels_per_step=batch * dw * dh, alg_bytes_per_step=batch * algorithmic_bytes(sw, sh, sf, dw, dh, df))
     del srcs, dsts
     ctx.close()
@@ -219,9 +219,25 @@ def run_workload(name, batch, steps, warmup, rank, world, device_index, barrier)
     return res
 
 
-def cpu_baseline(name, seconds=10.0):
-    """The oracle ("port" of the reference C path) timed on this host: 1 thread and all cores, frame-parallel with
-    one context per thread (sws_scale itself never multi-threads)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+# port / reference, one thread: the oracle's time per frame over a C-only build of the real reference (no SIMD: --disable-asm), measured
+# by the round-2 review in a container of this class -- before oracle/ got the reference's own loop shape for the C2a converter (then
+# 6.6x; now see "c2a" below) -- and the SURVEY's own anchors (SURVEY.md 8d "Sanity anchors") for the reference's ms / frame.
+REFERENCE_MS_PER_FRAME_1T = {"c1": 3.3, "c2a": 9.95, "c2b": 81.0, "c3a": 29.0, "c3b": 220.0, "c4": 17.0, "c5": 530.0}
+
+
+def cpu_leg(name, seconds, nthreads_list):
+    """The oracle ("port" of the reference C path) timed on this host for one workload: frame-parallel with one context per thread
+    (sws_scale itself never multi-threads).  Returns {threads: (frames, Mpix/s, ms per frame and thread)}."""
     import oracle_lib as OL
     sw, sh, sf, dw, dh, df, flags, cs, _, desc = WORKLOADS[name]
     OL.lib()
@@ -242,33 +258,54 @@ def cpu_baseline(name, seconds=10.0):
         while True:
             o.scale(src, dst)
             n += 1
-            if time.perf_counter() >= deadline and n >= 3:
+            if time.perf_counter() >= deadline and n >= 2:
                 break
         out[idx] = (n, time.perf_counter() - t0)
 
-    def run(nthreads):
+    res = {}
+    for nthreads in nthreads_list:
         out = [None] * nthreads
         deadline = time.perf_counter() + seconds
         th = [threading.Thread(target=worker, args=(out, i, deadline)) for i in range(nthreads)]
-        t0 = time.perf_counter()
         for t in th:
             t.start()
         for t in th:
             t.join()
-        wall = time.perf_counter() - t0
         frames = sum(n for n, _ in out)
-        # per-thread rates summed (each thread times its own loop; setup/fill excluded)
-        rate = sum(n / dt for n, dt in out)
-        return frames, wall, rate * dw * dh / 1e6
+        rate = sum(n / dt for n, dt in out)          # per-thread rates summed (each thread times its own loop; setup / fill excluded)
+        res[nthreads] = (frames, rate * dw * dh / 1e6, 1e3 * nthreads / rate)
+    return res
 
+
+def cpu_baseline(name, seconds=6.0, others=("c1", "c2b", "c3b", "c4", "c5"), other_seconds=1.5):
+    """cpu_baseline of the JSON line: the headline workload on 1 thread and on all host cores, plus one short leg per other BASELINE
+    configuration (C1 is BASELINE's CPU-only configuration)."""
     cores = os.cpu_count() or 1
-    f1, w1, mp1 = run(1)
-    fN, wN, mpN = run(cores) if cores > 1 else (f1, w1, mp1)
-    return {"value": round(mpN, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "value_1core": round(mp1, 2),
-            "sample": f"{desc}; oracle/ (scalar C restatement of the reference C path, gcc -O3 -fno-tree-vectorize like "
-                      f"the reference's own flags), ~{seconds:.0f}s per leg: {f1} frames on 1 thread, {fN} frames on {cores} "
-                      f"threads (one context per thread)"}
+    tl = [1, cores] if cores > 1 else [1]
+    desc = WORKLOADS[name][9]
+    r = cpu_leg(name, seconds, tl)
+    f1, mp1, ms1 = r[1]
+    fN, mpN, msN = r[tl[-1]]
+    ref = REFERENCE_MS_PER_FRAME_1T.get(name)
+    configs = {}
+    for o in others:
+        if o == name:
+            continue
+        ro = cpu_leg(o, other_seconds, tl)
+        configs[o] = {"workload": WORKLOADS[o][9], "value_1thread": round(ro[1][1], 2), "ms_per_frame_1thread": round(ro[1][2], 2),
+                      "value_all_threads": round(ro[tl[-1]][1], 2), "frames_timed": [ro[1][0], ro[tl[-1]][0]], "unit": "Mpixels/s",
+                      "reference_c_ms_per_frame_1thread_other_host": REFERENCE_MS_PER_FRAME_1T.get(o)}
+    return {"value": round(mpN, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "value_1thread": round(mp1, 2), "ms_per_frame_1thread": round(ms1, 2),
+            "reference_c_ms_per_frame_1thread_other_host": ref,
+            "configs": configs,
+            "sample": f"{desc}; oracle/ = scalar C restatement of the reference's C path (gcc -O3 -fno-tree-vectorize like the reference's "
+                      f"own flags; the C2a converter in the reference's own loop shape), ~{seconds:.0f}s per leg: {f1} frames on 1 thread "
+                      f"({ms1:.2f} ms/frame), {fN} frames on {cores} threads (one context per thread, pinned).  A C-only build of the real "
+                      f"reference needs {ref} ms/frame for this workload on one core of the build container (round-2 review / SURVEY 8d): "
+                      f"the port is NOT the reference's hand-written x86 SIMD, which would be faster again.  `configs`: the other BASELINE "
+                      f"configurations, {other_seconds:.1f}s per leg (whole-frame int32 intermediates there: 1.5-1.8x slower than the reference's "
+                      f"C path per the same review)"}
 
 
 def main():
@@ -280,7 +317,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (0 = workload default)")
     ap.add_argument("--variants", default="auto", help="comma list of extra workloads to time (auto: c2b when workload is c2a)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=6.0)
     ap.add_argument("--opt", action="append", default=[], help="name=value launch heuristic (sws_hip_set_option), repeatable")
     ap.add_argument("--inproc", action="store_true", help="N GPUs from ONE process: in-library sharding of sws_scale_frames() (no launcher)")
     args = ap.parse_args()
@@ -331,7 +368,7 @@ def main():
                           "cpu_baseline": None}), flush=True)
         return
     main_res = run_workload(args.workload, args.batch, args.steps, args.warmup, rank, world, local_rank, barrier)
-    variants = [] if args.variants in ("", "none") else (["c2b"] if args.variants == "auto" and args.workload == "c2a"
+    variants = [] if args.variants in ("", "none") else (["c2b", "c3b", "d1", "c1"] if args.variants == "auto" and args.workload == "c2a"
                                                           else [] if args.variants == "auto" else args.variants.split(","))
     var_res = [run_workload(v, 0, args.steps, args.warmup, rank, world, local_rank, barrier) for v in variants]
 
@@ -377,7 +414,8 @@ def main():
                        "frames_resident": "HBM"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": main_res["kernel"], "kernel_ms_avg": round(kms, 4),
+                         "kernel": main_res["kernel"], "kernel_ms_avg": round(kms, 4), "kernel_ms_min": round(main_res["kernel_ms_min"], 4),
+                         "kernel_ms_median": round(main_res["kernel_ms_median"], 4),
                          "algorithmic_bytes_per_launch": main_res["alg_bytes_per_step"]},
         }
         if main_res["name"] == "c5":
@@ -390,7 +428,8 @@ def main():
             out["variants"][r["name"]] = {"workload": r["desc"], "value": round(m2, 1), "unit": "Mpixels/s",
                                           "ms_per_step": round(w2 / args.steps * 1e3, 4), "path": r["path"], "kernel": r["kernel"],
                                           "roofline": {"bound": "hbm", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                       "frac": round(a2 / HBM_PEAK_GBS, 4), "kernel_ms_avg": round(k2, 4)}}
+                                                       "frac": round(a2 / HBM_PEAK_GBS, 4), "kernel_ms_avg": round(k2, 4),
+                                                       "kernel_ms_min": round(r["kernel_ms_min"], 4), "kernel_ms_median": round(r["kernel_ms_median"], 4)}}
     if rank == 0:
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(main_res["name"], args.cpu_seconds)

@@ -227,9 +227,9 @@ void choose_unscaled(SwsInternal *c)
     }
     // bayer_to_rgb24_wrapper / bayer_to_rgb48_wrapper / bayer_to_yv12_wrapper (:2543-2555; AV_PIX_FMT_RGB48 is the native-endian name)
     if (isBayerFmt(s) && (d == AV_PIX_FMT_RGB24 || (d == AV_PIX_FMT_RGB48LE && !c->dstBE) || d == AV_PIX_FMT_YUV420P)) { k = PLAN_UNSC_BAYER; c->dst_slice_align = 2; }
-    // palToRgbWrapper / palToGbrpWrapper (:2619-2630) for the palette-expanded sources.  (usePal() also names gray8, whose grey palette makes
-    // these wrappers a plain replication: the scaler chain gives the same bytes, tests/test_oracle_properties_extra.py)
-    if ((s == AV_PIX_FMT_PAL8 || isRGB8class(s)) && (d == AV_PIX_FMT_GBRP || d == AV_PIX_FMT_GBRAP || d == AV_PIX_FMT_RGB24 || d == AV_PIX_FMT_BGR24 ||
+    // palToRgbWrapper / palToGbrpWrapper (:2619-2630) for the palette-expanded sources.  usePal() (swscale_internal.h:937-950) also names gray8:
+    // its grey ramp (swscale.c:901-902) makes the wrapper a plain replication of the sample, whatever sws_setColorspaceDetails() was given
+    if ((s == AV_PIX_FMT_PAL8 || isRGB8class(s) || s == AV_PIX_FMT_GRAY8) && (d == AV_PIX_FMT_GBRP || d == AV_PIX_FMT_GBRAP || d == AV_PIX_FMT_RGB24 || d == AV_PIX_FMT_BGR24 ||
                                                    d == AV_PIX_FMT_RGBA || d == AV_PIX_FMT_BGRA || d == AV_PIX_FMT_ARGB || d == AV_PIX_FMT_ABGR))
         k = PLAN_UNSC_PAL2RGB;
     if (s == d || (s == AV_PIX_FMT_YUVA420P && d == AV_PIX_FMT_YUV420P) || (s == AV_PIX_FMT_YUV420P && d == AV_PIX_FMT_YUVA420P) ||
@@ -261,7 +261,7 @@ static SwsInternal *new_context();
 static SwsInternal *alloc_set_opts(int srcW, int srcH, int srcFormat, int dstW, int dstH, int dstFormat, unsigned flags, const double *param);
 static int init_context_impl(SwsInternal *c, SwsFilter *srcFilter, SwsFilter *dstFilter);
 
-static int alphaless_fmt(int fmt)   // utils.c:1060-1118 (the stored formats are the little-endian twins; gbrap* is not built)
+static int alphaless_fmt(int fmt)   // utils.c:1060-1118 (the stored formats are the little-endian twins)
 {
     switch (fmt) {
     case AV_PIX_FMT_ARGB: case AV_PIX_FMT_RGBA: return AV_PIX_FMT_RGB24;
@@ -273,6 +273,9 @@ static int alphaless_fmt(int fmt)   // utils.c:1060-1118 (the stored formats are
     case AV_PIX_FMT_YUVA420P9LE: return AV_PIX_FMT_YUV420P9LE; case AV_PIX_FMT_YUVA422P9LE: return AV_PIX_FMT_YUV422P9LE; case AV_PIX_FMT_YUVA444P9LE: return AV_PIX_FMT_YUV444P9LE;
     case AV_PIX_FMT_YUVA420P10LE: return AV_PIX_FMT_YUV420P10LE; case AV_PIX_FMT_YUVA422P10LE: return AV_PIX_FMT_YUV422P10LE; case AV_PIX_FMT_YUVA444P10LE: return AV_PIX_FMT_YUV444P10LE;
     case AV_PIX_FMT_YUVA420P16LE: return AV_PIX_FMT_YUV420P16LE; case AV_PIX_FMT_YUVA422P16LE: return AV_PIX_FMT_YUV422P16LE; case AV_PIX_FMT_YUVA444P16LE: return AV_PIX_FMT_YUV444P16LE;
+    case AV_PIX_FMT_GBRAP: return AV_PIX_FMT_GBRP;   // :1073-1085
+    case AV_PIX_FMT_GBRAP10LE: return AV_PIX_FMT_GBRP10LE; case AV_PIX_FMT_GBRAP12LE: return AV_PIX_FMT_GBRP12LE;
+    case AV_PIX_FMT_GBRAP14LE: return AV_PIX_FMT_GBRP14LE; case AV_PIX_FMT_GBRAP16LE: return AV_PIX_FMT_GBRP16LE;
     }
     return AV_PIX_FMT_NONE;
 }
@@ -375,10 +378,8 @@ int init_single_context(SwsInternal *c)
         // Gamma-correct scaling (utils.c:1461-1522): source -> RGBA64LE at the source size, RGBA64LE scaled between a pow(x, 1/2.2) and a
         // pow(x, 2.2) table pass over its R, G, B words (gamma.c:31-58), RGBA64LE -> destination at the destination size.  The children are
         // plain sws_getContext() contexts (flags and scaler parameters only); both filters go to the scaling step.
-        if (c->srcXYZ || c->dstXYZ) {   // (the reference runs this cascade without its XYZ passes, swscale.c:1076 before :1106: not reproduced)
-            log_msg(c, 0, "gamma-correct scaling of an XYZ picture is not implemented on the HIP path\n");
-            return SWS_AVERROR(ENOTSUP);
-        }
+        // (an xyz12 picture on either side: scale_internal hands over to scale_gamma before its XYZ passes, swscale.c:1076 before :1126, and
+        //  the children get the formats handle_formats() aliased to rgb48 -- the picture is treated as rgb48, here too)
         auto fail = [&](int err) { for (auto &cc : c->cascade) { destroy(cc); cc = nullptr; } c->cascade_gamma = false; return err; };
         SwsFilter sf, df;
         SwsVector sv[4], dv[4];
@@ -397,6 +398,7 @@ int init_single_context(SwsInternal *c)
         c->cascade[0]->srcBE = c->srcBE;
         if (c->cascade[2]) c->cascade[2]->dstBE = c->dstBE;
         for (SwsInternal *cc : c->cascade) if (cc) cc->tune = c->tune;
+        c->cascade[1]->internal_gamma = true;   // is_internal_gamma (utils.c:1493-1505): gamma_convert runs inside this step's line loop
         if (init_context_impl(c->cascade[0], nullptr, nullptr) < 0 || init_context_impl(c->cascade[1], &sf, &df) < 0 ||
             (c->cascade[2] && init_context_impl(c->cascade[2], nullptr, nullptr) < 0)) return fail(SWS_AVERROR(ENOMEM));
         c->plan = PLAN_CASCADE;
@@ -510,10 +512,7 @@ int init_single_context(SwsInternal *c)
         const int tmpW = (int)std::sqrt((double)(srcW * (int64_t)dstW)), tmpH = (int)std::sqrt((double)(srcH * (int64_t)dstH));
         const int tmpFormat = isALPHA(srcFormat) ? AV_PIX_FMT_YUVA420P : AV_PIX_FMT_YUV420P;
         if (srcW * (int64_t)srcH <= 4LL * dstW * dstH) return SWS_AVERROR(EINVAL);
-        if (c->srcXYZ || c->dstXYZ) {   // (the reference runs such a cascade without its XYZ passes, swscale.c:1084-1090 before :1106: not reproduced)
-            log_msg(c, 0, "extreme scaling ratio with an XYZ picture is not implemented on the HIP path\n");
-            return SWS_AVERROR(ENOTSUP);
-        }
+        // (xyz12 on either side is treated as rgb48: scale_cascaded is entered before the XYZ passes, swscale.c:1080 before :1126)
         log_msg(c, 2, "extreme scaling ratio: cascading through %dx%d %s\n", tmpW, tmpH, pix_desc(tmpFormat)->name);
         auto fail = [&](int err) { destroy(c->cascade[0]); destroy(c->cascade[1]); c->cascade[0] = c->cascade[1] = nullptr; return err; };
         c->cascade_fmt = tmpFormat; c->cascade_w = tmpW; c->cascade_h = tmpH;

@@ -58,11 +58,12 @@ static void dev_state_free(DeviceState *d)
     if (d->stream && d->own_stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
     else if (d->stream) (void)hipStreamSynchronize(d->stream);
     for (void *p : { d->d_tables, d->scratch, d->stage_src, d->stage_dst, (void *)d->d_frames, d->casc_img, d->slice_img, d->d_tilegeom,
-                     d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2, d->casc_img2, d->d_gamma_tab, d->d_ed_err, d->d_pal })
+                     d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2, d->casc_img2, d->d_gamma_tab, d->d_ed_err, d->d_pal, d->d_vlines })
         if (p) (void)hipFree(p);
     if (d->h_frames) (void)hipHostFree(d->h_frames);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
+    if (d->ev_loan) (void)hipEventDestroy(d->ev_loan);
     delete d;
 }
 
@@ -74,6 +75,80 @@ void dev_release(SwsInternal *c)
     c->dev = nullptr;
     for (DeviceState *d : c->peers) dev_state_free(d);
     c->peers.clear();
+}
+
+// ---- the reference's line schedule (ff_swscale, swscale.c:388-535) for a frame that arrives in one slice ----
+// The reference pulls destination rows: for every dstY it makes sure the horizontal ring holds the source lines the row needs -- running
+// the line converters and the horizontal scaler over BATCHES of lines, ahead of need as far as the ring allows -- and then runs the
+// vertical scaler for that one row.  Two stages make the result depend on that order:
+//   mode 1  gamma_convert (gamma.c:31-58), first luma descriptor of the gamma cascade's scaling step (slice.c:325-328), rewrites the lines
+//           of a batch in place; a line converted ahead of need and pulled again after a hole (the ring is re-based when the vertical
+//           position jumps past lastInLumBuf + 1, :404-417) is converted again;
+//   mode 2  chr_convert (hscale.c:211-225) computes plane 0's line index once per batch ("sp0") and steps it by one LUMA line per chroma
+//           line: with SWS_SRC_V_CHR_DROP on a planar RGB source the G row of a chroma line depends on where its batch started.
+// The walk below replays the cursor arithmetic and writes, for every destination row and tap, which picture line the tap reads and with
+// which side term (mode 1: table passes the line had seen when it was h-scaled; mode 2: the plane-0 row).  The two-pass path then h-scales
+// those "virtual lines" (one per row and tap) instead of the picture's lines.  `uniform`: every tap of mode 1 saw exactly one pass.
+struct VLines { std::vector<int32_t> lum, chr, lumPos, chrPos; bool uniform = true; };
+static void build_vlines(const SwsInternal *c, int mode, VLines &out)
+{
+    const int srcH = c->opts.src_h, dstH = c->opts.dst_h, vsub = c->chrSrcVSubSample, chrSrcH = c->chrSrcH;
+    const FilterBank &vl = c->vLum, &vc = c->vChr;
+    const int chrSliceEnd = -((-srcH) >> vsub);
+    // get_min_buffer_size (slice.c:217-243) and the floor of :266-267 (MAX_LINES_AHEAD = 4)
+    int lumAvail = vl.size, chrAvail = vc.size;
+    for (int y = 0; y < dstH; y++) {
+        const int cy = (int)((int64_t)y * c->chrDstH / dstH);
+        int next = std::max(vl.pos[y] + vl.size - 1, (vc.pos[cy] + vc.size - 1) << vsub);
+        next >>= vsub; next <<= vsub;
+        lumAvail = std::max(lumAvail, next - vl.pos[y]);
+        chrAvail = std::max(chrAvail, (next >> vsub) - vc.pos[cy]);
+    }
+    lumAvail = std::max(lumAvail, vl.size + 4); chrAvail = std::max(chrAvail, vc.size + 4);
+    std::vector<int32_t> passes((size_t)srcH, 0);       // gamma passes a picture line has seen so far
+    std::vector<int32_t> inL((size_t)srcH, 0);          // ... when the ring last took it (luma)
+    std::vector<int32_t> inC((size_t)chrSrcH, 0);       // mode 1: passes of the line a chroma line was made from; mode 2: its plane-0 row
+    int lastInLum = -1, lastInChr = -1, lumHoles = 1, chrHoles = 1, lumY0 = 0, lumN = 0, chrY0 = 0, chrN = 0;
+    out.lum.clear(); out.chr.clear(); out.lumPos.assign((size_t)dstH, 0); out.chrPos.assign((size_t)c->chrDstH, 0); out.uniform = true;
+    std::vector<char> chrDone((size_t)c->chrDstH, 0);
+    for (int y = 0; y < dstH; y++) {
+        const int cy = y >> c->chrDstVSubSample;
+        const int firstL = std::max(1 - vl.size, vl.pos[y]), firstC = std::max(1 - vc.size, vc.pos[cy]);
+        const int lastL = std::min(srcH, firstL + vl.size) - 1, lastC = std::min(chrSrcH, firstC + vc.size) - 1;
+        if (firstL > lastInLum) { lumHoles = lastInLum != firstL - 1; if (lumHoles) { lumY0 = firstL; lumN = 0; } lastInLum = firstL - 1; }
+        if (firstC > lastInChr) { chrHoles = lastInChr != firstC - 1; if (chrHoles) { chrY0 = firstC; chrN = 0; } lastInChr = firstC - 1; }
+        const int posY = lumY0 + lumN, cPosY = chrY0 + chrN;
+        int fp, lp, fcp, lcp;
+        if (posY <= lastL && !lumHoles) { fp = std::max(firstL, posY); lp = std::min(firstL + lumAvail - 1, srcH - 1); } else { fp = posY; lp = lastL; }
+        if (cPosY <= lastC && !chrHoles) { fcp = std::max(firstC, cPosY); lcp = std::min(firstC + chrAvail - 1, chrSliceEnd - 1); } else { fcp = cPosY; lcp = lastC; }
+        if (posY < lastL + 1) {
+            for (int k = std::max(fp, 0); k <= lp && k < srcH; k++) { passes[(size_t)k]++; inL[(size_t)k] = passes[(size_t)k]; }
+            lumN += lp - fp + 1;
+        }
+        lastInLum = lastL;
+        if (cPosY < lastC + 1) {
+            for (int k = std::max(fcp, 0); k <= lcp && k < chrSrcH; k++)
+                inC[(size_t)k] = mode == 1 ? passes[(size_t)std::min(k << vsub, srcH - 1)] : (fcp << vsub) + (k - fcp);
+            chrN += lcp - fcp + 1;
+        }
+        lastInChr = lastC;
+        // the vertical stage of row y: its taps read the ring as it is now
+        out.lumPos[(size_t)y] = (int32_t)(out.lum.size() / 2);
+        for (int j = 0; j < vl.size; j++) {
+            const int k = std::min(std::max(firstL + j, 0), srcH - 1);
+            out.lum.push_back(k); out.lum.push_back(mode == 1 ? inL[(size_t)k] : -1);
+            if (mode == 1 && firstL + j <= lastL && inL[(size_t)k] != 1) out.uniform = false;
+        }
+        if (!chrDone[(size_t)cy]) {   // (a vertically sub-sampled chroma row is written with the first luma row over it, vscale.c:74-107)
+            chrDone[(size_t)cy] = 1;
+            out.chrPos[(size_t)cy] = (int32_t)(out.chr.size() / 2);
+            for (int j = 0; j < vc.size; j++) {
+                const int k = std::min(std::max(firstC + j, 0), chrSrcH - 1);
+                out.chr.push_back(k); out.chr.push_back(inC[(size_t)k]);
+                if (mode == 1 && firstC + j <= lastC && inC[(size_t)k] != 1) out.uniform = false;
+            }
+        }
+    }
 }
 
 static bool bank_is_identity(const FilterBank &b, int one)
@@ -334,6 +409,37 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         // the fast-bilinear chroma function weighs with (xalpha ^ 127): not the identity even at equal widths
         d->unity_h = bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14) && !p.fast_bilinear;
         d->unity_v = bank_is_identity(c->vLum, 1 << 12) && bank_is_identity(c->vChr, 1 << 12);
+        // ---- contexts whose result depends on the reference's line schedule (build_vlines): the two-pass path over virtual lines ----
+        d->vlines_on = false; c->gamma_in_reader = false; d->mixed_ok = false;
+        {
+            const int drop = (o.flags & SWS_SRC_V_CHR_DROP_MASK) >> SWS_SRC_V_CHR_DROP_SHIFT;
+            const int mode = c->internal_gamma ? 1 : (drop && isPlanarRGB(o.src_format) && !p.no_chroma) ? 2 : 0;
+            VLines vlx;
+            if (mode) build_vlines(c, mode, vlx);
+            if (mode == 2 || (mode == 1 && !vlx.uniform)) {
+                const size_t nL = vlx.lum.size() / 2, nC = vlx.chr.size() / 2;
+                std::vector<int32_t> hostv;
+                hostv.insert(hostv.end(), vlx.lum.begin(), vlx.lum.end());
+                hostv.insert(hostv.end(), vlx.chr.begin(), vlx.chr.end());
+                const size_t o_lp = hostv.size(); hostv.insert(hostv.end(), vlx.lumPos.begin(), vlx.lumPos.end());
+                const size_t o_cp = hostv.size(); hostv.insert(hostv.end(), vlx.chrPos.begin(), vlx.chrPos.end());
+                const size_t bytes = hostv.size() * sizeof(int32_t);
+                if (bytes > d->vlines_bytes) {
+                    if (d->d_vlines) HIPCHK(hipFree(d->d_vlines));
+                    d->d_vlines = nullptr; d->vlines_bytes = 0;
+                    HIPCHK(hipMalloc(&d->d_vlines, bytes));
+                    d->vlines_bytes = bytes;
+                }
+                HIPCHK(hipMemcpy(d->d_vlines, hostv.data(), bytes, hipMemcpyHostToDevice));
+                const int32_t *bv = (const int32_t *)d->d_vlines;
+                p.vlines = bv; p.nVL = (int32_t)nL; p.vline_mode = mode;
+                p.vLumPos = bv + o_lp; p.vChrPos = bv + o_cp;
+                p.srcH = (int32_t)nL; p.chrSrcH = (int32_t)nC;   // what the two passes see: one scratch row per (destination row, tap)
+                d->vlines_on = true; d->unity_h = false; d->unity_v = false;
+                c->gamma_in_reader = mode == 1;
+                log_msg(c, 2, "line-schedule dependent context (mode %d): %zu + %zu virtual lines\n", mode, nL, nC);
+            }
+        }
         // ---- packed 24 / 32 bpp RGB into 8-bit 4:2:0 / 4:2:2 YUV of the same size (sws_k_rgbsrc_unity): identity horizontal filters and luma
         //      vertical filter, chroma of the "half" readers through a vertical filter of up to 16 taps whose positions only move forward ----
         d->rgbsrc_ok = false;
@@ -370,6 +476,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         // ---- dot2 tile kernel (sws_k_tile_dot2): planar 8-bit / <= 15-bit sources, 15-bit intermediates, vfs >= 2 ----
         d->dot2_ok = false;
         {
+            const bool vlines_pending = d->vlines_on;
             const bool src_ok = p.srcKind == SRCK_PLANAR8 || (p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15 && p.src_shift == 0);
             // nv12 / nv21, p010 / p012 (and the 4:2:2 / 4:4:4 twins): the strip kernel de-interleaves plane 1 (and shifts the p01x samples down) while
             // staging; the dot2 tile kernel does not
@@ -382,9 +489,16 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             d->striprgb_ok = false;
             // (planar writers: a one-tap vertical filter takes the reference's yuv2plane1 form, not the "X" arithmetic of these kernels;
             //  the packed writers are in "X" mode unless both vertical filters are short, which all_x_mode checks row by row)
-            if (!d->unity_h && !p.fast_bilinear && !gray_any && (src_ok || (nv_src && dst_ok)) && ((dst_ok && c->vLum.size >= 2 && c->vChr.size >= 2) || rgb_ok) && !p.wide &&
-                fs2(c->hLum.size) <= 16 && fs2(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && fs2(c->vChr.size) <= 16 &&
-                !c->tune.no_dot2) {
+            const bool fullA = !d->unity_h && !p.fast_bilinear && !gray_any && (src_ok || (nv_src && dst_ok)) && ((dst_ok && c->vLum.size >= 2 && c->vChr.size >= 2) || rgb_ok) && !p.wide &&
+                               fs2(c->hLum.size) <= 16 && fs2(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && fs2(c->vChr.size) <= 16 && !c->tune.no_dot2;
+            // identity luma filters + scaled chroma (yuv422p -> yuv420p, yuv444p -> yuv420p, the 10-bit -> 8-bit twins ...): the luma plane streams
+            // (one tap: a per-sample pass), only the chroma planes need the strip kernel.  (The planar writers' one-tap form is what keeps these
+            // shapes off the full strip / dot2 plans above.)
+            const bool mixedM = !fullA && !vlines_pending && bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !(d->unity_h && d->unity_v) &&
+                                !p.fast_bilinear && !gray_any && (src_ok || nv_src) && dst_ok && c->vChr.size >= 2 && !p.wide && !p.range_active && !p.dst_alpha_fill &&
+                                fs2(c->hChr.size) <= 16 && fs2(c->vChr.size) <= 16 && !c->tune.no_strip && !c->tune.no_mixed && p.dstW >= c->tune.strip_min_w;
+            d->mixed_ok = false;
+            if (fullA || mixedM) {
                 const int SPC = (p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010) ? 8 : 16;
                 std::vector<uint8_t> blob;
                 auto put = [&](const void *ptr, size_t n) { size_t o = (blob.size() + 15) & ~(size_t)15; blob.resize(o + n); std::memcpy(blob.data() + o, ptr, n); return o; };
@@ -477,12 +591,31 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 const int strip_cols_c = c->tune.strip_cols_c == 1 ? 1 : 2;
                 // (narrow pictures leave most of a 256-column strip idle and pay the per-band ring fill: the tile kernel keeps them)
                 const int strip_min_w = c->tune.strip_min_w;
-                const bool strip_plan = dst_ok && !p.range_active && !c->tune.no_strip && p.dstW >= strip_min_w &&
+                const bool strip_plan = fullA && dst_ok && !p.range_active && !c->tune.no_strip && p.dstW >= strip_min_w &&
                                         plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sL) && plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sC);
                 d->strip_ok = false;
                 log_msg(c, 3, "strip plan: %d (windows %d/%d chunks of %d, taps %d/%d x %d/%d)\n", strip_plan, d->stripL.NCmax / SPC, d->stripC.NCmax / SPC, SPC,
                         d->stripL.nph, d->stripC.nph, d->stripL.npv, d->stripC.npv);
                 Off oL, oC;
+                if (mixedM) {
+                    SOff sM;
+                    if (plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sM)) {
+                        const std::vector<int16_t> htc = padded(c->hChr);
+                        const size_t ohc = put(htc.data(), htc.size() * 2);
+                        if (blob.size() > d->dot2_bytes) {
+                            if (d->d_dot2) HIPCHK(hipFree(d->d_dot2));
+                            d->d_dot2 = nullptr;
+                            HIPCHK(hipMalloc(&d->d_dot2, blob.size()));
+                            d->dot2_bytes = blob.size();
+                        }
+                        HIPCHK(hipMemcpy(d->d_dot2, blob.data(), blob.size(), hipMemcpyHostToDevice));
+                        const uint8_t *b = (const uint8_t *)d->d_dot2;
+                        d->stripC.colStart = (const int32_t *)(b + sM.cs); d->stripC.colCount = (const int32_t *)(b + sM.cc);
+                        d->stripC.rows = (const SwsStripRow *)(b + sM.rows);
+                        d->stripC.hT2 = (const int16_t *)(b + ohc); d->stripC.vT2 = nullptr;
+                        d->mixed_ok = true;
+                    }
+                } else
                 if (rgb_ok) {
                     // RGB epilogue: 256 luma columns + the 128 chroma columns under them per wave, one 16-byte chunk per lane and row for
                     // both (windows of up to 1024 source samples), rings of 5 / 3 row pairs (8 / 8 in the long form)
@@ -712,7 +845,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     case PLAN_CASCADE: c->path_name = "cascade"; c->kernel_name = ""; break;
     case PLAN_MAIN: {
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
-        if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
+        if (d->vlines_on) {
+            c->path_name = "main:two_pass"; c->kernel_name = "sws_k_hscale";
+        } else if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {
             c->path_name = "main:fused_rgb_unity";
             c->kernel_name = d->rgb_march_ok ? "sws_k_rgb_march" : (d->all_x_mode && d->chr_window2 <= 8 ? "sws_k_rgb_fused_unity_wave2" : "sws_k_rgb_fused_unity");
         } else if (d->unity_h && d->unity_v && !p.no_chroma && !p.need_alpha && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 && p.dst_shift == 0 &&
@@ -720,6 +855,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             c->path_name = "main:fused_f32rgb_yuv444"; c->kernel_name = "sws_k_f32rgb_to_yuv444_unity";
         } else if (d->rgbsrc_ok) {
             c->path_name = "main:rgbsrc_unity"; c->kernel_name = "sws_k_rgbsrc_unity";
+        } else if (d->mixed_ok) {
+            c->path_name = "main:plane1+strip_chroma"; c->kernel_name = "sws_k_strip_march";
         } else if (d->unity_h) {
             c->path_name = "main:fused_generic_unity";
             c->kernel_name = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) ? "sws_k_vscale_rgb" : "sws_k_vscale_planar";
@@ -908,13 +1045,15 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
     case PLAN_MAIN: {
         if (p.dst_alpha_fill) launch_fill_alpha(L, p.dstW, 0, p.dstH, p.dstKind == DSTK_GBRPF32 ? 32 : p.dst_bits > 8 ? p.dst_bits : 0);   // swscale.c:536-552
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
-        if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12))
+        if (d->vlines_on) ret = launch_generic(L);   // (virtual source lines: pass 1 of the two-pass path materialises them)
+        else if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12))
             ret = launch_rgb_unity(L);
         else if (vec && d->unity_h && d->unity_v && !p.no_chroma && !p.need_alpha && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 && p.dst_shift == 0 &&
                  (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16))
             ret = launch_f32rgb(L);
         else if (d->rgbsrc_ok && vec) ret = launch_rgbsrc(L);                                             // packed RGB source, same size
         else if (d->striprgb_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_striprgb(L);   // marching strip kernel, RGB epilogue
+        else if (d->mixed_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_mixed(L);   // identity luma: streaming pass + strip kernel on chroma
         else if (d->strip_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_strip(L);   // marching strip kernel
         else if (d->dot2_ok && vec) ret = launch_tile_dot2(L);                                              // dot2 LDS-tile kernel
         else if (d->tile_ok) ret = launch_tile(L);                                                          // fused h+v LDS-tile kernel
@@ -1186,7 +1325,9 @@ int dev_run(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4],
         }
         return 0;
     };
-    if (nthreads <= 1) {
+    // (a cascade's children -- their per-GPU device state, plan names and tables -- hang off the one shared context and are prepared inside
+    //  run_single(): those frames are staged GPU after GPU on this thread instead of one thread per GPU)
+    if (nthreads <= 1 || c->plan == PLAN_CASCADE) {
         for (int g = 0; g < ndev; g++) if (!staged[g].empty()) { ret = run_staged(g); if (ret < 0) return ret; }
     } else {
         std::vector<std::thread> th;
@@ -1298,7 +1439,10 @@ static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4
             HIPCHK(hipMemcpyAsync(d->d_gamma_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice, d->stream));   // (static storage: stays valid)
         }
         const uint16_t *gt = (const uint16_t *)d->d_gamma_tab;
-        launch_gamma_rgba64(d->stream, tmp[0], tls[0], o.src_w, o.src_h, gt + 65536);
+        // the inverse table on the scaling step's source: one pass over the picture when the step's line schedule converts every line it reads
+        // exactly once; otherwise (holes: FAST_BILINEAR / POINT down-scaling) pass 1 of the step applies it per virtual line (build_vlines)
+        if (c1->gamma_in_reader) cd[1]->params.gamma_tab = gt + 65536;
+        else launch_gamma_rgba64(d->stream, tmp[0], tls[0], o.src_w, o.src_h, gt + 65536);
         uint8_t *out1[4] = { dst[0], dst[1], dst[2], dst[3] };
         int os1[4] = { dstStride[0], dstStride[1], dstStride[2], dstStride[3] };
         bool out1_dev = true;
@@ -1416,27 +1560,63 @@ static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4
         }
     }
     if (!dst_dev || !src_dev) HIPCHK(hipStreamSynchronize(st)); // host buffers: synchronous like the reference
+    if (c->plan == PLAN_UNSC_ALPHABLEND) return 0;   // ff_sws_alphablendaway returns 0 (alphablend.c:176) and sws_scale() passes it on
     return unscaled ? sliceH : o.dst_h;
 }
 
 // A dynamic context's per-field child runs where the parent would: same home GPU, same launch heuristics, and on the stream of
 // the frames' AVHIPDeviceContext if they have one, else on the stream the caller gave the parent, else on its own.
-int dev_inherit(SwsInternal *child, SwsInternal *parent, bool have_stream, void *stream)
+int dev_inherit(SwsInternal *child, SwsInternal *parent, bool have_stream, void *stream, int device)
 {
     int r = ensure_dev(parent);
     if (r < 0) return r;
     if ((r = ensure_dev(child)) < 0) return r;
-    if (child->dev->device != parent->dev->device && (r = sws_hip_set_device(&child->opts, parent->dev->device)) < 0) return r;
+    // (HIP frames name their GPU: a stream of that GPU's device context must not end up on the state of another one)
+    const int want_dev = device >= 0 ? device : parent->dev->device;
+    if (child->dev->device != want_dev && (r = sws_hip_set_device(&child->opts, want_dev)) < 0) return r;
     if (std::memcmp(&child->tune, &parent->tune, sizeof(Tuning))) {
         child->tune = parent->tune;
         mark_tables_dirty(child);
         for (SwsInternal *cc : child->cascade) if (cc) { cc->tune = parent->tune; mark_tables_dirty(cc); }
     }
     if (child->dev->timing != parent->dev->timing && (r = sws_hip_set_timing(&child->opts, parent->dev->timing)) < 0) return r;
-    void *want = have_stream ? stream : (parent->dev->stream && !parent->dev->own_stream ? (void *)parent->dev->stream : nullptr);
+    // (a frames' hwdevice stream is not installed here: run_graphs() borrows it around the call, dev_borrow_stream)
+    (void)have_stream; (void)stream;
+    void *want = parent->dev->stream && !parent->dev->own_stream ? (void *)parent->dev->stream : nullptr;
     if (want) return dev_use_stream(child, want);
     if (child->dev->stream && !child->dev->own_stream) return sws_hip_set_stream(&child->opts, nullptr);
     return 0;
+}
+
+// A frames' hwdevice stream is BORROWED for one call: the context's own stream comes back afterwards, so that nothing of the caller's is held
+// (or synchronised, or found destroyed) later.  Work of the context on either stream stays ordered through two events: the borrowed stream
+// first waits for what the context still has in flight on its own stream, and the own stream then waits for the call's work.
+int dev_borrow_stream(SwsInternal *c, void *stream, StreamLoan *loan)
+{
+    loan->active = false;
+    int r = ensure_dev(c);
+    if (r < 0 || !stream) return r;
+    DeviceState *d = c->dev;
+    if ((void *)d->stream == stream) return 0;
+    DeviceGuard guard;
+    HIPCHK(hipSetDevice(d->device));
+    if (!d->stream) { HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)); d->own_stream = true; }
+    if (!d->ev_loan) HIPCHK(hipEventCreateWithFlags(&d->ev_loan, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(d->ev_loan, d->stream));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, d->ev_loan, 0));
+    loan->prev = (void *)d->stream; loan->prev_own = d->own_stream; loan->active = true;
+    d->stream = (hipStream_t)stream; d->own_stream = false;
+    return 0;
+}
+void dev_return_stream(SwsInternal *c, const StreamLoan &loan)
+{
+    if (!loan.active || !c->dev) return;
+    DeviceState *d = c->dev;
+    DeviceGuard guard;
+    (void)hipSetDevice(d->device);
+    if (d->ev_loan && hipEventRecord(d->ev_loan, d->stream) == hipSuccess) (void)hipStreamWaitEvent((hipStream_t)loan.prev, d->ev_loan, 0);
+    else (void)hipGetLastError();
+    d->stream = (hipStream_t)loan.prev; d->own_stream = loan.prev_own;
 }
 
 int dev_use_stream(SwsInternal *c, void *stream)
@@ -1789,7 +1969,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
     struct { const char *n; int *v; } tab[] = {
         { "strip_min_w", &c->tune.strip_min_w }, { "strip_cols_l", &c->tune.strip_cols_l }, { "strip_cols_c", &c->tune.strip_cols_c },
         { "strip_waves", &c->tune.strip_waves }, { "strip_rgb_cols", &c->tune.strip_rgb_cols }, { "rgb_march_waves", &c->tune.rgb_march_waves }, { "tile_lds_kb", &c->tune.tile_lds_kb },
-        { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
+        { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "layout_ch", &c->tune.layout_ch }, { "no_mixed", &c->tune.no_mixed }, { "no_layout_stream", &c->tune.no_layout_stream }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
         { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
         { "debug", &c->tune.debug },
     };

@@ -29,6 +29,7 @@ struct DeviceState {
     bool dot2_ok = false; SwsTileGeom dotL, dotC; void *d_dot2 = nullptr; size_t dot2_bytes = 0;
     const SwsRgbSrcRow *rgbsrc_rows = nullptr;             // (in d_dot2)
     bool rgbsrc_ok = false;                                // sws_k_rgbsrc_unity (packed 24 / 32 bpp RGB -> 8-bit 4:2:x YUV of the same size)
+    bool mixed_ok = false;                                 // identity luma (streaming plane pass) + strip kernel on the chroma planes only (launch_mixed)
     bool strip_ok = false; SwsStripGeom stripL, stripC;    // sws_k_strip_march (tables live in d_dot2)
     bool striprgb_ok = false; SwsStripGeom stripRL, stripRC; bool striprgb_long = false;   // sws_k_strip_rgb: scaled planar 8-bit YUV -> 24 / 32 bpp RGB
     void *scratch = nullptr; size_t scratch_bytes = 0;
@@ -40,7 +41,9 @@ struct DeviceState {
     void *d_ed_err = nullptr;   // error-diffusion line of an 8 / 4 bpp destination: 3 x (dst_w + 3) ints, zeroed once, carried between frames
     void *casc_img2 = nullptr; size_t casc_bytes2 = 0; void *d_gamma_tab = nullptr;   // gamma cascade: second RGBA64 intermediate, the two 65536-entry tables
     void *slice_img = nullptr; size_t slice_bytes = 0;   // source image assembled from sws_scale() slices (scaled path)
+    void *d_vlines = nullptr; size_t vlines_bytes = 0; bool vlines_on = false;   // virtual source lines of the two-pass path (SwsDevParams::vlines) + their vertical positions
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timing = false; bool timed = false;
+    hipEvent_t ev_loan = nullptr;   // orders the context's own stream against a borrowed frames stream (dev_borrow_stream)
 };
 
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
@@ -83,6 +86,9 @@ static inline bool frames_desc_ok(const SwsFramePtrs *fr, int n, int srcH, int d
 int  launch_misc(const LaunchCtx &L);                                   // every PLAN_UNSC_* plan not named below
 void launch_fill_alpha(const LaunchCtx &L, int w, int y0, int rows, int bits);
 void launch_update_palette(const LaunchCtx &L);
+int launch_layout_plane1(const LaunchCtx &L);   // k_layout.hip: the luma plane of a context with identity luma filters (launch_mixed)
+int launch_mixed(const LaunchCtx &L);           // k_strip.hip
+int launch_layout(const LaunchCtx &L);   // k_layout.hip: 1 = launched, 0 = not a shape of the streaming family
 void launch_ed_mono(hipStream_t st, const uint8_t *lum, int64_t lumStride, uint8_t *dst, int64_t dstStride, int n, int h, int *errline, int white);
 void launch_alpha_merge(const LaunchCtx &L, int npix, int y0, int rows, int a_pos);
 void launch_bswap(hipStream_t st, const uint8_t *src, int64_t sstride, uint8_t *dst, int64_t dstride, int rows, int row_bytes, int unit);

@@ -107,7 +107,12 @@ static bool fmt_equal(const SwsFmt &a, const SwsFmt &b)
            a.range == b.range && a.csp == b.csp && a.loc == b.loc && color_equal(a, b);
 }
 // what a cached conversion depends on beyond ff_fmt_equal: where the pixels live
-static bool fmt_same(const SwsFmt &a, const SwsFmt &b) { return fmt_equal(a, b) && a.hw_format == b.hw_format && a.hip_device == b.hip_device; }
+// (the stream and the device context travel with the frames: frames of another AVHWDeviceContext on the same ordinal are another graph, or the
+//  cached one would queue work on a stream that may be gone)
+static bool fmt_same(const SwsFmt &a, const SwsFmt &b)
+{
+    return fmt_equal(a, b) && a.hw_format == b.hw_format && a.hip_device == b.hip_device && a.hip_stream == b.hip_stream && a.device_ref == b.device_ref;
+}
 
 // ff_test_fmt(), format.c:683-693 with SWS_BACKEND_LEGACY
 static bool test_fmt(const SwsFmt &f, int output)
@@ -351,11 +356,14 @@ static int run_graphs(SwsInternal *c, SwsFrameView *const dst[], const SwsFrameV
             continue;
         }
         SwsInternal *lc = internal(g.legacy);
-        if ((ret = dev_inherit(lc, c, have, st)) < 0) return ret;
+        if ((ret = dev_inherit(lc, c, have, st, have ? g.src.hip_device : -1)) < 0) return ret;   // HIP frames: on THEIR GPU, ordered on their device context's stream
         for (int i = 0; i < n; i++)
             if (!check_image_pointers(sp[(size_t)i]->data, lc->opts.src_format, sp[(size_t)i]->linesize) ||
                 !check_image_pointers(dp[(size_t)i]->data, lc->opts.dst_format, dp[(size_t)i]->linesize)) return SWS_AVERROR(EINVAL);
+        StreamLoan loan;
+        if (have && (ret = dev_borrow_stream(lc, st, &loan)) < 0) return ret;
         ret = dev_run(lc, nullptr, nullptr, 0, lc->opts.src_h, nullptr, nullptr, n, sp.data(), dp.data());
+        dev_return_stream(lc, loan);
         if (ret < 0) return ret;
     }
     return 0;
@@ -414,11 +422,16 @@ int sws_scale_frame(SwsContext *sws, SwsFrameView *dstf, const SwsFrameView *src
         SwsFrameView sv = *srcf, dv = *dstf;
         const SwsFrameView *s1[1] = { &sv };
         SwsFrameView *d1[1] = { &dv };
+        StreamLoan loan;
         if (srcf->hw_frames_ctx) {
             SwsFmt f; (void)fmt_from_frame(srcf, 0, &f);
-            if (f.hip_stream && (r = dev_use_stream(c, f.hip_stream)) < 0) return r;
+            // the frames' AVHIPDeviceContext: the conversion runs on that GPU (it becomes the context's home) and on that stream, after the
+            // uploads queued there and before whatever the caller queues next
+            if (f.hip_stream && f.hip_device >= 0 && (r = sws_hip_set_device(sws, f.hip_device)) < 0) return r;
+            if (f.hip_stream && (r = dev_borrow_stream(c, f.hip_stream, &loan)) < 0) return r;
         }
         r = dev_run(c, nullptr, nullptr, 0, sws->src_h, nullptr, nullptr, 1, s1, d1);
+        dev_return_stream(c, loan);
         return r < 0 ? r : sws->dst_h;
     }
     int ret = sws_frame_setup(sws, dstf, srcf);
@@ -444,12 +457,16 @@ int sws_scale_frames(SwsContext *sws, SwsFrameView *const dst[], const SwsFrameV
             if (!check_image_pointers(src[i]->data, sws->src_format, src[i]->linesize) ||
                 !check_image_pointers(dst[i]->data, sws->dst_format, dst[i]->linesize)) return SWS_AVERROR(EINVAL);
         }
+        StreamLoan loan;
         if (src[0]->hw_frames_ctx) {
             SwsFmt f; (void)fmt_from_frame(src[0], 0, &f);
             int r;
-            if (f.hip_stream && (r = dev_use_stream(c, f.hip_stream)) < 0) return r;
+            if (f.hip_stream && f.hip_device >= 0 && (r = sws_hip_set_device(sws, f.hip_device)) < 0) return r;
+            if (f.hip_stream && (r = dev_borrow_stream(c, f.hip_stream, &loan)) < 0) return r;
         }
-        return dev_run(c, nullptr, nullptr, 0, sws->src_h, nullptr, nullptr, nb_frames, src, dst);
+        const int rr = dev_run(c, nullptr, nullptr, 0, sws->src_h, nullptr, nullptr, nb_frames, src, dst);
+        dev_return_stream(c, loan);
+        return rr;
     }
     // dynamic: one conversion for the batch, configured from the first pair; every other pair must have the same properties
     int ret = sws_frame_setup(sws, dst[0], src[0]);
@@ -478,36 +495,34 @@ int sws_frame_start(SwsContext *sws, SwsFrameView *dst, const SwsFrameView *src)
     int r = sws_frame_setup(sws, dst, src);
     if (r < 0) return r;
     if (!dst->data[0]) return SWS_AVERROR(ENOMEM);   // this library cannot allocate AVFrame buffers (no libavutil): bring your own
-    c->frame_src = src; c->frame_dst = dst; c->frame_rows_in = 0;
+    c->frame_src = src; c->frame_dst = dst; c->frame_ranges.clear(); c->frame_done = false;
     return 0;
 }
 
-void sws_frame_end(SwsContext *sws)
+void sws_frame_end(SwsContext *sws)   // swscale.c:1236-1244
 {
     if (!sws) return;
     SwsInternal *c = internal(sws);
-    c->frame_src = nullptr; c->frame_dst = nullptr; c->frame_rows_in = 0;
+    c->frame_src = nullptr; c->frame_dst = nullptr; c->frame_ranges.clear(); c->frame_done = false;
 }
 
+// sws_send_slice (swscale.c:1337-1351) only records which source rows are there: ff_range_add (utils.c:2384-2440) keeps a sorted list of
+// disjoint ranges, refuses a slice that overlaps one it has and merges neighbours; the conversion happens in sws_receive_slice() once the
+// list is the single range [0, src_h).
 int sws_send_slice(SwsContext *sws, unsigned int slice_start, unsigned int slice_height)
 {
     if (!sws) return SWS_AVERROR(EINVAL);
     SwsInternal *c = internal(sws);
     if (!c->legacy_init || !c->frame_src || !c->frame_dst) return SWS_AVERROR(EINVAL);
-    const SwsFrameView *s = c->frame_src;
-    const PixDesc *d = pix_desc(canonical_pix_fmt(frame_sw_format(s)));
-    const uint8_t *ptr[4] = { nullptr, nullptr, nullptr, nullptr };
-    int ls[4] = { 0, 0, 0, 0 };
-    for (int k = 0; k < 4 && s->data[k]; k++) {
-        bool chroma = false;
-        for (int q = 0; q < d->nb_components; q++) if (d->comp[q].plane == k) chroma = (q == 1 || q == 2);
-        const int sub = (chroma && !(d->flags & PIXFLAG_RGB)) ? d->log2_chroma_h : 0;
-        ptr[k] = (const uint8_t *)s->data[k] + (int64_t)(slice_start >> sub) * s->linesize[k];
-        ls[k] = s->linesize[k];
-    }
-    int r = sws_scale(sws, ptr, ls, (int)slice_start, (int)slice_height, (uint8_t *const *)c->frame_dst->data, c->frame_dst->linesize);
-    if (r >= 0) c->frame_rows_in += (int)slice_height;
-    return r;
+    auto &rl = c->frame_ranges;   // pairs {start, len}
+    size_t idx = 0;
+    while (idx < rl.size() && rl[idx].first <= slice_start) idx++;
+    if (idx > 0 && (uint64_t)rl[idx - 1].first + rl[idx - 1].second > slice_start) return SWS_AVERROR(EINVAL);
+    if (idx < rl.size() && (uint64_t)slice_start + slice_height > rl[idx].first) return SWS_AVERROR(EINVAL);
+    rl.insert(rl.begin() + (ptrdiff_t)idx, std::make_pair(slice_start, slice_height));
+    if (idx > 0 && rl[idx - 1].first + rl[idx - 1].second == rl[idx].first) { rl[idx - 1].second += rl[idx].second; rl.erase(rl.begin() + (ptrdiff_t)idx); idx--; }
+    if (idx + 1 < rl.size() && rl[idx].first + rl[idx].second == rl[idx + 1].first) { rl[idx].second += rl[idx + 1].second; rl.erase(rl.begin() + (ptrdiff_t)idx + 1); }
+    return 0;
 }
 
 unsigned int sws_receive_slice_alignment(const SwsContext *sws)
@@ -517,16 +532,25 @@ unsigned int sws_receive_slice_alignment(const SwsContext *sws)
     return c->dst_slice_align > 0 ? (unsigned)c->dst_slice_align : 1u;
 }
 
-int sws_receive_slice(SwsContext *sws, unsigned int slice_start, unsigned int slice_height)
+int sws_receive_slice(SwsContext *sws, unsigned int slice_start, unsigned int slice_height)   // swscale.c:1362-1402
 {
     if (!sws) return SWS_AVERROR(EINVAL);
     SwsInternal *c = internal(sws);
     if (!c->legacy_init || !c->frame_src || !c->frame_dst) return SWS_AVERROR(EINVAL);
-    // rows are final once every source row has been sent (the scaled path converts when the last slice arrives)
-    if (c->frame_rows_in < sws->src_h) return SWS_AVERROR(EAGAIN);
+    // "wait until complete input has been received"
+    if (!(c->frame_ranges.size() == 1 && c->frame_ranges[0].first == 0 && c->frame_ranges[0].second == (unsigned)sws->src_h)) return SWS_AVERROR(EAGAIN);
     const unsigned align = sws_receive_slice_alignment(sws);
     if ((slice_start > 0 || slice_height < (unsigned)sws->dst_h) && (slice_start % align || slice_height % align)) return SWS_AVERROR(EINVAL);
-    return 0;
+    if ((uint64_t)slice_start + slice_height > (unsigned)sws->dst_h) return SWS_AVERROR(EINVAL);   // (scale_internal's destination slice check, :1053-1058)
+    // The reference scales the whole source into the requested destination rows on every call (scale_internal with a destination slice).
+    // Here the frame is converted once, on the first call after the input is complete; later calls find their rows already there.
+    if (!c->frame_done) {
+        const SwsFrameView *s = c->frame_src;
+        int r = sws_scale(sws, (const uint8_t *const *)s->data, s->linesize, 0, sws->src_h, (uint8_t *const *)c->frame_dst->data, c->frame_dst->linesize);
+        if (r < 0) return r;
+        c->frame_done = true;
+    }
+    return c->plan == PLAN_UNSC_ALPHABLEND ? 0 : (int)slice_height;   // what scale_internal returns for the slice (ff_sws_alphablendaway: 0)
 }
 
 } // extern "C"

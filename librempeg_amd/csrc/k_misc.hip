@@ -12,6 +12,7 @@ int launch_misc(const LaunchCtx &L)
     const SwsFramePtrs *frames = L.frames; const int n = L.n, sliceY = L.sliceY, sliceH = L.sliceH; const bool vec = L.vec;
     const dim3 blk(256);
     (void)c; (void)d; (void)frames; (void)vec; (void)sliceY; (void)sliceH;
+    if (launch_layout(L) > 0) return 0;   // the streaming form of the layout converters takes 16-byte aligned pictures (k_layout.hip)
     switch (c->plan) {
     case PLAN_UNSC_PLANAR2NV12:
     case PLAN_UNSC_NV122PLANAR:
@@ -209,7 +210,8 @@ int launch_misc(const LaunchCtx &L)
         const int nbytes = planar ? (df == AV_PIX_FMT_GBRAP ? 4 : 3) : pix_desc(df)->comp[0].step;
         if (sliceH <= 0) break;
         const dim3 grid(cdiv(p.srcW, 256), sliceH, n);
-        hipLaunchKernelGGL(swsk::sws_k_pal2rgb, grid, blk, 0, st, fs, p.srcW, sliceY, nbytes, planar ? 1 : 0);
+        const int gray = c->opts.src_format != AV_PIX_FMT_GRAY8 ? 0 : (df == AV_PIX_FMT_ARGB || df == AV_PIX_FMT_ABGR) ? 2 : 1;
+        hipLaunchKernelGGL(swsk::sws_k_pal2rgb, grid, blk, 0, st, fs, p.srcW, sliceY, nbytes, planar ? 1 : 0, gray);
         break;
     }
     case PLAN_UNSC_YUV2RGB8: {
@@ -272,7 +274,9 @@ int launch_misc(const LaunchCtx &L)
         if (ap.planar) {
             for (int pl = 0; pl < ap.plane_count; pl++) {
                 const int xs = pl ? ap.lw : 0, ys = pl ? ap.lh : 0;
-                const int w = pl ? -((-p.srcW) >> xs) : p.srcW, rows = -((-sliceH) >> ys);
+                // (alphablend.c:52: "w = plane ? c->chrSrcW : c->opts.src_w" -- for a gbrap source that is half the width when init halved the
+                //  RGB chroma, utils.c:1369-1390 with SWS_FAST_BILINEAR: the right half of planes 1 and 2 is then left alone, as there)
+                const int w = pl ? c->chrSrcW : p.srcW, rows = -((-sliceH) >> ys);
                 const dim3 grid(cdiv(w, 256), rows, n);
                 hipLaunchKernelGGL(swsk::sws_k_alphablend, grid, blk, 0, st, fs, ap, pl, w, sliceY >> ys);
             }

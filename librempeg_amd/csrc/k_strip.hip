@@ -6,7 +6,8 @@
 
 namespace swship {
 
-int launch_strip(const LaunchCtx &L)
+// which: 1 = the luma launch, 2 = the chroma launch, 3 = both
+int launch_strip_planes(const LaunchCtx &L, int which)
 {
     SwsInternal *c = L.c; DeviceState *d = L.d; const SwsDevParams &p = *L.p; hipStream_t st = L.st; const SwsFrameSet &fs = L.fs;
     const SwsFramePtrs *frames = L.frames; const int n = L.n, sliceY = L.sliceY, sliceH = L.sliceH; const bool vec = L.vec;
@@ -35,9 +36,21 @@ int launch_strip(const LaunchCtx &L)
 #undef SWS_STRIP
 #undef SWS_STRIP_DMA
             };
-            launch(d->stripL, p.dstH, false);
-            launch(d->stripC, p.chrDstH, true);
+            if (which & 1) launch(d->stripL, p.dstH, false);
+            if (which & 2) launch(d->stripC, p.chrDstH, true);
     return 0;
+}
+
+int launch_strip(const LaunchCtx &L) { return launch_strip_planes(L, 3); }
+
+// Same-size planar YUV -> planar / semi-planar YUV whose luma filters are the identity in both directions and whose chroma is scaled
+// (yuv422p -> yuv420p, yuv444p -> yuv420p / nv12, 10-bit -> 8-bit twins ...): the luma plane is a streaming per-sample pass (the scaler's own
+// arithmetic with one tap: k_layout.hip launch_layout_plane1), the chroma planes are the strip kernel's chroma launch.
+int launch_mixed(const LaunchCtx &L)
+{
+    int r = launch_layout_plane1(L);
+    if (r < 0) return r;
+    return launch_strip_planes(L, 2);
 }
 
 } // namespace swship

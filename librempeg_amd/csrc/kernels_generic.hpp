@@ -13,7 +13,7 @@ namespace swsk {
 // input readers (libswscale/input.c): value of the "formatConv" line for component comp
 // (0 = Y, 1 = U, 2 = V) at source row `row` (luma or chroma row), column x.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFramePtrs &f, int comp, int row, int x)
+__device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFramePtrs &f, int comp, int row, int x, int aux = -1)
 {
     if (comp == 3 && p.srcKind == SRCK_RGB48)   // rgba64leToA_c: the 16-bit A word as is
         return ((const uint16_t *)(f.src[0] + (int64_t)row * f.srcStride[0]))[4 * x + 3];
@@ -23,7 +23,9 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
     // planar RGB sources: every line needs all three planes.  The reference's slices index planes 1 and 2 by chroma row and planes 0 and 3
     // by luma row whatever the line is for (slice.c ff_init_slice_from_src, hscale.c:lum_convert / chr_convert): a luma line y reads B and R
     // at chroma row y >> chrSrcVSub, a chroma line reads G at luma row y << chrSrcVSub (both the same row unless SWS_SRC_V_CHR_DROP is set)
-    const int grow = prow, brow = (comp == 1 || comp == 2) ? row : (row >> p.chrSrcVSub);
+    // (chr_convert derives the plane-0 row from the start of the BATCH of chroma lines it is called for, "sp0 + i": when the line schedule matters
+    //  -- SWS_SRC_V_CHR_DROP on a planar RGB source -- pass 1 gets that row as the line's side term, see SwsDevParams::vlines)
+    const int grow = ((comp == 1 || comp == 2) && aux >= 0 && p.vline_mode == 2) ? aux : prow, brow = (comp == 1 || comp == 2) ? row : (row >> p.chrSrcVSub);
     if (p.srcKind == SRCK_PACKEDHI) {   // the descriptor's field of component comp
         const uint8_t *s = f.src[0] + (int64_t)prow * f.srcStride[0] + pick4(p.shi_step, comp) * x + pick4(p.shi_off, comp);
         return (*(const uint16_t *)s >> pick4(p.shi_shift, comp)) & pick4(p.shi_mask, comp);
@@ -213,10 +215,14 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         const int32_t *t = p.rgb2yuv;
         const int st = p.s16_step;
         unsigned r, g, b;
+        // the scaling step of the gamma cascade: gamma_convert (gamma.c:31-58) has rewritten the line in place `aux` times by the time the
+        // ring takes it (a line pulled again after a hole is converted again, swscale.c:404-451): the table is applied that often here
+        const int npass = (p.vline_mode == 1 && aux > 0) ? aux : 0;
+        auto gw = [&](unsigned v) { for (int k = 0; k < npass; k++) v = p.gamma_tab[v]; return v; };
         if (comp != 0 && p.chr_half) {
             const uint16_t *q = s + 2 * st * x;
-            r = (q[p.s16_r] + q[st + p.s16_r] + 1u) >> 1; g = (q[p.s16_g] + q[st + p.s16_g] + 1u) >> 1; b = (q[p.s16_b] + q[st + p.s16_b] + 1u) >> 1;
-        } else { const uint16_t *q = s + st * x; r = q[p.s16_r]; g = q[p.s16_g]; b = q[p.s16_b]; }
+            r = (gw(q[p.s16_r]) + gw(q[st + p.s16_r]) + 1u) >> 1; g = (gw(q[p.s16_g]) + gw(q[st + p.s16_g]) + 1u) >> 1; b = (gw(q[p.s16_b]) + gw(q[st + p.s16_b]) + 1u) >> 1;
+        } else { const uint16_t *q = s + st * x; r = gw(q[p.s16_r]); g = gw(q[p.s16_g]); b = gw(q[p.s16_b]); }
         const int o = comp == 0 ? 0 : comp == 1 ? 3 : 6;
         const Rgb2YuvRow tr = rgb2yuv_row(p.rgb2yuv, o);
         return (uint16_t)(((unsigned)tr.r * r + (unsigned)tr.g * g + (unsigned)tr.b * b + ((comp == 0 ? 0x2001u : 0x10001u) << 14)) >> 15);
@@ -275,7 +281,7 @@ __device__ __forceinline__ int range_sample(const SwsDevParams &p, int v, int ch
 }
 
 // horizontal stage for one output sample (hScale8To15_c / 8To19 / 16To15 / 16To19, swscale.c:69-159)
-__device__ __forceinline__ int hscale_sample(const SwsDevParams &p, const SwsFramePtrs &f, int comp, int row, int x)
+__device__ __forceinline__ int hscale_sample(const SwsDevParams &p, const SwsFramePtrs &f, int comp, int row, int x, int aux = -1)
 {
     if (p.no_chroma && comp != 0 && comp != 3) return p.wide ? 1 << 18 : 1 << 14;   // ff_init_desc_no_chr: fill_ones() value, never range converted
     const bool lumlike = comp == 0 || comp == 3;   // the alpha plane goes through the luma functions (hscale.c:39-131)
@@ -284,9 +290,9 @@ __device__ __forceinline__ int hscale_sample(const SwsDevParams &p, const SwsFra
         const uint32_t xpos = (uint32_t)x * (uint32_t)(lumlike ? U(p.lumXInc) : U(p.chrXInc));
         const int xx = (int)(xpos >> 16), xalpha = (int)((xpos & 0xFFFF) >> 9);
         int r;
-        if (xx >= sW - 1) r = read_sample(p, f, comp, row, sW - 1) * 128;        // the tail loop of the reference
+        if (xx >= sW - 1) r = read_sample(p, f, comp, row, sW - 1, aux) * 128;        // the tail loop of the reference
         else {
-            const int a = read_sample(p, f, comp, row, xx), b = read_sample(p, f, comp, row, xx + 1);
+            const int a = read_sample(p, f, comp, row, xx, aux), b = read_sample(p, f, comp, row, xx + 1, aux);
             r = lumlike ? (a << 7) + (b - a) * xalpha : a * (xalpha ^ 127) + b * xalpha;
         }
         return comp == 3 ? (int16_t)r : range_sample(p, (int16_t)r, comp != 0);
@@ -296,7 +302,7 @@ __device__ __forceinline__ int hscale_sample(const SwsDevParams &p, const SwsFra
     const int fs = lumlike ? U(p.hLumFs) : U(p.hChrFs);
     const int sp = pos[x];
     int val = 0;
-    for (int j = 0; j < fs; j++) val += read_sample(p, f, comp, row, sp + j) * filter[fs * x + j];
+    for (int j = 0; j < fs; j++) val += read_sample(p, f, comp, row, sp + j, aux) * filter[fs * x + j];
     int r = min(val >> p.hshift, p.hclip);
     if (!p.wide) r = (int16_t)r;
     return comp == 3 ? r : range_sample(p, r, comp != 0);
@@ -338,7 +344,12 @@ __global__ void __launch_bounds__(256) sws_k_hscale(SwsFrameSet fs, SwsDevParams
     T *base = scratch + fi * frame_elems;
     const int64_t lumElems = (int64_t)p.srcH * p.dstW, chrElems = (int64_t)p.chrSrcH * p.chrDstW;
     T *plane = comp == 0 ? base : comp == 1 ? base + lumElems : comp == 2 ? base + lumElems + chrElems : base + lumElems + 2 * chrElems;
-    plane[(int64_t)row * W + x] = (T)hscale_sample(p, f, comp, row, x);
+    int srow = row, aux = -1;
+    if (p.vlines) {   // (the row of pass 1 is a virtual line: which picture line it is, and its side term)
+        const int32_t *e = p.vlines + 2 * ((comp == 0 || comp == 3) ? row : U(p.nVL) + row);
+        srow = e[0]; aux = e[1];
+    }
+    plane[(int64_t)row * W + x] = (T)hscale_sample(p, f, comp, srow, x, aux);
 }
 
 // ------------------------------------------------------------------------------------------

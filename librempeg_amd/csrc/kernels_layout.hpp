@@ -1,0 +1,308 @@
+// Streaming form of the pure layout / depth converters (planarCopyWrapper incl. DITHER_COPY, planarToNv12 / nv12ToPlanar and the nv24
+// twins, yuyv / uyvy <-> planar): the decoder -> filter -> encoder format changes.  Every sample is independent and the work is a
+// handful of shifts per 16 bytes, so the only thing that matters is how the bytes move: a lane owns 16-byte chunks spaced one wave apart
+// (every load / store instruction of a wave covers a contiguous KiB), plane pointers and strides sit in SGPRs (load_frame), all loads of a
+// lane are issued before its first store, stores are non-temporal.  The element-per-thread kernels of kernels_misc.hpp / kernels_shuffle.hpp
+// keep the pictures whose pointers or strides are not 16-byte aligned and the rare converters (yvu9, nv24 -> yuv420p).
+// Arithmetic: the same expressions as those kernels (cited there), per element.
+#pragma once
+#include "kernels_common.hpp"
+#include "wave_util.hpp"
+
+namespace swsk {
+
+// dithers[8][8][8] of swscale_unscaled.c:39-112 (DITHER_COPY): [src_depth - dst_depth - 1][row & 7][column & 7], eight bytes per row
+__device__ __constant__ const uint8_t k_layout_dithers[8][8][8] __attribute__((aligned(8))) = {
+{ {0,1,0,1,0,1,0,1},{1,0,1,0,1,0,1,0},{0,1,0,1,0,1,0,1},{1,0,1,0,1,0,1,0},{0,1,0,1,0,1,0,1},{1,0,1,0,1,0,1,0},{0,1,0,1,0,1,0,1},{1,0,1,0,1,0,1,0} },
+{ {1,2,1,2,1,2,1,2},{3,0,3,0,3,0,3,0},{1,2,1,2,1,2,1,2},{3,0,3,0,3,0,3,0},{1,2,1,2,1,2,1,2},{3,0,3,0,3,0,3,0},{1,2,1,2,1,2,1,2},{3,0,3,0,3,0,3,0} },
+{ {2,4,3,5,2,4,3,5},{6,0,7,1,6,0,7,1},{3,5,2,4,3,5,2,4},{7,1,6,0,7,1,6,0},{2,4,3,5,2,4,3,5},{6,0,7,1,6,0,7,1},{3,5,2,4,3,5,2,4},{7,1,6,0,7,1,6,0} },
+{ {4,8,7,11,4,8,7,11},{12,0,15,3,12,0,15,3},{6,10,5,9,6,10,5,9},{14,2,13,1,14,2,13,1},{4,8,7,11,4,8,7,11},{12,0,15,3,12,0,15,3},{6,10,5,9,6,10,5,9},{14,2,13,1,14,2,13,1} },
+{ {9,17,15,23,8,16,14,22},{25,1,31,7,24,0,30,6},{13,21,11,19,12,20,10,18},{29,5,27,3,28,4,26,2},{8,16,14,22,9,17,15,23},{24,0,30,6,25,1,31,7},{12,20,10,18,13,21,11,19},{28,4,26,2,29,5,27,3} },
+{ {18,34,30,46,17,33,29,45},{50,2,62,14,49,1,61,13},{26,42,22,38,25,41,21,37},{58,10,54,6,57,9,53,5},{16,32,28,44,19,35,31,47},{48,0,60,12,51,3,63,15},{24,40,20,36,27,43,23,39},{56,8,52,4,59,11,55,7} },
+{ {18,34,30,46,17,33,29,45},{50,2,62,14,49,1,61,13},{26,42,22,38,25,41,21,37},{58,10,54,6,57,9,53,5},{16,32,28,44,19,35,31,47},{48,0,60,12,51,3,63,15},{24,40,20,36,27,43,23,39},{56,8,52,4,59,11,55,7} },
+{ {36,68,60,92,34,66,58,90},{100,4,124,28,98,2,122,26},{52,84,44,76,50,82,42,74},{116,20,108,12,114,18,106,10},{32,64,56,88,38,70,62,94},{96,0,120,24,102,6,126,30},{48,80,40,72,54,86,46,78},{112,16,104,8,118,22,110,14} },
+};
+
+enum { LOP_COPY = 0, LOP_FILL, LOP_IL, LOP_DIL, LOP_8TO16, LOP_16TO8, LOP_16TO16, LOP_P422_SPLIT, LOP_P422_SPLIT420, LOP_P422_JOIN, LOP_P1_16TO8, LOP_P1_16TO16 };
+
+// one class of rows: `rows` rows starting at source row ys / destination row yd of the planes named below
+struct LayoutJob {
+    int32_t op, rows, ys, yd;
+    int32_t sa, sb, da, db;        // source planes A, B (B: second input of an interleave), destination planes A, B
+    int32_t n;                     // bytes of the job's widest row side that carry data (what the 16-byte chunks are counted over)
+    int32_t a0, a1, a2, a3, a4;    // op parameters
+};
+struct LayoutPlan { int32_t njobs; LayoutJob job[6]; };
+
+__device__ __forceinline__ void lstore16(uint8_t *d, u32x4 v, int nvalid) { if (nvalid >= 16) gstore16_nt(d, v); else gstore_partial(d, v, nvalid); }
+__device__ __forceinline__ void lstore8(uint8_t *d, u32x2 v, int nvalid)
+{
+    if (nvalid >= 8) __builtin_nontemporal_store(v, (SWS_GLOBAL u32x2 *)d);
+    else { const u32x4 t = { v[0], v[1], 0, 0 }; gstore_partial(d, t, nvalid); }
+}
+
+template <int CH>
+__global__ void __launch_bounds__(256) sws_k_layout_stream(SwsFrameSet fs, SwsDevParams p, LayoutPlan plan)
+{
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int r = blockIdx.y, ji = 0;
+    while (ji < plan.njobs && r >= U(plan.job[ji].rows)) { r -= U(plan.job[ji].rows); ji++; }
+    if (ji >= plan.njobs) return;
+    // (scalar copies of the job: a run-time index into the by-value argument would put it into scratch memory)
+    int op = 0, ys = 0, yd = 0, sa = 0, sb = 0, da = 0, db = 0, n = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        if (k == ji) {
+            const LayoutJob &J = plan.job[k];
+            op = U(J.op); ys = U(J.ys); yd = U(J.yd); sa = U(J.sa); sb = U(J.sb); da = U(J.da); db = U(J.db); n = U(J.n);
+            a0 = U(J.a0); a1 = U(J.a1); a2 = U(J.a2); a3 = U(J.a3); a4 = U(J.a4);
+        }
+    {   // chunks are counted in 16 bytes of n, or in 8 (the ops whose other side is twice as wide)
+        const int unit = (op == LOP_IL || op == LOP_8TO16 || op == LOP_P422_JOIN) ? 8 : 16;
+        if (wave * CH * 64 * unit >= n) return;
+    }
+    const uint8_t *srowA = pick4(f.src, sa) + (int64_t)(ys + r) * pick4(f.srcStride, sa);
+    const uint8_t *srowB = pick4(f.src, sb) + (int64_t)(ys + r) * pick4(f.srcStride, sb);
+    uint8_t *drowA = pick4(f.dst, da) + (int64_t)(yd + r) * pick4(f.dstStride, da);
+    uint8_t *drowB = pick4(f.dst, db) + (int64_t)(yd + r) * pick4(f.dstStride, db);
+    auto chunk = [&](int k) { return (wave * CH + k) * 64 + lane; };
+
+    switch (op) {
+    case LOP_COPY: {   // n bytes of a row as they are
+        u32x4 v[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 16; if (off < n) v[k] = load16_or_tail(srowA + off, n - off); }
+#pragma unroll
+        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 16; if (off < n) lstore16(drowA + off, v[k], n - off); }
+        break;
+    }
+    case LOP_FILL: {   // fillPlane / fillPlane16: a0 = the 32-bit pattern
+        const u32x4 v = { (uint32_t)a0, (uint32_t)a0, (uint32_t)a0, (uint32_t)a0 };
+#pragma unroll
+        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 16; if (off < n) lstore16(drowA + off, v, n - off); }
+        break;
+    }
+    case LOP_IL: {     // planarToNv12 / Nv24: n bytes of plane A and of plane B -> 2n interleaved bytes (A first)
+        u32x2 a[CH], b[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 8; if (off < n) { a[k] = load8_or_tail(srowA + off, n - off); b[k] = load8_or_tail(srowB + off, n - off); } }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int off = chunk(k) * 8;
+            if (off >= n) continue;
+            const u32x4 o = { __builtin_amdgcn_perm(b[k][0], a[k][0], 0x05010400u), __builtin_amdgcn_perm(b[k][0], a[k][0], 0x07030602u),
+                              __builtin_amdgcn_perm(b[k][1], a[k][1], 0x05010400u), __builtin_amdgcn_perm(b[k][1], a[k][1], 0x07030602u) };
+            lstore16(drowA + 2 * off, o, 2 * (n - off));
+        }
+        break;
+    }
+    case LOP_DIL: {    // nv12ToPlanar / nv24ToPlanar: n interleaved bytes -> n/2 to plane A (even bytes), n/2 to plane B (odd bytes)
+        u32x4 v[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 16; if (off < n) v[k] = load16_or_tail(srowA + off, n - off); }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int off = chunk(k) * 16;
+            if (off >= n) continue;
+            const u32x2 ea = { __builtin_amdgcn_perm(v[k][1], v[k][0], 0x06040200u), __builtin_amdgcn_perm(v[k][3], v[k][2], 0x06040200u) };
+            const u32x2 eb = { __builtin_amdgcn_perm(v[k][1], v[k][0], 0x07050301u), __builtin_amdgcn_perm(v[k][3], v[k][2], 0x07050301u) };
+            const int nv = (n - off + 1) >> 1, nb = (n - off) >> 1;
+            lstore8(drowA + (off >> 1), ea, nv); lstore8(drowB + (off >> 1), eb, nb);
+        }
+        break;
+    }
+    case LOP_8TO16: {  // planarCopy 8 -> 9..16 bit (swscale_unscaled.c:2266-2284): a0 = left shift, a1 = right shift of the replicated bits (32: none), a2 = dst_shift
+        u32x2 s[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 8; if (off < n) s[k] = load8_or_tail(srowA + off, n - off); }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int off = chunk(k) * 8;
+            if (off >= n) continue;
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t w = s[k][q >> 1] >> (16 * (q & 1));
+                const uint32_t e0 = w & 0xFF, e1 = (w >> 8) & 0xFF;
+                const uint32_t v0 = (((e0 << a0) | (a1 < 32 ? e0 >> a1 : 0u)) << a2) & 0xFFFFu, v1 = (((e1 << a0) | (a1 < 32 ? e1 >> a1 : 0u)) << a2) & 0xFFFFu;
+                o[q] = v0 | (v1 << 16);
+            }
+            const u32x4 ov = { o[0], o[1], o[2], o[3] };
+            lstore16(drowA + 2 * off, ov, 2 * (n - off));
+        }
+        break;
+    }
+    case LOP_16TO8:    // DITHER_COPY to 8 bit (:2159-2218): n = source bytes of the row
+    case LOP_16TO16: { // DITHER_COPY to 9..15 bit, or the widening copy N -> M (:2285-2331)
+        // a0 = mode: 0 dither off, 1 dither + shiftonly, 2 dither full range, 3 widening shiftonly, 4 widening with bit replication
+        // a1 = shift (|sd - dd|), a2 = src_shift, a3 = dst_shift, a4 = dd | body_end << 8 (elements), widening: a4 = 2 * sd - dd
+        const int mode = a0, shift = a1, ss = a2, dsh = a3, dd = a4 & 0xFF, body_end = a4 >> 8;
+        u32x4 s[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 16; if (off < n) s[k] = load16_or_tail(srowA + off, n - off); }
+        // the dither row of this picture row: eight bytes, the same for every lane (x & 7 = the element's place in its group of eight)
+        uint32_t dlo = 0, dhi = 0;
+        if (mode == 1 || mode == 2) {
+            const uint32_t *dr = (const uint32_t *)k_layout_dithers[shift - 1][r & 7];
+            dlo = U(dr[0]); dhi = U(dr[1]);
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int off = chunk(k) * 16;
+            if (off >= n) continue;
+            const bool body = (off >> 1) < body_end;
+            uint32_t e[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t sv = (s[k][q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+                const uint32_t dth = ((q < 4 ? dlo : dhi) >> (8 * (q & 3))) & 0xFFu;
+                uint32_t tmp, v;
+                if (mode == 0) { const uint32_t bias = 1u << (shift - 1); tmp = ((body ? sv >> ss : sv) + bias) >> shift; v = (tmp - (tmp >> dd)) << dsh; }
+                else if (mode == 1) { tmp = ((body ? sv >> ss : sv) + dth) >> shift; v = (tmp - (tmp >> dd)) << dsh; }
+                else if (mode == 2) { tmp = body ? sv >> ss : sv; v = (tmp - (tmp >> dd) + dth) >> shift; if (body) v <<= dsh; }
+                else if (mode == 3) { v = ((sv >> ss) << shift) << dsh; }
+                else { const uint32_t t = sv >> ss; v = ((t << shift) | (t >> (a4))) << dsh; }
+                e[q] = v;
+            }
+            if (op == LOP_16TO8) {
+                const u32x2 o = { (e[0] & 0xFF) | ((e[1] & 0xFF) << 8) | ((e[2] & 0xFF) << 16) | (e[3] << 24),
+                                  (e[4] & 0xFF) | ((e[5] & 0xFF) << 8) | ((e[6] & 0xFF) << 16) | (e[7] << 24) };
+                lstore8(drowA + (off >> 1), o, (n - off) >> 1);
+            } else {
+                const u32x4 o = { (e[0] & 0xFFFF) | (e[1] << 16), (e[2] & 0xFFFF) | (e[3] << 16), (e[4] & 0xFFFF) | (e[5] << 16), (e[6] & 0xFFFF) | (e[7] << 16) };
+                lstore16(drowA + off, o, n - off);
+            }
+        }
+        break;
+    }
+    case LOP_P1_16TO8:     // the scaler chain with identity filters on a plane of 9..16-bit samples: hScale16To15_c with the single tap 1 << 14
+    case LOP_P1_16TO16: {  // (swscale.c:99-125), then yuv2plane1_8_c with the row's ff_dither_8x8_128 line (output.c:485-493, swscale.c:519-522) or
+        // yuv2plane1_10 / 12 / 14 (output.c:327-341).  a0 = src_shift, a1 = hscale shift, a2 = destination bits, a3 = dst_shift; rows are absolute
+        u32x4 s[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 16; if (off < n) s[k] = load16_or_tail(srowA + off, n - off); }
+        uint32_t dth[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) dth[q] = U((uint32_t)k_dither_8x8_128[(yd + r) & 7][q]);
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int off = chunk(k) * 16;
+            if (off >= n) continue;
+            uint32_t e[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int sv = (int)((s[k][q >> 1] >> (16 * (q & 1))) & 0xFFFFu) >> a0;
+                const int hv = min((sv << 14) >> a1, (1 << 15) - 1);
+                if (op == LOP_P1_16TO8) e[q] = (uint32_t)clip_u8_shr(hv + (int)dth[q], 7);
+                else { const int sh = 15 - a2; e[q] = (uint32_t)clip_uintp2((hv + (1 << (sh - 1))) >> sh, a2) << a3; }
+            }
+            if (op == LOP_P1_16TO8) {
+                const u32x2 o = { e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24), e[4] | (e[5] << 8) | (e[6] << 16) | (e[7] << 24) };
+                lstore8(drowA + (off >> 1), o, (n - off) >> 1);
+            } else {
+                const u32x4 o = { e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16) };
+                lstore16(drowA + off, o, n - off);
+            }
+        }
+        break;
+    }
+    case LOP_P422_SPLIT: {   // yuyvtoyuv422_c / uyvytoyuv422_c (rgb2rgb_template.c:751-825): n = packed bytes that carry whole pairs; a0 = 1 for uyvy, a1 = swap U / V (yvyu)
+        // a2 = luma samples of the row (an odd width: the last pair's second luma byte is not stored)
+        u32x4 v[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 16; if (off < n) v[k] = load16_or_tail(srowA + off, n - off); }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int off = chunk(k) * 16;
+            if (off >= n) continue;
+            const uint32_t ysel = a0 ? 0x07050301u : 0x06040200u;
+            const u32x2 yv = { __builtin_amdgcn_perm(v[k][1], v[k][0], ysel), __builtin_amdgcn_perm(v[k][3], v[k][2], ysel) };
+            // chroma bytes of a dword pair: yuyv: U at 1, 5; V at 3, 7.  uyvy: U at 0, 4; V at 2, 6
+            const uint32_t usel = a0 ? 0x0c0c0400u : 0x0c0c0501u, vsel = a0 ? 0x0c0c0602u : 0x0c0c0703u;
+            const uint32_t u = __builtin_amdgcn_perm(v[k][1], v[k][0], usel) | (__builtin_amdgcn_perm(v[k][3], v[k][2], usel) << 16);
+            const uint32_t w = __builtin_amdgcn_perm(v[k][1], v[k][0], vsel) | (__builtin_amdgcn_perm(v[k][3], v[k][2], vsel) << 16);
+            lstore8(drowA + (off >> 1), yv, min(8, a2 - (off >> 1)));
+            const int nc = (n - off) >> 2;   // chroma samples behind this chunk
+            uint8_t *pu = (a1 ? pick4(f.dst, 2) + (int64_t)(yd + r) * pick4(f.dstStride, 2) : drowB) + (off >> 2);
+            uint8_t *pv = (a1 ? drowB : pick4(f.dst, 2) + (int64_t)(yd + r) * pick4(f.dstStride, 2)) + (off >> 2);
+            if (nc >= 4) { *(uint32_t *)pu = u; *(uint32_t *)pv = w; }
+            else for (int b = 0; b < nc; b++) { pu[b] = (uint8_t)(u >> (8 * b)); pv[b] = (uint8_t)(w >> (8 * b)); }
+        }
+        break;
+    }
+    case LOP_P422_SPLIT420: {   // yuyvtoyuv420_c / uyvytoyuv420_c: a ROW PAIR per job row (luma of both rows, chroma = truncating mean of the two);
+        // a3 = rows of the slice (an odd count: the last row has luma only); ys / yd count luma rows; da = 0, chroma planes 1 / 2
+        const int y0 = 2 * r, two = (y0 + 1 < a3);
+        const uint8_t *s0 = pick4(f.src, sa) + (int64_t)(ys + y0) * pick4(f.srcStride, sa), *s1 = s0 + pick4(f.srcStride, sa);
+        uint8_t *d0 = f.dst[0] + (int64_t)(yd + y0) * f.dstStride[0], *d1 = d0 + f.dstStride[0];
+        const int cr = (yd >> 1) + r;
+        uint8_t *pu = (a1 ? f.dst[2] : f.dst[1]) + (int64_t)cr * (a1 ? f.dstStride[2] : f.dstStride[1]);
+        uint8_t *pv = (a1 ? f.dst[1] : f.dst[2]) + (int64_t)cr * (a1 ? f.dstStride[1] : f.dstStride[2]);
+        u32x4 v0[CH], v1[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int off = chunk(k) * 16;
+            if (off < n) { v0[k] = load16_or_tail(s0 + off, n - off); v1[k] = two ? load16_or_tail(s1 + off, n - off) : v0[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int off = chunk(k) * 16;
+            if (off >= n) continue;
+            const uint32_t ysel = a0 ? 0x07050301u : 0x06040200u;
+            const u32x2 ya = { __builtin_amdgcn_perm(v0[k][1], v0[k][0], ysel), __builtin_amdgcn_perm(v0[k][3], v0[k][2], ysel) };
+            const u32x2 yb = { __builtin_amdgcn_perm(v1[k][1], v1[k][0], ysel), __builtin_amdgcn_perm(v1[k][3], v1[k][2], ysel) };
+            const int nl = min(8, a2 - (off >> 1));
+            lstore8(d0 + (off >> 1), ya, nl);
+            if (two) {
+                lstore8(d1 + (off >> 1), yb, nl);
+                // per-byte truncating mean (a + b) >> 1 = (a & b) + ((a ^ b) >> 1) on the chroma bytes
+                uint32_t m[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) m[q] = (v0[k][q] & v1[k][q]) + (((v0[k][q] ^ v1[k][q]) >> 1) & 0x7F7F7F7Fu);
+                const uint32_t usel = a0 ? 0x0c0c0400u : 0x0c0c0501u, vsel = a0 ? 0x0c0c0602u : 0x0c0c0703u;
+                const uint32_t u = __builtin_amdgcn_perm(m[1], m[0], usel) | (__builtin_amdgcn_perm(m[3], m[2], usel) << 16);
+                const uint32_t w = __builtin_amdgcn_perm(m[1], m[0], vsel) | (__builtin_amdgcn_perm(m[3], m[2], vsel) << 16);
+                const int nc = (n - off) >> 2;
+                if (nc >= 4) { *(uint32_t *)(pu + (off >> 2)) = u; *(uint32_t *)(pv + (off >> 2)) = w; }
+                else for (int b = 0; b < nc; b++) { pu[(off >> 2) + b] = (uint8_t)(u >> (8 * b)); pv[(off >> 2) + b] = (uint8_t)(w >> (8 * b)); }
+            }
+        }
+        break;
+    }
+    case LOP_P422_JOIN: {   // yuvPlanartoyuy2_c / yuvPlanartouyvy_c (rgb2rgb_template.c:379-470): n = luma bytes that are in whole pairs; a0 = 1 for uyvy;
+        // a1 = luma rows per chroma row (1: 4:2:2 source, 2: 4:2:0), chroma row = (ys_c + r / a1) with ys_c = a2
+        const int cr = a2 + (a1 == 2 ? (r >> 1) : r);
+        const uint8_t *su = f.src[1] + (int64_t)cr * f.srcStride[1], *sv = f.src[2] + (int64_t)cr * f.srcStride[2];
+        u32x2 yv[CH]; uint32_t u[CH], w[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int off = chunk(k) * 8;
+            if (off >= n) continue;
+            yv[k] = load8_or_tail(srowA + off, n - off);
+            if (n - off >= 8) { u[k] = *(const uint32_t *)(su + (off >> 1)); w[k] = *(const uint32_t *)(sv + (off >> 1)); }
+            else { u[k] = w[k] = 0; for (int b = 0; b < ((n - off) >> 1); b++) { u[k] |= (uint32_t)su[(off >> 1) + b] << (8 * b); w[k] |= (uint32_t)sv[(off >> 1) + b] << (8 * b); } }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int off = chunk(k) * 8;
+            if (off >= n) continue;
+            // chroma pairs: c01 = U0 V0 U1 V1, c23 = U2 V2 U3 V3
+            const uint32_t c01 = __builtin_amdgcn_perm(w[k], u[k], 0x05010400u), c23 = __builtin_amdgcn_perm(w[k], u[k], 0x07030602u);
+            u32x4 o;
+            if (!a0) {   // Y0 U Y1 V
+                o[0] = __builtin_amdgcn_perm(c01, yv[k][0], 0x05010400u); o[1] = __builtin_amdgcn_perm(c01, yv[k][0], 0x07030602u);
+                o[2] = __builtin_amdgcn_perm(c23, yv[k][1], 0x05010400u); o[3] = __builtin_amdgcn_perm(c23, yv[k][1], 0x07030602u);
+            } else {     // U Y0 V Y1
+                o[0] = __builtin_amdgcn_perm(yv[k][0], c01, 0x05010400u); o[1] = __builtin_amdgcn_perm(yv[k][0], c01, 0x07030602u);
+                o[2] = __builtin_amdgcn_perm(yv[k][1], c23, 0x05010400u); o[3] = __builtin_amdgcn_perm(yv[k][1], c23, 0x07030602u);
+            }
+            lstore16(drowA + 2 * off, o, 2 * (n - off));
+        }
+        break;
+    }
+    }
+}
+
+} // namespace swsk

@@ -600,13 +600,16 @@ __global__ void __launch_bounds__(256) sws_k_update_palette(SwsFrameSet fs, SwsD
 
 // palToRgbWrapper with sws_convertPalette8ToPacked32 / 24 (swscale_unscaled.c:600-644, :2707-2730) and palToGbrpWrapper with pal8ToPlanar8
 // (:531-545, :646-683): the bytes of the pal_rgb word are the destination's bytes.  nbytes = 3 / 4 (packed) or the number of planes.
-__global__ void __launch_bounds__(256) sws_k_pal2rgb(SwsFrameSet fs, int w, int sliceY, int nbytes, int planar)
+// gray: a gray8 source (usePal names it too): its palette is the grey ramp r = g = b = i, a = 255 (swscale.c:901-902), so the word is built
+// from the sample itself; 1 = alpha in the last byte, 2 = in the first (argb / abgr)
+__global__ void __launch_bounds__(256) sws_k_pal2rgb(SwsFrameSet fs, int w, int sliceY, int nbytes, int planar, int gray)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= w) return;
     const FrameRegs f = load_frame(fs, blockIdx.z);
     const int y = sliceY + blockIdx.y;
-    const uint32_t e = ((const uint32_t *)f.src[1])[256 + f.src[0][(int64_t)y * f.srcStride[0] + x]];
+    const uint32_t idx = f.src[0][(int64_t)y * f.srcStride[0] + x];
+    const uint32_t e = gray == 2 ? (idx * 0x01010100u | 0xFFu) : gray ? (idx * 0x00010101u | 0xFF000000u) : ((const uint32_t *)f.src[1])[256 + idx];
     if (planar) {   // (static plane indices: a run-time index into the frame descriptor would put it into scratch memory)
         f.dst[0][(int64_t)y * f.dstStride[0] + x] = (uint8_t)e;
         f.dst[1][(int64_t)y * f.dstStride[1] + x] = (uint8_t)(e >> 8);

@@ -106,6 +106,8 @@ struct Tuning {
     int rgb_march_waves = 12288;   // resident waves the packed-RGB march kernel is banded for
     int tile_lds_kb = 40, tile_threads = 256;
     int p01x_ch = 1;
+    int no_mixed = 0;               // off: identity-luma contexts keep the element-per-thread / tile kernels instead of plane pass + chroma strip
+    int layout_ch = 1, no_layout_stream = 0;   // streaming layout converters (kernels_layout.hpp): 16-byte chunks per lane; off = the element-per-thread kernels
     int no_wave = 0, no_march = 0, no_rgbsrc = 0, no_strip = 0, no_strip_dma = 0, no_dot2 = 0, no_tile = 0;
     int max_devices = 0;           // sws_scale_frames(): GPUs to shard over (0 = all visible)
     int debug = 0;
@@ -134,7 +136,7 @@ struct SwsInternal {
     bool legacy_init = false;
     std::vector<double> srcVec[4];   // copies of the SwsFilter vectors given to sws_init_context: lumH, lumV, chrH, chrV
     int dstVecLen[4] = {0, 0, 0, 0};
-    const SwsFrameView *frame_src = nullptr; SwsFrameView *frame_dst = nullptr; int frame_rows_in = 0;   // sws_frame_start .. sws_frame_end
+    const SwsFrameView *frame_src = nullptr; SwsFrameView *frame_dst = nullptr; std::vector<std::pair<unsigned, unsigned>> frame_ranges; bool frame_done = false;   // sws_frame_start .. sws_frame_end: source rows sent so far (ff_range_add), frame converted
     bool srcXYZ = false, dstXYZ = false; // handle_xyz (utils.c:822-842): the caller's formats were xyz12, opts.*_format hold rgb48le
     bool srcBE = false, dstBE = false;   // the caller's formats were big-endian: opts.src_format / dst_format hold the LE twins
     FrameGraph graph[2];          // dynamic mode (sws_alloc_context() only): top / bottom field conversions built by sws_frame_setup()
@@ -160,6 +162,8 @@ struct SwsInternal {
     bool cascade_gamma = false;   // gamma-correct scaling (utils.c:1461-1522): cascade[1] scales RGBA64 between two in-place table passes
     bool cascade_ed = false;      // 8 / 4 bpp destination with error diffusion: cascade[0] writes rgb24 at the destination size, a diffusion pass follows
     bool mono_y16 = false;        // (inner context of a 1 bpp error-diffusion context) the mono writer stores luma words instead of bits
+    bool internal_gamma = false;  // the scaling step of the gamma cascade (is_internal_gamma, utils.c:1493-1497): gamma_convert is its first luma descriptor
+    bool gamma_in_reader = false; // (set by dev_prepare_on) the line schedule converts some line more than once: pass 1 applies the table per virtual line
     bool force_scaler = false;    // (inner context of the above) never take an unscaled special converter
     int cascade_fmt = -1, cascade_w = 0, cascade_h = 0;
     std::string path_name, kernel_name;
@@ -183,7 +187,10 @@ void dev_release(SwsInternal *c);                         // frees the device st
 int  dev_run(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4], int srcSliceY, int srcSliceH,
              uint8_t *const dst[4], const int dstStride[4], int nb_frames,
              const SwsFrameView *const *srcFrames, SwsFrameView *const *dstFrames);
-int  dev_inherit(SwsInternal *child, SwsInternal *parent, bool have_stream, void *stream);  // a dynamic context's child runs on its GPU / stream / tuning
+struct StreamLoan { void *prev = nullptr; bool prev_own = false; bool active = false; };
+int  dev_borrow_stream(SwsInternal *c, void *stream, StreamLoan *loan);   // the frames' hwdevice stream, for one call
+void dev_return_stream(SwsInternal *c, const StreamLoan &loan);
+int  dev_inherit(SwsInternal *child, SwsInternal *parent, bool have_stream, void *stream, int device = -1);  // a dynamic context's child runs on its GPU / stream / tuning
 int  dev_use_stream(SwsInternal *c, void *stream);        // run on the stream of the frames' AVHIPDeviceContext
 int  dev_copy_frame(SwsInternal *c, SwsFrameView *dst, const SwsFrameView *src, bool have_stream, void *stream);   // no-op conversion: plane copies
 void frames_release(SwsInternal *c);                      // frees the per-field conversions of a dynamic context

@@ -290,6 +290,7 @@ static int isFloat16(int f) { return isFloat(f) && desc_get(f)->c[0].depth == 16
 /* usePal (swscale_internal.h:937-950) without gray8, whose grey palette only feeds palToRgbWrapper / palToGbrpWrapper: the scaler chain gives
  * the same bytes for it (tests/test_oracle_properties_extra.py) */
 static int isPalSrc(int f) { return f == ORF_PAL8 || f == ORF_RGB8 || f == ORF_BGR8 || f == ORF_RGB4_BYTE || f == ORF_BGR4_BYTE; }
+static int usePal(int f) { return isPalSrc(f) || f == ORF_GRAY8; }   /* swscale_internal.h:937-950: gray8 goes through the palette wrappers too (its readers are the plain ones) */
 static int isBayer(int f) { return !!(desc_get(f)->flags & PF_BAYER); }
 static int isInputOnly(int f) { return isBayer(f) || f == ORF_PAL8 || f == ORF_UYYVYY411 || f == ORF_RGBF32LE || f == ORF_RGBF16LE || f == ORF_RGBAF16LE || f == ORF_GRAYF16LE || f == ORF_YAF32LE || f == ORF_YAF16LE || f == ORF_GBRPF16LE || f == ORF_GBRAPF16LE; }
 static int isALPHA(int f) { return !!(desc_get(f)->flags & PF_ALPHA); }
@@ -367,6 +368,7 @@ struct OrSws {
     int casc_mainindex;   /* the child sws_setColorspaceDetails() is forwarded to (utils.c:909-910): 1 for the alpha-blend cascade */
     uint32_t pal_yuv[256], pal_rgb[256];   /* ff_update_palette (swscale.c:873-951) */
     int *dither_error[3];   /* utils.c:1744-1747: dst_w + 3 zeroed ints per channel; never reset between frames or slices */
+    const uint16_t *internal_gamma_tab;   /* is_internal_gamma (utils.c:1493-1497): the inverse-gamma table of the cascade's scaling step, applied by main_path() */
     int casc_gamma; uint8_t *casc_tmp2; int casc_stride2; uint16_t *gamma_tab, *inv_gamma_tab;
     int initialized;
 };
@@ -1043,6 +1045,9 @@ static int alphaless_fmt(int f) /* utils.c:1060-1118 (the big-endian rows are th
     case ORF_YUVA420P9LE: return ORF_YUV420P9LE; case ORF_YUVA422P9LE: return ORF_YUV422P9LE; case ORF_YUVA444P9LE: return ORF_YUV444P9LE;
     case ORF_YUVA420P10LE: return ORF_YUV420P10LE; case ORF_YUVA422P10LE: return ORF_YUV422P10LE; case ORF_YUVA444P10LE: return ORF_YUV444P10LE;
     case ORF_YUVA420P16LE: return ORF_YUV420P16LE; case ORF_YUVA422P16LE: return ORF_YUV422P16LE; case ORF_YUVA444P16LE: return ORF_YUV444P16LE;
+    case ORF_GBRAP: return ORF_GBRP;   /* utils.c:1073-1085 */
+    case ORF_GBRAP10LE: return ORF_GBRP10LE; case ORF_GBRAP12LE: return ORF_GBRP12LE;
+    case ORF_GBRAP14LE: return ORF_GBRP14LE; case ORF_GBRAP16LE: return ORF_GBRP16LE;
     }
     return ORF_NONE;
 }
@@ -1136,7 +1141,7 @@ static int unscaled_alphablend(const OrSws *c, const uint8_t *const src[], const
             }
         }
     }
-    return srcSliceH;
+    return 0;   /* alphablend.c:176: sws_scale() reports no rows for this converter */
 }
 
 /* planarRgbToplanarRgbWrapper (swscale_unscaled.c:1380-1402) with ff_copyPlane (:126-145) as it is: `width` is passed in pixels
@@ -1244,8 +1249,9 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
     if (s == ORF_GBRAP && (d == ORF_RGB24 || d == ORF_BGR24 || d == ORF_RGBA || d == ORF_BGRA || d == ORF_ARGB || d == ORF_ABGR)) c->unscaled_kind = UNSC_GBRP2PACKED;
     if (d == ORF_GBRAP && (s == ORF_RGB24 || s == ORF_BGR24 || s == ORF_RGBA || s == ORF_BGRA || s == ORF_ARGB || s == ORF_ABGR)) c->unscaled_kind = UNSC_PACKED2GBRP;
     if (isBayer(s) && (d == ORF_RGB24 || d == ORF_RGB48LE || d == ORF_YUV420P)) c->unscaled_kind = UNSC_BAYER;   /* bayer_to_rgb24 / rgb48 / yv12_wrapper (:2543-2555) */
-    /* palToRgbWrapper / palToGbrpWrapper (:2619-2630) for the palette-expanded sources (gray8 is left to the scaler chain, see isPalSrc) */
-    if (isPalSrc(s) && (d == ORF_GBRP || d == ORF_GBRAP || d == ORF_RGB24 || d == ORF_BGR24 || d == ORF_RGBA || d == ORF_BGRA || d == ORF_ARGB || d == ORF_ABGR))
+    /* palToRgbWrapper / palToGbrpWrapper (:2619-2630) for the palette-expanded sources, gray8 with its grey ramp among them: the index is
+     * replicated whatever sws_setColorspaceDetails() was given */
+    if (usePal(s) && (d == ORF_GBRP || d == ORF_GBRAP || d == ORF_RGB24 || d == ORF_BGR24 || d == ORF_RGBA || d == ORF_BGRA || d == ORF_ARGB || d == ORF_ABGR))
         c->unscaled_kind = UNSC_PAL2RGB;
     /* simple copy (:2647-2668) */
     if (s == d || (s == ORF_YUVA420P && d == ORF_YUV420P) || (s == ORF_YUV420P && d == ORF_YUVA420P) ||
@@ -1357,7 +1363,6 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
         /* utils.c:1461-1522: source -> RGBA64LE (same size), RGBA64LE scaled between pow(x, 1/2.2) and pow(x, 2.2) table passes, RGBA64LE ->
          * destination (same size).  Children are plain sws_getContext() contexts; the filters go to the scaling step. */
         int k;
-        if (c->src_xyz || c->dst_xyz) return -1;   /* (the reference runs this cascade without its XYZ passes: not restated) */
         c->casc_gamma = 1;
         c->casc_stride[0] = (((srcW + 7) & ~7) * 8 + 63) & ~63;
         c->casc_tmp[0] = calloc((size_t)c->casc_stride[0] * srcH + 64, 1);
@@ -1497,7 +1502,6 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
         const int np = tmpFormat == ORF_YUVA420P ? 4 : 3;
         int k;
         if (srcW * (int64_t)srcH <= 4LL * dstW * dstH) return -1;
-        if (c->src_xyz || c->dst_xyz) return -1;   /* (the reference skips its XYZ passes here: not restated) */
         for (k = 0; k < np; k++) {
             const int chroma = k == 1 || k == 2;
             const int rows = chroma ? (tmpH + 1) >> 1 : tmpH;
@@ -1647,6 +1651,28 @@ static int unscaled_yuv2rgb(OrSws *c, const uint8_t *const src[], const int srcS
     const int is422 = c->o.src_format == ORF_YUV422P;
     const int d = c->o.dst_format;
     const int npairs = ((c->o.dst_w >> 3) << 2) + ((c->o.dst_w & 4) ? 2 : 0) + ((c->o.dst_w & 2) ? 1 : 0);
+    if ((d == ORF_RGB24 || d == ORF_BGR24) && c->lut_elem == 1 && !is422 && !(srcSliceH & 1)) {
+        /* yuv2rgb_c_24_rgb / yuv2rgb_c_24_bgr (yuv2rgb.c:237-281) in the reference's own loop shape -- LOADCHROMA once per 2x2 block (three
+         * table pointers), PUTRGB24 for both lines -- so that the timed CPU baseline (bench.py cpu_baseline, BASELINE config C2a) runs the
+         * algorithm at the speed the reference's C path does.  Same tables, same results as the general loop below. */
+        const uint8_t *tab = c->yuvTable;
+        const int ro = d == ORF_RGB24 ? 0 : 2, bo = 2 - ro;
+        for (int y = 0; y < srcSliceH; y += 2) {
+            const uint8_t *py1 = src[0] + (ptrdiff_t)y * srcStride[0], *py2 = py1 + srcStride[0];
+            const uint8_t *pu = src[1] + (ptrdiff_t)(y >> 1) * srcStride[1], *pv = src[2] + (ptrdiff_t)(y >> 1) * srcStride[2];
+            uint8_t *d1 = dst[0] + (ptrdiff_t)(y + srcSliceY) * dstStride[0], *d2 = d1 + dstStride[0];
+            for (int i = 0; i < npairs; i++) {
+                const int U = pu[i], V = pv[i];
+                const uint8_t *r = tab + c->table_rV[V + HEADROOM], *g = tab + c->table_gU[U + HEADROOM] + c->table_gV[V + HEADROOM], *b = tab + c->table_bU[U + HEADROOM];
+                int Y;
+                Y = py1[2 * i];     d1[6 * i + ro] = r[Y]; d1[6 * i + 1] = g[Y]; d1[6 * i + bo] = b[Y];
+                Y = py1[2 * i + 1]; d1[6 * i + 3 + ro] = r[Y]; d1[6 * i + 4] = g[Y]; d1[6 * i + 3 + bo] = b[Y];
+                Y = py2[2 * i];     d2[6 * i + ro] = r[Y]; d2[6 * i + 1] = g[Y]; d2[6 * i + bo] = b[Y];
+                Y = py2[2 * i + 1]; d2[6 * i + 3 + ro] = r[Y]; d2[6 * i + 4] = g[Y]; d2[6 * i + 3 + bo] = b[Y];
+            }
+        }
+        return srcSliceH;
+    }
     for (int y = 0; y < srcSliceH; y += 2) {
         for (int l = 0; l < 2; l++) {
             int yy = y + l;
@@ -2409,6 +2435,7 @@ static void update_palette(OrSws *c, const uint8_t *pal)
         else if (f == ORF_RGB8) { r = (i >> 5) * 36; g = ((i >> 2) & 7) * 36; b = (i & 3) * 85; }
         else if (f == ORF_BGR8) { b = (i >> 6) * 85; g = ((i >> 3) & 7) * 36; r = (i & 7) * 36; }
         else if (f == ORF_RGB4_BYTE) { r = (i >> 3) * 255; g = ((i >> 1) & 3) * 85; b = (i & 1) * 255; }
+        else if (f == ORF_GRAY8) { r = g = b = i; }
         else { b = (i >> 3) * 255; g = ((i >> 1) & 3) * 85; r = (i & 1) * 255; }   /* bgr4_byte */
         y = clip_u8((t[RY] * r + t[GY] * g + t[BY] * b + (33 << (15 - 1))) >> 15);
         u = clip_u8((t[RU] * r + t[GU] * g + t[BU] * b + (257 << (15 - 1))) >> 15);
@@ -2756,12 +2783,15 @@ static const uint8_t *read_lum_line(const OrSws *c, const uint8_t *const src[], 
 }
 
 /* chroma line for chroma source row y -> (u,v) lines of chrSrcW samples */
-static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int stride[], int y,
+static void read_chr_line(const OrSws *c, const uint8_t *const src[], const int stride[], int y, int lum_row,
                           uint8_t *tu, uint8_t *tv, const uint8_t **pu, const uint8_t **pv)
 {
     const int f = c->o.src_format, w = c->chrSrcW;
     const int32_t *t = c->rgb2yuv;
-    const ptrdiff_t yl = (ptrdiff_t)y << c->chrSrcVSub;   /* planar RGB: plane 0 is indexed by luma row (hscale.c chr_convert) */
+    /* planar RGB: plane 0 is indexed by luma row.  chr_convert (hscale.c:211-225) computes that row ONCE per batch of chroma lines,
+     * "sp0 = (sliceY - (plane[0].sliceY >> v_chr_sub_sample)) << v_chr_sub_sample", and then steps it by one luma line per chroma line
+     * ("line[sp0 + i]"): the caller (main_path) hands in batch_start << chrSrcVSub + (y - batch_start) */
+    const ptrdiff_t yl = lum_row;
     int i;
     *pu = tu; *pv = tv;
     if (isPalSrc(f)) { /* palToUV_c input.c:498-512 */
@@ -3987,156 +4017,237 @@ static void write_planar_rgb_line(const OrSws *c, const Planes *P, uint8_t *cons
 #undef CV
 }
 
-/* ff_swscale (swscale.c:263-567) for a whole frame */
+/* ---- ff_swscale (swscale.c:263-567) for a whole frame, in the reference's own order of events ----
+ * The reference pulls destination rows: for every dstY it first makes sure the horizontal ring holds the source lines the row needs
+ * (running the line converters and the horizontal scaler over BATCHES of lines, ahead of need as far as the ring allows), then runs the
+ * vertical scaler for that one row.  For almost every context the result equals "h-scale the whole picture, then v-scale it"; the order
+ * matters where a stage has a side effect or a per-batch term:
+ *   - gamma_convert (gamma.c:31-58), the first luma descriptor of the gamma cascade's scaling step (slice.c:325-328), rewrites the source
+ *     lines of a batch IN PLACE.  A line that was converted ahead of need and is then pulled again after a "hole" (a jump of the vertical
+ *     filter position beyond lastInLumBuf + 1 re-bases the ring, swscale.c:404-417, :444-451) is converted a second time;
+ *   - chr_convert (hscale.c:211-225) derives plane 0's line index from the start of the batch, see read_chr_line().
+ * So the lines are produced here batch by batch exactly as swscale.c:388-535 schedules them; the h-scaled lines live in whole-frame arrays
+ * indexed by source line (what a ring slot holds is always the latest version of its line). */
+static void lum_line(OrSws *c, const uint8_t *const src[], const int srcStride[], int y, Planes *P, uint8_t *t0)
+{   /* lum_convert + lum_h_scale, hscale.c:39-131; plane 3 with the LUMA filter and no range conversion when needAlpha (desc->alpha) */
+    const int sf = c->o.src_format, srcW = c->o.src_w, dstW = c->o.dst_w;
+    const uint8_t *line = read_lum_line(c, src, srcStride, y, t0);
+    int32_t *d = P->lum + (size_t)y * dstW;
+    hscale_line(c, d, dstW, line, c->hLumFilter, c->hLumFilterPos, c->hLumFilterSize);
+    if (c->range_active) range_line(c, d, dstW, 0);
+    if (!c->needAlpha) return;
+    const uint8_t *aline;
+    if (sf == ORF_YA8) { /* uyvyToY_c on the alpha byte (input.c:2773-2775) */
+        for (int i = 0; i < srcW; i++) t0[i] = src[0][(ptrdiff_t)y * srcStride[0] + 2 * i + 1];
+        aline = t0;
+    } else if (sf == ORF_YA16LE) { /* read_ya16le_alpha_c input.c:639-645 */
+        uint16_t *d16 = (uint16_t *)t0;
+        for (int i = 0; i < srcW; i++) memcpy(&d16[i], src[0] + (ptrdiff_t)y * srcStride[0] + 4 * i + 2, 2);
+        aline = t0;
+    } else if (sf == ORF_PAL8) { /* palToA_c input.c:474-484 */
+        int16_t *d16 = (int16_t *)t0;
+        for (int i = 0; i < srcW; i++) { const uint32_t p = c->pal_yuv[src[0][(ptrdiff_t)y * srcStride[0] + i]]; d16[i] = (int16_t)((p >> 24) << 6 | p >> 26); }
+        aline = t0;
+    } else if (sf == ORF_YAF32LE || sf == ORF_YAF16LE || sf == ORF_RGBAF16LE) { /* read_yaf32_alpha_c (input.c:1422-1431), read_yaf16_alpha_c (:1620-1627),
+                                                                                 * rgbaf16ToA_endian (:1680-1687): the last element of the pixel */
+        const Desc *dsd = desc_get(sf);
+        const int half = dsd->c[0].depth == 16, ai = dsd->nb - 1;
+        const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0] + dsd->c[ai].offset;
+        uint16_t *d16 = (uint16_t *)t0;
+        for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)rdf16(sp + dsd->c[ai].step * i, half);
+        aline = t0;
+    } else if (sf == ORF_RGBA64LE || sf == ORF_BGRA64LE) { /* rgba64leToA_c: the 16-bit A sample as is */
+        const uint16_t *sp = (const uint16_t *)(src[0] + (ptrdiff_t)y * srcStride[0]) + 3;
+        uint16_t *d16 = (uint16_t *)t0;
+        for (int i = 0; i < srcW; i++) d16[i] = sp[4 * i];
+        aline = t0;
+    } else if (sf == ORF_AYUV64LE) { /* read_ayuv64le_A_c input.c:715-721 */
+        const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0];
+        uint16_t *d16 = (uint16_t *)t0;
+        for (int i = 0; i < srcW; i++) memcpy(&d16[i], sp + 8 * i, 2);
+        aline = t0;
+    } else if (isPacked444(sf)) { /* read_vuya_A_c / read_ayuv_A_c input.c:749-781 */
+        const Desc *dsd = desc_get(sf);
+        const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0] + dsd->c[3].offset;
+        for (int i = 0; i < srcW; i++) t0[i] = sp[4 * i];
+        aline = t0;
+    } else if (isPlanarRGB(sf)) { /* planar_rgb_to_a (input.c:1188-1194), planar_rgb16_s16_to_a (:1235-1247), planar_rgbf32_to_a (:1289-1298) */
+        const Desc *dsd = desc_get(sf);
+        uint16_t *d16 = (uint16_t *)t0;
+        const uint8_t *sp = src[3] + (ptrdiff_t)y * srcStride[3];
+        if ((dsd->flags & PF_FLOAT) && dsd->c[0].depth == 16) for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)rdf16(sp + 2 * i, 1);   /* planar_rgbf16_to_a :1561-1568 */
+        else if (dsd->flags & PF_FLOAT) for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)f2u16(((const float *)sp)[i]);
+        else if (dsd->c[0].depth == 8) for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)(sp[i] << 6);
+        else { const int bpc = dsd->c[0].depth, sh = 14 - (bpc < 16 ? bpc : 14); for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)(((const uint16_t *)sp)[i] << sh); }
+        aline = t0;
+    } else if (isAnyRGB(sf)) { /* rgbaToA_c / abgrToA_c input.c:454-472 */
+        const Desc *dsd = desc_get(sf);
+        const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0] + dsd->c[3].offset;
+        int16_t *d16 = (int16_t *)t0;
+        const int opaque = c->src0Alpha && !c->dst0Alpha; /* rgb0-style source: swscale.c:1106-1124 sets the X byte to 255 first */
+        for (int i = 0; i < srcW; i++) { const int a = opaque ? 255 : sp[4 * i]; d16[i] = (int16_t)(a << 6 | a >> 2); }
+        aline = t0;
+    } else aline = src[3] + (ptrdiff_t)y * srcStride[3];
+    hscale_line(c, P->alp + (size_t)y * dstW, dstW, aline, c->hLumFilter, c->hLumFilterPos, c->hLumFilterSize);
+}
+
+static void chr_line(OrSws *c, const uint8_t *const src[], const int srcStride[], int y, int lum_row, Planes *P, uint8_t *t0, uint8_t *t1)
+{   /* chr_convert + chr_h_scale, hscale.c:168-245 */
+    const uint8_t *pu, *pv;
+    int32_t *du = P->chrU + (size_t)y * c->chrDstW, *dv = P->chrV + (size_t)y * c->chrDstW;
+    read_chr_line(c, src, srcStride, y, lum_row, t0, t1, &pu, &pv);
+    hscale_line(c, du, c->chrDstW, pu, c->hChrFilter, c->hChrFilterPos, c->hChrFilterSize);
+    hscale_line(c, dv, c->chrDstW, pv, c->hChrFilter, c->hChrFilterPos, c->hChrFilterSize);
+    if (c->range_active) { range_line(c, du, c->chrDstW, 1); range_line(c, dv, c->chrDstW, 1); }
+}
+
+/* the vertical descriptors for destination row y (vscale.c, output.c) */
+static void out_row(OrSws *c, const Planes *P, uint8_t *const dst[], const int dstStride[], int y)
+{
+    const int srcH = c->o.src_h, dstW = c->o.dst_w;
+    const int df = c->o.dst_format, sf = c->o.src_format;
+    const int should_dither = isNBPS(sf) || is16BPS(sf);
+    const int chrDstY = y >> c->chrDstVSub;
+    const uint8_t *lumDither = should_dither ? dither_8x8_128[y & 7] : pb_64;       /* swscale.c:385-387, :519-522 */
+    const uint8_t *chrDither = should_dither ? dither_8x8_128[chrDstY & 7] : pb_64;
+    if (isGray(df) && !isYA(df)) { /* vscale.c:219-233: luma only */
+        int firstLum = ORMAX(1 - c->vLumFilterSize, c->vLumFilterPos[y]);
+        write_planar_line(c, dst[0] + (size_t)y * dstStride[0], dstW, P->lum, dstW, srcH, firstLum,
+                          c->vLumFilter + y * c->vLumFilterSize, c->vLumFilterSize, lumDither, 0, 1);
+    } else if (isPlanarYUV(df)) {
+        const Desc *dd = desc_get(df);
+        int firstLum = ORMAX(1 - c->vLumFilterSize, c->vLumFilterPos[y]);
+        write_planar_line(c, dst[0] + (size_t)y * dstStride[0], dstW, P->lum, dstW, srcH, firstLum,
+                          c->vLumFilter + y * c->vLumFilterSize, c->vLumFilterSize, lumDither, 0, 1);
+        if (isALPHA(df)) {
+            if (c->needAlpha) /* lum_planar_vscale vscale.c:59-71: same writer, luma filter, luma dither */
+                write_planar_line(c, dst[3] + (size_t)y * dstStride[3], dstW, P->alp, dstW, srcH, firstLum,
+                                  c->vLumFilter + y * c->vLumFilterSize, c->vLumFilterSize, lumDither, 0, 1);
+            else if (dd->c[0].depth > 8) { /* fillPlane16 (swscale.c:536-552, swscale_internal.h fillPlane16): 0xFFFF >> (16 - bits) */
+                uint16_t *a16 = (uint16_t *)(dst[3] + (size_t)y * dstStride[3]);
+                for (int i = 0; i < dstW; i++) a16[i] = (uint16_t)(0xFFFF >> (16 - dd->c[3].depth));
+            } else memset(dst[3] + (size_t)y * dstStride[3], 255, dstW); /* fillPlane swscale.c:536-552 */
+        }
+        if (!(y & ((1 << c->chrDstVSub) - 1))) { /* chr_planar_vscale vscale.c:74-107 */
+            int firstChr = ORMAX(1 - c->vChrFilterSize, c->vChrFilterPos[chrDstY]);
+            const int16_t *cf = c->vChrFilter + chrDstY * c->vChrFilterSize;
+            if (isSemiPlanarYUV(df)) {
+                write_nv_chroma_line(c, dst[1] + (size_t)chrDstY * dstStride[1], c->chrDstW, P->chrU, P->chrV,
+                                     c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither);
+            } else {
+                write_planar_line(c, dst[dd->c[1].plane] + (size_t)chrDstY * dstStride[dd->c[1].plane], c->chrDstW, P->chrU,
+                                  c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither, 0, 0);
+                write_planar_line(c, dst[dd->c[2].plane] + (size_t)chrDstY * dstStride[dd->c[2].plane], c->chrDstW, P->chrV,
+                                  c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither, 3, 0);
+            }
+        }
+    } else if (isYA(df)) {
+        write_ya_line(c, P, dst[0] + (size_t)y * dstStride[0], y);
+    } else if (isMono(df)) {
+        write_mono_line(c, P, dst[0] + (size_t)y * dstStride[0], y);
+    } else if (isPackedHi(df)) {
+        write_packedhi_line(c, P, dst[0] + (size_t)y * dstStride[0], y);
+    } else if (isPacked444(df)) {
+        write_packed444_line(c, P, dst[0] + (size_t)y * dstStride[0], y);
+    } else if (df == ORF_YUYV422 || df == ORF_UYVY422 || df == ORF_YVYU422) {
+        write_packed422_line(c, P, dst[0] + (size_t)y * dstStride[0], y);
+    } else if (df == ORF_RGB48LE || df == ORF_BGR48LE || df == ORF_RGBA64LE || df == ORF_BGRA64LE) {
+        write_packed_rgb16_line(c, P, dst[0] + (size_t)y * dstStride[0], y);
+    } else if (isAnyRGB(df) && !isPlanarRGB(df)) {
+        write_packed_rgb_line(c, P, dst[0] + (size_t)y * dstStride[0], y);
+    } else {
+        write_planar_rgb_line(c, P, dst, dstStride, y);
+    }
+}
+
+/* get_min_buffer_size (slice.c:217-243) and the floor of slice.c:266-267 (MAX_LINES_AHEAD = 4): lines per plane of the horizontal ring */
+static void ring_sizes(const OrSws *c, int *lum, int *chr)
+{
+    const int dstH = c->o.dst_h, sub = c->chrSrcVSub;
+    *lum = c->vLumFilterSize; *chr = c->vChrFilterSize;
+    for (int lumY = 0; lumY < dstH; lumY++) {
+        const int chrY = (int)((int64_t)lumY * c->chrDstH / dstH);
+        int nextSlice = ORMAX(c->vLumFilterPos[lumY] + c->vLumFilterSize - 1, (c->vChrFilterPos[chrY] + c->vChrFilterSize - 1) << sub);
+        nextSlice >>= sub; nextSlice <<= sub;
+        *lum = ORMAX(*lum, nextSlice - c->vLumFilterPos[lumY]);
+        *chr = ORMAX(*chr, (nextSlice >> sub) - c->vChrFilterPos[chrY]);
+    }
+    *lum = ORMAX(*lum, c->vLumFilterSize + 4);
+    *chr = ORMAX(*chr, c->vChrFilterSize + 4);
+}
+
 static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[],
                      uint8_t *const dst[], const int dstStride[])
 {
     const int srcW = c->o.src_w, srcH = c->o.src_h, dstW = c->o.dst_w, dstH = c->o.dst_h;
     const int df = c->o.dst_format, sf = c->o.src_format;
-    const int should_dither = isNBPS(sf) || is16BPS(sf);
+    const int vsub = c->chrSrcVSub, chrSrcSliceEnd = CEIL_RSHIFT(srcH, vsub);
+    const int needs_hcscale = !(isGray(sf) || isGray(df) || isMono(sf));   /* swscale.c:692-694 */
     Planes P;
     uint8_t *t0 = malloc((size_t)srcW * 4 + 128), *t1 = malloc((size_t)srcW * 4 + 128);
-    int y;
+    int y, lumAvail, chrAvail;
+    /* the cursor of swscale.c:294-300, :372-381 for a frame that arrives in one slice */
+    int lastInLumBuf = -1, lastInChrBuf = -1, hasLumHoles = 1, hasChrHoles = 1;
+    int lumSliceY = 0, lumSliceH = 0, chrSliceY = 0, chrSliceH = 0;   /* plane 0 / plane 1 of the horizontal scaler's output slice */
 
     /* scale_internal (swscale.c:1084-1086): a bit-exact context starts every frame from a clean error line; any other one carries it on */
     if ((c->o.flags & OR_SWS_BITEXACT) && c->o.dither == 3 && c->dither_error[0])
         for (y = 0; y < 3; y++) memset(c->dither_error[y], 0, sizeof(int) * ((size_t)dstW + 2));
 
-    P.lum = malloc((size_t)srcH * dstW * sizeof(int32_t));
+    P.lum = calloc((size_t)srcH * dstW, sizeof(int32_t));
     P.chrU = malloc((size_t)c->chrSrcH * c->chrDstW * sizeof(int32_t));
     P.chrV = malloc((size_t)c->chrSrcH * c->chrDstW * sizeof(int32_t));
-
-    for (y = 0; y < srcH; y++) { /* lum_convert + lum_h_scale, hscale.c:39-131 */
-        const uint8_t *line = read_lum_line(c, src, srcStride, y, t0);
-        int32_t *d = P.lum + (size_t)y * dstW;
-        hscale_line(c, d, dstW, line, c->hLumFilter, c->hLumFilterPos, c->hLumFilterSize);
-        if (c->range_active) range_line(c, d, dstW, 0);
-    }
-    P.alp = NULL;
-    if (c->needAlpha) { /* lum_convert/lum_h_scale also process plane 3 (hscale.c:39-131, desc->alpha) with the LUMA filter; no range conversion */
-        P.alp = malloc((size_t)srcH * dstW * sizeof(int32_t));
-        for (y = 0; y < srcH; y++) {
-            const uint8_t *line;
-            if (sf == ORF_YA8) { /* uyvyToY_c on the alpha byte (input.c:2773-2775) */
-                for (int i = 0; i < srcW; i++) t0[i] = src[0][(ptrdiff_t)y * srcStride[0] + 2 * i + 1];
-                line = t0;
-            } else if (sf == ORF_YA16LE) { /* read_ya16le_alpha_c input.c:639-645 */
-                uint16_t *d16 = (uint16_t *)t0;
-                for (int i = 0; i < srcW; i++) memcpy(&d16[i], src[0] + (ptrdiff_t)y * srcStride[0] + 4 * i + 2, 2);
-                line = t0;
-            } else if (sf == ORF_PAL8) { /* palToA_c input.c:474-484 */
-                int16_t *d16 = (int16_t *)t0;
-                for (int i = 0; i < srcW; i++) { const uint32_t p = c->pal_yuv[src[0][(ptrdiff_t)y * srcStride[0] + i]]; d16[i] = (int16_t)((p >> 24) << 6 | p >> 26); }
-                line = t0;
-            } else if (sf == ORF_YAF32LE || sf == ORF_YAF16LE || sf == ORF_RGBAF16LE) { /* read_yaf32_alpha_c (input.c:1422-1431), read_yaf16_alpha_c (:1620-1627),
-                                                                                         * rgbaf16ToA_endian (:1680-1687): the last element of the pixel */
-                const Desc *dsd = desc_get(sf);
-                const int half = dsd->c[0].depth == 16, ai = dsd->nb - 1;
-                const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0] + dsd->c[ai].offset;
-                uint16_t *d16 = (uint16_t *)t0;
-                for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)rdf16(sp + dsd->c[ai].step * i, half);
-                line = t0;
-            } else if (sf == ORF_RGBA64LE || sf == ORF_BGRA64LE) { /* rgba64leToA_c: the 16-bit A sample as is */
-                const uint16_t *sp = (const uint16_t *)(src[0] + (ptrdiff_t)y * srcStride[0]) + 3;
-                uint16_t *d16 = (uint16_t *)t0;
-                for (int i = 0; i < srcW; i++) d16[i] = sp[4 * i];
-                line = t0;
-            } else if (sf == ORF_AYUV64LE) { /* read_ayuv64le_A_c input.c:715-721 */
-                const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0];
-                uint16_t *d16 = (uint16_t *)t0;
-                for (int i = 0; i < srcW; i++) memcpy(&d16[i], sp + 8 * i, 2);
-                line = t0;
-            } else if (isPacked444(sf)) { /* read_vuya_A_c / read_ayuv_A_c input.c:749-781 */
-                const Desc *dsd = desc_get(sf);
-                const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0] + dsd->c[3].offset;
-                for (int i = 0; i < srcW; i++) t0[i] = sp[4 * i];
-                line = t0;
-            } else if (isPlanarRGB(sf)) { /* planar_rgb_to_a (input.c:1188-1194), planar_rgb16_s16_to_a (:1235-1247), planar_rgbf32_to_a (:1289-1298) */
-                const Desc *dsd = desc_get(sf);
-                uint16_t *d16 = (uint16_t *)t0;
-                const uint8_t *sp = src[3] + (ptrdiff_t)y * srcStride[3];
-                if ((dsd->flags & PF_FLOAT) && dsd->c[0].depth == 16) for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)rdf16(sp + 2 * i, 1);   /* planar_rgbf16_to_a :1561-1568 */
-                else if (dsd->flags & PF_FLOAT) for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)f2u16(((const float *)sp)[i]);
-                else if (dsd->c[0].depth == 8) for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)(sp[i] << 6);
-                else { const int bpc = dsd->c[0].depth, sh = 14 - (bpc < 16 ? bpc : 14); for (int i = 0; i < srcW; i++) d16[i] = (uint16_t)(((const uint16_t *)sp)[i] << sh); }
-                line = t0;
-            } else if (isAnyRGB(sf)) { /* rgbaToA_c / abgrToA_c input.c:454-472 */
-                const Desc *dsd = desc_get(sf);
-                const uint8_t *sp = src[0] + (ptrdiff_t)y * srcStride[0] + dsd->c[3].offset;
-                int16_t *d16 = (int16_t *)t0;
-                const int opaque = c->src0Alpha && !c->dst0Alpha; /* rgb0-style source: swscale.c:1106-1124 sets the X byte to 255 first */
-                for (int i = 0; i < srcW; i++) { const int a = opaque ? 255 : sp[4 * i]; d16[i] = (int16_t)(a << 6 | a >> 2); }
-                line = t0;
-            } else line = src[3] + (ptrdiff_t)y * srcStride[3];
-            hscale_line(c, P.alp + (size_t)y * dstW, dstW, line, c->hLumFilter, c->hLumFilterPos, c->hLumFilterSize);
-        }
-    }
-    const int needs_hcscale = !(isGray(sf) || isGray(df) || isMono(sf));   /* swscale.c:692-694 */
-    if (!needs_hcscale) { /* ff_init_desc_no_chr: the chroma lines keep fill_ones()' value (slice.c:190-208, :358-361) */
+    P.alp = c->needAlpha ? calloc((size_t)srcH * dstW, sizeof(int32_t)) : NULL;
+    {   /* fill_ones() (slice.c:190-208, :311): what a ring line holds before it is written -- the value a chroma line keeps for good when
+         * ff_init_desc_no_chr stands in for the chroma scaler (:358-361) */
         const int32_t neutral = c->dstBpc >= 16 ? 1 << 18 : 1 << 14;
         for (size_t k = 0; k < (size_t)c->chrSrcH * c->chrDstW; k++) P.chrU[k] = P.chrV[k] = neutral;
     }
-    for (y = 0; needs_hcscale && y < c->chrSrcH; y++) { /* chr_convert + chr_h_scale, hscale.c:168-245 */
-        const uint8_t *pu, *pv;
-        int32_t *du = P.chrU + (size_t)y * c->chrDstW, *dv = P.chrV + (size_t)y * c->chrDstW;
-        read_chr_line(c, src, srcStride, y, t0, t1, &pu, &pv);
-        hscale_line(c, du, c->chrDstW, pu, c->hChrFilter, c->hChrFilterPos, c->hChrFilterSize);
-        hscale_line(c, dv, c->chrDstW, pv, c->hChrFilter, c->hChrFilterPos, c->hChrFilterSize);
-        if (c->range_active) { range_line(c, du, c->chrDstW, 1); range_line(c, dv, c->chrDstW, 1); }
-    }
+    ring_sizes(c, &lumAvail, &chrAvail);
 
-    for (y = 0; y < dstH; y++) {
+    for (y = 0; y < dstH; y++) {   /* swscale.c:388-535 */
         const int chrDstY = y >> c->chrDstVSub;
-        const uint8_t *lumDither = should_dither ? dither_8x8_128[y & 7] : pb_64;       /* swscale.c:385-387, :519-522 */
-        const uint8_t *chrDither = should_dither ? dither_8x8_128[chrDstY & 7] : pb_64;
-        if (isGray(df) && !isYA(df)) { /* vscale.c:219-233: luma only */
-            int firstLum = ORMAX(1 - c->vLumFilterSize, c->vLumFilterPos[y]);
-            write_planar_line(c, dst[0] + (size_t)y * dstStride[0], dstW, P.lum, dstW, srcH, firstLum,
-                              c->vLumFilter + y * c->vLumFilterSize, c->vLumFilterSize, lumDither, 0, 1);
-        } else if (isPlanarYUV(df)) {
-            const Desc *dd = desc_get(df);
-            int firstLum = ORMAX(1 - c->vLumFilterSize, c->vLumFilterPos[y]);
-            write_planar_line(c, dst[0] + (size_t)y * dstStride[0], dstW, P.lum, dstW, srcH, firstLum,
-                              c->vLumFilter + y * c->vLumFilterSize, c->vLumFilterSize, lumDither, 0, 1);
-            if (isALPHA(df)) {
-                if (c->needAlpha) /* lum_planar_vscale vscale.c:59-71: same writer, luma filter, luma dither */
-                    write_planar_line(c, dst[3] + (size_t)y * dstStride[3], dstW, P.alp, dstW, srcH, firstLum,
-                                      c->vLumFilter + y * c->vLumFilterSize, c->vLumFilterSize, lumDither, 0, 1);
-                else if (dd->c[0].depth > 8) { /* fillPlane16 (swscale.c:536-552, swscale_internal.h fillPlane16): 0xFFFF >> (16 - bits) */
-                    uint16_t *a16 = (uint16_t *)(dst[3] + (size_t)y * dstStride[3]);
-                    for (int i = 0; i < dstW; i++) a16[i] = (uint16_t)(0xFFFF >> (16 - dd->c[3].depth));
-                } else memset(dst[3] + (size_t)y * dstStride[3], 255, dstW); /* fillPlane swscale.c:536-552 */
-            }
-            if (!(y & ((1 << c->chrDstVSub) - 1))) { /* chr_planar_vscale vscale.c:74-107 */
-                int firstChr = ORMAX(1 - c->vChrFilterSize, c->vChrFilterPos[chrDstY]);
-                const int16_t *cf = c->vChrFilter + chrDstY * c->vChrFilterSize;
-                if (isSemiPlanarYUV(df)) {
-                    write_nv_chroma_line(c, dst[1] + (size_t)chrDstY * dstStride[1], c->chrDstW, P.chrU, P.chrV,
-                                         c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither);
-                } else {
-                    write_planar_line(c, dst[dd->c[1].plane] + (size_t)chrDstY * dstStride[dd->c[1].plane], c->chrDstW, P.chrU,
-                                      c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither, 0, 0);
-                    write_planar_line(c, dst[dd->c[2].plane] + (size_t)chrDstY * dstStride[dd->c[2].plane], c->chrDstW, P.chrV,
-                                      c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither, 3, 0);
-                }
-            }
-        } else if (isYA(df)) {
-            write_ya_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
-        } else if (isMono(df)) {
-            write_mono_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
-        } else if (isPackedHi(df)) {
-            write_packedhi_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
-        } else if (isPacked444(df)) {
-            write_packed444_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
-        } else if (df == ORF_YUYV422 || df == ORF_UYVY422 || df == ORF_YVYU422) {
-            write_packed422_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
-        } else if (df == ORF_RGB48LE || df == ORF_BGR48LE || df == ORF_RGBA64LE || df == ORF_BGRA64LE) {
-            write_packed_rgb16_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
-        } else if (isAnyRGB(df) && !isPlanarRGB(df)) {
-            write_packed_rgb_line(c, &P, dst[0] + (size_t)y * dstStride[0], y);
-        } else {
-            write_planar_rgb_line(c, &P, dst, dstStride, y);
+        const int firstLumSrcY = ORMAX(1 - c->vLumFilterSize, c->vLumFilterPos[y]);
+        const int firstChrSrcY = ORMAX(1 - c->vChrFilterSize, c->vChrFilterPos[chrDstY]);
+        const int lastLumSrcY = ORMIN(srcH, firstLumSrcY + c->vLumFilterSize) - 1;
+        const int lastChrSrcY = ORMIN(c->chrSrcH, firstChrSrcY + c->vChrFilterSize) - 1;
+        int posY, cPosY, firstPosY, lastPosY, firstCPosY, lastCPosY, k;
+        if (firstLumSrcY > lastInLumBuf) {   /* "handle holes (FAST_BILINEAR & weird filters)" */
+            hasLumHoles = lastInLumBuf != firstLumSrcY - 1;
+            if (hasLumHoles) { lumSliceY = firstLumSrcY; lumSliceH = 0; }
+            lastInLumBuf = firstLumSrcY - 1;
         }
+        if (firstChrSrcY > lastInChrBuf) {
+            hasChrHoles = lastInChrBuf != firstChrSrcY - 1;
+            if (hasChrHoles) { chrSliceY = firstChrSrcY; chrSliceH = 0; }
+            lastInChrBuf = firstChrSrcY - 1;
+        }
+        /* (a whole frame always has "enough_lines") */
+        posY = lumSliceY + lumSliceH;
+        if (posY <= lastLumSrcY && !hasLumHoles) { firstPosY = ORMAX(firstLumSrcY, posY); lastPosY = ORMIN(firstLumSrcY + lumAvail - 1, srcH - 1); }
+        else { firstPosY = posY; lastPosY = lastLumSrcY; }
+        cPosY = chrSliceY + chrSliceH;
+        if (cPosY <= lastChrSrcY && !hasChrHoles) { firstCPosY = ORMAX(firstChrSrcY, cPosY); lastCPosY = ORMIN(firstChrSrcY + chrAvail - 1, chrSrcSliceEnd - 1); }
+        else { firstCPosY = cPosY; lastCPosY = lastChrSrcY; }
+        /* (ff_rotate_slice moves sliceY / sliceH by the ring size together: their sum, all that is used here, stays) */
+        if (posY < lastLumSrcY + 1) {
+            for (k = firstPosY; k <= lastPosY; k++) {
+                if (c->internal_gamma_tab) {   /* gamma_convert on the source line, in place (gamma.c:31-58) */
+                    uint16_t *row = (uint16_t *)(src[0] + (ptrdiff_t)k * srcStride[0]);
+                    for (int x = 0; x < srcW; x++) for (int q = 0; q < 3; q++) row[4 * x + q] = c->internal_gamma_tab[row[4 * x + q]];
+                }
+                lum_line(c, src, srcStride, k, &P, t0);
+            }
+            lumSliceH += lastPosY - firstPosY + 1;
+        }
+        lastInLumBuf = lastLumSrcY;
+        if (cPosY < lastChrSrcY + 1) {
+            if (needs_hcscale)
+                for (k = firstCPosY; k <= lastCPosY; k++) chr_line(c, src, srcStride, k, (firstCPosY << vsub) + (k - firstCPosY), &P, t0, t1);
+            chrSliceH += lastCPosY - firstCPosY + 1;   /* (no_chr_scale keeps its own books, hscale.c:271-278; nothing reads them) */
+        }
+        lastInChrBuf = lastChrSrcY;
+        out_row(c, &P, dst, dstStride, y);
     }
     free(P.lum); free(P.chrU); free(P.chrV); free(P.alp); free(t0); free(t1);
     return dstH;
@@ -4191,6 +4302,10 @@ static int scale_xyz(OrSws *c, const uint8_t *const src[4], const int srcStride[
     const uint8_t *sp[4] = { src[0], src[1], src[2], src[3] };
     uint8_t *scratch = NULL;
     int ret;
+    /* scale_internal (swscale.c:1076-1082) hands a cascaded context over to scale_gamma / scale_cascaded BEFORE it reaches its XYZ passes
+     * (:1126-1139, :1194-1210), and the children were created with the formats handle_formats() had already aliased to rgb48
+     * (utils.c:1461-1522, :1524-1550, :1565-1601, :1803-1833): an xyz12 picture on either side of a cascade is treated as rgb48 */
+    if (c->cascade[0]) return scale_le(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
     if (c->src_xyz && !same) {
         const int st = srcStride[0] < 0 ? -srcStride[0] : srcStride[0];
         uint8_t *base;
@@ -4288,10 +4403,8 @@ static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4
         const int *os1 = c->cascade[2] ? s1 : dstStride;
         int ret = or_sws_scale(c->cascade[0], src, srcStride, 0, srcSliceH, t0, s0), y, x, k;
         if (ret < 0) return ret;
-        for (y = 0; y < c->o.src_h; y++) {
-            uint16_t *row = (uint16_t *)(t0[0] + (ptrdiff_t)y * s0[0]);
-            for (x = 0; x < c->o.src_w; x++) for (k = 0; k < 3; k++) row[4 * x + k] = c->inv_gamma_tab[row[4 * x + k]];
-        }
+        /* (the inverse table is applied by the scaling step itself, line by line as its ring pulls them: main_path()) */
+        c->cascade[1]->internal_gamma_tab = c->inv_gamma_tab;
         ret = or_sws_scale(c->cascade[1], (const uint8_t *const *)t0, s0, 0, c->o.src_h, out1, os1);
         if (ret < 0) return ret;
         for (y = 0; y < c->o.dst_h; y++) {
@@ -4320,7 +4433,7 @@ static int scale_le(OrSws *c, const uint8_t *const src[4], const int srcStride[4
     if (c->o.dst_format == ORF_YUVA420P && dst[3] &&
         (c->unscaled_kind == UNSC_BGR24_YV12 || c->unscaled_kind == UNSC_YVU9_YV12 || c->unscaled_kind == UNSC_P4222PLANAR))
         for (int y = 0; y < srcSliceH; y++) memset(dst[3] + (ptrdiff_t)y * dstStride[3], 255, c->o.src_w);
-    if (isPalSrc(c->o.src_format)) update_palette(c, src[1]);   /* scale_internal, swscale.c:1088-1089 */
+    if (usePal(c->o.src_format)) update_palette(c, src[1]);   /* scale_internal, swscale.c:1088-1089 */
     switch (c->unscaled_kind) {
     case UNSC_PAL2RGB: return unscaled_pal2rgb(c, src, srcStride, 0, srcSliceH, dst, dstStride);
     case UNSC_BAYER: return unscaled_bayer(c, src, srcStride, 0, srcSliceH, dst, dstStride);
