@@ -443,7 +443,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         // ---- packed 24 / 32 bpp RGB into 8-bit 4:2:0 / 4:2:2 YUV of the same size (sws_k_rgbsrc_unity): identity horizontal filters and luma
         //      vertical filter, chroma of the "half" readers through a vertical filter of up to 16 taps whose positions only move forward ----
         d->rgbsrc_ok = false;
-        if (d->unity_h && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32) && p.chr_half && !p.range_active && !p.need_alpha && !p.no_chroma &&
+        if (d->unity_h && !d->vlines_on && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chr_half && !p.range_active && !p.need_alpha && !p.no_chroma &&
             !p.wide && !p.dst_alpha_fill && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_NV12) && p.dst_bits == 8 && p.chrDstHSub == 1 && p.chrDstVSub <= 1 &&
             p.chrSrcVSub == 0 && p.srcH == p.dstH && bank_is_identity(c->vLum, 1 << 12) && c->vChr.size <= 16 && p.chrDstW == ((p.dstW + 1) >> 1) &&
             !p.should_dither && !c->tune.no_rgbsrc) {
@@ -472,6 +472,15 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 d->rgbsrc_rows = (const SwsRgbSrcRow *)d->d_dot2;
                 d->rgbsrc_ok = true;
             }
+        }
+        // ---- 8-bit RGB (packed 24 / 32 bpp, planar) into planar 8-bit 4:4:4 YUV of the same size: all four banks the identity, full chroma readers ----
+        d->rgb444_ok = false;
+        if (d->unity_h && d->unity_v && !d->vlines_on && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && !p.chr_half && !p.range_active &&
+            !p.need_alpha && !p.no_chroma && !p.wide && !p.dst_alpha_fill && p.dstKind == DSTK_PLANAR8 && p.dst_bits == 8 && p.chrDstHSub == 0 && p.chrDstVSub == 0 &&
+            p.chrSrcVSub == 0 && !p.should_dither && !c->tune.no_rgbsrc) {
+            bool fits = true;
+            for (int k = 0; k < 9; k++) fits = fits && p.rgb2yuv[k] > -32768 && p.rgb2yuv[k] < 32768;   // (v_dot2_i32_i16 operands)
+            d->rgb444_ok = fits;
         }
         // ---- dot2 tile kernel (sws_k_tile_dot2): planar 8-bit / <= 15-bit sources, 15-bit intermediates, vfs >= 2 ----
         d->dot2_ok = false;
@@ -855,6 +864,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             c->path_name = "main:fused_f32rgb_yuv444"; c->kernel_name = "sws_k_f32rgb_to_yuv444_unity";
         } else if (d->rgbsrc_ok) {
             c->path_name = "main:rgbsrc_unity"; c->kernel_name = "sws_k_rgbsrc_unity";
+        } else if (d->rgb444_ok) {
+            c->path_name = "main:rgb_yuv444_unity"; c->kernel_name = "sws_k_rgb_yuv444_unity";
         } else if (d->mixed_ok) {
             c->path_name = "main:plane1+strip_chroma"; c->kernel_name = "sws_k_strip_march";
         } else if (d->unity_h) {
@@ -877,6 +888,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     }
     default: c->path_name = "none"; c->kernel_name = ""; break;
     }
+    // (16-byte aligned pictures of the layout converters take the streaming kernel, k_layout.hip; the names above are the fallback's)
+    if (!c->tune.no_layout_stream && (c->plan == PLAN_UNSC_PLANAR2NV12 || c->plan == PLAN_UNSC_NV122PLANAR || c->plan == PLAN_UNSC_PLANARCOPY || c->plan == PLAN_UNSC_PLANAR2NV24 ||
+                                      c->plan == PLAN_UNSC_NV242PLANAR || c->plan == PLAN_UNSC_P4222PLANAR || c->plan == PLAN_UNSC_PLANAR2P422))
+        c->kernel_name = "sws_k_layout_stream";
     log_msg(c, 2, "HIP path: %s (dominant kernel %s)\n", c->path_name.c_str(), c->kernel_name.c_str());
     d->epoch = c->tables_epoch;
     return 0;
@@ -1052,6 +1067,7 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
                  (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16))
             ret = launch_f32rgb(L);
         else if (d->rgbsrc_ok && vec) ret = launch_rgbsrc(L);                                             // packed RGB source, same size
+        else if (d->rgb444_ok && vec) ret = launch_rgb444(L);                                             // 8-bit RGB -> planar 4:4:4, same size
         else if (d->striprgb_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_striprgb(L);   // marching strip kernel, RGB epilogue
         else if (d->mixed_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_mixed(L);   // identity luma: streaming pass + strip kernel on chroma
         else if (d->strip_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_strip(L);   // marching strip kernel
@@ -1527,7 +1543,8 @@ static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4
         // the special converters leave the last pixel (pair) of an odd width untouched (yuv2rgb.c pair loops, planarToP01x's
         // "src_w / 2" chroma loop, nv24_to_yuv420p_chroma, planarToYuy2 ...): the staging picture starts from the caller's data
         // (planarRgbToplanarRgbWrapper on 16-bit formats leaves the second half of the slice's last row -- or of every row -- untouched)
-        if (unscaled && ((o.dst_w & 1) || (o.dst_h & 1) || c->plan == PLAN_UNSC_PLANARRGB_PLANARRGB)) {   // (odd heights: yuyvtoyuv420 writes chroma on odd rows only)
+        // (ff_sws_alphablendaway covers chrSrcW columns of planes 1 and 2: half of a gbrap picture when init halved the RGB chroma width)
+        if (unscaled && ((o.dst_w & 1) || (o.dst_h & 1) || c->plan == PLAN_UNSC_PLANARRGB_PLANARRGB || c->plan == PLAN_UNSC_ALPHABLEND)) {   // (odd heights: yuyvtoyuv420 writes chroma on odd rows only)
             for (int k = 0; k < npd; k++) {
                 int rb, prow; plane_geometry(o.dst_format, o.dst_w, o.dst_h, k, &rb, &prow);
                 int y0, rows; rows_of_slice(o.dst_format, k, outY, outH, &y0, &rows);

@@ -28,6 +28,7 @@ struct DeviceState {
     void *d_xyz = nullptr; size_t xyz_bytes = 0; void *d_xyz_tab = nullptr;   // rgb48 copies of xyz12 source pictures; the four gamma LUTs
     bool dot2_ok = false; SwsTileGeom dotL, dotC; void *d_dot2 = nullptr; size_t dot2_bytes = 0;
     const SwsRgbSrcRow *rgbsrc_rows = nullptr;             // (in d_dot2)
+    bool rgb444_ok = false;                                // sws_k_rgb_yuv444_unity (8-bit RGB -> planar 8-bit 4:4:4 YUV of the same size, all filters the identity)
     bool rgbsrc_ok = false;                                // sws_k_rgbsrc_unity (packed 24 / 32 bpp RGB -> 8-bit 4:2:x YUV of the same size)
     bool mixed_ok = false;                                 // identity luma (streaming plane pass) + strip kernel on the chroma planes only (launch_mixed)
     bool strip_ok = false; SwsStripGeom stripL, stripC;    // sws_k_strip_march (tables live in d_dot2)
@@ -88,6 +89,7 @@ void launch_fill_alpha(const LaunchCtx &L, int w, int y0, int rows, int bits);
 void launch_update_palette(const LaunchCtx &L);
 int launch_layout_plane1(const LaunchCtx &L);   // k_layout.hip: the luma plane of a context with identity luma filters (launch_mixed)
 int launch_mixed(const LaunchCtx &L);           // k_strip.hip
+int launch_rgb444(const LaunchCtx &L);          // k_stream.hip
 int launch_layout(const LaunchCtx &L);   // k_layout.hip: 1 = launched, 0 = not a shape of the streaming family
 void launch_ed_mono(hipStream_t st, const uint8_t *lum, int64_t lumStride, uint8_t *dst, int64_t dstStride, int n, int h, int *errline, int white);
 void launch_alpha_merge(const LaunchCtx &L, int npix, int y0, int rows, int a_pos);

@@ -78,16 +78,16 @@ int launch_layout(const LaunchCtx &L)
     default: return 0;
     }
     if (!plan.njobs) return 0;
-    int rows = 0, chunks = 0;
+    int groups = 0, chunks = 0;
     for (int i = 0; i < plan.njobs; i++) {
         const LayoutJob &j = plan.job[i];
-        rows += j.rows;
+        groups += cdiv(j.rows, LAYOUT_RPW);
         const int unit = (j.op == LOP_IL || j.op == LOP_8TO16 || j.op == LOP_P422_JOIN) ? 8 : 16;
         chunks = std::max(chunks, (int)cdiv(j.n, unit));
     }
-    const dim3 blk(256);
-    if (c->tune.layout_ch == 2) hipLaunchKernelGGL((sws_k_layout_stream<2>), dim3(cdiv(chunks, 512), rows, n), blk, 0, st, fs, p, plan);
-    else hipLaunchKernelGGL((sws_k_layout_stream<1>), dim3(cdiv(chunks, 256), rows, n), blk, 0, st, fs, p, plan);
+    const dim3 blk(256), grid(cdiv(chunks, 256), groups, n);
+    if (c->tune.layout_ch == 2) hipLaunchKernelGGL((sws_k_layout_stream<2>), grid, blk, 0, st, fs, p, plan);
+    else hipLaunchKernelGGL((sws_k_layout_stream<4>), grid, blk, 0, st, fs, p, plan);
     return 1;
 }
 
@@ -108,7 +108,7 @@ int launch_layout_plane1(const LaunchCtx &L)
     else if (s8) { j.op = LOP_8TO16; j.n = p.srcW; j.a0 = p.dst_bits - 8; j.a1 = 32; j.a2 = p.dst_shift; }
     else { j.op = d8 ? LOP_P1_16TO8 : LOP_P1_16TO16; j.n = 2 * p.srcW; j.a0 = p.src_shift; j.a1 = p.hshift; j.a2 = p.dst_bits; j.a3 = p.dst_shift; }
     const int unit = j.op == LOP_8TO16 ? 8 : 16;
-    hipLaunchKernelGGL((sws_k_layout_stream<1>), dim3(cdiv(cdiv(j.n, unit), 256), j.rows, L.n), dim3(256), 0, st, fs, p, plan);
+    hipLaunchKernelGGL((sws_k_layout_stream<4>), dim3(cdiv(cdiv(j.n, unit), 256), cdiv(j.rows, LAYOUT_RPW), L.n), dim3(256), 0, st, fs, p, plan);
     return 0;
 }
 

@@ -62,9 +62,25 @@ int launch_rgbsrc(const LaunchCtx &L)
     const bool r8 = p.vChrFs <= 8;
 #define SWS_RGBSRC(B, N) do { if (r8) hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity<B, N, 8>), grid, blk, 0, st, fs, p, g); \
                               else    hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity<B, N, 16>), grid, blk, 0, st, fs, p, g); } while (0)
-    if (p.srcKind == SRCK_RGB24) { if (nv) SWS_RGBSRC(3, true); else SWS_RGBSRC(3, false); }
+    if (p.srcKind == SRCK_GBRP) { if (nv) SWS_RGBSRC(0, true); else SWS_RGBSRC(0, false); }
+    else if (p.srcKind == SRCK_RGB24) { if (nv) SWS_RGBSRC(3, true); else SWS_RGBSRC(3, false); }
     else                         { if (nv) SWS_RGBSRC(4, true); else SWS_RGBSRC(4, false); }
 #undef SWS_RGBSRC
+    return 0;
+}
+
+// packed / planar 8-bit RGB -> planar 8-bit 4:4:4 YUV of the same size: every filter the identity (dev_prepare_on: rgb444_ok)
+int launch_rgb444(const LaunchCtx &L)
+{
+    const SwsDevParams &p = *L.p; hipStream_t st = L.st; const SwsFrameSet &fs = L.fs;
+    const int n = L.n;
+    const int lanes = cdiv(p.dstW, 4), waves_row = cdiv(lanes, 64);
+    const int bands = std::max(1, std::min((int)cdiv(8192, waves_row * n), (int)cdiv(p.dstH, 4)));
+    const int band_rows = cdiv(p.dstH, bands);
+    const dim3 grid(cdiv(lanes, 256), cdiv(p.dstH, band_rows), n), blk(256);
+    if (p.srcKind == SRCK_GBRP) hipLaunchKernelGGL((swsk::sws_k_rgb_yuv444_unity<0>), grid, blk, 0, st, fs, p, band_rows);
+    else if (p.srcKind == SRCK_RGB24) hipLaunchKernelGGL((swsk::sws_k_rgb_yuv444_unity<3>), grid, blk, 0, st, fs, p, band_rows);
+    else hipLaunchKernelGGL((swsk::sws_k_rgb_yuv444_unity<4>), grid, blk, 0, st, fs, p, band_rows);
     return 0;
 }
 

@@ -1,8 +1,8 @@
 // Streaming form of the pure layout / depth converters (planarCopyWrapper incl. DITHER_COPY, planarToNv12 / nv12ToPlanar and the nv24
 // twins, yuyv / uyvy <-> planar): the decoder -> filter -> encoder format changes.  Every sample is independent and the work is a
 // handful of shifts per 16 bytes, so the only thing that matters is how the bytes move: a lane owns 16-byte chunks spaced one wave apart
-// (every load / store instruction of a wave covers a contiguous KiB), plane pointers and strides sit in SGPRs (load_frame), all loads of a
-// lane are issued before its first store, stores are non-temporal.  The element-per-thread kernels of kernels_misc.hpp / kernels_shuffle.hpp
+// (every load / store instruction of a wave covers a contiguous KiB), plane pointers and strides sit in SGPRs (load_frame), a wave walks down
+// eight rows of its chunk column with the loads of four rows issued before the first store, stores are non-temporal.  The element-per-thread kernels of kernels_misc.hpp / kernels_shuffle.hpp
 // keep the pictures whose pointers or strides are not 16-byte aligned and the rare converters (yvu9, nv24 -> yuv420p).
 // Arithmetic: the same expressions as those kernels (cited there), per element.
 #pragma once
@@ -41,96 +41,104 @@ __device__ __forceinline__ void lstore8(uint8_t *d, u32x2 v, int nvalid)
     else { const u32x4 t = { v[0], v[1], 0, 0 }; gstore_partial(d, t, nvalid); }
 }
 
-template <int CH>
+// RPW rows per wave: a wave owns one 1 KiB chunk column of a job (64 lanes x 16 bytes of the wider side) and walks down RPW rows of it, RU rows
+// at a time: the loads of RU rows are issued before the first store, the per-wave set-up (frame descriptor, job look-up) is paid once per
+// RPW KiB instead of once per KiB.  blockIdx.y counts groups of RPW rows over all jobs (LayoutJob::rows rounded up per job).
+constexpr int LAYOUT_RPW = 8;
+
+template <int RU>
 __global__ void __launch_bounds__(256) sws_k_layout_stream(SwsFrameSet fs, SwsDevParams p, LayoutPlan plan)
 {
     const FrameRegs f = load_frame(fs, blockIdx.z);
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int r = blockIdx.y, ji = 0;
-    while (ji < plan.njobs && r >= U(plan.job[ji].rows)) { r -= U(plan.job[ji].rows); ji++; }
+    const int cx = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // chunk column of this wave
+    int g = blockIdx.y, ji = 0;
+    while (ji < plan.njobs && g >= (U(plan.job[ji].rows) + LAYOUT_RPW - 1) / LAYOUT_RPW) { g -= (U(plan.job[ji].rows) + LAYOUT_RPW - 1) / LAYOUT_RPW; ji++; }
     if (ji >= plan.njobs) return;
     // (scalar copies of the job: a run-time index into the by-value argument would put it into scratch memory)
-    int op = 0, ys = 0, yd = 0, sa = 0, sb = 0, da = 0, db = 0, n = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+    int op = 0, rows = 0, ys = 0, yd = 0, sa = 0, sb = 0, da = 0, db = 0, n = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
 #pragma unroll
     for (int k = 0; k < 6; k++)
         if (k == ji) {
             const LayoutJob &J = plan.job[k];
-            op = U(J.op); ys = U(J.ys); yd = U(J.yd); sa = U(J.sa); sb = U(J.sb); da = U(J.da); db = U(J.db); n = U(J.n);
+            op = U(J.op); rows = U(J.rows); ys = U(J.ys); yd = U(J.yd); sa = U(J.sa); sb = U(J.sb); da = U(J.da); db = U(J.db); n = U(J.n);
             a0 = U(J.a0); a1 = U(J.a1); a2 = U(J.a2); a3 = U(J.a3); a4 = U(J.a4);
         }
-    {   // chunks are counted in 16 bytes of n, or in 8 (the ops whose other side is twice as wide)
-        const int unit = (op == LOP_IL || op == LOP_8TO16 || op == LOP_P422_JOIN) ? 8 : 16;
-        if (wave * CH * 64 * unit >= n) return;
-    }
-    const uint8_t *srowA = pick4(f.src, sa) + (int64_t)(ys + r) * pick4(f.srcStride, sa);
-    const uint8_t *srowB = pick4(f.src, sb) + (int64_t)(ys + r) * pick4(f.srcStride, sb);
-    uint8_t *drowA = pick4(f.dst, da) + (int64_t)(yd + r) * pick4(f.dstStride, da);
-    uint8_t *drowB = pick4(f.dst, db) + (int64_t)(yd + r) * pick4(f.dstStride, db);
-    auto chunk = [&](int k) { return (wave * CH + k) * 64 + lane; };
+    // chunks are counted in 16 bytes of n, or in 8 (the ops whose other side is twice as wide)
+    const int unit = (op == LOP_IL || op == LOP_8TO16 || op == LOP_P422_JOIN) ? 8 : 16;
+    if (cx * 64 * unit >= n) return;
+    const int off = (cx * 64 + lane) * unit;          // this lane's byte offset into the n-byte side of a row
+    const bool in = off < n;
+    const int r0 = g * LAYOUT_RPW, r1 = min(rows, r0 + LAYOUT_RPW);
+    const int64_t ssA = pick4(f.srcStride, sa), ssB = pick4(f.srcStride, sb), dsA = pick4(f.dstStride, da), dsB = pick4(f.dstStride, db);
+    const uint8_t *sbaseA = pick4(f.src, sa) + (int64_t)ys * ssA, *sbaseB = pick4(f.src, sb) + (int64_t)ys * ssB;
+    uint8_t *dbaseA = pick4(f.dst, da) + (int64_t)yd * dsA, *dbaseB = pick4(f.dst, db) + (int64_t)yd * dsB;
 
     switch (op) {
     case LOP_COPY: {   // n bytes of a row as they are
-        u32x4 v[CH];
+        for (int r = r0; r < r1; r += RU) {
+            u32x4 v[RU];
 #pragma unroll
-        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 16; if (off < n) v[k] = load16_or_tail(srowA + off, n - off); }
+            for (int i = 0; i < RU; i++) if (in && r + i < r1) v[i] = load16_or_tail(sbaseA + (r + i) * ssA + off, n - off);
 #pragma unroll
-        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 16; if (off < n) lstore16(drowA + off, v[k], n - off); }
+            for (int i = 0; i < RU; i++) if (in && r + i < r1) lstore16(dbaseA + (r + i) * dsA + off, v[i], n - off);
+        }
         break;
     }
     case LOP_FILL: {   // fillPlane / fillPlane16: a0 = the 32-bit pattern
         const u32x4 v = { (uint32_t)a0, (uint32_t)a0, (uint32_t)a0, (uint32_t)a0 };
-#pragma unroll
-        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 16; if (off < n) lstore16(drowA + off, v, n - off); }
+        for (int r = r0; r < r1; r++) if (in) lstore16(dbaseA + r * dsA + off, v, n - off);
         break;
     }
     case LOP_IL: {     // planarToNv12 / Nv24: n bytes of plane A and of plane B -> 2n interleaved bytes (A first)
-        u32x2 a[CH], b[CH];
+        for (int r = r0; r < r1; r += RU) {
+            u32x2 a[RU], b[RU];
 #pragma unroll
-        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 8; if (off < n) { a[k] = load8_or_tail(srowA + off, n - off); b[k] = load8_or_tail(srowB + off, n - off); } }
+            for (int i = 0; i < RU; i++) if (in && r + i < r1) { a[i] = load8_or_tail(sbaseA + (r + i) * ssA + off, n - off); b[i] = load8_or_tail(sbaseB + (r + i) * ssB + off, n - off); }
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int off = chunk(k) * 8;
-            if (off >= n) continue;
-            const u32x4 o = { __builtin_amdgcn_perm(b[k][0], a[k][0], 0x05010400u), __builtin_amdgcn_perm(b[k][0], a[k][0], 0x07030602u),
-                              __builtin_amdgcn_perm(b[k][1], a[k][1], 0x05010400u), __builtin_amdgcn_perm(b[k][1], a[k][1], 0x07030602u) };
-            lstore16(drowA + 2 * off, o, 2 * (n - off));
+            for (int i = 0; i < RU; i++) {
+                if (!(in && r + i < r1)) continue;
+                const u32x4 o = { __builtin_amdgcn_perm(b[i][0], a[i][0], 0x05010400u), __builtin_amdgcn_perm(b[i][0], a[i][0], 0x07030602u),
+                                  __builtin_amdgcn_perm(b[i][1], a[i][1], 0x05010400u), __builtin_amdgcn_perm(b[i][1], a[i][1], 0x07030602u) };
+                lstore16(dbaseA + (r + i) * dsA + 2 * off, o, 2 * (n - off));
+            }
         }
         break;
     }
     case LOP_DIL: {    // nv12ToPlanar / nv24ToPlanar: n interleaved bytes -> n/2 to plane A (even bytes), n/2 to plane B (odd bytes)
-        u32x4 v[CH];
+        for (int r = r0; r < r1; r += RU) {
+            u32x4 v[RU];
 #pragma unroll
-        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 16; if (off < n) v[k] = load16_or_tail(srowA + off, n - off); }
+            for (int i = 0; i < RU; i++) if (in && r + i < r1) v[i] = load16_or_tail(sbaseA + (r + i) * ssA + off, n - off);
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int off = chunk(k) * 16;
-            if (off >= n) continue;
-            const u32x2 ea = { __builtin_amdgcn_perm(v[k][1], v[k][0], 0x06040200u), __builtin_amdgcn_perm(v[k][3], v[k][2], 0x06040200u) };
-            const u32x2 eb = { __builtin_amdgcn_perm(v[k][1], v[k][0], 0x07050301u), __builtin_amdgcn_perm(v[k][3], v[k][2], 0x07050301u) };
-            const int nv = (n - off + 1) >> 1, nb = (n - off) >> 1;
-            lstore8(drowA + (off >> 1), ea, nv); lstore8(drowB + (off >> 1), eb, nb);
+            for (int i = 0; i < RU; i++) {
+                if (!(in && r + i < r1)) continue;
+                const u32x2 ea = { __builtin_amdgcn_perm(v[i][1], v[i][0], 0x06040200u), __builtin_amdgcn_perm(v[i][3], v[i][2], 0x06040200u) };
+                const u32x2 eb = { __builtin_amdgcn_perm(v[i][1], v[i][0], 0x07050301u), __builtin_amdgcn_perm(v[i][3], v[i][2], 0x07050301u) };
+                lstore8(dbaseA + (r + i) * dsA + (off >> 1), ea, (n - off + 1) >> 1); lstore8(dbaseB + (r + i) * dsB + (off >> 1), eb, (n - off) >> 1);
+            }
         }
         break;
     }
     case LOP_8TO16: {  // planarCopy 8 -> 9..16 bit (swscale_unscaled.c:2266-2284): a0 = left shift, a1 = right shift of the replicated bits (32: none), a2 = dst_shift
-        u32x2 s[CH];
+        for (int r = r0; r < r1; r += RU) {
+            u32x2 s8[RU];
 #pragma unroll
-        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 8; if (off < n) s[k] = load8_or_tail(srowA + off, n - off); }
+            for (int i = 0; i < RU; i++) if (in && r + i < r1) s8[i] = load8_or_tail(sbaseA + (r + i) * ssA + off, n - off);
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int off = chunk(k) * 8;
-            if (off >= n) continue;
-            uint32_t o[4];
+            for (int i = 0; i < RU; i++) {
+                if (!(in && r + i < r1)) continue;
+                uint32_t o[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t w = s[k][q >> 1] >> (16 * (q & 1));
-                const uint32_t e0 = w & 0xFF, e1 = (w >> 8) & 0xFF;
-                const uint32_t v0 = (((e0 << a0) | (a1 < 32 ? e0 >> a1 : 0u)) << a2) & 0xFFFFu, v1 = (((e1 << a0) | (a1 < 32 ? e1 >> a1 : 0u)) << a2) & 0xFFFFu;
-                o[q] = v0 | (v1 << 16);
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t w = s8[i][q >> 1] >> (16 * (q & 1));
+                    const uint32_t e0 = w & 0xFF, e1 = (w >> 8) & 0xFF;
+                    const uint32_t v0 = (((e0 << a0) | (a1 < 32 ? e0 >> a1 : 0u)) << a2) & 0xFFFFu, v1 = (((e1 << a0) | (a1 < 32 ? e1 >> a1 : 0u)) << a2) & 0xFFFFu;
+                    o[q] = v0 | (v1 << 16);
+                }
+                const u32x4 ov = { o[0], o[1], o[2], o[3] };
+                lstore16(dbaseA + (r + i) * dsA + 2 * off, ov, 2 * (n - off));
             }
-            const u32x4 ov = { o[0], o[1], o[2], o[3] };
-            lstore16(drowA + 2 * off, ov, 2 * (n - off));
         }
         break;
     }
@@ -139,40 +147,41 @@ __global__ void __launch_bounds__(256) sws_k_layout_stream(SwsFrameSet fs, SwsDe
         // a0 = mode: 0 dither off, 1 dither + shiftonly, 2 dither full range, 3 widening shiftonly, 4 widening with bit replication
         // a1 = shift (|sd - dd|), a2 = src_shift, a3 = dst_shift, a4 = dd | body_end << 8 (elements), widening: a4 = 2 * sd - dd
         const int mode = a0, shift = a1, ss = a2, dsh = a3, dd = a4 & 0xFF, body_end = a4 >> 8;
-        u32x4 s[CH];
+        const bool body = (off >> 1) < body_end;
+        for (int r = r0; r < r1; r += RU) {
+            u32x4 s16[RU];
 #pragma unroll
-        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 16; if (off < n) s[k] = load16_or_tail(srowA + off, n - off); }
-        // the dither row of this picture row: eight bytes, the same for every lane (x & 7 = the element's place in its group of eight)
-        uint32_t dlo = 0, dhi = 0;
-        if (mode == 1 || mode == 2) {
-            const uint32_t *dr = (const uint32_t *)k_layout_dithers[shift - 1][r & 7];
-            dlo = U(dr[0]); dhi = U(dr[1]);
-        }
+            for (int i = 0; i < RU; i++) if (in && r + i < r1) s16[i] = load16_or_tail(sbaseA + (r + i) * ssA + off, n - off);
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int off = chunk(k) * 16;
-            if (off >= n) continue;
-            const bool body = (off >> 1) < body_end;
-            uint32_t e[8];
+            for (int i = 0; i < RU; i++) {
+                if (!(in && r + i < r1)) continue;
+                // the dither row of this picture row: eight bytes, the same for every lane (x & 7 = the element's place in its group of eight)
+                uint32_t dlo = 0, dhi = 0;
+                if (mode == 1 || mode == 2) {
+                    const uint32_t *dr = (const uint32_t *)k_layout_dithers[shift - 1][(r + i) & 7];
+                    dlo = U(dr[0]); dhi = U(dr[1]);
+                }
+                uint32_t e[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const uint32_t sv = (s[k][q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
-                const uint32_t dth = ((q < 4 ? dlo : dhi) >> (8 * (q & 3))) & 0xFFu;
-                uint32_t tmp, v;
-                if (mode == 0) { const uint32_t bias = 1u << (shift - 1); tmp = ((body ? sv >> ss : sv) + bias) >> shift; v = (tmp - (tmp >> dd)) << dsh; }
-                else if (mode == 1) { tmp = ((body ? sv >> ss : sv) + dth) >> shift; v = (tmp - (tmp >> dd)) << dsh; }
-                else if (mode == 2) { tmp = body ? sv >> ss : sv; v = (tmp - (tmp >> dd) + dth) >> shift; if (body) v <<= dsh; }
-                else if (mode == 3) { v = ((sv >> ss) << shift) << dsh; }
-                else { const uint32_t t = sv >> ss; v = ((t << shift) | (t >> (a4))) << dsh; }
-                e[q] = v;
-            }
-            if (op == LOP_16TO8) {
-                const u32x2 o = { (e[0] & 0xFF) | ((e[1] & 0xFF) << 8) | ((e[2] & 0xFF) << 16) | (e[3] << 24),
-                                  (e[4] & 0xFF) | ((e[5] & 0xFF) << 8) | ((e[6] & 0xFF) << 16) | (e[7] << 24) };
-                lstore8(drowA + (off >> 1), o, (n - off) >> 1);
-            } else {
-                const u32x4 o = { (e[0] & 0xFFFF) | (e[1] << 16), (e[2] & 0xFFFF) | (e[3] << 16), (e[4] & 0xFFFF) | (e[5] << 16), (e[6] & 0xFFFF) | (e[7] << 16) };
-                lstore16(drowA + off, o, n - off);
+                for (int q = 0; q < 8; q++) {
+                    const uint32_t sv = (s16[i][q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+                    const uint32_t dth = ((q < 4 ? dlo : dhi) >> (8 * (q & 3))) & 0xFFu;
+                    uint32_t tmp, v;
+                    if (mode == 0) { const uint32_t bias = 1u << (shift - 1); tmp = ((body ? sv >> ss : sv) + bias) >> shift; v = (tmp - (tmp >> dd)) << dsh; }
+                    else if (mode == 1) { tmp = ((body ? sv >> ss : sv) + dth) >> shift; v = (tmp - (tmp >> dd)) << dsh; }
+                    else if (mode == 2) { tmp = body ? sv >> ss : sv; v = (tmp - (tmp >> dd) + dth) >> shift; if (body) v <<= dsh; }
+                    else if (mode == 3) { v = ((sv >> ss) << shift) << dsh; }
+                    else { const uint32_t t = sv >> ss; v = ((t << shift) | (t >> (a4))) << dsh; }
+                    e[q] = v;
+                }
+                if (op == LOP_16TO8) {
+                    const u32x2 o = { (e[0] & 0xFF) | ((e[1] & 0xFF) << 8) | ((e[2] & 0xFF) << 16) | (e[3] << 24),
+                                      (e[4] & 0xFF) | ((e[5] & 0xFF) << 8) | ((e[6] & 0xFF) << 16) | (e[7] << 24) };
+                    lstore8(dbaseA + (r + i) * dsA + (off >> 1), o, (n - off) >> 1);
+                } else {
+                    const u32x4 o = { (e[0] & 0xFFFF) | (e[1] << 16), (e[2] & 0xFFFF) | (e[3] << 16), (e[4] & 0xFFFF) | (e[5] << 16), (e[6] & 0xFFFF) | (e[7] << 16) };
+                    lstore16(dbaseA + (r + i) * dsA + off, o, n - off);
+                }
             }
         }
         break;
@@ -180,125 +189,134 @@ __global__ void __launch_bounds__(256) sws_k_layout_stream(SwsFrameSet fs, SwsDe
     case LOP_P1_16TO8:     // the scaler chain with identity filters on a plane of 9..16-bit samples: hScale16To15_c with the single tap 1 << 14
     case LOP_P1_16TO16: {  // (swscale.c:99-125), then yuv2plane1_8_c with the row's ff_dither_8x8_128 line (output.c:485-493, swscale.c:519-522) or
         // yuv2plane1_10 / 12 / 14 (output.c:327-341).  a0 = src_shift, a1 = hscale shift, a2 = destination bits, a3 = dst_shift; rows are absolute
-        u32x4 s[CH];
+        for (int r = r0; r < r1; r += RU) {
+            u32x4 s16[RU];
 #pragma unroll
-        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 16; if (off < n) s[k] = load16_or_tail(srowA + off, n - off); }
-        uint32_t dth[8];
+            for (int i = 0; i < RU; i++) if (in && r + i < r1) s16[i] = load16_or_tail(sbaseA + (r + i) * ssA + off, n - off);
 #pragma unroll
-        for (int q = 0; q < 8; q++) dth[q] = U((uint32_t)k_dither_8x8_128[(yd + r) & 7][q]);
+            for (int i = 0; i < RU; i++) {
+                if (!(in && r + i < r1)) continue;
+                uint32_t dth[8];
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int off = chunk(k) * 16;
-            if (off >= n) continue;
-            uint32_t e[8];
+                for (int q = 0; q < 8; q++) dth[q] = U((uint32_t)k_dither_8x8_128[(yd + r + i) & 7][q]);
+                uint32_t e[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int sv = (int)((s[k][q >> 1] >> (16 * (q & 1))) & 0xFFFFu) >> a0;
-                const int hv = min((sv << 14) >> a1, (1 << 15) - 1);
-                if (op == LOP_P1_16TO8) e[q] = (uint32_t)clip_u8_shr(hv + (int)dth[q], 7);
-                else { const int sh = 15 - a2; e[q] = (uint32_t)clip_uintp2((hv + (1 << (sh - 1))) >> sh, a2) << a3; }
-            }
-            if (op == LOP_P1_16TO8) {
-                const u32x2 o = { e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24), e[4] | (e[5] << 8) | (e[6] << 16) | (e[7] << 24) };
-                lstore8(drowA + (off >> 1), o, (n - off) >> 1);
-            } else {
-                const u32x4 o = { e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16) };
-                lstore16(drowA + off, o, n - off);
+                for (int q = 0; q < 8; q++) {
+                    const int sv = (int)((s16[i][q >> 1] >> (16 * (q & 1))) & 0xFFFFu) >> a0;
+                    const int hv = min((sv << 14) >> a1, (1 << 15) - 1);
+                    if (op == LOP_P1_16TO8) e[q] = (uint32_t)clip_u8_shr(hv + (int)dth[q], 7);
+                    else { const int sh = 15 - a2; e[q] = (uint32_t)clip_uintp2((hv + (1 << (sh - 1))) >> sh, a2) << a3; }
+                }
+                if (op == LOP_P1_16TO8) {
+                    const u32x2 o = { e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24), e[4] | (e[5] << 8) | (e[6] << 16) | (e[7] << 24) };
+                    lstore8(dbaseA + (r + i) * dsA + (off >> 1), o, (n - off) >> 1);
+                } else {
+                    const u32x4 o = { e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16) };
+                    lstore16(dbaseA + (r + i) * dsA + off, o, n - off);
+                }
             }
         }
         break;
     }
     case LOP_P422_SPLIT: {   // yuyvtoyuv422_c / uyvytoyuv422_c (rgb2rgb_template.c:751-825): n = packed bytes that carry whole pairs; a0 = 1 for uyvy, a1 = swap U / V (yvyu)
         // a2 = luma samples of the row (an odd width: the last pair's second luma byte is not stored)
-        u32x4 v[CH];
+        const uint32_t ysel = a0 ? 0x07050301u : 0x06040200u;
+        // chroma bytes of a dword pair: yuyv: U at 1, 5; V at 3, 7.  uyvy: U at 0, 4; V at 2, 6
+        const uint32_t usel = a0 ? 0x0c0c0400u : 0x0c0c0501u, vsel = a0 ? 0x0c0c0602u : 0x0c0c0703u;
+        const int upl = a1 ? 2 : 1, vpl = 3 - upl;
+        const int64_t dsU = pick4(f.dstStride, upl), dsV = pick4(f.dstStride, vpl);
+        uint8_t *ubase = pick4(f.dst, upl) + (int64_t)yd * dsU, *vbase = pick4(f.dst, vpl) + (int64_t)yd * dsV;
+        for (int r = r0; r < r1; r += RU) {
+            u32x4 v[RU];
 #pragma unroll
-        for (int k = 0; k < CH; k++) { const int off = chunk(k) * 16; if (off < n) v[k] = load16_or_tail(srowA + off, n - off); }
+            for (int i = 0; i < RU; i++) if (in && r + i < r1) v[i] = load16_or_tail(sbaseA + (r + i) * ssA + off, n - off);
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int off = chunk(k) * 16;
-            if (off >= n) continue;
-            const uint32_t ysel = a0 ? 0x07050301u : 0x06040200u;
-            const u32x2 yv = { __builtin_amdgcn_perm(v[k][1], v[k][0], ysel), __builtin_amdgcn_perm(v[k][3], v[k][2], ysel) };
-            // chroma bytes of a dword pair: yuyv: U at 1, 5; V at 3, 7.  uyvy: U at 0, 4; V at 2, 6
-            const uint32_t usel = a0 ? 0x0c0c0400u : 0x0c0c0501u, vsel = a0 ? 0x0c0c0602u : 0x0c0c0703u;
-            const uint32_t u = __builtin_amdgcn_perm(v[k][1], v[k][0], usel) | (__builtin_amdgcn_perm(v[k][3], v[k][2], usel) << 16);
-            const uint32_t w = __builtin_amdgcn_perm(v[k][1], v[k][0], vsel) | (__builtin_amdgcn_perm(v[k][3], v[k][2], vsel) << 16);
-            lstore8(drowA + (off >> 1), yv, min(8, a2 - (off >> 1)));
-            const int nc = (n - off) >> 2;   // chroma samples behind this chunk
-            uint8_t *pu = (a1 ? pick4(f.dst, 2) + (int64_t)(yd + r) * pick4(f.dstStride, 2) : drowB) + (off >> 2);
-            uint8_t *pv = (a1 ? drowB : pick4(f.dst, 2) + (int64_t)(yd + r) * pick4(f.dstStride, 2)) + (off >> 2);
-            if (nc >= 4) { *(uint32_t *)pu = u; *(uint32_t *)pv = w; }
-            else for (int b = 0; b < nc; b++) { pu[b] = (uint8_t)(u >> (8 * b)); pv[b] = (uint8_t)(w >> (8 * b)); }
+            for (int i = 0; i < RU; i++) {
+                if (!(in && r + i < r1)) continue;
+                const u32x2 yv = { __builtin_amdgcn_perm(v[i][1], v[i][0], ysel), __builtin_amdgcn_perm(v[i][3], v[i][2], ysel) };
+                const uint32_t u = __builtin_amdgcn_perm(v[i][1], v[i][0], usel) | (__builtin_amdgcn_perm(v[i][3], v[i][2], usel) << 16);
+                const uint32_t w = __builtin_amdgcn_perm(v[i][1], v[i][0], vsel) | (__builtin_amdgcn_perm(v[i][3], v[i][2], vsel) << 16);
+                lstore8(dbaseA + (r + i) * dsA + (off >> 1), yv, min(8, a2 - (off >> 1)));
+                const int nc = (n - off) >> 2;   // chroma samples behind this chunk
+                uint8_t *pu = ubase + (r + i) * dsU + (off >> 2), *pv = vbase + (r + i) * dsV + (off >> 2);
+                if (nc >= 4) { *(uint32_t *)pu = u; *(uint32_t *)pv = w; }
+                else for (int b = 0; b < nc; b++) { pu[b] = (uint8_t)(u >> (8 * b)); pv[b] = (uint8_t)(w >> (8 * b)); }
+            }
         }
         break;
     }
     case LOP_P422_SPLIT420: {   // yuyvtoyuv420_c / uyvytoyuv420_c: a ROW PAIR per job row (luma of both rows, chroma = truncating mean of the two);
-        // a3 = rows of the slice (an odd count: the last row has luma only); ys / yd count luma rows; da = 0, chroma planes 1 / 2
-        const int y0 = 2 * r, two = (y0 + 1 < a3);
-        const uint8_t *s0 = pick4(f.src, sa) + (int64_t)(ys + y0) * pick4(f.srcStride, sa), *s1 = s0 + pick4(f.srcStride, sa);
-        uint8_t *d0 = f.dst[0] + (int64_t)(yd + y0) * f.dstStride[0], *d1 = d0 + f.dstStride[0];
-        const int cr = (yd >> 1) + r;
-        uint8_t *pu = (a1 ? f.dst[2] : f.dst[1]) + (int64_t)cr * (a1 ? f.dstStride[2] : f.dstStride[1]);
-        uint8_t *pv = (a1 ? f.dst[1] : f.dst[2]) + (int64_t)cr * (a1 ? f.dstStride[1] : f.dstStride[2]);
-        u32x4 v0[CH], v1[CH];
+        // a3 = rows of the slice (an odd count: the last row has luma only); ys / yd count luma rows; chroma planes 1 / 2
+        const uint32_t ysel = a0 ? 0x07050301u : 0x06040200u;
+        const uint32_t usel = a0 ? 0x0c0c0400u : 0x0c0c0501u, vsel = a0 ? 0x0c0c0602u : 0x0c0c0703u;
+        const int upl = a1 ? 2 : 1, vpl = 3 - upl;
+        const int64_t dsU = pick4(f.dstStride, upl), dsV = pick4(f.dstStride, vpl);
+        uint8_t *ubase = pick4(f.dst, upl) + (int64_t)(yd >> 1) * dsU, *vbase = pick4(f.dst, vpl) + (int64_t)(yd >> 1) * dsV;
+        constexpr int PU = RU > 2 ? 2 : RU;   // row pairs in flight
+        for (int r = r0; r < r1; r += PU) {
+            u32x4 v0[PU], v1[PU];
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int off = chunk(k) * 16;
-            if (off < n) { v0[k] = load16_or_tail(s0 + off, n - off); v1[k] = two ? load16_or_tail(s1 + off, n - off) : v0[k]; }
-        }
+            for (int i = 0; i < PU; i++) {
+                if (!(in && r + i < r1)) continue;
+                const int y0 = 2 * (r + i);
+                v0[i] = load16_or_tail(sbaseA + y0 * ssA + off, n - off);
+                v1[i] = (y0 + 1 < a3) ? load16_or_tail(sbaseA + (y0 + 1) * ssA + off, n - off) : v0[i];
+            }
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int off = chunk(k) * 16;
-            if (off >= n) continue;
-            const uint32_t ysel = a0 ? 0x07050301u : 0x06040200u;
-            const u32x2 ya = { __builtin_amdgcn_perm(v0[k][1], v0[k][0], ysel), __builtin_amdgcn_perm(v0[k][3], v0[k][2], ysel) };
-            const u32x2 yb = { __builtin_amdgcn_perm(v1[k][1], v1[k][0], ysel), __builtin_amdgcn_perm(v1[k][3], v1[k][2], ysel) };
-            const int nl = min(8, a2 - (off >> 1));
-            lstore8(d0 + (off >> 1), ya, nl);
-            if (two) {
-                lstore8(d1 + (off >> 1), yb, nl);
-                // per-byte truncating mean (a + b) >> 1 = (a & b) + ((a ^ b) >> 1) on the chroma bytes
-                uint32_t m[4];
+            for (int i = 0; i < PU; i++) {
+                if (!(in && r + i < r1)) continue;
+                const int y0 = 2 * (r + i);
+                const bool two = y0 + 1 < a3;
+                const u32x2 ya = { __builtin_amdgcn_perm(v0[i][1], v0[i][0], ysel), __builtin_amdgcn_perm(v0[i][3], v0[i][2], ysel) };
+                const u32x2 yb = { __builtin_amdgcn_perm(v1[i][1], v1[i][0], ysel), __builtin_amdgcn_perm(v1[i][3], v1[i][2], ysel) };
+                const int nl = min(8, a2 - (off >> 1));
+                lstore8(dbaseA + y0 * dsA + (off >> 1), ya, nl);
+                if (two) {
+                    lstore8(dbaseA + (y0 + 1) * dsA + (off >> 1), yb, nl);
+                    // per-byte truncating mean (a + b) >> 1 = (a & b) + ((a ^ b) >> 1) on the chroma bytes
+                    uint32_t m[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) m[q] = (v0[k][q] & v1[k][q]) + (((v0[k][q] ^ v1[k][q]) >> 1) & 0x7F7F7F7Fu);
-                const uint32_t usel = a0 ? 0x0c0c0400u : 0x0c0c0501u, vsel = a0 ? 0x0c0c0602u : 0x0c0c0703u;
-                const uint32_t u = __builtin_amdgcn_perm(m[1], m[0], usel) | (__builtin_amdgcn_perm(m[3], m[2], usel) << 16);
-                const uint32_t w = __builtin_amdgcn_perm(m[1], m[0], vsel) | (__builtin_amdgcn_perm(m[3], m[2], vsel) << 16);
-                const int nc = (n - off) >> 2;
-                if (nc >= 4) { *(uint32_t *)(pu + (off >> 2)) = u; *(uint32_t *)(pv + (off >> 2)) = w; }
-                else for (int b = 0; b < nc; b++) { pu[(off >> 2) + b] = (uint8_t)(u >> (8 * b)); pv[(off >> 2) + b] = (uint8_t)(w >> (8 * b)); }
+                    for (int q = 0; q < 4; q++) m[q] = (v0[i][q] & v1[i][q]) + (((v0[i][q] ^ v1[i][q]) >> 1) & 0x7F7F7F7Fu);
+                    const uint32_t u = __builtin_amdgcn_perm(m[1], m[0], usel) | (__builtin_amdgcn_perm(m[3], m[2], usel) << 16);
+                    const uint32_t w = __builtin_amdgcn_perm(m[1], m[0], vsel) | (__builtin_amdgcn_perm(m[3], m[2], vsel) << 16);
+                    const int nc = (n - off) >> 2;
+                    uint8_t *pu = ubase + (r + i) * dsU + (off >> 2), *pv = vbase + (r + i) * dsV + (off >> 2);
+                    if (nc >= 4) { *(uint32_t *)pu = u; *(uint32_t *)pv = w; }
+                    else for (int b = 0; b < nc; b++) { pu[b] = (uint8_t)(u >> (8 * b)); pv[b] = (uint8_t)(w >> (8 * b)); }
+                }
             }
         }
         break;
     }
     case LOP_P422_JOIN: {   // yuvPlanartoyuy2_c / yuvPlanartouyvy_c (rgb2rgb_template.c:379-470): n = luma bytes that are in whole pairs; a0 = 1 for uyvy;
-        // a1 = luma rows per chroma row (1: 4:2:2 source, 2: 4:2:0), chroma row = (ys_c + r / a1) with ys_c = a2
-        const int cr = a2 + (a1 == 2 ? (r >> 1) : r);
-        const uint8_t *su = f.src[1] + (int64_t)cr * f.srcStride[1], *sv = f.src[2] + (int64_t)cr * f.srcStride[2];
-        u32x2 yv[CH]; uint32_t u[CH], w[CH];
+        // a1 = luma rows per chroma row (1: 4:2:2 source, 2: 4:2:0), a2 = first chroma row
+        const int64_t ssU = f.srcStride[1], ssV = f.srcStride[2];
+        for (int r = r0; r < r1; r += RU) {
+            u32x2 yv[RU]; uint32_t u[RU], w[RU];
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int off = chunk(k) * 8;
-            if (off >= n) continue;
-            yv[k] = load8_or_tail(srowA + off, n - off);
-            if (n - off >= 8) { u[k] = *(const uint32_t *)(su + (off >> 1)); w[k] = *(const uint32_t *)(sv + (off >> 1)); }
-            else { u[k] = w[k] = 0; for (int b = 0; b < ((n - off) >> 1); b++) { u[k] |= (uint32_t)su[(off >> 1) + b] << (8 * b); w[k] |= (uint32_t)sv[(off >> 1) + b] << (8 * b); } }
-        }
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int off = chunk(k) * 8;
-            if (off >= n) continue;
-            // chroma pairs: c01 = U0 V0 U1 V1, c23 = U2 V2 U3 V3
-            const uint32_t c01 = __builtin_amdgcn_perm(w[k], u[k], 0x05010400u), c23 = __builtin_amdgcn_perm(w[k], u[k], 0x07030602u);
-            u32x4 o;
-            if (!a0) {   // Y0 U Y1 V
-                o[0] = __builtin_amdgcn_perm(c01, yv[k][0], 0x05010400u); o[1] = __builtin_amdgcn_perm(c01, yv[k][0], 0x07030602u);
-                o[2] = __builtin_amdgcn_perm(c23, yv[k][1], 0x05010400u); o[3] = __builtin_amdgcn_perm(c23, yv[k][1], 0x07030602u);
-            } else {     // U Y0 V Y1
-                o[0] = __builtin_amdgcn_perm(yv[k][0], c01, 0x05010400u); o[1] = __builtin_amdgcn_perm(yv[k][0], c01, 0x07030602u);
-                o[2] = __builtin_amdgcn_perm(yv[k][1], c23, 0x05010400u); o[3] = __builtin_amdgcn_perm(yv[k][1], c23, 0x07030602u);
+            for (int i = 0; i < RU; i++) {
+                if (!(in && r + i < r1)) continue;
+                const int cr = a2 + (a1 == 2 ? ((r + i) >> 1) : (r + i));
+                const uint8_t *su = f.src[1] + cr * ssU + (off >> 1), *sv = f.src[2] + cr * ssV + (off >> 1);
+                yv[i] = load8_or_tail(sbaseA + (r + i) * ssA + off, n - off);
+                if (n - off >= 8) { u[i] = *(const uint32_t *)su; w[i] = *(const uint32_t *)sv; }
+                else { u[i] = w[i] = 0; for (int b = 0; b < ((n - off) >> 1); b++) { u[i] |= (uint32_t)su[b] << (8 * b); w[i] |= (uint32_t)sv[b] << (8 * b); } }
             }
-            lstore16(drowA + 2 * off, o, 2 * (n - off));
+#pragma unroll
+            for (int i = 0; i < RU; i++) {
+                if (!(in && r + i < r1)) continue;
+                // chroma pairs: c01 = U0 V0 U1 V1, c23 = U2 V2 U3 V3
+                const uint32_t c01 = __builtin_amdgcn_perm(w[i], u[i], 0x05010400u), c23 = __builtin_amdgcn_perm(w[i], u[i], 0x07030602u);
+                u32x4 o;
+                if (!a0) {   // Y0 U Y1 V
+                    o[0] = __builtin_amdgcn_perm(c01, yv[i][0], 0x05010400u); o[1] = __builtin_amdgcn_perm(c01, yv[i][0], 0x07030602u);
+                    o[2] = __builtin_amdgcn_perm(c23, yv[i][1], 0x05010400u); o[3] = __builtin_amdgcn_perm(c23, yv[i][1], 0x07030602u);
+                } else {     // U Y0 V Y1
+                    o[0] = __builtin_amdgcn_perm(yv[i][0], c01, 0x05010400u); o[1] = __builtin_amdgcn_perm(yv[i][0], c01, 0x07030602u);
+                    o[2] = __builtin_amdgcn_perm(yv[i][1], c23, 0x05010400u); o[3] = __builtin_amdgcn_perm(yv[i][1], c23, 0x07030602u);
+                }
+                lstore16(dbaseA + (r + i) * dsA + 2 * off, o, 2 * (n - off));
+            }
         }
         break;
     }

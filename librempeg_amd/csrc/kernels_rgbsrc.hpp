@@ -52,7 +52,9 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
     // per-byte coefficients: rgb24 has r / b at byte 0 / 2 or 2 / 0; the 32-bit rows have every component at any of the four bytes.  Packed for
     // v_dot2_i32_i16 against a pixel split into {byte 0, byte 2} and {byte 1, byte 3} halves (every coefficient fits int16: host check)
     const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);
-    const int rp = U(p.src_r_pos), gp = BPP == 3 ? 1 : U(p.src_g_pos), bp = U(p.src_b_pos);
+    // (BPP == 0: planar 8-bit G, B, R planes -- gbrp, gbrap without its alpha: planar_rgb_to_y / gbr24pToUV_half_c (input.c:1174-1186, :414-432) are
+    //  rgb24ToY_c / rgb24ToUV_half_c with the bytes fetched from three planes; a pixel is assembled as {R, B} / {G} halves, i.e. r, g, b at bytes 0, 1, 2)
+    const int rp = BPP == 0 ? 0 : U(p.src_r_pos), gp = BPP == 4 ? U(p.src_g_pos) : 1, bp = BPP == 0 ? 2 : U(p.src_b_pos);
     auto coef = [&](const Rgb2YuvRow &w, int k) { return (uint32_t)(uint16_t)(k == rp ? w.r : k == gp ? w.g : k == bp ? w.b : 0); };
     const uint32_t cyA = coef(ty, 0) | coef(ty, 2) << 16, cyB = coef(ty, 1) | coef(ty, 3) << 16;
     const uint32_t cuA = coef(tu, 0) | coef(tu, 2) << 16, cuB = coef(tu, 1) | coef(tu, 3) << 16;
@@ -61,24 +63,30 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
     const bool full = x0 + 4 <= W;                     // (the last group of a ragged width goes byte by byte)
     const int ncol = min(2, cW - 2 * t);               // chroma columns of this lane
     const int uplane = U(p.u_plane_dst), vplane = U(p.v_plane_dst);
-    const uint8_t *s0 = f.src[0];
-    const int64_t sst = f.srcStride[0];
+    const uint8_t *s0 = f.src[0], *s1 = f.src[1], *s2 = f.src[2];
+    const int64_t sst = f.srcStride[0], sst1 = f.srcStride[1], sst2 = f.srcStride[2];
     // (the next row's load is issued before this row's arithmetic and stores: the compiler cannot move a load above a store that may alias)
     uint32_t nx[4] = {};
     auto fetch = [&](int r) {
-        const uint8_t *row = s0 + (int64_t)r * sst + (int64_t)BPP * x0;
-        if (BPP == 3) { nx[0] = ((const uint32_t *)row)[0]; nx[1] = ((const uint32_t *)row)[1]; nx[2] = ((const uint32_t *)row)[2]; }
+        const uint8_t *row = s0 + (int64_t)r * sst + (int64_t)(BPP ? BPP : 1) * x0;
+        if (BPP == 0) { nx[0] = *(const uint32_t *)row; nx[1] = *(const uint32_t *)(s1 + (int64_t)r * sst1 + x0); nx[2] = *(const uint32_t *)(s2 + (int64_t)r * sst2 + x0); }
+        else if (BPP == 3) { nx[0] = ((const uint32_t *)row)[0]; nx[1] = ((const uint32_t *)row)[1]; nx[2] = ((const uint32_t *)row)[2]; }
         else { const uint4 q = *(const uint4 *)row; nx[0] = q.x; nx[1] = q.y; nx[2] = q.z; nx[3] = q.w; }
     };
     if (full) fetch(rlo);
     for (int r = rlo; r <= rhi; r++) {
         // ---- the row's four pixels (and, for a ragged width, the partner of the last odd pixel: the half readers read it too) ----
         uint32_t lo[4], hi[4];     // per pixel: {byte 0, byte 2} and {byte 1, byte 3 (0 for 24 bpp)} as 16-bit halves
-        const uint8_t *row = s0 + (int64_t)r * sst + (int64_t)BPP * x0;
+        const uint8_t *row = s0 + (int64_t)r * sst + (int64_t)(BPP ? BPP : 1) * x0;
         if (full) {
             const uint32_t d[4] = { nx[0], nx[1], nx[2], nx[3] };
             if (r < rhi) fetch(r + 1);
-            if (BPP == 3) {
+            if (BPP == 0) {   // d[0] = four G, d[1] = four B, d[2] = four R
+                lo[0] = __builtin_amdgcn_perm(d[1], d[2], 0x0c040c00u); hi[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c00u);
+                lo[1] = __builtin_amdgcn_perm(d[1], d[2], 0x0c050c01u); hi[1] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c01u);
+                lo[2] = __builtin_amdgcn_perm(d[1], d[2], 0x0c060c02u); hi[2] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c02u);
+                lo[3] = __builtin_amdgcn_perm(d[1], d[2], 0x0c070c03u); hi[3] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c03u);
+            } else if (BPP == 3) {
                 lo[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c020c00u); hi[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c01u);
                 lo[1] = __builtin_amdgcn_perm(d[1], d[0], 0x0c050c03u); hi[1] = __builtin_amdgcn_perm(d[1], d[0], 0x0c0c0c04u);
                 lo[2] = __builtin_amdgcn_perm(d[2], d[1], 0x0c040c02u); hi[2] = __builtin_amdgcn_perm(d[2], d[1], 0x0c0c0c03u);
@@ -93,8 +101,13 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
             for (int k = 0; k < 4; k++) {
                 lo[k] = hi[k] = 0;
                 if (k < npx) {
-                    lo[k] = row[BPP * k] | (uint32_t)row[BPP * k + 2] << 16;
-                    hi[k] = row[BPP * k + 1] | (BPP == 4 ? (uint32_t)row[BPP * k + 3] << 16 : 0u);
+                    if (BPP == 0) {
+                        lo[k] = (s2 + (int64_t)r * sst2 + x0)[k] | (uint32_t)(s1 + (int64_t)r * sst1 + x0)[k] << 16;
+                        hi[k] = row[k];
+                    } else {
+                        lo[k] = row[BPP * k] | (uint32_t)row[BPP * k + 2] << 16;
+                        hi[k] = row[BPP * k + 1] | (BPP == 4 ? (uint32_t)row[BPP * k + 3] << 16 : 0u);
+                    }
                 }
             }
         }
@@ -105,7 +118,7 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
             for (int k = 0; k < 4; k++) {
                 const int S = sdot2(lo[k], cyA, sdot2_first_s(hi[k], cyB));
                 int yr;
-                if (BPP == 3) yr = (uint16_t)((S + (32 << 14) + (1 << 8)) >> 9);
+                if (BPP != 4) yr = (uint16_t)((S + (32 << 14) + (1 << 8)) >> 9);
                 else yr = (uint16_t)((((unsigned)S << 8) + ((32u << 22) + (1u << 16))) >> 17);
                 const int y15 = (int16_t)min((yr * 16384) >> hshift, hclip);
                 out |= (uint32_t)clip_u8_shr(y15 + 64, 7) << (8 * k);   // (8-bit sources: no dither pattern, swscale.c:292-293)
@@ -122,7 +135,7 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
                 const uint32_t al = lo[2 * k] + lo[2 * k + 1], ah = hi[2 * k] + hi[2 * k + 1];
                 const int Su = sdot2(al, cuA, sdot2_first_s(ah, cuB)), Sv = sdot2(al, cvA, sdot2_first_s(ah, cvB));
                 int ur, vr;
-                if (BPP == 3) {
+                if (BPP != 4) {
                     ur = (uint16_t)((Su + (256 << 15) + (1 << 9)) >> 10);
                     vr = (uint16_t)((Sv + (256 << 15) + (1 << 9)) >> 10);
                 } else {
@@ -168,6 +181,93 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
             if (cy < cy1) { e = load_rgbsrc_row(rows, cy); clast = clampc(e.last); }
             else clast = 0x7fffffff;
         }
+    }
+}
+
+// Packed 24 / 32 bpp RGB and planar 8-bit GBR into planar 8-bit 4:4:4 YUV of the same size: every filter is the identity, every pixel
+// independent.  rgb24ToY_c / rgb24ToUV_c (input.c:1068-1124), rgb16_32ToY / UV_c_template with the 32-bit rows (:264-334), planar_rgb_to_y /
+// _uv (:1174-1211), hScale16To15_c with one tap, yuv2plane1_8_c (8-bit source: the constant 64, swscale.c:385-387).  Lane = four pixels, a
+// wave walks down a band of rows with the next row's load in flight; three dword stores per row.
+template <int BPP>
+__global__ void __launch_bounds__(256) sws_k_rgb_yuv444_unity(SwsFrameSet fs, SwsDevParams p, int band_rows)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int W = U(p.dstW), H = U(p.dstH), x0 = 4 * t;
+    if (x0 >= W) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int y0 = blockIdx.y * U(band_rows), y1 = min(H, y0 + U(band_rows));
+    const int hshift = U(p.hshift), hclip = U(p.hclip);
+    const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);
+    const int rp = BPP == 0 ? 0 : U(p.src_r_pos), gp = BPP == 4 ? U(p.src_g_pos) : 1, bp = BPP == 0 ? 2 : U(p.src_b_pos);
+    auto coef = [&](const Rgb2YuvRow &w, int k) { return (uint32_t)(uint16_t)(k == rp ? w.r : k == gp ? w.g : k == bp ? w.b : 0); };
+    const uint32_t cyA = coef(ty, 0) | coef(ty, 2) << 16, cyB = coef(ty, 1) | coef(ty, 3) << 16;
+    const uint32_t cuA = coef(tu, 0) | coef(tu, 2) << 16, cuB = coef(tu, 1) | coef(tu, 3) << 16;
+    const uint32_t cvA = coef(tv, 0) | coef(tv, 2) << 16, cvB = coef(tv, 1) | coef(tv, 3) << 16;
+    const bool full = x0 + 4 <= W;
+    const int uplane = U(p.u_plane_dst), vplane = U(p.v_plane_dst);
+    const uint8_t *s0 = f.src[0], *s1 = f.src[1], *s2 = f.src[2];
+    const int64_t sst = f.srcStride[0], sst1 = f.srcStride[1], sst2 = f.srcStride[2];
+    uint32_t nx[4] = {};
+    auto fetch = [&](int r) {
+        const uint8_t *row = s0 + (int64_t)r * sst + (int64_t)(BPP ? BPP : 1) * x0;
+        if (BPP == 0) { nx[0] = *(const uint32_t *)row; nx[1] = *(const uint32_t *)(s1 + (int64_t)r * sst1 + x0); nx[2] = *(const uint32_t *)(s2 + (int64_t)r * sst2 + x0); }
+        else if (BPP == 3) { nx[0] = ((const uint32_t *)row)[0]; nx[1] = ((const uint32_t *)row)[1]; nx[2] = ((const uint32_t *)row)[2]; }
+        else { const uint4 q = *(const uint4 *)row; nx[0] = q.x; nx[1] = q.y; nx[2] = q.z; nx[3] = q.w; }
+    };
+    if (full && y0 < y1) fetch(y0);
+    for (int r = y0; r < y1; r++) {
+        uint32_t lo[4], hi[4];     // per pixel: {byte 0, byte 2} and {byte 1, byte 3 (0 for 24 bpp)} as 16-bit halves
+        const uint8_t *row = s0 + (int64_t)r * sst + (int64_t)(BPP ? BPP : 1) * x0;
+        if (full) {
+            const uint32_t d[4] = { nx[0], nx[1], nx[2], nx[3] };
+            if (r + 1 < y1) fetch(r + 1);
+            if (BPP == 0) {
+                lo[0] = __builtin_amdgcn_perm(d[1], d[2], 0x0c040c00u); hi[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c00u);
+                lo[1] = __builtin_amdgcn_perm(d[1], d[2], 0x0c050c01u); hi[1] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c01u);
+                lo[2] = __builtin_amdgcn_perm(d[1], d[2], 0x0c060c02u); hi[2] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c02u);
+                lo[3] = __builtin_amdgcn_perm(d[1], d[2], 0x0c070c03u); hi[3] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c03u);
+            } else if (BPP == 3) {
+                lo[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c020c00u); hi[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c01u);
+                lo[1] = __builtin_amdgcn_perm(d[1], d[0], 0x0c050c03u); hi[1] = __builtin_amdgcn_perm(d[1], d[0], 0x0c0c0c04u);
+                lo[2] = __builtin_amdgcn_perm(d[2], d[1], 0x0c040c02u); hi[2] = __builtin_amdgcn_perm(d[2], d[1], 0x0c0c0c03u);
+                lo[3] = __builtin_amdgcn_perm(d[2], d[2], 0x0c030c01u); hi[3] = __builtin_amdgcn_perm(d[2], d[2], 0x0c0c0c02u);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) { lo[k] = d[k] & 0x00FF00FFu; hi[k] = (d[k] >> 8) & 0x00FF00FFu; }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                lo[k] = hi[k] = 0;
+                if (k < W - x0) {
+                    if (BPP == 0) { lo[k] = (s2 + (int64_t)r * sst2 + x0)[k] | (uint32_t)(s1 + (int64_t)r * sst1 + x0)[k] << 16; hi[k] = row[k]; }
+                    else { lo[k] = row[BPP * k] | (uint32_t)row[BPP * k + 2] << 16; hi[k] = row[BPP * k + 1] | (BPP == 4 ? (uint32_t)row[BPP * k + 3] << 16 : 0u); }
+                }
+            }
+        }
+        uint32_t oy = 0, ou = 0, ov = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int Sy = sdot2(lo[k], cyA, sdot2_first_s(hi[k], cyB)), Su = sdot2(lo[k], cuA, sdot2_first_s(hi[k], cuB)), Sv = sdot2(lo[k], cvA, sdot2_first_s(hi[k], cvB));
+            int yr, ur, vr;
+            if (BPP != 4) {
+                yr = (uint16_t)((Sy + (32 << 14) + (1 << 8)) >> 9);
+                ur = (uint16_t)((Su + (256 << 14) + (1 << 8)) >> 9);
+                vr = (uint16_t)((Sv + (256 << 14) + (1 << 8)) >> 9);
+            } else {
+                yr = (uint16_t)((((unsigned)Sy << 8) + ((32u << 22) + (1u << 16))) >> 17);
+                ur = (uint16_t)((((unsigned)Su << 8) + ((256u << 22) + (1u << 16))) >> 17);
+                vr = (uint16_t)((((unsigned)Sv << 8) + ((256u << 22) + (1u << 16))) >> 17);
+            }
+            const int y15 = (int16_t)min((yr * 16384) >> hshift, hclip), u15 = (int16_t)min((ur * 16384) >> hshift, hclip), v15 = (int16_t)min((vr * 16384) >> hshift, hclip);
+            oy |= (uint32_t)clip_u8_shr(y15 + 64, 7) << (8 * k);
+            ou |= (uint32_t)clip_u8_shr(u15 + 64, 7) << (8 * k);
+            ov |= (uint32_t)clip_u8_shr(v15 + 64, 7) << (8 * k);
+        }
+        uint8_t *dy = f.dst[0] + (int64_t)r * f.dstStride[0] + x0;
+        uint8_t *du = pick4(f.dst, uplane) + (int64_t)r * pick4(f.dstStride, uplane) + x0, *dv = pick4(f.dst, vplane) + (int64_t)r * pick4(f.dstStride, vplane) + x0;
+        if (full) { *(uint32_t *)dy = oy; *(uint32_t *)du = ou; *(uint32_t *)dv = ov; }
+        else for (int k = 0; k < W - x0; k++) { dy[k] = (uint8_t)(oy >> (8 * k)); du[k] = (uint8_t)(ou >> (8 * k)); dv[k] = (uint8_t)(ov >> (8 * k)); }
     }
 }
 

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 BX = SWS_BITEXACT
 PATH = "main:rgbsrc_unity"
 
-SRC = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "0bgr"]
+SRC = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "0bgr", "gbrp", "gbrap"]   # (planar 8-bit GBR: the same arithmetic, three planes)
 DST = ["yuv420p", "yuv422p", "nv12", "nv21", "nv16", "yuvj420p"]
 
 
@@ -34,7 +34,7 @@ def test_formats(src, dst):
 @pytest.mark.parametrize("geom", [(640, 96), (130, 200), (4, 2), (2, 2), (1, 1), (5, 3), (1922, 34)], ids=lambda g: f"{g[0]}x{g[1]}")
 def test_scalers_and_ragged_sizes(flags, geom):
     w, h = geom
-    for src, dst in (("rgb24", "yuv420p"), ("bgra", "nv12"), ("argb", "yuv422p")):
+    for src, dst in (("rgb24", "yuv420p"), ("bgra", "nv12"), ("argb", "yuv422p"), ("gbrp", "yuv420p")):
         path, _ = run_case(w, h, src, w, h, dst, flags | BX, seed=7)
         if flags != SWS_FAST_BILINEAR and not (flags in (SWS_SINC, SWS_SPLINE) and dst != "yuv422p") and not w & 1:
             assert path == PATH, path     # (fast bilinear has its own horizontal functions; the 2:1 chroma filters of sinc and spline have more than 16 taps)
@@ -86,3 +86,19 @@ def test_batches_bands_and_host_frames():
                 assert np.array_equal(a[:, :rb], b[:, :rb]), (src, dst, k)
         p.close()
     assert run_case(322, 240, "rgba", 322, 240, "nv21", SWS_BICUBIC | BX, seed=4, device_frames=False)[0] == PATH
+
+
+PATH444 = "main:rgb_yuv444_unity"
+
+
+@pytest.mark.parametrize("src", SRC)
+def test_rgb_to_yuv444_unity(src):
+    """sws_k_rgb_yuv444_unity: 8-bit RGB into planar 8-bit 4:4:4 YUV of the same size (all filters the identity, full chroma readers)"""
+    for i, (w, h) in enumerate(((256, 64), (322, 50), (129, 33), (67, 18), (1026, 21), (1, 1), (3, 2), (1920, 1080))):
+        for flags in (SWS_BICUBIC, SWS_POINT | SWS_ACCURATE_RND):
+            path, _ = run_case(w, h, src, w, h, "yuv444p", flags | BX, seed=w + i)
+            assert path == PATH444, (path, w, h)
+        run_case(w, h, src, w, h, "yuv444p", SWS_BILINEAR | BX, seed=i, device_frames=False)
+    assert run_case(640, 48, src, 640, 48, "yuvj444p", SWS_BICUBIC | BX)[0] != PATH444        # a range conversion
+    assert run_case(640, 48, src, 640, 48, "yuv444p10le", SWS_BICUBIC | BX)[0] != PATH444
+    assert run_case(640, 48, src, 640, 48, "yuv444p", SWS_FAST_BILINEAR | BX)[0] in (PATH444, "main:fused_generic_unity", "main:two_pass")
