@@ -43,3 +43,22 @@ def test_fate_filter_scalechroma_crc_hip():
         assert ctx.scale(ds, dd) == FP.H
         ctx.sync()
         assert zlib.adler32(dd.download().visible(), 0) & 0xFFFFFFFF == want
+
+
+def test_fate_filter_scale_fast_bilinear_wide_edge_crc_hip():
+    """tests/ref/fate/filter-scale-fast-bilinear-wide-edge through the HIP library (see tests/test_oracle_fate_pixfmt.py)."""
+    import zlib
+    import oracle_lib as OL
+    import test_oracle_fate_pixfmt as TO
+    ctx = SwsContext(40000, 1, "yuv444p", 40032, 1, "yuv444p", OL.SWS_FAST_BILINEAR)
+    hs = HostFrame("yuv444p", 40000, 1)
+    for a, b in zip(hs.planes, TO.wide_edge_source().planes):
+        a[:] = b
+    ds = DeviceFrame("yuv444p", 40000, 1).upload(hs)
+    dd = DeviceFrame("yuv444p", 40032, 1)
+    torch.cuda.synchronize()
+    assert ctx.scale(ds, dd) == 1
+    ctx.sync()
+    out = dd.download()
+    px = bytes(int(p[0, 40031]) for p in out.planes)
+    assert zlib.adler32(px, 0) & 0xFFFFFFFF == TO.WIDE_EDGE_CRC

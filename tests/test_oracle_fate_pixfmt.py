@@ -32,3 +32,27 @@ def test_fate_filter_scalechroma_crc():
         dst = OL.Frame("yuv420p", FP.W, FP.H)
         assert o.scale(fr, dst) == FP.H
         assert zlib.adler32(dst.visible(), 0) & 0xFFFFFFFF == want
+
+
+# tests/ref/fate/filter-scale-fast-bilinear-wide-edge: framecrc of ONE pixel (3 bytes)
+WIDE_EDGE_CRC = 0x0297019b
+
+
+def wide_edge_source():
+    """`color=c=red:s=40000x1,format=yuv444p` (tests/fate/filter-video.mak:191-192): ff_draw_color's limited-range BT.601 red
+    (libavfilter/drawutils.c:172-219): Y = 0.299 * 219 + 16 -> 81, U = -0.168736 * 224 + 128 -> 90, V = 0.5 * 224 + 128 -> 240."""
+    s = OL.Frame("yuv444p", 40000, 1)
+    for pl, v in zip(s.planes, (81, 90, 240)):
+        pl[:] = v
+    return s
+
+
+def test_fate_filter_scale_fast_bilinear_wide_edge_crc():
+    """scale=40032:1:flags=fast_bilinear,crop=1:1:40031:0 -> adler32 of the last pixel: ff_hyscale_fast_c / ff_hcscale_fast_c with
+    their right-edge fix-up at a width where i * xInc no longer fits 31 bits (hscale_fast_bilinear.c)."""
+    import zlib
+    o = OL.Oracle(40000, 1, "yuv444p", 40032, 1, "yuv444p", OL.SWS_FAST_BILINEAR)
+    dst = OL.Frame("yuv444p", 40032, 1)
+    assert o.scale(wide_edge_source(), dst) == 1
+    px = bytes(int(p[0, 40031]) for p in dst.planes)
+    assert zlib.adler32(px, 0) & 0xFFFFFFFF == WIDE_EDGE_CRC
