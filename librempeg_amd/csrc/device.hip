@@ -58,9 +58,10 @@ static void dev_state_free(DeviceState *d)
     if (d->stream && d->own_stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
     else if (d->stream) (void)hipStreamSynchronize(d->stream);
     for (void *p : { d->d_tables, d->scratch, d->stage_src, d->stage_dst, (void *)d->d_frames, d->casc_img, d->slice_img, d->d_tilegeom,
-                     d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2, d->casc_img2, d->d_gamma_tab, d->d_ed_err, d->d_pal, d->d_vlines })
+                     d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2, d->casc_img2, d->d_gamma_tab, d->d_ed_err, d->d_pal, d->d_vlines, d->rgbread_img, (void *)d->d_frames2 })
         if (p) (void)hipFree(p);
     if (d->h_frames) (void)hipHostFree(d->h_frames);
+    if (d->h_frames2) (void)hipHostFree(d->h_frames2);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
     if (d->ev_loan) (void)hipEventDestroy(d->ev_loan);
@@ -498,7 +499,13 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             d->striprgb_ok = false;
             // (planar writers: a one-tap vertical filter takes the reference's yuv2plane1 form, not the "X" arithmetic of these kernels;
             //  the packed writers are in "X" mode unless both vertical filters are short, which all_x_mode checks row by row)
-            const bool fullA = !d->unity_h && !p.fast_bilinear && !gray_any && (src_ok || (nv_src && dst_ok)) && ((dst_ok && c->vLum.size >= 2 && c->vChr.size >= 2) || rgb_ok) && !p.wide &&
+            // scaled packed 24 / 32 bpp RGB sources: a reader pre-pass writes the 16-bit planes the horizontal scaler
+            // reads, the strip kernel takes them like a planar 16-bit source (launch_rgbread_strip); other shapes of these sources keep the tile kernel
+            bool rgbread = (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32) && p.chrSrcW == (p.chr_half ? p.srcW >> 1 : p.srcW) && !(p.srcW & 3) && p.chrSrcVSub == 0 && !p.range_active && !p.need_alpha &&
+                           !p.dst_alpha_fill && !p.no_chroma && !vlines_pending && dst_ok && !c->tune.no_strip && !c->tune.no_rgbsrc && p.dstW >= c->tune.strip_min_w;
+            for (int k = 0; k < 9 && rgbread; k++) rgbread = p.rgb2yuv[k] > -32768 && p.rgb2yuv[k] < 32768;   // (v_dot2_i32_i16 operands)
+            d->rgbread_on = false;
+            const bool fullA = !d->unity_h && !p.fast_bilinear && !gray_any && (src_ok || (nv_src && dst_ok) || rgbread) && ((dst_ok && c->vLum.size >= 2 && c->vChr.size >= 2) || rgb_ok) && !p.wide &&
                                fs2(c->hLum.size) <= 16 && fs2(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && fs2(c->vChr.size) <= 16 && !c->tune.no_dot2;
             // identity luma filters + scaled chroma (yuv422p -> yuv420p, yuv444p -> yuv420p, the 10-bit -> 8-bit twins ...): the luma plane streams
             // (one tap: a per-sample pass), only the chroma planes need the strip kernel.  (The planar writers' one-tap form is what keeps these
@@ -508,7 +515,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                                 fs2(c->hChr.size) <= 16 && fs2(c->vChr.size) <= 16 && !c->tune.no_strip && !c->tune.no_mixed && p.dstW >= c->tune.strip_min_w;
             d->mixed_ok = false;
             if (fullA || mixedM) {
-                const int SPC = (p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010) ? 8 : 16;
+                const int SPC = (p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010 || rgbread) ? 8 : 16;
                 std::vector<uint8_t> blob;
                 auto put = [&](const void *ptr, size_t n) { size_t o = (blob.size() + 15) & ~(size_t)15; blob.resize(o + n); std::memcpy(blob.data() + o, ptr, n); return o; };
                 auto padded = [&](const FilterBank &b) {
@@ -576,7 +583,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     // LDS-DMA form: a ring of 4 row pairs per wave, rows of ncmax 16-bit samples; every pair between the first and the last
                     // one a band needs is requested, so the windows of consecutive rows must touch (no skipped pair)
                     g.lds_dma_bytes = 4 * 4 * ncomp * 2 * (ncmax / 2) * 4;
-                    g.dma_ok = p.srcKind == SRCK_PLANAR16 && g.lds_dma_bytes <= 40 * 1024;   // (LDS-DMA copies rows as they are: planar 16-bit sources only)
+                    g.dma_ok = (p.srcKind == SRCK_PLANAR16 || rgbread) && g.lds_dma_bytes <= 40 * 1024;   // (LDS-DMA copies rows as they are: planar 16-bit sources, and the reader planes of a packed RGB source)
                     for (int y = 1; y < vb.count && g.dma_ok; y++)
                         if (((vb.pos[y] & ~1) >> 1) > ((vb.pos[y - 1] & ~1) >> 1) + npv) g.dma_ok = 0;
                     o.cs = put(cs.data(), cs.size() * 4); o.cc = put(cc.data(), cc.size() * 4);
@@ -679,6 +686,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         d->stripL.hT2 = d->dotL.hT2; d->stripL.vT2 = d->dotL.vT2; d->stripC.hT2 = d->dotC.hT2; d->stripC.vT2 = d->dotC.vT2;
                         d->stripL.rows = (const SwsStripRow *)(b + sL.rows); d->stripC.rows = (const SwsStripRow *)(b + sC.rows);
                         d->strip_ok = true;
+                        d->rgbread_on = rgbread;
                     }
                 }
             }
@@ -874,8 +882,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         } else if (d->striprgb_ok) {
             c->path_name = "main:strip_rgb"; c->kernel_name = "sws_k_strip_rgb";
         } else if (d->strip_ok) {
-            c->path_name = "main:strip_march";
-            c->kernel_name = (p.srcKind == SRCK_PLANAR16 && d->stripL.dma_ok && !c->tune.no_strip_dma) ? "sws_k_strip_dma" : "sws_k_strip_march";
+            c->path_name = d->rgbread_on ? "main:rgbread+strip_march" : "main:strip_march";
+            c->kernel_name = ((p.srcKind == SRCK_PLANAR16 || d->rgbread_on) && d->stripL.dma_ok && !c->tune.no_strip_dma) ? "sws_k_strip_dma" : "sws_k_strip_march";
         } else if (d->dot2_ok) {
             c->path_name = "main:fused_tile_dot2"; c->kernel_name = "sws_k_tile_dot2";
         } else if (d->tile_ok) {
@@ -1070,7 +1078,7 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         else if (d->rgb444_ok && vec) ret = launch_rgb444(L);                                             // 8-bit RGB -> planar 4:4:4, same size
         else if (d->striprgb_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_striprgb(L);   // marching strip kernel, RGB epilogue
         else if (d->mixed_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_mixed(L);   // identity luma: streaming pass + strip kernel on chroma
-        else if (d->strip_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_strip(L);   // marching strip kernel
+        else if (d->strip_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = d->rgbread_on ? launch_rgbread_strip(L) : launch_strip(L);   // marching strip kernel
         else if (d->dot2_ok && vec) ret = launch_tile_dot2(L);                                              // dot2 LDS-tile kernel
         else if (d->tile_ok) ret = launch_tile(L);                                                          // fused h+v LDS-tile kernel
         else ret = launch_generic(L);                                                                       // optional pass 1 into scratch, then writers
@@ -1246,8 +1254,10 @@ static int image_layout(int format, int w, int h, int align, int linesize[4], si
     return 0;
 }
 
+// casc_flip0: a bottom-up slice sequence through scale_cascaded: only the first context sees the flipped picture (it writes the intermediate one
+// upside down, i.e. upright again), the second one runs top-down on it
 static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4], const int srcStride[4], int sliceY, int sliceH,
-                      uint8_t *const dst[4], const int dstStride[4]);
+                      uint8_t *const dst[4], const int dstStride[4], bool casc_flip0 = false);
 
 } // namespace swship
 
@@ -1356,7 +1366,7 @@ int dev_run(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4],
 }
 
 static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4], const int srcStride[4], int sliceY, int sliceH,
-                      uint8_t *const dst[4], const int dstStride[4])
+                      uint8_t *const dst[4], const int dstStride[4], bool casc_flip0)
 {
     const SwsContext &o = c->opts;
 
@@ -1387,6 +1397,15 @@ static int run_single(SwsInternal *c, DeviceState *d, const uint8_t *const src[4
         uint8_t *tmp[4] = { nullptr, nullptr, nullptr, nullptr };   // bgr24 / bgra / bgr48 / bgra64 (matrix cascade) or yuv420p / yuva420p (extreme ratios)
         int tls[4] = { 0, 0, 0, 0 };
         for (int k = 0; k < pix_nb_planes(pix_desc(c->cascade_fmt)); k++) { tmp[k] = (uint8_t *)d->casc_img + offs[k]; tls[k] = ls[k]; }
+        if (casc_flip0) {
+            uint8_t *ft[4] = { nullptr, nullptr, nullptr, nullptr };
+            int fls[4] = { 0, 0, 0, 0 };
+            for (int k = 0; k < pix_nb_planes(pix_desc(c->cascade_fmt)); k++) {
+                int rb, prow; plane_geometry(c->cascade_fmt, c->cascade_w, c->cascade_h, k, &rb, &prow);
+                ft[k] = tmp[k] + (int64_t)(prow - 1) * tls[k]; fls[k] = -tls[k];
+            }
+            r = run_single(c0, cd[0], src, srcStride, sliceY, sliceH, ft, fls);
+        } else
         r = run_single(c0, cd[0], src, srcStride, sliceY, sliceH, tmp, tls);
         if (r < 0) return r;
         if (c->cascade_ed && c0->mono_y16) {   // error diffusion of the luma words into a 1 bpp destination (context.cpp; sws_k_ed_mono)
@@ -1729,19 +1748,28 @@ static int scale_slice(SwsInternal *c, const uint8_t *const src[], const int src
     }
     if (!src_dev) HIPCHK(hipStreamSynchronize(st));                            // the caller may reuse its slice buffer
     // ---- the reference's cursor: how many destination rows this slice completes ----
+    // Cascades: scale_cascaded (swscale.c:993-1020) lets its first context assemble the intermediate picture slice by slice and answers 0 until
+    // that context's sliceDir has reset, then runs the second one once and returns its row count.  scale_gamma (:959-990) hands the slice
+    // coordinates to its scaling context, whose cursor is the one that answers; the error-diffusion cascade of this library stands for ONE
+    // main-path context of the reference, the inner context's geometry.  (In the gamma cascade the reference's second context reads the rows of
+    // the slice from the intermediate picture whether or not the first one has produced them yet; here every row is there when it is read.)
+    const bool casc = c->plan == PLAN_CASCADE, casc_plain = casc && !c->cascade_gamma && !c->cascade_ed;
+    const SwsInternal *cur = !casc ? c : c->cascade_ed ? c->cascade[0] : c->cascade[1];
     if (yint == 0) c->slice_dstY = 0;
     const int last = c->slice_dstY;
     int dstY = last;
-    const int cvs = c->chrDstVSubSample;
-    for (; dstY < o.dst_h; dstY++) {
+    const int cvs = cur->chrDstVSubSample;
+    const bool cur_main = cur && cur->plan == PLAN_MAIN && cur->opts.src_h == o.src_h;
+    for (; cur_main && !casc_plain && dstY < cur->opts.dst_h; dstY++) {
         const int chrDstY = dstY >> cvs;
-        const int firstLum2 = std::max(1 - c->vLum.size, c->vLum.pos[std::min(dstY | ((1 << cvs) - 1), o.dst_h - 1)]);
-        const int firstChr = std::max(1 - c->vChr.size, c->vChr.pos[chrDstY]);
-        const int lastLum2 = std::min(o.src_h, firstLum2 + c->vLum.size) - 1;
-        const int lastChr = std::min(c->chrSrcH, firstChr + c->vChr.size) - 1;
-        const bool enough = lastLum2 < yint + srcSliceH && lastChr < -((-(yint + srcSliceH)) >> c->chrSrcVSubSample);
+        const int firstLum2 = std::max(1 - cur->vLum.size, cur->vLum.pos[std::min(dstY | ((1 << cvs) - 1), cur->opts.dst_h - 1)]);
+        const int firstChr = std::max(1 - cur->vChr.size, cur->vChr.pos[chrDstY]);
+        const int lastLum2 = std::min(o.src_h, firstLum2 + cur->vLum.size) - 1;
+        const int lastChr = std::min(cur->chrSrcH, firstChr + cur->vChr.size) - 1;
+        const bool enough = lastLum2 < yint + srcSliceH && lastChr < -((-(yint + srcSliceH)) >> cur->chrSrcVSubSample);
         if (!enough) break;
     }
+    if (casc && !casc_plain && !cur_main && yint + srcSliceH == o.src_h) dstY = o.dst_h;   // (an answering context without a row cursor: everything at the end)
     c->slice_dstY = dstY;
     if (yint + srcSliceH == o.src_h) {                                         // sequence complete (:1189-1190): convert
         const bool flip = c->sliceDir == -1;
@@ -1755,13 +1783,15 @@ static int scale_slice(SwsInternal *c, const uint8_t *const src[], const int src
             s4[k] = (const uint8_t *)d->slice_img + offs[k] + (flip ? (size_t)(prow - 1) * ls[k] : 0);
             ss4[k] = flip ? -ls[k] : ls[k];
         }
+        const bool flip_dst = flip && !casc_plain;   // (scale_cascaded: the second context runs once, top-down, whatever the slice order was)
         for (int k = 0; k < npd; k++) {
             int rb, prow; plane_geometry(o.dst_format, o.dst_w, o.dst_h, k, &rb, &prow);
-            d4[k] = dst[k] + (flip ? (int64_t)(prow - 1) * dstStride[k] : 0);
-            ds4[k] = flip ? -dstStride[k] : dstStride[k];
+            d4[k] = dst[k] + (flip_dst ? (int64_t)(prow - 1) * dstStride[k] : 0);
+            ds4[k] = flip_dst ? -dstStride[k] : dstStride[k];
         }
-        ret = run_single(c, d, s4, ss4, 0, o.src_h, d4, ds4);
+        ret = run_single(c, d, s4, ss4, 0, o.src_h, d4, ds4, flip && casc_plain);
         if (ret < 0) return ret;
+        if (casc_plain) return ret;
     }
     return dstY - last;
 }
@@ -1798,11 +1828,7 @@ int sws_scale(SwsContext *sws, const uint8_t *const srcSlice[], const int srcStr
     }
     if (srcSliceH == 0) return 0;               // :1072-1074
     const bool whole = srcSliceY == 0 && srcSliceH == sws->src_h;
-    if (!whole && c->plan == PLAN_CASCADE) {
-        log_msg(c, 0, "slice-wise sws_scale() through a cascade is not implemented on the HIP path; pass whole frames\n");
-        return SWS_AVERROR(ENOTSUP);
-    }
-    if (c->plan == PLAN_MAIN && (!whole || c->sliceDir != 0)) return scale_slice(c, srcSlice, srcStride, srcSliceY, srcSliceH, dst, dstStride);
+    if ((c->plan == PLAN_MAIN || c->plan == PLAN_CASCADE) && (!whole || c->sliceDir != 0)) return scale_slice(c, srcSlice, srcStride, srcSliceY, srcSliceH, dst, dstStride);
     const uint8_t *s4[4] = { srcSlice[0], nullptr, nullptr, nullptr };
     uint8_t *d4[4] = { dst[0], nullptr, nullptr, nullptr };
     int ss4[4] = { srcStride[0], 0, 0, 0 }, ds4[4] = { dstStride[0], 0, 0, 0 };

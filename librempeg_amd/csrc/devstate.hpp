@@ -43,6 +43,11 @@ struct DeviceState {
     void *casc_img2 = nullptr; size_t casc_bytes2 = 0; void *d_gamma_tab = nullptr;   // gamma cascade: second RGBA64 intermediate, the two 65536-entry tables
     void *slice_img = nullptr; size_t slice_bytes = 0;   // source image assembled from sws_scale() slices (scaled path)
     void *d_vlines = nullptr; size_t vlines_bytes = 0; bool vlines_on = false;   // virtual source lines of the two-pass path (SwsDevParams::vlines) + their vertical positions
+    // scaled packed-RGB sources: the reader pre-pass writes 16-bit Y / U / V planes per frame (k_stream.hip launch_rgb_read16), the strip kernel
+    // reads them through a second frame table (k_strip.hip launch_rgbread_strip)
+    bool rgbread_on = false; void *rgbread_img = nullptr; size_t rgbread_bytes = 0;
+    SwsFramePtrs *d_frames2 = nullptr, *h_frames2 = nullptr; int frames2_cap = 0, frames2_valid = 0;
+    void *spare_ptr[4] = { nullptr, nullptr, nullptr, nullptr }; size_t spare_sz[4] = { 0, 0, 0, 0 }; int spare_i[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timing = false; bool timed = false;
     hipEvent_t ev_loan = nullptr;   // orders the context's own stream against a borrowed frames stream (dev_borrow_stream)
 };
@@ -109,6 +114,8 @@ int  launch_f32rgb(const LaunchCtx &L);
 // ---- k_strip.hip / k_tile.hip: fused h+v polyphase kernels for planar / semi-planar outputs (C3b, C1) ----
 int  launch_strip(const LaunchCtx &L);
 int  launch_rgbsrc(const LaunchCtx &L);
+int  launch_rgbread_strip(const LaunchCtx &L);   // k_strip.hip: scaled packed 24 / 32 bpp RGB source: reader pre-pass + strip kernel on its 16-bit planes
+void launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, int64_t offU, int64_t offV, int strideY, int strideC);   // k_stream.hip
 int  launch_striprgb(const LaunchCtx &L);
 int  launch_tile_dot2(const LaunchCtx &L);
 int  launch_tile(const LaunchCtx &L);

@@ -57,9 +57,9 @@ int launch_layout(const LaunchCtx &L)
             else if (ddp == 8 || sd > ddp) {   // DITHER_COPY (:2159-2218)
                 const int shift = sd - ddp, body_end = len - 7 > 0 ? ((len - 7 + 7) / 8) * 8 : 0;
                 const int mode = c->opts.dither == SWS_DITHER_NONE ? 0 : so ? 1 : 2;
-                add(ddp == 8 ? LOP_16TO8 : LOP_16TO16, h, y0, y0, pl, pl, pl, pl, 2 * len, mode, shift, ss, dsh, ddp | (body_end << 8));
+                add(ddp == 8 ? LOP_16TO8 : LOP_16TO16, h, y0, y0, pl, pl, pl, pl, 2 * len, mode | (sd <= 15 ? 16 : 0), shift, ss, dsh, ddp | (body_end << 8));
             } else if (sd == 8) add(LOP_8TO16, h, y0, y0, pl, pl, pl, pl, len, ddp - 8, so ? 32 : 16 - ddp, dsh);
-            else add(LOP_16TO16, h, y0, y0, pl, pl, pl, pl, 2 * len, so ? 3 : 4, ddp - sd, ss, dsh, 2 * sd - ddp);
+            else add(LOP_16TO16, h, y0, y0, pl, pl, pl, pl, 2 * len, (so ? 3 : 4) | 16, ddp - sd, ss, dsh, 2 * sd - ddp);   // (widening: nothing leaves 16 bits)
         }
         break;
     }

@@ -69,6 +69,22 @@ int launch_rgbsrc(const LaunchCtx &L)
     return 0;
 }
 
+// reader pre-pass of a scaled packed 24 / 32 bpp RGB source (dev_prepare_on: rgbread_on): 16-bit Y / U / V planes per frame at `base`
+void launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, int64_t offU, int64_t offV, int strideY, int strideC)
+{
+    const SwsDevParams &p = *L.p;
+    swsk::RgbReadLayout lay;
+    lay.base = base; lay.frame_bytes = frame_bytes; lay.offU = offU; lay.offV = offV; lay.strideY = strideY; lay.strideC = strideC;
+    const dim3 grid(cdiv(cdiv(p.srcW, 4), 256), cdiv(p.srcH, swsk::RGBREAD_RPW), L.n), blk(256);
+    if (p.chr_half) {
+        if (p.srcKind == SRCK_RGB24) hipLaunchKernelGGL((swsk::sws_k_rgb_read16<3, true>), grid, blk, 0, L.st, L.fs, p, lay);
+        else hipLaunchKernelGGL((swsk::sws_k_rgb_read16<4, true>), grid, blk, 0, L.st, L.fs, p, lay);
+    } else {
+        if (p.srcKind == SRCK_RGB24) hipLaunchKernelGGL((swsk::sws_k_rgb_read16<3, false>), grid, blk, 0, L.st, L.fs, p, lay);
+        else hipLaunchKernelGGL((swsk::sws_k_rgb_read16<4, false>), grid, blk, 0, L.st, L.fs, p, lay);
+    }
+}
+
 // packed / planar 8-bit RGB -> planar 8-bit 4:4:4 YUV of the same size: every filter the identity (dev_prepare_on: rgb444_ok)
 int launch_rgb444(const LaunchCtx &L)
 {

@@ -14,7 +14,7 @@ int launch_strip_planes(const LaunchCtx &L, int which)
     const dim3 blk(256);
     (void)c; (void)d; (void)frames; (void)vec; (void)sliceY; (void)sliceH;
             const int target = c->tune.strip_waves;
-            const bool s16 = p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010;
+            const bool s16 = p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010;   // (launch_rgbread_strip passes its reader planes as SRCK_PLANAR16)
             auto launch = [&](SwsStripGeom g, int H, bool chroma) {
                 int bands = std::max(1, std::min(target / std::max(1, g.strips * n), (H + 15) / 16));
                 g.debug = c->tune.debug;
@@ -51,6 +51,53 @@ int launch_mixed(const LaunchCtx &L)
     int r = launch_layout_plane1(L);
     if (r < 0) return r;
     return launch_strip_planes(L, 2);
+}
+
+// Scaled packed 24 / 32 bpp RGB sources (dev_prepare_on: rgbread_on): the reader pre-pass writes what the reference's input stage hands to
+// hScale16To15_c -- 16-bit Y[srcH][srcW] and U / V[srcH][srcW / 2] -- into a per-frame working picture, and the strip kernel runs on those planes
+// as on a planar 16-bit source (same filters, same hshift: the context was initialised for the RGB source).
+int launch_rgbread_strip(const LaunchCtx &L)
+{
+    SwsInternal *c = L.c; DeviceState *d = L.d; const SwsDevParams &p = *L.p; hipStream_t st = L.st;
+    const int n = L.n;
+    auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
+    const int strideY = (int)a256(2 * (int64_t)p.srcW), strideC = (int)a256(2 * (int64_t)p.chrSrcW);
+    const int64_t offU = (int64_t)strideY * p.srcH, offV = offU + (int64_t)strideC * p.srcH, frame_bytes = a256(offV + (int64_t)strideC * p.srcH);
+    int r = grow(c, &d->rgbread_img, &d->rgbread_bytes, (size_t)frame_bytes * (size_t)n);
+    if (r < 0) return r;
+    uint8_t *base = (uint8_t *)d->rgbread_img;
+    launch_rgb_read16(L, base, frame_bytes, offU, offV, strideY, strideC);
+    std::vector<SwsFramePtrs> fr(L.frames, L.frames + n);
+    for (int i = 0; i < n; i++) {
+        uint8_t *fb = base + (size_t)i * (size_t)frame_bytes;
+        fr[(size_t)i].src[0] = fb; fr[(size_t)i].src[1] = fb + offU; fr[(size_t)i].src[2] = fb + offV; fr[(size_t)i].src[3] = nullptr;
+        fr[(size_t)i].srcStride[0] = strideY; fr[(size_t)i].srcStride[1] = fr[(size_t)i].srcStride[2] = strideC; fr[(size_t)i].srcStride[3] = 0;
+    }
+    LaunchCtx L2 = L;
+    SwsDevParams p2 = p;
+    p2.srcKind = SRCK_PLANAR16; p2.u_plane_src = 1; p2.src_shift = 0;
+    L2.p = &p2; L2.frames = fr.data();
+    if (n == 1) { L2.fs.table = nullptr; L2.fs.one = fr[0]; }
+    else {
+        const bool same = d->frames2_cap >= n && d->frames2_valid == n && !std::memcmp(d->h_frames2, fr.data(), sizeof(SwsFramePtrs) * (size_t)n);
+        if (!same) {
+            if (n > d->frames2_cap) {
+                if (d->d_frames2) HIPCHK(hipFree(d->d_frames2));
+                if (d->h_frames2) HIPCHK(hipHostFree(d->h_frames2));
+                d->d_frames2 = nullptr; d->h_frames2 = nullptr; d->frames2_cap = 0;
+                HIPCHK(hipMalloc((void **)&d->d_frames2, sizeof(SwsFramePtrs) * (size_t)n));
+                HIPCHK(hipHostMalloc((void **)&d->h_frames2, sizeof(SwsFramePtrs) * (size_t)n, hipHostMallocDefault));
+                d->frames2_cap = n;
+            } else {
+                HIPCHK(hipStreamSynchronize(st));   // a previous batch may still be reading the pinned table
+            }
+            std::memcpy(d->h_frames2, fr.data(), sizeof(SwsFramePtrs) * (size_t)n);
+            HIPCHK(hipMemcpyAsync(d->d_frames2, d->h_frames2, sizeof(SwsFramePtrs) * (size_t)n, hipMemcpyHostToDevice, st));
+            d->frames2_valid = n;
+        }
+        L2.fs.table = d->d_frames2;
+    }
+    return launch_strip_planes(L2, 3);
 }
 
 } // namespace swship

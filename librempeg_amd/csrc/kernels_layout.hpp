@@ -23,6 +23,18 @@ __device__ __constant__ const uint8_t k_layout_dithers[8][8][8] __attribute__((a
 { {36,68,60,92,34,66,58,90},{100,4,124,28,98,2,122,26},{52,84,44,76,50,82,42,74},{116,20,108,12,114,18,106,10},{32,64,56,88,38,70,62,94},{96,0,120,24,102,6,126,30},{48,80,40,72,54,86,46,78},{112,16,104,8,118,22,110,14} },
 };
 
+// two 16-bit samples per dword through the packed 16-bit ALU (v_pk_add_u16, v_pk_lshlrev_b16, v_pk_min_u16 ...): half the instructions of the
+// per-sample forms.  Every use below keeps its intermediate values inside 16 bits (the host checks the source depth), so the packed results are
+// the reference's int arithmetic.
+typedef unsigned short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16 pk_of(uint32_t w) { return __builtin_bit_cast(pk16, w); }
+__device__ __forceinline__ uint32_t pk_bits(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ pk16 pk_splat(int v) { const pk16 r = { (unsigned short)v, (unsigned short)v }; return r; }
+__device__ __forceinline__ pk16 pk_min(pk16 a, pk16 b) { return __builtin_elementwise_min(a, b); }
+// bytes {2k, 2k + 1} of a dword as two zero-extended 16-bit values
+__device__ __forceinline__ pk16 pk_bytes_lo(uint32_t w) { return pk_of(__builtin_amdgcn_perm(0, w, 0x0c010c00u)); }
+__device__ __forceinline__ pk16 pk_bytes_hi(uint32_t w) { return pk_of(__builtin_amdgcn_perm(0, w, 0x0c030c02u)); }
+
 enum { LOP_COPY = 0, LOP_FILL, LOP_IL, LOP_DIL, LOP_8TO16, LOP_16TO8, LOP_16TO16, LOP_P422_SPLIT, LOP_P422_SPLIT420, LOP_P422_JOIN, LOP_P1_16TO8, LOP_P1_16TO16 };
 
 // one class of rows: `rows` rows starting at source row ys / destination row yd of the planes named below
@@ -131,10 +143,11 @@ __global__ void __launch_bounds__(256) sws_k_layout_stream(SwsFrameSet fs, SwsDe
                 uint32_t o[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const uint32_t w = s8[i][q >> 1] >> (16 * (q & 1));
-                    const uint32_t e0 = w & 0xFF, e1 = (w >> 8) & 0xFF;
-                    const uint32_t v0 = (((e0 << a0) | (a1 < 32 ? e0 >> a1 : 0u)) << a2) & 0xFFFFu, v1 = (((e1 << a0) | (a1 < 32 ? e1 >> a1 : 0u)) << a2) & 0xFFFFu;
-                    o[q] = v0 | (v1 << 16);
+                    const pk16 e = (q & 1) ? pk_bytes_hi(s8[i][q >> 1]) : pk_bytes_lo(s8[i][q >> 1]);
+                    pk16 v = e << pk_splat(a0);
+                    if (a1 < 32) v |= e >> pk_splat(a1);
+                    if (a2) v = v << pk_splat(a2);
+                    o[q] = pk_bits(v);
                 }
                 const u32x4 ov = { o[0], o[1], o[2], o[3] };
                 lstore16(dbaseA + (r + i) * dsA + 2 * off, ov, 2 * (n - off));
@@ -144,9 +157,10 @@ __global__ void __launch_bounds__(256) sws_k_layout_stream(SwsFrameSet fs, SwsDe
     }
     case LOP_16TO8:    // DITHER_COPY to 8 bit (:2159-2218): n = source bytes of the row
     case LOP_16TO16: { // DITHER_COPY to 9..15 bit, or the widening copy N -> M (:2285-2331)
-        // a0 = mode: 0 dither off, 1 dither + shiftonly, 2 dither full range, 3 widening shiftonly, 4 widening with bit replication
+        // a0 & 15 = mode: 0 dither off, 1 dither + shiftonly, 2 dither full range, 3 widening shiftonly, 4 widening with bit replication
         // a1 = shift (|sd - dd|), a2 = src_shift, a3 = dst_shift, a4 = dd | body_end << 8 (elements), widening: a4 = 2 * sd - dd
-        const int mode = a0, shift = a1, ss = a2, dsh = a3, dd = a4 & 0xFF, body_end = a4 >> 8;
+        const int mode = a0 & 15, shift = a1, ss = a2, dsh = a3, dd = a4 & 0xFF, body_end = a4 >> 8;
+        const bool packed = (a0 & 16) != 0;   // (the host sets it for sources of at most 15 bits)
         const bool body = (off >> 1) < body_end;
         for (int r = r0; r < r1; r += RU) {
             u32x4 s16[RU];
@@ -160,6 +174,30 @@ __global__ void __launch_bounds__(256) sws_k_layout_stream(SwsFrameSet fs, SwsDe
                 if (mode == 1 || mode == 2) {
                     const uint32_t *dr = (const uint32_t *)k_layout_dithers[shift - 1][(r + i) & 7];
                     dlo = U(dr[0]); dhi = U(dr[1]);
+                }
+                if (packed) {   // source samples of at most 15 bits: sample + dither stays inside 16 bits
+                    const pk16 dt[4] = { pk_bytes_lo(dlo), pk_bytes_hi(dlo), pk_bytes_lo(dhi), pk_bytes_hi(dhi) };
+                    uint32_t o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const pk16 raw = pk_of(s16[i][q]);
+                        const pk16 sv = body ? raw >> pk_splat(ss) : raw;
+                        pk16 v;
+                        if (mode == 0) { const pk16 t = (sv + pk_splat(1 << (shift - 1))) >> pk_splat(shift); v = (t - (t >> pk_splat(dd))) << pk_splat(dsh); }
+                        else if (mode == 1) { const pk16 t = (sv + dt[q]) >> pk_splat(shift); v = (t - (t >> pk_splat(dd))) << pk_splat(dsh); }
+                        else if (mode == 2) { v = (sv - (sv >> pk_splat(dd)) + dt[q]) >> pk_splat(shift); if (body) v = v << pk_splat(dsh); }
+                        else if (mode == 3) { v = ((raw >> pk_splat(ss)) << pk_splat(shift)) << pk_splat(dsh); }
+                        else { const pk16 t = raw >> pk_splat(ss); v = ((t << pk_splat(shift)) | (t >> pk_splat(a4))) << pk_splat(dsh); }
+                        o[q] = pk_bits(v);
+                    }
+                    if (op == LOP_16TO8) {
+                        const u32x2 ob = { __builtin_amdgcn_perm(o[1], o[0], 0x06040200u), __builtin_amdgcn_perm(o[3], o[2], 0x06040200u) };
+                        lstore8(dbaseA + (r + i) * dsA + (off >> 1), ob, (n - off) >> 1);
+                    } else {
+                        const u32x4 ow = { o[0], o[1], o[2], o[3] };
+                        lstore16(dbaseA + (r + i) * dsA + off, ow, n - off);
+                    }
+                    continue;
                 }
                 uint32_t e[8];
 #pragma unroll
@@ -196,23 +234,28 @@ __global__ void __launch_bounds__(256) sws_k_layout_stream(SwsFrameSet fs, SwsDe
 #pragma unroll
             for (int i = 0; i < RU; i++) {
                 if (!(in && r + i < r1)) continue;
-                uint32_t dth[8];
+                // (the row's dither line: eight bytes, the same for every lane)
+                const uint32_t *dr = (const uint32_t *)k_dither_8x8_128[(yd + r + i) & 7];
+                const uint32_t dlo = U(dr[0]), dhi = U(dr[1]);
+                const pk16 dt[4] = { pk_bytes_lo(dlo), pk_bytes_hi(dlo), pk_bytes_lo(dhi), pk_bytes_hi(dhi) };
+                // min((sv << 14) >> a1, 32767) inside 16 bits: a sample of 2^(15 - L) or more saturates (L = 14 - a1), below that sv << L fits
+                const int L = 14 - a1;
+                uint32_t o[4];
 #pragma unroll
-                for (int q = 0; q < 8; q++) dth[q] = U((uint32_t)k_dither_8x8_128[(yd + r + i) & 7][q]);
-                uint32_t e[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int sv = (int)((s16[i][q >> 1] >> (16 * (q & 1))) & 0xFFFFu) >> a0;
-                    const int hv = min((sv << 14) >> a1, (1 << 15) - 1);
-                    if (op == LOP_P1_16TO8) e[q] = (uint32_t)clip_u8_shr(hv + (int)dth[q], 7);
-                    else { const int sh = 15 - a2; e[q] = (uint32_t)clip_uintp2((hv + (1 << (sh - 1))) >> sh, a2) << a3; }
+                for (int q = 0; q < 4; q++) {
+                    const pk16 sv = pk_of(s16[i][q]) >> pk_splat(a0);
+                    const pk16 hv = L >= 0 ? pk_min(pk_min(sv, pk_splat(1 << (15 - L))) << pk_splat(L), pk_splat(32767)) : pk_min(sv >> pk_splat(-L), pk_splat(32767));
+                    pk16 e;
+                    if (op == LOP_P1_16TO8) e = pk_min((hv + dt[q]) >> pk_splat(7), pk_splat(255));
+                    else { const int sh = 15 - a2; e = pk_min((hv + pk_splat(1 << (sh - 1))) >> pk_splat(sh), pk_splat((1 << a2) - 1)) << pk_splat(a3); }
+                    o[q] = pk_bits(e);
                 }
                 if (op == LOP_P1_16TO8) {
-                    const u32x2 o = { e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24), e[4] | (e[5] << 8) | (e[6] << 16) | (e[7] << 24) };
-                    lstore8(dbaseA + (r + i) * dsA + (off >> 1), o, (n - off) >> 1);
+                    const u32x2 ob = { __builtin_amdgcn_perm(o[1], o[0], 0x06040200u), __builtin_amdgcn_perm(o[3], o[2], 0x06040200u) };
+                    lstore8(dbaseA + (r + i) * dsA + (off >> 1), ob, (n - off) >> 1);
                 } else {
-                    const u32x4 o = { e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16) };
-                    lstore16(dbaseA + (r + i) * dsA + off, o, n - off);
+                    const u32x4 ow = { o[0], o[1], o[2], o[3] };
+                    lstore16(dbaseA + (r + i) * dsA + off, ow, n - off);
                 }
             }
         }

@@ -184,6 +184,101 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
     }
 }
 
+// Reader pre-pass for SCALED packed 24 / 32 bpp RGB sources (capture -> smaller / larger planar YUV): the input stage of the scaler on
+// whole rows -- rgb24ToY_c / rgb24ToUV_half_c (input.c:1068-1172), rgb16_32ToY / UV_half_c_template with the 32-bit rows (:264-393) -- written
+// as the 16-bit planes hScale16To15_c reads (formatConvBuffer of the line ring, swscale.c:69-97): Y[srcH][srcW], U / V[srcH][srcW / 2].
+// The marching strip kernel then takes these planes like a planar 16-bit source (k_strip.hip launch_rgbread_strip).  Lane = four pixels of a
+// row (12- or 16-byte load; 8 + 4 + 4 bytes stored), a wave walks down RGBREAD_RPW rows with the next row's load in flight.
+struct RgbReadLayout { uint8_t *base; int64_t frame_bytes, offU, offV; int32_t strideY, strideC; };
+constexpr int RGBREAD_RPW = 8;
+
+// HALF: the "half" chroma readers (chroma planes of srcW / 2 columns: every shape whose chroma destination is at most half as wide as the source,
+// utils.c:1419-1425); otherwise rgb24ToUV_c / the full-width 32-bit rows (input.c:1096-1124, :310-334): chroma planes of srcW columns
+template <int BPP, bool HALF>
+__global__ void __launch_bounds__(256) sws_k_rgb_read16(SwsFrameSet fs, SwsDevParams p, RgbReadLayout lay)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int W = U(p.srcW), H = U(p.srcH), x0 = 4 * t;
+    if (x0 >= W) return;                               // (W is a multiple of 4: host check)
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int y0 = blockIdx.y * RGBREAD_RPW, y1 = min(H, y0 + RGBREAD_RPW);
+    const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);
+    const int rp = U(p.src_r_pos), gp = BPP == 4 ? U(p.src_g_pos) : 1, bp = U(p.src_b_pos);
+    auto coef = [&](const Rgb2YuvRow &w, int k) { return (uint32_t)(uint16_t)(k == rp ? w.r : k == gp ? w.g : k == bp ? w.b : 0); };
+    const uint32_t cyA = coef(ty, 0) | coef(ty, 2) << 16, cyB = coef(ty, 1) | coef(ty, 3) << 16;
+    const uint32_t cuA = coef(tu, 0) | coef(tu, 2) << 16, cuB = coef(tu, 1) | coef(tu, 3) << 16;
+    const uint32_t cvA = coef(tv, 0) | coef(tv, 2) << 16, cvB = coef(tv, 1) | coef(tv, 3) << 16;
+    const uint8_t *s0 = f.src[0];
+    const int64_t sst = f.srcStride[0];
+    uint8_t *fb = U(lay.base) + (int64_t)blockIdx.z * U(lay.frame_bytes);
+    uint8_t *dY = fb + 2 * (int64_t)x0, *dU = fb + U(lay.offU) + (int64_t)x0 * (HALF ? 1 : 2), *dV = fb + U(lay.offV) + (int64_t)x0 * (HALF ? 1 : 2);
+    const int64_t dsY = U(lay.strideY), dsC = U(lay.strideC);
+    uint32_t nx[4] = {};
+    auto fetch = [&](int r) {
+        const uint8_t *row = s0 + (int64_t)r * sst + (int64_t)BPP * x0;
+        if (BPP == 3) { nx[0] = ((const uint32_t *)row)[0]; nx[1] = ((const uint32_t *)row)[1]; nx[2] = ((const uint32_t *)row)[2]; }
+        else { const uint4 q = *(const uint4 *)row; nx[0] = q.x; nx[1] = q.y; nx[2] = q.z; nx[3] = q.w; }
+    };
+    if (y0 < y1) fetch(y0);
+    for (int r = y0; r < y1; r++) {
+        uint32_t lo[4], hi[4];     // per pixel: {byte 0, byte 2} and {byte 1, byte 3 (0 for 24 bpp)} as 16-bit halves
+        const uint32_t d[4] = { nx[0], nx[1], nx[2], nx[3] };
+        if (r + 1 < y1) fetch(r + 1);
+        if (BPP == 3) {
+            lo[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c020c00u); hi[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c01u);
+            lo[1] = __builtin_amdgcn_perm(d[1], d[0], 0x0c050c03u); hi[1] = __builtin_amdgcn_perm(d[1], d[0], 0x0c0c0c04u);
+            lo[2] = __builtin_amdgcn_perm(d[2], d[1], 0x0c040c02u); hi[2] = __builtin_amdgcn_perm(d[2], d[1], 0x0c0c0c03u);
+            lo[3] = __builtin_amdgcn_perm(d[2], d[2], 0x0c030c01u); hi[3] = __builtin_amdgcn_perm(d[2], d[2], 0x0c0c0c02u);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { lo[k] = d[k] & 0x00FF00FFu; hi[k] = (d[k] >> 8) & 0x00FF00FFu; }
+        }
+        uint32_t yv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int S = sdot2(lo[k], cyA, sdot2_first_s(hi[k], cyB));
+            if (BPP != 4) yv[k] = (uint16_t)((S + (32 << 14) + (1 << 8)) >> 9);
+            else yv[k] = (uint16_t)((((unsigned)S << 8) + ((32u << 22) + (1u << 16))) >> 17);
+        }
+        const u32x2 oy = { yv[0] | yv[1] << 16, yv[2] | yv[3] << 16 };
+        *(u32x2 *)(dY + (int64_t)r * dsY) = oy;
+        if constexpr (HALF) {
+            uint32_t uv[2], vv[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t al = lo[2 * k] + lo[2 * k + 1], ah = hi[2 * k] + hi[2 * k + 1];
+                const int Su = sdot2(al, cuA, sdot2_first_s(ah, cuB)), Sv = sdot2(al, cvA, sdot2_first_s(ah, cvB));
+                if (BPP != 4) {
+                    uv[k] = (uint16_t)((Su + (256 << 15) + (1 << 9)) >> 10);
+                    vv[k] = (uint16_t)((Sv + (256 << 15) + (1 << 9)) >> 10);
+                } else {
+                    const unsigned rnd = (256u << 23) + (1u << 17);
+                    uv[k] = (uint16_t)((((unsigned)Su << 8) + rnd) >> 18);
+                    vv[k] = (uint16_t)((((unsigned)Sv << 8) + rnd) >> 18);
+                }
+            }
+            *(uint32_t *)(dU + (int64_t)r * dsC) = uv[0] | uv[1] << 16;
+            *(uint32_t *)(dV + (int64_t)r * dsC) = vv[0] | vv[1] << 16;
+        } else {
+            uint32_t uv[4], vv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int Su = sdot2(lo[k], cuA, sdot2_first_s(hi[k], cuB)), Sv = sdot2(lo[k], cvA, sdot2_first_s(hi[k], cvB));
+                if (BPP != 4) {
+                    uv[k] = (uint16_t)((Su + (256 << 14) + (1 << 8)) >> 9);
+                    vv[k] = (uint16_t)((Sv + (256 << 14) + (1 << 8)) >> 9);
+                } else {
+                    uv[k] = (uint16_t)((((unsigned)Su << 8) + ((256u << 22) + (1u << 16))) >> 17);
+                    vv[k] = (uint16_t)((((unsigned)Sv << 8) + ((256u << 22) + (1u << 16))) >> 17);
+                }
+            }
+            const u32x2 ou = { uv[0] | uv[1] << 16, uv[2] | uv[3] << 16 }, ov = { vv[0] | vv[1] << 16, vv[2] | vv[3] << 16 };
+            *(u32x2 *)(dU + (int64_t)r * dsC) = ou;
+            *(u32x2 *)(dV + (int64_t)r * dsC) = ov;
+        }
+    }
+}
+
 // Packed 24 / 32 bpp RGB and planar 8-bit GBR into planar 8-bit 4:4:4 YUV of the same size: every filter is the identity, every pixel
 // independent.  rgb24ToY_c / rgb24ToUV_c (input.c:1068-1124), rgb16_32ToY / UV_c_template with the 32-bit rows (:264-334), planar_rgb_to_y /
 // _uv (:1174-1211), hScale16To15_c with one tap, yuv2plane1_8_c (8-bit source: the constant 64, swscale.c:385-387).  Lane = four pixels, a
