@@ -505,14 +505,17 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                            !p.dst_alpha_fill && !p.no_chroma && !vlines_pending && dst_ok && !c->tune.no_strip && !c->tune.no_rgbsrc && p.dstW >= c->tune.strip_min_w;
             for (int k = 0; k < 9 && rgbread; k++) rgbread = p.rgb2yuv[k] > -32768 && p.rgb2yuv[k] < 32768;   // (v_dot2_i32_i16 operands)
             d->rgbread_on = false;
+            // vertical chroma filters of 17 .. 24 taps (a 4:1 chroma step: packed RGB or 4:2:2 sources into a 4:2:0 picture of half the size): the strip
+            // kernel's chroma instantiations with a ring of 12 row pairs; the tile kernel and the RGB epilogue stop at 16
+            const bool vchr_long = fs2(c->vChr.size) > 16 && fs2(c->vChr.size) <= 24 && dst_ok && !rgb_ok && !c->tune.no_strip;
             const bool fullA = !d->unity_h && !p.fast_bilinear && !gray_any && (src_ok || (nv_src && dst_ok) || rgbread) && ((dst_ok && c->vLum.size >= 2 && c->vChr.size >= 2) || rgb_ok) && !p.wide &&
-                               fs2(c->hLum.size) <= 16 && fs2(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && fs2(c->vChr.size) <= 16 && !c->tune.no_dot2;
+                               fs2(c->hLum.size) <= 16 && fs2(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long) && !c->tune.no_dot2;
             // identity luma filters + scaled chroma (yuv422p -> yuv420p, yuv444p -> yuv420p, the 10-bit -> 8-bit twins ...): the luma plane streams
             // (one tap: a per-sample pass), only the chroma planes need the strip kernel.  (The planar writers' one-tap form is what keeps these
             // shapes off the full strip / dot2 plans above.)
             const bool mixedM = !fullA && !vlines_pending && bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !(d->unity_h && d->unity_v) &&
                                 !p.fast_bilinear && !gray_any && (src_ok || nv_src) && dst_ok && c->vChr.size >= 2 && !p.wide && !p.range_active && !p.dst_alpha_fill &&
-                                fs2(c->hChr.size) <= 16 && fs2(c->vChr.size) <= 16 && !c->tune.no_strip && !c->tune.no_mixed && p.dstW >= c->tune.strip_min_w;
+                                fs2(c->hChr.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long) && !c->tune.no_strip && !c->tune.no_mixed && p.dstW >= c->tune.strip_min_w;
             d->mixed_ok = false;
             if (fullA || mixedM) {
                 const int SPC = (p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010 || rgbread) ? 8 : 16;
@@ -577,6 +580,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     if (ncmax / SPC > (ncomp == 2 ? 64 : 128)) return false;   // one (chroma) or two (luma) 16-byte chunks per lane and row
                     for (int x = 0; x < hb.count; x++) nph = std::max(nph, ((hb.pos[x] & 1) + hb.size + 1) / 2);
                     for (int y = 0; y < vb.count; y++) { if (vb.pos[y] < 0) return false; npv = std::max(npv, ((vb.pos[y] & 1) + vb.size + 1) / 2); }
+                    if (npv > (ncomp == 2 && !ring_of ? 12 : 8)) return false;   // ring depth of the instantiations: 8 row pairs, 12 for the planar chroma planes
                     for (int y = 1; y < vb.count; y++) if (vb.pos[y] < vb.pos[y - 1]) return false;   // the ring only moves forward
                     g.TW = TW; g.strips = strips; g.NCmax = ncmax; g.nph = nph; g.npv = npv; g.hfs2 = hf2; g.vfs2 = vf2;
                     g.lds_bytes = 4 * ncomp * 2 * ((ncmax + SPC) / 2) * 4;
@@ -596,7 +600,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         if (lead < 0) return false;
                         for (int j = 0; j < vb.size; j++) {
                             const int k = (vb.pos[y] & 1) + j + lead;
-                            e.vt[k >> 1] |= (uint32_t)(uint16_t)vb.taps[(size_t)y * vb.size + j] << (16 * (k & 1));
+                            // (pairs 8 .. 11 of a long chroma filter land in the four spare dwords behind vt[8]: load_strip_row_n)
+                            reinterpret_cast<uint32_t *>(&e)[4 + (k >> 1)] |= (uint32_t)(uint16_t)vb.taps[(size_t)y * vb.size + j] << (16 * (k & 1));
                         }
                     }
                     o.rows = put(rows.data(), rows.size() * sizeof(SwsStripRow));
@@ -663,7 +668,14 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         d->striprgb_ok = true;                           // (and every row in the "X" writer mode: checked below)
                     }
                 } else
-                if (plan2(c->hLum, c->vLum, p.dstW, p.dstH, 1, d->dotL, oL) && plan2(c->hChr, c->vChr, p.chrDstW, p.chrDstH, 2, d->dotC, oC)) {
+                {
+                  const bool tiles = plan2(c->hLum, c->vLum, p.dstW, p.dstH, 1, d->dotL, oL) && plan2(c->hChr, c->vChr, p.chrDstW, p.chrDstH, 2, d->dotC, oC);
+                  size_t ohl = 0, ohc = 0;
+                  if (!tiles && strip_plan) {   // (the strip kernel shares the tile kernel's padded horizontal taps; without a tile plan it gets its own copy)
+                      const std::vector<int16_t> htl = padded(c->hLum), htc = padded(c->hChr);
+                      ohl = put(htl.data(), htl.size() * 2); ohc = put(htc.data(), htc.size() * 2);
+                  }
+                  if (tiles || strip_plan) {
                     if (blob.size() > d->dot2_bytes) {
                         if (d->d_dot2) HIPCHK(hipFree(d->d_dot2));
                         d->d_dot2 = nullptr;
@@ -677,17 +689,19 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         g.colStart = (const int32_t *)(b + o.cs); g.colCount = (const int32_t *)(b + o.cc);
                         g.hT2 = (const int16_t *)(b + o.ht); g.vT2 = (const int16_t *)(b + o.vt);
                     };
-                    bind(d->dotL, oL); bind(d->dotC, oC);
-                    d->dot2_ok = src_ok;
+                    if (tiles) { bind(d->dotL, oL); bind(d->dotC, oC); }
+                    d->dot2_ok = tiles && src_ok && fs2(c->vChr.size) <= 16;
                     if (strip_plan) {
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         d->stripL.colStart = (const int32_t *)(b + sL.cs); d->stripL.colCount = (const int32_t *)(b + sL.cc);
                         d->stripC.colStart = (const int32_t *)(b + sC.cs); d->stripC.colCount = (const int32_t *)(b + sC.cc);
-                        d->stripL.hT2 = d->dotL.hT2; d->stripL.vT2 = d->dotL.vT2; d->stripC.hT2 = d->dotC.hT2; d->stripC.vT2 = d->dotC.vT2;
+                        if (tiles) { d->stripL.hT2 = d->dotL.hT2; d->stripL.vT2 = d->dotL.vT2; d->stripC.hT2 = d->dotC.hT2; d->stripC.vT2 = d->dotC.vT2; }
+                        else { d->stripL.hT2 = (const int16_t *)(b + ohl); d->stripC.hT2 = (const int16_t *)(b + ohc); d->stripL.vT2 = d->stripC.vT2 = nullptr; }
                         d->stripL.rows = (const SwsStripRow *)(b + sL.rows); d->stripC.rows = (const SwsStripRow *)(b + sC.rows);
                         d->strip_ok = true;
                         d->rgbread_on = rgbread;
                     }
+                  }
                 }
             }
         }

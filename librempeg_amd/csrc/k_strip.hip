@@ -24,6 +24,19 @@ int launch_strip_planes(const LaunchCtx &L, int which)
 #define SWS_STRIP(S, C, K) hipLaunchKernelGGL((swsk::sws_k_strip_march<S, C, K>), grid, blk, g.lds_bytes, st, fs, p, g)
 #define SWS_STRIP_DMA(C, K) hipLaunchKernelGGL((swsk::sws_k_strip_dma<C, K>), grid, blk, g.lds_dma_bytes, st, fs, p, g)
                 const int cols = g.TW / 64;
+                if (chroma && g.npv > 8) {   // long vertical chroma filters (4:1 steps): the instantiations with a ring of 12 row pairs
+                    if (s16 && g.dma_ok && !c->tune.no_strip_dma) {
+                        if (cols == 1) hipLaunchKernelGGL((swsk::sws_k_strip_dma<true, 1, 12>), grid, blk, g.lds_dma_bytes, st, fs, p, g);
+                        else hipLaunchKernelGGL((swsk::sws_k_strip_dma<true, 2, 12>), grid, blk, g.lds_dma_bytes, st, fs, p, g);
+                    } else if (s16) {
+                        if (cols == 1) hipLaunchKernelGGL((swsk::sws_k_strip_march<true, true, 1, 12>), grid, blk, g.lds_bytes, st, fs, p, g);
+                        else hipLaunchKernelGGL((swsk::sws_k_strip_march<true, true, 2, 12>), grid, blk, g.lds_bytes, st, fs, p, g);
+                    } else {
+                        if (cols == 1) hipLaunchKernelGGL((swsk::sws_k_strip_march<false, true, 1, 12>), grid, blk, g.lds_bytes, st, fs, p, g);
+                        else hipLaunchKernelGGL((swsk::sws_k_strip_march<false, true, 2, 12>), grid, blk, g.lds_bytes, st, fs, p, g);
+                    }
+                    return;
+                }
                 if (s16 && g.dma_ok && !c->tune.no_strip_dma) {   // 16-bit sources: LDS-DMA ring, 3 row pairs in flight per wave
                     if (chroma) { if (cols == 1) SWS_STRIP_DMA(true, 1); else SWS_STRIP_DMA(true, 2); }
                     else        { if (cols == 2) SWS_STRIP_DMA(false, 2); else SWS_STRIP_DMA(false, 4); }

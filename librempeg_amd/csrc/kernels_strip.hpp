@@ -20,6 +20,12 @@
 
 namespace swsk {
 
+// vertical stage over the N newest ring entries (the body of one case of the switch over the row-pair count)
+#define SWS_SVB(N) \
+    _Pragma("unroll") for (int ci = 0; ci < NCOMP; ci++) _Pragma("unroll") for (int c = 0; c < COLS; c++) { \
+        acc[ci][c] = sdot2_first_s(ring[ci][c][RD - (N)], e.vt[0]); \
+        _Pragma("unroll") for (int k = 1; k < (N); k++) acc[ci][c] = sdot2(ring[ci][c][RD - (N) + k], e.vt[k], acc[ci][c]); }
+
 // g.debug switches stages off for profiling (results are WRONG): only in -DSWS_HIP_PROFILING builds
 #ifdef SWS_HIP_PROFILING
 #define SWS_DBG(g, bit) ((g).debug & (bit))
@@ -44,6 +50,20 @@ __device__ __forceinline__ SwsStripRow load_strip_row(const SwsStripRow *rows, i
     for (int k = 0; k < 8; k++) e.vt[k] = q[4 + k];
     return e;
 }
+// The same entry with RD tap pairs: the host writes pairs 8 .. 11 of a long vertical filter (chroma at 4:1: 17 bicubic taps) into the four
+// spare dwords behind vt[8] of the 64-byte entry
+template <int RD> struct StripRowN { int pf; uint32_t vt[RD]; };
+template <int RD>
+__device__ __forceinline__ StripRowN<RD> load_strip_row_n(const SwsStripRow *rows, int idx)
+{
+    typedef const uint32_t __attribute__((address_space(4))) *cptr;
+    cptr q = (cptr)(uintptr_t)(rows + idx);
+    StripRowN<RD> e;
+    e.pf = (int)q[0];
+#pragma unroll
+    for (int k = 0; k < RD; k++) e.vt[k] = q[4 + k];
+    return e;
+}
 
 // horizontal stage of one row pair for COLS columns of NCOMP components -> one packed dword per (component, column)
 template <int NP, int NCOMP, int COLS>
@@ -63,7 +83,7 @@ __device__ __forceinline__ void strip_hstage(const StripLds &L, const int (&spd)
         }
 }
 
-template <bool SRC16, bool CHROMA, int COLS, int NPH>
+template <bool SRC16, bool CHROMA, int COLS, int NPH, int RD = 8>
 __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParams &p, const SwsStripGeom &g, int strip, int y0, int y1,
                                            uint8_t *smem, int wib, int lane)
 {
@@ -188,13 +208,13 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
         doff[c] = x < W ? x * dbytes : 0x7fffffff;
     }
 
-    uint32_t ring[NCOMP][COLS][8];
+    uint32_t ring[NCOMP][COLS][RD];
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
         for (int c = 0; c < COLS; c++)
 #pragma unroll
-            for (int k = 0; k < 8; k++) ring[ci][c][k] = 0;
+            for (int k = 0; k < RD; k++) ring[ci][c][k] = 0;
 
     // pending output row (its stores are issued after the next wait for prefetched rows, see the header)
     uint32_t pend[NCOMP][COLS];
@@ -231,7 +251,7 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
 
     // ---- march ----
     const SwsStripRow *rows = g.rows;
-    SwsStripRow e = load_strip_row(rows, y0);                  // scalar loads: first ring pair and vertical tap pairs of the row
+    StripRowN<RD> e = load_strip_row_n<RD>(rows, y0);                  // scalar loads: first ring pair and vertical tap pairs of the row
     int qnext = e.pf;                                          // next source-row pair to h-scale == the pair staged in LDS
     prefetch(qnext);
     __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): keep the fill out of the loop's wait arithmetic
@@ -239,7 +259,7 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
     prefetch(qnext + 1);
     const int bits = p.dst_bits;
     for (int y = y0; y < y1; y++) {
-        const SwsStripRow en = load_strip_row(rows, min(y + 1, H - 1));   // next row's scalars, one row ahead
+        const StripRowN<RD> en = load_strip_row_n<RD>(rows, min(y + 1, H - 1));   // next row's scalars, one row ahead
         const int pfy = e.pf;
         if (qnext < pfy) {                                     // rows nobody needs (steep down-scaling with short filters): skip
             qnext = pfy;
@@ -264,8 +284,8 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
 #pragma unroll
                 for (int c = 0; c < COLS; c++) {
 #pragma unroll
-                    for (int k = 0; k < 7; k++) ring[ci][c][k] = ring[ci][c][k + 1];
-                    ring[ci][c][7] = np[ci][c];
+                    for (int k = 0; k < RD - 1; k++) ring[ci][c][k] = ring[ci][c][k + 1];
+                    ring[ci][c][RD - 1] = np[ci][c];
                 }
             qnext++;
             // LDS rows are consumed: wait for the prefetched pair, stage it, release the pending row, prefetch the next pair
@@ -285,15 +305,19 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
 #pragma unroll
             for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
-                for (int c = 0; c < COLS; c++) acc[ci][c] = (int)ring[ci][c][7];
+                for (int c = 0; c < COLS; c++) acc[ci][c] = (int)ring[ci][c][RD - 1];
         } else
         switch (npv) {
 #define SWS_SV(N) case N: \
             _Pragma("unroll") for (int ci = 0; ci < NCOMP; ci++) _Pragma("unroll") for (int c = 0; c < COLS; c++) { \
-                acc[ci][c] = sdot2_first_s(ring[ci][c][8 - N], e.vt[0]); \
-                _Pragma("unroll") for (int k = 1; k < N; k++) acc[ci][c] = sdot2(ring[ci][c][8 - N + k], e.vt[k], acc[ci][c]); } \
+                acc[ci][c] = sdot2_first_s(ring[ci][c][RD - N], e.vt[0]); \
+                _Pragma("unroll") for (int k = 1; k < N; k++) acc[ci][c] = sdot2(ring[ci][c][RD - N + k], e.vt[k], acc[ci][c]); } \
             break;
         SWS_SV(1) SWS_SV(2) SWS_SV(3) SWS_SV(4) SWS_SV(5) SWS_SV(6) SWS_SV(7)
+        case 8: if constexpr (RD > 8) { SWS_SVB(8) } else { SWS_SVB(RD) } break;
+        case 9: if constexpr (RD > 8) { SWS_SVB(9) } break;
+        case 10: if constexpr (RD > 8) { SWS_SVB(10) } break;
+        case 11: if constexpr (RD > 8) { SWS_SVB(11) } break;
 #undef SWS_SV
         default:
 #pragma unroll
@@ -302,7 +326,7 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
                 for (int c = 0; c < COLS; c++) {
                     acc[ci][c] = sdot2_first_s(ring[ci][c][0], e.vt[0]);
 #pragma unroll
-                    for (int k = 1; k < 8; k++) acc[ci][c] = sdot2(ring[ci][c][k], e.vt[k], acc[ci][c]);
+                    for (int k = 1; k < RD; k++) acc[ci][c] = sdot2(ring[ci][c][k], e.vt[k], acc[ci][c]);
                 }
             break;
         }
@@ -334,7 +358,9 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
     flush();
 }
 
-template <bool SRC16, bool CHROMA, int COLS>
+// RD: depth of the register ring in row pairs = the longest vertical filter the instantiation takes (8: 16 taps; 12: the chroma planes of a
+// 4:1 vertical step -- packed RGB or 4:2:2 sources into a 4:2:0 picture of half the size -- with up to 24)
+template <bool SRC16, bool CHROMA, int COLS, int RD = 8>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) sws_k_strip_march(SwsFrameSet fs, SwsDevParams p, SwsStripGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -348,7 +374,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     if (y0 >= y1) return;
     const FrameRegs f = load_frame(fs, blockIdx.z);
     switch (g.nph) {        // the whole march is instantiated per horizontal tap-pair count: the loop body is branch-free
-#define SWS_SB(N) case N: strip_body<SRC16, CHROMA, COLS, N>(f, p, g, strip, y0, y1, smem, wib, lane); break;
+#define SWS_SB(N) case N: strip_body<SRC16, CHROMA, COLS, N, RD>(f, p, g, strip, y0, y1, smem, wib, lane); break;
     SWS_SB(1) SWS_SB(2) SWS_SB(3) SWS_SB(4) SWS_SB(5) SWS_SB(6) SWS_SB(7) SWS_SB(8)
 #undef SWS_SB
     }
@@ -388,7 +414,7 @@ __device__ __forceinline__ void strip_dma16(uint32_t lds_dst, int voff, const i3
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff), "s"(mask_lo), "s"(mask_hi) : "memory");
 }
 
-template <bool CHROMA, int COLS, int NPH>
+template <bool CHROMA, int COLS, int NPH, int RD = 8>
 __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevParams &p, const SwsStripGeom &g, int strip, int y0, int y1,
                                                uint8_t *smem, int wib, int lane)
 {
@@ -475,13 +501,13 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
         doff[c] = x < W ? x * dbytes : 0x7fffffff;
     }
 
-    uint32_t ring[NCOMP][COLS][8];
+    uint32_t ring[NCOMP][COLS][RD];
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
         for (int c = 0; c < COLS; c++)
 #pragma unroll
-            for (int k = 0; k < 8; k++) ring[ci][c][k] = 0;
+            for (int k = 0; k < RD; k++) ring[ci][c][k] = 0;
 
     uint32_t pend[NCOMP][COLS];
     int pend_y = -1;
@@ -517,14 +543,14 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
 
     // ---- march ----
     const SwsStripRow *rows = g.rows;
-    SwsStripRow e = load_strip_row(rows, y0);
+    StripRowN<RD> e = load_strip_row_n<RD>(rows, y0);
     int qnext = e.pf;                                          // next source-row pair to h-scale
     int qdma = qnext;                                          // next pair to request
 #pragma unroll
     for (int i = 0; i < D; i++) dma(qdma++);
     const int bits = p.dst_bits;
     for (int y = y0; y < y1; y++) {
-        const SwsStripRow en = load_strip_row(rows, min(y + 1, H - 1));
+        const StripRowN<RD> en = load_strip_row_n<RD>(rows, min(y + 1, H - 1));
         const int pfy = e.pf;
         while (qnext <= pfy + npv - 1) {
             wait_pair();
@@ -547,8 +573,8 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
 #pragma unroll
                 for (int c = 0; c < COLS; c++) {
 #pragma unroll
-                    for (int k = 0; k < 7; k++) ring[ci][c][k] = ring[ci][c][k + 1];
-                    ring[ci][c][7] = np[ci][c];
+                    for (int k = 0; k < RD - 1; k++) ring[ci][c][k] = ring[ci][c][k + 1];
+                    ring[ci][c][RD - 1] = np[ci][c];
                 }
             qnext++;
             // the slot's ds_reads have returned (their results are in np): pin that, release the pending row, re-request the slot
@@ -564,15 +590,19 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
 #pragma unroll
             for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
-                for (int c = 0; c < COLS; c++) acc[ci][c] = (int)ring[ci][c][7];
+                for (int c = 0; c < COLS; c++) acc[ci][c] = (int)ring[ci][c][RD - 1];
         } else
         switch (npv) {
 #define SWS_SV(N) case N: \
             _Pragma("unroll") for (int ci = 0; ci < NCOMP; ci++) _Pragma("unroll") for (int c = 0; c < COLS; c++) { \
-                acc[ci][c] = sdot2_first_s(ring[ci][c][8 - N], e.vt[0]); \
-                _Pragma("unroll") for (int k = 1; k < N; k++) acc[ci][c] = sdot2(ring[ci][c][8 - N + k], e.vt[k], acc[ci][c]); } \
+                acc[ci][c] = sdot2_first_s(ring[ci][c][RD - N], e.vt[0]); \
+                _Pragma("unroll") for (int k = 1; k < N; k++) acc[ci][c] = sdot2(ring[ci][c][RD - N + k], e.vt[k], acc[ci][c]); } \
             break;
         SWS_SV(1) SWS_SV(2) SWS_SV(3) SWS_SV(4) SWS_SV(5) SWS_SV(6) SWS_SV(7)
+        case 8: if constexpr (RD > 8) { SWS_SVB(8) } else { SWS_SVB(RD) } break;
+        case 9: if constexpr (RD > 8) { SWS_SVB(9) } break;
+        case 10: if constexpr (RD > 8) { SWS_SVB(10) } break;
+        case 11: if constexpr (RD > 8) { SWS_SVB(11) } break;
 #undef SWS_SV
         default:
 #pragma unroll
@@ -581,7 +611,7 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
                 for (int c = 0; c < COLS; c++) {
                     acc[ci][c] = sdot2_first_s(ring[ci][c][0], e.vt[0]);
 #pragma unroll
-                    for (int k = 1; k < 8; k++) acc[ci][c] = sdot2(ring[ci][c][k], e.vt[k], acc[ci][c]);
+                    for (int k = 1; k < RD; k++) acc[ci][c] = sdot2(ring[ci][c][k], e.vt[k], acc[ci][c]);
                 }
             break;
         }
@@ -614,7 +644,7 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA write may land after the wave has given up its LDS
 }
 
-template <bool CHROMA, int COLS>
+template <bool CHROMA, int COLS, int RD = 8>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) sws_k_strip_dma(SwsFrameSet fs, SwsDevParams p, SwsStripGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -628,7 +658,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     if (y0 >= y1) return;
     const FrameRegs f = load_frame(fs, blockIdx.z);
     switch (g.nph) {
-#define SWS_SB(N) case N: strip_body_dma<CHROMA, COLS, N>(f, p, g, strip, y0, y1, smem, wib, lane); break;
+#define SWS_SB(N) case N: strip_body_dma<CHROMA, COLS, N, RD>(f, p, g, strip, y0, y1, smem, wib, lane); break;
     SWS_SB(1) SWS_SB(2) SWS_SB(3) SWS_SB(4) SWS_SB(5) SWS_SB(6) SWS_SB(7) SWS_SB(8)
 #undef SWS_SB
     }

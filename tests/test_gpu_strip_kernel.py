@@ -63,3 +63,18 @@ def test_semi_planar_sources_take_the_strip_kernel(src, dst):
         assert path == tpath or (tpath == "main:fused_tile_dot2" and path == "main:fused_tile"), (path, tpath, sw, dw)
     if src not in ("nv24", "p410le") or dst == "yuv444p":     # 4:4:4 -> 4:2:0 / 4:2:2 bicubic chroma needs more than 16 horizontal taps
         assert run_case(640, 96, src, 320, 64, dst, SWS_BICUBIC | BX, seed=3, tune=dict(strip_min_w=64))[0] == "main:strip_march"
+
+
+@pytest.mark.parametrize("flags", [SWS_BICUBIC, SWS_BILINEAR, SWS_AREA, SWS_GAUSS], ids=["bicubic", "bilinear", "area", "gauss"])
+def test_long_vertical_chroma_filters(flags):
+    """a 4:1 vertical chroma step (packed RGB or 4:2:2 sources into a 4:2:0 picture of half the size): 17 .. 24 vertical chroma taps, the strip
+    kernel's chroma instantiations with a ring of 12 row pairs (register-staged and LDS-DMA forms), both strip widths"""
+    for tune in (STRIP, dict(strip_min_w=0, strip_cols_c=1)):
+        for sfmt, dfmt in (("yuv422p", "yuv420p"), ("yuv422p10le", "yuv420p"), ("yuv422p", "nv12"), ("yuv422p12le", "p010le"), ("nv16", "yuv420p"), ("rgb24", "yuv420p"), ("bgra", "nv12")):
+            for (sw, sh, dw, dh) in ((640, 128, 320, 64), (1288, 96, 644, 48), (520, 200, 300, 100)):
+                path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, flags | BX, seed=sw + dh, tune=tune)
+                if flags == SWS_BICUBIC and (sw, dw) != (520, 300):
+                    assert path in ("main:strip_march", "main:rgbread+strip_march"), (path, sfmt, dfmt, sw, dw)
+    # full size: 4K capture into a 1080p 4:2:0 picture
+    assert run_case(3840, 2160, "bgra", 1920, 1080, "yuv420p", SWS_BICUBIC | BX, seed=5)[0] == "main:rgbread+strip_march"
+    assert run_case(3840, 2160, "yuv422p10le", 1920, 1080, "yuv420p", SWS_BICUBIC | BX, seed=6)[0] == "main:strip_march"
