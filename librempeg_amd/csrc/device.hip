@@ -17,6 +17,7 @@
 #include "../../include/hwcontext_hip.h"
 
 namespace swship {
+void launch_layout_join422(const LaunchCtx &L, bool uyvy);   // k_layout.hip: planar 4:2:2 working picture -> yuyv422 / uyvy422 (yvyu422: planes swapped by the planner)
 
 static int ensure_dev(SwsInternal *c)
 {
@@ -62,6 +63,9 @@ static void dev_state_free(DeviceState *d)
         if (p) (void)hipFree(p);
     if (d->h_frames) (void)hipHostFree(d->h_frames);
     if (d->h_frames2) (void)hipHostFree(d->h_frames2);
+    if (d->spare_ptr[0]) (void)hipFree(d->spare_ptr[0]);
+    if (d->spare_ptr[1]) (void)hipFree(d->spare_ptr[1]);
+    if (d->spare_ptr[2]) (void)hipHostFree(d->spare_ptr[2]);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
     if (d->ev_loan) (void)hipEventDestroy(d->ev_loan);
@@ -243,6 +247,22 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     p.u_plane_dst = dd->comp[1].plane; p.v_plane_dst = dd->comp[2].plane;
     const bool gray_any = isGray(o.src_format) || isGray(o.dst_format) || c->needAlpha || p.srcKind == SRCK_MONO;   // paths the fused kernels do not cover
     p.should_dither = isNBPS(o.src_format) || is16BPS(o.src_format);     // swscale.c:292-293
+    // ---- packed 4:2:2 destinations (yuyv422 / uyvy422 / yvyu422) through the planar writers and an interleaving pass ----
+    // With an 8-bit source (no dither pattern: the constant 64) the packed writer's general form is the planar writers' arithmetic sample for
+    // sample: yuv2422_X_c_template (output.c:843-881) sums from 1 << 18, >> 19, clip; yuv2planeX_8_c / yuv2plane1_8_c (output.c:438-493) sum from
+    // 64 << 12, >> 19, and one tap of 4096 is (s + 64) >> 7 in both; yuv2422_1 with one chroma tap is the same.  The other short forms are not
+    // (yuv2422_1 with two chroma taps takes the nearer row or the plain mean, yuv2422_2 sums without a rounding term; vscale.c:136-158): those
+    // filter shapes keep the packed writer of the generic kernels.  The planner below then sees a planar 8-bit 4:2:2 destination (in a working
+    // picture per frame), so the conversion gets the strip / mixed / tile kernel of its shape; launch_plan_le interleaves afterwards
+    // (yuvPlanartoyuy2_c / yuvPlanartouyvy_c are plain byte interleaves: the streaming join of kernels_layout.hpp).
+    d->spare_i[0] = 0;
+    if (c->plan == PLAN_MAIN && p.dstKind == DSTK_PACKED422 && dd->comp[0].depth == 8 && !(o.dst_w & 1) && !p.should_dither && !c->needAlpha && !gray_any &&
+        !((c->vLum.size == 1 || c->vLum.size == 2) && c->vChr.size == 2) && !c->tune.no_mixed && !c->tune.no_layout_stream) {
+        const bool uyvy = dd->comp[0].offset == 1, vfirst = dd->comp[2].offset < dd->comp[1].offset;   // (yvyu422: V before U)
+        p.dstKind = DSTK_PLANAR8;
+        p.u_plane_dst = vfirst ? 2 : 1; p.v_plane_dst = vfirst ? 1 : 2;
+        d->spare_i[0] = uyvy ? 2 : 1;
+    }
     p.full_chr = ((o.flags & SWS_FULL_CHR_H_INT) && isAnyRGB(o.dst_format)) ? 1 : 0;
     if (p.srcKind == SRCK_PACKEDHI)
         for (int k = 0; k < ds->nb_components; k++) {
@@ -910,6 +930,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     }
     default: c->path_name = "none"; c->kernel_name = ""; break;
     }
+    if (c->plan == PLAN_MAIN && d->spare_i[0]) c->path_name += "+join422";
     // (16-byte aligned pictures of the layout converters take the streaming kernel, k_layout.hip; the names above are the fallback's)
     if (!c->tune.no_layout_stream && (c->plan == PLAN_UNSC_PLANAR2NV12 || c->plan == PLAN_UNSC_NV122PLANAR || c->plan == PLAN_UNSC_PLANARCOPY || c->plan == PLAN_UNSC_PLANAR2NV24 ||
                                       c->plan == PLAN_UNSC_NV242PLANAR || c->plan == PLAN_UNSC_P4222PLANAR || c->plan == PLAN_UNSC_PLANAR2P422))
@@ -1040,6 +1061,27 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         }
         frames = palfr.data();
     }
+    // packed 4:2:2 destination through planar writers (dev_prepare_on): the kernels write a planar 4:2:2 working picture per frame
+    std::vector<SwsFramePtrs> p422fr, p422join;
+    if (c->plan == PLAN_MAIN && d->spare_i[0]) {
+        auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
+        const int sY = (int)a256(p.dstW), sC = (int)a256(p.dstW >> 1);
+        const int64_t offU = (int64_t)sY * p.dstH, offV = offU + (int64_t)sC * p.dstH, fbytes = a256(offV + (int64_t)sC * p.dstH);
+        int r = grow(c, &d->spare_ptr[0], &d->spare_sz[0], (size_t)fbytes * (size_t)n);
+        if (r < 0) return r;
+        p422fr.assign(frames, frames + n);
+        p422join.resize((size_t)n);
+        for (int i = 0; i < n; i++) {
+            uint8_t *base = (uint8_t *)d->spare_ptr[0] + (size_t)i * (size_t)fbytes;
+            SwsFramePtrs &a = p422fr[(size_t)i], &j = p422join[(size_t)i];
+            std::memset(&j, 0, sizeof(j));
+            j.dst[0] = a.dst[0]; j.dstStride[0] = a.dstStride[0];
+            j.src[0] = base; j.src[1] = base + offU; j.src[2] = base + offV; j.srcStride[0] = sY; j.srcStride[1] = j.srcStride[2] = sC;
+            a.dst[0] = base; a.dst[1] = base + offU; a.dst[2] = base + offV; a.dst[3] = nullptr;
+            a.dstStride[0] = sY; a.dstStride[1] = a.dstStride[2] = sC; a.dstStride[3] = 0;
+        }
+        frames = p422fr.data();
+    }
     LaunchCtx L;
     std::memset(&L.fs, 0, sizeof(L.fs));
     SwsFrameSet &fs = L.fs;
@@ -1105,6 +1147,35 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
     default: ret = launch_misc(L); break;
     }
     if (ret < 0) return ret;
+    if (!p422join.empty()) {   // interleave the planar 4:2:2 working pictures into the packed destinations
+        LaunchCtx J = L;
+        std::memset(&J.fs, 0, sizeof(J.fs));
+        J.fs.count = n;
+        J.frames = p422join.data();
+        if (n == 1) { J.fs.table = nullptr; J.fs.one = p422join[0]; }
+        else {
+            SwsFramePtrs *&dtab = reinterpret_cast<SwsFramePtrs *&>(d->spare_ptr[1]), *&htab = reinterpret_cast<SwsFramePtrs *&>(d->spare_ptr[2]);
+            int &cap = d->spare_i[1], &valid = d->spare_i[2];
+            const bool same = cap >= n && valid == n && !std::memcmp(htab, p422join.data(), sizeof(SwsFramePtrs) * (size_t)n);
+            if (!same) {
+                if (n > cap) {
+                    if (dtab) HIPCHK(hipFree(dtab));
+                    if (htab) HIPCHK(hipHostFree(htab));
+                    dtab = nullptr; htab = nullptr; cap = 0;
+                    HIPCHK(hipMalloc((void **)&dtab, sizeof(SwsFramePtrs) * (size_t)n));
+                    HIPCHK(hipHostMalloc((void **)&htab, sizeof(SwsFramePtrs) * (size_t)n, hipHostMallocDefault));
+                    cap = n;
+                } else {
+                    HIPCHK(hipStreamSynchronize(st));   // a previous batch may still be reading the pinned table
+                }
+                std::memcpy(htab, p422join.data(), sizeof(SwsFramePtrs) * (size_t)n);
+                HIPCHK(hipMemcpyAsync(dtab, htab, sizeof(SwsFramePtrs) * (size_t)n, hipMemcpyHostToDevice, st));
+                valid = n;
+            }
+            J.fs.table = dtab;
+        }
+        launch_layout_join422(J, d->spare_i[0] == 2);
+    }
     HIPCHK(hipGetLastError());
     if (d->timing) { HIPCHK(hipEventRecord(d->ev1, st)); d->timed = true; }
     return 0;
@@ -1767,8 +1838,10 @@ static int scale_slice(SwsInternal *c, const uint8_t *const src[], const int src
     // coordinates to its scaling context, whose cursor is the one that answers; the error-diffusion cascade of this library stands for ONE
     // main-path context of the reference, the inner context's geometry.  (In the gamma cascade the reference's second context reads the rows of
     // the slice from the intermediate picture whether or not the first one has produced them yet; here every row is there when it is read.)
-    const bool casc = c->plan == PLAN_CASCADE, casc_plain = casc && !c->cascade_gamma && !c->cascade_ed;
-    const SwsInternal *cur = !casc ? c : c->cascade_ed ? c->cascade[0] : c->cascade[1];
+    // (force_scaler marks the inner context of a cascade that stands for ONE main-path context of the reference: error diffusion, packed 4:2:2)
+    const bool casc = c->plan == PLAN_CASCADE, casc_inner = casc && c->cascade[0] && c->cascade[0]->force_scaler;
+    const bool casc_plain = casc && !c->cascade_gamma && !casc_inner;
+    const SwsInternal *cur = !casc ? c : casc_inner ? c->cascade[0] : c->cascade[1];
     if (yint == 0) c->slice_dstY = 0;
     const int last = c->slice_dstY;
     int dstY = last;

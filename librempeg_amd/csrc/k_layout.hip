@@ -91,6 +91,21 @@ int launch_layout(const LaunchCtx &L)
     return 1;
 }
 
+// The interleaving pass behind a packed 4:2:2 destination of the scaler (device.hip: the planar writers filled a yuv422p working picture per
+// frame; L.fs holds {src = its planes, dst = the packed picture}): yuvPlanartoyuy2_c / yuvPlanartouyvy_c with one chroma row per luma row.
+void launch_layout_join422(const LaunchCtx &L, bool uyvy)
+{
+    const SwsDevParams &p = *L.p;
+    using namespace swsk;
+    LayoutPlan plan;
+    std::memset(&plan, 0, sizeof(plan));
+    LayoutJob &j = plan.job[0];
+    plan.njobs = 1;
+    j.op = LOP_P422_JOIN; j.rows = p.dstH; j.ys = 0; j.yd = 0; j.sa = j.sb = j.da = j.db = 0;
+    j.n = 2 * (p.dstW >> 1); j.a0 = uyvy ? 1 : 0; j.a1 = 1; j.a2 = 0;
+    hipLaunchKernelGGL((sws_k_layout_stream<4>), dim3(cdiv(cdiv(j.n, 8), 256), cdiv(j.rows, LAYOUT_RPW), L.n), dim3(256), 0, L.st, L.fs, p, plan);
+}
+
 // The luma plane of a PLAN_MAIN context whose horizontal and vertical luma filters are the identity (dev_prepare_on: mixed_ok): one tap of
 // 1 << 14 through hScale8To15_c / hScale16To15_c, one tap through yuv2plane1_* -- per sample, so a streaming pass.  8 -> 8 bit is the copy
 // ((s << 7) + 64) >> 7 == s), 8 -> N bit the plain left shift (the rounding term never carries).

@@ -1,0 +1,69 @@
+"""-m gpu parity for packed 4:2:2 destinations through the scaler (device.hip: planar writers + the streaming interleave, "+join422"):
+yuv2422_X_c_template / yuv2422_1 with one chroma tap (output.c:843-1000) against yuv2planeX_8_c / yuv2plane1_8_c (:438-493) on 8-bit sources;
+the short vertical forms (vscale.c:136-158) and everything with a dither pattern keep the packed writer of the generic kernels."""
+import numpy as np
+import pytest
+
+from librempeg_amd import (SWS_BICUBIC, SWS_BILINEAR, SWS_LANCZOS, SWS_BITEXACT, SWS_ACCURATE_RND, SWS_POINT, SWS_AREA, SWS_FAST_BILINEAR)
+from test_gpu_parity import run_case
+
+pytestmark = pytest.mark.gpu
+BX = SWS_BITEXACT
+TUNE = dict(strip_min_w=0)
+
+SRC = ["yuv420p", "yuv422p", "yuv444p", "yuv410p", "nv12", "nv21", "rgb24", "bgra", "yuvj420p", "gbrp"]
+DST = ["yuyv422", "uyvy422", "yvyu422"]
+
+
+@pytest.mark.parametrize("src", SRC)
+@pytest.mark.parametrize("dst", DST)
+def test_formats(src, dst):
+    for (sw, sh, dw, dh, fl) in ((256, 64, 256, 64, SWS_BICUBIC), (256, 64, 192, 48, SWS_BICUBIC), (320, 50, 512, 80, SWS_BICUBIC), (132, 34, 66, 17, SWS_AREA),
+                                 (256, 64, 320, 96, SWS_BILINEAR), (256, 64, 256, 64, SWS_BILINEAR), (256, 64, 250, 64, SWS_LANCZOS), (130, 30, 131, 31, SWS_BICUBIC)):
+        for tune in (None, TUNE):
+            r = run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh, tune=tune)
+            if r and fl == SWS_BICUBIC and not dw & 1 and (src, dst) not in (("yuv422p", "yuyv422"), ("yuv422p", "uyvy422")) and not (src in ("yuv422p",) and (sw, sh) == (dw, dh)):
+                if not ((sw, sh) == (dw, dh) and src in ("yuv422p", "yuv444p", "rgb24", "bgra", "gbrp")):      # (a one- or two-tap chroma filter may be a short form)
+                    assert r[0].endswith("+join422"), (r[0], src, dst, sw, sh, dw, dh)
+
+
+def test_short_vertical_forms_keep_the_packed_writer():
+    # bilinear 2x vertical upscale: two luma and two chroma taps (yuv2422_2); same-size 4:2:0 -> 4:2:2 bilinear: one luma, two chroma taps (yuv2422_1)
+    assert not run_case(256, 64, "yuv420p", 256, 128, "yuyv422", SWS_BILINEAR | BX)[0].endswith("+join422")
+    assert not run_case(256, 64, "yuv420p", 256, 64, "yuyv422", SWS_BILINEAR | BX)[0].endswith("+join422")
+    assert not run_case(256, 64, "yuv420p10le", 256, 64, "yuyv422", SWS_BICUBIC | BX)[0].endswith("+join422")     # a dither pattern on the planar side
+    assert not run_case(255, 64, "yuv420p", 255, 64, "yuyv422", SWS_BICUBIC | BX)[0].endswith("+join422")         # odd width: the last pair
+    assert run_case(256, 64, "yuv420p", 256, 64, "yuyv422", SWS_BICUBIC | BX)[0].endswith("+join422")
+    assert run_case(256, 64, "yuv420p", 256, 64, "uyvy422", SWS_BICUBIC | BX, tune=dict(no_mixed=1))[0] == "main:fused_generic_unity"
+
+
+def test_full_size_batches_and_host_frames():
+    import torch
+    import oracle_lib as OL
+    from librempeg_amd import SwsContext, HostFrame, DeviceFrame
+    assert run_case(1920, 1080, "yuv420p", 1920, 1080, "yuyv422", SWS_BICUBIC | BX, seed=2)[0].endswith("+join422")
+    assert run_case(1920, 1080, "yuv420p", 1280, 720, "uyvy422", SWS_BICUBIC | BX, seed=3, device_frames=False)[0].endswith("+join422")
+    assert run_case(1920, 1080, "bgra", 1280, 720, "yuyv422", SWS_BICUBIC | BX, seed=4)[0].endswith("+join422")
+    for src, dst, sw, sh, dw, dh, n, flags in (("yuv420p", "yuyv422", 1284, 70, 1028, 56, 5, SWS_BICUBIC | BX), ("nv12", "uyvy422", 1024, 64, 1024, 64, 3, SWS_BICUBIC | BX)):
+        o = OL.Oracle(sw, sh, src, dw, dh, dst, flags)
+        p = SwsContext(sw, sh, src, dw, dh, dst, flags)
+        refs, srcs, dsts = [], [], []
+        for k in range(n):
+            s = OL.fill_random(OL.Frame(src, sw, sh), 60 + k)
+            ref = OL.Frame(dst, dw, dh)
+            assert o.scale(s, ref) == dh
+            refs.append(ref)
+            hs = HostFrame(src, sw, sh)
+            for a, b in zip(hs.planes, s.planes):
+                a[:] = b
+            srcs.append(DeviceFrame(src, sw, sh).upload(hs))
+            dsts.append(DeviceFrame(dst, dw, dh))
+        torch.cuda.synchronize()
+        for rep in range(2):
+            assert p.scale_frames(srcs, dsts) == n
+            p.sync()
+            assert p.path().endswith("+join422"), p.path()
+            for k in range(n):
+                out = dsts[k].download()
+                for a, b, rb in zip(out.planes, refs[k].planes, out.row_bytes):
+                    assert np.array_equal(a[:, :rb], b[:, :rb]), (src, dst, k, rep)
