@@ -17,6 +17,7 @@
 #include "../../include/hwcontext_hip.h"
 
 namespace swship {
+void launch_layout_split422(const LaunchCtx &L, bool uyvy, bool vfirst);   // k_layout.hip: yuyv422 / uyvy422 / yvyu422 -> planar 4:2:2 working picture
 void launch_layout_join422(const LaunchCtx &L, bool uyvy);   // k_layout.hip: planar 4:2:2 working picture -> yuyv422 / uyvy422 (yvyu422: planes swapped by the planner)
 
 static int ensure_dev(SwsInternal *c)
@@ -64,6 +65,7 @@ static void dev_state_free(DeviceState *d)
     if (d->h_frames) (void)hipHostFree(d->h_frames);
     if (d->h_frames2) (void)hipHostFree(d->h_frames2);
     if (d->spare_ptr[0]) (void)hipFree(d->spare_ptr[0]);
+    if (d->spare_ptr[3]) (void)hipFree(d->spare_ptr[3]);
     if (d->spare_ptr[1]) (void)hipFree(d->spare_ptr[1]);
     if (d->spare_ptr[2]) (void)hipHostFree(d->spare_ptr[2]);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
@@ -255,6 +257,16 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     // filter shapes keep the packed writer of the generic kernels.  The planner below then sees a planar 8-bit 4:2:2 destination (in a working
     // picture per frame), so the conversion gets the strip / mixed / tile kernel of its shape; launch_plan_le interleaves afterwards
     // (yuvPlanartoyuy2_c / yuvPlanartouyvy_c are plain byte interleaves: the streaming join of kernels_layout.hpp).
+    // ---- packed 4:2:2 SOURCES (yuyv422 / uyvy422 / yvyu422: cameras, capture cards) through the planar kernels: yuy2ToY_c / yuy2ToUV_c / uyvyToY_c /
+    //      uyvyToUV_c / yvy2ToUV_c (input.c:550-578, :890-907) copy bytes, so a streaming de-interleave into a planar 4:2:2 working picture per frame
+    //      (yuyvtoyuv422_c / uyvytoyuv422_c of the layout kernel) followed by the kernels of a planar 8-bit source is the same arithmetic ----
+    d->spare_i[3] = 0;
+    if (c->plan == PLAN_MAIN && p.srcKind == SRCK_PACKED422 && ds->comp[0].depth == 8 && !(o.src_w & 1) && !gray_any && !(o.flags & SWS_SRC_V_CHR_DROP_MASK) &&
+        !c->tune.no_mixed && !c->tune.no_layout_stream) {
+        p.srcKind = SRCK_PLANAR8;
+        p.u_plane_src = 1; p.v_plane_src = 2;
+        d->spare_i[3] = (ds->comp[0].offset == 1 ? 2 : 1) | (ds->comp[2].offset < ds->comp[1].offset ? 4 : 0);   // 1 yuyv-like, 2 uyvy; 4: V before U (yvyu422)
+    }
     d->spare_i[0] = 0;
     if (c->plan == PLAN_MAIN && p.dstKind == DSTK_PACKED422 && dd->comp[0].depth == 8 && !(o.dst_w & 1) && !p.should_dither && !c->needAlpha && !gray_any &&
         !((c->vLum.size == 1 || c->vLum.size == 2) && c->vChr.size == 2) && !c->tune.no_mixed && !c->tune.no_layout_stream) {
@@ -528,8 +540,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // vertical chroma filters of 17 .. 24 taps (a 4:1 chroma step: packed RGB or 4:2:2 sources into a 4:2:0 picture of half the size): the strip
             // kernel's chroma instantiations with a ring of 12 row pairs; the tile kernel and the RGB epilogue stop at 16
             const bool vchr_long = fs2(c->vChr.size) > 16 && fs2(c->vChr.size) <= 24 && dst_ok && !rgb_ok && !c->tune.no_strip;
-            const bool fullA = !d->unity_h && !p.fast_bilinear && !gray_any && (src_ok || (nv_src && dst_ok) || rgbread) && ((dst_ok && c->vLum.size >= 2 && c->vChr.size >= 2) || rgb_ok) && !p.wide &&
-                               fs2(c->hLum.size) <= 16 && fs2(c->hChr.size) <= 16 && fs2(c->vLum.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long) && !c->tune.no_dot2;
+            // gray -> gray (8 .. 14 bit): one plane, the strip kernel's luma launch alone
+            const bool gray_both = isGray(o.src_format) && isGray(o.dst_format) && !c->needAlpha && src_ok && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && !c->tune.no_strip;
+            const bool fullA = !d->unity_h && !p.fast_bilinear && (!gray_any || gray_both) && (src_ok || (nv_src && dst_ok) || rgbread) &&
+                               ((dst_ok && c->vLum.size >= 2 && (c->vChr.size >= 2 || gray_both)) || rgb_ok) && !p.wide &&
+                               fs2(c->hLum.size) <= 16 && (fs2(c->hChr.size) <= 16 || gray_both) && fs2(c->vLum.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long || gray_both) && !c->tune.no_dot2;
             // identity luma filters + scaled chroma (yuv422p -> yuv420p, yuv444p -> yuv420p, the 10-bit -> 8-bit twins ...): the luma plane streams
             // (one tap: a per-sample pass), only the chroma planes need the strip kernel.  (The planar writers' one-tap form is what keeps these
             // shapes off the full strip / dot2 plans above.)
@@ -633,7 +648,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 // (narrow pictures leave most of a 256-column strip idle and pay the per-band ring fill: the tile kernel keeps them)
                 const int strip_min_w = c->tune.strip_min_w;
                 const bool strip_plan = fullA && dst_ok && !p.range_active && !c->tune.no_strip && p.dstW >= strip_min_w &&
-                                        plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sL) && plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sC);
+                                        plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sL) && (gray_both || plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sC));
                 d->strip_ok = false;
                 log_msg(c, 3, "strip plan: %d (windows %d/%d chunks of %d, taps %d/%d x %d/%d)\n", strip_plan, d->stripL.NCmax / SPC, d->stripC.NCmax / SPC, SPC,
                         d->stripL.nph, d->stripC.nph, d->stripL.npv, d->stripC.npv);
@@ -689,10 +704,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     }
                 } else
                 {
-                  const bool tiles = plan2(c->hLum, c->vLum, p.dstW, p.dstH, 1, d->dotL, oL) && plan2(c->hChr, c->vChr, p.chrDstW, p.chrDstH, 2, d->dotC, oC);
+                  const bool tiles = !gray_both && plan2(c->hLum, c->vLum, p.dstW, p.dstH, 1, d->dotL, oL) && plan2(c->hChr, c->vChr, p.chrDstW, p.chrDstH, 2, d->dotC, oC);
                   size_t ohl = 0, ohc = 0;
                   if (!tiles && strip_plan) {   // (the strip kernel shares the tile kernel's padded horizontal taps; without a tile plan it gets its own copy)
-                      const std::vector<int16_t> htl = padded(c->hLum), htc = padded(c->hChr);
+                      const std::vector<int16_t> htl = padded(c->hLum), htc = gray_both ? std::vector<int16_t>(2, 0) : padded(c->hChr);
                       ohl = put(htl.data(), htl.size() * 2); ohc = put(htc.data(), htc.size() * 2);
                   }
                   if (tiles || strip_plan) {
@@ -714,10 +729,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     if (strip_plan) {
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         d->stripL.colStart = (const int32_t *)(b + sL.cs); d->stripL.colCount = (const int32_t *)(b + sL.cc);
-                        d->stripC.colStart = (const int32_t *)(b + sC.cs); d->stripC.colCount = (const int32_t *)(b + sC.cc);
+                        if (!gray_both) { d->stripC.colStart = (const int32_t *)(b + sC.cs); d->stripC.colCount = (const int32_t *)(b + sC.cc); }
                         if (tiles) { d->stripL.hT2 = d->dotL.hT2; d->stripL.vT2 = d->dotL.vT2; d->stripC.hT2 = d->dotC.hT2; d->stripC.vT2 = d->dotC.vT2; }
                         else { d->stripL.hT2 = (const int16_t *)(b + ohl); d->stripC.hT2 = (const int16_t *)(b + ohc); d->stripL.vT2 = d->stripC.vT2 = nullptr; }
-                        d->stripL.rows = (const SwsStripRow *)(b + sL.rows); d->stripC.rows = (const SwsStripRow *)(b + sC.rows);
+                        d->stripL.rows = (const SwsStripRow *)(b + sL.rows); if (!gray_both) d->stripC.rows = (const SwsStripRow *)(b + sC.rows);
                         d->strip_ok = true;
                         d->rgbread_on = rgbread;
                     }
@@ -930,6 +945,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     }
     default: c->path_name = "none"; c->kernel_name = ""; break;
     }
+    if (c->plan == PLAN_MAIN && d->spare_i[3]) c->path_name = "main:split422+" + c->path_name.substr(c->path_name.find(':') + 1);
     if (c->plan == PLAN_MAIN && d->spare_i[0]) c->path_name += "+join422";
     // (16-byte aligned pictures of the layout converters take the streaming kernel, k_layout.hip; the names above are the fallback's)
     if (!c->tune.no_layout_stream && (c->plan == PLAN_UNSC_PLANAR2NV12 || c->plan == PLAN_UNSC_NV122PLANAR || c->plan == PLAN_UNSC_PLANARCOPY || c->plan == PLAN_UNSC_PLANAR2NV24 ||
@@ -1061,6 +1077,60 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         }
         frames = palfr.data();
     }
+    // frame tables of the helper passes around a packed 4:2:2 side (slot 0: the interleave behind the kernels, slot 1: the de-interleave ahead of
+    // them): one device block and one pinned host block of two tables, each cached like d_frames
+    auto aux_table = [&](int slot, const std::vector<SwsFramePtrs> &v, const SwsFramePtrs **out) -> int {
+        SwsFramePtrs *&dtab = reinterpret_cast<SwsFramePtrs *&>(d->spare_ptr[1]), *&htab = reinterpret_cast<SwsFramePtrs *&>(d->spare_ptr[2]);
+        int &cap = d->spare_i[1];
+        int *valid = &d->spare_i[4];   // [slot]
+        if (n > cap) {
+            if (dtab) HIPCHK(hipFree(dtab));
+            if (htab) HIPCHK(hipHostFree(htab));
+            dtab = nullptr; htab = nullptr; cap = 0; valid[0] = valid[1] = 0;
+            HIPCHK(hipMalloc((void **)&dtab, sizeof(SwsFramePtrs) * 2 * (size_t)n));
+            HIPCHK(hipHostMalloc((void **)&htab, sizeof(SwsFramePtrs) * 2 * (size_t)n, hipHostMallocDefault));
+            cap = n;
+        }
+        SwsFramePtrs *hd = htab + (size_t)slot * (size_t)cap, *dd2 = dtab + (size_t)slot * (size_t)cap;
+        if (!(valid[slot] == n && !std::memcmp(hd, v.data(), sizeof(SwsFramePtrs) * (size_t)n))) {
+            if (valid[slot]) HIPCHK(hipStreamSynchronize(st));   // a previous batch may still be reading the pinned table
+            std::memcpy(hd, v.data(), sizeof(SwsFramePtrs) * (size_t)n);
+            HIPCHK(hipMemcpyAsync(dd2, hd, sizeof(SwsFramePtrs) * (size_t)n, hipMemcpyHostToDevice, st));
+            valid[slot] = n;
+        }
+        *out = dd2;
+        return 0;
+    };
+    // packed 4:2:2 source through the planar kernels (dev_prepare_on): de-interleave into a planar 4:2:2 working picture per frame first
+    std::vector<SwsFramePtrs> s422fr, s422split;
+    bool timing_started = false;
+    if (c->plan == PLAN_MAIN && d->spare_i[3]) {
+        auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
+        const int sY = (int)a256(p.srcW), sC = (int)a256(p.srcW >> 1);
+        const int64_t offU = (int64_t)sY * p.srcH, offV = offU + (int64_t)sC * p.srcH, fbytes = a256(offV + (int64_t)sC * p.srcH);
+        int r = grow(c, &d->spare_ptr[3], &d->spare_sz[3], (size_t)fbytes * (size_t)n);
+        if (r < 0) return r;
+        s422fr.assign(frames, frames + n);
+        s422split.resize((size_t)n);
+        for (int i = 0; i < n; i++) {
+            uint8_t *base = (uint8_t *)d->spare_ptr[3] + (size_t)i * (size_t)fbytes;
+            SwsFramePtrs &a = s422fr[(size_t)i], &j = s422split[(size_t)i];
+            std::memset(&j, 0, sizeof(j));
+            j.src[0] = a.src[0]; j.srcStride[0] = a.srcStride[0];
+            j.dst[0] = base; j.dst[1] = base + offU; j.dst[2] = base + offV; j.dstStride[0] = sY; j.dstStride[1] = j.dstStride[2] = sC;
+            a.src[0] = base; a.src[1] = base + offU; a.src[2] = base + offV; a.src[3] = nullptr;
+            a.srcStride[0] = sY; a.srcStride[1] = a.srcStride[2] = sC; a.srcStride[3] = 0;
+        }
+        LaunchCtx S;
+        std::memset(&S.fs, 0, sizeof(S.fs));
+        S.c = c; S.d = d; S.p = &p; S.st = st; S.frames = s422split.data(); S.n = n; S.sliceY = sliceY; S.sliceH = sliceH; S.vec = true;
+        S.fs.count = n;
+        if (n == 1) { S.fs.table = nullptr; S.fs.one = s422split[0]; }
+        else { const SwsFramePtrs *t = nullptr; r = aux_table(1, s422split, &t); if (r < 0) return r; S.fs.table = t; }
+        if (d->timing) { HIPCHK(hipEventRecord(d->ev0, st)); timing_started = true; }
+        launch_layout_split422(S, (d->spare_i[3] & 3) == 2, (d->spare_i[3] & 4) != 0);
+        frames = s422fr.data();
+    }
     // packed 4:2:2 destination through planar writers (dev_prepare_on): the kernels write a planar 4:2:2 working picture per frame
     std::vector<SwsFramePtrs> p422fr, p422join;
     if (c->plan == PLAN_MAIN && d->spare_i[0]) {
@@ -1108,7 +1178,7 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
     }
     const bool vec = frames_vec_ok(frames, n);
     L.c = c; L.d = d; L.p = &p; L.st = st; L.frames = frames; L.n = n; L.sliceY = sliceY; L.sliceH = sliceH; L.vec = vec;
-    if (d->timing) { HIPCHK(hipEventRecord(d->ev0, st)); }
+    if (d->timing && !timing_started) { HIPCHK(hipEventRecord(d->ev0, st)); }
 
     // bgr24ToYv12Wrapper (:2062-2077), yvu9ToYv12Wrapper (:2079-2093), yuyv/uyvyToYuv420Wrapper (:423-470) with a yuva420p
     // destination: fillPlane(dst[3], ..., src_w, srcSliceH, srcSliceY, 255)
@@ -1153,27 +1223,7 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         J.fs.count = n;
         J.frames = p422join.data();
         if (n == 1) { J.fs.table = nullptr; J.fs.one = p422join[0]; }
-        else {
-            SwsFramePtrs *&dtab = reinterpret_cast<SwsFramePtrs *&>(d->spare_ptr[1]), *&htab = reinterpret_cast<SwsFramePtrs *&>(d->spare_ptr[2]);
-            int &cap = d->spare_i[1], &valid = d->spare_i[2];
-            const bool same = cap >= n && valid == n && !std::memcmp(htab, p422join.data(), sizeof(SwsFramePtrs) * (size_t)n);
-            if (!same) {
-                if (n > cap) {
-                    if (dtab) HIPCHK(hipFree(dtab));
-                    if (htab) HIPCHK(hipHostFree(htab));
-                    dtab = nullptr; htab = nullptr; cap = 0;
-                    HIPCHK(hipMalloc((void **)&dtab, sizeof(SwsFramePtrs) * (size_t)n));
-                    HIPCHK(hipHostMalloc((void **)&htab, sizeof(SwsFramePtrs) * (size_t)n, hipHostMallocDefault));
-                    cap = n;
-                } else {
-                    HIPCHK(hipStreamSynchronize(st));   // a previous batch may still be reading the pinned table
-                }
-                std::memcpy(htab, p422join.data(), sizeof(SwsFramePtrs) * (size_t)n);
-                HIPCHK(hipMemcpyAsync(dtab, htab, sizeof(SwsFramePtrs) * (size_t)n, hipMemcpyHostToDevice, st));
-                valid = n;
-            }
-            J.fs.table = dtab;
-        }
+        else { const SwsFramePtrs *t = nullptr; int r = aux_table(0, p422join, &t); if (r < 0) return r; J.fs.table = t; }
         launch_layout_join422(J, d->spare_i[0] == 2);
     }
     HIPCHK(hipGetLastError());

@@ -91,6 +91,22 @@ int launch_layout(const LaunchCtx &L)
     return 1;
 }
 
+// The de-interleaving pass ahead of the kernels for a packed 4:2:2 SOURCE of the scaler (device.hip; L.fs holds {src = the packed picture, dst = the
+// planes of the working picture}): yuyvtoyuv422_c / uyvytoyuv422_c over the whole source picture.
+void launch_layout_split422(const LaunchCtx &L, bool uyvy, bool vfirst)
+{
+    const SwsDevParams &p = *L.p;
+    using namespace swsk;
+    LayoutPlan plan;
+    std::memset(&plan, 0, sizeof(plan));
+    LayoutJob &j = plan.job[0];
+    plan.njobs = 1;
+    const int w = p.srcW, cw = (w + 1) >> 1;
+    j.op = LOP_P422_SPLIT; j.rows = p.srcH; j.ys = 0; j.yd = 0; j.sa = j.sb = 0; j.da = 0; j.db = 1;
+    j.n = 4 * cw; j.a0 = uyvy ? 1 : 0; j.a1 = vfirst ? 1 : 0; j.a2 = w;
+    hipLaunchKernelGGL((sws_k_layout_stream<4>), dim3(cdiv(cdiv(j.n, 16), 256), cdiv(j.rows, LAYOUT_RPW), L.n), dim3(256), 0, L.st, L.fs, p, plan);
+}
+
 // The interleaving pass behind a packed 4:2:2 destination of the scaler (device.hip: the planar writers filled a yuv422p working picture per
 // frame; L.fs holds {src = its planes, dst = the packed picture}): yuvPlanartoyuy2_c / yuvPlanartouyvy_c with one chroma row per luma row.
 void launch_layout_join422(const LaunchCtx &L, bool uyvy)

@@ -54,7 +54,7 @@ int launch_strip_planes(const LaunchCtx &L, int which)
     return 0;
 }
 
-int launch_strip(const LaunchCtx &L) { return launch_strip_planes(L, 3); }
+int launch_strip(const LaunchCtx &L) { return launch_strip_planes(L, L.p->no_chroma ? 1 : 3); }   // (gray -> gray: the luma launch alone)
 
 // Same-size planar YUV -> planar / semi-planar YUV whose luma filters are the identity in both directions and whose chroma is scaled
 // (yuv422p -> yuv420p, yuv444p -> yuv420p / nv12, 10-bit -> 8-bit twins ...): the luma plane is a streaming per-sample pass (the scaler's own

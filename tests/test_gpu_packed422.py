@@ -67,3 +67,51 @@ def test_full_size_batches_and_host_frames():
                 out = dsts[k].download()
                 for a, b, rb in zip(out.planes, refs[k].planes, out.row_bytes):
                     assert np.array_equal(a[:, :rb], b[:, :rb]), (src, dst, k, rep)
+
+
+PSRC = ["yuyv422", "uyvy422", "yvyu422"]
+
+
+@pytest.mark.parametrize("src", PSRC)
+@pytest.mark.parametrize("dst", ["yuv420p", "yuv422p", "nv12", "yuv420p10le", "rgb24", "bgra", "yuyv422", "uyvy422", "yuv444p"])
+def test_packed_sources(src, dst):
+    """packed 4:2:2 sources of the scaler: the streaming de-interleave into a planar working picture, then the kernels of a planar 8-bit
+    source ("main:split422+...")"""
+    for (sw, sh, dw, dh, fl) in ((256, 64, 192, 48, SWS_BICUBIC), (320, 50, 512, 80, SWS_BICUBIC), (132, 34, 66, 17, SWS_AREA), (256, 64, 320, 96, SWS_BILINEAR),
+                                 (256, 64, 250, 64, SWS_LANCZOS), (130, 30, 131, 31, SWS_BICUBIC), (256, 64, 128, 32, SWS_FAST_BILINEAR), (256, 64, 128, 32, SWS_POINT)):
+        for tune in (None, TUNE):
+            r = run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh, tune=tune)
+            assert r[0].startswith("main:split422+"), (r[0], src, dst, sw, dw)
+    assert not run_case(255, 64, src, 128, 32, dst, SWS_BICUBIC | BX)[0].startswith("main:split422+")      # odd source width: the readers keep it
+
+
+def test_packed_sources_full_size_and_batches():
+    import torch
+    import oracle_lib as OL
+    from librempeg_amd import SwsContext, HostFrame, DeviceFrame
+    assert run_case(1920, 1080, "yuyv422", 1280, 720, "yuv420p", SWS_BICUBIC | BX, seed=2)[0] == "main:split422+strip_march"
+    assert run_case(1920, 1080, "uyvy422", 1280, 720, "nv12", SWS_BILINEAR | BX, seed=3, device_frames=False)[0] == "main:split422+strip_march"
+    assert run_case(1920, 1080, "yuyv422", 1280, 720, "rgb24", SWS_BICUBIC | BX, seed=4)[0] == "main:split422+strip_rgb"
+    for src, dst, sw, sh, dw, dh, n, flags in (("yuyv422", "yuv420p", 1284, 70, 1028, 56, 5, SWS_BICUBIC | BX), ("uyvy422", "yuyv422", 1024, 64, 1280, 80, 3, SWS_BICUBIC | BX)):
+        o = OL.Oracle(sw, sh, src, dw, dh, dst, flags)
+        p = SwsContext(sw, sh, src, dw, dh, dst, flags)
+        refs, srcs, dsts = [], [], []
+        for k in range(n):
+            s = OL.fill_random(OL.Frame(src, sw, sh), 80 + k)
+            ref = OL.Frame(dst, dw, dh)
+            assert o.scale(s, ref) == dh
+            refs.append(ref)
+            hs = HostFrame(src, sw, sh)
+            for a, b in zip(hs.planes, s.planes):
+                a[:] = b
+            srcs.append(DeviceFrame(src, sw, sh).upload(hs))
+            dsts.append(DeviceFrame(dst, dw, dh))
+        torch.cuda.synchronize()
+        for rep in range(2):
+            assert p.scale_frames(srcs, dsts) == n
+            p.sync()
+            assert p.path().startswith("main:split422+"), p.path()
+            for k in range(n):
+                out = dsts[k].download()
+                for a, b, rb in zip(out.planes, refs[k].planes, out.row_bytes):
+                    assert np.array_equal(a[:, :rb], b[:, :rb]), (src, dst, k, rep)

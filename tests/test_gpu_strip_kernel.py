@@ -78,3 +78,15 @@ def test_long_vertical_chroma_filters(flags):
     # full size: 4K capture into a 1080p 4:2:0 picture
     assert run_case(3840, 2160, "bgra", 1920, 1080, "yuv420p", SWS_BICUBIC | BX, seed=5)[0] == "main:rgbread+strip_march"
     assert run_case(3840, 2160, "yuv422p10le", 1920, 1080, "yuv420p", SWS_BICUBIC | BX, seed=6)[0] == "main:strip_march"
+
+
+@pytest.mark.parametrize("sfmt", ["gray8", "gray10le", "gray12le", "gray14le"])
+@pytest.mark.parametrize("dfmt", ["gray8", "gray9le", "gray10le", "gray12le"])
+def test_gray_to_gray_takes_the_luma_launch(sfmt, dfmt):
+    """one plane: the strip kernel's luma launch alone (gray -> gray, 8 .. 14 bit; gray16 keeps the 19-bit generic path)"""
+    for (sw, sh, dw, dh, fl) in ((640, 96, 320, 48, SWS_BICUBIC), (322, 130, 200, 74, SWS_LANCZOS), (320, 48, 640, 96, SWS_BILINEAR), (1922, 50, 1280, 34, SWS_BICUBIC | SWS_ACCURATE_RND)):
+        path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=sw, tune=STRIP)
+        assert path == "main:strip_march", (path, sfmt, dfmt, sw, dw)
+    assert run_case(1920, 1080, sfmt, 1280, 720, dfmt, SWS_BICUBIC | BX, seed=9)[0] == "main:strip_march"
+    run_case(640, 96, sfmt, 320, 48, "gray16le", SWS_BICUBIC | BX, seed=3, tune=STRIP)
+    run_case(640, 96, "gray16le", 320, 48, dfmt, SWS_BICUBIC | BX, seed=3, tune=STRIP)
