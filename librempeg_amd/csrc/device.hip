@@ -529,8 +529,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             const bool rgb_ok = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr && p.srcKind == SRCK_PLANAR8 && c->srcBpc == 8 &&
                                 !p.no_chroma && !p.need_alpha && !(p.dstW & 1) && !p.range_active && !c->tune.no_strip;
             d->striprgb_ok = false;
-            // (planar writers: a one-tap vertical filter takes the reference's yuv2plane1 form, not the "X" arithmetic of these kernels;
-            //  the packed writers are in "X" mode unless both vertical filters are short, which all_x_mode checks row by row)
+            // (planar writers: a one-tap vertical filter takes the reference's yuv2plane1 form -- (s + d) >> 7, (s + (1 << (14 - bits))) >> (15 - bits),
+            //  output.c:327-341, :485-493 -- which is the "X" arithmetic of these kernels with the one tap 4096: (4096 s + (d << 12)) >> 19, sample for
+            //  sample; the strip kernel takes such planes (4:2:0 -> 4:2:2 at half the size, horizontal-only scaling), the dot2 tile kernel keeps its
+            //  two-tap minimum.  The packed writers are in "X" mode unless both vertical filters are short, which all_x_mode checks row by row)
             // scaled packed 24 / 32 bpp RGB sources: a reader pre-pass writes the 16-bit planes the horizontal scaler
             // reads, the strip kernel takes them like a planar 16-bit source (launch_rgbread_strip); other shapes of these sources keep the tile kernel
             bool rgbread = (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32) && p.chrSrcW == (p.chr_half ? p.srcW >> 1 : p.srcW) && !(p.srcW & 3) && p.chrSrcVSub == 0 && !p.range_active && !p.need_alpha &&
@@ -542,15 +544,14 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             const bool vchr_long = fs2(c->vChr.size) > 16 && fs2(c->vChr.size) <= 24 && dst_ok && !rgb_ok && !c->tune.no_strip;
             // gray -> gray (8 .. 14 bit): one plane, the strip kernel's luma launch alone
             const bool gray_both = isGray(o.src_format) && isGray(o.dst_format) && !c->needAlpha && src_ok && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && !c->tune.no_strip;
-            const bool fullA = !d->unity_h && !p.fast_bilinear && (!gray_any || gray_both) && (src_ok || (nv_src && dst_ok) || rgbread) &&
-                               ((dst_ok && c->vLum.size >= 2 && (c->vChr.size >= 2 || gray_both)) || rgb_ok) && !p.wide &&
-                               fs2(c->hLum.size) <= 16 && (fs2(c->hChr.size) <= 16 || gray_both) && fs2(c->vLum.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long || gray_both) && !c->tune.no_dot2;
             // identity luma filters + scaled chroma (yuv422p -> yuv420p, yuv444p -> yuv420p, the 10-bit -> 8-bit twins ...): the luma plane streams
-            // (one tap: a per-sample pass), only the chroma planes need the strip kernel.  (The planar writers' one-tap form is what keeps these
-            // shapes off the full strip / dot2 plans above.)
-            const bool mixedM = !fullA && !vlines_pending && bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !(d->unity_h && d->unity_v) &&
-                                !p.fast_bilinear && !gray_any && (src_ok || nv_src) && dst_ok && c->vChr.size >= 2 && !p.wide && !p.range_active && !p.dst_alpha_fill &&
+            // (one tap: a per-sample pass), only the chroma planes need the strip kernel
+            const bool mixedM = !vlines_pending && bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !(d->unity_h && d->unity_v) &&
+                                !p.fast_bilinear && !gray_any && (src_ok || nv_src) && dst_ok && !p.wide && !p.range_active && !p.dst_alpha_fill &&
                                 fs2(c->hChr.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long) && !c->tune.no_strip && !c->tune.no_mixed && p.dstW >= c->tune.strip_min_w;
+            const bool fullA = !mixedM && !d->unity_h && !p.fast_bilinear && (!gray_any || gray_both) && (src_ok || (nv_src && dst_ok) || rgbread) &&
+                               (dst_ok || rgb_ok) && !p.wide &&
+                               fs2(c->hLum.size) <= 16 && (fs2(c->hChr.size) <= 16 || gray_both) && fs2(c->vLum.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long || gray_both) && !c->tune.no_dot2;
             d->mixed_ok = false;
             if (fullA || mixedM) {
                 const int SPC = (p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010 || rgbread) ? 8 : 16;
@@ -725,7 +726,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         g.hT2 = (const int16_t *)(b + o.ht); g.vT2 = (const int16_t *)(b + o.vt);
                     };
                     if (tiles) { bind(d->dotL, oL); bind(d->dotC, oC); }
-                    d->dot2_ok = tiles && src_ok && fs2(c->vChr.size) <= 16;
+                    d->dot2_ok = tiles && src_ok && fs2(c->vChr.size) <= 16 && c->vLum.size >= 2 && c->vChr.size >= 2;
                     if (strip_plan) {
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         d->stripL.colStart = (const int32_t *)(b + sL.cs); d->stripL.colCount = (const int32_t *)(b + sL.cc);

@@ -49,7 +49,7 @@ def test_planner_and_fallbacks():
 def test_full_size_frames_and_host_frames():
     assert run_case(1920, 1080, "rgb24", 1280, 720, "yuv420p", SWS_BICUBIC | BX, seed=2)[0] == PATH
     assert run_case(1920, 1080, "bgra", 2560, 1440, "nv12", SWS_BILINEAR | BX, seed=3)[0] == PATH                                  # (chroma wider than half the source: full-width readers)
-    assert run_case(1920, 1080, "bgra", 3840, 2160, "nv12", SWS_BILINEAR | BX, seed=3)[0] != PATH                                  # (2x: the chroma planes are not scaled at all, one-tap writers)
+    assert run_case(1920, 1080, "bgra", 3840, 2160, "nv12", SWS_BILINEAR | BX, seed=3)[0] == PATH                                  # (2x: the chroma planes are not scaled at all: one-tap filters)
     assert run_case(2560, 1440, "rgb24", 1920, 1080, "yuv420p10le", SWS_LANCZOS | BX, seed=4, device_frames=False)[0] == PATH
 
 

@@ -90,3 +90,16 @@ def test_gray_to_gray_takes_the_luma_launch(sfmt, dfmt):
     assert run_case(1920, 1080, sfmt, 1280, 720, dfmt, SWS_BICUBIC | BX, seed=9)[0] == "main:strip_march"
     run_case(640, 96, sfmt, 320, 48, "gray16le", SWS_BICUBIC | BX, seed=3, tune=STRIP)
     run_case(640, 96, "gray16le", 320, 48, dfmt, SWS_BICUBIC | BX, seed=3, tune=STRIP)
+
+
+def test_one_tap_vertical_filters():
+    """a plane whose vertical filter is the identity next to scaled ones: yuv2plane1's (s + d) >> 7 is the X form with the one tap 4096
+    (4:2:0 -> 4:2:2 at half the height: chroma rows unscaled; horizontal-only scaling: both planes)"""
+    for sfmt, dfmt in (("yuv420p", "yuv422p"), ("yuv420p10le", "yuv422p10le"), ("yuv420p10le", "yuv422p"), ("nv12", "nv16"), ("yuv420p", "yuv422p12le")):
+        for (sw, sh, dw, dh, fl) in ((640, 96, 320, 48, SWS_BICUBIC), (1288, 96, 644, 48, SWS_LANCZOS), (640, 96, 400, 48, SWS_BILINEAR)):
+            assert run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=sw, tune=STRIP)[0] == "main:strip_march", (sfmt, dfmt, sw, dw)
+    for sfmt, dfmt in (("yuv420p", "yuv420p"), ("yuv422p10le", "yuv422p"), ("yuv444p", "yuv444p12le"), ("nv12", "yuv420p"), ("gray8", "gray8")):
+        for (sw, sh, dw, dh, fl) in ((1440, 64, 1920, 64, SWS_BICUBIC), (640, 50, 320, 50, SWS_BICUBIC), (322, 33, 200, 33, SWS_LANCZOS)):
+            assert run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=dw, tune=STRIP)[0] == "main:strip_march", (sfmt, dfmt, sw, dw)
+    assert run_case(3840, 2160, "yuv420p", 1920, 1080, "uyvy422", SWS_BICUBIC | BX, seed=5)[0] == "main:strip_march+join422"
+    assert run_case(1440, 1080, "yuv420p", 1920, 1080, "yuv420p", SWS_BICUBIC | BX, seed=6)[0] == "main:strip_march"

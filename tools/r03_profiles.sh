@@ -1,0 +1,21 @@
+#!/bin/bash
+# round-3 profile set: rocprofv3 kernel stats of every bench workload + the bench lines, PMC HBM traffic, layout / common-shape / conversion
+# tables and the kernel stats of the common-shape run.  usage: tools/r03_profiles.sh  -> gpurun_out/r03p/
+set -u
+OUT=$PWD/gpurun_out/r03p; mkdir -p $OUT
+export TMPDIR=/tmp
+ROOT=$PWD
+tools/profile_all.sh r03p > $OUT/bench_lines.jsonl 2>$OUT/profile_all.err
+tools/pmc_traffic.sh r03p "c2a c2b c4 c3a c3b c5 c1 d1" > $OUT/pmc_traffic.txt 2>&1
+python tools/layout_times.py > $OUT/layout.md 2>$OUT/layout.err
+python tools/common_shapes_times.py > $OUT/common.md 2>$OUT/common.err
+python tools/common_conversions_times.py > $OUT/conv.txt 2>$OUT/conv.err
+python tools/aux_kernel_times.py > $OUT/aux.txt 2>$OUT/aux.err
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_common -o res -- python $ROOT/tools/common_shapes_times.py > $OUT/prof_common.log 2>&1)
+db=$(find $OUT/prof_common -name "*.db" | head -1)
+[ -n "$db" ] && python tools/rocpd_summary.py "$db" "r03 common shapes: rocprofv3 --kernel-trace --stats -- python tools/common_shapes_times.py" > $OUT/kernel_stats_common_shapes.md
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_layout -o res -- python $ROOT/tools/layout_times.py > $OUT/prof_layout.log 2>&1)
+db=$(find $OUT/prof_layout -name "*.db" | head -1)
+[ -n "$db" ] && python tools/rocpd_summary.py "$db" "r03 layout converters (4K): rocprofv3 --kernel-trace --stats -- python tools/layout_times.py" > $OUT/kernel_stats_layout.md
+rm -rf $OUT/prof_common $OUT/prof_layout $OUT/traffic_*_FETCH_SIZE $OUT/traffic_*_WRITE_SIZE
+ls $OUT | head -60
