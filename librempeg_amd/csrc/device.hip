@@ -18,6 +18,7 @@
 
 namespace swship {
 void launch_layout_split422(const LaunchCtx &L, bool uyvy, bool vfirst);   // k_layout.hip: yuyv422 / uyvy422 / yvyu422 -> planar 4:2:2 working picture
+void launch_layout_splitnv(const LaunchCtx &L, bool vfirst);   // k_layout.hip: plane 1 of a semi-planar 8-bit picture -> planar U / V working planes
 void launch_layout_join422(const LaunchCtx &L, bool uyvy);   // k_layout.hip: planar 4:2:2 working picture -> yuyv422 / uyvy422 (yvyu422: planes swapped by the planner)
 
 static int ensure_dev(SwsInternal *c)
@@ -266,6 +267,16 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         p.srcKind = SRCK_PLANAR8;
         p.u_plane_src = 1; p.v_plane_src = 2;
         d->spare_i[3] = (ds->comp[0].offset == 1 ? 2 : 1) | (ds->comp[2].offset < ds->comp[1].offset ? 4 : 0);   // 1 yuyv-like, 2 uyvy; 4: V before U (yvyu422)
+    }
+    // ---- semi-planar 8-bit sources (nv12 / nv21 / nv16 / nv24 / nv42: what the hardware decoders deliver) scaled into the packed-RGB LUT writers:
+    //      nvXXtoUV_c (input.c:926-948) de-interleaves bytes, so the chroma plane is split into planar working planes first and the conversion takes the
+    //      strip kernel with the RGB epilogue like a planar source (planar / semi-planar destinations: the strip kernel de-interleaves while staging) ----
+    if (c->plan == PLAN_MAIN && p.srcKind == SRCK_NV12 && c->srcBpc == 8 && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !((o.flags & SWS_FULL_CHR_H_INT)) &&
+        !(bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14)) && !gray_any && !(o.flags & SWS_SRC_V_CHR_DROP_MASK) && !(o.flags & SWS_FAST_BILINEAR) &&
+        !c->tune.no_mixed && !c->tune.no_layout_stream && !c->tune.no_strip) {
+        d->spare_i[3] = 8 | (p.uv_swap_src ? 16 : 0);
+        p.srcKind = SRCK_PLANAR8;
+        p.u_plane_src = 1; p.v_plane_src = 2; p.uv_swap_src = 0;
     }
     d->spare_i[0] = 0;
     if (c->plan == PLAN_MAIN && p.dstKind == DSTK_PACKED422 && dd->comp[0].depth == 8 && !(o.dst_w & 1) && !p.should_dither && !c->needAlpha && !gray_any &&
@@ -946,7 +957,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     }
     default: c->path_name = "none"; c->kernel_name = ""; break;
     }
-    if (c->plan == PLAN_MAIN && d->spare_i[3]) c->path_name = "main:split422+" + c->path_name.substr(c->path_name.find(':') + 1);
+    if (c->plan == PLAN_MAIN && d->spare_i[3]) c->path_name = ((d->spare_i[3] & 8) ? "main:splitnv+" : "main:split422+") + c->path_name.substr(c->path_name.find(':') + 1);
     if (c->plan == PLAN_MAIN && d->spare_i[0]) c->path_name += "+join422";
     // (16-byte aligned pictures of the layout converters take the streaming kernel, k_layout.hip; the names above are the fallback's)
     if (!c->tune.no_layout_stream && (c->plan == PLAN_UNSC_PLANAR2NV12 || c->plan == PLAN_UNSC_NV122PLANAR || c->plan == PLAN_UNSC_PLANARCOPY || c->plan == PLAN_UNSC_PLANAR2NV24 ||
@@ -1107,8 +1118,9 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
     bool timing_started = false;
     if (c->plan == PLAN_MAIN && d->spare_i[3]) {
         auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
-        const int sY = (int)a256(p.srcW), sC = (int)a256(p.srcW >> 1);
-        const int64_t offU = (int64_t)sY * p.srcH, offV = offU + (int64_t)sC * p.srcH, fbytes = a256(offV + (int64_t)sC * p.srcH);
+        const bool nv = (d->spare_i[3] & 8) != 0;    // semi-planar source: only the chroma plane is split, the luma plane stays where it is
+        const int sY = nv ? 0 : (int)a256(p.srcW), sC = (int)a256(nv ? p.chrSrcW : p.srcW >> 1), crows = nv ? p.chrSrcH : p.srcH;
+        const int64_t offU = (int64_t)sY * p.srcH, offV = offU + (int64_t)sC * crows, fbytes = a256(offV + (int64_t)sC * crows);
         int r = grow(c, &d->spare_ptr[3], &d->spare_sz[3], (size_t)fbytes * (size_t)n);
         if (r < 0) return r;
         s422fr.assign(frames, frames + n);
@@ -1117,10 +1129,11 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
             uint8_t *base = (uint8_t *)d->spare_ptr[3] + (size_t)i * (size_t)fbytes;
             SwsFramePtrs &a = s422fr[(size_t)i], &j = s422split[(size_t)i];
             std::memset(&j, 0, sizeof(j));
-            j.src[0] = a.src[0]; j.srcStride[0] = a.srcStride[0];
-            j.dst[0] = base; j.dst[1] = base + offU; j.dst[2] = base + offV; j.dstStride[0] = sY; j.dstStride[1] = j.dstStride[2] = sC;
-            a.src[0] = base; a.src[1] = base + offU; a.src[2] = base + offV; a.src[3] = nullptr;
-            a.srcStride[0] = sY; a.srcStride[1] = a.srcStride[2] = sC; a.srcStride[3] = 0;
+            if (nv) { j.src[1] = a.src[1]; j.srcStride[1] = a.srcStride[1]; }
+            else { j.src[0] = a.src[0]; j.srcStride[0] = a.srcStride[0]; j.dst[0] = base; j.dstStride[0] = sY; a.src[0] = base; a.srcStride[0] = sY; }
+            j.dst[1] = base + offU; j.dst[2] = base + offV; j.dstStride[1] = j.dstStride[2] = sC;
+            a.src[1] = base + offU; a.src[2] = base + offV; a.src[3] = nullptr;
+            a.srcStride[1] = a.srcStride[2] = sC; a.srcStride[3] = 0;
         }
         LaunchCtx S;
         std::memset(&S.fs, 0, sizeof(S.fs));
@@ -1129,7 +1142,8 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         if (n == 1) { S.fs.table = nullptr; S.fs.one = s422split[0]; }
         else { const SwsFramePtrs *t = nullptr; r = aux_table(1, s422split, &t); if (r < 0) return r; S.fs.table = t; }
         if (d->timing) { HIPCHK(hipEventRecord(d->ev0, st)); timing_started = true; }
-        launch_layout_split422(S, (d->spare_i[3] & 3) == 2, (d->spare_i[3] & 4) != 0);
+        if (nv) launch_layout_splitnv(S, (d->spare_i[3] & 16) != 0);
+        else launch_layout_split422(S, (d->spare_i[3] & 3) == 2, (d->spare_i[3] & 4) != 0);
         frames = s422fr.data();
     }
     // packed 4:2:2 destination through planar writers (dev_prepare_on): the kernels write a planar 4:2:2 working picture per frame

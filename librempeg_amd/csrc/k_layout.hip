@@ -107,6 +107,22 @@ void launch_layout_split422(const LaunchCtx &L, bool uyvy, bool vfirst)
     hipLaunchKernelGGL((sws_k_layout_stream<4>), dim3(cdiv(cdiv(j.n, 16), 256), cdiv(j.rows, LAYOUT_RPW), L.n), dim3(256), 0, L.st, L.fs, p, plan);
 }
 
+// The chroma plane of a semi-planar 8-bit source of the scaler, split into planar working planes (device.hip; L.fs holds {src[1] = the interleaved
+// plane, dst[1] / dst[2] = the U / V planes}): nvXXtoUV_c over the whole plane (vfirst: nv21 / nv42).
+void launch_layout_splitnv(const LaunchCtx &L, bool vfirst)
+{
+    const SwsDevParams &p = *L.p;
+    using namespace swsk;
+    LayoutPlan plan;
+    std::memset(&plan, 0, sizeof(plan));
+    LayoutJob &j = plan.job[0];
+    plan.njobs = 1;
+    const int a = vfirst ? 2 : 1;
+    j.op = LOP_DIL; j.rows = p.chrSrcH; j.ys = 0; j.yd = 0; j.sa = j.sb = 1; j.da = a; j.db = 3 - a;
+    j.n = 2 * p.chrSrcW;
+    hipLaunchKernelGGL((sws_k_layout_stream<4>), dim3(cdiv(cdiv(j.n, 16), 256), cdiv(j.rows, LAYOUT_RPW), L.n), dim3(256), 0, L.st, L.fs, p, plan);
+}
+
 // The interleaving pass behind a packed 4:2:2 destination of the scaler (device.hip: the planar writers filled a yuv422p working picture per
 // frame; L.fs holds {src = its planes, dst = the packed picture}): yuvPlanartoyuy2_c / yuvPlanartouyvy_c with one chroma row per luma row.
 void launch_layout_join422(const LaunchCtx &L, bool uyvy)

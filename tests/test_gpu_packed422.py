@@ -115,3 +115,24 @@ def test_packed_sources_full_size_and_batches():
                 out = dsts[k].download()
                 for a, b, rb in zip(out.planes, refs[k].planes, out.row_bytes):
                     assert np.array_equal(a[:, :rb], b[:, :rb]), (src, dst, k, rep)
+
+
+@pytest.mark.parametrize("src", ["nv12", "nv21", "nv16", "nv24", "nv42"])
+@pytest.mark.parametrize("dst", ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0"])
+def test_semi_planar_sources_into_rgb(src, dst):
+    """decoder output scaled for display: the interleaved chroma plane is split into planar working planes (nvXXtoUV_c copies bytes), then the
+    strip kernel with the RGB epilogue as for a planar source ("main:splitnv+strip_rgb")"""
+    for (sw, sh, dw, dh, fl) in ((256, 64, 192, 48, SWS_BICUBIC), (320, 50, 512, 80, SWS_BICUBIC), (132, 34, 66, 18, SWS_AREA), (256, 64, 320, 96, SWS_BILINEAR),
+                                 (256, 64, 250, 64, SWS_LANCZOS), (130, 30, 131, 31, SWS_BICUBIC), (131, 31, 200, 40, SWS_BICUBIC | SWS_ACCURATE_RND)):
+        r = run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh)
+        # (an odd destination width and a 4:4:4 source force the full-chroma writers, utils.c:1330-1349: not the LUT writers this path is for)
+        if not dw & 1 and src not in ("nv24", "nv42"):
+            assert r[0].startswith("main:splitnv+"), (r[0], src, dst, sw, dw)
+    if src not in ("nv24", "nv42"):
+        assert run_case(1920, 1080, src, 1280, 720, dst, SWS_BICUBIC | BX, seed=7)[0] == "main:splitnv+strip_rgb"
+    assert not run_case(256, 64, src, 256, 64, dst, SWS_BICUBIC | BX, seed=8)[0].startswith("main:splitnv+")      # same size: sws_k_rgb_march reads nv12 itself
+
+
+def test_nv12_to_rgb_full_size_is_the_strip_kernel():
+    assert run_case(3840, 2160, "nv12", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=2)[0] == "main:splitnv+strip_rgb"
+    assert run_case(1920, 1080, "nv12", 1280, 720, "rgb24", SWS_BILINEAR | BX, seed=3, device_frames=False)[0] == "main:splitnv+strip_rgb"
