@@ -537,7 +537,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             const bool dst_ok = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010;
             auto fs2 = [](int fs) { return (fs + 2) & ~1; };
             // packed 24 / 32 bpp RGB through the LUT writers (not the full-chroma ones): the strip kernel with the RGB epilogue
-            const bool rgb_ok = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr && p.srcKind == SRCK_PLANAR8 && c->srcBpc == 8 &&
+            // (9 .. 15-bit planar sources too -- decoded HDR pictures for display: 128-column strips, a window of at most 64 eight-sample chunks)
+            const bool rgb_s16 = p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15 && p.src_shift == 0;
+            const bool rgb_ok = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr && ((p.srcKind == SRCK_PLANAR8 && c->srcBpc == 8) || rgb_s16) &&
                                 !p.no_chroma && !p.need_alpha && !(p.dstW & 1) && !p.range_active && !c->tune.no_strip;
             d->striprgb_ok = false;
             // (planar writers: a one-tap vertical filter takes the reference's yuv2plane1 form -- (s + d) >> 7, (s + (1 << (14 - bits))) >> (15 - bits),
@@ -546,7 +548,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             //  two-tap minimum.  The packed writers are in "X" mode unless both vertical filters are short, which all_x_mode checks row by row)
             // scaled packed 24 / 32 bpp RGB sources: a reader pre-pass writes the 16-bit planes the horizontal scaler
             // reads, the strip kernel takes them like a planar 16-bit source (launch_rgbread_strip); other shapes of these sources keep the tile kernel
-            bool rgbread = (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32) && p.chrSrcW == (p.chr_half ? p.srcW >> 1 : p.srcW) && !(p.srcW & 3) && p.chrSrcVSub == 0 && !p.range_active && !p.need_alpha &&
+            bool rgbread = (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chrSrcW == (p.chr_half ? p.srcW >> 1 : p.srcW) && !(p.srcW & 3) && p.chrSrcVSub == 0 && !p.range_active && !p.need_alpha &&
                            !p.dst_alpha_fill && !p.no_chroma && !vlines_pending && dst_ok && !c->tune.no_strip && !c->tune.no_rgbsrc && p.dstW >= c->tune.strip_min_w;
             for (int k = 0; k < 9 && rgbread; k++) rgbread = p.rgb2yuv[k] > -32768 && p.rgb2yuv[k] < 32768;   // (v_dot2_i32_i16 operands)
             d->rgbread_on = false;
@@ -691,12 +693,12 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     SwsStripGeom &gl = d->stripRL, &gc = d->stripRC;
                     auto ringL = [](int npv) { return npv <= 5 ? 5 : npv <= 8 ? 8 : -1; };
                     auto ringC = [](int npv) { return npv <= 1 ? 1 : npv <= 3 ? 3 : npv <= 8 ? 8 : -1; };
-                    const int rcl = c->tune.strip_rgb_cols == 2 ? 2 : 4;
+                    const int rcl = (c->tune.strip_rgb_cols == 2 || rgb_s16) ? 2 : 4;
                     const bool pl = plan3(c->hLum, c->vLum, p.dstW, rcl, 1, gl, rL, ringL), pc = pl && plan3(c->hChr, c->vChr, p.chrDstW, rcl / 2, 2, gc, rC, ringC);
                     log_msg(c, 3, "strip_rgb plan: luma %d chroma %d strips %d/%d window %d/%d nph %d/%d npv %d/%d chrDstH %d dstH %d\n", pl, pc, gl.strips, gc.strips,
                             gl.NCmax, gc.NCmax, gl.nph, gc.nph, gl.npv, gc.npv, p.chrDstH, p.dstH);
                     if (pl && pc && gl.strips == gc.strips &&
-                        gl.NCmax / 16 <= 64 && gc.NCmax / 16 <= 64 && std::max(gl.nph, gc.nph) <= 8 && gl.npv <= 8 && gc.npv <= 8 && p.chrDstH == p.dstH) {
+                        gl.NCmax / SPC <= 64 && gc.NCmax / SPC <= 64 && std::max(gl.nph, gc.nph) <= 8 && gl.npv <= 8 && gc.npv <= 8 && p.chrDstH == p.dstH) {
                         const std::vector<int16_t> htl = padded(c->hLum), htc = padded(c->hChr);
                         const size_t ohl = put(htl.data(), htl.size() * 2), ohc = put(htc.data(), htc.size() * 2);
                         if (blob.size() > d->dot2_bytes) {

@@ -77,10 +77,12 @@ void launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, i
     lay.base = base; lay.frame_bytes = frame_bytes; lay.offU = offU; lay.offV = offV; lay.strideY = strideY; lay.strideC = strideC;
     const dim3 grid(cdiv(cdiv(p.srcW, 4), 256), cdiv(p.srcH, swsk::RGBREAD_RPW), L.n), blk(256);
     if (p.chr_half) {
-        if (p.srcKind == SRCK_RGB24) hipLaunchKernelGGL((swsk::sws_k_rgb_read16<3, true>), grid, blk, 0, L.st, L.fs, p, lay);
+        if (p.srcKind == SRCK_GBRP) hipLaunchKernelGGL((swsk::sws_k_rgb_read16<0, true>), grid, blk, 0, L.st, L.fs, p, lay);
+        else if (p.srcKind == SRCK_RGB24) hipLaunchKernelGGL((swsk::sws_k_rgb_read16<3, true>), grid, blk, 0, L.st, L.fs, p, lay);
         else hipLaunchKernelGGL((swsk::sws_k_rgb_read16<4, true>), grid, blk, 0, L.st, L.fs, p, lay);
     } else {
-        if (p.srcKind == SRCK_RGB24) hipLaunchKernelGGL((swsk::sws_k_rgb_read16<3, false>), grid, blk, 0, L.st, L.fs, p, lay);
+        if (p.srcKind == SRCK_GBRP) hipLaunchKernelGGL((swsk::sws_k_rgb_read16<0, false>), grid, blk, 0, L.st, L.fs, p, lay);
+        else if (p.srcKind == SRCK_RGB24) hipLaunchKernelGGL((swsk::sws_k_rgb_read16<3, false>), grid, blk, 0, L.st, L.fs, p, lay);
         else hipLaunchKernelGGL((swsk::sws_k_rgb_read16<4, false>), grid, blk, 0, L.st, L.fs, p, lay);
     }
 }

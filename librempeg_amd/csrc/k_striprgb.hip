@@ -41,10 +41,13 @@ int SRGB_CAT(launch_striprgb_b, SRGB_BPP, SRGB_RL)(const LaunchCtx &L)
     gl.bands = (H + gl.band_rows - 1) / gl.band_rows;
     gl.debug = gc.debug = c->tune.debug;
     const int cl = gl.TW / 64;
-    const int wave_dw = 2 * ((gl.NCmax + 16) >> 1) + 4 * ((gc.NCmax + 16) >> 1) + 32 * cl;   // luma rows, chroma rows, exchange row
+    const bool s16 = p.srcKind == SRCK_PLANAR16;      // 9 .. 15-bit planar sources: eight samples per 16-byte chunk, staged as they are
+    const int spc = s16 ? 8 : 16;
+    const int wave_dw = 2 * ((gl.NCmax + spc) >> 1) + 4 * ((gc.NCmax + spc) >> 1) + 32 * cl;   // luma rows, chroma rows, exchange row
     const dim3 grid(cdiv((int64_t)gl.strips * gl.bands, 4), 1, n), blk(256);
     const int rc = gc.npv <= 1 ? 1 : gc.npv <= 3 ? 3 : 8;     // chroma ring depth of the instantiation (device.hip laid the taps out for it)
-#define SWS_SR(RC, N) do { if (cl == 4) hipLaunchKernelGGL((swsk::sws_k_strip_rgb<SRGB_BPP, SRGB_RL, RC, N, 4>), grid, blk, (size_t)4 * wave_dw * 4, st, fs, p, gl, gc, wave_dw); \
+#define SWS_SR(RC, N) do { if (s16) hipLaunchKernelGGL((swsk::sws_k_strip_rgb<SRGB_BPP, SRGB_RL, RC, N, 2, true>), grid, blk, (size_t)4 * wave_dw * 4, st, fs, p, gl, gc, wave_dw); \
+                           else if (cl == 4) hipLaunchKernelGGL((swsk::sws_k_strip_rgb<SRGB_BPP, SRGB_RL, RC, N, 4>), grid, blk, (size_t)4 * wave_dw * 4, st, fs, p, gl, gc, wave_dw); \
                            else hipLaunchKernelGGL((swsk::sws_k_strip_rgb<SRGB_BPP, SRGB_RL, RC, N, 2>), grid, blk, (size_t)4 * wave_dw * 4, st, fs, p, gl, gc, wave_dw); } while (0)
 #define SWS_SRN(RC) switch (gl.nph) { case 1: SWS_SR(RC, 1); break; case 2: SWS_SR(RC, 2); break; case 3: SWS_SR(RC, 3); break; case 4: SWS_SR(RC, 4); break; \
                                       case 5: SWS_SR(RC, 5); break; case 6: SWS_SR(RC, 6); break; case 7: SWS_SR(RC, 7); break; case 8: SWS_SR(RC, 8); break; \

@@ -203,20 +203,23 @@ __global__ void __launch_bounds__(256) sws_k_rgb_read16(SwsFrameSet fs, SwsDevPa
     const FrameRegs f = load_frame(fs, blockIdx.z);
     const int y0 = blockIdx.y * RGBREAD_RPW, y1 = min(H, y0 + RGBREAD_RPW);
     const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);
-    const int rp = U(p.src_r_pos), gp = BPP == 4 ? U(p.src_g_pos) : 1, bp = U(p.src_b_pos);
+    // (BPP == 0: planar 8-bit G, B, R planes: planar_rgb_to_y / _uv / gbr24pToUV_half_c (input.c:1174-1211, :414-432) are the rgb24 readers with the
+    //  bytes fetched from three planes; a pixel is assembled as {R, B} / {G} halves, i.e. r, g, b at bytes 0, 1, 2)
+    const int rp = BPP == 0 ? 0 : U(p.src_r_pos), gp = BPP == 4 ? U(p.src_g_pos) : 1, bp = BPP == 0 ? 2 : U(p.src_b_pos);
     auto coef = [&](const Rgb2YuvRow &w, int k) { return (uint32_t)(uint16_t)(k == rp ? w.r : k == gp ? w.g : k == bp ? w.b : 0); };
     const uint32_t cyA = coef(ty, 0) | coef(ty, 2) << 16, cyB = coef(ty, 1) | coef(ty, 3) << 16;
     const uint32_t cuA = coef(tu, 0) | coef(tu, 2) << 16, cuB = coef(tu, 1) | coef(tu, 3) << 16;
     const uint32_t cvA = coef(tv, 0) | coef(tv, 2) << 16, cvB = coef(tv, 1) | coef(tv, 3) << 16;
-    const uint8_t *s0 = f.src[0];
-    const int64_t sst = f.srcStride[0];
+    const uint8_t *s0 = f.src[0], *s1 = f.src[1], *s2 = f.src[2];
+    const int64_t sst = f.srcStride[0], sst1 = f.srcStride[1], sst2 = f.srcStride[2];
     uint8_t *fb = U(lay.base) + (int64_t)blockIdx.z * U(lay.frame_bytes);
     uint8_t *dY = fb + 2 * (int64_t)x0, *dU = fb + U(lay.offU) + (int64_t)x0 * (HALF ? 1 : 2), *dV = fb + U(lay.offV) + (int64_t)x0 * (HALF ? 1 : 2);
     const int64_t dsY = U(lay.strideY), dsC = U(lay.strideC);
     uint32_t nx[4] = {};
     auto fetch = [&](int r) {
-        const uint8_t *row = s0 + (int64_t)r * sst + (int64_t)BPP * x0;
-        if (BPP == 3) { nx[0] = ((const uint32_t *)row)[0]; nx[1] = ((const uint32_t *)row)[1]; nx[2] = ((const uint32_t *)row)[2]; }
+        const uint8_t *row = s0 + (int64_t)r * sst + (int64_t)(BPP ? BPP : 1) * x0;
+        if (BPP == 0) { nx[0] = *(const uint32_t *)row; nx[1] = *(const uint32_t *)(s1 + (int64_t)r * sst1 + x0); nx[2] = *(const uint32_t *)(s2 + (int64_t)r * sst2 + x0); }
+        else if (BPP == 3) { nx[0] = ((const uint32_t *)row)[0]; nx[1] = ((const uint32_t *)row)[1]; nx[2] = ((const uint32_t *)row)[2]; }
         else { const uint4 q = *(const uint4 *)row; nx[0] = q.x; nx[1] = q.y; nx[2] = q.z; nx[3] = q.w; }
     };
     if (y0 < y1) fetch(y0);
@@ -224,7 +227,12 @@ __global__ void __launch_bounds__(256) sws_k_rgb_read16(SwsFrameSet fs, SwsDevPa
         uint32_t lo[4], hi[4];     // per pixel: {byte 0, byte 2} and {byte 1, byte 3 (0 for 24 bpp)} as 16-bit halves
         const uint32_t d[4] = { nx[0], nx[1], nx[2], nx[3] };
         if (r + 1 < y1) fetch(r + 1);
-        if (BPP == 3) {
+        if (BPP == 0) {   // d[0] = four G, d[1] = four B, d[2] = four R
+            lo[0] = __builtin_amdgcn_perm(d[1], d[2], 0x0c040c00u); hi[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c00u);
+            lo[1] = __builtin_amdgcn_perm(d[1], d[2], 0x0c050c01u); hi[1] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c01u);
+            lo[2] = __builtin_amdgcn_perm(d[1], d[2], 0x0c060c02u); hi[2] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c02u);
+            lo[3] = __builtin_amdgcn_perm(d[1], d[2], 0x0c070c03u); hi[3] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c03u);
+        } else if (BPP == 3) {
             lo[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c020c00u); hi[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c01u);
             lo[1] = __builtin_amdgcn_perm(d[1], d[0], 0x0c050c03u); hi[1] = __builtin_amdgcn_perm(d[1], d[0], 0x0c0c0c04u);
             lo[2] = __builtin_amdgcn_perm(d[2], d[1], 0x0c040c02u); hi[2] = __builtin_amdgcn_perm(d[2], d[1], 0x0c0c0c03u);

@@ -25,7 +25,8 @@
 
 namespace swsk {
 
-template <int NCOMP, int COLS, int NPH, int RD>
+// S16: the source planes hold 9 .. 15-bit samples in 16-bit words (eight samples per 16-byte chunk, staged as they are); else bytes
+template <int NCOMP, int COLS, int NPH, int RD, bool S16 = false>
 struct StripPlane {
     StripLds L;
     int spd[COLS];
@@ -36,8 +37,8 @@ struct StripPlane {
     uint32_t ring[NCOMP][COLS][RD];
 };
 
-template <int NCOMP, int COLS, int NPH, int RD>
-__device__ __forceinline__ void sp_prefetch(StripPlane<NCOMP, COLS, NPH, RD> &P, int q)
+template <int NCOMP, int COLS, int NPH, int RD, bool S16>
+__device__ __forceinline__ void sp_prefetch(StripPlane<NCOMP, COLS, NPH, RD, S16> &P, int q)
 {
     const int r0 = min(max(2 * q, 0), P.sH - 1), r1 = min(max(2 * q + 1, 0), P.sH - 1);
 #pragma unroll
@@ -57,23 +58,25 @@ __device__ __forceinline__ void sp_put8(uint32_t *dst, const u32x4 &v)   // 16 b
     *(u32x4 *)dst = lo; *(u32x4 *)(dst + 4) = hi;
 }
 
-template <int NCOMP, int COLS, int NPH, int RD>
-__device__ __forceinline__ void sp_stage(StripPlane<NCOMP, COLS, NPH, RD> &P)
+template <int NCOMP, int COLS, int NPH, int RD, bool S16>
+__device__ __forceinline__ void sp_stage(StripPlane<NCOMP, COLS, NPH, RD, S16> &P)
 {
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++) {
         uint32_t *row0 = P.L.S + (ci * 2) * P.L.row_dw, *row1 = row0 + P.L.row_dw;
-        sp_put8(row0 + P.slot, P.pre[2 * ci + 0]); sp_put8(row1 + P.slot, P.pre[2 * ci + 1]);
+        if constexpr (S16) { *(u32x4 *)(row0 + P.slot) = P.pre[2 * ci + 0]; *(u32x4 *)(row1 + P.slot) = P.pre[2 * ci + 1]; }
+        else { sp_put8(row0 + P.slot, P.pre[2 * ci + 0]); sp_put8(row1 + P.slot, P.pre[2 * ci + 1]); }
     }
 }
 
 // per-lane column state of one plane class: window offsets, horizontal taps, source descriptors
-template <int NCOMP, int COLS, int NPH, int RD>
-__device__ __forceinline__ void sp_init(StripPlane<NCOMP, COLS, NPH, RD> &P, const SwsStripGeom &g, int strip, int W, int sH, const int32_t *hpos,
+template <int NCOMP, int COLS, int NPH, int RD, bool S16>
+__device__ __forceinline__ void sp_init(StripPlane<NCOMP, COLS, NPH, RD, S16> &P, const SwsStripGeom &g, int strip, int W, int sH, const int32_t *hpos,
                                         const uint8_t *const (&sb)[NCOMP], const int (&sst)[NCOMP], uint32_t *lds, int lane)
 {
-    const int xs = strip * g.TW, cs = g.colStart[strip], chunks = g.colCount[strip] / 16;
-    P.L.row_dw = (g.NCmax + 16) >> 1;      // one spare chunk per row: the dump slot of idle lanes
+    constexpr int SPC = S16 ? 8 : 16;      // samples per 16-byte source chunk
+    const int xs = strip * g.TW, cs = g.colStart[strip], chunks = g.colCount[strip] / SPC;
+    P.L.row_dw = (g.NCmax + SPC) >> 1;     // one spare chunk per row: the dump slot of idle lanes
     P.L.S = lds;
     P.sH = sH;
     const int nd = g.hfs2 >> 1;            // dwords per tap row (rows are padded to hfs2 taps: beyond that the next column's taps begin)
@@ -89,8 +92,8 @@ __device__ __forceinline__ void sp_init(StripPlane<NCOMP, COLS, NPH, RD> &P, con
     for (int ci = 0; ci < NCOMP; ci++) { P.sst[ci] = sst[ci]; P.rs[ci] = make_rsrc(sb[ci], (uint32_t)sst[ci] * (uint32_t)sH); }
     // one 16-byte chunk per lane and source row, unconditionally: a lane beyond the strip's window gets an out-of-range offset (the
     // descriptor answers 0 without touching memory) and dumps into the spare chunk
-    P.voff = lane < chunks ? cs + lane * 16 : 0x7fffffff;
-    P.slot = min(lane, chunks) * 8;
+    P.voff = lane < chunks ? cs * (S16 ? 2 : 1) + lane * 16 : 0x7fffffff;
+    P.slot = min(lane, chunks) * (SPC / 2);
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
@@ -101,8 +104,8 @@ __device__ __forceinline__ void sp_init(StripPlane<NCOMP, COLS, NPH, RD> &P, con
 
 // h-scale the staged row pair into the ring, then stage the prefetched pair and request the one after it.  `flush` releases the
 // pending output row between the wait for the prefetched pair and the next request (see the header of kernels_strip.hpp).
-template <int NCOMP, int COLS, int NPH, int RD, typename F>
-__device__ __forceinline__ void sp_step(StripPlane<NCOMP, COLS, NPH, RD> &P, int sh, int opaque_neg, F &&flush)
+template <int NCOMP, int COLS, int NPH, int RD, bool S16, typename F>
+__device__ __forceinline__ void sp_step(StripPlane<NCOMP, COLS, NPH, RD, S16> &P, int sh, int opaque_neg, F &&flush)
 {
     uint32_t np[NCOMP][COLS];
     // (a basic block of its own: see strip_body in kernels_strip.hpp -- straight-line code makes hipcc spill inside the loop)
@@ -132,8 +135,8 @@ __device__ __forceinline__ void sp_step(StripPlane<NCOMP, COLS, NPH, RD> &P, int
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int NCOMP, int COLS, int NPH, int RD>
-__device__ __forceinline__ void sp_restart(StripPlane<NCOMP, COLS, NPH, RD> &P, int q)   // (re)fill: pair q staged, pair q + 1 requested
+template <int NCOMP, int COLS, int NPH, int RD, bool S16>
+__device__ __forceinline__ void sp_restart(StripPlane<NCOMP, COLS, NPH, RD, S16> &P, int q)   // (re)fill: pair q staged, pair q + 1 requested
 {
     P.qnext = q;
     sp_prefetch(P, q);
@@ -143,8 +146,8 @@ __device__ __forceinline__ void sp_restart(StripPlane<NCOMP, COLS, NPH, RD> &P, 
 
 // vertical stage over the whole ring: the host lays the row's tap pairs out against the ring slots (slots older than the row's
 // window carry zero taps), so there is nothing to decide here.  Sums of sample * tap, no rounding constant.
-template <int NCOMP, int COLS, int NPH, int RD>
-__device__ __forceinline__ void sp_vstage(const StripPlane<NCOMP, COLS, NPH, RD> &P, const SwsStripRow &e, int (&acc)[NCOMP][COLS])
+template <int NCOMP, int COLS, int NPH, int RD, bool S16>
+__device__ __forceinline__ void sp_vstage(const StripPlane<NCOMP, COLS, NPH, RD, S16> &P, const SwsStripRow &e, int (&acc)[NCOMP][COLS])
 {
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++)
@@ -177,15 +180,16 @@ __device__ __forceinline__ void lut_pair(const SwsLutParams &L, const LutTabs &T
     }
 }
 
-template <int BPP, int NPH, int RL, int RC, int CL>
+template <int BPP, int NPH, int RL, int RC, int CL, bool S16>
 __device__ __forceinline__ void strip_rgb_body(const FrameRegs &f, const SwsDevParams &p, const SwsStripGeom &gl, const SwsStripGeom &gc,
                                                int strip, int y0, int y1, uint32_t *lds, const LutTabs &T, int lane)
 {
     const int W = p.dstW, H = p.dstH;
     constexpr int CC = CL / 2;             // lane l: luma columns l + 64 c (c < CL), chroma columns and pixel pairs l + 64 c (c < CC)
-    StripPlane<1, CL, NPH, RL> PL;
-    StripPlane<2, CC, NPH, RC> PC;
-    const int ldw = (gl.NCmax + 16) >> 1, cdw = (gc.NCmax + 16) >> 1;
+    StripPlane<1, CL, NPH, RL, S16> PL;
+    StripPlane<2, CC, NPH, RC, S16> PC;
+    constexpr int SPC = S16 ? 8 : 16;
+    const int ldw = (gl.NCmax + SPC) >> 1, cdw = (gc.NCmax + SPC) >> 1;
     uint32_t *ldsL = lds, *ldsC = lds + 2 * ldw, *ldsX = ldsC + 4 * cdw;       // luma rows, chroma rows, 256 x int16 exchange row
     {
         const uint8_t *const sb[1] = { f.src[0] };
@@ -269,7 +273,7 @@ __device__ __forceinline__ void strip_rgb_body(const FrameRegs &f, const SwsDevP
 #ifndef SWS_SRGB_ATTR
 #define SWS_SRGB_ATTR
 #endif
-template <int BPP, int RL, int RC, int NPH, int CL>      // one kernel per ring form and horizontal tap-pair count: each gets the register allocation it needs
+template <int BPP, int RL, int RC, int NPH, int CL, bool S16 = false>      // one kernel per ring form and horizontal tap-pair count: each gets the register allocation it needs
 __global__ void __launch_bounds__(256) SWS_SRGB_ATTR sws_k_strip_rgb(SwsFrameSet fs, SwsDevParams p, SwsStripGeom gl, SwsStripGeom gc, int wave_lds_dw)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -286,7 +290,7 @@ __global__ void __launch_bounds__(256) SWS_SRGB_ATTR sws_k_strip_rgb(SwsFrameSet
     if (y0 >= y1) return;
     const FrameRegs f = load_frame(fs, blockIdx.z);
     uint32_t *lds = (uint32_t *)smem + wib * wave_lds_dw;
-    strip_rgb_body<BPP, NPH, RL, RC, CL>(f, p, gl, gc, strip, y0, y1, lds, T, lane);
+    strip_rgb_body<BPP, NPH, RL, RC, CL, S16>(f, p, gl, gc, strip, y0, y1, lds, T, lane);
 }
 
 } // namespace swsk

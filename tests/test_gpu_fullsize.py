@@ -135,6 +135,23 @@ def test_strip_rgb_kernel_boundaries(case, dw):
         assert got == "main:strip_rgb"
 
 
+@pytest.mark.parametrize("dw", [126, 128, 130, 254, 258, 514, 1026, 1918])
+@pytest.mark.parametrize("case", [("yuv420p10le", "rgb24", 2, SWS_BICUBIC), ("yuv420p10le", "bgra", 1.5, SWS_BILINEAR), ("yuv422p12le", "abgr", 0.75, SWS_LANCZOS),
+                                  ("yuv420p9le", "bgr24", 1.5, SWS_BICUBIC), ("yuv420p14le", "rgb0", 2, SWS_LANCZOS | AR), ("yuv444p10le", "argb", 2, SWS_BICUBIC)],
+                         ids=lambda c: f"{c[0]}-{c[1]}-x{c[2]}")
+def test_strip_rgb_kernel_16bit_sources(case, dw):
+    """9 .. 15-bit planar sources into the packed-RGB LUT writers (decoded HDR pictures for display): the strip kernel with the RGB epilogue on
+    128-column strips, eight samples per 16-byte chunk staged as they are (hScale16To15_c, sh = depth - 1)"""
+    sfmt, dfmt, ratio, scaler = case
+    sw = int(dw * ratio) & ~1
+    for sh, dh in ((40, 22), (91, 37)):
+        got, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, scaler | BX, seed=dw + dh)
+        if "444" not in sfmt:      # (a 4:4:4 source forces the full-chroma writers: not this kernel)
+            assert got == "main:strip_rgb", (got, sfmt, dfmt, sw, dw)
+    if dw == 1918:
+        assert run_case(3840, 2160, "yuv420p10le", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=4)[0] == "main:strip_rgb"
+
+
 def test_c4_batch_of_512_frames_through_one_call():
     """BASELINE config 4 as written: 512 1080p nv12 frames -> bgr0 through ONE sws_scale_frames() call.  Frames 0..7 are random and
     compared with the oracle over the whole frame; frames 8..511 are distinct variations of them made on the GPU (luma xor a

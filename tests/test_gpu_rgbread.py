@@ -13,7 +13,7 @@ BX = SWS_BITEXACT
 PATH = "main:rgbread+strip_march"
 TUNE = dict(strip_min_w=0)     # (the planner keeps pictures narrower than 1024 columns on the tile kernel: force the path onto oracle-sized cases)
 
-SRC = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "0bgr"]
+SRC = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "0bgr", "gbrp", "gbrap"]   # (planar 8-bit GBR: the same readers, three planes)
 DST = ["yuv420p", "yuv422p", "yuv444p", "nv12", "nv21", "yuv420p10le", "p010le", "yuv422p12le"]
 
 
