@@ -19,6 +19,7 @@
 namespace swship {
 void launch_layout_split422(const LaunchCtx &L, bool uyvy, bool vfirst);   // k_layout.hip: yuyv422 / uyvy422 / yvyu422 -> planar 4:2:2 working picture
 void launch_layout_splitnv(const LaunchCtx &L, bool vfirst);   // k_layout.hip: plane 1 of a semi-planar 8-bit picture -> planar U / V working planes
+void launch_layout_splitp01x(const LaunchCtx &L, int shift);   // k_layout.hip: p010-style planes -> planar working picture, words >> shift
 void launch_layout_join422(const LaunchCtx &L, bool uyvy);   // k_layout.hip: planar 4:2:2 working picture -> yuyv422 / uyvy422 (yvyu422: planes swapped by the planner)
 
 static int ensure_dev(SwsInternal *c)
@@ -276,6 +277,15 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         !c->tune.no_mixed && !c->tune.no_layout_stream && !c->tune.no_strip) {
         d->spare_i[3] = 8 | (p.uv_swap_src ? 16 : 0);
         p.srcKind = SRCK_PLANAR8;
+        p.u_plane_src = 1; p.v_plane_src = 2; p.uv_swap_src = 0;
+    }
+    // (the 10 / 12-bit twins -- p010, p012, p210, p410 ...: words with the samples in the high bits -- become a planar working picture with the samples
+    //  shifted down, luma included, and take the 16-bit instantiation of that kernel)
+    if (c->plan == PLAN_MAIN && p.srcKind == SRCK_P010 && p.src_depth <= 15 && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !((o.flags & SWS_FULL_CHR_H_INT)) &&
+        !(bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14)) && !gray_any && !(o.flags & SWS_SRC_V_CHR_DROP_MASK) && !(o.flags & SWS_FAST_BILINEAR) &&
+        !c->tune.no_mixed && !c->tune.no_layout_stream && !c->tune.no_strip) {
+        d->spare_i[3] = 32; d->spare_i[6] = p.src_shift;
+        p.srcKind = SRCK_PLANAR16; p.src_shift = 0;
         p.u_plane_src = 1; p.v_plane_src = 2; p.uv_swap_src = 0;
     }
     d->spare_i[0] = 0;
@@ -959,7 +969,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     }
     default: c->path_name = "none"; c->kernel_name = ""; break;
     }
-    if (c->plan == PLAN_MAIN && d->spare_i[3]) c->path_name = ((d->spare_i[3] & 8) ? "main:splitnv+" : "main:split422+") + c->path_name.substr(c->path_name.find(':') + 1);
+    if (c->plan == PLAN_MAIN && d->spare_i[3]) c->path_name = ((d->spare_i[3] & 40) ? "main:splitnv+" : "main:split422+") + c->path_name.substr(c->path_name.find(':') + 1);
     if (c->plan == PLAN_MAIN && d->spare_i[0]) c->path_name += "+join422";
     // (16-byte aligned pictures of the layout converters take the streaming kernel, k_layout.hip; the names above are the fallback's)
     if (!c->tune.no_layout_stream && (c->plan == PLAN_UNSC_PLANAR2NV12 || c->plan == PLAN_UNSC_NV122PLANAR || c->plan == PLAN_UNSC_PLANARCOPY || c->plan == PLAN_UNSC_PLANAR2NV24 ||
@@ -1120,8 +1130,9 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
     bool timing_started = false;
     if (c->plan == PLAN_MAIN && d->spare_i[3]) {
         auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
-        const bool nv = (d->spare_i[3] & 8) != 0;    // semi-planar source: only the chroma plane is split, the luma plane stays where it is
-        const int sY = nv ? 0 : (int)a256(p.srcW), sC = (int)a256(nv ? p.chrSrcW : p.srcW >> 1), crows = nv ? p.chrSrcH : p.srcH;
+        const bool nv = (d->spare_i[3] & 8) != 0;    // semi-planar 8-bit source: only the chroma plane is split, the luma plane stays where it is
+        const bool p01x = (d->spare_i[3] & 32) != 0; // semi-planar 10 / 12-bit source: both planes (every word is shifted down)
+        const int sY = nv ? 0 : (int)a256(p01x ? 2 * p.srcW : p.srcW), sC = (int)a256(p01x ? 2 * p.chrSrcW : nv ? p.chrSrcW : p.srcW >> 1), crows = (nv || p01x) ? p.chrSrcH : p.srcH;
         const int64_t offU = (int64_t)sY * p.srcH, offV = offU + (int64_t)sC * crows, fbytes = a256(offV + (int64_t)sC * crows);
         int r = grow(c, &d->spare_ptr[3], &d->spare_sz[3], (size_t)fbytes * (size_t)n);
         if (r < 0) return r;
@@ -1131,8 +1142,8 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
             uint8_t *base = (uint8_t *)d->spare_ptr[3] + (size_t)i * (size_t)fbytes;
             SwsFramePtrs &a = s422fr[(size_t)i], &j = s422split[(size_t)i];
             std::memset(&j, 0, sizeof(j));
-            if (nv) { j.src[1] = a.src[1]; j.srcStride[1] = a.srcStride[1]; }
-            else { j.src[0] = a.src[0]; j.srcStride[0] = a.srcStride[0]; j.dst[0] = base; j.dstStride[0] = sY; a.src[0] = base; a.srcStride[0] = sY; }
+            if (nv || p01x) { j.src[1] = a.src[1]; j.srcStride[1] = a.srcStride[1]; }
+            if (!nv) { j.src[0] = a.src[0]; j.srcStride[0] = a.srcStride[0]; j.dst[0] = base; j.dstStride[0] = sY; a.src[0] = base; a.srcStride[0] = sY; }
             j.dst[1] = base + offU; j.dst[2] = base + offV; j.dstStride[1] = j.dstStride[2] = sC;
             a.src[1] = base + offU; a.src[2] = base + offV; a.src[3] = nullptr;
             a.srcStride[1] = a.srcStride[2] = sC; a.srcStride[3] = 0;
@@ -1144,7 +1155,8 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         if (n == 1) { S.fs.table = nullptr; S.fs.one = s422split[0]; }
         else { const SwsFramePtrs *t = nullptr; r = aux_table(1, s422split, &t); if (r < 0) return r; S.fs.table = t; }
         if (d->timing) { HIPCHK(hipEventRecord(d->ev0, st)); timing_started = true; }
-        if (nv) launch_layout_splitnv(S, (d->spare_i[3] & 16) != 0);
+        if (p01x) launch_layout_splitp01x(S, d->spare_i[6]);
+        else if (nv) launch_layout_splitnv(S, (d->spare_i[3] & 16) != 0);
         else launch_layout_split422(S, (d->spare_i[3] & 3) == 2, (d->spare_i[3] & 4) != 0);
         frames = s422fr.data();
     }

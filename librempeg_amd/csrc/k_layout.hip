@@ -1,5 +1,7 @@
 // Translation unit of the streaming layout / depth converters (kernels_layout.hpp): the plan of row classes for
 // planarCopyWrapper (+DITHER_COPY), planarToNv12 / Nv24, nv12 / nv24ToPlanar, yuyv / uyvy <-> planar.
+#include <algorithm>
+
 #include "devstate.hpp"
 #include "kernels_layout.hpp"
 
@@ -121,6 +123,25 @@ void launch_layout_splitnv(const LaunchCtx &L, bool vfirst)
     j.op = LOP_DIL; j.rows = p.chrSrcH; j.ys = 0; j.yd = 0; j.sa = j.sb = 1; j.da = a; j.db = 3 - a;
     j.n = 2 * p.chrSrcW;
     hipLaunchKernelGGL((sws_k_layout_stream<4>), dim3(cdiv(cdiv(j.n, 16), 256), cdiv(j.rows, LAYOUT_RPW), L.n), dim3(256), 0, L.st, L.fs, p, plan);
+}
+
+// A p010 / p012 / p210 / p410-style source of the scaler (16-bit words, samples in the high bits, chroma interleaved) as a planar working picture
+// with the samples in the low bits (device.hip; L.fs holds {src[0] / src[1] = the two planes, dst[0..2] = Y / U / V planes}): p010LEToY_c /
+// p010LEToUV_c (input.c:950-1008) are `word >> shift` and a de-interleave.
+void launch_layout_splitp01x(const LaunchCtx &L, int shift)
+{
+    const SwsDevParams &p = *L.p;
+    using namespace swsk;
+    LayoutPlan plan;
+    std::memset(&plan, 0, sizeof(plan));
+    plan.njobs = 2;
+    LayoutJob &y = plan.job[0], &cjob = plan.job[1];
+    y.op = LOP_16TO16; y.rows = p.srcH; y.sa = y.sb = y.da = y.db = 0; y.n = 2 * p.srcW;
+    y.a0 = 3 | 16; y.a1 = 0; y.a2 = shift; y.a3 = 0; y.a4 = 0;        // mode 3 (shift only), packed: (word >> shift) << 0
+    cjob.op = LOP_DIL16; cjob.rows = p.chrSrcH; cjob.sa = cjob.sb = 1; cjob.da = 1; cjob.db = 2; cjob.n = 4 * p.chrSrcW; cjob.a0 = shift;
+    int groups = 0, chunks = 0;
+    for (int i = 0; i < plan.njobs; i++) { groups += cdiv(plan.job[i].rows, LAYOUT_RPW); chunks = std::max(chunks, (int)cdiv(plan.job[i].n, 16)); }
+    hipLaunchKernelGGL((sws_k_layout_stream<4>), dim3(cdiv(chunks, 256), groups, L.n), dim3(256), 0, L.st, L.fs, p, plan);
 }
 
 // The interleaving pass behind a packed 4:2:2 destination of the scaler (device.hip: the planar writers filled a yuv422p working picture per

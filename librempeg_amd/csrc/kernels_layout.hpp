@@ -35,7 +35,7 @@ __device__ __forceinline__ pk16 pk_min(pk16 a, pk16 b) { return __builtin_elemen
 __device__ __forceinline__ pk16 pk_bytes_lo(uint32_t w) { return pk_of(__builtin_amdgcn_perm(0, w, 0x0c010c00u)); }
 __device__ __forceinline__ pk16 pk_bytes_hi(uint32_t w) { return pk_of(__builtin_amdgcn_perm(0, w, 0x0c030c02u)); }
 
-enum { LOP_COPY = 0, LOP_FILL, LOP_IL, LOP_DIL, LOP_8TO16, LOP_16TO8, LOP_16TO16, LOP_P422_SPLIT, LOP_P422_SPLIT420, LOP_P422_JOIN, LOP_P1_16TO8, LOP_P1_16TO16 };
+enum { LOP_COPY = 0, LOP_FILL, LOP_IL, LOP_DIL, LOP_8TO16, LOP_16TO8, LOP_16TO16, LOP_P422_SPLIT, LOP_P422_SPLIT420, LOP_P422_JOIN, LOP_P1_16TO8, LOP_P1_16TO16, LOP_DIL16 };
 
 // one class of rows: `rows` rows starting at source row ys / destination row yd of the planes named below
 struct LayoutJob {
@@ -128,6 +128,22 @@ __global__ void __launch_bounds__(256) sws_k_layout_stream(SwsFrameSet fs, SwsDe
                 const u32x2 ea = { __builtin_amdgcn_perm(v[i][1], v[i][0], 0x06040200u), __builtin_amdgcn_perm(v[i][3], v[i][2], 0x06040200u) };
                 const u32x2 eb = { __builtin_amdgcn_perm(v[i][1], v[i][0], 0x07050301u), __builtin_amdgcn_perm(v[i][3], v[i][2], 0x07050301u) };
                 lstore8(dbaseA + (r + i) * dsA + (off >> 1), ea, (n - off + 1) >> 1); lstore8(dbaseB + (r + i) * dsB + (off >> 1), eb, (n - off) >> 1);
+            }
+        }
+        break;
+    }
+    case LOP_DIL16: {  // p010ToUV-style split (input.c:950-1008): n bytes of interleaved 16-bit pairs -> n/2 bytes to plane A (first words), n/2 to plane B, every word >> a0
+        for (int r = r0; r < r1; r += RU) {
+            u32x4 v[RU];
+#pragma unroll
+            for (int i = 0; i < RU; i++) if (in && r + i < r1) v[i] = load16_or_tail(sbaseA + (r + i) * ssA + off, n - off);
+#pragma unroll
+            for (int i = 0; i < RU; i++) {
+                if (!(in && r + i < r1)) continue;
+                const pk16 sh = pk_splat(a0);
+                const u32x2 ea = { pk_bits(pk_of(__builtin_amdgcn_perm(v[i][1], v[i][0], 0x05040100u)) >> sh), pk_bits(pk_of(__builtin_amdgcn_perm(v[i][3], v[i][2], 0x05040100u)) >> sh) };
+                const u32x2 eb = { pk_bits(pk_of(__builtin_amdgcn_perm(v[i][1], v[i][0], 0x07060302u)) >> sh), pk_bits(pk_of(__builtin_amdgcn_perm(v[i][3], v[i][2], 0x07060302u)) >> sh) };
+                lstore8(dbaseA + (r + i) * dsA + (off >> 1), ea, (n - off) >> 1); lstore8(dbaseB + (r + i) * dsB + (off >> 1), eb, (n - off) >> 1);
             }
         }
         break;

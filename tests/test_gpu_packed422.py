@@ -136,3 +136,17 @@ def test_semi_planar_sources_into_rgb(src, dst):
 def test_nv12_to_rgb_full_size_is_the_strip_kernel():
     assert run_case(3840, 2160, "nv12", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=2)[0] == "main:splitnv+strip_rgb"
     assert run_case(1920, 1080, "nv12", 1280, 720, "rgb24", SWS_BILINEAR | BX, seed=3, device_frames=False)[0] == "main:splitnv+strip_rgb"
+
+
+@pytest.mark.parametrize("src", ["p010le", "p012le", "p210le", "p010be"])
+@pytest.mark.parametrize("dst", ["rgb24", "bgra", "argb", "rgb0"])
+def test_p01x_sources_into_rgb(src, dst):
+    """10 / 12-bit decoder output scaled for display: both planes become a planar working picture with the samples shifted down
+    (p010LEToY_c / p010LEToUV_c, input.c:950-1008), then the 16-bit instantiation of the strip kernel with the RGB epilogue"""
+    for (sw, sh, dw, dh, fl) in ((256, 64, 192, 48, SWS_BICUBIC), (320, 50, 512, 80, SWS_BICUBIC), (132, 34, 66, 18, SWS_AREA), (256, 64, 320, 96, SWS_BILINEAR),
+                                 (256, 64, 250, 64, SWS_LANCZOS), (130, 30, 131, 31, SWS_BICUBIC)):
+        r = run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh)
+        if not dw & 1:
+            assert r[0].startswith("main:splitnv+"), (r[0], src, dst, sw, dw)
+    assert run_case(1920, 1080, src, 1280, 720, dst, SWS_BICUBIC | BX, seed=7)[0] == "main:splitnv+strip_rgb"
+    assert not run_case(256, 64, src, 256, 64, dst, SWS_BICUBIC | BX, seed=8)[0].startswith("main:splitnv+")

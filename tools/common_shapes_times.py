@@ -13,7 +13,7 @@ CASES = [("yuv420p",1920,1080,"yuv420p",3840,2160,SWS_BICUBIC),("yuv420p",1920,1
          ("bgra",1920,1080,"nv12",1920,1080,SWS_BICUBIC),("yuv420p",1920,1080,"yuv420p10le",1920,1080,SWS_BICUBIC),("p010le",3840,2160,"nv12",1920,1080,SWS_BILINEAR),
          ("yuv422p10le",1920,1080,"yuv420p",1920,1080,SWS_BICUBIC),("yuv444p",1920,1080,"yuv420p",1920,1080,SWS_BICUBIC),
          ("bgra",3840,2160,"yuv420p",1920,1080,SWS_BICUBIC),("yuyv422",1920,1080,"yuv420p",1280,720,SWS_BICUBIC),("uyvy422",3840,2160,"nv12",1920,1080,SWS_BILINEAR),
-         ("nv12",3840,2160,"bgra",1920,1080,SWS_BICUBIC),("yuv420p10le",3840,2160,"bgra",1920,1080,SWS_BICUBIC),("gbrp",1920,1080,"yuv420p",1280,720,SWS_BICUBIC),("nv12",1920,1080,"rgb24",1280,720,SWS_BILINEAR),("yuv420p",1920,1080,"yuyv422",1920,1080,SWS_BICUBIC),("yuv420p",3840,2160,"uyvy422",1920,1080,SWS_BICUBIC)]
+         ("nv12",3840,2160,"bgra",1920,1080,SWS_BICUBIC),("yuv420p10le",3840,2160,"bgra",1920,1080,SWS_BICUBIC),("p010le",3840,2160,"bgra",1920,1080,SWS_BICUBIC),("gbrp",1920,1080,"yuv420p",1280,720,SWS_BICUBIC),("nv12",1920,1080,"rgb24",1280,720,SWS_BILINEAR),("yuv420p",1920,1080,"yuyv422",1920,1080,SWS_BICUBIC),("yuv420p",3840,2160,"uyvy422",1920,1080,SWS_BICUBIC)]
 print("| conversion | path / kernel | ms / frame | Gpix/s out | GB/s (src + dst bytes) |")
 print("|---|---|---|---|---|")
 for sf,sw,sh,df,dw,dh,fl in CASES:
