@@ -168,6 +168,15 @@ static bool bank_is_identity(const FilterBank &b, int one)
     return true;
 }
 
+// every tap of a one-tap bank equals `one` (initFilter's error-diffused normalisation leaves one - 1 in some rows)
+static bool bank_taps_all(const FilterBank &b, int one)
+{
+    if (b.size != 1) return false;
+    for (int i = 0; i < b.count; i++)
+        if (b.taps[i] != one) return false;
+    return true;
+}
+
 static int src_kind_of(int f)
 {
     const PixDesc *d = pix_desc(f);
@@ -290,7 +299,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     }
     d->spare_i[0] = 0;
     if (c->plan == PLAN_MAIN && p.dstKind == DSTK_PACKED422 && dd->comp[0].depth == 8 && !(o.dst_w & 1) && !p.should_dither && !c->needAlpha && !gray_any &&
-        !((c->vLum.size == 1 || c->vLum.size == 2) && c->vChr.size == 2) && !c->tune.no_mixed && !c->tune.no_layout_stream) {
+        !((c->vLum.size == 1 || c->vLum.size == 2) && c->vChr.size == 2) && !c->tune.no_mixed && !c->tune.no_layout_stream &&
+        // (one tap on ONE side only: the packed X form multiplies by the bank's value, which initFilter's normalisation leaves at 4095 in some
+        //  rows, where the planar one-tap form ignores it; one tap on both sides is yuv2422_1, which ignores both)
+        ((c->vLum.size == 1) == (c->vChr.size == 1) || bank_taps_all(c->vLum.size == 1 ? c->vLum : c->vChr, 1 << 12))) {
         const bool uyvy = dd->comp[0].offset == 1, vfirst = dd->comp[2].offset < dd->comp[1].offset;   // (yvyu422: V before U)
         p.dstKind = DSTK_PLANAR8;
         p.u_plane_dst = vfirst ? 2 : 1; p.v_plane_dst = vfirst ? 1 : 2;
@@ -624,7 +636,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 struct SOff { size_t cs, cc, rows; };
                 // ring_of(npv) != 0: the kernel multiplies a whole ring of that depth per output sample (sws_k_strip_rgb): the row's tap pairs
                 // are laid out against the newest npv slots, the older slots get zero taps
-                auto plan3 = [&](const FilterBank &hb, const FilterBank &vb, int W, int cols, int ncomp, SwsStripGeom &g, SOff &o, int (*ring_of)(int) = nullptr) -> bool {
+                // plane1_form: the plane's writer has the reference's one-tap form (yuv2plane1_*, yuv2p01xl1_c: (s + d) >> 7 and its N-bit twins), which
+                // never looks at the coefficient -- initFilter's error-diffused normalisation leaves 4095 in some one-tap rows -- so a one-tap bank
+                // enters the X arithmetic as 4096; the semi-planar chroma writers (yuv2nv12cX_c, yuv2p01xcX_c) have no such form and take the bank's value
+                auto plan3 = [&](const FilterBank &hb, const FilterBank &vb, int W, int cols, int ncomp, SwsStripGeom &g, SOff &o, int (*ring_of)(int) = nullptr, bool plane1_form = false) -> bool {
                     const int TW = 64 * cols, hf2 = fs2(hb.size), vf2 = fs2(vb.size);
                     const int strips = (W + TW - 1) / TW;
                     std::vector<int32_t> cs(strips), cc(strips);
@@ -660,26 +675,29 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         for (int j = 0; j < vb.size; j++) {
                             const int k = (vb.pos[y] & 1) + j + lead;
                             // (pairs 8 .. 11 of a long chroma filter land in the four spare dwords behind vt[8]: load_strip_row_n)
-                            reinterpret_cast<uint32_t *>(&e)[4 + (k >> 1)] |= (uint32_t)(uint16_t)vb.taps[(size_t)y * vb.size + j] << (16 * (k & 1));
+                            const int16_t tap = (vb.size == 1 && plane1_form) ? (int16_t)4096 : vb.taps[(size_t)y * vb.size + j];
+                            reinterpret_cast<uint32_t *>(&e)[4 + (k >> 1)] |= (uint32_t)(uint16_t)tap << (16 * (k & 1));
                         }
                     }
                     o.rows = put(rows.data(), rows.size() * sizeof(SwsStripRow));
                     return true;
                 };
                 SOff sL, sC;
+                const bool chr_plane1 = p.dstKind != DSTK_NV12 && p.dstKind != DSTK_P010;
                 const int strip_cols_l = c->tune.strip_cols_l == 2 ? 2 : 4;
                 const int strip_cols_c = c->tune.strip_cols_c == 1 ? 1 : 2;
                 // (narrow pictures leave most of a 256-column strip idle and pay the per-band ring fill: the tile kernel keeps them)
                 const int strip_min_w = c->tune.strip_min_w;
                 const bool strip_plan = fullA && dst_ok && !p.range_active && !c->tune.no_strip && p.dstW >= strip_min_w &&
-                                        plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sL) && (gray_both || plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sC));
+                                        plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sL, nullptr, true) &&
+                                        (gray_both || plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sC, nullptr, chr_plane1));
                 d->strip_ok = false;
                 log_msg(c, 3, "strip plan: %d (windows %d/%d chunks of %d, taps %d/%d x %d/%d)\n", strip_plan, d->stripL.NCmax / SPC, d->stripC.NCmax / SPC, SPC,
                         d->stripL.nph, d->stripC.nph, d->stripL.npv, d->stripC.npv);
                 Off oL, oC;
                 if (mixedM) {
                     SOff sM;
-                    if (plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sM)) {
+                    if (plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sM, nullptr, chr_plane1)) {
                         const std::vector<int16_t> htc = padded(c->hChr);
                         const size_t ohc = put(htc.data(), htc.size() * 2);
                         if (blob.size() > d->dot2_bytes) {

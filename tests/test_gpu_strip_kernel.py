@@ -103,3 +103,14 @@ def test_one_tap_vertical_filters():
             assert run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=dw, tune=STRIP)[0] == "main:strip_march", (sfmt, dfmt, sw, dw)
     assert run_case(3840, 2160, "yuv420p", 1920, 1080, "uyvy422", SWS_BICUBIC | BX, seed=5)[0] == "main:strip_march+join422"
     assert run_case(1440, 1080, "yuv420p", 1920, 1080, "yuv420p", SWS_BICUBIC | BX, seed=6)[0] == "main:strip_march"
+
+
+def test_one_tap_rows_with_the_tap_4095():
+    """initFilter's error-diffused normalisation leaves 4095 in some rows of a one-tap vertical bank (tiny source heights with a shifted chroma
+    position): yuv2plane1 never looks at the coefficient, the semi-planar chroma writers and the packed X forms do"""
+    opts = dict(dither=2, src_range=0, dst_range=0, src_h_chr_pos=0, src_v_chr_pos=256, dst_h_chr_pos=0, dst_v_chr_pos=-513)
+    for sfmt, dfmt in (("yuyv422", "yuyv422"), ("yuv422p", "yuv422p"), ("yuv422p", "nv16"), ("yuv422p", "uyvy422"), ("yuv444p12le", "yuv420p10be"), ("yuv422p", "p210le"),
+                       ("yuv444p", "rgb24"), ("yuv422p", "bgra")):
+        for (sw, sh, dw, dh) in ((60, 3, 302, 44), (340, 2, 352, 25), (64, 3, 128, 3), (128, 2, 64, 9)):
+            run_case(sw, sh, sfmt, dw, dh, dfmt, SWS_BICUBIC | SWS_ACCURATE_RND | BX, seed=sw, opts=opts, tune=STRIP)
+            run_case(sw, sh, sfmt, dw, dh, dfmt, SWS_LANCZOS | BX, seed=dw, opts=dict(opts, src_v_chr_pos=128), tune=STRIP)
