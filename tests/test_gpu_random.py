@@ -33,7 +33,12 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(6000, 20260928), ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
+import os
+# (SWS_RANDOM_N / SWS_RANDOM_SEED: a longer or different draw of every generator of this file for a bug hunt; the committed suite runs the defaults)
+_HUNT_N, _HUNT_SEED = os.environ.get("SWS_RANDOM_N"), os.environ.get("SWS_RANDOM_SEED")
+
+
+@pytest.mark.parametrize("case", _cases(int(_HUNT_N or 6000), int(_HUNT_SEED or 20260928)), ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
 def test_random_conversions(case):
     sw, sh, sf, dw, dh, df, flags, k = case
     try:
@@ -66,7 +71,7 @@ def _opt_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _opt_cases(3000, 777), ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
+@pytest.mark.parametrize("case", _opt_cases(int(_HUNT_N or 3000), int(_HUNT_SEED or 777)), ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
 def test_random_conversions_with_options(case):
     """the same with the sws_alloc_context() + public fields + sws_init_context() construction: dither mode, ranges, chroma positions,
     and sws_setColorspaceDetails() with brightness / contrast / saturation."""
@@ -124,9 +129,7 @@ def _strip_cases(n, seed):
     return out
 
 
-import os
-# (SWS_RANDOM_N / SWS_RANDOM_SEED: a longer or different draw for a bug hunt; the committed suite runs the default)
-@pytest.mark.parametrize("case", _strip_cases(int(os.environ.get("SWS_RANDOM_N", "4000")), int(os.environ.get("SWS_RANDOM_SEED", "31337"))), ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
+@pytest.mark.parametrize("case", _strip_cases(int(_HUNT_N or 4000), int(_HUNT_SEED or 31337)), ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
 def test_random_conversions_on_the_strip_family(case):
     sw, sh, sf, dw, dh, df, flags, k, opts, cs, tune = case
     try:
