@@ -16,7 +16,11 @@ int launch_strip_planes(const LaunchCtx &L, int which)
             const int target = c->tune.strip_waves;
             const bool s16 = p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010;   // (launch_rgbread_strip passes its reader planes as SRCK_PLANAR16)
             auto launch = [&](SwsStripGeom g, int H, bool chroma) {
-                int bands = std::max(1, std::min(target / std::max(1, g.strips * n), (H + 15) / 16));
+                // one resident round of waves; bands of at least `minrows` output rows.  The floor matters for ONE frame per call (what a filter
+                // chain issues): the kernel's time is then the serial walk of a wave (ring fill + one step per source row pair), not throughput,
+                // and the machine is otherwise idle -- 4-row bands: a 1080p plane is 2000 waves of 7 steps instead of 540 waves of 19
+                const int minrows = (c->tune.debug >> 8) & 63 ? (c->tune.debug >> 8) & 63 : 4;
+                int bands = std::max(1, std::min(target / std::max(1, g.strips * n), (H + minrows - 1) / minrows));
                 g.debug = c->tune.debug;
                 g.band_rows = (H + bands - 1) / bands;
                 g.bands = (H + g.band_rows - 1) / g.band_rows;
@@ -49,6 +53,28 @@ int launch_strip_planes(const LaunchCtx &L, int which)
 #undef SWS_STRIP
 #undef SWS_STRIP_DMA
             };
+            // Both plane classes in one grid (sws_k_strip_*_lc) when the call is small -- bands of at most six times the minimum length
+            // in one resident round, i.e. a few frames: such a call is launch- and tail-bound (two launches of about 8 us around 10 - 20 us of work; one 4K -> 1080p
+            // frame 34 -> 25 us, 1080p -> 720p 22 -> 15 us).  Larger calls keep the two launches: the combined kernel carries both bodies' registers
+            // (128 VGPRs and a few spills) and measured 15 - 35 % slower per frame on batches (C3b x32: 1.217 vs 0.898 ms).
+            const int minrows_f = (c->tune.debug >> 8) & 63 ? (c->tune.debug >> 8) & 63 : 4;
+            const int64_t wave_rows = ((int64_t)d->stripL.strips * p.dstH + (int64_t)d->stripC.strips * p.chrDstH) * n;     // rows of 256 samples, all waves together
+            if (which == 3 && d->stripL.TW == 256 && d->stripC.TW == 128 && d->stripC.npv <= 8 && !(c->tune.debug & 0x10000) &&
+                (wave_rows + target - 1) / target <= 6 * minrows_f) {
+                SwsStripGeom gl = d->stripL, gc = d->stripC;
+                const int minrows = minrows_f;
+                const int rows = (int)std::max<int64_t>(minrows, (wave_rows + target - 1) / target);
+                gl.band_rows = gc.band_rows = rows;
+                gl.bands = cdiv(p.dstH, rows); gc.bands = cdiv(p.chrDstH, rows);
+                gl.debug = gc.debug = c->tune.debug;
+                const int blocksL = (int)cdiv((int64_t)gl.strips * gl.bands, 4), blocksC = (int)cdiv((int64_t)gc.strips * gc.bands, 4);
+                const dim3 grid(blocksL + blocksC, 1, n);
+                const bool dma = s16 && gl.dma_ok && gc.dma_ok && !c->tune.no_strip_dma;
+                if (dma) hipLaunchKernelGGL((swsk::sws_k_strip_dma_lc<4, 2>), grid, blk, std::max(gl.lds_dma_bytes, gc.lds_dma_bytes), st, fs, p, gl, gc, blocksL);
+                else if (s16) hipLaunchKernelGGL((swsk::sws_k_strip_march_lc<true, 4, 2>), grid, blk, std::max(gl.lds_bytes, gc.lds_bytes), st, fs, p, gl, gc, blocksL);
+                else hipLaunchKernelGGL((swsk::sws_k_strip_march_lc<false, 4, 2>), grid, blk, std::max(gl.lds_bytes, gc.lds_bytes), st, fs, p, gl, gc, blocksL);
+                return 0;
+            }
             if (which & 1) launch(d->stripL, p.dstH, false);
             if (which & 2) launch(d->stripC, p.chrDstH, true);
     return 0;

@@ -664,4 +664,70 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Luma and chroma launch of the planar strip kernels as ONE grid (blocks [0, blocksL) walk luma bands, the rest chroma bands).  Two reasons:
+// a call with few frames is launch- and tail-bound (one frame: two launches of about 8 us each around 10 - 20 us of work), and with one grid the
+// bands of both plane classes can be cut to the same length (the separate launches each filled the machine on their own: a 4:2:0 chroma plane
+// got bands half as long as the luma plane's, i.e. twice the ring-fill share).
+// ------------------------------------------------------------------------------------------
+template <bool SRC16, int COLS_L, int COLS_C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) sws_k_strip_march_lc(SwsFrameSet fs, SwsDevParams p, SwsStripGeom gl, SwsStripGeom gc, int blocksL)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool chroma = (int)blockIdx.x >= blocksL;
+    const SwsStripGeom &g = chroma ? gc : gl;
+    const int wid = ((int)blockIdx.x - (chroma ? blocksL : 0)) * 4 + wib;
+    if (wid >= U(g.strips) * U(g.bands)) return;
+    const int strip = wid % U(g.strips), band = wid / U(g.strips);
+    const int H = chroma ? p.chrDstH : p.dstH;
+    const int y0 = band * U(g.band_rows), y1 = min(H, y0 + U(g.band_rows));
+    if (y0 >= y1) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    if (!chroma) {
+        switch (gl.nph) {
+#define SWS_SB(N) case N: strip_body<SRC16, false, COLS_L, N>(f, p, gl, strip, y0, y1, smem, wib, lane); break;
+        SWS_SB(1) SWS_SB(2) SWS_SB(3) SWS_SB(4) SWS_SB(5) SWS_SB(6) SWS_SB(7) SWS_SB(8)
+#undef SWS_SB
+        }
+    } else {
+        switch (gc.nph) {
+#define SWS_SB(N) case N: strip_body<SRC16, true, COLS_C, N>(f, p, gc, strip, y0, y1, smem, wib, lane); break;
+        SWS_SB(1) SWS_SB(2) SWS_SB(3) SWS_SB(4) SWS_SB(5) SWS_SB(6) SWS_SB(7) SWS_SB(8)
+#undef SWS_SB
+        }
+    }
+}
+
+template <int COLS_L, int COLS_C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) sws_k_strip_dma_lc(SwsFrameSet fs, SwsDevParams p, SwsStripGeom gl, SwsStripGeom gc, int blocksL)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool chroma = (int)blockIdx.x >= blocksL;
+    const SwsStripGeom &g = chroma ? gc : gl;
+    const int wid = ((int)blockIdx.x - (chroma ? blocksL : 0)) * 4 + wib;
+    if (wid >= U(g.strips) * U(g.bands)) return;
+    const int strip = wid % U(g.strips), band = wid / U(g.strips);
+    const int H = chroma ? p.chrDstH : p.dstH;
+    const int y0 = band * U(g.band_rows), y1 = min(H, y0 + U(g.band_rows));
+    if (y0 >= y1) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    if (!chroma) {
+        switch (gl.nph) {
+#define SWS_SB(N) case N: strip_body_dma<false, COLS_L, N>(f, p, gl, strip, y0, y1, smem, wib, lane); break;
+        SWS_SB(1) SWS_SB(2) SWS_SB(3) SWS_SB(4) SWS_SB(5) SWS_SB(6) SWS_SB(7) SWS_SB(8)
+#undef SWS_SB
+        }
+    } else {
+        switch (gc.nph) {
+#define SWS_SB(N) case N: strip_body_dma<true, COLS_C, N>(f, p, gc, strip, y0, y1, smem, wib, lane); break;
+        SWS_SB(1) SWS_SB(2) SWS_SB(3) SWS_SB(4) SWS_SB(5) SWS_SB(6) SWS_SB(7) SWS_SB(8)
+#undef SWS_SB
+        }
+    }
+}
+
 } // namespace swsk

@@ -11,6 +11,7 @@ python tools/layout_times.py > $OUT/layout.md 2>$OUT/layout.err
 python tools/common_shapes_times.py > $OUT/common.md 2>$OUT/common.err
 python tools/common_conversions_times.py > $OUT/conv.txt 2>$OUT/conv.err
 python tools/aux_kernel_times.py > $OUT/aux.txt 2>$OUT/aux.err
+python tools/single_frame_times.py > $OUT/single.md 2>$OUT/single.err
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_common -o res -- python $ROOT/tools/common_shapes_times.py > $OUT/prof_common.log 2>&1)
 db=$(find $OUT/prof_common -name "*.db" | head -1)
 [ -n "$db" ] && python tools/rocpd_summary.py "$db" "r03 common shapes: rocprofv3 --kernel-trace --stats -- python tools/common_shapes_times.py" > $OUT/kernel_stats_common_shapes.md
