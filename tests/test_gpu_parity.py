@@ -178,6 +178,8 @@ def _slice_ptrs(frame, fmt, y0):
     q = (C.c_void_p * 4)()
     for i in range(frame.nplanes):
         rows = y0 if (i == 0 or i == 3 or kind in ("rgbp", "packed", "gray")) else (y0 >> lh)   # plane 3 = alpha: full height
+        if kind == "pal" and i == 1:
+            rows = 0                                                                           # data[1] of a pal8 picture is the palette, for every slice
         q[i] = p[i] + rows * s[i]
     return q, s
 

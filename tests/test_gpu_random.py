@@ -138,3 +138,79 @@ def test_random_conversions_on_the_strip_family(case):
         pytest.skip("the oracle refuses this context")
     del o
     run_case(sw, sh, sf, dw, dh, df, flags, seed=k + 3, colorspace=cs, device_frames=bool(k % 3), opts=opts or None, tune=tune)
+
+
+def _slice_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for k in range(n):
+        sf, df = rng.choice(FORMAT_MATRIX_SRC + STRIP_SRC), rng.choice(FORMAT_MATRIX_DST + STRIP_DST)
+        if rng.random() < 0.45:
+            sw = dw = rng.randint(2, 300); sh = dh = 2 * rng.randint(4, 48)
+        else:
+            sw, dw, sh, dh = rng.randint(2, 400), rng.randint(2, 400), 2 * rng.randint(4, 48), rng.randint(2, 96)
+        flags = rng.choice(SCALERS) | rng.choice(EXTRA)
+        tune = {"strip_min_w": 0} if rng.random() < 0.5 else {}
+        out.append((sw, sh, sf, dw, dh, df, flags, k, tune, rng.randint(2, 4), rng.random()))
+    return out
+
+
+@pytest.mark.parametrize("case", _slice_cases(int(_HUNT_N or 2500), int(_HUNT_SEED or 8088)), ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
+def test_random_slice_sequences(case):
+    """top-down slice sequences with random cuts (multiples of four rows: whole chroma rows of every format, whole Bayer blocks) through whatever the
+    context is -- special converter, scaler, cascade: the assembled picture is the whole-frame result, no call fails"""
+    import numpy as np
+    import torch
+    from librempeg_amd import SwsContext, HostFrame, DeviceFrame
+    from test_gpu_parity import _slice_ptrs
+    sw, sh, sf, dw, dh, df, flags, k, tune, nsl, r = case
+    try:
+        o = OL.Oracle(sw, sh, sf, dw, dh, df, flags)
+    except Exception:
+        pytest.skip("the oracle refuses this context")
+    src = OL.fill_random(OL.Frame(sf, sw, sh), k + 11)
+    ref = OL.Frame(df, dw, dh, fill=0x5A)
+    whole = o.scale(src, ref)
+    assert whole >= 0
+    p = SwsContext(sw, sh, sf, dw, dh, df, flags)
+    for kk, v in tune.items():
+        p.set_option(kk, v)
+    rng = random.Random(k)
+    cuts = sorted({4 * rng.randint(1, max(1, sh // 4 - 1)) for _ in range(nsl - 1)} | {0, sh})
+    cuts = [c for c in cuts if c <= sh]
+    hs = HostFrame(sf, sw, sh)
+    for a, b in zip(hs.planes, src.planes):
+        a[:] = b
+    ds = DeviceFrame(sf, sw, sh).upload(hs)
+    dd = DeviceFrame(df, dw, dh)
+    dd.buf.fill_(0x5A)
+    torch.cuda.synchronize()
+    dp, dstr = dd.ptrs()
+    rets = []
+    for y0, y1 in zip(cuts[:-1], cuts[1:]):
+        sp, ss = _slice_ptrs(ds, sf, y0)
+        rets.append(p.L.sws_scale(p.c, sp, ss, y0, y1 - y0, dp, dstr))
+    p.sync()
+    assert all(x >= 0 for x in rets), (rets, cuts, p.path())
+    if p.path() in ("unscaled:planarCopy", "unscaled:yvu9ToYv12"):      # (yvu9ToYv12Wrapper: planar2x_c interpolates between the chroma rows of ONE slice, swscale_unscaled.c:2079-2093)
+        # DITHER_COPY (swscale_unscaled.c:2159-2218) indexes its dither rows with the row number INSIDE the slice ("dithers[shift-1][i&7]", i from 0 per call):
+        # the reference's result depends on the cuts.  planarCopyWrapper works row by row otherwise, so the expectation is every slice converted as a
+        # picture of its own
+        for y0, y1 in zip(cuts[:-1], cuts[1:]):
+            sub_s, sub_d = OL.Frame(sf, sw, y1 - y0), OL.Frame(df, dw, y1 - y0, fill=0x5A)
+            lay_s, lay_d = OL._FORMATS[sf], OL._FORMATS[df]
+            for i, pl in enumerate(sub_s.planes):
+                r0 = y0 if (i == 0 or i == 3 or lay_s[1] in ("rgbp", "packed", "gray")) else (y0 >> lay_s[3])
+                pl[:] = src.planes[i][r0:r0 + pl.shape[0]]
+            assert OL.Oracle(sw, y1 - y0, sf, dw, y1 - y0, df, flags).scale(sub_s, sub_d) >= 0
+            for i, pl in enumerate(sub_d.planes):
+                r0 = y0 if (i == 0 or i == 3 or lay_d[1] in ("rgbp", "packed", "gray")) else (y0 >> lay_d[3])
+                ref.planes[i][r0:r0 + pl.shape[0]] = pl
+    out = dd.download()
+    for i, (a, b) in enumerate(zip(out.planes, ref.planes)):
+        rb = out.row_bytes[i]
+        if df in ("monob", "monow") and (dw & 7):
+            a, b = a.copy(), b.copy()
+            m = (0xFF00 >> (dw & 7)) & 0xFF
+            a[:, rb - 1] &= m; b[:, rb - 1] &= m
+        assert np.array_equal(a[:, :rb], b[:, :rb]), (case[:7], cuts, rets, p.path(), i, int(np.count_nonzero(a[:, :rb] != b[:, :rb])))
