@@ -214,3 +214,65 @@ def test_random_slice_sequences(case):
             m = (0xFF00 >> (dw & 7)) & 0xFF
             a[:, rb - 1] &= m; b[:, rb - 1] &= m
         assert np.array_equal(a[:, :rb], b[:, :rb]), (case[:7], cuts, rets, p.path(), i, int(np.count_nonzero(a[:, :rb] != b[:, :rb])))
+
+
+def _batch_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for k in range(n):
+        sf, df = rng.choice(STRIP_SRC), rng.choice(STRIP_DST)
+        if rng.random() < 0.3:
+            sw = dw = 4 * rng.randint(2, 90); sh = dh = 2 * rng.randint(2, 30)
+        else:
+            sw, dw, sh, dh = rng.choice([rng.randint(2, 400), 4 * rng.randint(4, 100)]), rng.choice([rng.randint(2, 400), 2 * rng.randint(4, 200)]), rng.randint(2, 64), rng.randint(2, 64)
+        flags = rng.choice(SCALERS[:6]) | rng.choice(EXTRA)
+        tune = {"strip_min_w": 0} if rng.random() < 0.7 else {}
+        out.append((sw, sh, sf, dw, dh, df, flags, k, tune, [rng.randint(1, 5) for _ in range(3)]))
+    return out
+
+
+@pytest.mark.parametrize("case", _batch_cases(int(_HUNT_N or 1200), int(_HUNT_SEED or 4711)), ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
+def test_random_batches(case):
+    """sws_scale_frames() three times on one context with batches of different sizes and different frames (HBM frames, then a mix with host frames):
+    the per-frame working pictures and cached frame tables of the helper passes (reader pre-pass, 4:2:2 / semi-planar splits, 4:2:2 join) must follow"""
+    import numpy as np
+    import torch
+    from librempeg_amd import SwsContext, HostFrame, DeviceFrame
+    sw, sh, sf, dw, dh, df, flags, k, tune, sizes = case
+    try:
+        o = OL.Oracle(sw, sh, sf, dw, dh, df, flags)
+    except Exception:
+        pytest.skip("the oracle refuses this context")
+    p = SwsContext(sw, sh, sf, dw, dh, df, flags)
+    for kk, v in tune.items():
+        p.set_option(kk, v)
+    seed = 1000 * k
+    for rnd, n in enumerate(sizes):
+        refs, srcs, dsts = [], [], []
+        for i in range(n):
+            seed += 1
+            s = OL.fill_random(OL.Frame(sf, sw, sh), seed)
+            ref = OL.Frame(df, dw, dh, fill=0x33)
+            assert o.scale(s, ref) >= 0
+            refs.append(ref)
+            hs = HostFrame(sf, sw, sh)
+            for a, b in zip(hs.planes, s.planes):
+                a[:] = b
+            host = rnd == 2 and (i & 1)
+            if host:
+                hd = HostFrame(df, dw, dh)
+                for a in hd.planes:
+                    a[:] = 0x33
+                srcs.append(hs); dsts.append(hd)
+            else:
+                dd = DeviceFrame(df, dw, dh)
+                dd.buf.fill_(0x33)
+                srcs.append(DeviceFrame(sf, sw, sh).upload(hs)); dsts.append(dd)
+        torch.cuda.synchronize()
+        assert p.scale_frames(srcs, dsts) == n, (rnd, n, p.path())
+        p.sync()
+        for i in range(n):
+            out = dsts[i].download() if isinstance(dsts[i], DeviceFrame) else dsts[i]
+            for pl, (a, b) in enumerate(zip(out.planes, refs[i].planes)):
+                rb = out.row_bytes[pl]
+                assert np.array_equal(a[:, :rb], b[:, :rb]), (case[:7], p.path(), rnd, n, i, pl, int(np.count_nonzero(a[:, :rb] != b[:, :rb])))
