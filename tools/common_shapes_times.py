@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch
 import oracle_lib as OL
 from librempeg_amd import SwsContext, HostFrame, DeviceFrame, SWS_BICUBIC, SWS_BILINEAR, SWS_LANCZOS, SWS_BITEXACT
-N = 16
+N = int(os.environ.get("SWS_SHAPES_N", "16"))
+OPTS = {k[7:].lower(): int(v) for k, v in os.environ.items() if k.startswith("SWSOPT_")}
 CASES = [("yuv420p",1920,1080,"yuv420p",3840,2160,SWS_BICUBIC),("yuv420p",1920,1080,"yuv420p",1280,720,SWS_BICUBIC),("yuv420p",3840,2160,"nv12",1920,1080,SWS_BICUBIC),
          ("nv12",1920,1080,"nv12",1280,720,SWS_BILINEAR),("yuv420p",1920,1080,"rgb24",1280,720,SWS_BICUBIC),("yuv420p10le",3840,2160,"yuv420p",1920,1080,SWS_LANCZOS),
          ("rgb24",1920,1080,"yuv420p",1280,720,SWS_BICUBIC),("yuv420p",1920,1080,"bgra",3840,2160,SWS_BICUBIC),("rgb24",3840,2160,"yuv420p",3840,2160,SWS_BICUBIC),
@@ -18,6 +19,7 @@ print("| conversion | path / kernel | ms / frame | Gpix/s out | GB/s (src + dst 
 print("|---|---|---|---|---|")
 for sf,sw,sh,df,dw,dh,fl in CASES:
     ctx = SwsContext(sw, sh, sf, dw, dh, df, fl | SWS_BITEXACT)
+    for k, v in OPTS.items(): ctx.set_option(k, v)
     hs = HostFrame(sf, sw, sh); src = OL.fill_random(OL.Frame(sf, sw, sh), 1)
     for a, b in zip(hs.planes, src.planes): a[:] = b
     srcs = [DeviceFrame(sf, sw, sh).upload(hs) for _ in range(N)]; dsts = [DeviceFrame(df, dw, dh) for _ in range(N)]
