@@ -66,10 +66,10 @@ static void dev_state_free(DeviceState *d)
         if (p) (void)hipFree(p);
     if (d->h_frames) (void)hipHostFree(d->h_frames);
     if (d->h_frames2) (void)hipHostFree(d->h_frames2);
-    if (d->spare_ptr[0]) (void)hipFree(d->spare_ptr[0]);
-    if (d->spare_ptr[3]) (void)hipFree(d->spare_ptr[3]);
-    if (d->spare_ptr[1]) (void)hipFree(d->spare_ptr[1]);
-    if (d->spare_ptr[2]) (void)hipHostFree(d->spare_ptr[2]);
+    if (d->join_img) (void)hipFree(d->join_img);
+    if (d->split_img) (void)hipFree(d->split_img);
+    if (d->d_aux_tables) (void)hipFree(d->d_aux_tables);
+    if (d->h_aux_tables) (void)hipHostFree(d->h_aux_tables);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
     if (d->ev_loan) (void)hipEventDestroy(d->ev_loan);
@@ -271,12 +271,12 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     // ---- packed 4:2:2 SOURCES (yuyv422 / uyvy422 / yvyu422: cameras, capture cards) through the planar kernels: yuy2ToY_c / yuy2ToUV_c / uyvyToY_c /
     //      uyvyToUV_c / yvy2ToUV_c (input.c:550-578, :890-907) copy bytes, so a streaming de-interleave into a planar 4:2:2 working picture per frame
     //      (yuyvtoyuv422_c / uyvytoyuv422_c of the layout kernel) followed by the kernels of a planar 8-bit source is the same arithmetic ----
-    d->spare_i[3] = 0;
+    d->split_mode = 0;
     if (c->plan == PLAN_MAIN && p.srcKind == SRCK_PACKED422 && ds->comp[0].depth == 8 && !(o.src_w & 1) && !gray_any && !(o.flags & SWS_SRC_V_CHR_DROP_MASK) &&
         !c->tune.no_mixed && !c->tune.no_layout_stream) {
         p.srcKind = SRCK_PLANAR8;
         p.u_plane_src = 1; p.v_plane_src = 2;
-        d->spare_i[3] = (ds->comp[0].offset == 1 ? 2 : 1) | (ds->comp[2].offset < ds->comp[1].offset ? 4 : 0);   // 1 yuyv-like, 2 uyvy; 4: V before U (yvyu422)
+        d->split_mode = (ds->comp[0].offset == 1 ? 2 : 1) | (ds->comp[2].offset < ds->comp[1].offset ? 4 : 0);   // 1 yuyv-like, 2 uyvy; 4: V before U (yvyu422)
     }
     // ---- semi-planar 8-bit sources (nv12 / nv21 / nv16 / nv24 / nv42: what the hardware decoders deliver) scaled into the packed-RGB LUT writers:
     //      nvXXtoUV_c (input.c:926-948) de-interleaves bytes, so the chroma plane is split into planar working planes first and the conversion takes the
@@ -284,7 +284,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     if (c->plan == PLAN_MAIN && p.srcKind == SRCK_NV12 && c->srcBpc == 8 && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !((o.flags & SWS_FULL_CHR_H_INT)) &&
         !(bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14)) && !gray_any && !(o.flags & SWS_SRC_V_CHR_DROP_MASK) && !(o.flags & SWS_FAST_BILINEAR) &&
         !c->tune.no_mixed && !c->tune.no_layout_stream && !c->tune.no_strip) {
-        d->spare_i[3] = 8 | (p.uv_swap_src ? 16 : 0);
+        d->split_mode = 8 | (p.uv_swap_src ? 16 : 0);
         p.srcKind = SRCK_PLANAR8;
         p.u_plane_src = 1; p.v_plane_src = 2; p.uv_swap_src = 0;
     }
@@ -293,11 +293,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     if (c->plan == PLAN_MAIN && p.srcKind == SRCK_P010 && p.src_depth <= 15 && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !((o.flags & SWS_FULL_CHR_H_INT)) &&
         !(bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14)) && !gray_any && !(o.flags & SWS_SRC_V_CHR_DROP_MASK) && !(o.flags & SWS_FAST_BILINEAR) &&
         !c->tune.no_mixed && !c->tune.no_layout_stream && !c->tune.no_strip) {
-        d->spare_i[3] = 32; d->spare_i[6] = p.src_shift;
+        d->split_mode = 32; d->split_shift = p.src_shift;
         p.srcKind = SRCK_PLANAR16; p.src_shift = 0;
         p.u_plane_src = 1; p.v_plane_src = 2; p.uv_swap_src = 0;
     }
-    d->spare_i[0] = 0;
+    d->join422 = 0;
     if (c->plan == PLAN_MAIN && p.dstKind == DSTK_PACKED422 && dd->comp[0].depth == 8 && !(o.dst_w & 1) && !p.should_dither && !c->needAlpha && !gray_any &&
         !((c->vLum.size == 1 || c->vLum.size == 2) && c->vChr.size == 2) && !c->tune.no_mixed && !c->tune.no_layout_stream &&
         // (one tap on ONE side only: the packed X form multiplies by the bank's value, which initFilter's normalisation leaves at 4095 in some
@@ -306,7 +306,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         const bool uyvy = dd->comp[0].offset == 1, vfirst = dd->comp[2].offset < dd->comp[1].offset;   // (yvyu422: V before U)
         p.dstKind = DSTK_PLANAR8;
         p.u_plane_dst = vfirst ? 2 : 1; p.v_plane_dst = vfirst ? 1 : 2;
-        d->spare_i[0] = uyvy ? 2 : 1;
+        d->join422 = uyvy ? 2 : 1;
     }
     p.full_chr = ((o.flags & SWS_FULL_CHR_H_INT) && isAnyRGB(o.dst_format)) ? 1 : 0;
     if (p.srcKind == SRCK_PACKEDHI)
@@ -987,8 +987,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     }
     default: c->path_name = "none"; c->kernel_name = ""; break;
     }
-    if (c->plan == PLAN_MAIN && d->spare_i[3]) c->path_name = ((d->spare_i[3] & 40) ? "main:splitnv+" : "main:split422+") + c->path_name.substr(c->path_name.find(':') + 1);
-    if (c->plan == PLAN_MAIN && d->spare_i[0]) c->path_name += "+join422";
+    if (c->plan == PLAN_MAIN && d->split_mode) c->path_name = ((d->split_mode & 40) ? "main:splitnv+" : "main:split422+") + c->path_name.substr(c->path_name.find(':') + 1);
+    if (c->plan == PLAN_MAIN && d->join422) c->path_name += "+join422";
     // (16-byte aligned pictures of the layout converters take the streaming kernel, k_layout.hip; the names above are the fallback's)
     if (!c->tune.no_layout_stream && (c->plan == PLAN_UNSC_PLANAR2NV12 || c->plan == PLAN_UNSC_NV122PLANAR || c->plan == PLAN_UNSC_PLANARCOPY || c->plan == PLAN_UNSC_PLANAR2NV24 ||
                                       c->plan == PLAN_UNSC_NV242PLANAR || c->plan == PLAN_UNSC_P4222PLANAR || c->plan == PLAN_UNSC_PLANAR2P422))
@@ -1122,9 +1122,9 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
     // frame tables of the helper passes around a packed 4:2:2 side (slot 0: the interleave behind the kernels, slot 1: the de-interleave ahead of
     // them): one device block and one pinned host block of two tables, each cached like d_frames
     auto aux_table = [&](int slot, const std::vector<SwsFramePtrs> &v, const SwsFramePtrs **out) -> int {
-        SwsFramePtrs *&dtab = reinterpret_cast<SwsFramePtrs *&>(d->spare_ptr[1]), *&htab = reinterpret_cast<SwsFramePtrs *&>(d->spare_ptr[2]);
-        int &cap = d->spare_i[1];
-        int *valid = &d->spare_i[4];   // [slot]
+        SwsFramePtrs *&dtab = d->d_aux_tables, *&htab = d->h_aux_tables;
+        int &cap = d->aux_cap;
+        int *valid = d->aux_valid;     // [slot]
         if (n > cap) {
             if (dtab) HIPCHK(hipFree(dtab));
             if (htab) HIPCHK(hipHostFree(htab));
@@ -1146,18 +1146,18 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
     // packed 4:2:2 source through the planar kernels (dev_prepare_on): de-interleave into a planar 4:2:2 working picture per frame first
     std::vector<SwsFramePtrs> s422fr, s422split;
     bool timing_started = false;
-    if (c->plan == PLAN_MAIN && d->spare_i[3]) {
+    if (c->plan == PLAN_MAIN && d->split_mode) {
         auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
-        const bool nv = (d->spare_i[3] & 8) != 0;    // semi-planar 8-bit source: only the chroma plane is split, the luma plane stays where it is
-        const bool p01x = (d->spare_i[3] & 32) != 0; // semi-planar 10 / 12-bit source: both planes (every word is shifted down)
+        const bool nv = (d->split_mode & 8) != 0;    // semi-planar 8-bit source: only the chroma plane is split, the luma plane stays where it is
+        const bool p01x = (d->split_mode & 32) != 0; // semi-planar 10 / 12-bit source: both planes (every word is shifted down)
         const int sY = nv ? 0 : (int)a256(p01x ? 2 * p.srcW : p.srcW), sC = (int)a256(p01x ? 2 * p.chrSrcW : nv ? p.chrSrcW : p.srcW >> 1), crows = (nv || p01x) ? p.chrSrcH : p.srcH;
         const int64_t offU = (int64_t)sY * p.srcH, offV = offU + (int64_t)sC * crows, fbytes = a256(offV + (int64_t)sC * crows);
-        int r = grow(c, &d->spare_ptr[3], &d->spare_sz[3], (size_t)fbytes * (size_t)n);
+        int r = grow(c, &d->split_img, &d->split_bytes, (size_t)fbytes * (size_t)n);
         if (r < 0) return r;
         s422fr.assign(frames, frames + n);
         s422split.resize((size_t)n);
         for (int i = 0; i < n; i++) {
-            uint8_t *base = (uint8_t *)d->spare_ptr[3] + (size_t)i * (size_t)fbytes;
+            uint8_t *base = (uint8_t *)d->split_img + (size_t)i * (size_t)fbytes;
             SwsFramePtrs &a = s422fr[(size_t)i], &j = s422split[(size_t)i];
             std::memset(&j, 0, sizeof(j));
             if (nv || p01x) { j.src[1] = a.src[1]; j.srcStride[1] = a.srcStride[1]; }
@@ -1173,23 +1173,23 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         if (n == 1) { S.fs.table = nullptr; S.fs.one = s422split[0]; }
         else { const SwsFramePtrs *t = nullptr; r = aux_table(1, s422split, &t); if (r < 0) return r; S.fs.table = t; }
         if (d->timing) { HIPCHK(hipEventRecord(d->ev0, st)); timing_started = true; }
-        if (p01x) launch_layout_splitp01x(S, d->spare_i[6]);
-        else if (nv) launch_layout_splitnv(S, (d->spare_i[3] & 16) != 0);
-        else launch_layout_split422(S, (d->spare_i[3] & 3) == 2, (d->spare_i[3] & 4) != 0);
+        if (p01x) launch_layout_splitp01x(S, d->split_shift);
+        else if (nv) launch_layout_splitnv(S, (d->split_mode & 16) != 0);
+        else launch_layout_split422(S, (d->split_mode & 3) == 2, (d->split_mode & 4) != 0);
         frames = s422fr.data();
     }
     // packed 4:2:2 destination through planar writers (dev_prepare_on): the kernels write a planar 4:2:2 working picture per frame
     std::vector<SwsFramePtrs> p422fr, p422join;
-    if (c->plan == PLAN_MAIN && d->spare_i[0]) {
+    if (c->plan == PLAN_MAIN && d->join422) {
         auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
         const int sY = (int)a256(p.dstW), sC = (int)a256(p.dstW >> 1);
         const int64_t offU = (int64_t)sY * p.dstH, offV = offU + (int64_t)sC * p.dstH, fbytes = a256(offV + (int64_t)sC * p.dstH);
-        int r = grow(c, &d->spare_ptr[0], &d->spare_sz[0], (size_t)fbytes * (size_t)n);
+        int r = grow(c, &d->join_img, &d->join_bytes, (size_t)fbytes * (size_t)n);
         if (r < 0) return r;
         p422fr.assign(frames, frames + n);
         p422join.resize((size_t)n);
         for (int i = 0; i < n; i++) {
-            uint8_t *base = (uint8_t *)d->spare_ptr[0] + (size_t)i * (size_t)fbytes;
+            uint8_t *base = (uint8_t *)d->join_img + (size_t)i * (size_t)fbytes;
             SwsFramePtrs &a = p422fr[(size_t)i], &j = p422join[(size_t)i];
             std::memset(&j, 0, sizeof(j));
             j.dst[0] = a.dst[0]; j.dstStride[0] = a.dstStride[0];
@@ -1271,7 +1271,7 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         J.frames = p422join.data();
         if (n == 1) { J.fs.table = nullptr; J.fs.one = p422join[0]; }
         else { const SwsFramePtrs *t = nullptr; int r = aux_table(0, p422join, &t); if (r < 0) return r; J.fs.table = t; }
-        launch_layout_join422(J, d->spare_i[0] == 2);
+        launch_layout_join422(J, d->join422 == 2);
     }
     HIPCHK(hipGetLastError());
     if (d->timing) { HIPCHK(hipEventRecord(d->ev1, st)); d->timed = true; }
@@ -2198,6 +2198,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "strip_waves", &c->tune.strip_waves }, { "strip_rgb_cols", &c->tune.strip_rgb_cols }, { "rgb_march_waves", &c->tune.rgb_march_waves }, { "tile_lds_kb", &c->tune.tile_lds_kb },
         { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "layout_ch", &c->tune.layout_ch }, { "no_mixed", &c->tune.no_mixed }, { "no_layout_stream", &c->tune.no_layout_stream }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
         { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
+        { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse },
         { "debug", &c->tune.debug },
     };
     for (auto &e : tab)

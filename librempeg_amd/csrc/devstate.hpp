@@ -47,7 +47,13 @@ struct DeviceState {
     // reads them through a second frame table (k_strip.hip launch_rgbread_strip)
     bool rgbread_on = false; void *rgbread_img = nullptr; size_t rgbread_bytes = 0;
     SwsFramePtrs *d_frames2 = nullptr, *h_frames2 = nullptr; int frames2_cap = 0, frames2_valid = 0;
-    void *spare_ptr[4] = { nullptr, nullptr, nullptr, nullptr }; size_t spare_sz[4] = { 0, 0, 0, 0 }; int spare_i[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    // helper passes around a packed / semi-planar side of the scaler (dev_prepare_on decides, launch_plan_le runs them):
+    int join422 = 0;                                   // packed 4:2:2 destination through the planar writers + interleave: 1 yuyv-like, 2 uyvy
+    void *join_img = nullptr; size_t join_bytes = 0;   //   its planar 4:2:2 working pictures (one per frame of the call)
+    int split_mode = 0, split_shift = 0;               // source split into planar working planes: 1 / 2 packed 4:2:2 (yuyv-like / uyvy) | 4 V first; 8 semi-planar 8-bit
+                                                       //   chroma | 16 V first; 32 p010-style planes, every word >> split_shift
+    void *split_img = nullptr; size_t split_bytes = 0;
+    SwsFramePtrs *d_aux_tables = nullptr, *h_aux_tables = nullptr; int aux_cap = 0, aux_valid[2] = { 0, 0 };   // frame tables of the two passes (slot 0 join, 1 split)
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timing = false; bool timed = false;
     hipEvent_t ev_loan = nullptr;   // orders the context's own stream against a borrowed frames stream (dev_borrow_stream)
 };

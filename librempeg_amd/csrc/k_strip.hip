@@ -19,7 +19,7 @@ int launch_strip_planes(const LaunchCtx &L, int which)
                 // one resident round of waves; bands of at least `minrows` output rows.  The floor matters for ONE frame per call (what a filter
                 // chain issues): the kernel's time is then the serial walk of a wave (ring fill + one step per source row pair), not throughput,
                 // and the machine is otherwise idle -- 4-row bands: a 1080p plane is 2000 waves of 7 steps instead of 540 waves of 19
-                const int minrows = (c->tune.debug >> 8) & 63 ? (c->tune.debug >> 8) & 63 : 4;
+                const int minrows = std::max(1, c->tune.strip_min_rows);
                 int bands = std::max(1, std::min(target / std::max(1, g.strips * n), (H + minrows - 1) / minrows));
                 g.debug = c->tune.debug;
                 g.band_rows = (H + bands - 1) / bands;
@@ -57,9 +57,9 @@ int launch_strip_planes(const LaunchCtx &L, int which)
             // in one resident round, i.e. a few frames: such a call is launch- and tail-bound (two launches of about 8 us around 10 - 20 us of work; one 4K -> 1080p
             // frame 34 -> 25 us, 1080p -> 720p 22 -> 15 us).  Larger calls keep the two launches: the combined kernel carries both bodies' registers
             // (128 VGPRs and a few spills) and measured 15 - 35 % slower per frame on batches (C3b x32: 1.217 vs 0.898 ms).
-            const int minrows_f = (c->tune.debug >> 8) & 63 ? (c->tune.debug >> 8) & 63 : 4;
+            const int minrows_f = std::max(1, c->tune.strip_min_rows);
             const int64_t wave_rows = ((int64_t)d->stripL.strips * p.dstH + (int64_t)d->stripC.strips * p.chrDstH) * n;     // rows of 256 samples, all waves together
-            if (which == 3 && d->stripL.TW == 256 && d->stripC.TW == 128 && d->stripC.npv <= 8 && !(c->tune.debug & 0x10000) &&
+            if (which == 3 && d->stripL.TW == 256 && d->stripC.TW == 128 && d->stripC.npv <= 8 && !c->tune.no_strip_fuse &&
                 (wave_rows + target - 1) / target <= 6 * minrows_f) {
                 SwsStripGeom gl = d->stripL, gc = d->stripC;
                 const int minrows = minrows_f;

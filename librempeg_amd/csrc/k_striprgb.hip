@@ -36,7 +36,7 @@ int SRGB_CAT(launch_striprgb_b, SRGB_BPP, SRGB_RL)(const LaunchCtx &L)
     SwsStripGeom gl = d->stripRL, gc = d->stripRC;
     // one resident round of waves; bands of at least 16 rows (the ring fill at the top of a band costs npv row pairs per plane)
     const int target = c->tune.strip_waves, H = p.dstH;
-    const int minrows = (c->tune.debug >> 8) & 63 ? (c->tune.debug >> 8) & 63 : 4;    // (few frames per call: short bands, see k_strip.hip)
+    const int minrows = std::max(1, c->tune.strip_min_rows);    // (few frames per call: short bands, see k_strip.hip)
     int bands = std::max(1, std::min(target / std::max(1, gl.strips * n), (H + minrows - 1) / minrows));
     gl.band_rows = (H + bands - 1) / bands;
     gl.bands = (H + gl.band_rows - 1) / gl.band_rows;

@@ -102,6 +102,8 @@ struct DeviceState;  // HIP side (devstate.hpp)
 struct Tuning {
     int strip_min_w = 1024;        // narrower pictures stay on the LDS-tile kernel
     int strip_cols_l = 4, strip_cols_c = 2, strip_waves = 4096;
+    int strip_min_rows = 4;        // shortest band of a strip-kernel launch (few frames per call: the serial walk of a wave is what a call waits for)
+    int no_strip_fuse = 0;         // off: small calls put the luma and the chroma launch into one grid
     int strip_rgb_cols = 4;        // luma columns per lane of the strip kernel with the RGB epilogue (4: 256-pixel strips, 2: 128-pixel strips)
     int rgb_march_waves = 12288;   // resident waves the packed-RGB march kernel is banded for
     int tile_lds_kb = 40, tile_threads = 256;
