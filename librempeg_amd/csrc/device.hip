@@ -584,7 +584,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             const bool mixedM = !vlines_pending && bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !(d->unity_h && d->unity_v) &&
                                 !p.fast_bilinear && !gray_any && (src_ok || nv_src) && dst_ok && !p.wide && !p.range_active && !p.dst_alpha_fill &&
                                 fs2(c->hChr.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long) && !c->tune.no_strip && !c->tune.no_mixed && p.dstW >= c->tune.strip_min_w;
-            const bool fullA = !mixedM && !d->unity_h && !p.fast_bilinear && (!gray_any || gray_both) && (src_ok || (nv_src && dst_ok) || rgbread) &&
+            // (identity horizontal filters: 8-bit sources have kernels of their own -- sws_k_rgb_march, sws_k_rgbsrc_unity, the mixed plan -- but a 10-bit
+            //  picture into packed RGB (decoded HDR for display) or packed RGB into a 10-bit 4:2:0 picture at the same size had only the generic
+            //  kernels: the strip kernels take them with their one-tap horizontal banks)
+            const bool unity_ok = !d->unity_h || (rgb_ok && rgb_s16) || (rgbread && !d->rgbsrc_ok && !d->rgb444_ok);   // (sws_k_rgbsrc_unity's row table lives in the same device block as the strip plan)
+            const bool fullA = !mixedM && unity_ok && !(d->unity_h && d->unity_v && !rgb_ok) && !p.fast_bilinear && (!gray_any || gray_both) && (src_ok || (nv_src && dst_ok) || rgbread) &&
                                (dst_ok || rgb_ok) && !p.wide &&
                                fs2(c->hLum.size) <= 16 && (fs2(c->hChr.size) <= 16 || gray_both) && fs2(c->vLum.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long || gray_both) && !c->tune.no_dot2;
             d->mixed_ok = false;
@@ -965,13 +969,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             c->path_name = "main:rgbsrc_unity"; c->kernel_name = "sws_k_rgbsrc_unity";
         } else if (d->rgb444_ok) {
             c->path_name = "main:rgb_yuv444_unity"; c->kernel_name = "sws_k_rgb_yuv444_unity";
-        } else if (d->mixed_ok) {
-            c->path_name = "main:plane1+strip_chroma"; c->kernel_name = "sws_k_strip_march";
-        } else if (d->unity_h) {
-            c->path_name = "main:fused_generic_unity";
-            c->kernel_name = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) ? "sws_k_vscale_rgb" : "sws_k_vscale_planar";
         } else if (d->striprgb_ok) {
             c->path_name = "main:strip_rgb"; c->kernel_name = "sws_k_strip_rgb";
+        } else if (d->mixed_ok) {
+            c->path_name = "main:plane1+strip_chroma"; c->kernel_name = "sws_k_strip_march";
         } else if (d->strip_ok) {
             c->path_name = d->rgbread_on ? "main:rgbread+strip_march" : "main:strip_march";
             c->kernel_name = ((p.srcKind == SRCK_PLANAR16 || d->rgbread_on) && d->stripL.dma_ok && !c->tune.no_strip_dma) ? "sws_k_strip_dma" : "sws_k_strip_march";
@@ -979,6 +980,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             c->path_name = "main:fused_tile_dot2"; c->kernel_name = "sws_k_tile_dot2";
         } else if (d->tile_ok) {
             c->path_name = "main:fused_tile"; c->kernel_name = "sws_k_tile_planar";
+        } else if (d->unity_h) {
+            c->path_name = "main:fused_generic_unity";
+            c->kernel_name = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) ? "sws_k_vscale_rgb" : "sws_k_vscale_planar";
         } else {
             c->path_name = "main:two_pass";
             c->kernel_name = "sws_k_hscale";

@@ -150,3 +150,23 @@ def test_p01x_sources_into_rgb(src, dst):
             assert r[0].startswith("main:splitnv+"), (r[0], src, dst, sw, dw)
     assert run_case(1920, 1080, src, 1280, 720, dst, SWS_BICUBIC | BX, seed=7)[0] == "main:splitnv+strip_rgb"
     assert not run_case(256, 64, src, 256, 64, dst, SWS_BICUBIC | BX, seed=8)[0].startswith("main:splitnv+")
+
+
+def test_same_size_10bit_pictures_and_packed_rgb():
+    """identity horizontal filters: a 10 / 12-bit 4:2:x picture into packed RGB (decoded HDR for display) takes the 16-bit strip kernel with the RGB
+    epilogue, packed RGB into a 10-bit 4:2:0 picture the reader pre-pass + strip kernel (the 8-bit twins have kernels of their own)"""
+    for src in ("yuv420p10le", "yuv422p10le", "yuv420p12le", "yuv420p9le"):
+        for dst in ("rgb24", "bgra", "argb", "bgr24"):
+            for (w, h, fl) in ((256, 64, SWS_BICUBIC), (322, 50, SWS_LANCZOS), (130, 34, SWS_BICUBIC | SWS_ACCURATE_RND), (64, 18, SWS_BILINEAR), (131, 33, SWS_BICUBIC)):
+                r = run_case(w, h, src, w, h, dst, fl | BX, seed=w)
+                # (a 4:2:2 source has one luma and one chroma tap here: the packed writers' one-tap form, which rounds differently from the X form of this kernel)
+                if fl & SWS_BICUBIC and not w & 1 and "420" in src:
+                    assert r[0] == "main:strip_rgb", (r[0], src, dst, w)
+    for src in ("rgb24", "bgra", "argb", "gbrp"):
+        for dst in ("yuv420p10le", "yuv422p10le", "p010le", "yuv420p12le"):
+            for (w, h, fl) in ((256, 64, SWS_BICUBIC), (324, 50, SWS_LANCZOS), (132, 34, SWS_BICUBIC | SWS_ACCURATE_RND), (64, 18, SWS_BILINEAR), (130, 33, SWS_BICUBIC)):
+                r = run_case(w, h, src, w, h, dst, fl | BX, seed=w, tune=TUNE)
+                if not w & 3 and "422" not in dst:      # (4:2:2: every filter is the identity, the generic one-pass kernel keeps it)
+                    assert r[0] == "main:rgbread+strip_march", (r[0], src, dst, w)
+    assert run_case(1920, 1080, "yuv420p10le", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=3)[0] == "main:strip_rgb"
+    assert run_case(1920, 1080, "bgra", 1920, 1080, "yuv420p10le", SWS_BICUBIC | BX, seed=4)[0] == "main:rgbread+strip_march"
