@@ -309,6 +309,16 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         d->join422 = uyvy ? 2 : 1;
     }
     p.full_chr = ((o.flags & SWS_FULL_CHR_H_INT) && isAnyRGB(o.dst_format)) ? 1 : 0;
+    // ---- full-chroma 24 / 32 bpp RGB destinations (RGB -> RGB scaling, 4:4:4 sources, odd widths, the user's full_chroma_int) through the strip kernels:
+    //      Y, U and V are all scaled to the destination size; the kernels store their vertical sums as int32 planes (DSTK_RAW32) into a working picture
+    //      per frame and sws_k_fullchr_rgb finishes yuv2rgb_full_X_c_template.  Tentative: undone below when no strip plan fits or a row takes one of
+    //      the writer's short forms ----
+    d->fullchr_on = 0;
+    if (c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && p.full_chr && !c->needAlpha && !gray_any && !(o.flags & SWS_FAST_BILINEAR) &&
+        o.dst_w >= c->tune.strip_min_w && !c->tune.no_strip && !c->tune.no_mixed) {
+        d->fullchr_on = 1; d->fullchr_kind = p.dstKind;
+        p.dstKind = DSTK_RAW32; p.u_plane_dst = 1; p.v_plane_dst = 2;
+    }
     if (p.srcKind == SRCK_PACKEDHI)
         for (int k = 0; k < ds->nb_components; k++) {
             p.shi_step[k] = ds->comp[k].step; p.shi_off[k] = ds->comp[k].offset; p.shi_shift[k] = ds->comp[k].shift;
@@ -556,7 +566,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // nv12 / nv21, p010 / p012 (and the 4:2:2 / 4:4:4 twins): the strip kernel de-interleaves plane 1 (and shifts the p01x samples down) while
             // staging; the dot2 tile kernel does not
             const bool nv_src = (p.srcKind == SRCK_NV12 && c->srcBpc == 8) || (p.srcKind == SRCK_P010 && p.src_depth <= 15);
-            const bool dst_ok = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010;
+            const bool dst_ok = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010 || p.dstKind == DSTK_RAW32;
             auto fs2 = [](int fs) { return (fs + 2) & ~1; };
             // packed 24 / 32 bpp RGB through the LUT writers (not the full-chroma ones): the strip kernel with the RGB epilogue
             // (9 .. 15-bit planar sources too -- decoded HDR pictures for display: 128-column strips, a window of at most 64 eight-sample chunks)
@@ -581,7 +591,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             const bool gray_both = isGray(o.src_format) && isGray(o.dst_format) && !c->needAlpha && src_ok && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && !c->tune.no_strip;
             // identity luma filters + scaled chroma (yuv422p -> yuv420p, yuv444p -> yuv420p, the 10-bit -> 8-bit twins ...): the luma plane streams
             // (one tap: a per-sample pass), only the chroma planes need the strip kernel
-            const bool mixedM = !vlines_pending && bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !(d->unity_h && d->unity_v) &&
+            const bool mixedM = !vlines_pending && !d->fullchr_on && bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !(d->unity_h && d->unity_v) &&
                                 !p.fast_bilinear && !gray_any && (src_ok || nv_src) && dst_ok && !p.wide && !p.range_active && !p.dst_alpha_fill &&
                                 fs2(c->hChr.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long) && !c->tune.no_strip && !c->tune.no_mixed && p.dstW >= c->tune.strip_min_w;
             // (identity horizontal filters: 8-bit sources have kernels of their own -- sws_k_rgb_march, sws_k_rgbsrc_unity, the mixed plan -- but a 10-bit
@@ -687,13 +697,13 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     return true;
                 };
                 SOff sL, sC;
-                const bool chr_plane1 = p.dstKind != DSTK_NV12 && p.dstKind != DSTK_P010;
+                const bool chr_plane1 = p.dstKind != DSTK_NV12 && p.dstKind != DSTK_P010 && p.dstKind != DSTK_RAW32, lum_plane1 = p.dstKind != DSTK_RAW32;   // (raw sums: the packed X form's own taps)
                 const int strip_cols_l = c->tune.strip_cols_l == 2 ? 2 : 4;
                 const int strip_cols_c = c->tune.strip_cols_c == 1 ? 1 : 2;
                 // (narrow pictures leave most of a 256-column strip idle and pay the per-band ring fill: the tile kernel keeps them)
                 const int strip_min_w = c->tune.strip_min_w;
                 const bool strip_plan = fullA && dst_ok && !p.range_active && !c->tune.no_strip && p.dstW >= strip_min_w &&
-                                        plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sL, nullptr, true) &&
+                                        plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sL, nullptr, lum_plane1) &&
                                         (gray_both || plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sC, nullptr, chr_plane1));
                 d->strip_ok = false;
                 log_msg(c, 3, "strip plan: %d (windows %d/%d chunks of %d, taps %d/%d x %d/%d)\n", strip_plan, d->stripL.NCmax / SPC, d->stripC.NCmax / SPC, SPC,
@@ -771,7 +781,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         g.hT2 = (const int16_t *)(b + o.ht); g.vT2 = (const int16_t *)(b + o.vt);
                     };
                     if (tiles) { bind(d->dotL, oL); bind(d->dotC, oC); }
-                    d->dot2_ok = tiles && src_ok && fs2(c->vChr.size) <= 16 && c->vLum.size >= 2 && c->vChr.size >= 2;
+                    d->dot2_ok = tiles && src_ok && fs2(c->vChr.size) <= 16 && c->vLum.size >= 2 && c->vChr.size >= 2 && !d->fullchr_on;
                     if (strip_plan) {
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         d->stripL.colStart = (const int32_t *)(b + sL.cs); d->stripL.colCount = (const int32_t *)(b + sL.cc);
@@ -854,6 +864,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             }
             d->all_x_mode = all_x;
             d->striprgb_ok = d->striprgb_ok && all_x;
+            if (d->fullchr_on && (!all_x || !d->strip_ok)) {   // no strip plan, or a row in one of the short writer forms: the generic full-chroma writer keeps it
+                d->fullchr_on = 0; d->strip_ok = false; d->rgbread_on = false;
+                p.dstKind = d->fullchr_kind; p.u_plane_dst = dd->comp[1].plane; p.v_plane_dst = dd->comp[2].plane;
+            }
             int win = 0;
             for (int y = 0; y < o.dst_h; y += 2) {
                 const int c0 = y >> c->chrDstVSubSample, c1 = std::min(y + 1, o.dst_h - 1) >> c->chrDstVSubSample;
@@ -993,6 +1007,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     }
     if (c->plan == PLAN_MAIN && d->split_mode) c->path_name = ((d->split_mode & 40) ? "main:splitnv+" : "main:split422+") + c->path_name.substr(c->path_name.find(':') + 1);
     if (c->plan == PLAN_MAIN && d->join422) c->path_name += "+join422";
+    if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += "+fullchr_rgb";
     // (16-byte aligned pictures of the layout converters take the streaming kernel, k_layout.hip; the names above are the fallback's)
     if (!c->tune.no_layout_stream && (c->plan == PLAN_UNSC_PLANAR2NV12 || c->plan == PLAN_UNSC_NV122PLANAR || c->plan == PLAN_UNSC_PLANARCOPY || c->plan == PLAN_UNSC_PLANAR2NV24 ||
                                       c->plan == PLAN_UNSC_NV242PLANAR || c->plan == PLAN_UNSC_P4222PLANAR || c->plan == PLAN_UNSC_PLANAR2P422))
@@ -1182,8 +1197,27 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         else launch_layout_split422(S, (d->split_mode & 3) == 2, (d->split_mode & 4) != 0);
         frames = s422fr.data();
     }
-    // packed 4:2:2 destination through planar writers (dev_prepare_on): the kernels write a planar 4:2:2 working picture per frame
+    // full-chroma RGB destination (dev_prepare_on): the strip kernels write three int32 sum planes per frame, sws_k_fullchr_rgb follows
     std::vector<SwsFramePtrs> p422fr, p422join;
+    if (c->plan == PLAN_MAIN && d->fullchr_on) {
+        auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
+        const int sP = (int)a256(4 * (int64_t)p.dstW);
+        const int64_t plane = (int64_t)sP * p.dstH, fbytes = a256(3 * plane);
+        int r = grow(c, &d->join_img, &d->join_bytes, (size_t)fbytes * (size_t)n);
+        if (r < 0) return r;
+        p422fr.assign(frames, frames + n);
+        p422join.resize((size_t)n);
+        for (int i = 0; i < n; i++) {
+            uint8_t *base = (uint8_t *)d->join_img + (size_t)i * (size_t)fbytes;
+            SwsFramePtrs &a = p422fr[(size_t)i], &j = p422join[(size_t)i];
+            std::memset(&j, 0, sizeof(j));
+            j.dst[0] = a.dst[0]; j.dstStride[0] = a.dstStride[0];
+            for (int k = 0; k < 3; k++) { j.src[k] = base + k * plane; j.srcStride[k] = sP; a.dst[k] = base + k * plane; a.dstStride[k] = sP; }
+            a.dst[3] = nullptr; a.dstStride[3] = 0;
+        }
+        frames = p422fr.data();
+    }
+    // packed 4:2:2 destination through planar writers (dev_prepare_on): the kernels write a planar 4:2:2 working picture per frame
     if (c->plan == PLAN_MAIN && d->join422) {
         auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
         const int sY = (int)a256(p.dstW), sC = (int)a256(p.dstW >> 1);
@@ -1275,7 +1309,8 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         J.frames = p422join.data();
         if (n == 1) { J.fs.table = nullptr; J.fs.one = p422join[0]; }
         else { const SwsFramePtrs *t = nullptr; int r = aux_table(0, p422join, &t); if (r < 0) return r; J.fs.table = t; }
-        launch_layout_join422(J, d->join422 == 2);
+        if (d->fullchr_on) launch_fullchr_rgb(J);
+        else launch_layout_join422(J, d->join422 == 2);
     }
     HIPCHK(hipGetLastError());
     if (d->timing) { HIPCHK(hipEventRecord(d->ev1, st)); d->timed = true; }

@@ -52,6 +52,8 @@ enum DstKind {
     DSTK_RGB8,          // rgb8 / bgr8 / rgb4_byte / bgr4_byte (one byte per pixel): yuv2rgb_write "8/4 bits" output.c:1755-1784, yuv2rgb_write_full :2064-2158
     DSTK_RGB4,          // rgb4 / bgr4 (two pixels per byte): yuv2rgb_write output.c:1778-1780
     DSTK_RGB16,         // rgb565 / rgb555 / rgb444 (+ bgr): yuv2rgb_write 16/15/12 bpp with ordered dither output.c:1714-1748
+    DSTK_RAW32,         // not a pixel format: the vertical sums of the strip kernels as int32 planes (Y, U, V at the destination size), the input of the
+                        // full-chroma RGB epilogue (sws_k_fullchr_rgb: yuv2rgb_full_X_c_template + yuv2rgb_write_full, output.c:2005-2070, :2163-2207)
 };
 
 struct SwsFramePtrs {       // one frame: plane base pointers (device addresses) and byte strides

@@ -48,6 +48,7 @@ struct DeviceState {
     bool rgbread_on = false; void *rgbread_img = nullptr; size_t rgbread_bytes = 0;
     SwsFramePtrs *d_frames2 = nullptr, *h_frames2 = nullptr; int frames2_cap = 0, frames2_valid = 0;
     // helper passes around a packed / semi-planar side of the scaler (dev_prepare_on decides, launch_plan_le runs them):
+    int fullchr_on = 0, fullchr_kind = 0;              // full-chroma packed RGB destination: the strip kernels write int32 sum planes (DSTK_RAW32), sws_k_fullchr_rgb follows; the real dstKind
     int join422 = 0;                                   // packed 4:2:2 destination through the planar writers + interleave: 1 yuyv-like, 2 uyvy
     void *join_img = nullptr; size_t join_bytes = 0;   //   its planar 4:2:2 working pictures (one per frame of the call)
     int split_mode = 0, split_shift = 0;               // source split into planar working planes: 1 / 2 packed 4:2:2 (yuyv-like / uyvy) | 4 V first; 8 semi-planar 8-bit
@@ -121,6 +122,7 @@ int  launch_f32rgb(const LaunchCtx &L);
 int  launch_strip(const LaunchCtx &L);
 int  launch_rgbsrc(const LaunchCtx &L);
 int  launch_rgbread_strip(const LaunchCtx &L);   // k_strip.hip: scaled packed 24 / 32 bpp RGB source: reader pre-pass + strip kernel on its 16-bit planes
+void launch_fullchr_rgb(const LaunchCtx &L);   // k_stream.hip
 void launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, int64_t offU, int64_t offV, int strideY, int strideC);   // k_stream.hip
 int  launch_striprgb(const LaunchCtx &L);
 int  launch_tile_dot2(const LaunchCtx &L);

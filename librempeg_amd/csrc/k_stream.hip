@@ -87,6 +87,15 @@ void launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, i
     }
 }
 
+// the full-chroma RGB epilogue behind the strip kernels (dev_prepare_on: fullchr_on; L.fs holds {src = the int32 sum planes, dst = the packed picture})
+void launch_fullchr_rgb(const LaunchCtx &L)
+{
+    const SwsDevParams &p = *L.p;
+    const dim3 grid(cdiv(cdiv(p.dstW, 4), 256), cdiv(p.dstH, swsk::FULLCHR_RPW), L.n), blk(256);
+    if (p.lut.pix_step == 4) hipLaunchKernelGGL((swsk::sws_k_fullchr_rgb<4>), grid, blk, 0, L.st, L.fs, p);
+    else hipLaunchKernelGGL((swsk::sws_k_fullchr_rgb<3>), grid, blk, 0, L.st, L.fs, p);
+}
+
 // packed / planar 8-bit RGB -> planar 8-bit 4:4:4 YUV of the same size: every filter the identity (dev_prepare_on: rgb444_ok)
 int launch_rgb444(const LaunchCtx &L)
 {

@@ -84,6 +84,70 @@ __global__ void __launch_bounds__(256) sws_k_f32rgb_to_yuv444_unity(SwsFrameSet 
 }
 
 // ------------------------------------------------------------------------------------------
+// Full-chroma packed RGB epilogue (SWS_FULL_CHR_H_INT: RGB -> RGB scaling, 4:4:4 sources, odd widths, the user's full_chroma_int): the strip kernels
+// leave the vertical sums of Y, U and V -- all three at the destination size -- as int32 planes (DSTK_RAW32); this pass is
+// yuv2rgb_full_X_c_template's tail and yuv2rgb_write_full for the 24 / 32 bpp targets (output.c:2163-2207, :2005-2070): Y = (sum + (1 << 9)) >> 10,
+// U / V = (sum + (1 << 9) - (128 << 19)) >> 10, the 30-bit matrix with wrap-around 32-bit arithmetic, clip, >> 22.  Lane = four pixels (three 16-byte
+// loads), a wave walks down FULLCHR_RPW rows with the next row's loads in flight; 12- or 16-byte stores.
+// ------------------------------------------------------------------------------------------
+constexpr int FULLCHR_RPW = 4;
+template <int BPP>
+__global__ void __launch_bounds__(256) sws_k_fullchr_rgb(SwsFrameSet fs, SwsDevParams p)
+{
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int lane = threadIdx.x & 63;
+    const int cx = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = U(p.dstW), H = U(p.dstH);
+    if (cx * 256 >= W) return;
+    const int x = (cx * 64 + lane) * 4;
+    const bool in = x < W;
+    const int npx = min(4, W - x);
+    const int y0 = blockIdx.y * FULLCHR_RPW, y1 = min(H, y0 + FULLCHR_RPW);
+    const uint8_t *pY = f.src[0] + 4 * (int64_t)x, *pU = f.src[1] + 4 * (int64_t)x, *pV = f.src[2] + 4 * (int64_t)x;
+    const int64_t sY = f.srcStride[0], sU = f.srcStride[1], sV = f.srcStride[2];
+    const SwsLutParams &L = p.lut;
+    const int y_offset = U(L.y_offset), y_coeff = U(L.y_coeff), v2r = U(L.v2r), v2g = U(L.v2g), u2g = U(L.u2g), u2b = U(L.u2b);
+    const int r_pos = U(L.r_pos), g_pos = U(L.g_pos), b_pos = U(L.b_pos), a_pos = U(L.a_pos);
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 nY = { 0, 0, 0, 0 }, nU = nY, nV = nY;
+    auto fetch = [&](int y) {   // (the working planes are padded to whole 16-byte groups: no tail loads)
+        nY = *(const SWS_GLOBAL i32x4 *)(pY + y * sY); nU = *(const SWS_GLOBAL i32x4 *)(pU + y * sU); nV = *(const SWS_GLOBAL i32x4 *)(pV + y * sV);
+    };
+    if (in && y0 < y1) fetch(y0);
+    for (int y = y0; y < y1; y++) {
+        const i32x4 vY = nY, vU = nU, vV = nV;
+        if (in && y + 1 < y1) fetch(y + 1);
+        if (!in) continue;
+        uint32_t px[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int Y = (int)((unsigned)vY[k] + (1u << 9)) >> 10;
+            const int Uc = (int)((unsigned)vU[k] + (unsigned)((1 << 9) - (128 << 19))) >> 10, Vc = (int)((unsigned)vV[k] + (unsigned)((1 << 9) - (128 << 19))) >> 10;
+            Y -= y_offset;
+            Y = (int)((unsigned)Y * (unsigned)y_coeff);
+            Y = (int)((unsigned)Y + (1u << 21));
+            int R = (int)((unsigned)Y + (unsigned)Vc * (unsigned)v2r);
+            int G = (int)((unsigned)Y + (unsigned)Vc * (unsigned)v2g + (unsigned)Uc * (unsigned)u2g);
+            int B = (int)((unsigned)Y + (unsigned)Uc * (unsigned)u2b);
+            if ((R | G | B) & 0xC0000000) { R = clip_uintp2(R, 30); G = clip_uintp2(G, 30); B = clip_uintp2(B, 30); }
+            px[k] = ((uint32_t)(R >> 22) << (8 * r_pos)) | ((uint32_t)(G >> 22) << (8 * g_pos)) | ((uint32_t)(B >> 22) << (8 * b_pos));
+            if (BPP == 4) px[k] |= 255u << (8 * a_pos);
+        }
+        uint8_t *d = f.dst[0] + (int64_t)y * f.dstStride[0] + (int64_t)BPP * x;
+        if (BPP == 4) {
+            if (npx == 4) { const u32x4 o = { px[0], px[1], px[2], px[3] }; *(SWS_GLOBAL u32x4 *)d = o; }
+            else for (int k = 0; k < npx; k++) ((uint32_t *)d)[k] = px[k];
+        } else {
+            if (npx == 4) {
+                ((uint32_t *)d)[0] = (px[0] & 0xFFFFFFu) | (px[1] << 24);
+                ((uint32_t *)d)[1] = ((px[1] >> 8) & 0xFFFFu) | (px[2] << 16);
+                ((uint32_t *)d)[2] = ((px[2] >> 16) & 0xFFu) | (px[3] << 8);
+            } else for (int k = 0; k < npx; k++) { d[3 * k] = (uint8_t)px[k]; d[3 * k + 1] = (uint8_t)(px[k] >> 8); d[3 * k + 2] = (uint8_t)(px[k] >> 16); }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // C3a: planarToP01xWrapper (swscale_unscaled.c:273-322) for aligned 16-bit sources, streaming form.
 // grid.y = luma rows then chroma rows; a lane moves CH x 16 bytes spaced one wave apart, so every load/store
 // instruction of a wave covers 1 KiB of contiguous memory; plane pointers live in SGPRs; stores are non-temporal.

@@ -190,8 +190,9 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
     // ---- destination descriptors and per-lane offsets (columns beyond the plane get an out-of-range offset) ----
     const bool semi = CHROMA && (p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010);
     const bool d8 = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_NV12;
-    const int kind = semi ? (d8 ? 2 : 3) : (d8 ? 0 : 1);       // store form: b8 / b16 per component, or b16 / b32 of an interleaved pair
-    const int dbytes = (d8 ? 1 : 2) * (semi ? 2 : 1);          // bytes per stored element
+    const bool raw = p.dstKind == DSTK_RAW32;                  // the vertical sums themselves (int32 planes: the full-chroma RGB epilogue follows)
+    const int kind = raw ? 4 : semi ? (d8 ? 2 : 3) : (d8 ? 0 : 1);       // store form: b8 / b16 per component, or b16 / b32 of an interleaved pair; b32 sums
+    const int dbytes = raw ? 4 : (d8 ? 1 : 2) * (semi ? 2 : 1);          // bytes per stored element
     sws_rsrc_t rd[NCOMP];
     int dstr[NCOMP];
 #pragma unroll
@@ -238,6 +239,12 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
 #pragma unroll
                 for (int c = 0; c < COLS; c++)
                     __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(pend[0][c] | (pend[NCOMP - 1][c] << 8)), rd[0], doff[c], pend_y * dstr[0], 0);
+                break;
+            case 4:
+#pragma unroll
+                for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                    for (int c = 0; c < COLS; c++) __builtin_amdgcn_raw_buffer_store_b32(pend[ci][c], rd[ci], doff[c], pend_y * dstr[ci], 0);
                 break;
             default:
 #pragma unroll
@@ -331,7 +338,12 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
             break;
         }
         // ---- writers ("X" forms) ----
-        if (d8) {
+        if (raw) {
+#pragma unroll
+            for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++) pend[ci][c] = (uint32_t)acc[ci][c];
+        } else if (d8) {
 #pragma unroll
             for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
@@ -483,8 +495,9 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
     // ---- destination descriptors and per-lane offsets (columns beyond the plane get an out-of-range offset) ----
     const bool semi = CHROMA && (p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010);
     const bool d8 = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_NV12;
-    const int kind = semi ? (d8 ? 2 : 3) : (d8 ? 0 : 1);
-    const int dbytes = (d8 ? 1 : 2) * (semi ? 2 : 1);
+    const bool raw = p.dstKind == DSTK_RAW32;
+    const int kind = raw ? 4 : semi ? (d8 ? 2 : 3) : (d8 ? 0 : 1);
+    const int dbytes = raw ? 4 : (d8 ? 1 : 2) * (semi ? 2 : 1);
     sws_rsrc_t rd[NCOMP];
     int dstr[NCOMP];
 #pragma unroll
@@ -530,6 +543,12 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
 #pragma unroll
                 for (int c = 0; c < COLS; c++)
                     __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(pend[0][c] | (pend[NCOMP - 1][c] << 8)), rd[0], doff[c], pend_y * dstr[0], 0);
+                break;
+            case 4:
+#pragma unroll
+                for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                    for (int c = 0; c < COLS; c++) __builtin_amdgcn_raw_buffer_store_b32(pend[ci][c], rd[ci], doff[c], pend_y * dstr[ci], 0);
                 break;
             default:
 #pragma unroll
@@ -616,7 +635,12 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
             break;
         }
         // ---- writers ("X" forms) ----
-        if (d8) {
+        if (raw) {
+#pragma unroll
+            for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++) pend[ci][c] = (uint32_t)acc[ci][c];
+        } else if (d8) {
 #pragma unroll
             for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll

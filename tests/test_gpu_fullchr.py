@@ -1,0 +1,75 @@
+"""-m gpu parity for full-chroma packed RGB destinations through the strip kernels ("+fullchr_rgb"): SWS_FULL_CHR_H_INT -- set by the caller, or forced
+for RGB and 4:4:4 sources and odd destination widths (utils.c:1270-1286) -- scales Y, U and V to the destination size; the strip kernels leave their
+vertical sums as int32 planes and sws_k_fullchr_rgb finishes yuv2rgb_full_X_c_template / yuv2rgb_write_full (output.c:2005-2070, :2163-2207)."""
+import numpy as np
+import pytest
+
+from librempeg_amd import (SWS_BICUBIC, SWS_BILINEAR, SWS_LANCZOS, SWS_BITEXACT, SWS_ACCURATE_RND, SWS_AREA, SWS_GAUSS, SWS_FULL_CHR_H_INT)
+from test_gpu_parity import run_case
+
+pytestmark = pytest.mark.gpu
+BX = SWS_BITEXACT
+FC = SWS_FULL_CHR_H_INT
+TUNE = dict(strip_min_w=0)
+
+SRC = ["rgb24", "bgr24", "bgra", "argb", "rgb0", "gbrp", "yuv444p", "yuv420p", "yuv422p", "nv12", "nv21", "yuyv422", "uyvy422", "yuv420p10le", "yuv444p10le", "p010le", "yuvj420p", "yuv410p"]
+DST = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "0bgr"]
+
+
+@pytest.mark.parametrize("src", SRC)
+@pytest.mark.parametrize("dst", DST)
+def test_formats(src, dst):
+    for (sw, sh, dw, dh, fl) in ((256, 64, 192, 48, SWS_BICUBIC), (320, 50, 512, 80, SWS_BICUBIC), (132, 34, 67, 17, SWS_AREA), (256, 64, 321, 96, SWS_LANCZOS),
+                                 (256, 64, 250, 64, SWS_GAUSS), (130, 30, 131, 31, SWS_BICUBIC | SWS_ACCURATE_RND), (256, 64, 256, 64, SWS_BICUBIC)):
+        r = run_case(sw, sh, src, dw, dh, dst, fl | FC | BX, seed=sw + dh, tune=TUNE)
+        alpha_src = src in ("bgra", "argb", "gbrap") and dst in ("rgba", "bgra", "argb", "abgr", "rgb0", "0bgr")     # (a real alpha plane is scaled: the generic writer)
+        # (area at 2:1: two luma and two chroma taps, yuv2rgb_full_2; an unscaled height with unsubsampled chroma rows: one tap each, yuv2rgb_full_1;
+        #  rgb0 / 0bgr sources become their alpha twins with an opaque plane that IS scaled: the generic writer)
+        short = fl == SWS_AREA or (sh == dh and src not in ("yuv420p", "nv12", "nv21", "yuv420p10le", "p010le", "yuvj420p", "yuv410p"))
+        rgb_src = src in ("rgb24", "bgr24", "bgra", "argb", "rgb0", "gbrp")
+        if (sw, sh) != (dw, dh) and not alpha_src and not short and not (src == "rgb0" and dst not in ("rgb24", "bgr24")) and not (rgb_src and sw & 3):
+            assert r[0].endswith("+fullchr_rgb"), (r[0], src, dst, sw, dw)
+
+
+def test_forced_full_chroma_and_fallbacks():
+    assert run_case(256, 64, "rgb24", 192, 48, "bgr24", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")        # RGB source: forced
+    assert run_case(256, 64, "yuv444p", 192, 48, "bgra", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")        # 4:4:4 source: forced
+    assert run_case(256, 64, "yuv420p", 191, 48, "rgb24", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")       # odd width: forced
+    assert not run_case(256, 64, "yuv420p", 192, 48, "rgb24", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")   # the LUT writers
+    assert not run_case(256, 64, "bgra", 192, 48, "bgra", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")       # alpha plane scaled
+    assert not run_case(256, 64, "rgb24", 192, 48, "rgb565le", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")
+    assert not run_case(256, 64, "rgb24", 256, 128, "bgr24", SWS_BILINEAR | BX, tune=TUNE)[0].endswith("+fullchr_rgb")   # two luma and two chroma taps: yuv2rgb_full_2
+    assert not run_case(640, 48, "rgb24", 320, 24, "bgr24", SWS_BICUBIC | BX)[0].endswith("+fullchr_rgb")                # narrow: below the planner's width threshold
+
+
+def test_full_size_batches_and_host_frames():
+    import torch
+    import oracle_lib as OL
+    from librempeg_amd import SwsContext, HostFrame, DeviceFrame
+    assert run_case(3840, 2160, "rgb24", 1920, 1080, "rgb24", SWS_BICUBIC | BX, seed=2)[0] == "main:rgbread+strip_march+fullchr_rgb"
+    assert run_case(1920, 1080, "bgr24", 1280, 720, "bgra", SWS_BILINEAR | BX, seed=3, device_frames=False)[0] == "main:rgbread+strip_march+fullchr_rgb"
+    assert run_case(1920, 1080, "yuv444p", 1280, 720, "rgb24", SWS_BICUBIC | BX, seed=4)[0] == "main:strip_march+fullchr_rgb"
+    assert run_case(1920, 1080, "yuv420p", 1280, 720, "bgra", SWS_LANCZOS | FC | SWS_ACCURATE_RND | BX, seed=5)[0] == "main:strip_march+fullchr_rgb"
+    for src, dst, sw, sh, dw, dh, n, flags in (("rgb24", "bgr24", 1284, 70, 1028, 56, 5, SWS_BICUBIC | BX), ("nv12", "bgra", 1024, 64, 1283, 80, 3, SWS_BICUBIC | FC | BX)):
+        o = OL.Oracle(sw, sh, src, dw, dh, dst, flags)
+        p = SwsContext(sw, sh, src, dw, dh, dst, flags)
+        refs, srcs, dsts = [], [], []
+        for k in range(n):
+            s = OL.fill_random(OL.Frame(src, sw, sh), 60 + k)
+            ref = OL.Frame(dst, dw, dh)
+            assert o.scale(s, ref) == dh
+            refs.append(ref)
+            hs = HostFrame(src, sw, sh)
+            for a, b in zip(hs.planes, s.planes):
+                a[:] = b
+            srcs.append(DeviceFrame(src, sw, sh).upload(hs))
+            dsts.append(DeviceFrame(dst, dw, dh))
+        torch.cuda.synchronize()
+        for rep in range(2):
+            assert p.scale_frames(srcs, dsts) == n
+            p.sync()
+            assert p.path().endswith("+fullchr_rgb"), p.path()
+            for k in range(n):
+                out = dsts[k].download()
+                for a, b, rb in zip(out.planes, refs[k].planes, out.row_bytes):
+                    assert np.array_equal(a[:, :rb], b[:, :rb]), (src, dst, k, rep)
