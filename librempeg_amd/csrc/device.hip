@@ -20,6 +20,7 @@ namespace swship {
 void launch_layout_split422(const LaunchCtx &L, bool uyvy, bool vfirst);   // k_layout.hip: yuyv422 / uyvy422 / yvyu422 -> planar 4:2:2 working picture
 void launch_layout_splitnv(const LaunchCtx &L, bool vfirst);   // k_layout.hip: plane 1 of a semi-planar 8-bit picture -> planar U / V working planes
 void launch_layout_splitp01x(const LaunchCtx &L, int shift);   // k_layout.hip: p010-style planes -> planar working picture, words >> shift
+void launch_alpha_merge32(const LaunchCtx &L);                 // k_stream.hip: the alpha bytes behind sws_k_strip_rgb (alpha_launch == 2)
 void launch_layout_join422(const LaunchCtx &L, bool uyvy);   // k_layout.hip: planar 4:2:2 working picture -> yuyv422 / uyvy422 (yvyu422: planes swapped by the planner)
 
 static int ensure_dev(SwsInternal *c)
@@ -68,6 +69,7 @@ static void dev_state_free(DeviceState *d)
     if (d->h_frames2) (void)hipHostFree(d->h_frames2);
     if (d->join_img) (void)hipFree(d->join_img);
     if (d->split_img) (void)hipFree(d->split_img);
+    if (d->stage_img) (void)hipFree(d->stage_img);
     if (d->d_aux_tables) (void)hipFree(d->d_aux_tables);
     if (d->h_aux_tables) (void)hipHostFree(d->h_aux_tables);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
@@ -313,10 +315,22 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     //      Y, U and V are all scaled to the destination size; the kernels store their vertical sums as int32 planes (DSTK_RAW32) into a working picture
     //      per frame and sws_k_fullchr_rgb finishes yuv2rgb_full_X_c_template.  Tentative: undone below when no strip plan fits or a row takes one of
     //      the writer's short forms ----
+    // (a source alpha plane scaled into a 32 bpp destination -- bgra -> bgra, yuva420p -> rgba: needAlpha -- goes through the luma filters as a fourth sum
+    //  plane: the A bytes of a packed 32 bpp source come from the reader pre-pass, a planar source has them in plane 3)
+    // (planar RGB destinations of 8 .. 14 bits -- gbrp, gbrap, gbrp10le ...: yuv2gbrp_full_X_c is the same matrix with its own shifts, sws_k_fullchr_gbrp)
+    const bool fc_alpha = c->needAlpha && (p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP) &&
+                          ((p.srcKind == SRCK_RGB32 && !(o.src_w & 3)) || ((p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_PLANAR16) && isPlanarYUV(o.src_format)));
+    // (the same for a planar YUV destination with an alpha plane -- bgra -> yuva420p, yuva444p10le -> yuva420p: the A samples through the luma filters
+    //  and the luma plane's writer into dst[3], swscale.c:478-486 / vscale.c:66-70; decided with the strip plan below)
+    const bool alpha_planar = c->plan == PLAN_MAIN && c->needAlpha && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && isPlanarYUV(o.dst_format) &&
+                              !isGray(o.src_format) && !(o.flags & SWS_FAST_BILINEAR) && !c->tune.no_strip && !c->tune.no_mixed &&
+                              ((p.srcKind == SRCK_RGB32 && !(o.src_w & 3)) || ((p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_PLANAR16) && isPlanarYUV(o.src_format)));
+    d->alpha_launch = 0;
+    const bool fc_plain = !isGray(o.src_format) && !isGray(o.dst_format) && p.srcKind != SRCK_MONO;
     d->fullchr_on = 0;
-    if (c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && p.full_chr && !c->needAlpha && !gray_any && !(o.flags & SWS_FAST_BILINEAR) &&
+    if (c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP) && p.full_chr && (!c->needAlpha || fc_alpha) && fc_plain && !(o.flags & SWS_FAST_BILINEAR) &&
         o.dst_w >= c->tune.strip_min_w && !c->tune.no_strip && !c->tune.no_mixed) {
-        d->fullchr_on = 1; d->fullchr_kind = p.dstKind;
+        d->fullchr_on = c->needAlpha ? 2 : 1; d->fullchr_kind = p.dstKind;
         p.dstKind = DSTK_RAW32; p.u_plane_dst = 1; p.v_plane_dst = 2;
     }
     if (p.srcKind == SRCK_PACKEDHI)
@@ -571,8 +585,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // packed 24 / 32 bpp RGB through the LUT writers (not the full-chroma ones): the strip kernel with the RGB epilogue
             // (9 .. 15-bit planar sources too -- decoded HDR pictures for display: 128-column strips, a window of at most 64 eight-sample chunks)
             const bool rgb_s16 = p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15 && p.src_shift == 0;
+            // (a planar YUV source with alpha into a 32 bpp destination with alpha -- yuva420p -> bgra, needAlpha: the kernel stores opaque pixels, the A
+            //  samples go through one more luma launch with the raw writer and sws_k_alpha_merge32 puts the bytes in: alpha_launch == 2)
+            const bool rgb_alpha = c->needAlpha && p.dstKind == DSTK_RGB32 && isPlanarYUV(o.src_format) && !c->tune.no_mixed;
             const bool rgb_ok = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr && ((p.srcKind == SRCK_PLANAR8 && c->srcBpc == 8) || rgb_s16) &&
-                                !p.no_chroma && !p.need_alpha && !(p.dstW & 1) && !p.range_active && !c->tune.no_strip;
+                                !p.no_chroma && (!p.need_alpha || rgb_alpha) && !(p.dstW & 1) && !p.range_active && !c->tune.no_strip;
             d->striprgb_ok = false;
             // (planar writers: a one-tap vertical filter takes the reference's yuv2plane1 form -- (s + d) >> 7, (s + (1 << (14 - bits))) >> (15 - bits),
             //  output.c:327-341, :485-493 -- which is the "X" arithmetic of these kernels with the one tap 4096: (4096 s + (d << 12)) >> 19, sample for
@@ -580,8 +597,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             //  two-tap minimum.  The packed writers are in "X" mode unless both vertical filters are short, which all_x_mode checks row by row)
             // scaled packed 24 / 32 bpp RGB sources: a reader pre-pass writes the 16-bit planes the horizontal scaler
             // reads, the strip kernel takes them like a planar 16-bit source (launch_rgbread_strip); other shapes of these sources keep the tile kernel
-            bool rgbread = (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chrSrcW == (p.chr_half ? p.srcW >> 1 : p.srcW) && !(p.srcW & 3) && p.chrSrcVSub == 0 && !p.range_active && !p.need_alpha &&
-                           !p.dst_alpha_fill && !p.no_chroma && !vlines_pending && dst_ok && !c->tune.no_strip && !c->tune.no_rgbsrc && p.dstW >= c->tune.strip_min_w;
+            bool rgbread = (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chrSrcW == (p.chr_half ? p.srcW >> 1 : p.srcW) && !(p.srcW & 3) && p.chrSrcVSub == 0 && !p.range_active && (!p.need_alpha || d->fullchr_on == 2 || alpha_planar) &&
+                           (!p.dst_alpha_fill || d->fullchr_on) && !p.no_chroma && !vlines_pending && dst_ok && !c->tune.no_strip && !c->tune.no_rgbsrc && p.dstW >= c->tune.strip_min_w;
             for (int k = 0; k < 9 && rgbread; k++) rgbread = p.rgb2yuv[k] > -32768 && p.rgb2yuv[k] < 32768;   // (v_dot2_i32_i16 operands)
             d->rgbread_on = false;
             // vertical chroma filters of 17 .. 24 taps (a 4:1 chroma step: packed RGB or 4:2:2 sources into a 4:2:0 picture of half the size): the strip
@@ -598,7 +615,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             //  picture into packed RGB (decoded HDR for display) or packed RGB into a 10-bit 4:2:0 picture at the same size had only the generic
             //  kernels: the strip kernels take them with their one-tap horizontal banks)
             const bool unity_ok = !d->unity_h || (rgb_ok && rgb_s16) || (rgbread && !d->rgbsrc_ok && !d->rgb444_ok);   // (sws_k_rgbsrc_unity's row table lives in the same device block as the strip plan)
-            const bool fullA = !mixedM && unity_ok && !(d->unity_h && d->unity_v && !rgb_ok) && !p.fast_bilinear && (!gray_any || gray_both) && (src_ok || (nv_src && dst_ok) || rgbread) &&
+            const bool fullA = !mixedM && unity_ok && !(d->unity_h && d->unity_v && !rgb_ok) && !p.fast_bilinear && (!gray_any || gray_both || d->fullchr_on == 2 || alpha_planar || (rgb_ok && rgb_alpha)) && (src_ok || (nv_src && dst_ok) || rgbread) &&
                                (dst_ok || rgb_ok) && !p.wide &&
                                fs2(c->hLum.size) <= 16 && (fs2(c->hChr.size) <= 16 || gray_both) && fs2(c->vLum.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long || gray_both) && !c->tune.no_dot2;
             d->mixed_ok = false;
@@ -739,7 +756,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     const bool pl = plan3(c->hLum, c->vLum, p.dstW, rcl, 1, gl, rL, ringL), pc = pl && plan3(c->hChr, c->vChr, p.chrDstW, rcl / 2, 2, gc, rC, ringC);
                     log_msg(c, 3, "strip_rgb plan: luma %d chroma %d strips %d/%d window %d/%d nph %d/%d npv %d/%d chrDstH %d dstH %d\n", pl, pc, gl.strips, gc.strips,
                             gl.NCmax, gc.NCmax, gl.nph, gc.nph, gl.npv, gc.npv, p.chrDstH, p.dstH);
-                    if (pl && pc && gl.strips == gc.strips &&
+                    SOff sA;
+                    const bool wantA = p.need_alpha != 0;     // (rgb_ok: then rgb_alpha holds)
+                    const bool pa = !wantA || plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sA, nullptr, false);   // the plain luma launch, the X form's own taps
+                    if (pl && pc && pa && gl.strips == gc.strips &&
                         gl.NCmax / SPC <= 64 && gc.NCmax / SPC <= 64 && std::max(gl.nph, gc.nph) <= 8 && gl.npv <= 8 && gc.npv <= 8 && p.chrDstH == p.dstH) {
                         const std::vector<int16_t> htl = padded(c->hLum), htc = padded(c->hChr);
                         const size_t ohl = put(htl.data(), htl.size() * 2), ohc = put(htc.data(), htc.size() * 2);
@@ -755,6 +775,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         gc.colStart = (const int32_t *)(b + rC.cs); gc.colCount = (const int32_t *)(b + rC.cc); gc.rows = (const SwsStripRow *)(b + rC.rows);
                         gl.hT2 = (const int16_t *)(b + ohl); gc.hT2 = (const int16_t *)(b + ohc); gl.vT2 = gc.vT2 = nullptr;
                         gl.nph = gc.nph = std::max(gl.nph, gc.nph);      // one instantiation: the shorter tap rows are zero-extended in the kernel
+                        if (wantA) {
+                            d->stripL.colStart = (const int32_t *)(b + sA.cs); d->stripL.colCount = (const int32_t *)(b + sA.cc); d->stripL.rows = (const SwsStripRow *)(b + sA.rows);
+                            d->stripL.hT2 = gl.hT2; d->stripL.vT2 = nullptr;
+                            d->alpha_launch = 2;
+                        }
                         d->striprgb_long = gl.npv > 5;
                         d->striprgb_ok = true;                           // (and every row in the "X" writer mode: checked below)
                     }
@@ -781,7 +806,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         g.hT2 = (const int16_t *)(b + o.ht); g.vT2 = (const int16_t *)(b + o.vt);
                     };
                     if (tiles) { bind(d->dotL, oL); bind(d->dotC, oC); }
-                    d->dot2_ok = tiles && src_ok && fs2(c->vChr.size) <= 16 && c->vLum.size >= 2 && c->vChr.size >= 2 && !d->fullchr_on;
+                    d->dot2_ok = tiles && src_ok && fs2(c->vChr.size) <= 16 && c->vLum.size >= 2 && c->vChr.size >= 2 && !d->fullchr_on && !alpha_planar;
                     if (strip_plan) {
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         d->stripL.colStart = (const int32_t *)(b + sL.cs); d->stripL.colCount = (const int32_t *)(b + sL.cc);
@@ -791,6 +816,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         d->stripL.rows = (const SwsStripRow *)(b + sL.rows); if (!gray_both) d->stripC.rows = (const SwsStripRow *)(b + sC.rows);
                         d->strip_ok = true;
                         d->rgbread_on = rgbread;
+                        d->alpha_launch = alpha_planar ? 1 : 0;
                     }
                   }
                 }
@@ -864,7 +890,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             }
             d->all_x_mode = all_x;
             d->striprgb_ok = d->striprgb_ok && all_x;
-            if (d->fullchr_on && (!all_x || !d->strip_ok)) {   // no strip plan, or a row in one of the short writer forms: the generic full-chroma writer keeps it
+            if (d->alpha_launch == 2 && !d->striprgb_ok) d->alpha_launch = 0;
+            if (d->fullchr_on && ((!all_x && d->fullchr_kind != DSTK_GBRP) || !d->strip_ok)) {   // (planar RGB: any_vscale, always the X form)   // no strip plan, or a row in one of the short writer forms: the generic full-chroma writer keeps it
                 d->fullchr_on = 0; d->strip_ok = false; d->rgbread_on = false;
                 p.dstKind = d->fullchr_kind; p.u_plane_dst = dd->comp[1].plane; p.v_plane_dst = dd->comp[2].plane;
             }
@@ -1008,6 +1035,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     if (c->plan == PLAN_MAIN && d->split_mode) c->path_name = ((d->split_mode & 40) ? "main:splitnv+" : "main:split422+") + c->path_name.substr(c->path_name.find(':') + 1);
     if (c->plan == PLAN_MAIN && d->join422) c->path_name += "+join422";
     if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += "+fullchr_rgb";
+    if (c->plan == PLAN_MAIN && ((d->alpha_launch == 1 && d->strip_ok) || (d->alpha_launch == 2 && d->striprgb_ok))) c->path_name += "+alpha";
     // (16-byte aligned pictures of the layout converters take the streaming kernel, k_layout.hip; the names above are the fallback's)
     if (!c->tune.no_layout_stream && (c->plan == PLAN_UNSC_PLANAR2NV12 || c->plan == PLAN_UNSC_NV122PLANAR || c->plan == PLAN_UNSC_PLANARCOPY || c->plan == PLAN_UNSC_PLANAR2NV24 ||
                                       c->plan == PLAN_UNSC_NV242PLANAR || c->plan == PLAN_UNSC_P4222PLANAR || c->plan == PLAN_UNSC_PLANAR2P422))
@@ -1097,6 +1125,8 @@ int grow(SwsInternal *c, void **buf, size_t *cap, size_t need)
     return poison(c, *buf, need);
 }
 
+static void plane_extent(const PixDesc *d, int w, int h, int k, int *rows, int *row_bytes, int *vsub);
+
 static bool frames_vec_ok(const SwsFramePtrs *fr, int n)
 {
     for (int i = 0; i < n; i++)
@@ -1139,7 +1169,7 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         frames = palfr.data();
     }
     // frame tables of the helper passes around a packed 4:2:2 side (slot 0: the interleave behind the kernels, slot 1: the de-interleave ahead of
-    // them): one device block and one pinned host block of two tables, each cached like d_frames
+    // them; slot 2: the alpha launch of a full-chroma RGB destination; slots 3 / 4: staging copies in / out): one device block and one pinned host block of five tables, each cached like d_frames
     auto aux_table = [&](int slot, const std::vector<SwsFramePtrs> &v, const SwsFramePtrs **out) -> int {
         SwsFramePtrs *&dtab = d->d_aux_tables, *&htab = d->h_aux_tables;
         int &cap = d->aux_cap;
@@ -1147,9 +1177,9 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         if (n > cap) {
             if (dtab) HIPCHK(hipFree(dtab));
             if (htab) HIPCHK(hipHostFree(htab));
-            dtab = nullptr; htab = nullptr; cap = 0; valid[0] = valid[1] = 0;
-            HIPCHK(hipMalloc((void **)&dtab, sizeof(SwsFramePtrs) * 2 * (size_t)n));
-            HIPCHK(hipHostMalloc((void **)&htab, sizeof(SwsFramePtrs) * 2 * (size_t)n, hipHostMallocDefault));
+            dtab = nullptr; htab = nullptr; cap = 0; for (int k = 0; k < 5; k++) valid[k] = 0;
+            HIPCHK(hipMalloc((void **)&dtab, sizeof(SwsFramePtrs) * 5 * (size_t)n));
+            HIPCHK(hipHostMalloc((void **)&htab, sizeof(SwsFramePtrs) * 5 * (size_t)n, hipHostMallocDefault));
             cap = n;
         }
         SwsFramePtrs *hd = htab + (size_t)slot * (size_t)cap, *dd2 = dtab + (size_t)slot * (size_t)cap;
@@ -1162,9 +1192,57 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         *out = dd2;
         return 0;
     };
+    bool timing_started = false;
+    // pictures whose planes are not 16-byte aligned (a cropped view, a tightly packed rgb24 row) or bottom-up (negative line sizes) under the helper passes, which read and write 16-byte
+    // granules and have no per-byte twins: such planes are copied into aligned working planes first, and the written ones back afterwards (the visible
+    // bytes of every row only).  Contexts without helper passes fall back to their per-sample kernels instead
+    std::vector<SwsFramePtrs> stfr, st_in, st_out;
+    int st_rb[2][4] = { { 0 } }, st_rows[2][4] = { { 0 } };
+    bool stage_out = false;
+    if (c->plan == PLAN_MAIN && (d->split_mode || d->join422 || d->fullchr_on || d->alpha_launch) && (!frames_vec_ok(frames, n) || !frames_desc_ok(frames, n, p.srcH, p.dstH))) {
+        auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
+        const PixDesc *ds = pix_desc(c->opts.src_format), *dd = pix_desc(c->opts.dst_format);
+        int64_t off[2][4], fbytes = 0; int strd[2][4];
+        for (int side = 0; side < 2; side++)
+            for (int k = 0; k < 4; k++) {
+                int vs = 0;
+                plane_extent(side ? dd : ds, side ? c->opts.dst_w : c->opts.src_w, side ? c->opts.dst_h : c->opts.src_h, k, &st_rows[side][k], &st_rb[side][k], &vs);
+                strd[side][k] = (int)a256(st_rb[side][k]); off[side][k] = fbytes; fbytes += (int64_t)strd[side][k] * st_rows[side][k];
+            }
+        int r = grow(c, &d->stage_img, &d->stage_bytes, (size_t)fbytes * (size_t)n);
+        if (r < 0) return r;
+        stfr.assign(frames, frames + n); st_in.resize((size_t)n); st_out.resize((size_t)n);
+        bool stage_in = false;
+        for (int i = 0; i < n; i++) {
+            uint8_t *base = (uint8_t *)d->stage_img + (size_t)i * (size_t)fbytes;
+            SwsFramePtrs &a = stfr[(size_t)i], &in = st_in[(size_t)i], &out = st_out[(size_t)i];
+            std::memset(&in, 0, sizeof(in)); std::memset(&out, 0, sizeof(out));
+            for (int k = 0; k < 4; k++) {
+                if (a.src[k] && st_rows[0][k] && ((((uintptr_t)a.src[k] | (uintptr_t)(uint32_t)a.srcStride[k]) & 15) || a.srcStride[k] <= 0)) {
+                    in.src[k] = a.src[k]; in.srcStride[k] = a.srcStride[k]; in.dst[k] = base + off[0][k]; in.dstStride[k] = strd[0][k];
+                    a.src[k] = base + off[0][k]; a.srcStride[k] = strd[0][k]; stage_in = true;
+                }
+                if (a.dst[k] && st_rows[1][k] && ((((uintptr_t)a.dst[k] | (uintptr_t)(uint32_t)a.dstStride[k]) & 15) || a.dstStride[k] <= 0)) {
+                    out.dst[k] = a.dst[k]; out.dstStride[k] = a.dstStride[k]; out.src[k] = base + off[1][k]; out.srcStride[k] = strd[1][k];
+                    a.dst[k] = base + off[1][k]; a.dstStride[k] = strd[1][k]; stage_out = true;
+                }
+            }
+        }
+        if (!frames_vec_ok(stfr.data(), n)) { log_msg(c, 0, "internal error: staged pictures still unaligned\n"); return SWS_AVERROR(EINVAL); }
+        if (stage_in) {
+            LaunchCtx S;
+            std::memset(&S.fs, 0, sizeof(S.fs));
+            S.c = c; S.d = d; S.p = &p; S.st = st; S.frames = st_in.data(); S.n = n; S.sliceY = sliceY; S.sliceH = sliceH; S.vec = false;
+            S.fs.count = n;
+            if (n == 1) { S.fs.table = nullptr; S.fs.one = st_in[0]; }
+            else { const SwsFramePtrs *t = nullptr; r = aux_table(3, st_in, &t); if (r < 0) return r; S.fs.table = t; }
+            if (d->timing) { HIPCHK(hipEventRecord(d->ev0, st)); timing_started = true; }
+            launch_stage_planes(S, st_rb[0], st_rows[0], true);
+        }
+        frames = stfr.data();
+    }
     // packed 4:2:2 source through the planar kernels (dev_prepare_on): de-interleave into a planar 4:2:2 working picture per frame first
     std::vector<SwsFramePtrs> s422fr, s422split;
-    bool timing_started = false;
     if (c->plan == PLAN_MAIN && d->split_mode) {
         auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
         const bool nv = (d->split_mode & 8) != 0;    // semi-planar 8-bit source: only the chroma plane is split, the luma plane stays where it is
@@ -1191,7 +1269,7 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         S.fs.count = n;
         if (n == 1) { S.fs.table = nullptr; S.fs.one = s422split[0]; }
         else { const SwsFramePtrs *t = nullptr; r = aux_table(1, s422split, &t); if (r < 0) return r; S.fs.table = t; }
-        if (d->timing) { HIPCHK(hipEventRecord(d->ev0, st)); timing_started = true; }
+        if (d->timing && !timing_started) { HIPCHK(hipEventRecord(d->ev0, st)); timing_started = true; }
         if (p01x) launch_layout_splitp01x(S, d->split_shift);
         else if (nv) launch_layout_splitnv(S, (d->split_mode & 16) != 0);
         else launch_layout_split422(S, (d->split_mode & 3) == 2, (d->split_mode & 4) != 0);
@@ -1202,7 +1280,8 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
     if (c->plan == PLAN_MAIN && d->fullchr_on) {
         auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
         const int sP = (int)a256(4 * (int64_t)p.dstW);
-        const int64_t plane = (int64_t)sP * p.dstH, fbytes = a256(3 * plane);
+        const int nraw = d->fullchr_on == 2 ? 4 : 3;     // (2: the alpha sums as a fourth plane)
+        const int64_t plane = (int64_t)sP * p.dstH, fbytes = a256(nraw * plane);
         int r = grow(c, &d->join_img, &d->join_bytes, (size_t)fbytes * (size_t)n);
         if (r < 0) return r;
         p422fr.assign(frames, frames + n);
@@ -1211,9 +1290,10 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
             uint8_t *base = (uint8_t *)d->join_img + (size_t)i * (size_t)fbytes;
             SwsFramePtrs &a = p422fr[(size_t)i], &j = p422join[(size_t)i];
             std::memset(&j, 0, sizeof(j));
-            j.dst[0] = a.dst[0]; j.dstStride[0] = a.dstStride[0];
-            for (int k = 0; k < 3; k++) { j.src[k] = base + k * plane; j.srcStride[k] = sP; a.dst[k] = base + k * plane; a.dstStride[k] = sP; }
-            a.dst[3] = nullptr; a.dstStride[3] = 0;
+            for (int k = 0; k < 4; k++) { j.dst[k] = a.dst[k]; j.dstStride[k] = a.dstStride[k]; }
+            for (int k = 0; k < nraw; k++) { j.src[k] = base + k * plane; j.srcStride[k] = sP; }
+            for (int k = 0; k < 3; k++) { a.dst[k] = base + k * plane; a.dstStride[k] = sP; }
+            if (!p.dst_alpha_fill) { a.dst[3] = nullptr; a.dstStride[3] = 0; }   // (gbrap without source alpha: launch_fill_alpha writes the caller's plane 3)
         }
         frames = p422fr.data();
     }
@@ -1302,6 +1382,70 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
     default: ret = launch_misc(L); break;
     }
     if (ret < 0) return ret;
+    // full-chroma RGB destination with a scaled alpha plane: the A samples -- the reader pre-pass's fourth plane for a packed 32 bpp source
+    // (rgbaToA_c, input.c: a << 6 | a >> 2), plane 3 of a planar source -- go through the luma filters into the fourth sum plane
+    // (swscale.c:440-470 scales alpPixBuf with the luma banks; yuv2rgb_full_X: (sum + (1 << 18)) >> 19, output.c:2027-2038)
+    std::vector<SwsFramePtrs> alfr;
+    SwsDevParams pA;
+    const bool alpha_run = c->plan == PLAN_MAIN && d->alpha_launch == 1 && d->strip_ok && !d->fullchr_on && vec && frames_desc_ok(frames, n, p.srcH, p.dstH);   // (the strip launch above ran)
+    const bool alpha_rgb = c->plan == PLAN_MAIN && d->alpha_launch == 2 && d->striprgb_ok && !d->fullchr_on && vec && frames_desc_ok(frames, n, p.srcH, p.dstH);
+    if (alpha_rgb) {   // the LUT writers' strip kernel stored opaque pixels: the A sums into a working plane, then the alpha bytes into the picture
+        auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
+        const int sP = (int)a256(4 * (int64_t)p.dstW);
+        const int64_t fbytes = a256((int64_t)sP * p.dstH);
+        int r = grow(c, &d->join_img, &d->join_bytes, (size_t)fbytes * (size_t)n);
+        if (r < 0) return r;
+        std::vector<SwsFramePtrs> afr(frames, frames + n), mfr((size_t)n);
+        SwsDevParams pR = p;
+        pR.dstKind = DSTK_RAW32;
+        for (int i = 0; i < n; i++) {
+            uint8_t *base = (uint8_t *)d->join_img + (size_t)i * (size_t)fbytes;
+            SwsFramePtrs &a = afr[(size_t)i], &m = mfr[(size_t)i];
+            std::memset(&m, 0, sizeof(m));
+            a.src[0] = frames[i].src[3]; a.srcStride[0] = frames[i].srcStride[3];
+            a.src[1] = a.src[2] = a.src[3] = nullptr; a.srcStride[1] = a.srcStride[2] = a.srcStride[3] = 0;
+            a.dst[0] = base; a.dstStride[0] = sP;
+            a.dst[1] = a.dst[2] = a.dst[3] = nullptr; a.dstStride[1] = a.dstStride[2] = a.dstStride[3] = 0;
+            m.src[0] = base; m.srcStride[0] = sP; m.dst[0] = frames[i].dst[0]; m.dstStride[0] = frames[i].dstStride[0];
+        }
+        LaunchCtx A = L;
+        std::memset(&A.fs, 0, sizeof(A.fs));
+        A.fs.count = n; A.frames = afr.data(); A.p = &pR;
+        if (n == 1) { A.fs.table = nullptr; A.fs.one = afr[0]; }
+        else { const SwsFramePtrs *t = nullptr; r = aux_table(2, afr, &t); if (r < 0) return r; A.fs.table = t; }
+        ret = launch_strip_luma(A);
+        if (ret < 0) return ret;
+        LaunchCtx M = L;
+        std::memset(&M.fs, 0, sizeof(M.fs));
+        M.fs.count = n; M.frames = mfr.data();
+        if (n == 1) { M.fs.table = nullptr; M.fs.one = mfr[0]; }
+        else { const SwsFramePtrs *t = nullptr; r = aux_table(0, mfr, &t); if (r < 0) return r; M.fs.table = t; }
+        launch_alpha_merge32(M);
+    }
+    if ((c->plan == PLAN_MAIN && d->fullchr_on == 2) || alpha_run) {
+        if ((!alpha_run && p422join.empty()) || !d->strip_ok) { log_msg(c, 0, "internal error: alpha launch without the strip plan\n"); return SWS_AVERROR(EINVAL); }
+        alfr.assign(frames, frames + n);
+        pA = p;
+        const bool rd = d->rgbread_on;
+        if (rd) { if (d->rgbread_offA < 0) { log_msg(c, 0, "internal error: reader pre-pass without an alpha plane\n"); return SWS_AVERROR(EINVAL); }
+                  pA.srcKind = SRCK_PLANAR16; pA.src_shift = 0; }
+        for (int i = 0; i < n; i++) {
+            SwsFramePtrs &a = alfr[(size_t)i];
+            if (rd) { a.src[0] = (const uint8_t *)d->rgbread_img + (size_t)i * (size_t)d->rgbread_frame_bytes + d->rgbread_offA; a.srcStride[0] = d->rgbread_strideY; }
+            else { a.src[0] = frames[i].src[3]; a.srcStride[0] = frames[i].srcStride[3]; }
+            a.src[1] = a.src[2] = a.src[3] = nullptr; a.srcStride[1] = a.srcStride[2] = a.srcStride[3] = 0;
+            if (alpha_run) { a.dst[0] = frames[i].dst[3]; a.dstStride[0] = frames[i].dstStride[3]; }
+            else { a.dst[0] = const_cast<uint8_t *>(p422join[(size_t)i].src[3]); a.dstStride[0] = p422join[(size_t)i].srcStride[3]; }
+            a.dst[1] = a.dst[2] = a.dst[3] = nullptr; a.dstStride[1] = a.dstStride[2] = a.dstStride[3] = 0;
+        }
+        LaunchCtx A = L;
+        std::memset(&A.fs, 0, sizeof(A.fs));
+        A.fs.count = n; A.frames = alfr.data(); A.p = &pA;
+        if (n == 1) { A.fs.table = nullptr; A.fs.one = alfr[0]; }
+        else { const SwsFramePtrs *t = nullptr; int r = aux_table(2, alfr, &t); if (r < 0) return r; A.fs.table = t; }
+        ret = launch_strip_luma(A);
+        if (ret < 0) return ret;
+    }
     if (!p422join.empty()) {   // interleave the planar 4:2:2 working pictures into the packed destinations
         LaunchCtx J = L;
         std::memset(&J.fs, 0, sizeof(J.fs));
@@ -1311,6 +1455,14 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         else { const SwsFramePtrs *t = nullptr; int r = aux_table(0, p422join, &t); if (r < 0) return r; J.fs.table = t; }
         if (d->fullchr_on) launch_fullchr_rgb(J);
         else launch_layout_join422(J, d->join422 == 2);
+    }
+    if (stage_out) {   // the staged destination planes back into the caller's picture
+        LaunchCtx S = L;
+        std::memset(&S.fs, 0, sizeof(S.fs));
+        S.fs.count = n; S.frames = st_out.data(); S.vec = false;
+        if (n == 1) { S.fs.table = nullptr; S.fs.one = st_out[0]; }
+        else { const SwsFramePtrs *t = nullptr; int r = aux_table(4, st_out, &t); if (r < 0) return r; S.fs.table = t; }
+        launch_stage_planes(S, st_rb[1], st_rows[1], false);
     }
     HIPCHK(hipGetLastError());
     if (d->timing) { HIPCHK(hipEventRecord(d->ev1, st)); d->timed = true; }

@@ -46,15 +46,18 @@ struct DeviceState {
     // scaled packed-RGB sources: the reader pre-pass writes 16-bit Y / U / V planes per frame (k_stream.hip launch_rgb_read16), the strip kernel
     // reads them through a second frame table (k_strip.hip launch_rgbread_strip)
     bool rgbread_on = false; void *rgbread_img = nullptr; size_t rgbread_bytes = 0;
+    int64_t rgbread_frame_bytes = 0, rgbread_offA = -1; int rgbread_strideY = 0;   // layout of the last reader pre-pass (the alpha launch of a full-chroma RGB destination reads its A plane)
     SwsFramePtrs *d_frames2 = nullptr, *h_frames2 = nullptr; int frames2_cap = 0, frames2_valid = 0;
     // helper passes around a packed / semi-planar side of the scaler (dev_prepare_on decides, launch_plan_le runs them):
-    int fullchr_on = 0, fullchr_kind = 0;              // full-chroma packed RGB destination: the strip kernels write int32 sum planes (DSTK_RAW32), sws_k_fullchr_rgb follows; the real dstKind
+    int fullchr_on = 0, fullchr_kind = 0;              // full-chroma packed RGB destination (2: with a scaled alpha plane): the strip kernels write int32 sum planes (DSTK_RAW32), sws_k_fullchr_rgb follows; the real dstKind
+    int alpha_launch = 0;                              // planar YUV destination with a scaled alpha plane (needAlpha): one more luma launch of the strip kernel, A samples -> dst[3]
     int join422 = 0;                                   // packed 4:2:2 destination through the planar writers + interleave: 1 yuyv-like, 2 uyvy
     void *join_img = nullptr; size_t join_bytes = 0;   //   its planar 4:2:2 working pictures (one per frame of the call)
     int split_mode = 0, split_shift = 0;               // source split into planar working planes: 1 / 2 packed 4:2:2 (yuyv-like / uyvy) | 4 V first; 8 semi-planar 8-bit
                                                        //   chroma | 16 V first; 32 p010-style planes, every word >> split_shift
     void *split_img = nullptr; size_t split_bytes = 0;
-    SwsFramePtrs *d_aux_tables = nullptr, *h_aux_tables = nullptr; int aux_cap = 0, aux_valid[2] = { 0, 0 };   // frame tables of the two passes (slot 0 join, 1 split)
+    SwsFramePtrs *d_aux_tables = nullptr, *h_aux_tables = nullptr; int aux_cap = 0, aux_valid[5] = { 0, 0, 0, 0, 0 };   // frame tables of the helper passes (slot 0 join / RGB epilogue, 1 split, 2 alpha launch, 3 / 4 staging in / out)
+    void *stage_img = nullptr; size_t stage_bytes = 0; // 16-byte aligned copies of the planes of pictures that are not (launch_plan_le: only under the helper passes)
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timing = false; bool timed = false;
     hipEvent_t ev_loan = nullptr;   // orders the context's own stream against a borrowed frames stream (dev_borrow_stream)
 };
@@ -123,7 +126,9 @@ int  launch_strip(const LaunchCtx &L);
 int  launch_rgbsrc(const LaunchCtx &L);
 int  launch_rgbread_strip(const LaunchCtx &L);   // k_strip.hip: scaled packed 24 / 32 bpp RGB source: reader pre-pass + strip kernel on its 16-bit planes
 void launch_fullchr_rgb(const LaunchCtx &L);   // k_stream.hip
-void launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, int64_t offU, int64_t offV, int strideY, int strideC);   // k_stream.hip
+void launch_stage_planes(const LaunchCtx &L, const int row_bytes[4], const int rows[4], bool in);   // k_stream.hip: src[k] -> dst[k] plane copies, one side 16-byte aligned
+void launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, int64_t offU, int64_t offV, int strideY, int strideC, int64_t offA, int a_pos);   // k_stream.hip
+int  launch_strip_luma(const LaunchCtx &L);      // k_strip.hip: the luma launch alone (the alpha plane of a full-chroma RGB destination goes through the luma filters)
 int  launch_striprgb(const LaunchCtx &L);
 int  launch_tile_dot2(const LaunchCtx &L);
 int  launch_tile(const LaunchCtx &L);

@@ -70,11 +70,11 @@ int launch_rgbsrc(const LaunchCtx &L)
 }
 
 // reader pre-pass of a scaled packed 24 / 32 bpp RGB source (dev_prepare_on: rgbread_on): 16-bit Y / U / V planes per frame at `base`
-void launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, int64_t offU, int64_t offV, int strideY, int strideC)
+void launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, int64_t offU, int64_t offV, int strideY, int strideC, int64_t offA, int a_pos)
 {
     const SwsDevParams &p = *L.p;
     swsk::RgbReadLayout lay;
-    lay.base = base; lay.frame_bytes = frame_bytes; lay.offU = offU; lay.offV = offV; lay.strideY = strideY; lay.strideC = strideC;
+    lay.base = base; lay.frame_bytes = frame_bytes; lay.offU = offU; lay.offV = offV; lay.strideY = strideY; lay.strideC = strideC; lay.offA = offA; lay.a_pos = a_pos;
     const dim3 grid(cdiv(cdiv(p.srcW, 4), 256), cdiv(p.srcH, swsk::RGBREAD_RPW), L.n), blk(256);
     if (p.chr_half) {
         if (p.srcKind == SRCK_GBRP) hipLaunchKernelGGL((swsk::sws_k_rgb_read16<0, true>), grid, blk, 0, L.st, L.fs, p, lay);
@@ -92,8 +92,37 @@ void launch_fullchr_rgb(const LaunchCtx &L)
 {
     const SwsDevParams &p = *L.p;
     const dim3 grid(cdiv(cdiv(p.dstW, 4), 256), cdiv(p.dstH, swsk::FULLCHR_RPW), L.n), blk(256);
-    if (p.lut.pix_step == 4) hipLaunchKernelGGL((swsk::sws_k_fullchr_rgb<4>), grid, blk, 0, L.st, L.fs, p);
-    else hipLaunchKernelGGL((swsk::sws_k_fullchr_rgb<3>), grid, blk, 0, L.st, L.fs, p);
+    if (L.d->fullchr_kind == DSTK_GBRP) {
+        const bool wide = p.dst_bits > 8, alpha = L.d->fullchr_on == 2;
+        if (wide && alpha) hipLaunchKernelGGL((swsk::sws_k_fullchr_gbrp<true, true>), grid, blk, 0, L.st, L.fs, p);
+        else if (wide) hipLaunchKernelGGL((swsk::sws_k_fullchr_gbrp<true, false>), grid, blk, 0, L.st, L.fs, p);
+        else if (alpha) hipLaunchKernelGGL((swsk::sws_k_fullchr_gbrp<false, true>), grid, blk, 0, L.st, L.fs, p);
+        else hipLaunchKernelGGL((swsk::sws_k_fullchr_gbrp<false, false>), grid, blk, 0, L.st, L.fs, p);
+        return;
+    }
+    if (p.lut.pix_step == 4 && L.d->fullchr_on == 2) hipLaunchKernelGGL((swsk::sws_k_fullchr_rgb<4, true>), grid, blk, 0, L.st, L.fs, p);
+    else if (p.lut.pix_step == 4) hipLaunchKernelGGL((swsk::sws_k_fullchr_rgb<4, false>), grid, blk, 0, L.st, L.fs, p);
+    else hipLaunchKernelGGL((swsk::sws_k_fullchr_rgb<3, false>), grid, blk, 0, L.st, L.fs, p);
+}
+
+// plane copies between unaligned pictures and their aligned working copies (device.hip launch_plan_le; L.fs holds {src[k] -> dst[k]})
+void launch_stage_planes(const LaunchCtx &L, const int row_bytes[4], const int rows[4], bool in)
+{
+    swsk::StageExtents e;
+    int wmax = 0, hmax = 0;
+    for (int k = 0; k < 4; k++) { e.row_bytes[k] = row_bytes[k]; e.rows[k] = rows[k]; wmax = std::max(wmax, row_bytes[k]); hmax = std::max(hmax, rows[k]); }
+    if (wmax <= 0 || hmax <= 0) return;
+    const dim3 grid(cdiv(cdiv(wmax, 4), 256), cdiv(hmax, swsk::STAGE_RPW), L.n), blk(256);
+    if (in) hipLaunchKernelGGL((swsk::sws_k_stage_planes<true>), grid, blk, 0, L.st, L.fs, e);
+    else hipLaunchKernelGGL((swsk::sws_k_stage_planes<false>), grid, blk, 0, L.st, L.fs, e);
+}
+
+// the alpha bytes behind sws_k_strip_rgb (device.hip: alpha_launch == 2; L.fs holds {src[0] = the int32 sums of the A plane, dst[0] = the packed picture})
+void launch_alpha_merge32(const LaunchCtx &L)
+{
+    const SwsDevParams &p = *L.p;
+    const dim3 grid(cdiv(cdiv(p.dstW, 4), 256), cdiv(p.dstH, swsk::FULLCHR_RPW), L.n), blk(256);
+    hipLaunchKernelGGL((swsk::sws_k_alpha_merge32), grid, blk, 0, L.st, L.fs, p);
 }
 
 // packed / planar 8-bit RGB -> planar 8-bit 4:4:4 YUV of the same size: every filter the identity (dev_prepare_on: rgb444_ok)

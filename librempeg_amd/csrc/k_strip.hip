@@ -80,7 +80,8 @@ int launch_strip_planes(const LaunchCtx &L, int which)
     return 0;
 }
 
-int launch_strip(const LaunchCtx &L) { return launch_strip_planes(L, L.p->no_chroma ? 1 : 3); }   // (gray -> gray: the luma launch alone)
+int launch_strip(const LaunchCtx &L) { return launch_strip_planes(L, L.p->no_chroma ? 1 : 3); }
+int launch_strip_luma(const LaunchCtx &L) { return launch_strip_planes(L, 1); }   // (gray -> gray: the luma launch alone)
 
 // Same-size planar YUV -> planar / semi-planar YUV whose luma filters are the identity in both directions and whose chroma is scaled
 // (yuv422p -> yuv420p, yuv444p -> yuv420p / nv12, 10-bit -> 8-bit twins ...): the luma plane is a streaming per-sample pass (the scaler's own
@@ -101,11 +102,14 @@ int launch_rgbread_strip(const LaunchCtx &L)
     const int n = L.n;
     auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
     const int strideY = (int)a256(2 * (int64_t)p.srcW), strideC = (int)a256(2 * (int64_t)p.chrSrcW);
-    const int64_t offU = (int64_t)strideY * p.srcH, offV = offU + (int64_t)strideC * p.srcH, frame_bytes = a256(offV + (int64_t)strideC * p.srcH);
+    const bool alpha = (d->fullchr_on == 2 || d->alpha_launch) && p.srcKind == SRCK_RGB32;     // (a scaled alpha plane behind the strip kernels: device.hip)
+    const int64_t offU = (int64_t)strideY * p.srcH, offV = offU + (int64_t)strideC * p.srcH, offA = a256(offV + (int64_t)strideC * p.srcH);
+    const int64_t frame_bytes = a256(offA + (alpha ? (int64_t)strideY * p.srcH : 0));
+    d->rgbread_frame_bytes = frame_bytes; d->rgbread_offA = alpha ? offA : -1; d->rgbread_strideY = strideY;
     int r = grow(c, &d->rgbread_img, &d->rgbread_bytes, (size_t)frame_bytes * (size_t)n);
     if (r < 0) return r;
     uint8_t *base = (uint8_t *)d->rgbread_img;
-    launch_rgb_read16(L, base, frame_bytes, offU, offV, strideY, strideC);
+    launch_rgb_read16(L, base, frame_bytes, offU, offV, strideY, strideC, offA, alpha ? (p.src_a_pos | (p.src_alpha_opaque ? 8 : 0)) : -1);
     std::vector<SwsFramePtrs> fr(L.frames, L.frames + n);
     for (int i = 0; i < n; i++) {
         uint8_t *fb = base + (size_t)i * (size_t)frame_bytes;

@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity(SwsFrameSet fs, SwsDev
 // as the 16-bit planes hScale16To15_c reads (formatConvBuffer of the line ring, swscale.c:69-97): Y[srcH][srcW], U / V[srcH][srcW / 2].
 // The marching strip kernel then takes these planes like a planar 16-bit source (k_strip.hip launch_rgbread_strip).  Lane = four pixels of a
 // row (12- or 16-byte load; 8 + 4 + 4 bytes stored), a wave walks down RGBREAD_RPW rows with the next row's load in flight.
-struct RgbReadLayout { uint8_t *base; int64_t frame_bytes, offU, offV; int32_t strideY, strideC; };
+struct RgbReadLayout { uint8_t *base; int64_t frame_bytes, offU, offV, offA; int32_t strideY, strideC, a_pos; };   // a_pos < 0: no alpha plane (else rgbaToA_c / abgrToA_c, input.c:454-472)
 constexpr int RGBREAD_RPW = 8;
 
 // HALF: the "half" chroma readers (chroma planes of srcW / 2 columns: every shape whose chroma destination is at most half as wide as the source,
@@ -250,6 +250,15 @@ __global__ void __launch_bounds__(256) sws_k_rgb_read16(SwsFrameSet fs, SwsDevPa
         }
         const u32x2 oy = { yv[0] | yv[1] << 16, yv[2] | yv[3] << 16 };
         *(u32x2 *)(dY + (int64_t)r * dsY) = oy;
+        if (BPP == 4 && U(lay.a_pos) >= 0) {     // the alpha bytes as the 14-bit samples the luma scaler reads: a << 6 | a >> 2
+            const int sh8 = 8 * (U(lay.a_pos) & 3);
+            const uint32_t opaque = (U(lay.a_pos) & 8) ? 0xFFu : 0u;     // (an rgb0-style source feeding a real alpha channel: its X byte counts as 255, swscale.c:1106-1124)
+            uint32_t av[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint32_t a = ((d[k] >> sh8) & 0xFFu) | opaque; av[k] = (a << 6) | (a >> 2); }
+            const u32x2 oa = { av[0] | av[1] << 16, av[2] | av[3] << 16 };
+            *(u32x2 *)(fb + U(lay.offA) + 2 * (int64_t)x0 + (int64_t)r * dsY) = oa;
+        }
         if constexpr (HALF) {
             uint32_t uv[2], vv[2];
 #pragma unroll

@@ -83,6 +83,37 @@ __global__ void __launch_bounds__(256) sws_k_f32rgb_to_yuv444_unity(SwsFrameSet 
     }
 }
 
+// Plane copies between a picture whose planes are not 16-byte aligned and its aligned working copy (launch_plan_le stages such pictures when the
+// context runs helper passes, which read and write 16-byte granules): src[k] -> dst[k] for every plane present.  IN: the destination is the aligned
+// side (byte loads, dword stores into rows padded to 256 bytes); otherwise the source is (dword loads, byte stores of the visible bytes only).
+struct StageExtents { int32_t row_bytes[4], rows[4]; };
+constexpr int STAGE_RPW = 8;
+template <bool IN>
+__global__ void __launch_bounds__(256) sws_k_stage_planes(SwsFrameSet fs, StageExtents e)
+{
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int y0 = blockIdx.y * STAGE_RPW;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int rb = U(e.row_bytes[k]), rows = U(e.rows[k]);
+        if (!f.src[k] || !f.dst[k] || x >= rb) continue;
+        const int nb = min(4, rb - x);
+        for (int y = y0; y < min(rows, y0 + STAGE_RPW); y++) {
+            const uint8_t *s = f.src[k] + (int64_t)y * f.srcStride[k] + x;
+            uint8_t *d = f.dst[k] + (int64_t)y * f.dstStride[k] + x;
+            if (IN) {
+                uint32_t v = 0;
+                for (int b = 0; b < nb; b++) v |= (uint32_t)s[b] << (8 * b);
+                *(uint32_t *)d = v;
+            } else {
+                const uint32_t v = *(const uint32_t *)s;
+                for (int b = 0; b < nb; b++) d[b] = (uint8_t)(v >> (8 * b));
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Full-chroma packed RGB epilogue (SWS_FULL_CHR_H_INT: RGB -> RGB scaling, 4:4:4 sources, odd widths, the user's full_chroma_int): the strip kernels
 // leave the vertical sums of Y, U and V -- all three at the destination size -- as int32 planes (DSTK_RAW32); this pass is
@@ -91,7 +122,8 @@ __global__ void __launch_bounds__(256) sws_k_f32rgb_to_yuv444_unity(SwsFrameSet 
 // loads), a wave walks down FULLCHR_RPW rows with the next row's loads in flight; 12- or 16-byte stores.
 // ------------------------------------------------------------------------------------------
 constexpr int FULLCHR_RPW = 4;
-template <int BPP>
+// ALPHA: a fourth sum plane (the alpha plane through the luma filters): A = (sum + (1 << 18)) >> 19, clipped the way the writer does (output.c:2193-2201)
+template <int BPP, bool ALPHA>
 __global__ void __launch_bounds__(256) sws_k_fullchr_rgb(SwsFrameSet fs, SwsDevParams p)
 {
     const FrameRegs f = load_frame(fs, blockIdx.z);
@@ -103,19 +135,20 @@ __global__ void __launch_bounds__(256) sws_k_fullchr_rgb(SwsFrameSet fs, SwsDevP
     const bool in = x < W;
     const int npx = min(4, W - x);
     const int y0 = blockIdx.y * FULLCHR_RPW, y1 = min(H, y0 + FULLCHR_RPW);
-    const uint8_t *pY = f.src[0] + 4 * (int64_t)x, *pU = f.src[1] + 4 * (int64_t)x, *pV = f.src[2] + 4 * (int64_t)x;
-    const int64_t sY = f.srcStride[0], sU = f.srcStride[1], sV = f.srcStride[2];
+    const uint8_t *pY = f.src[0] + 4 * (int64_t)x, *pU = f.src[1] + 4 * (int64_t)x, *pV = f.src[2] + 4 * (int64_t)x, *pA = ALPHA ? f.src[3] + 4 * (int64_t)x : nullptr;
+    const int64_t sY = f.srcStride[0], sU = f.srcStride[1], sV = f.srcStride[2], sA = ALPHA ? f.srcStride[3] : 0;
     const SwsLutParams &L = p.lut;
     const int y_offset = U(L.y_offset), y_coeff = U(L.y_coeff), v2r = U(L.v2r), v2g = U(L.v2g), u2g = U(L.u2g), u2b = U(L.u2b);
     const int r_pos = U(L.r_pos), g_pos = U(L.g_pos), b_pos = U(L.b_pos), a_pos = U(L.a_pos);
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4 nY = { 0, 0, 0, 0 }, nU = nY, nV = nY;
+    i32x4 nY = { 0, 0, 0, 0 }, nU = nY, nV = nY, nA = nY;
     auto fetch = [&](int y) {   // (the working planes are padded to whole 16-byte groups: no tail loads)
         nY = *(const SWS_GLOBAL i32x4 *)(pY + y * sY); nU = *(const SWS_GLOBAL i32x4 *)(pU + y * sU); nV = *(const SWS_GLOBAL i32x4 *)(pV + y * sV);
+        if constexpr (ALPHA) nA = *(const SWS_GLOBAL i32x4 *)(pA + y * sA);
     };
     if (in && y0 < y1) fetch(y0);
     for (int y = y0; y < y1; y++) {
-        const i32x4 vY = nY, vU = nU, vV = nV;
+        const i32x4 vY = nY, vU = nU, vV = nV, vA = nA;
         if (in && y + 1 < y1) fetch(y + 1);
         if (!in) continue;
         uint32_t px[4];
@@ -131,7 +164,11 @@ __global__ void __launch_bounds__(256) sws_k_fullchr_rgb(SwsFrameSet fs, SwsDevP
             int B = (int)((unsigned)Y + (unsigned)Uc * (unsigned)u2b);
             if ((R | G | B) & 0xC0000000) { R = clip_uintp2(R, 30); G = clip_uintp2(G, 30); B = clip_uintp2(B, 30); }
             px[k] = ((uint32_t)(R >> 22) << (8 * r_pos)) | ((uint32_t)(G >> 22) << (8 * g_pos)) | ((uint32_t)(B >> 22) << (8 * b_pos));
-            if (BPP == 4) px[k] |= 255u << (8 * a_pos);
+            if (BPP == 4) {
+                int A = 255;
+                if constexpr (ALPHA) { A = (int)((unsigned)vA[k] + (1u << 18)) >> 19; if (A & 0x100) A = clip_u8(A); }
+                px[k] |= ((uint32_t)A & 0xFFu) << (8 * a_pos);
+            }
         }
         uint8_t *d = f.dst[0] + (int64_t)y * f.dstStride[0] + (int64_t)BPP * x;
         if (BPP == 4) {
@@ -143,6 +180,116 @@ __global__ void __launch_bounds__(256) sws_k_fullchr_rgb(SwsFrameSet fs, SwsDevP
                 ((uint32_t *)d)[1] = ((px[1] >> 8) & 0xFFFFu) | (px[2] << 16);
                 ((uint32_t *)d)[2] = ((px[2] >> 16) & 0xFFu) | (px[3] << 8);
             } else for (int k = 0; k < npx; k++) { d[3 * k] = (uint8_t)px[k]; d[3 * k + 1] = (uint8_t)(px[k] >> 8); d[3 * k + 2] = (uint8_t)(px[k] >> 16); }
+        }
+    }
+}
+
+// The same epilogue for planar RGB destinations of 8 .. 14 bits (gbrp, gbrap, gbrp10le ... and the msb-aligned twins): yuv2gbrp_full_X_c
+// (output.c:2342-2421) -- any_vscale always takes the X form for them, and full chroma is forced (utils.c:1270-1286).  Planes G, B, R (, A);
+// rounding 1 << (SH - 1) and >> SH with SH = 22 + 8 - depth; alpha: (1 << 18) + sum, clipped to 27 bits, >> (SH - 3).
+template <bool WIDE, bool ALPHA>
+__global__ void __launch_bounds__(256) sws_k_fullchr_gbrp(SwsFrameSet fs, SwsDevParams p)
+{
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int lane = threadIdx.x & 63;
+    const int cx = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = U(p.dstW), H = U(p.dstH);
+    if (cx * 256 >= W) return;
+    const int x = (cx * 64 + lane) * 4;
+    const bool in = x < W;
+    const int npx = min(4, W - x);
+    const int y0 = blockIdx.y * FULLCHR_RPW, y1 = min(H, y0 + FULLCHR_RPW);
+    const uint8_t *pY = f.src[0] + 4 * (int64_t)x, *pU = f.src[1] + 4 * (int64_t)x, *pV = f.src[2] + 4 * (int64_t)x, *pA = ALPHA ? f.src[3] + 4 * (int64_t)x : nullptr;
+    const int64_t sY = f.srcStride[0], sU = f.srcStride[1], sV = f.srcStride[2], sA = ALPHA ? f.srcStride[3] : 0;
+    const SwsLutParams &L = p.lut;
+    const int y_offset = U(L.y_offset), y_coeff = U(L.y_coeff), v2r = U(L.v2r), v2g = U(L.v2g), u2g = U(L.u2g), u2b = U(L.u2b);
+    const int SH = 22 + 8 - U(p.dst_bits), dsh = U(p.dst_shift);
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 nY = { 0, 0, 0, 0 }, nU = nY, nV = nY, nA = nY;
+    auto fetch = [&](int y) {
+        nY = *(const SWS_GLOBAL i32x4 *)(pY + y * sY); nU = *(const SWS_GLOBAL i32x4 *)(pU + y * sU); nV = *(const SWS_GLOBAL i32x4 *)(pV + y * sV);
+        if constexpr (ALPHA) nA = *(const SWS_GLOBAL i32x4 *)(pA + y * sA);
+    };
+    if (in && y0 < y1) fetch(y0);
+    for (int y = y0; y < y1; y++) {
+        const i32x4 vY = nY, vU = nU, vV = nV, vA = nA;
+        if (in && y + 1 < y1) fetch(y + 1);
+        if (!in) continue;
+        uint32_t g[4], b[4], r[4], a[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int Y = (int)((unsigned)vY[k] + (1u << 9)) >> 10;
+            const int Uc = (int)((unsigned)vU[k] + (unsigned)((1 << 9) - (128 << 19))) >> 10, Vc = (int)((unsigned)vV[k] + (unsigned)((1 << 9) - (128 << 19))) >> 10;
+            Y -= y_offset;
+            Y = (int)((unsigned)Y * (unsigned)y_coeff);
+            Y = (int)((unsigned)Y + (1u << (SH - 1)));
+            int R = (int)((unsigned)Y + (unsigned)Vc * (unsigned)v2r);
+            int G = (int)((unsigned)Y + (unsigned)Vc * (unsigned)v2g + (unsigned)Uc * (unsigned)u2g);
+            int B = (int)((unsigned)Y + (unsigned)Uc * (unsigned)u2b);
+            if ((R | G | B) & 0xC0000000) { R = clip_uintp2(R, 30); G = clip_uintp2(G, 30); B = clip_uintp2(B, 30); }
+            g[k] = (uint32_t)(G >> SH); b[k] = (uint32_t)(B >> SH); r[k] = (uint32_t)(R >> SH);
+            if constexpr (ALPHA) {
+                int A = (int)((unsigned)vA[k] + (1u << 18));
+                if (A & 0xF8000000) A = clip_uintp2(A, 27);
+                a[k] = (uint32_t)(A >> (SH - 3));
+            }
+            if constexpr (WIDE) {
+                g[k] = (g[k] << dsh) & 0xFFFFu; b[k] = (b[k] << dsh) & 0xFFFFu; r[k] = (r[k] << dsh) & 0xFFFFu;
+                if constexpr (ALPHA) a[k] &= 0xFFFFu;
+            } else {
+                g[k] &= 0xFFu; b[k] &= 0xFFu; r[k] &= 0xFFu;
+                if constexpr (ALPHA) a[k] &= 0xFFu;
+            }
+        }
+        auto put = [&](int plane, const uint32_t (&v)[4]) {
+            uint8_t *d = f.dst[plane] + (int64_t)y * f.dstStride[plane] + (int64_t)(WIDE ? 2 : 1) * x;
+            if constexpr (WIDE) {
+                if (npx == 4) { const u32x2 o = { v[0] | v[1] << 16, v[2] | v[3] << 16 }; *(SWS_GLOBAL u32x2 *)d = o; }
+                else for (int k = 0; k < npx; k++) ((uint16_t *)d)[k] = (uint16_t)v[k];
+            } else {
+                if (npx == 4) *(SWS_GLOBAL uint32_t *)d = v[0] | v[1] << 8 | v[2] << 16 | v[3] << 24;
+                else for (int k = 0; k < npx; k++) d[k] = (uint8_t)v[k];
+            }
+        };
+        put(0, g); put(1, b); put(2, r);
+        if constexpr (ALPHA) put(3, a);
+    }
+}
+
+// The alpha bytes of a 32 bpp destination written by the LUT writers' strip kernel (sws_k_strip_rgb stores 255): yuva420p -> bgra and the like
+// (needAlpha without full chroma).  The A samples went through one more luma launch with the raw writer (int32 sums); this pass is the alpha part of
+// yuv2rgb_X_c_template (output.c:1820-1835): A = (sum + (1 << 18)) >> 19 per pixel, and both pixels of a pair are clipped when either has bit 8 set.
+// Lane = four pixels: one 16-byte load of sums, a 16-byte read-modify-write of the destination.
+__global__ void __launch_bounds__(256) sws_k_alpha_merge32(SwsFrameSet fs, SwsDevParams p)
+{
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int lane = threadIdx.x & 63;
+    const int cx = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = U(p.dstW), H = U(p.dstH);
+    const int x = (cx * 64 + lane) * 4;
+    if (x >= W) return;
+    const int npx = min(4, W - x);
+    const int sh = 8 * U(p.lut.a_pos);
+    const uint32_t keep = ~(0xFFu << sh);
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const int y0 = blockIdx.y * FULLCHR_RPW, y1 = min(H, y0 + FULLCHR_RPW);
+    for (int y = y0; y < y1; y++) {
+        const i32x4 v = *(const SWS_GLOBAL i32x4 *)(f.src[0] + (int64_t)y * f.srcStride[0] + 4 * (int64_t)x);   // (the working plane is padded to whole 16-byte groups)
+        int A[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) A[k] = (int)((unsigned)v[k] + (1u << 18)) >> 19;
+#pragma unroll
+        for (int k = 0; k < 4; k += 2)
+            if ((A[k] | A[k + 1]) & 0x100) { A[k] = clip_u8(A[k]); A[k + 1] = clip_u8(A[k + 1]); }
+        uint32_t *d = (uint32_t *)(f.dst[0] + (int64_t)y * f.dstStride[0] + 4 * (int64_t)x);
+        if (npx == 4) {
+            u32x4 o = *(const SWS_GLOBAL u32x4 *)d;
+#pragma unroll
+            for (int k = 0; k < 4; k++) o[k] = (o[k] & keep) | (((uint32_t)A[k] & 0xFFu) << sh);
+            *(SWS_GLOBAL u32x4 *)d = o;
+        } else {
+            // (an odd width never gets here -- full chroma is forced for it -- but a width of 4 n + 2 does: the pair rule still sees whole pairs)
+            for (int k = 0; k < npx; k++) d[k] = (d[k] & keep) | (((uint32_t)A[k] & 0xFFu) << sh);
         }
     }
 }

@@ -12,7 +12,9 @@ BX = SWS_BITEXACT
 FC = SWS_FULL_CHR_H_INT
 TUNE = dict(strip_min_w=0)
 
-SRC = ["rgb24", "bgr24", "bgra", "argb", "rgb0", "gbrp", "yuv444p", "yuv420p", "yuv422p", "nv12", "nv21", "yuyv422", "uyvy422", "yuv420p10le", "yuv444p10le", "p010le", "yuvj420p", "yuv410p"]
+SRC = ["rgb24", "bgr24", "bgra", "argb", "rgb0", "0bgr", "gbrp", "gbrap", "yuv444p", "yuv420p", "yuv422p", "nv12", "nv21", "yuyv422", "uyvy422", "yuv420p10le", "yuv444p10le", "p010le", "yuvj420p",
+       "yuv410p", "yuva420p", "yuva444p", "yuva422p10le"]
+SUBSAMPLED_V = ("yuv420p", "nv12", "nv21", "yuv420p10le", "p010le", "yuvj420p", "yuv410p", "yuva420p")
 DST = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "0bgr"]
 
 
@@ -22,21 +24,44 @@ def test_formats(src, dst):
     for (sw, sh, dw, dh, fl) in ((256, 64, 192, 48, SWS_BICUBIC), (320, 50, 512, 80, SWS_BICUBIC), (132, 34, 67, 17, SWS_AREA), (256, 64, 321, 96, SWS_LANCZOS),
                                  (256, 64, 250, 64, SWS_GAUSS), (130, 30, 131, 31, SWS_BICUBIC | SWS_ACCURATE_RND), (256, 64, 256, 64, SWS_BICUBIC)):
         r = run_case(sw, sh, src, dw, dh, dst, fl | FC | BX, seed=sw + dh, tune=TUNE)
-        alpha_src = src in ("bgra", "argb", "gbrap") and dst in ("rgba", "bgra", "argb", "abgr", "rgb0", "0bgr")     # (a real alpha plane is scaled: the generic writer)
-        # (area at 2:1: two luma and two chroma taps, yuv2rgb_full_2; an unscaled height with unsubsampled chroma rows: one tap each, yuv2rgb_full_1;
-        #  rgb0 / 0bgr sources become their alpha twins with an opaque plane that IS scaled: the generic writer)
-        short = fl == SWS_AREA or (sh == dh and src not in ("yuv420p", "nv12", "nv21", "yuv420p10le", "p010le", "yuvj420p", "yuv410p"))
-        rgb_src = src in ("rgb24", "bgr24", "bgra", "argb", "rgb0", "gbrp")
-        if (sw, sh) != (dw, dh) and not alpha_src and not short and not (src == "rgb0" and dst not in ("rgb24", "bgr24")) and not (rgb_src and sw & 3):
+        # (a real alpha plane scaled into a 32 bpp destination -- needAlpha -- is a fourth sum plane: the reader pre-pass hands the A bytes of a packed
+        #  source to the luma filters, a planar YUV source has them in plane 3; planar RGB with alpha keeps the generic writer)
+        alpha_generic = src == "gbrap" and dst not in ("rgb24", "bgr24")
+        # (area at 2:1: two luma and two chroma taps, yuv2rgb_full_2; an unscaled height with unsubsampled chroma rows: one tap each, yuv2rgb_full_1)
+        short = fl == SWS_AREA or (sh == dh and src not in SUBSAMPLED_V)
+        rgb_src = src in ("rgb24", "bgr24", "bgra", "argb", "rgb0", "0bgr", "gbrp", "gbrap")
+        if (sw, sh) != (dw, dh) and not alpha_generic and not short and not (rgb_src and sw & 3):
+            assert r[0].endswith("+fullchr_rgb"), (r[0], src, dst, sw, dw)
+
+
+GBR_DST = ["gbrp", "gbrap", "gbrp9le", "gbrp10le", "gbrp12le", "gbrp14le", "gbrap10le", "gbrap12le", "gbrap14le", "gbrp10msble", "gbrp12msble", "gbrp10be", "gbrap12be"]
+
+
+@pytest.mark.parametrize("src", ["yuv420p", "nv12", "yuv444p", "yuv420p10le", "p010le", "rgb24", "bgra", "rgb0", "gbrp", "yuva420p", "yuva444p10le", "yuyv422", "yuvj420p"])
+@pytest.mark.parametrize("dst", GBR_DST)
+def test_planar_rgb_destinations(src, dst):
+    """yuv2gbrp_full_X_c (output.c:2342-2421): planar RGB of 8 .. 14 bits always takes the X form and forced full chroma: sws_k_fullchr_gbrp"""
+    for (sw, sh, dw, dh, fl) in ((256, 64, 192, 48, SWS_BICUBIC), (320, 50, 512, 80, SWS_BILINEAR), (132, 34, 67, 17, SWS_AREA), (256, 64, 321, 96, SWS_LANCZOS),
+                                 (256, 64, 250, 64, SWS_GAUSS), (132, 30, 131, 31, SWS_BICUBIC | SWS_ACCURATE_RND), (256, 64, 256, 32, SWS_BICUBIC)):
+        r = run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh, tune=TUNE)
+        if sw != dw and not (src in ("rgb24", "bgra", "rgb0", "gbrp") and sw & 3):
             assert r[0].endswith("+fullchr_rgb"), (r[0], src, dst, sw, dw)
 
 
 def test_forced_full_chroma_and_fallbacks():
+    assert run_case(3840, 2160, "yuv420p", 1920, 1080, "gbrp", SWS_BICUBIC | BX, seed=9)[0] == "main:strip_march+fullchr_rgb"
+    assert run_case(1920, 1080, "nv12", 1280, 720, "gbrap", SWS_BILINEAR | BX, seed=10, device_frames=False)[0] == "main:strip_march+fullchr_rgb"
+    assert run_case(1920, 1080, "bgra", 1280, 720, "gbrap10le", SWS_BICUBIC | BX, seed=11)[0] == "main:rgbread+strip_march+fullchr_rgb"
+    assert not run_case(256, 64, "yuv420p", 192, 48, "gbrp16le", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")     # 19-bit intermediates
+    assert not run_case(256, 64, "yuv420p", 192, 48, "gbrpf32le", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")
     assert run_case(256, 64, "rgb24", 192, 48, "bgr24", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")        # RGB source: forced
     assert run_case(256, 64, "yuv444p", 192, 48, "bgra", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")        # 4:4:4 source: forced
     assert run_case(256, 64, "yuv420p", 191, 48, "rgb24", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")       # odd width: forced
     assert not run_case(256, 64, "yuv420p", 192, 48, "rgb24", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")   # the LUT writers
-    assert not run_case(256, 64, "bgra", 192, 48, "bgra", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")       # alpha plane scaled
+    assert run_case(256, 64, "bgra", 192, 48, "bgra", SWS_BICUBIC | BX, tune=TUNE)[0] == "main:rgbread+strip_march+fullchr_rgb"   # alpha plane scaled: a fourth sum plane
+    assert run_case(256, 64, "yuva420p", 192, 48, "rgba", SWS_BICUBIC | FC | BX, tune=TUNE)[0] == "main:strip_march+fullchr_rgb"
+    assert not run_case(256, 64, "gbrap", 192, 48, "rgba", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")      # planar RGB with alpha: the generic writer
+    assert not run_case(256, 64, "yuva420p16le", 192, 48, "rgba", SWS_BICUBIC | FC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")   # 16-bit samples: 19-bit intermediates
     assert not run_case(256, 64, "rgb24", 192, 48, "rgb565le", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")
     assert not run_case(256, 64, "rgb24", 256, 128, "bgr24", SWS_BILINEAR | BX, tune=TUNE)[0].endswith("+fullchr_rgb")   # two luma and two chroma taps: yuv2rgb_full_2
     assert not run_case(640, 48, "rgb24", 320, 24, "bgr24", SWS_BICUBIC | BX)[0].endswith("+fullchr_rgb")                # narrow: below the planner's width threshold
@@ -50,7 +75,11 @@ def test_full_size_batches_and_host_frames():
     assert run_case(1920, 1080, "bgr24", 1280, 720, "bgra", SWS_BILINEAR | BX, seed=3, device_frames=False)[0] == "main:rgbread+strip_march+fullchr_rgb"
     assert run_case(1920, 1080, "yuv444p", 1280, 720, "rgb24", SWS_BICUBIC | BX, seed=4)[0] == "main:strip_march+fullchr_rgb"
     assert run_case(1920, 1080, "yuv420p", 1280, 720, "bgra", SWS_LANCZOS | FC | SWS_ACCURATE_RND | BX, seed=5)[0] == "main:strip_march+fullchr_rgb"
-    for src, dst, sw, sh, dw, dh, n, flags in (("rgb24", "bgr24", 1284, 70, 1028, 56, 5, SWS_BICUBIC | BX), ("nv12", "bgra", 1024, 64, 1283, 80, 3, SWS_BICUBIC | FC | BX)):
+    assert run_case(3840, 2160, "bgra", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=6)[0] == "main:rgbread+strip_march+fullchr_rgb"
+    assert run_case(1920, 1080, "rgba", 1280, 720, "argb", SWS_LANCZOS | BX, seed=7, device_frames=False)[0] == "main:rgbread+strip_march+fullchr_rgb"
+    assert run_case(1920, 1080, "yuva420p", 1280, 720, "bgra", SWS_BICUBIC | FC | BX, seed=8)[0] == "main:strip_march+fullchr_rgb"
+    for src, dst, sw, sh, dw, dh, n, flags in (("rgb24", "bgr24", 1284, 70, 1028, 56, 5, SWS_BICUBIC | BX), ("nv12", "bgra", 1024, 64, 1283, 80, 3, SWS_BICUBIC | FC | BX),
+                                               ("abgr", "rgba", 1284, 70, 1028, 56, 5, SWS_BICUBIC | BX), ("yuva444p10le", "bgra", 1024, 64, 1283, 80, 3, SWS_BICUBIC | BX)):
         o = OL.Oracle(sw, sh, src, dw, dh, dst, flags)
         p = SwsContext(sw, sh, src, dw, dh, dst, flags)
         refs, srcs, dsts = [], [], []
