@@ -89,9 +89,11 @@ def test_random_conversions_with_options(case):
 # width threshold would keep on the tile kernels (strip_min_w = 0), sizes from degenerate to a few strips wide
 STRIP_SRC = ["yuv420p", "yuv422p", "yuv444p", "yuv410p", "yuv411p", "yuv440p", "yuvj420p", "yuvj444p", "yuv420p10le", "yuv422p10le", "yuv444p12le", "yuv420p9le", "yuv420p14le",
              "yuv420p16le", "yuv420p10be", "nv12", "nv21", "nv16", "nv24", "p010le", "p012le", "p210le", "p010be", "p016le", "yuyv422", "uyvy422", "yvyu422", "rgb24", "bgr24",
-             "rgba", "bgra", "argb", "abgr", "rgb0", "gbrp", "gbrap", "gray8", "gray10le", "gray12le", "gray16le", "yuva420p", "rgb48le", "gbrp10le"]
+             "rgba", "bgra", "argb", "abgr", "rgb0", "gbrp", "gbrap", "gray8", "gray10le", "gray12le", "gray16le", "yuva420p", "rgb48le", "gbrp10le", "yuva444p", "yuva422p10le", "0bgr",
+             "yuva420p16le"]
 STRIP_DST = ["yuv420p", "yuv422p", "yuv444p", "yuv411p", "yuvj420p", "yuv420p10le", "yuv422p12le", "yuv444p9le", "yuv420p16le", "nv12", "nv21", "nv16", "p010le", "p012le", "p016le",
-             "yuyv422", "uyvy422", "yvyu422", "rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "bgr0", "gray8", "gray10le", "yuva420p", "gbrp", "rgb48le", "yuv420p10be"]
+             "yuyv422", "uyvy422", "yvyu422", "rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "bgr0", "gray8", "gray10le", "yuva420p", "gbrp", "rgb48le", "yuv420p10be",
+             "yuva444p10le", "yuva422p", "gbrap", "gbrp10le", "gbrap12le", "gbrp12msble", "rgb0", "gbrp16le"]
 
 
 def _strip_cases(n, seed):
@@ -276,3 +278,25 @@ def test_random_batches(case):
             for pl, (a, b) in enumerate(zip(out.planes, refs[i].planes)):
                 rb = out.row_bytes[pl]
                 assert np.array_equal(a[:, :rb], b[:, :rb]), (case[:7], p.path(), rnd, n, i, pl, int(np.count_nonzero(a[:, :rb] != b[:, :rb])))
+
+
+# HBM-resident frames with odd plane pointers and line sizes, or stored bottom-up (tests/test_gpu_unaligned_frames.py): the strip family's draws on
+# such frames -- the helper passes go through aligned working copies, everything else through the per-sample kernels
+def _odd_cases(n, seed):
+    rng = random.Random(seed ^ 0x5EED)
+    out = []
+    for c in _strip_cases(n, seed + 77):
+        out.append(c + ((rng.choice([0, 1, 2, 6, 13]), rng.choice([0, 1, 2, 3, 6]), rng.choice([0, 0, 1, 2, 3])),))
+    return out
+
+
+@pytest.mark.parametrize("case", _odd_cases(int(_HUNT_N or 1500), int(_HUNT_SEED or 4242)), ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
+def test_random_conversions_on_unaligned_frames(case):
+    from test_gpu_unaligned_frames import run_odd
+    sw, sh, sf, dw, dh, df, flags, k, opts, cs, tune, (pad, shift, flip) = case
+    try:
+        o = OL.Oracle(sw, sh, sf, dw, dh, df, flags, **opts)
+    except Exception:
+        pytest.skip("the oracle refuses this context")
+    del o
+    run_odd(sw, sh, sf, dw, dh, df, flags, pad, shift, flip, nframes=1 + k % 3, opts=opts, colorspace=cs, tune=tune, seed=k + 11)
