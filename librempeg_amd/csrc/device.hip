@@ -326,10 +326,14 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                               !isGray(o.src_format) && !(o.flags & SWS_FAST_BILINEAR) && !c->tune.no_strip && !c->tune.no_mixed &&
                               ((p.srcKind == SRCK_RGB32 && !(o.src_w & 3)) || ((p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_PLANAR16) && isPlanarYUV(o.src_format)));
     d->alpha_launch = 0;
+    // (filters of more than 16 taps -- ratios of 4:1 and more -- have the strip kernel's long form with 128-column strips on one side and the element-per-thread
+    //  kernels on the other: the planner's width threshold for them is 256 columns)
+    const bool long_taps = c->plan == PLAN_MAIN && (c->hLum.size >= 16 || c->hChr.size >= 16 || c->vLum.size >= 16 || c->vChr.size >= 24);   // (padded to an even start: 16 taps already take 9 pairs)
+    const int strip_min_w_eff = long_taps ? std::min(c->tune.strip_min_w, 256) : c->tune.strip_min_w;
     const bool fc_plain = !isGray(o.src_format) && !isGray(o.dst_format) && p.srcKind != SRCK_MONO;
     d->fullchr_on = 0;
     if (c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP) && p.full_chr && (!c->needAlpha || fc_alpha) && fc_plain && !(o.flags & SWS_FAST_BILINEAR) &&
-        o.dst_w >= c->tune.strip_min_w && !c->tune.no_strip && !c->tune.no_mixed) {
+        o.dst_w >= strip_min_w_eff && !c->tune.no_strip && !c->tune.no_mixed) {
         d->fullchr_on = c->needAlpha ? 2 : 1; d->fullchr_kind = p.dstKind;
         p.dstKind = DSTK_RAW32; p.u_plane_dst = 1; p.v_plane_dst = 2;
     }
@@ -598,7 +602,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // scaled packed 24 / 32 bpp RGB sources: a reader pre-pass writes the 16-bit planes the horizontal scaler
             // reads, the strip kernel takes them like a planar 16-bit source (launch_rgbread_strip); other shapes of these sources keep the tile kernel
             bool rgbread = (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chrSrcW == (p.chr_half ? p.srcW >> 1 : p.srcW) && !(p.srcW & 3) && p.chrSrcVSub == 0 && !p.range_active && (!p.need_alpha || d->fullchr_on == 2 || alpha_planar) &&
-                           (!p.dst_alpha_fill || d->fullchr_on) && !p.no_chroma && !vlines_pending && dst_ok && !c->tune.no_strip && !c->tune.no_rgbsrc && p.dstW >= c->tune.strip_min_w;
+                           (!p.dst_alpha_fill || d->fullchr_on) && !p.no_chroma && !vlines_pending && dst_ok && !c->tune.no_strip && !c->tune.no_rgbsrc && p.dstW >= strip_min_w_eff;
             for (int k = 0; k < 9 && rgbread; k++) rgbread = p.rgb2yuv[k] > -32768 && p.rgb2yuv[k] < 32768;   // (v_dot2_i32_i16 operands)
             d->rgbread_on = false;
             // vertical chroma filters of 17 .. 24 taps (a 4:1 chroma step: packed RGB or 4:2:2 sources into a 4:2:0 picture of half the size): the strip
@@ -615,16 +619,21 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             //  picture into packed RGB (decoded HDR for display) or packed RGB into a 10-bit 4:2:0 picture at the same size had only the generic
             //  kernels: the strip kernels take them with their one-tap horizontal banks)
             const bool unity_ok = !d->unity_h || (rgb_ok && rgb_s16) || (rgbread && !d->rgbsrc_ok && !d->rgb444_ok);   // (sws_k_rgbsrc_unity's row table lives in the same device block as the strip plan)
+            // filters of 17 .. 32 taps (ratios of 4:1 and more -- the lower rungs of an ABR ladder, thumbnails: bicubic at 4:1 has 17 taps, at 6:1 25; Lanczos at
+            // 3:1 19): the strip kernel's long form (sws_k_strip_long: 16 tap pairs each way, strips of 128 / 64 columns); the RGB epilogue stops at 16
+            const bool fs_ok16 = fs2(c->hLum.size) <= 16 && (fs2(c->hChr.size) <= 16 || gray_both) && fs2(c->vLum.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long || gray_both);
+            const bool fs_ok32 = fs2(c->hLum.size) <= 32 && fs2(c->hChr.size) <= 32 && fs2(c->vLum.size) <= 32 && fs2(c->vChr.size) <= 48 && dst_ok && !rgb_ok && !gray_both &&
+                                 !c->tune.no_strip && !c->tune.no_mixed;
             const bool fullA = !mixedM && unity_ok && !(d->unity_h && d->unity_v && !rgb_ok) && !p.fast_bilinear && (!gray_any || gray_both || d->fullchr_on == 2 || alpha_planar || (rgb_ok && rgb_alpha)) && (src_ok || (nv_src && dst_ok) || rgbread) &&
-                               (dst_ok || rgb_ok) && !p.wide &&
-                               fs2(c->hLum.size) <= 16 && (fs2(c->hChr.size) <= 16 || gray_both) && fs2(c->vLum.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long || gray_both) && !c->tune.no_dot2;
+                               (dst_ok || rgb_ok) && !p.wide && (fs_ok16 || fs_ok32) && !c->tune.no_dot2;
+            const bool long_form = fullA && !fs_ok16;
             d->mixed_ok = false;
             if (fullA || mixedM) {
                 const int SPC = (p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010 || rgbread) ? 8 : 16;
                 std::vector<uint8_t> blob;
                 auto put = [&](const void *ptr, size_t n) { size_t o = (blob.size() + 15) & ~(size_t)15; blob.resize(o + n); std::memcpy(blob.data() + o, ptr, n); return o; };
-                auto padded = [&](const FilterBank &b) {
-                    const int f2 = fs2(b.size);
+                auto padded = [&](const FilterBank &b, int f2_long = 0) {
+                    const int f2 = f2_long ? f2_long : fs2(b.size);
                     std::vector<int16_t> t((size_t)b.count * f2, 0);
                     for (int i = 0; i < b.count; i++)
                         for (int j = 0; j < b.size; j++) t[(size_t)i * f2 + (b.pos[i] & 1) + j] = b.taps[(size_t)i * b.size + j];
@@ -670,7 +679,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 // plane1_form: the plane's writer has the reference's one-tap form (yuv2plane1_*, yuv2p01xl1_c: (s + d) >> 7 and its N-bit twins), which
                 // never looks at the coefficient -- initFilter's error-diffused normalisation leaves 4095 in some one-tap rows -- so a one-tap bank
                 // enters the X arithmetic as 4096; the semi-planar chroma writers (yuv2nv12cX_c, yuv2p01xcX_c) have no such form and take the bank's value
-                auto plan3 = [&](const FilterBank &hb, const FilterBank &vb, int W, int cols, int ncomp, SwsStripGeom &g, SOff &o, int (*ring_of)(int) = nullptr, bool plane1_form = false) -> bool {
+                auto plan3 = [&](const FilterBank &hb, const FilterBank &vb, int W, int cols, int ncomp, SwsStripGeom &g, SOff &o, int (*ring_of)(int) = nullptr, bool plane1_form = false, bool longf = false) -> bool {
                     const int TW = 64 * cols, hf2 = fs2(hb.size), vf2 = fs2(vb.size);
                     const int strips = (W + TW - 1) / TW;
                     std::vector<int32_t> cs(strips), cc(strips);
@@ -685,21 +694,24 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     if (ncmax / SPC > (ncomp == 2 ? 64 : 128)) return false;   // one (chroma) or two (luma) 16-byte chunks per lane and row
                     for (int x = 0; x < hb.count; x++) nph = std::max(nph, ((hb.pos[x] & 1) + hb.size + 1) / 2);
                     for (int y = 0; y < vb.count; y++) { if (vb.pos[y] < 0) return false; npv = std::max(npv, ((vb.pos[y] & 1) + vb.size + 1) / 2); }
-                    if (npv > (ncomp == 2 && !ring_of ? 12 : 8)) return false;   // ring depth of the instantiations: 8 row pairs, 12 for the planar chroma planes
+                    if (npv > (longf ? (ncomp == 2 ? 24 : 16) : ncomp == 2 && !ring_of ? 12 : 8)) return false;   // ring depth of the instantiations: 8 row pairs, 12 for the planar chroma planes, 16 in the long form
+                    if (longf) { nph = std::max(10, (nph + 1) & ~1); if (nph > 16) return false; }   // (the long form's instantiations: 10 / 12 / 14 / 16 horizontal tap pairs, zero-padded rows)
+                    else if (nph > 8) return false;
                     for (int y = 1; y < vb.count; y++) if (vb.pos[y] < vb.pos[y - 1]) return false;   // the ring only moves forward
-                    g.TW = TW; g.strips = strips; g.NCmax = ncmax; g.nph = nph; g.npv = npv; g.hfs2 = hf2; g.vfs2 = vf2;
+                    g.TW = TW; g.strips = strips; g.NCmax = ncmax; g.nph = nph; g.npv = npv; g.hfs2 = longf ? 2 * nph : hf2; g.vfs2 = vf2;
                     g.lds_bytes = 4 * ncomp * 2 * ((ncmax + SPC) / 2) * 4;
                     // LDS-DMA form: a ring of 4 row pairs per wave, rows of ncmax 16-bit samples; every pair between the first and the last
                     // one a band needs is requested, so the windows of consecutive rows must touch (no skipped pair)
                     g.lds_dma_bytes = 4 * 4 * ncomp * 2 * (ncmax / 2) * 4;
-                    g.dma_ok = (p.srcKind == SRCK_PLANAR16 || rgbread) && g.lds_dma_bytes <= 40 * 1024;   // (LDS-DMA copies rows as they are: planar 16-bit sources, and the reader planes of a packed RGB source)
+                    g.dma_ok = !longf && (p.srcKind == SRCK_PLANAR16 || rgbread) && g.lds_dma_bytes <= 40 * 1024;   // (LDS-DMA copies rows as they are: planar 16-bit sources, and the reader planes of a packed RGB source)
                     for (int y = 1; y < vb.count && g.dma_ok; y++)
                         if (((vb.pos[y] & ~1) >> 1) > ((vb.pos[y - 1] & ~1) >> 1) + npv) g.dma_ok = 0;
                     o.cs = put(cs.data(), cs.size() * 4); o.cc = put(cc.data(), cc.size() * 4);
-                    std::vector<SwsStripRow> rows((size_t)vb.count);
+                    const int epr = longf ? 2 : 1;                 // 64-byte entries per row: the long form's 16 tap pairs run on into a second one
+                    std::vector<SwsStripRow> rows((size_t)vb.count * epr);
+                    std::memset(rows.data(), 0, rows.size() * sizeof(SwsStripRow));
                     for (int y = 0; y < vb.count; y++) {
-                        SwsStripRow &e = rows[(size_t)y];
-                        std::memset(&e, 0, sizeof(e));
+                        SwsStripRow &e = rows[(size_t)y * epr];
                         e.pf = (vb.pos[y] & ~1) >> 1;
                         const int lead = ring_of ? 2 * (ring_of(npv) - npv) : 0;
                         if (lead < 0) return false;
@@ -707,7 +719,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                             const int k = (vb.pos[y] & 1) + j + lead;
                             // (pairs 8 .. 11 of a long chroma filter land in the four spare dwords behind vt[8]: load_strip_row_n)
                             const int16_t tap = (vb.size == 1 && plane1_form) ? (int16_t)4096 : vb.taps[(size_t)y * vb.size + j];
-                            reinterpret_cast<uint32_t *>(&e)[4 + (k >> 1)] |= (uint32_t)(uint16_t)tap << (16 * (k & 1));
+                            reinterpret_cast<uint32_t *>(rows.data())[(size_t)y * epr * 16 + 4 + (k >> 1)] |= (uint32_t)(uint16_t)tap << (16 * (k & 1));
                         }
                     }
                     o.rows = put(rows.data(), rows.size() * sizeof(SwsStripRow));
@@ -719,9 +731,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 const int strip_cols_c = c->tune.strip_cols_c == 1 ? 1 : 2;
                 // (narrow pictures leave most of a 256-column strip idle and pay the per-band ring fill: the tile kernel keeps them)
                 const int strip_min_w = c->tune.strip_min_w;
-                const bool strip_plan = fullA && dst_ok && !p.range_active && !c->tune.no_strip && p.dstW >= strip_min_w &&
-                                        plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sL, nullptr, lum_plane1) &&
-                                        (gray_both || plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sC, nullptr, chr_plane1));
+                const bool strip_plan = fullA && dst_ok && !p.range_active && !c->tune.no_strip && p.dstW >= (long_form ? strip_min_w_eff : strip_min_w) &&   // (the long form's strips are 128 columns, and what it replaces is the element-per-thread tile kernel)
+                                        plan3(c->hLum, c->vLum, p.dstW, long_form ? 2 : strip_cols_l, 1, d->stripL, sL, nullptr, lum_plane1, long_form) &&
+                                        (gray_both || plan3(c->hChr, c->vChr, p.chrDstW, long_form ? 1 : strip_cols_c, 2, d->stripC, sC, long_form ? +[](int) { return 24; } : nullptr, chr_plane1, long_form));
                 d->strip_ok = false;
                 log_msg(c, 3, "strip plan: %d (windows %d/%d chunks of %d, taps %d/%d x %d/%d)\n", strip_plan, d->stripL.NCmax / SPC, d->stripC.NCmax / SPC, SPC,
                         d->stripL.nph, d->stripC.nph, d->stripL.npv, d->stripC.npv);
@@ -785,10 +797,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     }
                 } else
                 {
-                  const bool tiles = !gray_both && plan2(c->hLum, c->vLum, p.dstW, p.dstH, 1, d->dotL, oL) && plan2(c->hChr, c->vChr, p.chrDstW, p.chrDstH, 2, d->dotC, oC);
+                  const bool tiles = !gray_both && !long_form && plan2(c->hLum, c->vLum, p.dstW, p.dstH, 1, d->dotL, oL) && plan2(c->hChr, c->vChr, p.chrDstW, p.chrDstH, 2, d->dotC, oC);
                   size_t ohl = 0, ohc = 0;
                   if (!tiles && strip_plan) {   // (the strip kernel shares the tile kernel's padded horizontal taps; without a tile plan it gets its own copy)
-                      const std::vector<int16_t> htl = padded(c->hLum), htc = gray_both ? std::vector<int16_t>(2, 0) : padded(c->hChr);
+                      const std::vector<int16_t> htl = padded(c->hLum, long_form ? d->stripL.hfs2 : 0), htc = gray_both ? std::vector<int16_t>(2, 0) : padded(c->hChr, long_form ? d->stripC.hfs2 : 0);
                       ohl = put(htl.data(), htl.size() * 2); ohc = put(htc.data(), htc.size() * 2);
                   }
                   if (tiles || strip_plan) {
@@ -1017,6 +1029,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         } else if (d->strip_ok) {
             c->path_name = d->rgbread_on ? "main:rgbread+strip_march" : "main:strip_march";
             c->kernel_name = ((p.srcKind == SRCK_PLANAR16 || d->rgbread_on) && d->stripL.dma_ok && !c->tune.no_strip_dma) ? "sws_k_strip_dma" : "sws_k_strip_march";
+            if (d->stripL.nph > 8 || d->stripL.npv > 8) c->kernel_name = "sws_k_strip_long";   // (filters of 17 .. 32 taps)
         } else if (d->dot2_ok) {
             c->path_name = "main:fused_tile_dot2"; c->kernel_name = "sws_k_tile_dot2";
         } else if (d->tile_ok) {

@@ -53,11 +53,12 @@ __device__ __forceinline__ SwsStripRow load_strip_row(const SwsStripRow *rows, i
 // The same entry with RD tap pairs: the host writes pairs 8 .. 11 of a long vertical filter (chroma at 4:1: 17 bicubic taps) into the four
 // spare dwords behind vt[8] of the 64-byte entry
 template <int RD> struct StripRowN { int pf; uint32_t vt[RD]; };
+// (RD == 16, the long-filter form: two 64-byte entries per row, the tap pairs run on from the first into the second)
 template <int RD>
 __device__ __forceinline__ StripRowN<RD> load_strip_row_n(const SwsStripRow *rows, int idx)
 {
     typedef const uint32_t __attribute__((address_space(4))) *cptr;
-    cptr q = (cptr)(uintptr_t)(rows + idx);
+    cptr q = (cptr)(uintptr_t)(rows + (RD > 12 ? 2 : 1) * idx);     // (two entries hold pf + up to 28 pairs)
     StripRowN<RD> e;
     e.pf = (int)q[0];
 #pragma unroll
@@ -314,6 +315,9 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
 #pragma unroll
                 for (int c = 0; c < COLS; c++) acc[ci][c] = (int)ring[ci][c][RD - 1];
         } else
+        if constexpr (RD > 16) {   // (the long form's chroma ring: the host lays every row's tap pairs out against the whole ring, older slots get zero taps)
+            SWS_SVB(RD)
+        } else
         switch (npv) {
 #define SWS_SV(N) case N: \
             _Pragma("unroll") for (int ci = 0; ci < NCOMP; ci++) _Pragma("unroll") for (int c = 0; c < COLS; c++) { \
@@ -325,6 +329,10 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
         case 9: if constexpr (RD > 8) { SWS_SVB(9) } break;
         case 10: if constexpr (RD > 8) { SWS_SVB(10) } break;
         case 11: if constexpr (RD > 8) { SWS_SVB(11) } break;
+        case 12: if constexpr (RD > 12) { SWS_SVB(12) } else { SWS_SVB(RD) } break;
+        case 13: if constexpr (RD > 12) { SWS_SVB(13) } break;
+        case 14: if constexpr (RD > 12) { SWS_SVB(14) } break;
+        case 15: if constexpr (RD > 12) { SWS_SVB(15) } break;
 #undef SWS_SV
         default:
 #pragma unroll
@@ -388,6 +396,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     switch (g.nph) {        // the whole march is instantiated per horizontal tap-pair count: the loop body is branch-free
 #define SWS_SB(N) case N: strip_body<SRC16, CHROMA, COLS, N, RD>(f, p, g, strip, y0, y1, smem, wib, lane); break;
     SWS_SB(1) SWS_SB(2) SWS_SB(3) SWS_SB(4) SWS_SB(5) SWS_SB(6) SWS_SB(7) SWS_SB(8)
+#undef SWS_SB
+    }
+}
+
+// Long filters (ratios of 4:1 and more: the lower rungs of an ABR ladder, thumbnails -- bicubic at 4:1 has 17 taps, at 6:1 25): the same march with
+// up to 16 horizontal tap pairs and a ring of 16 row pairs (24 for the chroma planes: a packed RGB source into a 4:2:0 picture doubles the vertical
+// chroma ratio), on narrower strips (luma 128, chroma 64 columns: the taps and the ring live in registers per column).  The host pads the horizontal
+// tap rows to 10 / 12 / 14 / 16 pairs and lays the vertical taps of the chroma planes out against the whole ring (device.hip).
+template <bool SRC16, bool CHROMA>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) sws_k_strip_long(SwsFrameSet fs, SwsDevParams p, SwsStripGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int COLS = CHROMA ? 1 : 2;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wid = blockIdx.x * 4 + wib;
+    if (wid >= g.strips * g.bands) return;
+    const int strip = wid % g.strips, band = wid / g.strips;
+    const int H = CHROMA ? p.chrDstH : p.dstH;
+    const int y0 = band * g.band_rows, y1 = min(H, y0 + g.band_rows);
+    if (y0 >= y1) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    switch (g.nph) {
+#define SWS_SB(N) case N: strip_body<SRC16, CHROMA, COLS, N, (CHROMA ? 24 : 16)>(f, p, g, strip, y0, y1, smem, wib, lane); break;
+    SWS_SB(10) SWS_SB(12) SWS_SB(14) SWS_SB(16)
 #undef SWS_SB
     }
 }
@@ -611,6 +644,9 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
 #pragma unroll
                 for (int c = 0; c < COLS; c++) acc[ci][c] = (int)ring[ci][c][RD - 1];
         } else
+        if constexpr (RD > 16) {   // (the long form's chroma ring: the host lays every row's tap pairs out against the whole ring, older slots get zero taps)
+            SWS_SVB(RD)
+        } else
         switch (npv) {
 #define SWS_SV(N) case N: \
             _Pragma("unroll") for (int ci = 0; ci < NCOMP; ci++) _Pragma("unroll") for (int c = 0; c < COLS; c++) { \
@@ -622,6 +658,10 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
         case 9: if constexpr (RD > 8) { SWS_SVB(9) } break;
         case 10: if constexpr (RD > 8) { SWS_SVB(10) } break;
         case 11: if constexpr (RD > 8) { SWS_SVB(11) } break;
+        case 12: if constexpr (RD > 12) { SWS_SVB(12) } else { SWS_SVB(RD) } break;
+        case 13: if constexpr (RD > 12) { SWS_SVB(13) } break;
+        case 14: if constexpr (RD > 12) { SWS_SVB(14) } break;
+        case 15: if constexpr (RD > 12) { SWS_SVB(15) } break;
 #undef SWS_SV
         default:
 #pragma unroll

@@ -114,3 +114,35 @@ def test_one_tap_rows_with_the_tap_4095():
         for (sw, sh, dw, dh) in ((60, 3, 302, 44), (340, 2, 352, 25), (64, 3, 128, 3), (128, 2, 64, 9)):
             run_case(sw, sh, sfmt, dw, dh, dfmt, SWS_BICUBIC | SWS_ACCURATE_RND | BX, seed=sw, opts=opts, tune=STRIP)
             run_case(sw, sh, sfmt, dw, dh, dfmt, SWS_LANCZOS | BX, seed=dw, opts=dict(opts, src_v_chr_pos=128), tune=STRIP)
+
+
+@pytest.mark.parametrize("flags", [SWS_BICUBIC, SWS_BILINEAR, SWS_AREA, SWS_GAUSS, SWS_LANCZOS, SWS_SPLINE, SWS_BICUBIC | SWS_ACCURATE_RND],
+                         ids=["bicubic", "bilinear", "area", "gauss", "lanczos", "spline", "bicubic_ar"])
+@pytest.mark.parametrize("geom", [(1024, 256, 256, 64), (1280, 360, 256, 60), (1536, 384, 256, 64), (1792, 224, 256, 32), (1024, 128, 341, 43), (1000, 250, 203, 51),
+                                  (1024, 64, 256, 64), (512, 256, 512, 64), (1920, 270, 426, 60), (1100, 140, 157, 20)],
+                         ids=lambda g: f"{g[0]}x{g[1]}-{g[2]}x{g[3]}")
+def test_long_filters(flags, geom):
+    """ratios of 3:1 .. 7:1 (the lower rungs of an ABR ladder, thumbnails): filters of 17 .. 32 taps take the strip kernel's long form (16 tap pairs each
+    way, a ring of 16 row pairs, strips of 128 / 64 columns); longer ones still fall back"""
+    sw, sh, dw, dh = geom
+    for sfmt, dfmt in (("yuv420p", "yuv420p"), ("yuv420p10le", "nv12"), ("nv12", "yuv420p10le"), ("yuv444p", "yuv420p"), ("rgb24", "yuv420p"), ("bgra", "rgb24"),
+                       ("yuv422p", "p010le"), ("yuv420p", "gbrp"), ("yuyv422", "yuv422p"), ("yuva420p", "yuva420p")):
+        run_case(sw, sh, sfmt, dw, dh, dfmt, flags | BX, seed=sw + dh, tune=STRIP)
+
+
+def test_long_filters_take_the_strip_kernel():
+    from librempeg_amd import SwsContext
+    for (sw, sh, sf, dw, dh, df, fl) in ((3840, 2160, "yuv420p", 960, 540, "yuv420p", SWS_BICUBIC), (3840, 2160, "yuv420p", 640, 360, "yuv420p", SWS_BICUBIC),
+                                         (3840, 2160, "yuv420p", 1280, 720, "nv12", SWS_LANCZOS), (1920, 1080, "yuv420p10le", 426, 240, "yuv420p", SWS_BICUBIC),
+                                         (3840, 2160, "rgb24", 960, 540, "yuv420p", SWS_BICUBIC), (3840, 2160, "bgra", 960, 540, "bgra", SWS_BICUBIC)):
+        c = SwsContext(sw, sh, sf, dw, dh, df, fl | BX)      # (the planner's own thresholds: 256 columns for the long form)
+        assert "strip_march" in c.path() and c.kernel_name() == "sws_k_strip_long", (c.path(), c.kernel_name(), sf, df, dw)
+        c.close()
+    path, _ = run_case(3840, 2160, "yuv420p", 960, 540, "yuv420p", SWS_BICUBIC | BX, seed=21)
+    assert path == "main:strip_march"
+    path, _ = run_case(3840, 2160, "yuv420p10le", 640, 360, "p010le", SWS_BICUBIC | BX, seed=22)
+    assert path == "main:strip_march"
+    path, _ = run_case(3840, 2160, "rgb24", 960, 540, "yuv420p", SWS_BICUBIC | BX, seed=23)
+    assert path == "main:rgbread+strip_march"
+    path, _ = run_case(3840, 2160, "bgra", 640, 360, "bgra", SWS_BICUBIC | BX, seed=24)
+    assert path == "main:rgbread+strip_march+fullchr_rgb"

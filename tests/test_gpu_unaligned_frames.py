@@ -48,7 +48,7 @@ class _BottomUp:
         import torch
         for i, a in enumerate(host.planes):
             rb = self.f.row_bytes[i]
-            self.f.plane_tensor(i)[:, :rb].copy_(torch.from_numpy(np.ascontiguousarray(a[::-1, :rb])))
+            self.f.plane_tensor(i)[:, :rb].copy_(torch.from_numpy(a[::-1, :rb].copy()))
         torch.cuda.synchronize()
         return self
 

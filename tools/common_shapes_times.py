@@ -15,6 +15,12 @@ CASES = [("yuv420p",1920,1080,"yuv420p",3840,2160,SWS_BICUBIC),("yuv420p",1920,1
          ("yuv422p10le",1920,1080,"yuv420p",1920,1080,SWS_BICUBIC),("yuv444p",1920,1080,"yuv420p",1920,1080,SWS_BICUBIC),
          ("bgra",3840,2160,"yuv420p",1920,1080,SWS_BICUBIC),("yuyv422",1920,1080,"yuv420p",1280,720,SWS_BICUBIC),("uyvy422",3840,2160,"nv12",1920,1080,SWS_BILINEAR),
          ("nv12",3840,2160,"bgra",1920,1080,SWS_BICUBIC),("yuv420p10le",3840,2160,"bgra",1920,1080,SWS_BICUBIC),("p010le",3840,2160,"bgra",1920,1080,SWS_BICUBIC),("gbrp",1920,1080,"yuv420p",1280,720,SWS_BICUBIC),("nv12",1920,1080,"rgb24",1280,720,SWS_BILINEAR),("yuv420p",1920,1080,"yuyv422",1920,1080,SWS_BICUBIC),("yuv420p",3840,2160,"uyvy422",1920,1080,SWS_BICUBIC)]
+if os.environ.get("SWS_SHAPES_SET") == "ladder":     # the lower rungs of an ABR ladder and thumbnails: ratios of 3:1 and more (filters of 13 .. 33 taps)
+    CASES = [("yuv420p",3840,2160,"yuv420p",1280,720,SWS_BICUBIC),("yuv420p",3840,2160,"yuv420p",960,540,SWS_BICUBIC),("yuv420p",3840,2160,"yuv420p",640,360,SWS_BICUBIC),
+             ("yuv420p",3840,2160,"yuv420p",1280,720,SWS_LANCZOS),("yuv420p",3840,2160,"yuv420p",1920,1080,SWS_LANCZOS),("yuv420p",1920,1080,"yuv420p",640,360,SWS_BICUBIC),
+             ("yuv420p",1920,1080,"yuv420p",426,240,SWS_BICUBIC),("yuv420p",1920,1080,"yuv420p",640,360,SWS_LANCZOS),("yuv420p10le",3840,2160,"yuv420p10le",960,540,SWS_BICUBIC),
+             ("nv12",3840,2160,"nv12",960,540,SWS_BICUBIC),("yuv420p",3840,2160,"rgb24",960,540,SWS_BICUBIC),("yuv420p",3840,2160,"rgb24",640,360,SWS_BICUBIC),
+             ("yuv420p",1920,1080,"rgb24",320,180,SWS_BICUBIC),("yuv420p",3840,2160,"yuv420p",960,540,SWS_BILINEAR),("rgb24",3840,2160,"yuv420p",960,540,SWS_BICUBIC)]
 print("| conversion | path / kernel | ms / frame | Gpix/s out | GB/s (src + dst bytes) |")
 print("|---|---|---|---|---|")
 for sf,sw,sh,df,dw,dh,fl in CASES:
