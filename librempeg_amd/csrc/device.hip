@@ -337,6 +337,13 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         d->fullchr_on = c->needAlpha ? 2 : 1; d->fullchr_kind = p.dstKind;
         p.dstKind = DSTK_RAW32; p.u_plane_dst = 1; p.v_plane_dst = 2;
     }
+    // (the LUT writers with filters too long for sws_k_strip_rgb -- ratios of 4:1 and more: the same route with the chroma sums at half the width and
+    //  sws_k_lut_rgb as the epilogue: fullchr_on == 3)
+    if (!d->fullchr_on && c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr && long_taps && !c->needAlpha && fc_plain &&
+        !(o.flags & SWS_FAST_BILINEAR) && !(o.dst_w & 1) && o.dst_w >= strip_min_w_eff && !c->tune.no_strip && !c->tune.no_mixed) {
+        d->fullchr_on = 3; d->fullchr_kind = p.dstKind;
+        p.dstKind = DSTK_RAW32; p.u_plane_dst = 1; p.v_plane_dst = 2;
+    }
     if (p.srcKind == SRCK_PACKEDHI)
         for (int k = 0; k < ds->nb_components; k++) {
             p.shi_step[k] = ds->comp[k].step; p.shi_off[k] = ds->comp[k].offset; p.shi_shift[k] = ds->comp[k].shift;
@@ -1047,7 +1054,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     }
     if (c->plan == PLAN_MAIN && d->split_mode) c->path_name = ((d->split_mode & 40) ? "main:splitnv+" : "main:split422+") + c->path_name.substr(c->path_name.find(':') + 1);
     if (c->plan == PLAN_MAIN && d->join422) c->path_name += "+join422";
-    if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += "+fullchr_rgb";
+    if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += d->fullchr_on == 3 ? "+lut_rgb" : "+fullchr_rgb";
     if (c->plan == PLAN_MAIN && ((d->alpha_launch == 1 && d->strip_ok) || (d->alpha_launch == 2 && d->striprgb_ok))) c->path_name += "+alpha";
     // (16-byte aligned pictures of the layout converters take the streaming kernel, k_layout.hip; the names above are the fallback's)
     if (!c->tune.no_layout_stream && (c->plan == PLAN_UNSC_PLANAR2NV12 || c->plan == PLAN_UNSC_NV122PLANAR || c->plan == PLAN_UNSC_PLANARCOPY || c->plan == PLAN_UNSC_PLANAR2NV24 ||

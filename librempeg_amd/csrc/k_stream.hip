@@ -2,6 +2,7 @@
 // RGB -> 4:4:4 YUV chain (C5).
 #include "devstate.hpp"
 #include "kernels_fast.hpp"
+#include "kernels_striprgb.hpp"   // (lut_pair, LutTabs: sws_k_lut_rgb)
 #include "kernels_stream.hpp"
 #include "kernels_rgbsrc.hpp"
 
@@ -92,6 +93,11 @@ void launch_fullchr_rgb(const LaunchCtx &L)
 {
     const SwsDevParams &p = *L.p;
     const dim3 grid(cdiv(cdiv(p.dstW, 4), 256), cdiv(p.dstH, swsk::FULLCHR_RPW), L.n), blk(256);
+    if (L.d->fullchr_on == 3) {   // the LUT writers (no full chroma): chroma sums at half the width
+        if (p.lut.pix_step == 4) hipLaunchKernelGGL((swsk::sws_k_lut_rgb<4>), grid, blk, 0, L.st, L.fs, p);
+        else hipLaunchKernelGGL((swsk::sws_k_lut_rgb<3>), grid, blk, 0, L.st, L.fs, p);
+        return;
+    }
     if (L.d->fullchr_kind == DSTK_GBRP) {
         const bool wide = p.dst_bits > 8, alpha = L.d->fullchr_on == 2;
         if (wide && alpha) hipLaunchKernelGGL((swsk::sws_k_fullchr_gbrp<true, true>), grid, blk, 0, L.st, L.fs, p);

@@ -256,6 +256,51 @@ __global__ void __launch_bounds__(256) sws_k_fullchr_gbrp(SwsFrameSet fs, SwsDev
     }
 }
 
+// The LUT writers behind the strip kernels' raw sums (dev_prepare_on: fullchr_on == 3): 24 / 32 bpp RGB destinations WITHOUT full chroma whose filters are
+// too long for sws_k_strip_rgb (ratios of 4:1 and more: thumbnails for display or inference).  Y sums at the destination size, U / V sums at half the
+// width; yuv2rgb_X_c_template (output.c:1795-1850): every sum + (1 << 18) >> 19, then the table look-ups in their closed form (lut_pair, kernels_striprgb.hpp).
+// Lane = two pixel pairs, a wave walks down FULLCHR_RPW rows.
+template <int BPP>
+__global__ void __launch_bounds__(256) sws_k_lut_rgb(SwsFrameSet fs, SwsDevParams p)
+{
+    __shared__ __attribute__((aligned(16))) u32x2 lds_tab[2][256];
+    build_lut_tabs(p.lut, lds_tab[0], lds_tab[1], (int)threadIdx.x);
+    __syncthreads();
+    const LutTabs T = { (const uint8_t *)lds_tab[0], (const uint8_t *)lds_tab[1] };
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int lane = threadIdx.x & 63;
+    const int cx = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = U(p.dstW), H = U(p.dstH);
+    const int x = (cx * 64 + lane) * 4;
+    if (x >= W) return;
+    const int npx = min(4, W - x);                            // 2 or 4: the planner takes even widths only
+    const bool swap_rb = BPP == 4 ? p.lut.swap_rb32 != 0 : p.lut.rgb_order != 0;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    const int y0 = blockIdx.y * FULLCHR_RPW, y1 = min(H, y0 + FULLCHR_RPW);
+    for (int y = y0; y < y1; y++) {
+        const i32x4 vY = *(const SWS_GLOBAL i32x4 *)(f.src[0] + (int64_t)y * f.srcStride[0] + 4 * (int64_t)x);     // (planes padded to whole 16-byte groups)
+        const i32x2 vU = *(const SWS_GLOBAL i32x2 *)(f.src[1] + (int64_t)y * f.srcStride[1] + 2 * (int64_t)x);
+        const i32x2 vV = *(const SWS_GLOBAL i32x2 *)(f.src[2] + (int64_t)y * f.srcStride[2] + 2 * (int64_t)x);
+        uint32_t w[2][2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int Y1 = (int)((unsigned)vY[2 * k] + (1u << 18)) >> 19, Y2 = (int)((unsigned)vY[2 * k + 1] + (1u << 18)) >> 19;
+            const int Uc = (int)((unsigned)vU[k] + (1u << 18)) >> 19, Vc = (int)((unsigned)vV[k] + (1u << 18)) >> 19;
+            lut_pair<BPP>(p.lut, T, swap_rb, Y1, Y2, Uc, Vc, w[k]);
+        }
+        uint8_t *d = f.dst[0] + (int64_t)y * f.dstStride[0] + (int64_t)BPP * x;
+        if (BPP == 4) {
+            if (npx == 4) { const u32x4 o = { w[0][0], w[0][1], w[1][0], w[1][1] }; *(SWS_GLOBAL u32x4 *)d = o; }
+            else { const u32x2 o = { w[0][0], w[0][1] }; *(SWS_GLOBAL u32x2 *)d = o; }
+        } else {
+            ((uint32_t *)d)[0] = w[0][0];
+            if (npx == 4) { ((uint32_t *)d)[1] = (w[0][1] & 0xFFFFu) | (w[1][0] << 16); ((uint32_t *)d)[2] = (w[1][0] >> 16) | (w[1][1] << 16); }
+            else ((uint16_t *)d)[2] = (uint16_t)w[0][1];
+        }
+    }
+}
+
 // The alpha bytes of a 32 bpp destination written by the LUT writers' strip kernel (sws_k_strip_rgb stores 255): yuva420p -> bgra and the like
 // (needAlpha without full chroma).  The A samples went through one more luma launch with the raw writer (int32 sums); this pass is the alpha part of
 // yuv2rgb_X_c_template (output.c:1820-1835): A = (sum + (1 << 18)) >> 19 per pixel, and both pixels of a pair are clipped when either has bit 8 set.

@@ -126,7 +126,8 @@ def test_long_filters(flags, geom):
     way, a ring of 16 row pairs, strips of 128 / 64 columns); longer ones still fall back"""
     sw, sh, dw, dh = geom
     for sfmt, dfmt in (("yuv420p", "yuv420p"), ("yuv420p10le", "nv12"), ("nv12", "yuv420p10le"), ("yuv444p", "yuv420p"), ("rgb24", "yuv420p"), ("bgra", "rgb24"),
-                       ("yuv422p", "p010le"), ("yuv420p", "gbrp"), ("yuyv422", "yuv422p"), ("yuva420p", "yuva420p")):
+                       ("yuv422p", "p010le"), ("yuv420p", "gbrp"), ("yuyv422", "yuv422p"), ("yuva420p", "yuva420p"),
+                       ("yuv420p", "rgb24"), ("nv12", "bgra"), ("yuv420p10le", "rgba"), ("yuv422p", "bgr24"), ("p010le", "argb"), ("uyvy422", "rgb24"), ("yuvj420p", "bgr0")):
         run_case(sw, sh, sfmt, dw, dh, dfmt, flags | BX, seed=sw + dh, tune=STRIP)
 
 
@@ -144,5 +145,9 @@ def test_long_filters_take_the_strip_kernel():
     assert path == "main:strip_march"
     path, _ = run_case(3840, 2160, "rgb24", 960, 540, "yuv420p", SWS_BICUBIC | BX, seed=23)
     assert path == "main:rgbread+strip_march"
+    path, _ = run_case(3840, 2160, "yuv420p", 960, 540, "rgb24", SWS_BICUBIC | BX, seed=25)      # the LUT writers: raw sums + sws_k_lut_rgb
+    assert path == "main:strip_march+lut_rgb"
+    path, _ = run_case(1920, 1080, "nv12", 320, 180, "bgra", SWS_BICUBIC | BX, seed=26)
+    assert path == "main:splitnv+strip_march+lut_rgb" or path == "main:strip_march+lut_rgb", path
     path, _ = run_case(3840, 2160, "bgra", 640, 360, "bgra", SWS_BICUBIC | BX, seed=24)
     assert path == "main:rgbread+strip_march+fullchr_rgb"
