@@ -292,8 +292,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     }
     // (the 10 / 12-bit twins -- p010, p012, p210, p410 ...: words with the samples in the high bits -- become a planar working picture with the samples
     //  shifted down, luma included, and take the 16-bit instantiation of that kernel)
+    //  (same-size pictures too -- a hardware decoder's p010 into RGB for display: the 16-bit instantiation takes identity horizontal filters as one-tap banks)
     if (c->plan == PLAN_MAIN && p.srcKind == SRCK_P010 && p.src_depth <= 15 && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !((o.flags & SWS_FULL_CHR_H_INT)) &&
-        !(bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14)) && !gray_any && !(o.flags & SWS_SRC_V_CHR_DROP_MASK) && !(o.flags & SWS_FAST_BILINEAR) &&
+        !gray_any && !(o.flags & SWS_SRC_V_CHR_DROP_MASK) && !(o.flags & SWS_FAST_BILINEAR) &&
         !c->tune.no_mixed && !c->tune.no_layout_stream && !c->tune.no_strip) {
         d->split_mode = 32; d->split_shift = p.src_shift;
         p.srcKind = SRCK_PLANAR16; p.src_shift = 0;
@@ -625,13 +626,17 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // (identity horizontal filters: 8-bit sources have kernels of their own -- sws_k_rgb_march, sws_k_rgbsrc_unity, the mixed plan -- but a 10-bit
             //  picture into packed RGB (decoded HDR for display) or packed RGB into a 10-bit 4:2:0 picture at the same size had only the generic
             //  kernels: the strip kernels take them with their one-tap horizontal banks)
-            const bool unity_ok = !d->unity_h || (rgb_ok && rgb_s16) || (rgbread && !d->rgbsrc_ok && !d->rgb444_ok);   // (sws_k_rgbsrc_unity's row table lives in the same device block as the strip plan)
+            // (... and so had every planar / semi-planar YUV -> YUV conversion whose horizontal filters are the identity and which the mixed plan does not
+            //  take: all four filters the identity -- p010le -> yuv420p10le, nv12 -> yuv420p10le, yuv420p10le -> nv12, nv12 <-> nv21, bgra -> yuv444p10le: pure
+            //  per-sample conversions the reference has no special converter for -- or vertical-only scaling)
+            const bool unity_yuv = d->unity_h && !d->rgbsrc_ok && !d->rgb444_ok && dst_ok && p.dstKind != DSTK_RAW32 && (src_ok || nv_src || rgbread) && !c->tune.no_mixed;
+            const bool unity_ok = !d->unity_h || (rgb_ok && rgb_s16) || (rgbread && !d->rgbsrc_ok && !d->rgb444_ok) || unity_yuv;   // (sws_k_rgbsrc_unity's row table lives in the same device block as the strip plan)
             // filters of 17 .. 32 taps (ratios of 4:1 and more -- the lower rungs of an ABR ladder, thumbnails: bicubic at 4:1 has 17 taps, at 6:1 25; Lanczos at
             // 3:1 19): the strip kernel's long form (sws_k_strip_long: 16 tap pairs each way, strips of 128 / 64 columns); the RGB epilogue stops at 16
             const bool fs_ok16 = fs2(c->hLum.size) <= 16 && (fs2(c->hChr.size) <= 16 || gray_both) && fs2(c->vLum.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long || gray_both);
             const bool fs_ok32 = fs2(c->hLum.size) <= 32 && fs2(c->hChr.size) <= 32 && fs2(c->vLum.size) <= 32 && fs2(c->vChr.size) <= 48 && dst_ok && !rgb_ok && !gray_both &&
                                  !c->tune.no_strip && !c->tune.no_mixed;
-            const bool fullA = !mixedM && unity_ok && !(d->unity_h && d->unity_v && !rgb_ok) && !p.fast_bilinear && (!gray_any || gray_both || d->fullchr_on == 2 || alpha_planar || (rgb_ok && rgb_alpha)) && (src_ok || (nv_src && dst_ok) || rgbread) &&
+            const bool fullA = !mixedM && unity_ok && !(d->unity_h && d->unity_v && !rgb_ok && !unity_yuv) && !p.fast_bilinear && (!gray_any || gray_both || d->fullchr_on == 2 || alpha_planar || (rgb_ok && rgb_alpha)) && (src_ok || (nv_src && dst_ok) || rgbread) &&
                                (dst_ok || rgb_ok) && !p.wide && (fs_ok16 || fs_ok32) && !c->tune.no_dot2;
             const bool long_form = fullA && !fs_ok16;
             d->mixed_ok = false;
@@ -825,7 +830,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         g.hT2 = (const int16_t *)(b + o.ht); g.vT2 = (const int16_t *)(b + o.vt);
                     };
                     if (tiles) { bind(d->dotL, oL); bind(d->dotC, oC); }
-                    d->dot2_ok = tiles && src_ok && fs2(c->vChr.size) <= 16 && c->vLum.size >= 2 && c->vChr.size >= 2 && !d->fullchr_on && !alpha_planar;
+                    d->dot2_ok = tiles && src_ok && fs2(c->vChr.size) <= 16 && c->vLum.size >= 2 && c->vChr.size >= 2 && !d->fullchr_on && !alpha_planar && !d->unity_h;
                     if (strip_plan) {
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         d->stripL.colStart = (const int32_t *)(b + sL.cs); d->stripL.colCount = (const int32_t *)(b + sL.cc);

@@ -151,3 +151,29 @@ def test_long_filters_take_the_strip_kernel():
     assert path == "main:splitnv+strip_march+lut_rgb" or path == "main:strip_march+lut_rgb", path
     path, _ = run_case(3840, 2160, "bgra", 640, 360, "bgra", SWS_BICUBIC | BX, seed=24)
     assert path == "main:rgbread+strip_march+fullchr_rgb"
+
+
+UNITY_PAIRS = [("p010le", "yuv420p10le"), ("p010le", "yuv420p"), ("nv12", "yuv420p10le"), ("yuv420p10le", "nv12"), ("nv12", "nv21"), ("nv21", "yuv420p10le"), ("p010le", "nv12"),
+               ("yuv420p", "yuv420p12le"), ("yuv422p10le", "nv16"), ("bgra", "yuv444p10le"), ("rgb24", "yuv422p10le"), ("nv12", "yuva420p"), ("p012le", "yuv420p10le"),
+               ("yuv444p", "yuv444p10le"), ("yuv420p10le", "p012le"), ("nv16", "yuv422p10le"), ("p210le", "yuv422p"), ("gbrp", "yuv444p12le")]
+
+
+@pytest.mark.parametrize("pair", UNITY_PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")
+def test_unity_conversions_without_a_special_converter(pair):
+    """same-size conversions whose four filters are the identity and for which the reference has no unscaled converter (a hardware decoder's p010 / nv12 into the
+    planar layouts of the software encoders and back): per-sample work of the scaler chain, one-tap banks on the strip kernels; and vertical-only scaling"""
+    sf, df = pair
+    for (sw, sh, dw, dh, fl) in ((256, 64, 256, 64, SWS_BICUBIC), (322, 50, 322, 50, SWS_BILINEAR), (1920, 32, 1920, 32, SWS_BICUBIC), (256, 64, 256, 40, SWS_BICUBIC),
+                                 (256, 40, 256, 96, SWS_LANCZOS), (1280, 36, 1280, 24, SWS_AREA)):
+        path, _ = run_case(sw, sh, sf, dw, dh, df, fl | BX, seed=sw + dh, tune=STRIP if sw < 1024 else None)
+        if (sw, sh) == (1920, 32):
+            assert "strip_march" in path or "strip_chroma" in path or path.startswith("unscaled:"), (path, sf, df)   # (p010le -> nv12: planarCopy)
+
+
+def test_p010_to_rgb_at_the_same_size():
+    for df in ("bgra", "rgb24", "argb"):
+        assert run_case(1920, 1080, "p010le", 1920, 1080, df, SWS_BICUBIC | BX, seed=31)[0] == "main:splitnv+strip_rgb"
+        assert run_case(322, 50, "p012le", 322, 50, df, SWS_BICUBIC | BX, seed=32, tune=STRIP)[0] == "main:splitnv+strip_rgb"
+    assert run_case(1920, 1080, "p010le", 1920, 1080, "yuv420p10le", SWS_BICUBIC | BX, seed=33)[0] == "main:strip_march"
+    assert run_case(1920, 1080, "nv12", 1920, 1080, "yuv420p10le", SWS_BICUBIC | BX, seed=34)[0] == "main:strip_march"
+    assert run_case(1920, 1080, "nv12", 1920, 1080, "bgr0", SWS_BICUBIC | BX, seed=35)[0] == "main:fused_rgb_unity"      # C4 keeps its kernel
