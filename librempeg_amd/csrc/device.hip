@@ -629,7 +629,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // (... and so had every planar / semi-planar YUV -> YUV conversion whose horizontal filters are the identity and which the mixed plan does not
             //  take: all four filters the identity -- p010le -> yuv420p10le, nv12 -> yuv420p10le, yuv420p10le -> nv12, nv12 <-> nv21, bgra -> yuv444p10le: pure
             //  per-sample conversions the reference has no special converter for -- or vertical-only scaling)
-            const bool unity_yuv = d->unity_h && !d->rgbsrc_ok && !d->rgb444_ok && dst_ok && p.dstKind != DSTK_RAW32 && (src_ok || nv_src || rgbread) && !c->tune.no_mixed;
+            const bool unity_yuv = d->unity_h && !d->rgbsrc_ok && !d->rgb444_ok && dst_ok && (src_ok || nv_src || rgbread) && !c->tune.no_mixed;
             const bool unity_ok = !d->unity_h || (rgb_ok && rgb_s16) || (rgbread && !d->rgbsrc_ok && !d->rgb444_ok) || unity_yuv;   // (sws_k_rgbsrc_unity's row table lives in the same device block as the strip plan)
             // filters of 17 .. 32 taps (ratios of 4:1 and more -- the lower rungs of an ABR ladder, thumbnails: bicubic at 4:1 has 17 taps, at 6:1 25; Lanczos at
             // 3:1 19): the strip kernel's long form (sws_k_strip_long: 16 tap pairs each way, strips of 128 / 64 columns); the RGB epilogue stops at 16
@@ -738,7 +738,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     return true;
                 };
                 SOff sL, sC;
-                const bool chr_plane1 = p.dstKind != DSTK_NV12 && p.dstKind != DSTK_P010 && p.dstKind != DSTK_RAW32, lum_plane1 = p.dstKind != DSTK_RAW32;   // (raw sums: the packed X form's own taps)
+                // (raw sums: the packed X form's own taps -- except when both vertical filters have one tap: the packed writers then take their "_1" forms
+                //  (yuv2rgb_full_1, yuv2rgb_1: vscale.c:136-141), which ignore the coefficients like yuv2plane1 does and equal the X arithmetic with the tap
+                //  4096: Y = buf << 2 == (buf << 12 + (1 << 9)) >> 10, (buf + 64) >> 7 == (buf << 12 + (1 << 18)) >> 19; planar RGB has no such form, vscale.c:173-212)
+                const bool raw_one_one = p.dstKind == DSTK_RAW32 && c->vLum.size == 1 && c->vChr.size == 1 && d->fullchr_kind != DSTK_GBRP;
+                const bool chr_plane1 = (p.dstKind != DSTK_NV12 && p.dstKind != DSTK_P010 && p.dstKind != DSTK_RAW32) || raw_one_one, lum_plane1 = p.dstKind != DSTK_RAW32 || raw_one_one;
                 const int strip_cols_l = c->tune.strip_cols_l == 2 ? 2 : 4;
                 const int strip_cols_c = c->tune.strip_cols_c == 1 ? 1 : 2;
                 // (narrow pictures leave most of a 256-column strip idle and pay the per-band ring fill: the tile kernel keeps them)
@@ -915,7 +919,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             d->all_x_mode = all_x;
             d->striprgb_ok = d->striprgb_ok && all_x;
             if (d->alpha_launch == 2 && !d->striprgb_ok) d->alpha_launch = 0;
-            if (d->fullchr_on && ((!all_x && d->fullchr_kind != DSTK_GBRP) || !d->strip_ok)) {   // (planar RGB: any_vscale, always the X form)   // no strip plan, or a row in one of the short writer forms: the generic full-chroma writer keeps it
+            if (d->fullchr_on && ((!all_x && !(lfs == 1 && cfs == 1) && d->fullchr_kind != DSTK_GBRP) || !d->strip_ok)) {   // (planar RGB: any_vscale, always the X form)   // no strip plan, or a row in one of the short writer forms: the generic full-chroma writer keeps it
                 d->fullchr_on = 0; d->strip_ok = false; d->rgbread_on = false;
                 p.dstKind = d->fullchr_kind; p.u_plane_dst = dd->comp[1].plane; p.v_plane_dst = dd->comp[2].plane;
             }

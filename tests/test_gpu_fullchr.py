@@ -27,8 +27,9 @@ def test_formats(src, dst):
         # (a real alpha plane scaled into a 32 bpp destination -- needAlpha -- is a fourth sum plane: the reader pre-pass hands the A bytes of a packed
         #  source to the luma filters, a planar YUV source has them in plane 3; planar RGB with alpha keeps the generic writer)
         alpha_generic = src == "gbrap" and dst not in ("rgb24", "bgr24")
-        # (area at 2:1: two luma and two chroma taps, yuv2rgb_full_2; an unscaled height with unsubsampled chroma rows: one tap each, yuv2rgb_full_1)
-        short = fl == SWS_AREA or (sh == dh and src not in SUBSAMPLED_V)
+        # (area at 2:1: two luma and two chroma taps, yuv2rgb_full_2: the generic writer.  An unscaled height with unsubsampled chroma rows -- one tap each,
+        #  yuv2rgb_full_1 -- is the X arithmetic with the tap 4096 and takes the strip kernels)
+        short = fl == SWS_AREA
         rgb_src = src in ("rgb24", "bgr24", "bgra", "argb", "rgb0", "0bgr", "gbrp", "gbrap")
         if (sw, sh) != (dw, dh) and not alpha_generic and not short and not (rgb_src and sw & 3):
             assert r[0].endswith("+fullchr_rgb"), (r[0], src, dst, sw, dw)
@@ -65,6 +66,20 @@ def test_forced_full_chroma_and_fallbacks():
     assert not run_case(256, 64, "rgb24", 192, 48, "rgb565le", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")
     assert not run_case(256, 64, "rgb24", 256, 128, "bgr24", SWS_BILINEAR | BX, tune=TUNE)[0].endswith("+fullchr_rgb")   # two luma and two chroma taps: yuv2rgb_full_2
     assert not run_case(640, 48, "rgb24", 320, 24, "bgr24", SWS_BICUBIC | BX)[0].endswith("+fullchr_rgb")                # narrow: below the planner's width threshold
+
+
+def test_one_tap_vertical_forms():
+    """both vertical filters with one tap: yuv2rgb_full_1 / yuv2rgb_1 ignore the coefficient (4095 in some rows of an error-diffused bank); same size (every filter the
+    identity: yuv444p -> bgra has no unscaled converter) and width-only scaling"""
+    for src in ("yuv444p", "yuv444p10le", "yuv422p", "yuvj444p", "rgb24", "bgra", "gbrp", "yuva444p", "nv24", "yuv440p10le"):
+        for dst in ("bgra", "rgb24", "argb", "bgr24", "gbrp", "gbrap"):
+            for (sw, sh, dw, dh, fl) in ((256, 64, 256, 64, SWS_BICUBIC), (320, 50, 200, 50, SWS_BICUBIC), (200, 37, 320, 37, SWS_LANCZOS), (1920, 24, 1920, 24, SWS_BILINEAR),
+                                         (1920, 24, 480, 24, SWS_BICUBIC)):
+                r = run_case(sw, sh, src, dw, dh, dst, fl | FC | BX, seed=sw + dh, tune=TUNE)
+    assert run_case(1920, 1080, "yuv444p", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=41)[0] == "main:strip_march+fullchr_rgb"
+    assert run_case(1920, 1080, "yuv444p10le", 1920, 1080, "rgb24", SWS_BICUBIC | BX, seed=42)[0] == "main:strip_march+fullchr_rgb"
+    assert run_case(1920, 1080, "rgb24", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=43)[0] == "main:rgbread+strip_march+fullchr_rgb"   # (BITEXACT: no rgb24 -> bgra shuffle, swscale_unscaled.c findRgbConvFn)
+    assert run_case(1920, 1080, "yuv444p", 1280, 1080, "bgra", SWS_BICUBIC | BX, seed=44)[0] == "main:strip_march+fullchr_rgb"
 
 
 def test_full_size_batches_and_host_frames():
