@@ -781,12 +781,15 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     auto ringL = [](int npv) { return npv <= 5 ? 5 : npv <= 8 ? 8 : -1; };
                     auto ringC = [](int npv) { return npv <= 1 ? 1 : npv <= 3 ? 3 : npv <= 8 ? 8 : -1; };
                     const int rcl = (c->tune.strip_rgb_cols == 2 || rgb_s16) ? 2 : 4;
-                    const bool pl = plan3(c->hLum, c->vLum, p.dstW, rcl, 1, gl, rL, ringL), pc = pl && plan3(c->hChr, c->vChr, p.chrDstW, rcl / 2, 2, gc, rC, ringC);
+                    // (one vertical tap each: yuv2rgb_1_c_template's (buf + 64) >> 7 -- the coefficient is never looked at -- is the X arithmetic with the tap 4096)
+                    const bool rgb_one_one = c->vLum.size == 1 && c->vChr.size == 1;
+                    const bool pl = plan3(c->hLum, c->vLum, p.dstW, rcl, 1, gl, rL, ringL, rgb_one_one), pc = pl && plan3(c->hChr, c->vChr, p.chrDstW, rcl / 2, 2, gc, rC, ringC, rgb_one_one);
                     log_msg(c, 3, "strip_rgb plan: luma %d chroma %d strips %d/%d window %d/%d nph %d/%d npv %d/%d chrDstH %d dstH %d\n", pl, pc, gl.strips, gc.strips,
                             gl.NCmax, gc.NCmax, gl.nph, gc.nph, gl.npv, gc.npv, p.chrDstH, p.dstH);
                     SOff sA;
                     const bool wantA = p.need_alpha != 0;     // (rgb_ok: then rgb_alpha holds)
-                    const bool pa = !wantA || plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sA, nullptr, false);   // the plain luma launch, the X form's own taps
+                    // (not the one-tap form: yuv2rgb_1_c_template's alpha is (a * 255 + 16384) >> 15, output.c:1904, not the X arithmetic)
+                    const bool pa = !wantA || (!rgb_one_one && plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sA, nullptr, false));   // the plain luma launch, the X form's own taps
                     if (pl && pc && pa && gl.strips == gc.strips &&
                         gl.NCmax / SPC <= 64 && gc.NCmax / SPC <= 64 && std::max(gl.nph, gc.nph) <= 8 && gl.npv <= 8 && gc.npv <= 8 && p.chrDstH == p.dstH) {
                         const std::vector<int16_t> htl = padded(c->hLum), htc = padded(c->hChr);
@@ -917,7 +920,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) all_x = false;
             }
             d->all_x_mode = all_x;
-            d->striprgb_ok = d->striprgb_ok && all_x;
+            d->striprgb_ok = d->striprgb_ok && (all_x || (lfs == 1 && cfs == 1));
             if (d->alpha_launch == 2 && !d->striprgb_ok) d->alpha_launch = 0;
             if (d->fullchr_on && ((!all_x && !(lfs == 1 && cfs == 1) && d->fullchr_kind != DSTK_GBRP) || !d->strip_ok)) {   // (planar RGB: any_vscale, always the X form)   // no strip plan, or a row in one of the short writer forms: the generic full-chroma writer keeps it
                 d->fullchr_on = 0; d->strip_ok = false; d->rgbread_on = false;

@@ -170,3 +170,16 @@ def test_same_size_10bit_pictures_and_packed_rgb():
                     assert r[0] == "main:rgbread+strip_march", (r[0], src, dst, w)
     assert run_case(1920, 1080, "yuv420p10le", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=3)[0] == "main:strip_rgb"
     assert run_case(1920, 1080, "bgra", 1920, 1080, "yuv420p10le", SWS_BICUBIC | BX, seed=4)[0] == "main:rgbread+strip_march"
+
+
+def test_one_tap_vertical_forms_through_the_lut_writers():
+    """one vertical tap for luma and chroma (4:2:2 / 4:4:0-free sources at an unscaled height): yuv2rgb_1_c_template never looks at the coefficient, i.e. the X arithmetic
+    with the tap 4096 -- the strip kernel with the RGB epilogue takes same-size 10-bit 4:2:2 pictures and width-only scaling"""
+    for src in ("yuv422p", "yuv422p10le", "yuv422p12le", "nv16", "p210le", "yuyv422", "uyvy422", "yuvj422p", "yuva422p"):
+        for dst in ("bgra", "rgb24", "argb", "bgr24", "rgb0"):
+            for (sw, sh, dw, dh, fl) in ((256, 64, 256, 64, SWS_BICUBIC), (320, 50, 200, 50, SWS_BICUBIC), (200, 37, 320, 37, SWS_LANCZOS), (1920, 24, 1920, 24, SWS_BILINEAR),
+                                         (1920, 24, 480, 24, SWS_BICUBIC), (1920, 24, 1280, 24, SWS_BICUBIC)):
+                run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh, tune=dict(strip_min_w=0))
+    assert run_case(1920, 1080, "yuv422p10le", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=51)[0] == "main:strip_rgb"
+    assert run_case(1920, 1080, "yuv422p", 1280, 1080, "rgb24", SWS_BICUBIC | BX, seed=52)[0] == "main:strip_rgb"
+    assert not run_case(1920, 64, "yuva422p", 1280, 64, "bgra", SWS_BICUBIC | BX, seed=53)[0].endswith("+alpha")      # yuv2rgb_1's alpha: (a * 255 + 16384) >> 15
