@@ -301,7 +301,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         p.u_plane_src = 1; p.v_plane_src = 2; p.uv_swap_src = 0;
     }
     d->join422 = 0;
-    if (c->plan == PLAN_MAIN && p.dstKind == DSTK_PACKED422 && dd->comp[0].depth == 8 && !(o.dst_w & 1) && !p.should_dither && !c->needAlpha && !gray_any &&
+    if (c->plan == PLAN_MAIN && p.dstKind == DSTK_PACKED422 && dd->comp[0].depth == 8 && !(o.dst_w & 1) && !c->needAlpha && !gray_any &&
         !((c->vLum.size == 1 || c->vLum.size == 2) && c->vChr.size == 2) && !c->tune.no_mixed && !c->tune.no_layout_stream &&
         // (one tap on ONE side only: the packed X form multiplies by the bank's value, which initFilter's normalisation leaves at 4095 in some
         //  rows, where the planar one-tap form ignores it; one tap on both sides is yuv2422_1, which ignores both)
@@ -310,6 +310,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         p.dstKind = DSTK_PLANAR8;
         p.u_plane_dst = vfirst ? 2 : 1; p.v_plane_dst = vfirst ? 1 : 2;
         d->join422 = uyvy ? 2 : 1;
+        p.should_dither = 0;     // (9 .. 16-bit sources: the ordered dither belongs to the planar 8-bit writers, swscale.c:292-300; the packed ones round with 1 << 18 == the undithered 64 << 12)
     }
     p.full_chr = ((o.flags & SWS_FULL_CHR_H_INT) && isAnyRGB(o.dst_format)) ? 1 : 0;
     // ---- full-chroma 24 / 32 bpp RGB destinations (RGB -> RGB scaling, 4:4:4 sources, odd widths, the user's full_chroma_int) through the strip kernels:

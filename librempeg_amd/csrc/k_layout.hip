@@ -174,7 +174,7 @@ int launch_layout_plane1(const LaunchCtx &L)
     const bool s8 = c->srcBpc == 8, d8 = p.dst_bits == 8;
     if (s8 && d8) { j.op = LOP_COPY; j.n = p.srcW; }
     else if (s8) { j.op = LOP_8TO16; j.n = p.srcW; j.a0 = p.dst_bits - 8; j.a1 = 32; j.a2 = p.dst_shift; }
-    else { j.op = d8 ? LOP_P1_16TO8 : LOP_P1_16TO16; j.n = 2 * p.srcW; j.a0 = p.src_shift; j.a1 = p.hshift; j.a2 = p.dst_bits; j.a3 = p.dst_shift; }
+    else { j.op = d8 ? LOP_P1_16TO8 : LOP_P1_16TO16; j.n = 2 * p.srcW; j.a0 = p.src_shift; j.a1 = p.hshift; j.a2 = p.dst_bits; j.a3 = p.dst_shift; j.a4 = p.should_dither ? 0 : 1; }
     const int unit = j.op == LOP_8TO16 ? 8 : 16;
     hipLaunchKernelGGL((sws_k_layout_stream<4>), dim3(cdiv(cdiv(j.n, unit), 256), cdiv(j.rows, LAYOUT_RPW), L.n), dim3(256), 0, st, fs, p, plan);
     return 0;

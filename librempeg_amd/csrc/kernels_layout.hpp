@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256) sws_k_layout_stream(SwsFrameSet fs, SwsDe
                 if (!(in && r + i < r1)) continue;
                 // (the row's dither line: eight bytes, the same for every lane)
                 const uint32_t *dr = (const uint32_t *)k_dither_8x8_128[(yd + r + i) & 7];
-                const uint32_t dlo = U(dr[0]), dhi = U(dr[1]);
+                const uint32_t dlo = a4 ? 0x40404040u : U(dr[0]), dhi = a4 ? 0x40404040u : U(dr[1]);   // (a4: no ordered dither -- the planar working picture behind a packed 4:2:2 destination)
                 const pk16 dt[4] = { pk_bytes_lo(dlo), pk_bytes_hi(dlo), pk_bytes_lo(dhi), pk_bytes_hi(dhi) };
                 // min((sv << 14) >> a1, 32767) inside 16 bits: a sample of 2^(15 - L) or more saturates (L = 14 - a1), below that sv << L fits
                 const int L = 14 - a1;
