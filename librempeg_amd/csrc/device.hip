@@ -637,9 +637,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             const bool fs_ok16 = fs2(c->hLum.size) <= 16 && (fs2(c->hChr.size) <= 16 || gray_both) && fs2(c->vLum.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long || gray_both);
             const bool fs_ok32 = fs2(c->hLum.size) <= 32 && fs2(c->hChr.size) <= 32 && fs2(c->vLum.size) <= 32 && fs2(c->vChr.size) <= 48 && dst_ok && !rgb_ok && !gray_both &&
                                  !c->tune.no_strip && !c->tune.no_mixed;
+            const bool fs_ok64 = fs2(c->hLum.size) <= 64 && fs2(c->hChr.size) <= 64 && fs2(c->vLum.size) <= 64 && fs2(c->vChr.size) <= 64 && dst_ok && !rgb_ok && !gray_both &&
+                                 !c->tune.no_strip && !c->tune.no_mixed;      // (33 .. 62 taps: the extra-long form, 32 pairs each way on strips of 64 columns)
             const bool fullA = !mixedM && unity_ok && !(d->unity_h && d->unity_v && !rgb_ok && !unity_yuv) && !p.fast_bilinear && (!gray_any || gray_both || d->fullchr_on == 2 || alpha_planar || (rgb_ok && rgb_alpha)) && (src_ok || (nv_src && dst_ok) || rgbread) &&
-                               (dst_ok || rgb_ok) && !p.wide && (fs_ok16 || fs_ok32) && !c->tune.no_dot2;
-            const bool long_form = fullA && !fs_ok16;
+                               (dst_ok || rgb_ok) && !p.wide && (fs_ok16 || fs_ok32 || fs_ok64) && !c->tune.no_dot2;
+            const int long_form = !fullA || fs_ok16 ? 0 : fs_ok32 ? 1 : 2;
             d->mixed_ok = false;
             if (fullA || mixedM) {
                 const int SPC = (p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010 || rgbread) ? 8 : 16;
@@ -692,7 +694,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 // plane1_form: the plane's writer has the reference's one-tap form (yuv2plane1_*, yuv2p01xl1_c: (s + d) >> 7 and its N-bit twins), which
                 // never looks at the coefficient -- initFilter's error-diffused normalisation leaves 4095 in some one-tap rows -- so a one-tap bank
                 // enters the X arithmetic as 4096; the semi-planar chroma writers (yuv2nv12cX_c, yuv2p01xcX_c) have no such form and take the bank's value
-                auto plan3 = [&](const FilterBank &hb, const FilterBank &vb, int W, int cols, int ncomp, SwsStripGeom &g, SOff &o, int (*ring_of)(int) = nullptr, bool plane1_form = false, bool longf = false) -> bool {
+                auto plan3 = [&](const FilterBank &hb, const FilterBank &vb, int W, int cols, int ncomp, SwsStripGeom &g, SOff &o, int (*ring_of)(int) = nullptr, bool plane1_form = false, int longf = 0) -> bool {   // longf: 1 the long form (16 / 24 pairs), 2 the extra-long one (32 / 32)
                     const int TW = 64 * cols, hf2 = fs2(hb.size), vf2 = fs2(vb.size);
                     const int strips = (W + TW - 1) / TW;
                     std::vector<int32_t> cs(strips), cc(strips);
@@ -707,8 +709,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     if (ncmax / SPC > (ncomp == 2 ? 64 : 128)) return false;   // one (chroma) or two (luma) 16-byte chunks per lane and row
                     for (int x = 0; x < hb.count; x++) nph = std::max(nph, ((hb.pos[x] & 1) + hb.size + 1) / 2);
                     for (int y = 0; y < vb.count; y++) { if (vb.pos[y] < 0) return false; npv = std::max(npv, ((vb.pos[y] & 1) + vb.size + 1) / 2); }
-                    if (npv > (longf ? (ncomp == 2 ? 24 : 16) : ncomp == 2 && !ring_of ? 12 : 8)) return false;   // ring depth of the instantiations: 8 row pairs, 12 for the planar chroma planes, 16 in the long form
-                    if (longf) { nph = std::max(10, (nph + 1) & ~1); if (nph > 16) return false; }   // (the long form's instantiations: 10 / 12 / 14 / 16 horizontal tap pairs, zero-padded rows)
+                    if (npv > (longf == 2 ? 32 : longf ? (ncomp == 2 ? 24 : 16) : ncomp == 2 && !ring_of ? 12 : 8)) return false;   // ring depth of the instantiations: 8 row pairs, 12 for the planar chroma planes, 16 in the long form
+                    if (longf == 2) { nph = std::max(20, (nph + 3) & ~3); if (nph > 32) return false; }   // (20 / 24 / 28 / 32 pairs)
+                    else if (longf) { nph = std::max(10, (nph + 1) & ~1); if (nph > 16) return false; }   // (the long form's instantiations: 10 / 12 / 14 / 16 horizontal tap pairs, zero-padded rows)
                     else if (nph > 8) return false;
                     for (int y = 1; y < vb.count; y++) if (vb.pos[y] < vb.pos[y - 1]) return false;   // the ring only moves forward
                     g.TW = TW; g.strips = strips; g.NCmax = ncmax; g.nph = nph; g.npv = npv; g.hfs2 = longf ? 2 * nph : hf2; g.vfs2 = vf2;
@@ -720,7 +723,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     for (int y = 1; y < vb.count && g.dma_ok; y++)
                         if (((vb.pos[y] & ~1) >> 1) > ((vb.pos[y - 1] & ~1) >> 1) + npv) g.dma_ok = 0;
                     o.cs = put(cs.data(), cs.size() * 4); o.cc = put(cc.data(), cc.size() * 4);
-                    const int epr = longf ? 2 : 1;                 // 64-byte entries per row: the long form's 16 tap pairs run on into a second one
+                    const int epr = longf == 2 ? 4 : longf ? 2 : 1;   // 64-byte entries per row: the long form's 16 tap pairs run on into a second one
                     std::vector<SwsStripRow> rows((size_t)vb.count * epr);
                     std::memset(rows.data(), 0, rows.size() * sizeof(SwsStripRow));
                     for (int y = 0; y < vb.count; y++) {
@@ -749,8 +752,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 // (narrow pictures leave most of a 256-column strip idle and pay the per-band ring fill: the tile kernel keeps them)
                 const int strip_min_w = c->tune.strip_min_w;
                 const bool strip_plan = fullA && dst_ok && !p.range_active && !c->tune.no_strip && p.dstW >= (long_form ? strip_min_w_eff : strip_min_w) &&   // (the long form's strips are 128 columns, and what it replaces is the element-per-thread tile kernel)
-                                        plan3(c->hLum, c->vLum, p.dstW, long_form ? 2 : strip_cols_l, 1, d->stripL, sL, nullptr, lum_plane1, long_form) &&
-                                        (gray_both || plan3(c->hChr, c->vChr, p.chrDstW, long_form ? 1 : strip_cols_c, 2, d->stripC, sC, long_form ? +[](int) { return 24; } : nullptr, chr_plane1, long_form));
+                                        plan3(c->hLum, c->vLum, p.dstW, long_form == 2 ? 1 : long_form ? 2 : strip_cols_l, 1, d->stripL, sL, long_form == 2 ? +[](int) { return 32; } : nullptr, lum_plane1, long_form) &&
+                                        (gray_both || plan3(c->hChr, c->vChr, p.chrDstW, long_form ? 1 : strip_cols_c, 2, d->stripC, sC,
+                                                            long_form == 2 ? +[](int) { return 32; } : long_form ? +[](int) { return 24; } : nullptr, chr_plane1, long_form));
                 d->strip_ok = false;
                 log_msg(c, 3, "strip plan: %d (windows %d/%d chunks of %d, taps %d/%d x %d/%d)\n", strip_plan, d->stripL.NCmax / SPC, d->stripC.NCmax / SPC, SPC,
                         d->stripL.nph, d->stripC.nph, d->stripL.npv, d->stripC.npv);
@@ -1049,7 +1053,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         } else if (d->strip_ok) {
             c->path_name = d->rgbread_on ? "main:rgbread+strip_march" : "main:strip_march";
             c->kernel_name = ((p.srcKind == SRCK_PLANAR16 || d->rgbread_on) && d->stripL.dma_ok && !c->tune.no_strip_dma) ? "sws_k_strip_dma" : "sws_k_strip_march";
-            if (d->stripL.nph > 8 || d->stripL.npv > 8) c->kernel_name = "sws_k_strip_long";   // (filters of 17 .. 32 taps)
+            if (d->stripL.nph > 8 || d->stripL.npv > 8) c->kernel_name = d->stripL.nph > 16 ? "sws_k_strip_xlong" : "sws_k_strip_long";   // (filters of 17 .. 32 / 33 .. 62 taps)
         } else if (d->dot2_ok) {
             c->path_name = "main:fused_tile_dot2"; c->kernel_name = "sws_k_tile_dot2";
         } else if (d->tile_ok) {

@@ -28,6 +28,14 @@ int launch_strip_planes(const LaunchCtx &L, int which)
 #define SWS_STRIP(S, C, K) hipLaunchKernelGGL((swsk::sws_k_strip_march<S, C, K>), grid, blk, g.lds_bytes, st, fs, p, g)
 #define SWS_STRIP_DMA(C, K) hipLaunchKernelGGL((swsk::sws_k_strip_dma<C, K>), grid, blk, g.lds_dma_bytes, st, fs, p, g)
                 const int cols = g.TW / 64;
+                if (g.nph > 16 || g.npv > (chroma ? 24 : 16)) {   // filters of 33 .. 62 taps (ratios of 8:1 and more): 32 tap pairs each way, strips of 64 columns
+                    if (cols != 1) { log_msg(c, 0, "internal error: extra-long-filter strip plan with %d columns per lane\n", cols); return; }
+                    if (chroma) { if (s16) hipLaunchKernelGGL((swsk::sws_k_strip_xlong<true, true>), grid, blk, g.lds_bytes, st, fs, p, g);
+                                  else hipLaunchKernelGGL((swsk::sws_k_strip_xlong<false, true>), grid, blk, g.lds_bytes, st, fs, p, g); }
+                    else        { if (s16) hipLaunchKernelGGL((swsk::sws_k_strip_xlong<true, false>), grid, blk, g.lds_bytes, st, fs, p, g);
+                                  else hipLaunchKernelGGL((swsk::sws_k_strip_xlong<false, false>), grid, blk, g.lds_bytes, st, fs, p, g); }
+                    return;
+                }
                 if (g.nph > 8 || g.npv > (chroma ? 12 : 8)) {   // long filters (ratios of 4:1 and more): 16 tap pairs each way, strips of 128 / 64 columns
                     if (cols != (chroma ? 1 : 2)) { log_msg(c, 0, "internal error: long-filter strip plan with %d columns per lane\n", cols); return; }
                     if (chroma) { if (s16) hipLaunchKernelGGL((swsk::sws_k_strip_long<true, true>), grid, blk, g.lds_bytes, st, fs, p, g);

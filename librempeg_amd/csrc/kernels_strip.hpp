@@ -58,7 +58,7 @@ template <int RD>
 __device__ __forceinline__ StripRowN<RD> load_strip_row_n(const SwsStripRow *rows, int idx)
 {
     typedef const uint32_t __attribute__((address_space(4))) *cptr;
-    cptr q = (cptr)(uintptr_t)(rows + (RD > 12 ? 2 : 1) * idx);     // (two entries hold pf + up to 28 pairs)
+    cptr q = (cptr)(uintptr_t)(rows + (RD > 24 ? 4 : RD > 12 ? 2 : 1) * idx);     // (two entries hold pf + up to 28 pairs, four as many as any form takes)
     StripRowN<RD> e;
     e.pf = (int)q[0];
 #pragma unroll
@@ -421,6 +421,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     switch (g.nph) {
 #define SWS_SB(N) case N: strip_body<SRC16, CHROMA, COLS, N, (CHROMA ? 24 : 16)>(f, p, g, strip, y0, y1, smem, wib, lane); break;
     SWS_SB(10) SWS_SB(12) SWS_SB(14) SWS_SB(16)
+#undef SWS_SB
+    }
+}
+
+// ... and filters of 33 .. 62 taps (ratios of 8:1 to 15:1: thumbnails, preview sprites): 20 / 24 / 28 / 32 horizontal tap pairs, rings of 32 row pairs
+// (every row's vertical taps laid out against the whole ring), strips of 64 columns for both plane classes; two waves per SIMD (the taps and the
+// rings of the chroma planes alone are 96 registers).
+template <bool SRC16, bool CHROMA>
+__global__ void __launch_bounds__(256) sws_k_strip_xlong(SwsFrameSet fs, SwsDevParams p, SwsStripGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wid = blockIdx.x * 4 + wib;
+    if (wid >= g.strips * g.bands) return;
+    const int strip = wid % g.strips, band = wid / g.strips;
+    const int H = CHROMA ? p.chrDstH : p.dstH;
+    const int y0 = band * g.band_rows, y1 = min(H, y0 + g.band_rows);
+    if (y0 >= y1) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    switch (g.nph) {
+#define SWS_SB(N) case N: strip_body<SRC16, CHROMA, 1, N, 32>(f, p, g, strip, y0, y1, smem, wib, lane); break;
+    SWS_SB(20) SWS_SB(24) SWS_SB(28) SWS_SB(32)
 #undef SWS_SB
     }
 }

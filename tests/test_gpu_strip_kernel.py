@@ -177,3 +177,29 @@ def test_p010_to_rgb_at_the_same_size():
     assert run_case(1920, 1080, "p010le", 1920, 1080, "yuv420p10le", SWS_BICUBIC | BX, seed=33)[0] == "main:strip_march"
     assert run_case(1920, 1080, "nv12", 1920, 1080, "yuv420p10le", SWS_BICUBIC | BX, seed=34)[0] == "main:strip_march"
     assert run_case(1920, 1080, "nv12", 1920, 1080, "bgr0", SWS_BICUBIC | BX, seed=35)[0] == "main:fused_rgb_unity"      # C4 keeps its kernel
+
+
+@pytest.mark.parametrize("flags", [SWS_BICUBIC, SWS_BILINEAR, SWS_AREA, SWS_GAUSS, SWS_LANCZOS, SWS_BICUBIC | SWS_ACCURATE_RND],
+                         ids=["bicubic", "bilinear", "area", "gauss", "lanczos", "bicubic_ar"])
+@pytest.mark.parametrize("geom", [(2048, 288, 256, 36), (2560, 360, 256, 36), (3072, 240, 256, 20), (3840, 270, 256, 18), (2048, 128, 300, 19), (2000, 250, 203, 21),
+                                  (2048, 32, 256, 32), (512, 400, 512, 40), (1920, 540, 240, 68), (2200, 140, 257, 20)],
+                         ids=lambda g: f"{g[0]}x{g[1]}-{g[2]}x{g[3]}")
+def test_extra_long_filters(flags, geom):
+    """ratios of 8:1 .. 15:1 (thumbnails, preview sprites): filters of 33 .. 62 taps take the extra-long form (32 tap pairs each way, strips of 64 columns);
+    still longer ones fall back"""
+    sw, sh, dw, dh = geom
+    for sfmt, dfmt in (("yuv420p", "yuv420p"), ("yuv420p10le", "nv12"), ("nv12", "yuv420p10le"), ("yuv444p", "yuv420p"), ("rgb24", "yuv444p"), ("bgra", "rgb24"),
+                       ("yuv420p", "gbrp"), ("yuv420p", "rgb24"), ("nv12", "bgra"), ("yuva420p", "yuva420p")):
+        run_case(sw, sh, sfmt, dw, dh, dfmt, flags | BX, seed=sw + dh, tune=STRIP)
+
+
+def test_extra_long_filters_take_the_strip_kernel():
+    from librempeg_amd import SwsContext
+    for (sw, sh, sf, dw, dh, df, fl) in ((3840, 2160, "yuv420p", 480, 270, "yuv420p", SWS_BICUBIC), (3840, 2160, "yuv420p", 320, 180, "yuv420p", SWS_BICUBIC),
+                                         (1920, 1080, "nv12", 256, 144, "nv12", SWS_LANCZOS), (3840, 2160, "yuv420p", 480, 270, "rgb24", SWS_BICUBIC)):
+        c = SwsContext(sw, sh, sf, dw, dh, df, fl | BX)
+        assert "strip_march" in c.path() and c.kernel_name() == "sws_k_strip_xlong", (c.path(), c.kernel_name(), sf, df, dw)
+        c.close()
+    assert run_case(3840, 2160, "yuv420p", 480, 270, "yuv420p", SWS_BICUBIC | BX, seed=61)[0] == "main:strip_march"
+    assert run_case(3840, 2160, "yuv420p", 320, 180, "rgb24", SWS_BICUBIC | BX, seed=62)[0] == "main:strip_march+lut_rgb"
+    assert run_case(1920, 1080, "yuv420p10le", 256, 144, "yuv420p", SWS_LANCZOS | BX, seed=63)[0] == "main:strip_march"
