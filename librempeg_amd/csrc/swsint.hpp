@@ -100,7 +100,7 @@ struct DeviceState;  // HIP side (devstate.hpp)
 // the planner would give to another one); every combination produces the same bytes.  `debug` is read only by
 // -DSWS_HIP_PROFILING builds (stage switches whose results are wrong).
 struct Tuning {
-    int strip_min_w = 1024;        // narrower pictures stay on the LDS-tile kernel
+    int strip_min_w = 320;         // narrower pictures stay on the LDS-tile kernel (measured: tools/narrow_shapes_times.py -- the strip kernels are level or ahead from 320 columns on)
     int strip_cols_l = 4, strip_cols_c = 2, strip_waves = 4096;
     int strip_min_rows = 4;        // shortest band of a strip-kernel launch (few frames per call: the serial walk of a wave is what a call waits for)
     int no_strip_fuse = 0;         // off: small calls put the luma and the chroma launch into one grid

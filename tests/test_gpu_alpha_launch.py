@@ -51,7 +51,7 @@ def test_range_conversion_and_fallbacks():
     assert not run_case(256, 64, "yuva420p16le", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+alpha")  # 19-bit intermediates
     assert not run_case(256, 64, "yuva420p", 192, 48, "yuva420p16le", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+alpha")
     assert not run_case(256, 64, "ya8", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+alpha")
-    assert not run_case(640, 48, "bgra", 320, 24, "yuva420p", SWS_BICUBIC | BX)[0].endswith("+alpha")                    # narrow: below the planner's width threshold
+    assert not run_case(480, 48, "bgra", 240, 24, "yuva420p", SWS_BICUBIC | BX)[0].endswith("+alpha")                    # narrow: below the planner's width threshold
 
 
 def test_full_size_batches_and_host_frames():

@@ -65,7 +65,7 @@ def test_forced_full_chroma_and_fallbacks():
     assert not run_case(256, 64, "yuva420p16le", 192, 48, "rgba", SWS_BICUBIC | FC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")   # 16-bit samples: 19-bit intermediates
     assert not run_case(256, 64, "rgb24", 192, 48, "rgb565le", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")
     assert not run_case(256, 64, "rgb24", 256, 128, "bgr24", SWS_BILINEAR | BX, tune=TUNE)[0].endswith("+fullchr_rgb")   # two luma and two chroma taps: yuv2rgb_full_2
-    assert not run_case(640, 48, "rgb24", 320, 24, "bgr24", SWS_BICUBIC | BX)[0].endswith("+fullchr_rgb")                # narrow: below the planner's width threshold
+    assert not run_case(480, 48, "rgb24", 240, 24, "bgr24", SWS_BICUBIC | BX)[0].endswith("+fullchr_rgb")                # narrow: below the planner's width threshold
 
 
 def test_one_tap_vertical_forms():

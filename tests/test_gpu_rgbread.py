@@ -11,7 +11,7 @@ from test_gpu_parity import run_case
 pytestmark = pytest.mark.gpu
 BX = SWS_BITEXACT
 PATH = "main:rgbread+strip_march"
-TUNE = dict(strip_min_w=0)     # (the planner keeps pictures narrower than 1024 columns on the tile kernel: force the path onto oracle-sized cases)
+TUNE = dict(strip_min_w=0)     # (the planner keeps pictures narrower than 320 columns on the tile kernel: force the path onto oracle-sized cases)
 
 SRC = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "0bgr", "gbrp", "gbrap"]   # (planar 8-bit GBR: the same readers, three planes)
 DST = ["yuv420p", "yuv422p", "yuv444p", "nv12", "nv21", "yuv420p10le", "p010le", "yuv422p12le"]
@@ -37,7 +37,7 @@ def test_scalers_and_geometries(flags, geom):
 
 def test_planner_and_fallbacks():
     assert run_case(1920, 54, "rgb24", 1280, 36, "yuv420p", SWS_BICUBIC | BX)[0] == PATH                       # wide enough without the option
-    assert run_case(640, 48, "rgb24", 320, 24, "yuv420p", SWS_BICUBIC | BX)[0] != PATH                         # narrow: tile kernel
+    assert run_case(480, 48, "rgb24", 240, 24, "yuv420p", SWS_BICUBIC | BX)[0] != PATH                         # narrow: tile kernel
     assert run_case(642, 48, "rgb24", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0] != PATH              # width not a multiple of 4
     assert run_case(640, 48, "rgb24", 480, 36, "yuv420p", SWS_BILINEAR | SWS_FULL_CHR_H_INP | BX, tune=TUNE)[0] == PATH            # the full-width chroma readers
     assert run_case(640, 48, "rgb24", 320, 24, "yuv420p", SWS_BICUBIC | SWS_FULL_CHR_H_INP | BX, tune=TUNE)[0] == PATH             # (4:1 bicubic chroma, 17 taps: the strip kernel's long form)

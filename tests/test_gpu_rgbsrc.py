@@ -101,4 +101,4 @@ def test_rgb_to_yuv444_unity(src):
         run_case(w, h, src, w, h, "yuv444p", SWS_BILINEAR | BX, seed=i, device_frames=False)
     assert run_case(640, 48, src, 640, 48, "yuvj444p", SWS_BICUBIC | BX)[0] != PATH444        # a range conversion
     assert run_case(640, 48, src, 640, 48, "yuv444p10le", SWS_BICUBIC | BX)[0] != PATH444
-    assert run_case(640, 48, src, 640, 48, "yuv444p", SWS_FAST_BILINEAR | BX)[0] in (PATH444, "main:fused_generic_unity", "main:two_pass", "main:fused_tile")
+    assert run_case(640, 48, src, 640, 48, "yuv444p", SWS_FAST_BILINEAR | BX)[0] in (PATH444, "main:fused_generic_unity", "main:two_pass", "main:fused_tile", "main:rgbread+strip_march")

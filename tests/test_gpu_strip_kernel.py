@@ -1,5 +1,5 @@
 """-m gpu parity for the marching strip kernel (kernels_strip.hpp) at oracle-friendly sizes.  The library keeps narrow
-pictures on the tile kernel (option "strip_min_w", default 1024 output columns); these tests lower the threshold so that the
+pictures on the tile kernel (option "strip_min_w", default 320 output columns); these tests lower the threshold so that the
 strip kernel itself is compared with the oracle: scalers, ratios, ragged widths, every planar / semi-planar writer."""
 import pytest
 
@@ -41,7 +41,9 @@ def test_strip_scalers_and_geometries(flags, geom):
 def test_strip_is_used_for_wide_pictures_by_default():
     path, _ = run_case(2048, 24, "yuv420p10le", 1024, 12, "p010le", SWS_LANCZOS | BX, seed=2)
     assert path == "main:strip_march"
-    path, _ = run_case(640, 48, "yuv420p", 320, 24, "yuv420p", SWS_BILINEAR | BX, seed=2)
+    path, _ = run_case(640, 48, "yuv420p", 320, 24, "yuv420p", SWS_BILINEAR | BX, seed=2)      # (from 320 columns on: tools/narrow_shapes_times.py)
+    assert path == "main:strip_march"
+    path, _ = run_case(480, 48, "yuv420p", 240, 24, "yuv420p", SWS_BILINEAR | BX, seed=2)
     assert path != "main:strip_march"
 
 
