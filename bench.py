@@ -44,13 +44,14 @@ WORKLOADS = {
             "C2a 3840x2160 yuv420p->rgb24 SWS_BICUBIC|SWS_BITEXACT (reference path: unscaled yuv2rgb_c_24_rgb)"),
     "c2b": (3840, 2160, "yuv420p", 3840, 2160, "rgb24", SWS_BICUBIC | SWS_BITEXACT | SWS_ACCURATE_RND, None, 32,
             "C2b 3840x2160 yuv420p->rgb24 SWS_BICUBIC|SWS_BITEXACT|SWS_ACCURATE_RND (polyphase chain, 4-tap vertical chroma)"),
-    "c1": (1280, 720, "yuv420p", 640, 360, "yuv420p", SWS_BILINEAR | SWS_BITEXACT, None, 128,
+    "c1": (1280, 720, "yuv420p", 640, 360, "yuv420p", SWS_BILINEAR | SWS_BITEXACT, None, 256,
            "C1 1280x720->640x360 yuv420p SWS_BILINEAR|SWS_BITEXACT"),
     "c3a": (7680, 4320, "yuv420p10le", 7680, 4320, "p010le", SWS_LANCZOS | SWS_BITEXACT, None, 8,
             "C3a 7680x4320 yuv420p10le->p010le same size (reference path: planarToP01xWrapper)"),
     # (batches: a strip-kernel launch is banded for one resident round of 4096 waves, so the fewer frames a call holds the shorter its bands and
-    #  the larger the share of the per-band ring fill -- C3b: 8 frames 0.44 - 0.47 of the HBM peak, 16 frames 0.51, 32 frames 0.56)
-    "c3b": (7680, 4320, "yuv420p10le", 3840, 2160, "p010le", SWS_LANCZOS | SWS_BITEXACT, None, 32,
+    #  the larger the share of the per-band ring fill -- C3b: 8 frames 0.44 - 0.47 of the HBM peak, 16 frames 0.51, 32 frames 0.52 - 0.56, 64 frames 0.59;
+    #  D1: 64 frames 0.34 - 0.37, 128 frames 0.40; C1: 128 frames 0.24, 256 frames 0.25)
+    "c3b": (7680, 4320, "yuv420p10le", 3840, 2160, "p010le", SWS_LANCZOS | SWS_BITEXACT, None, 64,
             "C3b 7680x4320->3840x2160 yuv420p10le->p010le SWS_LANCZOS (12-tap h and v)"),
     "c4": (1920, 1080, "nv12", 1920, 1080, "bgr0", SWS_BICUBIC | SWS_BITEXACT, None, 64,
            "C4 1920x1080 nv12->bgr0 SWS_BICUBIC|SWS_BITEXACT (main path, 4-tap vertical chroma)"),
@@ -58,9 +59,9 @@ WORKLOADS = {
            (SWS_CS_BT2020, 1, SWS_CS_BT2020, 1), 8,
            "C5 3840x2160 gbrpf32le->yuv444p16le BT.2020 full range"),
     # not BASELINE.json configs: the most common real use of sws_scale, kept as bench variants
-    "d1": (3840, 2160, "yuv420p", 1920, 1080, "rgb24", SWS_BICUBIC | SWS_BITEXACT, None, 64,
+    "d1": (3840, 2160, "yuv420p", 1920, 1080, "rgb24", SWS_BICUBIC | SWS_BITEXACT, None, 128,
            "D1 3840x2160->1920x1080 yuv420p->rgb24 SWS_BICUBIC|SWS_BITEXACT (downscale to packed RGB)"),
-    "d2": (3840, 2160, "yuv420p", 1920, 1080, "bgra", SWS_BICUBIC | SWS_BITEXACT, None, 64,
+    "d2": (3840, 2160, "yuv420p", 1920, 1080, "bgra", SWS_BICUBIC | SWS_BITEXACT, None, 128,
            "D2 3840x2160->1920x1080 yuv420p->bgra SWS_BICUBIC|SWS_BITEXACT (downscale to packed RGB)"),
 }
 
