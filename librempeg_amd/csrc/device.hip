@@ -329,9 +329,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                               ((p.srcKind == SRCK_RGB32 && !(o.src_w & 3)) || ((p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_PLANAR16) && isPlanarYUV(o.src_format)));
     d->alpha_launch = 0;
     // (filters of more than 16 taps -- ratios of 4:1 and more -- have the strip kernel's long form with 128-column strips on one side and the element-per-thread
-    //  kernels on the other: the planner's width threshold for them is 256 columns)
+    //  kernels on the other: the planner's width threshold for them is 64 columns)
     const bool long_taps = c->plan == PLAN_MAIN && (c->hLum.size >= 16 || c->hChr.size >= 16 || c->vLum.size >= 16 || c->vChr.size >= 24);   // (padded to an even start: 16 taps already take 9 pairs)
-    const int strip_min_w_eff = long_taps ? std::min(c->tune.strip_min_w, 256) : c->tune.strip_min_w;
+    const int strip_min_w_eff = long_taps ? std::min(c->tune.strip_min_w, 64) : c->tune.strip_min_w;   // (one strip of the long forms: thumbnails of 160 x 90 from 1080p are 0.05 ms on the two-pass kernels)
     const bool fc_plain = !isGray(o.src_format) && !isGray(o.dst_format) && p.srcKind != SRCK_MONO;
     d->fullchr_on = 0;
     if (c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP) && p.full_chr && (!c->needAlpha || fc_alpha) && fc_plain && !(o.flags & SWS_FAST_BILINEAR) &&

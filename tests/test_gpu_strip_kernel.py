@@ -138,7 +138,7 @@ def test_long_filters_take_the_strip_kernel():
     for (sw, sh, sf, dw, dh, df, fl) in ((3840, 2160, "yuv420p", 960, 540, "yuv420p", SWS_BICUBIC), (3840, 2160, "yuv420p", 640, 360, "yuv420p", SWS_BICUBIC),
                                          (3840, 2160, "yuv420p", 1280, 720, "nv12", SWS_LANCZOS), (1920, 1080, "yuv420p10le", 426, 240, "yuv420p", SWS_BICUBIC),
                                          (3840, 2160, "rgb24", 960, 540, "yuv420p", SWS_BICUBIC), (3840, 2160, "bgra", 960, 540, "bgra", SWS_BICUBIC)):
-        c = SwsContext(sw, sh, sf, dw, dh, df, fl | BX)      # (the planner's own thresholds: 256 columns for the long form)
+        c = SwsContext(sw, sh, sf, dw, dh, df, fl | BX)      # (the planner's own thresholds: 64 columns for the long forms)
         assert "strip_march" in c.path() and c.kernel_name() == "sws_k_strip_long", (c.path(), c.kernel_name(), sf, df, dw)
         c.close()
     path, _ = run_case(3840, 2160, "yuv420p", 960, 540, "yuv420p", SWS_BICUBIC | BX, seed=21)
@@ -205,3 +205,15 @@ def test_extra_long_filters_take_the_strip_kernel():
     assert run_case(3840, 2160, "yuv420p", 480, 270, "yuv420p", SWS_BICUBIC | BX, seed=61)[0] == "main:strip_march"
     assert run_case(3840, 2160, "yuv420p", 320, 180, "rgb24", SWS_BICUBIC | BX, seed=62)[0] == "main:strip_march+lut_rgb"
     assert run_case(1920, 1080, "yuv420p10le", 256, 144, "yuv420p", SWS_LANCZOS | BX, seed=63)[0] == "main:strip_march"
+
+
+def test_small_thumbnails_take_the_long_forms():
+    """outputs of 64 .. 319 columns with filters of more than 16 taps (160 x 90 from 1080p): the long forms' own width threshold"""
+    assert run_case(1920, 1080, "yuv420p", 160, 90, "yuv420p", SWS_BICUBIC | BX, seed=71)[0] == "main:strip_march"
+    assert run_case(1920, 1080, "yuv420p", 128, 72, "rgb24", SWS_BICUBIC | BX, seed=72)[0] == "main:strip_march+lut_rgb"
+    assert run_case(1280, 720, "nv12", 160, 90, "yuv420p", SWS_LANCZOS | BX, seed=73)[0] == "main:strip_march"
+    assert run_case(1280, 720, "bgra", 160, 90, "bgra", SWS_BICUBIC | BX, seed=74)[0] == "main:rgbread+strip_march+fullchr_rgb"
+    for (sw, sh, dw, dh) in ((640, 360, 64, 36), (650, 365, 70, 40), (1000, 300, 100, 30), (520, 130, 65, 26), (4 * 163, 90, 66, 9)):
+        for sf, df in (("yuv420p", "yuv420p"), ("yuv420p10le", "nv12"), ("rgb24", "yuv420p"), ("yuv420p", "bgra"), ("yuv420p", "rgb24"), ("yuva420p", "yuva420p"), ("bgra", "gbrp")):
+            run_case(sw, sh, sf, dw, dh, df, SWS_BICUBIC | BX, seed=sw + dh)
+    assert run_case(600, 300, "yuv420p", 60, 30, "yuv420p", SWS_BICUBIC | BX, seed=75)[0] != "main:strip_march"      # below 64 columns

@@ -22,7 +22,8 @@ if os.environ.get("SWS_SHAPES_SET") == "ladder":     # the lower rungs of an ABR
              ("nv12",3840,2160,"nv12",960,540,SWS_BICUBIC),("yuv420p",3840,2160,"rgb24",960,540,SWS_BICUBIC),("yuv420p",3840,2160,"rgb24",640,360,SWS_BICUBIC),
              ("yuv420p",1920,1080,"rgb24",320,180,SWS_BICUBIC),("yuv420p",3840,2160,"yuv420p",960,540,SWS_BILINEAR),("rgb24",3840,2160,"yuv420p",960,540,SWS_BICUBIC),
              ("yuv420p",3840,2160,"yuv420p",480,270,SWS_BICUBIC),("yuv420p",3840,2160,"yuv420p",320,180,SWS_BICUBIC),("yuv420p",1920,1080,"yuv420p",256,144,SWS_LANCZOS),
-             ("yuv420p",3840,2160,"rgb24",320,180,SWS_BICUBIC)]
+             ("yuv420p",3840,2160,"rgb24",320,180,SWS_BICUBIC),("yuv420p",1920,1080,"yuv420p",160,90,SWS_BICUBIC),("yuv420p",1920,1080,"rgb24",128,72,SWS_BICUBIC),
+             ("yuv420p",1280,720,"yuv420p",160,90,SWS_BICUBIC)]
 print("| conversion | path / kernel | ms / frame | Gpix/s out | GB/s (src + dst bytes) |")
 print("|---|---|---|---|---|")
 for sf,sw,sh,df,dw,dh,fl in CASES:
