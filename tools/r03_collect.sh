@@ -8,8 +8,8 @@ cp $R/common.md $P/r03_common_shapes.md; cp $R/conv.txt $P/r03_common_conversion
 cp $R/narrow.md $P/r03_narrow_shapes.md
 for m in same down up; do grep "^|" $R/survey_$m.md > $P/r03_survey_$m.md; done
 { echo "# Ratios of 3:1 and more (16 frames per call, wall time per frame), tools/common_shapes_times.py with SWS_SHAPES_SET=ladder"; echo
-  echo "## before the strip kernel's long forms (filters of more than 16 taps on the tile / two-pass kernels; the library of commit 178d04a, and of 9e2b7bc for the last four rows)"
-  grep "^|" gpurun_out/a5/ladder_before.txt; grep "^| yuv420p 3840x2160 -> yuv420p 480x270\|^| yuv420p 3840x2160 -> yuv420p 320x180\|^| yuv420p 1920x1080 -> yuv420p 256x144\|^| yuv420p 3840x2160 -> rgb24 320x180" gpurun_out/b5_before.txt 2>/dev/null
+  echo "## before the strip kernel's long forms (filters of more than 16 taps on the tile / two-pass kernels; the library of commit 178d04a, and of later commits with the long forms switched off -- SWSOPT_NO_MIXED=1 -- for the last seven rows)"
+  grep "^|" gpurun_out/a5/ladder_before.txt; grep "^|" gpurun_out/b5_before.txt 2>/dev/null
   echo; echo "## with sws_k_strip_long / sws_k_strip_xlong and the sws_k_lut_rgb epilogue (final library)"; grep "^|" $R/ladder.md; } > $P/r03_ladder.md
 python - <<'PY'
 import json,subprocess
