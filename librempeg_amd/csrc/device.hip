@@ -931,6 +931,13 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 d->fullchr_on = 0; d->strip_ok = false; d->rgbread_on = false;
                 p.dstKind = d->fullchr_kind; p.u_plane_dst = dd->comp[1].plane; p.v_plane_dst = dd->comp[2].plane;
             }
+            // a 4:4:4 planar source at the same size into a full-chroma destination: four identity filters, so the epilogue reads the source planes itself
+            // (sws_k_fullchr_rgb / sws_k_fullchr_gbrp with SRCM 1 / 2) -- no strip launch, no working picture
+            d->fullchr_direct = 0;
+            if ((d->fullchr_on == 1 || d->fullchr_on == 2) && d->strip_ok && d->unity_h && d->unity_v && !d->rgbread_on && !d->split_mode && isPlanarYUV(o.src_format) &&
+                ((p.srcKind == SRCK_PLANAR8 && c->srcBpc == 8) || (p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15 && p.src_shift == 0)) &&
+                p.chrSrcW == p.srcW && p.chrSrcH == p.srcH && c->vLum.size == 1 && c->vChr.size == 1 && !c->tune.no_mixed)
+                d->fullchr_direct = p.srcKind == SRCK_PLANAR8 ? 1 : 2;
             int win = 0;
             for (int y = 0; y < o.dst_h; y += 2) {
                 const int c0 = y >> c->chrDstVSubSample, c1 = std::min(y + 1, o.dst_h - 1) >> c->chrDstVSubSample;
@@ -1072,6 +1079,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     if (c->plan == PLAN_MAIN && d->split_mode) c->path_name = ((d->split_mode & 40) ? "main:splitnv+" : "main:split422+") + c->path_name.substr(c->path_name.find(':') + 1);
     if (c->plan == PLAN_MAIN && d->join422) c->path_name += "+join422";
     if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += d->fullchr_on == 3 ? "+lut_rgb" : "+fullchr_rgb";
+    if (c->plan == PLAN_MAIN && d->fullchr_on && d->fullchr_direct) { c->path_name = "main:fullchr_rgb_direct"; c->kernel_name = d->fullchr_kind == DSTK_GBRP ? "sws_k_fullchr_gbrp" : "sws_k_fullchr_rgb"; }
     if (c->plan == PLAN_MAIN && ((d->alpha_launch == 1 && d->strip_ok) || (d->alpha_launch == 2 && d->striprgb_ok))) c->path_name += "+alpha";
     // (16-byte aligned pictures of the layout converters take the streaming kernel, k_layout.hip; the names above are the fallback's)
     if (!c->tune.no_layout_stream && (c->plan == PLAN_UNSC_PLANAR2NV12 || c->plan == PLAN_UNSC_NV122PLANAR || c->plan == PLAN_UNSC_PLANARCOPY || c->plan == PLAN_UNSC_PLANAR2NV24 ||
@@ -1314,6 +1322,19 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
     }
     // full-chroma RGB destination (dev_prepare_on): the strip kernels write three int32 sum planes per frame, sws_k_fullchr_rgb follows
     std::vector<SwsFramePtrs> p422fr, p422join;
+    if (c->plan == PLAN_MAIN && d->fullchr_on && d->fullchr_direct) {   // the epilogue alone, on the caller's planes (Y, U, V, A order)
+        const bool u1 = p.u_plane_src == 1;
+        p422join.resize((size_t)n);
+        for (int i = 0; i < n; i++) {
+            const SwsFramePtrs &a = frames[i]; SwsFramePtrs &j = p422join[(size_t)i];
+            std::memset(&j, 0, sizeof(j));
+            for (int k = 0; k < 4; k++) { j.dst[k] = a.dst[k]; j.dstStride[k] = a.dstStride[k]; }
+            j.src[0] = a.src[0]; j.srcStride[0] = a.srcStride[0];
+            j.src[1] = a.src[u1 ? 1 : 2]; j.srcStride[1] = a.srcStride[u1 ? 1 : 2];
+            j.src[2] = a.src[u1 ? 2 : 1]; j.srcStride[2] = a.srcStride[u1 ? 2 : 1];
+            j.src[3] = a.src[3]; j.srcStride[3] = a.srcStride[3];
+        }
+    } else
     if (c->plan == PLAN_MAIN && d->fullchr_on) {
         auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
         const int sP = (int)a256(4 * (int64_t)p.dstW);
@@ -1395,6 +1416,7 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
     case PLAN_UNSC_8_P01X: ret = launch_p01x(L); break;
     case PLAN_MAIN: {
         if (p.dst_alpha_fill) launch_fill_alpha(L, p.dstW, 0, p.dstH, p.dstKind == DSTK_GBRPF32 ? 32 : p.dst_bits > 8 ? p.dst_bits : 0);   // swscale.c:536-552
+        if (d->fullchr_on && d->fullchr_direct) break;     // (the epilogue below is the whole conversion)
         const bool rgb_lut = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr;
         if (d->vlines_on) ret = launch_generic(L);   // (virtual source lines: pass 1 of the two-pass path materialises them)
         else if (d->unity_h && rgb_lut && !p.no_chroma && !p.need_alpha && c->srcBpc == 8 && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12))
@@ -1459,7 +1481,7 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         else { const SwsFramePtrs *t = nullptr; r = aux_table(0, mfr, &t); if (r < 0) return r; M.fs.table = t; }
         launch_alpha_merge32(M);
     }
-    if ((c->plan == PLAN_MAIN && d->fullchr_on == 2) || alpha_run) {
+    if ((c->plan == PLAN_MAIN && d->fullchr_on == 2 && !d->fullchr_direct) || alpha_run) {
         if ((!alpha_run && p422join.empty()) || !d->strip_ok) { log_msg(c, 0, "internal error: alpha launch without the strip plan\n"); return SWS_AVERROR(EINVAL); }
         alfr.assign(frames, frames + n);
         pA = p;

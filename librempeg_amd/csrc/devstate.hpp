@@ -50,6 +50,7 @@ struct DeviceState {
     SwsFramePtrs *d_frames2 = nullptr, *h_frames2 = nullptr; int frames2_cap = 0, frames2_valid = 0;
     // helper passes around a packed / semi-planar side of the scaler (dev_prepare_on decides, launch_plan_le runs them):
     int fullchr_on = 0, fullchr_kind = 0;              // full-chroma packed RGB destination (2: with a scaled alpha plane): the strip kernels write int32 sum planes (DSTK_RAW32), sws_k_fullchr_rgb follows; the real dstKind
+    int fullchr_direct = 0;                            // 1 / 2: the epilogue reads the 8 / 16-bit planes of a same-size 4:4:4 planar source itself (four identity filters): no strip launch, no working picture
     int alpha_launch = 0;                              // planar YUV destination with a scaled alpha plane (needAlpha): one more luma launch of the strip kernel, A samples -> dst[3]
     int join422 = 0;                                   // packed 4:2:2 destination through the planar writers + interleave: 1 yuyv-like, 2 uyvy
     void *join_img = nullptr; size_t join_bytes = 0;   //   its planar 4:2:2 working pictures (one per frame of the call)

@@ -93,22 +93,27 @@ void launch_fullchr_rgb(const LaunchCtx &L)
 {
     const SwsDevParams &p = *L.p;
     const dim3 grid(cdiv(cdiv(p.dstW, 4), 256), cdiv(p.dstH, swsk::FULLCHR_RPW), L.n), blk(256);
+    const int srcm = L.d->fullchr_direct;     // 0: the strip kernels' sums; 1 / 2: the 8 / 16-bit planes of a same-size 4:4:4 source
     if (L.d->fullchr_on == 3) {   // the LUT writers (no full chroma): chroma sums at half the width
         if (p.lut.pix_step == 4) hipLaunchKernelGGL((swsk::sws_k_lut_rgb<4>), grid, blk, 0, L.st, L.fs, p);
         else hipLaunchKernelGGL((swsk::sws_k_lut_rgb<3>), grid, blk, 0, L.st, L.fs, p);
         return;
     }
+#define SWS_FC_SRCM(K, ...) do { if (srcm == 1) hipLaunchKernelGGL((swsk::K<__VA_ARGS__, 1>), grid, blk, 0, L.st, L.fs, p); \
+                                 else if (srcm == 2) hipLaunchKernelGGL((swsk::K<__VA_ARGS__, 2>), grid, blk, 0, L.st, L.fs, p); \
+                                 else hipLaunchKernelGGL((swsk::K<__VA_ARGS__, 0>), grid, blk, 0, L.st, L.fs, p); } while (0)
     if (L.d->fullchr_kind == DSTK_GBRP) {
         const bool wide = p.dst_bits > 8, alpha = L.d->fullchr_on == 2;
-        if (wide && alpha) hipLaunchKernelGGL((swsk::sws_k_fullchr_gbrp<true, true>), grid, blk, 0, L.st, L.fs, p);
-        else if (wide) hipLaunchKernelGGL((swsk::sws_k_fullchr_gbrp<true, false>), grid, blk, 0, L.st, L.fs, p);
-        else if (alpha) hipLaunchKernelGGL((swsk::sws_k_fullchr_gbrp<false, true>), grid, blk, 0, L.st, L.fs, p);
-        else hipLaunchKernelGGL((swsk::sws_k_fullchr_gbrp<false, false>), grid, blk, 0, L.st, L.fs, p);
+        if (wide && alpha) SWS_FC_SRCM(sws_k_fullchr_gbrp, true, true);
+        else if (wide) SWS_FC_SRCM(sws_k_fullchr_gbrp, true, false);
+        else if (alpha) SWS_FC_SRCM(sws_k_fullchr_gbrp, false, true);
+        else SWS_FC_SRCM(sws_k_fullchr_gbrp, false, false);
         return;
     }
-    if (p.lut.pix_step == 4 && L.d->fullchr_on == 2) hipLaunchKernelGGL((swsk::sws_k_fullchr_rgb<4, true>), grid, blk, 0, L.st, L.fs, p);
-    else if (p.lut.pix_step == 4) hipLaunchKernelGGL((swsk::sws_k_fullchr_rgb<4, false>), grid, blk, 0, L.st, L.fs, p);
-    else hipLaunchKernelGGL((swsk::sws_k_fullchr_rgb<3, false>), grid, blk, 0, L.st, L.fs, p);
+    if (p.lut.pix_step == 4 && L.d->fullchr_on == 2) SWS_FC_SRCM(sws_k_fullchr_rgb, 4, true);
+    else if (p.lut.pix_step == 4) SWS_FC_SRCM(sws_k_fullchr_rgb, 4, false);
+    else SWS_FC_SRCM(sws_k_fullchr_rgb, 3, false);
+#undef SWS_FC_SRCM
 }
 
 // plane copies between unaligned pictures and their aligned working copies (device.hip launch_plan_le; L.fs holds {src[k] -> dst[k]})

@@ -122,8 +122,39 @@ __global__ void __launch_bounds__(256) sws_k_stage_planes(SwsFrameSet fs, StageE
 // loads), a wave walks down FULLCHR_RPW rows with the next row's loads in flight; 12- or 16-byte stores.
 // ------------------------------------------------------------------------------------------
 constexpr int FULLCHR_RPW = 4;
+// SRCM of the two epilogues below: 0 = the strip kernels' int32 sums; 1 / 2 = the source planes themselves, 8-bit / 9 .. 15-bit samples -- a 4:4:4 planar
+// source at the same size has four identity filters, and one-tap banks turn a sample into the sum (hScale8To15_c / hScale16To15_c of the tap 1 << 14, then the
+// tap 1 << 12): (s << 7) << 12, min((s << 14) >> (depth - 1), 32767) << 12.  No strip launch, no working picture (dev_prepare_on: fullchr_direct).
+template <int SRCM>
+__device__ __forceinline__ void fullchr_fetch4(const uint8_t *plane, int64_t stride, int y, int x, int npx, int sh, int (&out)[4])
+{
+    if constexpr (SRCM == 0) {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4 v = *(const SWS_GLOBAL i32x4 *)(plane + y * stride + 4 * (int64_t)x);   // (working planes: padded to whole 16-byte groups)
+        out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+    } else if constexpr (SRCM == 1) {
+        const uint8_t *q = plane + y * stride + x;
+        uint32_t w = 0;
+        if (npx == 4) w = *(const SWS_GLOBAL uint32_t *)q;
+        else for (int k = 0; k < npx; k++) w |= (uint32_t)q[k] << (8 * k);      // (the caller's planes: nothing is read past the row)
+#pragma unroll
+        for (int k = 0; k < 4; k++) out[k] = (int)(((w >> (8 * k)) & 0xFFu) << 19);
+    } else {
+        const uint16_t *q = (const uint16_t *)(plane + y * stride) + x;
+        uint32_t w[2] = { 0, 0 };
+        if (npx == 4) { const u32x2 t = *(const SWS_GLOBAL u32x2 *)q; w[0] = t[0]; w[1] = t[1]; }
+        else for (int k = 0; k < npx; k++) w[k >> 1] |= (uint32_t)q[k] << (16 * (k & 1));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t sv = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            out[k] = (int)(min((sv << 14) >> sh, 32767u) << 12);
+        }
+    }
+}
+
+
 // ALPHA: a fourth sum plane (the alpha plane through the luma filters): A = (sum + (1 << 18)) >> 19, clipped the way the writer does (output.c:2193-2201)
-template <int BPP, bool ALPHA>
+template <int BPP, bool ALPHA, int SRCM = 0>
 __global__ void __launch_bounds__(256) sws_k_fullchr_rgb(SwsFrameSet fs, SwsDevParams p)
 {
     const FrameRegs f = load_frame(fs, blockIdx.z);
@@ -135,20 +166,22 @@ __global__ void __launch_bounds__(256) sws_k_fullchr_rgb(SwsFrameSet fs, SwsDevP
     const bool in = x < W;
     const int npx = min(4, W - x);
     const int y0 = blockIdx.y * FULLCHR_RPW, y1 = min(H, y0 + FULLCHR_RPW);
-    const uint8_t *pY = f.src[0] + 4 * (int64_t)x, *pU = f.src[1] + 4 * (int64_t)x, *pV = f.src[2] + 4 * (int64_t)x, *pA = ALPHA ? f.src[3] + 4 * (int64_t)x : nullptr;
+    const uint8_t *pY = f.src[0], *pU = f.src[1], *pV = f.src[2], *pA = ALPHA ? f.src[3] : nullptr;
     const int64_t sY = f.srcStride[0], sU = f.srcStride[1], sV = f.srcStride[2], sA = ALPHA ? f.srcStride[3] : 0;
+    const int ssh = U(p.src_depth) - 1;                       // (SRCM == 2: hScale16To15_c's shift)
     const SwsLutParams &L = p.lut;
     const int y_offset = U(L.y_offset), y_coeff = U(L.y_coeff), v2r = U(L.v2r), v2g = U(L.v2g), u2g = U(L.u2g), u2b = U(L.u2b);
     const int r_pos = U(L.r_pos), g_pos = U(L.g_pos), b_pos = U(L.b_pos), a_pos = U(L.a_pos);
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4 nY = { 0, 0, 0, 0 }, nU = nY, nV = nY, nA = nY;
-    auto fetch = [&](int y) {   // (the working planes are padded to whole 16-byte groups: no tail loads)
-        nY = *(const SWS_GLOBAL i32x4 *)(pY + y * sY); nU = *(const SWS_GLOBAL i32x4 *)(pU + y * sU); nV = *(const SWS_GLOBAL i32x4 *)(pV + y * sV);
-        if constexpr (ALPHA) nA = *(const SWS_GLOBAL i32x4 *)(pA + y * sA);
+    int nY[4] = { 0, 0, 0, 0 }, nU[4] = { 0, 0, 0, 0 }, nV[4] = { 0, 0, 0, 0 }, nA[4] = { 0, 0, 0, 0 };
+    auto fetch = [&](int y) {
+        fullchr_fetch4<SRCM>(pY, sY, y, x, npx, ssh, nY); fullchr_fetch4<SRCM>(pU, sU, y, x, npx, ssh, nU); fullchr_fetch4<SRCM>(pV, sV, y, x, npx, ssh, nV);
+        if constexpr (ALPHA) fullchr_fetch4<SRCM>(pA, sA, y, x, npx, ssh, nA);
     };
     if (in && y0 < y1) fetch(y0);
     for (int y = y0; y < y1; y++) {
-        const i32x4 vY = nY, vU = nU, vV = nV, vA = nA;
+        int vY[4], vU[4], vV[4], vA[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { vY[k] = nY[k]; vU[k] = nU[k]; vV[k] = nV[k]; vA[k] = nA[k]; }
         if (in && y + 1 < y1) fetch(y + 1);
         if (!in) continue;
         uint32_t px[4];
@@ -187,7 +220,7 @@ __global__ void __launch_bounds__(256) sws_k_fullchr_rgb(SwsFrameSet fs, SwsDevP
 // The same epilogue for planar RGB destinations of 8 .. 14 bits (gbrp, gbrap, gbrp10le ... and the msb-aligned twins): yuv2gbrp_full_X_c
 // (output.c:2342-2421) -- any_vscale always takes the X form for them, and full chroma is forced (utils.c:1270-1286).  Planes G, B, R (, A);
 // rounding 1 << (SH - 1) and >> SH with SH = 22 + 8 - depth; alpha: (1 << 18) + sum, clipped to 27 bits, >> (SH - 3).
-template <bool WIDE, bool ALPHA>
+template <bool WIDE, bool ALPHA, int SRCM = 0>
 __global__ void __launch_bounds__(256) sws_k_fullchr_gbrp(SwsFrameSet fs, SwsDevParams p)
 {
     const FrameRegs f = load_frame(fs, blockIdx.z);
@@ -199,20 +232,22 @@ __global__ void __launch_bounds__(256) sws_k_fullchr_gbrp(SwsFrameSet fs, SwsDev
     const bool in = x < W;
     const int npx = min(4, W - x);
     const int y0 = blockIdx.y * FULLCHR_RPW, y1 = min(H, y0 + FULLCHR_RPW);
-    const uint8_t *pY = f.src[0] + 4 * (int64_t)x, *pU = f.src[1] + 4 * (int64_t)x, *pV = f.src[2] + 4 * (int64_t)x, *pA = ALPHA ? f.src[3] + 4 * (int64_t)x : nullptr;
+    const uint8_t *pY = f.src[0], *pU = f.src[1], *pV = f.src[2], *pA = ALPHA ? f.src[3] : nullptr;
     const int64_t sY = f.srcStride[0], sU = f.srcStride[1], sV = f.srcStride[2], sA = ALPHA ? f.srcStride[3] : 0;
+    const int ssh = U(p.src_depth) - 1;                       // (SRCM == 2: hScale16To15_c's shift)
     const SwsLutParams &L = p.lut;
     const int y_offset = U(L.y_offset), y_coeff = U(L.y_coeff), v2r = U(L.v2r), v2g = U(L.v2g), u2g = U(L.u2g), u2b = U(L.u2b);
     const int SH = 22 + 8 - U(p.dst_bits), dsh = U(p.dst_shift);
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4 nY = { 0, 0, 0, 0 }, nU = nY, nV = nY, nA = nY;
+    int nY[4] = { 0, 0, 0, 0 }, nU[4] = { 0, 0, 0, 0 }, nV[4] = { 0, 0, 0, 0 }, nA[4] = { 0, 0, 0, 0 };
     auto fetch = [&](int y) {
-        nY = *(const SWS_GLOBAL i32x4 *)(pY + y * sY); nU = *(const SWS_GLOBAL i32x4 *)(pU + y * sU); nV = *(const SWS_GLOBAL i32x4 *)(pV + y * sV);
-        if constexpr (ALPHA) nA = *(const SWS_GLOBAL i32x4 *)(pA + y * sA);
+        fullchr_fetch4<SRCM>(pY, sY, y, x, npx, ssh, nY); fullchr_fetch4<SRCM>(pU, sU, y, x, npx, ssh, nU); fullchr_fetch4<SRCM>(pV, sV, y, x, npx, ssh, nV);
+        if constexpr (ALPHA) fullchr_fetch4<SRCM>(pA, sA, y, x, npx, ssh, nA);
     };
     if (in && y0 < y1) fetch(y0);
     for (int y = y0; y < y1; y++) {
-        const i32x4 vY = nY, vU = nU, vV = nV, vA = nA;
+        int vY[4], vU[4], vV[4], vA[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { vY[k] = nY[k]; vU[k] = nU[k]; vV[k] = nV[k]; vA[k] = nA[k]; }
         if (in && y + 1 < y1) fetch(y + 1);
         if (!in) continue;
         uint32_t g[4], b[4], r[4], a[4];

@@ -76,8 +76,17 @@ def test_one_tap_vertical_forms():
             for (sw, sh, dw, dh, fl) in ((256, 64, 256, 64, SWS_BICUBIC), (320, 50, 200, 50, SWS_BICUBIC), (200, 37, 320, 37, SWS_LANCZOS), (1920, 24, 1920, 24, SWS_BILINEAR),
                                          (1920, 24, 480, 24, SWS_BICUBIC)):
                 r = run_case(sw, sh, src, dw, dh, dst, fl | FC | BX, seed=sw + dh, tune=TUNE)
-    assert run_case(1920, 1080, "yuv444p", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=41)[0] == "main:strip_march+fullchr_rgb"
-    assert run_case(1920, 1080, "yuv444p10le", 1920, 1080, "rgb24", SWS_BICUBIC | BX, seed=42)[0] == "main:strip_march+fullchr_rgb"
+    # (a 4:4:4 planar source at the same size: the epilogue reads the source planes itself)
+    assert run_case(1920, 1080, "yuv444p", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=41)[0] == "main:fullchr_rgb_direct"
+    assert run_case(1920, 1080, "yuv444p10le", 1920, 1080, "rgb24", SWS_BICUBIC | BX, seed=42)[0] == "main:fullchr_rgb_direct"
+    assert run_case(1920, 1080, "yuva444p", 1920, 1080, "rgba", SWS_BICUBIC | BX, seed=45, device_frames=False)[0] == "main:fullchr_rgb_direct"
+    assert run_case(1918, 1080, "yuv444p12le", 1918, 1080, "gbrp12le", SWS_BICUBIC | BX, seed=46)[0] == "main:fullchr_rgb_direct"
+    assert run_case(1921, 270, "yuvj444p", 1921, 270, "gbrap", SWS_BICUBIC | BX, seed=47)[0] == "main:fullchr_rgb_direct"
+    for src in ("yuv444p", "yuv444p9le", "yuv444p10le", "yuv444p14le", "yuva444p", "yuva444p10le", "yuvj444p"):
+        for dst in ("rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "gbrp", "gbrap", "gbrp10le", "gbrap12le", "gbrp12msble"):
+            for (w, h) in ((256, 64), (322, 50), (129, 33), (67, 18), (1026, 21), (1, 1), (3, 2), (5, 3)):
+                run_case(w, h, src, w, h, dst, SWS_BICUBIC | BX, seed=w + h, tune=TUNE)
+    assert run_case(1920, 1080, "yuv444p16le", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=48)[0] != "main:fullchr_rgb_direct"   # 16-bit samples
     assert run_case(1920, 1080, "rgb24", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=43)[0] == "main:rgbread+strip_march+fullchr_rgb"   # (BITEXACT: no rgb24 -> bgra shuffle, swscale_unscaled.c findRgbConvFn)
     assert run_case(1920, 1080, "yuv444p", 1280, 1080, "bgra", SWS_BICUBIC | BX, seed=44)[0] == "main:strip_march+fullchr_rgb"
 

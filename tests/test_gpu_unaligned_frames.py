@@ -73,6 +73,8 @@ CASES = [
     ("yuva420p", 256, 64, "rgba", 192, 48, SWS_BICUBIC | SWS_FULL_CHR_H_INT),
     ("bgra", 256, 64, "yuva420p", 192, 48, SWS_BICUBIC),      # rgbread + strip + alpha
     ("yuva420p", 256, 64, "yuva444p", 192, 48, SWS_BICUBIC),  # strip + alpha
+    ("yuv444p", 256, 64, "bgra", 256, 64, SWS_BICUBIC),       # the full-chroma epilogue on the source planes
+    ("yuva444p10le", 256, 64, "gbrap", 256, 64, SWS_BICUBIC),
     ("yuv420p", 256, 64, "rgb24", 191, 48, SWS_BICUBIC),      # strip + fullchr_rgb
     ("yuv420p", 256, 64, "bgra", 192, 48, SWS_BICUBIC),       # strip_rgb
     ("yuv420p", 256, 64, "yuyv422", 192, 48, SWS_BICUBIC),    # strip + join422
