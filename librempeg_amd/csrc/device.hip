@@ -1274,6 +1274,13 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
             }
         }
         if (!frames_vec_ok(stfr.data(), n)) { log_msg(c, 0, "internal error: staged pictures still unaligned\n"); return SWS_AVERROR(EINVAL); }
+        // (what staging cannot cure: a plane of 2 GiB or more -- the strip kernels address a plane as base + 32-bit offset and the helper passes have no other kernels)
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 4; k++)
+                if ((stfr[(size_t)i].src[k] && (int64_t)stfr[(size_t)i].srcStride[k] * p.srcH >= (int64_t)1 << 31) ||
+                    (stfr[(size_t)i].dst[k] && (int64_t)stfr[(size_t)i].dstStride[k] * p.dstH >= (int64_t)1 << 31)) {
+                    log_msg(c, 0, "planes of 2 GiB or more are not supported on this path\n"); return SWS_AVERROR(ENOTSUP);
+                }
         if (stage_in) {
             LaunchCtx S;
             std::memset(&S.fs, 0, sizeof(S.fs));
