@@ -60,8 +60,9 @@ static void dev_state_free(DeviceState *d)
 {
     if (!d) return;
     (void)hipSetDevice(d->device);
+    // (a stream the context does not own -- the caller's, or a frames' hwdevice stream on loan -- may be gone by now: it is never touched here;
+    //  hipFree below waits for the device, so nothing in flight can still be using the blocks)
     if (d->stream && d->own_stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
-    else if (d->stream) (void)hipStreamSynchronize(d->stream);
     for (void *p : { d->d_tables, d->scratch, d->stage_src, d->stage_dst, (void *)d->d_frames, d->casc_img, d->slice_img, d->d_tilegeom,
                      d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2, d->casc_img2, d->d_gamma_tab, d->d_ed_err, d->d_pal, d->d_vlines, d->rgbread_img, (void *)d->d_frames2 })
         if (p) (void)hipFree(p);
@@ -1182,8 +1183,9 @@ static bool frames_vec_ok(const SwsFramePtrs *fr, int n)
     return true;
 }
 
-// launch the kernels of one (non-cascaded) context over `n` device-resident frames
-static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
+// launch the kernels of one (non-cascaded) context over `n` device-resident frames (one sub-batch of launch_plan_le: rec0 / rec1 say whether
+// this sub-batch starts / ends the timed region of the call)
+static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePtrs *frames, int n, int sliceY, int sliceH, bool rec0, bool rec1)
 {
     const SwsDevParams &p = d->params;
     hipStream_t st = d->stream;
@@ -1237,7 +1239,7 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         *out = dd2;
         return 0;
     };
-    bool timing_started = false;
+    bool timing_started = !rec0;
     // pictures whose planes are not 16-byte aligned (a cropped view, a tightly packed rgb24 row) or bottom-up (negative line sizes) under the helper passes, which read and write 16-byte
     // granules and have no per-byte twins: such planes are copied into aligned working planes first, and the written ones back afterwards (the visible
     // bytes of every row only).  Contexts without helper passes fall back to their per-sample kernels instead
@@ -1288,7 +1290,7 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
             S.fs.count = n;
             if (n == 1) { S.fs.table = nullptr; S.fs.one = st_in[0]; }
             else { const SwsFramePtrs *t = nullptr; r = aux_table(3, st_in, &t); if (r < 0) return r; S.fs.table = t; }
-            if (d->timing) { HIPCHK(hipEventRecord(d->ev0, st)); timing_started = true; }
+            if (d->timing && !timing_started) { HIPCHK(hipEventRecord(d->ev0, st)); timing_started = true; }
             launch_stage_planes(S, st_rb[0], st_rows[0], true);
         }
         frames = stfr.data();
@@ -1531,7 +1533,50 @@ static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *fr
         launch_stage_planes(S, st_rb[1], st_rows[1], false);
     }
     HIPCHK(hipGetLastError());
-    if (d->timing) { HIPCHK(hipEventRecord(d->ev1, st)); d->timed = true; }
+    if (d->timing && rec1) { HIPCHK(hipEventRecord(d->ev1, st)); d->timed = true; }
+    return 0;
+}
+
+// The helper passes keep per-FRAME working pictures (the reader pre-pass's 16-bit planes, the split / join pictures, the int32 sum planes of the
+// full-chroma routes, staging copies of unaligned frames): bytes per frame x the frames of the call.  A large sws_scale_frames() batch is
+// therefore cut into sub-batches whose working pictures fit a budget (Tuning::work_mb, 2 GiB by default: bgra 4K -> rgb24 1080p needs ~83 MB per
+// frame, i.e. 24 frames per sub-batch -- far more than it takes to fill the GPU); the buffers are reused from sub-batch to sub-batch (same stream:
+// ordered).  Contexts without helper passes have no per-frame working memory and always go out as one launch set.
+static size_t helper_bytes_per_frame(const SwsInternal *c, const DeviceState *d)
+{
+    if (c->plan != PLAN_MAIN) return 0;
+    const SwsDevParams &p = d->params;
+    auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
+    int64_t b = 0;
+    const bool helpers = d->split_mode || d->join422 || d->fullchr_on || d->alpha_launch || d->rgbread_on;
+    if (!helpers) return 0;
+    // staging copies of unaligned / bottom-up planes (worst case: every plane of both pictures)
+    const PixDesc *ds = pix_desc(c->opts.src_format), *dd = pix_desc(c->opts.dst_format);
+    for (int side = 0; side < 2; side++)
+        for (int k = 0; k < 4; k++) {
+            int rows = 0, rb = 0, vs = 0;
+            plane_extent(side ? dd : ds, side ? c->opts.dst_w : c->opts.src_w, side ? c->opts.dst_h : c->opts.src_h, k, &rows, &rb, &vs);
+            b += a256(rb) * rows;
+        }
+    if (d->split_mode) b += a256(2 * (int64_t)p.srcW) * p.srcH + 2 * a256(2 * (int64_t)std::max(p.chrSrcW, p.srcW >> 1)) * p.srcH + 256;
+    if (d->fullchr_on && !d->fullchr_direct) b += 4 * a256(4 * (int64_t)p.dstW) * p.dstH + 256;
+    if (d->join422) b += (a256(p.dstW) + 2 * a256(p.dstW >> 1)) * (int64_t)p.dstH + 256;
+    if (d->alpha_launch == 2) b += a256(4 * (int64_t)p.dstW) * p.dstH + 256;
+    if (d->rgbread_on) b += 2 * a256(2 * (int64_t)p.srcW) * p.srcH + 2 * a256(2 * (int64_t)p.chrSrcW) * p.srcH + 512;
+    return (size_t)b;
+}
+
+static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
+{
+    const size_t per = n > 1 ? helper_bytes_per_frame(c, d) : 0;
+    const size_t budget = (size_t)std::max(1, c->tune.work_mb) << 20;
+    if (!per || per * (size_t)n <= budget) return launch_plan_le_batch(c, d, frames, n, sliceY, sliceH, true, true);
+    const int chunk = (int)std::max<size_t>(1, budget / per);
+    for (int i = 0; i < n; i += chunk) {
+        const int m = std::min(chunk, n - i);
+        int r = launch_plan_le_batch(c, d, frames + i, m, sliceY, sliceH, i == 0, i + m >= n);
+        if (r < 0) return r;
+    }
     return 0;
 }
 
@@ -2091,6 +2136,19 @@ void dev_return_stream(SwsInternal *c, const StreamLoan &loan)
     (void)hipSetDevice(d->device);
     if (d->ev_loan && hipEventRecord(d->ev_loan, d->stream) == hipSuccess) (void)hipStreamWaitEvent((hipStream_t)loan.prev, d->ev_loan, 0);
     else (void)hipGetLastError();
+    // a cascade's children copied the borrowed handle at run time (run_single: cd[k]->stream = d->stream): they go back to the parent's own
+    // stream too, so that nothing of the caller's is held once the loan is over
+    const hipStream_t lent = d->stream;
+    for (SwsInternal *cc : c->cascade) {
+        if (!cc) continue;
+        for (DeviceState *cd : { cc->dev, (size_t)d->device < cc->peers.size() ? cc->peers[(size_t)d->device] : nullptr })
+            if (cd && cd->device == d->device && cd->stream == lent && !cd->own_stream) cd->stream = (hipStream_t)loan.prev;
+        for (SwsInternal *gc : cc->cascade) {     // (a cascade step that is itself a cascade: error-diffusion contexts)
+            if (!gc) continue;
+            for (DeviceState *gd : { gc->dev, (size_t)d->device < gc->peers.size() ? gc->peers[(size_t)d->device] : nullptr })
+                if (gd && gd->device == d->device && gd->stream == lent && !gd->own_stream) gd->stream = (hipStream_t)loan.prev;
+        }
+    }
     d->stream = (hipStream_t)loan.prev; d->own_stream = loan.prev_own;
 }
 
@@ -2455,7 +2513,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "strip_waves", &c->tune.strip_waves }, { "strip_rgb_cols", &c->tune.strip_rgb_cols }, { "rgb_march_waves", &c->tune.rgb_march_waves }, { "tile_lds_kb", &c->tune.tile_lds_kb },
         { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "layout_ch", &c->tune.layout_ch }, { "no_mixed", &c->tune.no_mixed }, { "no_layout_stream", &c->tune.no_layout_stream }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
         { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
-        { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse },
+        { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb },
         { "debug", &c->tune.debug },
     };
     for (auto &e : tab)

@@ -106,12 +106,13 @@ static bool fmt_equal(const SwsFmt &a, const SwsFmt &b)
     return a.width == b.width && a.height == b.height && a.interlaced == b.interlaced && a.field == b.field && a.format == b.format &&
            a.range == b.range && a.csp == b.csp && a.loc == b.loc && color_equal(a, b);
 }
-// what a cached conversion depends on beyond ff_fmt_equal: where the pixels live
-// (the stream and the device context travel with the frames: frames of another AVHWDeviceContext on the same ordinal are another graph, or the
-//  cached one would queue work on a stream that may be gone)
+// what a cached conversion depends on beyond ff_fmt_equal: where the pixels live -- the hardware format and the GPU ordinal.  The stream and the
+// device context travel with the FRAMES, not with the graph: the stream is borrowed per call (dev_borrow_stream) and nothing cached depends on it,
+// so frames of another frames context on the same GPU, or frames that carry another stream, reuse the cached graph (graph_reinit refreshes the two
+// fields from the frames of the call; a rebuild would re-initialise the context, copy the tables synchronously and reallocate the working buffers)
 static bool fmt_same(const SwsFmt &a, const SwsFmt &b)
 {
-    return fmt_equal(a, b) && a.hw_format == b.hw_format && a.hip_device == b.hip_device && a.hip_stream == b.hip_stream && a.device_ref == b.device_ref;
+    return fmt_equal(a, b) && a.hw_format == b.hw_format && a.hip_device == b.hip_device;
 }
 
 // ff_test_fmt(), format.c:683-693 with SWS_BACKEND_LEGACY
@@ -238,7 +239,11 @@ static int build_legacy(SwsInternal *c, const SwsFmt &src, const SwsFmt &dst, Fr
 static int graph_reinit(SwsInternal *c, int field, const SwsFmt &src, const SwsFmt &dst)
 {
     FrameGraph *g = &c->graph[field];
-    if (g->valid && fmt_same(g->src, src) && fmt_same(g->dst, dst) && !std::memcmp(&g->opts_copy, &c->opts, sizeof(SwsContext))) return 0;
+    if (g->valid && fmt_same(g->src, src) && fmt_same(g->dst, dst) && !std::memcmp(&g->opts_copy, &c->opts, sizeof(SwsContext))) {
+        g->src.hip_stream = src.hip_stream; g->src.device_ref = src.device_ref;     // (this call's frames: frames_stream() reads them)
+        g->dst.hip_stream = dst.hip_stream; g->dst.device_ref = dst.device_ref;
+        return 0;
+    }
     graph_free(g);
     g->src = src; g->dst = dst; g->opts_copy = c->opts;
     bool inc = false;

@@ -112,6 +112,7 @@ struct Tuning {
     int layout_ch = 1, no_layout_stream = 0;   // streaming layout converters (kernels_layout.hpp): 16-byte chunks per lane; off = the element-per-thread kernels
     int no_wave = 0, no_march = 0, no_rgbsrc = 0, no_strip = 0, no_strip_dma = 0, no_dot2 = 0, no_tile = 0;
     int max_devices = 0;           // sws_scale_frames(): GPUs to shard over (0 = all visible)
+    int work_mb = 2048;            // budget for the helper passes' per-frame working pictures: larger batches are cut into sub-batches (device.hip launch_plan_le)
     int debug = 0;
 };
 
