@@ -643,7 +643,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             const bool fullA = !mixedM && unity_ok && !(d->unity_h && d->unity_v && !rgb_ok && !unity_yuv) && !p.fast_bilinear && (!gray_any || gray_both || d->fullchr_on == 2 || alpha_planar || (rgb_ok && rgb_alpha)) && (src_ok || (nv_src && dst_ok) || rgbread) &&
                                (dst_ok || rgb_ok) && !p.wide && (fs_ok16 || fs_ok32 || fs_ok64) && !c->tune.no_dot2;
             const int long_form = !fullA || fs_ok16 ? 0 : fs_ok32 ? 1 : 2;
-            d->mixed_ok = false;
+            d->mixed_ok = false; d->stripLs_ok = d->stripCs_ok = false;
             if (fullA || mixedM) {
                 const int SPC = (p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010 || rgbread) ? 8 : 16;
                 std::vector<uint8_t> blob;
@@ -717,6 +717,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     for (int y = 1; y < vb.count; y++) if (vb.pos[y] < vb.pos[y - 1]) return false;   // the ring only moves forward
                     g.TW = TW; g.strips = strips; g.NCmax = ncmax; g.nph = nph; g.npv = npv; g.hfs2 = longf ? 2 * nph : hf2; g.vfs2 = vf2;
                     g.lds_bytes = 4 * ncomp * 2 * ((ncmax + SPC) / 2) * 4;
+                    g.dma8_ok = 0; g.nph8 = 0; g.lds_dma8_bytes = 0; g.hT8 = nullptr;     // (the byte-row LDS-DMA form: plan3_alt)
                     // LDS-DMA form: a ring of 4 row pairs per wave, rows of ncmax 16-bit samples; every pair between the first and the last
                     // one a band needs is requested, so the windows of consecutive rows must touch (no skipped pair)
                     g.lds_dma_bytes = 4 * 4 * ncomp * 2 * (ncmax / 2) * 4;
@@ -742,6 +743,61 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     o.rows = put(rows.data(), rows.size() * sizeof(SwsStripRow));
                     return true;
                 };
+                // The same plan on strips of another width, for the short-filter instantiations (k_strip2.hip: 8-bit sources, at most 6 tap pairs each way,
+                // windows of at most 64 chunks): 3 .. 5 luma / 1 .. 3 chroma columns per lane, whichever leaves the fewest idle lane-columns in the last
+                // strip (640 columns: 2 strips of 320 instead of 2.5 of 256); only colStart / colCount differ from the base plan
+                auto plan3_alt = [&](const FilterBank &hb, const FilterBank &vb, int W, int ncomp, const SwsStripGeom &base, SwsStripGeom &alt, SOff &o) -> bool {
+                    if (c->tune.no_strip_short || SPC != 16 || (p.srcKind != SRCK_PLANAR8 && p.srcKind != SRCK_NV12) || base.npv > 6 || base.nph > 6) return false;
+                    const int hf2 = fs2(hb.size);
+                    int best = 0; int64_t best_cost = INT64_MAX;
+                    std::vector<int32_t> bcs, bcc; int bnc = 0;
+                    const int forced = ncomp == 2 ? c->tune.strip_cols_c : c->tune.strip_cols_l;
+                    // (the LDS-DMA form -- planar sources, no skipped row pair -- needs fewer registers per column and takes wider strips)
+                    bool dma8 = !c->tune.no_strip_dma8 && p.srcKind == SRCK_PLANAR8 && (hb.size + 1) / 2 <= 6;
+                    for (int y = 1; y < vb.count && dma8; y++)
+                        if (((vb.pos[y] & ~1) >> 1) > ((vb.pos[y - 1] & ~1) >> 1) + base.npv) dma8 = false;
+                    const std::vector<int> cand = dma8 ? (ncomp == 2 ? std::vector<int>{ 5, 4, 3, 2, 1 } : std::vector<int>{ 7, 6, 5, 4, 3 })
+                                                       : (ncomp == 2 ? std::vector<int>{ 3, 2, 1 } : std::vector<int>{ 5, 4, 3 });
+                    for (int cols : cand) {
+                        if (!c->tune.strip_cols_auto && cols != forced) continue;
+                        const int TW = 64 * cols, strips = (W + TW - 1) / TW;
+                        std::vector<int32_t> cs(strips), cc(strips);
+                        int ncmax = 0; bool ok = true;
+                        for (int t = 0; t < strips && ok; t++) {
+                            int lo = INT32_MAX, hi = -1;
+                            for (int x = t * TW; x < std::min(W, (t + 1) * TW); x++) { lo = std::min(lo, hb.pos[x] & ~1); hi = std::max(hi, (hb.pos[x] & ~1) + hf2); }
+                            if (lo < 0) { ok = false; break; }
+                            lo = lo / SPC * SPC;
+                            cs[t] = lo; cc[t] = (hi - lo + SPC - 1) / SPC * SPC; ncmax = std::max(ncmax, cc[t]);
+                        }
+                        if (!ok || ncmax / SPC > 64) continue;
+                        // what a launch pays per row: every strip its columns plus a fixed share (staging / requests, plan entry, waits, stores):
+                        // about two columns' worth (measured on C1: chroma strips of 64 / 128 / 192 columns, 5 / 3 / 2 per row)
+                        const int64_t cost = (int64_t)strips * (2 * cols + 3);
+                        if (cost < best_cost) { best_cost = cost; best = cols; bcs = cs; bcc = cc; bnc = ncmax; }
+                    }
+                    if (!best) return false;
+                    alt = base;
+                    alt.TW = 64 * best; alt.strips = (W + alt.TW - 1) / alt.TW; alt.NCmax = bnc;
+                    alt.lds_bytes = 4 * ncomp * 2 * ((bnc + SPC) / 2) * 4; alt.dma_ok = 0;
+                    o.cs = put(bcs.data(), bcs.size() * 4); o.cc = put(bcc.data(), bcc.size() * 4); o.rows = 0;
+                    // LDS-DMA form (kernels_strip8.hpp): raw byte rows, a ring of 4 row pairs per wave; planar sources only (semi-planar chroma bytes are
+                    // interleaved); every pair between the first and the last one a band needs is requested, so no pair may be skipped.  Its tap rows
+                    // start at the filter's own first tap (no even-position padding): o.rows carries their offset in the blob
+                    alt.nph8 = (hb.size + 1) / 2;
+                    alt.lds_dma8_bytes = 4 * 4 * ncomp * 2 * ((bnc + 16) / 4) * 4;
+                    alt.dma8_ok = dma8 && alt.lds_dma8_bytes <= 48 * 1024;
+                    if (alt.dma8_ok) {
+                        const int f8 = 2 * alt.nph8;
+                        std::vector<int16_t> t8((size_t)hb.count * f8, 0);
+                        for (int i = 0; i < hb.count; i++)
+                            for (int j = 0; j < hb.size; j++) t8[(size_t)i * f8 + j] = hb.taps[(size_t)i * hb.size + j];
+                        o.rows = put(t8.data(), t8.size() * 2);
+                    }
+                    return true;
+                };
+                d->stripLs_ok = d->stripCs_ok = false;
+                SOff sLs, sCs;
                 SOff sL, sC;
                 // (raw sums: the packed X form's own taps -- except when both vertical filters have one tap: the packed writers then take their "_1" forms
                 //  (yuv2rgb_full_1, yuv2rgb_1: vscale.c:136-141), which ignore the coefficients like yuv2plane1 does and equal the X arithmetic with the tap
@@ -765,6 +821,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     if (plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sM, nullptr, chr_plane1)) {
                         const std::vector<int16_t> htc = padded(c->hChr);
                         const size_t ohc = put(htc.data(), htc.size() * 2);
+                        const bool altC = plan3_alt(c->hChr, c->vChr, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
                         if (blob.size() > d->dot2_bytes) {
                             if (d->d_dot2) HIPCHK(hipFree(d->d_dot2));
                             d->d_dot2 = nullptr;
@@ -776,6 +833,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         d->stripC.colStart = (const int32_t *)(b + sM.cs); d->stripC.colCount = (const int32_t *)(b + sM.cc);
                         d->stripC.rows = (const SwsStripRow *)(b + sM.rows);
                         d->stripC.hT2 = (const int16_t *)(b + ohc); d->stripC.vT2 = nullptr;
+                        if (altC) { d->stripCs.colStart = (const int32_t *)(b + sCs.cs); d->stripCs.colCount = (const int32_t *)(b + sCs.cc);
+                                    d->stripCs.rows = d->stripC.rows; d->stripCs.hT2 = d->stripC.hT2; d->stripCs.vT2 = nullptr; d->stripCs.hT8 = (const int16_t *)(b + sCs.rows); d->stripCs_ok = true; }
                         d->mixed_ok = true;
                     }
                 } else
@@ -824,6 +883,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 {
                   const bool tiles = !gray_both && !long_form && plan2(c->hLum, c->vLum, p.dstW, p.dstH, 1, d->dotL, oL) && plan2(c->hChr, c->vChr, p.chrDstW, p.chrDstH, 2, d->dotC, oC);
                   size_t ohl = 0, ohc = 0;
+                  const bool altL = strip_plan && !long_form && plan3_alt(c->hLum, c->vLum, p.dstW, 1, d->stripL, d->stripLs, sLs);
+                  const bool altC = strip_plan && !long_form && !gray_both && plan3_alt(c->hChr, c->vChr, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
                   if (!tiles && strip_plan) {   // (the strip kernel shares the tile kernel's padded horizontal taps; without a tile plan it gets its own copy)
                       const std::vector<int16_t> htl = padded(c->hLum, long_form ? d->stripL.hfs2 : 0), htc = gray_both ? std::vector<int16_t>(2, 0) : padded(c->hChr, long_form ? d->stripC.hfs2 : 0);
                       ohl = put(htl.data(), htl.size() * 2); ohc = put(htc.data(), htc.size() * 2);
@@ -851,6 +912,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         if (tiles) { d->stripL.hT2 = d->dotL.hT2; d->stripL.vT2 = d->dotL.vT2; d->stripC.hT2 = d->dotC.hT2; d->stripC.vT2 = d->dotC.vT2; }
                         else { d->stripL.hT2 = (const int16_t *)(b + ohl); d->stripC.hT2 = (const int16_t *)(b + ohc); d->stripL.vT2 = d->stripC.vT2 = nullptr; }
                         d->stripL.rows = (const SwsStripRow *)(b + sL.rows); if (!gray_both) d->stripC.rows = (const SwsStripRow *)(b + sC.rows);
+                        if (altL) { d->stripLs.colStart = (const int32_t *)(b + sLs.cs); d->stripLs.colCount = (const int32_t *)(b + sLs.cc);
+                                    d->stripLs.rows = d->stripL.rows; d->stripLs.hT2 = d->stripL.hT2; d->stripLs.vT2 = d->stripL.vT2; d->stripLs.hT8 = (const int16_t *)(b + sLs.rows); d->stripLs_ok = true; }
+                        if (altC) { d->stripCs.colStart = (const int32_t *)(b + sCs.cs); d->stripCs.colCount = (const int32_t *)(b + sCs.cc);
+                                    d->stripCs.rows = d->stripC.rows; d->stripCs.hT2 = d->stripC.hT2; d->stripCs.vT2 = d->stripC.vT2; d->stripCs.hT8 = (const int16_t *)(b + sCs.rows); d->stripCs_ok = true; }
                         d->strip_ok = true;
                         d->rgbread_on = rgbread;
                         d->alpha_launch = alpha_planar ? 1 : 0;
@@ -1062,6 +1127,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             c->path_name = d->rgbread_on ? "main:rgbread+strip_march" : "main:strip_march";
             c->kernel_name = ((p.srcKind == SRCK_PLANAR16 || d->rgbread_on) && d->stripL.dma_ok && !c->tune.no_strip_dma) ? "sws_k_strip_dma" : "sws_k_strip_march";
             if (d->stripL.nph > 8 || d->stripL.npv > 8) c->kernel_name = d->stripL.nph > 16 ? "sws_k_strip_xlong" : "sws_k_strip_long";   // (filters of 17 .. 32 / 33 .. 62 taps)
+            else if (!c->tune.no_strip_short && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {   // the short family (k_strip2.hip launch_strip_short decides per launch: this is its choice for 16-byte aligned frames)
+                const SwsStripGeom &gs = d->stripLs_ok ? d->stripLs : d->stripL;
+                if (gs.npv <= 6 && gs.nph <= 6 && gs.NCmax / 16 <= 64) c->kernel_name = (gs.dma8_ok && !c->tune.no_strip_dma8) ? "sws_k_strip_dma8" : "sws_k_strip_short";
+            }
         } else if (d->dot2_ok) {
             c->path_name = "main:fused_tile_dot2"; c->kernel_name = "sws_k_tile_dot2";
         } else if (d->tile_ok) {
@@ -2514,6 +2583,8 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "layout_ch", &c->tune.layout_ch }, { "no_mixed", &c->tune.no_mixed }, { "no_layout_stream", &c->tune.no_layout_stream }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
         { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
         { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb },
+        { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_dma8_depth", &c->tune.strip_dma8_depth },
+        { "no_strip_short", &c->tune.no_strip_short }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "strip_short_waves", &c->tune.strip_short_waves },
         { "debug", &c->tune.debug },
     };
     for (auto &e : tab)

@@ -135,6 +135,10 @@ struct SwsStripGeom {        // marching strip kernel (kernels_strip.hpp), per p
     int32_t lds_bytes;                    // per block of 4 waves
     int32_t dma_ok, lds_dma_bytes;        // LDS-DMA form (16-bit sources): no source row pair is skipped inside a band; its LDS per block
     int32_t debug;                        // profiling builds only: 1 no h-stage, 2 no v-stage, 4 no stores
+    // LDS-DMA form for 8-bit planar sources (kernels_strip8.hpp): raw byte rows in LDS, the h-stage unpacks byte pairs with v_perm, so windows start at
+    // any byte and the tap rows carry no alignment padding
+    int32_t dma8_ok, nph8, lds_dma8_bytes;   // usable; tap pairs per output column ((taps + 1) / 2); LDS per block of 4 waves
+    const int16_t *hT8;                   // [plane width][2 * nph8] horizontal taps from the filter's own first tap on
 };
 
 struct SwsRgbGroupPlan {    // marching packed-RGB kernel: everything one pair of output rows needs, as scalars (64 bytes)

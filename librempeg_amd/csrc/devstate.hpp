@@ -32,6 +32,8 @@ struct DeviceState {
     bool rgbsrc_ok = false;                                // sws_k_rgbsrc_unity (packed 24 / 32 bpp RGB -> 8-bit 4:2:x YUV of the same size)
     bool mixed_ok = false;                                 // identity luma (streaming plane pass) + strip kernel on the chroma planes only (launch_mixed)
     bool strip_ok = false; SwsStripGeom stripL, stripC;    // sws_k_strip_march (tables live in d_dot2)
+    // the same plan on strips of another width for the short-filter instantiations (k_strip2.hip): own colStart / colCount, everything else shared
+    bool stripLs_ok = false, stripCs_ok = false; SwsStripGeom stripLs, stripCs;
     bool striprgb_ok = false; SwsStripGeom stripRL, stripRC; bool striprgb_long = false;   // sws_k_strip_rgb: scaled planar 8-bit YUV -> 24 / 32 bpp RGB
     void *scratch = nullptr; size_t scratch_bytes = 0;
     void *stage_src = nullptr; size_t stage_src_bytes = 0;
@@ -129,6 +131,7 @@ int  launch_rgbread_strip(const LaunchCtx &L);   // k_strip.hip: scaled packed 2
 void launch_fullchr_rgb(const LaunchCtx &L);   // k_stream.hip
 void launch_stage_planes(const LaunchCtx &L, const int row_bytes[4], const int rows[4], bool in);   // k_stream.hip: src[k] -> dst[k] plane copies, one side 16-byte aligned
 void launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, int64_t offU, int64_t offV, int strideY, int strideC, int64_t offA, int a_pos);   // k_stream.hip
+int  launch_strip_short(const LaunchCtx &L, const SwsStripGeom &g, int H, bool chroma);   // k_strip2.hip: 1 = launched, 0 = not a shape of the short family
 int  launch_strip_luma(const LaunchCtx &L);      // k_strip.hip: the luma launch alone (the alpha plane of a full-chroma RGB destination goes through the luma filters)
 int  launch_striprgb(const LaunchCtx &L);
 int  launch_tile_dot2(const LaunchCtx &L);

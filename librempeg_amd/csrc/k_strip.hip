@@ -91,8 +91,9 @@ int launch_strip_planes(const LaunchCtx &L, int which)
                 else hipLaunchKernelGGL((swsk::sws_k_strip_march_lc<false, 4, 2>), grid, blk, std::max(gl.lds_bytes, gc.lds_bytes), st, fs, p, gl, gc, blocksL);
                 return 0;
             }
-            if (which & 1) launch(d->stripL, p.dstH, false);
-            if (which & 2) launch(d->stripC, p.chrDstH, true);
+            // (8-bit sources with short filters: the short instantiations on the plan's own strip widths, k_strip2.hip)
+            if ((which & 1) && !launch_strip_short(L, d->stripLs_ok ? d->stripLs : d->stripL, p.dstH, false)) launch(d->stripL, p.dstH, false);
+            if ((which & 2) && !launch_strip_short(L, d->stripCs_ok ? d->stripCs : d->stripC, p.chrDstH, true)) launch(d->stripC, p.chrDstH, true);
     return 0;
 }
 

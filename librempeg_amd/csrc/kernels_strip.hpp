@@ -84,7 +84,9 @@ __device__ __forceinline__ void strip_hstage(const StripLds &L, const int (&spd)
         }
 }
 
-template <bool SRC16, bool CHROMA, int COLS, int NPH, int RD = 8>
+// PARTS: 16-byte chunks per lane and staged source row (1: windows of up to 64 chunks -- what 8-bit sources need at ratios up to about 3:1 on 320-column
+// strips; the second chunk's loads, byte expansion and LDS writes are straight-line code that costs the same whether any lane uses them or not)
+template <bool SRC16, bool CHROMA, int COLS, int NPH, int RD = 8, int PARTS = (CHROMA ? 1 : 2)>
 __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParams &p, const SwsStripGeom &g, int strip, int y0, int y1,
                                            uint8_t *smem, int wib, int lane)
 {
@@ -131,7 +133,7 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
     // window gets an out-of-range offset (the descriptor answers 0 without touching memory) and dumps into the spare LDS chunk.
     const int sbase = cs * (SRC16 ? 2 : 1) + lane * 16;
     // (chroma strips are 128 columns wide and take one chunk per lane: windows of up to 64 chunks, checked on the host)
-    constexpr bool TWO = !CHROMA;
+    constexpr bool TWO = PARTS == 2;
     const int voff0 = lane < chunks ? sbase : 0x7fffffff, voff1 = 64 + lane < chunks ? sbase + 1024 : 0x7fffffff;
     const int slot0 = min(lane, chunks) * (SPC / 2), slot1 = min(64 + lane, chunks) * (SPC / 2);
 
@@ -319,13 +321,13 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
             SWS_SVB(RD)
         } else
         switch (npv) {
-#define SWS_SV(N) case N: \
+#define SWS_SV(N) case N: if constexpr (N <= RD) { \
             _Pragma("unroll") for (int ci = 0; ci < NCOMP; ci++) _Pragma("unroll") for (int c = 0; c < COLS; c++) { \
-                acc[ci][c] = sdot2_first_s(ring[ci][c][RD - N], e.vt[0]); \
-                _Pragma("unroll") for (int k = 1; k < N; k++) acc[ci][c] = sdot2(ring[ci][c][RD - N + k], e.vt[k], acc[ci][c]); } \
+                acc[ci][c] = sdot2_first_s(ring[ci][c][RD - N < 0 ? 0 : RD - N], e.vt[0]); \
+                _Pragma("unroll") for (int k = 1; k < N; k++) acc[ci][c] = sdot2(ring[ci][c][RD - N + k < 0 ? 0 : RD - N + k], e.vt[k], acc[ci][c]); } } \
             break;
         SWS_SV(1) SWS_SV(2) SWS_SV(3) SWS_SV(4) SWS_SV(5) SWS_SV(6) SWS_SV(7)
-        case 8: if constexpr (RD > 8) { SWS_SVB(8) } else { SWS_SVB(RD) } break;
+        case 8: if constexpr (RD > 8) { SWS_SVB(8) } else if constexpr (RD == 8) { SWS_SVB(RD) } break;
         case 9: if constexpr (RD > 8) { SWS_SVB(9) } break;
         case 10: if constexpr (RD > 8) { SWS_SVB(10) } break;
         case 11: if constexpr (RD > 8) { SWS_SVB(11) } break;
