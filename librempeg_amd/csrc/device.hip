@@ -747,7 +747,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 // windows of at most 64 chunks): 3 .. 5 luma / 1 .. 3 chroma columns per lane, whichever leaves the fewest idle lane-columns in the last
                 // strip (640 columns: 2 strips of 320 instead of 2.5 of 256); only colStart / colCount differ from the base plan
                 auto plan3_alt = [&](const FilterBank &hb, const FilterBank &vb, int W, int ncomp, const SwsStripGeom &base, SwsStripGeom &alt, SOff &o) -> bool {
-                    if (c->tune.no_strip_short || SPC != 16 || (p.srcKind != SRCK_PLANAR8 && p.srcKind != SRCK_NV12) || base.npv > 6 || base.nph > 6) return false;
+                    if (c->tune.no_strip_short || SPC != 16 || (p.srcKind != SRCK_PLANAR8 && p.srcKind != SRCK_NV12) || base.npv > 8 || base.nph > 7) return false;
                     const int hf2 = fs2(hb.size);
                     int best = 0; int64_t best_cost = INT64_MAX;
                     std::vector<int32_t> bcs, bcc; int bnc = 0;
@@ -859,6 +859,23 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         gl.NCmax / SPC <= 64 && gc.NCmax / SPC <= 64 && std::max(gl.nph, gc.nph) <= 8 && gl.npv <= 8 && gc.npv <= 8 && p.chrDstH == p.dstH) {
                         const std::vector<int16_t> htl = padded(c->hLum), htc = padded(c->hChr);
                         const size_t ohl = put(htl.data(), htl.size() * 2), ohc = put(htc.data(), htc.size() * 2);
+                        // LDS-DMA form (kernels_striprgb.hpp sws_k_strip_rgb8): 8-bit planar sources, no source row pair skipped in either plane class;
+                        // its tap rows start at the filter's own first tap (no even-position padding)
+                        auto dma8_plan = [&](const FilterBank &hb, const FilterBank &vb, SwsStripGeom &g, size_t &off) {
+                            g.nph8 = (hb.size + 1) / 2;
+                            g.dma8_ok = !c->tune.no_strip_dma8 && p.srcKind == SRCK_PLANAR8 && !rgb_s16 && g.nph8 <= 6;
+                            for (int y = 1; y < vb.count && g.dma8_ok; y++)
+                                if (((vb.pos[y] & ~1) >> 1) > ((vb.pos[y - 1] & ~1) >> 1) + g.npv) g.dma8_ok = 0;
+                            if (!g.dma8_ok) return;
+                            const int f8 = 2 * g.nph8;
+                            std::vector<int16_t> t8((size_t)hb.count * f8, 0);
+                            for (int i = 0; i < hb.count; i++)
+                                for (int j = 0; j < hb.size; j++) t8[(size_t)i * f8 + j] = hb.taps[(size_t)i * hb.size + j];
+                            off = put(t8.data(), t8.size() * 2);
+                        };
+                        size_t o8l = 0, o8c = 0;
+                        dma8_plan(c->hLum, c->vLum, gl, o8l); dma8_plan(c->hChr, c->vChr, gc, o8c);
+                        if (!gl.dma8_ok || !gc.dma8_ok) gl.dma8_ok = gc.dma8_ok = 0;
                         if (blob.size() > d->dot2_bytes) {
                             if (d->d_dot2) HIPCHK(hipFree(d->d_dot2));
                             d->d_dot2 = nullptr;
@@ -870,6 +887,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         gl.colStart = (const int32_t *)(b + rL.cs); gl.colCount = (const int32_t *)(b + rL.cc); gl.rows = (const SwsStripRow *)(b + rL.rows);
                         gc.colStart = (const int32_t *)(b + rC.cs); gc.colCount = (const int32_t *)(b + rC.cc); gc.rows = (const SwsStripRow *)(b + rC.rows);
                         gl.hT2 = (const int16_t *)(b + ohl); gc.hT2 = (const int16_t *)(b + ohc); gl.vT2 = gc.vT2 = nullptr;
+                        if (gl.dma8_ok) { gl.hT8 = (const int16_t *)(b + o8l); gc.hT8 = (const int16_t *)(b + o8c); }
                         gl.nph = gc.nph = std::max(gl.nph, gc.nph);      // one instantiation: the shorter tap rows are zero-extended in the kernel
                         if (wantA) {
                             d->stripL.colStart = (const int32_t *)(b + sA.cs); d->stripL.colCount = (const int32_t *)(b + sA.cc); d->stripL.rows = (const SwsStripRow *)(b + sA.rows);
@@ -1120,7 +1138,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         } else if (d->rgb444_ok) {
             c->path_name = "main:rgb_yuv444_unity"; c->kernel_name = "sws_k_rgb_yuv444_unity";
         } else if (d->striprgb_ok) {
-            c->path_name = "main:strip_rgb"; c->kernel_name = "sws_k_strip_rgb";
+            c->path_name = "main:strip_rgb"; c->kernel_name = (d->stripRL.dma8_ok && !c->tune.no_strip_dma8) ? "sws_k_strip_rgb8" : "sws_k_strip_rgb";
         } else if (d->mixed_ok) {
             c->path_name = "main:plane1+strip_chroma"; c->kernel_name = "sws_k_strip_march";
         } else if (d->strip_ok) {
@@ -1129,7 +1147,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             if (d->stripL.nph > 8 || d->stripL.npv > 8) c->kernel_name = d->stripL.nph > 16 ? "sws_k_strip_xlong" : "sws_k_strip_long";   // (filters of 17 .. 32 / 33 .. 62 taps)
             else if (!c->tune.no_strip_short && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {   // the short family (k_strip2.hip launch_strip_short decides per launch: this is its choice for 16-byte aligned frames)
                 const SwsStripGeom &gs = d->stripLs_ok ? d->stripLs : d->stripL;
-                if (gs.npv <= 6 && gs.nph <= 6 && gs.NCmax / 16 <= 64) c->kernel_name = (gs.dma8_ok && !c->tune.no_strip_dma8) ? "sws_k_strip_dma8" : "sws_k_strip_short";
+                const bool d8 = gs.dma8_ok && !c->tune.no_strip_dma8;
+                if (gs.NCmax / 16 <= 64 && (d8 ? gs.npv <= 8 && gs.nph8 <= 6 : gs.npv <= 6 && gs.nph <= 6)) c->kernel_name = d8 ? "sws_k_strip_dma8" : "sws_k_strip_short";
             }
         } else if (d->dot2_ok) {
             c->path_name = "main:fused_tile_dot2"; c->kernel_name = "sws_k_tile_dot2";

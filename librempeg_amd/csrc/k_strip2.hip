@@ -77,7 +77,7 @@ static StripShortFn dma8_fn_nph(int nph)
 template <bool CH, int K>
 static StripShortFn dma8_fn_rd(int rd, int nph)
 {
-    return rd == 3 ? dma8_fn_nph<CH, K, 3>(nph) : rd == 4 ? dma8_fn_nph<CH, K, 4>(nph) : dma8_fn_nph<CH, K, 6>(nph);
+    return rd == 3 ? dma8_fn_nph<CH, K, 3>(nph) : rd == 4 ? dma8_fn_nph<CH, K, 4>(nph) : rd == 6 ? dma8_fn_nph<CH, K, 6>(nph) : dma8_fn_nph<CH, K, 8>(nph);
 }
 
 // resident waves per SIMD of a kernel at its LDS size (asked once per kernel and device)
@@ -104,12 +104,13 @@ int launch_strip_short(const LaunchCtx &L, const SwsStripGeom &g0, int H, bool c
     if (c->tune.no_strip_short) return 0;
     if (p.srcKind != SRCK_PLANAR8 && p.srcKind != SRCK_NV12) return 0;
     const int cols = g0.TW / 64;
-    if (g0.npv > 6 || g0.nph > 6 || g0.NCmax / 16 > 64) return 0;
     const bool dma8 = g0.dma8_ok && g0.hT8 && L.vec && !c->tune.no_strip_dma8 && p.srcKind == SRCK_PLANAR8;
+    // (the register-staged short instantiations stop at 6 tap pairs each way; the LDS-DMA form takes vertical filters of up to 8 row pairs: Lanczos at 2:1)
+    if (g0.npv > (dma8 ? 8 : 6) || (dma8 ? g0.nph8 : g0.nph) > 6 || g0.NCmax / 16 > 64) return 0;
     // (the LDS-DMA form needs fewer registers per column: strips of up to 448 luma / 320 chroma columns)
     if (dma8 ? (chroma ? (cols < 1 || cols > 5) : (cols < 3 || cols > 7)) : (chroma ? (cols < 1 || cols > 3) : (cols < 3 || cols > 5))) return 0;
     SwsStripGeom g = g0;
-    const int rd = g.npv <= 3 ? 3 : g.npv <= 4 ? 4 : 6;
+    const int rd = g.npv <= 3 ? 3 : g.npv <= 4 ? 4 : g.npv <= 6 ? 6 : 8;
     StripShortFn fn;
     int lds = (dma8 ? g.lds_dma8_bytes : g.lds_bytes) + (c->tune.strip_dma8_depth > 0 ? c->tune.strip_dma8_depth * 1024 : 0);
     if (dma8) {

@@ -47,6 +47,21 @@ int SRGB_CAT(launch_striprgb_b, SRGB_BPP, SRGB_RL)(const LaunchCtx &L)
     const int wave_dw = 2 * ((gl.NCmax + spc) >> 1) + 4 * ((gc.NCmax + spc) >> 1) + 32 * cl;   // luma rows, chroma rows, exchange row
     const dim3 grid(cdiv((int64_t)gl.strips * gl.bands, 4), 1, n), blk(256);
     const int rc = gc.npv <= 1 ? 1 : gc.npv <= 3 ? 3 : 8;     // chroma ring depth of the instantiation (device.hip laid the taps out for it)
+    // LDS-DMA form (sws_k_strip_rgb8): byte rows in rings of 4 row pairs per plane class, on 16-byte aligned frames
+    if (!s16 && cl == 4 && gl.dma8_ok && gc.dma8_ok && gl.hT8 && gc.hT8 && L.vec && !c->tune.no_strip_dma8) {
+        const int wave8 = SWS_RGB8_DEPTH * 2 * ((gl.NCmax + 16) >> 2) + SWS_RGB8_DEPTH * 4 * ((gc.NCmax + 16) >> 2) + 32 * cl;
+        const size_t lds8 = (size_t)4 * wave8 * 4 + (c->tune.strip_dma8_depth > 0 ? (size_t)c->tune.strip_dma8_depth * 1024 : 0);
+        const int nph8 = std::max(gl.nph8, gc.nph8);
+        if (lds8 <= 60 * 1024 && nph8 <= 6) {
+#define SWS_SR8(RC, N) hipLaunchKernelGGL((swsk::sws_k_strip_rgb8<SRGB_BPP, SRGB_RL, RC, N, 4>), grid, blk, lds8, st, fs, p, gl, gc, wave8)
+#define SWS_SR8N(RC) switch (nph8) { case 1: SWS_SR8(RC, 1); break; case 2: SWS_SR8(RC, 2); break; case 3: SWS_SR8(RC, 3); break; case 4: SWS_SR8(RC, 4); break; \
+                                     case 5: SWS_SR8(RC, 5); break; default: SWS_SR8(RC, 6); break; }
+            if (rc == 1) SWS_SR8N(1) else if (rc == 3) SWS_SR8N(3) else SWS_SR8N(8)
+#undef SWS_SR8N
+#undef SWS_SR8
+            return 0;
+        }
+    }
 #define SWS_SR(RC, N) do { if (s16) hipLaunchKernelGGL((swsk::sws_k_strip_rgb<SRGB_BPP, SRGB_RL, RC, N, 2, true>), grid, blk, (size_t)4 * wave_dw * 4, st, fs, p, gl, gc, wave_dw); \
                            else if (cl == 4) hipLaunchKernelGGL((swsk::sws_k_strip_rgb<SRGB_BPP, SRGB_RL, RC, N, 4>), grid, blk, (size_t)4 * wave_dw * 4, st, fs, p, gl, gc, wave_dw); \
                            else hipLaunchKernelGGL((swsk::sws_k_strip_rgb<SRGB_BPP, SRGB_RL, RC, N, 2>), grid, blk, (size_t)4 * wave_dw * 4, st, fs, p, gl, gc, wave_dw); } while (0)

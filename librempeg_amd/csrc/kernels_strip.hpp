@@ -544,11 +544,7 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
                 if (PARTS == 2 && nparts == 2) strip_dma16(dst + 1024u, voff + 1024, rs[ci], soff, m1lo, m1hi);
             }
     };
-    auto wait_pair = [&]() {                                   // at most (D - 1) * P operations outstanding
-        if (NCOMP * 2 * nparts == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    };
-    static_assert(D == 4, "the wait immediates above are (D - 1) * P for D = 4");
+    static_assert(D == 4, "the wait immediates below are (D - 1) * P for D = 4");
 
     // ---- destination descriptors and per-lane offsets (columns beyond the plane get an out-of-range offset) ----
     const bool semi = CHROMA && (p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010);
@@ -580,6 +576,12 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
 #pragma unroll
             for (int k = 0; k < RD; k++) ring[ci][c][k] = 0;
 
+    // at most (D - 1) * P operations outstanding.  (Only the younger LOADS bound the wait: stores are acknowledged independently of the loads, so
+    // allowing for the stores issued behind the request as well -- tried in round 4 -- lets the wait pass with pair q still in flight.)
+    auto wait_pair = [&]() {
+        if (NCOMP * 2 * nparts == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    };
     uint32_t pend[NCOMP][COLS];
     int pend_y = -1;
     auto flush = [&]() {
@@ -623,6 +625,17 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
     StripRowN<RD> e = load_strip_row_n<RD>(rows, y0);
     int qnext = e.pf;                                          // next source-row pair to h-scale
     int qdma = qnext;                                          // next pair to request
+    // The column state above came through vector loads the COMPILER counts; the DMA requests below are asm statements it does not see.  Its own
+    // `s_waitcnt vmcnt(n)` for those loads allows for the n operations it knows to be younger (none today: it drains everything) -- with the unseen requests
+    // in between, "at most n outstanding" would no longer imply that the loads have returned.  So they are consumed HERE, before the first request:
+    // the empty asm reads every loaded register, which makes the compiler wait for them while its count is still exact.
+#pragma unroll
+    for (int c = 0; c < COLS; c++) {
+        asm volatile("" : "+v"(spd[c]));
+#pragma unroll
+        for (int k = 0; k < NPH; k++) asm volatile("" : "+v"(ht[c][k]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < D; i++) dma(qdma++);
     const int bits = p.dst_bits;

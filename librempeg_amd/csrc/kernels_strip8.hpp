@@ -80,12 +80,13 @@ __device__ __forceinline__ void strip_body_dma8(const FrameRegs &f, const SwsDev
             for (int r = 0; r < 2; r++)
                 strip_dma16(slot + (uint32_t)((ci * 2 + r) * row_dw) * 4u, voff, rs[ci], (r ? r1 : r0) * sst[ci], m0lo, m0hi);
     };
-    auto wait_pair = [&]() {                                   // at most (D - 1) * P operations outstanding
-        if (NCOMP == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    };
-    static_assert(D == 4, "the wait immediates above are (D - 1) * P for D = 4");
-
+    // vmcnt counts the wave's loads AND stores, and only loads return in order among themselves (stores are acknowledged independently): the one safe
+    // bound is the younger LOADS -- if pair q were outstanding so would the (D - 1) * P requests behind it, hence "at most (D - 1) * P operations
+    // outstanding" implies that q has landed, whatever the stores of earlier rows are doing.  (Round 4 tried to allow for the stores issued behind the
+    // request as well, (D - 1) * (P + S): wrong -- with the stores acknowledged early, q and its younger requests alone stay below that bound; the
+    // band-start rows of a 6:1 conversion showed it.)
+    constexpr int P = NCOMP * 2;
+    auto wait_pair = [&]() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * P) : "memory"); };
     // ---- destination descriptors and per-lane offsets (columns beyond the plane get an out-of-range offset) ----
     const bool semi = CHROMA && (p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010);
     const bool d8 = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_NV12;
@@ -159,6 +160,17 @@ __device__ __forceinline__ void strip_body_dma8(const FrameRegs &f, const SwsDev
     StripRowN<RD> e = load_strip_row_n<RD>(rows, y0);
     int qnext = e.pf;                                          // next source-row pair to h-scale
     int qdma = qnext;                                          // next pair to request
+    // The column state above came through vector loads the COMPILER counts; the DMA requests below are asm statements it does not see.  Its own
+    // `s_waitcnt vmcnt(n)` for those loads allows for the n operations it knows to be younger (none today: it drains everything) -- with the unseen requests
+    // in between, "at most n outstanding" would no longer imply that the loads have returned.  So they are consumed HERE, before the first request:
+    // the empty asm reads every loaded register, which makes the compiler wait for them while its count is still exact.
+#pragma unroll
+    for (int c = 0; c < COLS; c++) {
+        asm volatile("" : "+v"(spd[c]), "+v"(sel0[c]), "+v"(sel1[c]));
+#pragma unroll
+        for (int k = 0; k < NPH; k++) asm volatile("" : "+v"(ht[c][k]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < D; i++) dma(qdma++);
     const int bits = p.dst_bits;
@@ -219,7 +231,7 @@ __device__ __forceinline__ void strip_body_dma8(const FrameRegs &f, const SwsDev
                 acc[ci][c] = sdot2_first_s(ring[ci][c][RD - N < 0 ? 0 : RD - N], e.vt[0]); \
                 _Pragma("unroll") for (int k = 1; k < N; k++) acc[ci][c] = sdot2(ring[ci][c][RD - N + k < 0 ? 0 : RD - N + k], e.vt[k], acc[ci][c]); } } \
             break;
-        SWS_SV8(1) SWS_SV8(2) SWS_SV8(3) SWS_SV8(4) SWS_SV8(5)
+        SWS_SV8(1) SWS_SV8(2) SWS_SV8(3) SWS_SV8(4) SWS_SV8(5) SWS_SV8(6) SWS_SV8(7)
 #undef SWS_SV8
         default:
 #pragma unroll

@@ -269,6 +269,269 @@ __device__ __forceinline__ void strip_rgb_body(const FrameRegs &f, const SwsDevP
     flush();
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-DMA form for 8-bit planar sources (round 4; kernels_strip8.hpp describes the planar twin): the raw bytes of a source row's window go
+// HBM -> LDS with one `buffer_load_dwordx4 ... lds` per row into a ring of D = 4 row pairs per plane class, the horizontal stage unpacks byte
+// pairs with v_perm_b32 while it reads (windows start at any byte: tap rows without alignment padding -- bicubic at 2:1 is 4 tap pairs, not 5).
+// Gone: the staging registers (24 VGPRs), 8 v_perm + 2 ds_write_b128 per staged row, and the single row pair in flight per plane.
+// Both plane classes share the one in-order vmcnt counter.  Before plane X reads its pair q it waits for `vmcnt((D - 1) * P_X)` (P_X = DMA
+// instructions per pair of X): when q is due, the D - 1 later pairs of X have been requested after it, whatever the other plane requested in
+// between, so "at most (D - 1) * P_X operations outstanding" implies q has landed (requests return in order; stores only make the wait longer).
+// ------------------------------------------------------------------------------------------
+#ifndef SWS_RGB8_DEPTH
+#define SWS_RGB8_DEPTH 2   // row pairs per plane class in the LDS ring (a power of two)
+#endif
+template <int NCOMP, int COLS, int NPH, int RD>
+struct StripPlane8 {
+    uint32_t *ringS; uint32_t lds_base;
+    int row_dw, pair_dw;
+    int spd[COLS];
+    uint32_t sel0[COLS], sel1[COLS];
+    uint32_t ht[COLS][NPH];
+    i32x4s rs[NCOMP];
+    int sst[NCOMP], sH, voff, qnext, qdma;
+    uint32_t mlo, mhi;
+    uint32_t ring[NCOMP][COLS][RD];
+};
+
+template <int NCOMP, int COLS, int NPH, int RD>
+__device__ __forceinline__ void sp8_dma(StripPlane8<NCOMP, COLS, NPH, RD> &P)     // request the next row pair into its ring slot
+{
+    constexpr int D = SWS_RGB8_DEPTH;
+    const int q = P.qdma++;
+    const int r0 = min(max(2 * q, 0), P.sH - 1), r1 = min(max(2 * q + 1, 0), P.sH - 1);
+    const uint32_t slot = P.lds_base + (uint32_t)((q & (D - 1)) * P.pair_dw) * 4u;
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            strip_dma16(slot + (uint32_t)((ci * 2 + r) * P.row_dw) * 4u, P.voff, P.rs[ci], (r ? r1 : r0) * P.sst[ci], P.mlo, P.mhi);
+}
+
+template <int NCOMP, int COLS, int NPH, int RD>
+__device__ __forceinline__ void sp8_init(StripPlane8<NCOMP, COLS, NPH, RD> &P, const SwsStripGeom &g, int strip, int W, int sH, const int32_t *hpos,
+                                         const uint8_t *const (&sb)[NCOMP], const int (&sst)[NCOMP], uint32_t *lds, int lane)
+{
+    const int xs = strip * g.TW, cs = g.colStart[strip], chunks = g.colCount[strip] / 16;
+    P.row_dw = (g.NCmax + 16) >> 2;        // bytes; one spare chunk: the last column's aligned reads
+    P.pair_dw = NCOMP * 2 * P.row_dw;
+    P.ringS = lds;
+    P.lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds);
+    P.sH = sH;
+    const int nd = g.nph8;                 // dwords per tap row of this plane (the kernel's NPH is the larger of the two planes': zero-extended)
+#pragma unroll
+    for (int c = 0; c < COLS; c++) {
+        const int x = min(xs + 64 * c + lane, W - 1);
+        const int o = hpos[x] - cs;
+        P.spd[c] = o >> 2;
+        const uint32_t b = (uint32_t)(o & 3);
+        P.sel0[c] = 0x0c000c00u | b | ((b + 1) << 16);
+        P.sel1[c] = 0x0c000c00u | (b + 2) | ((b + 3) << 16);
+        const uint32_t *tp = (const uint32_t *)(g.hT8 + (int64_t)x * (2 * nd));
+#pragma unroll
+        for (int k = 0; k < NPH; k++) P.ht[c][k] = k < nd ? tp[k] : 0u;
+    }
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++) {
+        P.sst[ci] = sst[ci];
+        const uint64_t a = uniform_u64((uint64_t)sb[ci]);
+        P.rs[ci][0] = (int)(uint32_t)a; P.rs[ci][1] = (int)(uint32_t)(a >> 32);
+        P.rs[ci][2] = __builtin_amdgcn_readfirstlane((int)((uint32_t)sst[ci] * (uint32_t)sH)); P.rs[ci][3] = 0x00020000;
+    }
+    P.voff = cs + lane * 16;
+    const int n0 = min(chunks, 64);
+    P.mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n0 >= 32 ? 0xffffffffu : ((1u << n0) - 1u)));
+    P.mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n0 >= 64 ? 0xffffffffu : (n0 > 32 ? ((1u << (n0 - 32)) - 1u) : 0u)));
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+        for (int c = 0; c < COLS; c++)
+#pragma unroll
+            for (int k = 0; k < RD; k++) P.ring[ci][c][k] = 0;
+}
+
+// h-scale the oldest requested pair into the ring, release the pending output row, re-request the slot
+template <int NCOMP, int COLS, int NPH, int RD, typename F>
+__device__ __forceinline__ void sp8_step(StripPlane8<NCOMP, COLS, NPH, RD> &P, int sh, int opaque_neg, F &&flush)
+{
+    constexpr int D = SWS_RGB8_DEPTH;
+    constexpr int NDW = (NPH - 1) / 2 + 2;
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * NCOMP * 2) : "memory");     // (D - 1) * P
+    const uint32_t *S = P.ringS + (P.qnext & (D - 1)) * P.pair_dw;
+    uint32_t np[NCOMP][COLS];
+    if (opaque_neg < 0) {      // (never: a basic block of its own for the horizontal stage, see strip_body in kernels_strip.hpp)
+#pragma unroll
+        for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+            for (int c = 0; c < COLS; c++) np[ci][c] = S[(ci * 2) * P.row_dw + P.spd[c]];
+    } else {
+#pragma unroll
+        for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+            for (int c = 0; c < COLS; c++) {
+                const uint32_t *s0 = S + (ci * 2) * P.row_dw + P.spd[c], *s1 = s0 + P.row_dw;
+                uint32_t d0[NDW], d1[NDW];
+#pragma unroll
+                for (int j = 0; j < NDW; j++) { d0[j] = s0[j]; d1[j] = s1[j]; }
+                int a = sdot2_first(__builtin_amdgcn_perm(d0[1], d0[0], P.sel0[c]), P.ht[c][0]);
+                int b = sdot2_first(__builtin_amdgcn_perm(d1[1], d1[0], P.sel0[c]), P.ht[c][0]);
+#pragma unroll
+                for (int k = 1; k < NPH; k++) {
+                    const uint32_t sl = (k & 1) ? P.sel1[c] : P.sel0[c];
+                    a = sdot2(__builtin_amdgcn_perm(d0[(k >> 1) + 1], d0[k >> 1], sl), P.ht[c][k], a);
+                    b = sdot2(__builtin_amdgcn_perm(d1[(k >> 1) + 1], d1[k >> 1], sl), P.ht[c][k], b);
+                }
+                np[ci][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(a >> sh, b >> sh));
+            }
+    }
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+        for (int c = 0; c < COLS; c++) {
+#pragma unroll
+            for (int k = 0; k < RD - 1; k++) P.ring[ci][c][k] = P.ring[ci][c][k + 1];
+            P.ring[ci][c][RD - 1] = np[ci][c];
+        }
+    P.qnext++;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot's reads have returned: it may be requested again
+    __builtin_amdgcn_wave_barrier();
+    flush();
+    sp8_dma(P);
+}
+
+template <int NCOMP, int COLS, int NPH, int RD>
+__device__ __forceinline__ void sp8_vstage(const StripPlane8<NCOMP, COLS, NPH, RD> &P, const SwsStripRow &e, int (&acc)[NCOMP][COLS])
+{
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+        for (int c = 0; c < COLS; c++) {
+            acc[ci][c] = sdot2_first_s(P.ring[ci][c][0], e.vt[0]);
+#pragma unroll
+            for (int k = 1; k < RD; k++) acc[ci][c] = sdot2(P.ring[ci][c][k], e.vt[k], acc[ci][c]);
+        }
+}
+
+template <int BPP, int NPH, int RL, int RC, int CL>
+__device__ __forceinline__ void strip_rgb8_body(const FrameRegs &f, const SwsDevParams &p, const SwsStripGeom &gl, const SwsStripGeom &gc,
+                                                int strip, int y0, int y1, uint32_t *lds, const LutTabs &T, int lane)
+{
+    constexpr int D = SWS_RGB8_DEPTH;
+    const int W = p.dstW, H = p.dstH;
+    constexpr int CC = CL / 2;
+    StripPlane8<1, CL, NPH, RL> PL;
+    StripPlane8<2, CC, NPH, RC> PC;
+    const int ldw = (gl.NCmax + 16) >> 2, cdw = (gc.NCmax + 16) >> 2;
+    uint32_t *ldsL = lds, *ldsC = lds + D * 2 * ldw, *ldsX = ldsC + D * 4 * cdw;       // luma ring, chroma ring, 64 * CL x int16 exchange row
+    {
+        const uint8_t *const sb[1] = { f.src[0] };
+        const int st[1] = { f.srcStride[0] };
+        sp8_init(PL, gl, strip, W, p.srcH, p.hLumPos, sb, st, ldsL, lane);
+    }
+    {
+        const bool u1 = p.u_plane_src == 1;
+        const uint8_t *const sb[2] = { u1 ? f.src[1] : f.src[2], u1 ? f.src[2] : f.src[1] };
+        const int st[2] = { u1 ? f.srcStride[1] : f.srcStride[2], u1 ? f.srcStride[2] : f.srcStride[1] };
+        sp8_init(PC, gc, strip, p.chrDstW, p.chrSrcH, p.hChrPos, sb, st, ldsC, lane);
+    }
+    const sws_rsrc_t rd = make_rsrc(f.dst[0], (uint32_t)f.dstStride[0] * (uint32_t)(H - 1) + (uint32_t)W * (uint32_t)BPP);
+    const int dstr = f.dstStride[0];
+    int doff[CC];
+#pragma unroll
+    for (int c = 0; c < CC; c++) {
+        const int x = strip * (64 * CL) + 2 * (64 * c + lane);
+        doff[c] = x < W ? x * BPP : 0x7fffffff;
+    }
+    uint32_t pend[CC][2];
+    int pend_y = -1;
+    auto flush = [&]() {
+        if (pend_y >= 0) {
+            const int ro = pend_y * dstr;
+#pragma unroll
+            for (int c = 0; c < CC; c++) {
+                if constexpr (BPP == 4) {
+                    u32x2 v = { pend[c][0], pend[c][1] };
+                    __builtin_amdgcn_raw_buffer_store_b64(v, rd, doff[c], ro, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(pend[c][0], rd, doff[c], ro, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)pend[c][1], rd, doff[c] + 4, ro, 0);
+                }
+            }
+            pend_y = -1;
+        }
+    };
+
+    const SwsStripRow *rowsL = gl.rows, *rowsC = gc.rows;
+    const int npvL = gl.npv, npvC = gc.npv, sh = p.hshift;
+    const bool swap_rb = BPP == 4 ? p.lut.swap_rb32 != 0 : p.lut.rgb_order != 0;
+    SwsStripRow el = load_strip_row(rowsL, y0), ec = load_strip_row(rowsC, y0);
+    PL.qnext = PL.qdma = el.pf; PC.qnext = PC.qdma = ec.pf;
+    // (the column state came through vector loads the compiler counts, the requests below are asm statements it does not see: everything loaded so far
+    //  is consumed here, while the compiler's own vmcnt arithmetic is still exact -- kernels_strip8.hpp)
+#pragma unroll
+    for (int c = 0; c < CL; c++) { asm volatile("" : "+v"(PL.spd[c]), "+v"(PL.sel0[c]), "+v"(PL.sel1[c]));
+#pragma unroll
+        for (int k = 0; k < NPH; k++) asm volatile("" : "+v"(PL.ht[c][k])); }
+#pragma unroll
+    for (int c = 0; c < CC; c++) { asm volatile("" : "+v"(PC.spd[c]), "+v"(PC.sel0[c]), "+v"(PC.sel1[c]));
+#pragma unroll
+        for (int k = 0; k < NPH; k++) asm volatile("" : "+v"(PC.ht[c][k])); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < D; i++) sp8_dma(PL);
+#pragma unroll
+    for (int i = 0; i < D; i++) sp8_dma(PC);
+    for (int y = y0; y < y1; y++) {
+        const int yn = min(y + 1, H - 1);
+        const SwsStripRow eln = load_strip_row(rowsL, yn), ecn = load_strip_row(rowsC, yn);
+        while (PL.qnext <= el.pf + npvL - 1) sp8_step(PL, sh, gl.hfs2, flush);
+        while (PC.qnext <= ec.pf + npvC - 1) sp8_step(PC, sh, gc.hfs2, flush);
+        flush();
+        int aL[1][CL], aC[2][CC];
+        sp8_vstage(PL, el, aL);
+        sp8_vstage(PC, ec, aC);
+        int16_t *X = (int16_t *)ldsX;
+#pragma unroll
+        for (int c = 0; c < CL; c++) X[64 * c + lane] = (int16_t)((aL[0][c] + (1 << 18)) >> 19);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int c = 0; c < CC; c++) {
+            const uint32_t yy = ((const uint32_t *)ldsX)[64 * c + lane];
+            const int Y1 = (int)(int16_t)(yy & 0xFFFFu), Y2 = (int)yy >> 16;
+            const int U = (aC[0][c] + (1 << 18)) >> 19, V = (aC[1][c] + (1 << 18)) >> 19;
+            lut_pair<BPP>(p.lut, T, swap_rb, Y1, Y2, U, V, pend[c]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the exchange row is rewritten by the next output row
+        __builtin_amdgcn_wave_barrier();
+        pend_y = y;
+        el = eln; ec = ecn;
+    }
+    flush();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA write may land after the wave has given up its LDS
+}
+
+template <int BPP, int RL, int RC, int NPH, int CL>
+__global__ void __launch_bounds__(256) sws_k_strip_rgb8(SwsFrameSet fs, SwsDevParams p, SwsStripGeom gl, SwsStripGeom gc, int wave_lds_dw)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ __attribute__((aligned(16))) u32x2 lds_tab[2][256];
+    build_lut_tabs(p.lut, lds_tab[0], lds_tab[1], (int)threadIdx.x);
+    __syncthreads();
+    const LutTabs T = { (const uint8_t *)lds_tab[0], (const uint8_t *)lds_tab[1] };
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wid = blockIdx.x * 4 + wib;
+    if (wid >= gl.strips * gl.bands) return;
+    const int strip = wid % gl.strips, band = wid / gl.strips;
+    const int y0 = band * gl.band_rows, y1 = min(p.dstH, y0 + gl.band_rows);
+    if (y0 >= y1) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    uint32_t *lds = (uint32_t *)smem + wib * wave_lds_dw;
+    strip_rgb8_body<BPP, NPH, RL, RC, CL>(f, p, gl, gc, strip, y0, y1, lds, T, lane);
+}
+
 // RL / RC: ring depths (row pairs) of the luma / chroma plane = the vertical tap pairs the kernel multiplies per output sample
 #ifndef SWS_SRGB_ATTR
 #define SWS_SRGB_ATTR

@@ -18,6 +18,32 @@ BX = SWS_BITEXACT
 AR = SWS_ACCURATE_RND
 
 
+def _forensics(p, out, ref, src_frame, dst_frame, hs, prefill):
+    """what a parity failure looks like (the rare unreproduced failures): per plane how many bytes differ and whether the wrong bytes are
+    zeros or still the prefill; whether a second read of the same destination gives other bytes (a late writer); whether the source the GPU holds
+    still equals what was uploaded; whether running the same context again gives the right answer."""
+    try:
+        info = []
+        for i, (a, b) in enumerate(zip(out.planes, ref.planes)):
+            rb = out.row_bytes[i]
+            d = a[:, :rb] != b[:, :rb]
+            info.append(f"plane{i}: {int(d.sum())}/{d.size} differ, zeros {int((a[:, :rb][d] == 0).sum())}, prefill {int((a[:, :rb][d] == prefill).sum())}")
+        if isinstance(dst_frame, DeviceFrame):
+            again = dst_frame.download()
+            info.append("second read equals first: " + str(all(np.array_equal(x[:, :r], y[:, :r]) for x, y, r in zip(again.planes, out.planes, out.row_bytes))))
+            back = src_frame.download()
+            info.append("source on the GPU intact: " + str(all(np.array_equal(x[:, :r], y[:, :r]) for x, y, r in zip(back.planes, hs.planes, back.row_bytes))))
+            dst_frame.buf.fill_(prefill)
+            import torch
+            torch.cuda.synchronize()
+            p.scale(src_frame, dst_frame); p.sync()
+            rerun = dst_frame.download()
+            info.append("rerun on the same context equals the oracle: " + str(all(np.array_equal(x[:, :r], y[:, :r]) for x, y, r in zip(rerun.planes, ref.planes, rerun.row_bytes))))
+        return " || forensics: " + "; ".join(info)
+    except Exception as e:   # never mask the original failure
+        return f" || forensics failed: {e!r}"
+
+
 def run_case(sw, sh, sfmt, dw, dh, dfmt, flags, seed=1, colorspace=None, device_frames=True, prefill=0xA5, opts=None, tune=None):
     o = OL.Oracle(sw, sh, sfmt, dw, dh, dfmt, flags, **(opts or {}))
     p = SwsContext(sw, sh, sfmt, dw, dh, dfmt, flags, **(opts or {}))
@@ -60,7 +86,8 @@ def run_case(sw, sh, sfmt, dw, dh, dfmt, flags, seed=1, colorspace=None, device_
             bad = np.argwhere(a[:, :rb] != b[:, :rb])
             y, x = bad[0]
             raise AssertionError(f"{sfmt}->{dfmt} {sw}x{sh}->{dw}x{dh} flags={flags:#x} path={p.path()} plane {i}: "
-                                 f"{len(bad)} bytes differ, first at row {y} byte {x}: got {a[y, x]} want {b[y, x]}")
+                                 f"{len(bad)} bytes differ, first at row {y} byte {x}: got {a[y, x]} want {b[y, x]}"
+                                 + _forensics(p, out, ref, ds if device_frames else hs, dd if device_frames else hd, hs, prefill))
     return p.path(), o.path()
 
 
