@@ -753,10 +753,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     std::vector<int32_t> bcs, bcc; int bnc = 0;
                     const int forced = ncomp == 2 ? c->tune.strip_cols_c : c->tune.strip_cols_l;
                     // (the LDS-DMA form -- planar sources, no skipped row pair -- needs fewer registers per column and takes wider strips)
-                    bool dma8 = !c->tune.no_strip_dma8 && p.srcKind == SRCK_PLANAR8 && (hb.size + 1) / 2 <= 6;
+                    const bool nvc = ncomp == 2 && p.srcKind == SRCK_NV12;      // interleaved chroma bytes: two bytes per sample in the DMA'd rows
+                    bool dma8 = !c->tune.no_strip_dma8 && (hb.size + 1) / 2 <= 6;
                     for (int y = 1; y < vb.count && dma8; y++)
                         if (((vb.pos[y] & ~1) >> 1) > ((vb.pos[y - 1] & ~1) >> 1) + base.npv) dma8 = false;
-                    const std::vector<int> cand = dma8 ? (ncomp == 2 ? std::vector<int>{ 5, 4, 3, 2, 1 } : std::vector<int>{ 7, 6, 5, 4, 3 })
+                    const std::vector<int> cand = dma8 ? (nvc ? std::vector<int>{ 3, 2, 1 } : ncomp == 2 ? std::vector<int>{ 5, 4, 3, 2, 1 } : std::vector<int>{ 7, 6, 5, 4, 3 })
                                                        : (ncomp == 2 ? std::vector<int>{ 3, 2, 1 } : std::vector<int>{ 5, 4, 3 });
                     for (int cols : cand) {
                         if (!c->tune.strip_cols_auto && cols != forced) continue;
@@ -770,7 +771,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                             lo = lo / SPC * SPC;
                             cs[t] = lo; cc[t] = (hi - lo + SPC - 1) / SPC * SPC; ncmax = std::max(ncmax, cc[t]);
                         }
-                        if (!ok || ncmax / SPC > 64) continue;
+                        if (!ok || ncmax / SPC > 64 || (nvc && dma8 && 2 * ncmax / SPC > 64)) continue;
                         // what a launch pays per row: every strip its columns plus a fixed share (staging / requests, plan entry, waits, stores):
                         // about two columns' worth (measured on C1: chroma strips of 64 / 128 / 192 columns, 5 / 3 / 2 per row)
                         const int64_t cost = (int64_t)strips * (2 * cols + 3);
@@ -785,7 +786,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     // interleaved); every pair between the first and the last one a band needs is requested, so no pair may be skipped.  Its tap rows
                     // start at the filter's own first tap (no even-position padding): o.rows carries their offset in the blob
                     alt.nph8 = (hb.size + 1) / 2;
-                    alt.lds_dma8_bytes = 4 * 4 * ncomp * 2 * ((bnc + 16) / 4) * 4;
+                    alt.lds_dma8_bytes = nvc ? 4 * 4 * 2 * ((2 * bnc + 16) / 4) * 4 : 4 * 4 * ncomp * 2 * ((bnc + 16) / 4) * 4;
                     alt.dma8_ok = dma8 && alt.lds_dma8_bytes <= 48 * 1024;
                     if (alt.dma8_ok) {
                         const int f8 = 2 * alt.nph8;

@@ -62,22 +62,22 @@ static StripShortFn short_fn_rd(int rd, int nph)
     return rd == 3 ? short_fn_nph<CH, K, 3>(nph) : rd == 4 ? short_fn_nph<CH, K, 4>(nph) : short_fn_nph<CH, K, 6>(nph);
 }
 
-template <bool CH, int K, int R>
+template <bool CH, int K, int R, bool NV>
 static StripShortFn dma8_fn_nph(int nph)
 {
     switch (nph) {
-    case 1: return swsk::sws_k_strip_dma8<CH, K, 1, R>;
-    case 2: return swsk::sws_k_strip_dma8<CH, K, 2, R>;
-    case 3: return swsk::sws_k_strip_dma8<CH, K, 3, R>;
-    case 4: return swsk::sws_k_strip_dma8<CH, K, 4, R>;
-    case 5: return swsk::sws_k_strip_dma8<CH, K, 5, R>;
-    default: return swsk::sws_k_strip_dma8<CH, K, 6, R>;
+    case 1: return swsk::sws_k_strip_dma8<CH, K, 1, R, NV>;
+    case 2: return swsk::sws_k_strip_dma8<CH, K, 2, R, NV>;
+    case 3: return swsk::sws_k_strip_dma8<CH, K, 3, R, NV>;
+    case 4: return swsk::sws_k_strip_dma8<CH, K, 4, R, NV>;
+    case 5: return swsk::sws_k_strip_dma8<CH, K, 5, R, NV>;
+    default: return swsk::sws_k_strip_dma8<CH, K, 6, R, NV>;
     }
 }
-template <bool CH, int K>
+template <bool CH, int K, bool NV = false>
 static StripShortFn dma8_fn_rd(int rd, int nph)
 {
-    return rd == 3 ? dma8_fn_nph<CH, K, 3>(nph) : rd == 4 ? dma8_fn_nph<CH, K, 4>(nph) : rd == 6 ? dma8_fn_nph<CH, K, 6>(nph) : dma8_fn_nph<CH, K, 8>(nph);
+    return rd == 3 ? dma8_fn_nph<CH, K, 3, NV>(nph) : rd == 4 ? dma8_fn_nph<CH, K, 4, NV>(nph) : rd == 6 ? dma8_fn_nph<CH, K, 6, NV>(nph) : dma8_fn_nph<CH, K, 8, NV>(nph);
 }
 
 // resident waves per SIMD of a kernel at its LDS size (asked once per kernel and device)
@@ -104,7 +104,8 @@ int launch_strip_short(const LaunchCtx &L, const SwsStripGeom &g0, int H, bool c
     if (c->tune.no_strip_short) return 0;
     if (p.srcKind != SRCK_PLANAR8 && p.srcKind != SRCK_NV12) return 0;
     const int cols = g0.TW / 64;
-    const bool dma8 = g0.dma8_ok && g0.hT8 && L.vec && !c->tune.no_strip_dma8 && p.srcKind == SRCK_PLANAR8;
+    const bool nv = chroma && p.srcKind == SRCK_NV12;          // interleaved chroma bytes: the NV instantiations (strips of up to 192 columns: windows of 2 bytes per sample)
+    const bool dma8 = g0.dma8_ok && g0.hT8 && L.vec && !c->tune.no_strip_dma8 && (!nv || cols <= 3);
     // (the register-staged short instantiations stop at 6 tap pairs each way; the LDS-DMA form takes vertical filters of up to 8 row pairs: Lanczos at 2:1)
     if (g0.npv > (dma8 ? 8 : 6) || (dma8 ? g0.nph8 : g0.nph) > 6 || g0.NCmax / 16 > 64) return 0;
     // (the LDS-DMA form needs fewer registers per column: strips of up to 448 luma / 320 chroma columns)
@@ -114,7 +115,8 @@ int launch_strip_short(const LaunchCtx &L, const SwsStripGeom &g0, int H, bool c
     StripShortFn fn;
     int lds = (dma8 ? g.lds_dma8_bytes : g.lds_bytes) + (c->tune.strip_dma8_depth > 0 ? c->tune.strip_dma8_depth * 1024 : 0);
     if (dma8) {
-        if (chroma) fn = cols == 1 ? dma8_fn_rd<true, 1>(rd, g.nph8) : cols == 2 ? dma8_fn_rd<true, 2>(rd, g.nph8) : cols == 3 ? dma8_fn_rd<true, 3>(rd, g.nph8) :
+        if (nv) fn = cols == 1 ? dma8_fn_rd<true, 1, true>(rd, g.nph8) : cols == 2 ? dma8_fn_rd<true, 2, true>(rd, g.nph8) : dma8_fn_rd<true, 3, true>(rd, g.nph8);
+        else if (chroma) fn = cols == 1 ? dma8_fn_rd<true, 1>(rd, g.nph8) : cols == 2 ? dma8_fn_rd<true, 2>(rd, g.nph8) : cols == 3 ? dma8_fn_rd<true, 3>(rd, g.nph8) :
                          cols == 4 ? dma8_fn_rd<true, 4>(rd, g.nph8) : dma8_fn_rd<true, 5>(rd, g.nph8);
         else fn = cols == 3 ? dma8_fn_rd<false, 3>(rd, g.nph8) : cols == 4 ? dma8_fn_rd<false, 4>(rd, g.nph8) : cols == 5 ? dma8_fn_rd<false, 5>(rd, g.nph8) :
                   cols == 6 ? dma8_fn_rd<false, 6>(rd, g.nph8) : dma8_fn_rd<false, 7>(rd, g.nph8);

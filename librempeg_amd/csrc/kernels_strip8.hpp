@@ -21,20 +21,26 @@
 
 namespace swsk {
 
-template <bool CHROMA, int COLS, int NPH, int RD>
+// NV: the chroma planes of a semi-planar source (nv12 / nv21 / nv16 / nv24: nvXXtoUV_c, input.c:926-948) -- ONE plane of interleaved {U, V} byte pairs.
+// Its rows land in LDS as they are (one request per row instead of two planes' worth); sample j of component ci is byte 2 j + ci, so pair k of a
+// window starting at sample o lies in the aligned dwords (k, k + 1) from byte (2 o & ~3) on, with ONE selector per component whatever k is
+// ({r + ci, 0, r + ci + 2, 0}, r = 2 o & 3): both components are unpacked from the same NPH + 1 dwords.
+template <bool CHROMA, int COLS, int NPH, int RD, bool NV = false>
 __device__ __forceinline__ void strip_body_dma8(const FrameRegs &f, const SwsDevParams &p, const SwsStripGeom &g, int strip, int y0, int y1,
                                                 uint8_t *smem, int wib, int lane)
 {
+    static_assert(CHROMA || !NV, "only the chroma planes are interleaved");
     constexpr int NCOMP = CHROMA ? 2 : 1, D = STRIP_DMA_DEPTH;
-    constexpr int NDW = (NPH - 1) / 2 + 2;                    // aligned dwords a column's window can touch
+    constexpr int NSRC = NV ? 1 : NCOMP;                      // source planes = rows requested per row of a pair
+    constexpr int NDW = NV ? NPH + 1 : (NPH - 1) / 2 + 2;     // aligned dwords a column's window can touch
     const int W = CHROMA ? p.chrDstW : p.dstW, H = CHROMA ? p.chrDstH : p.dstH;
     const int sH = CHROMA ? p.chrSrcH : p.srcH;
     const int xs = strip * g.TW;
-    const int cs = g.colStart[strip], chunks = g.colCount[strip] / 16;
+    const int cs = g.colStart[strip], chunks = (NV ? 2 : 1) * g.colCount[strip] / 16;
     const int32_t *hpos = CHROMA ? p.hChrPos : p.hLumPos;
     const int npv = g.npv, sh = p.hshift;
-    const int row_dw = (g.NCmax + 16) >> 2;                   // dwords of a staged row of bytes (one spare chunk: the last column's aligned reads)
-    const int pair_dw = NCOMP * 2 * row_dw;
+    const int row_dw = ((NV ? 2 : 1) * g.NCmax + 16) >> 2;    // dwords of a staged row of bytes (one spare chunk: the last column's aligned reads)
+    const int pair_dw = NSRC * 2 * row_dw;
     uint32_t *ringS = (uint32_t *)smem + wib * (D * pair_dw);
     const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)ringS);
 
@@ -45,29 +51,35 @@ __device__ __forceinline__ void strip_body_dma8(const FrameRegs &f, const SwsDev
 #pragma unroll
     for (int c = 0; c < COLS; c++) {
         const int x = min(xs + 64 * c + lane, W - 1);
-        const int o = hpos[x] - cs;
+        const int o = (NV ? 2 : 1) * (hpos[x] - cs);
         spd[c] = o >> 2;
         const uint32_t b = (uint32_t)(o & 3);
-        sel0[c] = 0x0c000c00u | b | ((b + 1) << 16);          // {byte b, 0, byte b + 1, 0}
-        sel1[c] = 0x0c000c00u | (b + 2) | ((b + 3) << 16);
+        if constexpr (NV) {                                   // sel0 / sel1: the first / second component's bytes of an interleaved pair of pairs
+            const uint32_t b0 = b + (p.uv_swap_src ? 1u : 0u), b1 = b + (p.uv_swap_src ? 0u : 1u);
+            sel0[c] = 0x0c000c00u | b0 | ((b0 + 2) << 16);
+            sel1[c] = 0x0c000c00u | b1 | ((b1 + 2) << 16);
+        } else {
+            sel0[c] = 0x0c000c00u | b | ((b + 1) << 16);      // {byte b, 0, byte b + 1, 0}
+            sel1[c] = 0x0c000c00u | (b + 2) | ((b + 3) << 16);
+        }
         const uint32_t *tp = (const uint32_t *)(g.hT8 + (int64_t)x * (2 * NPH));
 #pragma unroll
         for (int k = 0; k < NPH; k++) ht[c][k] = tp[k];
     }
     // ---- source descriptors (whole rows including their padding), as plain dwords for the asm statements ----
     const bool u1 = p.u_plane_src == 1;
-    i32x4s rs[NCOMP];
-    int sst[NCOMP];
+    i32x4s rs[NSRC];
+    int sst[NSRC];
 #pragma unroll
-    for (int ci = 0; ci < NCOMP; ci++) {
-        const bool first = !CHROMA || ((ci == 0) == u1);
+    for (int ci = 0; ci < NSRC; ci++) {
+        const bool first = !CHROMA || NV || ((ci == 0) == u1);
         const uint8_t *sb = !CHROMA ? f.src[0] : (first ? U(f.src[1]) : U(f.src[2]));
         sst[ci] = !CHROMA ? f.srcStride[0] : (first ? U(f.srcStride[1]) : U(f.srcStride[2]));
         const uint64_t a = uniform_u64((uint64_t)sb);
         rs[ci][0] = (int)(uint32_t)a; rs[ci][1] = (int)(uint32_t)(a >> 32);
         rs[ci][2] = __builtin_amdgcn_readfirstlane((int)((uint32_t)sst[ci] * (uint32_t)sH)); rs[ci][3] = 0x00020000;
     }
-    const int voff = cs + lane * 16;
+    const int voff = (NV ? 2 : 1) * cs + lane * 16;
     const int n0 = min(chunks, 64);
     const uint32_t m0lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n0 >= 32 ? 0xffffffffu : ((1u << n0) - 1u)));
     const uint32_t m0hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n0 >= 64 ? 0xffffffffu : (n0 > 32 ? ((1u << (n0 - 32)) - 1u) : 0u)));
@@ -75,7 +87,7 @@ __device__ __forceinline__ void strip_body_dma8(const FrameRegs &f, const SwsDev
         const int r0 = min(max(2 * q, 0), sH - 1), r1 = min(max(2 * q + 1, 0), sH - 1);
         const uint32_t slot = lds_base + (uint32_t)((q & (D - 1)) * pair_dw) * 4u;
 #pragma unroll
-        for (int ci = 0; ci < NCOMP; ci++)
+        for (int ci = 0; ci < NSRC; ci++)
 #pragma unroll
             for (int r = 0; r < 2; r++)
                 strip_dma16(slot + (uint32_t)((ci * 2 + r) * row_dw) * 4u, voff, rs[ci], (r ? r1 : r0) * sst[ci], m0lo, m0hi);
@@ -85,7 +97,7 @@ __device__ __forceinline__ void strip_body_dma8(const FrameRegs &f, const SwsDev
     // outstanding" implies that q has landed, whatever the stores of earlier rows are doing.  (Round 4 tried to allow for the stores issued behind the
     // request as well, (D - 1) * (P + S): wrong -- with the stores acknowledged early, q and its younger requests alone stay below that bound; the
     // band-start rows of a 6:1 conversion showed it.)
-    constexpr int P = NCOMP * 2;
+    constexpr int P = NSRC * 2;
     auto wait_pair = [&]() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * P) : "memory"); };
     // ---- destination descriptors and per-lane offsets (columns beyond the plane get an out-of-range offset) ----
     const bool semi = CHROMA && (p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010);
@@ -185,7 +197,27 @@ __device__ __forceinline__ void strip_body_dma8(const FrameRegs &f, const SwsDev
 #pragma unroll
                 for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
-                    for (int c = 0; c < COLS; c++) np[ci][c] = S[(ci * 2) * row_dw + spd[c]];
+                    for (int c = 0; c < COLS; c++) np[ci][c] = S[(NV ? 0 : ci * 2) * row_dw + spd[c]];
+            } else if constexpr (NV) {
+#pragma unroll
+                for (int c = 0; c < COLS; c++) {
+                    const uint32_t *s0 = S + spd[c], *s1 = s0 + row_dw;
+                    uint32_t d0[NDW], d1[NDW];
+#pragma unroll
+                    for (int j = 0; j < NDW; j++) { d0[j] = s0[j]; d1[j] = s1[j]; }
+#pragma unroll
+                    for (int ci = 0; ci < 2; ci++) {
+                        const uint32_t sl = ci ? sel1[c] : sel0[c];
+                        int a = sdot2_first(__builtin_amdgcn_perm(d0[1], d0[0], sl), ht[c][0]);
+                        int b = sdot2_first(__builtin_amdgcn_perm(d1[1], d1[0], sl), ht[c][0]);
+#pragma unroll
+                        for (int k = 1; k < NPH; k++) {
+                            a = sdot2(__builtin_amdgcn_perm(d0[k + 1], d0[k], sl), ht[c][k], a);
+                            b = sdot2(__builtin_amdgcn_perm(d1[k + 1], d1[k], sl), ht[c][k], b);
+                        }
+                        np[ci][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(a >> sh, b >> sh));
+                    }
+                }
             } else {
 #pragma unroll
                 for (int ci = 0; ci < NCOMP; ci++)
@@ -278,7 +310,7 @@ __device__ __forceinline__ void strip_body_dma8(const FrameRegs &f, const SwsDev
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA write may land after the wave has given up its LDS
 }
 
-template <bool CHROMA, int COLS, int NPH, int RD>
+template <bool CHROMA, int COLS, int NPH, int RD, bool NV = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) sws_k_strip_dma8(SwsFrameSet fs, SwsDevParams p, SwsStripGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -291,7 +323,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     const int y0 = band * g.band_rows, y1 = min(H, y0 + g.band_rows);
     if (y0 >= y1) return;
     const FrameRegs f = load_frame(fs, blockIdx.z);
-    strip_body_dma8<CHROMA, COLS, NPH, RD>(f, p, g, strip, y0, y1, smem, wib, lane);
+    strip_body_dma8<CHROMA, COLS, NPH, RD, NV>(f, p, g, strip, y0, y1, smem, wib, lane);
 }
 
 } // namespace swsk

@@ -47,7 +47,7 @@ GEOMS = [(1280, 72, 640, 36), (640, 36, 1280, 72), (1282, 50, 641, 25), (1278, 5
 def test_scalers_and_geometries(form, geom):
     sw, sh, dw, dh = geom
     for fl in SCALERS:
-        for sfmt, dfmt in (("yuv420p", "yuv420p"), ("yuv444p", "nv12"), ("yuv422p", "yuv420p10le")):
+        for sfmt, dfmt in (("yuv420p", "yuv420p"), ("yuv444p", "nv12"), ("yuv422p", "yuv420p10le"), ("nv12", "yuv420p"), ("nv21", "nv12"), ("nv24", "yuv444p")):
             run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=dw, tune=FORMS[form])
 
 
@@ -63,7 +63,7 @@ def test_chroma_positions_and_ranges():
 
 def test_the_planner_names_the_kernel():
     from librempeg_amd import SwsContext
-    for fmt, tune, want in (("yuv420p", {}, "sws_k_strip_dma8"), ("nv12", {}, "sws_k_strip_short"), ("yuv420p", {"no_strip_dma8": 1}, "sws_k_strip_short"),
+    for fmt, tune, want in (("yuv420p", {}, "sws_k_strip_dma8"), ("nv12", {}, "sws_k_strip_dma8"), ("yuv420p", {"no_strip_dma8": 1}, "sws_k_strip_short"),
                             ("yuv420p", {"no_strip_short": 1}, "sws_k_strip_march")):
         p = SwsContext(1280, 720, fmt, 640, 360, "yuv420p", SWS_BILINEAR | BX)
         for k, v in tune.items():
@@ -79,6 +79,8 @@ def test_full_size_frames():
         assert run_case(1280, 720, "yuv420p", 640, 360, "yuv420p", SWS_BILINEAR | BX, seed=1, tune=FORMS[form])[0] == "main:strip_march"
         run_case(1920, 1080, "yuv420p", 1280, 720, "yuv420p", SWS_BICUBIC | BX, seed=2, tune=FORMS[form])
         run_case(3840, 2160, "yuv420p", 1920, 1080, "nv12", SWS_BICUBIC | BX, seed=3, tune=FORMS[form])
+        run_case(3840, 2160, "nv12", 1920, 1080, "nv12", SWS_BICUBIC | BX, seed=5, tune=FORMS[form])
+        run_case(1920, 1080, "nv12", 1280, 720, "yuv420p", SWS_BILINEAR | BX, seed=6, tune=FORMS[form])
         run_case(1920, 1080, "yuv444p", 1280, 720, "yuv420p10le", SWS_BILINEAR | BX, seed=4, tune=FORMS[form], device_frames=False)
 
 
