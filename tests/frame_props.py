@@ -29,7 +29,7 @@ def _subsampling(fmt):
     """(log2_chroma_w, log2_chroma_h)"""
     if _is_rgb(fmt) or _is_gray(fmt) or fmt.startswith("xyz"):
         return 0, 0
-    for key, sub in (("420", (1, 1)), ("nv12", (1, 1)), ("nv21", (1, 1)), ("p010", (1, 1)), ("p012", (1, 1)), ("p016", (1, 1)),
+    for key, sub in (("p41", (0, 0)), ("420", (1, 1)), ("nv12", (1, 1)), ("nv21", (1, 1)), ("p010", (1, 1)), ("p012", (1, 1)), ("p016", (1, 1)),
                      ("422", (1, 0)), ("nv16", (1, 0)), ("nv20", (1, 0)), ("p21", (1, 0)), ("yuyv", (1, 0)), ("uyvy", (1, 0)),
                      ("yvyu", (1, 0)), ("y21", (1, 0)), ("411", (2, 0)), ("410", (2, 2)), ("440", (0, 1))):
         if key in fmt:

@@ -24,3 +24,7 @@ import lzma
 dst2 = os.path.join(root, "tests", "golden", "vsynth1_f1-3_352x288.yuv420p.bin.xz")
 open(dst2, "wb").write(lzma.compress(data[fsz:4 * fsz], preset=9 | lzma.PRESET_EXTREME))
 print("wrote", dst2, os.path.getsize(dst2), "bytes")
+# frame 4: with frames 0..3 the five pictures FATE's video_filter() recipes encode (-frames:v 5: filter-null / -scale200 / -scale500 / -crop_scale ...)
+dst3 = os.path.join(root, "tests", "golden", "vsynth1_f4_352x288.yuv420p.bin.xz")
+open(dst3, "wb").write(lzma.compress(data[4 * fsz:5 * fsz], preset=9 | lzma.PRESET_EXTREME))
+print("wrote", dst3, os.path.getsize(dst3), "bytes")
