@@ -604,7 +604,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             const bool rgb_alpha = c->needAlpha && p.dstKind == DSTK_RGB32 && isPlanarYUV(o.src_format) && !c->tune.no_mixed;
             const bool rgb_ok = (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr && ((p.srcKind == SRCK_PLANAR8 && c->srcBpc == 8) || rgb_s16) &&
                                 !p.no_chroma && (!p.need_alpha || rgb_alpha) && !(p.dstW & 1) && !p.range_active && !c->tune.no_strip;
-            d->striprgb_ok = false;
+            d->striprgb_ok = false; d->striprgb_direct = 0;
             // (planar writers: a one-tap vertical filter takes the reference's yuv2plane1 form -- (s + d) >> 7, (s + (1 << (14 - bits))) >> (15 - bits),
             //  output.c:327-341, :485-493 -- which is the "X" arithmetic of these kernels with the one tap 4096: (4096 s + (d << 12)) >> 19, sample for
             //  sample; the strip kernel takes such planes (4:2:0 -> 4:2:2 at half the size, horizontal-only scaling), the dot2 tile kernel keeps its
@@ -897,6 +897,17 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         }
                         d->striprgb_long = gl.npv > 5;
                         d->striprgb_ok = true;                           // (and every row in the "X" writer mode: checked below)
+                        // the semi-planar source itself, without the split pass, where the kernel can read it: nv12-like through the LDS-DMA form's selectors
+                        // (chroma windows of two bytes per sample: <= 64 chunks), p010-like through the 16-bit instantiation's staging (128-column strips)
+                        d->striprgb_direct = 0;
+                        if (!c->tune.no_striprgb_direct && !wantA) {
+                            const size_t lds_nv = (size_t)16 * (2 * 2 * ((gl.NCmax + 16) >> 2) + 2 * 2 * ((2 * gc.NCmax + 16) >> 2) + 32 * 4);     // (k_striprgb.hip: ring depth 2)
+                            if ((d->split_mode & 8) && gl.dma8_ok && gc.dma8_ok && rcl == 4 && 2 * gc.NCmax / 16 <= 64 && lds_nv <= 60 * 1024 && std::max(gl.nph8, gc.nph8) <= 6) {
+                                d->striprgb_direct = 1; d->striprgb_direct_swap = (d->split_mode & 16) ? 1 : 0;
+                            } else if ((d->split_mode & 32) && rgb_s16 && rcl == 2) {
+                                d->striprgb_direct = 2; d->striprgb_direct_shift = d->split_shift;
+                            }
+                        }
                     }
                 } else
                 {
@@ -1166,7 +1177,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     }
     default: c->path_name = "none"; c->kernel_name = ""; break;
     }
-    if (c->plan == PLAN_MAIN && d->split_mode) c->path_name = ((d->split_mode & 40) ? "main:splitnv+" : "main:split422+") + c->path_name.substr(c->path_name.find(':') + 1);
+    // (nvdirect: the strip-RGB kernel reads the semi-planar source itself on 16-byte aligned frames -- launch_plan_le falls back to the split pass otherwise)
+    if (c->plan == PLAN_MAIN && d->split_mode) c->path_name = ((d->split_mode & 40) ? ((d->striprgb_ok && d->striprgb_direct && !c->tune.no_striprgb_direct) ? "main:nvdirect+" : "main:splitnv+") : "main:split422+") +
+                                                             c->path_name.substr(c->path_name.find(':') + 1);
     if (c->plan == PLAN_MAIN && d->join422) c->path_name += "+join422";
     if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += d->fullchr_on == 3 ? "+lut_rgb" : "+fullchr_rgb";
     if (c->plan == PLAN_MAIN && d->fullchr_on && d->fullchr_direct) { c->path_name = "main:fullchr_rgb_direct"; c->kernel_name = d->fullchr_kind == DSTK_GBRP ? "sws_k_fullchr_gbrp" : "sws_k_fullchr_rgb"; }
@@ -1386,7 +1399,10 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
     }
     // packed 4:2:2 source through the planar kernels (dev_prepare_on): de-interleave into a planar 4:2:2 working picture per frame first
     std::vector<SwsFramePtrs> s422fr, s422split;
-    if (c->plan == PLAN_MAIN && d->split_mode) {
+    // (a semi-planar source the strip-RGB kernel reads itself: no split pass on aligned frames)
+    d->striprgb_direct_now = c->plan == PLAN_MAIN && d->split_mode && d->striprgb_direct && d->striprgb_ok && !c->tune.no_striprgb_direct &&
+                             frames_vec_ok(frames, n) && frames_desc_ok(frames, n, p.srcH, p.dstH);
+    if (c->plan == PLAN_MAIN && d->split_mode && !d->striprgb_direct_now) {
         auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
         const bool nv = (d->split_mode & 8) != 0;    // semi-planar 8-bit source: only the chroma plane is split, the luma plane stays where it is
         const bool p01x = (d->split_mode & 32) != 0; // semi-planar 10 / 12-bit source: both planes (every word is shifted down)
@@ -2603,7 +2619,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "layout_ch", &c->tune.layout_ch }, { "no_mixed", &c->tune.no_mixed }, { "no_layout_stream", &c->tune.no_layout_stream }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
         { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
         { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb },
-        { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_dma8_depth", &c->tune.strip_dma8_depth },
+        { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_lds_pad_kb", &c->tune.strip_lds_pad_kb }, { "no_striprgb_direct", &c->tune.no_striprgb_direct },
         { "no_strip_short", &c->tune.no_strip_short }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "strip_short_waves", &c->tune.strip_short_waves },
         { "debug", &c->tune.debug },
     };

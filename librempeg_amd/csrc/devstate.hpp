@@ -35,6 +35,10 @@ struct DeviceState {
     // the same plan on strips of another width for the short-filter instantiations (k_strip2.hip): own colStart / colCount, everything else shared
     bool stripLs_ok = false, stripCs_ok = false; SwsStripGeom stripLs, stripCs;
     bool striprgb_ok = false; SwsStripGeom stripRL, stripRC; bool striprgb_long = false;   // sws_k_strip_rgb: scaled planar 8-bit YUV -> 24 / 32 bpp RGB
+    // a semi-planar source the strip-RGB kernels read THEMSELVES on 16-byte aligned frames (no split pass): 1 nv12-like (sws_k_strip_rgb8<..., NV>: chroma
+    // bytes de-interleaved by the h-stage), 2 p010-like (sws_k_strip_rgb<..., S16, P01X>: words shifted down and de-interleaved while staging);
+    // swap: V first (nv21 / nv42); shift: the words' right shift; now: launch_plan_le skipped the split for the call in flight
+    int striprgb_direct = 0, striprgb_direct_swap = 0, striprgb_direct_shift = 0; bool striprgb_direct_now = false;
     void *scratch = nullptr; size_t scratch_bytes = 0;
     void *stage_src = nullptr; size_t stage_src_bytes = 0;
     void *stage_dst = nullptr; size_t stage_dst_bytes = 0;

@@ -113,7 +113,7 @@ int launch_strip_short(const LaunchCtx &L, const SwsStripGeom &g0, int H, bool c
     SwsStripGeom g = g0;
     const int rd = g.npv <= 3 ? 3 : g.npv <= 4 ? 4 : g.npv <= 6 ? 6 : 8;
     StripShortFn fn;
-    int lds = (dma8 ? g.lds_dma8_bytes : g.lds_bytes) + (c->tune.strip_dma8_depth > 0 ? c->tune.strip_dma8_depth * 1024 : 0);
+    int lds = (dma8 ? g.lds_dma8_bytes : g.lds_bytes) + (c->tune.strip_lds_pad_kb > 0 ? c->tune.strip_lds_pad_kb * 1024 : 0);
     if (dma8) {
         if (nv) fn = cols == 1 ? dma8_fn_rd<true, 1, true>(rd, g.nph8) : cols == 2 ? dma8_fn_rd<true, 2, true>(rd, g.nph8) : dma8_fn_rd<true, 3, true>(rd, g.nph8);
         else if (chroma) fn = cols == 1 ? dma8_fn_rd<true, 1>(rd, g.nph8) : cols == 2 ? dma8_fn_rd<true, 2>(rd, g.nph8) : cols == 3 ? dma8_fn_rd<true, 3>(rd, g.nph8) :

@@ -26,21 +26,29 @@
 namespace swsk {
 
 // S16: the source planes hold 9 .. 15-bit samples in 16-bit words (eight samples per 16-byte chunk, staged as they are); else bytes
-template <int NCOMP, int COLS, int NPH, int RD, bool S16 = false>
+// P01X (with S16): a p010-style source -- words with the samples in the HIGH bits, the two chroma components interleaved in plane 1
+// (p010LEToY_c / p010LEToUV_c, input.c:950-1008): every word is shifted down while it is staged, a chroma row is two chunks per lane
+// (8 {U, V} word pairs) de-interleaved with v_perm into one chunk per component
+template <int NCOMP, int COLS, int NPH, int RD, bool S16 = false, bool P01X = false>
 struct StripPlane {
     StripLds L;
     int spd[COLS];
     uint32_t ht[COLS][NPH];
     sws_rsrc_t rs[NCOMP];
-    int sst[NCOMP], sH, voff, slot, qnext;
-    u32x4 pre[NCOMP * 2];                 // [component][row of the pair]
+    int sst[NCOMP], sH, voff, slot, qnext, sshift;
+    u32x4 pre[NCOMP * 2];                 // [component][row of the pair]; P01X chroma: [row of the pair][first / second chunk]
     uint32_t ring[NCOMP][COLS][RD];
 };
 
-template <int NCOMP, int COLS, int NPH, int RD, bool S16>
-__device__ __forceinline__ void sp_prefetch(StripPlane<NCOMP, COLS, NPH, RD, S16> &P, int q)
+template <int NCOMP, int COLS, int NPH, int RD, bool S16, bool P01X>
+__device__ __forceinline__ void sp_prefetch(StripPlane<NCOMP, COLS, NPH, RD, S16, P01X> &P, int q)
 {
     const int r0 = min(max(2 * q, 0), P.sH - 1), r1 = min(max(2 * q + 1, 0), P.sH - 1);
+    if constexpr (P01X && NCOMP == 2) {       // one interleaved plane: 32 bytes per lane and row
+        P.pre[0] = bload16(P.rs[0], P.voff, r0 * P.sst[0]); P.pre[1] = bload16(P.rs[0], P.voff == 0x7fffffff ? P.voff : P.voff + 16, r0 * P.sst[0]);
+        P.pre[2] = bload16(P.rs[0], P.voff, r1 * P.sst[0]); P.pre[3] = bload16(P.rs[0], P.voff == 0x7fffffff ? P.voff : P.voff + 16, r1 * P.sst[0]);
+        return;
+    }
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++) {
         P.pre[2 * ci + 0] = bload16(P.rs[ci], P.voff, r0 * P.sst[ci]);
@@ -58,9 +66,29 @@ __device__ __forceinline__ void sp_put8(uint32_t *dst, const u32x4 &v)   // 16 b
     *(u32x4 *)dst = lo; *(u32x4 *)(dst + 4) = hi;
 }
 
-template <int NCOMP, int COLS, int NPH, int RD, bool S16>
-__device__ __forceinline__ void sp_stage(StripPlane<NCOMP, COLS, NPH, RD, S16> &P)
+template <int NCOMP, int COLS, int NPH, int RD, bool S16, bool P01X>
+__device__ __forceinline__ void sp_stage(StripPlane<NCOMP, COLS, NPH, RD, S16, P01X> &P)
 {
+    if constexpr (P01X) {
+        const uint32_t mask = (0xFFFFu >> P.sshift) * 0x10001u;
+        auto down = [&](const u32x4 &v) { u32x4 w; w[0] = (v[0] >> P.sshift) & mask; w[1] = (v[1] >> P.sshift) & mask; w[2] = (v[2] >> P.sshift) & mask; w[3] = (v[3] >> P.sshift) & mask; return w; };
+        if constexpr (NCOMP == 1) {
+            *(u32x4 *)(P.L.S + P.slot) = down(P.pre[0]); *(u32x4 *)(P.L.S + P.L.row_dw + P.slot) = down(P.pre[1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const u32x4 a = P.pre[2 * r], b = P.pre[2 * r + 1];
+                u32x4 u, v;
+                u[0] = __builtin_amdgcn_perm(a[1], a[0], 0x05040100u); u[1] = __builtin_amdgcn_perm(a[3], a[2], 0x05040100u);
+                u[2] = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u); u[3] = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u);
+                v[0] = __builtin_amdgcn_perm(a[1], a[0], 0x07060302u); v[1] = __builtin_amdgcn_perm(a[3], a[2], 0x07060302u);
+                v[2] = __builtin_amdgcn_perm(b[1], b[0], 0x07060302u); v[3] = __builtin_amdgcn_perm(b[3], b[2], 0x07060302u);
+                *(u32x4 *)(P.L.S + (0 + r) * P.L.row_dw + P.slot) = down(u);
+                *(u32x4 *)(P.L.S + (2 + r) * P.L.row_dw + P.slot) = down(v);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++) {
         uint32_t *row0 = P.L.S + (ci * 2) * P.L.row_dw, *row1 = row0 + P.L.row_dw;
@@ -70,10 +98,11 @@ __device__ __forceinline__ void sp_stage(StripPlane<NCOMP, COLS, NPH, RD, S16> &
 }
 
 // per-lane column state of one plane class: window offsets, horizontal taps, source descriptors
-template <int NCOMP, int COLS, int NPH, int RD, bool S16>
-__device__ __forceinline__ void sp_init(StripPlane<NCOMP, COLS, NPH, RD, S16> &P, const SwsStripGeom &g, int strip, int W, int sH, const int32_t *hpos,
-                                        const uint8_t *const (&sb)[NCOMP], const int (&sst)[NCOMP], uint32_t *lds, int lane)
+template <int NCOMP, int COLS, int NPH, int RD, bool S16, bool P01X>
+__device__ __forceinline__ void sp_init(StripPlane<NCOMP, COLS, NPH, RD, S16, P01X> &P, const SwsStripGeom &g, int strip, int W, int sH, const int32_t *hpos,
+                                        const uint8_t *const (&sb)[NCOMP], const int (&sst)[NCOMP], uint32_t *lds, int lane, int sshift = 0)
 {
+    P.sshift = sshift;
     constexpr int SPC = S16 ? 8 : 16;      // samples per 16-byte source chunk
     const int xs = strip * g.TW, cs = g.colStart[strip], chunks = g.colCount[strip] / SPC;
     P.L.row_dw = (g.NCmax + SPC) >> 1;     // one spare chunk per row: the dump slot of idle lanes
@@ -92,7 +121,7 @@ __device__ __forceinline__ void sp_init(StripPlane<NCOMP, COLS, NPH, RD, S16> &P
     for (int ci = 0; ci < NCOMP; ci++) { P.sst[ci] = sst[ci]; P.rs[ci] = make_rsrc(sb[ci], (uint32_t)sst[ci] * (uint32_t)sH); }
     // one 16-byte chunk per lane and source row, unconditionally: a lane beyond the strip's window gets an out-of-range offset (the
     // descriptor answers 0 without touching memory) and dumps into the spare chunk
-    P.voff = lane < chunks ? cs * (S16 ? 2 : 1) + lane * 16 : 0x7fffffff;
+    P.voff = lane < chunks ? ((P01X && NCOMP == 2) ? cs * 4 + lane * 32 : cs * (S16 ? 2 : 1) + lane * 16) : 0x7fffffff;
     P.slot = min(lane, chunks) * (SPC / 2);
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++)
@@ -104,8 +133,8 @@ __device__ __forceinline__ void sp_init(StripPlane<NCOMP, COLS, NPH, RD, S16> &P
 
 // h-scale the staged row pair into the ring, then stage the prefetched pair and request the one after it.  `flush` releases the
 // pending output row between the wait for the prefetched pair and the next request (see the header of kernels_strip.hpp).
-template <int NCOMP, int COLS, int NPH, int RD, bool S16, typename F>
-__device__ __forceinline__ void sp_step(StripPlane<NCOMP, COLS, NPH, RD, S16> &P, int sh, int opaque_neg, F &&flush)
+template <int NCOMP, int COLS, int NPH, int RD, bool S16, bool P01X, typename F>
+__device__ __forceinline__ void sp_step(StripPlane<NCOMP, COLS, NPH, RD, S16, P01X> &P, int sh, int opaque_neg, F &&flush)
 {
     uint32_t np[NCOMP][COLS];
     // (a basic block of its own: see strip_body in kernels_strip.hpp -- straight-line code makes hipcc spill inside the loop)
@@ -135,8 +164,8 @@ __device__ __forceinline__ void sp_step(StripPlane<NCOMP, COLS, NPH, RD, S16> &P
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int NCOMP, int COLS, int NPH, int RD, bool S16>
-__device__ __forceinline__ void sp_restart(StripPlane<NCOMP, COLS, NPH, RD, S16> &P, int q)   // (re)fill: pair q staged, pair q + 1 requested
+template <int NCOMP, int COLS, int NPH, int RD, bool S16, bool P01X>
+__device__ __forceinline__ void sp_restart(StripPlane<NCOMP, COLS, NPH, RD, S16, P01X> &P, int q)   // (re)fill: pair q staged, pair q + 1 requested
 {
     P.qnext = q;
     sp_prefetch(P, q);
@@ -146,8 +175,8 @@ __device__ __forceinline__ void sp_restart(StripPlane<NCOMP, COLS, NPH, RD, S16>
 
 // vertical stage over the whole ring: the host lays the row's tap pairs out against the ring slots (slots older than the row's
 // window carry zero taps), so there is nothing to decide here.  Sums of sample * tap, no rounding constant.
-template <int NCOMP, int COLS, int NPH, int RD, bool S16>
-__device__ __forceinline__ void sp_vstage(const StripPlane<NCOMP, COLS, NPH, RD, S16> &P, const SwsStripRow &e, int (&acc)[NCOMP][COLS])
+template <int NCOMP, int COLS, int NPH, int RD, bool S16, bool P01X>
+__device__ __forceinline__ void sp_vstage(const StripPlane<NCOMP, COLS, NPH, RD, S16, P01X> &P, const SwsStripRow &e, int (&acc)[NCOMP][COLS])
 {
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++)
@@ -180,23 +209,27 @@ __device__ __forceinline__ void lut_pair(const SwsLutParams &L, const LutTabs &T
     }
 }
 
-template <int BPP, int NPH, int RL, int RC, int CL, bool S16>
+template <int BPP, int NPH, int RL, int RC, int CL, bool S16, bool P01X>
 __device__ __forceinline__ void strip_rgb_body(const FrameRegs &f, const SwsDevParams &p, const SwsStripGeom &gl, const SwsStripGeom &gc,
                                                int strip, int y0, int y1, uint32_t *lds, const LutTabs &T, int lane)
 {
     const int W = p.dstW, H = p.dstH;
     constexpr int CC = CL / 2;             // lane l: luma columns l + 64 c (c < CL), chroma columns and pixel pairs l + 64 c (c < CC)
-    StripPlane<1, CL, NPH, RL, S16> PL;
-    StripPlane<2, CC, NPH, RC, S16> PC;
+    StripPlane<1, CL, NPH, RL, S16, P01X> PL;
+    StripPlane<2, CC, NPH, RC, S16, P01X> PC;
     constexpr int SPC = S16 ? 8 : 16;
     const int ldw = (gl.NCmax + SPC) >> 1, cdw = (gc.NCmax + SPC) >> 1;
     uint32_t *ldsL = lds, *ldsC = lds + 2 * ldw, *ldsX = ldsC + 4 * cdw;       // luma rows, chroma rows, 256 x int16 exchange row
     {
         const uint8_t *const sb[1] = { f.src[0] };
         const int st[1] = { f.srcStride[0] };
-        sp_init(PL, gl, strip, W, p.srcH, p.hLumPos, sb, st, ldsL, lane);
+        sp_init(PL, gl, strip, W, p.srcH, p.hLumPos, sb, st, ldsL, lane, p.src_shift);
     }
-    {
+    if constexpr (P01X) {     // (both components out of plane 1; the second descriptor is not used)
+        const uint8_t *const sb[2] = { f.src[1], f.src[1] };
+        const int st[2] = { f.srcStride[1], f.srcStride[1] };
+        sp_init(PC, gc, strip, p.chrDstW, p.chrSrcH, p.hChrPos, sb, st, ldsC, lane, p.src_shift);
+    } else {
         const bool u1 = p.u_plane_src == 1;
         const uint8_t *const sb[2] = { u1 ? f.src[1] : f.src[2], u1 ? f.src[2] : f.src[1] };
         const int st[2] = { u1 ? f.srcStride[1] : f.srcStride[2], u1 ? f.srcStride[2] : f.srcStride[1] };
@@ -281,40 +314,46 @@ __device__ __forceinline__ void strip_rgb_body(const FrameRegs &f, const SwsDevP
 #ifndef SWS_RGB8_DEPTH
 #define SWS_RGB8_DEPTH 2   // row pairs per plane class in the LDS ring (a power of two)
 #endif
-template <int NCOMP, int COLS, int NPH, int RD>
+// NV: the two chroma components are ONE plane of interleaved byte pairs (nv12 / nv21 / nv16 / nv24: nvXXtoUV_c, input.c:926-948), DMA'd as it is
+// (one request per row); the selectors pick a component's bytes (kernels_strip8.hpp strip_body_dma8<..., NV>)
+template <int NCOMP, int COLS, int NPH, int RD, bool NV = false>
 struct StripPlane8 {
+    static constexpr int NSRC = NV ? 1 : NCOMP;
     uint32_t *ringS; uint32_t lds_base;
     int row_dw, pair_dw;
     int spd[COLS];
     uint32_t sel0[COLS], sel1[COLS];
     uint32_t ht[COLS][NPH];
-    i32x4s rs[NCOMP];
-    int sst[NCOMP], sH, voff, qnext, qdma;
+    i32x4s rs[NSRC];
+    int sst[NSRC], sH, voff, qnext, qdma;
     uint32_t mlo, mhi;
     uint32_t ring[NCOMP][COLS][RD];
 };
 
-template <int NCOMP, int COLS, int NPH, int RD>
-__device__ __forceinline__ void sp8_dma(StripPlane8<NCOMP, COLS, NPH, RD> &P)     // request the next row pair into its ring slot
+template <int NCOMP, int COLS, int NPH, int RD, bool NV>
+__device__ __forceinline__ void sp8_dma(StripPlane8<NCOMP, COLS, NPH, RD, NV> &P)     // request the next row pair into its ring slot
 {
+    constexpr int NSRC = NV ? 1 : NCOMP;
     constexpr int D = SWS_RGB8_DEPTH;
     const int q = P.qdma++;
     const int r0 = min(max(2 * q, 0), P.sH - 1), r1 = min(max(2 * q + 1, 0), P.sH - 1);
     const uint32_t slot = P.lds_base + (uint32_t)((q & (D - 1)) * P.pair_dw) * 4u;
 #pragma unroll
-    for (int ci = 0; ci < NCOMP; ci++)
+    for (int ci = 0; ci < NSRC; ci++)
 #pragma unroll
         for (int r = 0; r < 2; r++)
             strip_dma16(slot + (uint32_t)((ci * 2 + r) * P.row_dw) * 4u, P.voff, P.rs[ci], (r ? r1 : r0) * P.sst[ci], P.mlo, P.mhi);
 }
 
-template <int NCOMP, int COLS, int NPH, int RD>
-__device__ __forceinline__ void sp8_init(StripPlane8<NCOMP, COLS, NPH, RD> &P, const SwsStripGeom &g, int strip, int W, int sH, const int32_t *hpos,
-                                         const uint8_t *const (&sb)[NCOMP], const int (&sst)[NCOMP], uint32_t *lds, int lane)
+template <int NCOMP, int COLS, int NPH, int RD, bool NV, int NS>
+__device__ __forceinline__ void sp8_init(StripPlane8<NCOMP, COLS, NPH, RD, NV> &P, const SwsStripGeom &g, int strip, int W, int sH, const int32_t *hpos,
+                                         const uint8_t *const (&sb)[NS], const int (&sst)[NS], uint32_t *lds, int lane, int nv_swap = 0)
 {
-    const int xs = strip * g.TW, cs = g.colStart[strip], chunks = g.colCount[strip] / 16;
-    P.row_dw = (g.NCmax + 16) >> 2;        // bytes; one spare chunk: the last column's aligned reads
-    P.pair_dw = NCOMP * 2 * P.row_dw;
+    constexpr int NSRC = NV ? 1 : NCOMP;
+    static_assert(NS == NSRC, "one base pointer per source plane");
+    const int xs = strip * g.TW, cs = g.colStart[strip], chunks = (NV ? 2 : 1) * g.colCount[strip] / 16;
+    P.row_dw = ((NV ? 2 : 1) * g.NCmax + 16) >> 2;        // bytes; one spare chunk: the last column's aligned reads
+    P.pair_dw = NSRC * 2 * P.row_dw;
     P.ringS = lds;
     P.lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds);
     P.sH = sH;
@@ -322,23 +361,29 @@ __device__ __forceinline__ void sp8_init(StripPlane8<NCOMP, COLS, NPH, RD> &P, c
 #pragma unroll
     for (int c = 0; c < COLS; c++) {
         const int x = min(xs + 64 * c + lane, W - 1);
-        const int o = hpos[x] - cs;
+        const int o = (NV ? 2 : 1) * (hpos[x] - cs);
         P.spd[c] = o >> 2;
         const uint32_t b = (uint32_t)(o & 3);
-        P.sel0[c] = 0x0c000c00u | b | ((b + 1) << 16);
-        P.sel1[c] = 0x0c000c00u | (b + 2) | ((b + 3) << 16);
+        if constexpr (NV) {                    // sel0 / sel1: the first / second component's bytes of two interleaved pairs
+            const uint32_t b0 = b + (nv_swap ? 1u : 0u), b1 = b + (nv_swap ? 0u : 1u);
+            P.sel0[c] = 0x0c000c00u | b0 | ((b0 + 2) << 16);
+            P.sel1[c] = 0x0c000c00u | b1 | ((b1 + 2) << 16);
+        } else {
+            P.sel0[c] = 0x0c000c00u | b | ((b + 1) << 16);
+            P.sel1[c] = 0x0c000c00u | (b + 2) | ((b + 3) << 16);
+        }
         const uint32_t *tp = (const uint32_t *)(g.hT8 + (int64_t)x * (2 * nd));
 #pragma unroll
         for (int k = 0; k < NPH; k++) P.ht[c][k] = k < nd ? tp[k] : 0u;
     }
 #pragma unroll
-    for (int ci = 0; ci < NCOMP; ci++) {
+    for (int ci = 0; ci < NSRC; ci++) {
         P.sst[ci] = sst[ci];
         const uint64_t a = uniform_u64((uint64_t)sb[ci]);
         P.rs[ci][0] = (int)(uint32_t)a; P.rs[ci][1] = (int)(uint32_t)(a >> 32);
         P.rs[ci][2] = __builtin_amdgcn_readfirstlane((int)((uint32_t)sst[ci] * (uint32_t)sH)); P.rs[ci][3] = 0x00020000;
     }
-    P.voff = cs + lane * 16;
+    P.voff = (NV ? 2 : 1) * cs + lane * 16;
     const int n0 = min(chunks, 64);
     P.mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n0 >= 32 ? 0xffffffffu : ((1u << n0) - 1u)));
     P.mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n0 >= 64 ? 0xffffffffu : (n0 > 32 ? ((1u << (n0 - 32)) - 1u) : 0u)));
@@ -351,19 +396,40 @@ __device__ __forceinline__ void sp8_init(StripPlane8<NCOMP, COLS, NPH, RD> &P, c
 }
 
 // h-scale the oldest requested pair into the ring, release the pending output row, re-request the slot
-template <int NCOMP, int COLS, int NPH, int RD, typename F>
-__device__ __forceinline__ void sp8_step(StripPlane8<NCOMP, COLS, NPH, RD> &P, int sh, int opaque_neg, F &&flush)
+template <int NCOMP, int COLS, int NPH, int RD, bool NV, typename F>
+__device__ __forceinline__ void sp8_step(StripPlane8<NCOMP, COLS, NPH, RD, NV> &P, int sh, int opaque_neg, F &&flush)
 {
     constexpr int D = SWS_RGB8_DEPTH;
-    constexpr int NDW = (NPH - 1) / 2 + 2;
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * NCOMP * 2) : "memory");     // (D - 1) * P
+    constexpr int NSRC = NV ? 1 : NCOMP;
+    constexpr int NDW = NV ? NPH + 1 : (NPH - 1) / 2 + 2;
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * NSRC * 2) : "memory");     // (D - 1) * P
     const uint32_t *S = P.ringS + (P.qnext & (D - 1)) * P.pair_dw;
     uint32_t np[NCOMP][COLS];
     if (opaque_neg < 0) {      // (never: a basic block of its own for the horizontal stage, see strip_body in kernels_strip.hpp)
 #pragma unroll
         for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
-            for (int c = 0; c < COLS; c++) np[ci][c] = S[(ci * 2) * P.row_dw + P.spd[c]];
+            for (int c = 0; c < COLS; c++) np[ci][c] = S[(NV ? 0 : ci * 2) * P.row_dw + P.spd[c]];
+    } else if constexpr (NV) {
+#pragma unroll
+        for (int c = 0; c < COLS; c++) {
+            const uint32_t *s0 = S + P.spd[c], *s1 = s0 + P.row_dw;
+            uint32_t d0[NDW], d1[NDW];
+#pragma unroll
+            for (int j = 0; j < NDW; j++) { d0[j] = s0[j]; d1[j] = s1[j]; }
+#pragma unroll
+            for (int ci = 0; ci < 2; ci++) {
+                const uint32_t sl = ci ? P.sel1[c] : P.sel0[c];
+                int a = sdot2_first(__builtin_amdgcn_perm(d0[1], d0[0], sl), P.ht[c][0]);
+                int b = sdot2_first(__builtin_amdgcn_perm(d1[1], d1[0], sl), P.ht[c][0]);
+#pragma unroll
+                for (int k = 1; k < NPH; k++) {
+                    a = sdot2(__builtin_amdgcn_perm(d0[k + 1], d0[k], sl), P.ht[c][k], a);
+                    b = sdot2(__builtin_amdgcn_perm(d1[k + 1], d1[k], sl), P.ht[c][k], b);
+                }
+                np[ci][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(a >> sh, b >> sh));
+            }
+        }
     } else {
 #pragma unroll
         for (int ci = 0; ci < NCOMP; ci++)
@@ -399,8 +465,8 @@ __device__ __forceinline__ void sp8_step(StripPlane8<NCOMP, COLS, NPH, RD> &P, i
     sp8_dma(P);
 }
 
-template <int NCOMP, int COLS, int NPH, int RD>
-__device__ __forceinline__ void sp8_vstage(const StripPlane8<NCOMP, COLS, NPH, RD> &P, const SwsStripRow &e, int (&acc)[NCOMP][COLS])
+template <int NCOMP, int COLS, int NPH, int RD, bool NV>
+__device__ __forceinline__ void sp8_vstage(const StripPlane8<NCOMP, COLS, NPH, RD, NV> &P, const SwsStripRow &e, int (&acc)[NCOMP][COLS])
 {
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++)
@@ -412,7 +478,7 @@ __device__ __forceinline__ void sp8_vstage(const StripPlane8<NCOMP, COLS, NPH, R
         }
 }
 
-template <int BPP, int NPH, int RL, int RC, int CL>
+template <int BPP, int NPH, int RL, int RC, int CL, bool NV>
 __device__ __forceinline__ void strip_rgb8_body(const FrameRegs &f, const SwsDevParams &p, const SwsStripGeom &gl, const SwsStripGeom &gc,
                                                 int strip, int y0, int y1, uint32_t *lds, const LutTabs &T, int lane)
 {
@@ -420,15 +486,19 @@ __device__ __forceinline__ void strip_rgb8_body(const FrameRegs &f, const SwsDev
     const int W = p.dstW, H = p.dstH;
     constexpr int CC = CL / 2;
     StripPlane8<1, CL, NPH, RL> PL;
-    StripPlane8<2, CC, NPH, RC> PC;
-    const int ldw = (gl.NCmax + 16) >> 2, cdw = (gc.NCmax + 16) >> 2;
-    uint32_t *ldsL = lds, *ldsC = lds + D * 2 * ldw, *ldsX = ldsC + D * 4 * cdw;       // luma ring, chroma ring, 64 * CL x int16 exchange row
+    StripPlane8<2, CC, NPH, RC, NV> PC;
+    const int ldw = (gl.NCmax + 16) >> 2, cdw = ((NV ? 2 : 1) * gc.NCmax + 16) >> 2;
+    uint32_t *ldsL = lds, *ldsC = lds + D * 2 * ldw, *ldsX = ldsC + D * (NV ? 2 : 4) * cdw;       // luma ring, chroma ring, 64 * CL x int16 exchange row
     {
         const uint8_t *const sb[1] = { f.src[0] };
         const int st[1] = { f.srcStride[0] };
         sp8_init(PL, gl, strip, W, p.srcH, p.hLumPos, sb, st, ldsL, lane);
     }
-    {
+    if constexpr (NV) {     // (the planner keeps the interleaved plane in src[1]; nv_swap: V first -- nv21 / nv42)
+        const uint8_t *const sb[1] = { f.src[1] };
+        const int st[1] = { f.srcStride[1] };
+        sp8_init(PC, gc, strip, p.chrDstW, p.chrSrcH, p.hChrPos, sb, st, ldsC, lane, p.uv_swap_src);
+    } else {
         const bool u1 = p.u_plane_src == 1;
         const uint8_t *const sb[2] = { u1 ? f.src[1] : f.src[2], u1 ? f.src[2] : f.src[1] };
         const int st[2] = { u1 ? f.srcStride[1] : f.srcStride[2], u1 ? f.srcStride[2] : f.srcStride[1] };
@@ -512,7 +582,7 @@ __device__ __forceinline__ void strip_rgb8_body(const FrameRegs &f, const SwsDev
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA write may land after the wave has given up its LDS
 }
 
-template <int BPP, int RL, int RC, int NPH, int CL>
+template <int BPP, int RL, int RC, int NPH, int CL, bool NV = false>
 __global__ void __launch_bounds__(256) sws_k_strip_rgb8(SwsFrameSet fs, SwsDevParams p, SwsStripGeom gl, SwsStripGeom gc, int wave_lds_dw)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -529,14 +599,14 @@ __global__ void __launch_bounds__(256) sws_k_strip_rgb8(SwsFrameSet fs, SwsDevPa
     if (y0 >= y1) return;
     const FrameRegs f = load_frame(fs, blockIdx.z);
     uint32_t *lds = (uint32_t *)smem + wib * wave_lds_dw;
-    strip_rgb8_body<BPP, NPH, RL, RC, CL>(f, p, gl, gc, strip, y0, y1, lds, T, lane);
+    strip_rgb8_body<BPP, NPH, RL, RC, CL, NV>(f, p, gl, gc, strip, y0, y1, lds, T, lane);
 }
 
 // RL / RC: ring depths (row pairs) of the luma / chroma plane = the vertical tap pairs the kernel multiplies per output sample
 #ifndef SWS_SRGB_ATTR
 #define SWS_SRGB_ATTR
 #endif
-template <int BPP, int RL, int RC, int NPH, int CL, bool S16 = false>      // one kernel per ring form and horizontal tap-pair count: each gets the register allocation it needs
+template <int BPP, int RL, int RC, int NPH, int CL, bool S16 = false, bool P01X = false>      // one kernel per ring form and horizontal tap-pair count: each gets the register allocation it needs
 __global__ void __launch_bounds__(256) SWS_SRGB_ATTR sws_k_strip_rgb(SwsFrameSet fs, SwsDevParams p, SwsStripGeom gl, SwsStripGeom gc, int wave_lds_dw)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -553,7 +623,7 @@ __global__ void __launch_bounds__(256) SWS_SRGB_ATTR sws_k_strip_rgb(SwsFrameSet
     if (y0 >= y1) return;
     const FrameRegs f = load_frame(fs, blockIdx.z);
     uint32_t *lds = (uint32_t *)smem + wib * wave_lds_dw;
-    strip_rgb_body<BPP, NPH, RL, RC, CL, S16>(f, p, gl, gc, strip, y0, y1, lds, T, lane);
+    strip_rgb_body<BPP, NPH, RL, RC, CL, S16, P01X>(f, p, gl, gc, strip, y0, y1, lds, T, lane);
 }
 
 } // namespace swsk

@@ -114,7 +114,8 @@ struct Tuning {
     int no_strip_short = 0;        // off: 8-bit sources with short filters take the short instantiations of the strip kernel (k_strip2.hip)
     int strip_cols_auto = 1;       // strip widths of the short family chosen per picture width (3 .. 5 luma, 1 .. 3 chroma columns per lane)
     int no_strip_dma8 = 0;         // off: 8-bit planar sources of the short family take the LDS-DMA form (kernels_strip8.hpp)
-    int strip_dma8_depth = 0;      // experiments: LDS pad in KB per block of the short / dma8 kernels (lowers the occupancy; results never change)
+    int strip_lds_pad_kb = 0;      // experiments: LDS pad in KB per block of the short / dma8 kernels (lowers the occupancy; results never change)
+    int no_striprgb_direct = 0;    // off: semi-planar sources (nv12 / p010 families) are read by the strip-RGB kernels themselves instead of through a split pass
     int strip_short_waves = 0;     // experiments: waves per SIMD the short family is banded for (0: strip_waves scaled by the instantiation)
     int max_devices = 0;           // sws_scale_frames(): GPUs to shard over (0 = all visible)
     int work_mb = 2048;            // budget for the helper passes' per-frame working pictures: larger batches are cut into sub-batches (device.hip launch_plan_le)

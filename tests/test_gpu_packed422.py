@@ -121,21 +121,22 @@ def test_packed_sources_full_size_and_batches():
 @pytest.mark.parametrize("dst", ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0"])
 def test_semi_planar_sources_into_rgb(src, dst):
     """decoder output scaled for display: the interleaved chroma plane is split into planar working planes (nvXXtoUV_c copies bytes), then the
-    strip kernel with the RGB epilogue as for a planar source ("main:splitnv+strip_rgb")"""
+    strip kernel with the RGB epilogue as for a planar source ("main:splitnv+strip_rgb"); round 4: on aligned frames the strip-RGB kernel reads the
+    interleaved plane itself where its LDS-DMA form applies ("main:nvdirect+strip_rgb", tests/test_gpu_strip_short.py)"""
     for (sw, sh, dw, dh, fl) in ((256, 64, 192, 48, SWS_BICUBIC), (320, 50, 512, 80, SWS_BICUBIC), (132, 34, 66, 18, SWS_AREA), (256, 64, 320, 96, SWS_BILINEAR),
                                  (256, 64, 250, 64, SWS_LANCZOS), (130, 30, 131, 31, SWS_BICUBIC), (131, 31, 200, 40, SWS_BICUBIC | SWS_ACCURATE_RND)):
         r = run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh)
         # (an odd destination width and a 4:4:4 source force the full-chroma writers, utils.c:1330-1349: not the LUT writers this path is for)
         if not dw & 1 and src not in ("nv24", "nv42"):
-            assert r[0].startswith("main:splitnv+"), (r[0], src, dst, sw, dw)
+            assert r[0].startswith(("main:splitnv+", "main:nvdirect+")), (r[0], src, dst, sw, dw)
     if src not in ("nv24", "nv42"):
-        assert run_case(1920, 1080, src, 1280, 720, dst, SWS_BICUBIC | BX, seed=7)[0] == "main:splitnv+strip_rgb"
+        assert run_case(1920, 1080, src, 1280, 720, dst, SWS_BICUBIC | BX, seed=7)[0] == "main:nvdirect+strip_rgb"
     assert not run_case(256, 64, src, 256, 64, dst, SWS_BICUBIC | BX, seed=8)[0].startswith("main:splitnv+")      # same size: sws_k_rgb_march reads nv12 itself
 
 
 def test_nv12_to_rgb_full_size_is_the_strip_kernel():
-    assert run_case(3840, 2160, "nv12", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=2)[0] == "main:splitnv+strip_rgb"
-    assert run_case(1920, 1080, "nv12", 1280, 720, "rgb24", SWS_BILINEAR | BX, seed=3, device_frames=False)[0] == "main:splitnv+strip_rgb"
+    assert run_case(3840, 2160, "nv12", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=2)[0] == "main:nvdirect+strip_rgb"
+    assert run_case(1920, 1080, "nv12", 1280, 720, "rgb24", SWS_BILINEAR | BX, seed=3, device_frames=False)[0] == "main:nvdirect+strip_rgb"
 
 
 @pytest.mark.parametrize("src", ["p010le", "p012le", "p210le", "p010be"])
@@ -147,9 +148,9 @@ def test_p01x_sources_into_rgb(src, dst):
                                  (256, 64, 250, 64, SWS_LANCZOS), (130, 30, 131, 31, SWS_BICUBIC)):
         r = run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh)
         if not dw & 1:
-            assert r[0].startswith("main:splitnv+"), (r[0], src, dst, sw, dw)
-    assert run_case(1920, 1080, src, 1280, 720, dst, SWS_BICUBIC | BX, seed=7)[0] == "main:splitnv+strip_rgb"
-    assert run_case(256, 64, src, 256, 64, dst, SWS_BICUBIC | BX, seed=8)[0].startswith("main:splitnv+")      # same size too: one-tap horizontal banks
+            assert r[0].startswith(("main:splitnv+", "main:nvdirect+")), (r[0], src, dst, sw, dw)
+    assert run_case(1920, 1080, src, 1280, 720, dst, SWS_BICUBIC | BX, seed=7)[0] == "main:nvdirect+strip_rgb"
+    assert run_case(256, 64, src, 256, 64, dst, SWS_BICUBIC | BX, seed=8)[0].startswith(("main:splitnv+", "main:nvdirect+"))      # same size too: one-tap horizontal banks
 
 
 def test_same_size_10bit_pictures_and_packed_rgb():

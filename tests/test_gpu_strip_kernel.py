@@ -174,8 +174,8 @@ def test_unity_conversions_without_a_special_converter(pair):
 
 def test_p010_to_rgb_at_the_same_size():
     for df in ("bgra", "rgb24", "argb"):
-        assert run_case(1920, 1080, "p010le", 1920, 1080, df, SWS_BICUBIC | BX, seed=31)[0] == "main:splitnv+strip_rgb"
-        assert run_case(322, 50, "p012le", 322, 50, df, SWS_BICUBIC | BX, seed=32, tune=STRIP)[0] == "main:splitnv+strip_rgb"
+        assert run_case(1920, 1080, "p010le", 1920, 1080, df, SWS_BICUBIC | BX, seed=31)[0] == "main:nvdirect+strip_rgb"
+        assert run_case(322, 50, "p012le", 322, 50, df, SWS_BICUBIC | BX, seed=32, tune=STRIP)[0] == "main:nvdirect+strip_rgb"
     assert run_case(1920, 1080, "p010le", 1920, 1080, "yuv420p10le", SWS_BICUBIC | BX, seed=33)[0] == "main:strip_march"
     assert run_case(1920, 1080, "nv12", 1920, 1080, "yuv420p10le", SWS_BICUBIC | BX, seed=34)[0] == "main:strip_march"
     assert run_case(1920, 1080, "nv12", 1920, 1080, "bgr0", SWS_BICUBIC | BX, seed=35)[0] == "main:fused_rgb_unity"      # C4 keeps its kernel

@@ -123,3 +123,49 @@ def test_batches_unaligned_and_host_frames():
     for pad, shift, flip in ((0, 1, 0), (6, 3, 0), (13, 0, 1), (2, 2, 2)):
         run_odd(1284, 50, "yuv420p", 642, 26, "yuv420p", SWS_BICUBIC | BX, pad, shift, flip, nframes=2, tune=T0, seed=pad + 3)
         run_odd(644, 50, "yuv422p", 400, 40, "nv12", SWS_BILINEAR | BX, pad, shift, flip, nframes=3, tune=T0, seed=pad + 5)
+
+
+@pytest.mark.parametrize("direct", [1, 0], ids=["direct", "split"])
+@pytest.mark.parametrize("sfmt", ["nv12", "nv21", "nv16", "nv24", "nv42", "p010le", "p012le", "p010be", "p210le", "p410le", "p016le"])
+def test_semi_planar_sources_into_packed_rgb(sfmt, direct):
+    """decoder output -> display / inference: the strip-RGB kernels read a semi-planar source themselves on aligned frames (nv12 family: the LDS-DMA
+    form's selectors de-interleave the chroma bytes, sws_k_strip_rgb8<..., NV>; p010 family: the 16-bit instantiation shifts the words down and
+    de-interleaves them while staging, sws_k_strip_rgb<..., S16, P01X>) -- same bytes as through the split pass (no_striprgb_direct)"""
+    tune = dict(T0, no_striprgb_direct=0 if direct else 1)
+    for dfmt in ("rgb24", "bgra", "argb", "bgr24"):
+        for (sw, sh, dw, dh, fl) in ((1280, 72, 640, 36, SWS_BICUBIC), (644, 70, 322, 35, SWS_BILINEAR), (640, 36, 1280, 72, SWS_BICUBIC), (1920, 30, 1280, 20, SWS_LANCZOS),
+                                     (700, 64, 700, 32, SWS_BICUBIC | SWS_ACCURATE_RND), (1300, 31, 703, 31, SWS_AREA)):
+            run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=sw + len(dfmt), tune=tune)
+
+
+def test_semi_planar_sources_into_packed_rgb_full_size_and_batches():
+    import torch
+    from librempeg_amd import SwsContext, HostFrame, DeviceFrame
+    from test_gpu_unaligned_frames import run_odd
+    assert run_case(3840, 2160, "nv12", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=8)[0] == "main:nvdirect+strip_rgb"
+    assert run_case(3840, 2160, "p010le", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=9)[0] == "main:nvdirect+strip_rgb"
+    run_case(1920, 1080, "nv21", 1280, 720, "rgb24", SWS_BILINEAR | BX, seed=10, device_frames=False)
+    for sfmt in ("nv12", "p010le"):
+        sw, sh, dw, dh, fl = 1280, 96, 640, 48, SWS_BICUBIC | BX
+        o = OL.Oracle(sw, sh, sfmt, dw, dh, "bgra", fl)
+        p = SwsContext(sw, sh, sfmt, dw, dh, "bgra", fl)
+        p.set_option("strip_min_w", 0)
+        for n in (5, 2, 9):
+            refs, srcs, dsts = [], [], []
+            for k in range(n):
+                s = OL.fill_random(OL.Frame(sfmt, sw, sh), 700 + k + n)
+                ref = OL.Frame("bgra", dw, dh, fill=0x21); assert o.scale(s, ref) == dh; refs.append(ref)
+                hs = HostFrame(sfmt, sw, sh)
+                for a, b in zip(hs.planes, s.planes):
+                    a[:] = b
+                dd = DeviceFrame("bgra", dw, dh); dd.buf.fill_(0x21)
+                srcs.append(DeviceFrame(sfmt, sw, sh).upload(hs)); dsts.append(dd)
+            torch.cuda.synchronize()
+            assert p.scale_frames(srcs, dsts) == n
+            p.sync()
+            for k in range(n):
+                out = dsts[k].download()
+                assert np.array_equal(out.planes[0][:, :out.row_bytes[0]], refs[k].planes[0][:, :out.row_bytes[0]]), (sfmt, n, k)
+        p.close()
+        for pad, shift, flip in ((0, 1, 0), (6, 2, 0), (4, 0, 1)):       # unaligned / bottom-up frames: the split pass on aligned working copies
+            run_odd(644, 50, sfmt, 400, 40, "rgb24", SWS_BICUBIC | BX, pad, shift, flip, nframes=2, tune=T0, seed=pad + 7)
