@@ -786,7 +786,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     // interleaved); every pair between the first and the last one a band needs is requested, so no pair may be skipped.  Its tap rows
                     // start at the filter's own first tap (no even-position padding): o.rows carries their offset in the blob
                     alt.nph8 = (hb.size + 1) / 2;
-                    alt.lds_dma8_bytes = nvc ? 4 * 4 * 2 * ((2 * bnc + 16) / 4) * 4 : 4 * 4 * ncomp * 2 * ((bnc + 16) / 4) * 4;
+                    // (4 waves per block x ring depth x rows of a pair x dwords of a row; the chroma rings are 2 pairs deep: kernels_strip8.hpp)
+                    const int depth8 = ncomp == 2 ? 2 : 4;
+                    alt.lds_dma8_bytes = nvc ? 4 * depth8 * 2 * ((2 * bnc + 16) / 4) * 4 : 4 * depth8 * ncomp * 2 * ((bnc + 16) / 4) * 4;
                     alt.dma8_ok = dma8 && alt.lds_dma8_bytes <= 48 * 1024;
                     if (alt.dma8_ok) {
                         const int f8 = 2 * alt.nph8;

@@ -21,6 +21,11 @@
 
 namespace swsk {
 
+#ifndef STRIP_DMA8_DEPTH_C
+#define STRIP_DMA8_DEPTH_C 2
+#endif
+constexpr int strip_dma8_depth_c = STRIP_DMA8_DEPTH_C;     // (device.hip sizes the chroma launch's LDS with it)
+
 // NV: the chroma planes of a semi-planar source (nv12 / nv21 / nv16 / nv24: nvXXtoUV_c, input.c:926-948) -- ONE plane of interleaved {U, V} byte pairs.
 // Its rows land in LDS as they are (one request per row instead of two planes' worth); sample j of component ci is byte 2 j + ci, so pair k of a
 // window starting at sample o lies in the aligned dwords (k, k + 1) from byte (2 o & ~3) on, with ONE selector per component whatever k is
@@ -30,7 +35,10 @@ __device__ __forceinline__ void strip_body_dma8(const FrameRegs &f, const SwsDev
                                                 uint8_t *smem, int wib, int lane)
 {
     static_assert(CHROMA || !NV, "only the chroma planes are interleaved");
-    constexpr int NCOMP = CHROMA ? 2 : 1, D = STRIP_DMA_DEPTH;
+    // ring depth in row pairs: 4 for luma; 2 for the chroma planes, whose rings (two components, strips of up to 320 columns) would otherwise hold the
+    // kernel at 3 waves per SIMD through their LDS footprint (43 KB per block on C1).  Measured level with depth 4 (C1 x256 0.439 vs 0.436 - 0.446 of the
+    // HBM peak, x64 0.31 vs 0.30): the waves gained and the pairs in flight lost cancel; the smaller footprint is kept
+    constexpr int NCOMP = CHROMA ? 2 : 1, D = CHROMA ? STRIP_DMA8_DEPTH_C : STRIP_DMA_DEPTH;
     constexpr int NSRC = NV ? 1 : NCOMP;                      // source planes = rows requested per row of a pair
     constexpr int NDW = NV ? NPH + 1 : (NPH - 1) / 2 + 2;     // aligned dwords a column's window can touch
     const int W = CHROMA ? p.chrDstW : p.dstW, H = CHROMA ? p.chrDstH : p.dstH;
