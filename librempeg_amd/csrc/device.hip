@@ -546,7 +546,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         }
         // ---- packed 24 / 32 bpp RGB into 8-bit 4:2:0 / 4:2:2 YUV of the same size (sws_k_rgbsrc_unity): identity horizontal filters and luma
         //      vertical filter, chroma of the "half" readers through a vertical filter of up to 16 taps whose positions only move forward ----
-        d->rgbsrc_ok = false;
+        d->rgbsrc_ok = false; d->rgbsrc2_rows = nullptr;
         if (d->unity_h && !d->vlines_on && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chr_half && !p.range_active && !p.need_alpha && !p.no_chroma &&
             !p.wide && !p.dst_alpha_fill && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_NV12) && p.dst_bits == 8 && p.chrDstHSub == 1 && p.chrDstVSub <= 1 &&
             p.chrSrcVSub == 0 && p.srcH == p.dstH && bank_is_identity(c->vLum, 1 << 12) && c->vChr.size <= 16 && p.chrDstW == ((p.dstW + 1) >> 1) &&
@@ -565,15 +565,38 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     for (int j = 0; j < c->vChr.size; j++)
                         e.vt[j >> 1] |= (uint32_t)(uint16_t)(x_form ? c->vChr.taps[(size_t)y * c->vChr.size + j] : 1) << (16 * (j & 1));
                 }
-                const size_t bytes = rows.size() * sizeof(SwsRgbSrcRow);
+                // the wave-march form (sws_k_rgbsrc_unity2): per chroma row the first source-row PAIR and the tap pairs aligned to even source rows, laid out
+                // against the newest slots of its register ring (1 / 3 / 5 / 8 pairs); the planar one-tap form enters as the tap 4096
+                std::vector<SwsStripRow> rows2;
+                int npv2 = 1;
+                for (int y = 0; y < c->vChr.count; y++) npv2 = std::max(npv2, ((c->vChr.pos[y] & 1) + c->vChr.size + 1) / 2);
+                const int rd2 = npv2 <= 1 ? 1 : npv2 <= 3 ? 3 : npv2 <= 5 ? 5 : 8;
+                if (npv2 <= 8) {
+                    rows2.resize((size_t)c->vChr.count);
+                    std::memset(rows2.data(), 0, rows2.size() * sizeof(SwsStripRow));
+                    for (int y = 0; y < c->vChr.count; y++) {
+                        SwsStripRow &e2 = rows2[(size_t)y];
+                        e2.pf = (c->vChr.pos[y] & ~1) >> 1;
+                        for (int j = 0; j < c->vChr.size; j++) {
+                            const int k = (c->vChr.pos[y] & 1) + j + 2 * (rd2 - npv2);
+                            const int16_t tap = x_form ? c->vChr.taps[(size_t)y * c->vChr.size + j] : (int16_t)4096;
+                            e2.vt[k >> 1] |= (uint32_t)(uint16_t)tap << (16 * (k & 1));
+                        }
+                    }
+                }
+                const size_t bytes1 = (rows.size() * sizeof(SwsRgbSrcRow) + 63) & ~(size_t)63;
+                const size_t bytes = bytes1 + rows2.size() * sizeof(SwsStripRow);
                 if (bytes > d->dot2_bytes) {
                     if (d->d_dot2) HIPCHK(hipFree(d->d_dot2));
                     d->d_dot2 = nullptr;
                     HIPCHK(hipMalloc(&d->d_dot2, bytes));
                     d->dot2_bytes = bytes;
                 }
-                HIPCHK(hipMemcpy(d->d_dot2, rows.data(), bytes, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(d->d_dot2, rows.data(), rows.size() * sizeof(SwsRgbSrcRow), hipMemcpyHostToDevice));
+                if (!rows2.empty()) HIPCHK(hipMemcpy((uint8_t *)d->d_dot2 + bytes1, rows2.data(), rows2.size() * sizeof(SwsStripRow), hipMemcpyHostToDevice));
                 d->rgbsrc_rows = (const SwsRgbSrcRow *)d->d_dot2;
+                d->rgbsrc2_rows = rows2.empty() ? nullptr : (const SwsStripRow *)((const uint8_t *)d->d_dot2 + bytes1);
+                d->rgbsrc2_npv = npv2;
                 d->rgbsrc_ok = true;
             }
         }
@@ -1148,7 +1171,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                    (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16)) {
             c->path_name = "main:fused_f32rgb_yuv444"; c->kernel_name = "sws_k_f32rgb_to_yuv444_unity";
         } else if (d->rgbsrc_ok) {
-            c->path_name = "main:rgbsrc_unity"; c->kernel_name = "sws_k_rgbsrc_unity";
+            c->path_name = "main:rgbsrc_unity"; c->kernel_name = (d->rgbsrc2_rows && !c->tune.no_rgbsrc2 && !(p.dstW & 3)) ? "sws_k_rgbsrc_unity2" : "sws_k_rgbsrc_unity";
         } else if (d->rgb444_ok) {
             c->path_name = "main:rgb_yuv444_unity"; c->kernel_name = "sws_k_rgb_yuv444_unity";
         } else if (d->striprgb_ok) {
@@ -1540,7 +1563,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         else if (vec && d->unity_h && d->unity_v && !p.no_chroma && !p.need_alpha && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 && p.dst_shift == 0 &&
                  (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16))
             ret = launch_f32rgb(L);
-        else if (d->rgbsrc_ok && vec) ret = launch_rgbsrc(L);                                             // packed RGB source, same size
+        else if (d->rgbsrc_ok && vec) { if (!launch_rgbsrc2(L)) ret = launch_rgbsrc(L); }                                             // packed RGB source, same size
         else if (d->rgb444_ok && vec) ret = launch_rgb444(L);                                             // 8-bit RGB -> planar 4:4:4, same size
         else if (d->striprgb_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_striprgb(L);   // marching strip kernel, RGB epilogue
         else if (d->mixed_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_mixed(L);   // identity luma: streaming pass + strip kernel on chroma
@@ -2621,7 +2644,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "layout_ch", &c->tune.layout_ch }, { "no_mixed", &c->tune.no_mixed }, { "no_layout_stream", &c->tune.no_layout_stream }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
         { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
         { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb },
-        { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_lds_pad_kb", &c->tune.strip_lds_pad_kb }, { "no_striprgb_direct", &c->tune.no_striprgb_direct },
+        { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_lds_pad_kb", &c->tune.strip_lds_pad_kb }, { "no_striprgb_direct", &c->tune.no_striprgb_direct }, { "no_rgbsrc2", &c->tune.no_rgbsrc2 },
         { "no_strip_short", &c->tune.no_strip_short }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "strip_short_waves", &c->tune.strip_short_waves },
         { "debug", &c->tune.debug },
     };

@@ -28,6 +28,7 @@ struct DeviceState {
     void *d_xyz = nullptr; size_t xyz_bytes = 0; void *d_xyz_tab = nullptr;   // rgb48 copies of xyz12 source pictures; the four gamma LUTs
     bool dot2_ok = false; SwsTileGeom dotL, dotC; void *d_dot2 = nullptr; size_t dot2_bytes = 0;
     const SwsRgbSrcRow *rgbsrc_rows = nullptr;             // (in d_dot2)
+    const SwsStripRow *rgbsrc2_rows = nullptr; int rgbsrc2_npv = 0;   // sws_k_rgbsrc_unity2: the chroma rows' plan entries, taps laid out against its register ring (in d_dot2, behind rgbsrc_rows)
     bool rgb444_ok = false;                                // sws_k_rgb_yuv444_unity (8-bit RGB -> planar 8-bit 4:4:4 YUV of the same size, all filters the identity)
     bool rgbsrc_ok = false;                                // sws_k_rgbsrc_unity (packed 24 / 32 bpp RGB -> 8-bit 4:2:x YUV of the same size)
     bool mixed_ok = false;                                 // identity luma (streaming plane pass) + strip kernel on the chroma planes only (launch_mixed)
@@ -131,6 +132,7 @@ int  launch_f32rgb(const LaunchCtx &L);
 // ---- k_strip.hip / k_tile.hip: fused h+v polyphase kernels for planar / semi-planar outputs (C3b, C1) ----
 int  launch_strip(const LaunchCtx &L);
 int  launch_rgbsrc(const LaunchCtx &L);
+int  launch_rgbsrc2(const LaunchCtx &L);         // k_rgbsrc2.hip: the wave-march form; 1 = launched, 0 = not its shape
 int  launch_rgbread_strip(const LaunchCtx &L);   // k_strip.hip: scaled packed 24 / 32 bpp RGB source: reader pre-pass + strip kernel on its 16-bit planes
 void launch_fullchr_rgb(const LaunchCtx &L);   // k_stream.hip
 void launch_stage_planes(const LaunchCtx &L, const int row_bytes[4], const int rows[4], bool in);   // k_stream.hip: src[k] -> dst[k] plane copies, one side 16-byte aligned

@@ -40,6 +40,21 @@ def test_scalers_and_ragged_sizes(flags, geom):
             assert path == PATH, path     # (fast bilinear has its own horizontal functions; the 2:1 chroma filters of sinc and spline have more than 16 taps)
 
 
+def test_the_wave_march_form_and_the_first_form_agree_with_the_oracle():
+    """round 4: sws_k_rgbsrc_unity2 (register ring of row pairs, v_dot2 vertical chroma) takes widths that are multiples of 4; the first form keeps the
+    others and everything under `no_rgbsrc2` -- both are compared with the oracle on the same cases"""
+    from librempeg_amd import SwsContext
+    for w, want in ((640, "sws_k_rgbsrc_unity2"), (642, "sws_k_rgbsrc_unity")):
+        p = SwsContext(w, 48, "bgra", w, 48, "nv12", SWS_BICUBIC | BX)
+        assert p.path() == PATH and p.kernel_name() == want, (w, p.kernel_name())
+        p.close()
+    for flags in (SWS_POINT, SWS_BILINEAR, SWS_BICUBIC, SWS_LANCZOS, SWS_GAUSS, SWS_AREA):
+        for src, dst in (("rgb24", "yuv420p"), ("bgra", "nv12"), ("abgr", "nv21"), ("argb", "yuv422p"), ("gbrp", "nv16"), ("rgb0", "yuv420p")):
+            for (w, h) in ((640, 96), (1028, 50), (260, 201), (4, 2), (1924, 34), (512, 7)):
+                for tune in ({}, {"no_rgbsrc2": 1}):
+                    assert run_case(w, h, src, w, h, dst, flags | BX, seed=w + h, tune=tune)[0] == PATH
+
+
 def test_other_shapes_keep_their_kernels():
     assert run_case(640, 48, "rgb24", 640, 48, "yuv444p", SWS_BICUBIC | BX)[0] != PATH          # chroma is scaled up horizontally
     assert run_case(640, 48, "rgb24", 640, 48, "yuv420p", SWS_BICUBIC | SWS_FULL_CHR_H_INP | BX)[0] != PATH
