@@ -63,6 +63,11 @@ WORKLOADS = {
            "D1 3840x2160->1920x1080 yuv420p->rgb24 SWS_BICUBIC|SWS_BITEXACT (downscale to packed RGB)"),
     "d2": (3840, 2160, "yuv420p", 1920, 1080, "bgra", SWS_BICUBIC | SWS_BITEXACT, None, 128,
            "D2 3840x2160->1920x1080 yuv420p->bgra SWS_BICUBIC|SWS_BITEXACT (downscale to packed RGB)"),
+    # the capture / render -> encoder shape (scaled packed RGB into 4:2:0): sws_k_strip_rgbsrc
+    "e1": (1920, 1080, "rgb24", 1280, 720, "yuv420p", SWS_BICUBIC | SWS_BITEXACT, None, 64,
+           "E1 1920x1080->1280x720 rgb24->yuv420p SWS_BICUBIC|SWS_BITEXACT (packed RGB source, downscale)"),
+    "e2": (3840, 2160, "bgra", 1920, 1080, "yuv420p", SWS_BICUBIC | SWS_BITEXACT, None, 32,
+           "E2 3840x2160->1920x1080 bgra->yuv420p SWS_BICUBIC|SWS_BITEXACT (packed RGB source, downscale)"),
 }
 
 

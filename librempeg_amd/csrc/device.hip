@@ -666,7 +666,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             const bool fullA = !mixedM && unity_ok && !(d->unity_h && d->unity_v && !rgb_ok && !unity_yuv) && !p.fast_bilinear && (!gray_any || gray_both || d->fullchr_on == 2 || alpha_planar || (rgb_ok && rgb_alpha)) && (src_ok || (nv_src && dst_ok) || rgbread) &&
                                (dst_ok || rgb_ok) && !p.wide && (fs_ok16 || fs_ok32 || fs_ok64) && !c->tune.no_dot2;
             const int long_form = !fullA || fs_ok16 ? 0 : fs_ok32 ? 1 : 2;
-            d->mixed_ok = false; d->stripLs_ok = d->stripCs_ok = false;
+            d->mixed_ok = false; d->stripLs_ok = d->stripCs_ok = false; d->striprgbsrc_ok = false;
             if (fullA || mixedM) {
                 const int SPC = (p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010 || rgbread) ? 8 : 16;
                 std::vector<uint8_t> blob;
@@ -974,6 +974,22 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         d->strip_ok = true;
                         d->rgbread_on = rgbread;
                         d->alpha_launch = alpha_planar ? 1 : 0;
+                        // scaled packed RGB into half-width-chroma YUV: one launch that reads the RGB rows itself (k_striprgbsrc.hip) on the same plan tables --
+                        // luma strips of 256 columns over chroma strips of 128, every strip's pixel window (luma window and twice the chroma window, from a
+                        // multiple of 16 pixels on) at most 64 lanes x 16 pixels
+                        if (rgbread && !gray_both && !long_form && !c->tune.no_strip_rgbsrc && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32) && p.chr_half &&
+                            !alpha_planar && !p.need_alpha && !d->fullchr_on && d->stripL.TW == 256 && d->stripC.TW == 128 && d->stripL.strips == d->stripC.strips &&
+                            p.chrDstW == ((p.dstW + 1) >> 1) && (p.chrDstVSub == 0 ? p.chrDstH == p.dstH : (p.chrDstVSub == 1 && p.chrDstH == ((p.dstH + 1) >> 1))) &&
+                            std::max(d->stripL.nph, d->stripC.nph) <= 8 && d->stripL.npv <= 8 && d->stripC.npv <= 12) {
+                            const int32_t *csl = (const int32_t *)(blob.data() + sL.cs), *ccl = (const int32_t *)(blob.data() + sL.cc);
+                            const int32_t *csc = (const int32_t *)(blob.data() + sC.cs), *ccc = (const int32_t *)(blob.data() + sC.cc);
+                            int npx = 0;
+                            for (int s = 0; s < d->stripL.strips; s++) {
+                                const int w0 = std::min(csl[s], 2 * csc[s]) & ~15, e = std::max(csl[s] + ccl[s], 2 * (csc[s] + ccc[s]));
+                                npx = std::max(npx, (e - w0 + 15) & ~15);
+                            }
+                            d->striprgbsrc_ok = npx <= 1024; d->striprgbsrc_npx = npx;
+                        }
                     }
                   }
                 }
@@ -1049,7 +1065,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             d->striprgb_ok = d->striprgb_ok && (all_x || (lfs == 1 && cfs == 1));
             if (d->alpha_launch == 2 && !d->striprgb_ok) d->alpha_launch = 0;
             if (d->fullchr_on && ((!all_x && !(lfs == 1 && cfs == 1) && d->fullchr_kind != DSTK_GBRP) || !d->strip_ok)) {   // (planar RGB: any_vscale, always the X form)   // no strip plan, or a row in one of the short writer forms: the generic full-chroma writer keeps it
-                d->fullchr_on = 0; d->strip_ok = false; d->rgbread_on = false;
+                d->fullchr_on = 0; d->strip_ok = false; d->rgbread_on = false; d->striprgbsrc_ok = false;
                 p.dstKind = d->fullchr_kind; p.u_plane_dst = dd->comp[1].plane; p.v_plane_dst = dd->comp[2].plane;
             }
             // a 4:4:4 planar source at the same size into a full-chroma destination: four identity filters, so the epilogue reads the source planes itself
@@ -1179,9 +1195,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         } else if (d->mixed_ok) {
             c->path_name = "main:plane1+strip_chroma"; c->kernel_name = "sws_k_strip_march";
         } else if (d->strip_ok) {
-            c->path_name = d->rgbread_on ? "main:rgbread+strip_march" : "main:strip_march";
+            c->path_name = d->rgbread_on ? ((d->striprgbsrc_ok && !c->tune.no_strip_rgbsrc) ? "main:strip_rgbsrc" : "main:rgbread+strip_march") : "main:strip_march";
             c->kernel_name = ((p.srcKind == SRCK_PLANAR16 || d->rgbread_on) && d->stripL.dma_ok && !c->tune.no_strip_dma) ? "sws_k_strip_dma" : "sws_k_strip_march";
-            if (d->stripL.nph > 8 || d->stripL.npv > 8) c->kernel_name = d->stripL.nph > 16 ? "sws_k_strip_xlong" : "sws_k_strip_long";   // (filters of 17 .. 32 / 33 .. 62 taps)
+            if (d->rgbread_on && d->striprgbsrc_ok && !c->tune.no_strip_rgbsrc) c->kernel_name = "sws_k_strip_rgbsrc";
+            else if (d->stripL.nph > 8 || d->stripL.npv > 8) c->kernel_name = d->stripL.nph > 16 ? "sws_k_strip_xlong" : "sws_k_strip_long";   // (filters of 17 .. 32 / 33 .. 62 taps)
             else if (!c->tune.no_strip_short && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {   // the short family (k_strip2.hip launch_strip_short decides per launch: this is its choice for 16-byte aligned frames)
                 const SwsStripGeom &gs = d->stripLs_ok ? d->stripLs : d->stripL;
                 const bool d8 = gs.dma8_ok && !c->tune.no_strip_dma8;
@@ -1692,7 +1709,7 @@ static size_t helper_bytes_per_frame(const SwsInternal *c, const DeviceState *d)
     if (d->fullchr_on && !d->fullchr_direct) b += 4 * a256(4 * (int64_t)p.dstW) * p.dstH + 256;
     if (d->join422) b += (a256(p.dstW) + 2 * a256(p.dstW >> 1)) * (int64_t)p.dstH + 256;
     if (d->alpha_launch == 2) b += a256(4 * (int64_t)p.dstW) * p.dstH + 256;
-    if (d->rgbread_on) b += 2 * a256(2 * (int64_t)p.srcW) * p.srcH + 2 * a256(2 * (int64_t)p.chrSrcW) * p.srcH + 512;
+    if (d->rgbread_on && !(d->striprgbsrc_ok && !c->tune.no_strip_rgbsrc)) b += 2 * a256(2 * (int64_t)p.srcW) * p.srcH + 2 * a256(2 * (int64_t)p.chrSrcW) * p.srcH + 512;
     return (size_t)b;
 }
 
@@ -2644,7 +2661,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "layout_ch", &c->tune.layout_ch }, { "no_mixed", &c->tune.no_mixed }, { "no_layout_stream", &c->tune.no_layout_stream }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
         { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
         { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb },
-        { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_lds_pad_kb", &c->tune.strip_lds_pad_kb }, { "no_striprgb_direct", &c->tune.no_striprgb_direct }, { "no_rgbsrc2", &c->tune.no_rgbsrc2 },
+        { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_lds_pad_kb", &c->tune.strip_lds_pad_kb }, { "no_striprgb_direct", &c->tune.no_striprgb_direct }, { "no_rgbsrc2", &c->tune.no_rgbsrc2 }, { "no_strip_rgbsrc", &c->tune.no_strip_rgbsrc },
         { "no_strip_short", &c->tune.no_strip_short }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "strip_short_waves", &c->tune.strip_short_waves },
         { "debug", &c->tune.debug },
     };

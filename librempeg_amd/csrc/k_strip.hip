@@ -117,6 +117,7 @@ int launch_rgbread_strip(const LaunchCtx &L)
 {
     SwsInternal *c = L.c; DeviceState *d = L.d; const SwsDevParams &p = *L.p; hipStream_t st = L.st;
     const int n = L.n;
+    if (L.vec && launch_strip_rgbsrc(L)) return 0;      // half-width-chroma YUV destinations: one launch, no working picture (k_striprgbsrc.hip)
     auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
     const int strideY = (int)a256(2 * (int64_t)p.srcW), strideC = (int)a256(2 * (int64_t)p.chrSrcW);
     const bool alpha = (d->fullchr_on == 2 || d->alpha_launch) && p.srcKind == SRCK_RGB32;     // (a scaled alpha plane behind the strip kernels: device.hip)

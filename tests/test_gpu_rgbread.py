@@ -11,7 +11,9 @@ from test_gpu_parity import run_case
 pytestmark = pytest.mark.gpu
 BX = SWS_BITEXACT
 PATH = "main:rgbread+strip_march"
-TUNE = dict(strip_min_w=0)     # (the planner keeps pictures narrower than 320 columns on the tile kernel: force the path onto oracle-sized cases)
+TUNE = dict(strip_min_w=0, no_strip_rgbsrc=1)     # (no_strip_rgbsrc: this file is about the two-pass form; the one-launch form has test_gpu_strip_rgbsrc.py)
+TWO = dict(no_strip_rgbsrc=1)
+# (the planner keeps pictures narrower than 320 columns on the tile kernel: force the path onto oracle-sized cases)
 
 SRC = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "0bgr", "gbrp", "gbrap"]   # (planar 8-bit GBR: the same readers, three planes)
 DST = ["yuv420p", "yuv422p", "yuv444p", "nv12", "nv21", "yuv420p10le", "p010le", "yuv422p12le"]
@@ -36,8 +38,8 @@ def test_scalers_and_geometries(flags, geom):
 
 
 def test_planner_and_fallbacks():
-    assert run_case(1920, 54, "rgb24", 1280, 36, "yuv420p", SWS_BICUBIC | BX)[0] == PATH                       # wide enough without the option
-    assert run_case(480, 48, "rgb24", 240, 24, "yuv420p", SWS_BICUBIC | BX)[0] != PATH                         # narrow: tile kernel
+    assert run_case(1920, 54, "rgb24", 1280, 36, "yuv420p", SWS_BICUBIC | BX, tune=TWO)[0] == PATH                       # wide enough without the option
+    assert run_case(480, 48, "rgb24", 240, 24, "yuv420p", SWS_BICUBIC | BX, tune=TWO)[0] != PATH                         # narrow: tile kernel
     assert run_case(642, 48, "rgb24", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0] != PATH              # width not a multiple of 4
     assert run_case(640, 48, "rgb24", 480, 36, "yuv420p", SWS_BILINEAR | SWS_FULL_CHR_H_INP | BX, tune=TUNE)[0] == PATH            # the full-width chroma readers
     assert run_case(640, 48, "rgb24", 320, 24, "yuv420p", SWS_BICUBIC | SWS_FULL_CHR_H_INP | BX, tune=TUNE)[0] == PATH             # (4:1 bicubic chroma, 17 taps: the strip kernel's long form)
@@ -47,10 +49,10 @@ def test_planner_and_fallbacks():
 
 
 def test_full_size_frames_and_host_frames():
-    assert run_case(1920, 1080, "rgb24", 1280, 720, "yuv420p", SWS_BICUBIC | BX, seed=2)[0] == PATH
-    assert run_case(1920, 1080, "bgra", 2560, 1440, "nv12", SWS_BILINEAR | BX, seed=3)[0] == PATH                                  # (chroma wider than half the source: full-width readers)
-    assert run_case(1920, 1080, "bgra", 3840, 2160, "nv12", SWS_BILINEAR | BX, seed=3)[0] == PATH                                  # (2x: the chroma planes are not scaled at all: one-tap filters)
-    assert run_case(2560, 1440, "rgb24", 1920, 1080, "yuv420p10le", SWS_LANCZOS | BX, seed=4, device_frames=False)[0] == PATH
+    assert run_case(1920, 1080, "rgb24", 1280, 720, "yuv420p", SWS_BICUBIC | BX, seed=2, tune=TWO)[0] == PATH
+    assert run_case(1920, 1080, "bgra", 2560, 1440, "nv12", SWS_BILINEAR | BX, seed=3, tune=TWO)[0] == PATH                                  # (chroma wider than half the source: full-width readers)
+    assert run_case(1920, 1080, "bgra", 3840, 2160, "nv12", SWS_BILINEAR | BX, seed=3, tune=TWO)[0] == PATH                                  # (2x: the chroma planes are not scaled at all: one-tap filters)
+    assert run_case(2560, 1440, "rgb24", 1920, 1080, "yuv420p10le", SWS_LANCZOS | BX, seed=4, device_frames=False, tune=TWO)[0] == PATH
 
 
 def test_batches():
@@ -61,6 +63,7 @@ def test_batches():
     for src, dst, sw, sh, dw, dh, n, flags in (("rgb24", "yuv420p", 1284, 70, 1028, 56, 5, SWS_BICUBIC | BX), ("bgra", "nv12", 1024, 130, 1536, 190, 3, SWS_LANCZOS | BX)):
         o = OL.Oracle(sw, sh, src, dw, dh, dst, flags)
         p = SwsContext(sw, sh, src, dw, dh, dst, flags)
+        p.set_option("no_strip_rgbsrc", 1)
         refs, srcs, dsts = [], [], []
         for k in range(n):
             s = OL.fill_random(OL.Frame(src, sw, sh), 40 + k)

@@ -76,9 +76,9 @@ def test_long_vertical_chroma_filters(flags):
             for (sw, sh, dw, dh) in ((640, 128, 320, 64), (1288, 96, 644, 48), (520, 200, 300, 100)):
                 path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, flags | BX, seed=sw + dh, tune=tune)
                 if flags == SWS_BICUBIC and (sw, dw) != (520, 300):
-                    assert path in ("main:strip_march", "main:rgbread+strip_march"), (path, sfmt, dfmt, sw, dw)
+                    assert path in ("main:strip_march", "main:rgbread+strip_march", "main:strip_rgbsrc"), (path, sfmt, dfmt, sw, dw)
     # full size: 4K capture into a 1080p 4:2:0 picture
-    assert run_case(3840, 2160, "bgra", 1920, 1080, "yuv420p", SWS_BICUBIC | BX, seed=5)[0] == "main:rgbread+strip_march"
+    assert run_case(3840, 2160, "bgra", 1920, 1080, "yuv420p", SWS_BICUBIC | BX, seed=5)[0] == "main:strip_rgbsrc"
     assert run_case(3840, 2160, "yuv422p10le", 1920, 1080, "yuv420p", SWS_BICUBIC | BX, seed=6)[0] == "main:strip_march"
 
 
@@ -169,7 +169,7 @@ def test_unity_conversions_without_a_special_converter(pair):
                                  (256, 40, 256, 96, SWS_LANCZOS), (1280, 36, 1280, 24, SWS_AREA)):
         path, _ = run_case(sw, sh, sf, dw, dh, df, fl | BX, seed=sw + dh, tune=STRIP if sw < 1024 else None)
         if (sw, sh) == (1920, 32):
-            assert "strip_march" in path or "strip_chroma" in path or path.startswith("unscaled:"), (path, sf, df)   # (p010le -> nv12: planarCopy)
+            assert "strip_march" in path or "strip_chroma" in path or path == "main:strip_rgbsrc" or path.startswith("unscaled:"), (path, sf, df)   # (p010le -> nv12: planarCopy)
 
 
 def test_p010_to_rgb_at_the_same_size():
