@@ -977,7 +977,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         // scaled packed RGB into half-width-chroma YUV: one launch that reads the RGB rows itself (k_striprgbsrc.hip) on the same plan tables --
                         // luma strips of 256 columns over chroma strips of 128, every strip's pixel window (luma window and twice the chroma window, from a
                         // multiple of 16 pixels on) at most 64 lanes x 16 pixels
-                        if (rgbread && !gray_both && !long_form && !c->tune.no_strip_rgbsrc && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32) && p.chr_half &&
+                        if (rgbread && !gray_both && !long_form && !c->tune.no_strip_rgbsrc && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chr_half &&
                             !alpha_planar && !p.need_alpha && !d->fullchr_on && d->stripL.TW == 256 && d->stripC.TW == 128 && d->stripL.strips == d->stripC.strips &&
                             p.chrDstW == ((p.dstW + 1) >> 1) && (p.chrDstVSub == 0 ? p.chrDstH == p.dstH : (p.chrDstVSub == 1 && p.chrDstH == ((p.dstH + 1) >> 1))) &&
                             std::max(d->stripL.nph, d->stripC.nph) <= 8 && d->stripL.npv <= 8 && d->stripC.npv <= 12) {

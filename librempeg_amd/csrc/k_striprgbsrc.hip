@@ -1,6 +1,6 @@
 // Translation unit of the marching strip kernel for scaled packed-RGB sources (kernels_striprgbsrc.hpp: bgra / rgb24 ... -> planar / semi-planar YUV
 // with half-width chroma in one launch, no reader pre-pass).  Compiled once per (bytes per pixel, luma ring depth) part
-// (-DRSRC_BPP=3|4 -DRSRC_RL=5|8) so that the chroma ring depths and horizontal tap counts of a part build in parallel with the other parts;
+// (-DRSRC_BPP=0|3|4 -DRSRC_RL=5|8; 0 = planar G / B / R) so that the chroma ring depths and horizontal tap counts of a part build in parallel with the other parts;
 // without the macros it compiles the launcher.
 #include <algorithm>
 #include <map>
@@ -12,6 +12,7 @@ namespace swship {
 typedef void (*StripRgbSrcFn)(SwsFrameSet, SwsDevParams, SwsStripGeom, SwsStripGeom, int, int);
 StripRgbSrcFn striprgbsrc_fn_b3l5(int nph, int rc, int ng); StripRgbSrcFn striprgbsrc_fn_b3l8(int nph, int rc, int ng);
 StripRgbSrcFn striprgbsrc_fn_b4l5(int nph, int rc, int ng); StripRgbSrcFn striprgbsrc_fn_b4l8(int nph, int rc, int ng);
+StripRgbSrcFn striprgbsrc_fn_b0l5(int nph, int rc, int ng); StripRgbSrcFn striprgbsrc_fn_b0l8(int nph, int rc, int ng);   // (0: planar 8-bit G, B, R planes)
 }
 
 #ifndef RSRC_BPP
@@ -47,7 +48,8 @@ int launch_strip_rgbsrc(const LaunchCtx &L)
     const bool b4 = p.srcKind == SRCK_RGB32;
     const int npx = d->striprgbsrc_npx;
     const int ng = npx <= 512 ? 2 : 4;                  // groups of four pixels per lane the widest strip window needs
-    StripRgbSrcFn fn = b4 ? (l8 ? striprgbsrc_fn_b4l8(nph, rc, ng) : striprgbsrc_fn_b4l5(nph, rc, ng)) : (l8 ? striprgbsrc_fn_b3l8(nph, rc, ng) : striprgbsrc_fn_b3l5(nph, rc, ng));
+    StripRgbSrcFn fn = p.srcKind == SRCK_GBRP ? (l8 ? striprgbsrc_fn_b0l8(nph, rc, ng) : striprgbsrc_fn_b0l5(nph, rc, ng)) :
+                       b4 ? (l8 ? striprgbsrc_fn_b4l8(nph, rc, ng) : striprgbsrc_fn_b4l5(nph, rc, ng)) : (l8 ? striprgbsrc_fn_b3l8(nph, rc, ng) : striprgbsrc_fn_b3l5(nph, rc, ng));
     if (!fn) return 0;
     const int wave_dw = 2 * (npx + 16);                 // two Y rows of npx + 16 samples, four chroma rows of half as many (u16)
     const int lds = 4 * wave_dw * 4 + 64;

@@ -11,8 +11,12 @@
 // Schedule: a wave owns a strip of 256 luma columns and the 128 chroma columns under them and walks down a band of output rows.  Luma and chroma
 // march in LOCKSTEP over the source row pairs (the half readers give chroma planes of the source height: both plane classes consume every source
 // row), so one set of loads feeds both:
-//  * per step and lane: 16 pixels of the two rows of a pair (3 or 4 buffer_load_dwordx4 per row, the next pair in flight while this one is
-//    computed) -> 16 Y + 8 U + 8 V reader values per row, written as u16 rows of the strip's window (the same rows the 16-bit strip kernel stages);
+//  * per step: the window's pixels of the two rows of a pair in groups of FOUR per lane (one 12- or 16-byte buffer load per row and group: group g
+//    belongs to lane g % 64 in turn g / 64, so a turn is one fully coalesced 768- or 1024-byte wave load; a 1.5:1 strip's 400 pixels take two turns,
+//    a 2:1 strip's 528 three -- the turn count is wave-uniform and the code of unused turns is branched over; lanes of 16 pixels, the first form,
+//    left 60 % of the lanes converting zeros), the next pair's loads in flight while this one is computed -> per group 4 Y + 2 U + 2 V reader
+//    values per row (v_perm byte pairs, v_dot2_i32_i16 against per-byte-position coefficient pairs with the rounding constant as the addend),
+//    written as u16 rows of the strip's window (the same rows the 16-bit strip kernel stages);
 //  * the horizontal stage (strip_hstage: v_dot2_i32_i16 against taps held in registers) turns the pair into one packed dword per column and
 //    component and pushes it into the register rings (luma RL deep, chroma RC deep);
 //  * every luma / chroma output row whose last source pair this was leaves through the vertical stage (scalar tap pairs, 64-byte plan entries)
@@ -20,6 +24,10 @@
 //    emitted row's last pair.
 // The plan tables are the ones the two-pass form uses (d->stripL / d->stripC: windows in reader samples); the pixel window of a strip is the union
 // of its luma window and twice its chroma window, rounded to 16 pixels.
+// Bound: instruction issue (rocprofv3 PMC, E1 = rgb24 1080p -> yuv420p 720p: 1.66 M vector instructions per frame, two thirds of them the reader
+// arithmetic before the group form; VALU busy 68 % at two waves per SIMD).  What moved it: groups of four pixels (-45 % reader instructions),
+// instantiations with two turns for windows of up to 512 pixels (162 VGPRs: three waves per SIMD), constants folded into the dot2 addends.
+// What did not: two row pairs in flight (+32 VGPRs, same time -- it is not latency).
 #pragma once
 #include <type_traits>
 
@@ -158,6 +166,11 @@ __device__ __forceinline__ void rgb4px_read(const GT &d, const RgbReadCoefs &k, 
     if constexpr (BPP == 4) {
 #pragma unroll
         for (int i = 0; i < 4; i++) { lo[i] = d[i] & 0x00FF00FFu; hi[i] = __builtin_amdgcn_perm(0, d[i], 0x0c030c01u); }
+    } else if constexpr (BPP == 0) {   // planar 8-bit G, B, R planes (gbrp, gbrap without its alpha: planar_rgb_to_y / gbr24pToUV_half_c, input.c:1174-1186, :414-432): d[0] = four G, d[1] = four B, d[2] = four R; a pixel is assembled as {R, B} / {G} halves, i.e. r, g, b at bytes 0, 1, 2
+        lo[0] = __builtin_amdgcn_perm(d[1], d[2], 0x0c040c00u); hi[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c00u);
+        lo[1] = __builtin_amdgcn_perm(d[1], d[2], 0x0c050c01u); hi[1] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c01u);
+        lo[2] = __builtin_amdgcn_perm(d[1], d[2], 0x0c060c02u); hi[2] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c02u);
+        lo[3] = __builtin_amdgcn_perm(d[1], d[2], 0x0c070c03u); hi[3] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c03u);
     } else {
         lo[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c020c00u); hi[0] = __builtin_amdgcn_perm(d[0], d[0], 0x0c0c0c01u);
         lo[1] = __builtin_amdgcn_perm(d[1], d[0], 0x0c050c03u); hi[1] = __builtin_amdgcn_perm(d[1], d[0], 0x0c0c0c04u);
@@ -229,7 +242,7 @@ __device__ __forceinline__ void strip_rgbsrc_body(const FrameRegs &f, const SwsD
     RgbReadCoefs rk;
     {
         const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);
-        const int rp = U(p.src_r_pos), gp = BPP == 4 ? U(p.src_g_pos) : 1, bp = U(p.src_b_pos);
+        const int rp = BPP == 0 ? 0 : U(p.src_r_pos), gp = BPP == 4 ? U(p.src_g_pos) : 1, bp = BPP == 0 ? 2 : U(p.src_b_pos);
         auto coef = [&](const Rgb2YuvRow &w, int k) { return (uint32_t)(uint16_t)(k == rp ? w.r : k == gp ? w.g : k == bp ? w.b : 0); };
         rk.yA = coef(ty, 0) | coef(ty, 2) << 16; rk.yB = coef(ty, 1) | coef(ty, 3) << 16;
         rk.uA = coef(tu, 0) | coef(tu, 2) << 16; rk.uB = coef(tu, 1) | coef(tu, 3) << 16;
@@ -237,7 +250,11 @@ __device__ __forceinline__ void strip_rgbsrc_body(const FrameRegs &f, const SwsD
     }
     const int sst = f.srcStride[0];
     const sws_rsrc_t rs = make_rsrc(f.src[0], (uint32_t)sst * (uint32_t)sH);
-    const int vbase = (w0 + 4 * lane) * BPP;
+    // (planar RGB: the B and R planes; packed sources never touch these)
+    const int sst1 = BPP == 0 ? U(f.srcStride[1]) : sst, sst2 = BPP == 0 ? U(f.srcStride[2]) : sst;
+    const sws_rsrc_t rs1 = BPP == 0 ? make_rsrc(f.src[1], (uint32_t)sst1 * (uint32_t)sH) : rs, rs2 = BPP == 0 ? make_rsrc(f.src[2], (uint32_t)sst2 * (uint32_t)sH) : rs;
+    constexpr int PXB = BPP ? BPP : 1;                          // bytes per pixel and plane
+    const int vbase = (w0 + 4 * lane) * PXB;
     rk.ky = (32 << 14) + (1 << 8); rk.kc = (256 << 15) + (1 << 9);
 
     // ONE row pair in flight per wave, requested before the pair in LDS is h-scaled (two in flight, measured: no gain -- at 2 - 3 waves per SIMD the
@@ -249,10 +266,15 @@ __device__ __forceinline__ void strip_rgbsrc_body(const FrameRegs &f, const SwsD
         for (int j = 0; j < NG; j++)
             if (j < ng) {
                 // (beyond the window: the descriptor answers 0 without touching memory)
-                const int vo = lane + 64 * j < n4 ? vbase + j * (256 * BPP) : 0x7fffffff;
+                const int vo = lane + 64 * j < n4 ? vbase + j * (256 * PXB) : 0x7fffffff;
                 if constexpr (BPP == 4) {
                     pre[0][j] = bload16(rs, vo, r0 * sst);
                     pre[1][j] = bload16(rs, vo, r1 * sst);
+                } else if constexpr (BPP == 0) {
+                    pre[0][j][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, r0 * sst, 0); pre[0][j][1] = __builtin_amdgcn_raw_buffer_load_b32(rs1, vo, r0 * sst1, 0);
+                    pre[0][j][2] = __builtin_amdgcn_raw_buffer_load_b32(rs2, vo, r0 * sst2, 0);
+                    pre[1][j][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, r1 * sst, 0); pre[1][j][1] = __builtin_amdgcn_raw_buffer_load_b32(rs1, vo, r1 * sst1, 0);
+                    pre[1][j][2] = __builtin_amdgcn_raw_buffer_load_b32(rs2, vo, r1 * sst2, 0);
                 } else {
                     pre[0][j] = __builtin_bit_cast(rsrc_u32x3, __builtin_amdgcn_raw_buffer_load_b96(rs, vo, r0 * sst, 0));
                     pre[1][j] = __builtin_bit_cast(rsrc_u32x3, __builtin_amdgcn_raw_buffer_load_b96(rs, vo, r1 * sst, 0));

@@ -18,7 +18,7 @@ BX = SWS_BITEXACT
 AR = SWS_ACCURATE_RND
 
 
-def _forensics(p, out, ref, src_frame, dst_frame, hs, prefill):
+def _forensics(p, out, ref, src_frame, dst_frame, hs, prefill, redo=None):
     """what a parity failure looks like (the rare unreproduced failures): per plane how many bytes differ and whether the wrong bytes are
     zeros or still the prefill; whether a second read of the same destination gives other bytes (a late writer); whether the source the GPU holds
     still equals what was uploaded; whether running the same context again gives the right answer."""
@@ -39,6 +39,11 @@ def _forensics(p, out, ref, src_frame, dst_frame, hs, prefill):
             p.scale(src_frame, dst_frame); p.sync()
             rerun = dst_frame.download()
             info.append("rerun on the same context equals the oracle: " + str(all(np.array_equal(x[:, :r], y[:, :r]) for x, y, r in zip(rerun.planes, ref.planes, rerun.row_bytes))))
+        if redo is not None:     # the oracle once more, and a FRESH context on the same input: whose answer was the odd one?
+            ref2, out2 = redo()
+            info.append("oracle recomputed equals its first answer: " + str(all(np.array_equal(x, y) for x, y in zip(ref2.planes, ref.planes))))
+            info.append("a fresh context equals the oracle: " + str(all(np.array_equal(x[:, :r], y[:, :r]) for x, y, r in zip(out2.planes, ref2.planes, out2.row_bytes))))
+            info.append("a fresh context equals the failed output: " + str(all(np.array_equal(x[:, :r], y[:, :r]) for x, y, r in zip(out2.planes, out.planes, out2.row_bytes))))
         return " || forensics: " + "; ".join(info)
     except Exception as e:   # never mask the original failure
         return f" || forensics failed: {e!r}"
@@ -76,6 +81,23 @@ def run_case(sw, sh, sfmt, dw, dh, dfmt, flags, seed=1, colorspace=None, device_
         ret = p.scale(hs, hd)
         out = hd
     assert ret >= 0, f"sws_scale returned {ret}"
+
+    def redo():
+        o2 = OL.Oracle(sw, sh, sfmt, dw, dh, dfmt, flags, **(opts or {}))
+        p2 = SwsContext(sw, sh, sfmt, dw, dh, dfmt, flags, **(opts or {}))
+        for k, v in (tune or {}).items():
+            p2.set_option(k, v)
+        if colorspace:
+            o2.set_colorspace(*colorspace); p2.set_colorspace(*colorspace)
+        ref2 = OL.Frame(dfmt, dw, dh, fill=prefill)
+        o2.scale(src, ref2)
+        hd2 = HostFrame(dfmt, dw, dh)
+        for a in hd2.planes:
+            a[:] = prefill
+        p2.scale(hs, hd2)
+        p2.close()
+        return ref2, hd2
+
     for i, (a, b) in enumerate(zip(out.planes, ref.planes)):
         rb = out.row_bytes[i]
         if dfmt in ("monob", "monow") and (dw & 7):   # bits past the width in the last byte are outside the picture (the unscaled
@@ -87,7 +109,7 @@ def run_case(sw, sh, sfmt, dw, dh, dfmt, flags, seed=1, colorspace=None, device_
             y, x = bad[0]
             raise AssertionError(f"{sfmt}->{dfmt} {sw}x{sh}->{dw}x{dh} flags={flags:#x} path={p.path()} plane {i}: "
                                  f"{len(bad)} bytes differ, first at row {y} byte {x}: got {a[y, x]} want {b[y, x]}"
-                                 + _forensics(p, out, ref, ds if device_frames else hs, dd if device_frames else hd, hs, prefill))
+                                 + _forensics(p, out, ref, ds if device_frames else hs, dd if device_frames else hd, hs, prefill, redo))
     return p.path(), o.path()
 
 

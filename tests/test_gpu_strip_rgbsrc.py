@@ -14,7 +14,7 @@ BX = SWS_BITEXACT
 PATH = "main:strip_rgbsrc"
 TUNE = dict(strip_min_w=0)     # (the planner keeps pictures narrower than 320 columns on the tile kernel: force the path onto oracle-sized cases)
 
-SRC = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "0bgr"]
+SRC = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "0bgr", "gbrp", "gbrap"]   # (planar 8-bit GBR: the same readers, three planes)
 DST = ["yuv420p", "yuv422p", "nv12", "nv21", "yuv420p10le", "p010le", "yuv422p12le", "yuv420p16le", "yuv420p9be", "nv16", "p012be"]
 
 
@@ -35,7 +35,7 @@ def test_formats(src, dst):
                          ids=lambda g: f"{g[0]}x{g[1]}-{g[2]}x{g[3]}")
 def test_scalers_and_geometries(flags, geom):
     sw, sh, dw, dh = geom
-    for src, dst in (("rgb24", "yuv420p"), ("bgra", "nv12"), ("argb", "yuv422p10le"), ("bgr24", "p010le")):
+    for src, dst in (("rgb24", "yuv420p"), ("bgra", "nv12"), ("argb", "yuv422p10le"), ("bgr24", "p010le"), ("gbrp", "yuv420p")):
         run_case(sw, sh, src, dw, dh, dst, flags | BX, seed=7, tune=TUNE)
 
 
@@ -46,7 +46,8 @@ def test_planner_and_fallbacks():
     assert run_case(642, 48, "rgb24", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0] != PATH              # width not a multiple of 4
     assert run_case(640, 48, "rgb24", 480, 36, "yuv420p", SWS_BILINEAR | SWS_FULL_CHR_H_INP | BX, tune=TUNE)[0] == "main:rgbread+strip_march"   # the full-width chroma readers
     assert run_case(640, 48, "rgb24", 480, 36, "yuv444p", SWS_BILINEAR | BX, tune=TUNE)[0] == "main:rgbread+strip_march"    # full-width chroma planes
-    assert run_case(640, 48, "gbrp", 480, 36, "yuv420p", SWS_BILINEAR | BX, tune=TUNE)[0] == "main:rgbread+strip_march"     # planar RGB
+    assert run_case(640, 48, "gbrp", 480, 36, "yuv420p", SWS_BILINEAR | BX, tune=TUNE)[0] == PATH                           # planar RGB: three planes, the same readers
+    assert run_case(640, 48, "gbrp10le", 480, 36, "yuv420p", SWS_BILINEAR | BX, tune=TUNE)[0] != PATH                       # (deeper planar RGB: other readers)
     assert run_case(640, 48, "rgba", 320, 24, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0] == "main:rgbread+strip_march+alpha"
     assert run_case(1280, 96, "rgb24", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0] == "main:rgbread+strip_march"    # 17 taps: the long forms
     assert run_case(640, 48, "rgb24", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=TUNE)[0] not in (PATH,)      # a range conversion
@@ -57,6 +58,7 @@ def test_full_size_frames_and_host_frames():
     assert run_case(3840, 2160, "bgra", 1920, 1080, "yuv420p", SWS_BICUBIC | BX, seed=3)[0] == PATH            # (chroma: a 4:1 vertical step, 17 taps: the ring of 12 row pairs)
     assert run_case(3840, 2160, "bgra", 1920, 1080, "nv12", SWS_BILINEAR | BX, seed=5)[0] == PATH
     assert run_case(1920, 1080, "bgra", 1280, 720, "p010le", SWS_LANCZOS | BX, seed=6)[0] == PATH
+    assert run_case(1920, 1080, "gbrp", 1280, 720, "yuv420p", SWS_BICUBIC | BX, seed=9)[0] == PATH
     assert run_case(2560, 1440, "rgb24", 1920, 1080, "yuv420p10le", SWS_LANCZOS | BX, seed=4, device_frames=False)[0] == PATH
     assert run_case(1280, 720, "bgra", 1920, 1080, "yuv420p", SWS_BICUBIC | BX, seed=8)[0] in (PATH, "main:rgbread+strip_march")   # (up: chroma wider than half the source takes the full-width readers)
 
