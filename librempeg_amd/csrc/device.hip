@@ -977,7 +977,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         // scaled packed RGB into half-width-chroma YUV: one launch that reads the RGB rows itself (k_striprgbsrc.hip) on the same plan tables --
                         // luma strips of 256 columns over chroma strips of 128, every strip's pixel window (luma window and twice the chroma window, from a
                         // multiple of 16 pixels on) at most 64 lanes x 16 pixels
-                        if (rgbread && !gray_both && !long_form && !c->tune.no_strip_rgbsrc && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chr_half &&
+                        // (packed 8-bit 4:2:2 sources -- yuyv422 / uyvy422 / yvyu422 -- have the same shape: chroma samples under pixel pairs on every source row;
+                        //  the kernel's byte-selector reader takes them from the caller's frame, without the split pass: striprgb_direct = 3)
+                        const bool packed422_src = (d->split_mode & 3) && !(d->split_mode & 40) && p.srcKind == SRCK_PLANAR8 && p.chrSrcW == (p.srcW >> 1) && p.chrSrcVSub == 0 && !p.range_active && !vlines_pending;
+                        if (((rgbread && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chr_half) || packed422_src) && !gray_both && !long_form && !c->tune.no_strip_rgbsrc &&
                             !alpha_planar && !p.need_alpha && !d->fullchr_on && d->stripL.TW == 256 && d->stripC.TW == 128 && d->stripL.strips == d->stripC.strips &&
                             p.chrDstW == ((p.dstW + 1) >> 1) && (p.chrDstVSub == 0 ? p.chrDstH == p.dstH : (p.chrDstVSub == 1 && p.chrDstH == ((p.dstH + 1) >> 1))) &&
                             std::max(d->stripL.nph, d->stripC.nph) <= 8 && d->stripL.npv <= 8 && d->stripC.npv <= 12) {
@@ -989,6 +992,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                                 npx = std::max(npx, (e - w0 + 15) & ~15);
                             }
                             d->striprgbsrc_ok = npx <= 1024; d->striprgbsrc_npx = npx;
+                            if (packed422_src) d->striprgb_direct = d->striprgbsrc_ok ? 3 : 0;
                         }
                     }
                   }
@@ -1222,6 +1226,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     // (nvdirect: the strip-RGB kernel reads the semi-planar source itself on 16-byte aligned frames -- launch_plan_le falls back to the split pass otherwise)
     if (c->plan == PLAN_MAIN && d->split_mode) c->path_name = ((d->split_mode & 40) ? ((d->striprgb_ok && d->striprgb_direct && !c->tune.no_striprgb_direct) ? "main:nvdirect+" : "main:splitnv+") : "main:split422+") +
                                                              c->path_name.substr(c->path_name.find(':') + 1);
+    if (c->plan == PLAN_MAIN && d->split_mode && d->striprgb_direct == 3 && d->strip_ok && d->striprgbsrc_ok && !d->mixed_ok && !d->striprgb_ok && !d->fullchr_on && !d->alpha_launch && !d->rgbread_on &&
+        !c->tune.no_strip_rgbsrc) { c->path_name = "main:strip_packed422"; c->kernel_name = "sws_k_strip_rgbsrc"; }     // (aligned frames; launch_plan_le falls back to split422 + strip_march otherwise)
     if (c->plan == PLAN_MAIN && d->join422) c->path_name += "+join422";
     if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += d->fullchr_on == 3 ? "+lut_rgb" : "+fullchr_rgb";
     if (c->plan == PLAN_MAIN && d->fullchr_on && d->fullchr_direct) { c->path_name = "main:fullchr_rgb_direct"; c->kernel_name = d->fullchr_kind == DSTK_GBRP ? "sws_k_fullchr_gbrp" : "sws_k_fullchr_rgb"; }
@@ -1442,7 +1448,9 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
     // packed 4:2:2 source through the planar kernels (dev_prepare_on): de-interleave into a planar 4:2:2 working picture per frame first
     std::vector<SwsFramePtrs> s422fr, s422split;
     // (a semi-planar source the strip-RGB kernel reads itself: no split pass on aligned frames)
-    d->striprgb_direct_now = c->plan == PLAN_MAIN && d->split_mode && d->striprgb_direct && d->striprgb_ok && !c->tune.no_striprgb_direct &&
+    // (... or a packed 4:2:2 source the lockstep strip kernel reads itself: striprgb_direct == 3, k_striprgbsrc.hip)
+    const bool direct422 = d->striprgb_direct == 3 && d->strip_ok && d->striprgbsrc_ok && !d->mixed_ok && !d->striprgb_ok && !d->fullchr_on && !d->alpha_launch && !d->rgbread_on && !c->tune.no_strip_rgbsrc;
+    d->striprgb_direct_now = c->plan == PLAN_MAIN && d->split_mode && d->striprgb_direct && ((d->striprgb_ok && d->striprgb_direct != 3 && !c->tune.no_striprgb_direct) || direct422) &&
                              frames_vec_ok(frames, n) && frames_desc_ok(frames, n, p.srcH, p.dstH);
     if (c->plan == PLAN_MAIN && d->split_mode && !d->striprgb_direct_now) {
         auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
@@ -1584,7 +1592,12 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         else if (d->rgb444_ok && vec) ret = launch_rgb444(L);                                             // 8-bit RGB -> planar 4:4:4, same size
         else if (d->striprgb_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_striprgb(L);   // marching strip kernel, RGB epilogue
         else if (d->mixed_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_mixed(L);   // identity luma: streaming pass + strip kernel on chroma
-        else if (d->strip_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = d->rgbread_on ? launch_rgbread_strip(L) : launch_strip(L);   // marching strip kernel
+        else if (d->strip_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) {   // marching strip kernel
+            if (d->rgbread_on) ret = launch_rgbread_strip(L);
+            else if (d->striprgb_direct_now && d->striprgb_direct == 3) {
+                if (!launch_strip_rgbsrc(L)) { log_msg(c, 0, "internal error: no lockstep strip kernel for a packed 4:2:2 source whose split pass was skipped\n"); return SWS_AVERROR(EINVAL); }
+            } else ret = launch_strip(L);
+        }
         else if (d->dot2_ok && vec) ret = launch_tile_dot2(L);                                              // dot2 LDS-tile kernel
         else if (d->tile_ok) ret = launch_tile(L);                                                          // fused h+v LDS-tile kernel
         else ret = launch_generic(L);                                                                       // optional pass 1 into scratch, then writers

@@ -1,6 +1,6 @@
 // Translation unit of the marching strip kernel for scaled packed-RGB sources (kernels_striprgbsrc.hpp: bgra / rgb24 ... -> planar / semi-planar YUV
 // with half-width chroma in one launch, no reader pre-pass).  Compiled once per (bytes per pixel, luma ring depth) part
-// (-DRSRC_BPP=0|3|4 -DRSRC_RL=5|8; 0 = planar G / B / R) so that the chroma ring depths and horizontal tap counts of a part build in parallel with the other parts;
+// (-DRSRC_BPP=0|2|3|4 -DRSRC_RL=5|8; 0 = planar G / B / R, 2 = packed 8-bit 4:2:2) so that the chroma ring depths and horizontal tap counts of a part build in parallel with the other parts;
 // without the macros it compiles the launcher.
 #include <algorithm>
 #include <map>
@@ -13,6 +13,7 @@ typedef void (*StripRgbSrcFn)(SwsFrameSet, SwsDevParams, SwsStripGeom, SwsStripG
 StripRgbSrcFn striprgbsrc_fn_b3l5(int nph, int rc, int ng); StripRgbSrcFn striprgbsrc_fn_b3l8(int nph, int rc, int ng);
 StripRgbSrcFn striprgbsrc_fn_b4l5(int nph, int rc, int ng); StripRgbSrcFn striprgbsrc_fn_b4l8(int nph, int rc, int ng);
 StripRgbSrcFn striprgbsrc_fn_b0l5(int nph, int rc, int ng); StripRgbSrcFn striprgbsrc_fn_b0l8(int nph, int rc, int ng);   // (0: planar 8-bit G, B, R planes)
+StripRgbSrcFn striprgbsrc_fn_b2l5(int nph, int rc, int ng); StripRgbSrcFn striprgbsrc_fn_b2l8(int nph, int rc, int ng);   // (2: packed 8-bit 4:2:2 -- yuyv422 / uyvy422 / yvyu422)
 }
 
 #ifndef RSRC_BPP
@@ -48,7 +49,9 @@ int launch_strip_rgbsrc(const LaunchCtx &L)
     const bool b4 = p.srcKind == SRCK_RGB32;
     const int npx = d->striprgbsrc_npx;
     const int ng = npx <= 512 ? 2 : 4;                  // groups of four pixels per lane the widest strip window needs
-    StripRgbSrcFn fn = p.srcKind == SRCK_GBRP ? (l8 ? striprgbsrc_fn_b0l8(nph, rc, ng) : striprgbsrc_fn_b0l5(nph, rc, ng)) :
+    // (a packed 4:2:2 source whose split pass launch_plan_le skipped: the planner's parameters describe the planar working picture)
+    const bool packed422 = d->striprgb_direct_now && d->striprgb_direct == 3;
+    StripRgbSrcFn fn = packed422 ? (l8 ? striprgbsrc_fn_b2l8(nph, rc, ng) : striprgbsrc_fn_b2l5(nph, rc, ng)) : p.srcKind == SRCK_GBRP ? (l8 ? striprgbsrc_fn_b0l8(nph, rc, ng) : striprgbsrc_fn_b0l5(nph, rc, ng)) :
                        b4 ? (l8 ? striprgbsrc_fn_b4l8(nph, rc, ng) : striprgbsrc_fn_b4l5(nph, rc, ng)) : (l8 ? striprgbsrc_fn_b3l8(nph, rc, ng) : striprgbsrc_fn_b3l5(nph, rc, ng));
     if (!fn) return 0;
     const int wave_dw = 2 * (npx + 16);                 // two Y rows of npx + 16 samples, four chroma rows of half as many (u16)

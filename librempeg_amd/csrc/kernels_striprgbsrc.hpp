@@ -162,6 +162,11 @@ struct RgbReadCoefs { uint32_t yA, yB, uA, uB, vA, vB; int ky, kc; };
 template <int BPP, typename GT>
 __device__ __forceinline__ void rgb4px_read(const GT &d, const RgbReadCoefs &k, u32x2 &yo, uint32_t &uo, uint32_t &vo)
 {
+    if constexpr (BPP == 2) {       // packed 8-bit 4:2:2 (yuyv422 / uyvy422 / yvyu422: yuy2ToY_c / yuy2ToUV_c / uyvyTo*_c / yvy2ToUV_c, input.c:550-578, :890-907): bytes, picked by selectors
+        yo[0] = __builtin_amdgcn_perm(0, d[0], k.yA); yo[1] = __builtin_amdgcn_perm(0, d[1], k.yA);
+        uo = __builtin_amdgcn_perm(d[1], d[0], k.uA); vo = __builtin_amdgcn_perm(d[1], d[0], k.vA);
+        return;
+    } else {
     uint32_t lo[4], hi[4];          // per pixel: {byte 0, byte 2} and {byte 1, byte 3 (0 for 24 bpp)} as 16-bit halves
     if constexpr (BPP == 4) {
 #pragma unroll
@@ -195,6 +200,7 @@ __device__ __forceinline__ void rgb4px_read(const GT &d, const RgbReadCoefs &k, 
     }
     yo[0] = __builtin_amdgcn_perm(yv[1], yv[0], 0x05040100u); yo[1] = __builtin_amdgcn_perm(yv[3], yv[2], 0x05040100u);
     uo = __builtin_amdgcn_perm(uu[1], uu[0], 0x05040100u); vo = __builtin_amdgcn_perm(vv[1], vv[0], 0x05040100u);
+    }
 }
 
 template <int BPP, int NPH, int RL, int RC, int NG>
@@ -204,7 +210,7 @@ __device__ __forceinline__ void strip_rgbsrc_body(const FrameRegs &f, const SwsD
     constexpr int CL = 4, CC = 2;
     // NG: groups of four pixels per lane and source row the instantiation takes (group g of the window: lane g % 64, turn g / 64): 2 = windows of
     // up to 512 pixels (ratios up to about 1.9:1), 4 = up to 1024; the staging registers are 2 * NG * 3 or 4 dwords
-    typedef typename std::conditional<BPP == 4, u32x4, rsrc_u32x3>::type GT;
+    typedef typename std::conditional<BPP == 4, u32x4, typename std::conditional<BPP == 2, u32x2, rsrc_u32x3>::type>::type GT;
     const int W = p.dstW, H = p.dstH, cW = p.chrDstW, cH = p.chrDstH, sH = p.srcH, sh = p.hshift;
     const int vs = p.chrDstVSub;
     const int cy0 = y0 >> vs, cy1 = min(cH, (y1 + (1 << vs) - 1) >> vs);
@@ -240,7 +246,12 @@ __device__ __forceinline__ void strip_rgbsrc_body(const FrameRegs &f, const SwsD
     }
     // reader coefficients per byte position, packed for v_dot2_i32_i16 against {byte 0, byte 2} / {byte 1, byte 3} halves (kernels_rgbsrc.hpp)
     RgbReadCoefs rk;
-    {
+    if constexpr (BPP == 2) {   // byte selectors: Y0 | Y1 << 16 of a dword; U (V) of two neighbouring dwords
+        const uint32_t y = (uint32_t)U(p.s422_y), u = (uint32_t)U(p.s422_u), v = (uint32_t)U(p.s422_v);
+        rk.yA = 0x0c000c00u | y | (y + 2) << 16;
+        rk.uA = 0x0c000c00u | u | (u + 4) << 16; rk.vA = 0x0c000c00u | v | (v + 4) << 16;
+        rk.yB = rk.uB = rk.vB = 0;
+    } else {
         const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);
         const int rp = BPP == 0 ? 0 : U(p.src_r_pos), gp = BPP == 4 ? U(p.src_g_pos) : 1, bp = BPP == 0 ? 2 : U(p.src_b_pos);
         auto coef = [&](const Rgb2YuvRow &w, int k) { return (uint32_t)(uint16_t)(k == rp ? w.r : k == gp ? w.g : k == bp ? w.b : 0); };
@@ -270,6 +281,9 @@ __device__ __forceinline__ void strip_rgbsrc_body(const FrameRegs &f, const SwsD
                 if constexpr (BPP == 4) {
                     pre[0][j] = bload16(rs, vo, r0 * sst);
                     pre[1][j] = bload16(rs, vo, r1 * sst);
+                } else if constexpr (BPP == 2) {
+                    pre[0][j] = bload8(rs, vo, r0 * sst);
+                    pre[1][j] = bload8(rs, vo, r1 * sst);
                 } else if constexpr (BPP == 0) {
                     pre[0][j][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, r0 * sst, 0); pre[0][j][1] = __builtin_amdgcn_raw_buffer_load_b32(rs1, vo, r0 * sst1, 0);
                     pre[0][j][2] = __builtin_amdgcn_raw_buffer_load_b32(rs2, vo, r0 * sst2, 0);

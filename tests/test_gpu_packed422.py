@@ -79,9 +79,15 @@ def test_packed_sources(src, dst):
     source ("main:split422+...")"""
     for (sw, sh, dw, dh, fl) in ((256, 64, 192, 48, SWS_BICUBIC), (320, 50, 512, 80, SWS_BICUBIC), (132, 34, 66, 17, SWS_AREA), (256, 64, 320, 96, SWS_BILINEAR),
                                  (256, 64, 250, 64, SWS_LANCZOS), (130, 30, 131, 31, SWS_BICUBIC), (256, 64, 128, 32, SWS_FAST_BILINEAR), (256, 64, 128, 32, SWS_POINT)):
-        for tune in (None, TUNE):
+        # (half-width-chroma YUV destinations at ratios the plain strip plan takes: the lockstep strip kernel reads the packed frame itself, "main:strip_packed422";
+        #  no_strip_rgbsrc keeps the split pass in the test)
+        for tune in (None, TUNE, dict(TUNE, no_strip_rgbsrc=1)):
             r = run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh, tune=tune)
-            assert r[0].startswith("main:split422+"), (r[0], src, dst, sw, dw)
+            assert r[0].startswith("main:split422+") or r[0].startswith("main:strip_packed422"), (r[0], src, dst, sw, dw)
+            if tune and "no_strip_rgbsrc" in tune:
+                assert r[0].startswith("main:split422+"), (r[0], src, dst, sw, dw)
+            elif tune and dst in ("yuv420p", "yuv422p", "nv12", "yuv420p10le", "yuyv422", "uyvy422") and (sw, dw) == (256, 192):
+                assert r[0].startswith("main:strip_packed422"), (r[0], src, dst, sw, dw)
     assert not run_case(255, 64, src, 128, 32, dst, SWS_BICUBIC | BX)[0].startswith("main:split422+")      # odd source width: the readers keep it
 
 
@@ -89,8 +95,11 @@ def test_packed_sources_full_size_and_batches():
     import torch
     import oracle_lib as OL
     from librempeg_amd import SwsContext, HostFrame, DeviceFrame
-    assert run_case(1920, 1080, "yuyv422", 1280, 720, "yuv420p", SWS_BICUBIC | BX, seed=2)[0] == "main:split422+strip_march"
-    assert run_case(1920, 1080, "uyvy422", 1280, 720, "nv12", SWS_BILINEAR | BX, seed=3, device_frames=False)[0] == "main:split422+strip_march"
+    assert run_case(1920, 1080, "yuyv422", 1280, 720, "yuv420p", SWS_BICUBIC | BX, seed=2)[0] == "main:strip_packed422"
+    assert run_case(1920, 1080, "yuyv422", 1280, 720, "yuv420p", SWS_BICUBIC | BX, seed=2, tune=dict(no_strip_rgbsrc=1))[0] == "main:split422+strip_march"
+    assert run_case(3840, 2160, "uyvy422", 1920, 1080, "nv12", SWS_BILINEAR | BX, seed=5)[0] == "main:strip_packed422"
+    assert run_case(1920, 1080, "yvyu422", 1280, 720, "p010le", SWS_LANCZOS | BX, seed=6)[0] == "main:strip_packed422"
+    assert run_case(1920, 1080, "uyvy422", 1280, 720, "nv12", SWS_BILINEAR | BX, seed=3, device_frames=False)[0] == "main:strip_packed422"
     assert run_case(1920, 1080, "yuyv422", 1280, 720, "rgb24", SWS_BICUBIC | BX, seed=4)[0] == "main:split422+strip_rgb"
     for src, dst, sw, sh, dw, dh, n, flags in (("yuyv422", "yuv420p", 1284, 70, 1028, 56, 5, SWS_BICUBIC | BX), ("uyvy422", "yuyv422", 1024, 64, 1280, 80, 3, SWS_BICUBIC | BX)):
         o = OL.Oracle(sw, sh, src, dw, dh, dst, flags)
@@ -110,7 +119,7 @@ def test_packed_sources_full_size_and_batches():
         for rep in range(2):
             assert p.scale_frames(srcs, dsts) == n
             p.sync()
-            assert p.path().startswith("main:split422+"), p.path()
+            assert p.path().startswith("main:split422+") or p.path().startswith("main:strip_packed422"), p.path()
             for k in range(n):
                 out = dsts[k].download()
                 for a, b, rb in zip(out.planes, refs[k].planes, out.row_bytes):

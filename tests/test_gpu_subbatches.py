@@ -35,7 +35,7 @@ def test_sub_batches(case, work_mb):
     p = SwsContext(sw, sh, src, dw, dh, dst, flags)
     p.set_option("strip_min_w", 0)
     p.set_option("work_mb", work_mb)
-    if frag == "rgbread":
+    if frag in ("rgbread", "split422"):
         p.set_option("no_strip_rgbsrc", 1)         # (likewise: the reader pre-pass the one-launch form replaces)
     if frag == "splitnv":
         p.set_option("no_striprgb_direct", 1)      # (this file is about the helper passes: keep the split pass the direct reader of round 4 replaces)
