@@ -666,7 +666,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             const bool fullA = !mixedM && unity_ok && !(d->unity_h && d->unity_v && !rgb_ok && !unity_yuv) && !p.fast_bilinear && (!gray_any || gray_both || d->fullchr_on == 2 || alpha_planar || (rgb_ok && rgb_alpha)) && (src_ok || (nv_src && dst_ok) || rgbread) &&
                                (dst_ok || rgb_ok) && !p.wide && (fs_ok16 || fs_ok32 || fs_ok64) && !c->tune.no_dot2;
             const int long_form = !fullA || fs_ok16 ? 0 : fs_ok32 ? 1 : 2;
-            d->mixed_ok = false; d->stripLs_ok = d->stripCs_ok = false; d->striprgbsrc_ok = false;
+            d->mixed_ok = false; d->stripLs_ok = d->stripCs_ok = false; d->striprgbsrc_ok = false; d->rgb2rgb_ok = false;
             if (fullA || mixedM) {
                 const int SPC = (p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010 || rgbread) ? 8 : 16;
                 std::vector<uint8_t> blob;
@@ -940,6 +940,17 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                   size_t ohl = 0, ohc = 0;
                   const bool altL = strip_plan && !long_form && plan3_alt(c->hLum, c->vLum, p.dstW, 1, d->stripL, d->stripLs, sLs);
                   const bool altC = strip_plan && !long_form && !gray_both && plan3_alt(c->hChr, c->vChr, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
+                  // scaled packed RGB -> packed RGB in one launch (k_striprgb2rgb.hip): the same filters planned once more on strips of 128 columns for both plane
+                  // classes (a lane owns the same destination columns of Y, U, V and A).  Luma and chroma share the vertical bank there (same source and destination
+                  // heights), which the kernel's lockstep march relies on: checked tap position by tap position
+                  SOff s2l, s2c;
+                  d->rgb2rgb_ok = false;
+                  bool r2r = strip_plan && rgbread && !gray_both && !long_form && !c->tune.no_strip_rgb2rgb && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32) && !alpha_planar &&
+                             (d->fullchr_on == 1 || d->fullchr_on == 2) && (d->fullchr_kind == DSTK_RGB24 || d->fullchr_kind == DSTK_RGB32) &&
+                             (d->fullchr_on != 2 || (p.srcKind == SRCK_RGB32 && d->fullchr_kind == DSTK_RGB32)) && p.chrDstW == p.dstW && p.chrDstH == p.dstH && p.chrSrcVSub == 0 &&
+                             c->vLum.size == c->vChr.size && c->vLum.pos == c->vChr.pos;
+                  r2r = r2r && plan3(c->hLum, c->vLum, p.dstW, 2, 1, d->stripL2, s2l, nullptr, lum_plane1) && plan3(c->hChr, c->vChr, p.chrDstW, 2, 2, d->stripC2, s2c, nullptr, chr_plane1) &&
+                        d->stripL2.strips == d->stripC2.strips && d->stripL2.npv == d->stripC2.npv && std::max(d->stripL2.nph, d->stripC2.nph) <= 8 && d->stripL2.npv <= 8;
                   if (!tiles && strip_plan) {   // (the strip kernel shares the tile kernel's padded horizontal taps; without a tile plan it gets its own copy)
                       const std::vector<int16_t> htl = padded(c->hLum, long_form ? d->stripL.hfs2 : 0), htc = gray_both ? std::vector<int16_t>(2, 0) : padded(c->hChr, long_form ? d->stripC.hfs2 : 0);
                       ohl = put(htl.data(), htl.size() * 2); ohc = put(htc.data(), htc.size() * 2);
@@ -971,6 +982,20 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                                     d->stripLs.rows = d->stripL.rows; d->stripLs.hT2 = d->stripL.hT2; d->stripLs.vT2 = d->stripL.vT2; d->stripLs.hT8 = (const int16_t *)(b + sLs.rows); d->stripLs_ok = true; }
                         if (altC) { d->stripCs.colStart = (const int32_t *)(b + sCs.cs); d->stripCs.colCount = (const int32_t *)(b + sCs.cc);
                                     d->stripCs.rows = d->stripC.rows; d->stripCs.hT2 = d->stripC.hT2; d->stripCs.vT2 = d->stripC.vT2; d->stripCs.hT8 = (const int16_t *)(b + sCs.rows); d->stripCs_ok = true; }
+                        if (r2r) {
+                            const int32_t *csl = (const int32_t *)(blob.data() + s2l.cs), *ccl = (const int32_t *)(blob.data() + s2l.cc);
+                            const int32_t *csc = (const int32_t *)(blob.data() + s2c.cs), *ccc = (const int32_t *)(blob.data() + s2c.cc);
+                            const int hm = p.chr_half ? 2 : 1;
+                            int npx = 0;
+                            for (int s = 0; s < d->stripL2.strips; s++) {
+                                const int w0 = std::min(csl[s], hm * csc[s]) & ~15, e = std::max(csl[s] + ccl[s], hm * (csc[s] + ccc[s]));
+                                npx = std::max(npx, (e - w0 + 15) & ~15);
+                            }
+                            d->stripL2.colStart = (const int32_t *)(b + s2l.cs); d->stripL2.colCount = (const int32_t *)(b + s2l.cc); d->stripL2.rows = (const SwsStripRow *)(b + s2l.rows);
+                            d->stripC2.colStart = (const int32_t *)(b + s2c.cs); d->stripC2.colCount = (const int32_t *)(b + s2c.cc); d->stripC2.rows = (const SwsStripRow *)(b + s2c.rows);
+                            d->stripL2.hT2 = d->stripL.hT2; d->stripC2.hT2 = d->stripC.hT2; d->stripL2.vT2 = d->stripC2.vT2 = nullptr;
+                            d->rgb2rgb_ok = npx <= 512; d->rgb2rgb_npx = npx;     // (two turns of 64 groups of four pixels)
+                        }
                         d->strip_ok = true;
                         d->rgbread_on = rgbread;
                         d->alpha_launch = alpha_planar ? 1 : 0;
@@ -1069,7 +1094,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             d->striprgb_ok = d->striprgb_ok && (all_x || (lfs == 1 && cfs == 1));
             if (d->alpha_launch == 2 && !d->striprgb_ok) d->alpha_launch = 0;
             if (d->fullchr_on && ((!all_x && !(lfs == 1 && cfs == 1) && d->fullchr_kind != DSTK_GBRP) || !d->strip_ok)) {   // (planar RGB: any_vscale, always the X form)   // no strip plan, or a row in one of the short writer forms: the generic full-chroma writer keeps it
-                d->fullchr_on = 0; d->strip_ok = false; d->rgbread_on = false; d->striprgbsrc_ok = false;
+                d->fullchr_on = 0; d->strip_ok = false; d->rgbread_on = false; d->striprgbsrc_ok = false; d->rgb2rgb_ok = false;
                 p.dstKind = d->fullchr_kind; p.u_plane_dst = dd->comp[1].plane; p.v_plane_dst = dd->comp[2].plane;
             }
             // a 4:4:4 planar source at the same size into a full-chroma destination: four identity filters, so the epilogue reads the source planes itself
@@ -1230,6 +1255,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         !c->tune.no_strip_rgbsrc) { c->path_name = "main:strip_packed422"; c->kernel_name = "sws_k_strip_rgbsrc"; }     // (aligned frames; launch_plan_le falls back to split422 + strip_march otherwise)
     if (c->plan == PLAN_MAIN && d->join422) c->path_name += "+join422";
     if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += d->fullchr_on == 3 ? "+lut_rgb" : "+fullchr_rgb";
+    if (c->plan == PLAN_MAIN && d->rgb2rgb_ok && !c->tune.no_strip_rgb2rgb && (d->fullchr_on == 1 || d->fullchr_on == 2) && !d->fullchr_direct && d->rgbread_on && d->strip_ok) {
+        c->path_name = "main:strip_rgb2rgb"; c->kernel_name = "sws_k_strip_rgb2rgb";      // (aligned frames; launch_plan_le falls back to rgbread + strip_march + fullchr_rgb otherwise)
+    }
     if (c->plan == PLAN_MAIN && d->fullchr_on && d->fullchr_direct) { c->path_name = "main:fullchr_rgb_direct"; c->kernel_name = d->fullchr_kind == DSTK_GBRP ? "sws_k_fullchr_gbrp" : "sws_k_fullchr_rgb"; }
     if (c->plan == PLAN_MAIN && ((d->alpha_launch == 1 && d->strip_ok) || (d->alpha_launch == 2 && d->striprgb_ok))) c->path_name += "+alpha";
     // (16-byte aligned pictures of the layout converters take the streaming kernel, k_layout.hip; the names above are the fallback's)
@@ -1484,6 +1512,9 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         else launch_layout_split422(S, (d->split_mode & 3) == 2, (d->split_mode & 4) != 0);
         frames = s422fr.data();
     }
+    // (scaled packed RGB -> packed RGB on aligned frames: one launch, no working pictures at all -- k_striprgb2rgb.hip)
+    d->rgb2rgb_now = c->plan == PLAN_MAIN && d->rgb2rgb_ok && !c->tune.no_strip_rgb2rgb && (d->fullchr_on == 1 || d->fullchr_on == 2) && !d->fullchr_direct && d->rgbread_on && d->strip_ok &&
+                     !d->mixed_ok && !d->striprgb_ok && !d->rgbsrc_ok && !d->rgb444_ok && frames_vec_ok(frames, n) && frames_desc_ok(frames, n, p.srcH, p.dstH);
     // full-chroma RGB destination (dev_prepare_on): the strip kernels write three int32 sum planes per frame, sws_k_fullchr_rgb follows
     std::vector<SwsFramePtrs> p422fr, p422join;
     if (c->plan == PLAN_MAIN && d->fullchr_on && d->fullchr_direct) {   // the epilogue alone, on the caller's planes (Y, U, V, A order)
@@ -1499,7 +1530,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
             j.src[3] = a.src[3]; j.srcStride[3] = a.srcStride[3];
         }
     } else
-    if (c->plan == PLAN_MAIN && d->fullchr_on) {
+    if (c->plan == PLAN_MAIN && d->fullchr_on && !d->rgb2rgb_now) {
         auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
         const int sP = (int)a256(4 * (int64_t)p.dstW);
         const int nraw = d->fullchr_on == 2 ? 4 : 3;     // (2: the alpha sums as a fourth plane)
@@ -1593,7 +1624,9 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         else if (d->striprgb_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_striprgb(L);   // marching strip kernel, RGB epilogue
         else if (d->mixed_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_mixed(L);   // identity luma: streaming pass + strip kernel on chroma
         else if (d->strip_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) {   // marching strip kernel
-            if (d->rgbread_on) ret = launch_rgbread_strip(L);
+            if (d->rgb2rgb_now) {
+                if (!launch_strip_rgb2rgb(L)) { log_msg(c, 0, "internal error: no one-launch RGB -> RGB strip kernel for a plan that counted on it\n"); return SWS_AVERROR(EINVAL); }
+            } else if (d->rgbread_on) ret = launch_rgbread_strip(L);
             else if (d->striprgb_direct_now && d->striprgb_direct == 3) {
                 if (!launch_strip_rgbsrc(L)) { log_msg(c, 0, "internal error: no lockstep strip kernel for a packed 4:2:2 source whose split pass was skipped\n"); return SWS_AVERROR(EINVAL); }
             } else ret = launch_strip(L);
@@ -1650,7 +1683,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         else { const SwsFramePtrs *t = nullptr; r = aux_table(0, mfr, &t); if (r < 0) return r; M.fs.table = t; }
         launch_alpha_merge32(M);
     }
-    if ((c->plan == PLAN_MAIN && d->fullchr_on == 2 && !d->fullchr_direct) || alpha_run) {
+    if ((c->plan == PLAN_MAIN && d->fullchr_on == 2 && !d->fullchr_direct && !d->rgb2rgb_now) || alpha_run) {
         if ((!alpha_run && p422join.empty()) || !d->strip_ok) { log_msg(c, 0, "internal error: alpha launch without the strip plan\n"); return SWS_AVERROR(EINVAL); }
         alfr.assign(frames, frames + n);
         pA = p;
@@ -2674,7 +2707,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "layout_ch", &c->tune.layout_ch }, { "no_mixed", &c->tune.no_mixed }, { "no_layout_stream", &c->tune.no_layout_stream }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
         { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
         { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb },
-        { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_lds_pad_kb", &c->tune.strip_lds_pad_kb }, { "no_striprgb_direct", &c->tune.no_striprgb_direct }, { "no_rgbsrc2", &c->tune.no_rgbsrc2 }, { "no_strip_rgbsrc", &c->tune.no_strip_rgbsrc },
+        { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_lds_pad_kb", &c->tune.strip_lds_pad_kb }, { "no_striprgb_direct", &c->tune.no_striprgb_direct }, { "no_rgbsrc2", &c->tune.no_rgbsrc2 }, { "no_strip_rgbsrc", &c->tune.no_strip_rgbsrc }, { "no_strip_rgb2rgb", &c->tune.no_strip_rgb2rgb },
         { "no_strip_short", &c->tune.no_strip_short }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "strip_short_waves", &c->tune.strip_short_waves },
         { "debug", &c->tune.debug },
     };

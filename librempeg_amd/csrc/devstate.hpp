@@ -52,6 +52,7 @@ struct DeviceState {
     void *d_vlines = nullptr; size_t vlines_bytes = 0; bool vlines_on = false;   // virtual source lines of the two-pass path (SwsDevParams::vlines) + their vertical positions
     // scaled packed-RGB sources: the reader pre-pass writes 16-bit Y / U / V planes per frame (k_stream.hip launch_rgb_read16), the strip kernel
     // reads them through a second frame table (k_strip.hip launch_rgbread_strip)
+    bool rgb2rgb_ok = false, rgb2rgb_now = false; int rgb2rgb_npx = 0; SwsStripGeom stripL2{}, stripC2{};   // ... and packed RGB destinations through the full-chroma writers in the same launch (k_striprgb2rgb.hip): plans on strips of 128 columns
     bool striprgbsrc_ok = false; int striprgbsrc_npx = 0;   // ... or, for half-width-chroma YUV destinations, one launch that reads the RGB rows itself (k_striprgbsrc.hip); widest strip window in pixels
     bool rgbread_on = false; void *rgbread_img = nullptr; size_t rgbread_bytes = 0;
     int64_t rgbread_frame_bytes = 0, rgbread_offA = -1; int rgbread_strideY = 0;   // layout of the last reader pre-pass (the alpha launch of a full-chroma RGB destination reads its A plane)
@@ -133,6 +134,7 @@ int  launch_f32rgb(const LaunchCtx &L);
 // ---- k_strip.hip / k_tile.hip: fused h+v polyphase kernels for planar / semi-planar outputs (C3b, C1) ----
 int  launch_strip(const LaunchCtx &L);
 int  launch_rgbsrc(const LaunchCtx &L);
+int  launch_strip_rgb2rgb(const LaunchCtx &L);   // k_striprgb2rgb.hip: scaled packed RGB -> packed RGB, one launch; 1 = launched, 0 = not its shape
 int  launch_strip_rgbsrc(const LaunchCtx &L);    // k_striprgbsrc.hip: scaled packed-RGB source, one launch; 1 = launched, 0 = not its shape
 int  launch_rgbsrc2(const LaunchCtx &L);         // k_rgbsrc2.hip: the wave-march form; 1 = launched, 0 = not its shape
 int  launch_rgbread_strip(const LaunchCtx &L);   // k_strip.hip: scaled packed 24 / 32 bpp RGB source: reader pre-pass + strip kernel on its 16-bit planes

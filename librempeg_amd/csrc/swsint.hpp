@@ -115,6 +115,7 @@ struct Tuning {
     int strip_cols_auto = 1;       // strip widths of the short family chosen per picture width (3 .. 5 luma, 1 .. 3 chroma columns per lane)
     int no_strip_dma8 = 0;         // off: 8-bit planar sources of the short family take the LDS-DMA form (kernels_strip8.hpp)
     int strip_lds_pad_kb = 0;      // experiments: LDS pad in KB per block of the short / dma8 kernels (lowers the occupancy; results never change)
+    int no_strip_rgb2rgb = 0;      // off: scaled packed RGB -> packed RGB (full-chroma writers) takes the one-launch form (sws_k_strip_rgb2rgb) where it applies
     int no_strip_rgbsrc = 0;       // off: scaled packed-RGB sources into half-width-chroma YUV take the one-launch strip form (sws_k_strip_rgbsrc) where it applies
     int no_rgbsrc2 = 0;            // off: same-size 8-bit RGB -> 4:2:0 / 4:2:2 YUV takes the wave-march form (sws_k_rgbsrc_unity2) where it applies
     int no_striprgb_direct = 0;    // off: semi-planar sources (nv12 / p010 families) are read by the strip-RGB kernels themselves instead of through a split pass

@@ -32,7 +32,7 @@ def test_formats(src, dst):
         short = fl == SWS_AREA
         rgb_src = src in ("rgb24", "bgr24", "bgra", "argb", "rgb0", "0bgr", "gbrp", "gbrap")
         if (sw, sh) != (dw, dh) and not alpha_generic and not short and not (rgb_src and sw & 3):
-            assert r[0].endswith("+fullchr_rgb"), (r[0], src, dst, sw, dw)
+            assert r[0].endswith("+fullchr_rgb") or r[0] == "main:strip_rgb2rgb", (r[0], src, dst, sw, dw)     # (packed RGB -> packed RGB: the one-launch form, test_gpu_strip_rgb2rgb.py)
 
 
 GBR_DST = ["gbrp", "gbrap", "gbrp9le", "gbrp10le", "gbrp12le", "gbrp14le", "gbrap10le", "gbrap12le", "gbrap14le", "gbrp10msble", "gbrp12msble", "gbrp10be", "gbrap12be"]
@@ -55,11 +55,11 @@ def test_forced_full_chroma_and_fallbacks():
     assert run_case(1920, 1080, "bgra", 1280, 720, "gbrap10le", SWS_BICUBIC | BX, seed=11)[0] == "main:rgbread+strip_march+fullchr_rgb"
     assert not run_case(256, 64, "yuv420p", 192, 48, "gbrp16le", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")     # 19-bit intermediates
     assert not run_case(256, 64, "yuv420p", 192, 48, "gbrpf32le", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")
-    assert run_case(256, 64, "rgb24", 192, 48, "bgr24", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")        # RGB source: forced
+    assert run_case(256, 64, "rgb24", 192, 48, "bgr24", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_rgb2rgb=1))[0].endswith("+fullchr_rgb")        # RGB source: forced
     assert run_case(256, 64, "yuv444p", 192, 48, "bgra", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")        # 4:4:4 source: forced
     assert run_case(256, 64, "yuv420p", 191, 48, "rgb24", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")       # odd width: forced
     assert not run_case(256, 64, "yuv420p", 192, 48, "rgb24", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")   # the LUT writers
-    assert run_case(256, 64, "bgra", 192, 48, "bgra", SWS_BICUBIC | BX, tune=TUNE)[0] == "main:rgbread+strip_march+fullchr_rgb"   # alpha plane scaled: a fourth sum plane
+    assert run_case(256, 64, "bgra", 192, 48, "bgra", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_rgb2rgb=1))[0] == "main:rgbread+strip_march+fullchr_rgb"   # alpha plane scaled: a fourth sum plane
     assert run_case(256, 64, "yuva420p", 192, 48, "rgba", SWS_BICUBIC | FC | BX, tune=TUNE)[0] == "main:strip_march+fullchr_rgb"
     assert not run_case(256, 64, "gbrap", 192, 48, "rgba", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")      # planar RGB with alpha: the generic writer
     assert not run_case(256, 64, "yuva420p16le", 192, 48, "rgba", SWS_BICUBIC | FC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")   # 16-bit samples: 19-bit intermediates
@@ -87,7 +87,7 @@ def test_one_tap_vertical_forms():
             for (w, h) in ((256, 64), (322, 50), (129, 33), (67, 18), (1026, 21), (1, 1), (3, 2), (5, 3)):
                 run_case(w, h, src, w, h, dst, SWS_BICUBIC | BX, seed=w + h, tune=TUNE)
     assert run_case(1920, 1080, "yuv444p16le", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=48)[0] != "main:fullchr_rgb_direct"   # 16-bit samples
-    assert run_case(1920, 1080, "rgb24", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=43)[0] == "main:rgbread+strip_march+fullchr_rgb"   # (BITEXACT: no rgb24 -> bgra shuffle, swscale_unscaled.c findRgbConvFn)
+    assert run_case(1920, 1080, "rgb24", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=43, tune=dict(no_strip_rgb2rgb=1))[0] == "main:rgbread+strip_march+fullchr_rgb"   # (BITEXACT: no rgb24 -> bgra shuffle, swscale_unscaled.c findRgbConvFn)
     assert run_case(1920, 1080, "yuv444p", 1280, 1080, "bgra", SWS_BICUBIC | BX, seed=44)[0] == "main:strip_march+fullchr_rgb"
 
 
@@ -95,17 +95,18 @@ def test_full_size_batches_and_host_frames():
     import torch
     import oracle_lib as OL
     from librempeg_amd import SwsContext, HostFrame, DeviceFrame
-    assert run_case(3840, 2160, "rgb24", 1920, 1080, "rgb24", SWS_BICUBIC | BX, seed=2)[0] == "main:rgbread+strip_march+fullchr_rgb"
-    assert run_case(1920, 1080, "bgr24", 1280, 720, "bgra", SWS_BILINEAR | BX, seed=3, device_frames=False)[0] == "main:rgbread+strip_march+fullchr_rgb"
+    assert run_case(3840, 2160, "rgb24", 1920, 1080, "rgb24", SWS_BICUBIC | BX, seed=2, tune=dict(no_strip_rgb2rgb=1))[0] == "main:rgbread+strip_march+fullchr_rgb"
+    assert run_case(1920, 1080, "bgr24", 1280, 720, "bgra", SWS_BILINEAR | BX, seed=3, device_frames=False, tune=dict(no_strip_rgb2rgb=1))[0] == "main:rgbread+strip_march+fullchr_rgb"
     assert run_case(1920, 1080, "yuv444p", 1280, 720, "rgb24", SWS_BICUBIC | BX, seed=4)[0] == "main:strip_march+fullchr_rgb"
     assert run_case(1920, 1080, "yuv420p", 1280, 720, "bgra", SWS_LANCZOS | FC | SWS_ACCURATE_RND | BX, seed=5)[0] == "main:strip_march+fullchr_rgb"
-    assert run_case(3840, 2160, "bgra", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=6)[0] == "main:rgbread+strip_march+fullchr_rgb"
-    assert run_case(1920, 1080, "rgba", 1280, 720, "argb", SWS_LANCZOS | BX, seed=7, device_frames=False)[0] == "main:rgbread+strip_march+fullchr_rgb"
+    assert run_case(3840, 2160, "bgra", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=6, tune=dict(no_strip_rgb2rgb=1))[0] == "main:rgbread+strip_march+fullchr_rgb"
+    assert run_case(1920, 1080, "rgba", 1280, 720, "argb", SWS_LANCZOS | BX, seed=7, device_frames=False, tune=dict(no_strip_rgb2rgb=1))[0] == "main:rgbread+strip_march+fullchr_rgb"
     assert run_case(1920, 1080, "yuva420p", 1280, 720, "bgra", SWS_BICUBIC | FC | BX, seed=8)[0] == "main:strip_march+fullchr_rgb"
     for src, dst, sw, sh, dw, dh, n, flags in (("rgb24", "bgr24", 1284, 70, 1028, 56, 5, SWS_BICUBIC | BX), ("nv12", "bgra", 1024, 64, 1283, 80, 3, SWS_BICUBIC | FC | BX),
                                                ("abgr", "rgba", 1284, 70, 1028, 56, 5, SWS_BICUBIC | BX), ("yuva444p10le", "bgra", 1024, 64, 1283, 80, 3, SWS_BICUBIC | BX)):
         o = OL.Oracle(sw, sh, src, dw, dh, dst, flags)
         p = SwsContext(sw, sh, src, dw, dh, dst, flags)
+        p.set_option("no_strip_rgb2rgb", 1)        # (this file is about the helper-pass form)
         refs, srcs, dsts = [], [], []
         for k in range(n):
             s = OL.fill_random(OL.Frame(src, sw, sh), 60 + k)

@@ -35,6 +35,8 @@ def test_sub_batches(case, work_mb):
     p = SwsContext(sw, sh, src, dw, dh, dst, flags)
     p.set_option("strip_min_w", 0)
     p.set_option("work_mb", work_mb)
+    if frag == "fullchr_rgb":
+        p.set_option("no_strip_rgb2rgb", 1)        # (likewise: the helper passes the one-launch RGB -> RGB form replaces)
     if frag in ("rgbread", "split422"):
         p.set_option("no_strip_rgbsrc", 1)         # (likewise: the reader pre-pass the one-launch form replaces)
     if frag == "splitnv":
@@ -74,6 +76,7 @@ def test_timed_region_spans_the_sub_batches():
     for work_mb in (2048, 4):
         p = SwsContext(sw, sh, "bgra", dw, dh, "rgb24", SWS_BICUBIC | BX)
         p.set_option("work_mb", work_mb)
+        p.set_option("no_strip_rgb2rgb", 1)        # (the helper-pass form: the one-launch form has no working pictures to cut a batch for)
         p.set_timing(True)
         srcs = [DeviceFrame("bgra", sw, sh) for _ in range(n)]; dsts = [DeviceFrame("rgb24", dw, dh) for _ in range(n)]
         torch.cuda.synchronize()
