@@ -718,8 +718,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 // plane1_form: the plane's writer has the reference's one-tap form (yuv2plane1_*, yuv2p01xl1_c: (s + d) >> 7 and its N-bit twins), which
                 // never looks at the coefficient -- initFilter's error-diffused normalisation leaves 4095 in some one-tap rows -- so a one-tap bank
                 // enters the X arithmetic as 4096; the semi-planar chroma writers (yuv2nv12cX_c, yuv2p01xcX_c) have no such form and take the bank's value
-                auto plan3 = [&](const FilterBank &hb, const FilterBank &vb, int W, int cols, int ncomp, SwsStripGeom &g, SOff &o, int (*ring_of)(int) = nullptr, bool plane1_form = false, int longf = 0) -> bool {   // longf: 1 the long form (16 / 24 pairs), 2 the extra-long one (32 / 32)
-                    const int TW = 64 * cols, hf2 = fs2(hb.size), vf2 = fs2(vb.size);
+                auto plan3 = [&](const FilterBank &hb, const FilterBank &vb, int W, int cols, int ncomp, SwsStripGeom &g, SOff &o, int (*ring_of)(int) = nullptr, bool plane1_form = false, int longf = 0, int tw_over = 0) -> bool {   // longf: 1 the long form (16 / 24 pairs), 2 the extra-long one (32 / 32); tw_over: strips narrower than 64 * cols columns (the lockstep kernels: a window that fits one reader turn less)
+                    const int TW = tw_over ? tw_over : 64 * cols, hf2 = fs2(hb.size), vf2 = fs2(vb.size);
                     const int strips = (W + TW - 1) / TW;
                     std::vector<int32_t> cs(strips), cc(strips);
                     int ncmax = 0, nph = 1, npv = 1;
@@ -949,8 +949,54 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                              (d->fullchr_on == 1 || d->fullchr_on == 2) && (d->fullchr_kind == DSTK_RGB24 || d->fullchr_kind == DSTK_RGB32) &&
                              (d->fullchr_on != 2 || (p.srcKind == SRCK_RGB32 && d->fullchr_kind == DSTK_RGB32)) && p.chrDstW == p.dstW && p.chrDstH == p.dstH && p.chrSrcVSub == 0 &&
                              c->vLum.size == c->vChr.size && c->vLum.pos == c->vChr.pos;
-                  r2r = r2r && plan3(c->hLum, c->vLum, p.dstW, 2, 1, d->stripL2, s2l, nullptr, lum_plane1) && plan3(c->hChr, c->vChr, p.chrDstW, 2, 2, d->stripC2, s2c, nullptr, chr_plane1) &&
+                  // (strips a little narrower than 128 columns where that brings the widest pixel window down to one reader turn -- 256 pixels: 120 columns at 2:1)
+                  int r2r_tw = 128;
+                  if (r2r && c->tune.strip_cols_auto) {
+                      const int hm = p.chr_half ? 2 : 1, hfl = fs2(c->hLum.size), hfc = fs2(c->hChr.size);
+                      auto widest = [&](int tw) {
+                          int npx = 0;
+                          for (int x0 = 0; x0 < p.dstW; x0 += tw) {
+                              int lo = INT32_MAX, hi = 0;
+                              for (int x = x0; x < std::min(p.dstW, x0 + tw); x++) {
+                                  lo = std::min(lo, std::min(c->hLum.pos[x] & ~1, hm * (c->hChr.pos[x] & ~1)));
+                                  hi = std::max(hi, std::max((c->hLum.pos[x] & ~1) + hfl, hm * ((c->hChr.pos[x] & ~1) + hfc)));
+                              }
+                              npx = std::max(npx, ((hi + 7) & ~7) - (lo & ~15));
+                          }
+                          return npx;
+                      };
+                      if (widest(128) > 256) for (int tw : { 124, 120, 116, 112, 104, 96 }) if (widest(tw) <= 256) { r2r_tw = tw; break; }
+                  }
+                  r2r = r2r && plan3(c->hLum, c->vLum, p.dstW, 2, 1, d->stripL2, s2l, nullptr, lum_plane1, 0, r2r_tw) && plan3(c->hChr, c->vChr, p.chrDstW, 2, 2, d->stripC2, s2c, nullptr, chr_plane1, 0, r2r_tw) &&
                         d->stripL2.strips == d->stripC2.strips && d->stripL2.npv == d->stripC2.npv && std::max(d->stripL2.nph, d->stripC2.nph) <= 8 && d->stripL2.npv <= 8;
+                  // the lockstep strip kernel of packed sources into half-width-chroma YUV (k_striprgbsrc.hip) likewise plans for itself: luma strips of up to 256
+                  // columns over chroma strips of half as many, a few columns narrower where that brings the widest pixel window down by a reader turn of 256
+                  // pixels (248 columns at 2:1: 504 pixels, two turns instead of three).  (YUV destinations: never together with the RGB -> RGB plans above)
+                  const bool packed422_src = (d->split_mode & 3) && !(d->split_mode & 40) && p.srcKind == SRCK_PLANAR8 && p.chrSrcW == (p.srcW >> 1) && p.chrSrcVSub == 0 && !p.range_active && !vlines_pending;
+                  SOff s3l, s3c;
+                  bool rsrc = strip_plan && !r2r && ((rgbread && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chr_half) || packed422_src) && !gray_both && !long_form &&
+                              !c->tune.no_strip_rgbsrc && !alpha_planar && !p.need_alpha && !d->fullchr_on &&
+                              p.chrDstW == ((p.dstW + 1) >> 1) && (p.chrDstVSub == 0 ? p.chrDstH == p.dstH : (p.chrDstVSub == 1 && p.chrDstH == ((p.dstH + 1) >> 1)));
+                  if (rsrc) {
+                      const int hfl = fs2(c->hLum.size), hfc = fs2(c->hChr.size);
+                      auto widest = [&](int tw) {
+                          int npx = 0;
+                          for (int x0 = 0, s = 0; x0 < p.dstW; x0 += tw, s++) {
+                              int lo = INT32_MAX, hi = 0;
+                              for (int x = x0; x < std::min(p.dstW, x0 + tw); x++) { lo = std::min(lo, c->hLum.pos[x] & ~1); hi = std::max(hi, (c->hLum.pos[x] & ~1) + hfl); }
+                              for (int x = s * (tw / 2); x < std::min(p.chrDstW, (s + 1) * (tw / 2)); x++) { lo = std::min(lo, 2 * (c->hChr.pos[x] & ~1)); hi = std::max(hi, 2 * ((c->hChr.pos[x] & ~1) + hfc)); }
+                              npx = std::max(npx, ((hi + 15) & ~15) - (lo & ~15));
+                          }
+                          return npx;
+                      };
+                      int tw3 = 256;
+                      if (c->tune.strip_cols_auto) {
+                          const int turns = (widest(256) + 255) / 256;
+                          if (turns > 1) for (int tw : { 248, 240, 232 }) if ((widest(tw) + 255) / 256 < turns) { tw3 = tw; break; }
+                      }
+                      rsrc = plan3(c->hLum, c->vLum, p.dstW, 4, 1, d->stripL2, s3l, nullptr, lum_plane1, 0, tw3) && plan3(c->hChr, c->vChr, p.chrDstW, 2, 2, d->stripC2, s3c, nullptr, chr_plane1, 0, tw3 / 2) &&
+                             d->stripL2.strips == d->stripC2.strips && std::max(d->stripL2.nph, d->stripC2.nph) <= 8 && d->stripL2.npv <= 8 && d->stripC2.npv <= 12;
+                  }
                   if (!tiles && strip_plan) {   // (the strip kernel shares the tile kernel's padded horizontal taps; without a tile plan it gets its own copy)
                       const std::vector<int16_t> htl = padded(c->hLum, long_form ? d->stripL.hfs2 : 0), htc = gray_both ? std::vector<int16_t>(2, 0) : padded(c->hChr, long_form ? d->stripC.hfs2 : 0);
                       ohl = put(htl.data(), htl.size() * 2); ohc = put(htc.data(), htc.size() * 2);
@@ -1002,20 +1048,19 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         // scaled packed RGB into half-width-chroma YUV: one launch that reads the RGB rows itself (k_striprgbsrc.hip) on the same plan tables --
                         // luma strips of 256 columns over chroma strips of 128, every strip's pixel window (luma window and twice the chroma window, from a
                         // multiple of 16 pixels on) at most 64 lanes x 16 pixels
-                        // (packed 8-bit 4:2:2 sources -- yuyv422 / uyvy422 / yvyu422 -- have the same shape: chroma samples under pixel pairs on every source row;
-                        //  the kernel's byte-selector reader takes them from the caller's frame, without the split pass: striprgb_direct = 3)
-                        const bool packed422_src = (d->split_mode & 3) && !(d->split_mode & 40) && p.srcKind == SRCK_PLANAR8 && p.chrSrcW == (p.srcW >> 1) && p.chrSrcVSub == 0 && !p.range_active && !vlines_pending;
-                        if (((rgbread && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chr_half) || packed422_src) && !gray_both && !long_form && !c->tune.no_strip_rgbsrc &&
-                            !alpha_planar && !p.need_alpha && !d->fullchr_on && d->stripL.TW == 256 && d->stripC.TW == 128 && d->stripL.strips == d->stripC.strips &&
-                            p.chrDstW == ((p.dstW + 1) >> 1) && (p.chrDstVSub == 0 ? p.chrDstH == p.dstH : (p.chrDstVSub == 1 && p.chrDstH == ((p.dstH + 1) >> 1))) &&
-                            std::max(d->stripL.nph, d->stripC.nph) <= 8 && d->stripL.npv <= 8 && d->stripC.npv <= 12) {
-                            const int32_t *csl = (const int32_t *)(blob.data() + sL.cs), *ccl = (const int32_t *)(blob.data() + sL.cc);
-                            const int32_t *csc = (const int32_t *)(blob.data() + sC.cs), *ccc = (const int32_t *)(blob.data() + sC.cc);
+                        // (packed 8-bit 4:2:2 sources -- yuyv422 / uyvy422 / yvyu422 -- have the shape of the half readers: chroma samples under pixel pairs on every source
+                        //  row; the kernel's byte-selector reader takes them from the caller's frame, without the split pass: striprgb_direct = 3)
+                        if (rsrc) {
+                            const int32_t *csl = (const int32_t *)(blob.data() + s3l.cs), *ccl = (const int32_t *)(blob.data() + s3l.cc);
+                            const int32_t *csc = (const int32_t *)(blob.data() + s3c.cs), *ccc = (const int32_t *)(blob.data() + s3c.cc);
                             int npx = 0;
-                            for (int s = 0; s < d->stripL.strips; s++) {
+                            for (int s = 0; s < d->stripL2.strips; s++) {
                                 const int w0 = std::min(csl[s], 2 * csc[s]) & ~15, e = std::max(csl[s] + ccl[s], 2 * (csc[s] + ccc[s]));
                                 npx = std::max(npx, (e - w0 + 15) & ~15);
                             }
+                            d->stripL2.colStart = (const int32_t *)(b + s3l.cs); d->stripL2.colCount = (const int32_t *)(b + s3l.cc); d->stripL2.rows = (const SwsStripRow *)(b + s3l.rows);
+                            d->stripC2.colStart = (const int32_t *)(b + s3c.cs); d->stripC2.colCount = (const int32_t *)(b + s3c.cc); d->stripC2.rows = (const SwsStripRow *)(b + s3c.rows);
+                            d->stripL2.hT2 = d->stripL.hT2; d->stripC2.hT2 = d->stripC.hT2; d->stripL2.vT2 = d->stripC2.vT2 = nullptr;
                             d->striprgbsrc_ok = npx <= 1024; d->striprgbsrc_npx = npx;
                             if (packed422_src) d->striprgb_direct = d->striprgbsrc_ok ? 3 : 0;
                         }

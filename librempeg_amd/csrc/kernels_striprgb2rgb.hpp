@@ -93,7 +93,7 @@ __device__ __forceinline__ void strip_rgb2rgb_body(const FrameRegs &f, const Sws
         const int ndL = gl.hfs2 >> 1, ndC = gc.hfs2 >> 1;
 #pragma unroll
         for (int c = 0; c < CL; c++) {
-            const int x = min(strip * (64 * CL) + 64 * c + lane, W - 1);
+            const int x = min(min(strip * gl.TW + 64 * c + lane, (strip + 1) * gl.TW - 1), W - 1);     // (gl.TW <= 128: the host narrows the strips where that saves a reader turn)
             spdL[c] = ((p.hLumPos[x] & ~1) - w0) >> 1;
             spdC[c] = ((p.hChrPos[x] & ~1) - (HALF ? w0 >> 1 : w0)) >> 1;
             const uint32_t *tl = (const uint32_t *)(gl.hT2 + (int64_t)x * gl.hfs2), *tc = (const uint32_t *)(gc.hT2 + (int64_t)x * gc.hfs2);
@@ -160,7 +160,7 @@ __device__ __forceinline__ void strip_rgb2rgb_body(const FrameRegs &f, const Sws
     const int dstr = f.dstStride[0];
     int doff[CL];
 #pragma unroll
-    for (int c = 0; c < CL; c++) { const int x = strip * (64 * CL) + 64 * c + lane; doff[c] = x < W ? x * BPPD : 0x7fffffff; }
+    for (int c = 0; c < CL; c++) { const int x = strip * gl.TW + 64 * c + lane; doff[c] = (x < W && 64 * c + lane < gl.TW) ? x * BPPD : 0x7fffffff; }
     uint32_t pend[CL];
     int pend_y = -1;
     auto flush = [&]() {

@@ -47,7 +47,7 @@ struct StripOut {
 };
 
 template <bool CHROMA, int COLS>
-__device__ __forceinline__ void so_init(StripOut<CHROMA, COLS> &O, const FrameRegs &f, const SwsDevParams &p, int xs, int lane)
+__device__ __forceinline__ void so_init(StripOut<CHROMA, COLS> &O, const FrameRegs &f, const SwsDevParams &p, int xs, int lane, int tw)
 {
     constexpr int NCOMP = CHROMA ? 2 : 1;
     const int W = CHROMA ? p.chrDstW : p.dstW, H = CHROMA ? p.chrDstH : p.dstH;
@@ -65,7 +65,7 @@ __device__ __forceinline__ void so_init(StripOut<CHROMA, COLS> &O, const FrameRe
 #pragma unroll
     for (int c = 0; c < COLS; c++) {
         const int x = xs + 64 * c + lane;
-        O.doff[c] = x < W ? x * dbytes : 0x7fffffff;
+        O.doff[c] = (x < W && 64 * c + lane < tw) ? x * dbytes : 0x7fffffff;     // (columns beyond the strip belong to the next one)
     }
     O.pend_y = -1; O.xs = xs;
 }
@@ -229,7 +229,7 @@ __device__ __forceinline__ void strip_rgbsrc_body(const FrameRegs &f, const SwsD
         const int ndL = gl.hfs2 >> 1, ndC = gc.hfs2 >> 1;       // dwords per tap row
 #pragma unroll
         for (int c = 0; c < CL; c++) {
-            const int x = min(strip * (64 * CL) + 64 * c + lane, W - 1);
+            const int x = min(min(strip * gl.TW + 64 * c + lane, (strip + 1) * gl.TW - 1), W - 1);     // (gl.TW <= 256, gc.TW = gl.TW / 2: the host narrows the strips where that saves a reader turn)
             spdL[c] = ((p.hLumPos[x] & ~1) - w0) >> 1;
             const uint32_t *tp = (const uint32_t *)(gl.hT2 + (int64_t)x * gl.hfs2);
 #pragma unroll
@@ -237,7 +237,7 @@ __device__ __forceinline__ void strip_rgbsrc_body(const FrameRegs &f, const SwsD
         }
 #pragma unroll
         for (int c = 0; c < CC; c++) {
-            const int x = min(strip * (64 * CC) + 64 * c + lane, cW - 1);
+            const int x = min(min(strip * gc.TW + 64 * c + lane, (strip + 1) * gc.TW - 1), cW - 1);
             spdC[c] = ((p.hChrPos[x] & ~1) - (w0 >> 1)) >> 1;
             const uint32_t *tp = (const uint32_t *)(gc.hT2 + (int64_t)x * gc.hfs2);
 #pragma unroll
@@ -312,8 +312,8 @@ __device__ __forceinline__ void strip_rgbsrc_body(const FrameRegs &f, const SwsD
 
     StripOut<false, CL> OL;
     StripOut<true, CC> OC;
-    so_init(OL, f, p, strip * (64 * CL), lane);
-    so_init(OC, f, p, strip * (64 * CC), lane);
+    so_init(OL, f, p, strip * gl.TW, lane, gl.TW);
+    so_init(OC, f, p, strip * gc.TW, lane, gc.TW);
 
     uint32_t ringL[1][CL][RL], ringC[2][CC][RC];
 #pragma unroll
