@@ -393,7 +393,7 @@ def main():
                           "cpu_baseline": None}), flush=True)
         return
     main_res = run_workload(args.workload, args.batch, args.steps, args.warmup, rank, world, local_rank, barrier)
-    variants = [] if args.variants in ("", "none") else (["c2b", "c3b", "d1", "c1"] if args.variants == "auto" and args.workload == "c2a"
+    variants = [] if args.variants in ("", "none") else (["c2b", "c3b", "d1", "c1", "e2"] if args.variants == "auto" and args.workload == "c2a"
                                                           else [] if args.variants == "auto" else args.variants.split(","))
     var_res = []
     for v in variants:

@@ -3,9 +3,10 @@
 set -u
 R=gpurun_out/r04p; P=profiles
 cp $R/bench_lines.jsonl $P/r04_bench.jsonl
-for k in c1 c2a c2b c3a c3b c4 c5 d1 d2 common_shapes layout ladder; do [ -f $R/kernel_stats_$k.md ] && cp $R/kernel_stats_$k.md $P/r04_kernel_stats_$k.md; done
+for k in c1 c2a c2b c3a c3b c4 c5 d1 d2 e1 e2 common_shapes layout ladder; do [ -f $R/kernel_stats_$k.md ] && cp $R/kernel_stats_$k.md $P/r04_kernel_stats_$k.md; done
 cp $R/common.md $P/r04_common_shapes.md; cp $R/conv.txt $P/r04_common_conversions.txt; cp $R/aux.txt $P/r04_aux_kernels.md; cp $R/layout.md $P/r04_layout_times.md; cp $R/single.md $P/r04_single_frame.md
 cp $R/narrow.md $P/r04_narrow_shapes.md
+cp $R/rgb2rgb.md $P/r04_rgb2rgb.md
 for m in same down up; do grep "^|" $R/survey_$m.md > $P/r04_survey_$m.md; done
 cp $R/ladder.md $P/r04_ladder.md
 cp $R/bench_default.json $P/r04_bench_default.json 2>/dev/null

@@ -9,6 +9,7 @@ tools/profile_all.sh r04p > $OUT/bench_lines.jsonl 2>$OUT/profile_all.err
 tools/pmc_traffic.sh r04p "c2a c2b c4 c3a c3b c5 c1 d1" > $OUT/pmc_traffic.txt 2>&1
 python tools/layout_times.py > $OUT/layout.md 2>$OUT/layout.err
 python tools/common_shapes_times.py > $OUT/common.md 2>$OUT/common.err
+python tools/rgb2rgb_times.py > $OUT/rgb2rgb.md 2>$OUT/rgb2rgb.err
 python tools/common_conversions_times.py > $OUT/conv.txt 2>$OUT/conv.err
 python tools/aux_kernel_times.py > $OUT/aux.txt 2>$OUT/aux.err
 python tools/single_frame_times.py > $OUT/single.md 2>$OUT/single.err
