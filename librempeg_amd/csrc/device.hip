@@ -1780,10 +1780,20 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
 // therefore cut into sub-batches whose working pictures fit a budget (Tuning::work_mb, 2 GiB by default: bgra 4K -> rgb24 1080p needs ~83 MB per
 // frame, i.e. 24 frames per sub-batch -- far more than it takes to fill the GPU); the buffers are reused from sub-batch to sub-batch (same stream:
 // ordered).  Contexts without helper passes have no per-frame working memory and always go out as one launch set.
-static size_t helper_bytes_per_frame(const SwsInternal *c, const DeviceState *d)
+static size_t helper_bytes_per_frame(const SwsInternal *c, const DeviceState *d, const SwsFramePtrs *frames, int n)
 {
     if (c->plan != PLAN_MAIN) return 0;
     const SwsDevParams &p = d->params;
+    // the one-launch forms of round 4 read the caller's aligned frames themselves and keep no working picture (the conditions of launch_plan_le_batch)
+    if (frames_vec_ok(frames, n) && frames_desc_ok(frames, n, p.srcH, p.dstH)) {
+        if (d->rgb2rgb_ok && !c->tune.no_strip_rgb2rgb && (d->fullchr_on == 1 || d->fullchr_on == 2) && !d->fullchr_direct && d->rgbread_on && d->strip_ok &&
+            !d->mixed_ok && !d->striprgb_ok && !d->rgbsrc_ok && !d->rgb444_ok) return 0;
+        if (d->rgbread_on && d->strip_ok && d->striprgbsrc_ok && !c->tune.no_strip_rgbsrc && !d->fullchr_on && !d->alpha_launch && !d->split_mode && !d->join422 &&
+            !d->mixed_ok && !d->striprgb_ok && !d->rgbsrc_ok && !d->rgb444_ok) return 0;
+        if (d->split_mode && d->striprgb_direct == 3 && d->strip_ok && d->striprgbsrc_ok && !d->mixed_ok && !d->striprgb_ok && !d->fullchr_on && !d->alpha_launch && !d->rgbread_on &&
+            !d->join422 && !c->tune.no_strip_rgbsrc) return 0;
+        if (d->split_mode && (d->striprgb_direct == 1 || d->striprgb_direct == 2) && d->striprgb_ok && !c->tune.no_striprgb_direct && !d->fullchr_on && !d->alpha_launch && !d->join422) return 0;
+    }
     auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
     int64_t b = 0;
     const bool helpers = d->split_mode || d->join422 || d->fullchr_on || d->alpha_launch || d->rgbread_on;
@@ -1806,7 +1816,7 @@ static size_t helper_bytes_per_frame(const SwsInternal *c, const DeviceState *d)
 
 static int launch_plan_le(SwsInternal *c, DeviceState *d, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
 {
-    const size_t per = n > 1 ? helper_bytes_per_frame(c, d) : 0;
+    const size_t per = n > 1 ? helper_bytes_per_frame(c, d, frames, n) : 0;
     const size_t budget = (size_t)std::max(1, c->tune.work_mb) << 20;
     if (!per || per * (size_t)n <= budget) return launch_plan_le_batch(c, d, frames, n, sliceY, sliceH, true, true);
     const int chunk = (int)std::max<size_t>(1, budget / per);
