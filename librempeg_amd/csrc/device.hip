@@ -225,6 +225,23 @@ static int dst_kind_of(int f)
 }
 
 // upload filter banks (one blob) and fill SwsDevParams
+static bool poison_enabled();
+static int poison(SwsInternal *c, void *buf, size_t bytes);
+// Device tables (filter banks, plan blobs, geometry): grown like grow().  Under SWS_HIP_DEBUG & 16 every table block carries 4 KiB of slack and is
+// refilled with 0xCD before each upload: a kernel that reads past the end of its table (a vector load over the last tap row, a row entry fetched ahead)
+// then meets garbage on every run, as it would in a block recycled from another context, instead of the zeros of a fresh allocation.
+static int table_alloc(SwsInternal *c, void **buf, size_t *cap, size_t need)
+{
+    const size_t slack = poison_enabled() ? 4096 : 0;
+    if (need + slack > *cap) {
+        if (*buf) HIPCHK(hipFree(*buf));
+        *buf = nullptr; *cap = 0;
+        HIPCHK(hipMalloc(buf, need + slack));
+        *cap = need + slack;
+    }
+    return poison(c, *buf, *cap);
+}
+
 static int dev_prepare_on(SwsInternal *c, DeviceState *d)
 {
     if (d->epoch == c->tables_epoch && d->stream) return 0;
@@ -492,12 +509,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             offs_t[i] = off; off = align(off + banks[i]->taps.size() * sizeof(int16_t));
             offs_p[i] = off; off = align(off + banks[i]->pos.size() * sizeof(int32_t));
         }
-        if (off > d->tables_bytes) {
-            if (d->d_tables) HIPCHK(hipFree(d->d_tables));
-            d->d_tables = nullptr;
-            HIPCHK(hipMalloc(&d->d_tables, off));
-            d->tables_bytes = off;
-        }
+        { int r_ = table_alloc(c, &d->d_tables, &d->tables_bytes, off); if (r_ < 0) return r_; }
         std::vector<uint8_t> host(off, 0);
         for (int i = 0; i < 4; i++) {
             std::memcpy(host.data() + offs_t[i], banks[i]->taps.data(), banks[i]->taps.size() * sizeof(int16_t));
@@ -528,12 +540,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 const size_t o_lp = hostv.size(); hostv.insert(hostv.end(), vlx.lumPos.begin(), vlx.lumPos.end());
                 const size_t o_cp = hostv.size(); hostv.insert(hostv.end(), vlx.chrPos.begin(), vlx.chrPos.end());
                 const size_t bytes = hostv.size() * sizeof(int32_t);
-                if (bytes > d->vlines_bytes) {
-                    if (d->d_vlines) HIPCHK(hipFree(d->d_vlines));
-                    d->d_vlines = nullptr; d->vlines_bytes = 0;
-                    HIPCHK(hipMalloc(&d->d_vlines, bytes));
-                    d->vlines_bytes = bytes;
-                }
+                { int r_ = table_alloc(c, &d->d_vlines, &d->vlines_bytes, bytes); if (r_ < 0) return r_; }
                 HIPCHK(hipMemcpy(d->d_vlines, hostv.data(), bytes, hipMemcpyHostToDevice));
                 const int32_t *bv = (const int32_t *)d->d_vlines;
                 p.vlines = bv; p.nVL = (int32_t)nL; p.vline_mode = mode;
@@ -586,12 +593,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 }
                 const size_t bytes1 = (rows.size() * sizeof(SwsRgbSrcRow) + 63) & ~(size_t)63;
                 const size_t bytes = bytes1 + rows2.size() * sizeof(SwsStripRow);
-                if (bytes > d->dot2_bytes) {
-                    if (d->d_dot2) HIPCHK(hipFree(d->d_dot2));
-                    d->d_dot2 = nullptr;
-                    HIPCHK(hipMalloc(&d->d_dot2, bytes));
-                    d->dot2_bytes = bytes;
-                }
+                { int r_ = table_alloc(c, &d->d_dot2, &d->dot2_bytes, bytes); if (r_ < 0) return r_; }
                 HIPCHK(hipMemcpy(d->d_dot2, rows.data(), rows.size() * sizeof(SwsRgbSrcRow), hipMemcpyHostToDevice));
                 if (!rows2.empty()) HIPCHK(hipMemcpy((uint8_t *)d->d_dot2 + bytes1, rows2.data(), rows2.size() * sizeof(SwsStripRow), hipMemcpyHostToDevice));
                 d->rgbsrc_rows = (const SwsRgbSrcRow *)d->d_dot2;
@@ -848,12 +850,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         const std::vector<int16_t> htc = padded(c->hChr);
                         const size_t ohc = put(htc.data(), htc.size() * 2);
                         const bool altC = plan3_alt(c->hChr, c->vChr, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
-                        if (blob.size() > d->dot2_bytes) {
-                            if (d->d_dot2) HIPCHK(hipFree(d->d_dot2));
-                            d->d_dot2 = nullptr;
-                            HIPCHK(hipMalloc(&d->d_dot2, blob.size()));
-                            d->dot2_bytes = blob.size();
-                        }
+                        { int r_ = table_alloc(c, &d->d_dot2, &d->dot2_bytes, blob.size()); if (r_ < 0) return r_; }
                         HIPCHK(hipMemcpy(d->d_dot2, blob.data(), blob.size(), hipMemcpyHostToDevice));
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         d->stripC.colStart = (const int32_t *)(b + sM.cs); d->stripC.colCount = (const int32_t *)(b + sM.cc);
@@ -902,12 +899,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         size_t o8l = 0, o8c = 0;
                         dma8_plan(c->hLum, c->vLum, gl, o8l); dma8_plan(c->hChr, c->vChr, gc, o8c);
                         if (!gl.dma8_ok || !gc.dma8_ok) gl.dma8_ok = gc.dma8_ok = 0;
-                        if (blob.size() > d->dot2_bytes) {
-                            if (d->d_dot2) HIPCHK(hipFree(d->d_dot2));
-                            d->d_dot2 = nullptr;
-                            HIPCHK(hipMalloc(&d->d_dot2, blob.size()));
-                            d->dot2_bytes = blob.size();
-                        }
+                        { int r_ = table_alloc(c, &d->d_dot2, &d->dot2_bytes, blob.size()); if (r_ < 0) return r_; }
                         HIPCHK(hipMemcpy(d->d_dot2, blob.data(), blob.size(), hipMemcpyHostToDevice));
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         gl.colStart = (const int32_t *)(b + rL.cs); gl.colCount = (const int32_t *)(b + rL.cc); gl.rows = (const SwsStripRow *)(b + rL.rows);
@@ -1002,12 +994,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                       ohl = put(htl.data(), htl.size() * 2); ohc = put(htc.data(), htc.size() * 2);
                   }
                   if (tiles || strip_plan) {
-                    if (blob.size() > d->dot2_bytes) {
-                        if (d->d_dot2) HIPCHK(hipFree(d->d_dot2));
-                        d->d_dot2 = nullptr;
-                        HIPCHK(hipMalloc(&d->d_dot2, blob.size()));
-                        d->dot2_bytes = blob.size();
-                    }
+                    { int r_ = table_alloc(c, &d->d_dot2, &d->dot2_bytes, blob.size()); if (r_ < 0) return r_; }
                     HIPCHK(hipMemcpy(d->d_dot2, blob.data(), blob.size(), hipMemcpyHostToDevice));
                     auto bind = [&](SwsTileGeom &g, const Off &o) {
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
@@ -1109,12 +1096,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             if (plan(c->hLum, c->vLum, p.dstW, p.dstH, p.srcW, p.srcH, 1, d->tileL, aL) &&
                 plan(c->hChr, c->vChr, p.chrDstW, p.chrDstH, p.chrSrcW, p.chrSrcH, 2, d->tileC, aC)) {
                 const size_t bytes = (aL.size() + aC.size()) * sizeof(int32_t);
-                if (bytes > d->tilegeom_bytes) {
-                    if (d->d_tilegeom) HIPCHK(hipFree(d->d_tilegeom));
-                    d->d_tilegeom = nullptr;
-                    HIPCHK(hipMalloc(&d->d_tilegeom, bytes));
-                    d->tilegeom_bytes = bytes;
-                }
+                { int r_ = table_alloc(c, &d->d_tilegeom, &d->tilegeom_bytes, bytes); if (r_ < 0) return r_; }
                 std::vector<int32_t> all(aL); all.insert(all.end(), aC.begin(), aC.end());
                 HIPCHK(hipMemcpy(d->d_tilegeom, all.data(), bytes, hipMemcpyHostToDevice));
                 const int32_t *bL = (const int32_t *)d->d_tilegeom, *bC = bL + aL.size();
@@ -1198,12 +1180,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         for (int r = 0; r < 2; r++) e.wp[r][2] = (e.wp[r][2] & 0xFFFFu) | (2048u << 16);
                 if (ok) {
                     const size_t bytes = plan.size() * sizeof(SwsRgbGroupPlan);
-                    if (bytes > d->rgbplan_bytes) {
-                        if (d->d_rgbplan) HIPCHK(hipFree(d->d_rgbplan));
-                        d->d_rgbplan = nullptr;
-                        HIPCHK(hipMalloc(&d->d_rgbplan, bytes));
-                        d->rgbplan_bytes = bytes;
-                    }
+                    { int r_ = table_alloc(c, &d->d_rgbplan, &d->rgbplan_bytes, bytes); if (r_ < 0) return r_; }
                     HIPCHK(hipMemcpy(d->d_rgbplan, plan.data(), bytes, hipMemcpyHostToDevice));
                     d->rgb_groups = groups;
                     d->rgb_march_ok = true;
@@ -2763,7 +2740,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
         { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb },
         { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_lds_pad_kb", &c->tune.strip_lds_pad_kb }, { "no_striprgb_direct", &c->tune.no_striprgb_direct }, { "no_rgbsrc2", &c->tune.no_rgbsrc2 }, { "no_strip_rgbsrc", &c->tune.no_strip_rgbsrc }, { "no_strip_rgb2rgb", &c->tune.no_strip_rgb2rgb },
-        { "no_strip_short", &c->tune.no_strip_short }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "strip_short_waves", &c->tune.strip_short_waves },
+        { "no_strip_short", &c->tune.no_strip_short }, { "no_generic_kinds", &c->tune.no_generic_kinds }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "strip_short_waves", &c->tune.strip_short_waves },
         { "debug", &c->tune.debug },
     };
     for (auto &e : tab)

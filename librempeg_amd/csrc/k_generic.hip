@@ -1,9 +1,36 @@
 // Translation unit of the generic element-per-thread path: every reader (input.c), hScale*_c, every writer (output.c) in their
 // _1 / _2 / _X forms.  Two passes through an HBM scratch, or one pass when both horizontal banks are the identity.
-#include "devstate.hpp"
+#include "generic_kinds.hpp"
 #include "kernels_generic.hpp"
 
 namespace swship {
+
+// the kernels of one source kind (k_generic_kinds.hip); null: the all-kinds forms below
+const GenericKindFns *generic_kind_fns(int srcKind)
+{
+    static GenericKindFns tab[SRCK_RGB16 + 1];
+    static const bool once = [] {
+#define GENERIC_KIND_FILL(n) generic_kind_fns_##n(&tab[n]);
+        GENERIC_KIND_PARTS(GENERIC_KIND_FILL)
+#undef GENERIC_KIND_FILL
+        return true; }();
+    (void)once;
+    if (srcKind < 0 || srcKind > SRCK_RGB16 || srcKind == SRCK_BAYER) return nullptr;
+    return &tab[srcKind];
+}
+
+static const GenericDstFns *dst_fns(int dstKind)
+{
+    static GenericDstFns tab[DSTK_RAW32];
+    static const bool once = [] {
+#define GENERIC_DST_FILL(n) generic_dst_fns_##n(&tab[n]);
+        GENERIC_DST_PARTS(GENERIC_DST_FILL)
+#undef GENERIC_DST_FILL
+        return true; }();
+    (void)once;
+    if (dstKind < 0 || dstKind >= DSTK_RAW32) return nullptr;
+    return &tab[dstKind];
+}
 
 int launch_generic(const LaunchCtx &L)
 {
@@ -20,6 +47,18 @@ int launch_generic(const LaunchCtx &L)
         const int64_t frame_elems = lumElems + 2 * chrElems + (p.need_alpha ? lumElems : 0);
         const size_t esz = p.wide ? 4 : 2;
         const bool direct = d->unity_h;
+        const GenericKindFns *ks = c->tune.no_generic_kinds ? nullptr : generic_kind_fns(p.srcKind);
+        const GenericKindFns::Direct *kf = (ks && direct && p.dstKind >= 0 && p.dstKind <= DSTK_RAW32) ? &ks->direct[p.dstKind] : nullptr;
+        const GenericDstFns *kd = (direct || c->tune.no_generic_kinds) ? nullptr : dst_fns(p.dstKind);
+#define KIND_MEMBER_sws_k_vscale_rgb rgb
+#define KIND_MEMBER_sws_k_vscale_planar planar
+#define KIND_MEMBER_sws_k_vscale_nvchroma nvchroma
+#define KIND_MEMBER16_sws_k_vscale_rgb rgb16
+#define KIND_MEMBER32_sws_k_vscale_rgb rgb32
+#define KIND_MEMBER16_sws_k_vscale_planar planar16
+#define KIND_MEMBER32_sws_k_vscale_planar planar32
+#define KIND_MEMBER16_sws_k_vscale_nvchroma nvchroma16
+#define KIND_MEMBER32_sws_k_vscale_nvchroma nvchroma32
         int chunk = n;
         if (!direct) {
             const size_t budget = (size_t)2 << 30; // scratch budget per launch group
@@ -35,11 +74,14 @@ int launch_generic(const LaunchCtx &L)
             if (!direct) {
                 const int maxW = std::max(p.dstW, p.chrDstW), maxH = std::max(p.srcH, p.chrSrcH);
                 const dim3 g1(cdiv(maxW, 256), maxH, (p.need_alpha ? 4 : 3) * m);
-                if (p.wide) hipLaunchKernelGGL((swsk::sws_k_hscale<int32_t>), g1, blk, 0, st, sub, p, (int32_t *)d->scratch, frame_elems);
-                else hipLaunchKernelGGL((swsk::sws_k_hscale<int16_t>), g1, blk, 0, st, sub, p, (int16_t *)d->scratch, frame_elems);
+                if (p.wide) hipLaunchKernelGGL(ks ? ks->hscale32 : swsk::sws_k_hscale<int32_t>, g1, blk, 0, st, sub, p, (int32_t *)d->scratch, frame_elems);
+                else hipLaunchKernelGGL(ks ? ks->hscale16 : swsk::sws_k_hscale<int16_t>, g1, blk, 0, st, sub, p, (int16_t *)d->scratch, frame_elems);
             }
 #define LAUNCH_W(K, G, ...) do { \
-    if (direct) hipLaunchKernelGGL((swsk::K<true, int16_t>), G, blk, 0, st, sub, p, (const int16_t *)nullptr, frame_elems, ##__VA_ARGS__); \
+    if (direct && kf && kf->KIND_MEMBER_##K) hipLaunchKernelGGL(kf->KIND_MEMBER_##K, G, blk, 0, st, sub, p, (const int16_t *)nullptr, frame_elems, ##__VA_ARGS__); \
+    else if (direct) hipLaunchKernelGGL((swsk::K<true, int16_t>), G, blk, 0, st, sub, p, (const int16_t *)nullptr, frame_elems, ##__VA_ARGS__); \
+    else if (kd && p.wide && kd->KIND_MEMBER32_##K) hipLaunchKernelGGL(kd->KIND_MEMBER32_##K, G, blk, 0, st, sub, p, (const int32_t *)d->scratch, frame_elems, ##__VA_ARGS__); \
+    else if (kd && !p.wide && kd->KIND_MEMBER16_##K) hipLaunchKernelGGL(kd->KIND_MEMBER16_##K, G, blk, 0, st, sub, p, (const int16_t *)d->scratch, frame_elems, ##__VA_ARGS__); \
     else if (p.wide) hipLaunchKernelGGL((swsk::K<false, int32_t>), G, blk, 0, st, sub, p, (const int32_t *)d->scratch, frame_elems, ##__VA_ARGS__); \
     else hipLaunchKernelGGL((swsk::K<false, int16_t>), G, blk, 0, st, sub, p, (const int16_t *)d->scratch, frame_elems, ##__VA_ARGS__); } while (0)
             if (rgb) {

@@ -1,5 +1,5 @@
 // Translation unit of the LDS-tile kernels (C1 and the narrow pictures of the same family; 16-bit outputs).
-#include "devstate.hpp"
+#include "generic_kinds.hpp"
 #include "kernels_tile.hpp"
 
 namespace swship {
@@ -30,7 +30,11 @@ int launch_tile(const LaunchCtx &L)
     const dim3 blk(256);
     (void)c; (void)d; (void)frames; (void)vec; (void)sliceY; (void)sliceH;
             const dim3 gl(d->tileL.tilesX, d->tileL.tilesY, n), gc(d->tileC.tilesX, d->tileC.tilesY, n);
-            if (p.wide) {
+            const GenericKindFns *ks = c->tune.no_generic_kinds ? nullptr : generic_kind_fns(p.srcKind);   // the instantiations for this source kind (k_generic_kinds.hip)
+            if (ks) {
+                hipLaunchKernelGGL(ks->tile[p.wide ? 1 : 0][0], gl, blk, d->tileL.lds_bytes, st, fs, p, d->tileL);
+                hipLaunchKernelGGL(ks->tile[p.wide ? 1 : 0][1], gc, blk, d->tileC.lds_bytes, st, fs, p, d->tileC);
+            } else if (p.wide) {
                 hipLaunchKernelGGL((swsk::sws_k_tile_planar<int32_t, false>), gl, blk, d->tileL.lds_bytes, st, fs, p, d->tileL);
                 hipLaunchKernelGGL((swsk::sws_k_tile_planar<int32_t, true>), gc, blk, d->tileC.lds_bytes, st, fs, p, d->tileC);
             } else {

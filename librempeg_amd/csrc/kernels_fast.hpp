@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) sws_k_rgb_fused_unity(SwsFrameSet fs, Sws
         emit8<BPP, VEC>(L, drow + (int64_t)8 * BPP * cb, Y, U, V);
     } else {
         // row tail: scalar pairs through the generic routine (identical arithmetic)
-        const DirectSampler smp{&p, &f};
+        const DirectSampler<SwsDevParams> smp{&p, &f};
         for (int i = 4 * cb; i < npairs; i++) rgb_write_unit(p, smp, f, i, y);
     }
 }

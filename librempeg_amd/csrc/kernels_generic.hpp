@@ -13,7 +13,8 @@ namespace swsk {
 // input readers (libswscale/input.c): value of the "formatConv" line for component comp
 // (0 = Y, 1 = U, 2 = V) at source row `row` (luma or chroma row), column x.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFramePtrs &f, int comp, int row, int x, int aux = -1)
+template <typename P>
+__device__ __forceinline__ int read_sample(const P &p, const SwsFramePtrs &f, int comp, int row, int x, int aux = -1)
 {
     if (comp == 3 && p.srcKind == SRCK_RGB48)   // rgba64leToA_c: the 16-bit A word as is
         return ((const uint16_t *)(f.src[0] + (int64_t)row * f.srcStride[0]))[4 * x + 3];
@@ -258,12 +259,14 @@ __device__ __forceinline__ int read_sample(const SwsDevParams &p, const SwsFrame
         const Rgb2YuvRow tr = rgb2yuv_row(p.rgb2yuv, o);
         return (uint16_t)((int)((unsigned)tr.r * r + (unsigned)tr.g * g + (unsigned)tr.b * b + (0x10001u << 14)) >> 15);
     }
+    default: break;   // (the kinds answered above the switch)
     }
     return 0;
 }
 
 // range conversion of one intermediate sample (lum/chrRange{To,From}Jpeg(16)_c, swscale.c:163-255)
-__device__ __forceinline__ int range_sample(const SwsDevParams &p, int v, int chroma)
+template <typename P>
+__device__ __forceinline__ int range_sample(const P &p, int v, int chroma)
 {
     if (!p.range_active) return v;
     if (!p.wide) {
@@ -281,7 +284,8 @@ __device__ __forceinline__ int range_sample(const SwsDevParams &p, int v, int ch
 }
 
 // horizontal stage for one output sample (hScale8To15_c / 8To19 / 16To15 / 16To19, swscale.c:69-159)
-__device__ __forceinline__ int hscale_sample(const SwsDevParams &p, const SwsFramePtrs &f, int comp, int row, int x, int aux = -1)
+template <typename P>
+__device__ __forceinline__ int hscale_sample(const P &p, const SwsFramePtrs &f, int comp, int row, int x, int aux = -1)
 {
     if (p.no_chroma && comp != 0 && comp != 3) return p.wide ? 1 << 18 : 1 << 14;   // ff_init_desc_no_chr: fill_ones() value, never range converted
     const bool lumlike = comp == 0 || comp == 3;   // the alpha plane goes through the luma functions (hscale.c:39-131)
@@ -317,8 +321,9 @@ template <typename T> struct ScratchSampler { // pass-1 output in HBM
                comp == 2 ? v[(int64_t)row * chrW + x] : a[(int64_t)row * lumW + x];
     }
 };
+template <typename P = SwsDevParams>
 struct DirectSampler { // horizontal filters are 1-tap identity: compute the sample on the fly
-    const SwsDevParams *p; const SwsFramePtrs *f;
+    const P *p; const SwsFramePtrs *f;
     __device__ __forceinline__ int get(int comp, int row, int x) const
     {
         if (p->no_chroma && comp != 0 && comp != 3) return p->wide ? 1 << 18 : 1 << 14;
@@ -328,13 +333,30 @@ struct DirectSampler { // horizontal filters are 1-tap identity: compute the sam
     }
 };
 
+// SK / DK >= 0: an instantiation for ONE source / destination kind -- the same routines with the kind switches folded at compile time.  (The all-kinds
+// form of the single-pass kernels carries every reader at every tap of every writer: 24 000 instructions, 256 + 256 registers and spills, one wave
+// per SIMD with every load of a tap waiting for the one before.)  The routines take the parameter block as a template type; the views below hide the
+// kind fields behind constants of the same names, so `p.srcKind == SRCK_...` is decided by the compiler and everything else reads the kernel argument.
+template <int SK, int DK> struct KindView : SwsDevParams { static constexpr int32_t srcKind = SK, dstKind = DK; };
+template <int SK> struct SrcKindView : SwsDevParams { static constexpr int32_t srcKind = SK; };
+template <int DK> struct DstKindView : SwsDevParams { static constexpr int32_t dstKind = DK; };
+template <int SK, int DK>
+__device__ __forceinline__ decltype(auto) kind_view(const SwsDevParams &p)
+{
+    if constexpr (SK >= 0 && DK >= 0) return reinterpret_cast<const KindView<SK, DK> &>(p);
+    else if constexpr (SK >= 0) return reinterpret_cast<const SrcKindView<SK> &>(p);
+    else if constexpr (DK >= 0) return reinterpret_cast<const DstKindView<DK> &>(p);
+    else return (p);
+}
+
 // ------------------------------------------------------------------------------------------
 // pass 1: reader + hscale + range -> scratch planes
 // grid: x over output columns, y over source rows, z = frame * 3 + comp
 // ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256) sws_k_hscale(SwsFrameSet fs, SwsDevParams p, T *scratch, int64_t frame_elems)
+template <typename T, int SK = -1>
+__global__ void __launch_bounds__(256) sws_k_hscale(SwsFrameSet fs, SwsDevParams pa, T *scratch, int64_t frame_elems)
 {
+    const auto &p = kind_view<SK, -1>(pa);
     const int ncomp = p.need_alpha ? 4 : 3;
     const int comp = blockIdx.z % ncomp, fi = blockIdx.z / ncomp;
     const int W = (comp == 0 || comp == 3) ? U(p.dstW) : U(p.chrDstW), H = (comp == 0 || comp == 3) ? U(p.srcH) : U(p.chrSrcH);
@@ -357,8 +379,8 @@ __global__ void __launch_bounds__(256) sws_k_hscale(SwsFrameSet fs, SwsDevParams
 // writers output.c:149-187, :327-357, :468-493, :538-569)
 // comp 0 -> luma plane, 1/2 -> separate chroma planes (planar YUV only)
 // ------------------------------------------------------------------------------------------
-template <typename S>
-__device__ __forceinline__ void planar_write_one(const SwsDevParams &p, const S &smp, const SwsFramePtrs &f, int comp, int x, int y)
+template <typename S, typename P>
+__device__ __forceinline__ void planar_write_one(const P &p, const S &smp, const SwsFramePtrs &f, int comp, int x, int y)
 {
     const bool lumlike = comp == 0 || comp == 3;   // alpha: vscale.c:59-71
     const int fs = lumlike ? U(p.vLumFs) : U(p.vChrFs);
@@ -423,8 +445,8 @@ __device__ __forceinline__ void planar_write_one(const SwsDevParams &p, const S 
 }
 
 // interleaved chroma writers: yuv2nv12cX_c (output.c:495-528), yuv2p01xcX_c (:571-589)
-template <typename S>
-__device__ __forceinline__ void nv_chroma_write_one(const SwsDevParams &p, const S &smp, const SwsFramePtrs &f, int x, int cy)
+template <typename S, typename P>
+__device__ __forceinline__ void nv_chroma_write_one(const P &p, const S &smp, const SwsFramePtrs &f, int x, int cy)
 {
     const int fs = p.vChrFs;
     const int16_t *vf = p.vChrF + cy * fs;
@@ -465,8 +487,8 @@ __device__ __forceinline__ void nv_chroma_write_one(const SwsDevParams &p, const
 
 // packed RGB: packed_vscale (vscale.c:109-171) choosing yuv2rgb_{1,2,X}_c_template (output.c:1788-1939)
 // or yuv2rgb_full_{1,2,X}_c_template (output.c:2163-2312); unit = pixel pair (LUT) or pixel (full chroma)
-template <typename S>
-__device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &smp, const SwsFramePtrs &f, int i, int y)
+template <typename S, typename P>
+__device__ __forceinline__ void rgb_write_unit(const P &p, const S &smp, const SwsFramePtrs &f, int i, int y)
 {
     const int cy = y >> p.chrDstVSub;
     const int lfs = p.vLumFs, cfs = p.vChrFs;
@@ -924,10 +946,11 @@ __device__ __forceinline__ void rgb_write_unit(const SwsDevParams &p, const S &s
 // DIRECT = false: samples come from the pass-1 scratch planes
 template <bool DIRECT, typename T>
 struct SamplerFor {
-    static __device__ __forceinline__ auto make(const SwsDevParams &p, const SwsFramePtrs &f, const T *scratch, int64_t frame_elems, int fi)
+    template <typename P>
+    static __device__ __forceinline__ auto make(const P &p, const SwsFramePtrs &f, const T *scratch, int64_t frame_elems, int fi)
     {
         if constexpr (DIRECT) {
-            return DirectSampler{&p, &f};
+            return DirectSampler<P>{&p, &f};
         } else {
             const T *base = scratch + fi * frame_elems;
             const int64_t lumElems = (int64_t)p.srcH * p.dstW, chrElems = (int64_t)p.chrSrcH * p.chrDstW;
@@ -937,9 +960,10 @@ struct SamplerFor {
 };
 
 // planar: grid x over columns, y over output rows of that plane, z = frame * ncomp + comp
-template <bool DIRECT, typename T>
-__global__ void __launch_bounds__(256) sws_k_vscale_planar(SwsFrameSet fs, SwsDevParams p, const T *scratch, int64_t frame_elems, int ncomp)
+template <bool DIRECT, typename T, int SK = -1, int DK = -1>
+__global__ void __launch_bounds__(256) sws_k_vscale_planar(SwsFrameSet fs, SwsDevParams pa, const T *scratch, int64_t frame_elems, int ncomp)
 {
+    const auto &p = kind_view<SK, DK>(pa);
     const int comp = blockIdx.z % ncomp, fi = blockIdx.z / ncomp;
     const int W = (comp == 0 || comp == 3) ? U(p.dstW) : U(p.chrDstW), H = (comp == 0 || comp == 3) ? U(p.dstH) : U(p.chrDstH);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -950,9 +974,10 @@ __global__ void __launch_bounds__(256) sws_k_vscale_planar(SwsFrameSet fs, SwsDe
 }
 
 // semi-planar chroma: grid x over chroma columns, y over chroma rows, z = frame
-template <bool DIRECT, typename T>
-__global__ void __launch_bounds__(256) sws_k_vscale_nvchroma(SwsFrameSet fs, SwsDevParams p, const T *scratch, int64_t frame_elems)
+template <bool DIRECT, typename T, int SK = -1, int DK = -1>
+__global__ void __launch_bounds__(256) sws_k_vscale_nvchroma(SwsFrameSet fs, SwsDevParams pa, const T *scratch, int64_t frame_elems)
 {
+    const auto &p = kind_view<SK, DK>(pa);
     const int fi = blockIdx.z;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, cy = blockIdx.y;
     if (x >= p.chrDstW || cy >= p.chrDstH) return;
@@ -962,9 +987,10 @@ __global__ void __launch_bounds__(256) sws_k_vscale_nvchroma(SwsFrameSet fs, Sws
 }
 
 // packed RGB: grid x over units (pixel pairs, or pixels with full chroma), y over rows, z = frame
-template <bool DIRECT, typename T>
-__global__ void __launch_bounds__(256) sws_k_vscale_rgb(SwsFrameSet fs, SwsDevParams p, const T *scratch, int64_t frame_elems)
+template <bool DIRECT, typename T, int SK = -1, int DK = -1>
+__global__ void __launch_bounds__(256) sws_k_vscale_rgb(SwsFrameSet fs, SwsDevParams pa, const T *scratch, int64_t frame_elems)
 {
+    const auto &p = kind_view<SK, DK>(pa);
     const int fi = blockIdx.z;
     const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     const int units = p.dstKind == DSTK_MONO ? (p.dstW + 7) >> 3 : (p.full_chr || p.dstKind == DSTK_YA) ? p.dstW : (p.dstW + 1) >> 1;

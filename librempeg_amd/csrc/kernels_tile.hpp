@@ -26,9 +26,11 @@ template <typename HT> struct LdsSampler {
     __device__ __forceinline__ int get(int comp, int row, int x) const { return h[comp][(row - r0) * tw + (x - x0)]; }
 };
 
-template <typename HT, bool CHROMA>
-__global__ void __launch_bounds__(256) sws_k_tile_planar(SwsFrameSet fs, SwsDevParams p, SwsTileGeom g)
+// (SK >= 0: the instantiation for one source kind -- phase 1 is a loop around the reader, kernels_generic.hpp kind_view)
+template <typename HT, bool CHROMA, int SK = -1>
+__global__ void __launch_bounds__(256) sws_k_tile_planar(SwsFrameSet fs, SwsDevParams pa, SwsTileGeom g)
 {
+    const auto &p = kind_view<SK, -1>(pa);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tx = blockIdx.x, ty = blockIdx.y, tid = threadIdx.x;
     const SwsFramePtrs &f = frame_of(fs, blockIdx.z);
