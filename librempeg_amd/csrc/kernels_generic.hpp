@@ -283,6 +283,27 @@ __device__ __forceinline__ int range_sample(const P &p, int v, int chroma)
     return r;
 }
 
+// the parameter block with the chr_half field (half-width chroma readers: rgb24ToUV_half_c and friends) behind a constant, like KindView below
+template <typename P, int H> struct ChrHalfView : P { static constexpr int32_t chr_half = H; };
+
+// sum of fs taps of one output sample of component COMP.  Four taps at a time, their loads issued together: a thread that waits for every sample
+// before it asks for the next one spends the pass on memory latency (4K bgra -> 1080p, 8 taps: 0.49 ms per frame for 66 M samples in the rolled
+// loop).  The sum is the reference's 32-bit sum in any order.
+template <int COMP, typename P>
+__device__ __forceinline__ int tap_sum(const P &p, const SwsFramePtrs &f, int row, int sp, const int16_t *taps, int fs, int aux)
+{
+    int val = 0, j = 0;
+    for (; j + 4 <= fs; j += 4) {
+        int s[4], t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { s[u] = read_sample(p, f, COMP, row, sp + j + u, aux); t[u] = taps[j + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) val += s[u] * t[u];
+    }
+    for (; j < fs; j++) val += read_sample(p, f, COMP, row, sp + j, aux) * taps[j];
+    return val;
+}
+
 // horizontal stage for one output sample (hScale8To15_c / 8To19 / 16To15 / 16To19, swscale.c:69-159)
 template <typename P>
 __device__ __forceinline__ int hscale_sample(const P &p, const SwsFramePtrs &f, int comp, int row, int x, int aux = -1)
@@ -305,8 +326,19 @@ __device__ __forceinline__ int hscale_sample(const P &p, const SwsFramePtrs &f, 
     const int32_t *pos = lumlike ? U(p.hLumPos) : U(p.hChrPos);
     const int fs = lumlike ? U(p.hLumFs) : U(p.hChrFs);
     const int sp = pos[x];
-    int val = 0;
-    for (int j = 0; j < fs; j++) val += read_sample(p, f, comp, row, sp + j, aux) * filter[fs * x + j];
+    // (the component and the half-width chroma readers are the same for a whole block: decided here, outside the tap loop, so that the loop body is
+    //  the straight-line code of one reader form)
+    const int16_t *taps = filter + (int64_t)fs * x;
+    int val;
+    if (p.chr_half) {
+        const auto &q = reinterpret_cast<const ChrHalfView<P, 1> &>(p);
+        val = comp == 0 ? tap_sum<0>(q, f, row, sp, taps, fs, aux) : comp == 1 ? tap_sum<1>(q, f, row, sp, taps, fs, aux) :
+              comp == 2 ? tap_sum<2>(q, f, row, sp, taps, fs, aux) : tap_sum<3>(q, f, row, sp, taps, fs, aux);
+    } else {
+        const auto &q = reinterpret_cast<const ChrHalfView<P, 0> &>(p);
+        val = comp == 0 ? tap_sum<0>(q, f, row, sp, taps, fs, aux) : comp == 1 ? tap_sum<1>(q, f, row, sp, taps, fs, aux) :
+              comp == 2 ? tap_sum<2>(q, f, row, sp, taps, fs, aux) : tap_sum<3>(q, f, row, sp, taps, fs, aux);
+    }
     int r = min(val >> p.hshift, p.hclip);
     if (!p.wide) r = (int16_t)r;
     return comp == 3 ? r : range_sample(p, r, comp != 0);

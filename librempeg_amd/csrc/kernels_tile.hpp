@@ -8,6 +8,7 @@
 // No intermediate ever touches HBM.  Window origins/sizes per tile row/column are precomputed on the host
 // from the filter banks (SwsTileGeom); arithmetic is the generic kernels' (same device functions).
 #pragma once
+#include <type_traits>
 #include "kernels_generic.hpp"
 #include "wave_util.hpp"
 
@@ -51,10 +52,24 @@ __global__ void __launch_bounds__(256) sws_k_tile_planar(SwsFrameSet fs, SwsDevP
         const int comp = CHROMA ? 1 + ci : 0;
         // phase 1: source window -> LDS (reader fused; coordinates clamped to the plane, so taps that the filter
         // folded onto the border (utils.c:519-560) never read outside)
-        for (int i = tid; i < nr * nc; i += 256) {
-            const int r = i / nc, cc = i - r * nc;
-            S[r * g.NCmax + cc] = (uint16_t)read_sample(p, f, comp, min(r0 + r, sH - 1), min(c0 + cc, sW - 1));
-        }
+        // (four samples per thread and turn, their loads issued together; the reader form -- component, half-width chroma -- decided outside the loop)
+        auto stage = [&](const auto &q) {
+            const int tot = nr * nc;
+            for (int i0 = tid; i0 < tot; i0 += 4 * 256) {
+                int v[4], o[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = min(i0 + 256 * u, tot - 1);
+                    const int r = i / nc, cc = i - r * nc;
+                    o[u] = r * g.NCmax + cc;
+                    v[u] = read_sample(q, f, comp, min(r0 + r, sH - 1), min(c0 + cc, sW - 1));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (i0 + 256 * u < tot) S[o[u]] = (uint16_t)v[u];
+            }
+        };
+        typedef typename std::remove_cv<typename std::remove_reference<decltype(p)>::type>::type PT;
+        if (p.chr_half) stage(reinterpret_cast<const ChrHalfView<PT, 1> &>(p)); else stage(reinterpret_cast<const ChrHalfView<PT, 0> &>(p));
         __syncthreads();
         // phase 2: horizontal stage; thread = one output column, marching down the window rows
         HT *Hc = Hbase + ci * hplane;
