@@ -127,8 +127,12 @@ __device__ __forceinline__ int read_sample(const P &p, const SwsFramePtrs &f, in
         const uint8_t *s = f.src[0] + (int64_t)srow * f.srcStride[0];
         const int32_t *t = p.rgb2yuv;
         const int S = 15 + 8;
+        // (the pixel as ONE dword -- the reference reads it with AV_RN32A -- and the bytes out of the register: a third of the load instructions, which
+        //  is what this per-sample reader is bound by)
+        const int rsh = 8 * p.src_r_pos, gsh = 8 * p.src_g_pos, bsh = 8 * p.src_b_pos;
         if (comp == 0) {
-            const int r = s[4 * x + p.src_r_pos], g = s[4 * x + p.src_g_pos] << 8, b = s[4 * x + p.src_b_pos];
+            const uint32_t px = *(const uint32_t *)(s + 4 * x);
+            const int r = (px >> rsh) & 0xFF, g = ((px >> gsh) & 0xFF) << 8, b = (px >> bsh) & 0xFF;
             const unsigned rnd = (32u << (S - 1)) + (1u << (S - 7));
             return (uint16_t)((unsigned)((t[0] << 8) * r + t[1] * g + (t[2] << 8) * b + rnd) >> (S - 6));
         }
@@ -136,13 +140,15 @@ __device__ __forceinline__ int read_sample(const P &p, const SwsFramePtrs &f, in
         const Rgb2YuvRow tr = rgb2yuv_row(p.rgb2yuv, o);
         const int cr = tr.r * (1 << 8), cg = tr.g, cb = tr.b * (1 << 8);
         if (p.chr_half) {
-            const int r = s[8 * x + p.src_r_pos] + s[8 * x + 4 + p.src_r_pos];
-            const int g = (s[8 * x + p.src_g_pos] + s[8 * x + 4 + p.src_g_pos]) << 8;
-            const int b = s[8 * x + p.src_b_pos] + s[8 * x + 4 + p.src_b_pos];
+            const uint32_t p0 = *(const uint32_t *)(s + 8 * x), p1 = *(const uint32_t *)(s + 8 * x + 4);
+            const int r = (int)((p0 >> rsh) & 0xFF) + (int)((p1 >> rsh) & 0xFF);
+            const int g = (int)(((p0 >> gsh) & 0xFF) + ((p1 >> gsh) & 0xFF)) << 8;
+            const int b = (int)((p0 >> bsh) & 0xFF) + (int)((p1 >> bsh) & 0xFF);
             const unsigned rnd = (256U << S) + (1 << (S - 6));
             return (uint16_t)((unsigned)(cr * r + cg * g + cb * b + rnd) >> (S - 6 + 1)); // unsigned expr, logical shift
         }
-        const int r = s[4 * x + p.src_r_pos], g = s[4 * x + p.src_g_pos] << 8, b = s[4 * x + p.src_b_pos];
+        const uint32_t px = *(const uint32_t *)(s + 4 * x);
+        const int r = (px >> rsh) & 0xFF, g = ((px >> gsh) & 0xFF) << 8, b = (px >> bsh) & 0xFF;
         const unsigned rnd = (256u << (S - 1)) + (1 << (S - 7));
         return (uint16_t)((unsigned)(cr * r + cg * g + cb * b + rnd) >> (S - 6));
     }
@@ -381,6 +387,10 @@ __device__ __forceinline__ decltype(auto) kind_view(const SwsDevParams &p)
     else return (p);
 }
 
+// (likewise the chr_half field, for the single-pass kernels: the reader form of a whole launch, decided once per thread instead of at every tap)
+template <int H, typename P>
+__device__ __forceinline__ const ChrHalfView<P, H> &chr_half_view(const P &p) { return reinterpret_cast<const ChrHalfView<P, H> &>(p); }
+
 // ------------------------------------------------------------------------------------------
 // pass 1: reader + hscale + range -> scratch planes
 // grid: x over output columns, y over source rows, z = frame * 3 + comp
@@ -404,6 +414,24 @@ __global__ void __launch_bounds__(256) sws_k_hscale(SwsFrameSet fs, SwsDevParams
         srow = e[0]; aux = e[1];
     }
     plane[(int64_t)row * W + x] = (T)hscale_sample(p, f, comp, srow, x, aux);
+}
+
+// sum of fs vertical taps of one output sample, from `init`: four taps at a time with their loads in flight together (like tap_sum); the
+// reference's 32-bit sum in any order (its signed and its unsigned-cast forms are the same bits)
+template <typename S>
+__device__ __forceinline__ int vtap_sum(const S &smp, int comp, int first, int last, int x, const int16_t *vf, int fs, int init)
+{
+    unsigned val = (unsigned)init;
+    int j = 0;
+    for (; j + 4 <= fs; j += 4) {
+        int s[4], t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { s[u] = smp.get(comp, min(first + j + u, last), x); t[u] = vf[j + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) val += (unsigned)s[u] * (unsigned)t[u];
+    }
+    for (; j < fs; j++) val += (unsigned)smp.get(comp, min(first + j, last), x) * (unsigned)(int)vf[j];
+    return (int)val;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -430,7 +458,7 @@ __device__ __forceinline__ void planar_write_one(const P &p, const S &smp, const
         } else {
             const int shift = 11 + 16 - bits;
             int val = 1 << (shift - 1);
-            for (int j = 0; j < fs; j++) val += smp.get(comp, min(first + j, srcRows - 1), x) * vf[j];
+            val = vtap_sum(smp, comp, first, srcRows - 1, x, vf, fs, val);
             d[x] = (uint16_t)(clip_uintp2(val >> shift, bits) << p.dst_shift);
         }
     } else if (p.dstKind == DSTK_PLANARF32) {   // yuv2plane1_float / yuv2planeX_float_c_template (output.c:219-260): the 16-bit value times 1 / 65535
@@ -440,7 +468,7 @@ __device__ __forceinline__ void planar_write_one(const P &p, const S &smp, const
             d[x] = float_mult * (float)clip_u16((smp.get(comp, min(first, srcRows - 1), x) + 4) >> 3);
         } else {
             int val = (1 << 14) - 0x40000000;
-            for (int j = 0; j < fs; j++) val += (int)((unsigned)smp.get(comp, min(first + j, srcRows - 1), x) * (unsigned)(int)vf[j]);
+            val = vtap_sum(smp, comp, first, srcRows - 1, x, vf, fs, val);
             d[x] = float_mult * (float)(0x8000 + clip_i16(val >> 15));
         }
     } else if (p.dstKind == DSTK_PLANAR16 || p.dstKind == DSTK_P016) {
@@ -449,7 +477,7 @@ __device__ __forceinline__ void planar_write_one(const P &p, const S &smp, const
             d[x] = (uint16_t)clip_u16((smp.get(comp, min(first, srcRows - 1), x) + 4) >> 3);
         } else {
             int val = (1 << 14) - 0x40000000;
-            for (int j = 0; j < fs; j++) val += (int)((unsigned)smp.get(comp, min(first + j, srcRows - 1), x) * (unsigned)(int)vf[j]);
+            val = vtap_sum(smp, comp, first, srcRows - 1, x, vf, fs, val);
             d[x] = (uint16_t)(0x8000 + clip_i16(val >> 15));
         }
     } else if (p.dstKind == DSTK_PLANARN) {
@@ -460,7 +488,7 @@ __device__ __forceinline__ void planar_write_one(const P &p, const S &smp, const
         } else {
             const int shift = 11 + 16 - bits;
             int val = 1 << (shift - 1);
-            for (int j = 0; j < fs; j++) val += smp.get(comp, min(first + j, srcRows - 1), x) * vf[j];
+            val = vtap_sum(smp, comp, first, srcRows - 1, x, vf, fs, val);
             d[x] = (uint16_t)(clip_uintp2(val >> shift, bits) << p.dst_shift);
         }
     } else { // 8 bit (also the luma plane of NV12)
@@ -470,7 +498,7 @@ __device__ __forceinline__ void planar_write_one(const P &p, const S &smp, const
             drow[x] = (uint8_t)clip_u8_shr(smp.get(comp, min(first, srcRows - 1), x) + dv, 7);
         } else {
             int val = dv << 12;
-            for (int j = 0; j < fs; j++) val += (int)(unsigned)(smp.get(comp, min(first + j, srcRows - 1), x) * vf[j]);
+            val = vtap_sum(smp, comp, first, srcRows - 1, x, vf, fs, val);
             drow[x] = (uint8_t)clip_u8_shr(val, 19);
         }
     }
@@ -486,32 +514,23 @@ __device__ __forceinline__ void nv_chroma_write_one(const P &p, const S &smp, co
     uint8_t *drow = f.dst[1] + (int64_t)cy * f.dstStride[1];
     if (p.dstKind == DSTK_P016) {   // yuv2nv12cX_16_c_template, output.c:189-217
         int u = (1 << 14) - 0x40000000, v = (1 << 14) - 0x40000000;
-        for (int j = 0; j < fs; j++) {
-            const int r = min(first + j, p.chrSrcH - 1);
-            u += (int)((unsigned)smp.get(1, r, x) * (unsigned)(int)vf[j]);
-            v += (int)((unsigned)smp.get(2, r, x) * (unsigned)(int)vf[j]);
-        }
+        u = vtap_sum(smp, 1, first, p.chrSrcH - 1, x, vf, fs, u);
+        v = vtap_sum(smp, 2, first, p.chrSrcH - 1, x, vf, fs, v);
         uint16_t *d = (uint16_t *)drow;
         d[2 * x] = (uint16_t)(0x8000 + clip_i16(u >> 15));
         d[2 * x + 1] = (uint16_t)(0x8000 + clip_i16(v >> 15));
     } else if (p.dstKind == DSTK_P010) {
         const int bits = p.dst_bits, shift = 11 + 16 - bits;
         int u = 1 << (shift - 1), v = 1 << (shift - 1);
-        for (int j = 0; j < fs; j++) {
-            const int r = min(first + j, p.chrSrcH - 1);
-            u += (int)((unsigned)smp.get(1, r, x) * (unsigned)(int)vf[j]);
-            v += (int)((unsigned)smp.get(2, r, x) * (unsigned)(int)vf[j]);
-        }
+        u = vtap_sum(smp, 1, first, p.chrSrcH - 1, x, vf, fs, u);
+        v = vtap_sum(smp, 2, first, p.chrSrcH - 1, x, vf, fs, v);
         uint16_t *d = (uint16_t *)drow;
         d[2 * x] = (uint16_t)(clip_uintp2(u >> shift, bits) << p.dst_shift);
         d[2 * x + 1] = (uint16_t)(clip_uintp2(v >> shift, bits) << p.dst_shift);
     } else {
         int u = dither8(p.should_dither, cy, x) << 12, v = dither8(p.should_dither, cy, x + 3) << 12;
-        for (int j = 0; j < fs; j++) {
-            const int r = min(first + j, p.chrSrcH - 1);
-            u += (int)((unsigned)smp.get(1, r, x) * (unsigned)(int)vf[j]);
-            v += (int)((unsigned)smp.get(2, r, x) * (unsigned)(int)vf[j]);
-        }
+        u = vtap_sum(smp, 1, first, p.chrSrcH - 1, x, vf, fs, u);
+        v = vtap_sum(smp, 2, first, p.chrSrcH - 1, x, vf, fs, v);
         drow[2 * x + p.uv_swap_dst] = (uint8_t)clip_u8_shr(u, 19);
         drow[2 * x + 1 - p.uv_swap_dst] = (uint8_t)clip_u8_shr(v, 19);
     }
@@ -1001,8 +1020,17 @@ __global__ void __launch_bounds__(256) sws_k_vscale_planar(SwsFrameSet fs, SwsDe
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W || y >= H) return;
     const SwsFramePtrs f = frame_copy(fs, fi);
-    const auto smp = SamplerFor<DIRECT, T>::make(p, f, scratch, frame_elems, fi);
-    planar_write_one(p, smp, f, comp, x, y);
+    if constexpr (DIRECT && SK >= 0) {   // (the component and the reader form are the same for a whole block: one straight-line reader per branch)
+        auto body = [&](const auto &q) {
+            const auto smp = SamplerFor<DIRECT, T>::make(q, f, scratch, frame_elems, fi);
+            if (comp == 0) planar_write_one(q, smp, f, 0, x, y); else if (comp == 1) planar_write_one(q, smp, f, 1, x, y);
+            else if (comp == 2) planar_write_one(q, smp, f, 2, x, y); else planar_write_one(q, smp, f, 3, x, y);
+        };
+        if (p.chr_half) body(chr_half_view<1>(p)); else body(chr_half_view<0>(p));
+    } else {
+        const auto smp = SamplerFor<DIRECT, T>::make(p, f, scratch, frame_elems, fi);
+        planar_write_one(p, smp, f, comp, x, y);
+    }
 }
 
 // semi-planar chroma: grid x over chroma columns, y over chroma rows, z = frame
@@ -1014,8 +1042,16 @@ __global__ void __launch_bounds__(256) sws_k_vscale_nvchroma(SwsFrameSet fs, Sws
     const int x = blockIdx.x * blockDim.x + threadIdx.x, cy = blockIdx.y;
     if (x >= p.chrDstW || cy >= p.chrDstH) return;
     const SwsFramePtrs f = frame_copy(fs, fi);
-    const auto smp = SamplerFor<DIRECT, T>::make(p, f, scratch, frame_elems, fi);
-    nv_chroma_write_one(p, smp, f, x, cy);
+    if constexpr (DIRECT && SK >= 0) {
+        auto body = [&](const auto &q) {
+            const auto smp = SamplerFor<DIRECT, T>::make(q, f, scratch, frame_elems, fi);
+            nv_chroma_write_one(q, smp, f, x, cy);
+        };
+        if (p.chr_half) body(chr_half_view<1>(p)); else body(chr_half_view<0>(p));
+    } else {
+        const auto smp = SamplerFor<DIRECT, T>::make(p, f, scratch, frame_elems, fi);
+        nv_chroma_write_one(p, smp, f, x, cy);
+    }
 }
 
 // packed RGB: grid x over units (pixel pairs, or pixels with full chroma), y over rows, z = frame
@@ -1028,8 +1064,16 @@ __global__ void __launch_bounds__(256) sws_k_vscale_rgb(SwsFrameSet fs, SwsDevPa
     const int units = p.dstKind == DSTK_MONO ? (p.dstW + 7) >> 3 : (p.full_chr || p.dstKind == DSTK_YA) ? p.dstW : (p.dstW + 1) >> 1;
     if (i >= units || y >= p.dstH) return;
     const SwsFramePtrs f = frame_copy(fs, fi);
-    const auto smp = SamplerFor<DIRECT, T>::make(p, f, scratch, frame_elems, fi);
-    rgb_write_unit(p, smp, f, i, y);
+    if constexpr (DIRECT && SK >= 0) {
+        auto body = [&](const auto &q) {
+            const auto smp = SamplerFor<DIRECT, T>::make(q, f, scratch, frame_elems, fi);
+            rgb_write_unit(q, smp, f, i, y);
+        };
+        if (p.chr_half) body(chr_half_view<1>(p)); else body(chr_half_view<0>(p));
+    } else {
+        const auto smp = SamplerFor<DIRECT, T>::make(p, f, scratch, frame_elems, fi);
+        rgb_write_unit(p, smp, f, i, y);
+    }
 }
 
 } // namespace swsk
