@@ -291,6 +291,8 @@ __device__ __forceinline__ int range_sample(const P &p, int v, int chroma)
 
 // the parameter block with the chr_half field (half-width chroma readers: rgb24ToUV_half_c and friends) behind a constant, like KindView below
 template <typename P, int H> struct ChrHalfView : P { static constexpr int32_t chr_half = H; };
+template <int H, typename P>
+__device__ __forceinline__ const ChrHalfView<P, H> &chr_half_view(const P &p) { return reinterpret_cast<const ChrHalfView<P, H> &>(p); }
 
 // sum of fs taps of one output sample of component COMP.  Four taps at a time, their loads issued together: a thread that waits for every sample
 // before it asks for the next one spends the pass on memory latency (4K bgra -> 1080p, 8 taps: 0.49 ms per frame for 66 M samples in the rolled
@@ -308,6 +310,23 @@ __device__ __forceinline__ int tap_sum(const P &p, const SwsFramePtrs &f, int ro
     }
     for (; j < fs; j++) val += read_sample(p, f, COMP, row, sp + j, aux) * taps[j];
     return val;
+}
+
+// the same for the U and the V sample of one chroma position: one pass over the taps, so the loads both components share (a packed or semi-planar
+// source's pixel / chroma pair) are issued once
+template <typename P>
+__device__ __forceinline__ void tap_sum_uv(const P &p, const SwsFramePtrs &f, int row, int sp, const int16_t *taps, int fs, int aux, int &su, int &sv)
+{
+    int u = 0, v = 0, j = 0;
+    for (; j + 4 <= fs; j += 4) {
+        int a[4], b[4], t[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { a[k] = read_sample(p, f, 1, row, sp + j + k, aux); b[k] = read_sample(p, f, 2, row, sp + j + k, aux); t[k] = taps[j + k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { u += a[k] * t[k]; v += b[k] * t[k]; }
+    }
+    for (; j < fs; j++) { const int t = taps[j]; u += read_sample(p, f, 1, row, sp + j, aux) * t; v += read_sample(p, f, 2, row, sp + j, aux) * t; }
+    su = u; sv = v;
 }
 
 // horizontal stage for one output sample (hScale8To15_c / 8To19 / 16To15 / 16To19, swscale.c:69-159)
@@ -350,6 +369,20 @@ __device__ __forceinline__ int hscale_sample(const P &p, const SwsFramePtrs &f, 
     return comp == 3 ? r : range_sample(p, r, comp != 0);
 }
 
+// ... and for the U and V samples of chroma column x together (callers: contexts with chroma and without the fast-bilinear functions)
+template <typename P>
+__device__ __forceinline__ void hscale_sample_uv(const P &p, const SwsFramePtrs &f, int row, int x, int aux, int &ru, int &rv)
+{
+    const int fs = U(p.hChrFs);
+    const int sp = U(p.hChrPos)[x];
+    const int16_t *taps = U(p.hChrF) + (int64_t)fs * x;
+    int u, v;
+    if (p.chr_half) tap_sum_uv(chr_half_view<1>(p), f, row, sp, taps, fs, aux, u, v); else tap_sum_uv(chr_half_view<0>(p), f, row, sp, taps, fs, aux, u, v);
+    u = min(u >> p.hshift, p.hclip); v = min(v >> p.hshift, p.hclip);
+    if (!p.wide) { u = (int16_t)u; v = (int16_t)v; }
+    ru = range_sample(p, u, 1); rv = range_sample(p, v, 1);
+}
+
 // ---- samplers: where the vertical stage gets h-scaled samples from ----
 template <typename T> struct ScratchSampler { // pass-1 output in HBM
     const T *lum, *u, *v; int lumW, chrW; const T *a;
@@ -387,10 +420,6 @@ __device__ __forceinline__ decltype(auto) kind_view(const SwsDevParams &p)
     else return (p);
 }
 
-// (likewise the chr_half field, for the single-pass kernels: the reader form of a whole launch, decided once per thread instead of at every tap)
-template <int H, typename P>
-__device__ __forceinline__ const ChrHalfView<P, H> &chr_half_view(const P &p) { return reinterpret_cast<const ChrHalfView<P, H> &>(p); }
-
 // ------------------------------------------------------------------------------------------
 // pass 1: reader + hscale + range -> scratch planes
 // grid: x over output columns, y over source rows, z = frame * 3 + comp
@@ -403,7 +432,9 @@ __global__ void __launch_bounds__(256) sws_k_hscale(SwsFrameSet fs, SwsDevParams
     const int comp = blockIdx.z % ncomp, fi = blockIdx.z / ncomp;
     const int W = (comp == 0 || comp == 3) ? U(p.dstW) : U(p.chrDstW), H = (comp == 0 || comp == 3) ? U(p.srcH) : U(p.chrSrcH);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
-    if (x >= W || row >= H) return;
+    // the blocks of component 1 produce the U and the V line (one pass over the taps, shared loads issued once); the blocks of component 2 have nothing to do
+    const bool uv_together = !p.no_chroma && !p.fast_bilinear;
+    if (x >= W || row >= H || (uv_together && comp == 2)) return;
     const SwsFramePtrs f = frame_copy(fs, fi);
     T *base = scratch + fi * frame_elems;
     const int64_t lumElems = (int64_t)p.srcH * p.dstW, chrElems = (int64_t)p.chrSrcH * p.chrDstW;
@@ -412,6 +443,12 @@ __global__ void __launch_bounds__(256) sws_k_hscale(SwsFrameSet fs, SwsDevParams
     if (p.vlines) {   // (the row of pass 1 is a virtual line: which picture line it is, and its side term)
         const int32_t *e = p.vlines + 2 * ((comp == 0 || comp == 3) ? row : U(p.nVL) + row);
         srow = e[0]; aux = e[1];
+    }
+    if (uv_together && comp == 1) {
+        int u, v;
+        hscale_sample_uv(p, f, srow, x, aux, u, v);
+        plane[(int64_t)row * W + x] = (T)u; plane[chrElems + (int64_t)row * W + x] = (T)v;
+        return;
     }
     plane[(int64_t)row * W + x] = (T)hscale_sample(p, f, comp, srow, x, aux);
 }

@@ -53,3 +53,13 @@ def test_kinds_larger_pictures(sfmt, dfmt, geo):
     """pictures of several blocks per row: ragged last block, odd widths"""
     sw, sh, dw, dh = geo
     _both(sw, sh, sfmt, dw, dh, dfmt, SWS_BICUBIC | BX, 13)
+
+
+@pytest.mark.parametrize("geo", [(130, 40, 130, 40), (130, 40, 86, 26)])
+@pytest.mark.parametrize("sfmt,dfmt", [("bgra", "ayuv"), ("argb", "vuya"), ("rgba", "uyva")])
+@pytest.mark.parametrize("pad,shift", [(1, 1), (3, 3), (2, 2)])
+def test_rgb32_reader_on_unaligned_pixels(sfmt, dfmt, geo, pad, shift):
+    """the 32 bpp RGB reader loads a pixel as one dword: frames whose pixels are not 4-byte aligned (a view into a byte buffer) must read the same"""
+    from test_gpu_unaligned_frames import run_odd
+    sw, sh, dw, dh = geo
+    run_odd(sw, sh, sfmt, dw, dh, dfmt, SWS_BICUBIC | BX, pad, shift, 0)
