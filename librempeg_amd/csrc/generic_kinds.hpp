@@ -4,6 +4,9 @@
 
 namespace swship {
 
+// where the reader pre-pass of a scaled source puts its 16-bit Y / U / V lines (k_strip.hip launch_rgbread_strip: one working picture per frame)
+struct Read16Layout { uint8_t *base; int64_t frame_bytes, offU, offV; int32_t strideY, strideC; };
+
 // the kernels of ONE source kind
 struct GenericKindFns {
     // single pass (identity horizontal filters), per destination kind; null where the kernel does not write that kind
@@ -17,6 +20,8 @@ struct GenericKindFns {
     void (*hscale32)(SwsFrameSet, SwsDevParams, int32_t *, int64_t);
     // the fused h + v tile kernel (kernels_tile.hpp sws_k_tile_planar): [19-bit intermediates][chroma]
     void (*tile[2][2])(SwsFrameSet, SwsDevParams, SwsTileGeom);
+    // the reader pre-pass in front of the strip kernels for the source kinds without a vector form of it (sws_k_read16_kind)
+    void (*read16)(SwsFrameSet, SwsDevParams, Read16Layout);
 };
 const GenericKindFns *generic_kind_fns(int srcKind);   // k_generic.hip; null: no per-kind kernels for this source kind
 // pass 2 of the two-pass path for ONE destination kind (k_generic_dst.hip); null where the kernel does not write that kind

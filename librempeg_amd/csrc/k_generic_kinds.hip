@@ -13,6 +13,37 @@
 #error "compile with -DGK_SK=<source kind>"
 #endif
 
+namespace swsk {
+
+// Reader pre-pass for ONE source kind: what the reference's input stage hands to the horizontal scaler -- the reader's 16-bit line of every source row,
+// Y at the picture's width, U and V at the chroma width -- as planes of a working picture, element per thread (a streaming pass: the strip kernels
+// that follow read these planes like a planar 16-bit source).  Used for the RGB sources beyond the 8-bit ones, which have a vector form of this
+// pass (kernels_rgbsrc.hpp sws_k_rgb_read16): x2rgb10 / x2bgr10, the 16 / 15 / 12 bpp formats, planar RGB of 9 - 14 bits.
+template <int SK>
+__global__ void __launch_bounds__(256) sws_k_read16_kind(SwsFrameSet fs, SwsDevParams pa, swship::Read16Layout lay)
+{
+    const auto &p = kind_view<SK, -1>(pa);
+    const int fi = blockIdx.z, row = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;   // chroma column: one thread delivers the Y, U and V samples under it, so a pixel is loaded once
+    if (row >= p.srcH || x >= p.chrSrcW) return;
+    const SwsFramePtrs f = frame_copy(fs, fi);
+    uint8_t *fb = lay.base + (int64_t)fi * lay.frame_bytes;
+    uint16_t *dy = (uint16_t *)(fb + (int64_t)row * lay.strideY);
+    uint16_t *du = (uint16_t *)(fb + lay.offU + (int64_t)row * lay.strideC), *dv = (uint16_t *)(fb + lay.offV + (int64_t)row * lay.strideC);
+    if (p.chr_half) {   // half-width chroma readers: a pixel pair (the planner asks for chrSrcW == srcW / 2)
+        const auto &q = chr_half_view<1>(p);
+        const int y0 = read_sample(q, f, 0, row, 2 * x), y1 = read_sample(q, f, 0, row, 2 * x + 1);
+        const int u = read_sample(q, f, 1, row, x), v = read_sample(q, f, 2, row, x);
+        *(uint32_t *)(dy + 2 * x) = (uint32_t)(uint16_t)y0 | ((uint32_t)(uint16_t)y1 << 16);
+        du[x] = (uint16_t)u; dv[x] = (uint16_t)v;
+    } else {            // full-width chroma readers (chrSrcW == srcW)
+        const auto &q = chr_half_view<0>(p);
+        dy[x] = (uint16_t)read_sample(q, f, 0, row, x); du[x] = (uint16_t)read_sample(q, f, 1, row, x); dv[x] = (uint16_t)read_sample(q, f, 2, row, x);
+    }
+}
+
+} // namespace swsk
+
 namespace swship {
 
 template <int DK> static constexpr bool gk_rgb_kind =
@@ -43,6 +74,7 @@ void GK_CAT(generic_kind_fns_, GK_SK)(GenericKindFns *t)
     t->hscale16 = swsk::sws_k_hscale<int16_t, GK_SK>;
     t->hscale32 = swsk::sws_k_hscale<int32_t, GK_SK>;
     t->tile[0][0] = swsk::sws_k_tile_planar<int16_t, false, GK_SK>; t->tile[0][1] = swsk::sws_k_tile_planar<int16_t, true, GK_SK>;
+    t->read16 = swsk::sws_k_read16_kind<GK_SK>;
     t->tile[1][0] = swsk::sws_k_tile_planar<int32_t, false, GK_SK>; t->tile[1][1] = swsk::sws_k_tile_planar<int32_t, true, GK_SK>;
 }
 

@@ -1,6 +1,6 @@
 // Translation unit of the streaming converters: planarToP01xWrapper / planar8ToP01xleWrapper (C3a) and the fused planar float
 // RGB -> 4:4:4 YUV chain (C5).
-#include "devstate.hpp"
+#include "generic_kinds.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_striprgb.hpp"   // (lut_pair, LutTabs: sws_k_lut_rgb)
 #include "kernels_stream.hpp"
@@ -74,6 +74,14 @@ int launch_rgbsrc(const LaunchCtx &L)
 void launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, int64_t offU, int64_t offV, int strideY, int strideC, int64_t offA, int a_pos)
 {
     const SwsDevParams &p = *L.p;
+    if (p.srcKind != SRCK_RGB24 && p.srcKind != SRCK_RGB32 && p.srcKind != SRCK_GBRP) {   // the other RGB kinds (dev_prepare_on: rgbread_kindN): the per-kind element-per-thread reader
+        const GenericKindFns *ks = generic_kind_fns(p.srcKind);
+        Read16Layout l16;
+        l16.base = base; l16.frame_bytes = frame_bytes; l16.offU = offU; l16.offV = offV; l16.strideY = strideY; l16.strideC = strideC;
+        const dim3 grid(cdiv(p.chrSrcW, 256), p.srcH, L.n), blk(256);
+        hipLaunchKernelGGL(ks->read16, grid, blk, 0, L.st, L.fs, p, l16);
+        return;
+    }
     swsk::RgbReadLayout lay;
     lay.base = base; lay.frame_bytes = frame_bytes; lay.offU = offU; lay.offV = offV; lay.strideY = strideY; lay.strideC = strideC; lay.offA = offA; lay.a_pos = a_pos;
     const dim3 grid(cdiv(cdiv(p.srcW, 4), 256), cdiv(p.srcH, swsk::RGBREAD_RPW), L.n), blk(256);

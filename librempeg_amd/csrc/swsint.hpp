@@ -113,6 +113,7 @@ struct Tuning {
     int no_wave = 0, no_march = 0, no_rgbsrc = 0, no_strip = 0, no_strip_dma = 0, no_dot2 = 0, no_tile = 0;
     int no_strip_short = 0;        // off: 8-bit sources with short filters take the short instantiations of the strip kernel (k_strip2.hip)
     int no_generic_kinds = 0;      // off: single-pass element-per-thread launches take the kernel of their (source kind, destination kind) pair (k_generic_kinds.hip)
+    int no_rgbread_kinds = 0;      // off: scaled x2rgb10 / rgb565-family / 9 - 14-bit planar RGB sources reach the strip kernels through the per-kind reader pre-pass
     int strip_cols_auto = 1;       // strip widths of the short family chosen per picture width (3 .. 5 luma, 1 .. 3 chroma columns per lane)
     int no_strip_dma8 = 0;         // off: 8-bit planar sources of the short family take the LDS-DMA form (kernels_strip8.hpp)
     int strip_lds_pad_kb = 0;      // experiments: LDS pad in KB per block of the short / dma8 kernels (lowers the occupancy; results never change)
