@@ -639,9 +639,12 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // (round 4: the other RGB sources whose readers deliver the same 15-bit lines to the same hScale16To15_c -- x2rgb10 / x2bgr10, the 16 / 15 / 12 bpp
             //  formats (rgb16_32ToY/UV(_half)_c_template, input.c:264-412), planar RGB of 9 - 14 bits (planar_rgb16_s16_to_y / _uv, :1216-1270) -- through the
             //  per-kind element-per-thread reader (k_generic_kinds.hip sws_k_read16_kind); without an alpha plane)
-            const bool rgbread_kindN = (p.srcKind == SRCK_RGB30 || p.srcKind == SRCK_RGB16 || (p.srcKind == SRCK_GBRP16 && p.src_depth < 16)) && !p.need_alpha && !c->needAlpha &&
+            //  (... and the packed YUV sources of 10 / 12 bits -- y210 / y212, xv30 / v30x, xv36: read_*_c, y21xle_Y/UV_c, input.c:580-606, :663-729, :811-866 -- whose
+            //  lines are those of a planar yuv422p10 / yuv444p10 / ...12 picture, sh = depth - 1: the pre-pass de-interleaves them)
+            const bool rgbread_kindN = (p.srcKind == SRCK_RGB30 || p.srcKind == SRCK_RGB16 || (p.srcKind == SRCK_GBRP16 && p.src_depth < 16) ||
+                                        (p.srcKind == SRCK_PACKEDHI && p.src_depth >= 9 && p.src_depth <= 15 && c->srcBpc == p.src_depth)) && !p.need_alpha && !c->needAlpha &&
                                        !isALPHA(o.src_format) && !c->tune.no_rgbread_kinds;
-            bool rgbread = (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || rgbread_kindN) && p.chrSrcW == (p.chr_half ? p.srcW >> 1 : p.srcW) && !(p.srcW & 3) && p.chrSrcVSub == 0 && !p.range_active && (!p.need_alpha || d->fullchr_on == 2 || alpha_planar) &&
+            bool rgbread = (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || rgbread_kindN) && p.chrSrcHSub <= 1 && p.chrSrcW == (p.srcW >> p.chrSrcHSub) && !(p.srcW & 3) && p.chrSrcVSub == 0 && !p.range_active && (!p.need_alpha || d->fullchr_on == 2 || alpha_planar) &&
                            (!p.dst_alpha_fill || d->fullchr_on) && !p.no_chroma && !vlines_pending && dst_ok && !c->tune.no_strip && !c->tune.no_rgbsrc && p.dstW >= strip_min_w_eff;
             for (int k = 0; k < 9 && rgbread; k++) rgbread = p.rgb2yuv[k] > -32768 && p.rgb2yuv[k] < 32768;   // (v_dot2_i32_i16 operands)
             d->rgbread_on = false;

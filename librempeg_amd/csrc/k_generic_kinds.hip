@@ -18,7 +18,8 @@ namespace swsk {
 // Reader pre-pass for ONE source kind: what the reference's input stage hands to the horizontal scaler -- the reader's 16-bit line of every source row,
 // Y at the picture's width, U and V at the chroma width -- as planes of a working picture, element per thread (a streaming pass: the strip kernels
 // that follow read these planes like a planar 16-bit source).  Used for the RGB sources beyond the 8-bit ones, which have a vector form of this
-// pass (kernels_rgbsrc.hpp sws_k_rgb_read16): x2rgb10 / x2bgr10, the 16 / 15 / 12 bpp formats, planar RGB of 9 - 14 bits.
+// pass (kernels_rgbsrc.hpp sws_k_rgb_read16): x2rgb10 / x2bgr10, the 16 / 15 / 12 bpp formats, planar RGB of 9 - 14 bits -- and for the packed YUV sources of
+// 10 / 12 bits (y210, xv30, xv36 ...), which it turns into the planes of the planar picture with the same lines.
 template <int SK>
 __global__ void __launch_bounds__(256) sws_k_read16_kind(SwsFrameSet fs, SwsDevParams pa, swship::Read16Layout lay)
 {
@@ -30,16 +31,17 @@ __global__ void __launch_bounds__(256) sws_k_read16_kind(SwsFrameSet fs, SwsDevP
     uint8_t *fb = lay.base + (int64_t)fi * lay.frame_bytes;
     uint16_t *dy = (uint16_t *)(fb + (int64_t)row * lay.strideY);
     uint16_t *du = (uint16_t *)(fb + lay.offU + (int64_t)row * lay.strideC), *dv = (uint16_t *)(fb + lay.offV + (int64_t)row * lay.strideC);
-    if (p.chr_half) {   // half-width chroma readers: a pixel pair (the planner asks for chrSrcW == srcW / 2)
-        const auto &q = chr_half_view<1>(p);
-        const int y0 = read_sample(q, f, 0, row, 2 * x), y1 = read_sample(q, f, 0, row, 2 * x + 1);
-        const int u = read_sample(q, f, 1, row, x), v = read_sample(q, f, 2, row, x);
-        *(uint32_t *)(dy + 2 * x) = (uint32_t)(uint16_t)y0 | ((uint32_t)(uint16_t)y1 << 16);
-        du[x] = (uint16_t)u; dv[x] = (uint16_t)v;
-    } else {            // full-width chroma readers (chrSrcW == srcW)
-        const auto &q = chr_half_view<0>(p);
-        dy[x] = (uint16_t)read_sample(q, f, 0, row, x); du[x] = (uint16_t)read_sample(q, f, 1, row, x); dv[x] = (uint16_t)read_sample(q, f, 2, row, x);
-    }
+    auto body = [&](const auto &q) {
+        if (p.chrSrcHSub) {   // half-width chroma (the RGB readers' half forms, packed 4:2:2): the pixel pair over chroma column x (the planner asks for chrSrcW == srcW / 2)
+            const int y0 = read_sample(q, f, 0, row, 2 * x), y1 = read_sample(q, f, 0, row, 2 * x + 1);
+            const int u = read_sample(q, f, 1, row, x), v = read_sample(q, f, 2, row, x);
+            *(uint32_t *)(dy + 2 * x) = (uint32_t)(uint16_t)y0 | ((uint32_t)(uint16_t)y1 << 16);
+            du[x] = (uint16_t)u; dv[x] = (uint16_t)v;
+        } else {              // chrSrcW == srcW
+            dy[x] = (uint16_t)read_sample(q, f, 0, row, x); du[x] = (uint16_t)read_sample(q, f, 1, row, x); dv[x] = (uint16_t)read_sample(q, f, 2, row, x);
+        }
+    };
+    if (p.chr_half) body(chr_half_view<1>(p)); else body(chr_half_view<0>(p));
 }
 
 } // namespace swsk
