@@ -642,8 +642,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             //  (... and the packed YUV sources of 10 / 12 bits -- y210 / y212, xv30 / v30x, xv36: read_*_c, y21xle_Y/UV_c, input.c:580-606, :663-729, :811-866 -- whose
             //  lines are those of a planar yuv422p10 / yuv444p10 / ...12 picture, sh = depth - 1: the pre-pass de-interleaves them)
             const bool rgbread_kindN = (p.srcKind == SRCK_RGB30 || p.srcKind == SRCK_RGB16 || (p.srcKind == SRCK_GBRP16 && p.src_depth < 16) ||
-                                        (p.srcKind == SRCK_PACKEDHI && p.src_depth >= 9 && p.src_depth <= 15 && c->srcBpc == p.src_depth)) && !p.need_alpha && !c->needAlpha &&
-                                       !isALPHA(o.src_format) && !c->tune.no_rgbread_kinds;
+                                        (p.srcKind == SRCK_PACKEDHI && p.src_depth >= 9 && p.src_depth <= 15 && c->srcBpc == p.src_depth) ||
+                                        // (the 8-bit packed 4:4:4 formats -- ayuv / vuya / vuyx / uyva / vyu444: bytes, hScale8To15_c's sh = 7 -- as 16-bit words with 8 significant bits)
+                                        (p.srcKind == SRCK_PACKED444 && p.src_depth == 8 && c->srcBpc == 8)) && !p.need_alpha && !c->needAlpha &&   // (an alpha component nobody reads is skipped)
+                                       !c->tune.no_rgbread_kinds;
             bool rgbread = (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || rgbread_kindN) && p.chrSrcHSub <= 1 && p.chrSrcW == (p.srcW >> p.chrSrcHSub) && !(p.srcW & 3) && p.chrSrcVSub == 0 && !p.range_active && (!p.need_alpha || d->fullchr_on == 2 || alpha_planar) &&
                            (!p.dst_alpha_fill || d->fullchr_on) && !p.no_chroma && !vlines_pending && dst_ok && !c->tune.no_strip && !c->tune.no_rgbsrc && p.dstW >= strip_min_w_eff;
             for (int k = 0; k < 9 && rgbread; k++) rgbread = p.rgb2yuv[k] > -32768 && p.rgb2yuv[k] < 32768;   // (v_dot2_i32_i16 operands)

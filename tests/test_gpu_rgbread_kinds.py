@@ -15,7 +15,8 @@ OLD = dict(strip_min_w=0, no_rgbread_kinds=1)
 
 SRC = ["x2rgb10le", "x2bgr10le", "rgb565le", "bgr565le", "rgb555le", "bgr555le", "rgb444le", "bgr444le", "rgb565be", "gbrp9le", "gbrp10le", "gbrp12le", "gbrp14le", "gbrp10be",
        "gbrp10msble", "gbrp12msble",
-       "y210le", "y212le", "xv30le", "v30xle", "xv36le", "xv36be"]   # (packed YUV of 10 / 12 bits: the lines of a planar yuv422p10 / yuv444p10 / ...12 picture)
+       "y210le", "y212le", "xv30le", "v30xle", "xv36le", "xv36be",
+       "vyu444", "vuyx", "ayuv", "vuya", "uyva", "gbrap10le", "gbrap12le"]   # (packed YUV of 10 / 12 bits: the lines of a planar yuv422p10 / yuv444p10 / ...12 picture)
 DST = ["yuv420p", "yuv422p", "yuv444p", "nv12", "yuv420p10le", "p010le", "bgra", "rgb24", "gbrp", "uyvy422"]
 
 
@@ -36,14 +37,16 @@ def test_formats(src, dst):
                          ids=lambda g: f"{g[0]}x{g[1]}-{g[2]}x{g[3]}")
 def test_scalers_and_geometries(flags, geom):
     sw, sh, dw, dh = geom
-    for src, dst in (("x2rgb10le", "yuv420p"), ("rgb565le", "nv12"), ("gbrp10le", "yuv422p10le"), ("gbrp12le", "bgra"), ("y210le", "yuv420p"), ("xv30le", "yuv420p10le"), ("xv36le", "nv12")):
+    for src, dst in (("x2rgb10le", "yuv420p"), ("rgb565le", "nv12"), ("gbrp10le", "yuv422p10le"), ("gbrp12le", "bgra"), ("y210le", "yuv420p"), ("xv30le", "yuv420p10le"), ("xv36le", "nv12"), ("vuya", "yuv420p"), ("vyu444", "nv12")):
         run_case(sw, sh, src, dw, dh, dst, flags | BX, seed=7, tune=TUNE)
 
 
 def test_planner_and_fallbacks():
     assert "rgbread" in run_case(1920, 54, "gbrp10le", 1280, 36, "yuv420p", SWS_BICUBIC | BX)[0]                   # wide enough without the option
     assert "rgbread" not in run_case(642, 48, "rgb565le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0]      # width not a multiple of 4
-    assert "rgbread" not in run_case(640, 48, "gbrap10le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0]     # a source with an alpha plane
+    assert "rgbread" in run_case(640, 48, "gbrap10le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0]         # a source with an alpha plane nobody reads
+    assert "rgbread" not in run_case(640, 48, "gbrap10le", 320, 24, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0]    # ... and one the destination wants scaled
+    assert "rgbread" not in run_case(640, 48, "ayuv", 320, 24, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0]
     assert "rgbread" not in run_case(640, 48, "gbrp16le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0]      # 16-bit samples: 16-bit lines
     assert "rgbread" not in run_case(640, 48, "x2rgb10le", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=TUNE)[0]    # a range conversion
     assert "rgbread" not in run_case(640, 48, "x2rgb10le", 320, 24, "yuv420p16le", SWS_BICUBIC | BX, tune=TUNE)[0]  # 19-bit intermediates

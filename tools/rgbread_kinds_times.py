@@ -9,7 +9,7 @@ import oracle_lib as OL
 from librempeg_amd import SwsContext, HostFrame, DeviceFrame, SWS_BICUBIC, SWS_BITEXACT
 mode = sys.argv[1] if len(sys.argv) > 1 else "down"
 N = 4
-PAIRS = {"down": [(a, b) for a in ("x2rgb10le", "rgb565le", "gbrp10le", "bgr444le", "y210le", "xv30le", "xv36le") for b in ("yuv420p", "nv12", "yuv420p10le", "bgra", "rgb24", "yuv444p")]}
+PAIRS = {"down": [(a, b) for a in ("x2rgb10le", "rgb565le", "gbrp10le", "bgr444le", "y210le", "xv30le", "xv36le", "vuya", "vyu444") for b in ("yuv420p", "nv12", "yuv420p10le", "bgra", "rgb24", "yuv444p")]}
 PAIRS["same"] = PAIRS["down"]
 PAIRS["up"] = PAIRS["down"]
 geo = {"same": (1920, 1080, 1920, 1080), "down": (3840, 2160, 1920, 1080), "up": (1280, 720, 1920, 1080)}[mode]
