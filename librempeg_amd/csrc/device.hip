@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "devstate.hpp"
+#include "generic_kinds.hpp"
 #include "../../include/hwcontext_hip.h"
 
 namespace swship {
@@ -499,6 +500,18 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     p.copy_shiftonly_luma = !o.src_range;
     p.dither_mode = o.dither;
 
+    // ---- the other packed destinations behind the strip kernels (fullchr_on == 4): rgb565 / 555 / 444, x2rgb10 / x2bgr10, the 8-bit packed 4:4:4 formats
+    //      (ayuv / vuya / vuyx / uyva / vyu444) and the packed YUV formats of 10 / 12 bits (y210 / y212, xv30 / v30x, xv36).  Same route as fullchr_on 1 / 3:
+    //      the strip kernels store the vertical sums of Y, U and V as int32 planes (chroma at the writer's own chroma width), and the epilogue is the generic
+    //      writer itself in its X form over those sums (k_generic_dst.hip sws_k_sum_writer).  Tentative like the others: undone below when no strip plan
+    //      fits or a row takes one of the writer's short forms (the 10 / 12-bit packed YUV formats have X writers only) ----
+    if (!d->fullchr_on && c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB16 || p.dstKind == DSTK_RGB30 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI) && !p.wide &&
+        c->dstBpc <= 14 && !c->needAlpha && fc_plain && !(o.flags & SWS_FAST_BILINEAR) && !(o.dst_w & 3) && o.dst_w >= strip_min_w_eff && c->chrDstVSubSample == 0 &&
+        !(bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14)) &&   // (identity horizontal filters: the single-pass per-kind kernels are as fast or faster -- no sum planes)
+        !c->tune.no_strip && !c->tune.no_mixed && !(c->tune.no_rgbread_kinds & 2)) {
+        d->fullchr_on = 4; d->fullchr_kind = p.dstKind;
+        p.dstKind = DSTK_RAW32; p.u_plane_dst = 1; p.v_plane_dst = 2;
+    }
     // ---- filter tables -> one device blob ----
     d->unity_h = false;
     if (c->plan == PLAN_MAIN) {
@@ -1130,7 +1143,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             d->all_x_mode = all_x;
             d->striprgb_ok = d->striprgb_ok && (all_x || (lfs == 1 && cfs == 1));
             if (d->alpha_launch == 2 && !d->striprgb_ok) d->alpha_launch = 0;
-            if (d->fullchr_on && ((!all_x && !(lfs == 1 && cfs == 1) && d->fullchr_kind != DSTK_GBRP) || !d->strip_ok)) {   // (planar RGB: any_vscale, always the X form)   // no strip plan, or a row in one of the short writer forms: the generic full-chroma writer keeps it
+            if (d->fullchr_on && ((!all_x && !(lfs == 1 && cfs == 1) && d->fullchr_kind != DSTK_GBRP && d->fullchr_kind != DSTK_PACKEDHI) ||
+                                  (d->fullchr_on == 4 && lfs == 1 && cfs == 1 && d->fullchr_kind != DSTK_PACKEDHI) || !d->strip_ok)) {   // (planar RGB: any_vscale, always the X form)   // no strip plan, or a row in one of the short writer forms: the generic full-chroma writer keeps it
                 d->fullchr_on = 0; d->strip_ok = false; d->rgbread_on = false; d->striprgbsrc_ok = false; d->rgb2rgb_ok = false;
                 p.dstKind = d->fullchr_kind; p.u_plane_dst = dd->comp[1].plane; p.v_plane_dst = dd->comp[2].plane;
             }
@@ -1286,7 +1300,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     if (c->plan == PLAN_MAIN && d->split_mode && d->striprgb_direct == 3 && d->strip_ok && d->striprgbsrc_ok && !d->mixed_ok && !d->striprgb_ok && !d->fullchr_on && !d->alpha_launch && !d->rgbread_on &&
         !c->tune.no_strip_rgbsrc) { c->path_name = "main:strip_packed422"; c->kernel_name = "sws_k_strip_rgbsrc"; }     // (aligned frames; launch_plan_le falls back to split422 + strip_march otherwise)
     if (c->plan == PLAN_MAIN && d->join422) c->path_name += "+join422";
-    if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += d->fullchr_on == 3 ? "+lut_rgb" : "+fullchr_rgb";
+    if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += d->fullchr_on == 3 ? "+lut_rgb" : d->fullchr_on == 4 ? "+sum_writer" : "+fullchr_rgb";
     if (c->plan == PLAN_MAIN && d->rgb2rgb_ok && !c->tune.no_strip_rgb2rgb && (d->fullchr_on == 1 || d->fullchr_on == 2) && !d->fullchr_direct && d->rgbread_on && d->strip_ok) {
         c->path_name = "main:strip_rgb2rgb"; c->kernel_name = "sws_k_strip_rgb2rgb";      // (aligned frames; launch_plan_le falls back to rgbread + strip_march + fullchr_rgb otherwise)
     }
@@ -1549,6 +1563,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
                      !d->mixed_ok && !d->striprgb_ok && !d->rgbsrc_ok && !d->rgb444_ok && frames_vec_ok(frames, n) && frames_desc_ok(frames, n, p.srcH, p.dstH);
     // full-chroma RGB destination (dev_prepare_on): the strip kernels write three int32 sum planes per frame, sws_k_fullchr_rgb follows
     std::vector<SwsFramePtrs> p422fr, p422join;
+    uint8_t *sum_tab = nullptr;   // fullchr_on == 4: the epilogue's one-tap bank (behind the sum planes of the call)
     if (c->plan == PLAN_MAIN && d->fullchr_on && d->fullchr_direct) {   // the epilogue alone, on the caller's planes (Y, U, V, A order)
         const bool u1 = p.u_plane_src == 1;
         p422join.resize((size_t)n);
@@ -1567,8 +1582,9 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         const int sP = (int)a256(4 * (int64_t)p.dstW);
         const int nraw = d->fullchr_on == 2 ? 4 : 3;     // (2: the alpha sums as a fourth plane)
         const int64_t plane = (int64_t)sP * p.dstH, fbytes = a256(nraw * plane);
-        int r = grow(c, &d->join_img, &d->join_bytes, (size_t)fbytes * (size_t)n);
+        int r = grow(c, &d->join_img, &d->join_bytes, (size_t)fbytes * (size_t)n + (d->fullchr_on == 4 ? sum_writer_table_bytes(p.dstH) : 0));   // (4: the epilogue's one-tap bank behind the frames)
         if (r < 0) return r;
+        sum_tab = (uint8_t *)d->join_img + (size_t)fbytes * (size_t)n;
         p422fr.assign(frames, frames + n);
         p422join.resize((size_t)n);
         for (int i = 0; i < n; i++) {
@@ -1746,7 +1762,8 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         J.frames = p422join.data();
         if (n == 1) { J.fs.table = nullptr; J.fs.one = p422join[0]; }
         else { const SwsFramePtrs *t = nullptr; int r = aux_table(0, p422join, &t); if (r < 0) return r; J.fs.table = t; }
-        if (d->fullchr_on) launch_fullchr_rgb(J);
+        if (d->fullchr_on == 4) { int r = launch_sum_writer(J, d->fullchr_kind, sum_tab); if (r < 0) return r; }
+        else if (d->fullchr_on) launch_fullchr_rgb(J);
         else launch_layout_join422(J, d->join422 == 2);
     }
     if (stage_out) {   // the staged destination planes back into the caller's picture

@@ -32,7 +32,12 @@ struct GenericDstFns {
     void (*planar32)(SwsFrameSet, SwsDevParams, const int32_t *, int64_t, int);
     void (*nvchroma16)(SwsFrameSet, SwsDevParams, const int16_t *, int64_t);
     void (*nvchroma32)(SwsFrameSet, SwsDevParams, const int32_t *, int64_t);
+    // the packed writer of this kind over the strip kernels' int32 sum planes (sws_k_sum_writer; dev_prepare_on: fullchr_on == 4); null: not built for this kind
+    void (*sum_writer)(SwsFrameSet, SwsDevParams);
 };
+// k_generic.hip: the epilogue of fullchr_on == 4 (J.fs holds {src = the int32 sum planes, dst = the packed picture}); tab: device memory for the one-tap bank it runs with
+int launch_sum_writer(const LaunchCtx &J, int dst_kind, uint8_t *tab);
+size_t sum_writer_table_bytes(int dstH);
 // (every DstKind but DSTK_RAW32 = 22)
 #define GENERIC_DST_PARTS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21)
 #define GENERIC_DST_DECL(n) void generic_dst_fns_##n(GenericDstFns *t);
