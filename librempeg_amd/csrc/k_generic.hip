@@ -36,25 +36,25 @@ static __global__ void sws_k_sum_table(int16_t *taps, int32_t *pos, int rows)
 {
     const int y = blockIdx.x * blockDim.x + threadIdx.x;
     if (y >= rows) return;
-    taps[3 * y] = 1; taps[3 * y + 1] = 0; taps[3 * y + 2] = 0;
+    taps[2 * y] = 1; taps[2 * y + 1] = 0;   // (two taps that do not add up to 4096: packed_vscale's X form, vscale.c:135-157)
     pos[y] = y;
 }
 
-size_t sum_writer_table_bytes(int dstH) { return (((size_t)6 * dstH + 255) & ~(size_t)255) + (((size_t)4 * dstH + 255) & ~(size_t)255); }
+size_t sum_writer_table_bytes(int dstH) { return (((size_t)4 * dstH + 255) & ~(size_t)255) + (((size_t)4 * dstH + 255) & ~(size_t)255); }
 
 // the packed writer of `dst_kind` over the strip kernels' sum planes (k_generic_dst.hip sws_k_sum_writer): the context's parameter block with the real
-// destination kind and a vertical bank of the taps {1, 0, 0} at position y over "source" pictures of the destination's height -- the sum planes
+// destination kind and a vertical bank of the taps {1, 0} at position y over "source" pictures of the destination's height -- the sum planes
 int launch_sum_writer(const LaunchCtx &J, int dst_kind, uint8_t *tab)
 {
     const SwsDevParams &p = *J.p;
     const GenericDstFns *kd = dst_fns(dst_kind);
     if (!kd || !kd->sum_writer) { log_msg(J.c, 0, "internal error: no sum writer for destination kind %d\n", dst_kind); return SWS_AVERROR(EINVAL); }
     int16_t *taps = (int16_t *)tab;
-    int32_t *pos = (int32_t *)(tab + (((size_t)6 * p.dstH + 255) & ~(size_t)255));
+    int32_t *pos = (int32_t *)(tab + (((size_t)4 * p.dstH + 255) & ~(size_t)255));
     hipLaunchKernelGGL(sws_k_sum_table, dim3(cdiv(p.dstH, 256)), dim3(256), 0, J.st, taps, pos, p.dstH);
     SwsDevParams pe = p;
     pe.dstKind = dst_kind;
-    pe.vLumF = pe.vChrF = taps; pe.vLumPos = pe.vChrPos = pos; pe.vLumFs = pe.vChrFs = 3;
+    pe.vLumF = pe.vChrF = taps; pe.vLumPos = pe.vChrPos = pos; pe.vLumFs = pe.vChrFs = 2;
     pe.srcH = p.dstH; pe.chrSrcH = p.chrDstH;
     pe.need_alpha = 0;
     const int units = p.full_chr ? p.dstW : (p.dstW + 1) >> 1;

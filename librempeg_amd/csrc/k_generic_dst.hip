@@ -13,7 +13,7 @@ namespace swsk {
 
 // The packed writers behind the STRIP kernels (dev_prepare_on: fullchr_on == 4): the strip kernels leave the vertical sums of Y, U and V as int32 planes
 // (DSTK_RAW32, chroma at the writer's chroma width), and this epilogue runs the writer's X form -- init + sum of taps x lines, output.c -- over them with a
-// bank of the three taps {1, 0, 0} at position y, whose "lines" are the sum planes themselves: init + S * 1 + S' * 0 + S'' * 0.  No new arithmetic: the
+// bank of the two taps {1, 0} at position y, whose "lines" are the sum planes themselves: init + S * 1 + S' * 0.  No new arithmetic: the
 // routine is rgb_write_unit, the kind folded at compile time.
 struct SumSampler {
     const uint8_t *pl[3]; int st[3];

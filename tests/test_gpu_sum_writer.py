@@ -2,7 +2,7 @@
 x2rgb10 / x2bgr10 (yuv2rgb_X_c_template + yuv2rgb_write, yuv2rgb_full_X_c_template + yuv2rgb_write_full: output.c:1714-1784, :2005-2070), the 8-bit packed
 4:4:4 formats (yuv2ayuv_X_c_template, yuv2vyu444_X_c: :2903-3290) and the packed YUV formats of 10 / 12 bits (yuv2y2xxle_X_c, yuv2xv30le / v30xle_X_c,
 yuv2xv36le_X_c: :2712-2866, :3088-3169).  The strip kernels leave the vertical sums as int32 planes and the generic writer's X form runs over them with the
-one-tap bank {1, 0, 0} (k_generic_dst.hip sws_k_sum_writer).  Every case also runs with the option no_rgbread_kinds = 2 (the two-pass kernels)."""
+bank of the two taps {1, 0} (k_generic_dst.hip sws_k_sum_writer).  Every case also runs with the option no_rgbread_kinds = 2 (the two-pass kernels)."""
 import pytest
 
 from librempeg_amd import (SWS_BICUBIC, SWS_BILINEAR, SWS_LANCZOS, SWS_AREA, SWS_POINT, SWS_BITEXACT, SWS_ACCURATE_RND, SWS_FULL_CHR_H_INT,
