@@ -26,11 +26,36 @@ __global__ void __launch_bounds__(256) sws_k_read16_kind(SwsFrameSet fs, SwsDevP
     const auto &p = kind_view<SK, -1>(pa);
     const int fi = blockIdx.z, row = blockIdx.y;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;   // chroma column: one thread delivers the Y, U and V samples under it, so a pixel is loaded once
-    if (row >= p.srcH || x >= p.chrSrcW) return;
+    if (row >= p.srcH) return;
     const SwsFramePtrs f = frame_copy(fs, fi);
     uint8_t *fb = lay.base + (int64_t)fi * lay.frame_bytes;
     uint16_t *dy = (uint16_t *)(fb + (int64_t)row * lay.strideY);
     uint16_t *du = (uint16_t *)(fb + lay.offU + (int64_t)row * lay.strideC), *dv = (uint16_t *)(fb + lay.offV + (int64_t)row * lay.strideC);
+    if constexpr (SK == SRCK_GBRP16) {
+        // planar RGB of 9 - 14 bits: eight pixels per thread, one 16-byte load per plane.  The arithmetic stays read_sample's: the loaded words are presented to it
+        // as a one-row picture in registers.  (planar_rgb16_s16_to_uv has no half-width form: chroma column x is pixel x, input.c:1249-1270.)
+        const uint8_t *pg = f.src[0] + (int64_t)row * f.srcStride[0], *pb = f.src[1] + (int64_t)row * f.srcStride[1], *pr = f.src[2] + (int64_t)row * f.srcStride[2];
+        if (!(p.srcW & 7) && !(((uintptr_t)pg | (uintptr_t)pb | (uintptr_t)pr) & 15)) {   // (wave-uniform)
+            const int x0 = 8 * x;
+            if (x0 >= p.srcW) return;
+            union V8 { uint4 q; uint16_t h[8]; };
+            V8 g, bb, r, oy, ou, ov;
+            g.q = *(const uint4 *)(pg + 2 * x0); bb.q = *(const uint4 *)(pb + 2 * x0); r.q = *(const uint4 *)(pr + 2 * x0);
+            SwsFramePtrs fl = f;
+            fl.src[0] = (const uint8_t *)g.h; fl.src[1] = (const uint8_t *)bb.h; fl.src[2] = (const uint8_t *)r.h;
+            fl.srcStride[0] = fl.srcStride[1] = fl.srcStride[2] = 0;
+            const auto &q = chr_half_view<0>(p);   // (this reader has one form)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                oy.h[k] = (uint16_t)read_sample(q, fl, 0, 0, k); ou.h[k] = (uint16_t)read_sample(q, fl, 1, 0, k); ov.h[k] = (uint16_t)read_sample(q, fl, 2, 0, k);
+            }
+            *(uint4 *)(dy + x0) = oy.q;
+            if (x0 + 8 <= p.chrSrcW) { *(uint4 *)(du + x0) = ou.q; *(uint4 *)(dv + x0) = ov.q; }
+            else for (int k = 0; k < 8; k++) if (x0 + k < p.chrSrcW) { du[x0 + k] = ou.h[k]; dv[x0 + k] = ov.h[k]; }
+            return;
+        }
+    }
+    if (x >= p.chrSrcW) return;
     auto body = [&](const auto &q) {
         if (p.chrSrcHSub) {   // half-width chroma (the RGB readers' half forms, packed 4:2:2): the pixel pair over chroma column x (the planner asks for chrSrcW == srcW / 2)
             const int y0 = read_sample(q, f, 0, row, 2 * x), y1 = read_sample(q, f, 0, row, 2 * x + 1);
