@@ -96,11 +96,12 @@ STRIP_DST = ["yuv420p", "yuv422p", "yuv444p", "yuv411p", "yuvj420p", "yuv420p10l
              "yuva444p10le", "yuva422p", "gbrap", "gbrp10le", "gbrap12le", "gbrp12msble", "rgb0", "gbrp16le"]
 
 
-def _strip_cases(n, seed):
+def _strip_cases(n, seed, srcs=None, dsts=None):
     rng = random.Random(seed)
     out = []
+    srcs, dsts = srcs or STRIP_SRC, dsts or STRIP_DST
     for k in range(n):
-        sf, df = rng.choice(STRIP_SRC), rng.choice(STRIP_DST)
+        sf, df = rng.choice(srcs), rng.choice(dsts)
         mode = rng.random()
         if mode < 0.2:        # same size
             sw = dw = rng.choice([rng.randint(2, 400), 4 * rng.randint(1, 120)]); sh = dh = rng.randint(2, 90)
@@ -140,6 +141,29 @@ def test_random_conversions_on_the_strip_family(case):
         pytest.skip("the oracle refuses this context")
     del o
     run_case(sw, sh, sf, dw, dh, df, flags, seed=k + 3, colorspace=cs, device_frames=bool(k % 3), opts=opts or None, tune=tune)
+
+
+# the formats round 4 moved behind the strip kernels (reader pre-pass per source kind: sws_k_read16_kind; packed destinations through the int32 sums:
+# sws_k_sum_writer; scaled packed RGB -> packed RGB in one launch: sws_k_strip_rgb2rgb; packed 4:2:2 sources without the split pass), drawn against
+# each other and against the plain planar / semi-planar formats with the strip generator's sizes, options, colourspace details and strip-width tunes
+R4_SRC = ["x2rgb10le", "x2bgr10le", "rgb565le", "bgr565le", "rgb555le", "bgr555be", "rgb444le", "bgr444le", "rgb565be", "gbrp9le", "gbrp10le", "gbrp12le", "gbrp14le", "gbrp10be",
+          "gbrap10le", "gbrap12le", "y210le", "y212le", "xv30le", "v30xle", "xv36le", "xv36be", "ayuv", "vuya", "vuyx", "uyva", "vyu444", "yuva420p", "yuva444p", "rgba", "bgra",
+          "rgb24", "bgr24", "argb", "0rgb", "yuyv422", "uyvy422", "yvyu422", "yuv420p", "nv12", "yuv444p", "yuv422p10le", "p010le", "gbrp", "gbrap"]
+R4_DST = ["rgb565le", "bgr565le", "rgb555le", "bgr555le", "rgb444le", "bgr444le", "rgb565be", "bgr555be", "x2rgb10le", "x2bgr10le", "ayuv", "vuya", "vuyx", "uyva", "vyu444",
+          "y210le", "y212le", "xv30le", "v30xle", "xv36le", "xv36be", "yuv420p", "yuv422p", "yuv444p", "nv12", "nv21", "nv16", "p010le", "yuv420p10le", "yuyv422", "uyvy422",
+          "rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "gbrp", "gbrap", "gray8", "yuva420p"]
+
+
+@pytest.mark.parametrize("case", _strip_cases(int(_HUNT_N or 3000), int(_HUNT_SEED or 40404), R4_SRC, R4_DST),
+                         ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
+def test_random_conversions_on_the_round4_routes(case):
+    sw, sh, sf, dw, dh, df, flags, k, opts, cs, tune = case
+    try:
+        o = OL.Oracle(sw, sh, sf, dw, dh, df, flags, **opts)
+    except Exception:
+        pytest.skip("the oracle refuses this context")
+    del o
+    run_case(sw, sh, sf, dw, dh, df, flags, seed=k + 5, colorspace=cs, device_frames=bool(k % 3), opts=opts or None, tune=tune)
 
 
 def _slice_cases(n, seed):
