@@ -853,7 +853,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 // (raw sums: the packed X form's own taps -- except when both vertical filters have one tap: the packed writers then take their "_1" forms
                 //  (yuv2rgb_full_1, yuv2rgb_1: vscale.c:136-141), which ignore the coefficients like yuv2plane1 does and equal the X arithmetic with the tap
                 //  4096: Y = buf << 2 == (buf << 12 + (1 << 9)) >> 10, (buf + 64) >> 7 == (buf << 12 + (1 << 18)) >> 19; planar RGB has no such form, vscale.c:173-212)
-                const bool raw_one_one = p.dstKind == DSTK_RAW32 && c->vLum.size == 1 && c->vChr.size == 1 && d->fullchr_kind != DSTK_GBRP;
+                //  The packed YUV formats of 10 / 12 bits (DSTK_PACKEDHI) have X writers only, which multiply by the bank's value even when it is the only tap
+                //  (4095 after initFilter's normalisation, 0 in the zero-vector rows of a source of fewer than four rows with shifted chroma): their own taps.
+                const bool raw_one_one = p.dstKind == DSTK_RAW32 && c->vLum.size == 1 && c->vChr.size == 1 && d->fullchr_kind != DSTK_GBRP && d->fullchr_kind != DSTK_PACKEDHI;
                 const bool chr_plane1 = (p.dstKind != DSTK_NV12 && p.dstKind != DSTK_P010 && p.dstKind != DSTK_RAW32) || raw_one_one, lum_plane1 = p.dstKind != DSTK_RAW32 || raw_one_one;
                 const int strip_cols_l = c->tune.strip_cols_l == 2 ? 2 : 4;
                 const int strip_cols_c = c->tune.strip_cols_c == 1 ? 1 : 2;

@@ -63,6 +63,21 @@ def test_planner_and_fallbacks():
     run_case(640, 48, "yuv420p", 320, 48, "rgb565le", SWS_BILINEAR | BX, tune=TUNE)     # two chroma taps adding up to 4096: the _1 / _2 forms
 
 
+@pytest.mark.parametrize("dst", ["y210le", "y212le", "xv30le", "v30xle", "xv36le", "xv36be"])
+@pytest.mark.parametrize("src", ["yuv444p", "yuv422p", "yuv422p10le", "gbrp14le", "bgra", "rgb565le"])
+def test_one_tap_vertical_banks_keep_their_coefficients(src, dst):
+    """a source of fewer than four rows gives BOTH vertical banks one tap (initFilter, utils.c:575-610), and the packed YUV formats of 10 / 12 bits have X writers
+    only (output.c:2712-2866, :3088-3169): the one tap multiplies -- 4095 after the normalisation, 0 in the zero-vector rows a shifted chroma position leaves at
+    the top of the picture (chroma 0 there) -- where the other packed writers' _1 forms ignore it.  Found by the round-4 random draw (seed 2222, case 9759)."""
+    for (sw, sh, dw, dh, flags, opts) in ((1836, 3, 1512, 39, SWS_BILINEAR | SWS_FULL_CHR_H_INT | SWS_ACCURATE_RND, dict(src_v_chr_pos=256)),
+                                          (1836, 2, 1512, 39, SWS_BILINEAR | BX, dict(src_v_chr_pos=256)),
+                                          (640, 3, 320, 12, SWS_BILINEAR | BX, dict(src_v_chr_pos=512)),
+                                          (640, 3, 320, 40, SWS_LANCZOS | BX, dict(src_v_chr_pos=384)),
+                                          (640, 3, 428, 3, SWS_BICUBIC | BX, None),
+                                          (640, 2, 320, 7, SWS_BICUBIC | BX, dict(dst_v_chr_pos=256))):
+        run_case(sw, sh, src, dw, dh, dst, flags, seed=sw + dh, opts=opts, tune=TUNE)
+
+
 def test_full_size_frames_host_frames_and_unaligned():
     assert "sum_writer" in run_case(1920, 1080, "yuv420p", 1280, 720, "rgb565le", SWS_BICUBIC | BX, seed=2)[0]
     assert "sum_writer" in run_case(1920, 1080, "nv12", 2560, 1440, "x2rgb10le", SWS_BICUBIC | BX, seed=3)[0]
