@@ -166,6 +166,40 @@ def test_random_conversions_on_the_round4_routes(case):
     run_case(sw, sh, sf, dw, dh, df, flags, seed=k + 5, colorspace=cs, device_frames=bool(k % 3), opts=opts or None, tune=tune)
 
 
+# sources of one to four rows (initFilter gives their vertical banks one tap, with zero-vector rows under a shifted chroma position) and destinations of a few
+# rows, wide enough for the strip family: the corner the one-tap rules of the planner (plane1 forms, the packed writers' _1 / _2 / X choice per row) live in
+def _short_cases(n, seed):
+    rng = random.Random(seed)
+    srcs, dsts = sorted(set(STRIP_SRC + R4_SRC)), sorted(set(STRIP_DST + R4_DST))
+    out = []
+    for k in range(n):
+        sf, df = rng.choice(srcs), rng.choice(dsts)
+        sw = rng.choice([4 * rng.randint(80, 480), rng.randint(320, 2000)]); dw = rng.choice([sw, 4 * rng.randint(80, 480), rng.randint(320, 2000)])
+        sh = rng.randint(1, 4); dh = rng.choice([sh, rng.randint(1, 6), rng.randint(1, 60)])
+        if rng.random() < 0.25:
+            sh, dh = dh, sh
+        flags = rng.choice(SCALERS) | rng.choice(EXTRA)
+        opts = {}
+        if rng.random() < 0.6:
+            opts = dict(src_v_chr_pos=rng.choice([-513, 0, 128, 256, 384, 512]), dst_v_chr_pos=rng.choice([-513, 0, 128, 256, 512]))
+            if rng.random() < 0.3:
+                opts.update(dither=rng.choice([0, 1, 2]), src_range=rng.choice([0, 1]), dst_range=rng.choice([0, 1]))
+        tune = {"strip_min_w": 0} if rng.random() < 0.5 else {}
+        out.append((sw, sh, sf, dw, dh, df, flags, k, opts, None, tune))
+    return out
+
+
+@pytest.mark.parametrize("case", _short_cases(int(_HUNT_N or 2500), int(_HUNT_SEED or 60606)), ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
+def test_random_conversions_of_pictures_of_a_few_rows(case):
+    sw, sh, sf, dw, dh, df, flags, k, opts, cs, tune = case
+    try:
+        o = OL.Oracle(sw, sh, sf, dw, dh, df, flags, **opts)
+    except Exception:
+        pytest.skip("the oracle refuses this context")
+    del o
+    run_case(sw, sh, sf, dw, dh, df, flags, seed=k + 9, device_frames=bool(k % 3), opts=opts or None, tune=tune)
+
+
 def _slice_cases(n, seed):
     rng = random.Random(seed)
     out = []
