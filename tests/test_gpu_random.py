@@ -278,11 +278,11 @@ def test_random_slice_sequences(case):
         assert np.array_equal(a[:, :rb], b[:, :rb]), (case[:7], cuts, rets, p.path(), i, int(np.count_nonzero(a[:, :rb] != b[:, :rb])))
 
 
-def _batch_cases(n, seed):
+def _batch_cases(n, seed, srcs=None, dsts=None):
     rng = random.Random(seed)
     out = []
     for k in range(n):
-        sf, df = rng.choice(STRIP_SRC), rng.choice(STRIP_DST)
+        sf, df = rng.choice(srcs or STRIP_SRC), rng.choice(dsts or STRIP_DST)
         if rng.random() < 0.3:
             sw = dw = 4 * rng.randint(2, 90); sh = dh = 2 * rng.randint(2, 30)
         else:
@@ -295,6 +295,16 @@ def _batch_cases(n, seed):
 
 @pytest.mark.parametrize("case", _batch_cases(int(_HUNT_N or 1200), int(_HUNT_SEED or 4711)), ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
 def test_random_batches(case):
+    _run_batches(case)
+
+
+@pytest.mark.parametrize("case", _batch_cases(int(_HUNT_N or 800), int(_HUNT_SEED or 4712), R4_SRC, R4_DST), ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
+def test_random_batches_on_the_round4_routes(case):
+    """the same over the formats of round 4's helper passes: per-kind reader planes (sws_k_read16_kind) and the int32 sum planes of the packed writers"""
+    _run_batches(case)
+
+
+def _run_batches(case):
     """sws_scale_frames() three times on one context with batches of different sizes and different frames (HBM frames, then a mix with host frames):
     the per-frame working pictures and cached frame tables of the helper passes (reader pre-pass, 4:2:2 / semi-planar splits, 4:2:2 join) must follow"""
     import numpy as np
@@ -342,16 +352,25 @@ def test_random_batches(case):
 
 # HBM-resident frames with odd plane pointers and line sizes, or stored bottom-up (tests/test_gpu_unaligned_frames.py): the strip family's draws on
 # such frames -- the helper passes go through aligned working copies, everything else through the per-sample kernels
-def _odd_cases(n, seed):
+def _odd_cases(n, seed, srcs=None, dsts=None):
     rng = random.Random(seed ^ 0x5EED)
     out = []
-    for c in _strip_cases(n, seed + 77):
+    for c in _strip_cases(n, seed + 77, srcs, dsts):
         out.append(c + ((rng.choice([0, 1, 2, 6, 13]), rng.choice([0, 1, 2, 3, 6]), rng.choice([0, 0, 1, 2, 3])),))
     return out
 
 
 @pytest.mark.parametrize("case", _odd_cases(int(_HUNT_N or 1500), int(_HUNT_SEED or 4242)), ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
 def test_random_conversions_on_unaligned_frames(case):
+    _run_odd_case(case)
+
+
+@pytest.mark.parametrize("case", _odd_cases(int(_HUNT_N or 1000), int(_HUNT_SEED or 4343), R4_SRC, R4_DST), ids=lambda c: f"{c[7]}-{c[2]}_{c[0]}x{c[1]}-{c[5]}_{c[3]}x{c[4]}-{c[6]:x}")
+def test_random_conversions_on_unaligned_frames_of_the_round4_formats(case):
+    _run_odd_case(case)
+
+
+def _run_odd_case(case):
     from test_gpu_unaligned_frames import run_odd
     sw, sh, sf, dw, dh, df, flags, k, opts, cs, tune, (pad, shift, flip) = case
     try:
