@@ -171,6 +171,8 @@ def test_random_conversions_on_the_round4_routes(case):
 def _short_cases(n, seed):
     rng = random.Random(seed)
     srcs, dsts = sorted(set(STRIP_SRC + R4_SRC)), sorted(set(STRIP_DST + R4_DST))
+    if os.environ.get("SWS_RANDOM_ALL_FORMATS"):      # (hunts: every format of the matrix instead of the strip family's)
+        srcs, dsts = sorted(FORMAT_MATRIX_SRC), sorted(FORMAT_MATRIX_DST)
     out = []
     for k in range(n):
         sf, df = rng.choice(srcs), rng.choice(dsts)
