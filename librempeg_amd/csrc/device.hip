@@ -61,19 +61,20 @@ static void dev_state_free(DeviceState *d)
 {
     if (!d) return;
     (void)hipSetDevice(d->device);
-    // (a stream the context does not own -- the caller's, or a frames' hwdevice stream on loan -- may be gone by now: it is never touched here;
-    //  hipFree below waits for the device, so nothing in flight can still be using the blocks)
+    // (a stream the context does not own -- the caller's, or a frames' hwdevice stream on loan -- may be gone by now: it is never touched here)
     if (d->stream && d->own_stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
-    for (void *p : { d->d_tables, d->scratch, d->stage_src, d->stage_dst, (void *)d->d_frames, d->casc_img, d->slice_img, d->d_tilegeom,
-                     d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2, d->casc_img2, d->d_gamma_tab, d->d_ed_err, d->d_pal, d->d_vlines, d->rgbread_img, (void *)d->d_frames2 })
+    // everything this state queued -- on its own stream or on one it borrowed -- is behind the device: wait for the device once, explicitly, before
+    // blocks, pinned tables and events go (no reliance on hipFree's implicit wait, which an asynchronous allocator need not give)
+    (void)hipDeviceSynchronize();
+    for (void *p : { d->d_tables, d->scratch, d->stage_src, d->stage_dst, (void *)d->ring.dev, d->casc_img, d->slice_img, d->d_tilegeom,
+                     d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2, d->casc_img2, d->d_gamma_tab, d->d_ed_err, d->d_pal, d->d_vlines, d->rgbread_img })
         if (p) (void)hipFree(p);
-    if (d->h_frames) (void)hipHostFree(d->h_frames);
-    if (d->h_frames2) (void)hipHostFree(d->h_frames2);
+    if (d->ring.host) (void)hipHostFree(d->ring.host);
+    for (auto &b : d->ring.inflight) if (b.ev) (void)hipEventDestroy(b.ev);
+    for (hipEvent_t e : d->ring.pool) (void)hipEventDestroy(e);
     if (d->join_img) (void)hipFree(d->join_img);
     if (d->split_img) (void)hipFree(d->split_img);
     if (d->stage_img) (void)hipFree(d->stage_img);
-    if (d->d_aux_tables) (void)hipFree(d->d_aux_tables);
-    if (d->h_aux_tables) (void)hipHostFree(d->h_aux_tables);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
     if (d->ev_loan) (void)hipEventDestroy(d->ev_loan);
@@ -1399,6 +1400,97 @@ int grow(SwsInternal *c, void **buf, size_t *cap, size_t need)
 
 static void plane_extent(const PixDesc *d, int w, int h, int k, int *rows, int *row_bytes, int *vsub);
 
+// ---- frame tables of the batched launches (TableRing, devstate.hpp) ----
+static void ring_release(TableRing &R, size_t i)
+{
+    if (R.inflight[i].ev) R.pool.push_back(R.inflight[i].ev);
+    R.inflight.erase(R.inflight.begin() + (long)i);
+}
+
+static int ring_regrow(SwsInternal *c, DeviceState *d, hipStream_t st, int need)
+{
+    TableRing &R = d->ring;
+    // every launch set that reads the old blocks has to be over: the closed ones have events, the open one is on `st`
+    for (auto &b : R.inflight) if (b.ev) { HIPCHK(hipEventSynchronize(b.ev)); R.pool.push_back(b.ev); b.ev = nullptr; }
+    R.inflight.clear();
+    if (!R.cur.empty()) HIPCHK(hipStreamSynchronize(st));
+    R.cur.clear();
+    for (auto &cc : R.cache) { cc.off = -1; cc.n = 0; }
+    if (R.dev) HIPCHK(hipFree(R.dev));
+    if (R.host) HIPCHK(hipHostFree(R.host));
+    R.dev = nullptr; R.host = nullptr; R.cap = 0; R.head = 0;
+    int cap = 512;
+    while (cap < need) cap *= 2;
+    HIPCHK(hipMalloc((void **)&R.dev, sizeof(SwsFramePtrs) * (size_t)cap));
+    HIPCHK(hipHostMalloc((void **)&R.host, sizeof(SwsFramePtrs) * (size_t)cap, hipHostMallocDefault));
+    R.cap = cap;
+    return 0;
+}
+
+static const SwsFramePtrs *table_upload_(SwsInternal *c, DeviceState *d, hipStream_t st, int slot, const SwsFramePtrs *v, int n, int *err)
+{
+    TableRing &R = d->ring;
+    auto fail = [&](int e) -> const SwsFramePtrs * { *err = e; return nullptr; };
+    TableRing::Cached &cc = R.cache[slot];
+    if (cc.off >= 0 && cc.n == n && !std::memcmp(R.host + cc.off, v, sizeof(SwsFramePtrs) * (size_t)n)) {   // the table of the previous call (a caller looping over the same frames)
+        R.cur.push_back({ cc.off, n });
+        return R.dev + cc.off;
+    }
+    auto overlaps = [](const TableRing::Span &s, int off, int m) { return s.off < off + m && off < s.off + s.n; };
+    for (int attempt = 0; ; attempt++) {
+        if (8 * (int64_t)n > R.cap) { int r = ring_regrow(c, d, st, 8 * n); if (r < 0) return fail(r); }
+        if (R.head + n > R.cap) R.head = 0;
+        const int off = R.head;
+        bool open_hit = false;
+        for (const auto &sp : R.cur) open_hit = open_hit || overlaps(sp, off, n);
+        if (open_hit) {   // the launch set being built already fills the ring: twice the size (one synchronisation, once)
+            if (attempt) { log_msg(c, 0, "internal error: frame-table ring\n"); return fail(SWS_AVERROR(EINVAL)); }
+            int r = ring_regrow(c, d, st, std::max(2 * R.cap, 8 * n)); if (r < 0) return fail(r);
+            continue;
+        }
+        for (size_t i = 0; i < R.inflight.size(); ) {
+            bool hit = false;
+            for (const auto &sp : R.inflight[i].spans) hit = hit || overlaps(sp, off, n);
+            if (!hit) { i++; continue; }
+            if (R.inflight[i].ev && hipEventSynchronize(R.inflight[i].ev) != hipSuccess) { (void)hipGetLastError(); return fail(AVERROR_EXTERNAL_); }
+            ring_release(R, i);
+        }
+        for (auto &o : R.cache) if (o.off >= 0 && overlaps({ o.off, o.n }, off, n)) { o.off = -1; o.n = 0; }
+        std::memcpy(R.host + off, v, sizeof(SwsFramePtrs) * (size_t)n);
+        if (hipMemcpyAsync(R.dev + off, R.host + off, sizeof(SwsFramePtrs) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess) {
+            (void)hipGetLastError(); log_msg(c, 0, "HIP error uploading a frame table\n"); return fail(AVERROR_EXTERNAL_);
+        }
+        cc.off = off; cc.n = n;
+        R.cur.push_back({ off, n });
+        R.head = off + n;
+        return R.dev + off;
+    }
+}
+
+const SwsFramePtrs *table_upload(SwsInternal *c, DeviceState *d, hipStream_t st, int slot, const SwsFramePtrs *v, int n)
+{
+    int err = 0;
+    return table_upload_(c, d, st, slot, v, n, &err);
+}
+
+int table_batch_end(SwsInternal *c, DeviceState *d, hipStream_t st)
+{
+    TableRing &R = d->ring;
+    // forget the launch sets that are over (oldest first; an event that is still pending ends the sweep)
+    while (!R.inflight.empty() && (!R.inflight[0].ev || hipEventQuery(R.inflight[0].ev) == hipSuccess)) ring_release(R, 0);
+    (void)hipGetLastError();   // (hipErrorNotReady from the query is not an error)
+    if (R.cur.empty()) return 0;
+    hipEvent_t ev = nullptr;
+    if (!R.pool.empty()) { ev = R.pool.back(); R.pool.pop_back(); }
+    else HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (hipEventRecord(ev, st) != hipSuccess) { (void)hipGetLastError(); R.pool.push_back(ev); HIPCHK(hipStreamSynchronize(st)); R.cur.clear(); return 0; }
+    TableRing::Batch b;
+    b.spans.swap(R.cur);
+    b.ev = ev;
+    R.inflight.push_back(std::move(b));
+    return 0;
+}
+
 static bool frames_vec_ok(const SwsFramePtrs *fr, int n)
 {
     for (int i = 0; i < n; i++)
@@ -1415,6 +1507,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
 {
     const SwsDevParams &p = d->params;
     hipStream_t st = d->stream;
+    { int r_ = table_batch_end(c, d, st); if (r_ < 0) return r_; }   // (a launch set an error path left open)
     // SWS_SRC_V_CHR_DROP (swscale.c:333-334): "srcStride2[1] *= 1 << c->vChrDrop; srcStride2[2] *= 1 << c->vChrDrop" -- the scaler (not the
     // special converters) reads every 2^vChrDrop-th row of the chroma planes; packed sources reach the same rows through
     // `row << chrSrcVSub` in their readers
@@ -1442,28 +1535,10 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         frames = palfr.data();
     }
     // frame tables of the helper passes around a packed 4:2:2 side (slot 0: the interleave behind the kernels, slot 1: the de-interleave ahead of
-    // them; slot 2: the alpha launch of a full-chroma RGB destination; slots 3 / 4: staging copies in / out): one device block and one pinned host block of five tables, each cached like d_frames
+    // them; slot 2: the alpha launch of a full-chroma RGB destination; slots 3 / 4: staging copies in / out): spans of the frame-table ring (table_upload), cached per slot
     auto aux_table = [&](int slot, const std::vector<SwsFramePtrs> &v, const SwsFramePtrs **out) -> int {
-        SwsFramePtrs *&dtab = d->d_aux_tables, *&htab = d->h_aux_tables;
-        int &cap = d->aux_cap;
-        int *valid = d->aux_valid;     // [slot]
-        if (n > cap) {
-            if (dtab) HIPCHK(hipFree(dtab));
-            if (htab) HIPCHK(hipHostFree(htab));
-            dtab = nullptr; htab = nullptr; cap = 0; for (int k = 0; k < 5; k++) valid[k] = 0;
-            HIPCHK(hipMalloc((void **)&dtab, sizeof(SwsFramePtrs) * 5 * (size_t)n));
-            HIPCHK(hipHostMalloc((void **)&htab, sizeof(SwsFramePtrs) * 5 * (size_t)n, hipHostMallocDefault));
-            cap = n;
-        }
-        SwsFramePtrs *hd = htab + (size_t)slot * (size_t)cap, *dd2 = dtab + (size_t)slot * (size_t)cap;
-        if (!(valid[slot] == n && !std::memcmp(hd, v.data(), sizeof(SwsFramePtrs) * (size_t)n))) {
-            if (valid[slot]) HIPCHK(hipStreamSynchronize(st));   // a previous batch may still be reading the pinned table
-            std::memcpy(hd, v.data(), sizeof(SwsFramePtrs) * (size_t)n);
-            HIPCHK(hipMemcpyAsync(dd2, hd, sizeof(SwsFramePtrs) * (size_t)n, hipMemcpyHostToDevice, st));
-            valid[slot] = n;
-        }
-        *out = dd2;
-        return 0;
+        *out = table_upload(c, d, st, TAB_AUX0 + slot, v.data(), n);
+        return *out ? 0 : AVERROR_EXTERNAL_;
     };
     bool timing_started = !rec0;
     // pictures whose planes are not 16-byte aligned (a cropped view, a tightly packed rgb24 row) or bottom-up (negative line sizes) under the helper passes, which read and write 16-byte
@@ -1626,23 +1701,8 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
     fs.count = n;
     if (n == 1) { fs.table = nullptr; fs.one = frames[0]; }
     else {
-        const bool same_table = d->frames_cap >= n && d->frames_valid == n && !std::memcmp(d->h_frames, frames, sizeof(SwsFramePtrs) * n);
-        if (!same_table) {
-            if (n > d->frames_cap) {
-                if (d->d_frames) HIPCHK(hipFree(d->d_frames));
-                if (d->h_frames) HIPCHK(hipHostFree(d->h_frames));
-                d->d_frames = nullptr; d->h_frames = nullptr; d->frames_cap = 0;
-                HIPCHK(hipMalloc((void **)&d->d_frames, sizeof(SwsFramePtrs) * n));
-                HIPCHK(hipHostMalloc((void **)&d->h_frames, sizeof(SwsFramePtrs) * n, hipHostMallocDefault));
-                d->frames_cap = n;
-            } else {
-                HIPCHK(hipStreamSynchronize(st)); // a previous batch may still be reading the pinned table
-            }
-            std::memcpy(d->h_frames, frames, sizeof(SwsFramePtrs) * n);
-            HIPCHK(hipMemcpyAsync(d->d_frames, d->h_frames, sizeof(SwsFramePtrs) * n, hipMemcpyHostToDevice, st));
-            d->frames_valid = n;
-        }
-        fs.table = d->d_frames;
+        fs.table = table_upload(c, d, st, TAB_MAIN, frames, n);
+        if (!fs.table) return AVERROR_EXTERNAL_;
     }
     const bool vec = frames_vec_ok(frames, n);
     L.c = c; L.d = d; L.p = &p; L.st = st; L.frames = frames; L.n = n; L.sliceY = sliceY; L.sliceH = sliceH; L.vec = vec;
@@ -1778,7 +1838,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
     }
     HIPCHK(hipGetLastError());
     if (d->timing && rec1) { HIPCHK(hipEventRecord(d->ev1, st)); d->timed = true; }
-    return 0;
+    return table_batch_end(c, d, st);
 }
 
 // The helper passes keep per-FRAME working pictures (the reader pre-pass's 16-bit planes, the split / join pictures, the int32 sum planes of the
@@ -1804,14 +1864,16 @@ static size_t helper_bytes_per_frame(const SwsInternal *c, const DeviceState *d,
     int64_t b = 0;
     const bool helpers = d->split_mode || d->join422 || d->fullchr_on || d->alpha_launch || d->rgbread_on;
     if (!helpers) return 0;
-    // staging copies of unaligned / bottom-up planes (worst case: every plane of both pictures)
-    const PixDesc *ds = pix_desc(c->opts.src_format), *dd = pix_desc(c->opts.dst_format);
-    for (int side = 0; side < 2; side++)
-        for (int k = 0; k < 4; k++) {
-            int rows = 0, rb = 0, vs = 0;
-            plane_extent(side ? dd : ds, side ? c->opts.dst_w : c->opts.src_w, side ? c->opts.dst_h : c->opts.src_h, k, &rows, &rb, &vs);
-            b += a256(rb) * rows;
-        }
+    // staging copies of unaligned / bottom-up planes (launch_plan_le_batch stages under the same condition; worst case: every plane of both pictures)
+    if ((d->split_mode || d->join422 || d->fullchr_on || d->alpha_launch) && (!frames_vec_ok(frames, n) || !frames_desc_ok(frames, n, p.srcH, p.dstH))) {
+        const PixDesc *ds = pix_desc(c->opts.src_format), *dd = pix_desc(c->opts.dst_format);
+        for (int side = 0; side < 2; side++)
+            for (int k = 0; k < 4; k++) {
+                int rows = 0, rb = 0, vs = 0;
+                plane_extent(side ? dd : ds, side ? c->opts.dst_w : c->opts.src_w, side ? c->opts.dst_h : c->opts.src_h, k, &rows, &rb, &vs);
+                b += a256(rb) * rows;
+            }
+    }
     if (d->split_mode) b += a256(2 * (int64_t)p.srcW) * p.srcH + 2 * a256(2 * (int64_t)std::max(p.chrSrcW, p.srcW >> 1)) * p.srcH + 256;
     if (d->fullchr_on && !d->fullchr_direct) b += 4 * a256(4 * (int64_t)p.dstW) * p.dstH + 256;
     if (d->join422) b += (a256(p.dstW) + 2 * a256(p.dstW >> 1)) * (int64_t)p.dstH + 256;

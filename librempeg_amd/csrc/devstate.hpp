@@ -12,6 +12,21 @@
 
 namespace swship {
 
+// Frame tables (SwsFramePtrs arrays: fs.table of a batched launch) live in ONE pinned host block and ONE device block per DeviceState, used as a
+// ring: every upload takes the next span, a span is recycled only when the launch sets that read it have passed an event recorded behind them,
+// so neither a call with new frame pointers nor the sub-batches of one call ever wait for the stream (table_upload / table_batch_end, device.hip).
+struct TableRing {
+    SwsFramePtrs *dev = nullptr, *host = nullptr;
+    int cap = 0, head = 0;
+    struct Span { int off, n; };
+    struct Batch { std::vector<Span> spans; hipEvent_t ev = nullptr; };
+    std::vector<Batch> inflight;     // launch sets whose event has not been seen complete yet, oldest first
+    std::vector<Span> cur;           // spans handed out (or reused) since the last table_batch_end()
+    std::vector<hipEvent_t> pool;    // spare events
+    struct Cached { int off = -1, n = 0; } cache[8];   // last span of a slot: an identical table is not uploaded again
+};
+enum { TAB_MAIN = 0, TAB_AUX0 = 1 /* .. TAB_AUX0 + 4 */, TAB_FRAMES2 = 6 };
+
 struct DeviceState {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -43,7 +58,7 @@ struct DeviceState {
     void *scratch = nullptr; size_t scratch_bytes = 0;
     void *stage_src = nullptr; size_t stage_src_bytes = 0;
     void *stage_dst = nullptr; size_t stage_dst_bytes = 0;
-    SwsFramePtrs *d_frames = nullptr, *h_frames = nullptr; int frames_cap = 0, frames_valid = 0;
+    TableRing ring;            // frame tables of the batched launches
     void *casc_img = nullptr; size_t casc_bytes = 0; int casc_stride = 0;
     void *d_pal = nullptr; size_t d_pal_bytes = 0;   // palette-expanded sources: per frame pal_yuv[256] + pal_rgb[256]
     void *d_ed_err = nullptr;   // error-diffusion line of an 8 / 4 bpp destination: 3 x (dst_w + 3) ints, zeroed once, carried between frames
@@ -56,7 +71,6 @@ struct DeviceState {
     bool striprgbsrc_ok = false; int striprgbsrc_npx = 0;   // ... or, for half-width-chroma YUV destinations, one launch that reads the RGB rows itself (k_striprgbsrc.hip); widest strip window in pixels
     bool rgbread_on = false; void *rgbread_img = nullptr; size_t rgbread_bytes = 0;
     int64_t rgbread_frame_bytes = 0, rgbread_offA = -1; int rgbread_strideY = 0;   // layout of the last reader pre-pass (the alpha launch of a full-chroma RGB destination reads its A plane)
-    SwsFramePtrs *d_frames2 = nullptr, *h_frames2 = nullptr; int frames2_cap = 0, frames2_valid = 0;
     // helper passes around a packed / semi-planar side of the scaler (dev_prepare_on decides, launch_plan_le runs them):
     int fullchr_on = 0, fullchr_kind = 0;              // full-chroma packed RGB destination (2: with a scaled alpha plane): the strip kernels write int32 sum planes (DSTK_RAW32), sws_k_fullchr_rgb follows; the real dstKind
     int fullchr_direct = 0;                            // 1 / 2: the epilogue reads the 8 / 16-bit planes of a same-size 4:4:4 planar source itself (four identity filters): no strip launch, no working picture
@@ -66,7 +80,7 @@ struct DeviceState {
     int split_mode = 0, split_shift = 0;               // source split into planar working planes: 1 / 2 packed 4:2:2 (yuyv-like / uyvy) | 4 V first; 8 semi-planar 8-bit
                                                        //   chroma | 16 V first; 32 p010-style planes, every word >> split_shift
     void *split_img = nullptr; size_t split_bytes = 0;
-    SwsFramePtrs *d_aux_tables = nullptr, *h_aux_tables = nullptr; int aux_cap = 0, aux_valid[5] = { 0, 0, 0, 0, 0 };   // frame tables of the helper passes (slot 0 join / RGB epilogue, 1 split, 2 alpha launch, 3 / 4 staging in / out)
+    // (frame tables of the helper passes: ring slots TAB_AUX0 + 0 join / RGB epilogue, 1 split, 2 alpha launch, 3 / 4 staging in / out)
     void *stage_img = nullptr; size_t stage_bytes = 0; // 16-byte aligned copies of the planes of pictures that are not (launch_plan_le: only under the helper passes)
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool timing = false; bool timed = false;
     hipEvent_t ev_loan = nullptr;   // orders the context's own stream against a borrowed frames stream (dev_borrow_stream)
@@ -140,7 +154,7 @@ int  launch_rgbsrc2(const LaunchCtx &L);         // k_rgbsrc2.hip: the wave-marc
 int  launch_rgbread_strip(const LaunchCtx &L);   // k_strip.hip: scaled packed 24 / 32 bpp RGB source: reader pre-pass + strip kernel on its 16-bit planes
 void launch_fullchr_rgb(const LaunchCtx &L);   // k_stream.hip
 void launch_stage_planes(const LaunchCtx &L, const int row_bytes[4], const int rows[4], bool in);   // k_stream.hip: src[k] -> dst[k] plane copies, one side 16-byte aligned
-void launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, int64_t offU, int64_t offV, int strideY, int strideC, int64_t offA, int a_pos);   // k_stream.hip
+int  launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, int64_t offU, int64_t offV, int strideY, int strideC, int64_t offA, int a_pos);   // k_stream.hip
 int  launch_strip_short(const LaunchCtx &L, const SwsStripGeom &g, int H, bool chroma);   // k_strip2.hip: 1 = launched, 0 = not a shape of the short family
 int  launch_strip_luma(const LaunchCtx &L);      // k_strip.hip: the luma launch alone (the alpha plane of a full-chroma RGB destination goes through the luma filters)
 int  launch_striprgb(const LaunchCtx &L);
@@ -151,5 +165,9 @@ int  launch_generic(const LaunchCtx &L);
 
 // device.hip
 int grow(SwsInternal *c, void **buf, size_t *cap, size_t need);
+// a device copy of v[0 .. n) for launches on `st` (nullptr: a HIP error, logged); `slot` names the table's role for the identical-table cache
+const SwsFramePtrs *table_upload(SwsInternal *c, DeviceState *d, hipStream_t st, int slot, const SwsFramePtrs *v, int n);
+// closes the launch set that used the tables uploaded since the last call: records the event their spans are recycled behind
+int table_batch_end(SwsInternal *c, DeviceState *d, hipStream_t st);
 
 } // namespace swship

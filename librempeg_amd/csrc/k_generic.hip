@@ -100,7 +100,7 @@ int launch_generic(const LaunchCtx &L)
             const int m = std::min(chunk, n - f0);
             SwsFrameSet sub = fs;
             sub.count = m;
-            if (n == 1) sub.one = frames[0]; else sub.table = d->d_frames + f0;
+            if (n == 1) sub.one = frames[0]; else sub.table = fs.table + f0;
             if (!direct) {
                 const int maxW = std::max(p.dstW, p.chrDstW), maxH = std::max(p.srcH, p.chrSrcH);
                 const dim3 g1(cdiv(maxW, 256), maxH, (p.need_alpha ? 4 : 3) * m);

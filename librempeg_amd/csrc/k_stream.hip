@@ -71,16 +71,17 @@ int launch_rgbsrc(const LaunchCtx &L)
 }
 
 // reader pre-pass of a scaled packed 24 / 32 bpp RGB source (dev_prepare_on: rgbread_on): 16-bit Y / U / V planes per frame at `base`
-void launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, int64_t offU, int64_t offV, int strideY, int strideC, int64_t offA, int a_pos)
+int launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, int64_t offU, int64_t offV, int strideY, int strideC, int64_t offA, int a_pos)
 {
     const SwsDevParams &p = *L.p;
     if (p.srcKind != SRCK_RGB24 && p.srcKind != SRCK_RGB32 && p.srcKind != SRCK_GBRP) {   // the other RGB kinds (dev_prepare_on: rgbread_kindN): the per-kind element-per-thread reader
         const GenericKindFns *ks = generic_kind_fns(p.srcKind);
+        if (!ks || !ks->read16) { log_msg(L.c, 0, "internal error: no reader pre-pass kernel for source kind %d\n", p.srcKind); return SWS_AVERROR(EINVAL); }
         Read16Layout l16;
         l16.base = base; l16.frame_bytes = frame_bytes; l16.offU = offU; l16.offV = offV; l16.strideY = strideY; l16.strideC = strideC;
         const dim3 grid(cdiv(p.chrSrcW, 256), p.srcH, L.n), blk(256);
         hipLaunchKernelGGL(ks->read16, grid, blk, 0, L.st, L.fs, p, l16);
-        return;
+        return 0;
     }
     swsk::RgbReadLayout lay;
     lay.base = base; lay.frame_bytes = frame_bytes; lay.offU = offU; lay.offV = offV; lay.strideY = strideY; lay.strideC = strideC; lay.offA = offA; lay.a_pos = a_pos;
@@ -94,6 +95,7 @@ void launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, i
         else if (p.srcKind == SRCK_RGB24) hipLaunchKernelGGL((swsk::sws_k_rgb_read16<3, false>), grid, blk, 0, L.st, L.fs, p, lay);
         else hipLaunchKernelGGL((swsk::sws_k_rgb_read16<4, false>), grid, blk, 0, L.st, L.fs, p, lay);
     }
+    return 0;
 }
 
 // the full-chroma RGB epilogue behind the strip kernels (dev_prepare_on: fullchr_on; L.fs holds {src = the int32 sum planes, dst = the packed picture})

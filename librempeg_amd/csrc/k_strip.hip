@@ -127,7 +127,8 @@ int launch_rgbread_strip(const LaunchCtx &L)
     int r = grow(c, &d->rgbread_img, &d->rgbread_bytes, (size_t)frame_bytes * (size_t)n);
     if (r < 0) return r;
     uint8_t *base = (uint8_t *)d->rgbread_img;
-    launch_rgb_read16(L, base, frame_bytes, offU, offV, strideY, strideC, offA, alpha ? (p.src_a_pos | (p.src_alpha_opaque ? 8 : 0)) : -1);
+    r = launch_rgb_read16(L, base, frame_bytes, offU, offV, strideY, strideC, offA, alpha ? (p.src_a_pos | (p.src_alpha_opaque ? 8 : 0)) : -1);
+    if (r < 0) return r;
     std::vector<SwsFramePtrs> fr(L.frames, L.frames + n);
     for (int i = 0; i < n; i++) {
         uint8_t *fb = base + (size_t)i * (size_t)frame_bytes;
@@ -140,23 +141,8 @@ int launch_rgbread_strip(const LaunchCtx &L)
     L2.p = &p2; L2.frames = fr.data();
     if (n == 1) { L2.fs.table = nullptr; L2.fs.one = fr[0]; }
     else {
-        const bool same = d->frames2_cap >= n && d->frames2_valid == n && !std::memcmp(d->h_frames2, fr.data(), sizeof(SwsFramePtrs) * (size_t)n);
-        if (!same) {
-            if (n > d->frames2_cap) {
-                if (d->d_frames2) HIPCHK(hipFree(d->d_frames2));
-                if (d->h_frames2) HIPCHK(hipHostFree(d->h_frames2));
-                d->d_frames2 = nullptr; d->h_frames2 = nullptr; d->frames2_cap = 0;
-                HIPCHK(hipMalloc((void **)&d->d_frames2, sizeof(SwsFramePtrs) * (size_t)n));
-                HIPCHK(hipHostMalloc((void **)&d->h_frames2, sizeof(SwsFramePtrs) * (size_t)n, hipHostMallocDefault));
-                d->frames2_cap = n;
-            } else {
-                HIPCHK(hipStreamSynchronize(st));   // a previous batch may still be reading the pinned table
-            }
-            std::memcpy(d->h_frames2, fr.data(), sizeof(SwsFramePtrs) * (size_t)n);
-            HIPCHK(hipMemcpyAsync(d->d_frames2, d->h_frames2, sizeof(SwsFramePtrs) * (size_t)n, hipMemcpyHostToDevice, st));
-            d->frames2_valid = n;
-        }
-        L2.fs.table = d->d_frames2;
+        L2.fs.table = table_upload(c, d, st, TAB_FRAMES2, fr.data(), n);
+        if (!L2.fs.table) return AVERROR_EXTERNAL_;
     }
     return launch_strip_planes(L2, 3);
 }

@@ -5,6 +5,7 @@
 // Arithmetic contract: every shift, rounding constant and clip sits at the
 // same point as in the reference's C functions cited next to each routine.
 #pragma once
+#include <type_traits>
 #include "kernels_common.hpp"
 
 namespace swsk {
@@ -290,9 +291,16 @@ __device__ __forceinline__ int range_sample(const P &p, int v, int chroma)
 }
 
 // the parameter block with the chr_half field (half-width chroma readers: rgb24ToUV_half_c and friends) behind a constant, like KindView below
+// (a VIEW type: no data of its own -- size, alignment and member offsets are the base's, checked below -- and never constructed; the routines see the
+//  parameter block through it so that `p.chr_half` names the constant.  A cast to a type the object was not created as is outside the letter of
+//  the C++ object model; what it relies on is what the static_asserts pin: identical layout, and the shadowed member read nowhere through the view)
 template <typename P, int H> struct ChrHalfView : P { static constexpr int32_t chr_half = H; };
 template <int H, typename P>
-__device__ __forceinline__ const ChrHalfView<P, H> &chr_half_view(const P &p) { return reinterpret_cast<const ChrHalfView<P, H> &>(p); }
+__device__ __forceinline__ const ChrHalfView<P, H> &chr_half_view(const P &p)
+{
+    static_assert(sizeof(ChrHalfView<P, H>) == sizeof(P) && alignof(ChrHalfView<P, H>) == alignof(P), "ChrHalfView adds no data to the parameter block");
+    return reinterpret_cast<const ChrHalfView<P, H> &>(p);
+}
 
 // sum of fs taps of one output sample of component COMP.  Four taps at a time, their loads issued together: a thread that waits for every sample
 // before it asks for the next one spends the pass on memory latency (4K bgra -> 1080p, 8 taps: 0.49 ms per frame for 66 M samples in the rolled
@@ -356,11 +364,11 @@ __device__ __forceinline__ int hscale_sample(const P &p, const SwsFramePtrs &f, 
     const int16_t *taps = filter + (int64_t)fs * x;
     int val;
     if (p.chr_half) {
-        const auto &q = reinterpret_cast<const ChrHalfView<P, 1> &>(p);
+        const auto &q = chr_half_view<1>(p);
         val = comp == 0 ? tap_sum<0>(q, f, row, sp, taps, fs, aux) : comp == 1 ? tap_sum<1>(q, f, row, sp, taps, fs, aux) :
               comp == 2 ? tap_sum<2>(q, f, row, sp, taps, fs, aux) : tap_sum<3>(q, f, row, sp, taps, fs, aux);
     } else {
-        const auto &q = reinterpret_cast<const ChrHalfView<P, 0> &>(p);
+        const auto &q = chr_half_view<0>(p);
         val = comp == 0 ? tap_sum<0>(q, f, row, sp, taps, fs, aux) : comp == 1 ? tap_sum<1>(q, f, row, sp, taps, fs, aux) :
               comp == 2 ? tap_sum<2>(q, f, row, sp, taps, fs, aux) : tap_sum<3>(q, f, row, sp, taps, fs, aux);
     }
@@ -411,6 +419,9 @@ struct DirectSampler { // horizontal filters are 1-tap identity: compute the sam
 template <int SK, int DK> struct KindView : SwsDevParams { static constexpr int32_t srcKind = SK, dstKind = DK; };
 template <int SK> struct SrcKindView : SwsDevParams { static constexpr int32_t srcKind = SK; };
 template <int DK> struct DstKindView : SwsDevParams { static constexpr int32_t dstKind = DK; };
+static_assert(std::is_standard_layout<SwsDevParams>::value && std::is_trivially_copyable<SwsDevParams>::value, "the parameter block is plain data");
+static_assert(sizeof(KindView<0, 0>) == sizeof(SwsDevParams) && sizeof(SrcKindView<0>) == sizeof(SwsDevParams) && sizeof(DstKindView<0>) == sizeof(SwsDevParams) &&
+              alignof(KindView<0, 0>) == alignof(SwsDevParams), "the kind views add no data to the parameter block (see ChrHalfView)");
 template <int SK, int DK>
 __device__ __forceinline__ decltype(auto) kind_view(const SwsDevParams &p)
 {

@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) sws_k_tile_planar(SwsFrameSet fs, SwsDevP
             }
         };
         typedef typename std::remove_cv<typename std::remove_reference<decltype(p)>::type>::type PT;
-        if (p.chr_half) stage(reinterpret_cast<const ChrHalfView<PT, 1> &>(p)); else stage(reinterpret_cast<const ChrHalfView<PT, 0> &>(p));
+        if (p.chr_half) stage(chr_half_view<1>(p)); else stage(chr_half_view<0>(p));
         __syncthreads();
         // phase 2: horizontal stage; thread = one output column, marching down the window rows
         HT *Hc = Hbase + ci * hplane;

@@ -24,6 +24,14 @@ if os.environ.get("SWS_SHAPES_SET") == "ladder":     # the lower rungs of an ABR
              ("yuv420p",3840,2160,"yuv420p",480,270,SWS_BICUBIC),("yuv420p",3840,2160,"yuv420p",320,180,SWS_BICUBIC),("yuv420p",1920,1080,"yuv420p",256,144,SWS_LANCZOS),
              ("yuv420p",3840,2160,"rgb24",320,180,SWS_BICUBIC),("yuv420p",1920,1080,"yuv420p",160,90,SWS_BICUBIC),("yuv420p",1920,1080,"rgb24",128,72,SWS_BICUBIC),
              ("yuv420p",1280,720,"yuv420p",160,90,SWS_BICUBIC)]
+if os.environ.get("SWS_SHAPES_SET") == "range":      # MPEG <-> JPEG range conversions (lum/chrRange{To,From}Jpeg_c on the h-scaled lines): MJPEG cameras -> encoders, thumbnails -> JPEG
+    CASES = [("yuvj420p",1920,1080,"yuv420p",1920,1080,SWS_BICUBIC),("yuvj422p",1280,720,"yuv420p",1280,720,SWS_BICUBIC),("yuvj422p",1920,1080,"nv12",1920,1080,SWS_BICUBIC),
+             ("yuvj420p",3840,2160,"yuv420p",1920,1080,SWS_BICUBIC),("yuv420p",1920,1080,"yuvj420p",1920,1080,SWS_BICUBIC),("yuv420p",1920,1080,"yuvj420p",320,180,SWS_BICUBIC),
+             ("yuv420p",3840,2160,"yuvj420p",1280,720,SWS_BICUBIC),("yuv420p",1920,1080,"yuvj420p",1280,720,SWS_BILINEAR),("nv12",1920,1080,"yuvj420p",640,360,SWS_BICUBIC),
+             ("rgb24",1920,1080,"yuvj420p",1920,1080,SWS_BICUBIC),("bgra",1920,1080,"yuvj420p",1920,1080,SWS_BICUBIC),("bgra",3840,2160,"yuvj420p",1920,1080,SWS_BICUBIC),
+             ("rgb24",1920,1080,"yuvj420p",1280,720,SWS_BICUBIC),("yuvj420p",1920,1080,"yuv420p10le",1920,1080,SWS_BICUBIC),("yuv420p10le",3840,2160,"yuvj420p",1920,1080,SWS_BICUBIC),
+             ("yuv420p",1920,1080,"gray",1920,1080,SWS_BICUBIC),("yuv420p",1920,1080,"gray",640,360,SWS_BICUBIC),("gray",1920,1080,"yuv420p",1920,1080,SWS_BICUBIC),
+             ("yuvj420p",1920,1080,"yuvj420p",1280,720,SWS_BICUBIC),("yuvj444p",1920,1080,"yuv420p",1920,1080,SWS_BICUBIC),("yuyv422",1280,720,"yuvj420p",1280,720,SWS_BICUBIC)]
 print("| conversion | path / kernel | ms / frame | Gpix/s out | GB/s (src + dst bytes) |")
 print("|---|---|---|---|---|")
 for sf,sw,sh,df,dw,dh,fl in CASES:

@@ -9,7 +9,7 @@
     or, for a format without an entry, takes the muxer's first RAWVIDEO tag (nut.c:50).
 Data only: tables of names, tags and checksums."""
 import json, os, re, sys
-REF = "/root/reference"
+REF = os.environ.get("SWS_REFERENCE_ROOT", sys.argv[1] if len(sys.argv) > 1 else "/root/reference")   # reference tree: argv[1] or $SWS_REFERENCE_ROOT
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-REF = "/root/reference/tests/ref/pixfmt"
+REF = os.path.join(os.environ.get("SWS_REFERENCE_ROOT", sys.argv[1] if len(sys.argv) > 1 else "/root/reference"), "tests/ref/pixfmt")   # reference tree: argv[1] or $SWS_REFERENCE_ROOT
 SCOPE = ["bgr24", "nv12", "rgb24", "rgb32", "yuv420p", "yuv422p", "yuv444p", "yuvj420p", "yuv420p16le",
          "yuv444p16le", "yuv420p10le", "yuv444p10le", "p010le",
          "nv16", "nv24", "yuv410p", "yuv411p", "yuv440p", "yuvj422p", "yuvj440p", "yuvj444p",

@@ -2,8 +2,9 @@
 """Writes tests/golden/legacy_format_entries.json: the reference's table of supported input / output pixel formats
 (libswscale/format.c legacy_format_entries: { is_supported_in, is_supported_out } per AVPixelFormat), with the enum values of
 libavutil/pixfmt.h.  Data only; run here, where /root/reference exists."""
+import sys
 import json, os, re
-REF = "/root/reference"
+REF = os.environ.get("SWS_REFERENCE_ROOT", sys.argv[1] if len(sys.argv) > 1 else "/root/reference")   # reference tree: argv[1] or $SWS_REFERENCE_ROOT
 src = open(os.path.join(REF, "libswscale/format.c")).read()
 i = src.index("legacy_format_entries"); j = src.index("};", i)
 ents = re.findall(r"\[AV_PIX_FMT_(\w+)\]\s*=\s*\{\s*(\d)\s*,\s*(\d)", src[i:j])
