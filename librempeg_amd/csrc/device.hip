@@ -568,7 +568,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         // ---- packed 24 / 32 bpp RGB into 8-bit 4:2:0 / 4:2:2 YUV of the same size (sws_k_rgbsrc_unity): identity horizontal filters and luma
         //      vertical filter, chroma of the "half" readers through a vertical filter of up to 16 taps whose positions only move forward ----
         d->rgbsrc_ok = false; d->rgbsrc2_rows = nullptr;
-        if (d->unity_h && !d->vlines_on && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chr_half && !p.range_active && !p.need_alpha && !p.no_chroma &&
+        if (d->unity_h && !d->vlines_on && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chr_half && (!p.range_active || (!(p.dstW & 3) && p.range_to_jpeg && !c->tune.no_strip_range && !c->tune.no_rgbsrc2)) && !p.need_alpha && !p.no_chroma &&
             !p.wide && !p.dst_alpha_fill && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_NV12) && p.dst_bits == 8 && p.chrDstHSub == 1 && p.chrDstVSub <= 1 &&
             p.chrSrcVSub == 0 && p.srcH == p.dstH && bank_is_identity(c->vLum, 1 << 12) && c->vChr.size <= 16 && p.chrDstW == ((p.dstW + 1) >> 1) &&
             !p.should_dither && !c->tune.no_rgbsrc) {
@@ -660,7 +660,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                                         // (the 8-bit packed 4:4:4 formats -- ayuv / vuya / vuyx / uyva / vyu444: bytes, hScale8To15_c's sh = 7 -- as 16-bit words with 8 significant bits)
                                         (p.srcKind == SRCK_PACKED444 && p.src_depth == 8 && c->srcBpc == 8)) && !p.need_alpha && !c->needAlpha &&   // (an alpha component nobody reads is skipped)
                                        !c->tune.no_rgbread_kinds;
-            bool rgbread = (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || rgbread_kindN) && p.chrSrcHSub <= 1 && p.chrSrcW == (p.srcW >> p.chrSrcHSub) && !(p.srcW & 3) && p.chrSrcVSub == 0 && !p.range_active && (!p.need_alpha || d->fullchr_on == 2 || alpha_planar) &&
+            bool rgbread = (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || rgbread_kindN) && p.chrSrcHSub <= 1 && p.chrSrcW == (p.srcW >> p.chrSrcHSub) && !(p.srcW & 3) && p.chrSrcVSub == 0 && (!p.need_alpha || d->fullchr_on == 2 || alpha_planar) &&
                            (!p.dst_alpha_fill || d->fullchr_on) && !p.no_chroma && !vlines_pending && dst_ok && !c->tune.no_strip && !c->tune.no_rgbsrc && p.dstW >= strip_min_w_eff;
             for (int k = 0; k < 9 && rgbread; k++) rgbread = p.rgb2yuv[k] > -32768 && p.rgb2yuv[k] < 32768;   // (v_dot2_i32_i16 operands)
             d->rgbread_on = false;
@@ -668,7 +668,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // kernel's chroma instantiations with a ring of 12 row pairs; the tile kernel and the RGB epilogue stop at 16
             const bool vchr_long = fs2(c->vChr.size) > 16 && fs2(c->vChr.size) <= 24 && dst_ok && !rgb_ok && !c->tune.no_strip;
             // gray -> gray (8 .. 14 bit): one plane, the strip kernel's luma launch alone
-            const bool gray_both = isGray(o.src_format) && isGray(o.dst_format) && !c->needAlpha && src_ok && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && !c->tune.no_strip;
+            // (round 5: ... and planar / semi-planar YUV -> gray: the destination has no chroma planes, so the conversion is the luma launch as well -- thumbnails
+            //  for analysis; it needed the range conversion in the strip kernels, gray8 being full range, handle_jpeg utils.c:773-809)
+            const bool gray_both = isGray(o.dst_format) && (isGray(o.src_format) || ((src_ok || nv_src) && !c->tune.no_strip_range)) && !c->needAlpha && (src_ok || nv_src) &&
+                                   (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && !c->tune.no_strip;
             // identity luma filters + scaled chroma (yuv422p -> yuv420p, yuv444p -> yuv420p, the 10-bit -> 8-bit twins ...): the luma plane streams
             // (one tap: a per-sample pass), only the chroma planes need the strip kernel
             const bool mixedM = !vlines_pending && !d->fullchr_on && bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !(d->unity_h && d->unity_v) &&
@@ -862,7 +865,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 const int strip_cols_c = c->tune.strip_cols_c == 1 ? 1 : 2;
                 // (narrow pictures leave most of a 256-column strip idle and pay the per-band ring fill: the tile kernel keeps them)
                 const int strip_min_w = c->tune.strip_min_w;
-                const bool strip_plan = fullA && dst_ok && !p.range_active && !c->tune.no_strip && p.dstW >= (long_form ? strip_min_w_eff : strip_min_w) &&   // (the long form's strips are 128 columns, and what it replaces is the element-per-thread tile kernel)
+                const bool strip_plan = fullA && dst_ok && !(p.range_active && c->tune.no_strip_range) && !c->tune.no_strip && p.dstW >= (long_form ? strip_min_w_eff : strip_min_w) &&   // (the long form's strips are 128 columns, and what it replaces is the element-per-thread tile kernel)
                                         plan3(c->hLum, c->vLum, p.dstW, long_form == 2 ? 1 : long_form ? 2 : strip_cols_l, 1, d->stripL, sL, long_form == 2 ? +[](int) { return 32; } : nullptr, lum_plane1, long_form) &&
                                         (gray_both || plan3(c->hChr, c->vChr, p.chrDstW, long_form ? 1 : strip_cols_c, 2, d->stripC, sC,
                                                             long_form == 2 ? +[](int) { return 32; } : long_form ? +[](int) { return 24; } : nullptr, chr_plane1, long_form));
@@ -990,7 +993,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                   // the lockstep strip kernel of packed sources into half-width-chroma YUV (k_striprgbsrc.hip) likewise plans for itself: luma strips of up to 256
                   // columns over chroma strips of half as many, a few columns narrower where that brings the widest pixel window down by a reader turn of 256
                   // pixels (248 columns at 2:1: 504 pixels, two turns instead of three).  (YUV destinations: never together with the RGB -> RGB plans above)
-                  const bool packed422_src = (d->split_mode & 3) && !(d->split_mode & 40) && p.srcKind == SRCK_PLANAR8 && p.chrSrcW == (p.srcW >> 1) && p.chrSrcVSub == 0 && !p.range_active && !vlines_pending;
+                  const bool packed422_src = (d->split_mode & 3) && !(d->split_mode & 40) && p.srcKind == SRCK_PLANAR8 && p.chrSrcW == (p.srcW >> 1) && p.chrSrcVSub == 0 && !vlines_pending;
                   SOff s3l, s3c;
                   bool rsrc = strip_plan && !r2r && ((rgbread && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chr_half) || packed422_src) && !gray_both && !long_form &&
                               !c->tune.no_strip_rgbsrc && !alpha_planar && !p.need_alpha && !d->fullchr_on &&
@@ -1729,7 +1732,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         else if (vec && d->unity_h && d->unity_v && !p.no_chroma && !p.need_alpha && p.srcKind == SRCK_GBRPF32 && p.chrDstHSub == 0 && p.chrDstVSub == 0 && p.dst_shift == 0 &&
                  (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_PLANAR16))
             ret = launch_f32rgb(L);
-        else if (d->rgbsrc_ok && vec) { if (!launch_rgbsrc2(L)) ret = launch_rgbsrc(L); }                                             // packed RGB source, same size
+        else if (d->rgbsrc_ok && vec && (!p.range_active || (d->rgbsrc2_rows && !c->tune.no_rgbsrc2 && !(p.dstW & 3) && frames_desc_ok(frames, n, p.srcH, p.dstH)))) { if (!launch_rgbsrc2(L)) ret = launch_rgbsrc(L); }   // (range conversion: the wave-march form only)                                             // packed RGB source, same size
         else if (d->rgb444_ok && vec) ret = launch_rgb444(L);                                             // 8-bit RGB -> planar 4:4:4, same size
         else if (d->striprgb_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_striprgb(L);   // marching strip kernel, RGB epilogue
         else if (d->mixed_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_mixed(L);   // identity luma: streaming pass + strip kernel on chroma
@@ -1768,7 +1771,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         if (r < 0) return r;
         std::vector<SwsFramePtrs> afr(frames, frames + n), mfr((size_t)n);
         SwsDevParams pR = p;
-        pR.dstKind = DSTK_RAW32;
+        pR.dstKind = DSTK_RAW32; pR.range_active = 0;   // (the alpha line is h-scaled by the luma function but never range converted: hscale.c:61-63 vs :66-79)
         for (int i = 0; i < n; i++) {
             uint8_t *base = (uint8_t *)d->join_img + (size_t)i * (size_t)fbytes;
             SwsFramePtrs &a = afr[(size_t)i], &m = mfr[(size_t)i];
@@ -1796,7 +1799,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
     if ((c->plan == PLAN_MAIN && d->fullchr_on == 2 && !d->fullchr_direct && !d->rgb2rgb_now) || alpha_run) {
         if ((!alpha_run && p422join.empty()) || !d->strip_ok) { log_msg(c, 0, "internal error: alpha launch without the strip plan\n"); return SWS_AVERROR(EINVAL); }
         alfr.assign(frames, frames + n);
-        pA = p;
+        pA = p; pA.range_active = 0;   // (no range conversion on the alpha line)
         const bool rd = d->rgbread_on;
         if (rd) { if (d->rgbread_offA < 0) { log_msg(c, 0, "internal error: reader pre-pass without an alpha plane\n"); return SWS_AVERROR(EINVAL); }
                   pA.srcKind = SRCK_PLANAR16; pA.src_shift = 0; }
@@ -2829,7 +2832,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "strip_waves", &c->tune.strip_waves }, { "strip_rgb_cols", &c->tune.strip_rgb_cols }, { "rgb_march_waves", &c->tune.rgb_march_waves }, { "tile_lds_kb", &c->tune.tile_lds_kb },
         { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "layout_ch", &c->tune.layout_ch }, { "no_mixed", &c->tune.no_mixed }, { "no_layout_stream", &c->tune.no_layout_stream }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
         { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
-        { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb },
+        { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb }, { "no_strip_range", &c->tune.no_strip_range },
         { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_lds_pad_kb", &c->tune.strip_lds_pad_kb }, { "no_striprgb_direct", &c->tune.no_striprgb_direct }, { "no_rgbsrc2", &c->tune.no_rgbsrc2 }, { "no_strip_rgbsrc", &c->tune.no_strip_rgbsrc }, { "no_strip_rgb2rgb", &c->tune.no_strip_rgb2rgb },
         { "no_strip_short", &c->tune.no_strip_short }, { "no_generic_kinds", &c->tune.no_generic_kinds }, { "no_rgbread_kinds", &c->tune.no_rgbread_kinds }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "strip_short_waves", &c->tune.strip_short_waves },
         { "debug", &c->tune.debug },

@@ -17,7 +17,7 @@ int launch_rgbsrc2(const LaunchCtx &L)
     // two groups of 256 pixels per wave where the ring leaves room for them and the picture is wide enough to fill the machine that way
     // (two groups of 256 pixels per wave were measured too: slower at 1080p and at 4K -- the kernel wants waves, not work per wave)
     int G = 1;
-    if (!c->tune.strip_cols_auto && rd <= 5) G = c->tune.strip_cols_l == 2 ? 2 : 1;      // (experiments)
+    if (!c->tune.strip_cols_auto && rd <= 5 && !p.range_active) G = c->tune.strip_cols_l == 2 ? 2 : 1;      // (experiments)
     swsk::RgbSrc2Geom g;
     g.strips = (int)cdiv(p.dstW, 256 * G);
     g.npv = npv;                                  // (a row is due when pair pf + npv - 1 has entered the ring; its taps sit in the newest npv of the rd slots)
@@ -29,9 +29,12 @@ int launch_rgbsrc2(const LaunchCtx &L)
     g.bands = (int)cdiv(p.dstH, g.band_rows);
     const dim3 grid(cdiv((int64_t)g.strips * g.bands, 4), 1, n), blk(256);
     const bool nv = p.dstKind == DSTK_NV12;
-#define SWS_R2G(B, N, R) do { if (G == 2) hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity2<B, N, R, 2>), grid, blk, 0, st, fs, p, g); \
+    const bool rng = p.range_active;     // (dev_prepare_on admits a range conversion only into full range: the RNG instantiations)
+#define SWS_R2G(B, N, R) do { if (rng) hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity2<B, N, R, 1, true>), grid, blk, 0, st, fs, p, g); \
+                              else if (G == 2) hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity2<B, N, R, 2>), grid, blk, 0, st, fs, p, g); \
                               else hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity2<B, N, R, 1>), grid, blk, 0, st, fs, p, g); } while (0)
 #define SWS_R2R(B, N) do { if (rd == 1) SWS_R2G(B, N, 1); else if (rd == 3) SWS_R2G(B, N, 3); else if (rd == 5) SWS_R2G(B, N, 5); \
+                           else if (rng) hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity2<B, N, 8, 1, true>), grid, blk, 0, st, fs, p, g); \
                            else hipLaunchKernelGGL((swsk::sws_k_rgbsrc_unity2<B, N, 8, 1>), grid, blk, 0, st, fs, p, g); } while (0)
     if (p.srcKind == SRCK_GBRP) { if (nv) SWS_R2R(0, true); else SWS_R2R(0, false); }
     else if (p.srcKind == SRCK_RGB24) { if (nv) SWS_R2R(3, true); else SWS_R2R(3, false); }

@@ -22,7 +22,10 @@ namespace swsk {
 // ------------------------------------------------------------------------------------------
 struct RgbSrc2Geom { int32_t band_rows, bands, strips, npv; const SwsStripRow *rows; };
 
-template <int BPP, bool NV, int RD, int G>
+// RNG: the destination is full range (yuvj*: RGB sources are limited range behind the readers, utils.c:877-880) -- lum / chrRangeToJpeg_c on the 15-bit
+// samples between the (identity) horizontal scaler and the vertical stage (swscale.c:163-209), an instantiation of its own so that the capture ->
+// encoder form pays nothing for it.
+template <int BPP, bool NV, int RD, int G, bool RNG = false>
 __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity2(SwsFrameSet fs, SwsDevParams p, RgbSrc2Geom g)
 {
     const int lane = threadIdx.x & 63;
@@ -37,6 +40,8 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity2(SwsFrameSet fs, SwsDe
     const int cy1 = min(cH, (y1 + (1 << vs) - 1) >> vs);
     const FrameRegs f = load_frame(fs, blockIdx.z);
     const int hshift = p.hshift, hclip = p.hclip, npv = g.npv;
+    const StripRange rngL = strip_range_of(p, false), rngC = strip_range_of(p, true);
+    auto rconv = [](int v, const StripRange &r) { return (int)(int16_t)min(mad24(v, r.coeff, r.offset) >> 14, r.clipmax); };
 
     const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);
     const int rp = BPP == 0 ? 0 : U(p.src_r_pos), gp = BPP == 4 ? U(p.src_g_pos) : 1, bp = BPP == 0 ? 2 : U(p.src_b_pos);
@@ -151,7 +156,8 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity2(SwsFrameSet fs, SwsDe
                         int yv;
                         if (BPP != 4) yv = (uint16_t)((S + (32 << 14) + (1 << 8)) >> 9);
                         else yv = (uint16_t)((((unsigned)S << 8) + ((32u << 22) + (1u << 16))) >> 17);
-                        const int y15 = (int16_t)min((yv * 16384) >> hshift, hclip);
+                        int y15 = (int16_t)min((yv * 16384) >> hshift, hclip);
+                        if constexpr (RNG) y15 = rconv(y15, rngL);
                         out |= (uint32_t)clip_u8_shr(y15 + 64, 7) << (8 * j);
                     }
                     __builtin_amdgcn_raw_buffer_store_b32(out, rdY, doffY[k], yr * dsY, 0);
@@ -169,8 +175,10 @@ __global__ void __launch_bounds__(256) sws_k_rgbsrc_unity2(SwsFrameSet fs, SwsDe
                         ur = (uint16_t)((((unsigned)Su << 8) + rnd) >> 18);
                         vr = (uint16_t)((((unsigned)Sv << 8) + rnd) >> 18);
                     }
-                    uvp[k][j][0][r] = (uint32_t)(uint16_t)(int16_t)min((ur * 16384) >> hshift, hclip);
-                    uvp[k][j][1][r] = (uint32_t)(uint16_t)(int16_t)min((vr * 16384) >> hshift, hclip);
+                    int u15 = (int16_t)min((ur * 16384) >> hshift, hclip), v15 = (int16_t)min((vr * 16384) >> hshift, hclip);
+                    if constexpr (RNG) { u15 = rconv(u15, rngC); v15 = rconv(v15, rngC); }
+                    uvp[k][j][0][r] = (uint32_t)(uint16_t)(int16_t)u15;
+                    uvp[k][j][1][r] = (uint32_t)(uint16_t)(int16_t)v15;
                 }
             }
         }

@@ -84,6 +84,33 @@ __device__ __forceinline__ void strip_hstage(const StripLds &L, const int (&spd)
         }
 }
 
+// MPEG <-> JPEG range conversion of the h-scaled lines (lum / chrRange{To,From}Jpeg_c, swscale.c:163-209; applied per line behind the horizontal
+// scaler, hscale.c:61-63, :195-197): dst = (dst * coeff + offset) >> 14 in int arithmetic on the int16 line, the ToJpeg forms clip to 2^15 - 1, the
+// store truncates to int16.  Here the line is the packed {even row, odd row} dword of a column on its way into the ring.  Wave-uniform; a block of
+// its own behind the stage, so that contexts without range conversion pay one scalar branch per step.
+struct StripRange { int on, coeff, offset, clipmax; };
+__device__ __forceinline__ StripRange strip_range_of(const SwsDevParams &p, bool chroma)
+{
+    StripRange r;
+    r.on = p.range_active;
+    r.coeff = (int)(uint16_t)(chroma ? p.chrCoeff : p.lumCoeff);
+    r.offset = (int32_t)(chroma ? p.chrOffset : p.lumOffset);
+    r.clipmax = p.range_to_jpeg ? (1 << 15) - 1 : 0x7fffffff;
+    return r;
+}
+template <int NCOMP, int COLS>
+__device__ __forceinline__ void strip_range(uint32_t (&np)[NCOMP][COLS], const StripRange &r)
+{
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+        for (int c = 0; c < COLS; c++) {
+            const int lo = min(mad24((int)(int16_t)(uint16_t)np[ci][c], r.coeff, r.offset) >> 14, r.clipmax);
+            const int hi = min(mad24((int)np[ci][c] >> 16, r.coeff, r.offset) >> 14, r.clipmax);
+            np[ci][c] = __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);      // {(int16)lo, (int16)hi}
+        }
+}
+
 // PARTS: 16-byte chunks per lane and staged source row (1: windows of up to 64 chunks -- what 8-bit sources need at ratios up to about 3:1 on 320-column
 // strips; the second chunk's loads, byte expansion and LDS writes are straight-line code that costs the same whether any lane uses them or not)
 template <bool SRC16, bool CHROMA, int COLS, int NPH, int RD = 8, int PARTS = (CHROMA ? 1 : 2)>
@@ -98,6 +125,7 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
     const int cs = g.colStart[strip], chunks = g.colCount[strip] / SPC;
     const int32_t *hpos = CHROMA ? p.hChrPos : p.hLumPos;
     const int npv = g.npv, sh = p.hshift;
+    const StripRange rng = strip_range_of(p, CHROMA);
     StripLds L;
     L.row_dw = (g.NCmax + SPC) >> 1;                          // one spare chunk per row: the dump slot of idle lanes
     L.S = (uint32_t *)smem + wib * (NCOMP * 2 * L.row_dw);
@@ -289,6 +317,7 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
                     for (int c = 0; c < COLS; c++) np[ci][c] = L.S[(ci * 2) * L.row_dw + spd[c]];
             } else
             strip_hstage<NPH, NCOMP, COLS>(L, spd, ht, sh, np);
+            if (rng.on) strip_range<NCOMP, COLS>(np, rng);
 #pragma unroll
             for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
@@ -496,6 +525,7 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
     const int cs = g.colStart[strip], chunks = g.colCount[strip] / SPC;
     const int32_t *hpos = CHROMA ? p.hChrPos : p.hLumPos;
     const int npv = g.npv, sh = p.hshift;
+    const StripRange rng = strip_range_of(p, CHROMA);
     const int row_dw = g.NCmax >> 1;                          // dwords of a staged row (NCmax is a multiple of the 8-sample chunk)
     const int pair_dw = NCOMP * 2 * row_dw;
     uint32_t *ringS = (uint32_t *)smem + wib * (D * pair_dw);
@@ -658,6 +688,7 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
                     for (int c = 0; c < COLS; c++) np[ci][c] = L.S[(ci * 2) * L.row_dw + spd[c]];
             } else
             strip_hstage<NPH, NCOMP, COLS>(L, spd, ht, sh, np);
+            if (rng.on) strip_range<NCOMP, COLS>(np, rng);
 #pragma unroll
             for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll

@@ -47,6 +47,7 @@ __device__ __forceinline__ void strip_body_dma8(const FrameRegs &f, const SwsDev
     const int cs = g.colStart[strip], chunks = (NV ? 2 : 1) * g.colCount[strip] / 16;
     const int32_t *hpos = CHROMA ? p.hChrPos : p.hLumPos;
     const int npv = g.npv, sh = p.hshift;
+    const StripRange rng = strip_range_of(p, CHROMA);
     const int row_dw = ((NV ? 2 : 1) * g.NCmax + 16) >> 2;    // dwords of a staged row of bytes (one spare chunk: the last column's aligned reads)
     const int pair_dw = NSRC * 2 * row_dw;
     uint32_t *ringS = (uint32_t *)smem + wib * (D * pair_dw);
@@ -247,6 +248,7 @@ __device__ __forceinline__ void strip_body_dma8(const FrameRegs &f, const SwsDev
                         np[ci][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(a >> sh, b >> sh));
                     }
             }
+            if (rng.on) strip_range<NCOMP, COLS>(np, rng);
 #pragma unroll
             for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll

@@ -212,6 +212,7 @@ __device__ __forceinline__ void strip_rgbsrc_body(const FrameRegs &f, const SwsD
     // up to 512 pixels (ratios up to about 1.9:1), 4 = up to 1024; the staging registers are 2 * NG * 3 or 4 dwords
     typedef typename std::conditional<BPP == 4, u32x4, typename std::conditional<BPP == 2, u32x2, rsrc_u32x3>::type>::type GT;
     const int W = p.dstW, H = p.dstH, cW = p.chrDstW, cH = p.chrDstH, sH = p.srcH, sh = p.hshift;
+    const StripRange rngL = strip_range_of(p, false), rngC = strip_range_of(p, true);
     const int vs = p.chrDstVSub;
     const int cy0 = y0 >> vs, cy1 = min(cH, (y1 + (1 << vs) - 1) >> vs);
     // the strip's pixel window: luma window and twice the chroma window, from a multiple of 16 pixels on, in groups of four pixels
@@ -367,6 +368,7 @@ __device__ __forceinline__ void strip_rgbsrc_body(const FrameRegs &f, const SwsD
                 strip_hstage<NPH, 1, CL>(LL, spdL, htL, sh, npL);
                 strip_hstage<NPH, 2, CC>(LC, spdC, htC, sh, npC);
             }
+            if (rngL.on) { strip_range<1, CL>(npL, rngL); strip_range<2, CC>(npC, rngC); }
 #pragma unroll
             for (int c = 0; c < CL; c++) {
 #pragma unroll

@@ -43,7 +43,10 @@ def test_lut_writers_with_alpha(src, dst):
 def test_range_conversion_and_fallbacks():
     assert run_case(1920, 1080, "yuva420p", 1280, 720, "bgra", SWS_BICUBIC | BX, seed=12)[0] == "main:strip_rgb+alpha"
     assert run_case(3840, 2160, "yuva420p10le", 1920, 1080, "rgba", SWS_LANCZOS | BX, seed=13, device_frames=False)[0] == "main:strip_rgb+alpha"
-    # (a luma range conversion never touches the alpha plane: the strip planner leaves contexts with one to the generic kernels)
+    # (a luma range conversion never touches the alpha plane -- hscale.c:61-63 vs :66-79 -- the alpha launch runs with the conversion switched off)
+    ro = dict(dither=1, src_range=0, dst_range=1, src_h_chr_pos=-513, src_v_chr_pos=-513, dst_h_chr_pos=-513, dst_v_chr_pos=-513, threads=1)
+    assert run_case(256, 64, "yuva420p", 192, 48, "yuva444p10le", SWS_BICUBIC | BX, tune=TUNE, opts=ro)[0] == "main:strip_march+alpha"
+    assert run_case(256, 64, "bgra", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE, opts=ro)[0] == "main:rgbread+strip_march+alpha"
     assert run_case(256, 64, "bgra", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0] == "main:rgbread+strip_march+alpha"
     assert run_case(256, 64, "yuva420p", 192, 48, "yuva444p10le", SWS_BICUBIC | BX, tune=TUNE)[0] == "main:strip_march+alpha"
     assert not run_case(254, 64, "bgra", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+alpha")         # the reader pre-pass takes widths of 4 n

@@ -44,7 +44,8 @@ def test_planner_and_fallbacks():
     assert run_case(640, 48, "rgb24", 480, 36, "yuv420p", SWS_BILINEAR | SWS_FULL_CHR_H_INP | BX, tune=TUNE)[0] == PATH            # the full-width chroma readers
     assert run_case(640, 48, "rgb24", 320, 24, "yuv420p", SWS_BICUBIC | SWS_FULL_CHR_H_INP | BX, tune=TUNE)[0] == PATH             # (4:1 bicubic chroma, 17 taps: the strip kernel's long form)
     assert run_case(640, 48, "rgba", 320, 24, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0] != PATH
-    assert run_case(640, 48, "rgb24", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=TUNE)[0] != PATH             # a range conversion
+    assert run_case(640, 48, "rgb24", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=TUNE)[0] == PATH             # a range conversion (round 5: converted on the way into the ring)
+    assert run_case(640, 48, "rgb24", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_range=1))[0] != PATH
     assert run_case(640, 48, "rgb24", 320, 24, "yuv420p", SWS_POINT | BX, tune=TUNE)[0] is not None
 
 

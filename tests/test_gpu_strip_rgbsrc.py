@@ -50,7 +50,8 @@ def test_planner_and_fallbacks():
     assert run_case(640, 48, "gbrp10le", 480, 36, "yuv420p", SWS_BILINEAR | BX, tune=TUNE)[0] != PATH                       # (deeper planar RGB: other readers)
     assert run_case(640, 48, "rgba", 320, 24, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0] == "main:rgbread+strip_march+alpha"
     assert run_case(1280, 96, "rgb24", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0] == "main:rgbread+strip_march"    # 17 taps: the long forms
-    assert run_case(640, 48, "rgb24", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=TUNE)[0] not in (PATH,)      # a range conversion
+    assert run_case(640, 48, "rgb24", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=TUNE)[0] == PATH             # a range conversion (round 5: converted on the way into the rings)
+    assert run_case(640, 48, "rgb24", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_range=1))[0] != PATH
 
 
 def test_full_size_frames_and_host_frames():

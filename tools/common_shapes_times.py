@@ -30,7 +30,7 @@ if os.environ.get("SWS_SHAPES_SET") == "range":      # MPEG <-> JPEG range conve
              ("yuv420p",3840,2160,"yuvj420p",1280,720,SWS_BICUBIC),("yuv420p",1920,1080,"yuvj420p",1280,720,SWS_BILINEAR),("nv12",1920,1080,"yuvj420p",640,360,SWS_BICUBIC),
              ("rgb24",1920,1080,"yuvj420p",1920,1080,SWS_BICUBIC),("bgra",1920,1080,"yuvj420p",1920,1080,SWS_BICUBIC),("bgra",3840,2160,"yuvj420p",1920,1080,SWS_BICUBIC),
              ("rgb24",1920,1080,"yuvj420p",1280,720,SWS_BICUBIC),("yuvj420p",1920,1080,"yuv420p10le",1920,1080,SWS_BICUBIC),("yuv420p10le",3840,2160,"yuvj420p",1920,1080,SWS_BICUBIC),
-             ("yuv420p",1920,1080,"gray",1920,1080,SWS_BICUBIC),("yuv420p",1920,1080,"gray",640,360,SWS_BICUBIC),("gray",1920,1080,"yuv420p",1920,1080,SWS_BICUBIC),
+             ("yuv420p",1920,1080,"gray8",1920,1080,SWS_BICUBIC),("yuv420p",1920,1080,"gray8",640,360,SWS_BICUBIC),("gray8",1920,1080,"yuv420p",1920,1080,SWS_BICUBIC),
              ("yuvj420p",1920,1080,"yuvj420p",1280,720,SWS_BICUBIC),("yuvj444p",1920,1080,"yuv420p",1920,1080,SWS_BICUBIC),("yuyv422",1280,720,"yuvj420p",1280,720,SWS_BICUBIC)]
 print("| conversion | path / kernel | ms / frame | Gpix/s out | GB/s (src + dst bytes) |")
 print("|---|---|---|---|---|")
