@@ -506,8 +506,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     //      the strip kernels store the vertical sums of Y, U and V as int32 planes (chroma at the writer's own chroma width), and the epilogue is the generic
     //      writer itself in its X form over those sums (k_generic_dst.hip sws_k_sum_writer).  Tentative like the others: undone below when no strip plan
     //      fits or a row takes one of the writer's short forms (the 10 / 12-bit packed YUV formats have X writers only) ----
-    if (!d->fullchr_on && c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB16 || p.dstKind == DSTK_RGB30 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI) && !p.wide &&
-        c->dstBpc <= 14 && !c->needAlpha && fc_plain && !(o.flags & SWS_FAST_BILINEAR) && !(o.dst_w & 3) && o.dst_w >= strip_min_w_eff && c->chrDstVSubSample == 0 &&
+    // (round 5: planar RGB of 16 bits and float32 -- gbrp16le, gbrpf32le: yuv2gbrp16_full_X_c / yuv2gbrpf32_full_X_c, output.c:2424-2610, always the X form -- over the
+    //  sums of the 19-bit strip kernel, sws_k_strip_wide: decoded video into planar float RGB for inference)
+    const bool wide_gbrp = (p.dstKind == DSTK_GBRP16 || p.dstKind == DSTK_GBRPF32) && p.wide && c->dstBpc >= 16 && !isALPHA(o.dst_format) && !c->tune.no_strip_wide;
+    if (!d->fullchr_on && c->plan == PLAN_MAIN && (((p.dstKind == DSTK_RGB16 || p.dstKind == DSTK_RGB30 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI) && !p.wide &&
+        c->dstBpc <= 14) || wide_gbrp) && !c->needAlpha && fc_plain && !(o.flags & SWS_FAST_BILINEAR) && !(o.dst_w & 3) && o.dst_w >= strip_min_w_eff && c->chrDstVSubSample == 0 &&
         !(bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14)) &&   // (identity horizontal filters: the single-pass per-kind kernels are as fast or faster -- no sum planes)
         !c->tune.no_strip && !c->tune.no_mixed && !(c->tune.no_rgbread_kinds & 2)) {
         d->fullchr_on = 4; d->fullchr_kind = p.dstKind;
@@ -633,7 +636,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // nv12 / nv21, p010 / p012 (and the 4:2:2 / 4:4:4 twins): the strip kernel de-interleaves plane 1 (and shifts the p01x samples down) while
             // staging; the dot2 tile kernel does not
             const bool nv_src = (p.srcKind == SRCK_NV12 && c->srcBpc == 8) || (p.srcKind == SRCK_P010 && p.src_depth <= 15);
-            const bool dst_ok = p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010 || p.dstKind == DSTK_RAW32;
+            // (19-bit intermediates, round 5: destinations of 16 bits per component -- yuv4xxp16, gray16, p016 -- and the int32 sums of the wide planar RGB route,
+            //  from sources whose samples are v_dot2 operands as they are: sws_k_strip_wide, k_stripwide.hip)
+            const bool wide_dst = p.wide && c->dstBpc >= 16 && !c->tune.no_strip_wide && !c->tune.no_strip &&
+                                  ((p.dstKind == DSTK_PLANAR16 && p.dst_shift == 0 && !isALPHA(o.dst_format)) || p.dstKind == DSTK_P016 || (p.dstKind == DSTK_RAW32 && d->fullchr_on == 4));
+            const bool dst_ok = ((p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010 || p.dstKind == DSTK_RAW32) && !p.wide) || wide_dst;
             auto fs2 = [](int fs) { return (fs + 2) & ~1; };
             // packed 24 / 32 bpp RGB through the LUT writers (not the full-chroma ones): the strip kernel with the RGB epilogue
             // (9 .. 15-bit planar sources too -- decoded HDR pictures for display: 128-column strips, a window of at most 64 eight-sample chunks)
@@ -660,7 +667,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                                         // (the 8-bit packed 4:4:4 formats -- ayuv / vuya / vuyx / uyva / vyu444: bytes, hScale8To15_c's sh = 7 -- as 16-bit words with 8 significant bits)
                                         (p.srcKind == SRCK_PACKED444 && p.src_depth == 8 && c->srcBpc == 8)) && !p.need_alpha && !c->needAlpha &&   // (an alpha component nobody reads is skipped)
                                        !c->tune.no_rgbread_kinds;
-            bool rgbread = (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || rgbread_kindN) && p.chrSrcHSub <= 1 && p.chrSrcW == (p.srcW >> p.chrSrcHSub) && !(p.srcW & 3) && p.chrSrcVSub == 0 && (!p.need_alpha || d->fullchr_on == 2 || alpha_planar) &&
+            bool rgbread = !p.wide && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || rgbread_kindN) && p.chrSrcHSub <= 1 && p.chrSrcW == (p.srcW >> p.chrSrcHSub) && !(p.srcW & 3) && p.chrSrcVSub == 0 && (!p.need_alpha || d->fullchr_on == 2 || alpha_planar) &&
                            (!p.dst_alpha_fill || d->fullchr_on) && !p.no_chroma && !vlines_pending && dst_ok && !c->tune.no_strip && !c->tune.no_rgbsrc && p.dstW >= strip_min_w_eff;
             for (int k = 0; k < 9 && rgbread; k++) rgbread = p.rgb2yuv[k] > -32768 && p.rgb2yuv[k] < 32768;   // (v_dot2_i32_i16 operands)
             d->rgbread_on = false;
@@ -671,7 +678,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // (round 5: ... and planar / semi-planar YUV -> gray: the destination has no chroma planes, so the conversion is the luma launch as well -- thumbnails
             //  for analysis; it needed the range conversion in the strip kernels, gray8 being full range, handle_jpeg utils.c:773-809)
             const bool gray_both = isGray(o.dst_format) && (isGray(o.src_format) || ((src_ok || nv_src) && !c->tune.no_strip_range)) && !c->needAlpha && (src_ok || nv_src) &&
-                                   (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && !c->tune.no_strip;
+                                   (((p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && !p.wide) || (p.dstKind == DSTK_PLANAR16 && wide_dst)) && !c->tune.no_strip;
             // identity luma filters + scaled chroma (yuv422p -> yuv420p, yuv444p -> yuv420p, the 10-bit -> 8-bit twins ...): the luma plane streams
             // (one tap: a per-sample pass), only the chroma planes need the strip kernel
             const bool mixedM = !vlines_pending && !d->fullchr_on && bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !(d->unity_h && d->unity_v) &&
@@ -692,8 +699,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                                  !c->tune.no_strip && !c->tune.no_mixed;
             const bool fs_ok64 = fs2(c->hLum.size) <= 64 && fs2(c->hChr.size) <= 64 && fs2(c->vLum.size) <= 64 && fs2(c->vChr.size) <= 64 && dst_ok && !rgb_ok && !gray_both &&
                                  !c->tune.no_strip && !c->tune.no_mixed;      // (33 .. 62 taps: the extra-long form, 32 pairs each way on strips of 64 columns)
+            const bool wide_ok = wide_dst && (src_ok || nv_src) && !p.range_active && !c->needAlpha && !p.need_alpha && !p.fast_bilinear && !vlines_pending && fs_ok16 &&
+                                 !(p.srcKind == SRCK_PLANAR8 && c->srcBpc != 8);
             const bool fullA = !mixedM && unity_ok && !(d->unity_h && d->unity_v && !rgb_ok && !unity_yuv) && !p.fast_bilinear && (!gray_any || gray_both || d->fullchr_on == 2 || alpha_planar || (rgb_ok && rgb_alpha)) && (src_ok || (nv_src && dst_ok) || rgbread) &&
-                               (dst_ok || rgb_ok) && !p.wide && (fs_ok16 || fs_ok32 || fs_ok64) && !c->tune.no_dot2;
+                               (dst_ok || rgb_ok) && (!p.wide || wide_ok) && (fs_ok16 || fs_ok32 || fs_ok64) && !c->tune.no_dot2;
             const int long_form = !fullA || fs_ok16 ? 0 : fs_ok32 ? 1 : 2;
             d->mixed_ok = false; d->stripLs_ok = d->stripCs_ok = false; d->striprgbsrc_ok = false; d->rgb2rgb_ok = false;
             if (fullA || mixedM) {
@@ -859,16 +868,18 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 //  4096: Y = buf << 2 == (buf << 12 + (1 << 9)) >> 10, (buf + 64) >> 7 == (buf << 12 + (1 << 18)) >> 19; planar RGB has no such form, vscale.c:173-212)
                 //  The packed YUV formats of 10 / 12 bits (DSTK_PACKEDHI) have X writers only, which multiply by the bank's value even when it is the only tap
                 //  (4095 after initFilter's normalisation, 0 in the zero-vector rows of a source of fewer than four rows with shifted chroma): their own taps.
-                const bool raw_one_one = p.dstKind == DSTK_RAW32 && c->vLum.size == 1 && c->vChr.size == 1 && d->fullchr_kind != DSTK_GBRP && d->fullchr_kind != DSTK_PACKEDHI;
-                const bool chr_plane1 = (p.dstKind != DSTK_NV12 && p.dstKind != DSTK_P010 && p.dstKind != DSTK_RAW32) || raw_one_one, lum_plane1 = p.dstKind != DSTK_RAW32 || raw_one_one;
+                const bool raw_one_one = p.dstKind == DSTK_RAW32 && c->vLum.size == 1 && c->vChr.size == 1 && d->fullchr_kind != DSTK_GBRP && d->fullchr_kind != DSTK_PACKEDHI && d->fullchr_kind != DSTK_GBRP16 && d->fullchr_kind != DSTK_GBRPF32;
+                const bool chr_plane1 = (p.dstKind != DSTK_NV12 && p.dstKind != DSTK_P010 && p.dstKind != DSTK_P016 && p.dstKind != DSTK_RAW32) || raw_one_one, lum_plane1 = p.dstKind != DSTK_RAW32 || raw_one_one;
                 const int strip_cols_l = c->tune.strip_cols_l == 2 ? 2 : 4;
                 const int strip_cols_c = c->tune.strip_cols_c == 1 ? 1 : 2;
                 // (narrow pictures leave most of a 256-column strip idle and pay the per-band ring fill: the tile kernel keeps them)
                 const int strip_min_w = c->tune.strip_min_w;
                 const bool strip_plan = fullA && dst_ok && !(p.range_active && c->tune.no_strip_range) && !c->tune.no_strip && p.dstW >= (long_form ? strip_min_w_eff : strip_min_w) &&   // (the long form's strips are 128 columns, and what it replaces is the element-per-thread tile kernel)
-                                        plan3(c->hLum, c->vLum, p.dstW, long_form == 2 ? 1 : long_form ? 2 : strip_cols_l, 1, d->stripL, sL, long_form == 2 ? +[](int) { return 32; } : nullptr, lum_plane1, long_form) &&
-                                        (gray_both || plan3(c->hChr, c->vChr, p.chrDstW, long_form ? 1 : strip_cols_c, 2, d->stripC, sC,
-                                                            long_form == 2 ? +[](int) { return 32; } : long_form ? +[](int) { return 24; } : nullptr, chr_plane1, long_form));
+                                        plan3(c->hLum, c->vLum, p.dstW, p.wide ? 2 : long_form == 2 ? 1 : long_form ? 2 : strip_cols_l, 1, d->stripL, sL,
+                                              p.wide ? +[](int n) { return n <= 4 ? 4 : 8; } : long_form == 2 ? +[](int) { return 32; } : nullptr, lum_plane1, long_form) &&
+                                        (gray_both || plan3(c->hChr, c->vChr, p.chrDstW, p.wide ? 1 : long_form ? 1 : strip_cols_c, 2, d->stripC, sC,
+                                                            p.wide ? +[](int n) { return n <= 4 ? 4 : 8; } : long_form == 2 ? +[](int) { return 32; } : long_form ? +[](int) { return 24; } : nullptr, chr_plane1, long_form)) &&
+                                        (!p.wide || d->stripL.NCmax / SPC <= 64);      // (the wide kernel stages one chunk per lane and row)
                 d->strip_ok = false;
                 log_msg(c, 3, "strip plan: %d (windows %d/%d chunks of %d, taps %d/%d x %d/%d)\n", strip_plan, d->stripL.NCmax / SPC, d->stripC.NCmax / SPC, SPC,
                         d->stripL.nph, d->stripC.nph, d->stripL.npv, d->stripC.npv);
@@ -959,8 +970,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 {
                   const bool tiles = !gray_both && !long_form && plan2(c->hLum, c->vLum, p.dstW, p.dstH, 1, d->dotL, oL) && plan2(c->hChr, c->vChr, p.chrDstW, p.chrDstH, 2, d->dotC, oC);
                   size_t ohl = 0, ohc = 0;
-                  const bool altL = strip_plan && !long_form && plan3_alt(c->hLum, c->vLum, p.dstW, 1, d->stripL, d->stripLs, sLs);
-                  const bool altC = strip_plan && !long_form && !gray_both && plan3_alt(c->hChr, c->vChr, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
+                  const bool altL = strip_plan && !long_form && !p.wide && plan3_alt(c->hLum, c->vLum, p.dstW, 1, d->stripL, d->stripLs, sLs);
+                  const bool altC = strip_plan && !long_form && !p.wide && !gray_both && plan3_alt(c->hChr, c->vChr, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
                   // scaled packed RGB -> packed RGB in one launch (k_striprgb2rgb.hip): the same filters planned once more on strips of 128 columns for both plane
                   // classes (a lane owns the same destination columns of Y, U, V and A).  Luma and chroma share the vertical bank there (same source and destination
                   // heights), which the kernel's lockstep march relies on: checked tap position by tap position
@@ -995,7 +1006,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                   // pixels (248 columns at 2:1: 504 pixels, two turns instead of three).  (YUV destinations: never together with the RGB -> RGB plans above)
                   const bool packed422_src = (d->split_mode & 3) && !(d->split_mode & 40) && p.srcKind == SRCK_PLANAR8 && p.chrSrcW == (p.srcW >> 1) && p.chrSrcVSub == 0 && !vlines_pending;
                   SOff s3l, s3c;
-                  bool rsrc = strip_plan && !r2r && ((rgbread && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chr_half) || packed422_src) && !gray_both && !long_form &&
+                  bool rsrc = strip_plan && !r2r && !p.wide && ((rgbread && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chr_half) || packed422_src) && !gray_both && !long_form &&
                               !c->tune.no_strip_rgbsrc && !alpha_planar && !p.need_alpha && !d->fullchr_on &&
                               p.chrDstW == ((p.dstW + 1) >> 1) && (p.chrDstVSub == 0 ? p.chrDstH == p.dstH : (p.chrDstVSub == 1 && p.chrDstH == ((p.dstH + 1) >> 1)));
                   if (rsrc) {
@@ -1032,7 +1043,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         g.hT2 = (const int16_t *)(b + o.ht); g.vT2 = (const int16_t *)(b + o.vt);
                     };
                     if (tiles) { bind(d->dotL, oL); bind(d->dotC, oC); }
-                    d->dot2_ok = tiles && src_ok && fs2(c->vChr.size) <= 16 && c->vLum.size >= 2 && c->vChr.size >= 2 && !d->fullchr_on && !alpha_planar && !d->unity_h;
+                    d->dot2_ok = tiles && !p.wide && src_ok && fs2(c->vChr.size) <= 16 && c->vLum.size >= 2 && c->vChr.size >= 2 && !d->fullchr_on && !alpha_planar && !d->unity_h;
                     if (strip_plan) {
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         d->stripL.colStart = (const int32_t *)(b + sL.cs); d->stripL.colCount = (const int32_t *)(b + sL.cc);
@@ -1149,8 +1160,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             d->all_x_mode = all_x;
             d->striprgb_ok = d->striprgb_ok && (all_x || (lfs == 1 && cfs == 1));
             if (d->alpha_launch == 2 && !d->striprgb_ok) d->alpha_launch = 0;
-            if (d->fullchr_on && ((!all_x && !(lfs == 1 && cfs == 1) && d->fullchr_kind != DSTK_GBRP && d->fullchr_kind != DSTK_PACKEDHI) ||
-                                  (d->fullchr_on == 4 && lfs == 1 && cfs == 1 && d->fullchr_kind != DSTK_PACKEDHI) || !d->strip_ok)) {   // (planar RGB: any_vscale, always the X form)   // no strip plan, or a row in one of the short writer forms: the generic full-chroma writer keeps it
+            const bool kind_x = d->fullchr_kind == DSTK_GBRP || d->fullchr_kind == DSTK_PACKEDHI || d->fullchr_kind == DSTK_GBRP16 || d->fullchr_kind == DSTK_GBRPF32;   // (writers with the X form only)
+            if (d->fullchr_on && ((!all_x && !(lfs == 1 && cfs == 1) && !kind_x) ||
+                                  (d->fullchr_on == 4 && lfs == 1 && cfs == 1 && d->fullchr_kind != DSTK_PACKEDHI && d->fullchr_kind != DSTK_GBRP16 && d->fullchr_kind != DSTK_GBRPF32) || !d->strip_ok)) {   // (planar RGB: any_vscale, always the X form)   // no strip plan, or a row in one of the short writer forms: the generic full-chroma writer keeps it
                 d->fullchr_on = 0; d->strip_ok = false; d->rgbread_on = false; d->striprgbsrc_ok = false; d->rgb2rgb_ok = false;
                 p.dstKind = d->fullchr_kind; p.u_plane_dst = dd->comp[1].plane; p.v_plane_dst = dd->comp[2].plane;
             }
@@ -1277,10 +1289,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             c->path_name = "main:plane1+strip_chroma"; c->kernel_name = "sws_k_strip_march";
         } else if (d->strip_ok) {
             c->path_name = d->rgbread_on ? ((d->striprgbsrc_ok && !c->tune.no_strip_rgbsrc) ? "main:strip_rgbsrc" : "main:rgbread+strip_march") : "main:strip_march";
-            c->kernel_name = ((p.srcKind == SRCK_PLANAR16 || d->rgbread_on) && d->stripL.dma_ok && !c->tune.no_strip_dma) ? "sws_k_strip_dma" : "sws_k_strip_march";
+            c->kernel_name = p.wide ? "sws_k_strip_wide" : ((p.srcKind == SRCK_PLANAR16 || d->rgbread_on) && d->stripL.dma_ok && !c->tune.no_strip_dma) ? "sws_k_strip_dma" : "sws_k_strip_march";
             if (d->rgbread_on && d->striprgbsrc_ok && !c->tune.no_strip_rgbsrc) c->kernel_name = "sws_k_strip_rgbsrc";
             else if (d->stripL.nph > 8 || d->stripL.npv > 8) c->kernel_name = d->stripL.nph > 16 ? "sws_k_strip_xlong" : "sws_k_strip_long";   // (filters of 17 .. 32 / 33 .. 62 taps)
-            else if (!c->tune.no_strip_short && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {   // the short family (k_strip2.hip launch_strip_short decides per launch: this is its choice for 16-byte aligned frames)
+            else if (!p.wide && !c->tune.no_strip_short && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12)) {   // the short family (k_strip2.hip launch_strip_short decides per launch: this is its choice for 16-byte aligned frames)
                 const SwsStripGeom &gs = d->stripLs_ok ? d->stripLs : d->stripL;
                 const bool d8 = gs.dma8_ok && !c->tune.no_strip_dma8;
                 if (gs.NCmax / 16 <= 64 && (d8 ? gs.npv <= 8 && gs.nph8 <= 6 : gs.npv <= 6 && gs.nph <= 6)) c->kernel_name = d8 ? "sws_k_strip_dma8" : "sws_k_strip_short";
@@ -2832,7 +2844,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "strip_waves", &c->tune.strip_waves }, { "strip_rgb_cols", &c->tune.strip_rgb_cols }, { "rgb_march_waves", &c->tune.rgb_march_waves }, { "tile_lds_kb", &c->tune.tile_lds_kb },
         { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "layout_ch", &c->tune.layout_ch }, { "no_mixed", &c->tune.no_mixed }, { "no_layout_stream", &c->tune.no_layout_stream }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
         { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
-        { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb }, { "no_strip_range", &c->tune.no_strip_range },
+        { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb }, { "no_strip_range", &c->tune.no_strip_range }, { "no_strip_wide", &c->tune.no_strip_wide },
         { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_lds_pad_kb", &c->tune.strip_lds_pad_kb }, { "no_striprgb_direct", &c->tune.no_striprgb_direct }, { "no_rgbsrc2", &c->tune.no_rgbsrc2 }, { "no_strip_rgbsrc", &c->tune.no_strip_rgbsrc }, { "no_strip_rgb2rgb", &c->tune.no_strip_rgb2rgb },
         { "no_strip_short", &c->tune.no_strip_short }, { "no_generic_kinds", &c->tune.no_generic_kinds }, { "no_rgbread_kinds", &c->tune.no_rgbread_kinds }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "strip_short_waves", &c->tune.strip_short_waves },
         { "debug", &c->tune.debug },

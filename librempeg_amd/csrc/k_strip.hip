@@ -13,6 +13,7 @@ int launch_strip_planes(const LaunchCtx &L, int which)
     const SwsFramePtrs *frames = L.frames; const int n = L.n, sliceY = L.sliceY, sliceH = L.sliceH; const bool vec = L.vec;
     const dim3 blk(256);
     (void)c; (void)d; (void)frames; (void)vec; (void)sliceY; (void)sliceH;
+    if (p.wide) return launch_strip_wide(L, which);     // 19-bit intermediates: k_stripwide.hip
             const int target = c->tune.strip_waves;
             const bool s16 = p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010;   // (launch_rgbread_strip passes its reader planes as SRCK_PLANAR16)
             auto launch = [&](SwsStripGeom g, int H, bool chroma) {

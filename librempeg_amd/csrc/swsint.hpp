@@ -103,6 +103,7 @@ struct Tuning {
     int strip_min_w = 320;         // narrower pictures stay on the LDS-tile kernel (measured: tools/narrow_shapes_times.py -- the strip kernels are level or ahead from 320 columns on)
     int strip_cols_l = 4, strip_cols_c = 2, strip_waves = 4096;
     int strip_min_rows = 4;        // shortest band of a strip-kernel launch (few frames per call: the serial walk of a wave is what a call waits for)
+    int no_strip_wide = 0;         // on: destinations of 16 bits per component (19-bit intermediates) keep the tile / element-per-thread kernels (round 4 behaviour)
     int no_strip_range = 0;        // on: conversions with MPEG <-> JPEG range conversion keep the tile / element-per-thread kernels (round 4 behaviour)
     int no_strip_fuse = 0;         // off: small calls put the luma and the chroma launch into one grid
     int strip_rgb_cols = 4;        // luma columns per lane of the strip kernel with the RGB epilogue (4: 256-pixel strips, 2: 128-pixel strips)

@@ -32,6 +32,12 @@ if os.environ.get("SWS_SHAPES_SET") == "range":      # MPEG <-> JPEG range conve
              ("rgb24",1920,1080,"yuvj420p",1280,720,SWS_BICUBIC),("yuvj420p",1920,1080,"yuv420p10le",1920,1080,SWS_BICUBIC),("yuv420p10le",3840,2160,"yuvj420p",1920,1080,SWS_BICUBIC),
              ("yuv420p",1920,1080,"gray8",1920,1080,SWS_BICUBIC),("yuv420p",1920,1080,"gray8",640,360,SWS_BICUBIC),("gray8",1920,1080,"yuv420p",1920,1080,SWS_BICUBIC),
              ("yuvj420p",1920,1080,"yuvj420p",1280,720,SWS_BICUBIC),("yuvj444p",1920,1080,"yuv420p",1920,1080,SWS_BICUBIC),("yuyv422",1280,720,"yuvj420p",1280,720,SWS_BICUBIC)]
+if os.environ.get("SWS_SHAPES_SET") == "wide":       # destinations of 16 bits per component (19-bit intermediates): decoded video -> planar float RGB for inference, 16-bit masters
+    CASES = [("nv12",1920,1080,"gbrpf32le",640,360,SWS_BILINEAR),("nv12",1920,1080,"gbrpf32le",960,540,SWS_BICUBIC),("yuv420p",3840,2160,"gbrpf32le",1920,1080,SWS_BICUBIC),
+             ("yuv420p",1920,1080,"gbrpf32le",1280,720,SWS_BILINEAR),("nv12",3840,2160,"gbrp16le",1920,1080,SWS_BICUBIC),("yuv420p10le",3840,2160,"gbrpf32le",1920,1080,SWS_BICUBIC),
+             ("yuv420p",3840,2160,"yuv420p16le",1920,1080,SWS_BICUBIC),("yuv420p10le",3840,2160,"p016le",1920,1080,SWS_LANCZOS),("yuv420p",1920,1080,"yuv444p16le",1280,720,SWS_BICUBIC),
+             ("nv12",1920,1080,"p016le",1280,720,SWS_BILINEAR),("yuv420p",1920,1080,"gray16le",960,540,SWS_BICUBIC),("yuv420p",1280,720,"gbrpf32le",1920,1080,SWS_BICUBIC),
+             ("nv12",1920,1080,"gbrpf32le",1920,1080,SWS_BICUBIC),("nv12",1920,1080,"gbrpf32le",224,224,SWS_BILINEAR),("nv12",1920,1080,"gbrpf32le",640,640,SWS_BICUBIC)]
 print("| conversion | path / kernel | ms / frame | Gpix/s out | GB/s (src + dst bytes) |")
 print("|---|---|---|---|---|")
 for sf,sw,sh,df,dw,dh,fl in CASES:

@@ -1,0 +1,31 @@
+#!/bin/bash
+# round-5 profile set: rocprofv3 kernel stats of every bench workload + the bench lines, PMC HBM traffic, layout / common-shape / conversion
+# tables and the kernel stats of the common-shape run.  usage: tools/r05_profiles.sh  -> gpurun_out/r05p/
+set -u
+OUT=$PWD/gpurun_out/r05p; mkdir -p $OUT
+export TMPDIR=/tmp
+ROOT=$PWD
+tools/profile_all.sh r05p > $OUT/bench_lines.jsonl 2>$OUT/profile_all.err
+tools/pmc_traffic.sh r05p "c2a c2b c4 c3a c3b c5 c1 d1" > $OUT/pmc_traffic.txt 2>&1
+python tools/layout_times.py > $OUT/layout.md 2>$OUT/layout.err
+python tools/common_shapes_times.py > $OUT/common.md 2>$OUT/common.err
+python tools/rgb2rgb_times.py > $OUT/rgb2rgb.md 2>$OUT/rgb2rgb.err
+python tools/common_conversions_times.py > $OUT/conv.txt 2>$OUT/conv.err
+python tools/aux_kernel_times.py > $OUT/aux.txt 2>$OUT/aux.err
+python tools/single_frame_times.py > $OUT/single.md 2>$OUT/single.err
+SWS_SHAPES_SET=ladder python tools/common_shapes_times.py > $OUT/ladder.md 2>$OUT/ladder.err
+SWS_SHAPES_SET=range python tools/common_shapes_times.py > $OUT/range.md 2>$OUT/range.err
+SWS_SHAPES_SET=wide python tools/common_shapes_times.py > $OUT/wide.md 2>$OUT/wide.err
+{ python tools/narrow_shapes_times.py; SWS_NARROW_SET=small python tools/narrow_shapes_times.py; } 2>$OUT/narrow.err | grep '^|' > $OUT/narrow.md
+for m in same down up; do python tools/format_survey.py $m > $OUT/survey_$m.md 2>$OUT/survey_$m.err; done
+(cd /tmp && SWS_SHAPES_SET=ladder rocprofv3 --kernel-trace --stats -d $OUT/prof_ladder -o res -- python $ROOT/tools/common_shapes_times.py > $OUT/prof_ladder.log 2>&1)
+db=$(find $OUT/prof_ladder -name "*.db" | head -1)
+[ -n "$db" ] && python tools/rocpd_summary.py "$db" "r05 ladder shapes (ratios of 3:1 and more): SWS_SHAPES_SET=ladder rocprofv3 --kernel-trace --stats -- python tools/common_shapes_times.py" > $OUT/kernel_stats_ladder.md
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_common -o res -- python $ROOT/tools/common_shapes_times.py > $OUT/prof_common.log 2>&1)
+db=$(find $OUT/prof_common -name "*.db" | head -1)
+[ -n "$db" ] && python tools/rocpd_summary.py "$db" "r05 common shapes: rocprofv3 --kernel-trace --stats -- python tools/common_shapes_times.py" > $OUT/kernel_stats_common_shapes.md
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_layout -o res -- python $ROOT/tools/layout_times.py > $OUT/prof_layout.log 2>&1)
+db=$(find $OUT/prof_layout -name "*.db" | head -1)
+[ -n "$db" ] && python tools/rocpd_summary.py "$db" "r05 layout converters (4K): rocprofv3 --kernel-trace --stats -- python tools/layout_times.py" > $OUT/kernel_stats_layout.md
+rm -rf $OUT/prof_common $OUT/prof_layout $OUT/prof_ladder $OUT/traffic_*_FETCH_SIZE $OUT/traffic_*_WRITE_SIZE
+ls $OUT | head -60
