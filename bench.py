@@ -68,6 +68,14 @@ WORKLOADS = {
            "E1 1920x1080->1280x720 rgb24->yuv420p SWS_BICUBIC|SWS_BITEXACT (packed RGB source, downscale)"),
     "e2": (3840, 2160, "bgra", 1920, 1080, "yuv420p", SWS_BICUBIC | SWS_BITEXACT, None, 32,
            "E2 3840x2160->1920x1080 bgra->yuv420p SWS_BICUBIC|SWS_BITEXACT (packed RGB source, downscale)"),
+    # round 5: MPEG <-> JPEG range conversion inside the strip kernels (an MJPEG camera's frames into an encoder's format; capture into a JPEG encoder's)
+    "r1": (1920, 1080, "yuvj422p", 1920, 1080, "yuv420p", SWS_BICUBIC | SWS_BITEXACT, None, 64,
+           "R1 1920x1080 yuvj422p->yuv420p SWS_BICUBIC|SWS_BITEXACT (full -> limited range, vertical chroma step)"),
+    "r2": (1920, 1080, "bgra", 1920, 1080, "yuvj420p", SWS_BICUBIC | SWS_BITEXACT, None, 64,
+           "R2 1920x1080 bgra->yuvj420p SWS_BICUBIC|SWS_BITEXACT (same size, into full range)"),
+    # round 5: 19-bit intermediates -- decoder output into planar float RGB (inference input)
+    "w1": (3840, 2160, "nv12", 1920, 1080, "gbrpf32le", SWS_BICUBIC | SWS_BITEXACT, None, 32,
+           "W1 3840x2160->1920x1080 nv12->gbrpf32le SWS_BICUBIC|SWS_BITEXACT (decoder output -> planar float RGB)"),
 }
 
 
@@ -393,7 +401,7 @@ def main():
                           "cpu_baseline": None}), flush=True)
         return
     main_res = run_workload(args.workload, args.batch, args.steps, args.warmup, rank, world, local_rank, barrier)
-    variants = [] if args.variants in ("", "none") else (["c2b", "c3b", "d1", "c1", "e2"] if args.variants == "auto" and args.workload == "c2a"
+    variants = [] if args.variants in ("", "none") else (["c2b", "c3b", "d1", "c1", "e2", "r1", "w1"] if args.variants == "auto" and args.workload == "c2a"
                                                           else [] if args.variants == "auto" else args.variants.split(","))
     var_res = []
     for v in variants:

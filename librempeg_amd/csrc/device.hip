@@ -636,6 +636,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // nv12 / nv21, p010 / p012 (and the 4:2:2 / 4:4:4 twins): the strip kernel de-interleaves plane 1 (and shifts the p01x samples down) while
             // staging; the dot2 tile kernel does not
             const bool nv_src = (p.srcKind == SRCK_NV12 && c->srcBpc == 8) || (p.srcKind == SRCK_P010 && p.src_depth <= 15);
+            // (round 5: samples of 16 significant bits -- yuv4xxp16, gray16, p016 / p216 / p416 -- through the register-staged strip kernels: top bit flipped while
+            //  staging, the difference given back as a per-column addend, strip_hstage_b)
+            const bool src_u16 = !c->tune.no_strip_u16 && !c->tune.no_strip && c->srcBpc == 16 && p.src_depth == 16 && p.src_shift == 0 && (p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010);
             // (19-bit intermediates, round 5: destinations of 16 bits per component -- yuv4xxp16, gray16, p016 -- and the int32 sums of the wide planar RGB route,
             //  from sources whose samples are v_dot2 operands as they are: sws_k_strip_wide, k_stripwide.hip)
             const bool wide_dst = p.wide && c->dstBpc >= 16 && !c->tune.no_strip_wide && !c->tune.no_strip &&
@@ -662,7 +665,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             //  per-kind element-per-thread reader (k_generic_kinds.hip sws_k_read16_kind); without an alpha plane)
             //  (... and the packed YUV sources of 10 / 12 bits -- y210 / y212, xv30 / v30x, xv36: read_*_c, y21xle_Y/UV_c, input.c:580-606, :663-729, :811-866 -- whose
             //  lines are those of a planar yuv422p10 / yuv444p10 / ...12 picture, sh = depth - 1: the pre-pass de-interleaves them)
-            const bool rgbread_kindN = (p.srcKind == SRCK_RGB30 || p.srcKind == SRCK_RGB16 || (p.srcKind == SRCK_GBRP16 && p.src_depth < 16) ||
+            const bool rgbread_kindN = (p.srcKind == SRCK_RGB30 || p.srcKind == SRCK_RGB16 || (p.srcKind == SRCK_GBRP16 && (p.src_depth < 16 || !c->tune.no_strip_u16)) ||
+                                        // (round 5: rgb48 / rgba64, planar RGB of 16 bits and float32 -- lines of 16 significant bits, see src_u16)
+                                        ((p.srcKind == SRCK_RGB48 || p.srcKind == SRCK_GBRPF32) && !c->tune.no_strip_u16) ||
                                         (p.srcKind == SRCK_PACKEDHI && p.src_depth >= 9 && p.src_depth <= 15 && c->srcBpc == p.src_depth) ||
                                         // (the 8-bit packed 4:4:4 formats -- ayuv / vuya / vuyx / uyva / vyu444: bytes, hScale8To15_c's sh = 7 -- as 16-bit words with 8 significant bits)
                                         (p.srcKind == SRCK_PACKED444 && p.src_depth == 8 && c->srcBpc == 8)) && !p.need_alpha && !c->needAlpha &&   // (an alpha component nobody reads is skipped)
@@ -677,7 +682,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // gray -> gray (8 .. 14 bit): one plane, the strip kernel's luma launch alone
             // (round 5: ... and planar / semi-planar YUV -> gray: the destination has no chroma planes, so the conversion is the luma launch as well -- thumbnails
             //  for analysis; it needed the range conversion in the strip kernels, gray8 being full range, handle_jpeg utils.c:773-809)
-            const bool gray_both = isGray(o.dst_format) && (isGray(o.src_format) || ((src_ok || nv_src) && !c->tune.no_strip_range)) && !c->needAlpha && (src_ok || nv_src) &&
+            const bool gray_both = isGray(o.dst_format) && (isGray(o.src_format) || ((src_ok || nv_src || src_u16) && !c->tune.no_strip_range)) && !c->needAlpha && (src_ok || nv_src || src_u16) &&
                                    (((p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && !p.wide) || (p.dstKind == DSTK_PLANAR16 && wide_dst)) && !c->tune.no_strip;
             // identity luma filters + scaled chroma (yuv422p -> yuv420p, yuv444p -> yuv420p, the 10-bit -> 8-bit twins ...): the luma plane streams
             // (one tap: a per-sample pass), only the chroma planes need the strip kernel
@@ -690,7 +695,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // (... and so had every planar / semi-planar YUV -> YUV conversion whose horizontal filters are the identity and which the mixed plan does not
             //  take: all four filters the identity -- p010le -> yuv420p10le, nv12 -> yuv420p10le, yuv420p10le -> nv12, nv12 <-> nv21, bgra -> yuv444p10le: pure
             //  per-sample conversions the reference has no special converter for -- or vertical-only scaling)
-            const bool unity_yuv = d->unity_h && !d->rgbsrc_ok && !d->rgb444_ok && dst_ok && (src_ok || nv_src || rgbread) && !c->tune.no_mixed;
+            const bool unity_yuv = d->unity_h && !d->rgbsrc_ok && !d->rgb444_ok && dst_ok && (src_ok || nv_src || rgbread || src_u16) && !c->tune.no_mixed;
             const bool unity_ok = !d->unity_h || (rgb_ok && rgb_s16) || (rgbread && !d->rgbsrc_ok && !d->rgb444_ok) || unity_yuv;   // (sws_k_rgbsrc_unity's row table lives in the same device block as the strip plan)
             // filters of 17 .. 32 taps (ratios of 4:1 and more -- the lower rungs of an ABR ladder, thumbnails: bicubic at 4:1 has 17 taps, at 6:1 25; Lanczos at
             // 3:1 19): the strip kernel's long form (sws_k_strip_long: 16 tap pairs each way, strips of 128 / 64 columns); the RGB epilogue stops at 16
@@ -699,9 +704,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                                  !c->tune.no_strip && !c->tune.no_mixed;
             const bool fs_ok64 = fs2(c->hLum.size) <= 64 && fs2(c->hChr.size) <= 64 && fs2(c->vLum.size) <= 64 && fs2(c->vChr.size) <= 64 && dst_ok && !rgb_ok && !gray_both &&
                                  !c->tune.no_strip && !c->tune.no_mixed;      // (33 .. 62 taps: the extra-long form, 32 pairs each way on strips of 64 columns)
-            const bool wide_ok = wide_dst && (src_ok || nv_src) && !p.range_active && !c->needAlpha && !p.need_alpha && !p.fast_bilinear && !vlines_pending && fs_ok16 &&
+            const bool wide_ok = wide_dst && (src_ok || nv_src || src_u16) && !p.range_active && !c->needAlpha && !p.need_alpha && !p.fast_bilinear && !vlines_pending && fs_ok16 &&
                                  !(p.srcKind == SRCK_PLANAR8 && c->srcBpc != 8);
-            const bool fullA = !mixedM && unity_ok && !(d->unity_h && d->unity_v && !rgb_ok && !unity_yuv) && !p.fast_bilinear && (!gray_any || gray_both || d->fullchr_on == 2 || alpha_planar || (rgb_ok && rgb_alpha)) && (src_ok || (nv_src && dst_ok) || rgbread) &&
+            const bool fullA = !mixedM && unity_ok && !(d->unity_h && d->unity_v && !rgb_ok && !unity_yuv) && !p.fast_bilinear && (!gray_any || gray_both || d->fullchr_on == 2 || alpha_planar || (rgb_ok && rgb_alpha)) && (src_ok || (nv_src && dst_ok) || rgbread || (src_u16 && dst_ok)) &&
                                (dst_ok || rgb_ok) && (!p.wide || wide_ok) && (fs_ok16 || fs_ok32 || fs_ok64) && !c->tune.no_dot2;
             const int long_form = !fullA || fs_ok16 ? 0 : fs_ok32 ? 1 : 2;
             d->mixed_ok = false; d->stripLs_ok = d->stripCs_ok = false; d->striprgbsrc_ok = false; d->rgb2rgb_ok = false;
@@ -782,7 +787,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     // LDS-DMA form: a ring of 4 row pairs per wave, rows of ncmax 16-bit samples; every pair between the first and the last
                     // one a band needs is requested, so the windows of consecutive rows must touch (no skipped pair)
                     g.lds_dma_bytes = 4 * 4 * ncomp * 2 * (ncmax / 2) * 4;
-                    g.dma_ok = !longf && (p.srcKind == SRCK_PLANAR16 || rgbread) && g.lds_dma_bytes <= 40 * 1024;   // (LDS-DMA copies rows as they are: planar 16-bit sources, and the reader planes of a packed RGB source)
+                    g.dma_ok = !longf && (p.srcKind == SRCK_PLANAR16 || rgbread) && p.src_depth < 16 && g.lds_dma_bytes <= 40 * 1024;   // (LDS-DMA copies rows as they are: planar 16-bit sources, and the reader planes of a packed RGB source)
                     for (int y = 1; y < vb.count && g.dma_ok; y++)
                         if (((vb.pos[y] & ~1) >> 1) > ((vb.pos[y - 1] & ~1) >> 1) + npv) g.dma_ok = 0;
                     o.cs = put(cs.data(), cs.size() * 4); o.cc = put(cc.data(), cc.size() * 4);
@@ -1318,7 +1323,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     if (c->plan == PLAN_MAIN && d->split_mode && d->striprgb_direct == 3 && d->strip_ok && d->striprgbsrc_ok && !d->mixed_ok && !d->striprgb_ok && !d->fullchr_on && !d->alpha_launch && !d->rgbread_on &&
         !c->tune.no_strip_rgbsrc) { c->path_name = "main:strip_packed422"; c->kernel_name = "sws_k_strip_rgbsrc"; }     // (aligned frames; launch_plan_le falls back to split422 + strip_march otherwise)
     if (c->plan == PLAN_MAIN && d->join422) c->path_name += "+join422";
-    if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += d->fullchr_on == 3 ? "+lut_rgb" : d->fullchr_on == 4 ? "+sum_writer" : "+fullchr_rgb";
+    if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += d->fullchr_on == 3 ? "+lut_rgb" : d->fullchr_on == 4 ? (((d->fullchr_kind == DSTK_GBRP16 || d->fullchr_kind == DSTK_GBRPF32) && !c->tune.no_wide_epilogue) ? "+fullchr_gbrp16" : "+sum_writer") : "+fullchr_rgb";
     if (c->plan == PLAN_MAIN && d->rgb2rgb_ok && !c->tune.no_strip_rgb2rgb && (d->fullchr_on == 1 || d->fullchr_on == 2) && !d->fullchr_direct && d->rgbread_on && d->strip_ok) {
         c->path_name = "main:strip_rgb2rgb"; c->kernel_name = "sws_k_strip_rgb2rgb";      // (aligned frames; launch_plan_le falls back to rgbread + strip_march + fullchr_rgb otherwise)
     }
@@ -1839,7 +1844,8 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         J.frames = p422join.data();
         if (n == 1) { J.fs.table = nullptr; J.fs.one = p422join[0]; }
         else { const SwsFramePtrs *t = nullptr; int r = aux_table(0, p422join, &t); if (r < 0) return r; J.fs.table = t; }
-        if (d->fullchr_on == 4) { int r = launch_sum_writer(J, d->fullchr_kind, sum_tab); if (r < 0) return r; }
+        if (d->fullchr_on == 4 && (d->fullchr_kind == DSTK_GBRP16 || d->fullchr_kind == DSTK_GBRPF32) && !c->tune.no_wide_epilogue) launch_fullchr_rgb(J);   // (sws_k_fullchr_gbrp16: the vector form of the writer)
+        else if (d->fullchr_on == 4) { int r = launch_sum_writer(J, d->fullchr_kind, sum_tab); if (r < 0) return r; }
         else if (d->fullchr_on) launch_fullchr_rgb(J);
         else launch_layout_join422(J, d->join422 == 2);
     }
@@ -2844,7 +2850,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "strip_waves", &c->tune.strip_waves }, { "strip_rgb_cols", &c->tune.strip_rgb_cols }, { "rgb_march_waves", &c->tune.rgb_march_waves }, { "tile_lds_kb", &c->tune.tile_lds_kb },
         { "tile_threads", &c->tune.tile_threads }, { "p01x_ch", &c->tune.p01x_ch }, { "layout_ch", &c->tune.layout_ch }, { "no_mixed", &c->tune.no_mixed }, { "no_layout_stream", &c->tune.no_layout_stream }, { "no_wave", &c->tune.no_wave }, { "no_march", &c->tune.no_march },
         { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
-        { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb }, { "no_strip_range", &c->tune.no_strip_range }, { "no_strip_wide", &c->tune.no_strip_wide },
+        { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb }, { "no_strip_range", &c->tune.no_strip_range }, { "no_strip_wide", &c->tune.no_strip_wide }, { "no_wide_epilogue", &c->tune.no_wide_epilogue }, { "no_strip_u16", &c->tune.no_strip_u16 },
         { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_lds_pad_kb", &c->tune.strip_lds_pad_kb }, { "no_striprgb_direct", &c->tune.no_striprgb_direct }, { "no_rgbsrc2", &c->tune.no_rgbsrc2 }, { "no_strip_rgbsrc", &c->tune.no_strip_rgbsrc }, { "no_strip_rgb2rgb", &c->tune.no_strip_rgb2rgb },
         { "no_strip_short", &c->tune.no_strip_short }, { "no_generic_kinds", &c->tune.no_generic_kinds }, { "no_rgbread_kinds", &c->tune.no_rgbread_kinds }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "strip_short_waves", &c->tune.strip_short_waves },
         { "debug", &c->tune.debug },

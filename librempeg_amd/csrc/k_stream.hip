@@ -112,6 +112,11 @@ void launch_fullchr_rgb(const LaunchCtx &L)
 #define SWS_FC_SRCM(K, ...) do { if (srcm == 1) hipLaunchKernelGGL((swsk::K<__VA_ARGS__, 1>), grid, blk, 0, L.st, L.fs, p); \
                                  else if (srcm == 2) hipLaunchKernelGGL((swsk::K<__VA_ARGS__, 2>), grid, blk, 0, L.st, L.fs, p); \
                                  else hipLaunchKernelGGL((swsk::K<__VA_ARGS__, 0>), grid, blk, 0, L.st, L.fs, p); } while (0)
+    if (L.d->fullchr_kind == DSTK_GBRP16 || L.d->fullchr_kind == DSTK_GBRPF32) {   // (the 19-bit strip kernel's sums: fullchr_on == 4 without the generic writer)
+        if (L.d->fullchr_kind == DSTK_GBRPF32) hipLaunchKernelGGL((swsk::sws_k_fullchr_gbrp16<true>), grid, blk, 0, L.st, L.fs, p);
+        else hipLaunchKernelGGL((swsk::sws_k_fullchr_gbrp16<false>), grid, blk, 0, L.st, L.fs, p);
+        return;
+    }
     if (L.d->fullchr_kind == DSTK_GBRP) {
         const bool wide = p.dst_bits > 8, alpha = L.d->fullchr_on == 2;
         if (wide && alpha) SWS_FC_SRCM(sws_k_fullchr_gbrp, true, true);

@@ -291,6 +291,75 @@ __global__ void __launch_bounds__(256) sws_k_fullchr_gbrp(SwsFrameSet fs, SwsDev
     }
 }
 
+// The epilogue for planar RGB of 16 bits and float32 (gbrp16le, gbrpf32le; round 5) behind the 19-bit strip kernel's int32 sums:
+// yuv2gbrp16_full_X_c / yuv2gbrpf32_full_X_c (output.c:2467-2605) from "Y >>= 14" on -- Y = (Σ - 0x40000000 >> 14) + 0x10000, U / V = Σ - (128 << 23) >> 14,
+// the 13-bit matrix in 32-bit wrap-around arithmetic, then ((Y + R) >> 14) + (1 << 15) clipped to 16 bits: the 16-bit writer adds Y and R in 64 bits,
+// the float writer in 32 (as the reference's two routines do), and the float is float_mult * (float)v with float_mult = 1.0f / 65535.0f.
+// Lane = 4 pixels (three 16-byte loads of sums; three 8- or 16-byte stores), a wave walks down FULLCHR_RPW rows with the next row's loads in flight.
+template <bool F32>
+__global__ void __launch_bounds__(256) sws_k_fullchr_gbrp16(SwsFrameSet fs, SwsDevParams p)
+{
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int lane = threadIdx.x & 63;
+    const int cx = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = U(p.dstW), H = U(p.dstH);
+    if (cx * 256 >= W) return;
+    const int x = (cx * 64 + lane) * 4;
+    const bool in = x < W;
+    const int npx = min(4, W - x);
+    const int y0 = blockIdx.y * FULLCHR_RPW, y1 = min(H, y0 + FULLCHR_RPW);
+    const uint8_t *pY = f.src[0], *pU = f.src[1], *pV = f.src[2];
+    const int64_t sY = f.srcStride[0], sU = f.srcStride[1], sV = f.srcStride[2];
+    const SwsLutParams &L = p.lut;
+    const int y_offset = U(L.y_offset), y_coeff = U(L.y_coeff), v2r = U(L.v2r), v2g = U(L.v2g), u2g = U(L.u2g), u2b = U(L.u2b);
+    int nY[4] = { 0, 0, 0, 0 }, nU[4] = { 0, 0, 0, 0 }, nV[4] = { 0, 0, 0, 0 };
+    auto fetch = [&](int y) { fullchr_fetch4<0>(pY, sY, y, x, npx, 0, nY); fullchr_fetch4<0>(pU, sU, y, x, npx, 0, nU); fullchr_fetch4<0>(pV, sV, y, x, npx, 0, nV); };
+    if (in && y0 < y1) fetch(y0);
+    for (int y = y0; y < y1; y++) {
+        int vY[4], vU[4], vV[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { vY[k] = nY[k]; vU[k] = nU[k]; vV[k] = nV[k]; }
+        if (in && y + 1 < y1) fetch(y + 1);
+        if (!in) continue;
+        uint32_t g[4], b[4], r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int Y = ((int)((unsigned)vY[k] - 0x40000000u) >> 14) + 0x10000;
+            const int Uc = (int)((unsigned)vU[k] - (unsigned)(128 << 23)) >> 14, Vc = (int)((unsigned)vV[k] - (unsigned)(128 << 23)) >> 14;
+            Y -= y_offset;
+            Y = (int)((unsigned)Y * (unsigned)y_coeff);
+            Y = (int)((unsigned)Y + (unsigned)((1 << 13) - (1 << 29)));
+            const int R = (int)((unsigned)Vc * (unsigned)v2r);
+            const int G = (int)((unsigned)Vc * (unsigned)v2g + (unsigned)Uc * (unsigned)u2g);
+            const int B = (int)((unsigned)Uc * (unsigned)u2b);
+            if constexpr (F32) {
+                r[k] = (uint32_t)clip_uintp2(((int)((unsigned)Y + (unsigned)R) >> 14) + (1 << 15), 16);
+                g[k] = (uint32_t)clip_uintp2(((int)((unsigned)Y + (unsigned)G) >> 14) + (1 << 15), 16);
+                b[k] = (uint32_t)clip_uintp2(((int)((unsigned)Y + (unsigned)B) >> 14) + (1 << 15), 16);
+            } else {
+                r[k] = (uint32_t)clip_uintp2((int)(((int64_t)Y + R) >> 14) + (1 << 15), 16);
+                g[k] = (uint32_t)clip_uintp2((int)(((int64_t)Y + G) >> 14) + (1 << 15), 16);
+                b[k] = (uint32_t)clip_uintp2((int)(((int64_t)Y + B) >> 14) + (1 << 15), 16);
+            }
+        }
+        auto put = [&](int plane, const uint32_t (&v)[4]) {
+            uint8_t *d = f.dst[plane] + (int64_t)y * f.dstStride[plane] + (int64_t)(F32 ? 4 : 2) * x;
+            if constexpr (F32) {
+                const float float_mult = 1.0f / 65535.0f;
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) o[k] = __fmul_rn(float_mult, (float)(int)v[k]);
+                if (npx == 4) { const u32x4 w = { __float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]) }; *(SWS_GLOBAL u32x4 *)d = w; }
+                else for (int k = 0; k < npx; k++) ((float *)d)[k] = o[k];
+            } else {
+                if (npx == 4) { const u32x2 o = { v[0] | v[1] << 16, v[2] | v[3] << 16 }; *(SWS_GLOBAL u32x2 *)d = o; }
+                else for (int k = 0; k < npx; k++) ((uint16_t *)d)[k] = (uint16_t)v[k];
+            }
+        };
+        put(0, g); put(1, b); put(2, r);
+    }
+}
+
 // The LUT writers behind the strip kernels' raw sums (dev_prepare_on: fullchr_on == 3): 24 / 32 bpp RGB destinations WITHOUT full chroma whose filters are
 // too long for sws_k_strip_rgb (ratios of 4:1 and more: thumbnails for display or inference).  Y sums at the destination size, U / V sums at half the
 // width; yuv2rgb_X_c_template (output.c:1795-1850): every sum + (1 << 18) >> 19, then the table look-ups in their closed form (lut_pair, kernels_striprgb.hpp).

@@ -84,6 +84,39 @@ __device__ __forceinline__ void strip_hstage(const StripLds &L, const int (&spd)
         }
 }
 
+// The same stage for SRC16 instantiations, with a per-column addend.  Samples of 16 significant bits (yuv4xxp16, p016, the reader planes of 16-bit RGB
+// sources) are no v_dot2_i32_i16 operands as they are: the staging step flips their top bit (s' = s - 32768 as a signed 16-bit value) and the addend gives
+// the difference back -- Σ s t = Σ s' t + 32768 Σ t, with Σ t the column's own tap sum (initFilter leaves it at 16384 give or take its error
+// diffusion: summed from the tap registers, not assumed).  |Σ s' t| <= 2^15 Σ|t| and the reference's own int sum Σ s t both stay inside 32 bits.
+// Sources of up to 15 bits run the same code with a zero addend.
+template <int NP, int NCOMP, int COLS>
+__device__ __forceinline__ void strip_hstage_b(const StripLds &L, const int (&spd)[COLS], const uint32_t (&ht)[COLS][NP], const int (&hb)[COLS], int sh,
+                                               uint32_t (&out)[NCOMP][COLS])
+{
+#pragma unroll
+    for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+        for (int c = 0; c < COLS; c++) {
+            const uint32_t *s0 = L.S + (ci * 2) * L.row_dw + spd[c], *s1 = s0 + L.row_dw;
+            int a = hb[c], b = hb[c];
+#pragma unroll
+            for (int k = 0; k < NP; k++) { a = sdot2(s0[k], ht[c][k], a); b = sdot2(s1[k], ht[c][k], b); }
+            out[ci][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(a >> sh, b >> sh));
+        }
+}
+// the addend of column taps ht[c][0 .. NP): 32768 * (sum of the 2 NP taps) for 16-bit samples, else 0
+template <int NP, int COLS>
+__device__ __forceinline__ void strip_u16_bias(const uint32_t (&ht)[COLS][NP], bool u16, int (&hb)[COLS])
+{
+#pragma unroll
+    for (int c = 0; c < COLS; c++) {
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < NP; k++) sum += (int)(int16_t)(uint16_t)ht[c][k] + ((int)ht[c][k] >> 16);
+        hb[c] = u16 ? sum << 15 : 0;
+    }
+}
+
 // MPEG <-> JPEG range conversion of the h-scaled lines (lum / chrRange{To,From}Jpeg_c, swscale.c:163-209; applied per line behind the horizontal
 // scaler, hscale.c:61-63, :195-197): dst = (dst * coeff + offset) >> 14 in int arithmetic on the int16 line, the ToJpeg forms clip to 2^15 - 1, the
 // store truncates to int16.  Here the line is the packed {even row, odd row} dword of a column on its way into the ring.  Wave-uniform; a block of
@@ -141,6 +174,11 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
 #pragma unroll
         for (int k = 0; k < NPH; k++) ht[c][k] = tp[k];
     }
+    // (16-bit samples: see strip_hstage_b)
+    const bool u16 = SRC16 && p.src_depth >= 16;
+    const uint32_t sxor = u16 ? 0x80008000u : 0u;
+    int hb[COLS];
+    strip_u16_bias<NPH, COLS>(ht, u16, hb);
     // ---- source descriptors (whole rows including their padding) ----
     const bool u1 = p.u_plane_src == 1;
     // nv12 / nv21 sources (8-bit): both chroma components come out of plane 1, de-interleaved on the way into LDS (nvXXtoUV_c, input.c:926-948)
@@ -199,7 +237,7 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
     auto put = [&](uint32_t *dst, const u32x4 &v) {
         if constexpr (SRC16) {
             if (sshift) { u32x4 w; w[0] = (v[0] >> sshift) & smask; w[1] = (v[1] >> sshift) & smask; w[2] = (v[2] >> sshift) & smask; w[3] = (v[3] >> sshift) & smask; *(u32x4 *)dst = w; }
-            else *(u32x4 *)dst = v;
+            else { u32x4 w; w[0] = v[0] ^ sxor; w[1] = v[1] ^ sxor; w[2] = v[2] ^ sxor; w[3] = v[3] ^ sxor; *(u32x4 *)dst = w; }
         } else {
             u32x4 lo, hi;                                      // bytes -> u16 pairs
             lo[0] = __builtin_amdgcn_perm(0, v[0], 0x0c010c00u); lo[1] = __builtin_amdgcn_perm(0, v[0], 0x0c030c02u);
@@ -316,7 +354,8 @@ __device__ __forceinline__ void strip_body(const FrameRegs &f, const SwsDevParam
 #pragma unroll
                     for (int c = 0; c < COLS; c++) np[ci][c] = L.S[(ci * 2) * L.row_dw + spd[c]];
             } else
-            strip_hstage<NPH, NCOMP, COLS>(L, spd, ht, sh, np);
+            if constexpr (SRC16) strip_hstage_b<NPH, NCOMP, COLS>(L, spd, ht, hb, sh, np);
+            else strip_hstage<NPH, NCOMP, COLS>(L, spd, ht, sh, np);
             if (rng.on) strip_range<NCOMP, COLS>(np, rng);
 #pragma unroll
             for (int ci = 0; ci < NCOMP; ci++)

@@ -44,6 +44,11 @@ __device__ __forceinline__ void strip_body_wide(const FrameRegs &f, const SwsDev
 #pragma unroll
         for (int k = 0; k < NPH; k++) ht[c][k] = tp[k];
     }
+    // (16-bit samples: top bit flipped while staging, 32768 * (the column's tap sum) as the chains' addend -- strip_hstage_b, kernels_strip.hpp)
+    const bool u16 = SRC16 && p.src_depth >= 16;
+    const uint32_t sxor = u16 ? 0x80008000u : 0u;
+    int hb[COLS];
+    strip_u16_bias<NPH, COLS>(ht, u16, hb);
     // ---- source descriptors and staging: strip_body's (one 16-byte chunk per lane and staged row: windows of at most 64 chunks, checked on the host) ----
     const bool u1 = p.u_plane_src == 1;
     const bool nvsrc = CHROMA && (SRC16 ? p.srcKind == SRCK_P010 : p.srcKind == SRCK_NV12);
@@ -93,7 +98,7 @@ __device__ __forceinline__ void strip_body_wide(const FrameRegs &f, const SwsDev
     auto put = [&](uint32_t *dst, const u32x4 &v) {
         if constexpr (SRC16) {
             if (sshift) { u32x4 w; w[0] = (v[0] >> sshift) & smask; w[1] = (v[1] >> sshift) & smask; w[2] = (v[2] >> sshift) & smask; w[3] = (v[3] >> sshift) & smask; *(u32x4 *)dst = w; }
-            else *(u32x4 *)dst = v;
+            else { u32x4 w; w[0] = v[0] ^ sxor; w[1] = v[1] ^ sxor; w[2] = v[2] ^ sxor; w[3] = v[3] ^ sxor; *(u32x4 *)dst = w; }
         } else {
             u32x4 lo, hi;                                      // bytes -> u16 pairs
             lo[0] = __builtin_amdgcn_perm(0, v[0], 0x0c010c00u); lo[1] = __builtin_amdgcn_perm(0, v[0], 0x0c030c02u);
@@ -191,9 +196,9 @@ __device__ __forceinline__ void strip_body_wide(const FrameRegs &f, const SwsDev
 #pragma unroll
                     for (int c = 0; c < COLS; c++) {
                         const uint32_t *s0 = L.S + (ci * 2) * L.row_dw + spd[c], *s1 = s0 + L.row_dw;
-                        int a = sdot2_first(s0[0], ht[c][0]), b = sdot2_first(s1[0], ht[c][0]);
+                        int a = SRC16 ? hb[c] : 0, b = a;
 #pragma unroll
-                        for (int k = 1; k < NPH; k++) { a = sdot2(s0[k], ht[c][k], a); b = sdot2(s1[k], ht[c][k], b); }
+                        for (int k = 0; k < NPH; k++) { a = sdot2(s0[k], ht[c][k], a); b = sdot2(s1[k], ht[c][k], b); }
                         na[ci][c] = min(a >> sh, hclip); nb[ci][c] = min(b >> sh, hclip);      // FFMIN(val >> sh, (1 << 19) - 1)
                     }
             }

@@ -103,6 +103,8 @@ struct Tuning {
     int strip_min_w = 320;         // narrower pictures stay on the LDS-tile kernel (measured: tools/narrow_shapes_times.py -- the strip kernels are level or ahead from 320 columns on)
     int strip_cols_l = 4, strip_cols_c = 2, strip_waves = 4096;
     int strip_min_rows = 4;        // shortest band of a strip-kernel launch (few frames per call: the serial walk of a wave is what a call waits for)
+    int no_strip_u16 = 0;          // on: sources with samples of 16 significant bits keep the tile / element-per-thread kernels (round 4 behaviour)
+    int no_wide_epilogue = 0;      // on: planar RGB of 16 bits / float32 behind the 19-bit strip kernel through the generic writer (sws_k_sum_writer) instead of sws_k_fullchr_gbrp16
     int no_strip_wide = 0;         // on: destinations of 16 bits per component (19-bit intermediates) keep the tile / element-per-thread kernels (round 4 behaviour)
     int no_strip_range = 0;        // on: conversions with MPEG <-> JPEG range conversion keep the tile / element-per-thread kernels (round 4 behaviour)
     int no_strip_fuse = 0;         // off: small calls put the luma and the chroma launch into one grid

@@ -51,7 +51,8 @@ def test_range_conversion_and_fallbacks():
     assert run_case(256, 64, "yuva420p", 192, 48, "yuva444p10le", SWS_BICUBIC | BX, tune=TUNE)[0] == "main:strip_march+alpha"
     assert not run_case(254, 64, "bgra", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+alpha")         # the reader pre-pass takes widths of 4 n
     assert not run_case(256, 64, "gbrap", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+alpha")        # planar RGB with alpha: a << 6 samples
-    assert not run_case(256, 64, "yuva420p16le", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+alpha")  # 19-bit intermediates
+    assert run_case(256, 64, "yuva420p16le", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+alpha")      # 16-bit samples: round 5 (strip_hstage_b), the A plane included
+    assert not run_case(256, 64, "yuva420p16le", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_u16=1))[0].endswith("+alpha")
     assert not run_case(256, 64, "yuva420p", 192, 48, "yuva420p16le", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+alpha")
     assert not run_case(256, 64, "ya8", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+alpha")
     assert not run_case(480, 48, "bgra", 240, 24, "yuva420p", SWS_BICUBIC | BX)[0].endswith("+alpha")                    # narrow: below the planner's width threshold

@@ -62,7 +62,8 @@ def test_forced_full_chroma_and_fallbacks():
     assert run_case(256, 64, "bgra", 192, 48, "bgra", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_rgb2rgb=1))[0] == "main:rgbread+strip_march+fullchr_rgb"   # alpha plane scaled: a fourth sum plane
     assert run_case(256, 64, "yuva420p", 192, 48, "rgba", SWS_BICUBIC | FC | BX, tune=TUNE)[0] == "main:strip_march+fullchr_rgb"
     assert not run_case(256, 64, "gbrap", 192, 48, "rgba", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")      # planar RGB with alpha: the generic writer
-    assert not run_case(256, 64, "yuva420p16le", 192, 48, "rgba", SWS_BICUBIC | FC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")   # 16-bit samples: 19-bit intermediates
+    assert run_case(256, 64, "yuva420p16le", 192, 48, "rgba", SWS_BICUBIC | FC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")       # 16-bit samples: round 5 (strip_hstage_b)
+    assert not run_case(256, 64, "yuva420p16le", 192, 48, "rgba", SWS_BICUBIC | FC | BX, tune=dict(TUNE, no_strip_u16=1))[0].endswith("+fullchr_rgb")
     assert not run_case(256, 64, "rgb24", 192, 48, "rgb565le", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")
     assert not run_case(256, 64, "rgb24", 256, 128, "bgr24", SWS_BILINEAR | BX, tune=TUNE)[0].endswith("+fullchr_rgb")   # two luma and two chroma taps: yuv2rgb_full_2
     assert not run_case(480, 48, "rgb24", 240, 24, "bgr24", SWS_BICUBIC | BX)[0].endswith("+fullchr_rgb")                # narrow: below the planner's width threshold

@@ -47,7 +47,8 @@ def test_planner_and_fallbacks():
     assert "rgbread" in run_case(640, 48, "gbrap10le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0]         # a source with an alpha plane nobody reads
     assert "rgbread" not in run_case(640, 48, "gbrap10le", 320, 24, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0]    # ... and one the destination wants scaled
     assert "rgbread" not in run_case(640, 48, "ayuv", 320, 24, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0]
-    assert "rgbread" not in run_case(640, 48, "gbrp16le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0]      # 16-bit samples: 16-bit lines
+    assert "rgbread" in run_case(640, 48, "gbrp16le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0]          # 16-bit samples: 16-bit lines (round 5: strip_hstage_b)
+    assert "rgbread" not in run_case(640, 48, "gbrp16le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_u16=1))[0]
     assert "rgbread" in run_case(640, 48, "x2rgb10le", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=TUNE)[0]        # a range conversion (round 5: in the strip kernels)
     assert "rgbread" not in run_case(640, 48, "x2rgb10le", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_range=1))[0]
     assert "rgbread" not in run_case(640, 48, "x2rgb10le", 320, 24, "yuv420p16le", SWS_BICUBIC | BX, tune=TUNE)[0]  # 19-bit intermediates

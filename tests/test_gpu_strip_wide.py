@@ -46,7 +46,7 @@ def test_planar_rgb_16_bit_and_float_destinations(form, sfmt):
             path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=sw + len(dfmt), tune=T0 if form == "wide" else OLD)
             long_chroma = fl == SWS_LANCZOS and sfmt == "yuv444p"
             if form == "wide" and not (dw & 3) and not long_chroma and not (sw == dw and sfmt in ("yuv444p", "yuyv422", "yuv422p")):     # (identity horizontal filters: the single-pass kernels)     # (the sum-writer route takes widths that are multiples of 4)
-                assert path.endswith("+sum_writer") and "strip" in path, (sfmt, dfmt, sw, dw, path)
+                assert path.endswith("+fullchr_gbrp16") and "strip" in path, (sfmt, dfmt, sw, dw, path)
 
 
 @pytest.mark.parametrize("fl", [SWS_POINT, SWS_AREA, SWS_BILINEAR, SWS_BICUBIC, SWS_GAUSS, SWS_LANCZOS, SWS_SPLINE, SWS_BICUBIC | SWS_ACCURATE_RND])
@@ -55,6 +55,12 @@ def test_scalers_and_geometries(fl):
         for sfmt, dfmt in (("yuv420p", "yuv420p16le"), ("nv12", "p016le"), ("yuv420p10le", "yuv444p16le"), ("yuv420p", "gbrpf32le"), ("nv12", "gbrp16le"), ("gray8", "gray16le"), ("yuv420p", "gray16le"),
                            ("gray10le", "gray16le")):
             run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=dw, tune=T0)
+
+
+def test_generic_writer_over_the_sums_equals_the_vector_epilogue():
+    for dfmt in ("gbrp16le", "gbrpf32le"):
+        assert run_case(640, 48, "yuv420p", 320, 24, dfmt, SWS_BICUBIC | BX, tune=dict(T0, no_wide_epilogue=1))[0].endswith("+sum_writer")
+        assert run_case(644, 50, "nv12", 484, 33, dfmt, SWS_BILINEAR | BX, tune=dict(T0, no_wide_epilogue=1))[0].endswith("+sum_writer")
 
 
 def test_options_chroma_positions_and_colourspace_details():
@@ -71,7 +77,8 @@ def test_options_chroma_positions_and_colourspace_details():
 def test_planner_and_fallbacks():
     assert "strip" in run_case(1920, 54, "yuv420p", 1280, 36, "yuv420p16le", SWS_BICUBIC | BX)[0]                     # wide enough without the option
     assert "strip" not in run_case(480, 48, "yuv420p", 240, 24, "yuv420p16le", SWS_BICUBIC | BX)[0]                   # narrow: the old kernels
-    assert "strip" not in run_case(640, 48, "yuv420p16le", 320, 24, "yuv420p16le", SWS_BICUBIC | BX, tune=T0)[0]      # 16-bit samples are no v_dot2 operands
+    assert "strip" in run_case(640, 48, "yuv420p16le", 320, 24, "yuv420p16le", SWS_BICUBIC | BX, tune=T0)[0]          # 16-bit samples: top bit flipped, per-column addend (tests/test_gpu_strip_u16.py)
+    assert "strip" not in run_case(640, 48, "yuv420p16le", 320, 24, "yuv420p16le", SWS_BICUBIC | BX, tune=dict(T0, no_strip_u16=1))[0]
     assert "strip" not in run_case(640, 48, "rgb24", 320, 24, "yuv420p16le", SWS_BICUBIC | BX, tune=T0)[0]            # RGB sources: not in this round
     assert "strip" not in run_case(640, 48, "yuva420p", 320, 24, "yuva420p16le", SWS_BICUBIC | BX, tune=T0)[0]        # a scaled alpha plane
     assert "strip" not in run_case(1280, 96, "yuv420p", 160, 12, "yuv420p16le", SWS_BICUBIC | BX, tune=T0)[0]         # 8:1: filters beyond the ring

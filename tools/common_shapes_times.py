@@ -38,6 +38,12 @@ if os.environ.get("SWS_SHAPES_SET") == "wide":       # destinations of 16 bits p
              ("yuv420p",3840,2160,"yuv420p16le",1920,1080,SWS_BICUBIC),("yuv420p10le",3840,2160,"p016le",1920,1080,SWS_LANCZOS),("yuv420p",1920,1080,"yuv444p16le",1280,720,SWS_BICUBIC),
              ("nv12",1920,1080,"p016le",1280,720,SWS_BILINEAR),("yuv420p",1920,1080,"gray16le",960,540,SWS_BICUBIC),("yuv420p",1280,720,"gbrpf32le",1920,1080,SWS_BICUBIC),
              ("nv12",1920,1080,"gbrpf32le",1920,1080,SWS_BICUBIC),("nv12",1920,1080,"gbrpf32le",224,224,SWS_BILINEAR),("nv12",1920,1080,"gbrpf32le",640,640,SWS_BICUBIC)]
+if os.environ.get("SWS_SHAPES_SET") == "u16":        # sources with samples of 16 significant bits (16-bit masters, PNG-16 / TIFF / EXR pictures, float tensors) into delivery formats
+    CASES = [("yuv420p16le",3840,2160,"yuv420p",1920,1080,SWS_BICUBIC),("yuv444p16le",3840,2160,"yuv420p10le",1920,1080,SWS_BICUBIC),("p016le",3840,2160,"nv12",1920,1080,SWS_BILINEAR),
+             ("rgb48le",3840,2160,"yuv420p",1920,1080,SWS_BICUBIC),("rgba64le",3840,2160,"yuv420p",1920,1080,SWS_BICUBIC),("gbrpf32le",3840,2160,"yuv420p",1920,1080,SWS_BICUBIC),
+             ("gbrpf32le",1920,1080,"nv12",1280,720,SWS_BICUBIC),("gbrp16le",3840,2160,"yuv420p10le",1920,1080,SWS_BICUBIC),("gray16le",3840,2160,"gray8",1920,1080,SWS_BICUBIC),
+             ("yuv420p16le",1920,1080,"yuv420p",1920,1080,SWS_BICUBIC),("rgb48le",1920,1080,"yuv420p",1920,1080,SWS_BICUBIC),("gbrpf32le",1920,1080,"yuv420p",1920,1080,SWS_BICUBIC),
+             ("yuv420p16le",3840,2160,"yuv420p16le",1920,1080,SWS_LANCZOS),("rgb48le",1280,720,"yuv420p",1920,1080,SWS_BICUBIC)]
 print("| conversion | path / kernel | ms / frame | Gpix/s out | GB/s (src + dst bytes) |")
 print("|---|---|---|---|---|")
 for sf,sw,sh,df,dw,dh,fl in CASES:

@@ -16,6 +16,7 @@ python tools/single_frame_times.py > $OUT/single.md 2>$OUT/single.err
 SWS_SHAPES_SET=ladder python tools/common_shapes_times.py > $OUT/ladder.md 2>$OUT/ladder.err
 SWS_SHAPES_SET=range python tools/common_shapes_times.py > $OUT/range.md 2>$OUT/range.err
 SWS_SHAPES_SET=wide python tools/common_shapes_times.py > $OUT/wide.md 2>$OUT/wide.err
+SWS_SHAPES_SET=u16 python tools/common_shapes_times.py > $OUT/u16.md 2>$OUT/u16.err
 { python tools/narrow_shapes_times.py; SWS_NARROW_SET=small python tools/narrow_shapes_times.py; } 2>$OUT/narrow.err | grep '^|' > $OUT/narrow.md
 for m in same down up; do python tools/format_survey.py $m > $OUT/survey_$m.md 2>$OUT/survey_$m.err; done
 (cd /tmp && SWS_SHAPES_SET=ladder rocprofv3 --kernel-trace --stats -d $OUT/prof_ladder -o res -- python $ROOT/tools/common_shapes_times.py > $OUT/prof_ladder.log 2>&1)
