@@ -22,6 +22,7 @@ void launch_layout_split422(const LaunchCtx &L, bool uyvy, bool vfirst);   // k_
 void launch_layout_splitnv(const LaunchCtx &L, bool vfirst);   // k_layout.hip: plane 1 of a semi-planar 8-bit picture -> planar U / V working planes
 void launch_layout_splitp01x(const LaunchCtx &L, int shift);   // k_layout.hip: p010-style planes -> planar working picture, words >> shift
 void launch_alpha_merge32(const LaunchCtx &L);                 // k_stream.hip: the alpha bytes behind sws_k_strip_rgb (alpha_launch == 2)
+void launch_gray_chroma(const LaunchCtx &L);                   // k_stream.hip: the chroma planes of a gray source in a YUV destination
 void launch_layout_join422(const LaunchCtx &L, bool uyvy);   // k_layout.hip: planar 4:2:2 working picture -> yuyv422 / uyvy422 (yvyu422: planes swapped by the planner)
 
 static int ensure_dev(SwsInternal *c)
@@ -508,7 +509,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     //      fits or a row takes one of the writer's short forms (the 10 / 12-bit packed YUV formats have X writers only) ----
     // (round 5: planar RGB of 16 bits and float32 -- gbrp16le, gbrpf32le: yuv2gbrp16_full_X_c / yuv2gbrpf32_full_X_c, output.c:2424-2610, always the X form -- over the
     //  sums of the 19-bit strip kernel, sws_k_strip_wide: decoded video into planar float RGB for inference)
-    const bool wide_gbrp = (p.dstKind == DSTK_GBRP16 || p.dstKind == DSTK_GBRPF32) && p.wide && c->dstBpc >= 16 && !isALPHA(o.dst_format) && !c->tune.no_strip_wide;
+    // (... and rgb48 / bgr48 / rgba64 / bgra64 without a scaled alpha plane: yuv2rgba64_X_c_template / yuv2rgba64_full_X_c_template, output.c:1115-1652, the generic
+    //  writer's X form over the sums; rows in the writer's _1 / _2 forms keep the old kernels like the other packed kinds)
+    const bool wide_gbrp = (((p.dstKind == DSTK_GBRP16 || p.dstKind == DSTK_GBRPF32) && !isALPHA(o.dst_format)) || p.dstKind == DSTK_RGB48) && p.wide && c->dstBpc >= 16 && !c->tune.no_strip_wide;
     if (!d->fullchr_on && c->plan == PLAN_MAIN && (((p.dstKind == DSTK_RGB16 || p.dstKind == DSTK_RGB30 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI) && !p.wide &&
         c->dstBpc <= 14) || wide_gbrp) && !c->needAlpha && fc_plain && !(o.flags & SWS_FAST_BILINEAR) && !(o.dst_w & 3) && o.dst_w >= strip_min_w_eff && c->chrDstVSubSample == 0 &&
         !(bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14)) &&   // (identity horizontal filters: the single-pass per-kind kernels are as fast or faster -- no sum planes)
@@ -672,7 +675,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                                         // (the 8-bit packed 4:4:4 formats -- ayuv / vuya / vuyx / uyva / vyu444: bytes, hScale8To15_c's sh = 7 -- as 16-bit words with 8 significant bits)
                                         (p.srcKind == SRCK_PACKED444 && p.src_depth == 8 && c->srcBpc == 8)) && !p.need_alpha && !c->needAlpha &&   // (an alpha component nobody reads is skipped)
                                        !c->tune.no_rgbread_kinds;
-            bool rgbread = !p.wide && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || rgbread_kindN) && p.chrSrcHSub <= 1 && p.chrSrcW == (p.srcW >> p.chrSrcHSub) && !(p.srcW & 3) && p.chrSrcVSub == 0 && (!p.need_alpha || d->fullchr_on == 2 || alpha_planar) &&
+            bool rgbread = (!p.wide || !c->tune.no_strip_wide) && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || rgbread_kindN) && p.chrSrcHSub <= 1 && p.chrSrcW == (p.srcW >> p.chrSrcHSub) && !(p.srcW & 3) && p.chrSrcVSub == 0 && (!p.need_alpha || d->fullchr_on == 2 || alpha_planar) &&
                            (!p.dst_alpha_fill || d->fullchr_on) && !p.no_chroma && !vlines_pending && dst_ok && !c->tune.no_strip && !c->tune.no_rgbsrc && p.dstW >= strip_min_w_eff;
             for (int k = 0; k < 9 && rgbread; k++) rgbread = p.rgb2yuv[k] > -32768 && p.rgb2yuv[k] < 32768;   // (v_dot2_i32_i16 operands)
             d->rgbread_on = false;
@@ -682,8 +685,13 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // gray -> gray (8 .. 14 bit): one plane, the strip kernel's luma launch alone
             // (round 5: ... and planar / semi-planar YUV -> gray: the destination has no chroma planes, so the conversion is the luma launch as well -- thumbnails
             //  for analysis; it needed the range conversion in the strip kernels, gray8 being full range, handle_jpeg utils.c:773-809)
-            const bool gray_both = isGray(o.dst_format) && (isGray(o.src_format) || ((src_ok || nv_src || src_u16) && !c->tune.no_strip_range)) && !c->needAlpha && (src_ok || nv_src || src_u16) &&
-                                   (((p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && !p.wide) || (p.dstKind == DSTK_PLANAR16 && wide_dst)) && !c->tune.no_strip;
+            // (round 5: ... and gray sources into planar / semi-planar YUV: the luma launch, then sws_k_gray_chroma writes what the reference's chroma writers make of
+            //  their constant lines -- launch_plan_le_batch)
+            const bool gray_src = isGray(o.src_format) && !isGray(o.dst_format) && !c->needAlpha && !isALPHA(o.dst_format) && (src_ok || src_u16) && !c->tune.no_strip_range &&
+                                  (((p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010) && !p.wide) ||
+                                   ((p.dstKind == DSTK_PLANAR16 || p.dstKind == DSTK_P016) && wide_dst)) && !d->join422 && !d->fullchr_on && !c->tune.no_strip;
+            const bool gray_both = gray_src || (isGray(o.dst_format) && (isGray(o.src_format) || ((src_ok || nv_src || src_u16) && !c->tune.no_strip_range)) && !c->needAlpha && (src_ok || nv_src || src_u16) &&
+                                   (((p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && !p.wide) || (p.dstKind == DSTK_PLANAR16 && wide_dst)) && !c->tune.no_strip);
             // identity luma filters + scaled chroma (yuv422p -> yuv420p, yuv444p -> yuv420p, the 10-bit -> 8-bit twins ...): the luma plane streams
             // (one tap: a per-sample pass), only the chroma planes need the strip kernel
             const bool mixedM = !vlines_pending && !d->fullchr_on && bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !(d->unity_h && d->unity_v) &&
@@ -704,7 +712,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                                  !c->tune.no_strip && !c->tune.no_mixed;
             const bool fs_ok64 = fs2(c->hLum.size) <= 64 && fs2(c->hChr.size) <= 64 && fs2(c->vLum.size) <= 64 && fs2(c->vChr.size) <= 64 && dst_ok && !rgb_ok && !gray_both &&
                                  !c->tune.no_strip && !c->tune.no_mixed;      // (33 .. 62 taps: the extra-long form, 32 pairs each way on strips of 64 columns)
-            const bool wide_ok = wide_dst && (src_ok || nv_src || src_u16) && !p.range_active && !c->needAlpha && !p.need_alpha && !p.fast_bilinear && !vlines_pending && fs_ok16 &&
+            const bool wide_ok = wide_dst && (src_ok || nv_src || src_u16 || rgbread) && !p.range_active && !c->needAlpha && !p.need_alpha && !p.fast_bilinear && !vlines_pending && fs_ok16 &&
                                  !(p.srcKind == SRCK_PLANAR8 && c->srcBpc != 8);
             const bool fullA = !mixedM && unity_ok && !(d->unity_h && d->unity_v && !rgb_ok && !unity_yuv) && !p.fast_bilinear && (!gray_any || gray_both || d->fullchr_on == 2 || alpha_planar || (rgb_ok && rgb_alpha)) && (src_ok || (nv_src && dst_ok) || rgbread || (src_u16 && dst_ok)) &&
                                (dst_ok || rgb_ok) && (!p.wide || wide_ok) && (fs_ok16 || fs_ok32 || fs_ok64) && !c->tune.no_dot2;
@@ -1760,6 +1768,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
             else if (d->striprgb_direct_now && d->striprgb_direct == 3) {
                 if (!launch_strip_rgbsrc(L)) { log_msg(c, 0, "internal error: no lockstep strip kernel for a packed 4:2:2 source whose split pass was skipped\n"); return SWS_AVERROR(EINVAL); }
             } else ret = launch_strip(L);
+            if (ret >= 0 && p.no_chroma && isGray(c->opts.src_format) && !isGray(c->opts.dst_format) && p.dstKind != DSTK_RAW32) launch_gray_chroma(L);   // (a gray source: the luma launch alone ran)
         }
         else if (d->dot2_ok && vec) ret = launch_tile_dot2(L);                                              // dot2 LDS-tile kernel
         else if (d->tile_ok) ret = launch_tile(L);                                                          // fused h+v LDS-tile kernel

@@ -49,7 +49,7 @@ void GK_CAT(generic_dst_fns_, GK_DK)(GenericDstFns *t)
     constexpr bool rgb = DK == DSTK_RGB24 || DK == DSTK_RGB32 || DK == DSTK_GBRP || DK == DSTK_GBRP16 || DK == DSTK_GBRPF32 || DK == DSTK_PACKED422 || DK == DSTK_PACKED444 ||
         DK == DSTK_PACKEDHI || DK == DSTK_RGB48 || DK == DSTK_RGB16 || DK == DSTK_RGB30 || DK == DSTK_MONO || DK == DSTK_RGB8 || DK == DSTK_RGB4 || DK == DSTK_YA;
     constexpr bool nv = DK == DSTK_NV12 || DK == DSTK_P010 || DK == DSTK_P016;
-    if constexpr (DK == DSTK_RGB16 || DK == DSTK_RGB30 || DK == DSTK_PACKED444 || DK == DSTK_PACKEDHI || DK == DSTK_GBRP16 || DK == DSTK_GBRPF32) t->sum_writer = swsk::sws_k_sum_writer<DK>;
+    if constexpr (DK == DSTK_RGB16 || DK == DSTK_RGB30 || DK == DSTK_PACKED444 || DK == DSTK_PACKEDHI || DK == DSTK_GBRP16 || DK == DSTK_GBRPF32 || DK == DSTK_RGB48) t->sum_writer = swsk::sws_k_sum_writer<DK>;
     if constexpr (rgb) {
         t->rgb16 = swsk::sws_k_vscale_rgb<false, int16_t, -1, DK>;
         t->rgb32 = swsk::sws_k_vscale_rgb<false, int32_t, -1, DK>;

@@ -131,6 +131,14 @@ void launch_fullchr_rgb(const LaunchCtx &L)
 #undef SWS_FC_SRCM
 }
 
+// the chroma planes of a gray source in a YUV destination (dev_prepare_on: a gray source on the strip kernels' luma launch)
+void launch_gray_chroma(const LaunchCtx &L)
+{
+    const SwsDevParams &p = *L.p;
+    if (p.chrDstW <= 0 || p.chrDstH <= 0) return;
+    hipLaunchKernelGGL(swsk::sws_k_gray_chroma, dim3(cdiv(p.chrDstW, 256), p.chrDstH, L.n), dim3(256), 0, L.st, L.fs, p);
+}
+
 // plane copies between unaligned pictures and their aligned working copies (device.hip launch_plan_le; L.fs holds {src[k] -> dst[k]})
 void launch_stage_planes(const LaunchCtx &L, const int row_bytes[4], const int rows[4], bool in)
 {

@@ -360,6 +360,48 @@ __global__ void __launch_bounds__(256) sws_k_fullchr_gbrp16(SwsFrameSet fs, SwsD
     }
 }
 
+// The chroma planes of a gray source scaled into a planar / semi-planar YUV picture (round 5; the luma plane is the strip kernels' luma launch).
+// The reference gives such a conversion chroma LINES that hold the line buffers' initial value (ff_init_desc_no_chr: fill_ones, slice.c:190-208 -- 1 << 14,
+// or 1 << 18 for the 19-bit lines; never h-scaled, never range converted) and runs the chroma writers over them with the real vertical bank: a sample is
+// writer(C * sum of row cy's taps), which only the dither pattern varies along a row.  Writers as in strip_body / strip_body_wide: yuv2planeX_8_c / the N-bit
+// and 16-bit forms / yuv2nv12cX_c / yuv2p01xcX_c / yuv2nv12cX_16_c (output.c:149-217, :327-357, :468-589); a one-tap bank enters the planar forms as 4096
+// (yuv2plane1_*: the coefficient is not looked at), the semi-planar chroma writers multiply by its value.  One thread per chroma column.
+__global__ void __launch_bounds__(256) sws_k_gray_chroma(SwsFrameSet fs, SwsDevParams p)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, cy = blockIdx.y;
+    const int cW = U(p.chrDstW), cH = U(p.chrDstH);
+    if (x >= cW || cy >= cH) return;
+    const SwsFramePtrs f = frame_copy(fs, blockIdx.z);
+    const int kind = U(p.dstKind), fsz = U(p.vChrFs), bits = U(p.dst_bits), osh = U(p.dst_shift);
+    const bool semi = kind == DSTK_NV12 || kind == DSTK_P010 || kind == DSTK_P016;
+    int tsum = 0;
+    if (fsz == 1 && !semi) tsum = 4096;
+    else for (int j = 0; j < fsz; j++) tsum += p.vChrF[(int64_t)cy * fsz + j];
+    const uint32_t acc = (uint32_t)(p.wide ? 1 << 18 : 1 << 14) * (uint32_t)tsum;     // (32-bit wrap-around like the writers' own sums)
+    uint32_t u, v;
+    if (p.wide) {
+        const int val = (int)(acc + (uint32_t)((1 << 14) - 0x40000000));
+        u = v = (uint32_t)(0x8000 + min(max(val >> 15, -32768), 32767));
+    } else if (kind == DSTK_PLANAR8 || kind == DSTK_NV12) {
+        u = (uint32_t)clip_u8_shr((dither8(p.should_dither, cy, x) << 12) + (int)acc, 19);
+        v = (uint32_t)clip_u8_shr((dither8(p.should_dither, cy, x + 3) << 12) + (int)acc, 19);
+    } else {
+        const int shift = 11 + 16 - bits;
+        u = v = (uint32_t)(clip_uintp2(((1 << (shift - 1)) + (int)acc) >> shift, bits) << osh);
+    }
+    if (semi) {
+        if (p.uv_swap_dst) { const uint32_t t = u; u = v; v = t; }
+        uint8_t *d = f.dst[1] + (int64_t)cy * f.dstStride[1];
+        if (kind == DSTK_NV12) ((uint16_t *)d)[x] = (uint16_t)(u | v << 8);
+        else ((uint32_t *)d)[x] = u | v << 16;
+    } else {
+        const int up = U(p.u_plane_dst), vp = U(p.v_plane_dst);
+        uint8_t *du = f.dst[up] + (int64_t)cy * f.dstStride[up], *dv = f.dst[vp] + (int64_t)cy * f.dstStride[vp];
+        if (kind == DSTK_PLANAR8) { du[x] = (uint8_t)u; dv[x] = (uint8_t)v; }
+        else { ((uint16_t *)du)[x] = (uint16_t)u; ((uint16_t *)dv)[x] = (uint16_t)v; }
+    }
+}
+
 // The LUT writers behind the strip kernels' raw sums (dev_prepare_on: fullchr_on == 3): 24 / 32 bpp RGB destinations WITHOUT full chroma whose filters are
 // too long for sws_k_strip_rgb (ratios of 4:1 and more: thumbnails for display or inference).  Y sums at the destination size, U / V sums at half the
 // width; yuv2rgb_X_c_template (output.c:1795-1850): every sum + (1 << 18) >> 19, then the table look-ups in their closed form (lut_pair, kernels_striprgb.hpp).

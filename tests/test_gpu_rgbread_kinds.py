@@ -51,7 +51,8 @@ def test_planner_and_fallbacks():
     assert "rgbread" not in run_case(640, 48, "gbrp16le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_u16=1))[0]
     assert "rgbread" in run_case(640, 48, "x2rgb10le", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=TUNE)[0]        # a range conversion (round 5: in the strip kernels)
     assert "rgbread" not in run_case(640, 48, "x2rgb10le", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_range=1))[0]
-    assert "rgbread" not in run_case(640, 48, "x2rgb10le", 320, 24, "yuv420p16le", SWS_BICUBIC | BX, tune=TUNE)[0]  # 19-bit intermediates
+    assert "rgbread" in run_case(640, 48, "x2rgb10le", 320, 24, "yuv420p16le", SWS_BICUBIC | BX, tune=TUNE)[0]      # 19-bit intermediates: round 5 (sws_k_strip_wide on the reader planes)
+    assert "rgbread" not in run_case(640, 48, "x2rgb10le", 320, 24, "yuv420p16le", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_wide=1))[0]
     assert "rgbread" not in run_case(640, 48, "y216le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0]        # 16-bit samples
     assert "rgbread" not in run_case(640, 48, "ayuv64le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0]      # 16-bit samples, alpha
     assert "rgbread" in run_case(1920, 54, "y210le", 1280, 36, "yuv420p", SWS_BICUBIC | BX)[0]

@@ -104,3 +104,20 @@ def test_full_size_camera_and_thumbnail_shapes():
     run_case(1920, 1080, "yuv420p", 320, 180, "yuvj420p", SWS_BICUBIC | BX, seed=13)
     run_case(1920, 1080, "bgra", 1920, 1080, "yuvj420p", SWS_BICUBIC | BX, seed=14)
     run_case(1920, 1080, "yuv420p", 640, 360, "gray8", SWS_BILINEAR | BX, seed=15)
+
+
+def test_gray_sources_into_yuv():
+    """gray -> planar / semi-planar YUV (round 5): the strip kernels' luma launch (gray8 is full range: a range conversion into limited-range YUV) and
+    sws_k_gray_chroma for the chroma planes -- the reference's chroma writers over constant lines (ff_init_desc_no_chr), with the real vertical bank
+    and the dither of sources beyond 8 bits"""
+    for sfmt in ("gray8", "gray10le", "gray12le", "gray16le", "gray10be"):
+        for dfmt in ("yuv420p", "yuv422p", "yuv444p", "nv12", "nv21", "yuv420p10le", "p010le", "yuv444p12le", "yuv420p16le", "p016le", "yuvj420p", "yuv410p"):
+            for (sw, sh, dw, dh, fl) in ((644, 70, 324, 35, SWS_BILINEAR), (400, 66, 332, 54, SWS_BICUBIC), (320, 40, 640, 80, SWS_BICUBIC), (640, 48, 640, 48, SWS_BICUBIC),
+                                         (640, 3, 320, 24, SWS_BICUBIC), (1284, 36, 428, 12, SWS_LANCZOS)):
+                path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=sw + len(dfmt), tune=T0)
+                if (sw, dw) == (400, 332) and dfmt not in ("yuv420p16le", "p016le"):     # (19-bit lines with a range conversion: 64-bit arithmetic, the old kernels)
+                    assert "strip" in path, (sfmt, dfmt, path)
+    opts = dict(dither=1, src_range=0, dst_range=1, src_h_chr_pos=-513, src_v_chr_pos=-513, dst_h_chr_pos=0, dst_v_chr_pos=128, threads=1)
+    run_case(640, 48, "gray8", 320, 24, "yuv420p", SWS_BICUBIC | BX, seed=3, opts=opts, tune=T0)
+    run_case(1920, 1080, "gray8", 1280, 720, "nv12", SWS_BICUBIC | BX, seed=4)
+    run_case(1920, 1080, "gray16le", 960, 540, "yuv420p10le", SWS_BILINEAR | BX, seed=5, device_frames=False)

@@ -57,6 +57,26 @@ def test_scalers_and_geometries(fl):
             run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=dw, tune=T0)
 
 
+@pytest.mark.parametrize("sfmt", ["rgb24", "bgra", "gbrp", "rgb565le", "x2rgb10le", "gbrp10le", "rgb48le", "gbrpf32le"])
+def test_rgb_sources_into_16_bit_destinations(sfmt):
+    for dfmt in ("yuv420p16le", "yuv444p16le", "p016le", "gbrpf32le", "gbrp16le", "rgb48le"):
+        for (sw, sh, dw, dh, fl) in ((644, 40, 516, 32, SWS_BICUBIC), (640, 48, 320, 24, SWS_BICUBIC), (320, 24, 640, 48, SWS_BILINEAR)):
+            path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=dw + len(sfmt), tune=T0)
+            if dfmt in ("yuv420p16le", "p016le") and fl == SWS_BICUBIC and sfmt not in ("gbrp10le", "gbrpf32le"):   # (planar RGB beyond 8 bits has no half-width chroma reader: a 4:1 chroma step, long filters)
+                assert "rgbread" in path, (sfmt, dfmt, sw, dw, path)
+
+
+@pytest.mark.parametrize("dfmt", ["rgb48le", "bgr48le", "rgba64le", "bgra64le", "rgb48be"])
+def test_packed_rgb_of_16_bits(dfmt):
+    """yuv2rgba64_X_c_template / the full-chroma form over the strip kernel's sums (the generic writer's X form); rows in its _1 / _2 forms keep the old kernels"""
+    for sfmt in ("yuv420p", "nv12", "yuv420p10le", "yuv444p", "yuv422p"):
+        for (sw, sh, dw, dh, fl) in ((644, 70, 324, 35, SWS_BILINEAR), (400, 66, 332, 54, SWS_BICUBIC), (320, 40, 640, 80, SWS_BICUBIC), (640, 48, 320, 24, SWS_BICUBIC | SWS_FULL_CHR_H_INT),
+                                     (640, 48, 640, 96, SWS_BICUBIC), (640, 48, 644, 24, SWS_LANCZOS)):
+            path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=sw + len(dfmt), tune=T0)
+            if (sw, dw) in ((400, 332), (320, 640)) and sfmt != "yuv444p":
+                assert path.endswith("+sum_writer"), (sfmt, dfmt, sw, dw, path)
+
+
 def test_generic_writer_over_the_sums_equals_the_vector_epilogue():
     for dfmt in ("gbrp16le", "gbrpf32le"):
         assert run_case(640, 48, "yuv420p", 320, 24, dfmt, SWS_BICUBIC | BX, tune=dict(T0, no_wide_epilogue=1))[0].endswith("+sum_writer")
@@ -79,7 +99,7 @@ def test_planner_and_fallbacks():
     assert "strip" not in run_case(480, 48, "yuv420p", 240, 24, "yuv420p16le", SWS_BICUBIC | BX)[0]                   # narrow: the old kernels
     assert "strip" in run_case(640, 48, "yuv420p16le", 320, 24, "yuv420p16le", SWS_BICUBIC | BX, tune=T0)[0]          # 16-bit samples: top bit flipped, per-column addend (tests/test_gpu_strip_u16.py)
     assert "strip" not in run_case(640, 48, "yuv420p16le", 320, 24, "yuv420p16le", SWS_BICUBIC | BX, tune=dict(T0, no_strip_u16=1))[0]
-    assert "strip" not in run_case(640, 48, "rgb24", 320, 24, "yuv420p16le", SWS_BICUBIC | BX, tune=T0)[0]            # RGB sources: not in this round
+    assert "rgbread" in run_case(640, 48, "rgb24", 320, 24, "yuv420p16le", SWS_BICUBIC | BX, tune=T0)[0]             # RGB sources: the reader pre-pass's planes
     assert "strip" not in run_case(640, 48, "yuva420p", 320, 24, "yuva420p16le", SWS_BICUBIC | BX, tune=T0)[0]        # a scaled alpha plane
     assert "strip" not in run_case(1280, 96, "yuv420p", 160, 12, "yuv420p16le", SWS_BICUBIC | BX, tune=T0)[0]         # 8:1: filters beyond the ring
     run_case(642, 48, "yuv420p", 322, 24, "gbrpf32le", SWS_BICUBIC | BX, tune=T0)                                    # width not a multiple of 4
