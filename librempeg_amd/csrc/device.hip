@@ -362,7 +362,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     }
     // (the LUT writers with filters too long for sws_k_strip_rgb -- ratios of 4:1 and more: the same route with the chroma sums at half the width and
     //  sws_k_lut_rgb as the epilogue: fullchr_on == 3)
-    if (!d->fullchr_on && c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr && long_taps && !c->needAlpha && fc_plain &&
+    // (round 5: ... and for planar / semi-planar sources with samples of 16 significant bits -- yuv4xxp16, p016: sws_k_strip_rgb's own staging takes samples of up to
+    //  15 bits, the planar strip kernels take these, strip_hstage_b)
+    const bool lut_u16 = !c->tune.no_strip_u16 && c->srcBpc == 16 && p.src_depth == 16 && p.src_shift == 0 && (p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010);
+    if (!d->fullchr_on && c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr && (long_taps || lut_u16) && !c->needAlpha && fc_plain &&
         !(o.flags & SWS_FAST_BILINEAR) && !(o.dst_w & 1) && o.dst_w >= strip_min_w_eff && !c->tune.no_strip && !c->tune.no_mixed) {
         d->fullchr_on = 3; d->fullchr_kind = p.dstKind;
         p.dstKind = DSTK_RAW32; p.u_plane_dst = 1; p.v_plane_dst = 2;
@@ -676,7 +679,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                                         (p.srcKind == SRCK_PACKED444 && p.src_depth == 8 && c->srcBpc == 8)) && !p.need_alpha && !c->needAlpha &&   // (an alpha component nobody reads is skipped)
                                        !c->tune.no_rgbread_kinds;
             bool rgbread = (!p.wide || !c->tune.no_strip_wide) && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || rgbread_kindN) && p.chrSrcHSub <= 1 && p.chrSrcW == (p.srcW >> p.chrSrcHSub) && !(p.srcW & 3) && p.chrSrcVSub == 0 && (!p.need_alpha || d->fullchr_on == 2 || alpha_planar) &&
-                           (!p.dst_alpha_fill || d->fullchr_on) && !p.no_chroma && !vlines_pending && dst_ok && !c->tune.no_strip && !c->tune.no_rgbsrc && p.dstW >= strip_min_w_eff;
+                           (!p.dst_alpha_fill || d->fullchr_on) && (!p.no_chroma || (isGray(o.dst_format) && !isGray(o.src_format) && !c->tune.no_strip_range)) && !vlines_pending && dst_ok && !c->tune.no_strip && !c->tune.no_rgbsrc && p.dstW >= strip_min_w_eff;
             for (int k = 0; k < 9 && rgbread; k++) rgbread = p.rgb2yuv[k] > -32768 && p.rgb2yuv[k] < 32768;   // (v_dot2_i32_i16 operands)
             d->rgbread_on = false;
             // vertical chroma filters of 17 .. 24 taps (a 4:1 chroma step: packed RGB or 4:2:2 sources into a 4:2:0 picture of half the size): the strip
@@ -690,7 +693,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             const bool gray_src = isGray(o.src_format) && !isGray(o.dst_format) && !c->needAlpha && !isALPHA(o.dst_format) && (src_ok || src_u16) && !c->tune.no_strip_range &&
                                   (((p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010) && !p.wide) ||
                                    ((p.dstKind == DSTK_PLANAR16 || p.dstKind == DSTK_P016) && wide_dst)) && !d->join422 && !d->fullchr_on && !c->tune.no_strip;
-            const bool gray_both = gray_src || (isGray(o.dst_format) && (isGray(o.src_format) || ((src_ok || nv_src || src_u16) && !c->tune.no_strip_range)) && !c->needAlpha && (src_ok || nv_src || src_u16) &&
+            const bool gray_both = gray_src || (isGray(o.dst_format) && (isGray(o.src_format) || ((src_ok || nv_src || src_u16 || rgbread) && !c->tune.no_strip_range)) && !c->needAlpha && (src_ok || nv_src || src_u16 || rgbread) &&
                                    (((p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && !p.wide) || (p.dstKind == DSTK_PLANAR16 && wide_dst)) && !c->tune.no_strip);
             // identity luma filters + scaled chroma (yuv422p -> yuv420p, yuv444p -> yuv420p, the 10-bit -> 8-bit twins ...): the luma plane streams
             // (one tap: a per-sample pass), only the chroma planes need the strip kernel
@@ -712,7 +715,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                                  !c->tune.no_strip && !c->tune.no_mixed;
             const bool fs_ok64 = fs2(c->hLum.size) <= 64 && fs2(c->hChr.size) <= 64 && fs2(c->vLum.size) <= 64 && fs2(c->vChr.size) <= 64 && dst_ok && !rgb_ok && !gray_both &&
                                  !c->tune.no_strip && !c->tune.no_mixed;      // (33 .. 62 taps: the extra-long form, 32 pairs each way on strips of 64 columns)
-            const bool wide_ok = wide_dst && (src_ok || nv_src || src_u16 || rgbread) && !p.range_active && !c->needAlpha && !p.need_alpha && !p.fast_bilinear && !vlines_pending && fs_ok16 &&
+            const bool wide_ok = wide_dst && (src_ok || nv_src || src_u16 || rgbread) && !(p.range_active && c->tune.no_strip_range) && !c->needAlpha && !p.need_alpha && !p.fast_bilinear && !vlines_pending && fs_ok16 &&
                                  !(p.srcKind == SRCK_PLANAR8 && c->srcBpc != 8);
             const bool fullA = !mixedM && unity_ok && !(d->unity_h && d->unity_v && !rgb_ok && !unity_yuv) && !p.fast_bilinear && (!gray_any || gray_both || d->fullchr_on == 2 || alpha_planar || (rgb_ok && rgb_alpha)) && (src_ok || (nv_src && dst_ok) || rgbread || (src_u16 && dst_ok)) &&
                                (dst_ok || rgb_ok) && (!p.wide || wide_ok) && (fs_ok16 || fs_ok32 || fs_ok64) && !c->tune.no_dot2;

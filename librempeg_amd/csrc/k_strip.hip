@@ -145,7 +145,7 @@ int launch_rgbread_strip(const LaunchCtx &L)
         L2.fs.table = table_upload(c, d, st, TAB_FRAMES2, fr.data(), n);
         if (!L2.fs.table) return AVERROR_EXTERNAL_;
     }
-    return launch_strip_planes(L2, 3);
+    return launch_strip_planes(L2, p.no_chroma ? 1 : 3);     // (a gray destination: the luma launch alone)
 }
 
 } // namespace swship

@@ -17,6 +17,23 @@
 
 namespace swsk {
 
+// MPEG <-> JPEG range conversion of the 19-bit lines (lum / chrRange{To,From}Jpeg16_c, swscale.c:211-255): ((int64_t)dst * coeff + offset) >> 18 stored as int, the
+// ToJpeg forms clip to 2^19 - 1.  Wave-uniform parameters; a block of its own behind the horizontal stage (contexts without it pay one scalar branch per step).
+struct StripRangeW { int on; uint32_t coeff; int64_t offset; int clipmax; };
+__device__ __forceinline__ StripRangeW strip_range_wide_of(const SwsDevParams &p, bool chroma)
+{
+    StripRangeW r;
+    r.on = p.range_active;
+    r.coeff = chroma ? p.chrCoeff : p.lumCoeff;
+    r.offset = chroma ? p.chrOffset : p.lumOffset;
+    r.clipmax = p.range_to_jpeg ? (1 << 19) - 1 : 0x7fffffff;
+    return r;
+}
+__device__ __forceinline__ int strip_range_wide(int v, const StripRangeW &r)
+{
+    return min((int)(((int64_t)v * (int64_t)r.coeff + r.offset) >> 18), r.clipmax);
+}
+
 template <bool SRC16, bool CHROMA, int COLS, int NPH, int RD>
 __device__ __forceinline__ void strip_body_wide(const FrameRegs &f, const SwsDevParams &p, const SwsStripGeom &g, int strip, int y0, int y1,
                                                 uint8_t *smem, int wib, int lane)
@@ -29,6 +46,7 @@ __device__ __forceinline__ void strip_body_wide(const FrameRegs &f, const SwsDev
     const int cs = g.colStart[strip], chunks = g.colCount[strip] / SPC;
     const int32_t *hpos = CHROMA ? p.hChrPos : p.hLumPos;
     const int npv = g.npv, sh = p.hshift, hclip = p.hclip;
+    const StripRangeW rng = strip_range_wide_of(p, CHROMA);
     StripLds L;
     L.row_dw = (g.NCmax + SPC) >> 1;                          // one spare chunk per row: the dump slot of idle lanes
     L.S = (uint32_t *)smem + wib * (NCOMP * 2 * L.row_dw);
@@ -201,6 +219,12 @@ __device__ __forceinline__ void strip_body_wide(const FrameRegs &f, const SwsDev
                         for (int k = 0; k < NPH; k++) { a = sdot2(s0[k], ht[c][k], a); b = sdot2(s1[k], ht[c][k], b); }
                         na[ci][c] = min(a >> sh, hclip); nb[ci][c] = min(b >> sh, hclip);      // FFMIN(val >> sh, (1 << 19) - 1)
                     }
+            }
+            if (rng.on) {
+#pragma unroll
+                for (int ci = 0; ci < NCOMP; ci++)
+#pragma unroll
+                    for (int c = 0; c < COLS; c++) { na[ci][c] = strip_range_wide(na[ci][c], rng); nb[ci][c] = strip_range_wide(nb[ci][c], rng); }
             }
 #pragma unroll
             for (int ci = 0; ci < NCOMP; ci++)

@@ -121,3 +121,22 @@ def test_gray_sources_into_yuv():
     run_case(640, 48, "gray8", 320, 24, "yuv420p", SWS_BICUBIC | BX, seed=3, opts=opts, tune=T0)
     run_case(1920, 1080, "gray8", 1280, 720, "nv12", SWS_BICUBIC | BX, seed=4)
     run_case(1920, 1080, "gray16le", 960, 540, "yuv420p10le", SWS_BILINEAR | BX, seed=5, device_frames=False)
+
+
+def test_rgb_sources_into_gray_and_ranges_with_19_bit_lines():
+    """RGB -> gray (frames for analysis: the reader pre-pass's luma plane under the luma launch alone; gray is full range, RGB's lines limited: ToJpeg) and
+    the 19-bit range conversion (lum / chrRangeToJpeg16_c ...: 64-bit arithmetic) in sws_k_strip_wide: YUV -> gray16, gray -> 16-bit YUV, yuvj -> 16-bit YUV"""
+    for sfmt in ("rgb24", "bgra", "gbrp", "rgb565le", "x2rgb10le", "rgb48le"):
+        for dfmt in ("gray8", "gray10le", "gray16le"):
+            for (sw, sh, dw, dh, fl) in ((644, 40, 516, 32, SWS_BICUBIC), (640, 48, 320, 24, SWS_BILINEAR), (640, 32, 640, 32, SWS_BICUBIC), (320, 24, 644, 48, SWS_BICUBIC)):
+                path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=dw + len(sfmt), tune=T0)
+                if (sw, dw) == (644, 516):
+                    assert "rgbread" in path, (sfmt, dfmt, path)
+    for sfmt, dfmt in (("yuv420p", "gray16le"), ("nv12", "gray16le"), ("yuv420p10le", "gray16le"), ("gray8", "yuv420p16le"), ("gray16le", "p016le"), ("yuvj420p", "yuv420p16le"),
+                       ("yuv420p", "yuv444p16le"), ("yuvj444p", "gbrpf32le"), ("rgb24", "yuv420p16le")):
+        for (sr, dr) in ((None, None), (0, 1), (1, 0)):
+            opts = None if sr is None else dict(dither=1, src_range=sr, dst_range=dr, src_h_chr_pos=-513, src_v_chr_pos=-513, dst_h_chr_pos=-513, dst_v_chr_pos=-513, threads=1)
+            for (sw, sh, dw, dh, fl) in ((644, 70, 324, 35, SWS_BILINEAR), (400, 66, 332, 54, SWS_BICUBIC), (320, 40, 640, 80, SWS_BICUBIC)):
+                path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=sw + len(dfmt), tune=T0, opts=opts)
+                if sw == 400:
+                    assert "strip" in path, (sfmt, dfmt, sr, path)

@@ -81,3 +81,15 @@ def test_full_size_frames():
     assert "rgbread" in run_case(1920, 1080, "rgb48le", 1280, 720, "yuv420p", SWS_BICUBIC | BX, seed=4)[0]
     assert "rgbread" in run_case(1920, 1080, "gbrpf32le", 1280, 720, "yuv420p", SWS_BICUBIC | BX, seed=5)[0]
     assert "strip" in run_case(1920, 1080, "gray16le", 960, 540, "gray8", SWS_BICUBIC | BX, seed=6)[0]
+
+
+def test_16_bit_sources_into_packed_rgb():
+    """yuv4xxp16 / p016 into 24 / 32 bpp RGB through the LUT writers (strip kernels' sums + sws_k_lut_rgb) and, with full chroma, sws_k_fullchr_rgb; rgb48 into
+    bgra / rgb24 (RGB -> RGB: forced full chroma)"""
+    for sfmt in ("yuv420p16le", "yuv422p16le", "p016le", "yuv444p16le", "rgb48le", "gbrp16le"):
+        for dfmt in ("rgb24", "bgra", "bgr24", "argb", "gbrp"):
+            for (sw, sh, dw, dh, fl) in ((644, 70, 324, 36, SWS_BILINEAR), (400, 66, 332, 54, SWS_BICUBIC), (320, 40, 640, 80, SWS_BICUBIC), (640, 48, 640, 48, SWS_BICUBIC)):
+                path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=sw + len(dfmt), tune=T0)
+                if (sw, dw) == (400, 332) and sfmt != "gbrp16le":
+                    assert "strip" in path, (sfmt, dfmt, path)
+    assert run_case(3840, 2160, "p016le", 1920, 1080, "bgra", SWS_BICUBIC | BX, seed=9)[0].endswith("+lut_rgb")
