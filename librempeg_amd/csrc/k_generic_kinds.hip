@@ -5,6 +5,7 @@
 // Same routines as the all-kinds forms in k_generic.hip (kernels_generic.hpp), with `p.srcKind` / `p.dstKind` compile-time constants (KindView): a
 // pair's single-pass kernel is 1 500 - 3 000 instructions in 30 - 110 registers instead of 24 000 in 256 + 256 with spills, i.e. 4 - 8 waves per SIMD
 // instead of one, and the tap loops around a reader of a few instructions are unrolled with their loads in flight together.
+#include <type_traits>
 #include "generic_kinds.hpp"
 #include "kernels_generic.hpp"
 #include "kernels_tile.hpp"
@@ -52,6 +53,89 @@ __global__ void __launch_bounds__(256) sws_k_read16_kind(SwsFrameSet fs, SwsDevP
             *(uint4 *)(dy + x0) = oy.q;
             if (x0 + 8 <= p.chrSrcW) { *(uint4 *)(du + x0) = ou.q; *(uint4 *)(dv + x0) = ov.q; }
             else for (int k = 0; k < 8; k++) if (x0 + k < p.chrSrcW) { du[x0 + k] = ou.h[k]; dv[x0 + k] = ov.h[k]; }
+            return;
+        }
+    }
+    if constexpr (SK == SRCK_GBRPF32) {
+        // planar float RGB (round 5: gbrpf32 sources reach the strip kernels): eight pixels per thread, two 16-byte loads per plane, read_sample's own arithmetic on the
+        // loaded floats as a one-row picture in registers (planar_rgbf32_to_y / _uv: no half-width form, chroma column x is pixel x)
+        const uint8_t *pg = f.src[0] + (int64_t)row * f.srcStride[0], *pb = f.src[1] + (int64_t)row * f.srcStride[1], *pr = f.src[2] + (int64_t)row * f.srcStride[2];
+        if (!(p.srcW & 7) && p.chrSrcW == p.srcW && p.chrSrcVSub == 0 && !(((uintptr_t)pg | (uintptr_t)pb | (uintptr_t)pr) & 15)) {   // (wave-uniform)
+            const int x0 = 8 * x;
+            if (x0 >= p.srcW) return;
+            union F8 { uint4 q[2]; float v[8]; };
+            union V8 { uint4 q; uint16_t h[8]; };
+            F8 g, bb, r; V8 oy, ou, ov;
+            g.q[0] = *(const uint4 *)(pg + 4 * x0); g.q[1] = *(const uint4 *)(pg + 4 * x0 + 16);
+            bb.q[0] = *(const uint4 *)(pb + 4 * x0); bb.q[1] = *(const uint4 *)(pb + 4 * x0 + 16);
+            r.q[0] = *(const uint4 *)(pr + 4 * x0); r.q[1] = *(const uint4 *)(pr + 4 * x0 + 16);
+            SwsFramePtrs fl = f;
+            fl.src[0] = (const uint8_t *)g.v; fl.src[1] = (const uint8_t *)bb.v; fl.src[2] = (const uint8_t *)r.v;
+            fl.srcStride[0] = fl.srcStride[1] = fl.srcStride[2] = 0;
+            const auto &q = chr_half_view<0>(p);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                oy.h[k] = (uint16_t)read_sample(q, fl, 0, 0, k); ou.h[k] = (uint16_t)read_sample(q, fl, 1, 0, k); ov.h[k] = (uint16_t)read_sample(q, fl, 2, 0, k);
+            }
+            *(uint4 *)(dy + x0) = oy.q; *(uint4 *)(du + x0) = ou.q; *(uint4 *)(dv + x0) = ov.q;
+            return;
+        }
+    }
+    if constexpr (SK == SRCK_RGB48) {
+        // rgb48 / bgr48 / rgba64 / bgra64 (round 5): eight pixels per thread, three or four 16-byte loads; rgb48ToY / UV(_half)_c_template and the 64-bit twins
+        // (input.c:45-203) written over the pixel's WORDS -- the component order is a coefficient permutation (word j of a pixel times the coefficient of whichever of
+        // r, g, b sits there; the alpha word times 0), so nothing is indexed at run time; 16-bit word x 15-bit coefficient as v_mad_i32_i24, whose low 32 bits are the
+        // reference's unsigned wrap-around product
+        const uint8_t *ps = f.src[0] + (int64_t)row * f.srcStride[0];
+        const int st = U(p.s16_step);
+        if (!(p.srcW & 7) && p.chrSrcVSub == 0 && p.vline_mode == 0 && !((uintptr_t)ps & 15) && (p.chrSrcW == p.srcW || (p.chr_half && p.chrSrcW == (p.srcW >> 1)))) {   // (wave-uniform)
+            const int x0 = 8 * x;
+            if (x0 >= p.srcW) return;
+            const int rp = U(p.s16_r), gp = U(p.s16_g), bp = U(p.s16_b);
+            const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);
+            auto coef = [&](const Rgb2YuvRow &w, int j) { return j == rp ? w.r : j == gp ? w.g : j == bp ? w.b : 0; };
+            const int cy[4] = { coef(ty, 0), coef(ty, 1), coef(ty, 2), coef(ty, 3) }, cu[4] = { coef(tu, 0), coef(tu, 1), coef(tu, 2), coef(tu, 3) },
+                      cv[4] = { coef(tv, 0), coef(tv, 1), coef(tv, 2), coef(tv, 3) };
+            union V8 { uint4 q; uint16_t h[8]; };
+            V8 oy, ou, ov;
+            auto run = [&](auto ST_) {
+                constexpr int ST = decltype(ST_)::value;          // words per pixel: 3 or 4
+                union W { uint4 q[ST]; uint16_t h[8 * ST]; };
+                W w;
+#pragma unroll
+                for (int j = 0; j < ST; j++) w.q[j] = *(const uint4 *)(ps + 2 * ST * x0 + 16 * j);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    int sy = (int)(0x2001u << 14);
+#pragma unroll
+                    for (int j = 0; j < ST; j++) sy = mad24((int)w.h[ST * k + j], cy[j], sy);
+                    oy.h[k] = (uint16_t)((unsigned)sy >> 15);
+                }
+                if (p.chr_half) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        int su = (int)(0x10001u << 14), sv = su;
+#pragma unroll
+                        for (int j = 0; j < ST; j++) {
+                            const int a = (int)(((unsigned)w.h[ST * 2 * k + j] + (unsigned)w.h[ST * (2 * k + 1) + j] + 1u) >> 1);
+                            su = mad24(a, cu[j], su); sv = mad24(a, cv[j], sv);
+                        }
+                        ou.h[k] = (uint16_t)((unsigned)su >> 15); ov.h[k] = (uint16_t)((unsigned)sv >> 15);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        int su = (int)(0x10001u << 14), sv = su;
+#pragma unroll
+                        for (int j = 0; j < ST; j++) { su = mad24((int)w.h[ST * k + j], cu[j], su); sv = mad24((int)w.h[ST * k + j], cv[j], sv); }
+                        ou.h[k] = (uint16_t)((unsigned)su >> 15); ov.h[k] = (uint16_t)((unsigned)sv >> 15);
+                    }
+                }
+            };
+            if (st == 3) run(std::integral_constant<int, 3>{}); else run(std::integral_constant<int, 4>{});
+            *(uint4 *)(dy + x0) = oy.q;
+            if (p.chr_half) { *(uint2 *)(du + (x0 >> 1)) = make_uint2(ou.q.x, ou.q.y); *(uint2 *)(dv + (x0 >> 1)) = make_uint2(ov.q.x, ov.q.y); }
+            else { *(uint4 *)(du + x0) = ou.q; *(uint4 *)(dv + x0) = ov.q; }
             return;
         }
     }

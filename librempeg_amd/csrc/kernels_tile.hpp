@@ -68,7 +68,6 @@ __global__ void __launch_bounds__(256) sws_k_tile_planar(SwsFrameSet fs, SwsDevP
                 for (int u = 0; u < 4; u++) if (i0 + 256 * u < tot) S[o[u]] = (uint16_t)v[u];
             }
         };
-        typedef typename std::remove_cv<typename std::remove_reference<decltype(p)>::type>::type PT;
         if (p.chr_half) stage(chr_half_view<1>(p)); else stage(chr_half_view<0>(p));
         __syncthreads();
         // phase 2: horizontal stage; thread = one output column, marching down the window rows

@@ -6,7 +6,7 @@ OUT=$PWD/gpurun_out/r05p; mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$PWD
 tools/profile_all.sh r05p > $OUT/bench_lines.jsonl 2>$OUT/profile_all.err
-tools/pmc_traffic.sh r05p "c2a c2b c4 c3a c3b c5 c1 d1" > $OUT/pmc_traffic.txt 2>&1
+tools/pmc_traffic.sh r05p "c2a c2b c4 c3a c3b c5 c1 d1 r1 w1" > $OUT/pmc_traffic.txt 2>&1
 python tools/layout_times.py > $OUT/layout.md 2>$OUT/layout.err
 python tools/common_shapes_times.py > $OUT/common.md 2>$OUT/common.err
 python tools/rgb2rgb_times.py > $OUT/rgb2rgb.md 2>$OUT/rgb2rgb.err
