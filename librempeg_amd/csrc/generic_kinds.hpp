@@ -5,7 +5,8 @@
 namespace swship {
 
 // where the reader pre-pass of a scaled source puts its 16-bit Y / U / V lines (k_strip.hip launch_rgbread_strip: one working picture per frame)
-struct Read16Layout { uint8_t *base; int64_t frame_bytes, offU, offV; int32_t strideY, strideC; };
+struct Read16Layout { uint8_t *base; int64_t frame_bytes, offU, offV; int32_t strideY, strideC;
+                      int32_t vec; };   // vec: pixels per thread of the kind's vector form (8 / 4; the host checked widths and alignment and sized the grid for it), 0: one chroma column per thread
 
 // the kernels of ONE source kind
 struct GenericKindFns {

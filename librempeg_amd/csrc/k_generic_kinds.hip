@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256) sws_k_read16_kind(SwsFrameSet fs, SwsDevP
         // planar RGB of 9 - 14 bits: eight pixels per thread, one 16-byte load per plane.  The arithmetic stays read_sample's: the loaded words are presented to it
         // as a one-row picture in registers.  (planar_rgb16_s16_to_uv has no half-width form: chroma column x is pixel x, input.c:1249-1270.)
         const uint8_t *pg = f.src[0] + (int64_t)row * f.srcStride[0], *pb = f.src[1] + (int64_t)row * f.srcStride[1], *pr = f.src[2] + (int64_t)row * f.srcStride[2];
-        if (!(p.srcW & 7) && !(((uintptr_t)pg | (uintptr_t)pb | (uintptr_t)pr) & 15)) {   // (wave-uniform)
+        if (lay.vec) {   // (the host checked the width and the alignment of every frame of the call and sized the grid: k_stream.hip launch_rgb_read16)
             const int x0 = 8 * x;
             if (x0 >= p.srcW) return;
             union V8 { uint4 q; uint16_t h[8]; };
@@ -57,27 +57,27 @@ __global__ void __launch_bounds__(256) sws_k_read16_kind(SwsFrameSet fs, SwsDevP
         }
     }
     if constexpr (SK == SRCK_GBRPF32) {
-        // planar float RGB (round 5: gbrpf32 sources reach the strip kernels): eight pixels per thread, two 16-byte loads per plane, read_sample's own arithmetic on the
-        // loaded floats as a one-row picture in registers (planar_rgbf32_to_y / _uv: no half-width form, chroma column x is pixel x)
+        // planar float RGB (round 5: gbrpf32 sources reach the strip kernels): four pixels per thread, one 16-byte load per plane (neighbouring lanes read
+        // neighbouring chunks), planar_rgbf32_to_y / _uv (input.c:1300-1334) written out -- lrintf(av_clipf(65535 x, 0, 65535)) per component, then the 15-bit matrix as
+        // v_mad_i32_i24 (a 16-bit sample times a 15-bit coefficient: the low 32 bits are the reference's wrap-around sum) and the arithmetic shift; no half-width form
         const uint8_t *pg = f.src[0] + (int64_t)row * f.srcStride[0], *pb = f.src[1] + (int64_t)row * f.srcStride[1], *pr = f.src[2] + (int64_t)row * f.srcStride[2];
-        if (!(p.srcW & 7) && p.chrSrcW == p.srcW && p.chrSrcVSub == 0 && !(((uintptr_t)pg | (uintptr_t)pb | (uintptr_t)pr) & 15)) {   // (wave-uniform)
-            const int x0 = 8 * x;
+        if (lay.vec) {   // (host-checked, see above)
+            const int x0 = 4 * x;
             if (x0 >= p.srcW) return;
-            union F8 { uint4 q[2]; float v[8]; };
-            union V8 { uint4 q; uint16_t h[8]; };
-            F8 g, bb, r; V8 oy, ou, ov;
-            g.q[0] = *(const uint4 *)(pg + 4 * x0); g.q[1] = *(const uint4 *)(pg + 4 * x0 + 16);
-            bb.q[0] = *(const uint4 *)(pb + 4 * x0); bb.q[1] = *(const uint4 *)(pb + 4 * x0 + 16);
-            r.q[0] = *(const uint4 *)(pr + 4 * x0); r.q[1] = *(const uint4 *)(pr + 4 * x0 + 16);
-            SwsFramePtrs fl = f;
-            fl.src[0] = (const uint8_t *)g.v; fl.src[1] = (const uint8_t *)bb.v; fl.src[2] = (const uint8_t *)r.v;
-            fl.srcStride[0] = fl.srcStride[1] = fl.srcStride[2] = 0;
-            const auto &q = chr_half_view<0>(p);
+            const float4 g = *(const float4 *)(pg + 4 * x0), bb = *(const float4 *)(pb + 4 * x0), r = *(const float4 *)(pr + 4 * x0);
+            const float gv[4] = { g.x, g.y, g.z, g.w }, bv[4] = { bb.x, bb.y, bb.z, bb.w }, rv[4] = { r.x, r.y, r.z, r.w };
+            const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);
+            uint32_t oy[4], ou[4], ov[4];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                oy.h[k] = (uint16_t)read_sample(q, fl, 0, 0, k); ou.h[k] = (uint16_t)read_sample(q, fl, 1, 0, k); ov.h[k] = (uint16_t)read_sample(q, fl, 2, 0, k);
+            for (int k = 0; k < 4; k++) {
+                const int R = f32_to_u16(rv[k]), G = f32_to_u16(gv[k]), B = f32_to_u16(bv[k]);
+                oy[k] = (uint32_t)(uint16_t)(mad24(R, ty.r, mad24(G, ty.g, mad24(B, ty.b, (int)(0x2001u << 14)))) >> 15);
+                ou[k] = (uint32_t)(uint16_t)(mad24(R, tu.r, mad24(G, tu.g, mad24(B, tu.b, (int)(0x10001u << 14)))) >> 15);
+                ov[k] = (uint32_t)(uint16_t)(mad24(R, tv.r, mad24(G, tv.g, mad24(B, tv.b, (int)(0x10001u << 14)))) >> 15);
             }
-            *(uint4 *)(dy + x0) = oy.q; *(uint4 *)(du + x0) = ou.q; *(uint4 *)(dv + x0) = ov.q;
+            *(uint2 *)(dy + x0) = make_uint2(oy[0] | oy[1] << 16, oy[2] | oy[3] << 16);
+            *(uint2 *)(du + x0) = make_uint2(ou[0] | ou[1] << 16, ou[2] | ou[3] << 16);
+            *(uint2 *)(dv + x0) = make_uint2(ov[0] | ov[1] << 16, ov[2] | ov[3] << 16);
             return;
         }
     }
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) sws_k_read16_kind(SwsFrameSet fs, SwsDevP
         // reference's unsigned wrap-around product
         const uint8_t *ps = f.src[0] + (int64_t)row * f.srcStride[0];
         const int st = U(p.s16_step);
-        if (!(p.srcW & 7) && p.chrSrcVSub == 0 && p.vline_mode == 0 && !((uintptr_t)ps & 15) && (p.chrSrcW == p.srcW || (p.chr_half && p.chrSrcW == (p.srcW >> 1)))) {   // (wave-uniform)
+        if (lay.vec) {   // (host-checked, see above)
             const int x0 = 8 * x;
             if (x0 >= p.srcW) return;
             const int rp = U(p.s16_r), gp = U(p.s16_g), bp = U(p.s16_b);

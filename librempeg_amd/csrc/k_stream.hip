@@ -79,7 +79,14 @@ int launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, in
         if (!ks || !ks->read16) { log_msg(L.c, 0, "internal error: no reader pre-pass kernel for source kind %d\n", p.srcKind); return SWS_AVERROR(EINVAL); }
         Read16Layout l16;
         l16.base = base; l16.frame_bytes = frame_bytes; l16.offU = offU; l16.offV = offV; l16.strideY = strideY; l16.strideC = strideC;
-        const dim3 grid(cdiv(p.chrSrcW, 256), p.srcH, L.n), blk(256);
+        // the vector forms of k_generic_kinds.hip (16-byte loads from 16-byte aligned rows): planar RGB of 9 - 16 bits and rgb48 / rgba64 eight pixels per thread, gbrpf32 four
+        l16.vec = 0;
+        if (L.vec && p.chrSrcVSub == 0 && p.vline_mode == 0) {
+            if (p.srcKind == SRCK_GBRP16 && !(p.srcW & 7) && p.chrSrcW == p.srcW) l16.vec = 8;
+            else if (p.srcKind == SRCK_RGB48 && !(p.srcW & 7) && (p.chrSrcW == p.srcW || (p.chr_half && p.chrSrcW == (p.srcW >> 1)))) l16.vec = 8;
+            else if (p.srcKind == SRCK_GBRPF32 && !(p.srcW & 3) && p.chrSrcW == p.srcW) l16.vec = 4;
+        }
+        const dim3 grid(cdiv(l16.vec ? p.srcW / l16.vec : p.chrSrcW, 256), p.srcH, L.n), blk(256);
         hipLaunchKernelGGL(ks->read16, grid, blk, 0, L.st, L.fs, p, l16);
         return 0;
     }
