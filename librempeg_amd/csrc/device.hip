@@ -25,6 +25,14 @@ void launch_alpha_merge32(const LaunchCtx &L);                 // k_stream.hip: 
 void launch_gray_chroma(const LaunchCtx &L);                   // k_stream.hip: the chroma planes of a gray source in a YUV destination
 void launch_layout_join422(const LaunchCtx &L, bool uyvy);   // k_layout.hip: planar 4:2:2 working picture -> yuyv422 / uyvy422 (yvyu422: planes swapped by the planner)
 
+// the plan geometries of a fresh state start out as zeros (`new DeviceState()` runs the default member initialisers and leaves members without one as the
+// heap had them: a field a planner path does not set -- band counts, the byte-row form's flags -- would otherwise differ from process to process)
+static void zero_geoms(DeviceState *d)
+{
+    for (SwsTileGeom *g : { &d->tileL, &d->tileC, &d->dotL, &d->dotC }) std::memset(g, 0, sizeof(*g));
+    for (SwsStripGeom *g : { &d->stripL, &d->stripC, &d->stripLs, &d->stripCs, &d->stripRL, &d->stripRC, &d->stripL2, &d->stripC2 }) std::memset(g, 0, sizeof(*g));
+}
+
 static int ensure_dev(SwsInternal *c)
 {
     if (c->dev) return 0;
@@ -36,6 +44,7 @@ static int ensure_dev(SwsInternal *c)
     }
     DeviceState *d = new DeviceState();
     std::memset(&d->params, 0, sizeof(d->params));
+    zero_geoms(d);
     if (hipGetDevice(&d->device) != hipSuccess) d->device = 0;
     c->dev = d;
     return 0;
@@ -51,6 +60,7 @@ static DeviceState *dev_state_for(SwsInternal *c, int device)
     if (!c->peers[(size_t)device]) {
         DeviceState *d = new DeviceState();
         std::memset(&d->params, 0, sizeof(d->params));
+        zero_geoms(d);
         d->device = device;
         d->timing = false;
         c->peers[(size_t)device] = d;
@@ -243,6 +253,35 @@ static int table_alloc(SwsInternal *c, void **buf, size_t *cap, size_t need)
         *cap = need + slack;
     }
     return poison(c, *buf, *cap);
+}
+
+// Uploads of the per-context device tables go out on the CONTEXT'S OWN STREAM and are waited for there (round 5): the kernels that read them are launched on that
+// stream, so table and reader share one queue whatever the other queues of the process -- or of the other processes on the GPU -- are doing.  (Rounds 1 - 4 used
+// the blocking hipMemcpy of the null stream for most of them.  Two of the rare parity events of section 8 were contexts whose results were wrong for their whole
+// lifetime while a fresh context was right, on paths that read such tables; nothing proves the copy was at fault, this just removes the cross-queue step.)
+// SWS_HIP_DEBUG & 32: every upload is read back and compared -- a mismatch fails the call loudly instead of giving wrong pixels.
+static bool verify_uploads()
+{
+    static const bool on = std::getenv("SWS_HIP_DEBUG") && (std::atoi(std::getenv("SWS_HIP_DEBUG")) & 32);
+    return on;
+}
+static int table_put(SwsInternal *c, DeviceState *d, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return 0;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    if (verify_uploads()) {
+        std::vector<uint8_t> back(bytes);
+        HIPCHK(hipMemcpyAsync(back.data(), dst, bytes, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        if (std::memcmp(back.data(), src, bytes)) {
+            size_t bad = 0, first = bytes;
+            for (size_t i = 0; i < bytes; i++) if (back[i] != ((const uint8_t *)src)[i]) { if (first == bytes) first = i; bad++; }
+            log_msg(c, 0, "table upload verification FAILED: %zu of %zu bytes differ at %p (first at +%zu)\n", bad, bytes, dst, first);
+            return AVERROR_EXTERNAL_;
+        }
+    }
+    return 0;
 }
 
 static int dev_prepare_on(SwsInternal *c, DeviceState *d)
@@ -538,8 +577,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             std::memcpy(host.data() + offs_t[i], banks[i]->taps.data(), banks[i]->taps.size() * sizeof(int16_t));
             std::memcpy(host.data() + offs_p[i], banks[i]->pos.data(), banks[i]->pos.size() * sizeof(int32_t));
         }
-        HIPCHK(hipMemcpyAsync(d->d_tables, host.data(), off, hipMemcpyHostToDevice, d->stream));
-        HIPCHK(hipStreamSynchronize(d->stream)); // host vector goes out of scope
+        { int r_ = table_put(c, d, d->d_tables, host.data(), off); if (r_ < 0) return r_; }
         uint8_t *b = (uint8_t *)d->d_tables;
         p.hLumF = (const int16_t *)(b + offs_t[0]); p.hLumPos = (const int32_t *)(b + offs_p[0]); p.hLumFs = c->hLum.size;
         p.hChrF = (const int16_t *)(b + offs_t[1]); p.hChrPos = (const int32_t *)(b + offs_p[1]); p.hChrFs = c->hChr.size;
@@ -564,7 +602,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 const size_t o_cp = hostv.size(); hostv.insert(hostv.end(), vlx.chrPos.begin(), vlx.chrPos.end());
                 const size_t bytes = hostv.size() * sizeof(int32_t);
                 { int r_ = table_alloc(c, &d->d_vlines, &d->vlines_bytes, bytes); if (r_ < 0) return r_; }
-                HIPCHK(hipMemcpy(d->d_vlines, hostv.data(), bytes, hipMemcpyHostToDevice));
+                { int r_ = table_put(c, d, d->d_vlines, hostv.data(), bytes); if (r_ < 0) return r_; }
                 const int32_t *bv = (const int32_t *)d->d_vlines;
                 p.vlines = bv; p.nVL = (int32_t)nL; p.vline_mode = mode;
                 p.vLumPos = bv + o_lp; p.vChrPos = bv + o_cp;
@@ -617,8 +655,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 const size_t bytes1 = (rows.size() * sizeof(SwsRgbSrcRow) + 63) & ~(size_t)63;
                 const size_t bytes = bytes1 + rows2.size() * sizeof(SwsStripRow);
                 { int r_ = table_alloc(c, &d->d_dot2, &d->dot2_bytes, bytes); if (r_ < 0) return r_; }
-                HIPCHK(hipMemcpy(d->d_dot2, rows.data(), rows.size() * sizeof(SwsRgbSrcRow), hipMemcpyHostToDevice));
-                if (!rows2.empty()) HIPCHK(hipMemcpy((uint8_t *)d->d_dot2 + bytes1, rows2.data(), rows2.size() * sizeof(SwsStripRow), hipMemcpyHostToDevice));
+                { int r_ = table_put(c, d, d->d_dot2, rows.data(), rows.size() * sizeof(SwsRgbSrcRow)); if (r_ < 0) return r_; }
+                if (!rows2.empty()) { int r_ = table_put(c, d, (uint8_t *)d->d_dot2 + bytes1, rows2.data(), rows2.size() * sizeof(SwsStripRow)); if (r_ < 0) return r_; }
                 d->rgbsrc_rows = (const SwsRgbSrcRow *)d->d_dot2;
                 d->rgbsrc2_rows = rows2.empty() ? nullptr : (const SwsStripRow *)((const uint8_t *)d->d_dot2 + bytes1);
                 d->rgbsrc2_npv = npv2;
@@ -907,7 +945,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         const size_t ohc = put(htc.data(), htc.size() * 2);
                         const bool altC = plan3_alt(c->hChr, c->vChr, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
                         { int r_ = table_alloc(c, &d->d_dot2, &d->dot2_bytes, blob.size()); if (r_ < 0) return r_; }
-                        HIPCHK(hipMemcpy(d->d_dot2, blob.data(), blob.size(), hipMemcpyHostToDevice));
+                        { int r_ = table_put(c, d, d->d_dot2, blob.data(), blob.size()); if (r_ < 0) return r_; }
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         d->stripC.colStart = (const int32_t *)(b + sM.cs); d->stripC.colCount = (const int32_t *)(b + sM.cc);
                         d->stripC.rows = (const SwsStripRow *)(b + sM.rows);
@@ -956,7 +994,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         dma8_plan(c->hLum, c->vLum, gl, o8l); dma8_plan(c->hChr, c->vChr, gc, o8c);
                         if (!gl.dma8_ok || !gc.dma8_ok) gl.dma8_ok = gc.dma8_ok = 0;
                         { int r_ = table_alloc(c, &d->d_dot2, &d->dot2_bytes, blob.size()); if (r_ < 0) return r_; }
-                        HIPCHK(hipMemcpy(d->d_dot2, blob.data(), blob.size(), hipMemcpyHostToDevice));
+                        { int r_ = table_put(c, d, d->d_dot2, blob.data(), blob.size()); if (r_ < 0) return r_; }
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         gl.colStart = (const int32_t *)(b + rL.cs); gl.colCount = (const int32_t *)(b + rL.cc); gl.rows = (const SwsStripRow *)(b + rL.rows);
                         gc.colStart = (const int32_t *)(b + rC.cs); gc.colCount = (const int32_t *)(b + rC.cc); gc.rows = (const SwsStripRow *)(b + rC.rows);
@@ -1051,7 +1089,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                   }
                   if (tiles || strip_plan) {
                     { int r_ = table_alloc(c, &d->d_dot2, &d->dot2_bytes, blob.size()); if (r_ < 0) return r_; }
-                    HIPCHK(hipMemcpy(d->d_dot2, blob.data(), blob.size(), hipMemcpyHostToDevice));
+                    { int r_ = table_put(c, d, d->d_dot2, blob.data(), blob.size()); if (r_ < 0) return r_; }
                     auto bind = [&](SwsTileGeom &g, const Off &o) {
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         g.rowStart = (const int32_t *)(b + o.rs); g.rowCount = (const int32_t *)(b + o.rc);
@@ -1154,7 +1192,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 const size_t bytes = (aL.size() + aC.size()) * sizeof(int32_t);
                 { int r_ = table_alloc(c, &d->d_tilegeom, &d->tilegeom_bytes, bytes); if (r_ < 0) return r_; }
                 std::vector<int32_t> all(aL); all.insert(all.end(), aC.begin(), aC.end());
-                HIPCHK(hipMemcpy(d->d_tilegeom, all.data(), bytes, hipMemcpyHostToDevice));
+                { int r_ = table_put(c, d, d->d_tilegeom, all.data(), bytes); if (r_ < 0) return r_; }
                 const int32_t *bL = (const int32_t *)d->d_tilegeom, *bC = bL + aL.size();
                 auto bind = [](SwsTileGeom &g, const int32_t *b) {
                     g.rowStart = b; g.rowCount = b + g.tilesY; g.colStart = b + 2 * g.tilesY; g.colCount = b + 2 * g.tilesY + g.tilesX;
@@ -1239,7 +1277,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 if (ok) {
                     const size_t bytes = plan.size() * sizeof(SwsRgbGroupPlan);
                     { int r_ = table_alloc(c, &d->d_rgbplan, &d->rgbplan_bytes, bytes); if (r_ < 0) return r_; }
-                    HIPCHK(hipMemcpy(d->d_rgbplan, plan.data(), bytes, hipMemcpyHostToDevice));
+                    { int r_ = table_put(c, d, d->d_rgbplan, plan.data(), bytes); if (r_ < 0) return r_; }
                     d->rgb_groups = groups;
                     d->rgb_march_ok = true;
                 }
