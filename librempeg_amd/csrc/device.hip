@@ -736,7 +736,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // identity luma filters + scaled chroma (yuv422p -> yuv420p, yuv444p -> yuv420p, the 10-bit -> 8-bit twins ...): the luma plane streams
             // (one tap: a per-sample pass), only the chroma planes need the strip kernel
             const bool mixedM = !vlines_pending && !d->fullchr_on && bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !(d->unity_h && d->unity_v) &&
-                                !p.fast_bilinear && !gray_any && (src_ok || nv_src) && dst_ok && !p.wide && !p.range_active && !p.dst_alpha_fill &&
+                                !p.fast_bilinear && !gray_any && (src_ok || nv_src) && dst_ok && !p.wide && (!p.range_active || (c->srcBpc == 8 && p.dst_bits == 8 && !c->tune.no_strip_range)) && !p.dst_alpha_fill &&
                                 fs2(c->hChr.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long) && !c->tune.no_strip && !c->tune.no_mixed && p.dstW >= c->tune.strip_min_w;
             // (identity horizontal filters: 8-bit sources have kernels of their own -- sws_k_rgb_march, sws_k_rgbsrc_unity, the mixed plan -- but a 10-bit
             //  picture into packed RGB (decoded HDR for display) or packed RGB into a 10-bit 4:2:0 picture at the same size had only the generic

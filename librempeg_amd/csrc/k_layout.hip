@@ -172,7 +172,10 @@ int launch_layout_plane1(const LaunchCtx &L)
     plan.njobs = 1;
     j.rows = p.dstH; j.ys = 0; j.yd = 0; j.sa = j.sb = j.da = j.db = 0;
     const bool s8 = c->srcBpc == 8, d8 = p.dst_bits == 8;
-    if (s8 && d8) { j.op = LOP_COPY; j.n = p.srcW; }
+    if (s8 && d8 && p.range_active) {   // (dev_prepare_on admits a range conversion into the mixed plan for 8-bit planes only)
+        j.op = LOP_P1_8TO8R; j.n = p.srcW; j.a0 = (int)(128u * (uint32_t)(uint16_t)p.lumCoeff); j.a1 = (int32_t)p.lumOffset; j.a2 = p.range_to_jpeg ? 32767 : 0x7fffffff;
+    }
+    else if (s8 && d8) { j.op = LOP_COPY; j.n = p.srcW; }
     else if (s8) { j.op = LOP_8TO16; j.n = p.srcW; j.a0 = p.dst_bits - 8; j.a1 = 32; j.a2 = p.dst_shift; }
     else { j.op = d8 ? LOP_P1_16TO8 : LOP_P1_16TO16; j.n = 2 * p.srcW; j.a0 = p.src_shift; j.a1 = p.hshift; j.a2 = p.dst_bits; j.a3 = p.dst_shift; j.a4 = p.should_dither ? 0 : 1; }
     const int unit = j.op == LOP_8TO16 ? 8 : 16;

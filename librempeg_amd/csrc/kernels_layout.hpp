@@ -35,7 +35,7 @@ __device__ __forceinline__ pk16 pk_min(pk16 a, pk16 b) { return __builtin_elemen
 __device__ __forceinline__ pk16 pk_bytes_lo(uint32_t w) { return pk_of(__builtin_amdgcn_perm(0, w, 0x0c010c00u)); }
 __device__ __forceinline__ pk16 pk_bytes_hi(uint32_t w) { return pk_of(__builtin_amdgcn_perm(0, w, 0x0c030c02u)); }
 
-enum { LOP_COPY = 0, LOP_FILL, LOP_IL, LOP_DIL, LOP_8TO16, LOP_16TO8, LOP_16TO16, LOP_P422_SPLIT, LOP_P422_SPLIT420, LOP_P422_JOIN, LOP_P1_16TO8, LOP_P1_16TO16, LOP_DIL16 };
+enum { LOP_COPY = 0, LOP_FILL, LOP_IL, LOP_DIL, LOP_8TO16, LOP_16TO8, LOP_16TO16, LOP_P422_SPLIT, LOP_P422_SPLIT420, LOP_P422_JOIN, LOP_P1_16TO8, LOP_P1_16TO16, LOP_DIL16, LOP_P1_8TO8R };
 
 // one class of rows: `rows` rows starting at source row ys / destination row yd of the planes named below
 struct LayoutJob {
@@ -236,6 +236,33 @@ __global__ void __launch_bounds__(256) sws_k_layout_stream(SwsFrameSet fs, SwsDe
                     const u32x4 o = { (e[0] & 0xFFFF) | (e[1] << 16), (e[2] & 0xFFFF) | (e[3] << 16), (e[4] & 0xFFFF) | (e[5] << 16), (e[6] & 0xFFFF) | (e[7] << 16) };
                     lstore16(dbaseA + (r + i) * dsA + off, o, n - off);
                 }
+            }
+        }
+        break;
+    }
+    case LOP_P1_8TO8R: {   // (round 5) the scaler chain with identity filters and a RANGE CONVERSION on an 8-bit plane into an 8-bit plane: hScale8To15_c with the single tap
+        // 1 << 14 (s * 128), lumRange{To,From}Jpeg_c ((v * coeff + offset) >> 14, the ToJpeg clip: swscale.c:163-209), yuv2plane1_8_c with the constant dither 64 of 8-bit
+        // sources ((v + 64) >> 7, clipped).  a0 = 128 * coeff (23 bits), a1 = offset, a2 = 32767 or INT_MAX
+        for (int r = r0; r < r1; r += RU) {
+            u32x4 v[RU];
+#pragma unroll
+            for (int i = 0; i < RU; i++) if (in && r + i < r1) v[i] = load16_or_tail(sbaseA + (r + i) * ssA + off, n - off);
+#pragma unroll
+            for (int i = 0; i < RU; i++) {
+                if (!(in && r + i < r1)) continue;
+                u32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t e[4];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int sv = (int)((v[i][q] >> (8 * b)) & 0xFFu);
+                        const int rv = (int)(int16_t)min(mad24(sv, a0, a1) >> 14, a2);
+                        e[b] = (uint32_t)clip_u8_shr(rv + 64, 7);     // (clamp, then shift: hipcc 7.2 turns sat_u8(x >> n) pairs into v_ashr_pk_u8_i32 with stale upper bits)
+                    }
+                    o[q] = e[0] | e[1] << 8 | e[2] << 16 | e[3] << 24;
+                }
+                lstore16(dbaseA + (r + i) * dsA + off, o, n - off);
             }
         }
         break;
