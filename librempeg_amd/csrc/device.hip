@@ -1372,7 +1372,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     if (c->plan == PLAN_MAIN && d->split_mode && d->striprgb_direct == 3 && d->strip_ok && d->striprgbsrc_ok && !d->mixed_ok && !d->striprgb_ok && !d->fullchr_on && !d->alpha_launch && !d->rgbread_on &&
         !c->tune.no_strip_rgbsrc) { c->path_name = "main:strip_packed422"; c->kernel_name = "sws_k_strip_rgbsrc"; }     // (aligned frames; launch_plan_le falls back to split422 + strip_march otherwise)
     if (c->plan == PLAN_MAIN && d->join422) c->path_name += "+join422";
-    if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += d->fullchr_on == 3 ? "+lut_rgb" : d->fullchr_on == 4 ? (((d->fullchr_kind == DSTK_GBRP16 || d->fullchr_kind == DSTK_GBRPF32) && !c->tune.no_wide_epilogue) ? "+fullchr_gbrp16" : "+sum_writer") : "+fullchr_rgb";
+    if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += d->fullchr_on == 3 ? "+lut_rgb" : d->fullchr_on == 4 ? (((d->fullchr_kind == DSTK_GBRP16 || d->fullchr_kind == DSTK_GBRPF32) && c->tune.no_wide_epilogue != 1) ? ((d->rgbread_on || c->tune.no_wide_epilogue == 2) ? "+fullchr_gbrp16" : "+fused_gbrp16") : "+sum_writer") : "+fullchr_rgb";
     if (c->plan == PLAN_MAIN && d->rgb2rgb_ok && !c->tune.no_strip_rgb2rgb && (d->fullchr_on == 1 || d->fullchr_on == 2) && !d->fullchr_direct && d->rgbread_on && d->strip_ok) {
         c->path_name = "main:strip_rgb2rgb"; c->kernel_name = "sws_k_strip_rgb2rgb";      // (aligned frames; launch_plan_le falls back to rgbread + strip_march + fullchr_rgb otherwise)
     }
@@ -1764,6 +1764,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         }
         frames = p422fr.data();
     }
+    bool wide_fused = false;     // (the chroma launch of sws_k_strip_wide wrote the planar RGB destination itself: no epilogue)
     LaunchCtx L;
     std::memset(&L.fs, 0, sizeof(L.fs));
     SwsFrameSet &fs = L.fs;
@@ -1808,6 +1809,28 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
             } else if (d->rgbread_on) ret = launch_rgbread_strip(L);
             else if (d->striprgb_direct_now && d->striprgb_direct == 3) {
                 if (!launch_strip_rgbsrc(L)) { log_msg(c, 0, "internal error: no lockstep strip kernel for a packed 4:2:2 source whose split pass was skipped\n"); return SWS_AVERROR(EINVAL); }
+            } else if (d->fullchr_on == 4 && (d->fullchr_kind == DSTK_GBRP16 || d->fullchr_kind == DSTK_GBRPF32) && !c->tune.no_wide_epilogue && !p422join.empty() && !p.no_chroma &&
+                       frames_desc_ok(p422join.data(), n, 1, p.dstH)) {
+                // planar RGB of 16 bits / float32 behind the 19-bit strip kernel, fused form: the luma launch leaves its sums in the working plane, the chroma launch reads
+                // them next to its own U / V sums and writes the destination planes (kernels_stripwide.hpp: the U / V sums and the epilogue's pass over all three are gone)
+                ret = launch_strip_wide(L, 1);
+                if (ret < 0) return ret;
+                std::vector<SwsFramePtrs> ffr(frames, frames + n);
+                for (int i = 0; i < n; i++) {
+                    SwsFramePtrs &a = ffr[(size_t)i];
+                    a.src[3] = frames[i].dst[0]; a.srcStride[3] = frames[i].dstStride[0];
+                    for (int k = 0; k < 3; k++) { a.dst[k] = p422join[(size_t)i].dst[k]; a.dstStride[k] = p422join[(size_t)i].dstStride[k]; }
+                }
+                SwsDevParams pF = p;
+                pF.dstKind = d->fullchr_kind;
+                LaunchCtx F = L;
+                std::memset(&F.fs, 0, sizeof(F.fs));
+                F.fs.count = n; F.frames = ffr.data(); F.p = &pF;
+                if (n == 1) { F.fs.table = nullptr; F.fs.one = ffr[0]; }
+                else { const SwsFramePtrs *t = nullptr; int r = aux_table(2, ffr, &t); if (r < 0) return r; F.fs.table = t; }
+                ret = launch_strip_wide(F, 2);
+                if (ret < 0) return ret;
+                wide_fused = true;
             } else ret = launch_strip(L);
             if (ret >= 0 && p.no_chroma && isGray(c->opts.src_format) && !isGray(c->opts.dst_format) && p.dstKind != DSTK_RAW32) launch_gray_chroma(L);   // (a gray source: the luma launch alone ran)
         }
@@ -1887,14 +1910,14 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         ret = launch_strip_luma(A);
         if (ret < 0) return ret;
     }
-    if (!p422join.empty()) {   // interleave the planar 4:2:2 working pictures into the packed destinations
+    if (!p422join.empty() && !wide_fused) {   // interleave the planar 4:2:2 working pictures into the packed destinations
         LaunchCtx J = L;
         std::memset(&J.fs, 0, sizeof(J.fs));
         J.fs.count = n;
         J.frames = p422join.data();
         if (n == 1) { J.fs.table = nullptr; J.fs.one = p422join[0]; }
         else { const SwsFramePtrs *t = nullptr; int r = aux_table(0, p422join, &t); if (r < 0) return r; J.fs.table = t; }
-        if (d->fullchr_on == 4 && (d->fullchr_kind == DSTK_GBRP16 || d->fullchr_kind == DSTK_GBRPF32) && !c->tune.no_wide_epilogue) launch_fullchr_rgb(J);   // (sws_k_fullchr_gbrp16: the vector form of the writer)
+        if (d->fullchr_on == 4 && (d->fullchr_kind == DSTK_GBRP16 || d->fullchr_kind == DSTK_GBRPF32) && c->tune.no_wide_epilogue != 1) launch_fullchr_rgb(J);   // (sws_k_fullchr_gbrp16: the vector form of the writer)
         else if (d->fullchr_on == 4) { int r = launch_sum_writer(J, d->fullchr_kind, sum_tab); if (r < 0) return r; }
         else if (d->fullchr_on) launch_fullchr_rgb(J);
         else launch_layout_join422(J, d->join422 == 2);

@@ -154,6 +154,37 @@ __device__ __forceinline__ void strip_body_wide(const FrameRegs &f, const SwsDev
         doff[c] = x < W ? x * dbytes : 0x7fffffff;
     }
 
+    // ---- fused planar RGB writer (CHROMA launch only; p.dstKind names the real destination: DSTK_GBRP16 / DSTK_GBRPF32): the luma launch left its int32 sums in a
+    //      working plane (f.src[3], stride f.srcStride[3]); this launch holds the U and V sums of the same destination columns and rows (planar RGB forces full chroma:
+    //      the chroma planes are scaled to the destination size), so it finishes yuv2gbrp16_full_X_c / yuv2gbrpf32_full_X_c itself (output.c:2467-2605, arithmetic as
+    //      in sws_k_fullchr_gbrp16) and writes the three destination planes: the U / V sums never travel through memory ----
+    const int fuse = !CHROMA ? 0 : p.dstKind == DSTK_GBRP16 ? 1 : p.dstKind == DSTK_GBRPF32 ? 2 : 0;
+    sws_rsrc_t rdP[3], rsY = rd[0];
+    int dstrP[3] = { 0, 0, 0 }, strY = 0, doffP[COLS], doffY[COLS];
+#pragma unroll
+    for (int k = 0; k < 3; k++) rdP[k] = rd[0];
+#pragma unroll
+    for (int c = 0; c < COLS; c++) { doffP[c] = 0x7fffffff; doffY[c] = 0x7fffffff; }
+    const SwsLutParams &LUT = p.lut;
+    const int y_offset = U(LUT.y_offset), y_coeff = U(LUT.y_coeff), v2r = U(LUT.v2r), v2g = U(LUT.v2g), u2g = U(LUT.u2g), u2b = U(LUT.u2b);
+    if (fuse) {
+        const int eb = fuse == 2 ? 4 : 2;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            uint8_t *db = k == 0 ? U(f.dst[0]) : k == 1 ? U(f.dst[1]) : U(f.dst[2]);
+            dstrP[k] = k == 0 ? U(f.dstStride[0]) : k == 1 ? U(f.dstStride[1]) : U(f.dstStride[2]);
+            rdP[k] = make_rsrc(db, (uint32_t)dstrP[k] * (uint32_t)(H - 1) + (uint32_t)W * (uint32_t)eb);
+        }
+        strY = U(f.srcStride[3]);
+        rsY = make_rsrc(U(f.src[3]), (uint32_t)strY * (uint32_t)(H - 1) + (uint32_t)W * 4u);
+#pragma unroll
+        for (int c = 0; c < COLS; c++) {
+            const int x = xs + 64 * c + lane;
+            doffP[c] = x < W ? x * eb : 0x7fffffff; doffY[c] = x < W ? x * 4 : 0x7fffffff;
+        }
+    }
+    uint32_t pend3[3][COLS];
+
     int ringA[NCOMP][COLS][RD], ringB[NCOMP][COLS][RD];        // rows 2q and 2q + 1 of the last RD pairs
 #pragma unroll
     for (int ci = 0; ci < NCOMP; ci++)
@@ -166,6 +197,15 @@ __device__ __forceinline__ void strip_body_wide(const FrameRegs &f, const SwsDev
     int pend_y = -1;
     auto flush = [&]() {
         if (pend_y >= 0) {
+            if (fuse) {
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+#pragma unroll
+                    for (int c = 0; c < COLS; c++) {
+                        if (fuse == 2) __builtin_amdgcn_raw_buffer_store_b32(pend3[k][c], rdP[k], doffP[c], pend_y * dstrP[k], 0);
+                        else __builtin_amdgcn_raw_buffer_store_b16((uint16_t)pend3[k][c], rdP[k], doffP[c], pend_y * dstrP[k], 0);
+                    }
+            } else
             if (raw) {
 #pragma unroll
                 for (int ci = 0; ci < NCOMP; ci++)
@@ -195,6 +235,9 @@ __device__ __forceinline__ void strip_body_wide(const FrameRegs &f, const SwsDev
     for (int y = y0; y < y1; y++) {
         const StripRowN<RD> en = load_strip_row_n<RD>(rows, min(y + 1, H - 1));
         const int pfy = e.pf;
+        int ysum[COLS];
+#pragma unroll
+        for (int c = 0; c < COLS; c++) ysum[c] = fuse ? __builtin_amdgcn_raw_buffer_load_b32(rsY, doffY[c], y * strY, 0) : 0;     // (the luma launch's sums of this row: in flight over the march)
         if (qnext < pfy) {                                     // rows nobody needs: skip
             qnext = pfy;
             prefetch(qnext);
@@ -260,6 +303,35 @@ __device__ __forceinline__ void strip_body_wide(const FrameRegs &f, const SwsDev
                 for (int c = 0; c < COLS; c++) acc[ci][c] = mad24(ringA[ci][c][k], t0, mad24(ringB[ci][c][k], t1, acc[ci][c]));
         }
         // ---- writers ----
+        if (fuse) {
+            if constexpr (NCOMP == 2) {
+#pragma unroll
+                for (int c = 0; c < COLS; c++) {
+                    int Y = ((int)((unsigned)ysum[c] - 0x40000000u) >> 14) + 0x10000;
+                    const int Uc = (int)((unsigned)acc[0][c] - (unsigned)(128 << 23)) >> 14, Vc = (int)((unsigned)acc[NCOMP - 1][c] - (unsigned)(128 << 23)) >> 14;
+                    Y -= y_offset;
+                    Y = (int)((unsigned)Y * (unsigned)y_coeff);
+                    Y = (int)((unsigned)Y + (unsigned)((1 << 13) - (1 << 29)));
+                    const int R = (int)((unsigned)Vc * (unsigned)v2r);
+                    const int G = (int)((unsigned)Vc * (unsigned)v2g + (unsigned)Uc * (unsigned)u2g);
+                    const int B = (int)((unsigned)Uc * (unsigned)u2b);
+                    int r, g2, b;
+                    if (fuse == 2) {
+                        r = clip_uintp2(((int)((unsigned)Y + (unsigned)R) >> 14) + (1 << 15), 16);
+                        g2 = clip_uintp2(((int)((unsigned)Y + (unsigned)G) >> 14) + (1 << 15), 16);
+                        b = clip_uintp2(((int)((unsigned)Y + (unsigned)B) >> 14) + (1 << 15), 16);
+                        const float float_mult = 1.0f / 65535.0f;
+                        pend3[0][c] = __float_as_uint(__fmul_rn(float_mult, (float)g2)); pend3[1][c] = __float_as_uint(__fmul_rn(float_mult, (float)b));
+                        pend3[2][c] = __float_as_uint(__fmul_rn(float_mult, (float)r));
+                    } else {
+                        r = clip_uintp2((int)(((int64_t)Y + R) >> 14) + (1 << 15), 16);
+                        g2 = clip_uintp2((int)(((int64_t)Y + G) >> 14) + (1 << 15), 16);
+                        b = clip_uintp2((int)(((int64_t)Y + B) >> 14) + (1 << 15), 16);
+                        pend3[0][c] = (uint32_t)g2; pend3[1][c] = (uint32_t)b; pend3[2][c] = (uint32_t)r;
+                    }
+                }
+            }
+        } else
         if (raw) {
 #pragma unroll
             for (int ci = 0; ci < NCOMP; ci++)

@@ -46,7 +46,7 @@ def test_planar_rgb_16_bit_and_float_destinations(form, sfmt):
             path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=sw + len(dfmt), tune=T0 if form == "wide" else OLD)
             long_chroma = fl == SWS_LANCZOS and sfmt == "yuv444p"
             if form == "wide" and not (dw & 3) and not long_chroma and not (sw == dw and sfmt in ("yuv444p", "yuyv422", "yuv422p")):     # (identity horizontal filters: the single-pass kernels)     # (the sum-writer route takes widths that are multiples of 4)
-                assert path.endswith("+fullchr_gbrp16") and "strip" in path, (sfmt, dfmt, sw, dw, path)
+                assert path.endswith("+fused_gbrp16") and "strip" in path, (sfmt, dfmt, sw, dw, path)
 
 
 @pytest.mark.parametrize("fl", [SWS_POINT, SWS_AREA, SWS_BILINEAR, SWS_BICUBIC, SWS_GAUSS, SWS_LANCZOS, SWS_SPLINE, SWS_BICUBIC | SWS_ACCURATE_RND])
@@ -78,7 +78,13 @@ def test_packed_rgb_of_16_bits(dfmt):
 
 
 def test_generic_writer_over_the_sums_equals_the_vector_epilogue():
+    """three forms of the planar RGB writer behind the 19-bit strip kernel: fused into the chroma launch (the default), the vector epilogue over the sums
+    (no_wide_epilogue = 2; what RGB sources keep), the generic writer's X form over the sums (no_wide_epilogue = 1)"""
     for dfmt in ("gbrp16le", "gbrpf32le"):
+        assert run_case(640, 48, "yuv420p", 320, 24, dfmt, SWS_BICUBIC | BX, tune=T0)[0].endswith("+fused_gbrp16")
+        assert run_case(640, 48, "yuv420p", 320, 24, dfmt, SWS_BICUBIC | BX, tune=dict(T0, no_wide_epilogue=2))[0].endswith("+fullchr_gbrp16")
+        assert run_case(1284, 50, "nv12", 484, 34, dfmt, SWS_BILINEAR | BX, tune=dict(T0, no_wide_epilogue=2))[0].endswith("+fullchr_gbrp16")
+        assert run_case(640, 48, "bgra", 320, 24, dfmt, SWS_BICUBIC | BX, tune=T0)[0].endswith("+fullchr_gbrp16")
         assert run_case(640, 48, "yuv420p", 320, 24, dfmt, SWS_BICUBIC | BX, tune=dict(T0, no_wide_epilogue=1))[0].endswith("+sum_writer")
         assert run_case(644, 50, "nv12", 484, 33, dfmt, SWS_BILINEAR | BX, tune=dict(T0, no_wide_epilogue=1))[0].endswith("+sum_writer")
 
