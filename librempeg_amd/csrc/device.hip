@@ -928,12 +928,33 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 const int strip_cols_c = c->tune.strip_cols_c == 1 ? 1 : 2;
                 // (narrow pictures leave most of a 256-column strip idle and pay the per-band ring fill: the tile kernel keeps them)
                 const int strip_min_w = c->tune.strip_min_w;
+                // the 19-bit kernel's strips: 128 luma columns, 128 chroma columns where the window fits one 16-byte chunk per lane, else 64
+                auto wide_cols = [&](const FilterBank &hb, const FilterBank &vb, int W, bool chroma) {
+                    int npvw = 1;
+                    for (int y = 0; y < vb.count; y++) npvw = std::max(npvw, ((vb.pos[y] & 1) + vb.size + 1) / 2);
+                    const int hf2 = fs2(hb.size);
+                    for (int cols : { 2, 1 }) {      // (measured: 256-column strips spill at 128 registers -- the rings hold two int32 rows per pair: bench w1 0.22 -> 0.08; 128-column chroma strips
+                        //  with a ring of 4 pairs: w1 0.21 -> 0.26; with a ring of 8 pairs they spill too: yuv420p 4K -> yuv420p16le 1080p 0.0109 -> 0.0256 ms / frame)
+                        if (chroma ? (cols == 2 && npvw > 4) : cols == 1) continue;
+                        if (c->tune.strip_cols_auto == 0 && cols != (chroma ? (c->tune.strip_cols_c == 1 ? 1 : 2) : (c->tune.strip_cols_l == 2 ? 2 : 4))) continue;   // (experiments / tests: forced widths)
+                        const int TW = 64 * cols; int ncmax = 0;
+                        for (int t = 0; t * TW < W; t++) {
+                            int lo = INT32_MAX, hi = -1;
+                            for (int x = t * TW; x < std::min(W, (t + 1) * TW); x++) { lo = std::min(lo, hb.pos[x] & ~1); hi = std::max(hi, (hb.pos[x] & ~1) + hf2); }
+                            lo = std::max(lo, 0) / SPC * SPC;
+                            ncmax = std::max(ncmax, (hi - lo + SPC - 1) / SPC * SPC);
+                        }
+                        if (ncmax / SPC <= 64) return cols;
+                    }
+                    return chroma ? 1 : 2;
+                };
+                const int wcl = p.wide ? wide_cols(c->hLum, c->vLum, p.dstW, false) : 0, wcc = (p.wide && !gray_both) ? wide_cols(c->hChr, c->vChr, p.chrDstW, true) : 0;
                 const bool strip_plan = fullA && dst_ok && !(p.range_active && c->tune.no_strip_range) && !c->tune.no_strip && p.dstW >= (long_form ? strip_min_w_eff : strip_min_w) &&   // (the long form's strips are 128 columns, and what it replaces is the element-per-thread tile kernel)
-                                        plan3(c->hLum, c->vLum, p.dstW, p.wide ? 2 : long_form == 2 ? 1 : long_form ? 2 : strip_cols_l, 1, d->stripL, sL,
+                                        plan3(c->hLum, c->vLum, p.dstW, p.wide ? wcl : long_form == 2 ? 1 : long_form ? 2 : strip_cols_l, 1, d->stripL, sL,
                                               p.wide ? +[](int n) { return n <= 4 ? 4 : 8; } : long_form == 2 ? +[](int) { return 32; } : nullptr, lum_plane1, long_form) &&
-                                        (gray_both || plan3(c->hChr, c->vChr, p.chrDstW, p.wide ? 1 : long_form ? 1 : strip_cols_c, 2, d->stripC, sC,
+                                        (gray_both || plan3(c->hChr, c->vChr, p.chrDstW, p.wide ? wcc : long_form ? 1 : strip_cols_c, 2, d->stripC, sC,
                                                             p.wide ? +[](int n) { return n <= 4 ? 4 : 8; } : long_form == 2 ? +[](int) { return 32; } : long_form ? +[](int) { return 24; } : nullptr, chr_plane1, long_form)) &&
-                                        (!p.wide || d->stripL.NCmax / SPC <= 64);      // (the wide kernel stages one chunk per lane and row)
+                                        (!p.wide || (d->stripL.NCmax / SPC <= 64 && (gray_both || d->stripC.NCmax / SPC <= 64)));      // (the wide kernel stages one chunk per lane and row)
                 d->strip_ok = false;
                 log_msg(c, 3, "strip plan: %d (windows %d/%d chunks of %d, taps %d/%d x %d/%d)\n", strip_plan, d->stripL.NCmax / SPC, d->stripC.NCmax / SPC, SPC,
                         d->stripL.nph, d->stripC.nph, d->stripL.npv, d->stripC.npv);
