@@ -394,7 +394,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     const int strip_min_w_eff = long_taps ? std::min(c->tune.strip_min_w, 64) : c->tune.strip_min_w;   // (one strip of the long forms: thumbnails of 160 x 90 from 1080p are 0.05 ms on the two-pass kernels)
     const bool fc_plain = !isGray(o.src_format) && !isGray(o.dst_format) && p.srcKind != SRCK_MONO;
     d->fullchr_on = 0;
-    if (c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP) && p.full_chr && (!c->needAlpha || fc_alpha) && fc_plain && !(o.flags & SWS_FAST_BILINEAR) &&
+    // (round 5: gray sources of up to 16 bits into 24 / 32 bpp RGB take these routes too -- the luma launch's sums, the chroma sums written by sws_k_gray_chroma from the
+    //  reference's constant chroma lines; a gray source counts as 4:4:4, so it is the full-chroma route unless the caller's flags say otherwise)
+    const bool lut_gray = isGray(o.src_format) && !isALPHA(o.src_format) && !c->needAlpha && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_PLANAR16) && !c->tune.no_strip_range && !p.wide &&
+                          (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32);
+    if (c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP) && p.full_chr && (!c->needAlpha || fc_alpha) && (fc_plain || lut_gray) && !(o.flags & SWS_FAST_BILINEAR) &&
         o.dst_w >= strip_min_w_eff && !c->tune.no_strip && !c->tune.no_mixed) {
         d->fullchr_on = c->needAlpha ? 2 : 1; d->fullchr_kind = p.dstKind;
         p.dstKind = DSTK_RAW32; p.u_plane_dst = 1; p.v_plane_dst = 2;
@@ -404,7 +408,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     // (round 5: ... and for planar / semi-planar sources with samples of 16 significant bits -- yuv4xxp16, p016: sws_k_strip_rgb's own staging takes samples of up to
     //  15 bits, the planar strip kernels take these, strip_hstage_b)
     const bool lut_u16 = !c->tune.no_strip_u16 && c->srcBpc == 16 && p.src_depth == 16 && p.src_shift == 0 && (p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010);
-    if (!d->fullchr_on && c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr && (long_taps || lut_u16) && !c->needAlpha && fc_plain &&
+    // (... and for the packed YUV sources the per-kind reader pre-pass serves -- y210 / y212 / xv30 / v30x / xv36, vyu444 / vuyx: sws_k_strip_rgb reads planar sources only)
+    const bool lut_kind = !c->tune.no_rgbread_kinds && !isALPHA(o.src_format) &&
+                          ((p.srcKind == SRCK_PACKEDHI && p.src_depth >= 9 && p.src_depth <= 15 && c->srcBpc == p.src_depth) || (p.srcKind == SRCK_PACKED444 && p.src_depth == 8 && c->srcBpc == 8));
+    if (!d->fullchr_on && c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr && (long_taps || lut_u16 || lut_kind || lut_gray) && !c->needAlpha && (fc_plain || lut_gray) &&
         !(o.flags & SWS_FAST_BILINEAR) && !(o.dst_w & 1) && o.dst_w >= strip_min_w_eff && !c->tune.no_strip && !c->tune.no_mixed) {
         d->fullchr_on = 3; d->fullchr_kind = p.dstKind;
         p.dstKind = DSTK_RAW32; p.u_plane_dst = 1; p.v_plane_dst = 2;
@@ -728,9 +735,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             //  for analysis; it needed the range conversion in the strip kernels, gray8 being full range, handle_jpeg utils.c:773-809)
             // (round 5: ... and gray sources into planar / semi-planar YUV: the luma launch, then sws_k_gray_chroma writes what the reference's chroma writers make of
             //  their constant lines -- launch_plan_le_batch)
-            const bool gray_src = isGray(o.src_format) && !isGray(o.dst_format) && !c->needAlpha && !isALPHA(o.dst_format) && (src_ok || src_u16) && !c->tune.no_strip_range &&
+            const bool gray_src = isGray(o.src_format) && !isGray(o.dst_format) && !c->needAlpha && (!isALPHA(o.dst_format) || (p.dstKind == DSTK_RAW32 && (d->fullchr_on == 3 || d->fullchr_on == 1))) && (src_ok || src_u16) && !c->tune.no_strip_range &&
                                   (((p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN || p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010) && !p.wide) ||
-                                   ((p.dstKind == DSTK_PLANAR16 || p.dstKind == DSTK_P016) && wide_dst)) && !d->join422 && !d->fullchr_on && !c->tune.no_strip;
+                                   ((p.dstKind == DSTK_PLANAR16 || p.dstKind == DSTK_P016) && wide_dst) || (p.dstKind == DSTK_RAW32 && (d->fullchr_on == 3 || d->fullchr_on == 1) && d->fullchr_kind != DSTK_GBRP)) && !d->join422 &&
+                                  (!d->fullchr_on || d->fullchr_on == 3 || d->fullchr_on == 1) && !c->tune.no_strip;
             const bool gray_both = gray_src || (isGray(o.dst_format) && (isGray(o.src_format) || ((src_ok || nv_src || src_u16 || rgbread) && !c->tune.no_strip_range)) && !c->needAlpha && (src_ok || nv_src || src_u16 || rgbread) &&
                                    (((p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && !p.wide) || (p.dstKind == DSTK_PLANAR16 && wide_dst)) && !c->tune.no_strip);
             // identity luma filters + scaled chroma (yuv422p -> yuv420p, yuv444p -> yuv420p, the 10-bit -> 8-bit twins ...): the luma plane streams
@@ -1853,7 +1861,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
                 if (ret < 0) return ret;
                 wide_fused = true;
             } else ret = launch_strip(L);
-            if (ret >= 0 && p.no_chroma && isGray(c->opts.src_format) && !isGray(c->opts.dst_format) && p.dstKind != DSTK_RAW32) launch_gray_chroma(L);   // (a gray source: the luma launch alone ran)
+            if (ret >= 0 && p.no_chroma && isGray(c->opts.src_format) && !isGray(c->opts.dst_format) && (p.dstKind != DSTK_RAW32 || d->fullchr_on == 3 || d->fullchr_on == 1)) launch_gray_chroma(L);   // (a gray source: the luma launch alone ran)
         }
         else if (d->dot2_ok && vec) ret = launch_tile_dot2(L);                                              // dot2 LDS-tile kernel
         else if (d->tile_ok) ret = launch_tile(L);                                                          // fused h+v LDS-tile kernel

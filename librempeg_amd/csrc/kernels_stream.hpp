@@ -374,11 +374,19 @@ __global__ void __launch_bounds__(256) sws_k_gray_chroma(SwsFrameSet fs, SwsDevP
     const SwsFramePtrs f = frame_copy(fs, blockIdx.z);
     const int kind = U(p.dstKind), fsz = U(p.vChrFs), bits = U(p.dst_bits), osh = U(p.dst_shift);
     const bool semi = kind == DSTK_NV12 || kind == DSTK_P010 || kind == DSTK_P016;
+    const bool rawk = kind == DSTK_RAW32;     // (a gray source into 24 / 32 bpp RGB through the LUT epilogue: the chroma SUMS, int32, for sws_k_lut_rgb; the packed writers' one-tap form
+                                              //  -- both banks one tap -- is the X arithmetic with the tap 4096 like the planar one, device.hip raw_one_one)
     int tsum = 0;
-    if (fsz == 1 && !semi) tsum = 4096;
+    if (fsz == 1 && !semi && (!rawk || U(p.vLumFs) == 1)) tsum = 4096;
     else for (int j = 0; j < fsz; j++) tsum += p.vChrF[(int64_t)cy * fsz + j];
     const uint32_t acc = (uint32_t)(p.wide ? 1 << 18 : 1 << 14) * (uint32_t)tsum;     // (32-bit wrap-around like the writers' own sums)
     uint32_t u, v;
+    if (rawk) {
+        const int up = U(p.u_plane_dst), vp = U(p.v_plane_dst);
+        ((uint32_t *)(f.dst[up] + (int64_t)cy * f.dstStride[up]))[x] = acc;
+        ((uint32_t *)(f.dst[vp] + (int64_t)cy * f.dstStride[vp]))[x] = acc;
+        return;
+    }
     if (p.wide) {
         const int val = (int)(acc + (uint32_t)((1 << 14) - 0x40000000));
         u = v = (uint32_t)(0x8000 + min(max(val >> 15, -32768), 32767));

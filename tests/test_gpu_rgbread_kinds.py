@@ -67,3 +67,13 @@ def test_full_size_frames_host_frames_and_batches():
     for src, dst in (("rgb565le", "yuv420p"), ("gbrp10le", "nv12"), ("x2rgb10le", "bgra")):
         for pad, shift, flip in ((4, 4, 0), (0, 0, 3), (12, 8, 1)):
             run_odd(640, 40, src, 426, 26, dst, SWS_BICUBIC | BX, pad, shift, flip, tune=TUNE)
+
+
+def test_packed_yuv_sources_into_packed_rgb_through_the_lut_epilogue():
+    """round 5: y210 / xv30 / xv36 / vyu444 scaled into 24 / 32 bpp RGB through the LUT writers -- reader pre-pass, strip kernels' sums, sws_k_lut_rgb"""
+    for sfmt in ("y210le", "y212le", "xv30le", "xv36le", "vyu444", "vuyx"):
+        for dfmt in ("bgra", "rgb24", "argb"):
+            for (sw, sh, dw, dh, fl) in ((640, 48, 320, 24, SWS_BICUBIC), (644, 40, 516, 32, SWS_BILINEAR), (320, 24, 640, 48, SWS_BICUBIC)):
+                path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=dw + len(sfmt), tune=TUNE)
+                if (sw, dw) == (640, 320) and sfmt in ("y210le", "y212le"):     # (4:4:4 sources into RGB: full chroma is forced, the other epilogue)
+                    assert path.endswith("+lut_rgb"), (sfmt, dfmt, path)

@@ -140,3 +140,18 @@ def test_rgb_sources_into_gray_and_ranges_with_19_bit_lines():
                 path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=sw + len(dfmt), tune=T0, opts=opts)
                 if sw == 400:
                     assert "strip" in path, (sfmt, dfmt, sr, path)
+
+
+def test_gray_sources_into_packed_rgb():
+    """gray -> 24 / 32 bpp RGB through the LUT writers (round 5): luma launch (raw sums), sws_k_gray_chroma writes the chroma SUMS of the reference's constant chroma lines,
+    sws_k_fullchr_rgb finishes (a gray source counts as 4:4:4: forced full chroma)"""
+    from librempeg_amd import SWS_FULL_CHR_H_INT
+    for sfmt in ("gray8", "gray10le", "gray16le"):
+        for dfmt in ("bgra", "rgb24", "argb", "bgr24", "rgb0"):
+            for (sw, sh, dw, dh, fl) in ((644, 70, 324, 35, SWS_BILINEAR), (400, 66, 332, 54, SWS_BICUBIC), (320, 40, 640, 80, SWS_BICUBIC), (640, 48, 640, 48, SWS_BICUBIC),
+                                         (640, 3, 320, 24, SWS_BICUBIC), (640, 48, 320, 48, SWS_BICUBIC), (400, 66, 331, 54, SWS_BICUBIC)):
+                path, _ = run_case(sw, sh, sfmt, dw, dh, dfmt, fl | BX, seed=sw + len(dfmt), tune=T0)
+                if (sw, dw) == (400, 332):
+                    assert path.endswith("+fullchr_rgb"), (sfmt, dfmt, path)     # (a gray source counts as 4:4:4: full chroma is forced, utils.c:1277-1285)
+            run_case(400, 66, sfmt, 332, 54, dfmt, SWS_BICUBIC | SWS_FULL_CHR_H_INT | BX, seed=9, tune=T0)
+    run_case(1920, 1080, "gray8", 1280, 720, "bgra", SWS_BICUBIC | BX, seed=4)
