@@ -959,9 +959,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 const int wcl = p.wide ? wide_cols(c->hLum, c->vLum, p.dstW, false) : 0, wcc = (p.wide && !gray_both) ? wide_cols(c->hChr, c->vChr, p.chrDstW, true) : 0;
                 const bool strip_plan = fullA && dst_ok && !(p.range_active && c->tune.no_strip_range) && !c->tune.no_strip && p.dstW >= (long_form ? strip_min_w_eff : strip_min_w) &&   // (the long form's strips are 128 columns, and what it replaces is the element-per-thread tile kernel)
                                         plan3(c->hLum, c->vLum, p.dstW, p.wide ? wcl : long_form == 2 ? 1 : long_form ? 2 : strip_cols_l, 1, d->stripL, sL,
-                                              p.wide ? +[](int n) { return n <= 4 ? 4 : 8; } : long_form == 2 ? +[](int) { return 32; } : nullptr, lum_plane1, long_form) &&
+                                              p.wide ? +[](int n) { return n <= 2 ? 2 : n <= 4 ? 4 : 8; } : long_form == 2 ? +[](int) { return 32; } : nullptr, lum_plane1, long_form) &&
                                         (gray_both || plan3(c->hChr, c->vChr, p.chrDstW, p.wide ? wcc : long_form ? 1 : strip_cols_c, 2, d->stripC, sC,
-                                                            p.wide ? +[](int n) { return n <= 4 ? 4 : 8; } : long_form == 2 ? +[](int) { return 32; } : long_form ? +[](int) { return 24; } : nullptr, chr_plane1, long_form)) &&
+                                                            p.wide ? +[](int n) { return n <= 2 ? 2 : n <= 4 ? 4 : 8; } : long_form == 2 ? +[](int) { return 32; } : long_form ? +[](int) { return 24; } : nullptr, chr_plane1, long_form)) &&
                                         (!p.wide || (d->stripL.NCmax / SPC <= 64 && (gray_both || d->stripC.NCmax / SPC <= 64)));      // (the wide kernel stages one chunk per lane and row)
                 d->strip_ok = false;
                 log_msg(c, 3, "strip plan: %d (windows %d/%d chunks of %d, taps %d/%d x %d/%d)\n", strip_plan, d->stripL.NCmax / SPC, d->stripC.NCmax / SPC, SPC,

@@ -27,7 +27,7 @@ int launch_strip_wide_s8(const LaunchCtx &L, int which)
     const dim3 blk(256);
     const bool s16 = p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010;
     auto launch = [&](SwsStripGeom g, int H, bool chroma) -> int {
-        const int cols = g.TW / 64, rd = g.npv <= 4 ? 4 : 8;
+        const int cols = g.TW / 64, rd = g.npv <= 2 ? 2 : g.npv <= 4 ? 4 : 8;
         // strips of 64 * cols columns (device.hip picks the widest whose window fits one chunk per lane and whose rings fit the registers: two int32 rows per pair)
         const bool cols_ok = chroma ? (cols == 1 || cols == 2) : cols == 2;
         if (!cols_ok || g.nph > 8 || g.npv > 8 || g.NCmax / (s16 ? 8 : 16) > 64) {
@@ -41,7 +41,8 @@ int launch_strip_wide_s8(const LaunchCtx &L, int which)
         g.band_rows = (H + bands - 1) / bands;
         g.bands = (H + g.band_rows - 1) / g.band_rows;
         const dim3 grid(cdiv((int64_t)g.strips * g.bands, 4), 1, n);
-#define SWS_WIDE(S, C, K) do { if (rd == 4) hipLaunchKernelGGL((swsk::sws_k_strip_wide<S, C, K, 4>), grid, blk, g.lds_bytes, st, fs, p, g); \
+#define SWS_WIDE(S, C, K) do { if (rd == 2) hipLaunchKernelGGL((swsk::sws_k_strip_wide<S, C, K, 2>), grid, blk, g.lds_bytes, st, fs, p, g); \
+                               else if (rd == 4) hipLaunchKernelGGL((swsk::sws_k_strip_wide<S, C, K, 4>), grid, blk, g.lds_bytes, st, fs, p, g); \
                                else hipLaunchKernelGGL((swsk::sws_k_strip_wide<S, C, K, 8>), grid, blk, g.lds_bytes, st, fs, p, g); } while (0)
 #ifdef SWIDE_S16
         constexpr bool S = SWIDE_S16 != 0;

@@ -10,8 +10,8 @@
 // What differs: a 19-bit sample does not fit a dot2 operand, so the ring keeps the two rows of a pair as two int32 registers and the vertical
 // stage is one v_mad_i32_i24 per row and column (19-bit sample x 13-bit tap: both inside 24 bits, the product's low 32 bits are the reference's
 // wrap-around product) against taps the scalar unit unpacks from the plan entry's packed pairs.  The host lays a row's tap pairs out against the
-// WHOLE ring (older slots get zero taps: plan3's ring_of), so there is one vertical loop of RD pairs: instantiations RD = 4 (bilinear, bicubic up to
-// 2:1 ...) and RD = 8.
+// WHOLE ring (older slots get zero taps: plan3's ring_of), so there is one vertical loop of RD pairs: instantiations RD = 2 (one- and two-row vertical banks: a plane that is
+// not scaled vertically, 2x up-sampled chroma), RD = 4 (bilinear, bicubic up to 2:1 ...) and RD = 8.
 #pragma once
 #include "kernels_strip.hpp"
 
