@@ -1541,6 +1541,8 @@ static const SwsFramePtrs *table_upload_(SwsInternal *c, DeviceState *d, hipStre
         const int off = R.head;
         bool open_hit = false;
         for (const auto &sp : R.cur) open_hit = open_hit || overlaps(sp, off, n);
+        // (callers launch with a table before they ask for the next one -- launch_plan_le_batch, launch_rgbread_strip -- so a regrow below, which frees the old device block
+        //  behind a stream synchronisation, never strands a pointer that has not been launched with yet; a ring holds eight tables of the largest batch seen, a call uses at most six)
         if (open_hit) {   // the launch set being built already fills the ring: twice the size (one synchronisation, once)
             if (attempt) { log_msg(c, 0, "internal error: frame-table ring\n"); return fail(SWS_AVERROR(EINVAL)); }
             int r = ring_regrow(c, d, st, std::max(2 * R.cap, 8 * n)); if (r < 0) return fail(r);

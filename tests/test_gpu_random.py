@@ -349,7 +349,43 @@ def _run_batches(case):
             out = dsts[i].download() if isinstance(dsts[i], DeviceFrame) else dsts[i]
             for pl, (a, b) in enumerate(zip(out.planes, refs[i].planes)):
                 rb = out.row_bytes[pl]
-                assert np.array_equal(a[:, :rb], b[:, :rb]), (case[:7], p.path(), rnd, n, i, pl, int(np.count_nonzero(a[:, :rb] != b[:, :rb])))
+                if not np.array_equal(a[:, :rb], b[:, :rb]):
+                    raise AssertionError(f"{case[:7]} path={p.path()} call {rnd} of {sizes}, frame {i} of {n}, plane {pl}: {int(np.count_nonzero(a[:, :rb] != b[:, :rb]))} bytes differ"
+                                         + _batch_forensics(p, o, case, srcs[i], dsts[i], refs[i], seed - n + i + 1))
+
+
+def _batch_forensics(p, o, case, src_frame, dst_frame, ref, frame_seed):
+    """what a failing frame of a batch says on a second look (the rare events of DESIGN.md 8): the frame alone on the same context, on a fresh context, the oracle again"""
+    import numpy as np
+    from librempeg_amd import SwsContext, HostFrame, DeviceFrame
+    sw, sh, sf, dw, dh, df, flags, k, tune, sizes = case
+    notes = []
+    try:
+        def planes_equal(x, y):
+            return all(np.array_equal(a[:, :rb], b[:, :rb]) for a, b, rb in zip(x.planes, y.planes, x.row_bytes))
+        s = OL.fill_random(OL.Frame(sf, sw, sh), frame_seed)
+        ref2 = OL.Frame(df, dw, dh, fill=0x33)
+        o.scale(s, ref2)
+        notes.append(f"oracle recomputed equals its first answer: {all(np.array_equal(a, b) for a, b in zip(ref2.planes, ref.planes))}")
+        hs = HostFrame(sf, sw, sh)
+        for a, b in zip(hs.planes, s.planes):
+            a[:] = b
+        if isinstance(src_frame, DeviceFrame):
+            back = src_frame.download()
+            notes.append(f"source on the GPU intact: {planes_equal(back, hs)}")
+        hd = HostFrame(df, dw, dh)
+        p.scale(hs, hd)
+        notes.append(f"the frame alone on the same context equals the oracle: {planes_equal(hd, ref)}")
+        p2 = SwsContext(sw, sh, sf, dw, dh, df, flags)
+        for kk, v in tune.items():
+            p2.set_option(kk, v)
+        hd2 = HostFrame(df, dw, dh)
+        p2.scale(hs, hd2)
+        notes.append(f"a fresh context equals the oracle: {planes_equal(hd2, ref)}")
+        p2.close()
+    except Exception as e:   # (forensics must never hide the failure itself)
+        notes.append(f"forensics stopped: {e!r}")
+    return " || forensics: " + "; ".join(notes)
 
 
 # HBM-resident frames with odd plane pointers and line sizes, or stored bottom-up (tests/test_gpu_unaligned_frames.py): the strip family's draws on
