@@ -1089,7 +1089,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                   // pixels (248 columns at 2:1: 504 pixels, two turns instead of three).  (YUV destinations: never together with the RGB -> RGB plans above)
                   const bool packed422_src = (d->split_mode & 3) && !(d->split_mode & 40) && p.srcKind == SRCK_PLANAR8 && p.chrSrcW == (p.srcW >> 1) && p.chrSrcVSub == 0 && !vlines_pending;
                   SOff s3l, s3c;
-                  bool rsrc = strip_plan && !r2r && !p.wide && ((rgbread && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chr_half) || packed422_src) && !gray_both && !long_form &&
+                  bool rsrc = strip_plan && !r2r && !p.wide && ((rgbread && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || p.srcKind == SRCK_RGB30) && p.chr_half) || packed422_src) && !gray_both && !long_form &&
                               !c->tune.no_strip_rgbsrc && !alpha_planar && !p.need_alpha && !d->fullchr_on &&
                               p.chrDstW == ((p.dstW + 1) >> 1) && (p.chrDstVSub == 0 ? p.chrDstH == p.dstH : (p.chrDstVSub == 1 && p.chrDstH == ((p.dstH + 1) >> 1)));
                   if (rsrc) {

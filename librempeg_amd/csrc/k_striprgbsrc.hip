@@ -1,6 +1,6 @@
 // Translation unit of the marching strip kernel for scaled packed-RGB sources (kernels_striprgbsrc.hpp: bgra / rgb24 ... -> planar / semi-planar YUV
 // with half-width chroma in one launch, no reader pre-pass).  Compiled once per (bytes per pixel, luma ring depth) part
-// (-DRSRC_BPP=0|2|3|4 -DRSRC_RL=5|8; 0 = planar G / B / R, 2 = packed 8-bit 4:2:2) so that the chroma ring depths and horizontal tap counts of a part build in parallel with the other parts;
+// (-DRSRC_BPP=0|2|3|4|30 -DRSRC_RL=5|8; 0 = planar G / B / R, 2 = packed 8-bit 4:2:2, 30 = x2rgb10 / x2bgr10) so that the chroma ring depths and horizontal tap counts of a part build in parallel with the other parts;
 // without the macros it compiles the launcher.
 #include <algorithm>
 #include <map>
@@ -14,6 +14,7 @@ StripRgbSrcFn striprgbsrc_fn_b3l5(int nph, int rc, int ng); StripRgbSrcFn stripr
 StripRgbSrcFn striprgbsrc_fn_b4l5(int nph, int rc, int ng); StripRgbSrcFn striprgbsrc_fn_b4l8(int nph, int rc, int ng);
 StripRgbSrcFn striprgbsrc_fn_b0l5(int nph, int rc, int ng); StripRgbSrcFn striprgbsrc_fn_b0l8(int nph, int rc, int ng);   // (0: planar 8-bit G, B, R planes)
 StripRgbSrcFn striprgbsrc_fn_b2l5(int nph, int rc, int ng); StripRgbSrcFn striprgbsrc_fn_b2l8(int nph, int rc, int ng);   // (2: packed 8-bit 4:2:2 -- yuyv422 / uyvy422 / yvyu422)
+StripRgbSrcFn striprgbsrc_fn_b30l5(int nph, int rc, int ng); StripRgbSrcFn striprgbsrc_fn_b30l8(int nph, int rc, int ng);  // (30: x2rgb10le / x2bgr10le)
 }
 
 #ifndef RSRC_BPP
@@ -52,6 +53,7 @@ int launch_strip_rgbsrc(const LaunchCtx &L)
     // (a packed 4:2:2 source whose split pass launch_plan_le skipped: the planner's parameters describe the planar working picture)
     const bool packed422 = d->striprgb_direct_now && d->striprgb_direct == 3;
     StripRgbSrcFn fn = packed422 ? (l8 ? striprgbsrc_fn_b2l8(nph, rc, ng) : striprgbsrc_fn_b2l5(nph, rc, ng)) : p.srcKind == SRCK_GBRP ? (l8 ? striprgbsrc_fn_b0l8(nph, rc, ng) : striprgbsrc_fn_b0l5(nph, rc, ng)) :
+                       p.srcKind == SRCK_RGB30 ? (l8 ? striprgbsrc_fn_b30l8(nph, rc, ng) : striprgbsrc_fn_b30l5(nph, rc, ng)) :
                        b4 ? (l8 ? striprgbsrc_fn_b4l8(nph, rc, ng) : striprgbsrc_fn_b4l5(nph, rc, ng)) : (l8 ? striprgbsrc_fn_b3l8(nph, rc, ng) : striprgbsrc_fn_b3l5(nph, rc, ng));
     if (!fn) return 0;
     const int wave_dw = 2 * (npx + 16);                 // two Y rows of npx + 16 samples, four chroma rows of half as many (u16)

@@ -166,6 +166,33 @@ __device__ __forceinline__ void rgb4px_read(const GT &d, const RgbReadCoefs &k, 
         yo[0] = __builtin_amdgcn_perm(0, d[0], k.yA); yo[1] = __builtin_amdgcn_perm(0, d[1], k.yA);
         uo = __builtin_amdgcn_perm(d[1], d[0], k.uA); vo = __builtin_amdgcn_perm(d[1], d[0], k.vA);
         return;
+    } else if constexpr (BPP == 30) {
+        // x2rgb10le / x2bgr10le (round 5: HDR desktop capture): rgb16_32ToY_c_template / rgb16_32ToUV_half_c_template with the rgb30le / bgr30le rows (input.c:264-372,
+        // :411-412; S = RGB2YUV_SHIFT + 6).  A pixel's fields: T = bits 29:20, G = bits 19:10, B = bits 9:0; the reference takes T and G shifted left by four with the
+        // plain coefficient and the low field as it is with 16 x its coefficient -- {T << 4, G << 4} are v_dot2 operands (14 bits; 15 for the half readers' pair sums),
+        // the low field goes through v_mad_i32_i24 (10 / 11 bits x 19 bits).  k.yA / uA / vA = {coef(T), coef(G)} packed, k.yB / uB / vB = 16 x coef(low field);
+        // x2rgb10: T is red, x2bgr10: T is blue.  32-bit wrap-around sums like the C code, the results are the low 16 bits of the shifted sums.
+        uint32_t yv[4], uu[2], vv[2];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t px = d[i];
+            const uint32_t tg = ((px >> 16) & 0x3FF0u) | (((px >> 6) & 0x3FF0u) << 16);
+            const int S = mad24((int)(px & 0x3FFu), (int)k.yB, sdot2(tg, k.yA, k.ky));
+            yv[i] = (uint32_t)S >> 15;                                        // (sum + (32 << 20) + (1 << 14)) >> 15
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t p0 = d[2 * j], p1 = d[2 * j + 1];
+            const uint32_t g2 = (p0 & 0xC00FFC00u) + (p1 & 0xC00FFC00u);       // maskgx = ~(maskr | maskb): the G field and the two X bits
+            const uint32_t rb = p0 + p1 - g2;
+            const uint32_t tg = ((rb >> 16) & 0x7FF0u) | (((g2 >> 6) & 0x7FF0u) << 16);   // (rb & (mask | mask << 1)) >> 16, (g & (maskg | maskg << 1)) >> 6
+            const int lowf = (int)(rb & 0x7FFu);
+            const int Su = mad24(lowf, (int)k.uB, sdot2(tg, k.uA, k.kc)), Sv = mad24(lowf, (int)k.vB, sdot2(tg, k.vA, k.kc));
+            uu[j] = (uint32_t)Su >> 16; vv[j] = (uint32_t)Sv >> 16;          // (sum + (256 << 21) + (1 << 15)) >> 16
+        }
+        yo[0] = __builtin_amdgcn_perm(yv[1], yv[0], 0x05040100u); yo[1] = __builtin_amdgcn_perm(yv[3], yv[2], 0x05040100u);
+        uo = __builtin_amdgcn_perm(uu[1], uu[0], 0x05040100u); vo = __builtin_amdgcn_perm(vv[1], vv[0], 0x05040100u);
+        return;
     } else {
     uint32_t lo[4], hi[4];          // per pixel: {byte 0, byte 2} and {byte 1, byte 3 (0 for 24 bpp)} as 16-bit halves
     if constexpr (BPP == 4) {
@@ -210,7 +237,7 @@ __device__ __forceinline__ void strip_rgbsrc_body(const FrameRegs &f, const SwsD
     constexpr int CL = 4, CC = 2;
     // NG: groups of four pixels per lane and source row the instantiation takes (group g of the window: lane g % 64, turn g / 64): 2 = windows of
     // up to 512 pixels (ratios up to about 1.9:1), 4 = up to 1024; the staging registers are 2 * NG * 3 or 4 dwords
-    typedef typename std::conditional<BPP == 4, u32x4, typename std::conditional<BPP == 2, u32x2, rsrc_u32x3>::type>::type GT;
+    typedef typename std::conditional<BPP == 4 || BPP == 30, u32x4, typename std::conditional<BPP == 2, u32x2, rsrc_u32x3>::type>::type GT;
     const int W = p.dstW, H = p.dstH, cW = p.chrDstW, cH = p.chrDstH, sH = p.srcH, sh = p.hshift;
     const StripRange rngL = strip_range_of(p, false), rngC = strip_range_of(p, true);
     const int vs = p.chrDstVSub;
@@ -252,6 +279,14 @@ __device__ __forceinline__ void strip_rgbsrc_body(const FrameRegs &f, const SwsD
         rk.yA = 0x0c000c00u | y | (y + 2) << 16;
         rk.uA = 0x0c000c00u | u | (u + 4) << 16; rk.vA = 0x0c000c00u | v | (v + 4) << 16;
         rk.yB = rk.uB = rk.vB = 0;
+    } else if constexpr (BPP == 30) {
+        const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);
+        const bool x2rgb = U(p.s16_is565) != 0;                 // (x2rgb10le: red in the top field; x2bgr10le: blue)
+        auto top = [&](const Rgb2YuvRow &w) { return (uint32_t)(uint16_t)(x2rgb ? w.r : w.b); };
+        auto low = [&](const Rgb2YuvRow &w) { return (uint32_t)(16 * (x2rgb ? w.b : w.r)); };
+        rk.yA = top(ty) | (uint32_t)(uint16_t)ty.g << 16; rk.yB = low(ty);
+        rk.uA = top(tu) | (uint32_t)(uint16_t)tu.g << 16; rk.uB = low(tu);
+        rk.vA = top(tv) | (uint32_t)(uint16_t)tv.g << 16; rk.vB = low(tv);
     } else {
         const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);
         const int rp = BPP == 0 ? 0 : U(p.src_r_pos), gp = BPP == 4 ? U(p.src_g_pos) : 1, bp = BPP == 0 ? 2 : U(p.src_b_pos);
@@ -265,9 +300,10 @@ __device__ __forceinline__ void strip_rgbsrc_body(const FrameRegs &f, const SwsD
     // (planar RGB: the B and R planes; packed sources never touch these)
     const int sst1 = BPP == 0 ? U(f.srcStride[1]) : sst, sst2 = BPP == 0 ? U(f.srcStride[2]) : sst;
     const sws_rsrc_t rs1 = BPP == 0 ? make_rsrc(f.src[1], (uint32_t)sst1 * (uint32_t)sH) : rs, rs2 = BPP == 0 ? make_rsrc(f.src[2], (uint32_t)sst2 * (uint32_t)sH) : rs;
-    constexpr int PXB = BPP ? BPP : 1;                          // bytes per pixel and plane
+    constexpr int PXB = BPP == 30 ? 4 : BPP ? BPP : 1;          // bytes per pixel and plane
     const int vbase = (w0 + 4 * lane) * PXB;
     rk.ky = (32 << 14) + (1 << 8); rk.kc = (256 << 15) + (1 << 9);
+    if constexpr (BPP == 30) { rk.ky = (int)((32u << 20) + (1u << 14)); rk.kc = (int)((256u << 21) + (1u << 15)); }
 
     // ONE row pair in flight per wave, requested before the pair in LDS is h-scaled (two in flight, measured: no gain -- at 2 - 3 waves per SIMD the
     // kernel is bound by instruction issue, not by latency -- and 24 - 32 registers)
@@ -279,7 +315,7 @@ __device__ __forceinline__ void strip_rgbsrc_body(const FrameRegs &f, const SwsD
             if (j < ng) {
                 // (beyond the window: the descriptor answers 0 without touching memory)
                 const int vo = lane + 64 * j < n4 ? vbase + j * (256 * PXB) : 0x7fffffff;
-                if constexpr (BPP == 4) {
+                if constexpr (BPP == 4 || BPP == 30) {
                     pre[0][j] = bload16(rs, vo, r0 * sst);
                     pre[1][j] = bload16(rs, vo, r1 * sst);
                 } else if constexpr (BPP == 2) {

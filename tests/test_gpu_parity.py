@@ -49,7 +49,7 @@ def _forensics(p, out, ref, src_frame, dst_frame, hs, prefill, redo=None):
         return f" || forensics failed: {e!r}"
 
 
-def run_case(sw, sh, sfmt, dw, dh, dfmt, flags, seed=1, colorspace=None, device_frames=True, prefill=0xA5, opts=None, tune=None):
+def run_case(sw, sh, sfmt, dw, dh, dfmt, flags, seed=1, colorspace=None, device_frames=True, prefill=0xA5, opts=None, tune=None, source=None):
     o = OL.Oracle(sw, sh, sfmt, dw, dh, dfmt, flags, **(opts or {}))
     p = SwsContext(sw, sh, sfmt, dw, dh, dfmt, flags, **(opts or {}))
     for k, v in (tune or {}).items():   # launch heuristics (sws_hip_set_option): force a kernel onto shapes the planner gives to another one
@@ -59,7 +59,7 @@ def run_case(sw, sh, sfmt, dw, dh, dfmt, flags, seed=1, colorspace=None, device_
         assert rc == p.set_colorspace(*colorspace)
         if rc < 0:   # refused by both (an error return of sws_setColorspaceDetails leaves the context unusable in the reference)
             return
-    src = OL.fill_random(OL.Frame(sfmt, sw, sh), seed)
+    src = source if source is not None else OL.fill_random(OL.Frame(sfmt, sw, sh), seed)   # (source: a picture the caller built -- extremes, patterns)
     ref = OL.Frame(dfmt, dw, dh, fill=prefill)
     assert o.scale(src, ref) >= 0
     hs = HostFrame(sfmt, sw, sh)

@@ -26,7 +26,9 @@ def test_formats(src, dst):
     for (sw, sh, dw, dh) in ((256, 64, 192, 48), (320, 50, 512, 80), (132, 33, 66, 17)):
         path, _ = run_case(sw, sh, src, dw, dh, dst, SWS_BICUBIC | BX, seed=sw, tune=TUNE)
         if dst in DST[:6]:      # (the YUV destinations; the RGB / packed 4:2:2 ones add their own planner conditions behind the strip kernels)
-            assert "rgbread" in path, (path, sw, sh, dw, dh)
+            assert "rgbread" in path or (src in SRC[:2] and path == "main:strip_rgbsrc"), (path, sw, sh, dw, dh)   # (x2rgb10 / x2bgr10 into half-width chroma: the one-launch kernel reads them itself)
+            if src in SRC[:2]:
+                assert "rgbread" in run_case(sw, sh, src, dw, dh, dst, SWS_BICUBIC | BX, seed=sw, tune=dict(TUNE, no_strip_rgbsrc=1))[0]
         old, _ = run_case(sw, sh, src, dw, dh, dst, SWS_BICUBIC | BX, seed=sw, tune=OLD)
         assert "rgbread" not in old, old
 
@@ -49,8 +51,10 @@ def test_planner_and_fallbacks():
     assert "rgbread" not in run_case(640, 48, "ayuv", 320, 24, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0]
     assert "rgbread" in run_case(640, 48, "gbrp16le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0]          # 16-bit samples: 16-bit lines (round 5: strip_hstage_b)
     assert "rgbread" not in run_case(640, 48, "gbrp16le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_u16=1))[0]
-    assert "rgbread" in run_case(640, 48, "x2rgb10le", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=TUNE)[0]        # a range conversion (round 5: in the strip kernels)
-    assert "rgbread" not in run_case(640, 48, "x2rgb10le", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_range=1))[0]
+    assert run_case(640, 48, "x2rgb10le", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=TUNE)[0] == "main:strip_rgbsrc"   # a range conversion (round 5: in the strip kernels; x2rgb10 / x2bgr10 read by the one-launch kernel)
+    assert "rgbread" in run_case(640, 48, "x2rgb10le", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_rgbsrc=1))[0]
+    assert "rgbread" in run_case(640, 48, "rgb565le", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=TUNE)[0]
+    assert "rgbread" not in run_case(640, 48, "rgb565le", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_range=1))[0]
     assert "rgbread" in run_case(640, 48, "x2rgb10le", 320, 24, "yuv420p16le", SWS_BICUBIC | BX, tune=TUNE)[0]      # 19-bit intermediates: round 5 (sws_k_strip_wide on the reader planes)
     assert "rgbread" not in run_case(640, 48, "x2rgb10le", 320, 24, "yuv420p16le", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_wide=1))[0]
     assert "rgbread" not in run_case(640, 48, "y216le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0]        # 16-bit samples

@@ -14,7 +14,8 @@ BX = SWS_BITEXACT
 PATH = "main:strip_rgbsrc"
 TUNE = dict(strip_min_w=0)     # (the planner keeps pictures narrower than 320 columns on the tile kernel: force the path onto oracle-sized cases)
 
-SRC = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "0bgr", "gbrp", "gbrap"]   # (planar 8-bit GBR: the same readers, three planes)
+SRC = ["rgb24", "bgr24", "rgba", "bgra", "argb", "abgr", "rgb0", "0bgr", "gbrp", "gbrap",    # (planar 8-bit GBR: the same readers, three planes)
+       "x2rgb10le", "x2bgr10le"]                                                             # (round 5: the rgb30le / bgr30le rows of rgb16_32To*_c_template, input.c:411-412)
 DST = ["yuv420p", "yuv422p", "nv12", "nv21", "yuv420p10le", "p010le", "yuv422p12le", "yuv420p16le", "yuv420p9be", "nv16", "p012be"]
 
 
@@ -35,7 +36,7 @@ def test_formats(src, dst):
                          ids=lambda g: f"{g[0]}x{g[1]}-{g[2]}x{g[3]}")
 def test_scalers_and_geometries(flags, geom):
     sw, sh, dw, dh = geom
-    for src, dst in (("rgb24", "yuv420p"), ("bgra", "nv12"), ("argb", "yuv422p10le"), ("bgr24", "p010le"), ("gbrp", "yuv420p")):
+    for src, dst in (("rgb24", "yuv420p"), ("bgra", "nv12"), ("argb", "yuv422p10le"), ("bgr24", "p010le"), ("gbrp", "yuv420p"), ("x2rgb10le", "p010le"), ("x2bgr10le", "yuv420p")):
         run_case(sw, sh, src, dw, dh, dst, flags | BX, seed=7, tune=TUNE)
 
 
@@ -54,7 +55,23 @@ def test_planner_and_fallbacks():
     assert run_case(640, 48, "rgb24", 320, 24, "yuvj420p", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_range=1))[0] != PATH
 
 
+def test_x2rgb10_extremes():
+    """all-ones / all-zeros / X bits set / single-field pictures through the 30 bpp reader: the 32-bit wrap-around sums of the reference
+    (input.c:283-294, :348-366) and the pair sums' carries into the neighbouring field"""
+    import oracle_lib as OL
+    for src in ("x2rgb10le", "x2bgr10le"):
+        for k, word in enumerate((0xFFFFFFFF, 0x00000000, 0xC0000000, 0x3FF00000, 0x000FFC00, 0x000003FF, 0x3FFFFFFF, 0xEAAAAAAA, 0x95555555)):
+            f = OL.Frame(src, 640, 48)
+            f.planes[0].view(np.uint32)[:] = word
+            if k >= 7:
+                f.planes[0].view(np.uint32)[:, ::2] ^= 0xFFFFFFFF
+            for dst, dw, dh in (("yuv420p", 320, 24), ("p010le", 640, 48), ("yuvj420p", 480, 36)):
+                assert run_case(640, 48, src, dw, dh, dst, SWS_BICUBIC | BX, tune=TUNE, source=f)[0] == PATH
+
+
 def test_full_size_frames_and_host_frames():
+    assert run_case(3840, 2160, "x2rgb10le", 3840, 2160, "p010le", SWS_BICUBIC | BX, seed=12)[0] == PATH       # (HDR desktop capture into a 10-bit encoder)
+    assert run_case(3840, 2160, "x2bgr10le", 1920, 1080, "yuv420p10le", SWS_BILINEAR | BX, seed=13)[0] == PATH
     assert run_case(1920, 1080, "rgb24", 1280, 720, "yuv420p", SWS_BICUBIC | BX, seed=2)[0] == PATH
     assert run_case(3840, 2160, "bgra", 1920, 1080, "yuv420p", SWS_BICUBIC | BX, seed=3)[0] == PATH            # (chroma: a 4:1 vertical step, 17 taps: the ring of 12 row pairs)
     assert run_case(3840, 2160, "bgra", 1920, 1080, "nv12", SWS_BILINEAR | BX, seed=5)[0] == PATH
