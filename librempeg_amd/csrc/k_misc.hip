@@ -319,8 +319,19 @@ int launch_misc(const LaunchCtx &L)
         break;
     }
     case PLAN_UNSC_BGR24_YV12: {
-        const dim3 grid(cdiv(cdiv(p.srcW >> 1, 4), 256), (sliceH + 1) / 2, n);
-        if (p.srcW >> 1) hipLaunchKernelGGL(swsk::sws_k_bgr24_to_yv12, grid, blk, 0, st, fs, p, sliceY, sliceH);
+        // (16-byte aligned frames: whole groups of 8 chroma columns through the vector form, the columns behind them -- and everything else -- through the scalar one)
+        bool fits16 = true;     // (the vector form's v_dot2 operands: every table of sws_setColorspaceDetails() built from sane coefficients does)
+        for (int k : { 1, 2, 4, 5, 7, 8 }) fits16 = fits16 && p.rgb2yuv[k] >= -32768 && p.rgb2yuv[k] <= 32767;
+        for (int k : { 0, 3, 6 }) fits16 = fits16 && p.rgb2yuv[k] >= -(1 << 22) && p.rgb2yuv[k] < (1 << 22);
+        const int cw = p.srcW >> 1, cgroups = (L.vec && fits16 && !c->tune.no_wave) ? cw / 8 : 0, cbase = cgroups * 8;
+        if (cgroups) {
+            const dim3 grid(cdiv(cgroups, 256), (sliceH + 1) / 2, n);
+            hipLaunchKernelGGL(swsk::sws_k_bgr24_to_yv12_vec, grid, blk, 0, st, fs, p, sliceY, sliceH, cgroups);
+        }
+        if (cw > cbase) {
+            const dim3 grid(cdiv(cdiv(cw - cbase, 4), 256), (sliceH + 1) / 2, n);
+            hipLaunchKernelGGL(swsk::sws_k_bgr24_to_yv12, grid, blk, 0, st, fs, p, sliceY, sliceH, cbase);
+        }
         break;
     }
     case PLAN_UNSC_PACKEDCOPY: {

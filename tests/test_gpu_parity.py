@@ -219,6 +219,28 @@ def test_bgr24_to_yuv420p_special_converter(w, h):
     assert opath == "main"
 
 
+@pytest.mark.parametrize("w,h", [(1920, 1080), (1280, 721), (16, 2), (18, 3), (30, 4), (4098, 6), (3840, 2160), (1366, 768), (2046, 9)])
+def test_bgr24_to_yuv420p_vector_form(w, h):
+    """the 16-pixel form of the same converter (sws_k_bgr24_to_yv12_vec: aligned frames, whole groups of 8 chroma columns) with the scalar kernel on the columns
+    behind them; destinations with an alpha plane (filled with 255 by the wrapper, swscale_unscaled.c:2073-2074); host frames; the scalar kernel alone (no_wave)"""
+    for dst in ("yuv420p", "yuva420p"):
+        path, opath = run_case(w, h, "bgr24", w, h, dst, SWS_BICUBIC, seed=w + h)
+        assert (path, opath) == ("unscaled:bgr24ToYv12", "bgr24ToYv12")
+    run_case(w, h, "bgr24", w, h, "yuv420p", SWS_BICUBIC, seed=w + 1, device_frames=False)
+    run_case(w, h, "bgr24", w, h, "yuv420p", SWS_BICUBIC, seed=w + 2, tune=dict(no_wave=1))
+    run_case(w, h, "bgr24", w, h, "yuv420p", SWS_BICUBIC, seed=w + 3, colorspace=(SWS_CS_BT2020, 1, SWS_CS_ITU709, 0))
+
+
+def test_bgr24_to_yuv420p_extremes():
+    """all-0 / all-255 / single-channel pictures: the sums wrap in 32 bits and the stores keep the low byte like the reference's uint8_t stores"""
+    import oracle_lib as OL
+    for k, (b, g, r) in enumerate(((255, 255, 255), (0, 0, 0), (255, 0, 0), (0, 255, 0), (0, 0, 255), (1, 254, 3))):
+        f = OL.Frame("bgr24", 64, 6)
+        f.planes[0][:, 0::3] = b; f.planes[0][:, 1::3] = g; f.planes[0][:, 2::3] = r
+        run_case(64, 6, "bgr24", 64, 6, "yuv420p", SWS_BICUBIC, source=f)
+        run_case(64, 6, "bgr24", 64, 6, "yuv420p", SWS_BICUBIC, source=f, colorspace=(SWS_CS_BT2020, 1, SWS_CS_BT2020, 1))
+
+
 def _slice_ptrs(frame, fmt, y0):
     """plane pointers of a DeviceFrame advanced to luma row y0 (what a caller feeding slices passes as srcSlice[])."""
     import ctypes as C
