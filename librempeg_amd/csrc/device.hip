@@ -767,7 +767,12 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                                (dst_ok || rgb_ok) && (!p.wide || wide_ok) && (fs_ok16 || fs_ok32 || fs_ok64) && !c->tune.no_dot2;
             const int long_form = !fullA || fs_ok16 ? 0 : fs_ok32 ? 1 : 2;
             d->mixed_ok = false; d->stripLs_ok = d->stripCs_ok = false; d->striprgbsrc_ok = false; d->rgb2rgb_ok = false;
-            if (fullA || mixedM) {
+            // (a gray source into planar / semi-planar YUV at the same size -- a monochrome camera into an encoder: the luma plane is the mixed plan's streaming pass, the
+            //  chroma planes are sws_k_gray_chroma's constants; no strip plan at all.  launch_mixed tells the two by the source format)
+            const bool gray_mixed = gray_src && !vlines_pending && !d->fullchr_on && bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !p.fast_bilinear && src_ok && dst_ok &&
+                                    p.dstKind != DSTK_RAW32 && !p.wide && (!p.range_active || (c->srcBpc == 8 && p.dst_bits == 8)) && !p.dst_alpha_fill && !c->tune.no_mixed;
+            if (gray_mixed) d->mixed_ok = true;
+            else if (fullA || mixedM) {
                 const int SPC = (p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010 || rgbread) ? 8 : 16;
                 std::vector<uint8_t> blob;
                 auto put = [&](const void *ptr, size_t n) { size_t o = (blob.size() + 15) & ~(size_t)15; blob.resize(o + n); std::memcpy(blob.data() + o, ptr, n); return o; };
@@ -1370,6 +1375,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             c->path_name = "main:strip_rgb"; c->kernel_name = (d->stripRL.dma8_ok && !c->tune.no_strip_dma8) ? "sws_k_strip_rgb8" : "sws_k_strip_rgb";
         } else if (d->mixed_ok) {
             c->path_name = "main:plane1+strip_chroma"; c->kernel_name = "sws_k_strip_march";
+            if (isGray(c->opts.src_format)) { c->path_name = "main:plane1+gray_chroma"; c->kernel_name = "sws_k_layout_stream"; }
         } else if (d->strip_ok) {
             c->path_name = d->rgbread_on ? ((d->striprgbsrc_ok && !c->tune.no_strip_rgbsrc) ? "main:strip_rgbsrc" : "main:rgbread+strip_march") : "main:strip_march";
             c->kernel_name = p.wide ? "sws_k_strip_wide" : ((p.srcKind == SRCK_PLANAR16 || d->rgbread_on) && d->stripL.dma_ok && !c->tune.no_strip_dma) ? "sws_k_strip_dma" : "sws_k_strip_march";

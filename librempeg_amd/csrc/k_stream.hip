@@ -143,6 +143,17 @@ void launch_gray_chroma(const LaunchCtx &L)
 {
     const SwsDevParams &p = *L.p;
     if (p.chrDstW <= 0 || p.chrDstH <= 0) return;
+    // (16-byte aligned chroma planes: 16 bytes per thread, row and plane)
+    const bool semi = p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010 || p.dstKind == DSTK_P016;
+    const int up = semi ? 1 : p.u_plane_dst, vp = semi ? 1 : p.v_plane_dst;
+    bool al = !L.c->tune.no_wave;
+    for (int i = 0; i < L.n && al; i++)
+        for (int k : { up, vp }) al = al && L.frames[i].dst[k] && (((uintptr_t)L.frames[i].dst[k] | (uintptr_t)(int64_t)L.frames[i].dstStride[k]) & 15) == 0;
+    if (al) {
+        const int sbytes = p.dstKind == DSTK_RAW32 ? 4 : (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_NV12) ? 1 : 2, spt = 16 / (sbytes * (semi ? 2 : 1));
+        hipLaunchKernelGGL(swsk::sws_k_gray_chroma_vec, dim3(cdiv(cdiv(p.chrDstW, spt), 64), p.chrDstH, L.n), dim3(64), 0, L.st, L.fs, p);
+        return;
+    }
     hipLaunchKernelGGL(swsk::sws_k_gray_chroma, dim3(cdiv(p.chrDstW, 256), p.chrDstH, L.n), dim3(256), 0, L.st, L.fs, p);
 }
 

@@ -7,6 +7,8 @@
 namespace swship {
 
 // which: 1 = the luma launch, 2 = the chroma launch, 3 = both
+void launch_gray_chroma(const LaunchCtx &L);      // k_stream.hip
+
 int launch_strip_planes(const LaunchCtx &L, int which)
 {
     SwsInternal *c = L.c; DeviceState *d = L.d; const SwsDevParams &p = *L.p; hipStream_t st = L.st; const SwsFrameSet &fs = L.fs;
@@ -108,6 +110,7 @@ int launch_mixed(const LaunchCtx &L)
 {
     int r = launch_layout_plane1(L);
     if (r < 0) return r;
+    if (isGray(L.c->opts.src_format)) { launch_gray_chroma(L); return 0; }     // (a gray source: constant chroma planes, k_stream.hip)
     return launch_strip_planes(L, 2);
 }
 

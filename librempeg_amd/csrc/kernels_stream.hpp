@@ -410,6 +410,67 @@ __global__ void __launch_bounds__(256) sws_k_gray_chroma(SwsFrameSet fs, SwsDevP
     }
 }
 
+// The same for 16-byte aligned planes: one thread = 16 bytes of a row of each chroma plane (16 / 8 / 4 samples of 8 / 16 / 32 bits; 8 / 4 pairs of a semi-planar row).
+// Only the 8-bit writers' dither varies along a row (period 8: output.c:420-431, :468-482); the others store one value.  The thread behind the last whole group
+// of a row stores its samples one by one.
+__global__ void __launch_bounds__(256) sws_k_gray_chroma_vec(SwsFrameSet fs, SwsDevParams p)
+{
+    const int cy = blockIdx.y;
+    const int cW = U(p.chrDstW);
+    const SwsFramePtrs f = frame_copy(fs, blockIdx.z);
+    const int kind = U(p.dstKind), fsz = U(p.vChrFs), bits = U(p.dst_bits), osh = U(p.dst_shift);
+    const bool semi = kind == DSTK_NV12 || kind == DSTK_P010 || kind == DSTK_P016, rawk = kind == DSTK_RAW32;
+    const bool b8 = kind == DSTK_PLANAR8 || kind == DSTK_NV12;
+    const int sbytes = rawk ? 4 : b8 ? 1 : 2;                                  // bytes per stored sample
+    const int spt = 16 / (sbytes * (semi ? 2 : 1));                            // chroma columns per thread
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * spt;
+    if (x0 >= cW) return;
+    int tsum = 0;
+    if (fsz == 1 && !semi && (!rawk || U(p.vLumFs) == 1)) tsum = 4096;
+    else for (int j = 0; j < fsz; j++) tsum += p.vChrF[(int64_t)cy * fsz + j];
+    const uint32_t acc = (uint32_t)(p.wide ? 1 << 18 : 1 << 14) * (uint32_t)tsum;
+    uint32_t cu, cv;                                                           // the value of the writers without dither
+    if (rawk) cu = cv = acc;
+    else if (p.wide) { const int val = (int)(acc + (uint32_t)((1 << 14) - 0x40000000)); cu = cv = (uint32_t)(0x8000 + min(max(val >> 15, -32768), 32767)); }
+    else if (b8) cu = cv = 0;
+    else { const int shift = 11 + 16 - bits; cu = cv = (uint32_t)(clip_uintp2(((1 << (shift - 1)) + (int)acc) >> shift, bits) << osh); }
+    auto u8 = [&](int x) -> uint32_t { return (uint32_t)clip_u8_shr((dither8(p.should_dither, cy, x) << 12) + (int)acc, 19); };
+    auto v8 = [&](int x) -> uint32_t { return (uint32_t)clip_u8_shr((dither8(p.should_dither, cy, x + 3) << 12) + (int)acc, 19); };
+    const bool sw = semi && p.uv_swap_dst;
+    const int up = semi ? 1 : U(p.u_plane_dst), vp = semi ? 1 : U(p.v_plane_dst);
+    uint8_t *du = f.dst[up] + (int64_t)cy * f.dstStride[up], *dv = f.dst[vp] + (int64_t)cy * f.dstStride[vp];
+    if (x0 + spt > cW) {                                                       // the ragged end of a row
+        for (int x = x0; x < cW; x++) {
+            uint32_t u = b8 ? u8(x) : cu, v = b8 ? v8(x) : cv;
+            if (sw) { const uint32_t t = u; u = v; v = t; }
+            if (semi) { if (b8) ((uint16_t *)du)[x] = (uint16_t)(u | v << 8); else ((uint32_t *)du)[x] = u | v << 16; }
+            else if (sbytes == 1) { du[x] = (uint8_t)u; dv[x] = (uint8_t)v; }
+            else if (sbytes == 2) { ((uint16_t *)du)[x] = (uint16_t)u; ((uint16_t *)dv)[x] = (uint16_t)v; }
+            else { ((uint32_t *)du)[x] = u; ((uint32_t *)dv)[x] = v; }
+        }
+        return;
+    }
+    u32x4 ou, ov;
+    if (b8) {                    // x0 is a multiple of 8: the dither pattern of columns 0 .. 7, twice (planar) or interleaved (semi-planar)
+        uint32_t pu[2] = { 0, 0 }, pv[2] = { 0, 0 };
+#pragma unroll
+        for (int k = 0; k < 8; k++) { pu[k >> 2] |= u8(k) << (8 * (k & 3)); pv[k >> 2] |= v8(k) << (8 * (k & 3)); }
+        if (semi) {
+            const uint32_t *a = sw ? pv : pu, *b = sw ? pu : pv;
+            ou = u32x4{ __builtin_amdgcn_perm(b[0], a[0], 0x05010400u), __builtin_amdgcn_perm(b[0], a[0], 0x07030602u),
+                        __builtin_amdgcn_perm(b[1], a[1], 0x05010400u), __builtin_amdgcn_perm(b[1], a[1], 0x07030602u) };
+            ov = ou;
+        } else { ou = u32x4{ pu[0], pu[1], pu[0], pu[1] }; ov = u32x4{ pv[0], pv[1], pv[0], pv[1] }; }
+    } else if (sbytes == 2) {
+        const uint32_t a = sw ? cv : cu, b = sw ? cu : cv;
+        const uint32_t wu = semi ? (a | b << 16) : (cu | cu << 16), wv = semi ? wu : (cv | cv << 16);
+        ou = u32x4{ wu, wu, wu, wu }; ov = u32x4{ wv, wv, wv, wv };
+    } else { ou = u32x4{ cu, cu, cu, cu }; ov = u32x4{ cv, cv, cv, cv }; }
+    const int boff = x0 * sbytes * (semi ? 2 : 1);
+    *(u32x4 *)(du + boff) = ou;
+    if (!semi) *(u32x4 *)(dv + boff) = ov;
+}
+
 // The LUT writers behind the strip kernels' raw sums (dev_prepare_on: fullchr_on == 3): 24 / 32 bpp RGB destinations WITHOUT full chroma whose filters are
 // too long for sws_k_strip_rgb (ratios of 4:1 and more: thumbnails for display or inference).  Y sums at the destination size, U / V sums at half the
 // width; yuv2rgb_X_c_template (output.c:1795-1850): every sum + (1 << 18) >> 19, then the table look-ups in their closed form (lut_pair, kernels_striprgb.hpp).

@@ -123,6 +123,25 @@ def test_gray_sources_into_yuv():
     run_case(1920, 1080, "gray16le", 960, 540, "yuv420p10le", SWS_BILINEAR | BX, seed=5, device_frames=False)
 
 
+def test_gray_sources_into_yuv_at_the_same_size():
+    """a monochrome camera into an encoder (round 5): identity luma filters -- the mixed plan's streaming plane pass (with the range conversion for 8-bit planes) and
+    sws_k_gray_chroma(_vec) alone, no strip plan; ragged widths (the thread behind the last whole 16-byte group), the scalar chroma kernel (no_wave), host frames,
+    limited-range gray (no range conversion), dither of sources beyond 8 bits"""
+    P = "main:plane1+gray_chroma"
+    for sfmt, dfmt, want in (("gray8", "yuv420p", P), ("gray8", "nv12", P), ("gray8", "nv21", P), ("gray8", "yuv422p", P), ("gray8", "yuv444p", P), ("gray8", "yuvj420p", None), ("gray8", "yuv410p", P),
+                             ("gray10le", "yuv420p10le", None), ("gray10le", "yuv420p", None), ("gray16le", "p010le", None), ("gray12le", "yuv444p12le", None), ("gray8", "yuv420p10le", None),
+                             ("gray8", "p010le", None), ("gray10le", "nv12", None), ("gray8", "yuv420p16le", None)):
+        for (w, h) in ((640, 48), (1920, 1080), (642, 37), (1366, 50), (30, 9), (18, 2)):
+            for tune in (None, dict(no_wave=1)):
+                path, _ = run_case(w, h, sfmt, w, h, dfmt, SWS_BICUBIC | BX, seed=w + len(dfmt), tune=tune)
+                if want:
+                    assert path == want, (sfmt, dfmt, w, h, path)
+        run_case(1280, 720, sfmt, 1280, 720, dfmt, SWS_BILINEAR | BX, seed=2, device_frames=False)
+        opts = dict(dither=1, src_range=0, dst_range=0, src_h_chr_pos=-513, src_v_chr_pos=-513, dst_h_chr_pos=-513, dst_v_chr_pos=-513, threads=1)
+        run_case(644, 36, sfmt, 644, 36, dfmt, SWS_BICUBIC | BX, seed=3, opts=opts)
+    assert run_case(640, 48, "gray8", 640, 48, "yuv420p", SWS_BICUBIC | BX, tune=dict(no_mixed=1))[0] != P
+
+
 def test_rgb_sources_into_gray_and_ranges_with_19_bit_lines():
     """RGB -> gray (frames for analysis: the reader pre-pass's luma plane under the luma launch alone; gray is full range, RGB's lines limited: ToJpeg) and
     the 19-bit range conversion (lum / chrRangeToJpeg16_c ...: 64-bit arithmetic) in sws_k_strip_wide: YUV -> gray16, gray -> 16-bit YUV, yuvj -> 16-bit YUV"""

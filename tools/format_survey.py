@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which kernel a conversion gets and how fast it is: one source format against many destination formats (and the reverse), 4 HBM-resident
-1080p / 4K frames per call.  usage: tools/format_survey.py [same|down|up]"""
+1080p / 4K frames per call.  usage: tools/format_survey.py [same|down|up|same4k]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
@@ -10,13 +10,14 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "same"
 N = 4
 FMTS = ["yuv420p", "yuv422p", "yuv444p", "nv12", "nv21", "p010le", "yuv420p10le", "yuv422p10le", "yuv444p10le", "yuv444p16le", "yuyv422", "uyvy422", "rgb24", "bgr24", "rgba", "bgra",
         "argb", "rgb0", "gbrp", "gbrap", "gbrp10le", "gbrpf32le", "rgb48le", "rgba64le", "rgb565le", "gray8", "gray10le", "gray16le", "yuva420p", "ya8", "x2rgb10le", "ayuv", "vuya", "y210le", "xv30le", "p016le"]
-geo = {"same": (1920, 1080, 1920, 1080), "down": (3840, 2160, 1920, 1080), "up": (1280, 720, 1920, 1080)}[mode]
+geo = {"same": (1920, 1080, 1920, 1080), "down": (3840, 2160, 1920, 1080), "up": (1280, 720, 1920, 1080), "same4k": (3840, 2160, 3840, 2160)}[mode]
+if mode == "same4k": N = 8
 sw, sh, dw, dh = geo
 rows = []
 for base in ("yuv420p", "nv12", "bgra", "yuv420p10le"):
     for other in FMTS:
         for sf, df in ((base, other), (other, base)):
-            if sf == df and mode == "same": continue
+            if sf == df and mode in ("same", "same4k"): continue
             try:
                 ctx = SwsContext(sw, sh, sf, dw, dh, df, SWS_BICUBIC | SWS_BITEXACT)
             except Exception as e:
