@@ -23,6 +23,7 @@ void launch_layout_splitnv(const LaunchCtx &L, bool vfirst);   // k_layout.hip: 
 void launch_layout_splitp01x(const LaunchCtx &L, int shift);   // k_layout.hip: p010-style planes -> planar working picture, words >> shift
 void launch_alpha_merge32(const LaunchCtx &L);                 // k_stream.hip: the alpha bytes behind sws_k_strip_rgb (alpha_launch == 2)
 void launch_gray_chroma(const LaunchCtx &L);                   // k_stream.hip: the chroma planes of a gray source in a YUV destination
+bool fullchr_gray_const(const LaunchCtx &L);                   // k_stream.hip: ... or no launch: the full-chroma RGB epilogue computes the constants itself
 void launch_layout_join422(const LaunchCtx &L, bool uyvy);   // k_layout.hip: planar 4:2:2 working picture -> yuyv422 / uyvy422 (yvyu422: planes swapped by the planner)
 
 // the plan geometries of a fresh state start out as zeros (`new DeviceState()` runs the default member initialisers and leaves members without one as the
@@ -1869,7 +1870,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
                 if (ret < 0) return ret;
                 wide_fused = true;
             } else ret = launch_strip(L);
-            if (ret >= 0 && p.no_chroma && isGray(c->opts.src_format) && !isGray(c->opts.dst_format) && (p.dstKind != DSTK_RAW32 || d->fullchr_on == 3 || d->fullchr_on == 1)) launch_gray_chroma(L);   // (a gray source: the luma launch alone ran)
+            if (ret >= 0 && p.no_chroma && isGray(c->opts.src_format) && !isGray(c->opts.dst_format) && (p.dstKind != DSTK_RAW32 || d->fullchr_on == 3 || d->fullchr_on == 1) && !fullchr_gray_const(L)) launch_gray_chroma(L);   // (a gray source: the luma launch alone ran)
         }
         else if (d->dot2_ok && vec) ret = launch_tile_dot2(L);                                              // dot2 LDS-tile kernel
         else if (d->tile_ok) ret = launch_tile(L);                                                          // fused h+v LDS-tile kernel

@@ -105,6 +105,15 @@ int launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, in
     return 0;
 }
 
+// a gray source into 24 / 32 bpp RGB through the full-chroma epilogue: its chroma sums are constants of the row, which sws_k_fullchr_rgb<.., 3> computes itself
+// (device.hip skips the sws_k_gray_chroma launch on the same predicate)
+bool fullchr_gray_const(const LaunchCtx &L)
+{
+    const SwsDevParams &p = *L.p;
+    return L.d->fullchr_on == 1 && (L.d->fullchr_kind == DSTK_RGB24 || L.d->fullchr_kind == DSTK_RGB32) && p.no_chroma && isGray(L.c->opts.src_format) && !L.d->fullchr_direct &&
+           !L.c->tune.no_wave;
+}
+
 // the full-chroma RGB epilogue behind the strip kernels (dev_prepare_on: fullchr_on; L.fs holds {src = the int32 sum planes, dst = the packed picture})
 void launch_fullchr_rgb(const LaunchCtx &L)
 {
@@ -130,6 +139,11 @@ void launch_fullchr_rgb(const LaunchCtx &L)
         else if (wide) SWS_FC_SRCM(sws_k_fullchr_gbrp, true, false);
         else if (alpha) SWS_FC_SRCM(sws_k_fullchr_gbrp, false, true);
         else SWS_FC_SRCM(sws_k_fullchr_gbrp, false, false);
+        return;
+    }
+    if (fullchr_gray_const(L)) {     // a gray source: the chroma sums are constants of the row, computed in the epilogue (no sws_k_gray_chroma launch, no U / V planes)
+        if (p.lut.pix_step == 4) hipLaunchKernelGGL((swsk::sws_k_fullchr_rgb<4, false, 3>), grid, blk, 0, L.st, L.fs, p);
+        else hipLaunchKernelGGL((swsk::sws_k_fullchr_rgb<3, false, 3>), grid, blk, 0, L.st, L.fs, p);
         return;
     }
     if (p.lut.pix_step == 4 && L.d->fullchr_on == 2) SWS_FC_SRCM(sws_k_fullchr_rgb, 4, true);

@@ -174,8 +174,19 @@ __global__ void __launch_bounds__(256) sws_k_fullchr_rgb(SwsFrameSet fs, SwsDevP
     const int r_pos = U(L.r_pos), g_pos = U(L.g_pos), b_pos = U(L.b_pos), a_pos = U(L.a_pos);
     int nY[4] = { 0, 0, 0, 0 }, nU[4] = { 0, 0, 0, 0 }, nV[4] = { 0, 0, 0, 0 }, nA[4] = { 0, 0, 0, 0 };
     auto fetch = [&](int y) {
-        fullchr_fetch4<SRCM>(pY, sY, y, x, npx, ssh, nY); fullchr_fetch4<SRCM>(pU, sU, y, x, npx, ssh, nU); fullchr_fetch4<SRCM>(pV, sV, y, x, npx, ssh, nV);
-        if constexpr (ALPHA) fullchr_fetch4<SRCM>(pA, sA, y, x, npx, ssh, nA);
+        if constexpr (SRCM == 3) {      // a gray source (round 5): the luma sums, and the chroma sums of the reference's constant chroma lines -- what sws_k_gray_chroma would have
+            fullchr_fetch4<0>(pY, sY, y, x, npx, ssh, nY);      // written into two planes of sums for this kernel to read back: (1 << 14) x the row's vertical chroma taps
+            const int fsz = U(p.vChrFs);
+            int tsum = 0;
+            if (fsz == 1 && U(p.vLumFs) == 1) tsum = 4096;
+            else for (int j = 0; j < fsz; j++) tsum += p.vChrF[(int64_t)y * fsz + j];
+            const int acc = (int)((uint32_t)(1 << 14) * (uint32_t)tsum);
+#pragma unroll
+            for (int k = 0; k < 4; k++) nU[k] = nV[k] = acc;
+        } else {
+            fullchr_fetch4<SRCM>(pY, sY, y, x, npx, ssh, nY); fullchr_fetch4<SRCM>(pU, sU, y, x, npx, ssh, nU); fullchr_fetch4<SRCM>(pV, sV, y, x, npx, ssh, nV);
+            if constexpr (ALPHA) fullchr_fetch4<SRCM>(pA, sA, y, x, npx, ssh, nA);
+        }
     };
     if (in && y0 < y1) fetch(y0);
     for (int y = y0; y < y1; y++) {

@@ -173,4 +173,10 @@ def test_gray_sources_into_packed_rgb():
                 if (sw, dw) == (400, 332):
                     assert path.endswith("+fullchr_rgb"), (sfmt, dfmt, path)     # (a gray source counts as 4:4:4: full chroma is forced, utils.c:1277-1285)
             run_case(400, 66, sfmt, 332, 54, dfmt, SWS_BICUBIC | SWS_FULL_CHR_H_INT | BX, seed=9, tune=T0)
+            # (the epilogue computes the constant chroma sums itself; no_wave: sws_k_gray_chroma writes them into planes as before)
+            for (sw, sh, dw, dh) in ((400, 66, 332, 54), (640, 48, 640, 48), (644, 70, 324, 35), (640, 3, 320, 24), (322, 31, 322, 31)):
+                run_case(sw, sh, sfmt, dw, dh, dfmt, SWS_LANCZOS | BX, seed=sw + 1, tune=dict(T0, no_wave=1))
+                run_case(sw, sh, sfmt, dw, dh, dfmt, SWS_LANCZOS | BX, seed=sw + 2, tune=T0)
     run_case(1920, 1080, "gray8", 1280, 720, "bgra", SWS_BICUBIC | BX, seed=4)
+    run_case(3840, 2160, "gray16le", 3840, 2160, "bgra", SWS_BICUBIC | BX, seed=5)
+    run_case(1920, 1080, "gray10le", 1920, 1080, "rgb24", SWS_BICUBIC | BX, seed=6, device_frames=False)
