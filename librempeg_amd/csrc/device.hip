@@ -23,6 +23,7 @@ void launch_layout_splitnv(const LaunchCtx &L, bool vfirst);   // k_layout.hip: 
 void launch_layout_splitp01x(const LaunchCtx &L, int shift);   // k_layout.hip: p010-style planes -> planar working picture, words >> shift
 void launch_alpha_merge32(const LaunchCtx &L);                 // k_stream.hip: the alpha bytes behind sws_k_strip_rgb (alpha_launch == 2)
 void launch_gray_chroma(const LaunchCtx &L);                   // k_stream.hip: the chroma planes of a gray source in a YUV destination
+int  launch_mixed_join422(const LaunchCtx &L, bool uyvy);        // k_stream.hip: 1 = the mixed plan and its interleave ran as one pass
 bool fullchr_gray_const(const LaunchCtx &L);                   // k_stream.hip: ... or no launch: the full-chroma RGB epilogue computes the constants itself
 void launch_layout_join422(const LaunchCtx &L, bool uyvy);   // k_layout.hip: planar 4:2:2 working picture -> yuyv422 / uyvy422 (yvyu422: planes swapped by the planner)
 
@@ -1408,6 +1409,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     if (c->plan == PLAN_MAIN && d->split_mode && d->striprgb_direct == 3 && d->strip_ok && d->striprgbsrc_ok && !d->mixed_ok && !d->striprgb_ok && !d->fullchr_on && !d->alpha_launch && !d->rgbread_on &&
         !c->tune.no_strip_rgbsrc) { c->path_name = "main:strip_packed422"; c->kernel_name = "sws_k_strip_rgbsrc"; }     // (aligned frames; launch_plan_le falls back to split422 + strip_march otherwise)
     if (c->plan == PLAN_MAIN && d->join422) c->path_name += "+join422";
+    // (aligned frames: k_stream.hip launch_mixed_join422 takes the mixed plan and its interleave as one pass)
+    if (c->plan == PLAN_MAIN && d->join422 && d->mixed_ok && d->unity_h && !d->fullchr_on && !isGray(c->opts.src_format) && c->srcBpc == 8 && !p.range_active && !c->tune.no_wave &&
+        (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12) && !(p.dstW & 7) && p.vChrFs <= 16) { c->path_name = "main:mixed_join422"; c->kernel_name = "sws_k_mixed_join422"; }
     if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += d->fullchr_on == 3 ? "+lut_rgb" : d->fullchr_on == 4 ? (((d->fullchr_kind == DSTK_GBRP16 || d->fullchr_kind == DSTK_GBRPF32) && c->tune.no_wide_epilogue != 1) ? ((d->rgbread_on || c->tune.no_wide_epilogue == 2) ? "+fullchr_gbrp16" : "+fused_gbrp16") : "+sum_writer") : "+fullchr_rgb";
     if (c->plan == PLAN_MAIN && d->rgb2rgb_ok && !c->tune.no_strip_rgb2rgb && (d->fullchr_on == 1 || d->fullchr_on == 2) && !d->fullchr_direct && d->rgbread_on && d->strip_ok) {
         c->path_name = "main:strip_rgb2rgb"; c->kernel_name = "sws_k_strip_rgb2rgb";      // (aligned frames; launch_plan_le falls back to rgbread + strip_march + fullchr_rgb otherwise)
@@ -1840,7 +1844,26 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         else if (d->rgbsrc_ok && vec && (!p.range_active || (d->rgbsrc2_rows && !c->tune.no_rgbsrc2 && !(p.dstW & 3) && frames_desc_ok(frames, n, p.srcH, p.dstH)))) { if (!launch_rgbsrc2(L)) ret = launch_rgbsrc(L); }   // (range conversion: the wave-march form only)                                             // packed RGB source, same size
         else if (d->rgb444_ok && vec) ret = launch_rgb444(L);                                             // 8-bit RGB -> planar 4:4:4, same size
         else if (d->striprgb_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_striprgb(L);   // marching strip kernel, RGB epilogue
-        else if (d->mixed_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) ret = launch_mixed(L);   // identity luma: streaming pass + strip kernel on chroma
+        else if (d->mixed_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) {                        // identity luma: streaming pass + strip kernel on chroma
+            bool fusedj = false;
+            if (d->join422 && !p422join.empty() && !d->fullchr_on && !isGray(c->opts.src_format)) {
+                // ... into packed 4:2:2 with identity horizontal filters (yuv420p / nv12 -> yuyv422 / uyvy422 at the same size): one pass from the caller's planes into the
+                // caller's picture instead of plane pass + chroma strip launch + interleave (k_stream.hip; it refuses what it does not take)
+                std::vector<SwsFramePtrs> fj(frames, frames + n);
+                for (int i = 0; i < n; i++) {
+                    SwsFramePtrs &a = fj[(size_t)i];
+                    a.dst[0] = p422join[(size_t)i].dst[0]; a.dstStride[0] = p422join[(size_t)i].dstStride[0];
+                    a.dst[1] = a.dst[2] = a.dst[3] = nullptr; a.dstStride[1] = a.dstStride[2] = a.dstStride[3] = 0;
+                }
+                LaunchCtx F = L;
+                std::memset(&F.fs, 0, sizeof(F.fs));
+                F.fs.count = n; F.frames = fj.data();
+                if (n == 1) { F.fs.table = nullptr; F.fs.one = fj[0]; }
+                else { const SwsFramePtrs *t = nullptr; int r = aux_table(0, fj, &t); if (r < 0) return r; F.fs.table = t; }
+                if (launch_mixed_join422(F, d->join422 == 2)) { fusedj = true; wide_fused = true; }
+            }
+            if (!fusedj) ret = launch_mixed(L);
+        }
         else if (d->strip_ok && vec && frames_desc_ok(frames, n, p.srcH, p.dstH)) {   // marching strip kernel
             if (d->rgb2rgb_now) {
                 if (!launch_strip_rgb2rgb(L)) { log_msg(c, 0, "internal error: no one-launch RGB -> RGB strip kernel for a plan that counted on it\n"); return SWS_AVERROR(EINVAL); }

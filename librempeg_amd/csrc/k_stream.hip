@@ -105,6 +105,25 @@ int launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, in
     return 0;
 }
 
+// yuv420p / nv12 ... -> yuyv422 / uyvy422 / yvyu422 at the same size: the mixed plan and its interleave in one pass over whole groups of 8 pixels (kernels_stream.hpp);
+// L.fs holds {the caller's source planes -> the caller's packed picture}.  0 = not a shape of this kernel (the caller runs the three passes)
+int launch_mixed_join422(const LaunchCtx &L, bool uyvy)
+{
+    const SwsDevParams &p = *L.p;
+    SwsInternal *c = L.c;
+    if (c->tune.no_wave || !L.d->unity_h || c->srcBpc != 8 || p.range_active || (p.srcKind != SRCK_PLANAR8 && p.srcKind != SRCK_NV12) || (p.dstW & 7) || p.vChrFs > 16) return 0;
+    for (int i = 0; i < L.n; i++) {
+        const SwsFramePtrs &a = L.frames[i];
+        for (int k = 0; k < (p.srcKind == SRCK_NV12 ? 2 : 3); k++) if (!a.src[k] || (((uintptr_t)a.src[k] | (uintptr_t)(int64_t)a.srcStride[k]) & 15)) return 0;
+        if (!a.dst[0] || (((uintptr_t)a.dst[0] | (uintptr_t)(int64_t)a.dstStride[0]) & 15)) return 0;
+    }
+    const int groups = p.dstW / 8;
+    const dim3 grid(cdiv(groups, 64), cdiv(p.dstH, 4 * swsk::MJ422_ROWS), L.n), blk(256);
+    if (p.srcKind == SRCK_NV12) hipLaunchKernelGGL((swsk::sws_k_mixed_join422<true>), grid, blk, 0, L.st, L.fs, p, uyvy ? 1 : 0, groups);
+    else hipLaunchKernelGGL((swsk::sws_k_mixed_join422<false>), grid, blk, 0, L.st, L.fs, p, uyvy ? 1 : 0, groups);
+    return 1;
+}
+
 // a gray source into 24 / 32 bpp RGB through the full-chroma epilogue: its chroma sums are constants of the row, which sws_k_fullchr_rgb<.., 3> computes itself
 // (device.hip skips the sws_k_gray_chroma launch on the same predicate)
 bool fullchr_gray_const(const LaunchCtx &L)

@@ -482,6 +482,69 @@ __global__ void __launch_bounds__(256) sws_k_gray_chroma_vec(SwsFrameSet fs, Sws
     if (!semi) *(u32x4 *)(dv + boff) = ov;
 }
 
+// Planar / semi-planar 8-bit YUV into packed 8-bit 4:2:2 at the same size with a vertical chroma step only (yuv420p / nv12 -> yuyv422 / uyvy422 / yvyu422: a decoder's
+// picture for a playout card or a V4L2 sink; round 5).  The mixed plan + join (plane pass, chroma strip launch into a planar 4:2:2 working picture, interleave) moved 62 MB
+// per 4K frame for 29 MB of pictures; this is the same arithmetic in one pass: luma bytes as they are (identity filters: yuv2422_X_c's (4096 (y << 7) + (1 << 18)) >> 19),
+// chroma through hScale8To15_c's one tap (<< 7) and the vertical bank, (sum + (1 << 18)) >> 19 clipped (output.c:880-917; one tap on both sides: yuv2422_1_c, the
+// sample itself) -- computed as (sum of tap x byte + (1 << 11)) >> 12, the same number, so that two tap rows go through one v_dot2_i32_i16 ({byte of row j, byte of row
+// j + 1} assembled by one v_perm).  One thread = 4 chroma columns = 8 pixels of MJ422_ROWS consecutive rows: every wave instruction reads or writes one contiguous run
+// (8 luma bytes, 4 + 4 (NV: 8 interleaved) chroma bytes per tap row -- neighbouring output rows share them: L2 hits -- and 16 bytes out per lane).
+constexpr int MJ422_ROWS = 8;
+template <bool NV>
+__global__ void __launch_bounds__(256) sws_k_mixed_join422(SwsFrameSet fs, SwsDevParams p, int uyvy, int groups)
+{
+    const int gx = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (gx >= groups) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    const int H = U(p.dstH), cH = U(p.chrSrcH), fsz = U(p.vChrFs);
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * MJ422_ROWS, y1 = min(H, y0 + MJ422_ROWS);
+    const bool vfirst = U(p.u_plane_dst) == 2;                                  // (yvyu422: the planner swapped the planes of the working picture)
+    const bool swapc = NV ? ((U(p.uv_swap_src) != 0) != vfirst) : vfirst;       // the FIRST chroma byte of a group comes from the second source component
+    const int pu = NV ? 1 : U(p.u_plane_src), pv = NV ? 1 : U(p.v_plane_src);
+    const uint8_t *s0 = pu == 1 ? f.src[1] : f.src[2], *s1 = pv == 1 ? f.src[1] : f.src[2];
+    const int64_t st0 = pu == 1 ? f.srcStride[1] : f.srcStride[2], st1 = pv == 1 ? f.srcStride[1] : f.srcStride[2];
+    auto chroma_row = [&](int r, uint32_t &cu, uint32_t &cv) {
+        r = min(max(r, 0), cH - 1);
+        if constexpr (NV) {
+            const u32x2 a = *((const SWS_GLOBAL u32x2 *)(s0 + (int64_t)r * st0) + gx);     // {u0 v0 u1 v1} {u2 v2 u3 v3}
+            cu = __builtin_amdgcn_perm(a[1], a[0], 0x06040200u); cv = __builtin_amdgcn_perm(a[1], a[0], 0x07050301u);
+        } else {
+            cu = *((const SWS_GLOBAL uint32_t *)(s0 + (int64_t)r * st0) + gx); cv = *((const SWS_GLOBAL uint32_t *)(s1 + (int64_t)r * st1) + gx);
+        }
+    };
+    for (int y = y0; y < y1; y++) {
+        const u32x2 yw = *((const SWS_GLOBAL u32x2 *)(f.src[0] + (int64_t)y * f.srcStride[0]) + gx);
+        const int pos = p.vChrPos[y];
+        int au[4], av[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) au[k] = av[k] = 1 << 11;
+        for (int j = 0; j < fsz; j += 2) {
+            const int t0 = fsz == 1 ? 4096 : (int)p.vChrF[(int64_t)y * fsz + j], t1 = j + 1 < fsz ? (int)p.vChrF[(int64_t)y * fsz + j + 1] : 0;
+            const uint32_t tp = ((uint32_t)t0 & 0xFFFFu) | (uint32_t)t1 << 16;
+            uint32_t ua, va, ub, vb;
+            chroma_row(pos + j, ua, va);
+            chroma_row(pos + (j + 1 < fsz ? j + 1 : j), ub, vb);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t sel = 0x0C000C00u | (uint32_t)k | (uint32_t)(4 + k) << 16;           // {byte k of row j, 0, byte k of row j + 1, 0}
+                au[k] = sdot2(__builtin_amdgcn_perm(ub, ua, sel), tp, au[k]);
+                av[k] = sdot2(__builtin_amdgcn_perm(vb, va, sel), tp, av[k]);
+            }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t c0 = (uint32_t)clip_u8_shr(au[k], 12), c1 = (uint32_t)clip_u8_shr(av[k], 12);
+            if (swapc) { const uint32_t t = c0; c0 = c1; c1 = t; }
+            const uint32_t cc = c0 | c1 << 16;
+            const uint32_t m = 2 * (k & 1);                                    // the column's luma pair: bytes m, m + 1 of its dword
+            const uint32_t sy = m | 4u << 8 | (m + 1) << 16 | 6u << 24, su = 4u | m << 8 | 6u << 16 | (m + 1) << 24;     // y0 c0 y1 c1 / c0 y0 c1 y1
+            o[k] = __builtin_amdgcn_perm(cc, yw[k >> 1], uyvy ? su : sy);
+        }
+        *((SWS_GLOBAL u32x4 *)(f.dst[0] + (int64_t)y * f.dstStride[0]) + gx) = o;
+    }
+}
+
 // The LUT writers behind the strip kernels' raw sums (dev_prepare_on: fullchr_on == 3): 24 / 32 bpp RGB destinations WITHOUT full chroma whose filters are
 // too long for sws_k_strip_rgb (ratios of 4:1 and more: thumbnails for display or inference).  Y sums at the destination size, U / V sums at half the
 // width; yuv2rgb_X_c_template (output.c:1795-1850): every sum + (1 << 18) >> 19, then the table look-ups in their closed form (lut_pair, kernels_striprgb.hpp).

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from librempeg_amd import (SWS_BICUBIC, SWS_BILINEAR, SWS_LANCZOS, SWS_BITEXACT, SWS_ACCURATE_RND, SWS_POINT, SWS_AREA, SWS_FAST_BILINEAR)
+AR = SWS_ACCURATE_RND
 from test_gpu_parity import run_case
 
 pytestmark = pytest.mark.gpu
@@ -24,7 +25,7 @@ def test_formats(src, dst):
             r = run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh, tune=tune)
             if r and fl == SWS_BICUBIC and not dw & 1 and (src, dst) not in (("yuv422p", "yuyv422"), ("yuv422p", "uyvy422")) and not (src in ("yuv422p",) and (sw, sh) == (dw, dh)):
                 if not ((sw, sh) == (dw, dh) and src in ("yuv422p", "yuv444p", "rgb24", "bgra", "gbrp")):      # (a one- or two-tap chroma filter may be a short form)
-                    assert r[0].endswith("+join422"), (r[0], src, dst, sw, sh, dw, dh)
+                    assert r[0].endswith("join422"), (r[0], src, dst, sw, sh, dw, dh)
 
 
 def test_short_vertical_forms_keep_the_packed_writer():
@@ -33,15 +34,36 @@ def test_short_vertical_forms_keep_the_packed_writer():
     assert not run_case(256, 64, "yuv420p", 256, 64, "yuyv422", SWS_BILINEAR | BX)[0].endswith("+join422")
     assert run_case(256, 64, "yuv420p10le", 256, 64, "yuyv422", SWS_BICUBIC | BX)[0].endswith("+join422")     # (the ordered dither belongs to the planar 8-bit writers only)
     assert not run_case(255, 64, "yuv420p", 255, 64, "yuyv422", SWS_BICUBIC | BX)[0].endswith("+join422")         # odd width: the last pair
-    assert run_case(256, 64, "yuv420p", 256, 64, "yuyv422", SWS_BICUBIC | BX)[0].endswith("+join422")
+    assert run_case(640, 64, "yuv420p", 640, 64, "yuyv422", SWS_BICUBIC | BX)[0] == "main:mixed_join422"       # (round 5: plane pass, chroma strip launch and interleave as one pass)
+    assert run_case(640, 64, "yuv420p", 640, 64, "yuyv422", SWS_BICUBIC | BX, tune=dict(no_wave=1))[0] == "main:plane1+strip_chroma+join422"
+    assert run_case(644, 64, "yuv420p", 644, 64, "yuyv422", SWS_BICUBIC | BX)[0] == "main:plane1+strip_chroma+join422"      # (whole groups of 8 pixels only)
+    assert run_case(256, 64, "yuv420p", 256, 64, "yuyv422", SWS_BICUBIC | BX)[0] == "main:fused_generic_unity+join422"      # (narrow pictures: no mixed plan)
     assert run_case(256, 64, "yuv420p", 256, 64, "uyvy422", SWS_BICUBIC | BX, tune=dict(no_mixed=1))[0] == "main:fused_generic_unity"
+
+
+@pytest.mark.parametrize("src", ["yuv420p", "nv12", "nv21", "yuv410p", "yuv440p", "yuvj420p", "yuv411p"])
+@pytest.mark.parametrize("dst", DST)
+def test_same_size_one_pass(src, dst):
+    """sws_k_mixed_join422: vertical chroma filters of every scaler, odd heights, one-row pictures, host frames, sources with other horizontal chroma steps (not its shape)"""
+    from librempeg_amd import SWS_GAUSS, SWS_SPLINE, SWS_SINC, SWS_POINT
+    for (w, h) in ((256, 64), (1920, 1080), (640, 37), (64, 1), (32, 2), (3840, 6)):
+        for fl in (SWS_BICUBIC, SWS_LANCZOS, SWS_AREA, SWS_GAUSS, SWS_SPLINE, SWS_SINC, SWS_POINT, SWS_BICUBIC | AR):
+            if (w, h) == (1920, 1080) and fl not in (SWS_BICUBIC, SWS_LANCZOS):
+                continue
+            r = run_case(w, h, src, w, h, dst, fl | BX, seed=w + h, tune=TUNE)
+            if fl == SWS_BICUBIC and src in ("yuv420p", "nv12", "nv21") and h > 2:
+                assert r[0] == "main:mixed_join422", (r[0], src, dst, w, h)
+    run_case(1280, 720, src, 1280, 720, dst, SWS_BICUBIC | BX, seed=5, device_frames=False)
+    opts = dict(dither=1, src_range=0, dst_range=0, src_h_chr_pos=-513, src_v_chr_pos=128, dst_h_chr_pos=-513, dst_v_chr_pos=-513, threads=1)
+    run_case(640, 48, src, 640, 48, dst, SWS_BICUBIC | BX, seed=6, opts=opts)
 
 
 def test_full_size_batches_and_host_frames():
     import torch
     import oracle_lib as OL
     from librempeg_amd import SwsContext, HostFrame, DeviceFrame
-    assert run_case(1920, 1080, "yuv420p", 1920, 1080, "yuyv422", SWS_BICUBIC | BX, seed=2)[0].endswith("+join422")
+    assert run_case(1920, 1080, "yuv420p", 1920, 1080, "yuyv422", SWS_BICUBIC | BX, seed=2)[0] == "main:mixed_join422"
+    assert run_case(3840, 2160, "nv12", 3840, 2160, "uyvy422", SWS_BICUBIC | BX, seed=7)[0] == "main:mixed_join422"
     assert run_case(1920, 1080, "yuv420p", 1280, 720, "uyvy422", SWS_BICUBIC | BX, seed=3, device_frames=False)[0].endswith("+join422")
     assert run_case(1920, 1080, "bgra", 1280, 720, "yuyv422", SWS_BICUBIC | BX, seed=4)[0].endswith("+join422")
     for src, dst, sw, sh, dw, dh, n, flags in (("yuv420p", "yuyv422", 1284, 70, 1028, 56, 5, SWS_BICUBIC | BX), ("nv12", "uyvy422", 1024, 64, 1024, 64, 3, SWS_BICUBIC | BX)):
@@ -62,7 +84,7 @@ def test_full_size_batches_and_host_frames():
         for rep in range(2):
             assert p.scale_frames(srcs, dsts) == n
             p.sync()
-            assert p.path().endswith("+join422"), p.path()
+            assert p.path().endswith("join422"), p.path()
             for k in range(n):
                 out = dsts[k].download()
                 for a, b, rb in zip(out.planes, refs[k].planes, out.row_bytes):
