@@ -22,9 +22,6 @@ void launch_layout_split422(const LaunchCtx &L, bool uyvy, bool vfirst);   // k_
 void launch_layout_splitnv(const LaunchCtx &L, bool vfirst);   // k_layout.hip: plane 1 of a semi-planar 8-bit picture -> planar U / V working planes
 void launch_layout_splitp01x(const LaunchCtx &L, int shift);   // k_layout.hip: p010-style planes -> planar working picture, words >> shift
 void launch_alpha_merge32(const LaunchCtx &L);                 // k_stream.hip: the alpha bytes behind sws_k_strip_rgb (alpha_launch == 2)
-void launch_gray_chroma(const LaunchCtx &L);                   // k_stream.hip: the chroma planes of a gray source in a YUV destination
-int  launch_mixed_join422(const LaunchCtx &L, bool uyvy);        // k_stream.hip: 1 = the mixed plan and its interleave ran as one pass
-bool fullchr_gray_const(const LaunchCtx &L);                   // k_stream.hip: ... or no launch: the full-chroma RGB epilogue computes the constants itself
 void launch_layout_join422(const LaunchCtx &L, bool uyvy);   // k_layout.hip: planar 4:2:2 working picture -> yuyv422 / uyvy422 (yvyu422: planes swapped by the planner)
 
 // the plan geometries of a fresh state start out as zeros (`new DeviceState()` runs the default member initialisers and leaves members without one as the
@@ -298,6 +295,40 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     std::memset(&p, 0, sizeof(p));
     const SwsContext &o = c->opts;
     const PixDesc *ds = pix_desc(o.src_format), *dd = pix_desc(o.dst_format);
+    // SWS_FAST_BILINEAR on 8-bit lines (ff_hyscale_fast_c / ff_hcscale_fast_c, hscale_fast_bilinear.c:23-55: dst = a (128 - xalpha) + b xalpha for luma and alpha,
+    // a (127 - xalpha) + b xalpha for chroma, with xalpha = the top 7 bits of the 16-bit position fraction; the columns at and behind the last source sample: 128 x that
+    // sample) is hScale8To15_c over a two-tap bank with the taps {(128 - xalpha) << 7, xalpha << 7} (chroma: {(xalpha ^ 127) << 7, xalpha << 7}) -- the sum's low 7 bits
+    // are zero, so the >> 7 is exact and the 15-bit clip never acts.  Round 5: every plan below is made on these banks (hLumB / hChrB), which puts the strip kernels
+    // behind the flag that players and capture tools pass most often (4K -> 1080p yuv420p: 0.090 ms per frame on the two-pass kernels, 0.012 with SWS_BILINEAR);
+    // same widths give one-tap banks (chroma: 127 << 7, the reference's own quirk).  The context's banks stay what build_filter_bank() made (sws_hip_get_filter, the blob).
+    FilterBank fastL, fastC;
+    const bool fast_banks = c->plan == PLAN_MAIN && (o.flags & SWS_FAST_BILINEAR) && c->srcBpc == 8 && c->dstBpc <= 14 && !c->tune.no_fast_banks && o.src_w >= 2 && c->chrSrcW >= 2;
+    if (fast_banks) {
+        auto make = [](FilterBank &fb, int dstW, int srcW, int xInc, bool chroma) {
+            std::vector<int32_t> pos((size_t)dstW); std::vector<int16_t> t0((size_t)dstW), t1((size_t)dstW);
+            bool two = false;
+            for (int x = 0; x < dstW; x++) {
+                const uint32_t xpos = (uint32_t)x * (uint32_t)xInc;
+                const int xx = (int)(xpos >> 16), xalpha = (int)((xpos & 0xFFFF) >> 9);
+                if (xx >= srcW - 1) { pos[(size_t)x] = srcW - 1; t0[(size_t)x] = 1 << 14; t1[(size_t)x] = 0; }
+                else { pos[(size_t)x] = xx; t0[(size_t)x] = (int16_t)((chroma ? (xalpha ^ 127) : 128 - xalpha) << 7); t1[(size_t)x] = (int16_t)(xalpha << 7); two = two || xalpha; }
+            }
+            fb.size = two ? 2 : 1; fb.count = dstW;
+            fb.pos.assign((size_t)dstW + 3, 0); fb.taps.assign(((size_t)dstW + 3) * (size_t)fb.size, 0);
+            for (int x = 0; x < dstW + 3; x++) {        // (+ 3 replicated rows like build_filter_bank's)
+                const size_t q = (size_t)std::min(x, dstW - 1);
+                int ps = pos[q]; int16_t a = t0[q], b = t1[q];
+                if (two && ps >= srcW - 1) { ps = srcW - 2; b = a; a = 0; }       // (the window of two taps ends inside the row: the last sample is its second tap)
+                fb.pos[(size_t)x] = ps; fb.taps[(size_t)x * (size_t)fb.size] = a;
+                if (two) fb.taps[(size_t)x * 2 + 1] = b;
+            }
+        };
+        make(fastL, o.dst_w, o.src_w, c->lumXInc, false);
+        make(fastC, c->chrDstW, c->chrSrcW, c->chrXInc, true);
+    }
+    const FilterBank &hLumB = fast_banks ? fastL : c->hLum, &hChrB = fast_banks ? fastC : c->hChr;
+    bool striprgb_short = false;     // (the strip-RGB plan carries the packed writers' short forms in its taps and rounding offsets: below)
+    const bool fast_flag = (o.flags & SWS_FAST_BILINEAR) && !fast_banks;     // (the flag with the fast functions still in the kernels: the element-per-thread readers)
     p.srcW = o.src_w; p.srcH = o.src_h; p.dstW = o.dst_w; p.dstH = o.dst_h;
     p.chrSrcW = c->chrSrcW; p.chrSrcH = c->chrSrcH; p.chrDstW = c->chrDstW; p.chrDstH = c->chrDstH;
     p.chrSrcHSub = c->chrSrcHSubSample; p.chrSrcVSub = c->chrSrcVSubSample;
@@ -346,7 +377,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     //      nvXXtoUV_c (input.c:926-948) de-interleaves bytes, so the chroma plane is split into planar working planes first and the conversion takes the
     //      strip kernel with the RGB epilogue like a planar source (planar / semi-planar destinations: the strip kernel de-interleaves while staging) ----
     if (c->plan == PLAN_MAIN && p.srcKind == SRCK_NV12 && c->srcBpc == 8 && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !((o.flags & SWS_FULL_CHR_H_INT)) &&
-        !(bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14)) && !gray_any && !(o.flags & SWS_SRC_V_CHR_DROP_MASK) && !(o.flags & SWS_FAST_BILINEAR) &&
+        !(bank_is_identity(hLumB, 1 << 14) && bank_is_identity(hChrB, 1 << 14)) && !gray_any && !(o.flags & SWS_SRC_V_CHR_DROP_MASK) && !fast_flag &&
         !c->tune.no_mixed && !c->tune.no_layout_stream && !c->tune.no_strip) {
         d->split_mode = 8 | (p.uv_swap_src ? 16 : 0);
         p.srcKind = SRCK_PLANAR8;
@@ -356,7 +387,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     //  shifted down, luma included, and take the 16-bit instantiation of that kernel)
     //  (same-size pictures too -- a hardware decoder's p010 into RGB for display: the 16-bit instantiation takes identity horizontal filters as one-tap banks)
     if (c->plan == PLAN_MAIN && p.srcKind == SRCK_P010 && p.src_depth <= 15 && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !((o.flags & SWS_FULL_CHR_H_INT)) &&
-        !gray_any && !(o.flags & SWS_SRC_V_CHR_DROP_MASK) && !(o.flags & SWS_FAST_BILINEAR) &&
+        !gray_any && !(o.flags & SWS_SRC_V_CHR_DROP_MASK) && !fast_flag &&
         !c->tune.no_mixed && !c->tune.no_layout_stream && !c->tune.no_strip) {
         d->split_mode = 32; d->split_shift = p.src_shift;
         p.srcKind = SRCK_PLANAR16; p.src_shift = 0;
@@ -387,12 +418,12 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     // (the same for a planar YUV destination with an alpha plane -- bgra -> yuva420p, yuva444p10le -> yuva420p: the A samples through the luma filters
     //  and the luma plane's writer into dst[3], swscale.c:478-486 / vscale.c:66-70; decided with the strip plan below)
     const bool alpha_planar = c->plan == PLAN_MAIN && c->needAlpha && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && isPlanarYUV(o.dst_format) &&
-                              !isGray(o.src_format) && !(o.flags & SWS_FAST_BILINEAR) && !c->tune.no_strip && !c->tune.no_mixed &&
+                              !isGray(o.src_format) && !fast_flag && !c->tune.no_strip && !c->tune.no_mixed &&
                               ((p.srcKind == SRCK_RGB32 && !(o.src_w & 3)) || ((p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_PLANAR16) && isPlanarYUV(o.src_format)));
     d->alpha_launch = 0;
     // (filters of more than 16 taps -- ratios of 4:1 and more -- have the strip kernel's long form with 128-column strips on one side and the element-per-thread
     //  kernels on the other: the planner's width threshold for them is 64 columns)
-    const bool long_taps = c->plan == PLAN_MAIN && (c->hLum.size >= 16 || c->hChr.size >= 16 || c->vLum.size >= 16 || c->vChr.size >= 24);   // (padded to an even start: 16 taps already take 9 pairs)
+    const bool long_taps = c->plan == PLAN_MAIN && (hLumB.size >= 16 || hChrB.size >= 16 || c->vLum.size >= 16 || c->vChr.size >= 24);   // (padded to an even start: 16 taps already take 9 pairs)
     const int strip_min_w_eff = long_taps ? std::min(c->tune.strip_min_w, 64) : c->tune.strip_min_w;   // (one strip of the long forms: thumbnails of 160 x 90 from 1080p are 0.05 ms on the two-pass kernels)
     const bool fc_plain = !isGray(o.src_format) && !isGray(o.dst_format) && p.srcKind != SRCK_MONO;
     d->fullchr_on = 0;
@@ -400,7 +431,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     //  reference's constant chroma lines; a gray source counts as 4:4:4, so it is the full-chroma route unless the caller's flags say otherwise)
     const bool lut_gray = isGray(o.src_format) && !isALPHA(o.src_format) && !c->needAlpha && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_PLANAR16) && !c->tune.no_strip_range && !p.wide &&
                           (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32);
-    if (c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP) && p.full_chr && (!c->needAlpha || fc_alpha) && (fc_plain || lut_gray) && !(o.flags & SWS_FAST_BILINEAR) &&
+    if (c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP) && p.full_chr && (!c->needAlpha || fc_alpha) && (fc_plain || lut_gray) && !fast_flag &&
         o.dst_w >= strip_min_w_eff && !c->tune.no_strip && !c->tune.no_mixed) {
         d->fullchr_on = c->needAlpha ? 2 : 1; d->fullchr_kind = p.dstKind;
         p.dstKind = DSTK_RAW32; p.u_plane_dst = 1; p.v_plane_dst = 2;
@@ -414,7 +445,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     const bool lut_kind = !c->tune.no_rgbread_kinds && !isALPHA(o.src_format) &&
                           ((p.srcKind == SRCK_PACKEDHI && p.src_depth >= 9 && p.src_depth <= 15 && c->srcBpc == p.src_depth) || (p.srcKind == SRCK_PACKED444 && p.src_depth == 8 && c->srcBpc == 8));
     if (!d->fullchr_on && c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr && (long_taps || lut_u16 || lut_kind || lut_gray) && !c->needAlpha && (fc_plain || lut_gray) &&
-        !(o.flags & SWS_FAST_BILINEAR) && !(o.dst_w & 1) && o.dst_w >= strip_min_w_eff && !c->tune.no_strip && !c->tune.no_mixed) {
+        !fast_flag && !(o.dst_w & 1) && o.dst_w >= strip_min_w_eff && !c->tune.no_strip && !c->tune.no_mixed) {
         d->fullchr_on = 3; d->fullchr_kind = p.dstKind;
         p.dstKind = DSTK_RAW32; p.u_plane_dst = 1; p.v_plane_dst = 2;
     }
@@ -546,7 +577,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     p.src_alpha_opaque = c->src0Alpha && !c->dst0Alpha && isALPHA(o.dst_format);
     p.dst_alpha_fill = isALPHA(o.dst_format) && isPlanarFmt(o.dst_format) && !c->needAlpha;
     p.no_chroma = isGray(o.src_format) || isGray(o.dst_format) || p.srcKind == SRCK_MONO;                              // swscale.c:692-694
-    p.fast_bilinear = (o.flags & SWS_FAST_BILINEAR) && c->srcBpc == 8 && c->dstBpc <= 14;   // swscale.c:676-681
+    p.fast_bilinear = (o.flags & SWS_FAST_BILINEAR) && c->srcBpc == 8 && c->dstBpc <= 14 && !fast_banks;   // swscale.c:676-681
     p.lumXInc = c->lumXInc; p.chrXInc = c->chrXInc;
     p.copy_depth_src = ds->comp[0].depth; p.copy_depth_dst = dd->comp[0].depth;
     p.copy_shift_src = ds->comp[0].shift; p.copy_shift_dst = dd->comp[0].shift;
@@ -564,8 +595,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     //  writer's X form over the sums; rows in the writer's _1 / _2 forms keep the old kernels like the other packed kinds)
     const bool wide_gbrp = (((p.dstKind == DSTK_GBRP16 || p.dstKind == DSTK_GBRPF32) && !isALPHA(o.dst_format)) || p.dstKind == DSTK_RGB48) && p.wide && c->dstBpc >= 16 && !c->tune.no_strip_wide;
     if (!d->fullchr_on && c->plan == PLAN_MAIN && (((p.dstKind == DSTK_RGB16 || p.dstKind == DSTK_RGB30 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI) && !p.wide &&
-        c->dstBpc <= 14) || wide_gbrp) && !c->needAlpha && fc_plain && !(o.flags & SWS_FAST_BILINEAR) && !(o.dst_w & 3) && o.dst_w >= strip_min_w_eff && c->chrDstVSubSample == 0 &&
-        !(bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14)) &&   // (identity horizontal filters: the single-pass per-kind kernels are as fast or faster -- no sum planes)
+        c->dstBpc <= 14) || wide_gbrp) && !c->needAlpha && fc_plain && !fast_flag && !(o.dst_w & 3) && o.dst_w >= strip_min_w_eff && c->chrDstVSubSample == 0 &&
+        !(bank_is_identity(hLumB, 1 << 14) && bank_is_identity(hChrB, 1 << 14)) &&   // (identity horizontal filters: the single-pass per-kind kernels are as fast or faster -- no sum planes)
         !c->tune.no_strip && !c->tune.no_mixed && !(c->tune.no_rgbread_kinds & 2)) {
         d->fullchr_on = 4; d->fullchr_kind = p.dstKind;
         p.dstKind = DSTK_RAW32; p.u_plane_dst = 1; p.v_plane_dst = 2;
@@ -573,7 +604,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     // ---- filter tables -> one device blob ----
     d->unity_h = false;
     if (c->plan == PLAN_MAIN) {
-        const FilterBank *banks[4] = { &c->hLum, &c->hChr, &c->vLum, &c->vChr };
+        const FilterBank *banks[4] = { &hLumB, &hChrB, &c->vLum, &c->vChr };
         size_t off = 0, offs_t[4], offs_p[4];
         auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
         for (int i = 0; i < 4; i++) {
@@ -588,12 +619,12 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         }
         { int r_ = table_put(c, d, d->d_tables, host.data(), off); if (r_ < 0) return r_; }
         uint8_t *b = (uint8_t *)d->d_tables;
-        p.hLumF = (const int16_t *)(b + offs_t[0]); p.hLumPos = (const int32_t *)(b + offs_p[0]); p.hLumFs = c->hLum.size;
-        p.hChrF = (const int16_t *)(b + offs_t[1]); p.hChrPos = (const int32_t *)(b + offs_p[1]); p.hChrFs = c->hChr.size;
+        p.hLumF = (const int16_t *)(b + offs_t[0]); p.hLumPos = (const int32_t *)(b + offs_p[0]); p.hLumFs = hLumB.size;
+        p.hChrF = (const int16_t *)(b + offs_t[1]); p.hChrPos = (const int32_t *)(b + offs_p[1]); p.hChrFs = hChrB.size;
         p.vLumF = (const int16_t *)(b + offs_t[2]); p.vLumPos = (const int32_t *)(b + offs_p[2]); p.vLumFs = c->vLum.size;
         p.vChrF = (const int16_t *)(b + offs_t[3]); p.vChrPos = (const int32_t *)(b + offs_p[3]); p.vChrFs = c->vChr.size;
         // the fast-bilinear chroma function weighs with (xalpha ^ 127): not the identity even at equal widths
-        d->unity_h = bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->hChr, 1 << 14) && !p.fast_bilinear;
+        d->unity_h = bank_is_identity(hLumB, 1 << 14) && bank_is_identity(hChrB, 1 << 14) && !p.fast_bilinear;
         d->unity_v = bank_is_identity(c->vLum, 1 << 12) && bank_is_identity(c->vChr, 1 << 12);
         // ---- contexts whose result depends on the reference's line schedule (build_vlines): the two-pass path over virtual lines ----
         d->vlines_on = false; c->gamma_in_reader = false; d->mixed_ok = false;
@@ -745,9 +776,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                                    (((p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && !p.wide) || (p.dstKind == DSTK_PLANAR16 && wide_dst)) && !c->tune.no_strip);
             // identity luma filters + scaled chroma (yuv422p -> yuv420p, yuv444p -> yuv420p, the 10-bit -> 8-bit twins ...): the luma plane streams
             // (one tap: a per-sample pass), only the chroma planes need the strip kernel
-            const bool mixedM = !vlines_pending && !d->fullchr_on && bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !(d->unity_h && d->unity_v) &&
+            const bool mixedM = !vlines_pending && !d->fullchr_on && bank_is_identity(hLumB, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !(d->unity_h && d->unity_v) &&
                                 !p.fast_bilinear && !gray_any && (src_ok || nv_src) && dst_ok && !p.wide && (!p.range_active || (c->srcBpc == 8 && p.dst_bits == 8 && !c->tune.no_strip_range)) && !p.dst_alpha_fill &&
-                                fs2(c->hChr.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long) && !c->tune.no_strip && !c->tune.no_mixed && p.dstW >= c->tune.strip_min_w;
+                                fs2(hChrB.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long) && !c->tune.no_strip && !c->tune.no_mixed && p.dstW >= c->tune.strip_min_w;
             // (identity horizontal filters: 8-bit sources have kernels of their own -- sws_k_rgb_march, sws_k_rgbsrc_unity, the mixed plan -- but a 10-bit
             //  picture into packed RGB (decoded HDR for display) or packed RGB into a 10-bit 4:2:0 picture at the same size had only the generic
             //  kernels: the strip kernels take them with their one-tap horizontal banks)
@@ -758,10 +789,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             const bool unity_ok = !d->unity_h || (rgb_ok && rgb_s16) || (rgbread && !d->rgbsrc_ok && !d->rgb444_ok) || unity_yuv;   // (sws_k_rgbsrc_unity's row table lives in the same device block as the strip plan)
             // filters of 17 .. 32 taps (ratios of 4:1 and more -- the lower rungs of an ABR ladder, thumbnails: bicubic at 4:1 has 17 taps, at 6:1 25; Lanczos at
             // 3:1 19): the strip kernel's long form (sws_k_strip_long: 16 tap pairs each way, strips of 128 / 64 columns); the RGB epilogue stops at 16
-            const bool fs_ok16 = fs2(c->hLum.size) <= 16 && (fs2(c->hChr.size) <= 16 || gray_both) && fs2(c->vLum.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long || gray_both);
-            const bool fs_ok32 = fs2(c->hLum.size) <= 32 && fs2(c->hChr.size) <= 32 && fs2(c->vLum.size) <= 32 && fs2(c->vChr.size) <= 48 && dst_ok && !rgb_ok && !gray_both &&
+            const bool fs_ok16 = fs2(hLumB.size) <= 16 && (fs2(hChrB.size) <= 16 || gray_both) && fs2(c->vLum.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long || gray_both);
+            const bool fs_ok32 = fs2(hLumB.size) <= 32 && fs2(hChrB.size) <= 32 && fs2(c->vLum.size) <= 32 && fs2(c->vChr.size) <= 48 && dst_ok && !rgb_ok && !gray_both &&
                                  !c->tune.no_strip && !c->tune.no_mixed;
-            const bool fs_ok64 = fs2(c->hLum.size) <= 64 && fs2(c->hChr.size) <= 64 && fs2(c->vLum.size) <= 64 && fs2(c->vChr.size) <= 64 && dst_ok && !rgb_ok && !gray_both &&
+            const bool fs_ok64 = fs2(hLumB.size) <= 64 && fs2(hChrB.size) <= 64 && fs2(c->vLum.size) <= 64 && fs2(c->vChr.size) <= 64 && dst_ok && !rgb_ok && !gray_both &&
                                  !c->tune.no_strip && !c->tune.no_mixed;      // (33 .. 62 taps: the extra-long form, 32 pairs each way on strips of 64 columns)
             const bool wide_ok = wide_dst && (src_ok || nv_src || src_u16 || rgbread) && !(p.range_active && c->tune.no_strip_range) && !c->needAlpha && !p.need_alpha && !p.fast_bilinear && !vlines_pending && fs_ok16 &&
                                  !(p.srcKind == SRCK_PLANAR8 && c->srcBpc != 8);
@@ -771,7 +802,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             d->mixed_ok = false; d->stripLs_ok = d->stripCs_ok = false; d->striprgbsrc_ok = false; d->rgb2rgb_ok = false;
             // (a gray source into planar / semi-planar YUV at the same size -- a monochrome camera into an encoder: the luma plane is the mixed plan's streaming pass, the
             //  chroma planes are sws_k_gray_chroma's constants; no strip plan at all.  launch_mixed tells the two by the source format)
-            const bool gray_mixed = gray_src && !vlines_pending && !d->fullchr_on && bank_is_identity(c->hLum, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !p.fast_bilinear && src_ok && dst_ok &&
+            const bool gray_mixed = gray_src && !vlines_pending && !d->fullchr_on && bank_is_identity(hLumB, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !p.fast_bilinear && src_ok && dst_ok &&
                                     p.dstKind != DSTK_RAW32 && !p.wide && (!p.range_active || (c->srcBpc == 8 && p.dst_bits == 8)) && !p.dst_alpha_fill && !c->tune.no_mixed;
             if (gray_mixed) d->mixed_ok = true;
             else if (fullA || mixedM) {
@@ -825,6 +856,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 // plane1_form: the plane's writer has the reference's one-tap form (yuv2plane1_*, yuv2p01xl1_c: (s + d) >> 7 and its N-bit twins), which
                 // never looks at the coefficient -- initFilter's error-diffused normalisation leaves 4095 in some one-tap rows -- so a one-tap bank
                 // enters the X arithmetic as 4096; the semi-planar chroma writers (yuv2nv12cX_c, yuv2p01xcX_c) have no such form and take the bank's value
+                const std::vector<int32_t> *plan_rnd = nullptr;      // per output row: SwsStripRow::rnd_off of the plans made while it is set (the packed writers' short forms below)
                 auto plan3 = [&](const FilterBank &hb, const FilterBank &vb, int W, int cols, int ncomp, SwsStripGeom &g, SOff &o, int (*ring_of)(int) = nullptr, bool plane1_form = false, int longf = 0, int tw_over = 0) -> bool {   // longf: 1 the long form (16 / 24 pairs), 2 the extra-long one (32 / 32); tw_over: strips narrower than 64 * cols columns (the lockstep kernels: a window that fits one reader turn less)
                     const int TW = tw_over ? tw_over : 64 * cols, hf2 = fs2(hb.size), vf2 = fs2(vb.size);
                     const int strips = (W + TW - 1) / TW;
@@ -861,6 +893,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     for (int y = 0; y < vb.count; y++) {
                         SwsStripRow &e = rows[(size_t)y * epr];
                         e.pf = (vb.pos[y] & ~1) >> 1;
+                        if (plan_rnd && (size_t)y < plan_rnd->size()) e.rnd_off = (*plan_rnd)[(size_t)y];
                         const int lead = ring_of ? 2 * (ring_of(npv) - npv) : 0;
                         if (lead < 0) return false;
                         for (int j = 0; j < vb.size; j++) {
@@ -963,11 +996,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     }
                     return chroma ? 1 : 2;
                 };
-                const int wcl = p.wide ? wide_cols(c->hLum, c->vLum, p.dstW, false) : 0, wcc = (p.wide && !gray_both) ? wide_cols(c->hChr, c->vChr, p.chrDstW, true) : 0;
+                const int wcl = p.wide ? wide_cols(hLumB, c->vLum, p.dstW, false) : 0, wcc = (p.wide && !gray_both) ? wide_cols(hChrB, c->vChr, p.chrDstW, true) : 0;
                 const bool strip_plan = fullA && dst_ok && !(p.range_active && c->tune.no_strip_range) && !c->tune.no_strip && p.dstW >= (long_form ? strip_min_w_eff : strip_min_w) &&   // (the long form's strips are 128 columns, and what it replaces is the element-per-thread tile kernel)
-                                        plan3(c->hLum, c->vLum, p.dstW, p.wide ? wcl : long_form == 2 ? 1 : long_form ? 2 : strip_cols_l, 1, d->stripL, sL,
+                                        plan3(hLumB, c->vLum, p.dstW, p.wide ? wcl : long_form == 2 ? 1 : long_form ? 2 : strip_cols_l, 1, d->stripL, sL,
                                               p.wide ? +[](int n) { return n <= 2 ? 2 : n <= 4 ? 4 : 8; } : long_form == 2 ? +[](int) { return 32; } : nullptr, lum_plane1, long_form) &&
-                                        (gray_both || plan3(c->hChr, c->vChr, p.chrDstW, p.wide ? wcc : long_form ? 1 : strip_cols_c, 2, d->stripC, sC,
+                                        (gray_both || plan3(hChrB, c->vChr, p.chrDstW, p.wide ? wcc : long_form ? 1 : strip_cols_c, 2, d->stripC, sC,
                                                             p.wide ? +[](int n) { return n <= 2 ? 2 : n <= 4 ? 4 : 8; } : long_form == 2 ? +[](int) { return 32; } : long_form ? +[](int) { return 24; } : nullptr, chr_plane1, long_form)) &&
                                         (!p.wide || (d->stripL.NCmax / SPC <= 64 && (gray_both || d->stripC.NCmax / SPC <= 64)));      // (the wide kernel stages one chunk per lane and row)
                 d->strip_ok = false;
@@ -976,10 +1009,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 Off oL, oC;
                 if (mixedM) {
                     SOff sM;
-                    if (plan3(c->hChr, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sM, nullptr, chr_plane1)) {
-                        const std::vector<int16_t> htc = padded(c->hChr);
+                    if (plan3(hChrB, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sM, nullptr, chr_plane1)) {
+                        const std::vector<int16_t> htc = padded(hChrB);
                         const size_t ohc = put(htc.data(), htc.size() * 2);
-                        const bool altC = plan3_alt(c->hChr, c->vChr, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
+                        const bool altC = plan3_alt(hChrB, c->vChr, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
                         { int r_ = table_alloc(c, &d->d_dot2, &d->dot2_bytes, blob.size()); if (r_ < 0) return r_; }
                         { int r_ = table_put(c, d, d->d_dot2, blob.data(), blob.size()); if (r_ < 0) return r_; }
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
@@ -1001,16 +1034,37 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     const int rcl = (c->tune.strip_rgb_cols == 2 || rgb_s16) ? 2 : 4;
                     // (one vertical tap each: yuv2rgb_1_c_template's (buf + 64) >> 7 -- the coefficient is never looked at -- is the X arithmetic with the tap 4096)
                     const bool rgb_one_one = c->vLum.size == 1 && c->vChr.size == 1;
-                    const bool pl = plan3(c->hLum, c->vLum, p.dstW, rcl, 1, gl, rL, ringL, rgb_one_one), pc = pl && plan3(c->hChr, c->vChr, p.chrDstW, rcl / 2, 2, gc, rC, ringC, rgb_one_one);
+                    // The writers' short forms (packed_vscale, vscale.c:135-157, picks per output row): one luma tap with two chroma taps that sum to 4096 is yuv2rgb_1_c_template
+                    // with a chroma blend -- (u0 (4096 - a) + u1 a + (128 << 11)) >> 19, output.c:1913-1937: the X arithmetic on the bank's own taps, the luma tap
+                    // taken as 4096; two taps each that sum to 4096 (bilinear up-scaling: a player's 720p -> 1080p into bgra) is yuv2rgb_2_c_template, the X
+                    // arithmetic without the rounding constant (SwsStripRow::rnd_off).  Round 5; not with an alpha plane (its own formulas there).
+                    FilterBank vLumS, vChrS;
+                    std::vector<int32_t> rnd_rows;
+                    bool short_rows = false;
+                    if (!rgb_one_one && !c->needAlpha && !c->tune.no_short_forms && p.chrDstH == p.dstH && (c->vLum.size == 1 || c->vLum.size == 2) && c->vChr.size == 2) {
+                        vLumS = c->vLum; vChrS = c->vChr;
+                        rnd_rows.assign((size_t)o.dst_h, 0);
+                        for (int y = 0; y < o.dst_h; y++) {
+                            int16_t *lf = &vLumS.taps[(size_t)y * vLumS.size], *cf = &vChrS.taps[(size_t)y * 2];
+                            const bool csum = (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U;
+                            if (vLumS.size == 1 && csum) { lf[0] = 4096; short_rows = true; }      // (the X arithmetic as it is: the blend rounds with 128 << 11 == 1 << 18)
+                            else if (vLumS.size == 2 && csum && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U) { rnd_rows[(size_t)y] = 1 << 18; short_rows = true; }
+                        }
+                    }
+                    const FilterBank &vLumR = short_rows ? vLumS : c->vLum, &vChrR = short_rows ? vChrS : c->vChr;
+                    striprgb_short = short_rows;
+                    plan_rnd = short_rows ? &rnd_rows : nullptr;
+                    const bool pl = plan3(hLumB, vLumR, p.dstW, rcl, 1, gl, rL, ringL, rgb_one_one || vLumR.size == 1), pc = pl && plan3(hChrB, vChrR, p.chrDstW, rcl / 2, 2, gc, rC, ringC, rgb_one_one);
+                    plan_rnd = nullptr;
                     log_msg(c, 3, "strip_rgb plan: luma %d chroma %d strips %d/%d window %d/%d nph %d/%d npv %d/%d chrDstH %d dstH %d\n", pl, pc, gl.strips, gc.strips,
                             gl.NCmax, gc.NCmax, gl.nph, gc.nph, gl.npv, gc.npv, p.chrDstH, p.dstH);
                     SOff sA;
                     const bool wantA = p.need_alpha != 0;     // (rgb_ok: then rgb_alpha holds)
                     // (not the one-tap form: yuv2rgb_1_c_template's alpha is (a * 255 + 16384) >> 15, output.c:1904, not the X arithmetic)
-                    const bool pa = !wantA || (!rgb_one_one && plan3(c->hLum, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sA, nullptr, false));   // the plain luma launch, the X form's own taps
+                    const bool pa = !wantA || (!rgb_one_one && plan3(hLumB, c->vLum, p.dstW, strip_cols_l, 1, d->stripL, sA, nullptr, false));   // the plain luma launch, the X form's own taps
                     if (pl && pc && pa && gl.strips == gc.strips &&
                         gl.NCmax / SPC <= 64 && gc.NCmax / SPC <= 64 && std::max(gl.nph, gc.nph) <= 8 && gl.npv <= 8 && gc.npv <= 8 && p.chrDstH == p.dstH) {
-                        const std::vector<int16_t> htl = padded(c->hLum), htc = padded(c->hChr);
+                        const std::vector<int16_t> htl = padded(hLumB), htc = padded(hChrB);
                         const size_t ohl = put(htl.data(), htl.size() * 2), ohc = put(htc.data(), htc.size() * 2);
                         // LDS-DMA form (kernels_striprgb.hpp sws_k_strip_rgb8): 8-bit planar sources, no source row pair skipped in either plane class;
                         // its tap rows start at the filter's own first tap (no even-position padding)
@@ -1027,7 +1081,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                             off = put(t8.data(), t8.size() * 2);
                         };
                         size_t o8l = 0, o8c = 0;
-                        dma8_plan(c->hLum, c->vLum, gl, o8l); dma8_plan(c->hChr, c->vChr, gc, o8c);
+                        dma8_plan(hLumB, vLumR, gl, o8l); dma8_plan(hChrB, vChrR, gc, o8c);
                         if (!gl.dma8_ok || !gc.dma8_ok) gl.dma8_ok = gc.dma8_ok = 0;
                         { int r_ = table_alloc(c, &d->d_dot2, &d->dot2_bytes, blob.size()); if (r_ < 0) return r_; }
                         { int r_ = table_put(c, d, d->d_dot2, blob.data(), blob.size()); if (r_ < 0) return r_; }
@@ -1058,10 +1112,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     }
                 } else
                 {
-                  const bool tiles = !gray_both && !long_form && plan2(c->hLum, c->vLum, p.dstW, p.dstH, 1, d->dotL, oL) && plan2(c->hChr, c->vChr, p.chrDstW, p.chrDstH, 2, d->dotC, oC);
+                  const bool tiles = !gray_both && !long_form && plan2(hLumB, c->vLum, p.dstW, p.dstH, 1, d->dotL, oL) && plan2(hChrB, c->vChr, p.chrDstW, p.chrDstH, 2, d->dotC, oC);
                   size_t ohl = 0, ohc = 0;
-                  const bool altL = strip_plan && !long_form && !p.wide && plan3_alt(c->hLum, c->vLum, p.dstW, 1, d->stripL, d->stripLs, sLs);
-                  const bool altC = strip_plan && !long_form && !p.wide && !gray_both && plan3_alt(c->hChr, c->vChr, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
+                  const bool altL = strip_plan && !long_form && !p.wide && plan3_alt(hLumB, c->vLum, p.dstW, 1, d->stripL, d->stripLs, sLs);
+                  const bool altC = strip_plan && !long_form && !p.wide && !gray_both && plan3_alt(hChrB, c->vChr, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
                   // scaled packed RGB -> packed RGB in one launch (k_striprgb2rgb.hip): the same filters planned once more on strips of 128 columns for both plane
                   // classes (a lane owns the same destination columns of Y, U, V and A).  Luma and chroma share the vertical bank there (same source and destination
                   // heights), which the kernel's lockstep march relies on: checked tap position by tap position
@@ -1074,14 +1128,14 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                   // (strips a little narrower than 128 columns where that brings the widest pixel window down to one reader turn -- 256 pixels: 120 columns at 2:1)
                   int r2r_tw = 128;
                   if (r2r && c->tune.strip_cols_auto) {
-                      const int hm = p.chr_half ? 2 : 1, hfl = fs2(c->hLum.size), hfc = fs2(c->hChr.size);
+                      const int hm = p.chr_half ? 2 : 1, hfl = fs2(hLumB.size), hfc = fs2(hChrB.size);
                       auto widest = [&](int tw) {
                           int npx = 0;
                           for (int x0 = 0; x0 < p.dstW; x0 += tw) {
                               int lo = INT32_MAX, hi = 0;
                               for (int x = x0; x < std::min(p.dstW, x0 + tw); x++) {
-                                  lo = std::min(lo, std::min(c->hLum.pos[x] & ~1, hm * (c->hChr.pos[x] & ~1)));
-                                  hi = std::max(hi, std::max((c->hLum.pos[x] & ~1) + hfl, hm * ((c->hChr.pos[x] & ~1) + hfc)));
+                                  lo = std::min(lo, std::min(hLumB.pos[x] & ~1, hm * (hChrB.pos[x] & ~1)));
+                                  hi = std::max(hi, std::max((hLumB.pos[x] & ~1) + hfl, hm * ((hChrB.pos[x] & ~1) + hfc)));
                               }
                               npx = std::max(npx, ((hi + 7) & ~7) - (lo & ~15));
                           }
@@ -1089,7 +1143,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                       };
                       if (widest(128) > 256) for (int tw : { 124, 120, 116, 112, 104, 96 }) if (widest(tw) <= 256) { r2r_tw = tw; break; }
                   }
-                  r2r = r2r && plan3(c->hLum, c->vLum, p.dstW, 2, 1, d->stripL2, s2l, nullptr, lum_plane1, 0, r2r_tw) && plan3(c->hChr, c->vChr, p.chrDstW, 2, 2, d->stripC2, s2c, nullptr, chr_plane1, 0, r2r_tw) &&
+                  r2r = r2r && plan3(hLumB, c->vLum, p.dstW, 2, 1, d->stripL2, s2l, nullptr, lum_plane1, 0, r2r_tw) && plan3(hChrB, c->vChr, p.chrDstW, 2, 2, d->stripC2, s2c, nullptr, chr_plane1, 0, r2r_tw) &&
                         d->stripL2.strips == d->stripC2.strips && d->stripL2.npv == d->stripC2.npv && std::max(d->stripL2.nph, d->stripC2.nph) <= 8 && d->stripL2.npv <= 8;
                   // the lockstep strip kernel of packed sources into half-width-chroma YUV (k_striprgbsrc.hip) likewise plans for itself: luma strips of up to 256
                   // columns over chroma strips of half as many, a few columns narrower where that brings the widest pixel window down by a reader turn of 256
@@ -1100,13 +1154,13 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                               !c->tune.no_strip_rgbsrc && !alpha_planar && !p.need_alpha && !d->fullchr_on &&
                               p.chrDstW == ((p.dstW + 1) >> 1) && (p.chrDstVSub == 0 ? p.chrDstH == p.dstH : (p.chrDstVSub == 1 && p.chrDstH == ((p.dstH + 1) >> 1)));
                   if (rsrc) {
-                      const int hfl = fs2(c->hLum.size), hfc = fs2(c->hChr.size);
+                      const int hfl = fs2(hLumB.size), hfc = fs2(hChrB.size);
                       auto widest = [&](int tw) {
                           int npx = 0;
                           for (int x0 = 0, s = 0; x0 < p.dstW; x0 += tw, s++) {
                               int lo = INT32_MAX, hi = 0;
-                              for (int x = x0; x < std::min(p.dstW, x0 + tw); x++) { lo = std::min(lo, c->hLum.pos[x] & ~1); hi = std::max(hi, (c->hLum.pos[x] & ~1) + hfl); }
-                              for (int x = s * (tw / 2); x < std::min(p.chrDstW, (s + 1) * (tw / 2)); x++) { lo = std::min(lo, 2 * (c->hChr.pos[x] & ~1)); hi = std::max(hi, 2 * ((c->hChr.pos[x] & ~1) + hfc)); }
+                              for (int x = x0; x < std::min(p.dstW, x0 + tw); x++) { lo = std::min(lo, hLumB.pos[x] & ~1); hi = std::max(hi, (hLumB.pos[x] & ~1) + hfl); }
+                              for (int x = s * (tw / 2); x < std::min(p.chrDstW, (s + 1) * (tw / 2)); x++) { lo = std::min(lo, 2 * (hChrB.pos[x] & ~1)); hi = std::max(hi, 2 * ((hChrB.pos[x] & ~1) + hfc)); }
                               npx = std::max(npx, ((hi + 15) & ~15) - (lo & ~15));
                           }
                           return npx;
@@ -1116,11 +1170,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                           const int turns = (widest(256) + 255) / 256;
                           if (turns > 1) for (int tw : { 248, 240, 232 }) if ((widest(tw) + 255) / 256 < turns) { tw3 = tw; break; }
                       }
-                      rsrc = plan3(c->hLum, c->vLum, p.dstW, 4, 1, d->stripL2, s3l, nullptr, lum_plane1, 0, tw3) && plan3(c->hChr, c->vChr, p.chrDstW, 2, 2, d->stripC2, s3c, nullptr, chr_plane1, 0, tw3 / 2) &&
+                      rsrc = plan3(hLumB, c->vLum, p.dstW, 4, 1, d->stripL2, s3l, nullptr, lum_plane1, 0, tw3) && plan3(hChrB, c->vChr, p.chrDstW, 2, 2, d->stripC2, s3c, nullptr, chr_plane1, 0, tw3 / 2) &&
                              d->stripL2.strips == d->stripC2.strips && std::max(d->stripL2.nph, d->stripC2.nph) <= 8 && d->stripL2.npv <= 8 && d->stripC2.npv <= 12;
                   }
                   if (!tiles && strip_plan) {   // (the strip kernel shares the tile kernel's padded horizontal taps; without a tile plan it gets its own copy)
-                      const std::vector<int16_t> htl = padded(c->hLum, long_form ? d->stripL.hfs2 : 0), htc = gray_both ? std::vector<int16_t>(2, 0) : padded(c->hChr, long_form ? d->stripC.hfs2 : 0);
+                      const std::vector<int16_t> htl = padded(hLumB, long_form ? d->stripL.hfs2 : 0), htc = gray_both ? std::vector<int16_t>(2, 0) : padded(hChrB, long_form ? d->stripC.hfs2 : 0);
                       ohl = put(htl.data(), htl.size() * 2); ohc = put(htc.data(), htc.size() * 2);
                   }
                   if (tiles || strip_plan) {
@@ -1223,8 +1277,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 return false;
             };
             std::vector<int32_t> aL, aC;
-            if (plan(c->hLum, c->vLum, p.dstW, p.dstH, p.srcW, p.srcH, 1, d->tileL, aL) &&
-                plan(c->hChr, c->vChr, p.chrDstW, p.chrDstH, p.chrSrcW, p.chrSrcH, 2, d->tileC, aC)) {
+            if (plan(hLumB, c->vLum, p.dstW, p.dstH, p.srcW, p.srcH, 1, d->tileL, aL) &&
+                plan(hChrB, c->vChr, p.chrDstW, p.chrDstH, p.chrSrcW, p.chrSrcH, 2, d->tileC, aC)) {
                 const size_t bytes = (aL.size() + aC.size()) * sizeof(int32_t);
                 { int r_ = table_alloc(c, &d->d_tilegeom, &d->tilegeom_bytes, bytes); if (r_ < 0) return r_; }
                 std::vector<int32_t> all(aL); all.insert(all.end(), aC.begin(), aC.end());
@@ -1248,7 +1302,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) all_x = false;
             }
             d->all_x_mode = all_x;
-            d->striprgb_ok = d->striprgb_ok && (all_x || (lfs == 1 && cfs == 1));
+            d->striprgb_ok = d->striprgb_ok && (all_x || (lfs == 1 && cfs == 1) || striprgb_short);     // (striprgb_short: the plan's taps and rounding offsets carry the short forms)
             if (d->alpha_launch == 2 && !d->striprgb_ok) d->alpha_launch = 0;
             const bool kind_x = d->fullchr_kind == DSTK_GBRP || d->fullchr_kind == DSTK_PACKEDHI || d->fullchr_kind == DSTK_GBRP16 || d->fullchr_kind == DSTK_GBRPF32;   // (writers with the X form only)
             if (d->fullchr_on && ((!all_x && !(lfs == 1 && cfs == 1) && !kind_x) ||
@@ -2986,7 +3040,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
         { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb }, { "no_strip_range", &c->tune.no_strip_range }, { "no_strip_wide", &c->tune.no_strip_wide }, { "no_wide_epilogue", &c->tune.no_wide_epilogue }, { "no_strip_u16", &c->tune.no_strip_u16 },
         { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_lds_pad_kb", &c->tune.strip_lds_pad_kb }, { "no_striprgb_direct", &c->tune.no_striprgb_direct }, { "no_rgbsrc2", &c->tune.no_rgbsrc2 }, { "no_strip_rgbsrc", &c->tune.no_strip_rgbsrc }, { "no_strip_rgb2rgb", &c->tune.no_strip_rgb2rgb },
-        { "no_strip_short", &c->tune.no_strip_short }, { "no_generic_kinds", &c->tune.no_generic_kinds }, { "no_rgbread_kinds", &c->tune.no_rgbread_kinds }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "strip_short_waves", &c->tune.strip_short_waves },
+        { "no_strip_short", &c->tune.no_strip_short }, { "no_generic_kinds", &c->tune.no_generic_kinds }, { "no_rgbread_kinds", &c->tune.no_rgbread_kinds }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "no_fast_banks", &c->tune.no_fast_banks }, { "no_short_forms", &c->tune.no_short_forms }, { "strip_short_waves", &c->tune.strip_short_waves },
         { "debug", &c->tune.debug },
     };
     for (auto &e : tab)

@@ -112,7 +112,8 @@ struct SwsMarchGeom {       // wave-marching fused kernel (kernels_march.hpp), p
 
 struct SwsStripRow {         // marching strip kernel: the scalars of one output row (64 bytes, fetched with one scalar load)
     int32_t pf;               // first source-row PAIR of the row's vertical window ((vpos & ~1) >> 1)
-    int32_t pad0[3];
+    int32_t rnd_off;          // what the packed writers' rounding constant of this row lacks: 0 (the X forms, yuv2packed1), 1 << 18 for a row that takes yuv2packed2 (no rounding: vscale.c:146-157, output.c:1853-1895)
+    int32_t pad0[2];
     uint32_t vt[8];           // vertical taps as pairs aligned to even source rows, zero beyond the filter
     int32_t pad1[4];
 };

@@ -156,6 +156,9 @@ void launch_fullchr_rgb(const LaunchCtx &L);   // k_stream.hip
 void launch_stage_planes(const LaunchCtx &L, const int row_bytes[4], const int rows[4], bool in);   // k_stream.hip: src[k] -> dst[k] plane copies, one side 16-byte aligned
 int  launch_rgb_read16(const LaunchCtx &L, uint8_t *base, int64_t frame_bytes, int64_t offU, int64_t offV, int strideY, int strideC, int64_t offA, int a_pos);   // k_stream.hip
 int  launch_strip_wide(const LaunchCtx &L, int which);   // k_stripwide.hip: the 19-bit form (destinations of 16 bits per component, int32 sums of the wide planar RGB route)
+void launch_gray_chroma(const LaunchCtx &L);                    // k_stream.hip: the chroma planes of a gray source in a YUV destination (or the chroma sums behind an RGB epilogue)
+bool fullchr_gray_const(const LaunchCtx &L);                    // k_stream.hip: ... or no launch: the full-chroma RGB epilogue computes the constants itself
+int  launch_mixed_join422(const LaunchCtx &L, bool uyvy);       // k_stream.hip: 1 = the mixed plan and its interleave ran as one pass
 int  launch_strip_short(const LaunchCtx &L, const SwsStripGeom &g, int H, bool chroma);   // k_strip2.hip: 1 = launched, 0 = not a shape of the short family
 int  launch_strip_luma(const LaunchCtx &L);      // k_strip.hip: the luma launch alone (the alpha plane of a full-chroma RGB destination goes through the luma filters)
 int  launch_striprgb(const LaunchCtx &L);

@@ -7,8 +7,6 @@
 namespace swship {
 
 // which: 1 = the luma launch, 2 = the chroma launch, 3 = both
-void launch_gray_chroma(const LaunchCtx &L);      // k_stream.hip
-
 int launch_strip_planes(const LaunchCtx &L, int which)
 {
     SwsInternal *c = L.c; DeviceState *d = L.d; const SwsDevParams &p = *L.p; hipStream_t st = L.st; const SwsFrameSet &fs = L.fs;

@@ -29,6 +29,16 @@ namespace swsk {
 // P01X (with S16): a p010-style source -- words with the samples in the HIGH bits, the two chroma components interleaved in plane 1
 // (p010LEToY_c / p010LEToUV_c, input.c:950-1008): every word is shifted down while it is staged, a chroma row is two chunks per lane
 // (8 {U, V} word pairs) de-interleaved with v_perm into one chunk per component
+// the rounding constant of the packed writers for one output row: 1 << 18 (yuv2rgb_X_c_template, yuv2rgb_1_c_template: output.c:1795-1850, :1897-1960) minus what
+// the host wrote into the row's entry -- 1 << 18 for the rows packed_vscale gives to yuv2rgb_2_c_template (two vertical taps each that sum to 4096: bilinear
+// up-scaling; (buf0 * (4096 - a) + buf1 * a) >> 19, no rounding: output.c:1853-1895, vscale.c:146-157).  Round 5.
+__device__ __forceinline__ int strip_row_rnd(const SwsStripRow *rows, int idx)
+{
+    typedef const uint32_t __attribute__((address_space(4))) *cptr;
+    cptr q = (cptr)(uintptr_t)(rows + idx);
+    return (1 << 18) - (int)q[1];
+}
+
 template <int NCOMP, int COLS, int NPH, int RD, bool S16 = false, bool P01X = false>
 struct StripPlane {
     StripLds L;
@@ -267,11 +277,13 @@ __device__ __forceinline__ void strip_rgb_body(const FrameRegs &f, const SwsDevP
     const int npvL = gl.npv, npvC = gc.npv, sh = p.hshift;
     const bool swap_rb = BPP == 4 ? p.lut.swap_rb32 != 0 : p.lut.rgb_order != 0;
     SwsStripRow el = load_strip_row(rowsL, y0), ec = load_strip_row(rowsC, y0);
+    int rnd = strip_row_rnd(rowsL, y0);
     sp_restart(PL, el.pf);
     sp_restart(PC, ec.pf);
     for (int y = y0; y < y1; y++) {
         const int yn = min(y + 1, H - 1);
         const SwsStripRow eln = load_strip_row(rowsL, yn), ecn = load_strip_row(rowsC, yn);     // next row's scalars, one row ahead
+        const int rndn = strip_row_rnd(rowsL, yn);
         if (PL.qnext < el.pf) sp_restart(PL, el.pf);            // pairs nobody needs (steep down-scaling with short filters)
         if (PC.qnext < ec.pf) sp_restart(PC, ec.pf);
         while (PL.qnext <= el.pf + npvL - 1) sp_step(PL, sh, gl.hfs2, flush);
@@ -283,7 +295,7 @@ __device__ __forceinline__ void strip_rgb_body(const FrameRegs &f, const SwsDevP
         // luma across lanes: column 64 c + l (lane l) -> pairs (2j, 2j + 1) for j = l, l + 64
         int16_t *X = (int16_t *)ldsX;
 #pragma unroll
-        for (int c = 0; c < CL; c++) X[64 * c + lane] = (int16_t)((aL[0][c] + (1 << 18)) >> 19);
+        for (int c = 0; c < CL; c++) X[64 * c + lane] = (int16_t)((aL[0][c] + rnd) >> 19);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -291,13 +303,13 @@ __device__ __forceinline__ void strip_rgb_body(const FrameRegs &f, const SwsDevP
         for (int c = 0; c < CC; c++) {
             const uint32_t yy = ((const uint32_t *)ldsX)[64 * c + lane];
             const int Y1 = (int)(int16_t)(yy & 0xFFFFu), Y2 = (int)yy >> 16;
-            const int U = (aC[0][c] + (1 << 18)) >> 19, V = (aC[1][c] + (1 << 18)) >> 19;
+            const int U = (aC[0][c] + rnd) >> 19, V = (aC[1][c] + rnd) >> 19;
             lut_pair<BPP>(p.lut, T, swap_rb, Y1, Y2, U, V, pend[c]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the exchange row is rewritten by the next output row
         __builtin_amdgcn_wave_barrier();
         pend_y = y;
-        el = eln; ec = ecn;
+        el = eln; ec = ecn; rnd = rndn;
     }
     flush();
 }
@@ -535,6 +547,7 @@ __device__ __forceinline__ void strip_rgb8_body(const FrameRegs &f, const SwsDev
     const int npvL = gl.npv, npvC = gc.npv, sh = p.hshift;
     const bool swap_rb = BPP == 4 ? p.lut.swap_rb32 != 0 : p.lut.rgb_order != 0;
     SwsStripRow el = load_strip_row(rowsL, y0), ec = load_strip_row(rowsC, y0);
+    int rnd = strip_row_rnd(rowsL, y0);
     PL.qnext = PL.qdma = el.pf; PC.qnext = PC.qdma = ec.pf;
     // (the column state came through vector loads the compiler counts, the requests below are asm statements it does not see: everything loaded so far
     //  is consumed here, while the compiler's own vmcnt arithmetic is still exact -- kernels_strip8.hpp)
@@ -554,6 +567,7 @@ __device__ __forceinline__ void strip_rgb8_body(const FrameRegs &f, const SwsDev
     for (int y = y0; y < y1; y++) {
         const int yn = min(y + 1, H - 1);
         const SwsStripRow eln = load_strip_row(rowsL, yn), ecn = load_strip_row(rowsC, yn);
+        const int rndn = strip_row_rnd(rowsL, yn);
         while (PL.qnext <= el.pf + npvL - 1) sp8_step(PL, sh, gl.hfs2, flush);
         while (PC.qnext <= ec.pf + npvC - 1) sp8_step(PC, sh, gc.hfs2, flush);
         flush();
@@ -562,7 +576,7 @@ __device__ __forceinline__ void strip_rgb8_body(const FrameRegs &f, const SwsDev
         sp8_vstage(PC, ec, aC);
         int16_t *X = (int16_t *)ldsX;
 #pragma unroll
-        for (int c = 0; c < CL; c++) X[64 * c + lane] = (int16_t)((aL[0][c] + (1 << 18)) >> 19);
+        for (int c = 0; c < CL; c++) X[64 * c + lane] = (int16_t)((aL[0][c] + rnd) >> 19);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -570,13 +584,13 @@ __device__ __forceinline__ void strip_rgb8_body(const FrameRegs &f, const SwsDev
         for (int c = 0; c < CC; c++) {
             const uint32_t yy = ((const uint32_t *)ldsX)[64 * c + lane];
             const int Y1 = (int)(int16_t)(yy & 0xFFFFu), Y2 = (int)yy >> 16;
-            const int U = (aC[0][c] + (1 << 18)) >> 19, V = (aC[1][c] + (1 << 18)) >> 19;
+            const int U = (aC[0][c] + rnd) >> 19, V = (aC[1][c] + rnd) >> 19;
             lut_pair<BPP>(p.lut, T, swap_rb, Y1, Y2, U, V, pend[c]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the exchange row is rewritten by the next output row
         __builtin_amdgcn_wave_barrier();
         pend_y = y;
-        el = eln; ec = ecn;
+        el = eln; ec = ecn; rnd = rndn;
     }
     flush();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA write may land after the wave has given up its LDS

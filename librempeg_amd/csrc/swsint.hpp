@@ -122,6 +122,8 @@ struct Tuning {
     int no_strip_dma8 = 0;         // off: 8-bit planar sources of the short family take the LDS-DMA form (kernels_strip8.hpp)
     int strip_lds_pad_kb = 0;      // experiments: LDS pad in KB per block of the short / dma8 kernels (lowers the occupancy; results never change)
     int no_strip_rgb2rgb = 0;      // off: scaled packed RGB -> packed RGB (full-chroma writers) takes the one-launch form (sws_k_strip_rgb2rgb) where it applies
+    int no_fast_banks = 0;         // on: SWS_FAST_BILINEAR contexts keep ff_hyscale_fast_c / ff_hcscale_fast_c in the element-per-thread readers (round 4 behaviour) instead of two-tap banks under every plan
+    int no_short_forms = 0;        // on: packed destinations whose rows take yuv2packed1 (blended chroma) / yuv2packed2 keep the element-per-thread writers (round 4 behaviour)
     int no_strip_rgbsrc = 0;       // off: scaled packed-RGB sources into half-width-chroma YUV take the one-launch strip form (sws_k_strip_rgbsrc) where it applies
     int no_rgbsrc2 = 0;            // off: same-size 8-bit RGB -> 4:2:0 / 4:2:2 YUV takes the wave-march form (sws_k_rgbsrc_unity2) where it applies
     int no_striprgb_direct = 0;    // off: semi-planar sources (nv12 / p010 families) are read by the strip-RGB kernels themselves instead of through a split pass

@@ -1,0 +1,56 @@
+"""-m gpu parity for the packed writers' short vertical forms behind the strip kernel with the RGB epilogue (round 5).  packed_vscale (vscale.c:135-157) picks per
+output row: yuv2rgb_1_c_template with a chroma blend (one luma tap, two chroma taps that sum to 4096: (u0 (4096 - a) + u1 a + (128 << 11)) >> 19, output.c:1913-1937
+-- the X arithmetic on the bank's taps) and yuv2rgb_2_c_template (two taps each that sum to 4096 -- bilinear up-scaling: no rounding constant, output.c:1853-1895).
+The planner writes both into the strip plan: the luma tap 4096, a per-row rounding offset.  Compared with the oracle byte for byte, with the
+plan (main:strip_rgb) and without it (no_short_forms: the element-per-thread writers)."""
+import pytest
+
+from librempeg_amd import SWS_BILINEAR, SWS_FAST_BILINEAR, SWS_BICUBIC, SWS_POINT, SWS_AREA, SWS_BITEXACT, SWS_ACCURATE_RND
+from test_gpu_parity import run_case
+
+pytestmark = pytest.mark.gpu
+BX = SWS_BITEXACT
+T0 = dict(strip_min_w=0)
+PATHS = ("main:strip_rgb", "main:nvdirect+strip_rgb", "main:split422+strip_rgb", "main:splitnv+strip_rgb")
+
+SRC = ["yuv420p", "yuv422p", "yuv444p", "nv12", "nv21", "yuv410p", "yuvj420p", "yuv420p10le", "yuv422p12le", "yuyv422", "p010le", "yuv440p"]
+DST = ["bgra", "rgb24", "argb", "bgr24", "rgb0", "abgr"]
+#        two taps each (up, bilinear)              one luma tap + two chroma taps (same height)     mixed ratios
+GEOM = [(640, 48, 1280, 96), (640, 48, 642, 97), (640, 48, 320, 48), (640, 48, 640, 48), (322, 31, 644, 31), (640, 24, 1280, 25), (640, 5, 640, 64), (400, 66, 332, 132)]
+
+
+@pytest.mark.parametrize("src", SRC)
+@pytest.mark.parametrize("dst", DST)
+def test_formats(src, dst):
+    for k, (sw, sh, dw, dh) in enumerate(GEOM):
+        for fl in (SWS_BILINEAR, SWS_FAST_BILINEAR):
+            if fl == SWS_FAST_BILINEAR and (SRC.index(src) + DST.index(dst) + k) % 2:
+                continue
+            r = run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh, tune=T0)
+            if k == 0 and fl == SWS_BILINEAR and src in ("yuv420p", "yuv422p", "nv12", "nv21", "yuv420p10le"):      # (yuv444p: full chroma is forced, another route)
+                assert r[0] in PATHS, (r[0], src, dst)
+            if k < 3:
+                old = run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh, tune=dict(T0, no_short_forms=1))
+                if k == 0 and fl == SWS_BILINEAR:
+                    assert old[0] not in PATHS, old[0]
+
+
+@pytest.mark.parametrize("flags", [SWS_BILINEAR, SWS_BILINEAR | SWS_ACCURATE_RND, SWS_POINT, SWS_AREA, SWS_BICUBIC, SWS_FAST_BILINEAR | SWS_ACCURATE_RND],
+                         ids=["bilinear", "accurate", "point", "area", "bicubic", "fast_accurate"])
+def test_scalers(flags):
+    """point and area up-scaling have one or two vertical taps too (not always summing to 4096 in two non-negative taps: the X form row by row)"""
+    for src, dst in (("yuv420p", "bgra"), ("nv12", "rgb24"), ("yuv422p", "argb"), ("yuv444p", "bgr24"), ("yuv420p10le", "rgb0")):
+        for (sw, sh, dw, dh) in GEOM + [(640, 360, 656, 372), (640, 100, 640, 101), (640, 100, 640, 199), (320, 9, 960, 27)]:
+            run_case(sw, sh, src, dw, dh, dst, flags | BX, seed=dh, tune=T0)
+
+
+def test_options_and_full_size():
+    opts = dict(dither=1, src_range=1, dst_range=0, src_h_chr_pos=0, src_v_chr_pos=128, dst_h_chr_pos=-513, dst_v_chr_pos=-513, threads=1)
+    for (sw, sh, dw, dh) in GEOM:
+        run_case(sw, sh, "yuv420p", dw, dh, "bgra", SWS_BILINEAR | BX, seed=3, opts=opts, tune=T0)
+        run_case(sw, sh, "yuva420p", dw, dh, "bgra", SWS_BILINEAR | BX, seed=4, tune=T0)        # (an alpha plane: the writers' own alpha formulas, not this plan)
+    assert run_case(1280, 720, "yuv420p", 1920, 1080, "bgra", SWS_BILINEAR, seed=5)[0] == "main:strip_rgb"
+    assert run_case(1280, 720, "nv12", 1920, 1080, "rgb24", SWS_BILINEAR | BX, seed=6)[0] in PATHS
+    assert run_case(1920, 1080, "yuv420p", 3840, 2160, "bgra", SWS_FAST_BILINEAR, seed=7)[0] == "main:strip_rgb"
+    run_case(1920, 1080, "yuv420p", 1280, 1080, "rgb24", SWS_BILINEAR | BX, seed=8, device_frames=False)
+    run_case(1280, 720, "yuv420p10le", 1920, 1080, "bgra", SWS_BILINEAR | BX, seed=9)

@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))));
 import torch
 import oracle_lib as OL
 from librempeg_amd import SwsContext, HostFrame, DeviceFrame, SWS_BICUBIC, SWS_BITEXACT
+FLAGS = int(os.environ.get("SWS_SURVEY_FLAGS", str(SWS_BICUBIC | SWS_BITEXACT)), 0)      # (SWS_BILINEAR = 2, SWS_FAST_BILINEAR = 1, SWS_POINT = 0x10, ...)
 mode = sys.argv[1] if len(sys.argv) > 1 else "same"
 N = 4
 FMTS = ["yuv420p", "yuv422p", "yuv444p", "nv12", "nv21", "p010le", "yuv420p10le", "yuv422p10le", "yuv444p10le", "yuv444p16le", "yuyv422", "uyvy422", "rgb24", "bgr24", "rgba", "bgra",
@@ -19,7 +20,7 @@ for base in ("yuv420p", "nv12", "bgra", "yuv420p10le"):
         for sf, df in ((base, other), (other, base)):
             if sf == df and mode in ("same", "same4k"): continue
             try:
-                ctx = SwsContext(sw, sh, sf, dw, dh, df, SWS_BICUBIC | SWS_BITEXACT)
+                ctx = SwsContext(sw, sh, sf, dw, dh, df, FLAGS)
             except Exception as e:
                 continue
             hs = HostFrame(sf, sw, sh); src = OL.fill_random(OL.Frame(sf, sw, sh), 1)
