@@ -328,7 +328,9 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     }
     const FilterBank &hLumB = fast_banks ? fastL : c->hLum, &hChrB = fast_banks ? fastC : c->hChr;
     bool striprgb_short = false;     // (the strip-RGB plan carries the packed writers' short forms in its taps and rounding offsets: below)
-    const bool fast_flag = (o.flags & SWS_FAST_BILINEAR) && !fast_banks;     // (the flag with the fast functions still in the kernels: the element-per-thread readers)
+    // (the flag with the fast functions still in the kernels -- the element-per-thread readers; sources whose lines are not 8-bit -- RGB, 9 .. 16-bit YUV -- get
+    //  bilinear banks from the flag and nothing else, swscale.c:676-681)
+    const bool fast_flag = (o.flags & SWS_FAST_BILINEAR) && c->srcBpc == 8 && c->dstBpc <= 14 && !fast_banks;
     p.srcW = o.src_w; p.srcH = o.src_h; p.dstW = o.dst_w; p.dstH = o.dst_h;
     p.chrSrcW = c->chrSrcW; p.chrSrcH = c->chrSrcH; p.chrDstW = c->chrDstW; p.chrDstH = c->chrDstH;
     p.chrSrcHSub = c->chrSrcHSubSample; p.chrSrcVSub = c->chrSrcVSubSample;
@@ -1305,7 +1307,12 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             d->striprgb_ok = d->striprgb_ok && (all_x || (lfs == 1 && cfs == 1) || striprgb_short);     // (striprgb_short: the plan's taps and rounding offsets carry the short forms)
             if (d->alpha_launch == 2 && !d->striprgb_ok) d->alpha_launch = 0;
             const bool kind_x = d->fullchr_kind == DSTK_GBRP || d->fullchr_kind == DSTK_PACKEDHI || d->fullchr_kind == DSTK_GBRP16 || d->fullchr_kind == DSTK_GBRPF32;   // (writers with the X form only)
-            if (d->fullchr_on && ((!all_x && !(lfs == 1 && cfs == 1) && !kind_x) ||
+            // (round 5: sws_k_fullchr_rgb tells the rows of the short forms by their taps and leaves the rounding constant out there -- yuv2rgb_full_2_c_template, the chroma
+            //  blend of yuv2rgb_full_1_c_template; the one-launch RGB -> RGB kernel has the X arithmetic only: such contexts take reader pre-pass + strip launches + epilogue)
+            const bool short_full = !all_x && !c->tune.no_short_forms && (d->fullchr_on == 1 || d->fullchr_on == 2) && (d->fullchr_kind == DSTK_RGB24 || d->fullchr_kind == DSTK_RGB32) &&
+                                    (lfs == 1 || lfs == 2) && cfs == 2;
+            if (!all_x && !(lfs == 1 && cfs == 1)) d->rgb2rgb_ok = false;
+            if (d->fullchr_on && ((!all_x && !(lfs == 1 && cfs == 1) && !kind_x && !short_full) ||
                                   (d->fullchr_on == 4 && lfs == 1 && cfs == 1 && d->fullchr_kind != DSTK_PACKEDHI && d->fullchr_kind != DSTK_GBRP16 && d->fullchr_kind != DSTK_GBRPF32) || !d->strip_ok)) {   // (planar RGB: any_vscale, always the X form)   // no strip plan, or a row in one of the short writer forms: the generic full-chroma writer keeps it
                 d->fullchr_on = 0; d->strip_ok = false; d->rgbread_on = false; d->striprgbsrc_ok = false; d->rgb2rgb_ok = false;
                 p.dstKind = d->fullchr_kind; p.u_plane_dst = dd->comp[1].plane; p.v_plane_dst = dd->comp[2].plane;

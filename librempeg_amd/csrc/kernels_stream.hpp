@@ -153,6 +153,23 @@ __device__ __forceinline__ void fullchr_fetch4(const uint8_t *plane, int64_t str
 }
 
 
+// The rounding constant of the full-chroma packed writers for output row y: 1 << 9 in yuv2rgb_full_X_c_template (output.c:2130-2180) and, where it matters, in
+// yuv2rgb_full_1_c_template's one-row form; none in the rows packed_vscale (vscale.c:135-157) gives to yuv2rgb_full_2_c_template (two taps each that sum to 4096:
+// bilinear up-scaling, output.c:2225-2252) and to yuv2rgb_full_1_c_template's chroma blend (one luma tap, two chroma taps that sum to 4096, output.c:2289-2306;
+// its luma 4 buf0 and its one-row chroma are exact either way).  The alpha sums keep their 1 << 18 in every form.  Round 5; wave-uniform, a few scalar loads per row.
+__device__ __forceinline__ unsigned fullchr_row_rnd(const SwsDevParams &p, int y)
+{
+    const int lfs = U(p.vLumFs), cfs = U(p.vChrFs);
+    if (cfs != 2 || lfs > 2) return 1u << 9;      // (the planner keeps such rows away from this kernel when the option no_short_forms is set: device.hip)
+    const int16_t *cf = p.vChrF + 2 * (int64_t)y;
+    const unsigned c0 = (uint16_t)cf[0], c1 = (uint16_t)cf[1];
+    if (c0 + c1 != 4096u || c1 > 4096u) return 1u << 9;
+    if (lfs == 1) return 0;
+    const int16_t *lf = p.vLumF + 2 * (int64_t)y;
+    const unsigned l0 = (uint16_t)lf[0], l1 = (uint16_t)lf[1];
+    return (l0 + l1 == 4096u && l1 <= 4096u) ? 0u : 1u << 9;
+}
+
 // ALPHA: a fourth sum plane (the alpha plane through the luma filters): A = (sum + (1 << 18)) >> 19, clipped the way the writer does (output.c:2193-2201)
 template <int BPP, bool ALPHA, int SRCM = 0>
 __global__ void __launch_bounds__(256) sws_k_fullchr_rgb(SwsFrameSet fs, SwsDevParams p)
@@ -196,10 +213,11 @@ __global__ void __launch_bounds__(256) sws_k_fullchr_rgb(SwsFrameSet fs, SwsDevP
         if (in && y + 1 < y1) fetch(y + 1);
         if (!in) continue;
         uint32_t px[4];
+        const unsigned rq = fullchr_row_rnd(p, y);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            int Y = (int)((unsigned)vY[k] + (1u << 9)) >> 10;
-            const int Uc = (int)((unsigned)vU[k] + (unsigned)((1 << 9) - (128 << 19))) >> 10, Vc = (int)((unsigned)vV[k] + (unsigned)((1 << 9) - (128 << 19))) >> 10;
+            int Y = (int)((unsigned)vY[k] + rq) >> 10;
+            const int Uc = (int)((unsigned)vU[k] + rq - (unsigned)(128 << 19)) >> 10, Vc = (int)((unsigned)vV[k] + rq - (unsigned)(128 << 19)) >> 10;
             Y -= y_offset;
             Y = (int)((unsigned)Y * (unsigned)y_coeff);
             Y = (int)((unsigned)Y + (1u << 21));
