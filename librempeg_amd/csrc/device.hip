@@ -327,7 +327,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         make(fastC, c->chrDstW, c->chrSrcW, c->chrXInc, true);
     }
     const FilterBank &hLumB = fast_banks ? fastL : c->hLum, &hChrB = fast_banks ? fastC : c->hChr;
-    bool striprgb_short = false;     // (the strip-RGB plan carries the packed writers' short forms in its taps and rounding offsets: below)
+    FilterBank vChrJ; bool join_short = false;      // (the chroma bank of a packed 4:2:2 destination whose rows take yuv2422_1_c_template's blend: below)
+    bool striprgb_short = false, rgb2rgb_short = false;     // (the strip-RGB / one-launch RGB -> RGB plans carry the packed writers' short forms in their rounding offsets: below)
     // (the flag with the fast functions still in the kernels -- the element-per-thread readers; sources whose lines are not 8-bit -- RGB, 9 .. 16-bit YUV -- get
     //  bilinear banks from the flag and nothing else, swscale.c:676-681)
     const bool fast_flag = (o.flags & SWS_FAST_BILINEAR) && c->srcBpc == 8 && c->dstBpc <= 14 && !fast_banks;
@@ -397,7 +398,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     }
     d->join422 = 0;
     if (c->plan == PLAN_MAIN && p.dstKind == DSTK_PACKED422 && dd->comp[0].depth == 8 && !(o.dst_w & 1) && !c->needAlpha && !gray_any &&
-        !((c->vLum.size == 1 || c->vLum.size == 2) && c->vChr.size == 2) && !c->tune.no_mixed && !c->tune.no_layout_stream &&
+        !(c->vLum.size == 2 && c->vChr.size == 2) && !(c->vLum.size == 1 && c->vChr.size == 2 && c->tune.no_short_forms) && !c->tune.no_mixed && !c->tune.no_layout_stream &&
         // (one tap on ONE side only: the packed X form multiplies by the bank's value, which initFilter's normalisation leaves at 4095 in some
         //  rows, where the planar one-tap form ignores it; one tap on both sides is yuv2422_1, which ignores both)
         ((c->vLum.size == 1) == (c->vChr.size == 1) || bank_taps_all(c->vLum.size == 1 ? c->vLum : c->vChr, 1 << 12))) {
@@ -406,7 +407,18 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         p.u_plane_dst = vfirst ? 2 : 1; p.v_plane_dst = vfirst ? 1 : 2;
         d->join422 = uyvy ? 2 : 1;
         p.should_dither = 0;     // (9 .. 16-bit sources: the ordered dither belongs to the planar 8-bit writers, swscale.c:292-300; the packed ones round with 1 << 18 == the undithered 64 << 12)
+        // One luma tap with two chroma taps (4:2:0 -> packed 4:2:2 at the same height with SWS_BILINEAR): the rows whose chroma taps sum to 4096 go to yuv2422_1_c_template
+        // with a chroma blend -- the first chroma row alone while the second tap is below 2048, the mean of the two rows from there on, (u0 + u1 + 128) >> 8
+        // (output.c:959-990; vscale.c:139-145) -- which is the X arithmetic over the taps {4096, 0} / {2048, 2048}: the chroma bank every plan and kernel below sees (vChrB).  Round 5.
+        if (c->vLum.size == 1 && c->vChr.size == 2) {
+            vChrJ = c->vChr;
+            for (size_t y = 0; y + 1 < vChrJ.taps.size(); y += 2) {
+                int16_t *cf = &vChrJ.taps[y];
+                if ((uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { if (cf[1] < 2048) { cf[0] = 4096; cf[1] = 0; } else cf[0] = cf[1] = 2048; join_short = true; }
+            }
+        }
     }
+    const FilterBank &vChrB = join_short ? vChrJ : c->vChr;
     p.full_chr = ((o.flags & SWS_FULL_CHR_H_INT) && isAnyRGB(o.dst_format)) ? 1 : 0;
     // ---- full-chroma 24 / 32 bpp RGB destinations (RGB -> RGB scaling, 4:4:4 sources, odd widths, the user's full_chroma_int) through the strip kernels:
     //      Y, U and V are all scaled to the destination size; the kernels store their vertical sums as int32 planes (DSTK_RAW32) into a working picture
@@ -425,7 +437,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     d->alpha_launch = 0;
     // (filters of more than 16 taps -- ratios of 4:1 and more -- have the strip kernel's long form with 128-column strips on one side and the element-per-thread
     //  kernels on the other: the planner's width threshold for them is 64 columns)
-    const bool long_taps = c->plan == PLAN_MAIN && (hLumB.size >= 16 || hChrB.size >= 16 || c->vLum.size >= 16 || c->vChr.size >= 24);   // (padded to an even start: 16 taps already take 9 pairs)
+    const bool long_taps = c->plan == PLAN_MAIN && (hLumB.size >= 16 || hChrB.size >= 16 || c->vLum.size >= 16 || vChrB.size >= 24);   // (padded to an even start: 16 taps already take 9 pairs)
     const int strip_min_w_eff = long_taps ? std::min(c->tune.strip_min_w, 64) : c->tune.strip_min_w;   // (one strip of the long forms: thumbnails of 160 x 90 from 1080p are 0.05 ms on the two-pass kernels)
     const bool fc_plain = !isGray(o.src_format) && !isGray(o.dst_format) && p.srcKind != SRCK_MONO;
     d->fullchr_on = 0;
@@ -606,7 +618,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     // ---- filter tables -> one device blob ----
     d->unity_h = false;
     if (c->plan == PLAN_MAIN) {
-        const FilterBank *banks[4] = { &hLumB, &hChrB, &c->vLum, &c->vChr };
+        const FilterBank *banks[4] = { &hLumB, &hChrB, &c->vLum, &vChrB };
         size_t off = 0, offs_t[4], offs_p[4];
         auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
         for (int i = 0; i < 4; i++) {
@@ -624,10 +636,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         p.hLumF = (const int16_t *)(b + offs_t[0]); p.hLumPos = (const int32_t *)(b + offs_p[0]); p.hLumFs = hLumB.size;
         p.hChrF = (const int16_t *)(b + offs_t[1]); p.hChrPos = (const int32_t *)(b + offs_p[1]); p.hChrFs = hChrB.size;
         p.vLumF = (const int16_t *)(b + offs_t[2]); p.vLumPos = (const int32_t *)(b + offs_p[2]); p.vLumFs = c->vLum.size;
-        p.vChrF = (const int16_t *)(b + offs_t[3]); p.vChrPos = (const int32_t *)(b + offs_p[3]); p.vChrFs = c->vChr.size;
+        p.vChrF = (const int16_t *)(b + offs_t[3]); p.vChrPos = (const int32_t *)(b + offs_p[3]); p.vChrFs = vChrB.size;
         // the fast-bilinear chroma function weighs with (xalpha ^ 127): not the identity even at equal widths
         d->unity_h = bank_is_identity(hLumB, 1 << 14) && bank_is_identity(hChrB, 1 << 14) && !p.fast_bilinear;
-        d->unity_v = bank_is_identity(c->vLum, 1 << 12) && bank_is_identity(c->vChr, 1 << 12);
+        d->unity_v = bank_is_identity(c->vLum, 1 << 12) && bank_is_identity(vChrB, 1 << 12);
         // ---- contexts whose result depends on the reference's line schedule (build_vlines): the two-pass path over virtual lines ----
         d->vlines_on = false; c->gamma_in_reader = false; d->mixed_ok = false;
         {
@@ -659,37 +671,37 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         d->rgbsrc_ok = false; d->rgbsrc2_rows = nullptr;
         if (d->unity_h && !d->vlines_on && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP) && p.chr_half && (!p.range_active || (!(p.dstW & 3) && p.range_to_jpeg && !c->tune.no_strip_range && !c->tune.no_rgbsrc2)) && !p.need_alpha && !p.no_chroma &&
             !p.wide && !p.dst_alpha_fill && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_NV12) && p.dst_bits == 8 && p.chrDstHSub == 1 && p.chrDstVSub <= 1 &&
-            p.chrSrcVSub == 0 && p.srcH == p.dstH && bank_is_identity(c->vLum, 1 << 12) && c->vChr.size <= 16 && p.chrDstW == ((p.dstW + 1) >> 1) &&
+            p.chrSrcVSub == 0 && p.srcH == p.dstH && bank_is_identity(c->vLum, 1 << 12) && vChrB.size <= 16 && p.chrDstW == ((p.dstW + 1) >> 1) &&
             !p.should_dither && !c->tune.no_rgbsrc) {
             bool fwd = true;
             for (int k = 0; k < 9; k++) fwd = fwd && p.rgb2yuv[k] > -32768 && p.rgb2yuv[k] < 32768;   // (v_dot2_i32_i16 operands)
-            for (int y = 0; y < c->vChr.count && fwd; y++) fwd = c->vChr.pos[y] >= 0 && (y == 0 || c->vChr.pos[y] >= c->vChr.pos[y - 1]);
+            for (int y = 0; y < vChrB.count && fwd; y++) fwd = vChrB.pos[y] >= 0 && (y == 0 || vChrB.pos[y] >= vChrB.pos[y - 1]);
             if (fwd) {
-                const bool x_form = p.dstKind == DSTK_NV12 || c->vChr.size > 1;   // yuv2nv12cX_c has no one-tap form
-                std::vector<SwsRgbSrcRow> rows((size_t)c->vChr.count);
-                for (int y = 0; y < c->vChr.count; y++) {
+                const bool x_form = p.dstKind == DSTK_NV12 || vChrB.size > 1;   // yuv2nv12cX_c has no one-tap form
+                std::vector<SwsRgbSrcRow> rows((size_t)vChrB.count);
+                for (int y = 0; y < vChrB.count; y++) {
                     SwsRgbSrcRow &e = rows[(size_t)y];
                     std::memset(&e, 0, sizeof(e));
-                    e.first = std::max(1 - c->vChr.size, c->vChr.pos[y]);
-                    e.last = e.first + c->vChr.size - 1;
-                    for (int j = 0; j < c->vChr.size; j++)
-                        e.vt[j >> 1] |= (uint32_t)(uint16_t)(x_form ? c->vChr.taps[(size_t)y * c->vChr.size + j] : 1) << (16 * (j & 1));
+                    e.first = std::max(1 - vChrB.size, vChrB.pos[y]);
+                    e.last = e.first + vChrB.size - 1;
+                    for (int j = 0; j < vChrB.size; j++)
+                        e.vt[j >> 1] |= (uint32_t)(uint16_t)(x_form ? vChrB.taps[(size_t)y * vChrB.size + j] : 1) << (16 * (j & 1));
                 }
                 // the wave-march form (sws_k_rgbsrc_unity2): per chroma row the first source-row PAIR and the tap pairs aligned to even source rows, laid out
                 // against the newest slots of its register ring (1 / 3 / 5 / 8 pairs); the planar one-tap form enters as the tap 4096
                 std::vector<SwsStripRow> rows2;
                 int npv2 = 1;
-                for (int y = 0; y < c->vChr.count; y++) npv2 = std::max(npv2, ((c->vChr.pos[y] & 1) + c->vChr.size + 1) / 2);
+                for (int y = 0; y < vChrB.count; y++) npv2 = std::max(npv2, ((vChrB.pos[y] & 1) + vChrB.size + 1) / 2);
                 const int rd2 = npv2 <= 1 ? 1 : npv2 <= 3 ? 3 : npv2 <= 5 ? 5 : 8;
                 if (npv2 <= 8) {
-                    rows2.resize((size_t)c->vChr.count);
+                    rows2.resize((size_t)vChrB.count);
                     std::memset(rows2.data(), 0, rows2.size() * sizeof(SwsStripRow));
-                    for (int y = 0; y < c->vChr.count; y++) {
+                    for (int y = 0; y < vChrB.count; y++) {
                         SwsStripRow &e2 = rows2[(size_t)y];
-                        e2.pf = (c->vChr.pos[y] & ~1) >> 1;
-                        for (int j = 0; j < c->vChr.size; j++) {
-                            const int k = (c->vChr.pos[y] & 1) + j + 2 * (rd2 - npv2);
-                            const int16_t tap = x_form ? c->vChr.taps[(size_t)y * c->vChr.size + j] : (int16_t)4096;
+                        e2.pf = (vChrB.pos[y] & ~1) >> 1;
+                        for (int j = 0; j < vChrB.size; j++) {
+                            const int k = (vChrB.pos[y] & 1) + j + 2 * (rd2 - npv2);
+                            const int16_t tap = x_form ? vChrB.taps[(size_t)y * vChrB.size + j] : (int16_t)4096;
                             e2.vt[k >> 1] |= (uint32_t)(uint16_t)tap << (16 * (k & 1));
                         }
                     }
@@ -764,7 +776,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             d->rgbread_on = false;
             // vertical chroma filters of 17 .. 24 taps (a 4:1 chroma step: packed RGB or 4:2:2 sources into a 4:2:0 picture of half the size): the strip
             // kernel's chroma instantiations with a ring of 12 row pairs; the tile kernel and the RGB epilogue stop at 16
-            const bool vchr_long = fs2(c->vChr.size) > 16 && fs2(c->vChr.size) <= 24 && dst_ok && !rgb_ok && !c->tune.no_strip;
+            const bool vchr_long = fs2(vChrB.size) > 16 && fs2(vChrB.size) <= 24 && dst_ok && !rgb_ok && !c->tune.no_strip;
             // gray -> gray (8 .. 14 bit): one plane, the strip kernel's luma launch alone
             // (round 5: ... and planar / semi-planar YUV -> gray: the destination has no chroma planes, so the conversion is the luma launch as well -- thumbnails
             //  for analysis; it needed the range conversion in the strip kernels, gray8 being full range, handle_jpeg utils.c:773-809)
@@ -780,7 +792,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             // (one tap: a per-sample pass), only the chroma planes need the strip kernel
             const bool mixedM = !vlines_pending && !d->fullchr_on && bank_is_identity(hLumB, 1 << 14) && bank_is_identity(c->vLum, 1 << 12) && !(d->unity_h && d->unity_v) &&
                                 !p.fast_bilinear && !gray_any && (src_ok || nv_src) && dst_ok && !p.wide && (!p.range_active || (c->srcBpc == 8 && p.dst_bits == 8 && !c->tune.no_strip_range)) && !p.dst_alpha_fill &&
-                                fs2(hChrB.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long) && !c->tune.no_strip && !c->tune.no_mixed && p.dstW >= c->tune.strip_min_w;
+                                fs2(hChrB.size) <= 16 && (fs2(vChrB.size) <= 16 || vchr_long) && !c->tune.no_strip && !c->tune.no_mixed && p.dstW >= c->tune.strip_min_w;
             // (identity horizontal filters: 8-bit sources have kernels of their own -- sws_k_rgb_march, sws_k_rgbsrc_unity, the mixed plan -- but a 10-bit
             //  picture into packed RGB (decoded HDR for display) or packed RGB into a 10-bit 4:2:0 picture at the same size had only the generic
             //  kernels: the strip kernels take them with their one-tap horizontal banks)
@@ -791,10 +803,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             const bool unity_ok = !d->unity_h || (rgb_ok && rgb_s16) || (rgbread && !d->rgbsrc_ok && !d->rgb444_ok) || unity_yuv;   // (sws_k_rgbsrc_unity's row table lives in the same device block as the strip plan)
             // filters of 17 .. 32 taps (ratios of 4:1 and more -- the lower rungs of an ABR ladder, thumbnails: bicubic at 4:1 has 17 taps, at 6:1 25; Lanczos at
             // 3:1 19): the strip kernel's long form (sws_k_strip_long: 16 tap pairs each way, strips of 128 / 64 columns); the RGB epilogue stops at 16
-            const bool fs_ok16 = fs2(hLumB.size) <= 16 && (fs2(hChrB.size) <= 16 || gray_both) && fs2(c->vLum.size) <= 16 && (fs2(c->vChr.size) <= 16 || vchr_long || gray_both);
-            const bool fs_ok32 = fs2(hLumB.size) <= 32 && fs2(hChrB.size) <= 32 && fs2(c->vLum.size) <= 32 && fs2(c->vChr.size) <= 48 && dst_ok && !rgb_ok && !gray_both &&
+            const bool fs_ok16 = fs2(hLumB.size) <= 16 && (fs2(hChrB.size) <= 16 || gray_both) && fs2(c->vLum.size) <= 16 && (fs2(vChrB.size) <= 16 || vchr_long || gray_both);
+            const bool fs_ok32 = fs2(hLumB.size) <= 32 && fs2(hChrB.size) <= 32 && fs2(c->vLum.size) <= 32 && fs2(vChrB.size) <= 48 && dst_ok && !rgb_ok && !gray_both &&
                                  !c->tune.no_strip && !c->tune.no_mixed;
-            const bool fs_ok64 = fs2(hLumB.size) <= 64 && fs2(hChrB.size) <= 64 && fs2(c->vLum.size) <= 64 && fs2(c->vChr.size) <= 64 && dst_ok && !rgb_ok && !gray_both &&
+            const bool fs_ok64 = fs2(hLumB.size) <= 64 && fs2(hChrB.size) <= 64 && fs2(c->vLum.size) <= 64 && fs2(vChrB.size) <= 64 && dst_ok && !rgb_ok && !gray_both &&
                                  !c->tune.no_strip && !c->tune.no_mixed;      // (33 .. 62 taps: the extra-long form, 32 pairs each way on strips of 64 columns)
             const bool wide_ok = wide_dst && (src_ok || nv_src || src_u16 || rgbread) && !(p.range_active && c->tune.no_strip_range) && !c->needAlpha && !p.need_alpha && !p.fast_bilinear && !vlines_pending && fs_ok16 &&
                                  !(p.srcKind == SRCK_PLANAR8 && c->srcBpc != 8);
@@ -972,7 +984,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 //  4096: Y = buf << 2 == (buf << 12 + (1 << 9)) >> 10, (buf + 64) >> 7 == (buf << 12 + (1 << 18)) >> 19; planar RGB has no such form, vscale.c:173-212)
                 //  The packed YUV formats of 10 / 12 bits (DSTK_PACKEDHI) have X writers only, which multiply by the bank's value even when it is the only tap
                 //  (4095 after initFilter's normalisation, 0 in the zero-vector rows of a source of fewer than four rows with shifted chroma): their own taps.
-                const bool raw_one_one = p.dstKind == DSTK_RAW32 && c->vLum.size == 1 && c->vChr.size == 1 && d->fullchr_kind != DSTK_GBRP && d->fullchr_kind != DSTK_PACKEDHI && d->fullchr_kind != DSTK_GBRP16 && d->fullchr_kind != DSTK_GBRPF32;
+                const bool raw_one_one = p.dstKind == DSTK_RAW32 && c->vLum.size == 1 && vChrB.size == 1 && d->fullchr_kind != DSTK_GBRP && d->fullchr_kind != DSTK_PACKEDHI && d->fullchr_kind != DSTK_GBRP16 && d->fullchr_kind != DSTK_GBRPF32;
                 const bool chr_plane1 = (p.dstKind != DSTK_NV12 && p.dstKind != DSTK_P010 && p.dstKind != DSTK_P016 && p.dstKind != DSTK_RAW32) || raw_one_one, lum_plane1 = p.dstKind != DSTK_RAW32 || raw_one_one;
                 const int strip_cols_l = c->tune.strip_cols_l == 2 ? 2 : 4;
                 const int strip_cols_c = c->tune.strip_cols_c == 1 ? 1 : 2;
@@ -998,11 +1010,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     }
                     return chroma ? 1 : 2;
                 };
-                const int wcl = p.wide ? wide_cols(hLumB, c->vLum, p.dstW, false) : 0, wcc = (p.wide && !gray_both) ? wide_cols(hChrB, c->vChr, p.chrDstW, true) : 0;
+                const int wcl = p.wide ? wide_cols(hLumB, c->vLum, p.dstW, false) : 0, wcc = (p.wide && !gray_both) ? wide_cols(hChrB, vChrB, p.chrDstW, true) : 0;
                 const bool strip_plan = fullA && dst_ok && !(p.range_active && c->tune.no_strip_range) && !c->tune.no_strip && p.dstW >= (long_form ? strip_min_w_eff : strip_min_w) &&   // (the long form's strips are 128 columns, and what it replaces is the element-per-thread tile kernel)
                                         plan3(hLumB, c->vLum, p.dstW, p.wide ? wcl : long_form == 2 ? 1 : long_form ? 2 : strip_cols_l, 1, d->stripL, sL,
                                               p.wide ? +[](int n) { return n <= 2 ? 2 : n <= 4 ? 4 : 8; } : long_form == 2 ? +[](int) { return 32; } : nullptr, lum_plane1, long_form) &&
-                                        (gray_both || plan3(hChrB, c->vChr, p.chrDstW, p.wide ? wcc : long_form ? 1 : strip_cols_c, 2, d->stripC, sC,
+                                        (gray_both || plan3(hChrB, vChrB, p.chrDstW, p.wide ? wcc : long_form ? 1 : strip_cols_c, 2, d->stripC, sC,
                                                             p.wide ? +[](int n) { return n <= 2 ? 2 : n <= 4 ? 4 : 8; } : long_form == 2 ? +[](int) { return 32; } : long_form ? +[](int) { return 24; } : nullptr, chr_plane1, long_form)) &&
                                         (!p.wide || (d->stripL.NCmax / SPC <= 64 && (gray_both || d->stripC.NCmax / SPC <= 64)));      // (the wide kernel stages one chunk per lane and row)
                 d->strip_ok = false;
@@ -1011,10 +1023,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 Off oL, oC;
                 if (mixedM) {
                     SOff sM;
-                    if (plan3(hChrB, c->vChr, p.chrDstW, strip_cols_c, 2, d->stripC, sM, nullptr, chr_plane1)) {
+                    if (plan3(hChrB, vChrB, p.chrDstW, strip_cols_c, 2, d->stripC, sM, nullptr, chr_plane1)) {
                         const std::vector<int16_t> htc = padded(hChrB);
                         const size_t ohc = put(htc.data(), htc.size() * 2);
-                        const bool altC = plan3_alt(hChrB, c->vChr, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
+                        const bool altC = plan3_alt(hChrB, vChrB, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
                         { int r_ = table_alloc(c, &d->d_dot2, &d->dot2_bytes, blob.size()); if (r_ < 0) return r_; }
                         { int r_ = table_put(c, d, d->d_dot2, blob.data(), blob.size()); if (r_ < 0) return r_; }
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
@@ -1035,7 +1047,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     auto ringC = [](int npv) { return npv <= 1 ? 1 : npv <= 3 ? 3 : npv <= 8 ? 8 : -1; };
                     const int rcl = (c->tune.strip_rgb_cols == 2 || rgb_s16) ? 2 : 4;
                     // (one vertical tap each: yuv2rgb_1_c_template's (buf + 64) >> 7 -- the coefficient is never looked at -- is the X arithmetic with the tap 4096)
-                    const bool rgb_one_one = c->vLum.size == 1 && c->vChr.size == 1;
+                    const bool rgb_one_one = c->vLum.size == 1 && vChrB.size == 1;
                     // The writers' short forms (packed_vscale, vscale.c:135-157, picks per output row): one luma tap with two chroma taps that sum to 4096 is yuv2rgb_1_c_template
                     // with a chroma blend -- (u0 (4096 - a) + u1 a + (128 << 11)) >> 19, output.c:1913-1937: the X arithmetic on the bank's own taps, the luma tap
                     // taken as 4096; two taps each that sum to 4096 (bilinear up-scaling: a player's 720p -> 1080p into bgra) is yuv2rgb_2_c_template, the X
@@ -1043,8 +1055,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     FilterBank vLumS, vChrS;
                     std::vector<int32_t> rnd_rows;
                     bool short_rows = false;
-                    if (!rgb_one_one && !c->needAlpha && !c->tune.no_short_forms && p.chrDstH == p.dstH && (c->vLum.size == 1 || c->vLum.size == 2) && c->vChr.size == 2) {
-                        vLumS = c->vLum; vChrS = c->vChr;
+                    if (!rgb_one_one && !c->needAlpha && !c->tune.no_short_forms && p.chrDstH == p.dstH && (c->vLum.size == 1 || c->vLum.size == 2) && vChrB.size == 2) {
+                        vLumS = c->vLum; vChrS = vChrB;
                         rnd_rows.assign((size_t)o.dst_h, 0);
                         for (int y = 0; y < o.dst_h; y++) {
                             int16_t *lf = &vLumS.taps[(size_t)y * vLumS.size], *cf = &vChrS.taps[(size_t)y * 2];
@@ -1053,7 +1065,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                             else if (vLumS.size == 2 && csum && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U) { rnd_rows[(size_t)y] = 1 << 18; short_rows = true; }
                         }
                     }
-                    const FilterBank &vLumR = short_rows ? vLumS : c->vLum, &vChrR = short_rows ? vChrS : c->vChr;
+                    const FilterBank &vLumR = short_rows ? vLumS : c->vLum, &vChrR = short_rows ? vChrS : vChrB;
                     striprgb_short = short_rows;
                     plan_rnd = short_rows ? &rnd_rows : nullptr;
                     const bool pl = plan3(hLumB, vLumR, p.dstW, rcl, 1, gl, rL, ringL, rgb_one_one || vLumR.size == 1), pc = pl && plan3(hChrB, vChrR, p.chrDstW, rcl / 2, 2, gc, rC, ringC, rgb_one_one);
@@ -1114,10 +1126,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     }
                 } else
                 {
-                  const bool tiles = !gray_both && !long_form && plan2(hLumB, c->vLum, p.dstW, p.dstH, 1, d->dotL, oL) && plan2(hChrB, c->vChr, p.chrDstW, p.chrDstH, 2, d->dotC, oC);
+                  const bool tiles = !gray_both && !long_form && plan2(hLumB, c->vLum, p.dstW, p.dstH, 1, d->dotL, oL) && plan2(hChrB, vChrB, p.chrDstW, p.chrDstH, 2, d->dotC, oC);
                   size_t ohl = 0, ohc = 0;
                   const bool altL = strip_plan && !long_form && !p.wide && plan3_alt(hLumB, c->vLum, p.dstW, 1, d->stripL, d->stripLs, sLs);
-                  const bool altC = strip_plan && !long_form && !p.wide && !gray_both && plan3_alt(hChrB, c->vChr, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
+                  const bool altC = strip_plan && !long_form && !p.wide && !gray_both && plan3_alt(hChrB, vChrB, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
                   // scaled packed RGB -> packed RGB in one launch (k_striprgb2rgb.hip): the same filters planned once more on strips of 128 columns for both plane
                   // classes (a lane owns the same destination columns of Y, U, V and A).  Luma and chroma share the vertical bank there (same source and destination
                   // heights), which the kernel's lockstep march relies on: checked tap position by tap position
@@ -1126,7 +1138,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                   bool r2r = strip_plan && rgbread && !gray_both && !long_form && !c->tune.no_strip_rgb2rgb && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32) && !alpha_planar &&
                              (d->fullchr_on == 1 || d->fullchr_on == 2) && (d->fullchr_kind == DSTK_RGB24 || d->fullchr_kind == DSTK_RGB32) &&
                              (d->fullchr_on != 2 || (p.srcKind == SRCK_RGB32 && d->fullchr_kind == DSTK_RGB32)) && p.chrDstW == p.dstW && p.chrDstH == p.dstH && p.chrSrcVSub == 0 &&
-                             c->vLum.size == c->vChr.size && c->vLum.pos == c->vChr.pos;
+                             c->vLum.size == vChrB.size && c->vLum.pos == vChrB.pos;
                   // (strips a little narrower than 128 columns where that brings the widest pixel window down to one reader turn -- 256 pixels: 120 columns at 2:1)
                   int r2r_tw = 128;
                   if (r2r && c->tune.strip_cols_auto) {
@@ -1145,7 +1157,22 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                       };
                       if (widest(128) > 256) for (int tw : { 124, 120, 116, 112, 104, 96 }) if (widest(tw) <= 256) { r2r_tw = tw; break; }
                   }
-                  r2r = r2r && plan3(hLumB, c->vLum, p.dstW, 2, 1, d->stripL2, s2l, nullptr, lum_plane1, 0, r2r_tw) && plan3(hChrB, c->vChr, p.chrDstW, 2, 2, d->stripC2, s2c, nullptr, chr_plane1, 0, r2r_tw) &&
+                  // (the full-chroma writers' short forms, per output row: SwsStripRow::rnd_off = 1 << 9 where the reference leaves the rounding out -- kernels_stream.hpp
+                  //  fullchr_row_rnd has the rule and the citations; the kernel subtracts it from its 1 << 9)
+                  std::vector<int32_t> r2r_rnd;
+                  if (r2r && !c->tune.no_short_forms && (c->vLum.size == 1 || c->vLum.size == 2) && vChrB.size == 2 && p.chrDstH == p.dstH) {
+                      r2r_rnd.assign((size_t)o.dst_h, 0);
+                      for (int y = 0; y < o.dst_h; y++) {
+                          const int16_t *lf = &c->vLum.taps[(size_t)y * c->vLum.size], *cf = &vChrB.taps[(size_t)y * 2];
+                          const bool csum = (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U;
+                          if (csum && (c->vLum.size == 1 || ((uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U))) r2r_rnd[(size_t)y] = 1 << 9;
+                      }
+                      plan_rnd = &r2r_rnd;
+                  }
+                  rgb2rgb_short = plan_rnd != nullptr;
+                  r2r = r2r && plan3(hLumB, c->vLum, p.dstW, 2, 1, d->stripL2, s2l, nullptr, lum_plane1, 0, r2r_tw);
+                  plan_rnd = nullptr;
+                  r2r = r2r && plan3(hChrB, vChrB, p.chrDstW, 2, 2, d->stripC2, s2c, nullptr, chr_plane1, 0, r2r_tw) &&
                         d->stripL2.strips == d->stripC2.strips && d->stripL2.npv == d->stripC2.npv && std::max(d->stripL2.nph, d->stripC2.nph) <= 8 && d->stripL2.npv <= 8;
                   // the lockstep strip kernel of packed sources into half-width-chroma YUV (k_striprgbsrc.hip) likewise plans for itself: luma strips of up to 256
                   // columns over chroma strips of half as many, a few columns narrower where that brings the widest pixel window down by a reader turn of 256
@@ -1172,7 +1199,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                           const int turns = (widest(256) + 255) / 256;
                           if (turns > 1) for (int tw : { 248, 240, 232 }) if ((widest(tw) + 255) / 256 < turns) { tw3 = tw; break; }
                       }
-                      rsrc = plan3(hLumB, c->vLum, p.dstW, 4, 1, d->stripL2, s3l, nullptr, lum_plane1, 0, tw3) && plan3(hChrB, c->vChr, p.chrDstW, 2, 2, d->stripC2, s3c, nullptr, chr_plane1, 0, tw3 / 2) &&
+                      rsrc = plan3(hLumB, c->vLum, p.dstW, 4, 1, d->stripL2, s3l, nullptr, lum_plane1, 0, tw3) && plan3(hChrB, vChrB, p.chrDstW, 2, 2, d->stripC2, s3c, nullptr, chr_plane1, 0, tw3 / 2) &&
                              d->stripL2.strips == d->stripC2.strips && std::max(d->stripL2.nph, d->stripC2.nph) <= 8 && d->stripL2.npv <= 8 && d->stripC2.npv <= 12;
                   }
                   if (!tiles && strip_plan) {   // (the strip kernel shares the tile kernel's padded horizontal taps; without a tile plan it gets its own copy)
@@ -1189,7 +1216,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         g.hT2 = (const int16_t *)(b + o.ht); g.vT2 = (const int16_t *)(b + o.vt);
                     };
                     if (tiles) { bind(d->dotL, oL); bind(d->dotC, oC); }
-                    d->dot2_ok = tiles && !p.wide && src_ok && fs2(c->vChr.size) <= 16 && c->vLum.size >= 2 && c->vChr.size >= 2 && !d->fullchr_on && !alpha_planar && !d->unity_h;
+                    d->dot2_ok = tiles && !p.wide && src_ok && fs2(vChrB.size) <= 16 && c->vLum.size >= 2 && vChrB.size >= 2 && !d->fullchr_on && !alpha_planar && !d->unity_h;
                     if (strip_plan) {
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         d->stripL.colStart = (const int32_t *)(b + sL.cs); d->stripL.colCount = (const int32_t *)(b + sL.cc);
@@ -1280,7 +1307,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             };
             std::vector<int32_t> aL, aC;
             if (plan(hLumB, c->vLum, p.dstW, p.dstH, p.srcW, p.srcH, 1, d->tileL, aL) &&
-                plan(hChrB, c->vChr, p.chrDstW, p.chrDstH, p.chrSrcW, p.chrSrcH, 2, d->tileC, aC)) {
+                plan(hChrB, vChrB, p.chrDstW, p.chrDstH, p.chrSrcW, p.chrSrcH, 2, d->tileC, aC)) {
                 const size_t bytes = (aL.size() + aC.size()) * sizeof(int32_t);
                 { int r_ = table_alloc(c, &d->d_tilegeom, &d->tilegeom_bytes, bytes); if (r_ < 0) return r_; }
                 std::vector<int32_t> all(aL); all.insert(all.end(), aC.begin(), aC.end());
@@ -1294,11 +1321,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             }
         }
         {   // packed_vscale picks yuv2packed1 / yuv2packed2 per row from (lfs, cfs, taps): vscale.c:135-157
-            const int lfs = c->vLum.size, cfs = c->vChr.size;
+            const int lfs = c->vLum.size, cfs = vChrB.size;
             bool all_x = !(lfs == 1 && cfs == 1);
             for (int y = 0; y < o.dst_h && all_x; y++) {
                 const int cy = y >> c->chrDstVSubSample;
-                const int16_t *lf = &c->vLum.taps[(size_t)y * lfs], *cf = &c->vChr.taps[(size_t)cy * cfs];
+                const int16_t *lf = &c->vLum.taps[(size_t)y * lfs], *cf = &vChrB.taps[(size_t)cy * cfs];
                 if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) all_x = false;
                 if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
                     (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) all_x = false;
@@ -1308,10 +1335,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             if (d->alpha_launch == 2 && !d->striprgb_ok) d->alpha_launch = 0;
             const bool kind_x = d->fullchr_kind == DSTK_GBRP || d->fullchr_kind == DSTK_PACKEDHI || d->fullchr_kind == DSTK_GBRP16 || d->fullchr_kind == DSTK_GBRPF32;   // (writers with the X form only)
             // (round 5: sws_k_fullchr_rgb tells the rows of the short forms by their taps and leaves the rounding constant out there -- yuv2rgb_full_2_c_template, the chroma
-            //  blend of yuv2rgb_full_1_c_template; the one-launch RGB -> RGB kernel has the X arithmetic only: such contexts take reader pre-pass + strip launches + epilogue)
+            //  blend of yuv2rgb_full_1_c_template; the one-launch RGB -> RGB kernel reads the same decision from its row entries)
             const bool short_full = !all_x && !c->tune.no_short_forms && (d->fullchr_on == 1 || d->fullchr_on == 2) && (d->fullchr_kind == DSTK_RGB24 || d->fullchr_kind == DSTK_RGB32) &&
                                     (lfs == 1 || lfs == 2) && cfs == 2;
-            if (!all_x && !(lfs == 1 && cfs == 1)) d->rgb2rgb_ok = false;
+            if (!all_x && !(lfs == 1 && cfs == 1) && !(short_full && rgb2rgb_short)) d->rgb2rgb_ok = false;
             if (d->fullchr_on && ((!all_x && !(lfs == 1 && cfs == 1) && !kind_x && !short_full) ||
                                   (d->fullchr_on == 4 && lfs == 1 && cfs == 1 && d->fullchr_kind != DSTK_PACKEDHI && d->fullchr_kind != DSTK_GBRP16 && d->fullchr_kind != DSTK_GBRPF32) || !d->strip_ok)) {   // (planar RGB: any_vscale, always the X form)   // no strip plan, or a row in one of the short writer forms: the generic full-chroma writer keeps it
                 d->fullchr_on = 0; d->strip_ok = false; d->rgbread_on = false; d->striprgbsrc_ok = false; d->rgb2rgb_ok = false;
@@ -1322,12 +1349,12 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             d->fullchr_direct = 0;
             if ((d->fullchr_on == 1 || d->fullchr_on == 2) && d->strip_ok && d->unity_h && d->unity_v && !d->rgbread_on && !d->split_mode && isPlanarYUV(o.src_format) &&
                 ((p.srcKind == SRCK_PLANAR8 && c->srcBpc == 8) || (p.srcKind == SRCK_PLANAR16 && p.src_depth <= 15 && p.src_shift == 0)) &&
-                p.chrSrcW == p.srcW && p.chrSrcH == p.srcH && c->vLum.size == 1 && c->vChr.size == 1 && !c->tune.no_mixed)
+                p.chrSrcW == p.srcW && p.chrSrcH == p.srcH && c->vLum.size == 1 && vChrB.size == 1 && !c->tune.no_mixed)
                 d->fullchr_direct = p.srcKind == SRCK_PLANAR8 ? 1 : 2;
             int win = 0;
             for (int y = 0; y < o.dst_h; y += 2) {
                 const int c0 = y >> c->chrDstVSubSample, c1 = std::min(y + 1, o.dst_h - 1) >> c->chrDstVSubSample;
-                const int lo = std::min(c->vChr.pos[c0], c->vChr.pos[c1]), hi = std::max(c->vChr.pos[c0], c->vChr.pos[c1]) + cfs - 1;
+                const int lo = std::min(vChrB.pos[c0], vChrB.pos[c1]), hi = std::max(vChrB.pos[c0], vChrB.pos[c1]) + cfs - 1;
                 win = std::max(win, hi - lo + 1);
             }
             d->chr_window2 = win;
@@ -1347,7 +1374,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     int first[2], yy[2];
                     for (int r = 0; r < 2; r++) {
                         yy[r] = std::min(2 * g + r, o.dst_h - 1);
-                        first[r] = std::max(1 - cfs, c->vChr.pos[yy[r] >> c->chrDstVSubSample]);
+                        first[r] = std::max(1 - cfs, vChrB.pos[yy[r] >> c->chrDstVSubSample]);
                     }
                     e.cbase = std::min(first[0], first[1]);
                     if (prev != INT32_MIN && (e.cbase < prev || e.cbase - prev > 1)) ok = false;
@@ -1355,7 +1382,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                     e.ylum0 = std::min(std::max(c->vLum.pos[yy[0]], 0), o.src_h - 1);
                     e.ylum1 = std::min(std::max(c->vLum.pos[yy[1]], 0), o.src_h - 1);
                     for (int r = 0; r < 2; r++) {
-                        const int16_t *cf = &c->vChr.taps[(size_t)(yy[r] >> c->chrDstVSubSample) * cfs];
+                        const int16_t *cf = &vChrB.taps[(size_t)(yy[r] >> c->chrDstVSubSample) * cfs];
                         if (first[r] + cfs - 1 - e.cbase >= 8) ok = false;
                         maxspan = std::max(maxspan, first[r] + cfs - 1 - e.cbase);
                         for (int ip = 0; ip < 4; ip++) {

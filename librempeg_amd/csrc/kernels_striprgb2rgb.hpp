@@ -195,6 +195,14 @@ __device__ __forceinline__ void strip_rgb2rgb_body(const FrameRegs &f, const Sws
     const SwsStripRow *rowsL = gl.rows, *rowsC = gc.rows;
     const int npv = gl.npv;                                      // (== gc.npv, and every row's first pair is the same for both: host check)
     StripRowN<RD> el = load_strip_row_n<RD>(rowsL, y0), ec = load_strip_row_n<RD>(rowsC, y0);
+    // (the writers' rounding constant of a row: 1 << 9 minus what the host wrote for the rows of yuv2rgb_full_2_c_template / the chroma blend of yuv2rgb_full_1_c_template,
+    //  which have none -- SwsStripRow::rnd_off, device.hip; round 5)
+    auto row_rnd = [&](int yy) -> unsigned {
+        typedef const uint32_t __attribute__((address_space(4))) *cptr;
+        cptr q = (cptr)(uintptr_t)(rowsL + (RD > 24 ? 4 : RD > 12 ? 2 : 1) * yy);
+        return (1u << 9) - q[1];
+    };
+    unsigned rq = row_rnd(y0);
     int qnext = el.pf;
     auto refill = [&]() {                                        // pair qnext staged, pair qnext + 1 requested
         prefetch(qnext);
@@ -210,6 +218,7 @@ __device__ __forceinline__ void strip_rgb2rgb_body(const FrameRegs &f, const Sws
     for (int y = y0; y < y1; y++) {
         const int yn = min(y + 1, H - 1);
         const StripRowN<RD> eln = load_strip_row_n<RD>(rowsL, yn), ecn = load_strip_row_n<RD>(rowsC, yn);     // next row's scalars, one row ahead
+        const unsigned rqn = row_rnd(yn);
         const int need = el.pf + npv - 1;
         if (qnext < el.pf) { qnext = el.pf; refill(); }          // pairs nobody needs (steep down-scaling with short filters)
         while (qnext <= need) {
@@ -255,8 +264,8 @@ __device__ __forceinline__ void strip_rgb2rgb_body(const FrameRegs &f, const Sws
         // yuv2rgb_full_X_c_template's tail on the sums (kernels_stream.hpp sws_k_fullchr_rgb has the same arithmetic on the int32 planes of the two-pass form)
 #pragma unroll
         for (int c = 0; c < CL; c++) {
-            int Y = (int)((unsigned)aL[0][c] + (1u << 9)) >> 10;
-            const int Uc = (int)((unsigned)aC[0][c] + (unsigned)((1 << 9) - (128 << 19))) >> 10, Vc = (int)((unsigned)aC[1][c] + (unsigned)((1 << 9) - (128 << 19))) >> 10;
+            int Y = (int)((unsigned)aL[0][c] + rq) >> 10;
+            const int Uc = (int)((unsigned)aC[0][c] + rq - (unsigned)(128 << 19)) >> 10, Vc = (int)((unsigned)aC[1][c] + rq - (unsigned)(128 << 19)) >> 10;
             Y -= y_offset;
             Y = (int)((unsigned)Y * (unsigned)y_coeff);
             Y = (int)((unsigned)Y + (1u << 21));
@@ -273,7 +282,7 @@ __device__ __forceinline__ void strip_rgb2rgb_body(const FrameRegs &f, const Sws
             pend[c] = px;
         }
         pend_y = y;
-        el = eln; ec = ecn;
+        el = eln; ec = ecn; rq = rqn;
     }
     flush();
 }

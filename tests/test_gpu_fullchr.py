@@ -65,7 +65,8 @@ def test_forced_full_chroma_and_fallbacks():
     assert run_case(256, 64, "yuva420p16le", 192, 48, "rgba", SWS_BICUBIC | FC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")       # 16-bit samples: round 5 (strip_hstage_b)
     assert not run_case(256, 64, "yuva420p16le", 192, 48, "rgba", SWS_BICUBIC | FC | BX, tune=dict(TUNE, no_strip_u16=1))[0].endswith("+fullchr_rgb")
     assert not run_case(256, 64, "rgb24", 192, 48, "rgb565le", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+fullchr_rgb")
-    assert run_case(256, 64, "rgb24", 256, 128, "bgr24", SWS_BILINEAR | BX, tune=TUNE)[0].endswith("+fullchr_rgb")       # two luma and two chroma taps: yuv2rgb_full_2 (round 5: the epilogue leaves the rounding out of such rows)
+    assert run_case(256, 64, "rgb24", 256, 128, "bgr24", SWS_BILINEAR | BX, tune=dict(TUNE, no_strip_rgb2rgb=1))[0].endswith("+fullchr_rgb")     # two luma and two chroma taps: yuv2rgb_full_2 (round 5: the epilogue leaves the rounding out of such rows)
+    assert run_case(256, 64, "rgb24", 256, 128, "bgr24", SWS_BILINEAR | BX, tune=TUNE)[0] == "main:strip_rgb2rgb"        # (... and so does the one-launch kernel, from its row entries)
     assert not run_case(256, 64, "rgb24", 256, 128, "bgr24", SWS_BILINEAR | BX, tune=dict(TUNE, no_short_forms=1))[0].endswith("+fullchr_rgb")
     assert not run_case(480, 48, "rgb24", 240, 24, "bgr24", SWS_BICUBIC | BX)[0].endswith("+fullchr_rgb")                # narrow: below the planner's width threshold
 

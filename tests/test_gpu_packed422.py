@@ -31,7 +31,10 @@ def test_formats(src, dst):
 def test_short_vertical_forms_keep_the_packed_writer():
     # bilinear 2x vertical upscale: two luma and two chroma taps (yuv2422_2); same-size 4:2:0 -> 4:2:2 bilinear: one luma, two chroma taps (yuv2422_1)
     assert not run_case(256, 64, "yuv420p", 256, 128, "yuyv422", SWS_BILINEAR | BX)[0].endswith("+join422")
-    assert not run_case(256, 64, "yuv420p", 256, 64, "yuyv422", SWS_BILINEAR | BX)[0].endswith("+join422")
+    # (round 5: ... whose blend -- the first chroma row below 2048, the mean of both rows from there on -- is the X arithmetic over substituted taps: the planar writers + join, or the one-pass kernel)
+    assert run_case(640, 64, "yuv420p", 640, 64, "yuyv422", SWS_BILINEAR | BX)[0] == "main:mixed_join422"
+    assert run_case(640, 64, "yuv420p", 320, 64, "yuyv422", SWS_BILINEAR | BX)[0].endswith("+join422")
+    assert not run_case(640, 64, "yuv420p", 640, 64, "yuyv422", SWS_BILINEAR | BX, tune=dict(no_short_forms=1))[0].endswith("join422")
     assert run_case(256, 64, "yuv420p10le", 256, 64, "yuyv422", SWS_BICUBIC | BX)[0].endswith("+join422")     # (the ordered dither belongs to the planar 8-bit writers only)
     assert not run_case(255, 64, "yuv420p", 255, 64, "yuyv422", SWS_BICUBIC | BX)[0].endswith("+join422")         # odd width: the last pair
     assert run_case(640, 64, "yuv420p", 640, 64, "yuyv422", SWS_BICUBIC | BX)[0] == "main:mixed_join422"       # (round 5: plane pass, chroma strip launch and interleave as one pass)
@@ -47,11 +50,11 @@ def test_same_size_one_pass(src, dst):
     """sws_k_mixed_join422: vertical chroma filters of every scaler, odd heights, one-row pictures, host frames, sources with other horizontal chroma steps (not its shape)"""
     from librempeg_amd import SWS_GAUSS, SWS_SPLINE, SWS_SINC, SWS_POINT
     for (w, h) in ((256, 64), (1920, 1080), (640, 37), (64, 1), (32, 2), (3840, 6)):
-        for fl in (SWS_BICUBIC, SWS_LANCZOS, SWS_AREA, SWS_GAUSS, SWS_SPLINE, SWS_SINC, SWS_POINT, SWS_BICUBIC | AR):
-            if (w, h) == (1920, 1080) and fl not in (SWS_BICUBIC, SWS_LANCZOS):
+        for fl in (SWS_BICUBIC, SWS_LANCZOS, SWS_AREA, SWS_GAUSS, SWS_SPLINE, SWS_SINC, SWS_POINT, SWS_BICUBIC | AR, SWS_BILINEAR, SWS_FAST_BILINEAR):
+            if (w, h) == (1920, 1080) and fl not in (SWS_BICUBIC, SWS_LANCZOS, SWS_BILINEAR):
                 continue
             r = run_case(w, h, src, w, h, dst, fl | BX, seed=w + h, tune=TUNE)
-            if fl == SWS_BICUBIC and src in ("yuv420p", "nv12", "nv21") and h > 2:
+            if fl in (SWS_BICUBIC, SWS_BILINEAR) and src in ("yuv420p", "nv12", "nv21") and h > 2:
                 assert r[0] == "main:mixed_join422", (r[0], src, dst, w, h)
     run_case(1280, 720, src, 1280, 720, dst, SWS_BICUBIC | BX, seed=5, device_frames=False)
     opts = dict(dither=1, src_range=0, dst_range=0, src_h_chr_pos=-513, src_v_chr_pos=128, dst_h_chr_pos=-513, dst_v_chr_pos=-513, threads=1)
