@@ -34,7 +34,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from librempeg_amd import (SwsContext, DeviceFrame, HostFrame, plane_layout,  # noqa: E402
-                           SWS_BICUBIC, SWS_BILINEAR, SWS_LANCZOS, SWS_BITEXACT, SWS_ACCURATE_RND, SWS_CS_BT2020)
+                           SWS_BICUBIC, SWS_BILINEAR, SWS_FAST_BILINEAR, SWS_LANCZOS, SWS_BITEXACT, SWS_ACCURATE_RND, SWS_CS_BT2020)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -76,6 +76,12 @@ WORKLOADS = {
     # round 5: 19-bit intermediates -- decoder output into planar float RGB (inference input)
     "w1": (3840, 2160, "nv12", 1920, 1080, "gbrpf32le", SWS_BICUBIC | SWS_BITEXACT, None, 32,
            "W1 3840x2160->1920x1080 nv12->gbrpf32le SWS_BICUBIC|SWS_BITEXACT (decoder output -> planar float RGB)"),
+    # round 5: the flags players and capture tools pass -- SWS_FAST_BILINEAR (ff_hyscale_fast_c as two-tap banks under the strip kernels) and bilinear up-scaling into
+    # packed RGB (the writers' short vertical forms in the strip plan)
+    "f1": (3840, 2160, "yuv420p", 1920, 1080, "yuv420p", SWS_FAST_BILINEAR, None, 64,
+           "F1 3840x2160->1920x1080 yuv420p SWS_FAST_BILINEAR (the fast horizontal functions as two-tap banks)"),
+    "u1": (1280, 720, "yuv420p", 1920, 1080, "bgra", SWS_BILINEAR, None, 64,
+           "U1 1280x720->1920x1080 yuv420p->bgra SWS_BILINEAR (a player's up-scaling: yuv2rgb_2 rows in the strip plan)"),
 }
 
 
@@ -401,7 +407,7 @@ def main():
                           "cpu_baseline": None}), flush=True)
         return
     main_res = run_workload(args.workload, args.batch, args.steps, args.warmup, rank, world, local_rank, barrier)
-    variants = [] if args.variants in ("", "none") else (["c2b", "c3b", "d1", "c1", "e2", "r1", "w1"] if args.variants == "auto" and args.workload == "c2a"
+    variants = [] if args.variants in ("", "none") else (["c2b", "c3b", "d1", "c1", "e2", "r1", "w1", "f1", "u1"] if args.variants == "auto" and args.workload == "c2a"
                                                           else [] if args.variants == "auto" else args.variants.split(","))
     var_res = []
     for v in variants:
