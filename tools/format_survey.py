@@ -15,7 +15,8 @@ geo = {"same": (1920, 1080, 1920, 1080), "down": (3840, 2160, 1920, 1080), "up":
 if mode == "same4k": N = 8
 sw, sh, dw, dh = geo
 rows = []
-for base in ("yuv420p", "nv12", "bgra", "yuv420p10le"):
+BASES = os.environ.get("SWS_SURVEY_BASES", "yuv420p,nv12,bgra,yuv420p10le").split(",")
+for base in BASES:
     for other in FMTS:
         for sf, df in ((base, other), (other, base)):
             if sf == df and mode in ("same", "same4k"): continue

@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-for w in ${SWS_PROFILE_WLS:-c2a c2b c4 c3a c3b c5 c1 d1 d2 e1 e2 r1 r2 w1}; do
+for w in ${SWS_PROFILE_WLS:-c2a c2b c4 c3a c3b c5 c1 d1 d2 e1 e2 r1 r2 w1 f1 u1}; do
     python bench.py --workload $w --variants none --no-cpu --steps 20 --warmup 3 > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"
     (cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/prof_$w" -o res -- python "$OLDPWD/bench.py" --workload $w --variants none --no-cpu --steps 20 --warmup 3 > "$OUT/prof_$w.log" 2>&1)
     db=$(find "$OUT/prof_$w" -name "*.db" | head -1)

@@ -6,7 +6,7 @@ OUT=$PWD/gpurun_out/r05p; mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$PWD
 tools/profile_all.sh r05p > $OUT/bench_lines.jsonl 2>$OUT/profile_all.err
-tools/pmc_traffic.sh r05p "c2a c2b c4 c3a c3b c5 c1 d1 r1 w1" > $OUT/pmc_traffic.txt 2>&1
+tools/pmc_traffic.sh r05p "c2a c2b c4 c3a c3b c5 c1 d1 r1 w1 f1 u1" > $OUT/pmc_traffic.txt 2>&1
 python tools/layout_times.py > $OUT/layout.md 2>$OUT/layout.err
 python tools/common_shapes_times.py > $OUT/common.md 2>$OUT/common.err
 python tools/rgb2rgb_times.py > $OUT/rgb2rgb.md 2>$OUT/rgb2rgb.err
@@ -18,7 +18,16 @@ SWS_SHAPES_SET=range python tools/common_shapes_times.py > $OUT/range.md 2>$OUT/
 SWS_SHAPES_SET=wide python tools/common_shapes_times.py > $OUT/wide.md 2>$OUT/wide.err
 SWS_SHAPES_SET=u16 python tools/common_shapes_times.py > $OUT/u16.md 2>$OUT/u16.err
 { python tools/narrow_shapes_times.py; SWS_NARROW_SET=small python tools/narrow_shapes_times.py; } 2>$OUT/narrow.err | grep '^|' > $OUT/narrow.md
-for m in same down up; do python tools/format_survey.py $m > $OUT/survey_$m.md 2>$OUT/survey_$m.err; done
+for m in same down up same4k; do python tools/format_survey.py $m > $OUT/survey_$m.md 2>$OUT/survey_$m.err; done
+# the same surveys with the flags players and capture tools pass (SWS_BILINEAR = 2, SWS_FAST_BILINEAR = 1, SWS_POINT = 0x10), and the shapes with the options switched off
+for m in same4k down up; do
+  SWS_SURVEY_FLAGS=2 python tools/format_survey.py $m > $OUT/flags_bilinear_$m.md 2>/dev/null
+  SWS_SURVEY_FLAGS=1 python tools/format_survey.py $m > $OUT/flags_fastbilinear_$m.md 2>/dev/null
+done
+SWS_SURVEY_FLAGS=16 python tools/format_survey.py down > $OUT/flags_point_down.md 2>/dev/null
+python tools/hdr_capture_times.py > $OUT/hdr_capture.md 2>$OUT/hdr_capture.err
+python tools/flags_before_after.py > $OUT/flags_before_after.md 2>$OUT/flags_before_after.err
+python bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err
 (cd /tmp && SWS_SHAPES_SET=ladder rocprofv3 --kernel-trace --stats -d $OUT/prof_ladder -o res -- python $ROOT/tools/common_shapes_times.py > $OUT/prof_ladder.log 2>&1)
 db=$(find $OUT/prof_ladder -name "*.db" | head -1)
 [ -n "$db" ] && python tools/rocpd_summary.py "$db" "r05 ladder shapes (ratios of 3:1 and more): SWS_SHAPES_SET=ladder rocprofv3 --kernel-trace --stats -- python tools/common_shapes_times.py" > $OUT/kernel_stats_ladder.md
