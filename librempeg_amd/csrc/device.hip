@@ -770,7 +770,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                                         // (the 8-bit packed 4:4:4 formats -- ayuv / vuya / vuyx / uyva / vyu444: bytes, hScale8To15_c's sh = 7 -- as 16-bit words with 8 significant bits)
                                         (p.srcKind == SRCK_PACKED444 && p.src_depth == 8 && c->srcBpc == 8)) && !p.need_alpha && !c->needAlpha &&   // (an alpha component nobody reads is skipped)
                                        !c->tune.no_rgbread_kinds;
-            bool rgbread = (!p.wide || !c->tune.no_strip_wide) && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || rgbread_kindN) && p.chrSrcHSub <= 1 && p.chrSrcW == (p.srcW >> p.chrSrcHSub) && !(p.srcW & 3) && p.chrSrcVSub == 0 && (!p.need_alpha || d->fullchr_on == 2 || alpha_planar) &&
+            bool rgbread = (!p.wide || !c->tune.no_strip_wide) && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || rgbread_kindN) && p.chrSrcHSub <= 1 && p.chrSrcW == (p.srcW >> p.chrSrcHSub) && !(p.srcW & 1) && p.chrSrcVSub == 0 && (!p.need_alpha || d->fullchr_on == 2 || alpha_planar) &&
                            (!p.dst_alpha_fill || d->fullchr_on) && (!p.no_chroma || (isGray(o.dst_format) && !isGray(o.src_format) && !c->tune.no_strip_range)) && !vlines_pending && dst_ok && !c->tune.no_strip && !c->tune.no_rgbsrc && p.dstW >= strip_min_w_eff;
             for (int k = 0; k < 9 && rgbread; k++) rgbread = p.rgb2yuv[k] > -32768 && p.rgb2yuv[k] < 32768;   // (v_dot2_i32_i16 operands)
             d->rgbread_on = false;
@@ -1135,7 +1135,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                   // heights), which the kernel's lockstep march relies on: checked tap position by tap position
                   SOff s2l, s2c;
                   d->rgb2rgb_ok = false;
-                  bool r2r = strip_plan && rgbread && !gray_both && !long_form && !c->tune.no_strip_rgb2rgb && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32) && !alpha_planar &&
+                  bool r2r = strip_plan && rgbread && !(p.srcW & 3) && !gray_both && !long_form && !c->tune.no_strip_rgb2rgb && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32) && !alpha_planar &&
                              (d->fullchr_on == 1 || d->fullchr_on == 2) && (d->fullchr_kind == DSTK_RGB24 || d->fullchr_kind == DSTK_RGB32) &&
                              (d->fullchr_on != 2 || (p.srcKind == SRCK_RGB32 && d->fullchr_kind == DSTK_RGB32)) && p.chrDstW == p.dstW && p.chrDstH == p.dstH && p.chrSrcVSub == 0 &&
                              c->vLum.size == vChrB.size && c->vLum.pos == vChrB.pos;
@@ -1179,7 +1179,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                   // pixels (248 columns at 2:1: 504 pixels, two turns instead of three).  (YUV destinations: never together with the RGB -> RGB plans above)
                   const bool packed422_src = (d->split_mode & 3) && !(d->split_mode & 40) && p.srcKind == SRCK_PLANAR8 && p.chrSrcW == (p.srcW >> 1) && p.chrSrcVSub == 0 && !vlines_pending;
                   SOff s3l, s3c;
-                  bool rsrc = strip_plan && !r2r && !p.wide && ((rgbread && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || p.srcKind == SRCK_RGB30) && p.chr_half) || packed422_src) && !gray_both && !long_form &&
+                  bool rsrc = strip_plan && !r2r && !p.wide && ((rgbread && !(p.srcW & 3) && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || p.srcKind == SRCK_RGB30) && p.chr_half) || packed422_src) && !gray_both && !long_form &&
                               !c->tune.no_strip_rgbsrc && !alpha_planar && !p.need_alpha && !d->fullchr_on &&
                               p.chrDstW == ((p.dstW + 1) >> 1) && (p.chrDstVSub == 0 ? p.chrDstH == p.dstH : (p.chrDstVSub == 1 && p.chrDstH == ((p.dstH + 1) >> 1)));
                   if (rsrc) {
@@ -1904,7 +1904,13 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         fs.table = table_upload(c, d, st, TAB_MAIN, frames, n);
         if (!fs.table) return AVERROR_EXTERNAL_;
     }
-    const bool vec = frames_vec_ok(frames, n);
+    bool vec = frames_vec_ok(frames, n);
+    // (round 5: the reader pre-pass of 24 / 32 bpp and planar 8-bit RGB sources takes widths of 4 k + 2 -- 1366 x 768 screens -- and reads the last group of four
+    //  pixels whole: the row must hold it; a tightly packed rgb24 row whose padding is shorter goes to the per-sample kernels like an unaligned frame)
+    if (vec && d->rgbread_on && (p.srcW & 3) && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP))
+        for (int i = 0; i < n && vec; i++)
+            for (int k = 0; k < (p.srcKind == SRCK_GBRP ? 3 : 1); k++)
+                if (frames[i].srcStride[k] < (p.srcKind == SRCK_RGB24 ? 3 : p.srcKind == SRCK_RGB32 ? 4 : 1) * (p.srcW + 2)) vec = false;
     L.c = c; L.d = d; L.p = &p; L.st = st; L.frames = frames; L.n = n; L.sliceY = sliceY; L.sliceH = sliceH; L.vec = vec;
     if (d->timing && !timing_started) { HIPCHK(hipEventRecord(d->ev0, st)); }
 

@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) sws_k_rgb_read16(SwsFrameSet fs, SwsDevPa
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int W = U(p.srcW), H = U(p.srcH), x0 = 4 * t;
-    if (x0 >= W) return;                               // (W is a multiple of 4: host check)
+    if (x0 >= W) return;                               // (W even; a width of 4 k + 2 reads and writes its last group whole: the rows hold it, device.hip)
     const FrameRegs f = load_frame(fs, blockIdx.z);
     const int y0 = blockIdx.y * RGBREAD_RPW, y1 = min(H, y0 + RGBREAD_RPW);
     const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);

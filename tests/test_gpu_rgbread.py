@@ -40,7 +40,8 @@ def test_scalers_and_geometries(flags, geom):
 def test_planner_and_fallbacks():
     assert run_case(1920, 54, "rgb24", 1280, 36, "yuv420p", SWS_BICUBIC | BX, tune=TWO)[0] == PATH                       # wide enough without the option
     assert run_case(480, 48, "rgb24", 240, 24, "yuv420p", SWS_BICUBIC | BX, tune=TWO)[0] != PATH                         # narrow: tile kernel
-    assert run_case(642, 48, "rgb24", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0] != PATH              # width not a multiple of 4
+    assert run_case(642, 48, "rgb24", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0] == PATH              # a width of 4 k + 2 (round 5: the last group of four pixels is read whole)
+    assert run_case(643, 48, "rgb24", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0] != PATH              # odd width
     assert run_case(640, 48, "rgb24", 480, 36, "yuv420p", SWS_BILINEAR | SWS_FULL_CHR_H_INP | BX, tune=TUNE)[0] == PATH            # the full-width chroma readers
     assert run_case(640, 48, "rgb24", 320, 24, "yuv420p", SWS_BICUBIC | SWS_FULL_CHR_H_INP | BX, tune=TUNE)[0] == PATH             # (4:1 bicubic chroma, 17 taps: the strip kernel's long form)
     assert run_case(640, 48, "rgba", 320, 24, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0] != PATH
@@ -85,3 +86,17 @@ def test_batches():
                 out = dsts[k].download()
                 for a, b, rb in zip(out.planes, refs[k].planes, out.row_bytes):
                     assert np.array_equal(a[:, :rb], b[:, :rb]), (src, dst, k, rep)
+
+
+@pytest.mark.parametrize("src", ["rgb24", "bgr24", "bgra", "rgba", "argb", "rgb0", "gbrp", "gbrap", "x2rgb10le", "rgb565le", "gbrp10le", "rgb48le", "rgba64le", "gbrpf32le"])
+def test_widths_of_4k_plus_2(src):
+    """1366 x 768 screens, 854 x 480: source widths that are even but not multiples of 4 through the reader pre-pass (the last group of four pixels is read and written whole;
+    the one-launch kernels keep their multiple-of-4 rule and hand such pictures to the pre-pass), into YUV, gray and RGB destinations, from HBM frames with padded rows and from
+    host frames"""
+    for dst in ("yuv420p", "nv12", "yuv444p", "yuv420p10le", "bgra", "rgb24", "gray8", "yuyv422", "yuva420p", "yuv420p16le"):
+        for (sw, sh, dw, dh, fl) in ((1366, 48, 1280, 44, SWS_BICUBIC), (854, 48, 1282, 72, SWS_BICUBIC), (642, 30, 322, 15, SWS_BILINEAR), (1918, 22, 1278, 14, SWS_LANCZOS), (646, 26, 646, 26, SWS_BICUBIC),
+                                     (650, 33, 400, 33, SWS_BILINEAR)):
+            run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh)
+    assert "rgbread" in run_case(1366, 48, src, 1280, 44, "yuv420p", SWS_BICUBIC | BX, seed=1)[0]
+    run_case(1366, 768, src, 1280, 720, "yuv420p", SWS_BICUBIC | BX, seed=2, device_frames=False)
+    run_case(1366, 768, src, 1280, 720, "bgra", SWS_BILINEAR, seed=3)

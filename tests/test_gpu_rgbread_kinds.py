@@ -45,7 +45,8 @@ def test_scalers_and_geometries(flags, geom):
 
 def test_planner_and_fallbacks():
     assert "rgbread" in run_case(1920, 54, "gbrp10le", 1280, 36, "yuv420p", SWS_BICUBIC | BX)[0]                   # wide enough without the option
-    assert "rgbread" not in run_case(642, 48, "rgb565le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0]      # width not a multiple of 4
+    assert "rgbread" in run_case(642, 48, "rgb565le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0]          # a width of 4 k + 2 (round 5)
+    assert "rgbread" not in run_case(643, 48, "rgb565le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0]      # odd width
     assert "rgbread" in run_case(640, 48, "gbrap10le", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0]         # a source with an alpha plane nobody reads
     assert "rgbread" not in run_case(640, 48, "gbrap10le", 320, 24, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0]    # ... and one the destination wants scaled
     assert "rgbread" not in run_case(640, 48, "ayuv", 320, 24, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0]

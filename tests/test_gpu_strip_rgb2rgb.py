@@ -43,7 +43,7 @@ def test_scalers_and_geometries(flags, geom):
 def test_planner_and_fallbacks():
     assert run_case(1920, 54, "bgra", 1280, 36, "bgra", SWS_BICUBIC | BX)[0] == PATH
     assert run_case(1920, 54, "bgra", 1280, 36, "bgra", SWS_BICUBIC | BX, tune=dict(no_strip_rgb2rgb=1))[0] == OLD
-    assert run_case(1282, 48, "rgb24", 642, 24, "rgb24", SWS_BICUBIC | BX, tune=TUNE)[0] != PATH               # source width not a multiple of 4: the reader pre-pass does not take it either
+    assert run_case(1282, 48, "rgb24", 642, 24, "rgb24", SWS_BICUBIC | BX, tune=TUNE)[0] == OLD                # source width not a multiple of 4: the reader pre-pass (which takes 4 k + 2), strip launches, epilogue
     assert run_case(1280, 96, "rgb24", 320, 24, "rgb24", SWS_BICUBIC | BX, tune=TUNE)[0] != PATH               # 17 taps: the long forms
     assert run_case(640, 48, "gbrp", 480, 36, "rgb24", SWS_BILINEAR | BX, tune=TUNE)[0] != PATH                # planar RGB source
     assert run_case(640, 48, "rgb24", 480, 36, "gbrp", SWS_BILINEAR | BX, tune=TUNE)[0] != PATH                # planar RGB destination: its own epilogue

@@ -44,7 +44,7 @@ def test_planner_and_fallbacks():
     assert run_case(1920, 54, "rgb24", 1280, 36, "yuv420p", SWS_BICUBIC | BX)[0] == PATH                       # wide enough without the option
     assert run_case(1920, 54, "rgb24", 1280, 36, "yuv420p", SWS_BICUBIC | BX, tune=dict(no_strip_rgbsrc=1))[0] == "main:rgbread+strip_march"
     assert run_case(480, 48, "rgb24", 240, 24, "yuv420p", SWS_BICUBIC | BX)[0] != PATH                         # narrow: tile kernel
-    assert run_case(642, 48, "rgb24", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0] != PATH              # width not a multiple of 4
+    assert run_case(642, 48, "rgb24", 320, 24, "yuv420p", SWS_BICUBIC | BX, tune=TUNE)[0] == "main:rgbread+strip_march"    # width not a multiple of 4: the reader pre-pass (which takes 4 k + 2)
     assert run_case(640, 48, "rgb24", 480, 36, "yuv420p", SWS_BILINEAR | SWS_FULL_CHR_H_INP | BX, tune=TUNE)[0] == "main:rgbread+strip_march"   # the full-width chroma readers
     assert run_case(640, 48, "rgb24", 480, 36, "yuv444p", SWS_BILINEAR | BX, tune=TUNE)[0] == "main:rgbread+strip_march"    # full-width chroma planes
     assert run_case(640, 48, "gbrp", 480, 36, "yuv420p", SWS_BILINEAR | BX, tune=TUNE)[0] == PATH                           # planar RGB: three planes, the same readers

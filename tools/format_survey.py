@@ -14,6 +14,7 @@ FMTS = ["yuv420p", "yuv422p", "yuv444p", "nv12", "nv21", "p010le", "yuv420p10le"
 geo = {"same": (1920, 1080, 1920, 1080), "down": (3840, 2160, 1920, 1080), "up": (1280, 720, 1920, 1080), "same4k": (3840, 2160, 3840, 2160)}[mode]
 if mode == "same4k": N = 8
 sw, sh, dw, dh = geo
+if os.environ.get("SWS_SURVEY_GEOM"): sw, sh, dw, dh = [int(v) for v in os.environ["SWS_SURVEY_GEOM"].split(",")]
 rows = []
 BASES = os.environ.get("SWS_SURVEY_BASES", "yuv420p,nv12,bgra,yuv420p10le").split(",")
 for base in BASES:
