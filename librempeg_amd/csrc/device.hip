@@ -428,12 +428,12 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     //  plane: the A bytes of a packed 32 bpp source come from the reader pre-pass, a planar source has them in plane 3)
     // (planar RGB destinations of 8 .. 14 bits -- gbrp, gbrap, gbrp10le ...: yuv2gbrp_full_X_c is the same matrix with its own shifts, sws_k_fullchr_gbrp)
     const bool fc_alpha = c->needAlpha && (p.dstKind == DSTK_RGB32 || p.dstKind == DSTK_GBRP) &&
-                          ((p.srcKind == SRCK_RGB32 && !(o.src_w & 3)) || ((p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_PLANAR16) && isPlanarYUV(o.src_format)));
+                          ((p.srcKind == SRCK_RGB32 && !(o.src_w & 1)) || ((p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_PLANAR16) && isPlanarYUV(o.src_format)));
     // (the same for a planar YUV destination with an alpha plane -- bgra -> yuva420p, yuva444p10le -> yuva420p: the A samples through the luma filters
     //  and the luma plane's writer into dst[3], swscale.c:478-486 / vscale.c:66-70; decided with the strip plan below)
     const bool alpha_planar = c->plan == PLAN_MAIN && c->needAlpha && (p.dstKind == DSTK_PLANAR8 || p.dstKind == DSTK_PLANARN) && isPlanarYUV(o.dst_format) &&
                               !isGray(o.src_format) && !fast_flag && !c->tune.no_strip && !c->tune.no_mixed &&
-                              ((p.srcKind == SRCK_RGB32 && !(o.src_w & 3)) || ((p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_PLANAR16) && isPlanarYUV(o.src_format)));
+                              ((p.srcKind == SRCK_RGB32 && !(o.src_w & 1)) || ((p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_PLANAR16) && isPlanarYUV(o.src_format)));
     d->alpha_launch = 0;
     // (filters of more than 16 taps -- ratios of 4:1 and more -- have the strip kernel's long form with 128-column strips on one side and the element-per-thread
     //  kernels on the other: the planner's width threshold for them is 64 columns)

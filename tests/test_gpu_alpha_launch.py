@@ -49,7 +49,8 @@ def test_range_conversion_and_fallbacks():
     assert run_case(256, 64, "bgra", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE, opts=ro)[0] == "main:rgbread+strip_march+alpha"
     assert run_case(256, 64, "bgra", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0] == "main:rgbread+strip_march+alpha"
     assert run_case(256, 64, "yuva420p", 192, 48, "yuva444p10le", SWS_BICUBIC | BX, tune=TUNE)[0] == "main:strip_march+alpha"
-    assert not run_case(254, 64, "bgra", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+alpha")         # the reader pre-pass takes widths of 4 n
+    assert run_case(254, 64, "bgra", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+alpha")             # (round 5: the reader pre-pass takes widths of 4 n + 2 too)
+    assert not run_case(253, 64, "bgra", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+alpha")         # odd widths: not
     assert not run_case(256, 64, "gbrap", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+alpha")        # planar RGB with alpha: a << 6 samples
     assert run_case(256, 64, "yuva420p16le", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=TUNE)[0].endswith("+alpha")      # 16-bit samples: round 5 (strip_hstage_b), the A plane included
     assert not run_case(256, 64, "yuva420p16le", 192, 48, "yuva420p", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_u16=1))[0].endswith("+alpha")

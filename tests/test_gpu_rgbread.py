@@ -93,7 +93,7 @@ def test_widths_of_4k_plus_2(src):
     """1366 x 768 screens, 854 x 480: source widths that are even but not multiples of 4 through the reader pre-pass (the last group of four pixels is read and written whole;
     the one-launch kernels keep their multiple-of-4 rule and hand such pictures to the pre-pass), into YUV, gray and RGB destinations, from HBM frames with padded rows and from
     host frames"""
-    for dst in ("yuv420p", "nv12", "yuv444p", "yuv420p10le", "bgra", "rgb24", "gray8", "yuyv422", "yuva420p", "yuv420p16le"):
+    for dst in ("yuv420p", "nv12", "yuv444p", "yuv420p10le", "bgra", "rgb24", "gray8", "yuyv422", "yuva420p", "yuv420p16le", "rgba", "yuva444p", "gbrap"):
         for (sw, sh, dw, dh, fl) in ((1366, 48, 1280, 44, SWS_BICUBIC), (854, 48, 1282, 72, SWS_BICUBIC), (642, 30, 322, 15, SWS_BILINEAR), (1918, 22, 1278, 14, SWS_LANCZOS), (646, 26, 646, 26, SWS_BICUBIC),
                                      (650, 33, 400, 33, SWS_BILINEAR)):
             run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh)
