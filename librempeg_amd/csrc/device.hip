@@ -1904,13 +1904,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
         fs.table = table_upload(c, d, st, TAB_MAIN, frames, n);
         if (!fs.table) return AVERROR_EXTERNAL_;
     }
-    bool vec = frames_vec_ok(frames, n);
-    // (round 5: the reader pre-pass of 24 / 32 bpp and planar 8-bit RGB sources takes widths of 4 k + 2 -- 1366 x 768 screens -- and reads the last group of four
-    //  pixels whole: the row must hold it; a tightly packed rgb24 row whose padding is shorter goes to the per-sample kernels like an unaligned frame)
-    if (vec && d->rgbread_on && (p.srcW & 3) && (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP))
-        for (int i = 0; i < n && vec; i++)
-            for (int k = 0; k < (p.srcKind == SRCK_GBRP ? 3 : 1); k++)
-                if (frames[i].srcStride[k] < (p.srcKind == SRCK_RGB24 ? 3 : p.srcKind == SRCK_RGB32 ? 4 : 1) * (p.srcW + 2)) vec = false;
+    const bool vec = frames_vec_ok(frames, n);
     L.c = c; L.d = d; L.p = &p; L.st = st; L.frames = frames; L.n = n; L.sliceY = sliceY; L.sliceH = sliceH; L.vec = vec;
     if (d->timing && !timing_started) { HIPCHK(hipEventRecord(d->ev0, st)); }
 

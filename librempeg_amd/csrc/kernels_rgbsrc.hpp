@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) sws_k_rgb_read16(SwsFrameSet fs, SwsDevPa
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int W = U(p.srcW), H = U(p.srcH), x0 = 4 * t;
-    if (x0 >= W) return;                               // (W even; a width of 4 k + 2 reads and writes its last group whole: the rows hold it, device.hip)
+    if (x0 >= W) return;                               // (W even; a width of 4 k + 2 writes its last group whole: the working planes hold it)
     const FrameRegs f = load_frame(fs, blockIdx.z);
     const int y0 = blockIdx.y * RGBREAD_RPW, y1 = min(H, y0 + RGBREAD_RPW);
     const Rgb2YuvRow ty = rgb2yuv_row(p.rgb2yuv, 0), tu = rgb2yuv_row(p.rgb2yuv, 3), tv = rgb2yuv_row(p.rgb2yuv, 6);
@@ -216,8 +216,15 @@ __global__ void __launch_bounds__(256) sws_k_rgb_read16(SwsFrameSet fs, SwsDevPa
     uint8_t *dY = fb + 2 * (int64_t)x0, *dU = fb + U(lay.offU) + (int64_t)x0 * (HALF ? 1 : 2), *dV = fb + U(lay.offV) + (int64_t)x0 * (HALF ? 1 : 2);
     const int64_t dsY = U(lay.strideY), dsC = U(lay.strideC);
     uint32_t nx[4] = {};
+    const bool tail = x0 + 4 > W;                      // (a width of 4 k + 2: the last group holds two pixels -- nothing is read behind the row's last pixel)
     auto fetch = [&](int r) {
         const uint8_t *row = s0 + (int64_t)r * sst + (int64_t)(BPP ? BPP : 1) * x0;
+        if (tail) {
+            if (BPP == 0) { nx[0] = *(const uint16_t *)row; nx[1] = *(const uint16_t *)(s1 + (int64_t)r * sst1 + x0); nx[2] = *(const uint16_t *)(s2 + (int64_t)r * sst2 + x0); }
+            else if (BPP == 3) { nx[0] = ((const uint32_t *)row)[0]; nx[1] = ((const uint16_t *)row)[2]; nx[2] = 0; }
+            else { nx[0] = ((const uint32_t *)row)[0]; nx[1] = ((const uint32_t *)row)[1]; nx[2] = nx[3] = 0; }
+            return;
+        }
         if (BPP == 0) { nx[0] = *(const uint32_t *)row; nx[1] = *(const uint32_t *)(s1 + (int64_t)r * sst1 + x0); nx[2] = *(const uint32_t *)(s2 + (int64_t)r * sst2 + x0); }
         else if (BPP == 3) { nx[0] = ((const uint32_t *)row)[0]; nx[1] = ((const uint32_t *)row)[1]; nx[2] = ((const uint32_t *)row)[2]; }
         else { const uint4 q = *(const uint4 *)row; nx[0] = q.x; nx[1] = q.y; nx[2] = q.z; nx[3] = q.w; }

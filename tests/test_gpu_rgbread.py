@@ -97,6 +97,10 @@ def test_widths_of_4k_plus_2(src):
         for (sw, sh, dw, dh, fl) in ((1366, 48, 1280, 44, SWS_BICUBIC), (854, 48, 1282, 72, SWS_BICUBIC), (642, 30, 322, 15, SWS_BILINEAR), (1918, 22, 1278, 14, SWS_LANCZOS), (646, 26, 646, 26, SWS_BICUBIC),
                                      (650, 33, 400, 33, SWS_BILINEAR)):
             run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh)
+    # (rows without room behind their last pixel: 170 x 3 = 510 bytes in a line of 512, 426 x 3 = 1278 in 1280 -- the last group's loads stop at the last pixel)
+    for dst in ("rgb0", "gbrp10le", "argb", "yuv420p", "bgr444le"):
+        for (sw, sh, dw, dh, fl) in ((170, 77, 608, 63, SWS_BICUBIC), (170, 20, 161, 26, SWS_BICUBIC), (170, 23, 334, 28, SWS_BILINEAR), (426, 78, 580, 79, SWS_BICUBIC)):
+            run_case(sw, sh, src, dw, dh, dst, fl | BX, seed=sw + dh, tune=dict(strip_min_w=0))
     assert "rgbread" in run_case(1366, 48, src, 1280, 44, "yuv420p", SWS_BICUBIC | BX, seed=1)[0]
     run_case(1366, 768, src, 1280, 720, "yuv420p", SWS_BICUBIC | BX, seed=2, device_frames=False)
     run_case(1366, 768, src, 1280, 720, "bgra", SWS_BILINEAR, seed=3)

@@ -1,7 +1,13 @@
 import sys; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+from test_gpu_parity import run_case
 from librempeg_amd import *
-for tune in ({}, dict(no_fast_banks=1), dict(strip_min_w=0, no_fast_banks=1), dict(no_fast_banks=1, strip_min_w=0)):
-    p = SwsContext(400, 66, "yuv420p", 332, 54, "yuv420p", SWS_FAST_BILINEAR | SWS_BITEXACT)
-    for k,v in tune.items(): print("set", k, v, p.set_option(k,v))
-    hs = HostFrame("yuv420p", 400, 66); hd = HostFrame("yuv420p", 332, 54); p.scale(hs, hd)
-    print(tune, p.path(), p.kernel_name())
+import traceback
+for args in ((224,36,"nv21",224,36,"yuv420p10be",2), (89,49,"yuv444p",226,8,"yuyv422",4), (6,33,"rgb24",224,49,"yuyv422",0x200), (224,36,"nv12",224,36,"yuv420p10le",2), (224,36,"yuv420p",224,36,"yuv420p10be",2),(224,36,"nv21",224,36,"yuv420p10be",4)):
+    for tune in (None, dict(no_short_forms=1), dict(no_fast_banks=1), dict(no_wave=1), dict(no_mixed=1)):
+        try:
+            r = run_case(*args[:6], args[6], seed=3, tune=tune)
+            print(args, tune, "OK", r[0])
+        except AssertionError as e:
+            print(args, tune, "FAIL", str(e)[:260])
+        except Exception as e:
+            print(args, tune, "EXC", repr(e)[:200])
