@@ -609,7 +609,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     //  writer's X form over the sums; rows in the writer's _1 / _2 forms keep the old kernels like the other packed kinds)
     const bool wide_gbrp = (((p.dstKind == DSTK_GBRP16 || p.dstKind == DSTK_GBRPF32) && !isALPHA(o.dst_format)) || p.dstKind == DSTK_RGB48) && p.wide && c->dstBpc >= 16 && !c->tune.no_strip_wide;
     if (!d->fullchr_on && c->plan == PLAN_MAIN && (((p.dstKind == DSTK_RGB16 || p.dstKind == DSTK_RGB30 || p.dstKind == DSTK_PACKED444 || p.dstKind == DSTK_PACKEDHI) && !p.wide &&
-        c->dstBpc <= 14) || wide_gbrp) && !c->needAlpha && fc_plain && !fast_flag && !(o.dst_w & 3) && o.dst_w >= strip_min_w_eff && c->chrDstVSubSample == 0 &&
+        c->dstBpc <= 14) || wide_gbrp) && !c->needAlpha && fc_plain && !fast_flag && !(o.dst_w & 1) && o.dst_w >= strip_min_w_eff && c->chrDstVSubSample == 0 &&
         !(bank_is_identity(hLumB, 1 << 14) && bank_is_identity(hChrB, 1 << 14)) &&   // (identity horizontal filters: the single-pass per-kind kernels are as fast or faster -- no sum planes)
         !c->tune.no_strip && !c->tune.no_mixed && !(c->tune.no_rgbread_kinds & 2)) {
         d->fullchr_on = 4; d->fullchr_kind = p.dstKind;

@@ -54,7 +54,8 @@ def test_dither_modes(dither):
 def test_planner_and_fallbacks():
     assert "sum_writer" in run_case(1920, 54, "yuv420p", 1280, 36, "rgb565le", SWS_BICUBIC | BX)[0]                  # wide enough without the option
     assert "sum_writer" in run_case(1920, 54, "nv12", 1280, 36, "y210le", SWS_BICUBIC | BX)[0]
-    assert "sum_writer" not in run_case(642, 48, "yuv420p", 322, 24, "rgb565le", SWS_BICUBIC | BX, tune=TUNE)[0]     # width not a multiple of 4
+    assert "sum_writer" in run_case(642, 48, "yuv420p", 322, 24, "rgb565le", SWS_BICUBIC | BX, tune=TUNE)[0]         # a width of 4 k + 2 (round 5)
+    assert "sum_writer" not in run_case(642, 48, "yuv420p", 323, 24, "rgb565le", SWS_BICUBIC | BX, tune=TUNE)[0]     # odd width
     assert "sum_writer" in run_case(640, 48, "yuv420p", 320, 24, "rgb48le", SWS_BICUBIC | BX, tune=TUNE)[0]          # 19-bit intermediates: round 5 (sws_k_strip_wide's sums)
     assert "sum_writer" not in run_case(640, 48, "yuv420p", 320, 24, "rgb48le", SWS_BICUBIC | BX, tune=dict(TUNE, no_strip_wide=1))[0]
     assert "sum_writer" not in run_case(640, 48, "yuv420p", 320, 24, "y216le", SWS_BICUBIC | BX, tune=TUNE)[0]
