@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -67,6 +68,7 @@ static DeviceState *dev_state_for(SwsInternal *c, int device)
     return c->peers[(size_t)device];
 }
 
+static void guard_forget(void *p);      // (SWS_HIP_DEBUG & 64: below)
 static void dev_state_free(DeviceState *d)
 {
     if (!d) return;
@@ -78,13 +80,11 @@ static void dev_state_free(DeviceState *d)
     (void)hipDeviceSynchronize();
     for (void *p : { d->d_tables, d->scratch, d->stage_src, d->stage_dst, (void *)d->ring.dev, d->casc_img, d->slice_img, d->d_tilegeom,
                      d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2, d->casc_img2, d->d_gamma_tab, d->d_ed_err, d->d_pal, d->d_vlines, d->rgbread_img })
-        if (p) (void)hipFree(p);
+        if (p) { guard_forget(p); (void)hipFree(p); }
     if (d->ring.host) (void)hipHostFree(d->ring.host);
     for (auto &b : d->ring.inflight) if (b.ev) (void)hipEventDestroy(b.ev);
     for (hipEvent_t e : d->ring.pool) (void)hipEventDestroy(e);
-    if (d->join_img) (void)hipFree(d->join_img);
-    if (d->split_img) (void)hipFree(d->split_img);
-    if (d->stage_img) (void)hipFree(d->stage_img);
+    for (void *p : { d->join_img, d->split_img, d->stage_img }) if (p) { guard_forget(p); (void)hipFree(p); }
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
     if (d->ev_loan) (void)hipEventDestroy(d->ev_loan);
@@ -239,19 +239,60 @@ static int dst_kind_of(int f)
 // upload filter banks (one blob) and fill SwsDevParams
 static bool poison_enabled();
 static int poison(SwsInternal *c, void *buf, size_t bytes);
+// SWS_HIP_DEBUG & 64 (round 5, DESIGN.md 8 iv): every working buffer and table block of the library carries GUARD_BYTES of a known pattern behind its last byte, and every
+// conversion ends by waiting for its stream and comparing the guards of ALL live blocks of the process: a kernel that writes behind a working picture or a table fails the call
+// that did it -- loudly, with the block and the offset -- instead of damaging whatever the allocator placed there (another context's tables, another picture).
+static const size_t GUARD_BYTES = 64 * 1024;
+static bool guards_enabled()
+{
+    static const bool on = std::getenv("SWS_HIP_DEBUG") && (std::atoi(std::getenv("SWS_HIP_DEBUG")) & 64);
+    return on;
+}
+static std::mutex g_guard_mu;
+static std::map<void *, size_t> g_guarded;      // block -> bytes in front of its guard
+static void guard_forget(void *p) { if (p && guards_enabled()) { std::lock_guard<std::mutex> lk(g_guard_mu); g_guarded.erase(p); } }
+static int guard_arm(SwsInternal *c, void *p, size_t bytes)
+{
+    if (!guards_enabled() || !p) return 0;
+    HIPCHK(hipMemset((uint8_t *)p + bytes, 0xA7, GUARD_BYTES));
+    HIPCHK(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guarded[p] = bytes;
+    return 0;
+}
+static int guards_check(SwsInternal *c, hipStream_t st)
+{
+    if (!guards_enabled()) return 0;
+    HIPCHK(hipStreamSynchronize(st));
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    std::vector<uint8_t> h(GUARD_BYTES);
+    for (const auto &e : g_guarded) {
+        HIPCHK(hipMemcpy(h.data(), (const uint8_t *)e.first + e.second, GUARD_BYTES, hipMemcpyDeviceToHost));
+        size_t bad = 0, first = 0;
+        for (size_t i = 0; i < GUARD_BYTES; i++) if (h[i] != 0xA7) { if (!bad) first = i; bad++; }
+        if (bad) {
+            log_msg(c, 0, "GUARD VIOLATION: %zu bytes written behind the block %p (%zu bytes), first at +%zu (value %u) -- %s -> %s %dx%d -> %dx%d flags 0x%x path %s\n", bad, e.first, e.second, first,
+                    (unsigned)h[first], pix_desc(c->opts.src_format)->name, pix_desc(c->opts.dst_format)->name, c->opts.src_w, c->opts.src_h, c->opts.dst_w, c->opts.dst_h, (unsigned)c->opts.flags, c->path_name.c_str());
+            return AVERROR_EXTERNAL_;
+        }
+    }
+    return 0;
+}
 // Device tables (filter banks, plan blobs, geometry): grown like grow().  Under SWS_HIP_DEBUG & 16 every table block carries 4 KiB of slack and is
 // refilled with 0xCD before each upload: a kernel that reads past the end of its table (a vector load over the last tap row, a row entry fetched ahead)
 // then meets garbage on every run, as it would in a block recycled from another context, instead of the zeros of a fresh allocation.
 static int table_alloc(SwsInternal *c, void **buf, size_t *cap, size_t need)
 {
-    const size_t slack = poison_enabled() ? 4096 : 0;
+    const size_t slack = guards_enabled() ? GUARD_BYTES : poison_enabled() ? 4096 : 0;
     if (need + slack > *cap) {
+        guard_forget(*buf);
         if (*buf) HIPCHK(hipFree(*buf));
         *buf = nullptr; *cap = 0;
         HIPCHK(hipMalloc(buf, need + slack));
         *cap = need + slack;
     }
-    return poison(c, *buf, *cap);
+    { int r_ = poison(c, *buf, *cap); if (r_ < 0) return r_; }
+    return guard_arm(c, *buf, need);
 }
 
 // Uploads of the per-context device tables go out on the CONTEXT'S OWN STREAM and are waited for there (round 5): the kernels that read them are launched on that
@@ -1588,11 +1629,13 @@ static int poison(SwsInternal *c, void *buf, size_t bytes)
 int grow(SwsInternal *c, void **buf, size_t *cap, size_t need)
 {
     if (need <= *cap) return 0;
+    guard_forget(*buf);
     if (*buf) HIPCHK(hipFree(*buf));   // (hipFree waits for the device: nothing in flight can still be using the old block)
     *buf = nullptr; *cap = 0;
-    HIPCHK(hipMalloc(buf, need));
+    HIPCHK(hipMalloc(buf, need + (guards_enabled() ? GUARD_BYTES : 0)));
     *cap = need;
-    return poison(c, *buf, need);
+    { int r_ = poison(c, *buf, need); if (r_ < 0) return r_; }
+    return guard_arm(c, *buf, need);
 }
 
 static void plane_extent(const PixDesc *d, int w, int h, int k, int *rows, int *row_bytes, int *vsub);
@@ -2081,7 +2124,8 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
     }
     HIPCHK(hipGetLastError());
     if (d->timing && rec1) { HIPCHK(hipEventRecord(d->ev1, st)); d->timed = true; }
-    return table_batch_end(c, d, st);
+    { int r_ = table_batch_end(c, d, st); if (r_ < 0) return r_; }
+    return guards_check(c, st);
 }
 
 // The helper passes keep per-FRAME working pictures (the reader pre-pass's 16-bit planes, the split / join pictures, the int32 sum planes of the
