@@ -499,7 +499,11 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
     // (... and for the packed YUV sources the per-kind reader pre-pass serves -- y210 / y212 / xv30 / v30x / xv36, vyu444 / vuyx: sws_k_strip_rgb reads planar sources only)
     const bool lut_kind = !c->tune.no_rgbread_kinds && !isALPHA(o.src_format) &&
                           ((p.srcKind == SRCK_PACKEDHI && p.src_depth >= 9 && p.src_depth <= 15 && c->srcBpc == p.src_depth) || (p.srcKind == SRCK_PACKED444 && p.src_depth == 8 && c->srcBpc == 8));
-    if (!d->fullchr_on && c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr && (long_taps || lut_u16 || lut_kind || lut_gray) && !c->needAlpha && (fc_plain || lut_gray) &&
+    // (... and for RGB sources whose destination is not forced to full chroma -- RGB -> RGB with SWS_FAST_BILINEAR or an ordered dither, utils.c:1277-1285: the reader
+    //  pre-pass in front, the LUT epilogue behind; round 5, without an alpha plane; rgb565 / x2rgb10 / 9 .. 16-bit RGB sources likewise through their per-kind readers)
+    const bool lut_rgbsrc = !c->tune.no_short_forms && isAnyRGB(o.src_format) && !(o.src_w & 1) &&
+                            (p.srcKind == SRCK_RGB24 || p.srcKind == SRCK_RGB32 || p.srcKind == SRCK_GBRP || p.srcKind == SRCK_RGB30 || p.srcKind == SRCK_RGB16 || p.srcKind == SRCK_GBRP16 || p.srcKind == SRCK_RGB48);
+    if (!d->fullchr_on && c->plan == PLAN_MAIN && (p.dstKind == DSTK_RGB24 || p.dstKind == DSTK_RGB32) && !p.full_chr && (long_taps || lut_u16 || lut_kind || lut_gray || lut_rgbsrc) && !c->needAlpha && (fc_plain || lut_gray) &&
         !fast_flag && !(o.dst_w & 1) && o.dst_w >= strip_min_w_eff && !c->tune.no_strip && !c->tune.no_mixed) {
         d->fullchr_on = 3; d->fullchr_kind = p.dstKind;
         p.dstKind = DSTK_RAW32; p.u_plane_dst = 1; p.v_plane_dst = 2;
@@ -1377,8 +1381,8 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             const bool kind_x = d->fullchr_kind == DSTK_GBRP || d->fullchr_kind == DSTK_PACKEDHI || d->fullchr_kind == DSTK_GBRP16 || d->fullchr_kind == DSTK_GBRPF32;   // (writers with the X form only)
             // (round 5: sws_k_fullchr_rgb tells the rows of the short forms by their taps and leaves the rounding constant out there -- yuv2rgb_full_2_c_template, the chroma
             //  blend of yuv2rgb_full_1_c_template; the one-launch RGB -> RGB kernel reads the same decision from its row entries)
-            const bool short_full = !all_x && !c->tune.no_short_forms && (d->fullchr_on == 1 || d->fullchr_on == 2) && (d->fullchr_kind == DSTK_RGB24 || d->fullchr_kind == DSTK_RGB32) &&
-                                    (lfs == 1 || lfs == 2) && cfs == 2;
+            const bool short_full = !all_x && !c->tune.no_short_forms && (d->fullchr_on == 1 || d->fullchr_on == 2 || d->fullchr_on == 3) && (d->fullchr_kind == DSTK_RGB24 || d->fullchr_kind == DSTK_RGB32) &&
+                                    (lfs == 1 || lfs == 2) && cfs == 2;      // (3: sws_k_lut_rgb likewise, for yuv2rgb_2 rows)
             if (!all_x && !(lfs == 1 && cfs == 1) && !(short_full && rgb2rgb_short)) d->rgb2rgb_ok = false;
             if (d->fullchr_on && ((!all_x && !(lfs == 1 && cfs == 1) && !kind_x && !short_full) ||
                                   (d->fullchr_on == 4 && lfs == 1 && cfs == 1 && d->fullchr_kind != DSTK_PACKEDHI && d->fullchr_kind != DSTK_GBRP16 && d->fullchr_kind != DSTK_GBRPF32) || !d->strip_ok)) {   // (planar RGB: any_vscale, always the X form)   // no strip plan, or a row in one of the short writer forms: the generic full-chroma writer keeps it

@@ -590,10 +590,17 @@ __global__ void __launch_bounds__(256) sws_k_lut_rgb(SwsFrameSet fs, SwsDevParam
         const i32x2 vU = *(const SWS_GLOBAL i32x2 *)(f.src[1] + (int64_t)y * f.srcStride[1] + 2 * (int64_t)x);
         const i32x2 vV = *(const SWS_GLOBAL i32x2 *)(f.src[2] + (int64_t)y * f.srcStride[2] + 2 * (int64_t)x);
         uint32_t w[2][2];
+        // (rows packed_vscale gives to yuv2rgb_2_c_template -- two taps each that sum to 4096 -- have no rounding constant, output.c:1853-1895; the blend of yuv2rgb_1 rounds like X)
+        unsigned rq = 1u << 18;
+        if (U(p.vLumFs) == 2 && U(p.vChrFs) == 2) {
+            const int16_t *lf = p.vLumF + 2 * (int64_t)y, *cf = p.vChrF + 2 * (int64_t)y;
+            const unsigned l0 = (uint16_t)lf[0], l1 = (uint16_t)lf[1], c0 = (uint16_t)cf[0], c1 = (uint16_t)cf[1];
+            if (l0 + l1 == 4096u && l1 <= 4096u && c0 + c1 == 4096u && c1 <= 4096u) rq = 0;
+        }
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const int Y1 = (int)((unsigned)vY[2 * k] + (1u << 18)) >> 19, Y2 = (int)((unsigned)vY[2 * k + 1] + (1u << 18)) >> 19;
-            const int Uc = (int)((unsigned)vU[k] + (1u << 18)) >> 19, Vc = (int)((unsigned)vV[k] + (1u << 18)) >> 19;
+            const int Y1 = (int)((unsigned)vY[2 * k] + rq) >> 19, Y2 = (int)((unsigned)vY[2 * k + 1] + rq) >> 19;
+            const int Uc = (int)((unsigned)vU[k] + rq) >> 19, Vc = (int)((unsigned)vV[k] + rq) >> 19;
             lut_pair<BPP>(p.lut, T, swap_rb, Y1, Y2, Uc, Vc, w[k]);
         }
         uint8_t *d = f.dst[0] + (int64_t)y * f.dstStride[0] + (int64_t)BPP * x;

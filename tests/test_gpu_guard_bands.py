@@ -17,7 +17,7 @@ import test_gpu_random as R
 from librempeg_amd.swscale import DeviceFrame, HostFrame, SwsContext, image_layout
 
 pytestmark = pytest.mark.gpu
-GUARD = 8192
+GUARD = int(os.environ.get("SWS_GUARD_BYTES", "8192"))      # (hunts for far writes: 1 MiB and more)
 
 
 class GuardedFrame(DeviceFrame):

@@ -87,3 +87,18 @@ def test_full_chroma_from_half_width_chroma_sources():
             for (sw, sh, dw, dh) in GEOM:
                 run_case(sw, sh, src, dw, dh, dst, SWS_BILINEAR | SWS_FULL_CHR_H_INT | BX, seed=dh, tune=T0)
                 run_case(sw, sh, src, dw, dh, dst, SWS_FAST_BILINEAR | SWS_FULL_CHR_H_INT | SWS_ACCURATE_RND, seed=dh + 1, tune=T0)
+
+
+@pytest.mark.parametrize("src", ["rgb24", "bgr24", "rgb0", "bgra", "gbrp", "rgb565le", "x2rgb10le", "gbrp10le", "rgb48le", "gbrpf32le"])
+def test_rgb_sources_under_the_lut_writers(src):
+    """RGB -> RGB without forced full chroma (SWS_FAST_BILINEAR switches it off, utils.c:1277-1285; so does an ordered dither): the LUT writers over a packed source -- reader
+    pre-pass, strip launches on half-width chroma, sws_k_lut_rgb.  Without an alpha plane (bgra -> bgra keeps the element-per-thread writers); all four geometries, bitexact and not"""
+    for dst in ("rgb24", "bgra", "bgr24", "argb", "rgb0"):
+        for (sw, sh, dw, dh) in ((644, 70, 324, 35), (400, 66, 332, 54), (320, 40, 640, 80), (1366, 36, 1282, 34), (640, 48, 640, 24)):
+            for fl in (SWS_FAST_BILINEAR, SWS_FAST_BILINEAR | BX):
+                r = run_case(sw, sh, src, dw, dh, dst, fl, seed=sw + dh, tune=T0)
+                if (sw, dw) == (400, 332) and src in ("rgb24", "bgr24", "gbrp") and fl == SWS_FAST_BILINEAR | BX:      # (rgb0 into a destination with alpha: its X byte feeds the alpha channel as 255 -- an alpha plane, not this route)
+                    assert r[0].endswith("+lut_rgb"), (r[0], src, dst)
+            opts = dict(dither=1, src_range=0, dst_range=0, src_h_chr_pos=-513, src_v_chr_pos=-513, dst_h_chr_pos=-513, dst_v_chr_pos=-513, threads=1)
+            run_case(sw, sh, src, dw, dh, dst, SWS_BILINEAR | BX, seed=sw, opts=opts, tune=T0)
+    run_case(1920, 1080, src, 1280, 720, "rgb24", SWS_FAST_BILINEAR, seed=3)
