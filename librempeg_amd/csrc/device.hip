@@ -1408,7 +1408,10 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             d->rgb_march_ok = false;
             bool lum_unity = lfs == 1;
             for (int y = 0; y < o.dst_h && lum_unity; y++) lum_unity = c->vLum.taps[y] == 4096;
-            if (all_x && lum_unity && win <= 8 && cfs <= 8) {
+            // (round 5: one luma tap with two chroma taps -- SWS_BILINEAR at the same size from 4:2:0: yuv2rgb_1_c_template with its chroma blend, which rounds with 128 << 11 and IS the
+            //  X arithmetic on the bank's taps, output.c:1913-1937; its one-row form (u0 + 64) >> 7 is the X arithmetic over {4096, 0}.  Not with an alpha plane: other formulas there)
+            const bool lut_rows_x = all_x || (lfs == 1 && cfs == 2 && !c->needAlpha && !c->tune.no_short_forms);
+            if (lut_rows_x && lum_unity && win <= 8 && cfs <= 8) {
                 const int groups = (o.dst_h + 1) / 2;
                 std::vector<SwsRgbGroupPlan> plan((size_t)groups);
                 bool ok = true;
