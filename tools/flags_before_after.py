@@ -13,7 +13,8 @@ CASES = [("yuv420p", 3840, 2160, "yuv420p", 1920, 1080, FB, "no_fast_banks"), ("
          ("yuyv422", 1920, 1080, "yuv420p", 1280, 720, FB, "no_fast_banks"), ("yuv420p", 1280, 720, "bgra", 1920, 1080, FB, "no_fast_banks"),
          ("yuv420p", 1280, 720, "bgra", 1920, 1080, BL, "no_short_forms"), ("nv12", 1280, 720, "rgb24", 1920, 1080, BL, "no_short_forms"), ("yuv420p", 1920, 1080, "bgra", 3840, 2160, BL, "no_short_forms"),
          ("bgra", 1280, 720, "bgra", 1920, 1080, BL, "no_short_forms"), ("rgb24", 1920, 1080, "rgb24", 3840, 2160, BL, "no_short_forms"), ("yuv444p", 1280, 720, "bgra", 1920, 1080, BL, "no_short_forms"),
-         ("yuv420p", 1920, 1080, "bgra", 1280, 1080, BL, "no_short_forms"), ("yuv420p", 3840, 2160, "yuyv422", 3840, 2160, BL, "no_short_forms"), ("nv12", 1920, 1080, "uyvy422", 1920, 1080, BL, "no_short_forms"),
+         ("yuv420p", 1920, 1080, "bgra", 1280, 1080, BL, "no_short_forms"), ("nv12", 3840, 2160, "bgra", 3840, 2160, BL, "no_short_forms"), ("nv12", 1920, 1080, "rgb24", 1920, 1080, BL, "no_short_forms"),
+         ("rgb24", 3840, 2160, "bgra", 1920, 1080, FB, "no_short_forms"), ("bgra", 1366, 768, "yuv420p", 1280, 720, BC, None), ("yuv420p", 3840, 2160, "yuyv422", 3840, 2160, BL, "no_short_forms"), ("nv12", 1920, 1080, "uyvy422", 1920, 1080, BL, "no_short_forms"),
          ("yuv420p", 3840, 2160, "yuyv422", 3840, 2160, BC, "no_wave"), ("nv12", 3840, 2160, "uyvy422", 3840, 2160, BC, "no_wave"), ("bgr24", 3840, 2160, "yuv420p", 3840, 2160, BC, "no_wave"),
          ("gray8", 3840, 2160, "yuv420p", 3840, 2160, BC, "no_mixed"), ("gray16le", 3840, 2160, "bgra", 3840, 2160, BC, "no_wave"), ("gray8", 3840, 2160, "bgra", 1920, 1080, BC, "no_wave"),
          ("x2rgb10le", 3840, 2160, "p010le", 3840, 2160, BC, "no_strip_rgbsrc")]
@@ -42,6 +43,10 @@ def run(sf, sw, sh, df, dw, dh, fl, off):
 print("| conversion | flags | option off: path, ms / frame | round 5: path, ms / frame |")
 print("|---|---|---|---|")
 for sf, sw, sh, df, dw, dh, fl, off in CASES:
+    if off is None:
+        t1, p1 = run(sf, sw, sh, df, dw, dh, fl, None)
+        print(f"| {sf} {sw}x{sh} -> {df} {dw}x{dh} | {FL[fl]} | (no switch: width of 4 k + 2, 0.0325 on `main:fused_tile` before) | {p1}, **{t1:.4f}** |")
+        continue
     t0, p0 = run(sf, sw, sh, df, dw, dh, fl, off)
     t1, p1 = run(sf, sw, sh, df, dw, dh, fl, None)
     print(f"| {sf} {sw}x{sh} -> {df} {dw}x{dh} | {FL[fl]} | `{off}`: {p0}, {t0:.4f} | {p1}, **{t1:.4f}** |")
