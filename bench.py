@@ -88,6 +88,10 @@ WORKLOADS = {
 # The strip-kernel variants are reported at TWO batch sizes: the workload's default above (large: the ring fill of a band and the launch
 # tail are amortised) and the batch the round-1 / round-2 records quote, so that numbers stay comparable from round to round.
 SMALL_BATCH = {"c3b": 8, "d1": 32, "d2": 32, "c1": 64}
+# what the default run (`--variants auto` next to the headline c2a) times: EVERY BASELINE.json configuration first (c2b = the polyphase twin of
+# configs[1], c3a / c3b = configs[2] same size / scaled, c4 = configs[3] at one GPU's 64-frame share of the 512-frame batch, c5 = configs[4],
+# c1 = configs[0]), then the strip-family workloads the rounds' reviews follow
+AUTO_VARIANTS = ["c2b", "c3a", "c3b", "c4", "c5", "c1", "d1", "e2", "r1", "w1", "f1", "u1"]
 
 
 def clamp_batch(name, batch, device_index):
@@ -268,10 +272,15 @@ def cpu_model():
     return "unknown"
 
 
-# port / reference, one thread: the oracle's time per frame over a C-only build of the real reference (no SIMD: --disable-asm), measured
-# by the round-2 review in a container of this class -- before oracle/ got the reference's own loop shape for the C2a converter (then
-# 6.6x; now see "c2a" below) -- and the SURVEY's own anchors (SURVEY.md 8d "Sanity anchors") for the reference's ms / frame.
-REFERENCE_MS_PER_FRAME_1T = {"c1": 3.3, "c2a": 9.95, "c2b": 81.0, "c3a": 29.0, "c3b": 220.0, "c4": 17.0, "c5": 530.0}
+# port / reference, one thread: profiles/ref_vs_port.json holds, per BASELINE configuration, the ms per frame of a C-only build of the REAL
+# reference (configure --disable-asm, built under /tmp in the build container, never shipped) and of oracle/ ("the port") in the SAME
+# container on one thread, best of N, as tools/ref_vs_port.sh measured them.  The GPU box has no reference, so the line this bench prints
+# times the port there and carries (a) that ratio and (b) the port's rate scaled by it as the estimate of the reference's C path on this host.
+def ref_vs_port():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "ref_vs_port.json")))
+    except Exception:
+        return {}
 
 
 def cpu_leg(name, seconds, nthreads_list):
@@ -316,35 +325,46 @@ def cpu_leg(name, seconds, nthreads_list):
     return res
 
 
-def cpu_baseline(name, seconds=6.0, others=("c1", "c2b", "c3b", "c4", "c5"), other_seconds=1.5):
+def cpu_baseline(name, seconds=6.0, others=("c1", "c2b", "c3a", "c3b", "c4", "c5"), other_seconds=1.5):
     """cpu_baseline of the JSON line: the headline workload on 1 thread and on all host cores, plus one short leg per other BASELINE
     configuration (C1 is BASELINE's CPU-only configuration)."""
     cores = os.cpu_count() or 1
     tl = [1, cores] if cores > 1 else [1]
     desc = WORKLOADS[name][9]
+    rvp = ref_vs_port()
+
+    def anchors(n, mp_all, mp_1):
+        e = rvp.get(n)
+        if not e:
+            return {}
+        k = e["port_over_reference"]
+        return {"port_over_reference_1thread": k, "reference_c_ms_per_frame_1thread_build_container": e["reference_ms"],
+                "port_ms_per_frame_1thread_build_container": e["port_ms"],
+                "reference_c_estimate_all_threads": round(mp_all * k, 2), "reference_c_estimate_1thread": round(mp_1 * k, 2)}
+
     r = cpu_leg(name, seconds, tl)
     f1, mp1, ms1 = r[1]
     fN, mpN, msN = r[tl[-1]]
-    ref = REFERENCE_MS_PER_FRAME_1T.get(name)
     configs = {}
     for o in others:
         if o == name:
             continue
         ro = cpu_leg(o, other_seconds, tl)
         configs[o] = {"workload": WORKLOADS[o][9], "value_1thread": round(ro[1][1], 2), "ms_per_frame_1thread": round(ro[1][2], 2),
-                      "value_all_threads": round(ro[tl[-1]][1], 2), "frames_timed": [ro[1][0], ro[tl[-1]][0]], "unit": "Mpixels/s",
-                      "reference_c_ms_per_frame_1thread_other_host": REFERENCE_MS_PER_FRAME_1T.get(o)}
-    return {"value": round(mpN, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-            "value_1thread": round(mp1, 2), "ms_per_frame_1thread": round(ms1, 2),
-            "reference_c_ms_per_frame_1thread_other_host": ref,
-            "configs": configs,
-            "sample": f"{desc}; oracle/ = scalar C restatement of the reference's C path (gcc -O3 -fno-tree-vectorize like the reference's "
-                      f"own flags; the C2a converter in the reference's own loop shape), ~{seconds:.0f}s per leg: {f1} frames on 1 thread "
-                      f"({ms1:.2f} ms/frame), {fN} frames on {cores} threads (one context per thread, pinned).  A C-only build of the real "
-                      f"reference needs {ref} ms/frame for this workload on one core of the build container (round-2 review / SURVEY 8d): "
-                      f"the port is NOT the reference's hand-written x86 SIMD, which would be faster again.  `configs`: the other BASELINE "
-                      f"configurations, {other_seconds:.1f}s per leg (whole-frame int32 intermediates there: 1.5-1.8x slower than the reference's "
-                      f"C path per the same review)"}
+                      "value_all_threads": round(ro[tl[-1]][1], 2), "frames_timed": [ro[1][0], ro[tl[-1]][0]], "unit": "Mpixels/s"}
+        configs[o].update(anchors(o, ro[tl[-1]][1], ro[1][1]))
+    out = {"value": round(mpN, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+           "value_1thread": round(mp1, 2), "ms_per_frame_1thread": round(ms1, 2)}
+    out.update(anchors(name, mpN, mp1))
+    out["ratio_source"] = rvp.get("_source")
+    out["configs"] = configs
+    out["sample"] = (f"{desc}; oracle/ = scalar C restatement of the reference's C path (gcc -O3 -fno-tree-vectorize like the reference's "
+                     f"own flags), ~{seconds:.0f}s per leg: {f1} frames on 1 thread ({ms1:.2f} ms/frame), {fN} frames on {cores} threads "
+                     f"(one context per thread, pinned).  `value` is the PORT on this host.  `port_over_reference_1thread` = port ms / real "
+                     f"reference ms (C-only build, no SIMD) measured side by side in the build container; `reference_c_estimate_*` = the port's "
+                     f"rate here x that ratio.  Neither is the reference's hand-written x86 SIMD, which would be faster again.  `configs`: the "
+                     f"other BASELINE configurations, {other_seconds:.1f}s per leg")
+    return out
 
 
 def main():
@@ -407,7 +427,7 @@ def main():
                           "cpu_baseline": None}), flush=True)
         return
     main_res = run_workload(args.workload, args.batch, args.steps, args.warmup, rank, world, local_rank, barrier)
-    variants = [] if args.variants in ("", "none") else (["c2b", "c3b", "d1", "c1", "e2", "r1", "w1", "f1", "u1"] if args.variants == "auto" and args.workload == "c2a"
+    variants = [] if args.variants in ("", "none") else (AUTO_VARIANTS if args.variants == "auto" and args.workload == "c2a"
                                                           else [] if args.variants == "auto" else args.variants.split(","))
     var_res = []
     for v in variants:
@@ -437,7 +457,7 @@ def main():
     if rank == 0:
         # HBM bytes per launch from the PMC counters: NOT measured by this run (counters need their own rocprofv3 --pmc passes);
         # read from the committed summary of the latest such passes over the same command and labelled with its source
-        traffic, traffic_source = None, None
+        traffic, traffic_source, pmc = None, None, {}
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
             try:
@@ -445,7 +465,7 @@ def main():
                 traffic = pmc.get(main_res["name"], {}).get("hbm_bytes_per_launch")
                 traffic_source = "profiles/pmc_latest.json (" + str(pmc.get("_source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.sh")) + ")"
             except Exception:
-                traffic = None
+                traffic, pmc = None, {}
         out = {
             "metric": "Mpixels/sec sws_scale 4K yuv420p->rgb24 bicubic" if main_res["name"].startswith("c2")
                       else f"Mpixels/sec sws_scale {main_res['name']}",
@@ -470,10 +490,13 @@ def main():
     for r in var_res:
         w2, k2, m2, a2 = summarize(r)
         if rank == 0:
+            vt = None      # PMC traffic of the committed passes: only for the batch those passes ran (the workload's default)
+            if "key" not in r and r["batch"] == WORKLOADS[r["name"]][8]:
+                vt = pmc.get(r["name"], {}).get("hbm_bytes_per_launch")
             out["variants"][r.get("key", r["name"])] = {"workload": r["desc"], "frames_per_step_per_gpu": r["batch"], "value": round(m2, 1), "unit": "Mpixels/s",
                                           "ms_per_step": round(w2 / args.steps * 1e3, 4), "path": r["path"], "kernel": r["kernel"],
                                           "roofline": {"bound": "hbm", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                       "frac": round(a2 / HBM_PEAK_GBS, 4), "kernel_ms_avg": round(k2, 4),
+                                                       "frac": round(a2 / HBM_PEAK_GBS, 4), "traffic": vt, "algorithmic_bytes_per_launch": r["alg_bytes_per_step"], "kernel_ms_avg": round(k2, 4),
                                                        "kernel_ms_min": round(r["kernel_ms_min"], 4), "kernel_ms_median": round(r["kernel_ms_median"], 4)}}
     if rank == 0:
         if world == 1 and not args.no_cpu:

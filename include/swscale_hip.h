@@ -32,7 +32,13 @@ extern "C" {
 
 /* ---- libavutil/pixfmt.h enum AVPixelFormat (numeric values are ABI) ---- */
 #ifndef AVUTIL_PIXFMT_H
+#ifdef __cplusplus
+/* a C caller may hand ANY int through this type (the reference answers EINVAL / NULL for an unknown one, utils.c:1234-1246); with a fixed
+ * underlying type every int is a valid value on the C++ side of the boundary too (found by -fsanitize=enum, round 6) */
+enum AVPixelFormat : int {
+#else
 enum AVPixelFormat {
+#endif
     AV_PIX_FMT_NONE = -1,
     AV_PIX_FMT_YUV420P = 0,
     AV_PIX_FMT_RGB24 = 2,
@@ -402,6 +408,9 @@ double sws_hip_last_kernel_ms(SwsContext *c);         /* HIP-event time of the l
 int    sws_hip_set_timing(SwsContext *c, int enable); /* record hipEvents around each launch on the context's stream */
 /* launch heuristics ("strip_min_w", "rgb_march_waves", "max_devices", "no_strip", ...): every setting gives the same bytes */
 int    sws_hip_set_option(SwsContext *c, const char *name, int value);
+/* debugging aid: reads every device table block of the context back and compares it with what was uploaded (and the host-side kernel parameters with
+ * what context preparation left); returns the number of anomalies (0 = intact, < 0 = HIP error), a short text per anomaly goes to buf */
+int    sws_hip_debug_check(SwsContext *c, char *buf, int cap);
 
 #pragma GCC visibility pop
 

@@ -27,12 +27,6 @@ void launch_layout_join422(const LaunchCtx &L, bool uyvy);   // k_layout.hip: pl
 
 // the plan geometries of a fresh state start out as zeros (`new DeviceState()` runs the default member initialisers and leaves members without one as the
 // heap had them: a field a planner path does not set -- band counts, the byte-row form's flags -- would otherwise differ from process to process)
-static void zero_geoms(DeviceState *d)
-{
-    for (SwsTileGeom *g : { &d->tileL, &d->tileC, &d->dotL, &d->dotC }) std::memset(g, 0, sizeof(*g));
-    for (SwsStripGeom *g : { &d->stripL, &d->stripC, &d->stripLs, &d->stripCs, &d->stripRL, &d->stripRC, &d->stripL2, &d->stripC2 }) std::memset(g, 0, sizeof(*g));
-}
-
 static int ensure_dev(SwsInternal *c)
 {
     if (c->dev) return 0;
@@ -42,9 +36,7 @@ static int ensure_dev(SwsInternal *c)
         log_msg(c, 0, "no HIP device available: libswscale_hip has no CPU fallback\n");
         return AVERROR_EXTERNAL_;
     }
-    DeviceState *d = new DeviceState();
-    std::memset(&d->params, 0, sizeof(d->params));
-    zero_geoms(d);
+    DeviceState *d = new DeviceState();          // (value-initialised: every member without an initialiser starts as zero)
     if (hipGetDevice(&d->device) != hipSuccess) d->device = 0;
     c->dev = d;
     return 0;
@@ -58,9 +50,7 @@ static DeviceState *dev_state_for(SwsInternal *c, int device)
     if (device < 0) return nullptr;
     if ((size_t)device >= c->peers.size()) c->peers.resize((size_t)device + 1, nullptr);
     if (!c->peers[(size_t)device]) {
-        DeviceState *d = new DeviceState();
-        std::memset(&d->params, 0, sizeof(d->params));
-        zero_geoms(d);
+        DeviceState *d = new DeviceState();      // (value-initialised: every member without an initialiser starts as zero)
         d->device = device;
         d->timing = false;
         c->peers[(size_t)device] = d;
@@ -281,10 +271,24 @@ static int guards_check(SwsInternal *c, hipStream_t st)
 // Device tables (filter banks, plan blobs, geometry): grown like grow().  Under SWS_HIP_DEBUG & 16 every table block carries 4 KiB of slack and is
 // refilled with 0xCD before each upload: a kernel that reads past the end of its table (a vector load over the last tap row, a row entry fetched ahead)
 // then meets garbage on every run, as it would in a block recycled from another context, instead of the zeros of a fresh allocation.
-static int table_alloc(SwsInternal *c, void **buf, size_t *cap, size_t need)
+static uint64_t fnv1a64(const void *p, size_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) { h ^= ((const uint8_t *)p)[i]; h *= 1099511628211ull; }
+    return h;
+}
+static void table_records_drop(DeviceState *d, const void *lo, size_t bytes)
+{
+    auto &v = d->tab_recs;
+    for (size_t i = 0; i < v.size();)
+        if ((const uint8_t *)v[i].dst < (const uint8_t *)lo + bytes && (const uint8_t *)lo < (const uint8_t *)v[i].dst + v[i].bytes) { v[i] = v.back(); v.pop_back(); }
+        else i++;
+}
+static int table_alloc(SwsInternal *c, DeviceState *d, void **buf, size_t *cap, size_t need)
 {
     const size_t slack = guards_enabled() ? GUARD_BYTES : poison_enabled() ? 4096 : 0;
     if (need + slack > *cap) {
+        if (*buf) table_records_drop(d, *buf, *cap);
         guard_forget(*buf);
         if (*buf) HIPCHK(hipFree(*buf));
         *buf = nullptr; *cap = 0;
@@ -310,6 +314,8 @@ static int table_put(SwsInternal *c, DeviceState *d, void *dst, const void *src,
     if (!bytes) return 0;
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
+    table_records_drop(d, dst, bytes);
+    d->tab_recs.push_back({ dst, bytes, fnv1a64(src, bytes) });
     if (verify_uploads()) {
         std::vector<uint8_t> back(bytes);
         HIPCHK(hipMemcpyAsync(back.data(), dst, bytes, hipMemcpyDeviceToHost, d->stream));
@@ -670,7 +676,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             offs_t[i] = off; off = align(off + banks[i]->taps.size() * sizeof(int16_t));
             offs_p[i] = off; off = align(off + banks[i]->pos.size() * sizeof(int32_t));
         }
-        { int r_ = table_alloc(c, &d->d_tables, &d->tables_bytes, off); if (r_ < 0) return r_; }
+        { int r_ = table_alloc(c, d, &d->d_tables, &d->tables_bytes, off); if (r_ < 0) return r_; }
         std::vector<uint8_t> host(off, 0);
         for (int i = 0; i < 4; i++) {
             std::memcpy(host.data() + offs_t[i], banks[i]->taps.data(), banks[i]->taps.size() * sizeof(int16_t));
@@ -700,7 +706,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 const size_t o_lp = hostv.size(); hostv.insert(hostv.end(), vlx.lumPos.begin(), vlx.lumPos.end());
                 const size_t o_cp = hostv.size(); hostv.insert(hostv.end(), vlx.chrPos.begin(), vlx.chrPos.end());
                 const size_t bytes = hostv.size() * sizeof(int32_t);
-                { int r_ = table_alloc(c, &d->d_vlines, &d->vlines_bytes, bytes); if (r_ < 0) return r_; }
+                { int r_ = table_alloc(c, d, &d->d_vlines, &d->vlines_bytes, bytes); if (r_ < 0) return r_; }
                 { int r_ = table_put(c, d, d->d_vlines, hostv.data(), bytes); if (r_ < 0) return r_; }
                 const int32_t *bv = (const int32_t *)d->d_vlines;
                 p.vlines = bv; p.nVL = (int32_t)nL; p.vline_mode = mode;
@@ -753,7 +759,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                 }
                 const size_t bytes1 = (rows.size() * sizeof(SwsRgbSrcRow) + 63) & ~(size_t)63;
                 const size_t bytes = bytes1 + rows2.size() * sizeof(SwsStripRow);
-                { int r_ = table_alloc(c, &d->d_dot2, &d->dot2_bytes, bytes); if (r_ < 0) return r_; }
+                { int r_ = table_alloc(c, d, &d->d_dot2, &d->dot2_bytes, bytes); if (r_ < 0) return r_; }
                 { int r_ = table_put(c, d, d->d_dot2, rows.data(), rows.size() * sizeof(SwsRgbSrcRow)); if (r_ < 0) return r_; }
                 if (!rows2.empty()) { int r_ = table_put(c, d, (uint8_t *)d->d_dot2 + bytes1, rows2.data(), rows2.size() * sizeof(SwsStripRow)); if (r_ < 0) return r_; }
                 d->rgbsrc_rows = (const SwsRgbSrcRow *)d->d_dot2;
@@ -1072,7 +1078,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         const std::vector<int16_t> htc = padded(hChrB);
                         const size_t ohc = put(htc.data(), htc.size() * 2);
                         const bool altC = plan3_alt(hChrB, vChrB, p.chrDstW, 2, d->stripC, d->stripCs, sCs);
-                        { int r_ = table_alloc(c, &d->d_dot2, &d->dot2_bytes, blob.size()); if (r_ < 0) return r_; }
+                        { int r_ = table_alloc(c, d, &d->d_dot2, &d->dot2_bytes, blob.size()); if (r_ < 0) return r_; }
                         { int r_ = table_put(c, d, d->d_dot2, blob.data(), blob.size()); if (r_ < 0) return r_; }
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         d->stripC.colStart = (const int32_t *)(b + sM.cs); d->stripC.colCount = (const int32_t *)(b + sM.cc);
@@ -1142,7 +1148,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         size_t o8l = 0, o8c = 0;
                         dma8_plan(hLumB, vLumR, gl, o8l); dma8_plan(hChrB, vChrR, gc, o8c);
                         if (!gl.dma8_ok || !gc.dma8_ok) gl.dma8_ok = gc.dma8_ok = 0;
-                        { int r_ = table_alloc(c, &d->d_dot2, &d->dot2_bytes, blob.size()); if (r_ < 0) return r_; }
+                        { int r_ = table_alloc(c, d, &d->d_dot2, &d->dot2_bytes, blob.size()); if (r_ < 0) return r_; }
                         { int r_ = table_put(c, d, d->d_dot2, blob.data(), blob.size()); if (r_ < 0) return r_; }
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
                         gl.colStart = (const int32_t *)(b + rL.cs); gl.colCount = (const int32_t *)(b + rL.cc); gl.rows = (const SwsStripRow *)(b + rL.rows);
@@ -1252,7 +1258,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                       ohl = put(htl.data(), htl.size() * 2); ohc = put(htc.data(), htc.size() * 2);
                   }
                   if (tiles || strip_plan) {
-                    { int r_ = table_alloc(c, &d->d_dot2, &d->dot2_bytes, blob.size()); if (r_ < 0) return r_; }
+                    { int r_ = table_alloc(c, d, &d->d_dot2, &d->dot2_bytes, blob.size()); if (r_ < 0) return r_; }
                     { int r_ = table_put(c, d, d->d_dot2, blob.data(), blob.size()); if (r_ < 0) return r_; }
                     auto bind = [&](SwsTileGeom &g, const Off &o) {
                         const uint8_t *b = (const uint8_t *)d->d_dot2;
@@ -1354,7 +1360,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
             if (plan(hLumB, c->vLum, p.dstW, p.dstH, p.srcW, p.srcH, 1, d->tileL, aL) &&
                 plan(hChrB, vChrB, p.chrDstW, p.chrDstH, p.chrSrcW, p.chrSrcH, 2, d->tileC, aC)) {
                 const size_t bytes = (aL.size() + aC.size()) * sizeof(int32_t);
-                { int r_ = table_alloc(c, &d->d_tilegeom, &d->tilegeom_bytes, bytes); if (r_ < 0) return r_; }
+                { int r_ = table_alloc(c, d, &d->d_tilegeom, &d->tilegeom_bytes, bytes); if (r_ < 0) return r_; }
                 std::vector<int32_t> all(aL); all.insert(all.end(), aC.begin(), aC.end());
                 { int r_ = table_put(c, d, d->d_tilegeom, all.data(), bytes); if (r_ < 0) return r_; }
                 const int32_t *bL = (const int32_t *)d->d_tilegeom, *bC = bL + aL.size();
@@ -1448,7 +1454,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                         for (int r = 0; r < 2; r++) e.wp[r][2] = (e.wp[r][2] & 0xFFFFu) | (2048u << 16);
                 if (ok) {
                     const size_t bytes = plan.size() * sizeof(SwsRgbGroupPlan);
-                    { int r_ = table_alloc(c, &d->d_rgbplan, &d->rgbplan_bytes, bytes); if (r_ < 0) return r_; }
+                    { int r_ = table_alloc(c, d, &d->d_rgbplan, &d->rgbplan_bytes, bytes); if (r_ < 0) return r_; }
                     { int r_ = table_put(c, d, d->d_rgbplan, plan.data(), bytes); if (r_ < 0) return r_; }
                     d->rgb_groups = groups;
                     d->rgb_march_ok = true;
@@ -1559,8 +1565,40 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
                                       c->plan == PLAN_UNSC_NV242PLANAR || c->plan == PLAN_UNSC_P4222PLANAR || c->plan == PLAN_UNSC_PLANAR2P422))
         c->kernel_name = "sws_k_layout_stream";
     log_msg(c, 2, "HIP path: %s (dominant kernel %s)\n", c->path_name.c_str(), c->kernel_name.c_str());
+    d->params_hash = fnv1a64(&d->params, sizeof(d->params));
     d->epoch = c->tables_epoch;
     return 0;
+}
+
+// sws_hip_debug_check(): every table block of the context's device states is read back and compared (by hash) with what was uploaded, and the
+// host-side kernel parameters with what dev_prepare_on() left.  Returns the number of anomalies (0 = intact), < 0 on a HIP error; a short text
+// per anomaly goes to `buf`.  A debugging aid for the test harness: a parity failure records whether the context's tables were still the
+// host's (a wild writer's victim) or not.
+int dev_check_state(SwsInternal *c, DeviceState *d, std::string &out)
+{
+    if (!d) return 0;
+    int bad = 0;
+    HIPCHK(hipSetDevice(d->device));
+    if (d->stream) HIPCHK(hipStreamSynchronize(d->stream));
+    std::vector<uint8_t> back;
+    for (const TableRecord &r : d->tab_recs) {
+        back.resize(r.bytes);
+        HIPCHK(hipMemcpy(back.data(), r.dst, r.bytes, hipMemcpyDeviceToHost));
+        if (fnv1a64(back.data(), r.bytes) != r.hash) {
+            bad++;
+            char line[160];
+            std::snprintf(line, sizeof(line), "gpu %d: table block %p (%zu bytes) differs from its upload; ", d->device, r.dst, r.bytes);
+            out += line;
+        }
+    }
+    if (d->epoch && d->params_hash != fnv1a64(&d->params, sizeof(d->params))) {
+        bad++;
+        out += "host-side SwsDevParams changed since dev_prepare_on(); ";
+    }
+    char line[96];
+    std::snprintf(line, sizeof(line), "gpu %d: %zu table blocks checked; ", d->device, d->tab_recs.size());
+    out += line;
+    return bad;
 }
 
 int dev_prepare(SwsInternal *c)
@@ -3070,6 +3108,20 @@ void *sws_hip_get_stream(SwsContext *sws)
     SwsInternal *c = internal(sws);
     if (dev_prepare(c) < 0) return nullptr;
     return (void *)c->dev->stream;
+}
+
+int sws_hip_debug_check(SwsContext *sws, char *buf, int cap)
+{
+    if (!sws) return SWS_AVERROR(EINVAL);
+    SwsInternal *c = internal(sws);
+    DeviceGuard guard;
+    std::string out;
+    int bad = 0;
+    { int r = dev_check_state(c, c->dev, out); if (r < 0) return r; bad += r; }
+    for (DeviceState *d : c->peers) { int r = dev_check_state(c, d, out); if (r < 0) return r; bad += r; }
+    for (const FrameGraph &g : c->graph) if (g.legacy) { int r = sws_hip_debug_check(g.legacy, nullptr, 0); if (r > 0) { bad += r; out += "(a child context of the frame graph differs); "; } }
+    if (buf && cap > 0) { std::snprintf(buf, (size_t)cap, "%s", out.c_str()); }
+    return bad;
 }
 
 int sws_hip_sync(SwsContext *sws)   // waits for the context's work on every GPU it has used

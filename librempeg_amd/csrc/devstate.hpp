@@ -27,8 +27,14 @@ struct TableRing {
 };
 enum { TAB_MAIN = 0, TAB_AUX0 = 1 /* .. TAB_AUX0 + 4 */, TAB_FRAMES2 = 6 };
 
+// What table_put() uploaded into a device table block: kept so that sws_hip_debug_check() can read the block back at any later time and say whether the
+// context's device tables are still what the host built (the rare events whose context stays wrong for its lifetime)
+struct TableRecord { const void *dst; size_t bytes; uint64_t hash; };
+
 struct DeviceState {
     int device = 0;
+    std::vector<TableRecord> tab_recs;
+    uint64_t params_hash = 0;  // hash of `params` as dev_prepare_on() left it
     hipStream_t stream = nullptr;
     bool own_stream = false;
     uint64_t epoch = 0;        // SwsInternal::tables_epoch this state was built for (0 = never)

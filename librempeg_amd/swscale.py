@@ -274,6 +274,7 @@ def load_library():
     L.sws_hip_path_name.argtypes = [vp]
     L.sws_hip_kernel_name.restype = C.c_char_p
     L.sws_hip_kernel_name.argtypes = [vp]
+    L.sws_hip_debug_check.argtypes = [vp, C.c_char_p, ci]
     L.sws_hip_get_filter.argtypes = [vp, ci, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(ci)]
     L.sws_hip_get_tables.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(ci), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]
     L.sws_hip_last_kernel_ms.restype = C.c_double
@@ -531,6 +532,12 @@ class SwsContext:
 
     def kernel_name(self):
         return self.L.sws_hip_kernel_name(self.c).decode()
+
+    def debug_check(self):
+        """(anomalies, text): the context's device tables read back and compared with what was uploaded (sws_hip_debug_check)"""
+        buf = C.create_string_buffer(2048)
+        n = self.L.sws_hip_debug_check(self.c, buf, len(buf))
+        return n, buf.value.decode(errors="replace")
 
     def filter(self, which):
         f = C.POINTER(C.c_int16)()

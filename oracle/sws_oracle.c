@@ -3173,7 +3173,7 @@ static void write_planar_line(const OrSws *c, uint8_t *dest, int w, const int32_
         } else {
             for (i = 0; i < w; i++) {
                 int val = (1 << 14) - 0x40000000;
-                for (j = 0; j < fs; j++) val += (int)(ROW(j)[i] * (unsigned)filter[j]);
+                for (j = 0; j < fs; j++) val = (int)((unsigned)val + ROW(j)[i] * (unsigned)filter[j]);
                 d[i] = float_mult * (float)(0x8000 + clip_i16(val >> 15));
             }
         }
@@ -3185,7 +3185,7 @@ static void write_planar_line(const OrSws *c, uint8_t *dest, int w, const int32_
         } else {
             for (i = 0; i < w; i++) {
                 int val = (1 << 14) - 0x40000000;
-                for (j = 0; j < fs; j++) val += (int)(ROW(j)[i] * (unsigned)filter[j]);
+                for (j = 0; j < fs; j++) val = (int)((unsigned)val + ROW(j)[i] * (unsigned)filter[j]);
                 d[i] = (uint16_t)(0x8000 + clip_i16(val >> 15));
             }
         }
@@ -3231,8 +3231,8 @@ static void write_nv_chroma_line(const OrSws *c, uint8_t *dest, int w, const int
         for (i = 0; i < w; i++) {
             int u = (1 << 14) - 0x40000000, v = (1 << 14) - 0x40000000;
             for (j = 0; j < fs; j++) {
-                u += (int)(ROWU(j)[i] * (unsigned)filter[j]);
-                v += (int)(ROWV(j)[i] * (unsigned)filter[j]);
+                u = (int)((unsigned)u + ROWU(j)[i] * (unsigned)filter[j]);
+                v = (int)((unsigned)v + ROWV(j)[i] * (unsigned)filter[j]);
             }
             d[2 * i] = (uint16_t)(0x8000 + clip_i16(u >> 15));
             d[2 * i + 1] = (uint16_t)(0x8000 + clip_i16(v >> 15));
@@ -3243,8 +3243,8 @@ static void write_nv_chroma_line(const OrSws *c, uint8_t *dest, int w, const int
         for (i = 0; i < w; i++) {
             int u = 1 << (shift - 1), v = 1 << (shift - 1);
             for (j = 0; j < fs; j++) {
-                u += (int)(ROWU(j)[i] * (unsigned)filter[j]);
-                v += (int)(ROWV(j)[i] * (unsigned)filter[j]);
+                u = (int)((unsigned)u + ROWU(j)[i] * (unsigned)filter[j]);
+                v = (int)((unsigned)v + ROWV(j)[i] * (unsigned)filter[j]);
             }
             d[2 * i] = (uint16_t)(clip_uintp2(u >> shift, bits) << oshift);
             d[2 * i + 1] = (uint16_t)(clip_uintp2(v >> shift, bits) << oshift);
@@ -3254,8 +3254,8 @@ static void write_nv_chroma_line(const OrSws *c, uint8_t *dest, int w, const int
         for (i = 0; i < w; i++) {
             int u = dither[i & 7] << 12, v = dither[(i + 3) & 7] << 12;
             for (j = 0; j < fs; j++) {
-                u += (int)(ROWU(j)[i] * (unsigned)filter[j]);
-                v += (int)(ROWV(j)[i] * (unsigned)filter[j]);
+                u = (int)((unsigned)u + ROWU(j)[i] * (unsigned)filter[j]);
+                v = (int)((unsigned)v + ROWV(j)[i] * (unsigned)filter[j]);
             }
             dest[2 * i + swap] = (uint8_t)clip_u8(u >> 19);
             dest[2 * i + 1 - swap] = (uint8_t)clip_u8(v >> 19);
@@ -3435,8 +3435,8 @@ static void write_packed_rgb_line(OrSws *c, const Planes *P, uint8_t *dest, int 
             int Y1, Y2, U, V;
             if (mode == 0) {
                 Y1 = Y2 = U = V = 1 << 18;
-                for (j = 0; j < lfs; j++) { Y1 += (int)(L(j)[2 * i] * (unsigned)lf[j]); Y2 += (int)(LB(j) * (unsigned)lf[j]); }
-                for (j = 0; j < cfs; j++) { U += (int)(CU(j)[i] * (unsigned)cf[j]); V += (int)(CV(j)[i] * (unsigned)cf[j]); }
+                for (j = 0; j < lfs; j++) { Y1 = (int)((unsigned)Y1 + L(j)[2 * i] * (unsigned)lf[j]); Y2 = (int)((unsigned)Y2 + LB(j) * (unsigned)lf[j]); }
+                for (j = 0; j < cfs; j++) { U = (int)((unsigned)U + CU(j)[i] * (unsigned)cf[j]); V = (int)((unsigned)V + CV(j)[i] * (unsigned)cf[j]); }
                 Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
             } else if (mode == 2) {
                 int ya1 = 4096 - ya, ua1 = 4096 - ua;
@@ -3459,7 +3459,7 @@ static void write_packed_rgb_line(OrSws *c, const Planes *P, uint8_t *dest, int 
                 if (hasAlpha) {
                     if (mode == 0) {
                         A1 = A2 = 1 << 18;
-                        for (j = 0; j < lfs; j++) { A1 += (int)(AL(j)[2 * i] * (unsigned)lf[j]); A2 += (int)(AL(j)[2 * i + 1] * (unsigned)lf[j]); }
+                        for (j = 0; j < lfs; j++) { A1 = (int)((unsigned)A1 + AL(j)[2 * i] * (unsigned)lf[j]); A2 = (int)((unsigned)A2 + AL(j)[2 * i + 1] * (unsigned)lf[j]); }
                         A1 >>= 19; A2 >>= 19;
                         if ((A1 | A2) & 0x100) { A1 = clip_u8(A1); A2 = clip_u8(A2); }
                     } else if (mode == 2) {
@@ -3481,8 +3481,8 @@ static void write_packed_rgb_line(OrSws *c, const Planes *P, uint8_t *dest, int 
             int Y, U, V;
             if (mode == 0) { /* :2163-2212 */
                 Y = 1 << 9; U = (1 << 9) - (128 << 19); V = (1 << 9) - (128 << 19);
-                for (j = 0; j < lfs; j++) Y += (int)(L(j)[i] * (unsigned)lf[j]);
-                for (j = 0; j < cfs; j++) { U += (int)(CU(j)[i] * (unsigned)cf[j]); V += (int)(CV(j)[i] * (unsigned)cf[j]); }
+                for (j = 0; j < lfs; j++) Y = (int)((unsigned)Y + L(j)[i] * (unsigned)lf[j]);
+                for (j = 0; j < cfs; j++) { U = (int)((unsigned)U + CU(j)[i] * (unsigned)cf[j]); V = (int)((unsigned)V + CV(j)[i] * (unsigned)cf[j]); }
                 Y >>= 10; U >>= 10; V >>= 10;
             } else if (mode == 2) { /* :2214-2260 */
                 int ya1 = 4096 - ya, ua1 = 4096 - ua;
@@ -3503,7 +3503,7 @@ static void write_packed_rgb_line(OrSws *c, const Planes *P, uint8_t *dest, int 
                 if (hasAlpha) {
                     if (mode == 0) {
                         A = 1 << 18;
-                        for (j = 0; j < lfs; j++) A += (int)(AL(j)[i] * (unsigned)lf[j]);
+                        for (j = 0; j < lfs; j++) A = (int)((unsigned)A + AL(j)[i] * (unsigned)lf[j]);
                         A >>= 19;
                     } else if (mode == 2) A = (AL(0)[i] * (4096 - ya) + AL(1)[i] * ya + (1 << 18)) >> 19;
                     else A = (AL(0)[i] + 64) >> 7;
@@ -3632,9 +3632,9 @@ static void write_ya_line(const OrSws *c, const Planes *P, uint8_t *dest, int y)
                 if (hasAlpha) A = clip_u8((AL(0)[i] * (4096 - ya) + AL(1)[i] * ya) >> 19);
             } else {
                 Y = 1 << 18; A = 1 << 18;
-                for (j = 0; j < lfs; j++) Y += (int)(L(j)[i] * (unsigned)lf[j]);
+                for (j = 0; j < lfs; j++) Y = (int)((unsigned)Y + L(j)[i] * (unsigned)lf[j]);
                 Y >>= 19; if (Y & 0x100) Y = clip_u8(Y);
-                if (hasAlpha) { for (j = 0; j < lfs; j++) A += (int)(AL(j)[i] * (unsigned)lf[j]); A >>= 19; if (A & 0x100) A = clip_u8(A); }
+                if (hasAlpha) { for (j = 0; j < lfs; j++) A = (int)((unsigned)A + AL(j)[i] * (unsigned)lf[j]); A >>= 19; if (A & 0x100) A = clip_u8(A); }
             }
             dest[2 * i] = (uint8_t)Y; dest[2 * i + 1] = hasAlpha ? (uint8_t)A : 255;
         } else {
@@ -3649,11 +3649,11 @@ static void write_ya_line(const OrSws *c, const Planes *P, uint8_t *dest, int y)
                 A = hasAlpha ? clip_u16((int)((unsigned)AL(0)[i] * ya1 + (unsigned)AL(1)[i] * (unsigned)ya) >> 15) : 65535;
             } else {
                 Y = -0x40000000; A = 0xffff;
-                for (j = 0; j < lfs; j++) Y += (int)(L(j)[i] * (unsigned)lf[j]);
+                for (j = 0; j < lfs; j++) Y = (int)((unsigned)Y + L(j)[i] * (unsigned)lf[j]);
                 Y >>= 15; Y += (1 << 3) + 0x8000; Y = clip_u16(Y);
                 if (hasAlpha) {
                     A = -0x40000000 + (1 << 14);
-                    for (j = 0; j < lfs; j++) A += (int)(AL(j)[i] * (unsigned)lf[j]);
+                    for (j = 0; j < lfs; j++) A = (int)((unsigned)A + AL(j)[i] * (unsigned)lf[j]);
                     A >>= 15; A += 0x8000; A = clip_u16(A);
                 }
             }
@@ -3700,7 +3700,7 @@ static void write_mono_line(OrSws *c, const Planes *P, uint8_t *dest, int y)
             int Y1, Y2;
             if (mode == 0) {
                 Y1 = Y2 = 1 << 18;
-                for (j = 0; j < lfs; j++) { Y1 += (int)(L(j)[i] * (unsigned)lf[j]); Y2 += (int)(LBM(j, i + 1) * (unsigned)lf[j]); }
+                for (j = 0; j < lfs; j++) { Y1 = (int)((unsigned)Y1 + L(j)[i] * (unsigned)lf[j]); Y2 = (int)((unsigned)Y2 + LBM(j, i + 1) * (unsigned)lf[j]); }
                 Y1 >>= 19; Y2 >>= 19;
                 if ((Y1 | Y2) & 0x100) { Y1 = clip_u8(Y1); Y2 = clip_u8(Y2); }
             } else if (mode == 2) {
@@ -3722,7 +3722,7 @@ static void write_mono_line(OrSws *c, const Planes *P, uint8_t *dest, int y)
         unsigned acc = 0;
         for (i = 0; i < dstW; i += 2) {
             int Y1 = 1 << 18, Y2 = 1 << 18;
-            for (j = 0; j < lfs; j++) { Y1 += (int)(L(j)[i] * (unsigned)lf[j]); Y2 += (int)(LBM(j, i + 1) * (unsigned)lf[j]); }
+            for (j = 0; j < lfs; j++) { Y1 = (int)((unsigned)Y1 + L(j)[i] * (unsigned)lf[j]); Y2 = (int)((unsigned)Y2 + LBM(j, i + 1) * (unsigned)lf[j]); }
             Y1 >>= 19; Y2 >>= 19;
             if ((Y1 | Y2) & 0x100) { Y1 = clip_u8(Y1); Y2 = clip_u8(Y2); }
             acc = (acc << 1) | (Y1 + d128[i & 7] >= 234);
@@ -3770,8 +3770,8 @@ static void write_packed422_line(const OrSws *c, const Planes *P, uint8_t *dest,
         int Y1, Y2, U, V;
         if (mode == 0) {
             Y1 = Y2 = U = V = 1 << 18;
-            for (j = 0; j < lfs; j++) { Y1 += (int)(L(j)[2 * i] * (unsigned)lf[j]); Y2 += (int)(L2(j) * (unsigned)lf[j]); }
-            for (j = 0; j < cfs; j++) { U += (int)(CU(j)[i] * (unsigned)cf[j]); V += (int)(CV(j)[i] * (unsigned)cf[j]); }
+            for (j = 0; j < lfs; j++) { Y1 = (int)((unsigned)Y1 + L(j)[2 * i] * (unsigned)lf[j]); Y2 = (int)((unsigned)Y2 + L2(j) * (unsigned)lf[j]); }
+            for (j = 0; j < cfs; j++) { U = (int)((unsigned)U + CU(j)[i] * (unsigned)cf[j]); V = (int)((unsigned)V + CV(j)[i] * (unsigned)cf[j]); }
             Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
         } else if (mode == 2) {
             Y1 = (L(0)[2 * i] * (4096 - ya) + L(1)[2 * i] * ya) >> 19;
@@ -3827,19 +3827,19 @@ static void write_packedhi_line(const OrSws *c, const Planes *P, uint8_t *dest, 
 #define SMP(j) (chroma ? (k == 1 ? CU(j) : CV(j))[x] : (x < dstW ? L(j)[x] : (bits == 16 ? 1 << 18 : 1 << 14)))
             if (bits == 16) { /* 0x40000000 bias trick of yuv2planeX_16_c_template */
                 acc = (1 << 14) - 0x40000000;
-                for (j = 0; j < fs; j++) acc += (int)(SMP(j) * (unsigned)f[j]);
+                for (j = 0; j < fs; j++) acc = (int)((unsigned)acc + SMP(j) * (unsigned)f[j]);
                 v[k] = 0x8000 + clip_i16(acc >> 15);
             } else {
                 const int shift = 11 + 16 - bits;
                 acc = 1 << (shift - 1);
-                for (j = 0; j < fs; j++) acc += (int)(SMP(j) * (unsigned)f[j]);
+                for (j = 0; j < fs; j++) acc = (int)((unsigned)acc + SMP(j) * (unsigned)f[j]);
                 v[k] = clip_uintp2(acc >> shift, bits);
             }
         }
         if (df == ORF_AYUV64LE) {
             if (c->needAlpha) {
                 int acc = (1 << 14) - 0x40000000;
-                for (j = 0; j < lfs; j++) acc += (int)(AL(j)[i] * (unsigned)lf[j]);
+                for (j = 0; j < lfs; j++) acc = (int)((unsigned)acc + AL(j)[i] * (unsigned)lf[j]);
                 v[4] = 0x8000 + clip_i16(acc >> 15);
             } else v[4] = 65535;
         }
@@ -3892,12 +3892,12 @@ static void write_packed444_line(const OrSws *c, const Planes *P, uint8_t *dest,
         int Y, U, V, A = 255;
         if (mode == 0) {
             Y = U = V = 1 << 18;
-            for (j = 0; j < lfs; j++) Y += (int)(L(j)[i] * (unsigned)lf[j]);
-            for (j = 0; j < cfs; j++) { U += (int)(CU(j)[i] * (unsigned)cf[j]); V += (int)(CV(j)[i] * (unsigned)cf[j]); }
+            for (j = 0; j < lfs; j++) Y = (int)((unsigned)Y + L(j)[i] * (unsigned)lf[j]);
+            for (j = 0; j < cfs; j++) { U = (int)((unsigned)U + CU(j)[i] * (unsigned)cf[j]); V = (int)((unsigned)V + CV(j)[i] * (unsigned)cf[j]); }
             Y >>= 19; U >>= 19; V >>= 19;
             if (hasAlpha) {
                 A = 1 << 18;
-                for (j = 0; j < lfs; j++) A += (int)(AL(j)[i] * (unsigned)lf[j]);
+                for (j = 0; j < lfs; j++) A = (int)((unsigned)A + AL(j)[i] * (unsigned)lf[j]);
                 A >>= 19;
                 if (A & 0x100) A = clip_u8(A);
             }
@@ -3947,8 +3947,8 @@ static void write_planar_rgb_line(const OrSws *c, const Planes *P, uint8_t *cons
         if (depth <= 14) { /* yuv2gbrp_full_X_c :2342-2421, 15-bit intermediates */
             const int SH = 22 + 8 - depth;
             Y = 1 << 9; U = (1 << 9) - (128 << 19); V = (1 << 9) - (128 << 19);
-            for (j = 0; j < lfs; j++) Y += (int)(L(j)[i] * (unsigned)lf[j]);
-            for (j = 0; j < cfs; j++) { U += (int)(CU(j)[i] * (unsigned)cf[j]); V += (int)(CV(j)[i] * (unsigned)cf[j]); }
+            for (j = 0; j < lfs; j++) Y = (int)((unsigned)Y + L(j)[i] * (unsigned)lf[j]);
+            for (j = 0; j < cfs; j++) { U = (int)((unsigned)U + CU(j)[i] * (unsigned)cf[j]); V = (int)((unsigned)V + CV(j)[i] * (unsigned)cf[j]); }
             Y >>= 10; U >>= 10; V >>= 10;
             Y -= c->yuv2rgb_y_offset;
             Y = (int)((unsigned)Y * (unsigned)c->yuv2rgb_y_coeff);
@@ -3965,8 +3965,8 @@ static void write_planar_rgb_line(const OrSws *c, const Planes *P, uint8_t *cons
             }
         } else { /* yuv2gbrp16_full_X_c :2467-2530 / yuv2gbrpf32_full_X_c :2533-2605, 19-bit intermediates */
             Y = -0x40000000; U = -(128 << 23); V = -(128 << 23);
-            for (j = 0; j < lfs; j++) Y += (int)(L(j)[i] * (unsigned)lf[j]);
-            for (j = 0; j < cfs; j++) { U += (int)(CU(j)[i] * (unsigned)cf[j]); V += (int)(CV(j)[i] * (unsigned)cf[j]); }
+            for (j = 0; j < lfs; j++) Y = (int)((unsigned)Y + L(j)[i] * (unsigned)lf[j]);
+            for (j = 0; j < cfs; j++) { U = (int)((unsigned)U + CU(j)[i] * (unsigned)cf[j]); V = (int)((unsigned)V + CV(j)[i] * (unsigned)cf[j]); }
             Y >>= 14; Y += 0x10000; U >>= 14; V >>= 14;
             Y -= c->yuv2rgb_y_offset;
             Y = (int)((unsigned)Y * (unsigned)c->yuv2rgb_y_coeff);
@@ -3997,12 +3997,12 @@ static void write_planar_rgb_line(const OrSws *c, const Planes *P, uint8_t *cons
                 if (depth <= 14) {
                     const int SH = 22 + 8 - depth;
                     A = 1 << 18;
-                    for (j = 0; j < lfs; j++) { al = P->alp + (size_t)ORMIN(firstLum + j, srcH - 1) * lw; A += (int)(al[i] * (unsigned)lf[j]); }
+                    for (j = 0; j < lfs; j++) { al = P->alp + (size_t)ORMIN(firstLum + j, srcH - 1) * lw; A = (int)((unsigned)A + al[i] * (unsigned)lf[j]); }
                     if (A & 0xF8000000) A = clip_uintp2(A, 27);
                     if (SH != 22) ((uint16_t *)da)[i] = (uint16_t)(A >> (SH - 3)); else da[i] = (uint8_t)(A >> 19);
                 } else {
                     A = -0x40000000;
-                    for (j = 0; j < lfs; j++) { al = P->alp + (size_t)ORMIN(firstLum + j, srcH - 1) * lw; A += (int)(al[i] * (unsigned)lf[j]); }
+                    for (j = 0; j < lfs; j++) { al = P->alp + (size_t)ORMIN(firstLum + j, srcH - 1) * lw; A = (int)((unsigned)A + al[i] * (unsigned)lf[j]); }
                     A >>= 1; A += 0x20002000;
                     if (isf) ((float *)da)[i] = (1.0f / 65535.0f) * (float)(clip_uintp2(A, 30) >> 14);
                     else ((uint16_t *)da)[i] = (uint16_t)(clip_uintp2(A, 30) >> 14);

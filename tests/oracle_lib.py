@@ -207,8 +207,15 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        so = os.path.join(ORACLE_DIR, "libsws_oracle.so")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(ORACLE_DIR, "sws_oracle.c")):
+        so = os.environ.get("SWS_ORACLE_LIBRARY")          # tools/asan_env.sh: the sanitizer build of the checker
+        if so:
+            if not os.path.exists(so):
+                raise RuntimeError(f"SWS_ORACLE_LIBRARY={so} does not exist (make -C oracle asan)")
+        else:
+            so = os.path.join(ORACLE_DIR, "libsws_oracle.so")
+        if "SWS_ORACLE_LIBRARY" in os.environ:
+            pass
+        elif not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(ORACLE_DIR, "sws_oracle.c")):
             build()
         L = C.CDLL(so)
         L.or_sws_get_context.restype = C.c_void_p

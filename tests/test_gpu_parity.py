@@ -28,6 +28,11 @@ def _forensics(p, out, ref, src_frame, dst_frame, hs, prefill, redo=None):
             rb = out.row_bytes[i]
             d = a[:, :rb] != b[:, :rb]
             info.append(f"plane{i}: {int(d.sum())}/{d.size} differ, zeros {int((a[:, :rb][d] == 0).sum())}, prefill {int((a[:, :rb][d] == prefill).sum())}")
+        try:                     # are the context's device tables still what the host uploaded? (a wild writer's victim if not)
+            nbad, text = p.debug_check()
+            info.append(f"device tables of the failed context: {nbad} anomalies ({text.strip()})")
+        except Exception as e:
+            info.append(f"device table check unavailable: {e!r}")
         if isinstance(dst_frame, DeviceFrame):
             again = dst_frame.download()
             info.append("second read equals first: " + str(all(np.array_equal(x[:, :r], y[:, :r]) for x, y, r in zip(again.planes, out.planes, out.row_bytes))))

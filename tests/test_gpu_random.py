@@ -363,6 +363,11 @@ def _batch_forensics(p, o, case, src_frame, dst_frame, ref, frame_seed):
     try:
         def planes_equal(x, y):
             return all(np.array_equal(a[:, :rb], b[:, :rb]) for a, b, rb in zip(x.planes, y.planes, x.row_bytes))
+        try:      # before anything else runs on it: are the context's device tables still what the host uploaded?
+            nbad, text = p.debug_check()
+            notes.append(f"device tables of the failed context: {nbad} anomalies ({text.strip()})")
+        except Exception as e:
+            notes.append(f"device table check unavailable: {e!r}")
         s = OL.fill_random(OL.Frame(sf, sw, sh), frame_seed)
         ref2 = OL.Frame(df, dw, dh, fill=0x33)
         o.scale(s, ref2)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs a command (normally pytest) with the sanitizer builds of the product's host side and of the oracle:
+#   make -C librempeg_amd/csrc asan ; make -C oracle asan ; tools/asan_env.sh python -m pytest tests -m gpu -x -q
+# Both are built with clang and -shared-libsan, so ONE AddressSanitizer runtime (preloaded into python) watches numpy's buffers,
+# the ctypes call frames, the library's host code and the oracle.  UBSan reports are logged and the run goes on (tools/asan_summary.py lists the unique sites).
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+export SWS_HIP_LIBRARY=$ROOT/librempeg_amd/lib_asan/libswscale_hip.so
+export SWS_ORACLE_LIBRARY=$ROOT/oracle/asan/libsws_oracle.so
+# python "leaks" by design; the HSA runtime maps the shadow gap; abort on the first report so that pytest shows the test
+export ASAN_OPTIONS=${ASAN_OPTIONS:-detect_leaks=0:protect_shadow_gap=0:verify_asan_link_order=0:abort_on_error=0:halt_on_error=1:log_path=${ASAN_LOG:-/tmp/asan_report}:print_stacktrace=1:detect_odr_violation=0}
+export UBSAN_OPTIONS=${UBSAN_OPTIONS:-print_stacktrace=1:halt_on_error=0:log_path=${ASAN_LOG:-/tmp/asan_report}}
+# ROCm's ASan runtime interposes the HSA allocation calls for device ASan and fails them on this image's uninstrumented runtime:
+# tools/asan_hsa_passthrough.c hands them straight to libhsa-runtime64 (built here if missing; must come FIRST in the preload list)
+SHIM=$ROOT/tools/bin/libasan_hsa_passthrough.so
+[ -f $SHIM ] || { mkdir -p $ROOT/tools/bin; gcc -O2 -shared -fPIC -I/opt/rocm/include -o $SHIM $ROOT/tools/asan_hsa_passthrough.c -ldl; }
+export LD_PRELOAD=$SHIM:$RT${LD_PRELOAD:+:$LD_PRELOAD}
+exec "$@"
