@@ -30,6 +30,12 @@ void launch_layout_join422(const LaunchCtx &L, bool uyvy);   // k_layout.hip: pl
 static int ensure_dev(SwsInternal *c)
 {
     if (c->dev) return 0;
+    if (c->tune.dry_plan) {      // planner-only context: no device is asked for
+        DeviceState *d = new DeviceState();
+        d->dry = true;
+        c->dev = d;
+        return 0;
+    }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         (void)hipGetLastError();
@@ -59,19 +65,31 @@ static DeviceState *dev_state_for(SwsInternal *c, int device)
 }
 
 static void guard_forget(void *p);      // (SWS_HIP_DEBUG & 64: below)
+static bool guards_enabled();
 static void dev_state_free(DeviceState *d)
 {
     if (!d) return;
+    if (d->dry) { delete d; return; }      // (its table "blocks" are fake addresses; it holds no stream, event or allocation)
     (void)hipSetDevice(d->device);
     // (a stream the context does not own -- the caller's, or a frames' hwdevice stream on loan -- may be gone by now: it is never touched here)
+    // Wait for what THIS state queued before its blocks, pinned tables and events go (no reliance on hipFree's implicit wait, which an asynchronous
+    // allocator need not give) -- and for nothing else: freeing one scaler must not stall the other contexts' pipelines on the GPU (advisor r5).
+    //  * its own stream: everything it launched there, and what it launched on a borrowed stream (dev_return_stream made the own stream wait for it);
+    //  * the frame-table ring's launch sets (events recorded behind them on whatever stream they ran);
+    //  * a loan that was never returned: its event;
+    //  * a state that last ran on a stream it does not own (the caller's, sws_hip_set_stream; a cascade child on its parent's): that handle may be gone,
+    //    so it cannot be waited for -- the device is, as before.
+    const bool foreign = d->stream && !d->own_stream;
     if (d->stream && d->own_stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
-    // everything this state queued -- on its own stream or on one it borrowed -- is behind the device: wait for the device once, explicitly, before
-    // blocks, pinned tables and events go (no reliance on hipFree's implicit wait, which an asynchronous allocator need not give)
-    (void)hipDeviceSynchronize();
+    for (auto &b : d->ring.inflight) if (b.ev) (void)hipEventSynchronize(b.ev);
+    if (d->ev_loan) (void)hipEventSynchronize(d->ev_loan);
+    if (foreign || guards_enabled()) (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
     for (void *p : { d->d_tables, d->scratch, d->stage_src, d->stage_dst, (void *)d->ring.dev, d->casc_img, d->slice_img, d->d_tilegeom,
                      d->d_rgbplan, d->d_be, d->d_xyz, d->d_xyz_tab, d->d_dot2, d->casc_img2, d->d_gamma_tab, d->d_ed_err, d->d_pal, d->d_vlines, d->rgbread_img })
         if (p) { guard_forget(p); (void)hipFree(p); }
     if (d->ring.host) (void)hipHostFree(d->ring.host);
+    for (auto &r : d->ring.retired) { if (r.dev) (void)hipFree(r.dev); if (r.host) (void)hipHostFree(r.host); }
     for (auto &b : d->ring.inflight) if (b.ev) (void)hipEventDestroy(b.ev);
     for (hipEvent_t e : d->ring.pool) (void)hipEventDestroy(e);
     for (void *p : { d->join_img, d->split_img, d->stage_img }) if (p) { guard_forget(p); (void)hipFree(p); }
@@ -238,8 +256,11 @@ static bool guards_enabled()
     static const bool on = std::getenv("SWS_HIP_DEBUG") && (std::atoi(std::getenv("SWS_HIP_DEBUG")) & 64);
     return on;
 }
-static std::mutex g_guard_mu;
-static std::map<void *, size_t> g_guarded;      // block -> bytes in front of its guard
+// (leaked on purpose: contexts freed during process teardown -- python finalisers, atexit -- still find the registry alive)
+struct GuardRegistry { std::mutex mu; std::map<void *, size_t> blocks; };      // block -> bytes in front of its guard
+static GuardRegistry &guard_registry() { static GuardRegistry *r = new GuardRegistry(); return *r; }
+#define g_guard_mu (guard_registry().mu)
+#define g_guarded (guard_registry().blocks)
 static void guard_forget(void *p) { if (p && guards_enabled()) { std::lock_guard<std::mutex> lk(g_guard_mu); g_guarded.erase(p); } }
 static int guard_arm(SwsInternal *c, void *p, size_t bytes)
 {
@@ -253,7 +274,9 @@ static int guard_arm(SwsInternal *c, void *p, size_t bytes)
 static int guards_check(SwsInternal *c, hipStream_t st)
 {
     if (!guards_enabled()) return 0;
-    HIPCHK(hipStreamSynchronize(st));
+    // the guards of ALL live blocks of the process are compared: every stream has to be quiet, or another context's conversion still in flight could be blamed on this one
+    (void)st;
+    HIPCHK(hipDeviceSynchronize());
     std::lock_guard<std::mutex> lk(g_guard_mu);
     std::vector<uint8_t> h(GUARD_BYTES);
     for (const auto &e : g_guarded) {
@@ -286,6 +309,12 @@ static void table_records_drop(DeviceState *d, const void *lo, size_t bytes)
 }
 static int table_alloc(SwsInternal *c, DeviceState *d, void **buf, size_t *cap, size_t need)
 {
+    if (d->dry) {     // a fixed fake address per table member of the state: the plan (pointers into the blocks included) is the same on every run
+        table_records_drop(d, *buf, *cap);
+        *buf = (void *)(uintptr_t)(0x100000000000ull + (uint64_t)((const char *)buf - (const char *)d) * 0x100000000ull);
+        *cap = need;
+        return 0;
+    }
     const size_t slack = guards_enabled() ? GUARD_BYTES : poison_enabled() ? 4096 : 0;
     if (need + slack > *cap) {
         if (*buf) table_records_drop(d, *buf, *cap);
@@ -312,6 +341,11 @@ static bool verify_uploads()
 static int table_put(SwsInternal *c, DeviceState *d, void *dst, const void *src, size_t bytes)
 {
     if (!bytes) return 0;
+    if (d->dry) {
+        table_records_drop(d, dst, bytes);
+        d->tab_recs.push_back({ dst, bytes, fnv1a64(src, bytes) });
+        return 0;
+    }
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     table_records_drop(d, dst, bytes);
@@ -333,10 +367,13 @@ static int table_put(SwsInternal *c, DeviceState *d, void *dst, const void *src,
 static int dev_prepare_on(SwsInternal *c, DeviceState *d)
 {
     if (d->epoch == c->tables_epoch && d->stream) return 0;
+    if (d->dry) d->stream = (hipStream_t)(uintptr_t)1;      // (never handed to HIP: a planner-only state is never launched on)
+    else {
     HIPCHK(hipSetDevice(d->device));
     if (!d->stream) { HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)); d->own_stream = true; }
     // a rebuild rewrites plan tables that launches still in flight on the (non-blocking) stream may be reading
     else HIPCHK(hipStreamSynchronize(d->stream));
+    }
 
     SwsDevParams &p = d->params;
     std::memset(&p, 0, sizeof(p));
@@ -1552,8 +1589,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
         !c->tune.no_strip_rgbsrc) { c->path_name = "main:strip_packed422"; c->kernel_name = "sws_k_strip_rgbsrc"; }     // (aligned frames; launch_plan_le falls back to split422 + strip_march otherwise)
     if (c->plan == PLAN_MAIN && d->join422) c->path_name += "+join422";
     // (aligned frames: k_stream.hip launch_mixed_join422 takes the mixed plan and its interleave as one pass)
-    if (c->plan == PLAN_MAIN && d->join422 && d->mixed_ok && d->unity_h && !d->fullchr_on && !isGray(c->opts.src_format) && c->srcBpc == 8 && !p.range_active && !c->tune.no_wave &&
-        (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12) && !(p.dstW & 7) && p.vChrFs <= 16) { c->path_name = "main:mixed_join422"; c->kernel_name = "sws_k_mixed_join422"; }
+    if (c->plan == PLAN_MAIN && d->join422 && d->mixed_ok && !d->fullchr_on && !isGray(c->opts.src_format) && mixed_join422_shape(c, d, p)) { c->path_name = "main:mixed_join422"; c->kernel_name = "sws_k_mixed_join422"; }
     if (c->plan == PLAN_MAIN && d->fullchr_on) c->path_name += d->fullchr_on == 3 ? "+lut_rgb" : d->fullchr_on == 4 ? (((d->fullchr_kind == DSTK_GBRP16 || d->fullchr_kind == DSTK_GBRPF32) && c->tune.no_wide_epilogue != 1) ? ((d->rgbread_on || c->tune.no_wide_epilogue == 2) ? "+fullchr_gbrp16" : "+fused_gbrp16") : "+sum_writer") : "+fullchr_rgb";
     if (c->plan == PLAN_MAIN && d->rgb2rgb_ok && !c->tune.no_strip_rgb2rgb && (d->fullchr_on == 1 || d->fullchr_on == 2) && !d->fullchr_direct && d->rgbread_on && d->strip_ok) {
         c->path_name = "main:strip_rgb2rgb"; c->kernel_name = "sws_k_strip_rgb2rgb";      // (aligned frames; launch_plan_le falls back to rgbread + strip_march + fullchr_rgb otherwise)
@@ -1576,7 +1612,7 @@ static int dev_prepare_on(SwsInternal *c, DeviceState *d)
 // host's (a wild writer's victim) or not.
 int dev_check_state(SwsInternal *c, DeviceState *d, std::string &out)
 {
-    if (!d) return 0;
+    if (!d || d->dry) return 0;
     int bad = 0;
     HIPCHK(hipSetDevice(d->device));
     if (d->stream) HIPCHK(hipStreamSynchronize(d->stream));
@@ -1607,6 +1643,24 @@ int dev_prepare(SwsInternal *c)
     if (ret < 0) return ret;
     DeviceGuard guard;
     return dev_prepare_on(c, c->dev);
+}
+
+// The plan of a context as two numbers: a digest of every table block the planner uploaded (sizes, order of the blocks in the state, contents) and a digest of the
+// kernel parameters (SwsDevParams: geometry, constants and the pointers into the table blocks).  The first is the same with and without a GPU; the second is
+// reproducible for dry_plan contexts only (fake table addresses).  tests/test_planner_table.py pins (path, kernel, digests) per conversion on the CPU box.
+int dev_plan_digest(SwsInternal *c, uint64_t out[2])
+{
+    int r = dev_prepare(c);
+    if (r < 0) return r;
+    DeviceState *d = c->dev;
+    std::vector<TableRecord> recs = d->tab_recs;
+    std::sort(recs.begin(), recs.end(), [](const TableRecord &a, const TableRecord &b) { return (uintptr_t)a.dst < (uintptr_t)b.dst; });
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { for (int i = 0; i < 8; i++) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ull; } };
+    for (size_t i = 0; i < recs.size(); i++) { mix(i); mix(recs[i].bytes); mix(recs[i].hash); }
+    out[0] = h;
+    out[1] = d->params_hash;
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1698,11 +1752,21 @@ static int ring_regrow(SwsInternal *c, DeviceState *d, hipStream_t st, int need)
     // every launch set that reads the old blocks has to be over: the closed ones have events, the open one is on `st`
     for (auto &b : R.inflight) if (b.ev) { HIPCHK(hipEventSynchronize(b.ev)); R.pool.push_back(b.ev); b.ev = nullptr; }
     R.inflight.clear();
-    if (!R.cur.empty()) HIPCHK(hipStreamSynchronize(st));
+    const bool open_set = !R.cur.empty();
+    if (open_set) HIPCHK(hipStreamSynchronize(st));
+    // blocks retired by an earlier regrow: the set that held pointers into them has been launched and waited for by now
+    for (auto &r : R.retired) { if (r.dev) (void)hipFree(r.dev); if (r.host) (void)hipHostFree(r.host); }
+    R.retired.clear();
     R.cur.clear();
     for (auto &cc : R.cache) { cc.off = -1; cc.n = 0; }
-    if (R.dev) HIPCHK(hipFree(R.dev));
-    if (R.host) HIPCHK(hipHostFree(R.host));
+    // A launch set under construction may hold table pointers it has NOT launched with yet (the main table is taken before the helper passes'
+    // tables): the old blocks outlive this regrow and are freed by the next one or with the state (advisor r5: a freed block under such a pointer
+    // would hand a kernel another context's frame addresses)
+    if (open_set) R.retired.push_back({ R.dev, R.host });
+    else {
+        if (R.dev) HIPCHK(hipFree(R.dev));
+        if (R.host) HIPCHK(hipHostFree(R.host));
+    }
     R.dev = nullptr; R.host = nullptr; R.cap = 0; R.head = 0;
     int cap = 512;
     while (cap < need) cap *= 2;
@@ -1757,7 +1821,9 @@ static const SwsFramePtrs *table_upload_(SwsInternal *c, DeviceState *d, hipStre
 const SwsFramePtrs *table_upload(SwsInternal *c, DeviceState *d, hipStream_t st, int slot, const SwsFramePtrs *v, int n)
 {
     int err = 0;
-    return table_upload_(c, d, st, slot, v, n, &err);
+    const SwsFramePtrs *t = table_upload_(c, d, st, slot, v, n, &err);
+    d->ring.last_err = t ? 0 : (err ? err : AVERROR_EXTERNAL_);
+    return t;
 }
 
 int table_batch_end(SwsInternal *c, DeviceState *d, hipStream_t st)
@@ -1825,7 +1891,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
     // them; slot 2: the alpha launch of a full-chroma RGB destination; slots 3 / 4: staging copies in / out): spans of the frame-table ring (table_upload), cached per slot
     auto aux_table = [&](int slot, const std::vector<SwsFramePtrs> &v, const SwsFramePtrs **out) -> int {
         *out = table_upload(c, d, st, TAB_AUX0 + slot, v.data(), n);
-        return *out ? 0 : AVERROR_EXTERNAL_;
+        return *out ? 0 : d->ring.last_err;
     };
     bool timing_started = !rec0;
     // pictures whose planes are not 16-byte aligned (a cropped view, a tightly packed rgb24 row) or bottom-up (negative line sizes) under the helper passes, which read and write 16-byte
@@ -1990,7 +2056,7 @@ static int launch_plan_le_batch(SwsInternal *c, DeviceState *d, const SwsFramePt
     if (n == 1) { fs.table = nullptr; fs.one = frames[0]; }
     else {
         fs.table = table_upload(c, d, st, TAB_MAIN, frames, n);
-        if (!fs.table) return AVERROR_EXTERNAL_;
+        if (!fs.table) return d->ring.last_err;
     }
     const bool vec = frames_vec_ok(frames, n);
     L.c = c; L.d = d; L.p = &p; L.st = st; L.frames = frames; L.n = n; L.sliceY = sliceY; L.sliceH = sliceH; L.vec = vec;
@@ -2418,6 +2484,7 @@ int dev_run(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4],
 {
     int ret = ensure_dev(c);
     if (ret < 0) return ret;
+    if (c->dev->dry) { log_msg(c, 0, "a dry_plan context only plans: it cannot convert\n"); return SWS_AVERROR(ENOSYS); }
     DeviceGuard guard;
     if (nb_frames <= 0) {   // sws_scale(): the home GPU, or the GPU the caller's device buffers live on
         DeviceState *d = c->dev;
@@ -3110,6 +3177,18 @@ void *sws_hip_get_stream(SwsContext *sws)
     return (void *)c->dev->stream;
 }
 
+int sws_hip_plan(SwsContext *sws, uint64_t digest[2])
+{
+    if (!sws) return SWS_AVERROR(EINVAL);
+    SwsInternal *c = internal(sws);
+    if (!c->legacy_init) return SWS_AVERROR(EINVAL);     // (a dynamic context plans per frame)
+    uint64_t dg[2] = { 0, 0 };
+    int r = dev_plan_digest(c, dg);
+    if (r < 0) return r;
+    if (digest) { digest[0] = dg[0]; digest[1] = dg[1]; }
+    return 0;
+}
+
 int sws_hip_debug_check(SwsContext *sws, char *buf, int cap)
 {
     if (!sws) return SWS_AVERROR(EINVAL);
@@ -3177,7 +3256,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
         { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb }, { "no_strip_range", &c->tune.no_strip_range }, { "no_strip_wide", &c->tune.no_strip_wide }, { "no_wide_epilogue", &c->tune.no_wide_epilogue }, { "no_strip_u16", &c->tune.no_strip_u16 },
         { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_lds_pad_kb", &c->tune.strip_lds_pad_kb }, { "no_striprgb_direct", &c->tune.no_striprgb_direct }, { "no_rgbsrc2", &c->tune.no_rgbsrc2 }, { "no_strip_rgbsrc", &c->tune.no_strip_rgbsrc }, { "no_strip_rgb2rgb", &c->tune.no_strip_rgb2rgb },
-        { "no_strip_short", &c->tune.no_strip_short }, { "no_generic_kinds", &c->tune.no_generic_kinds }, { "no_rgbread_kinds", &c->tune.no_rgbread_kinds }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "no_fast_banks", &c->tune.no_fast_banks }, { "no_short_forms", &c->tune.no_short_forms }, { "strip_short_waves", &c->tune.strip_short_waves },
+        { "no_strip_short", &c->tune.no_strip_short }, { "no_generic_kinds", &c->tune.no_generic_kinds }, { "no_rgbread_kinds", &c->tune.no_rgbread_kinds }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "no_fast_banks", &c->tune.no_fast_banks }, { "no_short_forms", &c->tune.no_short_forms }, { "strip_short_waves", &c->tune.strip_short_waves }, { "dry_plan", &c->tune.dry_plan }, { "exp0", &c->tune.exp[0] }, { "exp1", &c->tune.exp[1] }, { "exp2", &c->tune.exp[2] }, { "exp3", &c->tune.exp[3] }, { "exp4", &c->tune.exp[4] }, { "exp5", &c->tune.exp[5] }, { "exp6", &c->tune.exp[6] }, { "exp7", &c->tune.exp[7] },
         { "debug", &c->tune.debug },
     };
     for (auto &e : tab)

@@ -24,6 +24,11 @@ struct TableRing {
     std::vector<Span> cur;           // spans handed out (or reused) since the last table_batch_end()
     std::vector<hipEvent_t> pool;    // spare events
     struct Cached { int off = -1, n = 0; } cache[8];   // last span of a slot: an identical table is not uploaded again
+    // blocks a regrow replaced while a launch set was still being built: table pointers already handed out for that set stay valid until the next
+    // regrow (behind its waits) or the end of the state
+    struct Retired { SwsFramePtrs *dev, *host; };
+    std::vector<Retired> retired;
+    int last_err = 0;                // why the last table_upload() returned nullptr
 };
 enum { TAB_MAIN = 0, TAB_AUX0 = 1 /* .. TAB_AUX0 + 4 */, TAB_FRAMES2 = 6 };
 
@@ -33,6 +38,7 @@ struct TableRecord { const void *dst; size_t bytes; uint64_t hash; };
 
 struct DeviceState {
     int device = 0;
+    bool dry = false;          // Tuning::dry_plan: planned without a GPU (fake table addresses, nothing uploaded, never launched)
     std::vector<TableRecord> tab_recs;
     uint64_t params_hash = 0;  // hash of `params` as dev_prepare_on() left it
     hipStream_t stream = nullptr;
@@ -126,6 +132,13 @@ static inline bool frames_desc_ok(const SwsFramePtrs *fr, int n, int srcH, int d
             if (fr[i].dst[k] && (fr[i].dstStride[k] <= 0 || (int64_t)fr[i].dstStride[k] * dstH >= (int64_t)1 << 31)) return false;
         }
     return true;
+}
+
+// The context-level half of sws_k_mixed_join422's shape test: ONE predicate for the planner's path name (device.hip) and the launcher (k_stream.hip), which adds
+// the per-call alignment test of the frames -- a context whose frames are not 16-byte aligned still runs the three passes under the fused kernel's name
+static inline bool mixed_join422_shape(const SwsInternal *c, const DeviceState *d, const SwsDevParams &p)
+{
+    return d->unity_h && c->srcBpc == 8 && !p.range_active && !c->tune.no_wave && (p.srcKind == SRCK_PLANAR8 || p.srcKind == SRCK_NV12) && !(p.dstW & 7) && p.vChrFs <= 16;
 }
 
 // ---- k_misc.hip: element-per-thread unscaled converters and helper passes ----

@@ -111,7 +111,7 @@ int launch_mixed_join422(const LaunchCtx &L, bool uyvy)
 {
     const SwsDevParams &p = *L.p;
     SwsInternal *c = L.c;
-    if (c->tune.no_wave || !L.d->unity_h || c->srcBpc != 8 || p.range_active || (p.srcKind != SRCK_PLANAR8 && p.srcKind != SRCK_NV12) || (p.dstW & 7) || p.vChrFs > 16) return 0;
+    if (!mixed_join422_shape(c, L.d, p)) return 0;
     for (int i = 0; i < L.n; i++) {
         const SwsFramePtrs &a = L.frames[i];
         for (int k = 0; k < (p.srcKind == SRCK_NV12 ? 2 : 3); k++) if (!a.src[k] || (((uintptr_t)a.src[k] | (uintptr_t)(int64_t)a.srcStride[k]) & 15)) return 0;

@@ -58,6 +58,24 @@ int launch_strip_planes(const LaunchCtx &L, int which)
                     }
                     return;
                 }
+                // experiments (sws_hip_set_option "exp0" = ring depth D in row pairs (2 / 3; 0 = the shipped 4), "exp1" = absolute register-ring slots,
+                // "exp2" = waves per SIMD the variant is compiled for): C3b's two launches only
+                if (s16 && g.dma_ok && !c->tune.no_strip_dma && (c->tune.exp[0] || c->tune.exp[1]) && cols == (chroma ? 2 : 4)) {
+                    const int D = c->tune.exp[0] ? c->tune.exp[0] : 4, wpe = c->tune.exp[2] ? c->tune.exp[2] : 4;
+                    const bool abs = c->tune.exp[1] != 0;
+                    const size_t lds = (size_t)g.lds_dma_bytes * D / 4;
+#define SWS_V(C, K, DD, A, W) hipLaunchKernelGGL((swsk::sws_k_strip_dma_v<C, K, DD, A, W>), grid, blk, lds, st, fs, p, g)
+#define SWS_VC(DD, A, W) do { if (chroma) SWS_V(true, 2, DD, A, W); else SWS_V(false, 4, DD, A, W); } while (0)
+                    if (D == 4 && abs && wpe == 4) SWS_VC(4, true, 4);
+                    else if (D == 2 && !abs && wpe == 8) SWS_VC(2, false, 8);
+                    else if (D == 2 && abs && wpe == 8) SWS_VC(2, true, 8);
+                    else if (D == 3 && abs && wpe == 5) SWS_VC(3, true, 5);
+                    else if (D == 2 && abs && wpe == 6) SWS_VC(2, true, 6);
+                    else { log_msg(c, 0, "no such strip_dma experiment variant\n"); }
+#undef SWS_VC
+#undef SWS_V
+                    return;
+                }
                 if (s16 && g.dma_ok && !c->tune.no_strip_dma) {   // 16-bit sources: LDS-DMA ring, 3 row pairs in flight per wave
                     if (chroma) { if (cols == 1) SWS_STRIP_DMA(true, 1); else SWS_STRIP_DMA(true, 2); }
                     else        { if (cols == 2) SWS_STRIP_DMA(false, 2); else SWS_STRIP_DMA(false, 4); }
@@ -144,7 +162,7 @@ int launch_rgbread_strip(const LaunchCtx &L)
     if (n == 1) { L2.fs.table = nullptr; L2.fs.one = fr[0]; }
     else {
         L2.fs.table = table_upload(c, d, st, TAB_FRAMES2, fr.data(), n);
-        if (!L2.fs.table) return AVERROR_EXTERNAL_;
+        if (!L2.fs.table) return d->ring.last_err;
     }
     return launch_strip_planes(L2, p.no_chroma ? 1 : 3);     // (a gray destination: the luma launch alone)
 }

@@ -552,11 +552,17 @@ __device__ __forceinline__ void strip_dma16(uint32_t lds_dst, int voff, const i3
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff), "s"(mask_lo), "s"(mask_hi) : "memory");
 }
 
-template <bool CHROMA, int COLS, int NPH, int RD = 8>
+// D: row pairs of the LDS ring (pairs in flight + 1).  ABS: row pair q lives in register-ring slot q & (RD - 1) for the whole band -- a new pair overwrites
+// ONE slot (selected by a wave-uniform switch) instead of shifting the ring down by one (RD - 1 moves per column and pair: a fifth of the vector
+// instructions of the C3b luma launch), and the vertical stage picks its rotation of the taps by the row's first pair (pf & (RD - 1)): eight
+// straight-line variants over all RD slots, the plan entry's taps beyond the filter being zero (devparams.h SwsStripRow).
+template <bool CHROMA, int COLS, int NPH, int RD = 8, int D = STRIP_DMA_DEPTH, bool ABS = false>
 __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevParams &p, const SwsStripGeom &g, int strip, int y0, int y1,
                                                uint8_t *smem, int wib, int lane)
 {
-    constexpr int NCOMP = CHROMA ? 2 : 1, SPC = 8, D = STRIP_DMA_DEPTH;
+    constexpr int NCOMP = CHROMA ? 2 : 1, SPC = 8;
+    static_assert(!ABS || RD == 8, "the absolute-slot form is written for a ring of 8 row pairs");
+    auto slot_of = [](int q) { return (D & (D - 1)) == 0 ? (q & (D - 1)) : ((q % D) + D) % D; };
     constexpr int PARTS = CHROMA ? 1 : 2;                     // 1 KiB pieces per staged row (chroma windows are <= 64 chunks: host)
     const int W = CHROMA ? p.chrDstW : p.dstW, H = CHROMA ? p.chrDstH : p.dstH;
     const int sH = CHROMA ? p.chrSrcH : p.srcH;
@@ -602,7 +608,7 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
     const uint32_t m0lo = lanes_lo(n0), m0hi = lanes_hi(n0), m1lo = lanes_lo(n1), m1hi = lanes_hi(n1);   // EXEC masks of the two pieces
     auto dma = [&](int q) {                                    // request source rows 2q, 2q + 1 (clamped) into ring slot q % D
         const int r0 = min(max(2 * q, 0), sH - 1), r1 = min(max(2 * q + 1, 0), sH - 1);
-        const uint32_t slot = lds_base + (uint32_t)((q & (D - 1)) * pair_dw) * 4u;
+        const uint32_t slot = lds_base + (uint32_t)(slot_of(q) * pair_dw) * 4u;
 #pragma unroll
         for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
@@ -613,7 +619,6 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
                 if (PARTS == 2 && nparts == 2) strip_dma16(dst + 1024u, voff + 1024, rs[ci], soff, m1lo, m1hi);
             }
     };
-    static_assert(D == 4, "the wait immediates below are (D - 1) * P for D = 4");
 
     // ---- destination descriptors and per-lane offsets (columns beyond the plane get an out-of-range offset) ----
     const bool semi = CHROMA && (p.dstKind == DSTK_NV12 || p.dstKind == DSTK_P010);
@@ -648,8 +653,8 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
     // at most (D - 1) * P operations outstanding.  (Only the younger LOADS bound the wait: stores are acknowledged independently of the loads, so
     // allowing for the stores issued behind the request as well -- tried in round 4 -- lets the wait pass with pair q still in flight.)
     auto wait_pair = [&]() {
-        if (NCOMP * 2 * nparts == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (NCOMP * 2 * nparts == 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * 2) : "memory");
     };
     uint32_t pend[NCOMP][COLS];
     int pend_y = -1;
@@ -715,7 +720,7 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
             wait_pair();
             StripLds L;
             L.row_dw = row_dw;
-            L.S = ringS + (qnext & (D - 1)) * pair_dw;
+            L.S = ringS + slot_of(qnext) * pair_dw;
             uint32_t np[NCOMP][COLS];
             // The horizontal stage sits in a basic block of its own: straight-line code lets hipcc interleave it with the ring and the
             // vertical stage until the live set overshoots the 128 VGPRs of 4 waves per SIMD and the loop spills (4x slower, measured).
@@ -728,6 +733,13 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
             } else
             strip_hstage<NPH, NCOMP, COLS>(L, spd, ht, sh, np);
             if (rng.on) strip_range<NCOMP, COLS>(np, rng);
+            if constexpr (ABS) {
+                switch (qnext & (RD - 1)) {
+#define SWS_RING_PUT(K) case K: _Pragma("unroll") for (int ci = 0; ci < NCOMP; ci++) _Pragma("unroll") for (int c = 0; c < COLS; c++) ring[ci][c][K] = np[ci][c]; break;
+                SWS_RING_PUT(0) SWS_RING_PUT(1) SWS_RING_PUT(2) SWS_RING_PUT(3) SWS_RING_PUT(4) SWS_RING_PUT(5) SWS_RING_PUT(6) SWS_RING_PUT(7)
+#undef SWS_RING_PUT
+                }
+            } else {
 #pragma unroll
             for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
@@ -736,6 +748,7 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
                     for (int k = 0; k < RD - 1; k++) ring[ci][c][k] = ring[ci][c][k + 1];
                     ring[ci][c][RD - 1] = np[ci][c];
                 }
+            }
             qnext++;
             // the slot's ds_reads have returned (their results are in np): pin that, release the pending row, re-request the slot
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -751,6 +764,17 @@ __device__ __forceinline__ void strip_body_dma(const FrameRegs &f, const SwsDevP
             for (int ci = 0; ci < NCOMP; ci++)
 #pragma unroll
                 for (int c = 0; c < COLS; c++) acc[ci][c] = (int)ring[ci][c][RD - 1];
+        } else
+        if constexpr (ABS) {       // pair pfy + j sits in slot (pfy + j) & 7: one straight-line rotation per value of pfy & 7
+            switch (pfy & (RD - 1)) {
+#define SWS_SVA(R) case R: \
+                _Pragma("unroll") for (int ci = 0; ci < NCOMP; ci++) _Pragma("unroll") for (int c = 0; c < COLS; c++) { \
+                    acc[ci][c] = sdot2_first_s(ring[ci][c][R], e.vt[0]); \
+                    _Pragma("unroll") for (int k = 1; k < RD; k++) acc[ci][c] = sdot2(ring[ci][c][(R + k) & (RD - 1)], e.vt[k], acc[ci][c]); } \
+                break;
+            SWS_SVA(0) SWS_SVA(1) SWS_SVA(2) SWS_SVA(3) SWS_SVA(4) SWS_SVA(5) SWS_SVA(6) SWS_SVA(7)
+#undef SWS_SVA
+            }
         } else
         if constexpr (RD > 16) {   // (the long form's chroma ring: the host lays every row's tap pairs out against the whole ring, older slots get zero taps)
             SWS_SVB(RD)
@@ -831,6 +855,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     const FrameRegs f = load_frame(fs, blockIdx.z);
     switch (g.nph) {
 #define SWS_SB(N) case N: strip_body_dma<CHROMA, COLS, N, RD>(f, p, g, strip, y0, y1, smem, wib, lane); break;
+    SWS_SB(1) SWS_SB(2) SWS_SB(3) SWS_SB(4) SWS_SB(5) SWS_SB(6) SWS_SB(7) SWS_SB(8)
+#undef SWS_SB
+    }
+}
+
+// The same body with the ring depth, the register-ring form and the occupancy as template arguments (k_strip.hip picks by `strip_dma_depth` / `strip_ring_abs`)
+template <bool CHROMA, int COLS, int D, bool ABS, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) sws_k_strip_dma_v(SwsFrameSet fs, SwsDevParams p, SwsStripGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wid = blockIdx.x * 4 + wib;
+    if (wid >= g.strips * g.bands) return;
+    const int strip = wid % g.strips, band = wid / g.strips;
+    const int H = CHROMA ? p.chrDstH : p.dstH;
+    const int y0 = band * g.band_rows, y1 = min(H, y0 + g.band_rows);
+    if (y0 >= y1) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    switch (g.nph) {
+#define SWS_SB(N) case N: strip_body_dma<CHROMA, COLS, N, 8, D, ABS>(f, p, g, strip, y0, y1, smem, wib, lane); break;
     SWS_SB(1) SWS_SB(2) SWS_SB(3) SWS_SB(4) SWS_SB(5) SWS_SB(6) SWS_SB(7) SWS_SB(8)
 #undef SWS_SB
     }

@@ -1,7 +1,7 @@
 /* Times the REAL reference's C path (a C-only, --disable-asm build of /root/reference made by tools/ref_vs_port.sh under /tmp; nothing
  * of that build is kept in the repo) on the BASELINE configurations, one thread, best of N -- the denominator of bench.py's
  * "port / reference" ratios.  Uses only the public API (libswscale/swscale.h:424-457, 522-548).
- *   usage: ref_time <name> <srcW> <srcH> <srcFmtName> <dstW> <dstH> <dstFmtName> <flags> <bt2020 0|1> <reps>            */
+ *   usage: ref_time <name> <srcW> <srcH> <srcFmtName> <dstW> <dstH> <dstFmtName> <flags> <bt2020 0|1> <reps> [source planes file] */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -27,6 +27,16 @@ int main(int argc, char **argv)
         if (d->flags & AV_PIX_FMT_FLAG_FLOAT) { float *f = (float *)src[p]; for (long i = 0; i < (long)sls[p] * rows / 4; i++) { s = s * 1664525u + 1013904223u; f[i] = (s >> 8) / 16777216.0f * 1.5f - 0.25f; } }
         else if (d->comp[0].depth > 8) { uint16_t *w = (uint16_t *)src[p]; for (long i = 0; i < (long)sls[p] * rows / 2; i++) { s = s * 1664525u + 1013904223u; w[i] = (s >> 16) & ((1 << d->comp[0].depth) - 1); } }
         else for (long i = 0; i < (long)sls[p] * rows; i++) { s = s * 1664525u + 1013904223u; src[p][i] = s >> 24; }
+    }
+    if (argc > 11) {   /* the SAME picture the port is timed on: planes as tools/ref/ref_vs_port.py wrote them (visible bytes of each row, top to bottom) */
+        FILE *f = fopen(argv[11], "rb");
+        if (!f) return 5;
+        int ls[4]; av_image_fill_linesizes(ls, sf, sw);
+        for (int p = 0; p < 4 && src[p]; p++) {
+            int rows = (p == 1 || p == 2) ? AV_CEIL_RSHIFT(sh, d->log2_chroma_h) : sh;
+            for (int y = 0; y < rows; y++) if (fread(src[p] + (long)y * sls[p], 1, ls[p], f) != (size_t)ls[p]) return 6;
+        }
+        fclose(f);
     }
     SwsContext *c = sws_getContext(sw, sh, sf, dw, dh, df, flags, NULL, NULL, NULL);
     if (!c) return 4;

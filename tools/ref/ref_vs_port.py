@@ -23,11 +23,10 @@ CONFIGS = {  # name: srcW srcH srcFmt dstW dstH dstFmt flags bt2020 reps
 }
 
 
-def port_ms(sw, sh, sf, dw, dh, df, flags, bt2020, reps):
+def port_ms(sw, sh, sf, dw, dh, df, flags, bt2020, reps, src):
     o = OL.Oracle(sw, sh, sf, dw, dh, df, flags)
     if bt2020:
         o.set_colorspace(9, 1, 9, 1)
-    src = OL.fill_random(OL.Frame(sf, sw, sh), 77)
     dst = OL.Frame(df, dw, dh)
     o.scale(src, dst)
     best = 1e30
@@ -44,9 +43,14 @@ def main():
                       "(gcc -O3 -fno-tree-vectorize), one thread, best of N; ms per frame",
            "_cpu": open("/proc/cpuinfo").read().split("model name")[1].split(":")[1].split("\n")[0].strip()}
     for name, cfg in CONFIGS.items():
-        r = subprocess.check_output([timer, name] + [str(x) for x in cfg]).decode().split()
+        sw, sh, sf = cfg[:3]
+        src = OL.fill_random(OL.Frame(sf, sw, sh), 77)       # one picture for both sides (clipping / rounding paths are data dependent)
+        with open("/tmp/ref_vs_port_src.bin", "wb") as f:
+            for pl, rb in zip(src.planes, src.row_bytes):
+                f.write(pl[:, :rb].tobytes())
+        r = subprocess.check_output([timer, name] + [str(x) for x in cfg] + ["/tmp/ref_vs_port_src.bin"], stderr=subprocess.DEVNULL).decode().split()
         ref = float(r[1])
-        port = port_ms(*cfg)
+        port = port_ms(*cfg, src)
         out[name] = {"reference_ms": round(ref, 3), "port_ms": round(port, 3), "port_over_reference": round(port / ref, 3)}
         print(name, out[name], flush=True)
     json.dump(out, open(os.path.join(ROOT, "profiles", "ref_vs_port.json"), "w"), indent=1)
