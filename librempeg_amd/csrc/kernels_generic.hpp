@@ -290,17 +290,16 @@ __device__ __forceinline__ int range_sample(const P &p, int v, int chroma)
     return r;
 }
 
-// the parameter block with the chr_half field (half-width chroma readers: rgb24ToUV_half_c and friends) behind a constant, like KindView below
-// (a VIEW type: no data of its own -- size, alignment and member offsets are the base's, checked below -- and never constructed; the routines see the
-//  parameter block through it so that `p.chr_half` names the constant.  A cast to a type the object was not created as is outside the letter of
-//  the C++ object model; what it relies on is what the static_asserts pin: identical layout, and the shadowed member read nowhere through the view)
-template <typename P, int H> struct ChrHalfView : P { static constexpr int32_t chr_half = H; };
+// the parameter block with the chr_half field (half-width chroma readers: rgb24ToUV_half_c and friends) behind a constant, like KindView below: a COPY of the
+// block in a derived type whose static member of the same name hides the field, so `p.chr_half` names the constant in the routines that see the copy.  (The copy is
+// a real object of its type -- rounds 4 / 5 cast the kernel argument to a type it was not created as -- and costs nothing: the block is a read-only kernel argument,
+// the compiler forwards every field read to it; tools/kregs.sh and the ISA comparison of round 6 show identical code.)
+template <typename P, int H> struct ChrHalfView : P {
+    static constexpr int32_t chr_half = H;
+    __device__ __forceinline__ explicit ChrHalfView(const P &b) : P(b) {}
+};
 template <int H, typename P>
-__device__ __forceinline__ const ChrHalfView<P, H> &chr_half_view(const P &p)
-{
-    static_assert(sizeof(ChrHalfView<P, H>) == sizeof(P) && alignof(ChrHalfView<P, H>) == alignof(P), "ChrHalfView adds no data to the parameter block");
-    return reinterpret_cast<const ChrHalfView<P, H> &>(p);
-}
+__device__ __forceinline__ ChrHalfView<P, H> chr_half_view(const P &p) { return ChrHalfView<P, H>(p); }
 
 // sum of fs taps of one output sample of component COMP.  Four taps at a time, their loads issued together: a thread that waits for every sample
 // before it asks for the next one spends the pass on memory latency (4K bgra -> 1080p, 8 taps: 0.49 ms per frame for 66 M samples in the rolled
@@ -416,18 +415,17 @@ struct DirectSampler { // horizontal filters are 1-tap identity: compute the sam
 // form of the single-pass kernels carries every reader at every tap of every writer: 24 000 instructions, 256 + 256 registers and spills, one wave
 // per SIMD with every load of a tap waiting for the one before.)  The routines take the parameter block as a template type; the views below hide the
 // kind fields behind constants of the same names, so `p.srcKind == SRCK_...` is decided by the compiler and everything else reads the kernel argument.
-template <int SK, int DK> struct KindView : SwsDevParams { static constexpr int32_t srcKind = SK, dstKind = DK; };
-template <int SK> struct SrcKindView : SwsDevParams { static constexpr int32_t srcKind = SK; };
-template <int DK> struct DstKindView : SwsDevParams { static constexpr int32_t dstKind = DK; };
+template <int SK, int DK> struct KindView : SwsDevParams { static constexpr int32_t srcKind = SK, dstKind = DK; __device__ __forceinline__ explicit KindView(const SwsDevParams &b) : SwsDevParams(b) {} };
+template <int SK> struct SrcKindView : SwsDevParams { static constexpr int32_t srcKind = SK; __device__ __forceinline__ explicit SrcKindView(const SwsDevParams &b) : SwsDevParams(b) {} };
+template <int DK> struct DstKindView : SwsDevParams { static constexpr int32_t dstKind = DK; __device__ __forceinline__ explicit DstKindView(const SwsDevParams &b) : SwsDevParams(b) {} };
 static_assert(std::is_standard_layout<SwsDevParams>::value && std::is_trivially_copyable<SwsDevParams>::value, "the parameter block is plain data");
-static_assert(sizeof(KindView<0, 0>) == sizeof(SwsDevParams) && sizeof(SrcKindView<0>) == sizeof(SwsDevParams) && sizeof(DstKindView<0>) == sizeof(SwsDevParams) &&
-              alignof(KindView<0, 0>) == alignof(SwsDevParams), "the kind views add no data to the parameter block (see ChrHalfView)");
+// (a copy of the kernel argument in the view type, see ChrHalfView; SK = DK = -1: the argument itself)
 template <int SK, int DK>
 __device__ __forceinline__ decltype(auto) kind_view(const SwsDevParams &p)
 {
-    if constexpr (SK >= 0 && DK >= 0) return reinterpret_cast<const KindView<SK, DK> &>(p);
-    else if constexpr (SK >= 0) return reinterpret_cast<const SrcKindView<SK> &>(p);
-    else if constexpr (DK >= 0) return reinterpret_cast<const DstKindView<DK> &>(p);
+    if constexpr (SK >= 0 && DK >= 0) return KindView<SK, DK>(p);
+    else if constexpr (SK >= 0) return SrcKindView<SK>(p);
+    else if constexpr (DK >= 0) return DstKindView<DK>(p);
     else return (p);
 }
 
