@@ -16,7 +16,7 @@ Rank 0 prints ONE JSON line.
 
 `python bench.py --gpus N --inproc` (no launcher) measures the OTHER multi-GPU form: ONE process, ONE context, ONE
 sws_scale_frames() call per step over frames that live on N GPUs -- the library shards them itself (a frame is converted on the
-GPU that holds it; device.hip: dev_run), each GPU gets its own copy of the tables at first use, launches go out on every GPU's
+GPU that holds it; dev_exec.hip: dev_run), each GPU gets its own copy of the tables at first use, launches go out on every GPU's
 stream before anything is waited for.
 """
 import argparse

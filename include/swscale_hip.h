@@ -409,8 +409,8 @@ int    sws_hip_set_timing(SwsContext *c, int enable); /* record hipEvents around
 /* launch heuristics ("strip_min_w", "rgb_march_waves", "max_devices", "no_strip", ...): every setting gives the same bytes */
 int    sws_hip_set_option(SwsContext *c, const char *name, int value);
 /* plans the context now (sws_scale() does it on first use) and digests the plan: digest[0] over the table blocks the planner built, digest[1] over the kernel
- * parameters.  With the option "dry_plan" set before, no GPU is touched (the context can name its path -- sws_hip_path_name -- but not convert). */
-int    sws_hip_plan(SwsContext *c, uint64_t digest[2]);
+ * parameters, digest[2] over the host-side launch state (which kernels, on what strip / tile geometry).  With the option "dry_plan" set before, no GPU is touched (the context can name its path -- sws_hip_path_name -- but not convert). */
+int    sws_hip_plan(SwsContext *c, uint64_t digest[3]);
 /* debugging aid: reads every device table block of the context back and compares it with what was uploaded (and the host-side kernel parameters with
  * what context preparation left); returns the number of anomalies (0 = intact, < 0 = HIP error), a short text per anomaly goes to buf */
 int    sws_hip_debug_check(SwsContext *c, char *buf, int cap);

@@ -349,7 +349,7 @@ int init_single_context(SwsInternal *c)
     if (isAnyRGB(dstFormat) && !(flags & SWS_FULL_CHR_H_INT)) c->chrDstHSubSample = 1;         // :1359-1360
 
     // "drop some chroma lines if the user wants it" (:1362-1365): the scaler sees a chroma plane of every 2^vChrDrop-th row
-    // (device.hip multiplies the chroma strides, like ff_swscale does at swscale.c:333-334)
+    // (dev_exec.hip multiplies the chroma strides, like ff_swscale does at swscale.c:333-334)
     c->chrSrcVSubSample += (flags & SWS_SRC_V_CHR_DROP_MASK) >> SWS_SRC_V_CHR_DROP_SHIFT;
     // RGB sources: chroma is taken from horizontally averaged pixel pairs unless full chroma input
     // is requested (:1369-1390; planar float/high-depth RGB are exempt)
@@ -569,7 +569,7 @@ int init_single_context(SwsInternal *c)
         // error line (c->dither_error, utils.c:1744-1747) lives as long as the context.  The sums that enter the diffusion are R >> 22,
         // G >> 22, B >> 22, which is the rgb24 full-chroma writer's output: an inner context produces that picture with this context's
         // geometry, filters and colour tables (the scaler chain always: the reference has no special converter for these destinations),
-        // and a wavefront pass diffuses it into the destination (device.hip, sws_k_ed_rgb8).
+        // and a wavefront pass diffuses it into the destination (dev_exec.hip, sws_k_ed_rgb8).
         SwsInternal *in = new_context();
         if (!in) return SWS_AVERROR(ENOMEM);
         in->opts = *o;

@@ -205,7 +205,7 @@ struct SwsDevParams {
     int32_t s422_y, s422_u, s422_v, d422_y, d422_u, d422_v;   // packed 4:2:2: byte offsets of Y0, U, V inside a 4-byte pixel pair
     int32_t s16_maskr, s16_maskg, s16_maskb, s16_rsh, s16_gsh, s16_bsh, s16_S, s16_is565;   // SRCK_RGB16 reader rows (input.c:396-401)
     int32_t src_alpha_opaque;   // rgb0-style source feeding a real alpha channel: its X byte counts as 255 (swscale.c:1106-1124)
-    // "virtual source lines" of the two-pass path (device.hip build_vlines): row r of pass 1 is picture line vlines[2r] read with the
+    // "virtual source lines" of the two-pass path (dev_plan*.hip build_vlines): row r of pass 1 is picture line vlines[2r] read with the
     // side term vlines[2r + 1]; luma / alpha rows first (srcH of them), chroma rows from entry nVL on.  vline_mode 1: the side term is the
     // number of gamma table passes the line has seen (gamma_tab, gamma.c:31-58); 2: the plane-0 row of a planar RGB chroma line
     // (hscale.c:211-225).  Null for every context whose result does not depend on the reference's line schedule.

@@ -1,4 +1,4 @@
-// Host-side device state of a context and the interface between the launch planner (device.hip) and the translation units
+// Host-side device state of a context and the interface between the launch planner (dev_plan*.hip) and the translation units
 // that hold the kernels (k_*.hip).  One DeviceState per (context, GPU): tables, plans, scratch and the stream live on that GPU.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -14,7 +14,7 @@ namespace swship {
 
 // Frame tables (SwsFramePtrs arrays: fs.table of a batched launch) live in ONE pinned host block and ONE device block per DeviceState, used as a
 // ring: every upload takes the next span, a span is recycled only when the launch sets that read it have passed an event recorded behind them,
-// so neither a call with new frame pointers nor the sub-batches of one call ever wait for the stream (table_upload / table_batch_end, device.hip).
+// so neither a call with new frame pointers nor the sub-batches of one call ever wait for the stream (table_upload / table_batch_end, dev_state.hip).
 struct TableRing {
     SwsFramePtrs *dev = nullptr, *host = nullptr;
     int cap = 0, head = 0;
@@ -134,7 +134,7 @@ static inline bool frames_desc_ok(const SwsFramePtrs *fr, int n, int srcH, int d
     return true;
 }
 
-// The context-level half of sws_k_mixed_join422's shape test: ONE predicate for the planner's path name (device.hip) and the launcher (k_stream.hip), which adds
+// The context-level half of sws_k_mixed_join422's shape test: ONE predicate for the planner's path name (dev_plan*.hip) and the launcher (k_stream.hip), which adds
 // the per-call alignment test of the frames -- a context whose frames are not 16-byte aligned still runs the three passes under the fused kernel's name
 static inline bool mixed_join422_shape(const SwsInternal *c, const DeviceState *d, const SwsDevParams &p)
 {
@@ -186,7 +186,7 @@ int  launch_tile(const LaunchCtx &L);
 // ---- k_generic.hip: two-pass / direct element-per-thread path ----
 int  launch_generic(const LaunchCtx &L);
 
-// device.hip
+// dev_state.hip
 int grow(SwsInternal *c, void **buf, size_t *cap, size_t need);
 // a device copy of v[0 .. n) for launches on `st` (nullptr: a HIP error, logged); `slot` names the table's role for the identical-table cache
 const SwsFramePtrs *table_upload(SwsInternal *c, DeviceState *d, hipStream_t st, int slot, const SwsFramePtrs *v, int n);

@@ -93,7 +93,7 @@ int launch_layout(const LaunchCtx &L)
     return 1;
 }
 
-// The de-interleaving pass ahead of the kernels for a packed 4:2:2 SOURCE of the scaler (device.hip; L.fs holds {src = the packed picture, dst = the
+// The de-interleaving pass ahead of the kernels for a packed 4:2:2 SOURCE of the scaler (dev_exec.hip; L.fs holds {src = the packed picture, dst = the
 // planes of the working picture}): yuyvtoyuv422_c / uyvytoyuv422_c over the whole source picture.
 void launch_layout_split422(const LaunchCtx &L, bool uyvy, bool vfirst)
 {
@@ -109,7 +109,7 @@ void launch_layout_split422(const LaunchCtx &L, bool uyvy, bool vfirst)
     hipLaunchKernelGGL((sws_k_layout_stream<4>), dim3(cdiv(cdiv(j.n, 16), 256), cdiv(j.rows, LAYOUT_RPW), L.n), dim3(256), 0, L.st, L.fs, p, plan);
 }
 
-// The chroma plane of a semi-planar 8-bit source of the scaler, split into planar working planes (device.hip; L.fs holds {src[1] = the interleaved
+// The chroma plane of a semi-planar 8-bit source of the scaler, split into planar working planes (dev_exec.hip; L.fs holds {src[1] = the interleaved
 // plane, dst[1] / dst[2] = the U / V planes}): nvXXtoUV_c over the whole plane (vfirst: nv21 / nv42).
 void launch_layout_splitnv(const LaunchCtx &L, bool vfirst)
 {
@@ -126,7 +126,7 @@ void launch_layout_splitnv(const LaunchCtx &L, bool vfirst)
 }
 
 // A p010 / p012 / p210 / p410-style source of the scaler (16-bit words, samples in the high bits, chroma interleaved) as a planar working picture
-// with the samples in the low bits (device.hip; L.fs holds {src[0] / src[1] = the two planes, dst[0..2] = Y / U / V planes}): p010LEToY_c /
+// with the samples in the low bits (dev_exec.hip; L.fs holds {src[0] / src[1] = the two planes, dst[0..2] = Y / U / V planes}): p010LEToY_c /
 // p010LEToUV_c (input.c:950-1008) are `word >> shift` and a de-interleave.
 void launch_layout_splitp01x(const LaunchCtx &L, int shift)
 {
@@ -144,7 +144,7 @@ void launch_layout_splitp01x(const LaunchCtx &L, int shift)
     hipLaunchKernelGGL((sws_k_layout_stream<4>), dim3(cdiv(chunks, 256), groups, L.n), dim3(256), 0, L.st, L.fs, p, plan);
 }
 
-// The interleaving pass behind a packed 4:2:2 destination of the scaler (device.hip: the planar writers filled a yuv422p working picture per
+// The interleaving pass behind a packed 4:2:2 destination of the scaler (dev_exec.hip: the planar writers filled a yuv422p working picture per
 // frame; L.fs holds {src = its planes, dst = the packed picture}): yuvPlanartoyuy2_c / yuvPlanartouyvy_c with one chroma row per luma row.
 void launch_layout_join422(const LaunchCtx &L, bool uyvy)
 {

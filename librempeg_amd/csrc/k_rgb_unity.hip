@@ -22,7 +22,7 @@ int launch_rgb_unity(const LaunchCtx &L)
     SwsInternal *c = L.c; DeviceState *d = L.d; const SwsDevParams &p = *L.p;
     const bool nv = p.srcKind == SRCK_NV12, b4 = p.dstKind == DSTK_RGB32;
     const bool wave_ok = L.vec && !c->tune.no_wave && d->all_x_mode && d->chr_window2 <= 8 && p.vChrFs <= 64;
-    // (rgb_march_ok covers rows of yuv2rgb_1's chroma blend as well: the X arithmetic, device.hip)
+    // (rgb_march_ok covers rows of yuv2rgb_1's chroma blend as well: the X arithmetic, dev_plan*.hip)
     const bool march_ok = L.vec && !c->tune.no_wave && d->rgb_march_ok && d->chr_window2 <= 8 && p.vChrFs <= 64;
     if (march_ok && !c->tune.no_march && frames_desc_ok(L.frames, L.n, p.srcH, p.dstH))
         return b4 ? (nv ? launch_rgbu_march_b4nv1(L) : launch_rgbu_march_b4nv0(L)) : (nv ? launch_rgbu_march_b3nv1(L) : launch_rgbu_march_b3nv0(L));

@@ -125,7 +125,7 @@ int launch_mixed_join422(const LaunchCtx &L, bool uyvy)
 }
 
 // a gray source into 24 / 32 bpp RGB through the full-chroma epilogue: its chroma sums are constants of the row, which sws_k_fullchr_rgb<.., 3> computes itself
-// (device.hip skips the sws_k_gray_chroma launch on the same predicate)
+// (dev_exec.hip skips the sws_k_gray_chroma launch on the same predicate)
 bool fullchr_gray_const(const LaunchCtx &L)
 {
     const SwsDevParams &p = *L.p;
@@ -190,7 +190,7 @@ void launch_gray_chroma(const LaunchCtx &L)
     hipLaunchKernelGGL(swsk::sws_k_gray_chroma, dim3(cdiv(p.chrDstW, 256), p.chrDstH, L.n), dim3(256), 0, L.st, L.fs, p);
 }
 
-// plane copies between unaligned pictures and their aligned working copies (device.hip launch_plan_le; L.fs holds {src[k] -> dst[k]})
+// plane copies between unaligned pictures and their aligned working copies (dev_exec.hip launch_plan_le; L.fs holds {src[k] -> dst[k]})
 void launch_stage_planes(const LaunchCtx &L, const int row_bytes[4], const int rows[4], bool in)
 {
     swsk::StageExtents e;
@@ -202,7 +202,7 @@ void launch_stage_planes(const LaunchCtx &L, const int row_bytes[4], const int r
     else hipLaunchKernelGGL((swsk::sws_k_stage_planes<false>), grid, blk, 0, L.st, L.fs, e);
 }
 
-// the alpha bytes behind sws_k_strip_rgb (device.hip: alpha_launch == 2; L.fs holds {src[0] = the int32 sums of the A plane, dst[0] = the packed picture})
+// the alpha bytes behind sws_k_strip_rgb (dev_exec.hip: alpha_launch == 2; L.fs holds {src[0] = the int32 sums of the A plane, dst[0] = the packed picture})
 void launch_alpha_merge32(const LaunchCtx &L)
 {
     const SwsDevParams &p = *L.p;

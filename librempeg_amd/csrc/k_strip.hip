@@ -140,7 +140,7 @@ int launch_rgbread_strip(const LaunchCtx &L)
     if (L.vec && launch_strip_rgbsrc(L)) return 0;      // half-width-chroma YUV destinations: one launch, no working picture (k_striprgbsrc.hip)
     auto a256 = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
     const int strideY = (int)a256(2 * (int64_t)p.srcW), strideC = (int)a256(2 * (int64_t)p.chrSrcW);
-    const bool alpha = (d->fullchr_on == 2 || d->alpha_launch) && p.srcKind == SRCK_RGB32;     // (a scaled alpha plane behind the strip kernels: device.hip)
+    const bool alpha = (d->fullchr_on == 2 || d->alpha_launch) && p.srcKind == SRCK_RGB32;     // (a scaled alpha plane behind the strip kernels: dev_plan*.hip)
     const int64_t offU = (int64_t)strideY * p.srcH, offV = offU + (int64_t)strideC * p.srcH, offA = a256(offV + (int64_t)strideC * p.srcH);
     const int64_t frame_bytes = a256(offA + (alpha ? (int64_t)strideY * p.srcH : 0));
     d->rgbread_frame_bytes = frame_bytes; d->rgbread_offA = alpha ? offA : -1; d->rgbread_strideY = strideY;

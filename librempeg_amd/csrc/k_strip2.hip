@@ -6,7 +6,7 @@
 //     step of C1 at RD = 8), and the ring's registers decide how many waves fit a SIMD;
 //   * PARTS = 1: one chunk per lane and staged row -- the general luma form issues the loads, the byte -> u16 expansion (8 v_perm) and the two
 //     ds_write_b128 of a second chunk per row whether or not any lane has one (straight-line code);
-//   * strips of 64 * COLS columns with COLS chosen per picture width (device.hip): 640 columns are 2 strips of 320 (COLS = 5) instead of 3
+//   * strips of 64 * COLS columns with COLS chosen per picture width (dev_plan*.hip): 640 columns are 2 strips of 320 (COLS = 5) instead of 3
 //     strips of 256 with the last one half empty;
 //   * one kernel per horizontal tap-pair count, so that each gets its own register allocation (the general form's switch over 1 .. 8 pairs
 //     allocates for 8): 5 to 8 waves per SIMD instead of 4.  With one source-row pair in flight per wave the march is bound by memory latency

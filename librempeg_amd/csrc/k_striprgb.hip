@@ -52,7 +52,7 @@ int SRGB_CAT(launch_striprgb_b, SRGB_BPP, SRGB_RL)(const LaunchCtx &L)
     const int spc = s16 ? 8 : 16;
     const int wave_dw = 2 * ((gl.NCmax + spc) >> 1) + 4 * ((gc.NCmax + spc) >> 1) + 32 * cl;   // luma rows, chroma rows, exchange row
     const dim3 grid(cdiv((int64_t)gl.strips * gl.bands, 4), 1, n), blk(256);
-    const int rc = gc.npv <= 1 ? 1 : gc.npv <= 3 ? 3 : 8;     // chroma ring depth of the instantiation (device.hip laid the taps out for it)
+    const int rc = gc.npv <= 1 ? 1 : gc.npv <= 3 ? 3 : 8;     // chroma ring depth of the instantiation (dev_plan*.hip laid the taps out for it)
     // LDS-DMA form (sws_k_strip_rgb8): byte rows in rings of 4 row pairs per plane class, on 16-byte aligned frames
     if (!s16 && cl == 4 && gl.dma8_ok && gc.dma8_ok && gl.hT8 && gc.hT8 && L.vec && !c->tune.no_strip_dma8) {
         const int wave8 = SWS_RGB8_DEPTH * 2 * ((gl.NCmax + 16) >> 2) + (direct == 1 ? SWS_RGB8_DEPTH * 2 * ((2 * gc.NCmax + 16) >> 2) : SWS_RGB8_DEPTH * 4 * ((gc.NCmax + 16) >> 2)) + 32 * cl;

@@ -42,7 +42,7 @@ int launch_strip_rgbsrc(const LaunchCtx &L)
     SwsInternal *c = L.c; DeviceState *d = L.d; const SwsDevParams &p = *L.p; hipStream_t st = L.st; const SwsFrameSet &fs = L.fs;
     const int n = L.n;
     if (!d->striprgbsrc_ok || c->tune.no_strip_rgbsrc) return 0;
-    SwsStripGeom gl = d->stripL2, gc = d->stripC2;       // (the kernel's own plans: device.hip)
+    SwsStripGeom gl = d->stripL2, gc = d->stripC2;       // (the kernel's own plans: dev_plan*.hip)
     const int nph_need = std::max(gl.nph, gc.nph);
     const int nph = nph_need <= 3 ? 3 : nph_need <= 4 ? 4 : nph_need <= 5 ? 5 : nph_need <= 6 ? 6 : 8;
     const bool l8 = gl.npv > 5;

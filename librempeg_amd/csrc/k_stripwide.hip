@@ -28,7 +28,7 @@ int launch_strip_wide_s8(const LaunchCtx &L, int which)
     const bool s16 = p.srcKind == SRCK_PLANAR16 || p.srcKind == SRCK_P010;
     auto launch = [&](SwsStripGeom g, int H, bool chroma) -> int {
         const int cols = g.TW / 64, rd = g.npv <= 2 ? 2 : g.npv <= 4 ? 4 : 8;
-        // strips of 64 * cols columns (device.hip picks the widest whose window fits one chunk per lane and whose rings fit the registers: two int32 rows per pair)
+        // strips of 64 * cols columns (dev_plan*.hip picks the widest whose window fits one chunk per lane and whose rings fit the registers: two int32 rows per pair)
         const bool cols_ok = chroma ? (cols == 1 || cols == 2) : cols == 2;
         if (!cols_ok || g.nph > 8 || g.npv > 8 || g.NCmax / (s16 ? 8 : 16) > 64) {
             log_msg(c, 0, "internal error: strip plan of %d columns per lane, %d x %d tap pairs, windows of %d samples for the 19-bit strip kernel\n", cols, g.nph, g.npv, g.NCmax);

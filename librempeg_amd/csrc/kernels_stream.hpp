@@ -160,7 +160,7 @@ __device__ __forceinline__ void fullchr_fetch4(const uint8_t *plane, int64_t str
 __device__ __forceinline__ unsigned fullchr_row_rnd(const SwsDevParams &p, int y)
 {
     const int lfs = U(p.vLumFs), cfs = U(p.vChrFs);
-    if (cfs != 2 || lfs > 2) return 1u << 9;      // (the planner keeps such rows away from this kernel when the option no_short_forms is set: device.hip)
+    if (cfs != 2 || lfs > 2) return 1u << 9;      // (the planner keeps such rows away from this kernel when the option no_short_forms is set: dev_plan*.hip)
     const int16_t *cf = p.vChrF + 2 * (int64_t)y;
     const unsigned c0 = (uint16_t)cf[0], c1 = (uint16_t)cf[1];
     if (c0 + c1 != 4096u || c1 > 4096u) return 1u << 9;
@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(256) sws_k_gray_chroma(SwsFrameSet fs, SwsDevP
     const int kind = U(p.dstKind), fsz = U(p.vChrFs), bits = U(p.dst_bits), osh = U(p.dst_shift);
     const bool semi = kind == DSTK_NV12 || kind == DSTK_P010 || kind == DSTK_P016;
     const bool rawk = kind == DSTK_RAW32;     // (a gray source into 24 / 32 bpp RGB through the LUT epilogue: the chroma SUMS, int32, for sws_k_lut_rgb; the packed writers' one-tap form
-                                              //  -- both banks one tap -- is the X arithmetic with the tap 4096 like the planar one, device.hip raw_one_one)
+                                              //  -- both banks one tap -- is the X arithmetic with the tap 4096 like the planar one, dev_plan*.hip raw_one_one)
     int tsum = 0;
     if (fsz == 1 && !semi && (!rawk || U(p.vLumFs) == 1)) tsum = 4096;
     else for (int j = 0; j < fsz; j++) tsum += p.vChrF[(int64_t)cy * fsz + j];

@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 // Long filters (ratios of 4:1 and more: the lower rungs of an ABR ladder, thumbnails -- bicubic at 4:1 has 17 taps, at 6:1 25): the same march with
 // up to 16 horizontal tap pairs and a ring of 16 row pairs (24 for the chroma planes: a packed RGB source into a 4:2:0 picture doubles the vertical
 // chroma ratio), on narrower strips (luma 128, chroma 64 columns: the taps and the ring live in registers per column).  The host pads the horizontal
-// tap rows to 10 / 12 / 14 / 16 pairs and lays the vertical taps of the chroma planes out against the whole ring (device.hip).
+// tap rows to 10 / 12 / 14 / 16 pairs and lays the vertical taps of the chroma planes out against the whole ring (dev_plan*.hip).
 template <bool SRC16, bool CHROMA>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) sws_k_strip_long(SwsFrameSet fs, SwsDevParams p, SwsStripGeom g)
 {

@@ -15,7 +15,7 @@
 // The waits are written by hand as in strip_body_dma: `s_waitcnt vmcnt((D - 1) * P)` before pair q is read (P = DMA instructions per pair;
 // loads return in order among themselves), `lgkmcnt(0)` before a slot is re-requested, `vmcnt(0)` before the wave ends.
 // The host selects the form for planar 8-bit sources (not semi-planar: their chroma bytes are interleaved) whose plan skips no source row pair
-// inside a band (device.hip plan3_alt: dma8_ok), on 16-byte aligned frames.
+// inside a band (dev_plan*.hip plan3_alt: dma8_ok), on 16-byte aligned frames.
 #pragma once
 #include "kernels_strip.hpp"
 
@@ -24,7 +24,7 @@ namespace swsk {
 #ifndef STRIP_DMA8_DEPTH_C
 #define STRIP_DMA8_DEPTH_C 2
 #endif
-constexpr int strip_dma8_depth_c = STRIP_DMA8_DEPTH_C;     // (device.hip sizes the chroma launch's LDS with it)
+constexpr int strip_dma8_depth_c = STRIP_DMA8_DEPTH_C;     // (dev_plan*.hip sizes the chroma launch's LDS with it)
 
 // NV: the chroma planes of a semi-planar source (nv12 / nv21 / nv16 / nv24: nvXXtoUV_c, input.c:926-948) -- ONE plane of interleaved {U, V} byte pairs.
 // Its rows land in LDS as they are (one request per row instead of two planes' worth); sample j of component ci is byte 2 j + ci, so pair k of a

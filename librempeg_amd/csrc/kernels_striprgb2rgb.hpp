@@ -196,7 +196,7 @@ __device__ __forceinline__ void strip_rgb2rgb_body(const FrameRegs &f, const Sws
     const int npv = gl.npv;                                      // (== gc.npv, and every row's first pair is the same for both: host check)
     StripRowN<RD> el = load_strip_row_n<RD>(rowsL, y0), ec = load_strip_row_n<RD>(rowsC, y0);
     // (the writers' rounding constant of a row: 1 << 9 minus what the host wrote for the rows of yuv2rgb_full_2_c_template / the chroma blend of yuv2rgb_full_1_c_template,
-    //  which have none -- SwsStripRow::rnd_off, device.hip; round 5)
+    //  which have none -- SwsStripRow::rnd_off, dev_plan*.hip; round 5)
     auto row_rnd = [&](int yy) -> unsigned {
         typedef const uint32_t __attribute__((address_space(4))) *cptr;
         cptr q = (cptr)(uintptr_t)(rowsL + (RD > 24 ? 4 : RD > 12 ? 2 : 1) * yy);

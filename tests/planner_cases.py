@@ -54,10 +54,10 @@ def plan_line(L, key, sw, sh, sf, dw, dh, df, flags):
     try:
         if ctx.set_option("dry_plan", 1) != 0:
             return f"{key} no-dry-plan"
-        dg = (C.c_uint64 * 2)()
+        dg = (C.c_uint64 * 3)()
         r = L.sws_hip_plan(ctx.c, dg)
         if r < 0:
             return f"{key} plan-error {r}"
-        return f"{key} {ctx.path()} {ctx.kernel_name() or '-'} {dg[0]:016x} {dg[1]:016x}"
+        return f"{key} {ctx.path()} {ctx.kernel_name() or '-'} {dg[0]:016x} {dg[1]:016x} {dg[2]:016x}"
     finally:
         ctx.close()

@@ -1,4 +1,4 @@
-"""-m gpu parity for packed 4:2:2 destinations through the scaler (device.hip: planar writers + the streaming interleave, "+join422"):
+"""-m gpu parity for packed 4:2:2 destinations through the scaler (dev_exec.hip: planar writers + the streaming interleave, "+join422"):
 yuv2422_X_c_template / yuv2422_1 with one chroma tap (output.c:843-1000) against yuv2planeX_8_c / yuv2plane1_8_c (:438-493) on 8-bit sources;
 the short vertical forms (vscale.c:136-158) keep the packed writer of the generic kernels."""
 import numpy as np

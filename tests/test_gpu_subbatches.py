@@ -1,4 +1,4 @@
-"""-m gpu: sws_scale_frames() batches whose per-frame working pictures exceed the helper passes' budget (Tuning::work_mb, device.hip
+"""-m gpu: sws_scale_frames() batches whose per-frame working pictures exceed the helper passes' budget (Tuning::work_mb, dev_exec.hip
 launch_plan_le) are cut into sub-batches that reuse the working buffers.  With the budget forced down to 1 MiB every family of helper pass
 (reader pre-pass, 4:2:2 / semi-planar splits, 4:2:2 join, full-chroma sums, alpha launches, staging of unaligned frames) runs a 7-frame call
 as several sub-batches; results must equal the oracle frame by frame, and a second call with other frames must follow."""

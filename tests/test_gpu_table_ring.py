@@ -1,4 +1,4 @@
-"""-m gpu: the frame tables of batched launches live in a ring (TableRing, device.hip table_upload / table_batch_end): a call with new frame
+"""-m gpu: the frame tables of batched launches live in a ring (TableRing, dev_state.hip table_upload / table_batch_end): a call with new frame
 pointers takes the next span instead of waiting for the stream, spans are recycled behind an event recorded after the launch set that read them.
 Many sws_scale_frames() calls are queued back to back on DIFFERENT frame sets with no synchronisation in between -- enough of them to wrap the
 ring several times and, with larger batches, to regrow it -- and every output is compared with the oracle afterwards."""

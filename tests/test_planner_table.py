@@ -1,6 +1,6 @@
 """CPU box, no GPU: the planner's answer for 10 000 conversions against a committed table (tests/golden/planner_table.txt.xz).
 
-Every line is `key path kernel table-digest params-digest` from a dry_plan context (sws_hip_plan(): the planner runs as on a GPU, its table
+Every line is `key path kernel table-digest params-digest state-digest` from a dry_plan context (sws_hip_plan(): the planner runs as on a GPU, its table
 blocks get fixed fake addresses, uploads are hashed instead of copied).  A changed rule shows up as changed lines; an INTENDED change is
 recorded by regenerating the table (SWS_PLANNER_REGEN=1 python -m pytest tests/test_planner_table.py) and reviewing the diff it prints."""
 import ctypes as C
@@ -42,7 +42,7 @@ def test_planner_table(lines):
 
 def test_table_covers_every_path_family(lines):
     """the table is only a net if the conversions reach the planner's families: every one of these path names must occur"""
-    paths = {l.split(" ")[1] for l in lines if len(l.split(" ")) >= 5}
+    paths = {l.split(" ")[1] for l in lines if len(l.split(" ")) >= 6}
     for must in ("unscaled:yuv2rgb", "main:fused_rgb_unity", "main:strip_march", "main:strip_rgb2rgb", "main:strip_rgbsrc", "main:strip_packed422",
                  "main:plane1+strip_chroma", "main:two_pass", "main:fused_tile"):
         assert any(p == must or p.startswith(must) for p in paths), f"no conversion of tests/planner_cases.py plans as {must}: {sorted(paths)[:60]}"
