@@ -349,10 +349,12 @@ def cpu_baseline(name, seconds=6.0, others=("c1", "c2b", "c3a", "c3b", "c4", "c5
     for o in others:
         if o == name:
             continue
-        ro = cpu_leg(o, other_seconds, tl)
+        # (the 8K workloads hold 125 - 200 MB of pictures per thread: at most 32 threads, so that a many-core host is not asked for tens of GB)
+        tlo = [1, min(tl[-1], 32)] if o in ("c3a", "c3b") and tl[-1] > 1 else tl
+        ro = cpu_leg(o, other_seconds, tlo)
         configs[o] = {"workload": WORKLOADS[o][9], "value_1thread": round(ro[1][1], 2), "ms_per_frame_1thread": round(ro[1][2], 2),
-                      "value_all_threads": round(ro[tl[-1]][1], 2), "frames_timed": [ro[1][0], ro[tl[-1]][0]], "unit": "Mpixels/s"}
-        configs[o].update(anchors(o, ro[tl[-1]][1], ro[1][1]))
+                      "value_all_threads": round(ro[tlo[-1]][1], 2), "threads": tlo[-1], "frames_timed": [ro[1][0], ro[tlo[-1]][0]], "unit": "Mpixels/s"}
+        configs[o].update(anchors(o, ro[tlo[-1]][1], ro[1][1]))
     out = {"value": round(mpN, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
            "value_1thread": round(mp1, 2), "ms_per_frame_1thread": round(ms1, 2)}
     out.update(anchors(name, mpN, mp1))
@@ -378,11 +380,14 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
     ap.add_argument("--opt", action="append", default=[], help="name=value launch heuristic (sws_hip_set_option), repeatable")
+    ap.add_argument("--rccl", action="store_true", help="with --inproc: the peers' tables by ncclBroadcast from the home GPU (option rccl_tables) instead of one H2D copy per GPU")
     ap.add_argument("--inproc", action="store_true", help="N GPUs from ONE process: in-library sharding of sws_scale_frames() (no launcher)")
     args = ap.parse_args()
     for o in args.opt:
         k, v = o.split("=")
         TUNE[k] = int(v)
+    if args.rccl:
+        TUNE["rccl_tables"] = 1
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

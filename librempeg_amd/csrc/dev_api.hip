@@ -329,7 +329,7 @@ int sws_hip_set_option(SwsContext *sws, const char *name, int value)
         { "no_rgbsrc", &c->tune.no_rgbsrc }, { "no_strip", &c->tune.no_strip }, { "no_strip_dma", &c->tune.no_strip_dma }, { "no_dot2", &c->tune.no_dot2 }, { "no_tile", &c->tune.no_tile }, { "max_devices", &c->tune.max_devices },
         { "strip_min_rows", &c->tune.strip_min_rows }, { "no_strip_fuse", &c->tune.no_strip_fuse }, { "work_mb", &c->tune.work_mb }, { "no_strip_range", &c->tune.no_strip_range }, { "no_strip_wide", &c->tune.no_strip_wide }, { "no_wide_epilogue", &c->tune.no_wide_epilogue }, { "no_strip_u16", &c->tune.no_strip_u16 },
         { "no_strip_dma8", &c->tune.no_strip_dma8 }, { "strip_lds_pad_kb", &c->tune.strip_lds_pad_kb }, { "no_striprgb_direct", &c->tune.no_striprgb_direct }, { "no_rgbsrc2", &c->tune.no_rgbsrc2 }, { "no_strip_rgbsrc", &c->tune.no_strip_rgbsrc }, { "no_strip_rgb2rgb", &c->tune.no_strip_rgb2rgb },
-        { "no_strip_short", &c->tune.no_strip_short }, { "no_generic_kinds", &c->tune.no_generic_kinds }, { "no_rgbread_kinds", &c->tune.no_rgbread_kinds }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "no_fast_banks", &c->tune.no_fast_banks }, { "no_short_forms", &c->tune.no_short_forms }, { "strip_short_waves", &c->tune.strip_short_waves }, { "dry_plan", &c->tune.dry_plan }, { "exp0", &c->tune.exp[0] }, { "exp1", &c->tune.exp[1] }, { "exp2", &c->tune.exp[2] }, { "exp3", &c->tune.exp[3] }, { "exp4", &c->tune.exp[4] }, { "exp5", &c->tune.exp[5] }, { "exp6", &c->tune.exp[6] }, { "exp7", &c->tune.exp[7] },
+        { "no_strip_short", &c->tune.no_strip_short }, { "no_generic_kinds", &c->tune.no_generic_kinds }, { "no_rgbread_kinds", &c->tune.no_rgbread_kinds }, { "strip_cols_auto", &c->tune.strip_cols_auto }, { "no_fast_banks", &c->tune.no_fast_banks }, { "no_short_forms", &c->tune.no_short_forms }, { "strip_short_waves", &c->tune.strip_short_waves }, { "rccl_tables", &c->tune.rccl_tables }, { "dry_plan", &c->tune.dry_plan }, { "exp0", &c->tune.exp[0] }, { "exp1", &c->tune.exp[1] }, { "exp2", &c->tune.exp[2] }, { "exp3", &c->tune.exp[3] }, { "exp4", &c->tune.exp[4] }, { "exp5", &c->tune.exp[5] }, { "exp6", &c->tune.exp[6] }, { "exp7", &c->tune.exp[7] },
         { "debug", &c->tune.debug },
     };
     for (auto &e : tab)

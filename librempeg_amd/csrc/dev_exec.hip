@@ -737,12 +737,23 @@ int dev_run(SwsInternal *c, const uint8_t *const src[4], const int srcStride[4],
         (res ? resident : staged)[(size_t)owner[i]].push_back(i);
     }
     std::vector<DeviceState *> st(ndev, nullptr);
+    // first use on a GPU: its own copy of the tables.  The home GPU's go up by a host -> device copy; the peers' likewise, or -- option rccl_tables -- by
+    // ONE ncclBroadcast per table block from the home GPU over xGMI (dev_rccl.hip: the peers plan with their uploads held back, then the blocks are delivered)
+    const bool use_rccl = rccl_tables_wanted(c) && c->plan != PLAN_CASCADE;
+    std::vector<DeviceState *> fed;
+    if (use_rccl) { ret = dev_prepare_on(c, c->dev); if (ret < 0) return ret; }
     for (int g = 0; g < ndev; g++) {
         if (resident[g].empty() && staged[g].empty()) continue;
         st[g] = dev_state_for(c, g);
         if (!st[g]) return AVERROR_EXTERNAL_;
-        ret = dev_prepare_on(c, st[g]);     // first use on a GPU: its own copy of the tables (one H2D copy of the blob per GPU)
-        if (ret < 0) return ret;
+        const bool peer = st[g] != c->dev;
+        if (use_rccl && peer && !(st[g]->epoch == c->tables_epoch && st[g]->stream)) { st[g]->defer_uploads = true; st[g]->deferred.clear(); fed.push_back(st[g]); }
+        ret = dev_prepare_on(c, st[g]);
+        if (ret < 0) { for (DeviceState *d : fed) { d->defer_uploads = false; d->deferred.clear(); d->epoch = 0; } return ret; }
+    }
+    if (!fed.empty()) {
+        ret = rccl_deliver_tables(c, c->dev, fed);
+        if (ret < 0) { for (DeviceState *d : fed) { d->defer_uploads = false; d->deferred.clear(); d->epoch = 0; } return ret; }
     }
     for (int g = 0; g < ndev; g++) {
         if (resident[g].empty()) continue;

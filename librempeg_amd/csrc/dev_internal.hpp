@@ -20,6 +20,9 @@ int table_put(SwsInternal *c, DeviceState *d, void *dst, const void *src, size_t
 int dev_check_state(SwsInternal *c, DeviceState *d, std::string &out);
 int ptr_device(const void *p);                               // HIP device that owns a pointer, -1 for host memory
 bool is_device_ptr(const void *p);
+// ---- dev_rccl.hip ----
+bool rccl_tables_wanted(const SwsInternal *c);
+int rccl_deliver_tables(SwsInternal *c, DeviceState *home, const std::vector<DeviceState *> &peers);
 // ---- dev_plan.hip ----
 int dev_prepare_on(SwsInternal *c, DeviceState *d);
 int dev_plan_digest(SwsInternal *c, uint64_t out[3]);

@@ -172,7 +172,10 @@ int table_alloc(SwsInternal *c, DeviceState *d, void **buf, size_t *cap, size_t 
 {
     if (d->dry) {     // a fixed fake address per table member of the state: the plan (pointers into the blocks included) is the same on every run
         table_records_drop(d, *buf, *cap);
-        *buf = (void *)(uintptr_t)(0x100000000000ull + (uint64_t)((const char *)buf - (const char *)d) * 0x100000000ull);
+        void **const slots[] = { &d->d_tables, &d->d_tilegeom, &d->d_rgbplan, &d->d_dot2, &d->d_vlines };      // (by role, not by offset: a new member of DeviceState must not move the fake addresses)
+        uint64_t slot = 15;
+        for (size_t i = 0; i < sizeof(slots) / sizeof(slots[0]); i++) if (buf == slots[i]) slot = i;
+        *buf = (void *)(uintptr_t)(0x100000000000ull + slot * 0x1000000000ull);
         *cap = need;
         return 0;
     }
@@ -205,6 +208,16 @@ int table_put(SwsInternal *c, DeviceState *d, void *dst, const void *src, size_t
     if (d->dry) {
         table_records_drop(d, dst, bytes);
         d->tab_recs.push_back({ dst, bytes, fnv1a64(src, bytes) });
+        return 0;
+    }
+    if (d->defer_uploads) {     // a peer GPU of an RCCL-fed call: the block arrives by broadcast from the home GPU (dev_rccl.hip), or by this very copy if that fails
+        table_records_drop(d, dst, bytes);
+        const uint64_t h = fnv1a64(src, bytes);
+        d->tab_recs.push_back({ dst, bytes, h });
+        for (size_t i = 0; i < d->deferred.size();)      // (a block rewritten within one planning run: the last contents count)
+            if ((const uint8_t *)d->deferred[i].dst < (const uint8_t *)dst + bytes && (const uint8_t *)dst < (const uint8_t *)d->deferred[i].dst + d->deferred[i].bytes) d->deferred.erase(d->deferred.begin() + (long)i);
+            else i++;
+        d->deferred.push_back({ dst, bytes, h, std::vector<uint8_t>((const uint8_t *)src, (const uint8_t *)src + bytes) });
         return 0;
     }
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream));

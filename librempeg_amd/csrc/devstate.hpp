@@ -36,8 +36,13 @@ enum { TAB_MAIN = 0, TAB_AUX0 = 1 /* .. TAB_AUX0 + 4 */, TAB_FRAMES2 = 6 };
 // context's device tables are still what the host built (the rare events whose context stays wrong for its lifetime)
 struct TableRecord { const void *dst; size_t bytes; uint64_t hash; };
 
+// a peer GPU's table upload held back for the RCCL broadcast of dev_rccl.hip (the host copy stays for the fallback)
+struct TableDeferred { void *dst; size_t bytes; uint64_t hash; std::vector<uint8_t> data; };
+
 struct DeviceState {
     int device = 0;
+    bool defer_uploads = false;            // table_put() records instead of copying: rccl_deliver_tables() delivers
+    std::vector<TableDeferred> deferred;
     bool dry = false;          // Tuning::dry_plan: planned without a GPU (fake table addresses, nothing uploaded, never launched)
     std::vector<TableRecord> tab_recs;
     uint64_t params_hash = 0;  // hash of `params` as dev_prepare_on() left it

@@ -130,6 +130,7 @@ struct Tuning {
     int strip_short_waves = 0;     // experiments: waves per SIMD the short family is banded for (0: strip_waves scaled by the instantiation)
     int max_devices = 0;           // sws_scale_frames(): GPUs to shard over (0 = all visible)
     int work_mb = 2048;            // budget for the helper passes' per-frame working pictures: larger batches are cut into sub-batches (dev_exec.hip launch_plan_le)
+    int rccl_tables = 0;           // on: sws_scale_frames() over several GPUs uploads the tables to the home GPU only and ncclBroadcast()s them to the peers (dev_rccl.hip; also SWS_HIP_RCCL=1)
     int dry_plan = 0;              // on: the context plans WITHOUT a GPU -- no HIP call, table blocks get fixed fake addresses, uploads are hashed instead of copied; such a context
                                    //     names its path and digests its plan (sws_hip_plan) and refuses to run.  The planner test of the CPU suite (tests/test_planner_table.py)
     int exp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // "exp0" .. "exp7": free knobs for A/B measurements of a kernel variant under development (no header change per experiment)

@@ -1,12 +1,13 @@
 #!/bin/bash
-# round-5 profile set: rocprofv3 kernel stats of every bench workload + the bench lines, PMC HBM traffic, layout / common-shape / conversion
-# tables and the kernel stats of the common-shape run.  usage: tools/r05_profiles.sh  -> gpurun_out/r05p/
+# the profile set of a round (tag r05, r06 ...; one parameterised script since round 6, the per-round copies of rounds 3 - 5 are gone): rocprofv3 kernel stats of every bench workload + the bench lines, PMC HBM traffic, layout / common-shape / conversion
+# tables and the kernel stats of the common-shape run.  usage: tools/round_profiles.sh <tag>  -> gpurun_out/<tag>p/, then tools/round_collect.sh <tag> copies the summaries into profiles/<tag>_*
 set -u
-OUT=$PWD/gpurun_out/r05p; mkdir -p $OUT
+TAG=${1:?round tag, e.g. r06}
+OUT=$PWD/gpurun_out/${TAG}p; mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$PWD
-tools/profile_all.sh r05p > $OUT/bench_lines.jsonl 2>$OUT/profile_all.err
-tools/pmc_traffic.sh r05p "c2a c2b c4 c3a c3b c5 c1 d1 r1 w1 f1 u1" > $OUT/pmc_traffic.txt 2>&1
+tools/profile_all.sh ${TAG}p > $OUT/bench_lines.jsonl 2>$OUT/profile_all.err
+tools/pmc_traffic.sh ${TAG}p "c2a c2b c4 c3a c3b c5 c1 d1 e2 r1 w1 f1 u1" > $OUT/pmc_traffic.txt 2>&1
 python tools/layout_times.py > $OUT/layout.md 2>$OUT/layout.err
 python tools/common_shapes_times.py > $OUT/common.md 2>$OUT/common.err
 python tools/rgb2rgb_times.py > $OUT/rgb2rgb.md 2>$OUT/rgb2rgb.err
