@@ -153,10 +153,27 @@ int dst_kind_of(int f)
 }
 
 // upload filter banks (one blob) and fill SwsDevParams
+// Everything a planning run decides starts from what a FRESH state holds (zeros): a context that is planned again -- sws_hip_set_option() or
+// sws_setColorspaceDetails() after its first conversion -- must not keep a flag or a geometry of the plan before, which the new plan may not touch (a stage it skips)
+// while the tables that geometry points into are rewritten.  (Found in round 6 by tools/replan_hunt.py on the CPU box: 350 of 9 000 re-planned contexts kept e.g.
+// `strip_ok` under no_strip.  Buffers, streams, the table blocks and their records are not plan state and stay.)
+static void reset_plan_state(DeviceState *d)
+{
+    d->unity_h = d->unity_v = d->all_x_mode = false; d->chr_window2 = 0;
+    d->tile_ok = d->rgb_march_ok = d->dot2_ok = d->rgb444_ok = d->rgbsrc_ok = d->mixed_ok = d->strip_ok = d->stripLs_ok = d->stripCs_ok = d->striprgb_ok = d->striprgb_long = false;
+    d->rgb_groups = 0; d->rgb_ncr = 6; d->rgbsrc_rows = nullptr; d->rgbsrc2_rows = nullptr; d->rgbsrc2_npv = 0;
+    d->striprgb_direct = d->striprgb_direct_swap = d->striprgb_direct_shift = 0; d->striprgb_direct_now = false;
+    d->rgb2rgb_ok = d->rgb2rgb_now = false; d->rgb2rgb_npx = 0; d->striprgbsrc_ok = false; d->striprgbsrc_npx = 0;
+    d->rgbread_on = false; d->fullchr_on = d->fullchr_kind = d->fullchr_direct = d->alpha_launch = d->join422 = d->split_mode = d->split_shift = 0; d->vlines_on = false;
+    for (SwsTileGeom *g : { &d->tileL, &d->tileC, &d->dotL, &d->dotC }) std::memset(g, 0, sizeof(*g));
+    for (SwsStripGeom *g : { &d->stripL, &d->stripC, &d->stripLs, &d->stripCs, &d->stripRL, &d->stripRC, &d->stripL2, &d->stripC2 }) std::memset(g, 0, sizeof(*g));
+}
+
 // ---- stage 1: the parameters every path reads, and the helper passes around the scaler ----
 int plan_common(PlanBuild &B)
 {
     PLAN_HANDLES(B);
+    reset_plan_state(d);
     std::memset(&p, 0, sizeof(p));
     // SWS_FAST_BILINEAR on 8-bit lines (ff_hyscale_fast_c / ff_hcscale_fast_c, hscale_fast_bilinear.c:23-55: dst = a (128 - xalpha) + b xalpha for luma and alpha,
     // a (127 - xalpha) + b xalpha for chroma, with xalpha = the top 7 bits of the 16-bit position fraction; the columns at and behind the last source sample: 128 x that

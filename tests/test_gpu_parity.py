@@ -18,7 +18,7 @@ BX = SWS_BITEXACT
 AR = SWS_ACCURATE_RND
 
 
-def _forensics(p, out, ref, src_frame, dst_frame, hs, prefill, redo=None):
+def _forensics(p, out, ref, src_frame, dst_frame, hs, prefill, redo=None, fresh=None):
     """what a parity failure looks like (the rare unreproduced failures): per plane how many bytes differ and whether the wrong bytes are
     zeros or still the prefill; whether a second read of the same destination gives other bytes (a late writer); whether the source the GPU holds
     still equals what was uploaded; whether running the same context again gives the right answer."""
@@ -44,6 +44,26 @@ def _forensics(p, out, ref, src_frame, dst_frame, hs, prefill, redo=None):
             p.scale(src_frame, dst_frame); p.sync()
             rerun = dst_frame.download()
             info.append("rerun on the same context equals the oracle: " + str(all(np.array_equal(x[:, :r], y[:, :r]) for x, y, r in zip(rerun.planes, ref.planes, rerun.row_bytes))))
+            # context state or frame addresses?  (round 6: the record so far compared the failed context on ITS device frames with a fresh context on HOST frames --
+            # it could not tell a context whose state is wrong from a conversion that is wrong on THESE buffers, whose addresses depend on the process's history)
+            try:
+                eq = lambda fr: all(np.array_equal(x[:, :r], y[:, :r]) for x, y, r in zip(fr.planes, ref.planes, fr.row_bytes))
+                info.append(f"device addresses: src {[hex(a) for a in src_frame.ptrs()[0][:4] if a]} dst {[hex(a) for a in dst_frame.ptrs()[0][:4] if a]}")
+                s2 = DeviceFrame(src_frame.fmt, src_frame.w, src_frame.h).upload(hs)
+                d2 = DeviceFrame(dst_frame.fmt, dst_frame.w, dst_frame.h)
+                d2.buf.fill_(prefill)
+                torch.cuda.synchronize()
+                p.scale(s2, d2); p.sync()
+                info.append("the SAME context on FRESH device frames equals the oracle: " + str(eq(d2.download())))
+                if fresh is not None:
+                    p3 = fresh()
+                    dst_frame.buf.fill_(prefill)
+                    torch.cuda.synchronize()
+                    p3.scale(src_frame, dst_frame); p3.sync()
+                    info.append("a FRESH context on the SAME device frames equals the oracle: " + str(eq(dst_frame.download())))
+                    p3.close()
+            except Exception as e:
+                info.append(f"frame / context cross-check stopped: {e!r}")
         if redo is not None:     # the oracle once more, and a FRESH context on the same input: whose answer was the odd one?
             ref2, out2 = redo()
             info.append("oracle recomputed equals its first answer: " + str(all(np.array_equal(x, y) for x, y in zip(ref2.planes, ref.planes))))
@@ -103,6 +123,14 @@ def run_case(sw, sh, sfmt, dw, dh, dfmt, flags, seed=1, colorspace=None, device_
         p2.close()
         return ref2, hd2
 
+    def fresh():
+        p2 = SwsContext(sw, sh, sfmt, dw, dh, dfmt, flags, **(opts or {}))
+        for k, v in (tune or {}).items():
+            p2.set_option(k, v)
+        if colorspace:
+            p2.set_colorspace(*colorspace)
+        return p2
+
     for i, (a, b) in enumerate(zip(out.planes, ref.planes)):
         rb = out.row_bytes[i]
         if dfmt in ("monob", "monow") and (dw & 7):   # bits past the width in the last byte are outside the picture (the unscaled
@@ -114,7 +142,7 @@ def run_case(sw, sh, sfmt, dw, dh, dfmt, flags, seed=1, colorspace=None, device_
             y, x = bad[0]
             raise AssertionError(f"{sfmt}->{dfmt} {sw}x{sh}->{dw}x{dh} flags={flags:#x} path={p.path()} plane {i}: "
                                  f"{len(bad)} bytes differ, first at row {y} byte {x}: got {a[y, x]} want {b[y, x]}"
-                                 + _forensics(p, out, ref, ds if device_frames else hs, dd if device_frames else hd, hs, prefill, redo))
+                                 + _forensics(p, out, ref, ds if device_frames else hs, dd if device_frames else hd, hs, prefill, redo, fresh))
     return p.path(), o.path()
 
 
