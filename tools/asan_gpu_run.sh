@@ -1,10 +1,12 @@
 #!/bin/bash
 # The sanitizer pass of round 6 on a GPU box: the full GPU suite, then the random generators, under
-# lib_asan/libswscale_hip.so + oracle/asan/libsws_oracle.so (tools/asan_env.sh), four pytest workers on the one GPU -- the condition
-# of every rare event of DESIGN.md section 8.  usage: tools/asan_gpu_run.sh <tag> [N per generator] [seed]
+# the sanitizer builds (tools/asan_env.sh; on a GPU box with the gcc runtime: SWS_ASAN_RUNTIME=gnu, set below), four pytest workers on the one GPU -- the condition
+# of every rare event of DESIGN.md section 8.  Run tools/asan_probe.sh first (bounded: does one test file get through?).
+# usage: tools/asan_gpu_run.sh <tag> [N per generator] [seed]
 TAG=${1:-asan}; N=${2:-8000}; SEED=${3:-606}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export ASAN_LOG=$OUT/report
+export SWS_ASAN_RUNTIME=${SWS_ASAN_RUNTIME:-gnu}
 {
   echo "== suite under ASan+UBSan, -n 4"; date
   tools/asan_env.sh python -m pytest tests -m gpu -q -n 4 -p no:cacheprovider 2>&1 | tail -15
