@@ -57,3 +57,22 @@ def test_dry_plan_context_refuses_to_convert():
         a[:] = 7
     assert ctx.scale(src, dst) < 0
     ctx.close()
+
+
+def test_plan_and_debug_entry_points_without_a_gpu():
+    """sws_hip_plan() / sws_hip_debug_check() / the round-6 option names on planner-only contexts: defined answers, no HIP call"""
+    L = S.load_library()
+    L.sws_hip_plan.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    ctx = S.SwsContext(1280, 720, "yuv420p", 640, 360, "yuv420p", S.SWS_BILINEAR | S.SWS_BITEXACT)
+    for name in ("dry_plan", "rccl_tables", "exp0", "exp7"):
+        assert ctx.set_option(name, 1 if name == "dry_plan" else 0) == 0, name
+    assert ctx.set_option("no_such_option", 1) < 0
+    dg = (C.c_uint64 * 3)()
+    assert L.sws_hip_plan(ctx.c, dg) == 0 and dg[0] and dg[1] and dg[2]
+    assert ctx.path() == "main:strip_march" and ctx.kernel_name() == "sws_k_strip_dma8"      # BASELINE configs[0]
+    again = (C.c_uint64 * 3)()
+    assert L.sws_hip_plan(ctx.c, again) == 0 and list(again) == list(dg)                     # planning is idempotent
+    n, text = ctx.debug_check()
+    assert n == 0, text                                                                       # (nothing on a device to compare: no anomaly, no HIP call)
+    assert L.sws_hip_plan(None, dg) < 0
+    ctx.close()
