@@ -66,7 +66,8 @@ def test_plan_and_debug_entry_points_without_a_gpu():
     ctx = S.SwsContext(1280, 720, "yuv420p", 640, 360, "yuv420p", S.SWS_BILINEAR | S.SWS_BITEXACT)
     for name in ("dry_plan", "rccl_tables", "exp0", "exp7"):
         assert ctx.set_option(name, 1 if name == "dry_plan" else 0) == 0, name
-    assert ctx.set_option("no_such_option", 1) < 0
+    with pytest.raises(ValueError):
+        ctx.set_option("no_such_option", 1)
     dg = (C.c_uint64 * 3)()
     assert L.sws_hip_plan(ctx.c, dg) == 0 and dg[0] and dg[1] and dg[2]
     assert ctx.path() == "main:strip_march" and ctx.kernel_name() == "sws_k_strip_dma8"      # BASELINE configs[0]
