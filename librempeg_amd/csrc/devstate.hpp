@@ -183,7 +183,8 @@ int  launch_strip_wide(const LaunchCtx &L, int which);   // k_stripwide.hip: the
 void launch_gray_chroma(const LaunchCtx &L);                    // k_stream.hip: the chroma planes of a gray source in a YUV destination (or the chroma sums behind an RGB epilogue)
 bool fullchr_gray_const(const LaunchCtx &L);                    // k_stream.hip: ... or no launch: the full-chroma RGB epilogue computes the constants itself
 int  launch_mixed_join422(const LaunchCtx &L, bool uyvy);       // k_stream.hip: 1 = the mixed plan and its interleave ran as one pass
-int  launch_strip_short(const LaunchCtx &L, const SwsStripGeom &g, int H, bool chroma);   // k_strip2.hip: 1 = launched, 0 = not a shape of the short family
+int  launch_strip_short(const LaunchCtx &L, const SwsStripGeom &g, int H, bool chroma);
+int  launch_strip_short_lc(const LaunchCtx &L);   // k_strip2.hip, experiment "exp3": luma and chroma of the byte-DMA form as one grid; 1 = launched   // k_strip2.hip: 1 = launched, 0 = not a shape of the short family
 int  launch_strip_luma(const LaunchCtx &L);      // k_strip.hip: the luma launch alone (the alpha plane of a full-chroma RGB destination goes through the luma filters)
 int  launch_striprgb(const LaunchCtx &L);
 int  launch_tile_dot2(const LaunchCtx &L);

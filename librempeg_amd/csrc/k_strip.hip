@@ -60,6 +60,14 @@ int launch_strip_planes(const LaunchCtx &L, int which)
                 }
                 // experiments (sws_hip_set_option "exp0" = ring depth D in row pairs (2 / 3; 0 = the shipped 4), "exp1" = absolute register-ring slots,
                 // "exp2" = waves per SIMD the variant is compiled for): C3b's two launches only
+                if (s16 && g.dma_ok && !c->tune.no_strip_dma && c->tune.exp[2] == 7 && cols == (chroma ? 1 : 2)) {     // 128 / 64-column strips (strip_cols_l=2 strip_cols_c=1) compiled for 7 waves per SIMD
+                    const bool abs = c->tune.exp[1] != 0;
+                    if (chroma) { if (abs) hipLaunchKernelGGL((swsk::sws_k_strip_dma_v<true, 1, 4, true, 7>), grid, blk, g.lds_dma_bytes, st, fs, p, g);
+                                  else hipLaunchKernelGGL((swsk::sws_k_strip_dma_v<true, 1, 4, false, 7>), grid, blk, g.lds_dma_bytes, st, fs, p, g); }
+                    else        { if (abs) hipLaunchKernelGGL((swsk::sws_k_strip_dma_v<false, 2, 4, true, 7>), grid, blk, g.lds_dma_bytes, st, fs, p, g);
+                                  else hipLaunchKernelGGL((swsk::sws_k_strip_dma_v<false, 2, 4, false, 7>), grid, blk, g.lds_dma_bytes, st, fs, p, g); }
+                    return;
+                }
                 if (s16 && g.dma_ok && !c->tune.no_strip_dma && (c->tune.exp[0] || c->tune.exp[1]) && cols == (chroma ? 2 : 4)) {
                     const int D = c->tune.exp[0] ? c->tune.exp[0] : 4, wpe = c->tune.exp[2] ? c->tune.exp[2] : 4;
                     const bool abs = c->tune.exp[1] != 0;
@@ -110,6 +118,7 @@ int launch_strip_planes(const LaunchCtx &L, int which)
                 else hipLaunchKernelGGL((swsk::sws_k_strip_march_lc<false, 4, 2>), grid, blk, std::max(gl.lds_bytes, gc.lds_bytes), st, fs, p, gl, gc, blocksL);
                 return 0;
             }
+            if (which == 3 && launch_strip_short_lc(L)) return 0;       // (experiment "exp3": off unless asked for)
             // (8-bit sources with short filters: the short instantiations on the plan's own strip widths, k_strip2.hip)
             if ((which & 1) && !launch_strip_short(L, d->stripLs_ok ? d->stripLs : d->stripL, p.dstH, false)) launch(d->stripL, p.dstH, false);
             if ((which & 2) && !launch_strip_short(L, d->stripCs_ok ? d->stripCs : d->stripC, p.chrDstH, true)) launch(d->stripC, p.chrDstH, true);

@@ -136,4 +136,30 @@ int launch_strip_short(const LaunchCtx &L, const SwsStripGeom &g0, int H, bool c
     return 1;
 }
 
+// EXPERIMENT ("exp3", unmeasured): both plane classes of the byte-DMA form in one grid, for the shapes whose luma and chroma plans agree in ring depth -- C1
+// (640 + 320 columns: 5 columns per lane both, 2 tap pairs, ring of 3).  1 = launched, 0 = not such a shape (the caller runs the two launches).
+int launch_strip_short_lc(const LaunchCtx &L)
+{
+    SwsInternal *c = L.c; DeviceState *d = L.d; const SwsDevParams &p = *L.p;
+    if (!c->tune.exp[3] || c->tune.no_strip_short || c->tune.no_strip_dma8 || p.srcKind != SRCK_PLANAR8 || !L.vec || p.no_chroma) return 0;
+    SwsStripGeom gl = d->stripLs_ok ? d->stripLs : d->stripL, gc = d->stripCs_ok ? d->stripCs : d->stripC;
+    if (!gl.dma8_ok || !gc.dma8_ok || !gl.hT8 || !gc.hT8 || gl.NCmax / 16 > 64 || gc.NCmax / 16 > 64) return 0;
+    const int rdl = gl.npv <= 3 ? 3 : gl.npv <= 4 ? 4 : gl.npv <= 6 ? 6 : 8, rdc = gc.npv <= 3 ? 3 : gc.npv <= 4 ? 4 : gc.npv <= 6 ? 6 : 8;
+    if (rdl != 3 || rdc != 3 || gl.TW != 320 || gc.TW != 320 || gl.nph8 != 2 || gc.nph8 != 2) return 0;          // (the one instantiation built for the measurement)
+    auto fn = swsk::sws_k_strip_dma8_lc<5, 5, 2, 2, 3>;
+    const int lds = std::max(gl.lds_dma8_bytes, gc.lds_dma8_bytes);
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (const void *)fn, 256, (size_t)lds) != hipSuccess) { (void)hipGetLastError(); blocks = 4; }
+    const int wps = std::max(1, std::min(8, blocks));
+    const int target = (int)((int64_t)c->tune.strip_waves * wps / 4), minrows = std::max(1, c->tune.strip_min_rows), n = L.n;
+    const int64_t wave_rows = ((int64_t)gl.strips * p.dstH + (int64_t)gc.strips * p.chrDstH) * n;
+    const int rows = (int)std::max<int64_t>(minrows, (wave_rows + target - 1) / target);
+    gl.band_rows = gc.band_rows = rows;
+    gl.bands = cdiv(p.dstH, rows); gc.bands = cdiv(p.chrDstH, rows);
+    gl.debug = gc.debug = c->tune.debug;
+    const int blocksL = (int)cdiv((int64_t)gl.strips * gl.bands, 4), blocksC = (int)cdiv((int64_t)gc.strips * gc.bands, 4);
+    hipLaunchKernelGGL(fn, dim3(blocksL + blocksC, 1, n), dim3(256), lds, L.st, L.fs, p, gl, gc, blocksL);
+    return 1;
+}
+
 } // namespace swship

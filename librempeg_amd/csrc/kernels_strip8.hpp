@@ -336,4 +336,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     strip_body_dma8<CHROMA, COLS, NPH, RD, NV>(f, p, g, strip, y0, y1, smem, wib, lane);
 }
 
+// EXPERIMENT (round 6, unmeasured: `sws_hip_set_option("exp3", 1)`): the luma and the chroma launch of the byte-DMA form as ONE grid -- blocks [0, blocksL) walk luma
+// bands, the rest chroma bands, both bodies unchanged (the pattern of sws_k_strip_dma_lc, kernels_strip.hpp).  C1 at batch sizes pays two dependent launches and
+// their tails per call (70 + 46 us for 256 frames).
+template <int COLS_L, int COLS_C, int NPH_L, int NPH_C, int RD>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) sws_k_strip_dma8_lc(SwsFrameSet fs, SwsDevParams p, SwsStripGeom gl, SwsStripGeom gc, int blocksL)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool chroma = (int)blockIdx.x >= blocksL;
+    const SwsStripGeom &g = chroma ? gc : gl;
+    const int wid = ((int)blockIdx.x - (chroma ? blocksL : 0)) * 4 + wib;
+    if (wid >= g.strips * g.bands) return;
+    const int strip = wid % g.strips, band = wid / g.strips;
+    const int H = chroma ? p.chrDstH : p.dstH;
+    const int y0 = band * g.band_rows, y1 = min(H, y0 + g.band_rows);
+    if (y0 >= y1) return;
+    const FrameRegs f = load_frame(fs, blockIdx.z);
+    if (chroma) strip_body_dma8<true, COLS_C, NPH_C, RD, false>(f, p, gc, strip, y0, y1, smem, wib, lane);
+    else strip_body_dma8<false, COLS_L, NPH_L, RD, false>(f, p, gl, strip, y0, y1, smem, wib, lane);
+}
+
 } // namespace swsk
