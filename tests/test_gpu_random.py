@@ -381,12 +381,24 @@ def _batch_forensics(p, o, case, src_frame, dst_frame, ref, frame_seed):
         hd = HostFrame(df, dw, dh)
         p.scale(hs, hd)
         notes.append(f"the frame alone on the same context equals the oracle: {planes_equal(hd, ref)}")
+        if isinstance(src_frame, DeviceFrame) and isinstance(dst_frame, DeviceFrame):      # context state or frame addresses? (tests/test_gpu_parity.py _forensics)
+            import torch
+            notes.append(f"device addresses: src {[hex(a) for a in src_frame.ptrs()[0][:4] if a]} dst {[hex(a) for a in dst_frame.ptrs()[0][:4] if a]}")
+            dst_frame.buf.fill_(0x33)
+            torch.cuda.synchronize()
+            p.scale(src_frame, dst_frame); p.sync()
+            notes.append(f"the frame alone on the same context and the SAME device frames equals the oracle: {planes_equal(dst_frame.download(), ref)}")
         p2 = SwsContext(sw, sh, sf, dw, dh, df, flags)
         for kk, v in tune.items():
             p2.set_option(kk, v)
         hd2 = HostFrame(df, dw, dh)
         p2.scale(hs, hd2)
         notes.append(f"a fresh context equals the oracle: {planes_equal(hd2, ref)}")
+        if isinstance(src_frame, DeviceFrame) and isinstance(dst_frame, DeviceFrame):
+            dst_frame.buf.fill_(0x33)
+            torch.cuda.synchronize()
+            p2.scale(src_frame, dst_frame); p2.sync()
+            notes.append(f"a FRESH context on the SAME device frames equals the oracle: {planes_equal(dst_frame.download(), ref)}")
         p2.close()
     except Exception as e:   # (forensics must never hide the failure itself)
         notes.append(f"forensics stopped: {e!r}")
