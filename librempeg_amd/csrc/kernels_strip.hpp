@@ -549,7 +549,7 @@ __device__ __forceinline__ void strip_dma16(uint32_t lds_dst, int voff, const i3
                  "s_nop 0\n\t"
                  "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
                  "s_mov_b64 exec, %0"
-                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff), "s"(mask_lo), "s"(mask_hi) : "memory");
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff), "s"(mask_lo), "s"(mask_hi) : "memory", "m0");
 }
 
 // D: row pairs of the LDS ring (pairs in flight + 1).  ABS: row pair q lives in register-ring slot q & (RD - 1) for the whole band -- a new pair overwrites
