@@ -467,6 +467,10 @@ def main():
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
+                if pmc.get("_tool_version", 1) < 2:
+                    # passes made with the round-5 tool: it averaged the launches of a two-launch workload instead of adding them (half the traffic) -- only the
+                    # single-launch workloads' figures stand; the others are dropped until the passes are re-run (tools/pmc_traffic.sh since round 6)
+                    pmc = {k: v for k, v in pmc.items() if k.startswith("_") or k in ("c2a", "c2b", "c3a", "c4", "c5")}
                 traffic = pmc.get(main_res["name"], {}).get("hbm_bytes_per_launch")
                 traffic_source = "profiles/pmc_latest.json (" + str(pmc.get("_source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.sh")) + ")"
             except Exception:

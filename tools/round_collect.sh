@@ -19,6 +19,7 @@ import json,subprocess,sys
 TAG=sys.argv[1]
 d=json.load(open("gpurun_out/"+TAG+"p/pmc_latest.json"))      # tools/pmc_traffic.sh: per workload, all sws_k* dispatches summed per sws_scale_frames() call
 commit=subprocess.check_output(["git","rev-parse","--short","HEAD"]).decode().strip()
+d["_tool_version"]=2
 d["_source"]=f"tools/round_profiles.sh (tools/pmc_traffic.sh) on 1x MI355X, library at commit {commit}"
 json.dump(d,open("profiles/"+TAG+"_pmc_traffic.json","w"),indent=1); json.dump(d,open("profiles/pmc_latest.json","w"),indent=1)
 PY
