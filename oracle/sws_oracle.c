@@ -3141,14 +3141,16 @@ static void range_line(const OrSws *c, int32_t *d, int w, int chroma)
 typedef struct { const int32_t *rows[64]; } RowSet; /* only used for small fs; general path indexes planes */
 
 /* planar writers: one output line of width w from fs rows. rows(j) = plane + (first+j clipped)*w */
-static void write_planar_line(const OrSws *c, uint8_t *dest, int w, const int32_t *plane, int planeW, int planeH,
+/* slot of line r in a ring of mask + 1 lines (Planes below) */
+#define RING(mask, r) ((size_t)((r) & (mask)))
+static void write_planar_line(const OrSws *c, uint8_t *dest, int w, const int32_t *plane, int mask, int planeW, int planeH,
                               int first, const int16_t *filter, int fs, const uint8_t *dither, int offset,
                               int is_luma_of_p01x)
 {
     const Desc *dd = desc_get(c->o.dst_format);
     const int bits = dd->c[0].depth;
     int i, j;
-#define ROW(j) (plane + (size_t)ORMIN(first + (j), planeH - 1) * planeW)
+#define ROW(j) (plane + RING(mask, ORMIN(first + (j), planeH - 1)) * planeW)
     (void)is_luma_of_p01x;
     if (isDataInHighBits(c->o.dst_format) && bits < 16) { /* yuv2p01xl1_c / lX_c output.c:538-569; yuv2msbplane1/X_10_c_template :396-426 (same arithmetic) */
         uint16_t *d = (uint16_t *)dest;
@@ -3218,14 +3220,14 @@ static void write_planar_line(const OrSws *c, uint8_t *dest, int w, const int32_
 }
 
 /* interleaved chroma writers: yuv2nv12cX_c, yuv2p01xcX_c (output.c:495-528, 571-589) */
-static void write_nv_chroma_line(const OrSws *c, uint8_t *dest, int w, const int32_t *up, const int32_t *vp,
+static void write_nv_chroma_line(const OrSws *c, uint8_t *dest, int w, const int32_t *up, const int32_t *vp, int mask,
                                  int planeW, int planeH, int first, const int16_t *filter, int fs, const uint8_t *dither)
 {
     const Desc *dd = desc_get(c->o.dst_format);
     const int bits = dd->c[0].depth;
     int i, j;
-#define ROWU(j) (up + (size_t)ORMIN(first + (j), planeH - 1) * planeW)
-#define ROWV(j) (vp + (size_t)ORMIN(first + (j), planeH - 1) * planeW)
+#define ROWU(j) (up + RING(mask, ORMIN(first + (j), planeH - 1)) * planeW)
+#define ROWV(j) (vp + RING(mask, ORMIN(first + (j), planeH - 1)) * planeW)
     if (bits == 16) { /* yuv2nv12cX_16_c_template output.c:189-217 */
         uint16_t *d = (uint16_t *)dest;
         for (i = 0; i < w; i++) {
@@ -3394,8 +3396,11 @@ static void rgb_write_full(OrSws *c, uint8_t *dest, int i, int y, int Y, int U, 
 }
 
 typedef struct {
-    int32_t *lum, *chrU, *chrV; /* h-scaled planes: [srcH][dstW], [chrSrcH][chrDstW] */
-    int32_t *alp;               /* h-scaled alpha plane [srcH][dstW] when needAlpha (hscale.c:137, vscale.c:59-71) */
+    int32_t *lum, *chrU, *chrV; /* h-scaled lines, [ring][dstW] and [ring][chrDstW]: line r of a plane lives in slot r & mask -- like the reference's own line rings
+                                 * (slice.c), only addressed by the absolute line number; the ring is at least twice what ring_sizes() says is ever alive at once,
+                                 * so the working set of a 4K frame stays in the cache instead of streaming through 33 MB planes */
+    int32_t *alp;               /* h-scaled alpha lines when needAlpha (hscale.c:137, vscale.c:59-71), the luma ring's size */
+    int lmask, cmask;           /* ring sizes - 1 (powers of two) of the luma / alpha and the chroma lines */
 } Planes;
 
 /* packed_vscale (vscale.c:109-171) + yuv2rgb_{X,2,1}_c_template (output.c:1788-1939)
@@ -3413,10 +3418,10 @@ static void write_packed_rgb_line(OrSws *c, const Planes *P, uint8_t *dest, int 
     const int step = isRGB8class(c->o.dst_format) ? 1 : c->lut_elem == 4 || c->dstFormatBpp == 32 ? 4 : 3;
     int err[4] = { 0, 0, 0, 0 };   /* the running error of the row (yuv2rgb_full_{X,2,1}_c_template: "int err[4] = {0}") */
     int i, j;
-#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
-#define CU(j) (P->chrU + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
-#define CV(j) (P->chrV + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
-#define AL(j) (P->alp + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+#define L(j) (P->lum + RING(P->lmask, ORMIN(firstLum + (j), srcH - 1)) * lw)
+#define CU(j) (P->chrU + RING(P->cmask, ORMIN(firstChr + (j), chrSrcH - 1)) * cw)
+#define CV(j) (P->chrV + RING(P->cmask, ORMIN(firstChr + (j), chrSrcH - 1)) * cw)
+#define AL(j) (P->alp + RING(P->lmask, ORMIN(firstLum + (j), srcH - 1)) * lw)
     const int hasAlpha = c->needAlpha;
     int mode; /* 1: packed1 (uvalpha in ua), 2: packed2, 0: X */
     int ua = 0, ya = 0;
@@ -3541,10 +3546,10 @@ static void write_packed_rgb16_line(const OrSws *c, const Planes *P, uint8_t *de
     uint16_t *dest = (uint16_t *)dest8;
     int j, mode;
     unsigned ua = 0, ya = 0;
-#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
-#define CU(j) (P->chrU + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
-#define CV(j) (P->chrV + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
-#define AL(j) (P->alp + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+#define L(j) (P->lum + RING(P->lmask, ORMIN(firstLum + (j), srcH - 1)) * lw)
+#define CU(j) (P->chrU + RING(P->cmask, ORMIN(firstChr + (j), chrSrcH - 1)) * cw)
+#define CV(j) (P->chrV + RING(P->cmask, ORMIN(firstChr + (j), chrSrcH - 1)) * cw)
+#define AL(j) (P->alp + RING(P->lmask, ORMIN(firstLum + (j), srcH - 1)) * lw)
     if (lfs == 1 && cfs == 1) mode = 1;
     else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 1; ua = (uint16_t)cf[1]; }
     else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
@@ -3614,8 +3619,8 @@ static void write_ya_line(const OrSws *c, const Planes *P, uint8_t *dest, int y)
     const int firstLum = ORMAX(1 - lfs, c->vLumFilterPos[y]);
     const int hasAlpha = c->needAlpha, wide = c->o.dst_format == ORF_YA16LE;
     int i, j, mode, ya = 0;
-#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
-#define AL(j) (P->alp + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+#define L(j) (P->lum + RING(P->lmask, ORMIN(firstLum + (j), srcH - 1)) * lw)
+#define AL(j) (P->alp + RING(P->lmask, ORMIN(firstLum + (j), srcH - 1)) * lw)
     if (lfs == 1 && cfs == 1) mode = 1;
     else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) mode = 1;
     else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
@@ -3684,7 +3689,7 @@ static void write_mono_line(OrSws *c, const Planes *P, uint8_t *dest, int y)
     const uint8_t *d128 = dither_8x8_220[y & 7];
     const int white = c->o.dst_format == ORF_MONOWHITE;
     int i, j, mode, ya = 0;
-#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+#define L(j) (P->lum + RING(P->lmask, ORMIN(firstLum + (j), srcH - 1)) * lw)
 #define LBM(j, x) ((x) < dstW ? L(j)[x] : (1 << 14))
     if (lfs == 1 && cfs == 1) mode = 1;
     else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) mode = 1;
@@ -3755,9 +3760,9 @@ static void write_packed422_line(const OrSws *c, const Planes *P, uint8_t *dest,
     const int firstChr = ORMAX(1 - cfs, c->vChrFilterPos[chrY]);
     const Desc *dd = desc_get(c->o.dst_format);
     int i, j, mode, ua = 0, ya = 0;
-#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
-#define CU(j) (P->chrU + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
-#define CV(j) (P->chrV + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+#define L(j) (P->lum + RING(P->lmask, ORMIN(firstLum + (j), srcH - 1)) * lw)
+#define CU(j) (P->chrU + RING(P->cmask, ORMIN(firstChr + (j), chrSrcH - 1)) * cw)
+#define CV(j) (P->chrV + RING(P->cmask, ORMIN(firstChr + (j), chrSrcH - 1)) * cw)
     /* the second pixel of the last pair of an odd-width picture: the line buffers are pre-filled with 1 << 14 (fill_ones, slice.c:190-208)
      * and the horizontal scaler writes dstW entries only */
 #define L2(j) (2 * i + 1 < dstW ? L(j)[2 * i + 1] : (1 << 14))
@@ -3810,10 +3815,10 @@ static void write_packedhi_line(const OrSws *c, const Planes *P, uint8_t *dest, 
     const int bits = dd->c[0].depth, sub = dd->lw;          /* sub: 4:2:2 (y21x) */
     const int units = sub ? (dstW + 1) >> 1 : dstW;
     int i, j;
-#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
-#define CU(j) (P->chrU + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
-#define CV(j) (P->chrV + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
-#define AL(j) (P->alp + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+#define L(j) (P->lum + RING(P->lmask, ORMIN(firstLum + (j), srcH - 1)) * lw)
+#define CU(j) (P->chrU + RING(P->cmask, ORMIN(firstChr + (j), chrSrcH - 1)) * cw)
+#define CV(j) (P->chrV + RING(P->cmask, ORMIN(firstChr + (j), chrSrcH - 1)) * cw)
+#define AL(j) (P->alp + RING(P->lmask, ORMIN(firstLum + (j), srcH - 1)) * lw)
     for (i = 0; i < units; i++) {
         int v[5];        /* Y (Y1), U, V, Y2, A as final sample values */
         int n = sub ? 4 : 3, k;
@@ -3879,10 +3884,10 @@ static void write_packed444_line(const OrSws *c, const Planes *P, uint8_t *dest,
     const Desc *dd = desc_get(c->o.dst_format);
     const int step = dd->c[0].step, hasAlpha = c->needAlpha;
     int i, j, mode, ua = 0, ya = 0;
-#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
-#define CU(j) (P->chrU + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
-#define CV(j) (P->chrV + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
-#define AL(j) (P->alp + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
+#define L(j) (P->lum + RING(P->lmask, ORMIN(firstLum + (j), srcH - 1)) * lw)
+#define CU(j) (P->chrU + RING(P->cmask, ORMIN(firstChr + (j), chrSrcH - 1)) * cw)
+#define CV(j) (P->chrV + RING(P->cmask, ORMIN(firstChr + (j), chrSrcH - 1)) * cw)
+#define AL(j) (P->alp + RING(P->lmask, ORMIN(firstLum + (j), srcH - 1)) * lw)
     if (lfs == 1 && cfs == 1) mode = 1;
     else if (lfs == 1 && cfs == 2 && (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 1; ua = (uint16_t)cf[1]; }
     else if (lfs == 2 && cfs == 2 && (uint16_t)lf[1] + (uint16_t)lf[0] == 4096 && (uint16_t)lf[1] <= 4096U &&
@@ -3939,9 +3944,9 @@ static void write_planar_rgb_line(const OrSws *c, const Planes *P, uint8_t *cons
     const int depth = dd->c[0].depth, isf = !!(dd->flags & PF_FLOAT);
     uint8_t *dg = dst[0] + (size_t)y * dstStride[0], *db = dst[1] + (size_t)y * dstStride[1], *dr = dst[2] + (size_t)y * dstStride[2];
     int i, j;
-#define L(j) (P->lum + (size_t)ORMIN(firstLum + (j), srcH - 1) * lw)
-#define CU(j) (P->chrU + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
-#define CV(j) (P->chrV + (size_t)ORMIN(firstChr + (j), chrSrcH - 1) * cw)
+#define L(j) (P->lum + RING(P->lmask, ORMIN(firstLum + (j), srcH - 1)) * lw)
+#define CU(j) (P->chrU + RING(P->cmask, ORMIN(firstChr + (j), chrSrcH - 1)) * cw)
+#define CV(j) (P->chrV + RING(P->cmask, ORMIN(firstChr + (j), chrSrcH - 1)) * cw)
     for (i = 0; i < dstW; i++) {
         int Y, U, V, R, G, B;
         if (depth <= 14) { /* yuv2gbrp_full_X_c :2342-2421, 15-bit intermediates */
@@ -3997,12 +4002,12 @@ static void write_planar_rgb_line(const OrSws *c, const Planes *P, uint8_t *cons
                 if (depth <= 14) {
                     const int SH = 22 + 8 - depth;
                     A = 1 << 18;
-                    for (j = 0; j < lfs; j++) { al = P->alp + (size_t)ORMIN(firstLum + j, srcH - 1) * lw; A = (int)((unsigned)A + al[i] * (unsigned)lf[j]); }
+                    for (j = 0; j < lfs; j++) { al = P->alp + RING(P->lmask, ORMIN(firstLum + j, srcH - 1)) * lw; A = (int)((unsigned)A + al[i] * (unsigned)lf[j]); }
                     if (A & 0xF8000000) A = clip_uintp2(A, 27);
                     if (SH != 22) ((uint16_t *)da)[i] = (uint16_t)(A >> (SH - 3)); else da[i] = (uint8_t)(A >> 19);
                 } else {
                     A = -0x40000000;
-                    for (j = 0; j < lfs; j++) { al = P->alp + (size_t)ORMIN(firstLum + j, srcH - 1) * lw; A = (int)((unsigned)A + al[i] * (unsigned)lf[j]); }
+                    for (j = 0; j < lfs; j++) { al = P->alp + RING(P->lmask, ORMIN(firstLum + j, srcH - 1)) * lw; A = (int)((unsigned)A + al[i] * (unsigned)lf[j]); }
                     A >>= 1; A += 0x20002000;
                     if (isf) ((float *)da)[i] = (1.0f / 65535.0f) * (float)(clip_uintp2(A, 30) >> 14);
                     else ((uint16_t *)da)[i] = (uint16_t)(clip_uintp2(A, 30) >> 14);
@@ -4032,7 +4037,7 @@ static void lum_line(OrSws *c, const uint8_t *const src[], const int srcStride[]
 {   /* lum_convert + lum_h_scale, hscale.c:39-131; plane 3 with the LUMA filter and no range conversion when needAlpha (desc->alpha) */
     const int sf = c->o.src_format, srcW = c->o.src_w, dstW = c->o.dst_w;
     const uint8_t *line = read_lum_line(c, src, srcStride, y, t0);
-    int32_t *d = P->lum + (size_t)y * dstW;
+    int32_t *d = P->lum + RING(P->lmask, y) * dstW;
     hscale_line(c, d, dstW, line, c->hLumFilter, c->hLumFilterPos, c->hLumFilterSize);
     if (c->range_active) range_line(c, d, dstW, 0);
     if (!c->needAlpha) return;
@@ -4088,13 +4093,13 @@ static void lum_line(OrSws *c, const uint8_t *const src[], const int srcStride[]
         for (int i = 0; i < srcW; i++) { const int a = opaque ? 255 : sp[4 * i]; d16[i] = (int16_t)(a << 6 | a >> 2); }
         aline = t0;
     } else aline = src[3] + (ptrdiff_t)y * srcStride[3];
-    hscale_line(c, P->alp + (size_t)y * dstW, dstW, aline, c->hLumFilter, c->hLumFilterPos, c->hLumFilterSize);
+    hscale_line(c, P->alp + RING(P->lmask, y) * dstW, dstW, aline, c->hLumFilter, c->hLumFilterPos, c->hLumFilterSize);
 }
 
 static void chr_line(OrSws *c, const uint8_t *const src[], const int srcStride[], int y, int lum_row, Planes *P, uint8_t *t0, uint8_t *t1)
 {   /* chr_convert + chr_h_scale, hscale.c:168-245 */
     const uint8_t *pu, *pv;
-    int32_t *du = P->chrU + (size_t)y * c->chrDstW, *dv = P->chrV + (size_t)y * c->chrDstW;
+    int32_t *du = P->chrU + RING(P->cmask, y) * c->chrDstW, *dv = P->chrV + RING(P->cmask, y) * c->chrDstW;
     read_chr_line(c, src, srcStride, y, lum_row, t0, t1, &pu, &pv);
     hscale_line(c, du, c->chrDstW, pu, c->hChrFilter, c->hChrFilterPos, c->hChrFilterSize);
     hscale_line(c, dv, c->chrDstW, pv, c->hChrFilter, c->hChrFilterPos, c->hChrFilterSize);
@@ -4112,16 +4117,16 @@ static void out_row(OrSws *c, const Planes *P, uint8_t *const dst[], const int d
     const uint8_t *chrDither = should_dither ? dither_8x8_128[chrDstY & 7] : pb_64;
     if (isGray(df) && !isYA(df)) { /* vscale.c:219-233: luma only */
         int firstLum = ORMAX(1 - c->vLumFilterSize, c->vLumFilterPos[y]);
-        write_planar_line(c, dst[0] + (size_t)y * dstStride[0], dstW, P->lum, dstW, srcH, firstLum,
+        write_planar_line(c, dst[0] + (size_t)y * dstStride[0], dstW, P->lum, P->lmask, dstW, srcH, firstLum,
                           c->vLumFilter + y * c->vLumFilterSize, c->vLumFilterSize, lumDither, 0, 1);
     } else if (isPlanarYUV(df)) {
         const Desc *dd = desc_get(df);
         int firstLum = ORMAX(1 - c->vLumFilterSize, c->vLumFilterPos[y]);
-        write_planar_line(c, dst[0] + (size_t)y * dstStride[0], dstW, P->lum, dstW, srcH, firstLum,
+        write_planar_line(c, dst[0] + (size_t)y * dstStride[0], dstW, P->lum, P->lmask, dstW, srcH, firstLum,
                           c->vLumFilter + y * c->vLumFilterSize, c->vLumFilterSize, lumDither, 0, 1);
         if (isALPHA(df)) {
             if (c->needAlpha) /* lum_planar_vscale vscale.c:59-71: same writer, luma filter, luma dither */
-                write_planar_line(c, dst[3] + (size_t)y * dstStride[3], dstW, P->alp, dstW, srcH, firstLum,
+                write_planar_line(c, dst[3] + (size_t)y * dstStride[3], dstW, P->alp, P->lmask, dstW, srcH, firstLum,
                                   c->vLumFilter + y * c->vLumFilterSize, c->vLumFilterSize, lumDither, 0, 1);
             else if (dd->c[0].depth > 8) { /* fillPlane16 (swscale.c:536-552, swscale_internal.h fillPlane16): 0xFFFF >> (16 - bits) */
                 uint16_t *a16 = (uint16_t *)(dst[3] + (size_t)y * dstStride[3]);
@@ -4132,12 +4137,12 @@ static void out_row(OrSws *c, const Planes *P, uint8_t *const dst[], const int d
             int firstChr = ORMAX(1 - c->vChrFilterSize, c->vChrFilterPos[chrDstY]);
             const int16_t *cf = c->vChrFilter + chrDstY * c->vChrFilterSize;
             if (isSemiPlanarYUV(df)) {
-                write_nv_chroma_line(c, dst[1] + (size_t)chrDstY * dstStride[1], c->chrDstW, P->chrU, P->chrV,
+                write_nv_chroma_line(c, dst[1] + (size_t)chrDstY * dstStride[1], c->chrDstW, P->chrU, P->chrV, P->cmask,
                                      c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither);
             } else {
-                write_planar_line(c, dst[dd->c[1].plane] + (size_t)chrDstY * dstStride[dd->c[1].plane], c->chrDstW, P->chrU,
+                write_planar_line(c, dst[dd->c[1].plane] + (size_t)chrDstY * dstStride[dd->c[1].plane], c->chrDstW, P->chrU, P->cmask,
                                   c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither, 0, 0);
-                write_planar_line(c, dst[dd->c[2].plane] + (size_t)chrDstY * dstStride[dd->c[2].plane], c->chrDstW, P->chrV,
+                write_planar_line(c, dst[dd->c[2].plane] + (size_t)chrDstY * dstStride[dd->c[2].plane], c->chrDstW, P->chrV, P->cmask,
                                   c->chrDstW, c->chrSrcH, firstChr, cf, c->vChrFilterSize, chrDither, 3, 0);
             }
         }
@@ -4194,16 +4199,21 @@ static int main_path(OrSws *c, const uint8_t *const src[], const int srcStride[]
     if ((c->o.flags & OR_SWS_BITEXACT) && c->o.dither == 3 && c->dither_error[0])
         for (y = 0; y < 3; y++) memset(c->dither_error[y], 0, sizeof(int) * ((size_t)dstW + 2));
 
-    P.lum = calloc((size_t)srcH * dstW, sizeof(int32_t));
-    P.chrU = malloc((size_t)c->chrSrcH * c->chrDstW * sizeof(int32_t));
-    P.chrV = malloc((size_t)c->chrSrcH * c->chrDstW * sizeof(int32_t));
-    P.alp = c->needAlpha ? calloc((size_t)srcH * dstW, sizeof(int32_t)) : NULL;
-    {   /* fill_ones() (slice.c:190-208, :311): what a ring line holds before it is written -- the value a chroma line keeps for good when
+    ring_sizes(c, &lumAvail, &chrAvail);
+    {   /* line rings: twice what is ever alive at once (the lines of an output row's window plus what the schedule below converts ahead), a power of two */
+        int lr = 1, cr = 1;
+        while (lr < 2 * lumAvail + 2) lr <<= 1;
+        while (cr < 2 * chrAvail + 2) cr <<= 1;
+        P.lmask = lr - 1; P.cmask = cr - 1;
+        P.lum = calloc((size_t)lr * dstW, sizeof(int32_t));
+        P.chrU = malloc((size_t)cr * c->chrDstW * sizeof(int32_t));
+        P.chrV = malloc((size_t)cr * c->chrDstW * sizeof(int32_t));
+        P.alp = c->needAlpha ? calloc((size_t)lr * dstW, sizeof(int32_t)) : NULL;
+        /* fill_ones() (slice.c:190-208, :311): what a ring line holds before it is written -- the value a chroma line keeps for good when
          * ff_init_desc_no_chr stands in for the chroma scaler (:358-361) */
         const int32_t neutral = c->dstBpc >= 16 ? 1 << 18 : 1 << 14;
-        for (size_t k = 0; k < (size_t)c->chrSrcH * c->chrDstW; k++) P.chrU[k] = P.chrV[k] = neutral;
+        for (size_t k = 0; k < (size_t)cr * c->chrDstW; k++) P.chrU[k] = P.chrV[k] = neutral;
     }
-    ring_sizes(c, &lumAvail, &chrAvail);
 
     for (y = 0; y < dstH; y++) {   /* swscale.c:388-535 */
         const int chrDstY = y >> c->chrDstVSub;

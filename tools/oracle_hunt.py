@@ -25,6 +25,8 @@ def main():
     if os.environ.get("SWS_HUNT_ONLY"):
         gens = [g for g in gens if os.environ["SWS_HUNT_ONLY"] in g[0]]
     total = refused = 0
+    import hashlib
+    dump = open(os.environ["SWS_ORACLE_DUMP"], "w") if os.environ.get("SWS_ORACLE_DUMP") else None      # one digest per conversion: two oracle builds (SWS_ORACLE_LIBRARY) must agree
     for name, cases in gens:
         for c in cases:
             sw, sh, sf, dw, dh, df, flags = c[:7]
@@ -42,6 +44,9 @@ def main():
             src = OL.fill_random(OL.Frame(sf, sw, sh), total)
             ref = OL.Frame(df, dw, dh, fill=0xA5)
             o.scale(src, ref)
+            if dump:
+                digest = hashlib.md5(b"".join(a.tobytes() for a in ref.planes)).hexdigest()
+                dump.write(f"{name} {c[:7]} {digest}\n")
             if total % 5 == 0:      # twice on one context: the answer must repeat
                 ref2 = OL.Frame(df, dw, dh, fill=0xA5)
                 o.scale(src, ref2)
