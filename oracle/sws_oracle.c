@@ -3418,10 +3418,20 @@ static void write_packed_rgb_line(OrSws *c, const Planes *P, uint8_t *dest, int 
     const int step = isRGB8class(c->o.dst_format) ? 1 : c->lut_elem == 4 || c->dstFormatBpp == 32 ? 4 : 3;
     int err[4] = { 0, 0, 0, 0 };   /* the running error of the row (yuv2rgb_full_{X,2,1}_c_template: "int err[4] = {0}") */
     int i, j;
-#define L(j) (P->lum + RING(P->lmask, ORMIN(firstLum + (j), srcH - 1)) * lw)
-#define CU(j) (P->chrU + RING(P->cmask, ORMIN(firstChr + (j), chrSrcH - 1)) * cw)
-#define CV(j) (P->chrV + RING(P->cmask, ORMIN(firstChr + (j), chrSrcH - 1)) * cw)
-#define AL(j) (P->alp + RING(P->lmask, ORMIN(firstLum + (j), srcH - 1)) * lw)
+    /* the lines of the row's two vertical windows, looked up once (the pixel loops below index them by tap) */
+    const int32_t *lrow[lfs > 0 ? lfs : 1], *urow[cfs > 0 ? cfs : 1], *vrow[cfs > 0 ? cfs : 1], *arow[lfs > 0 ? lfs : 1];
+    for (j = 0; j < lfs; j++) {
+        lrow[j] = P->lum + RING(P->lmask, ORMIN(firstLum + j, srcH - 1)) * lw;
+        arow[j] = P->alp ? P->alp + RING(P->lmask, ORMIN(firstLum + j, srcH - 1)) * lw : NULL;
+    }
+    for (j = 0; j < cfs; j++) {
+        urow[j] = P->chrU + RING(P->cmask, ORMIN(firstChr + j, chrSrcH - 1)) * cw;
+        vrow[j] = P->chrV + RING(P->cmask, ORMIN(firstChr + j, chrSrcH - 1)) * cw;
+    }
+#define L(j) lrow[j]
+#define CU(j) urow[j]
+#define CV(j) vrow[j]
+#define AL(j) arow[j]
     const int hasAlpha = c->needAlpha;
     int mode; /* 1: packed1 (uvalpha in ua), 2: packed2, 0: X */
     int ua = 0, ya = 0;
@@ -3431,6 +3441,30 @@ static void write_packed_rgb_line(OrSws *c, const Planes *P, uint8_t *dest, int 
              (uint16_t)cf[1] + (uint16_t)cf[0] == 4096 && (uint16_t)cf[1] <= 4096U) { mode = 2; ya = (uint16_t)lf[1]; ua = (uint16_t)cf[1]; }
     else mode = 0;
 
+    if (!full && mode == 0 && !hasAlpha && !(dstW & 1) && ((c->lut_elem == 1 && c->dstFormatBpp == 24) || (c->lut_elem == 4 && c->dstFormatBpp == 32))) {
+        /* the common case on its own (yuv2rgb24_X_c / yuv2rgbx32_X_c: the X form, no alpha, whole pixel pairs): the arithmetic of the general loop below
+         * with the per-pixel mode / format tests taken out of the loop -- what the reference gets from instantiating its template per format */
+        const int d = c->o.dst_format;
+        const int swap = !(d == ORF_RGB24);       /* 24 bpp: byte order R G B for rgb24, B G R for bgr24 */
+        for (i = 0; i < (dstW >> 1); i++) {
+            int Y1 = 1 << 18, Y2 = 1 << 18, U = 1 << 18, V = 1 << 18;
+            for (j = 0; j < lfs; j++) { Y1 = (int)((unsigned)Y1 + lrow[j][2 * i] * (unsigned)lf[j]); Y2 = (int)((unsigned)Y2 + lrow[j][2 * i + 1] * (unsigned)lf[j]); }
+            for (j = 0; j < cfs; j++) { U = (int)((unsigned)U + urow[j][i] * (unsigned)cf[j]); V = (int)((unsigned)V + vrow[j][i] * (unsigned)cf[j]); }
+            Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
+            const int r = c->table_rV[V + HEADROOM], g = c->table_gU[U + HEADROOM] + c->table_gV[V + HEADROOM], bb = c->table_bU[U + HEADROOM];
+            if (c->lut_elem == 4) {
+                const uint32_t *T = (const uint32_t *)c->yuvTable;
+                const uint32_t v1 = T[r + Y1] + T[g + Y1] + T[bb + Y1], v2 = T[r + Y2] + T[g + Y2] + T[bb + Y2];
+                memcpy(dest + 8 * i, &v1, 4); memcpy(dest + 8 * i + 4, &v2, 4);
+            } else {
+                const uint8_t *T = c->yuvTable;
+                uint8_t *q = dest + 6 * i;
+                const int rb = swap ? bb : r, br = swap ? r : bb;
+                q[0] = T[rb + Y1]; q[1] = T[g + Y1]; q[2] = T[br + Y1];
+                q[3] = T[rb + Y2]; q[4] = T[g + Y2]; q[5] = T[br + Y2];
+            }
+        }
+    } else
     if (!full) {
         /* odd widths reach the pair writers only for the 16 bpp formats (no full-chroma writer): the second pixel of the last pair lies
          * beyond the picture; the reference computes it from the line buffers' fill value and stores it into the row padding, the oracle
