@@ -281,7 +281,9 @@ int plan_strip(PlanBuild &B)
             //  (4095 after initFilter's normalisation, 0 in the zero-vector rows of a source of fewer than four rows with shifted chroma): their own taps.
             const bool raw_one_one = p.dstKind == DSTK_RAW32 && c->vLum.size == 1 && vChrB.size == 1 && d->fullchr_kind != DSTK_GBRP && d->fullchr_kind != DSTK_PACKEDHI && d->fullchr_kind != DSTK_GBRP16 && d->fullchr_kind != DSTK_GBRPF32;
             const bool chr_plane1 = (p.dstKind != DSTK_NV12 && p.dstKind != DSTK_P010 && p.dstKind != DSTK_P016 && p.dstKind != DSTK_RAW32) || raw_one_one, lum_plane1 = p.dstKind != DSTK_RAW32 || raw_one_one;
-            const int strip_cols_l = c->tune.strip_cols_l == 2 ? 2 : 4;
+            // (experiment "exp4", round 6, unmeasured: 192-column luma strips for planar sources of 9 .. 15 bits -- at 2:1 their window is 396 samples = 50 chunks, ONE
+            //  LDS-DMA request per row where a 256-column strip's 524 samples need a second request of 32 bytes; k_strip.hip has the two instantiations it can reach)
+            const int strip_cols_l = c->tune.strip_cols_l == 2 ? 2 : (c->tune.strip_cols_l == 3 && c->tune.exp[4] && p.srcKind == SRCK_PLANAR16 && p.src_depth < 16 && !p.wide) ? 3 : 4;
             const int strip_cols_c = c->tune.strip_cols_c == 1 ? 1 : 2;
             // (narrow pictures leave most of a 256-column strip idle and pay the per-band ring fill: the tile kernel keeps them)
             const int strip_min_w = c->tune.strip_min_w;

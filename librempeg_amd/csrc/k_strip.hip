@@ -60,6 +60,15 @@ int launch_strip_planes(const LaunchCtx &L, int which)
                 }
                 // experiments (sws_hip_set_option "exp0" = ring depth D in row pairs (2 / 3; 0 = the shipped 4), "exp1" = absolute register-ring slots,
                 // "exp2" = waves per SIMD the variant is compiled for): C3b's two launches only
+                if (!chroma && cols == 3) {       // experiment "exp4" (dev_plan_strip.hip): 192-column luma strips, planar 9 .. 15-bit sources only
+                    if (!s16) { log_msg(c, 0, "internal error: 192-column strip plan for an 8-bit source\n"); return; }
+                    const size_t lds = (size_t)g.lds_dma_bytes;
+                    if (g.dma_ok && !c->tune.no_strip_dma) {
+                        if (c->tune.exp[1]) hipLaunchKernelGGL((swsk::sws_k_strip_dma_v<false, 3, 4, true, 5>), grid, blk, lds, st, fs, p, g);
+                        else hipLaunchKernelGGL((swsk::sws_k_strip_dma_v<false, 3, 4, false, 5>), grid, blk, lds, st, fs, p, g);
+                    } else hipLaunchKernelGGL((swsk::sws_k_strip_march<true, false, 3>), grid, blk, g.lds_bytes, st, fs, p, g);
+                    return;
+                }
                 if (s16 && g.dma_ok && !c->tune.no_strip_dma && c->tune.exp[2] == 7 && cols == (chroma ? 1 : 2)) {     // 128 / 64-column strips (strip_cols_l=2 strip_cols_c=1) compiled for 7 waves per SIMD
                     const bool abs = c->tune.exp[1] != 0;
                     if (chroma) { if (abs) hipLaunchKernelGGL((swsk::sws_k_strip_dma_v<true, 1, 4, true, 7>), grid, blk, g.lds_dma_bytes, st, fs, p, g);

@@ -11,7 +11,8 @@ import test_gpu_parity as T  # noqa: E402
 from librempeg_amd import SWS_BILINEAR, SWS_BICUBIC, SWS_LANCZOS, SWS_BITEXACT  # noqa: E402
 
 C3B = [dict(exp1=1), dict(exp0=3, exp1=1, exp2=5), dict(exp0=2, exp1=1, exp2=6), dict(exp0=2, exp2=8),
-       dict(strip_cols_l=2, strip_cols_c=1, exp2=7), dict(strip_cols_l=2, strip_cols_c=1, exp2=7, exp1=1)]
+       dict(strip_cols_l=2, strip_cols_c=1, exp2=7), dict(strip_cols_l=2, strip_cols_c=1, exp2=7, exp1=1),
+       dict(strip_cols_l=3, exp4=1), dict(strip_cols_l=3, exp4=1, exp1=1), dict(strip_cols_l=3, exp4=1, no_strip_dma=1)]
 C1 = [dict(exp3=1)]
 ok = True
 for tune in [{}] + C3B:

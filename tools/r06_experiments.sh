@@ -9,7 +9,7 @@ echo "== experiment parity"; date
 timeout 600 python tools/exp_parity.py 2>&1 | tail -40
 echo "== bench A/B"; date
 B="python bench.py --variants none --no-cpu --steps 20 --warmup 3"
-for o in "" "--opt exp1=1" "--opt exp0=3 --opt exp1=1 --opt exp2=5" "--opt strip_cols_l=2 --opt strip_cols_c=1 --opt exp2=7 --opt strip_waves=7168" "--opt strip_cols_l=2 --opt strip_cols_c=1 --opt exp2=7 --opt exp1=1 --opt strip_waves=7168"; do
+for o in "" "--opt exp1=1" "--opt exp0=3 --opt exp1=1 --opt exp2=5" "--opt strip_cols_l=2 --opt strip_cols_c=1 --opt exp2=7 --opt strip_waves=7168" "--opt strip_cols_l=2 --opt strip_cols_c=1 --opt exp2=7 --opt exp1=1 --opt strip_waves=7168" "--opt strip_cols_l=3 --opt exp4=1 --opt strip_waves=5120" "--opt strip_cols_l=3 --opt exp4=1 --opt exp1=1 --opt strip_waves=5120"; do
   for b in 64 8; do echo "c3b x$b [$o]"; timeout 300 $B --workload c3b --batch $b $o 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('   frac', d['roofline']['frac'], 'kernel_ms', d['roofline']['kernel_ms_avg'], d['config']['path'])"; done
 done
 # (C1's planner picks 5 columns per lane for both plane classes: 76 VGPRs luma, 114 chroma -- narrower chroma strips buy waves per SIMD)
