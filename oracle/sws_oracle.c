@@ -3150,7 +3150,9 @@ static void write_planar_line(const OrSws *c, uint8_t *dest, int w, const int32_
     const Desc *dd = desc_get(c->o.dst_format);
     const int bits = dd->c[0].depth;
     int i, j;
-#define ROW(j) (plane + RING(mask, ORMIN(first + (j), planeH - 1)) * planeW)
+    const int32_t *rows_[fs > 0 ? fs : 1];       /* the lines of the row's vertical window, looked up once */
+    for (j = 0; j < fs; j++) rows_[j] = plane + RING(mask, ORMIN(first + j, planeH - 1)) * planeW;
+#define ROW(j) rows_[j]
     (void)is_luma_of_p01x;
     if (isDataInHighBits(c->o.dst_format) && bits < 16) { /* yuv2p01xl1_c / lX_c output.c:538-569; yuv2msbplane1/X_10_c_template :396-426 (same arithmetic) */
         uint16_t *d = (uint16_t *)dest;
@@ -3226,8 +3228,10 @@ static void write_nv_chroma_line(const OrSws *c, uint8_t *dest, int w, const int
     const Desc *dd = desc_get(c->o.dst_format);
     const int bits = dd->c[0].depth;
     int i, j;
-#define ROWU(j) (up + RING(mask, ORMIN(first + (j), planeH - 1)) * planeW)
-#define ROWV(j) (vp + RING(mask, ORMIN(first + (j), planeH - 1)) * planeW)
+    const int32_t *urows_[fs > 0 ? fs : 1], *vrows_[fs > 0 ? fs : 1];       /* the lines of the row's vertical window, looked up once */
+    for (j = 0; j < fs; j++) { urows_[j] = up + RING(mask, ORMIN(first + j, planeH - 1)) * planeW; vrows_[j] = vp + RING(mask, ORMIN(first + j, planeH - 1)) * planeW; }
+#define ROWU(j) urows_[j]
+#define ROWV(j) vrows_[j]
     if (bits == 16) { /* yuv2nv12cX_16_c_template output.c:189-217 */
         uint16_t *d = (uint16_t *)dest;
         for (i = 0; i < w; i++) {
