@@ -161,7 +161,7 @@ void choose_unscaled(SwsInternal *c)
         else if (d == AV_PIX_FMT_MONOBLACK) k = PLAN_UNSC_YUV2MONO;   // yuv2rgb_c_1_ordered_dither (yuv2rgb.c:457-517, :624, :671)
         c->dst_slice_align = 2;
     }
-    if ((s == AV_PIX_FMT_YUV420P10LE || s == AV_PIX_FMT_YUV420P12LE || s == AV_PIX_FMT_YUV420P14LE || s == AV_PIX_FMT_YUV420P16LE) &&
+    if ((s == AV_PIX_FMT_YUV420P10LE || s == AV_PIX_FMT_YUVA420P10LE || s == AV_PIX_FMT_YUV420P12LE || s == AV_PIX_FMT_YUV420P14LE || s == AV_PIX_FMT_YUV420P16LE || s == AV_PIX_FMT_YUVA420P16LE) &&   // (yuva420p10 / 16 are on the reference's list too: the alpha plane is dropped; round 6, tools/ref/ref_crosscheck.py)
         (d == AV_PIX_FMT_P010LE || d == AV_PIX_FMT_P016LE) && !c->srcBE && !c->dstBE) k = PLAN_UNSC_P01X;           // :2432-2439 (native-endian names only)
     if ((s == AV_PIX_FMT_YUV420P || s == AV_PIX_FMT_YUVA420P) && (d == AV_PIX_FMT_P010LE || d == AV_PIX_FMT_P016LE) && !c->dstBE) k = PLAN_UNSC_8_P01X; // :2440-2444
     if (s == AV_PIX_FMT_YUV410P && !(c->opts.dst_h & 3) && (d == AV_PIX_FMT_YUV420P || d == AV_PIX_FMT_YUVA420P) && !(flags & SWS_BITEXACT)) {       // :2446-2451

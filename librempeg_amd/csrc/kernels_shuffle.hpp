@@ -642,7 +642,10 @@ __global__ void __launch_bounds__(256) sws_k_yuv2rgb8_unscaled(SwsFrameSet fs, S
         const ChromaIdx k = lut_chroma(L, U, V);
         const uint8_t *py = f.src[0] + (int64_t)yy * f.srcStride[0] + 2 * i;
         uint8_t *drow = f.dst[0] + (int64_t)yy * f.dstStride[0];
-        const uint32_t v0 = lut_rgb8(L, k, py[0], yy, 2 * i), v1 = lut_rgb8(L, k, py[1], yy, 2 * i + 1);
+        // (the 2-pixel tail behind a 4-pixel tail -- dstW & 6 == 6 -- starts its dither row over at column 0: every section of YUV420FUNC_DITHER begins with
+        //  PUTFUNC(1, 0, 0), yuv2rgb.c:283-318; round 6, found against the real reference on the CPU box)
+        const int xd = ((p.dstW & 6) == 6 && i == npairs - 1) ? 0 : 2 * i;
+        const uint32_t v0 = lut_rgb8(L, k, py[0], yy, xd), v1 = lut_rgb8(L, k, py[1], yy, xd + 1);
         if (p.dstKind == DSTK_RGB4) drow[i] = (uint8_t)(v0 | (v1 << 4));
         else { drow[2 * i] = (uint8_t)v0; drow[2 * i + 1] = (uint8_t)v1; }
     }

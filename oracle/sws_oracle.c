@@ -1186,7 +1186,7 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
     }
     if (s == ORF_YUV444P && (d == ORF_NV24 || d == ORF_NV42)) c->unscaled_kind = UNSC_PLANAR2NV24;   /* :2410-2413 */
     if (d == ORF_YUV444P && (s == ORF_NV24 || s == ORF_NV42)) c->unscaled_kind = UNSC_NV242PLANAR;   /* :2420-2423 */
-    if ((s == ORF_YUV420P10LE || s == ORF_YUV420P12LE || s == ORF_YUV420P14LE || s == ORF_YUV420P16LE) &&
+    if ((s == ORF_YUV420P10LE || s == ORF_YUVA420P10LE || s == ORF_YUV420P12LE || s == ORF_YUV420P14LE || s == ORF_YUV420P16LE || s == ORF_YUVA420P16LE) &&   /* (the two yuva420p formats of the reference's list: found missing by tools/ref/ref_crosscheck.py, round 6) */
         (d == ORF_P010LE || d == ORF_P016LE) && !c->src_be && !c->dst_be) c->unscaled_kind = UNSC_P01X;                           /* :2432-2439 */
     if ((s == ORF_YUV420P || s == ORF_YUVA420P) && (d == ORF_P010LE || d == ORF_P016LE) && !c->dst_be) c->unscaled_kind = UNSC_8_P01X; /* :2440-2444 */
     if (s == ORF_YUV410P && !(c->o.dst_h & 3) && (d == ORF_YUV420P || d == ORF_YUVA420P) && !(flags & OR_SWS_BITEXACT))
@@ -1701,7 +1701,10 @@ static int unscaled_yuv2rgb(OrSws *c, const uint8_t *const src[], const int srcS
                                                                    * of the 8x8 tables by the ABSOLUTE even row, the second line reads the following row */
                         int dr, dg, db;
                         uint8_t v;
-                        dither_rgb8_rows(d, ((y + srcSliceY) & 7) + l, 2 * (i & 3) + k, &dr, &dg, &db);
+                        /* (the 2-pixel tail behind a 4-pixel tail -- dst_w & 6 == 6 -- starts its dither row over at column 0: every section of YUV420FUNC_DITHER begins
+                         *  with PUTFUNC(1, 0, 0), yuv2rgb.c:283-318; found against the real reference by tools/ref/ref_crosscheck.py, round 6) */
+                        const int tail2 = (c->o.dst_w & 6) == 6 && i == npairs - 1;
+                        dither_rgb8_rows(d, ((y + srcSliceY) & 7) + l, (tail2 ? 0 : 2 * (i & 3)) + k, &dr, &dg, &db);
                         v = (uint8_t)(lut_at(c, r + Y + dr) + lut_at(c, g + Y + dg) + lut_at(c, b + Y + db));
                         if (isRGB4bits(d)) { if (!k) out[i] = v; else out[i] = (uint8_t)(out[i] | (v << 4)); }
                         else out[2 * i + k] = v;

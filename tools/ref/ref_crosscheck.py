@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""oracle/ against the REAL reference (a C-only build under /tmp: tools/ref_vs_port.sh makes it) on the random conversions of tests/test_gpu_random.py -- whole
+destination pictures byte for byte and the return value.  Build container only.  usage: python tools/ref/ref_crosscheck.py <N per generator> <seed>
+(round 6: run after the oracle's h-scaled lines moved into rings and its writers were restructured)"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("SWS_RANDOM_N", "1")
+import numpy as np  # noqa: E402
+import test_gpu_random as R  # noqa: E402
+import oracle_lib as OL  # noqa: E402
+
+B = os.environ.get("REFBUILD", "/tmp/refbuild")
+REF = os.environ.get("SWS_REFERENCE_ROOT", "/root/reference")
+
+
+def main():
+    n, seed = int(sys.argv[1]), int(sys.argv[2])
+    exe = os.path.join(B, "ref_batch")
+    subprocess.check_call(["gcc", "-O2", f"-I{REF}", f"-I{B}", "-o", exe, os.path.join(ROOT, "tools", "ref", "ref_batch.c"),
+                           os.path.join(B, "libswscale", "libswscale.a"), os.path.join(B, "libavutil", "libavutil.a"), "-lm", "-lpthread"])
+    p = subprocess.Popen([exe], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+    gens = [("conversions", R._cases(n, seed)), ("strip family", R._strip_cases(n, seed + 2)), ("round-4 routes", R._strip_cases(n, seed + 3, R.R4_SRC, R.R4_DST)),
+            ("few rows", R._short_cases(n, seed + 4)), ("batches", R._batch_cases(n, seed + 5)), ("slice sequences (whole frames)", R._slice_cases(n, seed + 7))]
+    total = diff = refused = ref_only = 0
+    for name, cases in gens:
+        for c in cases:
+            sw, sh, sf, dw, dh, df, flags = c[:7]
+            if any(isinstance(x, dict) and ("dither" in x or "src_range" in x) for x in c[7:]) or any(isinstance(x, tuple) and len(x) == 7 for x in c[7:]):
+                continue      # (options / colourspace need the sws_alloc_context() construction: not in the batch tool)
+            total += 1
+            try:
+                o = OL.Oracle(sw, sh, sf, dw, dh, df, flags)
+            except Exception:
+                o = None
+            src = OL.fill_random(OL.Frame(sf, sw, sh), total)
+            p.stdin.write(f"CASE {sw} {sh} {sf} {dw} {dh} {df} {flags} 165\n".encode())
+            for a, rb in zip(src.planes, src.row_bytes):
+                p.stdin.write(np.ascontiguousarray(a[:, :rb]).tobytes())
+            p.stdin.flush()
+            hdr = p.stdout.readline().split()
+            ret, nbytes = int(hdr[1]), int(hdr[2])
+            got = p.stdout.read(nbytes) if nbytes else b""
+            if o is None or ret < 0:
+                refused += 1
+                if (o is None) != (ret < 0):
+                    ref_only += 1
+                    print("REFUSAL DIFFERS", c[:7], "oracle refuses" if o is None else "reference refuses", flush=True)
+                continue
+            ref = OL.Frame(df, dw, dh, fill=165)
+            r = o.scale(src, ref)
+            want = b"".join(np.ascontiguousarray(a[:, :rb]).tobytes() for a, rb in zip(ref.planes, ref.row_bytes))
+            if df in ("monob", "monow") and (dw & 7) and len(want) == len(got):      # bits past the width in a row's last byte are outside the picture (built from source padding: yuv2rgb.c:488-517)
+                rbm = (dw + 7) >> 3
+                m = (0xFF00 >> (dw & 7)) & 0xFF
+                wa, ga = np.frombuffer(want, np.uint8).reshape(-1, rbm).copy(), np.frombuffer(got, np.uint8).reshape(-1, rbm).copy()
+                wa[:, -1] &= m; ga[:, -1] &= m
+                want, got = wa.tobytes(), ga.tobytes()
+            if r != ret or want != got:
+                diff += 1
+                nb = sum(x != y for x, y in zip(want, got)) if len(want) == len(got) else -1
+                if diff <= 30:
+                    print("DIFF", c[:7], "ret oracle", r, "reference", ret, "bytes differing", nb, "of", len(want), flush=True)
+        print(f"{name}: done ({total} so far)", flush=True)
+    p.stdin.close(); p.wait()
+    print(f"total {total}, refused by both {refused - ref_only}, refusals that differ {ref_only}, DIFFERENT {diff}")
+
+
+if __name__ == "__main__":
+    main()
