@@ -1,0 +1,31 @@
+"""-m gpu: the product against answers of the REAL reference (tests/golden/reference_answers_r06.json; tests/test_oracle_reference_answers_r06.py holds the oracle to the same
+answers on the CPU box) for the two divergences round 6 found with tools/ref/ref_crosscheck.py and fixed: the last tail pair of the 8 / 4 bpp ordered-dither converters and
+yuva420p10le / yuva420p16le -> p010le / p016le through planarToP01xWrapper."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as OL
+from librempeg_amd import SwsContext, HostFrame
+
+pytestmark = pytest.mark.gpu
+G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_answers_r06.json")))
+
+
+@pytest.mark.parametrize("g", G["cases"], ids=lambda g: "{2}_{0}x{1}-{5}".format(*g["case"]))
+def test_product_equals_the_reference(g):
+    sw, sh, sf, dw, dh, df, flags = g["case"]
+    p = SwsContext(sw, sh, sf, dw, dh, df, flags)
+    src = OL.fill_random(OL.Frame(sf, sw, sh), g["seed"])
+    hs, hd = HostFrame(sf, sw, sh), HostFrame(df, dw, dh)
+    for a, b in zip(hs.planes, src.planes):
+        a[:] = b
+    for a in hd.planes:
+        a[:] = g["prefill"]
+    assert p.scale(hs, hd) == dh
+    data = b"".join(np.ascontiguousarray(a[:, :rb]).tobytes() for a, rb in zip(hd.planes, hd.row_bytes))
+    assert hashlib.md5(data).hexdigest() == g["md5"], p.path()
+    p.close()
