@@ -30,7 +30,7 @@ def main():
     out = []
     for (sw, sh, sf, dw, dh, df, flags, seed) in CASES:
         src = OL.fill_random(OL.Frame(sf, sw, sh), seed)
-        inp = f"CASE {sw} {sh} {sf} {dw} {dh} {df} {flags} 165 0 1 0 0 -513 -513 -513 -513 0 0 0 0 0 0 0 0\n".encode()
+        inp = f"CASE {sw} {sh} {sf} {dw} {dh} {df} {flags} 165 0 1 0 0 -513 -513 -513 -513 0 0 0 0 0 0 0 0 0 0 123456 123456\n".encode()
         inp += b"".join(np.ascontiguousarray(a[:, :rb]).tobytes() for a, rb in zip(src.planes, src.row_bytes))
         o = subprocess.run([EXE], input=inp, capture_output=True, check=True).stdout
         hdr, data = o[:o.index(b"\n")].split(), o[o.index(b"\n") + 1:]

@@ -18,6 +18,32 @@ B = os.environ.get("REFBUILD", "/tmp/refbuild")
 REF = os.environ.get("SWS_REFERENCE_ROOT", "/root/reference")
 
 
+def _feature_cases(n, seed):
+    """what the generators of the GPU tests draw thinly: every dither mode (error diffusion, a_dither, x_dither), alpha blending, gamma-correct scaling, SWS_SRC_V_CHR_DROP,
+    scaler parameters, every format of the matrix on either side"""
+    import random
+    rng = random.Random(seed)
+    out = []
+    for k in range(n):
+        sf, df = rng.choice(R.FORMAT_MATRIX_SRC), rng.choice(R.FORMAT_MATRIX_DST)
+        if rng.random() < 0.3:
+            sw = dw = rng.randint(2, 180); sh = dh = rng.randint(2, 90)
+        else:
+            sw, dw, sh, dh = rng.randint(2, 220), rng.randint(2, 220), rng.randint(2, 100), rng.randint(2, 100)
+        flags = rng.choice(R.SCALERS) | rng.choice(R.EXTRA)
+        if rng.random() < 0.15:
+            flags |= rng.choice([1, 2, 3]) << 16                       # SWS_SRC_V_CHR_DROP_MASK: drop 1 .. 3 chroma line levels
+        opts = {"dither": rng.choice([0, 1, 2, 3, 4, 5]), "src_range": rng.choice([0, 1]), "dst_range": rng.choice([0, 1]), "threads": 1,
+                "alpha_blend": rng.choice([0, 0, 1, 2]), "gamma_flag": rng.choice([0, 0, 0, 1])}
+        par = [float(rng.choice([0, 1, 2, 3])), float(rng.choice([0, 1, 2]))] if rng.random() < 0.3 else None
+        if par and (flags & 0x200) and par[0] == 0:
+            par = None                                                  # (Lanczos with param0 = 0: the reference asserts)
+        if opts["alpha_blend"] and "rgba64" in sf and "xyz" in df:
+            opts["alpha_blend"] = 0                                     # (rgba64 -> xyz12 with alpha_blend: the reference crashes, round-5 review)
+        out.append((sw, sh, sf, dw, dh, df, flags, k, opts) + ((par,) if par else ()))
+    return out
+
+
 def main():
     n, seed = int(sys.argv[1]), int(sys.argv[2])
     exe = os.path.join(B, "ref_batch")
@@ -25,7 +51,9 @@ def main():
                            os.path.join(B, "libswscale", "libswscale.a"), os.path.join(B, "libavutil", "libavutil.a"), "-lm", "-lpthread"])
     p = subprocess.Popen([exe], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
     gens = [("conversions", R._cases(n, seed)), ("options", R._opt_cases(n, seed + 1)), ("strip family", R._strip_cases(n, seed + 2)), ("round-4 routes", R._strip_cases(n, seed + 3, R.R4_SRC, R.R4_DST)),
-            ("few rows", R._short_cases(n, seed + 4)), ("batches", R._batch_cases(n, seed + 5)), ("slice sequences (whole frames)", R._slice_cases(n, seed + 7))]
+            ("few rows", R._short_cases(n, seed + 4)), ("batches", R._batch_cases(n, seed + 5)), ("slice sequences (whole frames)", R._slice_cases(n, seed + 7)), ("features", _feature_cases(n, seed + 8))]
+    if os.environ.get("SWS_HUNT_ONLY"):
+        gens = [g for g in gens if os.environ["SWS_HUNT_ONLY"] in g[0]]
     total = diff = refused = ref_only = uninit = 0
     for name, cases in gens:
         for c in cases:
@@ -34,7 +62,7 @@ def main():
             cs = next((x for x in c[7:] if isinstance(x, tuple) and len(x) == 7 and all(isinstance(v, int) for v in x)), None)
             total += 1
             try:
-                o = OL.Oracle(sw, sh, sf, dw, dh, df, flags, **(opts or {}))
+                o = OL.Oracle(sw, sh, sf, dw, dh, df, flags, param=next((tuple(x) for x in c[7:] if isinstance(x, list) and len(x) == 2 and all(isinstance(v, float) for v in x)), None), **(opts or {}))
                 if cs and o.set_colorspace(*cs) < 0:
                     o = None
             except Exception:
@@ -43,7 +71,9 @@ def main():
             ov = opts or {}
             otxt = f"{1 if opts else 0} {ov.get('dither', 1)} {ov.get('src_range', 0)} {ov.get('dst_range', 0)} {ov.get('src_h_chr_pos', -513)} {ov.get('src_v_chr_pos', -513)} {ov.get('dst_h_chr_pos', -513)} {ov.get('dst_v_chr_pos', -513)}"
             ctxt = "1 " + " ".join(str(v) for v in cs) if cs else "0 0 0 0 0 0 0 0"
-            p.stdin.write(f"CASE {sw} {sh} {sf} {dw} {dh} {df} {flags} 165 {otxt} {ctxt}\n".encode())
+            par = next((x for x in c[7:] if isinstance(x, list) and len(x) == 2 and all(isinstance(v, float) for v in x)), None)
+            ptxt = f"{ov.get('alpha_blend', 0)} {ov.get('gamma_flag', 0)} {par[0] if par else 123456.0} {par[1] if par else 123456.0}"
+            p.stdin.write(f"CASE {sw} {sh} {sf} {dw} {dh} {df} {flags} 165 {otxt} {ctxt} {ptxt}\n".encode())
             for a, rb in zip(src.planes, src.row_bytes):
                 p.stdin.write(np.ascontiguousarray(a[:, :rb]).tobytes())
             p.stdin.flush()
