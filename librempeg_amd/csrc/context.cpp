@@ -232,7 +232,29 @@ void choose_unscaled(SwsInternal *c)
     if ((s == AV_PIX_FMT_PAL8 || isRGB8class(s) || s == AV_PIX_FMT_GRAY8) && (d == AV_PIX_FMT_GBRP || d == AV_PIX_FMT_GBRAP || d == AV_PIX_FMT_RGB24 || d == AV_PIX_FMT_BGR24 ||
                                                    d == AV_PIX_FMT_RGBA || d == AV_PIX_FMT_BGRA || d == AV_PIX_FMT_ARGB || d == AV_PIX_FMT_ABGR))
         k = PLAN_UNSC_PAL2RGB;
-    if (s == d || (s == AV_PIX_FMT_YUVA420P && d == AV_PIX_FMT_YUV420P) || (s == AV_PIX_FMT_YUV420P && d == AV_PIX_FMT_YUVA420P) ||
+    // The same format in the other byte order (s and d are the LE twins: "s == d" alone does not say the caller's formats are equal).  The reference has bswap_16bpc /
+    // bswap_32bpc for the formats of two lists (swscale_unscaled.c:545-597, rules :2560-2617) and lets the simple-copy rule below override them where it applies (same bytes).
+    // Every row of every plane swapped is what the plane / packed copy of this library produces, so the listed formats take those plans -- with ONE exception, which the
+    // reference gets from bswap_16bpc's own row count (every plane, luma included, srcSliceH >> chrDstVSubSample rows): vertically subsampled planar YUV under
+    // SWS_SRC_V_CHR_DROP, where the copy rule does not apply.  That half-written luma plane is not restated on the GPU: refused, never approximated.  (Formats on neither list
+    // -- YUVA planes, the semi-planar families -- go through the scaler under the flag, as in the reference.)  Round 6, found by tools/ref/ref_crosscheck.py
+    if (s == d && c->srcBE != c->dstBE) {
+        static const int list16[] = { AV_PIX_FMT_BAYER_BGGR16LE, AV_PIX_FMT_BAYER_RGGB16LE, AV_PIX_FMT_BAYER_GBRG16LE, AV_PIX_FMT_BAYER_GRBG16LE, AV_PIX_FMT_BGR444LE, AV_PIX_FMT_BGR48LE,
+            AV_PIX_FMT_BGR555LE, AV_PIX_FMT_BGR565LE, AV_PIX_FMT_BGRA64LE, AV_PIX_FMT_GRAY9LE, AV_PIX_FMT_GRAY10LE, AV_PIX_FMT_GRAY12LE, AV_PIX_FMT_GRAY14LE, AV_PIX_FMT_GRAY16LE,
+            AV_PIX_FMT_YA16LE, AV_PIX_FMT_AYUV64LE, AV_PIX_FMT_GBRP9LE, AV_PIX_FMT_GBRP10LE, AV_PIX_FMT_GBRP12LE, AV_PIX_FMT_GBRP14LE, AV_PIX_FMT_GBRP16LE, AV_PIX_FMT_GBRP10MSBLE,
+            AV_PIX_FMT_GBRP12MSBLE, AV_PIX_FMT_GBRAP10LE, AV_PIX_FMT_GBRAP12LE, AV_PIX_FMT_GBRAP14LE, AV_PIX_FMT_GBRAP16LE, AV_PIX_FMT_RGB444LE, AV_PIX_FMT_RGB48LE, AV_PIX_FMT_RGB555LE,
+            AV_PIX_FMT_RGB565LE, AV_PIX_FMT_RGBA64LE, AV_PIX_FMT_XV36LE, AV_PIX_FMT_XV48LE, AV_PIX_FMT_XYZ12LE, AV_PIX_FMT_YUV420P9LE, AV_PIX_FMT_YUV420P10LE, AV_PIX_FMT_YUV420P12LE,
+            AV_PIX_FMT_YUV420P14LE, AV_PIX_FMT_YUV420P16LE, AV_PIX_FMT_YUV422P9LE, AV_PIX_FMT_YUV422P10LE, AV_PIX_FMT_YUV422P12LE, AV_PIX_FMT_YUV422P14LE, AV_PIX_FMT_YUV422P16LE,
+            AV_PIX_FMT_YUV440P10LE, AV_PIX_FMT_YUV440P12LE, AV_PIX_FMT_YUV444P9LE, AV_PIX_FMT_YUV444P10LE, AV_PIX_FMT_YUV444P12LE, AV_PIX_FMT_YUV444P14LE, AV_PIX_FMT_YUV444P16LE,
+            AV_PIX_FMT_YUV444P10MSBLE, AV_PIX_FMT_YUV444P12MSBLE, AV_PIX_FMT_GBRPF32LE, AV_PIX_FMT_GBRAPF32LE };
+        bool listed = false;
+        for (int f : list16) listed = listed || f == s;
+        if (listed) {
+            if (isPlanarYUV(s) && c->chrDstVSubSample > 0 && c->chrDstVSubSample != c->chrSrcVSubSample) unsupported = true;
+            else k = isPackedFmt(s) ? PLAN_UNSC_PACKEDCOPY : PLAN_UNSC_PLANARCOPY;
+        }
+    }
+    if ((s == d && c->srcBE == c->dstBE) || (s == AV_PIX_FMT_YUVA420P && d == AV_PIX_FMT_YUV420P) || (s == AV_PIX_FMT_YUV420P && d == AV_PIX_FMT_YUVA420P) ||
         (isFloatFmt(s) == isFloatFmt(d) && isFloat16Fmt(s) == isFloat16Fmt(d) && ((isPlanarYUV(s) && isGray(d) && !isALPHA(d)) || (isPlanarYUV(d) && isGray(s) && !isALPHA(s)) ||
                                            (isGray(d) && !isALPHA(d) && isGray(s) && !isALPHA(s)))) ||   // isPlanarGray(x) = isGray(x) && !isALPHA(x) (:2673)
         (isFloatFmt(s) == isFloatFmt(d) && isFloat16Fmt(s) == isFloat16Fmt(d) && isPlanarYUV(s) && isPlanarYUV(d) &&

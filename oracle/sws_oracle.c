@@ -268,6 +268,20 @@ static const int be_pairs[][2] = {
     { 104, 105 } /* rgba64 */,
     { 106, 107 } /* bgra64 */
 };
+/* the formats IS_DIFFERENT_ENDIANESS() is asked about for bswap_16bpc (swscale_unscaled.c:2560-2612), as LE twins */
+static int bswap16_listed(int f)
+{
+    const Desc *d = desc_get(f);
+    const char *n = d ? d->name : "";
+    static const char *const names[] = { "bayer_bggr16le", "bayer_rggb16le", "bayer_gbrg16le", "bayer_grbg16le", "bgr444le", "bgr48le", "bgr555le", "bgr565le", "bgra64le",
+        "gray9le", "gray10le", "gray12le", "gray14le", "gray16le", "ya16le", "ayuv64le", "gbrp9le", "gbrp10le", "gbrp12le", "gbrp14le", "gbrp16le", "gbrp10msble", "gbrp12msble",
+        "gbrap10le", "gbrap12le", "gbrap14le", "gbrap16le", "rgb444le", "rgb48le", "rgb555le", "rgb565le", "rgba64le", "xv36le", "xv48le", "xyz12le",
+        "yuv420p9le", "yuv420p10le", "yuv420p12le", "yuv420p14le", "yuv420p16le", "yuv422p9le", "yuv422p10le", "yuv422p12le", "yuv422p14le", "yuv422p16le",
+        "yuv440p10le", "yuv440p12le", "yuv444p9le", "yuv444p10le", "yuv444p12le", "yuv444p14le", "yuv444p16le", "yuv444p10msble", "yuv444p12msble" };
+    for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); i++) if (!strcmp(n, names[i])) return 1;
+    return 0;
+}
+
 static int be_twin(int *fmt)
 {
     for (size_t i = 0; i < sizeof(be_pairs) / sizeof(be_pairs[0]); i++)
@@ -334,13 +348,14 @@ enum { UNSC_NONE = 0, UNSC_YUV2RGB, UNSC_P01X, UNSC_8_P01X, UNSC_PLANAR2NV12,
        UNSC_NV122PLANAR, UNSC_PLANARCOPY, UNSC_RGB2RGB, UNSC_RGBLOW, UNSC_PACKEDCOPY, UNSC_BGR24_YV12, UNSC_GBRP2PACKED,
        UNSC_PLANAR2NV24, UNSC_NV242PLANAR, UNSC_NV242YUV420, UNSC_YVU9_YV12, UNSC_PACKED2GBRP, UNSC_RGB30_TO_16, UNSC_RGB30_TO_GBRP, UNSC_GBRP_TO_RGB30, UNSC_YUV2MONO, UNSC_U8_TO_F32, UNSC_F32_TO_U8,
        UNSC_PLANAR2P422, UNSC_P4222PLANAR,
-       UNSC_RGB16SHUFFLE, UNSC_PACKED16_TO_GBRP16, UNSC_GBRP16_TO_PACKED16, UNSC_ALPHABLEND, UNSC_PLANARRGB_PLANARRGB, UNSC_PAL2RGB, UNSC_BAYER,
+       UNSC_RGB16SHUFFLE, UNSC_PACKED16_TO_GBRP16, UNSC_GBRP16_TO_PACKED16, UNSC_ALPHABLEND, UNSC_PLANARRGB_PLANARRGB, UNSC_PAL2RGB, UNSC_BAYER, UNSC_BSWAP16,
        UNSC_REFUSE = -1 /* a special converter of the reference that is not restated */ };
 
 struct OrSws {
     OrSwsOpts o;
     int src0Alpha, dst0Alpha;
     int src_xyz, dst_xyz; /* handle_xyz (utils.c:822-842): the formats were xyz12, o.src_format / o.dst_format hold rgb48le */
+    int bswap16;          /* the conversion is bswap_16bpc (swscale_unscaled.c:545-570): or_sws_scale() runs it on the caller's planes */
     int src_be, dst_be;   /* the caller's formats were big-endian: o.src_format / o.dst_format hold the LE twins */
     int brightness, contrast, saturation;
     int srcColorspaceTable[4], dstColorspaceTable[4];
@@ -1253,8 +1268,16 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
      * replicated whatever sws_setColorspaceDetails() was given */
     if (usePal(s) && (d == ORF_GBRP || d == ORF_GBRAP || d == ORF_RGB24 || d == ORF_BGR24 || d == ORF_RGBA || d == ORF_BGRA || d == ORF_ARGB || d == ORF_ABGR))
         c->unscaled_kind = UNSC_PAL2RGB;
+    /* bswap_16bpc (:545-570, rule :2560-2612): the same format in the other byte order.  Where the simple-copy rule below applies too it comes later and wins (same bytes);
+     * it does NOT apply to planar YUV with SWS_SRC_V_CHR_DROP (chrSrcVSubSample != chrDstVSubSample), and then bswap_16bpc's own row count shows: EVERY plane, luma
+     * included, gets srcSliceH >> chrDstVSubSample rows.  Formats of the list only (YUVA planes and the semi-planar families are not on it: they go through the scaler).
+     * (c->o formats are the LE twins: "s == d" alone does not say the caller's formats are equal.)  Round 6, found by tools/ref/ref_crosscheck.py */
+    c->bswap16 = 0;
+    if (s == d && c->src_be != c->dst_be && bswap16_listed(s)) { c->unscaled_kind = UNSC_BSWAP16; c->bswap16 = 1; }
+    /* bswap_32bpc (:572-597, rule :2614-2617): gbrpf32 / gbrapf32 in the other byte order -- every row of every plane (no chroma planes): the plane copy's bytes */
+    if (s == d && c->src_be != c->dst_be && (s == ORF_GBRPF32LE || s == ORF_GBRAPF32LE)) c->unscaled_kind = UNSC_PLANARCOPY;
     /* simple copy (:2647-2668) */
-    if (s == d || (s == ORF_YUVA420P && d == ORF_YUV420P) || (s == ORF_YUV420P && d == ORF_YUVA420P) ||
+    if ((s == d && c->src_be == c->dst_be) || (s == ORF_YUVA420P && d == ORF_YUV420P) || (s == ORF_YUV420P && d == ORF_YUVA420P) ||
         (isFloat(s) == isFloat(d) && isFloat16(s) == isFloat16(d) &&
          ((isPlanarYUV(s) && isGray(d) && !isALPHA(d)) || (isPlanarYUV(d) && isGray(s) && !isALPHA(s)) ||
           (isGray(d) && !isALPHA(d) && isGray(s) && !isALPHA(s)))) ||   /* isPlanarGray(x) = isGray(x) && !isALPHA(x) (:2673) */
@@ -1263,6 +1286,7 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
           isSemiPlanarYUV(s) == isSemiPlanarYUV(d) && isSwappedChroma(s) == isSwappedChroma(d)))) {
         if (!isPacked(s)) c->unscaled_kind = UNSC_PLANARCOPY;
         else c->unscaled_kind = UNSC_PACKEDCOPY; /* packedCopyWrapper (:2138-2157) */
+        c->bswap16 = 0;
     }
     /* uint_y_to_float_y_wrapper / float_y_to_uint_y_wrapper (:2639-2647); rules name the native-endian format */
     if (s == ORF_GRAY8 && d == ORF_GRAYF32LE && !c->dst_be) c->unscaled_kind = UNSC_U8_TO_F32;
@@ -4411,6 +4435,21 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
 {
     if (!c || !src || !dst || !srcStride || !dstStride) return -22;
     if (srcSliceY != 0 || srcSliceH != c->o.src_h) return -22; /* oracle: whole frames only */
+    if (c->bswap16) {   /* bswap_16bpc (swscale_unscaled.c:545-570) on the caller's planes: min(|strides|) / 2 words of srcSliceH >> chrDstVSubSample rows of every plane */
+        for (int p = 0; p < 4; p++) {
+            const int srcstr = srcStride[p] / 2, dststr = dstStride[p] / 2;
+            const int min_stride = ORMIN(abs(srcstr), abs(dststr));
+            const uint16_t *sp = (const uint16_t *)src[p];
+            uint16_t *dp = (uint16_t *)dst[p];
+            if (!sp || !dp) continue;
+            dp += (srcSliceY >> c->chrDstVSub) * dststr;
+            for (int i = 0; i < (srcSliceH >> c->chrDstVSub); i++) {
+                for (int j = 0; j < min_stride; j++) dp[j] = (uint16_t)((sp[j] << 8) | (sp[j] >> 8));
+                sp += srcstr; dp += dststr;
+            }
+        }
+        return srcSliceH;
+    }
     if (c->src_be || c->dst_be) {
         const Desc *ds = desc_get(c->o.src_format), *dd = desc_get(c->o.dst_format);
         const uint8_t *sp[4] = { src[0], src[1], src[2], src[3] };
@@ -4553,7 +4592,7 @@ const char *or_sws_path_name(const OrSws *c)
                                "rgbToRgb", "rgbToRgb", "packedCopy", "bgr24ToYv12", "planarRgbToRgb",
                                "planarToNv24", "nv24ToPlanar", "nv24ToYuv420", "yvu9ToYv12", "rgbToPlanarRgb", "rgbToRgb", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "yuv2rgb_c", "uint_y_to_float_y", "float_y_to_uint_y",
                                "planarToYuy2", "yuyvToPlanar",
-                               "rgb16Shuffle", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "alphablendaway", "planarRgbToplanarRgb", "palToRgb", "bayer" };
+                               "rgb16Shuffle", "Rgb16ToPlanarRgb16", "planarRgb16ToRgb16", "alphablendaway", "planarRgbToplanarRgb", "palToRgb", "bayer", "bswap_16bpc" };
     return c->cascade[0] ? "cascade" : n[c->unscaled_kind];
 }
 const int32_t *or_sws_rgb2yuv_table(const OrSws *c) { return c->rgb2yuv; }

