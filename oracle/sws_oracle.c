@@ -355,6 +355,7 @@ struct OrSws {
     OrSwsOpts o;
     int src0Alpha, dst0Alpha;
     int src_xyz, dst_xyz; /* handle_xyz (utils.c:822-842): the formats were xyz12, o.src_format / o.dst_format hold rgb48le */
+    int casc_child_dst_be; /* the alpha-blend cascade's second step writes the caller's (big-endian) byte order itself */
     int bswap16;          /* the conversion is bswap_16bpc (swscale_unscaled.c:545-570): or_sws_scale() runs it on the caller's planes */
     int src_be, dst_be;   /* the caller's formats were big-endian: o.src_format / o.dst_format hold the LE twins */
     int brightness, contrast, saturation;
@@ -1273,7 +1274,12 @@ static void get_unscaled(OrSws *c) /* ff_get_unscaled_swscale, swscale_unscaled.
      * included, gets srcSliceH >> chrDstVSubSample rows.  Formats of the list only (YUVA planes and the semi-planar families are not on it: they go through the scaler).
      * (c->o formats are the LE twins: "s == d" alone does not say the caller's formats are equal.)  Round 6, found by tools/ref/ref_crosscheck.py */
     c->bswap16 = 0;
-    if (s == d && c->src_be != c->dst_be && bswap16_listed(s)) { c->unscaled_kind = UNSC_BSWAP16; c->bswap16 = 1; }
+    if (s == d && c->src_be != c->dst_be && bswap16_listed(s)) {
+        /* everywhere but the row-dropping case the words bswap_16bpc writes are the copy wrappers' between this oracle's byte-order wrappers (which also carry the
+         * xyz12 conversions: xyz12 is rgb48 here as in the reference, utils.c:822-823), so only that case runs the function itself */
+        if (isPlanarYUV(s) && c->chrDstVSub > 0 && c->chrDstVSub != c->chrSrcVSub) { c->unscaled_kind = UNSC_BSWAP16; c->bswap16 = 1; }
+        else c->unscaled_kind = isPacked(s) ? UNSC_PACKEDCOPY : UNSC_PLANARCOPY;
+    }
     /* bswap_32bpc (:572-597, rule :2614-2617): gbrpf32 / gbrapf32 in the other byte order -- every row of every plane (no chroma planes): the plane copy's bytes */
     if (s == d && c->src_be != c->dst_be && (s == ORF_GBRPF32LE || s == ORF_GBRAPF32LE)) c->unscaled_kind = UNSC_PLANARCOPY;
     /* simple copy (:2647-2668) */
@@ -1467,6 +1473,9 @@ static int or_init(OrSws *c) /* ff_sws_init_single_context, utils.c:1137-1835 */
                 c->cascade[0]->o.alpha_blend = c->o.alpha_blend;
                 c->cascade[1] = alloc_set_opts(srcW, srcH, tmpFormat, dstW, dstH, dstFormat, flags, c->o.scaler_params);
                 c->cascade[1]->o.src_range = c->o.src_range; c->cascade[1]->o.dst_range = c->o.dst_range;
+                /* the second step is given the caller's destination format in the reference, byte order included (its temporary is native): its own rules see
+                 * "native -> the other byte order" (bswap_16bpc with SWS_SRC_V_CHR_DROP among them), so it writes the caller's byte order itself */
+                c->cascade[1]->dst_be = c->dst_be; c->casc_child_dst_be = c->dst_be;
                 for (k = 0; k < 4; k++) {
                     c->cascade[1]->o.src_vec[k] = c->o.src_vec[k]; c->cascade[1]->o.src_vec_len[k] = c->o.src_vec_len[k];
                     c->cascade[1]->o.dst_vec_len[k] = c->o.dst_vec_len[k];
@@ -4435,7 +4444,7 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
 {
     if (!c || !src || !dst || !srcStride || !dstStride) return -22;
     if (srcSliceY != 0 || srcSliceH != c->o.src_h) return -22; /* oracle: whole frames only */
-    if (c->bswap16) {   /* bswap_16bpc (swscale_unscaled.c:545-570) on the caller's planes: min(|strides|) / 2 words of srcSliceH >> chrDstVSubSample rows of every plane */
+    if (c->bswap16 && !c->cascade[0] && !c->casc_gamma) {   /* bswap_16bpc (swscale_unscaled.c:545-570) on the caller's planes: min(|strides|) / 2 words of srcSliceH >> chrDstVSubSample rows of every plane */
         for (int p = 0; p < 4; p++) {
             const int srcstr = srcStride[p] / 2, dststr = dstStride[p] / 2;
             const int min_stride = ORMIN(abs(srcstr), abs(dststr));
@@ -4469,7 +4478,7 @@ int or_sws_scale(OrSws *c, const uint8_t *const src[4], const int srcStride[4], 
         }
         ret = scale_xyz(c, sp, ss, srcSliceY, srcSliceH, dst, dstStride);
         for (int k = 0; k < 4; k++) free(tmp[k]);
-        if (ret >= 0 && c->dst_be) {
+        if (ret >= 0 && c->dst_be && !c->casc_child_dst_be) {
             const int unit = dd->c[0].depth == 32 ? 4 : 2;
             for (int k = 0; k < 4; k++) {
                 int rows, rb;
