@@ -10,6 +10,12 @@
 # PYTHONMALLOC=malloc: python's small-object arenas would hide ctypes buffers from the sanitizer (tools/asan_selftest.py checks that an overflow IS seen).
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 export PYTHONMALLOC=malloc
+# SWS_HIPSTUB=1 (a box WITHOUT a GPU): the HIP runtime's test double (tests/hipstub: bounds-checked host memory as device memory, launches dropped) goes behind the
+# sanitizer runtime in the preload list, so that the product's device-state / upload / ring / staging / teardown code runs under ASan here (tools/hipstub_hunt.py)
+if [ "${SWS_HIPSTUB:-0}" = 1 ]; then
+  make -s -C $ROOT/tests/hipstub || exit 1
+  LD_PRELOAD=$ROOT/tests/hipstub/libhipstub.so${LD_PRELOAD:+:$LD_PRELOAD}
+fi
 if [ "${SWS_ASAN_RUNTIME:-clang}" = gnu ]; then
   STUB=$ROOT/tools/bin/libubsan_fn_stub.so
   [ -f $STUB ] || { mkdir -p $ROOT/tools/bin; printf '#include <stdio.h>\nvoid __ubsan_handle_function_type_mismatch(void *d, void *v) { (void)d; (void)v; fprintf(stderr, "ubsan: function type mismatch\\n"); }\nvoid __ubsan_handle_function_type_mismatch_abort(void *d, void *v) { __ubsan_handle_function_type_mismatch(d, v); }\n' > /tmp/ubsan_fn_stub.c; gcc -O2 -shared -fPIC -o $STUB /tmp/ubsan_fn_stub.c; }
