@@ -221,10 +221,12 @@ def load_library():
         return _LIB
     # torch bundles its own ROCm runtime (libamdhip64.so.7 / libhsa-runtime64); load it FIRST so that
     # libswscale_hip.so binds to the same HIP/HSA instance -- two HSA runtimes in one process lose the GPU.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # (SWS_HIP_NO_TORCH=1: a process that will not use torch -- the library then binds to the system ROCm runtime of its RUNPATH)
+    if os.environ.get("SWS_HIP_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     path = library_path()
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build it with librempeg_amd.build_library() "

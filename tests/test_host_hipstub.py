@@ -17,14 +17,16 @@ STUBDIR = os.path.join(ROOT, "tests", "hipstub")
 
 @pytest.fixture(scope="module")
 def stub():
-    r = subprocess.run(["make", "-s", "-C", STUBDIR], capture_output=True, text=True)
+    r = subprocess.run(["make", "-s", "-C", STUBDIR, "all"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return os.path.join(STUBDIR, "libhipstub.so")
 
 
-def _run(stub, code_or_args, tmp_path, ndev=4, script=None, defer=0):
+def _run(stub, code_or_args, tmp_path, ndev=4, script=None, defer=0, rccl=None):
     log = tmp_path / "hipstub.log"
-    env = dict(os.environ, LD_PRELOAD=stub, HIPSTUB_DEFER=str(defer), HIPSTUB_DEVICES=str(ndev), HIPSTUB_LOG=str(log), PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")]))
+    env = dict(os.environ, LD_PRELOAD=stub + (":" + os.path.join(STUBDIR, "librccl.so.1") if rccl is not None else ""), HIPSTUB_DEFER=str(defer), RCCLSTUB_FAIL=rccl or "",
+               SWS_HIP_NO_TORCH="1" if rccl is not None else "0",        # (torch brings its own librccl.so.1: the double must be the one dlopen() finds)
+               HIPSTUB_DEVICES=str(ndev), HIPSTUB_LOG=str(log), PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")]))
     env.pop("SWS_HIP_LIBRARY", None)
     cmd = [sys.executable, script] + code_or_args if script else [sys.executable, "-c", code_or_args]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
@@ -191,3 +193,38 @@ print("NOT REACHED")
     r, _ = _run(stub, code, tmp_path, defer=1)
     assert r.returncode != 0 and "UNCHANGED: OK" in r.stdout and "NOT REACHED" not in r.stdout, r.stdout + r.stderr[-500:]
     assert "PINNED host memory runs after the host rewrote its source" in r.stderr, r.stderr[-500:]
+
+
+RCCL = PEERS.replace('c = SwsContext(640, 360, "yuv420p", 1280, 720, "rgb24", SWS_BICUBIC | SWS_BITEXACT)',
+                     'c = SwsContext(640, 360, "yuv420p", 1280, 720, "rgb24", SWS_BICUBIC | SWS_BITEXACT)\nassert c.set_option("rccl_tables", 1) == 0') + r"""
+import ctypes as C
+R = C.CDLL(None)
+R.rcclstub_broadcasts.restype = R.rcclstub_inits.restype = C.c_ulong
+print("RCCL", R.rcclstub_broadcasts(), R.rcclstub_inits())
+"""
+
+
+@pytest.mark.parametrize("defer", [0, 1])
+def test_rccl_table_delivery(stub, tmp_path, defer):
+    """option rccl_tables over the RCCL test double (csrc/dev_rccl.hip): the home GPU's two table blocks are uploaded once, each goes to the three
+    peers with ONE grouped ncclBroadcast over ONE communicator, the peers' copies read back equal to the upload (sws_hip_debug_check compares hashes), the second call
+    sends nothing.  Immediate and laziest-GPU execution."""
+    r, log = _run(stub, RCCL, tmp_path, defer=defer, rccl="")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "RCCL 2 1" in r.stdout and "LIVE 0" in r.stdout, r.stdout
+    assert all(f"gpu {g}: 2 table blocks checked" in r.stdout for g in range(4)), r.stdout
+    copies = [ln for ln in log.splitlines() if ln.startswith("copy ") and "bytes=192" not in ln]
+    h2d = sorted(int(ln.split("dev=")[1].split()[0]) for ln in copies if "kind=1" in ln)
+    d2d = sorted(int(ln.split("dev=")[1].split()[0]) for ln in copies if "kind=3" in ln)
+    assert h2d == [0, 0] and d2d == [1, 1, 2, 2, 3, 3], (h2d, d2d)
+
+
+@pytest.mark.parametrize("what", ["init", "bcast"])
+def test_rccl_failure_falls_back_to_host_copies(stub, tmp_path, what):
+    """a communicator that cannot be made, a broadcast that fails: not an error of the call -- every GPU gets its tables by the host -> device copy, and they are right"""
+    r, log = _run(stub, RCCL, tmp_path, rccl=what)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "tables go by host -> device copies" in r.stderr, r.stderr[-800:]
+    assert all(f"gpu {g}: 2 table blocks checked" in r.stdout for g in range(4)) and "LIVE 0" in r.stdout, r.stdout
+    copies = [ln for ln in log.splitlines() if ln.startswith("copy ") and "bytes=192" not in ln]
+    assert sorted(int(ln.split("dev=")[1].split()[0]) for ln in copies if "kind=1" in ln) == [0, 0, 1, 1, 2, 2, 3, 3] and not [ln for ln in copies if "kind=3" in ln], copies
