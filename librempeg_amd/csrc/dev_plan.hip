@@ -159,6 +159,7 @@ int dst_kind_of(int f)
 // `strip_ok` under no_strip.  Buffers, streams, the table blocks and their records are not plan state and stay.)
 static void reset_plan_state(DeviceState *d)
 {
+    d->plan_serial++;
     d->unity_h = d->unity_v = d->all_x_mode = false; d->chr_window2 = 0;
     d->tile_ok = d->rgb_march_ok = d->dot2_ok = d->rgb444_ok = d->rgbsrc_ok = d->mixed_ok = d->strip_ok = d->stripLs_ok = d->stripCs_ok = d->striprgb_ok = d->striprgb_long = false;
     d->rgb_groups = 0; d->rgb_ncr = 6; d->rgbsrc_rows = nullptr; d->rgbsrc2_rows = nullptr; d->rgbsrc2_npv = 0;
@@ -677,8 +678,10 @@ int dev_plan_digest(SwsInternal *c, uint64_t out[3])
     int r = dev_prepare(c);
     if (r < 0) return r;
     DeviceState *d = c->dev;
-    std::vector<TableRecord> recs = d->tab_recs;
-    std::sort(recs.begin(), recs.end(), [](const TableRecord &a, const TableRecord &b) { return (uintptr_t)a.dst < (uintptr_t)b.dst; });
+    std::vector<TableRecord> recs;
+    for (const TableRecord &r : d->tab_recs) if (r.serial == d->plan_serial) recs.push_back(r);      // what THIS plan wrote (a re-planned context may still hold blocks of an earlier plan)
+    // (by size and contents, not by address: the digest of a context that ran on a GPU is then comparable with a fresh context's and with the dry planner's)
+    std::sort(recs.begin(), recs.end(), [](const TableRecord &a, const TableRecord &b) { return a.bytes != b.bytes ? a.bytes < b.bytes : a.hash < b.hash; });
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { for (int i = 0; i < 8; i++) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ull; } };
     for (size_t i = 0; i < recs.size(); i++) { mix(i); mix(recs[i].bytes); mix(recs[i].hash); }

@@ -207,13 +207,13 @@ int table_put(SwsInternal *c, DeviceState *d, void *dst, const void *src, size_t
     if (!bytes) return 0;
     if (d->dry) {
         table_records_drop(d, dst, bytes);
-        d->tab_recs.push_back({ dst, bytes, fnv1a64(src, bytes) });
+        d->tab_recs.push_back({ dst, bytes, fnv1a64(src, bytes), d->plan_serial });
         return 0;
     }
     if (d->defer_uploads) {     // a peer GPU of an RCCL-fed call: the block arrives by broadcast from the home GPU (dev_rccl.hip), or by this very copy if that fails
         table_records_drop(d, dst, bytes);
         const uint64_t h = fnv1a64(src, bytes);
-        d->tab_recs.push_back({ dst, bytes, h });
+        d->tab_recs.push_back({ dst, bytes, h, d->plan_serial });
         for (size_t i = 0; i < d->deferred.size();)      // (a block rewritten within one planning run: the last contents count)
             if ((const uint8_t *)d->deferred[i].dst < (const uint8_t *)dst + bytes && (const uint8_t *)dst < (const uint8_t *)d->deferred[i].dst + d->deferred[i].bytes) d->deferred.erase(d->deferred.begin() + (long)i);
             else i++;
@@ -223,7 +223,7 @@ int table_put(SwsInternal *c, DeviceState *d, void *dst, const void *src, size_t
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     table_records_drop(d, dst, bytes);
-    d->tab_recs.push_back({ dst, bytes, fnv1a64(src, bytes) });
+    d->tab_recs.push_back({ dst, bytes, fnv1a64(src, bytes), d->plan_serial });
     if (verify_uploads()) {
         std::vector<uint8_t> back(bytes);
         HIPCHK(hipMemcpyAsync(back.data(), dst, bytes, hipMemcpyDeviceToHost, d->stream));

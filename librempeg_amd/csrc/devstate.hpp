@@ -34,7 +34,7 @@ enum { TAB_MAIN = 0, TAB_AUX0 = 1 /* .. TAB_AUX0 + 4 */, TAB_FRAMES2 = 6 };
 
 // What table_put() uploaded into a device table block: kept so that sws_hip_debug_check() can read the block back at any later time and say whether the
 // context's device tables are still what the host built (the rare events whose context stays wrong for its lifetime)
-struct TableRecord { const void *dst; size_t bytes; uint64_t hash; };
+struct TableRecord { const void *dst; size_t bytes; uint64_t hash; uint64_t serial; };   // serial: the planning run that wrote it (DeviceState::plan_serial)
 
 // a peer GPU's table upload held back for the RCCL broadcast of dev_rccl.hip (the host copy stays for the fallback)
 struct TableDeferred { void *dst; size_t bytes; uint64_t hash; std::vector<uint8_t> data; };
@@ -45,6 +45,7 @@ struct DeviceState {
     std::vector<TableDeferred> deferred;
     bool dry = false;          // Tuning::dry_plan: planned without a GPU (fake table addresses, nothing uploaded, never launched)
     std::vector<TableRecord> tab_recs;
+    uint64_t plan_serial = 0;       // counts planning runs (reset_plan_state): a block a re-plan no longer writes keeps its old serial and stays out of the plan digest
     uint64_t params_hash = 0;  // hash of `params` as dev_prepare_on() left it
     hipStream_t stream = nullptr;
     bool own_stream = false;

@@ -105,6 +105,12 @@ def slice_ptrs(frame, fmt, y0):
     return q, s
 
 
+def plan_digest(p):
+    dg = (C.c_uint64 * 3)()
+    p.L.sws_hip_plan.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    return (p.L.sws_hip_plan(p.c, dg), dg[0])
+
+
 def parts(c):
     opts = next((x for x in c[7:] if isinstance(x, dict) and ("dither" in x or "src_range" in x or "threads" in x)), None)
     tune = next((x for x in c[7:] if isinstance(x, dict) and x is not opts and any(k.startswith(("strip_", "no_")) for k in x)), None)
@@ -138,14 +144,15 @@ def interleaved(n, seed, rng, stats, failures):
             if cs and p.set_colorspace(*cs) < 0:
                 p.close()
                 continue
-            pool.append(dict(p=p, c=c, frames=[], pairs=[]))
+            pool.append(dict(p=p, c=c, frames=[], pairs=[], tune=dict(tune or {}), opts=opts, cs=cs))
         elif op < 0.82:
             e = rng.choice(pool)
             p, c = e["p"], e["c"]
             sw, sh, sf, dw, dh, df = c[:6]
             if rng.random() < 0.15:
                 k = rng.choice(TUNE)
-                p.set_option(k, rng.choice(TUNE_VALUES.get(k, [0, 1])))                  # the next conversion re-plans
+                e["tune"][k] = rng.choice(TUNE_VALUES.get(k, [0, 1]))
+                p.set_option(k, e["tune"][k])                                            # the next conversion re-plans
             nb = rng.randint(1, 4)
             pairs = []
             for i in range(nb):
@@ -163,6 +170,24 @@ def interleaved(n, seed, rng, stats, failures):
             r = p.scale_frames([s for s, _ in pairs], [d for _, d in pairs]) if (len(pairs) > 1 or rng.random() < 0.5) else p.scale(*pairs[0])
             done += 1
             stats["total"] += 1
+            if r > 0 and rng.random() < 0.25:
+                # what this long-lived, re-planned context now holds against a FRESH context given the same options and the same frames: the path, the kernel
+                # and the contents of every table block (digest 0 of sws_hip_plan: no addresses in it)
+                q = S.SwsContext(*c[:7], **(e["opts"] or {}))
+                for k, v in e["tune"].items():
+                    q.set_option(k, v)
+                if e["cs"]:
+                    q.set_colorspace(*e["cs"])
+                if len(pairs) > 1:
+                    q.scale_frames([s for s, _ in pairs], [d for _, d in pairs])
+                else:
+                    q.scale(*pairs[0])
+                a, b = (p.path(), p.kernel_name(), plan_digest(p)), (q.path(), q.kernel_name(), plan_digest(q))
+                stats["compared"] = stats.get("compared", 0) + 1
+                if a != b:
+                    stats["stale_state"] = stats.get("stale_state", 0) + 1
+                    failures.append(("a long-lived context differs from a fresh one", c[:7], e["tune"], a, b))
+                q.close()
             if r != (len(pairs) if (len(pairs) > 1 or r == 1) else dh) and r != dh:
                 stats["failed_calls"] += 1
                 failures.append(("call failed (interleaved)", c[:7], r, p.path()))
