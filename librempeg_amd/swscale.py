@@ -367,13 +367,19 @@ class HostFrame:
 
 
 class DeviceFrame:
-    """HBM-resident frame backed by ONE torch uint8 tensor (planes at 256-byte aligned offsets)."""
+    """HBM-resident frame backed by ONE torch uint8 tensor (planes at 256-byte aligned offsets).
+
+    The tensor is allocated with GUARD bytes of a known pattern on either side of `buf` (the part the frame and the tests' prefills use); download() checks them, so a
+    kernel that writes outside the destination picture it was given fails the conversion that did it, in every GPU test, instead of damaging whatever torch placed
+    next to the frame (hunt for the writer, not the victim)."""
+    GUARD = 1024
+    GUARD_BYTE = 0xA5
 
     def __init__(self, fmt, w, h, device="cuda:0"):
         import torch
         self.fmt, self.w, self.h = fmt, w, h
         self.linesize, self.offset, self.total = image_layout(fmt, w, h, 256)
-        self.buf = torch.zeros(self.total + 256, dtype=torch.uint8, device=device)
+        self._allocate(self.total + 256, device)
         base = self.buf.data_ptr()
         self.base = (base + 255) // 256 * 256
         self._shift = self.base - base
@@ -410,11 +416,31 @@ class DeviceFrame:
         torch.cuda.synchronize()  # the context runs on its own stream: make the upload visible to it
         return self
 
+    def _allocate(self, nbytes, device):
+        """`buf` = nbytes zeroed bytes between two guard bands of one allocation"""
+        import torch
+        G = self.GUARD
+        self._alloc = torch.full((G + nbytes + G,), self.GUARD_BYTE, dtype=torch.uint8, device=device)
+        self.buf = self._alloc[G:G + nbytes]
+        self.buf.zero_()
+
+    def check_guards(self):
+        """raises if anything wrote into the guard bytes around the frame (host-synchronous)"""
+        G = self.GUARD
+        if getattr(self, "_alloc", None) is None or self.buf.data_ptr() != self._alloc.data_ptr() + G:
+            return      # a frame whose storage a test replaced with its own
+        lo, hi = self._alloc[:G], self._alloc[G + self.buf.numel():]
+        bad_lo, bad_hi = int((lo != self.GUARD_BYTE).sum()), int((hi != self.GUARD_BYTE).sum())
+        if bad_lo or bad_hi:
+            raise AssertionError(f"{self.fmt} {self.w}x{self.h} frame at {self.base:#x}: {bad_lo} guard bytes BEFORE and {bad_hi} AFTER the frame were overwritten "
+                                 f"(something wrote outside the picture it was given)")
+
     def download(self, host=None):
         host = host or HostFrame(self.fmt, self.w, self.h)
         for i, a in enumerate(host.planes):
             rb = self.row_bytes[i]
             a[:, :rb] = self.plane_tensor(i)[:, :rb].cpu().numpy()
+        self.check_guards()
         return host
 
 

@@ -23,7 +23,7 @@ def _odd_frame(fmt, w, h, pad, shift):
         off.append(o); ls.append(rb + pad)
         o = (o + (rb + pad) * rows + 255) // 256 * 256 + shift
     f.linesize, f.offset, f.total = ls + [0] * (4 - len(ls)), off + [0] * (4 - len(off)), o
-    f.buf = torch.zeros(o + 256, dtype=torch.uint8, device="cuda:0")
+    f._allocate(o + 256, "cuda:0")           # (guard bands on either side: download() checks them)
     base = f.buf.data_ptr()
     f.base = (base + 255) // 256 * 256
     f._shift = f.base - base
