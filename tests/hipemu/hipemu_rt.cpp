@@ -8,9 +8,28 @@
 #include <sys/mman.h>
 #include <ucontext.h>
 
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <string>
 #include <vector>
+
+// AddressSanitizer must be told about every stack switch (make asan)
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#include <sanitizer/common_interface_defs.h>
+#define HIPEMU_ASAN 1
+#endif
+#endif
+#ifdef HIPEMU_ASAN
+#define FIBER_START_SWITCH(save, bottom, size) __sanitizer_start_switch_fiber((save), (bottom), (size))
+#define FIBER_FINISH_SWITCH(save, bottom, size) __sanitizer_finish_switch_fiber((save), (bottom), (size))
+#else
+#define FIBER_START_SWITCH(save, bottom, size) ((void)0)
+#define FIBER_FINISH_SWITCH(save, bottom, size) ((void)0)
+#endif
 
 namespace swsk { alignas(4096) unsigned char smem[160 * 1024 + 4096]; }      // the dynamic LDS of `extern __shared__ uint8_t smem[]`
 namespace swship { alignas(4096) unsigned char smem[160 * 1024 + 4096]; }
@@ -20,7 +39,7 @@ namespace hipemu {
 Ctx *cur = nullptr;
 
 namespace {
-constexpr size_t STACK = 256 * 1024;
+constexpr size_t STACK = 4096 * 1024;     // (-O0 frames of the generic kernels pass 800-byte argument structs down many levels)
 constexpr int MAXT = 1024, MAXW = MAXT / 64;
 enum { READY, WAIT_WAVE, WAIT_BLOCK, DONE };
 struct Fiber { ucontext_t ctx; Ctx c; int state; unsigned gen; };
@@ -35,18 +54,30 @@ void (*g_thunk)(void *); void *g_closure; const char *g_name = "?";
 unsigned long g_launches = 0, g_threads = 0;
 const bool g_reverse = std::getenv("HIPEMU_REVERSE") && std::atoi(std::getenv("HIPEMU_REVERSE"));
 
+const void *sched_bottom = nullptr; size_t sched_size = 0;
+// from a fiber back to the scheduler, to be resumed later
+void yield(Fiber &f)
+{
+    void *fake = nullptr;
+    FIBER_START_SWITCH(&fake, sched_bottom, sched_size);
+    swapcontext(&f.ctx, &sched);
+    FIBER_FINISH_SWITCH(fake, nullptr, nullptr);
+}
+
 void release_wave(int w) { arrived_wave[w] = 0; gen_wave[w]++; }
 void release_block() { arrived_block = 0; gen_block++; }
 
 void entry()
 {
     Fiber &f = fib[cur_i];
+    FIBER_FINISH_SWITCH(nullptr, &sched_bottom, &sched_size);
     g_thunk(g_closure);
     f.state = DONE;
     const int w = f.c.wave;
     live_block--; live_wave[w]--;
     if (arrived_wave[w] && arrived_wave[w] == live_wave[w]) release_wave(w);       // the others were waiting for this lane only
     if (arrived_block && arrived_block == live_block) release_block();
+    FIBER_START_SWITCH(nullptr, sched_bottom, sched_size);      // (this fiber's stack is done with)
     swapcontext(&f.ctx, &sched);
 }
 } // namespace
@@ -57,7 +88,7 @@ void sync_wave()
     const int w = f.c.wave;
     if (++arrived_wave[w] == live_wave[w]) { release_wave(w); return; }
     f.state = WAIT_WAVE; f.gen = gen_wave[w];
-    while (gen_wave[w] == f.gen) swapcontext(&f.ctx, &sched);
+    while (gen_wave[w] == f.gen) yield(f);
     f.state = READY;
     cur = &f.c;
 }
@@ -67,7 +98,7 @@ void sync_block()
     Fiber &f = fib[cur_i];
     if (++arrived_block == live_block) { release_block(); return; }
     f.state = WAIT_BLOCK; f.gen = gen_block;
-    while (gen_block == f.gen) swapcontext(&f.ctx, &sched);
+    while (gen_block == f.gen) yield(f);
     f.state = READY;
     cur = &f.c;
 }
@@ -80,6 +111,32 @@ unsigned long long wave_read(unsigned long long v, int src_lane)
     const unsigned long long r = slots[f.c.wave][src_lane & 63];
     sync_wave();
     return r;
+}
+
+bool check_buffers = std::getenv("HIPEMU_CHECK_BUFFERS") && std::atoi(std::getenv("HIPEMU_CHECK_BUFFERS"));
+namespace {
+struct Oob { unsigned long count; unsigned long long max_past; };
+std::map<std::string, Oob> g_oob;
+typedef int (*find_block_t)(const void *, unsigned long long *, unsigned long long *);
+}
+bool in_block(const void *p, unsigned bytes, bool store)
+{
+    static find_block_t find = (find_block_t)dlsym(RTLD_DEFAULT, "hipstub_find_block");
+    if (!find) return true;
+    unsigned long long base = 0, size = 0;
+    if (find(p, &base, &size) && (unsigned long long)(uintptr_t)p + bytes <= base + size) return true;
+    if (store) {
+        std::fprintf(stderr, "hipemu: %s: a buffer STORE of %u bytes at %p leaves the device block it starts in (or is in none)\n", g_name, bytes, p);
+        std::abort();
+    }
+    // how far past the end of the nearest block below
+    unsigned long long past = 0;
+    for (unsigned back = 1; back <= 4096 && !past; back++)
+        if (find((const unsigned char *)p - back, &base, &size)) past = (unsigned long long)(uintptr_t)p + bytes - (base + size);
+    Oob &o = g_oob[g_name];
+    o.count++;
+    if (past > o.max_past) o.max_past = past;
+    return false;
 }
 
 unsigned char *lds_ptr(unsigned lds_addr)
@@ -131,7 +188,12 @@ void run_grid(const char *name, dim3 grid, dim3 block, size_t shmem, void (*thun
                         if (f.state == WAIT_WAVE && gen_wave[f.c.wave] == f.gen) continue;
                         if (f.state == WAIT_BLOCK && gen_block == f.gen) continue;
                         cur_i = t; cur = &f.c;
-                        swapcontext(&sched, &f.ctx);
+                        {
+                            void *fake = nullptr;
+                            FIBER_START_SWITCH(&fake, stacks + (size_t)t * STACK, STACK);
+                            swapcontext(&sched, &f.ctx);
+                            FIBER_FINISH_SWITCH(fake, nullptr, nullptr);
+                        }
                         progress = true;
                         if (f.state == DONE) done++;
                     }
@@ -146,5 +208,13 @@ void run_grid(const char *name, dim3 grid, dim3 block, size_t shmem, void (*thun
 
 } // namespace hipemu
 
+// one line per kernel whose buffer loads left their block: "name count max_bytes_past_the_end"
+extern "C" int hipemu_oob_report(char *buf, int cap)
+{
+    std::string s;
+    for (auto &e : hipemu::g_oob) { char line[512]; std::snprintf(line, sizeof(line), "%s %lu %llu\n", e.first.c_str(), e.second.count, e.second.max_past); s += line; }
+    if (buf && cap > 0) { std::snprintf(buf, cap, "%s", s.c_str()); }
+    return (int)hipemu::g_oob.size();
+}
 extern "C" unsigned long hipemu_launches(void) { return hipemu::g_launches; }
 extern "C" unsigned long hipemu_threads(void) { return hipemu::g_threads; }

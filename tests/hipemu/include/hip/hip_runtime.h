@@ -95,6 +95,11 @@ inline unsigned sat_u8(int v) { return v < 0 ? 0u : v > 255 ? 255u : (unsigned)v
 inline unsigned pack4_u8_shr(int t0, int t1, int t2, int t3, int n) { return sat_u8(t0 >> n) | (sat_u8(t1 >> n) << 8) | (sat_u8(t2 >> n) << 16) | (sat_u8(t3 >> n) << 24); }
 inline int dot2_i16(unsigned a, unsigned b, int c) { return (int)((unsigned)((short)a * (int)(short)b) + (unsigned)((short)(a >> 16) * (int)(short)(b >> 16)) + (unsigned)c); }
 
+// HIPEMU_CHECK_BUFFERS=1: every dword a buffer instruction moves is looked up in the test double's device blocks first.  A LOAD that leaves its block is counted per
+// kernel and answers 0 (on the GPU it reads whatever is mapped there -- the descriptor's range check does not cover the SGPR offset the kernels put the row into);
+// a STORE that leaves its block aborts.
+extern bool check_buffers;
+bool in_block(const void *p, unsigned bytes, bool store);
 struct Range { const unsigned char *p; unsigned long long room; };
 inline Range buf_at(const __amdgpu_buffer_rsrc_t &r, int voff, int soff)
 {
@@ -108,17 +113,17 @@ inline Range buf_at(const __amdgpu_buffer_rsrc_t &r, int voff, int soff)
 template <int NDW> inline void buf_load(const __amdgpu_buffer_rsrc_t &r, int voff, int soff, unsigned *out)
 {
     const Range g = buf_at(r, voff, soff);
-    for (int i = 0; i < NDW; i++) { if (g.room >= 4ull * i + 4) std::memcpy(&out[i], g.p + 4 * i, 4); else out[i] = 0; }
+    for (int i = 0; i < NDW; i++) { if (g.room >= 4ull * i + 4 && (!check_buffers || in_block(g.p + 4 * i, 4, false))) std::memcpy(&out[i], g.p + 4 * i, 4); else out[i] = 0; }
 }
 template <int NDW> inline void buf_store(const __amdgpu_buffer_rsrc_t &r, int voff, int soff, const unsigned *in)
 {
     const Range g = buf_at(r, voff, soff);
-    for (int i = 0; i < NDW; i++) if (g.room >= 4ull * i + 4) std::memcpy(const_cast<unsigned char *>(g.p) + 4 * i, &in[i], 4);
+    for (int i = 0; i < NDW; i++) if (g.room >= 4ull * i + 4 && (!check_buffers || in_block(g.p + 4 * i, 4, true))) std::memcpy(const_cast<unsigned char *>(g.p) + 4 * i, &in[i], 4);
 }
 inline void buf_store_small(const __amdgpu_buffer_rsrc_t &r, int voff, int soff, unsigned v, int bytes)
 {
     const Range g = buf_at(r, voff, soff);
-    if (g.room >= (unsigned)bytes) std::memcpy(const_cast<unsigned char *>(g.p), &v, bytes);
+    if (g.room >= (unsigned)bytes && (!check_buffers || in_block(g.p, (unsigned)bytes, true))) std::memcpy(const_cast<unsigned char *>(g.p), &v, bytes);
 }
 // buffer_load_dwordx4 ... offen lds under an EXEC mask: lane L's 16 bytes go to LDS address M0 + 16 L
 inline void dma16(unsigned lds_dst, int voff, const hipemu_i32x4 &rsrc, int soff, unsigned mask_lo, unsigned mask_hi)

@@ -105,8 +105,10 @@ def main():
             q = os.path.join(dst, name)
             if not os.path.exists(q) or open(q).read() != new:
                 open(q, "w").write(new)
-        elif name == "Makefile" or name.endswith(".v"):
+        elif name == "Makefile":
             shutil.copy(p, os.path.join(dst, name))
+        elif name.endswith(".v"):           # the emulator's counters are exported next to the library's own symbols
+            open(os.path.join(dst, name), "w").write(open(p).read().replace("global:", "global:\n        hipemu_*;", 1))
 
 
 if __name__ == "__main__":

@@ -144,11 +144,17 @@ def main():
     paths = stats.pop("paths", {})
     for k in sorted(paths):
         print(f"   {k}: {paths[k][0]} compared, {paths[k][1]} different")
-    E = C.CDLL(None)
+    E = S.load_library()
     extra = ""
     if hasattr(E, "hipemu_threads"):
         E.hipemu_threads.restype = E.hipemu_launches.restype = C.c_ulong
         extra = f"; {E.hipemu_launches()} launches, {E.hipemu_threads()} kernel threads executed"
+        if hasattr(E, "hipemu_oob_report"):
+            buf = C.create_string_buffer(1 << 16)
+            if E.hipemu_oob_report(buf, len(buf)):
+                print("buffer LOADS that left their device block (HIPEMU_CHECK_BUFFERS=1; kernel, dwords, most bytes past the end):")
+                for ln in buf.value.decode().splitlines():
+                    print("   ", ln)
     print(f"{stats}{extra}")
     return 1 if failures else 0
 

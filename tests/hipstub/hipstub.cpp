@@ -603,6 +603,16 @@ hipError_t hipLaunchKernel(const void *f, dim3 grid, dim3 block, void **args, si
 }
 
 // for the tests
+// the live device block that holds p: 1 and its bounds, or 0 (tests/hipemu checks the kernels' buffer accesses against it)
+int hipstub_find_block(const void *p, unsigned long long *base, unsigned long long *bytes)
+{
+    LOCK;
+    uintptr_t b;
+    const Block *blk = find(p, &b);
+    if (!blk || blk->dead) return 0;
+    *base = b; *bytes = blk->bytes;
+    return 1;
+}
 unsigned long hipstub_launches(void) { LOCK; return S().launches; }
 unsigned long hipstub_copies(void) { LOCK; return S().copies; }
 unsigned long hipstub_live_blocks(void)
