@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -150,6 +151,8 @@ void run_grid(const char *name, dim3 grid, dim3 block, size_t shmem, void (*thun
     const unsigned long long n = (unsigned long long)block.x * block.y * block.z;
     if (!grid.x || !grid.y || !grid.z || !n || n > MAXT || shmem > 160 * 1024) { std::fprintf(stderr, "hipemu: invalid launch of %s\n", name); std::abort(); }
     if (((uintptr_t)swsk::smem >> 32) != (((uintptr_t)swsk::smem + sizeof(swsk::smem)) >> 32)) { std::fprintf(stderr, "hipemu: the LDS arena crosses a 4 GiB line\n"); std::abort(); }
+    static std::mutex one_launch;                 // (the library launches from one host thread per GPU when a batch spans several: the emulator runs them in turn)
+    std::lock_guard<std::mutex> only(one_launch);
     if (cur_i >= 0) { std::fprintf(stderr, "hipemu: nested launch\n"); std::abort(); }
     if (!stacks) {
         stacks = (unsigned char *)mmap(nullptr, STACK * MAXT, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
