@@ -25,6 +25,8 @@ class GuardedFrame(DeviceFrame):
 
     def __init__(self, fmt, w, h, device="cuda:0"):
         import torch
+        if os.environ.get("SWS_SUITE_ON_EMU") == "1":       # (tests/conftest.py: the suite against the x86 emulation build, CPU box)
+            device = "cpu"
         self.fmt, self.w, self.h = fmt, w, h
         self.linesize, self.offset, self.total = image_layout(fmt, w, h, 256)
         self.buf = torch.zeros(GUARD + self.total + 256 + GUARD, dtype=torch.uint8, device=device)
