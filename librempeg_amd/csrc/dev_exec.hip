@@ -665,10 +665,11 @@ int image_layout(int format, int w, int h, int align, int linesize[4], size_t of
         off += (size_t)linesize[pl] * rows;
         off = (off + 255) & ~(size_t)255;
     }
-    // 1 KiB of readable tail: the marching kernels fetch a row in 16-byte chunks of its window through a whole-plane buffer descriptor with the row offset in the
-    // SGPR operand, which the descriptor's range check does not cover -- in the last rows of a plane the chunks of lanes beyond the picture (never stored) reach
-    // up to 384 bytes past its end (measured on the x86 emulation of the kernels, profiles/r06_emulation.md; INTEGRATION.md 3 states the contract for callers' own frames)
-    *total = off + 1024;
+    // 2 KiB of readable tail: the marching kernels fetch a row in 16-byte chunks through a whole-plane buffer descriptor with the row offset in the SGPR operand,
+    // which the descriptor's range check does not cover -- in the last rows of a plane the chunks of lanes beyond the picture (never stored) reach behind its end:
+    // by up to one 1 024-byte row segment in sws_k_rgb_march (768 bytes seen on the x86 emulation of the kernels, profiles/r06_emulation.md), 16 bytes in the strip
+    // kernels.  INTEGRATION.md 3 states the contract for callers' own frames
+    *total = off + 2048;
     return 0;
 }
 

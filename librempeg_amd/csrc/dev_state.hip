@@ -302,8 +302,8 @@ int grow(SwsInternal *c, void **buf, size_t *cap, size_t need)
     guard_forget(*buf);
     if (*buf) HIPCHK(hipFree(*buf));   // (hipFree waits for the device: nothing in flight can still be using the old block)
     *buf = nullptr; *cap = 0;
-    // (+ 1 KiB: the readable tail the marching kernels' chunked row loads may reach behind a picture that ends the block, dev_exec.hip image_layout)
-    HIPCHK(hipMalloc(buf, need + (guards_enabled() ? GUARD_BYTES : 0) + 1024));
+    // (+ 2 KiB: the readable tail the marching kernels' chunked row loads may reach behind a picture that ends the block, dev_exec.hip image_layout)
+    HIPCHK(hipMalloc(buf, need + (guards_enabled() ? GUARD_BYTES : 0) + 2048));
     *cap = need;
     { int r_ = poison(c, *buf, need); if (r_ < 0) return r_; }
     return guard_arm(c, *buf, need);
