@@ -595,6 +595,7 @@ static int launch_plan_xyz(SwsInternal *c, DeviceState *d, const SwsFramePtrs *f
 
 int launch_plan(SwsInternal *c, DeviceState *d, const SwsFramePtrs *frames, int n, int sliceY, int sliceH)
 {
+    { int v_ = verify_tables_once(c, d); if (v_ < 0) return v_; }       // (first launch of a plan: its table blocks are read back once, dev_state.hip)
     if (!c->srcBE && !c->dstBE) return launch_plan_xyz(c, d, frames, n, sliceY, sliceH);
     hipStream_t st = d->stream;
     const SwsContext &o = c->opts;

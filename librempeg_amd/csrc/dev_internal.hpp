@@ -18,6 +18,9 @@ uint64_t fnv1a64(const void *p, size_t n);
 int table_alloc(SwsInternal *c, DeviceState *d, void **buf, size_t *cap, size_t need);
 int table_put(SwsInternal *c, DeviceState *d, void *dst, const void *src, size_t bytes);
 int dev_check_state(SwsInternal *c, DeviceState *d, std::string &out);
+// bit 63 of TableRecord::serial: the block was read back and compared with its upload at the first launch of the plan that wrote it (verify_tables_once)
+constexpr uint64_t TAB_VERIFIED = 1ull << 63;
+int verify_tables_once(SwsInternal *c, DeviceState *d);
 int ptr_device(const void *p);                               // HIP device that owns a pointer, -1 for host memory
 bool is_device_ptr(const void *p);
 // ---- dev_rccl.hip ----

@@ -679,7 +679,7 @@ int dev_plan_digest(SwsInternal *c, uint64_t out[3])
     if (r < 0) return r;
     DeviceState *d = c->dev;
     std::vector<TableRecord> recs;
-    for (const TableRecord &r : d->tab_recs) if (r.serial == d->plan_serial) recs.push_back(r);      // what THIS plan wrote (a re-planned context may still hold blocks of an earlier plan)
+    for (const TableRecord &r : d->tab_recs) if ((r.serial & ~TAB_VERIFIED) == d->plan_serial) recs.push_back(r);      // what THIS plan wrote (a re-planned context may still hold blocks of an earlier plan)
     // (by size and contents, not by address: the digest of a context that ran on a GPU is then comparable with a fresh context's and with the dry planner's)
     std::sort(recs.begin(), recs.end(), [](const TableRecord &a, const TableRecord &b) { return a.bytes != b.bytes ? a.bytes < b.bytes : a.hash < b.hash; });
     uint64_t h = 1469598103934665603ull;

@@ -269,6 +269,30 @@ int dev_check_state(SwsInternal *c, DeviceState *d, std::string &out)
     return bad;
 }
 
+// The always-on integrity check of the advisor's round-5 review: at the FIRST launch of a plan, every table block that plan wrote is read back once and compared with the
+// hash of its upload -- a block damaged between upload and use (another context's stray store, a failed copy) fails that conversion loudly and names the context, instead
+// of giving wrong pictures for the context's lifetime.  One device -> host copy of the tables (tens to a few hundred KB) and one wait per plan;
+// SWS_HIP_NO_TABLE_VERIFY=1 switches it off.  Exercised on the CPU box over tests/hipstub (every conversion of tools/hipstub_hunt.py passes through it).
+int verify_tables_once(SwsInternal *c, DeviceState *d)
+{
+    static const bool off = std::getenv("SWS_HIP_NO_TABLE_VERIFY") && std::atoi(std::getenv("SWS_HIP_NO_TABLE_VERIFY")) > 0;
+    if (off || !d || d->dry || !d->stream) return 0;
+    std::vector<uint8_t> back;
+    for (TableRecord &r : d->tab_recs) {
+        if ((r.serial & ~TAB_VERIFIED) != d->plan_serial || (r.serial & TAB_VERIFIED)) continue;
+        back.resize(r.bytes);
+        HIPCHK(hipMemcpyAsync(back.data(), r.dst, r.bytes, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        if (fnv1a64(back.data(), r.bytes) != r.hash) {
+            log_msg(c, 0, "gpu %d: table block %p (%zu bytes) no longer holds what was uploaded to it: refusing to convert with it (the context re-plans on the next call)\n", d->device, r.dst, r.bytes);
+            d->epoch = 0;
+            return AVERROR_EXTERNAL_;
+        }
+        r.serial |= TAB_VERIFIED;
+    }
+    return 0;
+}
+
 // HIP device that owns a pointer, -1 for host memory
 int ptr_device(const void *p)
 {

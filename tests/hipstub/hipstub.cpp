@@ -613,6 +613,14 @@ int hipstub_find_block(const void *p, unsigned long long *base, unsigned long lo
     *base = b; *bytes = blk->bytes;
     return 1;
 }
+// flips one byte in the middle of the first live device block of exactly `bytes` bytes (the tests damage a table block with it); 1 if there was one
+int hipstub_scribble(unsigned long long bytes)
+{
+    LOCK;
+    for (auto &b : S().blocks)
+        if (!b.second.dead && !b.second.host && b.second.bytes == bytes) { ((unsigned char *)b.first)[bytes / 2] ^= 0x40; return 1; }
+    return 0;
+}
 unsigned long hipstub_launches(void) { LOCK; return S().launches; }
 unsigned long hipstub_copies(void) { LOCK; return S().copies; }
 unsigned long hipstub_live_blocks(void)

@@ -228,3 +228,35 @@ def test_rccl_failure_falls_back_to_host_copies(stub, tmp_path, what):
     assert all(f"gpu {g}: 2 table blocks checked" in r.stdout for g in range(4)) and "LIVE 0" in r.stdout, r.stdout
     copies = [ln for ln in log.splitlines() if ln.startswith("copy ") and "bytes=192" not in ln]
     assert sorted(int(ln.split("dev=")[1].split()[0]) for ln in copies if "kind=1" in ln) == [0, 0, 1, 1, 2, 2, 3, 3] and not [ln for ln in copies if "kind=3" in ln], copies
+
+
+def test_a_damaged_table_block_fails_the_first_conversion_loudly(stub, tmp_path):
+    """the always-on integrity check (csrc/dev_state.hip verify_tables_once): a table block that no longer holds its upload when the plan is first launched fails THAT call
+    with a message naming the block; the context re-plans and converts on the next call; an undamaged context reads its tables back exactly once"""
+    code = r"""
+import ctypes as C, sys
+sys.argv = ["x", "1", "1"]
+import hipstub_hunt as H
+from librempeg_amd import SwsContext, SWS_BICUBIC, SWS_BITEXACT
+c = SwsContext(640, 360, "yuv420p", 1280, 720, "rgb24", SWS_BICUBIC | SWS_BITEXACT)
+c.L.sws_hip_plan.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+assert c.L.sws_hip_plan(c.c, (C.c_uint64 * 3)()) == 0          # planned: the tables are on the "GPU", nothing launched yet
+H.STUB.hipstub_scribble.argtypes = [C.c_ulonglong]
+assert H.STUB.hipstub_scribble(130688) == 1                     # (the larger of this conversion's two table blocks)
+s, d = H.StubFrame("yuv420p", 640, 360, 0), H.StubFrame("rgb24", 1280, 720, 0)
+r1 = c.scale(s, d)
+print("FIRST", r1, H.STUB.hipstub_launches(), flush=True)
+r2 = c.scale(s, d)
+print("SECOND", r2, H.STUB.hipstub_launches(), flush=True)
+r3 = c.scale(s, d)
+print("THIRD", r3, H.STUB.hipstub_launches(), flush=True)
+"""
+    r, log = _run(stub, code, tmp_path)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.split() and ln.split()[0] in ("FIRST", "SECOND", "THIRD")}
+    assert int(out["FIRST"][0]) < 0 and out["FIRST"][1] == "0", out           # refused, nothing launched
+    assert "no longer holds what was uploaded" in r.stderr, r.stderr[-600:]
+    assert out["SECOND"] == ["720", "1"] and out["THIRD"] == ["720", "2"], out  # re-planned, converts
+    # read-backs (device -> host copies of the table sizes): the failed check stopped at the damaged block or before it, the re-plan read both back once; the third call none
+    d2h = [ln for ln in log.splitlines() if ln.startswith("copy ") and "kind=2" in ln and ("bytes=130688" in ln or "bytes=41984" in ln)]
+    assert 3 <= len(d2h) <= 4, d2h
