@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: the round-6 experiment instantiations (sws_hip_set_option exp0 .. exp3) against the oracle, bit-exact, before any of them is timed.
+"""GPU box (or, with SWS_SUITE_ON_EMU=1 and the emulation library, the CPU box): the round-6 experiment instantiations (sws_hip_set_option exp0 .. exp3) against the oracle, bit-exact, before any of them is timed.
 usage: python tools/exp_parity.py"""
 import os
 import sys
@@ -7,6 +7,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+import conftest  # noqa: E402,F401  (SWS_SUITE_ON_EMU=1: the same cases against the x86 emulation build on the CPU box, tests/hipemu/README.md)
 import test_gpu_parity as T  # noqa: E402
 from librempeg_amd import SWS_BILINEAR, SWS_BICUBIC, SWS_LANCZOS, SWS_BITEXACT  # noqa: E402
 
