@@ -123,6 +123,69 @@ def run_case(c, name, rng, stats, failures, max_pixels):
             f.free()
 
 
+def interleaved(n, seed, rng, stats, failures, max_pixels):
+    """up to 6 contexts alive, converted with in turn, their launch options changed between conversions (the next call re-plans), closed in any order: every picture of
+    every long-lived, re-planned context against the oracle"""
+    cases = [c for c in R._strip_cases(n, seed) + R._cases(n, seed + 1) + R._strip_cases(n, seed + 2, R.R4_SRC, R.R4_DST) if c[0] * c[1] <= max_pixels and c[3] * c[4] <= max_pixels]
+    pool = []
+    for step in range(5 * n):
+        op = rng.random()
+        if not pool or (op < 0.25 and len(pool) < 6):
+            c = rng.choice(cases)
+            opts, tune, cs = H.parts(c)
+            try:
+                o = OL.Oracle(*c[:7], **(opts or {}))
+                p = S.SwsContext(*c[:7], **(opts or {}))
+            except Exception:
+                continue
+            for k, v in (tune or {}).items():
+                p.set_option(k, v)
+            if cs and (o.set_colorspace(*cs) < 0 or p.set_colorspace(*cs) < 0):
+                p.close()
+                continue
+            pool.append(dict(p=p, o=o, c=c, n=0))
+        elif op < 0.9:
+            e = rng.choice(pool)
+            p, o, c = e["p"], e["o"], e["c"]
+            sw, sh, sf, dw, dh, df = c[:6]
+            if rng.random() < 0.3:
+                k = rng.choice(H.TUNE)
+                p.set_option(k, rng.choice(H.TUNE_VALUES.get(k, [0, 1])))
+            e["n"] += 1
+            src = OL.fill_random(OL.Frame(sf, sw, sh), c[7] * 13 + e["n"])
+            ref = OL.Frame(df, dw, dh, fill=FILL)
+            if o.scale(src, ref) < 0:
+                continue
+            s, d = H.StubFrame(sf, sw, sh, 0, fill=0), H.StubFrame(df, dw, dh, 0, fill=FILL)
+            to_stub(s, src)
+            r = p.scale(s, d)
+            p.sync()
+            stats["compared"] += 1
+            path = p.path()
+            stats.setdefault("paths", {}).setdefault(path, [0, 0])[0] += 1
+            if r < 0:
+                stats["product call fails"] += 1
+                failures.append(("call failed (interleaved)", c[:7], r, path))
+            else:
+                got = from_stub(d, ref)
+                for i, (a, b, rb) in enumerate(zip(got, ref.planes, ref.row_bytes)):
+                    b = b[:, :rb]
+                    if df in ("monob", "monow") and (dw & 7):
+                        a, b = a.copy(), b.copy()
+                        m = (0xFF00 >> (dw & 7)) & 0xFF
+                        a[:, rb - 1] &= m; b[:, rb - 1] &= m
+                    if not np.array_equal(a, b):
+                        stats["different"] += 1
+                        stats["paths"][path][1] += 1
+                        failures.append(("DIFFERENT (a long-lived, re-planned context)", c[:7], path, p.kernel_name(), f"conversion {e['n']} plane {i}: {int(np.count_nonzero(a != b))} bytes"))
+                        break
+            s.free(); d.free()
+        else:
+            pool.pop(rng.randrange(len(pool)))["p"].close()
+    for e in pool:
+        e["p"].close()
+
+
 def main():
     n, seed = int(sys.argv[1]), int(sys.argv[2])
     want = sys.argv[3:]
@@ -139,6 +202,9 @@ def main():
         for c in make():
             run_case(c, name, rng, stats, failures, max_pixels)
         print(f"{name}: {stats['compared']} compared so far, {stats['different']} different", flush=True)
+    if not want or "interleaved" in want:
+        interleaved(n, seed + 9, rng, stats, failures, max_pixels)
+        print(f"interleaved contexts: {stats['compared']} compared so far, {stats['different']} different", flush=True)
     for f in failures[:60]:
         print("FAIL", f, flush=True)
     paths = stats.pop("paths", {})
