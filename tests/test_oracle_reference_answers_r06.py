@@ -16,7 +16,7 @@ G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "gol
 @pytest.mark.parametrize("g", G["cases"], ids=lambda g: "{2}_{0}x{1}-{5}".format(*g["case"]))
 def test_oracle_equals_the_reference(g):
     sw, sh, sf, dw, dh, df, flags = g["case"]
-    o = OL.Oracle(sw, sh, sf, dw, dh, df, flags)
+    o = OL.Oracle(sw, sh, sf, dw, dh, df, flags, **g.get("opts", {}))
     src = OL.fill_random(OL.Frame(sf, sw, sh), g["seed"])
     dst = OL.Frame(df, dw, dh, fill=g["prefill"])
     assert o.scale(src, dst) == dh

@@ -30,18 +30,26 @@ for sf, df in (("yuv420p10be", "yuv420p10le"), ("yuv440p10le", "yuv440p10be"), (
     for drop in (0, 1, 2):
         CASES.append((64, 36, sf, 64, 36, df, BICUBIC | BX | (drop << 16), 3000 + drop))
 
+# xyz12 against rgb48 in the other byte order (xyz12 IS rgb48 inside the scaler, utils.c:822-823: bswap_16bpc applies, between the XYZ conversions), and the alpha-blend cascade into
+# the alpha-less twin in big-endian order under SWS_SRC_V_CHR_DROP (its second step is native -> big-endian: bswap_16bpc's row count again) -- round 6, fourth finding
+for sf, df in (("xyz12le", "rgb48be"), ("xyz12be", "rgb48le"), ("rgb48be", "xyz12le"), ("xyz12le", "xyz12be")):
+    CASES.append((64, 36, sf, 64, 36, df, BICUBIC | BX, 4000))
+for drop in (0, 1):
+    CASES.append((64, 36, "yuva420p10be", 64, 36, "yuv420p10be", 2 | BX | (drop << 16), 4100 + drop, dict(alpha_blend=1)))
+    CASES.append((64, 36, "yuva420p10le", 64, 36, "yuv420p10be", 2 | BX | (drop << 16), 4200 + drop, dict(alpha_blend=2)))
 
 
 def main():
     out = []
-    for (sw, sh, sf, dw, dh, df, flags, seed) in CASES:
+    for case in CASES:
+        (sw, sh, sf, dw, dh, df, flags, seed), opts = case[:8], (case[8] if len(case) > 8 else {})
         src = OL.fill_random(OL.Frame(sf, sw, sh), seed)
-        inp = f"CASE {sw} {sh} {sf} {dw} {dh} {df} {flags} 165 0 1 0 0 -513 -513 -513 -513 0 0 0 0 0 0 0 0 0 0 123456 123456\n".encode()
+        inp = f"CASE {sw} {sh} {sf} {dw} {dh} {df} {flags} 165 {1 if opts else 0} 1 0 0 -513 -513 -513 -513 0 0 0 0 0 0 0 0 {opts.get('alpha_blend', 0)} 0 123456 123456\n".encode()
         inp += b"".join(np.ascontiguousarray(a[:, :rb]).tobytes() for a, rb in zip(src.planes, src.row_bytes))
         o = subprocess.run([EXE], input=inp, capture_output=True, check=True).stdout
         hdr, data = o[:o.index(b"\n")].split(), o[o.index(b"\n") + 1:]
         assert int(hdr[1]) == dh and len(data) == int(hdr[2])
-        out.append({"case": [sw, sh, sf, dw, dh, df, flags], "seed": seed, "prefill": 165, "md5": hashlib.md5(data).hexdigest()})
+        out.append({"case": [sw, sh, sf, dw, dh, df, flags], "seed": seed, "prefill": 165, "md5": hashlib.md5(data).hexdigest(), **({"opts": opts} if opts else {})})
     json.dump({"_source": "tools/gen_crosscheck_golden.py: the real reference (C-only build), whole destination pictures (visible rows, planes in order)", "cases": out},
               open(os.path.join(ROOT, "tests", "golden", "reference_answers_r06.json"), "w"), indent=0)
     print(len(out), "cases")
